@@ -1,0 +1,331 @@
+// ORACLE — test infrastructure only (see oracle.hpp).
+// Flat C entry points so tests/ (ctypes) and bench.py's cpu_baseline leg can drive the restatement.
+#include "oracle.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <numeric>
+#include <random>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace oracle;
+
+static std::vector<feature_2d> make_features(const double *loc, const float *strength, const uint64_t *desc, size_t n)
+{
+    std::vector<feature_2d> f(n);
+    for (size_t i = 0; i < n; i++)
+    {
+        if (loc)
+        {
+            f[i].location[0] = loc[2 * i];
+            f[i].location[1] = loc[2 * i + 1];
+        }
+        if (strength)
+            f[i].strength = strength[i];
+        if (desc)
+        {
+            // std::bitset<486> on LP64 libstdc++ is 8 little-endian 64-bit words
+            static_assert(sizeof(f[i].descriptor) == 64, "bitset<486> layout");
+            uint64_t w[8];
+            std::memcpy(w, desc + 8 * i, 64);
+            w[7] &= (uint64_t(1) << (486 - 448)) - 1; // bits 486..511 are always zero in a bitset<486>
+            std::memcpy((void *)&f[i].descriptor, w, 64);
+        }
+    }
+    return f;
+}
+
+static camera_model make_model(const double *m) // f, ppx, ppy, k1, k2, k3, p1, p2, cols, rows
+{
+    camera_model c;
+    c.focal_length_pixels = m[0];
+    c.principle_point[0] = m[1];
+    c.principle_point[1] = m[2];
+    c.radial_distortion[0] = m[3];
+    c.radial_distortion[1] = m[4];
+    c.radial_distortion[2] = m[5];
+    c.tangential_distortion[0] = m[6];
+    c.tangential_distortion[1] = m[7];
+    c.pixels_cols = (size_t)m[8];
+    c.pixels_rows = (size_t)m[9];
+    return c;
+}
+
+static std::vector<correspondence> make_corrs(const double *corr, size_t M)
+{
+    std::vector<correspondence> c(M);
+    for (size_t i = 0; i < M; i++)
+    {
+        c[i].measurement1 = Vec3{corr[7 * i], corr[7 * i + 1], corr[7 * i + 2]};
+        c[i].measurement2 = Vec3{corr[7 * i + 3], corr[7 * i + 4], corr[7 * i + 5]};
+        c[i].quality = corr[7 * i + 6];
+    }
+    return c;
+}
+
+extern "C"
+{
+
+// libstdc++ behaviour the reference depends on (SURVEY.md §8c golden values)
+void oc_libstdcxx_selfcheck(uint64_t *out /*17*/)
+{
+    std::default_random_engine g(42);
+    out[0] = g();
+    std::default_random_engine g2(42);
+    std::vector<size_t> v(10);
+    std::iota(v.begin(), v.end(), 0);
+    std::shuffle(v.begin(), v.end(), g2);
+    for (int i = 0; i < 10; i++)
+        out[1 + i] = v[i];
+    std::uniform_int_distribution<size_t> d(0, 9);
+    for (int i = 0; i < 6; i++)
+        out[11 + i] = d(g2);
+}
+
+size_t oc_subsample(const double *loc, const float *strength, size_t n, double spacing, size_t count, uint64_t *out)
+{
+    auto f = make_features(loc, strength, nullptr, n);
+    auto idx = spatially_subsample_feature_indices(f, spacing, count);
+    for (size_t i = 0; i < idx.size(); i++)
+        out[i] = idx[i];
+    return idx.size();
+}
+
+size_t oc_match(const uint64_t *desc1, size_t n1, const uint64_t *desc2, size_t n2, const uint64_t *idx1, size_t n_idx1,
+                const uint64_t *idx2, size_t n_idx2, uint64_t *out_i1, uint64_t *out_i2, double *out_dist)
+{
+    auto f1 = make_features(nullptr, nullptr, desc1, n1);
+    auto f2 = make_features(nullptr, nullptr, desc2, n2);
+    std::vector<size_t> i1(idx1, idx1 + n_idx1), i2(idx2, idx2 + n_idx2);
+    auto m = match_features_subset(f1, f2, i1, i2);
+    for (size_t i = 0; i < m.size(); i++)
+    {
+        out_i1[i] = m[i].feature_index_1;
+        out_i2[i] = m[i].feature_index_2;
+        out_dist[i] = m[i].distance;
+    }
+    return m.size();
+}
+
+void oc_image_to_3d(const double *px, size_t n, const double *model, double *rays)
+{
+    const camera_model c = make_model(model);
+    for (size_t i = 0; i < n; i++)
+    {
+        const Vec3 r = image_to_3d(px + 2 * i, c);
+        rays[3 * i] = r.x;
+        rays[3 * i + 1] = r.y;
+        rays[3 * i + 2] = r.z;
+    }
+}
+
+void oc_image_from_3d(const double *rays, size_t n, const double *model, double *px)
+{
+    const camera_model c = make_model(model);
+    for (size_t i = 0; i < n; i++)
+    {
+        const Vec2 p = image_from_3d(Vec3{rays[3 * i], rays[3 * i + 1], rays[3 * i + 2]}, c);
+        px[2 * i] = p.x;
+        px[2 * i + 1] = p.y;
+    }
+}
+
+void oc_homography_fit4(const double *corr, size_t M, const uint64_t *idx4, double *H, double *Hinv)
+{
+    auto c = make_corrs(corr, M);
+    homography_model h;
+    h.fit(c, {idx4[0], idx4[1], idx4[2], idx4[3]});
+    std::memcpy(H, h.homography.m, 72);
+    std::memcpy(Hinv, h.homography_inverse.m, 72);
+}
+
+void oc_homography_fit_inliers(const double *corr, size_t M, const uint8_t *inl, double *H, double *Hinv)
+{
+    auto c = make_corrs(corr, M);
+    std::vector<bool> in(M);
+    for (size_t i = 0; i < M; i++)
+        in[i] = inl[i] != 0;
+    homography_model h;
+    h.fitInliers(c, in);
+    std::memcpy(H, h.homography.m, 72);
+    std::memcpy(Hinv, h.homography_inverse.m, 72);
+}
+
+double oc_homography_evaluate(const double *corr, size_t M, const double *H, const double *Hinv, uint8_t *inl,
+                              double *errors)
+{
+    auto c = make_corrs(corr, M);
+    homography_model h;
+    std::memcpy(h.homography.m, H, 72);
+    std::memcpy(h.homography_inverse.m, Hinv, 72);
+    std::vector<bool> in;
+    const double s = h.evaluate(c, in);
+    for (size_t i = 0; i < M; i++)
+    {
+        inl[i] = in[i];
+        if (errors)
+            errors[i] = h.error(c[i]);
+    }
+    return s;
+}
+
+// returns score; H (9, row-major), inliers (M); optional trace of the minimal samples
+double oc_ransac_homography(const double *corr, size_t M, double *H, uint8_t *inl, uint64_t *trace_samples,
+                            size_t max_trace, uint64_t *iterations)
+{
+    auto c = make_corrs(corr, M);
+    homography_model h;
+    std::vector<bool> in;
+    ransac_trace tr;
+    const double s = ransac(c, h, in, &tr);
+    std::memcpy(H, h.homography.m, 72);
+    for (size_t i = 0; i < in.size(); i++)
+        inl[i] = in[i];
+    if (iterations)
+    {
+        iterations[0] = tr.iterations;
+        iterations[1] = tr.improvements;
+    }
+    if (trace_samples)
+        for (size_t i = 0; i < tr.samples.size() && i < max_trace; i++)
+            for (int j = 0; j < 4; j++)
+                trace_samples[4 * i + j] = tr.samples[i][j];
+    return s;
+}
+
+// poses: 4 x {qx,qy,qz,qw, tx,ty,tz, score}
+int oc_homography_decompose(const double *H, const double *corr, size_t M, const uint8_t *inl, double *poses)
+{
+    auto c = make_corrs(corr, M);
+    std::vector<bool> in(M);
+    for (size_t i = 0; i < M; i++)
+        in[i] = inl[i] != 0;
+    homography_model h;
+    std::memcpy(h.homography.m, H, 72);
+    h.homography_inverse = inverse3(h.homography);
+    std::array<decomposed_pose, 4> p;
+    const bool ok = h.decompose(c, in, p);
+    for (int i = 0; i < 4; i++)
+    {
+        double *o = poses + 8 * i;
+        o[0] = p[i].orientation.x;
+        o[1] = p[i].orientation.y;
+        o[2] = p[i].orientation.z;
+        o[3] = p[i].orientation.w;
+        o[4] = p[i].position.x;
+        o[5] = p[i].position.y;
+        o[6] = p[i].position.z;
+        o[7] = p[i].score;
+    }
+    return ok ? 1 : 0;
+}
+
+// One directed pair of link_stage.cpp:75-112.  Output buffers sized for n_idx1 matches.
+// summary: [n_matches, n_inliers, can_decompose, accepted(edge has inlier list), ransac_score]
+void oc_link_pair(const double *loc1, const uint64_t *desc1, size_t n1, const uint64_t *idx1, size_t n_idx1,
+                  const double *loc2, const uint64_t *desc2, size_t n2, const uint64_t *idx2, size_t n_idx2,
+                  const double *model1, const double *model2, uint64_t *m_i1, uint64_t *m_i2, double *m_dist,
+                  uint8_t *inl, double *H, double *poses, double *summary)
+{
+    auto f1 = make_features(loc1, nullptr, desc1, n1);
+    auto f2 = make_features(loc2, nullptr, desc2, n2);
+    std::vector<size_t> i1(idx1, idx1 + n_idx1), i2(idx2, idx2 + n_idx2);
+    camera_relations r = link_pair(f1, f2, i1, i2, make_model(model1), make_model(model2));
+    // matches are only kept in relations when accepted; re-run match for the full list (deterministic)
+    auto m = match_features_subset(f1, f2, i1, i2);
+    for (size_t i = 0; i < m.size(); i++)
+    {
+        m_i1[i] = m[i].feature_index_1;
+        m_i2[i] = m[i].feature_index_2;
+        m_dist[i] = m[i].distance;
+        inl[i] = r.coarse_inliers[i];
+    }
+    std::memcpy(H, r.ransac_relation.m, 72);
+    for (int i = 0; i < 4; i++)
+    {
+        double *o = poses + 8 * i;
+        const auto &p = r.relative_poses[i];
+        o[0] = p.orientation.x, o[1] = p.orientation.y, o[2] = p.orientation.z, o[3] = p.orientation.w;
+        o[4] = p.position.x, o[5] = p.position.y, o[6] = p.position.z, o[7] = p.score;
+    }
+    summary[0] = (double)m.size();
+    summary[1] = (double)std::count(r.coarse_inliers.begin(), r.coarse_inliers.end(), true);
+    summary[2] = r.can_decompose;
+    summary[3] = !r.inlier_matches.empty();
+    summary[4] = r.ransac_score;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CPU baseline driver (bench.py cpu_baseline leg): the reference's scheduling, i.e. one closure per
+// directed pair under `#pragma omp parallel for schedule(dynamic,1)` (pipeline.cpp:42-49), with the
+// destination subset recomputed inside each closure exactly as link_stage.cpp:80-81 does
+// ("faithful") or cached per image ("cached").  Features of image i: loc[off[i]..off[i+1]).
+// seconds_out: [total wall, sum match, sum undistort, sum ransac] (bucket names of link_stage.cpp:77,86,90)
+void oc_link_batch_cpu(const double *loc, const float *strength, const uint64_t *desc, const uint64_t *off,
+                       size_t n_images, const uint64_t *num_sparse, const double *model, const uint32_t *pairs,
+                       size_t n_pairs, int faithful, int threads, uint64_t *out_counts /*n_pairs x 2*/,
+                       double *out_H /*n_pairs x 9*/, double *seconds_out)
+{
+    std::vector<std::vector<feature_2d>> feats(n_images);
+    for (size_t i = 0; i < n_images; i++)
+        feats[i] = make_features(loc + 2 * off[i], strength + off[i], desc + 8 * off[i], off[i + 1] - off[i]);
+    const camera_model cm = make_model(model);
+#ifdef _OPENMP
+    if (threads > 0)
+        omp_set_num_threads(threads);
+#endif
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t0 = clk::now();
+    std::vector<std::vector<size_t>> subset(n_images);
+    // the source subset is computed once per source image (link_stage.cpp:63-65)
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t i = 0; i < n_images; i++)
+        subset[i] = spatially_subsample_feature_indices(feats[i], 40.0, num_sparse[i]);
+    double t_match = 0, t_und = 0, t_ransac = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : t_match, t_und, t_ransac)
+    for (size_t p = 0; p < n_pairs; p++)
+    {
+        const uint32_t a = pairs[2 * p], b = pairs[2 * p + 1];
+        const auto ta = clk::now();
+        std::vector<size_t> idx2_local;
+        if (faithful)
+            idx2_local = spatially_subsample_feature_indices(feats[b], 40.0, num_sparse[b]);
+        const std::vector<size_t> &idx2 = faithful ? idx2_local : subset[b];
+        auto matches = match_features_subset(feats[a], feats[b], subset[a], idx2);
+        const auto tb = clk::now();
+        auto corr = distort_keypoints(feats[a], feats[b], matches, cm, cm);
+        const auto tc = clk::now();
+        homography_model h;
+        std::vector<bool> inl;
+        ransac(corr, h, inl);
+        std::array<decomposed_pose, 4> poses;
+        h.decompose(corr, inl, poses);
+        const auto td = clk::now();
+        t_match += secs(ta, tb);
+        t_und += secs(tb, tc);
+        t_ransac += secs(tc, td);
+        out_counts[2 * p] = matches.size();
+        out_counts[2 * p + 1] = std::count(inl.begin(), inl.end(), true);
+        std::memcpy(out_H + 9 * p, h.homography.m, 72);
+    }
+    seconds_out[0] = secs(t0, clk::now());
+    seconds_out[1] = t_match;
+    seconds_out[2] = t_und;
+    seconds_out[3] = t_ransac;
+}
+
+int oc_num_threads()
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+} // extern "C"

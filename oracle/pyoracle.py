@@ -1,0 +1,213 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle.so (the CPU restatement of the reference hot path) and of
+oracle/_ref/libref.so (the reference's own std-only KD-tree header compiled in place).  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing under
+opencalibration_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+
+
+def build():
+    """Compile the restatement (and oracle/_ref when /root/reference is mounted)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all", "ref"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.oc_libstdcxx_selfcheck.argtypes = [u64p]
+        L.oc_subsample.restype = C.c_size_t
+        L.oc_subsample.argtypes = [f64p, f32p, C.c_size_t, C.c_double, C.c_size_t, u64p]
+        L.oc_match.restype = C.c_size_t
+        L.oc_match.argtypes = [u64p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, f64p]
+        L.oc_image_to_3d.argtypes = [f64p, C.c_size_t, f64p, f64p]
+        L.oc_image_from_3d.argtypes = [f64p, C.c_size_t, f64p, f64p]
+        L.oc_homography_fit4.argtypes = [f64p, C.c_size_t, u64p, f64p, f64p]
+        L.oc_homography_fit_inliers.argtypes = [f64p, C.c_size_t, u8p, f64p, f64p]
+        L.oc_homography_evaluate.restype = C.c_double
+        L.oc_homography_evaluate.argtypes = [f64p, C.c_size_t, f64p, f64p, u8p, C.c_void_p]
+        L.oc_ransac_homography.restype = C.c_double
+        L.oc_ransac_homography.argtypes = [f64p, C.c_size_t, f64p, u8p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.oc_homography_decompose.restype = C.c_int
+        L.oc_homography_decompose.argtypes = [f64p, f64p, C.c_size_t, u8p, f64p]
+        L.oc_link_pair.argtypes = [f64p, u64p, C.c_size_t, u64p, C.c_size_t, f64p, u64p, C.c_size_t, u64p, C.c_size_t,
+                                   f64p, f64p, u64p, u64p, f64p, u8p, f64p, f64p, f64p]
+        L.oc_link_batch_cpu.argtypes = [f64p, f32p, u64p, u64p, C.c_size_t, u64p, f64p, u32p, C.c_size_t, C.c_int,
+                                        C.c_int, u64p, f64p, f64p]
+        L.oc_scene_homography.argtypes = [C.c_size_t, C.c_size_t, C.c_uint, f64p, u8p, f64p]
+        L.oc_scene_near_degenerate.argtypes = [f64p, f64p]
+        L.oc_num_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def ref():
+    """oracle/_ref/libref.so or None if it was never built (it needs /root/reference to build)."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "libref.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_subsample_kdtree.restype = C.c_size_t
+        R.ref_subsample_kdtree.argtypes = [f64p, f32p, C.c_size_t, C.c_double, C.c_size_t, u64p]
+        R.ref_knn.argtypes = [f64p, C.c_size_t, C.c_size_t, u64p]
+        _REF = R
+    return _REF
+
+
+def model_vec(f, ppx, ppy, radial=(0, 0, 0), tangential=(0, 0), cols=4000, rows=3000):
+    return np.array([f, ppx, ppy, *radial, *tangential, cols, rows], dtype=np.float64)
+
+
+def selfcheck():
+    out = np.zeros(17, np.uint64)
+    lib().oc_libstdcxx_selfcheck(out)
+    return out
+
+
+def subsample(loc, strength, spacing, count=0):
+    loc = np.ascontiguousarray(loc, np.float64)
+    strength = np.ascontiguousarray(strength, np.float32)
+    out = np.zeros(max(len(strength), 1), np.uint64)
+    n = lib().oc_subsample(loc, strength, len(strength), spacing, count, out)
+    return out[:n].copy()
+
+
+def ref_subsample(loc, strength, spacing, count=0):
+    loc = np.ascontiguousarray(loc, np.float64)
+    strength = np.ascontiguousarray(strength, np.float32)
+    out = np.zeros(max(len(strength), 1), np.uint64)
+    n = ref().ref_subsample_kdtree(loc, strength, len(strength), spacing, count, out)
+    return out[:n].copy()
+
+
+def ref_knn(xy, k):
+    xy = np.ascontiguousarray(xy, np.float64)
+    out = np.zeros((len(xy), k), np.uint64)
+    ref().ref_knn(xy, len(xy), k, out)
+    return out
+
+
+def match(desc1, desc2, idx1, idx2):
+    desc1 = np.ascontiguousarray(desc1, np.uint64)
+    desc2 = np.ascontiguousarray(desc2, np.uint64)
+    idx1 = np.ascontiguousarray(idx1, np.uint64)
+    idx2 = np.ascontiguousarray(idx2, np.uint64)
+    n = max(len(idx1), 1)
+    i1, i2, d = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.float64)
+    m = lib().oc_match(desc1, len(desc1), desc2, len(desc2), idx1, len(idx1), idx2, len(idx2), i1, i2, d)
+    return i1[:m].copy(), i2[:m].copy(), d[:m].copy()
+
+
+def image_to_3d(px, model):
+    px = np.ascontiguousarray(px, np.float64).reshape(-1, 2)
+    out = np.zeros((len(px), 3))
+    lib().oc_image_to_3d(px, len(px), model, out)
+    return out
+
+
+def image_from_3d(rays, model):
+    rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 3)
+    out = np.zeros((len(rays), 2))
+    lib().oc_image_from_3d(rays, len(rays), model, out)
+    return out
+
+
+def corr_array(m1, m2, quality=None):
+    m1 = np.asarray(m1, np.float64).reshape(-1, 3)
+    m2 = np.asarray(m2, np.float64).reshape(-1, 3)
+    q = np.zeros(len(m1)) if quality is None else np.asarray(quality, np.float64)
+    return np.ascontiguousarray(np.concatenate([m1, m2, q[:, None]], axis=1))
+
+
+def fit4(corr, idx4):
+    H, Hi = np.zeros((3, 3)), np.zeros((3, 3))
+    lib().oc_homography_fit4(corr, len(corr), np.asarray(idx4, np.uint64), H, Hi)
+    return H, Hi
+
+
+def fit_inliers(corr, inl):
+    H, Hi = np.zeros((3, 3)), np.zeros((3, 3))
+    lib().oc_homography_fit_inliers(corr, len(corr), np.ascontiguousarray(inl, np.uint8), H, Hi)
+    return H, Hi
+
+
+def evaluate(corr, H, Hi):
+    inl = np.zeros(max(len(corr), 1), np.uint8)
+    err = np.zeros(max(len(corr), 1), np.float64)
+    s = lib().oc_homography_evaluate(corr, len(corr), np.ascontiguousarray(H), np.ascontiguousarray(Hi), inl,
+                                     err.ctypes.data)
+    return s, inl[:len(corr)], err[:len(corr)]
+
+
+def ransac_homography(corr, max_trace=0):
+    corr = np.ascontiguousarray(corr, np.float64).reshape(-1, 7)
+    M = len(corr)
+    H = np.zeros((3, 3))
+    inl = np.zeros(max(M, 1), np.uint8)
+    it = np.zeros(2, np.uint64)
+    tr = np.zeros((max(max_trace, 1), 4), np.uint64)
+    if M == 0:
+        corr = np.zeros((1, 7))
+    s = lib().oc_ransac_homography(corr, M, H, inl, tr.ctypes.data if max_trace else None, max_trace, it.ctypes.data)
+    return dict(score=s, H=H, inliers=inl[:M].copy(), iterations=int(it[0]), improvements=int(it[1]),
+                samples=tr[:min(max_trace, int(it[0]))].copy())
+
+
+def decompose(H, corr, inl):
+    poses = np.zeros((4, 8))
+    ok = lib().oc_homography_decompose(np.ascontiguousarray(H, np.float64), corr, len(corr),
+                                       np.ascontiguousarray(inl, np.uint8), poses)
+    return bool(ok), poses
+
+
+def link_pair(loc1, desc1, idx1, loc2, desc2, idx2, model1, model2):
+    loc1 = np.ascontiguousarray(loc1, np.float64)
+    loc2 = np.ascontiguousarray(loc2, np.float64)
+    desc1 = np.ascontiguousarray(desc1, np.uint64)
+    desc2 = np.ascontiguousarray(desc2, np.uint64)
+    idx1 = np.ascontiguousarray(idx1, np.uint64)
+    idx2 = np.ascontiguousarray(idx2, np.uint64)
+    n = max(len(idx1), 1)
+    mi1, mi2, md = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n)
+    inl = np.zeros(n, np.uint8)
+    H, poses, summary = np.zeros((3, 3)), np.zeros((4, 8)), np.zeros(5)
+    lib().oc_link_pair(loc1, desc1, len(desc1), idx1, len(idx1), loc2, desc2, len(desc2), idx2, len(idx2), model1,
+                       model2, mi1, mi2, md, inl, H, poses, summary)
+    m = int(summary[0])
+    return dict(i1=mi1[:m].copy(), i2=mi2[:m].copy(), dist=md[:m].copy(), inliers=inl[:m].copy(), H=H, poses=poses,
+                n_inliers=int(summary[1]), can_decompose=bool(summary[2]), accepted=bool(summary[3]),
+                score=float(summary[4]))
+
+
+def scene_homography(n_in, n_out, seed):
+    n = n_in + n_out
+    corr, gt, H = np.zeros((n, 7)), np.zeros(n, np.uint8), np.zeros((3, 3))
+    lib().oc_scene_homography(n_in, n_out, seed, corr, gt, H)
+    return corr, gt, H
+
+
+def scene_near_degenerate():
+    corr, H = np.zeros((100, 7)), np.zeros((3, 3))
+    lib().oc_scene_near_degenerate(corr, H)
+    return corr, H

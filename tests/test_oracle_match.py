@@ -1,0 +1,125 @@
+"""Pins oracle/match.cpp and oracle/distort.cpp with restated reference tests
+(test/test_match.cpp:44-129, test/test_distort.cpp:8-137) and against oracle/_ref (the reference's
+own KD-tree header compiled in place)."""
+import numpy as np
+import pytest
+
+from opencalibration_amd import synth
+
+
+def test_spatial_subsample_keeps_strongest_features(oracle):  # test_match.cpp:90-129
+    loc = np.array([[100, 100], [110, 105], [200, 200], [205, 202], [300, 300]], float)
+    strength = np.array([0.5, 0.9, 0.3, 0.7, 0.4], np.float32)
+    sub = oracle.subsample(loc, strength, 20.0)
+    assert list(sub) == [1, 3, 4]
+    for kept in sub:
+        for other in range(5):
+            if other != kept and np.linalg.norm(loc[kept] - loc[other]) <= 20.0:
+                assert strength[kept] >= strength[other]
+
+
+def test_spatial_subsample_properties(oracle):  # test_match.cpp:44-88 (monotone in spacing, min spacing holds)
+    rng = np.random.default_rng(3)
+    loc = rng.uniform(0, 2000, (3000, 2))
+    strength = rng.uniform(0, 1, 3000).astype(np.float32)
+    prev = None
+    for spacing in (10.0, 20.0, 40.0, 80.0):
+        sub = oracle.subsample(loc, strength, spacing)
+        assert len(np.unique(sub)) == len(sub) and sub.max() < 3000
+        p = loc[sub.astype(int)]
+        d = np.linalg.norm(p[:, None] - p[None], axis=-1) + np.eye(len(p)) * 1e9
+        assert d.min() > spacing
+        if prev is not None:
+            assert len(sub) <= prev
+        prev = len(sub)
+    assert len(oracle.subsample(np.zeros((0, 2)), np.zeros(0, np.float32), 40.0)) == 0
+    # `count` restricts the candidates to the first num_sparse features (link_stage.cpp:63-65)
+    sub = oracle.subsample(loc, strength, 40.0, 500)
+    assert sub.max() < 500
+
+
+def test_subsample_matches_reference_kdtree(oracle):
+    """The hash-grid restatement must agree with the reference's jk::tree::KDTree driver loop."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    rng = np.random.default_rng(11)
+    for n, spacing in ((1, 40.0), (50, 40.0), (4000, 40.0), (4000, 8.0), (2000, 123.5)):
+        loc = rng.uniform(0, 4000, (n, 2))
+        # heavy strength ties exercise the unstable std::sort path both sides share
+        strength = (rng.integers(0, 50, n) / 50).astype(np.float32)
+        assert np.array_equal(oracle.subsample(loc, strength, spacing), oracle.ref_subsample(loc, strength, spacing))
+    g = synth.make_grid(1, 2, feats=1024, seed=5)
+    loc, st, _, _ = g.image(0)
+    assert np.array_equal(oracle.subsample(loc, st, 40.0), oracle.ref_subsample(loc, st, 40.0))
+
+
+def _popcount(a):
+    return np.unpackbits(a.view(np.uint8), axis=-1).sum(-1)
+
+
+def test_match_against_numpy_definition(oracle):
+    """match_features.cpp:54-103 semantics: strict '<' (lowest k wins ties), a tie with the best makes
+    second == best (ratio fails), Lowe 0.8 in f64 on count/486, output sorted by distance descending."""
+    rng = np.random.default_rng(5)
+    base = synth.descriptors_for_ids(np.arange(300))
+    d1 = base[:200].copy()
+    d2 = base[100:300].copy()
+    for d in (d1, d2):  # bit noise
+        bits = rng.integers(0, 486, (len(d), 25))
+        for j in range(25):
+            d[np.arange(len(d)), bits[:, j] >> 6] ^= np.uint64(1) << (bits[:, j] & 63).astype(np.uint64)
+    d2[7] = d2[5]      # exact duplicate reference descriptor -> tie -> no match for its query
+    idx1 = rng.permutation(200)[:150].astype(np.uint64)
+    idx2 = rng.permutation(200)[:180].astype(np.uint64)
+    i1, i2, dist = oracle.match(d1, d2, idx1, idx2)
+
+    ham = _popcount(d1[idx1.astype(int)][:, None, :] ^ d2[idx2.astype(int)][None, :, :])
+    exp = []
+    for a in range(len(idx1)):
+        order = np.argsort(ham[a], kind="stable")
+        best, second = ham[a][order[0]], (ham[a][order[1]] if len(order) > 1 else np.inf)
+        if best * (1.0 / 486) < 0.8 * (second * (1.0 / 486)):
+            exp.append((int(idx1[a]), int(idx2[order[0]]), best * (1.0 / 486)))
+    got = sorted(zip(i1.tolist(), i2.tolist(), dist.tolist()))
+    assert got == sorted(exp)
+    assert np.all(np.diff(dist) <= 0)                      # sorted by distance descending
+    assert 105 not in [int(x) for x in i1]                 # query whose best is tied (d2[5]==d2[7]) is dropped
+    # empty subsets
+    assert len(oracle.match(d1, d2, idx1, np.zeros(0, np.uint64))[0]) == 0
+    assert len(oracle.match(d1, d2, np.zeros(0, np.uint64), idx2)[0]) == 0
+    # a single reference descriptor: second stays +inf, the ratio test passes
+    assert len(oracle.match(d1, d2, idx1[:3], idx2[:1])[0]) == 3
+
+
+def _verify_roundtrip(oracle, model, eps):  # test_distort.cpp:8-27
+    cols, rows = int(model[8]), int(model[9])
+    px = np.array([[i, j] for i in range(0, cols, cols // 20) for j in range(0, rows, rows // 20)], float)
+    back = oracle.image_from_3d(oracle.image_to_3d(px, model), model)
+    assert np.max(np.abs(back - px)) <= eps
+
+
+def test_distort_no_distortion(oracle):  # test_distort.cpp:34-43
+    _verify_roundtrip(oracle, oracle.model_vec(6000, 2000, 1500), 1e-12)
+
+
+def test_distort_radial(oracle):  # test_distort.cpp:45-55
+    _verify_roundtrip(oracle, oracle.model_vec(6000, 2000, 1500, radial=(0.02, -0.07, 0.1)), 1e-2)
+
+
+def test_distort_radial_tangential(oracle):  # test_distort.cpp:57-68
+    _verify_roundtrip(oracle, oracle.model_vec(6000, 2000, 1500, radial=(0.02, -0.07, 0.1), tangential=(0.01, -0.005)),
+                      1e-2)
+
+
+def test_knn_reference_has_no_ties_on_synthetic_grid(oracle):
+    """positions are jittered so the kNN(10) pair set is tree-independent."""
+    if oracle.ref() is None:
+        pytest.skip("oracle/_ref not built")
+    g = synth.make_grid(4, 6, feats=64, seed=1)
+    knn = oracle.ref_knn(g.position[:, :2], 10)
+    xy = g.position[:, :2]
+    d = np.sum((xy[:, None] - xy[None]) ** 2, -1)
+    for i in range(len(xy)):
+        order = np.argsort(d[i], kind="stable")[:10]
+        assert set(knn[i].tolist()) == set(order.tolist())
+        assert len(np.unique(d[i][order])) == 10
