@@ -1,0 +1,101 @@
+/* ochip.h — C ABI of libochip.so, the MI355X (gfx950) device side of the opencalibration hot path.
+ *
+ * The reference (jkflying/opencalibration) has no plugin/FFI layer; its seam is the stage triple
+ * init/get_runners/finalize (src/pipeline/link_stage.hpp:25-30, relax_stage.hpp:24-35) over
+ * value-semantic free functions.  Each entry point below replaces the inner loop of one of those
+ * functions and is what a reference-side binding would call (INTEGRATION.md shows the C++ stub).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * OCHIP_E* code and never throws; ochip_last_error() gives the text.  Pointers are HOST pointers
+ * unless the name says `_dev`.  A context owns one HIP device, its streams and device arenas; calls
+ * on one context must be serialised by the caller (the host stages call from one thread per context,
+ * SURVEY.md §8b), different contexts are independent.
+ */
+#ifndef OCHIP_H
+#define OCHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+#define OCHIP_OK 0
+#define OCHIP_EINVAL (-1)  /* bad argument */
+#define OCHIP_ENOMEM (-2)  /* device or host allocation failed */
+#define OCHIP_EHIP (-3)    /* HIP runtime error, see ochip_last_error */
+#define OCHIP_ENODEV (-4)  /* no usable gfx950 device */
+#define OCHIP_ESTATE (-5)  /* call order violated (e.g. match before upload) */
+
+#define OCHIP_DESC_WORDS64 8 /* std::bitset<486> = 8 x u64, bits 486..511 zero (feature_2d.hpp:9-21) */
+#define OCHIP_DESC_BITS 486
+#define OCHIP_NO_SECOND 0xFFFFu /* second_count sentinel: fewer than two reference descriptors */
+
+    typedef struct ochip_ctx ochip_ctx;
+
+    typedef struct ochip_pair
+    {
+        uint32_t image_1; /* query image (source node, link_stage.cpp:57) */
+        uint32_t image_2; /* reference image (match_node_id, link_stage.cpp:67) */
+    } ochip_pair;
+
+    /* per query descriptor of image_1, in subset order */
+    typedef struct ochip_match
+    {
+        uint32_t best_k;       /* position in image_2's uploaded subset of the nearest descriptor; lowest k on ties */
+        uint16_t best_count;   /* Hamming distance (popcount of xor over 486 bits) */
+        uint16_t second_count; /* distance of the 2nd nearest (== best_count on a tie); OCHIP_NO_SECOND if n2 < 2 */
+    } ochip_match;
+
+    /* kernel ids for ochip_profile_get */
+    enum
+    {
+        OCHIP_K_MATCH = 0,
+        OCHIP_K_RANSAC = 1,
+        OCHIP_K_RELAX_EVAL = 2,
+        OCHIP_K_RELAX_SOLVE = 3,
+        OCHIP_K_COUNT = 8
+    };
+
+    /* ---- context ------------------------------------------------------------------------------ */
+    int ochip_ctx_create(int device, ochip_ctx **out);
+    void ochip_ctx_destroy(ochip_ctx *ctx);
+    const char *ochip_last_error(const ochip_ctx *ctx); /* ctx may be NULL: error of the last failed create */
+    int ochip_device_info(const ochip_ctx *ctx, char *name, size_t name_len, int *compute_units, size_t *hbm_bytes);
+    int ochip_synchronize(ochip_ctx *ctx);
+
+    /* ---- descriptor store (replaces the packed_2 build, src/match/match_features.cpp:62-66) ----- */
+    /* Size the arena once: n_images slots, total_descriptors descriptors over all images. */
+    int ochip_descriptors_reserve(ochip_ctx *ctx, uint32_t n_images, uint64_t total_descriptors);
+    /* Copy one image's 40-px-subset descriptors (subset order, n x 8 u64) into HBM.  The caller keeps
+     * ownership of `desc`.  An image may be uploaded once. */
+    int ochip_upload_descriptors(ochip_ctx *ctx, uint32_t image_id, const uint64_t *desc, uint32_t n);
+    int ochip_descriptor_count(const ochip_ctx *ctx, uint32_t image_id, uint32_t *n);
+
+    /* ---- brute-force Hamming 2-NN (replaces the double loop src/match/match_features.cpp:71-93) - */
+    /* For pair p, out[out_offset[p] + i] describes query i of image_1 (i < n(image_1)).
+     * out_offset has n_pairs entries; the caller sizes `out` as sum of n(image_1).  The Lowe ratio
+     * test (:94), the index remap through indices_2 (:86) and the std::sort (:100-101) stay on the
+     * host so libstdc++'s tie order is preserved. */
+    int ochip_match_batch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs, const uint64_t *out_offset,
+                          ochip_match *out);
+    /* Asynchronous flavour: results stay in HBM until ochip_match_fetch (lets the caller overlap). */
+    int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs, const uint64_t *out_offset,
+                           uint64_t out_total);
+    int ochip_match_fetch(ochip_ctx *ctx, ochip_match *out, uint64_t out_total);
+
+    /* ---- profiling: HIP-event time of every launch of a kernel since the last reset ------------- */
+    int ochip_profile_reset(ochip_ctx *ctx);
+    int ochip_profile_get(ochip_ctx *ctx, int kernel_id, uint64_t *launches, double *total_ms);
+
+    /* ---- diagnostics ----------------------------------------------------------------------------- */
+    /* out[i] = x[i] op y[i] computed on the device with the hot-path kernels' compile flags:
+     * op 0: x/y, 1: sqrt(x), 2: log(x), 3: x*y+x (unfused), 4: x+y.  Host pointers. */
+    int ochip_debug_fp64(ochip_ctx *ctx, int op, const double *x, const double *y, size_t n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCHIP_H */

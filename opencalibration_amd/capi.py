@@ -1,0 +1,135 @@
+"""ctypes binding of libochip.so (include/ochip.h).  No fallbacks: if the library is missing or no
+gfx950 device is present the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libochip.so")
+
+K_MATCH, K_RANSAC, K_RELAX_EVAL, K_RELAX_SOLVE = 0, 1, 2, 3
+NO_SECOND = 0xFFFF
+
+PAIR_DTYPE = np.dtype([("image_1", np.uint32), ("image_2", np.uint32)])
+MATCH_DTYPE = np.dtype([("best_k", np.uint32), ("best_count", np.uint16), ("second_count", np.uint16)])
+
+# every symbol include/ochip.h declares; tests check that the built library exports all of them
+EXPORTS = [
+    "ochip_ctx_create", "ochip_ctx_destroy", "ochip_last_error", "ochip_device_info", "ochip_synchronize",
+    "ochip_descriptors_reserve", "ochip_upload_descriptors", "ochip_descriptor_count",
+    "ochip_match_batch", "ochip_match_launch", "ochip_match_fetch",
+    "ochip_profile_reset", "ochip_profile_get",
+    "ochip_debug_fp64",
+]
+
+_lib = None
+
+
+class OchipError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OchipError(f"{LIB_PATH} is missing: run `python -m opencalibration_amd.build` "
+                             "(there is no CPU fallback for the hot path)")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        L.ochip_ctx_create.argtypes = [i32, C.POINTER(vp)]
+        L.ochip_ctx_destroy.argtypes = [vp]
+        L.ochip_ctx_destroy.restype = None
+        L.ochip_last_error.argtypes = [vp]
+        L.ochip_last_error.restype = C.c_char_p
+        L.ochip_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32), C.POINTER(C.c_size_t)]
+        L.ochip_synchronize.argtypes = [vp]
+        L.ochip_descriptors_reserve.argtypes = [vp, u32, u64]
+        L.ochip_upload_descriptors.argtypes = [vp, u32, vp, u32]
+        L.ochip_descriptor_count.argtypes = [vp, u32, C.POINTER(u32)]
+        L.ochip_match_batch.argtypes = [vp, vp, u32, vp, vp]
+        L.ochip_match_launch.argtypes = [vp, vp, u32, vp, u64]
+        L.ochip_match_fetch.argtypes = [vp, vp, u64]
+        L.ochip_profile_reset.argtypes = [vp]
+        L.ochip_profile_get.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(C.c_double)]
+        L.ochip_debug_fp64.argtypes = [vp, i32, vp, vp, C.c_size_t, vp]
+        _lib = L
+    return _lib
+
+
+class Context:
+    """Owns one ochip_ctx (one GPU)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.ochip_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise OchipError(f"ochip_ctx_create({device}) = {rc}: {self.L.ochip_last_error(None).decode()}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ochip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise OchipError(f"{what} = {rc}: {self.L.ochip_last_error(self.h).decode()}")
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu, mem = C.c_int(), C.c_size_t()
+        self._check(self.L.ochip_device_info(self.h, name, 256, C.byref(cu), C.byref(mem)), "ochip_device_info")
+        return dict(name=name.value.decode(), compute_units=cu.value, hbm_bytes=mem.value)
+
+    def synchronize(self):
+        self._check(self.L.ochip_synchronize(self.h), "ochip_synchronize")
+
+    def descriptors_reserve(self, n_images, total):
+        self._check(self.L.ochip_descriptors_reserve(self.h, n_images, total), "ochip_descriptors_reserve")
+
+    def upload_descriptors(self, image_id, desc):
+        desc = np.ascontiguousarray(desc, np.uint64).reshape(-1, 8)
+        self._check(self.L.ochip_upload_descriptors(self.h, image_id, desc.ctypes.data, len(desc)),
+                    "ochip_upload_descriptors")
+
+    def match_batch(self, pairs, out_offset, out_total=None):
+        pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
+        out_offset = np.ascontiguousarray(out_offset, np.uint64)
+        if out_total is None:
+            raise ValueError("out_total required")
+        out = np.zeros(max(out_total, 1), MATCH_DTYPE)
+        self._check(self.L.ochip_match_launch(self.h, pairs.ctypes.data, len(pairs), out_offset.ctypes.data, out_total),
+                    "ochip_match_launch")
+        self._check(self.L.ochip_match_fetch(self.h, out.ctypes.data, out_total), "ochip_match_fetch")
+        return out[:out_total]
+
+    def match_launch(self, pairs, out_offset, out_total):
+        pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
+        out_offset = np.ascontiguousarray(out_offset, np.uint64)
+        self._check(self.L.ochip_match_launch(self.h, pairs.ctypes.data, len(pairs), out_offset.ctypes.data, out_total),
+                    "ochip_match_launch")
+
+    def debug_fp64(self, op, x, y=None):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.ascontiguousarray(x if y is None else y, np.float64)
+        out = np.zeros_like(x)
+        self._check(self.L.ochip_debug_fp64(self.h, op, x.ctypes.data, y.ctypes.data, x.size, out.ctypes.data),
+                    "ochip_debug_fp64")
+        return out
+
+    def profile_reset(self):
+        self._check(self.L.ochip_profile_reset(self.h), "ochip_profile_reset")
+
+    def profile_get(self, kid):
+        n, ms = C.c_uint64(), C.c_double()
+        self._check(self.L.ochip_profile_get(self.h, kid, C.byref(n), C.byref(ms)), "ochip_profile_get")
+        return n.value, ms.value

@@ -1,0 +1,267 @@
+// libochip.so — context, device arenas, descriptor store, profiling.  gfx950 only.
+#include "ctx.hpp"
+
+#include <cstring>
+
+static std::string g_create_error;
+
+int ochip_fail(ochip_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->error = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+int ochip_ensure(ochip_ctx *ctx, void **ptr, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap)
+        return OCHIP_OK;
+    if (*ptr)
+        OCHIP_HIP(ctx, hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    if (hipMalloc(ptr, want) != hipSuccess)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc(%zu) failed", want);
+    *cap = want;
+    return OCHIP_OK;
+}
+
+void ochip_prof_begin(ochip_ctx *ctx, int kid, hipEvent_t *start, hipEvent_t *stop)
+{
+    auto &s = ctx->prof[kid];
+    if (!s.free_list.empty())
+    {
+        *start = s.free_list.back().first;
+        *stop = s.free_list.back().second;
+        s.free_list.pop_back();
+    }
+    else
+    {
+        (void)hipEventCreate(start);
+        (void)hipEventCreate(stop);
+    }
+    (void)hipEventRecord(*start, ctx->stream);
+}
+
+static void prof_drain(ochip_ctx *ctx, int kid)
+{
+    auto &s = ctx->prof[kid];
+    for (auto &p : s.pending)
+    {
+        float ms = 0;
+        (void)hipEventSynchronize(p.second);
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess)
+        {
+            s.total_ms += ms;
+            s.launches++;
+        }
+        s.free_list.push_back(p);
+    }
+    s.pending.clear();
+}
+
+void ochip_prof_end(ochip_ctx *ctx, int kid, hipEvent_t start, hipEvent_t stop)
+{
+    (void)hipEventRecord(stop, ctx->stream);
+    auto &s = ctx->prof[kid];
+    s.pending.emplace_back(start, stop);
+    if (s.pending.size() >= 4096)
+        prof_drain(ctx, kid);
+}
+
+extern "C"
+{
+
+int ochip_ctx_create(int device, ochip_ctx **out)
+{
+    if (!out)
+        return ochip_fail(nullptr, OCHIP_EINVAL, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return ochip_fail(nullptr, OCHIP_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= count)
+        return ochip_fail(nullptr, OCHIP_EINVAL, "device %d out of range (0..%d)", device, count - 1);
+    ochip_ctx *ctx = new (std::nothrow) ochip_ctx();
+    if (!ctx)
+        return ochip_fail(nullptr, OCHIP_ENOMEM, "host allocation failed");
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess)
+        e = hipGetDeviceProperties(&ctx->prop, device);
+    if (e == hipSuccess && std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0)
+    {
+        int rc = ochip_fail(nullptr, OCHIP_ENODEV, "device %d is %s; libochip is built for gfx950 only", device,
+                            ctx->prop.gcnArchName);
+        delete ctx;
+        return rc;
+    }
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e != hipSuccess)
+    {
+        int rc = ochip_fail(nullptr, OCHIP_EHIP, "context creation failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return OCHIP_OK;
+}
+
+void ochip_ctx_destroy(ochip_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &s : ctx->prof)
+    {
+        for (auto &p : s.pending)
+            s.free_list.push_back(p);
+        for (auto &p : s.free_list)
+        {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    }
+    void *bufs[] = {ctx->desc_dev, ctx->img_off_dev, ctx->img_n_dev, ctx->pairs_dev, ctx->out_off_dev, ctx->match_out_dev};
+    for (void *b : bufs)
+        if (b)
+            (void)hipFree(b);
+    for (void *b : ctx->scratch_dev)
+        if (b)
+            (void)hipFree(b);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream)
+        (void)hipStreamDestroy(ctx->copy_stream);
+    delete ctx;
+}
+
+const char *ochip_last_error(const ochip_ctx *ctx)
+{
+    return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+int ochip_device_info(const ochip_ctx *ctx, char *name, size_t name_len, int *compute_units, size_t *hbm_bytes)
+{
+    if (!ctx)
+        return OCHIP_EINVAL;
+    if (name && name_len)
+        snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (compute_units)
+        *compute_units = ctx->prop.multiProcessorCount;
+    if (hbm_bytes)
+        *hbm_bytes = ctx->prop.totalGlobalMem;
+    return OCHIP_OK;
+}
+
+int ochip_synchronize(ochip_ctx *ctx)
+{
+    if (!ctx)
+        return OCHIP_EINVAL;
+    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    return OCHIP_OK;
+}
+
+int ochip_descriptors_reserve(ochip_ctx *ctx, uint32_t n_images, uint64_t total_descriptors)
+{
+    if (!ctx)
+        return OCHIP_EINVAL;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (void **b : {(void **)&ctx->desc_dev, (void **)&ctx->img_off_dev, (void **)&ctx->img_n_dev})
+        if (*b)
+        {
+            OCHIP_HIP(ctx, hipFree(*b));
+            *b = nullptr;
+        }
+    ctx->desc_capacity = ctx->desc_used = 0;
+    ctx->n_images = n_images;
+    ctx->img_off.assign(n_images, 0);
+    ctx->img_n.assign(n_images, 0);
+    ctx->img_set.assign(n_images, 0);
+    ctx->img_tables_dirty = true;
+    const size_t bytes = (size_t)(total_descriptors ? total_descriptors : 1) * 64;
+    if (hipMalloc((void **)&ctx->desc_dev, bytes) != hipSuccess)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc(%zu) for the descriptor arena failed", bytes);
+    if (hipMalloc((void **)&ctx->img_off_dev, (size_t)(n_images ? n_images : 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&ctx->img_n_dev, (size_t)(n_images ? n_images : 1) * 4) != hipSuccess)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc for the image tables failed");
+    ctx->desc_capacity = total_descriptors;
+    return OCHIP_OK;
+}
+
+int ochip_upload_descriptors(ochip_ctx *ctx, uint32_t image_id, const uint64_t *desc, uint32_t n)
+{
+    if (!ctx)
+        return OCHIP_EINVAL;
+    if (image_id >= ctx->n_images)
+        return ochip_fail(ctx, OCHIP_EINVAL, "image_id %u >= reserved %u", image_id, ctx->n_images);
+    if (ctx->img_set[image_id])
+        return ochip_fail(ctx, OCHIP_ESTATE, "image %u already uploaded", image_id);
+    if (n && !desc)
+        return ochip_fail(ctx, OCHIP_EINVAL, "desc is NULL");
+    if (ctx->desc_used + n > ctx->desc_capacity)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "descriptor arena full (%llu + %u > %llu)",
+                          (unsigned long long)ctx->desc_used, n, (unsigned long long)ctx->desc_capacity);
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    if (n)
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->desc_dev + ctx->desc_used * 16, desc, (size_t)n * 64, hipMemcpyHostToDevice,
+                                      ctx->stream));
+    ctx->img_off[image_id] = ctx->desc_used;
+    ctx->img_n[image_id] = n;
+    ctx->img_set[image_id] = 1;
+    ctx->desc_used += n;
+    ctx->img_tables_dirty = true;
+    // pageable source: hipMemcpyAsync has consumed it when it returns only after a sync
+    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return OCHIP_OK;
+}
+
+int ochip_descriptor_count(const ochip_ctx *ctx, uint32_t image_id, uint32_t *n)
+{
+    if (!ctx || !n || image_id >= ctx->n_images || !ctx->img_set[image_id])
+        return OCHIP_EINVAL;
+    *n = ctx->img_n[image_id];
+    return OCHIP_OK;
+}
+
+int ochip_profile_reset(ochip_ctx *ctx)
+{
+    if (!ctx)
+        return OCHIP_EINVAL;
+    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < OCHIP_K_COUNT; k++)
+    {
+        prof_drain(ctx, k);
+        ctx->prof[k].launches = 0;
+        ctx->prof[k].total_ms = 0;
+    }
+    return OCHIP_OK;
+}
+
+int ochip_profile_get(ochip_ctx *ctx, int kernel_id, uint64_t *launches, double *total_ms)
+{
+    if (!ctx || kernel_id < 0 || kernel_id >= OCHIP_K_COUNT)
+        return OCHIP_EINVAL;
+    prof_drain(ctx, kernel_id);
+    if (launches)
+        *launches = ctx->prof[kernel_id].launches;
+    if (total_ms)
+        *total_ms = ctx->prof[kernel_id].total_ms;
+    return OCHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,67 @@
+// Internal context of libochip.so (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/ochip.h"
+
+struct ochip_profile_slot
+{
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_list;
+    uint64_t launches = 0;
+    double total_ms = 0;
+};
+
+struct ochip_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;     // compute stream: every kernel of the hot path is launched here
+    hipStream_t copy_stream = nullptr;
+    std::string error;
+    hipDeviceProp_t prop{};
+
+    // descriptor arena: [total][16] u32, image i at img_off[i] with img_n[i] descriptors
+    uint32_t *desc_dev = nullptr;
+    uint64_t desc_capacity = 0, desc_used = 0;
+    uint32_t n_images = 0;
+    std::vector<uint64_t> img_off;
+    std::vector<uint32_t> img_n;
+    std::vector<uint8_t> img_set;
+    uint64_t *img_off_dev = nullptr;
+    uint32_t *img_n_dev = nullptr;
+    bool img_tables_dirty = true;
+
+    // match scratch
+    ochip_pair *pairs_dev = nullptr;
+    uint64_t *out_off_dev = nullptr;
+    size_t pairs_cap = 0;
+    ochip_match *match_out_dev = nullptr;
+    size_t match_out_cap = 0;
+    uint64_t match_out_total = 0;
+
+    // generic scratch for the RANSAC / relax kernels (grown on demand)
+    void *scratch_dev[8] = {nullptr};
+    size_t scratch_cap[8] = {0};
+
+    ochip_profile_slot prof[OCHIP_K_COUNT];
+};
+
+int ochip_fail(ochip_ctx *ctx, int code, const char *fmt, ...);
+int ochip_ensure(ochip_ctx *ctx, void **ptr, size_t *cap, size_t bytes); // grow-only device buffer
+void ochip_prof_begin(ochip_ctx *ctx, int kid, hipEvent_t *start, hipEvent_t *stop);
+void ochip_prof_end(ochip_ctx *ctx, int kid, hipEvent_t start, hipEvent_t stop);
+
+#define OCHIP_HIP(ctx, call)                                                                                           \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e__ = (call);                                                                                       \
+        if (e__ != hipSuccess)                                                                                         \
+            return ochip_fail((ctx), OCHIP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,    \
+                              __LINE__);                                                                               \
+    } while (0)

@@ -1,0 +1,60 @@
+"""CPU-side checks of the C ABI: the built library exports every symbol include/ochip.h declares, the
+header and the ctypes binding agree, and the product path refuses to run without its native code."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from opencalibration_amd import build, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    return build.build_ochip()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ochip.h")).read()
+    return sorted(set(re.findall(r"\b(ochip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_list_agree():
+    assert _declared_symbols() == sorted(capi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(libpath):
+    lib = ctypes.CDLL(libpath)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/ochip.h but not exported"
+
+
+def test_struct_layouts_match_header():
+    assert capi.PAIR_DTYPE.itemsize == 8
+    assert capi.MATCH_DTYPE.itemsize == 8
+    assert capi.MATCH_DTYPE.fields["best_count"][1] == 4 and capi.MATCH_DTYPE.fields["second_count"][1] == 6
+
+
+def test_no_device_fails_loudly(libpath):
+    """Without a GPU the context cannot be created and nothing falls back to a CPU path."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.OchipError):
+        capi.Context(0)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under opencalibration_amd/ may import or link it."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "opencalibration_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"(from|import)\s+oracle\b|oracle/|liboracle|pyoracle", text):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
