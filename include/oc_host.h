@@ -27,6 +27,31 @@ extern "C"
     size_t och_matches_from_device(const ochip_match *raw, const uint64_t *idx1, size_t n1, const uint64_t *idx2,
                                    size_t n2, uint64_t *out_i1, uint64_t *out_i2, double *out_dist);
 
+    /* ---- MeasurementGraph + LinkStage driver (opencalibration_amd/csrc/host/link_stage.hpp) ---- */
+    typedef struct och_graph och_graph;
+    och_graph *och_graph_create(void);
+    void och_graph_destroy(och_graph *g);
+    const char *och_last_error(const och_graph *g);
+    /* m10 = {f, ppx, ppy, k1, k2, k3, p1, p2, pixels_cols, pixels_rows}; returns the model handle */
+    uint32_t och_graph_add_model(och_graph *g, const double *m10);
+    /* one image = what extract_features hands to the link stage; returns the node id */
+    uint64_t och_graph_add_image(och_graph *g, const double *loc, const float *strength, const uint64_t *desc, size_t n,
+                                 size_t num_sparse, uint32_t model, const double *position3);
+    size_t och_graph_num_nodes(const och_graph *g);
+    size_t och_graph_num_edges(const och_graph *g);
+    void och_graph_node_ids(const och_graph *g, uint64_t *out);
+    /* LinkStage::init + the batch runner + finalize; timers = 8 doubles {link_init, subsample, upload,
+     * match_device, match_host, ransac_device, decompose_host, link_finalize} seconds */
+    int och_link_stage_run(och_graph *g, ochip_ctx *ctx, const uint64_t *node_ids, size_t n, int keep_debug,
+                           double *timers);
+    size_t och_link_debug_count(const och_graph *g);
+    void och_link_debug_pair(const och_graph *g, size_t p, uint64_t *ids2, uint64_t *n_matches, double *score,
+                             uint32_t *iters3);
+    void och_link_debug_matches(const och_graph *g, size_t p, uint64_t *i1, uint64_t *i2, double *dist, uint8_t *inl);
+    void och_graph_edge_info(const och_graph *g, size_t e, uint64_t *ids2, uint64_t *counts2, double *H, double *poses);
+    void och_graph_edge_inliers(const och_graph *g, size_t e, uint64_t *f1, uint64_t *f2, uint64_t *match_index,
+                                double *px4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,49 @@ extern "C"
                            uint64_t out_total);
     int ochip_match_fetch(ochip_ctx *ctx, ochip_match *out, uint64_t out_total);
 
+    /* ---- keypoints -> unit rays (replaces image_to_3d of src/distort/distort_keypoints.cpp:68-103,
+     *      hoisted from once per match to once per keypoint) ------------------------------------------ */
+    /* xy: n x 2 pixel locations in the same subset order as the descriptors of image_id (n must equal
+     * the uploaded descriptor count).  model8 = {focal_length_pixels, pp_x, pp_y, k1, k2, k3, p1, p2}
+     * (DifferentiableCameraModel, include/opencalibration/types/camera_model.hpp:22-60). */
+    int ochip_upload_keypoints(ochip_ctx *ctx, uint32_t image_id, const double *xy, uint32_t n, const double *model8);
+
+    /* ---- homography RANSAC, one job per directed pair (replaces ransac<homography_model>,
+     *      src/model_inliers/ransac.cpp:53-257 + homography_model.cpp:19-136) -------------------------- */
+    typedef struct ochip_ransac_match
+    {
+        uint32_t k1, k2;   /* positions of the matched keypoints in the uploaded subsets of image_1 / image_2 */
+        uint16_t count;    /* Hamming distance; correspondence.quality = count * (1.0/486) */
+        uint16_t reserved; /* 0 */
+    } ochip_ransac_match;
+
+    typedef struct ochip_ransac_job
+    {
+        uint32_t image_1, image_2;
+        uint32_t n;            /* number of matches = correspondences, in match_features_subset's output order */
+        uint32_t rng_state;    /* std::default_random_engine(42) state after std::shuffle(eval_order) */
+        uint64_t match_offset; /* into matches[], sorted_idx[] and inliers[] */
+        uint64_t eval_offset;  /* into eval_order[]: iota(n) after std::shuffle (ransac.cpp:158) */
+    } ochip_ransac_job;
+
+    typedef struct ochip_ransac_result
+    {
+        double H[9];           /* row-major homography (model.homography), NaN if nothing was fitted */
+        double score;          /* return value of ransac(): evaluate(best) / n */
+        uint32_t iterations;   /* loop trips executed */
+        uint32_t n_inliers;
+        uint32_t improvements; /* times a hypothesis beat the best score */
+        uint32_t reserved;
+    } ochip_ransac_result;
+
+    /* sorted_idx: per job, iota(n) std::sort-ed by quality ascending (the PROSAC order, ransac.cpp:83-90);
+     * both it and eval_order come from the host's libstdc++ so tie order is the reference's.
+     * inliers: total_matches bytes, 1 = inlier, indexed like matches[]. */
+    int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs,
+                                      const ochip_ransac_match *matches, const uint32_t *sorted_idx,
+                                      uint64_t total_matches, const uint32_t *eval_order, uint64_t eval_total,
+                                      double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers);
+
     /* ---- profiling: HIP-event time of every launch of a kernel since the last reset ------------- */
     int ochip_profile_reset(ochip_ctx *ctx);
     int ochip_profile_get(ochip_ctx *ctx, int kernel_id, uint64_t *launches, double *total_ms);

@@ -19,6 +19,7 @@ EXPORTS = [
     "ochip_ctx_create", "ochip_ctx_destroy", "ochip_last_error", "ochip_device_info", "ochip_synchronize",
     "ochip_descriptors_reserve", "ochip_upload_descriptors", "ochip_descriptor_count",
     "ochip_match_batch", "ochip_match_launch", "ochip_match_fetch",
+    "ochip_upload_keypoints", "ochip_ransac_homography_batch",
     "ochip_profile_reset", "ochip_profile_get",
     "ochip_debug_fp64",
 ]

@@ -134,7 +134,8 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
             (void)hipEventDestroy(p.second);
         }
     }
-    void *bufs[] = {ctx->desc_dev, ctx->img_off_dev, ctx->img_n_dev, ctx->pairs_dev, ctx->out_off_dev, ctx->match_out_dev};
+    void *bufs[] = {ctx->desc_dev,      ctx->img_off_dev,   ctx->img_n_dev, ctx->pairs_dev,    ctx->out_off_dev,
+                    ctx->match_out_dev, ctx->kp_xy_dev,     ctx->rays_dev,  ctx->kp_image_dev, ctx->models_dev};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -181,12 +182,16 @@ int ochip_descriptors_reserve(ochip_ctx *ctx, uint32_t n_images, uint64_t total_
         return OCHIP_EINVAL;
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
     OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (void **b : {(void **)&ctx->desc_dev, (void **)&ctx->img_off_dev, (void **)&ctx->img_n_dev})
+    for (void **b : {(void **)&ctx->desc_dev, (void **)&ctx->img_off_dev, (void **)&ctx->img_n_dev,
+                     (void **)&ctx->kp_xy_dev, (void **)&ctx->rays_dev, (void **)&ctx->kp_image_dev,
+                     (void **)&ctx->models_dev})
         if (*b)
         {
             OCHIP_HIP(ctx, hipFree(*b));
             *b = nullptr;
         }
+    ctx->kp_set.clear();
+    ctx->rays_dirty = false;
     ctx->desc_capacity = ctx->desc_used = 0;
     ctx->n_images = n_images;
     ctx->img_off.assign(n_images, 0);

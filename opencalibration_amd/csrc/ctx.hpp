@@ -37,6 +37,14 @@ struct ochip_ctx
     uint32_t *img_n_dev = nullptr;
     bool img_tables_dirty = true;
 
+    // keypoint store, same indexing as the descriptor arena: pixel xy, owning image, unit rays
+    double *kp_xy_dev = nullptr;
+    double *rays_dev = nullptr;
+    uint32_t *kp_image_dev = nullptr;
+    double *models_dev = nullptr; // [n_images][8]: f, ppx, ppy, k1, k2, k3, p1, p2
+    std::vector<uint8_t> kp_set;
+    bool rays_dirty = false;
+
     // match scratch
     ochip_pair *pairs_dev = nullptr;
     uint64_t *out_off_dev = nullptr;

@@ -53,3 +53,172 @@ size_t och_matches_from_device(const ochip_match *raw, const uint64_t *idx1, siz
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// graph + link stage driver
+#include "link_stage.hpp"
+
+struct och_graph
+{
+    MeasurementGraph graph;
+    std::vector<std::shared_ptr<CameraModel>> models;
+    std::unique_ptr<LinkStage> link;
+    std::string error;
+};
+
+extern "C"
+{
+
+och_graph *och_graph_create(void)
+{
+    return new (std::nothrow) och_graph();
+}
+
+void och_graph_destroy(och_graph *g)
+{
+    delete g;
+}
+
+const char *och_last_error(const och_graph *g)
+{
+    return g ? g->error.c_str() : "null graph";
+}
+
+uint32_t och_graph_add_model(och_graph *g, const double *m10)
+{
+    auto m = std::make_shared<CameraModel>();
+    m->focal_length_pixels = m10[0];
+    m->principle_point[0] = m10[1];
+    m->principle_point[1] = m10[2];
+    for (int i = 0; i < 3; i++)
+        m->radial_distortion[i] = m10[3 + i];
+    m->tangential_distortion[0] = m10[6];
+    m->tangential_distortion[1] = m10[7];
+    m->pixels_cols = (size_t)m10[8];
+    m->pixels_rows = (size_t)m10[9];
+    m->id = g->models.size() + 1;
+    g->models.push_back(m);
+    return (uint32_t)(g->models.size() - 1);
+}
+
+uint64_t och_graph_add_image(och_graph *g, const double *loc, const float *strength, const uint64_t *desc, size_t n,
+                             size_t num_sparse, uint32_t model, const double *position3)
+{
+    image img;
+    img.features = features_from(loc, strength, desc, n);
+    img.num_sparse_features = num_sparse;
+    img.model = g->models.at(model);
+    for (int i = 0; i < 3; i++)
+        img.position[i] = position3[i];
+    img.path = "synthetic_" + std::to_string(g->graph.size_nodes());
+    return g->graph.addNode(std::move(img));
+}
+
+size_t och_graph_num_nodes(const och_graph *g)
+{
+    return g->graph.size_nodes();
+}
+size_t och_graph_num_edges(const och_graph *g)
+{
+    return g->graph.size_edges();
+}
+void och_graph_node_ids(const och_graph *g, uint64_t *out)
+{
+    size_t i = 0;
+    for (const auto &n : g->graph.nodes())
+        out[i++] = n.id;
+}
+
+// init + the single runner + finalize over the given nodes.  timers: 8 doubles (LinkTimers order).
+int och_link_stage_run(och_graph *g, ochip_ctx *ctx, const uint64_t *node_ids, size_t n, int keep_debug, double *timers)
+{
+    g->link = std::make_unique<LinkStage>(ctx);
+    g->link->keep_debug = keep_debug != 0;
+    std::vector<size_t> ids(node_ids, node_ids + n);
+    g->link->init(g->graph, ids);
+    for (auto &f : g->link->get_runners(g->graph))
+        f();
+    if (!g->link->error.empty())
+    {
+        g->error = g->link->error;
+        return -1;
+    }
+    g->link->finalize(g->graph);
+    if (timers)
+    {
+        const LinkTimers &t = g->link->timers;
+        const double v[8] = {t.link_init,  t.subsample,     t.upload,         t.match_device,
+                             t.match_host, t.ransac_device, t.decompose_host, t.link_finalize};
+        std::memcpy(timers, v, sizeof v);
+    }
+    return 0;
+}
+
+size_t och_link_debug_count(const och_graph *g)
+{
+    return g->link ? g->link->debug.size() : 0;
+}
+
+void och_link_debug_pair(const och_graph *g, size_t p, uint64_t *ids2, uint64_t *n_matches, double *score,
+                         uint32_t *iters3 /*iterations, improvements, can_decompose*/)
+{
+    const auto &d = g->link->debug.at(p);
+    ids2[0] = d.node_id;
+    ids2[1] = d.match_node_id;
+    *n_matches = d.matches.size();
+    *score = d.score;
+    iters3[0] = d.iterations;
+    iters3[1] = d.improvements;
+    iters3[2] = d.can_decompose ? 1 : 0;
+}
+
+void och_link_debug_matches(const och_graph *g, size_t p, uint64_t *i1, uint64_t *i2, double *dist, uint8_t *inl)
+{
+    const auto &d = g->link->debug.at(p);
+    for (size_t i = 0; i < d.matches.size(); i++)
+    {
+        i1[i] = d.matches[i].feature_index_1;
+        i2[i] = d.matches[i].feature_index_2;
+        dist[i] = d.matches[i].distance;
+        inl[i] = d.inliers[i];
+    }
+}
+
+// edge e in insertion order: ids2 = {source, dest}; counts2 = {matches, inlier_matches}; H 9; poses 4x8
+void och_graph_edge_info(const och_graph *g, size_t e, uint64_t *ids2, uint64_t *counts2, double *H, double *poses)
+{
+    const auto &ed = g->graph.edges().at(e);
+    ids2[0] = ed.source;
+    ids2[1] = ed.dest;
+    counts2[0] = ed.payload.matches.size();
+    counts2[1] = ed.payload.inlier_matches.size();
+    std::memcpy(H, ed.payload.ransac_relation, 72);
+    for (int i = 0; i < 4; i++)
+    {
+        const auto &p = ed.payload.relative_poses[i];
+        double *o = poses + 8 * i;
+        for (int k = 0; k < 4; k++)
+            o[k] = p.orientation[k];
+        for (int k = 0; k < 3; k++)
+            o[4 + k] = p.position[k];
+        o[7] = p.score;
+    }
+}
+
+void och_graph_edge_inliers(const och_graph *g, size_t e, uint64_t *f1, uint64_t *f2, uint64_t *match_index, double *px4)
+{
+    const auto &ed = g->graph.edges().at(e);
+    for (size_t i = 0; i < ed.payload.inlier_matches.size(); i++)
+    {
+        const auto &m = ed.payload.inlier_matches[i];
+        f1[i] = m.feature_index_1;
+        f2[i] = m.feature_index_2;
+        match_index[i] = m.match_index;
+        px4[4 * i] = m.pixel_1[0];
+        px4[4 * i + 1] = m.pixel_1[1];
+        px4[4 * i + 2] = m.pixel_2[0];
+        px4[4 * i + 3] = m.pixel_2[1];
+    }
+}
+
+} // extern "C"

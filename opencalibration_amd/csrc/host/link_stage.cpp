@@ -1,0 +1,329 @@
+#include "link_stage.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <limits>
+#include <tuple>
+
+namespace opencalibration_amd
+{
+
+namespace
+{
+using clk = std::chrono::steady_clock;
+double since(clk::time_point t0)
+{
+    return std::chrono::duration<double>(clk::now() - t0).count();
+}
+} // namespace
+
+void LinkStage::init(const MeasurementGraph &graph, const std::vector<size_t> &node_ids)
+{
+    const auto t0 = clk::now();
+    _links.clear();
+    _links.reserve(node_ids.size());
+    const auto &nodes = graph.nodes();
+    std::vector<std::pair<double, size_t>> dist(nodes.size());
+    for (size_t node_id : node_ids)
+    {
+        const image &img = graph.getNode(node_id)->payload;
+        for (size_t j = 0; j < nodes.size(); j++)
+        {
+            // SquaredL2 of the reference's KD-tree (external/jk-tree/include/jk/KDTree.h:681-691)
+            const double dx = img.position[0] - nodes[j].payload.position[0];
+            const double dy = img.position[1] - nodes[j].payload.position[1];
+            double d = 0;
+            d += dx * dx;
+            d += dy * dy;
+            dist[j] = {d, nodes[j].id};
+        }
+        const size_t k = std::min<size_t>(10, dist.size());
+        std::partial_sort(dist.begin(), dist.begin() + k, dist.end(),
+                          [](const auto &a, const auto &b) { return a.first < b.first; });
+        NodeLinks link;
+        link.node_id = node_id;
+        link.link_ids.reserve(k);
+        for (size_t j = 0; j < k; j++)
+            if (dist[j].second != node_id)
+                link.link_ids.push_back(dist[j].second);
+        _links.emplace_back(std::move(link));
+    }
+    timers.link_init += since(t0);
+}
+
+std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph &graph)
+{
+    std::vector<std::function<void()>> funcs;
+    funcs.push_back([this, &graph]() { run_batch(graph); });
+    return funcs;
+}
+
+void LinkStage::run_batch(const MeasurementGraph &graph)
+{
+    struct pair_job
+    {
+        size_t loop_index, node_id, match_node_id;
+        uint32_t slot_1, slot_2;
+    };
+    // ---- images of this batch -> device slots
+    std::vector<size_t> slot_node;
+    std::unordered_map<size_t, uint32_t> slot_of;
+    auto slot_for = [&](size_t id) {
+        auto it = slot_of.find(id);
+        if (it != slot_of.end())
+            return it->second;
+        const uint32_t s = (uint32_t)slot_node.size();
+        slot_of.emplace(id, s);
+        slot_node.push_back(id);
+        return s;
+    };
+    std::vector<pair_job> jobs;
+    for (size_t i = 0; i < _links.size(); i++)
+        for (size_t match_node_id : _links[i].link_ids)
+        {
+            if (graph.getNode(match_node_id) == nullptr) // link_stage.cpp:69-73
+                continue;
+            jobs.push_back(pair_job{i, _links[i].node_id, match_node_id, slot_for(_links[i].node_id), slot_for(match_node_id)});
+        }
+    const size_t n_slots = slot_node.size(), n_pairs = jobs.size();
+    if (n_pairs == 0)
+        return;
+    auto fail = [this](const char *what) {
+        error = std::string(what) + ": " + ochip_last_error(_ctx);
+    };
+
+    // ---- 40 px subsets, once per image (link_stage.cpp:63-65,80-81; the per-pair recomputation of
+    //      the reference yields the same vector every time)
+    auto t0 = clk::now();
+    const double coarse_spacing_pixels = 40.0;
+    std::vector<std::vector<size_t>> subset(n_slots);
+    std::vector<std::vector<double>> rays(n_slots); // unit rays of the subset keypoints (for decompose)
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t s = 0; s < n_slots; s++)
+    {
+        const image &img = graph.getNode(slot_node[s])->payload;
+        subset[s] = spatially_subsample_feature_indices(img.features, coarse_spacing_pixels, img.num_sparse_features);
+        rays[s].resize(subset[s].size() * 3);
+        for (size_t k = 0; k < subset[s].size(); k++)
+            image_to_3d(img.features[subset[s][k]].location, *img.model, &rays[s][3 * k]);
+    }
+    timers.subsample += since(t0);
+
+    // ---- upload descriptors + keypoints
+    t0 = clk::now();
+    uint64_t total_desc = 0;
+    for (const auto &s : subset)
+        total_desc += s.size();
+    if (ochip_descriptors_reserve(_ctx, (uint32_t)n_slots, total_desc) != OCHIP_OK)
+        return fail("ochip_descriptors_reserve");
+    {
+        std::vector<uint64_t> dbuf;
+        std::vector<double> xybuf;
+        for (size_t s = 0; s < n_slots; s++)
+        {
+            const image &img = graph.getNode(slot_node[s])->payload;
+            const size_t n = subset[s].size();
+            dbuf.resize(n * 8);
+            xybuf.resize(n * 2);
+            for (size_t k = 0; k < n; k++)
+            {
+                const feature_2d &f = img.features[subset[s][k]];
+                std::memcpy(&dbuf[8 * k], f.descriptor, 64);
+                xybuf[2 * k] = f.location[0];
+                xybuf[2 * k + 1] = f.location[1];
+            }
+            const CameraModel &m = *img.model;
+            const double model8[8] = {m.focal_length_pixels,   m.principle_point[0],    m.principle_point[1],
+                                      m.radial_distortion[0],  m.radial_distortion[1],  m.radial_distortion[2],
+                                      m.tangential_distortion[0], m.tangential_distortion[1]};
+            if (ochip_upload_descriptors(_ctx, (uint32_t)s, dbuf.data(), (uint32_t)n) != OCHIP_OK)
+                return fail("ochip_upload_descriptors");
+            if (ochip_upload_keypoints(_ctx, (uint32_t)s, xybuf.data(), (uint32_t)n, model8) != OCHIP_OK)
+                return fail("ochip_upload_keypoints");
+        }
+    }
+    timers.upload += since(t0);
+
+    // ---- device: Hamming 2-NN for every pair
+    t0 = clk::now();
+    std::vector<ochip_pair> pairs(n_pairs);
+    std::vector<uint64_t> out_off(n_pairs);
+    uint64_t out_total = 0;
+    for (size_t p = 0; p < n_pairs; p++)
+    {
+        pairs[p] = ochip_pair{jobs[p].slot_1, jobs[p].slot_2};
+        out_off[p] = out_total;
+        out_total += subset[jobs[p].slot_1].size();
+    }
+    std::vector<ochip_match> raw(out_total ? out_total : 1);
+    if (ochip_match_launch(_ctx, pairs.data(), (uint32_t)n_pairs, out_off.data(), out_total) != OCHIP_OK)
+        return fail("ochip_match_launch");
+    if (ochip_match_fetch(_ctx, raw.data(), out_total) != OCHIP_OK)
+        return fail("ochip_match_fetch");
+    timers.match_device += since(t0);
+
+    // ---- host: ratio test, std::sort, PROSAC order; pack the RANSAC jobs
+    t0 = clk::now();
+    struct sorted_match
+    {
+        feature_match m;
+        uint32_t k1, k2;
+        uint16_t count;
+    };
+    std::vector<std::vector<feature_match>> matches(n_pairs);
+    std::vector<std::vector<ochip_ransac_match>> rmatches(n_pairs);
+    std::vector<std::vector<uint32_t>> sorted_idx(n_pairs);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t p = 0; p < n_pairs; p++)
+    {
+        const auto &idx1 = subset[jobs[p].slot_1], &idx2 = subset[jobs[p].slot_2];
+        const ochip_match *r = raw.data() + out_off[p];
+        // match_features_subset tail (match_features.cpp:94-101) with the subset positions carried along:
+        // the permutation std::sort produces depends only on the comparison results, which are those
+        // of the reference's comparator on the same sequence
+        std::vector<sorted_match> sm;
+        sm.reserve(idx1.size());
+        if (!idx2.empty())
+            for (size_t a = 0; a < idx1.size(); a++)
+            {
+                const double best = (size_t)r[a].best_count * (1.0 / feature_2d::DESCRIPTOR_BITS);
+                const double second = r[a].second_count == OCHIP_NO_SECOND
+                                          ? std::numeric_limits<double>::infinity()
+                                          : (size_t)r[a].second_count * (1.0 / feature_2d::DESCRIPTOR_BITS);
+                if (best < 0.8 * second)
+                    sm.push_back(sorted_match{feature_match{idx1[a], idx2[r[a].best_k], best}, (uint32_t)a,
+                                              r[a].best_k, r[a].best_count});
+            }
+        std::sort(sm.begin(), sm.end(),
+                  [](const sorted_match &f1, const sorted_match &f2) -> bool { return f1.m.distance > f2.m.distance; });
+        matches[p].resize(sm.size());
+        rmatches[p].resize(sm.size());
+        for (size_t i = 0; i < sm.size(); i++)
+        {
+            matches[p][i] = sm[i].m;
+            rmatches[p][i] = ochip_ransac_match{sm[i].k1, sm[i].k2, sm[i].count, 0};
+        }
+        sorted_idx[p] = prosac_sorted_idx(matches[p]);
+    }
+    std::vector<ochip_ransac_job> rjobs(n_pairs);
+    uint64_t total_matches = 0;
+    std::map<size_t, uint64_t> eval_off_of; // distinct M -> offset into the eval_order table
+    std::vector<uint32_t> eval_table;
+    for (size_t p = 0; p < n_pairs; p++)
+    {
+        const size_t M = matches[p].size();
+        auto it = eval_off_of.find(M);
+        uint32_t rng_state = 42;
+        if (it == eval_off_of.end())
+        {
+            const eval_order_entry &e = _eval_cache.get(M);
+            it = eval_off_of.emplace(M, eval_table.size()).first;
+            eval_table.insert(eval_table.end(), e.order.begin(), e.order.end());
+            rng_state = e.rng_state;
+        }
+        else
+            rng_state = _eval_cache.get(M).rng_state;
+        rjobs[p] = ochip_ransac_job{jobs[p].slot_1, jobs[p].slot_2, (uint32_t)M, rng_state, total_matches, it->second};
+        total_matches += M;
+    }
+    std::vector<ochip_ransac_match> rm_flat(total_matches ? total_matches : 1);
+    std::vector<uint32_t> si_flat(total_matches ? total_matches : 1, 0);
+    for (size_t p = 0; p < n_pairs; p++)
+    {
+        std::copy(rmatches[p].begin(), rmatches[p].end(), rm_flat.begin() + rjobs[p].match_offset);
+        if (!sorted_idx[p].empty())
+            std::copy(sorted_idx[p].begin(), sorted_idx[p].end(), si_flat.begin() + rjobs[p].match_offset);
+    }
+    timers.match_host += since(t0);
+
+    // ---- device: RANSAC
+    t0 = clk::now();
+    std::vector<ochip_ransac_result> results(n_pairs);
+    std::vector<uint8_t> inl_flat(total_matches ? total_matches : 1);
+    const homography_model model_defaults;
+    if (ochip_ransac_homography_batch(_ctx, rjobs.data(), (uint32_t)n_pairs, rm_flat.data(), si_flat.data(),
+                                      total_matches, eval_table.data(), eval_table.size(),
+                                      model_defaults.inlier_threshold, results.data(), inl_flat.data()) != OCHIP_OK)
+        return fail("ochip_ransac_homography_batch");
+    timers.ransac_device += since(t0);
+
+    // ---- host: decompose, accept, assemble (link_stage.cpp:95-111)
+    t0 = clk::now();
+    std::vector<edge_payload> payloads(n_pairs);
+    std::vector<pair_debug> dbg(keep_debug ? n_pairs : 0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t p = 0; p < n_pairs; p++)
+    {
+        const image &img = graph.getNode(jobs[p].node_id)->payload;
+        const image &near_image = graph.getNode(jobs[p].match_node_id)->payload;
+        const size_t M = matches[p].size();
+        const uint8_t *inl = inl_flat.data() + rjobs[p].match_offset;
+        camera_relations relations;
+        homography_model h;
+        std::memcpy(h.homography, results[p].H, sizeof h.homography);
+        std::memcpy(relations.ransac_relation, results[p].H, sizeof relations.ransac_relation);
+        relations.relationType = camera_relations::RelationType::HOMOGRAPHY;
+
+        std::vector<bool> coarse_inliers(M);
+        std::vector<correspondence> coarse_correspondences(M);
+        const auto &ray1 = rays[jobs[p].slot_1], &ray2 = rays[jobs[p].slot_2];
+        for (size_t i = 0; i < M; i++)
+        {
+            coarse_inliers[i] = inl[i] != 0;
+            std::memcpy(coarse_correspondences[i].measurement1, &ray1[3 * rmatches[p][i].k1], 24);
+            std::memcpy(coarse_correspondences[i].measurement2, &ray2[3 * rmatches[p][i].k2], 24);
+            coarse_correspondences[i].quality = matches[p][i].distance;
+        }
+        const bool can_decompose = h.decompose(coarse_correspondences, coarse_inliers, relations.relative_poses);
+        const size_t num_coarse_inliers = std::count(coarse_inliers.begin(), coarse_inliers.end(), true);
+        if (keep_debug)
+        {
+            dbg[p].node_id = jobs[p].node_id;
+            dbg[p].match_node_id = jobs[p].match_node_id;
+            dbg[p].matches = matches[p];
+            dbg[p].inliers.assign(inl, inl + M);
+            dbg[p].score = results[p].score;
+            dbg[p].iterations = results[p].iterations;
+            dbg[p].improvements = results[p].improvements;
+            dbg[p].can_decompose = can_decompose;
+        }
+        if (can_decompose && num_coarse_inliers > h.MINIMUM_POINTS * 1.5)
+        {
+            relations.matches = std::move(matches[p]);
+            assembleInliers(relations.matches, coarse_inliers, img.features, near_image.features,
+                            relations.inlier_matches);
+        }
+        payloads[p] = edge_payload{jobs[p].loop_index, jobs[p].node_id, jobs[p].match_node_id, std::move(relations)};
+    }
+    {
+        std::lock_guard<std::mutex> lock(_measurement_mutex);
+        for (auto &pl : payloads)
+            _all_inlier_measurements.emplace_back(std::move(pl));
+        for (auto &d : dbg)
+            debug.emplace_back(std::move(d));
+    }
+    timers.decompose_host += since(t0);
+}
+
+std::vector<size_t> LinkStage::finalize(MeasurementGraph &graph)
+{
+    const auto t0 = clk::now();
+    std::sort(_all_inlier_measurements.begin(), _all_inlier_measurements.end(), [](const auto &a, const auto &b) {
+        return std::make_tuple(a.loop_index, a.node_id, a.match_node_id) <
+               std::make_tuple(b.loop_index, b.node_id, b.match_node_id);
+    });
+    for (auto &measurements : _all_inlier_measurements)
+        graph.addEdge(std::move(measurements.relations), measurements.node_id, measurements.match_node_id);
+    _all_inlier_measurements.clear();
+
+    std::vector<size_t> node_ids;
+    node_ids.reserve(_links.size());
+    for (const auto &link : _links)
+        node_ids.push_back(link.node_id);
+    _links.clear();
+    timers.link_finalize += since(t0);
+    return node_ids;
+}
+
+} // namespace opencalibration_amd

@@ -1,0 +1,79 @@
+// LinkStage with the reference's interface (src/pipeline/link_stage.hpp:25-30: init / get_runners /
+// finalize), re-stated for a device: get_runners returns ONE runner that pushes the whole batch of
+// directed pairs through libochip.so instead of one closure per pair.
+#pragma once
+
+#include "match_features.hpp"
+#include "ransac.hpp"
+#include "types.hpp"
+
+#include <functional>
+#include <map>
+#include <mutex>
+
+namespace opencalibration_amd
+{
+
+struct LinkTimers // seconds; names follow the reference's PerformanceMeasure keys where one exists
+{
+    double link_init = 0;          // "Link init"
+    double subsample = 0;          // part of "Link runner coarse match" in the reference
+    double upload = 0;             // host -> HBM (descriptors, keypoints)
+    double match_device = 0;       // "Link runner coarse match": device kernel + result fetch
+    double match_host = 0;         // ratio test + std::sort + PROSAC order
+    double ransac_device = 0;      // "Link runner coarse ransac": device
+    double decompose_host = 0;     // decompose + assembleInliers
+    double link_finalize = 0;      // "Link finalize"
+};
+
+class LinkStage
+{
+  public:
+    struct pair_debug // per directed pair, in runner order; kept only when keep_debug is set
+    {
+        size_t node_id, match_node_id;
+        std::vector<feature_match> matches;
+        std::vector<uint8_t> inliers;
+        double score = 0;
+        uint32_t iterations = 0, improvements = 0;
+        bool can_decompose = false;
+    };
+
+    explicit LinkStage(ochip_ctx *ctx) : _ctx(ctx)
+    {
+    }
+
+    // link_stage.cpp:13-38.  The reference queries the GPS KD-tree LoadStage::finalize filled with every
+    // loaded image (load_stage.cpp:102-103); here the graph's nodes are searched directly (exact kNN,
+    // k = 10 including the node itself).
+    void init(const MeasurementGraph &graph, const std::vector<size_t> &node_ids);
+
+    // link_stage.cpp:41-117
+    std::vector<std::function<void()>> get_runners(const MeasurementGraph &graph);
+
+    // link_stage.cpp:119-143
+    std::vector<size_t> finalize(MeasurementGraph &graph);
+
+    bool keep_debug = false;
+    std::vector<pair_debug> debug;
+    LinkTimers timers;
+    std::string error; // non-empty if the runner failed (the reference has no exceptions on this path)
+
+  private:
+    struct edge_payload
+    {
+        size_t loop_index;
+        size_t node_id;
+        size_t match_node_id;
+        camera_relations relations;
+    };
+    void run_batch(const MeasurementGraph &graph);
+
+    ochip_ctx *_ctx;
+    std::vector<edge_payload> _all_inlier_measurements;
+    std::mutex _measurement_mutex;
+    std::vector<NodeLinks> _links;
+    EvalOrderCache _eval_cache;
+};
+
+} // namespace opencalibration_amd

@@ -1,0 +1,344 @@
+#include "ransac.hpp"
+
+#include <algorithm>
+#include <numeric>
+#include <sstream>
+
+namespace opencalibration_amd
+{
+
+const eval_order_entry &EvalOrderCache::get(size_t M)
+{
+    std::lock_guard<std::mutex> lock(_mutex);
+    auto it = _cache.find(M);
+    if (it != _cache.end())
+        return *it->second;
+    // ransac.cpp:92-98,158 — same engine, same seed, same libstdc++ std::shuffle
+    std::vector<size_t> eval_order(M);
+    std::iota(eval_order.begin(), eval_order.end(), 0);
+    std::default_random_engine generator(42);
+    std::shuffle(eval_order.begin(), eval_order.end(), generator);
+    auto e = std::make_unique<eval_order_entry>();
+    e->order.assign(eval_order.begin(), eval_order.end());
+    std::ostringstream os;
+    os << generator; // minstd_rand0 streams its single state word
+    e->rng_state = (uint32_t)std::stoul(os.str());
+    return *_cache.emplace(M, std::move(e)).first->second;
+}
+
+std::vector<uint32_t> prosac_sorted_idx(const std::vector<feature_match> &matches)
+{
+    bool has_quality = false;
+    for (const auto &m : matches)
+        if (m.distance != 0)
+        {
+            has_quality = true;
+            break;
+        }
+    std::vector<uint32_t> out;
+    if (!has_quality)
+        return out;
+    std::vector<size_t> sorted_idx(matches.size());
+    std::iota(sorted_idx.begin(), sorted_idx.end(), 0);
+    std::sort(sorted_idx.begin(), sorted_idx.end(),
+              [&matches](size_t a, size_t b) { return matches[a].distance < matches[b].distance; });
+    out.assign(sorted_idx.begin(), sorted_idx.end());
+    return out;
+}
+
+void image_to_3d(const double keypoint[2], const CameraModel &model, double ray[3])
+{
+    const double u = (keypoint[0] - model.principle_point[0]) / model.focal_length_pixels;
+    const double v = (keypoint[1] - model.principle_point[1]) / model.focal_length_pixels;
+    const double z = u * u + v * v + 1.0 * 1.0;
+    ray[0] = u;
+    ray[1] = v;
+    ray[2] = 1.0;
+    if (z > 0)
+    {
+        const double n = std::sqrt(z);
+        ray[0] = u / n;
+        ray[1] = v / n;
+        ray[2] = 1.0 / n;
+    }
+}
+
+void assembleInliers(const std::vector<feature_match> &matches, const std::vector<bool> &inliers,
+                     const std::vector<feature_2d> &source_features, const std::vector<feature_2d> &dest_features,
+                     std::vector<feature_match_denormalized> &inlier_list)
+{
+    inlier_list.reserve(std::count(inliers.begin(), inliers.end(), true));
+    for (size_t i = 0; i < matches.size(); i++)
+    {
+        if (!inliers[i])
+            continue;
+        feature_match_denormalized fmd;
+        const feature_2d &s = source_features[matches[i].feature_index_1], &d = dest_features[matches[i].feature_index_2];
+        fmd.pixel_1[0] = s.location[0];
+        fmd.pixel_1[1] = s.location[1];
+        fmd.pixel_2[0] = d.location[0];
+        fmd.pixel_2[1] = d.location[1];
+        fmd.feature_index_1 = matches[i].feature_index_1;
+        fmd.feature_index_2 = matches[i].feature_index_2;
+        fmd.match_index = i;
+        inlier_list.push_back(fmd);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::decomposeHomographyMat(H, K = I): analytical decomposition of Malis & Vargas (INRIA RR-6303),
+// as implemented by OpenCV's HomographyDecompInria.  Third-party algorithm restated from its
+// publication; results are pinned by the reference's test/test_ransac_unit.cpp tolerances.
+namespace
+{
+struct M3
+{
+    double a[3][3];
+};
+
+M3 mul(const M3 &x, const M3 &y)
+{
+    M3 r;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            r.a[i][j] = x.a[i][0] * y.a[0][j] + x.a[i][1] * y.a[1][j] + x.a[i][2] * y.a[2][j];
+    return r;
+}
+M3 transposed(const M3 &x)
+{
+    M3 r;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            r.a[i][j] = x.a[j][i];
+    return r;
+}
+double det3(const M3 &m)
+{
+    return m.a[0][0] * (m.a[1][1] * m.a[2][2] - m.a[1][2] * m.a[2][1]) -
+           m.a[0][1] * (m.a[1][0] * m.a[2][2] - m.a[1][2] * m.a[2][0]) +
+           m.a[0][2] * (m.a[1][0] * m.a[2][1] - m.a[1][1] * m.a[2][0]);
+}
+
+// middle eigenvalue of a symmetric positive semi-definite 3x3 via cyclic Jacobi rotations
+double middle_eigenvalue(M3 s)
+{
+    for (int sweep = 0; sweep < 64; sweep++)
+    {
+        if (s.a[0][1] == 0 && s.a[0][2] == 0 && s.a[1][2] == 0)
+            break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++)
+            {
+                const double apq = s.a[p][q];
+                if (apq == 0)
+                    continue;
+                const double theta = (s.a[q][q] - s.a[p][p]) / (2 * apq);
+                const double t = std::copysign(1.0, theta) / (std::abs(theta) + std::sqrt(theta * theta + 1));
+                const double c = 1 / std::sqrt(t * t + 1), sn = t * c;
+                for (int k = 0; k < 3; k++)
+                {
+                    const double x = s.a[k][p], y = s.a[k][q];
+                    s.a[k][p] = c * x - sn * y;
+                    s.a[k][q] = sn * x + c * y;
+                }
+                for (int k = 0; k < 3; k++)
+                {
+                    const double x = s.a[p][k], y = s.a[q][k];
+                    s.a[p][k] = c * x - sn * y;
+                    s.a[q][k] = sn * x + c * y;
+                }
+            }
+    }
+    double e[3] = {s.a[0][0], s.a[1][1], s.a[2][2]};
+    std::sort(e, e + 3);
+    return e[1];
+}
+
+inline double opp_minor(const M3 &m, int row, int col)
+{
+    const int x1 = col == 0 ? 1 : 0, x2 = col == 2 ? 1 : 2, y1 = row == 0 ? 1 : 0, y2 = row == 2 ? 1 : 2;
+    return m.a[y1][x2] * m.a[y2][x1] - m.a[y1][x1] * m.a[y2][x2];
+}
+inline int sgn(double x)
+{
+    return x >= 0 ? 1 : -1;
+}
+
+struct motion
+{
+    M3 R;
+    double t[3], n[3];
+};
+
+M3 rotation_from_tstar_n(const M3 &Hn, const double ts[3], const double n[3], double v)
+{
+    M3 m;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            m.a[i][j] = (i == j ? 1.0 : 0.0) - (2 / v) * ts[i] * n[j];
+    M3 R = mul(Hn, m);
+    if (det3(R) < 0)
+        for (auto &row : R.a)
+            for (double &x : row)
+                x *= -1;
+    return R;
+}
+
+size_t decompose_homography(const double H[9], motion out[4])
+{
+    M3 h;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            h.a[i][j] = H[3 * i + j];
+    const double ev = middle_eigenvalue(mul(transposed(h), h));
+    const double sv = std::sqrt(ev > 0 ? ev : 0.0);
+    M3 Hn;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            Hn.a[i][j] = h.a[i][j] * (1.0 / sv);
+
+    M3 S = mul(transposed(Hn), Hn);
+    for (int i = 0; i < 3; i++)
+        S.a[i][i] -= 1.0;
+    double ninf = 0;
+    for (auto &row : S.a)
+        for (double x : row)
+            ninf = std::max(ninf, std::abs(x));
+    if (ninf < 0.001) // pure rotation
+    {
+        out[0].R = Hn;
+        for (int i = 0; i < 3; i++)
+            out[0].t[i] = out[0].n[i] = 0;
+        return 1;
+    }
+    const double M00 = opp_minor(S, 0, 0), M11 = opp_minor(S, 1, 1), M22 = opp_minor(S, 2, 2);
+    const double r00 = std::sqrt(M00), r11 = std::sqrt(M11), r22 = std::sqrt(M22);
+    const int e12 = sgn(opp_minor(S, 1, 2)), e02 = sgn(opp_minor(S, 0, 2)), e01 = sgn(opp_minor(S, 0, 1));
+    const double n0 = std::abs(S.a[0][0]), n1 = std::abs(S.a[1][1]), n2 = std::abs(S.a[2][2]);
+    int idx = 0;
+    if (n0 < n1)
+    {
+        idx = 1;
+        if (n1 < n2)
+            idx = 2;
+    }
+    else if (n0 < n2)
+        idx = 2;
+    double pa[3], pb[3];
+    if (idx == 0)
+    {
+        pa[0] = pb[0] = S.a[0][0];
+        pa[1] = S.a[0][1] + r22, pb[1] = S.a[0][1] - r22;
+        pa[2] = S.a[0][2] + e12 * r11, pb[2] = S.a[0][2] - e12 * r11;
+    }
+    else if (idx == 1)
+    {
+        pa[0] = S.a[0][1] + r22, pb[0] = S.a[0][1] - r22;
+        pa[1] = pb[1] = S.a[1][1];
+        pa[2] = S.a[1][2] - e02 * r00, pb[2] = S.a[1][2] + e02 * r00;
+    }
+    else
+    {
+        pa[0] = S.a[0][2] + e01 * r11, pb[0] = S.a[0][2] - e01 * r11;
+        pa[1] = S.a[1][2] + r00, pb[1] = S.a[1][2] - r00;
+        pa[2] = pb[2] = S.a[2][2];
+    }
+    const double tr = S.a[0][0] + S.a[1][1] + S.a[2][2];
+    const double v = 2.0 * (double)sqrtf((float)(1 + tr - M00 - M11 - M22)); // OpenCV uses sqrtf here
+    const double es = sgn(S.a[idx][idx]);
+    const double r = std::sqrt(2 + tr + v), nt = std::sqrt(2 + tr - v);
+    const double la = std::sqrt(pa[0] * pa[0] + pa[1] * pa[1] + pa[2] * pa[2]);
+    const double lb = std::sqrt(pb[0] * pb[0] + pb[1] * pb[1] + pb[2] * pb[2]);
+    double na[3], nb[3], tas[3], tbs[3];
+    for (int i = 0; i < 3; i++)
+    {
+        na[i] = pa[i] / la;
+        nb[i] = pb[i] / lb;
+    }
+    const double half_nt = 0.5 * nt, esr = es * r;
+    for (int i = 0; i < 3; i++)
+    {
+        tas[i] = (nb[i] * esr - na[i] * nt) * half_nt;
+        tbs[i] = (na[i] * esr - nb[i] * nt) * half_nt;
+    }
+    const M3 Ra = rotation_from_tstar_n(Hn, tas, na, v), Rb = rotation_from_tstar_n(Hn, tbs, nb, v);
+    for (int s = 0; s < 4; s++)
+    {
+        const M3 &R = s < 2 ? Ra : Rb;
+        const double *ts = s < 2 ? tas : tbs, *nn = s < 2 ? na : nb;
+        const double sign = (s % 2 == 0) ? 1.0 : -1.0;
+        out[s].R = R;
+        for (int i = 0; i < 3; i++)
+        {
+            out[s].t[i] = (R.a[i][0] * ts[0] + R.a[i][1] * ts[1] + R.a[i][2] * ts[2]) * sign;
+            out[s].n[i] = nn[i] * sign;
+        }
+    }
+    return 4;
+}
+
+// Eigen::Quaterniond(Matrix3d): Shoemake's method, Eigen/src/Geometry/Quaternion.h
+void quaternion_from_rotation(const M3 &m, double q[4])
+{
+    double t = m.a[0][0] + m.a[1][1] + m.a[2][2];
+    if (t > 0)
+    {
+        t = std::sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m.a[2][1] - m.a[1][2]) * t;
+        q[1] = (m.a[0][2] - m.a[2][0]) * t;
+        q[2] = (m.a[1][0] - m.a[0][1]) * t;
+        return;
+    }
+    int i = 0;
+    if (m.a[1][1] > m.a[0][0])
+        i = 1;
+    if (m.a[2][2] > m.a[i][i])
+        i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m.a[i][i] - m.a[j][j] - m.a[k][k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (m.a[k][j] - m.a[j][k]) * t;
+    q[j] = (m.a[j][i] + m.a[i][j]) * t;
+    q[k] = (m.a[k][i] + m.a[i][k]) * t;
+}
+} // namespace
+
+bool homography_model::decompose(const std::vector<correspondence> &corrs, const std::vector<bool> &inliers,
+                                 std::array<decomposed_pose, 4> &poses) const
+{
+    motion motions[4];
+    const size_t solutions = decompose_homography(homography, motions);
+    for (size_t i = 0; i < solutions; i++)
+    {
+        const M3 &R = motions[i].R;
+        const double *N = motions[i].n;
+        const double RN[3] = {R.a[0][0] * N[0] + R.a[0][1] * N[1] + R.a[0][2] * N[2],
+                              R.a[1][0] * N[0] + R.a[1][1] * N[1] + R.a[1][2] * N[2],
+                              R.a[2][0] * N[0] + R.a[2][1] * N[1] + R.a[2][2] * N[2]};
+        int score = 0;
+        for (size_t j = 0; j < corrs.size(); j++)
+        {
+            if (!inliers[j])
+                continue;
+            const double *m1 = corrs[j].measurement1, *m2 = corrs[j].measurement2;
+            const double dot1 = N[0] * m1[0] + N[1] * m1[1] + N[2] * m1[2];
+            const double dot2 = RN[0] * m2[0] + RN[1] * m2[1] + RN[2] * m2[2];
+            if (dot1 >= 0 && dot2 >= 0)
+                score++;
+        }
+        poses[i].score = score;
+        quaternion_from_rotation(R, poses[i].orientation);
+        for (int c = 0; c < 3; c++)
+            poses[i].position[c] = motions[i].t[c];
+    }
+    for (size_t i = solutions; i < poses.size(); i++)
+        poses[i].score = -1;
+    std::stable_sort(poses.begin(), poses.end(),
+                     [](const decomposed_pose &p1, const decomposed_pose &p2) { return p1.score >= p2.score; });
+    return poses[0].score > 0;
+}
+
+} // namespace opencalibration_amd

@@ -1,0 +1,56 @@
+// Host half of the RANSAC step (reference: include/opencalibration/model_inliers/ransac.hpp,
+// homography_model.hpp).  The hypothesis loop itself runs on the device
+// (ochip_ransac_homography_batch); the host contributes the two libstdc++-defined orders and the
+// homography decomposition.
+#pragma once
+
+#include "types.hpp"
+
+#include <mutex>
+
+namespace opencalibration_amd
+{
+
+// iota(M) after std::shuffle with std::default_random_engine(42) (ransac.cpp:92-98,158) and the engine
+// state right after the shuffle.  Depends on M only, so it is cached.
+struct eval_order_entry
+{
+    std::vector<uint32_t> order;
+    uint32_t rng_state;
+};
+class EvalOrderCache
+{
+  public:
+    const eval_order_entry &get(size_t M);
+
+  private:
+    std::mutex _mutex;
+    std::unordered_map<size_t, std::unique_ptr<eval_order_entry>> _cache;
+};
+
+// PROSAC order (ransac.cpp:83-90): iota(M) std::sort-ed by quality ascending; quality[i] is the match
+// distance.  Empty if no quality is non-zero (has_quality == false): the device then samples uniformly.
+std::vector<uint32_t> prosac_sorted_idx(const std::vector<feature_match> &matches);
+
+struct homography_model // include/opencalibration/model_inliers/homography_model.hpp:16-37 (host-visible part)
+{
+    static constexpr size_t MINIMUM_POINTS = 4;
+    double inlier_threshold = 0.005;
+    double homography[9] = {NAN, NAN, NAN, NAN, NAN, NAN, NAN, NAN, NAN}; // row-major
+
+    // homography_model.cpp:138-185: cv::decomposeHomographyMat(H, I) + cheirality vote over the inlier
+    // rays + std::stable_sort by score.
+    bool decompose(const std::vector<correspondence> &corrs, const std::vector<bool> &inliers,
+                   std::array<decomposed_pose, 4> &poses) const;
+};
+
+// ransac.cpp:263-282
+void assembleInliers(const std::vector<feature_match> &matches, const std::vector<bool> &inliers,
+                     const std::vector<feature_2d> &source_features, const std::vector<feature_2d> &dest_features,
+                     std::vector<feature_match_denormalized> &inlier_list);
+
+// distort_keypoints.cpp:68-103 for a camera without distortion (host copy used only to hand the
+// cheirality vote the same unit rays the device computed)
+void image_to_3d(const double keypoint[2], const CameraModel &model, double ray[3]);
+
+} // namespace opencalibration_amd

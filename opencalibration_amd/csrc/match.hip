@@ -198,15 +198,28 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
     if (max_n1 == 0)
         return OCHIP_OK;
 
-    constexpr int QPT = 2;
-    const uint32_t chunks = (max_n1 + BLOCK * QPT - 1) / (BLOCK * QPT);
+    static const int qpt = []() {
+        const char *e = getenv("OCHIP_MATCH_QPT"); // tuning knob; default chosen from measurements
+        const int v = e ? atoi(e) : 1;
+        return (v == 1 || v == 2 || v == 4) ? v : 1;
+    }();
+    const uint32_t chunks = (max_n1 + BLOCK * qpt - 1) / (BLOCK * qpt);
     const uint64_t blocks = (uint64_t)chunks * n_pairs;
     if (blocks > 0x7FFFFFFFull)
         return ochip_fail(ctx, OCHIP_EINVAL, "batch too large: %llu workgroups", (unsigned long long)blocks);
     hipEvent_t e0, e1;
     ochip_prof_begin(ctx, OCHIP_K_MATCH, &e0, &e1);
-    hipLaunchKernelGGL(hamming_2nn_kernel<QPT>, dim3((uint32_t)blocks), dim3(BLOCK), 0, ctx->stream, ctx->desc_dev,
-                       ctx->img_off_dev, ctx->img_n_dev, ctx->pairs_dev, ctx->out_off_dev, ctx->match_out_dev, chunks);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(BLOCK), 0, ctx->stream, ctx->desc_dev,
+                           ctx->img_off_dev, ctx->img_n_dev, ctx->pairs_dev, ctx->out_off_dev, ctx->match_out_dev,
+                           chunks);
+    };
+    if (qpt == 1)
+        launch(hamming_2nn_kernel<1>);
+    else if (qpt == 4)
+        launch(hamming_2nn_kernel<4>);
+    else
+        launch(hamming_2nn_kernel<2>);
     ochip_prof_end(ctx, OCHIP_K_MATCH, e0, e1);
     OCHIP_HIP(ctx, hipGetLastError());
     return OCHIP_OK;

@@ -26,8 +26,114 @@ def load():
         L.och_subsample.argtypes = [_f64p, _f32p, C.c_size_t, C.c_double, C.c_size_t, _u64p]
         L.och_matches_from_device.restype = C.c_size_t
         L.och_matches_from_device.argtypes = [C.c_void_p, _u64p, C.c_size_t, _u64p, C.c_size_t, _u64p, _u64p, _f64p]
+        vp, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
+        L.och_graph_create.restype = vp
+        L.och_graph_destroy.argtypes = [vp]
+        L.och_graph_destroy.restype = None
+        L.och_last_error.argtypes = [vp]
+        L.och_last_error.restype = C.c_char_p
+        L.och_graph_add_model.argtypes = [vp, _f64p]
+        L.och_graph_add_model.restype = u32
+        L.och_graph_add_image.argtypes = [vp, _f64p, _f32p, _u64p, sz, sz, u32, _f64p]
+        L.och_graph_add_image.restype = u64
+        L.och_graph_num_nodes.argtypes = [vp]
+        L.och_graph_num_nodes.restype = sz
+        L.och_graph_num_edges.argtypes = [vp]
+        L.och_graph_num_edges.restype = sz
+        L.och_graph_node_ids.argtypes = [vp, _u64p]
+        L.och_link_stage_run.argtypes = [vp, vp, _u64p, sz, C.c_int, _f64p]
+        L.och_link_debug_count.argtypes = [vp]
+        L.och_link_debug_count.restype = sz
+        L.och_link_debug_pair.argtypes = [vp, sz, _u64p, _u64p, _f64p, np.ctypeslib.ndpointer(np.uint32)]
+        L.och_link_debug_matches.argtypes = [vp, sz, _u64p, _u64p, _f64p, np.ctypeslib.ndpointer(np.uint8)]
+        L.och_graph_edge_info.argtypes = [vp, sz, _u64p, _u64p, _f64p, _f64p]
+        L.och_graph_edge_inliers.argtypes = [vp, sz, _u64p, _u64p, _u64p, _f64p]
         _lib = L
     return _lib
+
+
+LINK_TIMER_NAMES = ["link_init", "subsample", "upload", "match_device", "match_host", "ransac_device",
+                    "decompose_host", "link_finalize"]
+
+
+class Graph:
+    """MeasurementGraph + stage drivers (opencalibration_amd/csrc/host)."""
+
+    def __init__(self):
+        self.L = load()
+        self.h = C.c_void_p(self.L.och_graph_create())
+        self.node_ids = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.och_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_model(self, model10):
+        return self.L.och_graph_add_model(self.h, np.ascontiguousarray(model10, np.float64))
+
+    def add_image(self, loc, strength, desc, num_sparse, model, position):
+        nid = self.L.och_graph_add_image(self.h, np.ascontiguousarray(loc, np.float64),
+                                         np.ascontiguousarray(strength, np.float32),
+                                         np.ascontiguousarray(desc, np.uint64), len(strength), int(num_sparse), model,
+                                         np.ascontiguousarray(position, np.float64))
+        self.node_ids.append(nid)
+        return nid
+
+    @classmethod
+    def from_synthetic(cls, grid):
+        g = cls()
+        m = g.add_model(grid.model)
+        for i in range(grid.n_images):
+            loc, st, de, _ = grid.image(i)
+            g.add_image(loc, st, de, grid.num_sparse[i], m, grid.position[i])
+        return g
+
+    @property
+    def num_edges(self):
+        return self.L.och_graph_num_edges(self.h)
+
+    def link(self, ctx, node_ids=None, keep_debug=False):
+        """LinkStage init -> runner -> finalize on the device owned by `ctx`; returns the stage timers."""
+        ids = np.ascontiguousarray(self.node_ids if node_ids is None else node_ids, np.uint64)
+        timers = np.zeros(8)
+        rc = self.L.och_link_stage_run(self.h, ctx.h, ids, len(ids), int(keep_debug), timers)
+        if rc != 0:
+            raise capi.OchipError("link stage failed: " + self.L.och_last_error(self.h).decode())
+        return dict(zip(LINK_TIMER_NAMES, timers.tolist()))
+
+    def link_debug(self):
+        out = []
+        for p in range(self.L.och_link_debug_count(self.h)):
+            ids, n, score, it = np.zeros(2, np.uint64), np.zeros(1, np.uint64), np.zeros(1), np.zeros(3, np.uint32)
+            self.L.och_link_debug_pair(self.h, p, ids, n, score, it)
+            m = max(int(n[0]), 1)
+            i1, i2, d, inl = np.zeros(m, np.uint64), np.zeros(m, np.uint64), np.zeros(m), np.zeros(m, np.uint8)
+            self.L.och_link_debug_matches(self.h, p, i1, i2, d, inl)
+            k = int(n[0])
+            out.append(dict(node=int(ids[0]), match_node=int(ids[1]), i1=i1[:k], i2=i2[:k], dist=d[:k], inliers=inl[:k],
+                            score=float(score[0]), iterations=int(it[0]), improvements=int(it[1]),
+                            can_decompose=bool(it[2])))
+        return out
+
+    def edges(self):
+        out = []
+        for e in range(self.num_edges):
+            ids, cnt, H, poses = np.zeros(2, np.uint64), np.zeros(2, np.uint64), np.zeros((3, 3)), np.zeros((4, 8))
+            self.L.och_graph_edge_info(self.h, e, ids, cnt, H, poses)
+            k = max(int(cnt[1]), 1)
+            f1, f2, mi, px = np.zeros(k, np.uint64), np.zeros(k, np.uint64), np.zeros(k, np.uint64), np.zeros((k, 4))
+            self.L.och_graph_edge_inliers(self.h, e, f1, f2, mi, px)
+            k = int(cnt[1])
+            out.append(dict(source=int(ids[0]), dest=int(ids[1]), n_matches=int(cnt[0]), n_inliers=k, H=H, poses=poses,
+                            f1=f1[:k], f2=f2[:k], match_index=mi[:k], px=px[:k]))
+        return out
 
 
 def subsample(loc, strength, spacing, count=0):
