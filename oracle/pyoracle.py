@@ -56,8 +56,79 @@ def lib():
         L.oc_scene_homography.argtypes = [C.c_size_t, C.c_size_t, C.c_uint, f64p, u8p, f64p]
         L.oc_scene_near_degenerate.argtypes = [f64p, f64p]
         L.oc_num_threads.restype = C.c_int
+        vp = C.c_void_p
+        L.oc_relax_ground_plane.argtypes = [C.c_size_t, f64p, f64p, f64p, C.c_size_t, u64p, f64p, C.c_size_t, u64p, u64p,
+                                            f64p, u8p, u64p, f64p, u64p, vp, vp, C.c_size_t, u64p, f64p, f64p]
+        L.oc_points_downwards_prior.restype = C.c_double
+        L.oc_points_downwards_prior.argtypes = [f64p, C.c_double]
+        L.oc_robust_centroid.argtypes = [f64p, C.c_int, C.c_double, f64p]
+        L.oc_plane_intersection_cost.restype = C.c_int
+        L.oc_plane_intersection_cost.argtypes = [f64p, f64p, f64p, f64p, f64p, f64p, f64p, vp]
         _LIB = L
     return _LIB
+
+
+def pack_edges(edges):
+    """edges: list of dicts {src, dst, H (3x3) or None, px (k x 4), match_index (k,), dist (m,) or None}.
+    Returns the flat arrays oc_relax_ground_plane (and the product's relax entry points) take."""
+    n = len(edges)
+    src = np.array([e["src"] for e in edges], np.uint64)
+    dst = np.array([e["dst"] for e in edges], np.uint64)
+    H = np.full((max(n, 1), 9), np.nan)
+    ish = np.zeros(max(n, 1), np.uint8)
+    for i, e in enumerate(edges):
+        if e.get("H") is not None:
+            H[i] = np.asarray(e["H"], np.float64).reshape(9)
+            ish[i] = 1
+    counts = [len(e["px"]) for e in edges]
+    inl_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    px = np.ascontiguousarray(np.concatenate([np.asarray(e["px"], np.float64).reshape(-1, 4) for e in edges])
+                              if n and sum(counts) else np.zeros((1, 4)))
+    mi = np.ascontiguousarray(np.concatenate([np.asarray(e["match_index"], np.uint64) for e in edges])
+                              if n and sum(counts) else np.zeros(1, np.uint64))
+    dcounts = [0 if e.get("dist") is None else len(e["dist"]) for e in edges]
+    dist_off = np.concatenate([[0], np.cumsum(dcounts)]).astype(np.uint64)
+    dist = np.ascontiguousarray(np.concatenate([np.asarray(e["dist"], np.float64) for e in edges if e.get("dist") is not None])
+                                if sum(dcounts) else np.zeros(1))
+    return dict(src=src, dst=dst, H=np.ascontiguousarray(H), is_h=ish, inl_off=inl_off, px=px, match_index=mi,
+                dist_off=dist_off, dist=dist)
+
+
+def relax_ground_plane(node_pos, node_ori, model10, pose_node, pose_ori, edges, opt_edges=None):
+    """relax(graph, nodes, cam_models, edges, {ORIENTATION, GROUND_PLANE}) of the restatement."""
+    node_pos = np.ascontiguousarray(node_pos, np.float64)
+    node_ori = np.ascontiguousarray(node_ori, np.float64)
+    pose_node = np.ascontiguousarray(pose_node, np.uint64)
+    pose_ori = np.ascontiguousarray(pose_ori, np.float64).copy()
+    pk = pack_edges(edges)
+    opt = np.ascontiguousarray(np.arange(len(edges)) if opt_edges is None else opt_edges, np.uint64)
+    plane, summary = np.zeros(9), np.zeros(6)
+    lib().oc_relax_ground_plane(len(node_pos), node_pos, node_ori, np.ascontiguousarray(model10, np.float64),
+                                len(pose_node), pose_node, pose_ori, len(edges), pk["src"], pk["dst"], pk["H"],
+                                pk["is_h"], pk["inl_off"], pk["px"], pk["match_index"], pk["dist_off"].ctypes.data,
+                                pk["dist"].ctypes.data, len(opt), opt, plane, summary)
+    return dict(orientation=pose_ori, plane=plane.reshape(3, 3), solves=int(summary[0]),
+                iterations_total=int(summary[1]), last_iterations=int(summary[2]), initial_cost=summary[3],
+                final_cost=summary[4], residual_blocks=int(summary[5]))
+
+
+def points_downwards_prior(q, weight):
+    return lib().oc_points_downwards_prior(np.ascontiguousarray(q, np.float64), weight)
+
+
+def robust_centroid(points, thr):
+    points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+    out = np.zeros(3)
+    lib().oc_robust_centroid(points, len(points), thr, out)
+    return out
+
+
+def plane_intersection_cost(locs, rays, plane_xy, q0, q1, z, want_jac=True):
+    res, jac = np.zeros(6), np.zeros((6, 11))
+    c = lambda a: np.ascontiguousarray(a, np.float64)
+    ok = lib().oc_plane_intersection_cost(c(locs), c(rays), c(plane_xy), c(q0), c(q1), c(z), res,
+                                          jac.ctypes.data if want_jac else None)
+    return bool(ok), res, jac
 
 
 def ref():

@@ -1,0 +1,576 @@
+// ORACLE — test infrastructure only.  See mini_ceres.hpp for what is restated and from where. [3P]
+#include "mini_ceres.hpp"
+
+#include <algorithm>
+#include <limits>
+
+namespace oracle
+{
+namespace mc
+{
+
+int Problem::AddParameterBlock(double *p, int size)
+{
+    auto it = index.find(p);
+    if (it != index.end())
+        return it->second;
+    ParameterBlock b;
+    b.data = p;
+    b.size = size;
+    blocks.push_back(b);
+    index.emplace(p, (int)blocks.size() - 1);
+    return (int)blocks.size() - 1;
+}
+
+void Problem::AddResidualBlock(CostFunction *cost, const LossFunction *loss, const std::vector<double *> &params)
+{
+    ResidualBlock rb;
+    rb.cost.reset(cost);
+    rb.loss = loss;
+    for (size_t i = 0; i < params.size(); i++)
+        rb.blocks.push_back(AddParameterBlock(params[i], cost->block_sizes[i]));
+    residuals.push_back(std::move(rb));
+}
+
+void Problem::SetManifold(double *p, Manifold m)
+{
+    blocks[index.at(p)].manifold = m;
+}
+void Problem::SetParameterBlockConstant(double *p)
+{
+    blocks[index.at(p)].constant = true;
+}
+void Problem::SetParameterBlockVariable(double *p)
+{
+    blocks[index.at(p)].constant = false;
+}
+bool Problem::IsParameterBlockConstant(double *p) const
+{
+    return blocks[index.at(p)].constant;
+}
+std::vector<double *> Problem::GetParameterBlocks() const
+{
+    std::vector<double *> out;
+    for (const auto &b : blocks)
+        out.push_back(b.data);
+    return out;
+}
+
+namespace
+{
+
+// EigenQuaternionManifold (ceres/manifold.cc, Order XYZW): plus = q_delta * x, q_delta = (sin|d|/|d| d, cos|d|)
+void quat_plus(const double *x, const double *delta, double *out)
+{
+    const double n2 = delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2];
+    const double n = std::sqrt(n2);
+    if (n == 0.0)
+    {
+        for (int i = 0; i < 4; i++)
+            out[i] = x[i];
+        return;
+    }
+    const double s = std::sin(n) / n;
+    const double dx = s * delta[0], dy = s * delta[1], dz = s * delta[2], dw = std::cos(n);
+    const double qx = x[0], qy = x[1], qz = x[2], qw = x[3];
+    // Eigen quaternion product (a = q_delta, b = x)
+    out[3] = dw * qw - dx * qx - dy * qy - dz * qz;
+    out[0] = dw * qx + dx * qw + dy * qz - dz * qy;
+    out[1] = dw * qy + dy * qw + dz * qx - dx * qz;
+    out[2] = dw * qz + dz * qw + dx * qy - dy * qx;
+}
+void quat_plus_jacobian(const double *x, double *J /*4x3 row-major*/)
+{
+    const double qx = x[0], qy = x[1], qz = x[2], qw = x[3];
+    const double v[12] = {qw, qz, -qy, -qz, qw, qx, qy, -qx, qw, -qx, -qy, -qz};
+    for (int i = 0; i < 12; i++)
+        J[i] = v[i];
+}
+
+struct Program
+{
+    Problem *problem;
+    std::vector<int> var_blocks;          // indices of non-constant parameter blocks, program order
+    std::vector<int> tangent_offset;      // per problem block (-1 if constant)
+    std::vector<int> ambient_offset;      // per problem block (-1 if constant)
+    std::vector<int> active_residuals;    // residual blocks with at least one variable block
+    int num_tangent = 0, num_ambient = 0, num_res = 0;
+    double fixed_cost = 0;
+};
+
+struct Evaluation
+{
+    double cost = 0;
+    std::vector<double> residuals;               // stacked, corrected
+    std::vector<std::vector<double>> jac;        // per active residual block: rows x (sum tangent of its var blocks)
+};
+
+// Evaluate one residual block at the parameter values in `state` (ambient vector for variable blocks).
+bool eval_block(const Program &prog, const ResidualBlock &rb, const std::vector<double> &state, bool want_jac,
+                double *cost, std::vector<double> &res, std::vector<double> *jac_tangent)
+{
+    const Problem &P = *prog.problem;
+    const int nb = (int)rb.blocks.size();
+    const int nr = rb.cost->num_residuals;
+    std::vector<const double *> params(nb);
+    for (int i = 0; i < nb; i++)
+    {
+        const int b = rb.blocks[i];
+        params[i] = prog.ambient_offset[b] >= 0 ? &state[prog.ambient_offset[b]] : P.blocks[b].data;
+    }
+    res.assign(nr, 0.0);
+    std::vector<std::vector<double>> jac_store(nb);
+    std::vector<double *> jac_ptr(nb, nullptr);
+    if (want_jac)
+        for (int i = 0; i < nb; i++)
+            if (prog.ambient_offset[rb.blocks[i]] >= 0)
+            {
+                jac_store[i].assign((size_t)nr * P.blocks[rb.blocks[i]].size, 0.0);
+                jac_ptr[i] = jac_store[i].data();
+            }
+    if (!rb.cost->Evaluate(params.data(), res.data(), want_jac ? jac_ptr.data() : nullptr))
+        return false;
+    for (double r : res)
+        if (!std::isfinite(r))
+            return false;
+    double sq = 0;
+    for (double r : res)
+        sq += r * r;
+
+    // ambient -> tangent
+    int tcols = 0;
+    if (want_jac)
+    {
+        for (int i = 0; i < nb; i++)
+            if (jac_ptr[i])
+                tcols += P.blocks[rb.blocks[i]].tangent_size();
+        jac_tangent->assign((size_t)nr * tcols, 0.0);
+        int c0 = 0;
+        for (int i = 0; i < nb; i++)
+        {
+            if (!jac_ptr[i])
+                continue;
+            const ParameterBlock &pb = P.blocks[rb.blocks[i]];
+            if (pb.manifold == Manifold::EIGEN_QUATERNION)
+            {
+                double PJ[12];
+                quat_plus_jacobian(params[i], PJ);
+                for (int r = 0; r < nr; r++)
+                    for (int c = 0; c < 3; c++)
+                    {
+                        double s = 0;
+                        for (int k = 0; k < 4; k++)
+                            s += jac_ptr[i][r * 4 + k] * PJ[k * 3 + c];
+                        (*jac_tangent)[(size_t)r * tcols + c0 + c] = s;
+                    }
+                c0 += 3;
+            }
+            else
+            {
+                for (int r = 0; r < nr; r++)
+                    for (int c = 0; c < pb.size; c++)
+                        (*jac_tangent)[(size_t)r * tcols + c0 + c] = jac_ptr[i][r * pb.size + c];
+                c0 += pb.size;
+            }
+        }
+        for (double v : *jac_tangent)
+            if (!std::isfinite(v))
+                return false;
+    }
+
+    if (!rb.loss)
+    {
+        *cost = 0.5 * sq;
+        return true;
+    }
+    double rho[3];
+    rb.loss->Evaluate(sq, rho);
+    *cost = 0.5 * rho[0];
+    // Corrector (ceres/corrector.cc)
+    const double sqrt_rho1 = std::sqrt(rho[1]);
+    double residual_scaling, alpha_sq_norm;
+    if (sq == 0.0 || rho[2] <= 0.0)
+    {
+        residual_scaling = sqrt_rho1;
+        alpha_sq_norm = 0.0;
+    }
+    else
+    {
+        const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
+        const double alpha = 1.0 - std::sqrt(D);
+        residual_scaling = sqrt_rho1 / (1 - alpha);
+        alpha_sq_norm = alpha / sq;
+    }
+    if (want_jac)
+    {
+        if (alpha_sq_norm == 0.0)
+            for (double &v : *jac_tangent)
+                v *= sqrt_rho1;
+        else
+            for (int c = 0; c < tcols; c++)
+            {
+                double rtj = 0;
+                for (int r = 0; r < nr; r++)
+                    rtj += (*jac_tangent)[(size_t)r * tcols + c] * res[r];
+                for (int r = 0; r < nr; r++)
+                    (*jac_tangent)[(size_t)r * tcols + c] =
+                        sqrt_rho1 * ((*jac_tangent)[(size_t)r * tcols + c] - alpha_sq_norm * res[r] * rtj);
+            }
+    }
+    for (double &r : res)
+        r *= residual_scaling;
+    return true;
+}
+
+bool evaluate(const Program &prog, const std::vector<double> &state, bool want_jac, Evaluation *ev)
+{
+    ev->cost = 0;
+    ev->residuals.clear();
+    if (want_jac)
+        ev->jac.assign(prog.active_residuals.size(), {});
+    std::vector<double> res;
+    for (size_t k = 0; k < prog.active_residuals.size(); k++)
+    {
+        const ResidualBlock &rb = prog.problem->residuals[prog.active_residuals[k]];
+        double c = 0;
+        if (!eval_block(prog, rb, state, want_jac, &c, res, want_jac ? &ev->jac[k] : nullptr))
+            return false;
+        ev->cost += c;
+        ev->residuals.insert(ev->residuals.end(), res.begin(), res.end());
+    }
+    return true;
+}
+
+// dense Cholesky solve of A x = b (A symmetric positive definite, row-major n x n, destroyed)
+bool cholesky_solve(std::vector<double> &A, std::vector<double> &b, int n)
+{
+    for (int j = 0; j < n; j++)
+    {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; k++)
+            d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        if (!(d > 0) || !std::isfinite(d))
+            return false;
+        d = std::sqrt(d);
+        A[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; i++)
+        {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; k++)
+                s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            A[(size_t)i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; i++)
+    {
+        double s = b[i];
+        for (int k = 0; k < i; k++)
+            s -= A[(size_t)i * n + k] * b[k];
+        b[i] = s / A[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--)
+    {
+        double s = b[i];
+        for (int k = i + 1; k < n; k++)
+            s -= A[(size_t)k * n + i] * b[k];
+        b[i] = s / A[(size_t)i * n + i];
+    }
+    return true;
+}
+
+} // namespace
+
+void Solve(const SolverOptions &opt, Problem *problem, SolverSummary *summary)
+{
+    *summary = SolverSummary();
+    Program prog;
+    prog.problem = problem;
+    const int nblocks = (int)problem->blocks.size();
+    prog.tangent_offset.assign(nblocks, -1);
+    prog.ambient_offset.assign(nblocks, -1);
+    // reduced program: drop constant blocks and blocks no residual touches (ceres/reduced_program)
+    std::vector<char> used(nblocks, 0);
+    for (const auto &rb : problem->residuals)
+        for (int b : rb.blocks)
+            used[b] = 1;
+    for (int b = 0; b < nblocks; b++)
+        if (used[b] && !problem->blocks[b].constant)
+        {
+            prog.var_blocks.push_back(b);
+            prog.tangent_offset[b] = prog.num_tangent;
+            prog.ambient_offset[b] = prog.num_ambient;
+            prog.num_tangent += problem->blocks[b].tangent_size();
+            prog.num_ambient += problem->blocks[b].size;
+        }
+    std::vector<double> x(prog.num_ambient);
+    for (int b : prog.var_blocks)
+        for (int k = 0; k < problem->blocks[b].size; k++)
+            x[prog.ambient_offset[b] + k] = problem->blocks[b].data[k];
+    for (size_t r = 0; r < problem->residuals.size(); r++)
+    {
+        bool any = false;
+        for (int b : problem->residuals[r].blocks)
+            any |= prog.ambient_offset[b] >= 0;
+        if (any)
+        {
+            prog.active_residuals.push_back((int)r);
+            prog.num_res += problem->residuals[r].cost->num_residuals;
+        }
+        else
+        {
+            double c = 0;
+            std::vector<double> res;
+            if (eval_block(prog, problem->residuals[r], x, false, &c, res, nullptr))
+                prog.fixed_cost += c;
+        }
+    }
+    summary->fixed_cost = prog.fixed_cost;
+    summary->num_parameters_reduced = prog.num_tangent;
+    summary->num_residuals_reduced = prog.num_res;
+    if (prog.var_blocks.empty() || prog.active_residuals.empty())
+    {
+        summary->message = "no non-constant parameter blocks";
+        summary->initial_cost = summary->final_cost = prog.fixed_cost;
+        summary->usable = true;
+        return;
+    }
+
+    const int n = prog.num_tangent;
+    auto write_back = [&](const std::vector<double> &state) {
+        for (int b : prog.var_blocks)
+            for (int k = 0; k < problem->blocks[b].size; k++)
+                problem->blocks[b].data[k] = state[prog.ambient_offset[b] + k];
+    };
+    auto plus = [&](const std::vector<double> &state, const std::vector<double> &delta, std::vector<double> &out) {
+        out.resize(state.size());
+        for (int b : prog.var_blocks)
+        {
+            const ParameterBlock &pb = problem->blocks[b];
+            const double *s = &state[prog.ambient_offset[b]];
+            const double *d = &delta[prog.tangent_offset[b]];
+            double *o = &out[prog.ambient_offset[b]];
+            if (pb.manifold == Manifold::EIGEN_QUATERNION)
+                quat_plus(s, d, o);
+            else
+                for (int k = 0; k < pb.size; k++)
+                    o[k] = s[k] + d[k];
+        }
+    };
+    // scatter block Jacobians into (optionally scaled) J'J and J'r
+    auto normal_equations = [&](const Evaluation &ev, const std::vector<double> &scale, std::vector<double> &JtJ,
+                                std::vector<double> &Jtr, std::vector<double> &colnorm2) {
+        JtJ.assign((size_t)n * n, 0.0);
+        Jtr.assign(n, 0.0);
+        colnorm2.assign(n, 0.0);
+        size_t roff = 0;
+        for (size_t k = 0; k < prog.active_residuals.size(); k++)
+        {
+            const ResidualBlock &rb = problem->residuals[prog.active_residuals[k]];
+            const int nr = rb.cost->num_residuals;
+            std::vector<int> cols;
+            for (int b : rb.blocks)
+                if (prog.tangent_offset[b] >= 0)
+                    for (int c = 0; c < problem->blocks[b].tangent_size(); c++)
+                        cols.push_back(prog.tangent_offset[b] + c);
+            const int tc = (int)cols.size();
+            const std::vector<double> &J = ev.jac[k];
+            for (int a = 0; a < tc; a++)
+            {
+                double g = 0;
+                for (int r = 0; r < nr; r++)
+                    g += J[(size_t)r * tc + a] * scale[cols[a]] * ev.residuals[roff + r];
+                Jtr[cols[a]] += g;
+                for (int b2 = 0; b2 < tc; b2++)
+                {
+                    double s = 0;
+                    for (int r = 0; r < nr; r++)
+                        s += J[(size_t)r * tc + a] * J[(size_t)r * tc + b2];
+                    JtJ[(size_t)cols[a] * n + cols[b2]] += s * scale[cols[a]] * scale[cols[b2]];
+                }
+            }
+            roff += nr;
+        }
+        for (int i = 0; i < n; i++)
+            colnorm2[i] = JtJ[(size_t)i * n + i];
+    };
+    auto max_abs = [](const std::vector<double> &v) {
+        double m = 0;
+        for (double e : v)
+            m = std::max(m, std::abs(e));
+        return m;
+    };
+    auto norm = [](const std::vector<double> &v) {
+        double s = 0;
+        for (double e : v)
+            s += e * e;
+        return std::sqrt(s);
+    };
+
+    // ---- Init (trust_region_minimizer.cc: Init + IterationZero)
+    Evaluation ev;
+    if (!evaluate(prog, x, true, &ev))
+    {
+        summary->message = "initial evaluation failed";
+        return;
+    }
+    std::vector<double> ones(n, 1.0), JtJ, g, cn2, scale(n, 1.0);
+    normal_equations(ev, ones, JtJ, g, cn2);
+    if (opt.jacobi_scaling)
+        for (int i = 0; i < n; i++)
+            scale[i] = 1.0 / (1.0 + std::sqrt(cn2[i]));
+    double x_cost = ev.cost, x_norm = norm(x);
+    summary->initial_cost = x_cost + prog.fixed_cost;
+    double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
+    bool reuse_diagonal = false;
+    std::vector<double> diagonal(n, 0.0);
+    int num_consecutive_invalid = 0;
+
+    IterationSummary it0;
+    it0.iteration = 0;
+    it0.step_is_valid = it0.step_is_successful = true;
+    it0.cost = x_cost + prog.fixed_cost;
+    it0.gradient_max_norm = max_abs(g);
+    it0.trust_region_radius = radius;
+    summary->iterations.push_back(it0);
+    summary->usable = true;
+    auto finish = [&](const char *msg) {
+        summary->message = msg;
+        summary->final_cost = x_cost + prog.fixed_cost;
+        write_back(x);
+    };
+    if (it0.gradient_max_norm <= opt.gradient_tolerance)
+        return finish("Gradient tolerance reached");
+
+    std::vector<double> sJtJ, sg, scn2, A, step, delta, cand;
+    normal_equations(ev, scale, sJtJ, sg, scn2);
+    while (true)
+    {
+        IterationSummary is;
+        is.iteration = summary->iterations.back().iteration + 1;
+        // FinalizeIterationAndCheckIfMinimizerCanContinue checks of the previous iteration
+        if (summary->iterations.back().iteration >= opt.max_num_iterations)
+            return finish("Maximum number of iterations reached");
+        if (radius <= opt.min_trust_region_radius)
+            return finish("Minimum trust region radius reached");
+
+        // ---- ComputeTrustRegionStep (LevenbergMarquardtStrategy::ComputeStep)
+        if (!reuse_diagonal)
+            for (int i = 0; i < n; i++)
+                diagonal[i] = std::min(std::max(scn2[i], opt.min_lm_diagonal), opt.max_lm_diagonal);
+        A = sJtJ;
+        for (int i = 0; i < n; i++)
+        {
+            const double d = std::sqrt(diagonal[i] / radius);
+            A[(size_t)i * n + i] += d * d;
+        }
+        step = sg;
+        bool solved = cholesky_solve(A, step, n);
+        for (double &s : step)
+        {
+            if (!std::isfinite(s))
+                solved = false;
+            s = -s;
+        }
+        reuse_diagonal = true;
+        double model_cost_change = 0;
+        if (solved)
+        {
+            // model_cost_change = -(J step)'(r + J step / 2) = -(step'g + step'J'J step / 2)
+            double sg_dot = 0, quad = 0;
+            for (int i = 0; i < n; i++)
+            {
+                sg_dot += step[i] * sg[i];
+                double row = 0;
+                for (int j = 0; j < n; j++)
+                    row += sJtJ[(size_t)i * n + j] * step[j];
+                quad += step[i] * row;
+            }
+            model_cost_change = -(sg_dot + quad / 2.0);
+        }
+        is.step_is_valid = solved && model_cost_change > 0.0;
+        if (!is.step_is_valid)
+        {
+            // HandleInvalidStep
+            if (++num_consecutive_invalid >= opt.max_num_consecutive_invalid_steps)
+            {
+                summary->iterations.push_back(is);
+                return finish("Too many consecutive invalid steps");
+            }
+            radius *= 0.5; // LevenbergMarquardtStrategy::StepIsInvalid
+            reuse_diagonal = true;
+            is.cost = x_cost + prog.fixed_cost;
+            is.trust_region_radius = radius;
+            is.gradient_max_norm = summary->iterations.back().gradient_max_norm;
+            summary->iterations.push_back(is);
+            continue;
+        }
+        num_consecutive_invalid = 0;
+        delta.resize(n);
+        for (int i = 0; i < n; i++)
+            delta[i] = step[i] * scale[i];
+        plus(x, delta, cand);
+        Evaluation cev;
+        double candidate_cost = std::numeric_limits<double>::max();
+        if (evaluate(prog, cand, false, &cev))
+            candidate_cost = cev.cost;
+
+        // ParameterToleranceReached
+        {
+            double s = 0;
+            for (size_t i = 0; i < x.size(); i++)
+                s += (x[i] - cand[i]) * (x[i] - cand[i]);
+            is.step_norm = std::sqrt(s);
+        }
+        if (is.step_norm <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance))
+        {
+            summary->iterations.push_back(is);
+            return finish("Parameter tolerance reached");
+        }
+        // FunctionToleranceReached
+        is.cost_change = x_cost - candidate_cost;
+        if (std::abs(is.cost_change) <= opt.function_tolerance * x_cost)
+        {
+            summary->iterations.push_back(is);
+            return finish("Function tolerance reached");
+        }
+        is.relative_decrease = is.cost_change / model_cost_change;
+        if (is.relative_decrease > opt.min_relative_decrease)
+        {
+            // HandleSuccessfulStep
+            x = cand;
+            x_norm = norm(x);
+            if (!evaluate(prog, x, true, &ev))
+            {
+                summary->iterations.push_back(is);
+                return finish("Jacobian evaluation failed");
+            }
+            x_cost = ev.cost;
+            normal_equations(ev, ones, JtJ, g, cn2);
+            normal_equations(ev, scale, sJtJ, sg, scn2);
+            is.step_is_successful = true;
+            is.gradient_max_norm = max_abs(g);
+            const double t = 2.0 * is.relative_decrease - 1.0;
+            radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+            radius = std::min(opt.max_trust_region_radius, radius);
+            decrease_factor = 2.0;
+            reuse_diagonal = false;
+            summary->num_successful_steps++;
+        }
+        else
+        {
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+            reuse_diagonal = true;
+            is.gradient_max_norm = summary->iterations.back().gradient_max_norm;
+            summary->num_unsuccessful_steps++;
+        }
+        is.cost = x_cost + prog.fixed_cost;
+        is.trust_region_radius = radius;
+        summary->iterations.push_back(is);
+        if (is.step_is_successful && is.gradient_max_norm <= opt.gradient_tolerance)
+            return finish("Gradient tolerance reached");
+    }
+}
+
+} // namespace mc
+} // namespace oracle

@@ -1,0 +1,101 @@
+"""Fixtures of the reference's relax tests, restated (data only):
+test/test_relax.cpp:19-167 (3 cameras + 100 planar points) and :685-812 (grid of cameras over a plane)."""
+import numpy as np
+
+
+def axis_angle(axis, ang):
+    axis = np.asarray(axis, float)
+    return np.array([*(axis * np.sin(ang / 2)), np.cos(ang / 2)])
+
+
+def qmul(a, b):  # xyzw, Eigen product a*b
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def qinv(q):
+    return np.array([-q[0], -q[1], -q[2], q[3]]) / np.dot(q, q)
+
+
+def qrot(q, v):
+    return qmul(qmul(q, np.array([*v, 0.0])), qinv(q))[:3]
+
+
+def qangle(a, b):
+    """Eigen::AngleAxisd(a.inverse() * b).angle()"""
+    d = qmul(qinv(a), b)
+    d = d / np.linalg.norm(d)
+    return 2 * np.arctan2(np.linalg.norm(d[:3]), abs(d[3]))
+
+
+DOWN = axis_angle([1, 0, 0], np.pi)
+MODEL_600 = np.array([600.0, 400, 300, 0, 0, 0, 0, 0, 800, 600])
+
+
+def project(q, pos, p, model):
+    ray = qrot(qinv(q), (p - pos) / np.linalg.norm(p - pos))
+    z = max(ray[2], 1e-3)
+    return ray[:2] / z * model[0] + model[1:3]
+
+
+def three_cameras():
+    """init_cameras(): test_relax.cpp:30-59"""
+    ori = [qmul(axis_angle([0, 0, 1], 0.2), DOWN), qmul(axis_angle([0, 1, 0], -0.3), DOWN),
+           qmul(axis_angle([1, 0, 0], -0.3), DOWN)]
+    pos = [np.array([9.0, 9, 9]), np.array([11.0, 9, 9]), np.array([11.0, 11, 9])]
+    return np.array(ori), np.array(pos)
+
+
+def planar_points():
+    """generate_planar_points(): test_relax.cpp:61-73"""
+    return np.array([[i + 5, j + 5, -10 + 1e-3 * i + 1e-2 * j] for i in range(10) for j in range(10)], float)
+
+
+def ring_edges(ori, pos, points, model=MODEL_600):
+    """add_point_measurements(): edge i -> (i+1)%3, every point an inlier (test_relax.cpp:91-125)"""
+    n = len(ori)
+    px = [np.array([project(ori[i], pos[i], p, model) for p in points]) for i in range(n)]
+    edges = []
+    for i in range(n):
+        j = (i + 1) % n
+        edges.append(dict(src=i, dst=j, H=None, px=np.concatenate([px[i], px[j]], axis=1),
+                          match_index=np.arange(len(points)), dist=None))
+    return edges
+
+
+def add_ori_noise(ori, noise):
+    """add_ori_noise(): right-multiplied per-camera perturbations (test_relax.cpp:151-156)"""
+    axes = [[0, 1, 0], [0, 0, 1], [1, 0, 0]]
+    return np.array([qmul(ori[i], axis_angle(axes[i], noise[i])) for i in range(3)])
+
+
+def camera_grid(rows, cols, seed=3, height=10.0, spacing=2.0, yaw_sigma=0.05, pts_per_side=14):
+    """A rows x cols nadir grid over the tilted plane z = 1e-3 x + 1e-2 y with every 4-neighbour pair
+    linked in both directions (pattern of test/test_relax.cpp:685-812)."""
+    rng = np.random.default_rng(seed)
+    n = rows * cols
+    pos = np.array([[c * spacing + rng.uniform(-0.1, 0.1), r * spacing + rng.uniform(-0.1, 0.1), height]
+                    for r in range(rows) for c in range(cols)])
+    ori = np.array([qmul(axis_angle([0, 0, 1], rng.normal(0, yaw_sigma)), DOWN) for _ in range(n)])
+    gx = np.linspace(-spacing, cols * spacing, pts_per_side)
+    gy = np.linspace(-spacing, rows * spacing, pts_per_side)
+    pts = np.array([[x + rng.uniform(-0.2, 0.2), y + rng.uniform(-0.2, 0.2), 0.0] for x in gx for y in gy])
+    pts[:, 2] = 1e-3 * pts[:, 0] + 1e-2 * pts[:, 1]
+    model = MODEL_600
+    px = [np.array([project(ori[i], pos[i], p, model) for p in pts]) for i in range(n)]
+    vis = [np.all((px[i] >= 0) & (px[i] < model[8:10]), axis=1) for i in range(n)]
+    edges = []
+    for r in range(rows):
+        for c in range(cols):
+            i = r * cols + c
+            for dr, dc in ((0, 1), (1, 0), (0, -1), (-1, 0)):
+                rr, cc = r + dr, c + dc
+                if 0 <= rr < rows and 0 <= cc < cols:
+                    j = rr * cols + cc
+                    both = np.flatnonzero(vis[i] & vis[j])
+                    if len(both) >= 8:
+                        edges.append(dict(src=i, dst=j, H=None, px=np.concatenate([px[i][both], px[j][both]], axis=1),
+                                          match_index=np.arange(len(both)), dist=None))
+    return ori, pos, edges, model
