@@ -52,6 +52,27 @@ extern "C"
     void och_graph_edge_inliers(const och_graph *g, size_t e, uint64_t *f1, uint64_t *f2, uint64_t *match_index,
                                 double *px4);
 
+    /* ---- relax (opencalibration_amd/csrc/host/relax.hpp): relax(graph, nodes, cam_models, edges,
+     *      {ORIENTATION, GROUND_PLANE}, {}) of src/relax/relax.cpp:122-134 ------------------------------ */
+    /* Stand-alone problem from flat arrays.  graph: n_nodes x {pos3, ori4 xyzw (may be NaN)} + one shared
+     * camera model; poses: node indices + orientations (in/out, NaN = uninitialised); edges: src/dst node
+     * index, H (9), is_homography, inlier offsets, per inlier {px1 xy, px2 xy} + match_index, optional
+     * per-edge match distances; opt_edges: whitelist order.  plane_out: 3 corners x (x,y,z).
+     * summary_out (8): solves, iterations_total, last_iterations, last_initial_cost, last_final_cost,
+     * last_residual_blocks, host setup seconds, device seconds.  Returns 0 or -1. */
+    int och_relax_ground_plane(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const double *node_ori,
+                               const double *model10, size_t n_poses, const uint64_t *pose_node, double *pose_ori,
+                               size_t n_edges, const uint64_t *edge_src, const uint64_t *edge_dst,
+                               const double *edge_H, const uint8_t *edge_is_homography, const uint64_t *inl_off,
+                               const double *inl_px, const uint64_t *inl_match_index, const uint64_t *dist_off,
+                               const double *dist, size_t n_opt_edges, const uint64_t *opt_edges, double *plane_out,
+                               double *summary_out);
+    const char *och_relax_last_error(void);
+    /* Every node of a linked graph as one group, every edge whitelisted (the single-group global relax,
+     * src/pipeline/pipeline.cpp:653-655).  ori_inout: n_nodes x 4 in node order. */
+    int och_graph_relax_ground_plane(och_graph *g, ochip_ctx *ctx, double *ori_inout, double *plane_out,
+                                     double *summary_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,6 +129,69 @@ extern "C"
                                       uint64_t total_matches, const uint32_t *eval_order, uint64_t eval_total,
                                       double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers);
 
+    /* ---- relax: ground-plane bundle adjustment (replaces ceres::Solver::Solve on the problem
+     *      RelaxProblem::setupGroundPlaneProblem builds, src/relax/relax_problem.cpp:61-81,1390-1420) ---- */
+    typedef struct ochip_relax_problem ochip_relax_problem;
+
+    typedef struct ochip_relax_desc
+    {
+        uint32_t n_cams;
+        const double *cam_pos;       /* n_cams x 3, constants (GPS positions are never optimised) */
+        const double *cam_q;         /* n_cams x 4 initial orientation, Eigen coefficient order x y z w */
+        const uint8_t *cam_optimize; /* n_cams: 1 = in _nodes_to_optimize, 0 = constant context camera */
+        double plane_xy[6];          /* the three plane corners' x,y (initializeGroundPlane, :1189-1242) */
+        double plane_z[3];           /* initial corner heights (the structure parameters) */
+        uint8_t z_optimize[3];
+        uint32_t n_blocks;           /* 2-ray PlaneIntersectionAngleCost blocks (relax_cost_function.hpp:658-684) */
+        const uint32_t *blk_cam_a;   /* n_blocks: source camera */
+        const uint32_t *blk_cam_b;   /* n_blocks: dest camera */
+        const double *blk_rays;      /* n_blocks x 6: camera-frame unit rays of the source and dest keypoint */
+        uint32_t n_prior;            /* PointsDownwardsPrior blocks (relax_cost_function.hpp:21-49) */
+        const uint32_t *prior_cam;
+        double huber_a;              /* HuberLoss scale of the 2-ray blocks (1 degree in radians, :68) */
+        double prior_weight;         /* 1e-3 (:1297) */
+    } ochip_relax_desc;
+
+    typedef struct ochip_relax_options /* the ceres::Solver::Options fields the reference sets or relies on */
+    {
+        int max_num_iterations;             /* 100 (:32) */
+        double initial_trust_region_radius; /* 1 (:36) */
+        double function_tolerance;          /* 1e-6 */
+        double gradient_tolerance;          /* 1e-10 */
+        double parameter_tolerance;         /* 1e-8 */
+    } ochip_relax_options;
+
+    enum
+    {
+        OCHIP_RELAX_NO_PARAMETERS = 0,
+        OCHIP_RELAX_CONVERGENCE_GRADIENT = 1,
+        OCHIP_RELAX_CONVERGENCE_PARAMETER = 2,
+        OCHIP_RELAX_CONVERGENCE_FUNCTION = 3,
+        OCHIP_RELAX_CONVERGENCE_RADIUS = 4,
+        OCHIP_RELAX_NO_CONVERGENCE = 5,
+        OCHIP_RELAX_FAILURE = 6
+    };
+
+    typedef struct ochip_relax_summary
+    {
+        int termination;
+        int iterations; /* summary.iterations.size(): iteration 0 + every trust-region step attempted */
+        int successful_steps, unsuccessful_steps;
+        int num_parameters; /* tangent dimension of the reduced program */
+        int num_residual_blocks;
+        double initial_cost, final_cost;
+    } ochip_relax_summary;
+
+    int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *desc, ochip_relax_problem **out);
+    void ochip_relax_problem_destroy(ochip_relax_problem *p);
+    /* relaxObservedModelOnly (:931-984): freeze every camera, leave the plane heights variable (or undo) */
+    int ochip_relax_set_cameras_constant(ochip_relax_problem *p, int constant);
+    /* Levenberg-Marquardt trust-region solve; the state stays in HBM */
+    int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, ochip_relax_summary *summary);
+    /* cam_q: n_cams x 4; ochip_relax_solve leaves the optimised cameras' quaternions normalised exactly as
+     * RelaxProblem::solve does after every Solve (:1410-1413); plane_z: 3 */
+    int ochip_relax_get_state(ochip_relax_problem *p, double *cam_q, double *plane_z);
+
     /* ---- profiling: HIP-event time of every launch of a kernel since the last reset ------------- */
     int ochip_profile_reset(ochip_ctx *ctx);
     int ochip_profile_get(ochip_ctx *ctx, int kernel_id, uint64_t *launches, double *total_ms);

@@ -56,15 +56,7 @@ size_t och_matches_from_device(const ochip_match *raw, const uint64_t *idx1, siz
 
 // ------------------------------------------------------------------------------------------------
 // graph + link stage driver
-#include "link_stage.hpp"
-
-struct och_graph
-{
-    MeasurementGraph graph;
-    std::vector<std::shared_ptr<CameraModel>> models;
-    std::unique_ptr<LinkStage> link;
-    std::string error;
-};
+#include "capi_graph.hpp"
 
 extern "C"
 {

@@ -1,0 +1,43 @@
+// Host side of the relax step (reference: include/opencalibration/relax/relax.hpp:12-15,
+// relax_problem.hpp).  Problem assembly (pose lookup, grid filter, triangle lookup) stays on the host
+// as in the reference; the Ceres solve is replaced by ochip_relax_solve on the device.
+#pragma once
+
+#include "types.hpp"
+
+#include "../../../include/ochip.h"
+
+namespace opencalibration_amd
+{
+
+struct NodePose // include/opencalibration/types/node_pose.hpp
+{
+    size_t node_id;
+    double orientation[4]; // x y z w
+    double position[3];
+};
+
+struct surface_model_plane // the part of surface_model the ground-plane flavour produces: one triangle
+{
+    double corner[3][3] = {{NAN, NAN, NAN}, {NAN, NAN, NAN}, {NAN, NAN, NAN}};
+};
+
+struct RelaxTimers
+{
+    double setup_host = 0; // grid filter + block assembly
+    double device = 0;     // problem upload + LM solves
+    int solves = 0;
+    int iterations_total = 0; // sum of summary.iterations.size() over solves ("LM iters")
+    int last_iterations = 0;
+    double last_initial_cost = 0, last_final_cost = 0;
+    int last_residual_blocks = 0;
+};
+
+// relax(graph, nodes, cam_models, edges_to_optimize, {ORIENTATION, GROUND_PLANE}, {}) — src/relax/relax.cpp:122-134
+// routed to runGroundPlane (:44-87).  edges_to_optimize holds edge ids in whitelist order.
+// Returns false (poses untouched) if the device reported an error; `error` then has the text.
+bool relax_ground_plane(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,
+                        const std::vector<size_t> &edges_to_optimize, surface_model_plane *surface,
+                        RelaxTimers *timers, std::string *error);
+
+} // namespace opencalibration_amd

@@ -1,0 +1,1263 @@
+// libochip.so — relax (bundle adjustment) for the ground-plane problem on the device (gfx950).
+//
+// Replaces what ceres::Solver::Solve does for RelaxProblem::setupGroundPlaneProblem
+// (src/relax/relax_problem.cpp:61-81,1390-1420): evaluation of the 2-ray plane-intersection residual
+// blocks (include/opencalibration/relax/relax_cost_function.hpp:601-684) and downward priors (:21-49)
+// with forward-mode derivatives in the quaternion tangent space, Huber corrector, assembly of the
+// normal equations, and the Levenberg-Marquardt trust-region loop with a dense
+// Cholesky solve of (J'J + D'D) y = J'r.
+//
+// Data-parallel structure (DESIGN.md "relax kernels"):
+//   * residual blocks are sorted by unordered camera pair; one wavefront owns one pair segment,
+//     evaluates its blocks lane-strided, keeps the 9x9 (J'J), 9 (J'r) and cost partial sums in
+//     registers and reduces them with a fixed shuffle tree -> one 55-double record per pair.  No
+//     atomics: the sums are bitwise reproducible run to run.
+//   * a per-camera gather (CSR camera -> pairs) writes the 3x3 diagonal / camera-plane blocks and the
+//     prior; a per-pair scatter writes the off-diagonal 3x3 blocks; one workgroup reduces the plane
+//     block, gradient and cost.  Streams observation arrays once per evaluation: HBM bound.
+//   * the reduced system is dense (3 dof per camera + 3 plane heights); blocked right-looking Cholesky
+//     (64-wide panels: diagonal factor in LDS, row-parallel panel solve, 64x64 tiled trailing update).
+#include "ctx.hpp"
+#include "dual.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <vector>
+
+using namespace ochip;
+
+namespace
+{
+
+constexpr int W = 64;
+constexpr int ACC = 55; // 45 upper-triangular entries of the 9x9 [p|q|z] block + 9 gradient + cost
+
+__host__ __device__ inline int tri(int i, int j) // i <= j, 9x9 upper triangle
+{
+    return i * 9 - i * (i - 1) / 2 + (j - i);
+}
+
+struct relax_dev
+{
+    // cameras
+    uint32_t n_cams;
+    double *cam_pos;  // [n][3]
+    double *cam_q;    // [n][4] current state (x y z w)
+    double *cam_q2;   // candidate state
+    int32_t *cam_t;   // tangent offset or -1
+    double z[2][3];   // unused on device (kept on host)
+    // plane
+    double *plane;    // [0..5] xy of 3 corners, [6..8] z current, [9..11] z candidate
+    int32_t *z_t;     // [3]
+    // blocks sorted by pair
+    uint32_t n_blocks, n_pairs, n_prior;
+    uint32_t *blk_a, *blk_b; // camera indices
+    double *blk_rays;        // [n][6] camera-frame unit rays a, b
+    uint32_t *pair_off;      // [n_pairs+1]
+    uint32_t *pair_p, *pair_q;
+    uint32_t *prior_cam;
+    // CSR camera -> (pair, role)
+    uint32_t *cam_pair_off, *cam_pair_idx; // idx = pair*2 + role (0: camera is p, 1: camera is q)
+    // outputs
+    double *pair_acc;  // [n_pairs][ACC]
+    double *pair_cost; // [n_pairs]
+    int32_t *fail;
+    double huber_a, prior_weight;
+};
+
+// ---- the cost functor (relax_cost_function.hpp:601-656 with N = 2), T = double or Dual<3>
+template <typename T> struct functor_io
+{
+    T qa[4], qb[4], z[3];
+};
+
+template <typename T> __device__ __forceinline__ Vec3T<T> quat_rotate(const T *q, const Vec3T<T> &v)
+{
+    // Eigen QuaternionBase::_transformVector
+    const Vec3T<T> qv{q[0], q[1], q[2]};
+    Vec3T<T> uv = cross(qv, v);
+    uv = uv + uv;
+    return v + scale(uv, q[3]) + cross(qv, uv);
+}
+
+template <typename T>
+__device__ bool plane_intersection_residuals(const functor_io<T> &in, const double *loc_a, const double *loc_b,
+                                             const double *rays, const double *plane_xy, T *res)
+{
+    Vec3T<T> corner[3];
+    for (int i = 0; i < 3; i++)
+        corner[i] = {T(plane_xy[2 * i]), T(plane_xy[2 * i + 1]), in.z[i]};
+    // cornerPlane2normOffsetPlane (intersection.hpp:26-32)
+    Vec3T<T> nrm = cross(corner[0] - corner[1], corner[0] - corner[2]);
+    {
+        const T zz = dot(nrm, nrm);
+        if (value_of(zz) > 0.0)
+            nrm = divide(nrm, dsqrt(zz));
+    }
+    const Vec3T<T> offset = corner[0];
+    Vec3T<T> isect[2];
+    bool all_valid = true;
+    T avg_dist = T(0.0);
+    for (int i = 0; i < 2; i++)
+    {
+        const double *l = i == 0 ? loc_a : loc_b;
+        const T *q = i == 0 ? in.qa : in.qb;
+        const Vec3T<T> ray_cam{T(rays[3 * i]), T(rays[3 * i + 1]), T(rays[3 * i + 2])};
+        const Vec3T<T> dir = quat_rotate(q, ray_cam);
+        const Vec3T<T> off{T(l[0]), T(l[1]), T(l[2])};
+        // rayPlaneIntersection (intersection.hpp:34-47)
+        const T denom = dot(nrm, dir);
+        if (fabs(value_of(denom)) < 1e-9)
+        {
+            all_valid = false;
+            isect[i] = {T(NAN), T(NAN), T(NAN)};
+        }
+        else
+        {
+            const T t = (dot(nrm, offset) - dot(off, nrm)) / denom;
+            isect[i] = off + scale(dir, t);
+        }
+        avg_dist = avg_dist + norm(isect[i] - off);
+    }
+    avg_dist = avg_dist / T(2.0);
+    const T huber_threshold = avg_dist * T(0.01);
+    // robustCentroid (relax_cost_function.hpp:73-117), n = 2
+    Vec3T<T> centroid = divide(isect[0] + isect[1], T(2.0));
+    for (int stage = 0; stage < 3; stage++)
+    {
+        T total_w = T(0.0), w[2];
+        double min_w = 1.7976931348623157e308, max_w = 0.0;
+        for (int i = 0; i < 2; i++)
+        {
+            const T err = norm(isect[i] - centroid);
+            T wi = T(1.0) / (err + T(1e-8));
+            if (value_of(err) > value_of(huber_threshold))
+                wi = wi * (huber_threshold / err);
+            w[i] = wi;
+            total_w = total_w + wi;
+            if (value_of(wi) < min_w)
+                min_w = value_of(wi);
+            if (value_of(wi) > max_w)
+                max_w = value_of(wi);
+        }
+        const Vec3T<T> ws = scale(isect[0], w[0]) + scale(isect[1], w[1]);
+        centroid = divide(ws, total_w);
+        if (min_w > max_w * 0.5)
+            break;
+    }
+    for (int i = 0; i < 2; i++)
+    {
+        const Vec3T<T> r = divide(isect[i] - centroid, avg_dist);
+        res[3 * i] = r.x;
+        res[3 * i + 1] = r.y;
+        res[3 * i + 2] = r.z;
+    }
+    return all_valid;
+}
+
+// tangent seed of the EigenQuaternionManifold at q: d(q_delta * q)/d delta (ceres manifold.cc, Order XYZW)
+__device__ __forceinline__ void seed_quat(const double *q, Dual<3> *out)
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double pj[4][3] = {{w, z, -y}, {-z, w, x}, {y, -x, w}, {-x, -y, -z}};
+    for (int k = 0; k < 4; k++)
+    {
+        out[k] = Dual<3>(q[k]);
+        for (int c = 0; c < 3; c++)
+            out[k].v[c] = pj[k][c];
+    }
+}
+
+template <bool WITH_JAC>
+__global__ __launch_bounds__(W) void relax_pair_eval_kernel(relax_dev P, int which_state)
+{
+    const int lane = threadIdx.x;
+    const uint32_t pair = blockIdx.x;
+    const uint32_t b0 = P.pair_off[pair], b1 = P.pair_off[pair + 1];
+    const uint32_t p = P.pair_p[pair];
+    const double *Q = which_state ? P.cam_q2 : P.cam_q;
+    const double *Z = P.plane + (which_state ? 9 : 6);
+    const double a2 = P.huber_a * P.huber_a;
+
+    double acc[WITH_JAC ? ACC : 1];
+    for (int i = 0; i < (WITH_JAC ? ACC : 1); i++)
+        acc[i] = 0;
+    double cost = 0;
+    bool failed = false;
+
+    for (uint32_t blk = b0 + lane; blk < b1; blk += W)
+    {
+        const uint32_t ca = P.blk_a[blk], cb = P.blk_b[blk];
+        const double *rays = P.blk_rays + (size_t)blk * 6;
+        const double *la = P.cam_pos + (size_t)ca * 3, *lb = P.cam_pos + (size_t)cb * 3;
+        const double *qa = Q + (size_t)ca * 4, *qb = Q + (size_t)cb * 4;
+        double r[6];
+        double J[6][9]; // columns: a-tangent | b-tangent | z
+        {
+            functor_io<double> in;
+            for (int k = 0; k < 4; k++)
+            {
+                in.qa[k] = qa[k];
+                in.qb[k] = qb[k];
+            }
+            for (int k = 0; k < 3; k++)
+                in.z[k] = Z[k];
+            if (!plane_intersection_residuals<double>(in, la, lb, rays, P.plane, r))
+                failed = true;
+        }
+        double s = 0;
+        for (int k = 0; k < 6; k++)
+        {
+            s += r[k] * r[k];
+            if (!(r[k] - r[k] == 0.0))
+                failed = true;
+        }
+        // Huber + Triggs corrector (rho'' <= 0 for Huber: plain sqrt(rho') scaling)
+        double sqrt_rho1 = 1.0, c = 0.5 * s;
+        if (s > a2)
+        {
+            const double rn = sqrt(s);
+            const double rho1 = fmax(2.2250738585072014e-308, P.huber_a / rn);
+            sqrt_rho1 = sqrt(rho1);
+            c = 0.5 * (2.0 * P.huber_a * rn - a2);
+        }
+        cost += c;
+        if (WITH_JAC)
+        {
+#pragma unroll 1
+            for (int pass = 0; pass < 3; pass++)
+            {
+                functor_io<Dual<3>> in;
+                if (pass == 0)
+                    seed_quat(qa, in.qa);
+                else
+                    for (int k = 0; k < 4; k++)
+                        in.qa[k] = Dual<3>(qa[k]);
+                if (pass == 1)
+                    seed_quat(qb, in.qb);
+                else
+                    for (int k = 0; k < 4; k++)
+                        in.qb[k] = Dual<3>(qb[k]);
+                for (int k = 0; k < 3; k++)
+                {
+                    in.z[k] = Dual<3>(Z[k]);
+                    if (pass == 2)
+                        in.z[k].v[k] = 1.0;
+                }
+                Dual<3> rd[6];
+                plane_intersection_residuals<Dual<3>>(in, la, lb, rays, P.plane, rd);
+                for (int k = 0; k < 6; k++)
+                    for (int cidx = 0; cidx < 3; cidx++)
+                    {
+                        const double v = rd[k].v[cidx] * sqrt_rho1;
+                        J[k][pass * 3 + cidx] = v;
+                        if (!(v - v == 0.0))
+                            failed = true;
+                    }
+            }
+            for (int k = 0; k < 6; k++)
+                r[k] *= sqrt_rho1;
+            // role normalisation: pair columns are [p | q | z]
+            const bool flip = ca != p;
+            int col[9];
+            for (int k = 0; k < 9; k++)
+                col[k] = k < 6 ? (flip ? (k + 3) % 6 : k) : k;
+            for (int i = 0; i < 9; i++)
+            {
+                double g = 0;
+                for (int k = 0; k < 6; k++)
+                    g += J[k][i] * r[k];
+                acc[45 + col[i]] += g;
+                for (int j = i; j < 9; j++)
+                {
+                    double m = 0;
+                    for (int k = 0; k < 6; k++)
+                        m += J[k][i] * J[k][j];
+                    const int ci = col[i], cj = col[j];
+                    acc[ci <= cj ? tri(ci, cj) : tri(cj, ci)] += m;
+                }
+            }
+        }
+    }
+    // fixed shuffle tree: bitwise reproducible
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        cost += __shfl_xor(cost, off);
+        if (WITH_JAC)
+            for (int i = 0; i < 54; i++)
+                acc[i] += __shfl_xor(acc[i], off);
+    }
+    if (__ballot(failed) && lane == 0)
+        atomicOr(P.fail, 1);
+    if (lane == 0)
+    {
+        P.pair_cost[pair] = cost;
+        if (WITH_JAC)
+        {
+            double *o = P.pair_acc + (size_t)pair * ACC;
+            for (int i = 0; i < 54; i++)
+                o[i] = acc[i];
+            o[54] = cost;
+        }
+    }
+}
+
+// downward prior of one camera (relax_cost_function.hpp:21-49): residual and tangent Jacobian
+__device__ void downward_prior(const double *q, double weight, double *res, double *jac3)
+{
+    Dual<3> qd[4];
+    seed_quat(q, qd);
+    const Vec3T<Dual<3>> cam_center{Dual<3>(0.0), Dual<3>(0.0), Dual<3>(1.0)};
+    const Vec3T<Dual<3>> rot = quat_rotate(qd, cam_center);
+    // angleBetweenUnitVectors(rot, (0,0,-1)) with the clamp of relax_cost_function.hpp:16-19
+    Dual<3> d = Dual<3>(0.0) * rot.x + Dual<3>(0.0) * rot.y + Dual<3>(-1.0) * rot.z;
+    const double lo = -1 + 1e-12, hi = 1 - 1e-12;
+    if (d.a < lo)
+        d = Dual<3>(lo);
+    else if (hi < d.a)
+        d = Dual<3>(hi);
+    const Dual<3> ang = Dual<3>(weight) * dacos(d);
+    *res = ang.a;
+    for (int c = 0; c < 3; c++)
+        jac3[c] = ang.v[c];
+}
+
+// Per-camera gather: diagonal 3x3, camera-plane 3x3, gradient; plus the prior.  One thread per camera.
+__global__ void relax_scatter_cam_kernel(relax_dev P, double *A, double *g, int n, const uint8_t *cam_has_prior)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.n_cams)
+        return;
+    const int tc = P.cam_t[c];
+    if (tc < 0)
+        return;
+    double D[6] = {0, 0, 0, 0, 0, 0}, CZ[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, G[3] = {0, 0, 0};
+    for (uint32_t e = P.cam_pair_off[c]; e < P.cam_pair_off[c + 1]; e++)
+    {
+        const uint32_t idx = P.cam_pair_idx[e];
+        const double *a = P.pair_acc + (size_t)(idx >> 1) * ACC;
+        const int o = (idx & 1) ? 3 : 0;
+        int k = 0;
+        for (int i = 0; i < 3; i++)
+            for (int j = i; j < 3; j++)
+                D[k++] += a[tri(o + i, o + j)];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                CZ[i * 3 + j] += a[tri(o + i, 6 + j)];
+        for (int i = 0; i < 3; i++)
+            G[i] += a[45 + o + i];
+    }
+    if (cam_has_prior[c])
+    {
+        double r, j3[3];
+        downward_prior(P.cam_q + (size_t)c * 4, P.prior_weight, &r, j3);
+        int k = 0;
+        for (int i = 0; i < 3; i++)
+        {
+            for (int j = i; j < 3; j++)
+                D[k++] += j3[i] * j3[j];
+            G[i] += j3[i] * r;
+        }
+    }
+    int k = 0;
+    for (int i = 0; i < 3; i++)
+        for (int j = i; j < 3; j++)
+        {
+            A[(size_t)(tc + i) * n + tc + j] = D[k];
+            A[(size_t)(tc + j) * n + tc + i] = D[k];
+            k++;
+        }
+    for (int i = 0; i < 3; i++)
+    {
+        g[tc + i] = G[i];
+        for (int j = 0; j < 3; j++)
+        {
+            const int tz = P.z_t[j];
+            if (tz >= 0)
+            {
+                A[(size_t)(tc + i) * n + tz] = CZ[i * 3 + j];
+                A[(size_t)tz * n + tc + i] = CZ[i * 3 + j];
+            }
+        }
+    }
+}
+
+// Per-pair scatter of the off-diagonal camera-camera block.  One thread per pair.
+__global__ void relax_scatter_pair_kernel(relax_dev P, double *A, int n)
+{
+    const uint32_t pr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pr >= P.n_pairs)
+        return;
+    const int tp = P.cam_t[P.pair_p[pr]], tq = P.cam_t[P.pair_q[pr]];
+    if (tp < 0 || tq < 0)
+        return;
+    const double *a = P.pair_acc + (size_t)pr * ACC;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+        {
+            const double v = a[tri(i, 3 + j)];
+            A[(size_t)(tp + i) * n + tq + j] = v;
+            A[(size_t)(tq + j) * n + tp + i] = v;
+        }
+}
+
+// One workgroup: plane-plane block, plane gradient, total cost (pairs + priors).  scal[0] = cost.
+__global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, double *A, double *g, int n,
+                                                                 const uint8_t *cam_has_prior, double *scal,
+                                                                 int with_jac, int which_state)
+{
+    __shared__ double sh[256];
+    const int t = threadIdx.x;
+    double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // zz (6), gz (3), cost
+    for (uint32_t pr = t; pr < P.n_pairs; pr += 256)
+    {
+        if (with_jac)
+        {
+            const double *a = P.pair_acc + (size_t)pr * ACC;
+            int k = 0;
+            for (int i = 0; i < 3; i++)
+                for (int j = i; j < 3; j++)
+                    v[k++] += a[tri(6 + i, 6 + j)];
+            for (int i = 0; i < 3; i++)
+                v[6 + i] += a[45 + 6 + i];
+        }
+        v[9] += P.pair_cost[pr];
+    }
+    const double *Q = which_state ? P.cam_q2 : P.cam_q;
+    for (uint32_t c = t; c < P.n_cams; c += 256)
+        if (cam_has_prior[c] && P.cam_t[c] >= 0) // priors of constant cameras are fixed cost (not in the reduced program)
+        {
+            double r, j3[3];
+            downward_prior(Q + (size_t)c * 4, P.prior_weight, &r, j3);
+            v[9] += 0.5 * r * r;
+        }
+    for (int q = 0; q < 10; q++)
+    {
+        sh[t] = v[q];
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1)
+        {
+            if (t < s)
+                sh[t] += sh[t + s];
+            __syncthreads();
+        }
+        if (t == 0)
+            v[q] = sh[0];
+        __syncthreads();
+    }
+    if (t == 0)
+    {
+        scal[0] = v[9];
+        if (with_jac)
+        {
+            int k = 0;
+            for (int i = 0; i < 3; i++)
+                for (int j = i; j < 3; j++)
+                {
+                    const int ti = P.z_t[i], tj = P.z_t[j];
+                    if (ti >= 0 && tj >= 0)
+                    {
+                        A[(size_t)ti * n + tj] = v[k];
+                        A[(size_t)tj * n + ti] = v[k];
+                    }
+                    k++;
+                }
+            for (int i = 0; i < 3; i++)
+                if (P.z_t[i] >= 0)
+                    g[P.z_t[i]] = v[6 + i];
+        }
+    }
+}
+
+// ---- dense linear algebra on the reduced system -------------------------------------------------
+constexpr int NB = 64;
+
+// Wm = S A S + diag(D), gs = S g; also column norms^2 of the scaled Jacobian = diag(S A S)
+__global__ void lm_build_kernel(const double *A, const double *g, const double *scale, const double *lm_diag,
+                                double *Wm, double *gs, int n)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * n)
+        return;
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    double v = A[idx] * scale[i] * scale[j];
+    if (i == j)
+    {
+        v += lm_diag[i];
+        gs[i] = g[i] * scale[i];
+    }
+    Wm[idx] = v;
+}
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(double *A, int n, int k0, int nb, int *fail)
+{
+    __shared__ double L[NB][NB + 1];
+    const int t = threadIdx.x;
+    for (int e = t; e < nb * nb; e += 256)
+    {
+        const int i = e / nb, j = e % nb;
+        L[i][j] = A[(size_t)(k0 + i) * n + k0 + j];
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; j++)
+    {
+        if (t == 0)
+        {
+            const double d = L[j][j];
+            if (!(d > 0.0))
+            {
+                *fail = 1;
+                L[j][j] = __builtin_nan("");
+            }
+            else
+                L[j][j] = sqrt(d);
+        }
+        __syncthreads();
+        const double djj = L[j][j];
+        for (int i = j + 1 + t; i < nb; i += 256)
+            L[i][j] /= djj;
+        __syncthreads();
+        for (int e = t; e < (nb - j - 1) * (nb - j - 1); e += 256)
+        {
+            const int i = j + 1 + e / (nb - j - 1), c = j + 1 + e % (nb - j - 1);
+            if (c <= i)
+                L[i][c] -= L[i][j] * L[c][j];
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < nb * nb; e += 256)
+    {
+        const int i = e / nb, j = e % nb;
+        if (j <= i)
+            A[(size_t)(k0 + i) * n + k0 + j] = L[i][j];
+    }
+}
+
+// rows below the diagonal block: X = A[i, k0:k0+nb] * L_kk^{-T}
+__global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, int k0, int nb)
+{
+    __shared__ double L[NB][NB + 1];
+    const int t = threadIdx.x;
+    for (int e = t; e < nb * nb; e += 256)
+    {
+        const int i = e / nb, j = e % nb;
+        L[i][j] = A[(size_t)(k0 + i) * n + k0 + j];
+    }
+    __syncthreads();
+    const int row = k0 + nb + blockIdx.x * 256 + t;
+    if (row >= n)
+        return;
+    double x[NB];
+    double *a = A + (size_t)row * n + k0;
+    for (int c = 0; c < nb; c++)
+        x[c] = a[c];
+    for (int c = 0; c < nb; c++)
+    {
+        double s = x[c];
+        for (int m = 0; m < c; m++)
+            s -= x[m] * L[c][m];
+        x[c] = s / L[c][c];
+    }
+    for (int c = 0; c < nb; c++)
+        a[c] = x[c];
+}
+
+// trailing update, lower tiles only: C[i][j] -= sum_m P[i][m] P[j][m], 64x64 tile per workgroup
+__global__ __launch_bounds__(256) void chol_update_kernel(double *A, int n, int k0, int nb)
+{
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti)
+        return;
+    constexpr int KC = 32;
+    __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
+    const int base = k0 + nb;
+    const int r0 = base + ti * 64, c0 = base + tj * 64;
+    const int t = threadIdx.x;
+    const int tr = (t / 16) * 4, tc = (t % 16) * 4;
+    double c[4][4] = {{0}};
+    for (int m0 = 0; m0 < nb; m0 += KC)
+    {
+        const int mc = min(KC, nb - m0);
+        __syncthreads();
+        for (int e = t; e < 64 * KC; e += 256)
+        {
+            const int r = e / KC, m = e % KC;
+            Pi[r][m] = (r0 + r < n && m < mc) ? A[(size_t)(r0 + r) * n + k0 + m0 + m] : 0.0;
+            Pj[r][m] = (c0 + r < n && m < mc) ? A[(size_t)(c0 + r) * n + k0 + m0 + m] : 0.0;
+        }
+        __syncthreads();
+        for (int m = 0; m < KC; m++)
+        {
+            double a[4], b[4];
+            for (int i = 0; i < 4; i++)
+            {
+                a[i] = Pi[tr + i][m];
+                b[i] = Pj[tc + i][m];
+            }
+            for (int i = 0; i < 4; i++)
+                for (int j = 0; j < 4; j++)
+                    c[i][j] = __builtin_fma(a[i], b[j], c[i][j]);
+        }
+    }
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+        {
+            const int r = r0 + tr + i, cc = c0 + tc + j;
+            if (r < n && cc < n && cc <= r)
+                A[(size_t)r * n + cc] -= c[i][j];
+        }
+}
+
+// Single workgroup blocked triangular solves with the factor L (lower, row-major): L y = b, then L' x = y.
+__global__ __launch_bounds__(1024) void chol_solve_kernel(const double *L, double *x, int n)
+{
+    __shared__ double xb[NB];
+    const int t = threadIdx.x;
+    // forward
+    for (int k0 = 0; k0 < n; k0 += NB)
+    {
+        const int nb = min(NB, n - k0);
+        for (int j = 0; j < nb; j++)
+        {
+            if (t == 0)
+                x[k0 + j] /= L[(size_t)(k0 + j) * n + k0 + j];
+            __syncthreads();
+            const double xj = x[k0 + j];
+            for (int i = j + 1 + t; i < nb; i += 1024)
+                x[k0 + i] -= L[(size_t)(k0 + i) * n + k0 + j] * xj;
+            __syncthreads();
+        }
+        if (t < nb)
+            xb[t] = x[k0 + t];
+        __syncthreads();
+        for (int i = k0 + nb + t; i < n; i += 1024)
+        {
+            double s = 0;
+            const double *row = L + (size_t)i * n + k0;
+            for (int m = 0; m < nb; m++)
+                s += row[m] * xb[m];
+            x[i] -= s;
+        }
+        __syncthreads();
+    }
+    // backward with L'
+    for (int k1 = n; k1 > 0; k1 -= NB)
+    {
+        const int k0 = max(0, k1 - NB), nb = k1 - k0;
+        for (int j = nb - 1; j >= 0; j--)
+        {
+            if (t == 0)
+                x[k0 + j] /= L[(size_t)(k0 + j) * n + k0 + j];
+            __syncthreads();
+            const double xj = x[k0 + j];
+            for (int i = t; i < j; i += 1024)
+                x[k0 + i] -= L[(size_t)(k0 + j) * n + k0 + i] * xj;
+            __syncthreads();
+        }
+        if (t < nb)
+            xb[t] = x[k0 + t];
+        __syncthreads();
+        for (int i = t; i < k0; i += 1024)
+        {
+            double s = 0;
+            for (int m = 0; m < nb; m++)
+                s += L[(size_t)(k0 + m) * n + i] * xb[m];
+            x[i] -= s;
+        }
+        __syncthreads();
+    }
+}
+
+// step = -y; model_cost_change = -(step.gs + step' As step / 2) with As = S A S; delta = S step;
+// candidate state = x (+) delta; step_norm^2 in ambient space.  One workgroup.
+// scal: [1] model_cost_change, [2] step_norm^2, [3] x_norm^2 (candidate)
+__global__ __launch_bounds__(1024) void lm_step_kernel(relax_dev P, const double *A, const double *gs,
+                                                       const double *scale, double *y, int n, double *scal)
+{
+    __shared__ double sh[1024];
+    const int t = threadIdx.x;
+    double part = 0;
+    for (int i = t; i < n; i += 1024)
+    {
+        const double si = -y[i];
+        double row = 0;
+        for (int j = 0; j < n; j++) // A is symmetric: read column i as row elements A[j][i] (coalesced over i)
+            row += A[(size_t)j * n + i] * scale[i] * scale[j] * (-y[j]);
+        part += si * gs[i] + 0.5 * si * row;
+    }
+    sh[t] = part;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1)
+    {
+        if (t < s)
+            sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    if (t == 0)
+        scal[1] = -sh[0];
+    __syncthreads();
+    // candidate state
+    double sn = 0, xn = 0;
+    for (uint32_t c = t; c < P.n_cams; c += 1024)
+    {
+        const int tc = P.cam_t[c];
+        const double *q = P.cam_q + (size_t)c * 4;
+        double *o = P.cam_q2 + (size_t)c * 4;
+        if (tc < 0)
+        {
+            for (int k = 0; k < 4; k++)
+                o[k] = q[k];
+            continue;
+        }
+        double d[3];
+        for (int k = 0; k < 3; k++)
+            d[k] = -y[tc + k] * scale[tc + k];
+        const double nrm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (nrm == 0.0)
+        {
+            for (int k = 0; k < 4; k++)
+                o[k] = q[k];
+        }
+        else
+        {
+            const double s = sin(nrm) / nrm;
+            const double dx = s * d[0], dy = s * d[1], dz = s * d[2], dw = cos(nrm);
+            const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+            o[3] = dw * qw - dx * qx - dy * qy - dz * qz;
+            o[0] = dw * qx + dx * qw + dy * qz - dz * qy;
+            o[1] = dw * qy + dy * qw + dz * qx - dx * qz;
+            o[2] = dw * qz + dz * qw + dx * qy - dy * qx;
+        }
+        for (int k = 0; k < 4; k++)
+        {
+            sn += (q[k] - o[k]) * (q[k] - o[k]);
+            xn += o[k] * o[k];
+        }
+    }
+    if (t < 3)
+    {
+        const int tz = P.z_t[t];
+        const double z0 = P.plane[6 + t];
+        const double z1 = tz >= 0 ? z0 + (-y[tz] * scale[tz]) : z0;
+        P.plane[9 + t] = z1;
+        if (tz >= 0)
+        {
+            sn += (z0 - z1) * (z0 - z1);
+            xn += z1 * z1;
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < 2; q++)
+    {
+        sh[t] = q == 0 ? sn : xn;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1)
+        {
+            if (t < s)
+                sh[t] += sh[t + s];
+            __syncthreads();
+        }
+        if (t == 0)
+            scal[2 + q] = sh[0];
+        __syncthreads();
+    }
+}
+
+__global__ void lm_accept_kernel(relax_dev P)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.n_cams * 4)
+        P.cam_q[i] = P.cam_q2[i];
+    if (i < 3)
+        P.plane[6 + i] = P.plane[9 + i];
+}
+
+// p.second->orientation.normalize() for every node of _nodes_to_optimize (relax_problem.cpp:1410-1413)
+__global__ void normalize_kernel(relax_dev P, const uint8_t *cam_optimize)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.n_cams || !cam_optimize[c])
+        return;
+    double *q = P.cam_q + (size_t)c * 4;
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int k = 0; k < 4; k++)
+        q[k] = q[k] / n;
+}
+
+// diag(A) and max|g| -> scal[4] = max|g|; diag_out[i] = A_ii
+__global__ __launch_bounds__(1024) void lm_diag_kernel(const double *A, const double *g, double *diag_out, int n,
+                                                       double *scal)
+{
+    __shared__ double sh[1024];
+    const int t = threadIdx.x;
+    double m = 0;
+    for (int i = t; i < n; i += 1024)
+    {
+        diag_out[i] = A[(size_t)i * n + i];
+        m = fmax(m, fabs(g[i]));
+    }
+    sh[t] = m;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1)
+    {
+        if (t < s)
+            sh[t] = fmax(sh[t], sh[t + s]);
+        __syncthreads();
+    }
+    if (t == 0)
+        scal[4] = sh[0];
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------
+struct ochip_relax_problem
+{
+    ochip_ctx *ctx = nullptr;
+    relax_dev dev{};
+    std::vector<void *> allocs;
+    int n_tangent = 0;
+    std::vector<int32_t> cam_t;
+    int32_t z_t[3] = {-1, -1, -1};
+    std::vector<uint8_t> cam_optimize, cam_has_prior_host;
+    uint8_t z_optimize[3] = {1, 1, 1};
+    bool cams_frozen = false;
+    uint8_t *cam_has_prior = nullptr, *cam_optimize_dev = nullptr;
+    double *A = nullptr, *Wm = nullptr, *g = nullptr, *gs = nullptr, *scale = nullptr, *lm_diag = nullptr,
+           *diag_tmp = nullptr, *y = nullptr, *scal = nullptr;
+    int *fail_chol = nullptr;
+    size_t cap_n = 0;
+    uint32_t n_cams = 0;
+    std::vector<uint32_t> cam_pair_count;
+};
+
+namespace
+{
+template <typename T> int dev_upload(ochip_relax_problem *p, T **dst, const T *src, size_t n)
+{
+    void *d = nullptr;
+    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess)
+        return ochip_fail(p->ctx, OCHIP_ENOMEM, "hipMalloc(%zu) failed in relax problem", n * sizeof(T));
+    p->allocs.push_back(d);
+    if (n && src)
+        if (hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+            return ochip_fail(p->ctx, OCHIP_EHIP, "hipMemcpy failed in relax problem");
+    *dst = (T *)d;
+    return OCHIP_OK;
+}
+
+int assign_tangent(ochip_relax_problem *p)
+{
+    int t = 0;
+    p->cam_t.assign(p->n_cams, -1);
+    for (uint32_t c = 0; c < p->n_cams; c++)
+        if (p->cam_optimize[c] && !p->cams_frozen && p->cam_pair_count[c] + p->cam_has_prior_host[c] > 0)
+        {
+            p->cam_t[c] = t;
+            t += 3;
+        }
+    for (int i = 0; i < 3; i++)
+    {
+        p->z_t[i] = -1;
+        if (p->z_optimize[i] && p->dev.n_blocks > 0)
+            p->z_t[i] = t++;
+    }
+    p->n_tangent = t;
+    if (hipMemcpy(p->dev.cam_t, p->cam_t.data(), p->n_cams * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->dev.z_t, p->z_t, 12, hipMemcpyHostToDevice) != hipSuccess)
+        return ochip_fail(p->ctx, OCHIP_EHIP, "hipMemcpy failed (tangent map)");
+    const size_t n = (size_t)std::max(t, 1);
+    if (n > p->cap_n)
+    {
+        for (double **b : {&p->A, &p->Wm, &p->g, &p->gs, &p->scale, &p->lm_diag, &p->diag_tmp, &p->y})
+            if (*b)
+            {
+                (void)hipFree(*b);
+                *b = nullptr;
+            }
+        if (hipMalloc((void **)&p->A, n * n * 8) != hipSuccess || hipMalloc((void **)&p->Wm, n * n * 8) != hipSuccess ||
+            hipMalloc((void **)&p->g, n * 8) != hipSuccess || hipMalloc((void **)&p->gs, n * 8) != hipSuccess ||
+            hipMalloc((void **)&p->scale, n * 8) != hipSuccess || hipMalloc((void **)&p->lm_diag, n * 8) != hipSuccess ||
+            hipMalloc((void **)&p->diag_tmp, n * 8) != hipSuccess || hipMalloc((void **)&p->y, n * 8) != hipSuccess)
+            return ochip_fail(p->ctx, OCHIP_ENOMEM, "hipMalloc for the %zu x %zu normal matrix failed", n, n);
+        p->cap_n = n;
+    }
+    return OCHIP_OK;
+}
+} // namespace
+
+extern "C"
+{
+
+int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *d, ochip_relax_problem **out)
+{
+    if (!ctx || !d || !out)
+        return OCHIP_EINVAL;
+    *out = nullptr;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    auto *p = new (std::nothrow) ochip_relax_problem();
+    if (!p)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "host allocation failed");
+    p->ctx = ctx;
+    p->n_cams = d->n_cams;
+    for (uint32_t b = 0; b < d->n_blocks; b++)
+        if (d->blk_cam_a[b] >= d->n_cams || d->blk_cam_b[b] >= d->n_cams || d->blk_cam_a[b] == d->blk_cam_b[b])
+        {
+            delete p;
+            return ochip_fail(ctx, OCHIP_EINVAL, "residual block %u has bad camera indices", b);
+        }
+    // sort blocks by unordered camera pair (stable), build segments and the camera -> pair CSR
+    std::vector<uint32_t> order(d->n_blocks);
+    for (uint32_t i = 0; i < d->n_blocks; i++)
+        order[i] = i;
+    auto key = [&](uint32_t b) {
+        const uint32_t a = d->blk_cam_a[b], c = d->blk_cam_b[b];
+        return ((uint64_t)std::min(a, c) << 32) | std::max(a, c);
+    };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
+    std::vector<uint32_t> blk_a(d->n_blocks), blk_b(d->n_blocks), pair_off, pair_p, pair_q;
+    std::vector<double> rays((size_t)d->n_blocks * 6);
+    for (uint32_t i = 0; i < d->n_blocks; i++)
+    {
+        const uint32_t b = order[i];
+        blk_a[i] = d->blk_cam_a[b];
+        blk_b[i] = d->blk_cam_b[b];
+        for (int k = 0; k < 6; k++)
+            rays[(size_t)i * 6 + k] = d->blk_rays[(size_t)b * 6 + k];
+        if (i == 0 || key(order[i - 1]) != key(b))
+        {
+            pair_off.push_back(i);
+            pair_p.push_back(std::min(blk_a[i], blk_b[i]));
+            pair_q.push_back(std::max(blk_a[i], blk_b[i]));
+        }
+    }
+    pair_off.push_back(d->n_blocks);
+    const uint32_t n_pairs = (uint32_t)pair_p.size();
+    p->cam_pair_count.assign(d->n_cams, 0);
+    for (uint32_t pr = 0; pr < n_pairs; pr++)
+    {
+        p->cam_pair_count[pair_p[pr]]++;
+        p->cam_pair_count[pair_q[pr]]++;
+    }
+    std::vector<uint32_t> cpo(d->n_cams + 1, 0), cpi(2 * (size_t)n_pairs);
+    for (uint32_t c = 0; c < d->n_cams; c++)
+        cpo[c + 1] = cpo[c] + p->cam_pair_count[c];
+    {
+        std::vector<uint32_t> fill(cpo.begin(), cpo.end() - 1);
+        for (uint32_t pr = 0; pr < n_pairs; pr++)
+        {
+            cpi[fill[pair_p[pr]]++] = pr * 2;
+            cpi[fill[pair_q[pr]]++] = pr * 2 + 1;
+        }
+    }
+    p->cam_optimize.assign(d->cam_optimize, d->cam_optimize + d->n_cams);
+    p->cam_has_prior_host.assign(d->n_cams, 0);
+    for (uint32_t i = 0; i < d->n_prior; i++)
+        if (d->prior_cam[i] < d->n_cams)
+            p->cam_has_prior_host[d->prior_cam[i]] = 1;
+    for (int i = 0; i < 3; i++)
+        p->z_optimize[i] = d->z_optimize[i];
+
+    relax_dev &D = p->dev;
+    D.n_cams = d->n_cams;
+    D.n_blocks = d->n_blocks;
+    D.n_pairs = n_pairs;
+    D.n_prior = d->n_prior;
+    D.huber_a = d->huber_a;
+    D.prior_weight = d->prior_weight;
+    double plane[12];
+    for (int i = 0; i < 6; i++)
+        plane[i] = d->plane_xy[i];
+    for (int i = 0; i < 3; i++)
+        plane[6 + i] = plane[9 + i] = d->plane_z[i];
+    int rc = OCHIP_OK;
+    auto chk = [&](int r) {
+        if (rc == OCHIP_OK)
+            rc = r;
+    };
+    chk(dev_upload(p, &D.cam_pos, d->cam_pos, (size_t)d->n_cams * 3));
+    chk(dev_upload(p, &D.cam_q, d->cam_q, (size_t)d->n_cams * 4));
+    chk(dev_upload(p, &D.cam_q2, d->cam_q, (size_t)d->n_cams * 4));
+    chk(dev_upload<int32_t>(p, &D.cam_t, nullptr, d->n_cams));
+    chk(dev_upload(p, &D.plane, plane, 12));
+    chk(dev_upload<int32_t>(p, &D.z_t, nullptr, 3));
+    chk(dev_upload(p, &D.blk_a, blk_a.data(), blk_a.size()));
+    chk(dev_upload(p, &D.blk_b, blk_b.data(), blk_b.size()));
+    chk(dev_upload(p, &D.blk_rays, rays.data(), rays.size()));
+    chk(dev_upload(p, &D.pair_off, pair_off.data(), pair_off.size()));
+    chk(dev_upload(p, &D.pair_p, pair_p.data(), pair_p.size()));
+    chk(dev_upload(p, &D.pair_q, pair_q.data(), pair_q.size()));
+    chk(dev_upload(p, &D.cam_pair_off, cpo.data(), cpo.size()));
+    chk(dev_upload(p, &D.cam_pair_idx, cpi.data(), cpi.size()));
+    chk(dev_upload<double>(p, &D.pair_acc, nullptr, (size_t)n_pairs * ACC));
+    chk(dev_upload<double>(p, &D.pair_cost, nullptr, n_pairs));
+    chk(dev_upload<int32_t>(p, &D.fail, nullptr, 1));
+    chk(dev_upload(p, &p->cam_has_prior, p->cam_has_prior_host.data(), p->cam_has_prior_host.size()));
+    chk(dev_upload(p, &p->cam_optimize_dev, p->cam_optimize.data(), p->cam_optimize.size()));
+    chk(dev_upload<double>(p, &p->scal, nullptr, 8));
+    chk(dev_upload<int>(p, &p->fail_chol, nullptr, 1));
+    if (rc == OCHIP_OK)
+        rc = assign_tangent(p);
+    if (rc != OCHIP_OK)
+    {
+        ochip_relax_problem_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return OCHIP_OK;
+}
+
+void ochip_relax_problem_destroy(ochip_relax_problem *p)
+{
+    if (!p)
+        return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (void *a : p->allocs)
+        (void)hipFree(a);
+    for (double *b : {p->A, p->Wm, p->g, p->gs, p->scale, p->lm_diag, p->diag_tmp, p->y})
+        if (b)
+            (void)hipFree(b);
+    delete p;
+}
+
+int ochip_relax_set_cameras_constant(ochip_relax_problem *p, int constant)
+{
+    if (!p)
+        return OCHIP_EINVAL;
+    p->cams_frozen = constant != 0;
+    return assign_tangent(p);
+}
+
+int ochip_relax_get_state(ochip_relax_problem *p, double *cam_q, double *plane_z)
+{
+    if (!p)
+        return OCHIP_EINVAL;
+    ochip_ctx *ctx = p->ctx;
+    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (cam_q)
+        OCHIP_HIP(ctx, hipMemcpy(cam_q, p->dev.cam_q, (size_t)p->n_cams * 32, hipMemcpyDeviceToHost));
+    if (plane_z)
+        OCHIP_HIP(ctx, hipMemcpy(plane_z, p->dev.plane + 6, 24, hipMemcpyDeviceToHost));
+    return OCHIP_OK;
+}
+
+// Trust-region Levenberg-Marquardt, monotonic steps (Ceres TrustRegionMinimizer +
+// LevenbergMarquardtStrategy semantics).  The control flow runs on the host
+// side of the library; every O(problem) operation is a kernel.
+int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, ochip_relax_summary *sum)
+{
+    if (!p || !opt || !sum)
+        return OCHIP_EINVAL;
+    ochip_ctx *ctx = p->ctx;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    *sum = ochip_relax_summary{};
+    const int n = p->n_tangent;
+    relax_dev &D = p->dev;
+    sum->num_parameters = n;
+    sum->num_residual_blocks = D.n_blocks + D.n_prior;
+    auto normalize = [&]() {
+        if (D.n_cams)
+            hipLaunchKernelGGL(normalize_kernel, dim3((D.n_cams + 255) / 256), dim3(256), 0, st, D, p->cam_optimize_dev);
+    };
+    if (D.n_blocks == 0 && D.n_prior == 0)
+    {
+        sum->termination = OCHIP_RELAX_NO_PARAMETERS; // RelaxProblem::solve returns before Solve (:1398-1402)
+        return OCHIP_OK;
+    }
+    if (n == 0)
+    {
+        sum->termination = OCHIP_RELAX_NO_PARAMETERS;
+        normalize();
+        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        return OCHIP_OK;
+    }
+    double h[8];
+    int hfail = 0;
+    auto evaluate = [&](bool with_jac, int which, double *cost) -> int {
+        OCHIP_HIP(ctx, hipMemsetAsync(D.fail, 0, 4, st));
+        hipEvent_t e0, e1;
+        ochip_prof_begin(ctx, OCHIP_K_RELAX_EVAL, &e0, &e1);
+        if (D.n_pairs)
+        {
+            if (with_jac)
+                hipLaunchKernelGGL(relax_pair_eval_kernel<true>, dim3(D.n_pairs), dim3(W), 0, st, D, which);
+            else
+                hipLaunchKernelGGL(relax_pair_eval_kernel<false>, dim3(D.n_pairs), dim3(W), 0, st, D, which);
+        }
+        ochip_prof_end(ctx, OCHIP_K_RELAX_EVAL, e0, e1);
+        if (with_jac)
+        {
+            OCHIP_HIP(ctx, hipMemsetAsync(p->A, 0, (size_t)n * n * 8, st));
+            OCHIP_HIP(ctx, hipMemsetAsync(p->g, 0, (size_t)n * 8, st));
+            hipLaunchKernelGGL(relax_scatter_cam_kernel, dim3((D.n_cams + 255) / 256), dim3(256), 0, st, D, p->A, p->g,
+                               n, p->cam_has_prior);
+            if (D.n_pairs)
+                hipLaunchKernelGGL(relax_scatter_pair_kernel, dim3((D.n_pairs + 255) / 256), dim3(256), 0, st, D, p->A, n);
+        }
+        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(1), dim3(256), 0, st, D, p->A, p->g, n, p->cam_has_prior,
+                           p->scal, with_jac ? 1 : 0, which);
+        OCHIP_HIP(ctx, hipGetLastError());
+        OCHIP_HIP(ctx, hipMemcpyAsync(h, p->scal, 8, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(&hfail, D.fail, 4, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        *cost = h[0];
+        return hfail ? 1 : 0;
+    };
+    auto grad_and_diag = [&](double *gmax) -> int {
+        hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(1024), 0, st, p->A, p->g, p->diag_tmp, n, p->scal);
+        OCHIP_HIP(ctx, hipMemcpyAsync(h, p->scal, 64, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        *gmax = h[4];
+        return OCHIP_OK;
+    };
+
+    std::vector<double> diag(n), scale(n, 1.0), lmd(n), diagonal(n, 0.0);
+    double x_cost = 0, gmax = 0;
+    if (evaluate(true, 0, &x_cost) != 0)
+    {
+        sum->termination = OCHIP_RELAX_FAILURE;
+        normalize();
+        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        return OCHIP_OK;
+    }
+    int rc = grad_and_diag(&gmax);
+    if (rc)
+        return rc;
+    OCHIP_HIP(ctx, hipMemcpy(diag.data(), p->diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++)
+        scale[i] = 1.0 / (1.0 + std::sqrt(diag[i])); // jacobi scaling, fixed from the first Jacobian
+    OCHIP_HIP(ctx, hipMemcpy(p->scale, scale.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    // x_norm over the variable blocks
+    double x_norm = 0;
+    {
+        std::vector<double> q((size_t)p->n_cams * 4);
+        double z[3];
+        OCHIP_HIP(ctx, hipMemcpy(q.data(), D.cam_q, q.size() * 8, hipMemcpyDeviceToHost));
+        OCHIP_HIP(ctx, hipMemcpy(z, D.plane + 6, 24, hipMemcpyDeviceToHost));
+        for (uint32_t c = 0; c < p->n_cams; c++)
+            if (p->cam_t[c] >= 0)
+                for (int k = 0; k < 4; k++)
+                    x_norm += q[c * 4 + k] * q[c * 4 + k];
+        for (int i = 0; i < 3; i++)
+            if (p->z_t[i] >= 0)
+                x_norm += z[i] * z[i];
+        x_norm = std::sqrt(x_norm);
+    }
+    sum->initial_cost = x_cost;
+    sum->iterations = 1; // iteration 0
+    double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
+    bool reuse_diagonal = false;
+    int invalid = 0, iter = 0;
+    auto finish = [&](int term) {
+        sum->termination = term;
+        sum->final_cost = x_cost;
+        normalize();
+        (void)hipStreamSynchronize(st);
+        return OCHIP_OK;
+    };
+    if (gmax <= opt->gradient_tolerance)
+        return finish(OCHIP_RELAX_CONVERGENCE_GRADIENT);
+
+    while (true)
+    {
+        if (iter >= opt->max_num_iterations)
+            return finish(OCHIP_RELAX_NO_CONVERGENCE);
+        if (radius <= 1e-32)
+            return finish(OCHIP_RELAX_CONVERGENCE_RADIUS);
+        iter++;
+        sum->iterations++;
+        if (!reuse_diagonal)
+            for (int i = 0; i < n; i++)
+                diagonal[i] = std::min(std::max(diag[i] * scale[i] * scale[i], 1e-6), 1e32);
+        for (int i = 0; i < n; i++)
+        {
+            const double dd = std::sqrt(diagonal[i] / radius);
+            lmd[i] = dd * dd;
+        }
+        OCHIP_HIP(ctx, hipMemcpyAsync(p->lm_diag, lmd.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+        hipEvent_t e0, e1;
+        ochip_prof_begin(ctx, OCHIP_K_RELAX_SOLVE, &e0, &e1);
+        const size_t nn = (size_t)n * n;
+        hipLaunchKernelGGL(lm_build_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, p->A, p->g, p->scale,
+                           p->lm_diag, p->Wm, p->gs, n);
+        OCHIP_HIP(ctx, hipMemsetAsync(p->fail_chol, 0, 4, st));
+        for (int k0 = 0; k0 < n; k0 += NB)
+        {
+            const int nb = std::min(NB, n - k0);
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, p->Wm, n, k0, nb, p->fail_chol);
+            const int rows = n - k0 - nb;
+            if (rows > 0)
+            {
+                hipLaunchKernelGGL(chol_panel_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, p->Wm, n, k0, nb);
+                const int tiles = (rows + 63) / 64;
+                hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, p->Wm, n, k0, nb);
+            }
+        }
+        OCHIP_HIP(ctx, hipMemcpyAsync(p->y, p->gs, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(1024), 0, st, p->Wm, p->y, n);
+        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(1024), 0, st, D, p->A, p->gs, p->scale, p->y, n, p->scal);
+        ochip_prof_end(ctx, OCHIP_K_RELAX_SOLVE, e0, e1);
+        OCHIP_HIP(ctx, hipGetLastError());
+        int cfail = 0;
+        OCHIP_HIP(ctx, hipMemcpyAsync(h, p->scal, 64, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(&cfail, p->fail_chol, 4, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        reuse_diagonal = true;
+        const double model_cost_change = h[1], step_norm = std::sqrt(h[2]), cand_norm = std::sqrt(h[3]);
+        const bool valid = !cfail && std::isfinite(model_cost_change) && model_cost_change > 0.0;
+        static const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+        if (verbose)
+            fprintf(stderr, "[ochip relax] n=%d iter=%d cost=%.17g radius=%.6g model=%.17g step_norm=%.6g cfail=%d gmax=%.6g\n",
+                    n, iter, x_cost, radius, model_cost_change, step_norm, cfail, gmax);
+        if (!valid)
+        {
+            if (++invalid >= 5)
+                return finish(OCHIP_RELAX_FAILURE);
+            radius *= 0.5;
+            continue;
+        }
+        invalid = 0;
+        double cand_cost = 1.7976931348623157e308;
+        {
+            double c;
+            if (evaluate(false, 1, &c) == 0)
+                cand_cost = c;
+        }
+        if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance))
+            return finish(OCHIP_RELAX_CONVERGENCE_PARAMETER);
+        const double cost_change = x_cost - cand_cost;
+        if (std::abs(cost_change) <= opt->function_tolerance * x_cost)
+            return finish(OCHIP_RELAX_CONVERGENCE_FUNCTION);
+        const double rho = cost_change / model_cost_change;
+        if (rho > 1e-3)
+        {
+            hipLaunchKernelGGL(lm_accept_kernel, dim3((p->n_cams * 4 + 255) / 256 + 1), dim3(256), 0, st, D);
+            x_norm = cand_norm;
+            if (evaluate(true, 0, &x_cost) != 0)
+                return finish(OCHIP_RELAX_FAILURE);
+            rc = grad_and_diag(&gmax);
+            if (rc)
+                return rc;
+            OCHIP_HIP(ctx, hipMemcpy(diag.data(), p->diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost));
+            const double t = 2.0 * rho - 1.0;
+            radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+            radius = std::min(1e16, radius);
+            decrease_factor = 2.0;
+            reuse_diagonal = false;
+            sum->successful_steps++;
+            if (gmax <= opt->gradient_tolerance)
+                return finish(OCHIP_RELAX_CONVERGENCE_GRADIENT);
+        }
+        else
+        {
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+            sum->unsuccessful_steps++;
+        }
+    }
+}
+
+} // extern "C"

@@ -48,8 +48,42 @@ def load():
         L.och_link_debug_matches.argtypes = [vp, sz, _u64p, _u64p, _f64p, np.ctypeslib.ndpointer(np.uint8)]
         L.och_graph_edge_info.argtypes = [vp, sz, _u64p, _u64p, _f64p, _f64p]
         L.och_graph_edge_inliers.argtypes = [vp, sz, _u64p, _u64p, _u64p, _f64p]
+        u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+        L.och_relax_ground_plane.argtypes = [vp, sz, _f64p, _f64p, _f64p, sz, _u64p, _f64p, sz, _u64p, _u64p, _f64p, u8p,
+                                             _u64p, _f64p, _u64p, vp, vp, sz, _u64p, _f64p, _f64p]
+        L.och_relax_last_error.restype = C.c_char_p
+        L.och_graph_relax_ground_plane.argtypes = [vp, vp, _f64p, _f64p, _f64p]
         _lib = L
     return _lib
+
+
+RELAX_SUMMARY_NAMES = ["solves", "iterations_total", "last_iterations", "initial_cost", "final_cost", "residual_blocks",
+                       "setup_host_s", "device_s"]
+
+
+def relax_ground_plane(ctx, node_pos, node_ori, model10, pose_node, pose_ori, packed_edges, opt_edges=None):
+    """relax(graph, nodes, cam_models, edges, {ORIENTATION, GROUND_PLANE}, {}) on the device.  `packed_edges` is
+    the dict of flat arrays (src, dst, H, is_h, inl_off, px, match_index, dist_off, dist)."""
+    L = load()
+    node_pos = np.ascontiguousarray(node_pos, np.float64)
+    node_ori = np.ascontiguousarray(node_ori, np.float64)
+    pose_node = np.ascontiguousarray(pose_node, np.uint64)
+    pose_ori = np.ascontiguousarray(pose_ori, np.float64).copy()
+    pk = packed_edges
+    n_edges = len(pk["src"])
+    opt = np.ascontiguousarray(np.arange(n_edges) if opt_edges is None else opt_edges, np.uint64)
+    plane, summary = np.zeros(9), np.zeros(8)
+    rc = L.och_relax_ground_plane(ctx.h, len(node_pos), node_pos, node_ori, np.ascontiguousarray(model10, np.float64),
+                                  len(pose_node), pose_node, pose_ori, n_edges, pk["src"], pk["dst"], pk["H"], pk["is_h"],
+                                  pk["inl_off"], pk["px"], pk["match_index"], pk["dist_off"].ctypes.data,
+                                  pk["dist"].ctypes.data, len(opt), opt, plane, summary)
+    if rc != 0:
+        raise capi.OchipError("relax failed: " + L.och_relax_last_error().decode())
+    out = dict(zip(RELAX_SUMMARY_NAMES, summary.tolist()))
+    out.update(orientation=pose_ori, plane=plane.reshape(3, 3))
+    for k in ("solves", "iterations_total", "last_iterations", "residual_blocks"):
+        out[k] = int(out[k])
+    return out
 
 
 LINK_TIMER_NAMES = ["link_init", "subsample", "upload", "match_device", "match_host", "ransac_device",
@@ -107,6 +141,17 @@ class Graph:
         if rc != 0:
             raise capi.OchipError("link stage failed: " + self.L.och_last_error(self.h).decode())
         return dict(zip(LINK_TIMER_NAMES, timers.tolist()))
+
+    def relax_ground_plane(self, ctx, orientations):
+        """All nodes as one relax group, every edge whitelisted; updates and returns the orientations."""
+        ori = np.ascontiguousarray(orientations, np.float64).copy()
+        plane, summary = np.zeros(9), np.zeros(8)
+        rc = self.L.och_graph_relax_ground_plane(self.h, ctx.h, ori, plane, summary)
+        if rc != 0:
+            raise capi.OchipError("relax failed: " + self.L.och_last_error(self.h).decode())
+        out = dict(zip(RELAX_SUMMARY_NAMES, summary.tolist()))
+        out.update(orientation=ori, plane=plane.reshape(3, 3))
+        return out
 
     def link_debug(self):
         out = []

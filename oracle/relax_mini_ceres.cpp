@@ -2,6 +2,8 @@
 #include "mini_ceres.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 
 namespace oracle
@@ -488,6 +490,10 @@ void Solve(const SolverOptions &opt, Problem *problem, SolverSummary *summary)
             model_cost_change = -(sg_dot + quad / 2.0);
         }
         is.step_is_valid = solved && model_cost_change > 0.0;
+        static const bool verbose = getenv("OC_RELAX_VERBOSE") != nullptr;
+        if (verbose)
+            fprintf(stderr, "[oracle relax] n=%d iter=%d cost=%.17g radius=%.6g model=%.17g solved=%d gmax=%.6g\n", n,
+                    is.iteration, x_cost, radius, model_cost_change, (int)solved, summary->iterations.back().gradient_max_norm);
         if (!is.step_is_valid)
         {
             // HandleInvalidStep

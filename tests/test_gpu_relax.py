@@ -1,0 +1,86 @@
+"""GPU parity of the relax step (ground-plane flavour) against the oracle, through liboc_host.so
+(relax_ground_plane -> ochip_relax_*).  Floating point: tolerance 1e-6 rad on poses as BASELINE.json
+states ("relax-stage pose deltas within 1e-6 of reference"); in practice the two LM trajectories agree
+to ~1e-10 and use the same number of iterations."""
+import numpy as np
+import pytest
+
+from opencalibration_amd import capi, host
+from relax_fixtures import (MODEL_600, add_ori_noise, axis_angle, camera_grid, planar_points, qangle, qmul, ring_edges,
+                            three_cameras)
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _both(ctx, oracle, pos, ori, model, pose_node, start, edges):
+    exp = oracle.relax_ground_plane(pos, ori, model, pose_node, start, edges)
+    got = host.relax_ground_plane(ctx, pos, ori, model, pose_node, start, oracle.pack_edges(edges))
+    return exp, got
+
+
+def _assert_same(exp, got):
+    n = len(exp["orientation"])
+    worst = max(qangle(exp["orientation"][i], got["orientation"][i]) for i in range(n))
+    assert worst < POSE_TOL, worst
+    assert np.allclose(exp["plane"], got["plane"], rtol=0, atol=1e-5)
+    assert got["residual_blocks"] == exp["residual_blocks"]
+    assert got["solves"] == exp["solves"]
+    assert abs(got["iterations_total"] - exp["iterations_total"]) <= 2
+    assert got["final_cost"] == pytest.approx(exp["final_cost"], rel=1e-6, abs=1e-14)
+
+
+def test_measurement_3_images_plane(ctx, oracle):  # test/test_relax.cpp:416-434 on the device
+    ori, pos = three_cameras()
+    edges = ring_edges(ori, pos, planar_points())
+    noisy = add_ori_noise(ori, [-0.1, 0.1, 0.1])
+    exp, got = _both(ctx, oracle, pos, ori, MODEL_600, [0, 1, 2], noisy, edges)
+    _assert_same(exp, got)
+    exp2, got2 = _both(ctx, oracle, pos, ori, MODEL_600, [0, 1, 2], got["orientation"], edges)
+    _assert_same(exp2, got2)
+    for i in range(3):
+        assert qangle(got2["orientation"][i], ori[i]) < 1e-3
+
+
+def test_context_cameras_stay_constant(ctx, oracle):
+    """Only camera 1 is optimised; 0 and 2 come from the graph as constant context (nodeid2poseopt)."""
+    ori, pos = three_cameras()
+    edges = ring_edges(ori, pos, planar_points())
+    start = qmul(ori[1], axis_angle([0, 0, 1], 0.1))[None, :]
+    exp, got = _both(ctx, oracle, pos, ori, MODEL_600, [1], start, edges)
+    _assert_same(exp, got)
+    assert qangle(got["orientation"][0], ori[1]) < 1e-3
+
+
+def test_nan_bootstrap(ctx, oracle):
+    ori, pos, edges, model = camera_grid(2, 3, seed=4)
+    start = np.full_like(ori, np.nan)
+    exp, got = _both(ctx, oracle, pos, ori, model, np.arange(6), start, edges)
+    _assert_same(exp, got)
+
+
+@pytest.mark.parametrize("rows,cols", [(3, 4), (6, 8)])
+def test_grid_parity(ctx, oracle, rows, cols):
+    ori, pos, edges, model = camera_grid(rows, cols, seed=7)
+    rng = np.random.default_rng(0)
+    noisy = np.array([qmul(q, axis_angle(rng.normal(size=3) / 1.7, 0.1)) for q in ori])
+    exp, got = _both(ctx, oracle, pos, ori, model, np.arange(len(ori)), noisy, edges)
+    _assert_same(exp, got)
+    assert max(qangle(got["orientation"][i], ori[i]) for i in range(len(ori))) < 1e-6
+
+
+def test_large_system_uses_blocked_cholesky(ctx, oracle):
+    """> 64 tangent dimensions per panel: 10 x 12 cameras = 363 unknowns exercises the multi-panel
+    Cholesky and the blocked triangular solves; checked against the oracle's dense solve."""
+    ori, pos, edges, model = camera_grid(10, 12, seed=11, pts_per_side=30)
+    rng = np.random.default_rng(1)
+    noisy = np.array([qmul(q, axis_angle(rng.normal(size=3) / 1.7, 0.05)) for q in ori])
+    exp, got = _both(ctx, oracle, pos, ori, model, np.arange(len(ori)), noisy, edges)
+    _assert_same(exp, got)
