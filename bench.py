@@ -64,13 +64,30 @@ def main():
     grid = synth.make_grid(seed=12345 + rank, **cfg)
     ctx = capi.Context(local_rank)
 
+    # relax start: true orientation with a 0.1 rad error about a random axis (test/test_relax.cpp:421)
+    rng = np.random.default_rng(99 + rank)
+    axes = rng.normal(size=(grid.n_images, 3))
+    axes /= np.linalg.norm(axes, axis=1, keepdims=True)
+    dq = np.concatenate([axes * np.sin(0.05), np.full((grid.n_images, 1), np.cos(0.05))], axis=1)
+    start_ori = synth.quat_mul(grid.orientation, dq)
+
     def one_step(keep=False):
         g = host.Graph.from_synthetic(grid)          # host-side graph build: not part of the hot path
+        g.set_orientations(start_ori)
         t0 = time.perf_counter()
         timers = g.link(ctx)
+        t1 = time.perf_counter()
+        rel = g.relax_ground_plane(ctx, start_ori)   # every camera in ONE group: the global relax of pipeline.cpp:653-655
         ctx.synchronize()
-        dt = time.perf_counter() - t0
+        t2 = time.perf_counter()
+        timers = dict(timers)
+        timers["relax_total"] = t2 - t1
+        timers["relax_setup_host"] = rel["setup_host_s"]
+        timers["relax_device"] = rel["device_s"]
+        timers["relax_lm_iterations"] = rel["iterations_total"]
+        dt = t2 - t0
         edges = g.num_edges
+        one_step.last_relax = rel
         if not keep:
             g.close()
         return dt, timers, edges, g
@@ -99,6 +116,13 @@ def main():
     # ---- roofline of the dominant kernel (Hamming 2-NN), HIP events on the library's compute stream
     n_launch, ms_match = ctx.profile_get(capi.K_MATCH)
     n_ransac, ms_ransac = ctx.profile_get(capi.K_RANSAC)
+    n_eval, ms_eval = ctx.profile_get(capi.K_RELAX_EVAL)
+    n_solve, ms_solve = ctx.profile_get(capi.K_RELAX_SOLVE)
+    rel = one_step.last_relax
+    err = rel["orientation"] - grid.orientation
+    # angle between relaxed and true orientation (sanity: the solve converged to the synthetic truth)
+    dots = np.abs(np.sum(rel["orientation"] * grid.orientation, axis=1))
+    relax_max_err = float(np.max(2 * np.arccos(np.clip(dots, 0, 1))))
     # algorithmic bytes per launch: every pair reads both descriptor sets once and writes 8 B per query
     sub = [host.subsample(*grid.image(i)[:2], 40.0, int(grid.num_sparse[i])) for i in range(grid.n_images)]
     nsub = np.array([len(s) for s in sub], np.int64)
@@ -120,7 +144,14 @@ def main():
                  "measured_issue_bound_compares_per_s": 1.15e12,
                  "frac": round(compares / (avg_ms * 1e-3) / 1.15e12, 4) if avg_ms > 0 else 0.0},
         "ransac_avg_launch_ms": round(ms_ransac / max(n_ransac, 1), 4),
+        "relax_eval_avg_launch_ms": round(ms_eval / max(n_eval, 1), 4), "relax_eval_launches": int(n_eval),
+        "relax_linear_solve_avg_ms": round(ms_solve / max(n_solve, 1), 4), "relax_linear_solves": int(n_solve),
     }
+    lm_iters = float((timers_acc or {}).get("relax_lm_iterations", 0.0))
+    lm = {"lm_iterations_per_step": lm_iters / max(args.steps, 1),
+          "lm_iters_per_s": round(lm_iters / max((timers_acc or {}).get("relax_device", 1e-9), 1e-9), 2),
+          "unknowns": int(3 * grid.n_images + 3), "residual_blocks": int(rel["residual_blocks"]),
+          "max_orientation_error_rad_vs_truth": relax_max_err}
 
     # ---- CPU baseline: the oracle restatement with the reference's scheduling, bounded sample
     cpu = None
@@ -145,7 +176,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "images/sec end-to-end on synthetic aerial grid (link stages: subsample+match+RANSAC+decompose)",
+            "metric": "images/sec end-to-end on synthetic aerial grid (match+RANSAC+relax; extract not yet on path); LM iters/sec",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(hot_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 popcount (match) + f64 (RANSAC)", "data": "synthetic",
@@ -154,12 +185,15 @@ def main():
                                    f"matcher, {len(pairs)} directed kNN(10) pairs, {edges} edges",
                        "stages_timed": ["LinkStage.init (kNN)", "40px subsample (host)", "descriptor upload (PCIe)",
                                         "Hamming 2-NN (device)", "ratio+std::sort+PROSAC order (host)",
-                                        "homography RANSAC (device)", "decompose+assemble (host)", "finalize"],
-                       "stages_not_yet_on_path": ["extract (AKAZE)", "relax (LM)"],
+                                        "homography RANSAC (device)", "decompose+assemble (host)", "finalize",
+                                        "relax: ground-plane problem assembly (host)",
+                                        "relax: LM with dense Cholesky, all cameras in one group (device)"],
+                       "stages_not_yet_on_path": ["extract (AKAZE)"],
                        "host_threads_per_rank": int(os.environ["OMP_NUM_THREADS"]),
                        "per_rank": "one grid of this shape per GPU, no data-path collective"},
             "stage_seconds_per_step": {k: round(v / args.steps, 5) for k, v in (timers_acc or {}).items()},
             "wall_s_including_graph_build": round(wall, 3),
+            "relax": lm,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -51,6 +51,8 @@ extern "C"
     void och_graph_edge_info(const och_graph *g, size_t e, uint64_t *ids2, uint64_t *counts2, double *H, double *poses);
     void och_graph_edge_inliers(const och_graph *g, size_t e, uint64_t *f1, uint64_t *f2, uint64_t *match_index,
                                 double *px4);
+    void och_graph_edge_match_distances(const och_graph *g, size_t e, double *out); /* relations.matches[i].distance */
+    void och_graph_set_orientations(och_graph *g, const double *ori /* n_nodes x 4, node order */);
 
     /* ---- relax (opencalibration_amd/csrc/host/relax.hpp): relax(graph, nodes, cam_models, edges,
      *      {ORIENTATION, GROUND_PLANE}, {}) of src/relax/relax.cpp:122-134 ------------------------------ */

@@ -93,6 +93,16 @@ extern "C"
      * (DifferentiableCameraModel, include/opencalibration/types/camera_model.hpp:22-60). */
     int ochip_upload_keypoints(ochip_ctx *ctx, uint32_t image_id, const double *xy, uint32_t n, const double *model8);
 
+    /* One-call flavour of reserve + upload_descriptors + upload_keypoints for a whole batch: image i owns
+     * counts[i] consecutive rows of desc_all (x 8 u64) and xy_all (x 2 f64); models8 is n_images x 8. */
+    int ochip_upload_batch(ochip_ctx *ctx, uint32_t n_images, const uint32_t *counts, const uint64_t *desc_all,
+                           const double *xy_all, const double *models8);
+
+    /* Page-locked host memory for the large transfers (match results, RANSAC inputs): PCIe copies from
+     * pageable memory run at a fraction of the link rate. */
+    int ochip_host_alloc(ochip_ctx *ctx, size_t bytes, void **out);
+    void ochip_host_free(ochip_ctx *ctx, void *p);
+
     /* ---- homography RANSAC, one job per directed pair (replaces ransac<homography_model>,
      *      src/model_inliers/ransac.cpp:53-257 + homography_model.cpp:19-136) -------------------------- */
     typedef struct ochip_ransac_match

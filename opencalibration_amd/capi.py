@@ -20,6 +20,7 @@ EXPORTS = [
     "ochip_descriptors_reserve", "ochip_upload_descriptors", "ochip_descriptor_count",
     "ochip_match_batch", "ochip_match_launch", "ochip_match_fetch",
     "ochip_upload_keypoints", "ochip_ransac_homography_batch",
+    "ochip_upload_batch", "ochip_host_alloc", "ochip_host_free",
     "ochip_relax_problem_create", "ochip_relax_problem_destroy", "ochip_relax_set_cameras_constant",
     "ochip_relax_solve", "ochip_relax_get_state",
     "ochip_profile_reset", "ochip_profile_get",

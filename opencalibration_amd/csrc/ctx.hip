@@ -142,6 +142,10 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
     for (void *b : ctx->scratch_dev)
         if (b)
             (void)hipFree(b);
+    for (auto &b : ctx->pinned_pool)
+        (void)hipHostFree(b.first);
+    for (auto &b : ctx->pinned_live)
+        (void)hipHostFree(b.first);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream)
@@ -233,6 +237,107 @@ int ochip_upload_descriptors(ochip_ctx *ctx, uint32_t image_id, const uint64_t *
     // pageable source: hipMemcpyAsync has consumed it when it returns only after a sync
     OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return OCHIP_OK;
+}
+
+int ochip_upload_batch(ochip_ctx *ctx, uint32_t n_images, const uint32_t *counts, const uint64_t *desc_all,
+                       const double *xy_all, const double *models8)
+{
+    if (!ctx || (n_images && (!counts || !models8)))
+        return OCHIP_EINVAL;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_images; i++)
+        total += counts[i];
+    if (total && (!desc_all || !xy_all))
+        return ochip_fail(ctx, OCHIP_EINVAL, "NULL descriptor / keypoint array");
+    for (uint32_t i = 0; i < n_images; i++)
+        for (int k = 3; k < 8; k++)
+            if (models8[(size_t)i * 8 + k] != 0)
+                return ochip_fail(ctx, OCHIP_EINVAL,
+                                  "lens distortion is not supported by the device ray kernel yet (image %u)", i);
+    int rc = ochip_descriptors_reserve(ctx, n_images, total);
+    if (rc)
+        return rc;
+    const size_t cap = total ? total : 1;
+    if (hipMalloc((void **)&ctx->kp_xy_dev, cap * 16) != hipSuccess ||
+        hipMalloc((void **)&ctx->rays_dev, cap * 24) != hipSuccess ||
+        hipMalloc((void **)&ctx->kp_image_dev, cap * 4) != hipSuccess ||
+        hipMalloc((void **)&ctx->models_dev, (size_t)(n_images ? n_images : 1) * 64) != hipSuccess)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc for the keypoint store failed");
+    std::vector<uint32_t> ids(cap);
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n_images; i++)
+    {
+        ctx->img_off[i] = off;
+        ctx->img_n[i] = counts[i];
+        ctx->img_set[i] = 1;
+        for (uint32_t k = 0; k < counts[i]; k++)
+            ids[off + k] = i;
+        off += counts[i];
+    }
+    ctx->desc_used = total;
+    ctx->kp_set.assign(n_images, 1);
+    if (total)
+    {
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->desc_dev, desc_all, (size_t)total * 64, hipMemcpyHostToDevice, ctx->stream));
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->kp_xy_dev, xy_all, (size_t)total * 16, hipMemcpyHostToDevice, ctx->stream));
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->kp_image_dev, ids.data(), (size_t)total * 4, hipMemcpyHostToDevice,
+                                      ctx->stream));
+    }
+    if (n_images)
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->models_dev, models8, (size_t)n_images * 64, hipMemcpyHostToDevice,
+                                      ctx->stream));
+    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->img_tables_dirty = true;
+    ctx->rays_dirty = true;
+    return OCHIP_OK;
+}
+
+int ochip_host_alloc(ochip_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out)
+        return OCHIP_EINVAL;
+    *out = nullptr;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    // page-locking is expensive (tens of ms for hundreds of MB): recycle blocks between batches
+    int best = -1;
+    for (size_t i = 0; i < ctx->pinned_pool.size(); i++)
+        if (ctx->pinned_pool[i].second >= bytes && (best < 0 || ctx->pinned_pool[i].second < ctx->pinned_pool[best].second))
+            best = (int)i;
+    if (best >= 0 && ctx->pinned_pool[best].second <= 2 * bytes + (1 << 20))
+    {
+        *out = ctx->pinned_pool[best].first;
+        ctx->pinned_live.emplace_back(ctx->pinned_pool[best]);
+        ctx->pinned_pool.erase(ctx->pinned_pool.begin() + best);
+        return OCHIP_OK;
+    }
+    const size_t want = bytes ? bytes + bytes / 8 : 1;
+    if (hipHostMalloc(out, want, hipHostMallocDefault) != hipSuccess)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "hipHostMalloc(%zu) failed", want);
+    ctx->pinned_live.emplace_back(*out, want);
+    return OCHIP_OK;
+}
+
+void ochip_host_free(ochip_ctx *ctx, void *p)
+{
+    if (!ctx || !p)
+        return;
+    for (size_t i = 0; i < ctx->pinned_live.size(); i++)
+        if (ctx->pinned_live[i].first == p)
+        {
+            ctx->pinned_pool.push_back(ctx->pinned_live[i]);
+            ctx->pinned_live.erase(ctx->pinned_live.begin() + i);
+            // keep the pool bounded: drop the smallest blocks beyond 16 entries
+            while (ctx->pinned_pool.size() > 16)
+            {
+                size_t s = 0;
+                for (size_t k = 1; k < ctx->pinned_pool.size(); k++)
+                    if (ctx->pinned_pool[k].second < ctx->pinned_pool[s].second)
+                        s = k;
+                (void)hipHostFree(ctx->pinned_pool[s].first);
+                ctx->pinned_pool.erase(ctx->pinned_pool.begin() + s);
+            }
+            return;
+        }
 }
 
 int ochip_descriptor_count(const ochip_ctx *ctx, uint32_t image_id, uint32_t *n)

@@ -57,6 +57,9 @@ struct ochip_ctx
     void *scratch_dev[8] = {nullptr};
     size_t scratch_cap[8] = {0};
 
+    // page-locked host blocks handed out by ochip_host_alloc (live) and recycled ones (pool)
+    std::vector<std::pair<void *, size_t>> pinned_live, pinned_pool;
+
     ochip_profile_slot prof[OCHIP_K_COUNT];
 };
 

@@ -197,6 +197,20 @@ void och_graph_edge_info(const och_graph *g, size_t e, uint64_t *ids2, uint64_t 
     }
 }
 
+void och_graph_edge_match_distances(const och_graph *g, size_t e, double *out)
+{
+    const auto &ed = g->graph.edges().at(e);
+    for (size_t i = 0; i < ed.payload.matches.size(); i++)
+        out[i] = ed.payload.matches[i].distance;
+}
+
+void och_graph_set_orientations(och_graph *g, const double *ori)
+{
+    auto &nodes = g->graph.nodes();
+    for (size_t i = 0; i < nodes.size(); i++)
+        std::memcpy(nodes[i].payload.orientation, ori + 4 * i, 32);
+}
+
 void och_graph_edge_inliers(const och_graph *g, size_t e, uint64_t *f1, uint64_t *f2, uint64_t *match_index, double *px4)
 {
     const auto &ed = g->graph.edges().at(e);

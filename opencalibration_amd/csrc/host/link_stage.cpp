@@ -11,6 +11,24 @@ namespace opencalibration_amd
 
 namespace
 {
+// page-locked host buffer from the device library (freed on scope exit)
+template <typename T> struct pinned
+{
+    ochip_ctx *ctx;
+    T *ptr = nullptr;
+    pinned(ochip_ctx *c, size_t n) : ctx(c)
+    {
+        void *p = nullptr;
+        if (ochip_host_alloc(c, n * sizeof(T), &p) == OCHIP_OK)
+            ptr = (T *)p;
+    }
+    ~pinned()
+    {
+        ochip_host_free(ctx, ptr);
+    }
+    pinned(const pinned &) = delete;
+    pinned &operator=(const pinned &) = delete;
+};
 using clk = std::chrono::steady_clock;
 double since(clk::time_point t0)
 {
@@ -110,38 +128,43 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
     }
     timers.subsample += since(t0);
 
-    // ---- upload descriptors + keypoints
+    // ---- upload descriptors + keypoints (one packed batch, packed in parallel)
     t0 = clk::now();
-    uint64_t total_desc = 0;
-    for (const auto &s : subset)
-        total_desc += s.size();
-    if (ochip_descriptors_reserve(_ctx, (uint32_t)n_slots, total_desc) != OCHIP_OK)
-        return fail("ochip_descriptors_reserve");
+    std::vector<uint32_t> counts(n_slots);
+    std::vector<uint64_t> slot_off(n_slots + 1, 0);
+    for (size_t s = 0; s < n_slots; s++)
     {
-        std::vector<uint64_t> dbuf;
-        std::vector<double> xybuf;
+        counts[s] = (uint32_t)subset[s].size();
+        slot_off[s + 1] = slot_off[s] + counts[s];
+    }
+    const uint64_t total_desc = slot_off[n_slots];
+    {
+        pinned<uint64_t> dbuf(_ctx, total_desc * 8);
+        pinned<double> xybuf(_ctx, total_desc * 2);
+        std::vector<double> models((size_t)n_slots * 8);
+        if (!dbuf.ptr || !xybuf.ptr)
+            return fail("ochip_host_alloc");
+#pragma omp parallel for schedule(dynamic, 1)
         for (size_t s = 0; s < n_slots; s++)
         {
             const image &img = graph.getNode(slot_node[s])->payload;
-            const size_t n = subset[s].size();
-            dbuf.resize(n * 8);
-            xybuf.resize(n * 2);
-            for (size_t k = 0; k < n; k++)
+            uint64_t *d = dbuf.ptr + slot_off[s] * 8;
+            double *xy = xybuf.ptr + slot_off[s] * 2;
+            for (size_t k = 0; k < subset[s].size(); k++)
             {
                 const feature_2d &f = img.features[subset[s][k]];
-                std::memcpy(&dbuf[8 * k], f.descriptor, 64);
-                xybuf[2 * k] = f.location[0];
-                xybuf[2 * k + 1] = f.location[1];
+                std::memcpy(d + 8 * k, f.descriptor, 64);
+                xy[2 * k] = f.location[0];
+                xy[2 * k + 1] = f.location[1];
             }
             const CameraModel &m = *img.model;
-            const double model8[8] = {m.focal_length_pixels,   m.principle_point[0],    m.principle_point[1],
-                                      m.radial_distortion[0],  m.radial_distortion[1],  m.radial_distortion[2],
+            const double model8[8] = {m.focal_length_pixels,      m.principle_point[0],      m.principle_point[1],
+                                      m.radial_distortion[0],     m.radial_distortion[1],    m.radial_distortion[2],
                                       m.tangential_distortion[0], m.tangential_distortion[1]};
-            if (ochip_upload_descriptors(_ctx, (uint32_t)s, dbuf.data(), (uint32_t)n) != OCHIP_OK)
-                return fail("ochip_upload_descriptors");
-            if (ochip_upload_keypoints(_ctx, (uint32_t)s, xybuf.data(), (uint32_t)n, model8) != OCHIP_OK)
-                return fail("ochip_upload_keypoints");
+            std::memcpy(&models[s * 8], model8, sizeof model8);
         }
+        if (ochip_upload_batch(_ctx, (uint32_t)n_slots, counts.data(), dbuf.ptr, xybuf.ptr, models.data()) != OCHIP_OK)
+            return fail("ochip_upload_batch");
     }
     timers.upload += since(t0);
 
@@ -156,10 +179,12 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
         out_off[p] = out_total;
         out_total += subset[jobs[p].slot_1].size();
     }
-    std::vector<ochip_match> raw(out_total ? out_total : 1);
+    pinned<ochip_match> raw(_ctx, out_total ? out_total : 1);
+    if (!raw.ptr)
+        return fail("ochip_host_alloc");
     if (ochip_match_launch(_ctx, pairs.data(), (uint32_t)n_pairs, out_off.data(), out_total) != OCHIP_OK)
         return fail("ochip_match_launch");
-    if (ochip_match_fetch(_ctx, raw.data(), out_total) != OCHIP_OK)
+    if (ochip_match_fetch(_ctx, raw.ptr, out_total) != OCHIP_OK)
         return fail("ochip_match_fetch");
     timers.match_device += since(t0);
 
@@ -178,7 +203,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
     for (size_t p = 0; p < n_pairs; p++)
     {
         const auto &idx1 = subset[jobs[p].slot_1], &idx2 = subset[jobs[p].slot_2];
-        const ochip_match *r = raw.data() + out_off[p];
+        const ochip_match *r = raw.ptr + out_off[p];
         // match_features_subset tail (match_features.cpp:94-101) with the subset positions carried along:
         // the permutation std::sort produces depends only on the comparison results, which are those
         // of the reference's comparator on the same sequence
@@ -227,24 +252,29 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
         rjobs[p] = ochip_ransac_job{jobs[p].slot_1, jobs[p].slot_2, (uint32_t)M, rng_state, total_matches, it->second};
         total_matches += M;
     }
-    std::vector<ochip_ransac_match> rm_flat(total_matches ? total_matches : 1);
-    std::vector<uint32_t> si_flat(total_matches ? total_matches : 1, 0);
+    pinned<ochip_ransac_match> rm_flat(_ctx, total_matches ? total_matches : 1);
+    pinned<uint32_t> si_flat(_ctx, total_matches ? total_matches : 1);
+    pinned<uint8_t> inl_flat(_ctx, total_matches ? total_matches : 1);
+    if (!rm_flat.ptr || !si_flat.ptr || !inl_flat.ptr)
+        return fail("ochip_host_alloc");
+#pragma omp parallel for schedule(dynamic, 8)
     for (size_t p = 0; p < n_pairs; p++)
     {
-        std::copy(rmatches[p].begin(), rmatches[p].end(), rm_flat.begin() + rjobs[p].match_offset);
+        std::copy(rmatches[p].begin(), rmatches[p].end(), rm_flat.ptr + rjobs[p].match_offset);
         if (!sorted_idx[p].empty())
-            std::copy(sorted_idx[p].begin(), sorted_idx[p].end(), si_flat.begin() + rjobs[p].match_offset);
+            std::copy(sorted_idx[p].begin(), sorted_idx[p].end(), si_flat.ptr + rjobs[p].match_offset);
+        else
+            std::fill(si_flat.ptr + rjobs[p].match_offset, si_flat.ptr + rjobs[p].match_offset + rjobs[p].n, 0u);
     }
     timers.match_host += since(t0);
 
     // ---- device: RANSAC
     t0 = clk::now();
     std::vector<ochip_ransac_result> results(n_pairs);
-    std::vector<uint8_t> inl_flat(total_matches ? total_matches : 1);
     const homography_model model_defaults;
-    if (ochip_ransac_homography_batch(_ctx, rjobs.data(), (uint32_t)n_pairs, rm_flat.data(), si_flat.data(),
-                                      total_matches, eval_table.data(), eval_table.size(),
-                                      model_defaults.inlier_threshold, results.data(), inl_flat.data()) != OCHIP_OK)
+    if (ochip_ransac_homography_batch(_ctx, rjobs.data(), (uint32_t)n_pairs, rm_flat.ptr, si_flat.ptr, total_matches,
+                                      eval_table.data(), eval_table.size(), model_defaults.inlier_threshold,
+                                      results.data(), inl_flat.ptr) != OCHIP_OK)
         return fail("ochip_ransac_homography_batch");
     timers.ransac_device += since(t0);
 
@@ -258,7 +288,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
         const image &img = graph.getNode(jobs[p].node_id)->payload;
         const image &near_image = graph.getNode(jobs[p].match_node_id)->payload;
         const size_t M = matches[p].size();
-        const uint8_t *inl = inl_flat.data() + rjobs[p].match_offset;
+        const uint8_t *inl = inl_flat.ptr + rjobs[p].match_offset;
         camera_relations relations;
         homography_model h;
         std::memcpy(h.homography, results[p].H, sizeof h.homography);

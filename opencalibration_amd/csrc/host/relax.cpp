@@ -158,13 +158,30 @@ class GroundPlaneProblem
                 keep[k] = grid_filter(*e, src[k], dst[k], 0.15);
         }
 
-        // addRayTriangleMeasurementCost (:388-560), fixed intrinsics
+        // addRayTriangleMeasurementCost (:388-560), fixed intrinsics.  The searcher's orientation fix-up of
+        // the single triangle happens on its first use and is the same for every edge, so do it once and
+        // build the per-edge block lists in parallel; they are concatenated in edge order.
+        fix_triangle_orientation();
+        std::vector<edge_blocks> per_edge(edges_to_optimize.size());
+#pragma omp parallel for schedule(dynamic, 8)
         for (size_t k = 0; k < edges_to_optimize.size(); k++)
         {
             const MeasurementGraph::Edge *e = _graph.getEdge(edges_to_optimize[k]);
             if (e == nullptr || src[k].loc == nullptr || dst[k].loc == nullptr)
                 continue;
-            add_edge_blocks(*e, src[k], dst[k], keep[k]);
+            add_edge_blocks(*e, src[k], dst[k], keep[k], per_edge[k]);
+        }
+        size_t total_blocks = 0;
+        for (const auto &pe : per_edge)
+            total_blocks += pe.a.size();
+        _blk_a.reserve(total_blocks);
+        _blk_b.reserve(total_blocks);
+        _blk_rays.reserve(total_blocks * 6);
+        for (const auto &pe : per_edge)
+        {
+            _blk_a.insert(_blk_a.end(), pe.a.begin(), pe.a.end());
+            _blk_b.insert(_blk_b.end(), pe.b.begin(), pe.b.end());
+            _blk_rays.insert(_blk_rays.end(), pe.rays.begin(), pe.rays.end());
         }
         // addDownwardsPrior (:1290-1301)
         for (size_t i = 0; i < poses.size(); i++)
@@ -386,13 +403,17 @@ class GroundPlaneProblem
 
     // MeshIntersectionSearcher::triangleIntersect (src/surface/intersect.cpp:56-163) on the single
     // border triangle: orientation fix-up (persistent), then the three edge tests.
-    bool vertical_ray_hits_plane_triangle(double px, double py)
+    static bool anticlockwise(const double *a, const double *b, const double *c)
     {
-        auto anticlockwise = [](const double *a, const double *b, const double *c) {
-            return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]) < 0;
-        };
+        return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]) < 0;
+    }
+    void fix_triangle_orientation()
+    {
         if (anticlockwise(_xy[_tri[0]], _xy[_tri[1]], _xy[_tri[2]]))
             std::swap(_tri[0], _tri[1]);
+    }
+    bool vertical_ray_hits_plane_triangle(double px, double py) const
+    {
         const double P[2] = {px, py};
         for (int i = 0; i < 3; i++)
             if (anticlockwise(P, _xy[_tri[i]], _xy[_tri[(i + 1) % 3]]))
@@ -400,8 +421,14 @@ class GroundPlaneProblem
         return true;
     }
 
+    struct edge_blocks
+    {
+        std::vector<uint32_t> a, b;
+        std::vector<double> rays;
+    };
+
     void add_edge_blocks(const MeasurementGraph::Edge &edge, const pose_ref &s, const pose_ref &d,
-                         const std::vector<uint8_t> &keep)
+                         const std::vector<uint8_t> &keep, edge_blocks &out) const
     {
         const camera_relations &rel = edge.payload;
         const CameraModel &sm = *_graph.getNode(edge.source)->payload.model, &dm = *_graph.getNode(edge.dest)->payload.model;
@@ -422,10 +449,10 @@ class GroundPlaneProblem
                 continue;
             if (!vertical_ray_hits_plane_triangle(mid.x, mid.y))
                 continue;
-            _blk_a.push_back(s.cam);
-            _blk_b.push_back(d.cam);
-            _blk_rays.insert(_blk_rays.end(), r1, r1 + 3);
-            _blk_rays.insert(_blk_rays.end(), r2, r2 + 3);
+            out.a.push_back(s.cam);
+            out.b.push_back(d.cam);
+            out.rays.insert(out.rays.end(), r1, r1 + 3);
+            out.rays.insert(out.rays.end(), r2, r2 + 3);
         }
     }
 

@@ -340,7 +340,7 @@ __device__ __forceinline__ void write_dlt_rows(double *A, uint32_t ld, uint32_t 
     }
 }
 
-__global__ __launch_bounds__(W) void ransac_homography_kernel(
+template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_kernel(
     const ochip_ransac_job *__restrict__ jobs, const ochip_ransac_match *__restrict__ matches,
     const uint32_t *__restrict__ sorted_idx_all, const uint32_t *__restrict__ eval_order_all, rays_view rv,
     double *__restrict__ coord_scratch /*4 x total*/, uint8_t *__restrict__ flag_scratch /*total*/,
@@ -744,12 +744,25 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
     uint8_t *inl_dev = (uint8_t *)ctx->scratch_dev[S_OUT] + (size_t)n_jobs * sizeof(ochip_ransac_result);
     hipEvent_t e0, e1;
     ochip_prof_begin(ctx, OCHIP_K_RANSAC, &e0, &e1);
-    hipLaunchKernelGGL(ransac_homography_kernel, dim3(n_jobs), dim3(W), 0, ctx->stream,
-                       (const ochip_ransac_job *)ctx->scratch_dev[S_JOBS],
-                       (const ochip_ransac_match *)ctx->scratch_dev[S_MATCH],
-                       (const uint32_t *)ctx->scratch_dev[S_SORTED], (const uint32_t *)ctx->scratch_dev[S_EVAL], rv,
-                       (double *)ctx->scratch_dev[S_COORD], (uint8_t *)ctx->scratch_dev[S_FLAGS],
-                       (double *)ctx->scratch_dev[S_P], (uint64_t)T, inlier_threshold, res_dev, inl_dev);
+    static const int occ = []() {
+        const char *e = getenv("OCHIP_RANSAC_OCC"); // waves per SIMD the register allocator targets (tuning knob)
+        const int v = e ? atoi(e) : 4;
+        return (v == 1 || v == 2 || v == 4) ? v : 4;
+    }();
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(n_jobs), dim3(W), 0, ctx->stream,
+                           (const ochip_ransac_job *)ctx->scratch_dev[S_JOBS],
+                           (const ochip_ransac_match *)ctx->scratch_dev[S_MATCH],
+                           (const uint32_t *)ctx->scratch_dev[S_SORTED], (const uint32_t *)ctx->scratch_dev[S_EVAL], rv,
+                           (double *)ctx->scratch_dev[S_COORD], (uint8_t *)ctx->scratch_dev[S_FLAGS],
+                           (double *)ctx->scratch_dev[S_P], (uint64_t)T, inlier_threshold, res_dev, inl_dev);
+    };
+    if (occ == 1)
+        launch(ransac_homography_kernel<1>);
+    else if (occ == 2)
+        launch(ransac_homography_kernel<2>);
+    else
+        launch(ransac_homography_kernel<4>);
     ochip_prof_end(ctx, OCHIP_K_RANSAC, e0, e1);
     OCHIP_HIP(ctx, hipGetLastError());
     OCHIP_HIP(ctx, hipMemcpyAsync(results, res_dev, (size_t)n_jobs * sizeof(ochip_ransac_result), hipMemcpyDeviceToHost,

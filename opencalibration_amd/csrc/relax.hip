@@ -472,6 +472,7 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, do
 
 // ---- dense linear algebra on the reduced system -------------------------------------------------
 constexpr int NB = 64;
+typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // Wm = S A S + diag(D), gs = S g; also column norms^2 of the scaled Jacobian = diag(S A S)
 __global__ void lm_build_kernel(const double *A, const double *g, const double *scale, const double *lm_diag,
@@ -485,86 +486,137 @@ __global__ void lm_build_kernel(const double *A, const double *g, const double *
     if (i == j)
     {
         v += lm_diag[i];
-        gs[i] = g[i] * scale[i];
+        const double gi = g[i] * scale[i];
+        gs[i] = gi;
+        Wm[(size_t)n * n + i] = gi; // augmented row n: the factorisation performs the forward solve L y = gs on it
     }
     Wm[idx] = v;
 }
 
-__global__ __launch_bounds__(256) void chol_diag_kernel(double *A, int n, int k0, int nb, int *fail)
+__global__ __launch_bounds__(256) void chol_diag_kernel(double *A, int n, int k0, int nb, int *fail,
+                                                        double *Linv /*[NB][NB] row-major, zero padded*/)
 {
     __shared__ double L[NB][NB + 1];
+    __shared__ double Y[NB][NB + 1];
     const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 256)
+    {
+        const int i = e / NB, j = e % NB;
+        L[i][j] = (i < nb && j < nb) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    // right-looking elimination with the pivots kept unscaled (one barrier per step); columns are scaled
+    // by 1/sqrt(pivot) afterwards, which yields the Cholesky factor
+    for (int j = 0; j < nb; j++)
+    {
+        const double piv = L[j][j];
+        const int m = nb - j - 1;
+        for (int e = t; e < m * m; e += 256)
+        {
+            const int i = j + 1 + e / m, c = j + 1 + e % m;
+            if (c <= i)
+                L[i][c] -= L[i][j] * L[c][j] / piv;
+        }
+        __syncthreads();
+    }
+    if (t < nb)
+    {
+        const double d = L[t][t];
+        if (!(d > 0.0))
+            *fail = 1;
+    }
+    __syncthreads();
     for (int e = t; e < nb * nb; e += 256)
     {
         const int i = e / nb, j = e % nb;
-        L[i][j] = A[(size_t)(k0 + i) * n + k0 + j];
+        if (j < i)
+            Y[i][j] = L[i][j] / sqrt(L[j][j]);
     }
     __syncthreads();
-    for (int j = 0; j < nb; j++)
+    for (int e = t; e < nb * nb; e += 256)
     {
-        if (t == 0)
-        {
-            const double d = L[j][j];
-            if (!(d > 0.0))
-            {
-                *fail = 1;
-                L[j][j] = __builtin_nan("");
-            }
-            else
-                L[j][j] = sqrt(d);
-        }
-        __syncthreads();
-        const double djj = L[j][j];
-        for (int i = j + 1 + t; i < nb; i += 256)
-            L[i][j] /= djj;
-        __syncthreads();
-        for (int e = t; e < (nb - j - 1) * (nb - j - 1); e += 256)
-        {
-            const int i = j + 1 + e / (nb - j - 1), c = j + 1 + e % (nb - j - 1);
-            if (c <= i)
-                L[i][c] -= L[i][j] * L[c][j];
-        }
-        __syncthreads();
+        const int i = e / nb, j = e % nb;
+        if (j < i)
+            L[i][j] = Y[i][j];
     }
+    __syncthreads();
+    if (t < nb)
+        L[t][t] = sqrt(L[t][t]);
+    __syncthreads();
     for (int e = t; e < nb * nb; e += 256)
     {
         const int i = e / nb, j = e % nb;
         if (j <= i)
             A[(size_t)(k0 + i) * n + k0 + j] = L[i][j];
     }
-}
-
-// rows below the diagonal block: X = A[i, k0:k0+nb] * L_kk^{-T}
-__global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, int k0, int nb)
-{
-    __shared__ double L[NB][NB + 1];
-    const int t = threadIdx.x;
-    for (int e = t; e < nb * nb; e += 256)
+    // explicit inverse of the (lower triangular) diagonal block: column c of Y solves L y = e_c
+    for (int e = t; e < NB * NB; e += 256)
+        Y[e / NB][e % NB] = 0.0;
+    __syncthreads();
+    if (t < NB)
     {
-        const int i = e / nb, j = e % nb;
-        L[i][j] = A[(size_t)(k0 + i) * n + k0 + j];
+        const int c = t;
+        for (int i = c; i < NB; i++)
+        {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int m = c; m < i; m++)
+                s -= L[i][m] * Y[m][c];
+            Y[i][c] = s / L[i][i];
+        }
     }
     __syncthreads();
-    const int row = k0 + nb + blockIdx.x * 256 + t;
-    if (row >= n)
-        return;
-    double x[NB];
-    double *a = A + (size_t)row * n + k0;
-    for (int c = 0; c < nb; c++)
-        x[c] = a[c];
-    for (int c = 0; c < nb; c++)
+    for (int e = t; e < NB * NB; e += 256)
+        Linv[e] = Y[e / NB][e % NB];
+}
+
+// rows below the diagonal block: X = A[i, k0:k0+nb] * L_kk^{-T} = A_tile * Linv' as a 64x64x64 GEMM on the
+// matrix cores (same tiling as the trailing update), in place.
+__global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, int nrows, int k0, int nb, const double *Linv)
+{
+    constexpr int KC = 32;
+    __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
+    const int r0 = k0 + nb + blockIdx.x * 64;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+    v4f64 acc[2][2];
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            acc[i][j] = v4f64{0, 0, 0, 0};
+    for (int m0 = 0; m0 < NB; m0 += KC)
     {
-        double s = x[c];
-        for (int m = 0; m < c; m++)
-            s -= x[m] * L[c][m];
-        x[c] = s / L[c][c];
+        __syncthreads();
+        for (int e = t; e < 64 * KC; e += 256)
+        {
+            const int r = e / KC, m = e % KC;
+            Pi[r][m] = (r0 + r < nrows && m0 + m < nb) ? A[(size_t)(r0 + r) * n + k0 + m0 + m] : 0.0;
+            Pj[r][m] = Linv[r * NB + m0 + m]; // X[i][c] = sum_m A[i][m] Linv[c][m]
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4)
+        {
+            const double a0 = Pi[wr + lr][kk + lk], a1 = Pi[wr + 16 + lr][kk + lk];
+            const double b0 = Pj[wc + lr][kk + lk], b1 = Pj[wc + 16 + lr][kk + lk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
     }
-    for (int c = 0; c < nb; c++)
-        a[c] = x[c];
+    __syncthreads();
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            for (int e = 0; e < 4; e++)
+            {
+                const int r = r0 + wr + 16 * i + 4 * e + lk, cc = wc + 16 * j + lr;
+                if (r < nrows && cc < nb)
+                    A[(size_t)r * n + k0 + cc] = acc[i][j][e];
+            }
 }
 
 // trailing update, lower tiles only: C[i][j] -= sum_m P[i][m] P[j][m], 64x64 tile per workgroup
-__global__ __launch_bounds__(256) void chol_update_kernel(double *A, int n, int k0, int nb)
+__global__ __launch_bounds__(256) void chol_update_kernel(double *A, int n, int nrows, int k0, int nb)
 {
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti)
@@ -583,7 +635,7 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *A, int n, int 
         for (int e = t; e < 64 * KC; e += 256)
         {
             const int r = e / KC, m = e % KC;
-            Pi[r][m] = (r0 + r < n && m < mc) ? A[(size_t)(r0 + r) * n + k0 + m0 + m] : 0.0;
+            Pi[r][m] = (r0 + r < nrows && m < mc) ? A[(size_t)(r0 + r) * n + k0 + m0 + m] : 0.0;
             Pj[r][m] = (c0 + r < n && m < mc) ? A[(size_t)(c0 + r) * n + k0 + m0 + m] : 0.0;
         }
         __syncthreads();
@@ -604,88 +656,108 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double *A, int n, int 
         for (int j = 0; j < 4; j++)
         {
             const int r = r0 + tr + i, cc = c0 + tc + j;
-            if (r < n && cc < n && cc <= r)
+            if (r < nrows && cc < n && cc <= r)
                 A[(size_t)r * n + cc] -= c[i][j];
         }
 }
 
-// Single workgroup blocked triangular solves with the factor L (lower, row-major): L y = b, then L' x = y.
-__global__ __launch_bounds__(1024) void chol_solve_kernel(const double *L, double *x, int n)
+// Same trailing update on the matrix cores: v_mfma_f64_16x16x4_f64, one 32x32 sub-tile per wave
+// (2x2 accumulators), operands staged through LDS in 32-deep K chunks.  This dense fp64 update of the
+// reduced system is the only MFMA use on the path.
+__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n, int nrows, int k0, int nb)
+{
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti)
+        return;
+    constexpr int KC = 32;
+    __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
+    const int base = k0 + nb;
+    const int r0 = base + ti * 64, c0 = base + tj * 64;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+    v4f64 acc[2][2];
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            acc[i][j] = v4f64{0, 0, 0, 0};
+    for (int m0 = 0; m0 < nb; m0 += KC)
+    {
+        const int mc = min(KC, nb - m0);
+        __syncthreads();
+        for (int e = t; e < 64 * KC; e += 256)
+        {
+            const int r = e / KC, m = e % KC;
+            Pi[r][m] = (r0 + r < nrows && m < mc) ? A[(size_t)(r0 + r) * n + k0 + m0 + m] : 0.0;
+            Pj[r][m] = (c0 + r < n && m < mc) ? A[(size_t)(c0 + r) * n + k0 + m0 + m] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4)
+        {
+            const double a0 = Pi[wr + lr][kk + lk], a1 = Pi[wr + 16 + lr][kk + lk];
+            const double b0 = Pj[wc + lr][kk + lk], b1 = Pj[wc + 16 + lr][kk + lk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            for (int e = 0; e < 4; e++)
+            {
+                // f64 16x16x4 result layout (measured, scripts/probe_mfma_f64.hip): D[4*reg + lane/16][lane%16]
+                const int r = r0 + wr + 16 * i + 4 * e + lk, cc = c0 + wc + 16 * j + lr;
+                if (r < nrows && cc < n && cc <= r)
+                    A[(size_t)r * n + cc] -= acc[i][j][e];
+            }
+}
+
+// Backward substitution L' x = y, blocked: the diagonal block in LDS by one workgroup ...
+__global__ __launch_bounds__(64) void back_diag_kernel(const double *Linv, double *x, int k0, int nb)
 {
     __shared__ double xb[NB];
     const int t = threadIdx.x;
-    // forward
-    for (int k0 = 0; k0 < n; k0 += NB)
+    xb[t] = t < nb ? x[k0 + t] : 0.0;
+    __syncthreads();
+    if (t < nb)
     {
-        const int nb = min(NB, n - k0);
-        for (int j = 0; j < nb; j++)
-        {
-            if (t == 0)
-                x[k0 + j] /= L[(size_t)(k0 + j) * n + k0 + j];
-            __syncthreads();
-            const double xj = x[k0 + j];
-            for (int i = j + 1 + t; i < nb; i += 1024)
-                x[k0 + i] -= L[(size_t)(k0 + i) * n + k0 + j] * xj;
-            __syncthreads();
-        }
-        if (t < nb)
-            xb[t] = x[k0 + t];
-        __syncthreads();
-        for (int i = k0 + nb + t; i < n; i += 1024)
-        {
-            double s = 0;
-            const double *row = L + (size_t)i * n + k0;
-            for (int m = 0; m < nb; m++)
-                s += row[m] * xb[m];
-            x[i] -= s;
-        }
-        __syncthreads();
-    }
-    // backward with L'
-    for (int k1 = n; k1 > 0; k1 -= NB)
-    {
-        const int k0 = max(0, k1 - NB), nb = k1 - k0;
-        for (int j = nb - 1; j >= 0; j--)
-        {
-            if (t == 0)
-                x[k0 + j] /= L[(size_t)(k0 + j) * n + k0 + j];
-            __syncthreads();
-            const double xj = x[k0 + j];
-            for (int i = t; i < j; i += 1024)
-                x[k0 + i] -= L[(size_t)(k0 + j) * n + k0 + i] * xj;
-            __syncthreads();
-        }
-        if (t < nb)
-            xb[t] = x[k0 + t];
-        __syncthreads();
-        for (int i = t; i < k0; i += 1024)
-        {
-            double s = 0;
-            for (int m = 0; m < nb; m++)
-                s += L[(size_t)(k0 + m) * n + i] * xb[m];
-            x[i] -= s;
-        }
-        __syncthreads();
+        double s = 0; // (L^-T y)[t] = sum_m Linv[m][t] y[m]
+        for (int m = t; m < nb; m++)
+            s += Linv[m * NB + t] * xb[m];
+        x[k0 + t] = s;
     }
 }
 
-// step = -y; model_cost_change = -(step.gs + step' As step / 2) with As = S A S; delta = S step;
-// candidate state = x (+) delta; step_norm^2 in ambient space.  One workgroup.
+// ... then every earlier unknown: x[i] -= sum_m L[k0+m][i] x[k0+m]  (coalesced over i)
+__global__ __launch_bounds__(256) void back_update_kernel(const double *L, int n, double *x, int k0, int nb)
+{
+    __shared__ double xb[NB];
+    const int t = threadIdx.x;
+    if (t < nb)
+        xb[t] = x[k0 + t];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + t;
+    if (i >= k0)
+        return;
+    double s = 0;
+    for (int m = 0; m < nb; m++)
+        s += L[(size_t)(k0 + m) * n + i] * xb[m];
+    x[i] -= s;
+}
+
+// step = -y with (As + D) y = gs, As = S A S.  model_cost_change = -(step.gs + step' As step / 2)
+// = y.gs - (y.gs - y'D y)/2 = (y.gs + sum D_i y_i^2)/2 by the normal equations (no n^2 product needed).
+// delta = S step; candidate state = x (+) delta; step_norm^2 in ambient space.  One workgroup.
 // scal: [1] model_cost_change, [2] step_norm^2, [3] x_norm^2 (candidate)
-__global__ __launch_bounds__(1024) void lm_step_kernel(relax_dev P, const double *A, const double *gs,
+__global__ __launch_bounds__(1024) void lm_step_kernel(relax_dev P, const double *lm_diag, const double *gs,
                                                        const double *scale, double *y, int n, double *scal)
 {
     __shared__ double sh[1024];
     const int t = threadIdx.x;
     double part = 0;
     for (int i = t; i < n; i += 1024)
-    {
-        const double si = -y[i];
-        double row = 0;
-        for (int j = 0; j < n; j++) // A is symmetric: read column i as row elements A[j][i] (coalesced over i)
-            row += A[(size_t)j * n + i] * scale[i] * scale[j] * (-y[j]);
-        part += si * gs[i] + 0.5 * si * row;
-    }
+        part += y[i] * gs[i] + lm_diag[i] * y[i] * y[i];
     sh[t] = part;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1)
@@ -695,7 +767,7 @@ __global__ __launch_bounds__(1024) void lm_step_kernel(relax_dev P, const double
         __syncthreads();
     }
     if (t == 0)
-        scal[1] = -sh[0];
+        scal[1] = 0.5 * sh[0];
     __syncthreads();
     // candidate state
     double sn = 0, xn = 0;
@@ -827,6 +899,8 @@ struct ochip_relax_problem
     double *A = nullptr, *Wm = nullptr, *g = nullptr, *gs = nullptr, *scale = nullptr, *lm_diag = nullptr,
            *diag_tmp = nullptr, *y = nullptr, *scal = nullptr;
     int *fail_chol = nullptr;
+    double *linv = nullptr; // [panels][NB*NB] inverses of the diagonal blocks
+    size_t linv_cap = 0;
     size_t cap_n = 0;
     uint32_t n_cams = 0;
     std::vector<uint32_t> cam_pair_count;
@@ -876,7 +950,8 @@ int assign_tangent(ochip_relax_problem *p)
                 (void)hipFree(*b);
                 *b = nullptr;
             }
-        if (hipMalloc((void **)&p->A, n * n * 8) != hipSuccess || hipMalloc((void **)&p->Wm, n * n * 8) != hipSuccess ||
+        if (hipMalloc((void **)&p->A, n * n * 8) != hipSuccess ||
+            hipMalloc((void **)&p->Wm, (n + 1) * n * 8) != hipSuccess ||
             hipMalloc((void **)&p->g, n * 8) != hipSuccess || hipMalloc((void **)&p->gs, n * 8) != hipSuccess ||
             hipMalloc((void **)&p->scale, n * 8) != hipSuccess || hipMalloc((void **)&p->lm_diag, n * 8) != hipSuccess ||
             hipMalloc((void **)&p->diag_tmp, n * 8) != hipSuccess || hipMalloc((void **)&p->y, n * 8) != hipSuccess)
@@ -908,14 +983,33 @@ int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *d, ochip_
             return ochip_fail(ctx, OCHIP_EINVAL, "residual block %u has bad camera indices", b);
         }
     // sort blocks by unordered camera pair (stable), build segments and the camera -> pair CSR
-    std::vector<uint32_t> order(d->n_blocks);
-    for (uint32_t i = 0; i < d->n_blocks; i++)
-        order[i] = i;
     auto key = [&](uint32_t b) {
         const uint32_t a = d->blk_cam_a[b], c = d->blk_cam_b[b];
         return ((uint64_t)std::min(a, c) << 32) | std::max(a, c);
     };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
+    // blocks arrive edge by edge, i.e. in runs of equal key: sort the runs (stable), then expand
+    std::vector<uint32_t> order(d->n_blocks);
+    {
+        struct run
+        {
+            uint64_t key;
+            uint32_t start, len;
+        };
+        std::vector<run> runs;
+        for (uint32_t i = 0; i < d->n_blocks; i++)
+        {
+            const uint64_t k = key(i);
+            if (runs.empty() || runs.back().key != k)
+                runs.push_back(run{k, i, 1});
+            else
+                runs.back().len++;
+        }
+        std::stable_sort(runs.begin(), runs.end(), [](const run &x, const run &y) { return x.key < y.key; });
+        uint32_t o = 0;
+        for (const run &r : runs)
+            for (uint32_t i = 0; i < r.len; i++)
+                order[o++] = r.start + i;
+    }
     std::vector<uint32_t> blk_a(d->n_blocks), blk_b(d->n_blocks), pair_off, pair_p, pair_q;
     std::vector<double> rays((size_t)d->n_blocks * 6);
     for (uint32_t i = 0; i < d->n_blocks; i++)
@@ -1016,7 +1110,7 @@ void ochip_relax_problem_destroy(ochip_relax_problem *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     for (void *a : p->allocs)
         (void)hipFree(a);
-    for (double *b : {p->A, p->Wm, p->g, p->gs, p->scale, p->lm_diag, p->diag_tmp, p->y})
+    for (double *b : {p->A, p->Wm, p->g, p->gs, p->scale, p->lm_diag, p->diag_tmp, p->y, p->linv})
         if (b)
             (void)hipFree(b);
     delete p;
@@ -1184,21 +1278,48 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
         hipLaunchKernelGGL(lm_build_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, p->A, p->g, p->scale,
                            p->lm_diag, p->Wm, p->gs, n);
         OCHIP_HIP(ctx, hipMemsetAsync(p->fail_chol, 0, 4, st));
+        {
+            const size_t need = (size_t)((n + NB - 1) / NB) * NB * NB;
+            if (need > p->linv_cap)
+            {
+                if (p->linv)
+                    OCHIP_HIP(ctx, hipFree(p->linv));
+                p->linv = nullptr;
+                p->linv_cap = 0;
+                if (hipMalloc((void **)&p->linv, need * 8) != hipSuccess)
+                    return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc for the diagonal-block inverses failed");
+                p->linv_cap = need;
+            }
+        }
         for (int k0 = 0; k0 < n; k0 += NB)
         {
             const int nb = std::min(NB, n - k0);
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, p->Wm, n, k0, nb, p->fail_chol);
-            const int rows = n - k0 - nb;
-            if (rows > 0)
+            double *linv_k = p->linv + (size_t)(k0 / NB) * NB * NB;
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, p->Wm, n, k0, nb, p->fail_chol, linv_k);
+            const int rows = n + 1 - k0 - nb; // includes the augmented row
+            hipLaunchKernelGGL(chol_panel_kernel, dim3((rows + 63) / 64), dim3(256), 0, st, p->Wm, n, n + 1, k0, nb, linv_k);
+            if (k0 + nb < n)
             {
-                hipLaunchKernelGGL(chol_panel_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, p->Wm, n, k0, nb);
                 const int tiles = (rows + 63) / 64;
-                hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, p->Wm, n, k0, nb);
+                static const bool use_valu = getenv("OCHIP_CHOL_VALU") != nullptr; // A/B knob: VALU FMA tiles
+                if (use_valu)
+                    hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, p->Wm, n, n + 1, k0, nb);
+                else
+                    hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, st, p->Wm, n, n + 1,
+                                       k0, nb);
             }
         }
-        OCHIP_HIP(ctx, hipMemcpyAsync(p->y, p->gs, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(1024), 0, st, p->Wm, p->y, n);
-        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(1024), 0, st, D, p->A, p->gs, p->scale, p->y, n, p->scal);
+        // row n now holds y = L^-1 gs; back-substitute L' x = y block by block
+        OCHIP_HIP(ctx, hipMemcpyAsync(p->y, p->Wm + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        for (int k1 = n; k1 > 0;)
+        {
+            const int nb = (k1 % NB) ? (k1 % NB) : NB, k0 = k1 - nb;
+            hipLaunchKernelGGL(back_diag_kernel, dim3(1), dim3(64), 0, st, p->linv + (size_t)(k0 / NB) * NB * NB, p->y, k0, nb);
+            if (k0 > 0)
+                hipLaunchKernelGGL(back_update_kernel, dim3((k0 + 255) / 256), dim3(256), 0, st, p->Wm, n, p->y, k0, nb);
+            k1 = k0;
+        }
+        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(1024), 0, st, D, p->lm_diag, p->gs, p->scale, p->y, n, p->scal);
         ochip_prof_end(ctx, OCHIP_K_RELAX_SOLVE, e0, e1);
         OCHIP_HIP(ctx, hipGetLastError());
         int cfail = 0;

@@ -48,6 +48,8 @@ def load():
         L.och_link_debug_matches.argtypes = [vp, sz, _u64p, _u64p, _f64p, np.ctypeslib.ndpointer(np.uint8)]
         L.och_graph_edge_info.argtypes = [vp, sz, _u64p, _u64p, _f64p, _f64p]
         L.och_graph_edge_inliers.argtypes = [vp, sz, _u64p, _u64p, _u64p, _f64p]
+        L.och_graph_edge_match_distances.argtypes = [vp, sz, _f64p]
+        L.och_graph_set_orientations.argtypes = [vp, _f64p]
         u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
         L.och_relax_ground_plane.argtypes = [vp, sz, _f64p, _f64p, _f64p, sz, _u64p, _f64p, sz, _u64p, _u64p, _f64p, u8p,
                                              _u64p, _f64p, _u64p, vp, vp, sz, _u64p, _f64p, _f64p]
@@ -167,7 +169,7 @@ class Graph:
                             can_decompose=bool(it[2])))
         return out
 
-    def edges(self):
+    def edges(self, with_distances=False):
         out = []
         for e in range(self.num_edges):
             ids, cnt, H, poses = np.zeros(2, np.uint64), np.zeros(2, np.uint64), np.zeros((3, 3)), np.zeros((4, 8))
@@ -176,8 +178,27 @@ class Graph:
             f1, f2, mi, px = np.zeros(k, np.uint64), np.zeros(k, np.uint64), np.zeros(k, np.uint64), np.zeros((k, 4))
             self.L.och_graph_edge_inliers(self.h, e, f1, f2, mi, px)
             k = int(cnt[1])
+            dist = np.zeros(max(int(cnt[0]), 1))
+            if with_distances and cnt[0]:
+                self.L.och_graph_edge_match_distances(self.h, e, dist)
             out.append(dict(source=int(ids[0]), dest=int(ids[1]), n_matches=int(cnt[0]), n_inliers=k, H=H, poses=poses,
-                            f1=f1[:k], f2=f2[:k], match_index=mi[:k], px=px[:k]))
+                            f1=f1[:k], f2=f2[:k], match_index=mi[:k], px=px[:k], dist=dist[:int(cnt[0])]))
+        return out
+
+    def set_orientations(self, ori):
+        self.L.och_graph_set_orientations(self.h, np.ascontiguousarray(ori, np.float64))
+
+    def edges_for_oracle(self, node_subset=None):
+        """The linked edges in the flat-dict form oracle.pyoracle.relax_ground_plane / pack_edges take, with
+        node ids mapped to node indices; optionally restricted to edges inside a node-index subset."""
+        index_of = {nid: i for i, nid in enumerate(self.node_ids)}
+        keep = None if node_subset is None else set(int(i) for i in node_subset)
+        out = []
+        for ed in self.edges(with_distances=True):
+            s, d = index_of[ed["source"]], index_of[ed["dest"]]
+            if keep is not None and (s not in keep or d not in keep):
+                continue
+            out.append(dict(src=s, dst=d, H=ed["H"], px=ed["px"], match_index=ed["match_index"], dist=ed["dist"]))
         return out
 
 
