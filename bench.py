@@ -40,8 +40,10 @@ def main():
     args = ap.parse_args()
 
     rank, world, local_rank = _env_int("RANK", 0), _env_int("WORLD_SIZE", 1), _env_int("LOCAL_RANK", 0)
-    cores = len(os.sched_getaffinity(0))
-    # the host side of every rank is OpenMP-parallel: split the host cores between the ranks of this node
+    from opencalibration_amd import host as _host_mod
+
+    cores = _host_mod.effective_cpus()   # affinity mask capped by the cgroup CPU quota
+    # the host side of every rank is OpenMP-parallel: split the usable host cores between the ranks of this node
     os.environ.setdefault("OMP_NUM_THREADS", str(max(1, cores // max(world, 1))))
 
     import torch

@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
@@ -124,6 +126,13 @@ class GroundPlaneProblem
     // setupGroundPlaneProblem (relax_problem.cpp:61-81)
     bool setup(std::vector<NodePose> &poses, const std::vector<size_t> &edges_to_optimize, std::string *error)
     {
+        const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+        auto tmark = clk::now();
+        auto lap = [&](const char *what) {
+            if (verbose)
+                fprintf(stderr, "[relax setup] %-28s %.3f ms\n", what, since(tmark) * 1e3);
+            tmark = clk::now();
+        };
         _poses = &poses;
         for (size_t i = 0; i < poses.size(); i++)
             _opt_index.emplace(poses[i].node_id, i);
@@ -149,6 +158,7 @@ class GroundPlaneProblem
             if ((src[k].loc == nullptr || dst[k].loc == nullptr) && n_filter == edges_to_optimize.size())
                 n_filter = k;
         }
+        lap("pose lookup");
         std::vector<std::vector<uint8_t>> keep(edges_to_optimize.size());
 #pragma omp parallel for schedule(dynamic, 1)
         for (size_t k = 0; k < n_filter; k++)
@@ -161,6 +171,7 @@ class GroundPlaneProblem
         // addRayTriangleMeasurementCost (:388-560), fixed intrinsics.  The searcher's orientation fix-up of
         // the single triangle happens on its first use and is the same for every edge, so do it once and
         // build the per-edge block lists in parallel; they are concatenated in edge order.
+        lap("grid filter");
         fix_triangle_orientation();
         std::vector<edge_blocks> per_edge(edges_to_optimize.size());
 #pragma omp parallel for schedule(dynamic, 8)
@@ -171,6 +182,7 @@ class GroundPlaneProblem
                 continue;
             add_edge_blocks(*e, src[k], dst[k], keep[k], per_edge[k]);
         }
+        lap("edge blocks");
         size_t total_blocks = 0;
         for (const auto &pe : per_edge)
             total_blocks += pe.a.size();
@@ -188,6 +200,7 @@ class GroundPlaneProblem
             if (!hasnan4(poses[i].orientation))
                 _prior_cam.push_back((uint32_t)i);
 
+        lap("concatenate");
         ochip_relax_desc d{};
         d.n_cams = (uint32_t)_cam_opt.size();
         d.cam_pos = _cam_pos.data();
@@ -213,6 +226,7 @@ class GroundPlaneProblem
             *error = std::string("ochip_relax_problem_create: ") + ochip_last_error(_ctx);
             return false;
         }
+        lap("ochip_relax_problem_create");
         return true;
     }
 

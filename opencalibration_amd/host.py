@@ -15,11 +15,32 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 
 
+def effective_cpus():
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU
+    boxes expose 256 hardware threads but run the job under a 16-CPU cfs quota; 256 OpenMP threads inside
+    such a quota only thrash)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise capi.OchipError(f"{LIB_PATH} is missing: run `python -m opencalibration_amd.build`")
+        os.environ.setdefault("OMP_NUM_THREADS", str(effective_cpus()))  # read by libgomp when the library loads
         capi.load()  # libochip.so first (liboc_host.so links against it)
         L = C.CDLL(LIB_PATH)
         L.och_subsample.restype = C.c_size_t
