@@ -209,9 +209,10 @@ class Graph:
     def set_orientations(self, ori):
         self.L.och_graph_set_orientations(self.h, np.ascontiguousarray(ori, np.float64))
 
-    def edges_for_oracle(self, node_subset=None):
-        """The linked edges in the flat-dict form oracle.pyoracle.relax_ground_plane / pack_edges take, with
-        node ids mapped to node indices; optionally restricted to edges inside a node-index subset."""
+    def edges_flat(self, node_subset=None):
+        """The linked edges as flat dicts (src/dst node index, H, inlier pixel pairs, match indices, match
+        distances): the form the stand-alone relax entry points and the parity checker take; optionally
+        restricted to edges inside a node-index subset."""
         index_of = {nid: i for i, nid in enumerate(self.node_ids)}
         keep = None if node_subset is None else set(int(i) for i in node_subset)
         out = []

@@ -27,7 +27,7 @@ def test_c1_link_then_relax_matches_oracle(oracle):
     start = perturbed(grid.orientation, 0.1, 1)      # 0.1 rad initial error (test/test_relax.cpp:421)
     g.set_orientations(start)
     got = g.relax_ground_plane(ctx, start)
-    edges = g.edges_for_oracle()
+    edges = g.edges_flat()
     assert len(edges) == 90
     exp = oracle.relax_ground_plane(grid.position, start, grid.model, np.arange(grid.n_images), start, edges)
     worst = max(qangle(exp["orientation"][i], got["orientation"][i]) for i in range(grid.n_images))
