@@ -54,6 +54,15 @@ extern "C"
     void och_graph_edge_match_distances(const och_graph *g, size_t e, double *out); /* relations.matches[i].distance */
     void och_graph_set_orientations(och_graph *g, const double *ori /* n_nodes x 4, node order */);
 
+    /* ---- extract (opencalibration_amd/csrc/host/extract_features.hpp): extract_features(cv::Mat) of
+     *      src/extract/extract_features.cpp:11-88 for a batch of equally sized BGR images ------------------ */
+    /* Per image up to max_out features at stride max_out: loc (x, y in full-resolution pixels), strength, desc
+     * (8 u64); counts[i] features of image i, the first num_sparse[i] of which passed the 8 px NMS. */
+    int och_extract_features_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
+                                   uint32_t max_keypoints, uint32_t max_out, double *loc, float *strength,
+                                   uint64_t *desc, uint32_t *counts, uint32_t *num_sparse);
+    const char *och_extract_last_error(void);
+
     /* ---- relax (opencalibration_amd/csrc/host/relax.hpp): relax(graph, nodes, cam_models, edges,
      *      {ORIENTATION, GROUND_PLANE}, {}) of src/relax/relax.cpp:122-134 ------------------------------ */
     /* Stand-alone problem from flat arrays.  graph: n_nodes x {pos3, ori4 xyzw (may be NaN)} + one shared

@@ -56,6 +56,7 @@ extern "C"
         OCHIP_K_RANSAC = 1,
         OCHIP_K_RELAX_EVAL = 2,
         OCHIP_K_RELAX_SOLVE = 3,
+        OCHIP_K_AKAZE = 4,
         OCHIP_K_COUNT = 8
     };
 
@@ -85,6 +86,17 @@ extern "C"
     int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs, const uint64_t *out_offset,
                            uint64_t out_total);
     int ochip_match_fetch(ochip_ctx *ctx, ochip_match *out, uint64_t out_total);
+
+    /* ---- extract: AKAZE keypoints + 486-bit M-LDB descriptors for a batch of equally sized BGR images
+     *      (replaces cvtColor + resize(INTER_AREA, max side 1600) + cv::AKAZE::detectAndCompute of
+     *      src/extract/extract_features.cpp:25-36; AKAZE restated from its publication) ---- */
+    /* images_bgr: n_images x height x width x 3 bytes.  Per image up to max_kp keypoints are written, in
+     * unspecified order: kp6[(i*max_kp + k)*6] = {x, y, diameter, angle (radians), response, evolution level}
+     * in pixels of the working (downscaled) image, desc[(i*max_kp + k)*8] = descriptor words (bit j = word j>>6,
+     * bit j&63, the packing of extract_features.cpp:47-51); counts[i] = keypoints of image i;
+     * work_wh = working width, height. */
+    int ochip_akaze_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
+                          uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh);
 
     /* ---- keypoints -> unit rays (replaces image_to_3d of src/distort/distort_keypoints.cpp:68-103,
      *      hoisted from once per match to once per keypoint) ------------------------------------------ */

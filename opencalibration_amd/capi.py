@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libochip.so")
 
-K_MATCH, K_RANSAC, K_RELAX_EVAL, K_RELAX_SOLVE = 0, 1, 2, 3
+K_MATCH, K_RANSAC, K_RELAX_EVAL, K_RELAX_SOLVE, K_AKAZE = 0, 1, 2, 3, 4
 NO_SECOND = 0xFFFF
 
 PAIR_DTYPE = np.dtype([("image_1", np.uint32), ("image_2", np.uint32)])
@@ -20,7 +20,7 @@ EXPORTS = [
     "ochip_descriptors_reserve", "ochip_upload_descriptors", "ochip_descriptor_count",
     "ochip_match_batch", "ochip_match_launch", "ochip_match_fetch",
     "ochip_upload_keypoints", "ochip_ransac_homography_batch",
-    "ochip_upload_batch", "ochip_host_alloc", "ochip_host_free",
+    "ochip_upload_batch", "ochip_host_alloc", "ochip_host_free", "ochip_akaze_batch",
     "ochip_relax_problem_create", "ochip_relax_problem_destroy", "ochip_relax_set_cameras_constant",
     "ochip_relax_solve", "ochip_relax_get_state",
     "ochip_profile_reset", "ochip_profile_get",
@@ -58,6 +58,7 @@ def load():
         L.ochip_profile_reset.argtypes = [vp]
         L.ochip_profile_get.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(C.c_double)]
         L.ochip_debug_fp64.argtypes = [vp, i32, vp, vp, C.c_size_t, vp]
+        L.ochip_akaze_batch.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -121,6 +122,18 @@ class Context:
         out_offset = np.ascontiguousarray(out_offset, np.uint64)
         self._check(self.L.ochip_match_launch(self.h, pairs.ctypes.data, len(pairs), out_offset.ctypes.data, out_total),
                     "ochip_match_launch")
+
+    def akaze_batch(self, images_bgr, max_kp=20000):
+        """images_bgr: (n, h, w, 3) uint8.  Returns (list of (kp6, desc) per image, (work_w, work_h))."""
+        imgs = np.ascontiguousarray(images_bgr, np.uint8)
+        n, h, w, _ = imgs.shape
+        kp = np.zeros((n, max_kp, 6), np.float32)
+        desc = np.zeros((n, max_kp, 8), np.uint64)
+        counts = np.zeros(n, np.uint32)
+        wh = np.zeros(2, np.int32)
+        self._check(self.L.ochip_akaze_batch(self.h, imgs.ctypes.data, n, w, h, max_kp, kp.ctypes.data, desc.ctypes.data,
+                                             counts.ctypes.data, wh.ctypes.data), "ochip_akaze_batch")
+        return [(kp[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(n)], (int(wh[0]), int(wh[1]))
 
     def debug_fp64(self, op, x, y=None):
         x = np.ascontiguousarray(x, np.float64)

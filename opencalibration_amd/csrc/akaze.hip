@@ -1,0 +1,1006 @@
+// libochip.so — extract: AKAZE features (nonlinear FED scale space, Hessian-determinant extrema, 486-bit
+// 3-channel M-LDB) for a batch of equally sized images (gfx950).
+//
+// Replaces cv::AKAZE::detectAndCompute behind src/extract/extract_features.cpp:35-36 together with the
+// grey conversion and INTER_AREA downscale in front of it (:25-27).  AKAZE lives in OpenCV (absent from
+// this image): the algorithm is restated from its publication (Alcantarilla, Nuevo, Bartoli, BMVC 2013)
+// in the structure of OpenCV's implementation; parity with OpenCV itself is unpinned and the
+// kernels are checked against the CPU restatement, with which they share every table (Gaussian taps,
+// FED step sizes, orientation weights are computed on the host in double) and every float32 operation
+// order (no FMA, no device transcendentals), so level images, keypoints and descriptors are bit-identical.
+//
+// All stencil passes are HBM-streaming kernels over [image][y][x] float planes, 256-thread workgroups
+// walking rows (coalesced 4-byte lanes; the 3..13-tap neighbourhoods are served by L1/L2).  One launch
+// covers the whole batch (blockIdx.z = image) so a 1 000-image job needs ~200 launches per batch of B
+// images instead of per image.
+#include "ctx.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace
+{
+
+struct level_info
+{
+    int octave, w, h, sigma_size;
+    float esigma;
+    size_t off; // plane offset (floats) inside one image's pyramid
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi)
+{
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+__device__ __forceinline__ int reflect101(int v, int n)
+{
+    if (n == 1)
+        return 0;
+    while (v < 0 || v >= n)
+        v = v < 0 ? -v : 2 * (n - 1) - v;
+    return v;
+}
+
+// ---- grey + INTER_AREA (extract_features.cpp:25-27)
+__global__ void gray_kernel(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        gray[i] = (uint8_t)((bgr[3 * i] * 1868 + bgr[3 * i + 1] * 9617 + bgr[3 * i + 2] * 4899 + (1 << 13)) >> 14);
+}
+
+__global__ void resize_area_kernel(const uint8_t *__restrict__ src, int sw, int sh, uint8_t *__restrict__ dst, int dw,
+                                   int dh, const int *__restrict__ xoff, const int *__restrict__ xsi,
+                                   const float *__restrict__ xal, const int *__restrict__ yoff,
+                                   const int *__restrict__ ysi, const float *__restrict__ yal)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dw)
+        return;
+    const uint8_t *s = src + (size_t)blockIdx.z * sw * sh;
+    float acc = 0.0f;
+    for (int e = yoff[y]; e < yoff[y + 1]; e++)
+    {
+        const uint8_t *row = s + (size_t)ysi[e] * sw;
+        float r = 0.0f;
+        for (int k = xoff[x]; k < xoff[x + 1]; k++)
+            r += (float)row[xsi[k]] * xal[k];
+        acc += r * yal[e];
+    }
+    const float v = rintf(acc);
+    dst[(size_t)blockIdx.z * dw * dh + (size_t)y * dw + x] = (uint8_t)fminf(255.0f, fmaxf(0.0f, v));
+}
+
+__global__ void to_float_kernel(const uint8_t *__restrict__ g, float *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = (float)g[i] * (1.0f / 255.0f);
+}
+
+// ---- separable Gaussian, replicate border, ascending tap order
+constexpr int MAX_TAPS = 33;
+struct taps_t
+{
+    int n;
+    float k[MAX_TAPS];
+};
+
+template <bool ROWS>
+__global__ void conv_kernel(const float *__restrict__ in, float *__restrict__ out, int w, int h, size_t in_stride,
+                            size_t out_stride, taps_t t)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w)
+        return;
+    const float *I = in + (size_t)blockIdx.z * in_stride;
+    const int r = t.n / 2;
+    float acc = 0.0f;
+    if (ROWS)
+        for (int i = 0; i < t.n; i++)
+            acc = acc + t.k[i] * I[(size_t)y * w + clampi(x + i - r, 0, w - 1)];
+    else
+        for (int i = 0; i < t.n; i++)
+            acc = acc + t.k[i] * I[(size_t)clampi(y + i - r, 0, h - 1) * w + x];
+    out[(size_t)blockIdx.z * out_stride + (size_t)y * w + x] = acc;
+}
+
+__device__ __forceinline__ void scharr3(const float *I, int w, int h, int x, int y, float *lx, float *ly)
+{
+    const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w), ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+    const float a = I[(size_t)ym * w + xp] - I[(size_t)ym * w + xm];
+    const float b = I[(size_t)y * w + xp] - I[(size_t)y * w + xm];
+    const float c = I[(size_t)yp * w + xp] - I[(size_t)yp * w + xm];
+    *lx = (3.0f * a + 10.0f * b) + 3.0f * c;
+    const float d = I[(size_t)yp * w + xm] - I[(size_t)ym * w + xm];
+    const float e = I[(size_t)yp * w + x] - I[(size_t)ym * w + x];
+    const float f = I[(size_t)yp * w + xp] - I[(size_t)ym * w + xp];
+    *ly = (3.0f * d + 10.0f * e) + 3.0f * f;
+}
+
+// ---- contrast factor: gradient-magnitude histogram of the smoothed input (compute_k_percentile)
+__global__ void modg_kernel(const float *__restrict__ sm, float *__restrict__ modg, int w, int h, size_t stride,
+                            unsigned int *__restrict__ hmax_bits)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w)
+        return;
+    float m = 0.0f;
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1)
+    {
+        float lx, ly;
+        scharr3(sm + (size_t)blockIdx.z * stride, w, h, x, y, &lx, &ly);
+        m = sqrtf(lx * lx + ly * ly);
+        atomicMax(hmax_bits + blockIdx.z, __float_as_uint(m)); // non-negative floats order like their bit patterns
+    }
+    modg[(size_t)blockIdx.z * stride + (size_t)y * w + x] = m;
+}
+
+__global__ void hist_kernel(const float *__restrict__ modg, int w, int h, size_t stride,
+                            const unsigned int *__restrict__ hmax_bits, int nbins, unsigned int *__restrict__ hist)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1)
+        return;
+    const float m = modg[(size_t)blockIdx.z * stride + (size_t)y * w + x];
+    if (m != 0.0f)
+    {
+        const float hmax = __uint_as_float(hmax_bits[blockIdx.z]);
+        int nbin = (int)floorf((float)nbins * (m / hmax));
+        if (nbin == nbins)
+            nbin--;
+        atomicAdd(hist + (size_t)blockIdx.z * (nbins + 1) + nbin, 1u);
+        atomicAdd(hist + (size_t)blockIdx.z * (nbins + 1) + nbins, 1u); // npoints
+    }
+}
+
+__global__ void kcontrast_kernel(const unsigned int *__restrict__ hist, const unsigned int *__restrict__ hmax_bits,
+                                 int nbins, float perc, float *__restrict__ kcontrast, int n_images)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_images)
+        return;
+    const unsigned int *hh = hist + (size_t)b * (nbins + 1);
+    const int npoints = (int)hh[nbins];
+    const int nthreshold = (int)((float)npoints * perc);
+    int nelements = 0, k = 0;
+    for (k = 0; nelements < nthreshold && k < nbins; k++)
+        nelements += (int)hh[k];
+    kcontrast[b] = nelements < nthreshold ? 0.03f : __uint_as_float(hmax_bits[b]) * ((float)k / (float)nbins);
+}
+
+// ---- diffusion
+__global__ void flow_kernel(const float *__restrict__ sm, float *__restrict__ flow, int w, int h, size_t stride,
+                            const float *__restrict__ kcontrast, int n_octave_steps)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w)
+        return;
+    float k = kcontrast[blockIdx.z];
+    for (int i = 0; i < n_octave_steps; i++) // kcontrast *= 0.75 at every new octave, one rounding per step
+        k = k * 0.75f;
+    const float inv = 1.0f / (k * k);
+    float lx, ly;
+    scharr3(sm + (size_t)blockIdx.z * stride, w, h, x, y, &lx, &ly);
+    flow[(size_t)blockIdx.z * stride + (size_t)y * w + x] = 1.0f / (1.0f + inv * (lx * lx + ly * ly));
+}
+
+__global__ void nld_step_kernel(const float *__restrict__ Lin, const float *__restrict__ cflow, float *__restrict__ Lout,
+                                int w, int h, size_t l_stride, size_t c_stride, size_t out_stride, float tau)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w)
+        return;
+    const float *L = Lin + (size_t)blockIdx.z * l_stride, *c = cflow + (size_t)blockIdx.z * c_stride;
+    const size_t i = (size_t)y * w + x;
+    const float half = 0.5f * tau;
+    const float xpos = x + 1 < w ? (c[i] + c[i + 1]) * (L[i + 1] - L[i]) : 0.0f;
+    const float xneg = x > 0 ? (c[i - 1] + c[i]) * (L[i] - L[i - 1]) : 0.0f;
+    const float ypos = y + 1 < h ? (c[i] + c[i + w]) * (L[i + w] - L[i]) : 0.0f;
+    const float yneg = y > 0 ? (c[i - w] + c[i]) * (L[i] - L[i - w]) : 0.0f;
+    Lout[(size_t)blockIdx.z * out_stride + i] = L[i] + half * ((xpos - xneg) + (ypos - yneg));
+}
+
+__global__ void halfsample_kernel(const float *__restrict__ in, int w, int h, size_t in_stride, float *__restrict__ out,
+                                  int ow, int oh, size_t out_stride)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow)
+        return;
+    const float *I = in + (size_t)blockIdx.z * in_stride;
+    const int x0 = min(2 * x, w - 1), x1 = min(2 * x + 1, w - 1), y0 = min(2 * y, h - 1), y1 = min(2 * y + 1, h - 1);
+    out[(size_t)blockIdx.z * out_stride + (size_t)y * ow + x] =
+        ((I[(size_t)y0 * w + x0] + I[(size_t)y0 * w + x1]) + (I[(size_t)y1 * w + x0] + I[(size_t)y1 * w + x1])) * 0.25f;
+}
+
+__global__ void copy_plane_kernel(const float *__restrict__ in, size_t in_stride, float *__restrict__ out,
+                                  size_t out_stride, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[(size_t)blockIdx.z * out_stride + i] = in[(size_t)blockIdx.z * in_stride + i];
+}
+
+// ---- derivatives at the level's integer scale
+__device__ __forceinline__ void deriv_at(const float *I, int w, int h, int s, int x, int y, float nrm, float wn, float *dx,
+                                         float *dy)
+{
+    const int ym = reflect101(y - s, h), yp = reflect101(y + s, h), xm = reflect101(x - s, w), xp = reflect101(x + s, w);
+    const float a = I[(size_t)ym * w + xp] - I[(size_t)ym * w + xm];
+    const float b = I[(size_t)y * w + xp] - I[(size_t)y * w + xm];
+    const float c = I[(size_t)yp * w + xp] - I[(size_t)yp * w + xm];
+    *dx = (nrm * a + wn * b) + nrm * c;
+    const float d = I[(size_t)yp * w + xm] - I[(size_t)ym * w + xm];
+    const float e = I[(size_t)yp * w + x] - I[(size_t)ym * w + x];
+    const float f = I[(size_t)yp * w + xp] - I[(size_t)ym * w + xp];
+    *dy = (nrm * d + wn * e) + nrm * f;
+}
+
+__global__ void deriv_kernel(const float *__restrict__ sm, size_t sm_stride, float *__restrict__ Lx, float *__restrict__ Ly,
+                             size_t out_stride, int w, int h, int s)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w)
+        return;
+    const float wgt = 10.0f / 3.0f;
+    const float nrm = 1.0f / (2.0f * (float)s * (wgt + 2.0f));
+    const float wn = wgt * nrm;
+    float dx, dy;
+    deriv_at(sm + (size_t)blockIdx.z * sm_stride, w, h, s, x, y, nrm, wn, &dx, &dy);
+    Lx[(size_t)blockIdx.z * out_stride + (size_t)y * w + x] = dx;
+    Ly[(size_t)blockIdx.z * out_stride + (size_t)y * w + x] = dy;
+}
+
+__global__ void det_kernel(const float *__restrict__ Lx, const float *__restrict__ Ly, size_t stride,
+                           float *__restrict__ Ldet, int w, int h, int s)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w)
+        return;
+    const float wgt = 10.0f / 3.0f;
+    const float nrm = 1.0f / (2.0f * (float)s * (wgt + 2.0f));
+    const float wn = wgt * nrm;
+    float lxx, lxy, tmp, lyy;
+    deriv_at(Lx + (size_t)blockIdx.z * stride, w, h, s, x, y, nrm, wn, &lxx, &lxy);
+    deriv_at(Ly + (size_t)blockIdx.z * stride, w, h, s, x, y, nrm, wn, &tmp, &lyy);
+    const float s4 = (float)(s * s * s * s);
+    Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = (lxx * lyy - lxy * lxy) * s4;
+}
+
+// ---- detection
+struct cand_t
+{
+    int level, x, y;
+    float response;
+};
+
+// 3x3 strict maxima above the threshold: appended to the image's candidate list and written to the level's
+// sparse maxima map (0 elsewhere) that the scale-space suppression scans
+__global__ void maxima_kernel(const float *__restrict__ Ldet, float *__restrict__ Rmax, size_t stride, int w, int h,
+                              int level, float thr, cand_t *__restrict__ cands, unsigned int *__restrict__ n_cands,
+                              unsigned int max_cands)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w)
+        return;
+    const float *D = Ldet + (size_t)blockIdx.z * stride;
+    float out = 0.0f;
+    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1)
+    {
+        const float v = D[(size_t)y * w + x];
+        if (v > thr)
+        {
+            bool mx = true;
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++)
+                    if ((dx || dy) && !(v > D[(size_t)(y + dy) * w + x + dx]))
+                        mx = false;
+            if (mx)
+            {
+                out = v;
+                const unsigned int slot = atomicAdd(n_cands + blockIdx.z, 1u);
+                if (slot < max_cands)
+                    cands[(size_t)blockIdx.z * max_cands + slot] = cand_t{level, x, y, v};
+            }
+        }
+    }
+    Rmax[(size_t)blockIdx.z * stride + (size_t)y * w + x] = out;
+}
+
+struct levels_dev
+{
+    int n;
+    level_info l[16];
+};
+
+// A candidate dies if a stronger maximum (ties: lower (level, y, x) wins) of an adjacent level lies within
+// its own size esigma * derivative_factor (base-image pixels).  One thread per candidate, window scans of
+// the sparse maxima maps.
+__global__ void suppress_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
+                                unsigned int max_cands, const float *__restrict__ Rmax, size_t img_stride, levels_dev L,
+                                float derivative_factor, unsigned char *__restrict__ dead)
+{
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
+    const unsigned int n = min(n_cands[b], max_cands);
+    if (k >= n)
+        return;
+    const cand_t c = cands[(size_t)b * max_cands + k];
+    const level_info lc = L.l[c.level];
+    const float ratio_c = (float)(1 << lc.octave);
+    const float rad = lc.esigma * derivative_factor, r2 = rad * rad;
+    const float cx = (float)c.x * ratio_c, cy = (float)c.y * ratio_c;
+    bool is_dead = false;
+    for (int j = max(c.level - 1, 0); j <= min(c.level + 1, L.n - 1) && !is_dead; j++)
+    {
+        const level_info lj = L.l[j];
+        const float ratio = (float)(1 << lj.octave);
+        const float *R = Rmax + (size_t)b * img_stride + lj.off;
+        const int x0 = max((int)floorf((cx - rad) / ratio), 0), x1 = min((int)ceilf((cx + rad) / ratio), lj.w - 1);
+        const int y0 = max((int)floorf((cy - rad) / ratio), 0), y1 = min((int)ceilf((cy + rad) / ratio), lj.h - 1);
+        for (int yy = y0; yy <= y1 && !is_dead; yy++)
+            for (int xx = x0; xx <= x1; xx++)
+            {
+                const float r = R[(size_t)yy * lj.w + xx];
+                if (r == 0.0f || (j == c.level && xx == c.x && yy == c.y))
+                    continue;
+                const float ex = (float)xx * ratio - cx, ey = (float)yy * ratio - cy;
+                if (!(ex * ex + ey * ey <= r2))
+                    continue;
+                const bool lower_key = j < c.level || (j == c.level && (yy < c.y || (yy == c.y && xx < c.x)));
+                if (r > c.response || (r == c.response && lower_key))
+                {
+                    is_dead = true;
+                    break;
+                }
+            }
+    }
+    dead[(size_t)b * max_cands + k] = is_dead ? 1 : 0;
+}
+
+// ---- float-only math shared with the CPU restatement (deterministic: + - * / and compares only)
+__device__ __forceinline__ float fast_atan2(float y, float x)
+{
+    const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f, HALF_PI_F = 1.57079632679489661923f;
+    const float p1 = 0.9997878412794807f, p3 = -0.3258083974640975f, p5 = 0.1555786518463281f, p7 = -0.04432655554792128f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay)
+    {
+        c = ay / (ax + 2.220446e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    else
+    {
+        c = ax / (ay + 2.220446e-16f);
+        c2 = c * c;
+        a = HALF_PI_F - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0)
+        a = PI_F - a;
+    if (y < 0)
+        a = TWO_PI_F - a;
+    return a;
+}
+
+__device__ __forceinline__ void sincos_poly(float a, float *s, float *c)
+{
+    const float HALF_PI_F = 1.57079632679489661923f;
+    int q = (int)(a / HALF_PI_F);
+    if (q > 3)
+        q = 3;
+    float r = a - (float)q * HALF_PI_F;
+    bool swp = false;
+    if (r > 0.78539816339744830962f)
+    {
+        r = HALF_PI_F - r;
+        swp = true;
+    }
+    const float r2 = r * r;
+    float sn = r * (1.0f + r2 * (-1.0f / 6.0f + r2 * (1.0f / 120.0f + r2 * (-1.0f / 5040.0f + r2 * (1.0f / 362880.0f)))));
+    float cs = 1.0f + r2 * (-0.5f + r2 * (1.0f / 24.0f + r2 * (-1.0f / 720.0f + r2 * (1.0f / 40320.0f))));
+    if (swp)
+    {
+        const float t = sn;
+        sn = cs;
+        cs = t;
+    }
+    if (q == 0)
+        *s = sn, *c = cs;
+    else if (q == 1)
+        *s = cs, *c = -sn;
+    else if (q == 2)
+        *s = -sn, *c = -cs;
+    else
+        *s = -cs, *c = sn;
+}
+
+struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cells numbered 0..3 | 4..12 | 13..28
+{
+    unsigned char a[486], b[486], ch[486];
+};
+
+// One 64-thread workgroup per surviving candidate: sub-pixel fit, dominant orientation, 486-bit M-LDB.
+// Sums run in the restatement's sequential order (one lane per window / per grid cell) so bits agree.
+__global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
+                                                      unsigned int max_cands, const unsigned char *__restrict__ dead,
+                                                      const float *__restrict__ Lt, const float *__restrict__ Lx,
+                                                      const float *__restrict__ Ly, const float *__restrict__ Ldet,
+                                                      size_t img_stride, levels_dev L, float derivative_factor,
+                                                      const float *__restrict__ gw /*13x13*/, const pair_tab *__restrict__ tab,
+                                                      float *__restrict__ kp_out /*[b][max][6]*/,
+                                                      unsigned long long *__restrict__ desc_out /*[b][max][8]*/,
+                                                      unsigned char *__restrict__ valid_out)
+{
+    __shared__ float resX[109], resY[109], Ang[109];
+    __shared__ float wm[42], wang[42];
+    __shared__ float vals[29][3];
+    const int lane = threadIdx.x;
+    const unsigned int k = blockIdx.x, b = blockIdx.z;
+    const unsigned int n = min(n_cands[b], max_cands);
+    if (k >= n)
+        return;
+    const size_t slot = (size_t)b * max_cands + k;
+    if (dead[slot])
+    {
+        if (lane == 0)
+            valid_out[slot] = 0;
+        return;
+    }
+    const cand_t c = cands[slot];
+    const level_info l = L.l[c.level];
+    const int w = l.w, h = l.h;
+    const float *D = Ldet + (size_t)b * img_stride + l.off;
+    const float v00 = D[(size_t)c.y * w + c.x];
+    const float vxp = D[(size_t)c.y * w + c.x + 1], vxm = D[(size_t)c.y * w + c.x - 1];
+    const float vyp = D[(size_t)(c.y + 1) * w + c.x], vym = D[(size_t)(c.y - 1) * w + c.x];
+    const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
+    const float Dxx = (vxp + vxm) - 2.0f * v00, Dyy = (vyp + vym) - 2.0f * v00;
+    const float Dxy = 0.25f * ((D[(size_t)(c.y + 1) * w + c.x + 1] + D[(size_t)(c.y - 1) * w + c.x - 1]) -
+                               (D[(size_t)(c.y + 1) * w + c.x - 1] + D[(size_t)(c.y - 1) * w + c.x + 1]));
+    const float det = Dxx * Dyy - Dxy * Dxy;
+    bool ok = det != 0.0f;
+    float dx = 0.0f, dy = 0.0f;
+    if (ok)
+    {
+        dx = (Dxy * Dy - Dyy * Dx) / det;
+        dy = (Dxy * Dx - Dxx * Dy) / det;
+        ok = fabsf(dx) <= 1.0f && fabsf(dy) <= 1.0f;
+    }
+    if (!ok)
+    {
+        if (lane == 0)
+            valid_out[slot] = 0;
+        return;
+    }
+    const float ratio = (float)(1 << l.octave);
+    const float kx = ((float)c.x + dx) * ratio + 0.5f * (ratio - 1.0f);
+    const float ky = ((float)c.y + dy) * ratio + 0.5f * (ratio - 1.0f);
+    const float size = 2.0f * (l.esigma * derivative_factor);
+    const float xf = kx / ratio, yf = ky / ratio;
+    const int s = (int)rintf(0.5f * size / ratio);
+    const float *pLt = Lt + (size_t)b * img_stride + l.off, *pLx = Lx + (size_t)b * img_stride + l.off,
+                *pLy = Ly + (size_t)b * img_stride + l.off;
+
+    // orientation samples: index order i (outer), j (inner) over the radius-6 disc
+    for (int q = lane; q < 169; q += 64)
+    {
+        const int i = q / 13 - 6, j = q % 13 - 6;
+        if (i * i + j * j < 36)
+        {
+            // position of (i, j) in the compacted list = number of disc members before it
+            int idx = 0;
+            for (int qq = 0; qq < q; qq++)
+            {
+                const int ii = qq / 13 - 6, jj = qq % 13 - 6;
+                idx += (ii * ii + jj * jj < 36) ? 1 : 0;
+            }
+            const int iy = clampi((int)rintf(yf + (float)(j * s)), 0, h - 1);
+            const int ix = clampi((int)rintf(xf + (float)(i * s)), 0, w - 1);
+            const float g = gw[(i + 6) * 13 + (j + 6)];
+            const float rx = g * pLx[(size_t)iy * w + ix], ry = g * pLy[(size_t)iy * w + ix];
+            resX[idx] = rx;
+            resY[idx] = ry;
+            Ang[idx] = fast_atan2(ry, rx);
+        }
+    }
+    __syncthreads();
+    const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
+    if (lane < 42)
+    {
+        const float ang1 = 0.15f * (float)lane;
+        const float ang2 = (ang1 + PI_F / 3.0f > TWO_PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
+        float sumX = 0.0f, sumY = 0.0f;
+        for (int q = 0; q < 109; q++)
+        {
+            const float a = Ang[q];
+            if ((ang1 < ang2 && ang1 < a && a < ang2) || (ang2 < ang1 && ((a > 0.0f && a < ang2) || (a > ang1 && a < TWO_PI_F))))
+            {
+                sumX = sumX + resX[q];
+                sumY = sumY + resY[q];
+            }
+        }
+        wm[lane] = sumX * sumX + sumY * sumY;
+        wang[lane] = fast_atan2(sumY, sumX);
+    }
+    __syncthreads();
+    float best = 0.0f, angle = 0.0f;
+    for (int st = 0; st < 42; st++) // first strict maximum in step order, as the sequential loop finds it
+        if (wm[st] > best)
+        {
+            best = wm[st];
+            angle = wang[st];
+        }
+    float si, co;
+    sincos_poly(angle, &si, &co);
+    const float fs = (float)s;
+    if (lane < 29)
+    {
+        int lvl, cell;
+        if (lane < 4)
+            lvl = 0, cell = lane;
+        else if (lane < 13)
+            lvl = 1, cell = lane - 4;
+        else
+            lvl = 2, cell = lane - 13;
+        const int g = lvl + 2;
+        const int step = (lvl == 0) ? 10 : (lvl == 1 ? 7 : 5); // ceil(20 / g)
+        const int i0 = -10 + (cell / g) * step, j0 = -10 + (cell % g) * step;
+        float di = 0.0f, ddx = 0.0f, ddy = 0.0f;
+        int ns = 0;
+        for (int a = i0; a < i0 + step; a++)
+            for (int bb = j0; bb < j0 + step; bb++)
+            {
+                const float sy = yf + ((float)bb * co * fs + (float)a * si * fs);
+                const float sx = xf + (-(float)bb * si * fs + (float)a * co * fs);
+                const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
+                if (x1 < 0 || y1 < 0 || x1 >= w || y1 >= h)
+                    continue;
+                const float ri = pLt[(size_t)y1 * w + x1], rx = pLx[(size_t)y1 * w + x1], ry = pLy[(size_t)y1 * w + x1];
+                di = di + ri;
+                const float rry = rx * co + ry * si, rrx = -rx * si + ry * co;
+                ddx = ddx + rrx;
+                ddy = ddy + rry;
+                ns++;
+            }
+        const float inv = (float)max(ns, 1);
+        vals[lane][0] = di / inv;
+        vals[lane][1] = ddx / inv;
+        vals[lane][2] = ddy / inv;
+    }
+    __syncthreads();
+    for (int wd = 0; wd < 8; wd++)
+    {
+        const int bit = wd * 64 + lane;
+        bool on = false;
+        if (bit < 486)
+            on = vals[tab->a[bit]][tab->ch[bit]] > vals[tab->b[bit]][tab->ch[bit]];
+        const unsigned long long word = __ballot(on);
+        if (lane == 0)
+            desc_out[slot * 8 + wd] = word;
+    }
+    if (lane == 0)
+    {
+        float *o = kp_out + slot * 6;
+        o[0] = kx;
+        o[1] = ky;
+        o[2] = size;
+        o[3] = angle;
+        o[4] = c.response;
+        o[5] = (float)c.level;
+        valid_out[slot] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------- host side
+std::vector<float> gaussian_taps(float sigma)
+{
+    int ksize = (int)std::ceil(2.0f * (1.0f + (sigma - 0.8f) / 0.3f));
+    if ((ksize % 2) == 0)
+        ksize += 1;
+    if (ksize < 1)
+        ksize = 1;
+    std::vector<double> k(ksize);
+    double sum = 0;
+    const int r = ksize / 2;
+    for (int i = 0; i < ksize; i++)
+    {
+        const double x = i - r;
+        k[i] = std::exp(-0.5 * x * x / ((double)sigma * sigma));
+        sum += k[i];
+    }
+    std::vector<float> out(ksize);
+    for (int i = 0; i < ksize; i++)
+        out[i] = (float)(k[i] / sum);
+    return out;
+}
+
+bool is_prime(int n)
+{
+    if (n < 2)
+        return false;
+    for (int d = 2; d * d <= n; d++)
+        if (n % d == 0)
+            return false;
+    return true;
+}
+
+std::vector<float> fed_taus(float T, float tau_max) // FED cycle for stopping time T, kappa-cycle reordering
+{
+    const double t = (double)T;
+    const int n = (int)(std::ceil(std::sqrt(3.0 * t / tau_max + 0.25) - 0.5 - 1.0e-8) + 0.5);
+    std::vector<float> tau;
+    if (n <= 0)
+        return tau;
+    const double scale = 3.0 * t / (tau_max * (double)(n * (n + 1)));
+    const double c = 1.0 / (4.0 * n + 2.0), d = scale * tau_max / 2.0;
+    std::vector<double> tauh(n);
+    for (int k = 0; k < n; k++)
+    {
+        const double hh = std::cos(M_PI * (2.0 * k + 1.0) * c);
+        tauh[k] = d / (hh * hh);
+    }
+    tau.resize(n);
+    const int kappa = n / 2;
+    int prime = n + 1;
+    while (!is_prime(prime))
+        prime++;
+    for (int k = 0, l = 0; l < n; ++k, ++l)
+    {
+        int index = 0;
+        while ((index = ((k + 1) * kappa) % prime - 1) >= n)
+            k++;
+        tau[l] = (float)tauh[index];
+    }
+    return tau;
+}
+
+struct area_tab
+{
+    std::vector<int> off, si;
+    std::vector<float> alpha;
+};
+area_tab area_table(int ssize, int dsize) // cv::resize INTER_AREA decimation table
+{
+    area_tab t;
+    const double scale = (double)ssize / dsize;
+    for (int dx = 0; dx < dsize; dx++)
+    {
+        t.off.push_back((int)t.si.size());
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3)
+        {
+            t.si.push_back(sx1 - 1);
+            t.alpha.push_back((float)((sx1 - fsx1) / cell));
+        }
+        for (int sx = sx1; sx < sx2; sx++)
+        {
+            t.si.push_back(sx);
+            t.alpha.push_back((float)(1.0 / cell));
+        }
+        if (fsx2 - sx2 > 1e-3)
+        {
+            t.si.push_back(sx2);
+            t.alpha.push_back((float)(std::min(std::min(fsx2 - sx2, 1.0), cell) / cell));
+        }
+    }
+    t.off.push_back((int)t.si.size());
+    return t;
+}
+
+template <typename T> int up(ochip_ctx *ctx, std::vector<void *> &allocs, T **dst, const T *src, size_t n)
+{
+    void *d = nullptr;
+    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc(%zu) failed in akaze", n * sizeof(T));
+    allocs.push_back(d);
+    if (src && n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+        return ochip_fail(ctx, OCHIP_EHIP, "hipMemcpy failed in akaze");
+    *dst = (T *)d;
+    return OCHIP_OK;
+}
+
+} // namespace
+
+extern "C"
+{
+
+// images: n_images x h x w x 3 BGR bytes (host).  Working size: the INTER_AREA downscale to max side 1600
+// of extract_features.cpp:26-27.  Outputs (host): per image up to max_kp keypoints, in unspecified order:
+// kp6 = {x, y, size, angle(rad), response, level} in working-image pixels, desc = 8 x u64, counts[i] = number
+// written for image i (<= max_kp).  work_wh receives the working width/height.
+int ochip_akaze_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
+                      uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh)
+{
+    if (!ctx || !counts || (n_images && (!images_bgr || !kp6 || !desc)))
+        return OCHIP_EINVAL;
+    if (width <= 0 || height <= 0)
+        return ochip_fail(ctx, OCHIP_EINVAL, "bad image size %d x %d", width, height);
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const double scale = std::min(1.f, float(1600) / (float)std::max(width, height));
+    const int W = (int)std::lrint(width * scale), H = (int)std::lrint(height * scale);
+    if (work_wh)
+    {
+        work_wh[0] = W;
+        work_wh[1] = H;
+    }
+    for (uint32_t i = 0; i < n_images; i++)
+        counts[i] = 0;
+    if (n_images == 0)
+        return OCHIP_OK;
+
+    // ---- level table (AKAZEFeatures::Allocate_Memory_Evolution)
+    const int omax = 4, nsub = 4;
+    const float soffset = 1.6f, dfactor = 1.5f, dthreshold = 0.00005f;
+    levels_dev LV{};
+    std::vector<std::vector<float>> tsteps;
+    size_t img_stride = 0;
+    {
+        std::vector<float> etime;
+        for (int i = 0; i < omax; i++)
+        {
+            const float rfactor = 1.0f / (float)(1 << i);
+            const int lw = (int)(W * rfactor), lh = (int)(H * rfactor);
+            if ((lw < 80 || lh < 80) && i != 0)
+                break;
+            for (int j = 0; j < nsub; j++)
+            {
+                level_info &l = LV.l[LV.n++];
+                l.octave = i;
+                l.w = lw;
+                l.h = lh;
+                l.esigma = soffset * std::pow(2.0f, (float)j / (float)nsub + (float)i);
+                l.sigma_size = (int)std::lrintf(l.esigma * dfactor / (float)(1 << i));
+                l.off = img_stride;
+                img_stride += (size_t)lw * lh;
+                etime.push_back(0.5f * (l.esigma * l.esigma));
+            }
+        }
+        tsteps.resize(LV.n);
+        for (int i = 1; i < LV.n; i++)
+            tsteps[i] = fed_taus(etime[i] - etime[i - 1], 0.25f);
+    }
+    const size_t plane0 = (size_t)W * H;
+    const uint32_t B = n_images;
+    const uint32_t max_cands = std::max<uint32_t>(max_kp * 4, 1u << 16);
+
+    std::vector<void *> allocs;
+    auto cleanup = [&]() {
+        for (void *a : allocs)
+            (void)hipFree(a);
+    };
+    int rc = OCHIP_OK;
+#define AK(call)                                                                                                       \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (rc == OCHIP_OK)                                                                                            \
+            rc = (call);                                                                                               \
+    } while (0)
+    uint8_t *d_bgr = nullptr, *d_gray = nullptr, *d_small = nullptr;
+    float *d_img = nullptr, *d_tmp = nullptr, *d_sm = nullptr, *d_flow = nullptr, *d_ping = nullptr;
+    float *d_Lt = nullptr, *d_Lx = nullptr, *d_Ly = nullptr, *d_Ldet = nullptr, *d_Rmax = nullptr, *d_kc = nullptr,
+          *d_gw = nullptr, *d_kp = nullptr;
+    unsigned int *d_hmax = nullptr, *d_hist = nullptr, *d_ncand = nullptr;
+    cand_t *d_cands = nullptr;
+    unsigned char *d_dead = nullptr, *d_valid = nullptr;
+    unsigned long long *d_desc = nullptr;
+    pair_tab *d_tab = nullptr;
+    const size_t src_px = (size_t)width * height;
+    AK(up(ctx, allocs, &d_bgr, images_bgr, (size_t)B * src_px * 3));
+    AK(up<uint8_t>(ctx, allocs, &d_gray, nullptr, (size_t)B * src_px));
+    AK(up<uint8_t>(ctx, allocs, &d_small, nullptr, (size_t)B * plane0));
+    AK(up<float>(ctx, allocs, &d_img, nullptr, (size_t)B * plane0));
+    AK(up<float>(ctx, allocs, &d_tmp, nullptr, (size_t)B * plane0));
+    AK(up<float>(ctx, allocs, &d_sm, nullptr, (size_t)B * plane0));
+    AK(up<float>(ctx, allocs, &d_flow, nullptr, (size_t)B * plane0));
+    AK(up<float>(ctx, allocs, &d_ping, nullptr, (size_t)B * plane0));
+    AK(up<float>(ctx, allocs, &d_Lt, nullptr, (size_t)B * img_stride));
+    AK(up<float>(ctx, allocs, &d_Lx, nullptr, (size_t)B * img_stride));
+    AK(up<float>(ctx, allocs, &d_Ly, nullptr, (size_t)B * img_stride));
+    AK(up<float>(ctx, allocs, &d_Ldet, nullptr, (size_t)B * img_stride));
+    AK(up<float>(ctx, allocs, &d_Rmax, nullptr, (size_t)B * img_stride));
+    AK(up<float>(ctx, allocs, &d_kc, nullptr, B));
+    AK(up<unsigned int>(ctx, allocs, &d_hmax, nullptr, B));
+    AK(up<unsigned int>(ctx, allocs, &d_hist, nullptr, (size_t)B * 301));
+    AK(up<unsigned int>(ctx, allocs, &d_ncand, nullptr, B));
+    AK(up<cand_t>(ctx, allocs, &d_cands, nullptr, (size_t)B * max_cands));
+    AK(up<unsigned char>(ctx, allocs, &d_dead, nullptr, (size_t)B * max_cands));
+    AK(up<unsigned char>(ctx, allocs, &d_valid, nullptr, (size_t)B * max_cands));
+    AK(up<float>(ctx, allocs, &d_kp, nullptr, (size_t)B * max_cands * 6));
+    AK(up<unsigned long long>(ctx, allocs, &d_desc, nullptr, (size_t)B * max_cands * 8));
+    {
+        std::vector<float> gw(169);
+        for (int i = -6; i <= 6; i++)
+            for (int j = -6; j <= 6; j++)
+                gw[(i + 6) * 13 + (j + 6)] =
+                    (float)(std::exp(-(double)(i * i + j * j) / (2.0 * 2.5 * 2.5)) / (2.0 * M_PI * 2.5 * 2.5));
+        AK(up(ctx, allocs, &d_gw, gw.data(), gw.size()));
+        pair_tab tab;
+        int dpos = 0;
+        const int base[3] = {0, 4, 13};
+        for (int lvl = 0; lvl < 3; lvl++)
+        {
+            const int nval = (lvl + 2) * (lvl + 2);
+            for (int ch = 0; ch < 3; ch++)
+                for (int a = 0; a < nval; a++)
+                    for (int bb = a + 1; bb < nval; bb++)
+                    {
+                        tab.a[dpos] = (unsigned char)(base[lvl] + a);
+                        tab.b[dpos] = (unsigned char)(base[lvl] + bb);
+                        tab.ch[dpos] = (unsigned char)ch;
+                        dpos++;
+                    }
+        }
+        AK(up(ctx, allocs, &d_tab, &tab, 1));
+    }
+    if (rc != OCHIP_OK)
+    {
+        cleanup();
+        return rc;
+    }
+    auto grid2 = [&](int w, int h) { return dim3((w + 255) / 256, h, B); };
+    auto taps_of = [](const std::vector<float> &k) {
+        taps_t t{};
+        t.n = (int)k.size();
+        for (int i = 0; i < t.n && i < MAX_TAPS; i++)
+            t.k[i] = k[i];
+        return t;
+    };
+    auto blur = [&](const float *in, size_t in_stride, float *out, size_t out_stride, int w, int h, const taps_t &t) {
+        hipLaunchKernelGGL(conv_kernel<true>, grid2(w, h), dim3(256), 0, st, in, d_tmp, w, h, in_stride, plane0, t);
+        hipLaunchKernelGGL(conv_kernel<false>, grid2(w, h), dim3(256), 0, st, (const float *)d_tmp, out, w, h, plane0,
+                           out_stride, t);
+    };
+    hipEvent_t e0, e1;
+    ochip_prof_begin(ctx, OCHIP_K_AKAZE, &e0, &e1);
+
+    // ---- grey, downscale, float
+    hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((B * src_px + 255) / 256)), dim3(256), 0, st, d_bgr, d_gray, B * src_px);
+    if (W == width && H == height)
+        OCHIP_HIP(ctx, hipMemcpyAsync(d_small, d_gray, B * src_px, hipMemcpyDeviceToDevice, st));
+    else
+    {
+        const area_tab tx = area_table(width, W), ty = area_table(height, H);
+        int *xo, *xs, *yo, *ys;
+        float *xa, *ya;
+        AK(up(ctx, allocs, &xo, tx.off.data(), tx.off.size()));
+        AK(up(ctx, allocs, &xs, tx.si.data(), tx.si.size()));
+        AK(up(ctx, allocs, &xa, tx.alpha.data(), tx.alpha.size()));
+        AK(up(ctx, allocs, &yo, ty.off.data(), ty.off.size()));
+        AK(up(ctx, allocs, &ys, ty.si.data(), ty.si.size()));
+        AK(up(ctx, allocs, &ya, ty.alpha.data(), ty.alpha.size()));
+        if (rc != OCHIP_OK)
+        {
+            cleanup();
+            return rc;
+        }
+        hipLaunchKernelGGL(resize_area_kernel, grid2(W, H), dim3(256), 0, st, d_gray, width, height, d_small, W, H, xo, xs,
+                           xa, yo, ys, ya);
+    }
+    hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)((B * plane0 + 255) / 256)), dim3(256), 0, st, d_small, d_img,
+                       B * plane0);
+
+    // ---- contrast factor
+    const taps_t g1 = taps_of(gaussian_taps(1.0f));
+    OCHIP_HIP(ctx, hipMemsetAsync(d_hmax, 0, B * 4, st));
+    OCHIP_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)B * 301 * 4, st));
+    blur(d_img, plane0, d_sm, plane0, W, H, g1);
+    hipLaunchKernelGGL(modg_kernel, grid2(W, H), dim3(256), 0, st, (const float *)d_sm, d_flow, W, H, plane0, d_hmax);
+    hipLaunchKernelGGL(hist_kernel, grid2(W, H), dim3(256), 0, st, (const float *)d_flow, W, H, plane0, d_hmax, 300, d_hist);
+    hipLaunchKernelGGL(kcontrast_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_hist, d_hmax, 300, 0.7f, d_kc, (int)B);
+
+    // ---- nonlinear scale space
+    blur(d_img, plane0, d_Lt + LV.l[0].off, img_stride, W, H, taps_of(gaussian_taps(soffset)));
+    int octave_steps = 0;
+    for (int i = 1; i < LV.n; i++)
+    {
+        const level_info &l = LV.l[i], &p = LV.l[i - 1];
+        float *cur = d_Lt + l.off;
+        const size_t np = (size_t)l.w * l.h;
+        if (l.octave > p.octave)
+        {
+            hipLaunchKernelGGL(halfsample_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Lt + p.off), p.w, p.h,
+                               img_stride, cur, l.w, l.h, img_stride);
+            octave_steps++;
+        }
+        else
+            hipLaunchKernelGGL(copy_plane_kernel, dim3((unsigned)((np + 255) / 256), 1, B), dim3(256), 0, st,
+                               (const float *)(d_Lt + p.off), img_stride, cur, img_stride, np);
+        blur(cur, img_stride, d_sm, plane0, l.w, l.h, g1);
+        hipLaunchKernelGGL(flow_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)d_sm, d_flow, l.w, l.h, plane0,
+                           (const float *)d_kc, octave_steps);
+        // FED inner steps, ping-pong between the level plane and a scratch plane
+        bool in_cur = true;
+        for (float tau : tsteps[i])
+        {
+            if (in_cur)
+                hipLaunchKernelGGL(nld_step_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)cur, (const float *)d_flow,
+                                   d_ping, l.w, l.h, img_stride, plane0, plane0, tau);
+            else
+                hipLaunchKernelGGL(nld_step_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)d_ping,
+                                   (const float *)d_flow, cur, l.w, l.h, plane0, plane0, img_stride, tau);
+            in_cur = !in_cur;
+        }
+        if (!in_cur) // odd number of steps: result sits in the scratch plane
+            hipLaunchKernelGGL(copy_plane_kernel, dim3((unsigned)((np + 255) / 256), 1, B), dim3(256), 0, st,
+                               (const float *)d_ping, plane0, cur, img_stride, np);
+    }
+    // ---- derivatives, determinant, maxima
+    OCHIP_HIP(ctx, hipMemsetAsync(d_ncand, 0, B * 4, st));
+    for (int i = 0; i < LV.n; i++)
+    {
+        const level_info &l = LV.l[i];
+        blur(d_Lt + l.off, img_stride, d_sm, plane0, l.w, l.h, g1);
+        hipLaunchKernelGGL(deriv_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)d_sm, plane0, d_Lx + l.off,
+                           d_Ly + l.off, img_stride, l.w, l.h, l.sigma_size);
+        hipLaunchKernelGGL(det_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Lx + l.off),
+                           (const float *)(d_Ly + l.off), img_stride, d_Ldet + l.off, l.w, l.h, l.sigma_size);
+        hipLaunchKernelGGL(maxima_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Ldet + l.off), d_Rmax + l.off,
+                           img_stride, l.w, l.h, i, dthreshold, d_cands, d_ncand, max_cands);
+    }
+    std::vector<unsigned int> ncand(B);
+    OCHIP_HIP(ctx, hipMemcpyAsync(ncand.data(), d_ncand, B * 4, hipMemcpyDeviceToHost, st));
+    OCHIP_HIP(ctx, hipStreamSynchronize(st));
+    unsigned int max_n = 0;
+    for (uint32_t b = 0; b < B; b++)
+    {
+        if (ncand[b] > max_cands)
+        {
+            cleanup();
+            return ochip_fail(ctx, OCHIP_ENOMEM, "image %u has %u extrema candidates; raise max_kp (candidate capacity %u)", b,
+                              ncand[b], max_cands);
+        }
+        max_n = std::max(max_n, ncand[b]);
+    }
+    if (max_n > 0)
+    {
+        hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 255) / 256, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
+                           (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride, LV, dfactor, d_dead);
+        hipLaunchKernelGGL(describe_kernel, dim3(max_n, 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
+                           (const unsigned int *)d_ncand, max_cands, (const unsigned char *)d_dead, (const float *)d_Lt,
+                           (const float *)d_Lx, (const float *)d_Ly, (const float *)d_Ldet, img_stride, LV, dfactor,
+                           (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid);
+    }
+    ochip_prof_end(ctx, OCHIP_K_AKAZE, e0, e1);
+    OCHIP_HIP(ctx, hipGetLastError());
+    // ---- compact on the host (keypoints are a few thousand per image)
+    std::vector<unsigned char> valid((size_t)max_n);
+    std::vector<float> kpb((size_t)max_n * 6);
+    std::vector<unsigned long long> db((size_t)max_n * 8);
+    for (uint32_t b = 0; b < B && rc == OCHIP_OK; b++)
+    {
+        const unsigned int n = ncand[b];
+        if (n == 0)
+            continue;
+        OCHIP_HIP(ctx, hipMemcpyAsync(valid.data(), d_valid + (size_t)b * max_cands, n, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(kpb.data(), d_kp + (size_t)b * max_cands * 6, (size_t)n * 24, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(db.data(), d_desc + (size_t)b * max_cands * 8, (size_t)n * 64, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        uint32_t cnt = 0;
+        for (unsigned int k = 0; k < n; k++)
+        {
+            if (!valid[k])
+                continue;
+            if (cnt >= max_kp)
+            {
+                rc = ochip_fail(ctx, OCHIP_ENOMEM, "image %u has more than max_kp = %u keypoints", b, max_kp);
+                break;
+            }
+            std::memcpy(kp6 + ((size_t)b * max_kp + cnt) * 6, &kpb[(size_t)k * 6], 24);
+            std::memcpy(desc + ((size_t)b * max_kp + cnt) * 8, &db[(size_t)k * 8], 64);
+            cnt++;
+        }
+        counts[b] = cnt;
+    }
+    cleanup();
+    return rc;
+#undef AK
+}
+
+} // extern "C"

@@ -1,0 +1,52 @@
+// Flat C driver API for the extract step (declared in include/oc_host.h).
+#include "../../../include/oc_host.h"
+
+#include "extract_features.hpp"
+
+#include <cstring>
+
+using namespace opencalibration_amd;
+
+static std::string g_extract_error;
+
+extern "C"
+{
+
+const char *och_extract_last_error(void)
+{
+    return g_extract_error.c_str();
+}
+
+// images: n x height x width x 3 BGR.  Per image up to max_out features are written at stride max_out:
+// loc (x,y full-resolution pixels), strength, desc (8 u64); counts[i] = features of image i,
+// num_sparse[i] = how many of them passed the 8 px NMS (they come first).  Returns 0 or -1.
+int och_extract_features_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
+                               uint32_t max_keypoints, uint32_t max_out, double *loc, float *strength, uint64_t *desc,
+                               uint32_t *counts, uint32_t *num_sparse)
+{
+    auto ex = extract_features_batch(ctx, images_bgr, n_images, width, height, max_keypoints, &g_extract_error);
+    if (ex.size() != n_images)
+        return -1;
+    for (uint32_t b = 0; b < n_images; b++)
+    {
+        const size_t n = ex[b].features.size();
+        if (n > max_out)
+        {
+            g_extract_error = "image " + std::to_string(b) + " produced " + std::to_string(n) + " features > max_out";
+            return -1;
+        }
+        counts[b] = (uint32_t)n;
+        num_sparse[b] = (uint32_t)ex[b].num_sparse_features;
+        for (size_t i = 0; i < n; i++)
+        {
+            const feature_2d &f = ex[b].features[i];
+            loc[((size_t)b * max_out + i) * 2] = f.location[0];
+            loc[((size_t)b * max_out + i) * 2 + 1] = f.location[1];
+            strength[(size_t)b * max_out + i] = f.strength;
+            std::memcpy(desc + ((size_t)b * max_out + i) * 8, f.descriptor, 64);
+        }
+    }
+    return 0;
+}
+
+} // extern "C"

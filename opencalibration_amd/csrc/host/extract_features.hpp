@@ -1,0 +1,26 @@
+// Host half of the extract step (reference: include/opencalibration/extract/extract_features.hpp:10-18).
+#pragma once
+
+#include "types.hpp"
+
+#include "../../../include/ochip.h"
+
+#include <string>
+
+namespace opencalibration_amd
+{
+
+struct extracted_features // extract_features.hpp:10-15
+{
+    std::vector<feature_2d> features;
+    size_t num_sparse_features = 0;
+};
+
+// extract_features(const cv::Mat&) for a batch of equally sized BGR images (n x height x width x 3 bytes):
+// grey + INTER_AREA downscale + AKAZE on the device (ochip_akaze_batch), then the host tail of
+// src/extract/extract_features.cpp:38-87: rescale to full-resolution pixels, std::sort by response, greedy
+// 8 px NMS, [sparse..., dense...].  On a device error returns an empty vector and sets *error.
+std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images,
+                                                       int width, int height, uint32_t max_keypoints, std::string *error);
+
+} // namespace opencalibration_amd

@@ -156,6 +156,36 @@ def make_grid(rows, cols, feats=4096, seed=12345, distractor_frac=0.3, flips=20,
         meta=dict(rows=rows, cols=cols, feats=feats, seed=seed, lattice_spacing_m=float(s)))
 
 
+def render_blobs(width, height, seed, n_blobs=None, shift=(0.0, 0.0), rot=0.0, channels=3):
+    """Synthetic 8-bit image for the extract stage: a fixed random field of Gaussian blobs (both polarities,
+    sigma 2..6 px) on mid-grey, viewed through a planar rigid motion (shift, rot) so that two renderings of one
+    seed are two views of the same scene.  Data only."""
+    rng = np.random.default_rng(seed)
+    n = n_blobs if n_blobs is not None else max(32, int(width * height / 768))
+    px = rng.uniform(-50, width + 50, n)
+    py = rng.uniform(-50, height + 50, n)
+    amp = rng.uniform(0.2, 0.8, n) * rng.choice([-1.0, 1.0], n)
+    sg = rng.uniform(2.0, 6.0, n)
+    c, s = np.cos(rot), np.sin(rot)
+    cx, cy = width / 2.0, height / 2.0
+    img = np.full((height, width), 0.5)
+    for i in range(n):
+        # scene position of the blob in this view: invert p = R (q - c) + c + shift
+        qx = c * (px[i] - cx - shift[0]) + s * (py[i] - cy - shift[1]) + cx
+        qy = -s * (px[i] - cx - shift[0]) + c * (py[i] - cy - shift[1]) + cy
+        r = int(np.ceil(4 * sg[i]))
+        x0, x1 = max(int(qx) - r, 0), min(int(qx) + r + 1, width)
+        y0, y1 = max(int(qy) - r, 0), min(int(qy) + r + 1, height)
+        if x0 >= x1 or y0 >= y1:
+            continue
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        img[y0:y1, x0:x1] += amp[i] * np.exp(-((xx - qx) ** 2 + (yy - qy) ** 2) / (2 * sg[i] ** 2))
+    g = np.clip(img * 255.0, 0, 255).astype(np.uint8)
+    if channels == 1:
+        return g
+    return np.ascontiguousarray(np.stack([g, g, g], axis=-1))
+
+
 CONFIGS = {  # BASELINE.md §3
     "C1": dict(rows=2, cols=5, feats=2048),
     "C2": dict(rows=10, cols=20, feats=4096),

@@ -1,0 +1,814 @@
+// ORACLE — test infrastructure only.  See akaze.hpp: restated AKAZE + extract_features, PARITY UNPINNED.
+#include "akaze.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+namespace oracle
+{
+namespace akaze
+{
+
+// ------------------------------------------------------------------------------------------ tables
+std::vector<float> gaussian_kernel(float sigma)
+{
+    int ksize = (int)std::ceil(2.0f * (1.0f + (sigma - 0.8f) / 0.3f));
+    if ((ksize % 2) == 0)
+        ksize += 1;
+    if (ksize < 1)
+        ksize = 1;
+    std::vector<double> k(ksize);
+    double sum = 0;
+    const int r = ksize / 2;
+    for (int i = 0; i < ksize; i++)
+    {
+        const double x = i - r;
+        k[i] = std::exp(-0.5 * x * x / ((double)sigma * sigma));
+        sum += k[i];
+    }
+    std::vector<float> out(ksize);
+    for (int i = 0; i < ksize; i++)
+        out[i] = (float)(k[i] / sum);
+    return out;
+}
+
+static bool is_prime(int n)
+{
+    if (n < 2)
+        return false;
+    for (int d = 2; d * d <= n; d++)
+        if (n % d == 0)
+            return false;
+    return true;
+}
+
+// fed.cpp of AKAZE: fed_tau_by_process_time -> fed_tau_by_cycle_time -> fed_tau_internal [3P]
+void fed_tau_by_process_time(float T, int M, float tau_max, bool reordering, std::vector<float> &tau)
+{
+    const double t = (double)T / M;
+    const int n = (int)(std::ceil(std::sqrt(3.0 * t / tau_max + 0.25) - 0.5 - 1.0e-8) + 0.5);
+    tau.clear();
+    if (n <= 0)
+        return;
+    const double scale = 3.0 * t / (tau_max * (double)(n * (n + 1)));
+    const double c = 1.0 / (4.0 * n + 2.0);
+    const double d = scale * tau_max / 2.0;
+    std::vector<double> tauh(n);
+    for (int k = 0; k < n; k++)
+    {
+        const double h = std::cos(M_PI * (2.0 * k + 1.0) * c);
+        tauh[k] = d / (h * h);
+    }
+    tau.resize(n);
+    if (!reordering)
+    {
+        for (int k = 0; k < n; k++)
+            tau[k] = (float)tauh[k];
+        return;
+    }
+    const int kappa = n / 2;
+    int prime = n + 1;
+    while (!is_prime(prime))
+        prime++;
+    for (int k = 0, l = 0; l < n; ++k, ++l)
+    {
+        int index = 0;
+        while ((index = ((k + 1) * kappa) % prime - 1) >= n)
+            k++;
+        tau[l] = (float)tauh[index];
+    }
+}
+
+std::vector<Level> make_levels(int width, int height, const Options &o)
+{
+    std::vector<Level> levels;
+    for (int i = 0; i < o.omax; i++)
+    {
+        const float rfactor = 1.0f / (float)(1 << i);
+        const int lw = (int)(width * rfactor), lh = (int)(height * rfactor);
+        if ((lw < 80 || lh < 80) && i != 0)
+            break;
+        for (int j = 0; j < o.nsublevels; j++)
+        {
+            Level l;
+            l.octave = i;
+            l.sublevel = j;
+            l.width = lw;
+            l.height = lh;
+            l.esigma = o.soffset * std::pow(2.0f, (float)j / (float)o.nsublevels + (float)i);
+            l.sigma_size = (int)std::lrintf(l.esigma * o.derivative_factor / (float)(1 << i));
+            l.etime = 0.5f * (l.esigma * l.esigma);
+            levels.push_back(l);
+        }
+    }
+    for (size_t i = 1; i < levels.size(); i++)
+        fed_tau_by_process_time(levels[i].etime - levels[i - 1].etime, 1, 0.25f, true, levels[i].tsteps);
+    return levels;
+}
+
+std::vector<float> orientation_weights()
+{
+    std::vector<float> w(13 * 13);
+    for (int i = -6; i <= 6; i++)
+        for (int j = -6; j <= 6; j++)
+            w[(i + 6) * 13 + (j + 6)] = (float)(std::exp(-(double)(i * i + j * j) / (2.0 * 2.5 * 2.5)) / (2.0 * M_PI * 2.5 * 2.5));
+    return w;
+}
+
+// ---------------------------------------------------------------------------- image building blocks
+void bgr_to_gray(const uint8_t *bgr, int w, int h, uint8_t *gray) // cv::cvtColor BGR2GRAY fixed point [3P]
+{
+    for (size_t i = 0; i < (size_t)w * h; i++)
+        gray[i] = (uint8_t)((bgr[3 * i] * 1868 + bgr[3 * i + 1] * 9617 + bgr[3 * i + 2] * 4899 + (1 << 13)) >> 14);
+}
+
+// cv::resize INTER_AREA, down-scaling, 8-bit single channel: overlap-weighted box average [3P]
+struct area_tab
+{
+    std::vector<int> si, di;
+    std::vector<float> alpha;
+};
+static area_tab area_table(int ssize, int dsize)
+{
+    area_tab t;
+    const double scale = (double)ssize / dsize;
+    for (int dx = 0; dx < dsize; dx++)
+    {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3)
+        {
+            t.si.push_back(sx1 - 1);
+            t.di.push_back(dx);
+            t.alpha.push_back((float)((sx1 - fsx1) / cell));
+        }
+        for (int sx = sx1; sx < sx2; sx++)
+        {
+            t.si.push_back(sx);
+            t.di.push_back(dx);
+            t.alpha.push_back((float)(1.0 / cell));
+        }
+        if (fsx2 - sx2 > 1e-3)
+        {
+            t.si.push_back(sx2);
+            t.di.push_back(dx);
+            t.alpha.push_back((float)(std::min(std::min(fsx2 - sx2, 1.0), cell) / cell));
+        }
+    }
+    return t;
+}
+void resize_area(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
+{
+    if (sw == dw && sh == dh)
+    {
+        std::memcpy(dst, src, (size_t)sw * sh);
+        return;
+    }
+    const area_tab tx = area_table(sw, dw), ty = area_table(sh, dh);
+    std::vector<float> acc((size_t)dw * dh, 0.0f), row(dw);
+    for (size_t e = 0; e < ty.si.size(); e++)
+    {
+        std::fill(row.begin(), row.end(), 0.0f);
+        const uint8_t *s = src + (size_t)ty.si[e] * sw;
+        for (size_t k = 0; k < tx.si.size(); k++)
+            row[tx.di[k]] += (float)s[tx.si[k]] * tx.alpha[k];
+        float *a = acc.data() + (size_t)ty.di[e] * dw;
+        for (int x = 0; x < dw; x++)
+            a[x] += row[x] * ty.alpha[e];
+    }
+    for (size_t i = 0; i < acc.size(); i++)
+    {
+        const long v = std::lrintf(acc[i]);
+        dst[i] = (uint8_t)std::min(255L, std::max(0L, v));
+    }
+}
+
+static inline int clampi(int v, int lo, int hi)
+{
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+static inline int reflect101(int v, int n)
+{
+    if (n == 1)
+        return 0;
+    while (v < 0 || v >= n)
+        v = v < 0 ? -v : 2 * (n - 1) - v;
+    return v;
+}
+
+// separable Gaussian, rows then columns, BORDER_REPLICATE, taps accumulated in ascending order
+static void gaussian_blur(const std::vector<float> &in, std::vector<float> &out, int w, int h, const std::vector<float> &k)
+{
+    const int n = (int)k.size(), r = n / 2;
+    std::vector<float> tmp((size_t)w * h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            float acc = 0.0f;
+            for (int t = 0; t < n; t++)
+                acc = acc + k[t] * in[(size_t)y * w + clampi(x + t - r, 0, w - 1)];
+            tmp[(size_t)y * w + x] = acc;
+        }
+    out.resize((size_t)w * h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            float acc = 0.0f;
+            for (int t = 0; t < n; t++)
+                acc = acc + k[t] * tmp[(size_t)clampi(y + t - r, 0, h - 1) * w + x];
+            out[(size_t)y * w + x] = acc;
+        }
+}
+
+// unnormalised 3x3 Scharr (cv::Scharr scale 1), BORDER_REFLECT_101
+static inline void scharr3(const float *I, int w, int h, int x, int y, float *lx, float *ly)
+{
+    const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w), ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+    const float a = I[(size_t)ym * w + xp] - I[(size_t)ym * w + xm];
+    const float b = I[(size_t)y * w + xp] - I[(size_t)y * w + xm];
+    const float c = I[(size_t)yp * w + xp] - I[(size_t)yp * w + xm];
+    *lx = (3.0f * a + 10.0f * b) + 3.0f * c;
+    const float d = I[(size_t)yp * w + xm] - I[(size_t)ym * w + xm];
+    const float e = I[(size_t)yp * w + x] - I[(size_t)ym * w + x];
+    const float f = I[(size_t)yp * w + xp] - I[(size_t)ym * w + xp];
+    *ly = (3.0f * d + 10.0f * e) + 3.0f * f;
+}
+
+float compute_k_percentile(const std::vector<float> &img, int w, int h, const Options &o)
+{
+    std::vector<float> sm;
+    gaussian_blur(img, sm, w, h, gaussian_kernel(1.0f));
+    float hmax = 0.0f;
+    std::vector<float> modg((size_t)w * h, 0.0f);
+    for (int y = 1; y < h - 1; y++)
+        for (int x = 1; x < w - 1; x++)
+        {
+            float lx, ly;
+            scharr3(sm.data(), w, h, x, y, &lx, &ly);
+            const float m = std::sqrt(lx * lx + ly * ly);
+            modg[(size_t)y * w + x] = m;
+            if (m > hmax)
+                hmax = m;
+        }
+    const int nbins = o.kcontrast_nbins;
+    std::vector<int> hist(nbins, 0);
+    int npoints = 0;
+    for (int y = 1; y < h - 1; y++)
+        for (int x = 1; x < w - 1; x++)
+        {
+            const float m = modg[(size_t)y * w + x];
+            if (m != 0.0f)
+            {
+                int nbin = (int)std::floor((float)nbins * (m / hmax));
+                if (nbin == nbins)
+                    nbin--;
+                hist[nbin]++;
+                npoints++;
+            }
+        }
+    const int nthreshold = (int)((float)npoints * o.kcontrast_percentile);
+    int nelements = 0, k = 0;
+    for (k = 0; nelements < nthreshold && k < nbins; k++)
+        nelements += hist[k];
+    if (nelements < nthreshold)
+        return 0.03f;
+    return hmax * ((float)k / (float)nbins);
+}
+
+static void pm_g2_flow(const std::vector<float> &sm, std::vector<float> &flow, int w, int h, float k)
+{
+    flow.resize((size_t)w * h);
+    const float inv = 1.0f / (k * k);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            float lx, ly;
+            scharr3(sm.data(), w, h, x, y, &lx, &ly);
+            flow[(size_t)y * w + x] = 1.0f / (1.0f + inv * (lx * lx + ly * ly));
+        }
+}
+
+static void nld_step(const std::vector<float> &L, const std::vector<float> &c, std::vector<float> &out, int w, int h, float tau)
+{
+    out.resize((size_t)w * h);
+    const float half = 0.5f * tau;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            const size_t i = (size_t)y * w + x;
+            const float xpos = x + 1 < w ? (c[i] + c[i + 1]) * (L[i + 1] - L[i]) : 0.0f;
+            const float xneg = x > 0 ? (c[i - 1] + c[i]) * (L[i] - L[i - 1]) : 0.0f;
+            const float ypos = y + 1 < h ? (c[i] + c[i + w]) * (L[i + w] - L[i]) : 0.0f;
+            const float yneg = y > 0 ? (c[i - w] + c[i]) * (L[i] - L[i - w]) : 0.0f;
+            out[i] = L[i] + half * ((xpos - xneg) + (ypos - yneg));
+        }
+}
+
+static void halfsample(const std::vector<float> &in, int w, int h, std::vector<float> &out, int ow, int oh)
+{
+    out.resize((size_t)ow * oh);
+    for (int y = 0; y < oh; y++)
+        for (int x = 0; x < ow; x++)
+        {
+            const int x0 = std::min(2 * x, w - 1), x1 = std::min(2 * x + 1, w - 1);
+            const int y0 = std::min(2 * y, h - 1), y1 = std::min(2 * y + 1, h - 1);
+            out[(size_t)y * ow + x] = ((in[(size_t)y0 * w + x0] + in[(size_t)y0 * w + x1]) +
+                                       (in[(size_t)y1 * w + x0] + in[(size_t)y1 * w + x1])) *
+                                      0.25f;
+        }
+}
+
+// first derivatives at integer scale s: Scharr-like 3-tap kernels spread to distance s, reflect101
+static void deriv_scale(const std::vector<float> &I, std::vector<float> &Dx, std::vector<float> &Dy, int w, int h, int s)
+{
+    const float wgt = 10.0f / 3.0f;
+    const float nrm = 1.0f / (2.0f * (float)s * (wgt + 2.0f));
+    const float wn = wgt * nrm;
+    Dx.resize((size_t)w * h);
+    Dy.resize((size_t)w * h);
+    for (int y = 0; y < h; y++)
+    {
+        const int ym = reflect101(y - s, h), yp = reflect101(y + s, h);
+        for (int x = 0; x < w; x++)
+        {
+            const int xm = reflect101(x - s, w), xp = reflect101(x + s, w);
+            const float a = I[(size_t)ym * w + xp] - I[(size_t)ym * w + xm];
+            const float b = I[(size_t)y * w + xp] - I[(size_t)y * w + xm];
+            const float c = I[(size_t)yp * w + xp] - I[(size_t)yp * w + xm];
+            Dx[(size_t)y * w + x] = (nrm * a + wn * b) + nrm * c;
+            const float d = I[(size_t)yp * w + xm] - I[(size_t)ym * w + xm];
+            const float e = I[(size_t)yp * w + x] - I[(size_t)ym * w + x];
+            const float f = I[(size_t)yp * w + xp] - I[(size_t)ym * w + xp];
+            Dy[(size_t)y * w + x] = (nrm * d + wn * e) + nrm * f;
+        }
+    }
+}
+
+ScaleSpace build_scale_space(const std::vector<float> &img, int w, int h, const Options &o)
+{
+    ScaleSpace ss;
+    ss.levels = make_levels(w, h, o);
+    const size_t N = ss.levels.size();
+    ss.Lt.resize(N);
+    ss.Lx.resize(N);
+    ss.Ly.resize(N);
+    ss.Ldet.resize(N);
+    gaussian_blur(img, ss.Lt[0], w, h, gaussian_kernel(o.soffset));
+    float kcontrast = compute_k_percentile(img, w, h, o);
+    ss.kcontrast = kcontrast;
+    const std::vector<float> g1 = gaussian_kernel(o.sderivatives);
+    std::vector<float> sm, flow, nxt;
+    for (size_t i = 1; i < N; i++)
+    {
+        const Level &l = ss.levels[i], &p = ss.levels[i - 1];
+        if (l.octave > p.octave)
+        {
+            halfsample(ss.Lt[i - 1], p.width, p.height, ss.Lt[i], l.width, l.height);
+            kcontrast = kcontrast * 0.75f;
+        }
+        else
+            ss.Lt[i] = ss.Lt[i - 1];
+        gaussian_blur(ss.Lt[i], sm, l.width, l.height, g1);
+        pm_g2_flow(sm, flow, l.width, l.height, kcontrast);
+        for (float tau : l.tsteps)
+        {
+            nld_step(ss.Lt[i], flow, nxt, l.width, l.height, tau);
+            ss.Lt[i].swap(nxt);
+        }
+    }
+    std::vector<float> lxx, lxy, lyy, tmp;
+    for (size_t i = 0; i < N; i++)
+    {
+        const Level &l = ss.levels[i];
+        gaussian_blur(ss.Lt[i], sm, l.width, l.height, g1);
+        deriv_scale(sm, ss.Lx[i], ss.Ly[i], l.width, l.height, l.sigma_size);
+        deriv_scale(ss.Lx[i], lxx, lxy, l.width, l.height, l.sigma_size);
+        deriv_scale(ss.Ly[i], tmp, lyy, l.width, l.height, l.sigma_size);
+        const float s4 = (float)(l.sigma_size * l.sigma_size * l.sigma_size * l.sigma_size);
+        ss.Ldet[i].resize(lxx.size());
+        for (size_t k = 0; k < lxx.size(); k++)
+            ss.Ldet[i][k] = (lxx[k] * lyy[k] - lxy[k] * lxy[k]) * s4;
+    }
+    return ss;
+}
+
+// ------------------------------------------------------------------------ float-only math helpers
+// (deterministic across CPU and GPU: only + - * / and comparisons)
+static const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f, HALF_PI_F = 1.57079632679489661923f;
+
+float fast_atan2(float y, float x) // cv::fastAtan2's polynomial, radians in [0, 2 pi)
+{
+    const float p1 = 0.9997878412794807f, p3 = -0.3258083974640975f, p5 = 0.1555786518463281f, p7 = -0.04432655554792128f;
+    const float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay)
+    {
+        c = ay / (ax + 2.220446e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    else
+    {
+        c = ax / (ay + 2.220446e-16f);
+        c2 = c * c;
+        a = HALF_PI_F - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0)
+        a = PI_F - a;
+    if (y < 0)
+        a = TWO_PI_F - a;
+    return a;
+}
+
+void sincos_poly(float a, float *s, float *c) // a in [0, 2 pi): quadrant reduction + Taylor polynomials
+{
+    int q = (int)(a / HALF_PI_F);
+    if (q > 3)
+        q = 3;
+    float r = a - (float)q * HALF_PI_F; // [0, pi/2)
+    bool swap = false;
+    if (r > 0.78539816339744830962f)
+    {
+        r = HALF_PI_F - r;
+        swap = true;
+    }
+    const float r2 = r * r;
+    float sn = r * (1.0f + r2 * (-1.0f / 6.0f + r2 * (1.0f / 120.0f + r2 * (-1.0f / 5040.0f + r2 * (1.0f / 362880.0f)))));
+    float cs = 1.0f + r2 * (-0.5f + r2 * (1.0f / 24.0f + r2 * (-1.0f / 720.0f + r2 * (1.0f / 40320.0f))));
+    if (swap)
+        std::swap(sn, cs);
+    switch (q)
+    {
+    case 0:
+        *s = sn, *c = cs;
+        break;
+    case 1:
+        *s = cs, *c = -sn;
+        break;
+    case 2:
+        *s = -sn, *c = -cs;
+        break;
+    default:
+        *s = -cs, *c = sn;
+        break;
+    }
+}
+
+// --------------------------------------------------------------------------------- detect + describe
+struct cand
+{
+    int level, x, y;
+    float response;
+};
+
+std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o)
+{
+    const size_t N = ss.levels.size();
+    // 1. per-level 3x3 maxima above the threshold
+    std::vector<cand> cands;
+    for (size_t i = 0; i < N; i++)
+    {
+        const Level &l = ss.levels[i];
+        const float *D = ss.Ldet[i].data();
+        const int w = l.width, h = l.height;
+        for (int y = 1; y < h - 1; y++)
+            for (int x = 1; x < w - 1; x++)
+            {
+                const float v = D[(size_t)y * w + x];
+                if (!(v > o.dthreshold))
+                    continue;
+                bool mx = true;
+                for (int dy = -1; dy <= 1 && mx; dy++)
+                    for (int dx = -1; dx <= 1; dx++)
+                        if ((dx || dy) && !(v > D[(size_t)(y + dy) * w + x + dx]))
+                        {
+                            mx = false;
+                            break;
+                        }
+                if (mx)
+                    cands.push_back(cand{(int)i, x, y, v});
+            }
+    }
+    // 2. scale-space suppression: a candidate dies if a stronger one (ties: lower (level,y,x) wins) of
+    //    an adjacent level lies within its own size (esigma * derivative_factor, base-image pixels)
+    std::vector<char> dead(cands.size(), 0);
+    {
+        std::map<std::pair<int, int>, std::vector<int>> grid; // 32 px buckets in base coordinates
+        auto bx = [&](const cand &c) { return (float)c.x * (float)(1 << ss.levels[c.level].octave); };
+        auto by = [&](const cand &c) { return (float)c.y * (float)(1 << ss.levels[c.level].octave); };
+        for (size_t k = 0; k < cands.size(); k++)
+            grid[{(int)(bx(cands[k]) / 32.0f), (int)(by(cands[k]) / 32.0f)}].push_back((int)k);
+        for (size_t k = 0; k < cands.size(); k++)
+        {
+            const cand &c = cands[k];
+            const float rad = ss.levels[c.level].esigma * o.derivative_factor, r2 = rad * rad;
+            const float cx = bx(c), cy = by(c);
+            const int gx0 = (int)((cx - rad) / 32.0f) - 1, gx1 = (int)((cx + rad) / 32.0f) + 1;
+            const int gy0 = (int)((cy - rad) / 32.0f) - 1, gy1 = (int)((cy + rad) / 32.0f) + 1;
+            for (int gy = gy0; gy <= gy1 && !dead[k]; gy++)
+                for (int gx = gx0; gx <= gx1 && !dead[k]; gx++)
+                {
+                    auto it = grid.find({gx, gy});
+                    if (it == grid.end())
+                        continue;
+                    for (int m : it->second)
+                    {
+                        if ((size_t)m == k)
+                            continue;
+                        const cand &d = cands[m];
+                        if (std::abs(d.level - c.level) > 1)
+                            continue;
+                        const float ex = bx(d) - cx, ey = by(d) - cy;
+                        if (!(ex * ex + ey * ey <= r2))
+                            continue;
+                        const bool stronger = d.response > c.response ||
+                                              (d.response == c.response &&
+                                               std::make_tuple(d.level, d.y, d.x) < std::make_tuple(c.level, c.y, c.x));
+                        if (stronger)
+                        {
+                            dead[k] = 1;
+                            break;
+                        }
+                    }
+                }
+        }
+    }
+    // 3. sub-pixel fit, orientation, descriptor
+    const std::vector<float> gw = orientation_weights();
+    std::vector<Keypoint> out;
+    for (size_t k = 0; k < cands.size(); k++)
+    {
+        if (dead[k])
+            continue;
+        const cand &c = cands[k];
+        const Level &l = ss.levels[c.level];
+        const int w = l.width, h = l.height;
+        const float *D = ss.Ldet[c.level].data();
+        auto at = [&](int x, int y) { return D[(size_t)y * w + x]; };
+        const float Dx = 0.5f * (at(c.x + 1, c.y) - at(c.x - 1, c.y));
+        const float Dy = 0.5f * (at(c.x, c.y + 1) - at(c.x, c.y - 1));
+        const float Dxx = (at(c.x + 1, c.y) + at(c.x - 1, c.y)) - 2.0f * at(c.x, c.y);
+        const float Dyy = (at(c.x, c.y + 1) + at(c.x, c.y - 1)) - 2.0f * at(c.x, c.y);
+        const float Dxy = 0.25f * ((at(c.x + 1, c.y + 1) + at(c.x - 1, c.y - 1)) - (at(c.x - 1, c.y + 1) + at(c.x + 1, c.y - 1)));
+        const float det = Dxx * Dyy - Dxy * Dxy;
+        if (det == 0.0f)
+            continue;
+        const float dx = (Dxy * Dy - Dyy * Dx) / det; // solves [Dxx Dxy; Dxy Dyy] d = -[Dx Dy]
+        const float dy = (Dxy * Dx - Dxx * Dy) / det;
+        if (!(std::fabs(dx) <= 1.0f && std::fabs(dy) <= 1.0f))
+            continue;
+        const float ratio = (float)(1 << l.octave);
+        Keypoint kp;
+        kp.x = ((float)c.x + dx) * ratio + 0.5f * (ratio - 1.0f);
+        kp.y = ((float)c.y + dy) * ratio + 0.5f * (ratio - 1.0f);
+        kp.size = 2.0f * (l.esigma * o.derivative_factor);
+        kp.response = c.response;
+        kp.level = c.level;
+        kp.octave = l.octave;
+        const float *Lt = ss.Lt[c.level].data(), *Lx = ss.Lx[c.level].data(), *Ly = ss.Ly[c.level].data();
+        const float xf = kp.x / ratio, yf = kp.y / ratio;
+        const int s = (int)std::lrintf(0.5f * kp.size / ratio);
+        // dominant orientation: 109 samples in a radius-6 disc, pi/3 sliding window
+        float resX[109], resY[109], Ang[109];
+        int idx = 0;
+        for (int i = -6; i <= 6; i++)
+            for (int j = -6; j <= 6; j++)
+                if (i * i + j * j < 36)
+                {
+                    const int iy = clampi((int)std::lrintf(yf + (float)(j * s)), 0, h - 1);
+                    const int ix = clampi((int)std::lrintf(xf + (float)(i * s)), 0, w - 1);
+                    const float g = gw[(i + 6) * 13 + (j + 6)];
+                    resX[idx] = g * Lx[(size_t)iy * w + ix];
+                    resY[idx] = g * Ly[(size_t)iy * w + ix];
+                    Ang[idx] = fast_atan2(resY[idx], resX[idx]);
+                    idx++;
+                }
+        float best = 0.0f, angle = 0.0f;
+        for (int step = 0; step < 42; step++)
+        {
+            const float ang1 = 0.15f * (float)step;
+            const float ang2 = (ang1 + PI_F / 3.0f > TWO_PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
+            float sumX = 0.0f, sumY = 0.0f;
+            for (int q = 0; q < 109; q++)
+            {
+                const float a = Ang[q];
+                if ((ang1 < ang2 && ang1 < a && a < ang2) ||
+                    (ang2 < ang1 && ((a > 0.0f && a < ang2) || (a > ang1 && a < TWO_PI_F))))
+                {
+                    sumX = sumX + resX[q];
+                    sumY = sumY + resY[q];
+                }
+            }
+            const float m = sumX * sumX + sumY * sumY;
+            if (m > best)
+            {
+                best = m;
+                angle = fast_atan2(sumY, sumX);
+            }
+        }
+        kp.angle = angle;
+        // M-LDB, 3 channels, grids 2x2 / 3x3 / 4x4 over [-10, 10) * scale, rotated by the orientation
+        float si, co;
+        sincos_poly(angle, &si, &co);
+        std::memset(kp.desc, 0, sizeof kp.desc);
+        int dpos = 0;
+        const int P = o.descriptor_pattern_size;
+        const float fs = (float)s;
+        for (int lvl = 0; lvl < 3; lvl++)
+        {
+            const int g = lvl + 2, nval = g * g;
+            const int step = (int)std::ceil((float)(P * 2) / (float)g);
+            float vals[16][3];
+            int cell = 0;
+            for (int i = -P; i < P; i += step)
+                for (int j = -P; j < P; j += step)
+                {
+                    float di = 0.0f, ddx = 0.0f, ddy = 0.0f;
+                    int ns = 0;
+                    for (int a = i; a < i + step; a++)
+                        for (int b = j; b < j + step; b++)
+                        {
+                            const float sy = yf + ((float)b * co * fs + (float)a * si * fs);
+                            const float sx = xf + (-(float)b * si * fs + (float)a * co * fs);
+                            const int y1 = (int)std::lrintf(sy), x1 = (int)std::lrintf(sx);
+                            if (x1 < 0 || y1 < 0 || x1 >= w || y1 >= h)
+                                continue;
+                            const float ri = Lt[(size_t)y1 * w + x1], rx = Lx[(size_t)y1 * w + x1], ry = Ly[(size_t)y1 * w + x1];
+                            di = di + ri;
+                            const float rry = rx * co + ry * si, rrx = -rx * si + ry * co;
+                            ddx = ddx + rrx;
+                            ddy = ddy + rry;
+                            ns++;
+                        }
+                    const float inv = (float)std::max(ns, 1);
+                    vals[cell][0] = di / inv;
+                    vals[cell][1] = ddx / inv;
+                    vals[cell][2] = ddy / inv;
+                    cell++;
+                }
+            for (int ch = 0; ch < 3; ch++)
+                for (int a = 0; a < nval; a++)
+                    for (int b = a + 1; b < nval; b++)
+                    {
+                        if (vals[a][ch] > vals[b][ch])
+                            kp.desc[dpos >> 6] |= (uint64_t)1 << (dpos & 63);
+                        dpos++;
+                    }
+        }
+        out.push_back(kp);
+    }
+    return out;
+}
+
+Extracted extract_features(const uint8_t *bgr, int w, int h) // src/extract/extract_features.cpp:11-88
+{
+    Extracted ex;
+    if (w <= 0 || h <= 0)
+        return ex;
+    std::vector<uint8_t> gray((size_t)w * h);
+    bgr_to_gray(bgr, w, h, gray.data());
+    const double scale = std::min(1.f, float(1600) / (float)std::max(w, h));
+    const int sw = (int)std::lrint(w * scale), sh = (int)std::lrint(h * scale);
+    std::vector<uint8_t> small((size_t)sw * sh);
+    resize_area(gray.data(), w, h, small.data(), sw, sh);
+    std::vector<float> img((size_t)sw * sh);
+    for (size_t i = 0; i < img.size(); i++)
+        img[i] = (float)small[i] * (1.0f / 255.0f);
+    Options o;
+    const ScaleSpace ss = build_scale_space(img, sw, sh, o);
+    const std::vector<Keypoint> kps = detect_and_describe(ss, o);
+
+    struct feat
+    {
+        double x, y;
+        float strength;
+        uint64_t d[8];
+    };
+    std::vector<feat> f(kps.size());
+    for (size_t i = 0; i < kps.size(); i++)
+    {
+        f[i].x = kps[i].x / scale;
+        f[i].y = kps[i].y / scale;
+        f[i].strength = kps[i].response;
+        std::memcpy(f[i].d, kps[i].desc, 64);
+    }
+    std::sort(f.begin(), f.end(), [](const feat &a, const feat &b) -> bool { return a.strength > b.strength; });
+    // NMS, radius 8 px in the scaled image; note the first keypoint is seeded into the tree AND visited by
+    // the loop, so it re-appears at the head of the dense list (faithful to :63-83)
+    std::vector<feat> results, dense;
+    std::vector<std::pair<double, double>> kept;
+    auto nearest2 = [&](double x, double y) {
+        double best = std::numeric_limits<double>::infinity();
+        for (auto &p : kept)
+        {
+            const double dx = x - p.first, dy = y - p.second;
+            double d = 0;
+            d += dx * dx;
+            d += dy * dy;
+            best = std::min(best, d);
+        }
+        return best;
+    };
+    if (!f.empty())
+    {
+        kept.emplace_back(f[0].x, f[0].y);
+        results.push_back(f[0]);
+    }
+    for (const feat &p : f)
+    {
+        if (nearest2(p.x, p.y) * (scale * scale) > 64.0)
+        {
+            kept.emplace_back(p.x, p.y);
+            results.push_back(p);
+        }
+        else
+            dense.push_back(p);
+    }
+    ex.num_sparse = results.size();
+    results.insert(results.end(), dense.begin(), dense.end());
+    for (const feat &p : results)
+    {
+        ex.loc.push_back(p.x);
+        ex.loc.push_back(p.y);
+        ex.strength.push_back(p.strength);
+        ex.desc.insert(ex.desc.end(), p.d, p.d + 8);
+    }
+    return ex;
+}
+
+} // namespace akaze
+} // namespace oracle
+
+using namespace oracle::akaze;
+
+extern "C"
+{
+
+// keypoints: n x {x, y, size, angle, response, level}; desc n x 8; returns n (capped at max_kp)
+size_t oc_akaze(const uint8_t *gray, int w, int h, size_t max_kp, float *kp6, uint64_t *desc, float *kcontrast)
+{
+    std::vector<float> img((size_t)w * h);
+    for (size_t i = 0; i < img.size(); i++)
+        img[i] = (float)gray[i] * (1.0f / 255.0f);
+    Options o;
+    const ScaleSpace ss = build_scale_space(img, w, h, o);
+    if (kcontrast)
+        *kcontrast = ss.kcontrast;
+    const std::vector<Keypoint> kps = detect_and_describe(ss, o);
+    const size_t n = std::min(kps.size(), max_kp);
+    for (size_t i = 0; i < n; i++)
+    {
+        kp6[6 * i] = kps[i].x;
+        kp6[6 * i + 1] = kps[i].y;
+        kp6[6 * i + 2] = kps[i].size;
+        kp6[6 * i + 3] = kps[i].angle;
+        kp6[6 * i + 4] = kps[i].response;
+        kp6[6 * i + 5] = (float)kps[i].level;
+        std::memcpy(desc + 8 * i, kps[i].desc, 64);
+    }
+    return kps.size();
+}
+
+// level images for stage-by-stage parity: which = 0 Lt, 1 Lx, 2 Ly, 3 Ldet; returns w*h of the level
+size_t oc_akaze_level(const uint8_t *gray, int w, int h, int level, int which, float *out, int *lw, int *lh)
+{
+    std::vector<float> img((size_t)w * h);
+    for (size_t i = 0; i < img.size(); i++)
+        img[i] = (float)gray[i] * (1.0f / 255.0f);
+    Options o;
+    const ScaleSpace ss = build_scale_space(img, w, h, o);
+    if (level < 0 || level >= (int)ss.levels.size())
+        return 0;
+    const std::vector<float> &src = which == 0 ? ss.Lt[level] : which == 1 ? ss.Lx[level] : which == 2 ? ss.Ly[level] : ss.Ldet[level];
+    std::memcpy(out, src.data(), src.size() * 4);
+    *lw = ss.levels[level].width;
+    *lh = ss.levels[level].height;
+    return src.size();
+}
+
+size_t oc_extract_features(const uint8_t *bgr, int w, int h, size_t max_n, double *loc, float *strength, uint64_t *desc,
+                           uint64_t *num_sparse)
+{
+    const Extracted ex = extract_features(bgr, w, h);
+    const size_t n = std::min(ex.strength.size(), max_n);
+    std::memcpy(loc, ex.loc.data(), n * 16);
+    std::memcpy(strength, ex.strength.data(), n * 4);
+    std::memcpy(desc, ex.desc.data(), n * 64);
+    *num_sparse = ex.num_sparse;
+    return ex.strength.size();
+}
+
+void oc_gray_resize(const uint8_t *bgr, int w, int h, uint8_t *out, int ow, int oh)
+{
+    std::vector<uint8_t> gray((size_t)w * h);
+    bgr_to_gray(bgr, w, h, gray.data());
+    resize_area(gray.data(), w, h, out, ow, oh);
+}
+
+} // extern "C"

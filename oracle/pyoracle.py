@@ -64,8 +64,46 @@ def lib():
         L.oc_robust_centroid.argtypes = [f64p, C.c_int, C.c_double, f64p]
         L.oc_plane_intersection_cost.restype = C.c_int
         L.oc_plane_intersection_cost.argtypes = [f64p, f64p, f64p, f64p, f64p, f64p, f64p, vp]
+        f32p_ = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        L.oc_akaze.restype = C.c_size_t
+        L.oc_akaze.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, f32p_, u64p, vp]
+        L.oc_akaze_level.restype = C.c_size_t
+        L.oc_akaze_level.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, f32p_, vp, vp]
+        L.oc_extract_features.restype = C.c_size_t
+        L.oc_extract_features.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, f64p, f32p_, u64p, u64p]
+        L.oc_gray_resize.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
         _LIB = L
     return _LIB
+
+
+def akaze(gray, max_kp=50000):
+    """Restated AKAZE on an 8-bit grey image: (kp6 [x, y, size, angle, response, level], desc [n x 8])."""
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    kp = np.zeros((max_kp, 6), np.float32)
+    d = np.zeros((max_kp, 8), np.uint64)
+    n = lib().oc_akaze(gray, w, h, max_kp, kp, d, None)
+    assert n <= max_kp
+    return kp[:n].copy(), d[:n].copy()
+
+
+def extract_features(bgr, max_n=100000):
+    """extract_features(cv::Mat) restated: (loc [n x 2] f64 full-res pixels, strength, desc, num_sparse)."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    loc, st, d = np.zeros((max_n, 2)), np.zeros(max_n, np.float32), np.zeros((max_n, 8), np.uint64)
+    ns = np.zeros(1, np.uint64)
+    n = lib().oc_extract_features(bgr, w, h, max_n, loc, st, d, ns)
+    assert n <= max_n
+    return loc[:n].copy(), st[:n].copy(), d[:n].copy(), int(ns[0])
+
+
+def gray_resize(bgr, ow, oh):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    out = np.zeros((oh, ow), np.uint8)
+    lib().oc_gray_resize(bgr, w, h, out, ow, oh)
+    return out
 
 
 def pack_edges(edges):
