@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py — images/sec of the opencalibration hot path on MI355X (BASELINE.json metric).
+"""bench.py — images/sec end-to-end (extract + match + relax) of the opencalibration hot path on MI355X
+(BASELINE.json metric), plus LM iters/sec.
 
-One "step" = one pass of the hot path over one synthetic aerial grid whose features are already
-extracted (the stand-in for extract_features output): LinkStage init -> device Hamming 2-NN ->
-host ratio/sort -> device RANSAC -> decompose/accept -> finalize, for every directed kNN(10) pair.
-N > 1: one process per GPU (torch.distributed, RCCL), each rank links its own grid of the same
-shape (pairs are independent units: no data-path collective), value = total images / max time.
+One "step" = one pass of the hot path over one synthetic aerial grid (default C3: 1 000 images, 25x40 grid):
+  extract   AKAZE features of every 4000x3000 view (views are rendered into HBM before the timed region)
+  link      kNN(10) pairs: 40 px subsample -> Hamming 2-NN -> ratio/sort -> homography RANSAC -> decompose
+  relax     ground-plane bundle adjustment of all cameras as one group (Levenberg-Marquardt)
+N > 1: one process per GPU (torch.distributed over RCCL), every rank runs its own grid of the same shape
+(image pairs / surveys are independent units: no data-path collective), value = total images / max time.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant device kernel (the Hamming 2-NN
-kernel) timed with HIP events on the stream it is launched on; `cpu_baseline` is the CPU
-restatement (oracle/) timed on this box's host cores on a bounded sample of the same workload.
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant device kernel, timed with HIP events on
+the stream it is launched on; `cpu_baseline` is the CPU restatement (oracle/) timed on this box's usable host
+cores on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -33,7 +35,7 @@ def _env_int(name, default):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", help="C1|C2|C3 (BASELINE.md §3); C3 = the 1 000-image grid of the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -43,13 +45,13 @@ def main():
     from opencalibration_amd import host as _host_mod
 
     cores = _host_mod.effective_cpus()   # affinity mask capped by the cgroup CPU quota
-    # the host side of every rank is OpenMP-parallel: split the usable host cores between the ranks of this node
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, cores // max(world, 1))))
+    threads = max(1, cores // max(world, 1))
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
 
     import torch
     import torch.distributed as dist
 
-    from opencalibration_amd import capi, host, synth
+    from opencalibration_amd import capi, host, pipeline, synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
@@ -63,143 +65,164 @@ def main():
         torch.cuda.synchronize()
 
     cfg = synth.CONFIGS[args.config]
-    grid = synth.make_grid(seed=12345 + rank, **cfg)
+    grid = synth.make_grid(seed=12345 + rank, rows=cfg["rows"], cols=cfg["cols"], feats=64)  # poses + camera model
     ctx = capi.Context(local_rank)
+    images, shape = pipeline.synthetic_views(ctx, grid, seed=7 + rank)    # resident in HBM before timing starts
+    start_ori = pipeline.perturbed_orientations(grid, 0.1, 99 + rank)
 
-    # relax start: true orientation with a 0.1 rad error about a random axis (test/test_relax.cpp:421)
-    rng = np.random.default_rng(99 + rank)
-    axes = rng.normal(size=(grid.n_images, 3))
-    axes /= np.linalg.norm(axes, axis=1, keepdims=True)
-    dq = np.concatenate([axes * np.sin(0.05), np.full((grid.n_images, 1), np.cos(0.05))], axis=1)
-    start_ori = synth.quat_mul(grid.orientation, dq)
+    last = {}
 
-    def one_step(keep=False):
-        g = host.Graph.from_synthetic(grid)          # host-side graph build: not part of the hot path
-        g.set_orientations(start_ori)
+    def one_step():
         t0 = time.perf_counter()
-        timers = g.link(ctx)
-        t1 = time.perf_counter()
-        rel = g.relax_ground_plane(ctx, start_ori)   # every camera in ONE group: the global relax of pipeline.cpp:653-655
-        ctx.synchronize()
-        t2 = time.perf_counter()
-        timers = dict(timers)
-        timers["relax_total"] = t2 - t1
-        timers["relax_setup_host"] = rel["setup_host_s"]
-        timers["relax_device"] = rel["device_s"]
-        timers["relax_lm_iterations"] = rel["iterations_total"]
-        dt = t2 - t0
-        edges = g.num_edges
-        one_step.last_relax = rel
-        if not keep:
-            g.close()
-        return dt, timers, edges, g
+        g, res, t = pipeline.run(ctx, grid, images, shape, start_ori)
+        dt = time.perf_counter() - t0
+        last.update(res=res, t=t)
+        g.close()
+        return dt - t["graph_build"], t, res     # Python marshalling of features into the graph is not the hot path
 
     for _ in range(args.warmup):
         one_step()
     ctx.profile_reset()
     barrier()
-    step_times, timers_acc, edges = [], None, 0
-    t_begin = time.perf_counter()
+    hot, acc = 0.0, {}
     for _ in range(args.steps):
-        dt, timers, edges, _g = one_step()
-        step_times.append(dt)
-        timers_acc = timers if timers_acc is None else {k: timers_acc[k] + v for k, v in timers.items()}
+        dt, t, res = one_step()
+        hot += dt
+        for k, v in list(t.items()) + [("link_" + k, v) for k, v in res["link_timers"].items()] + \
+                [("relax_setup_host", res["relax"]["setup_host_s"]), ("relax_device", res["relax"]["device_s"]),
+                 ("relax_lm_iterations", res["relax"]["iterations_total"])]:
+            acc[k] = acc.get(k, 0.0) + v
     barrier()
-    hot = float(sum(step_times))                     # graph construction between steps is excluded
-    wall = time.perf_counter() - t_begin
-
-    t = torch.tensor([hot], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([hot], dtype=torch.float64, device="cuda")
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    hot_max = float(t.item())
-    images_total = grid.n_images * world * args.steps
-    value = images_total / hot_max
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    hot_max = float(tt.item())
+    value = grid.n_images * world * args.steps / hot_max
 
-    # ---- roofline of the dominant kernel (Hamming 2-NN), HIP events on the library's compute stream
-    n_launch, ms_match = ctx.profile_get(capi.K_MATCH)
-    n_ransac, ms_ransac = ctx.profile_get(capi.K_RANSAC)
-    n_eval, ms_eval = ctx.profile_get(capi.K_RELAX_EVAL)
-    n_solve, ms_solve = ctx.profile_get(capi.K_RELAX_SOLVE)
-    rel = one_step.last_relax
-    err = rel["orientation"] - grid.orientation
-    # angle between relaxed and true orientation (sanity: the solve converged to the synthetic truth)
-    dots = np.abs(np.sum(rel["orientation"] * grid.orientation, axis=1))
-    relax_max_err = float(np.max(2 * np.arccos(np.clip(dots, 0, 1))))
-    # algorithmic bytes per launch: every pair reads both descriptor sets once and writes 8 B per query
-    sub = [host.subsample(*grid.image(i)[:2], 40.0, int(grid.num_sparse[i])) for i in range(grid.n_images)]
-    nsub = np.array([len(s) for s in sub], np.int64)
-    xy = grid.position[:, :2]
-    d2 = ((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1)
-    knn = np.argsort(d2, axis=1, kind="stable")[:, :10]
-    pairs = [(a, int(b)) for a in range(grid.n_images) for b in knn[a] if b != a]
-    alg_bytes = float(sum((nsub[a] + nsub[b]) * 64 + nsub[a] * 8 for a, b in pairs))
-    compares = float(sum(nsub[a] * nsub[b] for a, b in pairs))
-    avg_ms = ms_match / max(n_launch, 1)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # ---- device kernels (HIP events on the library's compute stream)
+    def prof(kid):
+        n, ms = ctx.profile_get(kid)
+        return int(n), float(ms)
+
+    n_match, ms_match = prof(capi.K_MATCH)
+    n_ransac, ms_ransac = prof(capi.K_RANSAC)
+    n_eval, ms_eval = prof(capi.K_RELAX_EVAL)
+    n_solve, ms_solve = prof(capi.K_RELAX_SOLVE)
+    n_akaze, ms_akaze = prof(capi.K_AKAZE)
+    res = last["res"]
+    rel = res["relax"]
+    n, h, w = shape
+    # dominant kernel group = the extract stencil passes (HBM streaming).  Algorithmic bytes per image: the
+    # working image is W x H float planes; per evolution level the passes read/write (in 4-byte pixels):
+    # blur 2x(1r+1w), flow 1r+1w, FED steps n x (2r+1w), blur 2x(1r+1w), deriv 1r+2w, det 2r+1w, maxima 1r+1w
+    sc = min(1.0, 1600.0 / max(w, h))
+    W, H = int(round(w * sc)), int(round(h * sc))
+    fed = [0, 2, 2, 3, 3, 4, 4, 5, 6, 8, 9, 10, 12, 15, 17, 20]       # ceil(sqrt(3 dT/0.25 + 0.25) - 0.5) per level
+    px_passes = 0.0
+    for lvl in range(16):
+        px = (W >> (lvl // 4)) * (H >> (lvl // 4))
+        px_passes += px * (4 + 2 + 3 * fed[lvl] + 4 + 3 + 3 + 2)
+    alg_bytes_img = 4.0 * px_passes + w * h * 4.0 + W * H * (1 + 4 + 4 * 4)   # + grey/resize/float + k-contrast passes
+    imgs_per_launch = grid.n_images * args.steps / max(n_akaze, 1)
+    avg_ms_akaze = ms_akaze / max(n_akaze, 1)
+    achieved = alg_bytes_img * imgs_per_launch / (avg_ms_akaze * 1e-3) / 1e9 if avg_ms_akaze > 0 else 0.0
     roofline = {
-        "kernel": "hamming_2nn_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0,
-        "unit": "GB/s", "frac": round(achieved / 8000.0, 5), "traffic": None,
-        "avg_launch_ms": round(avg_ms, 4), "launches": int(n_launch),
-        "note": "kernel is integer-VALU bound by design (16 v_xor + 16 v_bcnt per compare, no reuse of HBM bytes "
-                "is possible beyond L2); see valu",
-        "valu": {"compares_per_s": round(compares / (avg_ms * 1e-3), 1) if avg_ms > 0 else 0.0,
-                 "measured_issue_bound_compares_per_s": 1.15e12,
-                 "frac": round(compares / (avg_ms * 1e-3) / 1.15e12, 4) if avg_ms > 0 else 0.0},
-        "ransac_avg_launch_ms": round(ms_ransac / max(n_ransac, 1), 4),
-        "relax_eval_avg_launch_ms": round(ms_eval / max(n_eval, 1), 4), "relax_eval_launches": int(n_eval),
-        "relax_linear_solve_avg_ms": round(ms_solve / max(n_solve, 1), 4), "relax_linear_solves": int(n_solve),
+        "kernel": "extract (AKAZE) stencil passes, one batched launch sequence per %d images" % round(imgs_per_launch),
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+        "frac": round(achieved / 8000.0, 4), "traffic": None,
+        "avg_launch_ms": round(avg_ms_akaze, 3), "launches": n_akaze,
+        "algorithmic_bytes_per_image": round(alg_bytes_img),
+        "other_kernels_avg_ms": {
+            "hamming_2nn_kernel": round(ms_match / max(n_match, 1), 3),
+            "ransac_homography_kernel": round(ms_ransac / max(n_ransac, 1), 3),
+            "relax_pair_eval_kernel": round(ms_eval / max(n_eval, 1), 4),
+            "relax_linear_solve (Cholesky sequence)": round(ms_solve / max(n_solve, 1), 3)},
     }
-    lm_iters = float((timers_acc or {}).get("relax_lm_iterations", 0.0))
-    lm = {"lm_iterations_per_step": lm_iters / max(args.steps, 1),
-          "lm_iters_per_s": round(lm_iters / max((timers_acc or {}).get("relax_device", 1e-9), 1e-9), 2),
-          "unknowns": int(3 * grid.n_images + 3), "residual_blocks": int(rel["residual_blocks"]),
-          "max_orientation_error_rad_vs_truth": relax_max_err}
+    err = pipeline.orientation_errors(rel["orientation"], grid.orientation)
+    lm_iters = acc.get("relax_lm_iterations", 0.0)
+    relax_info = {"lm_iterations_per_step": lm_iters / args.steps,
+                  "lm_iters_per_s": round(lm_iters / max(acc.get("relax_device", 1e-9), 1e-9), 2),
+                  "unknowns": int(3 * grid.n_images + 3), "residual_blocks": int(rel["residual_blocks"]),
+                  "median_orientation_error_rad_vs_truth": float(np.median(err)),
+                  "cameras_left_unconstrained": int(np.sum(err > 0.02))}
 
-    # ---- CPU baseline: the oracle restatement with the reference's scheduling, bounded sample
+    # ---- CPU baseline: the restatement on a bounded sample of the same workload, all usable host cores
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
+        from concurrent.futures import ThreadPoolExecutor
+
         from oracle import pyoracle
 
-        L = pyoracle.lib()
-        threads = max(1, cores // max(world, 1))
-        n_sample = min(len(pairs), max(8, 2 * threads))
-        sample = np.ascontiguousarray(np.array(pairs[:n_sample], np.uint32))
-        counts = np.zeros((n_sample, 2), np.uint64)
-        Hs = np.zeros((n_sample, 9))
-        secs = np.zeros(4)
-        L.oc_link_batch_cpu(grid.loc, grid.strength, grid.desc, grid.off, grid.n_images, grid.num_sparse,
-                            grid.model, sample, n_sample, 1, threads, counts, Hs, secs)
-        src_images = n_sample / (len(pairs) / grid.n_images)
-        cpu = {"value": round(src_images / secs[0], 3), "unit": "images/s", "cores": threads, "kind": "port",
-               "sample": f"first {n_sample} of {len(pairs)} directed pairs of the same grid, faithful variant "
-                         f"(destination subset recomputed per pair, link_stage.cpp:80-81), OpenMP dynamic,1; "
-                         f"wall {secs[0]:.2f} s; cpu-seconds match/undistort/ransac "
-                         f"{secs[1]:.1f}/{secs[2]:.2f}/{secs[3]:.1f}"}
+        pyoracle.lib()
+        n_ex = min(grid.n_images, threads)
+        views = [ctx.synth_views_read(images, i, w, h) for i in range(n_ex)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:        # ctypes releases the GIL: one image per core, as the load stage does
+            cpu_feats = list(ex.map(pyoracle.extract_features, views))
+        t_extract = (time.perf_counter() - t0) / n_ex
+        # link: first pairs of the same grid, features from the (bit-identical) device extraction
+        feats = host.extract_features_batch(ctx, images, 30000, device_shape=(min(grid.n_images, 40), h, w))
+        xy = grid.position[:len(feats), :2]
+        d2 = ((xy[:, None, :] - xy[None, :, :]) ** 2).sum(-1)
+        knn = np.argsort(d2, axis=1, kind="stable")[:, :10]
+        pairs = [(a, int(b)) for a in range(len(feats)) for b in knn[a] if b != a][:max(8, 2 * threads)]
+        off = np.concatenate([[0], np.cumsum([len(f[1]) for f in feats])]).astype(np.uint64)
+        loc = np.ascontiguousarray(np.concatenate([f[0] for f in feats]))
+        st = np.ascontiguousarray(np.concatenate([f[1] for f in feats]))
+        de = np.ascontiguousarray(np.concatenate([f[2] for f in feats]))
+        ns = np.array([f[3] for f in feats], np.uint64)
+        sample = np.ascontiguousarray(np.array(pairs, np.uint32))
+        counts, Hs, secs = np.zeros((len(pairs), 2), np.uint64), np.zeros((len(pairs), 9)), np.zeros(4)
+        pyoracle.lib().oc_link_batch_cpu(loc, st, de, off, len(feats), ns, grid.model, sample, len(pairs), 1, threads,
+                                         counts, Hs, secs)
+        t_link = secs[0] / (len(pairs) / 9.0)          # seconds per source image (9 directed pairs each)
+        cpu = {"value": round(1.0 / (t_extract + t_link), 3), "unit": "images/s", "cores": threads, "kind": "port",
+               "sample": f"extract: {n_ex} views, one per core, {t_extract * n_ex:.2f} s wall; link: first {len(pairs)} "
+                         f"directed pairs, OpenMP dynamic,1, faithful variant (link_stage.cpp:80-81), {secs[0]:.2f} s wall "
+                         f"(cpu-seconds match/undistort/ransac {secs[1]:.1f}/{secs[2]:.2f}/{secs[3]:.1f}); value = "
+                         f"1 / (extract + link seconds per image); relax timed separately below",
+               "extract_s_per_image_per_core": round(t_extract * min(n_ex, threads), 3)}
+        try:
+            gg, _, _ = pipeline.run(ctx, grid, images, shape, start_ori)
+            sub = np.arange(min(50, grid.n_images))
+            e50 = gg.edges_flat(sub)
+            t0 = time.perf_counter()
+            r50 = pyoracle.relax_ground_plane(grid.position[sub], start_ori[sub], grid.model, sub, start_ori[sub], e50)
+            tcpu = time.perf_counter() - t0
+            cpu["relax_cpu"] = {"cameras": int(len(sub)), "residual_blocks": int(r50["residual_blocks"]),
+                                "lm_iterations": int(r50["iterations_total"]), "seconds": round(tcpu, 3),
+                                "lm_iters_per_s": round(r50["iterations_total"] / tcpu, 2), "cores": 1,
+                                "note": "one reference-sized relax group (50 cameras, relax_stage.cpp:52), single "
+                                        "thread like Ceres num_threads=1 (relax_problem.cpp:30)"}
+            gg.close()
+        except Exception as ex:  # informational only
+            cpu["relax_cpu"] = {"error": str(ex)}
 
     if rank == 0:
         out = {
-            "metric": "images/sec end-to-end on synthetic aerial grid (match+RANSAC+relax; extract not yet on path); LM iters/sec",
+            "metric": "images/sec end-to-end (extract+match+relax) on synthetic aerial grid; LM iters/sec",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(hot_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 popcount (match) + f64 (RANSAC)", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {grid.n_images}-image synthetic aerial grid "
-                                   f"{cfg['rows']}x{cfg['cols']}, ~{int(nsub.mean())} features/image entering the "
-                                   f"matcher, {len(pairs)} directed kNN(10) pairs, {edges} edges",
-                       "stages_timed": ["LinkStage.init (kNN)", "40px subsample (host)", "descriptor upload (PCIe)",
-                                        "Hamming 2-NN (device)", "ratio+std::sort+PROSAC order (host)",
-                                        "homography RANSAC (device)", "decompose+assemble (host)", "finalize",
-                                        "relax: ground-plane problem assembly (host)",
-                                        "relax: LM with dense Cholesky, all cameras in one group (device)"],
-                       "stages_not_yet_on_path": ["extract (AKAZE)"],
-                       "host_threads_per_rank": int(os.environ["OMP_NUM_THREADS"]),
+            "vs_baseline": None, "dtype": "f32 (extract) + u32 popcount (match) + f64 (RANSAC, relax)",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {grid.n_images}-image synthetic aerial grid {cfg['rows']}x{cfg['cols']}, "
+                                   f"{w}x{h} rendered views resident in HBM, {res['features_per_image']:.0f} AKAZE "
+                                   f"features/image ({res['sparse_per_image']:.0f} after the 8 px NMS), {res['edges']} edges",
+                       "stages_timed": ["extract: grey + INTER_AREA + AKAZE (device) + strength sort / NMS (host)",
+                                        "link: kNN, 40px subsample (host), upload, Hamming 2-NN (device), ratio+std::sort "
+                                        "(host), homography RANSAC (device), decompose (host)",
+                                        "relax: ground-plane assembly (host) + LM with dense Cholesky, all cameras in one "
+                                        "group (device)"],
+                       "excluded": "Python-side marshalling of extracted features into the host graph (ctypes glue)",
+                       "host_threads_per_rank": threads,
                        "per_rank": "one grid of this shape per GPU, no data-path collective"},
-            "stage_seconds_per_step": {k: round(v / args.steps, 5) for k, v in (timers_acc or {}).items()},
-            "wall_s_including_graph_build": round(wall, 3),
-            "relax": lm,
+            "stage_seconds_per_step": {k: round(v / args.steps, 5) for k, v in acc.items()},
+            "relax": relax_info,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
+    ctx.synth_views_free(images)
     if world > 1:
         dist.destroy_process_group()
 

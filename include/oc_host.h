@@ -57,10 +57,11 @@ extern "C"
     /* ---- extract (opencalibration_amd/csrc/host/extract_features.hpp): extract_features(cv::Mat) of
      *      src/extract/extract_features.cpp:11-88 for a batch of equally sized BGR images ------------------ */
     /* Per image up to max_out features at stride max_out: loc (x, y in full-resolution pixels), strength, desc
-     * (8 u64); counts[i] features of image i, the first num_sparse[i] of which passed the 8 px NMS. */
+     * (8 u64); counts[i] features of image i, the first num_sparse[i] of which passed the 8 px NMS.
+     * images_on_device != 0: images_bgr is a device pointer (images already resident in HBM). */
     int och_extract_features_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
                                    uint32_t max_keypoints, uint32_t max_out, double *loc, float *strength,
-                                   uint64_t *desc, uint32_t *counts, uint32_t *num_sparse);
+                                   uint64_t *desc, uint32_t *counts, uint32_t *num_sparse, int images_on_device);
     const char *och_extract_last_error(void);
 
     /* ---- relax (opencalibration_amd/csrc/host/relax.hpp): relax(graph, nodes, cam_models, edges,

@@ -98,6 +98,22 @@ extern "C"
     int ochip_akaze_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
                           uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh);
 
+    /* Same with the images already resident in HBM (device pointer): the PCIe upload is outside the call. */
+    int ochip_akaze_batch_dev(ochip_ctx *ctx, const uint8_t *images_bgr_dev, uint32_t n_images, int width, int height,
+                              uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh);
+
+    /* ---- synthetic views: benchmark / test DATA generated directly in HBM (no algorithm of the path) ---- */
+    /* A jittered ground lattice of Gaussian blobs on the plane z = a x + b y rendered through pinhole cameras;
+     * all views of one seed show the same ground.  cams: n x {pos3, quat4 (x y z w)}; model3 = {f, ppx, ppy};
+     * plane2 = {a, b}; lattice3 = {x0, y0, spacing}.  Images are BGR (grey replicated), n x height x width x 3. */
+    int ochip_synth_views_alloc(ochip_ctx *ctx, uint32_t n_images, int width, int height, uint8_t **images_dev);
+    void ochip_synth_views_free(ochip_ctx *ctx, uint8_t *images_dev);
+    int ochip_synth_views_read(ochip_ctx *ctx, const uint8_t *images_dev, uint32_t index, int width, int height,
+                               uint8_t *host_out); /* copy view `index` back to the host (for the CPU checker) */
+    int ochip_synth_render_views(ochip_ctx *ctx, uint8_t *images_dev, uint32_t first_image, uint32_t n_images, int width,
+                                 int height, const double *cams, const double *model3, const double *plane2,
+                                 const double *lattice3, uint32_t seed);
+
     /* ---- keypoints -> unit rays (replaces image_to_3d of src/distort/distort_keypoints.cpp:68-103,
      *      hoisted from once per match to once per keypoint) ------------------------------------------ */
     /* xy: n x 2 pixel locations in the same subset order as the descriptors of image_id (n must equal

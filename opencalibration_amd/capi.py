@@ -20,7 +20,8 @@ EXPORTS = [
     "ochip_descriptors_reserve", "ochip_upload_descriptors", "ochip_descriptor_count",
     "ochip_match_batch", "ochip_match_launch", "ochip_match_fetch",
     "ochip_upload_keypoints", "ochip_ransac_homography_batch",
-    "ochip_upload_batch", "ochip_host_alloc", "ochip_host_free", "ochip_akaze_batch",
+    "ochip_upload_batch", "ochip_host_alloc", "ochip_host_free", "ochip_akaze_batch", "ochip_akaze_batch_dev",
+    "ochip_synth_views_alloc", "ochip_synth_views_free", "ochip_synth_render_views", "ochip_synth_views_read",
     "ochip_relax_problem_create", "ochip_relax_problem_destroy", "ochip_relax_set_cameras_constant",
     "ochip_relax_solve", "ochip_relax_get_state",
     "ochip_profile_reset", "ochip_profile_get",
@@ -59,6 +60,12 @@ def load():
         L.ochip_profile_get.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(C.c_double)]
         L.ochip_debug_fp64.argtypes = [vp, i32, vp, vp, C.c_size_t, vp]
         L.ochip_akaze_batch.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
+        L.ochip_akaze_batch_dev.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
+        L.ochip_synth_views_alloc.argtypes = [vp, u32, i32, i32, C.POINTER(vp)]
+        L.ochip_synth_views_free.argtypes = [vp, vp]
+        L.ochip_synth_views_free.restype = None
+        L.ochip_synth_render_views.argtypes = [vp, vp, u32, u32, i32, i32, vp, vp, vp, vp, u32]
+        L.ochip_synth_views_read.argtypes = [vp, vp, u32, i32, i32, vp]
         _lib = L
     return _lib
 
@@ -134,6 +141,32 @@ class Context:
         self._check(self.L.ochip_akaze_batch(self.h, imgs.ctypes.data, n, w, h, max_kp, kp.ctypes.data, desc.ctypes.data,
                                              counts.ctypes.data, wh.ctypes.data), "ochip_akaze_batch")
         return [(kp[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(n)], (int(wh[0]), int(wh[1]))
+
+    def synth_views(self, position, orientation, width, height, f, pp, plane, spacing, origin, seed=7, chunk=64):
+        """Render one synthetic view per camera directly into HBM (benchmark / test data).  Returns an opaque
+        device pointer (int) to n x height x width x 3 bytes; free with synth_views_free."""
+        n = len(position)
+        ptr = C.c_void_p()
+        self._check(self.L.ochip_synth_views_alloc(self.h, n, width, height, C.byref(ptr)), "ochip_synth_views_alloc")
+        cams = np.ascontiguousarray(np.concatenate([position, orientation], axis=1), np.float64)
+        model3 = np.array([f, pp[0], pp[1]], np.float64)
+        plane2 = np.array(plane, np.float64)
+        lat3 = np.array([origin[0], origin[1], spacing], np.float64)
+        for i in range(0, n, chunk):
+            m = min(chunk, n - i)
+            c = np.ascontiguousarray(cams[i:i + m])
+            self._check(self.L.ochip_synth_render_views(self.h, ptr, i, m, width, height, c.ctypes.data, model3.ctypes.data,
+                                                        plane2.ctypes.data, lat3.ctypes.data, seed), "ochip_synth_render_views")
+        return ptr.value
+
+    def synth_views_read(self, ptr, index, width, height):
+        out = np.zeros((height, width, 3), np.uint8)
+        self._check(self.L.ochip_synth_views_read(self.h, C.c_void_p(ptr), index, width, height, out.ctypes.data),
+                    "ochip_synth_views_read")
+        return out
+
+    def synth_views_free(self, ptr):
+        self.L.ochip_synth_views_free(self.h, C.c_void_p(ptr))
 
     def debug_fp64(self, op, x, y=None):
         x = np.ascontiguousarray(x, np.float64)

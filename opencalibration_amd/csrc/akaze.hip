@@ -124,35 +124,56 @@ __global__ void modg_kernel(const float *__restrict__ sm, float *__restrict__ mo
                             unsigned int *__restrict__ hmax_bits)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w)
-        return;
     float m = 0.0f;
     if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1)
     {
         float lx, ly;
         scharr3(sm + (size_t)blockIdx.z * stride, w, h, x, y, &lx, &ly);
         m = sqrtf(lx * lx + ly * ly);
-        atomicMax(hmax_bits + blockIdx.z, __float_as_uint(m)); // non-negative floats order like their bit patterns
     }
-    modg[(size_t)blockIdx.z * stride + (size_t)y * w + x] = m;
+    if (x < w)
+        modg[(size_t)blockIdx.z * stride + (size_t)y * w + x] = m;
+    // one atomic per wavefront: non-negative floats order like their bit patterns
+    unsigned int bits = __float_as_uint(m);
+    for (int off = 32; off >= 1; off >>= 1)
+        bits = max(bits, (unsigned int)__shfl_xor((int)bits, off));
+    if ((threadIdx.x & 63) == 0 && bits != 0)
+        atomicMax(hmax_bits + blockIdx.z, bits);
 }
 
 __global__ void hist_kernel(const float *__restrict__ modg, int w, int h, size_t stride,
                             const unsigned int *__restrict__ hmax_bits, int nbins, unsigned int *__restrict__ hist)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1)
-        return;
-    const float m = modg[(size_t)blockIdx.z * stride + (size_t)y * w + x];
-    if (m != 0.0f)
+    // workgroup-private histogram in LDS (each workgroup walks `rows_per_block` image rows), flushed with
+    // one global atomic per non-empty bin: integer counts, so the result does not depend on the order
+    __shared__ unsigned int lh[304];
+    for (int i = threadIdx.x; i <= nbins; i += blockDim.x)
+        lh[i] = 0;
+    __syncthreads();
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const float hmax = __uint_as_float(hmax_bits[blockIdx.z]);
+    const int rows_per_block = 8;
+    for (int r = 0; r < rows_per_block; r++)
     {
-        const float hmax = __uint_as_float(hmax_bits[blockIdx.z]);
-        int nbin = (int)floorf((float)nbins * (m / hmax));
-        if (nbin == nbins)
-            nbin--;
-        atomicAdd(hist + (size_t)blockIdx.z * (nbins + 1) + nbin, 1u);
-        atomicAdd(hist + (size_t)blockIdx.z * (nbins + 1) + nbins, 1u); // npoints
+        const int y = blockIdx.y * rows_per_block + r;
+        const bool inside = !(x < 1 || x >= w - 1 || y < 1 || y >= h - 1);
+        const float m = inside ? modg[(size_t)blockIdx.z * stride + (size_t)y * w + x] : 0.0f;
+        const bool counted = m != 0.0f;
+        if (counted)
+        {
+            int nbin = (int)floorf((float)nbins * (m / hmax));
+            if (nbin == nbins)
+                nbin--;
+            atomicAdd(&lh[nbin], 1u);
+        }
+        const unsigned long long mask = __ballot(counted);
+        if ((threadIdx.x & 63) == 0 && mask)
+            atomicAdd(&lh[nbins], (unsigned int)__popcll(mask)); // npoints
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= nbins; i += blockDim.x)
+        if (lh[i])
+            atomicAdd(hist + (size_t)blockIdx.z * (nbins + 1) + i, lh[i]);
 }
 
 __global__ void kcontrast_kernel(const unsigned int *__restrict__ hist, const unsigned int *__restrict__ hmax_bits,
@@ -693,29 +714,180 @@ area_tab area_table(int ssize, int dsize) // cv::resize INTER_AREA decimation ta
     return t;
 }
 
-template <typename T> int up(ochip_ctx *ctx, std::vector<void *> &allocs, T **dst, const T *src, size_t n)
+template <typename T>
+int up(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> &allocs, T **dst, const T *src, size_t n)
 {
-    void *d = nullptr;
-    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess)
-        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc(%zu) failed in akaze", n * sizeof(T));
-    allocs.push_back(d);
+    size_t got = 0;
+    void *d = ochip_pool_get(ctx, (n ? n : 1) * sizeof(T), &got);
+    if (!d)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation of %zu bytes failed in akaze", n * sizeof(T));
+    allocs.emplace_back(d, got);
     if (src && n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
         return ochip_fail(ctx, OCHIP_EHIP, "hipMemcpy failed in akaze");
     *dst = (T *)d;
     return OCHIP_OK;
 }
 
+// ---- synthetic views (test / benchmark DATA, not part of the hot path): a jittered ground lattice of
+// Gaussian blobs on the plane z = a x + b y, seen through a pinhole camera.  Every view of one seed shows
+// the same ground, so features extracted from different views really correspond.
+__device__ __forceinline__ uint32_t hash32(uint32_t x)
+{
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float hashf(uint32_t x) // [0, 1)
+{
+    return (float)(hash32(x) >> 8) * (1.0f / 16777216.0f);
+}
+struct synth_cam
+{
+    float pos[3], q[4]; // camera -> world quaternion x y z w
+};
+__global__ void render_views_kernel(uint8_t *__restrict__ out, int w, int h, const synth_cam *__restrict__ cams, float f,
+                                    float ppx, float ppy, float pa, float pb, float x0, float y0, float spacing,
+                                    uint32_t seed)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w)
+        return;
+    const synth_cam c = cams[blockIdx.z];
+    // world ray of the pixel centre (Eigen _transformVector of the unit camera ray)
+    const float ux = ((float)x - ppx) / f, uy = ((float)y - ppy) / f;
+    const float qx = c.q[0], qy = c.q[1], qz = c.q[2], qw = c.q[3];
+    float uvx = qy * 1.0f - qz * uy, uvy = qz * ux - qx * 1.0f, uvz = qx * uy - qy * ux;
+    uvx += uvx;
+    uvy += uvy;
+    uvz += uvz;
+    const float dx = ux + qw * uvx + (qy * uvz - qz * uvy), dy = uy + qw * uvy + (qz * uvx - qx * uvz),
+                dz = 1.0f + qw * uvz + (qx * uvy - qy * uvx);
+    const float t = (pa * c.pos[0] + pb * c.pos[1] - c.pos[2]) / (dz - pa * dx - pb * dy);
+    const float gx = c.pos[0] + t * dx, gy = c.pos[1] + t * dy;
+    const int ci = (int)floorf((gx - x0) / spacing), cj = (int)floorf((gy - y0) / spacing);
+    float v = 0.5f;
+    for (int di = -1; di <= 1; di++)
+        for (int dj = -1; dj <= 1; dj++)
+        {
+            const uint32_t id = (uint32_t)(ci + di) * 73856093u ^ (uint32_t)(cj + dj) * 19349663u ^ seed;
+            const float bx = x0 + ((float)(ci + di) + 0.5f + 0.6f * (hashf(id) - 0.5f)) * spacing;
+            const float by = y0 + ((float)(cj + dj) + 0.5f + 0.6f * (hashf(id + 1) - 0.5f)) * spacing;
+            const float amp = (0.25f + 0.5f * hashf(id + 2)) * ((hash32(id + 3) & 1) ? 1.0f : -1.0f);
+            const float sg = spacing * (0.10f + 0.14f * hashf(id + 4));
+            const float r2 = (gx - bx) * (gx - bx) + (gy - by) * (gy - by);
+            v += amp * __expf(-r2 / (2.0f * sg * sg));
+        }
+    const float o = fminf(255.0f, fmaxf(0.0f, v * 255.0f));
+    const uint8_t g = (uint8_t)o;
+    uint8_t *p = out + ((size_t)blockIdx.z * w * h + (size_t)y * w + x) * 3;
+    p[0] = g;
+    p[1] = g;
+    p[2] = g;
+}
+
+int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_t n_images, int width, int height,
+              uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh);
+
 } // namespace
 
 extern "C"
 {
 
-// images: n_images x h x w x 3 BGR bytes (host).  Working size: the INTER_AREA downscale to max side 1600
-// of extract_features.cpp:26-27.  Outputs (host): per image up to max_kp keypoints, in unspecified order:
-// kp6 = {x, y, size, angle(rad), response, level} in working-image pixels, desc = 8 x u64, counts[i] = number
-// written for image i (<= max_kp).  work_wh receives the working width/height.
 int ochip_akaze_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
                       uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh)
+{
+    return akaze_run(ctx, images_bgr, false, n_images, width, height, max_kp, kp6, desc, counts, work_wh);
+}
+
+int ochip_akaze_batch_dev(ochip_ctx *ctx, const uint8_t *images_bgr_dev, uint32_t n_images, int width, int height,
+                          uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh)
+{
+    return akaze_run(ctx, images_bgr_dev, true, n_images, width, height, max_kp, kp6, desc, counts, work_wh);
+}
+
+int ochip_synth_views_alloc(ochip_ctx *ctx, uint32_t n_images, int width, int height, uint8_t **images_dev)
+{
+    if (!ctx || !images_dev)
+        return OCHIP_EINVAL;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    *images_dev = nullptr;
+    if (hipMalloc((void **)images_dev, (size_t)(n_images ? n_images : 1) * width * height * 3) != hipSuccess)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc(%zu) for synthetic views failed", (size_t)n_images * width * height * 3);
+    return OCHIP_OK;
+}
+
+int ochip_synth_views_read(ochip_ctx *ctx, const uint8_t *images_dev, uint32_t index, int width, int height,
+                           uint8_t *host_out)
+{
+    if (!ctx || !images_dev || !host_out)
+        return OCHIP_EINVAL;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)width * height * 3;
+    OCHIP_HIP(ctx, hipMemcpy(host_out, images_dev + (size_t)index * bytes, bytes, hipMemcpyDeviceToHost));
+    return OCHIP_OK;
+}
+
+void ochip_synth_views_free(ochip_ctx *ctx, uint8_t *images_dev)
+{
+    if (ctx && images_dev)
+    {
+        (void)hipSetDevice(ctx->device);
+        (void)hipFree(images_dev);
+    }
+}
+
+// cams: n_images x {pos3, quat4 (x y z w)} doubles; model3 = {f, ppx, ppy}; plane2 = {a, b} of z = a x + b y;
+// lattice3 = {x0, y0, spacing} of the blob lattice.  Writes n_images x height x width x 3 bytes at
+// images_dev + first_image * height * width * 3.
+int ochip_synth_render_views(ochip_ctx *ctx, uint8_t *images_dev, uint32_t first_image, uint32_t n_images, int width,
+                             int height, const double *cams, const double *model3, const double *plane2,
+                             const double *lattice3, uint32_t seed)
+{
+    if (!ctx || !images_dev || !cams || !model3 || !plane2 || !lattice3)
+        return OCHIP_EINVAL;
+    if (n_images == 0)
+        return OCHIP_OK;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<synth_cam> hc(n_images);
+    for (uint32_t i = 0; i < n_images; i++)
+    {
+        for (int k = 0; k < 3; k++)
+            hc[i].pos[k] = (float)cams[7 * i + k];
+        for (int k = 0; k < 4; k++)
+            hc[i].q[k] = (float)cams[7 * i + 3 + k];
+    }
+    synth_cam *dc = nullptr;
+    if (hipMalloc((void **)&dc, n_images * sizeof(synth_cam)) != hipSuccess)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc failed");
+    hipError_t e = hipMemcpy(dc, hc.data(), n_images * sizeof(synth_cam), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL(render_views_kernel, dim3((width + 255) / 256, height, n_images), dim3(256), 0, ctx->stream,
+                           images_dev + (size_t)first_image * width * height * 3, width, height, (const synth_cam *)dc,
+                           (float)model3[0], (float)model3[1], (float)model3[2], (float)plane2[0], (float)plane2[1],
+                           (float)lattice3[0], (float)lattice3[1], (float)lattice3[2], seed);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(dc);
+    if (e != hipSuccess)
+        return ochip_fail(ctx, OCHIP_EHIP, "ochip_synth_render_views: %s", hipGetErrorString(e));
+    return OCHIP_OK;
+}
+
+} // extern "C"
+
+namespace
+{
+
+// images: n_images x h x w x 3 BGR bytes (host, or device when on_device).  Working size: the INTER_AREA
+// downscale to max side 1600 of extract_features.cpp:26-27.  Outputs (host): per image up to max_kp keypoints,
+// in unspecified order: kp6 = {x, y, size, angle(rad), response, level} in working-image pixels, desc = 8 x u64,
+// counts[i] = number written for image i (<= max_kp).  work_wh receives the working width/height.
+int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_t n_images, int width, int height,
+              uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh)
 {
     if (!ctx || !counts || (n_images && (!images_bgr || !kp6 || !desc)))
         return OCHIP_EINVAL;
@@ -770,10 +942,11 @@ int ochip_akaze_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_imag
     const uint32_t B = n_images;
     const uint32_t max_cands = std::max<uint32_t>(max_kp * 4, 1u << 16);
 
-    std::vector<void *> allocs;
+    std::vector<std::pair<void *, size_t>> allocs;
     auto cleanup = [&]() {
-        for (void *a : allocs)
-            (void)hipFree(a);
+        (void)hipStreamSynchronize(st);
+        for (auto &a : allocs)
+            ochip_pool_put(ctx, a.first, a.second);
     };
     int rc = OCHIP_OK;
 #define AK(call)                                                                                                       \
@@ -792,7 +965,10 @@ int ochip_akaze_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_imag
     unsigned long long *d_desc = nullptr;
     pair_tab *d_tab = nullptr;
     const size_t src_px = (size_t)width * height;
-    AK(up(ctx, allocs, &d_bgr, images_bgr, (size_t)B * src_px * 3));
+    if (on_device)
+        d_bgr = const_cast<uint8_t *>(images_bgr);
+    else
+        AK(up(ctx, allocs, &d_bgr, images_bgr, (size_t)B * src_px * 3));
     AK(up<uint8_t>(ctx, allocs, &d_gray, nullptr, (size_t)B * src_px));
     AK(up<uint8_t>(ctx, allocs, &d_small, nullptr, (size_t)B * plane0));
     AK(up<float>(ctx, allocs, &d_img, nullptr, (size_t)B * plane0));
@@ -892,7 +1068,8 @@ int ochip_akaze_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_imag
     OCHIP_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)B * 301 * 4, st));
     blur(d_img, plane0, d_sm, plane0, W, H, g1);
     hipLaunchKernelGGL(modg_kernel, grid2(W, H), dim3(256), 0, st, (const float *)d_sm, d_flow, W, H, plane0, d_hmax);
-    hipLaunchKernelGGL(hist_kernel, grid2(W, H), dim3(256), 0, st, (const float *)d_flow, W, H, plane0, d_hmax, 300, d_hist);
+    hipLaunchKernelGGL(hist_kernel, dim3((W + 255) / 256, (H + 7) / 8, B), dim3(256), 0, st, (const float *)d_flow, W, H,
+                       plane0, d_hmax, 300, d_hist);
     hipLaunchKernelGGL(kcontrast_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_hist, d_hmax, 300, 0.7f, d_kc, (int)B);
 
     // ---- nonlinear scale space
@@ -1003,4 +1180,4 @@ int ochip_akaze_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_imag
 #undef AK
 }
 
-} // extern "C"
+} // namespace

@@ -34,6 +34,51 @@ int ochip_ensure(ochip_ctx *ctx, void **ptr, size_t *cap, size_t bytes)
     return OCHIP_OK;
 }
 
+void *ochip_pool_get(ochip_ctx *ctx, size_t bytes, size_t *got)
+{
+    if (bytes == 0)
+        bytes = 1;
+    int best = -1;
+    for (size_t i = 0; i < ctx->dev_pool.size(); i++)
+        if (ctx->dev_pool[i].second >= bytes && (best < 0 || ctx->dev_pool[i].second < ctx->dev_pool[best].second))
+            best = (int)i;
+    if (best >= 0 && ctx->dev_pool[best].second <= 2 * bytes + (1 << 20))
+    {
+        void *p = ctx->dev_pool[best].first;
+        *got = ctx->dev_pool[best].second;
+        ctx->dev_pool.erase(ctx->dev_pool.begin() + best);
+        return p;
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess)
+    {
+        // the pool may be hoarding memory: drop it and retry once
+        for (auto &b : ctx->dev_pool)
+            (void)hipFree(b.first);
+        ctx->dev_pool.clear();
+        if (hipMalloc(&p, bytes) != hipSuccess)
+            return nullptr;
+    }
+    *got = bytes;
+    return p;
+}
+
+void ochip_pool_put(ochip_ctx *ctx, void *p, size_t bytes)
+{
+    if (!p)
+        return;
+    ctx->dev_pool.emplace_back(p, bytes);
+    while (ctx->dev_pool.size() > 64)
+    {
+        size_t s = 0;
+        for (size_t k = 1; k < ctx->dev_pool.size(); k++)
+            if (ctx->dev_pool[k].second < ctx->dev_pool[s].second)
+                s = k;
+        (void)hipFree(ctx->dev_pool[s].first);
+        ctx->dev_pool.erase(ctx->dev_pool.begin() + s);
+    }
+}
+
 void ochip_prof_begin(ochip_ctx *ctx, int kid, hipEvent_t *start, hipEvent_t *stop)
 {
     auto &s = ctx->prof[kid];
@@ -142,6 +187,8 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
     for (void *b : ctx->scratch_dev)
         if (b)
             (void)hipFree(b);
+    for (auto &b : ctx->dev_pool)
+        (void)hipFree(b.first);
     for (auto &b : ctx->pinned_pool)
         (void)hipHostFree(b.first);
     for (auto &b : ctx->pinned_live)

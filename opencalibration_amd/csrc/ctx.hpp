@@ -59,12 +59,16 @@ struct ochip_ctx
 
     // page-locked host blocks handed out by ochip_host_alloc (live) and recycled ones (pool)
     std::vector<std::pair<void *, size_t>> pinned_live, pinned_pool;
+    // recycled device blocks for per-call temporaries (hipMalloc / hipFree are slow and synchronising)
+    std::vector<std::pair<void *, size_t>> dev_pool;
 
     ochip_profile_slot prof[OCHIP_K_COUNT];
 };
 
 int ochip_fail(ochip_ctx *ctx, int code, const char *fmt, ...);
 int ochip_ensure(ochip_ctx *ctx, void **ptr, size_t *cap, size_t bytes); // grow-only device buffer
+void *ochip_pool_get(ochip_ctx *ctx, size_t bytes, size_t *got);          // device block from the pool (or hipMalloc); nullptr on failure
+void ochip_pool_put(ochip_ctx *ctx, void *p, size_t bytes);              // hand it back (kept for reuse, freed with the context)
 void ochip_prof_begin(ochip_ctx *ctx, int kid, hipEvent_t *start, hipEvent_t *stop);
 void ochip_prof_end(ochip_ctx *ctx, int kid, hipEvent_t start, hipEvent_t stop);
 

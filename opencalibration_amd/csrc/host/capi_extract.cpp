@@ -22,9 +22,10 @@ const char *och_extract_last_error(void)
 // num_sparse[i] = how many of them passed the 8 px NMS (they come first).  Returns 0 or -1.
 int och_extract_features_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
                                uint32_t max_keypoints, uint32_t max_out, double *loc, float *strength, uint64_t *desc,
-                               uint32_t *counts, uint32_t *num_sparse)
+                               uint32_t *counts, uint32_t *num_sparse, int images_on_device)
 {
-    auto ex = extract_features_batch(ctx, images_bgr, n_images, width, height, max_keypoints, &g_extract_error);
+    auto ex = extract_features_batch(ctx, images_bgr, n_images, width, height, max_keypoints, &g_extract_error,
+                                     images_on_device != 0);
     if (ex.size() != n_images)
         return -1;
     for (uint32_t b = 0; b < n_images; b++)

@@ -53,7 +53,8 @@ struct nn_grid
 } // namespace
 
 std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images,
-                                                       int width, int height, uint32_t max_keypoints, std::string *error)
+                                                       int width, int height, uint32_t max_keypoints, std::string *error,
+                                                       bool images_on_device)
 {
     std::vector<extracted_features> out(n_images);
     if (n_images == 0 || width <= 0 || height <= 0) // image.empty(): {results, 0}, extract_features.cpp:20-23
@@ -64,8 +65,11 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
     std::vector<uint64_t> desc((size_t)n_images * max_keypoints * 8);
     std::vector<uint32_t> counts(n_images);
     int wh[2];
-    if (ochip_akaze_batch(ctx, images_bgr, n_images, width, height, max_keypoints, kp.data(), desc.data(), counts.data(),
-                          wh) != OCHIP_OK)
+    const int rc = images_on_device ? ochip_akaze_batch_dev(ctx, images_bgr, n_images, width, height, max_keypoints,
+                                                            kp.data(), desc.data(), counts.data(), wh)
+                                    : ochip_akaze_batch(ctx, images_bgr, n_images, width, height, max_keypoints, kp.data(),
+                                                        desc.data(), counts.data(), wh);
+    if (rc != OCHIP_OK)
     {
         if (error)
             *error = std::string("ochip_akaze_batch: ") + ochip_last_error(ctx);

@@ -20,7 +20,9 @@ struct extracted_features // extract_features.hpp:10-15
 // grey + INTER_AREA downscale + AKAZE on the device (ochip_akaze_batch), then the host tail of
 // src/extract/extract_features.cpp:38-87: rescale to full-resolution pixels, std::sort by response, greedy
 // 8 px NMS, [sparse..., dense...].  On a device error returns an empty vector and sets *error.
+// images_on_device: images_bgr is a device pointer (the images are already resident in HBM).
 std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images,
-                                                       int width, int height, uint32_t max_keypoints, std::string *error);
+                                                       int width, int height, uint32_t max_keypoints, std::string *error,
+                                                       bool images_on_device = false);
 
 } // namespace opencalibration_amd

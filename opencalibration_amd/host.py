@@ -76,25 +76,31 @@ def load():
                                              _u64p, _f64p, _u64p, vp, vp, sz, _u64p, _f64p, _f64p]
         L.och_relax_last_error.restype = C.c_char_p
         L.och_graph_relax_ground_plane.argtypes = [vp, vp, _f64p, _f64p, _f64p]
-        L.och_extract_features_batch.argtypes = [vp, vp, u32, C.c_int, C.c_int, u32, u32, vp, vp, vp, vp, vp]
+        L.och_extract_features_batch.argtypes = [vp, vp, u32, C.c_int, C.c_int, u32, u32, vp, vp, vp, vp, vp, C.c_int]
         L.och_extract_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 
 
-def extract_features_batch(ctx, images_bgr, max_keypoints=20000):
-    """extract_features for a batch of equally sized BGR images (n, h, w, 3) uint8 on the device.  Returns a
-    list of (loc [k x 2] f64, strength [k] f32, desc [k x 8] u64, num_sparse) per image."""
+def extract_features_batch(ctx, images_bgr, max_keypoints=20000, device_shape=None):
+    """extract_features for a batch of equally sized BGR images on the device.  images_bgr: (n, h, w, 3) uint8
+    host array, or - with device_shape=(n, h, w) - an integer device pointer to images already in HBM.  Returns
+    a list of (loc [k x 2] f64, strength [k] f32, desc [k x 8] u64, num_sparse) per image."""
     L = load()
-    imgs = np.ascontiguousarray(images_bgr, np.uint8)
-    n, h, w, _ = imgs.shape
+    if device_shape is None:
+        imgs = np.ascontiguousarray(images_bgr, np.uint8)
+        n, h, w, _ = imgs.shape
+        src, on_dev = imgs.ctypes.data, 0
+    else:
+        n, h, w = device_shape
+        src, on_dev = int(images_bgr), 1
     max_out = max_keypoints + 1   # the NMS seed re-enters the dense list (extract_features.cpp:63-83)
     loc = np.zeros((n, max_out, 2))
     st = np.zeros((n, max_out), np.float32)
     de = np.zeros((n, max_out, 8), np.uint64)
     counts, ns = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
-    rc = L.och_extract_features_batch(ctx.h, imgs.ctypes.data, n, w, h, max_keypoints, max_out, loc.ctypes.data,
-                                      st.ctypes.data, de.ctypes.data, counts.ctypes.data, ns.ctypes.data)
+    rc = L.och_extract_features_batch(ctx.h, src, n, w, h, max_keypoints, max_out, loc.ctypes.data,
+                                      st.ctypes.data, de.ctypes.data, counts.ctypes.data, ns.ctypes.data, on_dev)
     if rc != 0:
         raise capi.OchipError("extract failed: " + L.och_extract_last_error().decode())
     return [(loc[i, :counts[i]].copy(), st[i, :counts[i]].copy(), de[i, :counts[i]].copy(), int(ns[i])) for i in range(n)]

@@ -1,0 +1,71 @@
+"""End-to-end driver of the hot path on one GPU: images -> extract -> link (match + RANSAC) -> relax.
+
+Mirrors what Pipeline::Impl::initial_processing strings together (src/pipeline/pipeline.cpp:522-570): the
+load stage's extract_features per image, the link stage over kNN(10) pairs, one relax group over the linked
+cameras.  Used by bench.py and the end-to-end tests; the images come from the synthetic view renderer
+(data only) and are resident in HBM before any timed region starts.
+"""
+import time
+
+import numpy as np
+
+from . import host, synth
+
+
+def synthetic_views(ctx, grid, seed=7):
+    """Render one 4000x3000-class view per camera of `grid` into HBM.  Returns (device pointer, (n, h, w))."""
+    w, h = int(grid.model[8]), int(grid.model[9])
+    f, pp = float(grid.model[0]), (float(grid.model[1]), float(grid.model[2]))
+    # blob lattice: ~21 px apart in the 1600-px working image, i.e. (max(w,h)/1600) * 21 full-resolution pixels
+    gsd = (grid.position[0, 2] - (grid.plane[0] * grid.position[0, 0] + grid.plane[1] * grid.position[0, 1])) / f
+    spacing = 21.0 * (max(w, h) / 1600.0) * gsd
+    origin = (float(grid.position[:, 0].min() - 500.0), float(grid.position[:, 1].min() - 500.0))
+    ptr = ctx.synth_views(grid.position, grid.orientation, w, h, f, pp, grid.plane, spacing, origin, seed=seed)
+    return ptr, (grid.n_images, h, w)
+
+
+def run(ctx, grid, images_ptr, shape, start_orientation, batch=25, max_keypoints=30000):
+    """extract -> link -> relax.  Returns (graph, result dict, stage seconds)."""
+    n, h, w = shape
+    t = {}
+    t0 = time.perf_counter()
+    feats = []
+    px_bytes = h * w * 3
+    for i in range(0, n, batch):
+        m = min(batch, n - i)
+        feats += host.extract_features_batch(ctx, images_ptr + i * px_bytes, max_keypoints, device_shape=(m, h, w))
+    t["extract"] = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    g = host.Graph()
+    mid = g.add_model(grid.model)
+    for i, (loc, st, de, ns) in enumerate(feats):
+        g.add_image(loc, st, de, ns, mid, grid.position[i])
+    g.set_orientations(start_orientation)
+    t["graph_build"] = time.perf_counter() - t0       # Python-side marshalling of the features, not the hot path
+
+    t0 = time.perf_counter()
+    link_timers = g.link(ctx)
+    t["link"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rel = g.relax_ground_plane(ctx, start_orientation)
+    ctx.synchronize()
+    t["relax"] = time.perf_counter() - t0
+    res = dict(features_per_image=float(np.mean([len(f[1]) for f in feats])),
+               sparse_per_image=float(np.mean([f[3] for f in feats])), link_timers=link_timers, relax=rel,
+               edges=g.num_edges)
+    return g, res, t
+
+
+def perturbed_orientations(grid, sigma=0.1, seed=99):
+    """True orientation with a `sigma` rad error about a random axis (test/test_relax.cpp:421)."""
+    rng = np.random.default_rng(seed)
+    axes = rng.normal(size=(grid.n_images, 3))
+    axes /= np.linalg.norm(axes, axis=1, keepdims=True)
+    dq = np.concatenate([axes * np.sin(sigma / 2), np.full((grid.n_images, 1), np.cos(sigma / 2))], axis=1)
+    return synth.quat_mul(grid.orientation, dq)
+
+
+def orientation_errors(est, truth):
+    dots = np.abs(np.sum(est * truth, axis=1) / (np.linalg.norm(est, axis=1) * np.linalg.norm(truth, axis=1)))
+    return 2 * np.arccos(np.clip(dots, 0, 1))
