@@ -63,6 +63,14 @@ extern "C"
                                    uint32_t max_keypoints, uint32_t max_out, double *loc, float *strength,
                                    uint64_t *desc, uint32_t *counts, uint32_t *num_sparse, int images_on_device);
     const char *och_extract_last_error(void);
+    /* The load stage's job for a batch of equally sized images (src/pipeline/load_stage.cpp:43-110: extract_features,
+     * then one graph node per image): extract on the device in chunks (host tail of chunk k overlapped with the device
+     * work of chunk k + 1), then addNode in image order.  positions: n x 3; node_ids_out: n (may be NULL);
+     * totals2 (may be NULL) receives {features, sparse features} summed over the images.  Returns 0, or -1 with the
+     * message in och_last_error(g). */
+    int och_graph_load_images(och_graph *g, ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width,
+                              int height, uint32_t max_keypoints, int images_on_device, uint32_t model,
+                              const double *positions, uint64_t *node_ids_out, double *totals2);
 
     /* ---- relax (opencalibration_amd/csrc/host/relax.hpp): relax(graph, nodes, cam_models, edges,
      *      {ORIENTATION, GROUND_PLANE}, {}) of src/relax/relax.cpp:122-134 ------------------------------ */

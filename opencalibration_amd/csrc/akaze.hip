@@ -50,7 +50,7 @@ __global__ void gray_kernel(const uint8_t *__restrict__ bgr, uint8_t *__restrict
         gray[i] = (uint8_t)((bgr[3 * i] * 1868 + bgr[3 * i + 1] * 9617 + bgr[3 * i + 2] * 4899 + (1 << 13)) >> 14);
 }
 
-__global__ void resize_area_kernel(const uint8_t *__restrict__ src, int sw, int sh, uint8_t *__restrict__ dst, int dw,
+__global__ void resize_area_kernel(const uint8_t *__restrict__ src, int sw, int sh, float *__restrict__ dst, int dw,
                                    int dh, const int *__restrict__ xoff, const int *__restrict__ xsi,
                                    const float *__restrict__ xal, const int *__restrict__ yoff,
                                    const int *__restrict__ ysi, const float *__restrict__ yal)
@@ -69,7 +69,23 @@ __global__ void resize_area_kernel(const uint8_t *__restrict__ src, int sw, int 
         acc += r * yal[e];
     }
     const float v = rintf(acc);
-    dst[(size_t)blockIdx.z * dw * dh + (size_t)y * dw + x] = (uint8_t)fminf(255.0f, fmaxf(0.0f, v));
+    // saturate to the 8-bit working image, then the 1/255 float conversion in front of AKAZE
+    dst[(size_t)blockIdx.z * dw * dh + (size_t)y * dw + x] = (float)(uint8_t)fminf(255.0f, fmaxf(0.0f, v)) * (1.0f / 255.0f);
+}
+
+// four pixels per thread: three 32-bit loads carry 4 BGR triplets, one 32-bit store carries 4 grey bytes
+__global__ void gray4_kernel(const uint32_t *__restrict__ bgr, uint32_t *__restrict__ gray, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4)
+        return;
+    const uint32_t w0 = bgr[3 * i], w1 = bgr[3 * i + 1], w2 = bgr[3 * i + 2];
+    auto g = [](uint32_t b, uint32_t gg, uint32_t r) { return (b * 1868u + gg * 9617u + r * 4899u + (1u << 13)) >> 14; };
+    const uint32_t p0 = g(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
+    const uint32_t p1 = g(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
+    const uint32_t p2 = g((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
+    const uint32_t p3 = g((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
+    gray[i] = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
 }
 
 __global__ void to_float_kernel(const uint8_t *__restrict__ g, float *__restrict__ out, size_t n)
@@ -87,58 +103,166 @@ struct taps_t
     float k[MAX_TAPS];
 };
 
-template <bool ROWS>
-__global__ void conv_kernel(const float *__restrict__ in, float *__restrict__ out, int w, int h, size_t in_stride,
-                            size_t out_stride, taps_t t)
+// ---- fused separable Gaussian + the 3x3-pattern stencil that consumes it.  A 256-thread workgroup owns a
+// 64 x 32 output tile: the input tile (+ halo) is staged in LDS once, the row pass and the column pass run
+// LDS -> LDS, and the consumer (Scharr flow / gradient magnitude / scale-s derivatives) reads the blurred tile
+// from LDS, so one launch moves 4 B/pixel in and 4-8 B/pixel out instead of the 16 + 8..12 of separate passes.
+// Every value is the same float expression as the separate passes (ascending tap order, clamped source
+// coordinates for the blur, reflected coordinates for the stencil), so the fusion does not change a bit.
+constexpr int BT_X = 64, BT_Y = 32;
+enum
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w)
-        return;
-    const float *I = in + (size_t)blockIdx.z * in_stride;
-    const int r = t.n / 2;
-    float acc = 0.0f;
-    if (ROWS)
-        for (int i = 0; i < t.n; i++)
-            acc = acc + t.k[i] * I[(size_t)y * w + clampi(x + i - r, 0, w - 1)];
-    else
-        for (int i = 0; i < t.n; i++)
-            acc = acc + t.k[i] * I[(size_t)clampi(y + i - r, 0, h - 1) * w + x];
-    out[(size_t)blockIdx.z * out_stride + (size_t)y * w + x] = acc;
+    BLUR_PLAIN = 0,
+    BLUR_FLOW = 1,
+    BLUR_MODG = 2,
+    BLUR_DERIV = 3
+};
+
+// 3-row pattern (wa * a + wb * b) + wa * c of Scharr-type derivatives, samples fetched through `at(x, y)`
+template <typename F>
+__device__ __forceinline__ void pattern_xy(F at, int xm, int x, int xp, int ym, int y, int yp, float wa, float wb, float *dx,
+                                           float *dy)
+{
+    const float a = at(xp, ym) - at(xm, ym);
+    const float b = at(xp, y) - at(xm, y);
+    const float c = at(xp, yp) - at(xm, yp);
+    *dx = (wa * a + wb * b) + wa * c;
+    const float d = at(xm, yp) - at(xm, ym);
+    const float e = at(x, yp) - at(x, ym);
+    const float f = at(xp, yp) - at(xp, ym);
+    *dy = (wa * d + wb * e) + wa * f;
 }
 
-__device__ __forceinline__ void scharr3(const float *I, int w, int h, int x, int y, float *lx, float *ly)
+struct blur_args
 {
-    const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w), ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
-    const float a = I[(size_t)ym * w + xp] - I[(size_t)ym * w + xm];
-    const float b = I[(size_t)y * w + xp] - I[(size_t)y * w + xm];
-    const float c = I[(size_t)yp * w + xp] - I[(size_t)yp * w + xm];
-    *lx = (3.0f * a + 10.0f * b) + 3.0f * c;
-    const float d = I[(size_t)yp * w + xm] - I[(size_t)ym * w + xm];
-    const float e = I[(size_t)yp * w + x] - I[(size_t)ym * w + x];
-    const float f = I[(size_t)yp * w + xp] - I[(size_t)ym * w + xp];
-    *ly = (3.0f * d + 10.0f * e) + 3.0f * f;
-}
+    const float *in;
+    size_t in_stride;
+    float *out0, *out1;
+    size_t out_stride;
+    int w, h;
+    const float *kcontrast; // FLOW
+    int n_octave_steps;     // FLOW
+    unsigned int *partial_max; // MODG: [image][workgroup] bit patterns of the tile maxima
+};
 
-// ---- contrast factor: gradient-magnitude histogram of the smoothed input (compute_k_percentile)
-__global__ void modg_kernel(const float *__restrict__ sm, float *__restrict__ modg, int w, int h, size_t stride,
-                            unsigned int *__restrict__ hmax_bits)
+template <int MODE, int M /*margin of the blurred tile*/, int R /*tap radius*/>
+__global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    float m = 0.0f;
-    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1)
+    constexpr int BW = BT_X + 2 * M, BH = BT_Y + 2 * M, IW = BW + 2 * R, IH = BH + 2 * R;
+    __shared__ float tin[IW * IH];  // input tile; reused for the blurred tile (BW x BH)
+    __shared__ float trow[BW * IH]; // row pass
+    const int w = A.w, h = A.h;
+    const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
+    const int bx0 = x0 - M, by0 = y0 - M;
+    const float *I = A.in + (size_t)blockIdx.z * A.in_stride;
+    for (int idx = threadIdx.x; idx < IW * IH; idx += 256)
     {
-        float lx, ly;
-        scharr3(sm + (size_t)blockIdx.z * stride, w, h, x, y, &lx, &ly);
-        m = sqrtf(lx * lx + ly * ly);
+        const int ly = idx / IW, lx = idx - ly * IW;
+        tin[idx] = I[(size_t)clampi(by0 - R + ly, 0, h - 1) * w + clampi(bx0 - R + lx, 0, w - 1)];
     }
-    if (x < w)
-        modg[(size_t)blockIdx.z * stride + (size_t)y * w + x] = m;
-    // one atomic per wavefront: non-negative floats order like their bit patterns
-    unsigned int bits = __float_as_uint(m);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < BW * IH; idx += 256)
+    {
+        const int ly = idx / BW, lx = idx - ly * BW;
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2 * R + 1; i++)
+            acc = acc + t.k[i] * tin[ly * IW + lx + i];
+        trow[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < BW * BH; idx += 256)
+    {
+        const int ly = idx / BW, lx = idx - ly * BW;
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2 * R + 1; i++)
+            acc = acc + t.k[i] * trow[(ly + i) * BW + lx];
+        if (MODE == BLUR_PLAIN)
+        {
+            const int x = bx0 + lx, y = by0 + ly;
+            if (x < w && y < h)
+                A.out0[(size_t)blockIdx.z * A.out_stride + (size_t)y * w + x] = acc;
+        }
+        else
+            tin[idx] = acc;
+    }
+    if (MODE == BLUR_PLAIN)
+        return;
+    __syncthreads();
+    auto at = [&](int xx, int yy) { return tin[(yy - by0) * BW + (xx - bx0)]; };
+    float k = 0.0f, inv = 0.0f, vmax = 0.0f;
+    if (MODE == BLUR_FLOW)
+    {
+        k = A.kcontrast[blockIdx.z];
+        for (int i = 0; i < A.n_octave_steps; i++) // kcontrast *= 0.75 at every new octave, one rounding per step
+            k = k * 0.75f;
+        inv = 1.0f / (k * k);
+    }
+    for (int idx = threadIdx.x; idx < BT_X * BT_Y; idx += 256)
+    {
+        const int ly = idx / BT_X, lx = idx - ly * BT_X;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= w || y >= h)
+            continue;
+        const size_t o = (size_t)blockIdx.z * A.out_stride + (size_t)y * w + x;
+        if (MODE == BLUR_DERIV)
+        {
+            const float wgt = 10.0f / 3.0f;
+            const float nrm = 1.0f / (2.0f * (float)M * (wgt + 2.0f));
+            const float wn = wgt * nrm;
+            float dx, dy;
+            pattern_xy(at, reflect101(x - M, w), x, reflect101(x + M, w), reflect101(y - M, h), y, reflect101(y + M, h), nrm,
+                       wn, &dx, &dy);
+            A.out0[o] = dx;
+            A.out1[o] = dy;
+        }
+        else
+        {
+            float lx_, ly_;
+            pattern_xy(at, reflect101(x - 1, w), x, reflect101(x + 1, w), reflect101(y - 1, h), y, reflect101(y + 1, h), 3.0f,
+                       10.0f, &lx_, &ly_);
+            if (MODE == BLUR_FLOW)
+                A.out0[o] = 1.0f / (1.0f + inv * (lx_ * lx_ + ly_ * ly_));
+            else
+            {
+                const bool interior = x >= 1 && x < w - 1 && y >= 1 && y < h - 1;
+                const float m = interior ? sqrtf(lx_ * lx_ + ly_ * ly_) : 0.0f;
+                A.out0[o] = m;
+                vmax = fmaxf(vmax, m);
+            }
+        }
+    }
+    if (MODE == BLUR_MODG)
+    {
+        // tile maximum -> partial_max (non-negative floats order like their bit patterns); reduced per image
+        // by hmax_reduce_kernel: no same-address atomics
+        __shared__ unsigned int wmax[4];
+        unsigned int bits = __float_as_uint(vmax);
+        for (int off = 32; off >= 1; off >>= 1)
+            bits = max(bits, (unsigned int)__shfl_xor((int)bits, off));
+        if ((threadIdx.x & 63) == 0)
+            wmax[threadIdx.x >> 6] = bits;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            A.partial_max[(size_t)blockIdx.z * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+                max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    }
+}
+
+__global__ void hmax_reduce_kernel(const unsigned int *__restrict__ partial, int n_partial, unsigned int *__restrict__ hmax_bits)
+{
+    __shared__ unsigned int wmax[4];
+    unsigned int bits = 0;
+    for (int i = threadIdx.x; i < n_partial; i += 256)
+        bits = max(bits, partial[(size_t)blockIdx.x * n_partial + i]);
     for (int off = 32; off >= 1; off >>= 1)
         bits = max(bits, (unsigned int)__shfl_xor((int)bits, off));
-    if ((threadIdx.x & 63) == 0 && bits != 0)
-        atomicMax(hmax_bits + blockIdx.z, bits);
+    if ((threadIdx.x & 63) == 0)
+        wmax[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        hmax_bits[blockIdx.x] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
 }
 
 __global__ void hist_kernel(const float *__restrict__ modg, int w, int h, size_t stride,
@@ -191,36 +315,37 @@ __global__ void kcontrast_kernel(const unsigned int *__restrict__ hist, const un
     kcontrast[b] = nelements < nthreshold ? 0.03f : __uint_as_float(hmax_bits[b]) * ((float)k / (float)nbins);
 }
 
-// ---- diffusion
-__global__ void flow_kernel(const float *__restrict__ sm, float *__restrict__ flow, int w, int h, size_t stride,
-                            const float *__restrict__ kcontrast, int n_octave_steps)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w)
-        return;
-    float k = kcontrast[blockIdx.z];
-    for (int i = 0; i < n_octave_steps; i++) // kcontrast *= 0.75 at every new octave, one rounding per step
-        k = k * 0.75f;
-    const float inv = 1.0f / (k * k);
-    float lx, ly;
-    scharr3(sm + (size_t)blockIdx.z * stride, w, h, x, y, &lx, &ly);
-    flow[(size_t)blockIdx.z * stride + (size_t)y * w + x] = 1.0f / (1.0f + inv * (lx * lx + ly * ly));
-}
-
-__global__ void nld_step_kernel(const float *__restrict__ Lin, const float *__restrict__ cflow, float *__restrict__ Lout,
+// ---- diffusion (the PM-G2 conductivity is BLUR_FLOW above)
+constexpr int NLD_ROWS = 16;
+__global__ __launch_bounds__(256) void nld_step_kernel(const float *__restrict__ Lin, const float *__restrict__ cflow, float *__restrict__ Lout,
                                 int w, int h, size_t l_stride, size_t c_stride, size_t out_stride, float tau)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    // a workgroup walks NLD_ROWS rows of a 256-pixel column band; the centre column of L and c slides through
+    // registers (one new load of each per row), the left / right neighbours come from L1
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= w)
         return;
     const float *L = Lin + (size_t)blockIdx.z * l_stride, *c = cflow + (size_t)blockIdx.z * c_stride;
-    const size_t i = (size_t)y * w + x;
+    float *O = Lout + (size_t)blockIdx.z * out_stride;
     const float half = 0.5f * tau;
-    const float xpos = x + 1 < w ? (c[i] + c[i + 1]) * (L[i + 1] - L[i]) : 0.0f;
-    const float xneg = x > 0 ? (c[i - 1] + c[i]) * (L[i] - L[i - 1]) : 0.0f;
-    const float ypos = y + 1 < h ? (c[i] + c[i + w]) * (L[i + w] - L[i]) : 0.0f;
-    const float yneg = y > 0 ? (c[i - w] + c[i]) * (L[i] - L[i - w]) : 0.0f;
-    Lout[(size_t)blockIdx.z * out_stride + i] = L[i] + half * ((xpos - xneg) + (ypos - yneg));
+    const int y_begin = blockIdx.y * NLD_ROWS, y_end = min(y_begin + NLD_ROWS, h);
+    size_t i = (size_t)y_begin * w + x;
+    float Lm = y_begin > 0 ? L[i - w] : 0.0f, cm = y_begin > 0 ? c[i - w] : 0.0f;
+    float Lc = L[i], cc = c[i];
+    for (int y = y_begin; y < y_end; y++, i += w)
+    {
+        const bool has_next = y + 1 < h;
+        const float Lp = has_next ? L[i + w] : 0.0f, cp = has_next ? c[i + w] : 0.0f;
+        const float xpos = x + 1 < w ? (cc + c[i + 1]) * (L[i + 1] - Lc) : 0.0f;
+        const float xneg = x > 0 ? (c[i - 1] + cc) * (Lc - L[i - 1]) : 0.0f;
+        const float ypos = has_next ? (cc + cp) * (Lp - Lc) : 0.0f;
+        const float yneg = y > 0 ? (cm + cc) * (Lc - Lm) : 0.0f;
+        O[i] = Lc + half * ((xpos - xneg) + (ypos - yneg));
+        Lm = Lc;
+        cm = cc;
+        Lc = Lp;
+        cc = cp;
+    }
 }
 
 __global__ void halfsample_kernel(const float *__restrict__ in, int w, int h, size_t in_stride, float *__restrict__ out,
@@ -258,21 +383,6 @@ __device__ __forceinline__ void deriv_at(const float *I, int w, int h, int s, in
     *dy = (nrm * d + wn * e) + nrm * f;
 }
 
-__global__ void deriv_kernel(const float *__restrict__ sm, size_t sm_stride, float *__restrict__ Lx, float *__restrict__ Ly,
-                             size_t out_stride, int w, int h, int s)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w)
-        return;
-    const float wgt = 10.0f / 3.0f;
-    const float nrm = 1.0f / (2.0f * (float)s * (wgt + 2.0f));
-    const float wn = wgt * nrm;
-    float dx, dy;
-    deriv_at(sm + (size_t)blockIdx.z * sm_stride, w, h, s, x, y, nrm, wn, &dx, &dy);
-    Lx[(size_t)blockIdx.z * out_stride + (size_t)y * w + x] = dx;
-    Ly[(size_t)blockIdx.z * out_stride + (size_t)y * w + x] = dy;
-}
-
 __global__ void det_kernel(const float *__restrict__ Lx, const float *__restrict__ Ly, size_t stride,
                            float *__restrict__ Ldet, int w, int h, int s)
 {
@@ -298,35 +408,54 @@ struct cand_t
 
 // 3x3 strict maxima above the threshold: appended to the image's candidate list and written to the level's
 // sparse maxima map (0 elsewhere) that the scale-space suppression scans
-__global__ void maxima_kernel(const float *__restrict__ Ldet, float *__restrict__ Rmax, size_t stride, int w, int h,
+constexpr int MAXIMA_ROWS = 32;
+__global__ __launch_bounds__(256) void maxima_kernel(const float *__restrict__ Ldet, float *__restrict__ Rmax, size_t stride, int w, int h,
                               int level, float thr, cand_t *__restrict__ cands, unsigned int *__restrict__ n_cands,
                               unsigned int max_cands)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w)
-        return;
+    // a workgroup owns a 256 x MAXIMA_ROWS pixel tile; its maxima are collected in LDS and appended to the
+    // image's list with ONE global atomic (same-address atomics serialise at ~0.2 us each on this part).
+    // Strict 3x3 maxima cannot touch, so a tile holds at most 128 x MAXIMA_ROWS / 2 of them.
+    __shared__ cand_t lc[128 * MAXIMA_ROWS / 2];
+    __shared__ unsigned int lcount, lbase;
+    if (threadIdx.x == 0)
+        lcount = 0;
+    __syncthreads();
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const float *D = Ldet + (size_t)blockIdx.z * stride;
-    float out = 0.0f;
-    if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1)
-    {
-        const float v = D[(size_t)y * w + x];
-        if (v > thr)
+    if (x < w)
+        for (int r = 0; r < MAXIMA_ROWS; r++)
         {
-            bool mx = true;
-            for (int dy = -1; dy <= 1; dy++)
-                for (int dx = -1; dx <= 1; dx++)
-                    if ((dx || dy) && !(v > D[(size_t)(y + dy) * w + x + dx]))
-                        mx = false;
-            if (mx)
+            const int y = blockIdx.y * MAXIMA_ROWS + r;
+            if (y >= h)
+                break;
+            float out = 0.0f;
+            if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1)
             {
-                out = v;
-                const unsigned int slot = atomicAdd(n_cands + blockIdx.z, 1u);
-                if (slot < max_cands)
-                    cands[(size_t)blockIdx.z * max_cands + slot] = cand_t{level, x, y, v};
+                const float v = D[(size_t)y * w + x];
+                if (v > thr)
+                {
+                    bool mx = true;
+                    for (int dy = -1; dy <= 1; dy++)
+                        for (int dx = -1; dx <= 1; dx++)
+                            if ((dx || dy) && !(v > D[(size_t)(y + dy) * w + x + dx]))
+                                mx = false;
+                    if (mx)
+                    {
+                        out = v;
+                        lc[atomicAdd(&lcount, 1u)] = cand_t{level, x, y, v};
+                    }
+                }
             }
+            Rmax[(size_t)blockIdx.z * stride + (size_t)y * w + x] = out;
         }
-    }
-    Rmax[(size_t)blockIdx.z * stride + (size_t)y * w + x] = out;
+    __syncthreads();
+    if (threadIdx.x == 0 && lcount)
+        lbase = atomicAdd(n_cands + blockIdx.z, lcount);
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < lcount; i += blockDim.x)
+        if (lbase + i < max_cands)
+            cands[(size_t)blockIdx.z * max_cands + lbase + i] = lc[i];
 }
 
 struct levels_dev
@@ -440,6 +569,7 @@ __device__ __forceinline__ void sincos_poly(float a, float *s, float *c)
 struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cells numbered 0..3 | 4..12 | 13..28
 {
     unsigned char a[486], b[486], ch[486];
+    unsigned char ori_q[109]; // orientation samples: position (i + 6) * 13 + (j + 6) of the n-th member of the radius-6 disc
 };
 
 // One 64-thread workgroup per surviving candidate: sub-pixel fit, dominant orientation, 486-bit M-LDB.
@@ -457,6 +587,8 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
     __shared__ float resX[109], resY[109], Ang[109];
     __shared__ float wm[42], wang[42];
     __shared__ float vals[29][3];
+    __shared__ float smp[3][441];        // the 21 x 21 descriptor sample lattice: intensity, rotated dx, rotated dy
+    __shared__ unsigned char smp_ok[441]; // sample inside the level image
     const int lane = threadIdx.x;
     const unsigned int k = blockIdx.x, b = blockIdx.z;
     const unsigned int n = min(n_cands[b], max_cands);
@@ -505,26 +637,17 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
                 *pLy = Ly + (size_t)b * img_stride + l.off;
 
     // orientation samples: index order i (outer), j (inner) over the radius-6 disc
-    for (int q = lane; q < 169; q += 64)
+    for (int idx = lane; idx < 109; idx += 64)
     {
+        const int q = tab->ori_q[idx]; // the idx-th member of the disc in (i, j) scan order
         const int i = q / 13 - 6, j = q % 13 - 6;
-        if (i * i + j * j < 36)
-        {
-            // position of (i, j) in the compacted list = number of disc members before it
-            int idx = 0;
-            for (int qq = 0; qq < q; qq++)
-            {
-                const int ii = qq / 13 - 6, jj = qq % 13 - 6;
-                idx += (ii * ii + jj * jj < 36) ? 1 : 0;
-            }
-            const int iy = clampi((int)rintf(yf + (float)(j * s)), 0, h - 1);
-            const int ix = clampi((int)rintf(xf + (float)(i * s)), 0, w - 1);
-            const float g = gw[(i + 6) * 13 + (j + 6)];
-            const float rx = g * pLx[(size_t)iy * w + ix], ry = g * pLy[(size_t)iy * w + ix];
-            resX[idx] = rx;
-            resY[idx] = ry;
-            Ang[idx] = fast_atan2(ry, rx);
-        }
+        const int iy = clampi((int)rintf(yf + (float)(j * s)), 0, h - 1);
+        const int ix = clampi((int)rintf(xf + (float)(i * s)), 0, w - 1);
+        const float g = gw[q];
+        const float rx = g * pLx[(size_t)iy * w + ix], ry = g * pLy[(size_t)iy * w + ix];
+        resX[idx] = rx;
+        resY[idx] = ry;
+        Ang[idx] = fast_atan2(ry, rx);
     }
     __syncthreads();
     const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
@@ -556,6 +679,29 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
     float si, co;
     sincos_poly(angle, &si, &co);
     const float fs = (float)s;
+    // every grid (2x2, 3x3, 4x4) samples the same rotated 21 x 21 lattice: gather it once with all lanes,
+    // then run the per-cell sums in their sequential order out of LDS
+    for (int p = lane; p < 441; p += 64)
+    {
+        const int a = p / 21 - 10, bb = p % 21 - 10;
+        const float sy = yf + ((float)bb * co * fs + (float)a * si * fs);
+        const float sx = xf + (-(float)bb * si * fs + (float)a * co * fs);
+        const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
+        const bool inside = !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
+        float ri = 0.0f, rrx = 0.0f, rry = 0.0f;
+        if (inside)
+        {
+            ri = pLt[(size_t)y1 * w + x1];
+            const float rx = pLx[(size_t)y1 * w + x1], ry = pLy[(size_t)y1 * w + x1];
+            rry = rx * co + ry * si;
+            rrx = -rx * si + ry * co;
+        }
+        smp[0][p] = ri;
+        smp[1][p] = rrx;
+        smp[2][p] = rry;
+        smp_ok[p] = inside ? 1 : 0;
+    }
+    __syncthreads();
     if (lane < 29)
     {
         int lvl, cell;
@@ -573,17 +719,13 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         for (int a = i0; a < i0 + step; a++)
             for (int bb = j0; bb < j0 + step; bb++)
             {
-                const float sy = yf + ((float)bb * co * fs + (float)a * si * fs);
-                const float sx = xf + (-(float)bb * si * fs + (float)a * co * fs);
-                const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
-                if (x1 < 0 || y1 < 0 || x1 >= w || y1 >= h)
-                    continue;
-                const float ri = pLt[(size_t)y1 * w + x1], rx = pLx[(size_t)y1 * w + x1], ry = pLy[(size_t)y1 * w + x1];
-                di = di + ri;
-                const float rry = rx * co + ry * si, rrx = -rx * si + ry * co;
-                ddx = ddx + rrx;
-                ddy = ddy + rry;
-                ns++;
+                // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
+                // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch here
+                const int p = (a + 10) * 21 + (bb + 10);
+                di = di + smp[0][p];
+                ddx = ddx + smp[1][p];
+                ddy = ddy + smp[2][p];
+                ns += smp_ok[p];
             }
         const float inv = (float)max(ns, 1);
         vals[lane][0] = di / inv;
@@ -612,6 +754,50 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         o[5] = (float)c.level;
         valid_out[slot] = 1;
     }
+}
+
+// Stream compaction of the described keypoints of one image (one workgroup per image, ascending slot order):
+// only the survivors cross PCIe.  counts[b] is the number found; entries beyond max_kp are dropped and the host
+// reports the overflow.
+__global__ __launch_bounds__(256) void compact_kernel(const unsigned char *__restrict__ valid, const unsigned int *__restrict__ n_cands,
+                                                      unsigned int max_cands, const float *__restrict__ kp,
+                                                      const unsigned long long *__restrict__ desc, float *__restrict__ kp_out,
+                                                      unsigned long long *__restrict__ desc_out, unsigned int max_kp,
+                                                      unsigned int *__restrict__ counts)
+{
+    __shared__ unsigned int wsum[4], base;
+    const unsigned int b = blockIdx.x, n = min(n_cands[b], max_cands);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        base = 0;
+    __syncthreads();
+    for (unsigned int start = 0; start < n; start += 256)
+    {
+        const unsigned int k = start + threadIdx.x;
+        const size_t slot = (size_t)b * max_cands + k;
+        const bool v = k < n && valid[slot] != 0;
+        const unsigned long long mask = __ballot(v);
+        if (lane == 0)
+            wsum[wv] = (unsigned int)__popcll(mask);
+        __syncthreads();
+        unsigned int pos = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+        for (int j = 0; j < wv; j++)
+            pos += wsum[j];
+        if (v && pos < max_kp)
+        {
+            const size_t o = (size_t)b * max_kp + pos;
+            for (int i = 0; i < 6; i++)
+                kp_out[o * 6 + i] = kp[slot * 6 + i];
+            for (int i = 0; i < 8; i++)
+                desc_out[o * 8 + i] = desc[slot * 8 + i];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        counts[b] = base;
 }
 
 // ---------------------------------------------------------------------------------------- host side
@@ -955,27 +1141,30 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         if (rc == OCHIP_OK)                                                                                            \
             rc = (call);                                                                                               \
     } while (0)
-    uint8_t *d_bgr = nullptr, *d_gray = nullptr, *d_small = nullptr;
-    float *d_img = nullptr, *d_tmp = nullptr, *d_sm = nullptr, *d_flow = nullptr, *d_ping = nullptr;
+    uint8_t *d_bgr = nullptr, *d_gray = nullptr;
+    float *d_img = nullptr, *d_flow = nullptr, *d_ping = nullptr;
     float *d_Lt = nullptr, *d_Lx = nullptr, *d_Ly = nullptr, *d_Ldet = nullptr, *d_Rmax = nullptr, *d_kc = nullptr,
           *d_gw = nullptr, *d_kp = nullptr;
-    unsigned int *d_hmax = nullptr, *d_hist = nullptr, *d_ncand = nullptr;
+    unsigned int *d_hmax = nullptr, *d_hist = nullptr, *d_ncand = nullptr, *d_pmax = nullptr;
     cand_t *d_cands = nullptr;
     unsigned char *d_dead = nullptr, *d_valid = nullptr;
-    unsigned long long *d_desc = nullptr;
+    unsigned long long *d_desc = nullptr, *d_descc = nullptr;
+    float *d_kpc = nullptr;
+    unsigned int *d_counts = nullptr;
     pair_tab *d_tab = nullptr;
     const size_t src_px = (size_t)width * height;
+    auto tiles = [&](int w, int h) { return dim3((w + BT_X - 1) / BT_X, (h + BT_Y - 1) / BT_Y, B); };
+    const dim3 tiles0 = tiles(W, H);
+    const int n_tiles0 = (int)(tiles0.x * tiles0.y);
     if (on_device)
         d_bgr = const_cast<uint8_t *>(images_bgr);
     else
         AK(up(ctx, allocs, &d_bgr, images_bgr, (size_t)B * src_px * 3));
-    AK(up<uint8_t>(ctx, allocs, &d_gray, nullptr, (size_t)B * src_px));
-    AK(up<uint8_t>(ctx, allocs, &d_small, nullptr, (size_t)B * plane0));
+    AK(up<uint8_t>(ctx, allocs, &d_gray, nullptr, (size_t)B * src_px + 4));
     AK(up<float>(ctx, allocs, &d_img, nullptr, (size_t)B * plane0));
-    AK(up<float>(ctx, allocs, &d_tmp, nullptr, (size_t)B * plane0));
-    AK(up<float>(ctx, allocs, &d_sm, nullptr, (size_t)B * plane0));
     AK(up<float>(ctx, allocs, &d_flow, nullptr, (size_t)B * plane0));
     AK(up<float>(ctx, allocs, &d_ping, nullptr, (size_t)B * plane0));
+    AK(up<unsigned int>(ctx, allocs, &d_pmax, nullptr, (size_t)B * n_tiles0));
     AK(up<float>(ctx, allocs, &d_Lt, nullptr, (size_t)B * img_stride));
     AK(up<float>(ctx, allocs, &d_Lx, nullptr, (size_t)B * img_stride));
     AK(up<float>(ctx, allocs, &d_Ly, nullptr, (size_t)B * img_stride));
@@ -990,6 +1179,9 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     AK(up<unsigned char>(ctx, allocs, &d_valid, nullptr, (size_t)B * max_cands));
     AK(up<float>(ctx, allocs, &d_kp, nullptr, (size_t)B * max_cands * 6));
     AK(up<unsigned long long>(ctx, allocs, &d_desc, nullptr, (size_t)B * max_cands * 8));
+    AK(up<float>(ctx, allocs, &d_kpc, nullptr, (size_t)B * max_kp * 6));
+    AK(up<unsigned long long>(ctx, allocs, &d_descc, nullptr, (size_t)B * max_kp * 8));
+    AK(up<unsigned int>(ctx, allocs, &d_counts, nullptr, B));
     {
         std::vector<float> gw(169);
         for (int i = -6; i <= 6; i++)
@@ -1013,6 +1205,13 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                         dpos++;
                     }
         }
+        int nq = 0;
+        for (int q = 0; q < 169; q++)
+        {
+            const int i = q / 13 - 6, j = q % 13 - 6;
+            if (i * i + j * j < 36)
+                tab.ori_q[nq++] = (unsigned char)q;
+        }
         AK(up(ctx, allocs, &d_tab, &tab, 1));
     }
     if (rc != OCHIP_OK)
@@ -1028,18 +1227,30 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             t.k[i] = k[i];
         return t;
     };
-    auto blur = [&](const float *in, size_t in_stride, float *out, size_t out_stride, int w, int h, const taps_t &t) {
-        hipLaunchKernelGGL(conv_kernel<true>, grid2(w, h), dim3(256), 0, st, in, d_tmp, w, h, in_stride, plane0, t);
-        hipLaunchKernelGGL(conv_kernel<false>, grid2(w, h), dim3(256), 0, st, (const float *)d_tmp, out, w, h, plane0,
-                           out_stride, t);
-    };
+    const taps_t g1 = taps_of(gaussian_taps(1.0f)), g0 = taps_of(gaussian_taps(soffset));
+    if (g1.n != 5 || g0.n != 9)
+    {
+        cleanup();
+        return ochip_fail(ctx, OCHIP_EINVAL, "akaze: unexpected Gaussian kernel sizes %d / %d", g1.n, g0.n);
+    }
     hipEvent_t e0, e1;
     ochip_prof_begin(ctx, OCHIP_K_AKAZE, &e0, &e1);
 
     // ---- grey, downscale, float
-    hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((B * src_px + 255) / 256)), dim3(256), 0, st, d_bgr, d_gray, B * src_px);
+    const size_t n_px = (size_t)B * src_px;
+    if (((uintptr_t)d_bgr & 3) == 0)
+        hipLaunchKernelGGL(gray4_kernel, dim3((unsigned)(((n_px + 3) / 4 + 255) / 256)), dim3(256), 0, st,
+                           (const uint32_t *)d_bgr, (uint32_t *)d_gray, n_px / 4);
+    if (((uintptr_t)d_bgr & 3) != 0 || (n_px & 3))
+    {
+        // unaligned source or a tail of < 4 pixels: byte-wise
+        const size_t first = ((uintptr_t)d_bgr & 3) ? 0 : (n_px & ~(size_t)3);
+        hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((n_px - first + 255) / 256)), dim3(256), 0, st, d_bgr + 3 * first,
+                           d_gray + first, n_px - first);
+    }
     if (W == width && H == height)
-        OCHIP_HIP(ctx, hipMemcpyAsync(d_small, d_gray, B * src_px, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)((B * plane0 + 255) / 256)), dim3(256), 0, st, d_gray, d_img,
+                           B * plane0);
     else
     {
         const area_tab tx = area_table(width, W), ty = area_table(height, H);
@@ -1056,69 +1267,87 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             cleanup();
             return rc;
         }
-        hipLaunchKernelGGL(resize_area_kernel, grid2(W, H), dim3(256), 0, st, d_gray, width, height, d_small, W, H, xo, xs,
-                           xa, yo, ys, ya);
+        hipLaunchKernelGGL(resize_area_kernel, grid2(W, H), dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs, xa,
+                           yo, ys, ya);
     }
-    hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)((B * plane0 + 255) / 256)), dim3(256), 0, st, d_small, d_img,
-                       B * plane0);
 
-    // ---- contrast factor
-    const taps_t g1 = taps_of(gaussian_taps(1.0f));
-    OCHIP_HIP(ctx, hipMemsetAsync(d_hmax, 0, B * 4, st));
+    // ---- contrast factor: Gaussian(1) + gradient magnitude + per-tile maxima in one pass, then the histogram
     OCHIP_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)B * 301 * 4, st));
-    blur(d_img, plane0, d_sm, plane0, W, H, g1);
-    hipLaunchKernelGGL(modg_kernel, grid2(W, H), dim3(256), 0, st, (const float *)d_sm, d_flow, W, H, plane0, d_hmax);
+    {
+        blur_args a{d_img, plane0, d_flow, nullptr, plane0, W, H, nullptr, 0, d_pmax};
+        hipLaunchKernelGGL((blur_fused_kernel<BLUR_MODG, 1, 2>), tiles0, dim3(256), 0, st, a, g1);
+        hipLaunchKernelGGL(hmax_reduce_kernel, dim3(B), dim3(256), 0, st, (const unsigned int *)d_pmax, n_tiles0, d_hmax);
+    }
     hipLaunchKernelGGL(hist_kernel, dim3((W + 255) / 256, (H + 7) / 8, B), dim3(256), 0, st, (const float *)d_flow, W, H,
                        plane0, d_hmax, 300, d_hist);
     hipLaunchKernelGGL(kcontrast_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_hist, d_hmax, 300, 0.7f, d_kc, (int)B);
 
     // ---- nonlinear scale space
-    blur(d_img, plane0, d_Lt + LV.l[0].off, img_stride, W, H, taps_of(gaussian_taps(soffset)));
+    {
+        blur_args a{d_img, plane0, d_Lt + LV.l[0].off, nullptr, img_stride, W, H, nullptr, 0, nullptr};
+        hipLaunchKernelGGL((blur_fused_kernel<BLUR_PLAIN, 0, 4>), tiles0, dim3(256), 0, st, a, g0);
+    }
     int octave_steps = 0;
     for (int i = 1; i < LV.n; i++)
     {
         const level_info &l = LV.l[i], &p = LV.l[i - 1];
         float *cur = d_Lt + l.off;
         const size_t np = (size_t)l.w * l.h;
+        const size_t n_steps = tsteps[i].size();
+        // the level starts from the previous level's image (half-sampled at a new octave); the FED steps ping-pong
+        // between the level plane and a scratch plane, arranged so that the last step lands in the level plane
+        const float *src = d_Lt + p.off;
+        size_t src_stride = img_stride;
         if (l.octave > p.octave)
         {
+            float *dst = (n_steps % 2 == 0) ? cur : d_ping;
+            const size_t dst_stride = (n_steps % 2 == 0) ? img_stride : plane0;
             hipLaunchKernelGGL(halfsample_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Lt + p.off), p.w, p.h,
-                               img_stride, cur, l.w, l.h, img_stride);
+                               img_stride, dst, l.w, l.h, dst_stride);
+            src = dst;
+            src_stride = dst_stride;
             octave_steps++;
         }
-        else
-            hipLaunchKernelGGL(copy_plane_kernel, dim3((unsigned)((np + 255) / 256), 1, B), dim3(256), 0, st,
-                               (const float *)(d_Lt + p.off), img_stride, cur, img_stride, np);
-        blur(cur, img_stride, d_sm, plane0, l.w, l.h, g1);
-        hipLaunchKernelGGL(flow_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)d_sm, d_flow, l.w, l.h, plane0,
-                           (const float *)d_kc, octave_steps);
-        // FED inner steps, ping-pong between the level plane and a scratch plane
-        bool in_cur = true;
-        for (float tau : tsteps[i])
         {
-            if (in_cur)
-                hipLaunchKernelGGL(nld_step_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)cur, (const float *)d_flow,
-                                   d_ping, l.w, l.h, img_stride, plane0, plane0, tau);
-            else
-                hipLaunchKernelGGL(nld_step_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)d_ping,
-                                   (const float *)d_flow, cur, l.w, l.h, plane0, plane0, img_stride, tau);
-            in_cur = !in_cur;
+            blur_args a{src, src_stride, d_flow, nullptr, plane0, l.w, l.h, d_kc, octave_steps, nullptr};
+            hipLaunchKernelGGL((blur_fused_kernel<BLUR_FLOW, 1, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
         }
-        if (!in_cur) // odd number of steps: result sits in the scratch plane
-            hipLaunchKernelGGL(copy_plane_kernel, dim3((unsigned)((np + 255) / 256), 1, B), dim3(256), 0, st,
-                               (const float *)d_ping, plane0, cur, img_stride, np);
+        if (n_steps == 0)
+            hipLaunchKernelGGL(copy_plane_kernel, dim3((unsigned)((np + 255) / 256), 1, B), dim3(256), 0, st, src, src_stride,
+                               cur, img_stride, np);
+        for (size_t k = 0; k < n_steps; k++)
+        {
+            const bool to_cur = ((n_steps - 1 - k) % 2) == 0;
+            float *dst = to_cur ? cur : d_ping;
+            const size_t dst_stride = to_cur ? img_stride : plane0;
+            hipLaunchKernelGGL(nld_step_kernel, dim3((l.w + 255) / 256, (l.h + NLD_ROWS - 1) / NLD_ROWS, B), dim3(256), 0, st,
+                               src, (const float *)d_flow, dst, l.w, l.h, src_stride, plane0, dst_stride, tsteps[i][k]);
+            src = dst;
+            src_stride = dst_stride;
+        }
     }
     // ---- derivatives, determinant, maxima
     OCHIP_HIP(ctx, hipMemsetAsync(d_ncand, 0, B * 4, st));
     for (int i = 0; i < LV.n; i++)
     {
         const level_info &l = LV.l[i];
-        blur(d_Lt + l.off, img_stride, d_sm, plane0, l.w, l.h, g1);
-        hipLaunchKernelGGL(deriv_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)d_sm, plane0, d_Lx + l.off,
-                           d_Ly + l.off, img_stride, l.w, l.h, l.sigma_size);
+        {
+            blur_args a{d_Lt + l.off, img_stride, d_Lx + l.off, d_Ly + l.off, img_stride, l.w, l.h, nullptr, 0, nullptr};
+            if (l.sigma_size == 2)
+                hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 2, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
+            else if (l.sigma_size == 3)
+                hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 3, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
+            else if (l.sigma_size == 4)
+                hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 4, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
+            else
+            {
+                cleanup();
+                return ochip_fail(ctx, OCHIP_EINVAL, "akaze: derivative scale %d outside 2..4", l.sigma_size);
+            }
+        }
         hipLaunchKernelGGL(det_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Lx + l.off),
                            (const float *)(d_Ly + l.off), img_stride, d_Ldet + l.off, l.w, l.h, l.sigma_size);
-        hipLaunchKernelGGL(maxima_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Ldet + l.off), d_Rmax + l.off,
+        hipLaunchKernelGGL(maxima_kernel, dim3((l.w + 255) / 256, (l.h + MAXIMA_ROWS - 1) / MAXIMA_ROWS, B), dim3(256), 0, st, (const float *)(d_Ldet + l.off), d_Rmax + l.off,
                            img_stride, l.w, l.h, i, dthreshold, d_cands, d_ncand, max_cands);
     }
     std::vector<unsigned int> ncand(B);
@@ -1144,37 +1373,35 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                            (const float *)d_Lx, (const float *)d_Ly, (const float *)d_Ldet, img_stride, LV, dfactor,
                            (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid);
     }
+    if (max_n > 0)
+        hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, st, (const unsigned char *)d_valid,
+                           (const unsigned int *)d_ncand, max_cands, (const float *)d_kp, (const unsigned long long *)d_desc,
+                           d_kpc, d_descc, max_kp, d_counts);
+    else
+        OCHIP_HIP(ctx, hipMemsetAsync(d_counts, 0, B * 4, st));
     ochip_prof_end(ctx, OCHIP_K_AKAZE, e0, e1);
     OCHIP_HIP(ctx, hipGetLastError());
-    // ---- compact on the host (keypoints are a few thousand per image)
-    std::vector<unsigned char> valid((size_t)max_n);
-    std::vector<float> kpb((size_t)max_n * 6);
-    std::vector<unsigned long long> db((size_t)max_n * 8);
+    // ---- results: the per-image counts first, then exactly the compacted keypoints and descriptors, straight
+    // into the caller's arrays (page-locked ones from ochip_host_alloc make these copies run at link speed)
+    OCHIP_HIP(ctx, hipMemcpyAsync(counts, d_counts, B * 4, hipMemcpyDeviceToHost, st));
+    OCHIP_HIP(ctx, hipStreamSynchronize(st));
     for (uint32_t b = 0; b < B && rc == OCHIP_OK; b++)
     {
-        const unsigned int n = ncand[b];
-        if (n == 0)
-            continue;
-        OCHIP_HIP(ctx, hipMemcpyAsync(valid.data(), d_valid + (size_t)b * max_cands, n, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(kpb.data(), d_kp + (size_t)b * max_cands * 6, (size_t)n * 24, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(db.data(), d_desc + (size_t)b * max_cands * 8, (size_t)n * 64, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipStreamSynchronize(st));
-        uint32_t cnt = 0;
-        for (unsigned int k = 0; k < n; k++)
+        if (counts[b] > max_kp)
         {
-            if (!valid[k])
-                continue;
-            if (cnt >= max_kp)
-            {
-                rc = ochip_fail(ctx, OCHIP_ENOMEM, "image %u has more than max_kp = %u keypoints", b, max_kp);
-                break;
-            }
-            std::memcpy(kp6 + ((size_t)b * max_kp + cnt) * 6, &kpb[(size_t)k * 6], 24);
-            std::memcpy(desc + ((size_t)b * max_kp + cnt) * 8, &db[(size_t)k * 8], 64);
-            cnt++;
+            rc = ochip_fail(ctx, OCHIP_ENOMEM, "image %u has %u keypoints, more than max_kp = %u", b, counts[b], max_kp);
+            break;
         }
-        counts[b] = cnt;
+        if (counts[b] == 0)
+            continue;
+        OCHIP_HIP(ctx, hipMemcpyAsync(kp6 + (size_t)b * max_kp * 6, d_kpc + (size_t)b * max_kp * 6, (size_t)counts[b] * 24,
+                                      hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(desc + (size_t)b * max_kp * 8, d_descc + (size_t)b * max_kp * 8, (size_t)counts[b] * 64,
+                                      hipMemcpyDeviceToHost, st));
     }
+    if (rc != OCHIP_OK)
+        for (uint32_t b = 0; b < B; b++)
+            counts[b] = 0;
     cleanup();
     return rc;
 #undef AK

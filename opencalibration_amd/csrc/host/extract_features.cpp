@@ -2,17 +2,21 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <limits>
-#include <tuple>
+#include <mutex>
+#include <thread>
 
 namespace opencalibration_amd
 {
 
 namespace
 {
-// nearest kept feature by exact search over a bucket grid (cell = NMS radius in full-resolution pixels);
-// only the exact minimum squared distance enters the decision, as with the reference's KD-tree
+// kept features in a bucket grid (cell = NMS radius in full-resolution pixels): the exact nearest-neighbour
+// squared distance is what enters the decision, as with the reference's KD-tree (extract_features.cpp:66-73)
 struct nn_grid
 {
     double cell, minx, miny;
@@ -32,10 +36,10 @@ struct nn_grid
         head[cy * gw + cx] = (int32_t)pts.size();
         pts.emplace_back(x, y);
     }
-    // true if some kept point lies within sqrt(limit2) (i.e. squared distance <= limit2)
-    bool any_within(double x, double y, double limit2) const
+    double nearest2(double x, double y) const
     {
         const long cx = (long)((x - minx) / cell), cy = (long)((y - miny) / cell);
+        double best = std::numeric_limits<double>::infinity();
         for (long yy = std::max(cy - 1, 0L); yy <= std::min(cy + 1, (long)gh - 1); yy++)
             for (long xx = std::max(cx - 1, 0L); xx <= std::min(cx + 1, (long)gw - 1); xx++)
                 for (int32_t e = head[(size_t)yy * gw + xx]; e >= 0; e = next[e])
@@ -44,13 +48,102 @@ struct nn_grid
                     double d = 0;
                     d += dx * dx;
                     d += dy * dy;
-                    if (!(d > limit2))
-                        return true;
+                    best = std::min(best, d);
                 }
-        return false;
+        return best;
     }
 };
+
+// The host tail of src/extract/extract_features.cpp:38-87 for one image: n device keypoints (k6 = x, y, size,
+// angle, response, level in working-image pixels; arbitrary order) -> [sparse..., dense...] features.
+void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale, extracted_features &out)
+{
+    const double nms_pixel_radius = 8;
+    // device order is arbitrary: restore detection order (level, y, x), then the reference's unstable std::sort
+    // by response.  Both sorts permute 4-byte indices; std::sort's compare/move sequence depends only on the
+    // comparator's answers, so the permutation is the one sorting the feature structs themselves would give.
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++)
+        order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
+        const float *p = k6 + 6 * (size_t)a, *q = k6 + 6 * (size_t)c;
+        if (p[5] != q[5])
+            return p[5] < q[5];
+        if (p[1] != q[1])
+            return p[1] < q[1];
+        return p[0] < q[0];
+    });
+    std::sort(order.begin(), order.end(),
+              [&](uint32_t a, uint32_t c) -> bool { return k6[6 * (size_t)a + 4] > k6[6 * (size_t)c + 4]; });
+    auto make = [&](uint32_t s) {
+        feature_2d p;
+        p.location[0] = k6[6 * (size_t)s] / scale; // keypoints[i].pt.x / scale, extract_features.cpp:44-45
+        p.location[1] = k6[6 * (size_t)s + 1] / scale;
+        p.strength = k6[6 * (size_t)s + 4];
+        std::memcpy(p.descriptor, dd + 8 * (size_t)s, 64);
+        return p;
+    };
+    out.features.clear();
+    out.num_sparse_features = 0;
+    if (n == 0)
+        return;
+    // non-maximal suppression, extract_features.cpp:58-83 (the seeded first keypoint is visited again by the
+    // loop and therefore also heads the dense list)
+    std::vector<double> lx(n), ly(n);
+    double minx = std::numeric_limits<double>::infinity(), miny = minx, maxx = -minx, maxy = -minx;
+    for (uint32_t i = 0; i < n; i++)
+    {
+        lx[i] = k6[6 * (size_t)order[i]] / scale;
+        ly[i] = k6[6 * (size_t)order[i] + 1] / scale;
+        minx = std::min(minx, lx[i]);
+        maxx = std::max(maxx, lx[i]);
+        miny = std::min(miny, ly[i]);
+        maxy = std::max(maxy, ly[i]);
+    }
+    nn_grid grid(nms_pixel_radius / scale, minx, miny, maxx, maxy);
+    std::vector<uint32_t> sparse, dense;
+    sparse.reserve(n);
+    dense.reserve(n);
+    grid.add(lx[0], ly[0]);
+    sparse.push_back(0);
+    for (uint32_t i = 0; i < n; i++)
+    {
+        // nn[0].distance * sqr(scale) > sqr(nms_pixel_radius)
+        if (grid.nearest2(lx[i], ly[i]) * (scale * scale) > nms_pixel_radius * nms_pixel_radius)
+        {
+            grid.add(lx[i], ly[i]);
+            sparse.push_back(i);
+        }
+        else
+            dense.push_back(i);
+    }
+    out.num_sparse_features = sparse.size();
+    out.features.reserve(sparse.size() + dense.size());
+    for (uint32_t i : sparse)
+        out.features.push_back(make(order[i]));
+    for (uint32_t i : dense)
+        out.features.push_back(make(order[i]));
+}
+
+struct chunk_buffers
+{
+    float *kp = nullptr;      // page-locked: chunk x max_keypoints x 6
+    uint64_t *desc = nullptr; // page-locked: chunk x max_keypoints x 8
+    std::vector<uint32_t> counts;
+    uint32_t first = 0, n = 0;
+};
 } // namespace
+
+uint32_t extract_chunk_size()
+{
+    if (const char *e = std::getenv("OCHIP_EXTRACT_CHUNK"))
+    {
+        const long v = std::atol(e);
+        if (v >= 1 && v <= 1024)
+            return (uint32_t)v;
+    }
+    return 50;
+}
 
 std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images,
                                                        int width, int height, uint32_t max_keypoints, std::string *error,
@@ -60,97 +153,109 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
     if (n_images == 0 || width <= 0 || height <= 0) // image.empty(): {results, 0}, extract_features.cpp:20-23
         return out;
     const int max_length_pixels = 1600;
-    const double nms_pixel_radius = 8;
-    std::vector<float> kp((size_t)n_images * max_keypoints * 6);
-    std::vector<uint64_t> desc((size_t)n_images * max_keypoints * 8);
-    std::vector<uint32_t> counts(n_images);
-    int wh[2];
-    const int rc = images_on_device ? ochip_akaze_batch_dev(ctx, images_bgr, n_images, width, height, max_keypoints,
-                                                            kp.data(), desc.data(), counts.data(), wh)
-                                    : ochip_akaze_batch(ctx, images_bgr, n_images, width, height, max_keypoints, kp.data(),
-                                                        desc.data(), counts.data(), wh);
-    if (rc != OCHIP_OK)
+    const double scale = std::min(1.f, float(max_length_pixels) / (float)std::max(width, height));
+    const uint32_t chunk = std::min(extract_chunk_size(), n_images);
+    const size_t image_bytes = (size_t)width * height * 3;
+
+    // Two chunk buffers: a driver thread keeps the device busy with chunk k + 1 (ochip_akaze_batch is a blocking
+    // call) while this thread's OpenMP team runs the host tail of chunk k.
+    chunk_buffers bufs[2];
+    std::string fail;
+    auto release = [&]() {
+        for (auto &b : bufs)
+        {
+            if (b.kp)
+                ochip_host_free(ctx, b.kp);
+            if (b.desc)
+                ochip_host_free(ctx, b.desc);
+            b.kp = nullptr;
+            b.desc = nullptr;
+        }
+    };
+    for (auto &b : bufs)
+    {
+        void *p = nullptr, *q = nullptr;
+        if (ochip_host_alloc(ctx, (size_t)chunk * max_keypoints * 6 * sizeof(float), &p) != OCHIP_OK ||
+            ochip_host_alloc(ctx, (size_t)chunk * max_keypoints * 8 * sizeof(uint64_t), &q) != OCHIP_OK)
+        {
+            if (p)
+                ochip_host_free(ctx, p);
+            release();
+            if (error)
+                *error = std::string("ochip_host_alloc: ") + ochip_last_error(ctx);
+            return {};
+        }
+        b.kp = (float *)p;
+        b.desc = (uint64_t *)q;
+        b.counts.resize(chunk);
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> ready;         // filled buffers, in chunk order
+    bool buffer_free[2] = {true, true};
+    bool producer_done = false;
+
+    std::thread producer([&]() {
+        int which = 0;
+        for (uint32_t first = 0; first < n_images; first += chunk, which ^= 1)
+        {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return buffer_free[which]; });
+                buffer_free[which] = false;
+            }
+            chunk_buffers &b = bufs[which];
+            b.first = first;
+            b.n = std::min(chunk, n_images - first);
+            int wh[2];
+            const uint8_t *src = images_bgr + (size_t)first * image_bytes;
+            const int rc = images_on_device ? ochip_akaze_batch_dev(ctx, src, b.n, width, height, max_keypoints, b.kp, b.desc,
+                                                                    b.counts.data(), wh)
+                                            : ochip_akaze_batch(ctx, src, b.n, width, height, max_keypoints, b.kp, b.desc,
+                                                                b.counts.data(), wh);
+            std::unique_lock<std::mutex> lk(mu);
+            if (rc != OCHIP_OK)
+            {
+                fail = std::string("ochip_akaze_batch: ") + ochip_last_error(ctx);
+                break;
+            }
+            ready.push_back(which);
+            cv.notify_all();
+        }
+        std::unique_lock<std::mutex> lk(mu);
+        producer_done = true;
+        cv.notify_all();
+    });
+
+    for (;;)
+    {
+        int which;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty() || producer_done; });
+            if (ready.empty())
+                break;
+            which = ready.front();
+            ready.pop_front();
+        }
+        chunk_buffers &b = bufs[which];
+#pragma omp parallel for schedule(dynamic, 1)
+        for (uint32_t i = 0; i < b.n; i++)
+            extract_tail(b.kp + (size_t)i * max_keypoints * 6, b.desc + (size_t)i * max_keypoints * 8, b.counts[i], scale,
+                         out[b.first + i]);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            buffer_free[which] = true;
+            cv.notify_all();
+        }
+    }
+    producer.join();
+    release();
+    if (!fail.empty())
     {
         if (error)
-            *error = std::string("ochip_akaze_batch: ") + ochip_last_error(ctx);
+            *error = fail;
         return {};
-    }
-    const double scale = std::min(1.f, float(max_length_pixels) / (float)std::max(width, height));
-#pragma omp parallel for schedule(dynamic, 1)
-    for (uint32_t b = 0; b < n_images; b++)
-    {
-        const uint32_t n = counts[b];
-        const float *k6 = kp.data() + (size_t)b * max_keypoints * 6;
-        const uint64_t *dd = desc.data() + (size_t)b * max_keypoints * 8;
-        // device order is arbitrary: restore detection order (level, y, x) before the (unstable) strength sort
-        std::vector<uint32_t> order(n);
-        for (uint32_t i = 0; i < n; i++)
-            order[i] = i;
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
-            return std::make_tuple(k6[6 * a + 5], k6[6 * a + 1], k6[6 * a]) < std::make_tuple(k6[6 * c + 5], k6[6 * c + 1], k6[6 * c]);
-        });
-        std::vector<feature_2d> oc_keypoints(n);
-        for (uint32_t i = 0; i < n; i++)
-        {
-            const uint32_t s = order[i];
-            feature_2d &p = oc_keypoints[i];
-            p.location[0] = k6[6 * s] / scale; // keypoints[i].pt.x / scale, extract_features.cpp:44-45
-            p.location[1] = k6[6 * s + 1] / scale;
-            p.strength = k6[6 * s + 4];
-            std::memcpy(p.descriptor, dd + 8 * s, 64);
-        }
-        std::sort(oc_keypoints.begin(), oc_keypoints.end(),
-                  [](const feature_2d &a, const feature_2d &c) -> bool { return a.strength > c.strength; });
-        // non-maximal suppression, extract_features.cpp:58-83 (the seeded first keypoint is visited again by the
-        // loop and therefore also heads the dense list)
-        std::vector<feature_2d> results, dense;
-        if (!oc_keypoints.empty())
-        {
-            double minx = std::numeric_limits<double>::infinity(), miny = minx, maxx = -minx, maxy = -minx;
-            for (const auto &f : oc_keypoints)
-            {
-                minx = std::min(minx, f.location[0]);
-                maxx = std::max(maxx, f.location[0]);
-                miny = std::min(miny, f.location[1]);
-                maxy = std::max(maxy, f.location[1]);
-            }
-            nn_grid grid(nms_pixel_radius / scale, minx, miny, maxx, maxy);
-            const double limit2 = (nms_pixel_radius * nms_pixel_radius) / (scale * scale); // d2 * scale^2 > r^2
-            grid.add(oc_keypoints[0].location[0], oc_keypoints[0].location[1]);
-            results.push_back(oc_keypoints[0]);
-            for (const feature_2d &f : oc_keypoints)
-            {
-                // nn[0].distance * sqr(scale) > sqr(nms_pixel_radius)
-                bool close = false;
-                {
-                    // exact form of the reference comparison on the nearest neighbour
-                    const long cx = (long)((f.location[0] - grid.minx) / grid.cell), cy = (long)((f.location[1] - grid.miny) / grid.cell);
-                    double best = std::numeric_limits<double>::infinity();
-                    for (long yy = std::max(cy - 1, 0L); yy <= std::min(cy + 1, (long)grid.gh - 1); yy++)
-                        for (long xx = std::max(cx - 1, 0L); xx <= std::min(cx + 1, (long)grid.gw - 1); xx++)
-                            for (int32_t e = grid.head[(size_t)yy * grid.gw + xx]; e >= 0; e = grid.next[e])
-                            {
-                                const double dx = f.location[0] - grid.pts[e].first, dy = f.location[1] - grid.pts[e].second;
-                                double d = 0;
-                                d += dx * dx;
-                                d += dy * dy;
-                                best = std::min(best, d);
-                            }
-                    close = !(best * (scale * scale) > nms_pixel_radius * nms_pixel_radius);
-                    (void)limit2;
-                }
-                if (!close)
-                {
-                    grid.add(f.location[0], f.location[1]);
-                    results.push_back(f);
-                }
-                else
-                    dense.push_back(f);
-            }
-        }
-        out[b].num_sparse_features = results.size();
-        results.insert(results.end(), dense.begin(), dense.end());
-        out[b].features = std::move(results);
     }
     return out;
 }

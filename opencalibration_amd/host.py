@@ -78,6 +78,7 @@ def load():
         L.och_graph_relax_ground_plane.argtypes = [vp, vp, _f64p, _f64p, _f64p]
         L.och_extract_features_batch.argtypes = [vp, vp, u32, C.c_int, C.c_int, u32, u32, vp, vp, vp, vp, vp, C.c_int]
         L.och_extract_last_error.restype = C.c_char_p
+        L.och_graph_load_images.argtypes = [vp, vp, vp, u32, C.c_int, C.c_int, u32, C.c_int, u32, _f64p, _u64p, _f64p]
         _lib = L
     return _lib
 
@@ -168,6 +169,25 @@ class Graph:
                                          np.ascontiguousarray(position, np.float64))
         self.node_ids.append(nid)
         return nid
+
+    def load_images(self, ctx, images_bgr, model, positions, max_keypoints=30000, device_shape=None):
+        """The load stage for a batch of equally sized images: extract_features on the device, one node per image.
+        images_bgr: (n, h, w, 3) uint8 host array or, with device_shape=(n, h, w), a device pointer.  Returns
+        (mean features per image, mean sparse features per image)."""
+        if device_shape is None:
+            imgs = np.ascontiguousarray(images_bgr, np.uint8)
+            n, h, w, _ = imgs.shape
+            src, on_dev = imgs.ctypes.data, 0
+        else:
+            n, h, w = device_shape
+            src, on_dev = int(images_bgr), 1
+        ids, totals = np.zeros(max(n, 1), np.uint64), np.zeros(2)
+        rc = self.L.och_graph_load_images(self.h, ctx.h, src, n, w, h, max_keypoints, on_dev, model,
+                                          np.ascontiguousarray(positions, np.float64).reshape(-1, 3), ids, totals)
+        if rc != 0:
+            raise capi.OchipError("load_images failed: " + self.L.och_last_error(self.h).decode())
+        self.node_ids += [int(i) for i in ids[:n]]
+        return totals[0] / max(n, 1), totals[1] / max(n, 1)
 
     @classmethod
     def from_synthetic(cls, grid):

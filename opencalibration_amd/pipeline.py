@@ -24,26 +24,16 @@ def synthetic_views(ctx, grid, seed=7):
     return ptr, (grid.n_images, h, w)
 
 
-def run(ctx, grid, images_ptr, shape, start_orientation, batch=25, max_keypoints=30000):
-    """extract -> link -> relax.  Returns (graph, result dict, stage seconds)."""
+def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000):
+    """load (extract) -> link -> relax.  Returns (graph, result dict, stage seconds)."""
     n, h, w = shape
     t = {}
-    t0 = time.perf_counter()
-    feats = []
-    px_bytes = h * w * 3
-    for i in range(0, n, batch):
-        m = min(batch, n - i)
-        feats += host.extract_features_batch(ctx, images_ptr + i * px_bytes, max_keypoints, device_shape=(m, h, w))
-    t["extract"] = time.perf_counter() - t0
-
-    t0 = time.perf_counter()
     g = host.Graph()
     mid = g.add_model(grid.model)
-    for i, (loc, st, de, ns) in enumerate(feats):
-        g.add_image(loc, st, de, ns, mid, grid.position[i])
+    t0 = time.perf_counter()
+    feats_mean, sparse_mean = g.load_images(ctx, images_ptr, mid, grid.position, max_keypoints, device_shape=(n, h, w))
+    t["extract"] = time.perf_counter() - t0
     g.set_orientations(start_orientation)
-    t["graph_build"] = time.perf_counter() - t0       # Python-side marshalling of the features, not the hot path
-
     t0 = time.perf_counter()
     link_timers = g.link(ctx)
     t["link"] = time.perf_counter() - t0
@@ -51,8 +41,7 @@ def run(ctx, grid, images_ptr, shape, start_orientation, batch=25, max_keypoints
     rel = g.relax_ground_plane(ctx, start_orientation)
     ctx.synchronize()
     t["relax"] = time.perf_counter() - t0
-    res = dict(features_per_image=float(np.mean([len(f[1]) for f in feats])),
-               sparse_per_image=float(np.mean([f[3] for f in feats])), link_timers=link_timers, relax=rel,
+    res = dict(features_per_image=feats_mean, sparse_per_image=sparse_mean, link_timers=link_timers, relax=rel,
                edges=g.num_edges)
     return g, res, t
 
