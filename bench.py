@@ -45,8 +45,9 @@ def main():
     from opencalibration_amd import host as _host_mod
 
     cores = _host_mod.effective_cpus()   # affinity mask capped by the cgroup CPU quota
-    threads = max(1, cores // max(world, 1))
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    threads = max(1, cores // max(world, 1))                        # CPU baseline: one thread per usable core
+    omp_threads = max(1, _host_mod.host_threads() // max(world, 1))  # host phases of the hot path (bursty, see host.py)
+    os.environ.setdefault("OMP_NUM_THREADS", str(omp_threads))
 
     import torch
     import torch.distributed as dist
@@ -219,7 +220,7 @@ def main():
                                         "(host), homography RANSAC (device), decompose (host)",
                                         "relax: ground-plane assembly (host) + LM with dense Cholesky, all cameras in one "
                                         "group (device)"],
-                       "host_threads_per_rank": threads,
+                       "host_threads_per_rank": int(os.environ["OMP_NUM_THREADS"]), "usable_host_cpus": cores,
                        "per_rank": "one grid of this shape per GPU, no data-path collective"},
             "stage_seconds_per_step": {k: round(v / args.steps, 5) for k, v in acc.items()},
             "relax": relax_info,

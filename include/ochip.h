@@ -63,6 +63,11 @@ extern "C"
     /* ---- context ------------------------------------------------------------------------------ */
     int ochip_ctx_create(int device, ochip_ctx **out);
     void ochip_ctx_destroy(ochip_ctx *ctx);
+    /* The index-th sibling of ctx: another context on the same device with its own streams, scratch buffers and
+     * pools, created on first use and destroyed with ctx.  Lets independent batches (e.g. the link stage's runners,
+     * src/pipeline/link_stage.cpp:41-117) be in flight at once: one host thread per context.  Kernel times of
+     * siblings are included in ochip_profile_get(ctx, ...). */
+    int ochip_ctx_sibling(ochip_ctx *ctx, uint32_t index, ochip_ctx **out);
     const char *ochip_last_error(const ochip_ctx *ctx); /* ctx may be NULL: error of the last failed create */
     int ochip_device_info(const ochip_ctx *ctx, char *name, size_t name_len, int *compute_units, size_t *hbm_bytes);
     int ochip_synchronize(ochip_ctx *ctx);

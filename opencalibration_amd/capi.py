@@ -16,7 +16,7 @@ MATCH_DTYPE = np.dtype([("best_k", np.uint32), ("best_count", np.uint16), ("seco
 
 # every symbol include/ochip.h declares; tests check that the built library exports all of them
 EXPORTS = [
-    "ochip_ctx_create", "ochip_ctx_destroy", "ochip_last_error", "ochip_device_info", "ochip_synchronize",
+    "ochip_ctx_create", "ochip_ctx_destroy", "ochip_ctx_sibling", "ochip_last_error", "ochip_device_info", "ochip_synchronize",
     "ochip_descriptors_reserve", "ochip_upload_descriptors", "ochip_descriptor_count",
     "ochip_match_batch", "ochip_match_launch", "ochip_match_fetch",
     "ochip_upload_keypoints", "ochip_ransac_homography_batch",

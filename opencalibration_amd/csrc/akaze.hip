@@ -316,35 +316,80 @@ __global__ void kcontrast_kernel(const unsigned int *__restrict__ hist, const un
 }
 
 // ---- diffusion (the PM-G2 conductivity is BLUR_FLOW above)
-constexpr int NLD_ROWS = 16;
-__global__ __launch_bounds__(256) void nld_step_kernel(const float *__restrict__ Lin, const float *__restrict__ cflow, float *__restrict__ Lout,
-                                int w, int h, size_t l_stride, size_t c_stride, size_t out_stride, float tau)
+// Up to FED_FUSE explicit diffusion steps per launch, in registers.  A wavefront owns a 64-column x (32 + 2K)-row
+// strip: each lane keeps its column of L and of the two conductivity sums (c[i] + c[i+1], c[i] + c[i+w]) in
+// VGPRs, the horizontal neighbours arrive by lane shuffles, and the strip is swept top to bottom once per step,
+// in place (a row needs the old row below and the already computed flux from the row above).  The valid region
+// shrinks by one pixel per step, so 64 - 2K columns x 32 rows are written: 12 B/pixel of HBM traffic per launch
+// instead of per step, at ~14 VALU instructions per pixel-step (the LDS-tiled form of this loop was VALU-bound).
+// The arithmetic is the one-step form's: flux (c_a + c_b) * (L_b - L_a) evaluated once per pixel pair and used
+// with both signs, 0 across the image border.
+constexpr int FED_FUSE = 4;
+struct fed_tau_group
 {
-    // a workgroup walks NLD_ROWS rows of a 256-pixel column band; the centre column of L and c slides through
-    // registers (one new load of each per row), the left / right neighbours come from L1
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= w)
+    float tau[FED_FUSE];
+};
+template <int K>
+__global__ __launch_bounds__(256) void nld_fused_kernel(const float *__restrict__ Lin, const float *__restrict__ cflow,
+                                                        float *__restrict__ Lout, int w, int h, size_t l_stride,
+                                                        size_t c_stride, size_t out_stride, fed_tau_group T)
+{
+    constexpr int TY = 32, RH = TY + 2 * K, OW = 64 - 2 * K;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int X0 = (blockIdx.x * 4 + wv) * OW; // first output column of this wavefront
+    if (X0 >= w)
         return;
+    const int Y0 = blockIdx.y * TY;
+    const int gx = X0 - K + lane;
+    const bool col_in = gx >= 0 && gx < w;
+    const bool has_right = col_in && gx + 1 < w, has_left = gx > 0 && col_in;
     const float *L = Lin + (size_t)blockIdx.z * l_stride, *c = cflow + (size_t)blockIdx.z * c_stride;
-    float *O = Lout + (size_t)blockIdx.z * out_stride;
-    const float half = 0.5f * tau;
-    const int y_begin = blockIdx.y * NLD_ROWS, y_end = min(y_begin + NLD_ROWS, h);
-    size_t i = (size_t)y_begin * w + x;
-    float Lm = y_begin > 0 ? L[i - w] : 0.0f, cm = y_begin > 0 ? c[i - w] : 0.0f;
-    float Lc = L[i], cc = c[i];
-    for (int y = y_begin; y < y_end; y++, i += w)
+    float Lr[RH], cx[RH], cy[RH];
+#pragma unroll
+    for (int r = 0; r < RH; r++)
     {
-        const bool has_next = y + 1 < h;
-        const float Lp = has_next ? L[i + w] : 0.0f, cp = has_next ? c[i + w] : 0.0f;
-        const float xpos = x + 1 < w ? (cc + c[i + 1]) * (L[i + 1] - Lc) : 0.0f;
-        const float xneg = x > 0 ? (c[i - 1] + cc) * (Lc - L[i - 1]) : 0.0f;
-        const float ypos = has_next ? (cc + cp) * (Lp - Lc) : 0.0f;
-        const float yneg = y > 0 ? (cm + cc) * (Lc - Lm) : 0.0f;
-        O[i] = Lc + half * ((xpos - xneg) + (ypos - yneg));
-        Lm = Lc;
-        cm = cc;
-        Lc = Lp;
-        cc = cp;
+        const int gy = Y0 - K + r;
+        const bool in = col_in && gy >= 0 && gy < h;
+        Lr[r] = in ? L[(size_t)gy * w + gx] : 0.0f;
+        cy[r] = in ? c[(size_t)gy * w + gx] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < RH; r++)
+        cx[r] = cy[r] + __shfl_down(cy[r], 1);
+#pragma unroll
+    for (int r = 0; r + 1 < RH; r++)
+        cy[r] = cy[r] + cy[r + 1];
+#pragma unroll
+    for (int j = 0; j < K; j++)
+    {
+        const float half = 0.5f * T.tau[j];
+        float flux_above = 0.0f;
+#pragma unroll
+        for (int r = 0; r < RH; r++)
+        {
+            const int gy = Y0 - K + r;
+            const float Lc = Lr[r];
+            const float d = __shfl_down(Lc, 1) - Lc;
+            const float xpos = has_right ? cx[r] * d : 0.0f;
+            const float xleft = __shfl_up(xpos, 1);
+            const float xneg = has_left ? xleft : 0.0f;
+            float ypos = 0.0f;
+            if (r + 1 < RH)
+                ypos = (gy + 1 < h) ? cy[r] * (Lr[r + 1] - Lc) : 0.0f;
+            const float yneg = gy > 0 ? flux_above : 0.0f;
+            Lr[r] = Lc + half * ((xpos - xneg) + (ypos - yneg));
+            flux_above = ypos;
+        }
+    }
+    if (lane >= K && lane < 64 - K && gx < w)
+    {
+#pragma unroll
+        for (int r = K; r < K + TY; r++)
+        {
+            const int gy = Y0 - K + r;
+            if (gy < h)
+                Lout[(size_t)blockIdx.z * out_stride + (size_t)gy * w + gx] = Lr[r];
+        }
     }
 }
 
@@ -368,37 +413,6 @@ __global__ void copy_plane_kernel(const float *__restrict__ in, size_t in_stride
         out[(size_t)blockIdx.z * out_stride + i] = in[(size_t)blockIdx.z * in_stride + i];
 }
 
-// ---- derivatives at the level's integer scale
-__device__ __forceinline__ void deriv_at(const float *I, int w, int h, int s, int x, int y, float nrm, float wn, float *dx,
-                                         float *dy)
-{
-    const int ym = reflect101(y - s, h), yp = reflect101(y + s, h), xm = reflect101(x - s, w), xp = reflect101(x + s, w);
-    const float a = I[(size_t)ym * w + xp] - I[(size_t)ym * w + xm];
-    const float b = I[(size_t)y * w + xp] - I[(size_t)y * w + xm];
-    const float c = I[(size_t)yp * w + xp] - I[(size_t)yp * w + xm];
-    *dx = (nrm * a + wn * b) + nrm * c;
-    const float d = I[(size_t)yp * w + xm] - I[(size_t)ym * w + xm];
-    const float e = I[(size_t)yp * w + x] - I[(size_t)ym * w + x];
-    const float f = I[(size_t)yp * w + xp] - I[(size_t)ym * w + xp];
-    *dy = (nrm * d + wn * e) + nrm * f;
-}
-
-__global__ void det_kernel(const float *__restrict__ Lx, const float *__restrict__ Ly, size_t stride,
-                           float *__restrict__ Ldet, int w, int h, int s)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w)
-        return;
-    const float wgt = 10.0f / 3.0f;
-    const float nrm = 1.0f / (2.0f * (float)s * (wgt + 2.0f));
-    const float wn = wgt * nrm;
-    float lxx, lxy, tmp, lyy;
-    deriv_at(Lx + (size_t)blockIdx.z * stride, w, h, s, x, y, nrm, wn, &lxx, &lxy);
-    deriv_at(Ly + (size_t)blockIdx.z * stride, w, h, s, x, y, nrm, wn, &tmp, &lyy);
-    const float s4 = (float)(s * s * s * s);
-    Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = (lxx * lyy - lxy * lxy) * s4;
-}
-
 // ---- detection
 struct cand_t
 {
@@ -406,56 +420,79 @@ struct cand_t
     float response;
 };
 
-// 3x3 strict maxima above the threshold: appended to the image's candidate list and written to the level's
-// sparse maxima map (0 elsewhere) that the scale-space suppression scans
-constexpr int MAXIMA_ROWS = 32;
-__global__ __launch_bounds__(256) void maxima_kernel(const float *__restrict__ Ldet, float *__restrict__ Rmax, size_t stride, int w, int h,
-                              int level, float thr, cand_t *__restrict__ cands, unsigned int *__restrict__ n_cands,
-                              unsigned int max_cands)
+// Scale-normalised Hessian determinant of a 64 x 32 tile and its strict 3x3 maxima above the threshold in one
+// pass: the Lx / Ly tiles (+ halo S + 1) are staged in LDS, the determinant tile (+ halo 1) is built over them,
+// and the level's sparse maxima map (response at maxima, 0 elsewhere) is written next to the determinant.
+template <int S>
+__global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict__ Lx, const float *__restrict__ Ly, size_t stride,
+                                                         float *__restrict__ Ldet, float *__restrict__ Rmax, int w, int h,
+                                                         float thr)
 {
-    // a workgroup owns a 256 x MAXIMA_ROWS pixel tile; its maxima are collected in LDS and appended to the
-    // image's list with ONE global atomic (same-address atomics serialise at ~0.2 us each on this part).
-    // Strict 3x3 maxima cannot touch, so a tile holds at most 128 x MAXIMA_ROWS / 2 of them.
-    __shared__ cand_t lc[128 * MAXIMA_ROWS / 2];
-    __shared__ unsigned int lcount, lbase;
-    if (threadIdx.x == 0)
-        lcount = 0;
-    __syncthreads();
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const float *D = Ldet + (size_t)blockIdx.z * stride;
-    if (x < w)
-        for (int r = 0; r < MAXIMA_ROWS; r++)
+    constexpr int HW = S + 1, RW = BT_X + 2 * HW, RH = BT_Y + 2 * HW, DW = BT_X + 2, DH = BT_Y + 2;
+    __shared__ float tx[RW * RH], ty[RW * RH];
+    __shared__ float td[DW * DH];
+    const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
+    const int rx0 = x0 - HW, ry0 = y0 - HW;
+    const float *X = Lx + (size_t)blockIdx.z * stride, *Y = Ly + (size_t)blockIdx.z * stride;
+    for (int idx = threadIdx.x; idx < RW * RH; idx += 256)
+    {
+        const int ly = idx / RW, lx = idx - ly * RW;
+        const int gx = rx0 + lx, gy = ry0 + ly;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h)
         {
-            const int y = blockIdx.y * MAXIMA_ROWS + r;
-            if (y >= h)
-                break;
-            float out = 0.0f;
-            if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1)
-            {
-                const float v = D[(size_t)y * w + x];
-                if (v > thr)
-                {
-                    bool mx = true;
-                    for (int dy = -1; dy <= 1; dy++)
-                        for (int dx = -1; dx <= 1; dx++)
-                            if ((dx || dy) && !(v > D[(size_t)(y + dy) * w + x + dx]))
-                                mx = false;
-                    if (mx)
-                    {
-                        out = v;
-                        lc[atomicAdd(&lcount, 1u)] = cand_t{level, x, y, v};
-                    }
-                }
-            }
-            Rmax[(size_t)blockIdx.z * stride + (size_t)y * w + x] = out;
+            tx[idx] = X[(size_t)gy * w + gx];
+            ty[idx] = Y[(size_t)gy * w + gx];
         }
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && lcount)
-        lbase = atomicAdd(n_cands + blockIdx.z, lcount);
+    const float wgt = 10.0f / 3.0f;
+    const float nrm = 1.0f / (2.0f * (float)S * (wgt + 2.0f));
+    const float wn = wgt * nrm;
+    const float s4 = (float)(S * S * S * S);
+    auto atx = [&](int xx, int yy) { return tx[(yy - ry0) * RW + (xx - rx0)]; };
+    auto aty = [&](int xx, int yy) { return ty[(yy - ry0) * RW + (xx - rx0)]; };
+    for (int idx = threadIdx.x; idx < DW * DH; idx += 256)
+    {
+        const int ly = idx / DW, lx = idx - ly * DW;
+        const int x = x0 - 1 + lx, y = y0 - 1 + ly;
+        if (x < 0 || x >= w || y < 0 || y >= h)
+            continue;
+        const int xm = reflect101(x - S, w), xp = reflect101(x + S, w), ym = reflect101(y - S, h), yp = reflect101(y + S, h);
+        float lxx, lxy, tmp, lyy;
+        pattern_xy(atx, xm, x, xp, ym, y, yp, nrm, wn, &lxx, &lxy);
+        pattern_xy(aty, xm, x, xp, ym, y, yp, nrm, wn, &tmp, &lyy);
+        const float d = (lxx * lyy - lxy * lxy) * s4;
+        td[idx] = d;
+        if (lx >= 1 && lx <= BT_X && ly >= 1 && ly <= BT_Y)
+            Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = d;
+    }
     __syncthreads();
-    for (unsigned int i = threadIdx.x; i < lcount; i += blockDim.x)
-        if (lbase + i < max_cands)
-            cands[(size_t)blockIdx.z * max_cands + lbase + i] = lc[i];
+    for (int idx = threadIdx.x; idx < BT_X * BT_Y; idx += 256)
+    {
+        const int ly = idx / BT_X, lx = idx - ly * BT_X;
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= w || y >= h)
+            continue;
+        float out = 0.0f;
+        if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1)
+        {
+            const int ci = (ly + 1) * DW + (lx + 1);
+            const float v = td[ci];
+            if (v > thr)
+            {
+                bool mx = true;
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++)
+                        if ((dx || dy) && !(v > td[ci + dy * DW + dx]))
+                            mx = false;
+                if (mx)
+                    out = v;
+            }
+        }
+        Rmax[(size_t)blockIdx.z * stride + (size_t)y * w + x] = out;
+    }
 }
 
 struct levels_dev
@@ -463,6 +500,63 @@ struct levels_dev
     int n;
     level_info l[16];
 };
+
+// Candidate list of an image = the non-zero entries of its maxima maps, all levels in one launch.  A workgroup
+// scans a 256 x COLLECT_ROWS band, gathers its maxima in LDS and appends them with one global atomic per flush
+// (device-scope same-address atomics cost ~0.2 us each here, so they are kept to a few hundred per image).
+constexpr int COLLECT_ROWS = 128, COLLECT_CAP = 2048;
+__global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ Rmax, size_t img_stride, levels_dev L,
+                                                      cand_t *__restrict__ cands, unsigned int *__restrict__ n_cands,
+                                                      unsigned int max_cands)
+{
+    __shared__ cand_t lc[COLLECT_CAP];
+    __shared__ unsigned int lcount, lbase;
+    const int level = blockIdx.y;
+    const unsigned int b = blockIdx.z;
+    const level_info l = L.l[level];
+    const int bands_x = (l.w + 255) / 256, bands_y = (l.h + COLLECT_ROWS - 1) / COLLECT_ROWS;
+    if ((int)blockIdx.x >= bands_x * bands_y)
+        return;
+    const int by = blockIdx.x / bands_x, bx = blockIdx.x - by * bands_x;
+    const int x = bx * 256 + threadIdx.x;
+    const float *R = Rmax + (size_t)b * img_stride + l.off;
+    if (threadIdx.x == 0)
+        lcount = 0;
+    __syncthreads();
+    auto flush = [&]() {
+        if (threadIdx.x == 0 && lcount)
+            lbase = atomicAdd(n_cands + b, lcount);
+        __syncthreads();
+        const unsigned int n = lcount;
+        for (unsigned int i = threadIdx.x; i < n; i += 256)
+            if (lbase + i < max_cands)
+                cands[(size_t)b * max_cands + lbase + i] = lc[i];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            lcount = 0;
+        __syncthreads();
+    };
+    for (int r = 0; r < COLLECT_ROWS; r++)
+    {
+        const int y = by * COLLECT_ROWS + r;
+        if (y >= l.h)
+            break;
+        if (x < l.w)
+        {
+            const float v = R[(size_t)y * l.w + x];
+            if (v != 0.0f)
+                lc[atomicAdd(&lcount, 1u)] = cand_t{level, x, y, v};
+        }
+        if ((r & 3) == 3) // at most 4 x 128 new entries since the last check
+        {
+            __syncthreads();
+            if (lcount > COLLECT_CAP - 512)
+                flush();
+        }
+    }
+    __syncthreads();
+    flush();
+}
 
 // A candidate dies if a stronger maximum (ties: lower (level, y, x) wins) of an adjacent level lies within
 // its own size esigma * derivative_factor (base-image pixels).  One thread per candidate, window scans of
@@ -1294,14 +1388,15 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         float *cur = d_Lt + l.off;
         const size_t np = (size_t)l.w * l.h;
         const size_t n_steps = tsteps[i].size();
+        const size_t n_groups = (n_steps + FED_FUSE - 1) / FED_FUSE; // launches: up to FED_FUSE steps fused in each
         // the level starts from the previous level's image (half-sampled at a new octave); the FED steps ping-pong
         // between the level plane and a scratch plane, arranged so that the last step lands in the level plane
         const float *src = d_Lt + p.off;
         size_t src_stride = img_stride;
         if (l.octave > p.octave)
         {
-            float *dst = (n_steps % 2 == 0) ? cur : d_ping;
-            const size_t dst_stride = (n_steps % 2 == 0) ? img_stride : plane0;
+            float *dst = (n_groups % 2 == 0) ? cur : d_ping;
+            const size_t dst_stride = (n_groups % 2 == 0) ? img_stride : plane0;
             hipLaunchKernelGGL(halfsample_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Lt + p.off), p.w, p.h,
                                img_stride, dst, l.w, l.h, dst_stride);
             src = dst;
@@ -1315,13 +1410,30 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         if (n_steps == 0)
             hipLaunchKernelGGL(copy_plane_kernel, dim3((unsigned)((np + 255) / 256), 1, B), dim3(256), 0, st, src, src_stride,
                                cur, img_stride, np);
-        for (size_t k = 0; k < n_steps; k++)
+        for (size_t g = 0, k = 0; g < n_groups; g++)
         {
-            const bool to_cur = ((n_steps - 1 - k) % 2) == 0;
+            const size_t gsz = n_steps / n_groups + (g < n_steps % n_groups ? 1 : 0); // balanced groups of <= FED_FUSE steps
+            fed_tau_group T{};
+            for (size_t q = 0; q < gsz; q++)
+                T.tau[q] = tsteps[i][k + q];
+            k += gsz;
+            const bool to_cur = ((n_groups - 1 - g) % 2) == 0;
             float *dst = to_cur ? cur : d_ping;
             const size_t dst_stride = to_cur ? img_stride : plane0;
-            hipLaunchKernelGGL(nld_step_kernel, dim3((l.w + 255) / 256, (l.h + NLD_ROWS - 1) / NLD_ROWS, B), dim3(256), 0, st,
-                               src, (const float *)d_flow, dst, l.w, l.h, src_stride, plane0, dst_stride, tsteps[i][k]);
+            const int ow = 64 - 2 * (int)gsz; // output columns per wavefront
+            const dim3 gr((l.w + 4 * ow - 1) / (4 * ow), (l.h + 31) / 32, B);
+            if (gsz == 1)
+                hipLaunchKernelGGL((nld_fused_kernel<1>), gr, dim3(256), 0, st, src, (const float *)d_flow, dst, l.w, l.h,
+                                   src_stride, plane0, dst_stride, T);
+            else if (gsz == 2)
+                hipLaunchKernelGGL((nld_fused_kernel<2>), gr, dim3(256), 0, st, src, (const float *)d_flow, dst, l.w, l.h,
+                                   src_stride, plane0, dst_stride, T);
+            else if (gsz == 3)
+                hipLaunchKernelGGL((nld_fused_kernel<3>), gr, dim3(256), 0, st, src, (const float *)d_flow, dst, l.w, l.h,
+                                   src_stride, plane0, dst_stride, T);
+            else
+                hipLaunchKernelGGL((nld_fused_kernel<4>), gr, dim3(256), 0, st, src, (const float *)d_flow, dst, l.w, l.h,
+                                   src_stride, plane0, dst_stride, T);
             src = dst;
             src_stride = dst_stride;
         }
@@ -1345,10 +1457,24 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 return ochip_fail(ctx, OCHIP_EINVAL, "akaze: derivative scale %d outside 2..4", l.sigma_size);
             }
         }
-        hipLaunchKernelGGL(det_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Lx + l.off),
-                           (const float *)(d_Ly + l.off), img_stride, d_Ldet + l.off, l.w, l.h, l.sigma_size);
-        hipLaunchKernelGGL(maxima_kernel, dim3((l.w + 255) / 256, (l.h + MAXIMA_ROWS - 1) / MAXIMA_ROWS, B), dim3(256), 0, st, (const float *)(d_Ldet + l.off), d_Rmax + l.off,
-                           img_stride, l.w, l.h, i, dthreshold, d_cands, d_ncand, max_cands);
+        {
+            const float *lx = d_Lx + l.off, *ly = d_Ly + l.off;
+            float *ld = d_Ldet + l.off, *rm = d_Rmax + l.off;
+            if (l.sigma_size == 2)
+                hipLaunchKernelGGL((det_maxima_kernel<2>), tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
+                                   l.h, dthreshold);
+            else if (l.sigma_size == 3)
+                hipLaunchKernelGGL((det_maxima_kernel<3>), tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
+                                   l.h, dthreshold);
+            else
+                hipLaunchKernelGGL((det_maxima_kernel<4>), tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
+                                   l.h, dthreshold);
+        }
+    }
+    {
+        const int bands0 = ((W + 255) / 256) * ((H + COLLECT_ROWS - 1) / COLLECT_ROWS);
+        hipLaunchKernelGGL(collect_kernel, dim3(bands0, LV.n, B), dim3(256), 0, st, (const float *)d_Rmax, img_stride, LV,
+                           d_cands, d_ncand, max_cands);
     }
     std::vector<unsigned int> ncand(B);
     OCHIP_HIP(ctx, hipMemcpyAsync(ncand.data(), d_ncand, B * 4, hipMemcpyDeviceToHost, st));

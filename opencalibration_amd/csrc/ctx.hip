@@ -140,6 +140,13 @@ int ochip_ctx_create(int device, ochip_ctx **out)
         return ochip_fail(nullptr, OCHIP_ENOMEM, "host allocation failed");
     ctx->device = device;
     hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess && getenv("OCHIP_BLOCKING_SYNC"))
+    {
+        // waits sleep instead of spinning: host threads that wait for the device do not eat into a CPU quota the
+        // OpenMP teams of the host phases need (refused harmlessly if the device is already active with other flags)
+        (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+        (void)hipGetLastError();
+    }
     if (e == hipSuccess)
         e = hipGetDeviceProperties(&ctx->prop, device);
     if (e == hipSuccess && std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0)
@@ -167,6 +174,9 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
 {
     if (!ctx)
         return;
+    for (ochip_ctx *sib : ctx->siblings)
+        ochip_ctx_destroy(sib);
+    ctx->siblings.clear();
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto &s : ctx->prof)
@@ -198,6 +208,25 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
     if (ctx->copy_stream)
         (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
+}
+
+int ochip_ctx_sibling(ochip_ctx *ctx, uint32_t index, ochip_ctx **out)
+{
+    if (!ctx || !out)
+        return OCHIP_EINVAL;
+    *out = nullptr;
+    if (index > 64)
+        return ochip_fail(ctx, OCHIP_EINVAL, "sibling index %u out of range", index);
+    while (ctx->siblings.size() <= index)
+    {
+        ochip_ctx *s = nullptr;
+        const int rc = ochip_ctx_create(ctx->device, &s);
+        if (rc != OCHIP_OK)
+            return ochip_fail(ctx, rc, "sibling context: %s", ochip_last_error(nullptr));
+        ctx->siblings.push_back(s);
+    }
+    *out = ctx->siblings[index];
+    return OCHIP_OK;
 }
 
 const char *ochip_last_error(const ochip_ctx *ctx)
@@ -406,6 +435,12 @@ int ochip_profile_reset(ochip_ctx *ctx)
         ctx->prof[k].launches = 0;
         ctx->prof[k].total_ms = 0;
     }
+    for (ochip_ctx *sib : ctx->siblings)
+    {
+        const int rc = ochip_profile_reset(sib);
+        if (rc != OCHIP_OK)
+            return rc;
+    }
     return OCHIP_OK;
 }
 
@@ -414,10 +449,22 @@ int ochip_profile_get(ochip_ctx *ctx, int kernel_id, uint64_t *launches, double 
     if (!ctx || kernel_id < 0 || kernel_id >= OCHIP_K_COUNT)
         return OCHIP_EINVAL;
     prof_drain(ctx, kernel_id);
+    uint64_t n = ctx->prof[kernel_id].launches;
+    double ms = ctx->prof[kernel_id].total_ms;
+    for (ochip_ctx *sib : ctx->siblings) // launches made through sibling contexts count for their owner
+    {
+        uint64_t sn = 0;
+        double sms = 0;
+        const int rc = ochip_profile_get(sib, kernel_id, &sn, &sms);
+        if (rc != OCHIP_OK)
+            return rc;
+        n += sn;
+        ms += sms;
+    }
     if (launches)
-        *launches = ctx->prof[kernel_id].launches;
+        *launches = n;
     if (total_ms)
-        *total_ms = ctx->prof[kernel_id].total_ms;
+        *total_ms = ms;
     return OCHIP_OK;
 }
 

@@ -63,6 +63,10 @@ struct ochip_ctx
     std::vector<std::pair<void *, size_t>> dev_pool;
 
     ochip_profile_slot prof[OCHIP_K_COUNT];
+
+    // sibling contexts on the same device (own streams, scratch and pools) handed out by ochip_ctx_sibling so
+    // that independent batches can be in flight at once; owned by this context
+    std::vector<ochip_ctx *> siblings;
 };
 
 int ochip_fail(ochip_ctx *ctx, int code, const char *fmt, ...);

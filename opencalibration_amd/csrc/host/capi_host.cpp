@@ -5,6 +5,7 @@
 #include "match_features.hpp"
 
 #include <cstring>
+#include <thread>
 
 using namespace opencalibration_amd;
 
@@ -128,8 +129,17 @@ int och_link_stage_run(och_graph *g, ochip_ctx *ctx, const uint64_t *node_ids, s
     g->link->keep_debug = keep_debug != 0;
     std::vector<size_t> ids(node_ids, node_ids + n);
     g->link->init(g->graph, ids);
-    for (auto &f : g->link->get_runners(g->graph))
-        f();
+    {
+        // the runners are independent batches: run them concurrently, as the reference's pipeline runs its closures
+        auto runners = g->link->get_runners(g->graph);
+        std::vector<std::thread> threads;
+        for (size_t r = 1; r < runners.size(); r++)
+            threads.emplace_back(runners[r]);
+        if (!runners.empty())
+            runners[0]();
+        for (auto &t : threads)
+            t.join();
+    }
     if (!g->link->error.empty())
     {
         g->error = g->link->error;

@@ -2,9 +2,12 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <tuple>
+
+#include <omp.h>
 
 namespace opencalibration_amd
 {
@@ -35,6 +38,16 @@ double since(clk::time_point t0)
     return std::chrono::duration<double>(clk::now() - t0).count();
 }
 } // namespace
+
+LinkStage::LinkStage(ochip_ctx *ctx, int runners) : _ctx(ctx), _runners(runners)
+{
+    if (_runners <= 0)
+    {
+        const char *e = std::getenv("OCHIP_LINK_RUNNERS");
+        _runners = e ? std::atoi(e) : 3;
+    }
+    _runners = std::max(1, std::min(_runners, 16));
+}
 
 void LinkStage::init(const MeasurementGraph &graph, const std::vector<size_t> &node_ids)
 {
@@ -73,12 +86,44 @@ void LinkStage::init(const MeasurementGraph &graph, const std::vector<size_t> &n
 std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph &graph)
 {
     std::vector<std::function<void()>> funcs;
-    funcs.push_back([this, &graph]() { run_batch(graph); });
+    // a runner needs enough pairs to fill the device; the debug record is kept in runner order, so one runner then
+    size_t n = keep_debug ? 1 : std::min<size_t>((size_t)_runners, std::max<size_t>(1, _links.size() / 64));
+    const int omp_threads = std::max(1, omp_get_max_threads() / (int)n);
+    for (size_t r = 0; r < n; r++)
+    {
+        const size_t begin = _links.size() * r / n, end = _links.size() * (r + 1) / n;
+        ochip_ctx *ctx = _ctx;
+        if (r > 0 && ochip_ctx_sibling(_ctx, (uint32_t)(r - 1), &ctx) != OCHIP_OK)
+        {
+            error = std::string("ochip_ctx_sibling: ") + ochip_last_error(_ctx);
+            ctx = nullptr;
+        }
+        funcs.push_back([this, &graph, begin, end, ctx, omp_threads]() {
+            if (ctx)
+                run_batch(graph, begin, end, ctx, omp_threads);
+        });
+    }
     return funcs;
 }
 
-void LinkStage::run_batch(const MeasurementGraph &graph)
+void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size_t link_end, ochip_ctx *ctx, int omp_threads)
 {
+    LinkTimers lt; // this runner's phases, added to `timers` at the end
+    struct timers_guard
+    {
+        LinkStage *self;
+        LinkTimers *lt;
+        ~timers_guard()
+        {
+            std::lock_guard<std::mutex> lock(self->_measurement_mutex);
+            self->timers.subsample += lt->subsample;
+            self->timers.upload += lt->upload;
+            self->timers.match_device += lt->match_device;
+            self->timers.match_host += lt->match_host;
+            self->timers.ransac_device += lt->ransac_device;
+            self->timers.decompose_host += lt->decompose_host;
+        }
+    } guard{this, &lt};
     struct pair_job
     {
         size_t loop_index, node_id, match_node_id;
@@ -97,7 +142,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
         return s;
     };
     std::vector<pair_job> jobs;
-    for (size_t i = 0; i < _links.size(); i++)
+    for (size_t i = link_begin; i < link_end; i++)
         for (size_t match_node_id : _links[i].link_ids)
         {
             if (graph.getNode(match_node_id) == nullptr) // link_stage.cpp:69-73
@@ -107,8 +152,9 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
     const size_t n_slots = slot_node.size(), n_pairs = jobs.size();
     if (n_pairs == 0)
         return;
-    auto fail = [this](const char *what) {
-        error = std::string(what) + ": " + ochip_last_error(_ctx);
+    auto fail = [this, ctx](const char *what) {
+        std::lock_guard<std::mutex> lock(_measurement_mutex);
+        error = std::string(what) + ": " + ochip_last_error(ctx);
     };
 
     // ---- 40 px subsets, once per image (link_stage.cpp:63-65,80-81; the per-pair recomputation of
@@ -117,7 +163,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
     const double coarse_spacing_pixels = 40.0;
     std::vector<std::vector<size_t>> subset(n_slots);
     std::vector<std::vector<double>> rays(n_slots); // unit rays of the subset keypoints (for decompose)
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(omp_threads)
     for (size_t s = 0; s < n_slots; s++)
     {
         const image &img = graph.getNode(slot_node[s])->payload;
@@ -126,7 +172,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
         for (size_t k = 0; k < subset[s].size(); k++)
             image_to_3d(img.features[subset[s][k]].location, *img.model, &rays[s][3 * k]);
     }
-    timers.subsample += since(t0);
+    lt.subsample += since(t0);
 
     // ---- upload descriptors + keypoints (one packed batch, packed in parallel)
     t0 = clk::now();
@@ -139,12 +185,12 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
     }
     const uint64_t total_desc = slot_off[n_slots];
     {
-        pinned<uint64_t> dbuf(_ctx, total_desc * 8);
-        pinned<double> xybuf(_ctx, total_desc * 2);
+        pinned<uint64_t> dbuf(ctx, total_desc * 8);
+        pinned<double> xybuf(ctx, total_desc * 2);
         std::vector<double> models((size_t)n_slots * 8);
         if (!dbuf.ptr || !xybuf.ptr)
             return fail("ochip_host_alloc");
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(omp_threads)
         for (size_t s = 0; s < n_slots; s++)
         {
             const image &img = graph.getNode(slot_node[s])->payload;
@@ -163,10 +209,10 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
                                       m.tangential_distortion[0], m.tangential_distortion[1]};
             std::memcpy(&models[s * 8], model8, sizeof model8);
         }
-        if (ochip_upload_batch(_ctx, (uint32_t)n_slots, counts.data(), dbuf.ptr, xybuf.ptr, models.data()) != OCHIP_OK)
+        if (ochip_upload_batch(ctx, (uint32_t)n_slots, counts.data(), dbuf.ptr, xybuf.ptr, models.data()) != OCHIP_OK)
             return fail("ochip_upload_batch");
     }
-    timers.upload += since(t0);
+    lt.upload += since(t0);
 
     // ---- device: Hamming 2-NN for every pair
     t0 = clk::now();
@@ -179,14 +225,14 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
         out_off[p] = out_total;
         out_total += subset[jobs[p].slot_1].size();
     }
-    pinned<ochip_match> raw(_ctx, out_total ? out_total : 1);
+    pinned<ochip_match> raw(ctx, out_total ? out_total : 1);
     if (!raw.ptr)
         return fail("ochip_host_alloc");
-    if (ochip_match_launch(_ctx, pairs.data(), (uint32_t)n_pairs, out_off.data(), out_total) != OCHIP_OK)
+    if (ochip_match_launch(ctx, pairs.data(), (uint32_t)n_pairs, out_off.data(), out_total) != OCHIP_OK)
         return fail("ochip_match_launch");
-    if (ochip_match_fetch(_ctx, raw.ptr, out_total) != OCHIP_OK)
+    if (ochip_match_fetch(ctx, raw.ptr, out_total) != OCHIP_OK)
         return fail("ochip_match_fetch");
-    timers.match_device += since(t0);
+    lt.match_device += since(t0);
 
     // ---- host: ratio test, std::sort, PROSAC order; pack the RANSAC jobs
     t0 = clk::now();
@@ -199,7 +245,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
     std::vector<std::vector<feature_match>> matches(n_pairs);
     std::vector<std::vector<ochip_ransac_match>> rmatches(n_pairs);
     std::vector<std::vector<uint32_t>> sorted_idx(n_pairs);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(omp_threads)
     for (size_t p = 0; p < n_pairs; p++)
     {
         const auto &idx1 = subset[jobs[p].slot_1], &idx2 = subset[jobs[p].slot_2];
@@ -252,12 +298,12 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
         rjobs[p] = ochip_ransac_job{jobs[p].slot_1, jobs[p].slot_2, (uint32_t)M, rng_state, total_matches, it->second};
         total_matches += M;
     }
-    pinned<ochip_ransac_match> rm_flat(_ctx, total_matches ? total_matches : 1);
-    pinned<uint32_t> si_flat(_ctx, total_matches ? total_matches : 1);
-    pinned<uint8_t> inl_flat(_ctx, total_matches ? total_matches : 1);
+    pinned<ochip_ransac_match> rm_flat(ctx, total_matches ? total_matches : 1);
+    pinned<uint32_t> si_flat(ctx, total_matches ? total_matches : 1);
+    pinned<uint8_t> inl_flat(ctx, total_matches ? total_matches : 1);
     if (!rm_flat.ptr || !si_flat.ptr || !inl_flat.ptr)
         return fail("ochip_host_alloc");
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(omp_threads)
     for (size_t p = 0; p < n_pairs; p++)
     {
         std::copy(rmatches[p].begin(), rmatches[p].end(), rm_flat.ptr + rjobs[p].match_offset);
@@ -266,23 +312,23 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
         else
             std::fill(si_flat.ptr + rjobs[p].match_offset, si_flat.ptr + rjobs[p].match_offset + rjobs[p].n, 0u);
     }
-    timers.match_host += since(t0);
+    lt.match_host += since(t0);
 
     // ---- device: RANSAC
     t0 = clk::now();
     std::vector<ochip_ransac_result> results(n_pairs);
     const homography_model model_defaults;
-    if (ochip_ransac_homography_batch(_ctx, rjobs.data(), (uint32_t)n_pairs, rm_flat.ptr, si_flat.ptr, total_matches,
+    if (ochip_ransac_homography_batch(ctx, rjobs.data(), (uint32_t)n_pairs, rm_flat.ptr, si_flat.ptr, total_matches,
                                       eval_table.data(), eval_table.size(), model_defaults.inlier_threshold,
                                       results.data(), inl_flat.ptr) != OCHIP_OK)
         return fail("ochip_ransac_homography_batch");
-    timers.ransac_device += since(t0);
+    lt.ransac_device += since(t0);
 
     // ---- host: decompose, accept, assemble (link_stage.cpp:95-111)
     t0 = clk::now();
     std::vector<edge_payload> payloads(n_pairs);
     std::vector<pair_debug> dbg(keep_debug ? n_pairs : 0);
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(omp_threads)
     for (size_t p = 0; p < n_pairs; p++)
     {
         const image &img = graph.getNode(jobs[p].node_id)->payload;
@@ -333,7 +379,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph)
         for (auto &d : dbg)
             debug.emplace_back(std::move(d));
     }
-    timers.decompose_host += since(t0);
+    lt.decompose_host += since(t0);
 }
 
 std::vector<size_t> LinkStage::finalize(MeasurementGraph &graph)

@@ -1,6 +1,9 @@
 // LinkStage with the reference's interface (src/pipeline/link_stage.hpp:25-30: init / get_runners /
-// finalize), re-stated for a device: get_runners returns ONE runner that pushes the whole batch of
-// directed pairs through libochip.so instead of one closure per pair.
+// finalize), re-stated for a device: instead of one closure per pair, get_runners returns a few batch runners
+// (contiguous ranges of the source images), each pushing its directed pairs through libochip.so
+// on its own device context, so that the host phases of one runner (ratio test + std::sort, decompose +
+// assembleInliers) overlap the device phases (Hamming 2-NN, RANSAC) of the others.  The caller runs the
+// runners concurrently, as the reference's pipeline does with its closures.
 #pragma once
 
 #include "match_features.hpp"
@@ -39,9 +42,8 @@ class LinkStage
         bool can_decompose = false;
     };
 
-    explicit LinkStage(ochip_ctx *ctx) : _ctx(ctx)
-    {
-    }
+    // runners: number of concurrent batch runners (0: OCHIP_LINK_RUNNERS or the default of 3)
+    explicit LinkStage(ochip_ctx *ctx, int runners = 0);
 
     // link_stage.cpp:13-38.  The reference queries the GPS KD-tree LoadStage::finalize filled with every
     // loaded image (load_stage.cpp:102-103); here the graph's nodes are searched directly (exact kNN,
@@ -56,7 +58,7 @@ class LinkStage
 
     bool keep_debug = false;
     std::vector<pair_debug> debug;
-    LinkTimers timers;
+    LinkTimers timers; // summed over the concurrent runners (so the phases can add up to more than the wall time)
     std::string error; // non-empty if the runner failed (the reference has no exceptions on this path)
 
   private:
@@ -67,9 +69,10 @@ class LinkStage
         size_t match_node_id;
         camera_relations relations;
     };
-    void run_batch(const MeasurementGraph &graph);
+    void run_batch(const MeasurementGraph &graph, size_t link_begin, size_t link_end, ochip_ctx *ctx, int omp_threads);
 
     ochip_ctx *_ctx;
+    int _runners;
     std::vector<edge_payload> _all_inlier_measurements;
     std::mutex _measurement_mutex;
     std::vector<NodeLinks> _links;
