@@ -118,8 +118,10 @@ def main():
     #   source: BGR read (3 B/px) + grey write/read (2 B/px) at full resolution, working image write (4 B/px)
     #   k-contrast: image read, gradient magnitude write + read                            3 floats / working px
     #   level 0: Gaussian(1.6) read + write                                               2
-    #   per evolution level: conductivity (read L, write c) 2, FED steps 3 each (read L, c; write L)
+    #   per evolution level: conductivity (read L, write c) 2; FED steps: 3 (read L, c; write L) per group of <= 4
+    #     steps (steps fused in registers are not charged: the figure is what the pass structure must move)
     #   per level detection: derivatives (read L, write Lx, Ly) 3, determinant (read Lx, Ly, write) 3, maxima (r, w) 2
+    #   per level description: maxima map read once (list + suppression) 1, L / Lx / Ly read once by the sampler 3
     sc = min(1.0, 1600.0 / max(w, h))
     W, H = int(round(w * sc)), int(round(h * sc))
     sig = [1.6 * 2.0 ** (j / 4.0 + o) for o in range(4) for j in range(4)]
@@ -128,16 +130,29 @@ def main():
     px_floats = 5.0 * W * H
     for lvl in range(16):
         px = (W >> (lvl // 4)) * (H >> (lvl // 4))
-        px_floats += px * (8 + (2 + 3 * fed[lvl] if lvl else 0))
+        px_floats += px * (12 + (2 + 3 * ((fed[lvl] + 3) // 4) if lvl else 0))
     alg_bytes_img = 4.0 * px_floats + w * h * 5.0
     imgs_per_launch = grid.n_images * args.steps / max(n_akaze, 1)
-    avg_ms_akaze = ms_akaze / max(n_akaze, 1)
-    achieved = alg_bytes_img * imgs_per_launch / (avg_ms_akaze * 1e-3) / 1e9 if avg_ms_akaze > 0 else 0.0
+    avg_ms_akaze = ms_akaze / max(n_akaze, 1)          # HIP events around one chunk's launch sequence, on its stream
+    # two device contexts keep two chunks in flight (their sequences overlap in time), so the rate is taken over the
+    # extract stage's wall time - device-bound, the host tail runs underneath it - which can only understate it
+    t_extract = acc["extract"] / args.steps
+    achieved = alg_bytes_img * grid.n_images / t_extract / 1e9
+    launch_ms = t_extract * 1e3 / (grid.n_images / imgs_per_launch)
+    traffic = None
+    try:   # HBM bytes from the committed PMC pass (profiles/, FETCH_SIZE x 2 + WRITE_SIZE, see scripts/summarise_profile.py)
+        with open(os.path.join(ROOT, "profiles", "r01_e2e_pmc_hbm.json")) as fh:
+            traffic = round(json.load(fh)["extract_hbm_bytes_per_image"] * imgs_per_launch)
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {
-        "kernel": "extract (AKAZE) stencil passes, one batched launch sequence per %d images" % round(imgs_per_launch),
+        "kernel": "extract (AKAZE) kernel sequence, one batched launch sequence per %d images, 2 sequences in flight"
+                  % round(imgs_per_launch),
         "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-        "frac": round(achieved / 8000.0, 4), "traffic": None,
-        "avg_launch_ms": round(avg_ms_akaze, 3), "launches": n_akaze,
+        "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+        "avg_launch_ms": round(launch_ms, 3), "launches": n_akaze,
+        "hip_event_ms_per_sequence_overlapped": round(avg_ms_akaze, 3),
+        "algorithmic_bytes_per_launch": round(alg_bytes_img * imgs_per_launch),
         "algorithmic_bytes_per_image": round(alg_bytes_img),
         "other_kernels_avg_ms": {
             "hamming_2nn_kernel": round(ms_match / max(n_match, 1), 3),

@@ -27,6 +27,7 @@ struct level_info
     int octave, w, h, sigma_size;
     float esigma;
     size_t off; // plane offset (floats) inside one image's pyramid
+    int tile_off, tiles_x; // first id and row length of the level's 64 x 32 detection tiles
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi)
@@ -426,7 +427,8 @@ struct cand_t
 template <int S>
 __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict__ Lx, const float *__restrict__ Ly, size_t stride,
                                                          float *__restrict__ Ldet, float *__restrict__ Rmax, int w, int h,
-                                                         float thr)
+                                                         float thr, unsigned int *__restrict__ tile_counts, int tile_off,
+                                                         int n_tiles)
 {
     constexpr int HW = S + 1, RW = BT_X + 2 * HW, RH = BT_Y + 2 * HW, DW = BT_X + 2, DH = BT_Y + 2;
     __shared__ float tx[RW * RH], ty[RW * RH];
@@ -467,6 +469,7 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
             Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = d;
     }
     __syncthreads();
+    unsigned int found = 0;
     for (int idx = threadIdx.x; idx < BT_X * BT_Y; idx += 256)
     {
         const int ly = idx / BT_X, lx = idx - ly * BT_X;
@@ -488,11 +491,24 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
                         if ((dx || dy) && !(v > td[ci + dy * DW + dx]))
                             mx = false;
                 if (mx)
+                {
                     out = v;
+                    found++;
+                }
             }
         }
         Rmax[(size_t)blockIdx.z * stride + (size_t)y * w + x] = out;
     }
+    // number of maxima of this tile: the candidate list is laid out tile by tile (scan_tiles_kernel)
+    __shared__ unsigned int wsum[4];
+    for (int off = 32; off >= 1; off >>= 1)
+        found += (unsigned int)__shfl_xor((int)found, off);
+    if ((threadIdx.x & 63) == 0)
+        wsum[threadIdx.x >> 6] = found;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        tile_counts[(size_t)blockIdx.z * n_tiles + tile_off + blockIdx.y * gridDim.x + blockIdx.x] =
+            wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 struct levels_dev
@@ -501,61 +517,105 @@ struct levels_dev
     level_info l[16];
 };
 
-// Candidate list of an image = the non-zero entries of its maxima maps, all levels in one launch.  A workgroup
-// scans a 256 x COLLECT_ROWS band, gathers its maxima in LDS and appends them with one global atomic per flush
-// (device-scope same-address atomics cost ~0.2 us each here, so they are kept to a few hundred per image).
-constexpr int COLLECT_ROWS = 128, COLLECT_CAP = 2048;
-__global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ Rmax, size_t img_stride, levels_dev L,
-                                                      cand_t *__restrict__ cands, unsigned int *__restrict__ n_cands,
-                                                      unsigned int max_cands)
+// Candidate list of an image = the non-zero entries of its maxima maps, laid out tile by tile in a space-filling
+// order (tile_seq: level by level, Morton order of the 64 x 32 tiles inside a level).  Neighbouring list entries
+// are neighbouring pixels, which is what keeps the window scans of the suppression and the patch gathers of the
+// descriptor inside the L2: with an arbitrary order the descriptor kernel alone pulled ~0.9 GB per image through
+// the fabric, 14x the size of the pyramid it samples.  No global atomics: the offsets come from a prefix sum of the
+// per-tile counts det_maxima_kernel leaves behind.
+__global__ __launch_bounds__(256) void scan_tiles_kernel(const unsigned int *__restrict__ tile_counts,
+                                                         const unsigned int *__restrict__ tile_seq, int n_tiles,
+                                                         unsigned int *__restrict__ tile_base, unsigned int *__restrict__ n_cands)
 {
-    __shared__ cand_t lc[COLLECT_CAP];
-    __shared__ unsigned int lcount, lbase;
-    const int level = blockIdx.y;
+    __shared__ unsigned int wsum[4], carry;
+    const unsigned int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry = 0;
+    __syncthreads();
+    for (int start = 0; start < n_tiles; start += 256)
+    {
+        const int i = start + threadIdx.x;
+        const unsigned int tile = i < n_tiles ? tile_seq[i] : 0;
+        const unsigned int v = i < n_tiles ? tile_counts[(size_t)b * n_tiles + tile] : 0;
+        unsigned int incl = v; // inclusive scan inside the wavefront
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const unsigned int t = (unsigned int)__shfl_up((int)incl, off);
+            if (lane >= off)
+                incl += t;
+        }
+        if (lane == 63)
+            wsum[wv] = incl;
+        __syncthreads();
+        unsigned int base = carry;
+        for (int j = 0; j < wv; j++)
+            base += wsum[j];
+        if (i < n_tiles)
+            tile_base[(size_t)b * n_tiles + tile] = base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        n_cands[b] = carry;
+}
+
+__global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restrict__ Rmax, size_t img_stride, levels_dev L,
+                                                            const unsigned int *__restrict__ tile_base, int n_tiles,
+                                                            cand_t *__restrict__ cands, unsigned int max_cands)
+{
+    __shared__ unsigned int lcount;
     const unsigned int b = blockIdx.z;
+    const int tile = blockIdx.x;
+    int level = 0;
+    while (level + 1 < L.n && tile >= L.l[level + 1].tile_off)
+        level++;
     const level_info l = L.l[level];
-    const int bands_x = (l.w + 255) / 256, bands_y = (l.h + COLLECT_ROWS - 1) / COLLECT_ROWS;
-    if ((int)blockIdx.x >= bands_x * bands_y)
-        return;
-    const int by = blockIdx.x / bands_x, bx = blockIdx.x - by * bands_x;
-    const int x = bx * 256 + threadIdx.x;
+    const int t = tile - l.tile_off;
+    const int ty = t / l.tiles_x, tx = t - ty * l.tiles_x;
     const float *R = Rmax + (size_t)b * img_stride + l.off;
+    const unsigned int base = tile_base[(size_t)b * n_tiles + tile];
     if (threadIdx.x == 0)
         lcount = 0;
     __syncthreads();
-    auto flush = [&]() {
-        if (threadIdx.x == 0 && lcount)
-            lbase = atomicAdd(n_cands + b, lcount);
-        __syncthreads();
-        const unsigned int n = lcount;
-        for (unsigned int i = threadIdx.x; i < n; i += 256)
-            if (lbase + i < max_cands)
-                cands[(size_t)b * max_cands + lbase + i] = lc[i];
-        __syncthreads();
-        if (threadIdx.x == 0)
-            lcount = 0;
-        __syncthreads();
-    };
-    for (int r = 0; r < COLLECT_ROWS; r++)
+    for (int idx = threadIdx.x; idx < BT_X * BT_Y; idx += 256)
     {
-        const int y = by * COLLECT_ROWS + r;
-        if (y >= l.h)
-            break;
-        if (x < l.w)
+        const int ly = idx / BT_X, lx = idx - ly * BT_X;
+        const int x = tx * BT_X + lx, y = ty * BT_Y + ly;
+        if (x >= l.w || y >= l.h)
+            continue;
+        const float v = R[(size_t)y * l.w + x];
+        if (v != 0.0f)
         {
-            const float v = R[(size_t)y * l.w + x];
-            if (v != 0.0f)
-                lc[atomicAdd(&lcount, 1u)] = cand_t{level, x, y, v};
-        }
-        if ((r & 3) == 3) // at most 4 x 128 new entries since the last check
-        {
-            __syncthreads();
-            if (lcount > COLLECT_CAP - 512)
-                flush();
+            const unsigned int slot = base + atomicAdd(&lcount, 1u);
+            if (slot < max_cands)
+                cands[(size_t)b * max_cands + slot] = cand_t{level, x, y, v};
         }
     }
-    __syncthreads();
-    flush();
+}
+
+// Workgroup -> work item map.  Workgroups are dealt to the 8 XCDs round-robin (id % 8); mode 2 hands each XCD
+// whole groups of 64 consecutive items in turn, so that list neighbours - spatial neighbours - share an L2 while
+// the XCDs stay balanced (a static eighth per XCD, mode 1, left XCDs idle: the share of suppressed candidates
+// varies along the list).  Mode 0 is the identity.  Returns false when there is no item for this workgroup.
+__device__ __forceinline__ bool xcd_contiguous(unsigned int block, unsigned int n_items, unsigned int *item, int mode)
+{
+    if (mode == 0)
+    {
+        *item = block;
+        return block < n_items;
+    }
+    const unsigned int x = block & 7, j = block >> 3;
+    if (mode == 1)
+    {
+        const unsigned int chunk = (n_items + 7) / 8;
+        *item = x * chunk + j;
+        return j < chunk && *item < n_items;
+    }
+    *item = ((j >> 6) * 8 + x) * 64 + (j & 63);
+    return *item < n_items;
 }
 
 // A candidate dies if a stronger maximum (ties: lower (level, y, x) wins) of an adjacent level lies within
@@ -563,10 +623,14 @@ __global__ __launch_bounds__(256) void collect_kernel(const float *__restrict__ 
 // the sparse maxima maps.
 __global__ void suppress_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
                                 unsigned int max_cands, const float *__restrict__ Rmax, size_t img_stride, levels_dev L,
-                                float derivative_factor, unsigned char *__restrict__ dead)
+                                float derivative_factor, unsigned char *__restrict__ dead, int remap)
 {
-    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
+    const unsigned int b = blockIdx.z;
     const unsigned int n = min(n_cands[b], max_cands);
+    unsigned int group;
+    if (!xcd_contiguous(blockIdx.x, (n + blockDim.x - 1) / blockDim.x, &group, remap))
+        return;
+    const unsigned int k = group * blockDim.x + threadIdx.x;
     if (k >= n)
         return;
     const cand_t c = cands[(size_t)b * max_cands + k];
@@ -676,7 +740,7 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
                                                       const float *__restrict__ gw /*13x13*/, const pair_tab *__restrict__ tab,
                                                       float *__restrict__ kp_out /*[b][max][6]*/,
                                                       unsigned long long *__restrict__ desc_out /*[b][max][8]*/,
-                                                      unsigned char *__restrict__ valid_out)
+                                                      unsigned char *__restrict__ valid_out, int remap)
 {
     __shared__ float resX[109], resY[109], Ang[109];
     __shared__ float wm[42], wang[42];
@@ -684,9 +748,10 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
     __shared__ float smp[3][441];        // the 21 x 21 descriptor sample lattice: intensity, rotated dx, rotated dy
     __shared__ unsigned char smp_ok[441]; // sample inside the level image
     const int lane = threadIdx.x;
-    const unsigned int k = blockIdx.x, b = blockIdx.z;
+    const unsigned int b = blockIdx.z;
     const unsigned int n = min(n_cands[b], max_cands);
-    if (k >= n)
+    unsigned int k;
+    if (!xcd_contiguous(blockIdx.x, n, &k, remap))
         return;
     const size_t slot = (size_t)b * max_cands + k;
     if (dead[slot])
@@ -1193,6 +1258,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     levels_dev LV{};
     std::vector<std::vector<float>> tsteps;
     size_t img_stride = 0;
+    int n_tiles = 0;
     {
         std::vector<float> etime;
         for (int i = 0; i < omax; i++)
@@ -1211,6 +1277,9 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 l.sigma_size = (int)std::lrintf(l.esigma * dfactor / (float)(1 << i));
                 l.off = img_stride;
                 img_stride += (size_t)lw * lh;
+                l.tiles_x = (lw + BT_X - 1) / BT_X;
+                l.tile_off = n_tiles;
+                n_tiles += l.tiles_x * ((lh + BT_Y - 1) / BT_Y);
                 etime.push_back(0.5f * (l.esigma * l.esigma));
             }
         }
@@ -1244,7 +1313,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned char *d_dead = nullptr, *d_valid = nullptr;
     unsigned long long *d_desc = nullptr, *d_descc = nullptr;
     float *d_kpc = nullptr;
-    unsigned int *d_counts = nullptr;
+    unsigned int *d_counts = nullptr, *d_tile_counts = nullptr, *d_tile_base = nullptr, *d_tile_seq = nullptr;
     pair_tab *d_tab = nullptr;
     const size_t src_px = (size_t)width * height;
     auto tiles = [&](int w, int h) { return dim3((w + BT_X - 1) / BT_X, (h + BT_Y - 1) / BT_Y, B); };
@@ -1276,6 +1345,36 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     AK(up<float>(ctx, allocs, &d_kpc, nullptr, (size_t)B * max_kp * 6));
     AK(up<unsigned long long>(ctx, allocs, &d_descc, nullptr, (size_t)B * max_kp * 8));
     AK(up<unsigned int>(ctx, allocs, &d_counts, nullptr, B));
+    AK(up<unsigned int>(ctx, allocs, &d_tile_counts, nullptr, (size_t)B * n_tiles));
+    AK(up<unsigned int>(ctx, allocs, &d_tile_base, nullptr, (size_t)B * n_tiles));
+    {
+        // processing order of the detection tiles: level by level, Morton order inside a level
+        std::vector<std::pair<uint64_t, unsigned int>> keyed;
+        keyed.reserve(n_tiles);
+        auto spread = [](uint32_t v) {
+            uint64_t x = v;
+            x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+            x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+            x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+            x = (x | (x << 2)) & 0x3333333333333333ull;
+            x = (x | (x << 1)) & 0x5555555555555555ull;
+            return x;
+        };
+        for (int i = 0; i < LV.n; i++)
+        {
+            const level_info &l = LV.l[i];
+            const int ty_n = (l.h + BT_Y - 1) / BT_Y;
+            for (int ty = 0; ty < ty_n; ty++)
+                for (int tx = 0; tx < l.tiles_x; tx++)
+                    keyed.emplace_back(((uint64_t)i << 48) | spread((uint32_t)tx) | (spread((uint32_t)ty) << 1),
+                                       (unsigned int)(l.tile_off + ty * l.tiles_x + tx));
+        }
+        std::sort(keyed.begin(), keyed.end());
+        std::vector<unsigned int> seq(keyed.size());
+        for (size_t i = 0; i < keyed.size(); i++)
+            seq[i] = keyed[i].second;
+        AK(up(ctx, allocs, &d_tile_seq, seq.data(), seq.size()));
+    }
     {
         std::vector<float> gw(169);
         for (int i = -6; i <= 6; i++)
@@ -1462,20 +1561,19 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             float *ld = d_Ldet + l.off, *rm = d_Rmax + l.off;
             if (l.sigma_size == 2)
                 hipLaunchKernelGGL((det_maxima_kernel<2>), tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
-                                   l.h, dthreshold);
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles);
             else if (l.sigma_size == 3)
                 hipLaunchKernelGGL((det_maxima_kernel<3>), tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
-                                   l.h, dthreshold);
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles);
             else
                 hipLaunchKernelGGL((det_maxima_kernel<4>), tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
-                                   l.h, dthreshold);
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles);
         }
     }
-    {
-        const int bands0 = ((W + 255) / 256) * ((H + COLLECT_ROWS - 1) / COLLECT_ROWS);
-        hipLaunchKernelGGL(collect_kernel, dim3(bands0, LV.n, B), dim3(256), 0, st, (const float *)d_Rmax, img_stride, LV,
-                           d_cands, d_ncand, max_cands);
-    }
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(B), dim3(256), 0, st, (const unsigned int *)d_tile_counts,
+                       (const unsigned int *)d_tile_seq, n_tiles, d_tile_base, d_ncand);
+    hipLaunchKernelGGL(collect_tiles_kernel, dim3(n_tiles, 1, B), dim3(256), 0, st, (const float *)d_Rmax, img_stride, LV,
+                       (const unsigned int *)d_tile_base, n_tiles, d_cands, max_cands);
     std::vector<unsigned int> ncand(B);
     OCHIP_HIP(ctx, hipMemcpyAsync(ncand.data(), d_ncand, B * 4, hipMemcpyDeviceToHost, st));
     OCHIP_HIP(ctx, hipStreamSynchronize(st));
@@ -1490,14 +1588,15 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         }
         max_n = std::max(max_n, ncand[b]);
     }
+    static const int xcd_remap = getenv("OCHIP_XCD_REMAP") ? atoi(getenv("OCHIP_XCD_REMAP")) : 2; // tuning knob, see xcd_contiguous
     if (max_n > 0)
     {
         hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 255) / 256, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
-                           (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride, LV, dfactor, d_dead);
-        hipLaunchKernelGGL(describe_kernel, dim3(max_n, 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
+                           (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride, LV, dfactor, d_dead, 0);
+        hipLaunchKernelGGL(describe_kernel, dim3(512 * ((max_n + 511) / 512), 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
                            (const unsigned int *)d_ncand, max_cands, (const unsigned char *)d_dead, (const float *)d_Lt,
                            (const float *)d_Lx, (const float *)d_Ly, (const float *)d_Ldet, img_stride, LV, dfactor,
-                           (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid);
+                           (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap);
     }
     if (max_n > 0)
         hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, st, (const unsigned char *)d_valid,

@@ -157,32 +157,52 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
     const uint32_t chunk = std::min(extract_chunk_size(), n_images);
     const size_t image_bytes = (size_t)width * height * 3;
 
-    // Two chunk buffers: a driver thread keeps the device busy with chunk k + 1 (ochip_akaze_batch is a blocking
-    // call) while this thread's OpenMP team runs the host tail of chunk k.
-    chunk_buffers bufs[2];
+    // Driver threads (one per device context: the caller's and its siblings) keep the device busy - a chunk's
+    // result copies over PCIe, table uploads and launch gaps overlap the kernels of the other context's chunk -
+    // while this thread's OpenMP team runs the host tail of the finished chunks.  ochip_akaze_batch is a blocking
+    // call; every driver owns two result buffers.
+    uint32_t n_drivers = 2;
+    if (const char *e = std::getenv("OCHIP_EXTRACT_STREAMS"))
+        n_drivers = (uint32_t)std::max(1L, std::min(4L, std::atol(e)));
+    const uint32_t n_chunks = (n_images + chunk - 1) / chunk;
+    n_drivers = std::min(n_drivers, n_chunks);
+    std::vector<ochip_ctx *> ctxs(n_drivers, ctx);
+    for (uint32_t d = 1; d < n_drivers; d++)
+        if (ochip_ctx_sibling(ctx, d - 1, &ctxs[d]) != OCHIP_OK)
+        {
+            if (error)
+                *error = std::string("ochip_ctx_sibling: ") + ochip_last_error(ctx);
+            return {};
+        }
+    const uint32_t n_bufs = 2 * n_drivers;
+    std::vector<chunk_buffers> bufs(n_bufs);
+    std::vector<ochip_ctx *> buf_ctx(n_bufs);
     std::string fail;
     auto release = [&]() {
-        for (auto &b : bufs)
+        for (uint32_t i = 0; i < n_bufs; i++)
         {
+            chunk_buffers &b = bufs[i];
             if (b.kp)
-                ochip_host_free(ctx, b.kp);
+                ochip_host_free(buf_ctx[i], b.kp);
             if (b.desc)
-                ochip_host_free(ctx, b.desc);
+                ochip_host_free(buf_ctx[i], b.desc);
             b.kp = nullptr;
             b.desc = nullptr;
         }
     };
-    for (auto &b : bufs)
+    for (uint32_t i = 0; i < n_bufs; i++)
     {
+        chunk_buffers &b = bufs[i];
+        buf_ctx[i] = ctxs[i / 2];
         void *p = nullptr, *q = nullptr;
-        if (ochip_host_alloc(ctx, (size_t)chunk * max_keypoints * 6 * sizeof(float), &p) != OCHIP_OK ||
-            ochip_host_alloc(ctx, (size_t)chunk * max_keypoints * 8 * sizeof(uint64_t), &q) != OCHIP_OK)
+        if (ochip_host_alloc(buf_ctx[i], (size_t)chunk * max_keypoints * 6 * sizeof(float), &p) != OCHIP_OK ||
+            ochip_host_alloc(buf_ctx[i], (size_t)chunk * max_keypoints * 8 * sizeof(uint64_t), &q) != OCHIP_OK)
         {
             if (p)
-                ochip_host_free(ctx, p);
+                ochip_host_free(buf_ctx[i], p);
             release();
             if (error)
-                *error = std::string("ochip_host_alloc: ") + ochip_last_error(ctx);
+                *error = std::string("ochip_host_alloc: ") + ochip_last_error(buf_ctx[i]);
             return {};
         }
         b.kp = (float *)p;
@@ -191,48 +211,59 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
     }
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<int> ready;         // filled buffers, in chunk order
-    bool buffer_free[2] = {true, true};
-    bool producer_done = false;
+    std::deque<int> ready; // filled buffers
+    std::vector<char> buffer_free(n_bufs, 1);
+    uint32_t next_chunk = 0, drivers_done = 0;
 
-    std::thread producer([&]() {
-        int which = 0;
-        for (uint32_t first = 0; first < n_images; first += chunk, which ^= 1)
+    auto driver = [&](uint32_t d) {
+        ochip_ctx *dctx = ctxs[d];
+        int which = 2 * (int)d;
+        for (;;)
         {
+            uint32_t c;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return buffer_free[which]; });
-                buffer_free[which] = false;
+                cv.wait(lk, [&] { return buffer_free[which] != 0; });
+                if (!fail.empty() || next_chunk >= n_chunks)
+                    break;
+                c = next_chunk++;
+                buffer_free[which] = 0;
             }
             chunk_buffers &b = bufs[which];
-            b.first = first;
-            b.n = std::min(chunk, n_images - first);
+            b.first = c * chunk;
+            b.n = std::min(chunk, n_images - b.first);
             int wh[2];
-            const uint8_t *src = images_bgr + (size_t)first * image_bytes;
-            const int rc = images_on_device ? ochip_akaze_batch_dev(ctx, src, b.n, width, height, max_keypoints, b.kp, b.desc,
+            const uint8_t *src = images_bgr + (size_t)b.first * image_bytes;
+            const int rc = images_on_device ? ochip_akaze_batch_dev(dctx, src, b.n, width, height, max_keypoints, b.kp, b.desc,
                                                                     b.counts.data(), wh)
-                                            : ochip_akaze_batch(ctx, src, b.n, width, height, max_keypoints, b.kp, b.desc,
+                                            : ochip_akaze_batch(dctx, src, b.n, width, height, max_keypoints, b.kp, b.desc,
                                                                 b.counts.data(), wh);
             std::unique_lock<std::mutex> lk(mu);
             if (rc != OCHIP_OK)
             {
-                fail = std::string("ochip_akaze_batch: ") + ochip_last_error(ctx);
+                if (fail.empty())
+                    fail = std::string("ochip_akaze_batch: ") + ochip_last_error(dctx);
+                buffer_free[which] = 1;
                 break;
             }
             ready.push_back(which);
             cv.notify_all();
+            which = 2 * (int)d + ((which + 1) & 1);
         }
         std::unique_lock<std::mutex> lk(mu);
-        producer_done = true;
+        drivers_done++;
         cv.notify_all();
-    });
+    };
+    std::vector<std::thread> drivers;
+    for (uint32_t d = 0; d < n_drivers; d++)
+        drivers.emplace_back(driver, d);
 
     for (;;)
     {
         int which;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return !ready.empty() || producer_done; });
+            cv.wait(lk, [&] { return !ready.empty() || drivers_done == n_drivers; });
             if (ready.empty())
                 break;
             which = ready.front();
@@ -245,11 +276,12 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
                          out[b.first + i]);
         {
             std::unique_lock<std::mutex> lk(mu);
-            buffer_free[which] = true;
+            buffer_free[which] = 1;
             cv.notify_all();
         }
     }
-    producer.join();
+    for (auto &t : drivers)
+        t.join();
     release();
     if (!fail.empty())
     {
