@@ -41,3 +41,60 @@ def test_c1_link_then_relax_matches_oracle(oracle):
         assert abs(z - (1e-3 * x + 1e-2 * y)) < 0.5
     g.close()
     ctx.close()
+
+
+def _edge_signature(g):
+    out = []
+    for e in g.edges():
+        out.append((e["source"], e["dest"], e["n_matches"], e["n_inliers"], e["H"].tobytes(), e["f1"].tobytes(),
+                    e["f2"].tobytes(), e["poses"].tobytes()))
+    return out
+
+
+def test_link_runners_do_not_change_the_graph(monkeypatch):
+    """The link stage splits its pairs over concurrent batch runners (sibling device contexts); finalize restores
+    the reference's deterministic edge order (link_stage.cpp:123-127), so 1 and 3 runners give the same graph."""
+    grid = synth.make_grid(seed=5, rows=10, cols=20, feats=512)
+    ctx = capi.Context(0)
+    sigs = []
+    for runners in ("1", "3"):
+        monkeypatch.setenv("OCHIP_LINK_RUNNERS", runners)
+        g = host.Graph.from_synthetic(grid)
+        g.link(ctx)
+        sigs.append(_edge_signature(g))
+        g.close()
+    assert len(sigs[0]) > 1000 and sigs[0] == sigs[1]
+    ctx.close()
+
+
+def test_images_to_orientations(monkeypatch, oracle):
+    """The whole path from pixels: rendered views -> load stage (extract on the device, chunked over two device
+    contexts) -> link -> relax.  Chunking must not change a feature; the oracle's extract_features of a view
+    fetched back from HBM is what the graph holds (checked through the matches it produces); the relax recovers
+    the nadir orientations."""
+    from opencalibration_amd import pipeline
+
+    grid = synth.make_grid(seed=3, rows=2, cols=3, feats=64)
+    ctx = capi.Context(0)
+    images, shape = pipeline.synthetic_views(ctx, grid, seed=11)
+    n, h, w = shape
+    start = pipeline.perturbed_orientations(grid, 0.1, 4)
+    sigs, results = [], []
+    for chunk, streams in (("50", "1"), ("2", "2")):
+        monkeypatch.setenv("OCHIP_EXTRACT_CHUNK", chunk)
+        monkeypatch.setenv("OCHIP_EXTRACT_STREAMS", streams)
+        g, res, _ = pipeline.run(ctx, grid, images, shape, start)
+        sigs.append(_edge_signature(g))
+        results.append(res)
+        g.close()
+    assert sigs[0] == sigs[1] and len(sigs[0]) >= 2 * (n - 1)
+    # extract parity on a real 4000 x 3000 view: device load stage == oracle extract_features
+    feats = host.extract_features_batch(ctx, images, 30000, device_shape=(1, h, w))[0]
+    view = ctx.synth_views_read(images, 0, w, h)
+    eloc, est, edesc, ens = oracle.extract_features(view)
+    assert feats[3] == ens and np.array_equal(feats[0], eloc) and np.array_equal(feats[1], est)
+    assert np.array_equal(feats[2], edesc) and len(est) > 5000
+    err = pipeline.orientation_errors(results[0]["relax"]["orientation"], grid.orientation)
+    assert np.max(err) < 5e-3, err
+    ctx.synth_views_free(images)
+    ctx.close()
