@@ -493,80 +493,114 @@ __global__ void lm_build_kernel(const double *A, const double *g, const double *
     Wm[idx] = v;
 }
 
+// Cholesky factor of the 64 x 64 diagonal block and its inverse, one workgroup.  The block lives in registers:
+// thread (ty, tx) of a 16 x 16 grid owns rows ty + 16p and columns tx + 16q (cyclic, so the shrinking trailing
+// matrix stays spread over all threads).  Step j: the owners of column j publish it (and the owners of row j of
+// the inverse accumulator publish that) in LDS, one barrier, then every thread applies the rank-1 update to its
+// register tile and the forward-elimination step  X_j /= l_jj,  X_i -= l_ij X_j  that turns the identity into
+// L^-1.  The 64 steps run as 4 phases of 16 with the phase (j / 16) a compile-time constant: which register
+// rows / columns are finished, live or on the pivot is then static, only the 16-row band of the pivot needs a
+// runtime comparison, and finished parts cost nothing.  (This kernel is the critical path of the linear solve:
+// 47 sequential launches per factorisation at n = 3003.)
+template <int JB>
+__device__ __forceinline__ void chol_diag_phase(double (&a)[4][4], double (&x)[4][4], double (*colA)[NB], double (*rowX)[NB],
+                                                int ty, int tx, int nb, bool &bad)
+{
+#pragma unroll 1
+    for (int jt = 0; jt < 16; jt++)
+    {
+        const int j = JB * 16 + jt, buf = jt & 1;
+        if (tx == jt) // owners of column j: rows of band JB and below
+#pragma unroll
+            for (int p = JB; p < 4; p++)
+                colA[buf][ty + 16 * p] = a[p][JB];
+        if (ty == jt) // owners of row j of the inverse accumulator: columns up to band JB
+#pragma unroll
+            for (int q = 0; q <= JB; q++)
+                rowX[buf][tx + 16 * q] = x[JB][q];
+        __syncthreads();
+        const double piv = colA[buf][j];
+        if (j < nb && !(piv > 0.0))
+            bad = true;
+        // 1 / sqrt(pivot): hardware estimate + two Newton steps (the factor is not on a bit-parity path)
+        double rs = __builtin_amdgcn_rsq(piv);
+        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        double li[4], lc[4], xr[4];
+#pragma unroll
+        for (int p = JB; p < 4; p++)
+        {
+            const double v = colA[buf][ty + 16 * p] * rs;
+            li[p] = (p > JB || ty > jt) ? v : 0.0;
+        }
+#pragma unroll
+        for (int q = JB; q < 4; q++)
+        {
+            const double v = colA[buf][tx + 16 * q] * rs;
+            lc[q] = (q > JB || tx > jt) ? v : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q <= JB; q++)
+            xr[q] = rowX[buf][tx + 16 * q] * rs;
+#pragma unroll
+        for (int p = JB; p < 4; p++)
+        {
+#pragma unroll
+            for (int q = JB; q < 4; q++)
+                a[p][q] -= li[p] * lc[q];
+#pragma unroll
+            for (int q = 0; q <= JB; q++)
+                x[p][q] -= li[p] * xr[q];
+        }
+        // column j becomes final (l_ij below the diagonal, sqrt(pivot) = pivot * rs on it, 0 above); row j of X too
+        if (tx == jt)
+#pragma unroll
+            for (int p = JB; p < 4; p++)
+            {
+                const double v = colA[buf][ty + 16 * p] * rs;
+                a[p][JB] = (p > JB || ty >= jt) ? v : 0.0;
+            }
+        if (ty == jt)
+#pragma unroll
+            for (int q = 0; q <= JB; q++)
+                x[JB][q] = xr[q];
+    }
+}
+
 __global__ __launch_bounds__(256) void chol_diag_kernel(double *A, int n, int k0, int nb, int *fail,
                                                         double *Linv /*[NB][NB] row-major, zero padded*/)
 {
-    __shared__ double L[NB][NB + 1];
-    __shared__ double Y[NB][NB + 1];
-    const int t = threadIdx.x;
-    for (int e = t; e < NB * NB; e += 256)
-    {
-        const int i = e / NB, j = e % NB;
-        L[i][j] = (i < nb && j < nb) ? A[(size_t)(k0 + i) * n + k0 + j] : (i == j ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    // right-looking elimination with the pivots kept unscaled (one barrier per step); columns are scaled
-    // by 1/sqrt(pivot) afterwards, which yields the Cholesky factor
-    for (int j = 0; j < nb; j++)
-    {
-        const double piv = L[j][j];
-        const int m = nb - j - 1;
-        for (int e = t; e < m * m; e += 256)
+    __shared__ double colA[2][NB], rowX[2][NB];
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    double a[4][4], x[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
         {
-            const int i = j + 1 + e / m, c = j + 1 + e % m;
-            if (c <= i)
-                L[i][c] -= L[i][j] * L[c][j] / piv;
+            const int i = ty + 16 * p, c = tx + 16 * q;
+            // only the lower triangle of the input is meaningful; mirror it so that both triangles update alike
+            const int lo = i > c ? i : c, hi = i > c ? c : i;
+            a[p][q] = (lo < nb) ? A[(size_t)(k0 + lo) * n + k0 + hi] : (i == c ? 1.0 : 0.0);
+            x[p][q] = (i == c) ? 1.0 : 0.0;
         }
-        __syncthreads();
-    }
-    if (t < nb)
-    {
-        const double d = L[t][t];
-        if (!(d > 0.0))
-            *fail = 1;
-    }
-    __syncthreads();
-    for (int e = t; e < nb * nb; e += 256)
-    {
-        const int i = e / nb, j = e % nb;
-        if (j < i)
-            Y[i][j] = L[i][j] / sqrt(L[j][j]);
-    }
-    __syncthreads();
-    for (int e = t; e < nb * nb; e += 256)
-    {
-        const int i = e / nb, j = e % nb;
-        if (j < i)
-            L[i][j] = Y[i][j];
-    }
-    __syncthreads();
-    if (t < nb)
-        L[t][t] = sqrt(L[t][t]);
-    __syncthreads();
-    for (int e = t; e < nb * nb; e += 256)
-    {
-        const int i = e / nb, j = e % nb;
-        if (j <= i)
-            A[(size_t)(k0 + i) * n + k0 + j] = L[i][j];
-    }
-    // explicit inverse of the (lower triangular) diagonal block: column c of Y solves L y = e_c
-    for (int e = t; e < NB * NB; e += 256)
-        Y[e / NB][e % NB] = 0.0;
-    __syncthreads();
-    if (t < NB)
-    {
-        const int c = t;
-        for (int i = c; i < NB; i++)
+    bool bad = false;
+    chol_diag_phase<0>(a, x, colA, rowX, ty, tx, nb, bad);
+    chol_diag_phase<1>(a, x, colA, rowX, ty, tx, nb, bad);
+    chol_diag_phase<2>(a, x, colA, rowX, ty, tx, nb, bad);
+    chol_diag_phase<3>(a, x, colA, rowX, ty, tx, nb, bad);
+    if (bad)
+        *fail = 1;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
         {
-            double s = (i == c) ? 1.0 : 0.0;
-            for (int m = c; m < i; m++)
-                s -= L[i][m] * Y[m][c];
-            Y[i][c] = s / L[i][i];
+            const int i = ty + 16 * p, c = tx + 16 * q;
+            if (i < nb && c <= i)
+                A[(size_t)(k0 + i) * n + k0 + c] = a[p][q];
+            Linv[i * NB + c] = (i < nb && c <= i) ? x[p][q] : ((i == c) ? 1.0 : 0.0);
         }
-    }
-    __syncthreads();
-    for (int e = t; e < NB * NB; e += 256)
-        Linv[e] = Y[e / NB][e % NB];
 }
 
 // rows below the diagonal block: X = A[i, k0:k0+nb] * L_kk^{-T} = A_tile * Linv' as a 64x64x64 GEMM on the
