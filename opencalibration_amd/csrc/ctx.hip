@@ -325,11 +325,6 @@ int ochip_upload_batch(ochip_ctx *ctx, uint32_t n_images, const uint32_t *counts
         total += counts[i];
     if (total && (!desc_all || !xy_all))
         return ochip_fail(ctx, OCHIP_EINVAL, "NULL descriptor / keypoint array");
-    for (uint32_t i = 0; i < n_images; i++)
-        for (int k = 3; k < 8; k++)
-            if (models8[(size_t)i * 8 + k] != 0)
-                return ochip_fail(ctx, OCHIP_EINVAL,
-                                  "lens distortion is not supported by the device ray kernel yet (image %u)", i);
     int rc = ochip_descriptors_reserve(ctx, n_images, total);
     if (rc)
         return rc;

@@ -1,5 +1,7 @@
 #include "ransac.hpp"
 
+#include "../undistort.hpp"
+
 #include <algorithm>
 #include <numeric>
 #include <sstream>
@@ -48,19 +50,10 @@ std::vector<uint32_t> prosac_sorted_idx(const std::vector<feature_match> &matche
 
 void image_to_3d(const double keypoint[2], const CameraModel &model, double ray[3])
 {
-    const double u = (keypoint[0] - model.principle_point[0]) / model.focal_length_pixels;
-    const double v = (keypoint[1] - model.principle_point[1]) / model.focal_length_pixels;
-    const double z = u * u + v * v + 1.0 * 1.0;
-    ray[0] = u;
-    ray[1] = v;
-    ray[2] = 1.0;
-    if (z > 0)
-    {
-        const double n = std::sqrt(z);
-        ray[0] = u / n;
-        ray[1] = v / n;
-        ray[2] = 1.0 / n;
-    }
+    const double model8[8] = {model.focal_length_pixels,      model.principle_point[0],      model.principle_point[1],
+                              model.radial_distortion[0],     model.radial_distortion[1],    model.radial_distortion[2],
+                              model.tangential_distortion[0], model.tangential_distortion[1]};
+    ochip_ud::image_to_3d(keypoint, model8, ray);
 }
 
 void assembleInliers(const std::vector<feature_match> &matches, const std::vector<bool> &inliers,

@@ -23,6 +23,7 @@
 // bits/uniform_int_dist.h "downscaling" branch); std::sort (PROSAC order) and std::shuffle
 // (evaluation order) are executed on the host with the real libstdc++ and handed in.
 #include "ctx.hpp"
+#include "undistort.hpp"
 
 #include <cmath>
 
@@ -591,7 +592,8 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
         results[job_id] = res;
 }
 
-// pixel -> unit ray, distort_keypoints.cpp:68-103 for a model without distortion
+// pixel -> unit ray, distort_keypoints.cpp:68-103 (csrc/undistort.hpp: lens distortion is inverted per keypoint with
+// the restated TinySolver; one thread per keypoint, the solver's <= 10 iterations are a few hundred flops)
 __global__ void keypoints_to_rays_kernel(const double *__restrict__ xy, const double *__restrict__ models /*[img][8]*/,
                                          const uint32_t *__restrict__ kp_image, double *__restrict__ rays, uint64_t n)
 {
@@ -599,19 +601,13 @@ __global__ void keypoints_to_rays_kernel(const double *__restrict__ xy, const do
     if (i >= n)
         return;
     const double *m = models + (size_t)kp_image[i] * 8;
-    const double u = (xy[2 * i] - m[1]) / m[0], v = (xy[2 * i + 1] - m[2]) / m[0];
-    const double z = u * u + v * v + 1.0 * 1.0;
-    double rx = u, ry = v, rz = 1.0;
-    if (z > 0)
-    {
-        const double nrm = sqrt(z);
-        rx = u / nrm;
-        ry = v / nrm;
-        rz = 1.0 / nrm;
-    }
-    rays[3 * i] = rx;
-    rays[3 * i + 1] = ry;
-    rays[3 * i + 2] = rz;
+    double model8[8], kp[2] = {xy[2 * i], xy[2 * i + 1]}, ray[3];
+    for (int k = 0; k < 8; k++)
+        model8[k] = m[k];
+    ochip_ud::image_to_3d(kp, model8, ray);
+    rays[3 * i] = ray[0];
+    rays[3 * i + 1] = ray[1];
+    rays[3 * i + 2] = ray[2];
 }
 
 } // namespace
@@ -630,11 +626,6 @@ int ochip_upload_keypoints(ochip_ctx *ctx, uint32_t image_id, const double *xy, 
                           ctx->img_n[image_id]);
     if (!model8 || (n && !xy))
         return ochip_fail(ctx, OCHIP_EINVAL, "NULL argument");
-    for (int i = 3; i < 8; i++)
-        if (model8[i] != 0)
-            return ochip_fail(ctx, OCHIP_EINVAL,
-                              "lens distortion is not supported by the device ray kernel yet (model[%d] = %g)", i,
-                              model8[i]);
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->kp_xy_dev)
     {

@@ -77,3 +77,26 @@ def test_link_stage_with_outliers_and_few_matches(ctx, oracle):
     images that do not overlap at all (few or no matches, RANSAC early-outs, edge not accepted)."""
     grid = synth.make_grid(1, 4, feats=300, seed=5, flips=95, distractor_frac=1.0, along=60.0)
     assert _check_grid(ctx, oracle, grid) == 4 * 3
+
+
+def test_link_and_relax_with_lens_distortion(ctx, oracle):
+    """Radial + tangential distortion: image_to_3d inverts the lens model per keypoint with the restated TinySolver
+    (src/distort/distort_keypoints.cpp:68-103) on the device (rays for RANSAC) and on the host (cheirality vote, relax
+    rays); same arithmetic as the oracle's, so match lists, inlier sets and scores stay bit-exact, and the relaxed
+    orientations stay within 1e-6."""
+    grid = synth.make_grid(2, 3, feats=512, seed=33, distortion=(-0.05, 0.01, -0.002, 1e-3, -5e-4))
+    assert np.any(grid.model[3:8] != 0)
+    assert _check_grid(ctx, oracle, grid) == 2 * 3 * 5
+    g = host.Graph.from_synthetic(grid)
+    g.link(ctx)
+    rng = np.random.default_rng(8)
+    axes = rng.normal(size=(grid.n_images, 3))
+    axes /= np.linalg.norm(axes, axis=1, keepdims=True)
+    start = synth.quat_mul(grid.orientation, np.concatenate([axes * np.sin(0.05), np.full((grid.n_images, 1), np.cos(0.05))], 1))
+    g.set_orientations(start)
+    got = g.relax_ground_plane(ctx, start)
+    exp = oracle.relax_ground_plane(grid.position, start, grid.model, np.arange(grid.n_images), start, g.edges_flat())
+    dots = np.abs(np.sum(got["orientation"] * exp["orientation"], axis=1))
+    assert np.all(2 * np.arccos(np.clip(dots, 0, 1)) < 1e-6)
+    assert int(got["residual_blocks"]) == exp["residual_blocks"] > 0
+    g.close()
