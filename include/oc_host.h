@@ -92,6 +92,12 @@ extern "C"
      * src/pipeline/pipeline.cpp:653-655).  ori_inout: n_nodes x 4 in node order. */
     int och_graph_relax_ground_plane(och_graph *g, ochip_ctx *ctx, double *ori_inout, double *plane_out,
                                      double *summary_out);
+    /* The same relax with the residual-block evaluation sharded over `world` ranks (one process per GPU, each holding
+     * the same graph); `exchange` all-gathers the per-pair records, see ochip_relax_set_shard in ochip.h.  Results
+     * are bit-identical to the unsharded call on every rank. */
+    int och_graph_relax_ground_plane_sharded(och_graph *g, ochip_ctx *ctx, double *ori_inout, double *plane_out,
+                                             double *summary_out, uint32_t rank, uint32_t world,
+                                             ochip_relax_exchange_fn exchange, void *user);
 
 #ifdef __cplusplus
 }

@@ -231,6 +231,19 @@ extern "C"
     int ochip_relax_set_cameras_constant(ochip_relax_problem *p, int constant);
     /* Levenberg-Marquardt trust-region solve; the state stays in HBM */
     int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, ochip_relax_summary *summary);
+    /* Sharded evaluation of one relax problem over `world` ranks (one process per GPU, every rank creates the same
+     * problem): rank r evaluates the residual blocks of camera pairs [r * chunk, (r + 1) * chunk),
+     * chunk = ceil(n_pairs / world); after every evaluation `exchange` must all-gather the record arrays in place
+     * (rank r's slice of an array starts at ptr + r * bytes_per_rank; acc_bytes_per_rank is 0 for a cost-only
+     * evaluation) - an RCCL all-gather over xGMI in production (torch.distributed backend "nccl"), any transport
+     * in tests - and return 0 once the gathered data is visible to the device.  The library synchronises its
+     * stream before the call.  Every rank then runs the same deterministic assembly and linear solve on the same
+     * records, so the result is bit-identical to the unsharded solve.  This is the one exchange step of the path
+     * (single-group global relax, src/pipeline/pipeline.cpp:653-655; Ceres itself is single-process). */
+    typedef int (*ochip_relax_exchange_fn)(void *user, void *acc_dev, uint64_t acc_bytes_per_rank, void *cost_dev,
+                                           uint64_t cost_bytes_per_rank, void *fail_dev, uint64_t fail_bytes_per_rank);
+    int ochip_relax_set_shard(ochip_relax_problem *p, uint32_t rank, uint32_t world, ochip_relax_exchange_fn exchange,
+                              void *user);
     /* cam_q: n_cams x 4; ochip_relax_solve leaves the optimised cameras' quaternions normalised exactly as
      * RelaxProblem::solve does after every Solve (:1410-1413); plane_z: 3 */
     int ochip_relax_get_state(ochip_relax_problem *p, double *cam_q, double *plane_z);

@@ -23,7 +23,7 @@ EXPORTS = [
     "ochip_upload_batch", "ochip_host_alloc", "ochip_host_free", "ochip_akaze_batch", "ochip_akaze_batch_dev",
     "ochip_synth_views_alloc", "ochip_synth_views_free", "ochip_synth_render_views", "ochip_synth_views_read",
     "ochip_relax_problem_create", "ochip_relax_problem_destroy", "ochip_relax_set_cameras_constant",
-    "ochip_relax_solve", "ochip_relax_get_state",
+    "ochip_relax_solve", "ochip_relax_get_state", "ochip_relax_set_shard",
     "ochip_profile_reset", "ochip_profile_get",
     "ochip_debug_fp64",
 ]

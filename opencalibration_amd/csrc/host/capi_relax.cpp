@@ -106,8 +106,8 @@ int och_relax_ground_plane(ochip_ctx *ctx, size_t n_nodes, const double *node_po
 // pipeline.cpp:653-655): poses = all nodes with the given initial orientations, whitelist = all edges.
 // ori_inout: n_nodes x 4 in node order.  The graph's node orientations are updated on success
 // (RelaxGroup::finalize, relax_group.cpp:125-135).
-int och_graph_relax_ground_plane(och_graph *g, ochip_ctx *ctx, double *ori_inout, double *plane_out,
-                                 double *summary_out)
+static int graph_relax_ground_plane(och_graph *g, ochip_ctx *ctx, double *ori_inout, double *plane_out, double *summary_out,
+                                    const RelaxShard *shard)
 {
     auto &nodes = g->graph.nodes();
     std::vector<NodePose> poses(nodes.size());
@@ -123,7 +123,7 @@ int och_graph_relax_ground_plane(och_graph *g, ochip_ctx *ctx, double *ori_inout
         opt.push_back(e.id);
     surface_model_plane surf;
     RelaxTimers t;
-    if (!relax_ground_plane(ctx, g->graph, poses, opt, &surf, &t, &g->error))
+    if (!relax_ground_plane(ctx, g->graph, poses, opt, &surf, &t, &g->error, shard))
         return -1;
     for (size_t i = 0; i < nodes.size(); i++)
     {
@@ -134,6 +134,24 @@ int och_graph_relax_ground_plane(och_graph *g, ochip_ctx *ctx, double *ori_inout
         std::memcpy(plane_out, surf.corner, 72);
     fill_summary(t, summary_out);
     return 0;
+}
+
+int och_graph_relax_ground_plane(och_graph *g, ochip_ctx *ctx, double *ori_inout, double *plane_out,
+                                 double *summary_out)
+{
+    return graph_relax_ground_plane(g, ctx, ori_inout, plane_out, summary_out, nullptr);
+}
+
+int och_graph_relax_ground_plane_sharded(och_graph *g, ochip_ctx *ctx, double *ori_inout, double *plane_out,
+                                         double *summary_out, uint32_t rank, uint32_t world,
+                                         ochip_relax_exchange_fn exchange, void *user)
+{
+    RelaxShard shard;
+    shard.rank = rank;
+    shard.world = world;
+    shard.exchange = exchange;
+    shard.user = user;
+    return graph_relax_ground_plane(g, ctx, ori_inout, plane_out, summary_out, &shard);
 }
 
 } // extern "C"

@@ -124,7 +124,8 @@ class GroundPlaneProblem
     }
 
     // setupGroundPlaneProblem (relax_problem.cpp:61-81)
-    bool setup(std::vector<NodePose> &poses, const std::vector<size_t> &edges_to_optimize, std::string *error)
+    bool setup(std::vector<NodePose> &poses, const std::vector<size_t> &edges_to_optimize, std::string *error,
+               const RelaxShard *shard = nullptr)
     {
         const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
         auto tmark = clk::now();
@@ -224,6 +225,12 @@ class GroundPlaneProblem
         if (ochip_relax_problem_create(_ctx, &d, &_dev) != OCHIP_OK)
         {
             *error = std::string("ochip_relax_problem_create: ") + ochip_last_error(_ctx);
+            return false;
+        }
+        if (shard && shard->world > 1 &&
+            ochip_relax_set_shard(_dev, shard->rank, shard->world, shard->exchange, shard->user) != OCHIP_OK)
+        {
+            *error = std::string("ochip_relax_set_shard: ") + ochip_last_error(_ctx);
             return false;
         }
         lap("ochip_relax_problem_create");
@@ -487,13 +494,13 @@ class GroundPlaneProblem
 
 bool relax_ground_plane(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,
                         const std::vector<size_t> &edges_to_optimize, surface_model_plane *surface,
-                        RelaxTimers *timers, std::string *error)
+                        RelaxTimers *timers, std::string *error, const RelaxShard *shard)
 {
     // runGroundPlane (src/relax/relax.cpp:44-87)
     auto run = [&](std::vector<NodePose> &poses, surface_model_plane *out) -> bool {
         auto t0 = clk::now();
         GroundPlaneProblem rp(ctx, graph);
-        if (!rp.setup(poses, edges_to_optimize, error))
+        if (!rp.setup(poses, edges_to_optimize, error, shard))
             return false;
         if (timers)
             timers->setup_host += since(t0);

@@ -33,11 +33,20 @@ struct RelaxTimers
     int last_residual_blocks = 0;
 };
 
+// One process per GPU, every rank calling relax_ground_plane on the same graph: the residual-block evaluation is
+// sharded over the ranks and `exchange` all-gathers the per-pair records (ochip_relax_set_shard, include/ochip.h).
+struct RelaxShard
+{
+    uint32_t rank = 0, world = 1;
+    ochip_relax_exchange_fn exchange = nullptr;
+    void *user = nullptr;
+};
+
 // relax(graph, nodes, cam_models, edges_to_optimize, {ORIENTATION, GROUND_PLANE}, {}) — src/relax/relax.cpp:122-134
 // routed to runGroundPlane (:44-87).  edges_to_optimize holds edge ids in whitelist order.
 // Returns false (poses untouched) if the device reported an error; `error` then has the text.
 bool relax_ground_plane(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,
                         const std::vector<size_t> &edges_to_optimize, surface_model_plane *surface,
-                        RelaxTimers *timers, std::string *error);
+                        RelaxTimers *timers, std::string *error, const RelaxShard *shard = nullptr);
 
 } // namespace opencalibration_amd

@@ -60,9 +60,10 @@ struct relax_dev
     // CSR camera -> (pair, role)
     uint32_t *cam_pair_off, *cam_pair_idx; // idx = pair*2 + role (0: camera is p, 1: camera is q)
     // outputs
-    double *pair_acc;  // [n_pairs][ACC]
-    double *pair_cost; // [n_pairs]
-    int32_t *fail;
+    double *pair_acc;  // [n_pairs (padded to world * chunk when sharded)][ACC]
+    double *pair_cost; // [same]
+    int32_t *fail;     // this rank's flag inside fail_ranks[world]
+    uint32_t pair_lo;  // first pair this rank evaluates (0 unless sharded)
     double huber_a, prior_weight;
 };
 
@@ -173,7 +174,7 @@ template <bool WITH_JAC>
 __global__ __launch_bounds__(W) void relax_pair_eval_kernel(relax_dev P, int which_state)
 {
     const int lane = threadIdx.x;
-    const uint32_t pair = blockIdx.x;
+    const uint32_t pair = P.pair_lo + blockIdx.x;
     const uint32_t b0 = P.pair_off[pair], b1 = P.pair_off[pair + 1];
     const uint32_t p = P.pair_p[pair];
     const double *Q = which_state ? P.cam_q2 : P.cam_q;
@@ -938,6 +939,11 @@ struct ochip_relax_problem
     size_t cap_n = 0;
     uint32_t n_cams = 0;
     std::vector<uint32_t> cam_pair_count;
+    // sharded evaluation (ochip_relax_set_shard): this rank evaluates pairs [pair_lo, pair_hi)
+    uint32_t shard_rank = 0, shard_world = 1, shard_chunk = 0, pair_hi = 0;
+    ochip_relax_exchange_fn exchange = nullptr;
+    void *exchange_user = nullptr;
+    int32_t *fail_ranks = nullptr;
 };
 
 namespace
@@ -1120,7 +1126,11 @@ int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *d, ochip_
     chk(dev_upload(p, &D.cam_pair_idx, cpi.data(), cpi.size()));
     chk(dev_upload<double>(p, &D.pair_acc, nullptr, (size_t)n_pairs * ACC));
     chk(dev_upload<double>(p, &D.pair_cost, nullptr, n_pairs));
-    chk(dev_upload<int32_t>(p, &D.fail, nullptr, 1));
+    chk(dev_upload<int32_t>(p, &p->fail_ranks, nullptr, 1));
+    D.fail = p->fail_ranks;
+    D.pair_lo = 0;
+    p->pair_hi = n_pairs;
+    p->shard_chunk = n_pairs;
     chk(dev_upload(p, &p->cam_has_prior, p->cam_has_prior_host.data(), p->cam_has_prior_host.size()));
     chk(dev_upload(p, &p->cam_optimize_dev, p->cam_optimize.data(), p->cam_optimize.size()));
     chk(dev_upload<double>(p, &p->scal, nullptr, 8));
@@ -1156,6 +1166,42 @@ int ochip_relax_set_cameras_constant(ochip_relax_problem *p, int constant)
         return OCHIP_EINVAL;
     p->cams_frozen = constant != 0;
     return assign_tangent(p);
+}
+
+int ochip_relax_set_shard(ochip_relax_problem *p, uint32_t rank, uint32_t world, ochip_relax_exchange_fn fn, void *user)
+{
+    if (!p)
+        return OCHIP_EINVAL;
+    ochip_ctx *ctx = p->ctx;
+    if (world == 0 || rank >= world || (world > 1 && !fn))
+        return ochip_fail(ctx, OCHIP_EINVAL, "bad shard (rank %u of %u%s)", rank, world, fn ? "" : ", no exchange function");
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    relax_dev &D = p->dev;
+    const uint32_t n_pairs = D.n_pairs;
+    const uint32_t chunk = std::max<uint32_t>(1, (n_pairs + world - 1) / world);
+    int rc = OCHIP_OK;
+    auto chk = [&](int r) {
+        if (rc == OCHIP_OK)
+            rc = r;
+    };
+    // record arrays padded to world equal slices so that the exchange is a plain in-place all-gather
+    chk(dev_upload<double>(p, &D.pair_acc, nullptr, (size_t)world * chunk * ACC));
+    chk(dev_upload<double>(p, &D.pair_cost, nullptr, (size_t)world * chunk));
+    chk(dev_upload<int32_t>(p, &p->fail_ranks, nullptr, world));
+    if (rc != OCHIP_OK)
+        return rc;
+    OCHIP_HIP(ctx, hipMemset(D.pair_acc, 0, (size_t)world * chunk * ACC * 8));
+    OCHIP_HIP(ctx, hipMemset(D.pair_cost, 0, (size_t)world * chunk * 8));
+    OCHIP_HIP(ctx, hipMemset(p->fail_ranks, 0, (size_t)world * 4));
+    D.pair_lo = std::min(rank * chunk, n_pairs);
+    p->pair_hi = std::min((rank + 1) * chunk, n_pairs);
+    D.fail = p->fail_ranks + rank;
+    p->shard_rank = rank;
+    p->shard_world = world;
+    p->shard_chunk = chunk;
+    p->exchange = world > 1 ? fn : nullptr;
+    p->exchange_user = user;
+    return OCHIP_OK;
 }
 
 int ochip_relax_get_state(ochip_relax_problem *p, double *cam_q, double *plane_z)
@@ -1208,14 +1254,25 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
         OCHIP_HIP(ctx, hipMemsetAsync(D.fail, 0, 4, st));
         hipEvent_t e0, e1;
         ochip_prof_begin(ctx, OCHIP_K_RELAX_EVAL, &e0, &e1);
-        if (D.n_pairs)
+        const uint32_t my_pairs = p->pair_hi > D.pair_lo ? p->pair_hi - D.pair_lo : 0;
+        if (my_pairs)
         {
             if (with_jac)
-                hipLaunchKernelGGL(relax_pair_eval_kernel<true>, dim3(D.n_pairs), dim3(W), 0, st, D, which);
+                hipLaunchKernelGGL(relax_pair_eval_kernel<true>, dim3(my_pairs), dim3(W), 0, st, D, which);
             else
-                hipLaunchKernelGGL(relax_pair_eval_kernel<false>, dim3(D.n_pairs), dim3(W), 0, st, D, which);
+                hipLaunchKernelGGL(relax_pair_eval_kernel<false>, dim3(my_pairs), dim3(W), 0, st, D, which);
         }
         ochip_prof_end(ctx, OCHIP_K_RELAX_EVAL, e0, e1);
+        if (p->exchange)
+        {
+            // the ranks' pair records (and failure flags) are all-gathered in place; from here on every rank holds
+            // the same arrays and runs the same deterministic assembly
+            OCHIP_HIP(ctx, hipStreamSynchronize(st));
+            const int xrc = p->exchange(p->exchange_user, D.pair_acc, with_jac ? (uint64_t)p->shard_chunk * ACC * 8 : 0,
+                                        D.pair_cost, (uint64_t)p->shard_chunk * 8, p->fail_ranks, 4);
+            if (xrc != 0)
+                return ochip_fail(ctx, OCHIP_EHIP, "relax exchange callback failed (%d)", xrc);
+        }
         if (with_jac)
         {
             OCHIP_HIP(ctx, hipMemsetAsync(p->A, 0, (size_t)n * n * 8, st));
@@ -1229,9 +1286,13 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
                            p->scal, with_jac ? 1 : 0, which);
         OCHIP_HIP(ctx, hipGetLastError());
         OCHIP_HIP(ctx, hipMemcpyAsync(h, p->scal, 8, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(&hfail, D.fail, 4, hipMemcpyDeviceToHost, st));
+        std::vector<int32_t> hfails(p->shard_world, 0);
+        OCHIP_HIP(ctx, hipMemcpyAsync(hfails.data(), p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, hipStreamSynchronize(st));
         *cost = h[0];
+        hfail = 0;
+        for (int32_t f : hfails)
+            hfail |= f;
         return hfail ? 1 : 0;
     };
     auto grad_and_diag = [&](double *gmax) -> int {

@@ -15,6 +15,10 @@ _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 
 
+# ochip_relax_exchange_fn (include/ochip.h): all-gather the per-pair record arrays of a sharded relax in place
+RELAX_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64)
+
+
 def effective_cpus():
     """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU
     boxes expose 256 hardware threads but run the job under a 16-CPU cfs quota; 256 OpenMP threads inside
@@ -84,6 +88,7 @@ def load():
                                              _u64p, _f64p, _u64p, vp, vp, sz, _u64p, _f64p, _f64p]
         L.och_relax_last_error.restype = C.c_char_p
         L.och_graph_relax_ground_plane.argtypes = [vp, vp, _f64p, _f64p, _f64p]
+        L.och_graph_relax_ground_plane_sharded.argtypes = [vp, vp, _f64p, _f64p, _f64p, u32, u32, RELAX_EXCHANGE_FN, vp]
         L.och_extract_features_batch.argtypes = [vp, vp, u32, C.c_int, C.c_int, u32, u32, vp, vp, vp, vp, vp, C.c_int]
         L.och_extract_last_error.restype = C.c_char_p
         L.och_graph_load_images.argtypes = [vp, vp, vp, u32, C.c_int, C.c_int, u32, C.c_int, u32, _f64p, _u64p, _f64p]
@@ -219,11 +224,18 @@ class Graph:
             raise capi.OchipError("link stage failed: " + self.L.och_last_error(self.h).decode())
         return dict(zip(LINK_TIMER_NAMES, timers.tolist()))
 
-    def relax_ground_plane(self, ctx, orientations):
-        """All nodes as one relax group, every edge whitelisted; updates and returns the orientations."""
+    def relax_ground_plane(self, ctx, orientations, shard=None):
+        """All nodes as one relax group, every edge whitelisted; updates and returns the orientations.
+        shard = (rank, world, exchange): evaluate only this rank's share of the residual blocks; `exchange` is a
+        RELAX_EXCHANGE_FN (parallel.relax_exchange builds one on torch.distributed) and every rank gets the same,
+        bit-identical result."""
         ori = np.ascontiguousarray(orientations, np.float64).copy()
         plane, summary = np.zeros(9), np.zeros(8)
-        rc = self.L.och_graph_relax_ground_plane(self.h, ctx.h, ori, plane, summary)
+        if shard is None:
+            rc = self.L.och_graph_relax_ground_plane(self.h, ctx.h, ori, plane, summary)
+        else:
+            rank, world, exchange = shard
+            rc = self.L.och_graph_relax_ground_plane_sharded(self.h, ctx.h, ori, plane, summary, rank, world, exchange, None)
         if rc != 0:
             raise capi.OchipError("relax failed: " + self.L.och_last_error(self.h).decode())
         out = dict(zip(RELAX_SUMMARY_NAMES, summary.tolist()))

@@ -47,3 +47,52 @@ def gather_edges(local_records, group=None):
         merged = [r for part in out for r in part]
     merged.sort(key=lambda r: (r[0], r[1]))
     return merged
+
+
+class _DeviceBytes:
+    """Zero-copy view of `nbytes` of device memory at `ptr` for torch (CUDA array interface, version 2)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def relax_exchange(group=None):
+    """The exchange step of a sharded single-group relax (ochip_relax_set_shard, include/ochip.h) on
+    torch.distributed: every rank's slice of the per-pair record arrays is all-gathered in place.  Backend
+    "nccl" (RCCL over xGMI) gathers device to device; "gloo" stages the slices through host memory (tests).
+    Returns the ctypes callback to pass as Graph.relax_ground_plane(..., shard=(rank, world, callback)); keep a
+    reference to it for as long as the relax runs."""
+    import torch
+    import torch.distributed as dist
+
+    from .host import RELAX_EXCHANGE_FN
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on_device = dist.get_backend(group) == "nccl"
+
+    def gather(ptr, per_rank):
+        if not ptr or per_rank == 0:
+            return
+        full = torch.as_tensor(_DeviceBytes(ptr, per_rank * world), device="cuda")
+        mine = full[rank * per_rank:(rank + 1) * per_rank].clone()
+        if on_device:
+            dist.all_gather_into_tensor(full, mine, group=group)
+        else:
+            host = mine.cpu()
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(parts, host, group=group)
+            full.copy_(torch.cat(parts))
+
+    def callback(_user, acc, acc_bytes, cost, cost_bytes, fail, fail_bytes):
+        try:
+            gather(acc, acc_bytes)
+            gather(cost, cost_bytes)
+            gather(fail, fail_bytes)
+            torch.cuda.synchronize()
+            return 0
+        except Exception as ex:  # a Python exception must not unwind through the C caller
+            import sys
+            print(f"relax exchange failed on rank {rank}: {ex!r}", file=sys.stderr, flush=True)
+            return 1
+
+    return RELAX_EXCHANGE_FN(callback)
