@@ -87,3 +87,23 @@ def test_two_views_match(ctx):
     pred = np.stack([c * (q[:, 0] - 320) - s * (q[:, 1] - 240) + 320 + 7.3, s * (q[:, 0] - 320) + c * (q[:, 1] - 240) + 240 - 4.2], 1)
     err = np.linalg.norm(pred - fa[0][i1.astype(int)], axis=1)
     assert np.mean(err < 3.0) > 0.9
+
+
+def test_featureless_tiny_and_overflowing_inputs(ctx, oracle):
+    """Edge cases of the extract boundary: an image without any structure yields {[], 0} like the reference's empty
+    result (extract_features.cpp:20-23 / no keypoints); a tiny image (smaller than one 64 x 32 tile in the upper
+    octaves) still matches the restatement; a keypoint budget that is too small fails loudly instead of truncating."""
+    flat = np.full((1, 240, 320, 3), 127, np.uint8)
+    (loc, st, desc, ns), = host.extract_features_batch(ctx, flat)
+    assert len(st) == 0 and ns == 0 and loc.shape == (0, 2) and desc.shape == (0, 8)
+    tiny = synth.render_blobs(96, 80, 4)
+    got, _ = ctx.akaze_batch(tiny[None], max_kp=5000)
+    ekp, edesc = _sorted(*oracle.akaze(tiny[:, :, 0]))
+    gkp, gdesc = _sorted(*got[0])
+    assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32)) and np.array_equal(gdesc, edesc)
+    busy = synth.render_blobs(640, 480, 2)
+    with pytest.raises(capi.OchipError, match="max_kp|keypoints|candidates"):
+        ctx.akaze_batch(busy[None], max_kp=50)
+    # the context is still usable afterwards
+    got, _ = ctx.akaze_batch(busy[None], max_kp=20000)
+    assert len(got[0][0]) > 500

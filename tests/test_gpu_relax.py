@@ -84,3 +84,20 @@ def test_large_system_uses_blocked_cholesky(ctx, oracle):
     noisy = np.array([qmul(q, axis_angle(rng.normal(size=3) / 1.7, 0.05)) for q in ori])
     exp, got = _both(ctx, oracle, pos, ori, model, np.arange(len(ori)), noisy, edges)
     _assert_same(exp, got)
+
+
+def test_graph_without_edges(ctx, oracle):
+    """No measurements: only the PointsDownwardsPrior blocks remain (relax_problem.cpp:1297), the cameras barely
+    move and the device agrees with the oracle on that degenerate problem too."""
+    from opencalibration_amd import host, synth
+
+    grid = synth.make_grid(1, 3, feats=64, seed=2)
+    g = host.Graph.from_synthetic(grid)     # never linked: no edges
+    got = g.relax_ground_plane(ctx, grid.orientation)
+    exp = oracle.relax_ground_plane(grid.position, grid.orientation, grid.model, np.arange(3), grid.orientation, [])
+    assert int(got["residual_blocks"]) == exp["residual_blocks"]
+    dots = np.abs(np.sum(got["orientation"] * exp["orientation"], axis=1))
+    assert np.all(2 * np.arccos(np.clip(dots, 0, 1)) < 1e-6)
+    dots = np.abs(np.sum(got["orientation"] * grid.orientation, axis=1))
+    assert np.all(2 * np.arccos(np.clip(dots, 0, 1)) < 1e-2)
+    g.close()
