@@ -47,7 +47,9 @@ def main():
     cores = _host_mod.effective_cpus()   # affinity mask capped by the cgroup CPU quota
     threads = max(1, cores // max(world, 1))                        # CPU baseline: one thread per usable core
     omp_threads = max(1, _host_mod.host_threads() // max(world, 1))  # host phases of the hot path (bursty, see host.py)
-    os.environ.setdefault("OMP_NUM_THREADS", str(omp_threads))
+    # torch.distributed.run exports OMP_NUM_THREADS=1 for every worker unless the user set it; that default is not a
+    # choice made for this program (its host phases are OpenMP-parallel), so it is replaced.  OCHIP_HOST_THREADS pins it.
+    os.environ["OMP_NUM_THREADS"] = str(int(os.environ.get("OCHIP_HOST_THREADS", omp_threads)))
 
     import torch
     import torch.distributed as dist
@@ -56,9 +58,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU over RCCL ("nccl").  OCHIP_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path
+    # (barriers, thread split, max-over-ranks) run on a box with fewer GPUs than ranks, ranks sharing devices.
+    backend = os.environ.get("OCHIP_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -67,7 +76,7 @@ def main():
 
     cfg = synth.CONFIGS[args.config]
     grid = synth.make_grid(seed=12345 + rank, rows=cfg["rows"], cols=cfg["cols"], feats=64)  # poses + camera model
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(device_index)
     images, shape = pipeline.synthetic_views(ctx, grid, seed=7 + rank)    # resident in HBM before timing starts
     start_ori = pipeline.perturbed_orientations(grid, 0.1, 99 + rank)
 
@@ -94,7 +103,7 @@ def main():
                  ("relax_lm_iterations", res["relax"]["iterations_total"])]:
             acc[k] = acc.get(k, 0.0) + v
     barrier()
-    tt = torch.tensor([hot], dtype=torch.float64, device="cuda")
+    tt = torch.tensor([hot], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     hot_max = float(tt.item())
@@ -170,7 +179,7 @@ def main():
 
     # ---- CPU baseline: the restatement on a bounded sample of the same workload, all usable host cores
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU leg is timed at N = 1 only
         from concurrent.futures import ThreadPoolExecutor
 
         from oracle import pyoracle
