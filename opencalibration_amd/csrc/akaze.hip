@@ -34,6 +34,12 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi)
 {
     return v < lo ? lo : (v > hi ? hi : v);
 }
+// BORDER_REFLECT_101 for an index at most one image size outside [0, n): no loop, no branch
+__device__ __forceinline__ int reflect101_once(int v, int n)
+{
+    v = v < 0 ? -v : v;
+    return v >= n ? 2 * (n - 1) - v : v;
+}
 __device__ __forceinline__ int reflect101(int v, int n)
 {
     if (n == 1)
@@ -156,12 +162,28 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
     const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
     const int bx0 = x0 - M, by0 = y0 - M;
     const float *I = A.in + (size_t)blockIdx.z * A.in_stride;
-    for (int idx = threadIdx.x; idx < IW * IH; idx += 256)
     {
-        const int ly = idx / IW, lx = idx - ly * IW;
-        tin[idx] = I[(size_t)clampi(by0 - R + ly, 0, h - 1) * w + clampi(bx0 - R + lx, 0, w - 1)];
+        // every load of the tile is issued before the first LDS store (a rolled loop would wait out one memory
+        // latency per iteration)
+        constexpr int ITERS = (IW * IH + 255) / 256;
+        float v[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; it++)
+        {
+            const int idx = threadIdx.x + it * 256;
+            const int ly = idx / IW, lx = idx - ly * IW;
+            v[it] = (idx < IW * IH) ? I[(size_t)clampi(by0 - R + ly, 0, h - 1) * w + clampi(bx0 - R + lx, 0, w - 1)] : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; it++)
+        {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < IW * IH)
+                tin[idx] = v[it];
+        }
     }
     __syncthreads();
+#pragma unroll 2
     for (int idx = threadIdx.x; idx < BW * IH; idx += 256)
     {
         const int ly = idx / BW, lx = idx - ly * BW;
@@ -172,6 +194,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
         trow[idx] = acc;
     }
     __syncthreads();
+#pragma unroll 2
     for (int idx = threadIdx.x; idx < BW * BH; idx += 256)
     {
         const int ly = idx / BW, lx = idx - ly * BW;
@@ -200,6 +223,8 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
             k = k * 0.75f;
         inv = 1.0f / (k * k);
     }
+    const bool tiny = w <= 2 * M + 2 || h <= 2 * M + 2; // uniform: only then can an index need more than one reflection
+#pragma unroll 4
     for (int idx = threadIdx.x; idx < BT_X * BT_Y; idx += 256)
     {
         const int ly = idx / BT_X, lx = idx - ly * BT_X;
@@ -213,16 +238,25 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
             const float nrm = 1.0f / (2.0f * (float)M * (wgt + 2.0f));
             const float wn = wgt * nrm;
             float dx, dy;
-            pattern_xy(at, reflect101(x - M, w), x, reflect101(x + M, w), reflect101(y - M, h), y, reflect101(y + M, h), nrm,
-                       wn, &dx, &dy);
+            if (tiny)
+                pattern_xy(at, reflect101(x - M, w), x, reflect101(x + M, w), reflect101(y - M, h), y, reflect101(y + M, h),
+                           nrm, wn, &dx, &dy);
+            else
+                pattern_xy(at, reflect101_once(x - M, w), x, reflect101_once(x + M, w), reflect101_once(y - M, h), y,
+                           reflect101_once(y + M, h), nrm, wn, &dx, &dy);
+
             A.out0[o] = dx;
             A.out1[o] = dy;
         }
         else
         {
             float lx_, ly_;
-            pattern_xy(at, reflect101(x - 1, w), x, reflect101(x + 1, w), reflect101(y - 1, h), y, reflect101(y + 1, h), 3.0f,
-                       10.0f, &lx_, &ly_);
+            if (tiny)
+                pattern_xy(at, reflect101(x - 1, w), x, reflect101(x + 1, w), reflect101(y - 1, h), y, reflect101(y + 1, h),
+                           3.0f, 10.0f, &lx_, &ly_);
+            else
+                pattern_xy(at, reflect101_once(x - 1, w), x, reflect101_once(x + 1, w), reflect101_once(y - 1, h), y,
+                           reflect101_once(y + 1, h), 3.0f, 10.0f, &lx_, &ly_);
             if (MODE == BLUR_FLOW)
                 A.out0[o] = 1.0f / (1.0f + inv * (lx_ * lx_ + ly_ * ly_));
             else
@@ -436,14 +470,28 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
     const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
     const int rx0 = x0 - HW, ry0 = y0 - HW;
     const float *X = Lx + (size_t)blockIdx.z * stride, *Y = Ly + (size_t)blockIdx.z * stride;
-    for (int idx = threadIdx.x; idx < RW * RH; idx += 256)
     {
-        const int ly = idx / RW, lx = idx - ly * RW;
-        const int gx = rx0 + lx, gy = ry0 + ly;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h)
+        constexpr int ITERS = (RW * RH + 255) / 256; // all loads in flight before the first LDS store
+        float vx[ITERS], vy[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; it++)
         {
-            tx[idx] = X[(size_t)gy * w + gx];
-            ty[idx] = Y[(size_t)gy * w + gx];
+            const int idx = threadIdx.x + it * 256;
+            const int ly = idx / RW, lx = idx - ly * RW;
+            const int gx = rx0 + lx, gy = ry0 + ly;
+            const bool in = idx < RW * RH && gx >= 0 && gx < w && gy >= 0 && gy < h;
+            vx[it] = in ? X[(size_t)gy * w + gx] : 0.0f;
+            vy[it] = in ? Y[(size_t)gy * w + gx] : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; it++)
+        {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < RW * RH)
+            {
+                tx[idx] = vx[it];
+                ty[idx] = vy[it];
+            }
         }
     }
     __syncthreads();
@@ -453,13 +501,24 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
     const float s4 = (float)(S * S * S * S);
     auto atx = [&](int xx, int yy) { return tx[(yy - ry0) * RW + (xx - rx0)]; };
     auto aty = [&](int xx, int yy) { return ty[(yy - ry0) * RW + (xx - rx0)]; };
+    const bool tiny = w <= 2 * S + 2 || h <= 2 * S + 2; // uniform: only then can an index need more than one reflection
+#pragma unroll 3
     for (int idx = threadIdx.x; idx < DW * DH; idx += 256)
     {
         const int ly = idx / DW, lx = idx - ly * DW;
         const int x = x0 - 1 + lx, y = y0 - 1 + ly;
         if (x < 0 || x >= w || y < 0 || y >= h)
             continue;
-        const int xm = reflect101(x - S, w), xp = reflect101(x + S, w), ym = reflect101(y - S, h), yp = reflect101(y + S, h);
+        int xm, xp, ym, yp;
+        if (tiny)
+        {
+            xm = reflect101(x - S, w), xp = reflect101(x + S, w), ym = reflect101(y - S, h), yp = reflect101(y + S, h);
+        }
+        else
+        {
+            xm = reflect101_once(x - S, w), xp = reflect101_once(x + S, w), ym = reflect101_once(y - S, h),
+            yp = reflect101_once(y + S, h);
+        }
         float lxx, lxy, tmp, lyy;
         pattern_xy(atx, xm, x, xp, ym, y, yp, nrm, wn, &lxx, &lxy);
         pattern_xy(aty, xm, x, xp, ym, y, yp, nrm, wn, &tmp, &lyy);
@@ -470,6 +529,7 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
     }
     __syncthreads();
     unsigned int found = 0;
+#pragma unroll 4
     for (int idx = threadIdx.x; idx < BT_X * BT_Y; idx += 256)
     {
         const int ly = idx / BT_X, lx = idx - ly * BT_X;
@@ -580,13 +640,22 @@ __global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restr
     if (threadIdx.x == 0)
         lcount = 0;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < BT_X * BT_Y; idx += 256)
+    float vals[BT_X * BT_Y / 256]; // the tile's 8 loads per thread in flight together
+#pragma unroll
+    for (int it = 0; it < BT_X * BT_Y / 256; it++)
     {
+        const int idx = threadIdx.x + it * 256;
         const int ly = idx / BT_X, lx = idx - ly * BT_X;
         const int x = tx * BT_X + lx, y = ty * BT_Y + ly;
-        if (x >= l.w || y >= l.h)
-            continue;
-        const float v = R[(size_t)y * l.w + x];
+        vals[it] = (x < l.w && y < l.h) ? R[(size_t)y * l.w + x] : 0.0f;
+    }
+#pragma unroll
+    for (int it = 0; it < BT_X * BT_Y / 256; it++)
+    {
+        const int idx = threadIdx.x + it * 256;
+        const int ly = idx / BT_X, lx = idx - ly * BT_X;
+        const int x = tx * BT_X + lx, y = ty * BT_Y + ly;
+        const float v = vals[it];
         if (v != 0.0f)
         {
             const unsigned int slot = base + atomicAdd(&lcount, 1u);

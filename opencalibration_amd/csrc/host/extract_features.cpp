@@ -3,12 +3,15 @@
 #include <algorithm>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <limits>
 #include <mutex>
 #include <thread>
+
+#include <omp.h>
 
 namespace opencalibration_amd
 {
@@ -209,6 +212,7 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
         b.desc = (uint64_t *)q;
         b.counts.resize(chunk);
     }
+    double tail_cpu_seconds = 0;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<int> ready; // filled buffers
@@ -270,10 +274,16 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
             ready.pop_front();
         }
         chunk_buffers &b = bufs[which];
-#pragma omp parallel for schedule(dynamic, 1)
+        double cpu = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : cpu)
         for (uint32_t i = 0; i < b.n; i++)
+        {
+            const double t0 = omp_get_wtime();
             extract_tail(b.kp + (size_t)i * max_keypoints * 6, b.desc + (size_t)i * max_keypoints * 8, b.counts[i], scale,
                          out[b.first + i]);
+            cpu += omp_get_wtime() - t0;
+        }
+        tail_cpu_seconds += cpu;
         {
             std::unique_lock<std::mutex> lk(mu);
             buffer_free[which] = 1;
@@ -282,6 +292,9 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
     }
     for (auto &t : drivers)
         t.join();
+    if (std::getenv("OCHIP_EXTRACT_VERBOSE"))
+        fprintf(stderr, "[extract] %u images: host tail %.3f thread-seconds (%.2f ms per image)\n", n_images, tail_cpu_seconds,
+                1e3 * tail_cpu_seconds / n_images);
     release();
     if (!fail.empty())
     {
