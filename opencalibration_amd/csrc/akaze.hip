@@ -27,7 +27,7 @@ struct level_info
     int octave, w, h, sigma_size;
     float esigma;
     size_t off; // plane offset (floats) inside one image's pyramid
-    int tile_off, tiles_x; // first id and row length of the level's 64 x 32 detection tiles
+    int tile_off, tiles_x; // first id and row length of the level's 64 x 16 detection tiles
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi)
@@ -116,7 +116,8 @@ struct taps_t
 // from LDS, so one launch moves 4 B/pixel in and 4-8 B/pixel out instead of the 16 + 8..12 of separate passes.
 // Every value is the same float expression as the separate passes (ascending tap order, clamped source
 // coordinates for the blur, reflected coordinates for the stencil), so the fusion does not change a bit.
-constexpr int BT_X = 64, BT_Y = 32;
+constexpr int BT_X = 64, BT_Y = 32; // blur tiles
+constexpr int DT_Y = 16;             // detection tiles are 64 x 16: the determinant kernel holds three planes in LDS
 enum
 {
     BLUR_PLAIN = 0,
@@ -455,7 +456,7 @@ struct cand_t
     float response;
 };
 
-// Scale-normalised Hessian determinant of a 64 x 32 tile and its strict 3x3 maxima above the threshold in one
+// Scale-normalised Hessian determinant of a 64 x 16 tile and its strict 3x3 maxima above the threshold in one
 // pass: the Lx / Ly tiles (+ halo S + 1) are staged in LDS, the determinant tile (+ halo 1) is built over them,
 // and the level's sparse maxima map (response at maxima, 0 elsewhere) is written next to the determinant.
 template <int S>
@@ -464,10 +465,10 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
                                                          float thr, unsigned int *__restrict__ tile_counts, int tile_off,
                                                          int n_tiles)
 {
-    constexpr int HW = S + 1, RW = BT_X + 2 * HW, RH = BT_Y + 2 * HW, DW = BT_X + 2, DH = BT_Y + 2;
+    constexpr int HW = S + 1, RW = BT_X + 2 * HW, RH = DT_Y + 2 * HW, DW = BT_X + 2, DH = DT_Y + 2;
     __shared__ float tx[RW * RH], ty[RW * RH];
     __shared__ float td[DW * DH];
-    const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
+    const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * DT_Y;
     const int rx0 = x0 - HW, ry0 = y0 - HW;
     const float *X = Lx + (size_t)blockIdx.z * stride, *Y = Ly + (size_t)blockIdx.z * stride;
     {
@@ -524,13 +525,13 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
         pattern_xy(aty, xm, x, xp, ym, y, yp, nrm, wn, &tmp, &lyy);
         const float d = (lxx * lyy - lxy * lxy) * s4;
         td[idx] = d;
-        if (lx >= 1 && lx <= BT_X && ly >= 1 && ly <= BT_Y)
+        if (lx >= 1 && lx <= BT_X && ly >= 1 && ly <= DT_Y)
             Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = d;
     }
     __syncthreads();
     unsigned int found = 0;
 #pragma unroll 4
-    for (int idx = threadIdx.x; idx < BT_X * BT_Y; idx += 256)
+    for (int idx = threadIdx.x; idx < BT_X * DT_Y; idx += 256)
     {
         const int ly = idx / BT_X, lx = idx - ly * BT_X;
         const int x = x0 + lx, y = y0 + ly;
@@ -578,7 +579,7 @@ struct levels_dev
 };
 
 // Candidate list of an image = the non-zero entries of its maxima maps, laid out tile by tile in a space-filling
-// order (tile_seq: level by level, Morton order of the 64 x 32 tiles inside a level).  Neighbouring list entries
+// order (tile_seq: level by level, Morton order of the 64 x 16 detection tiles inside a level).  Neighbouring list entries
 // are neighbouring pixels, which is what keeps the window scans of the suppression and the patch gathers of the
 // descriptor inside the L2: with an arbitrary order the descriptor kernel alone pulled ~0.9 GB per image through
 // the fabric, 14x the size of the pyramid it samples.  No global atomics: the offsets come from a prefix sum of the
@@ -640,21 +641,21 @@ __global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restr
     if (threadIdx.x == 0)
         lcount = 0;
     __syncthreads();
-    float vals[BT_X * BT_Y / 256]; // the tile's 8 loads per thread in flight together
+    float vals[BT_X * DT_Y / 256]; // the tile's loads in flight together
 #pragma unroll
-    for (int it = 0; it < BT_X * BT_Y / 256; it++)
+    for (int it = 0; it < BT_X * DT_Y / 256; it++)
     {
         const int idx = threadIdx.x + it * 256;
         const int ly = idx / BT_X, lx = idx - ly * BT_X;
-        const int x = tx * BT_X + lx, y = ty * BT_Y + ly;
+        const int x = tx * BT_X + lx, y = ty * DT_Y + ly;
         vals[it] = (x < l.w && y < l.h) ? R[(size_t)y * l.w + x] : 0.0f;
     }
 #pragma unroll
-    for (int it = 0; it < BT_X * BT_Y / 256; it++)
+    for (int it = 0; it < BT_X * DT_Y / 256; it++)
     {
         const int idx = threadIdx.x + it * 256;
         const int ly = idx / BT_X, lx = idx - ly * BT_X;
-        const int x = tx * BT_X + lx, y = ty * BT_Y + ly;
+        const int x = tx * BT_X + lx, y = ty * DT_Y + ly;
         const float v = vals[it];
         if (v != 0.0f)
         {
@@ -1348,7 +1349,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 img_stride += (size_t)lw * lh;
                 l.tiles_x = (lw + BT_X - 1) / BT_X;
                 l.tile_off = n_tiles;
-                n_tiles += l.tiles_x * ((lh + BT_Y - 1) / BT_Y);
+                n_tiles += l.tiles_x * ((lh + DT_Y - 1) / DT_Y);
                 etime.push_back(0.5f * (l.esigma * l.esigma));
             }
         }
@@ -1386,6 +1387,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     pair_tab *d_tab = nullptr;
     const size_t src_px = (size_t)width * height;
     auto tiles = [&](int w, int h) { return dim3((w + BT_X - 1) / BT_X, (h + BT_Y - 1) / BT_Y, B); };
+    auto det_tiles = [&](int w, int h) { return dim3((w + BT_X - 1) / BT_X, (h + DT_Y - 1) / DT_Y, B); };
     const dim3 tiles0 = tiles(W, H);
     const int n_tiles0 = (int)(tiles0.x * tiles0.y);
     if (on_device)
@@ -1432,7 +1434,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         for (int i = 0; i < LV.n; i++)
         {
             const level_info &l = LV.l[i];
-            const int ty_n = (l.h + BT_Y - 1) / BT_Y;
+            const int ty_n = (l.h + DT_Y - 1) / DT_Y;
             for (int ty = 0; ty < ty_n; ty++)
                 for (int tx = 0; tx < l.tiles_x; tx++)
                     keyed.emplace_back(((uint64_t)i << 48) | spread((uint32_t)tx) | (spread((uint32_t)ty) << 1),
@@ -1629,13 +1631,13 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             const float *lx = d_Lx + l.off, *ly = d_Ly + l.off;
             float *ld = d_Ldet + l.off, *rm = d_Rmax + l.off;
             if (l.sigma_size == 2)
-                hipLaunchKernelGGL((det_maxima_kernel<2>), tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
+                hipLaunchKernelGGL((det_maxima_kernel<2>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles);
             else if (l.sigma_size == 3)
-                hipLaunchKernelGGL((det_maxima_kernel<3>), tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
+                hipLaunchKernelGGL((det_maxima_kernel<3>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles);
             else
-                hipLaunchKernelGGL((det_maxima_kernel<4>), tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
+                hipLaunchKernelGGL((det_maxima_kernel<4>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles);
         }
     }
