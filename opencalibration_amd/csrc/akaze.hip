@@ -57,27 +57,54 @@ __global__ void gray_kernel(const uint8_t *__restrict__ bgr, uint8_t *__restrict
         gray[i] = (uint8_t)((bgr[3 * i] * 1868 + bgr[3 * i + 1] * 9617 + bgr[3 * i + 2] * 4899 + (1 << 13)) >> 14);
 }
 
-__global__ void resize_area_kernel(const uint8_t *__restrict__ src, int sw, int sh, float *__restrict__ dst, int dw,
-                                   int dh, const int *__restrict__ xoff, const int *__restrict__ xsi,
-                                   const float *__restrict__ xal, const int *__restrict__ yoff,
-                                   const int *__restrict__ ysi, const float *__restrict__ yal)
+constexpr int RESIZE_ROWS = 8, RESIZE_MAX_TAPS = 8;
+__global__ __launch_bounds__(256) void resize_area_kernel(const uint8_t *__restrict__ src, int sw, int sh, float *__restrict__ dst,
+                                                          int dw, int dh, const int *__restrict__ xoff,
+                                                          const int *__restrict__ xsi, const float *__restrict__ xal,
+                                                          const int *__restrict__ yoff, const int *__restrict__ ysi,
+                                                          const float *__restrict__ yal)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    // a thread keeps the horizontal taps of its destination column in registers and walks RESIZE_ROWS rows; the
+    // vertical taps are uniform per row.  Sums run in table order exactly like the per-pixel form.
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= dw)
         return;
     const uint8_t *s = src + (size_t)blockIdx.z * sw * sh;
-    float acc = 0.0f;
-    for (int e = yoff[y]; e < yoff[y + 1]; e++)
+    const int k0 = xoff[x], nk = xoff[x + 1] - k0;
+    int si[RESIZE_MAX_TAPS];
+    float al[RESIZE_MAX_TAPS];
+#pragma unroll
+    for (int k = 0; k < RESIZE_MAX_TAPS; k++)
     {
-        const uint8_t *row = s + (size_t)ysi[e] * sw;
-        float r = 0.0f;
-        for (int k = xoff[x]; k < xoff[x + 1]; k++)
-            r += (float)row[xsi[k]] * xal[k];
-        acc += r * yal[e];
+        si[k] = k < nk ? xsi[k0 + k] : 0;
+        al[k] = k < nk ? xal[k0 + k] : 0.0f;
     }
-    const float v = rintf(acc);
-    // saturate to the 8-bit working image, then the 1/255 float conversion in front of AKAZE
-    dst[(size_t)blockIdx.z * dw * dh + (size_t)y * dw + x] = (float)(uint8_t)fminf(255.0f, fmaxf(0.0f, v)) * (1.0f / 255.0f);
+    for (int r = 0; r < RESIZE_ROWS; r++)
+    {
+        const int y = blockIdx.y * RESIZE_ROWS + r;
+        if (y >= dh)
+            break;
+        float acc = 0.0f;
+        for (int e = yoff[y]; e < yoff[y + 1]; e++)
+        {
+            const uint8_t *row = s + (size_t)ysi[e] * sw;
+            float rr = 0.0f;
+            if (nk <= RESIZE_MAX_TAPS)
+            {
+#pragma unroll
+                for (int k = 0; k < RESIZE_MAX_TAPS; k++)
+                    if (k < nk)
+                        rr += (float)row[si[k]] * al[k];
+            }
+            else // very large decimation factors: taps straight from the table
+                for (int k = k0; k < k0 + nk; k++)
+                    rr += (float)row[xsi[k]] * xal[k];
+            acc += rr * yal[e];
+        }
+        const float v = rintf(acc);
+        // saturate to the 8-bit working image, then the 1/255 float conversion in front of AKAZE
+        dst[(size_t)blockIdx.z * dw * dh + (size_t)y * dw + x] = (float)(uint8_t)fminf(255.0f, fmaxf(0.0f, v)) * (1.0f / 255.0f);
+    }
 }
 
 // four pixels per thread: three 32-bit loads carry 4 BGR triplets, one 32-bit store carries 4 grey bytes
@@ -1531,7 +1558,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             cleanup();
             return rc;
         }
-        hipLaunchKernelGGL(resize_area_kernel, grid2(W, H), dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs, xa,
+        hipLaunchKernelGGL(resize_area_kernel, dim3((W + 255) / 256, (H + RESIZE_ROWS - 1) / RESIZE_ROWS, B), dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs, xa,
                            yo, ys, ya);
     }
 
