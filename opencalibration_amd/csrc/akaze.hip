@@ -716,18 +716,17 @@ __device__ __forceinline__ bool xcd_contiguous(unsigned int block, unsigned int 
 }
 
 // A candidate dies if a stronger maximum (ties: lower (level, y, x) wins) of an adjacent level lies within
-// its own size esigma * derivative_factor (base-image pixels).  One thread per candidate, window scans of
-// the sparse maxima maps.
-__global__ void suppress_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
-                                unsigned int max_cands, const float *__restrict__ Rmax, size_t img_stride, levels_dev L,
-                                float derivative_factor, unsigned char *__restrict__ dead, int remap)
+// its own size esigma * derivative_factor (base-image pixels).  One wavefront per candidate: the 64 lanes scan the
+// window of the sparse maxima map together and vote with a ballot (any killer decides, so the order of the scan
+// does not matter); a thread per candidate spent its time waiting for one dependent load after the other.
+__global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
+                                                       unsigned int max_cands, const float *__restrict__ Rmax, size_t img_stride,
+                                                       levels_dev L, float derivative_factor, unsigned char *__restrict__ dead)
 {
     const unsigned int b = blockIdx.z;
     const unsigned int n = min(n_cands[b], max_cands);
-    unsigned int group;
-    if (!xcd_contiguous(blockIdx.x, (n + blockDim.x - 1) / blockDim.x, &group, remap))
-        return;
-    const unsigned int k = group * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= n)
         return;
     const cand_t c = cands[(size_t)b * max_cands + k];
@@ -735,7 +734,7 @@ __global__ void suppress_kernel(const cand_t *__restrict__ cands, const unsigned
     const float ratio_c = (float)(1 << lc.octave);
     const float rad = lc.esigma * derivative_factor, r2 = rad * rad;
     const float cx = (float)c.x * ratio_c, cy = (float)c.y * ratio_c;
-    bool is_dead = false;
+    bool is_dead = false; // early exit pays: most suppressed candidates die in the first window (measured)
     for (int j = max(c.level - 1, 0); j <= min(c.level + 1, L.n - 1) && !is_dead; j++)
     {
         const level_info lj = L.l[j];
@@ -743,24 +742,30 @@ __global__ void suppress_kernel(const cand_t *__restrict__ cands, const unsigned
         const float *R = Rmax + (size_t)b * img_stride + lj.off;
         const int x0 = max((int)floorf((cx - rad) / ratio), 0), x1 = min((int)ceilf((cx + rad) / ratio), lj.w - 1);
         const int y0 = max((int)floorf((cy - rad) / ratio), 0), y1 = min((int)ceilf((cy + rad) / ratio), lj.h - 1);
-        for (int yy = y0; yy <= y1 && !is_dead; yy++)
-            for (int xx = x0; xx <= x1; xx++)
+        const int ww = x1 - x0 + 1, total = ww * (y1 - y0 + 1);
+        for (int t0 = 0; t0 < total && !is_dead; t0 += 64)
+        {
+            const int t = t0 + lane;
+            bool kill = false;
+            if (t < total)
             {
+                const int yy = y0 + t / ww, xx = x0 + t % ww;
                 const float r = R[(size_t)yy * lj.w + xx];
-                if (r == 0.0f || (j == c.level && xx == c.x && yy == c.y))
-                    continue;
-                const float ex = (float)xx * ratio - cx, ey = (float)yy * ratio - cy;
-                if (!(ex * ex + ey * ey <= r2))
-                    continue;
-                const bool lower_key = j < c.level || (j == c.level && (yy < c.y || (yy == c.y && xx < c.x)));
-                if (r > c.response || (r == c.response && lower_key))
+                if (r != 0.0f && !(j == c.level && xx == c.x && yy == c.y))
                 {
-                    is_dead = true;
-                    break;
+                    const float ex = (float)xx * ratio - cx, ey = (float)yy * ratio - cy;
+                    if (ex * ex + ey * ey <= r2)
+                    {
+                        const bool lower_key = j < c.level || (j == c.level && (yy < c.y || (yy == c.y && xx < c.x)));
+                        kill = r > c.response || (r == c.response && lower_key);
+                    }
                 }
             }
+            is_dead = __ballot(kill) != 0;
+        }
     }
-    dead[(size_t)b * max_cands + k] = is_dead ? 1 : 0;
+    if (lane == 0)
+        dead[(size_t)b * max_cands + k] = is_dead ? 1 : 0;
 }
 
 // ---- float-only math shared with the CPU restatement (deterministic: + - * / and compares only)
@@ -1689,8 +1694,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     static const int xcd_remap = getenv("OCHIP_XCD_REMAP") ? atoi(getenv("OCHIP_XCD_REMAP")) : 2; // tuning knob, see xcd_contiguous
     if (max_n > 0)
     {
-        hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 255) / 256, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
-                           (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride, LV, dfactor, d_dead, 0);
+        hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 3) / 4, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
+                           (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride, LV, dfactor, d_dead);
         hipLaunchKernelGGL(describe_kernel, dim3(512 * ((max_n + 511) / 512), 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
                            (const unsigned int *)d_ncand, max_cands, (const unsigned char *)d_dead, (const float *)d_Lt,
                            (const float *)d_Lx, (const float *)d_Ly, (const float *)d_Ldet, img_stride, LV, dfactor,
