@@ -844,11 +844,9 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
                                                       unsigned long long *__restrict__ desc_out /*[b][max][8]*/,
                                                       unsigned char *__restrict__ valid_out, int remap)
 {
-    __shared__ float resX[109], resY[109], Ang[109];
-    __shared__ float wm[42], wang[42];
+    __shared__ float4 osmp[109]; // orientation samples: weighted dx, dy, their angle (one 16-byte LDS read each)
     __shared__ float vals[29][3];
-    __shared__ float smp[3][441];        // the 21 x 21 descriptor sample lattice: intensity, rotated dx, rotated dy
-    __shared__ unsigned char smp_ok[441]; // sample inside the level image
+    __shared__ float4 smp[441];  // the 21 x 21 descriptor sample lattice: intensity, rotated dx, rotated dy, inside flag
     const int lane = threadIdx.x;
     const unsigned int b = blockIdx.z;
     const unsigned int n = min(n_cands[b], max_cands);
@@ -906,37 +904,45 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         const int ix = clampi((int)rintf(xf + (float)(i * s)), 0, w - 1);
         const float g = gw[q];
         const float rx = g * pLx[(size_t)iy * w + ix], ry = g * pLy[(size_t)iy * w + ix];
-        resX[idx] = rx;
-        resY[idx] = ry;
-        Ang[idx] = fast_atan2(ry, rx);
+        osmp[idx] = make_float4(rx, ry, fast_atan2(ry, rx), 0.0f);
     }
     __syncthreads();
     const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
+    // 42 sliding windows of pi/3, one per lane; the sums run over the samples in their order.  A sample outside the
+    // window adds +0, which leaves a sum that starts at +0 unchanged bit for bit.
+    float wmag = -1.0f, wangle = 0.0f;
     if (lane < 42)
     {
         const float ang1 = 0.15f * (float)lane;
         const float ang2 = (ang1 + PI_F / 3.0f > TWO_PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
+        const bool plain = ang1 < ang2, wrapped = ang2 < ang1;
         float sumX = 0.0f, sumY = 0.0f;
+#pragma unroll 4
         for (int q = 0; q < 109; q++)
         {
-            const float a = Ang[q];
-            if ((ang1 < ang2 && ang1 < a && a < ang2) || (ang2 < ang1 && ((a > 0.0f && a < ang2) || (a > ang1 && a < TWO_PI_F))))
-            {
-                sumX = sumX + resX[q];
-                sumY = sumY + resY[q];
-            }
+            const float4 sm = osmp[q];
+            const float a = sm.z;
+            const bool in = (plain && ang1 < a && a < ang2) || (wrapped && ((a > 0.0f && a < ang2) || (a > ang1 && a < TWO_PI_F)));
+            sumX = sumX + (in ? sm.x : 0.0f);
+            sumY = sumY + (in ? sm.y : 0.0f);
         }
-        wm[lane] = sumX * sumX + sumY * sumY;
-        wang[lane] = fast_atan2(sumY, sumX);
+        wmag = sumX * sumX + sumY * sumY;
+        wangle = fast_atan2(sumY, sumX);
     }
-    __syncthreads();
-    float best = 0.0f, angle = 0.0f;
-    for (int st = 0; st < 42; st++) // first strict maximum in step order, as the sequential loop finds it
-        if (wm[st] > best)
+    // first strict maximum in window order (the sequential loop's choice): largest magnitude, lowest window on ties
+    int widx = lane;
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        const float om = __shfl_xor(wmag, off), oa = __shfl_xor(wangle, off);
+        const int oi = __shfl_xor(widx, off);
+        if (om > wmag || (om == wmag && oi < widx))
         {
-            best = wm[st];
-            angle = wang[st];
+            wmag = om;
+            wangle = oa;
+            widx = oi;
         }
+    }
+    const float angle = wmag > 0.0f ? wangle : 0.0f;
     float si, co;
     sincos_poly(angle, &si, &co);
     const float fs = (float)s;
@@ -957,10 +963,7 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
             rry = rx * co + ry * si;
             rrx = -rx * si + ry * co;
         }
-        smp[0][p] = ri;
-        smp[1][p] = rrx;
-        smp[2][p] = rry;
-        smp_ok[p] = inside ? 1 : 0;
+        smp[p] = make_float4(ri, rrx, rry, inside ? 1.0f : 0.0f);
     }
     __syncthreads();
     if (lane < 29)
@@ -975,20 +978,22 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         const int g = lvl + 2;
         const int step = (lvl == 0) ? 10 : (lvl == 1 ? 7 : 5); // ceil(20 / g)
         const int i0 = -10 + (cell / g) * step, j0 = -10 + (cell % g) * step;
-        float di = 0.0f, ddx = 0.0f, ddy = 0.0f;
-        int ns = 0;
+        float di = 0.0f, ddx = 0.0f, ddy = 0.0f, ns = 0.0f;
         for (int a = i0; a < i0 + step; a++)
-            for (int bb = j0; bb < j0 + step; bb++)
+        {
+            int p = (a + 10) * 21 + (j0 + 10);
+            for (int bb = 0; bb < step; bb++, p++)
             {
                 // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
                 // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch here
-                const int p = (a + 10) * 21 + (bb + 10);
-                di = di + smp[0][p];
-                ddx = ddx + smp[1][p];
-                ddy = ddy + smp[2][p];
-                ns += smp_ok[p];
+                const float4 v = smp[p];
+                di = di + v.x;
+                ddx = ddx + v.y;
+                ddy = ddy + v.z;
+                ns = ns + v.w; // small integers: exact in float
             }
-        const float inv = (float)max(ns, 1);
+        }
+        const float inv = fmaxf(ns, 1.0f);
         vals[lane][0] = di / inv;
         vals[lane][1] = ddx / inv;
         vals[lane][2] = ddy / inv;
