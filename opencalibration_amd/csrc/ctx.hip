@@ -34,6 +34,21 @@ int ochip_ensure(ochip_ctx *ctx, void **ptr, size_t *cap, size_t bytes)
     return OCHIP_OK;
 }
 
+int ochip_ensure_keypoint_store(ochip_ctx *ctx, size_t n_keypoints, size_t n_images)
+{
+    const size_t n = n_keypoints ? n_keypoints : 1, m = n_images ? n_images : 1;
+    int rc = ochip_ensure(ctx, (void **)&ctx->kp_xy_dev, &ctx->kp_xy_bytes, n * 16);
+    if (rc == OCHIP_OK)
+        rc = ochip_ensure(ctx, (void **)&ctx->rays_dev, &ctx->rays_bytes, n * 24);
+    if (rc == OCHIP_OK)
+        rc = ochip_ensure(ctx, (void **)&ctx->kp_image_dev, &ctx->kp_image_bytes, n * 4);
+    if (rc == OCHIP_OK)
+        rc = ochip_ensure(ctx, (void **)&ctx->models_dev, &ctx->models_bytes, m * 64);
+    if (rc == OCHIP_OK)
+        ctx->kp_store_ready = true;
+    return rc;
+}
+
 void *ochip_pool_get(ochip_ctx *ctx, size_t bytes, size_t *got)
 {
     if (bytes == 0)
@@ -68,7 +83,7 @@ void ochip_pool_put(ochip_ctx *ctx, void *p, size_t bytes)
     if (!p)
         return;
     ctx->dev_pool.emplace_back(p, bytes);
-    while (ctx->dev_pool.size() > 64)
+    while (ctx->dev_pool.size() > 256)
     {
         size_t s = 0;
         for (size_t k = 1; k < ctx->dev_pool.size(); k++)
@@ -262,28 +277,23 @@ int ochip_descriptors_reserve(ochip_ctx *ctx, uint32_t n_images, uint64_t total_
         return OCHIP_EINVAL;
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
     OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (void **b : {(void **)&ctx->desc_dev, (void **)&ctx->img_off_dev, (void **)&ctx->img_n_dev,
-                     (void **)&ctx->kp_xy_dev, (void **)&ctx->rays_dev, (void **)&ctx->kp_image_dev,
-                     (void **)&ctx->models_dev})
-        if (*b)
-        {
-            OCHIP_HIP(ctx, hipFree(*b));
-            *b = nullptr;
-        }
     ctx->kp_set.clear();
     ctx->rays_dirty = false;
+    ctx->kp_store_ready = false;
     ctx->desc_capacity = ctx->desc_used = 0;
     ctx->n_images = n_images;
     ctx->img_off.assign(n_images, 0);
     ctx->img_n.assign(n_images, 0);
     ctx->img_set.assign(n_images, 0);
     ctx->img_tables_dirty = true;
-    const size_t bytes = (size_t)(total_descriptors ? total_descriptors : 1) * 64;
-    if (hipMalloc((void **)&ctx->desc_dev, bytes) != hipSuccess)
-        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc(%zu) for the descriptor arena failed", bytes);
-    if (hipMalloc((void **)&ctx->img_off_dev, (size_t)(n_images ? n_images : 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&ctx->img_n_dev, (size_t)(n_images ? n_images : 1) * 4) != hipSuccess)
-        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc for the image tables failed");
+    const size_t n_img = n_images ? n_images : 1;
+    int rc = ochip_ensure(ctx, (void **)&ctx->desc_dev, &ctx->desc_bytes, (size_t)(total_descriptors ? total_descriptors : 1) * 64);
+    if (rc == OCHIP_OK)
+        rc = ochip_ensure(ctx, (void **)&ctx->img_off_dev, &ctx->img_off_bytes, n_img * 8);
+    if (rc == OCHIP_OK)
+        rc = ochip_ensure(ctx, (void **)&ctx->img_n_dev, &ctx->img_n_bytes, n_img * 4);
+    if (rc != OCHIP_OK)
+        return rc;
     ctx->desc_capacity = total_descriptors;
     return OCHIP_OK;
 }
@@ -329,11 +339,9 @@ int ochip_upload_batch(ochip_ctx *ctx, uint32_t n_images, const uint32_t *counts
     if (rc)
         return rc;
     const size_t cap = total ? total : 1;
-    if (hipMalloc((void **)&ctx->kp_xy_dev, cap * 16) != hipSuccess ||
-        hipMalloc((void **)&ctx->rays_dev, cap * 24) != hipSuccess ||
-        hipMalloc((void **)&ctx->kp_image_dev, cap * 4) != hipSuccess ||
-        hipMalloc((void **)&ctx->models_dev, (size_t)(n_images ? n_images : 1) * 64) != hipSuccess)
-        return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc for the keypoint store failed");
+    rc = ochip_ensure_keypoint_store(ctx, cap, n_images);
+    if (rc)
+        return rc;
     std::vector<uint32_t> ids(cap);
     uint64_t off = 0;
     for (uint32_t i = 0; i < n_images; i++)

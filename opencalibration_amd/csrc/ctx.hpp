@@ -44,6 +44,11 @@ struct ochip_ctx
     double *models_dev = nullptr; // [n_images][8]: f, ppx, ppy, k1, k2, k3, p1, p2
     std::vector<uint8_t> kp_set;
     bool rays_dirty = false;
+    bool kp_store_ready = false; // keypoint buffers sized for the current reservation
+    // capacities (bytes) of the grow-only buffers above: a reservation reuses them instead of hipFree / hipMalloc,
+    // which synchronise the whole device and would stall the other contexts' streams
+    size_t desc_bytes = 0, img_off_bytes = 0, img_n_bytes = 0, kp_xy_bytes = 0, rays_bytes = 0, kp_image_bytes = 0,
+           models_bytes = 0;
 
     // match scratch
     ochip_pair *pairs_dev = nullptr;
@@ -71,6 +76,7 @@ struct ochip_ctx
 
 int ochip_fail(ochip_ctx *ctx, int code, const char *fmt, ...);
 int ochip_ensure(ochip_ctx *ctx, void **ptr, size_t *cap, size_t bytes); // grow-only device buffer
+int ochip_ensure_keypoint_store(ochip_ctx *ctx, size_t n_keypoints, size_t n_images); // kp_xy, rays, kp_image, models
 void *ochip_pool_get(ochip_ctx *ctx, size_t bytes, size_t *got);          // device block from the pool (or hipMalloc); nullptr on failure
 void ochip_pool_put(ochip_ctx *ctx, void *p, size_t bytes);              // hand it back (kept for reuse, freed with the context)
 void ochip_prof_begin(ochip_ctx *ctx, int kid, hipEvent_t *start, hipEvent_t *stop);

@@ -627,14 +627,11 @@ int ochip_upload_keypoints(ochip_ctx *ctx, uint32_t image_id, const double *xy, 
     if (!model8 || (n && !xy))
         return ochip_fail(ctx, OCHIP_EINVAL, "NULL argument");
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->kp_xy_dev)
+    if (!ctx->kp_store_ready)
     {
-        const size_t cap = ctx->desc_capacity ? ctx->desc_capacity : 1;
-        if (hipMalloc((void **)&ctx->kp_xy_dev, cap * 16) != hipSuccess ||
-            hipMalloc((void **)&ctx->rays_dev, cap * 24) != hipSuccess ||
-            hipMalloc((void **)&ctx->kp_image_dev, cap * 4) != hipSuccess ||
-            hipMalloc((void **)&ctx->models_dev, (size_t)(ctx->n_images ? ctx->n_images : 1) * 64) != hipSuccess)
-            return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc for the keypoint store failed");
+        const int rc = ochip_ensure_keypoint_store(ctx, ctx->desc_capacity, ctx->n_images);
+        if (rc)
+            return rc;
         ctx->kp_set.assign(ctx->n_images, 0);
     }
     const uint64_t off = ctx->img_off[image_id];
@@ -664,7 +661,7 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
         return OCHIP_OK;
     if (!jobs || !results || (total_matches && (!matches || !sorted_idx || !inliers)) || (eval_total && !eval_order))
         return ochip_fail(ctx, OCHIP_EINVAL, "NULL argument");
-    if (!ctx->rays_dev)
+    if (!ctx->kp_store_ready)
         return ochip_fail(ctx, OCHIP_ESTATE, "ochip_upload_keypoints has not been called");
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
     for (uint32_t j = 0; j < n_jobs; j++)

@@ -923,7 +923,7 @@ struct ochip_relax_problem
 {
     ochip_ctx *ctx = nullptr;
     relax_dev dev{};
-    std::vector<void *> allocs;
+    std::vector<std::pair<void *, size_t>> allocs; // device blocks from the context's pool (returned on destroy)
     int n_tangent = 0;
     std::vector<int32_t> cam_t;
     int32_t z_t[3] = {-1, -1, -1};
@@ -950,10 +950,11 @@ namespace
 {
 template <typename T> int dev_upload(ochip_relax_problem *p, T **dst, const T *src, size_t n)
 {
-    void *d = nullptr;
-    if (hipMalloc(&d, (n ? n : 1) * sizeof(T)) != hipSuccess)
-        return ochip_fail(p->ctx, OCHIP_ENOMEM, "hipMalloc(%zu) failed in relax problem", n * sizeof(T));
-    p->allocs.push_back(d);
+    size_t got = 0;
+    void *d = ochip_pool_get(p->ctx, (n ? n : 1) * sizeof(T), &got);
+    if (!d)
+        return ochip_fail(p->ctx, OCHIP_ENOMEM, "device allocation of %zu bytes failed in relax problem", n * sizeof(T));
+    p->allocs.emplace_back(d, got);
     if (n && src)
         if (hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
             return ochip_fail(p->ctx, OCHIP_EHIP, "hipMemcpy failed in relax problem");
@@ -984,18 +985,12 @@ int assign_tangent(ochip_relax_problem *p)
     const size_t n = (size_t)std::max(t, 1);
     if (n > p->cap_n)
     {
-        for (double **b : {&p->A, &p->Wm, &p->g, &p->gs, &p->scale, &p->lm_diag, &p->diag_tmp, &p->y})
-            if (*b)
-            {
-                (void)hipFree(*b);
-                *b = nullptr;
-            }
-        if (hipMalloc((void **)&p->A, n * n * 8) != hipSuccess ||
-            hipMalloc((void **)&p->Wm, (n + 1) * n * 8) != hipSuccess ||
-            hipMalloc((void **)&p->g, n * 8) != hipSuccess || hipMalloc((void **)&p->gs, n * 8) != hipSuccess ||
-            hipMalloc((void **)&p->scale, n * 8) != hipSuccess || hipMalloc((void **)&p->lm_diag, n * 8) != hipSuccess ||
-            hipMalloc((void **)&p->diag_tmp, n * 8) != hipSuccess || hipMalloc((void **)&p->y, n * 8) != hipSuccess)
-            return ochip_fail(p->ctx, OCHIP_ENOMEM, "hipMalloc for the %zu x %zu normal matrix failed", n, n);
+        // (blocks of a smaller earlier size stay with the problem until it is destroyed)
+        if (dev_upload<double>(p, &p->A, nullptr, n * n) != OCHIP_OK || dev_upload<double>(p, &p->Wm, nullptr, (n + 1) * n) != OCHIP_OK ||
+            dev_upload<double>(p, &p->g, nullptr, n) != OCHIP_OK || dev_upload<double>(p, &p->gs, nullptr, n) != OCHIP_OK ||
+            dev_upload<double>(p, &p->scale, nullptr, n) != OCHIP_OK || dev_upload<double>(p, &p->lm_diag, nullptr, n) != OCHIP_OK ||
+            dev_upload<double>(p, &p->diag_tmp, nullptr, n) != OCHIP_OK || dev_upload<double>(p, &p->y, nullptr, n) != OCHIP_OK)
+            return ochip_fail(p->ctx, OCHIP_ENOMEM, "device allocation for the %zu x %zu normal matrix failed", n, n);
         p->cap_n = n;
     }
     return OCHIP_OK;
@@ -1152,11 +1147,8 @@ void ochip_relax_problem_destroy(ochip_relax_problem *p)
         return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
-    for (void *a : p->allocs)
-        (void)hipFree(a);
-    for (double *b : {p->A, p->Wm, p->g, p->gs, p->scale, p->lm_diag, p->diag_tmp, p->y, p->linv})
-        if (b)
-            (void)hipFree(b);
+    for (auto &a : p->allocs)
+        ochip_pool_put(p->ctx, a.first, a.second);
     delete p;
 }
 
@@ -1377,12 +1369,10 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
             const size_t need = (size_t)((n + NB - 1) / NB) * NB * NB;
             if (need > p->linv_cap)
             {
-                if (p->linv)
-                    OCHIP_HIP(ctx, hipFree(p->linv));
                 p->linv = nullptr;
                 p->linv_cap = 0;
-                if (hipMalloc((void **)&p->linv, need * 8) != hipSuccess)
-                    return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc for the diagonal-block inverses failed");
+                if (dev_upload<double>(p, &p->linv, nullptr, need) != OCHIP_OK)
+                    return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the diagonal-block inverses failed");
                 p->linv_cap = need;
             }
         }
