@@ -83,11 +83,46 @@ void LinkStage::init(const MeasurementGraph &graph, const std::vector<size_t> &n
     timers.link_init += since(t0);
 }
 
+void LinkStage::prepare(const MeasurementGraph &graph)
+{
+    const auto t0 = clk::now();
+    _prepared_index.clear();
+    std::vector<size_t> ids;
+    auto add = [&](size_t id) {
+        if (graph.getNode(id) != nullptr && _prepared_index.emplace(id, ids.size()).second)
+            ids.push_back(id);
+    };
+    for (const auto &link : _links)
+    {
+        add(link.node_id);
+        for (size_t m : link.link_ids)
+            add(m);
+    }
+    _subsets.assign(ids.size(), {});
+    _rays.assign(ids.size(), {});
+    const double coarse_spacing_pixels = 40.0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (size_t s = 0; s < ids.size(); s++)
+    {
+        const image &img = graph.getNode(ids[s])->payload;
+        _subsets[s] = spatially_subsample_feature_indices(img.features, coarse_spacing_pixels, img.num_sparse_features);
+        _rays[s].resize(_subsets[s].size() * 3);
+        for (size_t k = 0; k < _subsets[s].size(); k++)
+            image_to_3d(img.features[_subsets[s][k]].location, *img.model, &_rays[s][3 * k]);
+    }
+    timers.subsample += since(t0);
+}
+
 std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph &graph)
 {
     std::vector<std::function<void()>> funcs;
-    // a runner needs enough pairs to fill the device; the debug record is kept in runner order, so one runner then
+    prepare(graph);
+    // a runner needs enough pairs to fill the device; the debug record is kept in runner order, so one runner then.
+    // A runner may walk its range in sub-batches (OCHIP_LINK_SUBBATCHES) so that the runners drift out of phase;
+    // measured on C3 it does not pay (smaller launches, more uploads), so the default is one batch per runner.
     size_t n = keep_debug ? 1 : std::min<size_t>((size_t)_runners, std::max<size_t>(1, _links.size() / 64));
+    static const size_t sub_env = std::getenv("OCHIP_LINK_SUBBATCHES") ? (size_t)std::atoi(std::getenv("OCHIP_LINK_SUBBATCHES")) : 1;
+    const size_t sub = keep_debug ? 1 : std::max<size_t>(1, std::min<size_t>(sub_env, _links.size() / (n * 64)));
     const int omp_threads = std::max(1, omp_get_max_threads() / (int)n);
     for (size_t r = 0; r < n; r++)
     {
@@ -98,9 +133,18 @@ std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph
             error = std::string("ochip_ctx_sibling: ") + ochip_last_error(_ctx);
             ctx = nullptr;
         }
-        funcs.push_back([this, &graph, begin, end, ctx, omp_threads]() {
-            if (ctx)
-                run_batch(graph, begin, end, ctx, omp_threads);
+        funcs.push_back([this, &graph, begin, end, ctx, omp_threads, sub, r]() {
+            if (!ctx)
+                return;
+            // uneven first sub-batch (shorter for later runners) staggers the runners from the start
+            const size_t len = end - begin;
+            std::vector<size_t> cuts{begin};
+            for (size_t k = 1; k < sub; k++)
+                cuts.push_back(begin + len * k / sub - (len / (sub * 4)) * (r % 3));
+            cuts.push_back(end);
+            for (size_t k = 0; k + 1 < cuts.size(); k++)
+                if (cuts[k + 1] > cuts[k])
+                    run_batch(graph, cuts[k], cuts[k + 1], ctx, omp_threads);
         });
     }
     return funcs;
@@ -157,22 +201,33 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
         error = std::string(what) + ": " + ochip_last_error(ctx);
     };
 
-    // ---- 40 px subsets, once per image (link_stage.cpp:63-65,80-81; the per-pair recomputation of
-    //      the reference yields the same vector every time)
+    // ---- 40 px subsets and unit rays: computed once per image by prepare() (link_stage.cpp:63-65,80-81; the
+    //      per-pair recomputation of the reference yields the same vector every time)
     auto t0 = clk::now();
-    const double coarse_spacing_pixels = 40.0;
-    std::vector<std::vector<size_t>> subset(n_slots);
-    std::vector<std::vector<double>> rays(n_slots); // unit rays of the subset keypoints (for decompose)
-#pragma omp parallel for schedule(dynamic, 1) num_threads(omp_threads)
+    std::vector<const std::vector<size_t> *> subset_p(n_slots);
+    std::vector<const std::vector<double> *> rays_p(n_slots);
     for (size_t s = 0; s < n_slots; s++)
     {
-        const image &img = graph.getNode(slot_node[s])->payload;
-        subset[s] = spatially_subsample_feature_indices(img.features, coarse_spacing_pixels, img.num_sparse_features);
-        rays[s].resize(subset[s].size() * 3);
-        for (size_t k = 0; k < subset[s].size(); k++)
-            image_to_3d(img.features[subset[s][k]].location, *img.model, &rays[s][3 * k]);
+        const size_t k = _prepared_index.at(slot_node[s]);
+        subset_p[s] = &_subsets[k];
+        rays_p[s] = &_rays[k];
     }
-    lt.subsample += since(t0);
+    struct deref_subsets
+    {
+        const std::vector<const std::vector<size_t> *> &p;
+        const std::vector<size_t> &operator[](size_t i) const
+        {
+            return *p[i];
+        }
+    } subset{subset_p};
+    struct deref_rays
+    {
+        const std::vector<const std::vector<double> *> &p;
+        const std::vector<double> &operator[](size_t i) const
+        {
+            return *p[i];
+        }
+    } rays{rays_p};
 
     // ---- upload descriptors + keypoints (one packed batch, packed in parallel)
     t0 = clk::now();
@@ -236,9 +291,8 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
 
     // ---- host: ratio test, std::sort, PROSAC order; pack the RANSAC jobs
     t0 = clk::now();
-    struct sorted_match
+    struct sorted_match // 12 bytes: what the comparator and the outputs need (distance = count / 486 is monotone in count)
     {
-        feature_match m;
         uint32_t k1, k2;
         uint16_t count;
     };
@@ -250,9 +304,9 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
     {
         const auto &idx1 = subset[jobs[p].slot_1], &idx2 = subset[jobs[p].slot_2];
         const ochip_match *r = raw.ptr + out_off[p];
-        // match_features_subset tail (match_features.cpp:94-101) with the subset positions carried along:
-        // the permutation std::sort produces depends only on the comparison results, which are those
-        // of the reference's comparator on the same sequence
+        // match_features_subset tail (match_features.cpp:94-101) on compact records: the permutation std::sort
+        // produces depends only on the comparison results, which are those of the reference's comparator
+        // (f1.distance > f2.distance) on the same sequence
         std::vector<sorted_match> sm;
         sm.reserve(idx1.size());
         if (!idx2.empty())
@@ -263,19 +317,28 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
                                           ? std::numeric_limits<double>::infinity()
                                           : (size_t)r[a].second_count * (1.0 / feature_2d::DESCRIPTOR_BITS);
                 if (best < 0.8 * second)
-                    sm.push_back(sorted_match{feature_match{idx1[a], idx2[r[a].best_k], best}, (uint32_t)a,
-                                              r[a].best_k, r[a].best_count});
+                    sm.push_back(sorted_match{(uint32_t)a, r[a].best_k, r[a].best_count});
             }
-        std::sort(sm.begin(), sm.end(),
-                  [](const sorted_match &f1, const sorted_match &f2) -> bool { return f1.m.distance > f2.m.distance; });
-        matches[p].resize(sm.size());
-        rmatches[p].resize(sm.size());
-        for (size_t i = 0; i < sm.size(); i++)
+        std::sort(sm.begin(), sm.end(), [](const sorted_match &f1, const sorted_match &f2) -> bool { return f1.count > f2.count; });
+        const size_t M = sm.size();
+        matches[p].resize(M);
+        rmatches[p].resize(M);
+        bool has_quality = false;
+        for (size_t i = 0; i < M; i++)
         {
-            matches[p][i] = sm[i].m;
+            matches[p][i] = feature_match{idx1[sm[i].k1], idx2[sm[i].k2], (size_t)sm[i].count * (1.0 / feature_2d::DESCRIPTOR_BITS)};
             rmatches[p][i] = ochip_ransac_match{sm[i].k1, sm[i].k2, sm[i].count, 0};
+            has_quality = has_quality || sm[i].count != 0;
         }
-        sorted_idx[p] = prosac_sorted_idx(matches[p]);
+        // PROSAC order (ransac.cpp:83-90): iota sorted by quality ascending; empty if no quality is non-zero
+        if (has_quality)
+        {
+            std::vector<size_t> order(M);
+            for (size_t i = 0; i < M; i++)
+                order[i] = i;
+            std::sort(order.begin(), order.end(), [&sm](size_t a, size_t b) { return sm[a].count < sm[b].count; });
+            sorted_idx[p].assign(order.begin(), order.end());
+        }
     }
     std::vector<ochip_ransac_job> rjobs(n_pairs);
     uint64_t total_matches = 0;
@@ -342,17 +405,22 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
         relations.relationType = camera_relations::RelationType::HOMOGRAPHY;
 
         std::vector<bool> coarse_inliers(M);
-        std::vector<correspondence> coarse_correspondences(M);
+        std::vector<double> inlier_rays; // {measurement1, measurement2} of the inliers, in match order
+        inlier_rays.reserve(6 * (size_t)results[p].n_inliers);
         const auto &ray1 = rays[jobs[p].slot_1], &ray2 = rays[jobs[p].slot_2];
+        size_t num_coarse_inliers = 0;
         for (size_t i = 0; i < M; i++)
         {
             coarse_inliers[i] = inl[i] != 0;
-            std::memcpy(coarse_correspondences[i].measurement1, &ray1[3 * rmatches[p][i].k1], 24);
-            std::memcpy(coarse_correspondences[i].measurement2, &ray2[3 * rmatches[p][i].k2], 24);
-            coarse_correspondences[i].quality = matches[p][i].distance;
+            if (inl[i])
+            {
+                const double *a = &ray1[3 * rmatches[p][i].k1], *b = &ray2[3 * rmatches[p][i].k2];
+                inlier_rays.insert(inlier_rays.end(), a, a + 3);
+                inlier_rays.insert(inlier_rays.end(), b, b + 3);
+                num_coarse_inliers++;
+            }
         }
-        const bool can_decompose = h.decompose(coarse_correspondences, coarse_inliers, relations.relative_poses);
-        const size_t num_coarse_inliers = std::count(coarse_inliers.begin(), coarse_inliers.end(), true);
+        const bool can_decompose = h.decompose_inlier_rays(inlier_rays.data(), num_coarse_inliers, relations.relative_poses);
         if (keep_debug)
         {
             dbg[p].node_id = jobs[p].node_id;

@@ -13,6 +13,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <unordered_map>
 
 namespace opencalibration_amd
 {
@@ -69,6 +70,7 @@ class LinkStage
         size_t match_node_id;
         camera_relations relations;
     };
+    void prepare(const MeasurementGraph &graph); // 40 px subsets + unit rays of every image the links touch
     void run_batch(const MeasurementGraph &graph, size_t link_begin, size_t link_end, ochip_ctx *ctx, int omp_threads);
 
     ochip_ctx *_ctx;
@@ -76,6 +78,9 @@ class LinkStage
     std::vector<edge_payload> _all_inlier_measurements;
     std::mutex _measurement_mutex;
     std::vector<NodeLinks> _links;
+    std::unordered_map<size_t, size_t> _prepared_index; // node id -> position in _subsets / _rays
+    std::vector<std::vector<size_t>> _subsets;
+    std::vector<std::vector<double>> _rays;
     EvalOrderCache _eval_cache;
 };
 

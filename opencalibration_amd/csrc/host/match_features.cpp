@@ -20,20 +20,27 @@ std::vector<size_t> spatially_subsample_feature_indices(const std::vector<featur
         return {};
     count = std::min(count, features.size());
 
+    // strengths and locations side by side in flat arrays: the sort and the bucket walk below would otherwise
+    // stride through the 88-byte feature records (same comparator answers, hence the same permutation)
+    std::vector<float> strength(count);
+    std::vector<double> lx(count), ly(count);
+    double min_x = std::numeric_limits<double>::infinity(), min_y = min_x, max_x = -min_x, max_y = -min_x;
+    for (size_t i = 0; i < count; i++)
+    {
+        strength[i] = features[i].strength;
+        lx[i] = features[i].location[0];
+        ly[i] = features[i].location[1];
+        min_x = std::min(min_x, lx[i]);
+        max_x = std::max(max_x, lx[i]);
+        min_y = std::min(min_y, ly[i]);
+        max_y = std::max(max_y, ly[i]);
+    }
     std::vector<size_t> sorted_indices(count);
     for (size_t i = 0; i < count; i++)
         sorted_indices[i] = i;
     std::sort(sorted_indices.begin(), sorted_indices.end(),
-              [&features](size_t a, size_t b) { return features[a].strength > features[b].strength; });
+              [&strength](size_t a, size_t b) { return strength[a] > strength[b]; });
 
-    double min_x = std::numeric_limits<double>::infinity(), min_y = min_x, max_x = -min_x, max_y = -min_x;
-    for (size_t i = 0; i < count; i++)
-    {
-        min_x = std::min(min_x, features[i].location[0]);
-        max_x = std::max(max_x, features[i].location[0]);
-        min_y = std::min(min_y, features[i].location[1]);
-        max_y = std::max(max_y, features[i].location[1]);
-    }
     const double cell = spacing_pixels > 0 ? spacing_pixels : 1.0;
     const double limit = spacing_pixels * spacing_pixels;
     size_t gw = (size_t)std::floor((max_x - min_x) / cell) + 1, gh = (size_t)std::floor((max_y - min_y) / cell) + 1;
@@ -49,7 +56,7 @@ std::vector<size_t> spatially_subsample_feature_indices(const std::vector<featur
 
     for (size_t idx : sorted_indices)
     {
-        const double x = features[idx].location[0], y = features[idx].location[1];
+        const double x = lx[idx], y = ly[idx];
         const long cx = gw == 1 ? 0 : (long)((x - min_x) * inv_w), cy = gh == 1 ? 0 : (long)((y - min_y) * inv_h);
         bool accept = true;
         const long x0 = gw == 1 ? 0 : std::max(cx - 1, 0L), x1 = gw == 1 ? 0 : std::min(cx + 1, (long)gw - 1);
@@ -58,8 +65,8 @@ std::vector<size_t> spatially_subsample_feature_indices(const std::vector<featur
             for (long xx = x0; xx <= x1 && accept; xx++)
                 for (int32_t e = head[(size_t)yy * gw + xx]; e >= 0; e = next[e])
                 {
-                    const feature_2d &o = features[indices[e]];
-                    const double dx = x - o.location[0], dy = y - o.location[1];
+                    const size_t o = indices[e];
+                    const double dx = x - lx[o], dy = y - ly[o];
                     double d = 0;
                     d += dx * dx;
                     d += dy * dy;

@@ -302,6 +302,19 @@ void quaternion_from_rotation(const M3 &m, double q[4])
 bool homography_model::decompose(const std::vector<correspondence> &corrs, const std::vector<bool> &inliers,
                                  std::array<decomposed_pose, 4> &poses) const
 {
+    std::vector<double> packed;
+    packed.reserve(corrs.size() * 6);
+    for (size_t j = 0; j < corrs.size(); j++)
+        if (inliers[j])
+        {
+            packed.insert(packed.end(), corrs[j].measurement1, corrs[j].measurement1 + 3);
+            packed.insert(packed.end(), corrs[j].measurement2, corrs[j].measurement2 + 3);
+        }
+    return decompose_inlier_rays(packed.data(), packed.size() / 6, poses);
+}
+
+bool homography_model::decompose_inlier_rays(const double *m1m2, size_t n_inliers, std::array<decomposed_pose, 4> &poses) const
+{
     motion motions[4];
     const size_t solutions = decompose_homography(homography, motions);
     for (size_t i = 0; i < solutions; i++)
@@ -312,11 +325,9 @@ bool homography_model::decompose(const std::vector<correspondence> &corrs, const
                               R.a[1][0] * N[0] + R.a[1][1] * N[1] + R.a[1][2] * N[2],
                               R.a[2][0] * N[0] + R.a[2][1] * N[1] + R.a[2][2] * N[2]};
         int score = 0;
-        for (size_t j = 0; j < corrs.size(); j++)
+        for (size_t j = 0; j < n_inliers; j++)
         {
-            if (!inliers[j])
-                continue;
-            const double *m1 = corrs[j].measurement1, *m2 = corrs[j].measurement2;
+            const double *m1 = m1m2 + 6 * j, *m2 = m1 + 3;
             const double dot1 = N[0] * m1[0] + N[1] * m1[1] + N[2] * m1[2];
             const double dot2 = RN[0] * m2[0] + RN[1] * m2[1] + RN[2] * m2[2];
             if (dot1 >= 0 && dot2 >= 0)

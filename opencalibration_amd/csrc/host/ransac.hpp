@@ -42,6 +42,9 @@ struct homography_model // include/opencalibration/model_inliers/homography_mode
     // rays + std::stable_sort by score.
     bool decompose(const std::vector<correspondence> &corrs, const std::vector<bool> &inliers,
                    std::array<decomposed_pose, 4> &poses) const;
+    // the same on the inlier correspondences only, packed as n x {measurement1(3), measurement2(3)}: the vote only
+    // ever looks at inliers, so the batch runner does not materialise a correspondence per match
+    bool decompose_inlier_rays(const double *m1m2, size_t n_inliers, std::array<decomposed_pose, 4> &poses) const;
 };
 
 // ransac.cpp:263-282
