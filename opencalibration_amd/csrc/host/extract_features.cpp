@@ -65,19 +65,33 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
     // device order is arbitrary: restore detection order (level, y, x), then the reference's unstable std::sort
     // by response.  Both sorts permute 4-byte indices; std::sort's compare/move sequence depends only on the
     // comparator's answers, so the permutation is the one sorting the feature structs themselves would give.
-    std::vector<uint32_t> order(n);
+    // (the keys of the first sort are unique, so any sorting algorithm restores the same order: positive floats
+    // order like their bit patterns, which makes the key two integers in one contiguous record)
+    struct det_key
+    {
+        uint64_t level_y;
+        uint32_t x, idx;
+    };
+    std::vector<det_key> keys(n);
     for (uint32_t i = 0; i < n; i++)
-        order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
-        const float *p = k6 + 6 * (size_t)a, *q = k6 + 6 * (size_t)c;
-        if (p[5] != q[5])
-            return p[5] < q[5];
-        if (p[1] != q[1])
-            return p[1] < q[1];
-        return p[0] < q[0];
+    {
+        const float *p = k6 + 6 * (size_t)i;
+        uint32_t xb, yb;
+        std::memcpy(&xb, p, 4);
+        std::memcpy(&yb, p + 1, 4);
+        keys[i] = det_key{((uint64_t)(uint32_t)p[5] << 32) | yb, xb, i};
+    }
+    std::sort(keys.begin(), keys.end(), [](const det_key &a, const det_key &c) {
+        return a.level_y != c.level_y ? a.level_y < c.level_y : a.x < c.x;
     });
-    std::sort(order.begin(), order.end(),
-              [&](uint32_t a, uint32_t c) -> bool { return k6[6 * (size_t)a + 4] > k6[6 * (size_t)c + 4]; });
+    std::vector<uint32_t> order(n);
+    std::vector<float> response(n); // by keypoint index, contiguous for the comparator below
+    for (uint32_t i = 0; i < n; i++)
+    {
+        order[i] = keys[i].idx;
+        response[i] = k6[6 * (size_t)i + 4];
+    }
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) -> bool { return response[a] > response[c]; });
     auto make = [&](uint32_t s) {
         feature_2d p;
         p.location[0] = k6[6 * (size_t)s] / scale; // keypoints[i].pt.x / scale, extract_features.cpp:44-45
