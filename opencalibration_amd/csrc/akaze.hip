@@ -828,8 +828,9 @@ __device__ __forceinline__ void sincos_poly(float a, float *s, float *c)
 
 struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cells numbered 0..3 | 4..12 | 13..28
 {
-    unsigned char a[486], b[486], ch[486];
-    unsigned char ori_q[109]; // orientation samples: position (i + 6) * 13 + (j + 6) of the n-th member of the radius-6 disc
+    unsigned int bits[512];  // bit -> a | b << 8 | channel << 16 (one dword per comparison; entries >= 486 unused)
+    unsigned int ori_q[128]; // orientation samples: position (i + 6) * 13 + (j + 6) of the n-th member of the radius-6 disc
+    float ori_g[128];        // and its Gaussian weight
 };
 
 // One 64-thread workgroup per surviving candidate: sub-pixel fit, dominant orientation, 486-bit M-LDB.
@@ -854,13 +855,24 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
     if (!xcd_contiguous(blockIdx.x, n, &k, remap))
         return;
     const size_t slot = (size_t)b * max_cands + k;
-    if (dead[slot])
+    // A keypoint is a chain of dependent phases; what bounds this kernel is the number of memory round trips on
+    // that chain times the waves a CU can hold.  Everything whose address is known up front is therefore requested
+    // here, together: the candidate record, the per-lane table entries of the orientation samples and of the
+    // descriptor bits (the compiler keeps them in flight across the early exits).
+    const unsigned char is_dead = dead[slot];
+    const cand_t c = cands[slot];
+    const unsigned int oq0 = tab->ori_q[lane], oq1 = tab->ori_q[lane + 64];
+    const float og0 = tab->ori_g[lane], og1 = tab->ori_g[lane + 64];
+    unsigned int tbits[8];
+#pragma unroll
+    for (int wd = 0; wd < 8; wd++)
+        tbits[wd] = tab->bits[wd * 64 + lane];
+    if (is_dead)
     {
         if (lane == 0)
             valid_out[slot] = 0;
         return;
     }
-    const cand_t c = cands[slot];
     const level_info l = L.l[c.level];
     const int w = l.w, h = l.h;
     const float *D = Ldet + (size_t)b * img_stride + l.off;
@@ -895,16 +907,22 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
     const float *pLt = Lt + (size_t)b * img_stride + l.off, *pLx = Lx + (size_t)b * img_stride + l.off,
                 *pLy = Ly + (size_t)b * img_stride + l.off;
 
-    // orientation samples: index order i (outer), j (inner) over the radius-6 disc
-    for (int idx = lane; idx < 109; idx += 64)
+    // orientation samples: index order i (outer), j (inner) over the radius-6 disc; lane handles samples lane and
+    // lane + 64, the four loads issued together
     {
-        const int q = tab->ori_q[idx]; // the idx-th member of the disc in (i, j) scan order
-        const int i = q / 13 - 6, j = q % 13 - 6;
-        const int iy = clampi((int)rintf(yf + (float)(j * s)), 0, h - 1);
-        const int ix = clampi((int)rintf(xf + (float)(i * s)), 0, w - 1);
-        const float g = gw[q];
-        const float rx = g * pLx[(size_t)iy * w + ix], ry = g * pLy[(size_t)iy * w + ix];
-        osmp[idx] = make_float4(rx, ry, fast_atan2(ry, rx), 0.0f);
+        const int i0 = (int)oq0 / 13 - 6, j0 = (int)oq0 % 13 - 6, i1 = (int)oq1 / 13 - 6, j1 = (int)oq1 % 13 - 6;
+        const bool second = lane + 64 < 109;
+        const int iy0 = clampi((int)rintf(yf + (float)(j0 * s)), 0, h - 1), ix0 = clampi((int)rintf(xf + (float)(i0 * s)), 0, w - 1);
+        const int iy1 = clampi((int)rintf(yf + (float)(j1 * s)), 0, h - 1), ix1 = clampi((int)rintf(xf + (float)(i1 * s)), 0, w - 1);
+        const float lx0 = pLx[(size_t)iy0 * w + ix0], ly0 = pLy[(size_t)iy0 * w + ix0];
+        const float lx1 = second ? pLx[(size_t)iy1 * w + ix1] : 0.0f, ly1 = second ? pLy[(size_t)iy1 * w + ix1] : 0.0f;
+        const float rx0 = og0 * lx0, ry0 = og0 * ly0;
+        osmp[lane] = make_float4(rx0, ry0, fast_atan2(ry0, rx0), 0.0f);
+        if (second)
+        {
+            const float rx1 = og1 * lx1, ry1 = og1 * ly1;
+            osmp[lane + 64] = make_float4(rx1, ry1, fast_atan2(ry1, rx1), 0.0f);
+        }
     }
     __syncthreads();
     const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
@@ -915,14 +933,19 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
     {
         const float ang1 = 0.15f * (float)lane;
         const float ang2 = (ang1 + PI_F / 3.0f > TWO_PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
+        // the window as two open intervals: (ang1, ang2) and nothing, or - wrapped - (0, ang2) and (ang1, 2 pi);
+        // written without short-circuits so that the loop has no branches and its LDS reads are issued in batches
         const bool plain = ang1 < ang2, wrapped = ang2 < ang1;
+        const float INF = __builtin_huge_valf();
+        const float lo1 = plain ? ang1 : 0.0f, hi1 = (plain || wrapped) ? ang2 : -INF;
+        const float lo2 = wrapped ? ang1 : INF, hi2 = wrapped ? TWO_PI_F : -INF;
         float sumX = 0.0f, sumY = 0.0f;
-#pragma unroll 4
+#pragma unroll 8
         for (int q = 0; q < 109; q++)
         {
             const float4 sm = osmp[q];
             const float a = sm.z;
-            const bool in = (plain && ang1 < a && a < ang2) || (wrapped && ((a > 0.0f && a < ang2) || (a > ang1 && a < TWO_PI_F)));
+            const bool in = ((a > lo1) & (a < hi1)) | ((a > lo2) & (a < hi2));
             sumX = sumX + (in ? sm.x : 0.0f);
             sumY = sumY + (in ? sm.y : 0.0f);
         }
@@ -948,22 +971,35 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
     const float fs = (float)s;
     // every grid (2x2, 3x3, 4x4) samples the same rotated 21 x 21 lattice: gather it once with all lanes,
     // then run the per-cell sums in their sequential order out of LDS
-    for (int p = lane; p < 441; p += 64)
     {
-        const int a = p / 21 - 10, bb = p % 21 - 10;
-        const float sy = yf + ((float)bb * co * fs + (float)a * si * fs);
-        const float sx = xf + (-(float)bb * si * fs + (float)a * co * fs);
-        const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
-        const bool inside = !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
-        float ri = 0.0f, rrx = 0.0f, rry = 0.0f;
-        if (inside)
+        // 7 rounds of 64 lattice points: first every address, then every load (21 in flight per lane), then the
+        // rotations and the LDS stores
+        float ri[7], rx[7], ry[7];
+        bool inside[7];
+#pragma unroll
+        for (int t = 0; t < 7; t++)
         {
-            ri = pLt[(size_t)y1 * w + x1];
-            const float rx = pLx[(size_t)y1 * w + x1], ry = pLy[(size_t)y1 * w + x1];
-            rry = rx * co + ry * si;
-            rrx = -rx * si + ry * co;
+            const int p = lane + 64 * t;
+            const int a = p / 21 - 10, bb = p % 21 - 10;
+            const float sy = yf + ((float)bb * co * fs + (float)a * si * fs);
+            const float sx = xf + (-(float)bb * si * fs + (float)a * co * fs);
+            const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
+            inside[t] = p < 441 && !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
+            const size_t o = inside[t] ? (size_t)y1 * w + x1 : 0;
+            ri[t] = pLt[o];
+            rx[t] = pLx[o];
+            ry[t] = pLy[o];
         }
-        smp[p] = make_float4(ri, rrx, rry, inside ? 1.0f : 0.0f);
+#pragma unroll
+        for (int t = 0; t < 7; t++)
+        {
+            const int p = lane + 64 * t;
+            if (p < 441)
+            {
+                const float rry = rx[t] * co + ry[t] * si, rrx = -rx[t] * si + ry[t] * co;
+                smp[p] = inside[t] ? make_float4(ri[t], rrx, rry, 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
     }
     __syncthreads();
     if (lane < 29)
@@ -1004,7 +1040,10 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         const int bit = wd * 64 + lane;
         bool on = false;
         if (bit < 486)
-            on = vals[tab->a[bit]][tab->ch[bit]] > vals[tab->b[bit]][tab->ch[bit]];
+        {
+            const unsigned int e = tbits[wd], ch = e >> 16;
+            on = vals[e & 255u][ch] > vals[(e >> 8) & 255u][ch];
+        }
         const unsigned long long word = __ballot(on);
         if (lane == 0)
             desc_out[slot * 8 + wd] = word;
@@ -1490,7 +1529,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 gw[(i + 6) * 13 + (j + 6)] =
                     (float)(std::exp(-(double)(i * i + j * j) / (2.0 * 2.5 * 2.5)) / (2.0 * M_PI * 2.5 * 2.5));
         AK(up(ctx, allocs, &d_gw, gw.data(), gw.size()));
-        pair_tab tab;
+        pair_tab tab{};
         int dpos = 0;
         const int base[3] = {0, 4, 13};
         for (int lvl = 0; lvl < 3; lvl++)
@@ -1500,9 +1539,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 for (int a = 0; a < nval; a++)
                     for (int bb = a + 1; bb < nval; bb++)
                     {
-                        tab.a[dpos] = (unsigned char)(base[lvl] + a);
-                        tab.b[dpos] = (unsigned char)(base[lvl] + bb);
-                        tab.ch[dpos] = (unsigned char)ch;
+                        tab.bits[dpos] = (unsigned int)(base[lvl] + a) | ((unsigned int)(base[lvl] + bb) << 8) | ((unsigned int)ch << 16);
                         dpos++;
                     }
         }
@@ -1511,7 +1548,11 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         {
             const int i = q / 13 - 6, j = q % 13 - 6;
             if (i * i + j * j < 36)
-                tab.ori_q[nq++] = (unsigned char)q;
+            {
+                tab.ori_q[nq] = (unsigned int)q;
+                tab.ori_g[nq] = gw[q];
+                nq++;
+            }
         }
         AK(up(ctx, allocs, &d_tab, &tab, 1));
     }
