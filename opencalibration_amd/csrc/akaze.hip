@@ -734,35 +734,58 @@ __global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict_
     const float ratio_c = (float)(1 << lc.octave);
     const float rad = lc.esigma * derivative_factor, r2 = rad * rad;
     const float cx = (float)c.x * ratio_c, cy = (float)c.y * ratio_c;
-    bool is_dead = false; // early exit pays: most suppressed candidates die in the first window (measured)
-    for (int j = max(c.level - 1, 0); j <= min(c.level + 1, L.n - 1) && !is_dead; j++)
+    // up to three windows (levels c.level - 1 .. c.level + 1); each round loads 64 pixels of every window together
+    // (independent loads, one memory round trip per round), the lanes vote, and the scan stops at the first killer
+    const float *R[3];
+    int wx0[3], wy0[3], ww[3], wtotal[3], wlw[3], wj[3];
+    float wratio[3];
+    int max_total = 0;
+#pragma unroll
+    for (int q = 0; q < 3; q++)
     {
-        const level_info lj = L.l[j];
+        const int j = c.level - 1 + q;
+        const bool use = j >= 0 && j < L.n;
+        const level_info lj = L.l[use ? j : c.level];
         const float ratio = (float)(1 << lj.octave);
-        const float *R = Rmax + (size_t)b * img_stride + lj.off;
         const int x0 = max((int)floorf((cx - rad) / ratio), 0), x1 = min((int)ceilf((cx + rad) / ratio), lj.w - 1);
         const int y0 = max((int)floorf((cy - rad) / ratio), 0), y1 = min((int)ceilf((cy + rad) / ratio), lj.h - 1);
-        const int ww = x1 - x0 + 1, total = ww * (y1 - y0 + 1);
-        for (int t0 = 0; t0 < total && !is_dead; t0 += 64)
+        R[q] = Rmax + (size_t)b * img_stride + lj.off;
+        wx0[q] = x0;
+        wy0[q] = y0;
+        ww[q] = x1 - x0 + 1;
+        wtotal[q] = use ? ww[q] * (y1 - y0 + 1) : 0;
+        wlw[q] = lj.w;
+        wj[q] = j;
+        wratio[q] = ratio;
+        max_total = max(max_total, wtotal[q]);
+    }
+    bool is_dead = false;
+    for (int t0 = 0; t0 < max_total && !is_dead; t0 += 64)
+    {
+        const int t = t0 + lane;
+        float r[3];
+        int xx[3], yy[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
         {
-            const int t = t0 + lane;
-            bool kill = false;
-            if (t < total)
+            const bool act = t < wtotal[q];
+            yy[q] = wy0[q] + (act ? t / ww[q] : 0);
+            xx[q] = wx0[q] + (act ? t % ww[q] : 0);
+            r[q] = act ? R[q][(size_t)yy[q] * wlw[q] + xx[q]] : 0.0f;
+        }
+        bool kill = false;
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            if (r[q] != 0.0f && !(wj[q] == c.level && xx[q] == c.x && yy[q] == c.y))
             {
-                const int yy = y0 + t / ww, xx = x0 + t % ww;
-                const float r = R[(size_t)yy * lj.w + xx];
-                if (r != 0.0f && !(j == c.level && xx == c.x && yy == c.y))
+                const float ex = (float)xx[q] * wratio[q] - cx, ey = (float)yy[q] * wratio[q] - cy;
+                if (ex * ex + ey * ey <= r2)
                 {
-                    const float ex = (float)xx * ratio - cx, ey = (float)yy * ratio - cy;
-                    if (ex * ex + ey * ey <= r2)
-                    {
-                        const bool lower_key = j < c.level || (j == c.level && (yy < c.y || (yy == c.y && xx < c.x)));
-                        kill = r > c.response || (r == c.response && lower_key);
-                    }
+                    const bool lower_key = wj[q] < c.level || (wj[q] == c.level && (yy[q] < c.y || (yy[q] == c.y && xx[q] < c.x)));
+                    kill = kill || r[q] > c.response || (r[q] == c.response && lower_key);
                 }
             }
-            is_dead = __ballot(kill) != 0;
-        }
+        is_dead = __ballot(kill) != 0;
     }
     if (lane == 0)
         dead[(size_t)b * max_cands + k] = is_dead ? 1 : 0;
