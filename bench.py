@@ -143,7 +143,7 @@ def main():
     alg_bytes_img = 4.0 * px_floats + w * h * 5.0
     imgs_per_launch = grid.n_images * args.steps / max(n_akaze, 1)
     avg_ms_akaze = ms_akaze / max(n_akaze, 1)          # HIP events around one chunk's launch sequence, on its stream
-    # two device contexts keep two chunks in flight (their sequences overlap in time), so the rate is taken over the
+    # three device contexts keep three chunks in flight (their sequences overlap in time), so the rate is taken over the
     # extract stage's wall time - device-bound, the host tail runs underneath it - which can only understate it
     t_extract = acc["extract"] / args.steps
     achieved = alg_bytes_img * grid.n_images / t_extract / 1e9
@@ -155,7 +155,7 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
     roofline = {
-        "kernel": "extract (AKAZE) kernel sequence, one batched launch sequence per %d images, 2 sequences in flight"
+        "kernel": "extract (AKAZE) kernel sequence, one batched launch sequence per %d images, up to 3 sequences in flight"
                   % round(imgs_per_launch),
         "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
         "frac": round(achieved / 8000.0, 4), "traffic": traffic,

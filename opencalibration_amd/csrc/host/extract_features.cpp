@@ -159,7 +159,7 @@ uint32_t extract_chunk_size()
         if (v >= 1 && v <= 1024)
             return (uint32_t)v;
     }
-    return 50;
+    return 100;
 }
 
 std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images,
@@ -178,7 +178,7 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
     // result copies over PCIe, table uploads and launch gaps overlap the kernels of the other context's chunk -
     // while this thread's OpenMP team runs the host tail of the finished chunks.  ochip_akaze_batch is a blocking
     // call; every driver owns two result buffers.
-    uint32_t n_drivers = 2;
+    uint32_t n_drivers = 3;
     if (const char *e = std::getenv("OCHIP_EXTRACT_STREAMS"))
         n_drivers = (uint32_t)std::max(1L, std::min(4L, std::atol(e)));
     const uint32_t n_chunks = (n_images + chunk - 1) / chunk;
