@@ -150,7 +150,8 @@ enum
     BLUR_PLAIN = 0,
     BLUR_FLOW = 1,
     BLUR_MODG = 2,
-    BLUR_DERIV = 3
+    BLUR_DERIV = 3,
+    BLUR_FLOW_DERIV = 4 // a level's Lsmooth feeds both its conductivity and its detector derivatives: one pass
 };
 
 // 3-row pattern (wa * a + wb * b) + wa * c of Scharr-type derivatives, samples fetched through `at(x, y)`
@@ -178,6 +179,8 @@ struct blur_args
     const float *kcontrast; // FLOW
     int n_octave_steps;     // FLOW
     unsigned int *partial_max; // MODG: [image][workgroup] bit patterns of the tile maxima
+    float *out2;               // FLOW_DERIV: Ly (out1 = Lx), both with out2_stride; out0 = conductivity with out_stride
+    size_t out2_stride;
 };
 
 template <int MODE, int M /*margin of the blurred tile*/, int R /*tap radius*/>
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
     __syncthreads();
     auto at = [&](int xx, int yy) { return tin[(yy - by0) * BW + (xx - bx0)]; };
     float k = 0.0f, inv = 0.0f, vmax = 0.0f;
-    if (MODE == BLUR_FLOW)
+    if (MODE == BLUR_FLOW || MODE == BLUR_FLOW_DERIV)
     {
         k = A.kcontrast[blockIdx.z];
         for (int i = 0; i < A.n_octave_steps; i++) // kcontrast *= 0.75 at every new octave, one rounding per step
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
         if (x >= w || y >= h)
             continue;
         const size_t o = (size_t)blockIdx.z * A.out_stride + (size_t)y * w + x;
-        if (MODE == BLUR_DERIV)
+        if (MODE == BLUR_DERIV || MODE == BLUR_FLOW_DERIV)
         {
             const float wgt = 10.0f / 3.0f;
             const float nrm = 1.0f / (2.0f * (float)M * (wgt + 2.0f));
@@ -273,10 +276,19 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
                 pattern_xy(at, reflect101_once(x - M, w), x, reflect101_once(x + M, w), reflect101_once(y - M, h), y,
                            reflect101_once(y + M, h), nrm, wn, &dx, &dy);
 
-            A.out0[o] = dx;
-            A.out1[o] = dy;
+            if (MODE == BLUR_DERIV)
+            {
+                A.out0[o] = dx;
+                A.out1[o] = dy;
+            }
+            else
+            {
+                const size_t o2 = (size_t)blockIdx.z * A.out2_stride + (size_t)y * w + x;
+                A.out1[o2] = dx;
+                A.out2[o2] = dy;
+            }
         }
-        else
+        if (MODE != BLUR_DERIV)
         {
             float lx_, ly_;
             if (tiny)
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
             else
                 pattern_xy(at, reflect101_once(x - 1, w), x, reflect101_once(x + 1, w), reflect101_once(y - 1, h), y,
                            reflect101_once(y + 1, h), 3.0f, 10.0f, &lx_, &ly_);
-            if (MODE == BLUR_FLOW)
+            if (MODE == BLUR_FLOW || MODE == BLUR_FLOW_DERIV)
                 A.out0[o] = 1.0f / (1.0f + inv * (lx_ * lx_ + ly_ * ly_));
             else
             {
@@ -1639,7 +1651,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     // ---- contrast factor: Gaussian(1) + gradient magnitude + per-tile maxima in one pass, then the histogram
     OCHIP_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)B * 301 * 4, st));
     {
-        blur_args a{d_img, plane0, d_flow, nullptr, plane0, W, H, nullptr, 0, d_pmax};
+        blur_args a{d_img, plane0, d_flow, nullptr, plane0, W, H, nullptr, 0, d_pmax, nullptr, 0};
         hipLaunchKernelGGL((blur_fused_kernel<BLUR_MODG, 1, 2>), tiles0, dim3(256), 0, st, a, g1);
         hipLaunchKernelGGL(hmax_reduce_kernel, dim3(B), dim3(256), 0, st, (const unsigned int *)d_pmax, n_tiles0, d_hmax);
     }
@@ -1649,7 +1661,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
 
     // ---- nonlinear scale space
     {
-        blur_args a{d_img, plane0, d_Lt + LV.l[0].off, nullptr, img_stride, W, H, nullptr, 0, nullptr};
+        blur_args a{d_img, plane0, d_Lt + LV.l[0].off, nullptr, img_stride, W, H, nullptr, 0, nullptr, nullptr, 0};
         hipLaunchKernelGGL((blur_fused_kernel<BLUR_PLAIN, 0, 4>), tiles0, dim3(256), 0, st, a, g0);
     }
     int octave_steps = 0;
@@ -1675,8 +1687,20 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             octave_steps++;
         }
         {
-            blur_args a{src, src_stride, d_flow, nullptr, plane0, l.w, l.h, d_kc, octave_steps, nullptr};
-            hipLaunchKernelGGL((blur_fused_kernel<BLUR_FLOW, 1, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
+            // Lsmooth of the level (Gaussian(1) of the image it starts from) -> conductivity AND the detector's
+            // scale-s derivatives Lx, Ly (AKAZE computes both on evolution[i].Lsmooth), one pass
+            blur_args a{src, src_stride, d_flow, d_Lx + l.off, plane0, l.w, l.h, d_kc, octave_steps, nullptr, d_Ly + l.off, img_stride};
+            if (l.sigma_size == 2)
+                hipLaunchKernelGGL((blur_fused_kernel<BLUR_FLOW_DERIV, 2, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
+            else if (l.sigma_size == 3)
+                hipLaunchKernelGGL((blur_fused_kernel<BLUR_FLOW_DERIV, 3, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
+            else if (l.sigma_size == 4)
+                hipLaunchKernelGGL((blur_fused_kernel<BLUR_FLOW_DERIV, 4, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
+            else
+            {
+                cleanup();
+                return ochip_fail(ctx, OCHIP_EINVAL, "akaze: derivative scale %d outside 2..4", l.sigma_size);
+            }
         }
         if (n_steps == 0)
             hipLaunchKernelGGL(copy_plane_kernel, dim3((unsigned)((np + 255) / 256), 1, B), dim3(256), 0, st, src, src_stride,
@@ -1714,14 +1738,20 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     for (int i = 0; i < LV.n; i++)
     {
         const level_info &l = LV.l[i];
+        if (i == 0)
         {
-            blur_args a{d_Lt + l.off, img_stride, d_Lx + l.off, d_Ly + l.off, img_stride, l.w, l.h, nullptr, 0, nullptr};
+            // level 0's Lsmooth is its Lt: derivatives without a further blur (a one-tap identity kernel keeps the
+            // same code path; 0 + 1 * x is exact)
+            taps_t one{};
+            one.n = 1;
+            one.k[0] = 1.0f;
+            blur_args a{d_Lt + l.off, img_stride, d_Lx + l.off, d_Ly + l.off, img_stride, l.w, l.h, nullptr, 0, nullptr, nullptr, 0};
             if (l.sigma_size == 2)
-                hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 2, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
+                hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 2, 0>), tiles(l.w, l.h), dim3(256), 0, st, a, one);
             else if (l.sigma_size == 3)
-                hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 3, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
+                hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 3, 0>), tiles(l.w, l.h), dim3(256), 0, st, a, one);
             else if (l.sigma_size == 4)
-                hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 4, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
+                hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 4, 0>), tiles(l.w, l.h), dim3(256), 0, st, a, one);
             else
             {
                 cleanup();

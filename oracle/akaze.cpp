@@ -363,7 +363,13 @@ ScaleSpace build_scale_space(const std::vector<float> &img, int w, int h, const 
     float kcontrast = compute_k_percentile(img, w, h, o);
     ss.kcontrast = kcontrast;
     const std::vector<float> g1 = gaussian_kernel(o.sderivatives);
-    std::vector<float> sm, flow, nxt;
+    // Lsmooth of every level: what the conductivity AND the detector's multiscale derivatives are computed on
+    // (AKAZE's Compute_Multiscale_Derivatives works on evolution[i].Lsmooth).  It is the Gaussian(1) smoothing of the
+    // image the level STARTS from - the previous level's result, half-sampled at a new octave - taken before the
+    // level's own diffusion steps; level 0's Lsmooth is its Lt.
+    std::vector<std::vector<float>> Lsmooth(N);
+    Lsmooth[0] = ss.Lt[0];
+    std::vector<float> flow, nxt;
     for (size_t i = 1; i < N; i++)
     {
         const Level &l = ss.levels[i], &p = ss.levels[i - 1];
@@ -374,8 +380,8 @@ ScaleSpace build_scale_space(const std::vector<float> &img, int w, int h, const 
         }
         else
             ss.Lt[i] = ss.Lt[i - 1];
-        gaussian_blur(ss.Lt[i], sm, l.width, l.height, g1);
-        pm_g2_flow(sm, flow, l.width, l.height, kcontrast);
+        gaussian_blur(ss.Lt[i], Lsmooth[i], l.width, l.height, g1);
+        pm_g2_flow(Lsmooth[i], flow, l.width, l.height, kcontrast);
         for (float tau : l.tsteps)
         {
             nld_step(ss.Lt[i], flow, nxt, l.width, l.height, tau);
@@ -386,8 +392,7 @@ ScaleSpace build_scale_space(const std::vector<float> &img, int w, int h, const 
     for (size_t i = 0; i < N; i++)
     {
         const Level &l = ss.levels[i];
-        gaussian_blur(ss.Lt[i], sm, l.width, l.height, g1);
-        deriv_scale(sm, ss.Lx[i], ss.Ly[i], l.width, l.height, l.sigma_size);
+        deriv_scale(Lsmooth[i], ss.Lx[i], ss.Ly[i], l.width, l.height, l.sigma_size);
         deriv_scale(ss.Lx[i], lxx, lxy, l.width, l.height, l.sigma_size);
         deriv_scale(ss.Ly[i], tmp, lyy, l.width, l.height, l.sigma_size);
         const float s4 = (float)(l.sigma_size * l.sigma_size * l.sigma_size * l.sigma_size);
