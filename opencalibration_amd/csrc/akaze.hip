@@ -502,7 +502,7 @@ template <int S>
 __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict__ Lx, const float *__restrict__ Ly, size_t stride,
                                                          float *__restrict__ Ldet, float *__restrict__ Rmax, int w, int h,
                                                          float thr, unsigned int *__restrict__ tile_counts, int tile_off,
-                                                         int n_tiles)
+                                                         int n_tiles, float margin)
 {
     constexpr int HW = S + 1, RW = BT_X + 2 * HW, RH = DT_Y + 2 * HW, DW = BT_X + 2, DH = DT_Y + 2;
     __shared__ float tx[RW * RH], ty[RW * RH];
@@ -577,7 +577,11 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
         if (x >= w || y >= h)
             continue;
         float out = 0.0f;
-        if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1)
+        // interior pixel whose descriptor window [round(x - margin) - 1, round(x + margin) + 1] stays inside the level
+        // image (AKAZE's Find_Scale_Space_Extrema; margin = 10 sqrt(2) * sigma_size)
+        const bool in_bounds = (int)rintf((float)x - margin) - 1 >= 0 && (int)rintf((float)x + margin) + 1 < w &&
+                               (int)rintf((float)y - margin) - 1 >= 0 && (int)rintf((float)y + margin) + 1 < h;
+        if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1 && in_bounds)
         {
             const int ci = (ly + 1) * DW + (lx + 1);
             const float v = td[ci];
@@ -1761,15 +1765,16 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         {
             const float *lx = d_Lx + l.off, *ly = d_Ly + l.off;
             float *ld = d_Ldet + l.off, *rm = d_Rmax + l.off;
+            const float margin = (10.0f * std::sqrt(2.0f)) * (float)l.sigma_size; // descriptor window half width, M-LDB
             if (l.sigma_size == 2)
                 hipLaunchKernelGGL((det_maxima_kernel<2>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
-                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles);
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin);
             else if (l.sigma_size == 3)
                 hipLaunchKernelGGL((det_maxima_kernel<3>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
-                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles);
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin);
             else
                 hipLaunchKernelGGL((det_maxima_kernel<4>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
-                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles);
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin);
         }
     }
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(B), dim3(256), 0, st, (const unsigned int *)d_tile_counts,

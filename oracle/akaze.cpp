@@ -482,11 +482,17 @@ std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o
         const Level &l = ss.levels[i];
         const float *D = ss.Ldet[i].data();
         const int w = l.width, h = l.height;
+        // AKAZE's Find_Scale_Space_Extrema drops points whose descriptor window would leave the level image:
+        // [round(x - smax s) - 1, round(x + smax s) + 1] must lie inside, smax = 10 sqrt(2) for M-LDB, s = sigma_size
+        const float margin = (10.0f * std::sqrt(2.0f)) * (float)l.sigma_size;
         for (int y = 1; y < h - 1; y++)
             for (int x = 1; x < w - 1; x++)
             {
                 const float v = D[(size_t)y * w + x];
                 if (!(v > o.dthreshold))
+                    continue;
+                if ((int)std::rint((float)x - margin) - 1 < 0 || (int)std::rint((float)x + margin) + 1 >= w ||
+                    (int)std::rint((float)y - margin) - 1 < 0 || (int)std::rint((float)y + margin) + 1 >= h)
                     continue;
                 bool mx = true;
                 for (int dy = -1; dy <= 1 && mx; dy++)
