@@ -870,6 +870,7 @@ struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cell
     unsigned int bits[512];  // bit -> a | b << 8 | channel << 16 (one dword per comparison; entries >= 486 unused)
     unsigned int ori_q[128]; // orientation samples: position (i + 6) * 13 + (j + 6) of the n-th member of the radius-6 disc
     float ori_g[128];        // and its Gaussian weight
+    float win_ang1[64];      // start angles of the 42 orientation windows: for (a = 0; a < 2 pi; a += 0.15f)
 };
 
 // One 64-thread workgroup per surviving candidate: sub-pixel fit, dominant orientation, 486-bit M-LDB.
@@ -970,7 +971,7 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
     float wmag = -1.0f, wangle = 0.0f;
     if (lane < 42)
     {
-        const float ang1 = 0.15f * (float)lane;
+        const float ang1 = tab->win_ang1[lane]; // float-accumulated window starts (host table, as the restatement's loop)
         const float ang2 = (ang1 + PI_F / 3.0f > TWO_PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
         // the window as two open intervals: (ang1, ang2) and nothing, or - wrapped - (0, ang2) and (ang1, 2 pi);
         // written without short-circuits so that the loop has no branches and its LDS reads are issued in batches
@@ -1581,6 +1582,16 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                         tab.bits[dpos] = (unsigned int)(base[lvl] + a) | ((unsigned int)(base[lvl] + bb) << 8) | ((unsigned int)ch << 16);
                         dpos++;
                     }
+        }
+        {
+            int nw = 0;
+            for (float a1 = 0.0f; a1 < 6.28318530717958647692f && nw < 64; a1 += 0.15f)
+                tab.win_ang1[nw++] = a1;
+            if (nw != 42)
+            {
+                cleanup();
+                return ochip_fail(ctx, OCHIP_EINVAL, "akaze: %d orientation windows instead of 42", nw);
+            }
         }
         int nq = 0;
         for (int q = 0; q < 169; q++)

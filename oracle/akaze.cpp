@@ -601,9 +601,10 @@ std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o
                     idx++;
                 }
         float best = 0.0f, angle = 0.0f;
-        for (int step = 0; step < 42; step++)
+        // for (ang1 = 0; ang1 < 2 pi; ang1 += 0.15f), as AKAZE's Compute_Main_Orientation steps its window: the start
+        // angles are the float-accumulated sums (42 of them), not multiples of 0.15
+        for (float ang1 = 0.0f; ang1 < TWO_PI_F; ang1 += 0.15f)
         {
-            const float ang1 = 0.15f * (float)step;
             const float ang2 = (ang1 + PI_F / 3.0f > TWO_PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
             float sumX = 0.0f, sumY = 0.0f;
             for (int q = 0; q < 109; q++)
