@@ -127,9 +127,10 @@ def main():
     #   source: BGR read (3 B/px) + grey write/read (2 B/px) at full resolution, working image write (4 B/px)
     #   k-contrast: image read, gradient magnitude write + read                            3 floats / working px
     #   level 0: Gaussian(1.6) read + write                                               2
-    #   per evolution level: conductivity (read L, write c) 2; FED steps: 3 (read L, c; write L) per group of <= 4
-    #     steps (steps fused in registers are not charged: the figure is what the pass structure must move)
-    #   per level detection: derivatives (read L, write Lx, Ly) 3, determinant (read Lx, Ly, write) 3, maxima (r, w) 2
+    #   per evolution level: Lsmooth pass (read L; write conductivity, Lx, Ly) 4; FED steps: 3 (read L, c; write L) per
+    #     group of <= 4 steps (steps fused in registers are not charged: the figure is what the pass structure must move)
+    #   level 0: derivatives (read L, write Lx, Ly) 3
+    #   per level detection: determinant (read Lx, Ly, write) 3, maxima (r, w) 2
     #   per level description: maxima map read once (list + suppression) 1, L / Lx / Ly read once by the sampler 3
     sc = min(1.0, 1600.0 / max(w, h))
     W, H = int(round(w * sc)), int(round(h * sc))
@@ -139,7 +140,7 @@ def main():
     px_floats = 5.0 * W * H
     for lvl in range(16):
         px = (W >> (lvl // 4)) * (H >> (lvl // 4))
-        px_floats += px * (12 + (2 + 3 * ((fed[lvl] + 3) // 4) if lvl else 0))
+        px_floats += px * (9 + (4 + 3 * ((fed[lvl] + 3) // 4) if lvl else 3))
     alg_bytes_img = 4.0 * px_floats + w * h * 5.0
     imgs_per_launch = grid.n_images * args.steps / max(n_akaze, 1)
     avg_ms_akaze = ms_akaze / max(n_akaze, 1)          # HIP events around one chunk's launch sequence, on its stream
