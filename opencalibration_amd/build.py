@@ -44,7 +44,8 @@ def build_host(force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(hdir, "*.cpp")))
     if not srcs:
         return None
-    deps = srcs + glob.glob(os.path.join(hdir, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    deps = srcs + glob.glob(os.path.join(hdir, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
+        glob.glob(os.path.join(HERE, "..", "include", "*.h"))   # csrc/undistort.hpp is shared with the device side
     out = os.path.join(HERE, "liboc_host.so")
     if force or _stale(out, deps):
         cmd = ["g++", *HOST_FLAGS, "-shared", "-o", out, *srcs, "-I", os.path.join(HERE, "..", "include"),
