@@ -169,6 +169,21 @@ __device__ __forceinline__ void pattern_xy(F at, int xm, int x, int xp, int ym, 
     *dy = (wa * d + wb * e) + wa * f;
 }
 
+// the same pattern on an LDS tile whose row stride and sample distance are compile-time constants: every access is
+// the centre address plus an immediate offset (tiles away from the image border need no reflection)
+template <int D, int STRIDE>
+__device__ __forceinline__ void pattern_lds(const float *c, float wa, float wb, float *dx, float *dy)
+{
+    const float a = c[-D * STRIDE + D] - c[-D * STRIDE - D];
+    const float b = c[D] - c[-D];
+    const float cc = c[D * STRIDE + D] - c[D * STRIDE - D];
+    *dx = (wa * a + wb * b) + wa * cc;
+    const float d = c[D * STRIDE - D] - c[-D * STRIDE - D];
+    const float e = c[D * STRIDE] - c[-D * STRIDE];
+    const float f = c[D * STRIDE + D] - c[-D * STRIDE + D];
+    *dy = (wa * d + wb * e) + wa * f;
+}
+
 struct blur_args
 {
     const float *in;
@@ -255,6 +270,54 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
         inv = 1.0f / (k * k);
     }
     const bool tiny = w <= 2 * M + 2 || h <= 2 * M + 2; // uniform: only then can an index need more than one reflection
+    // uniform per workgroup: the tile and its stencil margin lie inside the image, so nothing reflects and every
+    // pixel exists - the consumer then reads the blurred tile at fixed offsets from its own position
+    const bool inner_tile = M > 0 && bx0 >= 0 && by0 >= 0 && x0 + BT_X + M <= w && y0 + BT_Y + M <= h;
+    if (inner_tile)
+    {
+#pragma unroll 4
+        for (int idx = threadIdx.x; idx < BT_X * BT_Y; idx += 256)
+        {
+            const int ly = idx / BT_X, lx = idx - ly * BT_X;
+            const int x = x0 + lx, y = y0 + ly;
+            const float *c = &tin[(ly + M) * BW + (lx + M)];
+            const size_t o = (size_t)blockIdx.z * A.out_stride + (size_t)y * w + x;
+            if (MODE == BLUR_DERIV || MODE == BLUR_FLOW_DERIV)
+            {
+                const float wgt = 10.0f / 3.0f;
+                const float nrm = 1.0f / (2.0f * (float)M * (wgt + 2.0f));
+                const float wn = wgt * nrm;
+                float dx, dy;
+                pattern_lds<(M > 0 ? M : 1), BW>(c, nrm, wn, &dx, &dy);
+                if (MODE == BLUR_DERIV)
+                {
+                    A.out0[o] = dx;
+                    A.out1[o] = dy;
+                }
+                else
+                {
+                    const size_t o2 = (size_t)blockIdx.z * A.out2_stride + (size_t)y * w + x;
+                    A.out1[o2] = dx;
+                    A.out2[o2] = dy;
+                }
+            }
+            if (MODE != BLUR_DERIV)
+            {
+                float lx_, ly_;
+                pattern_lds<1, BW>(c, 3.0f, 10.0f, &lx_, &ly_);
+                if (MODE == BLUR_FLOW || MODE == BLUR_FLOW_DERIV)
+                    A.out0[o] = 1.0f / (1.0f + inv * (lx_ * lx_ + ly_ * ly_));
+                else
+                {
+                    const bool interior = x >= 1 && x < w - 1 && y >= 1 && y < h - 1;
+                    const float m = interior ? sqrtf(lx_ * lx_ + ly_ * ly_) : 0.0f;
+                    A.out0[o] = m;
+                    vmax = fmaxf(vmax, m);
+                }
+            }
+        }
+    }
+    else
 #pragma unroll 4
     for (int idx = threadIdx.x; idx < BT_X * BT_Y; idx += 256)
     {
@@ -542,6 +605,26 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
     auto atx = [&](int xx, int yy) { return tx[(yy - ry0) * RW + (xx - rx0)]; };
     auto aty = [&](int xx, int yy) { return ty[(yy - ry0) * RW + (xx - rx0)]; };
     const bool tiny = w <= 2 * S + 2 || h <= 2 * S + 2; // uniform: only then can an index need more than one reflection
+    // uniform per workgroup: tile + halo inside the image -> no reflection, every pixel exists, fixed LDS offsets
+    const bool inner_tile = rx0 >= 0 && ry0 >= 0 && x0 + BT_X + HW <= w && y0 + DT_Y + HW <= h;
+    if (inner_tile)
+    {
+#pragma unroll 3
+        for (int idx = threadIdx.x; idx < DW * DH; idx += 256)
+        {
+            const int ly = idx / DW, lx = idx - ly * DW;
+            const int x = x0 - 1 + lx, y = y0 - 1 + ly;
+            const int ci = (ly + S) * RW + (lx + S); // (x, y) in the Lx / Ly tiles: their origin is (x0 - S - 1, y0 - S - 1)
+            float lxx, lxy, tmp, lyy;
+            pattern_lds<S, RW>(&tx[ci], nrm, wn, &lxx, &lxy);
+            pattern_lds<S, RW>(&ty[ci], nrm, wn, &tmp, &lyy);
+            const float d = (lxx * lyy - lxy * lxy) * s4;
+            td[idx] = d;
+            if (lx >= 1 && lx <= BT_X && ly >= 1 && ly <= DT_Y)
+                Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = d;
+        }
+    }
+    else
 #pragma unroll 3
     for (int idx = threadIdx.x; idx < DW * DH; idx += 256)
     {
