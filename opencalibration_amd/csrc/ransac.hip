@@ -734,8 +734,10 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
     ochip_prof_begin(ctx, OCHIP_K_RANSAC, &e0, &e1);
     static const int occ = []() {
         const char *e = getenv("OCHIP_RANSAC_OCC"); // waves per SIMD the register allocator targets (tuning knob)
-        const int v = e ? atoi(e) : 4;
-        return (v == 1 || v == 2 || v == 4) ? v : 4;
+        // 2: with ~1 200 matches per pair a pair's LU workspace is ~170 KB, and more than ~2 000 resident pairs push
+        // the combined working set out of the 256 MB Infinity Cache (C3: 160 ms per 9 000 pairs at 2, 209 ms at 4)
+        const int v = e ? atoi(e) : 2;
+        return (v == 1 || v == 2 || v == 4) ? v : 2;
     }();
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(n_jobs), dim3(W), 0, ctx->stream,
