@@ -9,10 +9,11 @@
 // FED step sizes, orientation weights are computed on the host in double) and every float32 operation
 // order (no FMA, no device transcendentals), so level images, keypoints and descriptors are bit-identical.
 //
-// All stencil passes are HBM-streaming kernels over [image][y][x] float planes, 256-thread workgroups
-// walking rows (coalesced 4-byte lanes; the 3..13-tap neighbourhoods are served by L1/L2).  One launch
-// covers the whole batch (blockIdx.z = image) so a 1 000-image job needs ~200 launches per batch of B
-// images instead of per image.
+// All planes are [image][y][x] float and one launch covers the whole batch (blockIdx.z = image), ~170 launches
+// per batch.  The stencil passes are LDS-tiled and fused with their consumers (Gaussian + conductivity +
+// derivatives; determinant + maxima), the diffusion steps run up to four at a time out of registers, the
+// candidate list is built without global atomics in a space-filling tile order, and a wavefront per
+// candidate does suppression and description.  DESIGN.md section 4.4 has the per-kernel numbers.
 #include "ctx.hpp"
 
 #include <cmath>

@@ -123,7 +123,10 @@ std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph
     size_t n = keep_debug ? 1 : std::min<size_t>((size_t)_runners, std::max<size_t>(1, _links.size() / 64));
     static const size_t sub_env = std::getenv("OCHIP_LINK_SUBBATCHES") ? (size_t)std::atoi(std::getenv("OCHIP_LINK_SUBBATCHES")) : 1;
     const size_t sub = keep_debug ? 1 : std::max<size_t>(1, std::min<size_t>(sub_env, _links.size() / (n * 64)));
-    const int omp_threads = std::max(1, omp_get_max_threads() / (int)n);
+    // share of the OpenMP team per runner: OCHIP_LINK_TEAM_SHARE = 1 gives every runner the whole team (their host
+    // phases rarely coincide), the default divides it
+    static const bool whole_team = std::getenv("OCHIP_LINK_TEAM_SHARE") && std::atoi(std::getenv("OCHIP_LINK_TEAM_SHARE")) == 1;
+    const int omp_threads = whole_team ? omp_get_max_threads() : std::max(1, omp_get_max_threads() / (int)n);
     for (size_t r = 0; r < n; r++)
     {
         const size_t begin = _links.size() * r / n, end = _links.size() * (r + 1) / n;
