@@ -72,6 +72,17 @@ extern "C"
                               int height, uint32_t max_keypoints, int images_on_device, uint32_t model,
                               const double *positions, uint64_t *node_ids_out, double *totals2);
 
+    /* Load and link overlapped, the way the reference's pipeline overlaps the stages of consecutive image batches
+     * (src/pipeline/pipeline.cpp:522-570): nodes are created first (positions, optional orientations n x 4, model),
+     * extraction streams chunk by chunk, and every range of links whose images all have their features is linked on
+     * its own device context while later chunks are still being extracted.  The graph is the one och_graph_load_images
+     * followed by och_link_stage_run produces.  link_timers8 as och_link_stage_run; stage_seconds2 = {seconds until
+     * the last features were final, seconds until the graph was linked}.  Any output pointer may be NULL. */
+    int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width,
+                                   int height, uint32_t max_keypoints, int images_on_device, uint32_t model,
+                                   const double *positions, const double *orientations, uint64_t *node_ids_out,
+                                   double *totals2, double *link_timers8, double *stage_seconds2);
+
     /* ---- relax (opencalibration_amd/csrc/host/relax.hpp): relax(graph, nodes, cam_models, edges,
      *      {ORIENTATION, GROUND_PLANE}, {}) of src/relax/relax.cpp:122-134 ------------------------------ */
     /* Stand-alone problem from flat arrays.  graph: n_nodes x {pos3, ori4 xyzw (may be NaN)} + one shared

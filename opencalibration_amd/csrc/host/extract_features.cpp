@@ -167,8 +167,31 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
                                                        bool images_on_device)
 {
     std::vector<extracted_features> out(n_images);
-    if (n_images == 0 || width <= 0 || height <= 0) // image.empty(): {results, 0}, extract_features.cpp:20-23
-        return out;
+    const bool ok = extract_features_stream(ctx, images_bgr, n_images, width, height, max_keypoints, images_on_device, 0,
+                                            [&](uint32_t first, uint32_t count, extracted_features *f) {
+                                                for (uint32_t i = 0; i < count; i++)
+                                                    out[first + i] = std::move(f[i]);
+                                            },
+                                            error);
+    if (!ok)
+        return {};
+    return out;
+}
+
+bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
+                             uint32_t max_keypoints, bool images_on_device, int host_threads,
+                             const std::function<void(uint32_t, uint32_t, extracted_features *)> &on_chunk,
+                             std::string *error)
+{
+    if (n_images == 0)
+        return true;
+    if (width <= 0 || height <= 0) // image.empty(): {results, 0}, extract_features.cpp:20-23
+    {
+        std::vector<extracted_features> empty(n_images);
+        on_chunk(0, n_images, empty.data());
+        return true;
+    }
+    const int tail_threads = host_threads > 0 ? host_threads : omp_get_max_threads();
     const int max_length_pixels = 1600;
     const double scale = std::min(1.f, float(max_length_pixels) / (float)std::max(width, height));
     const uint32_t chunk = std::min(extract_chunk_size(), n_images);
@@ -189,7 +212,7 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
         {
             if (error)
                 *error = std::string("ochip_ctx_sibling: ") + ochip_last_error(ctx);
-            return {};
+            return false;
         }
     const uint32_t n_bufs = 2 * n_drivers;
     std::vector<chunk_buffers> bufs(n_bufs);
@@ -220,7 +243,7 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
             release();
             if (error)
                 *error = std::string("ochip_host_alloc: ") + ochip_last_error(buf_ctx[i]);
-            return {};
+            return false;
         }
         b.kp = (float *)p;
         b.desc = (uint64_t *)q;
@@ -289,20 +312,23 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
         }
         chunk_buffers &b = bufs[which];
         double cpu = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : cpu)
+        std::vector<extracted_features> done(b.n);
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : cpu) num_threads(tail_threads)
         for (uint32_t i = 0; i < b.n; i++)
         {
             const double t0 = omp_get_wtime();
             extract_tail(b.kp + (size_t)i * max_keypoints * 6, b.desc + (size_t)i * max_keypoints * 8, b.counts[i], scale,
-                         out[b.first + i]);
+                         done[i]);
             cpu += omp_get_wtime() - t0;
         }
         tail_cpu_seconds += cpu;
+        const uint32_t chunk_first = b.first, chunk_n = b.n;
         {
             std::unique_lock<std::mutex> lk(mu);
             buffer_free[which] = 1;
             cv.notify_all();
         }
+        on_chunk(chunk_first, chunk_n, done.data()); // the device is already busy with the next chunks
     }
     for (auto &t : drivers)
         t.join();
@@ -314,9 +340,9 @@ std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uin
     {
         if (error)
             *error = fail;
-        return {};
+        return false;
     }
-    return out;
+    return true;
 }
 
 } // namespace opencalibration_amd

@@ -5,6 +5,7 @@
 
 #include "../../../include/ochip.h"
 
+#include <functional>
 #include <string>
 
 namespace opencalibration_amd
@@ -24,5 +25,14 @@ struct extracted_features // extract_features.hpp:10-15
 std::vector<extracted_features> extract_features_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images,
                                                        int width, int height, uint32_t max_keypoints, std::string *error,
                                                        bool images_on_device = false);
+
+// The same, streaming: `on_chunk(first, count, features)` is called (from the calling thread, chunks in completion
+// order) as soon as the features of images [first, first + count) are final, while later chunks are still on the
+// device; `features` points at the `count` results, which the callback may move from.  host_threads caps the OpenMP
+// team of the host tail (0 = the whole team).  Returns false and sets *error on a device error.
+bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
+                             uint32_t max_keypoints, bool images_on_device, int host_threads,
+                             const std::function<void(uint32_t, uint32_t, extracted_features *)> &on_chunk,
+                             std::string *error);
 
 } // namespace opencalibration_amd

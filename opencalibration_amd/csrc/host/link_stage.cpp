@@ -83,14 +83,13 @@ void LinkStage::init(const MeasurementGraph &graph, const std::vector<size_t> &n
     timers.link_init += since(t0);
 }
 
-void LinkStage::prepare(const MeasurementGraph &graph)
+void LinkStage::prepare_index(const MeasurementGraph &graph)
 {
-    const auto t0 = clk::now();
     _prepared_index.clear();
-    std::vector<size_t> ids;
+    size_t n = 0;
     auto add = [&](size_t id) {
-        if (graph.getNode(id) != nullptr && _prepared_index.emplace(id, ids.size()).second)
-            ids.push_back(id);
+        if (graph.getNode(id) != nullptr && _prepared_index.emplace(id, n).second)
+            n++;
     };
     for (const auto &link : _links)
     {
@@ -98,19 +97,46 @@ void LinkStage::prepare(const MeasurementGraph &graph)
         for (size_t m : link.link_ids)
             add(m);
     }
-    _subsets.assign(ids.size(), {});
-    _rays.assign(ids.size(), {});
+    _subsets.assign(n, {});
+    _rays.assign(n, {});
+}
+
+void LinkStage::prepare_images(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, int threads)
+{
+    const auto t0 = clk::now();
     const double coarse_spacing_pixels = 40.0;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (size_t s = 0; s < ids.size(); s++)
+    const int nt = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
+    for (size_t k = 0; k < node_ids.size(); k++)
     {
-        const image &img = graph.getNode(ids[s])->payload;
+        const auto it = _prepared_index.find(node_ids[k]);
+        if (it == _prepared_index.end())
+            continue;
+        const size_t s = it->second;
+        const image &img = graph.getNode(node_ids[k])->payload;
         _subsets[s] = spatially_subsample_feature_indices(img.features, coarse_spacing_pixels, img.num_sparse_features);
         _rays[s].resize(_subsets[s].size() * 3);
-        for (size_t k = 0; k < _subsets[s].size(); k++)
-            image_to_3d(img.features[_subsets[s][k]].location, *img.model, &_rays[s][3 * k]);
+        for (size_t q = 0; q < _subsets[s].size(); q++)
+            image_to_3d(img.features[_subsets[s][q]].location, *img.model, &_rays[s][3 * q]);
     }
-    timers.subsample += since(t0);
+    const double dt = since(t0);
+    std::lock_guard<std::mutex> lock(_measurement_mutex);
+    timers.subsample += dt;
+}
+
+void LinkStage::prepare(const MeasurementGraph &graph)
+{
+    prepare_index(graph);
+    std::vector<size_t> ids(_prepared_index.size());
+    for (const auto &kv : _prepared_index)
+        ids[kv.second] = kv.first;
+    prepare_images(graph, ids, 0);
+}
+
+void LinkStage::run_range(const MeasurementGraph &graph, size_t link_begin, size_t link_end, ochip_ctx *ctx, int omp_threads)
+{
+    if (link_end > link_begin)
+        run_batch(graph, link_begin, link_end, ctx, std::max(1, omp_threads));
 }
 
 std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph &graph)

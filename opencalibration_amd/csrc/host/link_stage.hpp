@@ -57,6 +57,17 @@ class LinkStage
     // link_stage.cpp:119-143
     std::vector<size_t> finalize(MeasurementGraph &graph);
 
+    // Streaming use (host/load_link.cpp): after init(), prepare_index() once, then - as the features of images
+    // arrive - prepare_images() for them and run_range() for every range of links whose images are all prepared
+    // (any thread, one device context per concurrent call), then finalize().
+    void prepare_index(const MeasurementGraph &graph);
+    void prepare_images(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, int threads);
+    void run_range(const MeasurementGraph &graph, size_t link_begin, size_t link_end, ochip_ctx *ctx, int omp_threads);
+    const std::vector<NodeLinks> &links() const
+    {
+        return _links;
+    }
+
     bool keep_debug = false;
     std::vector<pair_debug> debug;
     LinkTimers timers; // summed over the concurrent runners (so the phases can add up to more than the wall time)

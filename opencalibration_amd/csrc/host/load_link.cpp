@@ -1,0 +1,203 @@
+// Load and link stages overlapped, as the reference's pipeline overlaps the stages of consecutive image batches
+// (Pipeline::Impl::initial_processing runs the load, link and relax closures of different batches side by side,
+// src/pipeline/pipeline.cpp:522-570).  The images of one survey are extracted chunk by chunk on the device; as soon
+// as every image a range of links touches (the source images and their kNN neighbours) has its features, that range
+// is handed to a link runner on its own device context.  The link kernels then share the device with the extraction
+// of later chunks, and the host phases of linking (ratio test + std::sort, decompose, assembleInliers) hide under
+// device time that is needed anyway.  The resulting graph is the one the two stages produce one after the other:
+// nodes in image order, edges in LinkStage::finalize's deterministic order.
+#include "../../../include/oc_host.h"
+
+#include "capi_graph.hpp"
+#include "extract_features.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+#include <omp.h>
+
+using namespace opencalibration_amd;
+
+extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width,
+                                          int height, uint32_t max_keypoints, int images_on_device, uint32_t model,
+                                          const double *positions, const double *orientations, uint64_t *node_ids_out,
+                                          double *totals2, double *link_timers8, double *stage_seconds2)
+{
+    using clk = std::chrono::steady_clock;
+    auto seconds_since = [](clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); };
+    if (!g || !ctx || (n_images && (!images_bgr || !positions)) || model >= g->models.size())
+    {
+        if (g)
+            g->error = "och_graph_load_link_images: bad argument";
+        return -1;
+    }
+    const auto t_begin = clk::now();
+    // ---- nodes first (positions and camera model are known before any pixel is touched): the link stage's kNN only
+    //      needs those, and the node ids come out in image order as with the one-after-the-other path
+    std::vector<size_t> ids(n_images);
+    for (uint32_t b = 0; b < n_images; b++)
+    {
+        image img;
+        img.model = g->models[model];
+        for (int i = 0; i < 3; i++)
+            img.position[i] = positions[3 * (size_t)b + i];
+        if (orientations)
+            for (int i = 0; i < 4; i++)
+                img.orientation[i] = orientations[4 * (size_t)b + i];
+        img.path = "image_" + std::to_string(g->graph.size_nodes());
+        ids[b] = g->graph.addNode(std::move(img));
+        if (node_ids_out)
+            node_ids_out[b] = ids[b];
+    }
+    g->link = std::make_unique<LinkStage>(ctx);
+    LinkStage &link = *g->link;
+    link.init(g->graph, ids);
+    link.prepare_index(g->graph);
+    const auto &links = link.links();
+
+    // ---- ranges of links and the images each one waits for
+    std::unordered_map<size_t, uint32_t> image_of; // node id -> image index
+    for (uint32_t b = 0; b < n_images; b++)
+        image_of.emplace(ids[b], b);
+    const char *env = std::getenv("OCHIP_STREAM_LINK_RANGE");
+    const size_t range_len = std::max<size_t>(32, env ? (size_t)std::atol(env) : 125);
+    struct range
+    {
+        size_t begin, end;
+        uint32_t waiting; // images not ready yet
+    };
+    std::vector<range> ranges;
+    std::vector<std::vector<uint32_t>> ranges_of_image(n_images); // image -> ranges that need it
+    for (size_t first = 0; first < links.size(); first += range_len)
+    {
+        range r{first, std::min(links.size(), first + range_len), 0};
+        std::vector<uint32_t> need;
+        for (size_t i = r.begin; i < r.end; i++)
+        {
+            need.push_back(image_of.at(links[i].node_id));
+            for (size_t m : links[i].link_ids)
+            {
+                auto it = image_of.find(m);
+                if (it != image_of.end())
+                    need.push_back(it->second);
+            }
+        }
+        std::sort(need.begin(), need.end());
+        need.erase(std::unique(need.begin(), need.end()), need.end());
+        r.waiting = (uint32_t)need.size();
+        for (uint32_t im : need)
+            ranges_of_image[im].push_back((uint32_t)ranges.size());
+        ranges.push_back(r);
+    }
+
+    // ---- link runners: each owns a device context (siblings 4.. of ctx; extraction uses ctx and its first siblings)
+    const char *renv = std::getenv("OCHIP_LINK_RUNNERS");
+    const int n_runners = std::max(1, std::min(8, renv ? std::atoi(renv) : 3));
+    const int team = omp_get_max_threads();
+    const int tail_threads = std::max(1, team / 2), runner_threads = std::max(1, team / (2 * n_runners) + 1);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<uint32_t> ready;
+    bool no_more = false;
+    std::string fail;
+    std::vector<std::thread> runners;
+    for (int r = 0; r < n_runners; r++)
+    {
+        ochip_ctx *rctx = nullptr;
+        if (ochip_ctx_sibling(ctx, (uint32_t)(4 + r), &rctx) != OCHIP_OK)
+        {
+            g->error = std::string("ochip_ctx_sibling: ") + ochip_last_error(ctx);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                no_more = true;
+            }
+            cv.notify_all();
+            for (auto &t : runners)
+                t.join();
+            return -1;
+        }
+        runners.emplace_back([&, rctx]() {
+            for (;;)
+            {
+                uint32_t k;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !ready.empty() || no_more; });
+                    if (ready.empty())
+                        return;
+                    k = ready.front();
+                    ready.pop_front();
+                }
+                link.run_range(g->graph, ranges[k].begin, ranges[k].end, rctx, runner_threads);
+            }
+        });
+    }
+
+    // ---- extraction; every finished chunk fills its nodes, prepares their 40 px subsets and releases the ranges
+    //      that were only waiting for these images
+    double total = 0, sparse = 0, t_extract_done = 0;
+    const bool ok = extract_features_stream(
+        ctx, images_bgr, n_images, width, height, max_keypoints, images_on_device != 0, tail_threads,
+        [&](uint32_t first, uint32_t count, extracted_features *f) {
+            std::vector<size_t> chunk_ids(count);
+            for (uint32_t i = 0; i < count; i++)
+            {
+                image &img = g->graph.getNode(ids[first + i])->payload;
+                total += (double)f[i].features.size();
+                sparse += (double)f[i].num_sparse_features;
+                img.features = std::move(f[i].features);
+                img.num_sparse_features = f[i].num_sparse_features;
+                chunk_ids[i] = ids[first + i];
+            }
+            link.prepare_images(g->graph, chunk_ids, tail_threads);
+            std::lock_guard<std::mutex> lk(mu);
+            for (uint32_t i = 0; i < count; i++)
+                for (uint32_t k : ranges_of_image[first + i])
+                    if (--ranges[k].waiting == 0)
+                        ready.push_back(k);
+            cv.notify_all();
+        },
+        &g->error);
+    t_extract_done = seconds_since(t_begin);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        no_more = true; // runners drain what is queued, then stop
+        if (!ok)
+            ready.clear();
+    }
+    cv.notify_all();
+    for (auto &t : runners)
+        t.join();
+    if (!ok)
+        return -1;
+    if (!link.error.empty())
+    {
+        g->error = link.error;
+        return -1;
+    }
+    link.finalize(g->graph);
+    if (totals2)
+    {
+        totals2[0] = total;
+        totals2[1] = sparse;
+    }
+    if (link_timers8)
+    {
+        const LinkTimers &t = link.timers;
+        const double v[8] = {t.link_init,  t.subsample,     t.upload,         t.match_device,
+                             t.match_host, t.ransac_device, t.decompose_host, t.link_finalize};
+        for (int i = 0; i < 8; i++)
+            link_timers8[i] = v[i];
+    }
+    if (stage_seconds2)
+    {
+        stage_seconds2[0] = t_extract_done;            // until the last chunk's features were final
+        stage_seconds2[1] = seconds_since(t_begin);     // until the graph was linked
+    }
+    return 0;
+}

@@ -92,6 +92,8 @@ def load():
         L.och_extract_features_batch.argtypes = [vp, vp, u32, C.c_int, C.c_int, u32, u32, vp, vp, vp, vp, vp, C.c_int]
         L.och_extract_last_error.restype = C.c_char_p
         L.och_graph_load_images.argtypes = [vp, vp, vp, u32, C.c_int, C.c_int, u32, C.c_int, u32, _f64p, _u64p, _f64p]
+        L.och_graph_load_link_images.argtypes = [vp, vp, vp, u32, C.c_int, C.c_int, u32, C.c_int, u32, _f64p, vp, _u64p,
+                                                 _f64p, _f64p, _f64p]
         _lib = L
     return _lib
 
@@ -201,6 +203,27 @@ class Graph:
             raise capi.OchipError("load_images failed: " + self.L.och_last_error(self.h).decode())
         self.node_ids += [int(i) for i in ids[:n]]
         return totals[0] / max(n, 1), totals[1] / max(n, 1)
+
+    def load_link_images(self, ctx, images_bgr, model, positions, orientations=None, max_keypoints=30000, device_shape=None):
+        """Load and link overlapped (och_graph_load_link_images): extraction streams in chunks and ranges of links run
+        on their own device contexts as soon as their images are ready.  Same graph as load_images() + link().
+        Returns (mean features per image, mean sparse features per image, link timers, (extract_s, total_s))."""
+        if device_shape is None:
+            imgs = np.ascontiguousarray(images_bgr, np.uint8)
+            n, h, w, _ = imgs.shape
+            src, on_dev = imgs.ctypes.data, 0
+        else:
+            n, h, w = device_shape
+            src, on_dev = int(images_bgr), 1
+        ids, totals, timers, stage = np.zeros(max(n, 1), np.uint64), np.zeros(2), np.zeros(8), np.zeros(2)
+        ori = None if orientations is None else np.ascontiguousarray(orientations, np.float64)
+        rc = self.L.och_graph_load_link_images(self.h, ctx.h, src, n, w, h, max_keypoints, on_dev, model,
+                                               np.ascontiguousarray(positions, np.float64).reshape(-1, 3),
+                                               None if ori is None else ori.ctypes.data, ids, totals, timers, stage)
+        if rc != 0:
+            raise capi.OchipError("load_link_images failed: " + self.L.och_last_error(self.h).decode())
+        self.node_ids += [int(i) for i in ids[:n]]
+        return totals[0] / max(n, 1), totals[1] / max(n, 1), dict(zip(LINK_TIMER_NAMES, timers.tolist())), (stage[0], stage[1])
 
     @classmethod
     def from_synthetic(cls, grid):

@@ -24,12 +24,26 @@ def synthetic_views(ctx, grid, seed=7):
     return ptr, (grid.n_images, h, w)
 
 
-def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000):
-    """load (extract) -> link -> relax.  Returns (graph, result dict, stage seconds)."""
+def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000, overlap=True):
+    """load (extract) -> link -> relax.  Returns (graph, result dict, stage seconds).  overlap: the load and link
+    stages run overlapped (och_graph_load_link_images) as the reference's pipeline overlaps the stages of consecutive
+    batches; the graph is the same either way."""
     n, h, w = shape
     t = {}
     g = host.Graph()
     mid = g.add_model(grid.model)
+    if overlap:
+        t0 = time.perf_counter()
+        feats_mean, sparse_mean, link_timers, (t_ex, t_all) = g.load_link_images(
+            ctx, images_ptr, mid, grid.position, start_orientation, max_keypoints, device_shape=(n, h, w))
+        t["extract"], t["link"] = t_ex, time.perf_counter() - t0 - t_ex   # link = what the linking adds after the last features
+        t0 = time.perf_counter()
+        rel = g.relax_ground_plane(ctx, start_orientation)
+        ctx.synchronize()
+        t["relax"] = time.perf_counter() - t0
+        res = dict(features_per_image=feats_mean, sparse_per_image=sparse_mean, link_timers=link_timers, relax=rel,
+                   edges=g.num_edges)
+        return g, res, t
     t0 = time.perf_counter()
     feats_mean, sparse_mean = g.load_images(ctx, images_ptr, mid, grid.position, max_keypoints, device_shape=(n, h, w))
     t["extract"] = time.perf_counter() - t0

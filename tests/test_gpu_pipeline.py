@@ -80,14 +80,15 @@ def test_images_to_orientations(monkeypatch, oracle):
     n, h, w = shape
     start = pipeline.perturbed_orientations(grid, 0.1, 4)
     sigs, results = [], []
-    for chunk, streams in (("50", "1"), ("2", "2")):
+    # the last variant overlaps the load and link stages (ranges of links start while later chunks are extracted)
+    for chunk, streams, overlap in (("50", "1", False), ("2", "2", False), ("2", "2", True), ("1", "3", True)):
         monkeypatch.setenv("OCHIP_EXTRACT_CHUNK", chunk)
         monkeypatch.setenv("OCHIP_EXTRACT_STREAMS", streams)
-        g, res, _ = pipeline.run(ctx, grid, images, shape, start)
+        g, res, _ = pipeline.run(ctx, grid, images, shape, start, overlap=overlap)
         sigs.append(_edge_signature(g))
         results.append(res)
         g.close()
-    assert sigs[0] == sigs[1] and len(sigs[0]) >= 2 * (n - 1)
+    assert all(s == sigs[0] for s in sigs[1:]) and len(sigs[0]) >= 2 * (n - 1)
     # extract parity on a real 4000 x 3000 view: device load stage == oracle extract_features
     feats = host.extract_features_batch(ctx, images, 30000, device_shape=(1, h, w))[0]
     view = ctx.synth_views_read(images, 0, w, h)
