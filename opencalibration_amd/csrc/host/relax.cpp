@@ -403,8 +403,57 @@ class GroundPlaneProblem
             }
             scored.emplace_back(intersection_score * angle_score * descriptor_score * ransac_score, idx);
         }
-        std::sort(scored.begin(), scored.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
         std::vector<uint8_t> keep(rel.inlier_matches.size(), 0);
+        auto cell = [res](double x, double y, int *cx, int *cy) {
+            *cx = (int)std::floor(x / res);
+            *cy = (int)std::floor(y / res);
+        };
+        // GridFilter::addMeasurement keeps, per cell of each image, the first measurement in descending score order,
+        // i.e. the best-scoring one.  That needs no sort unless two candidates for a cell's best tie exactly (the
+        // unstable std::sort then decides): one pass over a small dense cell table, and the sorted walk only as the
+        // fall-back for ties or cells outside the table.
+        constexpr int G = 16; // cells per axis the table covers (pixels / image size lies in [0, 1): 1 / 0.15 < 7)
+        int best_s[G * G], best_d[G * G];
+        std::fill(best_s, best_s + G * G, -1);
+        std::fill(best_d, best_d + G * G, -1);
+        bool exact = true;
+        for (size_t k = 0; k < scored.size() && exact; k++)
+        {
+            const double score = scored[k].first;
+            if (!(score > 0))
+                continue;
+            const feature_match_denormalized &m = rel.inlier_matches[scored[k].second];
+            int cx, cy, dx, dy;
+            cell(m.pixel_1[0] / sm.pixels_cols, m.pixel_1[1] / sm.pixels_rows, &cx, &cy);
+            cell(m.pixel_2[0] / dm.pixels_cols, m.pixel_2[1] / dm.pixels_rows, &dx, &dy);
+            if (cx < 0 || cy < 0 || cx >= G || cy >= G || dx < 0 || dy < 0 || dx >= G || dy >= G)
+            {
+                exact = false;
+                break;
+            }
+            int &bs = best_s[cx * G + cy], &bd = best_d[dx * G + dy];
+            if (bs < 0 || score > scored[bs].first)
+                bs = (int)k;
+            else if (score == scored[bs].first)
+                exact = false;
+            if (bd < 0 || score > scored[bd].first)
+                bd = (int)k;
+            else if (score == scored[bd].first)
+                exact = false;
+        }
+        if (exact)
+        {
+            for (int c = 0; c < G * G; c++)
+            {
+                if (best_s[c] >= 0)
+                    keep[scored[best_s[c]].second] |= 1;
+                if (best_d[c] >= 0)
+                    keep[scored[best_d[c]].second] |= 2;
+            }
+            return keep;
+        }
+        std::fill(keep.begin(), keep.end(), 0);
+        std::sort(scored.begin(), scored.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
         std::unordered_map<uint64_t, char> scell, dcell;
         auto key = [res](double x, double y) {
             return (static_cast<uint64_t>((int)std::floor(x / res)) << 32) | static_cast<uint32_t>((int)std::floor(y / res));
