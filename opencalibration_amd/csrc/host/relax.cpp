@@ -187,14 +187,20 @@ class GroundPlaneProblem
         size_t total_blocks = 0;
         for (const auto &pe : per_edge)
             total_blocks += pe.a.size();
-        _blk_a.reserve(total_blocks);
-        _blk_b.reserve(total_blocks);
-        _blk_rays.reserve(total_blocks * 6);
-        for (const auto &pe : per_edge)
+        // concatenated in edge order (offsets first, then a parallel copy)
+        std::vector<size_t> first_block(per_edge.size() + 1, 0);
+        for (size_t k = 0; k < per_edge.size(); k++)
+            first_block[k + 1] = first_block[k] + per_edge[k].a.size();
+        _blk_a.resize(total_blocks);
+        _blk_b.resize(total_blocks);
+        _blk_rays.resize(total_blocks * 6);
+#pragma omp parallel for schedule(static)
+        for (size_t k = 0; k < per_edge.size(); k++)
         {
-            _blk_a.insert(_blk_a.end(), pe.a.begin(), pe.a.end());
-            _blk_b.insert(_blk_b.end(), pe.b.begin(), pe.b.end());
-            _blk_rays.insert(_blk_rays.end(), pe.rays.begin(), pe.rays.end());
+            const auto &pe = per_edge[k];
+            std::copy(pe.a.begin(), pe.a.end(), _blk_a.begin() + first_block[k]);
+            std::copy(pe.b.begin(), pe.b.end(), _blk_b.begin() + first_block[k]);
+            std::copy(pe.rays.begin(), pe.rays.end(), _blk_rays.begin() + 6 * first_block[k]);
         }
         // addDownwardsPrior (:1290-1301)
         for (size_t i = 0; i < poses.size(); i++)
