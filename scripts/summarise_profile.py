@@ -15,6 +15,9 @@ src, out = sys.argv[1], sys.argv[2]
 stats = sorted(glob.glob(src + "/trace/*/*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[-1], out + "_kernel_stats.csv")
+staged = sorted(glob.glob(src + "/trace_staged/*/*_kernel_stats.csv"))
+if staged:
+    shutil.copy(staged[-1], out + "_staged_kernel_stats.csv")
 for line in open(src + "/bench_trace.log", errors="replace"):
     if line.startswith('{"metric'):
         open(out + "_bench_line.json", "w").write(line)
