@@ -455,11 +455,11 @@ __global__ void kcontrast_kernel(const unsigned int *__restrict__ hist, const un
 }
 
 // ---- diffusion (the PM-G2 conductivity is BLUR_FLOW above)
-// Up to FED_FUSE explicit diffusion steps per launch, in registers.  A wavefront owns a 64-column x (32 + 2K)-row
+// Up to FED_FUSE explicit diffusion steps per launch, in registers.  A wavefront owns a 64-column x (NLD_TY + 2K)-row
 // strip: each lane keeps its column of L and of the two conductivity sums (c[i] + c[i+1], c[i] + c[i+w]) in
 // VGPRs, the horizontal neighbours arrive by lane shuffles, and the strip is swept top to bottom once per step,
 // in place (a row needs the old row below and the already computed flux from the row above).  The valid region
-// shrinks by one pixel per step, so 64 - 2K columns x 32 rows are written: 12 B/pixel of HBM traffic per launch
+// shrinks by one pixel per step, so 64 - 2K columns x NLD_TY rows are written: 12 B/pixel of HBM traffic per launch
 // instead of per step, at ~14 VALU instructions per pixel-step (the LDS-tiled form of this loop was VALU-bound).
 // The arithmetic is the one-step form's: flux (c_a + c_b) * (L_b - L_a) evaluated once per pixel pair and used
 // with both signs, 0 across the image border.
