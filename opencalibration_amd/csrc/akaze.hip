@@ -28,7 +28,7 @@ struct level_info
     int octave, w, h, sigma_size;
     float esigma;
     size_t off; // plane offset (floats) inside one image's pyramid
-    int tile_off, tiles_x; // first id and row length of the level's 64 x 16 detection tiles
+    int tile_off, tiles_x; // first id and row length of the level's 64 x 24 detection tiles
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi)
@@ -145,7 +145,7 @@ struct taps_t
 // Every value is the same float expression as the separate passes (ascending tap order, clamped source
 // coordinates for the blur, reflected coordinates for the stencil), so the fusion does not change a bit.
 constexpr int BT_X = 64, BT_Y = 32; // blur tiles
-constexpr int DT_Y = 16;             // detection tiles are 64 x 16: the determinant kernel holds three planes in LDS
+constexpr int DT_Y = 24;             // detection tiles are 64 x 24 (16, 24, 32 rows measured: 63, 57, 62 us per image for determinant + maxima + list)
 enum
 {
     BLUR_PLAIN = 0,
@@ -560,7 +560,7 @@ struct cand_t
     float response;
 };
 
-// Scale-normalised Hessian determinant of a 64 x 16 tile and its strict 3x3 maxima above the threshold in one
+// Scale-normalised Hessian determinant of a 64 x 24 tile and its strict 3x3 maxima above the threshold in one
 // pass: the Lx / Ly tiles (+ halo S + 1) are staged in LDS, the determinant tile (+ halo 1) is built over them,
 // and the level's sparse maxima map (response at maxima, 0 elsewhere) is written next to the determinant.
 template <int S>
@@ -707,7 +707,7 @@ struct levels_dev
 };
 
 // Candidate list of an image = the non-zero entries of its maxima maps, laid out tile by tile in a space-filling
-// order (tile_seq: level by level, Morton order of the 64 x 16 detection tiles inside a level).  Neighbouring list entries
+// order (tile_seq: level by level, Morton order of the 64 x 24 detection tiles inside a level).  Neighbouring list entries
 // are neighbouring pixels, which is what keeps the window scans of the suppression and the patch gathers of the
 // descriptor inside the L2: with an arbitrary order the descriptor kernel alone pulled ~0.9 GB per image through
 // the fabric, 14x the size of the pyramid it samples.  No global atomics: the offsets come from a prefix sum of the
