@@ -155,6 +155,21 @@ enum
     BLUR_FLOW_DERIV = 4 // a level's Lsmooth feeds both its conductivity and its detector derivatives: one pass
 };
 
+// Tile kernels are launched as a 1-D grid of 8 * ceil(tiles / 8) workgroups per image.  Workgroups are dealt to the 8
+// XCDs round-robin (id % 8), each XCD with its own L2; this map hands every XCD one contiguous eighth of the image's
+// tiles in row-major order, so the halos neighbouring tiles share are read through the same L2 instead of being
+// fetched from HBM once per XCD.  Returns false for the padding workgroups.
+__device__ __forceinline__ bool xcd_tile(int tiles_x, int tiles_y, int *tx, int *ty)
+{
+    const int total = tiles_x * tiles_y, chunk = (total + 7) / 8;
+    const int t = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || t >= total)
+        return false;
+    *ty = t / tiles_x;
+    *tx = t - *ty * tiles_x;
+    return true;
+}
+
 // 3-row pattern (wa * a + wb * b) + wa * c of Scharr-type derivatives, samples fetched through `at(x, y)`
 template <typename F>
 __device__ __forceinline__ void pattern_xy(F at, int xm, int x, int xp, int ym, int y, int yp, float wa, float wb, float *dx,
@@ -206,7 +221,11 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
     __shared__ float tin[IW * IH];  // input tile; reused for the blurred tile (BW x BH)
     __shared__ float trow[BW * IH]; // row pass
     const int w = A.w, h = A.h;
-    const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
+    const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
+    int tile_x, tile_y;
+    if (!xcd_tile(tiles_x, tiles_y, &tile_x, &tile_y))
+        return;
+    const int x0 = tile_x * BT_X, y0 = tile_y * BT_Y;
     const int bx0 = x0 - M, by0 = y0 - M;
     const float *I = A.in + (size_t)blockIdx.z * A.in_stride;
     {
@@ -384,7 +403,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
             wmax[threadIdx.x >> 6] = bits;
         __syncthreads();
         if (threadIdx.x == 0)
-            A.partial_max[(size_t)blockIdx.z * (gridDim.x * gridDim.y) + blockIdx.y * gridDim.x + blockIdx.x] =
+            A.partial_max[(size_t)blockIdx.z * (tiles_x * tiles_y) + tile_y * tiles_x + tile_x] =
                 max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
     }
 }
@@ -572,7 +591,11 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
     constexpr int HW = S + 1, RW = BT_X + 2 * HW, RH = DT_Y + 2 * HW, DW = BT_X + 2, DH = DT_Y + 2;
     __shared__ float tx[RW * RH], ty[RW * RH];
     __shared__ float td[DW * DH];
-    const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * DT_Y;
+    const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + DT_Y - 1) / DT_Y;
+    int tile_x, tile_y;
+    if (!xcd_tile(tiles_x, tiles_y, &tile_x, &tile_y))
+        return;
+    const int x0 = tile_x * BT_X, y0 = tile_y * DT_Y;
     const int rx0 = x0 - HW, ry0 = y0 - HW;
     const float *X = Lx + (size_t)blockIdx.z * stride, *Y = Ly + (size_t)blockIdx.z * stride;
     {
@@ -696,7 +719,7 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
         wsum[threadIdx.x >> 6] = found;
     __syncthreads();
     if (threadIdx.x == 0)
-        tile_counts[(size_t)blockIdx.z * n_tiles + tile_off + blockIdx.y * gridDim.x + blockIdx.x] =
+        tile_counts[(size_t)blockIdx.z * n_tiles + tile_off + tile_y * tiles_x + tile_x] =
             wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
@@ -1587,10 +1610,11 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned int *d_counts = nullptr, *d_tile_counts = nullptr, *d_tile_base = nullptr, *d_tile_seq = nullptr;
     pair_tab *d_tab = nullptr;
     const size_t src_px = (size_t)width * height;
-    auto tiles = [&](int w, int h) { return dim3((w + BT_X - 1) / BT_X, (h + BT_Y - 1) / BT_Y, B); };
-    auto det_tiles = [&](int w, int h) { return dim3((w + BT_X - 1) / BT_X, (h + DT_Y - 1) / DT_Y, B); };
+    // 1-D tile grids padded to a multiple of 8 workgroups (xcd_tile)
+    auto tiles = [&](int w, int h) { return dim3(8 * ((((w + BT_X - 1) / BT_X) * ((h + BT_Y - 1) / BT_Y) + 7) / 8), 1, B); };
+    auto det_tiles = [&](int w, int h) { return dim3(8 * ((((w + BT_X - 1) / BT_X) * ((h + DT_Y - 1) / DT_Y) + 7) / 8), 1, B); };
     const dim3 tiles0 = tiles(W, H);
-    const int n_tiles0 = (int)(tiles0.x * tiles0.y);
+    const int n_tiles0 = ((W + BT_X - 1) / BT_X) * ((H + BT_Y - 1) / BT_Y);
     if (on_device)
         d_bgr = const_cast<uint8_t *>(images_bgr);
     else
