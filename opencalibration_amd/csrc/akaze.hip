@@ -835,7 +835,12 @@ __device__ __forceinline__ bool xcd_contiguous(unsigned int block, unsigned int 
         *item = x * chunk + j;
         return j < chunk && *item < n_items;
     }
-    *item = ((j >> 6) * 8 + x) * 64 + (j & 63);
+    if (mode == 2)
+    {
+        *item = ((j >> 6) * 8 + x) * 64 + (j & 63);
+        return *item < n_items;
+    }
+    *item = ((j >> 8) * 8 + x) * 256 + (j & 255); // mode 3: groups of 256
     return *item < n_items;
 }
 
@@ -1920,7 +1925,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     {
         hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 3) / 4, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
                            (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride, LV, dfactor, d_dead);
-        hipLaunchKernelGGL(describe_kernel, dim3(512 * ((max_n + 511) / 512), 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
+        hipLaunchKernelGGL(describe_kernel, dim3(2048 * ((max_n + 2047) / 2048), 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
                            (const unsigned int *)d_ncand, max_cands, (const unsigned char *)d_dead, (const float *)d_Lt,
                            (const float *)d_Lx, (const float *)d_Ly, (const float *)d_Ldet, img_stride, LV, dfactor,
                            (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap);
