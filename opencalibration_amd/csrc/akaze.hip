@@ -29,6 +29,7 @@ struct level_info
     float esigma;
     size_t off; // plane offset (floats) inside one image's pyramid
     int tile_off, tiles_x; // first id and row length of the level's 64 x 24 detection tiles
+    int mask_off;          // first word of the level's maxima bit mask (one 64-bit word per row of a tile column)
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi)
@@ -586,7 +587,8 @@ template <int S>
 __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict__ Lx, const float *__restrict__ Ly, size_t stride,
                                                          float *__restrict__ Ldet, float *__restrict__ Rmax, int w, int h,
                                                          float thr, unsigned int *__restrict__ tile_counts, int tile_off,
-                                                         int n_tiles, float margin)
+                                                         int n_tiles, float margin, unsigned long long *__restrict__ mask,
+                                                         size_t mask_stride)
 {
     constexpr int HW = S + 1, RW = BT_X + 2 * HW, RH = DT_Y + 2 * HW, DW = BT_X + 2, DH = DT_Y + 2;
     __shared__ float tx[RW * RH], ty[RW * RH];
@@ -676,14 +678,15 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
             Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = d;
     }
     __syncthreads();
+    // one wavefront per tile row: the row's maxima as one 64-bit word of the level's bit mask, the responses only where a
+    // bit is set (the rest of Rmax is never read: the list builder and the suppression walk the mask)
     unsigned int found = 0;
-#pragma unroll 4
-    for (int idx = threadIdx.x; idx < BT_X * DT_Y; idx += 256)
+    static_assert(BT_X == 64 && DT_Y % 4 == 0, "a wavefront per tile row, four rows per pass");
+#pragma unroll
+    for (int it = 0; it < DT_Y / 4; it++)
     {
-        const int ly = idx / BT_X, lx = idx - ly * BT_X;
+        const int ly = it * 4 + (threadIdx.x >> 6), lx = threadIdx.x & 63;
         const int x = x0 + lx, y = y0 + ly;
-        if (x >= w || y >= h)
-            continue;
         float out = 0.0f;
         // interior pixel whose descriptor window [round(x - margin) - 1, round(x + margin) + 1] stays inside the level
         // image (AKAZE's Find_Scale_Space_Extrema; margin = 10 sqrt(2) * sigma_size)
@@ -703,13 +706,17 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
                         if ((dx || dy) && !(v > td[ci + dy * DW + dx]))
                             mx = false;
                 if (mx)
-                {
                     out = v;
-                    found++;
-                }
             }
         }
-        Rmax[(size_t)blockIdx.z * stride + (size_t)y * w + x] = out;
+        const unsigned long long m = __ballot(out != 0.0f);
+        if (out != 0.0f)
+            Rmax[(size_t)blockIdx.z * stride + (size_t)y * w + x] = out;
+        if (lx == 0 && y < h)
+        {
+            mask[(size_t)blockIdx.z * mask_stride + (size_t)y * tiles_x + tile_x] = m;
+            found += (unsigned int)__popcll(m);
+        }
     }
     // number of maxima of this tile: the candidate list is laid out tile by tile (scan_tiles_kernel)
     __shared__ unsigned int wsum[4];
@@ -774,13 +781,18 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(const unsigned int *__r
         n_cands[b] = carry;
 }
 
-__global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restrict__ Rmax, size_t img_stride, levels_dev L,
-                                                            const unsigned int *__restrict__ tile_base, int n_tiles,
+// One wavefront per tile: lane r holds the mask word of tile row r, a shuffle prefix sum of the popcounts gives each
+// row its slots, and only the responses of set bits are read.  List order inside a tile: row-major.
+__global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restrict__ Rmax, size_t img_stride,
+                                                            const unsigned long long *__restrict__ mask, size_t mask_stride,
+                                                            levels_dev L, const unsigned int *__restrict__ tile_base, int n_tiles,
                                                             cand_t *__restrict__ cands, unsigned int max_cands)
 {
-    __shared__ unsigned int lcount;
+    static_assert(DT_Y <= 64, "one lane per tile row");
     const unsigned int b = blockIdx.z;
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= n_tiles)
+        return;
     int level = 0;
     while (level + 1 < L.n && tile >= L.l[level + 1].tile_off)
         level++;
@@ -788,32 +800,27 @@ __global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restr
     const int t = tile - l.tile_off;
     const int ty = t / l.tiles_x, tx = t - ty * l.tiles_x;
     const float *R = Rmax + (size_t)b * img_stride + l.off;
-    const unsigned int base = tile_base[(size_t)b * n_tiles + tile];
-    if (threadIdx.x == 0)
-        lcount = 0;
-    __syncthreads();
-    float vals[BT_X * DT_Y / 256]; // the tile's loads in flight together
-#pragma unroll
-    for (int it = 0; it < BT_X * DT_Y / 256; it++)
+    const int y = ty * DT_Y + lane;
+    unsigned long long m = 0;
+    if (lane < DT_Y && y < l.h)
+        m = mask[(size_t)b * mask_stride + (size_t)l.mask_off + (size_t)y * l.tiles_x + tx];
+    const unsigned int cnt = (unsigned int)__popcll(m);
+    unsigned int incl = cnt;
+    for (int off = 1; off < 64; off <<= 1)
     {
-        const int idx = threadIdx.x + it * 256;
-        const int ly = idx / BT_X, lx = idx - ly * BT_X;
-        const int x = tx * BT_X + lx, y = ty * DT_Y + ly;
-        vals[it] = (x < l.w && y < l.h) ? R[(size_t)y * l.w + x] : 0.0f;
+        const unsigned int v = (unsigned int)__shfl_up((int)incl, off);
+        if (lane >= off)
+            incl += v;
     }
-#pragma unroll
-    for (int it = 0; it < BT_X * DT_Y / 256; it++)
+    unsigned int slot = tile_base[(size_t)b * n_tiles + tile] + incl - cnt;
+    while (m)
     {
-        const int idx = threadIdx.x + it * 256;
-        const int ly = idx / BT_X, lx = idx - ly * BT_X;
-        const int x = tx * BT_X + lx, y = ty * DT_Y + ly;
-        const float v = vals[it];
-        if (v != 0.0f)
-        {
-            const unsigned int slot = base + atomicAdd(&lcount, 1u);
-            if (slot < max_cands)
-                cands[(size_t)b * max_cands + slot] = cand_t{level, x, y, v};
-        }
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int x = tx * BT_X + bit;
+        if (slot < max_cands)
+            cands[(size_t)b * max_cands + slot] = cand_t{level, x, y, R[(size_t)y * l.w + x]};
+        slot++;
     }
 }
 
@@ -845,11 +852,14 @@ __device__ __forceinline__ bool xcd_contiguous(unsigned int block, unsigned int 
 }
 
 // A candidate dies if a stronger maximum (ties: lower (level, y, x) wins) of an adjacent level lies within
-// its own size esigma * derivative_factor (base-image pixels).  One wavefront per candidate: the 64 lanes scan the
-// window of the sparse maxima map together and vote with a ballot (any killer decides, so the order of the scan
-// does not matter); a thread per candidate spent its time waiting for one dependent load after the other.
+// its own size esigma * derivative_factor (base-image pixels).  One wavefront per candidate: each lane takes one
+// (row, mask word) of a window of the maxima bit masks of up to three levels (a window is at most ~17 pixels wide, so one
+// or two words per row and one round per candidate), walks the set bits inside the window and reads a response only for a
+// maximum that lies inside the radius; the lanes vote with a ballot (any killer decides, so the order of the scan does
+// not matter).  Scanning the float maps themselves cost 64x the loads for windows that are almost all zeros.
 __global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
                                                        unsigned int max_cands, const float *__restrict__ Rmax, size_t img_stride,
+                                                       const unsigned long long *__restrict__ mask, size_t mask_stride,
                                                        levels_dev L, float derivative_factor, unsigned char *__restrict__ dead)
 {
     const unsigned int b = blockIdx.z;
@@ -863,10 +873,9 @@ __global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict_
     const float ratio_c = (float)(1 << lc.octave);
     const float rad = lc.esigma * derivative_factor, r2 = rad * rad;
     const float cx = (float)c.x * ratio_c, cy = (float)c.y * ratio_c;
-    // up to three windows (levels c.level - 1 .. c.level + 1); each round loads 64 pixels of every window together
-    // (independent loads, one memory round trip per round), the lanes vote, and the scan stops at the first killer
     const float *R[3];
-    int wx0[3], wy0[3], ww[3], wtotal[3], wlw[3], wj[3];
+    const unsigned long long *M[3];
+    int wx0[3], wx1[3], wy0[3], ww0[3], wnw[3], wtotal[3], wlw[3], wtx[3], wj[3];
     float wratio[3];
     int max_total = 0;
 #pragma unroll
@@ -879,11 +888,15 @@ __global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict_
         const int x0 = max((int)floorf((cx - rad) / ratio), 0), x1 = min((int)ceilf((cx + rad) / ratio), lj.w - 1);
         const int y0 = max((int)floorf((cy - rad) / ratio), 0), y1 = min((int)ceilf((cy + rad) / ratio), lj.h - 1);
         R[q] = Rmax + (size_t)b * img_stride + lj.off;
+        M[q] = mask + (size_t)b * mask_stride + (size_t)lj.mask_off;
         wx0[q] = x0;
+        wx1[q] = x1;
         wy0[q] = y0;
-        ww[q] = x1 - x0 + 1;
-        wtotal[q] = use ? ww[q] * (y1 - y0 + 1) : 0;
+        ww0[q] = x0 >> 6;
+        wnw[q] = (x1 >> 6) - (x0 >> 6) + 1;
+        wtotal[q] = use && x1 >= x0 && y1 >= y0 ? wnw[q] * (y1 - y0 + 1) : 0;
         wlw[q] = lj.w;
+        wtx[q] = lj.tiles_x;
         wj[q] = j;
         wratio[q] = ratio;
         max_total = max(max_total, wtotal[q]);
@@ -892,28 +905,39 @@ __global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict_
     for (int t0 = 0; t0 < max_total && !is_dead; t0 += 64)
     {
         const int t = t0 + lane;
-        float r[3];
-        int xx[3], yy[3];
+        unsigned long long m[3];
+        int wx[3], yy[3];
 #pragma unroll
         for (int q = 0; q < 3; q++)
         {
             const bool act = t < wtotal[q];
-            yy[q] = wy0[q] + (act ? t / ww[q] : 0);
-            xx[q] = wx0[q] + (act ? t % ww[q] : 0);
-            r[q] = act ? R[q][(size_t)yy[q] * wlw[q] + xx[q]] : 0.0f;
+            const int row = act ? t / wnw[q] : 0;
+            yy[q] = wy0[q] + row;
+            wx[q] = ww0[q] + (act ? t - row * wnw[q] : 0);
+            m[q] = act ? M[q][(size_t)yy[q] * wtx[q] + wx[q]] : 0ull;
         }
         bool kill = false;
 #pragma unroll
         for (int q = 0; q < 3; q++)
-            if (r[q] != 0.0f && !(wj[q] == c.level && xx[q] == c.x && yy[q] == c.y))
+        {
+            // bits of this word inside [x0, x1]
+            const int lo = max(wx0[q] - wx[q] * 64, 0), hi = min(wx1[q] - wx[q] * 64, 63);
+            unsigned long long bits = hi >= lo ? m[q] & (~0ull << lo) & (~0ull >> (63 - hi)) : 0ull;
+            while (bits)
             {
-                const float ex = (float)xx[q] * wratio[q] - cx, ey = (float)yy[q] * wratio[q] - cy;
+                const int xx = wx[q] * 64 + __ffsll((long long)bits) - 1;
+                bits &= bits - 1;
+                if (wj[q] == c.level && xx == c.x && yy[q] == c.y)
+                    continue;
+                const float ex = (float)xx * wratio[q] - cx, ey = (float)yy[q] * wratio[q] - cy;
                 if (ex * ex + ey * ey <= r2)
                 {
-                    const bool lower_key = wj[q] < c.level || (wj[q] == c.level && (yy[q] < c.y || (yy[q] == c.y && xx[q] < c.x)));
-                    kill = kill || r[q] > c.response || (r[q] == c.response && lower_key);
+                    const float r = R[q][(size_t)yy[q] * wlw[q] + xx];
+                    const bool lower_key = wj[q] < c.level || (wj[q] == c.level && (yy[q] < c.y || (yy[q] == c.y && xx < c.x)));
+                    kill = kill || r > c.response || (r == c.response && lower_key);
                 }
             }
+        }
         is_dead = __ballot(kill) != 0;
     }
     if (lane == 0)
@@ -1558,6 +1582,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     std::vector<std::vector<float>> tsteps;
     size_t img_stride = 0;
     int n_tiles = 0;
+    size_t mask_stride = 0; // words of one image's maxima bit masks
     {
         std::vector<float> etime;
         for (int i = 0; i < omax; i++)
@@ -1579,6 +1604,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 l.tiles_x = (lw + BT_X - 1) / BT_X;
                 l.tile_off = n_tiles;
                 n_tiles += l.tiles_x * ((lh + DT_Y - 1) / DT_Y);
+                l.mask_off = (int)mask_stride;
+                mask_stride += (size_t)l.tiles_x * lh;
                 etime.push_back(0.5f * (l.esigma * l.esigma));
             }
         }
@@ -1613,6 +1640,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned long long *d_desc = nullptr, *d_descc = nullptr;
     float *d_kpc = nullptr;
     unsigned int *d_counts = nullptr, *d_tile_counts = nullptr, *d_tile_base = nullptr, *d_tile_seq = nullptr;
+    unsigned long long *d_mask = nullptr;
     pair_tab *d_tab = nullptr;
     const size_t src_px = (size_t)width * height;
     // 1-D tile grids padded to a multiple of 8 workgroups (xcd_tile)
@@ -1648,6 +1676,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     AK(up<unsigned int>(ctx, allocs, &d_counts, nullptr, B));
     AK(up<unsigned int>(ctx, allocs, &d_tile_counts, nullptr, (size_t)B * n_tiles));
     AK(up<unsigned int>(ctx, allocs, &d_tile_base, nullptr, (size_t)B * n_tiles));
+    AK(up<unsigned long long>(ctx, allocs, &d_mask, nullptr, (size_t)B * mask_stride));
     {
         // processing order of the detection tiles: level by level, Morton order inside a level
         std::vector<std::pair<uint64_t, unsigned int>> keyed;
@@ -1893,19 +1922,20 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             const float margin = (10.0f * std::sqrt(2.0f)) * (float)l.sigma_size; // descriptor window half width, M-LDB
             if (l.sigma_size == 2)
                 hipLaunchKernelGGL((det_maxima_kernel<2>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
-                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin);
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin, d_mask + l.mask_off, mask_stride);
             else if (l.sigma_size == 3)
                 hipLaunchKernelGGL((det_maxima_kernel<3>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
-                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin);
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin, d_mask + l.mask_off, mask_stride);
             else
                 hipLaunchKernelGGL((det_maxima_kernel<4>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
-                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin);
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin, d_mask + l.mask_off, mask_stride);
         }
     }
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(B), dim3(256), 0, st, (const unsigned int *)d_tile_counts,
                        (const unsigned int *)d_tile_seq, n_tiles, d_tile_base, d_ncand);
-    hipLaunchKernelGGL(collect_tiles_kernel, dim3(n_tiles, 1, B), dim3(256), 0, st, (const float *)d_Rmax, img_stride, LV,
-                       (const unsigned int *)d_tile_base, n_tiles, d_cands, max_cands);
+    hipLaunchKernelGGL(collect_tiles_kernel, dim3((n_tiles + 3) / 4, 1, B), dim3(256), 0, st, (const float *)d_Rmax, img_stride,
+                       (const unsigned long long *)d_mask, mask_stride, LV, (const unsigned int *)d_tile_base, n_tiles, d_cands,
+                       max_cands);
     std::vector<unsigned int> ncand(B);
     OCHIP_HIP(ctx, hipMemcpyAsync(ncand.data(), d_ncand, B * 4, hipMemcpyDeviceToHost, st));
     OCHIP_HIP(ctx, hipStreamSynchronize(st));
@@ -1924,7 +1954,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     if (max_n > 0)
     {
         hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 3) / 4, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
-                           (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride, LV, dfactor, d_dead);
+                           (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride,
+                           (const unsigned long long *)d_mask, mask_stride, LV, dfactor, d_dead);
         hipLaunchKernelGGL(describe_kernel, dim3(2048 * ((max_n + 2047) / 2048), 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
                            (const unsigned int *)d_ncand, max_cands, (const unsigned char *)d_dead, (const float *)d_Lt,
                            (const float *)d_Lx, (const float *)d_Ly, (const float *)d_Ldet, img_stride, LV, dfactor,
