@@ -863,12 +863,17 @@ __global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict_
                                                        levels_dev L, float derivative_factor, unsigned char *__restrict__ dead)
 {
     const unsigned int b = blockIdx.z;
-    const unsigned int n = min(n_cands[b], max_cands);
     const int lane = threadIdx.x & 63;
     const unsigned int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the candidate is fetched together with the count (one memory round trip, not two); its fields are the same in
+    // every lane, so the level records come through the scalar cache
+    cand_t c = cands[(size_t)b * max_cands + min(k, max_cands - 1)];
+    const unsigned int n = min(n_cands[b], max_cands);
     if (k >= n)
         return;
-    const cand_t c = cands[(size_t)b * max_cands + k];
+    c.level = __builtin_amdgcn_readfirstlane(c.level);
+    c.x = __builtin_amdgcn_readfirstlane(c.x);
+    c.y = __builtin_amdgcn_readfirstlane(c.y);
     const level_info lc = L.l[c.level];
     const float ratio_c = (float)(1 << lc.octave);
     const float rad = lc.esigma * derivative_factor, r2 = rad * rad;
@@ -884,9 +889,9 @@ __global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict_
         const int j = c.level - 1 + q;
         const bool use = j >= 0 && j < L.n;
         const level_info lj = L.l[use ? j : c.level];
-        const float ratio = (float)(1 << lj.octave);
-        const int x0 = max((int)floorf((cx - rad) / ratio), 0), x1 = min((int)ceilf((cx + rad) / ratio), lj.w - 1);
-        const int y0 = max((int)floorf((cy - rad) / ratio), 0), y1 = min((int)ceilf((cy + rad) / ratio), lj.h - 1);
+        const float ratio = (float)(1 << lj.octave), inv = 1.0f / ratio; // power of two: * inv == / ratio, bit for bit
+        const int x0 = max((int)floorf((cx - rad) * inv), 0), x1 = min((int)ceilf((cx + rad) * inv), lj.w - 1);
+        const int y0 = max((int)floorf((cy - rad) * inv), 0), y1 = min((int)ceilf((cy + rad) * inv), lj.h - 1);
         R[q] = Rmax + (size_t)b * img_stride + lj.off;
         M[q] = mask + (size_t)b * mask_stride + (size_t)lj.mask_off;
         wx0[q] = x0;
