@@ -57,18 +57,28 @@ __device__ __forceinline__ uint32_t minstd_next(uint32_t &x) // std::minstd_rand
     return x;
 }
 
-// std::uniform_int_distribution<size_t>(0, hi)(minstd_rand0) — bits/uniform_int_dist.h, urngrange > urange
-__device__ __forceinline__ uint32_t uniform_int(uint32_t &x, uint32_t hi)
+// std::uniform_int_distribution<size_t>(0, hi)(minstd_rand0) — bits/uniform_int_dist.h, urngrange > urange.
+// urngrange = max() - min() = 2147483646 - 1 and every operand stays below 2^31, so 32-bit arithmetic gives the
+// 64-bit results; the scaling only depends on hi and is shared by the draws of one sample.
+struct uniform_range
 {
-    const uint64_t urngrange = 2147483645ull; // max() - min() = 2147483646 - 1
-    const uint64_t uerange = (uint64_t)hi + 1;
-    const uint64_t scaling = urngrange / uerange;
-    const uint64_t past = uerange * scaling;
-    uint64_t ret;
+    uint32_t scaling, past;
+};
+__device__ __forceinline__ uniform_range make_range(uint32_t hi)
+{
+    const uint32_t uerange = hi + 1;
+    uniform_range r;
+    r.scaling = 2147483645u / uerange;
+    r.past = uerange * r.scaling;
+    return r;
+}
+__device__ __forceinline__ uint32_t uniform_int(uint32_t &x, const uniform_range &r)
+{
+    uint32_t ret;
     do
-        ret = (uint64_t)minstd_next(x) - 1ull;
-    while (ret >= past);
-    return (uint32_t)(ret / scaling);
+        ret = minstd_next(x) - 1u;
+    while (ret >= r.past);
+    return ret / r.scaling;
 }
 
 struct model_t // homography_model state, wave-uniform
@@ -120,30 +130,51 @@ __device__ __forceinline__ double transfer_error(const model_t &m, double x1, do
 
 struct pair_data // per-pair scratch in HBM (L2 resident while the pair is being processed)
 {
-    const double *x1, *y1, *x2, *y2; // [M] normalised coordinates
-    uint8_t *cand, *inl;             // [M] candidate / current inlier flags, indexed by correspondence
-    double *P;                       // column-major (2M+1) x 9 system of fitInliers
+    const double *x1, *y1, *x2, *y2;     // [M] normalised coordinates, correspondence order
+    const double *ex1, *ey1, *ex2, *ey2; // [M] the same in shuffled evaluation order (position p holds eval_order[p])
+    uint8_t *cand, *inl;                 // [M] candidate / current inlier flags, indexed by correspondence
+    double *P;                           // column-major (2M+1) x 9 system of fitInliers
     uint32_t M;
 };
 
-// MSAC scoring of one model.  ORDERED: walk `order` (the shuffled eval_order) and apply the SPRT early
+// MSAC scoring of one model.  ORDERED: walk the shuffled eval_order and apply the SPRT early
 // exit of ransac.cpp:187-203; otherwise natural order, no exit (homography_model::evaluate :99-118).
-// The running sum is accumulated one inlier at a time in walk order.  Returns the score; *rejected.
+// The running sum is accumulated one element at a time in walk order (non-inliers add +0.0, which changes nothing,
+// so the chain is a fixed 64 adds per chunk with the addend taken from lane l by v_readlane).  The walk is
+// software-pipelined: the next chunk's coordinates are requested before this chunk's arithmetic, and the ORDERED walk
+// reads coordinates that the prologue stored in evaluation order, so every load of the 20+ scorings of a pair is a
+// coalesced stream (the gather through eval_order cost two dependent memory round trips per 64 matches).
 template <bool ORDERED>
 __device__ double score_model(const model_t &m, const pair_data &pd, const uint32_t *__restrict__ order, uint8_t *flags,
                               double thr, double best_score, bool *rejected, uint32_t *n_inliers)
 {
     const int lane = threadIdx.x;
     const uint32_t M = pd.M;
+    const double *X1 = ORDERED ? pd.ex1 : pd.x1, *Y1 = ORDERED ? pd.ey1 : pd.y1, *X2 = ORDERED ? pd.ex2 : pd.x2,
+                 *Y2 = ORDERED ? pd.ey2 : pd.y2;
     double s = 0;
     uint32_t count = 0;
     *rejected = false;
+    double nx1, ny1, nx2, ny2;
+    uint32_t nidx;
+    {
+        const bool nv = (uint32_t)lane < M;
+        nx1 = nv ? X1[lane] : 0.0, ny1 = nv ? Y1[lane] : 0.0, nx2 = nv ? X2[lane] : 0.0, ny2 = nv ? Y2[lane] : 0.0;
+        nidx = nv ? (ORDERED ? order[lane] : (uint32_t)lane) : 0;
+    }
     for (uint32_t base = 0; base < M; base += W)
     {
         const uint32_t pos = base + lane;
         const bool valid = pos < M;
-        const uint32_t idx = valid ? (ORDERED ? order[pos] : pos) : 0;
-        const double e = transfer_error(m, pd.x1[idx], pd.y1[idx], pd.x2[idx], pd.y2[idx]);
+        const double x1 = nx1, y1 = ny1, x2 = nx2, y2 = ny2;
+        const uint32_t idx = nidx;
+        {
+            const uint32_t np = pos + W;
+            const bool nv = np < M;
+            nx1 = nv ? X1[np] : 0.0, ny1 = nv ? Y1[np] : 0.0, nx2 = nv ? X2[np] : 0.0, ny2 = nv ? Y2[np] : 0.0;
+            nidx = nv ? (ORDERED ? order[np] : np) : 0;
+        }
+        const double e = transfer_error(m, x1, y1, x2, y2);
         const bool inl = valid && (e < thr);
         double term = 0;
         if (inl)
@@ -153,16 +184,18 @@ __device__ double score_model(const model_t &m, const pair_data &pd, const uint3
         }
         if (valid)
             flags[idx] = inl ? 1 : 0;
-        unsigned long long mask = __ballot(inl);
+        const unsigned long long mask = __ballot(inl);
         count += __popcll(mask);
         double pref = s; // running sum as seen right after this lane's element
-        while (mask)
+        if (mask)
         {
-            const int l = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            s = s + bcast(term, l);
-            if (lane >= l)
-                pref = s;
+#pragma unroll
+            for (int l = 0; l < W; l++)
+            {
+                s = s + bcast(term, l);
+                if (ORDERED)
+                    pref = lane == l ? s : pref;
+            }
         }
         if (ORDERED)
         {
@@ -180,18 +213,72 @@ __device__ double score_model(const model_t &m, const pair_data &pd, const uint3
     return s;
 }
 
-// Eigen FullPivLU<Matrix<double, rows, 9>>::solve(e_last) with the wave cooperating: lanes stride over
-// rows.  A is column-major with leading dimension ld (generic pointer: LDS for the 9x9 fit, HBM for
-// fitInliers).  Pivot search order / ties, rank threshold, substitution order: exactly the restated
-// Eigen algorithm of the oracle (column-by-column scan, strict '>').
-__device__ void full_piv_lu_solve9(double *A, uint32_t rows, uint32_t ld, double *sol /*[9], uniform*/)
+// ---- Eigen FullPivLU<Matrix<double, rows, 9>>::solve(e_last).  Pivot search order / ties (column-by-column scan,
+//      strict '>'), rank threshold and substitution order are the restated Eigen algorithm of the oracle.
+struct lu_state
+{
+    uint32_t rowT[9], colT[9];
+    uint32_t nonzero_pivots;
+    double maxpivot;
+};
+
+// rank, then the solve steps on the factored leading 9 x 9 block B (column-major, ld 9, in LDS); uniform work
+__device__ void lu_finish(const double *B, uint32_t rows, uint32_t size, const lu_state &st, double *sol /*[9], uniform*/)
+{
+    const uint32_t ld = 9;
+    const double premult = fabs(st.maxpivot) * (2.220446049250313e-16 * (double)size);
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < st.nonzero_pivots; i++)
+        rank += (fabs(B[(size_t)i * ld + i]) > premult) ? 1 : 0;
+    for (int i = 0; i < 9; i++)
+        sol[i] = 0;
+    if (rank == 0)
+        return;
+    // c = P * e_last: follow the single 1 through the row transpositions
+    uint32_t pos = rows - 1;
+    for (uint32_t k = 0; k < size; k++)
+    {
+        if (pos == k)
+            pos = st.rowT[k];
+        else if (pos == st.rowT[k])
+            pos = k;
+    }
+    double c[9];
+    for (uint32_t i = 0; i < 9; i++)
+        c[i] = (i == pos) ? 1.0 : 0.0;
+    for (uint32_t j = 0; j < size; j++) // unit-lower forward substitution, column oriented
+    {
+        const double cj = c[j];
+        for (uint32_t i = j + 1; i < size; i++)
+            c[i] -= cj * B[(size_t)j * ld + i];
+    }
+    for (uint32_t jj = rank; jj-- > 0;) // upper back substitution, column oriented
+    {
+        c[jj] /= B[(size_t)jj * ld + jj];
+        const double cj = c[jj];
+        for (uint32_t i = 0; i < jj; i++)
+            c[i] -= cj * B[(size_t)jj * ld + i];
+    }
+    uint32_t perm[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+    for (uint32_t k = 0; k < size; k++)
+    {
+        const uint32_t t = perm[k];
+        perm[k] = perm[st.colT[k]];
+        perm[st.colT[k]] = t;
+    }
+    for (uint32_t i = 0; i < rank; i++)
+        sol[perm[i]] = c[i];
+}
+
+// The minimal-sample fit: A is the 9 x 9 system in LDS (ld 9), rows <= 9; the wave cooperates, lanes over rows.
+__device__ void full_piv_lu_solve9(double *A, uint32_t rows, double *sol /*[9], uniform*/)
 {
     const int lane = threadIdx.x;
-    const uint32_t cols = 9;
+    const uint32_t cols = 9, ld = 9;
     const uint32_t size = rows < cols ? rows : cols;
-    uint32_t rowT[9], colT[9];
-    uint32_t nonzero_pivots = size;
-    double maxpivot = 0;
+    lu_state st;
+    st.nonzero_pivots = size;
+    st.maxpivot = 0;
 
     for (uint32_t k = 0; k < size; k++)
     {
@@ -237,18 +324,18 @@ __device__ void full_piv_lu_solve9(double *A, uint32_t rows, uint32_t ld, double
         }
         if (bv == 0.0)
         {
-            nonzero_pivots = k;
+            st.nonzero_pivots = k;
             for (uint32_t i = k; i < size; i++)
             {
-                rowT[i] = i;
-                colT[i] = i;
+                st.rowT[i] = i;
+                st.colT[i] = i;
             }
             break;
         }
-        if (bv > maxpivot)
-            maxpivot = bv;
-        rowT[k] = bi;
-        colT[k] = bj;
+        if (bv > st.maxpivot)
+            st.maxpivot = bv;
+        st.rowT[k] = bi;
+        st.colT[k] = bj;
         // ---- row swap k <-> bi (lanes over the 9 columns), then column swap k <-> bj (lanes over rows)
         if (k != bi && lane < (int)cols)
         {
@@ -282,50 +369,206 @@ __device__ void full_piv_lu_solve9(double *A, uint32_t rows, uint32_t ld, double
             }
     }
     __syncthreads();
+    lu_finish(A, rows, size, st, sol);
+}
 
-    // ---- rank, then the solve steps on the leading 9x9 block (uniform work)
-    const double premult = fabs(maxpivot) * (2.220446049250313e-16 * (double)size);
-    uint32_t rank = 0;
-    for (uint32_t i = 0; i < nonzero_pivots; i++)
-        rank += (fabs(A[(size_t)i * ld + i]) > premult) ? 1 : 0;
-    for (int i = 0; i < 9; i++)
-        sol[i] = 0;
-    if (rank == 0)
-        return;
-    // c = P * e_last: follow the single 1 through the row transpositions
-    uint32_t pos = rows - 1;
-    for (uint32_t k = 0; k < size; k++)
+// ---- the tall (2n+1) x 9 system of fitInliers, column-major in HBM / L2, rows > 9.
+//      The same factorisation, arranged so that the wave goes over the tall matrix ONCE per elimination step and never
+//      waits for one load at a time: a lane takes RB of its rows per round and requests all their remaining columns
+//      together ((9 - k) * RB loads in flight), applies the column transposition of the step in registers, eliminates,
+//      stores, and looks for the next pivot among the values it just produced.  (Walking the columns with one load per
+//      loop trip, as the 9 x 9 version does, spent ~1 ms per factorisation waiting on memory latency.)
+struct piv_t
+{
+    double v;
+    uint32_t i, j;
+};
+__device__ __forceinline__ void piv_take(piv_t &b, double v, uint32_t i, uint32_t j)
+{
+    // the first maximum in column-by-column scan order, whatever order the candidates arrive in
+    if (v > b.v || (v == b.v && (j < b.j || (j == b.j && i < b.i))))
     {
-        if (pos == k)
-            pos = rowT[k];
-        else if (pos == rowT[k])
-            pos = k;
+        b.v = v;
+        b.i = i;
+        b.j = j;
     }
-    double c[9];
-    for (uint32_t i = 0; i < 9; i++)
-        c[i] = (i == pos) ? 1.0 : 0.0;
-    for (uint32_t j = 0; j < size; j++) // unit-lower forward substitution, column oriented
+}
+__device__ __forceinline__ void piv_reduce(piv_t &b)
+{
+    for (int off = 32; off >= 1; off >>= 1)
     {
-        const double cj = c[j];
-        for (uint32_t i = j + 1; i < size; i++)
-            c[i] -= cj * A[(size_t)j * ld + i];
+        const double ov = __shfl_xor(b.v, off);
+        const uint32_t oi = __shfl_xor(b.i, off), oj = __shfl_xor(b.j, off);
+        piv_take(b, ov, oi, oj);
     }
-    for (uint32_t jj = rank; jj-- > 0;) // upper back substitution, column oriented
+}
+
+constexpr int RB = 4; // rows per lane and round
+
+template <int K>
+__device__ __forceinline__ bool tall_lu_step(double *__restrict__ A, uint32_t rows, uint32_t ld, piv_t &pv, lu_state &st)
+{
+    const int lane = threadIdx.x;
+    __syncthreads(); // the stores of the previous step have landed
+    double bv = pv.v;
+    uint32_t bi = pv.i, bj = pv.j;
+    const double akk = A[(size_t)K * ld + K];
+    if (akk != akk) // a NaN in the first scanned cell sticks (nothing compares greater than NaN)
     {
-        c[jj] /= A[(size_t)jj * ld + jj];
-        const double cj = c[jj];
-        for (uint32_t i = 0; i < jj; i++)
-            c[i] -= cj * A[(size_t)jj * ld + i];
+        bv = akk;
+        bi = K;
+        bj = K;
     }
-    uint32_t perm[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
-    for (uint32_t k = 0; k < size; k++)
+    else if (bv < 0) // every candidate was NaN: keep (k,k)
     {
-        const uint32_t t = perm[k];
-        perm[k] = perm[colT[k]];
-        perm[colT[k]] = t;
+        bv = fabs(akk);
+        bi = K;
+        bj = K;
     }
-    for (uint32_t i = 0; i < rank; i++)
-        sol[perm[i]] = c[i];
+    if (bv == 0.0)
+        return false;
+    if (bv > st.maxpivot)
+        st.maxpivot = bv;
+    st.rowT[K] = bi;
+    st.colT[K] = bj;
+    // row swap k <-> bi over all nine columns
+    if (K != bi && lane < 9)
+    {
+        const double t = A[(size_t)lane * ld + K];
+        A[(size_t)lane * ld + K] = A[(size_t)lane * ld + bi];
+        A[(size_t)lane * ld + bi] = t;
+    }
+    __syncthreads();
+    // column swap k <-> bj: rows 0..k here, the rows below inside the elimination pass
+    if (K != bj && lane <= K)
+    {
+        const double t = A[(size_t)K * ld + lane];
+        A[(size_t)K * ld + lane] = A[(size_t)bj * ld + lane];
+        A[(size_t)bj * ld + lane] = t;
+    }
+    __syncthreads();
+    const double p = A[(size_t)K * ld + K];
+    double rowk[9];
+#pragma unroll
+    for (int j = K + 1; j < 9; j++)
+        rowk[j] = A[(size_t)j * ld + K];
+    piv_t nb{-1.0, (uint32_t)K + 1, (uint32_t)K + 1};
+    for (uint32_t base = K + 1; base < rows; base += W * RB)
+    {
+        double v[RB][9];
+#pragma unroll
+        for (int u = 0; u < RB; u++)
+        {
+            const uint32_t i = base + lane + W * u;
+#pragma unroll
+            for (int j = K; j < 9; j++)
+                v[u][j] = i < rows ? A[(size_t)j * ld + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < RB; u++)
+        {
+            const uint32_t i = base + lane + W * u;
+#pragma unroll
+            for (int j = K + 1; j < 9; j++)
+                if ((uint32_t)j == bj)
+                {
+                    const double t = v[u][K];
+                    v[u][K] = v[u][j];
+                    v[u][j] = t;
+                }
+            // col(k).tail /= pivot; block(k+1,k+1) -= col(k).tail * row(k).tail
+            const double l = v[u][K] / p;
+            v[u][K] = l;
+#pragma unroll
+            for (int j = K + 1; j < 9; j++)
+                v[u][j] = v[u][j] - l * rowk[j];
+            if (i < rows)
+            {
+#pragma unroll
+                for (int j = K; j < 9; j++)
+                    A[(size_t)j * ld + i] = v[u][j];
+#pragma unroll
+                for (int j = K + 1; j < 9; j++)
+                    piv_take(nb, fabs(v[u][j]), i, (uint32_t)j);
+            }
+        }
+    }
+    if (K < 8)
+    {
+        piv_reduce(nb);
+        pv = nb;
+    }
+    return true;
+}
+
+__device__ void tall_lu_solve9(double *__restrict__ A, uint32_t rows, double *T9 /*LDS 81*/, double *sol /*[9], uniform*/)
+{
+    const int lane = threadIdx.x;
+    const uint32_t ld = rows;
+    lu_state st;
+    st.nonzero_pivots = 9;
+    st.maxpivot = 0;
+    __syncthreads(); // the system's stores have landed
+    piv_t pv{-1.0, 0, 0};
+    for (uint32_t base = 0; base < rows; base += W * RB)
+    {
+        double v[RB][9];
+#pragma unroll
+        for (int u = 0; u < RB; u++)
+        {
+            const uint32_t i = base + lane + W * u;
+#pragma unroll
+            for (int j = 0; j < 9; j++)
+                v[u][j] = i < rows ? A[(size_t)j * ld + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < RB; u++)
+        {
+            const uint32_t i = base + lane + W * u;
+            if (i < rows)
+            {
+#pragma unroll
+                for (int j = 0; j < 9; j++)
+                    piv_take(pv, fabs(v[u][j]), i, (uint32_t)j);
+            }
+        }
+    }
+    piv_reduce(pv);
+    int stop = 9; // the step at which the remaining block was all zero
+    do
+    {
+#define OCHIP_LU_STEP(K)                                                                                               \
+    if (!tall_lu_step<K>(A, rows, ld, pv, st))                                                                         \
+    {                                                                                                                  \
+        stop = K;                                                                                                      \
+        break;                                                                                                         \
+    }
+        OCHIP_LU_STEP(0)
+        OCHIP_LU_STEP(1)
+        OCHIP_LU_STEP(2)
+        OCHIP_LU_STEP(3)
+        OCHIP_LU_STEP(4)
+        OCHIP_LU_STEP(5)
+        OCHIP_LU_STEP(6)
+        OCHIP_LU_STEP(7)
+        OCHIP_LU_STEP(8)
+#undef OCHIP_LU_STEP
+    } while (false);
+    if (stop < 9)
+    {
+        st.nonzero_pivots = (uint32_t)stop;
+        for (int i = stop; i < 9; i++)
+        {
+            st.rowT[i] = (uint32_t)i;
+            st.colT[i] = (uint32_t)i;
+        }
+    }
+    __syncthreads();
+    // the factored leading 9 x 9 block, once, into LDS for the (uniform, latency-bound) substitution
+    for (int t = lane; t < 81; t += W)
+        T9[t] = A[(size_t)(t / 9) * ld + (t % 9)];
+    __syncthreads();
+    lu_finish(T9, rows, 9, st, sol);
 }
 
 // the two DLT rows of one correspondence (homography_model.cpp:26-35), written column-major
@@ -341,14 +584,333 @@ __device__ __forceinline__ void write_dlt_rows(double *A, uint32_t ld, uint32_t 
     }
 }
 
+// four distinct positions of the sampling pool; distinct positions are distinct correspondences because the PROSAC
+// order is a permutation, so the uniqueness test of ransac.cpp:118-150 needs no loaded value and the four
+// sorted_idx reads go out together
+__device__ __forceinline__ void draw_distinct(uint32_t &rng, uint32_t hi, int first, uint32_t *c)
+{
+    const uniform_range range = make_range(hi);
+    for (int j = first; j < 4; j++)
+    {
+        uint32_t cand;
+        bool unique;
+        do
+        {
+            cand = uniform_int(rng, range);
+            unique = true;
+            for (int k = first; k < j; k++)
+                if (c[k] == cand)
+                    unique = false;
+        } while (!unique);
+        c[j] = cand;
+    }
+}
+
+// ---- fast-forward over iterations that change nothing -------------------------------------------------------------
+// An iteration of ransac.cpp:98-247 only touches the state when its model is neither degenerate nor SPRT-rejected and
+// scores above the best so far; every other iteration just consumes random numbers.  Link pairs with few matches and
+// a low inlier ratio run hundreds to thousands of such iterations (one C3 pair: 6 111, 33 us each when the whole wave
+// works on one 9 x 9 fit at a time — that single pair WAS the kernel's duration).  So the next up to FB iterations
+// are looked at side by side, one per lane: the sample stream is replayed (uniform, sequential, as it must be), every
+// lane fits its own sample with a private 9 x 9 full-pivot LU in LDS and walks the matches in evaluation order with the
+// SPRT test, exactly the arithmetic of the one-at-a-time path.  The iterations before the first lane that would
+// improve are skipped (rng and PROSAC state advanced past them); that iteration itself then runs on the normal path.
+constexpr int FB = 32;
+
+__device__ __forceinline__ uint32_t nib_get(uint64_t p, uint32_t k)
+{
+    return (uint32_t)(p >> (4 * k)) & 15u;
+}
+__device__ __forceinline__ uint64_t nib_set(uint64_t p, uint32_t k, uint32_t v)
+{
+    return (p & ~(15ull << (4 * k))) | ((uint64_t)v << (4 * k));
+}
+
+// homography_model::fit of one lane's sample; element (i, j) of the lane's 9 x 9 system lives at Aq[(j * 9 + i) * FB]
+__device__ void lane_fit(double *Aq /*already offset by the lane*/, const double *px, const double *py, const double *qx,
+                         const double *qy, model_t &m)
+{
+#define AQ(i, j) Aq[(((j) * 9 + (i)) * FB)]
+#pragma unroll
+    for (int t = 0; t < 81; t++)
+        Aq[t * FB] = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+    {
+        const double x = px[p], y = py[p], x_ = qx[p], y_ = qy[p];
+        AQ(2 * p, 0) = -x;
+        AQ(2 * p, 1) = -y;
+        AQ(2 * p, 2) = -1;
+        AQ(2 * p, 6) = x * x_;
+        AQ(2 * p, 7) = y * x_;
+        AQ(2 * p, 8) = x_;
+        AQ(2 * p + 1, 3) = -x;
+        AQ(2 * p + 1, 4) = -y;
+        AQ(2 * p + 1, 5) = -1;
+        AQ(2 * p + 1, 6) = x * y_;
+        AQ(2 * p + 1, 7) = y * y_;
+        AQ(2 * p + 1, 8) = y_;
+    }
+    AQ(8, 8) = 1.0;
+
+    uint64_t rowT = 0x876543210ull, colT = 0x876543210ull;
+    uint32_t nonzero_pivots = 9;
+    double maxpivot = 0;
+    bool alive = true;
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+    {
+        if (alive)
+        {
+            double bv = -1.0;
+            uint32_t bi = k, bj = k;
+#pragma unroll
+            for (int j = k; j < 9; j++)
+#pragma unroll
+                for (int i = k; i < 9; i++)
+                {
+                    const double v = fabs(AQ(i, j));
+                    if (v > bv) // column-by-column scan, strict '>' keeps the first maximum
+                    {
+                        bv = v;
+                        bi = i;
+                        bj = j;
+                    }
+                }
+            const double akk = AQ(k, k);
+            if (akk != akk)
+            {
+                bv = akk;
+                bi = k;
+                bj = k;
+            }
+            else if (bv < 0)
+            {
+                bv = fabs(akk);
+                bi = k;
+                bj = k;
+            }
+            if (bv == 0.0)
+            {
+                nonzero_pivots = k;
+                alive = false; // the remaining transpositions stay the identity
+            }
+            else
+            {
+                if (bv > maxpivot)
+                    maxpivot = bv;
+                rowT = nib_set(rowT, k, bi);
+                colT = nib_set(colT, k, bj);
+                if ((uint32_t)k != bi)
+                {
+#pragma unroll
+                    for (int j = 0; j < 9; j++)
+                    {
+                        const double t = AQ(k, j);
+                        AQ(k, j) = AQ(bi, j);
+                        AQ(bi, j) = t;
+                    }
+                }
+                if ((uint32_t)k != bj)
+                {
+#pragma unroll
+                    for (int i = 0; i < 9; i++)
+                    {
+                        const double t = AQ(i, k);
+                        AQ(i, k) = AQ(i, bj);
+                        AQ(i, bj) = t;
+                    }
+                }
+                const double p = AQ(k, k);
+                double rowk[9];
+#pragma unroll
+                for (int j = k + 1; j < 9; j++)
+                    rowk[j] = AQ(k, j);
+#pragma unroll
+                for (int i = k + 1; i < 9; i++)
+                {
+                    const double l = AQ(i, k) / p;
+                    AQ(i, k) = l;
+#pragma unroll
+                    for (int j = k + 1; j < 9; j++)
+                        AQ(i, j) = AQ(i, j) - l * rowk[j];
+                }
+            }
+        }
+    }
+    // rank, P e_last, the two substitutions, the column permutation (lu_finish, per lane)
+    const double premult = fabs(maxpivot) * (2.220446049250313e-16 * (double)9);
+    uint32_t rank = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+        if ((uint32_t)i < nonzero_pivots)
+            rank += (fabs(AQ(i, i)) > premult) ? 1 : 0;
+    double sol[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+        sol[i] = 0;
+    if (rank != 0)
+    {
+        uint32_t pos = 8;
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+        {
+            const uint32_t r = nib_get(rowT, k);
+            if (pos == (uint32_t)k)
+                pos = r;
+            else if (pos == r)
+                pos = k;
+        }
+        double c[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            c[i] = ((uint32_t)i == pos) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+        {
+            const double cj = c[j];
+#pragma unroll
+            for (int i = j + 1; i < 9; i++)
+                c[i] -= cj * AQ(i, j);
+        }
+#pragma unroll
+        for (int jj = 8; jj >= 0; jj--)
+            if ((uint32_t)jj < rank)
+            {
+                c[jj] /= AQ(jj, jj);
+                const double cj = c[jj];
+#pragma unroll
+                for (int i = 0; i < jj; i++)
+                    c[i] -= cj * AQ(i, jj);
+            }
+        uint64_t perm = 0x876543210ull;
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+        {
+            const uint32_t ck = nib_get(colT, k);
+            const uint32_t t = nib_get(perm, k);
+            perm = nib_set(perm, k, nib_get(perm, ck));
+            perm = nib_set(perm, ck, t);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            if ((uint32_t)i < rank)
+            {
+                const uint32_t pi = nib_get(perm, i);
+#pragma unroll
+                for (int mm = 0; mm < 9; mm++)
+                    if (pi == (uint32_t)mm)
+                        sol[mm] = c[i];
+            }
+    }
+#undef AQ
+    model_from_solution(m, sol);
+}
+
+// Returns the number of leading no-op iterations among the next n (rng / prosac_n advanced past them); *found says
+// whether the iteration after them would improve the best model (it then runs on the normal path).
+__device__ uint32_t fast_forward(const pair_data &pd, const uint32_t *__restrict__ sorted_idx, bool has_quality, uint32_t it,
+                                 uint32_t n, uint32_t &rng, uint32_t &prosac_n, double best_score, double thr, double *AQs,
+                                 bool *found)
+{
+    const int lane = threadIdx.x;
+    const uint32_t M = pd.M;
+    // ---- replay the sample stream of the next n iterations (ransac.cpp:100-154); lane L keeps iteration it + L
+    uint32_t rng_s = rng, prosac_s = prosac_n;
+    uint32_t my_rng = 0, my_prosac = 0, my_c[4] = {0, 0, 0, 0};
+    for (uint32_t L = 0; L < n; L++)
+    {
+        const uint32_t itL = it + L, rb = rng_s, pb = prosac_s;
+        if (has_quality && prosac_s < M && itL > 0 && itL % 10 == 0)
+            prosac_s++;
+        uint32_t c[4];
+        if (has_quality && prosac_s < M && prosac_s > 4)
+        {
+            c[0] = prosac_s - 1;
+            draw_distinct(rng_s, prosac_s - 2, 1, c);
+        }
+        else
+            draw_distinct(rng_s, (has_quality ? prosac_s : M) - 1, 0, c);
+        if ((uint32_t)lane == L)
+        {
+            my_rng = rb;
+            my_prosac = pb;
+            for (int j = 0; j < 4; j++)
+                my_c[j] = c[j];
+        }
+    }
+    // ---- every lane: its sample, the degeneracy test, the fit
+    const bool active = (uint32_t)lane < n;
+    bool live = active;
+    model_t m;
+    set_nan(m);
+    if (active)
+    {
+        uint32_t s4[4];
+        for (int j = 0; j < 4; j++)
+            s4[j] = has_quality ? sorted_idx[my_c[j]] : my_c[j];
+        double px[4], py[4], qx[4], qy[4];
+        for (int j = 0; j < 4; j++)
+        {
+            px[j] = pd.x1[s4[j]];
+            py[j] = pd.y1[s4[j]];
+            qx[j] = pd.x2[s4[j]];
+            qy[j] = pd.y2[s4[j]];
+        }
+        for (int a = 0; a < 4; a++)
+            for (int b = a + 1; b < 4; b++)
+                for (int c = b + 1; c < 4; c++)
+                {
+                    const double v1x = px[b] - px[a], v1y = py[b] - py[a];
+                    const double v2x = px[c] - px[a], v2y = py[c] - py[a];
+                    if (fabs(v1x * v2y - v1y * v2x) < 1e-10)
+                        live = false; // degenerate: the iteration ends here
+                }
+        if (live)
+            lane_fit(AQs + lane, px, py, qx, qy, m);
+    }
+    // ---- SPRT-pruned MSAC walk in evaluation order, one model per lane, the match uniform
+    double s = 0;
+    bool rej = false;
+    for (uint32_t pos = 0; pos < M; pos++)
+    {
+        if (__ballot(live && !rej) == 0)
+            break;
+        const double e = transfer_error(m, pd.ex1[pos], pd.ey1[pos], pd.ex2[pos], pd.ey2[pos]);
+        double term = 0;
+        if (e < thr)
+        {
+            const double ratio = e / thr;
+            term = 1.0 - ratio * ratio;
+        }
+        s = s + term;
+        const uint32_t checked = pos + 1;
+        if (checked > 20 && best_score > 0 && s < best_score * (double)checked / (double)M * 0.6)
+            rej = true;
+    }
+    const unsigned long long improving = __ballot(live && !rej && s > best_score);
+    if (improving == 0)
+    {
+        rng = rng_s;
+        prosac_n = prosac_s;
+        *found = false;
+        return n;
+    }
+    const int first = __builtin_ctzll(improving);
+    rng = (uint32_t)__builtin_amdgcn_readlane((int)my_rng, first);
+    prosac_n = (uint32_t)__builtin_amdgcn_readlane((int)my_prosac, first);
+    *found = true;
+    return (uint32_t)first;
+}
+
 template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_kernel(
     const ochip_ransac_job *__restrict__ jobs, const ochip_ransac_match *__restrict__ matches,
     const uint32_t *__restrict__ sorted_idx_all, const uint32_t *__restrict__ eval_order_all, rays_view rv,
-    double *__restrict__ coord_scratch /*4 x total*/, uint8_t *__restrict__ flag_scratch /*total*/,
+    double *__restrict__ coord_scratch /*8 x total*/, uint8_t *__restrict__ flag_scratch /*2 x total*/,
     double *__restrict__ P_scratch /*9 x (2 total + n_jobs)*/, uint64_t total, double thr,
     ochip_ransac_result *__restrict__ results, uint8_t *__restrict__ inliers_out)
 {
-    __shared__ double P9[81];
+    __shared__ double P9[81], T9[81], AQs[81 * FB];
     const int lane = threadIdx.x;
     const uint32_t job_id = blockIdx.x;
     const ochip_ransac_job job = jobs[job_id];
@@ -364,32 +926,43 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
     res.improvements = 0;
     res.reserved = 0;
 
-    uint8_t *inl = inliers_out + mo;
-    for (uint32_t i = lane; i < M; i += W)
-        inl[i] = 0;
     if (M < 4) // ransac.cpp:69-72
     {
+        for (uint32_t i = lane; i < M; i += W)
+            inliers_out[mo + i] = 0;
         if (lane == 0)
             results[job_id] = res;
         return;
     }
 
     // ---- prologue: gather the unit rays of the matched keypoints, divide by z once (error() and fit()
-    //      both start from measurement / measurement.z), detect has_quality (ransac.cpp:74-82)
+    //      both start from measurement / measurement.z), detect has_quality (ransac.cpp:74-82); the same
+    //      coordinates once more in evaluation order for the SPRT walks
+    const uint32_t *sorted_idx = sorted_idx_all + mo;
+    const uint32_t *eval_order = eval_order_all + job.eval_offset;
     pair_data pd;
     double *cx1 = coord_scratch + mo, *cy1 = coord_scratch + total + mo, *cx2 = coord_scratch + 2 * total + mo,
            *cy2 = coord_scratch + 3 * total + mo;
+    double *ex1 = coord_scratch + 4 * total + mo, *ey1 = coord_scratch + 5 * total + mo,
+           *ex2 = coord_scratch + 6 * total + mo, *ey2 = coord_scratch + 7 * total + mo;
     const double *r1 = rv.rays + rv.img_off[job.image_1] * 3, *r2 = rv.rays + rv.img_off[job.image_2] * 3;
     bool hq_lane = false;
     for (uint32_t i = lane; i < M; i += W)
     {
         const ochip_ransac_match mt = matches[mo + i];
+        const ochip_ransac_match me = matches[mo + eval_order[i]];
         const double ax = r1[(size_t)mt.k1 * 3], ay = r1[(size_t)mt.k1 * 3 + 1], az = r1[(size_t)mt.k1 * 3 + 2];
         const double bx = r2[(size_t)mt.k2 * 3], by = r2[(size_t)mt.k2 * 3 + 1], bz = r2[(size_t)mt.k2 * 3 + 2];
+        const double eax = r1[(size_t)me.k1 * 3], eay = r1[(size_t)me.k1 * 3 + 1], eaz = r1[(size_t)me.k1 * 3 + 2];
+        const double ebx = r2[(size_t)me.k2 * 3], eby = r2[(size_t)me.k2 * 3 + 1], ebz = r2[(size_t)me.k2 * 3 + 2];
         cx1[i] = ax / az;
         cy1[i] = ay / az;
         cx2[i] = bx / bz;
         cy2[i] = by / bz;
+        ex1[i] = eax / eaz;
+        ey1[i] = eay / eaz;
+        ex2[i] = ebx / ebz;
+        ey2[i] = eby / ebz;
         hq_lane |= (mt.count != 0); // quality = count * (1/486) != 0  <=>  count != 0
     }
     const bool has_quality = __ballot(hq_lane) != 0;
@@ -398,13 +971,16 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
     pd.y1 = cy1;
     pd.x2 = cx2;
     pd.y2 = cy2;
+    pd.ex1 = ex1;
+    pd.ey1 = ey1;
+    pd.ex2 = ex2;
+    pd.ey2 = ey2;
+    // two flag arrays that trade places on every improvement (the candidates of the improving model become the
+    // inliers); the final evaluation writes the caller's array
     pd.cand = flag_scratch + mo;
-    pd.inl = inl;
+    pd.inl = flag_scratch + total + mo;
     pd.P = P_scratch + 9 * (2 * mo + job_id);
     pd.M = M;
-
-    const uint32_t *sorted_idx = sorted_idx_all + mo;
-    const uint32_t *eval_order = eval_order_all + job.eval_offset;
 
     model_t model, best_model;
     set_nan(model);
@@ -418,6 +994,18 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
 
     for (; it < probability_iterations; it++)
     {
+        if (best_score > 0 && probability_iterations - it >= 4)
+        {
+            // look at the next iterations side by side and skip those that change nothing
+            const uint32_t n = min((uint32_t)FB, probability_iterations - it);
+            bool found;
+            it += fast_forward(pd, sorted_idx, has_quality, it, n, rng, prosac_n, best_score, thr, AQs, &found);
+            if (!found)
+            {
+                it--; // the loop's increment: the next iteration to look at is `it`
+                continue;
+            }
+        }
         if (has_quality && prosac_n < M && it > 0 && it % 10 == 0)
             prosac_n++;
 
@@ -425,46 +1013,18 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
         uint32_t s4[4];
         if (has_quality && prosac_n < M && prosac_n > 4)
         {
-            s4[0] = sorted_idx[prosac_n - 1];
-            for (int j = 1; j < 4; j++)
-            {
-                uint32_t cand;
-                bool unique;
-                do
-                {
-                    cand = sorted_idx[uniform_int(rng, prosac_n - 2)];
-                    unique = true;
-                    for (int k = 0; k < j; k++)
-                        if (s4[k] == cand)
-                        {
-                            unique = false;
-                            break;
-                        }
-                } while (!unique);
-                s4[j] = cand;
-            }
+            uint32_t c[4];
+            c[0] = prosac_n - 1; // never drawn again: the other three come from [0, prosac_n - 2]
+            draw_distinct(rng, prosac_n - 2, 1, c);
+            for (int j = 0; j < 4; j++)
+                s4[j] = sorted_idx[c[j]];
         }
         else
         {
-            const uint32_t pool = has_quality ? prosac_n : M;
+            uint32_t c[4];
+            draw_distinct(rng, (has_quality ? prosac_n : M) - 1, 0, c);
             for (int j = 0; j < 4; j++)
-            {
-                uint32_t cand;
-                bool unique;
-                do
-                {
-                    const uint32_t c = uniform_int(rng, pool - 1);
-                    cand = has_quality ? sorted_idx[c] : c;
-                    unique = true;
-                    for (int k = 0; k < j; k++)
-                        if (s4[k] == cand)
-                        {
-                            unique = false;
-                            break;
-                        }
-                } while (!unique);
-                s4[j] = cand;
-            }
+                s4[j] = has_quality ? sorted_idx[c[j]] : c[j];
         }
 
         // ---- checkSampleDegeneracy (homography_model.cpp:120-136) on measurement1.hnormalized()
@@ -496,7 +1056,7 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
         if (lane < 9)
             P9[lane * 9 + 8] = lane == 8 ? 1.0 : 0.0;
         double sol[9];
-        full_piv_lu_solve9(P9, 9, 9, sol);
+        full_piv_lu_solve9(P9, 9, sol);
         model_from_solution(model, sol);
 
         // ---- SPRT-pruned MSAC scoring in shuffled order (ransac.cpp:177-205)
@@ -512,43 +1072,59 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
             best_model = model;
             best_score = score;
             __syncthreads();
-            for (uint32_t i = lane; i < M; i += W)
-                pd.inl[i] = pd.cand[i];
-            __syncthreads();
+            {
+                uint8_t *t = pd.cand; // inliers = candidate flags of this model
+                pd.cand = pd.inl;
+                pd.inl = t;
+            }
+            uint32_t n_in = n_inl; // the scoring was not cut short, so it counted every inlier it flagged
 
             // local optimisation: fitInliers + evaluate, up to MAX_INNER_ITERATIONS (ransac.cpp:224-245)
             for (uint32_t j = 0; j < MAX_INNER_ITERATIONS; j++)
             {
-                // build the (2 n_inl + 1) x 9 system in index order (homography_model.cpp:52-79)
-                uint32_t n_in = 0;
-                for (uint32_t base = 0; base < M; base += W)
-                {
-                    const uint32_t i = base + lane;
-                    n_in += __popcll(__ballot(i < M && pd.inl[i]));
-                }
+                // build the (2 n_in + 1) x 9 system in index order (homography_model.cpp:52-79)
                 const uint32_t rows = 2 * n_in + 1, ld = rows;
                 uint32_t before = 0;
+                bool nf = (uint32_t)lane < M && pd.inl[lane];
+                double nx1 = nf ? pd.x1[lane] : 0.0, ny1 = nf ? pd.y1[lane] : 0.0, nx2 = nf ? pd.x2[lane] : 0.0,
+                       ny2 = nf ? pd.y2[lane] : 0.0;
                 for (uint32_t base = 0; base < M; base += W)
                 {
-                    const uint32_t i = base + lane;
-                    const bool f = i < M && pd.inl[i];
+                    const bool f = nf;
+                    const double x1 = nx1, y1 = ny1, x2 = nx2, y2 = ny2;
+                    {
+                        const uint32_t ni = base + W + lane;
+                        nf = ni < M && pd.inl[ni];
+                        nx1 = ni < M ? pd.x1[ni] : 0.0, ny1 = ni < M ? pd.y1[ni] : 0.0, nx2 = ni < M ? pd.x2[ni] : 0.0,
+                        ny2 = ni < M ? pd.y2[ni] : 0.0;
+                    }
                     const unsigned long long mask = __ballot(f);
                     if (f)
                     {
                         const uint32_t r = before + __popcll(mask & ((1ull << lane) - 1ull));
-                        write_dlt_rows(pd.P, ld, 2 * r, pd.x1[i], pd.y1[i], pd.x2[i], pd.y2[i]);
+                        write_dlt_rows(pd.P, ld, 2 * r, x1, y1, x2, y2);
                     }
                     before += __popcll(mask);
                 }
                 if (lane < 9)
                     pd.P[(size_t)lane * ld + rows - 1] = lane == 8 ? 1.0 : 0.0;
-                full_piv_lu_solve9(pd.P, rows, ld, sol);
+                if (rows > 9)
+                    tall_lu_solve9(pd.P, rows, T9, sol);
+                else
+                {
+                    // fewer than five inliers: the system is at most 9 x 9; the small factorisation runs it from LDS
+                    __syncthreads();
+                    for (uint32_t t = lane; t < rows * 9; t += W)
+                        T9[(t / rows) * 9 + (t % rows)] = pd.P[t];
+                    full_piv_lu_solve9(T9, rows, sol);
+                }
                 model_from_solution(model, sol);
                 bool dummy;
                 uint32_t cnt = 0;
                 __syncthreads();
                 const double inlier_score = score_model<false>(model, pd, nullptr, pd.inl, thr, 0.0, &dummy, &cnt);
                 __syncthreads();
+                n_in = cnt;
                 if (inlier_score > best_score)
                 {
                     best_model = model;
@@ -582,7 +1158,7 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
     bool dummy;
     uint32_t cnt = 0;
     __syncthreads();
-    const double final_score = score_model<false>(best_model, pd, nullptr, pd.inl, thr, 0.0, &dummy, &cnt);
+    const double final_score = score_model<false>(best_model, pd, nullptr, inliers_out + mo, thr, 0.0, &dummy, &cnt);
     for (int i = 0; i < 9; i++)
         res.H[i] = best_model.H[i];
     res.score = final_score / (double)M;
@@ -706,8 +1282,8 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
                              (size_t)T * sizeof(ochip_ransac_match),
                              (size_t)T * 4,
                              (size_t)(eval_total ? eval_total : 1) * 4,
-                             (size_t)T * 32,
-                             (size_t)T,
+                             (size_t)T * 64,
+                             (size_t)T * 2,
                              (size_t)(2 * T + n_jobs) * 72,
                              (size_t)n_jobs * sizeof(ochip_ransac_result) + T};
     for (int i = 0; i < 8; i++)
@@ -734,10 +1310,10 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
     ochip_prof_begin(ctx, OCHIP_K_RANSAC, &e0, &e1);
     static const int occ = []() {
         const char *e = getenv("OCHIP_RANSAC_OCC"); // waves per SIMD the register allocator targets (tuning knob)
-        // 2: with ~1 200 matches per pair a pair's LU workspace is ~170 KB, and more than ~2 000 resident pairs push
-        // the combined working set out of the 256 MB Infinity Cache (C3: 160 ms per 9 000 pairs at 2, 209 ms at 4)
+        // the wave keeps two models, a sample and the LU rows of a round in VGPRs (uniform fp64 values have no scalar
+        // home on gfx950): 2 waves per SIMD leaves it 256 registers, 1 leaves it 512
         const int v = e ? atoi(e) : 2;
-        return (v == 1 || v == 2 || v == 4) ? v : 2;
+        return (v == 1 || v == 2) ? v : 2;
     }();
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(n_jobs), dim3(W), 0, ctx->stream,
@@ -749,10 +1325,8 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
     };
     if (occ == 1)
         launch(ransac_homography_kernel<1>);
-    else if (occ == 2)
-        launch(ransac_homography_kernel<2>);
     else
-        launch(ransac_homography_kernel<4>);
+        launch(ransac_homography_kernel<2>);
     ochip_prof_end(ctx, OCHIP_K_RANSAC, e0, e1);
     OCHIP_HIP(ctx, hipGetLastError());
     OCHIP_HIP(ctx, hipMemcpyAsync(results, res_dev, (size_t)n_jobs * sizeof(ochip_ransac_result), hipMemcpyDeviceToHost,
