@@ -70,10 +70,11 @@ class SyntheticGrid:
 
 
 def make_grid(rows, cols, feats=4096, seed=12345, distractor_frac=0.3, flips=20, pixel_sigma=0.5, yaw_sigma=0.05,
-              height=100.0, along=25.0, cross=45.0, distortion=None):
+              height=100.0, along=25.0, cross=45.0, distortion=None, mismatch_frac=0.0):
     """rows x cols lawn-mower grid.  `feats` = ground points per footprint (they sit on a jittered
     lattice >= 40 px apart in every image, so they all survive the 40 px subsample of
-    link_stage.cpp:63-65)."""
+    link_stage.cpp:63-65).  `mismatch_frac`: share of an image's ground points that keep their descriptor but sit at a
+    random pixel - they still match across images and are true outliers for RANSAC."""
     rng = np.random.Generator(np.random.PCG64(seed))
     W, Hh, f = 4000, 3000, 3000.0
     model = np.array([f, W / 2, Hh / 2, 0, 0, 0, 0, 0, W, Hh], np.float64)
@@ -126,6 +127,9 @@ def make_grid(rows, cols, feats=4096, seed=12345, distractor_frac=0.3, flips=20,
             xd = rad * xn + 2 * xy * t[None, :] + t[None, ::-1] * (r2 + 2 * xn * xn)
             px = f * xd + model[1:3]
         px = px + rng.normal(0, pixel_sigma, px.shape)
+        if mismatch_frac > 0:   # (no draw otherwise: the default grids keep their random stream)
+            moved = rng.uniform(0, 1, len(px)) < mismatch_frac
+            px[moved] = np.stack([rng.uniform(0, W, int(moved.sum())), rng.uniform(0, Hh, int(moved.sum()))], -1)
         ok = (px[:, 0] >= 0) & (px[:, 0] < W) & (px[:, 1] >= 0) & (px[:, 1] < Hh) & (ray[:, 2] > 0)
         px, ids = px[ok], ids[ok]
         d = descriptors_for_ids(ids)

@@ -225,7 +225,8 @@ int oc_homography_decompose(const double *H, const double *corr, size_t M, const
 }
 
 // One directed pair of link_stage.cpp:75-112.  Output buffers sized for n_idx1 matches.
-// summary: [n_matches, n_inliers, can_decompose, accepted(edge has inlier list), ransac_score]
+// summary: [n_matches, n_inliers, can_decompose, accepted(edge has inlier list), ransac_score, ransac iterations,
+//           ransac improvements]
 void oc_link_pair(const double *loc1, const uint64_t *desc1, size_t n1, const uint64_t *idx1, size_t n_idx1,
                   const double *loc2, const uint64_t *desc2, size_t n2, const uint64_t *idx2, size_t n_idx2,
                   const double *model1, const double *model2, uint64_t *m_i1, uint64_t *m_i2, double *m_dist,
@@ -257,6 +258,8 @@ void oc_link_pair(const double *loc1, const uint64_t *desc1, size_t n1, const ui
     summary[2] = r.can_decompose;
     summary[3] = !r.inlier_matches.empty();
     summary[4] = r.ransac_score;
+    summary[5] = (double)r.ransac_iterations;
+    summary[6] = (double)r.ransac_improvements;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -21,7 +21,10 @@ camera_relations link_pair(const std::vector<feature_2d> &f1, const std::vector<
 
     homography_model h; // :91-93
     std::vector<bool> coarse_inliers;
-    relations.ransac_score = ransac(coarse_correspondences, h, coarse_inliers);
+    ransac_trace trace;
+    relations.ransac_score = ransac(coarse_correspondences, h, coarse_inliers, &trace);
+    relations.ransac_iterations = trace.iterations;
+    relations.ransac_improvements = trace.improvements;
 
     relations.ransac_relation = h.homography; // :95
 

@@ -239,6 +239,7 @@ struct camera_relations // camera_relations.hpp:13-35
     size_t num_coarse_matches = 0;
     bool can_decompose = false;
     double ransac_score = 0;
+    size_t ransac_iterations = 0, ransac_improvements = 0;
 };
 // link_stage.cpp:75-112 body of the per-pair closure.  idx1/idx2 are the 40 px subsets (the reference
 // recomputes idx2 per pair, link_stage.cpp:80-81; the result only depends on the image).

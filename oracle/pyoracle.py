@@ -300,13 +300,13 @@ def link_pair(loc1, desc1, idx1, loc2, desc2, idx2, model1, model2):
     n = max(len(idx1), 1)
     mi1, mi2, md = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n)
     inl = np.zeros(n, np.uint8)
-    H, poses, summary = np.zeros((3, 3)), np.zeros((4, 8)), np.zeros(5)
+    H, poses, summary = np.zeros((3, 3)), np.zeros((4, 8)), np.zeros(7)
     lib().oc_link_pair(loc1, desc1, len(desc1), idx1, len(idx1), loc2, desc2, len(desc2), idx2, len(idx2), model1,
                        model2, mi1, mi2, md, inl, H, poses, summary)
     m = int(summary[0])
     return dict(i1=mi1[:m].copy(), i2=mi2[:m].copy(), dist=md[:m].copy(), inliers=inl[:m].copy(), H=H, poses=poses,
                 n_inliers=int(summary[1]), can_decompose=bool(summary[2]), accepted=bool(summary[3]),
-                score=float(summary[4]))
+                score=float(summary[4]), iterations=int(summary[5]), improvements=int(summary[6]))
 
 
 def scene_homography(n_in, n_out, seed):

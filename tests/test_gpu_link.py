@@ -42,6 +42,7 @@ def _check_grid(ctx, oracle, grid, max_pairs=None):
         assert np.array_equal(d["inliers"], e["inliers"]), (a, b, d["iterations"])
         assert d["score"] == e["score"], (a, b)          # bit-exact fp64
         assert d["can_decompose"] == e["can_decompose"]
+        assert (d["iterations"], d["improvements"]) == (e["iterations"], e["improvements"]), (a, b)
         checked += 1
     # the graph edges carry the same payloads, in the reference's deterministic order
     edges = g.edges()
@@ -77,6 +78,23 @@ def test_link_stage_with_outliers_and_few_matches(ctx, oracle):
     images that do not overlap at all (few or no matches, RANSAC early-outs, edge not accepted)."""
     grid = synth.make_grid(1, 4, feats=300, seed=5, flips=95, distractor_frac=1.0, along=60.0)
     assert _check_grid(ctx, oracle, grid) == 4 * 3
+
+
+@pytest.mark.parametrize("kw, min_iterations", [
+    (dict(rows=1, cols=3, feats=300, seed=5, mismatch_frac=0.45), 2000),     # ~20 % inliers: thousands of iterations
+    (dict(rows=1, cols=3, feats=200, seed=6, mismatch_frac=0.6, along=40.0), 10000),  # 5 inliers: MAX_ITERATIONS, tiny LO systems
+    (dict(rows=2, cols=2, feats=1500, seed=8, mismatch_frac=0.35), 250),     # several hundred matches, hundreds of iterations
+])
+def test_ransac_with_true_outliers(ctx, oracle, kw, min_iterations):
+    """Matches that are wrong geometrically (same descriptor, random pixel): RANSAC runs hundreds to 10 000 iterations,
+    which the kernel walks 32 at a time (fast_forward) - iteration and improvement counts, inlier sets, scores and
+    homographies must still be the one-at-a-time loop's, bit for bit."""
+    grid = synth.make_grid(**kw)
+    g = host.Graph.from_synthetic(grid)
+    g.link(ctx, keep_debug=True)
+    assert min(d["iterations"] for d in g.link_debug()) >= min_iterations
+    g.close()
+    assert _check_grid(ctx, oracle, grid) == grid.n_images * (grid.n_images - 1)
 
 
 def test_link_and_relax_with_lens_distortion(ctx, oracle):
