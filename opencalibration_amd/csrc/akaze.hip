@@ -852,101 +852,70 @@ __device__ __forceinline__ bool xcd_contiguous(unsigned int block, unsigned int 
 }
 
 // A candidate dies if a stronger maximum (ties: lower (level, y, x) wins) of an adjacent level lies within
-// its own size esigma * derivative_factor (base-image pixels).  One wavefront per candidate: each lane takes one
-// (row, mask word) of a window of the maxima bit masks of up to three levels (a window is at most ~17 pixels wide, so one
-// or two words per row and one round per candidate), walks the set bits inside the window and reads a response only for a
-// maximum that lies inside the radius; the lanes vote with a ballot (any killer decides, so the order of the scan does
-// not matter).  Scanning the float maps themselves cost 64x the loads for windows that are almost all zeros.
+// its own size esigma * derivative_factor (base-image pixels).  One THREAD per candidate, walking the maxima bit
+// masks of up to three levels: a window is at most ~17 pixels wide, i.e. one or two 64-bit words per row, and almost
+// every word is zero, so a candidate costs ~100 word loads and a handful of response reads.  (A wavefront per candidate
+// - first over the float maps, then over the masks - spent ~300 wave instructions per candidate however little its
+// lanes had to do: 30 us per image, VALU-issue bound.)  List neighbours are spatial neighbours (tile order), so the
+// lanes of a wave read the same few mask lines.
 __global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
                                                        unsigned int max_cands, const float *__restrict__ Rmax, size_t img_stride,
                                                        const unsigned long long *__restrict__ mask, size_t mask_stride,
                                                        levels_dev L, float derivative_factor, unsigned char *__restrict__ dead)
 {
     const unsigned int b = blockIdx.z;
-    const int lane = threadIdx.x & 63;
-    const unsigned int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    // the candidate is fetched together with the count (one memory round trip, not two); its fields are the same in
-    // every lane, so the level records come through the scalar cache
-    cand_t c = cands[(size_t)b * max_cands + min(k, max_cands - 1)];
-    const unsigned int n = min(n_cands[b], max_cands);
-    if (k >= n)
+    const unsigned int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= min(n_cands[b], max_cands))
         return;
-    c.level = __builtin_amdgcn_readfirstlane(c.level);
-    c.x = __builtin_amdgcn_readfirstlane(c.x);
-    c.y = __builtin_amdgcn_readfirstlane(c.y);
+    const cand_t c = cands[(size_t)b * max_cands + k];
     const level_info lc = L.l[c.level];
     const float ratio_c = (float)(1 << lc.octave);
     const float rad = lc.esigma * derivative_factor, r2 = rad * rad;
     const float cx = (float)c.x * ratio_c, cy = (float)c.y * ratio_c;
-    const float *R[3];
-    const unsigned long long *M[3];
-    int wx0[3], wx1[3], wy0[3], ww0[3], wnw[3], wtotal[3], wlw[3], wtx[3], wj[3];
-    float wratio[3];
-    int max_total = 0;
-#pragma unroll
-    for (int q = 0; q < 3; q++)
+    bool is_dead = false;
+    for (int j = max(c.level - 1, 0); j <= min(c.level + 1, L.n - 1) && !is_dead; j++)
     {
-        const int j = c.level - 1 + q;
-        const bool use = j >= 0 && j < L.n;
-        const level_info lj = L.l[use ? j : c.level];
+        const level_info lj = L.l[j];
         const float ratio = (float)(1 << lj.octave), inv = 1.0f / ratio; // power of two: * inv == / ratio, bit for bit
         const int x0 = max((int)floorf((cx - rad) * inv), 0), x1 = min((int)ceilf((cx + rad) * inv), lj.w - 1);
         const int y0 = max((int)floorf((cy - rad) * inv), 0), y1 = min((int)ceilf((cy + rad) * inv), lj.h - 1);
-        R[q] = Rmax + (size_t)b * img_stride + lj.off;
-        M[q] = mask + (size_t)b * mask_stride + (size_t)lj.mask_off;
-        wx0[q] = x0;
-        wx1[q] = x1;
-        wy0[q] = y0;
-        ww0[q] = x0 >> 6;
-        wnw[q] = (x1 >> 6) - (x0 >> 6) + 1;
-        wtotal[q] = use && x1 >= x0 && y1 >= y0 ? wnw[q] * (y1 - y0 + 1) : 0;
-        wlw[q] = lj.w;
-        wtx[q] = lj.tiles_x;
-        wj[q] = j;
-        wratio[q] = ratio;
-        max_total = max(max_total, wtotal[q]);
-    }
-    bool is_dead = false;
-    for (int t0 = 0; t0 < max_total && !is_dead; t0 += 64)
-    {
-        const int t = t0 + lane;
-        unsigned long long m[3];
-        int wx[3], yy[3];
-#pragma unroll
-        for (int q = 0; q < 3; q++)
+        const float *R = Rmax + (size_t)b * img_stride + lj.off;
+        const unsigned long long *M = mask + (size_t)b * mask_stride + (size_t)lj.mask_off;
+        for (int wx = x0 >> 6; wx <= (x1 >> 6) && !is_dead; wx++)
         {
-            const bool act = t < wtotal[q];
-            const int row = act ? t / wnw[q] : 0;
-            yy[q] = wy0[q] + row;
-            wx[q] = ww0[q] + (act ? t - row * wnw[q] : 0);
-            m[q] = act ? M[q][(size_t)yy[q] * wtx[q] + wx[q]] : 0ull;
-        }
-        bool kill = false;
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-        {
-            // bits of this word inside [x0, x1]
-            const int lo = max(wx0[q] - wx[q] * 64, 0), hi = min(wx1[q] - wx[q] * 64, 63);
-            unsigned long long bits = hi >= lo ? m[q] & (~0ull << lo) & (~0ull >> (63 - hi)) : 0ull;
-            while (bits)
+            // bits of this word column inside [x0, x1]
+            const int lo = max(x0 - wx * 64, 0), hi = min(x1 - wx * 64, 63);
+            const unsigned long long window = (~0ull << lo) & (~0ull >> (63 - hi));
+            for (int yb = y0; yb <= y1 && !is_dead; yb += 4)
             {
-                const int xx = wx[q] * 64 + __ffsll((long long)bits) - 1;
-                bits &= bits - 1;
-                if (wj[q] == c.level && xx == c.x && yy[q] == c.y)
-                    continue;
-                const float ex = (float)xx * wratio[q] - cx, ey = (float)yy[q] * wratio[q] - cy;
-                if (ex * ex + ey * ey <= r2)
+                unsigned long long m[4]; // four rows' words requested together
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    m[r] = yb + r <= y1 ? M[(size_t)(yb + r) * lj.tiles_x + wx] & window : 0ull;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
                 {
-                    const float r = R[q][(size_t)yy[q] * wlw[q] + xx];
-                    const bool lower_key = wj[q] < c.level || (wj[q] == c.level && (yy[q] < c.y || (yy[q] == c.y && xx < c.x)));
-                    kill = kill || r > c.response || (r == c.response && lower_key);
+                    unsigned long long bits = m[r];
+                    const int yy = yb + r;
+                    while (bits)
+                    {
+                        const int xx = wx * 64 + __ffsll((long long)bits) - 1;
+                        bits &= bits - 1;
+                        if (j == c.level && xx == c.x && yy == c.y)
+                            continue;
+                        const float ex = (float)xx * ratio - cx, ey = (float)yy * ratio - cy;
+                        if (ex * ex + ey * ey <= r2)
+                        {
+                            const float rr = R[(size_t)yy * lj.w + xx];
+                            const bool lower_key = j < c.level || (j == c.level && (yy < c.y || (yy == c.y && xx < c.x)));
+                            is_dead = is_dead || rr > c.response || (rr == c.response && lower_key);
+                        }
+                    }
                 }
             }
         }
-        is_dead = __ballot(kill) != 0;
     }
-    if (lane == 0)
-        dead[(size_t)b * max_cands + k] = is_dead ? 1 : 0;
+    dead[(size_t)b * max_cands + k] = is_dead ? 1 : 0;
 }
 
 // ---- float-only math shared with the CPU restatement (deterministic: + - * / and compares only)
@@ -1958,7 +1927,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     static const int xcd_remap = getenv("OCHIP_XCD_REMAP") ? atoi(getenv("OCHIP_XCD_REMAP")) : 2; // tuning knob, see xcd_contiguous
     if (max_n > 0)
     {
-        hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 3) / 4, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
+        hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 255) / 256, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
                            (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride,
                            (const unsigned long long *)d_mask, mask_stride, LV, dfactor, d_dead);
         hipLaunchKernelGGL(describe_kernel, dim3(2048 * ((max_n + 2047) / 2048), 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
