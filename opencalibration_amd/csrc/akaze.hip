@@ -1067,12 +1067,17 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         const int iy1 = clampi((int)rintf(yf + (float)(j1 * s)), 0, h - 1), ix1 = clampi((int)rintf(xf + (float)(i1 * s)), 0, w - 1);
         const float lx0 = pLx[(size_t)iy0 * w + ix0], ly0 = pLy[(size_t)iy0 * w + ix0];
         const float lx1 = second ? pLx[(size_t)iy1 * w + ix1] : 0.0f, ly1 = second ? pLy[(size_t)iy1 * w + ix1] : 0.0f;
+        // an angle of exactly 0 or 2 pi lies in no window (they are open intervals inside (0, 2 pi)); stored as NaN
+        // it fails every comparison below, which lets a window test be two compares
+        const float TWO_PI = 6.28318530717958647692f, QNAN = __builtin_nanf("");
         const float rx0 = og0 * lx0, ry0 = og0 * ly0;
-        osmp[lane] = make_float4(rx0, ry0, fast_atan2(ry0, rx0), 0.0f);
+        const float a0 = fast_atan2(ry0, rx0);
+        osmp[lane] = make_float4(rx0, ry0, (a0 > 0.0f && a0 < TWO_PI) ? a0 : QNAN, 0.0f);
         if (second)
         {
             const float rx1 = og1 * lx1, ry1 = og1 * ly1;
-            osmp[lane + 64] = make_float4(rx1, ry1, fast_atan2(ry1, rx1), 0.0f);
+            const float a1 = fast_atan2(ry1, rx1);
+            osmp[lane + 64] = make_float4(rx1, ry1, (a1 > 0.0f && a1 < TWO_PI) ? a1 : QNAN, 0.0f);
         }
     }
     __syncthreads();
@@ -1084,21 +1089,20 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
     {
         const float ang1 = tab->win_ang1[lane]; // float-accumulated window starts (host table, as the restatement's loop)
         const float ang2 = (ang1 + PI_F / 3.0f > TWO_PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
-        // the window as two open intervals: (ang1, ang2) and nothing, or - wrapped - (0, ang2) and (ang1, 2 pi);
-        // written without short-circuits so that the loop has no branches and its LDS reads are issued in batches
-        const bool plain = ang1 < ang2, wrapped = ang2 < ang1;
-        const float INF = __builtin_huge_valf();
-        const float lo1 = plain ? ang1 : 0.0f, hi1 = (plain || wrapped) ? ang2 : -INF;
-        const float lo2 = wrapped ? ang1 : INF, hi2 = wrapped ? TWO_PI_F : -INF;
+        // the window is the open interval (ang1, ang2), or - wrapped - (0, ang2) and (ang1, 2 pi): with the angles 0
+        // and 2 pi out of the way (NaN) that is "above ang1 AND below ang2", or for a wrapped window OR.  No
+        // short-circuits: the loop has no branches and its LDS reads are issued in batches.  The selected sample enters
+        // as x * 1 + sum (one rounding, that of the add) or x * 0 + sum (the sum, unchanged).
+        const bool wrapped = ang2 < ang1;
         float sumX = 0.0f, sumY = 0.0f;
 #pragma unroll 8
         for (int q = 0; q < 109; q++)
         {
             const float4 sm = osmp[q];
-            const float a = sm.z;
-            const bool in = ((a > lo1) & (a < hi1)) | ((a > lo2) & (a < hi2));
-            sumX = sumX + (in ? sm.x : 0.0f);
-            sumY = sumY + (in ? sm.y : 0.0f);
+            const bool c1 = sm.z > ang1, c2 = sm.z < ang2;
+            const float in = ((c1 & c2) | (wrapped & (c1 | c2))) ? 1.0f : 0.0f;
+            sumX = __builtin_fmaf(sm.x, in, sumX);
+            sumY = __builtin_fmaf(sm.y, in, sumY);
         }
         wmag = sumX * sumX + sumY * sumY;
         wangle = fast_atan2(sumY, sumX);
@@ -1166,20 +1170,28 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         const int step = (lvl == 0) ? 10 : (lvl == 1 ? 7 : 5); // ceil(20 / g)
         const int i0 = -10 + (cell / g) * step, j0 = -10 + (cell % g) * step;
         float di = 0.0f, ddx = 0.0f, ddy = 0.0f, ns = 0.0f;
-        for (int a = i0; a < i0 + step; a++)
-        {
-            int p = (a + 10) * 21 + (j0 + 10);
-            for (int bb = 0; bb < step; bb++, p++)
+        // every cell walks its step x step samples row by row; the walk is written once over the largest cell (10 x 10,
+        // fully unrolled, LDS offsets immediate) and a lane takes part in a step while it is inside its own cell:
+        // the 4 x 4 grid's lanes (13..28, step 5) in the first 5 x 5, the 3 x 3 grid's (4..12, step 7) in the first
+        // 7 x 7, the 2 x 2 grid's (0..3) everywhere - each lane still adds its samples in its own row-major order
+        const float4 *pb = &smp[(i0 + 10) * 21 + (j0 + 10)];
+#pragma unroll
+        for (int a = 0; a < 10; a++)
+#pragma unroll
+            for (int bb = 0; bb < 10; bb++)
             {
-                // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
-                // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch here
-                const float4 v = smp[p];
-                di = di + v.x;
-                ddx = ddx + v.y;
-                ddy = ddy + v.z;
-                ns = ns + v.w; // small integers: exact in float
+                const int limit = (a < 5 && bb < 5) ? 29 : ((a < 7 && bb < 7) ? 13 : 4);
+                if (lane < limit)
+                {
+                    // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
+                    // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch here
+                    const float4 v = pb[a * 21 + bb];
+                    di = di + v.x;
+                    ddx = ddx + v.y;
+                    ddy = ddy + v.z;
+                    ns = ns + v.w; // small integers: exact in float
+                }
             }
-        }
         const float inv = fmaxf(ns, 1.0f);
         vals[lane][0] = di / inv;
         vals[lane][1] = ddx / inv;
