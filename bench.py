@@ -50,6 +50,11 @@ def main():
     # torch.distributed.run exports OMP_NUM_THREADS=1 for every worker unless the user set it; that default is not a
     # choice made for this program (its host phases are OpenMP-parallel), so it is replaced.  OCHIP_HOST_THREADS pins it.
     os.environ["OMP_NUM_THREADS"] = str(int(os.environ.get("OCHIP_HOST_THREADS", omp_threads)))
+    # idle team members sleep instead of spinning, and host threads waiting for the device block instead of polling: on a
+    # box whose CPU quota is smaller than the thread count the spinning was throttling the working threads (C3, 16-CPU
+    # quota: 668 -> 591 ms per step, 30 % less CPU time)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    os.environ.setdefault("OCHIP_BLOCKING_SYNC", "1")
 
     import torch
     import torch.distributed as dist

@@ -155,7 +155,8 @@ int ochip_ctx_create(int device, ochip_ctx **out)
         return ochip_fail(nullptr, OCHIP_ENOMEM, "host allocation failed");
     ctx->device = device;
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess && getenv("OCHIP_BLOCKING_SYNC"))
+    const char *bsync = getenv("OCHIP_BLOCKING_SYNC");
+    if (e == hipSuccess && !(bsync && bsync[0] == '0')) // default on; OCHIP_BLOCKING_SYNC=0 keeps the runtime's polling
     {
         // waits sleep instead of spinning: host threads that wait for the device do not eat into a CPU quota the
         // OpenMP teams of the host phases need (refused harmlessly if the device is already active with other flags)

@@ -41,10 +41,12 @@ def effective_cpus():
 
 def host_threads():
     """OpenMP team size for the host phases.  They are short bursts between device phases (tens of ms of every
-    100 ms cfs period), so a team of twice the quota finishes them sooner without exhausting the period's
-    budget; measured on the 16-CPU-quota MI355X boxes: 16 -> 32 threads gains ~8 % end to end, 64 and more get
-    throttled (DESIGN.md)."""
-    return max(1, min(len(os.sched_getaffinity(0)), 2 * effective_cpus()))
+    100 ms cfs period), so a team larger than the quota finishes them sooner without exhausting the period's
+    budget - provided idle members sleep (OMP_WAIT_POLICY=passive, set in load()) and threads waiting for the device
+    block (OCHIP_BLOCKING_SYNC, default on).  Measured on the 16-CPU-quota MI355X boxes, C3 ms per step:
+    24 threads 624, 32 600, 48 586, 64 563, 96 568, 128 582 (with spinning waits 32 threads took 668 and 64 were
+    throttled)."""
+    return max(1, min(len(os.sched_getaffinity(0)), 4 * effective_cpus()))
 
 
 def load():
@@ -53,6 +55,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise capi.OchipError(f"{LIB_PATH} is missing: run `python -m opencalibration_amd.build`")
         os.environ.setdefault("OMP_NUM_THREADS", str(host_threads()))  # read by libgomp when the library loads
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")           # idle team members sleep (CPU quota, see bench.py)
         capi.load()  # libochip.so first (liboc_host.so links against it)
         L = C.CDLL(LIB_PATH)
         L.och_subsample.restype = C.c_size_t
