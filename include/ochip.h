@@ -96,7 +96,9 @@ extern "C"
      *      (replaces cvtColor + resize(INTER_AREA, max side 1600) + cv::AKAZE::detectAndCompute of
      *      src/extract/extract_features.cpp:25-36; AKAZE restated from its publication) ---- */
     /* images_bgr: n_images x height x width x 3 bytes.  Per image up to max_kp keypoints are written, in
-     * unspecified order: kp6[(i*max_kp + k)*6] = {x, y, diameter, angle (radians), response, evolution level}
+     * cv::AKAZE's detection order (evolution level, then row, then column of the extremum - the order the
+     * unstable std::sort of extract_features.cpp:55-56 starts from, which decides the result when responses tie):
+     * kp6[(i*max_kp + k)*6] = {x, y, diameter, angle (radians), response, evolution level}
      * in pixels of the working (downscaled) image, desc[(i*max_kp + k)*8] = descriptor words (bit j = word j>>6,
      * bit j&63, the packing of extract_features.cpp:47-51); counts[i] = keypoints of image i;
      * work_wh = working width, height. */

@@ -994,7 +994,8 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
                                                       const float *__restrict__ gw /*13x13*/, const pair_tab *__restrict__ tab,
                                                       float *__restrict__ kp_out /*[b][max][6]*/,
                                                       unsigned long long *__restrict__ desc_out /*[b][max][8]*/,
-                                                      unsigned char *__restrict__ valid_out, int remap)
+                                                      unsigned char *__restrict__ valid_out, int remap,
+                                                      unsigned long long *__restrict__ vmask, size_t mask_stride)
 {
     __shared__ float4 osmp[109]; // orientation samples: weighted dx, dy, their angle (one 16-byte LDS read each)
     __shared__ float vals[29][3];
@@ -1221,51 +1222,99 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         o[4] = c.response;
         o[5] = (float)c.level;
         valid_out[slot] = 1;
+        // the keypoint's bit in the image's (level, y, x)-ordered mask: its rank there is its place in the output
+        atomicOr(&vmask[(size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6)],
+                 1ull << (c.x & 63));
     }
 }
 
-// Stream compaction of the described keypoints of one image (one workgroup per image, ascending slot order):
-// only the survivors cross PCIe.  counts[b] is the number found; entries beyond max_kp are dropped and the host
-// reports the overflow.
-__global__ __launch_bounds__(256) void compact_kernel(const unsigned char *__restrict__ valid, const unsigned int *__restrict__ n_cands,
-                                                      unsigned int max_cands, const float *__restrict__ kp,
-                                                      const unsigned long long *__restrict__ desc, float *__restrict__ kp_out,
-                                                      unsigned long long *__restrict__ desc_out, unsigned int max_kp,
-                                                      unsigned int *__restrict__ counts)
+// The keypoints leave the device in AKAZE's detection order (level, then row, then column of the extremum - the order
+// of Find_Scale_Space_Extrema's loops), not in the tile order of the candidate list: the reference sorts them by
+// response with an unstable std::sort, whose result depends on the order it starts from whenever two responses are
+// equal (918 of the 1 000 rendered C3 views have such ties).  The maxima-mask layout [level][row][64-pixel word] IS
+// that order, so a keypoint's output position is the number of valid bits before its own: rank_scan_kernel turns the
+// valid mask into per-word exclusive counts (one workgroup per image, 8 words per thread and pass), and
+// compact_ordered_kernel places every valid slot.  Entries beyond max_kp are dropped; counts[b] is the number found
+// and the host reports the overflow.
+__global__ __launch_bounds__(256) void rank_scan_kernel(const unsigned long long *__restrict__ vmask, size_t mask_stride,
+                                                        unsigned int *__restrict__ wbase, unsigned int *__restrict__ counts)
 {
-    __shared__ unsigned int wsum[4], base;
-    const unsigned int b = blockIdx.x, n = min(n_cands[b], max_cands);
+    constexpr int PER = 8;
+    __shared__ unsigned int wsum[4], carry;
+    const unsigned int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long *M = vmask + (size_t)b * mask_stride;
+    unsigned int *Wb = wbase + (size_t)b * mask_stride;
     if (threadIdx.x == 0)
-        base = 0;
+        carry = 0;
     __syncthreads();
-    for (unsigned int start = 0; start < n; start += 256)
+    for (size_t start = 0; start < mask_stride; start += 256 * PER)
     {
-        const unsigned int k = start + threadIdx.x;
-        const size_t slot = (size_t)b * max_cands + k;
-        const bool v = k < n && valid[slot] != 0;
-        const unsigned long long mask = __ballot(v);
-        if (lane == 0)
-            wsum[wv] = (unsigned int)__popcll(mask);
-        __syncthreads();
-        unsigned int pos = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
-        for (int j = 0; j < wv; j++)
-            pos += wsum[j];
-        if (v && pos < max_kp)
+        const size_t first = start + (size_t)threadIdx.x * PER;
+        unsigned int pc[PER], total = 0;
+#pragma unroll
+        for (int i = 0; i < PER; i++)
         {
-            const size_t o = (size_t)b * max_kp + pos;
-            for (int i = 0; i < 6; i++)
-                kp_out[o * 6 + i] = kp[slot * 6 + i];
-            for (int i = 0; i < 8; i++)
-                desc_out[o * 8 + i] = desc[slot * 8 + i];
+            pc[i] = first + i < mask_stride ? (unsigned int)__popcll(M[first + i]) : 0u;
+            total += pc[i];
+        }
+        unsigned int incl = total; // inclusive scan of the threads' totals inside the wavefront
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const unsigned int t = (unsigned int)__shfl_up((int)incl, off);
+            if (lane >= off)
+                incl += t;
+        }
+        if (lane == 63)
+            wsum[wv] = incl;
+        __syncthreads();
+        unsigned int base = carry + incl - total;
+        for (int j = 0; j < wv; j++)
+            base += wsum[j];
+#pragma unroll
+        for (int i = 0; i < PER; i++)
+        {
+            if (first + i < mask_stride)
+                Wb[first + i] = base;
+            base += pc[i];
         }
         __syncthreads();
         if (threadIdx.x == 0)
-            base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
         __syncthreads();
     }
     if (threadIdx.x == 0)
-        counts[b] = base;
+        counts[b] = carry;
+}
+
+__global__ __launch_bounds__(256) void compact_ordered_kernel(const unsigned char *__restrict__ valid, const cand_t *__restrict__ cands,
+                                                              const unsigned int *__restrict__ n_cands, unsigned int max_cands,
+                                                              const unsigned long long *__restrict__ vmask,
+                                                              const unsigned int *__restrict__ wbase, size_t mask_stride,
+                                                              levels_dev L, const float *__restrict__ kp,
+                                                              const unsigned long long *__restrict__ desc, float *__restrict__ kp_out,
+                                                              unsigned long long *__restrict__ desc_out, unsigned int max_kp)
+{
+    const unsigned int b = blockIdx.z, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= min(n_cands[b], max_cands))
+        return;
+    const size_t slot = (size_t)b * max_cands + k;
+    if (!valid[slot])
+        return;
+    const cand_t c = cands[slot];
+    const level_info l = L.l[c.level];
+    const size_t word = (size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6);
+    const unsigned int pos = wbase[word] + (unsigned int)__popcll(vmask[word] & ((1ull << (c.x & 63)) - 1ull));
+    if (pos < max_kp)
+    {
+        const size_t o = (size_t)b * max_kp + pos;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            kp_out[o * 6 + i] = kp[slot * 6 + i];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            desc_out[o * 8 + i] = desc[slot * 8 + i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------- host side
@@ -1626,7 +1675,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned long long *d_desc = nullptr, *d_descc = nullptr;
     float *d_kpc = nullptr;
     unsigned int *d_counts = nullptr, *d_tile_counts = nullptr, *d_tile_base = nullptr, *d_tile_seq = nullptr;
-    unsigned long long *d_mask = nullptr;
+    unsigned long long *d_mask = nullptr, *d_vmask = nullptr;
+    unsigned int *d_wbase = nullptr;
     pair_tab *d_tab = nullptr;
     const size_t src_px = (size_t)width * height;
     // 1-D tile grids padded to a multiple of 8 workgroups (xcd_tile)
@@ -1663,6 +1713,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     AK(up<unsigned int>(ctx, allocs, &d_tile_counts, nullptr, (size_t)B * n_tiles));
     AK(up<unsigned int>(ctx, allocs, &d_tile_base, nullptr, (size_t)B * n_tiles));
     AK(up<unsigned long long>(ctx, allocs, &d_mask, nullptr, (size_t)B * mask_stride));
+    AK(up<unsigned long long>(ctx, allocs, &d_vmask, nullptr, (size_t)B * mask_stride));
+    AK(up<unsigned int>(ctx, allocs, &d_wbase, nullptr, (size_t)B * mask_stride));
     {
         // processing order of the detection tiles: level by level, Morton order inside a level
         std::vector<std::pair<uint64_t, unsigned int>> keyed;
@@ -1939,18 +1991,24 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     static const int xcd_remap = getenv("OCHIP_XCD_REMAP") ? atoi(getenv("OCHIP_XCD_REMAP")) : 2; // tuning knob, see xcd_contiguous
     if (max_n > 0)
     {
+        OCHIP_HIP(ctx, hipMemsetAsync(d_vmask, 0, (size_t)B * mask_stride * 8, st));
         hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 255) / 256, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
                            (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride,
                            (const unsigned long long *)d_mask, mask_stride, LV, dfactor, d_dead);
         hipLaunchKernelGGL(describe_kernel, dim3(2048 * ((max_n + 2047) / 2048), 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
                            (const unsigned int *)d_ncand, max_cands, (const unsigned char *)d_dead, (const float *)d_Lt,
                            (const float *)d_Lx, (const float *)d_Ly, (const float *)d_Ldet, img_stride, LV, dfactor,
-                           (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap);
+                           (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap, d_vmask, mask_stride);
     }
     if (max_n > 0)
-        hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, st, (const unsigned char *)d_valid,
-                           (const unsigned int *)d_ncand, max_cands, (const float *)d_kp, (const unsigned long long *)d_desc,
-                           d_kpc, d_descc, max_kp, d_counts);
+    {
+        hipLaunchKernelGGL(rank_scan_kernel, dim3(B), dim3(256), 0, st, (const unsigned long long *)d_vmask, mask_stride, d_wbase,
+                           d_counts);
+        hipLaunchKernelGGL(compact_ordered_kernel, dim3((max_n + 255) / 256, 1, B), dim3(256), 0, st,
+                           (const unsigned char *)d_valid, (const cand_t *)d_cands, (const unsigned int *)d_ncand, max_cands,
+                           (const unsigned long long *)d_vmask, (const unsigned int *)d_wbase, mask_stride, LV,
+                           (const float *)d_kp, (const unsigned long long *)d_desc, d_kpc, d_descc, max_kp);
+    }
     else
         OCHIP_HIP(ctx, hipMemsetAsync(d_counts, 0, B * 4, st));
     ochip_prof_end(ctx, OCHIP_K_AKAZE, e0, e1);

@@ -58,55 +58,97 @@ struct nn_grid
 };
 
 // The host tail of src/extract/extract_features.cpp:38-87 for one image: n device keypoints (k6 = x, y, size,
-// angle, response, level in working-image pixels; arbitrary order) -> [sparse..., dense...] features.
+// angle, response, level in working-image pixels; AKAZE's detection order) -> [sparse..., dense...] features.
+static double g_tail_prof[5]; // CPU seconds: ordering, NMS, feature records, total (OCHIP_EXTRACT_VERBOSE)
+static double thread_cpu_now()
+{
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale, extracted_features &out)
 {
+    static const bool prof = std::getenv("OCHIP_EXTRACT_VERBOSE") != nullptr;
+    const double tp0 = prof ? thread_cpu_now() : 0;
+    double tp1 = 0, tp2 = 0;
     const double nms_pixel_radius = 8;
-    // device order is arbitrary: restore detection order (level, y, x), then the reference's unstable std::sort
-    // by response.  Both sorts permute 4-byte indices; std::sort's compare/move sequence depends only on the
-    // comparator's answers, so the permutation is the one sorting the feature structs themselves would give.
-    // (the keys of the first sort are unique, so any sorting algorithm restores the same order: positive floats
-    // order like their bit patterns, which makes the key two integers in one contiguous record)
-    struct det_key
-    {
-        uint64_t level_y;
-        uint32_t x, idx;
-    };
-    std::vector<det_key> keys(n);
-    for (uint32_t i = 0; i < n; i++)
-    {
-        const float *p = k6 + 6 * (size_t)i;
-        uint32_t xb, yb;
-        std::memcpy(&xb, p, 4);
-        std::memcpy(&yb, p + 1, 4);
-        keys[i] = det_key{((uint64_t)(uint32_t)p[5] << 32) | yb, xb, i};
-    }
-    std::sort(keys.begin(), keys.end(), [](const det_key &a, const det_key &c) {
-        return a.level_y != c.level_y ? a.level_y < c.level_y : a.x < c.x;
-    });
+    // The device hands the keypoints over in AKAZE's detection order (level, row, column of the extremum), which is
+    // what the reference's unstable std::sort by response starts from.  That starting order only matters when two
+    // responses are equal, so the responses are first ordered with a radix sort of their bit patterns (positive floats
+    // order like unsigned integers; three counting passes over 16 k keys); an image in which two keypoints share a
+    // response exactly (most of the rendered benchmark views do) takes the reference's route: std::sort of the
+    // indices 0..n-1, whose compare/move sequence depends only on the comparator's answers and therefore yields the
+    // permutation that sorting the feature structs themselves would.
     std::vector<uint32_t> order(n);
-    std::vector<float> response(n); // by keypoint index, contiguous for the comparator below
-    for (uint32_t i = 0; i < n; i++)
+    bool unique_responses = n > 0;
     {
-        order[i] = keys[i].idx;
-        response[i] = k6[6 * (size_t)i + 4];
+        static thread_local std::vector<uint64_t> a, c; // ~response bits << 32 | index: ascending = strongest first
+        a.resize(n);
+        c.resize(n);
+        for (uint32_t i = 0; i < n; i++)
+        {
+            uint32_t rb;
+            std::memcpy(&rb, k6 + 6 * (size_t)i + 4, 4);
+            if (rb & 0x80000000u) // a negative (or -0) response does not order like its bits: comparison route
+                unique_responses = false;
+            a[i] = ((uint64_t)(~rb) << 32) | i;
+        }
+        if (unique_responses)
+        {
+            for (int pass = 0; pass < 3; pass++)
+            {
+                const int shift = 32 + 11 * pass;
+                uint32_t count[2048] = {0};
+                for (uint32_t i = 0; i < n; i++)
+                    count[(a[i] >> shift) & 2047]++;
+                uint32_t sum = 0;
+                for (uint32_t d = 0; d < 2048; d++)
+                {
+                    const uint32_t t = count[d];
+                    count[d] = sum;
+                    sum += t;
+                }
+                for (uint32_t i = 0; i < n; i++)
+                    c[count[(a[i] >> shift) & 2047]++] = a[i];
+                a.swap(c);
+            }
+            for (uint32_t i = 0; i < n; i++)
+            {
+                order[i] = (uint32_t)a[i];
+                if (i && (a[i] >> 32) == (a[i - 1] >> 32))
+                    unique_responses = false;
+            }
+        }
     }
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) -> bool { return response[a] > response[c]; });
-    auto make = [&](uint32_t s) {
-        feature_2d p;
-        p.location[0] = k6[6 * (size_t)s] / scale; // keypoints[i].pt.x / scale, extract_features.cpp:44-45
-        p.location[1] = k6[6 * (size_t)s + 1] / scale;
-        p.strength = k6[6 * (size_t)s + 4];
-        std::memcpy(p.descriptor, dd + 8 * (size_t)s, 64);
-        return p;
-    };
+    if (!unique_responses)
+    {
+        if (prof)
+        {
+#pragma omp atomic
+            g_tail_prof[4] += 1.0;
+        }
+        static thread_local std::vector<float> response; // contiguous for the comparator below
+        response.resize(n);
+        for (uint32_t i = 0; i < n; i++)
+        {
+            order[i] = i;
+            response[i] = k6[6 * (size_t)i + 4];
+        }
+        const float *r = response.data();
+        std::sort(order.begin(), order.end(), [r](uint32_t a, uint32_t c) -> bool { return r[a] > r[c]; });
+    }
+    if (prof)
+        tp1 = thread_cpu_now();
     out.features.clear();
     out.num_sparse_features = 0;
     if (n == 0)
         return;
     // non-maximal suppression, extract_features.cpp:58-83 (the seeded first keypoint is visited again by the
     // loop and therefore also heads the dense list)
-    std::vector<double> lx(n), ly(n);
+    static thread_local std::vector<double> lx, ly;
+    lx.resize(n);
+    ly.resize(n);
     double minx = std::numeric_limits<double>::infinity(), miny = minx, maxx = -minx, maxy = -minx;
     for (uint32_t i = 0; i < n; i++)
     {
@@ -134,12 +176,33 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
         else
             dense.push_back(i);
     }
+    if (prof)
+        tp2 = thread_cpu_now();
     out.num_sparse_features = sparse.size();
     out.features.reserve(sparse.size() + dense.size());
+    auto emit = [&](uint32_t i) { // i = position in strength order
+        const uint32_t s = order[i];
+        out.features.emplace_back();
+        feature_2d &p = out.features.back();
+        p.location[0] = lx[i]; // keypoints[i].pt.x / scale, extract_features.cpp:44-45
+        p.location[1] = ly[i];
+        p.strength = k6[6 * (size_t)s + 4];
+        std::memcpy(p.descriptor, dd + 8 * (size_t)s, 64);
+    };
     for (uint32_t i : sparse)
-        out.features.push_back(make(order[i]));
+        emit(i);
     for (uint32_t i : dense)
-        out.features.push_back(make(order[i]));
+        emit(i);
+    if (prof)
+    {
+        const double tp3 = thread_cpu_now();
+        const double d[4] = {tp1 - tp0, tp2 - tp1, tp3 - tp2, tp3 - tp0};
+        for (int i = 0; i < 4; i++)
+        {
+#pragma omp atomic
+            g_tail_prof[i] += d[i];
+        }
+    }
 }
 
 struct chunk_buffers
@@ -333,8 +396,12 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
     for (auto &t : drivers)
         t.join();
     if (std::getenv("OCHIP_EXTRACT_VERBOSE"))
-        fprintf(stderr, "[extract] %u images: host tail %.3f thread-seconds (%.2f ms per image)\n", n_images, tail_cpu_seconds,
-                1e3 * tail_cpu_seconds / n_images);
+    {
+        fprintf(stderr, "[extract] %u images: host tail %.3f thread-seconds of wall time (%.2f ms per image)\n", n_images,
+                tail_cpu_seconds, 1e3 * tail_cpu_seconds / n_images);
+        fprintf(stderr, "[extract] cumulative CPU seconds of the tail: ordering %.3f, NMS %.3f, feature records %.3f, total %.3f; images with tied responses %.0f\n",
+                g_tail_prof[0], g_tail_prof[1], g_tail_prof[2], g_tail_prof[3], g_tail_prof[4]);
+    }
     release();
     if (!fail.empty())
     {

@@ -33,28 +33,33 @@ def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000, ov
     g = host.Graph()
     mid = g.add_model(grid.model)
     if overlap:
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         feats_mean, sparse_mean, link_timers, (t_ex, t_all) = g.load_link_images(
             ctx, images_ptr, mid, grid.position, start_orientation, max_keypoints, device_shape=(n, h, w))
         t["extract"], t["link"] = t_ex, time.perf_counter() - t0 - t_ex   # link = what the linking adds after the last features
-        t0 = time.perf_counter()
+        t["host_cpu_load_link"] = time.process_time() - c0                 # CPU seconds of all host threads
+        t0, c0 = time.perf_counter(), time.process_time()
         rel = g.relax_ground_plane(ctx, start_orientation)
         ctx.synchronize()
         t["relax"] = time.perf_counter() - t0
+        t["host_cpu_relax"] = time.process_time() - c0
         res = dict(features_per_image=feats_mean, sparse_per_image=sparse_mean, link_timers=link_timers, relax=rel,
                    edges=g.num_edges)
         return g, res, t
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     feats_mean, sparse_mean = g.load_images(ctx, images_ptr, mid, grid.position, max_keypoints, device_shape=(n, h, w))
     t["extract"] = time.perf_counter() - t0
+    t["host_cpu_extract"] = time.process_time() - c0   # CPU seconds of all host threads
     g.set_orientations(start_orientation)
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     link_timers = g.link(ctx)
     t["link"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
+    t["host_cpu_link"] = time.process_time() - c0
+    t0, c0 = time.perf_counter(), time.process_time()
     rel = g.relax_ground_plane(ctx, start_orientation)
     ctx.synchronize()
     t["relax"] = time.perf_counter() - t0
+    t["host_cpu_relax"] = time.process_time() - c0
     res = dict(features_per_image=feats_mean, sparse_per_image=sparse_mean, link_timers=link_timers, relax=rel,
                edges=g.num_edges)
     return g, res, t

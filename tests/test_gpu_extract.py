@@ -28,8 +28,8 @@ def test_akaze_matches_restatement_bitwise(ctx, oracle, w, h):
     got, (ww, wh) = ctx.akaze_batch(imgs, max_kp=20000)
     assert (ww, wh) == (w, h)
     for i in range(len(imgs)):
-        ekp, edesc = _sorted(*oracle.akaze(imgs[i][:, :, 0]))     # grey of a grey-valued BGR image is itself
-        gkp, gdesc = _sorted(*got[i])
+        ekp, edesc = oracle.akaze(imgs[i][:, :, 0])     # grey of a grey-valued BGR image is itself
+        gkp, gdesc = got[i]                             # same ORDER too: the detection order (level, row, column)
         assert len(gkp) == len(ekp) and len(ekp) > 50   # descriptor windows near the border are excluded (AKAZE)
         assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32))     # positions, sizes, angles, responses
         assert np.array_equal(gdesc, edesc)
