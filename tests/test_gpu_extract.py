@@ -70,6 +70,20 @@ def test_extract_features_host_tail(ctx, oracle):
     assert host.extract_features_batch(ctx, np.zeros((0, 4, 4, 3), np.uint8)) == []
 
 
+def test_tied_responses_follow_the_reference_sort(ctx, oracle):
+    """A periodic image has keypoints with bit-identical responses.  extract_features orders by response with an
+    unstable std::sort (extract_features.cpp:55-56), so the result depends on the order the keypoints arrive in:
+    AKAZE's detection order, which is the order the device hands them over in."""
+    base = synth.render_blobs(400, 304, 21)
+    img = np.ascontiguousarray(np.tile(base, (2, 2, 1)))
+    (gloc, gst, gdesc, gns), = host.extract_features_batch(ctx, img[None])
+    eloc, est, edesc, ens = oracle.extract_features(img)
+    _, counts = np.unique(est, return_counts=True)
+    assert int((counts > 1).sum()) > 100         # hundreds of tied groups
+    assert gns == ens and np.array_equal(gst, est)
+    assert np.array_equal(gloc, eloc) and np.array_equal(gdesc, edesc)
+
+
 def test_two_views_match(ctx):
     """The extracted descriptors are usable: two renderings of one scene (shift + rotation) match through the
     device matcher with the ratio test, and the matches are geometrically consistent."""
