@@ -152,6 +152,8 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
     double minx = std::numeric_limits<double>::infinity(), miny = minx, maxx = -minx, maxy = -minx;
     for (uint32_t i = 0; i < n; i++)
     {
+        if (i + 16 < n)
+            __builtin_prefetch(k6 + 6 * (size_t)order[i + 16]);
         lx[i] = k6[6 * (size_t)order[i]] / scale;
         ly[i] = k6[6 * (size_t)order[i] + 1] / scale;
         minx = std::min(minx, lx[i]);
@@ -189,10 +191,23 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
         p.strength = k6[6 * (size_t)s + 4];
         std::memcpy(p.descriptor, dd + 8 * (size_t)s, 64);
     };
-    for (uint32_t i : sparse)
-        emit(i);
-    for (uint32_t i : dense)
-        emit(i);
+    // the records are gathered in strength order, i.e. from random places of the device's arrays: ask for the lines of
+    // the entries a few steps ahead while this one is copied
+    auto emit_all = [&](const std::vector<uint32_t> &list) {
+        const size_t m = list.size();
+        for (size_t j = 0; j < m; j++)
+        {
+            if (j + 8 < m)
+            {
+                const uint32_t s = order[list[j + 8]];
+                __builtin_prefetch(dd + 8 * (size_t)s);
+                __builtin_prefetch(k6 + 6 * (size_t)s + 4);
+            }
+            emit(list[j]);
+        }
+    };
+    emit_all(sparse);
+    emit_all(dense);
     if (prof)
     {
         const double tp3 = thread_cpu_now();
