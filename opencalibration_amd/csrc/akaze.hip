@@ -211,7 +211,8 @@ struct blur_args
     const float *kcontrast; // FLOW
     int n_octave_steps;     // FLOW
     unsigned int *partial_max; // MODG: [image][workgroup] bit patterns of the tile maxima
-    float *out2;               // FLOW_DERIV: Ly (out1 = Lx), both with out2_stride; out0 = conductivity with out_stride
+    float *out2;               // unused.  DERIV: out0 = the interleaved (Lx, Ly) float2 plane, out_stride in float2;
+                               // FLOW_DERIV: out1 = that plane with out2_stride (float2), out0 = conductivity with out_stride
     size_t out2_stride;
 };
 
@@ -310,17 +311,12 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
                 const float wn = wgt * nrm;
                 float dx, dy;
                 pattern_lds<(M > 0 ? M : 1), BW>(c, nrm, wn, &dx, &dy);
+                // Lx and Ly leave as one interleaved float2 plane: their consumers (determinant, orientation, descriptor)
+                // always want both at the same pixel, and the descriptor's gathers are what bounds it
                 if (MODE == BLUR_DERIV)
-                {
-                    A.out0[o] = dx;
-                    A.out1[o] = dy;
-                }
+                    reinterpret_cast<float2 *>(A.out0)[o] = make_float2(dx, dy);
                 else
-                {
-                    const size_t o2 = (size_t)blockIdx.z * A.out2_stride + (size_t)y * w + x;
-                    A.out1[o2] = dx;
-                    A.out2[o2] = dy;
-                }
+                    reinterpret_cast<float2 *>(A.out1)[(size_t)blockIdx.z * A.out2_stride + (size_t)y * w + x] = make_float2(dx, dy);
             }
             if (MODE != BLUR_DERIV)
             {
@@ -361,16 +357,9 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
                            reflect101_once(y + M, h), nrm, wn, &dx, &dy);
 
             if (MODE == BLUR_DERIV)
-            {
-                A.out0[o] = dx;
-                A.out1[o] = dy;
-            }
+                reinterpret_cast<float2 *>(A.out0)[o] = make_float2(dx, dy);
             else
-            {
-                const size_t o2 = (size_t)blockIdx.z * A.out2_stride + (size_t)y * w + x;
-                A.out1[o2] = dx;
-                A.out2[o2] = dy;
-            }
+                reinterpret_cast<float2 *>(A.out1)[(size_t)blockIdx.z * A.out2_stride + (size_t)y * w + x] = make_float2(dx, dy);
         }
         if (MODE != BLUR_DERIV)
         {
@@ -584,7 +573,7 @@ struct cand_t
 // pass: the Lx / Ly tiles (+ halo S + 1) are staged in LDS, the determinant tile (+ halo 1) is built over them,
 // and the level's sparse maxima map (response at maxima, 0 elsewhere) is written next to the determinant.
 template <int S>
-__global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict__ Lx, const float *__restrict__ Ly, size_t stride,
+__global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restrict__ Lxy, size_t stride,
                                                          float *__restrict__ Ldet, float *__restrict__ Rmax, int w, int h,
                                                          float thr, unsigned int *__restrict__ tile_counts, int tile_off,
                                                          int n_tiles, float margin, unsigned long long *__restrict__ mask,
@@ -599,7 +588,7 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
         return;
     const int x0 = tile_x * BT_X, y0 = tile_y * DT_Y;
     const int rx0 = x0 - HW, ry0 = y0 - HW;
-    const float *X = Lx + (size_t)blockIdx.z * stride, *Y = Ly + (size_t)blockIdx.z * stride;
+    const float2 *XY = Lxy + (size_t)blockIdx.z * stride;
     {
         constexpr int ITERS = (RW * RH + 255) / 256; // all loads in flight before the first LDS store
         float vx[ITERS], vy[ITERS];
@@ -610,8 +599,9 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float *__restrict
             const int ly = idx / RW, lx = idx - ly * RW;
             const int gx = rx0 + lx, gy = ry0 + ly;
             const bool in = idx < RW * RH && gx >= 0 && gx < w && gy >= 0 && gy < h;
-            vx[it] = in ? X[(size_t)gy * w + gx] : 0.0f;
-            vy[it] = in ? Y[(size_t)gy * w + gx] : 0.0f;
+            const float2 v = in ? XY[(size_t)gy * w + gx] : make_float2(0.0f, 0.0f);
+            vx[it] = v.x;
+            vy[it] = v.y;
         }
 #pragma unroll
         for (int it = 0; it < ITERS; it++)
@@ -976,6 +966,8 @@ __device__ __forceinline__ void sincos_poly(float a, float *s, float *c)
         *s = -cs, *c = sn;
 }
 
+typedef float pkf2 __attribute__((ext_vector_type(2))); // two fp32 lanes of one packed VALU instruction
+
 struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cells numbered 0..3 | 4..12 | 13..28
 {
     unsigned int bits[512];  // bit -> a | b << 8 | channel << 16 (one dword per comparison; entries >= 486 unused)
@@ -988,8 +980,8 @@ struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cell
 // Sums run in the restatement's sequential order (one lane per window / per grid cell) so bits agree.
 __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
                                                       unsigned int max_cands, const unsigned char *__restrict__ dead,
-                                                      const float *__restrict__ Lt, const float *__restrict__ Lx,
-                                                      const float *__restrict__ Ly, const float *__restrict__ Ldet,
+                                                      const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
+                                                      const float *__restrict__ Ldet,
                                                       size_t img_stride, levels_dev L, float derivative_factor,
                                                       const float *__restrict__ gw /*13x13*/, const pair_tab *__restrict__ tab,
                                                       float *__restrict__ kp_out /*[b][max][6]*/,
@@ -1056,8 +1048,8 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
     const float size = 2.0f * (l.esigma * derivative_factor);
     const float xf = kx / ratio, yf = ky / ratio;
     const int s = (int)rintf(0.5f * size / ratio);
-    const float *pLt = Lt + (size_t)b * img_stride + l.off, *pLx = Lx + (size_t)b * img_stride + l.off,
-                *pLy = Ly + (size_t)b * img_stride + l.off;
+    const float *pLt = Lt + (size_t)b * img_stride + l.off;
+    const float2 *pLxy = Lxy + (size_t)b * img_stride + l.off;
 
     // orientation samples: index order i (outer), j (inner) over the radius-6 disc; lane handles samples lane and
     // lane + 64, the four loads issued together
@@ -1066,8 +1058,9 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         const bool second = lane + 64 < 109;
         const int iy0 = clampi((int)rintf(yf + (float)(j0 * s)), 0, h - 1), ix0 = clampi((int)rintf(xf + (float)(i0 * s)), 0, w - 1);
         const int iy1 = clampi((int)rintf(yf + (float)(j1 * s)), 0, h - 1), ix1 = clampi((int)rintf(xf + (float)(i1 * s)), 0, w - 1);
-        const float lx0 = pLx[(size_t)iy0 * w + ix0], ly0 = pLy[(size_t)iy0 * w + ix0];
-        const float lx1 = second ? pLx[(size_t)iy1 * w + ix1] : 0.0f, ly1 = second ? pLy[(size_t)iy1 * w + ix1] : 0.0f;
+        const float2 g0 = pLxy[(size_t)iy0 * w + ix0];
+        const float2 g1 = second ? pLxy[(size_t)iy1 * w + ix1] : make_float2(0.0f, 0.0f);
+        const float lx0 = g0.x, ly0 = g0.y, lx1 = g1.x, ly1 = g1.y;
         // an angle of exactly 0 or 2 pi lies in no window (they are open intervals inside (0, 2 pi)); stored as NaN
         // it fails every comparison below, which lets a window test be two compares
         const float TWO_PI = 6.28318530717958647692f, QNAN = __builtin_nanf("");
@@ -1095,16 +1088,16 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         // short-circuits: the loop has no branches and its LDS reads are issued in batches.  The selected sample enters
         // as x * 1 + sum (one rounding, that of the add) or x * 0 + sum (the sum, unchanged).
         const bool wrapped = ang2 < ang1;
-        float sumX = 0.0f, sumY = 0.0f;
+        pkf2 sum = {0.0f, 0.0f}; // (sumX, sumY): one packed fp32 FMA per sample (v_pk_fma_f32), IEEE per component
 #pragma unroll 8
         for (int q = 0; q < 109; q++)
         {
             const float4 sm = osmp[q];
             const bool c1 = sm.z > ang1, c2 = sm.z < ang2;
             const float in = ((c1 & c2) | (wrapped & (c1 | c2))) ? 1.0f : 0.0f;
-            sumX = __builtin_fmaf(sm.x, in, sumX);
-            sumY = __builtin_fmaf(sm.y, in, sumY);
+            sum = __builtin_elementwise_fma(pkf2{sm.x, sm.y}, pkf2{in, in}, sum);
         }
+        const float sumX = sum.x, sumY = sum.y;
         wmag = sumX * sumX + sumY * sumY;
         wangle = fast_atan2(sumY, sumX);
     }
@@ -1143,8 +1136,9 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
             inside[t] = p < 441 && !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
             const size_t o = inside[t] ? (size_t)y1 * w + x1 : 0;
             ri[t] = pLt[o];
-            rx[t] = pLx[o];
-            ry[t] = pLy[o];
+            const float2 g = pLxy[o];
+            rx[t] = g.x;
+            ry[t] = g.y;
         }
 #pragma unroll
         for (int t = 0; t < 7; t++)
@@ -1170,29 +1164,48 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         const int g = lvl + 2;
         const int step = (lvl == 0) ? 10 : (lvl == 1 ? 7 : 5); // ceil(20 / g)
         const int i0 = -10 + (cell / g) * step, j0 = -10 + (cell % g) * step;
-        float di = 0.0f, ddx = 0.0f, ddy = 0.0f, ns = 0.0f;
+        pkf2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f}; // (di, ddx), (ddy, ns): packed fp32 adds, IEEE per component
         // every cell walks its step x step samples row by row; the walk is written once over the largest cell (10 x 10,
         // fully unrolled, LDS offsets immediate) and a lane takes part in a step while it is inside its own cell:
         // the 4 x 4 grid's lanes (13..28, step 5) in the first 5 x 5, the 3 x 3 grid's (4..12, step 7) in the first
         // 7 x 7, the 2 x 2 grid's (0..3) everywhere - each lane still adds its samples in its own row-major order
         const float4 *pb = &smp[(i0 + 10) * 21 + (j0 + 10)];
+        // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
+        // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch here
+        auto run = [&](int a, int b0, int b1) { // columns b0..b1-1 of row a (compile-time after unrolling)
 #pragma unroll
-        for (int a = 0; a < 10; a++)
-#pragma unroll
-            for (int bb = 0; bb < 10; bb++)
+            for (int bb = b0; bb < b1; bb++)
             {
-                const int limit = (a < 5 && bb < 5) ? 29 : ((a < 7 && bb < 7) ? 13 : 4);
-                if (lane < limit)
-                {
-                    // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
-                    // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch here
-                    const float4 v = pb[a * 21 + bb];
-                    di = di + v.x;
-                    ddx = ddx + v.y;
-                    ddy = ddy + v.z;
-                    ns = ns + v.w; // small integers: exact in float
-                }
+                const float4 v = pb[a * 21 + bb];
+                acc01 = acc01 + pkf2{v.x, v.y};
+                acc23 = acc23 + pkf2{v.z, v.w}; // ns: small integers, exact in float
             }
+        };
+        // the set of lanes only changes where a row leaves a smaller cell: 22 predicated regions, not 100
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+        {
+            run(a, 0, 5); // every lane (29)
+            if (lane < 13)
+                run(a, 5, 7);
+            if (lane < 4)
+                run(a, 7, 10);
+        }
+#pragma unroll
+        for (int a = 5; a < 7; a++)
+        {
+            if (lane < 13)
+                run(a, 0, 7);
+            if (lane < 4)
+                run(a, 7, 10);
+        }
+        if (lane < 4)
+        {
+#pragma unroll
+            for (int a = 7; a < 10; a++)
+                run(a, 0, 10);
+        }
+        const float di = acc01.x, ddx = acc01.y, ddy = acc23.x, ns = acc23.y;
         const float inv = fmaxf(ns, 1.0f);
         vals[lane][0] = di / inv;
         vals[lane][1] = ddx / inv;
@@ -1667,7 +1680,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     } while (0)
     uint8_t *d_bgr = nullptr, *d_gray = nullptr;
     float *d_img = nullptr, *d_flow = nullptr, *d_ping = nullptr;
-    float *d_Lt = nullptr, *d_Lx = nullptr, *d_Ly = nullptr, *d_Ldet = nullptr, *d_Rmax = nullptr, *d_kc = nullptr,
+    float2 *d_Lxy = nullptr; // (Lx, Ly) interleaved, indexed like the other pyramids
+    float *d_Lt = nullptr, *d_Ldet = nullptr, *d_Rmax = nullptr, *d_kc = nullptr,
           *d_gw = nullptr, *d_kp = nullptr;
     unsigned int *d_hmax = nullptr, *d_hist = nullptr, *d_ncand = nullptr, *d_pmax = nullptr;
     cand_t *d_cands = nullptr;
@@ -1694,8 +1708,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     AK(up<float>(ctx, allocs, &d_ping, nullptr, (size_t)B * plane0));
     AK(up<unsigned int>(ctx, allocs, &d_pmax, nullptr, (size_t)B * n_tiles0));
     AK(up<float>(ctx, allocs, &d_Lt, nullptr, (size_t)B * img_stride));
-    AK(up<float>(ctx, allocs, &d_Lx, nullptr, (size_t)B * img_stride));
-    AK(up<float>(ctx, allocs, &d_Ly, nullptr, (size_t)B * img_stride));
+    AK(up<float2>(ctx, allocs, &d_Lxy, nullptr, (size_t)B * img_stride));
     AK(up<float>(ctx, allocs, &d_Ldet, nullptr, (size_t)B * img_stride));
     AK(up<float>(ctx, allocs, &d_Rmax, nullptr, (size_t)B * img_stride));
     AK(up<float>(ctx, allocs, &d_kc, nullptr, B));
@@ -1885,7 +1898,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         {
             // Lsmooth of the level (Gaussian(1) of the image it starts from) -> conductivity AND the detector's
             // scale-s derivatives Lx, Ly (AKAZE computes both on evolution[i].Lsmooth), one pass
-            blur_args a{src, src_stride, d_flow, d_Lx + l.off, plane0, l.w, l.h, d_kc, octave_steps, nullptr, d_Ly + l.off, img_stride};
+            blur_args a{src, src_stride, d_flow, (float *)(d_Lxy + l.off), plane0, l.w, l.h, d_kc, octave_steps, nullptr, nullptr, img_stride};
             if (l.sigma_size == 2)
                 hipLaunchKernelGGL((blur_fused_kernel<BLUR_FLOW_DERIV, 2, 2>), tiles(l.w, l.h), dim3(256), 0, st, a, g1);
             else if (l.sigma_size == 3)
@@ -1941,7 +1954,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             taps_t one{};
             one.n = 1;
             one.k[0] = 1.0f;
-            blur_args a{d_Lt + l.off, img_stride, d_Lx + l.off, d_Ly + l.off, img_stride, l.w, l.h, nullptr, 0, nullptr, nullptr, 0};
+            blur_args a{d_Lt + l.off, img_stride, (float *)(d_Lxy + l.off), nullptr, img_stride, l.w, l.h, nullptr, 0, nullptr, nullptr, 0};
             if (l.sigma_size == 2)
                 hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 2, 0>), tiles(l.w, l.h), dim3(256), 0, st, a, one);
             else if (l.sigma_size == 3)
@@ -1955,17 +1968,17 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             }
         }
         {
-            const float *lx = d_Lx + l.off, *ly = d_Ly + l.off;
+            const float2 *lxy = d_Lxy + l.off;
             float *ld = d_Ldet + l.off, *rm = d_Rmax + l.off;
             const float margin = (10.0f * std::sqrt(2.0f)) * (float)l.sigma_size; // descriptor window half width, M-LDB
             if (l.sigma_size == 2)
-                hipLaunchKernelGGL((det_maxima_kernel<2>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
+                hipLaunchKernelGGL((det_maxima_kernel<2>), det_tiles(l.w, l.h), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin, d_mask + l.mask_off, mask_stride);
             else if (l.sigma_size == 3)
-                hipLaunchKernelGGL((det_maxima_kernel<3>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
+                hipLaunchKernelGGL((det_maxima_kernel<3>), det_tiles(l.w, l.h), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin, d_mask + l.mask_off, mask_stride);
             else
-                hipLaunchKernelGGL((det_maxima_kernel<4>), det_tiles(l.w, l.h), dim3(256), 0, st, lx, ly, img_stride, ld, rm, l.w,
+                hipLaunchKernelGGL((det_maxima_kernel<4>), det_tiles(l.w, l.h), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin, d_mask + l.mask_off, mask_stride);
         }
     }
@@ -1997,7 +2010,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                            (const unsigned long long *)d_mask, mask_stride, LV, dfactor, d_dead);
         hipLaunchKernelGGL(describe_kernel, dim3(2048 * ((max_n + 2047) / 2048), 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
                            (const unsigned int *)d_ncand, max_cands, (const unsigned char *)d_dead, (const float *)d_Lt,
-                           (const float *)d_Lx, (const float *)d_Ly, (const float *)d_Ldet, img_stride, LV, dfactor,
+                           (const float2 *)d_Lxy, (const float *)d_Ldet, img_stride, LV, dfactor,
                            (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap, d_vmask, mask_stride);
     }
     if (max_n > 0)
