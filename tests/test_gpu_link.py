@@ -84,6 +84,9 @@ def test_link_stage_with_outliers_and_few_matches(ctx, oracle):
     (dict(rows=1, cols=3, feats=300, seed=5, mismatch_frac=0.45), 2000),     # ~20 % inliers: thousands of iterations
     (dict(rows=1, cols=3, feats=200, seed=6, mismatch_frac=0.6, along=40.0), 10000),  # 5 inliers: MAX_ITERATIONS, tiny LO systems
     (dict(rows=2, cols=2, feats=1500, seed=8, mismatch_frac=0.35), 250),     # several hundred matches, hundreds of iterations
+    # every Hamming distance 0 -> no correspondence has a quality -> uniform sampling instead of PROSAC (ransac.cpp:83-90)
+    (dict(rows=1, cols=3, feats=300, seed=9, mismatch_frac=0.4, flips=0, distractor_frac=0.0), 1000),
+    (dict(rows=1, cols=2, feats=60, seed=10, mismatch_frac=0.5, flips=0, distractor_frac=0.0, along=55.0), 10000),
 ])
 def test_ransac_with_true_outliers(ctx, oracle, kw, min_iterations):
     """Matches that are wrong geometrically (same descriptor, random pixel): RANSAC runs hundreds to 10 000 iterations,
