@@ -109,6 +109,76 @@ __global__ __launch_bounds__(256) void resize_area_kernel(const uint8_t *__restr
     }
 }
 
+// The same resize with the source window of a workgroup (256 destination columns x RESIZE_ROWS rows) staged in LDS by
+// dword loads: the per-tap single-byte global loads of the kernel above (about a dozen per destination pixel) were
+// what it spent its time on.  Needs a source width that is a multiple of 4 and a window that fits the tile; the host
+// checks both against the tables and falls back to the kernel above otherwise.  Same taps, same order, same sums.
+// FROM_BGR: the staging converts the BGR source to grey on the way in (cvtColor's fixed-point weights, four pixels from
+// three dwords as in gray4_kernel), so the full-resolution grey image is neither written nor read.
+constexpr int RS_PITCH = 704, RS_ROWS = 32; // bytes per staged row, staged rows (2.5 : 1 needs 648 x 21)
+template <bool FROM_BGR>
+__global__ __launch_bounds__(256) void resize_area_lds_kernel(const uint8_t *__restrict__ src, int sw, int sh, float *__restrict__ dst,
+                                                              int dw, int dh, const int *__restrict__ xoff,
+                                                              const int *__restrict__ xsi, const float *__restrict__ xal,
+                                                              const int *__restrict__ yoff, const int *__restrict__ ysi,
+                                                              const float *__restrict__ yal)
+{
+    __shared__ unsigned int tile[RS_ROWS * RS_PITCH / 4];
+    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * RESIZE_ROWS;
+    const int x1 = min(x0 + 256, dw), y1 = min(y0 + RESIZE_ROWS, dh);
+    const int cx0 = xsi[xoff[x0]] & ~3, cx1 = xsi[xoff[x1] - 1]; // source columns cx0..cx1
+    const int ry0 = ysi[yoff[y0]], ry1 = ysi[yoff[y1] - 1];      // source rows ry0..ry1
+    const int nd = (cx1 - cx0) / 4 + 1, nr = ry1 - ry0 + 1;
+    const uint8_t *s = src + (size_t)blockIdx.z * sw * sh * (FROM_BGR ? 3 : 1);
+    for (int idx = threadIdx.x; idx < nd * nr; idx += 256)
+    {
+        const int row = idx / nd, d = idx - row * nd;
+        if (FROM_BGR)
+        {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(s + 3 * ((size_t)(ry0 + row) * sw + cx0 + 4 * d));
+            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+            auto g = [](uint32_t b, uint32_t gg, uint32_t r) { return (b * 1868u + gg * 9617u + r * 4899u + (1u << 13)) >> 14; };
+            const uint32_t p0 = g(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
+            const uint32_t p1 = g(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
+            const uint32_t p2 = g((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
+            const uint32_t p3 = g((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
+            tile[row * (RS_PITCH / 4) + d] = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+        }
+        else
+            tile[row * (RS_PITCH / 4) + d] = *reinterpret_cast<const unsigned int *>(s + (size_t)(ry0 + row) * sw + cx0 + 4 * d);
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= dw)
+        return;
+    const uint8_t *t8 = reinterpret_cast<const uint8_t *>(tile);
+    const int k0 = xoff[x], nk = xoff[x + 1] - k0;
+    int si[RESIZE_MAX_TAPS];
+    float al[RESIZE_MAX_TAPS];
+#pragma unroll
+    for (int k = 0; k < RESIZE_MAX_TAPS; k++)
+    {
+        si[k] = k < nk ? xsi[k0 + k] - cx0 : 0;
+        al[k] = k < nk ? xal[k0 + k] : 0.0f;
+    }
+    for (int y = y0; y < y1; y++)
+    {
+        float acc = 0.0f;
+        for (int e = yoff[y]; e < yoff[y + 1]; e++)
+        {
+            const uint8_t *row = t8 + (ysi[e] - ry0) * RS_PITCH;
+            float rr = 0.0f;
+#pragma unroll
+            for (int k = 0; k < RESIZE_MAX_TAPS; k++)
+                if (k < nk)
+                    rr += (float)row[si[k]] * al[k];
+            acc += rr * yal[e];
+        }
+        const float v = rintf(acc);
+        dst[(size_t)blockIdx.z * dw * dh + (size_t)y * dw + x] = (float)(uint8_t)fminf(255.0f, fmaxf(0.0f, v)) * (1.0f / 255.0f);
+    }
+}
+
 // four pixels per thread: three 32-bit loads carry 4 BGR triplets, one 32-bit store carries 4 grey bytes
 __global__ void gray4_kernel(const uint32_t *__restrict__ bgr, uint32_t *__restrict__ gray, size_t n4)
 {
@@ -1824,22 +1894,47 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
 
     // ---- grey, downscale, float
     const size_t n_px = (size_t)B * src_px;
-    if (((uintptr_t)d_bgr & 3) == 0)
-        hipLaunchKernelGGL(gray4_kernel, dim3((unsigned)(((n_px + 3) / 4 + 255) / 256)), dim3(256), 0, st,
-                           (const uint32_t *)d_bgr, (uint32_t *)d_gray, n_px / 4);
-    if (((uintptr_t)d_bgr & 3) != 0 || (n_px & 3))
+    const bool resized = !(W == width && H == height);
+    area_tab tx, ty;
+    bool staged = false; // can every resize workgroup stage its source window in LDS? (taps per column, window size)
+    if (resized)
     {
-        // unaligned source or a tail of < 4 pixels: byte-wise
-        const size_t first = ((uintptr_t)d_bgr & 3) ? 0 : (n_px & ~(size_t)3);
-        hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((n_px - first + 255) / 256)), dim3(256), 0, st, d_bgr + 3 * first,
-                           d_gray + first, n_px - first);
+        tx = area_table(width, W);
+        ty = area_table(height, H);
+        staged = width % 4 == 0;
+        for (int x0 = 0; x0 < W && staged; x0 += 256)
+        {
+            const int x1 = std::min(x0 + 256, W);
+            const int c0 = tx.si[tx.off[x0]] & ~3, c1 = tx.si[tx.off[x1] - 1];
+            staged = c1 - c0 + 1 <= RS_PITCH - 3;
+            for (int x = x0; x < x1 && staged; x++)
+                staged = tx.off[x + 1] - tx.off[x] <= RESIZE_MAX_TAPS;
+        }
+        for (int y0 = 0; y0 < H && staged; y0 += RESIZE_ROWS)
+        {
+            const int y1 = std::min(y0 + RESIZE_ROWS, H);
+            staged = ty.si[ty.off[y1] - 1] - ty.si[ty.off[y0]] + 1 <= RS_ROWS;
+        }
+    }
+    const bool fused_grey = staged && ((uintptr_t)d_bgr & 3) == 0; // the resize converts BGR itself
+    if (!fused_grey)
+    {
+        if (((uintptr_t)d_bgr & 3) == 0)
+            hipLaunchKernelGGL(gray4_kernel, dim3((unsigned)(((n_px + 3) / 4 + 255) / 256)), dim3(256), 0, st,
+                               (const uint32_t *)d_bgr, (uint32_t *)d_gray, n_px / 4);
+        if (((uintptr_t)d_bgr & 3) != 0 || (n_px & 3))
+        {
+            // unaligned source or a tail of < 4 pixels: byte-wise
+            const size_t first = ((uintptr_t)d_bgr & 3) ? 0 : (n_px & ~(size_t)3);
+            hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((n_px - first + 255) / 256)), dim3(256), 0, st, d_bgr + 3 * first,
+                               d_gray + first, n_px - first);
+        }
     }
     if (W == width && H == height)
         hipLaunchKernelGGL(to_float_kernel, dim3((unsigned)((B * plane0 + 255) / 256)), dim3(256), 0, st, d_gray, d_img,
                            B * plane0);
     else
     {
-        const area_tab tx = area_table(width, W), ty = area_table(height, H);
         int *xo, *xs, *yo, *ys;
         float *xa, *ya;
         AK(up(ctx, allocs, &xo, tx.off.data(), tx.off.size()));
@@ -1853,8 +1948,16 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             cleanup();
             return rc;
         }
-        hipLaunchKernelGGL(resize_area_kernel, dim3((W + 255) / 256, (H + RESIZE_ROWS - 1) / RESIZE_ROWS, B), dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs, xa,
-                           yo, ys, ya);
+        const dim3 rgrid((W + 255) / 256, (H + RESIZE_ROWS - 1) / RESIZE_ROWS, B);
+        if (fused_grey)
+            hipLaunchKernelGGL((resize_area_lds_kernel<true>), rgrid, dim3(256), 0, st, (const uint8_t *)d_bgr, width, height, d_img,
+                               W, H, xo, xs, xa, yo, ys, ya);
+        else if (staged)
+            hipLaunchKernelGGL((resize_area_lds_kernel<false>), rgrid, dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs,
+                               xa, yo, ys, ya);
+        else
+            hipLaunchKernelGGL(resize_area_kernel, rgrid, dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs, xa, yo, ys,
+                               ya);
     }
 
     // ---- contrast factor: Gaussian(1) + gradient magnitude + per-tile maxima in one pass, then the histogram
