@@ -300,6 +300,47 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
     const int x0 = tile_x * BT_X, y0 = tile_y * BT_Y;
     const int bx0 = x0 - M, by0 = y0 - M;
     const float *I = A.in + (size_t)blockIdx.z * A.in_stride;
+    // workgroups whose input window lies inside the image fetch it as 16-byte quads from a 4-pixel aligned start (a third
+    // of the load instructions); needs rows that start 16-byte aligned, i.e. a width that is a multiple of 4
+    const int ix0 = bx0 - R, iy0 = by0 - R;
+    const int ax0 = ix0 & ~3;
+    const bool quad_window = M > 0 && (w & 3) == 0 && ((A.in_stride & 3) == 0) && ix0 >= 0 && iy0 >= 0 && ix0 + IW <= w && iy0 + IH <= h &&
+                             (((uintptr_t)A.in & 15) == 0);
+    if (quad_window)
+    {
+        constexpr int NQ = (IW + 3 + 3) / 4; // quads per row, whatever the misalignment of ix0 (0..3 pixels)
+        constexpr int QITERS = (NQ * IH + 255) / 256;
+        const int shift = ix0 - ax0;
+        float4 q[QITERS];
+#pragma unroll
+        for (int it = 0; it < QITERS; it++)
+        {
+            const int idx = threadIdx.x + it * 256;
+            const int ly = idx / NQ, j = idx - ly * NQ;
+            const bool in = idx < NQ * IH && ax0 + 4 * j < w;
+            q[it] = in ? *reinterpret_cast<const float4 *>(I + (size_t)(iy0 + ly) * w + ax0 + 4 * j) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int it = 0; it < QITERS; it++)
+        {
+            const int idx = threadIdx.x + it * 256;
+            const int ly = idx / NQ, j = idx - ly * NQ;
+            if (idx < NQ * IH)
+            {
+                const int lx = 4 * j - shift;
+                float *row = &tin[ly * IW];
+                if (lx >= 0 && lx < IW)
+                    row[lx] = q[it].x;
+                if (lx + 1 >= 0 && lx + 1 < IW)
+                    row[lx + 1] = q[it].y;
+                if (lx + 2 >= 0 && lx + 2 < IW)
+                    row[lx + 2] = q[it].z;
+                if (lx + 3 >= 0 && lx + 3 < IW)
+                    row[lx + 3] = q[it].w;
+            }
+        }
+    }
+    else
     {
         // every load of the tile is issued before the first LDS store (a rolled loop would wait out one memory
         // latency per iteration)
