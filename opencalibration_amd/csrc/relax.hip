@@ -604,13 +604,26 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *A, int n, int k0
         }
 }
 
+// The rows below a diagonal block that can be non-zero: the block column's envelope (cameras further down the list
+// than any camera linked to this block's cameras never get fill) and the tail (the plane unknowns, coupled to every
+// camera, and the augmented row).  Kernels index this set with a logical row number.
+struct row_set
+{
+    int begin, band_rows; // rows begin .. begin + band_rows - 1
+    int tail_begin, total; // then rows tail_begin .. ; total = band_rows + tail rows
+};
+__device__ __forceinline__ int set_row(const row_set &s, int i)
+{
+    return i < s.band_rows ? s.begin + i : s.tail_begin + (i - s.band_rows);
+}
+
 // rows below the diagonal block: X = A[i, k0:k0+nb] * L_kk^{-T} = A_tile * Linv' as a 64x64x64 GEMM on the
 // matrix cores (same tiling as the trailing update), in place.
-__global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, int nrows, int k0, int nb, const double *Linv)
+__global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, row_set rs, int k0, int nb, const double *Linv)
 {
     constexpr int KC = 32;
     __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
-    const int r0 = k0 + nb + blockIdx.x * 64;
+    const int r0 = blockIdx.x * 64; // logical
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
     const int lr = lane & 15, lk = lane >> 4;
@@ -624,7 +637,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, int n
         for (int e = t; e < 64 * KC; e += 256)
         {
             const int r = e / KC, m = e % KC;
-            Pi[r][m] = (r0 + r < nrows && m0 + m < nb) ? A[(size_t)(r0 + r) * n + k0 + m0 + m] : 0.0;
+            Pi[r][m] = (r0 + r < rs.total && m0 + m < nb) ? A[(size_t)set_row(rs, r0 + r) * n + k0 + m0 + m] : 0.0;
             Pj[r][m] = Linv[r * NB + m0 + m]; // X[i][c] = sum_m A[i][m] Linv[c][m]
         }
         __syncthreads();
@@ -645,69 +658,23 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, int n
             for (int e = 0; e < 4; e++)
             {
                 const int r = r0 + wr + 16 * i + 4 * e + lk, cc = wc + 16 * j + lr;
-                if (r < nrows && cc < nb)
-                    A[(size_t)r * n + k0 + cc] = acc[i][j][e];
+                if (r < rs.total && cc < nb)
+                    A[(size_t)set_row(rs, r) * n + k0 + cc] = acc[i][j][e];
             }
 }
 
-// trailing update, lower tiles only: C[i][j] -= sum_m P[i][m] P[j][m], 64x64 tile per workgroup
-__global__ __launch_bounds__(256) void chol_update_kernel(double *A, int n, int nrows, int k0, int nb)
-{
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    if (tj > ti)
-        return;
-    constexpr int KC = 32;
-    __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
-    const int base = k0 + nb;
-    const int r0 = base + ti * 64, c0 = base + tj * 64;
-    const int t = threadIdx.x;
-    const int tr = (t / 16) * 4, tc = (t % 16) * 4;
-    double c[4][4] = {{0}};
-    for (int m0 = 0; m0 < nb; m0 += KC)
-    {
-        const int mc = min(KC, nb - m0);
-        __syncthreads();
-        for (int e = t; e < 64 * KC; e += 256)
-        {
-            const int r = e / KC, m = e % KC;
-            Pi[r][m] = (r0 + r < nrows && m < mc) ? A[(size_t)(r0 + r) * n + k0 + m0 + m] : 0.0;
-            Pj[r][m] = (c0 + r < n && m < mc) ? A[(size_t)(c0 + r) * n + k0 + m0 + m] : 0.0;
-        }
-        __syncthreads();
-        for (int m = 0; m < KC; m++)
-        {
-            double a[4], b[4];
-            for (int i = 0; i < 4; i++)
-            {
-                a[i] = Pi[tr + i][m];
-                b[i] = Pj[tc + i][m];
-            }
-            for (int i = 0; i < 4; i++)
-                for (int j = 0; j < 4; j++)
-                    c[i][j] = __builtin_fma(a[i], b[j], c[i][j]);
-        }
-    }
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++)
-        {
-            const int r = r0 + tr + i, cc = c0 + tc + j;
-            if (r < nrows && cc < n && cc <= r)
-                A[(size_t)r * n + cc] -= c[i][j];
-        }
-}
-
+// trailing update, lower tiles only: C[i][j] -= sum_m P[i][m] P[j][m], 64x64 tile per workgroup.
 // Same trailing update on the matrix cores: v_mfma_f64_16x16x4_f64, one 32x32 sub-tile per wave
 // (2x2 accumulators), operands staged through LDS in 32-deep K chunks.  This dense fp64 update of the
 // reduced system is the only MFMA use on the path.
-__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n, int nrows, int k0, int nb)
+__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n, row_set rs, int k0, int nb)
 {
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti)
         return;
     constexpr int KC = 32;
     __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
-    const int base = k0 + nb;
-    const int r0 = base + ti * 64, c0 = base + tj * 64;
+    const int r0 = ti * 64, c0 = tj * 64; // logical rows of the set; columns are the same set (without the augmented row)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
     const int lr = lane & 15, lk = lane >> 4;
@@ -722,8 +689,8 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n,
         for (int e = t; e < 64 * KC; e += 256)
         {
             const int r = e / KC, m = e % KC;
-            Pi[r][m] = (r0 + r < nrows && m < mc) ? A[(size_t)(r0 + r) * n + k0 + m0 + m] : 0.0;
-            Pj[r][m] = (c0 + r < n && m < mc) ? A[(size_t)(c0 + r) * n + k0 + m0 + m] : 0.0;
+            Pi[r][m] = (r0 + r < rs.total && m < mc) ? A[(size_t)set_row(rs, r0 + r) * n + k0 + m0 + m] : 0.0;
+            Pj[r][m] = (c0 + r < rs.total && m < mc) ? A[(size_t)set_row(rs, c0 + r) * n + k0 + m0 + m] : 0.0;
         }
         __syncthreads();
 #pragma unroll
@@ -743,42 +710,71 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n,
             {
                 // f64 16x16x4 result layout (measured, scripts/probe_mfma_f64.hip): D[4*reg + lane/16][lane%16]
                 const int r = r0 + wr + 16 * i + 4 * e + lk, cc = c0 + wc + 16 * j + lr;
-                if (r < nrows && cc < n && cc <= r)
-                    A[(size_t)r * n + cc] -= acc[i][j][e];
+                if (r < rs.total && cc <= r)
+                {
+                    const int ar = set_row(rs, r), ac = set_row(rs, cc);
+                    if (ac < n)
+                        A[(size_t)ar * n + ac] -= acc[i][j][e];
+                }
             }
 }
 
-// Backward substitution L' x = y, blocked: the diagonal block in LDS by one workgroup ...
-__global__ __launch_bounds__(64) void back_diag_kernel(const double *Linv, double *x, int k0, int nb)
+// Backward substitution L' x = y by ONE workgroup, block by block from the bottom: x_k = L_kk^-T y_k out of the stored
+// inverse, then y_i -= sum_m L[k0+m][i] x[k0+m] for the columns i < k0 in which the rows of the block can be non-zero
+// (first_col[k]: the row envelope; everything for the tail rows).  The 94 launches this took per solve cost 1.0 ms, the
+// walk over the envelope takes a tenth of that.
+__global__ __launch_bounds__(1024) void back_solve_kernel(const double *L, int n, const double *Linv, double *x,
+                                                          const int *first_col, int n_blocks)
 {
     __shared__ double xb[NB];
     const int t = threadIdx.x;
-    xb[t] = t < nb ? x[k0 + t] : 0.0;
-    __syncthreads();
-    if (t < nb)
+    for (int k = n_blocks - 1; k >= 0; k--)
     {
-        double s = 0; // (L^-T y)[t] = sum_m Linv[m][t] y[m]
-        for (int m = t; m < nb; m++)
-            s += Linv[m * NB + t] * xb[m];
-        x[k0 + t] = s;
+        const int k0 = k * NB, nb = min(NB, n - k0);
+        const double *Li = Linv + (size_t)k * NB * NB;
+        __syncthreads(); // the updates of the previous block have landed
+        if (t < NB)
+            xb[t] = t < nb ? x[k0 + t] : 0.0;
+        __syncthreads();
+        double s = 0; // (L^-T y)[t] = sum_m Linv[m][t] y[m]; Linv is lower triangular with zeros above, so all 64 terms
+        if (t < nb)   // can be requested up front (16 loads in flight) instead of one per loop trip
+        {
+#pragma unroll
+            for (int m0 = 0; m0 < NB; m0 += 16)
+            {
+                double v[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    v[j] = Li[(m0 + j) * NB + t];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (m0 + j >= t && m0 + j < nb)
+                        s += v[j] * xb[m0 + j];
+            }
+        }
+        __syncthreads();
+        if (t < nb)
+        {
+            xb[t] = s;
+            x[k0 + t] = s;
+        }
+        __syncthreads();
+        for (int i = first_col[k] + t; i < k0; i += 1024)
+        {
+            double u = 0;
+            for (int m0 = 0; m0 < nb; m0 += 16)
+            {
+                double v[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    v[j] = m0 + j < nb ? L[(size_t)(k0 + m0 + j) * n + i] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    u += v[j] * xb[m0 + j];
+            }
+            x[i] -= u;
+        }
     }
-}
-
-// ... then every earlier unknown: x[i] -= sum_m L[k0+m][i] x[k0+m]  (coalesced over i)
-__global__ __launch_bounds__(256) void back_update_kernel(const double *L, int n, double *x, int k0, int nb)
-{
-    __shared__ double xb[NB];
-    const int t = threadIdx.x;
-    if (t < nb)
-        xb[t] = x[k0 + t];
-    __syncthreads();
-    const int i = blockIdx.x * 256 + t;
-    if (i >= k0)
-        return;
-    double s = 0;
-    for (int m = 0; m < nb; m++)
-        s += L[(size_t)(k0 + m) * n + i] * xb[m];
-    x[i] -= s;
 }
 
 // step = -y with (As + D) y = gs, As = S A S.  model_cost_change = -(step.gs + step' As step / 2)
@@ -935,6 +931,12 @@ struct ochip_relax_problem
            *diag_tmp = nullptr, *y = nullptr, *scal = nullptr;
     int *fail_chol = nullptr;
     double *linv = nullptr; // [panels][NB*NB] inverses of the diagonal blocks
+    // block envelope of the reduced system (assign_tangent): per block column the end of the camera rows that can be
+    // non-zero, the first tail row, and per block row the first column that can be non-zero
+    std::vector<int> env_end, first_col;
+    int tail_begin = 0;
+    int *first_col_dev = nullptr;
+    std::vector<uint32_t> pair_p_h, pair_q_h; // host copies of the camera pairs
     size_t linv_cap = 0;
     size_t cap_n = 0;
     uint32_t n_cams = 0;
@@ -979,6 +981,62 @@ int assign_tangent(ochip_relax_problem *p)
             p->z_t[i] = t++;
     }
     p->n_tangent = t;
+    {
+        // block envelope of the reduced system J'J: camera unknowns in camera order, then the plane unknowns (coupled to
+        // every camera: the tail).  A pair (p, q) puts a 3 x 3 block at rows t_q.., columns t_p..; Cholesky fill stays
+        // inside the column envelope once that is made monotone.
+        int cam_end = 0;
+        for (uint32_t c = 0; c < p->n_cams; c++)
+            if (p->cam_t[c] >= 0)
+                cam_end = p->cam_t[c] + 3;
+        const int n_all = std::max(t, 1), nblk = (n_all + NB - 1) / NB;
+        p->tail_begin = cam_end;
+        p->env_end.assign(nblk, 0);
+        for (int k = 0; k < nblk; k++)
+            p->env_end[k] = std::min((k + 1) * NB, cam_end);
+        for (uint32_t c = 0; c < p->n_cams; c++) // a camera's own 3 x 3 block may straddle two column blocks
+            if (p->cam_t[c] >= 0)
+                for (int k = p->cam_t[c] / NB; k <= (p->cam_t[c] + 2) / NB; k++)
+                    p->env_end[k] = std::max(p->env_end[k], p->cam_t[c] + 3);
+        for (size_t i = 0; i < p->pair_p_h.size(); i++)
+        {
+            const int ta = p->cam_t[p->pair_p_h[i]], tb = p->cam_t[p->pair_q_h[i]];
+            if (ta < 0 || tb < 0)
+                continue;
+            const int lo = std::min(ta, tb), hi = std::max(ta, tb) + 3;
+            for (int k = lo / NB; k <= (lo + 2) / NB; k++)
+                p->env_end[k] = std::max(p->env_end[k], hi);
+        }
+        for (int k = 1; k < nblk; k++)
+            p->env_end[k] = std::max(p->env_end[k], std::min(p->env_end[k - 1], cam_end));
+        // row envelope for the backward solve: the first column block whose envelope reaches into block row k
+        p->first_col.assign(nblk, 0);
+        for (int k = 0; k < nblk; k++)
+        {
+            const int k0 = k * NB;
+            int first = k0;
+            if (k0 + NB > cam_end) // the block holds tail rows: dense
+                first = 0;
+            else
+                for (int c = 0; c < k; c++)
+                    if (p->env_end[c] > k0)
+                    {
+                        first = c * NB;
+                        break;
+                    }
+            p->first_col[k] = first;
+        }
+        if (getenv("OCHIP_RELAX_VERBOSE"))
+        {
+            long band = 0;
+            for (int k = 0; k < nblk; k++)
+                band += std::max(0, p->env_end[k] - (k + 1) * NB);
+            fprintf(stderr, "[ochip relax] n=%d blocks=%d tail_begin=%d mean envelope rows below a block %.1f (dense: %.1f)\n", n_all, nblk,
+                    cam_end, (double)band / nblk, (double)n_all / 2);
+        }
+        if (dev_upload(p, &p->first_col_dev, p->first_col.data(), p->first_col.size()) != OCHIP_OK)
+            return ochip_fail(p->ctx, OCHIP_ENOMEM, "device allocation failed (envelope)");
+    }
     if (hipMemcpy(p->dev.cam_t, p->cam_t.data(), p->n_cams * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(p->dev.z_t, p->z_t, 12, hipMemcpyHostToDevice) != hipSuccess)
         return ochip_fail(p->ctx, OCHIP_EHIP, "hipMemcpy failed (tangent map)");
@@ -1115,6 +1173,8 @@ int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *d, ochip_
     chk(dev_upload(p, &D.blk_b, blk_b.data(), blk_b.size()));
     chk(dev_upload(p, &D.blk_rays, rays.data(), rays.size()));
     chk(dev_upload(p, &D.pair_off, pair_off.data(), pair_off.size()));
+    p->pair_p_h = pair_p;
+    p->pair_q_h = pair_q;
     chk(dev_upload(p, &D.pair_p, pair_p.data(), pair_p.size()));
     chk(dev_upload(p, &D.pair_q, pair_q.data(), pair_q.size()));
     chk(dev_upload(p, &D.cam_pair_off, cpo.data(), cpo.size()));
@@ -1381,29 +1441,21 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
             const int nb = std::min(NB, n - k0);
             double *linv_k = p->linv + (size_t)(k0 / NB) * NB * NB;
             hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, p->Wm, n, k0, nb, p->fail_chol, linv_k);
-            const int rows = n + 1 - k0 - nb; // includes the augmented row
-            hipLaunchKernelGGL(chol_panel_kernel, dim3((rows + 63) / 64), dim3(256), 0, st, p->Wm, n, n + 1, k0, nb, linv_k);
-            if (k0 + nb < n)
-            {
-                const int tiles = (rows + 63) / 64;
-                static const bool use_valu = getenv("OCHIP_CHOL_VALU") != nullptr; // A/B knob: VALU FMA tiles
-                if (use_valu)
-                    hipLaunchKernelGGL(chol_update_kernel, dim3(tiles, tiles), dim3(256), 0, st, p->Wm, n, n + 1, k0, nb);
-                else
-                    hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, st, p->Wm, n, n + 1,
-                                       k0, nb);
-            }
+            // rows below the block that can be non-zero: its envelope, then the tail (plane unknowns + augmented row)
+            static const bool dense = getenv("OCHIP_CHOL_DENSE") != nullptr; // A/B knob: ignore the envelope
+            const int below = k0 + nb;
+            const int band_end = dense ? n : std::max(below, std::min(p->env_end[k0 / NB], p->tail_begin));
+            const int tail0 = std::max(dense ? n : p->tail_begin, below);
+            row_set rs{below, band_end - below, tail0, (band_end - below) + (n + 1 - tail0)};
+            const int tiles = (rs.total + 63) / 64;
+            hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, st, p->Wm, n, rs, k0, nb, linv_k);
+            if (below < n)
+                hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, st, p->Wm, n, rs, k0, nb);
         }
         // row n now holds y = L^-1 gs; back-substitute L' x = y block by block
         OCHIP_HIP(ctx, hipMemcpyAsync(p->y, p->Wm + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-        for (int k1 = n; k1 > 0;)
-        {
-            const int nb = (k1 % NB) ? (k1 % NB) : NB, k0 = k1 - nb;
-            hipLaunchKernelGGL(back_diag_kernel, dim3(1), dim3(64), 0, st, p->linv + (size_t)(k0 / NB) * NB * NB, p->y, k0, nb);
-            if (k0 > 0)
-                hipLaunchKernelGGL(back_update_kernel, dim3((k0 + 255) / 256), dim3(256), 0, st, p->Wm, n, p->y, k0, nb);
-            k1 = k0;
-        }
+        hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->Wm, n, (const double *)p->linv, p->y,
+                           (const int *)p->first_col_dev, (n + NB - 1) / NB);
         hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(1024), 0, st, D, p->lm_diag, p->gs, p->scale, p->y, n, p->scal);
         ochip_prof_end(ctx, OCHIP_K_RELAX_SOLVE, e0, e1);
         OCHIP_HIP(ctx, hipGetLastError());
