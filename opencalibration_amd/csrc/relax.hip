@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <thread>
 #include <vector>
 
 using namespace ochip;
@@ -1105,13 +1106,30 @@ int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *d, ochip_
     }
     std::vector<uint32_t> blk_a(d->n_blocks), blk_b(d->n_blocks), pair_off, pair_p, pair_q;
     std::vector<double> rays((size_t)d->n_blocks * 6);
+    {
+        // the permuted copy of the blocks (tens of MB) on a few threads; the segment boundaries afterwards, in order
+        const uint32_t nthr = d->n_blocks > (1u << 16) ? 8u : 1u;
+        auto copy_range = [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t i = lo; i < hi; i++)
+            {
+                const uint32_t b = order[i];
+                blk_a[i] = d->blk_cam_a[b];
+                blk_b[i] = d->blk_cam_b[b];
+                for (int k = 0; k < 6; k++)
+                    rays[(size_t)i * 6 + k] = d->blk_rays[(size_t)b * 6 + k];
+            }
+        };
+        std::vector<std::thread> workers;
+        const uint32_t per = (d->n_blocks + nthr - 1) / nthr;
+        for (uint32_t w = 1; w < nthr; w++)
+            workers.emplace_back(copy_range, std::min(d->n_blocks, w * per), std::min(d->n_blocks, (w + 1) * per));
+        copy_range(0, std::min(d->n_blocks, per));
+        for (auto &t : workers)
+            t.join();
+    }
     for (uint32_t i = 0; i < d->n_blocks; i++)
     {
         const uint32_t b = order[i];
-        blk_a[i] = d->blk_cam_a[b];
-        blk_b[i] = d->blk_cam_b[b];
-        for (int k = 0; k < 6; k++)
-            rays[(size_t)i * 6 + k] = d->blk_rays[(size_t)b * 6 + k];
         if (i == 0 || key(order[i - 1]) != key(b))
         {
             pair_off.push_back(i);
