@@ -869,26 +869,46 @@ __device__ uint32_t fast_forward(const pair_data &pd, const uint32_t *__restrict
         if (live)
             lane_fit(AQs + lane, px, py, qx, qy, m);
     }
-    // ---- SPRT-pruned MSAC walk in evaluation order, one model per lane, the match uniform
+    // ---- SPRT-pruned MSAC walk in evaluation order, one model per lane of the lower half-wave; the upper half-wave
+    //      evaluates the odd positions for the same 32 models (the error is the expensive part, the running sum takes
+    //      the two terms in order)
+    static_assert(FB == 32, "the two half-waves share the FB models");
+    const int half = lane >> 5, src = lane & 31;
+    model_t mm;
+    for (int i = 0; i < 9; i++)
+    {
+        mm.H[i] = __shfl(m.H[i], src);
+        mm.Hi[i] = __shfl(m.Hi[i], src);
+    }
     double s = 0;
     bool rej = false;
-    for (uint32_t pos = 0; pos < M; pos++)
+    for (uint32_t pos0 = 0; pos0 < M; pos0 += 2)
     {
-        if (__ballot(live && !rej) == 0)
+        if (__ballot(lane < 32 && live && !rej) == 0)
             break;
-        const double e = transfer_error(m, pd.ex1[pos], pd.ey1[pos], pd.ex2[pos], pd.ey2[pos]);
+        const uint32_t pos = pos0 + (uint32_t)half;
         double term = 0;
-        if (e < thr)
+        if (pos < M)
         {
-            const double ratio = e / thr;
-            term = 1.0 - ratio * ratio;
+            const double e = transfer_error(mm, pd.ex1[pos], pd.ey1[pos], pd.ex2[pos], pd.ey2[pos]);
+            if (e < thr)
+            {
+                const double ratio = e / thr;
+                term = 1.0 - ratio * ratio;
+            }
         }
-        s = s + term;
-        const uint32_t checked = pos + 1;
-        if (checked > 20 && best_score > 0 && s < best_score * (double)checked / (double)M * 0.6)
+        const double term_odd = __shfl(term, src + 32);
+        s = s + term; // position pos0 (lower half-wave; the upper half's sums are not used)
+        if (pos0 + 1 > 20 && best_score > 0 && s < best_score * (double)(pos0 + 1) / (double)M * 0.6)
             rej = true;
+        if (pos0 + 1 < M)
+        {
+            s = s + term_odd; // position pos0 + 1
+            if (pos0 + 2 > 20 && best_score > 0 && s < best_score * (double)(pos0 + 2) / (double)M * 0.6)
+                rej = true;
+        }
     }
-    const unsigned long long improving = __ballot(live && !rej && s > best_score);
+    const unsigned long long improving = __ballot(lane < 32 && live && !rej && s > best_score);
     if (improving == 0)
     {
         rng = rng_s;
