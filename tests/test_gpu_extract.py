@@ -22,7 +22,7 @@ def _sorted(kp, desc):
     return kp[order], desc[order]
 
 
-@pytest.mark.parametrize("w,h", [(320, 240), (640, 480), (500, 333)])
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 480), (500, 333), (502, 331)])   # 502: rows not 16-byte aligned
 def test_akaze_matches_restatement_bitwise(ctx, oracle, w, h):
     imgs = np.stack([synth.render_blobs(w, h, seed) for seed in (1, 2, 3)])
     got, (ww, wh) = ctx.akaze_batch(imgs, max_kp=20000)
@@ -51,6 +51,19 @@ def test_grey_and_area_resize(ctx, oracle):
     assert len(gkp) == len(ekp) and len(ekp) > 1000
     assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32))
     assert np.array_equal(gdesc, edesc)
+
+
+def test_resize_fallback_for_unaligned_width(ctx, oracle):
+    """A source width that is not a multiple of 4 cannot be staged by dword loads: the separate grey and per-tap resize
+    kernels run instead and must give the same working image."""
+    w, h = 2002, 1500
+    img = synth.render_blobs(w, h, 13)
+    got, (ww, wh) = ctx.akaze_batch(img[None], max_kp=30000)
+    small = oracle.gray_resize(img, ww, wh)
+    ekp, edesc = oracle.akaze(small)
+    gkp, gdesc = got[0]
+    assert (ww, wh) == (1600, 1199) and len(gkp) == len(ekp) > 1000
+    assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32)) and np.array_equal(gdesc, edesc)
 
 
 def test_extract_features_host_tail(ctx, oracle):
