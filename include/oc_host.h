@@ -110,6 +110,15 @@ extern "C"
                                              double *summary_out, uint32_t rank, uint32_t world,
                                              ochip_relax_exchange_fn exchange, void *user);
 
+    /* ---- after a relax changed a camera model: the write-back half of RelaxGroup::finalize
+     *      (src/relax/relax_group.cpp:125-177).  och_graph_set_model replaces the intrinsics of model `model` (m10 as for
+     *      och_graph_add_model; every image sharing the model sees the change, as with the reference's
+     *      shared_ptr<CameraModel>); och_graph_refit_edges then re-fits EVERY edge of the graph on its previous inliers:
+     *      correspondences from the current models, three rounds of fitInliers + evaluate on the device
+     *      (ochip_refit_homography_batch), decomposition and inlier assembly on the host. */
+    int och_graph_set_model(och_graph *g, uint32_t model, const double *m10);
+    int och_graph_refit_edges(och_graph *g, ochip_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,6 +174,16 @@ extern "C"
                                       uint64_t total_matches, const uint32_t *eval_order, uint64_t eval_total,
                                       double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers);
 
+    /* ---- re-fit of accepted edges after the camera models changed (replaces the per-edge loop of
+     *      RelaxGroup::finalize, src/relax/relax_group.cpp:137-177: distort_keypoints with the current models, then
+     *      `rounds` (= 3 there) times fitInliers + evaluate starting from the previous inliers).  jobs / matches as for
+     *      ochip_ransac_homography_batch (rng_state and eval_offset unused); the keypoints and the CURRENT models must
+     *      have been uploaded (ochip_upload_keypoints / ochip_upload_batch).  inliers: in = the previous inlier flags,
+     *      out = the flags of the last evaluate; results[j].H = the last fit, .n_inliers, .score = evaluate / n. */
+    int ochip_refit_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs,
+                                     const ochip_ransac_match *matches, uint64_t total_matches, uint32_t rounds,
+                                     double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers);
+
     /* ---- relax: ground-plane bundle adjustment (replaces ceres::Solver::Solve on the problem
      *      RelaxProblem::setupGroundPlaneProblem builds, src/relax/relax_problem.cpp:61-81,1390-1420) ---- */
     typedef struct ochip_relax_problem ochip_relax_problem;

@@ -169,6 +169,10 @@ class MeasurementGraph
     {
         return _edges;
     }
+    std::vector<Edge> &edges()
+    {
+        return _edges;
+    }
     size_t nodeIndex(size_t id) const
     {
         return _node_index.at(id);

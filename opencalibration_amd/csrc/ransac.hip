@@ -584,6 +584,52 @@ __device__ __forceinline__ void write_dlt_rows(double *A, uint32_t ld, uint32_t 
     }
 }
 
+// homography_model::fitInliers (homography_model.cpp:52-87) on the flags pd.inl, of which n_in are set: the
+// (2 n_in + 1) x 9 system in index order, its full-pivot LU, H from the solution.
+__device__ __forceinline__ void fit_inliers(const pair_data &pd, uint32_t n_in, double *T9 /*LDS 81*/, model_t &model)
+{
+    const int lane = threadIdx.x;
+    const uint32_t M = pd.M;
+    double sol[9];
+    // build the (2 n_in + 1) x 9 system in index order (homography_model.cpp:52-79)
+    const uint32_t rows = 2 * n_in + 1, ld = rows;
+    uint32_t before = 0;
+    bool nf = (uint32_t)lane < M && pd.inl[lane];
+    double nx1 = nf ? pd.x1[lane] : 0.0, ny1 = nf ? pd.y1[lane] : 0.0, nx2 = nf ? pd.x2[lane] : 0.0,
+           ny2 = nf ? pd.y2[lane] : 0.0;
+    for (uint32_t base = 0; base < M; base += W)
+    {
+        const bool f = nf;
+        const double x1 = nx1, y1 = ny1, x2 = nx2, y2 = ny2;
+        {
+            const uint32_t ni = base + W + lane;
+            nf = ni < M && pd.inl[ni];
+            nx1 = ni < M ? pd.x1[ni] : 0.0, ny1 = ni < M ? pd.y1[ni] : 0.0, nx2 = ni < M ? pd.x2[ni] : 0.0,
+            ny2 = ni < M ? pd.y2[ni] : 0.0;
+        }
+        const unsigned long long mask = __ballot(f);
+        if (f)
+        {
+            const uint32_t r = before + __popcll(mask & ((1ull << lane) - 1ull));
+            write_dlt_rows(pd.P, ld, 2 * r, x1, y1, x2, y2);
+        }
+        before += __popcll(mask);
+    }
+    if (lane < 9)
+        pd.P[(size_t)lane * ld + rows - 1] = lane == 8 ? 1.0 : 0.0;
+    if (rows > 9)
+        tall_lu_solve9(pd.P, rows, T9, sol);
+    else
+    {
+        // fewer than five inliers: the system is at most 9 x 9; the small factorisation runs it from LDS
+        __syncthreads();
+        for (uint32_t t = lane; t < rows * 9; t += W)
+            T9[(t / rows) * 9 + (t % rows)] = pd.P[t];
+        full_piv_lu_solve9(T9, rows, sol);
+    }
+    model_from_solution(model, sol);
+}
+
 // four distinct positions of the sampling pool; distinct positions are distinct correspondences because the PROSAC
 // order is a permutation, so the uniqueness test of ransac.cpp:118-150 needs no loaded value and the four
 // sorted_idx reads go out together
@@ -1102,43 +1148,7 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
             // local optimisation: fitInliers + evaluate, up to MAX_INNER_ITERATIONS (ransac.cpp:224-245)
             for (uint32_t j = 0; j < MAX_INNER_ITERATIONS; j++)
             {
-                // build the (2 n_in + 1) x 9 system in index order (homography_model.cpp:52-79)
-                const uint32_t rows = 2 * n_in + 1, ld = rows;
-                uint32_t before = 0;
-                bool nf = (uint32_t)lane < M && pd.inl[lane];
-                double nx1 = nf ? pd.x1[lane] : 0.0, ny1 = nf ? pd.y1[lane] : 0.0, nx2 = nf ? pd.x2[lane] : 0.0,
-                       ny2 = nf ? pd.y2[lane] : 0.0;
-                for (uint32_t base = 0; base < M; base += W)
-                {
-                    const bool f = nf;
-                    const double x1 = nx1, y1 = ny1, x2 = nx2, y2 = ny2;
-                    {
-                        const uint32_t ni = base + W + lane;
-                        nf = ni < M && pd.inl[ni];
-                        nx1 = ni < M ? pd.x1[ni] : 0.0, ny1 = ni < M ? pd.y1[ni] : 0.0, nx2 = ni < M ? pd.x2[ni] : 0.0,
-                        ny2 = ni < M ? pd.y2[ni] : 0.0;
-                    }
-                    const unsigned long long mask = __ballot(f);
-                    if (f)
-                    {
-                        const uint32_t r = before + __popcll(mask & ((1ull << lane) - 1ull));
-                        write_dlt_rows(pd.P, ld, 2 * r, x1, y1, x2, y2);
-                    }
-                    before += __popcll(mask);
-                }
-                if (lane < 9)
-                    pd.P[(size_t)lane * ld + rows - 1] = lane == 8 ? 1.0 : 0.0;
-                if (rows > 9)
-                    tall_lu_solve9(pd.P, rows, T9, sol);
-                else
-                {
-                    // fewer than five inliers: the system is at most 9 x 9; the small factorisation runs it from LDS
-                    __syncthreads();
-                    for (uint32_t t = lane; t < rows * 9; t += W)
-                        T9[(t / rows) * 9 + (t % rows)] = pd.P[t];
-                    full_piv_lu_solve9(T9, rows, sol);
-                }
-                model_from_solution(model, sol);
+                fit_inliers(pd, n_in, T9, model);
                 bool dummy;
                 uint32_t cnt = 0;
                 __syncthreads();
@@ -1184,6 +1194,77 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
     res.score = final_score / (double)M;
     res.iterations = it;
     res.n_inliers = cnt;
+    if (lane == 0)
+        results[job_id] = res;
+}
+
+// ---- re-fit of an edge's homography on its previous inliers after the camera models changed
+//      (RelaxGroup::finalize, src/relax/relax_group.cpp:137-177): rays from the current models, then `rounds` times
+//      fitInliers + evaluate starting from the previous inlier set.  One wavefront per edge, the RANSAC kernel's
+//      device functions.
+__global__ __launch_bounds__(W, 2) void refit_homography_kernel(
+    const ochip_ransac_job *__restrict__ jobs, const ochip_ransac_match *__restrict__ matches, rays_view rv,
+    double *__restrict__ coord_scratch /*4 x total*/, double *__restrict__ P_scratch /*9 x (2 total + n_jobs)*/, uint64_t total,
+    double thr, uint32_t rounds, ochip_ransac_result *__restrict__ results, uint8_t *__restrict__ inliers /*in: previous, out: new*/)
+{
+    __shared__ double T9[81];
+    const int lane = threadIdx.x;
+    const uint32_t job_id = blockIdx.x;
+    const ochip_ransac_job job = jobs[job_id];
+    const uint32_t M = job.n;
+    const uint64_t mo = job.match_offset;
+    pair_data pd;
+    double *cx1 = coord_scratch + mo, *cy1 = coord_scratch + total + mo, *cx2 = coord_scratch + 2 * total + mo,
+           *cy2 = coord_scratch + 3 * total + mo;
+    const double *r1 = rv.rays + rv.img_off[job.image_1] * 3, *r2 = rv.rays + rv.img_off[job.image_2] * 3;
+    uint32_t n_in = 0;
+    for (uint32_t base = 0; base < M; base += W)
+    {
+        const uint32_t i = base + lane;
+        bool f = false;
+        if (i < M)
+        {
+            const ochip_ransac_match mt = matches[mo + i];
+            const double ax = r1[(size_t)mt.k1 * 3], ay = r1[(size_t)mt.k1 * 3 + 1], az = r1[(size_t)mt.k1 * 3 + 2];
+            const double bx = r2[(size_t)mt.k2 * 3], by = r2[(size_t)mt.k2 * 3 + 1], bz = r2[(size_t)mt.k2 * 3 + 2];
+            cx1[i] = ax / az;
+            cy1[i] = ay / az;
+            cx2[i] = bx / bz;
+            cy2[i] = by / bz;
+            f = inliers[mo + i] != 0;
+        }
+        n_in += __popcll(__ballot(f));
+    }
+    __syncthreads();
+    pd.x1 = cx1;
+    pd.y1 = cy1;
+    pd.x2 = cx2;
+    pd.y2 = cy2;
+    pd.ex1 = pd.ey1 = pd.ex2 = pd.ey2 = nullptr;
+    pd.cand = nullptr;
+    pd.inl = inliers + mo;
+    pd.P = P_scratch + 9 * (2 * mo + job_id);
+    pd.M = M;
+    model_t model;
+    set_nan(model);
+    double score = 0;
+    uint32_t cnt = n_in;
+    for (uint32_t r = 0; r < rounds; r++)
+    {
+        fit_inliers(pd, cnt, T9, model);
+        bool dummy;
+        __syncthreads();
+        score = score_model<false>(model, pd, nullptr, pd.inl, thr, 0.0, &dummy, &cnt);
+        __syncthreads();
+    }
+    ochip_ransac_result res;
+    for (int i = 0; i < 9; i++)
+        res.H[i] = model.H[i];
+    res.score = M ? score / (double)M : 0.0;
+    res.iterations = rounds;
+    res.n_inliers = cnt;
+    res.improvements = 0;
+    res.reserved = 0;
     if (lane == 0)
         results[job_id] = res;
 }
@@ -1351,6 +1432,76 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
     OCHIP_HIP(ctx, hipGetLastError());
     OCHIP_HIP(ctx, hipMemcpyAsync(results, res_dev, (size_t)n_jobs * sizeof(ochip_ransac_result), hipMemcpyDeviceToHost,
                                   ctx->stream));
+    if (total_matches)
+        OCHIP_HIP(ctx, hipMemcpyAsync(inliers, inl_dev, (size_t)total_matches, hipMemcpyDeviceToHost, ctx->stream));
+    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return OCHIP_OK;
+}
+
+int ochip_refit_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, const ochip_ransac_match *matches,
+                                 uint64_t total_matches, uint32_t rounds, double inlier_threshold, ochip_ransac_result *results,
+                                 uint8_t *inliers)
+{
+    if (!ctx)
+        return OCHIP_EINVAL;
+    if (n_jobs == 0)
+        return OCHIP_OK;
+    if (!jobs || !results || rounds == 0 || (total_matches && (!matches || !inliers)))
+        return ochip_fail(ctx, OCHIP_EINVAL, "NULL argument or zero rounds");
+    if (!ctx->kp_store_ready)
+        return ochip_fail(ctx, OCHIP_ESTATE, "ochip_upload_keypoints has not been called");
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t j = 0; j < n_jobs; j++)
+    {
+        const ochip_ransac_job &jb = jobs[j];
+        if (jb.image_1 >= ctx->n_images || jb.image_2 >= ctx->n_images || !ctx->kp_set[jb.image_1] || !ctx->kp_set[jb.image_2])
+            return ochip_fail(ctx, OCHIP_ESTATE, "job %u references an image without keypoints", j);
+        if (jb.match_offset + jb.n > total_matches)
+            return ochip_fail(ctx, OCHIP_EINVAL, "job %u: offsets exceed the arrays", j);
+    }
+    if (ctx->rays_dirty)
+    {
+        const uint64_t n = ctx->desc_used;
+        if (n)
+            hipLaunchKernelGGL(keypoints_to_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->kp_xy_dev, ctx->models_dev, ctx->kp_image_dev, ctx->rays_dev, n);
+        OCHIP_HIP(ctx, hipGetLastError());
+        ctx->rays_dirty = false;
+    }
+    if (ctx->img_tables_dirty)
+    {
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->img_off_dev, ctx->img_off.data(), (size_t)ctx->n_images * 8, hipMemcpyHostToDevice,
+                                      ctx->stream));
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->img_n_dev, ctx->img_n.data(), (size_t)ctx->n_images * 4, hipMemcpyHostToDevice,
+                                      ctx->stream));
+        ctx->img_tables_dirty = false;
+    }
+    const uint64_t T = total_matches ? total_matches : 1;
+    // scratch slots as in ochip_ransac_homography_batch: 0 jobs, 1 matches, 4 coordinates, 6 LU workspaces, 7 results + flags
+    const int slot[5] = {0, 1, 4, 6, 7};
+    const size_t sizes[5] = {(size_t)n_jobs * sizeof(ochip_ransac_job), (size_t)T * sizeof(ochip_ransac_match), (size_t)T * 64,
+                             (size_t)(2 * T + n_jobs) * 72, (size_t)n_jobs * sizeof(ochip_ransac_result) + T};
+    for (int i = 0; i < 5; i++)
+    {
+        int rc = ochip_ensure(ctx, &ctx->scratch_dev[slot[i]], &ctx->scratch_cap[slot[i]], sizes[i]);
+        if (rc)
+            return rc;
+    }
+    ochip_ransac_result *res_dev = (ochip_ransac_result *)ctx->scratch_dev[7];
+    uint8_t *inl_dev = (uint8_t *)ctx->scratch_dev[7] + (size_t)n_jobs * sizeof(ochip_ransac_result);
+    OCHIP_HIP(ctx, hipMemcpyAsync(ctx->scratch_dev[0], jobs, sizes[0], hipMemcpyHostToDevice, ctx->stream));
+    if (total_matches)
+    {
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->scratch_dev[1], matches, (size_t)total_matches * sizeof(ochip_ransac_match),
+                                      hipMemcpyHostToDevice, ctx->stream));
+        OCHIP_HIP(ctx, hipMemcpyAsync(inl_dev, inliers, (size_t)total_matches, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rays_view rv{ctx->rays_dev, ctx->img_off_dev};
+    hipLaunchKernelGGL(refit_homography_kernel, dim3(n_jobs), dim3(W), 0, ctx->stream, (const ochip_ransac_job *)ctx->scratch_dev[0],
+                       (const ochip_ransac_match *)ctx->scratch_dev[1], rv, (double *)ctx->scratch_dev[4],
+                       (double *)ctx->scratch_dev[6], (uint64_t)T, inlier_threshold, rounds, res_dev, inl_dev);
+    OCHIP_HIP(ctx, hipGetLastError());
+    OCHIP_HIP(ctx, hipMemcpyAsync(results, res_dev, (size_t)n_jobs * sizeof(ochip_ransac_result), hipMemcpyDeviceToHost, ctx->stream));
     if (total_matches)
         OCHIP_HIP(ctx, hipMemcpyAsync(inliers, inl_dev, (size_t)total_matches, hipMemcpyDeviceToHost, ctx->stream));
     OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));

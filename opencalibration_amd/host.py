@@ -92,6 +92,8 @@ def load():
         L.och_relax_last_error.restype = C.c_char_p
         L.och_graph_relax_ground_plane.argtypes = [vp, vp, _f64p, _f64p, _f64p]
         L.och_graph_relax_ground_plane_sharded.argtypes = [vp, vp, _f64p, _f64p, _f64p, u32, u32, RELAX_EXCHANGE_FN, vp]
+        L.och_graph_set_model.argtypes = [vp, u32, _f64p]
+        L.och_graph_refit_edges.argtypes = [vp, vp]
         L.och_extract_features_batch.argtypes = [vp, vp, u32, C.c_int, C.c_int, u32, u32, vp, vp, vp, vp, vp, C.c_int]
         L.och_extract_last_error.restype = C.c_char_p
         L.och_graph_load_images.argtypes = [vp, vp, vp, u32, C.c_int, C.c_int, u32, C.c_int, u32, _f64p, _u64p, _f64p]
@@ -179,6 +181,17 @@ class Graph:
 
     def add_model(self, model10):
         return self.L.och_graph_add_model(self.h, np.ascontiguousarray(model10, np.float64))
+
+    def set_model(self, model, model10):
+        """Replace the intrinsics of camera model `model` (what a relax with free intrinsics writes back)."""
+        if self.L.och_graph_set_model(self.h, int(model), np.ascontiguousarray(model10, np.float64)) != 0:
+            raise capi.OchipError("och_graph_set_model: bad model index")
+
+    def refit_edges(self, ctx):
+        """RelaxGroup::finalize's edge loop after a model change (relax_group.cpp:137-177): every edge re-fitted on its
+        previous inliers with the current camera models."""
+        if self.L.och_graph_refit_edges(self.h, ctx.h) != 0:
+            raise capi.OchipError("refit failed: " + self.L.och_last_error(self.h).decode())
 
     def add_image(self, loc, strength, desc, num_sparse, model, position):
         nid = self.L.och_graph_add_image(self.h, np.ascontiguousarray(loc, np.float64),

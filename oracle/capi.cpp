@@ -262,6 +262,47 @@ void oc_link_pair(const double *loc1, const uint64_t *desc1, size_t n1, const ui
     summary[6] = (double)r.ransac_improvements;
 }
 
+// The body of RelaxGroup::finalize's edge loop (src/relax/relax_group.cpp:142-176) for one edge: matches (i1, i2 into
+// the images' features) with their previous inlier flags in `inl` (in/out); H = the re-fitted homography;
+// summary: [n_inliers, can_decompose, accepted (inlier list kept)].
+void oc_refit_edge(const double *loc1, size_t n1, const double *loc2, size_t n2, const double *model1, const double *model2,
+                   const uint64_t *m_i1, const uint64_t *m_i2, const double *m_dist, size_t M, uint8_t *inl, double *H,
+                   double *poses, double *summary)
+{
+    auto f1 = make_features(loc1, nullptr, nullptr, n1);
+    auto f2 = make_features(loc2, nullptr, nullptr, n2);
+    std::vector<feature_match> matches(M);
+    for (size_t i = 0; i < M; i++)
+        matches[i] = feature_match{(size_t)m_i1[i], (size_t)m_i2[i], m_dist[i]};
+    const std::vector<correspondence> correspondences = distort_keypoints(f1, f2, matches, make_model(model1), make_model(model2));
+    std::vector<bool> inliers(correspondences.size(), false);
+    for (size_t i = 0; i < M; i++)
+        if (inl[i])
+            inliers[i] = true; // :152-155 (flags instead of the old inlier list's match_index values)
+    homography_model h;
+    for (int i = 0; i < 3; i++) // :158-162
+    {
+        h.fitInliers(correspondences, inliers);
+        h.evaluate(correspondences, inliers);
+    }
+    std::memcpy(H, h.homography.m, 72);
+    std::array<decomposed_pose, 4> rel;
+    const bool can_decompose = h.decompose(correspondences, inliers, rel);
+    const size_t num_inliers = std::count(inliers.begin(), inliers.end(), true);
+    for (size_t i = 0; i < M; i++)
+        inl[i] = inliers[i];
+    for (int i = 0; i < 4; i++)
+    {
+        double *o = poses + 8 * i;
+        const auto &p = rel[i];
+        o[0] = p.orientation.x, o[1] = p.orientation.y, o[2] = p.orientation.z, o[3] = p.orientation.w;
+        o[4] = p.position.x, o[5] = p.position.y, o[6] = p.position.z, o[7] = p.score;
+    }
+    summary[0] = (double)num_inliers;
+    summary[1] = can_decompose;
+    summary[2] = can_decompose && num_inliers > homography_model::MINIMUM_POINTS * 1.5;
+}
+
 // ---------------------------------------------------------------------------------------------
 // CPU baseline driver (bench.py cpu_baseline leg): the reference's scheduling, i.e. one closure per
 // directed pair under `#pragma omp parallel for schedule(dynamic,1)` (pipeline.cpp:42-49), with the

@@ -51,6 +51,8 @@ def lib():
         L.oc_homography_decompose.argtypes = [f64p, f64p, C.c_size_t, u8p, f64p]
         L.oc_link_pair.argtypes = [f64p, u64p, C.c_size_t, u64p, C.c_size_t, f64p, u64p, C.c_size_t, u64p, C.c_size_t,
                                    f64p, f64p, u64p, u64p, f64p, u8p, f64p, f64p, f64p]
+        L.oc_refit_edge.argtypes = [f64p, C.c_size_t, f64p, C.c_size_t, f64p, f64p, u64p, u64p, f64p, C.c_size_t, u8p, f64p,
+                                    f64p, f64p]
         L.oc_link_batch_cpu.argtypes = [f64p, f32p, u64p, u64p, C.c_size_t, u64p, f64p, u32p, C.c_size_t, C.c_int,
                                         C.c_int, u64p, f64p, f64p]
         L.oc_scene_homography.argtypes = [C.c_size_t, C.c_size_t, C.c_uint, f64p, u8p, f64p]
@@ -307,6 +309,25 @@ def link_pair(loc1, desc1, idx1, loc2, desc2, idx2, model1, model2):
     return dict(i1=mi1[:m].copy(), i2=mi2[:m].copy(), dist=md[:m].copy(), inliers=inl[:m].copy(), H=H, poses=poses,
                 n_inliers=int(summary[1]), can_decompose=bool(summary[2]), accepted=bool(summary[3]),
                 score=float(summary[4]), iterations=int(summary[5]), improvements=int(summary[6]))
+
+
+def refit_edge(loc1, loc2, model1, model2, i1, i2, dist, inliers):
+    """relax_group.cpp:142-176 for one edge: matches (i1, i2, dist) with their previous inlier flags."""
+    loc1 = np.ascontiguousarray(loc1, np.float64)
+    loc2 = np.ascontiguousarray(loc2, np.float64)
+    i1 = np.ascontiguousarray(i1, np.uint64)
+    i2 = np.ascontiguousarray(i2, np.uint64)
+    dist = np.ascontiguousarray(dist, np.float64)
+    M = len(i1)
+    inl = np.zeros(max(M, 1), np.uint8)
+    inl[:M] = inliers
+    H, poses, summary = np.zeros((3, 3)), np.zeros((4, 8)), np.zeros(3)
+    pad = lambda a, dt: a if M else np.zeros(1, dt)
+    lib().oc_refit_edge(loc1, len(loc1), loc2, len(loc2), np.ascontiguousarray(model1, np.float64),
+                        np.ascontiguousarray(model2, np.float64), pad(i1, np.uint64), pad(i2, np.uint64), pad(dist, np.float64), M,
+                        inl, H, poses, summary)
+    return dict(H=H, inliers=inl[:M].copy(), poses=poses, n_inliers=int(summary[0]), can_decompose=bool(summary[1]),
+                accepted=bool(summary[2]))
 
 
 def scene_homography(n_in, n_out, seed):
