@@ -1696,7 +1696,7 @@ int ochip_synth_render_views(ochip_ctx *ctx, uint8_t *images_dev, uint32_t first
                            images_dev + (size_t)first_image * width * height * 3, width, height, (const synth_cam *)dc,
                            (float)model3[0], (float)model3[1], (float)model3[2], (float)plane2[0], (float)plane2[1],
                            (float)lattice3[0], (float)lattice3[1], (float)lattice3[2], seed);
-        e = hipStreamSynchronize(ctx->stream);
+        e = ochip_stream_wait(ctx, ctx->stream);
     }
     (void)hipFree(dc);
     if (e != hipSuccess)
@@ -1778,7 +1778,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
 
     std::vector<std::pair<void *, size_t>> allocs;
     auto cleanup = [&]() {
-        (void)hipStreamSynchronize(st);
+        (void)ochip_stream_wait(ctx, st);
         for (auto &a : allocs)
             ochip_pool_put(ctx, a.first, a.second);
     };
@@ -2133,7 +2133,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                        max_cands);
     std::vector<unsigned int> ncand(B);
     OCHIP_HIP(ctx, hipMemcpyAsync(ncand.data(), d_ncand, B * 4, hipMemcpyDeviceToHost, st));
-    OCHIP_HIP(ctx, hipStreamSynchronize(st));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
     unsigned int max_n = 0;
     for (uint32_t b = 0; b < B; b++)
     {
@@ -2173,7 +2173,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     // ---- results: the per-image counts first, then exactly the compacted keypoints and descriptors, straight
     // into the caller's arrays (page-locked ones from ochip_host_alloc make these copies run at link speed)
     OCHIP_HIP(ctx, hipMemcpyAsync(counts, d_counts, B * 4, hipMemcpyDeviceToHost, st));
-    OCHIP_HIP(ctx, hipStreamSynchronize(st));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
     for (uint32_t b = 0; b < B && rc == OCHIP_OK; b++)
     {
         if (counts[b] > max_kp)

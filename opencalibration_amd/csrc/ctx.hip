@@ -156,7 +156,8 @@ int ochip_ctx_create(int device, ochip_ctx **out)
     ctx->device = device;
     hipError_t e = hipSetDevice(device);
     const char *bsync = getenv("OCHIP_BLOCKING_SYNC");
-    if (e == hipSuccess && !(bsync && bsync[0] == '0')) // default on; OCHIP_BLOCKING_SYNC=0 keeps the runtime's polling
+    ctx->blocking_wait = !(bsync && bsync[0] == '0');
+    if (e == hipSuccess && ctx->blocking_wait) // default on; OCHIP_BLOCKING_SYNC=0 keeps the runtime's polling
     {
         // waits sleep instead of spinning: host threads that wait for the device do not eat into a CPU quota the
         // OpenMP teams of the host phases need (refused harmlessly if the device is already active with other flags)
@@ -219,6 +220,8 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
         (void)hipHostFree(b.first);
     for (auto &b : ctx->pinned_live)
         (void)hipHostFree(b.first);
+    if (ctx->sync_event)
+        (void)hipEventDestroy(ctx->sync_event);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream)
@@ -267,8 +270,8 @@ int ochip_synchronize(ochip_ctx *ctx)
 {
     if (!ctx)
         return OCHIP_EINVAL;
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->copy_stream));
     return OCHIP_OK;
 }
 
@@ -277,7 +280,7 @@ int ochip_descriptors_reserve(ochip_ctx *ctx, uint32_t n_images, uint64_t total_
     if (!ctx)
         return OCHIP_EINVAL;
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     ctx->kp_set.clear();
     ctx->rays_dirty = false;
     ctx->kp_store_ready = false;
@@ -322,7 +325,7 @@ int ochip_upload_descriptors(ochip_ctx *ctx, uint32_t image_id, const uint64_t *
     ctx->desc_used += n;
     ctx->img_tables_dirty = true;
     // pageable source: hipMemcpyAsync has consumed it when it returns only after a sync
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     return OCHIP_OK;
 }
 
@@ -366,7 +369,7 @@ int ochip_upload_batch(ochip_ctx *ctx, uint32_t n_images, const uint32_t *counts
     if (n_images)
         OCHIP_HIP(ctx, hipMemcpyAsync(ctx->models_dev, models8, (size_t)n_images * 64, hipMemcpyHostToDevice,
                                       ctx->stream));
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     ctx->img_tables_dirty = true;
     ctx->rays_dirty = true;
     return OCHIP_OK;
@@ -432,7 +435,7 @@ int ochip_profile_reset(ochip_ctx *ctx)
 {
     if (!ctx)
         return OCHIP_EINVAL;
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     for (int k = 0; k < OCHIP_K_COUNT; k++)
     {
         prof_drain(ctx, k);

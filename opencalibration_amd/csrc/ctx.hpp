@@ -23,6 +23,8 @@ struct ochip_ctx
     int device = 0;
     hipStream_t stream = nullptr;     // compute stream: every kernel of the hot path is launched here
     hipStream_t copy_stream = nullptr;
+    hipEvent_t sync_event = nullptr;  // ochip_stream_wait: a blocking-sync event (created on first use)
+    bool blocking_wait = true;        // OCHIP_BLOCKING_SYNC=0: let the runtime poll instead
     std::string error;
     hipDeviceProp_t prop{};
 
@@ -73,6 +75,25 @@ struct ochip_ctx
     // that independent batches can be in flight at once; owned by this context
     std::vector<ochip_ctx *> siblings;
 };
+
+
+// Wait for a stream without spinning: an event created with hipEventBlockingSync puts the waiting host thread to sleep
+// whatever scheduling flags the device's primary context was created with (hipSetDeviceFlags is refused once another
+// library - PyTorch, RCCL - has initialised the device, which is exactly the multi-GPU case).  The threads that wait
+// here would otherwise eat the CPU quota the OpenMP teams of the host phases need.
+inline hipError_t ochip_stream_wait(ochip_ctx *ctx, hipStream_t st)
+{
+    if (!ctx->blocking_wait)
+        return hipStreamSynchronize(st);
+    if (!ctx->sync_event)
+    {
+        const hipError_t e = hipEventCreateWithFlags(&ctx->sync_event, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess)
+            return e;
+    }
+    const hipError_t e = hipEventRecord(ctx->sync_event, st);
+    return e != hipSuccess ? e : hipEventSynchronize(ctx->sync_event);
+}
 
 int ochip_fail(ochip_ctx *ctx, int code, const char *fmt, ...);
 int ochip_ensure(ochip_ctx *ctx, void **ptr, size_t *cap, size_t bytes); // grow-only device buffer

@@ -194,7 +194,7 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
     OCHIP_HIP(ctx, hipMemcpyAsync(ctx->out_off_dev, out_offset, (size_t)n_pairs * 8, hipMemcpyHostToDevice,
                                   ctx->stream));
     // the pageable sources above must be consumed before we return to the caller
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     if (max_n1 == 0)
         return OCHIP_OK;
 
@@ -239,7 +239,7 @@ int ochip_match_fetch(ochip_ctx *ctx, ochip_match *out, uint64_t out_total)
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
     OCHIP_HIP(ctx, hipMemcpyAsync(out, ctx->match_out_dev, (size_t)out_total * sizeof(ochip_match),
                                   hipMemcpyDeviceToHost, ctx->stream));
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     return OCHIP_OK;
 }
 

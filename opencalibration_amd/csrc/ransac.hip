@@ -1321,7 +1321,7 @@ int ochip_upload_keypoints(ochip_ctx *ctx, uint32_t image_id, const double *xy, 
     }
     OCHIP_HIP(ctx, hipMemcpyAsync(ctx->models_dev + (size_t)image_id * 8, model8, 64, hipMemcpyHostToDevice,
                                   ctx->stream));
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     ctx->kp_set[image_id] = 1;
     ctx->rays_dirty = true;
     return OCHIP_OK;
@@ -1434,7 +1434,7 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
                                   ctx->stream));
     if (total_matches)
         OCHIP_HIP(ctx, hipMemcpyAsync(inliers, inl_dev, (size_t)total_matches, hipMemcpyDeviceToHost, ctx->stream));
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     return OCHIP_OK;
 }
 
@@ -1504,7 +1504,7 @@ int ochip_refit_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, u
     OCHIP_HIP(ctx, hipMemcpyAsync(results, res_dev, (size_t)n_jobs * sizeof(ochip_ransac_result), hipMemcpyDeviceToHost, ctx->stream));
     if (total_matches)
         OCHIP_HIP(ctx, hipMemcpyAsync(inliers, inl_dev, (size_t)total_matches, hipMemcpyDeviceToHost, ctx->stream));
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     return OCHIP_OK;
 }
 

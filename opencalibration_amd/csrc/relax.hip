@@ -1224,7 +1224,7 @@ void ochip_relax_problem_destroy(ochip_relax_problem *p)
     if (!p)
         return;
     (void)hipSetDevice(p->ctx->device);
-    (void)hipStreamSynchronize(p->ctx->stream);
+    (void)ochip_stream_wait(p->ctx, p->ctx->stream);
     for (auto &a : p->allocs)
         ochip_pool_put(p->ctx, a.first, a.second);
     delete p;
@@ -1279,7 +1279,7 @@ int ochip_relax_get_state(ochip_relax_problem *p, double *cam_q, double *plane_z
     if (!p)
         return OCHIP_EINVAL;
     ochip_ctx *ctx = p->ctx;
-    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     if (cam_q)
         OCHIP_HIP(ctx, hipMemcpy(cam_q, p->dev.cam_q, (size_t)p->n_cams * 32, hipMemcpyDeviceToHost));
     if (plane_z)
@@ -1315,7 +1315,7 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
     {
         sum->termination = OCHIP_RELAX_NO_PARAMETERS;
         normalize();
-        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         return OCHIP_OK;
     }
     double h[8];
@@ -1337,7 +1337,7 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
         {
             // the ranks' pair records (and failure flags) are all-gathered in place; from here on every rank holds
             // the same arrays and runs the same deterministic assembly
-            OCHIP_HIP(ctx, hipStreamSynchronize(st));
+            OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
             const int xrc = p->exchange(p->exchange_user, D.pair_acc, with_jac ? (uint64_t)p->shard_chunk * ACC * 8 : 0,
                                         D.pair_cost, (uint64_t)p->shard_chunk * 8, p->fail_ranks, 4);
             if (xrc != 0)
@@ -1358,7 +1358,7 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
         OCHIP_HIP(ctx, hipMemcpyAsync(h, p->scal, 8, hipMemcpyDeviceToHost, st));
         std::vector<int32_t> hfails(p->shard_world, 0);
         OCHIP_HIP(ctx, hipMemcpyAsync(hfails.data(), p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         *cost = h[0];
         hfail = 0;
         for (int32_t f : hfails)
@@ -1368,7 +1368,7 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
     auto grad_and_diag = [&](double *gmax) -> int {
         hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(1024), 0, st, p->A, p->g, p->diag_tmp, n, p->scal);
         OCHIP_HIP(ctx, hipMemcpyAsync(h, p->scal, 64, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         *gmax = h[4];
         return OCHIP_OK;
     };
@@ -1379,7 +1379,7 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
     {
         sum->termination = OCHIP_RELAX_FAILURE;
         normalize();
-        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         return OCHIP_OK;
     }
     int rc = grad_and_diag(&gmax);
@@ -1414,7 +1414,7 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
         sum->termination = term;
         sum->final_cost = x_cost;
         normalize();
-        (void)hipStreamSynchronize(st);
+        (void)ochip_stream_wait(ctx, st);
         return OCHIP_OK;
     };
     if (gmax <= opt->gradient_tolerance)
@@ -1480,7 +1480,7 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
         int cfail = 0;
         OCHIP_HIP(ctx, hipMemcpyAsync(h, p->scal, 64, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, hipMemcpyAsync(&cfail, p->fail_chol, 4, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipStreamSynchronize(st));
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         reuse_diagonal = true;
         const double model_cost_change = h[1], step_norm = std::sqrt(h[2]), cand_norm = std::sqrt(h[3]);
         const bool valid = !cfail && std::isfinite(model_cost_change) && model_cost_change > 0.0;
