@@ -1105,7 +1105,18 @@ int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *d, ochip_
                 order[o++] = r.start + i;
     }
     std::vector<uint32_t> blk_a(d->n_blocks), blk_b(d->n_blocks), pair_off, pair_p, pair_q;
-    std::vector<double> rays((size_t)d->n_blocks * 6);
+    // the permuted rays (tens of MB) are written straight into page-locked memory: the upload then runs at link speed
+    // instead of through the runtime's bounce buffers
+    double *rays = nullptr;
+    {
+        void *pinned = nullptr;
+        if (ochip_host_alloc(ctx, std::max<size_t>((size_t)d->n_blocks * 48, 8), &pinned) != OCHIP_OK)
+        {
+            delete p;
+            return OCHIP_ENOMEM;
+        }
+        rays = (double *)pinned;
+    }
     {
         // the permuted copy of the blocks (tens of MB) on a few threads; the segment boundaries afterwards, in order
         const uint32_t nthr = d->n_blocks > (1u << 16) ? 8u : 1u;
@@ -1189,7 +1200,8 @@ int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *d, ochip_
     chk(dev_upload<int32_t>(p, &D.z_t, nullptr, 3));
     chk(dev_upload(p, &D.blk_a, blk_a.data(), blk_a.size()));
     chk(dev_upload(p, &D.blk_b, blk_b.data(), blk_b.size()));
-    chk(dev_upload(p, &D.blk_rays, rays.data(), rays.size()));
+    chk(dev_upload(p, &D.blk_rays, (const double *)rays, (size_t)d->n_blocks * 6));
+    ochip_host_free(ctx, rays);
     chk(dev_upload(p, &D.pair_off, pair_off.data(), pair_off.size()));
     p->pair_p_h = pair_p;
     p->pair_q_h = pair_q;
