@@ -128,15 +128,20 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
 #pragma omp atomic
             g_tail_prof[4] += 1.0;
         }
-        static thread_local std::vector<float> response; // contiguous for the comparator below
-        response.resize(n);
-        for (uint32_t i = 0; i < n; i++)
+        // the records carry the response next to the index: the comparator then touches one cache line per element
+        // (the permutation only depends on the comparator's answers, which are those of sorting the feature structs)
+        struct by_response
         {
-            order[i] = i;
-            response[i] = k6[6 * (size_t)i + 4];
-        }
-        const float *r = response.data();
-        std::sort(order.begin(), order.end(), [r](uint32_t a, uint32_t c) -> bool { return r[a] > r[c]; });
+            float response;
+            uint32_t index;
+        };
+        static thread_local std::vector<by_response> recs;
+        recs.resize(n);
+        for (uint32_t i = 0; i < n; i++)
+            recs[i] = by_response{k6[6 * (size_t)i + 4], i};
+        std::sort(recs.begin(), recs.end(), [](const by_response &a, const by_response &c) -> bool { return a.response > c.response; });
+        for (uint32_t i = 0; i < n; i++)
+            order[i] = recs[i].index;
     }
     if (prof)
         tp1 = thread_cpu_now();
