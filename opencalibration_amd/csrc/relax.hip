@@ -969,12 +969,81 @@ int assign_tangent(ochip_relax_problem *p)
 {
     int t = 0;
     p->cam_t.assign(p->n_cams, -1);
+    std::vector<uint32_t> active; // cameras that get unknowns, in the order of their unknowns
     for (uint32_t c = 0; c < p->n_cams; c++)
         if (p->cam_optimize[c] && !p->cams_frozen && p->cam_pair_count[c] + p->cam_has_prior_host[c] > 0)
+            active.push_back(c);
+    static const bool use_rcm = !(getenv("OCHIP_RELAX_RCM") && getenv("OCHIP_RELAX_RCM")[0] == '0');
+    if (use_rcm && active.size() > 2 * (size_t)NB / 3)
+    {
+        // Reverse Cuthill-McKee over the camera graph (a link = a pair with residual blocks): the block envelope the
+        // factorisation works in then does not depend on the order the images happen to arrive in.  Per connected
+        // component: start from a pseudo-peripheral camera (two breadth-first sweeps from the lowest-degree one),
+        // visit neighbours by increasing degree (ties: camera index), reverse the whole order at the end.
+        std::vector<int> slot(p->n_cams, -1);
+        for (size_t i = 0; i < active.size(); i++)
+            slot[active[i]] = (int)i;
+        std::vector<std::vector<uint32_t>> adj(active.size());
+        for (size_t i = 0; i < p->pair_p_h.size(); i++)
         {
-            p->cam_t[c] = t;
-            t += 3;
+            const int a = slot[p->pair_p_h[i]], b = slot[p->pair_q_h[i]];
+            if (a >= 0 && b >= 0)
+            {
+                adj[a].push_back((uint32_t)b);
+                adj[b].push_back((uint32_t)a);
+            }
         }
+        for (auto &l : adj)
+            std::sort(l.begin(), l.end(), [&](uint32_t x, uint32_t y) {
+                return adj[x].size() != adj[y].size() ? adj[x].size() < adj[y].size() : x < y;
+            });
+        std::vector<char> seen(active.size(), 0);
+        std::vector<uint32_t> order;
+        order.reserve(active.size());
+        auto bfs = [&](uint32_t start, std::vector<uint32_t> &out, std::vector<char> &mark) {
+            const size_t first = out.size();
+            out.push_back(start);
+            mark[start] = 1;
+            for (size_t h = first; h < out.size(); h++)
+                for (uint32_t v : adj[out[h]])
+                    if (!mark[v])
+                    {
+                        mark[v] = 1;
+                        out.push_back(v);
+                    }
+        };
+        for (uint32_t s0 = 0; s0 < active.size(); s0++)
+        {
+            if (seen[s0])
+                continue;
+            // the component of s0, then its lowest-degree member, then two sweeps towards the periphery
+            std::vector<uint32_t> comp;
+            std::vector<char> tmp(seen);
+            bfs(s0, comp, tmp);
+            uint32_t start = comp[0];
+            for (uint32_t v : comp)
+                if (adj[v].size() < adj[start].size() || (adj[v].size() == adj[start].size() && v < start))
+                    start = v;
+            for (int sweep = 0; sweep < 2; sweep++)
+            {
+                std::vector<uint32_t> lv;
+                std::vector<char> tmp2(seen);
+                bfs(start, lv, tmp2);
+                start = lv.back();
+            }
+            bfs(start, order, seen);
+        }
+        std::reverse(order.begin(), order.end());
+        std::vector<uint32_t> reordered(active.size());
+        for (size_t i = 0; i < order.size(); i++)
+            reordered[i] = active[order[i]];
+        active.swap(reordered);
+    }
+    for (uint32_t c : active)
+    {
+        p->cam_t[c] = t;
+        t += 3;
+    }
     for (int i = 0; i < 3; i++)
     {
         p->z_t[i] = -1;
@@ -986,10 +1055,7 @@ int assign_tangent(ochip_relax_problem *p)
         // block envelope of the reduced system J'J: camera unknowns in camera order, then the plane unknowns (coupled to
         // every camera: the tail).  A pair (p, q) puts a 3 x 3 block at rows t_q.., columns t_p..; Cholesky fill stays
         // inside the column envelope once that is made monotone.
-        int cam_end = 0;
-        for (uint32_t c = 0; c < p->n_cams; c++)
-            if (p->cam_t[c] >= 0)
-                cam_end = p->cam_t[c] + 3;
+        const int cam_end = 3 * (int)active.size();
         const int n_all = std::max(t, 1), nblk = (n_all + NB - 1) / NB;
         p->tail_begin = cam_end;
         p->env_end.assign(nblk, 0);
