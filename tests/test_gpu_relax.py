@@ -86,6 +86,20 @@ def test_large_system_uses_blocked_cholesky(ctx, oracle):
     _assert_same(exp, got)
 
 
+def test_shuffled_camera_order(ctx, oracle):
+    """The cameras arrive in random order: the unknowns are renumbered (reverse Cuthill-McKee) before the envelope
+    factorisation, and the result is still the oracle's dense solve of the same shuffled problem."""
+    ori, pos, edges, model = camera_grid(10, 12, seed=5, pts_per_side=30)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(ori))
+    inv = np.argsort(perm)
+    ori, pos = ori[perm], pos[perm]
+    edges = [dict(e, src=int(inv[e["src"]]), dst=int(inv[e["dst"]])) for e in edges]
+    noisy = np.array([qmul(q, axis_angle(rng.normal(size=3) / 1.7, 0.05)) for q in ori])
+    exp, got = _both(ctx, oracle, pos, ori, model, np.arange(len(ori)), noisy, edges)
+    _assert_same(exp, got)
+
+
 def test_graph_without_edges(ctx, oracle):
     """No measurements: only the PointsDownwardsPrior blocks remain (relax_problem.cpp:1297), the cameras barely
     move and the device agrees with the oracle on that degenerate problem too."""
