@@ -63,6 +63,10 @@ extern "C"
                                    uint32_t max_keypoints, uint32_t max_out, double *loc, float *strength,
                                    uint64_t *desc, uint32_t *counts, uint32_t *num_sparse, int images_on_device);
     const char *och_extract_last_error(void);
+    /* The host tail of extract_features alone (extract_features.cpp:38-87), no device involved: kp6 rows
+     * {x, y, size, angle, response, level} in cv::AKAZE's order -> loc / strength / desc as above; returns the count. */
+    size_t och_extract_tail(const float *kp6, const uint64_t *desc, uint32_t n, double scale, double *loc, float *strength,
+                            uint64_t *desc_out, uint64_t *num_sparse);
     /* The load stage's job for a batch of equally sized images (src/pipeline/load_stage.cpp:43-110: extract_features,
      * then one graph node per image): extract on the device in chunks (host tail of chunk k overlapped with the device
      * work of chunk k + 1), then addNode in image order.  positions: n x 3; node_ids_out: n (may be NULL);

@@ -433,3 +433,21 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
 }
 
 } // namespace opencalibration_amd
+
+// The host tail alone (no device): what extract_features.cpp:38-87 does with the keypoints cv::AKAZE returned, given
+// as kp6 rows {x, y, size, angle, response, level} in detection order.  For the CPU-side tests.
+extern "C" size_t och_extract_tail(const float *kp6, const uint64_t *desc, uint32_t n, double scale, double *loc, float *strength,
+                                   uint64_t *desc_out, uint64_t *num_sparse)
+{
+    opencalibration_amd::extracted_features out;
+    opencalibration_amd::extract_tail(kp6, desc, n, scale, out);
+    for (size_t i = 0; i < out.features.size(); i++)
+    {
+        loc[2 * i] = out.features[i].location[0];
+        loc[2 * i + 1] = out.features[i].location[1];
+        strength[i] = out.features[i].strength;
+        std::memcpy(desc_out + 8 * i, out.features[i].descriptor, 64);
+    }
+    *num_sparse = out.num_sparse_features;
+    return out.features.size();
+}

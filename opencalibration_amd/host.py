@@ -92,6 +92,8 @@ def load():
         L.och_relax_last_error.restype = C.c_char_p
         L.och_graph_relax_ground_plane.argtypes = [vp, vp, _f64p, _f64p, _f64p]
         L.och_graph_relax_ground_plane_sharded.argtypes = [vp, vp, _f64p, _f64p, _f64p, u32, u32, RELAX_EXCHANGE_FN, vp]
+        L.och_extract_tail.restype = C.c_size_t
+        L.och_extract_tail.argtypes = [_f32p, _u64p, u32, C.c_double, _f64p, _f32p, _u64p, _u64p]
         L.och_graph_set_model.argtypes = [vp, u32, _f64p]
         L.och_graph_refit_edges.argtypes = [vp, vp]
         L.och_extract_features_batch.argtypes = [vp, vp, u32, C.c_int, C.c_int, u32, u32, vp, vp, vp, vp, vp, C.c_int]
@@ -327,6 +329,17 @@ class Graph:
                 continue
             out.append(dict(src=s, dst=d, H=ed["H"], px=ed["px"], match_index=ed["match_index"], dist=ed["dist"]))
         return out
+
+
+def extract_tail(kp6, desc, scale):
+    """The host tail of extract_features on given keypoints (detection order): (loc, strength, desc, num_sparse)."""
+    L = load()
+    kp6 = np.ascontiguousarray(kp6, np.float32).reshape(-1, 6)
+    desc = np.ascontiguousarray(desc, np.uint64).reshape(-1, 8)
+    n = len(kp6)
+    loc, st, d, ns = np.zeros((n + 1, 2)), np.zeros(n + 1, np.float32), np.zeros((n + 1, 8), np.uint64), np.zeros(1, np.uint64)  # the seed keypoint appears twice
+    m = L.och_extract_tail(kp6 if n else np.zeros((1, 6), np.float32), desc if n else np.zeros((1, 8), np.uint64), n, float(scale), loc, st, d, ns)
+    return loc[:m].copy(), st[:m].copy(), d[:m].copy(), int(ns[0])
 
 
 def subsample(loc, strength, spacing, count=0):

@@ -678,24 +678,10 @@ std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o
     return out;
 }
 
-Extracted extract_features(const uint8_t *bgr, int w, int h) // src/extract/extract_features.cpp:11-88
+// The tail of extract_features (src/extract/extract_features.cpp:38-87): rescale to full-resolution pixels, the
+// unstable std::sort by strength from AKAZE's keypoint order, the 8 px NMS, [sparse..., dense...].
+void extract_tail(const std::vector<Keypoint> &kps, double scale, Extracted &ex)
 {
-    Extracted ex;
-    if (w <= 0 || h <= 0)
-        return ex;
-    std::vector<uint8_t> gray((size_t)w * h);
-    bgr_to_gray(bgr, w, h, gray.data());
-    const double scale = std::min(1.f, float(1600) / (float)std::max(w, h));
-    const int sw = (int)std::lrint(w * scale), sh = (int)std::lrint(h * scale);
-    std::vector<uint8_t> small((size_t)sw * sh);
-    resize_area(gray.data(), w, h, small.data(), sw, sh);
-    std::vector<float> img((size_t)sw * sh);
-    for (size_t i = 0; i < img.size(); i++)
-        img[i] = (float)small[i] * (1.0f / 255.0f);
-    Options o;
-    const ScaleSpace ss = build_scale_space(img, sw, sh, o);
-    const std::vector<Keypoint> kps = detect_and_describe(ss, o);
-
     struct feat
     {
         double x, y;
@@ -751,6 +737,27 @@ Extracted extract_features(const uint8_t *bgr, int w, int h) // src/extract/extr
         ex.strength.push_back(p.strength);
         ex.desc.insert(ex.desc.end(), p.d, p.d + 8);
     }
+}
+
+Extracted extract_features(const uint8_t *bgr, int w, int h) // src/extract/extract_features.cpp:11-88
+{
+    Extracted ex;
+    if (w <= 0 || h <= 0)
+        return ex;
+    std::vector<uint8_t> gray((size_t)w * h);
+    bgr_to_gray(bgr, w, h, gray.data());
+    const double scale = std::min(1.f, float(1600) / (float)std::max(w, h));
+    const int sw = (int)std::lrint(w * scale), sh = (int)std::lrint(h * scale);
+    std::vector<uint8_t> small((size_t)sw * sh);
+    resize_area(gray.data(), w, h, small.data(), sw, sh);
+    std::vector<float> img((size_t)sw * sh);
+    for (size_t i = 0; i < img.size(); i++)
+        img[i] = (float)small[i] * (1.0f / 255.0f);
+    Options o;
+    const ScaleSpace ss = build_scale_space(img, sw, sh, o);
+    const std::vector<Keypoint> kps = detect_and_describe(ss, o);
+
+    extract_tail(kps, scale, ex);
     return ex;
 }
 
@@ -761,6 +768,28 @@ using namespace oracle::akaze;
 
 extern "C"
 {
+
+// the host tail alone, on keypoints given as kp6 rows {x, y, size, angle, response, level} in detection order
+size_t oc_extract_tail(const float *kp6, const uint64_t *desc, size_t n, double scale, double *loc, float *strength, uint64_t *desc_out,
+                       uint64_t *num_sparse)
+{
+    std::vector<Keypoint> kps(n);
+    for (size_t i = 0; i < n; i++)
+    {
+        kps[i].x = kp6[6 * i];
+        kps[i].y = kp6[6 * i + 1];
+        kps[i].response = kp6[6 * i + 4];
+        std::memcpy(kps[i].desc, desc + 8 * i, 64);
+    }
+    Extracted ex;
+    extract_tail(kps, scale, ex);
+    const size_t m = ex.strength.size();
+    std::memcpy(loc, ex.loc.data(), m * 16);
+    std::memcpy(strength, ex.strength.data(), m * 4);
+    std::memcpy(desc_out, ex.desc.data(), m * 64);
+    *num_sparse = ex.num_sparse;
+    return m;
+}
 
 // keypoints: n x {x, y, size, angle, response, level}; desc n x 8; returns n (capped at max_kp)
 size_t oc_akaze(const uint8_t *gray, int w, int h, size_t max_kp, float *kp6, uint64_t *desc, float *kcontrast)

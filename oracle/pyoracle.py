@@ -51,6 +51,8 @@ def lib():
         L.oc_homography_decompose.argtypes = [f64p, f64p, C.c_size_t, u8p, f64p]
         L.oc_link_pair.argtypes = [f64p, u64p, C.c_size_t, u64p, C.c_size_t, f64p, u64p, C.c_size_t, u64p, C.c_size_t,
                                    f64p, f64p, u64p, u64p, f64p, u8p, f64p, f64p, f64p]
+        L.oc_extract_tail.restype = C.c_size_t
+        L.oc_extract_tail.argtypes = [f32p, u64p, C.c_size_t, C.c_double, f64p, f32p, u64p, u64p]
         L.oc_refit_edge.argtypes = [f64p, C.c_size_t, f64p, C.c_size_t, f64p, f64p, u64p, u64p, f64p, C.c_size_t, u8p, f64p,
                                     f64p, f64p]
         L.oc_link_batch_cpu.argtypes = [f64p, f32p, u64p, u64p, C.c_size_t, u64p, f64p, u32p, C.c_size_t, C.c_int,
@@ -98,6 +100,16 @@ def extract_features(bgr, max_n=100000):
     n = lib().oc_extract_features(bgr, w, h, max_n, loc, st, d, ns)
     assert n <= max_n
     return loc[:n].copy(), st[:n].copy(), d[:n].copy(), int(ns[0])
+
+
+def extract_tail(kp6, desc, scale):
+    """The tail of extract_features (sort by strength, 8 px NMS) on given keypoints in detection order."""
+    kp6 = np.ascontiguousarray(kp6, np.float32).reshape(-1, 6)
+    desc = np.ascontiguousarray(desc, np.uint64).reshape(-1, 8)
+    n = len(kp6)
+    loc, st, d, ns = np.zeros((n + 1, 2)), np.zeros(n + 1, np.float32), np.zeros((n + 1, 8), np.uint64), np.zeros(1, np.uint64)  # the seed keypoint appears twice
+    m = lib().oc_extract_tail(kp6 if n else np.zeros((1, 6), np.float32), desc if n else np.zeros((1, 8), np.uint64), n, float(scale), loc, st, d, ns)
+    return loc[:m].copy(), st[:m].copy(), d[:m].copy(), int(ns[0])
 
 
 def gray_resize(bgr, ow, oh):
