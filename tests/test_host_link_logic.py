@@ -1,0 +1,46 @@
+"""CPU checks of the product's host half of the link step against the oracle's restatement: the 40 px spatial
+subsample (csrc/host/match_features.cpp) and the tail of match_features_subset - ratio test, index remap and the
+reference's unstable std::sort by distance - applied to the records the Hamming kernel returns
+(och_matches_from_device).  The kernel's records are produced here with numpy, so no device is needed."""
+import numpy as np
+import pytest
+
+from opencalibration_amd import capi, host, synth
+
+
+def _popcount(a):
+    return np.unpackbits(np.ascontiguousarray(a).view(np.uint8), axis=-1).sum(-1)
+
+
+@pytest.mark.parametrize("seed,n,spacing,count", [(1, 3000, 40.0, 0), (2, 3000, 40.0, 2000), (3, 500, 300.0, 0), (4, 0, 40.0, 0)])
+def test_subsample_matches_restatement(oracle, seed, n, spacing, count):
+    rng = np.random.default_rng(seed)
+    loc = np.stack([rng.uniform(0, 4000, n), rng.uniform(0, 3000, n)], -1)
+    strength = rng.uniform(0, 1, n).astype(np.float32)
+    strength[: n // 10] = strength[n // 10: 2 * (n // 10)]          # exact ties in the strength sort
+    got = host.subsample(loc, strength, spacing, count)
+    exp = oracle.subsample(loc, strength, spacing, count)
+    assert np.array_equal(got, exp)
+
+
+def test_match_tail_matches_restatement(oracle):
+    rng = np.random.default_rng(9)
+    base = synth.descriptors_for_ids(np.arange(900))
+    d1, d2 = base[:600].copy(), base[300:900].copy()
+    for d in (d1, d2):
+        bits = rng.integers(0, 486, (len(d), 30))
+        for j in range(30):
+            d[np.arange(len(d)), bits[:, j] >> 6] ^= np.uint64(1) << (bits[:, j] & 63).astype(np.uint64)
+    d2[11] = d2[3]                                             # a tie between the two best references
+    idx1 = rng.permutation(600)[:500].astype(np.uint64)
+    idx2 = rng.permutation(600)[:550].astype(np.uint64)
+    ham = _popcount(d1[idx1.astype(int)][:, None, :] ^ d2[idx2.astype(int)][None, :, :]).astype(np.int64)
+    # what hamming_2nn_kernel returns per query: lowest k among the minima, second = next count (== best on a tie)
+    raw = np.zeros(len(idx1), capi.MATCH_DTYPE)
+    for a in range(len(idx1)):
+        order = np.argsort(ham[a], kind="stable")
+        raw[a] = (order[0], ham[a][order[0]], ham[a][order[1]])
+    i1, i2, dist = host.matches_from_device(raw, idx1, idx2)
+    e1, e2, edist = oracle.match(d1, d2, idx1, idx2)
+    assert len(i1) > 150 and len(np.unique(dist)) < len(dist)    # the sort has ties to break
+    assert np.array_equal(i1, e1) and np.array_equal(i2, e2) and np.array_equal(dist, edist)
