@@ -63,6 +63,10 @@ extern "C"
                                    uint32_t max_keypoints, uint32_t max_out, double *loc, float *strength,
                                    uint64_t *desc, uint32_t *counts, uint32_t *num_sparse, int images_on_device);
     const char *och_extract_last_error(void);
+    /* Host pieces of the link step, callable without a device (tests): homography_model::decompose on the inlier rays
+     * (n x {measurement1, measurement2}; poses 4 x {q xyzw, t xyz, score}; returns can_decompose) and image_to_3d. */
+    int och_homography_decompose(const double *H9, const double *m1m2, size_t n, double *poses);
+    void och_image_to_3d(const double *px, size_t n, const double *model10, double *rays);
     /* The host tail of extract_features alone (extract_features.cpp:38-87), no device involved: kp6 rows
      * {x, y, size, angle, response, level} in cv::AKAZE's order -> loc / strength / desc as above; returns the count. */
     size_t och_extract_tail(const float *kp6, const uint64_t *desc, uint32_t n, double scale, double *loc, float *strength,

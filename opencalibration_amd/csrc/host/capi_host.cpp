@@ -67,6 +67,39 @@ och_graph *och_graph_create(void)
     return new (std::nothrow) och_graph();
 }
 
+// homography_model::decompose (homography_model.cpp:138-185) on the inlier rays m1m2 = n x {measurement1, measurement2};
+// poses: 4 x {orientation xyzw, position xyz, score}.  Returns can_decompose.  No device involved.
+int och_homography_decompose(const double *H9, const double *m1m2, size_t n, double *poses)
+{
+    homography_model h;
+    std::memcpy(h.homography, H9, sizeof h.homography);
+    std::array<decomposed_pose, 4> rel;
+    const bool ok = h.decompose_inlier_rays(m1m2, n, rel);
+    for (int i = 0; i < 4; i++)
+    {
+        double *o = poses + 8 * i;
+        std::memcpy(o, rel[i].orientation, 32);
+        std::memcpy(o + 4, rel[i].position, 24);
+        o[7] = rel[i].score;
+    }
+    return ok ? 1 : 0;
+}
+
+// image_to_3d (distort_keypoints.cpp:68-103) of n pixels with model10 = {f, ppx, ppy, k1, k2, k3, p1, p2, cols, rows}
+void och_image_to_3d(const double *px, size_t n, const double *m10, double *rays)
+{
+    CameraModel m;
+    m.focal_length_pixels = m10[0];
+    m.principle_point[0] = m10[1];
+    m.principle_point[1] = m10[2];
+    for (int i = 0; i < 3; i++)
+        m.radial_distortion[i] = m10[3 + i];
+    m.tangential_distortion[0] = m10[6];
+    m.tangential_distortion[1] = m10[7];
+    for (size_t i = 0; i < n; i++)
+        image_to_3d(px + 2 * i, m, rays + 3 * i);
+}
+
 void och_graph_destroy(och_graph *g)
 {
     delete g;

@@ -92,6 +92,8 @@ def load():
         L.och_relax_last_error.restype = C.c_char_p
         L.och_graph_relax_ground_plane.argtypes = [vp, vp, _f64p, _f64p, _f64p]
         L.och_graph_relax_ground_plane_sharded.argtypes = [vp, vp, _f64p, _f64p, _f64p, u32, u32, RELAX_EXCHANGE_FN, vp]
+        L.och_homography_decompose.argtypes = [_f64p, _f64p, sz, _f64p]
+        L.och_image_to_3d.argtypes = [_f64p, sz, _f64p, _f64p]
         L.och_extract_tail.restype = C.c_size_t
         L.och_extract_tail.argtypes = [_f32p, _u64p, u32, C.c_double, _f64p, _f32p, _u64p, _u64p]
         L.och_graph_set_model.argtypes = [vp, u32, _f64p]
@@ -340,6 +342,22 @@ def extract_tail(kp6, desc, scale):
     loc, st, d, ns = np.zeros((n + 1, 2)), np.zeros(n + 1, np.float32), np.zeros((n + 1, 8), np.uint64), np.zeros(1, np.uint64)  # the seed keypoint appears twice
     m = L.och_extract_tail(kp6 if n else np.zeros((1, 6), np.float32), desc if n else np.zeros((1, 8), np.uint64), n, float(scale), loc, st, d, ns)
     return loc[:m].copy(), st[:m].copy(), d[:m].copy(), int(ns[0])
+
+
+def decompose(H, m1, m2):
+    """homography_model::decompose on inlier rays m1, m2 (n x 3 each): (can_decompose, poses 4 x 8)."""
+    rays = np.ascontiguousarray(np.concatenate([np.asarray(m1, np.float64).reshape(-1, 3), np.asarray(m2, np.float64).reshape(-1, 3)], 1))
+    poses = np.zeros((4, 8))
+    ok = load().och_homography_decompose(np.ascontiguousarray(H, np.float64).reshape(9), rays if len(rays) else np.zeros((1, 6)), len(rays), poses)
+    return bool(ok), poses
+
+
+def image_to_3d(px, model10):
+    px = np.ascontiguousarray(px, np.float64).reshape(-1, 2)
+    rays = np.zeros((len(px), 3))
+    if len(px):
+        load().och_image_to_3d(px, len(px), np.ascontiguousarray(model10, np.float64), rays)
+    return rays
 
 
 def subsample(loc, strength, spacing, count=0):

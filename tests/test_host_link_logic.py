@@ -44,3 +44,26 @@ def test_match_tail_matches_restatement(oracle):
     e1, e2, edist = oracle.match(d1, d2, idx1, idx2)
     assert len(i1) > 150 and len(np.unique(dist)) < len(dist)    # the sort has ties to break
     assert np.array_equal(i1, e1) and np.array_equal(i2, e2) and np.array_equal(dist, edist)
+
+
+def test_image_to_3d_matches_restatement(oracle):
+    """The host copy of image_to_3d (rays for the cheirality vote and the relax) with and without lens distortion."""
+    rng = np.random.default_rng(4)
+    px = np.stack([rng.uniform(0, 4000, 500), rng.uniform(0, 3000, 500)], -1)
+    for dist in [(0, 0, 0, 0, 0), (-0.05, 0.01, -0.002, 1e-3, -5e-4)]:
+        model = np.array([3000.0, 2011.5, 1489.25, *dist, 4000, 3000])
+        assert np.array_equal(host.image_to_3d(px, model), oracle.image_to_3d(px, model))
+
+
+@pytest.mark.parametrize("seed", [42, 43, 44])
+def test_decompose_matches_restatement(oracle, seed):
+    """cv::decomposeHomographyMat restated + cheirality vote + stable_sort (homography_model.cpp:138-185) on the
+    reference's synthetic homography scene (test_ransac_benchmark.cpp:18-58)."""
+    corr, gt, H = oracle.scene_homography(140, 60, seed)
+    r = oracle.ransac_homography(corr)
+    ok_e, poses_e = oracle.decompose(r["H"], corr, r["inliers"])
+    inl = r["inliers"].astype(bool)
+    ok_g, poses_g = host.decompose(r["H"], corr[inl, 0:3], corr[inl, 3:6])
+    assert ok_g == ok_e
+    assert np.allclose(poses_g, poses_e, rtol=0, atol=1e-12, equal_nan=True)
+    assert np.array_equal(poses_g[:, 7], poses_e[:, 7])
