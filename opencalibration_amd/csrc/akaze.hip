@@ -216,7 +216,7 @@ struct taps_t
 // Every value is the same float expression as the separate passes (ascending tap order, clamped source
 // coordinates for the blur, reflected coordinates for the stencil), so the fusion does not change a bit.
 constexpr int BT_X = 64, BT_Y = 32; // blur tiles
-constexpr int DT_Y = 24;             // detection tiles are 64 x 24 (16, 24, 32 rows measured: 63, 57, 62 us per image for determinant + maxima + list)
+constexpr int DT_Y = 24;             // detection tiles are 64 x 24 (16, 24, 32 rows measured: 43, 39, 40 us per image for the determinant kernels)
 enum
 {
     BLUR_PLAIN = 0,
@@ -692,7 +692,8 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
 {
     constexpr int HW = S + 1, RW = BT_X + 2 * HW, RH = DT_Y + 2 * HW, DW = BT_X + 2, DH = DT_Y + 2;
     __shared__ float tx[RW * RH], ty[RW * RH];
-    __shared__ float td[DW * DH];
+    static_assert(DW * DH <= RW * RH, "the determinant tile reuses the Lx tile's storage");
+    float *td = tx; // written only after every thread has its determinants in registers (barrier in between)
     const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + DT_Y - 1) / DT_Y;
     int tile_x, tile_y;
     if (!xcd_tile(tiles_x, tiles_y, &tile_x, &tile_y))
@@ -700,6 +701,8 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
     const int x0 = tile_x * BT_X, y0 = tile_y * DT_Y;
     const int rx0 = x0 - HW, ry0 = y0 - HW;
     const float2 *XY = Lxy + (size_t)blockIdx.z * stride;
+    constexpr int DITERS = (DW * DH + 255) / 256;
+    float dreg[DITERS]; // this thread's determinants (index threadIdx.x + 256 i); NaN = outside the image, not stored
     {
         constexpr int ITERS = (RW * RH + 255) / 256; // all loads in flight before the first LDS store
         float vx[ITERS], vy[ITERS];
@@ -737,9 +740,13 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
     const bool inner_tile = rx0 >= 0 && ry0 >= 0 && x0 + BT_X + HW <= w && y0 + DT_Y + HW <= h;
     if (inner_tile)
     {
-#pragma unroll 3
-        for (int idx = threadIdx.x; idx < DW * DH; idx += 256)
+#pragma unroll
+        for (int it = 0; it < DITERS; it++)
         {
+            const int idx = threadIdx.x + 256 * it;
+            dreg[it] = 0.0f;
+            if (idx >= DW * DH)
+                continue;
             const int ly = idx / DW, lx = idx - ly * DW;
             const int x = x0 - 1 + lx, y = y0 - 1 + ly;
             const int ci = (ly + S) * RW + (lx + S); // (x, y) in the Lx / Ly tiles: their origin is (x0 - S - 1, y0 - S - 1)
@@ -747,15 +754,19 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
             pattern_lds<S, RW>(&tx[ci], nrm, wn, &lxx, &lxy);
             pattern_lds<S, RW>(&ty[ci], nrm, wn, &tmp, &lyy);
             const float d = (lxx * lyy - lxy * lxy) * s4;
-            td[idx] = d;
+            dreg[it] = d;
             if (lx >= 1 && lx <= BT_X && ly >= 1 && ly <= DT_Y)
                 Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = d;
         }
     }
     else
-#pragma unroll 3
-    for (int idx = threadIdx.x; idx < DW * DH; idx += 256)
+#pragma unroll
+    for (int it = 0; it < DITERS; it++)
     {
+        const int idx = threadIdx.x + 256 * it;
+        dreg[it] = 0.0f;
+        if (idx >= DW * DH)
+            continue;
         const int ly = idx / DW, lx = idx - ly * DW;
         const int x = x0 - 1 + lx, y = y0 - 1 + ly;
         if (x < 0 || x >= w || y < 0 || y >= h)
@@ -774,9 +785,17 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
         pattern_xy(atx, xm, x, xp, ym, y, yp, nrm, wn, &lxx, &lxy);
         pattern_xy(aty, xm, x, xp, ym, y, yp, nrm, wn, &tmp, &lyy);
         const float d = (lxx * lyy - lxy * lxy) * s4;
-        td[idx] = d;
+        dreg[it] = d;
         if (lx >= 1 && lx <= BT_X && ly >= 1 && ly <= DT_Y)
             Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = d;
+    }
+    __syncthreads(); // every determinant is in a register: the Lx tile's storage becomes the determinant tile
+#pragma unroll
+    for (int it = 0; it < DITERS; it++)
+    {
+        const int idx = threadIdx.x + 256 * it;
+        if (idx < DW * DH)
+            td[idx] = dreg[it];
     }
     __syncthreads();
     // one wavefront per tile row: the row's maxima as one 64-bit word of the level's bit mask, the responses only where a
