@@ -179,8 +179,27 @@ std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph
     return funcs;
 }
 
+static double g_link_cpu[6]; // CPU seconds (OCHIP_LINK_VERBOSE): pack+upload, ratio+sort, prosac, pack jobs, decompose, assemble
+static double link_thread_cpu()
+{
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static void link_cpu_add(int i, double v)
+{
+#pragma omp atomic
+    g_link_cpu[i] += v;
+}
+void link_cpu_report()
+{
+    fprintf(stderr, "[link] CPU seconds: pack %.3f, ratio+sort %.3f, prosac order %.3f, pack jobs %.3f, decompose %.3f, assemble %.3f\n",
+            g_link_cpu[0], g_link_cpu[1], g_link_cpu[2], g_link_cpu[3], g_link_cpu[4], g_link_cpu[5]);
+}
+
 void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size_t link_end, ochip_ctx *ctx, int omp_threads)
 {
+    static const bool prof = std::getenv("OCHIP_LINK_VERBOSE") != nullptr;
     LinkTimers lt; // this runner's phases, added to `timers` at the end
     struct timers_guard
     {
@@ -277,6 +296,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
 #pragma omp parallel for schedule(dynamic, 1) num_threads(omp_threads)
         for (size_t s = 0; s < n_slots; s++)
         {
+            const double tc0 = prof ? link_thread_cpu() : 0;
             const image &img = graph.getNode(slot_node[s])->payload;
             uint64_t *d = dbuf.ptr + slot_off[s] * 8;
             double *xy = xybuf.ptr + slot_off[s] * 2;
@@ -292,6 +312,8 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
                                       m.radial_distortion[0],     m.radial_distortion[1],    m.radial_distortion[2],
                                       m.tangential_distortion[0], m.tangential_distortion[1]};
             std::memcpy(&models[s * 8], model8, sizeof model8);
+            if (prof)
+                link_cpu_add(0, link_thread_cpu() - tc0);
         }
         if (ochip_upload_batch(ctx, (uint32_t)n_slots, counts.data(), dbuf.ptr, xybuf.ptr, models.data()) != OCHIP_OK)
             return fail("ochip_upload_batch");
@@ -331,6 +353,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
 #pragma omp parallel for schedule(dynamic, 1) num_threads(omp_threads)
     for (size_t p = 0; p < n_pairs; p++)
     {
+        const double tc0 = prof ? link_thread_cpu() : 0;
         const auto &idx1 = subset[jobs[p].slot_1], &idx2 = subset[jobs[p].slot_2];
         const ochip_match *r = raw.ptr + out_off[p];
         // match_features_subset tail (match_features.cpp:94-101) on compact records: the permutation std::sort
@@ -359,14 +382,30 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
             rmatches[p][i] = ochip_ransac_match{sm[i].k1, sm[i].k2, sm[i].count, 0};
             has_quality = has_quality || sm[i].count != 0;
         }
+        const double tc1 = prof ? link_thread_cpu() : 0;
         // PROSAC order (ransac.cpp:83-90): iota sorted by quality ascending; empty if no quality is non-zero
         if (has_quality)
         {
-            std::vector<size_t> order(M);
+            // std::sort of iota(M) by quality: the records carry the key next to the index (the permutation depends on the
+            // comparator's answers only, which are those of the reference's indirect comparison)
+            struct by_quality
+            {
+                uint32_t index;
+                uint16_t count;
+            };
+            std::vector<by_quality> order(M);
             for (size_t i = 0; i < M; i++)
-                order[i] = i;
-            std::sort(order.begin(), order.end(), [&sm](size_t a, size_t b) { return sm[a].count < sm[b].count; });
-            sorted_idx[p].assign(order.begin(), order.end());
+                order[i] = by_quality{(uint32_t)i, sm[i].count};
+            std::sort(order.begin(), order.end(), [](const by_quality &a, const by_quality &b) { return a.count < b.count; });
+            sorted_idx[p].resize(M);
+            for (size_t i = 0; i < M; i++)
+                sorted_idx[p][i] = order[i].index;
+        }
+        if (prof)
+        {
+            const double tc2 = link_thread_cpu();
+            link_cpu_add(1, tc1 - tc0);
+            link_cpu_add(2, tc2 - tc1);
         }
     }
     std::vector<ochip_ransac_job> rjobs(n_pairs);
@@ -423,6 +462,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
 #pragma omp parallel for schedule(dynamic, 1) num_threads(omp_threads)
     for (size_t p = 0; p < n_pairs; p++)
     {
+        const double tc0 = prof ? link_thread_cpu() : 0;
         const image &img = graph.getNode(jobs[p].node_id)->payload;
         const image &near_image = graph.getNode(jobs[p].match_node_id)->payload;
         const size_t M = matches[p].size();
@@ -461,6 +501,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
             dbg[p].improvements = results[p].improvements;
             dbg[p].can_decompose = can_decompose;
         }
+        const double tc1 = prof ? link_thread_cpu() : 0;
         if (can_decompose && num_coarse_inliers > h.MINIMUM_POINTS * 1.5)
         {
             relations.matches = std::move(matches[p]);
@@ -468,6 +509,12 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
                             relations.inlier_matches);
         }
         payloads[p] = edge_payload{jobs[p].loop_index, jobs[p].node_id, jobs[p].match_node_id, std::move(relations)};
+        if (prof)
+        {
+            const double tc2 = link_thread_cpu();
+            link_cpu_add(4, tc1 - tc0);
+            link_cpu_add(5, tc2 - tc1);
+        }
     }
     {
         std::lock_guard<std::mutex> lock(_measurement_mutex);
@@ -496,6 +543,8 @@ std::vector<size_t> LinkStage::finalize(MeasurementGraph &graph)
         node_ids.push_back(link.node_id);
     _links.clear();
     timers.link_finalize += since(t0);
+    if (std::getenv("OCHIP_LINK_VERBOSE"))
+        link_cpu_report();
     return node_ids;
 }
 

@@ -63,6 +63,11 @@ void assembleInliers(const std::vector<feature_match> &matches, const std::vecto
     inlier_list.reserve(std::count(inliers.begin(), inliers.end(), true));
     for (size_t i = 0; i < matches.size(); i++)
     {
+        if (i + 8 < matches.size()) // the feature records are 88 bytes apart in strength order: random lines of two big arrays
+        {
+            __builtin_prefetch(&source_features[matches[i + 8].feature_index_1]);
+            __builtin_prefetch(&dest_features[matches[i + 8].feature_index_2]);
+        }
         if (!inliers[i])
             continue;
         feature_match_denormalized fmd;
