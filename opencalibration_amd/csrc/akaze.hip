@@ -1096,6 +1096,40 @@ __device__ __forceinline__ void sincos_poly(float a, float *s, float *c)
         *s = -cs, *c = sn;
 }
 
+// The candidates that survived the suppression, in list (tile) order: the descriptor kernel runs over these only, so that
+// the four wavefronts of one of its workgroups are four live spatial neighbours.  One workgroup per image, ballot prefix.
+__global__ __launch_bounds__(256) void live_list_kernel(const unsigned char *__restrict__ dead, const unsigned int *__restrict__ n_cands,
+                                                        unsigned int max_cands, unsigned int *__restrict__ live,
+                                                        unsigned int *__restrict__ n_live)
+{
+    __shared__ unsigned int wsum[4], base;
+    const unsigned int b = blockIdx.x, n = min(n_cands[b], max_cands);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        base = 0;
+    __syncthreads();
+    for (unsigned int start = 0; start < n; start += 256)
+    {
+        const unsigned int k = start + threadIdx.x;
+        const bool v = k < n && dead[(size_t)b * max_cands + k] == 0;
+        const unsigned long long mask = __ballot(v);
+        if (lane == 0)
+            wsum[wv] = (unsigned int)__popcll(mask);
+        __syncthreads();
+        unsigned int pos = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+        for (int j = 0; j < wv; j++)
+            pos += wsum[j];
+        if (v)
+            live[(size_t)b * max_cands + pos] = k;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        n_live[b] = base;
+}
+
 typedef float pkf2 __attribute__((ext_vector_type(2))); // two fp32 lanes of one packed VALU instruction
 
 struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cells numbered 0..3 | 4..12 | 13..28
@@ -1108,8 +1142,8 @@ struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cell
 
 // One 64-thread workgroup per surviving candidate: sub-pixel fit, dominant orientation, 486-bit M-LDB.
 // Sums run in the restatement's sequential order (one lane per window / per grid cell) so bits agree.
-__global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
-                                                      unsigned int max_cands, const unsigned char *__restrict__ dead,
+__global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
+                                                      unsigned int max_cands, const unsigned int *__restrict__ live,
                                                       const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
                                                       const float *__restrict__ Ldet,
                                                       size_t img_stride, levels_dev L, float derivative_factor,
@@ -1119,21 +1153,33 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
                                                       unsigned char *__restrict__ valid_out, int remap,
                                                       unsigned long long *__restrict__ vmask, size_t mask_stride)
 {
-    __shared__ float4 osmp[109]; // orientation samples: weighted dx, dy, their angle (one 16-byte LDS read each)
-    __shared__ float vals[29][3];
-    __shared__ float4 smp[441];  // the 21 x 21 descriptor sample lattice: intensity, rotated dx, rotated dy, inside flag
-    const int lane = threadIdx.x;
+    // four wavefronts = four CONSECUTIVE candidates per workgroup: list neighbours are spatial neighbours, their patches
+    // overlap, and a workgroup's waves share the CU's L1 - the descriptor is bound by the 128-byte lines its gathers pull
+    // from the L2.  The waves do not talk to each other: every wave has its own LDS arrays and only wave-level barriers.
+    __shared__ float4 osmp_all[4][109]; // orientation samples: weighted dx, dy, their angle (one 16-byte LDS read each)
+    __shared__ float vals_all[4][29][3];
+    __shared__ float4 smp_all[4][441];  // the 21 x 21 descriptor sample lattice: intensity, rotated dx, rotated dy, inside flag
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float4(&osmp)[109] = osmp_all[wv];
+    float(&vals)[29][3] = vals_all[wv];
+    float4(&smp)[441] = smp_all[wv];
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // LDS writes of the wave before LDS reads after
+        __builtin_amdgcn_wave_barrier();
+    };
     const unsigned int b = blockIdx.z;
-    const unsigned int n = min(n_cands[b], max_cands);
-    unsigned int k;
-    if (!xcd_contiguous(blockIdx.x, n, &k, remap))
+    const unsigned int n = n_live[b];
+    unsigned int kb;
+    if (!xcd_contiguous(blockIdx.x, (n + 3) / 4, &kb, remap))
         return;
-    const size_t slot = (size_t)b * max_cands + k;
+    const unsigned int kl = kb * 4 + wv;
+    if (kl >= n)
+        return;
+    const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
     // A keypoint is a chain of dependent phases; what bounds this kernel is the number of memory round trips on
     // that chain times the waves a CU can hold.  Everything whose address is known up front is therefore requested
     // here, together: the candidate record, the per-lane table entries of the orientation samples and of the
     // descriptor bits (the compiler keeps them in flight across the early exits).
-    const unsigned char is_dead = dead[slot];
     const cand_t c = cands[slot];
     const unsigned int oq0 = tab->ori_q[lane], oq1 = tab->ori_q[lane + 64];
     const float og0 = tab->ori_g[lane], og1 = tab->ori_g[lane + 64];
@@ -1141,12 +1187,6 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
 #pragma unroll
     for (int wd = 0; wd < 8; wd++)
         tbits[wd] = tab->bits[wd * 64 + lane];
-    if (is_dead)
-    {
-        if (lane == 0)
-            valid_out[slot] = 0;
-        return;
-    }
     const level_info l = L.l[c.level];
     const int w = l.w, h = l.h;
     const float *D = Ldet + (size_t)b * img_stride + l.off;
@@ -1204,7 +1244,7 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
             osmp[lane + 64] = make_float4(rx1, ry1, (a1 > 0.0f && a1 < TWO_PI) ? a1 : QNAN, 0.0f);
         }
     }
-    __syncthreads();
+    wave_sync();
     const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
     // 42 sliding windows of pi/3, one per lane; the sums run over the samples in their order.  A sample outside the
     // window adds +0, which leaves a sum that starts at +0 unchanged bit for bit.
@@ -1281,7 +1321,7 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
             }
         }
     }
-    __syncthreads();
+    wave_sync();
     if (lane < 29)
     {
         int lvl, cell;
@@ -1341,7 +1381,7 @@ __global__ __launch_bounds__(64) void describe_kernel(const cand_t *__restrict__
         vals[lane][1] = ddx / inv;
         vals[lane][2] = ddy / inv;
     }
-    __syncthreads();
+    wave_sync();
     for (int wd = 0; wd < 8; wd++)
     {
         const int bit = wd * 64 + lane;
@@ -1820,7 +1860,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     float *d_kpc = nullptr;
     unsigned int *d_counts = nullptr, *d_tile_counts = nullptr, *d_tile_base = nullptr, *d_tile_seq = nullptr;
     unsigned long long *d_mask = nullptr, *d_vmask = nullptr;
-    unsigned int *d_wbase = nullptr;
+    unsigned int *d_wbase = nullptr, *d_live = nullptr, *d_nlive = nullptr;
     pair_tab *d_tab = nullptr;
     const size_t src_px = (size_t)width * height;
     // 1-D tile grids padded to a multiple of 8 workgroups (xcd_tile)
@@ -1858,6 +1898,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     AK(up<unsigned long long>(ctx, allocs, &d_mask, nullptr, (size_t)B * mask_stride));
     AK(up<unsigned long long>(ctx, allocs, &d_vmask, nullptr, (size_t)B * mask_stride));
     AK(up<unsigned int>(ctx, allocs, &d_wbase, nullptr, (size_t)B * mask_stride));
+    AK(up<unsigned int>(ctx, allocs, &d_live, nullptr, (size_t)B * max_cands));
+    AK(up<unsigned int>(ctx, allocs, &d_nlive, nullptr, B));
     {
         // processing order of the detection tiles: level by level, Morton order inside a level
         std::vector<std::pair<uint64_t, unsigned int>> keyed;
@@ -2171,8 +2213,12 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 255) / 256, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
                            (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride,
                            (const unsigned long long *)d_mask, mask_stride, LV, dfactor, d_dead);
-        hipLaunchKernelGGL(describe_kernel, dim3(2048 * ((max_n + 2047) / 2048), 1, B), dim3(64), 0, st, (const cand_t *)d_cands,
-                           (const unsigned int *)d_ncand, max_cands, (const unsigned char *)d_dead, (const float *)d_Lt,
+        // the survivors in list order, then the descriptor over those only (slots it never visits stay invalid)
+        hipLaunchKernelGGL(live_list_kernel, dim3(B), dim3(256), 0, st, (const unsigned char *)d_dead, (const unsigned int *)d_ncand,
+                           max_cands, d_live, d_nlive);
+        OCHIP_HIP(ctx, hipMemsetAsync(d_valid, 0, (size_t)B * max_cands, st));
+        hipLaunchKernelGGL(describe_kernel, dim3(512 * (((max_n + 3) / 4 + 511) / 512), 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
+                           (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live, (const float *)d_Lt,
                            (const float2 *)d_Lxy, (const float *)d_Ldet, img_stride, LV, dfactor,
                            (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap, d_vmask, mask_stride);
     }
