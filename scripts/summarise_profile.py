@@ -61,7 +61,8 @@ elif r:
     cal["write_true_over_reported"] = n_images * dst_px * 4 / (r["sum_KB"] * 1024.0)
 extract = ["gray4_kernel", "gray_kernel", "resize_area_kernel", "resize_area_lds_kernel", "to_float_kernel", "blur_fused_kernel",
            "hmax_reduce_kernel", "hist_kernel", "kcontrast_kernel", "halfsample_kernel", "copy_plane_kernel", "nld_fused_kernel",
-           "det_maxima_kernel", "scan_tiles_kernel", "collect_tiles_kernel", "suppress_kernel", "describe_kernel", "rank_scan_kernel",
+           "det_maxima_kernel", "scan_tiles_kernel", "collect_tiles_kernel", "suppress_kernel", "live_list_kernel", "describe_kernel",
+           "rank_scan_kernel",
            "compact_ordered_kernel"]
 
 
