@@ -214,6 +214,10 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
     for (void *b : ctx->scratch_dev)
         if (b)
             (void)hipFree(b);
+    if (ctx->sym_jobs_dev)
+        (void)hipFree(ctx->sym_jobs_dev);
+    if (ctx->sym_part_dev)
+        (void)hipFree(ctx->sym_part_dev);
     for (auto &b : ctx->dev_pool)
         (void)hipFree(b.first);
     for (auto &b : ctx->pinned_pool)

@@ -59,6 +59,8 @@ struct ochip_ctx
     ochip_match *match_out_dev = nullptr;
     size_t match_out_cap = 0;
     uint64_t match_out_total = 0;
+    void *sym_jobs_dev = nullptr, *sym_part_dev = nullptr; // symmetric pairs of a match launch: job table, column partials
+    size_t sym_jobs_cap = 0, sym_part_cap = 0;
 
     // generic scratch for the RANSAC / relax kernels (grown on demand)
     void *scratch_dev[8] = {nullptr};

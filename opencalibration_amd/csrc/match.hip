@@ -17,6 +17,10 @@
 // second' = median(best, second, key).
 #include "ctx.hpp"
 
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
+
 namespace
 {
 
@@ -124,6 +128,167 @@ __global__ __launch_bounds__(BLOCK) void hamming_2nn_kernel(const uint32_t *__re
     }
 }
 
+// ---- both directions of an image pair from ONE pass over its distance matrix ---------------------------------------
+// The link stage asks for (A -> B) and, nearly always, (B -> A): the same n_A x n_B Hamming distances, reduced along
+// rows for one direction and along columns for the other.  The kernel above would compute the matrix twice.  Here a
+// wavefront owns 64 queries of A as before (row top-2 in registers) and walks B in tiles of 64 references; the 64 x 64
+// counts of a tile also go to LDS (two 16-bit counts per word, rows padded to 65 words: conflict-free both ways), the
+// wave then reads them transposed - lane j takes reference j's column - and keeps that column's top-2 over its 64
+// queries with the same key arithmetic (key = count << 20 | query index, so the lowest query wins ties, exactly what
+// the scan of (B -> A) over A's descriptors does).  Every wave writes one partial (best, second) per reference and tile
+// - the waves never wait for each other -, and sym_merge_kernel folds the n_A / 64 partials of every reference into
+// the (B -> A) records.  Cost per tile and wave: 64 x 35 VALU for the counts as before, plus ~320 instructions for
+// the transposed pass: 15 % on top instead of 100 %.  A slot without a distance (query beyond n_A, reference beyond
+// n_B) holds 0xFFFF, which the key arithmetic turns into a count of 0xFFF - larger than any real one.
+struct sym_job
+{
+    uint32_t a, b;           // images
+    uint64_t off_ab, off_ba; // output offsets of (a -> b) and (b -> a)
+    uint64_t part_off;       // first partial of this job: [tile of 64 queries of a][reference of b]
+};
+
+__device__ __forceinline__ void top2_merge(uint32_t &b, uint32_t &s, uint32_t ob, uint32_t os)
+{
+    const uint32_t lo = b < ob ? b : ob, hi = b < ob ? ob : b, ms = s < os ? s : os;
+    b = lo;
+    s = hi < ms ? hi : ms;
+}
+
+__global__ __launch_bounds__(BLOCK) void hamming_2nn_sym_kernel(const uint32_t *__restrict__ desc, const uint64_t *__restrict__ img_off,
+                                                                const uint32_t *__restrict__ img_n, const sym_job *__restrict__ jobs,
+                                                                ochip_match *__restrict__ out, uint2 *__restrict__ part,
+                                                                uint32_t chunks_per_pair)
+{
+    __shared__ uint32_t T[4][32 * 65]; // per wave: counts of a 64 (references) x 64 (queries) tile, references 2m and 2m + 1 share a word
+    const uint32_t pair = blockIdx.x / chunks_per_pair;
+    const uint32_t chunk = blockIdx.x - pair * chunks_per_pair;
+    const sym_job jb = jobs[pair];
+    const uint32_t nA = img_n[jb.a], nB = img_n[jb.b];
+    const uint32_t q0 = chunk * BLOCK;
+    if (q0 >= nA) // uniform for the workgroup
+        return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (q0 + wv * 64 >= nA) // this wave has no query (its row tile does not exist); the waves do not depend on each other
+        return;
+    const uint32_t *__restrict__ Q = desc + img_off[jb.a] * 16;
+    const uint32_t *__restrict__ R = desc + img_off[jb.b] * 16;
+    const uint32_t qi = q0 + threadIdx.x;
+    const bool q_valid = qi < nA;
+    uint32_t q[16];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(Q + (size_t)(q_valid ? qi : nA - 1) * 16);
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+        {
+            const uint4 t = src[v];
+            q[4 * v + 0] = t.x;
+            q[4 * v + 1] = t.y;
+            q[4 * v + 2] = t.z;
+            q[4 * v + 3] = t.w;
+        }
+    }
+    uint32_t best = 0xFFFFFFFFu, second = 0xFFFFFFFFu;
+    auto load_row = [&](uint32_t (&rw)[16], uint32_t k) {
+        const uint32_t kk = k < nB ? k : nB - 1;
+        const uint32_t *__restrict__ r = R + (size_t)kk * 16;
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            rw[w] = r[w];
+    };
+    auto count_row = [&](const uint32_t (&rw)[16]) {
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++)
+            cnt += __builtin_popcount(q[w] ^ rw[w]);
+        return cnt;
+    };
+    uint32_t *Tw = T[wv];
+    const uint32_t n_tiles = (nB + 63) / 64;
+    for (uint32_t jt = 0; jt < n_tiles; jt++)
+    {
+        const uint32_t k0 = jt * 64;
+        uint32_t ra[16], rb[16];
+        load_row(ra, k0);
+#pragma unroll 4
+        for (uint32_t j = 0; j < 64; j += 2)
+        {
+            load_row(rb, k0 + j + 1);
+            const uint32_t c0 = count_row(ra);
+            load_row(ra, k0 + j + 2);
+            const uint32_t c1 = count_row(rb);
+            const uint32_t ka = k0 + j, kb = ka + 1;
+            if (ka < nB) // uniform
+            {
+                const uint32_t key = (c0 << KEY_SHIFT) | ka;
+                second = med3_u32(best, second, key);
+                best = best < key ? best : key;
+            }
+            if (kb < nB)
+            {
+                const uint32_t key = (c1 << KEY_SHIFT) | kb;
+                second = med3_u32(best, second, key);
+                best = best < key ? best : key;
+            }
+            // 0xFFFF: no distance here (query beyond n_A or reference beyond n_B)
+            const uint32_t s0 = (q_valid && ka < nB) ? c0 : 0xFFFFu, s1 = (q_valid && kb < nB) ? c1 : 0xFFFFu;
+            Tw[(j >> 1) * 65 + lane] = s0 | (s1 << 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // transposed pass: lane j = reference k0 + j, over this wave's 64 queries in ascending order
+        uint32_t cb = 0xFFFFFFFFu, cs = 0xFFFFFFFFu;
+        {
+            const uint32_t *col = Tw + (lane >> 1) * 65;
+            const uint32_t sh = (lane & 1) * 16;
+            const uint32_t qbase = q0 + wv * 64;
+#pragma unroll 8
+            for (uint32_t i = 0; i < 64; i++)
+            {
+                const uint32_t c = (col[i] >> sh) & 0xFFFFu;
+                const uint32_t key = (c << KEY_SHIFT) | (qbase + i); // 0xFFFF << 20 keeps 0xFFF: "no distance" sorts last
+                cs = med3_u32(cb, cs, key);
+                cb = cb < key ? cb : key;
+            }
+        }
+        const uint32_t ref = k0 + lane;
+        if (ref < nB)
+            part[jb.part_off + (size_t)(chunk * 4 + wv) * nB + ref] = make_uint2(cb, cs);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the tile's LDS is rewritten by the next round
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (q_valid)
+    {
+        ochip_match m;
+        m.best_k = best & KEY_MASK;
+        m.best_count = (uint16_t)(best >> KEY_SHIFT);
+        m.second_count = second == 0xFFFFFFFFu ? (uint16_t)OCHIP_NO_SECOND : (uint16_t)(second >> KEY_SHIFT);
+        out[jb.off_ab + qi] = m;
+    }
+}
+
+// (b -> a) records of the symmetric jobs: per reference of b the top-2 over the partials of a's query chunks
+__global__ __launch_bounds__(BLOCK) void sym_merge_kernel(const sym_job *__restrict__ jobs, const uint32_t *__restrict__ img_n,
+                                                          const uint2 *__restrict__ part, ochip_match *__restrict__ out)
+{
+    const sym_job jb = jobs[blockIdx.x];
+    const uint32_t nA = img_n[jb.a], nB = img_n[jb.b];
+    const uint32_t r = blockIdx.y * BLOCK + threadIdx.x;
+    if (r >= nB)
+        return;
+    uint32_t b = 0xFFFFFFFFu, s = 0xFFFFFFFFu;
+    const uint32_t tiles = (nA + 63) / 64;
+    for (uint32_t c = 0; c < tiles; c++)
+    {
+        const uint2 p = part[jb.part_off + (size_t)c * nB + r];
+        top2_merge(b, s, p.x, p.y);
+    }
+    ochip_match m;
+    m.best_k = b & KEY_MASK;
+    m.best_count = (uint16_t)(b >> KEY_SHIFT);
+    m.second_count = (s >> KEY_SHIFT) == 0xFFFu ? (uint16_t)OCHIP_NO_SECOND : (uint16_t)(s >> KEY_SHIFT); // only one query in a
+    out[jb.off_ba + r] = m;
+}
+
 } // namespace
 
 extern "C"
@@ -158,6 +323,48 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
         max_n1 = ctx->img_n[pr.image_1] > max_n1 ? ctx->img_n[pr.image_1] : max_n1;
     }
 
+    // ---- pairs whose reverse is in the batch too are matched in both directions from one pass over their distances
+    static const bool use_sym = !(getenv("OCHIP_MATCH_SYM") && getenv("OCHIP_MATCH_SYM")[0] == '0'); // A/B knob
+    std::vector<sym_job> sym;
+    std::vector<ochip_pair> single_pairs;
+    std::vector<uint64_t> single_off;
+    uint64_t part_total = 0;
+    uint32_t sym_max_na = 0, sym_max_nb = 0;
+    {
+        std::unordered_map<uint64_t, uint32_t> first; // (image_1, image_2) -> first pair with these images
+        if (use_sym)
+            for (uint32_t p = 0; p < n_pairs; p++)
+                first.emplace(((uint64_t)pairs[p].image_1 << 32) | pairs[p].image_2, p);
+        std::vector<char> claimed(n_pairs, 0);
+        for (uint32_t p = 0; p < n_pairs; p++)
+        {
+            if (claimed[p])
+                continue;
+            const uint32_t a = pairs[p].image_1, b = pairs[p].image_2;
+            const uint32_t na = ctx->img_n[a], nb = ctx->img_n[b];
+            if (use_sym && a != b && na > 0 && nb > 0)
+            {
+                auto it = first.find(((uint64_t)b << 32) | a);
+                if (it != first.end() && it->second != p && !claimed[it->second])
+                {
+                    claimed[p] = claimed[it->second] = 1;
+                    sym.push_back(sym_job{a, b, out_offset[p], out_offset[it->second], part_total});
+                    part_total += (uint64_t)((na + 63) / 64) * nb;
+                    sym_max_na = std::max(sym_max_na, na);
+                    sym_max_nb = std::max(sym_max_nb, nb);
+                    continue;
+                }
+            }
+            claimed[p] = 1;
+            single_pairs.push_back(pairs[p]);
+            single_off.push_back(out_offset[p]);
+        }
+    }
+    const uint32_t n_single = (uint32_t)single_pairs.size(), n_sym = (uint32_t)sym.size();
+    uint32_t max_n1_single = 0;
+    for (const ochip_pair &pr : single_pairs)
+        max_n1_single = std::max(max_n1_single, ctx->img_n[pr.image_1]);
+
     if (ctx->img_tables_dirty)
     {
         OCHIP_HIP(ctx, hipMemcpyAsync(ctx->img_off_dev, ctx->img_off.data(), (size_t)ctx->n_images * 8,
@@ -166,7 +373,7 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
                                       hipMemcpyHostToDevice, ctx->stream));
         ctx->img_tables_dirty = false;
     }
-    if (n_pairs > ctx->pairs_cap)
+    if (n_single > ctx->pairs_cap)
     {
         if (ctx->pairs_dev)
             OCHIP_HIP(ctx, hipFree(ctx->pairs_dev));
@@ -175,10 +382,10 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
         ctx->pairs_dev = nullptr;
         ctx->out_off_dev = nullptr;
         ctx->pairs_cap = 0;
-        if (hipMalloc((void **)&ctx->pairs_dev, (size_t)n_pairs * sizeof(ochip_pair)) != hipSuccess ||
-            hipMalloc((void **)&ctx->out_off_dev, (size_t)n_pairs * 8) != hipSuccess)
+        if (hipMalloc((void **)&ctx->pairs_dev, (size_t)n_single * sizeof(ochip_pair)) != hipSuccess ||
+            hipMalloc((void **)&ctx->out_off_dev, (size_t)n_single * 8) != hipSuccess)
             return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc for the pair table failed");
-        ctx->pairs_cap = n_pairs;
+        ctx->pairs_cap = n_single;
     }
     {
         void *p = ctx->match_out_dev;
@@ -188,12 +395,24 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
         ctx->match_out_cap = cap / sizeof(ochip_match);
         if (rc)
             return rc;
+        if (n_sym)
+        {
+            rc = ochip_ensure(ctx, &ctx->sym_jobs_dev, &ctx->sym_jobs_cap, (size_t)n_sym * sizeof(sym_job));
+            if (rc == OCHIP_OK)
+                rc = ochip_ensure(ctx, &ctx->sym_part_dev, &ctx->sym_part_cap, (size_t)part_total * sizeof(uint2));
+            if (rc)
+                return rc;
+        }
     }
-    OCHIP_HIP(ctx, hipMemcpyAsync(ctx->pairs_dev, pairs, (size_t)n_pairs * sizeof(ochip_pair), hipMemcpyHostToDevice,
-                                  ctx->stream));
-    OCHIP_HIP(ctx, hipMemcpyAsync(ctx->out_off_dev, out_offset, (size_t)n_pairs * 8, hipMemcpyHostToDevice,
-                                  ctx->stream));
-    // the pageable sources above must be consumed before we return to the caller
+    if (n_single)
+    {
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->pairs_dev, single_pairs.data(), (size_t)n_single * sizeof(ochip_pair), hipMemcpyHostToDevice,
+                                      ctx->stream));
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->out_off_dev, single_off.data(), (size_t)n_single * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (n_sym)
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->sym_jobs_dev, sym.data(), (size_t)n_sym * sizeof(sym_job), hipMemcpyHostToDevice, ctx->stream));
+    // the pageable sources above must be consumed before they go out of scope
     OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     if (max_n1 == 0)
         return OCHIP_OK;
@@ -203,10 +422,12 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
         const int v = e ? atoi(e) : 1;
         return (v == 1 || v == 2 || v == 4) ? v : 1;
     }();
-    const uint32_t chunks = (max_n1 + BLOCK * qpt - 1) / (BLOCK * qpt);
-    const uint64_t blocks = (uint64_t)chunks * n_pairs;
-    if (blocks > 0x7FFFFFFFull)
-        return ochip_fail(ctx, OCHIP_EINVAL, "batch too large: %llu workgroups", (unsigned long long)blocks);
+    const uint32_t chunks = (max_n1_single + BLOCK * qpt - 1) / (BLOCK * qpt);
+    const uint64_t blocks = (uint64_t)chunks * n_single;
+    const uint32_t sym_chunks = (sym_max_na + BLOCK - 1) / BLOCK;
+    const uint64_t sym_blocks = (uint64_t)sym_chunks * n_sym;
+    if (blocks > 0x7FFFFFFFull || sym_blocks > 0x7FFFFFFFull)
+        return ochip_fail(ctx, OCHIP_EINVAL, "batch too large: %llu workgroups", (unsigned long long)(blocks + sym_blocks));
     hipEvent_t e0, e1;
     ochip_prof_begin(ctx, OCHIP_K_MATCH, &e0, &e1);
     auto launch = [&](auto kernel) {
@@ -214,12 +435,23 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
                            ctx->img_off_dev, ctx->img_n_dev, ctx->pairs_dev, ctx->out_off_dev, ctx->match_out_dev,
                            chunks);
     };
-    if (qpt == 1)
-        launch(hamming_2nn_kernel<1>);
-    else if (qpt == 4)
-        launch(hamming_2nn_kernel<4>);
-    else
-        launch(hamming_2nn_kernel<2>);
+    if (blocks)
+    {
+        if (qpt == 1)
+            launch(hamming_2nn_kernel<1>);
+        else if (qpt == 4)
+            launch(hamming_2nn_kernel<4>);
+        else
+            launch(hamming_2nn_kernel<2>);
+    }
+    if (sym_blocks)
+    {
+        hipLaunchKernelGGL(hamming_2nn_sym_kernel, dim3((uint32_t)sym_blocks), dim3(BLOCK), 0, ctx->stream, ctx->desc_dev,
+                           ctx->img_off_dev, ctx->img_n_dev, (const sym_job *)ctx->sym_jobs_dev, ctx->match_out_dev,
+                           (uint2 *)ctx->sym_part_dev, sym_chunks);
+        hipLaunchKernelGGL(sym_merge_kernel, dim3(n_sym, (sym_max_nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream,
+                           (const sym_job *)ctx->sym_jobs_dev, ctx->img_n_dev, (const uint2 *)ctx->sym_part_dev, ctx->match_out_dev);
+    }
     ochip_prof_end(ctx, OCHIP_K_MATCH, e0, e1);
     OCHIP_HIP(ctx, hipGetLastError());
     return OCHIP_OK;

@@ -57,6 +57,30 @@ def test_raw_top2_against_numpy(ctx, n1, n2):
         assert np.array_equal(got["second_count"], sc)
 
 
+def test_mixed_batch_of_paired_and_unpaired_directions(ctx):
+    """Pairs whose reverse is in the batch take the both-directions-from-one-pass kernel, the others the one-direction
+    kernel; a duplicate of a pair is matched on its own.  Every record must be the brute-force answer either way."""
+    rng = np.random.default_rng(77)
+    base = synth.descriptors_for_ids(np.arange(700))
+    sizes = [300, 517, 64, 129]
+    descs = []
+    for n in sizes:
+        d = base[rng.permutation(700)[:n]].copy()
+        bits = rng.integers(0, 486, (n, 25))
+        for j in range(25):
+            d[np.arange(n), bits[:, j] >> 6] ^= np.uint64(1) << (bits[:, j] & 63).astype(np.uint64)
+        descs.append(d)
+    _upload(ctx, descs)
+    plist = [(0, 1), (1, 0), (0, 2), (3, 1), (1, 3), (2, 3), (0, 1), (2, 2)]
+    pairs = np.array(plist, capi.PAIR_DTYPE)
+    off = np.cumsum([0] + [sizes[a] for a, _ in plist]).astype(np.uint64)
+    out = ctx.match_batch(pairs, off[:-1].copy(), int(off[-1]))
+    for p, (a, b) in enumerate(plist):
+        bk, bc, sc = _expect(descs[a], descs[b])
+        got = out[int(off[p]):int(off[p + 1])]
+        assert np.array_equal(got["best_k"], bk) and np.array_equal(got["best_count"], bc) and np.array_equal(got["second_count"], sc), (a, b)
+
+
 def test_empty_reference_set_and_empty_batch(ctx):
     d1 = synth.descriptors_for_ids(np.arange(10))
     _upload(ctx, [d1, np.zeros((0, 8), np.uint64)])
