@@ -35,6 +35,15 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
+// popcount(x) + acc in ONE instruction (the accumulating form of v_bcnt_u32_b32).  Left to itself the compiler counts
+// every word separately and sums the sixteen counts with a tree of v_add3_u32: 7-8 more VALU instructions per compare.
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 template <int QPT>
 __global__ __launch_bounds__(BLOCK) void hamming_2nn_kernel(const uint32_t *__restrict__ desc,
                                                             const uint64_t *__restrict__ img_off,
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(BLOCK) void hamming_2nn_kernel(const uint32_t *__re
             uint32_t cnt = 0;
 #pragma unroll
             for (int w = 0; w < 16; w++)
-                cnt += __builtin_popcount(q[j][w] ^ rw[w]);
+                cnt = bcnt_acc(q[j][w] ^ rw[w], cnt);
             const uint32_t key = (cnt << KEY_SHIFT) | k;
             second[j] = med3_u32(best[j], second[j], key);
             best[j] = best[j] < key ? best[j] : key;
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(BLOCK) void hamming_2nn_sym_kernel(const uint32_t *
         uint32_t cnt = 0;
 #pragma unroll
         for (int w = 0; w < 16; w++)
-            cnt += __builtin_popcount(q[w] ^ rw[w]);
+            cnt = bcnt_acc(q[w] ^ rw[w], cnt);
         return cnt;
     };
     uint32_t *Tw = T[wv];
