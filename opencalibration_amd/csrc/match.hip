@@ -168,7 +168,9 @@ __global__ __launch_bounds__(BLOCK) void hamming_2nn_sym_kernel(const uint32_t *
                                                                 ochip_match *__restrict__ out, uint2 *__restrict__ part,
                                                                 uint32_t chunks_per_pair)
 {
-    __shared__ uint32_t T[4][32 * 65]; // per wave: counts of a 64 (references) x 64 (queries) tile, references 2m and 2m + 1 share a word
+    // per wave: counts of a 32 (references) x 64 (queries) tile, references 2m and 2m + 1 share a word; 4 KB per wave keeps
+    // the occupancy the one-direction kernel has (the scalar reference loads need the other waves to hide behind)
+    __shared__ uint32_t T[4][16 * 65];
     const uint32_t pair = blockIdx.x / chunks_per_pair;
     const uint32_t chunk = blockIdx.x - pair * chunks_per_pair;
     const sym_job jb = jobs[pair];
@@ -212,14 +214,14 @@ __global__ __launch_bounds__(BLOCK) void hamming_2nn_sym_kernel(const uint32_t *
         return cnt;
     };
     uint32_t *Tw = T[wv];
-    const uint32_t n_tiles = (nB + 63) / 64;
+    const uint32_t n_tiles = (nB + 31) / 32;
     for (uint32_t jt = 0; jt < n_tiles; jt++)
     {
-        const uint32_t k0 = jt * 64;
+        const uint32_t k0 = jt * 32;
         uint32_t ra[16], rb[16];
         load_row(ra, k0);
 #pragma unroll 4
-        for (uint32_t j = 0; j < 64; j += 2)
+        for (uint32_t j = 0; j < 32; j += 2)
         {
             load_row(rb, k0 + j + 1);
             const uint32_t c0 = count_row(ra);
@@ -244,24 +246,28 @@ __global__ __launch_bounds__(BLOCK) void hamming_2nn_sym_kernel(const uint32_t *
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // transposed pass: lane j = reference k0 + j, over this wave's 64 queries in ascending order
+        // transposed pass: lane (j, half) = reference k0 + j over queries half * 32 .. half * 32 + 31 of this wave, ascending;
+        // the two halves of a reference are merged across the half-waves
         uint32_t cb = 0xFFFFFFFFu, cs = 0xFFFFFFFFu;
         {
-            const uint32_t *col = Tw + (lane >> 1) * 65;
-            const uint32_t sh = (lane & 1) * 16;
-            const uint32_t qbase = q0 + wv * 64;
+            const uint32_t jj = lane & 31, half = lane >> 5;
+            const uint32_t *col = Tw + (jj >> 1) * 65 + half * 32;
+            const uint32_t sh = (jj & 1) * 16;
+            const uint32_t qbase = q0 + wv * 64 + half * 32;
 #pragma unroll 8
-            for (uint32_t i = 0; i < 64; i++)
+            for (uint32_t i = 0; i < 32; i++)
             {
                 const uint32_t c = (col[i] >> sh) & 0xFFFFu;
                 const uint32_t key = (c << KEY_SHIFT) | (qbase + i); // 0xFFFF << 20 keeps 0xFFF: "no distance" sorts last
                 cs = med3_u32(cb, cs, key);
                 cb = cb < key ? cb : key;
             }
+            const uint32_t ob = (uint32_t)__shfl_xor((int)cb, 32), os = (uint32_t)__shfl_xor((int)cs, 32);
+            top2_merge(cb, cs, ob, os);
+            const uint32_t ref = k0 + jj;
+            if (half == 0 && ref < nB)
+                part[jb.part_off + (size_t)(chunk * 4 + wv) * nB + ref] = make_uint2(cb, cs);
         }
-        const uint32_t ref = k0 + lane;
-        if (ref < nB)
-            part[jb.part_off + (size_t)(chunk * 4 + wv) * nB + ref] = make_uint2(cb, cs);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the tile's LDS is rewritten by the next round
         __builtin_amdgcn_wave_barrier();
     }
