@@ -357,7 +357,8 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
                 continue;
             const uint32_t a = pairs[p].image_1, b = pairs[p].image_2;
             const uint32_t na = ctx->img_n[a], nb = ctx->img_n[b];
-            if (use_sym && a != b && na > 0 && nb > 0)
+            // (the partials of the paired jobs of one launch are capped at 2 GB; further pairs go one direction at a time)
+            if (use_sym && a != b && na > 0 && nb > 0 && part_total * sizeof(uint2) < (2ull << 30))
             {
                 auto it = first.find(((uint64_t)b << 32) | a);
                 if (it != first.end() && it->second != p && !claimed[it->second])
