@@ -115,7 +115,8 @@ struct HuberLoss : LossFunction // ceres/loss_function.cc
 enum class Manifold
 {
     EUCLIDEAN,
-    EIGEN_QUATERNION
+    EIGEN_QUATERNION,
+    SUBSET // ceres::SubsetManifold(size, constant_parameters): the listed coordinates are held constant
 };
 
 struct ParameterBlock
@@ -124,9 +125,22 @@ struct ParameterBlock
     int size = 0;
     Manifold manifold = Manifold::EUCLIDEAN;
     bool constant = false;
+    std::vector<int> subset_constant;       // Manifold::SUBSET: constant coordinates
+    std::vector<double> lower, upper;       // empty = unbounded (SetParameterLowerBound / UpperBound)
     int tangent_size() const
     {
-        return manifold == Manifold::EIGEN_QUATERNION ? 3 : size;
+        if (manifold == Manifold::EIGEN_QUATERNION)
+            return 3;
+        if (manifold == Manifold::SUBSET)
+            return size - (int)subset_constant.size();
+        return size;
+    }
+    bool is_subset_constant(int k) const
+    {
+        for (int c : subset_constant)
+            if (c == k)
+                return true;
+        return false;
     }
 };
 
@@ -143,6 +157,9 @@ class Problem
     int AddParameterBlock(double *p, int size);
     void AddResidualBlock(CostFunction *cost, const LossFunction *loss, const std::vector<double *> &params);
     void SetManifold(double *p, Manifold m);
+    void SetSubsetManifold(double *p, const std::vector<int> &constant_parameters);
+    void SetParameterLowerBound(double *p, int index, double v);
+    void SetParameterUpperBound(double *p, int index, double v);
     void SetParameterBlockConstant(double *p);
     void SetParameterBlockVariable(double *p);
     bool IsParameterBlockConstant(double *p) const;
@@ -179,6 +196,7 @@ struct SolverOptions
     double gradient_tolerance = 1e-10;
     double parameter_tolerance = 1e-8;
     bool jacobi_scaling = true;
+    int max_num_line_search_step_size_iterations = 20; // projected line search of bounds-constrained problems
 };
 
 struct IterationSummary

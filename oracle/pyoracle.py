@@ -353,3 +353,205 @@ def scene_near_degenerate():
     corr, H = np.zeros((100, 7)), np.zeros((3, 3))
     lib().oc_scene_near_degenerate(corr, H)
     return corr, H
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# oracle/relax_full.cpp: the whole relax stage over an in-memory MeasurementGraph (all flavours, RelaxGroup, meshes)
+OPT = dict(ORIENTATION=1 << 0, POSITION=1 << 1, GROUND_PLANE=1 << 2, GROUND_MESH=1 << 3, POINTS_3D=1 << 4,
+           FOCAL_LENGTH=1 << 5, PRINCIPAL_POINT=1 << 6, LENS_DISTORTIONS_RADIAL=1 << 7, BROWN2=1 << 8, BROWN24=1 << 9,
+           BROWN246=1 << 10, LENS_DISTORTIONS_TANGENTIAL=1 << 11, MINIMAL_MESH=1 << 12)
+_RX = False
+
+
+def _rx():
+    global _RX
+    L = lib()
+    if not _RX:
+        vp, sz = C.c_void_p, C.c_size_t
+        L.ocx_graph_create.restype = vp
+        L.ocx_graph_destroy.argtypes = [vp]
+        L.ocx_graph_add_model.restype = sz
+        L.ocx_graph_add_model.argtypes = [vp, f64p, sz]
+        L.ocx_graph_get_model.argtypes = [vp, sz, f64p]
+        L.ocx_graph_set_model.argtypes = [vp, sz, f64p]
+        L.ocx_graph_add_node.restype = sz
+        L.ocx_graph_add_node.argtypes = [vp, C.c_char_p, f64p, f64p, sz, sz, f64p]
+        L.ocx_graph_add_edge.restype = sz
+        L.ocx_graph_add_edge.argtypes = [vp, sz, sz, vp, C.c_int, sz, f64p, u64p, sz, f64p, vp]
+        L.ocx_graph_set_orientation.argtypes = [vp, sz, f64p]
+        L.ocx_graph_get_orientations.argtypes = [vp, f64p]
+        L.ocx_surface_create.restype = vp
+        L.ocx_surface_destroy.argtypes = [vp]
+        for f in (L.ocx_surface_num_vertices, L.ocx_surface_num_edges, L.ocx_surface_num_cloud_points):
+            f.restype = sz
+            f.argtypes = [vp]
+        L.ocx_surface_get.argtypes = [vp, vp, vp, vp]
+        L.ocx_surface_set.argtypes = [vp, sz, f64p, sz, u64p, sz, f64p]
+        L.ocx_rebuild_mesh.argtypes = [f64p, sz, vp, C.c_int, vp]
+        L.ocx_surface_triangle_at.restype = C.c_int
+        L.ocx_surface_triangle_at.argtypes = [vp, C.c_double, C.c_double, C.c_double, u64p, u64p]
+        L.ocx_relax.restype = C.c_int
+        L.ocx_relax.argtypes = [vp, sz, u64p, f64p, sz, u64p, C.c_uint32, C.c_double, vp, vp, f64p, vp, sz, vp, sz]
+        L.ocx_relax_group.restype = sz
+        L.ocx_relax_group.argtypes = [vp, sz, u64p, u64p, sz, C.c_uint32, C.c_double, vp, vp, C.c_int, f64p, u64p, sz, u64p,
+                                      sz, vp]
+        L.ocx_convert_model.argtypes = [f64p, C.c_int, f64p]
+        L.ocx_image_to_3d_inverse.argtypes = [f64p, sz, f64p, f64p]
+        _RX = True
+    return L
+
+
+def options(*names):
+    bits = 0
+    for n in names:
+        bits |= OPT[n]
+    return bits
+
+
+class RxSurface:
+    """surface_model (mesh + point cloud) of the restatement."""
+
+    def __init__(self):
+        self.h = _rx().ocx_surface_create()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _rx().ocx_surface_destroy(self.h)
+            self.h = None
+
+    def arrays(self):
+        L = _rx()
+        nv, ne, nc = L.ocx_surface_num_vertices(self.h), L.ocx_surface_num_edges(self.h), L.ocx_surface_num_cloud_points(self.h)
+        v, e, c = np.zeros((max(nv, 1), 3)), np.zeros((max(ne, 1), 5), np.uint64), np.zeros((max(nc, 1), 3))
+        L.ocx_surface_get(self.h, v.ctypes.data, e.ctypes.data, c.ctypes.data)
+        return dict(vertices=v[:nv], edges=e[:ne], cloud=c[:nc])
+
+    def set(self, vertices, edges, cloud=None):
+        v = np.ascontiguousarray(vertices, np.float64).reshape(-1, 3)
+        e = np.ascontiguousarray(edges, np.uint64).reshape(-1, 5)
+        c = np.zeros((0, 3)) if cloud is None else np.ascontiguousarray(cloud, np.float64).reshape(-1, 3)
+        _rx().ocx_surface_set(self.h, len(v), v if len(v) else np.zeros((1, 3)), len(e), e if len(e) else np.zeros((1, 5), np.uint64),
+                              len(c), c if len(c) else np.zeros((1, 3)))
+        return self
+
+    def triangle_at(self, x, y, z_from=1e3):
+        tri, steps = np.zeros(3, np.uint64), np.zeros(1, np.uint64)
+        t = _rx().ocx_surface_triangle_at(self.h, x, y, z_from, tri, steps)
+        return t, tri, int(steps[0])
+
+
+def rebuild_mesh(cam_xyz, prev=None, minimal=False):
+    cam_xyz = np.ascontiguousarray(cam_xyz, np.float64).reshape(-1, 3)
+    s = RxSurface()
+    _rx().ocx_rebuild_mesh(cam_xyz, len(cam_xyz), prev.h if prev is not None else None, int(minimal), s.h)
+    return s
+
+
+class RxGraph:
+    """MeasurementGraph of the restatement (node / edge ids = insertion indices)."""
+
+    def __init__(self):
+        self.h = _rx().ocx_graph_create()
+        self.n_nodes = 0
+        self.n_edges = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _rx().ocx_graph_destroy(self.h)
+            self.h = None
+
+    def add_model(self, model10, model_id=42):
+        return _rx().ocx_graph_add_model(self.h, np.ascontiguousarray(model10, np.float64), model_id)
+
+    def get_model(self, idx):
+        m = np.zeros(10)
+        _rx().ocx_graph_get_model(self.h, idx, m)
+        return m
+
+    def set_model(self, idx, model10):
+        _rx().ocx_graph_set_model(self.h, idx, np.ascontiguousarray(model10, np.float64))
+
+    def add_node(self, pos, ori, model_index=0, features=None, path=None):
+        f = np.zeros((0, 2)) if features is None else np.ascontiguousarray(features, np.float64).reshape(-1, 2)
+        path = ("%08d" % self.n_nodes) if path is None else path
+        i = _rx().ocx_graph_add_node(self.h, path.encode(), np.ascontiguousarray(pos, np.float64),
+                                     np.ascontiguousarray(ori, np.float64), model_index, len(f), f if len(f) else np.zeros((1, 2)))
+        self.n_nodes += 1
+        return i
+
+    def add_edge(self, src, dst, px, fidx1, fidx2, match_index=None, H=None, dist=None, poses=None):
+        px = np.ascontiguousarray(px, np.float64).reshape(-1, 4)
+        n = len(px)
+        idx = np.zeros((max(n, 1), 3), np.uint64)
+        idx[:n, 0], idx[:n, 1] = fidx1, fidx2
+        idx[:n, 2] = np.arange(n) if match_index is None else match_index
+        Hc = None if H is None else np.ascontiguousarray(H, np.float64)
+        d = np.zeros(0) if dist is None else np.ascontiguousarray(dist, np.float64)
+        pc = None if poses is None else np.ascontiguousarray(poses, np.float64)
+        e = _rx().ocx_graph_add_edge(self.h, src, dst, Hc.ctypes.data if Hc is not None else None, int(H is not None), n,
+                                     px if n else np.zeros((1, 4)), idx, len(d), d if len(d) else np.zeros(1),
+                                     pc.ctypes.data if pc is not None else None)
+        self.n_edges += 1
+        return e
+
+    def set_orientation(self, node, q):
+        _rx().ocx_graph_set_orientation(self.h, node, np.ascontiguousarray(q, np.float64))
+
+    def orientations(self):
+        o = np.zeros((self.n_nodes, 4))
+        _rx().ocx_graph_get_orientations(self.h, o)
+        return o
+
+    def relax(self, pose_node, pose_ori, opt_edges, opts, grid_fraction=0.1, prev=None):
+        pose_node = np.ascontiguousarray(pose_node, np.uint64)
+        pose_ori = np.ascontiguousarray(pose_ori, np.float64).copy()
+        opt_edges = np.ascontiguousarray(opt_edges, np.uint64)
+        out = RxSurface()
+        summary, iters, models = np.zeros(9), np.full(64, -1, np.int32), np.zeros((8, 11))
+        nm = _rx().ocx_relax(self.h, len(pose_node), pose_node, pose_ori, len(opt_edges),
+                             opt_edges if len(opt_edges) else np.zeros(1, np.uint64), opts, grid_fraction,
+                             prev.h if prev is not None else None, out.h, summary, iters.ctypes.data, len(iters),
+                             models.ctypes.data, len(models))
+        return dict(orientation=pose_ori, surface=out, solves=int(summary[0]), iterations_total=int(summary[1]),
+                    last_iterations=int(summary[2]), initial_cost=summary[3], final_cost=summary[4],
+                    residual_blocks=int(summary[5]), parameter_blocks=int(summary[6]), track_blocks=int(summary[7]),
+                    two_ray_blocks=int(summary[8]), iterations_per_solve=[int(i) for i in iters if i >= 0],
+                    models={int(m[0]): m[1:].copy() for m in models[:nm]})
+
+    def relax_group(self, node_ids, knn10, depth, opts, grid_fraction=0.1, prev=None, run=True):
+        node_ids = np.ascontiguousarray(node_ids, np.uint64)
+        knn10 = np.ascontiguousarray(knn10, np.uint64).reshape(self.n_nodes, 10)
+        out = RxSurface()
+        summary = np.zeros(9)
+        cap = 4 * self.n_nodes + 8
+        local, edges, ne = np.zeros(cap, np.uint64), np.zeros(self.n_edges + 1, np.uint64), C.c_size_t(0)
+        n = _rx().ocx_relax_group(self.h, len(node_ids), node_ids, knn10, depth, opts, grid_fraction,
+                                  prev.h if prev is not None else None, out.h, int(run), summary, local, cap, edges,
+                                  len(edges), C.byref(ne))
+        return dict(local_nodes=local[:n].copy(), opt_edges=edges[:ne.value].copy(), surface=out, solves=int(summary[0]),
+                    iterations_total=int(summary[1]), residual_blocks=int(summary[5]))
+
+
+def convert_model(model10, to_inverse):
+    out = np.zeros(10)
+    _rx().ocx_convert_model(np.ascontiguousarray(model10, np.float64), int(to_inverse), out)
+    return out
+
+
+def image_to_3d_inverse(px, inverse_model10):
+    px = np.ascontiguousarray(px, np.float64).reshape(-1, 2)
+    out = np.zeros((len(px), 3))
+    _rx().ocx_image_to_3d_inverse(px, len(px), np.ascontiguousarray(inverse_model10, np.float64), out)
+    return out
+
+
+def knn10_bruteforce(xy):
+    """imageGPSLocations.searchKnn(position, 10) (self included) by exhaustive search, ties to the lower index."""
+    xy = np.asarray(xy, np.float64)
+    n = len(xy)
+    out = np.full((n, 10), np.iinfo(np.uint64).max, np.uint64)
+    for i in range(n):
+        d = np.sum((xy - xy[i]) ** 2, axis=1)
+        order = np.argsort(d, kind="stable")[:10]
+        out[i, :len(order)] = order
+    return out

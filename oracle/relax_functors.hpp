@@ -202,4 +202,183 @@ struct PlaneIntersectionAngleCost
     }
 };
 
+
+// relax_cost_function.hpp:51-69
+struct DifferenceCost
+{
+    explicit DifferenceCost(double weight) : _weight(weight)
+    {
+    }
+    template <typename T> bool operator()(const T *val1, const T *val2, T *residual) const
+    {
+        residual[0] = T(_weight) * (val1[0] - val2[0]);
+        return true;
+    }
+    double _weight;
+};
+
+// relax_cost_function.hpp:119-155
+struct AdjacentTriangleNormalCost
+{
+    double xyA[2], xyB[2], xyC[2], xyD[2], weight;
+    template <typename T> bool operator()(const T *zA, const T *zB, const T *zC, const T *zD, T *residuals) const
+    {
+        const V3<T> A{T(xyA[0]), T(xyA[1]), *zA}, B{T(xyB[0]), T(xyB[1]), *zB}, C{T(xyC[0]), T(xyC[1]), *zC},
+            D{T(xyD[0]), T(xyD[1]), *zD};
+        const V3<T> AB = B - A;
+        const V3<T> n1 = normalized3(cross3(AB, C - A));
+        const V3<T> n2 = normalized3(cross3(AB, D - A));
+        residuals[0] = T(weight) * angleBetweenUnitVectors<T>(n1, n2);
+        return true;
+    }
+};
+
+// relax_cost_function.hpp:157-185
+struct DistortionMonotonicityCost
+{
+    double r_max, weight;
+    template <typename T> bool operator()(const T *radial, T *residuals) const
+    {
+        for (int i = 0; i < 10; i++)
+        {
+            const T r = T(r_max * (i + 1.0) / 10);
+            const T r2 = r * r;
+            const T r4 = r2 * r2;
+            const T r6 = r4 * r2;
+            const T deriv = T(1.0) + T(3.0) * radial[0] * r2 + T(5.0) * radial[1] * r4 + T(7.0) * radial[2] * r6;
+            residuals[i] = deriv < T(0.0) ? T(weight) * (-deriv) : T(0.0);
+        }
+        return true;
+    }
+};
+
+// distort_keypoints.hpp:26-42 on a scalar type, all coefficients of type T
+template <typename T> inline void distortProjectedRayT(const T p[2], const T radial[3], const T tangential[2], T out[2])
+{
+    T r2[3];
+    r2[0] = p[0] * p[0] + p[1] * p[1];
+    for (int i = 1; i < 3; i++)
+        r2[i] = r2[i - 1] * r2[0];
+    const T radial_dot = radial[0] * r2[0] + radial[1] * r2[1] + radial[2] * r2[2];
+    const T prod = p[0] * p[1];
+    for (int i = 0; i < 2; i++)
+        out[i] = (T(1.0) + radial_dot) * p[i] + T(2.0) * prod * tangential[i] +
+                 tangential[1 - i] * (r2[0] + T(2.0) * p[i] * p[i]);
+}
+
+// InverseDifferentiableCameraModel<T> (camera_model.hpp:22-66) and image_to_3d on it (distort_keypoints.hpp:97-116):
+// pixel -> ray in closed form
+template <typename T> struct inverse_model_t
+{
+    T focal_length_pixels;
+    T principle_point[2];
+    T radial_distortion[3];
+    T tangential_distortion[2];
+};
+template <typename T> inline V3<T> image_to_3d_inverse(const T keypoint[2], const inverse_model_t<T> &m)
+{
+    const T unprojected[2] = {(keypoint[0] - m.principle_point[0]) / m.focal_length_pixels,
+                              (keypoint[1] - m.principle_point[1]) / m.focal_length_pixels};
+    T und[2];
+    distortProjectedRayT<T>(unprojected, m.radial_distortion, m.tangential_distortion, und);
+    return normalized3(V3<T>{und[0], und[1], T(1.0)});
+}
+
+// relax_cost_function.hpp:601-656 (fixed intrinsics) and :501-566 (FocalRadial: rays recomputed from the pixels
+// through the shared inverse model) for N = 2..5 rays
+template <int N> struct MultiRayCost
+{
+    double camera_loc[N][3], camera_ray[N][3], camera_pixel[N][2], plane_point[3][2];
+    double shared_tangential[2] = {0, 0}; // the part of sharedModel that is not a parameter block
+
+    template <typename T>
+    bool finish(const V3<T> dir[N], const T *z0, const T *z1, const T *z2, T *residuals) const
+    {
+        const T plane_z[3] = {*z0, *z1, *z2};
+        V3<T> corner[3];
+        for (int i = 0; i < 3; i++)
+            corner[i] = {T(plane_point[i][0]), T(plane_point[i][1]), plane_z[i]};
+        const plane_norm_offset<T> pno = cornerPlane2normOffsetPlane(corner);
+        V3<T> intersection[N];
+        bool all_valid = true;
+        T avg_dist = T(0.0);
+        for (int i = 0; i < N; i++)
+        {
+            const V3<T> off{T(camera_loc[i][0]), T(camera_loc[i][1]), T(camera_loc[i][2])};
+            all_valid &= rayPlaneIntersection(dir[i], off, pno, intersection[i]);
+            avg_dist = avg_dist + norm3(intersection[i] - off);
+        }
+        avg_dist = avg_dist / T(double(N));
+        const T huber_threshold = avg_dist * T(0.01);
+        const V3<T> centroid = robustCentroid(intersection, N, huber_threshold);
+        for (int i = 0; i < N; i++)
+        {
+            const V3<T> r = (intersection[i] - centroid) / avg_dist;
+            residuals[i * 3 + 0] = r.x;
+            residuals[i * 3 + 1] = r.y;
+            residuals[i * 3 + 2] = r.z;
+        }
+        return all_valid;
+    }
+    template <typename T>
+    bool computeResiduals(const T *const *rotations, const T *z0, const T *z1, const T *z2, T *residuals) const
+    {
+        V3<T> dir[N];
+        for (int i = 0; i < N; i++)
+            dir[i] = quat_rotate(rotations[i], V3<T>{T(camera_ray[i][0]), T(camera_ray[i][1]), T(camera_ray[i][2])});
+        return finish<T>(dir, z0, z1, z2, residuals);
+    }
+    template <typename T>
+    bool computeResidualsFocalRadial(const T *const *rotations, const T *z0, const T *z1, const T *z2, const T *focal,
+                                     const T *principal, const T *radial, T *residuals) const
+    {
+        inverse_model_t<T> model;
+        model.focal_length_pixels = *focal;
+        model.principle_point[0] = principal[0], model.principle_point[1] = principal[1];
+        for (int i = 0; i < 3; i++)
+            model.radial_distortion[i] = radial[i];
+        model.tangential_distortion[0] = T(shared_tangential[0]), model.tangential_distortion[1] = T(shared_tangential[1]);
+        V3<T> dir[N];
+        for (int i = 0; i < N; i++)
+        {
+            const T px[2] = {T(camera_pixel[i][0]), T(camera_pixel[i][1])};
+            dir[i] = quat_rotate(rotations[i], image_to_3d_inverse<T>(px, model));
+        }
+        return finish<T>(dir, z0, z1, z2, residuals);
+    }
+};
+// parameter orders of the wrappers: 2-ray (:658-684, :568-599): r0 r1 z0 z1 z2 [f pp k];
+// N-ray (:686-735, :737-790): z0 z1 z2 [f pp k] r0 .. rN-1
+struct TwoRayFocalRadial
+{
+    MultiRayCost<2> impl;
+    template <typename T>
+    bool operator()(const T *r0, const T *r1, const T *z0, const T *z1, const T *z2, const T *f, const T *pp, const T *k,
+                    T *res) const
+    {
+        const T *rot[2] = {r0, r1};
+        return impl.computeResidualsFocalRadial<T>(rot, z0, z1, z2, f, pp, k, res);
+    }
+};
+template <int N> struct NRay
+{
+    MultiRayCost<N> impl;
+    template <typename T, typename... R> bool operator()(const T *z0, const T *z1, const T *z2, const R *...rest) const
+    {
+        // rest = r0 .. rN-1, residuals
+        const T *all[N + 1] = {rest...};
+        return impl.template computeResiduals<T>(all, z0, z1, z2, const_cast<T *>(all[N]));
+    }
+};
+template <int N> struct NRayFocalRadial
+{
+    MultiRayCost<N> impl;
+    template <typename T, typename... R>
+    bool operator()(const T *z0, const T *z1, const T *z2, const T *f, const T *pp, const T *k, const R *...rest) const
+    {
+        const T *all[N + 1] = {rest...};
+        return impl.template computeResidualsFocalRadial<T>(all, z0, z1, z2, f, pp, k, const_cast<T *>(all[N]));
+    }
+};
+
 } // namespace oracle

@@ -38,6 +38,26 @@ void Problem::SetManifold(double *p, Manifold m)
 {
     blocks[index.at(p)].manifold = m;
 }
+void Problem::SetSubsetManifold(double *p, const std::vector<int> &constant_parameters)
+{
+    ParameterBlock &b = blocks[index.at(p)];
+    b.manifold = Manifold::SUBSET;
+    b.subset_constant = constant_parameters;
+}
+void Problem::SetParameterLowerBound(double *p, int idx, double v)
+{
+    ParameterBlock &b = blocks[index.at(p)];
+    if (b.lower.empty())
+        b.lower.assign(b.size, -std::numeric_limits<double>::max());
+    b.lower[idx] = v;
+}
+void Problem::SetParameterUpperBound(double *p, int idx, double v)
+{
+    ParameterBlock &b = blocks[index.at(p)];
+    if (b.upper.empty())
+        b.upper.assign(b.size, std::numeric_limits<double>::max());
+    b.upper[idx] = v;
+}
 void Problem::SetParameterBlockConstant(double *p)
 {
     blocks[index.at(p)].constant = true;
@@ -167,6 +187,19 @@ bool eval_block(const Program &prog, const ResidualBlock &rb, const std::vector<
                     }
                 c0 += 3;
             }
+            else if (pb.manifold == Manifold::SUBSET)
+            {
+                int t = 0;
+                for (int c = 0; c < pb.size; c++)
+                {
+                    if (pb.is_subset_constant(c))
+                        continue;
+                    for (int r = 0; r < nr; r++)
+                        (*jac_tangent)[(size_t)r * tcols + c0 + t] = jac_ptr[i][r * pb.size + c];
+                    t++;
+                }
+                c0 += t;
+            }
             else
             {
                 for (int r = 0; r < nr; r++)
@@ -243,13 +276,23 @@ bool evaluate(const Program &prog, const std::vector<double> &state, bool want_j
     return true;
 }
 
-// dense Cholesky solve of A x = b (A symmetric positive definite, row-major n x n, destroyed)
+// Cholesky solve of A x = b (A symmetric positive definite, row-major n x n, destroyed).  Rows are walked inside their
+// profile only (first[i] = first non-zero column of row i; fill stays inside a row's profile), which skips exact zeros
+// and nothing else: the arithmetic on the non-zero entries is that of the plain dense factorisation.
 bool cholesky_solve(std::vector<double> &A, std::vector<double> &b, int n)
 {
+    std::vector<int> first(n);
+    for (int i = 0; i < n; i++)
+    {
+        int f = 0;
+        while (f < i && A[(size_t)i * n + f] == 0.0)
+            f++;
+        first[i] = f;
+    }
     for (int j = 0; j < n; j++)
     {
         double d = A[(size_t)j * n + j];
-        for (int k = 0; k < j; k++)
+        for (int k = first[j]; k < j; k++)
             d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
         if (!(d > 0) || !std::isfinite(d))
             return false;
@@ -257,8 +300,10 @@ bool cholesky_solve(std::vector<double> &A, std::vector<double> &b, int n)
         A[(size_t)j * n + j] = d;
         for (int i = j + 1; i < n; i++)
         {
+            if (first[i] > j)
+                continue;
             double s = A[(size_t)i * n + j];
-            for (int k = 0; k < j; k++)
+            for (int k = std::max(first[i], first[j]); k < j; k++)
                 s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
             A[(size_t)i * n + j] = s / d;
         }
@@ -266,16 +311,16 @@ bool cholesky_solve(std::vector<double> &A, std::vector<double> &b, int n)
     for (int i = 0; i < n; i++)
     {
         double s = b[i];
-        for (int k = 0; k < i; k++)
+        for (int k = first[i]; k < i; k++)
             s -= A[(size_t)i * n + k] * b[k];
         b[i] = s / A[(size_t)i * n + i];
     }
     for (int i = n - 1; i >= 0; i--)
     {
-        double s = b[i];
-        for (int k = i + 1; k < n; k++)
-            s -= A[(size_t)k * n + i] * b[k];
-        b[i] = s / A[(size_t)i * n + i];
+        // column sweep: x_i is final, remove it from the rows above inside row i's profile
+        b[i] = b[i] / A[(size_t)i * n + i];
+        for (int k = first[i]; k < i; k++)
+            b[k] -= A[(size_t)i * n + k] * b[i];
     }
     return true;
 }
@@ -353,11 +398,27 @@ void Solve(const SolverOptions &opt, Problem *problem, SolverSummary *summary)
             double *o = &out[prog.ambient_offset[b]];
             if (pb.manifold == Manifold::EIGEN_QUATERNION)
                 quat_plus(s, d, o);
+            else if (pb.manifold == Manifold::SUBSET)
+            {
+                int t = 0;
+                for (int k = 0; k < pb.size; k++)
+                    o[k] = pb.is_subset_constant(k) ? s[k] : s[k] + d[t++];
+            }
             else
                 for (int k = 0; k < pb.size; k++)
                     o[k] = s[k] + d[k];
+            // ParameterBlock::Plus projects onto the box constraints (ceres/parameter_block.h)
+            if (!pb.lower.empty())
+                for (int k = 0; k < pb.size; k++)
+                    o[k] = std::max(o[k], pb.lower[k]);
+            if (!pb.upper.empty())
+                for (int k = 0; k < pb.size; k++)
+                    o[k] = std::min(o[k], pb.upper[k]);
         }
     };
+    bool is_constrained = false;
+    for (int b : prog.var_blocks)
+        is_constrained |= !problem->blocks[b].lower.empty() || !problem->blocks[b].upper.empty();
     // scatter block Jacobians into (optionally scaled) J'J and J'r
     auto normal_equations = [&](const Evaluation &ev, const std::vector<double> &scale, std::vector<double> &JtJ,
                                 std::vector<double> &Jtr, std::vector<double> &colnorm2) {

@@ -99,3 +99,64 @@ def camera_grid(rows, cols, seed=3, height=10.0, spacing=2.0, yaw_sigma=0.05, pt
                         edges.append(dict(src=i, dst=j, H=None, px=np.concatenate([px[i][both], px[j][both]], axis=1),
                                           match_index=np.arange(len(both)), dist=None))
     return ori, pos, edges, model
+
+
+def rx_graph_from_edges(oracle, node_pos, node_ori, model10, edges, paths=None):
+    """The flat edge dicts of this module as a MeasurementGraph of oracle/relax_full.cpp: every inlier of an edge becomes a
+    feature of both images (feature indices = positions in the images' feature lists, as assembleInliers records them);
+    an inlier that carries 'pid' (a ground point id) shares its feature across the edges of an image, which is what
+    makes multi-image tracks (test_relax.cpp:91-125 indexes features by point that way)."""
+    g = oracle.RxGraph()
+    g.add_model(model10, 42)
+    n = len(node_pos)
+    feats = [[] for _ in range(n)]
+    index = [dict() for _ in range(n)]
+    plan = []
+    for e in edges:
+        k = len(e["px"])
+        pid = e.get("pid")
+        f1, f2 = np.zeros(k, np.uint64), np.zeros(k, np.uint64)
+        for j in range(k):
+            for node, col, out in ((e["src"], 0, f1), (e["dst"], 2, f2)):
+                key = None if pid is None else int(pid[j])
+                if key is not None and key in index[node]:
+                    out[j] = index[node][key]
+                else:
+                    out[j] = len(feats[node])
+                    if key is not None:
+                        index[node][key] = out[j]
+                    feats[node].append(e["px"][j][col:col + 2])
+        plan.append((f1, f2))
+    for i in range(n):
+        g.add_node(node_pos[i], node_ori[i], 0, np.array(feats[i]).reshape(-1, 2), None if paths is None else paths[i])
+    for e, (f1, f2) in zip(edges, plan):
+        g.add_edge(e["src"], e["dst"], e["px"], f1, f2, e["match_index"], e.get("H"), e.get("dist"))
+    return g, feats
+
+
+def ring_edges_tracks(ori, pos, points, model=MODEL_600):
+    """ring_edges with the point id of every inlier (features shared per point, as in test_relax.cpp:91-125)."""
+    edges = ring_edges(ori, pos, points, model)
+    for e in edges:
+        e["pid"] = np.arange(len(points))
+    return edges
+
+
+def grid_5x5():
+    """incremental_relax fixture (test_relax.cpp:685-812): 5 x 5 cameras, 20 x 20 planar points, edges between cameras
+    closer than 3.5 (i < j), features appended per edge (no sharing)."""
+    n = 25
+    pos = np.array([[10 + (i % 5) * 2, 10 + (i // 5) * 2, 10.0] for i in range(n)])
+    ori = np.array([qmul(axis_angle([0, 0, 1], 0.05 * (i - n / 2.0)), DOWN) for i in range(n)])
+    pts = np.array([[9 + i * 0.5, 9 + j * 0.5, -5 + 1e-3 * i + 1e-2 * j] for i in range(20) for j in range(20)])
+    px = [np.array([project(ori[i], pos[i], p, MODEL_600) for p in pts]) for i in range(n)]
+    vis = [np.all((px[i] >= 0) & (px[i] < MODEL_600[8:10]), axis=1) for i in range(n)]
+    edges = []
+    for i in range(n):
+        for j in range(i + 1, n):
+            if np.linalg.norm(pos[i] - pos[j]) < 3.5:
+                both = np.flatnonzero(vis[i] & vis[j])
+                if len(both):
+                    edges.append(dict(src=i, dst=j, H=None, px=np.concatenate([px[i][both], px[j][both]], axis=1),
+                                      match_index=both, dist=None))
+    return ori, pos, edges
