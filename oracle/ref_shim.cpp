@@ -1,11 +1,17 @@
 // ORACLE — test infrastructure only.  oracle/_ref/libref.so
 //
-// Thin C ABI over the std-only header of the reference that compiles in this image without any
-// stand-ins: external/jk-tree/include/jk/KDTree.h (included from /root/reference at build time, never
-// copied into this repo).  It lets the tests check the restated nearest-neighbour logic
+// Thin C ABI over the std-only headers of the reference that compile in this image without any
+// stand-ins (included from /root/reference at build time, never copied into this repo):
+//   external/jk-tree/include/jk/KDTree.h, external/unordered_dense/include/ankerl/unordered_dense.h,
+//   include/opencalibration/relax/grid_filter.hpp, types/union_find.hpp, geometry/KMeans.hpp,
+//   combinatorics/interleave.hpp.  It lets the tests check the restated nearest-neighbour logic
 // (oracle/match.cpp hash grid; the pair selection of link_stage.cpp:22-38) against the reference's
 // own KD-tree, including its tie behaviour.
 #include <jk/KDTree.h>
+#include <opencalibration/combinatorics/interleave.hpp>
+#include <opencalibration/geometry/KMeans.hpp>
+#include <opencalibration/relax/grid_filter.hpp>
+#include <opencalibration/types/union_find.hpp>
 
 #include <algorithm>
 #include <array>
@@ -63,6 +69,81 @@ void ref_knn(const double *xy, size_t n, size_t k, uint64_t *out)
         for (size_t j = 0; j < k; j++)
             out[i * k + j] = j < knn.size() ? knn[j].payload : UINT64_MAX;
     }
+}
+
+
+// GridFilter<size_t> (grid_filter.hpp:16-62): measurements added in the given order; out_best = 1 for the values left in
+// getBestMeasurementsPerCell().  Values are 0..n-1.
+void ref_grid_filter(const double *xy, const double *score, size_t n, double resolution, uint8_t *out_best)
+{
+    opencalibration::GridFilter<size_t> f;
+    f.setResolution(resolution);
+    for (size_t i = 0; i < n; i++)
+        f.addMeasurement(xy[2 * i], xy[2 * i + 1], score[i], i);
+    for (size_t i = 0; i < n; i++)
+        out_best[i] = 0;
+    for (size_t v : f.getBestMeasurementsPerCell())
+        out_best[v] = 1;
+}
+// the same with caller-chosen values (a value may be added to several cells: the set semantics of _best)
+void ref_grid_filter_values(const double *xy, const double *score, const uint64_t *value, size_t n, double resolution,
+                            uint64_t *out_values, size_t *n_out)
+{
+    opencalibration::GridFilter<size_t> f;
+    f.setResolution(resolution);
+    for (size_t i = 0; i < n; i++)
+        f.addMeasurement(xy[2 * i], xy[2 * i + 1], score[i], (size_t)value[i]);
+    size_t k = 0;
+    for (size_t v : f.getBestMeasurementsPerCell())
+        out_values[k++] = v;
+    *n_out = k;
+}
+uint64_t ref_grid_cell_key(int i, int j)
+{
+    return opencalibration::gridCellKey(i, j);
+}
+
+// UnionFind (union_find.hpp): unite the pairs in order, then roots[i] = find(i)
+void ref_union_find(size_t n, const uint64_t *pairs, size_t n_pairs, uint64_t *roots)
+{
+    opencalibration::UnionFind uf(n);
+    for (size_t i = 0; i < n_pairs; i++)
+        uf.unite(pairs[2 * i], pairs[2 * i + 1]);
+    for (size_t i = 0; i < n; i++)
+        roots[i] = uf.find(i);
+}
+
+// KMeans<size_t, 3> (KMeans.hpp): add every point (values 0..n-1), `iterations` x iterate(); out: per point the index of
+// its cluster in getClusters() order, centroids k x 3, sizes k
+void ref_kmeans3(const double *xyz, size_t n, size_t k, int iterations, uint64_t *assignment, double *centroids,
+                 uint64_t *sizes)
+{
+    opencalibration::KMeans<size_t, 3> km(k);
+    for (size_t i = 0; i < n; i++)
+        km.add({xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}, i);
+    for (int i = 0; i < iterations; i++)
+        km.iterate();
+    const auto &cl = km.getClusters();
+    for (size_t c = 0; c < cl.size(); c++)
+    {
+        for (int d = 0; d < 3; d++)
+            centroids[3 * c + d] = cl[c].centroid[d];
+        sizes[c] = cl[c].points.size();
+        for (const auto &p : cl[c].points)
+            assignment[p.second] = c;
+    }
+}
+
+// interleave (interleave.hpp) of up to three index lists
+size_t ref_interleave3(const uint64_t *a, size_t na, const uint64_t *b, size_t nb, const uint64_t *c, size_t nc,
+                       int full_dispersal, uint64_t *out)
+{
+    std::vector<uint64_t> va(a, a + na), vb(b, b + nb), vc(c, c + nc);
+    const std::vector<uint64_t> r =
+        opencalibration::interleave<std::vector<uint64_t>>({std::ref(va), std::ref(vb), std::ref(vc)}, full_dispersal != 0);
+    for (size_t i = 0; i < r.size(); i++)
+        out[i] = r[i];
+    return r.size();
 }
 
 } // extern "C"

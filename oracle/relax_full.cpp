@@ -2005,3 +2005,32 @@ std::vector<size_t> RelaxGroup::finalize(MeasurementGraph &graph)
 
 } // namespace rx
 } // namespace oracle
+
+// ---- test hooks: the restated GridFilter / UnionFind against the reference's own headers (oracle/_ref, tests/test_oracle_ref_pins.py)
+extern "C"
+{
+void ocx_grid_filter_values(const double *xy, const double *score, const uint64_t *value, size_t n, double resolution,
+                            uint64_t *out_values, size_t *n_out)
+{
+    oracle::rx::GridFilter<size_t> f;
+    f.setResolution(resolution);
+    for (size_t i = 0; i < n; i++)
+        f.addMeasurement(xy[2 * i], xy[2 * i + 1], score[i], (size_t)value[i]);
+    size_t k = 0;
+    for (size_t v : f.getBestMeasurementsPerCell())
+        out_values[k++] = v;
+    *n_out = k;
+}
+uint64_t ocx_grid_cell_key(int i, int j)
+{
+    return oracle::rx::gridCellKey(i, j);
+}
+void ocx_union_find(size_t n, const uint64_t *pairs, size_t n_pairs, uint64_t *roots)
+{
+    oracle::rx::UnionFind uf(n);
+    for (size_t i = 0; i < n_pairs; i++)
+        uf.unite(pairs[2 * i], pairs[2 * i + 1]);
+    for (size_t i = 0; i < n; i++)
+        roots[i] = uf.find(i);
+}
+}
