@@ -260,6 +260,64 @@ extern "C"
      * RelaxProblem::solve does after every Solve (:1410-1413); plane_z: 3 */
     int ochip_relax_get_state(ochip_relax_problem *p, double *cam_q, double *plane_z);
 
+    /* ---- relax, general form: ground mesh, multi-ray tracks, shared intrinsics (replaces ceres::Solver::Solve on the
+     *      problems RelaxProblem::setupGroundMeshProblem / setupGroundPlaneProblem build, src/relax/relax_problem.cpp:61-120:
+     *      residual blocks of 2..5 rays on a triangle of the surface mesh (relax_cost_function.hpp:601-790), mesh priors
+     *      (:51-69, :119-155; relax_problem.cpp:1303-1366), downward prior (:21-49), distortion monotonicity (:157-185)).
+     *      Unknowns: 3 per optimised camera (quaternion tangent), 1 per optimised mesh vertex (height), and the shared
+     *      inverse lens model: focal (bounded, :496-497), principal point, radial k1..k_n (SubsetManifold, :22-23). ---- */
+    typedef struct ochip_relaxg_problem ochip_relaxg_problem;
+
+    typedef struct ochip_relaxg_desc
+    {
+        uint32_t n_cams;
+        const double *cam_pos;       /* n_cams x 3 */
+        const double *cam_q;         /* n_cams x 4, x y z w */
+        const uint8_t *cam_optimize; /* n_cams */
+        uint32_t n_verts;            /* mesh vertices; their heights are the structure parameters */
+        const double *vert_xy;       /* n_verts x 2 */
+        const double *vert_z;        /* n_verts */
+        const uint8_t *vert_optimize;
+        uint32_t n_blocks;           /* ray blocks, in the order the reference adds them (tracks, then 2-ray blocks) */
+        const uint8_t *blk_n;        /* rays of block b: 2 (Huber loss huber_a) or 3..5 (no loss) */
+        const uint8_t *blk_intr;     /* 1 = the FocalRadial functor on the shared model (:501-566), NULL = none */
+        const uint32_t *blk_ray_off; /* n_blocks + 1 */
+        const uint32_t *blk_tri;     /* n_blocks x 3 vertex indices (the triangle under the rays) */
+        const uint32_t *ray_cam;     /* per ray */
+        const double *ray_dir;       /* per ray x 3: camera-frame unit ray (used by blocks with blk_intr = 0) */
+        const double *ray_px;        /* per ray x 2: pixel (used by blocks with blk_intr = 1); may be NULL */
+        uint32_t n_down;             /* PointsDownwardsPrior */
+        const uint32_t *down_cam;
+        double down_weight;          /* 1e-3 */
+        uint32_t n_diff;             /* DifferenceCost between the heights of the two ends of a mesh edge */
+        const uint32_t *diff_v;      /* n_diff x 2 */
+        double diff_weight;          /* 1e-4 */
+        double anchor_weight;        /* DifferenceCost of every vertex against its initial height (1e-5); 0 = none */
+        uint32_t n_smooth;           /* AdjacentTriangleNormalCost per inner mesh edge: vertices A B C D */
+        const uint32_t *smooth_v;    /* n_smooth x 4 */
+        double smooth_weight;        /* 1e-4 */
+        double huber_a;              /* 1 degree in radians */
+        /* shared inverse lens model (InverseDifferentiableCameraModel) of the blk_intr blocks */
+        double model[8];             /* f, ppx, ppy, k1, k2, k3, p1, p2 */
+        uint8_t opt_focal, opt_principal, n_radial_free; /* n_radial_free: 0..3 leading radial coefficients are variable */
+        double focal_lo, focal_hi;   /* 100, 20000 */
+        uint32_t mono_observations;  /* DistortionMonotonicityCost: weight sqrt(n / 10); 0 = none */
+        double mono_r_max;
+    } ochip_relaxg_desc;
+
+    int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *desc, ochip_relaxg_problem **out);
+    void ochip_relaxg_problem_destroy(ochip_relaxg_problem *p);
+    /* relaxObservedModelOnly (:931-984): 1 = everything but the mesh heights held constant, 0 = undo */
+    int ochip_relaxg_set_structure_only(ochip_relaxg_problem *p, int on);
+    int ochip_relaxg_solve(ochip_relaxg_problem *p, const ochip_relax_options *opt, ochip_relax_summary *summary);
+    /* cam_q: n_cams x 4 (optimised cameras normalised as RelaxProblem::solve leaves them), vert_z: n_verts, model: 8;
+     * any may be NULL */
+    int ochip_relaxg_get_state(ochip_relaxg_problem *p, double *cam_q, double *vert_z, double *model);
+    /* One evaluation at the current state for tests: total cost, and (when not NULL) the dense J'J (n x n) and J'r (n) of
+     * the reduced system in the library's unknown order; order_out (n_cams + n_verts + 3 entries) receives the first
+     * unknown of every camera / vertex / f / pp / k or -1. */
+    int ochip_relaxg_evaluate(ochip_relaxg_problem *p, double *cost, int *n_out, double *JtJ, double *Jtr, int32_t *order_out);
+
     /* ---- profiling: HIP-event time of every launch of a kernel since the last reset ------------- */
     int ochip_profile_reset(ochip_ctx *ctx);
     int ochip_profile_get(ochip_ctx *ctx, int kernel_id, uint64_t *launches, double *total_ms);

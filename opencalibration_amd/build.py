@@ -28,11 +28,27 @@ def _stale(target, sources):
 
 
 def build_ochip(force=False, verbose=False):
+    """One object per .hip source (opencalibration_amd/build/, git-ignored), linked into libochip.so: a change to one
+    kernel file recompiles that file only.  No relocatable device code: a kernel is launched from the file that defines it."""
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    hdrs = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     out = os.path.join(HERE, "libochip.so")
-    if force or _stale(out, deps):
-        cmd = [HIPCC, *HIP_FLAGS, "-shared", "-o", out, *srcs]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs, procs = [], []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [HIPCC, *HIP_FLAGS, "-c", "-o", o, s]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if force or procs or _stale(out, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -19,6 +19,7 @@
 //     (64-wide panels: diagonal factor in LDS, row-parallel panel solve, 64x64 tiled trailing update).
 #include "ctx.hpp"
 #include "dual.hpp"
+#include "relax_lm.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -32,6 +33,7 @@ namespace
 {
 
 constexpr int W = 64;
+constexpr int NB = LM_NB;
 constexpr int ACC = 55; // 45 upper-triangular entries of the 9x9 [p|q|z] block + 9 gradient + cost
 
 __host__ __device__ inline int tri(int i, int j) // i <= j, 9x9 upper triangle
@@ -472,335 +474,12 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, do
     }
 }
 
-// ---- dense linear algebra on the reduced system -------------------------------------------------
-constexpr int NB = 64;
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-
-// Wm = S A S + diag(D), gs = S g; also column norms^2 of the scaled Jacobian = diag(S A S)
-__global__ void lm_build_kernel(const double *A, const double *g, const double *scale, const double *lm_diag,
-                                double *Wm, double *gs, int n)
-{
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)n * n)
-        return;
-    const int i = (int)(idx / n), j = (int)(idx % n);
-    double v = A[idx] * scale[i] * scale[j];
-    if (i == j)
-    {
-        v += lm_diag[i];
-        const double gi = g[i] * scale[i];
-        gs[i] = gi;
-        Wm[(size_t)n * n + i] = gi; // augmented row n: the factorisation performs the forward solve L y = gs on it
-    }
-    Wm[idx] = v;
-}
-
-// Cholesky factor of the 64 x 64 diagonal block and its inverse, one workgroup.  The block lives in registers:
-// thread (ty, tx) of a 16 x 16 grid owns rows ty + 16p and columns tx + 16q (cyclic, so the shrinking trailing
-// matrix stays spread over all threads).  Step j: the owners of column j publish it (and the owners of row j of
-// the inverse accumulator publish that) in LDS, one barrier, then every thread applies the rank-1 update to its
-// register tile and the forward-elimination step  X_j /= l_jj,  X_i -= l_ij X_j  that turns the identity into
-// L^-1.  The 64 steps run as 4 phases of 16 with the phase (j / 16) a compile-time constant: which register
-// rows / columns are finished, live or on the pivot is then static, only the 16-row band of the pivot needs a
-// runtime comparison, and finished parts cost nothing.  (This kernel is the critical path of the linear solve:
-// 47 sequential launches per factorisation at n = 3003.)
-template <int JB>
-__device__ __forceinline__ void chol_diag_phase(double (&a)[4][4], double (&x)[4][4], double (*colA)[NB], double (*rowX)[NB],
-                                                int ty, int tx, int nb, bool &bad)
-{
-#pragma unroll 1
-    for (int jt = 0; jt < 16; jt++)
-    {
-        const int j = JB * 16 + jt, buf = jt & 1;
-        if (tx == jt) // owners of column j: rows of band JB and below
-#pragma unroll
-            for (int p = JB; p < 4; p++)
-                colA[buf][ty + 16 * p] = a[p][JB];
-        if (ty == jt) // owners of row j of the inverse accumulator: columns up to band JB
-#pragma unroll
-            for (int q = 0; q <= JB; q++)
-                rowX[buf][tx + 16 * q] = x[JB][q];
-        __syncthreads();
-        const double piv = colA[buf][j];
-        if (j < nb && !(piv > 0.0))
-            bad = true;
-        // 1 / sqrt(pivot): hardware estimate + two Newton steps (the factor is not on a bit-parity path)
-        double rs = __builtin_amdgcn_rsq(piv);
-        rs = rs * (1.5 - 0.5 * piv * rs * rs);
-        rs = rs * (1.5 - 0.5 * piv * rs * rs);
-        double li[4], lc[4], xr[4];
-#pragma unroll
-        for (int p = JB; p < 4; p++)
-        {
-            const double v = colA[buf][ty + 16 * p] * rs;
-            li[p] = (p > JB || ty > jt) ? v : 0.0;
-        }
-#pragma unroll
-        for (int q = JB; q < 4; q++)
-        {
-            const double v = colA[buf][tx + 16 * q] * rs;
-            lc[q] = (q > JB || tx > jt) ? v : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q <= JB; q++)
-            xr[q] = rowX[buf][tx + 16 * q] * rs;
-#pragma unroll
-        for (int p = JB; p < 4; p++)
-        {
-#pragma unroll
-            for (int q = JB; q < 4; q++)
-                a[p][q] -= li[p] * lc[q];
-#pragma unroll
-            for (int q = 0; q <= JB; q++)
-                x[p][q] -= li[p] * xr[q];
-        }
-        // column j becomes final (l_ij below the diagonal, sqrt(pivot) = pivot * rs on it, 0 above); row j of X too
-        if (tx == jt)
-#pragma unroll
-            for (int p = JB; p < 4; p++)
-            {
-                const double v = colA[buf][ty + 16 * p] * rs;
-                a[p][JB] = (p > JB || ty >= jt) ? v : 0.0;
-            }
-        if (ty == jt)
-#pragma unroll
-            for (int q = 0; q <= JB; q++)
-                x[JB][q] = xr[q];
-    }
-}
-
-__global__ __launch_bounds__(256) void chol_diag_kernel(double *A, int n, int k0, int nb, int *fail,
-                                                        double *Linv /*[NB][NB] row-major, zero padded*/)
-{
-    __shared__ double colA[2][NB], rowX[2][NB];
-    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
-    double a[4][4], x[4][4];
-#pragma unroll
-    for (int p = 0; p < 4; p++)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-        {
-            const int i = ty + 16 * p, c = tx + 16 * q;
-            // only the lower triangle of the input is meaningful; mirror it so that both triangles update alike
-            const int lo = i > c ? i : c, hi = i > c ? c : i;
-            a[p][q] = (lo < nb) ? A[(size_t)(k0 + lo) * n + k0 + hi] : (i == c ? 1.0 : 0.0);
-            x[p][q] = (i == c) ? 1.0 : 0.0;
-        }
-    bool bad = false;
-    chol_diag_phase<0>(a, x, colA, rowX, ty, tx, nb, bad);
-    chol_diag_phase<1>(a, x, colA, rowX, ty, tx, nb, bad);
-    chol_diag_phase<2>(a, x, colA, rowX, ty, tx, nb, bad);
-    chol_diag_phase<3>(a, x, colA, rowX, ty, tx, nb, bad);
-    if (bad)
-        *fail = 1;
-#pragma unroll
-    for (int p = 0; p < 4; p++)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-        {
-            const int i = ty + 16 * p, c = tx + 16 * q;
-            if (i < nb && c <= i)
-                A[(size_t)(k0 + i) * n + k0 + c] = a[p][q];
-            Linv[i * NB + c] = (i < nb && c <= i) ? x[p][q] : ((i == c) ? 1.0 : 0.0);
-        }
-}
-
-// The rows below a diagonal block that can be non-zero: the block column's envelope (cameras further down the list
-// than any camera linked to this block's cameras never get fill) and the tail (the plane unknowns, coupled to every
-// camera, and the augmented row).  Kernels index this set with a logical row number.
-struct row_set
-{
-    int begin, band_rows; // rows begin .. begin + band_rows - 1
-    int tail_begin, total; // then rows tail_begin .. ; total = band_rows + tail rows
-};
-__device__ __forceinline__ int set_row(const row_set &s, int i)
-{
-    return i < s.band_rows ? s.begin + i : s.tail_begin + (i - s.band_rows);
-}
-
-// rows below the diagonal block: X = A[i, k0:k0+nb] * L_kk^{-T} = A_tile * Linv' as a 64x64x64 GEMM on the
-// matrix cores (same tiling as the trailing update), in place.
-__global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, row_set rs, int k0, int nb, const double *Linv)
-{
-    constexpr int KC = 32;
-    __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
-    const int r0 = blockIdx.x * 64; // logical
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
-    const int lr = lane & 15, lk = lane >> 4;
-    v4f64 acc[2][2];
-    for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 2; j++)
-            acc[i][j] = v4f64{0, 0, 0, 0};
-    for (int m0 = 0; m0 < NB; m0 += KC)
-    {
-        __syncthreads();
-        for (int e = t; e < 64 * KC; e += 256)
-        {
-            const int r = e / KC, m = e % KC;
-            Pi[r][m] = (r0 + r < rs.total && m0 + m < nb) ? A[(size_t)set_row(rs, r0 + r) * n + k0 + m0 + m] : 0.0;
-            Pj[r][m] = Linv[r * NB + m0 + m]; // X[i][c] = sum_m A[i][m] Linv[c][m]
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 4)
-        {
-            const double a0 = Pi[wr + lr][kk + lk], a1 = Pi[wr + 16 + lr][kk + lk];
-            const double b0 = Pj[wc + lr][kk + lk], b1 = Pj[wc + 16 + lr][kk + lk];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 2; j++)
-            for (int e = 0; e < 4; e++)
-            {
-                const int r = r0 + wr + 16 * i + 4 * e + lk, cc = wc + 16 * j + lr;
-                if (r < rs.total && cc < nb)
-                    A[(size_t)set_row(rs, r) * n + k0 + cc] = acc[i][j][e];
-            }
-}
-
-// trailing update, lower tiles only: C[i][j] -= sum_m P[i][m] P[j][m], 64x64 tile per workgroup.
-// Same trailing update on the matrix cores: v_mfma_f64_16x16x4_f64, one 32x32 sub-tile per wave
-// (2x2 accumulators), operands staged through LDS in 32-deep K chunks.  This dense fp64 update of the
-// reduced system is the only MFMA use on the path.
-__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n, row_set rs, int k0, int nb)
-{
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    if (tj > ti)
-        return;
-    constexpr int KC = 32;
-    __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
-    const int r0 = ti * 64, c0 = tj * 64; // logical rows of the set; columns are the same set (without the augmented row)
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
-    const int lr = lane & 15, lk = lane >> 4;
-    v4f64 acc[2][2];
-    for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 2; j++)
-            acc[i][j] = v4f64{0, 0, 0, 0};
-    for (int m0 = 0; m0 < nb; m0 += KC)
-    {
-        const int mc = min(KC, nb - m0);
-        __syncthreads();
-        for (int e = t; e < 64 * KC; e += 256)
-        {
-            const int r = e / KC, m = e % KC;
-            Pi[r][m] = (r0 + r < rs.total && m < mc) ? A[(size_t)set_row(rs, r0 + r) * n + k0 + m0 + m] : 0.0;
-            Pj[r][m] = (c0 + r < rs.total && m < mc) ? A[(size_t)set_row(rs, c0 + r) * n + k0 + m0 + m] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 4)
-        {
-            const double a0 = Pi[wr + lr][kk + lk], a1 = Pi[wr + 16 + lr][kk + lk];
-            const double b0 = Pj[wc + lr][kk + lk], b1 = Pj[wc + 16 + lr][kk + lk];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    }
-    for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 2; j++)
-            for (int e = 0; e < 4; e++)
-            {
-                // f64 16x16x4 result layout (measured, scripts/probe_mfma_f64.hip): D[4*reg + lane/16][lane%16]
-                const int r = r0 + wr + 16 * i + 4 * e + lk, cc = c0 + wc + 16 * j + lr;
-                if (r < rs.total && cc <= r)
-                {
-                    const int ar = set_row(rs, r), ac = set_row(rs, cc);
-                    if (ac < n)
-                        A[(size_t)ar * n + ac] -= acc[i][j][e];
-                }
-            }
-}
-
-// Backward substitution L' x = y by ONE workgroup, block by block from the bottom: x_k = L_kk^-T y_k out of the stored
-// inverse, then y_i -= sum_m L[k0+m][i] x[k0+m] for the columns i < k0 in which the rows of the block can be non-zero
-// (first_col[k]: the row envelope; everything for the tail rows).  The 94 launches this took per solve cost 1.0 ms, the
-// walk over the envelope takes a tenth of that.
-__global__ __launch_bounds__(1024) void back_solve_kernel(const double *L, int n, const double *Linv, double *x,
-                                                          const int *first_col, int n_blocks)
-{
-    __shared__ double xb[NB];
-    const int t = threadIdx.x;
-    for (int k = n_blocks - 1; k >= 0; k--)
-    {
-        const int k0 = k * NB, nb = min(NB, n - k0);
-        const double *Li = Linv + (size_t)k * NB * NB;
-        __syncthreads(); // the updates of the previous block have landed
-        if (t < NB)
-            xb[t] = t < nb ? x[k0 + t] : 0.0;
-        __syncthreads();
-        double s = 0; // (L^-T y)[t] = sum_m Linv[m][t] y[m]; Linv is lower triangular with zeros above, so all 64 terms
-        if (t < nb)   // can be requested up front (16 loads in flight) instead of one per loop trip
-        {
-#pragma unroll
-            for (int m0 = 0; m0 < NB; m0 += 16)
-            {
-                double v[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++)
-                    v[j] = Li[(m0 + j) * NB + t];
-#pragma unroll
-                for (int j = 0; j < 16; j++)
-                    if (m0 + j >= t && m0 + j < nb)
-                        s += v[j] * xb[m0 + j];
-            }
-        }
-        __syncthreads();
-        if (t < nb)
-        {
-            xb[t] = s;
-            x[k0 + t] = s;
-        }
-        __syncthreads();
-        for (int i = first_col[k] + t; i < k0; i += 1024)
-        {
-            double u = 0;
-            for (int m0 = 0; m0 < nb; m0 += 16)
-            {
-                double v[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++)
-                    v[j] = m0 + j < nb ? L[(size_t)(k0 + m0 + j) * n + i] : 0.0;
-#pragma unroll
-                for (int j = 0; j < 16; j++)
-                    u += v[j] * xb[m0 + j];
-            }
-            x[i] -= u;
-        }
-    }
-}
-
-// step = -y with (As + D) y = gs, As = S A S.  model_cost_change = -(step.gs + step' As step / 2)
-// = y.gs - (y.gs - y'D y)/2 = (y.gs + sum D_i y_i^2)/2 by the normal equations (no n^2 product needed).
-// delta = S step; candidate state = x (+) delta; step_norm^2 in ambient space.  One workgroup.
-// scal: [1] model_cost_change, [2] step_norm^2, [3] x_norm^2 (candidate)
-__global__ __launch_bounds__(1024) void lm_step_kernel(relax_dev P, const double *lm_diag, const double *gs,
-                                                       const double *scale, double *y, int n, double *scal)
+// step = -y with (As + D) y = gs; delta = S step; candidate state = x (+) delta; step_norm^2 in ambient space.
+// One workgroup.  scal: [2] step_norm^2, [3] x_norm^2 (candidate)
+__global__ __launch_bounds__(1024) void plane_candidate_kernel(relax_dev P, const double *scale, const double *y, double *scal)
 {
     __shared__ double sh[1024];
     const int t = threadIdx.x;
-    double part = 0;
-    for (int i = t; i < n; i += 1024)
-        part += y[i] * gs[i] + lm_diag[i] * y[i] * y[i];
-    sh[t] = part;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1)
-    {
-        if (t < s)
-            sh[t] += sh[t + s];
-        __syncthreads();
-    }
-    if (t == 0)
-        scal[1] = 0.5 * sh[0];
-    __syncthreads();
     // candidate state
     double sn = 0, xn = 0;
     for (uint32_t c = t; c < P.n_cams; c += 1024)
@@ -889,30 +568,6 @@ __global__ void normalize_kernel(relax_dev P, const uint8_t *cam_optimize)
         q[k] = q[k] / n;
 }
 
-// diag(A) and max|g| -> scal[4] = max|g|; diag_out[i] = A_ii
-__global__ __launch_bounds__(1024) void lm_diag_kernel(const double *A, const double *g, double *diag_out, int n,
-                                                       double *scal)
-{
-    __shared__ double sh[1024];
-    const int t = threadIdx.x;
-    double m = 0;
-    for (int i = t; i < n; i += 1024)
-    {
-        diag_out[i] = A[(size_t)i * n + i];
-        m = fmax(m, fabs(g[i]));
-    }
-    sh[t] = m;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1)
-    {
-        if (t < s)
-            sh[t] = fmax(sh[t], sh[t + s]);
-        __syncthreads();
-    }
-    if (t == 0)
-        scal[4] = sh[0];
-}
-
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -928,18 +583,8 @@ struct ochip_relax_problem
     uint8_t z_optimize[3] = {1, 1, 1};
     bool cams_frozen = false;
     uint8_t *cam_has_prior = nullptr, *cam_optimize_dev = nullptr;
-    double *A = nullptr, *Wm = nullptr, *g = nullptr, *gs = nullptr, *scale = nullptr, *lm_diag = nullptr,
-           *diag_tmp = nullptr, *y = nullptr, *scal = nullptr;
-    int *fail_chol = nullptr;
-    double *linv = nullptr; // [panels][NB*NB] inverses of the diagonal blocks
-    // block envelope of the reduced system (assign_tangent): per block column the end of the camera rows that can be
-    // non-zero, the first tail row, and per block row the first column that can be non-zero
-    std::vector<int> env_end, first_col;
-    int tail_begin = 0;
-    int *first_col_dev = nullptr;
+    lm_system sys; // the reduced normal equations and their block envelope (assign_tangent), relax_lm.hpp
     std::vector<uint32_t> pair_p_h, pair_q_h; // host copies of the camera pairs
-    size_t linv_cap = 0;
-    size_t cap_n = 0;
     uint32_t n_cams = 0;
     std::vector<uint32_t> cam_pair_count;
     // sharded evaluation (ochip_relax_set_shard): this rank evaluates pairs [pair_lo, pair_hi)
@@ -1051,20 +696,21 @@ int assign_tangent(ochip_relax_problem *p)
             p->z_t[i] = t++;
     }
     p->n_tangent = t;
+    lm_envelope env;
     {
         // block envelope of the reduced system J'J: camera unknowns in camera order, then the plane unknowns (coupled to
         // every camera: the tail).  A pair (p, q) puts a 3 x 3 block at rows t_q.., columns t_p..; Cholesky fill stays
         // inside the column envelope once that is made monotone.
         const int cam_end = 3 * (int)active.size();
         const int n_all = std::max(t, 1), nblk = (n_all + NB - 1) / NB;
-        p->tail_begin = cam_end;
-        p->env_end.assign(nblk, 0);
+        env.tail_begin = cam_end;
+        env.env_end.assign(nblk, 0);
         for (int k = 0; k < nblk; k++)
-            p->env_end[k] = std::min((k + 1) * NB, cam_end);
+            env.env_end[k] = std::min((k + 1) * NB, cam_end);
         for (uint32_t c = 0; c < p->n_cams; c++) // a camera's own 3 x 3 block may straddle two column blocks
             if (p->cam_t[c] >= 0)
                 for (int k = p->cam_t[c] / NB; k <= (p->cam_t[c] + 2) / NB; k++)
-                    p->env_end[k] = std::max(p->env_end[k], p->cam_t[c] + 3);
+                    env.env_end[k] = std::max(env.env_end[k], p->cam_t[c] + 3);
         for (size_t i = 0; i < p->pair_p_h.size(); i++)
         {
             const int ta = p->cam_t[p->pair_p_h[i]], tb = p->cam_t[p->pair_q_h[i]];
@@ -1072,12 +718,12 @@ int assign_tangent(ochip_relax_problem *p)
                 continue;
             const int lo = std::min(ta, tb), hi = std::max(ta, tb) + 3;
             for (int k = lo / NB; k <= (lo + 2) / NB; k++)
-                p->env_end[k] = std::max(p->env_end[k], hi);
+                env.env_end[k] = std::max(env.env_end[k], hi);
         }
         for (int k = 1; k < nblk; k++)
-            p->env_end[k] = std::max(p->env_end[k], std::min(p->env_end[k - 1], cam_end));
+            env.env_end[k] = std::max(env.env_end[k], std::min(env.env_end[k - 1], cam_end));
         // row envelope for the backward solve: the first column block whose envelope reaches into block row k
-        p->first_col.assign(nblk, 0);
+        env.first_col.assign(nblk, 0);
         for (int k = 0; k < nblk; k++)
         {
             const int k0 = k * NB;
@@ -1086,38 +732,30 @@ int assign_tangent(ochip_relax_problem *p)
                 first = 0;
             else
                 for (int c = 0; c < k; c++)
-                    if (p->env_end[c] > k0)
+                    if (env.env_end[c] > k0)
                     {
                         first = c * NB;
                         break;
                     }
-            p->first_col[k] = first;
+            env.first_col[k] = first;
         }
         if (getenv("OCHIP_RELAX_VERBOSE"))
         {
             long band = 0;
             for (int k = 0; k < nblk; k++)
-                band += std::max(0, p->env_end[k] - (k + 1) * NB);
+                band += std::max(0, env.env_end[k] - (k + 1) * NB);
             fprintf(stderr, "[ochip relax] n=%d blocks=%d tail_begin=%d mean envelope rows below a block %.1f (dense: %.1f)\n", n_all, nblk,
                     cam_end, (double)band / nblk, (double)n_all / 2);
         }
-        if (dev_upload(p, &p->first_col_dev, p->first_col.data(), p->first_col.size()) != OCHIP_OK)
-            return ochip_fail(p->ctx, OCHIP_ENOMEM, "device allocation failed (envelope)");
     }
     if (hipMemcpy(p->dev.cam_t, p->cam_t.data(), p->n_cams * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(p->dev.z_t, p->z_t, 12, hipMemcpyHostToDevice) != hipSuccess)
         return ochip_fail(p->ctx, OCHIP_EHIP, "hipMemcpy failed (tangent map)");
-    const size_t n = (size_t)std::max(t, 1);
-    if (n > p->cap_n)
-    {
-        // (blocks of a smaller earlier size stay with the problem until it is destroyed)
-        if (dev_upload<double>(p, &p->A, nullptr, n * n) != OCHIP_OK || dev_upload<double>(p, &p->Wm, nullptr, (n + 1) * n) != OCHIP_OK ||
-            dev_upload<double>(p, &p->g, nullptr, n) != OCHIP_OK || dev_upload<double>(p, &p->gs, nullptr, n) != OCHIP_OK ||
-            dev_upload<double>(p, &p->scale, nullptr, n) != OCHIP_OK || dev_upload<double>(p, &p->lm_diag, nullptr, n) != OCHIP_OK ||
-            dev_upload<double>(p, &p->diag_tmp, nullptr, n) != OCHIP_OK || dev_upload<double>(p, &p->y, nullptr, n) != OCHIP_OK)
-            return ochip_fail(p->ctx, OCHIP_ENOMEM, "device allocation for the %zu x %zu normal matrix failed", n, n);
-        p->cap_n = n;
-    }
+    p->sys.ctx = p->ctx;
+    p->sys.allocs = &p->allocs;
+    const int rrc = lm_system_resize(&p->sys, t, env);
+    if (rrc != OCHIP_OK)
+        return rrc;
     return OCHIP_OK;
 }
 } // namespace
@@ -1284,8 +922,6 @@ int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *d, ochip_
     p->shard_chunk = n_pairs;
     chk(dev_upload(p, &p->cam_has_prior, p->cam_has_prior_host.data(), p->cam_has_prior_host.size()));
     chk(dev_upload(p, &p->cam_optimize_dev, p->cam_optimize.data(), p->cam_optimize.size()));
-    chk(dev_upload<double>(p, &p->scal, nullptr, 8));
-    chk(dev_upload<int>(p, &p->fail_chol, nullptr, 1));
     if (rc == OCHIP_OK)
         rc = assign_tangent(p);
     if (rc != OCHIP_OK)
@@ -1365,40 +1001,24 @@ int ochip_relax_get_state(ochip_relax_problem *p, double *cam_q, double *plane_z
     return OCHIP_OK;
 }
 
-// Trust-region Levenberg-Marquardt, monotonic steps (Ceres TrustRegionMinimizer +
-// LevenbergMarquardtStrategy semantics).  The control flow runs on the host
-// side of the library; every O(problem) operation is a kernel.
-int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, ochip_relax_summary *sum)
+} // extern "C"
+
+// The ground-plane flavour as an lm_model (relax_lm.hpp): evaluation = pair records (sharded + exchanged when
+// ochip_relax_set_shard is in effect), deterministic assembly into the dense system.
+namespace
 {
-    if (!p || !opt || !sum)
-        return OCHIP_EINVAL;
-    ochip_ctx *ctx = p->ctx;
-    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    *sum = ochip_relax_summary{};
-    const int n = p->n_tangent;
-    relax_dev &D = p->dev;
-    sum->num_parameters = n;
-    sum->num_residual_blocks = D.n_blocks + D.n_prior;
-    auto normalize = [&]() {
-        if (D.n_cams)
-            hipLaunchKernelGGL(normalize_kernel, dim3((D.n_cams + 255) / 256), dim3(256), 0, st, D, p->cam_optimize_dev);
-    };
-    if (D.n_blocks == 0 && D.n_prior == 0)
+struct plane_model final : lm_model
+{
+    ochip_relax_problem *p;
+    explicit plane_model(ochip_relax_problem *prob) : p(prob)
     {
-        sum->termination = OCHIP_RELAX_NO_PARAMETERS; // RelaxProblem::solve returns before Solve (:1398-1402)
-        return OCHIP_OK;
     }
-    if (n == 0)
+    int evaluate(bool with_jac, int which, double *cost) override
     {
-        sum->termination = OCHIP_RELAX_NO_PARAMETERS;
-        normalize();
-        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
-        return OCHIP_OK;
-    }
-    double h[8];
-    int hfail = 0;
-    auto evaluate = [&](bool with_jac, int which, double *cost) -> int {
+        ochip_ctx *ctx = p->ctx;
+        hipStream_t st = ctx->stream;
+        relax_dev &D = p->dev;
+        const int n = p->n_tangent;
         OCHIP_HIP(ctx, hipMemsetAsync(D.fail, 0, 4, st));
         hipEvent_t e0, e1;
         ochip_prof_begin(ctx, OCHIP_K_RELAX_EVAL, &e0, &e1);
@@ -1414,7 +1034,8 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
         if (p->exchange)
         {
             // the ranks' pair records (and failure flags) are all-gathered in place; from here on every rank holds
-            // the same arrays and runs the same deterministic assembly
+            // the same arrays and runs the same deterministic assembly.  A failed exchange is a hard error: the ranks
+            // would otherwise leave the solve on different schedules and the next collective would hang.
             OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
             const int xrc = p->exchange(p->exchange_user, D.pair_acc, with_jac ? (uint64_t)p->shard_chunk * ACC * 8 : 0,
                                         D.pair_cost, (uint64_t)p->shard_chunk * 8, p->fail_ranks, 4);
@@ -1423,57 +1044,48 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
         }
         if (with_jac)
         {
-            OCHIP_HIP(ctx, hipMemsetAsync(p->A, 0, (size_t)n * n * 8, st));
-            OCHIP_HIP(ctx, hipMemsetAsync(p->g, 0, (size_t)n * 8, st));
-            hipLaunchKernelGGL(relax_scatter_cam_kernel, dim3((D.n_cams + 255) / 256), dim3(256), 0, st, D, p->A, p->g,
+            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, (size_t)n * n * 8, st));
+            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.g, 0, (size_t)n * 8, st));
+            hipLaunchKernelGGL(relax_scatter_cam_kernel, dim3((D.n_cams + 255) / 256), dim3(256), 0, st, D, p->sys.A, p->sys.g,
                                n, p->cam_has_prior);
             if (D.n_pairs)
-                hipLaunchKernelGGL(relax_scatter_pair_kernel, dim3((D.n_pairs + 255) / 256), dim3(256), 0, st, D, p->A, n);
+                hipLaunchKernelGGL(relax_scatter_pair_kernel, dim3((D.n_pairs + 255) / 256), dim3(256), 0, st, D, p->sys.A, n);
         }
-        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(1), dim3(256), 0, st, D, p->A, p->g, n, p->cam_has_prior,
-                           p->scal, with_jac ? 1 : 0, which);
+        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(1), dim3(256), 0, st, D, p->sys.A, p->sys.g, n, p->cam_has_prior,
+                           p->sys.scal, with_jac ? 1 : 0, which);
         OCHIP_HIP(ctx, hipGetLastError());
-        OCHIP_HIP(ctx, hipMemcpyAsync(h, p->scal, 8, hipMemcpyDeviceToHost, st));
+        double h0 = 0;
+        OCHIP_HIP(ctx, hipMemcpyAsync(&h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
         std::vector<int32_t> hfails(p->shard_world, 0);
         OCHIP_HIP(ctx, hipMemcpyAsync(hfails.data(), p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
-        *cost = h[0];
-        hfail = 0;
+        *cost = h0;
+        int hfail = 0;
         for (int32_t f : hfails)
             hfail |= f;
         return hfail ? 1 : 0;
-    };
-    auto grad_and_diag = [&](double *gmax) -> int {
-        hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(1024), 0, st, p->A, p->g, p->diag_tmp, n, p->scal);
-        OCHIP_HIP(ctx, hipMemcpyAsync(h, p->scal, 64, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
-        *gmax = h[4];
-        return OCHIP_OK;
-    };
-
-    std::vector<double> diag(n), scale(n, 1.0), lmd(n), diagonal(n, 0.0);
-    double x_cost = 0, gmax = 0;
-    if (evaluate(true, 0, &x_cost) != 0)
-    {
-        sum->termination = OCHIP_RELAX_FAILURE;
-        normalize();
-        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
-        return OCHIP_OK;
     }
-    int rc = grad_and_diag(&gmax);
-    if (rc)
-        return rc;
-    OCHIP_HIP(ctx, hipMemcpy(diag.data(), p->diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; i++)
-        scale[i] = 1.0 / (1.0 + std::sqrt(diag[i])); // jacobi scaling, fixed from the first Jacobian
-    OCHIP_HIP(ctx, hipMemcpy(p->scale, scale.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-    // x_norm over the variable blocks
-    double x_norm = 0;
+    void launch_candidate(const double *y, const double *scale, double *scal) override
     {
+        hipLaunchKernelGGL(plane_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, scal);
+    }
+    void launch_accept() override
+    {
+        hipLaunchKernelGGL(lm_accept_kernel, dim3((p->n_cams * 4 + 255) / 256 + 1), dim3(256), 0, p->ctx->stream, p->dev);
+    }
+    void launch_normalize() override
+    {
+        if (p->dev.n_cams)
+            hipLaunchKernelGGL(normalize_kernel, dim3((p->dev.n_cams + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev,
+                               p->cam_optimize_dev);
+    }
+    int x_norm(double *out) override
+    {
+        ochip_ctx *ctx = p->ctx;
         std::vector<double> q((size_t)p->n_cams * 4);
-        double z[3];
-        OCHIP_HIP(ctx, hipMemcpy(q.data(), D.cam_q, q.size() * 8, hipMemcpyDeviceToHost));
-        OCHIP_HIP(ctx, hipMemcpy(z, D.plane + 6, 24, hipMemcpyDeviceToHost));
+        double z[3], x_norm = 0;
+        OCHIP_HIP(ctx, hipMemcpy(q.data(), p->dev.cam_q, q.size() * 8, hipMemcpyDeviceToHost));
+        OCHIP_HIP(ctx, hipMemcpy(z, p->dev.plane + 6, 24, hipMemcpyDeviceToHost));
         for (uint32_t c = 0; c < p->n_cams; c++)
             if (p->cam_t[c] >= 0)
                 for (int k = 0; k < 4; k++)
@@ -1481,137 +1093,42 @@ int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, oc
         for (int i = 0; i < 3; i++)
             if (p->z_t[i] >= 0)
                 x_norm += z[i] * z[i];
-        x_norm = std::sqrt(x_norm);
-    }
-    sum->initial_cost = x_cost;
-    sum->iterations = 1; // iteration 0
-    double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
-    bool reuse_diagonal = false;
-    int invalid = 0, iter = 0;
-    auto finish = [&](int term) {
-        sum->termination = term;
-        sum->final_cost = x_cost;
-        normalize();
-        (void)ochip_stream_wait(ctx, st);
+        *out = std::sqrt(x_norm);
         return OCHIP_OK;
-    };
-    if (gmax <= opt->gradient_tolerance)
-        return finish(OCHIP_RELAX_CONVERGENCE_GRADIENT);
-
-    while (true)
-    {
-        if (iter >= opt->max_num_iterations)
-            return finish(OCHIP_RELAX_NO_CONVERGENCE);
-        if (radius <= 1e-32)
-            return finish(OCHIP_RELAX_CONVERGENCE_RADIUS);
-        iter++;
-        sum->iterations++;
-        if (!reuse_diagonal)
-            for (int i = 0; i < n; i++)
-                diagonal[i] = std::min(std::max(diag[i] * scale[i] * scale[i], 1e-6), 1e32);
-        for (int i = 0; i < n; i++)
-        {
-            const double dd = std::sqrt(diagonal[i] / radius);
-            lmd[i] = dd * dd;
-        }
-        OCHIP_HIP(ctx, hipMemcpyAsync(p->lm_diag, lmd.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-        hipEvent_t e0, e1;
-        ochip_prof_begin(ctx, OCHIP_K_RELAX_SOLVE, &e0, &e1);
-        const size_t nn = (size_t)n * n;
-        hipLaunchKernelGGL(lm_build_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, p->A, p->g, p->scale,
-                           p->lm_diag, p->Wm, p->gs, n);
-        OCHIP_HIP(ctx, hipMemsetAsync(p->fail_chol, 0, 4, st));
-        {
-            const size_t need = (size_t)((n + NB - 1) / NB) * NB * NB;
-            if (need > p->linv_cap)
-            {
-                p->linv = nullptr;
-                p->linv_cap = 0;
-                if (dev_upload<double>(p, &p->linv, nullptr, need) != OCHIP_OK)
-                    return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the diagonal-block inverses failed");
-                p->linv_cap = need;
-            }
-        }
-        for (int k0 = 0; k0 < n; k0 += NB)
-        {
-            const int nb = std::min(NB, n - k0);
-            double *linv_k = p->linv + (size_t)(k0 / NB) * NB * NB;
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, p->Wm, n, k0, nb, p->fail_chol, linv_k);
-            // rows below the block that can be non-zero: its envelope, then the tail (plane unknowns + augmented row)
-            static const bool dense = getenv("OCHIP_CHOL_DENSE") != nullptr; // A/B knob: ignore the envelope
-            const int below = k0 + nb;
-            const int band_end = dense ? n : std::max(below, std::min(p->env_end[k0 / NB], p->tail_begin));
-            const int tail0 = std::max(dense ? n : p->tail_begin, below);
-            row_set rs{below, band_end - below, tail0, (band_end - below) + (n + 1 - tail0)};
-            const int tiles = (rs.total + 63) / 64;
-            hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, st, p->Wm, n, rs, k0, nb, linv_k);
-            if (below < n)
-                hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, st, p->Wm, n, rs, k0, nb);
-        }
-        // row n now holds y = L^-1 gs; back-substitute L' x = y block by block
-        OCHIP_HIP(ctx, hipMemcpyAsync(p->y, p->Wm + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->Wm, n, (const double *)p->linv, p->y,
-                           (const int *)p->first_col_dev, (n + NB - 1) / NB);
-        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(1024), 0, st, D, p->lm_diag, p->gs, p->scale, p->y, n, p->scal);
-        ochip_prof_end(ctx, OCHIP_K_RELAX_SOLVE, e0, e1);
-        OCHIP_HIP(ctx, hipGetLastError());
-        int cfail = 0;
-        OCHIP_HIP(ctx, hipMemcpyAsync(h, p->scal, 64, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(&cfail, p->fail_chol, 4, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
-        reuse_diagonal = true;
-        const double model_cost_change = h[1], step_norm = std::sqrt(h[2]), cand_norm = std::sqrt(h[3]);
-        const bool valid = !cfail && std::isfinite(model_cost_change) && model_cost_change > 0.0;
-        static const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
-        if (verbose)
-            fprintf(stderr, "[ochip relax] n=%d iter=%d cost=%.17g radius=%.6g model=%.17g step_norm=%.6g cfail=%d gmax=%.6g\n",
-                    n, iter, x_cost, radius, model_cost_change, step_norm, cfail, gmax);
-        if (!valid)
-        {
-            if (++invalid >= 5)
-                return finish(OCHIP_RELAX_FAILURE);
-            radius *= 0.5;
-            continue;
-        }
-        invalid = 0;
-        double cand_cost = 1.7976931348623157e308;
-        {
-            double c;
-            if (evaluate(false, 1, &c) == 0)
-                cand_cost = c;
-        }
-        if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance))
-            return finish(OCHIP_RELAX_CONVERGENCE_PARAMETER);
-        const double cost_change = x_cost - cand_cost;
-        if (std::abs(cost_change) <= opt->function_tolerance * x_cost)
-            return finish(OCHIP_RELAX_CONVERGENCE_FUNCTION);
-        const double rho = cost_change / model_cost_change;
-        if (rho > 1e-3)
-        {
-            hipLaunchKernelGGL(lm_accept_kernel, dim3((p->n_cams * 4 + 255) / 256 + 1), dim3(256), 0, st, D);
-            x_norm = cand_norm;
-            if (evaluate(true, 0, &x_cost) != 0)
-                return finish(OCHIP_RELAX_FAILURE);
-            rc = grad_and_diag(&gmax);
-            if (rc)
-                return rc;
-            OCHIP_HIP(ctx, hipMemcpy(diag.data(), p->diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost));
-            const double t = 2.0 * rho - 1.0;
-            radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
-            radius = std::min(1e16, radius);
-            decrease_factor = 2.0;
-            reuse_diagonal = false;
-            sum->successful_steps++;
-            if (gmax <= opt->gradient_tolerance)
-                return finish(OCHIP_RELAX_CONVERGENCE_GRADIENT);
-        }
-        else
-        {
-            radius = radius / decrease_factor;
-            decrease_factor *= 2.0;
-            sum->unsuccessful_steps++;
-        }
     }
+    int num_residual_blocks() override
+    {
+        return (int)(p->dev.n_blocks + p->dev.n_prior);
+    }
+};
+} // namespace
+
+extern "C"
+{
+
+int ochip_relax_solve(ochip_relax_problem *p, const ochip_relax_options *opt, ochip_relax_summary *sum)
+{
+    if (!p || !opt || !sum)
+        return OCHIP_EINVAL;
+    ochip_ctx *ctx = p->ctx;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    *sum = ochip_relax_summary{};
+    plane_model model(p);
+    sum->num_parameters = p->n_tangent;
+    sum->num_residual_blocks = model.num_residual_blocks();
+    if (p->dev.n_blocks == 0 && p->dev.n_prior == 0)
+    {
+        sum->termination = OCHIP_RELAX_NO_PARAMETERS; // RelaxProblem::solve returns before Solve (:1398-1402)
+        return OCHIP_OK;
+    }
+    if (p->n_tangent == 0)
+    {
+        sum->termination = OCHIP_RELAX_NO_PARAMETERS;
+        model.launch_normalize();
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
+        return OCHIP_OK;
+    }
+    return lm_solve(p->sys, model, opt, sum);
 }
 
 } // extern "C"

@@ -1,0 +1,1423 @@
+// libochip.so — relax (bundle adjustment) in its general form on the device (gfx950): ground mesh with per-vertex
+// heights, residual blocks of 2..5 rays, mesh priors, downward prior, shared intrinsics.  C ABI: ochip_relaxg_* (ochip.h).
+//
+// Replaces what ceres::Solver::Solve does for RelaxProblem::setupGroundMeshProblem / setupGroundPlaneProblem
+// (src/relax/relax_problem.cpp:61-120,1390-1420).  Data-parallel structure:
+//   * a RECORD per residual block: the packed upper triangle of its J'J (in the block's own columns), its J'r and its cost.
+//     Ray blocks are evaluated by (block, pass) lanes: a pass seeds forward-mode duals (Dual<3>) for one group of three
+//     columns (one camera's quaternion tangent, the three heights, f + principal point, the radial coefficients), the
+//     passes of a block sit in neighbouring lanes of one wavefront and meet in LDS, where the block's J'J entries are
+//     formed as dot products of Jacobian columns.  HBM-bound: one pass over the observation arrays, one record written.
+//   * ASSEMBLY without atomics: every unknown group (camera, vertex, intrinsic group) owns the rows of the dense
+//     system it stands for.  One wavefront per owner walks the owner's records in a fixed order and adds their
+//     contributions into an LDS strip that covers the columns the owner is coupled to (its band of the block envelope
+//     plus the dense tail), then stores the strip.  Sums are bitwise reproducible.
+//   * unknowns that couple to (nearly) everything - the heights of a coarse mesh, the shared intrinsics - form the dense
+//     TAIL of the system (last rows); their own rows are reduced by chunked owners + a merge.
+//   * the linear solve and the Levenberg-Marquardt loop are the shared ones (relax_lm.hip).
+#include "ctx.hpp"
+#include "dual.hpp"
+#include "relax_functors.hpp"
+#include "relax_lm.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+using namespace ochip;
+
+namespace
+{
+
+constexpr int W = 64;
+constexpr int NB = LM_NB;
+constexpr int MAXV = 11; // unknown groups of one record: <= 5 cameras + 3 vertices + focal, principal point, radial
+
+// record types: ray blocks = number of rays (2..5), + 8 with the shared lens model; then the priors
+enum : uint8_t
+{
+    T_INTR = 8,
+    T_DOWN = 16,
+    T_DIFF = 17,
+    T_ANCHOR = 18,
+    T_SMOOTH = 19,
+    T_MONO = 20
+};
+
+__host__ __device__ inline int rec_dim(int type)
+{
+    if (type < T_DOWN)
+        return 3 * (type & 7) + 3 + ((type & T_INTR) ? 6 : 0);
+    return type == T_DOWN ? 3 : type == T_DIFF ? 2 : type == T_ANCHOR ? 1 : type == T_SMOOTH ? 4 : 3;
+}
+__host__ __device__ inline int rec_nvars(int type)
+{
+    if (type < T_DOWN)
+        return (type & 7) + 3 + ((type & T_INTR) ? 3 : 0);
+    return type == T_DOWN ? 1 : type == T_DIFF ? 2 : type == T_ANCHOR ? 1 : type == T_SMOOTH ? 4 : 1;
+}
+// local column -> (slot of the record's unknown group, offset inside the group)
+__host__ __device__ inline void rec_col(int type, int c, int *slot, int *off)
+{
+    if (type < T_DOWN)
+    {
+        const int N = type & 7;
+        if (c < 3 * N)
+        {
+            *slot = c / 3;
+            *off = c % 3;
+        }
+        else if (c < 3 * N + 3)
+        {
+            *slot = N + (c - 3 * N);
+            *off = 0;
+        }
+        else if (c == 3 * N + 3)
+        {
+            *slot = N + 3;
+            *off = 0;
+        }
+        else if (c < 3 * N + 6)
+        {
+            *slot = N + 4;
+            *off = c - (3 * N + 4);
+        }
+        else
+        {
+            *slot = N + 5;
+            *off = c - (3 * N + 6);
+        }
+        return;
+    }
+    if (type == T_DOWN || type == T_MONO)
+    {
+        *slot = 0;
+        *off = c;
+        return;
+    }
+    *slot = c; // DIFF, ANCHOR, SMOOTH: one column per vertex
+    *off = 0;
+}
+// first local column of a slot
+__host__ __device__ inline int rec_slot_col(int type, int slot)
+{
+    if (type < T_DOWN)
+    {
+        const int N = type & 7;
+        if (slot < N)
+            return 3 * slot;
+        if (slot < N + 3)
+            return 3 * N + (slot - N);
+        return slot == N + 3 ? 3 * N + 3 : slot == N + 4 ? 3 * N + 4 : 3 * N + 6;
+    }
+    if (type == T_DOWN || type == T_MONO)
+        return 0;
+    return slot;
+}
+__host__ __device__ inline int tri_idx(int i, int j, int d) // i <= j, packed upper triangle of a d x d matrix
+{
+    return i * d - i * (i - 1) / 2 + (j - i);
+}
+
+struct g_dev
+{
+    uint32_t n_cams, n_verts;
+    double *cam_pos, *cam_q, *cam_q2;
+    double *vert_xy, *vert_z, *vert_z2, *vert_z0;
+    double *model, *model2; // 8 each
+    int32_t *var_t;         // first unknown of a group or -1
+    uint8_t *var_ts;        // its number of unknowns
+    // ray blocks, sorted by type
+    uint32_t *blk_ray_off, *ray_cam, *blk_tri;
+    double *ray_dir, *ray_px;
+    // records
+    uint32_t n_rec;
+    uint8_t *rec_type;
+    uint64_t *rec_off;
+    uint32_t *rec_var; // [n_rec][MAXV]
+    double *rec_data, *rec_cost;
+    // priors
+    uint32_t n_down, n_diff, n_anchor, n_smooth, n_mono, prior_base; // record ids: prior_base + [down | diff | anchor | smooth | mono]
+    uint32_t *down_cam, *diff_v, *smooth_v;
+    double down_w, diff_w, anchor_w, smooth_w, mono_w, mono_rmax, huber_a, f_lo, f_hi;
+    uint8_t n_k_free;
+    int32_t *fail;
+};
+
+// ---- ray blocks ------------------------------------------------------------------------------------------------
+template <typename T, int N, bool INTR>
+__device__ __forceinline__ bool ray_block_residuals(const g_dev &P, uint32_t blk, int which, int pass, T *res)
+{
+    // pass (only for T = Dual<3>): which group of three columns carries the dual parts: 0..N-1 camera, N heights,
+    // N + 1 focal + principal point, N + 2 radial; -1: none
+    const double *Q = which ? P.cam_q2 : P.cam_q;
+    const double *Z = which ? P.vert_z2 : P.vert_z;
+    const double *M = which ? P.model2 : P.model;
+    const uint32_t r0 = P.blk_ray_off[blk];
+    T q[N][4];
+    Vec3T<T> ray[N];
+    double loc[N][3];
+    T z[3];
+    double txy[6];
+    for (int j = 0; j < 3; j++)
+    {
+        const uint32_t v = P.blk_tri[3 * (size_t)blk + j];
+        txy[2 * j] = P.vert_xy[2 * (size_t)v];
+        txy[2 * j + 1] = P.vert_xy[2 * (size_t)v + 1];
+        z[j] = T(Z[v]);
+    }
+    T m[8];
+    if (INTR)
+        for (int k = 0; k < 8; k++)
+            m[k] = T(M[k]);
+    if constexpr (!std::is_same<T, double>::value)
+    {
+        if (pass == N)
+            for (int j = 0; j < 3; j++)
+                z[j].v[j] = 1.0;
+        if (INTR && pass == N + 1)
+            for (int j = 0; j < 3; j++)
+                m[j].v[j] = 1.0;
+        if (INTR && pass == N + 2)
+            for (int j = 0; j < 3; j++)
+                m[3 + j].v[j] = 1.0;
+    }
+    for (int i = 0; i < N; i++)
+    {
+        const uint32_t c = P.ray_cam[r0 + i];
+        const double *qc = Q + 4 * (size_t)c;
+        if constexpr (!std::is_same<T, double>::value)
+        {
+            if (pass == i)
+                gseed_quat(qc, q[i]);
+            else
+                for (int k = 0; k < 4; k++)
+                    q[i][k] = T(qc[k]);
+        }
+        else
+            for (int k = 0; k < 4; k++)
+                q[i][k] = qc[k];
+        for (int k = 0; k < 3; k++)
+            loc[i][k] = P.cam_pos[3 * (size_t)c + k];
+        if (INTR)
+            ray[i] = gimage_to_3d_inverse<T>(P.ray_px + 2 * (size_t)(r0 + i), m);
+        else
+        {
+            const double *d = P.ray_dir + 3 * (size_t)(r0 + i);
+            ray[i] = {T(d[0]), T(d[1]), T(d[2])};
+        }
+    }
+    return gmulti_ray_residuals<T, N>(q, ray, loc, txy, z, res);
+}
+
+// Huber loss + Triggs corrector of a block with squared norm s (rho'' <= 0 for Huber: plain sqrt(rho') scaling)
+__device__ __forceinline__ void huber(double s, double a, bool with_loss, double *rho1, double *cost)
+{
+    *rho1 = 1.0;
+    *cost = 0.5 * s;
+    if (with_loss && s > a * a)
+    {
+        const double rn = sqrt(s);
+        *rho1 = fmax(2.2250738585072014e-308, a / rn);
+        *cost = 0.5 * (2.0 * a * rn - a * a);
+    }
+}
+
+// cost of every block of one type at state `which`; one thread per block
+template <int N, bool INTR> __global__ __launch_bounds__(W) void ray_cost_kernel(g_dev P, uint32_t first, uint32_t count, int which)
+{
+    const uint32_t i = blockIdx.x * W + threadIdx.x;
+    if (i >= count)
+        return;
+    const uint32_t blk = first + i;
+    double r[3 * N];
+    bool failed = !ray_block_residuals<double, N, INTR>(P, blk, which, -1, r);
+    double s = 0;
+    for (int k = 0; k < 3 * N; k++)
+    {
+        s += r[k] * r[k];
+        if (!(r[k] - r[k] == 0.0))
+            failed = true;
+    }
+    double rho1, cost;
+    huber(s, P.huber_a, N == 2, &rho1, &cost);
+    P.rec_cost[blk] = cost;
+    if (failed)
+        atomicOr(P.fail, 1);
+}
+
+// records of every block of one type at the current state: (block, pass) lanes
+template <int N, bool INTR> __global__ __launch_bounds__(W) void ray_record_kernel(g_dev P, uint32_t first, uint32_t count)
+{
+    constexpr int PASSES = N + 1 + (INTR ? 2 : 0);
+    constexpr int G = W / PASSES; // blocks per wavefront
+    constexpr int D = 3 * N + 3 + (INTR ? 6 : 0);
+    constexpr int R = 3 * N;
+    constexpr int TRI = D * (D + 1) / 2;
+    __shared__ double Jt[G][D][R];
+    __shared__ uint16_t lut[TRI];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < D; i += W)
+        for (int j = i; j < D; j++)
+            lut[tri_idx(i, j, D)] = (uint16_t)((i << 8) | j);
+    const int g = lane / PASSES, pass = lane % PASSES;
+    const uint32_t bi = blockIdx.x * G + g;
+    const bool active = g < G && bi < count;
+    const uint32_t blk = first + (active ? bi : 0);
+    double r[R];
+    double rho1 = 1.0, cost = 0.0;
+    bool failed = false;
+    if (active)
+    {
+        Dual<3> rd[R];
+        if (!ray_block_residuals<Dual<3>, N, INTR>(P, blk, 0, pass, rd))
+            failed = true;
+        double s = 0;
+        for (int k = 0; k < R; k++)
+        {
+            r[k] = rd[k].a;
+            s += r[k] * r[k];
+            if (!(r[k] - r[k] == 0.0))
+                failed = true;
+        }
+        huber(s, P.huber_a, N == 2, &rho1, &cost);
+        const int c0 = 3 * pass; // the pass order is the column order: cameras, heights, (f, pp), radial
+        for (int cidx = 0; cidx < 3; cidx++)
+            for (int k = 0; k < R; k++)
+            {
+                const double v = rd[k].v[cidx];
+                Jt[g][c0 + cidx][k] = v;
+                if (!(v - v == 0.0))
+                    failed = true;
+            }
+    }
+    __syncthreads();
+    if (active)
+    {
+        double *o = P.rec_data + P.rec_off[blk];
+        for (int e = pass; e < TRI + D; e += PASSES)
+        {
+            double v = 0;
+            if (e < TRI)
+            {
+                const int i = lut[e] >> 8, j = lut[e] & 255;
+                for (int k = 0; k < R; k++)
+                    v += Jt[g][i][k] * Jt[g][j][k];
+            }
+            else
+            {
+                const int i = e - TRI;
+                for (int k = 0; k < R; k++)
+                    v += Jt[g][i][k] * r[k];
+            }
+            o[e] = v * rho1;
+        }
+        if (pass == 0)
+            P.rec_cost[blk] = cost;
+    }
+    if (failed)
+        atomicOr(P.fail, 1);
+}
+
+// ---- priors: one thread per prior --------------------------------------------------------------------------------
+__global__ void prior_kernel(g_dev P, int which, int with_jac)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_all = P.n_down + P.n_diff + P.n_anchor + P.n_smooth + P.n_mono;
+    if (i >= n_all)
+        return;
+    const uint32_t rec = P.prior_base + i;
+    const double *Q = which ? P.cam_q2 : P.cam_q;
+    const double *Z = which ? P.vert_z2 : P.vert_z;
+    const double *M = which ? P.model2 : P.model;
+    double *o = with_jac ? P.rec_data + P.rec_off[rec] : nullptr;
+    double cost = 0;
+    bool failed = false;
+    uint32_t k = i;
+    if (k < P.n_down)
+    {
+        double r, j3[3];
+        gdownward_prior(Q + 4 * (size_t)P.down_cam[k], P.down_w, &r, j3);
+        cost = 0.5 * r * r;
+        if (with_jac)
+        {
+            int e = 0;
+            for (int a = 0; a < 3; a++)
+                for (int b = a; b < 3; b++)
+                    o[e++] = j3[a] * j3[b];
+            for (int a = 0; a < 3; a++)
+                o[6 + a] = j3[a] * r;
+        }
+        failed = !(r - r == 0.0);
+    }
+    else if ((k -= P.n_down) < P.n_diff)
+    {
+        const double w = P.diff_w;
+        const double r = w * (Z[P.diff_v[2 * k]] - Z[P.diff_v[2 * k + 1]]);
+        cost = 0.5 * r * r;
+        if (with_jac)
+        {
+            o[0] = w * w;
+            o[1] = -w * w;
+            o[2] = w * w;
+            o[3] = w * r;
+            o[4] = -w * r;
+        }
+    }
+    else if ((k -= P.n_diff) < P.n_anchor)
+    {
+        const double w = P.anchor_w;
+        const double r = w * (Z[k] - P.vert_z0[k]);
+        cost = 0.5 * r * r;
+        if (with_jac)
+        {
+            o[0] = w * w;
+            o[1] = w * r;
+        }
+    }
+    else if ((k -= P.n_anchor) < P.n_smooth)
+    {
+        double xy[8];
+        Dual<4> z[4];
+        for (int a = 0; a < 4; a++)
+        {
+            const uint32_t v = P.smooth_v[4 * k + a];
+            xy[2 * a] = P.vert_xy[2 * (size_t)v];
+            xy[2 * a + 1] = P.vert_xy[2 * (size_t)v + 1];
+            z[a] = Dual<4>(Z[v]);
+            z[a].v[a] = 1.0;
+        }
+        const Dual<4> r = gadjacent_triangle_normal<Dual<4>>(xy, z, P.smooth_w);
+        cost = 0.5 * r.a * r.a;
+        if (with_jac)
+        {
+            int e = 0;
+            for (int a = 0; a < 4; a++)
+                for (int b = a; b < 4; b++)
+                    o[e++] = r.v[a] * r.v[b];
+            for (int a = 0; a < 4; a++)
+            {
+                o[10 + a] = r.v[a] * r.a;
+                if (!(r.v[a] - r.v[a] == 0.0))
+                    failed = true;
+            }
+        }
+        failed |= !(r.a - r.a == 0.0);
+    }
+    else
+    {
+        // DistortionMonotonicityCost (relax_cost_function.hpp:157-185): 10 hinge residuals on d(r_d)/dr
+        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < 10; t++)
+        {
+            const double rr = P.mono_rmax * (t + 1.0) / 10;
+            const double r2 = rr * rr, r4 = r2 * r2, r6 = r4 * r2;
+            const double deriv = 1.0 + 3.0 * M[3] * r2 + 5.0 * M[4] * r4 + 7.0 * M[5] * r6;
+            if (deriv < 0.0)
+            {
+                const double res = P.mono_w * (-deriv);
+                const double j[3] = {-P.mono_w * 3.0 * r2, -P.mono_w * 5.0 * r4, -P.mono_w * 7.0 * r6};
+                cost += 0.5 * res * res;
+                int e = 0;
+                for (int a = 0; a < 3; a++)
+                    for (int b = a; b < 3; b++)
+                        acc[e++] += j[a] * j[b];
+                for (int a = 0; a < 3; a++)
+                    acc[6 + a] += j[a] * res;
+            }
+        }
+        if (with_jac)
+            for (int e = 0; e < 9; e++)
+                o[e] = acc[e];
+    }
+    P.rec_cost[rec] = cost;
+    if (failed)
+        atomicOr(P.fail, 1);
+}
+
+// total cost: fixed-order strided sums + tree, one workgroup.  scal[0] = cost
+__global__ __launch_bounds__(1024) void cost_reduce_kernel(const double *rec_cost, uint32_t n, double *scal)
+{
+    __shared__ double sh[1024];
+    const int t = threadIdx.x;
+    double v = 0;
+    for (uint32_t i = t; i < n; i += 1024)
+        v += rec_cost[i];
+    sh[t] = v;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1)
+    {
+        if (t < s)
+            sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    if (t == 0)
+        scal[0] = sh[0];
+}
+
+// ---- assembly ------------------------------------------------------------------------------------------------------
+struct work_item
+{
+    uint32_t var;      // owner
+    uint32_t lo, hi;   // range of var_rec entries
+    int32_t col_lo;    // band strip = columns [col_lo, col_hi)  (tail owners: empty)
+    int32_t col_hi;
+    int32_t partial;   // >= 0: store the strip as partial #partial of a tail owner (tail columns only)
+};
+
+// One wavefront per work item.  strip[a][x]: a < rows of the owner, x over [band strip | tail | gradient].
+__global__ __launch_bounds__(W) void gather_kernel(g_dev P, const work_item *items, const uint32_t *var_rec, double *A, double *g,
+                                                   int n, int tail_begin, double *partials, int strip_cap)
+{
+    extern __shared__ double strip[];
+    __shared__ int16_t colmap[W][24];
+    __shared__ uint64_t roff[W];
+    __shared__ uint8_t rdim[W], rlo[W];
+    const int lane = threadIdx.x;
+    const work_item it = items[blockIdx.x];
+    const int tu = P.var_t[it.var], su = P.var_ts[it.var];
+    const int T = n - tail_begin;
+    const int wb = it.col_hi - it.col_lo; // band part
+    const int ws = wb + T + 1;            // + tail + gradient
+    for (int i = lane; i < su * ws; i += W)
+        strip[i] = 0.0;
+    __syncthreads();
+    for (uint32_t e0 = it.lo; e0 < it.hi; e0 += W)
+    {
+        const uint32_t cnt = min((uint32_t)W, it.hi - e0);
+        // phase A: one record per lane: where do its columns land in the strip?
+        if ((uint32_t)lane < cnt)
+        {
+            const uint32_t ent = var_rec[e0 + lane];
+            const uint32_t r = ent >> 4, slot = ent & 15;
+            const int type = P.rec_type[r], d = rec_dim(type);
+            roff[lane] = P.rec_off[r];
+            rdim[lane] = (uint8_t)d;
+            rlo[lane] = (uint8_t)rec_slot_col(type, slot);
+            int cached_slot = -1, tv = -1, tsz = 0;
+            for (int c = 0; c < d; c++)
+            {
+                int s, off;
+                rec_col(type, c, &s, &off);
+                if (s != cached_slot)
+                {
+                    const uint32_t v = P.rec_var[(size_t)r * MAXV + s];
+                    tv = P.var_t[v];
+                    tsz = P.var_ts[v];
+                    cached_slot = s;
+                }
+                int idx = -1;
+                if (tv >= 0 && off < tsz)
+                {
+                    const int x = tv + off;
+                    if (x >= tail_begin)
+                        idx = wb + (x - tail_begin);
+                    else if (x >= it.col_lo && x < it.col_hi)
+                        idx = x - it.col_lo;
+                }
+                colmap[lane][c] = (int16_t)idx;
+            }
+        }
+        __syncthreads();
+        // phase B: the records one after the other (fixed order), their entries spread over the lanes
+        for (uint32_t i = 0; i < cnt; i++)
+        {
+            const int d = rdim[i], lo_u = rlo[i];
+            const double *rec = P.rec_data + roff[i];
+            const int tri = d * (d + 1) / 2;
+            for (int l = lane; l < su * (d + 1); l += W)
+            {
+                const int a = l / (d + 1), c = l % (d + 1);
+                const int row = lo_u + a;
+                if (c == d)
+                    strip[a * ws + ws - 1] += rec[tri + row];
+                else
+                {
+                    const int idx = colmap[i][c];
+                    if (idx >= 0)
+                        strip[a * ws + idx] += rec[row <= c ? tri_idx(row, c, d) : tri_idx(c, row, d)];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (it.partial >= 0)
+    {
+        // tail owner: its tail columns and gradient go to the partial buffer [partial][su][T + 1]
+        double *o = partials + (size_t)it.partial * 3 * (T + 1);
+        for (int i = lane; i < su * (T + 1); i += W)
+        {
+            const int a = i / (T + 1), x = i % (T + 1);
+            o[a * (T + 1) + x] = strip[a * ws + wb + x];
+        }
+        return;
+    }
+    for (int a = 0; a < su; a++)
+    {
+        double *row = A + (size_t)(tu + a) * n;
+        for (int x = lane; x < wb; x += W)
+            row[it.col_lo + x] = strip[a * ws + x];
+        for (int x = lane; x < T; x += W)
+        {
+            const double v = strip[a * ws + wb + x];
+            row[tail_begin + x] = v;
+            A[(size_t)(tail_begin + x) * n + tu + a] = v; // the tail rows' band part is the mirror image
+        }
+        if (lane == 0)
+            g[tu + a] = strip[a * ws + ws - 1];
+    }
+}
+
+// tail rows: sum of the chunk partials in chunk order.  One workgroup per tail owner.
+__global__ void tail_merge_kernel(g_dev P, const uint32_t *tail_var, const uint32_t *tail_first, const uint32_t *tail_count,
+                                  const double *partials, double *A, double *g, int n, int tail_begin)
+{
+    const uint32_t u = tail_var[blockIdx.x];
+    const int tu = P.var_t[u], su = P.var_ts[u];
+    const int T = n - tail_begin;
+    for (int i = threadIdx.x; i < su * (T + 1); i += blockDim.x)
+    {
+        const int a = i / (T + 1), x = i % (T + 1);
+        double v = 0;
+        for (uint32_t c = 0; c < tail_count[blockIdx.x]; c++)
+            v += partials[(size_t)(tail_first[blockIdx.x] + c) * 3 * (T + 1) + a * (T + 1) + x];
+        if (x == T)
+            g[tu + a] = v;
+        else
+            A[(size_t)(tu + a) * n + tail_begin + x] = v;
+    }
+}
+
+// ---- state -------------------------------------------------------------------------------------------------------
+// candidate = x (+) delta, delta = -y .* scale.  One workgroup.  scal[2] = |x - candidate|^2, scal[3] = |candidate|^2
+__global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const double *scale, const double *y, double *scal)
+{
+    __shared__ double sh[1024];
+    const int t = threadIdx.x;
+    double sn = 0, xn = 0;
+    for (uint32_t c = t; c < P.n_cams; c += 1024)
+    {
+        const int tc = P.var_t[c];
+        const double *q = P.cam_q + (size_t)c * 4;
+        double *o = P.cam_q2 + (size_t)c * 4;
+        if (tc < 0)
+        {
+            for (int k = 0; k < 4; k++)
+                o[k] = q[k];
+            continue;
+        }
+        double d[3];
+        for (int k = 0; k < 3; k++)
+            d[k] = -y[tc + k] * scale[tc + k];
+        const double nrm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (nrm == 0.0)
+        {
+            for (int k = 0; k < 4; k++)
+                o[k] = q[k];
+        }
+        else
+        {
+            const double s = sin(nrm) / nrm;
+            const double dx = s * d[0], dy = s * d[1], dz = s * d[2], dw = cos(nrm);
+            const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+            o[3] = dw * qw - dx * qx - dy * qy - dz * qz;
+            o[0] = dw * qx + dx * qw + dy * qz - dz * qy;
+            o[1] = dw * qy + dy * qw + dz * qx - dx * qz;
+            o[2] = dw * qz + dz * qw + dx * qy - dy * qx;
+        }
+        for (int k = 0; k < 4; k++)
+        {
+            sn += (q[k] - o[k]) * (q[k] - o[k]);
+            xn += o[k] * o[k];
+        }
+    }
+    for (uint32_t v = t; v < P.n_verts; v += 1024)
+    {
+        const int tz = P.var_t[P.n_cams + v];
+        const double z0 = P.vert_z[v];
+        const double z1 = tz >= 0 ? z0 + (-y[tz] * scale[tz]) : z0;
+        P.vert_z2[v] = z1;
+        if (tz >= 0)
+        {
+            sn += (z0 - z1) * (z0 - z1);
+            xn += z1 * z1;
+        }
+    }
+    if (t == 0)
+    {
+        // shared lens model: focal (projected onto its bounds, ceres ParameterBlock::Plus), principal point, radial
+        const uint32_t vf = P.n_cams + P.n_verts;
+        for (int k = 0; k < 8; k++)
+            P.model2[k] = P.model[k];
+        const int tf = P.var_t[vf], tp = P.var_t[vf + 1], tk = P.var_t[vf + 2];
+        if (tf >= 0)
+        {
+            double f = P.model[0] + (-y[tf] * scale[tf]);
+            f = fmin(fmax(f, P.f_lo), P.f_hi);
+            P.model2[0] = f;
+            sn += (P.model[0] - f) * (P.model[0] - f);
+            xn += f * f;
+        }
+        if (tp >= 0)
+            for (int k = 0; k < 2; k++)
+            {
+                const double v = P.model[1 + k] + (-y[tp + k] * scale[tp + k]);
+                P.model2[1 + k] = v;
+                sn += (P.model[1 + k] - v) * (P.model[1 + k] - v);
+                xn += v * v;
+            }
+        if (tk >= 0)
+            for (int k = 0; k < 3; k++) // SubsetManifold: the trailing coefficients stay, but count in |x|
+            {
+                const double v = k < P.n_k_free ? P.model[3 + k] + (-y[tk + k] * scale[tk + k]) : P.model[3 + k];
+                P.model2[3 + k] = v;
+                sn += (P.model[3 + k] - v) * (P.model[3 + k] - v);
+                xn += v * v;
+            }
+    }
+    for (int q = 0; q < 2; q++)
+    {
+        sh[t] = q == 0 ? sn : xn;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1)
+        {
+            if (t < s)
+                sh[t] += sh[t + s];
+            __syncthreads();
+        }
+        if (t == 0)
+            scal[2 + q] = sh[0];
+        __syncthreads();
+    }
+}
+
+__global__ void general_accept_kernel(g_dev P)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.n_cams * 4)
+        P.cam_q[i] = P.cam_q2[i];
+    if (i < P.n_verts)
+        P.vert_z[i] = P.vert_z2[i];
+    if (i < 8)
+        P.model[i] = P.model2[i];
+}
+
+// p.second->orientation.normalize() for every node of _nodes_to_optimize (relax_problem.cpp:1410-1413)
+__global__ void general_normalize_kernel(g_dev P, const uint8_t *cam_optimize)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.n_cams || !cam_optimize[c])
+        return;
+    double *q = P.cam_q + (size_t)c * 4;
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int k = 0; k < 4; k++)
+        q[k] = q[k] / n;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct ochip_relaxg_problem
+{
+    ochip_ctx *ctx = nullptr;
+    g_dev dev{};
+    std::vector<std::pair<void *, size_t>> allocs;
+    lm_system sys;
+    uint32_t n_cams = 0, n_verts = 0, n_vars = 0, n_blocks = 0, n_rec = 0;
+    bool structure_only = false;
+    std::vector<uint8_t> cam_optimize, vert_optimize;
+    uint8_t opt_f = 0, opt_pp = 0, n_k_free = 0;
+    bool has_intr_blocks = false;
+    // host copies used by the ordering
+    std::vector<double> cam_xy, vert_xy;
+    std::vector<uint8_t> rec_type;
+    std::vector<uint32_t> rec_var; // [n_rec][MAXV]
+    std::vector<uint32_t> var_rec_off, var_rec; // CSR unknown group -> (record << 4 | slot)
+    std::vector<int32_t> var_t;
+    std::vector<uint8_t> var_ts;
+    int n_tangent = 0, tail_begin = 0;
+    // per block type: first record and count
+    struct type_range
+    {
+        int type;
+        uint32_t first, count;
+    };
+    std::vector<type_range> ranges;
+    // assembly plan (rebuilt by assign)
+    uint32_t n_items = 0, n_tail_owners = 0, n_partials = 0;
+    int max_strip = 0;
+    work_item *items_dev = nullptr;
+    uint32_t *var_rec_dev = nullptr, *tail_var_dev = nullptr, *tail_first_dev = nullptr, *tail_count_dev = nullptr;
+    double *partials_dev = nullptr;
+    uint8_t *cam_optimize_dev = nullptr;
+};
+
+namespace
+{
+
+constexpr int STRIP_CAP = 2300;       // band + tail columns one owner's LDS strip may span (3 rows x 2301 doubles = 55 KB)
+constexpr uint32_t TAIL_CHUNK = 4096; // records per chunk of a tail owner
+constexpr uint32_t DENSE_VERTS = 8;   // a mesh of at most this many vertices is dense (plane, minimal mesh): tail
+
+template <typename T> int up(ochip_relaxg_problem *p, T **dst, const T *src, size_t n)
+{
+    return lm_dev_upload(p->ctx, &p->allocs, dst, src, n);
+}
+template <typename T> int up(ochip_relaxg_problem *p, T **dst, const std::vector<T> &v)
+{
+    return lm_dev_upload(p->ctx, &p->allocs, dst, v.data(), v.size());
+}
+
+// Which unknown groups are variable, in which order, with which envelope; and the assembly plan.
+int assign(ochip_relaxg_problem *p)
+{
+    const uint32_t nc = p->n_cams, nv = p->n_verts, vf = nc + nv;
+    std::vector<char> variable(p->n_vars, 0), is_tail(p->n_vars, 0);
+    auto has_records = [&](uint32_t u) { return p->var_rec_off[u + 1] > p->var_rec_off[u]; };
+    for (uint32_t c = 0; c < nc; c++)
+        variable[c] = p->cam_optimize[c] && !p->structure_only && has_records(c);
+    uint32_t n_var_verts = 0;
+    for (uint32_t v = 0; v < nv; v++)
+    {
+        variable[nc + v] = p->vert_optimize[v] && has_records(nc + v);
+        n_var_verts += variable[nc + v];
+    }
+    variable[vf] = p->opt_f && !p->structure_only && has_records(vf);
+    variable[vf + 1] = p->opt_pp && !p->structure_only && has_records(vf + 1);
+    variable[vf + 2] = p->n_k_free > 0 && !p->structure_only && has_records(vf + 2);
+    for (uint32_t k = 0; k < 3; k++)
+        is_tail[vf + k] = 1;
+    if (n_var_verts <= DENSE_VERTS)
+        for (uint32_t v = 0; v < nv; v++)
+            is_tail[nc + v] = 1;
+    auto size_of = [&](uint32_t u) -> int { return u < nc ? 3 : u < vf ? 1 : u == vf ? 1 : u == vf + 1 ? 2 : (int)p->n_k_free; };
+
+    // band order: along the long axis of the bounding box of the band unknowns (cameras and vertices live in the same
+    // ground coordinates; an unknown is coupled to what lies within a camera footprint of it)
+    std::vector<uint32_t> band, tail;
+    std::vector<int> lo, hi;
+    for (int round = 0; round < 4; round++)
+    {
+        band.clear();
+        tail.clear();
+        for (uint32_t u = 0; u < p->n_vars; u++)
+            if (variable[u])
+                (is_tail[u] ? tail : band).push_back(u);
+        auto xy = [&](uint32_t u, int a) { return u < nc ? p->cam_xy[2 * u + a] : p->vert_xy[2 * (u - nc) + a]; };
+        double mn[2] = {1e300, 1e300}, mx[2] = {-1e300, -1e300};
+        for (uint32_t u : band)
+            for (int a = 0; a < 2; a++)
+            {
+                mn[a] = std::min(mn[a], xy(u, a));
+                mx[a] = std::max(mx[a], xy(u, a));
+            }
+        const int ax = (mx[0] - mn[0]) >= (mx[1] - mn[1]) ? 0 : 1;
+        std::stable_sort(band.begin(), band.end(), [&](uint32_t a, uint32_t b) {
+            const double ka = xy(a, ax), kb = xy(b, ax);
+            if (ka != kb)
+                return ka < kb;
+            return xy(a, 1 - ax) < xy(b, 1 - ax);
+        });
+        p->var_t.assign(p->n_vars, -1);
+        p->var_ts.assign(p->n_vars, 0);
+        int t = 0;
+        for (uint32_t u : band)
+        {
+            p->var_t[u] = t;
+            p->var_ts[u] = (uint8_t)size_of(u);
+            t += size_of(u);
+        }
+        p->tail_begin = t;
+        for (uint32_t u : tail)
+        {
+            p->var_t[u] = t;
+            p->var_ts[u] = (uint8_t)size_of(u);
+            t += size_of(u);
+        }
+        p->n_tangent = t;
+        // coupling ranges of the band unknowns: over every record, the span of its band unknowns
+        lo.assign(p->n_vars, INT32_MAX);
+        hi.assign(p->n_vars, -1);
+        for (uint32_t r = 0; r < p->n_rec; r++)
+        {
+            const int nvr = rec_nvars(p->rec_type[r]);
+            int rlo = INT32_MAX, rhi = -1;
+            for (int s = 0; s < nvr; s++)
+            {
+                const uint32_t u = p->rec_var[(size_t)r * MAXV + s];
+                if (p->var_t[u] >= 0 && !is_tail[u])
+                {
+                    rlo = std::min(rlo, p->var_t[u]);
+                    rhi = std::max(rhi, p->var_t[u] + p->var_ts[u]);
+                }
+            }
+            if (rhi < 0)
+                continue;
+            for (int s = 0; s < nvr; s++)
+            {
+                const uint32_t u = p->rec_var[(size_t)r * MAXV + s];
+                if (p->var_t[u] >= 0 && !is_tail[u])
+                {
+                    lo[u] = std::min(lo[u], rlo);
+                    hi[u] = std::max(hi[u], rhi);
+                }
+            }
+        }
+        // an unknown coupled to more columns than an LDS strip holds joins the tail; then order again
+        const int T = p->n_tangent - p->tail_begin;
+        bool moved = false;
+        for (uint32_t u : band)
+            if (hi[u] - lo[u] + T > STRIP_CAP)
+            {
+                is_tail[u] = 1;
+                moved = true;
+            }
+        if (!moved)
+            break;
+        if (round == 3)
+            return ochip_fail(p->ctx, OCHIP_EINVAL, "relax: the coupling structure does not fit the assembly strips");
+    }
+    const int n = p->n_tangent, T = n - p->tail_begin;
+    if (T > 1024)
+        return ochip_fail(p->ctx, OCHIP_EINVAL, "relax: %d dense unknowns (limit 1024)", T);
+
+    // block envelope for the factorisation
+    lm_envelope env;
+    {
+        const int band_end = p->tail_begin;
+        const int n_all = std::max(n, 1), nblk = (n_all + NB - 1) / NB;
+        env.tail_begin = band_end;
+        env.env_end.assign(nblk, 0);
+        for (int k = 0; k < nblk; k++)
+            env.env_end[k] = std::min((k + 1) * NB, band_end);
+        for (uint32_t u : band)
+            for (int k = p->var_t[u] / NB; k <= (p->var_t[u] + p->var_ts[u] - 1) / NB; k++)
+                env.env_end[k] = std::max(env.env_end[k], hi[u]);
+        for (int k = 1; k < nblk; k++)
+            env.env_end[k] = std::max(env.env_end[k], std::min(env.env_end[k - 1], band_end));
+        env.first_col.assign(nblk, 0);
+        for (int k = 0; k < nblk; k++)
+        {
+            const int k0 = k * NB;
+            int first = k0;
+            if (k0 + NB > band_end)
+                first = 0;
+            else
+                for (int c = 0; c < k; c++)
+                    if (env.env_end[c] > k0)
+                    {
+                        first = c * NB;
+                        break;
+                    }
+            env.first_col[k] = first;
+        }
+        if (getenv("OCHIP_RELAX_VERBOSE"))
+        {
+            long bandsum = 0;
+            for (int k = 0; k < nblk; k++)
+                bandsum += std::max(0, env.env_end[k] - (k + 1) * NB);
+            fprintf(stderr, "[ochip relaxg] n=%d band=%d tail=%d blocks=%d mean envelope rows below a block %.1f\n", n, band_end, T,
+                    nblk, (double)bandsum / nblk);
+        }
+    }
+    p->sys.ctx = p->ctx;
+    p->sys.allocs = &p->allocs;
+    int rc = lm_system_resize(&p->sys, n, env);
+    if (rc != OCHIP_OK)
+        return rc;
+
+    // assembly plan
+    std::vector<work_item> items;
+    std::vector<uint32_t> tail_var, tail_first, tail_count;
+    int max_strip = 1;
+    for (uint32_t u : band)
+    {
+        work_item it{u, p->var_rec_off[u], p->var_rec_off[u + 1], lo[u], hi[u], -1};
+        items.push_back(it);
+        max_strip = std::max(max_strip, (int)p->var_ts[u] * (hi[u] - lo[u] + T + 1));
+    }
+    uint32_t n_partials = 0;
+    for (uint32_t u : tail)
+    {
+        tail_var.push_back(u);
+        tail_first.push_back(n_partials);
+        uint32_t cnt = 0;
+        for (uint32_t e = p->var_rec_off[u]; e < p->var_rec_off[u + 1] || cnt == 0; e += TAIL_CHUNK)
+        {
+            work_item it{u, e, std::min(e + TAIL_CHUNK, p->var_rec_off[u + 1]), 0, 0, (int32_t)n_partials};
+            items.push_back(it);
+            n_partials++;
+            cnt++;
+            if (p->var_rec_off[u + 1] == p->var_rec_off[u])
+                break;
+        }
+        tail_count.push_back(cnt);
+        max_strip = std::max(max_strip, (int)p->var_ts[u] * (T + 1));
+    }
+    p->n_items = (uint32_t)items.size();
+    p->n_tail_owners = (uint32_t)tail_var.size();
+    p->n_partials = n_partials;
+    p->max_strip = max_strip;
+    auto chk = [&](int r) {
+        if (rc == OCHIP_OK)
+            rc = r;
+    };
+    chk(up(p, &p->items_dev, items));
+    chk(up(p, &p->tail_var_dev, tail_var));
+    chk(up(p, &p->tail_first_dev, tail_first));
+    chk(up(p, &p->tail_count_dev, tail_count));
+    chk(up<double>(p, &p->partials_dev, nullptr, (size_t)std::max<uint32_t>(n_partials, 1) * 3 * (T + 1)));
+    if (rc != OCHIP_OK)
+        return rc;
+    if (hipMemcpy(p->dev.var_t, p->var_t.data(), p->n_vars * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(p->dev.var_ts, p->var_ts.data(), p->n_vars, hipMemcpyHostToDevice) != hipSuccess)
+        return ochip_fail(p->ctx, OCHIP_EHIP, "hipMemcpy failed (unknown map)");
+    return OCHIP_OK;
+}
+
+template <int N, bool INTR> void launch_ray(const g_dev &D, hipStream_t st, uint32_t first, uint32_t count, bool with_jac, int which)
+{
+    if (with_jac)
+    {
+        constexpr int G = W / (N + 1 + (INTR ? 2 : 0));
+        hipLaunchKernelGGL((ray_record_kernel<N, INTR>), dim3((count + G - 1) / G), dim3(W), 0, st, D, first, count);
+    }
+    else
+        hipLaunchKernelGGL((ray_cost_kernel<N, INTR>), dim3((count + W - 1) / W), dim3(W), 0, st, D, first, count, which);
+}
+
+struct general_model final : lm_model
+{
+    ochip_relaxg_problem *p;
+    explicit general_model(ochip_relaxg_problem *prob) : p(prob)
+    {
+    }
+    int evaluate(bool with_jac, int which, double *cost) override
+    {
+        ochip_ctx *ctx = p->ctx;
+        hipStream_t st = ctx->stream;
+        g_dev &D = p->dev;
+        const int n = p->n_tangent;
+        OCHIP_HIP(ctx, hipMemsetAsync(D.fail, 0, 4, st));
+        hipEvent_t e0, e1;
+        ochip_prof_begin(ctx, OCHIP_K_RELAX_EVAL, &e0, &e1);
+        for (const auto &r : p->ranges)
+        {
+            if (r.count == 0)
+                continue;
+            const bool intr = (r.type & T_INTR) != 0;
+            switch (r.type & 7)
+            {
+            case 2:
+                intr ? launch_ray<2, true>(D, st, r.first, r.count, with_jac, which) : launch_ray<2, false>(D, st, r.first, r.count, with_jac, which);
+                break;
+            case 3:
+                intr ? launch_ray<3, true>(D, st, r.first, r.count, with_jac, which) : launch_ray<3, false>(D, st, r.first, r.count, with_jac, which);
+                break;
+            case 4:
+                intr ? launch_ray<4, true>(D, st, r.first, r.count, with_jac, which) : launch_ray<4, false>(D, st, r.first, r.count, with_jac, which);
+                break;
+            default:
+                intr ? launch_ray<5, true>(D, st, r.first, r.count, with_jac, which) : launch_ray<5, false>(D, st, r.first, r.count, with_jac, which);
+                break;
+            }
+        }
+        const uint32_t n_prior = D.n_down + D.n_diff + D.n_anchor + D.n_smooth + D.n_mono;
+        if (n_prior)
+            hipLaunchKernelGGL(prior_kernel, dim3((n_prior + 255) / 256), dim3(256), 0, st, D, which, with_jac ? 1 : 0);
+        ochip_prof_end(ctx, OCHIP_K_RELAX_EVAL, e0, e1);
+        if (with_jac)
+        {
+            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, (size_t)n * n * 8, st));
+            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.g, 0, (size_t)n * 8, st));
+            if (p->n_items)
+                hipLaunchKernelGGL(gather_kernel, dim3(p->n_items), dim3(W), (size_t)p->max_strip * 8, st, D, p->items_dev,
+                                   p->var_rec_dev, p->sys.A, p->sys.g, n, p->tail_begin, p->partials_dev, STRIP_CAP);
+            if (p->n_tail_owners)
+                hipLaunchKernelGGL(tail_merge_kernel, dim3(p->n_tail_owners), dim3(256), 0, st, D, p->tail_var_dev, p->tail_first_dev,
+                                   p->tail_count_dev, p->partials_dev, p->sys.A, p->sys.g, n, p->tail_begin);
+        }
+        hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(1024), 0, st, D.rec_cost, D.n_rec, p->sys.scal);
+        OCHIP_HIP(ctx, hipGetLastError());
+        double h0 = 0;
+        int32_t hfail = 0;
+        OCHIP_HIP(ctx, hipMemcpyAsync(&h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(&hfail, D.fail, 4, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+        *cost = h0;
+        return hfail ? 1 : 0;
+    }
+    void launch_candidate(const double *y, const double *scale, double *scal) override
+    {
+        hipLaunchKernelGGL(general_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, scal);
+    }
+    void launch_accept() override
+    {
+        const uint32_t m = std::max<uint32_t>(std::max(p->n_cams * 4, p->n_verts), 8);
+        hipLaunchKernelGGL(general_accept_kernel, dim3((m + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev);
+    }
+    void launch_normalize() override
+    {
+        if (p->n_cams)
+            hipLaunchKernelGGL(general_normalize_kernel, dim3((p->n_cams + 255) / 256), dim3(256), 0, p->ctx->stream, p->dev,
+                               p->cam_optimize_dev);
+    }
+    int x_norm(double *out) override
+    {
+        ochip_ctx *ctx = p->ctx;
+        std::vector<double> q((size_t)p->n_cams * 4), z(p->n_verts);
+        double m[8], s = 0;
+        if (p->n_cams)
+            OCHIP_HIP(ctx, hipMemcpy(q.data(), p->dev.cam_q, q.size() * 8, hipMemcpyDeviceToHost));
+        if (p->n_verts)
+            OCHIP_HIP(ctx, hipMemcpy(z.data(), p->dev.vert_z, z.size() * 8, hipMemcpyDeviceToHost));
+        OCHIP_HIP(ctx, hipMemcpy(m, p->dev.model, 64, hipMemcpyDeviceToHost));
+        for (uint32_t c = 0; c < p->n_cams; c++)
+            if (p->var_t[c] >= 0)
+                for (int k = 0; k < 4; k++)
+                    s += q[c * 4 + k] * q[c * 4 + k];
+        for (uint32_t v = 0; v < p->n_verts; v++)
+            if (p->var_t[p->n_cams + v] >= 0)
+                s += z[v] * z[v];
+        const uint32_t vf = p->n_cams + p->n_verts;
+        if (p->var_t[vf] >= 0)
+            s += m[0] * m[0];
+        if (p->var_t[vf + 1] >= 0)
+            s += m[1] * m[1] + m[2] * m[2];
+        if (p->var_t[vf + 2] >= 0)
+            s += m[3] * m[3] + m[4] * m[4] + m[5] * m[5];
+        *out = std::sqrt(s);
+        return OCHIP_OK;
+    }
+    int num_residual_blocks() override
+    {
+        return (int)p->n_rec;
+    }
+    bool is_constrained() override
+    {
+        return p->var_t[p->n_cams + p->n_verts] >= 0;
+    }
+};
+
+} // namespace
+
+extern "C"
+{
+
+int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochip_relaxg_problem **out)
+{
+    if (!ctx || !d || !out)
+        return OCHIP_EINVAL;
+    *out = nullptr;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t b = 0; b < d->n_blocks; b++)
+    {
+        const int N = d->blk_n[b];
+        if (N < 2 || N > 5 || d->blk_ray_off[b + 1] - d->blk_ray_off[b] != (uint32_t)N)
+            return ochip_fail(ctx, OCHIP_EINVAL, "residual block %u: %d rays", b, N);
+        for (uint32_t r = d->blk_ray_off[b]; r < d->blk_ray_off[b + 1]; r++)
+        {
+            if (d->ray_cam[r] >= d->n_cams)
+                return ochip_fail(ctx, OCHIP_EINVAL, "residual block %u has a bad camera index", b);
+            for (uint32_t r2 = d->blk_ray_off[b]; r2 < r; r2++)
+                if (d->ray_cam[r2] == d->ray_cam[r])
+                    return ochip_fail(ctx, OCHIP_EINVAL, "residual block %u names a camera twice", b);
+        }
+        for (int j = 0; j < 3; j++)
+            if (d->blk_tri[3 * (size_t)b + j] >= d->n_verts)
+                return ochip_fail(ctx, OCHIP_EINVAL, "residual block %u has a bad vertex index", b);
+        if (d->blk_intr && d->blk_intr[b] && !d->ray_px)
+            return ochip_fail(ctx, OCHIP_EINVAL, "intrinsics blocks need ray_px");
+    }
+    auto *p = new (std::nothrow) ochip_relaxg_problem();
+    if (!p)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "host allocation failed");
+    p->ctx = ctx;
+    const uint32_t nc = d->n_cams, nv = d->n_verts, vf = nc + nv;
+    p->n_cams = nc;
+    p->n_verts = nv;
+    p->n_vars = vf + 3;
+    p->n_blocks = d->n_blocks;
+    p->cam_optimize.assign(d->cam_optimize, d->cam_optimize + nc);
+    p->vert_optimize.assign(d->vert_optimize, d->vert_optimize + nv);
+    p->opt_f = d->opt_focal;
+    p->opt_pp = d->opt_principal;
+    p->n_k_free = std::min<uint8_t>(d->n_radial_free, 3);
+    p->cam_xy.resize(2 * (size_t)nc);
+    for (uint32_t c = 0; c < nc; c++)
+    {
+        p->cam_xy[2 * c] = d->cam_pos[3 * c];
+        p->cam_xy[2 * c + 1] = d->cam_pos[3 * c + 1];
+    }
+    p->vert_xy.assign(d->vert_xy, d->vert_xy + 2 * (size_t)nv);
+
+    // ray blocks sorted by type (stable: the order inside a type is the caller's)
+    std::vector<uint32_t> order(d->n_blocks);
+    std::iota(order.begin(), order.end(), 0u);
+    auto type_of = [&](uint32_t b) { return (int)d->blk_n[b] | ((d->blk_intr && d->blk_intr[b]) ? T_INTR : 0); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return type_of(a) < type_of(b); });
+    std::vector<uint32_t> blk_ray_off(d->n_blocks + 1, 0), ray_cam, blk_tri(3 * (size_t)d->n_blocks);
+    std::vector<double> ray_dir, ray_px;
+    const uint32_t n_rays = d->n_blocks ? d->blk_ray_off[d->n_blocks] : 0;
+    ray_cam.reserve(n_rays);
+    ray_dir.reserve(3 * (size_t)n_rays);
+    ray_px.reserve(2 * (size_t)n_rays);
+    const uint32_t n_anchor = d->anchor_weight != 0.0 ? nv : 0;
+    const uint32_t n_mono = d->mono_observations > 0 ? 1 : 0;
+    p->n_rec = d->n_blocks + d->n_down + d->n_diff + n_anchor + d->n_smooth + n_mono;
+    p->rec_type.resize(p->n_rec);
+    p->rec_var.assign((size_t)p->n_rec * MAXV, 0);
+    std::vector<uint64_t> rec_off(p->n_rec + 1, 0);
+    for (uint32_t i = 0; i < d->n_blocks; i++)
+    {
+        const uint32_t b = order[i];
+        const int type = type_of(b), N = d->blk_n[b];
+        if (p->ranges.empty() || p->ranges.back().type != type)
+            p->ranges.push_back({type, i, 0});
+        p->ranges.back().count++;
+        p->rec_type[i] = (uint8_t)type;
+        blk_ray_off[i + 1] = blk_ray_off[i] + N;
+        for (uint32_t r = d->blk_ray_off[b]; r < d->blk_ray_off[b + 1]; r++)
+        {
+            ray_cam.push_back(d->ray_cam[r]);
+            for (int k = 0; k < 3; k++)
+                ray_dir.push_back(d->ray_dir ? d->ray_dir[3 * (size_t)r + k] : NAN);
+            for (int k = 0; k < 2; k++)
+                ray_px.push_back(d->ray_px ? d->ray_px[2 * (size_t)r + k] : NAN);
+            p->rec_var[(size_t)i * MAXV + (r - d->blk_ray_off[b])] = d->ray_cam[r];
+        }
+        for (int j = 0; j < 3; j++)
+        {
+            blk_tri[3 * (size_t)i + j] = d->blk_tri[3 * (size_t)b + j];
+            p->rec_var[(size_t)i * MAXV + N + j] = nc + d->blk_tri[3 * (size_t)b + j];
+        }
+        if (type & T_INTR)
+        {
+            p->has_intr_blocks = true;
+            for (int k = 0; k < 3; k++)
+                p->rec_var[(size_t)i * MAXV + N + 3 + k] = vf + k;
+        }
+    }
+    {
+        uint32_t r = d->n_blocks;
+        for (uint32_t i = 0; i < d->n_down; i++, r++)
+        {
+            if (d->down_cam[i] >= nc)
+            {
+                delete p;
+                return ochip_fail(ctx, OCHIP_EINVAL, "downward prior %u has a bad camera index", i);
+            }
+            p->rec_type[r] = T_DOWN;
+            p->rec_var[(size_t)r * MAXV] = d->down_cam[i];
+        }
+        for (uint32_t i = 0; i < d->n_diff; i++, r++)
+        {
+            p->rec_type[r] = T_DIFF;
+            for (int k = 0; k < 2; k++)
+            {
+                if (d->diff_v[2 * i + k] >= nv)
+                {
+                    delete p;
+                    return ochip_fail(ctx, OCHIP_EINVAL, "height-difference prior %u has a bad vertex index", i);
+                }
+                p->rec_var[(size_t)r * MAXV + k] = nc + d->diff_v[2 * i + k];
+            }
+        }
+        for (uint32_t i = 0; i < n_anchor; i++, r++)
+        {
+            p->rec_type[r] = T_ANCHOR;
+            p->rec_var[(size_t)r * MAXV] = nc + i;
+        }
+        for (uint32_t i = 0; i < d->n_smooth; i++, r++)
+        {
+            p->rec_type[r] = T_SMOOTH;
+            for (int k = 0; k < 4; k++)
+            {
+                if (d->smooth_v[4 * i + k] >= nv)
+                {
+                    delete p;
+                    return ochip_fail(ctx, OCHIP_EINVAL, "smoothness prior %u has a bad vertex index", i);
+                }
+                p->rec_var[(size_t)r * MAXV + k] = nc + d->smooth_v[4 * i + k];
+            }
+        }
+        for (uint32_t i = 0; i < n_mono; i++, r++)
+        {
+            p->rec_type[r] = T_MONO;
+            p->rec_var[(size_t)r * MAXV] = vf + 2;
+        }
+    }
+    for (uint32_t r = 0; r < p->n_rec; r++)
+    {
+        const int dd = rec_dim(p->rec_type[r]);
+        rec_off[r + 1] = rec_off[r] + (uint64_t)(dd * (dd + 1) / 2 + dd);
+    }
+    // CSR unknown group -> records, in record order (the fixed summation order of the assembly)
+    p->var_rec_off.assign(p->n_vars + 1, 0);
+    for (uint32_t r = 0; r < p->n_rec; r++)
+        for (int s = 0; s < rec_nvars(p->rec_type[r]); s++)
+            p->var_rec_off[p->rec_var[(size_t)r * MAXV + s] + 1]++;
+    for (uint32_t u = 0; u < p->n_vars; u++)
+        p->var_rec_off[u + 1] += p->var_rec_off[u];
+    p->var_rec.resize(p->var_rec_off[p->n_vars]);
+    {
+        std::vector<uint32_t> fill(p->var_rec_off.begin(), p->var_rec_off.end() - 1);
+        for (uint32_t r = 0; r < p->n_rec; r++)
+            for (int s = 0; s < rec_nvars(p->rec_type[r]); s++)
+                p->var_rec[fill[p->rec_var[(size_t)r * MAXV + s]]++] = (r << 4) | (uint32_t)s;
+    }
+    if (p->n_rec >= (1u << 28))
+    {
+        delete p;
+        return ochip_fail(ctx, OCHIP_EINVAL, "too many residual blocks");
+    }
+
+    g_dev &D = p->dev;
+    D.n_cams = nc;
+    D.n_verts = nv;
+    D.n_rec = p->n_rec;
+    D.n_down = d->n_down;
+    D.n_diff = d->n_diff;
+    D.n_anchor = n_anchor;
+    D.n_smooth = d->n_smooth;
+    D.n_mono = n_mono;
+    D.prior_base = d->n_blocks;
+    D.down_w = d->down_weight;
+    D.diff_w = d->diff_weight;
+    D.anchor_w = d->anchor_weight;
+    D.smooth_w = d->smooth_weight;
+    D.mono_w = std::sqrt(d->mono_observations / 10.0);
+    D.mono_rmax = d->mono_r_max;
+    D.huber_a = d->huber_a;
+    D.f_lo = d->focal_lo;
+    D.f_hi = d->focal_hi;
+    D.n_k_free = p->n_k_free;
+    int rc = OCHIP_OK;
+    auto chk = [&](int r) {
+        if (rc == OCHIP_OK)
+            rc = r;
+    };
+    chk(up(p, &D.cam_pos, d->cam_pos, (size_t)nc * 3));
+    chk(up(p, &D.cam_q, d->cam_q, (size_t)nc * 4));
+    chk(up(p, &D.cam_q2, d->cam_q, (size_t)nc * 4));
+    chk(up(p, &D.vert_xy, d->vert_xy, (size_t)nv * 2));
+    chk(up(p, &D.vert_z, d->vert_z, (size_t)nv));
+    chk(up(p, &D.vert_z2, d->vert_z, (size_t)nv));
+    chk(up(p, &D.vert_z0, d->vert_z, (size_t)nv));
+    chk(up(p, &D.model, d->model, 8));
+    chk(up(p, &D.model2, d->model, 8));
+    chk(up<int32_t>(p, &D.var_t, nullptr, p->n_vars));
+    chk(up<uint8_t>(p, &D.var_ts, nullptr, p->n_vars));
+    chk(up(p, &D.blk_ray_off, blk_ray_off));
+    chk(up(p, &D.ray_cam, ray_cam));
+    chk(up(p, &D.blk_tri, blk_tri));
+    chk(up(p, &D.ray_dir, ray_dir));
+    chk(up(p, &D.ray_px, ray_px));
+    chk(up(p, &D.rec_type, p->rec_type));
+    chk(up(p, &D.rec_off, rec_off));
+    chk(up(p, &D.rec_var, p->rec_var));
+    chk(up<double>(p, &D.rec_data, nullptr, (size_t)rec_off[p->n_rec]));
+    chk(up<double>(p, &D.rec_cost, nullptr, p->n_rec));
+    chk(up(p, &D.down_cam, d->down_cam, d->n_down));
+    chk(up(p, &D.diff_v, d->diff_v, (size_t)d->n_diff * 2));
+    chk(up(p, &D.smooth_v, d->smooth_v, (size_t)d->n_smooth * 4));
+    chk(up<int32_t>(p, &D.fail, nullptr, 1));
+    chk(up(p, &p->var_rec_dev, p->var_rec));
+    chk(up(p, &p->cam_optimize_dev, p->cam_optimize));
+    if (rc == OCHIP_OK)
+        rc = assign(p);
+    if (rc != OCHIP_OK)
+    {
+        ochip_relaxg_problem_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return OCHIP_OK;
+}
+
+void ochip_relaxg_problem_destroy(ochip_relaxg_problem *p)
+{
+    if (!p)
+        return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)ochip_stream_wait(p->ctx, p->ctx->stream);
+    for (auto &a : p->allocs)
+        ochip_pool_put(p->ctx, a.first, a.second);
+    delete p;
+}
+
+int ochip_relaxg_set_structure_only(ochip_relaxg_problem *p, int on)
+{
+    if (!p)
+        return OCHIP_EINVAL;
+    OCHIP_HIP(p->ctx, hipSetDevice(p->ctx->device));
+    p->structure_only = on != 0;
+    return assign(p);
+}
+
+int ochip_relaxg_get_state(ochip_relaxg_problem *p, double *cam_q, double *vert_z, double *model)
+{
+    if (!p)
+        return OCHIP_EINVAL;
+    ochip_ctx *ctx = p->ctx;
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
+    if (cam_q && p->n_cams)
+        OCHIP_HIP(ctx, hipMemcpy(cam_q, p->dev.cam_q, (size_t)p->n_cams * 32, hipMemcpyDeviceToHost));
+    if (vert_z && p->n_verts)
+        OCHIP_HIP(ctx, hipMemcpy(vert_z, p->dev.vert_z, (size_t)p->n_verts * 8, hipMemcpyDeviceToHost));
+    if (model)
+        OCHIP_HIP(ctx, hipMemcpy(model, p->dev.model, 64, hipMemcpyDeviceToHost));
+    return OCHIP_OK;
+}
+
+int ochip_relaxg_evaluate(ochip_relaxg_problem *p, double *cost, int *n_out, double *JtJ, double *Jtr, int32_t *order_out)
+{
+    if (!p || !cost)
+        return OCHIP_EINVAL;
+    ochip_ctx *ctx = p->ctx;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    general_model model(p);
+    const int n = p->n_tangent;
+    if (n_out)
+        *n_out = n;
+    if (order_out)
+        for (uint32_t u = 0; u < p->n_vars; u++)
+            order_out[u] = p->var_t[u];
+    const int rc = model.evaluate(JtJ != nullptr || Jtr != nullptr, 0, cost);
+    if (rc < 0)
+        return rc;
+    if (JtJ && n)
+        OCHIP_HIP(ctx, hipMemcpy(JtJ, p->sys.A, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+    if (Jtr && n)
+        OCHIP_HIP(ctx, hipMemcpy(Jtr, p->sys.g, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return rc;
+}
+
+int ochip_relaxg_solve(ochip_relaxg_problem *p, const ochip_relax_options *opt, ochip_relax_summary *sum)
+{
+    if (!p || !opt || !sum)
+        return OCHIP_EINVAL;
+    ochip_ctx *ctx = p->ctx;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    *sum = ochip_relax_summary{};
+    general_model model(p);
+    sum->num_parameters = p->n_tangent;
+    sum->num_residual_blocks = model.num_residual_blocks();
+    if (p->n_rec == 0)
+    {
+        sum->termination = OCHIP_RELAX_NO_PARAMETERS; // RelaxProblem::solve returns before Solve (:1398-1402)
+        return OCHIP_OK;
+    }
+    if (p->n_tangent == 0)
+    {
+        sum->termination = OCHIP_RELAX_NO_PARAMETERS;
+        model.launch_normalize();
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
+        return OCHIP_OK;
+    }
+    return lm_solve(p->sys, model, opt, sum);
+}
+
+} // extern "C"

@@ -1,0 +1,584 @@
+// libochip.so — the shared part of the relax solve (see relax_lm.hpp): Levenberg-Marquardt trust-region loop with
+// Ceres' semantics and the linear solve of (J'J + D'D) y = J'r on the device.
+//
+// The reduced system is stored dense (row-major) and factored by a blocked right-looking Cholesky that only visits the
+// rows inside the block envelope (relax_lm.hpp: lm_envelope): 64 x 64 diagonal block + its inverse in registers
+// (chol_diag_kernel), panel = block x inverse and trailing update as v_mfma_f64_16x16x4f64 GEMMs.  The augmented row
+// carries the forward solve; the backward substitution is one workgroup walking the row envelope.
+#include "relax_lm.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace ochip;
+
+namespace
+{
+
+// ---- dense linear algebra on the reduced system -------------------------------------------------
+constexpr int NB = ochip::LM_NB;
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// Wm = S A S + diag(D), gs = S g; also column norms^2 of the scaled Jacobian = diag(S A S)
+__global__ void lm_build_kernel(const double *A, const double *g, const double *scale, const double *lm_diag,
+                                double *Wm, double *gs, int n)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * n)
+        return;
+    const int i = (int)(idx / n), j = (int)(idx % n);
+    double v = A[idx] * scale[i] * scale[j];
+    if (i == j)
+    {
+        v += lm_diag[i];
+        const double gi = g[i] * scale[i];
+        gs[i] = gi;
+        Wm[(size_t)n * n + i] = gi; // augmented row n: the factorisation performs the forward solve L y = gs on it
+    }
+    Wm[idx] = v;
+}
+
+// Cholesky factor of the 64 x 64 diagonal block and its inverse, one workgroup.  The block lives in registers:
+// thread (ty, tx) of a 16 x 16 grid owns rows ty + 16p and columns tx + 16q (cyclic, so the shrinking trailing
+// matrix stays spread over all threads).  Step j: the owners of column j publish it (and the owners of row j of
+// the inverse accumulator publish that) in LDS, one barrier, then every thread applies the rank-1 update to its
+// register tile and the forward-elimination step  X_j /= l_jj,  X_i -= l_ij X_j  that turns the identity into
+// L^-1.  The 64 steps run as 4 phases of 16 with the phase (j / 16) a compile-time constant: which register
+// rows / columns are finished, live or on the pivot is then static, only the 16-row band of the pivot needs a
+// runtime comparison, and finished parts cost nothing.  (This kernel is the critical path of the linear solve:
+// 47 sequential launches per factorisation at n = 3003.)
+template <int JB>
+__device__ __forceinline__ void chol_diag_phase(double (&a)[4][4], double (&x)[4][4], double (*colA)[NB], double (*rowX)[NB],
+                                                int ty, int tx, int nb, bool &bad)
+{
+#pragma unroll 1
+    for (int jt = 0; jt < 16; jt++)
+    {
+        const int j = JB * 16 + jt, buf = jt & 1;
+        if (tx == jt) // owners of column j: rows of band JB and below
+#pragma unroll
+            for (int p = JB; p < 4; p++)
+                colA[buf][ty + 16 * p] = a[p][JB];
+        if (ty == jt) // owners of row j of the inverse accumulator: columns up to band JB
+#pragma unroll
+            for (int q = 0; q <= JB; q++)
+                rowX[buf][tx + 16 * q] = x[JB][q];
+        __syncthreads();
+        const double piv = colA[buf][j];
+        if (j < nb && !(piv > 0.0))
+            bad = true;
+        // 1 / sqrt(pivot): hardware estimate + two Newton steps (the factor is not on a bit-parity path)
+        double rs = __builtin_amdgcn_rsq(piv);
+        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        double li[4], lc[4], xr[4];
+#pragma unroll
+        for (int p = JB; p < 4; p++)
+        {
+            const double v = colA[buf][ty + 16 * p] * rs;
+            li[p] = (p > JB || ty > jt) ? v : 0.0;
+        }
+#pragma unroll
+        for (int q = JB; q < 4; q++)
+        {
+            const double v = colA[buf][tx + 16 * q] * rs;
+            lc[q] = (q > JB || tx > jt) ? v : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q <= JB; q++)
+            xr[q] = rowX[buf][tx + 16 * q] * rs;
+#pragma unroll
+        for (int p = JB; p < 4; p++)
+        {
+#pragma unroll
+            for (int q = JB; q < 4; q++)
+                a[p][q] -= li[p] * lc[q];
+#pragma unroll
+            for (int q = 0; q <= JB; q++)
+                x[p][q] -= li[p] * xr[q];
+        }
+        // column j becomes final (l_ij below the diagonal, sqrt(pivot) = pivot * rs on it, 0 above); row j of X too
+        if (tx == jt)
+#pragma unroll
+            for (int p = JB; p < 4; p++)
+            {
+                const double v = colA[buf][ty + 16 * p] * rs;
+                a[p][JB] = (p > JB || ty >= jt) ? v : 0.0;
+            }
+        if (ty == jt)
+#pragma unroll
+            for (int q = 0; q <= JB; q++)
+                x[JB][q] = xr[q];
+    }
+}
+
+__global__ __launch_bounds__(256) void chol_diag_kernel(double *A, int n, int k0, int nb, int *fail,
+                                                        double *Linv /*[NB][NB] row-major, zero padded*/)
+{
+    __shared__ double colA[2][NB], rowX[2][NB];
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    double a[4][4], x[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int i = ty + 16 * p, c = tx + 16 * q;
+            // only the lower triangle of the input is meaningful; mirror it so that both triangles update alike
+            const int lo = i > c ? i : c, hi = i > c ? c : i;
+            a[p][q] = (lo < nb) ? A[(size_t)(k0 + lo) * n + k0 + hi] : (i == c ? 1.0 : 0.0);
+            x[p][q] = (i == c) ? 1.0 : 0.0;
+        }
+    bool bad = false;
+    chol_diag_phase<0>(a, x, colA, rowX, ty, tx, nb, bad);
+    chol_diag_phase<1>(a, x, colA, rowX, ty, tx, nb, bad);
+    chol_diag_phase<2>(a, x, colA, rowX, ty, tx, nb, bad);
+    chol_diag_phase<3>(a, x, colA, rowX, ty, tx, nb, bad);
+    if (bad)
+        *fail = 1;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int i = ty + 16 * p, c = tx + 16 * q;
+            if (i < nb && c <= i)
+                A[(size_t)(k0 + i) * n + k0 + c] = a[p][q];
+            Linv[i * NB + c] = (i < nb && c <= i) ? x[p][q] : ((i == c) ? 1.0 : 0.0);
+        }
+}
+
+// The rows below a diagonal block that can be non-zero: the block column's envelope (cameras further down the list
+// than any camera linked to this block's cameras never get fill) and the tail (the plane unknowns, coupled to every
+// camera, and the augmented row).  Kernels index this set with a logical row number.
+struct row_set
+{
+    int begin, band_rows; // rows begin .. begin + band_rows - 1
+    int tail_begin, total; // then rows tail_begin .. ; total = band_rows + tail rows
+};
+__device__ __forceinline__ int set_row(const row_set &s, int i)
+{
+    return i < s.band_rows ? s.begin + i : s.tail_begin + (i - s.band_rows);
+}
+
+// rows below the diagonal block: X = A[i, k0:k0+nb] * L_kk^{-T} = A_tile * Linv' as a 64x64x64 GEMM on the
+// matrix cores (same tiling as the trailing update), in place.
+__global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, row_set rs, int k0, int nb, const double *Linv)
+{
+    constexpr int KC = 32;
+    __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
+    const int r0 = blockIdx.x * 64; // logical
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+    v4f64 acc[2][2];
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            acc[i][j] = v4f64{0, 0, 0, 0};
+    for (int m0 = 0; m0 < NB; m0 += KC)
+    {
+        __syncthreads();
+        for (int e = t; e < 64 * KC; e += 256)
+        {
+            const int r = e / KC, m = e % KC;
+            Pi[r][m] = (r0 + r < rs.total && m0 + m < nb) ? A[(size_t)set_row(rs, r0 + r) * n + k0 + m0 + m] : 0.0;
+            Pj[r][m] = Linv[r * NB + m0 + m]; // X[i][c] = sum_m A[i][m] Linv[c][m]
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4)
+        {
+            const double a0 = Pi[wr + lr][kk + lk], a1 = Pi[wr + 16 + lr][kk + lk];
+            const double b0 = Pj[wc + lr][kk + lk], b1 = Pj[wc + 16 + lr][kk + lk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            for (int e = 0; e < 4; e++)
+            {
+                const int r = r0 + wr + 16 * i + 4 * e + lk, cc = wc + 16 * j + lr;
+                if (r < rs.total && cc < nb)
+                    A[(size_t)set_row(rs, r) * n + k0 + cc] = acc[i][j][e];
+            }
+}
+
+// trailing update, lower tiles only: C[i][j] -= sum_m P[i][m] P[j][m], 64x64 tile per workgroup.
+// Same trailing update on the matrix cores: v_mfma_f64_16x16x4_f64, one 32x32 sub-tile per wave
+// (2x2 accumulators), operands staged through LDS in 32-deep K chunks.  This dense fp64 update of the
+// reduced system is the only MFMA use on the path.
+__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n, row_set rs, int k0, int nb)
+{
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti)
+        return;
+    constexpr int KC = 32;
+    __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
+    const int r0 = ti * 64, c0 = tj * 64; // logical rows of the set; columns are the same set (without the augmented row)
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+    v4f64 acc[2][2];
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            acc[i][j] = v4f64{0, 0, 0, 0};
+    for (int m0 = 0; m0 < nb; m0 += KC)
+    {
+        const int mc = min(KC, nb - m0);
+        __syncthreads();
+        for (int e = t; e < 64 * KC; e += 256)
+        {
+            const int r = e / KC, m = e % KC;
+            Pi[r][m] = (r0 + r < rs.total && m < mc) ? A[(size_t)set_row(rs, r0 + r) * n + k0 + m0 + m] : 0.0;
+            Pj[r][m] = (c0 + r < rs.total && m < mc) ? A[(size_t)set_row(rs, c0 + r) * n + k0 + m0 + m] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4)
+        {
+            const double a0 = Pi[wr + lr][kk + lk], a1 = Pi[wr + 16 + lr][kk + lk];
+            const double b0 = Pj[wc + lr][kk + lk], b1 = Pj[wc + 16 + lr][kk + lk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            for (int e = 0; e < 4; e++)
+            {
+                // f64 16x16x4 result layout (measured, scripts/probe_mfma_f64.hip): D[4*reg + lane/16][lane%16]
+                const int r = r0 + wr + 16 * i + 4 * e + lk, cc = c0 + wc + 16 * j + lr;
+                if (r < rs.total && cc <= r)
+                {
+                    const int ar = set_row(rs, r), ac = set_row(rs, cc);
+                    if (ac < n)
+                        A[(size_t)ar * n + ac] -= acc[i][j][e];
+                }
+            }
+}
+
+// Backward substitution L' x = y by ONE workgroup, block by block from the bottom: x_k = L_kk^-T y_k out of the stored
+// inverse, then y_i -= sum_m L[k0+m][i] x[k0+m] for the columns i < k0 in which the rows of the block can be non-zero
+// (first_col[k]: the row envelope; everything for the tail rows).  The 94 launches this took per solve cost 1.0 ms, the
+// walk over the envelope takes a tenth of that.
+__global__ __launch_bounds__(1024) void back_solve_kernel(const double *L, int n, const double *Linv, double *x,
+                                                          const int *first_col, int n_blocks)
+{
+    __shared__ double xb[NB];
+    const int t = threadIdx.x;
+    for (int k = n_blocks - 1; k >= 0; k--)
+    {
+        const int k0 = k * NB, nb = min(NB, n - k0);
+        const double *Li = Linv + (size_t)k * NB * NB;
+        __syncthreads(); // the updates of the previous block have landed
+        if (t < NB)
+            xb[t] = t < nb ? x[k0 + t] : 0.0;
+        __syncthreads();
+        double s = 0; // (L^-T y)[t] = sum_m Linv[m][t] y[m]; Linv is lower triangular with zeros above, so all 64 terms
+        if (t < nb)   // can be requested up front (16 loads in flight) instead of one per loop trip
+        {
+#pragma unroll
+            for (int m0 = 0; m0 < NB; m0 += 16)
+            {
+                double v[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    v[j] = Li[(m0 + j) * NB + t];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (m0 + j >= t && m0 + j < nb)
+                        s += v[j] * xb[m0 + j];
+            }
+        }
+        __syncthreads();
+        if (t < nb)
+        {
+            xb[t] = s;
+            x[k0 + t] = s;
+        }
+        __syncthreads();
+        for (int i = first_col[k] + t; i < k0; i += 1024)
+        {
+            double u = 0;
+            for (int m0 = 0; m0 < nb; m0 += 16)
+            {
+                double v[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    v[j] = m0 + j < nb ? L[(size_t)(k0 + m0 + j) * n + i] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    u += v[j] * xb[m0 + j];
+            }
+            x[i] -= u;
+        }
+    }
+}
+
+
+// model_cost_change = -(step.gs + step' As step / 2) with step = -y, (As + D) y = gs
+//                   = y.gs - (y.gs - y'D y) / 2 = (y.gs + sum D_i y_i^2) / 2 by the normal equations (no n^2 product).
+__global__ __launch_bounds__(1024) void lm_model_change_kernel(const double *lm_diag, const double *gs, const double *y, int n,
+                                                                double *scal)
+{
+    __shared__ double sh[1024];
+    const int t = threadIdx.x;
+    double part = 0;
+    for (int i = t; i < n; i += 1024)
+        part += y[i] * gs[i] + lm_diag[i] * y[i] * y[i];
+    sh[t] = part;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1)
+    {
+        if (t < s)
+            sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    if (t == 0)
+        scal[1] = 0.5 * sh[0];
+}
+
+// diag(A) and max|g| -> scal[4] = max|g|; diag_out[i] = A_ii
+__global__ __launch_bounds__(1024) void lm_diag_kernel(const double *A, const double *g, double *diag_out, int n,
+                                                       double *scal)
+{
+    __shared__ double sh[1024];
+    const int t = threadIdx.x;
+    double m = 0;
+    for (int i = t; i < n; i += 1024)
+    {
+        diag_out[i] = A[(size_t)i * n + i];
+        m = fmax(m, fabs(g[i]));
+    }
+    sh[t] = m;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1)
+    {
+        if (t < s)
+            sh[t] = fmax(sh[t], sh[t + s]);
+        __syncthreads();
+    }
+    if (t == 0)
+        scal[4] = sh[0];
+}
+
+} // namespace
+
+namespace ochip
+{
+
+int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
+{
+    ochip_ctx *ctx = s->ctx;
+    s->env = env;
+    s->n = n_in;
+    if (lm_dev_upload(ctx, s->allocs, &s->first_col_dev, s->env.first_col.data(), s->env.first_col.size()) != OCHIP_OK)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (envelope)");
+    const size_t n = (size_t)std::max(n_in, 1);
+    if (n > s->cap_n)
+    {
+        // (blocks of a smaller earlier size stay with the owner until it is destroyed)
+        if (lm_dev_upload<double>(ctx, s->allocs, &s->A, nullptr, n * n) != OCHIP_OK ||
+            lm_dev_upload<double>(ctx, s->allocs, &s->Wm, nullptr, (n + 1) * n) != OCHIP_OK ||
+            lm_dev_upload<double>(ctx, s->allocs, &s->g, nullptr, n) != OCHIP_OK ||
+            lm_dev_upload<double>(ctx, s->allocs, &s->gs, nullptr, n) != OCHIP_OK ||
+            lm_dev_upload<double>(ctx, s->allocs, &s->scale, nullptr, n) != OCHIP_OK ||
+            lm_dev_upload<double>(ctx, s->allocs, &s->lm_diag, nullptr, n) != OCHIP_OK ||
+            lm_dev_upload<double>(ctx, s->allocs, &s->diag_tmp, nullptr, n) != OCHIP_OK ||
+            lm_dev_upload<double>(ctx, s->allocs, &s->y, nullptr, n) != OCHIP_OK)
+            return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the %zu x %zu normal matrix failed", n, n);
+        s->cap_n = n;
+    }
+    if (!s->scal && lm_dev_upload<double>(ctx, s->allocs, &s->scal, nullptr, 8) != OCHIP_OK)
+        return OCHIP_ENOMEM;
+    if (!s->fail_chol && lm_dev_upload<int>(ctx, s->allocs, &s->fail_chol, nullptr, 1) != OCHIP_OK)
+        return OCHIP_ENOMEM;
+    return OCHIP_OK;
+}
+
+// Trust-region Levenberg-Marquardt, monotonic steps (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy semantics,
+// SURVEY.md Appendix B).  The control flow runs on the host side of the library; every O(problem) operation is a kernel.
+int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_relax_summary *sum)
+{
+    ochip_ctx *ctx = S.ctx;
+    hipStream_t st = ctx->stream;
+    const int n = S.n;
+    double h[8];
+    auto grad_and_diag = [&](double *gmax) -> int {
+        hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(1024), 0, st, S.A, S.g, S.diag_tmp, n, S.scal);
+        OCHIP_HIP(ctx, hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+        *gmax = h[4];
+        return OCHIP_OK;
+    };
+    auto finish_state = [&]() {
+        M.launch_normalize();
+        return ochip_stream_wait(ctx, st);
+    };
+
+    std::vector<double> diag(n), scale(n, 1.0), lmd(n), diagonal(n, 0.0);
+    double x_cost = 0, gmax = 0;
+    int erc = M.evaluate(true, 0, &x_cost);
+    if (erc < 0)
+        return erc;
+    if (erc != 0)
+    {
+        sum->termination = OCHIP_RELAX_FAILURE;
+        OCHIP_HIP(ctx, finish_state());
+        return OCHIP_OK;
+    }
+    int rc = grad_and_diag(&gmax);
+    if (rc)
+        return rc;
+    OCHIP_HIP(ctx, hipMemcpy(diag.data(), S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++)
+        scale[i] = 1.0 / (1.0 + std::sqrt(diag[i])); // jacobi scaling, fixed from the first Jacobian
+    OCHIP_HIP(ctx, hipMemcpy(S.scale, scale.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    double x_norm = 0;
+    rc = M.x_norm(&x_norm);
+    if (rc)
+        return rc;
+    sum->initial_cost = x_cost;
+    sum->iterations = 1; // iteration 0
+    double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
+    bool reuse_diagonal = false;
+    int invalid = 0, iter = 0;
+    auto finish = [&](int term) -> int {
+        sum->termination = term;
+        sum->final_cost = x_cost;
+        OCHIP_HIP(ctx, finish_state());
+        return OCHIP_OK;
+    };
+    if (gmax <= opt->gradient_tolerance)
+        return finish(OCHIP_RELAX_CONVERGENCE_GRADIENT);
+
+    while (true)
+    {
+        if (iter >= opt->max_num_iterations)
+            return finish(OCHIP_RELAX_NO_CONVERGENCE);
+        if (radius <= 1e-32)
+            return finish(OCHIP_RELAX_CONVERGENCE_RADIUS);
+        iter++;
+        sum->iterations++;
+        if (!reuse_diagonal)
+            for (int i = 0; i < n; i++)
+                diagonal[i] = std::min(std::max(diag[i] * scale[i] * scale[i], 1e-6), 1e32);
+        for (int i = 0; i < n; i++)
+        {
+            const double dd = std::sqrt(diagonal[i] / radius);
+            lmd[i] = dd * dd;
+        }
+        OCHIP_HIP(ctx, hipMemcpyAsync(S.lm_diag, lmd.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+        hipEvent_t e0, e1;
+        ochip_prof_begin(ctx, OCHIP_K_RELAX_SOLVE, &e0, &e1);
+        const size_t nn = (size_t)n * n;
+        hipLaunchKernelGGL(lm_build_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, S.A, S.g, S.scale, S.lm_diag,
+                           S.Wm, S.gs, n);
+        OCHIP_HIP(ctx, hipMemsetAsync(S.fail_chol, 0, 4, st));
+        {
+            const size_t need = (size_t)((n + NB - 1) / NB) * NB * NB;
+            if (need > S.linv_cap)
+            {
+                S.linv = nullptr;
+                S.linv_cap = 0;
+                if (lm_dev_upload<double>(ctx, S.allocs, &S.linv, nullptr, need) != OCHIP_OK)
+                    return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the diagonal-block inverses failed");
+                S.linv_cap = need;
+            }
+        }
+        for (int k0 = 0; k0 < n; k0 += NB)
+        {
+            const int nb = std::min(NB, n - k0);
+            double *linv_k = S.linv + (size_t)(k0 / NB) * NB * NB;
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, S.Wm, n, k0, nb, S.fail_chol, linv_k);
+            // rows below the block that can be non-zero: its envelope, then the tail (dense unknowns + augmented row)
+            static const bool dense = getenv("OCHIP_CHOL_DENSE") != nullptr; // A/B knob: ignore the envelope
+            const int below = k0 + nb;
+            const int band_end = dense ? n : std::max(below, std::min(S.env.env_end[k0 / NB], S.env.tail_begin));
+            const int tail0 = std::max(dense ? n : S.env.tail_begin, below);
+            row_set rs{below, band_end - below, tail0, (band_end - below) + (n + 1 - tail0)};
+            const int tiles = (rs.total + 63) / 64;
+            hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, st, S.Wm, n, rs, k0, nb, linv_k);
+            if (below < n)
+                hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, st, S.Wm, n, rs, k0, nb);
+        }
+        // row n now holds y = L^-1 gs; back-substitute L' x = y block by block
+        OCHIP_HIP(ctx, hipMemcpyAsync(S.y, S.Wm + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, st, (const double *)S.Wm, n, (const double *)S.linv, S.y,
+                           (const int *)S.first_col_dev, (n + NB - 1) / NB);
+        hipLaunchKernelGGL(lm_model_change_kernel, dim3(1), dim3(1024), 0, st, S.lm_diag, S.gs, S.y, n, S.scal);
+        M.launch_candidate(S.y, S.scale, S.scal);
+        ochip_prof_end(ctx, OCHIP_K_RELAX_SOLVE, e0, e1);
+        OCHIP_HIP(ctx, hipGetLastError());
+        int cfail = 0;
+        OCHIP_HIP(ctx, hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(&cfail, S.fail_chol, 4, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+        reuse_diagonal = true;
+        const double model_cost_change = h[1], step_norm = std::sqrt(h[2]), cand_norm = std::sqrt(h[3]);
+        const bool valid = !cfail && std::isfinite(model_cost_change) && model_cost_change > 0.0;
+        static const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+        if (verbose)
+            fprintf(stderr, "[ochip relax] n=%d iter=%d cost=%.17g radius=%.6g model=%.17g step_norm=%.6g cfail=%d gmax=%.6g\n",
+                    n, iter, x_cost, radius, model_cost_change, step_norm, cfail, gmax);
+        if (!valid)
+        {
+            if (++invalid >= 5)
+                return finish(OCHIP_RELAX_FAILURE);
+            radius *= 0.5;
+            continue;
+        }
+        invalid = 0;
+        double cand_cost = 1.7976931348623157e308;
+        {
+            double c;
+            erc = M.evaluate(false, 1, &c);
+            if (erc < 0)
+                return erc;
+            if (erc == 0)
+                cand_cost = c;
+        }
+        if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance))
+            return finish(OCHIP_RELAX_CONVERGENCE_PARAMETER);
+        const double cost_change = x_cost - cand_cost;
+        if (std::abs(cost_change) <= opt->function_tolerance * x_cost)
+            return finish(OCHIP_RELAX_CONVERGENCE_FUNCTION);
+        const double rho = cost_change / model_cost_change;
+        if (rho > 1e-3)
+        {
+            M.launch_accept();
+            x_norm = cand_norm;
+            erc = M.evaluate(true, 0, &x_cost);
+            if (erc < 0)
+                return erc;
+            if (erc != 0)
+                return finish(OCHIP_RELAX_FAILURE);
+            rc = grad_and_diag(&gmax);
+            if (rc)
+                return rc;
+            OCHIP_HIP(ctx, hipMemcpy(diag.data(), S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost));
+            const double t = 2.0 * rho - 1.0;
+            radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+            radius = std::min(1e16, radius);
+            decrease_factor = 2.0;
+            reuse_diagonal = false;
+            sum->successful_steps++;
+            if (gmax <= opt->gradient_tolerance)
+                return finish(OCHIP_RELAX_CONVERGENCE_GRADIENT);
+        }
+        else
+        {
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+            sum->unsuccessful_steps++;
+        }
+    }
+}
+
+} // namespace ochip

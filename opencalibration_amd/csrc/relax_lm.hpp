@@ -1,0 +1,88 @@
+// libochip.so (internal) — the part of the relax solve every problem flavour shares: Levenberg-Marquardt trust-region
+// loop with Ceres' semantics (ceres::TrustRegionMinimizer + LevenbergMarquardtStrategy, what
+// RelaxProblem::solve -> ceres::Solver::Solve runs, src/relax/relax_problem.cpp:30-37,1404) on a
+// reduced normal-equation system held dense in HBM and factored inside its block envelope (relax_lm.hip).
+//
+// A problem flavour (ground plane: relax.hip; mesh / intrinsics: relax_general.hip) implements lm_model: it owns the
+// state, evaluates cost / J'J / J'r into the system's buffers, and applies a step to a candidate state.
+#pragma once
+
+#include "ctx.hpp"
+
+#include <vector>
+
+namespace ochip
+{
+
+constexpr int LM_NB = 64; // block size of the Cholesky factorisation (a 64 x 64 diagonal block per workgroup)
+
+// Block envelope of the reduced system (unknowns numbered so that coupled unknowns are close): per 64-column block the
+// end of the rows that can be non-zero below it, the first row of the dense tail (unknowns coupled to everything: plane
+// heights, shared intrinsics), and per block row the first column that can be non-zero (for the backward solve).
+struct lm_envelope
+{
+    std::vector<int> env_end, first_col;
+    int tail_begin = 0;
+};
+
+struct lm_system
+{
+    ochip_ctx *ctx = nullptr;
+    std::vector<std::pair<void *, size_t>> *allocs = nullptr; // device blocks are recorded here (owner returns them to the pool)
+    int n = 0;
+    size_t cap_n = 0, linv_cap = 0;
+    double *A = nullptr;       // [n][n] J'J, row-major, both triangles
+    double *g = nullptr;       // [n] J'r
+    double *Wm = nullptr;      // [(n + 1)][n] scaled + damped system, augmented row = scaled gradient
+    double *gs = nullptr, *scale = nullptr, *lm_diag = nullptr, *diag_tmp = nullptr, *y = nullptr;
+    double *scal = nullptr;    // [8] small results: [0] cost [1] model cost change [2] |step|^2 [3] |candidate|^2 [4] max |g|
+    int *fail_chol = nullptr;
+    double *linv = nullptr;    // inverses of the diagonal blocks
+    int *first_col_dev = nullptr;
+    lm_envelope env;
+};
+
+// (re)size the buffers for n unknowns and take the envelope; returns OCHIP_OK or a negative code
+int lm_system_resize(lm_system *s, int n, const lm_envelope &env);
+
+struct lm_model
+{
+    virtual ~lm_model() = default;
+    // Evaluate state `which` (0 = current, 1 = candidate).  with_jac: also fill sys.A (every entry: both triangles, zeros
+    // included) and sys.g.  *cost = total cost.  Returns 0, 1 for a numeric failure (non-finite residual or derivative:
+    // Ceres' "evaluation failed"), or a negative OCHIP_E* code for a hard error (HIP call, exchange) which ends the solve.
+    virtual int evaluate(bool with_jac, int which, double *cost) = 0;
+    // enqueue: candidate = x (+) delta with delta[i] = -y[i] * scale[i]; scal[2] = |x - candidate|^2 (ambient),
+    // scal[3] = |candidate|^2 over the variable parameter blocks
+    virtual void launch_candidate(const double *y, const double *scale, double *scal) = 0;
+    virtual void launch_accept() = 0;    // current = candidate
+    virtual void launch_normalize() = 0; // what RelaxProblem::solve does to the state after Solve (:1410-1413)
+    virtual int x_norm(double *out) = 0; // |x| over the variable parameter blocks of the current state
+    virtual int num_residual_blocks() = 0;
+    // bounds-constrained problems (focal length in [100, 20000], :496-497): Ceres then runs a projected line search
+    // along the step before it tests it
+    virtual bool is_constrained()
+    {
+        return false;
+    }
+};
+
+int lm_solve(lm_system &sys, lm_model &model, const ochip_relax_options *opt, ochip_relax_summary *sum);
+
+// shared by the flavours' problem_create: a device block from the context's pool, recorded in `allocs`
+template <typename T>
+inline int lm_dev_upload(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> *allocs, T **dst, const T *src, size_t n)
+{
+    size_t got = 0;
+    void *d = ochip_pool_get(ctx, (n ? n : 1) * sizeof(T), &got);
+    if (!d)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation of %zu bytes failed in relax problem", n * sizeof(T));
+    allocs->emplace_back(d, got);
+    if (n && src)
+        if (hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+            return ochip_fail(ctx, OCHIP_EHIP, "hipMemcpy failed in relax problem");
+    *dst = (T *)d;
+    return OCHIP_OK;
+}
+
+} // namespace ochip
