@@ -118,6 +118,36 @@ extern "C"
                                              double *summary_out, uint32_t rank, uint32_t world,
                                              ochip_relax_exchange_fn exchange, void *user);
 
+    /* ---- relax, every flavour the device runs (opencalibration_amd/csrc/host/relax_mesh.hpp):
+     *      relax(graph, nodes, cam_models, edges, config, previousSurfaces) of src/relax/relax.cpp:118-134 with
+     *      config.options = bits of include/opencalibration/types/relax_options.hpp:9-33 in enum order (ORIENTATION = 1,
+     *      POSITION = 2, GROUND_PLANE = 4, GROUND_MESH = 8, ..., MINIMAL_MESH = 4096). ------------------------------ */
+    typedef struct och_surface och_surface; /* surface_model: mesh (vertices, edges with their opposite vertices) + cloud */
+    och_surface *och_surface_create(void);
+    void och_surface_destroy(och_surface *s);
+    void och_surface_counts(const och_surface *s, size_t *n_vertices, size_t *n_edges, size_t *n_cloud);
+    /* vertices n x 3; edges n x 5 {source, dest, border, opposite 0, opposite 1} (UINT64_MAX = none); cloud n x 3 */
+    void och_surface_get(const och_surface *s, double *vertices, uint64_t *edges5, double *cloud);
+    void och_surface_set(och_surface *s, size_t n_vertices, const double *vertices, size_t n_edges, const uint64_t *edges5,
+                         size_t n_cloud, const double *cloud);
+    /* rebuildMesh / buildMinimalMesh (src/surface/expand_mesh.cpp) from camera positions and an optional previous surface */
+    void och_rebuild_mesh(const double *cam_xyz, size_t n, const och_surface *previous, int minimal, och_surface *out);
+    /* Stand-alone problem from flat arrays, as och_relax_ground_plane plus what the mesh flavour reads: per node its
+     * feature locations (feat_off n_nodes + 1, feat_xy), per inlier the two feature indices (inl_feat n x 2).
+     * previous / surface_out may be NULL.  summary_out (12): solves, iterations_total, last_iterations,
+     * last_initial_cost, last_final_cost, last_residual_blocks, host setup seconds, device seconds, track blocks,
+     * 2-ray blocks, mesh vertices, unknowns of the last solve. */
+    int och_relax(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const double *node_ori, const double *model10,
+                  const uint64_t *feat_off, const double *feat_xy, size_t n_poses, const uint64_t *pose_node,
+                  double *pose_ori, size_t n_edges, const uint64_t *edge_src, const uint64_t *edge_dst, const double *edge_H,
+                  const uint8_t *edge_is_homography, const uint64_t *inl_off, const double *inl_px,
+                  const uint64_t *inl_feat, const uint64_t *inl_match_index, const uint64_t *dist_off, const double *dist,
+                  size_t n_opt_edges, const uint64_t *opt_edges, uint32_t options, double grid_fraction,
+                  const och_surface *previous, och_surface *surface_out, double *summary_out);
+    /* Every node of a linked graph as one group, every edge whitelisted, any flavour.  ori_inout: n_nodes x 4. */
+    int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
+                        const och_surface *previous, och_surface *surface_out, double *summary_out);
+
     /* ---- after a relax changed a camera model: the write-back half of RelaxGroup::finalize
      *      (src/relax/relax_group.cpp:125-177).  och_graph_set_model replaces the intrinsics of model `model` (m10 as for
      *      och_graph_add_model; every image sharing the model sees the change, as with the reference's

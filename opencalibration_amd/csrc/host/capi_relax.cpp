@@ -3,6 +3,7 @@
 
 #include "capi_graph.hpp"
 #include "relax.hpp"
+#include "relax_mesh.hpp"
 
 #include <cstring>
 
@@ -152,6 +153,239 @@ int och_graph_relax_ground_plane_sharded(och_graph *g, ochip_ctx *ctx, double *o
     shard.exchange = exchange;
     shard.user = user;
     return graph_relax_ground_plane(g, ctx, ori_inout, plane_out, summary_out, &shard);
+}
+
+
+// ---- surfaces and the general relax entry points ------------------------------------------------------------------
+} // extern "C"
+
+struct och_surface
+{
+    surface_model s;
+};
+
+static void fill_summary12(const RelaxTimers &t, const RelaxMeshStats &st, double *summary)
+{
+    if (!summary)
+        return;
+    fill_summary(t, summary);
+    summary[8] = st.track_blocks;
+    summary[9] = st.two_ray_blocks;
+    summary[10] = st.mesh_vertices;
+    summary[11] = st.unknowns;
+}
+
+extern "C"
+{
+
+och_surface *och_surface_create(void)
+{
+    return new och_surface();
+}
+void och_surface_destroy(och_surface *s)
+{
+    delete s;
+}
+void och_surface_counts(const och_surface *s, size_t *n_vertices, size_t *n_edges, size_t *n_cloud)
+{
+    if (n_vertices)
+        *n_vertices = s->s.mesh.size_nodes();
+    if (n_edges)
+        *n_edges = s->s.mesh.size_edges();
+    if (n_cloud)
+    {
+        *n_cloud = 0;
+        for (const auto &c : s->s.cloud)
+            *n_cloud += c.size();
+    }
+}
+void och_surface_get(const och_surface *s, double *vertices, uint64_t *edges5, double *cloud)
+{
+    const MeshGraph &m = s->s.mesh;
+    if (vertices)
+        for (size_t i = 0; i < m.nodes.size(); i++)
+            std::memcpy(vertices + 3 * i, m.nodes[i].location, 24);
+    if (edges5)
+        for (size_t i = 0; i < m.edges.size(); i++)
+        {
+            const MeshEdge &e = m.edges[i];
+            edges5[5 * i] = e.source, edges5[5 * i + 1] = e.dest, edges5[5 * i + 2] = e.border;
+            edges5[5 * i + 3] = e.triangleOppositeNodes[0], edges5[5 * i + 4] = e.triangleOppositeNodes[1];
+        }
+    if (cloud)
+    {
+        size_t k = 0;
+        for (const auto &c : s->s.cloud)
+            for (const auto &p : c)
+            {
+                std::memcpy(cloud + 3 * k, p.data(), 24);
+                k++;
+            }
+    }
+}
+void och_surface_set(och_surface *s, size_t n_vertices, const double *vertices, size_t n_edges, const uint64_t *edges5,
+                     size_t n_cloud, const double *cloud)
+{
+    s->s = surface_model();
+    for (size_t i = 0; i < n_vertices; i++)
+        s->s.mesh.addNode(vertices[3 * i], vertices[3 * i + 1], vertices[3 * i + 2]);
+    for (size_t i = 0; i < n_edges; i++)
+    {
+        MeshEdge e;
+        e.border = edges5[5 * i + 2] != 0;
+        e.triangleOppositeNodes[0] = (size_t)edges5[5 * i + 3];
+        e.triangleOppositeNodes[1] = (size_t)edges5[5 * i + 4];
+        s->s.mesh.addEdge(e, (size_t)edges5[5 * i], (size_t)edges5[5 * i + 1]);
+    }
+    if (n_cloud)
+    {
+        point_cloud c(n_cloud);
+        for (size_t i = 0; i < n_cloud; i++)
+            c[i] = {cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2]};
+        s->s.cloud.push_back(std::move(c));
+    }
+}
+void och_rebuild_mesh(const double *cam_xyz, size_t n, const och_surface *previous, int minimal, och_surface *out)
+{
+    point_cloud cams(n);
+    for (size_t i = 0; i < n; i++)
+        cams[i] = {cam_xyz[3 * i], cam_xyz[3 * i + 1], cam_xyz[3 * i + 2]};
+    std::vector<surface_model> prev;
+    if (previous)
+        prev.push_back(previous->s);
+    out->s = surface_model();
+    out->s.mesh = minimal ? buildMinimalMesh(cams, prev) : rebuildMesh(cams, prev);
+}
+
+int och_relax(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const double *node_ori, const double *model10,
+              const uint64_t *feat_off, const double *feat_xy, size_t n_poses, const uint64_t *pose_node, double *pose_ori,
+              size_t n_edges, const uint64_t *edge_src, const uint64_t *edge_dst, const double *edge_H,
+              const uint8_t *edge_is_homography, const uint64_t *inl_off, const double *inl_px, const uint64_t *inl_feat,
+              const uint64_t *inl_match_index, const uint64_t *dist_off, const double *dist, size_t n_opt_edges,
+              const uint64_t *opt_edges, uint32_t options, double grid_fraction, const och_surface *previous,
+              och_surface *surface_out, double *summary_out)
+{
+    MeasurementGraph graph;
+    auto model = std::make_shared<CameraModel>();
+    model->focal_length_pixels = model10[0];
+    model->principle_point[0] = model10[1];
+    model->principle_point[1] = model10[2];
+    for (int i = 0; i < 3; i++)
+        model->radial_distortion[i] = model10[3 + i];
+    model->tangential_distortion[0] = model10[6];
+    model->tangential_distortion[1] = model10[7];
+    model->pixels_cols = (size_t)model10[8];
+    model->pixels_rows = (size_t)model10[9];
+    model->id = 42;
+    std::vector<size_t> node_ids(n_nodes), edge_ids(n_edges);
+    for (size_t i = 0; i < n_nodes; i++)
+    {
+        image img;
+        img.model = model;
+        std::memcpy(img.position, node_pos + 3 * i, 24);
+        std::memcpy(img.orientation, node_ori + 4 * i, 32);
+        if (feat_off)
+            for (uint64_t k = feat_off[i]; k < feat_off[i + 1]; k++)
+            {
+                feature_2d f;
+                f.location[0] = feat_xy[2 * k], f.location[1] = feat_xy[2 * k + 1];
+                img.features.push_back(f);
+            }
+        node_ids[i] = graph.addNode(std::move(img));
+    }
+    for (size_t e = 0; e < n_edges; e++)
+    {
+        camera_relations rel;
+        if (edge_H)
+            std::memcpy(rel.ransac_relation, edge_H + 9 * e, 72);
+        rel.relationType = (edge_is_homography && edge_is_homography[e]) ? camera_relations::RelationType::HOMOGRAPHY
+                                                                         : camera_relations::RelationType::UNKNOWN;
+        for (uint64_t k = inl_off[e]; k < inl_off[e + 1]; k++)
+        {
+            feature_match_denormalized f;
+            f.pixel_1[0] = inl_px[4 * k], f.pixel_1[1] = inl_px[4 * k + 1];
+            f.pixel_2[0] = inl_px[4 * k + 2], f.pixel_2[1] = inl_px[4 * k + 3];
+            if (inl_feat)
+                f.feature_index_1 = inl_feat[2 * k], f.feature_index_2 = inl_feat[2 * k + 1];
+            f.match_index = inl_match_index[k];
+            rel.inlier_matches.push_back(f);
+        }
+        if (dist_off)
+            for (uint64_t k = dist_off[e]; k < dist_off[e + 1]; k++)
+                rel.matches.push_back(feature_match{0, 0, dist[k]});
+        edge_ids[e] = graph.addEdge(std::move(rel), node_ids[edge_src[e]], node_ids[edge_dst[e]]);
+    }
+    std::vector<NodePose> poses(n_poses);
+    for (size_t i = 0; i < n_poses; i++)
+    {
+        poses[i].node_id = node_ids[pose_node[i]];
+        std::memcpy(poses[i].orientation, pose_ori + 4 * i, 32);
+        std::memcpy(poses[i].position, node_pos + 3 * pose_node[i], 24);
+    }
+    std::vector<size_t> opt(n_opt_edges);
+    for (size_t i = 0; i < n_opt_edges; i++)
+        opt[i] = edge_ids[opt_edges[i]];
+    std::vector<std::pair<size_t, CameraModel>> cam_models{{model->id, *model}};
+    RelaxConfig cfg;
+    cfg.options = options;
+    cfg.ground_mesh_grid_fraction = grid_fraction;
+    std::vector<surface_model> prev;
+    if (previous)
+        prev.push_back(previous->s);
+    RelaxTimers t;
+    RelaxMeshStats st;
+    surface_model out;
+    if (!relax(ctx, graph, poses, cam_models, opt, cfg, prev, &out, &t, &st, &g_relax_error))
+        return -1;
+    for (size_t i = 0; i < n_poses; i++)
+        std::memcpy(pose_ori + 4 * i, poses[i].orientation, 32);
+    if (surface_out)
+        surface_out->s = std::move(out);
+    fill_summary12(t, st, summary_out);
+    return 0;
+}
+
+int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
+                    const och_surface *previous, och_surface *surface_out, double *summary_out)
+{
+    auto &nodes = g->graph.nodes();
+    std::vector<NodePose> poses(nodes.size());
+    std::vector<std::pair<size_t, CameraModel>> cam_models;
+    for (size_t i = 0; i < nodes.size(); i++)
+    {
+        poses[i].node_id = nodes[i].id;
+        std::memcpy(poses[i].orientation, ori_inout + 4 * i, 32);
+        std::memcpy(poses[i].position, nodes[i].payload.position, 24);
+        bool have = false;
+        for (const auto &m : cam_models)
+            have |= m.first == nodes[i].payload.model->id;
+        if (!have)
+            cam_models.emplace_back(nodes[i].payload.model->id, *nodes[i].payload.model);
+    }
+    std::vector<size_t> opt;
+    opt.reserve(g->graph.size_edges());
+    for (const auto &e : g->graph.edges())
+        opt.push_back(e.id);
+    RelaxConfig cfg;
+    cfg.options = options;
+    cfg.ground_mesh_grid_fraction = grid_fraction;
+    std::vector<surface_model> prev;
+    if (previous)
+        prev.push_back(previous->s);
+    RelaxTimers t;
+    RelaxMeshStats st;
+    surface_model out;
+    if (!relax(ctx, g->graph, poses, cam_models, opt, cfg, prev, &out, &t, &st, &g->error))
+        return -1;
+    for (size_t i = 0; i < nodes.size(); i++)
+    {
+        std::memcpy(ori_inout + 4 * i, poses[i].orientation, 32);
+        std::memcpy(nodes[i].payload.orientation, poses[i].orientation, 32);
+    }
+    if (surface_out)
+        surface_out->s = std::move(out);
+    fill_summary12(t, st, summary_out);
+    return 0;
 }
 
 } // extern "C"

@@ -1,6 +1,6 @@
 #include "relax.hpp"
 
-#include "ransac.hpp" // image_to_3d
+#include "relax_util.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -14,101 +14,7 @@ namespace opencalibration_amd
 
 namespace
 {
-using clk = std::chrono::steady_clock;
-double since(clk::time_point t0)
-{
-    return std::chrono::duration<double>(clk::now() - t0).count();
-}
-
-struct v3
-{
-    double x, y, z;
-};
-inline v3 sub(const v3 &a, const v3 &b)
-{
-    return {a.x - b.x, a.y - b.y, a.z - b.z};
-}
-inline v3 add(const v3 &a, const v3 &b)
-{
-    return {a.x + b.x, a.y + b.y, a.z + b.z};
-}
-inline v3 mul(const v3 &a, double s)
-{
-    return {a.x * s, a.y * s, a.z * s};
-}
-inline double dot(const v3 &a, const v3 &b)
-{
-    return a.x * b.x + a.y * b.y + a.z * b.z;
-}
-inline v3 cross(const v3 &a, const v3 &b)
-{
-    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
-}
-inline bool finite4(const double *q)
-{
-    return std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]) && std::isfinite(q[3]);
-}
-inline bool finite3(const double *p)
-{
-    return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]);
-}
-inline bool hasnan4(const double *q)
-{
-    return std::isnan(q[0]) || std::isnan(q[1]) || std::isnan(q[2]) || std::isnan(q[3]);
-}
-
-// Eigen::Quaternion::toRotationMatrix
-void to_matrix(const double *q, double R[3][3])
-{
-    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
-    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
-    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
-    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
-    R[0][0] = 1 - (tyy + tzz), R[0][1] = txy - twz, R[0][2] = txz + twy;
-    R[1][0] = txy + twz, R[1][1] = 1 - (txx + tzz), R[1][2] = tyz - twx;
-    R[2][0] = txz - twy, R[2][1] = tyz + twx, R[2][2] = 1 - (txx + tyy);
-}
-inline v3 apply(const double R[3][3], const v3 &v)
-{
-    return {R[0][0] * v.x + R[0][1] * v.y + R[0][2] * v.z, R[1][0] * v.x + R[1][1] * v.y + R[1][2] * v.z,
-            R[2][0] * v.x + R[2][1] * v.y + R[2][2] * v.z};
-}
-// Eigen QuaternionBase::_transformVector
-inline v3 rotate(const double *q, const v3 &v)
-{
-    const v3 qv{q[0], q[1], q[2]};
-    v3 uv = cross(qv, v);
-    uv = add(uv, uv);
-    return add(add(v, mul(uv, q[3])), cross(qv, uv));
-}
-
-// src/geometry/intersection.cpp:116-143: midpoint of closest approach, signed squared gap
-void ray_intersection(const v3 &d1, const v3 &o1, const v3 &d2, const v3 &o2, v3 *mid, double *err)
-{
-    *mid = {NAN, NAN, NAN};
-    *err = NAN;
-    const double n11 = dot(d1, d1), n12 = dot(d1, d2), n22 = dot(d2, d2);
-    const double denom = n11 * n22 - n12 * n12;
-    if (std::abs(denom) > 1e-9)
-    {
-        const v3 off = sub(o1, o2);
-        const double od1 = dot(off, d1), od2 = dot(off, d2);
-        const double t = (n12 * od2 - n22 * od1) / denom;
-        const double s = (n11 * od2 - n12 * od1) / denom;
-        const v3 p1 = add(o1, mul(d1, t)), p2 = add(o2, mul(d2, s));
-        *mid = mul(add(p1, p2), 0.5);
-        const v3 g = sub(p1, p2);
-        *err = dot(g, g) * (t >= 0 && s >= 0 ? 1 : -1);
-    }
-}
-
-struct pose_ref // OptimizationPackage::PoseOpt (relax_problem.cpp:182-232)
-{
-    bool optimize = false;
-    const double *loc = nullptr;
-    const double *rot = nullptr;
-    uint32_t cam = 0; // index into the device camera table
-};
+using namespace relax_detail;
 
 // One ground-plane problem: host assembly + device solve.
 class GroundPlaneProblem
@@ -166,7 +72,7 @@ class GroundPlaneProblem
         {
             const MeasurementGraph::Edge *e = _graph.getEdge(edges_to_optimize[k]);
             if (e != nullptr)
-                keep[k] = grid_filter(*e, src[k], dst[k], 0.15);
+                keep[k] = grid_filter(_graph, *e, src[k], dst[k], 0.15);
         }
 
         // addRayTriangleMeasurementCost (:388-560), fixed intrinsics.  The searcher's orientation fix-up of
@@ -363,118 +269,6 @@ class GroundPlaneProblem
             _xy[i][1] = c[i][1];
             _z[i] = height;
         }
-    }
-
-    // Scores of gridFilterMatchesPerImage + GridFilter::addMeasurement (grid_filter.hpp:33-51): the
-    // measurements arrive best-first, so the first one in a cell stays.  Returns per inlier: bit0 = on the
-    // source whitelist, bit1 = on the dest whitelist.
-    std::vector<uint8_t> grid_filter(const MeasurementGraph::Edge &edge, const pose_ref &s, const pose_ref &d,
-                                     double res) const
-    {
-        const camera_relations &rel = edge.payload;
-        const CameraModel &sm = *_graph.getNode(edge.source)->payload.model, &dm = *_graph.getNode(edge.dest)->payload.model;
-        double Rs[3][3], Rd[3][3];
-        to_matrix(s.rot, Rs);
-        to_matrix(d.rot, Rd);
-        const v3 so{s.loc[0], s.loc[1], s.loc[2]}, d_o{d.loc[0], d.loc[1], d.loc[2]};
-        std::vector<std::pair<double, size_t>> scored;
-        scored.reserve(rel.inlier_matches.size());
-        for (size_t idx = 0; idx < rel.inlier_matches.size(); idx++)
-        {
-            const feature_match_denormalized &m = rel.inlier_matches[idx];
-            double r1[3], r2[3];
-            image_to_3d(m.pixel_1, sm, r1);
-            image_to_3d(m.pixel_2, dm, r2);
-            const v3 sd = apply(Rs, v3{r1[0], r1[1], r1[2]}), dd = apply(Rd, v3{r2[0], r2[1], r2[2]});
-            v3 mid;
-            double gap;
-            ray_intersection(sd, so, dd, d_o, &mid, &gap);
-            const double intersection_score = gap < 0 ? 0. : 1. / (1. + gap);
-            const double cos_angle = dot(sd, dd);
-            const double angle_score = 1.0 - cos_angle * cos_angle;
-            const double descriptor_score =
-                m.match_index < rel.matches.size() ? 1.0 - rel.matches[m.match_index].distance : 1.0;
-            double ransac_score = 1.0;
-            if (rel.relationType == camera_relations::RelationType::HOMOGRAPHY)
-            {
-                const double sx = (m.pixel_1[0] - sm.principle_point[0]) / sm.focal_length_pixels;
-                const double sy = (m.pixel_1[1] - sm.principle_point[1]) / sm.focal_length_pixels;
-                const double dx = (m.pixel_2[0] - dm.principle_point[0]) / dm.focal_length_pixels;
-                const double dy = (m.pixel_2[1] - dm.principle_point[1]) / dm.focal_length_pixels;
-                const double *H = rel.ransac_relation;
-                const double hx = H[0] * sx + H[1] * sy + H[2] * 1.0, hy = H[3] * sx + H[4] * sy + H[5] * 1.0,
-                             hz = H[6] * sx + H[7] * sy + H[8] * 1.0;
-                const double ex = dx - hx / hz, ey = dy - hy / hz;
-                ransac_score = 1.0 / (1.0 + std::sqrt(ex * ex + ey * ey));
-            }
-            scored.emplace_back(intersection_score * angle_score * descriptor_score * ransac_score, idx);
-        }
-        std::vector<uint8_t> keep(rel.inlier_matches.size(), 0);
-        auto cell = [res](double x, double y, int *cx, int *cy) {
-            *cx = (int)std::floor(x / res);
-            *cy = (int)std::floor(y / res);
-        };
-        // GridFilter::addMeasurement keeps, per cell of each image, the first measurement in descending score order,
-        // i.e. the best-scoring one.  That needs no sort unless two candidates for a cell's best tie exactly (the
-        // unstable std::sort then decides): one pass over a small dense cell table, and the sorted walk only as the
-        // fall-back for ties or cells outside the table.
-        constexpr int G = 16; // cells per axis the table covers (pixels / image size lies in [0, 1): 1 / 0.15 < 7)
-        int best_s[G * G], best_d[G * G];
-        std::fill(best_s, best_s + G * G, -1);
-        std::fill(best_d, best_d + G * G, -1);
-        bool exact = true;
-        for (size_t k = 0; k < scored.size() && exact; k++)
-        {
-            const double score = scored[k].first;
-            if (!(score > 0))
-                continue;
-            const feature_match_denormalized &m = rel.inlier_matches[scored[k].second];
-            int cx, cy, dx, dy;
-            cell(m.pixel_1[0] / sm.pixels_cols, m.pixel_1[1] / sm.pixels_rows, &cx, &cy);
-            cell(m.pixel_2[0] / dm.pixels_cols, m.pixel_2[1] / dm.pixels_rows, &dx, &dy);
-            if (cx < 0 || cy < 0 || cx >= G || cy >= G || dx < 0 || dy < 0 || dx >= G || dy >= G)
-            {
-                exact = false;
-                break;
-            }
-            int &bs = best_s[cx * G + cy], &bd = best_d[dx * G + dy];
-            if (bs < 0 || score > scored[bs].first)
-                bs = (int)k;
-            else if (score == scored[bs].first)
-                exact = false;
-            if (bd < 0 || score > scored[bd].first)
-                bd = (int)k;
-            else if (score == scored[bd].first)
-                exact = false;
-        }
-        if (exact)
-        {
-            for (int c = 0; c < G * G; c++)
-            {
-                if (best_s[c] >= 0)
-                    keep[scored[best_s[c]].second] |= 1;
-                if (best_d[c] >= 0)
-                    keep[scored[best_d[c]].second] |= 2;
-            }
-            return keep;
-        }
-        std::fill(keep.begin(), keep.end(), 0);
-        std::sort(scored.begin(), scored.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
-        std::unordered_map<uint64_t, char> scell, dcell;
-        auto key = [res](double x, double y) {
-            return (static_cast<uint64_t>((int)std::floor(x / res)) << 32) | static_cast<uint32_t>((int)std::floor(y / res));
-        };
-        for (const auto &[score, idx] : scored)
-        {
-            if (!(score > 0))
-                continue;
-            const feature_match_denormalized &m = rel.inlier_matches[idx];
-            if (scell.emplace(key(m.pixel_1[0] / sm.pixels_cols, m.pixel_1[1] / sm.pixels_rows), 1).second)
-                keep[idx] |= 1;
-            if (dcell.emplace(key(m.pixel_2[0] / dm.pixels_cols, m.pixel_2[1] / dm.pixels_rows), 1).second)
-                keep[idx] |= 2;
-        }
-        return keep;
     }
 
     // MeshIntersectionSearcher::triangleIntersect (src/surface/intersect.cpp:56-163) on the single

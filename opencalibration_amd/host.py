@@ -92,6 +92,20 @@ def load():
         L.och_relax_last_error.restype = C.c_char_p
         L.och_graph_relax_ground_plane.argtypes = [vp, vp, _f64p, _f64p, _f64p]
         L.och_graph_relax_ground_plane_sharded.argtypes = [vp, vp, _f64p, _f64p, _f64p, u32, u32, RELAX_EXCHANGE_FN, vp]
+        L.och_surface_create.restype = vp
+        L.och_surface_destroy.argtypes = [vp]
+        L.och_surface_destroy.restype = None
+        L.och_surface_counts.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+        L.och_surface_counts.restype = None
+        L.och_surface_get.argtypes = [vp, vp, vp, vp]
+        L.och_surface_get.restype = None
+        L.och_surface_set.argtypes = [vp, sz, _f64p, sz, _u64p, sz, _f64p]
+        L.och_surface_set.restype = None
+        L.och_rebuild_mesh.argtypes = [_f64p, sz, vp, C.c_int, vp]
+        L.och_rebuild_mesh.restype = None
+        L.och_relax.argtypes = [vp, sz, _f64p, _f64p, _f64p, _u64p, _f64p, sz, _u64p, _f64p, sz, _u64p, _u64p, vp, u8p, _u64p,
+                                _f64p, _u64p, _u64p, vp, vp, sz, _u64p, u32, C.c_double, vp, vp, _f64p]
+        L.och_graph_relax.argtypes = [vp, vp, _f64p, u32, C.c_double, vp, vp, _f64p]
         L.och_homography_decompose.argtypes = [_f64p, _f64p, sz, _f64p]
         L.och_image_to_3d.argtypes = [_f64p, sz, _f64p, _f64p]
         L.och_extract_tail.restype = C.c_size_t
@@ -133,6 +147,90 @@ def extract_features_batch(ctx, images_bgr, max_keypoints=20000, device_shape=No
 
 RELAX_SUMMARY_NAMES = ["solves", "iterations_total", "last_iterations", "initial_cost", "final_cost", "residual_blocks",
                        "setup_host_s", "device_s"]
+
+
+RELAX_OPTIONS = dict(ORIENTATION=1 << 0, POSITION=1 << 1, GROUND_PLANE=1 << 2, GROUND_MESH=1 << 3, POINTS_3D=1 << 4,
+                     FOCAL_LENGTH=1 << 5, PRINCIPAL_POINT=1 << 6, LENS_DISTORTIONS_RADIAL=1 << 7, BROWN2=1 << 8, BROWN24=1 << 9,
+                     BROWN246=1 << 10, LENS_DISTORTIONS_TANGENTIAL=1 << 11, MINIMAL_MESH=1 << 12)
+RELAX_SUMMARY12 = ["solves", "iterations_total", "last_iterations", "initial_cost", "final_cost", "residual_blocks",
+                   "setup_host_s", "device_s", "track_blocks", "two_ray_blocks", "mesh_vertices", "unknowns"]
+
+
+def relax_options(*names):
+    bits = 0
+    for n in names:
+        bits |= RELAX_OPTIONS[n]
+    return bits
+
+
+class Surface:
+    """surface_model of the host library: mesh (vertices, edges {source, dest, border, opposite 0, opposite 1}) + cloud."""
+
+    def __init__(self):
+        self.L = load()
+        self.h = self.L.och_surface_create()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.och_surface_destroy(self.h)
+            self.h = None
+
+    def arrays(self):
+        nv, ne, nc = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self.L.och_surface_counts(self.h, C.byref(nv), C.byref(ne), C.byref(nc))
+        v, e, c = np.zeros((max(nv.value, 1), 3)), np.zeros((max(ne.value, 1), 5), np.uint64), np.zeros((max(nc.value, 1), 3))
+        self.L.och_surface_get(self.h, v.ctypes.data, e.ctypes.data, c.ctypes.data)
+        return dict(vertices=v[:nv.value], edges=e[:ne.value], cloud=c[:nc.value])
+
+    def set(self, vertices, edges, cloud=None):
+        v = np.ascontiguousarray(vertices, np.float64).reshape(-1, 3)
+        e = np.ascontiguousarray(edges, np.uint64).reshape(-1, 5)
+        c = np.zeros((0, 3)) if cloud is None else np.ascontiguousarray(cloud, np.float64).reshape(-1, 3)
+        pad = lambda a, shape, dt: a if len(a) else np.zeros(shape, dt)
+        self.L.och_surface_set(self.h, len(v), pad(v, (1, 3), np.float64), len(e), pad(e, (1, 5), np.uint64), len(c),
+                               pad(c, (1, 3), np.float64))
+        return self
+
+
+def rebuild_mesh(cam_xyz, previous=None, minimal=False):
+    """rebuildMesh / buildMinimalMesh of the host library (no device involved)."""
+    cam_xyz = np.ascontiguousarray(cam_xyz, np.float64).reshape(-1, 3)
+    s = Surface()
+    s.L.och_rebuild_mesh(cam_xyz, len(cam_xyz), previous.h if previous is not None else None, int(minimal), s.h)
+    return s
+
+
+def relax(ctx, node_pos, node_ori, model10, features, pose_node, pose_ori, packed_edges, options, grid_fraction=0.1,
+          opt_edges=None, previous=None):
+    """relax(graph, nodes, cam_models, edges, config, previousSurfaces) on the device, any flavour.  features: per node
+    an (k x 2) array of feature locations; packed_edges as for relax_ground_plane plus 'feat' (inliers x 2 feature
+    indices)."""
+    L = load()
+    node_pos = np.ascontiguousarray(node_pos, np.float64)
+    node_ori = np.ascontiguousarray(node_ori, np.float64)
+    pose_node = np.ascontiguousarray(pose_node, np.uint64)
+    pose_ori = np.ascontiguousarray(pose_ori, np.float64).copy()
+    feat_off = np.concatenate([[0], np.cumsum([len(f) for f in features])]).astype(np.uint64)
+    feat_xy = np.ascontiguousarray(np.concatenate([np.asarray(f, np.float64).reshape(-1, 2) for f in features])
+                                   if feat_off[-1] else np.zeros((1, 2)))
+    pk = packed_edges
+    n_edges = len(pk["src"])
+    opt = np.ascontiguousarray(np.arange(n_edges) if opt_edges is None else opt_edges, np.uint64)
+    summary = np.zeros(12)
+    out_surface = Surface()
+    rc = L.och_relax(ctx.h, len(node_pos), node_pos, node_ori, np.ascontiguousarray(model10, np.float64), feat_off, feat_xy,
+                     len(pose_node), pose_node, pose_ori, n_edges, pk["src"], pk["dst"], pk["H"].ctypes.data, pk["is_h"],
+                     pk["inl_off"], pk["px"], np.ascontiguousarray(pk["feat"], np.uint64), pk["match_index"],
+                     pk["dist_off"].ctypes.data, pk["dist"].ctypes.data, len(opt), opt if len(opt) else np.zeros(1, np.uint64),
+                     options, grid_fraction, previous.h if previous is not None else None, out_surface.h, summary)
+    if rc != 0:
+        raise capi.OchipError("relax failed: " + L.och_relax_last_error().decode())
+    out = dict(zip(RELAX_SUMMARY12, summary.tolist()))
+    out.update(orientation=pose_ori, surface=out_surface)
+    for k in ("solves", "iterations_total", "last_iterations", "residual_blocks", "track_blocks", "two_ray_blocks",
+              "mesh_vertices", "unknowns"):
+        out[k] = int(out[k])
+    return out
 
 
 def relax_ground_plane(ctx, node_pos, node_ori, model10, pose_node, pose_ori, packed_edges, opt_edges=None):
@@ -283,6 +381,19 @@ class Graph:
             raise capi.OchipError("relax failed: " + self.L.och_last_error(self.h).decode())
         out = dict(zip(RELAX_SUMMARY_NAMES, summary.tolist()))
         out.update(orientation=ori, plane=plane.reshape(3, 3))
+        return out
+
+    def relax(self, ctx, orientations, options, grid_fraction=0.1, previous=None):
+        """All nodes as one relax group, every edge whitelisted, any flavour (options: relax_options(...))."""
+        ori = np.ascontiguousarray(orientations, np.float64).copy()
+        summary = np.zeros(12)
+        surface = Surface()
+        rc = self.L.och_graph_relax(self.h, ctx.h, ori, options, grid_fraction, previous.h if previous is not None else None,
+                                    surface.h, summary)
+        if rc != 0:
+            raise capi.OchipError("relax failed: " + self.L.och_last_error(self.h).decode())
+        out = dict(zip(RELAX_SUMMARY12, summary.tolist()))
+        out.update(orientation=ori, surface=surface)
         return out
 
     def link_debug(self):

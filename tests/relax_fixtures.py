@@ -101,16 +101,13 @@ def camera_grid(rows, cols, seed=3, height=10.0, spacing=2.0, yaw_sigma=0.05, pt
     return ori, pos, edges, model
 
 
-def rx_graph_from_edges(oracle, node_pos, node_ori, model10, edges, paths=None):
-    """The flat edge dicts of this module as a MeasurementGraph of oracle/relax_full.cpp: every inlier of an edge becomes a
+def features_of_edges(n_nodes, edges):
+    """Per node its feature list and per edge the feature indices of its inliers: every inlier of an edge becomes a
     feature of both images (feature indices = positions in the images' feature lists, as assembleInliers records them);
     an inlier that carries 'pid' (a ground point id) shares its feature across the edges of an image, which is what
     makes multi-image tracks (test_relax.cpp:91-125 indexes features by point that way)."""
-    g = oracle.RxGraph()
-    g.add_model(model10, 42)
-    n = len(node_pos)
-    feats = [[] for _ in range(n)]
-    index = [dict() for _ in range(n)]
+    feats = [[] for _ in range(n_nodes)]
+    index = [dict() for _ in range(n_nodes)]
     plan = []
     for e in edges:
         k = len(e["px"])
@@ -127,11 +124,43 @@ def rx_graph_from_edges(oracle, node_pos, node_ori, model10, edges, paths=None):
                         index[node][key] = out[j]
                     feats[node].append(e["px"][j][col:col + 2])
         plan.append((f1, f2))
+    return [np.array(f, np.float64).reshape(-1, 2) for f in feats], plan
+
+
+def rx_graph_from_edges(oracle, node_pos, node_ori, model10, edges, paths=None):
+    """The flat edge dicts of this module as a MeasurementGraph of oracle/relax_full.cpp."""
+    g = oracle.RxGraph()
+    g.add_model(model10, 42)
+    n = len(node_pos)
+    feats, plan = features_of_edges(n, edges)
     for i in range(n):
-        g.add_node(node_pos[i], node_ori[i], 0, np.array(feats[i]).reshape(-1, 2), None if paths is None else paths[i])
+        g.add_node(node_pos[i], node_ori[i], 0, feats[i], None if paths is None else paths[i])
     for e, (f1, f2) in zip(edges, plan):
         g.add_edge(e["src"], e["dst"], e["px"], f1, f2, e["match_index"], e.get("H"), e.get("dist"))
     return g, feats
+
+
+def pack_edges_with_features(oracle, n_nodes, edges):
+    """pack_edges + 'feat' (inliers x 2 feature indices) and the per-node feature lists, for the product's relax()."""
+    feats, plan = features_of_edges(n_nodes, edges)
+    pk = oracle.pack_edges(edges)
+    total = int(pk["inl_off"][-1])
+    feat = np.zeros((max(total, 1), 2), np.uint64)
+    o = 0
+    for f1, f2 in plan:
+        feat[o:o + len(f1), 0], feat[o:o + len(f1), 1] = f1, f2
+        o += len(f1)
+    pk["feat"] = feat
+    return pk, feats
+
+
+def camera_grid_tracks(rows, cols, **kw):
+    """camera_grid whose inliers carry the id of their ground point ('pid'), so that features are shared between the
+    edges of an image and multi-image tracks form."""
+    ori, pos, edges, model = camera_grid(rows, cols, **kw)
+    for e in edges:
+        e["pid"] = e["point_ids"]
+    return ori, pos, edges, model
 
 
 def ring_edges_tracks(ori, pos, points, model=MODEL_600):
