@@ -97,7 +97,7 @@ def camera_grid(rows, cols, seed=3, height=10.0, spacing=2.0, yaw_sigma=0.05, pt
                     both = np.flatnonzero(vis[i] & vis[j])
                     if len(both) >= 8:
                         edges.append(dict(src=i, dst=j, H=None, px=np.concatenate([px[i][both], px[j][both]], axis=1),
-                                          match_index=np.arange(len(both)), dist=None))
+                                          match_index=np.arange(len(both)), dist=None, point_ids=both))
     return ori, pos, edges, model
 
 

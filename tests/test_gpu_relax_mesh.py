@@ -74,14 +74,24 @@ def test_grid_two_ray_blocks_only(ctx, oracle, minimal):
 
 @pytest.mark.parametrize("frac", [0.1, 0.05])
 def test_grid_tracks_and_two_ray_fallback(ctx, oracle, frac):
-    """Shared features: tracks of 3..5 rays take the cells they cover, 2-ray blocks fill in (relax_problem.cpp:93-115)."""
+    """Shared features with pixel noise: tracks of 3..5 rays take the cells they cover, 2-ray blocks fill in
+    (relax_problem.cpp:93-115).  The grid mesh (783 vertices) takes its heights from a previous surface's point cloud;
+    the second run re-uses the relaxed mesh."""
     ori, pos, edges, model = camera_grid_tracks(6, 7)
     rng = np.random.default_rng(8)
+    for e in edges:
+        e["px"] = e["px"] + rng.normal(0, 0.3, e["px"].shape)
     q = np.array([qmul(ori[i], axis_angle(rng.normal(size=3) / 2, 0.05)) for i in range(len(ori))])
-    exp, got = _both(ctx, oracle, pos, ori, model, q, edges, ["ORIENTATION", "GROUND_MESH"], frac)
-    assert exp["track_blocks"] > 50 and exp["two_ray_blocks"] > 0
+    gx = np.linspace(-4, 16, 9)
+    cloud = np.array([[x, y, 1e-3 * x + 1e-2 * y] for x in gx for y in gx])
+    prev = dict(vertices=np.zeros((0, 3)), edges=np.zeros((0, 5), np.uint64), cloud=cloud)
+    exp, got = _both(ctx, oracle, pos, ori, model, q, edges, ["ORIENTATION", "GROUND_MESH"], frac, prev)
+    assert exp["track_blocks"] > 50 and exp["two_ray_blocks"] > 1000 and len(exp["surface"].arrays()["vertices"]) > 500
     _assert_same(exp, got, iter_slack=3)
-    assert np.median([qangle(got["orientation"][i], ori[i]) for i in range(len(ori))]) < 5e-3
+    exp2, got2 = _both(ctx, oracle, pos, ori, model, got["orientation"], edges, ["ORIENTATION", "GROUND_MESH"], frac,
+                       got["surface"].arrays())
+    _assert_same(exp2, got2, iter_slack=3)
+    assert np.median([qangle(got2["orientation"][i], ori[i]) for i in range(len(ori))]) < 2e-3
 
 
 def test_ground_plane_through_the_general_entry_point(ctx, oracle):
