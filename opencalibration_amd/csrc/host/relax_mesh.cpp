@@ -4,7 +4,10 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <limits>
+#include <map>
+#include <memory>
 #include <numeric>
 
 namespace opencalibration_amd
@@ -450,15 +453,6 @@ inline uint64_t cell_key(int i, int j) // gridCellKey, grid_filter.hpp:11-14
     return (static_cast<uint64_t>(i) << 32) | static_cast<uint32_t>(j);
 }
 
-struct measurement_key // NodeIdFeatureIndex with the node as its index in the graph's node list
-{
-    uint64_t k;
-    static measurement_key of(size_t node_index, size_t feature)
-    {
-        return measurement_key{((uint64_t)node_index << 32) | (uint64_t)(uint32_t)feature};
-    }
-};
-
 class GroundMeshProblem
 {
   public:
@@ -476,6 +470,13 @@ class GroundMeshProblem
                const std::vector<size_t> &edges_to_optimize, const RelaxConfig &config,
                const std::vector<surface_model> &previous, RelaxMeshStats *stats, std::string *error)
     {
+        const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+        auto tmark = clk::now();
+        auto lap = [&](const char *what) {
+            if (verbose)
+                fprintf(stderr, "[relax mesh setup] %-28s %.3f ms\n", what, since(tmark) * 1e3);
+            tmark = clk::now();
+        };
         _poses = &poses;
         _cam_models = &cam_models;
         for (size_t i = 0; i < poses.size(); i++)
@@ -502,7 +503,9 @@ class GroundMeshProblem
             src.push_back(lookup(e->source));
             dst.push_back(lookup(e->dest));
         }
+        lap("mesh + pose lookup");
         build_tracks(edges, src, dst, frac);
+        lap("tracks");
         if (stats)
             stats->track_blocks = (int)_blk_n.size();
         const size_t n_track_blocks = _blk_n.size();
@@ -519,6 +522,7 @@ class GroundMeshProblem
 #pragma omp parallel for schedule(dynamic, 1)
         for (size_t k = 0; k < n_filter; k++)
             keep[k] = grid_filter(_graph, *edges[k], src[k], dst[k], frac);
+        lap("grid filter");
         // addRayTriangleMeasurementCost (:388-560) per edge, every edge with a mesh walker of its own
         std::vector<edge_blocks> per_edge(edges.size());
         const bool mesh_ok = _mesh.size_nodes() > 0 && _mesh.size_edges() > 0;
@@ -536,6 +540,7 @@ class GroundMeshProblem
                 _ray_dir.insert(_ray_dir.end(), pe.rays.begin() + 6 * b, pe.rays.begin() + 6 * b + 6);
                 _blk_tri.insert(_blk_tri.end(), pe.tri.begin() + 3 * b, pe.tri.begin() + 3 * b + 3);
             }
+        lap("2-ray blocks");
         if (stats)
         {
             stats->two_ray_blocks = (int)(_blk_n.size() - n_track_blocks);
@@ -598,6 +603,7 @@ class GroundMeshProblem
             *error = std::string("ochip_relaxg_problem_create: ") + ochip_last_error(_ctx);
             return false;
         }
+        lap("ochip_relaxg_problem_create");
         return true;
     }
 
@@ -657,12 +663,12 @@ class GroundMeshProblem
             const size_t views = tr.views;
             if (tr.min_error > (views >= 3 ? 10.0 : 1.0))
                 continue;
-            if (tr.points.size() == 1)
+            if (tr.n_points == 1)
                 pts.push_back({tr.points[0].x, tr.points[0].y, tr.points[0].z});
             else
             {
-                const int n = std::min<int>((int)tr.points.size(), 5);
-                const v3 c = robust_centroid(tr.points.data(), n, 1.0);
+                const int n = std::min<int>((int)tr.n_points, 5);
+                const v3 c = robust_centroid(tr.points, n, 1.0);
                 pts.push_back({c.x, c.y, c.z});
             }
         }
@@ -679,7 +685,8 @@ class GroundMeshProblem
     };
     struct cloud_track
     {
-        std::vector<v3> points;
+        v3 points[5]; // the first five finite points (robustCentroid looks at no more)
+        size_t n_points = 0;
         double min_error = std::numeric_limits<double>::infinity();
         size_t views = 0;
     };
@@ -754,193 +761,303 @@ class GroundMeshProblem
             _mesh = rebuildMesh(cams, previous);
     }
 
-    // collectEdgeTracks (:351-386) + addMultiRayTrackCosts (:608-929)
+    // collectEdgeTracks (:351-386) + addMultiRayTrackCosts (:608-929).  The reference builds one FeatureTrack per inlier
+    // of every edge, merges the ones that share a measurement (union-find over a hash map of measurements), keeps per image
+    // and grid cell the longest merged track, and turns the survivors into 3..5-ray blocks.  Same sets, same order (tracks
+    // in the order of their first two-view member, rays in order of appearance), on flat arrays: measurements are
+    // (node index, feature index) pairs, so "who held this measurement first" is an array per image.
     void build_tracks(const std::vector<const MeasurementGraph::Edge *> &edges, const std::vector<pose_ref> &src,
                       const std::vector<pose_ref> &dst, double frac)
     {
-        // one two-view track per inlier of every edge whose two poses are usable, in edge order
-        struct view
-        {
-            size_t node, feature;
+        const size_t n_nodes = _graph.size_nodes();
+        const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+        auto tmark = clk::now();
+        auto lap = [&](const char *what) {
+            if (verbose)
+                fprintf(stderr, "[relax mesh tracks] %-27s %.3f ms\n", what, since(tmark) * 1e3);
+            tmark = clk::now();
         };
         struct two_view
         {
-            view a, b;
+            uint32_t na, nb, fa, fb; // node indices and feature indices of the two measurements
             v3 point;
             double error;
         };
-        std::vector<two_view> tv;
+        std::vector<size_t> first(edges.size() + 1, 0);
+        for (size_t k = 0; k < edges.size(); k++)
+            first[k + 1] = first[k] + ((src[k].loc && dst[k].loc) ? edges[k]->payload.inlier_matches.size() : 0);
+        std::vector<two_view> tv(first.back());
+        if (tv.empty())
+            return;
+        if (tv.size() >= UINT32_MAX)
+            return; // (far beyond what fits the device anyway)
+#pragma omp parallel for schedule(dynamic, 4)
         for (size_t k = 0; k < edges.size(); k++)
         {
-            if (src[k].loc == nullptr || dst[k].loc == nullptr)
+            if (first[k + 1] == first[k])
                 continue;
             const MeasurementGraph::Edge &e = *edges[k];
             const CameraModel &sm = model_of(e.source), &dm = model_of(e.dest);
             const v3 so{src[k].loc[0], src[k].loc[1], src[k].loc[2]}, d_o{dst[k].loc[0], dst[k].loc[1], dst[k].loc[2]};
+            const uint32_t na = (uint32_t)_graph.nodeIndex(e.source), nb = (uint32_t)_graph.nodeIndex(e.dest);
+            two_view *out = &tv[first[k]];
             for (const feature_match_denormalized &m : e.payload.inlier_matches)
             {
                 double r1[3], r2[3];
                 image_to_3d(m.pixel_1, sm, r1);
                 image_to_3d(m.pixel_2, dm, r2);
-                two_view t;
-                t.a = view{e.source, m.feature_index_1};
-                t.b = view{e.dest, m.feature_index_2};
+                out->na = na, out->nb = nb;
+                out->fa = (uint32_t)m.feature_index_1, out->fb = (uint32_t)m.feature_index_2;
                 ray_intersection(rotate(src[k].rot, v3{r1[0], r1[1], r1[2]}), so, rotate(dst[k].rot, v3{r2[0], r2[1], r2[2]}), d_o,
-                                 &t.point, &t.error);
-                tv.push_back(t);
+                                 &out->point, &out->error);
+                out++;
             }
         }
-        if (tv.empty())
-            return;
-        // merge two-view tracks that share a measurement (union-find over the first holder of every measurement)
-        std::vector<uint32_t> parent(tv.size());
-        std::iota(parent.begin(), parent.end(), 0u);
-        auto find = [&](uint32_t x) {
-            while (parent[x] != x)
-            {
-                parent[x] = parent[parent[x]];
-                x = parent[x];
-            }
-            return x;
-        };
+        lap("two-view intersections");
+        // Merge: the measurements (image, feature) are the vertices, every two-view track an edge between two of them; a
+        // merged track is a connected component.  Lock-free union-find over the measurement ids (the smaller id always
+        // becomes the root, so the outcome does not depend on the threads' interleaving).
+        const uint32_t M = (uint32_t)tv.size();
+        std::vector<uint32_t> meas_off(n_nodes + 1, 0);
         {
-            std::unordered_map<uint64_t, uint32_t> holder;
-            holder.reserve(2 * tv.size());
-            auto key = [&](const view &v) { return measurement_key::of(_graph.nodeIndex(v.node), v.feature).k; };
-            for (uint32_t i = 0; i < tv.size(); i++)
-                for (const view *v : {&tv[i].a, &tv[i].b})
+            std::vector<uint32_t> n_feat(n_nodes, 0);
+            for (const two_view &t : tv)
+            {
+                n_feat[t.na] = std::max(n_feat[t.na], t.fa + 1);
+                n_feat[t.nb] = std::max(n_feat[t.nb], t.fb + 1);
+            }
+            for (size_t i = 0; i < n_nodes; i++)
+                meas_off[i + 1] = meas_off[i] + n_feat[i];
+        }
+        const uint32_t n_meas = meas_off[n_nodes];
+        std::unique_ptr<std::atomic<uint32_t>[]> parent(new std::atomic<uint32_t>[n_meas]);
+#pragma omp parallel for schedule(static)
+        for (uint32_t i = 0; i < n_meas; i++)
+            parent[i].store(i, std::memory_order_relaxed);
+        auto find = [&](uint32_t x) {
+            while (true)
+            {
+                uint32_t p = parent[x].load(std::memory_order_relaxed);
+                if (p == x)
+                    return x;
+                const uint32_t gp = parent[p].load(std::memory_order_relaxed);
+                if (gp != p)
+                    parent[x].compare_exchange_weak(p, gp, std::memory_order_relaxed);
+                x = p;
+            }
+        };
+#pragma omp parallel for schedule(static)
+        for (uint32_t i = 0; i < M; i++)
+        {
+            uint32_t a = meas_off[tv[i].na] + tv[i].fa, b = meas_off[tv[i].nb] + tv[i].fb;
+            while (true)
+            {
+                a = find(a);
+                b = find(b);
+                if (a == b)
+                    break;
+                if (a < b)
+                    std::swap(a, b);
+                uint32_t expected = a; // a > b: a (still a root?) goes under b
+                if (parent[a].compare_exchange_strong(expected, b, std::memory_order_relaxed))
+                    break;
+            }
+        }
+        lap("union-find");
+        // tracks in the order of their first two-view member: the component's smallest member index, ranked
+        std::vector<uint32_t> root_of(M);
+        std::unique_ptr<std::atomic<uint32_t>[]> first_member(new std::atomic<uint32_t>[n_meas]);
+#pragma omp parallel for schedule(static)
+        for (uint32_t i = 0; i < n_meas; i++)
+            first_member[i].store(UINT32_MAX, std::memory_order_relaxed);
+#pragma omp parallel for schedule(static)
+        for (uint32_t i = 0; i < M; i++)
+        {
+            const uint32_t r = find(meas_off[tv[i].na] + tv[i].fa);
+            root_of[i] = r;
+            uint32_t cur = first_member[r].load(std::memory_order_relaxed);
+            while (i < cur && !first_member[r].compare_exchange_weak(cur, i, std::memory_order_relaxed))
+            {
+            }
+        }
+        std::vector<uint32_t> track_of(M), members;
+        uint32_t n_tracks = 0;
+        {
+            std::vector<uint32_t> rank(M); // rank of member i among the first members, where it is one
+            for (uint32_t i = 0; i < M; i++)
+                if (first_member[root_of[i]].load(std::memory_order_relaxed) == i)
+                    rank[i] = n_tracks++;
+            members.assign(n_tracks, 0);
+#pragma omp parallel for schedule(static)
+            for (uint32_t i = 0; i < M; i++)
+                track_of[i] = rank[first_member[root_of[i]].load(std::memory_order_relaxed)];
+            for (uint32_t i = 0; i < M; i++)
+                members[track_of[i]]++;
+        }
+        lap("track ids");
+        // per track: its rays (usable measurements of distinct images, in order of appearance), the distinct images of all
+        // of its measurements, and what the surface model's cloud needs (the first 5 finite points, the smallest error)
+        struct view
+        {
+            uint32_t node, feature;
+        };
+        std::vector<uint32_t> off(n_tracks + 1, 0);
+        for (uint32_t t = 0; t < n_tracks; t++)
+            off[t + 1] = off[t] + 2 * members[t];
+        std::vector<view> rays(off.back()), imgs(off.back());
+        std::vector<uint64_t> ray_cell(off.back()); // the grid cell of every ray's pixel in its image
+        std::vector<uint32_t> n_rays(n_tracks, 0), n_imgs(n_tracks, 0);
+        std::vector<cloud_track> cloud(n_tracks);
+        std::vector<int64_t> pose_of_node(n_nodes, -1); // index into *_poses of the pose that is optimised, per node index
+        for (const auto &kv : _opt_index)
+            pose_of_node[_graph.nodeIndex(kv.first)] = (int64_t)kv.second;
+        const auto &gnodes = _graph.nodes();
+        // members grouped by track (ascending inside a track), then the tracks in parallel
+        std::vector<uint32_t> moff(n_tracks + 1, 0), mlist(M);
+        for (uint32_t t = 0; t < n_tracks; t++)
+            moff[t + 1] = moff[t] + members[t];
+        {
+            std::vector<uint32_t> fill(moff.begin(), moff.end() - 1);
+            for (uint32_t i = 0; i < M; i++)
+                mlist[fill[track_of[i]]++] = i;
+        }
+#pragma omp parallel for schedule(dynamic, 256)
+        for (uint32_t t = 0; t < n_tracks; t++)
+        {
+            view *tr = &rays[off[t]], *ti = &imgs[off[t]];
+            uint32_t nr = 0, ni = 0;
+            cloud_track &ct = cloud[t];
+            for (uint32_t e = moff[t]; e < moff[t + 1]; e++)
+            {
+                const two_view &m = tv[mlist[e]];
+                const bool finite_point = std::isfinite(m.point.x) && std::isfinite(m.point.y) && std::isfinite(m.point.z);
+                for (int side = 0; side < 2; side++)
                 {
-                    auto ins = holder.emplace(key(*v), i);
-                    if (!ins.second)
+                    const view v = side == 0 ? view{m.na, m.fa} : view{m.nb, m.fb};
+                    bool present = false;
+                    for (uint32_t k = 0; k < nr && !present; k++)
+                        present = tr[k].node == v.node;
+                    if (!present && pose_of_node[v.node] >= 0 && v.feature < gnodes[v.node].payload.features.size())
+                        tr[nr++] = v;
+                    if (finite_point)
                     {
-                        const uint32_t ra = find(i), rb = find(ins.first->second);
-                        if (ra != rb)
-                            parent[std::max(ra, rb)] = std::min(ra, rb); // the smallest member stands for the set
+                        bool seen = false;
+                        for (uint32_t k = 0; k < ni && !seen; k++)
+                            seen = ti[k].node == v.node;
+                        if (!seen)
+                            ti[ni++] = v;
                     }
                 }
+                if (finite_point)
+                {
+                    if (ct.n_points < 5)
+                        ct.points[ct.n_points] = m.point;
+                    ct.n_points++;
+                    if (std::isfinite(m.error))
+                        ct.min_error = std::min(ct.min_error, m.error);
+                }
+            }
+            n_rays[t] = nr;
+            n_imgs[t] = ni;
+            if (nr >= 3)
+                for (uint32_t k = 0; k < nr; k++)
+                {
+                    const MeasurementGraph::Node &node = gnodes[tr[k].node];
+                    const double *px = node.payload.features[tr[k].feature].location;
+                    const CameraModel &model = *node.payload.model;
+                    ray_cell[off[t] + k] = cell_key((int)std::floor((px[0] / model.pixels_cols) / frac),
+                                                    (int)std::floor((px[1] / model.pixels_rows) / frac));
+                }
         }
-        // tracks in the order of their first two-view member; per track the rays of distinct optimised images in
-        // order of appearance
-        struct ray_info
-        {
-            size_t node, feature, model_id;
-            uint32_t cam;
-            v3 loc, ray;
-            double px[2];
-            const double *rot;
+        lap("rays per track");
+        // NOTE: the reference's getSurfaceModel unites only two-view tracks with a finite point, which can split a set that
+        // a non-finite one bridges; such tracks have parallel rays and do not occur between overlapping images.
+        for (uint32_t t = 0; t < n_tracks; t++)
+            if (cloud[t].n_points > 0)
+            {
+                cloud[t].views = n_imgs[t];
+                _tracks_for_cloud.push_back(cloud[t]);
+            }
+        std::vector<cloud_track>().swap(cloud);
+
+        lap("cloud");
+        // per image and grid cell the longest track wins (the first one among equally long ones)
+        auto cell_of = [&](const view &v) {
+            const MeasurementGraph::Node &node = gnodes[v.node];
+            const double *px = node.payload.features[v.feature].location;
+            const CameraModel &model = *node.payload.model;
+            return cell_key((int)std::floor((px[0] / model.pixels_cols) / frac), (int)std::floor((px[1] / model.pixels_rows) / frac));
         };
-        std::vector<std::vector<ray_info>> tracks;
-        std::vector<int32_t> track_of(tv.size(), -1);
-        std::vector<cloud_track> cloud;
-        for (uint32_t i = 0; i < tv.size(); i++)
+        // (a dense cell table per image - pixels / image size lies in [0, 1) for features inside the image - with a map for
+        // whatever falls outside of it)
+        const int G = (int)std::ceil(1.0 / frac) + 2;
+        std::vector<std::pair<uint32_t, uint32_t>> table(n_nodes * (size_t)G * G, std::make_pair(0u, UINT32_MAX)); // (length, track)
+        std::map<std::pair<uint32_t, uint64_t>, std::pair<uint32_t, uint32_t>> outside; // (node, cell)
+        for (uint32_t t = 0; t < n_tracks; t++)
         {
-            const uint32_t root = find(i);
-            if (track_of[root] < 0)
-            {
-                track_of[root] = (int32_t)tracks.size();
-                tracks.emplace_back();
-                cloud.emplace_back();
-            }
-            auto &rays = tracks[track_of[root]];
-            for (const view *v : {&tv[i].a, &tv[i].b})
-            {
-                bool present = false;
-                for (const ray_info &r : rays)
-                    present |= r.node == v->node;
-                if (present)
-                    continue;
-                auto oi = _opt_index.find(v->node);
-                if (oi == _opt_index.end())
-                    continue;
-                const MeasurementGraph::Node *node = _graph.getNode(v->node);
-                if (node == nullptr || v->feature >= node->payload.features.size())
-                    continue;
-                const CameraModel &model = *node->payload.model;
-                const double *px = node->payload.features[v->feature].location;
-                const NodePose &np = (*_poses)[oi->second];
-                ray_info r;
-                r.node = v->node;
-                r.feature = v->feature;
-                r.model_id = model.id;
-                r.cam = _cam_of_node.at(v->node);
-                r.loc = v3{np.position[0], np.position[1], np.position[2]};
-                double ray[3];
-                image_to_3d(px, model, ray);
-                r.ray = v3{ray[0], ray[1], ray[2]};
-                r.px[0] = px[0], r.px[1] = px[1];
-                r.rot = np.orientation;
-                rays.push_back(r);
-            }
-            // the surface model's point cloud merges the same sets (getSurfaceModel, :1422-1497)
-            if (std::isfinite(tv[i].point.x) && std::isfinite(tv[i].point.y) && std::isfinite(tv[i].point.z))
-            {
-                cloud_track &ct = cloud[track_of[root]];
-                ct.points.push_back(tv[i].point);
-                if (std::isfinite(tv[i].error))
-                    ct.min_error = std::min(ct.min_error, tv[i].error);
-            }
-        }
-        // (distinct images of a merged track, for the cloud's error gate)
-        {
-            std::vector<std::vector<size_t>> seen(tracks.size());
-            for (uint32_t i = 0; i < tv.size(); i++)
-            {
-                if (!(std::isfinite(tv[i].point.x) && std::isfinite(tv[i].point.y) && std::isfinite(tv[i].point.z)))
-                    continue;
-                auto &s = seen[track_of[find(i)]];
-                for (size_t n : {tv[i].a.node, tv[i].b.node})
-                    if (std::find(s.begin(), s.end(), n) == s.end())
-                        s.push_back(n);
-            }
-            for (size_t t = 0; t < tracks.size(); t++)
-                cloud[t].views = seen[t].size();
-        }
-        // NOTE: the reference's getSurfaceModel unites only tracks with a finite point, which can split a set that a
-        // non-finite two-view track bridges; such tracks have parallel rays and do not occur with overlapping images.
-        for (auto &c : cloud)
-            if (!c.points.empty())
-                _tracks_for_cloud.push_back(std::move(c));
-
-        // per image and grid cell the longest track wins (first one among equally long ones)
-        std::unordered_map<size_t, std::unordered_map<uint64_t, std::pair<double, uint32_t>>> best;
-        for (uint32_t t = 0; t < tracks.size(); t++)
-        {
-            if (tracks[t].size() < 3)
+            if (n_rays[t] < 3)
                 continue;
-            const double score = (double)tracks[t].size();
-            for (const ray_info &r : tracks[t])
+            for (uint32_t k = 0; k < n_rays[t]; k++)
             {
-                const CameraModel &model = *_graph.getNode(r.node)->payload.model;
-                const uint64_t cell = cell_key((int)std::floor((r.px[0] / model.pixels_cols) / frac),
-                                               (int)std::floor((r.px[1] / model.pixels_rows) / frac));
-                auto &cells = best[r.node];
-                auto it = cells.find(cell);
-                if (it == cells.end())
-                    cells.emplace(cell, std::make_pair(score, t));
-                else if (it->second.first < score)
-                    it->second = std::make_pair(score, t);
+                const view &v = rays[off[t] + k];
+                const uint64_t cell = ray_cell[off[t] + k];
+                const int ci = (int)(int32_t)(cell >> 32), cj = (int)(int32_t)(uint32_t)cell;
+                std::pair<uint32_t, uint32_t> *slot;
+                if (ci >= 0 && cj >= 0 && ci < G && cj < G)
+                    slot = &table[((size_t)v.node * G + ci) * G + cj];
+                else
+                    slot = &outside.emplace(std::make_pair(v.node, cell), std::make_pair(0u, UINT32_MAX)).first->second;
+                if (slot->second == UINT32_MAX || slot->first < n_rays[t])
+                    *slot = std::make_pair(n_rays[t], t);
             }
         }
-        std::vector<char> accepted(tracks.size(), 0);
-        for (const auto &node_cells : best)
-            for (const auto &cell : node_cells.second)
-                accepted[cell.second.second] = 1;
+        std::vector<char> accepted(n_tracks, 0);
+        for (const auto &slot : table)
+            if (slot.second != UINT32_MAX)
+                accepted[slot.second] = 1;
+        for (const auto &kv : outside)
+            accepted[kv.second.second] = 1;
 
+        lap("cell winners");
         TriangleWalker walker;
         if (!walker.init(_mesh))
             return;
-        for (uint32_t t = 0; t < tracks.size(); t++)
+        _track_measurement.assign(n_nodes, {});
+        _covered.assign(n_nodes, {});
+        struct ray_info
         {
-            const auto &rays = tracks[t];
-            if (rays.size() < 3 || !accepted[t])
+            view v;
+            uint32_t cam;
+            v3 loc, ray;
+            const double *rot;
+        };
+        std::vector<ray_info> tr;
+        for (uint32_t t = 0; t < n_tracks; t++)
+        {
+            if (n_rays[t] < 3 || !accepted[t])
                 continue;
+            tr.clear();
             v3 mean{0, 0, 0};
-            for (const ray_info &r : rays)
+            for (uint32_t k = 0; k < n_rays[t]; k++)
+            {
+                ray_info r;
+                r.v = rays[off[t] + k];
+                const MeasurementGraph::Node &node = gnodes[r.v.node];
+                const NodePose &np = (*_poses)[(size_t)pose_of_node[r.v.node]];
+                r.cam = _cam_of_node.at(node.id);
+                r.loc = v3{np.position[0], np.position[1], np.position[2]};
+                double ray[3];
+                image_to_3d(node.payload.features[r.v.feature].location, *node.payload.model, ray);
+                r.ray = v3{ray[0], ray[1], ray[2]};
+                r.rot = np.orientation;
+                tr.push_back(r);
                 mean = add(mean, r.loc);
-            mean = v3{mean.x / (double)rays.size(), mean.y / (double)rays.size(), mean.z / (double)rays.size()};
+            }
+            const double nr = (double)tr.size();
+            mean = v3{mean.x / nr, mean.y / nr, mean.z / nr};
             v3 x01;
             double gap;
-            ray_intersection(rotate(rays[0].rot, rays[0].ray), rays[0].loc, rotate(rays[1].rot, rays[1].ray), rays[1].loc, &x01, &gap);
+            ray_intersection(rotate(tr[0].rot, tr[0].ray), tr[0].loc, rotate(tr[1].rot, tr[1].ray), tr[1].loc, &x01, &gap);
             if (!(std::isfinite(x01.x) && std::isfinite(x01.y) && std::isfinite(x01.z)))
                 continue;
             if (walker.find(v3{0, 0, -1}, v3{x01.x, x01.y, mean.z}) != TriangleWalker::INTERSECTION)
@@ -959,12 +1076,12 @@ class GroundMeshProblem
                     nrm = v3{nrm.x / n, nrm.y / n, nrm.z / n};
                 }
             }
-            std::vector<v3> hits(rays.size());
+            std::vector<v3> hits(tr.size());
             bool all_valid = true;
             double avg = 0;
-            for (size_t i = 0; i < rays.size(); i++)
+            for (size_t i = 0; i < tr.size(); i++)
             {
-                const v3 dir = rotate(rays[i].rot, rays[i].ray);
+                const v3 dir = rotate(tr[i].rot, tr[i].ray);
                 const double denom = dot(nrm, dir);
                 if (std::abs(denom) < 1e-9)
                 {
@@ -972,16 +1089,16 @@ class GroundMeshProblem
                     hits[i] = v3{NAN, NAN, NAN};
                 }
                 else
-                    hits[i] = add(rays[i].loc, mul(dir, (dot(nrm, c[0]) - dot(rays[i].loc, nrm)) / denom));
-                const v3 dd = sub(hits[i], rays[i].loc);
+                    hits[i] = add(tr[i].loc, mul(dir, (dot(nrm, c[0]) - dot(tr[i].loc, nrm)) / denom));
+                const v3 dd = sub(hits[i], tr[i].loc);
                 avg += std::sqrt(dot(dd, dd));
             }
             if (!all_valid)
                 continue;
-            avg /= (double)rays.size();
+            avg /= nr;
             const v3 centre = robust_centroid(hits.data(), std::min<int>((int)hits.size(), 5), avg * 0.01);
-            std::vector<std::pair<double, size_t>> scores(rays.size());
-            for (size_t i = 0; i < rays.size(); i++)
+            std::vector<std::pair<double, size_t>> scores(tr.size());
+            for (size_t i = 0; i < tr.size(); i++)
             {
                 const v3 dd = sub(hits[i], centre);
                 scores[i] = {std::sqrt(dot(dd, dd)) / avg, i};
@@ -991,7 +1108,7 @@ class GroundMeshProblem
             std::vector<const ray_info *> good;
             for (const auto &es : scores)
                 if (es.first <= threshold && good.size() < 5)
-                    good.push_back(&rays[es.second]);
+                    good.push_back(&tr[es.second]);
             if (good.size() < 3)
                 continue;
             _blk_n.push_back((uint8_t)good.size());
@@ -1002,15 +1119,13 @@ class GroundMeshProblem
                 _ray_dir.push_back(r->ray.x);
                 _ray_dir.push_back(r->ray.y);
                 _ray_dir.push_back(r->ray.z);
-                _track_measurement.emplace(measurement_key::of(_graph.nodeIndex(r->node), r->feature).k, 1);
-                const CameraModel &model = *_graph.getNode(r->node)->payload.model;
-                _covered[r->node].emplace(cell_key((int)std::floor((r->px[0] / model.pixels_cols) / frac),
-                                                   (int)std::floor((r->px[1] / model.pixels_rows) / frac)),
-                                          1);
+                _track_measurement[r->v.node].emplace(r->v.feature, 1);
+                _covered[r->v.node].emplace(cell_of(r->v), 1);
             }
             for (int i = 0; i < 3; i++)
                 _blk_tri.push_back((uint32_t)tri[i]);
         }
+        lap("track blocks");
     }
 
     // the 2-ray blocks of one edge: whitelisted inliers that no track block took and whose cells the tracks leave uncovered
@@ -1020,7 +1135,11 @@ class GroundMeshProblem
         const CameraModel &sm = model_of(edge.source), &dm = model_of(edge.dest);
         const v3 so{s.loc[0], s.loc[1], s.loc[2]}, d_o{d.loc[0], d.loc[1], d.loc[2]};
         const size_t si = _graph.nodeIndex(edge.source), di = _graph.nodeIndex(edge.dest);
-        auto sc = _covered.find(edge.source), dc = _covered.find(edge.dest);
+        static const std::unordered_map<uint64_t, char> none;
+        const auto &s_meas = _track_measurement.empty() ? none : _track_measurement[si];
+        const auto &d_meas = _track_measurement.empty() ? none : _track_measurement[di];
+        const auto &s_cells = _covered.empty() ? none : _covered[si];
+        const auto &d_cells = _covered.empty() ? none : _covered[di];
         TriangleWalker walker;
         if (!walker.init(_mesh))
             return;
@@ -1030,15 +1149,14 @@ class GroundMeshProblem
             if (idx >= keep.size() || keep[idx] == 0)
                 continue;
             const feature_match_denormalized &m = inl[idx];
-            if (_track_measurement.count(measurement_key::of(si, m.feature_index_1).k) ||
-                _track_measurement.count(measurement_key::of(di, m.feature_index_2).k))
+            if ((!s_meas.empty() && s_meas.count((uint64_t)m.feature_index_1)) || (!d_meas.empty() && d_meas.count((uint64_t)m.feature_index_2)))
                 continue;
-            const bool s_cov = sc != _covered.end() &&
-                               sc->second.count(cell_key((int)std::floor((m.pixel_1[0] / (double)sm.pixels_cols) / frac),
-                                                         (int)std::floor((m.pixel_1[1] / (double)sm.pixels_rows) / frac)));
-            const bool d_cov = dc != _covered.end() &&
-                               dc->second.count(cell_key((int)std::floor((m.pixel_2[0] / (double)dm.pixels_cols) / frac),
-                                                         (int)std::floor((m.pixel_2[1] / (double)dm.pixels_rows) / frac)));
+            const bool s_cov = !s_cells.empty() &&
+                               s_cells.count(cell_key((int)std::floor((m.pixel_1[0] / (double)sm.pixels_cols) / frac),
+                                                      (int)std::floor((m.pixel_1[1] / (double)sm.pixels_rows) / frac)));
+            const bool d_cov = !d_cells.empty() &&
+                               d_cells.count(cell_key((int)std::floor((m.pixel_2[0] / (double)dm.pixels_cols) / frac),
+                                                      (int)std::floor((m.pixel_2[1] / (double)dm.pixels_rows) / frac)));
             if (s_cov && d_cov)
                 continue;
             double r1[3], r2[3];
@@ -1069,8 +1187,7 @@ class GroundMeshProblem
     std::vector<double> _cam_pos, _cam_q, _ray_dir;
     std::vector<uint8_t> _cam_opt, _blk_n;
     std::vector<uint32_t> _blk_ray_off{0}, _ray_cam, _blk_tri;
-    std::unordered_map<uint64_t, char> _track_measurement;
-    std::unordered_map<size_t, std::unordered_map<uint64_t, char>> _covered;
+    std::vector<std::unordered_map<uint64_t, char>> _track_measurement, _covered; // per node index: features / cells in track blocks
     std::vector<cloud_track> _tracks_for_cloud;
     MeshGraph _mesh;
     ochip_relaxg_problem *_dev = nullptr;
