@@ -1,0 +1,115 @@
+"""Parity at the sizes of BASELINE.json's configs C2 (200 images x 4k features) and C3 (1 000 images x 4k features, the
+configuration the headline metric is quoted on): the device link stage against the oracle on sampled directed pairs
+(match lists, inlier sets, RANSAC scores and homographies bit for bit), then the relax of the WHOLE linked graph against
+the oracle's solve (3 003 unknowns at C3: the envelope / reordered Cholesky path of the device against the oracle's plain
+factorisation), poses within 1e-6 rad.  C2 also runs the {ORIENTATION, GROUND_MESH} flavour on the linked graph (tracks
+formed by real matches) against the oracle."""
+import numpy as np
+import pytest
+
+from opencalibration_amd import capi, host, pipeline, synth
+from relax_fixtures import qangle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _linked(ctx, cfg, seed=12345):
+    grid = synth.make_grid(seed=seed, **synth.CONFIGS[cfg])
+    g = host.Graph.from_synthetic(grid)
+    start = pipeline.perturbed_orientations(grid, 0.1, 99)
+    g.set_orientations(start)
+    g.link(ctx, keep_debug=True)
+    return grid, g, start
+
+
+def _check_sampled_pairs(oracle, grid, g, n_sample):
+    index_of = {nid: i for i, nid in enumerate(g.node_ids)}
+    dbg = g.link_debug()
+    pick = np.unique(np.linspace(0, len(dbg) - 1, n_sample).astype(int))
+    subset_cache = {}
+
+    def subset(i):
+        if i not in subset_cache:
+            loc, st = grid.image(i)[:2]
+            subset_cache[i] = oracle.subsample(loc, st, 40.0, int(grid.num_sparse[i]))
+        return subset_cache[i]
+
+    edges = {(e["source"], e["dest"]): e for e in g.edges()}
+    for p in pick:
+        d = dbg[p]
+        a, b = index_of[d["node"]], index_of[d["match_node"]]
+        la, _, da, _ = grid.image(a)
+        lb, _, db, _ = grid.image(b)
+        e = oracle.link_pair(la, da, subset(a), lb, db, subset(b), grid.model, grid.model)
+        assert np.array_equal(d["i1"], e["i1"]) and np.array_equal(d["i2"], e["i2"]) and np.array_equal(d["dist"], e["dist"]), (a, b)
+        assert np.array_equal(d["inliers"], e["inliers"]) and d["score"] == e["score"], (a, b)
+        assert (d["iterations"], d["improvements"]) == (e["iterations"], e["improvements"]), (a, b)
+        ed = edges[(d["node"], d["match_node"])]
+        assert np.array_equal(ed["H"], e["H"], equal_nan=True)
+        if e["accepted"]:
+            assert np.array_equal(ed["match_index"], np.flatnonzero(e["inliers"]))
+    return len(pick), len(dbg)
+
+
+def _relax_plane_both(ctx, oracle, grid, g, start):
+    got = g.relax_ground_plane(ctx, start)
+    edges = g.edges_flat()
+    exp = oracle.relax_ground_plane(grid.position, start, grid.model, np.arange(grid.n_images), start, edges)
+    worst = max(qangle(exp["orientation"][i], got["orientation"][i]) for i in range(grid.n_images))
+    assert worst < 1e-6, worst
+    assert int(got["residual_blocks"]) == exp["residual_blocks"] and int(got["solves"]) == exp["solves"]
+    assert abs(int(got["iterations_total"]) - exp["iterations_total"]) <= 3
+    assert np.allclose(exp["plane"], got["plane"], rtol=0, atol=1e-5)
+    return got, exp
+
+
+def test_c2_link_relax_and_mesh(ctx, oracle):
+    grid, g, start = _linked(ctx, "C2")
+    checked, total = _check_sampled_pairs(oracle, grid, g, 200)
+    assert checked >= 190 and total == 1800
+    got, exp = _relax_plane_both(ctx, oracle, grid, g, start)
+    err = pipeline.orientation_errors(got["orientation"], grid.orientation)
+    assert np.median(err) < 1e-3
+    # ---- {ORIENTATION, GROUND_MESH} on the linked graph: minimal mesh over the plane found above (pipeline.cpp:681-707)
+    n = grid.n_images
+    rx = oracle.RxGraph()
+    rx.add_model(grid.model, 1)   # (the host library numbers its camera models from 1)
+    for i in range(n):
+        rx.add_node(grid.position[i], got["orientation"][i], 0, grid.image(i)[0])
+    index_of = {nid: i for i, nid in enumerate(g.node_ids)}
+    for ed in g.edges(with_distances=True):
+        rx.add_edge(index_of[ed["source"]], index_of[ed["dest"]], ed["px"], ed["f1"], ed["f2"], ed["match_index"], ed["H"], ed["dist"])
+    plane_v = np.asarray(got["plane"], np.float64)
+    tri_edges = np.array([[i, (i + 1) % 3, 1, (i + 2) % 3, np.iinfo(np.uint64).max] for i in range(3)], np.uint64)
+    hmin = host.rebuild_mesh(grid.position, host.Surface().set(plane_v, tri_edges), minimal=True)
+    omin = oracle.rebuild_mesh(grid.position, oracle.RxSurface().set(plane_v, tri_edges), minimal=True)
+    assert np.array_equal(hmin.arrays()["vertices"], omin.arrays()["vertices"])
+    O = host.relax_options("ORIENTATION", "GROUND_MESH")
+    hm = g.relax(ctx, got["orientation"], O, 0.1, previous=hmin)
+    om = rx.relax(np.arange(n), got["orientation"], np.arange(rx.n_edges), oracle.options("ORIENTATION", "GROUND_MESH"), 0.1, omin)
+    assert int(hm["track_blocks"]) == om["track_blocks"] > 1000 and int(hm["two_ray_blocks"]) == om["two_ray_blocks"] > 10000
+    assert int(hm["residual_blocks"]) == om["residual_blocks"]
+    worst = max(qangle(om["orientation"][i], hm["orientation"][i]) for i in range(n))
+    assert worst < 1e-6, worst
+    hz, oz = hm["surface"].arrays()["vertices"], om["surface"].arrays()["vertices"]
+    assert np.allclose(hz, oz, rtol=0, atol=1e-5)
+    assert abs(int(hm["iterations_total"]) - om["iterations_total"]) <= 3
+    g.close()
+
+
+def test_c3_link_and_relax(ctx, oracle):
+    grid, g, start = _linked(ctx, "C3")
+    checked, total = _check_sampled_pairs(oracle, grid, g, 120)
+    assert checked >= 100 and total == 9000
+    got, exp = _relax_plane_both(ctx, oracle, grid, g, start)
+    assert int(got["residual_blocks"]) > 300000
+    err = pipeline.orientation_errors(got["orientation"], grid.orientation)
+    assert np.median(err) < 1e-3
+    g.close()
