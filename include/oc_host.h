@@ -37,6 +37,13 @@ extern "C"
     /* one image = what extract_features hands to the link stage; returns the node id */
     uint64_t och_graph_add_image(och_graph *g, const double *loc, const float *strength, const uint64_t *desc, size_t n,
                                  size_t num_sparse, uint32_t model, const double *position3);
+    /* graph.addEdge(relations, source, dest) from flat arrays (a deserialised graph, a test): inl_px4 n x {pixel_1, pixel_2},
+     * inl_idx3 n x {feature_index_1, feature_index_2, match_index}; matches: match_idx2 (may be NULL), match_dist (may be
+     * NULL); poses32: 4 x {q xyzw, t xyz, score} or NULL.  Returns the edge id (0 + och_last_error on an unknown node). */
+    uint64_t och_graph_add_edge(och_graph *g, uint64_t source_id, uint64_t dest_id, const double *H9, int is_homography,
+                                size_t n_inliers, const double *inl_px4, const uint64_t *inl_idx3, size_t n_matches,
+                                const uint64_t *match_idx2, const double *match_dist, const double *poses32);
+    void och_graph_get_orientations(const och_graph *g, double *ori /* n_nodes x 4, node order */);
     size_t och_graph_num_nodes(const och_graph *g);
     size_t och_graph_num_edges(const och_graph *g);
     void och_graph_node_ids(const och_graph *g, uint64_t *out);
@@ -147,6 +154,22 @@ extern "C"
     /* Every node of a linked graph as one group, every edge whitelisted, any flavour.  ori_inout: n_nodes x 4. */
     int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
                         const och_surface *previous, och_surface *surface_out, double *summary_out);
+
+    /* RelaxStage (src/pipeline/relax_stage.cpp): init (partition into floor(n / 50) groups - 150 with free intrinsics -
+     * by spectral clustering of the link graph, or one group with two rings of context cameras when disable_parallelism),
+     * the groups' runners (concurrently, on sibling device contexts), finalize (write-back + merged surface).
+     * node_ids may be NULL with relax_all != 0.  max_groups > 0: trim_groups(max_groups) before running.
+     * group_of_node (n_nodes, may be NULL) receives for every node the group it is a primary node of (0 = largest) or -1.
+     * summary_out as och_relax (sums over the groups), summary_out[12] = number of groups run. */
+    int och_relax_stage_run(och_graph *g, ochip_ctx *ctx, const uint64_t *node_ids, size_t n_ids, int relax_all,
+                            int disable_parallelism, uint32_t options, double grid_fraction, size_t max_groups,
+                            const och_surface *previous, och_surface *surface_out, int64_t *group_of_node,
+                            double *summary_out);
+    /* the partition alone (no device): group_of_node as above, position_in_group (may be NULL) the node's place in its
+     * group's list; returns the number of groups */
+    size_t och_relax_partition(const och_graph *g, size_t num_groups, int64_t *group_of_node, int64_t *position_in_group);
+    /* mergeSurfaceModels of n surfaces (src/surface/refine_mesh.cpp:916-1016) */
+    void och_merge_surfaces(const och_surface *const *surfaces, size_t n, och_surface *out);
 
     /* ---- after a relax changed a camera model: the write-back half of RelaxGroup::finalize
      *      (src/relax/relax_group.cpp:125-177).  och_graph_set_model replaces the intrinsics of model `model` (m10 as for

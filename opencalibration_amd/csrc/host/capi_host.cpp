@@ -140,6 +140,49 @@ uint64_t och_graph_add_image(och_graph *g, const double *loc, const float *stren
     return g->graph.addNode(std::move(img));
 }
 
+// graph.addEdge(relations, source, dest) from flat arrays (what a deserialised graph or a test hands over)
+uint64_t och_graph_add_edge(och_graph *g, uint64_t source_id, uint64_t dest_id, const double *H9, int is_homography, size_t n_inliers,
+                            const double *inl_px4, const uint64_t *inl_idx3, size_t n_matches, const uint64_t *match_idx2,
+                            const double *match_dist, const double *poses32)
+{
+    camera_relations rel;
+    if (H9)
+        std::memcpy(rel.ransac_relation, H9, 72);
+    rel.relationType = is_homography ? camera_relations::RelationType::HOMOGRAPHY : camera_relations::RelationType::UNKNOWN;
+    rel.inlier_matches.resize(n_inliers);
+    for (size_t k = 0; k < n_inliers; k++)
+    {
+        feature_match_denormalized &f = rel.inlier_matches[k];
+        f.pixel_1[0] = inl_px4[4 * k], f.pixel_1[1] = inl_px4[4 * k + 1];
+        f.pixel_2[0] = inl_px4[4 * k + 2], f.pixel_2[1] = inl_px4[4 * k + 3];
+        f.feature_index_1 = inl_idx3[3 * k], f.feature_index_2 = inl_idx3[3 * k + 1], f.match_index = inl_idx3[3 * k + 2];
+    }
+    rel.matches.resize(n_matches);
+    for (size_t k = 0; k < n_matches; k++)
+        rel.matches[k] = feature_match{match_idx2 ? (size_t)match_idx2[2 * k] : 0, match_idx2 ? (size_t)match_idx2[2 * k + 1] : 0,
+                                       match_dist ? match_dist[k] : 0.0};
+    if (poses32)
+        for (int i = 0; i < 4; i++)
+        {
+            std::memcpy(rel.relative_poses[i].orientation, poses32 + 8 * i, 32);
+            std::memcpy(rel.relative_poses[i].position, poses32 + 8 * i + 4, 24);
+            rel.relative_poses[i].score = (int)poses32[8 * i + 7];
+        }
+    if (!g->graph.getNode(source_id) || !g->graph.getNode(dest_id))
+    {
+        g->error = "och_graph_add_edge: unknown node id";
+        return 0;
+    }
+    return g->graph.addEdge(std::move(rel), source_id, dest_id);
+}
+
+void och_graph_get_orientations(const och_graph *g, double *ori)
+{
+    size_t i = 0;
+    for (const auto &n : g->graph.nodes())
+        std::memcpy(ori + 4 * (i++), n.payload.orientation, 32);
+}
+
 size_t och_graph_num_nodes(const och_graph *g)
 {
     return g->graph.size_nodes();

@@ -4,6 +4,9 @@
 #include "capi_graph.hpp"
 #include "relax.hpp"
 #include "relax_mesh.hpp"
+#include "relax_stage.hpp"
+
+#include <thread>
 
 #include <cstring>
 
@@ -386,6 +389,100 @@ int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t op
         surface_out->s = std::move(out);
     fill_summary12(t, st, summary_out);
     return 0;
+}
+
+
+int och_relax_stage_run(och_graph *g, ochip_ctx *ctx, const uint64_t *node_ids, size_t n_ids, int relax_all,
+                        int disable_parallelism, uint32_t options, double grid_fraction, size_t max_groups,
+                        const och_surface *previous, och_surface *surface_out, int64_t *group_of_node, double *summary_out)
+{
+    RelaxStage stage;
+    RelaxConfig cfg;
+    cfg.options = options;
+    cfg.ground_mesh_grid_fraction = grid_fraction;
+    std::vector<size_t> ids(node_ids ? node_ids : nullptr, node_ids ? node_ids + n_ids : nullptr);
+    stage.init(g->graph, ids, relax_all != 0, disable_parallelism != 0, cfg);
+    if (max_groups > 0)
+        stage.trim_groups(max_groups);
+    if (group_of_node)
+    {
+        for (size_t i = 0; i < g->graph.size_nodes(); i++)
+            group_of_node[i] = -1;
+        const auto &part = stage.partition();
+        for (size_t k = 0; k < part.size() && k < stage.num_groups(); k++)
+            for (size_t id : part[k])
+                group_of_node[g->graph.nodeIndex(id)] = (int64_t)k;
+    }
+    if (previous)
+        stage.setSurfaceModels({previous->s});
+    const size_t n_groups = stage.num_groups();
+    auto runners = stage.get_runners(ctx, g->graph);
+    {
+        // the reference runs the runners under OpenMP (pipeline.cpp:42-49); here a few host threads, one per device context
+        size_t next = 0;
+        std::mutex m;
+        std::vector<std::thread> pool;
+        const size_t T = std::min<size_t>(runners.size(), 4);
+        for (size_t t = 0; t < T; t++)
+            pool.emplace_back([&]() {
+                while (true)
+                {
+                    size_t i;
+                    {
+                        std::lock_guard<std::mutex> lock(m);
+                        if (next >= runners.size())
+                            return;
+                        i = next++;
+                    }
+                    runners[i]();
+                }
+            });
+        for (auto &t : pool)
+            t.join();
+    }
+    stage.finalize(g->graph);
+    if (!stage.error().empty())
+    {
+        g->error = stage.error();
+        return -1;
+    }
+    if (surface_out)
+    {
+        const auto &s = stage.getSurfaceModels();
+        surface_out->s = s.empty() ? surface_model() : s[0];
+    }
+    if (summary_out)
+    {
+        fill_summary12(stage.timers, stage.stats, summary_out);
+        summary_out[12] = (double)n_groups;
+    }
+    return 0;
+}
+
+size_t och_relax_partition(const och_graph *g, size_t num_groups, int64_t *group_of_node, int64_t *position_in_group)
+{
+    std::vector<size_t> ids;
+    for (const auto &n : g->graph.nodes())
+        ids.push_back(n.id);
+    const auto groups = relax_partition(g->graph, ids, num_groups);
+    for (size_t i = 0; i < g->graph.size_nodes(); i++)
+        group_of_node[i] = -1;
+    for (size_t k = 0; k < groups.size(); k++)
+        for (size_t j = 0; j < groups[k].size(); j++)
+        {
+            group_of_node[g->graph.nodeIndex(groups[k][j])] = (int64_t)k;
+            if (position_in_group)
+                position_in_group[g->graph.nodeIndex(groups[k][j])] = (int64_t)j;
+        }
+    return groups.size();
+}
+
+void och_merge_surfaces(const och_surface *const *surfaces, size_t n, och_surface *out)
+{
+    std::vector<surface_model> v;
+    for (size_t i = 0; i < n; i++)
+        v.push_back(surfaces[i]->s);
+    out->s = mergeSurfaceModels(v);
 }
 
 } // extern "C"

@@ -41,16 +41,19 @@ class GroundPlaneProblem
             tmark = clk::now();
         };
         _poses = &poses;
+        // camera table: optimised poses first (their order), context cameras appended on first use.  A node that appears
+        // twice in the pose list (RelaxGroup::init appends the first ring of context cameras once per round,
+        // relax_group.cpp:40-66) is optimised through its FIRST pose only: _nodes_to_optimize.emplace keeps the first
+        // (relax_problem.cpp:150-154); the other pose is never touched.
+        _pose_cam.assign(poses.size(), UINT32_MAX);
         for (size_t i = 0; i < poses.size(); i++)
-            _opt_index.emplace(poses[i].node_id, i);
+            if (_opt_index.emplace(poses[i].node_id, i).second)
+            {
+                _pose_cam[i] = (uint32_t)_cam_opt.size();
+                _cam_of_node.emplace(poses[i].node_id, _pose_cam[i]);
+                push_camera(poses[i].position, poses[i].orientation, true);
+            }
         initialize_plane();
-
-        // camera table: optimised poses first (their order), context cameras appended on first use
-        for (size_t i = 0; i < poses.size(); i++)
-        {
-            _cam_of_node.emplace(poses[i].node_id, (uint32_t)i);
-            push_camera(poses[i].position, poses[i].orientation, true);
-        }
 
         // gridFilterMatchesPerImage (:234-309): an edge without usable poses stops the whole pass
         size_t n_filter = edges_to_optimize.size();
@@ -110,8 +113,8 @@ class GroundPlaneProblem
         }
         // addDownwardsPrior (:1290-1301)
         for (size_t i = 0; i < poses.size(); i++)
-            if (!hasnan4(poses[i].orientation))
-                _prior_cam.push_back((uint32_t)i);
+            if (_pose_cam[i] != UINT32_MAX && !hasnan4(poses[i].orientation))
+                _prior_cam.push_back(_pose_cam[i]);
 
         lap("concatenate");
         ochip_relax_desc d{};
@@ -183,8 +186,10 @@ class GroundPlaneProblem
             return fail(error, "ochip_relax_get_state");
         for (size_t i = 0; i < _poses->size(); i++) // p.second->orientation.normalize(), :1410-1413
         {
+            if (_pose_cam[i] == UINT32_MAX)
+                continue;
             double *o4 = (*_poses)[i].orientation;
-            const double *s4 = &q[4 * i];
+            const double *s4 = &q[4 * (size_t)_pose_cam[i]];
             const double n = std::sqrt(s4[0] * s4[0] + s4[1] * s4[1] + s4[2] * s4[2] + s4[3] * s4[3]);
             for (int k = 0; k < 4; k++)
                 o4[k] = s4[k] / n;
@@ -226,7 +231,7 @@ class GroundPlaneProblem
             po.optimize = true;
             po.loc = np.position;
             po.rot = np.orientation;
-            po.cam = (uint32_t)it->second;
+            po.cam = _pose_cam[it->second];
             return po;
         }
         const MeasurementGraph::Node *node = _graph.getNode(node_id);
@@ -248,8 +253,13 @@ class GroundPlaneProblem
     void initialize_plane() // initializeGroundPlane (:1189-1242)
     {
         double lo[2] = {1e12, 1e12}, hi[2] = {-1e12, -1e12}, height = 0;
-        for (const NodePose &p : *_poses)
+        size_t n_unique = 0;
+        for (size_t i = 0; i < _poses->size(); i++)
         {
+            if (_pose_cam[i] == UINT32_MAX)
+                continue;
+            const NodePose &p = (*_poses)[i];
+            n_unique++;
             for (int a = 0; a < 2; a++)
             {
                 lo[a] = std::min(lo[a], p.position[a]);
@@ -257,7 +267,7 @@ class GroundPlaneProblem
             }
             height += p.position[2];
         }
-        height /= (double)_poses->size();
+        height /= (double)n_unique;
         const double margin = 50;
         height -= margin;
         const double cx = (lo[0] + hi[0]) / 2, cy = (lo[1] + hi[1]) / 2;
@@ -333,7 +343,7 @@ class GroundPlaneProblem
     std::unordered_map<size_t, uint32_t> _cam_of_node;
     std::vector<double> _cam_pos, _cam_q, _blk_rays;
     std::vector<uint8_t> _cam_opt;
-    std::vector<uint32_t> _blk_a, _blk_b, _prior_cam;
+    std::vector<uint32_t> _blk_a, _blk_b, _prior_cam, _pose_cam;
     double _xy[3][2], _z[3];
     int _tri[3] = {0, 1, 2};
     ochip_relax_problem *_dev = nullptr;

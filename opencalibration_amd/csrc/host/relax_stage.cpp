@@ -1,0 +1,989 @@
+#include "relax_stage.hpp"
+
+#include "relax_util.hpp"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <numeric>
+#include <queue>
+
+namespace opencalibration_amd
+{
+
+using namespace relax_detail;
+
+// ---------------------------------------------------------------------------------------------------- kNN of the images
+std::vector<std::vector<size_t>> image_knn(const MeasurementGraph &graph, size_t k)
+{
+    const auto &nodes = graph.nodes();
+    const size_t n = nodes.size();
+    std::vector<std::vector<size_t>> out(n);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; i++)
+    {
+        std::vector<std::pair<double, size_t>> d(n);
+        for (size_t j = 0; j < n; j++)
+        {
+            const double dx = nodes[j].payload.position[0] - nodes[i].payload.position[0];
+            const double dy = nodes[j].payload.position[1] - nodes[i].payload.position[1];
+            d[j] = {dx * dx + dy * dy, j};
+        }
+        const size_t kk = std::min(k, n);
+        std::partial_sort(d.begin(), d.begin() + kk, d.end()); // (distance, insertion index): a total order
+        out[i].resize(kk);
+        for (size_t j = 0; j < kk; j++)
+            out[i][j] = nodes[d[j].second].id;
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------ RelaxGroup
+void RelaxGroup::init(const MeasurementGraph &graph, const std::vector<size_t> &node_ids,
+                      const std::vector<std::vector<size_t>> &knn10, size_t graph_connection_depth, const RelaxConfig &config)
+{
+    _directly_connected.clear();
+    _directly_set.clear();
+    _edges_to_optimize.clear();
+    _edge_set.clear();
+    _nodes_to_optimize.clear();
+    _local_poses.clear();
+    _config = config;
+    for (size_t id : node_ids)
+        _nodes_to_optimize.emplace(id, 1);
+    auto take = [&](size_t node_id) {
+        const MeasurementGraph::Node *node = graph.getNode(node_id);
+        NodePose pose;
+        pose.node_id = node_id;
+        std::memcpy(pose.orientation, node->payload.orientation, sizeof pose.orientation);
+        std::memcpy(pose.position, node->payload.position, sizeof pose.position);
+        _local_poses.push_back(pose);
+        bool known = false;
+        for (auto &m : _camera_models)
+            if (m.first == node->payload.model->id)
+            {
+                m.second = *node->payload.model;
+                known = true;
+            }
+        if (!known)
+            _camera_models.emplace_back(node->payload.model->id, *node->payload.model);
+        build_optimization_edges(graph, knn10, node_id);
+    };
+    for (size_t id : node_ids)
+        take(id);
+    for (size_t round = 0; round < graph_connection_depth; round++)
+    {
+        // every round takes ALL directly connected nodes that are not primary nodes, those of earlier rounds included
+        // (relax_group.cpp:40-66): their poses appear once per round in the list
+        std::vector<size_t> connected;
+        for (size_t id : _directly_connected)
+            if (!_nodes_to_optimize.count(id))
+                connected.push_back(id);
+        for (size_t id : connected)
+            take(id);
+    }
+    std::sort(_local_poses.begin(), _local_poses.end(), [&graph](const NodePose &a, const NodePose &b) {
+        return graph.getNode(a.node_id)->payload.path < graph.getNode(b.node_id)->payload.path;
+    });
+}
+
+void RelaxGroup::build_optimization_edges(const MeasurementGraph &graph, const std::vector<std::vector<size_t>> &knn10, size_t node_id)
+{
+    const MeasurementGraph::Node *node = graph.getNode(node_id);
+    std::unordered_map<size_t, char> ideal;
+    for (size_t other : knn10[graph.nodeIndex(node_id)])
+        ideal.emplace(other, 1);
+    ideal.erase(node_id);
+    auto link = [&](size_t other, size_t edge_id) {
+        if (_directly_set.emplace(other, 1).second)
+            _directly_connected.push_back(other);
+        if (_nodes_to_optimize.count(other) && _edge_set.emplace(edge_id, 1).second)
+            _edges_to_optimize.push_back(edge_id);
+    };
+    // Node::getEdges() is a set: an edge from a node to itself is listed once
+    size_t previous = (size_t)-1;
+    for (size_t edge_id : node->edges)
+    {
+        if (edge_id == previous)
+            continue;
+        previous = edge_id;
+        const MeasurementGraph::Edge *edge = graph.getEdge(edge_id);
+        if (edge->source == node_id && ideal.count(edge->dest))
+            link(edge->dest, edge_id);
+        else if (edge->dest == node_id && ideal.count(edge->source))
+            link(edge->source, edge_id);
+    }
+}
+
+bool RelaxGroup::run(ochip_ctx *ctx, const MeasurementGraph &graph, const std::vector<surface_model> &previousSurfaces,
+                     surface_model *out, RelaxTimers *timers, RelaxMeshStats *stats, std::string *error)
+{
+    return relax(ctx, graph, _local_poses, _camera_models, _edges_to_optimize, _config, previousSurfaces, out, timers, stats, error);
+}
+
+std::vector<size_t> RelaxGroup::finalize(MeasurementGraph &graph)
+{
+    std::vector<size_t> ids;
+    ids.reserve(_local_poses.size());
+    const bool model_changed = (_config.options & (OPT_FOCAL_LENGTH | OPT_PRINCIPAL_POINT | OPT_LENS_DISTORTIONS_RADIAL |
+                                                   OPT_LENS_DISTORTIONS_TANGENTIAL)) != 0;
+    for (const NodePose &pose : _local_poses)
+    {
+        MeasurementGraph::Node *node = graph.getNode(pose.node_id);
+        std::memcpy(node->payload.orientation, pose.orientation, sizeof pose.orientation);
+        std::memcpy(node->payload.position, pose.position, sizeof pose.position);
+        if (model_changed)
+            for (const auto &m : _camera_models)
+                if (m.first == node->payload.model->id)
+                    *node->payload.model = m.second;
+        ids.push_back(pose.node_id);
+    }
+    // (after a model change the caller re-fits every edge on its previous inliers: och_graph_refit_edges, refit_edges.cpp)
+    _local_poses.clear();
+    return ids;
+}
+
+// --------------------------------------------------------------------------------------------------------- partitioning
+namespace
+{
+
+using p3 = std::array<double, 3>;
+
+// KMeans<size_t, 3> (include/opencalibration/geometry/KMeans.hpp): k-center seeding from the first point, assignment,
+// and per iterate(): centres of the smallest clusters moved onto the largest ones' (when those are more than e times as
+// big), re-assignment, new centroids, clusters sorted by size.
+class KMeans3
+{
+  public:
+    struct cluster
+    {
+        p3 centroid{};
+        std::vector<std::pair<p3, size_t>> points;
+    };
+    explicit KMeans3(size_t k) : _c(k)
+    {
+    }
+    void add(const p3 &x, size_t value)
+    {
+        if (!_ready)
+        {
+            _c[0].points.emplace_back(x, value);
+            return;
+        }
+        cluster &c = _c[nearest(x)];
+        const size_t m = c.points.size();
+        for (int a = 0; a < 3; a++)
+            c.centroid[a] = (x[a] * 1. + c.centroid[a] * m) / (m + 1);
+        c.points.emplace_back(x, value);
+    }
+    bool iterate()
+    {
+        if (!_ready)
+            return seed();
+        // centres of small clusters jump next to the big ones
+        size_t moved = 0;
+        for (; moved < _c.size() / 2; moved++)
+            if (_c[moved].points.size() * 2.71828 > _c[_c.size() - 1 - moved].points.size())
+                break;
+        for (size_t i = 0; i < moved; i++)
+            for (size_t a = 0; a < 3; a++)
+                _c[i].centroid[a] = _c[_c.size() - 1 - i].centroid[a] * (1 + ((i + a) % 2 == 0 ? 1 : -1) * 1e-9);
+        auto all = drain();
+        for (const auto &p : all)
+            _c[nearest(p.first)].points.push_back(p);
+        centroids();
+        by_size();
+        return true;
+    }
+    const std::vector<cluster> &clusters() const
+    {
+        return _c;
+    }
+
+  private:
+    static double dist2(const p3 &a, const p3 &b)
+    {
+        double d = 0;
+        for (int i = 0; i < 3; i++)
+            d += (a[i] - b[i]) * (a[i] - b[i]);
+        return d;
+    }
+    size_t nearest(const p3 &x) const
+    {
+        size_t best = 0;
+        double bd = std::numeric_limits<double>::infinity();
+        for (size_t i = 0; i < _c.size(); i++)
+        {
+            const double d = dist2(x, _c[i].centroid);
+            if (d < bd)
+            {
+                bd = d;
+                best = i;
+            }
+        }
+        return best;
+    }
+    std::vector<std::pair<p3, size_t>> drain()
+    {
+        std::vector<std::pair<p3, size_t>> all;
+        for (cluster &c : _c)
+        {
+            all.insert(all.end(), c.points.begin(), c.points.end());
+            c.points.clear();
+        }
+        return all;
+    }
+    void centroids()
+    {
+        for (cluster &c : _c)
+        {
+            if (c.points.empty())
+                continue;
+            c.centroid = {0, 0, 0};
+            for (const auto &p : c.points)
+                for (int a = 0; a < 3; a++)
+                    c.centroid[a] += p.first[a];
+            for (int a = 0; a < 3; a++)
+                c.centroid[a] /= c.points.size();
+        }
+    }
+    void by_size() // std::sort(_clusters) with operator< on the sizes: the same comparisons, hence the same permutation
+    {
+        std::sort(_c.begin(), _c.end(), [](const cluster &a, const cluster &b) { return a.points.size() < b.points.size(); });
+    }
+    bool seed()
+    {
+        if (_c[0].points.size() < _c.size())
+            return false;
+        auto all = drain();
+        std::vector<size_t> seeds{0};
+        std::vector<double> far(all.size(), std::numeric_limits<double>::max());
+        for (size_t k = 1; k < _c.size(); k++)
+        {
+            const p3 &last = all[seeds.back()].first;
+            size_t pick = 0;
+            double best = -1.0;
+            for (size_t i = 0; i < all.size(); i++)
+            {
+                far[i] = std::min(far[i], dist2(all[i].first, last));
+                if (far[i] > best)
+                {
+                    best = far[i];
+                    pick = i;
+                }
+            }
+            seeds.push_back(pick);
+        }
+        for (size_t k = 0; k < _c.size(); k++)
+            _c[k].centroid = all[seeds[k]].first;
+        for (const auto &p : all)
+            _c[nearest(p.first)].points.push_back(p);
+        centroids();
+        by_size();
+        _ready = true;
+        return true;
+    }
+    std::vector<cluster> _c;
+    bool _ready = false;
+};
+
+// The few smallest eigenpairs of a sparse symmetric matrix with spectrum in [0, 2] (a normalised graph Laplacian):
+// Lanczos on 2 I - L with full re-orthogonalisation, the tridiagonal problem by implicit QL.  Stands in for
+// Spectra::SymEigsSolver (spectral_cluster.hpp:138-157), which is not part of this image.
+struct sparse_sym
+{
+    int n = 0;
+    std::vector<int> row_off, col;
+    std::vector<double> val;
+    void mul(const double *x, double *y) const
+    {
+#pragma omp parallel for schedule(static) if (n > 2000)
+        for (int i = 0; i < n; i++)
+        {
+            double s = 0;
+            for (int e = row_off[i]; e < row_off[i + 1]; e++)
+                s += val[e] * x[col[e]];
+            y[i] = s;
+        }
+    }
+};
+
+// eigenvalues d (ascending) and eigenvectors z (m x m, columns) of the symmetric tridiagonal (d, e): implicit QL
+bool tridiagonal_eigen(std::vector<double> &d, std::vector<double> &e, std::vector<double> &z, int m)
+{
+    z.assign((size_t)m * m, 0.0);
+    for (int i = 0; i < m; i++)
+        z[(size_t)i * m + i] = 1.0;
+    e.push_back(0.0);
+    for (int l = 0; l < m; l++)
+    {
+        int iter = 0, mm;
+        do
+        {
+            for (mm = l; mm < m - 1; mm++)
+            {
+                const double dd = std::abs(d[mm]) + std::abs(d[mm + 1]);
+                if (std::abs(e[mm]) <= 2.3e-16 * dd)
+                    break;
+            }
+            if (mm != l)
+            {
+                if (iter++ == 200)
+                    return false;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[mm] - d[l] + e[l] / (g + (g >= 0 ? std::abs(r) : -std::abs(r)));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = mm - 1; i >= l; i--)
+                {
+                    double f = s * e[i];
+                    const double b = c * e[i];
+                    e[i + 1] = (r = std::hypot(f, g));
+                    if (r == 0.0)
+                    {
+                        d[i + 1] -= p;
+                        e[mm] = 0.0;
+                        break;
+                    }
+                    s = f / r;
+                    c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    d[i + 1] = g + (p = s * r);
+                    g = c * r - b;
+                    for (int k = 0; k < m; k++)
+                    {
+                        f = z[(size_t)k * m + i + 1];
+                        z[(size_t)k * m + i + 1] = s * z[(size_t)k * m + i] + c * f;
+                        z[(size_t)k * m + i] = c * z[(size_t)k * m + i] - s * f;
+                    }
+                }
+                if (r == 0.0 && i >= l)
+                    continue;
+                d[l] -= p;
+                e[l] = g;
+                e[mm] = 0.0;
+            }
+        } while (mm != l);
+    }
+    return true;
+}
+
+// the `want` smallest eigenpairs of L; vectors as rows of `vecs` (want x n), values ascending
+bool smallest_eigenpairs(const sparse_sym &L, int want, std::vector<double> &vals, std::vector<double> &vecs)
+{
+    const int n = L.n;
+    int m = std::min(n, std::max(80, 4 * want));
+    std::vector<double> Q, alpha, beta, w(n), ritz, tz;
+    for (;; m = std::min(n, 2 * m))
+    {
+        Q.assign((size_t)m * n, 0.0);
+        alpha.assign(m, 0.0);
+        beta.assign(m, 0.0);
+        // deterministic start vector
+        {
+            uint64_t s = 0x9E3779B97F4A7C15ull;
+            double nn = 0;
+            for (int i = 0; i < n; i++)
+            {
+                s = s * 6364136223846793005ull + 1442695040888963407ull;
+                Q[i] = ((double)(s >> 11) / 9007199254740992.0) - 0.5;
+                nn += Q[i] * Q[i];
+            }
+            nn = std::sqrt(nn);
+            for (int i = 0; i < n; i++)
+                Q[i] /= nn;
+        }
+        int steps = m;
+        for (int j = 0; j < m; j++)
+        {
+            double *q = &Q[(size_t)j * n];
+            L.mul(q, w.data());
+            for (int i = 0; i < n; i++)
+                w[i] = 2.0 * q[i] - w[i]; // M = 2 I - L: the smallest of L are the largest of M
+            double a = 0;
+            for (int i = 0; i < n; i++)
+                a += w[i] * q[i];
+            alpha[j] = a;
+            // full re-orthogonalisation against every earlier Lanczos vector, twice
+            for (int pass = 0; pass < 2; pass++)
+                for (int k = 0; k <= j; k++)
+                {
+                    const double *qk = &Q[(size_t)k * n];
+                    double dotp = 0;
+                    for (int i = 0; i < n; i++)
+                        dotp += w[i] * qk[i];
+                    for (int i = 0; i < n; i++)
+                        w[i] -= dotp * qk[i];
+                }
+            double b = 0;
+            for (int i = 0; i < n; i++)
+                b += w[i] * w[i];
+            b = std::sqrt(b);
+            if (j + 1 < m)
+            {
+                if (b < 1e-12)
+                {
+                    steps = j + 1; // invariant subspace found
+                    break;
+                }
+                beta[j] = b;
+                double *qn = &Q[(size_t)(j + 1) * n];
+                for (int i = 0; i < n; i++)
+                    qn[i] = w[i] / b;
+            }
+            else
+                beta[j] = b;
+        }
+        std::vector<double> d(alpha.begin(), alpha.begin() + steps), e(beta.begin(), beta.begin() + std::max(steps - 1, 0));
+        if (!tridiagonal_eigen(d, e, tz, steps))
+            return false;
+        // the largest Ritz values of M; residual of Ritz pair i = |beta_last * last component of its tridiagonal vector|
+        std::vector<int> order(steps);
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return d[a] > d[b]; });
+        const int have = std::min(want, steps);
+        double worst = 0;
+        for (int t = 0; t < have; t++)
+            worst = std::max(worst, std::abs(beta[steps - 1] * tz[(size_t)(steps - 1) * steps + order[t]]));
+        if (worst < 1e-10 || steps >= n || steps < m)
+        {
+            vals.assign(have, 0.0);
+            vecs.assign((size_t)have * n, 0.0);
+            for (int t = 0; t < have; t++)
+            {
+                vals[t] = 2.0 - d[order[t]];
+                double *v = &vecs[(size_t)t * n];
+                for (int j = 0; j < steps; j++)
+                {
+                    const double c = tz[(size_t)j * steps + order[t]];
+                    const double *q = &Q[(size_t)j * n];
+                    for (int i = 0; i < n; i++)
+                        v[i] += c * q[i];
+                }
+            }
+            return have == want;
+        }
+    }
+}
+
+// SpectralClustering<size_t, 3> (include/opencalibration/geometry/spectral_cluster.hpp)
+class Spectral3
+{
+  public:
+    explicit Spectral3(size_t k) : _km(k)
+    {
+    }
+    void add(const p3 &x, size_t value)
+    {
+        _items.emplace_back(x, value);
+    }
+    void addLink(size_t a, size_t b, double w)
+    {
+        _links.push_back({a, b, w});
+    }
+    bool spectralize()
+    {
+        if (_km.clusters().size() <= 1)
+            return false;
+        const size_t n = _items.size();
+        std::unordered_map<size_t, size_t> at;
+        for (size_t i = 0; i < n; i++)
+            at.emplace(_items[i].second, i);
+        // weighted adjacency (parallel links add up) and degrees
+        std::vector<std::vector<std::pair<size_t, double>>> adj(n);
+        std::vector<double> degree(n, 0.0);
+        {
+            std::vector<std::tuple<size_t, size_t, double>> trip;
+            for (const link &l : _links)
+            {
+                auto a = at.find(l.a), b = at.find(l.b);
+                if (a == at.end() || b == at.end())
+                    continue;
+                trip.emplace_back(a->second, b->second, l.w);
+                trip.emplace_back(b->second, a->second, l.w);
+                degree[a->second] += l.w;
+                degree[b->second] += l.w;
+            }
+            std::stable_sort(trip.begin(), trip.end(), [](const auto &x, const auto &y) {
+                return std::get<0>(x) != std::get<0>(y) ? std::get<0>(x) < std::get<0>(y) : std::get<1>(x) < std::get<1>(y);
+            });
+            for (const auto &t : trip)
+            {
+                auto &row = adj[std::get<0>(t)];
+                if (!row.empty() && row.back().first == std::get<1>(t))
+                    row.back().second += std::get<2>(t);
+                else
+                    row.emplace_back(std::get<1>(t), std::get<2>(t));
+            }
+        }
+        for (double d : degree)
+            if (d == 0.)
+                return false;
+        // connected components, breadth first, neighbours by ascending index
+        std::vector<std::vector<size_t>> comps;
+        {
+            std::vector<char> seen(n, 0);
+            for (size_t s = 0; s < n; s++)
+            {
+                if (seen[s])
+                    continue;
+                comps.emplace_back();
+                std::queue<size_t> q;
+                q.push(s);
+                seen[s] = 1;
+                while (!q.empty())
+                {
+                    const size_t u = q.front();
+                    q.pop();
+                    comps.back().push_back(u);
+                    for (const auto &nb : adj[u])
+                        if (!seen[nb.first])
+                        {
+                            seen[nb.first] = 1;
+                            q.push(nb.first);
+                        }
+                }
+            }
+        }
+        if (comps.size() > 1)
+            return split_components(comps);
+        if (n < 6)
+            return false;
+        sparse_sym L;
+        L.n = (int)n;
+        L.row_off.assign(n + 1, 0);
+        for (size_t i = 0; i < n; i++)
+        {
+            bool diag = false;
+            for (const auto &nb : adj[i])
+            {
+                double v = -nb.second / (std::sqrt(degree[i]) * std::sqrt(degree[nb.first]));
+                if (nb.first == i)
+                {
+                    v += 1.0;
+                    diag = true;
+                }
+                L.col.push_back((int)nb.first);
+                L.val.push_back(v);
+            }
+            if (!diag)
+            {
+                L.col.push_back((int)i);
+                L.val.push_back(1.0);
+            }
+            L.row_off[i + 1] = (int)L.col.size();
+        }
+        std::vector<double> vals, vecs;
+        if (!smallest_eigenpairs(L, 4, vals, vecs))
+            return false;
+        for (size_t i = 0; i < n; i++)
+        {
+            // columns of Spectra's result: its 4 smallest eigenvalues, largest first
+            p3 x = {vecs[3 * n + i], vecs[2 * n + i], vecs[1 * n + i]};
+            const double z = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+            if (z > 0)
+                for (double &c : x)
+                    c /= std::sqrt(z);
+            _km.add(x, _items[i].second);
+        }
+        return true;
+    }
+    void fallback()
+    {
+        for (const auto &it : _items)
+            _km.add(it.first, it.second);
+    }
+    void iterate()
+    {
+        if (_sub.empty())
+        {
+            _km.iterate();
+            return;
+        }
+        for (Spectral3 &s : _sub)
+            s.iterate();
+        combine();
+    }
+    const std::vector<KMeans3::cluster> &clusters() const
+    {
+        return _sub.empty() ? _km.clusters() : _combined;
+    }
+
+  private:
+    struct link
+    {
+        size_t a, b;
+        double w;
+    };
+    bool split_components(const std::vector<std::vector<size_t>> &comps)
+    {
+        const size_t k = _km.clusters().size();
+        std::vector<size_t> share(comps.size(), 1);
+        for (size_t extra = comps.size(); extra < k; extra++)
+        {
+            size_t best = 0;
+            double br = 0;
+            for (size_t i = 0; i < comps.size(); i++)
+            {
+                const double r = (double)comps[i].size() / share[i];
+                if (r > br)
+                {
+                    br = r;
+                    best = i;
+                }
+            }
+            share[best]++;
+        }
+        for (size_t c = 0; c < comps.size(); c++)
+        {
+            std::unordered_map<size_t, char> ids;
+            for (size_t idx : comps[c])
+                ids.emplace(_items[idx].second, 1);
+            _sub.emplace_back(share[c]);
+            Spectral3 &s = _sub.back();
+            for (size_t idx : comps[c])
+                s.add(_items[idx].first, _items[idx].second);
+            for (const link &l : _links)
+                if (ids.count(l.a) && ids.count(l.b))
+                    s.addLink(l.a, l.b, l.w);
+            if (!(share[c] > 1 && s.spectralize()))
+                s.fallback();
+        }
+        combine();
+        return true;
+    }
+    void combine()
+    {
+        _combined.clear();
+        for (const Spectral3 &s : _sub)
+            for (const auto &c : s.clusters())
+                _combined.push_back(c);
+        std::sort(_combined.begin(), _combined.end(),
+                  [](const KMeans3::cluster &a, const KMeans3::cluster &b) { return a.points.size() < b.points.size(); });
+    }
+    std::vector<std::pair<p3, size_t>> _items;
+    std::vector<link> _links;
+    KMeans3 _km;
+    std::vector<Spectral3> _sub;
+    std::vector<KMeans3::cluster> _combined;
+};
+
+} // namespace
+
+std::vector<std::vector<size_t>> relax_partition(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, size_t num_groups)
+{
+    Spectral3 k(num_groups);
+    for (size_t id : node_ids)
+    {
+        const double *p = graph.getNode(id)->payload.position;
+        k.add({p[0], p[1], p[2]}, id);
+    }
+    if (num_groups > 1)
+    {
+        for (size_t id : node_ids)
+        {
+            k.addLink(id, id, 0.1);
+            size_t previous = (size_t)-1;
+            for (size_t e : graph.getNode(id)->edges)
+            {
+                if (e == previous)
+                    continue;
+                previous = e;
+                const MeasurementGraph::Edge *edge = graph.getEdge(e);
+                k.addLink(edge->source, edge->dest, 1);
+            }
+        }
+        if (!k.spectralize())
+            k.fallback();
+        for (int i = 0; i < 10; i++)
+            k.iterate();
+    }
+    else
+        k.fallback();
+    const auto &clusters = k.clusters();
+    std::vector<std::vector<size_t>> groups;
+    for (auto it = clusters.rbegin(); it != clusters.rend(); ++it)
+    {
+        std::vector<size_t> g;
+        for (const auto &p : it->points)
+            g.push_back(p.second);
+        groups.push_back(std::move(g));
+    }
+    return groups;
+}
+
+// ------------------------------------------------------------------------------------------------------ merged surfaces
+namespace
+{
+// which triangle (edge, side) of a mesh lies under a point: start at the triangle with the nearest centroid, cross the
+// most violated edge until the point is inside (TriangleLocator, refine_mesh.cpp:572-711)
+struct tri_id
+{
+    size_t edge = MeshEdge::NONE;
+    int side = 0;
+};
+class TriangleLocator
+{
+  public:
+    explicit TriangleLocator(const MeshGraph &m) : _m(m)
+    {
+        for (size_t e = 0; e < m.edges.size(); e++)
+            for (int side = 0; side < 2; side++)
+            {
+                if (side == 1 && m.edges[e].border)
+                    continue;
+                size_t v[3];
+                if (!verts(tri_id{e, side}, v))
+                    continue;
+                _tri.push_back(tri_id{e, side});
+                _cx.push_back((m.nodes[v[0]].location[0] + m.nodes[v[1]].location[0] + m.nodes[v[2]].location[0]) / 3.0);
+                _cy.push_back((m.nodes[v[0]].location[1] + m.nodes[v[1]].location[1] + m.nodes[v[2]].location[1]) / 3.0);
+            }
+    }
+    bool verts(const tri_id &t, size_t v[3]) const
+    {
+        if (t.edge >= _m.edges.size())
+            return false;
+        const MeshEdge &e = _m.edges[t.edge];
+        v[0] = e.source;
+        v[1] = e.dest;
+        v[2] = e.triangleOppositeNodes[t.side];
+        return v[2] < _m.nodes.size();
+    }
+    tri_id find(double x, double y) const
+    {
+        if (_tri.empty())
+            return tri_id();
+        size_t best = 0;
+        double bd = std::numeric_limits<double>::infinity();
+        for (size_t i = 0; i < _tri.size(); i++)
+        {
+            const double dx = _cx[i] - x, dy = _cy[i] - y, d = dx * dx + dy * dy;
+            if (d < bd)
+            {
+                bd = d;
+                best = i;
+            }
+        }
+        tri_id cur = _tri[best];
+        for (int step = 0; step < 100; step++)
+        {
+            size_t v[3];
+            if (!verts(cur, v))
+                return tri_id();
+            const double *p0 = _m.nodes[v[0]].location, *p1 = _m.nodes[v[1]].location, *p2 = _m.nodes[v[2]].location;
+            auto sign = [](double px, double py, double ax, double ay, double bx, double by) {
+                return (px - bx) * (ay - by) - (ax - bx) * (py - by);
+            };
+            const double d[3] = {sign(x, y, p0[0], p0[1], p1[0], p1[1]), sign(x, y, p1[0], p1[1], p2[0], p2[1]),
+                                 sign(x, y, p2[0], p2[1], p0[0], p0[1])};
+            const bool neg = d[0] < 0 || d[1] < 0 || d[2] < 0, pos = d[0] > 0 || d[1] > 0 || d[2] > 0;
+            if (!(neg && pos))
+                return cur;
+            const bool expect_positive = ((d[0] < 0) + (d[1] < 0) + (d[2] < 0)) < 2;
+            double worst = 0;
+            int leave = -1;
+            for (int i = 0; i < 3; i++)
+            {
+                if (d[i] == 0)
+                {
+                    worst = 0.000001;
+                    leave = i;
+                }
+                else if ((d[i] > 0) != expect_positive && std::abs(d[i]) > worst)
+                {
+                    worst = std::abs(d[i]);
+                    leave = i;
+                }
+            }
+            if (leave < 0)
+                return tri_id();
+            tri_id next;
+            if (leave == 0)
+            {
+                if (!_m.edges[cur.edge].border)
+                    next = tri_id{cur.edge, 1 - cur.side};
+            }
+            else
+            {
+                const size_t va = v[leave], vb = v[(leave + 1) % 3], opp = v[(leave + 2) % 3];
+                const MeshEdge *ce = _m.getEdge(va, vb);
+                if (!ce)
+                    ce = _m.getEdge(vb, va);
+                if (ce && !ce->border)
+                {
+                    const int side = ce->triangleOppositeNodes[0] == opp ? 0 : ce->triangleOppositeNodes[1] == opp ? 1 : -1;
+                    if (side >= 0)
+                        next = tri_id{(size_t)(ce - &_m.edges[0]), 1 - side};
+                }
+            }
+            if (next.edge == MeshEdge::NONE)
+                return tri_id();
+            cur = next;
+        }
+        // (the reference falls back to an exhaustive search here; a walk of 100 steps from the nearest centroid does
+        // not happen on a conforming mesh)
+        return tri_id();
+    }
+
+  private:
+    const MeshGraph &_m;
+    std::vector<tri_id> _tri;
+    std::vector<double> _cx, _cy;
+};
+} // namespace
+
+surface_model mergeSurfaceModels(const std::vector<surface_model> &surfaces)
+{
+    if (surfaces.empty())
+        return surface_model();
+    if (surfaces.size() == 1)
+        return surfaces[0];
+    surface_model result;
+    result.mesh = surfaces[0].mesh;
+    const size_t nv = result.mesh.size_nodes();
+    std::vector<std::array<double, 4>> sum(nv, {0, 0, 0, 0}); // weighted position, weight
+    for (const surface_model &s : surfaces)
+    {
+        if (s.mesh.size_nodes() == 0)
+            continue;
+        TriangleLocator loc(s.mesh);
+        std::vector<size_t> count(2 * s.mesh.size_edges(), 0); // points per (edge, side)
+        for (const point_cloud &c : s.cloud)
+            for (const auto &p : c)
+            {
+                const tri_id t = loc.find(p[0], p[1]);
+                if (t.edge != MeshEdge::NONE)
+                    count[2 * t.edge + t.side]++;
+            }
+        std::vector<size_t> per_vertex(s.mesh.size_nodes(), 0);
+        for (size_t e = 0; e < s.mesh.size_edges(); e++)
+            for (int side = 0; side < 2; side++)
+            {
+                size_t v[3];
+                if (count[2 * e + side] == 0 || !loc.verts(tri_id{e, side}, v))
+                    continue;
+                for (int i = 0; i < 3; i++)
+                    per_vertex[v[i]] += count[2 * e + side];
+            }
+        for (size_t v = 0; v < s.mesh.size_nodes() && v < nv; v++)
+            if (per_vertex[v] > 0)
+            {
+                const double w = (double)per_vertex[v];
+                for (int a = 0; a < 3; a++)
+                    sum[v][a] += s.mesh.nodes[v].location[a] * w;
+                sum[v][3] += w;
+            }
+        for (const point_cloud &c : s.cloud)
+            result.cloud.push_back(c);
+    }
+    for (size_t v = 0; v < nv; v++)
+        if (sum[v][3] > 0)
+            for (int a = 0; a < 3; a++)
+                result.mesh.nodes[v].location[a] = sum[v][a] / sum[v][3];
+    return result;
+}
+
+// ------------------------------------------------------------------------------------------------------------ RelaxStage
+void RelaxStage::init(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, bool relax_all, bool disable_parallelism,
+                      const RelaxConfig &config)
+{
+    _groups.clear();
+    std::vector<size_t> ids = node_ids;
+    if (relax_all)
+    {
+        ids.clear();
+        for (const auto &n : graph.nodes())
+            ids.push_back(n.id);
+    }
+    const bool global_params = (config.options & (OPT_FOCAL_LENGTH | OPT_PRINCIPAL_POINT | OPT_LENS_DISTORTIONS_RADIAL |
+                                                  OPT_LENS_DISTORTIONS_TANGENTIAL)) != 0;
+    const int optimal_cluster_size = global_params ? 150 : 50;
+    const size_t num_groups =
+        disable_parallelism ? 1 : std::max<size_t>(1, static_cast<size_t>(std::floor(ids.size() / optimal_cluster_size)));
+    const auto groups = relax_partition(graph, ids, num_groups);
+    _partition = groups;
+    const size_t depth = num_groups > 1 ? 0 : 2;
+    const auto knn10 = image_knn(graph, 10);
+    for (const auto &g : groups)
+    {
+        _groups.emplace_back();
+        _groups.back().init(graph, g, knn10, depth, config);
+    }
+}
+
+void RelaxStage::trim_groups(size_t max_size)
+{
+    while (_groups.size() > max_size)
+        _groups.pop_back();
+}
+
+std::vector<std::function<void()>> RelaxStage::get_runners(ochip_ctx *ctx, const MeasurementGraph &graph)
+{
+    std::swap(_surface_models, _previous_surface_models);
+    _surface_models.clear();
+    _surface_models.resize(_groups.size());
+    _group_timers.assign(_groups.size(), RelaxTimers());
+    _group_stats.assign(_groups.size(), RelaxMeshStats());
+    _group_errors.assign(_groups.size(), std::string());
+    // the runners may be called concurrently (the reference runs them under OpenMP): group i works on device context
+    // i mod R, the caller's context and R - 1 siblings of it, and runners that share a context take turns
+    size_t R = 4;
+    if (const char *e = getenv("OCHIP_RELAX_RUNNERS"))
+        R = std::max(1, atoi(e));
+    R = std::max<size_t>(1, std::min(R, _groups.size()));
+    while (_ctx_mutex.size() < R)
+        _ctx_mutex.emplace_back(new std::mutex());
+    std::vector<std::function<void()>> funcs;
+    for (size_t i = 0; i < _groups.size(); i++)
+        funcs.push_back([this, i, R, ctx, &graph]() {
+            ochip_ctx *c = ctx;
+            if (i % R > 0 && ochip_ctx_sibling(ctx, (uint32_t)(i % R - 1), &c) != OCHIP_OK)
+            {
+                _group_errors[i] = std::string("ochip_ctx_sibling: ") + ochip_last_error(ctx);
+                return;
+            }
+            std::lock_guard<std::mutex> lock(*_ctx_mutex[i % R]);
+            _groups[i].run(c, graph, _previous_surface_models, &_surface_models[i], &_group_timers[i], &_group_stats[i],
+                           &_group_errors[i]);
+        });
+    return funcs;
+}
+
+std::vector<std::vector<size_t>> RelaxStage::finalize(MeasurementGraph &graph)
+{
+    std::vector<std::vector<size_t>> ids;
+    timers = RelaxTimers();
+    stats = RelaxMeshStats();
+    _error.clear();
+    for (size_t i = 0; i < _groups.size(); i++)
+    {
+        ids.push_back(_groups[i].finalize(graph));
+        if (i < _group_timers.size())
+        {
+            timers.setup_host += _group_timers[i].setup_host;
+            timers.device += _group_timers[i].device;
+            timers.solves += _group_timers[i].solves;
+            timers.iterations_total += _group_timers[i].iterations_total;
+            timers.last_residual_blocks += _group_timers[i].last_residual_blocks;
+            stats.track_blocks += _group_stats[i].track_blocks;
+            stats.two_ray_blocks += _group_stats[i].two_ray_blocks;
+            stats.mesh_vertices = std::max(stats.mesh_vertices, _group_stats[i].mesh_vertices);
+            stats.unknowns += _group_stats[i].unknowns;
+            if (!_group_errors[i].empty() && _error.empty())
+                _error = _group_errors[i];
+        }
+    }
+    _groups.clear();
+    if (_surface_models.size() > 1)
+    {
+        surface_model merged = mergeSurfaceModels(_surface_models);
+        _surface_models.clear();
+        _surface_models.push_back(std::move(merged));
+    }
+    return ids;
+}
+
+} // namespace opencalibration_amd

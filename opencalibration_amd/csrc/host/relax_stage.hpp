@@ -1,0 +1,102 @@
+// RelaxStage / RelaxGroup (reference: src/pipeline/relax_stage.{hpp,cpp}, src/relax/relax_group.{hpp,cpp},
+// include/opencalibration/geometry/{KMeans,spectral_cluster}.hpp): the partition of the cameras into relax groups, the
+// edges and context cameras every group takes, one runner per group, write-back and the merge of the groups' surfaces.
+// Same interface as the reference's stage triple: init / get_runners / finalize (+ trim_groups, surface getters).
+#pragma once
+
+#include "relax_mesh.hpp"
+
+#include <functional>
+#include <memory>
+#include <mutex>
+
+namespace opencalibration_amd
+{
+
+// imageGPSLocations.searchKnn(position, k): the k nearest images of every image in the plane (itself included), nearest
+// first; ties by insertion index.  Exhaustive and exact.
+std::vector<std::vector<size_t>> image_knn(const MeasurementGraph &graph, size_t k);
+
+class RelaxGroup // include/opencalibration/relax/relax_group.hpp
+{
+  public:
+    void init(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, const std::vector<std::vector<size_t>> &knn10,
+              size_t graph_connection_depth, const RelaxConfig &config);
+    bool run(ochip_ctx *ctx, const MeasurementGraph &graph, const std::vector<surface_model> &previousSurfaces, surface_model *out,
+             RelaxTimers *timers, RelaxMeshStats *stats, std::string *error);
+    std::vector<size_t> finalize(MeasurementGraph &graph);
+
+    const std::vector<NodePose> &local_poses() const
+    {
+        return _local_poses;
+    }
+    const std::vector<size_t> &edges_to_optimize() const
+    {
+        return _edges_to_optimize;
+    }
+
+  private:
+    void build_optimization_edges(const MeasurementGraph &graph, const std::vector<std::vector<size_t>> &knn10, size_t node_id);
+    std::vector<NodePose> _local_poses;
+    std::vector<std::pair<size_t, CameraModel>> _camera_models;
+    std::vector<size_t> _edges_to_optimize, _directly_connected; // insertion-ordered sets
+    std::unordered_map<size_t, char> _edge_set, _nodes_to_optimize, _directly_set;
+    RelaxConfig _config;
+};
+
+// The k-means / spectral partition of RelaxStage::init: groups of primary node ids, largest first.
+std::vector<std::vector<size_t>> relax_partition(const MeasurementGraph &graph, const std::vector<size_t> &node_ids,
+                                                 size_t num_groups);
+
+// mergeSurfaceModels (src/surface/refine_mesh.cpp:916-1016): the groups relaxed copies of one mesh; every vertex becomes
+// the mean of the groups' positions weighted by the number of cloud points of the group in the triangles around it.
+surface_model mergeSurfaceModels(const std::vector<surface_model> &surfaces);
+
+class RelaxStage // src/pipeline/relax_stage.hpp
+{
+  public:
+    void init(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, bool relax_all, bool disable_parallelism,
+              const RelaxConfig &config);
+    void trim_groups(size_t max_size);
+    // one runner per group; a runner returns nothing, errors are collected in error()
+    std::vector<std::function<void()>> get_runners(ochip_ctx *ctx, const MeasurementGraph &graph);
+    std::vector<std::vector<size_t>> finalize(MeasurementGraph &graph);
+    const std::vector<surface_model> &getSurfaceModels() const
+    {
+        return _surface_models;
+    }
+    void setSurfaceModels(std::vector<surface_model> surfaces)
+    {
+        _surface_models = std::move(surfaces);
+    }
+    size_t num_groups() const
+    {
+        return _groups.size();
+    }
+    const RelaxGroup &group(size_t i) const
+    {
+        return _groups[i];
+    }
+    const std::string &error() const
+    {
+        return _error;
+    }
+    const std::vector<std::vector<size_t>> &partition() const // primary node ids per group, as init() formed them
+    {
+        return _partition;
+    }
+    RelaxTimers timers;
+    RelaxMeshStats stats;
+
+  private:
+    std::vector<RelaxGroup> _groups;
+    std::vector<std::vector<size_t>> _partition;
+    std::vector<surface_model> _surface_models, _previous_surface_models;
+    std::vector<RelaxTimers> _group_timers;
+    std::vector<RelaxMeshStats> _group_stats;
+    std::vector<std::string> _group_errors;
+    std::string _error;
+    std::vector<std::unique_ptr<std::mutex>> _ctx_mutex; // runners that share a device context take turns
+};
+
+} // namespace opencalibration_amd

@@ -72,6 +72,10 @@ def load():
         L.och_graph_add_model.restype = u32
         L.och_graph_add_image.argtypes = [vp, _f64p, _f32p, _u64p, sz, sz, u32, _f64p]
         L.och_graph_add_image.restype = u64
+        L.och_graph_add_edge.restype = u64
+        L.och_graph_add_edge.argtypes = [vp, u64, u64, vp, C.c_int, sz, _f64p, _u64p, sz, vp, vp, vp]
+        L.och_graph_get_orientations.argtypes = [vp, _f64p]
+        L.och_graph_get_orientations.restype = None
         L.och_graph_num_nodes.argtypes = [vp]
         L.och_graph_num_nodes.restype = sz
         L.och_graph_num_edges.argtypes = [vp]
@@ -106,6 +110,12 @@ def load():
         L.och_relax.argtypes = [vp, sz, _f64p, _f64p, _f64p, _u64p, _f64p, sz, _u64p, _f64p, sz, _u64p, _u64p, vp, u8p, _u64p,
                                 _f64p, _u64p, _u64p, vp, vp, sz, _u64p, u32, C.c_double, vp, vp, _f64p]
         L.och_graph_relax.argtypes = [vp, vp, _f64p, u32, C.c_double, vp, vp, _f64p]
+        i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+        L.och_relax_stage_run.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, u32, C.c_double, sz, vp, vp, i64p, _f64p]
+        L.och_relax_partition.restype = sz
+        L.och_relax_partition.argtypes = [vp, sz, i64p, i64p]
+        L.och_merge_surfaces.argtypes = [C.POINTER(vp), sz, vp]
+        L.och_merge_surfaces.restype = None
         L.och_homography_decompose.argtypes = [_f64p, _f64p, sz, _f64p]
         L.och_image_to_3d.argtypes = [_f64p, sz, _f64p, _f64p]
         L.och_extract_tail.restype = C.c_size_t
@@ -352,6 +362,32 @@ class Graph:
             g.add_image(loc, st, de, grid.num_sparse[i], m, grid.position[i])
         return g
 
+    def add_edge(self, source_id, dest_id, px, f1, f2, match_index=None, H=None, dist=None, poses=None):
+        """graph.addEdge from arrays: px n x 4 inlier pixels, f1 / f2 feature indices, match distances."""
+        px = np.ascontiguousarray(px, np.float64).reshape(-1, 4)
+        n = len(px)
+        idx = np.zeros((max(n, 1), 3), np.uint64)
+        idx[:n, 0], idx[:n, 1] = f1, f2
+        idx[:n, 2] = np.arange(n) if match_index is None else match_index
+        Hc = None if H is None else np.ascontiguousarray(H, np.float64)
+        d = None if dist is None or len(dist) == 0 else np.ascontiguousarray(dist, np.float64)
+        pc = None if poses is None else np.ascontiguousarray(poses, np.float64)
+        e = self.L.och_graph_add_edge(self.h, int(source_id), int(dest_id), None if Hc is None else Hc.ctypes.data,
+                                      int(H is not None), n, px if n else np.zeros((1, 4)), idx, 0 if d is None else len(d),
+                                      None, None if d is None else d.ctypes.data, None if pc is None else pc.ctypes.data)
+        if e == 0:
+            raise capi.OchipError(self.L.och_last_error(self.h).decode())
+        return e
+
+    def orientations(self):
+        out = np.zeros((max(self.num_nodes, 1), 4))
+        self.L.och_graph_get_orientations(self.h, out)
+        return out[:self.num_nodes]
+
+    @property
+    def num_nodes(self):
+        return self.L.och_graph_num_nodes(self.h)
+
     @property
     def num_edges(self):
         return self.L.och_graph_num_edges(self.h)
@@ -395,6 +431,32 @@ class Graph:
         out = dict(zip(RELAX_SUMMARY12, summary.tolist()))
         out.update(orientation=ori, surface=surface)
         return out
+
+    def relax_stage(self, ctx, options, grid_fraction=0.1, node_ids=None, disable_parallelism=False, max_groups=0,
+                    previous=None):
+        """RelaxStage::init + runners + finalize (relax_stage.cpp): node_ids None = relax_all.  Returns the summary, the
+        merged surface, the graph's orientations afterwards and the group of every node (-1: not a primary node)."""
+        ids = None if node_ids is None else np.ascontiguousarray(node_ids, np.uint64)
+        summary = np.zeros(13)
+        groups = np.full(max(self.num_nodes, 1), -1, np.int64)
+        surface = Surface()
+        rc = self.L.och_relax_stage_run(self.h, ctx.h, None if ids is None else ids.ctypes.data, 0 if ids is None else len(ids),
+                                        int(ids is None), int(disable_parallelism), options, grid_fraction, max_groups,
+                                        previous.h if previous is not None else None, surface.h, groups, summary)
+        if rc != 0:
+            raise capi.OchipError("relax stage failed: " + self.L.och_last_error(self.h).decode())
+        out = dict(zip(RELAX_SUMMARY12 + ["groups"], summary.tolist()))
+        out.update(surface=surface, group_of_node=groups[:self.num_nodes].copy())
+        return out
+
+    def relax_partition(self, num_groups, ordered=False):
+        """The spectral / k-means partition of RelaxStage::init alone (host only)."""
+        groups, pos = np.full(max(self.num_nodes, 1), -1, np.int64), np.full(max(self.num_nodes, 1), -1, np.int64)
+        n = self.L.och_relax_partition(self.h, num_groups, groups, pos)
+        groups, pos = groups[:self.num_nodes].copy(), pos[:self.num_nodes].copy()
+        if ordered:
+            return [[int(i) for i in sorted(np.flatnonzero(groups == g), key=lambda i: pos[i])] for g in range(n)]
+        return n, groups
 
     def link_debug(self):
         out = []

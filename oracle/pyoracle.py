@@ -555,3 +555,31 @@ def knn10_bruteforce(xy):
         order = np.argsort(d, kind="stable")[:10]
         out[i, :len(order)] = order
     return out
+
+
+def relax_stage_groups(rxgraph, node_ids=None, disable_parallelism=False, opts=0, ordered=False):
+    """RelaxStage::init's partition (oracle/relax_cluster.cpp): (number of groups, group of every node or -1, context depth)."""
+    L = _rx()
+    L.ocx_relax_stage_groups.restype = C.c_size_t
+    i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+    L.ocx_relax_stage_groups.argtypes = [C.c_void_p, C.c_size_t, u64p, C.c_int, C.c_int, C.c_uint32, i64p, C.c_void_p, i64p]
+    ids = np.zeros(1, np.uint64) if node_ids is None else np.ascontiguousarray(node_ids, np.uint64)
+    out = np.full(max(rxgraph.n_nodes, 1), -1, np.int64)
+    depth = C.c_size_t(0)
+    pos = np.full(max(rxgraph.n_nodes, 1), -1, np.int64)
+    n = L.ocx_relax_stage_groups(rxgraph.h, 0 if node_ids is None else len(ids), ids, int(node_ids is None),
+                                 int(disable_parallelism), opts, out, C.addressof(depth), pos)
+    out, pos = out[:rxgraph.n_nodes].copy(), pos[:rxgraph.n_nodes].copy()
+    if ordered:   # the groups as lists of node ids in the order the clustering holds them
+        return [[int(i) for i in sorted(np.flatnonzero(out == g), key=lambda i: pos[i])] for g in range(n)], depth.value
+    return n, out, depth.value
+
+
+def kmeans3(xyz, k, iterations, use_ref=False):
+    """KMeans<size_t, 3>: the restatement, or (use_ref) the reference's own header compiled into oracle/_ref."""
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+    a, c, s = np.zeros(len(xyz), np.uint64), np.zeros((k, 3)), np.zeros(k, np.uint64)
+    fn = ref().ref_kmeans3 if use_ref else lib().ocx_kmeans3
+    fn.argtypes = [f64p, C.c_size_t, C.c_size_t, C.c_int, u64p, f64p, u64p]
+    fn(xyz, len(xyz), k, iterations, a, c, s)
+    return a, c, s

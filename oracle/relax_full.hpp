@@ -212,6 +212,12 @@ surface_model relax(const MeasurementGraph &graph, std::vector<NodePose> &nodes,
                     const std::vector<size_t> &edges_to_optimize, const RelaxConfig &config,
                     const std::vector<surface_model> &previousSurfaces, relax_stats *stats = nullptr);
 
+// RelaxStage::init (src/pipeline/relax_stage.cpp:28-112): the primary node ids of every group, largest group first
+// (oracle/relax_cluster.cpp: k-means / spectral clustering restated)
+std::vector<std::vector<size_t>> relax_stage_groups(const MeasurementGraph &graph, const std::vector<size_t> &node_ids,
+                                                    bool relax_all, bool disable_parallelism, uint32_t options,
+                                                    size_t *graph_connection_depth);
+
 // src/surface/expand_mesh.cpp
 MeshGraph rebuildMesh(const point_cloud &cameraLocations, const std::vector<surface_model> &previousSurfaces);
 MeshGraph buildMinimalMesh(const point_cloud &cameraLocations, const std::vector<surface_model> &previousSurfaces);

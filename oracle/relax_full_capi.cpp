@@ -343,6 +343,28 @@ size_t ocx_relax_group(void *h, size_t n_ids, const uint64_t *node_ids, const ui
     return n_local;
 }
 
+// RelaxStage::init's partition: group_of_node[i] = index of the group (largest first) node i is a primary node of, or -1
+size_t ocx_relax_stage_groups(void *h, size_t n_ids, const uint64_t *node_ids, int relax_all, int disable_parallelism,
+                              uint32_t options, int64_t *group_of_node, size_t *depth_out, int64_t *position_in_group)
+{
+    auto *g = (graph_handle *)h;
+    std::vector<size_t> ids(node_ids, node_ids + n_ids);
+    size_t depth = 0;
+    const auto groups = relax_stage_groups(g->graph, ids, relax_all != 0, disable_parallelism != 0, options, &depth);
+    for (size_t i = 0; i < g->graph.nodes.size(); i++)
+        group_of_node[i] = -1;
+    for (size_t k = 0; k < groups.size(); k++)
+        for (size_t j = 0; j < groups[k].size(); j++)
+        {
+            group_of_node[groups[k][j]] = (int64_t)k;
+            if (position_in_group)
+                position_in_group[groups[k][j]] = (int64_t)j;
+        }
+    if (depth_out)
+        *depth_out = depth;
+    return groups.size();
+}
+
 // forward <-> inverse lens model fits (invert_distortion.cpp:105-191)
 void ocx_convert_model(const double *model10, int to_inverse, double *out10)
 {

@@ -189,3 +189,22 @@ def grid_5x5():
                     edges.append(dict(src=i, dst=j, H=None, px=np.concatenate([px[i][both], px[j][both]], axis=1),
                                       match_index=both, dist=None))
     return ori, pos, edges
+
+
+def host_graph_from_edges(host, node_pos, node_ori, model10, edges):
+    """The flat edge dicts as an och_graph of the host library (descriptor-less features: locations only)."""
+    n = len(node_pos)
+    feats, plan = features_of_edges(n, edges)
+    g = host.Graph()
+    m = g.add_model(model10)
+    for i in range(n):
+        k = len(feats[i])
+        g.add_image(feats[i] if k else np.zeros((0, 2)), np.zeros(k, np.float32), np.zeros((k, 8), np.uint64), k, m, node_pos[i])
+    g.set_orientations(node_ori)
+    for e, (f1, f2) in zip(edges, plan):
+        g.add_edge(g.node_ids[e["src"]], g.node_ids[e["dst"]], e["px"], f1, f2, e["match_index"], e.get("H"), e.get("dist"))
+    return g
+
+
+def host_paths(n):
+    return ["synthetic_%d" % i for i in range(n)]  # the paths och_graph_add_image gives its images

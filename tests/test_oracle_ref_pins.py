@@ -57,3 +57,18 @@ def test_union_find_matches_reference_header(oracle, ref):
         ref.ref_union_find(n, pairs, len(pairs), a)
         oracle.lib().ocx_union_find(n, pairs, len(pairs), b)
         assert np.array_equal(a, b)  # the same ROOT ids, not just the same partition: track order follows the roots
+
+
+def test_kmeans_matches_reference_header(oracle, ref):
+    """include/opencalibration/geometry/KMeans.hpp compiled in place against the restatement used by the partitioning
+    of the relax stage: same clusters (sizes, centroids bit for bit, assignment), after 0..10 iterate() calls."""
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        n, k = int(rng.integers(20, 600)), int(rng.integers(2, 9))
+        pts = rng.normal(size=(n, 3)) * rng.uniform(0.5, 20, 3)
+        if trial % 3 == 0:   # clumps: small clusters get re-seeded next to big ones (KMeans.hpp:196-214)
+            pts[: n // 2] = pts[: n // 2] * 0.01 + 50
+        for iters in (1, 2, 5, 11):
+            a1, c1, s1 = oracle.kmeans3(pts, k, iters, use_ref=True)
+            a2, c2, s2 = oracle.kmeans3(pts, k, iters, use_ref=False)
+            assert np.array_equal(s1, s2) and np.array_equal(c1, c2) and np.array_equal(a1, a2), (trial, iters)
