@@ -143,14 +143,15 @@ extern "C"
      * feature locations (feat_off n_nodes + 1, feat_xy), per inlier the two feature indices (inl_feat n x 2).
      * previous / surface_out may be NULL.  summary_out (12): solves, iterations_total, last_iterations,
      * last_initial_cost, last_final_cost, last_residual_blocks, host setup seconds, device seconds, track blocks,
-     * 2-ray blocks, mesh vertices, unknowns of the last solve. */
+     * 2-ray blocks, mesh vertices, unknowns of the last solve.  model10_inout (may be NULL): the caller's cam_models entry of
+     * the shared camera model, read before and written after the relax (the intrinsics flavours change it). */
     int och_relax(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const double *node_ori, const double *model10,
                   const uint64_t *feat_off, const double *feat_xy, size_t n_poses, const uint64_t *pose_node,
                   double *pose_ori, size_t n_edges, const uint64_t *edge_src, const uint64_t *edge_dst, const double *edge_H,
                   const uint8_t *edge_is_homography, const uint64_t *inl_off, const double *inl_px,
                   const uint64_t *inl_feat, const uint64_t *inl_match_index, const uint64_t *dist_off, const double *dist,
                   size_t n_opt_edges, const uint64_t *opt_edges, uint32_t options, double grid_fraction,
-                  const och_surface *previous, och_surface *surface_out, double *summary_out);
+                  const och_surface *previous, och_surface *surface_out, double *summary_out, double *model10_inout);
     /* Every node of a linked graph as one group, every edge whitelisted, any flavour.  ori_inout: n_nodes x 4. */
     int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
                         const och_surface *previous, och_surface *surface_out, double *summary_out);
@@ -168,6 +169,9 @@ extern "C"
     /* the partition alone (no device): group_of_node as above, position_in_group (may be NULL) the node's place in its
      * group's list; returns the number of groups */
     size_t och_relax_partition(const och_graph *g, size_t num_groups, int64_t *group_of_node, int64_t *position_in_group);
+    /* convertModel (src/distort/invert_distortion.cpp:105-191): the inverse lens model fitted to a forward one (to_inverse),
+     * or the forward model fitted to an inverse one; m10 as och_graph_add_model */
+    void och_convert_model(const double *m10, int to_inverse, double *out10);
     /* mergeSurfaceModels of n surfaces (src/surface/refine_mesh.cpp:916-1016) */
     void och_merge_surfaces(const och_surface *const *surfaces, size_t n, och_surface *out);
 

@@ -4,6 +4,7 @@
 #include "capi_graph.hpp"
 #include "relax.hpp"
 #include "relax_mesh.hpp"
+#include "invert_distortion.hpp"
 #include "relax_stage.hpp"
 
 #include <thread>
@@ -266,7 +267,7 @@ int och_relax(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const doub
               const uint8_t *edge_is_homography, const uint64_t *inl_off, const double *inl_px, const uint64_t *inl_feat,
               const uint64_t *inl_match_index, const uint64_t *dist_off, const double *dist, size_t n_opt_edges,
               const uint64_t *opt_edges, uint32_t options, double grid_fraction, const och_surface *previous,
-              och_surface *surface_out, double *summary_out)
+              och_surface *surface_out, double *summary_out, double *model10_inout)
 {
     MeasurementGraph graph;
     auto model = std::make_shared<CameraModel>();
@@ -329,6 +330,15 @@ int och_relax(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const doub
     for (size_t i = 0; i < n_opt_edges; i++)
         opt[i] = edge_ids[opt_edges[i]];
     std::vector<std::pair<size_t, CameraModel>> cam_models{{model->id, *model}};
+    if (model10_inout) // the caller's cam_models entry (it may differ from the graph's model after an earlier relax)
+    {
+        CameraModel &cm = cam_models[0].second;
+        cm.focal_length_pixels = model10_inout[0];
+        cm.principle_point[0] = model10_inout[1], cm.principle_point[1] = model10_inout[2];
+        for (int i = 0; i < 3; i++)
+            cm.radial_distortion[i] = model10_inout[3 + i];
+        cm.tangential_distortion[0] = model10_inout[6], cm.tangential_distortion[1] = model10_inout[7];
+    }
     RelaxConfig cfg;
     cfg.options = options;
     cfg.ground_mesh_grid_fraction = grid_fraction;
@@ -345,6 +355,15 @@ int och_relax(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const doub
     if (surface_out)
         surface_out->s = std::move(out);
     fill_summary12(t, st, summary_out);
+    if (model10_inout)
+    {
+        const CameraModel &cm = cam_models[0].second;
+        model10_inout[0] = cm.focal_length_pixels;
+        model10_inout[1] = cm.principle_point[0], model10_inout[2] = cm.principle_point[1];
+        for (int i = 0; i < 3; i++)
+            model10_inout[3 + i] = cm.radial_distortion[i];
+        model10_inout[6] = cm.tangential_distortion[0], model10_inout[7] = cm.tangential_distortion[1];
+    }
     return 0;
 }
 
@@ -483,6 +502,34 @@ void och_merge_surfaces(const och_surface *const *surfaces, size_t n, och_surfac
     for (size_t i = 0; i < n; i++)
         v.push_back(surfaces[i]->s);
     out->s = mergeSurfaceModels(v);
+}
+
+
+// convertModel (src/distort/invert_distortion.cpp:105-191): forward -> inverse lens model fit, or back
+void och_convert_model(const double *m10, int to_inverse, double *out10)
+{
+    CameraModel m;
+    m.focal_length_pixels = m10[0];
+    m.principle_point[0] = m10[1], m.principle_point[1] = m10[2];
+    for (int i = 0; i < 3; i++)
+        m.radial_distortion[i] = m10[3 + i];
+    m.tangential_distortion[0] = m10[6], m.tangential_distortion[1] = m10[7];
+    m.pixels_cols = (size_t)m10[8], m.pixels_rows = (size_t)m10[9];
+    CameraModel r;
+    if (to_inverse)
+        r = convertModel(m);
+    else
+    {
+        InverseCameraModel inv;
+        static_cast<CameraModel &>(inv) = m;
+        r = convertModel(inv, 0);
+    }
+    out10[0] = r.focal_length_pixels;
+    out10[1] = r.principle_point[0], out10[2] = r.principle_point[1];
+    for (int i = 0; i < 3; i++)
+        out10[3 + i] = r.radial_distortion[i];
+    out10[6] = r.tangential_distortion[0], out10[7] = r.tangential_distortion[1];
+    out10[8] = (double)r.pixels_cols, out10[9] = (double)r.pixels_rows;
 }
 
 } // extern "C"

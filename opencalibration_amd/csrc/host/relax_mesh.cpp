@@ -1,5 +1,6 @@
 #include "relax_mesh.hpp"
 
+#include "invert_distortion.hpp"
 #include "relax_util.hpp"
 
 #include <cstdio>
@@ -479,6 +480,8 @@ class GroundMeshProblem
         };
         _poses = &poses;
         _cam_models = &cam_models;
+        _options = config.options;
+        _intrinsics = (config.options & (OPT_FOCAL_LENGTH | OPT_PRINCIPAL_POINT | OPT_LENS_DISTORTIONS_RADIAL)) != 0;
         for (size_t i = 0; i < poses.size(); i++)
             if (_opt_index.emplace(poses[i].node_id, i).second) // the first pose of a node is the one optimised
             {
@@ -526,6 +529,9 @@ class GroundMeshProblem
         // addRayTriangleMeasurementCost (:388-560) per edge, every edge with a mesh walker of its own
         std::vector<edge_blocks> per_edge(edges.size());
         const bool mesh_ok = _mesh.size_nodes() > 0 && _mesh.size_edges() > 0;
+        for (size_t k = 0; k < edges.size(); k++) // every edge gives its source model an inverse twin (:402-407)
+            if (src[k].loc != nullptr && dst[k].loc != nullptr)
+                twin_for(model_of(edges[k]->source));
 #pragma omp parallel for schedule(dynamic, 4)
         for (size_t k = 0; k < edges.size(); k++)
             if (mesh_ok && src[k].loc != nullptr && dst[k].loc != nullptr)
@@ -534,10 +540,14 @@ class GroundMeshProblem
             for (size_t b = 0; b < pe.tri.size() / 3; b++)
             {
                 _blk_n.push_back(2);
+                _blk_intr.push_back(pe.intr_model != (size_t)-1 ? 1 : 0);
+                if (pe.intr_model != (size_t)-1)
+                    observe(pe.intr_model);
                 _blk_ray_off.push_back((uint32_t)_ray_cam.size() + 2);
                 _ray_cam.push_back(pe.cams[2 * b]);
                 _ray_cam.push_back(pe.cams[2 * b + 1]);
                 _ray_dir.insert(_ray_dir.end(), pe.rays.begin() + 6 * b, pe.rays.begin() + 6 * b + 6);
+                _ray_px.insert(_ray_px.end(), pe.px.begin() + 4 * b, pe.px.begin() + 4 * b + 4);
                 _blk_tri.insert(_blk_tri.end(), pe.tri.begin() + 3 * b, pe.tri.begin() + 3 * b + 3);
             }
         lap("2-ray blocks");
@@ -581,12 +591,38 @@ class GroundMeshProblem
         d.vert_optimize = vopt.data();
         d.n_blocks = (uint32_t)_blk_n.size();
         d.blk_n = _blk_n.data();
-        d.blk_intr = nullptr;
+        d.blk_intr = _blk_intr.data();
         d.blk_ray_off = _blk_ray_off.data();
         d.blk_tri = _blk_tri.data();
         d.ray_cam = _ray_cam.data();
         d.ray_dir = _ray_dir.data();
-        d.ray_px = nullptr;
+        d.ray_px = _ray_px.data();
+        if (_shared_model != (size_t)-1)
+        {
+            // the one inverse lens model the FocalRadial blocks share (:483-507, :799-853)
+            const InverseCameraModel &m = twin_of(_shared_model)->m;
+            d.model[0] = m.focal_length_pixels;
+            d.model[1] = m.principle_point[0], d.model[2] = m.principle_point[1];
+            for (int i = 0; i < 3; i++)
+                d.model[3 + i] = m.radial_distortion[i];
+            d.model[6] = m.tangential_distortion[0], d.model[7] = m.tangential_distortion[1];
+            d.opt_focal = (_options & OPT_FOCAL_LENGTH) != 0;
+            d.opt_principal = (_options & OPT_PRINCIPAL_POINT) != 0;
+            // SubsetManifold of the radial block (:533-556): Brown k1 / k1 k2 / k1 k2 k3; with no parameterisation chosen -
+            // also when LENS_DISTORTIONS_RADIAL is not among the options at all - the block stays a free Euclidean one
+            const bool radial = (_options & OPT_LENS_DISTORTIONS_RADIAL) != 0;
+            d.n_radial_free = 3;
+            if (radial && !(_options & OPT_LENS_DISTORTIONS_RADIAL_BROWN246_PARAMETERIZATION))
+            {
+                if (_options & OPT_LENS_DISTORTIONS_RADIAL_BROWN24_PARAMETERIZATION)
+                    d.n_radial_free = 2;
+                else if (_options & OPT_LENS_DISTORTIONS_RADIAL_BROWN2_PARAMETERIZATION)
+                    d.n_radial_free = 1;
+            }
+            d.mono_observations = (uint32_t)_mono_count; // addMonotonicityCosts (:1381-1388)
+            const double hc = m.pixels_cols / 2.0, hr = m.pixels_rows / 2.0;
+            d.mono_r_max = std::sqrt(hc * hc + hr * hr) / _mono_focal;
+        }
         d.n_down = 0;
         d.n_diff = (uint32_t)(diff_v.size() / 2);
         d.diff_v = diff_v.data();
@@ -598,6 +634,11 @@ class GroundMeshProblem
         d.huber_a = 1 * M_PI / 180;
         d.focal_lo = 100.0;
         d.focal_hi = 20000.0;
+        if (_several_models)
+        {
+            *error = "relax: the device path optimises one shared lens model per group; this group holds images of several";
+            return false;
+        }
         if (ochip_relaxg_problem_create(_ctx, &d, &_dev) != OCHIP_OK)
         {
             *error = std::string("ochip_relaxg_problem_create: ") + ochip_last_error(_ctx);
@@ -636,8 +677,22 @@ class GroundMeshProblem
         if (stats)
             stats->unknowns = s.num_parameters;
         std::vector<double> q(_cam_opt.size() * 4), z(_mesh.size_nodes());
-        if (ochip_relaxg_get_state(_dev, q.data(), z.data(), nullptr) != OCHIP_OK)
+        double model[8];
+        if (ochip_relaxg_get_state(_dev, q.data(), z.data(), model) != OCHIP_OK)
             return fail(error, "ochip_relaxg_get_state");
+        if (_shared_model != (size_t)-1)
+        {
+            InverseCameraModel &m = twin_of(_shared_model)->m;
+            m.focal_length_pixels = model[0];
+            m.principle_point[0] = model[1], m.principle_point[1] = model[2];
+            for (int i = 0; i < 3; i++)
+                m.radial_distortion[i] = model[3 + i];
+        }
+        // "copy back camera models" (:1415-1419): every model with an inverse twin becomes the forward fit of the twin
+        for (const twin &t : _twins)
+            for (auto &cm : *_cam_models)
+                if (cm.first == t.id)
+                    cm.second = convertModel(t.m, t.id);
         for (size_t i = 0; i < _poses->size(); i++) // p.second->orientation.normalize(), :1410-1413
         {
             if (_pose_cam[i] == UINT32_MAX)
@@ -681,8 +736,47 @@ class GroundMeshProblem
     struct edge_blocks
     {
         std::vector<uint32_t> cams, tri;
-        std::vector<double> rays;
+        std::vector<double> rays, px;
+        size_t intr_model = (size_t)-1; // id of the shared model when the edge's blocks use the FocalRadial functor
     };
+    struct twin // _inverse_cam_model_to_optimize
+    {
+        size_t id;
+        InverseCameraModel m;
+    };
+    twin *twin_of(size_t id)
+    {
+        for (twin &t : _twins)
+            if (t.id == id)
+                return &t;
+        return nullptr;
+    }
+    twin *twin_for(const CameraModel &forward)
+    {
+        if (twin *t = twin_of(forward.id))
+            return t;
+        _twins.push_back(twin{forward.id, convertModel(forward)});
+        return &_twins.back();
+    }
+    void observe(size_t model_id) // trackRadialObservation (:1368-1379) of a block on the shared model
+    {
+        if (_shared_model == (size_t)-1)
+        {
+            _shared_model = model_id;
+            _mono_focal = twin_of(model_id)->m.focal_length_pixels;
+        }
+        else if (_shared_model != model_id)
+            _several_models = true;
+        _mono_count++;
+    }
+    static bool same_model(const CameraModel &a, const CameraModel &b) // CameraModel::operator== (camera_model.hpp:78-81)
+    {
+        return a.id == b.id && a.pixels_rows == b.pixels_rows && a.pixels_cols == b.pixels_cols &&
+               a.focal_length_pixels == b.focal_length_pixels && a.principle_point[0] == b.principle_point[0] &&
+               a.principle_point[1] == b.principle_point[1] && a.radial_distortion[0] == b.radial_distortion[0] &&
+               a.radial_distortion[1] == b.radial_distortion[1] && a.radial_distortion[2] == b.radial_distortion[2] &&
+               a.tangential_distortion[0] == b.tangential_distortion[0] && a.tangential_distortion[1] == b.tangential_distortion[1];
+    }
     struct cloud_track
     {
         v3 points[5]; // the first five finite points (robustCentroid looks at no more)
@@ -1028,7 +1122,9 @@ class GroundMeshProblem
         {
             view v;
             uint32_t cam;
+            size_t model_id;
             v3 loc, ray;
+            double px[2];
             const double *rot;
         };
         std::vector<ray_info> tr;
@@ -1049,6 +1145,9 @@ class GroundMeshProblem
                 double ray[3];
                 image_to_3d(node.payload.features[r.v.feature].location, *node.payload.model, ray);
                 r.ray = v3{ray[0], ray[1], ray[2]};
+                r.model_id = node.payload.model->id;
+                r.px[0] = node.payload.features[r.v.feature].location[0];
+                r.px[1] = node.payload.features[r.v.feature].location[1];
                 r.rot = np.orientation;
                 tr.push_back(r);
                 mean = add(mean, r.loc);
@@ -1111,7 +1210,17 @@ class GroundMeshProblem
                     good.push_back(&tr[es.second]);
             if (good.size() < 3)
                 continue;
+            bool one_model = true;
+            for (const ray_info *r : good)
+                one_model &= r->model_id == good[0]->model_id;
+            const bool focal_radial = one_model && _intrinsics;
+            if (focal_radial)
+            {
+                twin_for(*gnodes[good[0]->v.node].payload.model);
+                observe(good[0]->model_id);
+            }
             _blk_n.push_back((uint8_t)good.size());
+            _blk_intr.push_back(focal_radial ? 1 : 0);
             _blk_ray_off.push_back((uint32_t)(_ray_cam.size() + good.size()));
             for (const ray_info *r : good)
             {
@@ -1119,6 +1228,8 @@ class GroundMeshProblem
                 _ray_dir.push_back(r->ray.x);
                 _ray_dir.push_back(r->ray.y);
                 _ray_dir.push_back(r->ray.z);
+                _ray_px.push_back(r->px[0]);
+                _ray_px.push_back(r->px[1]);
                 _track_measurement[r->v.node].emplace(r->v.feature, 1);
                 _covered[r->v.node].emplace(cell_of(r->v), 1);
             }
@@ -1172,6 +1283,10 @@ class GroundMeshProblem
             out.cams.push_back(d.cam);
             out.rays.insert(out.rays.end(), r1, r1 + 3);
             out.rays.insert(out.rays.end(), r2, r2 + 3);
+            out.px.insert(out.px.end(), m.pixel_1, m.pixel_1 + 2);
+            out.px.insert(out.px.end(), m.pixel_2, m.pixel_2 + 2);
+            if (_intrinsics && same_model(sm, dm))
+                out.intr_model = sm.id;
             for (int i = 0; i < 3; i++)
                 out.tri.push_back((uint32_t)walker.tri[i]);
         }
@@ -1184,7 +1299,13 @@ class GroundMeshProblem
     std::unordered_map<size_t, size_t> _opt_index;
     std::unordered_map<size_t, uint32_t> _cam_of_node;
     std::vector<uint32_t> _pose_cam; // per pose: its camera, or UINT32_MAX for a repeated node
-    std::vector<double> _cam_pos, _cam_q, _ray_dir;
+    std::vector<double> _cam_pos, _cam_q, _ray_dir, _ray_px;
+    std::vector<uint8_t> _blk_intr;
+    std::vector<twin> _twins;
+    uint32_t _options = 0;
+    bool _intrinsics = false, _several_models = false;
+    size_t _shared_model = (size_t)-1, _mono_count = 0;
+    double _mono_focal = 1;
     std::vector<uint8_t> _cam_opt, _blk_n;
     std::vector<uint32_t> _blk_ray_off{0}, _ray_cam, _blk_tri;
     std::vector<std::unordered_map<uint64_t, char>> _track_measurement, _covered; // per node index: features / cells in track blocks

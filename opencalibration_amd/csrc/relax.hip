@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, do
 
 // step = -y with (As + D) y = gs; delta = S step; candidate state = x (+) delta; step_norm^2 in ambient space.
 // One workgroup.  scal: [2] step_norm^2, [3] x_norm^2 (candidate)
-__global__ __launch_bounds__(1024) void plane_candidate_kernel(relax_dev P, const double *scale, const double *y, double *scal)
+__global__ __launch_bounds__(1024) void plane_candidate_kernel(relax_dev P, const double *scale, const double *y, double alpha, double *scal)
 {
     __shared__ double sh[1024];
     const int t = threadIdx.x;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(1024) void plane_candidate_kernel(relax_dev P, cons
         }
         double d[3];
         for (int k = 0; k < 3; k++)
-            d[k] = -y[tc + k] * scale[tc + k];
+            d[k] = alpha * (-y[tc + k] * scale[tc + k]);
         const double nrm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         if (nrm == 0.0)
         {
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(1024) void plane_candidate_kernel(relax_dev P, cons
     {
         const int tz = P.z_t[t];
         const double z0 = P.plane[6 + t];
-        const double z1 = tz >= 0 ? z0 + (-y[tz] * scale[tz]) : z0;
+        const double z1 = tz >= 0 ? z0 + alpha * (-y[tz] * scale[tz]) : z0;
         P.plane[9 + t] = z1;
         if (tz >= 0)
         {
@@ -1065,9 +1065,9 @@ struct plane_model final : lm_model
             hfail |= f;
         return hfail ? 1 : 0;
     }
-    void launch_candidate(const double *y, const double *scale, double *scal) override
+    void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override
     {
-        hipLaunchKernelGGL(plane_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, scal);
+        hipLaunchKernelGGL(plane_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, alpha, scal);
     }
     void launch_accept() override
     {

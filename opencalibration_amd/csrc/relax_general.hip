@@ -249,7 +249,7 @@ template <int N, bool INTR> __global__ __launch_bounds__(W) void ray_cost_kernel
 }
 
 // records of every block of one type at the current state: (block, pass) lanes
-template <int N, bool INTR> __global__ __launch_bounds__(W) void ray_record_kernel(g_dev P, uint32_t first, uint32_t count)
+template <int N, bool INTR> __global__ __launch_bounds__(W) void ray_record_kernel(g_dev P, uint32_t first, uint32_t count, int which)
 {
     constexpr int PASSES = N + 1 + (INTR ? 2 : 0);
     constexpr int G = W / PASSES; // blocks per wavefront
@@ -272,7 +272,7 @@ template <int N, bool INTR> __global__ __launch_bounds__(W) void ray_record_kern
     if (active)
     {
         Dual<3> rd[R];
-        if (!ray_block_residuals<Dual<3>, N, INTR>(P, blk, 0, pass, rd))
+        if (!ray_block_residuals<Dual<3>, N, INTR>(P, blk, which, pass, rd))
             failed = true;
         double s = 0;
         for (int k = 0; k < R; k++)
@@ -592,7 +592,7 @@ __global__ void tail_merge_kernel(g_dev P, const uint32_t *tail_var, const uint3
 
 // ---- state -------------------------------------------------------------------------------------------------------
 // candidate = x (+) delta, delta = -y .* scale.  One workgroup.  scal[2] = |x - candidate|^2, scal[3] = |candidate|^2
-__global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const double *scale, const double *y, double *scal)
+__global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const double *scale, const double *y, double alpha, double *scal)
 {
     __shared__ double sh[1024];
     const int t = threadIdx.x;
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const 
         }
         double d[3];
         for (int k = 0; k < 3; k++)
-            d[k] = -y[tc + k] * scale[tc + k];
+            d[k] = alpha * (-y[tc + k] * scale[tc + k]);
         const double nrm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         if (nrm == 0.0)
         {
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const 
     {
         const int tz = P.var_t[P.n_cams + v];
         const double z0 = P.vert_z[v];
-        const double z1 = tz >= 0 ? z0 + (-y[tz] * scale[tz]) : z0;
+        const double z1 = tz >= 0 ? z0 + alpha * (-y[tz] * scale[tz]) : z0;
         P.vert_z2[v] = z1;
         if (tz >= 0)
         {
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const 
         const int tf = P.var_t[vf], tp = P.var_t[vf + 1], tk = P.var_t[vf + 2];
         if (tf >= 0)
         {
-            double f = P.model[0] + (-y[tf] * scale[tf]);
+            double f = P.model[0] + alpha * (-y[tf] * scale[tf]);
             f = fmin(fmax(f, P.f_lo), P.f_hi);
             P.model2[0] = f;
             sn += (P.model[0] - f) * (P.model[0] - f);
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const 
         if (tp >= 0)
             for (int k = 0; k < 2; k++)
             {
-                const double v = P.model[1 + k] + (-y[tp + k] * scale[tp + k]);
+                const double v = P.model[1 + k] + alpha * (-y[tp + k] * scale[tp + k]);
                 P.model2[1 + k] = v;
                 sn += (P.model[1 + k] - v) * (P.model[1 + k] - v);
                 xn += v * v;
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const 
         if (tk >= 0)
             for (int k = 0; k < 3; k++) // SubsetManifold: the trailing coefficients stay, but count in |x|
             {
-                const double v = k < P.n_k_free ? P.model[3 + k] + (-y[tk + k] * scale[tk + k]) : P.model[3 + k];
+                const double v = k < P.n_k_free ? P.model[3 + k] + alpha * (-y[tk + k] * scale[tk + k]) : P.model[3 + k];
                 P.model2[3 + k] = v;
                 sn += (P.model[3 + k] - v) * (P.model[3 + k] - v);
                 xn += v * v;
@@ -982,7 +982,7 @@ template <int N, bool INTR> void launch_ray(const g_dev &D, hipStream_t st, uint
     if (with_jac)
     {
         constexpr int G = W / (N + 1 + (INTR ? 2 : 0));
-        hipLaunchKernelGGL((ray_record_kernel<N, INTR>), dim3((count + G - 1) / G), dim3(W), 0, st, D, first, count);
+        hipLaunchKernelGGL((ray_record_kernel<N, INTR>), dim3((count + G - 1) / G), dim3(W), 0, st, D, first, count, which);
     }
     else
         hipLaunchKernelGGL((ray_cost_kernel<N, INTR>), dim3((count + W - 1) / W), dim3(W), 0, st, D, first, count, which);
@@ -1049,9 +1049,9 @@ struct general_model final : lm_model
         *cost = h0;
         return hfail ? 1 : 0;
     }
-    void launch_candidate(const double *y, const double *scale, double *scal) override
+    void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override
     {
-        hipLaunchKernelGGL(general_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, scal);
+        hipLaunchKernelGGL(general_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, alpha, scal);
     }
     void launch_accept() override
     {

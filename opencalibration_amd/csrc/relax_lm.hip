@@ -368,6 +368,147 @@ __global__ __launch_bounds__(1024) void lm_diag_kernel(const double *A, const do
         scal[4] = sh[0];
 }
 
+
+// ---- the projected line search of a bounds-constrained problem (what ceres::TrustRegionMinimizer::DoLineSearch does with
+// an Armijo search and cubic interpolation; Ceres [3P] is not in the reference tree, this follows its documented
+// behaviour): samples (step, cost, directional derivative), the polynomial through them, its minimiser on an interval.
+struct ls_sample
+{
+    double x = 0, value = 0, slope = 0;
+    bool valid = false;
+};
+double poly_at(const std::vector<double> &p, double x)
+{
+    double v = 0;
+    for (double c : p)
+        v = v * x + c;
+    return v;
+}
+// polynomial (highest power first) through the samples' values and slopes: a small dense solve with full pivoting
+std::vector<double> poly_through(const std::vector<ls_sample> &samples)
+{
+    const int m = 2 * (int)samples.size(), deg = m - 1;
+    std::vector<double> A((size_t)m * m, 0.0), b(m, 0.0);
+    int r = 0;
+    for (const ls_sample &s : samples)
+    {
+        for (int j = 0; j <= deg; j++)
+            A[(size_t)r * m + j] = std::pow(s.x, deg - j);
+        b[r++] = s.value;
+        for (int j = 0; j < deg; j++)
+            A[(size_t)r * m + j] = (deg - j) * std::pow(s.x, deg - j - 1);
+        b[r++] = s.slope;
+    }
+    std::vector<int> perm(m);
+    for (int i = 0; i < m; i++)
+        perm[i] = i;
+    for (int k = 0; k < m; k++)
+    {
+        int pr = k, pc = k;
+        double best = -1;
+        for (int c = k; c < m; c++)
+            for (int rr = k; rr < m; rr++)
+                if (std::abs(A[(size_t)rr * m + c]) > best)
+                {
+                    best = std::abs(A[(size_t)rr * m + c]);
+                    pr = rr;
+                    pc = c;
+                }
+        if (!(best > 0))
+            break;
+        for (int c = 0; c < m; c++)
+            std::swap(A[(size_t)k * m + c], A[(size_t)pr * m + c]);
+        std::swap(b[k], b[pr]);
+        for (int rr = 0; rr < m; rr++)
+            std::swap(A[(size_t)rr * m + k], A[(size_t)rr * m + pc]);
+        std::swap(perm[k], perm[pc]);
+        for (int rr = k + 1; rr < m; rr++)
+        {
+            const double f = A[(size_t)rr * m + k] / A[(size_t)k * m + k];
+            for (int c = k; c < m; c++)
+                A[(size_t)rr * m + c] -= f * A[(size_t)k * m + c];
+            b[rr] -= f * b[k];
+        }
+    }
+    std::vector<double> y(m, 0.0), out(m, 0.0);
+    for (int k = m - 1; k >= 0; k--)
+    {
+        double v = b[k];
+        for (int c = k + 1; c < m; c++)
+            v -= A[(size_t)k * m + c] * y[c];
+        y[k] = A[(size_t)k * m + k] != 0 ? v / A[(size_t)k * m + k] : 0.0;
+    }
+    for (int k = 0; k < m; k++)
+        out[perm[k]] = y[k];
+    return out;
+}
+// candidates for the minimiser: the real parts of the roots of the derivative (closed form for a quadratic, a Newton
+// polish of a dense scan above that: the derivative of the quintic through three samples is a quartic)
+void derivative_root_candidates(const std::vector<double> &poly, double lo, double hi, std::vector<double> &out)
+{
+    std::vector<double> d;
+    const int deg = (int)poly.size() - 1;
+    for (int i = 0; i < deg; i++)
+        d.push_back((deg - i) * poly[i]);
+    while (!d.empty() && d.front() == 0.0)
+        d.erase(d.begin());
+    if (d.size() == 2)
+        out.push_back(-d[1] / d[0]);
+    else if (d.size() == 3)
+    {
+        const double a = d[0], b = d[1], c = d[2], D = b * b - 4 * a * c, sq = std::sqrt(std::abs(D));
+        if (D >= 0)
+        {
+            out.push_back(b >= 0 ? (-b - sq) / (2 * a) : (2 * c) / (-b + sq));
+            out.push_back(b >= 0 ? (2 * c) / (-b - sq) : (-b + sq) / (2 * a));
+        }
+        else
+            out.push_back(-b / (2 * a));
+    }
+    else if (d.size() > 3)
+    {
+        const int N = 4096;
+        double prev = poly_at(d, lo);
+        for (int i = 1; i <= N; i++)
+        {
+            const double x = lo + (hi - lo) * i / N, v = poly_at(d, x);
+            if ((prev <= 0 && v >= 0) || (prev >= 0 && v <= 0))
+            {
+                double a = lo + (hi - lo) * (i - 1) / N, b2 = x;
+                for (int it = 0; it < 80; it++)
+                {
+                    const double mid = 0.5 * (a + b2), vm = poly_at(d, mid);
+                    if ((poly_at(d, a) <= 0) == (vm <= 0))
+                        a = mid;
+                    else
+                        b2 = mid;
+                }
+                out.push_back(0.5 * (a + b2));
+            }
+            prev = v;
+        }
+    }
+}
+double interpolated_step(const ls_sample &at0, const ls_sample &previous, const ls_sample &current, double lo, double hi)
+{
+    if (!current.valid)
+        return std::min(std::max(current.x * 0.5, lo), hi);
+    std::vector<ls_sample> samples{at0, current};
+    if (previous.valid)
+        samples.push_back(previous);
+    const std::vector<double> poly = poly_through(samples);
+    double best_x = 0.5 * (lo + hi), best = poly_at(poly, best_x);
+    std::vector<double> cand{lo, hi};
+    derivative_root_candidates(poly, lo, hi, cand);
+    for (double x : cand)
+        if (x >= lo && x <= hi && poly_at(poly, x) < best)
+        {
+            best = poly_at(poly, x);
+            best_x = x;
+        }
+    return best_x;
+}
+
 } // namespace
 
 namespace ochip
@@ -513,7 +654,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, st, (const double *)S.Wm, n, (const double *)S.linv, S.y,
                            (const int *)S.first_col_dev, (n + NB - 1) / NB);
         hipLaunchKernelGGL(lm_model_change_kernel, dim3(1), dim3(1024), 0, st, S.lm_diag, S.gs, S.y, n, S.scal);
-        M.launch_candidate(S.y, S.scale, S.scal);
+        M.launch_candidate(S.y, S.scale, 1.0, S.scal);
         ochip_prof_end(ctx, OCHIP_K_RELAX_SOLVE, e0, e1);
         OCHIP_HIP(ctx, hipGetLastError());
         int cfail = 0;
@@ -521,12 +662,12 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         OCHIP_HIP(ctx, hipMemcpyAsync(&cfail, S.fail_chol, 4, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         reuse_diagonal = true;
-        const double model_cost_change = h[1], step_norm = std::sqrt(h[2]), cand_norm = std::sqrt(h[3]);
+        const double model_cost_change = h[1];
         const bool valid = !cfail && std::isfinite(model_cost_change) && model_cost_change > 0.0;
         static const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
         if (verbose)
             fprintf(stderr, "[ochip relax] n=%d iter=%d cost=%.17g radius=%.6g model=%.17g step_norm=%.6g cfail=%d gmax=%.6g\n",
-                    n, iter, x_cost, radius, model_cost_change, step_norm, cfail, gmax);
+                    n, iter, x_cost, radius, model_cost_change, std::sqrt(h[2]), cfail, gmax);
         if (!valid)
         {
             if (++invalid >= 5)
@@ -543,6 +684,90 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                 return erc;
             if (erc == 0)
                 cand_cost = c;
+        }
+        double step_norm = std::sqrt(h[2]), cand_norm = std::sqrt(h[3]);
+        if (M.is_constrained())
+        {
+            // Projected line search along the step (bounds on the focal length): Armijo with sufficient decrease 1e-4; the
+            // full step is the first trial and almost always passes, in which case nothing changes.  Otherwise the step is
+            // contracted within [1e-3, 0.6] of the last trial, at most 20 trials, by the minimiser of the polynomial
+            // through the trials' costs and directional derivatives (a Jacobian evaluation at every trial).
+            std::vector<double> gh(n), yh(n);
+            OCHIP_HIP(ctx, hipMemcpy(gh.data(), S.g, (size_t)n * 8, hipMemcpyDeviceToHost));
+            OCHIP_HIP(ctx, hipMemcpy(yh.data(), S.y, (size_t)n * 8, hipMemcpyDeviceToHost));
+            double gdd = 0, dmax = 0;
+            for (int i = 0; i < n; i++)
+            {
+                const double d = -yh[i] * scale[i];
+                gdd += gh[i] * d;
+                dmax = std::max(dmax, std::abs(d));
+            }
+            ls_sample at0, previous, current;
+            at0.x = 0, at0.value = x_cost, at0.slope = gdd, at0.valid = true;
+            current.x = 1.0, current.value = cand_cost, current.valid = cand_cost < 1e308;
+            bool contracted = false, ok = true;
+            int trials = 0;
+            while (!current.valid || current.value > x_cost + 1e-4 * gdd * current.x)
+            {
+                if (++trials >= 20)
+                {
+                    ok = false;
+                    break;
+                }
+                if (current.valid && !contracted) // the slope at the full step is needed from here on
+                {
+                    double c2;
+                    erc = M.evaluate(true, 1, &c2);
+                    if (erc < 0)
+                        return erc;
+                    std::vector<double> g1(n);
+                    OCHIP_HIP(ctx, hipMemcpy(g1.data(), S.g, (size_t)n * 8, hipMemcpyDeviceToHost));
+                    current.slope = 0;
+                    for (int i = 0; i < n; i++)
+                        current.slope += g1[i] * (-yh[i] * scale[i]);
+                    current.valid = erc == 0 && std::isfinite(current.slope);
+                }
+                contracted = true;
+                const double next = interpolated_step(at0, previous, current, 1e-3 * current.x, 0.6 * current.x);
+                if (next * dmax < 1e-9)
+                {
+                    ok = false;
+                    break;
+                }
+                previous = current;
+                M.launch_candidate(S.y, S.scale, next, S.scal);
+                double c2;
+                erc = M.evaluate(true, 1, &c2);
+                if (erc < 0)
+                    return erc;
+                std::vector<double> g1(n);
+                OCHIP_HIP(ctx, hipMemcpy(g1.data(), S.g, (size_t)n * 8, hipMemcpyDeviceToHost));
+                current.x = next;
+                current.value = c2;
+                current.slope = 0;
+                for (int i = 0; i < n; i++)
+                    current.slope += g1[i] * (-yh[i] * scale[i]);
+                current.valid = erc == 0 && std::isfinite(c2) && std::isfinite(current.slope);
+            }
+            if (contracted)
+            {
+                const double alpha = ok ? current.x : 1.0;
+                M.launch_candidate(S.y, S.scale, alpha, S.scal);
+                double c2;
+                erc = M.evaluate(false, 1, &c2);
+                if (erc < 0)
+                    return erc;
+                cand_cost = erc == 0 ? c2 : 1.7976931348623157e308;
+                OCHIP_HIP(ctx, hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st));
+                OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+                step_norm = std::sqrt(h[2]);
+                cand_norm = std::sqrt(h[3]);
+                // the trials overwrote J'J and J'r of the current point: restore them
+                double c0;
+                erc = M.evaluate(true, 0, &c0);
+                if (erc < 0)
+                    return erc;
+            }
         }
         if (step_norm <= opt->parameter_tolerance * (x_norm + opt->parameter_tolerance))
             return finish(OCHIP_RELAX_CONVERGENCE_PARAMETER);

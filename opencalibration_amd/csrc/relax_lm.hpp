@@ -52,9 +52,10 @@ struct lm_model
     // included) and sys.g.  *cost = total cost.  Returns 0, 1 for a numeric failure (non-finite residual or derivative:
     // Ceres' "evaluation failed"), or a negative OCHIP_E* code for a hard error (HIP call, exchange) which ends the solve.
     virtual int evaluate(bool with_jac, int which, double *cost) = 0;
-    // enqueue: candidate = x (+) delta with delta[i] = -y[i] * scale[i]; scal[2] = |x - candidate|^2 (ambient),
-    // scal[3] = |candidate|^2 over the variable parameter blocks
-    virtual void launch_candidate(const double *y, const double *scale, double *scal) = 0;
+    // enqueue: candidate = x (+) delta with delta[i] = alpha * (-y[i] * scale[i]); scal[2] = |x - candidate|^2 (ambient),
+    // scal[3] = |candidate|^2 over the variable parameter blocks.  alpha = 1 except inside the projected line search of a
+    // bounds-constrained problem.
+    virtual void launch_candidate(const double *y, const double *scale, double alpha, double *scal) = 0;
     virtual void launch_accept() = 0;    // current = candidate
     virtual void launch_normalize() = 0; // what RelaxProblem::solve does to the state after Solve (:1410-1413)
     virtual int x_norm(double *out) = 0; // |x| over the variable parameter blocks of the current state

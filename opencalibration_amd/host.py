@@ -108,7 +108,7 @@ def load():
         L.och_rebuild_mesh.argtypes = [_f64p, sz, vp, C.c_int, vp]
         L.och_rebuild_mesh.restype = None
         L.och_relax.argtypes = [vp, sz, _f64p, _f64p, _f64p, _u64p, _f64p, sz, _u64p, _f64p, sz, _u64p, _u64p, vp, u8p, _u64p,
-                                _f64p, _u64p, _u64p, vp, vp, sz, _u64p, u32, C.c_double, vp, vp, _f64p]
+                                _f64p, _u64p, _u64p, vp, vp, sz, _u64p, u32, C.c_double, vp, vp, _f64p, vp]
         L.och_graph_relax.argtypes = [vp, vp, _f64p, u32, C.c_double, vp, vp, _f64p]
         i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
         L.och_relax_stage_run.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, u32, C.c_double, sz, vp, vp, i64p, _f64p]
@@ -211,7 +211,7 @@ def rebuild_mesh(cam_xyz, previous=None, minimal=False):
 
 
 def relax(ctx, node_pos, node_ori, model10, features, pose_node, pose_ori, packed_edges, options, grid_fraction=0.1,
-          opt_edges=None, previous=None):
+          opt_edges=None, previous=None, cam_model=None):
     """relax(graph, nodes, cam_models, edges, config, previousSurfaces) on the device, any flavour.  features: per node
     an (k x 2) array of feature locations; packed_edges as for relax_ground_plane plus 'feat' (inliers x 2 feature
     indices)."""
@@ -228,15 +228,17 @@ def relax(ctx, node_pos, node_ori, model10, features, pose_node, pose_ori, packe
     opt = np.ascontiguousarray(np.arange(n_edges) if opt_edges is None else opt_edges, np.uint64)
     summary = np.zeros(12)
     out_surface = Surface()
+    cm = np.ascontiguousarray(model10 if cam_model is None else cam_model, np.float64).copy()
     rc = L.och_relax(ctx.h, len(node_pos), node_pos, node_ori, np.ascontiguousarray(model10, np.float64), feat_off, feat_xy,
                      len(pose_node), pose_node, pose_ori, n_edges, pk["src"], pk["dst"], pk["H"].ctypes.data, pk["is_h"],
                      pk["inl_off"], pk["px"], np.ascontiguousarray(pk["feat"], np.uint64), pk["match_index"],
                      pk["dist_off"].ctypes.data, pk["dist"].ctypes.data, len(opt), opt if len(opt) else np.zeros(1, np.uint64),
-                     options, grid_fraction, previous.h if previous is not None else None, out_surface.h, summary)
+                     options, grid_fraction, previous.h if previous is not None else None, out_surface.h, summary,
+                     cm.ctypes.data)
     if rc != 0:
         raise capi.OchipError("relax failed: " + L.och_relax_last_error().decode())
     out = dict(zip(RELAX_SUMMARY12, summary.tolist()))
-    out.update(orientation=pose_ori, surface=out_surface)
+    out.update(orientation=pose_ori, surface=out_surface, cam_model=cm)
     for k in ("solves", "iterations_total", "last_iterations", "residual_blocks", "track_blocks", "two_ray_blocks",
               "mesh_vertices", "unknowns"):
         out[k] = int(out[k])

@@ -494,6 +494,13 @@ class RxGraph:
         self.n_edges += 1
         return e
 
+    def persist_cam_models(self, on=True):
+        """Keep the cam_models map of relax() across calls (the graph's own models stay untouched), as a caller of the
+        reference's relax() does when it passes the same map again."""
+        L = _rx()
+        L.ocx_graph_persist_cam_models.argtypes = [C.c_void_p, C.c_int]
+        L.ocx_graph_persist_cam_models(self.h, int(on))
+
     def set_orientation(self, node, q):
         _rx().ocx_graph_set_orientation(self.h, node, np.ascontiguousarray(q, np.float64))
 

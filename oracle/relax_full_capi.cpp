@@ -12,6 +12,10 @@ struct graph_handle
 {
     MeasurementGraph graph;
     std::vector<std::shared_ptr<CameraModel>> models;
+    // the caller's cam_models map kept across relax() calls (test/test_relax.cpp:436-463 relaxes ten times with the same
+    // map, which every call updates while the graph's own models stay as they are)
+    bool persist_cam_models = false;
+    model_map cam_models;
 };
 CameraModel model_from10(const double *m, size_t id)
 {
@@ -276,7 +280,14 @@ int ocx_relax(void *h, size_t n_poses, const uint64_t *pose_node, double *pose_o
         for (auto &m : cam_models)
             found |= m.first == n.model->id;
         if (!found)
-            cam_models.emplace_back(n.model->id, *n.model);
+        {
+            const CameraModel *kept = nullptr;
+            if (g->persist_cam_models)
+                for (auto &m : g->cam_models)
+                    if (m.first == n.model->id)
+                        kept = &m.second;
+            cam_models.emplace_back(n.model->id, kept ? *kept : *n.model);
+        }
     }
     std::vector<size_t> opt(opt_edges, opt_edges + n_opt_edges);
     RelaxConfig cfg;
@@ -294,6 +305,8 @@ int ocx_relax(void *h, size_t n_poses, const uint64_t *pose_node, double *pose_o
     }
     if (out_surface)
         *(surface_model *)out_surface = std::move(s);
+    if (g->persist_cam_models)
+        g->cam_models = cam_models;
     stats_out(st, summary_out, iters_out, iters_cap);
     if (models_out)
         for (size_t i = 0; i < cam_models.size() && i < models_cap; i++)
@@ -363,6 +376,14 @@ size_t ocx_relax_stage_groups(void *h, size_t n_ids, const uint64_t *node_ids, i
     if (depth_out)
         *depth_out = depth;
     return groups.size();
+}
+
+void ocx_graph_persist_cam_models(void *h, int on)
+{
+    auto *g = (graph_handle *)h;
+    g->persist_cam_models = on != 0;
+    if (!on)
+        g->cam_models.clear();
 }
 
 // forward <-> inverse lens model fits (invert_distortion.cpp:105-191)

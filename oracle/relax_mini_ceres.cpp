@@ -325,6 +325,216 @@ bool cholesky_solve(std::vector<double> &A, std::vector<double> &b, int n)
     return true;
 }
 
+
+// ---- ceres/polynomial.cc restated [3P]: interpolating polynomial through samples (value and, where known, gradient),
+// its minimum on an interval.  Coefficients highest power first.
+struct FunctionSample
+{
+    double x = 0, value = 0, gradient = 0;
+    bool value_is_valid = false, gradient_is_valid = false;
+};
+double eval_poly(const std::vector<double> &p, double x)
+{
+    double v = 0;
+    for (double c : p)
+        v = v * x + c;
+    return v;
+}
+std::vector<double> find_interpolating_polynomial(const std::vector<FunctionSample> &samples)
+{
+    int num_constraints = 0;
+    for (const auto &s : samples)
+        num_constraints += (s.value_is_valid ? 1 : 0) + (s.gradient_is_valid ? 1 : 0);
+    const int degree = num_constraints - 1;
+    const int m = num_constraints;
+    std::vector<double> lhs((size_t)m * m, 0.0), rhs(m, 0.0);
+    int row = 0;
+    for (const auto &s : samples)
+    {
+        if (s.value_is_valid)
+        {
+            for (int j = 0; j <= degree; ++j)
+                lhs[(size_t)row * m + j] = std::pow(s.x, degree - j);
+            rhs[row++] = s.value;
+        }
+        if (s.gradient_is_valid)
+        {
+            for (int j = 0; j < degree; ++j)
+                lhs[(size_t)row * m + j] = (degree - j) * std::pow(s.x, degree - j - 1);
+            rhs[row++] = s.gradient;
+        }
+    }
+    // lhs.fullPivLu().solve(rhs)
+    std::vector<int> colperm(m);
+    for (int i = 0; i < m; i++)
+        colperm[i] = i;
+    for (int k = 0; k < m; k++)
+    {
+        int pr = k, pc = k;
+        double best = -1;
+        for (int c = k; c < m; c++)
+            for (int r = k; r < m; r++)
+                if (std::abs(lhs[(size_t)r * m + c]) > best)
+                {
+                    best = std::abs(lhs[(size_t)r * m + c]);
+                    pr = r;
+                    pc = c;
+                }
+        if (best <= 0)
+            break;
+        for (int c = 0; c < m; c++)
+            std::swap(lhs[(size_t)k * m + c], lhs[(size_t)pr * m + c]);
+        std::swap(rhs[k], rhs[pr]);
+        for (int r = 0; r < m; r++)
+            std::swap(lhs[(size_t)r * m + k], lhs[(size_t)r * m + pc]);
+        std::swap(colperm[k], colperm[pc]);
+        for (int r = k + 1; r < m; r++)
+        {
+            const double f = lhs[(size_t)r * m + k] / lhs[(size_t)k * m + k];
+            for (int c = k; c < m; c++)
+                lhs[(size_t)r * m + c] -= f * lhs[(size_t)k * m + c];
+            rhs[r] -= f * rhs[k];
+        }
+    }
+    std::vector<double> y(m, 0.0), out(m, 0.0);
+    for (int k = m - 1; k >= 0; k--)
+    {
+        double v = rhs[k];
+        for (int c = k + 1; c < m; c++)
+            v -= lhs[(size_t)k * m + c] * y[c];
+        y[k] = lhs[(size_t)k * m + k] != 0 ? v / lhs[(size_t)k * m + k] : 0.0;
+    }
+    for (int k = 0; k < m; k++)
+        out[colperm[k]] = y[k];
+    return out;
+}
+// real parts of the roots of a polynomial (FindPolynomialRoots with a null imaginary output): closed forms up to degree
+// 2 as in polynomial.cc, Durand-Kerner above (polynomial.cc takes the eigenvalues of the companion matrix)
+std::vector<double> polynomial_root_real_parts(std::vector<double> p)
+{
+    while (!p.empty() && p.front() == 0.0)
+        p.erase(p.begin());
+    const int degree = (int)p.size() - 1;
+    std::vector<double> out;
+    if (degree <= 0)
+        return out;
+    if (degree == 1)
+    {
+        out.push_back(-p[1] / p[0]);
+        return out;
+    }
+    if (degree == 2)
+    {
+        const double a = p[0], b = p[1], c = p[2];
+        const double D = b * b - 4 * a * c, sqrt_D = std::sqrt(std::abs(D));
+        if (D >= 0)
+        {
+            if (b >= 0)
+            {
+                out.push_back((-b - sqrt_D) / (2.0 * a));
+                out.push_back((2.0 * c) / (-b - sqrt_D));
+            }
+            else
+            {
+                out.push_back((2.0 * c) / (-b + sqrt_D));
+                out.push_back((-b + sqrt_D) / (2.0 * a));
+            }
+        }
+        else
+        {
+            out.push_back(-b / (2.0 * a));
+            out.push_back(-b / (2.0 * a));
+        }
+        return out;
+    }
+    std::vector<std::pair<double, double>> z(degree); // complex roots (re, im)
+    for (int i = 0; i < degree; i++)
+    {
+        const double ang = 2.0 * M_PI * i / degree + 0.4, rad = 1.0 + std::abs(p.back() / p[0]);
+        z[i] = {rad * std::cos(ang), rad * std::sin(ang)};
+    }
+    auto cmul = [](std::pair<double, double> a, std::pair<double, double> b) {
+        return std::make_pair(a.first * b.first - a.second * b.second, a.first * b.second + a.second * b.first);
+    };
+    auto cdiv = [](std::pair<double, double> a, std::pair<double, double> b) {
+        const double d = b.first * b.first + b.second * b.second;
+        return std::make_pair((a.first * b.first + a.second * b.second) / d, (a.second * b.first - a.first * b.second) / d);
+    };
+    for (int it = 0; it < 500; it++)
+    {
+        double change = 0;
+        for (int i = 0; i < degree; i++)
+        {
+            std::pair<double, double> v{p[0], 0.0};
+            for (int k = 1; k <= degree; k++)
+            {
+                v = cmul(v, z[i]);
+                v.first += p[k];
+            }
+            std::pair<double, double> den{p[0], 0.0};
+            for (int j = 0; j < degree; j++)
+                if (j != i)
+                    den = cmul(den, {z[i].first - z[j].first, z[i].second - z[j].second});
+            const auto d = cdiv(v, den);
+            z[i].first -= d.first;
+            z[i].second -= d.second;
+            change = std::max(change, std::abs(d.first) + std::abs(d.second));
+        }
+        if (change < 1e-15)
+            break;
+    }
+    for (const auto &r : z)
+        out.push_back(r.first);
+    return out;
+}
+void minimize_polynomial(const std::vector<double> &poly, double x_min, double x_max, double *optimal_x, double *optimal_value)
+{
+    *optimal_x = (x_min + x_max) / 2.0;
+    *optimal_value = eval_poly(poly, *optimal_x);
+    const double vmin = eval_poly(poly, x_min);
+    if (vmin < *optimal_value)
+    {
+        *optimal_value = vmin;
+        *optimal_x = x_min;
+    }
+    const double vmax = eval_poly(poly, x_max);
+    if (vmax < *optimal_value)
+    {
+        *optimal_value = vmax;
+        *optimal_x = x_max;
+    }
+    if (poly.size() <= 2)
+        return;
+    std::vector<double> deriv;
+    const int degree = (int)poly.size() - 1;
+    for (int i = 0; i < degree; i++)
+        deriv.push_back((degree - i) * poly[i]);
+    for (double root : polynomial_root_real_parts(deriv))
+    {
+        if (root < x_min || root > x_max)
+            continue;
+        const double v = eval_poly(poly, root);
+        if (v < *optimal_value)
+        {
+            *optimal_value = v;
+            *optimal_x = root;
+        }
+    }
+}
+// LineSearch::InterpolatingPolynomialMinimizingStepSize (ceres/line_search.cc), CUBIC interpolation
+double interpolating_step(const FunctionSample &lowerbound, const FunctionSample &previous, const FunctionSample &current,
+                          double min_step_size, double max_step_size)
+{
+    if (!current.value_is_valid || std::max(min_step_size, max_step_size) <= 0) // bisection when the value is not usable
+        return std::min(std::max(current.x * 0.5, min_step_size), max_step_size);
+    std::vector<FunctionSample> samples{lowerbound, current};
+    if (previous.value_is_valid)
+        samples.push_back(previous);
+    double step = 0, unused = 0;
+    minimize_polynomial(find_interpolating_polynomial(samples), min_step_size, max_step_size, &step, &unused);
+    return step;
+}
+
 } // namespace
 
 void Solve(const SolverOptions &opt, Problem *problem, SolverSummary *summary)
@@ -492,7 +702,20 @@ void Solve(const SolverOptions &opt, Problem *problem, SolverSummary *summary)
     it0.iteration = 0;
     it0.step_is_valid = it0.step_is_successful = true;
     it0.cost = x_cost + prog.fixed_cost;
-    it0.gradient_max_norm = max_abs(g);
+    auto gradient_max_norm = [&](const std::vector<double> &state, const std::vector<double> &grad) {
+        if (!is_constrained)
+            return max_abs(grad);
+        // |x - Plus(x, -gradient)| (ambient, projected onto the bounds): TrustRegionMinimizer::EvaluateGradientAndJacobian
+        std::vector<double> neg(grad.size()), moved;
+        for (size_t i = 0; i < grad.size(); i++)
+            neg[i] = -grad[i];
+        plus(state, neg, moved);
+        double m = 0;
+        for (size_t i = 0; i < state.size(); i++)
+            m = std::max(m, std::abs(state[i] - moved[i]));
+        return m;
+    };
+    it0.gradient_max_norm = gradient_max_norm(x, g);
     it0.trust_region_radius = radius;
     summary->iterations.push_back(it0);
     summary->usable = true;
@@ -575,6 +798,64 @@ void Solve(const SolverOptions &opt, Problem *problem, SolverSummary *summary)
         delta.resize(n);
         for (int i = 0; i < n; i++)
             delta[i] = step[i] * scale[i];
+        if (is_constrained && opt.max_num_line_search_step_size_iterations > 0)
+        {
+            // TrustRegionMinimizer::DoLineSearch: a projected Armijo search (cubic interpolation, sufficient decrease 1e-4,
+            // contraction within [1e-3, 0.6], at most 20 steps) along delta; on success delta *= the step found
+            double gdd = 0;
+            for (int i = 0; i < n; i++)
+                gdd += g[i] * delta[i];
+            double dmax = 0;
+            for (int i = 0; i < n; i++)
+                dmax = std::max(dmax, std::abs(delta[i]));
+            auto phi = [&](double a, FunctionSample *out) {
+                std::vector<double> sd(n), xa;
+                for (int i = 0; i < n; i++)
+                    sd[i] = a * delta[i];
+                plus(x, sd, xa);
+                Evaluation eva;
+                out->x = a;
+                out->value_is_valid = out->gradient_is_valid = false;
+                if (!evaluate(prog, xa, true, &eva))
+                    return;
+                std::vector<double> JtJa, ga, cna;
+                normal_equations(eva, ones, JtJa, ga, cna);
+                out->value = eva.cost;
+                out->value_is_valid = std::isfinite(eva.cost);
+                double gd = 0;
+                for (int i = 0; i < n; i++)
+                    gd += ga[i] * delta[i];
+                out->gradient = gd;
+                out->gradient_is_valid = out->value_is_valid && std::isfinite(gd);
+            };
+            FunctionSample initial, previous, current;
+            initial.x = 0;
+            initial.value = x_cost;
+            initial.gradient = gdd;
+            initial.value_is_valid = initial.gradient_is_valid = true;
+            phi(1.0, &current);
+            bool success = true;
+            int ls_iterations = 0;
+            while (!current.value_is_valid || current.value > (x_cost + 1e-4 * gdd * current.x))
+            {
+                if (++ls_iterations >= opt.max_num_line_search_step_size_iterations)
+                {
+                    success = false;
+                    break;
+                }
+                const double next = interpolating_step(initial, previous, current, 1e-3 * current.x, 0.6 * current.x);
+                if (next * dmax < 1e-9)
+                {
+                    success = false;
+                    break;
+                }
+                previous = current;
+                phi(next, &current);
+            }
+            if (success)
+                for (int i = 0; i < n; i++)
+                    delta[i] *= current.x;
+        }
         plus(x, delta, cand);
         Evaluation cev;
         double candidate_cost = std::numeric_limits<double>::max();
@@ -615,7 +896,7 @@ void Solve(const SolverOptions &opt, Problem *problem, SolverSummary *summary)
             normal_equations(ev, ones, JtJ, g, cn2);
             normal_equations(ev, scale, sJtJ, sg, scn2);
             is.step_is_successful = true;
-            is.gradient_max_norm = max_abs(g);
+            is.gradient_max_norm = gradient_max_norm(x, g);
             const double t = 2.0 * is.relative_decrease - 1.0;
             radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
             radius = std::min(opt.max_trust_region_radius, radius);
