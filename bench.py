@@ -80,6 +80,11 @@ def main():
         torch.cuda.synchronize()
 
     cfg = synth.CONFIGS[args.config]
+    # blob lattice of the rendered views: 16 px apart in the 1600 px working image.  The greedy 40 px subsample of
+    # match_features.cpp:8-52 saturates at about 3.5 k features on a 4000 x 3000 image (the nominal
+    # "4k features entering the matcher" cannot be reached at this image size with the reference's 40 px spacing); this
+    # density sits at that saturation (21 px gave 3.2 k).
+    os.environ.setdefault("OCHIP_BLOB_SPACING", "16")
     grid = synth.make_grid(seed=12345 + rank, rows=cfg["rows"], cols=cfg["cols"], feats=64)  # poses + camera model
     ctx = capi.Context(device_index)
     images, shape = pipeline.synthetic_views(ctx, grid, seed=7 + rank)    # resident in HBM before timing starts
@@ -94,7 +99,7 @@ def main():
         t0 = time.perf_counter()
         g, res, t = pipeline.run(ctx, grid, images, shape, start_ori, overlap=overlap)
         dt = time.perf_counter() - t0
-        last.update(res=res, t=t)
+        last.update(res=res, t=t, link_work=g.match_work())
         g.close()
         return dt, t, res
 
@@ -127,6 +132,8 @@ def main():
     n_eval, ms_eval = prof(capi.K_RELAX_EVAL)
     n_solve, ms_solve = prof(capi.K_RELAX_SOLVE)
     n_akaze, ms_akaze = prof(capi.K_AKAZE)
+    match_computed, match_delivered = ctx.match_work()
+    relax_flops = ctx.relax_work()
     res = last["res"]
     rel = res["relax"]
     n, h, w = shape
@@ -188,6 +195,27 @@ def main():
         "algorithmic_bytes_per_launch": round(alg_bytes_img * imgs_per_launch),
         "algorithmic_bytes_per_image": round(alg_bytes_img),
         "staged": staged,
+        # match: integer-VALU bound (16 v_xor + 16 accumulating v_bcnt per 512-bit distance per lane; the bound is the
+        # measured issue rate of exactly that instruction mix, scripts/ubench_valu.hip: 1.3e12 distances/s on 256 CUs).
+        # HBM traffic of the kernels is negligible (descriptors are read once per tile from L2, 64 B per feature).
+        "match": {"kernel": "hamming_2nn_sym_kernel + hamming_2nn_kernel + sym_merge_kernel", "bound": "valu",
+                  "achieved": round(match_computed / max(ms_match, 1e-9) * 1e3 / 1e12, 4), "peak": 1.3,
+                  "unit": "1e12 descriptor distances/s computed",
+                  "frac": round(match_computed / max(ms_match, 1e-9) * 1e3 / 1.3e12, 4),
+                  "delivered_1e12_per_s": round(match_delivered / max(ms_match, 1e-9) * 1e3 / 1e12, 4),
+                  "distances_per_step": round(match_computed / max(args.steps, 1)),
+                  "features_entering_matcher_per_image": round(last["link_work"]["subset_features"] / grid.n_images, 1),
+                  "directed_pairs": int(res["edges"]), "launches": n_match,
+                  "device_ms_per_step": round(ms_match / max(args.steps, 1), 3)},
+        # relax linear solve: the only MFMA use on the path (v_mfma_f64_16x16x4f64 in the panel and trailing-update GEMMs of
+        # the block-envelope Cholesky).  Inside the envelope the launches are small and latency-bound; the dense figure is the
+        # peak the guide's FP64-matrix rate gives, not a target for this path.
+        "relax_mfma": {"kernel": "chol_panel_kernel + chol_update_mfma_kernel", "bound": "mfma",
+                       "achieved": round(relax_flops / max(ms_solve, 1e-9) * 1e3 / 1e12, 4), "peak": 78.6, "unit": "TFLOP/s",
+                       "frac": round(relax_flops / max(ms_solve, 1e-9) * 1e3 / 78.6e12, 5),
+                       "note": "latency-bound: one factorisation is a chain of small launches inside the block envelope; the "
+                               "time base is the whole linear solve (build, factorisation, substitutions, step)",
+                       "flops_per_step": round(relax_flops / max(args.steps, 1)), "solves": n_solve},
         "other_kernels_avg_ms": {
             "hamming_2nn_kernel": round(ms_match / max(n_match, 1), 3),
             "ransac_homography_kernel": round(ms_ransac / max(n_ransac, 1), 3),
@@ -201,6 +229,61 @@ def main():
                   "unknowns": int(3 * grid.n_images + 3), "residual_blocks": int(rel["residual_blocks"]),
                   "median_orientation_error_rad_vs_truth": float(np.median(err)),
                   "cameras_left_unconstrained": int(np.sum(err > 0.02))}
+
+    # ---- beside the headline (rank 0, after the timed region; none of it is part of `value`)
+    extras = {}
+    if rank == 0 and world == 1:
+        try:
+            # (a) images that start in HOST memory, as the reference's boundary hands them over (cv::Mat): one chunk of
+            # views copied back from HBM into page-locked memory, then extracted from there (upload included)
+            n_h = min(grid.n_images, 100)
+            hostviews = np.stack([ctx.synth_views_read(images, i, w, h) for i in range(n_h)])
+            t0 = time.perf_counter()
+            host.extract_features_batch(ctx, hostviews, 30000)
+            t_host = (time.perf_counter() - t0) / n_h
+            t0 = time.perf_counter()
+            host.extract_features_batch(ctx, images, 30000, device_shape=(n_h, h, w))
+            t_dev = (time.perf_counter() - t0) / n_h
+            step_s = hot_max / args.steps
+            extras["pcie_inclusive"] = {
+                "extract_images_per_s_from_host_memory": round(1.0 / t_host, 1),
+                "extract_images_per_s_from_hbm_same_call": round(1.0 / t_dev, 1),
+                "images_per_s_end_to_end_estimate": round(grid.n_images / (step_s + grid.n_images * max(t_host - t_dev, 0.0)), 1),
+                "note": "pageable numpy buffers, synchronous copies per chunk of 100 images (36 MB of BGR per view); the "
+                        "estimate adds the extra seconds per image to the measured step"}
+            del hostviews
+        except Exception as ex:
+            extras["pcie_inclusive"] = {"error": str(ex)}
+        try:
+            gg, _, _ = pipeline.run(ctx, grid, images, shape, start_ori)
+            # (b) the same 50-camera group the CPU leg relaxes, on the device
+            sub = np.arange(min(50, grid.n_images))
+            e50 = gg.edges_flat(sub)
+            pk50 = host.pack_edges(e50)
+            t0 = time.perf_counter()
+            r50 = host.relax_ground_plane(ctx, grid.position[sub], start_ori[sub], grid.model, sub, start_ori[sub], pk50)
+            t50 = time.perf_counter() - t0
+            extras["relax_device_50_cameras"] = {"cameras": int(len(sub)), "residual_blocks": int(r50["residual_blocks"]),
+                                                 "lm_iterations": int(r50["iterations_total"]), "seconds": round(t50, 4),
+                                                 "device_seconds": round(r50["device_s"], 4),
+                                                 "lm_iters_per_s": round(r50["iterations_total"] / max(r50["device_s"], 1e-9), 1)}
+            # (c) what the pipeline states after INITIAL_PROCESSING run on this survey (pipeline.cpp:666-707): RelaxStage with
+            # floor(n / 50) spectral groups, {ORIENTATION, GROUND_MESH} on the minimal mesh seeded from the plane
+            plane = gg.relax(ctx, start_ori, host.relax_options("ORIENTATION", "GROUND_PLANE"))
+            seed_mesh = host.rebuild_mesh(grid.position, plane["surface"], minimal=True)
+            t0 = time.perf_counter()
+            ms = gg.relax_stage(ctx, host.relax_options("ORIENTATION", "GROUND_MESH"), 0.1, previous=seed_mesh)
+            tms = time.perf_counter() - t0
+            errm = pipeline.orientation_errors(gg.orientations(), grid.orientation)
+            extras["relax_stage_ground_mesh"] = {
+                "groups": int(ms["groups"]), "seconds": round(tms, 4), "host_setup_seconds_summed": round(ms["setup_host_s"], 4),
+                "device_seconds_summed": round(ms["device_s"], 4), "lm_iterations": int(ms["iterations_total"]),
+                "residual_blocks": int(ms["residual_blocks"]), "track_blocks": int(ms["track_blocks"]),
+                "two_ray_blocks": int(ms["two_ray_blocks"]), "images_per_s": round(grid.n_images / tms, 1),
+                "median_orientation_error_rad_vs_truth": float(np.median(errm))}
+            gg.close()
+        except Exception as ex:
+            extras["relax_extras_error"] = str(ex)
 
     # ---- CPU baseline: the restatement on a bounded sample of the same workload, all usable host cores
     cpu = None
@@ -275,6 +358,7 @@ def main():
                        "per_rank": "one grid of this shape per GPU, no data-path collective"},
             "stage_seconds_per_step": {k: round(v / args.steps, 5) for k, v in acc.items()},
             "relax": relax_info,
+            "beside_the_headline": extras,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

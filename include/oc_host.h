@@ -44,6 +44,8 @@ extern "C"
                                 size_t n_inliers, const double *inl_px4, const uint64_t *inl_idx3, size_t n_matches,
                                 const uint64_t *match_idx2, const double *match_dist, const double *poses32);
     void och_graph_get_orientations(const och_graph *g, double *ori /* n_nodes x 4, node order */);
+    /* work of the last link stage's match step: {directed pairs, descriptor distances needed = sum n1 * n2, subset features} */
+    void och_link_match_work(const och_graph *g, double *out3);
     size_t och_graph_num_nodes(const och_graph *g);
     size_t och_graph_num_edges(const och_graph *g);
     void och_graph_node_ids(const och_graph *g, uint64_t *out);

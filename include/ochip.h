@@ -321,6 +321,12 @@ extern "C"
     /* ---- profiling: HIP-event time of every launch of a kernel since the last reset ------------- */
     int ochip_profile_reset(ochip_ctx *ctx);
     int ochip_profile_get(ochip_ctx *ctx, int kernel_id, uint64_t *launches, double *total_ms);
+    /* descriptor distances of the match launches since the last ochip_profile_reset (siblings included): computed (a pair
+     * matched in both directions from one pass counts its n1 x n2 distances once) and delivered (twice) */
+    int ochip_match_work(ochip_ctx *ctx, uint64_t *computed, uint64_t *delivered);
+    /* fp64 flops the relax solves issued on the matrix cores (the panel and trailing-update GEMMs of their Cholesky
+     * factorisations, inside the block envelope) since the last ochip_profile_reset; their time is OCHIP_K_RELAX_SOLVE's */
+    int ochip_relax_work(ochip_ctx *ctx, double *mfma_flops);
 
     /* ---- diagnostics ----------------------------------------------------------------------------- */
     /* out[i] = x[i] op y[i] computed on the device with the hot-path kernels' compile flags:

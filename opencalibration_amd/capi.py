@@ -26,7 +26,7 @@ EXPORTS = [
     "ochip_relax_solve", "ochip_relax_get_state", "ochip_relax_set_shard",
     "ochip_relaxg_problem_create", "ochip_relaxg_problem_destroy", "ochip_relaxg_set_structure_only", "ochip_relaxg_solve",
     "ochip_relaxg_get_state", "ochip_relaxg_evaluate",
-    "ochip_profile_reset", "ochip_profile_get",
+    "ochip_profile_reset", "ochip_profile_get", "ochip_match_work", "ochip_relax_work",
     "ochip_debug_fp64",
 ]
 
@@ -60,6 +60,8 @@ def load():
         L.ochip_match_fetch.argtypes = [vp, vp, u64]
         L.ochip_profile_reset.argtypes = [vp]
         L.ochip_profile_get.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(C.c_double)]
+        L.ochip_match_work.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+        L.ochip_relax_work.argtypes = [vp, C.POINTER(C.c_double)]
         L.ochip_debug_fp64.argtypes = [vp, i32, vp, vp, C.c_size_t, vp]
         L.ochip_akaze_batch.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
         L.ochip_akaze_batch_dev.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
@@ -180,6 +182,17 @@ class Context:
 
     def profile_reset(self):
         self._check(self.L.ochip_profile_reset(self.h), "ochip_profile_reset")
+
+    def relax_work(self):
+        f = C.c_double()
+        self._check(self.L.ochip_relax_work(self.h, C.byref(f)), "ochip_relax_work")
+        return f.value
+
+    def match_work(self):
+        """(computed, delivered) descriptor distances of the match launches since the last profile_reset."""
+        c, d = C.c_uint64(), C.c_uint64()
+        self._check(self.L.ochip_match_work(self.h, C.byref(c), C.byref(d)), "ochip_match_work")
+        return c.value, d.value
 
     def profile_get(self, kid):
         n, ms = C.c_uint64(), C.c_double()

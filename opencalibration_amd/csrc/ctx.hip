@@ -446,12 +446,41 @@ int ochip_profile_reset(ochip_ctx *ctx)
         ctx->prof[k].launches = 0;
         ctx->prof[k].total_ms = 0;
     }
+    ctx->match_computed = ctx->match_delivered = 0;
+    ctx->relax_mfma_flops = 0;
     for (ochip_ctx *sib : ctx->siblings)
     {
         const int rc = ochip_profile_reset(sib);
         if (rc != OCHIP_OK)
             return rc;
     }
+    return OCHIP_OK;
+}
+
+int ochip_relax_work(ochip_ctx *ctx, double *mfma_flops)
+{
+    if (!ctx || !mfma_flops)
+        return OCHIP_EINVAL;
+    *mfma_flops = ctx->relax_mfma_flops;
+    for (ochip_ctx *sib : ctx->siblings)
+        *mfma_flops += sib->relax_mfma_flops;
+    return OCHIP_OK;
+}
+
+int ochip_match_work(ochip_ctx *ctx, uint64_t *computed, uint64_t *delivered)
+{
+    if (!ctx)
+        return OCHIP_EINVAL;
+    uint64_t c = ctx->match_computed, d = ctx->match_delivered;
+    for (ochip_ctx *sib : ctx->siblings)
+    {
+        c += sib->match_computed;
+        d += sib->match_delivered;
+    }
+    if (computed)
+        *computed = c;
+    if (delivered)
+        *delivered = d;
     return OCHIP_OK;
 }
 

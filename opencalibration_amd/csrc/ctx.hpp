@@ -72,6 +72,12 @@ struct ochip_ctx
     std::vector<std::pair<void *, size_t>> dev_pool;
 
     ochip_profile_slot prof[OCHIP_K_COUNT];
+    // descriptor distances the match launches computed / delivered since the last profile reset (a pair matched in both
+    // directions from one pass computes its n1 x n2 distances once and delivers them twice)
+    uint64_t match_computed = 0, match_delivered = 0;
+    // fp64 multiply-adds x 2 the Cholesky factorisations of the relax solves issued on the matrix cores (panel and
+    // trailing-update GEMMs over the rows inside the block envelope) since the last profile reset
+    double relax_mfma_flops = 0;
 
     // sibling contexts on the same device (own streams, scratch and pools) handed out by ochip_ctx_sibling so
     // that independent batches can be in flight at once; owned by this context

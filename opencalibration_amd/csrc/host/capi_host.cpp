@@ -176,6 +176,13 @@ uint64_t och_graph_add_edge(och_graph *g, uint64_t source_id, uint64_t dest_id, 
     return g->graph.addEdge(std::move(rel), source_id, dest_id);
 }
 
+void och_link_match_work(const och_graph *g, double *out3)
+{
+    out3[0] = out3[1] = out3[2] = 0;
+    if (g->link)
+        g->link->match_work(out3);
+}
+
 void och_graph_get_orientations(const och_graph *g, double *ori)
 {
     size_t i = 0;

@@ -67,6 +67,26 @@ class LinkStage
     {
         return _links;
     }
+    // work of the match step: directed pairs, descriptor distances they need (sum of n1 * n2 over the pairs, n = the
+    // 40 px subsets), subset features summed over the images
+    void match_work(double out[3]) const
+    {
+        out[0] = out[1] = out[2] = 0;
+        for (const auto &s : _subsets)
+            out[2] += (double)s.size();
+        for (const NodeLinks &l : _links)
+        {
+            auto a = _prepared_index.find(l.node_id);
+            for (size_t other : l.link_ids)
+            {
+                auto b = _prepared_index.find(other);
+                if (a == _prepared_index.end() || b == _prepared_index.end())
+                    continue;
+                out[0] += 1;
+                out[1] += (double)_subsets[a->second].size() * (double)_subsets[b->second].size();
+            }
+        }
+    }
 
     bool keep_debug = false;
     std::vector<pair_debug> debug;

@@ -357,21 +357,28 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
                 continue;
             const uint32_t a = pairs[p].image_1, b = pairs[p].image_2;
             const uint32_t na = ctx->img_n[a], nb = ctx->img_n[b];
-            // (the partials of the paired jobs of one launch are capped at 2 GB; further pairs go one direction at a time)
-            if (use_sym && a != b && na > 0 && nb > 0 && part_total * sizeof(uint2) < (2ull << 30))
+            // (the partials of the paired jobs of one launch are capped at 2 GB - OCHIP_MATCH_SYM_CAP_MB overrides it -;
+            // a pair whose partials would not fit any more goes one direction at a time)
+            static const uint64_t cap_bytes = getenv("OCHIP_MATCH_SYM_CAP_MB") ? (uint64_t)atoll(getenv("OCHIP_MATCH_SYM_CAP_MB")) << 20 : (2ull << 30);
+            const uint64_t need = (uint64_t)((na + 63) / 64) * nb;
+            if (use_sym && a != b && na > 0 && nb > 0 && (part_total + need) * sizeof(uint2) <= cap_bytes)
             {
                 auto it = first.find(((uint64_t)b << 32) | a);
                 if (it != first.end() && it->second != p && !claimed[it->second])
                 {
                     claimed[p] = claimed[it->second] = 1;
                     sym.push_back(sym_job{a, b, out_offset[p], out_offset[it->second], part_total});
-                    part_total += (uint64_t)((na + 63) / 64) * nb;
+                    part_total += need;
+                    ctx->match_computed += (uint64_t)na * nb;
+                    ctx->match_delivered += 2 * (uint64_t)na * nb;
                     sym_max_na = std::max(sym_max_na, na);
                     sym_max_nb = std::max(sym_max_nb, nb);
                     continue;
                 }
             }
             claimed[p] = 1;
+            ctx->match_computed += (uint64_t)na * nb;
+            ctx->match_delivered += (uint64_t)na * nb;
             single_pairs.push_back(pairs[p]);
             single_off.push_back(out_offset[p]);
         }

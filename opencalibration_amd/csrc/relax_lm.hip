@@ -645,6 +645,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             const int tail0 = std::max(dense ? n : S.env.tail_begin, below);
             row_set rs{below, band_end - below, tail0, (band_end - below) + (n + 1 - tail0)};
             const int tiles = (rs.total + 63) / 64;
+            ctx->relax_mfma_flops += 2.0 * rs.total * nb * nb + (below < n ? 1.0 * rs.total * rs.total * nb : 0.0);
             hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, st, S.Wm, n, rs, k0, nb, linv_k);
             if (below < n)
                 hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, st, S.Wm, n, rs, k0, nb);

@@ -74,6 +74,8 @@ def load():
         L.och_graph_add_image.restype = u64
         L.och_graph_add_edge.restype = u64
         L.och_graph_add_edge.argtypes = [vp, u64, u64, vp, C.c_int, sz, _f64p, _u64p, sz, vp, vp, vp]
+        L.och_link_match_work.argtypes = [vp, _f64p]
+        L.och_link_match_work.restype = None
         L.och_graph_get_orientations.argtypes = [vp, _f64p]
         L.och_graph_get_orientations.restype = None
         L.och_graph_num_nodes.argtypes = [vp]
@@ -157,6 +159,32 @@ def extract_features_batch(ctx, images_bgr, max_keypoints=20000, device_shape=No
 
 RELAX_SUMMARY_NAMES = ["solves", "iterations_total", "last_iterations", "initial_cost", "final_cost", "residual_blocks",
                        "setup_host_s", "device_s"]
+
+
+def pack_edges(edges):
+    """edges: list of dicts {src, dst, H (3x3) or None, px (k x 4), match_index (k,), dist (m,) or None}.
+    Returns the flat arrays the stand-alone relax entry points (och_relax_ground_plane, och_relax) take."""
+    n = len(edges)
+    src = np.array([e["src"] for e in edges], np.uint64)
+    dst = np.array([e["dst"] for e in edges], np.uint64)
+    H = np.full((max(n, 1), 9), np.nan)
+    ish = np.zeros(max(n, 1), np.uint8)
+    for i, e in enumerate(edges):
+        if e.get("H") is not None:
+            H[i] = np.asarray(e["H"], np.float64).reshape(9)
+            ish[i] = 1
+    counts = [len(e["px"]) for e in edges]
+    inl_off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    px = np.ascontiguousarray(np.concatenate([np.asarray(e["px"], np.float64).reshape(-1, 4) for e in edges])
+                              if n and sum(counts) else np.zeros((1, 4)))
+    mi = np.ascontiguousarray(np.concatenate([np.asarray(e["match_index"], np.uint64) for e in edges])
+                              if n and sum(counts) else np.zeros(1, np.uint64))
+    dcounts = [0 if e.get("dist") is None else len(e["dist"]) for e in edges]
+    dist_off = np.concatenate([[0], np.cumsum(dcounts)]).astype(np.uint64)
+    dist = np.ascontiguousarray(np.concatenate([np.asarray(e["dist"], np.float64) for e in edges if e.get("dist") is not None])
+                                if sum(dcounts) else np.zeros(1))
+    return dict(src=src, dst=dst, H=np.ascontiguousarray(H), is_h=ish, inl_off=inl_off, px=px, match_index=mi,
+                dist_off=dist_off, dist=dist)
 
 
 RELAX_OPTIONS = dict(ORIENTATION=1 << 0, POSITION=1 << 1, GROUND_PLANE=1 << 2, GROUND_MESH=1 << 3, POINTS_3D=1 << 4,
@@ -380,6 +408,12 @@ class Graph:
         if e == 0:
             raise capi.OchipError(self.L.och_last_error(self.h).decode())
         return e
+
+    def match_work(self):
+        """{pairs, distances needed, subset features} of the last link stage's match step."""
+        out = np.zeros(3)
+        self.L.och_link_match_work(self.h, out)
+        return dict(pairs=out[0], distances=out[1], subset_features=out[2])
 
     def orientations(self):
         out = np.zeros((max(self.num_nodes, 1), 4))

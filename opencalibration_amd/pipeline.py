@@ -5,6 +5,7 @@ load stage's extract_features per image, the link stage over kNN(10) pairs, one 
 cameras.  Used by bench.py and the end-to-end tests; the images come from the synthetic view renderer
 (data only) and are resident in HBM before any timed region starts.
 """
+import os
 import time
 
 import numpy as np
@@ -18,7 +19,7 @@ def synthetic_views(ctx, grid, seed=7):
     f, pp = float(grid.model[0]), (float(grid.model[1]), float(grid.model[2]))
     # blob lattice: ~21 px apart in the 1600-px working image, i.e. (max(w,h)/1600) * 21 full-resolution pixels
     gsd = (grid.position[0, 2] - (grid.plane[0] * grid.position[0, 0] + grid.plane[1] * grid.position[0, 1])) / f
-    spacing = 21.0 * (max(w, h) / 1600.0) * gsd
+    spacing = float(os.environ.get("OCHIP_BLOB_SPACING", "21.0")) * (max(w, h) / 1600.0) * gsd
     origin = (float(grid.position[:, 0].min() - 500.0), float(grid.position[:, 1].min() - 500.0))
     ptr = ctx.synth_views(grid.position, grid.orientation, w, h, f, pp, grid.plane, spacing, origin, seed=seed)
     return ptr, (grid.n_images, h, w)
