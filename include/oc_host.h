@@ -61,6 +61,8 @@ extern "C"
     void och_graph_edge_inliers(const och_graph *g, size_t e, uint64_t *f1, uint64_t *f2, uint64_t *match_index,
                                 double *px4);
     void och_graph_edge_match_distances(const och_graph *g, size_t e, double *out); /* relations.matches[i].distance */
+    /* relations.matches of edge e: feature index pairs (n_matches x 2) and distances; relationType == HOMOGRAPHY */
+    void och_graph_edge_matches(const och_graph *g, size_t e, uint64_t *idx2, double *dist, int *is_homography);
     void och_graph_set_orientations(och_graph *g, const double *ori /* n_nodes x 4, node order */);
 
     /* ---- extract (opencalibration_amd/csrc/host/extract_features.hpp): extract_features(cv::Mat) of

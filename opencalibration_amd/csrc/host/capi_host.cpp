@@ -297,6 +297,23 @@ void och_graph_edge_match_distances(const och_graph *g, size_t e, double *out)
         out[i] = ed.payload.matches[i].distance;
 }
 
+void och_graph_edge_matches(const och_graph *g, size_t e, uint64_t *idx2, double *dist, int *is_homography)
+{
+    const auto &ed = g->graph.edges().at(e);
+    for (size_t i = 0; i < ed.payload.matches.size(); i++)
+    {
+        if (idx2)
+        {
+            idx2[2 * i] = ed.payload.matches[i].feature_index_1;
+            idx2[2 * i + 1] = ed.payload.matches[i].feature_index_2;
+        }
+        if (dist)
+            dist[i] = ed.payload.matches[i].distance;
+    }
+    if (is_homography)
+        *is_homography = ed.payload.relationType == camera_relations::RelationType::HOMOGRAPHY;
+}
+
 void och_graph_set_orientations(och_graph *g, const double *ori)
 {
     auto &nodes = g->graph.nodes();

@@ -91,6 +91,8 @@ def load():
         L.och_graph_edge_info.argtypes = [vp, sz, _u64p, _u64p, _f64p, _f64p]
         L.och_graph_edge_inliers.argtypes = [vp, sz, _u64p, _u64p, _u64p, _f64p]
         L.och_graph_edge_match_distances.argtypes = [vp, sz, _f64p]
+        L.och_graph_edge_matches.argtypes = [vp, sz, vp, vp, C.POINTER(C.c_int)]
+        L.och_graph_edge_matches.restype = None
         L.och_graph_set_orientations.argtypes = [vp, _f64p]
         u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
         L.och_relax_ground_plane.argtypes = [vp, sz, _f64p, _f64p, _f64p, sz, _u64p, _f64p, sz, _u64p, _u64p, _f64p, u8p,
@@ -392,8 +394,10 @@ class Graph:
             g.add_image(loc, st, de, grid.num_sparse[i], m, grid.position[i])
         return g
 
-    def add_edge(self, source_id, dest_id, px, f1, f2, match_index=None, H=None, dist=None, poses=None):
-        """graph.addEdge from arrays: px n x 4 inlier pixels, f1 / f2 feature indices, match distances."""
+    def add_edge(self, source_id, dest_id, px, f1, f2, match_index=None, H=None, dist=None, poses=None, match_idx=None,
+                 is_homography=None):
+        """graph.addEdge from arrays: px n x 4 inlier pixels, f1 / f2 feature indices, match distances (and the matches'
+        feature index pairs)."""
         px = np.ascontiguousarray(px, np.float64).reshape(-1, 4)
         n = len(px)
         idx = np.zeros((max(n, 1), 3), np.uint64)
@@ -402,9 +406,12 @@ class Graph:
         Hc = None if H is None else np.ascontiguousarray(H, np.float64)
         d = None if dist is None or len(dist) == 0 else np.ascontiguousarray(dist, np.float64)
         pc = None if poses is None else np.ascontiguousarray(poses, np.float64)
+        mi2 = None if match_idx is None or d is None else np.ascontiguousarray(match_idx, np.uint64).reshape(-1, 2)
         e = self.L.och_graph_add_edge(self.h, int(source_id), int(dest_id), None if Hc is None else Hc.ctypes.data,
-                                      int(H is not None), n, px if n else np.zeros((1, 4)), idx, 0 if d is None else len(d),
-                                      None, None if d is None else d.ctypes.data, None if pc is None else pc.ctypes.data)
+                                      int(H is not None if is_homography is None else is_homography), n,
+                                      px if n else np.zeros((1, 4)), idx, 0 if d is None else len(d),
+                                      None if mi2 is None else mi2.ctypes.data, None if d is None else d.ctypes.data,
+                                      None if pc is None else pc.ctypes.data)
         if e == 0:
             raise capi.OchipError(self.L.och_last_error(self.h).decode())
         return e
@@ -518,10 +525,13 @@ class Graph:
             self.L.och_graph_edge_inliers(self.h, e, f1, f2, mi, px)
             k = int(cnt[1])
             dist = np.zeros(max(int(cnt[0]), 1))
-            if with_distances and cnt[0]:
-                self.L.och_graph_edge_match_distances(self.h, e, dist)
+            midx = np.zeros((max(int(cnt[0]), 1), 2), np.uint64)
+            is_h = C.c_int(0)
+            if with_distances:
+                self.L.och_graph_edge_matches(self.h, e, midx.ctypes.data, dist.ctypes.data, C.byref(is_h))
             out.append(dict(source=int(ids[0]), dest=int(ids[1]), n_matches=int(cnt[0]), n_inliers=k, H=H, poses=poses,
-                            f1=f1[:k], f2=f2[:k], match_index=mi[:k], px=px[:k], dist=dist[:int(cnt[0])]))
+                            f1=f1[:k], f2=f2[:k], match_index=mi[:k], px=px[:k], dist=dist[:int(cnt[0])],
+                            match_idx=midx[:int(cnt[0])], is_homography=bool(is_h.value)))
         return out
 
     def set_orientations(self, ori):

@@ -96,3 +96,33 @@ def relax_exchange(group=None):
             return 1
 
     return RELAX_EXCHANGE_FN(callback)
+
+
+def link_sharded(make_graph, ctx, group=None):
+    """One survey's link stage over the ranks of `group` on the DEVICE path.  `make_graph()` builds the survey's graph with
+    its nodes (all images' features: the descriptor sets are small) and no edges.  Every rank links
+    the directed pairs of its contiguous block of source images with LinkStage on its own GPU
+    (host.Graph.link(node_ids=block)); the edges are all-gathered (no device collective: pairs are independent units) and
+    added to a fresh graph in the serial order - rank blocks are contiguous and ascending and LinkStage::finalize orders a
+    rank's edges by source (link_stage.cpp:123-127), so concatenation in rank order IS the single-process order and
+    graph.addEdge draws the same ids.  Returns (merged graph, number of edges this rank linked itself)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    work = make_graph()
+    ids = list(work.node_ids)
+    lo, hi = source_block(len(ids), rank, world)
+    work.link(ctx, node_ids=ids[lo:hi])
+    mine = work.edges(with_distances=True)
+    work.close()
+    parts = [mine]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, mine, group=group)
+    merged = make_graph()
+    for part in parts:
+        for e in part:
+            merged.add_edge(e["source"], e["dest"], e["px"], e["f1"], e["f2"], e["match_index"], e["H"], e["dist"], e["poses"],
+                            match_idx=e["match_idx"], is_homography=e["is_homography"])
+    return merged, len(mine)
