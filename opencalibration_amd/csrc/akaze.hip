@@ -290,8 +290,12 @@ template <int MODE, int M /*margin of the blurred tile*/, int R /*tap radius*/>
 __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
 {
     constexpr int BW = BT_X + 2 * M, BH = BT_Y + 2 * M, IW = BW + 2 * R, IH = BH + 2 * R;
-    __shared__ float tin[IW * IH];  // input tile; reused for the blurred tile (BW x BH)
-    __shared__ float trow[BW * IH]; // row pass
+    // LDS rows are padded to multiples of 4 floats so that a thread can take 4 neighbouring outputs of the row pass
+    // from two 16-byte reads and store them with one 16-byte write
+    constexpr int BWQ = (BW + 3) / 4, BWP = 4 * BWQ, IWP = BWP + 2 * R + ((4 - ((2 * R) & 3)) & 3);
+    __shared__ __attribute__((aligned(16))) float tin[IWP * IH];  // input tile; reused for the blurred tile (BW x BH)
+    __shared__ __attribute__((aligned(16))) float trow[BWP * IH]; // row pass
+    static_assert(IWP * IH >= BW * BH && (IWP & 3) == 0, "blur tile layout");
     const int w = A.w, h = A.h;
     const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
     int tile_x, tile_y;
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
             if (idx < NQ * IH)
             {
                 const int lx = 4 * j - shift;
-                float *row = &tin[ly * IW];
+                float *row = &tin[ly * IWP];
                 if (lx >= 0 && lx < IW)
                     row[lx] = q[it].x;
                 if (lx + 1 >= 0 && lx + 1 < IW)
@@ -358,37 +362,70 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
         {
             const int idx = threadIdx.x + it * 256;
             if (idx < IW * IH)
-                tin[idx] = v[it];
+                tin[(idx / IW) * IWP + (idx % IW)] = v[it];
         }
     }
     __syncthreads();
-#pragma unroll 2
-    for (int idx = threadIdx.x; idx < BW * IH; idx += 256)
+    // Row pass: a thread takes 4 neighbouring outputs of one row - its 4 + 2R inputs arrive as 16-byte LDS reads and every
+    // tap feeds two packed fp32 multiplies and two packed adds (v_pk_mul_f32 / v_pk_add_f32; a multiply and an add per
+    // tap and output as before, in ascending tap order: the same float expression, a third of the LDS instructions).
+    typedef float pk2 __attribute__((ext_vector_type(2)));
+    for (int idx = threadIdx.x; idx < BWQ * IH; idx += 256)
     {
-        const int ly = idx / BW, lx = idx - ly * BW;
-        float acc = 0.0f;
+        const int ly = idx / BWQ, q = idx - ly * BWQ;
+        const float *src = &tin[ly * IWP + 4 * q];
+        float v[4 + 2 * R + 3];
 #pragma unroll
-        for (int i = 0; i < 2 * R + 1; i++)
-            acc = acc + t.k[i] * tin[ly * IW + lx + i];
-        trow[idx] = acc;
-    }
-    __syncthreads();
-#pragma unroll 2
-    for (int idx = threadIdx.x; idx < BW * BH; idx += 256)
-    {
-        const int ly = idx / BW, lx = idx - ly * BW;
-        float acc = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2 * R + 1; i++)
-            acc = acc + t.k[i] * trow[(ly + i) * BW + lx];
-        if (MODE == BLUR_PLAIN)
+        for (int i = 0; i < (4 + 2 * R + 3) / 4; i++)
         {
-            const int x = bx0 + lx, y = by0 + ly;
-            if (x < w && y < h)
-                A.out0[(size_t)blockIdx.z * A.out_stride + (size_t)y * w + x] = acc;
+            const float4 f = *reinterpret_cast<const float4 *>(src + 4 * i);
+            v[4 * i] = f.x, v[4 * i + 1] = f.y, v[4 * i + 2] = f.z, v[4 * i + 3] = f.w;
         }
-        else
-            tin[idx] = acc;
+        pk2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 2 * R + 1; i++)
+        {
+            const pk2 k = {t.k[i], t.k[i]};
+            a01 = a01 + k * pk2{v[i], v[i + 1]};
+            a23 = a23 + k * pk2{v[i + 2], v[i + 3]};
+        }
+        *reinterpret_cast<float4 *>(&trow[ly * BWP + 4 * q]) = make_float4(a01.x, a01.y, a23.x, a23.y);
+    }
+    __syncthreads();
+    // Column pass: a thread takes 4 vertically neighbouring outputs of one column: 4 + 2R reads for 4 outputs
+    constexpr int BHQ = (BH + 3) / 4;
+    for (int idx = threadIdx.x; idx < BW * BHQ; idx += 256)
+    {
+        const int qy = idx / BW, lx = idx - qy * BW;
+        const int ly0 = 4 * qy;
+        float v[4 + 2 * R];
+#pragma unroll
+        for (int i = 0; i < 4 + 2 * R; i++)
+            v[i] = (ly0 + i < IH) ? trow[(ly0 + i) * BWP + lx] : 0.0f;
+        pk2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 2 * R + 1; i++)
+        {
+            const pk2 k = {t.k[i], t.k[i]};
+            a01 = a01 + k * pk2{v[i], v[i + 1]};
+            a23 = a23 + k * pk2{v[i + 2], v[i + 3]};
+        }
+        const float acc4[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const int ly = ly0 + j;
+            if (ly >= BH)
+                continue;
+            if (MODE == BLUR_PLAIN)
+            {
+                const int x = bx0 + lx, y = by0 + ly;
+                if (x < w && y < h)
+                    A.out0[(size_t)blockIdx.z * A.out_stride + (size_t)y * w + x] = acc4[j];
+            }
+            else
+                tin[ly * BW + lx] = acc4[j];
+        }
     }
     if (MODE == BLUR_PLAIN)
         return;

@@ -521,23 +521,68 @@ __global__ __launch_bounds__(W) void gather_kernel(g_dev P, const work_item *ite
             }
         }
         __syncthreads();
-        // phase B: the records one after the other (fixed order), their entries spread over the lanes
-        for (uint32_t i = 0; i < cnt; i++)
+        // phase B: the records one after the other (fixed order), their entries spread over the lanes.  What bounds this
+        // loop is the latency of the record loads, so the values of 8 records are requested together before the first
+        // of them is added (the adds keep the record order: the sums stay reproducible).
+        constexpr int KB = 8;
+        for (uint32_t i0 = 0; i0 < cnt; i0 += KB)
         {
-            const int d = rdim[i], lo_u = rlo[i];
-            const double *rec = P.rec_data + roff[i];
-            const int tri = d * (d + 1) / 2;
-            for (int l = lane; l < su * (d + 1); l += W)
+            double v[KB];
+            int sidx[KB];
+#pragma unroll
+            for (int k = 0; k < KB; k++)
             {
-                const int a = l / (d + 1), c = l % (d + 1);
+                v[k] = 0.0;
+                sidx[k] = -1;
+                const uint32_t i = i0 + k;
+                if (i >= cnt)
+                    continue;
+                const int d = rdim[i], lo_u = rlo[i];
+                if (lane >= su * (d + 1))
+                    continue;
+                const int a = (lane >= d + 1) + (lane >= 2 * (d + 1)), c = lane - a * (d + 1);
                 const int row = lo_u + a;
+                const double *rec = P.rec_data + roff[i];
                 if (c == d)
-                    strip[a * ws + ws - 1] += rec[tri + row];
+                {
+                    sidx[k] = a * ws + ws - 1;
+                    v[k] = rec[d * (d + 1) / 2 + row];
+                }
                 else
                 {
                     const int idx = colmap[i][c];
                     if (idx >= 0)
-                        strip[a * ws + idx] += rec[row <= c ? tri_idx(row, c, d) : tri_idx(c, row, d)];
+                    {
+                        sidx[k] = a * ws + idx;
+                        v[k] = rec[row <= c ? tri_idx(row, c, d) : tri_idx(c, row, d)];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KB; k++)
+            {
+                if (sidx[k] >= 0)
+                    strip[sidx[k]] += v[k];
+                // entries beyond the first 64 of a wide record (3 rows x more than 21 columns: tracks of 5 rays with the
+                // shared lens model): a second round, same order
+                const uint32_t i = i0 + k;
+                if (i < cnt)
+                {
+                    const int d = rdim[i], lo_u = rlo[i];
+                    for (int l = lane + W; l < su * (d + 1); l += W)
+                    {
+                        const int a = l / (d + 1), c = l % (d + 1);
+                        const int row = lo_u + a;
+                        const double *rec = P.rec_data + roff[i];
+                        if (c == d)
+                            strip[a * ws + ws - 1] += rec[d * (d + 1) / 2 + row];
+                        else
+                        {
+                            const int idx = colmap[i][c];
+                            if (idx >= 0)
+                                strip[a * ws + idx] += rec[row <= c ? tri_idx(row, c, d) : tri_idx(c, row, d)];
+                        }
+                    }
                 }
             }
         }

@@ -4,7 +4,7 @@ then on a camera-spacing grid mesh (the legacy rebuildMesh surface: thousands of
 usage: probe_relax_mesh.py [C2|C3] [feats]"""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from opencalibration_amd import capi, host, pipeline, synth
 
 cfg = synth.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "C3"]
