@@ -188,6 +188,44 @@ extern "C"
     int och_graph_set_model(och_graph *g, uint32_t model, const double *m10);
     int och_graph_refit_edges(och_graph *g, ochip_ctx *ctx);
 
+    /* ---- the reference's on-disk formats (opencalibration_amd/csrc/host/graph_io.hpp): the MeasurementGraph as
+     *      graph.json (serialize / deserialize, src/io/serialize_MeasurementGraph.cpp:204-591,
+     *      src/io/deserialize_MeasurementGraph.cpp:30-272), a surface mesh as ASCII PLY (src/io/serialize_MeshGraph.cpp,
+     *      src/io/deserialize_MeshGraph.cpp) and the checkpoint directory (saveCheckpoint / loadCheckpoint /
+     *      validateCheckpoint, src/io/checkpoint.cpp:155-337).  Loading REPLACES the handle's graph and model table;
+     *      0 = ok, -1 + och_last_error(g) otherwise. ------------------------------------------------------------------ */
+    char *och_graph_to_json(const och_graph *g, size_t *len); /* malloc'd, NUL-terminated: och_free */
+    void och_free(void *p);
+    int och_graph_from_json(och_graph *g, const char *text, size_t len);
+    int och_graph_save_json(och_graph *g, const char *path);
+    int och_graph_load_json(och_graph *g, const char *path);
+    /* per node in the graph's order (any pointer may be NULL): id, index into the model table, features, sparse features */
+    void och_graph_node_table(const och_graph *g, uint64_t *ids, uint32_t *model_index, uint64_t *n_features, uint64_t *n_sparse);
+    /* one node's payload by its place in the graph's order (any pointer may be NULL): feature locations n x 2, strengths,
+     * descriptors n x 8 words, position 3, orientation 4 (x y z w); its image path */
+    int och_graph_node_payload(const och_graph *g, size_t index, double *loc, float *strength, uint64_t *desc,
+                               double *position3, double *orientation4);
+    const char *och_graph_node_path(const och_graph *g, size_t index);
+    int och_graph_set_node_path(och_graph *g, size_t index, const char *path);
+    size_t och_graph_num_models(const och_graph *g);
+    int och_graph_get_model(const och_graph *g, uint32_t index, double *m11); /* och_graph_add_model's ten, then the id */
+    int och_surface_save_ply(const och_surface *s, const char *path);
+    int och_surface_load_ply(och_surface *s, const char *path);
+    size_t och_surface_num_clouds(const och_surface *s);
+    void och_surface_cloud_sizes(const och_surface *s, uint64_t *sizes);
+    void och_surface_set_clouds(och_surface *s, size_t n_clouds, const uint64_t *sizes, const double *xyz);
+    typedef struct och_checkpoint och_checkpoint;
+    int och_checkpoint_validate(const char *dir); /* 1 = metadata.json and graph.json exist */
+    /* state: a PipelineState name (types/pipeline_state.hpp:25-55); info4: state_run_count, origin latitude, longitude, 0 */
+    int och_checkpoint_save(const char *dir, och_graph *g, const och_surface *const *surfaces, size_t n_surfaces,
+                            const char *state, const double *info4);
+    och_checkpoint *och_checkpoint_load(const char *dir, och_graph *g); /* NULL + och_last_error(g) on failure */
+    void och_checkpoint_destroy(och_checkpoint *cp);
+    size_t och_checkpoint_num_surfaces(const och_checkpoint *cp);
+    const char *och_checkpoint_state(const och_checkpoint *cp);
+    void och_checkpoint_info(const och_checkpoint *cp, double *info4);
+    int och_checkpoint_get_surface(const och_checkpoint *cp, size_t index, och_surface *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,16 +56,30 @@ def build_ochip(force=False, verbose=False):
 
 
 def build_host(force=False, verbose=False):
+    """One object per .cpp (opencalibration_amd/build/host_*.o), compiled in parallel, linked into liboc_host.so."""
     hdir = os.path.join(CSRC, "host")
     srcs = sorted(glob.glob(os.path.join(hdir, "*.cpp")))
     if not srcs:
         return None
-    deps = srcs + glob.glob(os.path.join(hdir, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
+    hdrs = glob.glob(os.path.join(hdir, "*.hpp")) + glob.glob(os.path.join(CSRC, "*.hpp")) + \
         glob.glob(os.path.join(HERE, "..", "include", "*.h"))   # csrc/undistort.hpp is shared with the device side
     out = os.path.join(HERE, "liboc_host.so")
-    if force or _stale(out, deps):
-        cmd = ["g++", *HOST_FLAGS, "-shared", "-o", out, *srcs, "-I", os.path.join(HERE, "..", "include"),
-               "-L", HERE, "-lochip", "-Wl,-rpath,$ORIGIN"]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs, procs = [], []
+    for s in srcs:
+        o = os.path.join(objdir, "host_" + os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = ["g++", *HOST_FLAGS, "-c", "-o", o, s, "-I", os.path.join(HERE, "..", "include")]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    if force or procs or _stale(out, objs):
+        cmd = ["g++", "-shared", "-fopenmp", "-o", out, *objs, "-L", HERE, "-lochip", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

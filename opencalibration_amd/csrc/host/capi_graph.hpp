@@ -2,6 +2,7 @@
 #pragma once
 
 #include "link_stage.hpp"
+#include "relax_mesh.hpp"
 
 struct och_graph
 {
@@ -9,4 +10,9 @@ struct och_graph
     std::vector<std::shared_ptr<opencalibration_amd::CameraModel>> models;
     std::unique_ptr<opencalibration_amd::LinkStage> link;
     std::string error;
+};
+
+struct och_surface // surface_model: mesh + point clouds
+{
+    opencalibration_amd::surface_model s;
 };

@@ -163,11 +163,6 @@ int och_graph_relax_ground_plane_sharded(och_graph *g, ochip_ctx *ctx, double *o
 // ---- surfaces and the general relax entry points ------------------------------------------------------------------
 } // extern "C"
 
-struct och_surface
-{
-    surface_model s;
-};
-
 static void fill_summary12(const RelaxTimers &t, const RelaxMeshStats &st, double *summary)
 {
     if (!summary)

@@ -88,6 +88,8 @@ struct image // types/image.hpp:17-33 (fields the hot path touches)
     std::shared_ptr<CameraModel> model;
     double position[3] = {NAN, NAN, NAN};
     double orientation[4] = {NAN, NAN, NAN, NAN};
+    // carried through graph.json untouched (graph_io.cpp): the base64 PNG thumbnail and the "metadata" object's text
+    std::string thumbnail_b64, metadata_json;
 };
 
 struct NodeLinks // types/node_links.hpp
@@ -133,6 +135,29 @@ class MeasurementGraph
         _nodes[_node_index.at(source)].edges.push_back(identifier);
         _nodes[_node_index.at(dest)].edges.push_back(identifier);
         return identifier;
+    }
+    // deserialisation (io/deserialize_MeasurementGraph.cpp:210,268-269): ids and the nodes' edge lists come from the
+    // file; iteration order becomes the file's order
+    bool insertNode(size_t identifier, image &&payload, std::vector<size_t> &&edge_ids)
+    {
+        if (!_node_index.emplace(identifier, _nodes.size()).second)
+            return false;
+        _nodes.push_back(Node{identifier, std::move(payload), std::move(edge_ids)});
+        return true;
+    }
+    bool insertEdge(size_t identifier, camera_relations &&payload, size_t source, size_t dest)
+    {
+        if (!_edge_index.emplace(identifier, _edges.size()).second)
+            return false;
+        _edges.push_back(Edge{identifier, source, dest, std::move(payload)});
+        return true;
+    }
+    void clear()
+    {
+        _nodes.clear();
+        _edges.clear();
+        _node_index.clear();
+        _edge_index.clear();
     }
     const Node *getNode(size_t id) const
     {

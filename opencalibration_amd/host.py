@@ -131,6 +131,43 @@ def load():
         L.och_graph_load_images.argtypes = [vp, vp, vp, u32, C.c_int, C.c_int, u32, C.c_int, u32, _f64p, _u64p, _f64p]
         L.och_graph_load_link_images.argtypes = [vp, vp, vp, u32, C.c_int, C.c_int, u32, C.c_int, u32, _f64p, vp, _u64p,
                                                  _f64p, _f64p, _f64p]
+        L.och_graph_to_json.argtypes = [vp, C.POINTER(sz)]
+        L.och_graph_to_json.restype = vp
+        L.och_free.argtypes = [vp]
+        L.och_free.restype = None
+        L.och_graph_from_json.argtypes = [vp, C.c_char_p, sz]
+        L.och_graph_save_json.argtypes = [vp, C.c_char_p]
+        L.och_graph_load_json.argtypes = [vp, C.c_char_p]
+        L.och_graph_node_table.argtypes = [vp, vp, vp, vp, vp]
+        L.och_graph_node_table.restype = None
+        L.och_graph_node_payload.argtypes = [vp, sz, vp, vp, vp, vp, vp]
+        L.och_graph_node_path.argtypes = [vp, sz]
+        L.och_graph_node_path.restype = C.c_char_p
+        L.och_graph_set_node_path.argtypes = [vp, sz, C.c_char_p]
+        L.och_graph_num_models.argtypes = [vp]
+        L.och_graph_num_models.restype = sz
+        L.och_graph_get_model.argtypes = [vp, u32, _f64p]
+        L.och_surface_save_ply.argtypes = [vp, C.c_char_p]
+        L.och_surface_load_ply.argtypes = [vp, C.c_char_p]
+        L.och_surface_num_clouds.argtypes = [vp]
+        L.och_surface_num_clouds.restype = sz
+        L.och_surface_cloud_sizes.argtypes = [vp, _u64p]
+        L.och_surface_cloud_sizes.restype = None
+        L.och_surface_set_clouds.argtypes = [vp, sz, _u64p, _f64p]
+        L.och_surface_set_clouds.restype = None
+        L.och_checkpoint_validate.argtypes = [C.c_char_p]
+        L.och_checkpoint_save.argtypes = [C.c_char_p, vp, C.POINTER(vp), sz, C.c_char_p, _f64p]
+        L.och_checkpoint_load.argtypes = [C.c_char_p, vp]
+        L.och_checkpoint_load.restype = vp
+        L.och_checkpoint_destroy.argtypes = [vp]
+        L.och_checkpoint_destroy.restype = None
+        L.och_checkpoint_num_surfaces.argtypes = [vp]
+        L.och_checkpoint_num_surfaces.restype = sz
+        L.och_checkpoint_state.argtypes = [vp]
+        L.och_checkpoint_state.restype = C.c_char_p
+        L.och_checkpoint_info.argtypes = [vp, _f64p]
+        L.och_checkpoint_info.restype = None
+        L.och_checkpoint_get_surface.argtypes = [vp, sz, vp]
         _lib = L
     return _lib
 
@@ -232,6 +269,70 @@ class Surface:
         return self
 
 
+    def clouds(self):
+        """The surface's point clouds one by one (arrays() concatenates them)."""
+        n = self.L.och_surface_num_clouds(self.h)
+        sizes = np.zeros(max(n, 1), np.uint64)
+        self.L.och_surface_cloud_sizes(self.h, sizes)
+        pts, out, k = self.arrays()["cloud"], [], 0
+        for i in range(n):
+            out.append(pts[k:k + int(sizes[i])].copy())
+            k += int(sizes[i])
+        return out
+
+    def set_clouds(self, clouds):
+        sizes = np.array([len(c) for c in clouds] or [0], np.uint64)
+        xyz = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float64).reshape(-1, 3) for c in clouds])
+                                   if len(clouds) and sizes.sum() else np.zeros((1, 3)))
+        self.L.och_surface_set_clouds(self.h, len(clouds), sizes, xyz)
+        return self
+
+    def save_ply(self, path):
+        """serialize(MeshGraph, ostream) of the reference (ASCII PLY, src/io/serialize_MeshGraph.cpp)."""
+        if self.L.och_surface_save_ply(self.h, str(path).encode()) != 0:
+            raise IOError("cannot write %s" % path)
+
+    def load_ply(self, path):
+        if self.L.och_surface_load_ply(self.h, str(path).encode()) != 0:
+            raise IOError("%s is not a surface PLY of the reference's layout" % path)
+        return self
+
+
+def validate_checkpoint(path):
+    """validateCheckpoint (src/io/checkpoint.cpp:318-337)."""
+    return bool(load().och_checkpoint_validate(str(path).encode()))
+
+
+def save_checkpoint(path, graph, surfaces=(), state="INITIAL_PROCESSING", state_run_count=0, origin=(0.0, 0.0)):
+    """saveCheckpoint (src/io/checkpoint.cpp:155-231): metadata.json, graph.json, surface_<i>.ply, pointcloud_<i>_<j>.xyz."""
+    L = load()
+    arr = (C.c_void_p * max(len(surfaces), 1))(*[s.h for s in surfaces])
+    info = np.array([state_run_count, origin[0], origin[1], 0.0])
+    if L.och_checkpoint_save(str(path).encode(), graph.h, arr, len(surfaces), state.encode(), info) != 0:
+        raise IOError(L.och_last_error(graph.h).decode())
+
+
+def load_checkpoint(path):
+    """loadCheckpoint (src/io/checkpoint.cpp:233-316).  Returns (Graph, [Surface], info dict)."""
+    L = load()
+    g = Graph()
+    cp = L.och_checkpoint_load(str(path).encode(), g.h)
+    if not cp:
+        raise IOError(L.och_last_error(g.h).decode())
+    try:
+        surfaces = []
+        for i in range(L.och_checkpoint_num_surfaces(cp)):
+            s = Surface()
+            L.och_checkpoint_get_surface(cp, i, s.h)
+            surfaces.append(s)
+        info = np.zeros(4)
+        L.och_checkpoint_info(cp, info)
+        meta = dict(state=L.och_checkpoint_state(cp).decode(), state_run_count=int(info[0]), origin=(info[1], info[2]))
+    finally:
+        L.och_checkpoint_destroy(cp)
+    return g, surfaces, meta
+
+
 def rebuild_mesh(cam_xyz, previous=None, minimal=False):
     """rebuildMesh / buildMinimalMesh of the host library (no device involved)."""
     cam_xyz = np.ascontiguousarray(cam_xyz, np.float64).reshape(-1, 3)
@@ -316,6 +417,68 @@ class Graph:
         if getattr(self, "h", None):
             self.L.och_graph_destroy(self.h)
             self.h = None
+
+    # ---- graph.json (src/io/serialize_MeasurementGraph.cpp, src/io/deserialize_MeasurementGraph.cpp)
+    def to_json(self):
+        n = C.c_size_t(0)
+        ptr = self.L.och_graph_to_json(self.h, C.byref(n))
+        if not ptr:
+            raise MemoryError("serialize failed")
+        try:
+            return C.string_at(ptr, n.value).decode("utf-8")
+        finally:
+            self.L.och_free(ptr)
+
+    def _refresh_ids(self):
+        ids = np.zeros(max(self.L.och_graph_num_nodes(self.h), 1), np.uint64)
+        self.L.och_graph_node_ids(self.h, ids)
+        self.node_ids = [int(i) for i in ids[:self.L.och_graph_num_nodes(self.h)]]
+
+    def from_json(self, text):
+        """deserialize(json, graph): replaces this graph.  Raises ValueError on anything but a version-1 document."""
+        raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        if self.L.och_graph_from_json(self.h, raw, len(raw)) != 0:
+            raise ValueError(self.L.och_last_error(self.h).decode())
+        self._refresh_ids()
+        return self
+
+    def save_json(self, path):
+        if self.L.och_graph_save_json(self.h, str(path).encode()) != 0:
+            raise IOError(self.L.och_last_error(self.h).decode())
+
+    def load_json(self, path):
+        if self.L.och_graph_load_json(self.h, str(path).encode()) != 0:
+            raise ValueError(self.L.och_last_error(self.h).decode())
+        self._refresh_ids()
+        return self
+
+    def node_table(self):
+        """Per node in graph order: id, index into models(), number of features, number of sparse features."""
+        n = self.L.och_graph_num_nodes(self.h)
+        ids, mi = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint32)
+        nf, ns = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64)
+        self.L.och_graph_node_table(self.h, ids.ctypes.data, mi.ctypes.data, nf.ctypes.data, ns.ctypes.data)
+        return dict(id=ids[:n], model=mi[:n], features=nf[:n], sparse=ns[:n])
+
+    def node_payload(self, index):
+        """Features (loc, strength, desc), position, orientation and path of the index-th node."""
+        n = int(self.node_table()["features"][index])
+        loc, st, de = np.zeros((max(n, 1), 2)), np.zeros(max(n, 1), np.float32), np.zeros((max(n, 1), 8), np.uint64)
+        pos, ori = np.zeros(3), np.zeros(4)
+        self.L.och_graph_node_payload(self.h, index, loc.ctypes.data, st.ctypes.data, de.ctypes.data, pos.ctypes.data,
+                                      ori.ctypes.data)
+        return dict(loc=loc[:n], strength=st[:n], desc=de[:n], position=pos, orientation=ori,
+                    path=self.L.och_graph_node_path(self.h, index).decode("utf-8"))
+
+    def set_node_path(self, index, path):
+        self.L.och_graph_set_node_path(self.h, index, path.encode("utf-8"))
+
+    def models(self):
+        """The graph's camera models: rows of och_graph_add_model's ten numbers followed by the model id."""
+        out = np.zeros((self.L.och_graph_num_models(self.h), 11))
+        for i in range(len(out)):
+            self.L.och_graph_get_model(self.h, i, out[i])
+        return out
 
     def __del__(self):
         try:

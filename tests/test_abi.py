@@ -32,6 +32,16 @@ def test_library_exports_every_declared_symbol(libpath):
         assert hasattr(lib, name), f"{name} declared in include/ochip.h but not exported"
 
 
+def test_host_library_exports_every_symbol_of_oc_host_h():
+    """include/oc_host.h is the second header of the boundary: liboc_host.so must export all of it."""
+    text = open(os.path.join(ROOT, "include", "oc_host.h")).read()
+    names = sorted(set(re.findall(r"\b(och_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) > 60
+    lib = ctypes.CDLL(build.build_host())
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
 def test_struct_layouts_match_header():
     assert capi.PAIR_DTYPE.itemsize == 8
     assert capi.MATCH_DTYPE.itemsize == 8
