@@ -226,6 +226,15 @@ extern "C"
     void och_checkpoint_info(const och_checkpoint *cp, double *info4);
     int och_checkpoint_get_surface(const och_checkpoint *cp, size_t index, och_surface *out);
 
+    /* ---- dense guided matching (opencalibration_amd/csrc/host/dense_stereo.hpp): densifyMesh(graph, surfaces) of
+     *      src/dense/dense_stereo.cpp:66-403 with the surface's mesh as surfaces[0]; the triangulated points are appended
+     *      to the surface as one more cloud.  stats10 (may be NULL): images, dense features, queries sent to the device,
+     *      accepted matches, tracks, points, then seconds {index build, rays + predictions, device, tracks}.  match_pairs
+     *      (may be NULL, match_cap pairs): accepted matches as measurement ids (image offset + dense feature number). */
+    int och_densify_mesh(och_graph *g, ochip_ctx *ctx, och_surface *surface, double *stats10, uint64_t *match_pairs,
+                         size_t match_cap);
+    uint32_t och_hilbert_xy2d(int order, int x, int y); /* types/hilbert.hpp:9-28 */
+
 #ifdef __cplusplus
 }
 #endif

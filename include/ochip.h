@@ -57,6 +57,7 @@ extern "C"
         OCHIP_K_RELAX_EVAL = 2,
         OCHIP_K_RELAX_SOLVE = 3,
         OCHIP_K_AKAZE = 4,
+        OCHIP_K_DENSE = 5,
         OCHIP_K_COUNT = 8
     };
 
@@ -332,6 +333,35 @@ extern "C"
     /* out[i] = x[i] op y[i] computed on the device with the hot-path kernels' compile flags:
      * op 0: x/y, 1: sqrt(x), 2: log(x), 3: x*y+x (unfused), 4: x+y.  Host pointers. */
     int ochip_debug_fp64(ochip_ctx *ctx, int op, const double *x, const double *y, size_t n, double *out);
+
+    /* ---- dense guided matching: the descriptor search of densifyMesh (src/dense/dense_stereo.cpp:245-283) ------------
+     * The index holds, for every image, its dense features sorted by the cell of a uniform grid over the image (cell edge
+     * cell_size > the search radius): feat_off (n_images + 1) offsets into desc8 (8 u64 per feature) / loc2 (x, y), per
+     * image a table of ncx * ncy + 1 cell starts (relative to the image's first feature) at cell_off[i] in cell_start,
+     * grid2 = {ncx, ncy} and origin2 = the grid's corner per image; a feature at (x, y) lies in cell
+     * (floor((x - ox) / cell_size), floor((y - oy) / cell_size)).  A query names a feature of the index (its descriptor is
+     * the probe), the image to search and the predicted pixel; the result is the nearest and second nearest Hamming
+     * distance among that image's features with squared pixel distance < radius^2, the nearest one's position in the
+     * image's sorted order, and how many features the disc held.  0xFFFF = no such neighbour. */
+    typedef struct ochip_dense_index ochip_dense_index;
+    typedef struct ochip_dense_query
+    {
+        uint32_t src_feature; /* position in the index (all images concatenated) */
+        uint32_t cand_image;
+        double px, py;
+    } ochip_dense_query;
+    typedef struct ochip_dense_result
+    {
+        uint32_t best_feature; /* position within cand_image's features */
+        uint16_t best_count, second_count;
+        uint32_t nearby;
+    } ochip_dense_result;
+    int ochip_dense_index_create(ochip_ctx *ctx, uint32_t n_images, const uint64_t *feat_off, const uint64_t *desc8,
+                                 const double *loc2, const uint64_t *cell_off, const uint32_t *cell_start, const int32_t *grid2,
+                                 const double *origin2, double cell_size, ochip_dense_index **out);
+    void ochip_dense_index_destroy(ochip_dense_index *ix);
+    int ochip_dense_match(ochip_dense_index *ix, const ochip_dense_query *queries, uint64_t n_queries, double radius,
+                          ochip_dense_result *out);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@ EXPORTS = [
     "ochip_relaxg_get_state", "ochip_relaxg_evaluate",
     "ochip_profile_reset", "ochip_profile_get", "ochip_match_work", "ochip_relax_work",
     "ochip_debug_fp64",
+    "ochip_dense_index_create", "ochip_dense_index_destroy", "ochip_dense_match",
 ]
 
 _lib = None

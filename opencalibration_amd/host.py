@@ -168,6 +168,9 @@ def load():
         L.och_checkpoint_info.argtypes = [vp, _f64p]
         L.och_checkpoint_info.restype = None
         L.och_checkpoint_get_surface.argtypes = [vp, sz, vp]
+        L.och_densify_mesh.argtypes = [vp, vp, vp, _f64p, vp, sz]
+        L.och_hilbert_xy2d.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.och_hilbert_xy2d.restype = u32
         _lib = L
     return _lib
 
@@ -319,6 +322,7 @@ def load_checkpoint(path):
     cp = L.och_checkpoint_load(str(path).encode(), g.h)
     if not cp:
         raise IOError(L.och_last_error(g.h).decode())
+    g._refresh_ids()
     try:
         surfaces = []
         for i in range(L.och_checkpoint_num_surfaces(cp)):
@@ -451,6 +455,23 @@ class Graph:
             raise ValueError(self.L.och_last_error(self.h).decode())
         self._refresh_ids()
         return self
+
+    def densify_mesh(self, ctx, surface, want_matches=False, match_cap=1 << 22):
+        """densifyMesh (src/dense/dense_stereo.cpp:66-403): dense guided matching on the device against `surface`'s mesh;
+        the triangulated points become one more cloud of `surface`.  Returns the stats (and the accepted matches)."""
+        stats = np.zeros(10)
+        pairs = np.zeros((match_cap if want_matches else 1, 2), np.uint64)
+        rc = self.L.och_densify_mesh(self.h, ctx.h, surface.h, stats, pairs.ctypes.data if want_matches else None,
+                                     match_cap if want_matches else 0)
+        if rc != 0:
+            raise capi.OchipError("densify failed: " + self.L.och_last_error(self.h).decode())
+        names = ["images", "dense_features", "queries", "matches", "tracks", "points", "index_s", "rays_s", "device_s", "tracks_s"]
+        out = dict(zip(names, stats.tolist()))
+        for k in names[:6]:
+            out[k] = int(out[k])
+        if want_matches:
+            out["match_pairs"] = pairs[:min(out["matches"], match_cap)].copy()
+        return out
 
     def node_table(self):
         """Per node in graph order: id, index into models(), number of features, number of sparse features."""
@@ -613,6 +634,8 @@ class Graph:
         RELAX_EXCHANGE_FN (parallel.relax_exchange builds one on torch.distributed) and every rank gets the same,
         bit-identical result."""
         ori = np.ascontiguousarray(orientations, np.float64).copy()
+        if ori.shape != (self.num_nodes, 4):
+            raise ValueError("orientations must be %d x 4, got %r" % (self.num_nodes, ori.shape))
         plane, summary = np.zeros(9), np.zeros(8)
         if shard is None:
             rc = self.L.och_graph_relax_ground_plane(self.h, ctx.h, ori, plane, summary)

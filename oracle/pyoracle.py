@@ -440,6 +440,34 @@ class RxSurface:
         return t, tri, int(steps[0])
 
 
+def densify_mesh(positions, orientations, models10, features, num_sparse, surface, match_cap=1 << 22):
+    """densifyMesh restated (oracle/dense.cpp).  features: per image (loc k x 2, desc k x 8 u64); models10: one row per
+    image.  The merged points are appended to `surface` (an RxSurface) and returned with the accepted matches."""
+    L = _rx()
+    n = len(features)
+    off = np.concatenate([[0], np.cumsum([len(f[0]) for f in features])]).astype(np.uint64)
+    loc = np.ascontiguousarray(np.concatenate([np.asarray(f[0], np.float64).reshape(-1, 2) for f in features]))
+    desc = np.ascontiguousarray(np.concatenate([np.asarray(f[1], np.uint64).reshape(-1, 8) for f in features]))
+    pairs = np.zeros((match_cap, 2), np.uint64)
+    points = np.zeros((int(off[-1]) + 1, 3))
+    counts = np.zeros(3, np.uint64)
+    L.ocx_densify.argtypes = [C.c_size_t, f64p, f64p, f64p, u64p, f64p, u64p, u64p, C.c_void_p, C.c_void_p, C.c_size_t,
+                              C.c_void_p, C.c_size_t, u64p]
+    L.ocx_densify.restype = None
+    L.ocx_densify(n, np.ascontiguousarray(positions, np.float64), np.ascontiguousarray(orientations, np.float64),
+                  np.ascontiguousarray(models10, np.float64).reshape(n, 10), off, loc, desc,
+                  np.ascontiguousarray(num_sparse, np.uint64), surface.h, pairs.ctypes.data, match_cap, points.ctypes.data,
+                  len(points), counts)
+    return dict(matches=int(counts[0]), tracks=int(counts[1]), points=points[:int(counts[2])].copy(),
+                match_pairs=pairs[:min(int(counts[0]), match_cap)].copy())
+
+
+def hilbert_xy2d(order, x, y):
+    L = lib()
+    L.ocx_hilbert_xy2d.restype = C.c_uint32
+    return int(L.ocx_hilbert_xy2d(int(order), int(x), int(y)))
+
+
 def rebuild_mesh(cam_xyz, prev=None, minimal=False):
     cam_xyz = np.ascontiguousarray(cam_xyz, np.float64).reshape(-1, 3)
     s = RxSurface()

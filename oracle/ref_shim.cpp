@@ -11,6 +11,7 @@
 #include <opencalibration/combinatorics/interleave.hpp>
 #include <opencalibration/geometry/KMeans.hpp>
 #include <opencalibration/relax/grid_filter.hpp>
+#include <opencalibration/types/hilbert.hpp>
 #include <opencalibration/types/union_find.hpp>
 
 #include <algorithm>
@@ -144,6 +145,38 @@ size_t ref_interleave3(const uint64_t *a, size_t na, const uint64_t *b, size_t n
     for (size_t i = 0; i < r.size(); i++)
         out[i] = r[i];
     return r.size();
+}
+
+// the Hilbert index of densifyMesh's feature walk (types/hilbert.hpp)
+uint32_t ref_hilbert_xy2d(int order, int x, int y)
+{
+    return opencalibration::xy2d(order, x, y);
+}
+
+// the 3-D nearest-camera query of densifyMesh (dense_stereo.cpp:104-109,212-213): payloads of the k nearest points
+size_t ref_knn3(const double *xyz, size_t n, const double *query3, size_t k, uint64_t *out)
+{
+    jk::tree::KDTree<size_t, 3, 8> tree;
+    for (size_t i = 0; i < n; i++)
+        tree.addPoint({xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}, i);
+    auto searcher = tree.searcher();
+    const auto &res = searcher.search({query3[0], query3[1], query3[2]}, std::numeric_limits<double>::max(), k);
+    for (size_t i = 0; i < res.size(); i++)
+        out[i] = res[i].payload;
+    return res.size();
+}
+
+// the disc query around a predicted pixel (dense_stereo.cpp:250-252): payloads inside, in the tree's order
+size_t ref_ball2(const double *xy, size_t n, const double *query2, double radius_sq, uint64_t *out)
+{
+    jk::tree::KDTree<size_t, 2, 8> tree;
+    for (size_t i = 0; i < n; i++)
+        tree.addPoint({xy[2 * i], xy[2 * i + 1]}, i);
+    auto searcher = tree.searcher();
+    const auto &res = searcher.search({query2[0], query2[1]}, radius_sq, std::numeric_limits<size_t>::max());
+    for (size_t i = 0; i < res.size(); i++)
+        out[i] = res[i].payload;
+    return res.size();
 }
 
 } // extern "C"
