@@ -235,6 +235,21 @@ extern "C"
                          size_t match_cap);
     uint32_t och_hilbert_xy2d(int order, int x, int y); /* types/hilbert.hpp:9-28 */
 
+    /* ---- mesh refinement (opencalibration_amd/csrc/host/refine_mesh.hpp; src/surface/refine_mesh.cpp:15-909) ----------
+     * refineByPointDensity / refineAtPoint on the surface's mesh with its clouds; countPointsPerTriangle as rows of
+     * (three vertices, {count, distance variance}) in the order the triangles first receive a point; the triangle under
+     * points (TriangleLocator).  och_mesh_refinement_run: the MESH_REFINEMENT state of the pipeline
+     * (src/pipeline/pipeline.cpp:666-819) - minimal mesh, RelaxStage {ORIENTATION, GROUND_MESH} at grid fraction
+     * 0.1 / 2^level on the device, count, refine or advance the level - repeated until the state is left or max_steps
+     * runs were made; log8 rows {level, grid fraction, gsd, triangles above threshold, max points per triangle,
+     * triangles created, mesh vertices, repeat flag}.  Returns the steps made, -1 + och_last_error(g) on a device error. */
+    size_t och_refine_by_point_density(och_surface *s, size_t max_points_per_triangle, double min_distance_variance,
+                                       int max_iterations, double min_triangle_size);
+    size_t och_refine_at_point(och_surface *s, double x, double y, int levels);
+    size_t och_count_points_per_triangle(const och_surface *s, uint64_t *tri3, double *stats2, size_t cap);
+    void och_surface_locate(const och_surface *s, const double *xy, size_t n, uint64_t *tri3);
+    int och_mesh_refinement_run(och_graph *g, ochip_ctx *ctx, och_surface *surface, int max_steps, double *log8);
+
 #ifdef __cplusplus
 }
 #endif

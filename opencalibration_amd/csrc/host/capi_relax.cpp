@@ -431,29 +431,7 @@ int och_relax_stage_run(och_graph *g, ochip_ctx *ctx, const uint64_t *node_ids, 
         stage.setSurfaceModels({previous->s});
     const size_t n_groups = stage.num_groups();
     auto runners = stage.get_runners(ctx, g->graph);
-    {
-        // the reference runs the runners under OpenMP (pipeline.cpp:42-49); here a few host threads, one per device context
-        size_t next = 0;
-        std::mutex m;
-        std::vector<std::thread> pool;
-        const size_t T = std::min<size_t>(runners.size(), 4);
-        for (size_t t = 0; t < T; t++)
-            pool.emplace_back([&]() {
-                while (true)
-                {
-                    size_t i;
-                    {
-                        std::lock_guard<std::mutex> lock(m);
-                        if (next >= runners.size())
-                            return;
-                        i = next++;
-                    }
-                    runners[i]();
-                }
-            });
-        for (auto &t : pool)
-            t.join();
-    }
+    run_parallel(runners);
     stage.finalize(g->graph);
     if (!stage.error().empty())
     {

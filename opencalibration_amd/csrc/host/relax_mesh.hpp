@@ -32,6 +32,7 @@ class MeshGraph
     size_t addNode(double x, double y, double z)
     {
         nodes.push_back(MeshNode{{x, y, z}});
+        node_edges.emplace_back();
         return nodes.size() - 1;
     }
     size_t addEdge(MeshEdge e, size_t source, size_t dest)
@@ -40,7 +41,23 @@ class MeshGraph
         e.dest = dest;
         edges.push_back(e);
         _lookup.emplace(key(source, dest), edges.size() - 1);
+        if (source < node_edges.size())
+            node_edges[source].push_back(edges.size() - 1);
+        if (dest < node_edges.size() && dest != source)
+            node_edges[dest].push_back(edges.size() - 1);
         return edges.size() - 1;
+    }
+    // mesh refinement (refine_mesh.cpp) removes and adds edges: it rewrites edges / node_edges and then calls this
+    void rebuild_lookup()
+    {
+        _lookup.clear();
+        for (size_t i = 0; i < edges.size(); i++)
+            if (edges[i].source != MeshEdge::NONE)
+                _lookup.emplace(key(edges[i].source, edges[i].dest), i);
+    }
+    void forget_edge(size_t source, size_t dest)
+    {
+        _lookup.erase(key(source, dest));
     }
     const MeshEdge *getEdge(size_t source, size_t dest) const
     {
@@ -62,6 +79,9 @@ class MeshGraph
     }
     std::vector<MeshNode> nodes;
     std::vector<MeshEdge> edges;
+    // Node::getEdges(): the ids of the edges at a vertex in the order the reference's ankerl::unordered_dense set holds
+    // them (insertion order; an erase moves the last element into the hole)
+    std::vector<std::vector<size_t>> node_edges;
 
   private:
     static uint64_t key(size_t s, size_t d)

@@ -1,4 +1,7 @@
 #include "relax_stage.hpp"
+#include "refine_mesh.hpp"
+
+#include <thread>
 
 #include "relax_util.hpp"
 
@@ -715,125 +718,29 @@ std::vector<std::vector<size_t>> relax_partition(const MeasurementGraph &graph, 
 }
 
 // ------------------------------------------------------------------------------------------------------ merged surfaces
-namespace
+void run_parallel(std::vector<std::function<void()>> &runners, size_t threads)
 {
-// which triangle (edge, side) of a mesh lies under a point: start at the triangle with the nearest centroid, cross the
-// most violated edge until the point is inside (TriangleLocator, refine_mesh.cpp:572-711)
-struct tri_id
-{
-    size_t edge = MeshEdge::NONE;
-    int side = 0;
-};
-class TriangleLocator
-{
-  public:
-    explicit TriangleLocator(const MeshGraph &m) : _m(m)
-    {
-        for (size_t e = 0; e < m.edges.size(); e++)
-            for (int side = 0; side < 2; side++)
+    size_t next = 0;
+    std::mutex m;
+    std::vector<std::thread> pool;
+    const size_t T = std::min<size_t>(runners.size(), threads);
+    for (size_t t = 0; t < T; t++)
+        pool.emplace_back([&]() {
+            while (true)
             {
-                if (side == 1 && m.edges[e].border)
-                    continue;
-                size_t v[3];
-                if (!verts(tri_id{e, side}, v))
-                    continue;
-                _tri.push_back(tri_id{e, side});
-                _cx.push_back((m.nodes[v[0]].location[0] + m.nodes[v[1]].location[0] + m.nodes[v[2]].location[0]) / 3.0);
-                _cy.push_back((m.nodes[v[0]].location[1] + m.nodes[v[1]].location[1] + m.nodes[v[2]].location[1]) / 3.0);
-            }
-    }
-    bool verts(const tri_id &t, size_t v[3]) const
-    {
-        if (t.edge >= _m.edges.size())
-            return false;
-        const MeshEdge &e = _m.edges[t.edge];
-        v[0] = e.source;
-        v[1] = e.dest;
-        v[2] = e.triangleOppositeNodes[t.side];
-        return v[2] < _m.nodes.size();
-    }
-    tri_id find(double x, double y) const
-    {
-        if (_tri.empty())
-            return tri_id();
-        size_t best = 0;
-        double bd = std::numeric_limits<double>::infinity();
-        for (size_t i = 0; i < _tri.size(); i++)
-        {
-            const double dx = _cx[i] - x, dy = _cy[i] - y, d = dx * dx + dy * dy;
-            if (d < bd)
-            {
-                bd = d;
-                best = i;
-            }
-        }
-        tri_id cur = _tri[best];
-        for (int step = 0; step < 100; step++)
-        {
-            size_t v[3];
-            if (!verts(cur, v))
-                return tri_id();
-            const double *p0 = _m.nodes[v[0]].location, *p1 = _m.nodes[v[1]].location, *p2 = _m.nodes[v[2]].location;
-            auto sign = [](double px, double py, double ax, double ay, double bx, double by) {
-                return (px - bx) * (ay - by) - (ax - bx) * (py - by);
-            };
-            const double d[3] = {sign(x, y, p0[0], p0[1], p1[0], p1[1]), sign(x, y, p1[0], p1[1], p2[0], p2[1]),
-                                 sign(x, y, p2[0], p2[1], p0[0], p0[1])};
-            const bool neg = d[0] < 0 || d[1] < 0 || d[2] < 0, pos = d[0] > 0 || d[1] > 0 || d[2] > 0;
-            if (!(neg && pos))
-                return cur;
-            const bool expect_positive = ((d[0] < 0) + (d[1] < 0) + (d[2] < 0)) < 2;
-            double worst = 0;
-            int leave = -1;
-            for (int i = 0; i < 3; i++)
-            {
-                if (d[i] == 0)
+                size_t i;
                 {
-                    worst = 0.000001;
-                    leave = i;
+                    std::lock_guard<std::mutex> lock(m);
+                    if (next >= runners.size())
+                        return;
+                    i = next++;
                 }
-                else if ((d[i] > 0) != expect_positive && std::abs(d[i]) > worst)
-                {
-                    worst = std::abs(d[i]);
-                    leave = i;
-                }
+                runners[i]();
             }
-            if (leave < 0)
-                return tri_id();
-            tri_id next;
-            if (leave == 0)
-            {
-                if (!_m.edges[cur.edge].border)
-                    next = tri_id{cur.edge, 1 - cur.side};
-            }
-            else
-            {
-                const size_t va = v[leave], vb = v[(leave + 1) % 3], opp = v[(leave + 2) % 3];
-                const MeshEdge *ce = _m.getEdge(va, vb);
-                if (!ce)
-                    ce = _m.getEdge(vb, va);
-                if (ce && !ce->border)
-                {
-                    const int side = ce->triangleOppositeNodes[0] == opp ? 0 : ce->triangleOppositeNodes[1] == opp ? 1 : -1;
-                    if (side >= 0)
-                        next = tri_id{(size_t)(ce - &_m.edges[0]), 1 - side};
-                }
-            }
-            if (next.edge == MeshEdge::NONE)
-                return tri_id();
-            cur = next;
-        }
-        // (the reference falls back to an exhaustive search here; a walk of 100 steps from the nearest centroid does
-        // not happen on a conforming mesh)
-        return tri_id();
-    }
-
-  private:
-    const MeshGraph &_m;
-    std::vector<tri_id> _tri;
-    std::vector<double> _cx, _cy;
-};
-} // namespace
+        });
+    for (auto &t : pool)
+        t.join();
+}
 
 surface_model mergeSurfaceModels(const std::vector<surface_model> &surfaces)
 {
@@ -854,16 +761,16 @@ surface_model mergeSurfaceModels(const std::vector<surface_model> &surfaces)
         for (const point_cloud &c : s.cloud)
             for (const auto &p : c)
             {
-                const tri_id t = loc.find(p[0], p[1]);
-                if (t.edge != MeshEdge::NONE)
-                    count[2 * t.edge + t.side]++;
+                const TriangleId t = loc.find(p[0], p[1]);
+                if (t.edgeId != MeshEdge::NONE)
+                    count[2 * t.edgeId + t.side]++;
             }
         std::vector<size_t> per_vertex(s.mesh.size_nodes(), 0);
         for (size_t e = 0; e < s.mesh.size_edges(); e++)
             for (int side = 0; side < 2; side++)
             {
                 size_t v[3];
-                if (count[2 * e + side] == 0 || !loc.verts(tri_id{e, side}, v))
+                if (count[2 * e + side] == 0 || !loc.vertices(TriangleId{e, side}, v))
                     continue;
                 for (int i = 0; i < 3; i++)
                     per_vertex[v[i]] += count[2 * e + side];

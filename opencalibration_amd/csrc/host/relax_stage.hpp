@@ -48,6 +48,9 @@ class RelaxGroup // include/opencalibration/relax/relax_group.hpp
 std::vector<std::vector<size_t>> relax_partition(const MeasurementGraph &graph, const std::vector<size_t> &node_ids,
                                                  size_t num_groups);
 
+// run_parallel (src/pipeline/pipeline.cpp:42-49): the runners on a few host threads (the reference: an OpenMP loop)
+void run_parallel(std::vector<std::function<void()>> &runners, size_t threads = 4);
+
 // mergeSurfaceModels (src/surface/refine_mesh.cpp:916-1016): the groups relaxed copies of one mesh; every vertex becomes
 // the mean of the groups' positions weighted by the number of cloud points of the group in the triangles around it.
 surface_model mergeSurfaceModels(const std::vector<surface_model> &surfaces);

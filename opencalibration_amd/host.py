@@ -169,6 +169,15 @@ def load():
         L.och_checkpoint_info.restype = None
         L.och_checkpoint_get_surface.argtypes = [vp, sz, vp]
         L.och_densify_mesh.argtypes = [vp, vp, vp, _f64p, vp, sz]
+        L.och_refine_by_point_density.argtypes = [vp, sz, C.c_double, C.c_int, C.c_double]
+        L.och_refine_by_point_density.restype = sz
+        L.och_refine_at_point.argtypes = [vp, C.c_double, C.c_double, C.c_int]
+        L.och_refine_at_point.restype = sz
+        L.och_count_points_per_triangle.argtypes = [vp, _u64p, _f64p, sz]
+        L.och_count_points_per_triangle.restype = sz
+        L.och_surface_locate.argtypes = [vp, _f64p, sz, _u64p]
+        L.och_surface_locate.restype = None
+        L.och_mesh_refinement_run.argtypes = [vp, vp, vp, C.c_int, _f64p]
         L.och_hilbert_xy2d.argtypes = [C.c_int, C.c_int, C.c_int]
         L.och_hilbert_xy2d.restype = u32
         _lib = L
@@ -289,6 +298,27 @@ class Surface:
                                    if len(clouds) and sizes.sum() else np.zeros((1, 3)))
         self.L.och_surface_set_clouds(self.h, len(clouds), sizes, xyz)
         return self
+
+    def refine_by_point_density(self, max_points_per_triangle, min_distance_variance=0.0, max_iterations=10, min_triangle_size=0.0):
+        """refineByPointDensity (src/surface/refine_mesh.cpp:827-909) with the surface's own clouds; returns triangles created."""
+        return self.L.och_refine_by_point_density(self.h, max_points_per_triangle, min_distance_variance, max_iterations,
+                                                  min_triangle_size)
+
+    def refine_at_point(self, x, y, levels=1):
+        return self.L.och_refine_at_point(self.h, x, y, levels)
+
+    def count_points_per_triangle(self):
+        """countPointsPerTriangle: (vertices n x 3, counts n, distance variances n) in first-point order."""
+        cap = 2 * max(len(self.arrays()["edges"]), 1)
+        tri, st = np.zeros((cap, 3), np.uint64), np.zeros((cap, 2))
+        n = self.L.och_count_points_per_triangle(self.h, tri, st, cap)
+        return tri[:n], st[:n, 0].astype(np.int64), st[:n, 1]
+
+    def locate(self, xy):
+        xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+        tri = np.zeros((max(len(xy), 1), 3), np.uint64)
+        self.L.och_surface_locate(self.h, xy if len(xy) else np.zeros((1, 2)), len(xy), tri)
+        return tri[:len(xy)]
 
     def save_ply(self, path):
         """serialize(MeshGraph, ostream) of the reference (ASCII PLY, src/io/serialize_MeshGraph.cpp)."""
@@ -472,6 +502,16 @@ class Graph:
         if want_matches:
             out["match_pairs"] = pairs[:min(out["matches"], match_cap)].copy()
         return out
+
+    def mesh_refinement(self, ctx, surface=None, max_steps=40):
+        """The pipeline's MESH_REFINEMENT state (src/pipeline/pipeline.cpp:666-819) run to its end: returns (surface, log)."""
+        surface = Surface() if surface is None else surface
+        log = np.zeros((max_steps, 8))
+        n = self.L.och_mesh_refinement_run(self.h, ctx.h, surface.h, max_steps, log)
+        if n < 0:
+            raise capi.OchipError("mesh refinement failed: " + self.L.och_last_error(self.h).decode())
+        names = ["level", "grid_fraction", "gsd", "above_threshold", "max_points", "created", "vertices", "repeat"]
+        return surface, [dict(zip(names, row)) for row in log[:n].tolist()]
 
     def node_table(self):
         """Per node in graph order: id, index into models(), number of features, number of sparse features."""

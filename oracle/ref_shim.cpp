@@ -7,6 +7,7 @@
 //   combinatorics/interleave.hpp.  It lets the tests check the restated nearest-neighbour logic
 // (oracle/match.cpp hash grid; the pair selection of link_stage.cpp:22-38) against the reference's
 // own KD-tree, including its tie behaviour.
+#include <ankerl/unordered_dense.h>
 #include <jk/KDTree.h>
 #include <opencalibration/combinatorics/interleave.hpp>
 #include <opencalibration/geometry/KMeans.hpp>
@@ -177,6 +178,24 @@ size_t ref_ball2(const double *xy, size_t n, const double *query2, double radius
     for (size_t i = 0; i < res.size(); i++)
         out[i] = res[i].payload;
     return res.size();
+}
+
+// ankerl::unordered_dense::set<size_t>: the iteration order after a sequence of inserts (op >= 0: insert op) and erases
+// (op < 0: erase -op - 1) - what the reference's mesh (DirectedGraph's edge map, a vertex's edge set) iterates in
+size_t ref_dense_set_order(const int64_t *ops, size_t n, uint64_t *out)
+{
+    ankerl::unordered_dense::set<size_t> s;
+    for (size_t i = 0; i < n; i++)
+    {
+        if (ops[i] >= 0)
+            s.insert((size_t)ops[i]);
+        else
+            s.erase((size_t)(-ops[i] - 1));
+    }
+    size_t k = 0;
+    for (size_t v : s)
+        out[k++] = v;
+    return k;
 }
 
 } // extern "C"
