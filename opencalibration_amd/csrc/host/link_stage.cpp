@@ -67,17 +67,19 @@ void LinkStage::init(const MeasurementGraph &graph, const std::vector<size_t> &n
             double d = 0;
             d += dx * dx;
             d += dy * dy;
-            dist[j] = {d, nodes[j].id};
+            dist[j] = {d, j};
         }
         const size_t k = std::min<size_t>(10, dist.size());
-        std::partial_sort(dist.begin(), dist.begin() + k, dist.end(),
-                          [](const auto &a, const auto &b) { return a.first < b.first; });
+        // a total order: distance, then the place in the graph (equidistant neighbours are the rule on a regular survey
+        // grid; the reference's KD-tree breaks such ties by its traversal - here, and in parallel.knn_pairs, the image
+        // added first wins, so the C++ stage and the Python sharding always agree on the pair set)
+        std::partial_sort(dist.begin(), dist.begin() + k, dist.end());
         NodeLinks link;
         link.node_id = node_id;
         link.link_ids.reserve(k);
         for (size_t j = 0; j < k; j++)
-            if (dist[j].second != node_id)
-                link.link_ids.push_back(dist[j].second);
+            if (nodes[dist[j].second].id != node_id)
+                link.link_ids.push_back(nodes[dist[j].second].id);
         _links.emplace_back(std::move(link));
     }
     timers.link_init += since(t0);

@@ -59,6 +59,20 @@ extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const ui
     link.init(g->graph, ids);
     link.prepare_index(g->graph);
     const auto &links = link.links();
+    {
+        // images of earlier calls are link partners of the new ones (the reference links a batch against everything
+        // already in the graph, link_stage.cpp:26-35): their 40 px subsets and rays are prepared here, no range waits
+        // for them
+        std::unordered_map<size_t, char> mine;
+        for (size_t id : ids)
+            mine.emplace(id, 1);
+        std::vector<size_t> earlier;
+        for (const auto &n : g->graph.nodes())
+            if (!mine.count(n.id) && !n.payload.features.empty())
+                earlier.push_back(n.id);
+        if (!earlier.empty())
+            link.prepare_images(g->graph, earlier, omp_get_max_threads());
+    }
 
     // ---- ranges of links and the images each one waits for
     std::unordered_map<size_t, uint32_t> image_of; // node id -> image index

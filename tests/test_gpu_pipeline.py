@@ -99,3 +99,39 @@ def test_images_to_orientations(monkeypatch, oracle):
     assert np.max(err) < 5e-3, err
     ctx.synth_views_free(images)
     ctx.close()
+
+
+def test_second_batch_links_against_the_first(monkeypatch):
+    """Incremental loading, as the reference's pipeline does it batch by batch: the overlapped load + link of a SECOND
+    batch must link the new images against the ones already in the graph (their subsets and rays are prepared although
+    no range waits for them) - the same graph as load_images + link over the same two batches."""
+    from opencalibration_amd import pipeline
+
+    grid = synth.make_grid(seed=3, rows=2, cols=4, feats=64)
+    ctx = capi.Context(0)
+    images, (n, h, w) = pipeline.synthetic_views(ctx, grid, seed=11)
+    half, bytes_per_image = n // 2, h * w * 3
+    start = pipeline.perturbed_orientations(grid, 0.1, 4)
+
+    def batches(g, overlapped):
+        mid = g.add_model(grid.model)
+        for lo, hi in ((0, half), (half, n)):
+            ptr = images + lo * bytes_per_image
+            if overlapped:
+                g.load_link_images(ctx, ptr, mid, grid.position[lo:hi], start[lo:hi], 30000, device_shape=(hi - lo, h, w))
+            else:
+                g.load_images(ctx, ptr, mid, grid.position[lo:hi], 30000, device_shape=(hi - lo, h, w))
+                g.set_orientations(start[:hi])
+                g.link(ctx, node_ids=g.node_ids[lo:hi])
+        return _edge_signature(g)
+
+    monkeypatch.setenv("OCHIP_EXTRACT_CHUNK", "2")
+    a, b = host.Graph(), host.Graph()
+    sa, sb = batches(a, True), batches(b, False)
+    assert a.node_ids == b.node_ids and sa == sb
+    first = set(a.node_ids[:half])
+    crossing = [s for s in sa if (s[0] in first) != (s[1] in first)]
+    assert len(crossing) >= half and all(s[3] > 6 for s in crossing)        # edges between the batches, with inliers
+    a.close(), b.close()
+    ctx.synth_views_free(images)
+    ctx.close()
