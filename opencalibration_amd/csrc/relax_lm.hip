@@ -1,10 +1,12 @@
 // libochip.so — the shared part of the relax solve (see relax_lm.hpp): Levenberg-Marquardt trust-region loop with
 // Ceres' semantics and the linear solve of (J'J + D'D) y = J'r on the device.
 //
-// The reduced system is stored dense (row-major) and factored by a blocked right-looking Cholesky that only visits the
-// rows inside the block envelope (relax_lm.hpp: lm_envelope): 64 x 64 diagonal block + its inverse in registers
-// (chol_diag_kernel), panel = block x inverse and trailing update as v_mfma_f64_16x16x4f64 GEMMs.  The augmented row
-// carries the forward solve; the backward substitution is one workgroup walking the row envelope.
+// The reduced system is stored dense (row-major) and factored inside its block envelope (relax_lm.hpp: lm_envelope) by
+// ONE launch per factorisation: chol_tiles_kernel, a left-looking tile Cholesky whose workgroups hand 64 x 64 tiles to
+// each other through flags (products on v_mfma_f64_16x16x4f64, the diagonal block and its inverse in registers).  The
+// augmented row carries the forward solve; the backward substitution is one workgroup walking the row envelope.
+// The launch chain it replaced (chol_diag_kernel / chol_panel_kernel / chol_update_mfma_kernel, three dependent launches
+// per block column) stays behind OCHIP_CHOL_CHAIN=1 for A/B runs.
 #include "relax_lm.hpp"
 
 #include <algorithm>
@@ -261,6 +263,247 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n,
                         A[(size_t)ar * n + ac] -= acc[i][j][e];
                 }
             }
+}
+
+// ---- the whole factorisation in ONE launch ------------------------------------------------------------------------
+// The chain above costs three dependent launches per 64-column block (141 at n = 3003): kernel time 55 us per block plus
+// the gaps between dependent launches.  Here the factorisation is a set of 64 x 64 tiles inside the same block envelope,
+// each computed ONCE by one workgroup (left-looking): tile (I, J) = A(I, J) - sum_K L(I, K) L(J, K)' over the column
+// blocks K < J whose envelope holds both, accumulated in the matrix cores' registers while the operands arrive; then the
+// diagonal tile is factored (the register kernel of chol_diag_kernel) and an off-diagonal tile is multiplied by the
+// inverse of its column's diagonal block.  Nothing is read-modified-written in HBM.  Workgroups claim tiles from a
+// list in which every tile follows the tiles it needs (rows of the dense tail first - their sums run along the whole
+// factorisation and must start early - then the band, column by column), so a claimed tile only ever waits for tiles that
+// are already running: no co-residency is required.  A tile is handed over as MI355X_MICROARCH.md prescribes
+// (per-XCD L2s are not coherent): write-through stores, every storing wave drained, barrier, ONE lane sets the tile's
+// flag with an agent-scope store; the consumer polls that word relaxed, ONE agent-scope acquire, drain, barrier, plain loads.
+struct chol_col
+{
+    int first_tile; // index of tile (J, J); the column's tiles follow: rows J + 1 .. bend - 1, then tail_start ..
+    int bend;       // end (exclusive) of the band's row blocks
+    int tail_start; // first tail row block that is not already in the band
+    int pad;
+};
+__device__ __forceinline__ int chol_tile_index(const chol_col *cols, int I, int J)
+{
+    const chol_col c = cols[J];
+    return c.first_tile + (I < c.bend ? I - J : (c.bend - J) + (I - c.tail_start));
+}
+__device__ __forceinline__ void store_through(double *p, double v) // global_store_dwordx2 sc1: write-through, agent scope
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const chol_col *__restrict__ cols,
+                                                         const int *__restrict__ kmin, const unsigned int *__restrict__ tiles,
+                                                         int n_tiles, int tb, unsigned int *sync, double *linv, int *fail)
+{
+    constexpr int KC = 32;
+    __shared__ double T[64][65];
+    __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
+    __shared__ double colA[2][NB], rowX[2][NB];
+    __shared__ int s_claim, s_ready;
+    unsigned int *flags = sync + 4;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int n_rows = n + 1; // the augmented row carries the forward solve
+    for (;;)
+    {
+        __syncthreads();
+        if (t == 0)
+            s_claim = (int)atomicAdd(&sync[0], 1u);
+        __syncthreads();
+        const int claim = s_claim;
+        if (claim >= n_tiles)
+            return;
+        const unsigned int ij = tiles[claim];
+        const int I = (int)(ij & 0xFFFFu), J = (int)(ij >> 16);
+        const int r0 = I * 64, c0 = J * 64;
+        const int nb = min(64, n - c0); // columns of this block column
+        const int k_begin = I < tb ? kmin[I] : (J >= tb ? 0 : kmin[J]);
+        v4f64 acc[2][2];
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++)
+                acc[i][j] = v4f64{0, 0, 0, 0};
+        int ready = k_begin; // steps whose operands are known to be complete (the same value in every thread)
+        for (int K = k_begin; K < J; K++)
+        {
+            if (K >= ready)
+            {
+                if (t == 0)
+                {
+                    // wait for the operands of step K, take along the following steps that are complete already,
+                    // ONE acquire for all of them
+                    int upto = K;
+                    for (;;)
+                    {
+                        const unsigned int *fa = flags + chol_tile_index(cols, I, upto);
+                        const unsigned int *fb = flags + chol_tile_index(cols, J, upto);
+                        const bool have = __hip_atomic_load(fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+                                          __hip_atomic_load(fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                        if (have)
+                        {
+                            if (++upto >= J || upto - K >= 16)
+                                break;
+                        }
+                        else if (upto > K)
+                            break;
+                        else
+                            __builtin_amdgcn_s_sleep(2);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    s_ready = upto;
+                }
+                __syncthreads();
+                ready = s_ready; // (rewritten only after every thread has passed the barriers of the loads below)
+            }
+            const int kc0 = K * 64;
+            for (int m0 = 0; m0 < 64; m0 += KC)
+            {
+                __syncthreads();
+                for (int e = t; e < 64 * KC; e += 256)
+                {
+                    const int r = e / KC, m = e % KC;
+                    Pi[r][m] = (r0 + r < n_rows) ? W[(size_t)(r0 + r) * n + kc0 + m0 + m] : 0.0;
+                    Pj[r][m] = (c0 + r < n_rows) ? W[(size_t)(c0 + r) * n + kc0 + m0 + m] : 0.0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < KC; kk += 4)
+                {
+                    const double a0 = Pi[wr + lr][kk + lk], a1 = Pi[wr + 16 + lr][kk + lk];
+                    const double b0 = Pj[wc + lr][kk + lk], b1 = Pj[wc + 16 + lr][kk + lk];
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+        // T = A(I, J) - acc (the tile's own entries were written by the launch before this one)
+        __syncthreads();
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++)
+                for (int e = 0; e < 4; e++)
+                {
+                    const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
+                    const double a = (r0 + r < n_rows && c < nb) ? W[(size_t)(r0 + r) * n + c0 + c] : 0.0;
+                    T[r][c] = a - acc[i][j][e];
+                }
+        __syncthreads();
+        if (I == J)
+        {
+            // the 64 x 64 diagonal block and its inverse in registers (chol_diag_kernel's layout and phases)
+            const int ty = t >> 4, tx = t & 15;
+            double a[4][4], x[4][4];
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                {
+                    const int i = ty + 16 * p, c = tx + 16 * q;
+                    const int lo = i > c ? i : c, hi = i > c ? c : i;
+                    a[p][q] = (lo < nb) ? T[lo][hi] : (i == c ? 1.0 : 0.0);
+                    x[p][q] = (i == c) ? 1.0 : 0.0;
+                }
+            // n not a multiple of 64: the augmented row shares this (last) tile with the diagonal block; it is a panel
+            // row, kept aside and multiplied by the inverse below
+            const bool has_aug = (r0 + nb == n) && nb < 64;
+            if (has_aug && t < 64)
+                Pi[t][0] = t < nb ? T[nb][t] : 0.0;
+            bool bad = false;
+            chol_diag_phase<0>(a, x, colA, rowX, ty, tx, nb, bad);
+            chol_diag_phase<1>(a, x, colA, rowX, ty, tx, nb, bad);
+            chol_diag_phase<2>(a, x, colA, rowX, ty, tx, nb, bad);
+            chol_diag_phase<3>(a, x, colA, rowX, ty, tx, nb, bad);
+            if (bad)
+                *fail = 1;
+            double *Li = linv + (size_t)J * NB * NB;
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                {
+                    const int i = ty + 16 * p, c = tx + 16 * q;
+                    if (i < nb && c <= i)
+                        store_through(&W[(size_t)(c0 + i) * n + c0 + c], a[p][q]);
+                    store_through(&Li[i * NB + c], (i < nb && c <= i) ? x[p][q] : ((i == c) ? 1.0 : 0.0));
+                }
+            if (has_aug)
+            {
+                __syncthreads();
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                    {
+                        const int i = ty + 16 * p, c = tx + 16 * q;
+                        T[i][c] = (i < nb && c <= i) ? x[p][q] : 0.0;
+                    }
+                __syncthreads();
+                if (t < nb) // y[c] = sum_m aug[m] Linv[c][m]
+                {
+                    double sum = 0;
+                    for (int m = 0; m <= t; m++)
+                        sum += Pi[m][0] * T[t][m];
+                    store_through(&W[(size_t)n * n + c0 + t], sum);
+                }
+            }
+        }
+        else
+        {
+            // X = T * Linv(J)': wait for the column's diagonal tile, then one more 64 x 64 x 64 product
+            if (t == 0)
+            {
+                const unsigned int *fd = flags + cols[J].first_tile;
+                while (__hip_atomic_load(fd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                    __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            const double *Li = linv + (size_t)J * NB * NB;
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = v4f64{0, 0, 0, 0};
+            for (int m0 = 0; m0 < 64; m0 += KC)
+            {
+                __syncthreads();
+                for (int e = t; e < 64 * KC; e += 256)
+                {
+                    const int r = e / KC, m = e % KC;
+                    Pi[r][m] = T[r][m0 + m];
+                    Pj[r][m] = Li[r * NB + m0 + m]; // X[i][c] = sum_m T[i][m] Linv[c][m]
+                }
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < KC; kk += 4)
+                {
+                    const double a0 = Pi[wr + lr][kk + lk], a1 = Pi[wr + 16 + lr][kk + lk];
+                    const double b0 = Pj[wc + lr][kk + lk], b1 = Pj[wc + 16 + lr][kk + lk];
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 2; j++)
+                    for (int e = 0; e < 4; e++)
+                    {
+                        const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
+                        if (r0 + r < n_rows && c < nb)
+                            store_through(&W[(size_t)(r0 + r) * n + c0 + c], acc[i][j][e]);
+                    }
+        }
+        // publish: every storing wave drained, barrier, one lane sets the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0)
+            __hip_atomic_store(flags + chol_tile_index(cols, I, J), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Backward substitution L' x = y by ONE workgroup, block by block from the bottom: x_k = L_kk^-T y_k out of the stored
@@ -540,6 +783,82 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
         return OCHIP_ENOMEM;
     if (!s->fail_chol && lm_dev_upload<int>(ctx, s->allocs, &s->fail_chol, nullptr, 1) != OCHIP_OK)
         return OCHIP_ENOMEM;
+
+    // ---- plan of the one-launch factorisation: the block envelope as tiles, their claim order
+    {
+        const int nn = n_in;
+        const int nbc = (nn + NB - 1) / NB, nbr = (nn + 1 + NB - 1) / NB, tb = std::min(s->env.tail_begin, nn) / NB;
+        std::vector<chol_col> cols((size_t)std::max(nbc, 1));
+        std::vector<int> kmin((size_t)std::max(nbr, 1), 0);
+        int n_tiles = 0;
+        for (int J = 0; J < nbc; J++)
+        {
+            int bend = std::max(J + 1, (std::min(s->env.env_end[J], s->env.tail_begin) + NB - 1) / NB);
+            if (J > 0)
+                bend = std::max(bend, cols[J - 1].bend); // fill stays inside a monotone envelope
+            bend = std::min(bend, nbr);
+            cols[J].bend = bend;
+            cols[J].tail_start = std::max(std::max(tb, bend), J + 1);
+            cols[J].first_tile = n_tiles;
+            cols[J].pad = 0;
+            n_tiles += (bend - J) + std::max(0, nbr - cols[J].tail_start);
+        }
+        for (int b = 0; b < std::min(tb, nbr); b++)
+        {
+            int K = 0;
+            while (K < nbc && cols[K].bend <= b)
+                K++;
+            kmin[b] = std::min(K, b);
+        }
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_tiles_kernel, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        const int slots = per_cu * ctx->prop.multiProcessorCount;
+        // claim order: the tail's rows first (their sums run along the whole factorisation), then the band, each column
+        // by column; when the tail alone would fill the machine, plain column order
+        std::vector<unsigned int> order;
+        order.reserve((size_t)n_tiles);
+        auto rows_of = [&](int J, bool want_tail, bool want_band) {
+            for (int I = J; I < cols[J].bend; I++)
+                if ((I >= tb) ? want_tail : want_band)
+                    order.push_back((unsigned int)I | ((unsigned int)J << 16));
+            for (int I = cols[J].tail_start; I < nbr; I++)
+                if (want_tail)
+                    order.push_back((unsigned int)I | ((unsigned int)J << 16));
+        };
+        size_t tail_tiles = 0;
+        for (int J = 0; J < nbc; J++)
+        {
+            for (int I = J; I < cols[J].bend; I++)
+                tail_tiles += I >= tb;
+            tail_tiles += (size_t)std::max(0, nbr - cols[J].tail_start);
+        }
+        if ((long)tail_tiles + 64 <= (long)slots)
+        {
+            for (int J = 0; J < nbc; J++)
+                rows_of(J, true, false);
+            for (int J = 0; J < nbc; J++)
+                rows_of(J, false, true);
+        }
+        else
+            for (int J = 0; J < nbc; J++)
+                rows_of(J, true, true);
+        if (nbr >= 65536 || (int)order.size() != n_tiles)
+            return ochip_fail(ctx, OCHIP_EINVAL, "relax: factorisation plan is inconsistent (%d tiles, %zu listed)", n_tiles, order.size());
+        s->chol_n_tiles = n_tiles;
+        s->chol_nbc = nbc;
+        s->chol_nbr = nbr;
+        s->chol_tb = tb;
+        s->chol_grid = std::max(1, std::min(n_tiles, slots));
+        s->chol_sync_bytes = (((size_t)n_tiles + 4) * 4 + 15) / 16 * 16;
+        chol_col *cols_dev = nullptr;
+        if (lm_dev_upload(ctx, s->allocs, &cols_dev, cols.data(), cols.size()) != OCHIP_OK ||
+            lm_dev_upload(ctx, s->allocs, &s->chol_kmin, kmin.data(), kmin.size()) != OCHIP_OK ||
+            lm_dev_upload(ctx, s->allocs, &s->chol_tiles, order.data(), std::max<size_t>(order.size(), 1)) != OCHIP_OK ||
+            lm_dev_upload<unsigned int>(ctx, s->allocs, &s->chol_sync, nullptr, s->chol_sync_bytes / 4) != OCHIP_OK)
+            return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (factorisation plan)");
+        s->chol_cols = cols_dev;
+    }
     return OCHIP_OK;
 }
 
@@ -633,22 +952,75 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                 S.linv_cap = need;
             }
         }
-        for (int k0 = 0; k0 < n; k0 += NB)
+        static const bool chain = getenv("OCHIP_CHOL_CHAIN") != nullptr;   // A/B knob: the launch chain per block column
+        static const bool verify = getenv("OCHIP_CHOL_VERIFY") != nullptr; // run both on the same system and compare
+        // the launch chain on (W, linv); count: add the algorithmic flops of the factorisation to the context's counter
+        auto launch_chain = [&](double *W, double *linv, bool launch, bool count) {
+            for (int k0 = 0; k0 < n; k0 += NB)
+            {
+                const int nb = std::min(NB, n - k0);
+                double *linv_k = linv + (size_t)(k0 / NB) * NB * NB;
+                if (launch)
+                    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, W, n, k0, nb, S.fail_chol, linv_k);
+                // rows below the block that can be non-zero: its envelope, then the tail (dense unknowns + augmented row)
+                static const bool dense = getenv("OCHIP_CHOL_DENSE") != nullptr; // A/B knob: ignore the envelope
+                const int below = k0 + nb;
+                const int band_end = dense ? n : std::max(below, std::min(S.env.env_end[k0 / NB], S.env.tail_begin));
+                const int tail0 = std::max(dense ? n : S.env.tail_begin, below);
+                row_set rs{below, band_end - below, tail0, (band_end - below) + (n + 1 - tail0)};
+                const int tiles = (rs.total + 63) / 64;
+                if (count)
+                    ctx->relax_mfma_flops += 2.0 * rs.total * nb * nb + (below < n ? 1.0 * rs.total * rs.total * nb : 0.0);
+                if (!launch)
+                    continue;
+                hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, st, W, n, rs, k0, nb, linv_k);
+                if (below < n)
+                    hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, st, W, n, rs, k0, nb);
+            }
+        };
+        if (chain)
+            launch_chain(S.Wm, S.linv, true, true);
+        else
         {
-            const int nb = std::min(NB, n - k0);
-            double *linv_k = S.linv + (size_t)(k0 / NB) * NB * NB;
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, S.Wm, n, k0, nb, S.fail_chol, linv_k);
-            // rows below the block that can be non-zero: its envelope, then the tail (dense unknowns + augmented row)
-            static const bool dense = getenv("OCHIP_CHOL_DENSE") != nullptr; // A/B knob: ignore the envelope
-            const int below = k0 + nb;
-            const int band_end = dense ? n : std::max(below, std::min(S.env.env_end[k0 / NB], S.env.tail_begin));
-            const int tail0 = std::max(dense ? n : S.env.tail_begin, below);
-            row_set rs{below, band_end - below, tail0, (band_end - below) + (n + 1 - tail0)};
-            const int tiles = (rs.total + 63) / 64;
-            ctx->relax_mfma_flops += 2.0 * rs.total * nb * nb + (below < n ? 1.0 * rs.total * rs.total * nb : 0.0);
-            hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, st, S.Wm, n, rs, k0, nb, linv_k);
-            if (below < n)
-                hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, st, S.Wm, n, rs, k0, nb);
+            double *Wv = nullptr, *linv_v = nullptr;
+            size_t got_w = 0, got_l = 0;
+            if (verify)
+            {
+                Wv = (double *)ochip_pool_get(ctx, ((size_t)n + 1) * n * 8, &got_w);
+                linv_v = (double *)ochip_pool_get(ctx, (size_t)((n + NB - 1) / NB) * NB * NB * 8, &got_l);
+                if (!Wv || !linv_v)
+                    return ochip_fail(ctx, OCHIP_ENOMEM, "OCHIP_CHOL_VERIFY: device allocation failed");
+                OCHIP_HIP(ctx, hipMemcpyAsync(Wv, S.Wm, ((size_t)n + 1) * n * 8, hipMemcpyDeviceToDevice, st));
+            }
+            OCHIP_HIP(ctx, hipMemsetAsync(S.chol_sync, 0, S.chol_sync_bytes, st));
+            hipLaunchKernelGGL(chol_tiles_kernel, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
+                               (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_tiles, S.chol_tb, S.chol_sync, S.linv,
+                               S.fail_chol);
+            launch_chain(S.Wm, S.linv, false, true);
+            if (verify)
+            {
+                launch_chain(Wv, linv_v, true, false);
+                std::vector<double> ya(n), yb(n);
+                OCHIP_HIP(ctx, hipMemcpyAsync(ya.data(), S.Wm + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+                OCHIP_HIP(ctx, hipMemcpyAsync(yb.data(), Wv + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+                OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+                double worst = 0, scale_y = 0;
+                bool nan = false;
+                for (int i = 0; i < n; i++)
+                {
+                    scale_y = std::max(scale_y, std::abs(yb[i]));
+                    worst = std::max(worst, std::abs(ya[i] - yb[i]));
+                    nan = nan || (std::isnan(ya[i]) != std::isnan(yb[i]));
+                }
+                ochip_pool_put(ctx, Wv, got_w);
+                ochip_pool_put(ctx, linv_v, got_l);
+                static const bool loud = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+                if (loud)
+                    fprintf(stderr, "[ochip relax] factorisation check: n=%d forward solve differs by %.3g (scale %.3g)\n", n, worst, scale_y);
+                if (nan || worst > 1e-9 * std::max(scale_y, 1e-300))
+                    return ochip_fail(ctx, OCHIP_EINVAL, "OCHIP_CHOL_VERIFY: the tile factorisation and the launch chain disagree (n = %d, "
+                                      "forward solve differs by %g at scale %g)", n, worst, scale_y);
+            }
         }
         // row n now holds y = L^-1 gs; back-substitute L' x = y block by block
         OCHIP_HIP(ctx, hipMemcpyAsync(S.y, S.Wm + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToDevice, st));

@@ -40,6 +40,13 @@ struct lm_system
     double *linv = nullptr;    // inverses of the diagonal blocks
     int *first_col_dev = nullptr;
     lm_envelope env;
+    // plan of the one-launch tile factorisation (relax_lm.hip: chol_tiles_kernel), rebuilt with the envelope
+    void *chol_cols = nullptr;       // per column block: first tile, band end, first tail block
+    int *chol_kmin = nullptr;        // per row block: first column block whose envelope reaches it
+    unsigned int *chol_tiles = nullptr; // tiles in claim order: row block | column block << 16
+    unsigned int *chol_sync = nullptr;  // [0] claim counter, [4 + tile] done flags; zeroed before every factorisation
+    int chol_n_tiles = 0, chol_nbc = 0, chol_nbr = 0, chol_tb = 0, chol_grid = 0;
+    size_t chol_sync_bytes = 0;
 };
 
 // (re)size the buffers for n unknowns and take the envelope; returns OCHIP_OK or a negative code

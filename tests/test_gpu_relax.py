@@ -115,3 +115,41 @@ def test_graph_without_edges(ctx, oracle):
     dots = np.abs(np.sum(got["orientation"] * grid.orientation, axis=1))
     assert np.all(2 * np.arccos(np.clip(dots, 0, 1)) < 1e-2)
     g.close()
+
+
+def test_tile_factorisation_equals_the_launch_chain():
+    """OCHIP_CHOL_VERIFY=1 factors every reduced system twice - the one-launch tile Cholesky (workgroups handing tiles to
+    each other) and the chain of dependent launches - and fails the solve when the forward solves differ by more than
+    1e-9 relative.  Run in a child process (the switch is read once) over a plane problem with the augmented row inside
+    the last diagonal tile (n % 64 != 0), one with n % 64 == 0, and a mesh problem with a dense tail."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys
+sys.path.insert(0, "tests")
+import numpy as np
+from opencalibration_amd import capi, host
+from relax_fixtures import camera_grid, camera_grid_tracks, pack_edges_with_features
+from oracle import pyoracle
+ctx = capi.Context(0)
+for rows, cols in ((5, 6), (3, 7), (8, 8)):          # 90 + 3 = 93, 63 + 3 = 66, 192 + 3 = 195 unknowns
+    ori, pos, edges, model = camera_grid(rows, cols)
+    rng = np.random.default_rng(rows)
+    start = ori + rng.normal(0, 0.02, ori.shape)
+    start /= np.linalg.norm(start, axis=1, keepdims=True)
+    out = host.relax_ground_plane(ctx, pos, ori, model, np.arange(len(pos)), start, host.pack_edges(edges))
+    assert out["iterations_total"] > 3, out
+ori, pos, edges, model = camera_grid_tracks(6, 7)
+pk, feats = pack_edges_with_features(pyoracle, len(pos), edges)
+gx = np.linspace(-4, 16, 9)
+prev = host.Surface().set(np.zeros((0, 3)), np.zeros((0, 5), np.uint64), np.array([[x, y, 1e-3 * x + 1e-2 * y] for x in gx for y in gx]))
+out = host.relax(ctx, pos, ori, model, feats, np.arange(len(pos)), ori, pk, host.relax_options("ORIENTATION", "GROUND_MESH"), 0.1, previous=prev)
+assert out["unknowns"] > 500 and out["iterations_total"] > 1, out
+print("verified", out["unknowns"])
+'''
+    env = dict(os.environ, OCHIP_CHOL_VERIFY="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "verified" in r.stdout, r.stdout + r.stderr
