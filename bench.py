@@ -207,20 +207,22 @@ def main():
                   "features_entering_matcher_per_image": round(last["link_work"]["subset_features"] / grid.n_images, 1),
                   "directed_pairs": int(res["edges"]), "launches": n_match,
                   "device_ms_per_step": round(ms_match / max(args.steps, 1), 3)},
-        # relax linear solve: the only MFMA use on the path (v_mfma_f64_16x16x4f64 in the panel and trailing-update GEMMs of
-        # the block-envelope Cholesky).  Inside the envelope the launches are small and latency-bound; the dense figure is the
-        # peak the guide's FP64-matrix rate gives, not a target for this path.
-        "relax_mfma": {"kernel": "chol_panel_kernel + chol_update_mfma_kernel", "bound": "mfma",
+        # relax linear solve: the only MFMA use on the path (v_mfma_f64_16x16x4f64 in the tile products of the block-envelope
+        # Cholesky, one launch per factorisation).  The factorisation is a dependency chain of 64 x 64 tiles and is bound by
+        # the diagonal tiles' latency, not by the matrix cores; the dense figure is the peak the guide's FP64-matrix rate
+        # gives, not a target for this path.
+        "relax_mfma": {"kernel": "chol_tiles_kernel", "bound": "mfma",
                        "achieved": round(relax_flops / max(ms_solve, 1e-9) * 1e3 / 1e12, 4), "peak": 78.6, "unit": "TFLOP/s",
                        "frac": round(relax_flops / max(ms_solve, 1e-9) * 1e3 / 78.6e12, 5),
-                       "note": "latency-bound: one factorisation is a chain of small launches inside the block envelope; the "
-                               "time base is the whole linear solve (build, factorisation, substitutions, step)",
+                       "note": "latency-bound: one launch per factorisation, a dependency chain of 64 x 64 tiles inside the block "
+                               "envelope (critical path = the diagonal tiles); the time base is the whole linear solve (build, "
+                               "factorisation, substitutions, step)",
                        "flops_per_step": round(relax_flops / max(args.steps, 1)), "solves": n_solve},
         "other_kernels_avg_ms": {
             "hamming_2nn_kernel": round(ms_match / max(n_match, 1), 3),
             "ransac_homography_kernel": round(ms_ransac / max(n_ransac, 1), 3),
             "relax_pair_eval_kernel": round(ms_eval / max(n_eval, 1), 4),
-            "relax_linear_solve (Cholesky sequence)": round(ms_solve / max(n_solve, 1), 3)},
+            "relax_linear_solve (build + tile Cholesky + substitutions + step)": round(ms_solve / max(n_solve, 1), 3)},
     }
     err = pipeline.orientation_errors(rel["orientation"], grid.orientation)
     lm_iters = acc.get("relax_lm_iterations", 0.0)
@@ -281,6 +283,29 @@ def main():
                 "residual_blocks": int(ms["residual_blocks"]), "track_blocks": int(ms["track_blocks"]),
                 "two_ray_blocks": int(ms["two_ray_blocks"]), "images_per_s": round(grid.n_images / tms, 1),
                 "median_orientation_error_rad_vs_truth": float(np.median(errm))}
+            # (d) dense guided matching (densifyMesh, dense_stereo.cpp:66-403) over the same survey: every dense feature's ray
+            # against the relaxed ground, the descriptor search in a 150 px disc on the device, tracks -> 3-D points
+            ground = host.rebuild_mesh(grid.position, minimal=True)
+            ga = ground.arrays()
+            gv = ga["vertices"].copy()
+            gv[:, 2] = grid.plane[0] * gv[:, 0] + grid.plane[1] * gv[:, 1]
+            ground.set(gv, ga["edges"])
+            ctx.profile_reset()
+            t0 = time.perf_counter()
+            ds = gg.densify_mesh(ctx, ground)
+            tds = time.perf_counter() - t0
+            kd_n, kd_ms = ctx.profile_get(5)   # OCHIP_K_DENSE
+            kd = {"total_ms": kd_ms}
+            cloud = ground.clouds()[-1] if ds["points"] else np.zeros((0, 3))
+            dz = cloud[:, 2] - (grid.plane[0] * cloud[:, 0] + grid.plane[1] * cloud[:, 1])
+            extras["dense_guided_matching"] = {
+                "images": ds["images"], "dense_features": ds["dense_features"], "queries": ds["queries"], "matches": ds["matches"],
+                "tracks": ds["tracks"], "points": ds["points"], "seconds": round(tds, 4),
+                "seconds_by_phase": {"index": round(ds["index_s"], 4), "rays_and_predictions_host": round(ds["rays_s"], 4),
+                                     "device_incl_pcie": round(ds["device_s"], 4), "tracks_host": round(ds["tracks_s"], 4)},
+                "search_kernel_ms": round(kd.get("total_ms", 0.0), 3),
+                "queries_per_s_kernel": round(ds["queries"] / max(kd.get("total_ms", 0.0) * 1e-3, 1e-9), 1),
+                "median_abs_height_error_m": float(np.median(np.abs(dz))) if len(dz) else None}
             gg.close()
         except Exception as ex:
             extras["relax_extras_error"] = str(ex)

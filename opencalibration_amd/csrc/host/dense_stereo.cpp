@@ -5,8 +5,10 @@
 #include "triangle_walker.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <numeric>
 
 namespace opencalibration_amd
@@ -28,44 +30,6 @@ double seconds_since(const std::chrono::steady_clock::time_point &t0)
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
-
-class UnionFind // types/union_find.hpp
-{
-  public:
-    explicit UnionFind(size_t n) : _parent(n), _rank(n, 0)
-    {
-        std::iota(_parent.begin(), _parent.end(), (size_t)0);
-    }
-    size_t find(size_t x)
-    {
-        while (_parent[x] != x) // path halving: the same partition as the reference's recursive compression
-        {
-            _parent[x] = _parent[_parent[x]];
-            x = _parent[x];
-        }
-        return x;
-    }
-    void unite(size_t a, size_t b)
-    {
-        a = find(a);
-        b = find(b);
-        if (a == b)
-            return;
-        if (_rank[a] < _rank[b])
-            std::swap(a, b);
-        _parent[b] = a;
-        if (_rank[a] == _rank[b])
-            _rank[a]++;
-    }
-    bool is_singleton(size_t x) const
-    {
-        return _parent[x] == x && _rank[x] == 0;
-    }
-
-  private:
-    std::vector<size_t> _parent;
-    std::vector<uint8_t> _rank;
-};
 
 // camera_tree.searcher().search(point, max, k) (jk::KDTree, 3-D): the k cameras nearest to a point, nearest first.
 // Exact: cameras binned on an x-y grid, rings of cells around the query until the k-th best squared distance is below
@@ -332,7 +296,45 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     camera_grid.build(cam_pos);
 
     const MeshGraph &mesh = surfaces[0].mesh;
-    UnionFind uf(total);
+    // union-find over the measurements, lock-free: the larger root goes under the smaller one, so a component's root is its
+    // smallest member and the partition does not depend on the order of the unions (the reference unites under a mutex
+    // in whatever order its OpenMP threads finish; only the partition reaches the result)
+    std::unique_ptr<std::atomic<uint32_t>[]> parent(new std::atomic<uint32_t>[std::max<size_t>(total, 1)]);
+    std::unique_ptr<std::atomic<uint8_t>[]> matched(new std::atomic<uint8_t>[std::max<size_t>(total, 1)]);
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < total; i++)
+    {
+        parent[i].store((uint32_t)i, std::memory_order_relaxed);
+        matched[i].store(0, std::memory_order_relaxed);
+    }
+    auto find = [&](uint32_t x) {
+        while (true)
+        {
+            uint32_t p = parent[x].load(std::memory_order_relaxed);
+            if (p == x)
+                return x;
+            const uint32_t gp = parent[p].load(std::memory_order_relaxed);
+            if (gp != p)
+                parent[x].compare_exchange_weak(p, gp, std::memory_order_relaxed);
+            x = p;
+        }
+    };
+    auto unite = [&](uint32_t a, uint32_t b) {
+        matched[a].store(1, std::memory_order_relaxed);
+        matched[b].store(1, std::memory_order_relaxed);
+        while (true)
+        {
+            a = find(a);
+            b = find(b);
+            if (a == b)
+                return;
+            if (a < b)
+                std::swap(a, b);
+            uint32_t expected = a;
+            if (parent[a].compare_exchange_strong(expected, b, std::memory_order_relaxed))
+                return;
+        }
+    };
     bool device_failed = false;
     // batches of source images: rays, mesh intersections and predictions on the host threads, the descriptor search of
     // the whole batch in one device call, the accept decisions and the union-find on the host
@@ -416,32 +418,42 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
         }
         st.device_seconds += seconds_since(t1);
         t1 = std::chrono::steady_clock::now();
-        // source image of a query: the index position tells it (feat_base is ascending)
-        size_t si = b0;
-        for (size_t qi = 0; qi < queries.size(); qi++)
+        // the accept decisions (dense_stereo.cpp:278-283) and the unions, one source image per task
+        std::vector<size_t> q_off(per_image.size() + 1, 0);
+        for (size_t i = 0; i < per_image.size(); i++)
+            q_off[i + 1] = q_off[i] + per_image[i].size();
+        std::vector<size_t> accepted(per_image.size(), 0);
+        std::vector<std::vector<std::pair<size_t, size_t>>> kept(matches_out ? per_image.size() : 0);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (size_t k = 0; k < per_image.size(); k++)
         {
-            const ochip_dense_result &r = results[qi];
-            if (r.nearby == 0)
-                continue;
-            const double best_dist = r.best_count * (1.0 / feature_2d::DESCRIPTOR_BITS);
-            const double second_best_dist =
-                r.second_count == 0xFFFF ? INFINITY : r.second_count * (1.0 / feature_2d::DESCRIPTOR_BITS);
-            const bool good_match =
-                r.nearby >= 2 ? best_dist < RATIO_THRESHOLD * second_best_dist : best_dist < MAX_ABSOLUTE_DESCRIPTOR_DISTANCE;
-            if (!good_match)
-                continue;
-            const uint32_t src_pos = queries[qi].src_feature;
-            while (si + 1 < n_img && src_pos >= images[si + 1].feat_base)
-                si++;
-            while (src_pos < images[si].feat_base)
-                si--;
-            const DenseImage &src = images[si], &dst = images[queries[qi].cand_image];
-            const size_t src_id = src.offset + src.sorted_to_dense[src_pos - src.feat_base];
-            const size_t dst_id = dst.offset + dst.sorted_to_dense[r.best_feature];
+            const DenseImage &src = images[b0 + k];
+            for (size_t qi = q_off[k]; qi < q_off[k + 1]; qi++)
+            {
+                const ochip_dense_result &r = results[qi];
+                if (r.nearby == 0)
+                    continue;
+                const double best_dist = r.best_count * (1.0 / feature_2d::DESCRIPTOR_BITS);
+                const double second_best_dist =
+                    r.second_count == 0xFFFF ? INFINITY : r.second_count * (1.0 / feature_2d::DESCRIPTOR_BITS);
+                const bool good_match =
+                    r.nearby >= 2 ? best_dist < RATIO_THRESHOLD * second_best_dist : best_dist < MAX_ABSOLUTE_DESCRIPTOR_DISTANCE;
+                if (!good_match)
+                    continue;
+                const DenseImage &dst = images[queries[qi].cand_image];
+                const size_t src_id = src.offset + src.sorted_to_dense[queries[qi].src_feature - src.feat_base];
+                const size_t dst_id = dst.offset + dst.sorted_to_dense[r.best_feature];
+                if (matches_out)
+                    kept[k].emplace_back(src_id, dst_id);
+                accepted[k]++;
+                unite((uint32_t)src_id, (uint32_t)dst_id);
+            }
+        }
+        for (size_t k = 0; k < per_image.size(); k++)
+        {
+            st.matches += accepted[k];
             if (matches_out)
-                matches_out->emplace_back(src_id, dst_id);
-            st.matches++;
-            uf.unite(src_id, dst_id);
+                matches_out->insert(matches_out->end(), kept[k].begin(), kept[k].end());
         }
         st.tracks_seconds += seconds_since(t1);
     }
@@ -453,18 +465,23 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     auto t2 = std::chrono::steady_clock::now();
     std::vector<std::vector<size_t>> multi_tracks;
     {
+        // a matched measurement's component: tracks in the order of their smallest member (= their root), members ascending
+        std::vector<uint32_t> root(total);
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < total; i++)
+            root[i] = matched[i].load(std::memory_order_relaxed) ? find((uint32_t)i) : UINT32_MAX;
         std::vector<size_t> track_of_root(total, (size_t)-1);
         for (size_t i = 0; i < total; i++)
         {
-            if (uf.is_singleton(i))
+            if (root[i] == UINT32_MAX) // is_singleton
                 continue;
-            const size_t root = uf.find(i);
-            if (track_of_root[root] == (size_t)-1)
+            size_t &t = track_of_root[root[i]];
+            if (t == (size_t)-1)
             {
-                track_of_root[root] = multi_tracks.size();
+                t = multi_tracks.size();
                 multi_tracks.emplace_back();
             }
-            multi_tracks[track_of_root[root]].push_back(i);
+            multi_tracks[t].push_back(i);
         }
     }
     st.tracks = multi_tracks.size();
