@@ -1,0 +1,129 @@
+"""Property pins of the restated AKAZE (oracle/akaze.cpp).  No OpenCV and no test image exist here, so identity with
+cv::AKAZE cannot be shown; what CAN be shown is that the restatement has the properties the publication (Alcantarilla,
+Nuevo, Bartoli: "Fast Explicit Diffusion for Accelerated Features in Nonlinear Scale Spaces", BMVC 2013) and the
+reference's own test (test/test_extract_features.cpp:8-75) give the detector / descriptor:
+  * the 90-degree rotations of the image grid map keypoints onto keypoints with the orientation turned by the same angle
+    and (nearly) the same M-LDB bits (rotation invariance through the dominant orientation);
+  * a positive affine change of the intensities keeps the descriptors (M-LDB compares means of cells);
+  * a 2x larger rendering of the same scene is found one octave up (scale covariance of the keypoint size);
+  * two views of one scene related by a rigid motion match by descriptor at the true motion (repeatability).
+Tolerances are wide (they are properties, not bit pins); the device kernels are bit-identical to this restatement
+(tests/test_gpu_extract.py), so the properties carry over."""
+import numpy as np
+import pytest
+
+from opencalibration_amd import synth
+from oracle import pyoracle
+
+
+def _hamming(a, b):
+    return np.unpackbits((a ^ b).view(np.uint8), axis=-1).sum(-1)
+
+
+def _nearest(kp_a, kp_b_xy, tol):
+    """For every row of kp_b_xy the index of the nearest keypoint of kp_a (same level) within tol, else -1."""
+    out = np.full(len(kp_b_xy), -1)
+    for i, p in enumerate(kp_b_xy):
+        d = np.hypot(kp_a[:, 0] - p[0], kp_a[:, 1] - p[1])
+        j = int(np.argmin(d))
+        if d[j] <= tol:
+            out[i] = j
+    return out
+
+
+@pytest.fixture(scope="module")
+def scene():
+    g = synth.render_blobs(480, 480, seed=5, channels=1)
+    kp, d = pyoracle.akaze(g)
+    assert len(kp) > 150
+    return g, kp, d
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_quarter_turns_map_keypoints_and_descriptors(scene, k):
+    g, kp, d = scene
+    n = g.shape[0]
+    gr = np.ascontiguousarray(np.rot90(g, k))              # k quarter turns counter-clockwise (array axes)
+    kr, dr = pyoracle.akaze(gr)
+    # pixel (x, y) of g lands at: one ccw turn of the array: (x, y) -> (y, n - 1 - x)
+    xy = kp[:, :2].astype(np.float64).copy()
+    for _ in range(k):
+        xy = np.stack([xy[:, 1], n - 1 - xy[:, 0]], -1)
+    idx = _nearest(kr, xy, 1.0)
+    found = idx >= 0
+    same_level = found & (kr[np.maximum(idx, 0), 5] == kp[:, 5])
+    assert same_level.mean() > 0.95, same_level.mean()    # the detector commutes with the symmetries of the grid
+    # image y points down: a ccw turn of the array turns image-frame angles by -90 degrees.  The dominant orientation
+    # comes from 42 sliding windows 0.15 rad apart (not a divisor of a quarter turn) and a blob field has keypoints
+    # without a clear direction: most, not all, orientations turn with the image
+    da = (kr[idx[same_level], 3] - kp[same_level, 3] + k * np.pi / 2 + np.pi) % (2 * np.pi) - np.pi
+    assert np.mean(np.abs(da) < 0.35) > 0.8, np.mean(np.abs(da) < 0.35)
+    # where the orientation turned with the image, so did the descriptor
+    agree = np.abs(da) < 0.2
+    ham = _hamming(dr[idx[same_level]], d[same_level])[agree]
+    assert np.median(ham) < 0.05 * 486 and np.mean(ham < 0.2 * 486) > 0.95, (np.median(ham), np.mean(ham < 0.2 * 486))
+
+
+def test_descriptors_survive_an_affine_intensity_change(scene):
+    g, kp, d = scene
+    g2 = np.clip(0.7 * g.astype(np.float64) + 30.0, 0, 255).round().astype(np.uint8)   # lower contrast, brighter
+    k2, d2 = pyoracle.akaze(g2)
+    idx = _nearest(k2, kp[:, :2], 1.0)
+    ok = (idx >= 0) & (k2[np.maximum(idx, 0), 5] == kp[:, 5])
+    strong = kp[:, 4] > 4 * 5e-5 / 0.49                     # responses scale with contrast^2: these stay above threshold
+    assert (ok & strong).sum() > 0.8 * strong.sum()
+    ham = _hamming(d2[idx[ok]], d[ok])
+    assert np.median(ham) < 0.05 * 486, np.median(ham)      # only the 8-bit rounding of the transformed image differs
+    # and every response scales by about 0.49 (the determinant of the Hessian is quadratic in the image)
+    ratio = k2[idx[ok], 4] / kp[ok, 4]
+    assert abs(np.median(ratio) - 0.49) < 0.03, np.median(ratio)
+
+
+def test_twice_the_size_one_octave_up():
+    small = synth.render_blobs(320, 320, seed=9, channels=1)
+    # the same scene rendered at twice the size (blob positions and sigmas doubled): pixel replication + blur would not be
+    rng = np.random.default_rng(9)                          # the same scene: re-render analytically
+    n = max(32, int(320 * 320 / 768))
+    px, py = rng.uniform(-50, 370, n), rng.uniform(-50, 370, n)
+    amp = rng.uniform(0.2, 0.8, n) * rng.choice([-1.0, 1.0], n)
+    sg = rng.uniform(2.0, 6.0, n)
+    yy, xx = np.mgrid[0:640, 0:640]
+    img = np.full((640, 640), 0.5)
+    for i in range(n):
+        img += amp[i] * np.exp(-((xx - (2 * px[i] + 0.5)) ** 2 + (yy - (2 * py[i] + 0.5)) ** 2) / (2 * (2 * sg[i]) ** 2))
+    big = np.clip(img * 255.0, 0, 255).astype(np.uint8)
+    ks, ds = pyoracle.akaze(small)
+    kb, db = pyoracle.akaze(big)
+    assert len(ks) > 60 and len(kb) > 60
+    idx = _nearest(kb, 2 * ks[:, :2] + 0.5, 3.0)
+    ok = idx >= 0
+    assert ok.mean() > 0.5, ok.mean()
+    size_ratio = kb[idx[ok], 2] / ks[ok, 2]
+    assert abs(np.median(size_ratio) - 2.0) < 0.35, np.median(size_ratio)
+    ham = _hamming(db[idx[ok]], ds[ok])
+    assert np.median(ham) < 0.15 * 486, np.median(ham)
+
+
+def test_two_views_match_at_the_true_motion():
+    a = synth.render_blobs(480, 360, seed=13, channels=1)
+    shift, rot = (17.0, -9.0), 0.35
+    b = synth.render_blobs(480, 360, seed=13, shift=shift, rot=rot, channels=1)
+    ka, da = pyoracle.akaze(a)
+    kb, db = pyoracle.akaze(b)
+    # nearest neighbour by descriptor with the 0.8 ratio of match_features.cpp:94
+    ham = np.array([_hamming(db, da[i]) for i in range(len(da))])
+    order = np.argsort(ham, axis=1)
+    best, second = ham[np.arange(len(da)), order[:, 0]], ham[np.arange(len(da)), order[:, 1]]
+    good = best < 0.8 * second
+    assert good.sum() > 0.3 * len(da)
+    c, s = np.cos(rot), np.sin(rot)
+    cx, cy = 240.0, 180.0
+    # render_blobs draws the scene point that view a shows at q at  R' (q - centre - shift) + centre  in view b
+    q = ka[good, :2].astype(np.float64)
+    ux, uy = q[:, 0] - cx - shift[0], q[:, 1] - cy - shift[1]
+    p = np.stack([c * ux + s * uy + cx, -s * ux + c * uy + cy], -1)
+    err = np.hypot(*(kb[order[good, 0], :2] - p).T)
+    assert np.mean(err < 2.0) > 0.9, np.mean(err < 2.0)
+    # the dominant orientations turn with the view
+    da_ang = (kb[order[good, 0], 3] - ka[good, 3] + rot + np.pi) % (2 * np.pi) - np.pi
+    assert np.mean(np.abs(da_ang[err < 2.0]) < 0.25) > 0.85
