@@ -166,7 +166,7 @@ def main():
     launch_ms = t_extract * 1e3 / (grid.n_images / imgs_per_launch)
     traffic = None
     try:   # HBM bytes from the committed PMC pass (profiles/, FETCH_SIZE x 2 + WRITE_SIZE, see scripts/summarise_profile.py)
-        with open(os.path.join(ROOT, "profiles", "r01_e2e_pmc_hbm.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r02_e2e_pmc_hbm.json")) as fh:
             traffic = round(json.load(fh)["extract_hbm_bytes_per_image"] * imgs_per_launch)
     except (OSError, KeyError, ValueError):
         pass

@@ -343,8 +343,9 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
     std::vector<sym_job> sym;
     std::vector<ochip_pair> single_pairs;
     std::vector<uint64_t> single_off;
-    uint64_t part_total = 0;
+    uint64_t part_total = 0, part_max = 0;
     uint32_t sym_max_na = 0, sym_max_nb = 0;
+    std::vector<uint32_t> sym_groups{0}; // first job of every group: a group's partials fit the cap, groups run one after the other
     {
         std::unordered_map<uint64_t, uint32_t> first; // (image_1, image_2) -> first pair with these images
         if (use_sym)
@@ -357,18 +358,25 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
                 continue;
             const uint32_t a = pairs[p].image_1, b = pairs[p].image_2;
             const uint32_t na = ctx->img_n[a], nb = ctx->img_n[b];
-            // (the partials of the paired jobs of one launch are capped at 2 GB - OCHIP_MATCH_SYM_CAP_MB overrides it -;
-            // a pair whose partials would not fit any more goes one direction at a time)
+            // (the partials of the paired jobs that are in flight together are capped at 2 GB - OCHIP_MATCH_SYM_CAP_MB
+            // overrides it -: when the next pair would not fit, a new group starts, which re-uses the buffer after the
+            // previous group's merge; a single pair larger than the cap goes one direction at a time)
             static const uint64_t cap_bytes = getenv("OCHIP_MATCH_SYM_CAP_MB") ? (uint64_t)atoll(getenv("OCHIP_MATCH_SYM_CAP_MB")) << 20 : (2ull << 30);
             const uint64_t need = (uint64_t)((na + 63) / 64) * nb;
-            if (use_sym && a != b && na > 0 && nb > 0 && (part_total + need) * sizeof(uint2) <= cap_bytes)
+            if (use_sym && a != b && na > 0 && nb > 0 && need * sizeof(uint2) <= cap_bytes)
             {
                 auto it = first.find(((uint64_t)b << 32) | a);
                 if (it != first.end() && it->second != p && !claimed[it->second])
                 {
                     claimed[p] = claimed[it->second] = 1;
+                    if ((part_total + need) * sizeof(uint2) > cap_bytes)
+                    {
+                        sym_groups.push_back((uint32_t)sym.size());
+                        part_total = 0;
+                    }
                     sym.push_back(sym_job{a, b, out_offset[p], out_offset[it->second], part_total});
                     part_total += need;
+                    part_max = std::max(part_max, part_total);
                     ctx->match_computed += (uint64_t)na * nb;
                     ctx->match_delivered += 2 * (uint64_t)na * nb;
                     sym_max_na = std::max(sym_max_na, na);
@@ -422,7 +430,7 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
         {
             rc = ochip_ensure(ctx, &ctx->sym_jobs_dev, &ctx->sym_jobs_cap, (size_t)n_sym * sizeof(sym_job));
             if (rc == OCHIP_OK)
-                rc = ochip_ensure(ctx, &ctx->sym_part_dev, &ctx->sym_part_cap, (size_t)part_total * sizeof(uint2));
+                rc = ochip_ensure(ctx, &ctx->sym_part_dev, &ctx->sym_part_cap, (size_t)part_max * sizeof(uint2));
             if (rc)
                 return rc;
         }
@@ -467,13 +475,17 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
         else
             launch(hamming_2nn_kernel<2>);
     }
-    if (sym_blocks)
+    sym_groups.push_back(n_sym);
+    for (size_t gi = 0; gi + 1 < sym_groups.size(); gi++)
     {
-        hipLaunchKernelGGL(hamming_2nn_sym_kernel, dim3((uint32_t)sym_blocks), dim3(BLOCK), 0, ctx->stream, ctx->desc_dev,
-                           ctx->img_off_dev, ctx->img_n_dev, (const sym_job *)ctx->sym_jobs_dev, ctx->match_out_dev,
-                           (uint2 *)ctx->sym_part_dev, sym_chunks);
-        hipLaunchKernelGGL(sym_merge_kernel, dim3(n_sym, (sym_max_nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream,
-                           (const sym_job *)ctx->sym_jobs_dev, ctx->img_n_dev, (const uint2 *)ctx->sym_part_dev, ctx->match_out_dev);
+        const uint32_t g0 = sym_groups[gi], gn = sym_groups[gi + 1] - g0;
+        if (gn == 0)
+            continue;
+        const sym_job *jobs = (const sym_job *)ctx->sym_jobs_dev + g0;
+        hipLaunchKernelGGL(hamming_2nn_sym_kernel, dim3(sym_chunks * gn), dim3(BLOCK), 0, ctx->stream, ctx->desc_dev, ctx->img_off_dev,
+                           ctx->img_n_dev, jobs, ctx->match_out_dev, (uint2 *)ctx->sym_part_dev, sym_chunks);
+        hipLaunchKernelGGL(sym_merge_kernel, dim3(gn, (sym_max_nb + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ctx->stream, jobs, ctx->img_n_dev,
+                           (const uint2 *)ctx->sym_part_dev, ctx->match_out_dev);
     }
     ochip_prof_end(ctx, OCHIP_K_MATCH, e0, e1);
     OCHIP_HIP(ctx, hipGetLastError());

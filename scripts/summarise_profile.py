@@ -40,6 +40,12 @@ for counter, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
             acc[k][1] += float(row.get("Counter_Value", 0))
     pmc[counter] = {k: {"dispatches": v[0], "sum_KB": v[1]} for k, v in acc.items()}
 n_images, src_px, dst_px = 200, 4000 * 3000, 1600 * 1200
+# the bench extracts the C2 grid more than once per run (timed step, the staged step, the PCIe-inclusive pass): count the
+# images from the launches of the first extract kernel, one launch per chunk of 100 images
+for first in ("resize_area_lds_kernel<true>", "gray4_kernel"):
+    if first in pmc["FETCH_SIZE"]:
+        n_images = 100 * pmc["FETCH_SIZE"][first]["dispatches"]
+        break
 cal = {}
 # calibration of the counters against a kernel whose HBM bytes are known: gray4_kernel (3 B read, 1 B written per source
 # pixel) when the separate grey pass runs, else the fused grey + resize kernel (reads the BGR source once - its window

@@ -139,3 +139,18 @@ def test_full_size_properties(ctx):
     b = out[n:]
     assert np.array_equal(b["best_k"], np.arange(n)) and np.all(b["best_count"] == 0)
     assert np.all(b["second_count"] > 150)
+
+
+def test_parity_holds_when_the_partials_do_not_fit():
+    """OCHIP_MATCH_SYM_CAP_MB=1: the column partials of the both-directions kernel are limited to 1 MB in flight, so the
+    paired jobs of a launch run in many groups that re-use the buffer (and a pair larger than the cap goes one direction
+    at a time).  The switch is read once per process: this file's parity tests are re-run in a child with it set."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OCHIP_MATCH_SYM_CAP_MB="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_match.py"), os.path.join(root, "tests", "test_gpu_link.py"),
+                        "-x", "-q", "-m", "gpu", "-k", "not partials_do_not_fit"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
