@@ -358,10 +358,10 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
                 continue;
             const uint32_t a = pairs[p].image_1, b = pairs[p].image_2;
             const uint32_t na = ctx->img_n[a], nb = ctx->img_n[b];
-            // (the partials of the paired jobs that are in flight together are capped at 2 GB - OCHIP_MATCH_SYM_CAP_MB
+            // (the partials of the paired jobs that are in flight together are capped at 8 GB per context - OCHIP_MATCH_SYM_CAP_MB
             // overrides it -: when the next pair would not fit, a new group starts, which re-uses the buffer after the
             // previous group's merge; a single pair larger than the cap goes one direction at a time)
-            static const uint64_t cap_bytes = getenv("OCHIP_MATCH_SYM_CAP_MB") ? (uint64_t)atoll(getenv("OCHIP_MATCH_SYM_CAP_MB")) << 20 : (2ull << 30);
+            static const uint64_t cap_bytes = getenv("OCHIP_MATCH_SYM_CAP_MB") ? (uint64_t)atoll(getenv("OCHIP_MATCH_SYM_CAP_MB")) << 20 : (8ull << 30);
             const uint64_t need = (uint64_t)((na + 63) / 64) * nb;
             if (use_sym && a != b && na > 0 && nb > 0 && need * sizeof(uint2) <= cap_bytes)
             {

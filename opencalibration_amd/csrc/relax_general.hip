@@ -496,18 +496,31 @@ __global__ __launch_bounds__(W) void gather_kernel(g_dev P, const work_item *ite
             roff[lane] = P.rec_off[r];
             rdim[lane] = (uint8_t)d;
             rlo[lane] = (uint8_t)rec_slot_col(type, slot);
-            int cached_slot = -1, tv = -1, tsz = 0;
+            // the unknown groups of the record: all their ids first, then all their places in the system (three dependent
+            // round trips for the whole record instead of two per group; unused slots hold group 0, a valid load)
+            uint32_t vv[MAXV];
+            int tvs[MAXV], tszs[MAXV];
+#pragma unroll
+            for (int s = 0; s < MAXV; s++)
+                vv[s] = P.rec_var[(size_t)r * MAXV + s];
+#pragma unroll
+            for (int s = 0; s < MAXV; s++)
+            {
+                tvs[s] = P.var_t[vv[s]];
+                tszs[s] = P.var_ts[vv[s]];
+            }
             for (int c = 0; c < d; c++)
             {
                 int s, off;
                 rec_col(type, c, &s, &off);
-                if (s != cached_slot)
-                {
-                    const uint32_t v = P.rec_var[(size_t)r * MAXV + s];
-                    tv = P.var_t[v];
-                    tsz = P.var_ts[v];
-                    cached_slot = s;
-                }
+                int tv = 0, tsz = 0;
+#pragma unroll
+                for (int k = 0; k < MAXV; k++) // (a select chain: the arrays stay in registers)
+                    if (k == s)
+                    {
+                        tv = tvs[k];
+                        tsz = tszs[k];
+                    }
                 int idx = -1;
                 if (tv >= 0 && off < tsz)
                 {
@@ -522,9 +535,9 @@ __global__ __launch_bounds__(W) void gather_kernel(g_dev P, const work_item *ite
         }
         __syncthreads();
         // phase B: the records one after the other (fixed order), their entries spread over the lanes.  What bounds this
-        // loop is the latency of the record loads, so the values of 8 records are requested together before the first
+        // loop is the latency of the record loads, so the values of 16 records are requested together before the first
         // of them is added (the adds keep the record order: the sums stay reproducible).
-        constexpr int KB = 8;
+        constexpr int KB = 16;
         for (uint32_t i0 = 0; i0 < cnt; i0 += KB)
         {
             double v[KB];
@@ -803,7 +816,7 @@ namespace
 {
 
 constexpr int STRIP_CAP = 2300;       // band + tail columns one owner's LDS strip may span (3 rows x 2301 doubles = 55 KB)
-constexpr uint32_t TAIL_CHUNK = 4096; // records per chunk of a tail owner
+constexpr uint32_t TAIL_CHUNK = 1024; // records per chunk of a tail owner (a chunk is one wavefront walking its records in order)
 constexpr uint32_t DENSE_VERTS = 8;   // a mesh of at most this many vertices is dense (plane, minimal mesh): tail
 
 template <typename T> int up(ochip_relaxg_problem *p, T **dst, const T *src, size_t n)
