@@ -262,7 +262,8 @@ int ochip_device_info(const ochip_ctx *ctx, char *name, size_t name_len, int *co
     if (!ctx)
         return OCHIP_EINVAL;
     if (name && name_len)
-        snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+        snprintf(name, name_len, "%s (%s)", ctx->prop.name[0] ? ctx->prop.name : "AMD Instinct (name table not installed)",
+                 ctx->prop.gcnArchName); // the marketing name comes from libdrm's amdgpu.ids, absent on some boxes
     if (compute_units)
         *compute_units = ctx->prop.multiProcessorCount;
     if (hbm_bytes)

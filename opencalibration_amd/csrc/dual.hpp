@@ -8,10 +8,12 @@
 namespace ochip
 {
 
-template <int N> struct Dual
+// P: the type the partials are kept and propagated in.  double everywhere on the path; float only for the C5 sweep of
+// Jacobian precision (OCHIP_RELAX_JACOBIAN_FP32, relax_general.hip) - values stay fp64 either way.
+template <int N, typename P = double> struct Dual
 {
     double a;
-    double v[N];
+    P v[N];
     __host__ __device__ Dual() : a(0)
     {
         for (int i = 0; i < N; i++)
@@ -26,73 +28,73 @@ template <int N> struct Dual
 
 #define OCHIP_HD __host__ __device__ __forceinline__
 
-template <int N> OCHIP_HD Dual<N> operator+(const Dual<N> &f, const Dual<N> &g)
+template <int N, typename P> OCHIP_HD Dual<N, P> operator+(const Dual<N, P> &f, const Dual<N, P> &g)
 {
-    Dual<N> h;
+    Dual<N, P> h;
     h.a = f.a + g.a;
     for (int i = 0; i < N; i++)
         h.v[i] = f.v[i] + g.v[i];
     return h;
 }
-template <int N> OCHIP_HD Dual<N> operator-(const Dual<N> &f, const Dual<N> &g)
+template <int N, typename P> OCHIP_HD Dual<N, P> operator-(const Dual<N, P> &f, const Dual<N, P> &g)
 {
-    Dual<N> h;
+    Dual<N, P> h;
     h.a = f.a - g.a;
     for (int i = 0; i < N; i++)
         h.v[i] = f.v[i] - g.v[i];
     return h;
 }
-template <int N> OCHIP_HD Dual<N> operator*(const Dual<N> &f, const Dual<N> &g)
+template <int N, typename P> OCHIP_HD Dual<N, P> operator*(const Dual<N, P> &f, const Dual<N, P> &g)
 {
-    Dual<N> h;
+    Dual<N, P> h;
     h.a = f.a * g.a;
     for (int i = 0; i < N; i++)
-        h.v[i] = f.a * g.v[i] + f.v[i] * g.a;
+        h.v[i] = (P)f.a * g.v[i] + f.v[i] * (P)g.a;
     return h;
 }
-template <int N> OCHIP_HD Dual<N> operator/(const Dual<N> &f, const Dual<N> &g)
+template <int N, typename P> OCHIP_HD Dual<N, P> operator/(const Dual<N, P> &f, const Dual<N, P> &g)
 {
-    Dual<N> h;
+    Dual<N, P> h;
     const double ginv = 1.0 / g.a;
     const double fg = f.a * ginv;
     h.a = fg;
     for (int i = 0; i < N; i++)
-        h.v[i] = (f.v[i] - fg * g.v[i]) * ginv;
+        h.v[i] = (f.v[i] - (P)fg * g.v[i]) * (P)ginv;
     return h;
 }
-template <int N> OCHIP_HD bool operator<(const Dual<N> &f, const Dual<N> &g)
+template <int N, typename P> OCHIP_HD bool operator<(const Dual<N, P> &f, const Dual<N, P> &g)
 {
     return f.a < g.a;
 }
-template <int N> OCHIP_HD bool operator>(const Dual<N> &f, const Dual<N> &g)
+template <int N, typename P> OCHIP_HD bool operator>(const Dual<N, P> &f, const Dual<N, P> &g)
 {
     return f.a > g.a;
 }
-template <int N> OCHIP_HD Dual<N> dsqrt(const Dual<N> &f)
+template <int N, typename P> OCHIP_HD Dual<N, P> dsqrt(const Dual<N, P> &f)
 {
-    Dual<N> h;
+    Dual<N, P> h;
     h.a = sqrt(f.a);
     const double d = 1.0 / (2.0 * h.a);
     for (int i = 0; i < N; i++)
-        h.v[i] = d * f.v[i];
+        h.v[i] = (P)d * f.v[i];
     return h;
 }
-template <int N> OCHIP_HD Dual<N> dabs(const Dual<N> &f)
+template <int N, typename P> OCHIP_HD Dual<N, P> dabs(const Dual<N, P> &f)
 {
-    Dual<N> h;
+    Dual<N, P> h;
     h.a = fabs(f.a);
     const double s = copysign(1.0, f.a);
     for (int i = 0; i < N; i++)
-        h.v[i] = s * f.v[i];
+        h.v[i] = (P)s * f.v[i];
     return h;
 }
-template <int N> OCHIP_HD Dual<N> dacos(const Dual<N> &f)
+template <int N, typename P> OCHIP_HD Dual<N, P> dacos(const Dual<N, P> &f)
 {
-    Dual<N> h;
+    Dual<N, P> h;
     h.a = acos(f.a);
     const double d = -1.0 / sqrt(1.0 - f.a * f.a);
     for (int i = 0; i < N; i++)
-        h.v[i] = d * f.v[i];
+        h.v[i] = (P)d * f.v[i];
     return h;
 }
 OCHIP_HD double dsqrt(double x)
@@ -111,7 +113,7 @@ OCHIP_HD double value_of(double x)
 {
     return x;
 }
-template <int N> OCHIP_HD double value_of(const Dual<N> &x)
+template <int N, typename P> OCHIP_HD double value_of(const Dual<N, P> &x)
 {
     return x.a;
 }

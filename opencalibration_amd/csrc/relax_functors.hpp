@@ -18,15 +18,15 @@ template <typename T> __device__ __forceinline__ Vec3T<T> gquat_rotate(const T *
 }
 
 // tangent seed of the EigenQuaternionManifold at q: d(q_delta * q)/d delta (ceres manifold.cc, Order XYZW)
-__device__ __forceinline__ void gseed_quat(const double *q, Dual<3> *out)
+template <typename P> __device__ __forceinline__ void gseed_quat(const double *q, Dual<3, P> *out)
 {
     const double x = q[0], y = q[1], z = q[2], w = q[3];
     const double pj[4][3] = {{w, z, -y}, {-z, w, x}, {y, -x, w}, {-x, -y, -z}};
     for (int k = 0; k < 4; k++)
     {
-        out[k] = Dual<3>(q[k]);
+        out[k] = Dual<3, P>(q[k]);
         for (int c = 0; c < 3; c++)
-            out[k].v[c] = pj[k][c];
+            out[k].v[c] = (P)pj[k][c];
     }
 }
 

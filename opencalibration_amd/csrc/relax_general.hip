@@ -249,7 +249,10 @@ template <int N, bool INTR> __global__ __launch_bounds__(W) void ray_cost_kernel
 }
 
 // records of every block of one type at the current state: (block, pass) lanes
-template <int N, bool INTR> __global__ __launch_bounds__(W) void ray_record_kernel(g_dev P, uint32_t first, uint32_t count, int which)
+// DT: the dual type of the pass (Dual<3>: everything in fp64; Dual<3, float>: the Jacobian propagated in fp32, for the C5
+// precision sweep only)
+template <int N, bool INTR, typename DT = Dual<3>>
+__global__ __launch_bounds__(W) void ray_record_kernel(g_dev P, uint32_t first, uint32_t count, int which)
 {
     constexpr int PASSES = N + 1 + (INTR ? 2 : 0);
     constexpr int G = W / PASSES; // blocks per wavefront
@@ -271,8 +274,8 @@ template <int N, bool INTR> __global__ __launch_bounds__(W) void ray_record_kern
     bool failed = false;
     if (active)
     {
-        Dual<3> rd[R];
-        if (!ray_block_residuals<Dual<3>, N, INTR>(P, blk, which, pass, rd))
+        DT rd[R];
+        if (!ray_block_residuals<DT, N, INTR>(P, blk, which, pass, rd))
             failed = true;
         double s = 0;
         for (int k = 0; k < R; k++)
@@ -287,7 +290,7 @@ template <int N, bool INTR> __global__ __launch_bounds__(W) void ray_record_kern
         for (int cidx = 0; cidx < 3; cidx++)
             for (int k = 0; k < R; k++)
             {
-                const double v = rd[k].v[cidx];
+                const double v = (double)rd[k].v[cidx];
                 Jt[g][c0 + cidx][k] = v;
                 if (!(v - v == 0.0))
                     failed = true;
@@ -1040,7 +1043,14 @@ template <int N, bool INTR> void launch_ray(const g_dev &D, hipStream_t st, uint
     if (with_jac)
     {
         constexpr int G = W / (N + 1 + (INTR ? 2 : 0));
-        hipLaunchKernelGGL((ray_record_kernel<N, INTR>), dim3((count + G - 1) / G), dim3(W), 0, st, D, first, count, which);
+        // SURVEY §8 / BASELINE C5: "fp32-vs-fp64 Jacobian sweep".  The path computes Jacobians in fp64 as Ceres does; this
+        // switch (read once) propagates the dual parts of the ray blocks in fp32 instead - residual values, J'J accumulation
+        // and the solve stay fp64 - so that scripts/sweep_jacobian_precision.py can measure what fp32 derivatives would cost
+        static const bool jac32 = getenv("OCHIP_RELAX_JACOBIAN_FP32") != nullptr;
+        if (jac32)
+            hipLaunchKernelGGL((ray_record_kernel<N, INTR, Dual<3, float>>), dim3((count + G - 1) / G), dim3(W), 0, st, D, first, count, which);
+        else
+            hipLaunchKernelGGL((ray_record_kernel<N, INTR>), dim3((count + G - 1) / G), dim3(W), 0, st, D, first, count, which);
     }
     else
         hipLaunchKernelGGL((ray_cost_kernel<N, INTR>), dim3((count + W - 1) / W), dim3(W), 0, st, D, first, count, which);
