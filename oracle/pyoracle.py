@@ -553,6 +553,26 @@ class RxGraph:
                     two_ray_blocks=int(summary[8]), iterations_per_solve=[int(i) for i in iters if i >= 0],
                     models={int(m[0]): m[1:].copy() for m in models[:nm]})
 
+    def points_problem(self, pose_node, pose_ori, opt_edges, opts, mode, model10=None):
+        """TestRelaxProblem of test/test_relax.cpp:470-483 on the restatement: setup3dPointProblem, then nothing (mode 0),
+        solve (1) or relaxObservedModelOnly (2).  Returns the tracks' points before / after, the summary of the last solve,
+        the orientations and the camera model afterwards."""
+        L = _rx()
+        pose_node = np.ascontiguousarray(pose_node, np.uint64)
+        pose_ori = np.ascontiguousarray(pose_ori, np.float64).copy()
+        opt_edges = np.ascontiguousarray(opt_edges, np.uint64)
+        cap = 100000
+        before, after, summary = np.zeros((cap, 3)), np.zeros((cap, 3)), np.zeros(9)
+        m = None if model10 is None else np.ascontiguousarray(model10, np.float64).copy()
+        L.ocx_points_problem.restype = C.c_size_t
+        L.ocx_points_problem.argtypes = [C.c_void_p, C.c_size_t, u64p, f64p, C.c_size_t, u64p, C.c_uint32, C.c_int, f64p, f64p,
+                                         C.c_size_t, f64p, C.c_void_p]
+        n = L.ocx_points_problem(self.h, len(pose_node), pose_node, pose_ori, len(opt_edges), opt_edges, opts, mode, before, after,
+                                 cap, summary, None if m is None else m.ctypes.data)
+        return dict(points_before=before[:n].copy(), points_after=after[:n].copy(), orientation=pose_ori, solves=int(summary[0]),
+                    iterations=int(summary[2]), iterations_total=int(summary[1]), initial_cost=summary[3], final_cost=summary[4],
+                    residual_blocks=int(summary[5]), model=m)
+
     def relax_group(self, node_ids, knn10, depth, opts, grid_fraction=0.1, prev=None, run=True):
         node_ids = np.ascontiguousarray(node_ids, np.uint64)
         knn10 = np.ascontiguousarray(knn10, np.uint64).reshape(self.n_nodes, 10)

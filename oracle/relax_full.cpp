@@ -567,6 +567,209 @@ inline bool all_zero_distortion(const camera_model &m)
            m.tangential_distortion[0] == 0 && m.tangential_distortion[1] == 0;
 }
 
+// ceres::TinySolver [3P, ceres/tiny_solver.h] for N parameters and the options intersection.cpp:175-180 sets.  F(params,
+// residuals, jacobian row-major m x N).  Returns the final cost.
+struct tiny_options
+{
+    double gradient_tolerance = 1e-10, parameter_tolerance = 1e-8, function_tolerance = 1e-6;
+    double cost_threshold = std::numeric_limits<double>::epsilon(), initial_trust_region_radius = 1e4;
+    int max_num_iterations = 50;
+};
+template <int N, typename F> double tiny_solve_n(F &&func, int m, double *x, const tiny_options &o)
+{
+    std::vector<double> r(m), J((size_t)m * N), fn(m);
+    double jac_scale[N], jtj[N][N], g[N], cost = 0, gmax = 0;
+    int iterations = 0;
+    auto update = [&](const double *xx) {
+        func(xx, r.data(), J.data());
+        for (double &v : r)
+            v = -v;
+        if (iterations == 0)
+            for (int c = 0; c < N; c++)
+            {
+                double s = 0;
+                for (int i = 0; i < m; i++)
+                    s += J[(size_t)i * N + c] * J[(size_t)i * N + c];
+                jac_scale[c] = 1.0 / (1.0 + std::sqrt(s));
+            }
+        for (int i = 0; i < m; i++)
+            for (int c = 0; c < N; c++)
+                J[(size_t)i * N + c] *= jac_scale[c];
+        for (int a = 0; a < N; a++)
+        {
+            for (int b = 0; b < N; b++)
+            {
+                double s = 0;
+                for (int i = 0; i < m; i++)
+                    s += J[(size_t)i * N + a] * J[(size_t)i * N + b];
+                jtj[a][b] = s;
+            }
+            double s = 0;
+            for (int i = 0; i < m; i++)
+                s += J[(size_t)i * N + a] * r[i];
+            g[a] = s;
+        }
+        gmax = 0;
+        for (int a = 0; a < N; a++)
+            gmax = std::max(gmax, std::abs(g[a]));
+        double s = 0;
+        for (int i = 0; i < m; i++)
+            s += r[i] * r[i];
+        cost = s / 2;
+    };
+    update(x);
+    if (gmax < o.gradient_tolerance || cost < o.cost_threshold)
+        return cost;
+    double u = 1.0 / o.initial_trust_region_radius, v = 2;
+    for (iterations = 1; iterations < o.max_num_iterations; iterations++)
+    {
+        double A[N][N], step[N];
+        for (int a = 0; a < N; a++)
+            for (int b = 0; b < N; b++)
+                A[a][b] = jtj[a][b];
+        for (int i = 0; i < N; i++)
+        {
+            const double d = std::sqrt(u * std::min(std::max(jtj[i][i], 1e-6), 1e32));
+            A[i][i] += d * d;
+        }
+        {
+            double L[N][N] = {}, D[N];
+            bool ok = true;
+            for (int j = 0; j < N && ok; j++)
+            {
+                double d = A[j][j];
+                for (int k = 0; k < j; k++)
+                    d -= L[j][k] * L[j][k] * D[k];
+                D[j] = d;
+                ok = d != 0 && std::isfinite(d);
+                L[j][j] = 1;
+                for (int i = j + 1; i < N && ok; i++)
+                {
+                    double e = A[i][j];
+                    for (int k = 0; k < j; k++)
+                        e -= L[i][k] * L[j][k] * D[k];
+                    L[i][j] = e / d;
+                }
+            }
+            double y[N];
+            for (int i = 0; i < N; i++)
+            {
+                double e = g[i];
+                for (int k = 0; k < i; k++)
+                    e -= L[i][k] * y[k];
+                y[i] = e;
+            }
+            for (int i = 0; i < N; i++)
+                y[i] /= D[i];
+            for (int i = N - 1; i >= 0; i--)
+            {
+                double e = y[i];
+                for (int k = i + 1; k < N; k++)
+                    e -= L[k][i] * step[k];
+                step[i] = e;
+            }
+        }
+        double dx[N], xn[N], dxn = 0, xnorm = 0;
+        for (int i = 0; i < N; i++)
+        {
+            dx[i] = jac_scale[i] * step[i];
+            dxn += dx[i] * dx[i];
+            xnorm += x[i] * x[i];
+        }
+        if (std::sqrt(dxn) < o.parameter_tolerance * (std::sqrt(xnorm) + o.parameter_tolerance))
+            break;
+        for (int i = 0; i < N; i++)
+            xn[i] = x[i] + dx[i];
+        func(xn, fn.data(), nullptr);
+        double cost_new = 0;
+        for (int i = 0; i < m; i++)
+            cost_new += fn[i] * fn[i];
+        const double cost_change = (2 * cost - cost_new);
+        double model_cost_change = 0; // lm_step' (2 g - jtj lm_step)
+        for (int a = 0; a < N; a++)
+        {
+            double t = 2 * g[a];
+            for (int b = 0; b < N; b++)
+                t -= jtj[a][b] * step[b];
+            model_cost_change += step[a] * t;
+        }
+        const double rho = cost_change / model_cost_change;
+        if (rho > 0)
+        {
+            for (int i = 0; i < N; i++)
+                x[i] = xn[i];
+            if (std::abs(cost_change) < o.function_tolerance)
+            {
+                update(x);
+                break;
+            }
+            double tmp = 2 * rho - 1;
+            u = u * std::max(1 / 3., 1 - tmp * tmp * tmp);
+            v = 2;
+            update(x);
+            if (gmax < o.gradient_tolerance || cost < o.cost_threshold)
+                break;
+        }
+        else
+        {
+            u *= v;
+            v *= 2;
+        }
+    }
+    return cost;
+}
+
+// rayIntersection(model1, model2, pos1, pos2, rot1, rot2, px1, px2) (src/geometry/intersection.cpp:163-186): the midpoint
+// of the two rays, refined by TinySolver on the four reprojection residuals; second = the solver's final cost
+std::pair<Vec3, double> rayIntersectionRefined(const camera_model &model1, const camera_model &model2, const Vec3 &pos1, const Vec3 &pos2,
+                                               const Quat &rot1, const Quat &rot2, const double px1[2], const double px2[2])
+{
+    std::pair<Vec3, double> guess = rayIntersection(quat_rotate_d(rot1, image_to_3d(px1, model1)), pos1,
+                                                    quat_rotate_d(rot2, image_to_3d(px2, model2)), pos2);
+    const camera_model *models[2] = {&model1, &model2};
+    const Vec3 *pos[2] = {&pos1, &pos2};
+    const Quat *rot[2] = {&rot1, &rot2};
+    const double *px[2] = {px1, px2};
+    auto func = [&](const double *params, double *res, double *jac) {
+        for (int c = 0; c < 2; c++)
+        {
+            PixelErrorCost f{*pos[c], *models[c], {px[c][0], px[c][1]}};
+            const double q[4] = {rot[c]->x, rot[c]->y, rot[c]->z, rot[c]->w};
+            if (jac)
+            {
+                using J3 = Jet<3>;
+                J3 p[3], qj[4], r[2];
+                for (int i = 0; i < 3; i++)
+                {
+                    p[i] = J3(params[i]);
+                    p[i].v[i] = 1;
+                }
+                for (int i = 0; i < 4; i++)
+                    qj[i] = J3(q[i]);
+                f.eval<J3>(qj, p, nullptr, nullptr, nullptr, nullptr, r);
+                for (int i = 0; i < 2; i++)
+                {
+                    res[2 * c + i] = r[i].a;
+                    for (int k = 0; k < 3; k++)
+                        jac[(size_t)(2 * c + i) * 3 + k] = r[i].v[k];
+                }
+            }
+            else
+                f.eval<double>(q, params, nullptr, nullptr, nullptr, nullptr, res + 2 * c);
+        }
+    };
+    tiny_options o;
+    o.max_num_iterations = 50;
+    o.cost_threshold = 1e-7;
+    o.parameter_tolerance = 1e-14;
+    o.gradient_tolerance = 1e-12;
+    o.initial_trust_region_radius = 1e6;
+    double x[3] = {guess.first.x, guess.first.y, guess.first.z};
+    guess.second = tiny_solve_n<3>(func, 4, x, o);
+    guess.first = Vec3{x[0], x[1], x[2]};
+    return guess;
+}
+
 // ceres::TinySolver<TinySolverAutoDiffFunction<F, Dynamic, 5>> [3P, ceres/tiny_solver.h]: LM with Jacobi scaling from
 // the first Jacobian, an LDLT solve of the regularised normal equations, Nielsen's damping update; default options
 // (50 iterations, gradient 1e-10, parameter 1e-8, function 1e-6, cost threshold machine epsilon, radius 1e4).
@@ -1014,6 +1217,200 @@ class RelaxProblem
         addMeshFlatPrior();
         addMeshSmoothPrior();
         addMonotonicityCosts();
+    }
+
+    // :40-59 (tests only in the reference: relax() with {ORIENTATION} alone)
+    void setupDecompositionProblem(const MeasurementGraph &graph, std::vector<NodePose> &nodes, const std::vector<size_t> &edges_to_optimize)
+    {
+        _loss.reset(new mc::HuberLoss(10 * M_PI / 180));
+        model_map cam_models;
+        initialize(nodes, cam_models);
+        _opt.initial_trust_region_radius = 0.1;
+        for (size_t edge_id : edges_to_optimize)
+        {
+            const graph_edge *edge = graph.getEdge(edge_id);
+            if (edge != nullptr && shouldAddEdgeToOptimization(edge_id))
+                addRelationCost(graph, edge_id, *edge);
+        }
+        addDownwardsPrior();
+    }
+
+    // :122-145 (tests only in the reference: {ORIENTATION, POINTS_3D, ...})
+    void setup3dPointProblem(const MeasurementGraph &graph, std::vector<NodePose> &nodes, model_map &cam_models,
+                             const std::vector<size_t> &edges_to_optimize, const RelaxOptionSet &options)
+    {
+        initialize(nodes, cam_models);
+        _loss.reset(new mc::HuberLoss(10));
+        gridFilterMatchesPerImage(graph, edges_to_optimize, 0.05);
+        for (size_t edge_id : edges_to_optimize)
+        {
+            const graph_edge *edge = graph.getEdge(edge_id);
+            if (edge != nullptr && shouldAddEdgeToOptimization(edge_id))
+                addPointMeasurementsCost(graph, edge_id, *edge, options);
+        }
+        addMonotonicityCosts();
+        _opt.max_num_iterations = 1000; // (SPARSE_SCHUR: another exact solve of the same normal equations)
+    }
+
+    // :311-350
+    void addRelationCost(const MeasurementGraph &graph, size_t edge_id, const graph_edge &edge)
+    {
+        if (edge.payload.inlier_matches.size() == 0)
+            return;
+        const PoseOpt src = nodeid2poseopt(graph, edge.source, false), dst = nodeid2poseopt(graph, edge.dest, false);
+        if (src.loc_ptr == nullptr || dst.loc_ptr == nullptr)
+            return;
+        if (!finiteq(*src.rot_ptr) || !finiteq(*dst.rot_ptr) || !finite3(*src.loc_ptr) || !finite3(*dst.loc_ptr))
+            return;
+        double *datas[2] = {&src.rot_ptr->x, &dst.rot_ptr->x};
+        _problem.AddResidualBlock(new mc::AutoDiffCostFunction<MultiDecomposedRotationCost, 3, 4, 4>(
+                                      new MultiDecomposedRotationCost(edge.payload.relative_poses, *src.loc_ptr, *dst.loc_ptr)),
+                                  _loss.get(), {datas[0], datas[1]});
+        _problem.SetManifold(datas[0], mc::Manifold::EIGEN_QUATERNION);
+        _problem.SetManifold(datas[1], mc::Manifold::EIGEN_QUATERNION);
+        if (!src.optimize)
+            _problem.SetParameterBlockConstant(datas[0]);
+        if (!dst.optimize)
+            _problem.SetParameterBlockConstant(datas[1]);
+        _edges_used.insert(edge_id);
+    }
+
+    // :986-1187
+    void addPointMeasurementsCost(const MeasurementGraph &graph, size_t edge_id, const graph_edge &edge, const RelaxOptionSet &options)
+    {
+        _edge_tracks.emplace_back(edge_id, std::vector<FeatureTrack>());
+        auto &points = _edge_tracks.back().second;
+        points.reserve(edge.payload.inlier_matches.size());
+        const PoseOpt src = nodeid2poseopt(graph, edge.source), dst = nodeid2poseopt(graph, edge.dest);
+        if (src.loc_ptr == nullptr || dst.loc_ptr == nullptr)
+            return;
+        if (options.hasAll(FOCAL_LENGTH) && (src.model_ptr == nullptr || dst.model_ptr == nullptr))
+            return;
+        CameraModel &source_model = *const_cast<CameraModel *>(src.model_ptr), &dest_model = *const_cast<CameraModel *>(dst.model_ptr);
+        const auto &swl = _grid_filter[edge.source][edge_id].getBestMeasurementsPerCell();
+        const auto &dwl = _grid_filter[edge.dest][edge_id].getBestMeasurementsPerCell();
+        double *orientation_ptrs[2] = {&src.rot_ptr->x, &dst.rot_ptr->x};
+        const Vec3 *locs[2] = {src.loc_ptr, dst.loc_ptr};
+        CameraModel *models[2] = {&source_model, &dest_model};
+        const bool tangential = options.hasAny(LENS_DISTORTIONS_TANGENTIAL) &&
+                                options.hasAll(LENS_DISTORTIONS_RADIAL | FOCAL_LENGTH | ORIENTATION | POINTS_3D);
+        const bool radial = !tangential && options.hasAny(LENS_DISTORTIONS_RADIAL) && options.hasAll(FOCAL_LENGTH | ORIENTATION | POINTS_3D);
+        const bool focal = !tangential && !radial && options.hasAny(FOCAL_LENGTH | PRINCIPAL_POINT) && options.hasAll(ORIENTATION | POINTS_3D);
+        const bool plain = !tangential && !radial && !focal && options.hasAll(ORIENTATION | POINTS_3D);
+        if (!tangential && !radial && !focal && !plain)
+            return; // "No viable bundle options found"
+        bool points_added = false;
+        for (const auto &inlier : edge.payload.inlier_matches)
+        {
+            if (swl.find(&inlier) == swl.end() && dwl.find(&inlier) == dwl.end())
+                continue;
+            const auto intersection = rayIntersectionRefined(source_model, dest_model, *src.loc_ptr, *dst.loc_ptr, *src.rot_ptr, *dst.rot_ptr,
+                                                             inlier.pixel_1, inlier.pixel_2);
+            FeatureTrack track;
+            track.point = intersection.first;
+            track.error = intersection.second;
+            track.measurements = {NodeIdFeatureIndex{edge.source, inlier.feature_index_1}, NodeIdFeatureIndex{edge.dest, inlier.feature_index_2}};
+            points.push_back(track);
+            double *point = &points.back().point.x;
+            mc::CostFunction *func[2];
+            std::vector<double *> args[2];
+            for (int i = 0; i < 2; i++)
+            {
+                const double *px = i == 0 ? inlier.pixel_1 : inlier.pixel_2;
+                PixelErrorCost base{*locs[i], static_cast<const camera_model &>(*models[i]), {px[0], px[1]}};
+                double *f = &models[i]->focal_length_pixels, *pp = models[i]->principle_point, *k = models[i]->radial_distortion,
+                       *tg = models[i]->tangential_distortion;
+                if (tangential)
+                {
+                    auto *fn = new PixelErrorCost_OrientationFocalRadialTangential();
+                    static_cast<PixelErrorCost &>(*fn) = base;
+                    func[i] = new mc::AutoDiffCostFunction<PixelErrorCost_OrientationFocalRadialTangential, 2, 4, 3, 1, 2, 3, 2>(fn);
+                    args[i] = {orientation_ptrs[i], point, f, pp, k, tg};
+                }
+                else if (radial)
+                {
+                    auto *fn = new PixelErrorCost_OrientationFocalRadial();
+                    static_cast<PixelErrorCost &>(*fn) = base;
+                    func[i] = new mc::AutoDiffCostFunction<PixelErrorCost_OrientationFocalRadial, 2, 4, 3, 1, 2, 3>(fn);
+                    args[i] = {orientation_ptrs[i], point, f, pp, k};
+                }
+                else if (focal)
+                {
+                    auto *fn = new PixelErrorCost_OrientationFocal();
+                    static_cast<PixelErrorCost &>(*fn) = base;
+                    func[i] = new mc::AutoDiffCostFunction<PixelErrorCost_OrientationFocal, 2, 4, 3, 1, 2>(fn);
+                    args[i] = {orientation_ptrs[i], point, f, pp};
+                }
+                else
+                {
+                    auto *fn = new PixelErrorCost_Orientation();
+                    static_cast<PixelErrorCost &>(*fn) = base;
+                    func[i] = new mc::AutoDiffCostFunction<PixelErrorCost_Orientation, 2, 4, 3>(fn);
+                    args[i] = {orientation_ptrs[i], point};
+                }
+            }
+            bool all_finite = true;
+            for (int i = 0; i < 2; i++)
+            {
+                double res[2] = {NAN, NAN};
+                func[i]->Evaluate(args[i].data(), res, nullptr);
+                if (!std::isfinite(res[0]) || !std::isfinite(res[1]))
+                    all_finite = false;
+            }
+            if (!all_finite)
+            {
+                delete func[0];
+                delete func[1];
+                continue;
+            }
+            for (int i = 0; i < 2; i++)
+                _problem.AddResidualBlock(func[i], _loss.get(), args[i]);
+            if (options.hasAny(LENS_DISTORTIONS_RADIAL))
+                for (int i = 0; i < 2; i++)
+                    trackRadialObservation(models[i]->radial_distortion, models[i]->pixels_rows, models[i]->pixels_cols,
+                                           models[i]->focal_length_pixels);
+            points_added = true;
+        }
+        if (points_added)
+        {
+            for (int i = 0; i < 2; i++)
+                _problem.SetManifold(orientation_ptrs[i], mc::Manifold::EIGEN_QUATERNION);
+            if (!src.optimize)
+                _problem.SetParameterBlockConstant(orientation_ptrs[0]);
+            if (!dst.optimize)
+                _problem.SetParameterBlockConstant(orientation_ptrs[1]);
+            if (options.hasAny(FOCAL_LENGTH | PRINCIPAL_POINT | LENS_DISTORTIONS_RADIAL | LENS_DISTORTIONS_TANGENTIAL))
+            {
+                for (int i = 0; i < 2; i++)
+                {
+                    if (!options.hasAny(FOCAL_LENGTH))
+                        _problem.SetParameterBlockConstant(&models[i]->focal_length_pixels);
+                    else
+                    {
+                        _problem.SetParameterLowerBound(&models[i]->focal_length_pixels, 0, 100.0);
+                        _problem.SetParameterUpperBound(&models[i]->focal_length_pixels, 0, 20000.0);
+                    }
+                    if (!options.hasAny(PRINCIPAL_POINT))
+                        _problem.SetParameterBlockConstant(models[i]->principle_point);
+                }
+            }
+            if (options.hasAll(LENS_DISTORTIONS_RADIAL))
+                for (int i = 0; i < 2; i++)
+                {
+                    if (options.hasAll(LENS_DISTORTIONS_RADIAL_BROWN246_PARAMETERIZATION))
+                        ; // all three coefficients free
+                    else if (options.hasAll(LENS_DISTORTIONS_RADIAL_BROWN24_PARAMETERIZATION))
+                        _problem.SetSubsetManifold(models[i]->radial_distortion, {2});
+                    else if (options.hasAll(LENS_DISTORTIONS_RADIAL_BROWN2_PARAMETERIZATION))
+                        _problem.SetSubsetManifold(models[i]->radial_distortion, {1, 2});
+                }
+        }
+        _edges_used.insert(edge_id);
+    }
+
+    const std::vector<std::pair<size_t, std::vector<FeatureTrack>>> &tracks() const // TestRelaxProblem::test_get_tracks
+    {
+        return _edge_tracks;
     }
 
     // :931-984
@@ -1888,6 +2285,33 @@ surface_model runGroundMesh(const MeasurementGraph &graph, std::vector<NodePose>
     return rp.getSurfaceModel();
 }
 
+surface_model runRelativeOrientation(const MeasurementGraph &graph, std::vector<NodePose> &nodes,
+                                     const std::vector<size_t> &edges_to_optimize, relax_stats *stats) // relax.cpp:14-42
+{
+    for (auto &node : nodes)
+        if (hasnanq(node.orientation))
+        {
+            node.orientation = DOWN_ORIENTED_NORTH;
+            RelaxProblem rp(stats);
+            rp.setupDecompositionProblem(graph, nodes, edges_to_optimize);
+            rp.solve();
+        }
+    RelaxProblem rp(stats);
+    rp.setupDecompositionProblem(graph, nodes, edges_to_optimize);
+    rp.solve();
+    return rp.getSurfaceModel();
+}
+
+surface_model runPoints(const MeasurementGraph &graph, std::vector<NodePose> &nodes, model_map &cam_models,
+                        const std::vector<size_t> &edges_to_optimize, const RelaxOptionSet &options, relax_stats *stats) // :104-116
+{
+    RelaxProblem rp(stats);
+    rp.setup3dPointProblem(graph, nodes, cam_models, edges_to_optimize, options);
+    rp.relaxObservedModelOnly();
+    rp.solve();
+    return rp.getSurfaceModel();
+}
+
 } // namespace
 
 surface_model relax(const MeasurementGraph &graph, std::vector<NodePose> &nodes, model_map &cam_models,
@@ -1896,9 +2320,33 @@ surface_model relax(const MeasurementGraph &graph, std::vector<NodePose> &nodes,
 {
     if (config.options.get(GROUND_MESH))
         return runGroundMesh(graph, nodes, cam_models, edges_to_optimize, config, previousSurfaces, stats);
+    if (config.options.get(POINTS_3D))
+        return runPoints(graph, nodes, cam_models, edges_to_optimize, config.options, stats);
     if (config.options.get(GROUND_PLANE))
         return runGroundPlane(graph, nodes, cam_models, edges_to_optimize, config.options, stats);
-    return surface_model(); // POINTS_3D and relative-orientation flavours: relax_full_extra.cpp (tests only in the reference)
+    return runRelativeOrientation(graph, nodes, edges_to_optimize, stats);
+}
+
+// TestRelaxProblem of test/test_relax.cpp:470-483: the 3-D point problem step by step.  mode 0: set-up only, 1: set-up +
+// solve, 2: set-up + relaxObservedModelOnly.  points_before / points_after: the tracks' points after the set-up / at the end.
+void points_problem_steps(const MeasurementGraph &graph, std::vector<NodePose> &nodes, model_map &cam_models,
+                          const std::vector<size_t> &edges_to_optimize, const RelaxOptionSet &options, int mode,
+                          std::vector<Vec3> *points_before, std::vector<Vec3> *points_after, relax_stats *stats)
+{
+    RelaxProblem rp(stats);
+    rp.setup3dPointProblem(graph, nodes, cam_models, edges_to_optimize, options);
+    auto collect = [&](std::vector<Vec3> *out) {
+        if (out)
+            for (const auto &et : rp.tracks())
+                for (const auto &t : et.second)
+                    out->push_back(t.point);
+    };
+    collect(points_before);
+    if (mode == 1)
+        rp.solve();
+    else if (mode == 2)
+        rp.relaxObservedModelOnly();
+    collect(points_after);
 }
 
 // ------------------------------------------------------------------------------------------------- relax_group.cpp

@@ -211,6 +211,11 @@ using model_map = std::vector<std::pair<size_t, CameraModel>>; // ankerl map<siz
 surface_model relax(const MeasurementGraph &graph, std::vector<NodePose> &nodes, model_map &cam_models,
                     const std::vector<size_t> &edges_to_optimize, const RelaxConfig &config,
                     const std::vector<surface_model> &previousSurfaces, relax_stats *stats = nullptr);
+// TestRelaxProblem of test/test_relax.cpp:470-483 (setup3dPointProblem, then solve / relaxObservedModelOnly, with the tracks'
+// points before and after): mode 0 = set-up only, 1 = + solve, 2 = + relaxObservedModelOnly
+void points_problem_steps(const MeasurementGraph &graph, std::vector<NodePose> &nodes, model_map &cam_models,
+                          const std::vector<size_t> &edges_to_optimize, const RelaxOptionSet &options, int mode,
+                          std::vector<Vec3> *points_before, std::vector<Vec3> *points_after, relax_stats *stats);
 
 // RelaxStage::init (src/pipeline/relax_stage.cpp:28-112): the primary node ids of every group, largest group first
 // (oracle/relax_cluster.cpp: k-means / spectral clustering restated)

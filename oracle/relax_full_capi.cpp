@@ -317,6 +317,59 @@ int ocx_relax(void *h, size_t n_poses, const uint64_t *pose_node, double *pose_o
     return (int)cam_models.size();
 }
 
+// TestRelaxProblem (test/test_relax.cpp:470-483): setup3dPointProblem, then nothing / solve / relaxObservedModelOnly
+// (mode 0 / 1 / 2).  before_xyz / after_xyz (cap points each): the tracks' 3-D points after the set-up and at the end.
+// model10_inout: the cam_models entry of the (single) camera model, in/out.  Returns the number of track points.
+size_t ocx_points_problem(void *h, size_t n_poses, const uint64_t *pose_node, double *pose_ori, size_t n_opt_edges,
+                          const uint64_t *opt_edges, uint32_t options, int mode, double *before_xyz, double *after_xyz, size_t cap,
+                          double *summary_out, double *model10_inout)
+{
+    auto *g = (graph_handle *)h;
+    std::vector<NodePose> poses(n_poses);
+    model_map cam_models;
+    for (size_t i = 0; i < n_poses; i++)
+    {
+        poses[i].node_id = pose_node[i];
+        poses[i].orientation = Quat{pose_ori[4 * i], pose_ori[4 * i + 1], pose_ori[4 * i + 2], pose_ori[4 * i + 3]};
+        const image_node &n = g->graph.nodes[pose_node[i]];
+        poses[i].position = n.position;
+        bool found = false;
+        for (auto &m : cam_models)
+            found |= m.first == n.model->id;
+        if (!found)
+        {
+            cam_models.emplace_back(n.model->id, *n.model);
+            if (model10_inout)
+            {
+                const size_t id = n.model->id;
+                cam_models.back().second = model_from10(model10_inout, id);
+            }
+        }
+    }
+    std::vector<size_t> opt(opt_edges, opt_edges + n_opt_edges);
+    RelaxOptionSet o;
+    o.bits = options;
+    relax_stats st;
+    std::vector<Vec3> before, after;
+    points_problem_steps(g->graph, poses, cam_models, opt, o, mode, &before, &after, &st);
+    for (size_t i = 0; i < n_poses; i++)
+    {
+        pose_ori[4 * i] = poses[i].orientation.x, pose_ori[4 * i + 1] = poses[i].orientation.y;
+        pose_ori[4 * i + 2] = poses[i].orientation.z, pose_ori[4 * i + 3] = poses[i].orientation.w;
+    }
+    for (size_t i = 0; i < before.size() && i < cap; i++)
+    {
+        if (before_xyz)
+            before_xyz[3 * i] = before[i].x, before_xyz[3 * i + 1] = before[i].y, before_xyz[3 * i + 2] = before[i].z;
+        if (after_xyz)
+            after_xyz[3 * i] = after[i].x, after_xyz[3 * i + 1] = after[i].y, after_xyz[3 * i + 2] = after[i].z;
+    }
+    stats_out(st, summary_out, nullptr, 0);
+    if (model10_inout && !cam_models.empty())
+        model_to10(cam_models[0].second, model10_inout);
+    return before.size();
+}
+
 // RelaxGroup::init + run + finalize (relax_group.cpp) on the graph.  knn10: n_nodes x 10 node ids (UINT64_MAX padded) =
 // imageGPSLocations.searchKnn(position, 10) per node.  Returns the number of local poses; local_nodes_out (cap entries)
 // receives their node ids in the sorted order, opt_edges_out the chosen edges.

@@ -4,10 +4,13 @@
 #pragma once
 
 #include "jet.hpp"
+#include "oracle.hpp"
 
 #include <algorithm>
 #include <cmath>
+#include <array>
 #include <limits>
+#include <vector>
 
 namespace oracle
 {
@@ -378,6 +381,189 @@ template <int N> struct NRayFocalRadial
     {
         const T *all[N + 1] = {rest...};
         return impl.template computeResidualsFocalRadial<T>(all, z0, z1, z2, f, pp, k, const_cast<T *>(all[N]));
+    }
+};
+
+// ---- the flavours only the reference's tests reach (relax.cpp:14-42 relative orientation, :104-115 3-D points) ----------
+template <typename T> inline void quat_inverse(const T *q, T *out) // Eigen QuaternionBase::inverse(): conjugate / squaredNorm
+{
+    const T n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (n2 > T(0.0))
+    {
+        out[0] = -q[0] / n2, out[1] = -q[1] / n2, out[2] = -q[2] / n2, out[3] = q[3] / n2;
+    }
+    else
+        out[0] = out[1] = out[2] = out[3] = T(0.0);
+}
+template <typename T> inline void quat_product(const T *a, const T *b, T *out) // Eigen quaternion product a * b (x y z w)
+{
+    out[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    out[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    out[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    out[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+template <typename T> inline T quat_angle(const T *q) // Eigen::AngleAxis<T>(q).angle()
+{
+    using std::abs;
+    using std::atan2;
+    using std::sqrt;
+    const T n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    if (n != T(0.0))
+        return T(2.0) * atan2(n, abs(q[3]));
+    return T(0.0);
+}
+
+// relax_cost_function.hpp:187-251
+struct DecomposedRotationCost
+{
+    DecomposedRotationCost(const Quat &relative_rotation, const Vec3 &relative_translation, const Vec3 &translation1,
+                           const Vec3 &translation2, int score)
+    {
+        const Vec3 d = translation2 - translation1;
+        has_translation = dot(d, d) > 1e-9 && dot(relative_translation, relative_translation) > 1e-9;
+        const double qn = std::sqrt(relative_rotation.x * relative_rotation.x + relative_rotation.y * relative_rotation.y +
+                                    relative_rotation.z * relative_rotation.z + relative_rotation.w * relative_rotation.w);
+        rel[0] = relative_rotation.x / qn, rel[1] = relative_rotation.y / qn, rel[2] = relative_rotation.z / qn, rel[3] = relative_rotation.w / qn;
+        const Vec3 td = normalized(d), rd = normalized(relative_translation);
+        tdir[0] = td.x, tdir[1] = td.y, tdir[2] = td.z;
+        rtdir[0] = rd.x, rtdir[1] = rd.y, rtdir[2] = rd.z;
+        weight = std::sqrt(score / 8.);
+    }
+    template <typename T> bool operator()(const T *rotation1, const T *rotation2, T *residuals) const
+    {
+        T res[3];
+        T inv1[4], inv2[4];
+        quat_inverse(rotation1, inv1);
+        quat_inverse(rotation2, inv2);
+        if (has_translation)
+        {
+            const V3<T> t21 = quat_rotate(inv1, V3<T>{T(tdir[0]), T(tdir[1]), T(tdir[2])});
+            res[0] = angleBetweenUnitVectors<T>(t21, V3<T>{T(rtdir[0]), T(rtdir[1]), T(rtdir[2])});
+            // rotation2.inverse() * (relative_rotation * -translation_direction).cast<T>(): the inner product in doubles
+            const V3<double> rt = quat_rotate<double>(rel, V3<double>{-tdir[0], -tdir[1], -tdir[2]});
+            const V3<T> t12 = quat_rotate(inv2, V3<T>{T(rt.x), T(rt.y), T(rt.z)});
+            res[1] = angleBetweenUnitVectors<T>(t12, V3<T>{T(-rtdir[0]), T(-rtdir[1]), T(-rtdir[2])});
+        }
+        else
+            res[0] = res[1] = T(M_PI);
+        T r21[4], relT[4] = {T(rel[0]), T(rel[1]), T(rel[2]), T(rel[3])}, prod[4];
+        quat_product(rotation1, inv2, r21);
+        quat_product(relT, r21, prod);
+        res[2] = quat_angle(prod);
+        for (int i = 0; i < 3; i++)
+            residuals[i] = T(weight) * res[i];
+        return true;
+    }
+    bool has_translation;
+    double rel[4], tdir[3], rtdir[3], weight;
+};
+
+// relax_cost_function.hpp:253-307: the decomposition with the smallest residual norm among those scoring > max / 4
+struct MultiDecomposedRotationCost
+{
+    MultiDecomposedRotationCost(const std::array<decomposed_pose, 4> &poses, const Vec3 &translation1, const Vec3 &translation2)
+    {
+        int max_score = 0;
+        for (const auto &pose : poses)
+            if (pose.score > max_score)
+                max_score = pose.score;
+        for (const auto &pose : poses)
+            if (pose.score > 0.25 * max_score)
+                decompose.emplace_back(pose.orientation, pose.position, translation1, translation2, pose.score);
+    }
+    template <typename T> bool operator()(const T *rotation1, const T *rotation2, T *residuals) const
+    {
+        using std::isfinite;
+        T lowest_res_norm(std::numeric_limits<double>::infinity());
+        T lowest_res[3] = {T(NAN), T(NAN), T(NAN)};
+        for (const auto &d : decompose)
+        {
+            T res[3];
+            if (!d(rotation1, rotation2, res))
+                continue;
+            const bool finite = isfinite(res[0]) && isfinite(res[1]) && isfinite(res[2]);
+            const T n2 = res[0] * res[0] + res[1] * res[1] + res[2] * res[2];
+            if (finite && n2 < lowest_res_norm)
+            {
+                lowest_res_norm = n2;
+                for (int i = 0; i < 3; i++)
+                    lowest_res[i] = res[i];
+            }
+        }
+        for (int i = 0; i < 3; i++)
+            residuals[i] = lowest_res[i];
+        return isfinite(lowest_res_norm);
+    }
+    std::vector<DecomposedRotationCost> decompose;
+};
+
+// image_from_3d<T>(ray, model) (distort_keypoints.hpp:44-66) with every intrinsic of type T
+template <typename T>
+inline void image_from_3d_T(const V3<T> &ray, const T &focal, const T pp[2], const T radial[3], const T tangential[2], T pixel[2])
+{
+    const T min_z = T(1e-3);
+    const T cz = (ray.z < min_z) ? min_z : ray.z;
+    const T projected[2] = {ray.x / cz, ray.y / cz};
+    T distorted[2];
+    distortProjectedRayT<T>(projected, radial, tangential, distorted);
+    pixel[0] = distorted[0] * focal + pp[0];
+    pixel[1] = distorted[1] * focal + pp[1];
+}
+
+// relax_cost_function.hpp:309-500: reprojection error of a 3-D point; which intrinsics are parameters is the variant
+struct PixelErrorCost
+{
+    Vec3 loc;
+    camera_model model;
+    double pixel[2];
+    template <typename T>
+    bool eval(const T *rotation, const T *point, const T *focal, const T *principal, const T *radial, const T *tangential, T *residuals) const
+    {
+        T inv[4];
+        quat_inverse(rotation, inv);
+        const V3<T> ray = quat_rotate(inv, V3<T>{point[0] - T(loc.x), point[1] - T(loc.y), point[2] - T(loc.z)});
+        const T f = focal ? *focal : T(model.focal_length_pixels);
+        const T pp[2] = {principal ? principal[0] : T(model.principle_point[0]), principal ? principal[1] : T(model.principle_point[1])};
+        const T k[3] = {radial ? radial[0] : T(model.radial_distortion[0]), radial ? radial[1] : T(model.radial_distortion[1]),
+                        radial ? radial[2] : T(model.radial_distortion[2])};
+        const T tg[2] = {tangential ? tangential[0] : T(model.tangential_distortion[0]),
+                         tangential ? tangential[1] : T(model.tangential_distortion[1])};
+        T px[2];
+        image_from_3d_T<T>(ray, f, pp, k, tg, px);
+        residuals[0] = px[0] - T(pixel[0]);
+        residuals[1] = px[1] - T(pixel[1]);
+        return true;
+    }
+};
+struct PixelErrorCost_Orientation : PixelErrorCost // :309-345
+{
+    template <typename T> bool operator()(const T *rotation, const T *point, T *residuals) const
+    {
+        return eval<T>(rotation, point, nullptr, nullptr, nullptr, nullptr, residuals);
+    }
+};
+struct PixelErrorCost_OrientationFocal : PixelErrorCost // :347-393
+{
+    template <typename T> bool operator()(const T *rotation, const T *point, const T *focal, const T *principal, T *residuals) const
+    {
+        return eval<T>(rotation, point, focal, principal, nullptr, nullptr, residuals);
+    }
+};
+struct PixelErrorCost_OrientationFocalRadial : PixelErrorCost // :395-445
+{
+    template <typename T>
+    bool operator()(const T *rotation, const T *point, const T *focal, const T *principal, const T *radial, T *residuals) const
+    {
+        return eval<T>(rotation, point, focal, principal, radial, nullptr, residuals);
+    }
+};
+struct PixelErrorCost_OrientationFocalRadialTangential : PixelErrorCost // :447-500
+{
+    template <typename T>
+    bool operator()(const T *rotation, const T *point, const T *focal, const T *principal, const T *radial, const T *tangential,
+                    T *residuals) const
+    {
+        return eval<T>(rotation, point, focal, principal, radial, tangential, residuals);
     }
 };
 
