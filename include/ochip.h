@@ -69,6 +69,10 @@ extern "C"
      * src/pipeline/link_stage.cpp:41-117) be in flight at once: one host thread per context.  Kernel times of
      * siblings are included in ochip_profile_get(ctx, ...). */
     int ochip_ctx_sibling(ochip_ctx *ctx, uint32_t index, ochip_ctx **out);
+    /* Re-creates the context's compute stream with the highest (high != 0) or lowest stream priority of the device: a
+     * latency-bound solve that shares the GPU with throughput kernels of other contexts is scheduled ahead of them.  The
+     * context must be idle. */
+    int ochip_ctx_set_priority(ochip_ctx *ctx, int high);
     const char *ochip_last_error(const ochip_ctx *ctx); /* ctx may be NULL: error of the last failed create */
     int ochip_device_info(const ochip_ctx *ctx, char *name, size_t name_len, int *compute_units, size_t *hbm_bytes);
     int ochip_synchronize(ochip_ctx *ctx);

@@ -16,7 +16,7 @@ MATCH_DTYPE = np.dtype([("best_k", np.uint32), ("best_count", np.uint16), ("seco
 
 # every symbol include/ochip.h declares; tests check that the built library exports all of them
 EXPORTS = [
-    "ochip_ctx_create", "ochip_ctx_destroy", "ochip_ctx_sibling", "ochip_last_error", "ochip_device_info", "ochip_synchronize",
+    "ochip_ctx_create", "ochip_ctx_destroy", "ochip_ctx_sibling", "ochip_ctx_set_priority", "ochip_last_error", "ochip_device_info", "ochip_synchronize",
     "ochip_descriptors_reserve", "ochip_upload_descriptors", "ochip_descriptor_count",
     "ochip_match_batch", "ochip_match_launch", "ochip_match_fetch",
     "ochip_upload_keypoints", "ochip_ransac_homography_batch", "ochip_refit_homography_batch",
@@ -100,6 +100,19 @@ class Context:
     def _check(self, rc, what):
         if rc != 0:
             raise OchipError(f"{what} = {rc}: {self.L.ochip_last_error(self.h).decode()}")
+
+    def sibling(self, index):
+        """The index-th sibling context (same device, own streams and scratch; owned by this context): independent work
+        submitted through it overlaps with this context's."""
+        h = C.c_void_p()
+        self._check(self.L.ochip_ctx_sibling(self.h, index, C.byref(h)), "ochip_ctx_sibling")
+        s = Context.__new__(Context)
+        s.L, s.h, s._owner = self.L, h, self
+        s.close = lambda: None          # the owner destroys it
+        return s
+
+    def set_priority(self, high=True):
+        self._check(self.L.ochip_ctx_set_priority(self.h, int(high)), "ochip_ctx_set_priority")
 
     def device_info(self):
         name = C.create_string_buffer(256)

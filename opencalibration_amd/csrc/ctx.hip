@@ -233,6 +233,21 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
     delete ctx;
 }
 
+int ochip_ctx_set_priority(ochip_ctx *ctx, int high)
+{
+    if (!ctx)
+        return OCHIP_EINVAL;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    int least = 0, greatest = 0;
+    OCHIP_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t s = nullptr;
+    OCHIP_HIP(ctx, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least));
+    (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = s;
+    return OCHIP_OK;
+}
+
 int ochip_ctx_sibling(ochip_ctx *ctx, uint32_t index, ochip_ctx **out)
 {
     if (!ctx || !out)

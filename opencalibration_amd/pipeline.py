@@ -25,10 +25,21 @@ def synthetic_views(ctx, grid, seed=7):
     return ptr, (grid.n_images, h, w)
 
 
-def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000, overlap=True):
+def relax_step(ctx, g, start_orientation, res, t):
+    """The relax stage of run() on its own (the bench pipelines it with the next survey's load + link)."""
+    t0, c0 = time.perf_counter(), time.process_time()
+    rel = g.relax_ground_plane(ctx, start_orientation)
+    ctx.synchronize()
+    t["relax"] = time.perf_counter() - t0
+    t["host_cpu_relax"] = time.process_time() - c0
+    res["relax"] = rel
+    return rel
+
+
+def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000, overlap=True, relax=True):
     """load (extract) -> link -> relax.  Returns (graph, result dict, stage seconds).  overlap: the load and link
     stages run overlapped (och_graph_load_link_images) as the reference's pipeline overlaps the stages of consecutive
-    batches; the graph is the same either way."""
+    batches; the graph is the same either way.  relax=False: stop after the link stage (relax_step() does the rest)."""
     n, h, w = shape
     t = {}
     g = host.Graph()
@@ -39,6 +50,8 @@ def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000, ov
             ctx, images_ptr, mid, grid.position, start_orientation, max_keypoints, device_shape=(n, h, w))
         t["extract"], t["link"] = t_ex, time.perf_counter() - t0 - t_ex   # link = what the linking adds after the last features
         t["host_cpu_load_link"] = time.process_time() - c0                 # CPU seconds of all host threads
+        if not relax:
+            return g, dict(features_per_image=feats_mean, sparse_per_image=sparse_mean, link_timers=link_timers, edges=g.num_edges), t
         t0, c0 = time.perf_counter(), time.process_time()
         rel = g.relax_ground_plane(ctx, start_orientation)
         ctx.synchronize()
