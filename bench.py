@@ -23,6 +23,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The step keeps ~8 HIP streams busy (3 extraction sequences, 3 link runners, the relax of the previous survey, copies).
+# The ROCm runtime maps streams onto 4 hardware queues by default, so a short latency-bound launch can sit behind another
+# stream's long kernel in the same queue; 16 queues measured +5-6 % images/s.  Read by the runtime
+# when it initialises, hence set before anything touches HIP.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def _env_int(name, default):

@@ -226,6 +226,8 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
         (void)hipHostFree(b.first);
     if (ctx->sync_event)
         (void)hipEventDestroy(ctx->sync_event);
+    for (hipStream_t r : ctx->retired_streams)
+        (void)hipStreamDestroy(r);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     if (ctx->copy_stream)
@@ -243,8 +245,8 @@ int ochip_ctx_set_priority(ochip_ctx *ctx, int high)
     OCHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     hipStream_t s = nullptr;
     OCHIP_HIP(ctx, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least));
-    (void)hipStreamDestroy(ctx->stream);
-    ctx->stream = s;
+    ctx->retired_streams.push_back(ctx->stream); // destroyed with the context, not here: tools that trace the process
+    ctx->stream = s;                             // (rocprofv3) keep per-stream state that other threads may still touch
     return OCHIP_OK;
 }
 

@@ -23,6 +23,7 @@ struct ochip_ctx
     int device = 0;
     hipStream_t stream = nullptr;     // compute stream: every kernel of the hot path is launched here
     hipStream_t copy_stream = nullptr;
+    std::vector<hipStream_t> retired_streams; // replaced by ochip_ctx_set_priority
     hipEvent_t sync_event = nullptr;  // ochip_stream_wait: a blocking-sync event (created on first use)
     bool blocking_wait = true;        // OCHIP_BLOCKING_SYNC=0: let the runtime poll instead
     std::string error;
