@@ -118,7 +118,8 @@ def main():
             if getattr(th, "error", None):
                 raise th.error
             last.update(res=res, t=t, link_work=last.get("link_work"))
-            g.close()
+            if not relax_overlap:
+                g.close()
             if acc is not None:
                 for k, v in list(t.items()) + [("link_" + k, v) for k, v in res["link_timers"].items()] + \
                         [("relax_setup_host", res["relax"]["setup_host_s"]), ("relax_device", res["relax"]["device_s"]),
@@ -140,6 +141,7 @@ def main():
                 def work(g=g, res=res, t=t):
                     try:
                         pipeline.relax_step(rctx, g, start_ori, res, t)
+                        g.close()                    # (1.8 GB of feature records: freed off the main thread)
                     except Exception as ex:          # surfaces in collect()
                         threading.current_thread().error = ex
 
