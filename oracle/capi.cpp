@@ -1,6 +1,7 @@
 // ORACLE — test infrastructure only (see oracle.hpp).
 // Flat C entry points so tests/ (ctypes) and bench.py's cpu_baseline leg can drive the restatement.
 #include "oracle.hpp"
+#include "akaze.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -370,6 +371,16 @@ int oc_num_threads()
 #else
     return 1;
 #endif
+}
+
+// FED step sizes of one diffusion cycle (fed_tau_by_process_time, fed.cpp of AKAZE [3P]); returns their number
+size_t oc_fed_tau(float T, int M, float tau_max, int reordering, float *out, size_t cap)
+{
+    std::vector<float> tau;
+    oracle::akaze::fed_tau_by_process_time(T, M, tau_max, reordering != 0, tau);
+    for (size_t i = 0; i < tau.size() && i < cap; i++)
+        out[i] = tau[i];
+    return tau.size();
 }
 
 } // extern "C"

@@ -127,3 +127,40 @@ def test_two_views_match_at_the_true_motion():
     # the dominant orientations turn with the view
     da_ang = (kb[order[good, 0], 3] - ka[good, 3] + rot + np.pi) % (2 * np.pi) - np.pi
     assert np.mean(np.abs(da_ang[err < 2.0]) < 0.25) > 0.85
+
+
+def test_fed_cycles_add_up_to_the_evolution_time():
+    """Fast Explicit Diffusion (the paper's section 3): one cycle of n steps tau_i = tau_max / (2 cos^2(pi (2i + 1) / (4n + 2))),
+    scaled so that they add up to the stopping time T of the level transition, reaches T with n = O(sqrt(T)) steps of
+    which the largest exceed the explicit scheme's stability limit tau_max = 0.25.  T_i = (sigma_i^2 - sigma_{i-1}^2) / 2
+    over AKAZE's 4 octaves x 4 sublevels, sigma_0 = 1.6."""
+    import ctypes as C
+    L = pyoracle.lib()
+    L.oc_fed_tau.restype = C.c_size_t
+    L.oc_fed_tau.argtypes = [C.c_float, C.c_int, C.c_float, C.c_int, np.ctypeslib.ndpointer(np.float32), C.c_size_t]
+    sig = [1.6 * 2.0 ** (o + j / 4.0) for o in range(4) for j in range(4)]
+    out = np.zeros(512, np.float32)
+    total_steps = 0
+    for a, b in zip(sig, sig[1:]):
+        T = np.float32(0.5 * (b * b - a * a))
+        n = L.oc_fed_tau(T, 1, 0.25, 1, out, len(out))
+        tau = out[:n].astype(np.float64)
+        assert n == int(np.ceil(np.sqrt(3.0 * T / 0.25 + 0.25) - 0.5 - 1e-8))
+        assert abs(tau.sum() - T) < 1e-4 * T and (tau > 0).all()
+        # the same multiset as the closed form (the cycle is only re-ordered for stability)
+        ideal = 0.25 / (2.0 * np.cos(np.pi * (2.0 * np.arange(n) + 1.0) / (4.0 * n + 2.0)) ** 2)
+        ideal *= T / ideal.sum()
+        assert np.allclose(np.sort(tau), np.sort(ideal), rtol=1e-5)
+        if n > 1:
+            assert tau.max() > 0.25                   # super-stable steps: the point of FED
+        total_steps += n
+    assert total_steps < 200                          # 15 transitions up to T = 118: an explicit scheme would need ~ 4 T steps each
+
+
+def test_descriptor_has_486_bits(scene):
+    """M-LDB with 3 channels over 2x2, 3x3 and 4x4 grids: (C(4,2) + C(9,2) + C(16,2)) x 3 = 486 comparisons."""
+    g, kp, d = scene
+    assert (6 + 36 + 120) * 3 == 486
+    assert ((d[:, 7] >> np.uint64(486 - 7 * 64)) == 0).all()          # nothing beyond bit 485
+    bits = np.unpackbits(d.view(np.uint8), axis=1, bitorder="little")[:, :486]
+    assert 0.2 < bits.mean() < 0.8 and bits.any(axis=0).mean() > 0.95   # every comparison fires somewhere
