@@ -1179,6 +1179,18 @@ struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cell
 
 // One 64-thread workgroup per surviving candidate: sub-pixel fit, dominant orientation, 486-bit M-LDB.
 // Sums run in the restatement's sequential order (one lane per window / per grid cell) so bits agree.
+// OCHIP_DESCRIBE_PROFILE=1: wave-resident cycles per phase of describe_kernel, summed over all waves (lane 0 of a wave
+// adds the time since the previous mark), printed after every launch - where a keypoint's life goes
+__device__ unsigned long long g_desc_prof[8];
+#define DESC_T(i)                                                                                                            \
+    if (PROFILE)                                                                                                             \
+    {                                                                                                                        \
+        const unsigned long long tn = __builtin_readcyclecounter();                                                          \
+        if (lane == 0)                                                                                                       \
+            atomicAdd(&g_desc_prof[i], tn - tprev);                                                                          \
+        tprev = tn;                                                                                                          \
+    }
+template <bool PROFILE>
 __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
                                                       unsigned int max_cands, const unsigned int *__restrict__ live,
                                                       const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
@@ -1193,13 +1205,21 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
     // four wavefronts = four CONSECUTIVE candidates per workgroup: list neighbours are spatial neighbours, their patches
     // overlap, and a workgroup's waves share the CU's L1 - the descriptor is bound by the 128-byte lines its gathers pull
     // from the L2.  The waves do not talk to each other: every wave has its own LDS arrays and only wave-level barriers.
-    __shared__ float4 osmp_all[4][109]; // orientation samples: weighted dx, dy, their angle (one 16-byte LDS read each)
+    // LDS is what limits the waves a CU holds here (59 VGPRs would allow 8 per SIMD), and the kernel spends its time
+    // waiting for gathers: the lattice is kept as 12-byte records (intensity, rotated dx, rotated dy - whether a sample
+    // lies inside the image is recomputed for the few keypoints near a border instead of stored), and the orientation
+    // samples (weighted dx, dy, their angle: one 16-byte LDS read each), dead before the lattice is gathered, share its
+    // space: 22.6 KB per workgroup, 7 waves per SIMD instead of 4.
     __shared__ float vals_all[4][29][3];
-    __shared__ float4 smp_all[4][441];  // the 21 x 21 descriptor sample lattice: intensity, rotated dx, rotated dy, inside flag
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float4(&osmp)[109] = osmp_all[wv];
+    __shared__ float4 smp_all[4][331]; // 441 x 3 floats, padded to a multiple of 16 bytes
+    // wv is the same in all lanes of a wave; saying so lets everything that hangs off it - the list entry, the candidate
+    // record, the level's geometry, the nine determinant values of the sub-pixel fit - travel as scalar loads, a path of
+    // its own beside the vector memory pipeline that the other waves' gathers keep busy (this chain of four dependent
+    // round trips was 47 % of a wave's life when it queued behind them)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float4 *const osmp = smp_all[wv]; // [109]
     float(&vals)[29][3] = vals_all[wv];
-    float4(&smp)[441] = smp_all[wv];
+    float *const smp = reinterpret_cast<float *>(smp_all[wv]);
     auto wave_sync = []() {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // LDS writes of the wave before LDS reads after
         __builtin_amdgcn_wave_barrier();
@@ -1217,6 +1237,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
     // that chain times the waves a CU can hold.  Everything whose address is known up front is therefore requested
     // here, together: the candidate record, the per-lane table entries of the orientation samples and of the
     // descriptor bits (the compiler keeps them in flight across the early exits).
+    unsigned long long tprev = PROFILE ? __builtin_readcyclecounter() : 0;
     const cand_t c = cands[slot];
     const unsigned int oq0 = tab->ori_q[lane], oq1 = tab->ori_q[lane + 64];
     const float og0 = tab->ori_g[lane], og1 = tab->ori_g[lane + 64];
@@ -1249,6 +1270,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
             valid_out[slot] = 0;
         return;
     }
+    DESC_T(0)
     const float ratio = (float)(1 << l.octave);
     const float kx = ((float)c.x + dx) * ratio + 0.5f * (ratio - 1.0f);
     const float ky = ((float)c.y + dy) * ratio + 0.5f * (ratio - 1.0f);
@@ -1268,20 +1290,23 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
         const float2 g0 = pLxy[(size_t)iy0 * w + ix0];
         const float2 g1 = second ? pLxy[(size_t)iy1 * w + ix1] : make_float2(0.0f, 0.0f);
         const float lx0 = g0.x, ly0 = g0.y, lx1 = g1.x, ly1 = g1.y;
-        // an angle of exactly 0 or 2 pi lies in no window (they are open intervals inside (0, 2 pi)); stored as NaN
-        // it fails every comparison below, which lets a window test be two compares
-        const float TWO_PI = 6.28318530717958647692f, QNAN = __builtin_nanf("");
+        // an angle of exactly 0 or 2 pi lies in no window (they are open intervals inside (0, 2 pi)): such a sample is
+        // stored as (+0, +0), which leaves every sum unchanged whether a window test lets it in or not - so the test
+        // itself never has to exclude it
+        const float TWO_PI = 6.28318530717958647692f;
         const float rx0 = og0 * lx0, ry0 = og0 * ly0;
         const float a0 = fast_atan2(ry0, rx0);
-        osmp[lane] = make_float4(rx0, ry0, (a0 > 0.0f && a0 < TWO_PI) ? a0 : QNAN, 0.0f);
+        osmp[lane] = (a0 > 0.0f && a0 < TWO_PI) ? make_float4(rx0, ry0, a0, 0.0f) : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
         if (second)
         {
             const float rx1 = og1 * lx1, ry1 = og1 * ly1;
             const float a1 = fast_atan2(ry1, rx1);
-            osmp[lane + 64] = make_float4(rx1, ry1, (a1 > 0.0f && a1 < TWO_PI) ? a1 : QNAN, 0.0f);
+            osmp[lane + 64] =
+                (a1 > 0.0f && a1 < TWO_PI) ? make_float4(rx1, ry1, a1, 0.0f) : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
         }
     }
     wave_sync();
+    DESC_T(1)
     const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
     // 42 sliding windows of pi/3, one per lane; the sums run over the samples in their order.  A sample outside the
     // window adds +0, which leaves a sum that starts at +0 unchanged bit for bit.
@@ -1290,18 +1315,23 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
     {
         const float ang1 = tab->win_ang1[lane]; // float-accumulated window starts (host table, as the restatement's loop)
         const float ang2 = (ang1 + PI_F / 3.0f > TWO_PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
-        // the window is the open interval (ang1, ang2), or - wrapped - (0, ang2) and (ang1, 2 pi): with the angles 0
-        // and 2 pi out of the way (NaN) that is "above ang1 AND below ang2", or for a wrapped window OR.  No
-        // short-circuits: the loop has no branches and its LDS reads are issued in batches.  The selected sample enters
-        // as x * 1 + sum (one rounding, that of the add) or x * 0 + sum (the sum, unchanged).
+        // the window is the open interval (ang1, ang2), or - wrapped - (0, ang2) and (ang1, 2 pi).  All these angles
+        // are positive floats, which order like their bit patterns, so "inside (ang1, ang2)" is ONE unsigned range
+        // test, (a - (ang1 + 1 ulp)) <= (ang2 - ang1 - 2 ulp) in wrapping integer arithmetic, and a wrapped window is
+        // the complement of the closed range [ang2, ang1]: the lane's constants (range start, length, and which of 1.0
+        // and 0.0 the test's two answers stand for) carry the case, the loop is four VALU instructions per sample
+        // without branches.  The selected sample enters as x * 1 + sum (one rounding, that of the add) or x * 0 + sum
+        // (the sum, unchanged).
         const bool wrapped = ang2 < ang1;
+        const unsigned int u1 = __float_as_uint(ang1), u2 = __float_as_uint(ang2);
+        const unsigned int range_start = wrapped ? u2 : u1 + 1u, range_len = wrapped ? u1 - u2 : u2 - u1 - 2u;
+        const float in_range = wrapped ? 0.0f : 1.0f, out_of_range = wrapped ? 1.0f : 0.0f;
         pkf2 sum = {0.0f, 0.0f}; // (sumX, sumY): one packed fp32 FMA per sample (v_pk_fma_f32), IEEE per component
 #pragma unroll 8
         for (int q = 0; q < 109; q++)
         {
             const float4 sm = osmp[q];
-            const bool c1 = sm.z > ang1, c2 = sm.z < ang2;
-            const float in = ((c1 & c2) | (wrapped & (c1 | c2))) ? 1.0f : 0.0f;
+            const float in = (__float_as_uint(sm.z) - range_start <= range_len) ? in_range : out_of_range;
             sum = __builtin_elementwise_fma(pkf2{sm.x, sm.y}, pkf2{in, in}, sum);
         }
         const float sumX = sum.x, sumY = sum.y;
@@ -1322,9 +1352,11 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
         }
     }
     const float angle = wmag > 0.0f ? wangle : 0.0f;
+    DESC_T(2)
     float si, co;
     sincos_poly(angle, &si, &co);
     const float fs = (float)s;
+    bool all_inside = true;
     // every grid (2x2, 3x3, 4x4) samples the same rotated 21 x 21 lattice: gather it once with all lanes,
     // then run the per-cell sums in their sequential order out of LDS
     {
@@ -1347,6 +1379,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
             rx[t] = g.x;
             ry[t] = g.y;
         }
+        wave_sync(); // the orientation samples (same LDS) have been read by every window
 #pragma unroll
         for (int t = 0; t < 7; t++)
         {
@@ -1354,11 +1387,16 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
             if (p < 441)
             {
                 const float rry = rx[t] * co + ry[t] * si, rrx = -rx[t] * si + ry[t] * co;
-                smp[p] = inside[t] ? make_float4(ri[t], rrx, rry, 1.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                smp[3 * p] = inside[t] ? ri[t] : 0.0f;
+                smp[3 * p + 1] = inside[t] ? rrx : 0.0f;
+                smp[3 * p + 2] = inside[t] ? rry : 0.0f;
+                all_inside = all_inside && inside[t];
             }
         }
     }
+    all_inside = __all(all_inside) != 0;
     wave_sync();
+    DESC_T(3)
     if (lane < 29)
     {
         int lvl, cell;
@@ -1371,21 +1409,22 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
         const int g = lvl + 2;
         const int step = (lvl == 0) ? 10 : (lvl == 1 ? 7 : 5); // ceil(20 / g)
         const int i0 = -10 + (cell / g) * step, j0 = -10 + (cell % g) * step;
-        pkf2 acc01 = {0.0f, 0.0f}, acc23 = {0.0f, 0.0f}; // (di, ddx), (ddy, ns): packed fp32 adds, IEEE per component
+        pkf2 acc01 = {0.0f, 0.0f}; // (di, ddx): packed fp32 adds, IEEE per component
+        float acc2 = 0.0f;         // ddy
         // every cell walks its step x step samples row by row; the walk is written once over the largest cell (10 x 10,
         // fully unrolled, LDS offsets immediate) and a lane takes part in a step while it is inside its own cell:
         // the 4 x 4 grid's lanes (13..28, step 5) in the first 5 x 5, the 3 x 3 grid's (4..12, step 7) in the first
         // 7 x 7, the 2 x 2 grid's (0..3) everywhere - each lane still adds its samples in its own row-major order
-        const float4 *pb = &smp[(i0 + 10) * 21 + (j0 + 10)];
+        const float *pb = &smp[3 * ((i0 + 10) * 21 + (j0 + 10))];
         // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
         // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch here
         auto run = [&](int a, int b0, int b1) { // columns b0..b1-1 of row a (compile-time after unrolling)
 #pragma unroll
             for (int bb = b0; bb < b1; bb++)
             {
-                const float4 v = pb[a * 21 + bb];
-                acc01 = acc01 + pkf2{v.x, v.y};
-                acc23 = acc23 + pkf2{v.z, v.w}; // ns: small integers, exact in float
+                const float *v = pb + 3 * (a * 21 + bb);
+                acc01 = acc01 + pkf2{v[0], v[1]};
+                acc2 = acc2 + v[2];
             }
         };
         // the set of lanes only changes where a row leaves a smaller cell: 22 predicated regions, not 100
@@ -1412,13 +1451,29 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
             for (int a = 7; a < 10; a++)
                 run(a, 0, 10);
         }
-        const float di = acc01.x, ddx = acc01.y, ddy = acc23.x, ns = acc23.y;
+        // number of samples of the cell inside the image: all of them, except for a keypoint near a border, whose lanes
+        // repeat the lattice arithmetic of the gather above (same expressions, same roundings, same answers)
+        int count = step * step;
+        if (!all_inside)
+        {
+            count = 0;
+            for (int a = i0; a < i0 + step; a++)
+                for (int bb = j0; bb < j0 + step; bb++)
+                {
+                    const float sy = yf + ((float)bb * co * fs + (float)a * si * fs);
+                    const float sx = xf + (-(float)bb * si * fs + (float)a * co * fs);
+                    const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
+                    count += !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h) ? 1 : 0;
+                }
+        }
+        const float di = acc01.x, ddx = acc01.y, ddy = acc2, ns = (float)count;
         const float inv = fmaxf(ns, 1.0f);
         vals[lane][0] = di / inv;
         vals[lane][1] = ddx / inv;
         vals[lane][2] = ddy / inv;
     }
     wave_sync();
+    DESC_T(4)
     for (int wd = 0; wd < 8; wd++)
     {
         const int bit = wd * 64 + lane;
@@ -1446,6 +1501,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
         atomicOr(&vmask[(size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6)],
                  1ull << (c.x & 63));
     }
+    DESC_T(5)
 }
 
 // The keypoints leave the device in AKAZE's detection order (level, then row, then column of the extremum - the order
@@ -2254,10 +2310,33 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         hipLaunchKernelGGL(live_list_kernel, dim3(B), dim3(256), 0, st, (const unsigned char *)d_dead, (const unsigned int *)d_ncand,
                            max_cands, d_live, d_nlive);
         OCHIP_HIP(ctx, hipMemsetAsync(d_valid, 0, (size_t)B * max_cands, st));
-        hipLaunchKernelGGL(describe_kernel, dim3(512 * (((max_n + 3) / 4 + 511) / 512), 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
-                           (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live, (const float *)d_Lt,
-                           (const float2 *)d_Lxy, (const float *)d_Ldet, img_stride, LV, dfactor,
-                           (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap, d_vmask, mask_stride);
+        // the grid covers the longest list of survivors, not of candidates (a third to a half of the workgroups would
+        // find nothing to do, and an empty workgroup still takes a slot with its 22 KB of LDS for a microsecond): one more
+        // 400-byte read-back per chunk, hidden under the other launch sequences in flight
+        std::vector<unsigned int> nlive(B);
+        OCHIP_HIP(ctx, hipMemcpyAsync(nlive.data(), d_nlive, B * 4, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+        const unsigned int max_live = *std::max_element(nlive.begin(), nlive.end());
+        static const bool profile_describe = getenv("OCHIP_DESCRIBE_PROFILE") != nullptr;
+#define OCHIP_LAUNCH_DESCRIBE(P)                                                                                               \
+    hipLaunchKernelGGL(describe_kernel<P>, dim3(512 * (((max_live + 3) / 4 + 511) / 512), 1, B), dim3(256), 0, st,             \
+                       (const cand_t *)d_cands, (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live,       \
+                       (const float *)d_Lt, (const float2 *)d_Lxy, (const float *)d_Ldet, img_stride, LV, dfactor,            \
+                       (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap, d_vmask, mask_stride)
+        if (max_live == 0)
+            ;
+        else if (!profile_describe)
+            OCHIP_LAUNCH_DESCRIBE(false);
+        else
+        {
+            OCHIP_LAUNCH_DESCRIBE(true);
+            unsigned long long hp[8];
+            OCHIP_HIP(ctx, hipStreamSynchronize(st));
+            OCHIP_HIP(ctx, hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_desc_prof), sizeof(hp)));
+            fprintf(stderr, "[describe] cumulative wave cycles: fit %llu, orientation gather %llu, windows %llu, lattice gather %llu, cells %llu, bits %llu\n",
+                    hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]);
+        }
+#undef OCHIP_LAUNCH_DESCRIBE
     }
     if (max_n > 0)
     {
