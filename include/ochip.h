@@ -253,14 +253,29 @@ extern "C"
      * chunk = ceil(n_pairs / world); after every evaluation `exchange` must all-gather the record arrays in place
      * (rank r's slice of an array starts at ptr + r * bytes_per_rank; acc_bytes_per_rank is 0 for a cost-only
      * evaluation) - an RCCL all-gather over xGMI in production (torch.distributed backend "nccl"), any transport
-     * in tests - and return 0 once the gathered data is visible to the device.  The library synchronises its
-     * stream before the call.  Every rank then runs the same deterministic assembly and linear solve on the same
+     * in tests - and return 0 once the gathered data is visible to later work on the context's stream.  The library
+     * synchronises its stream before the call.  `exchange` is called whenever it is given, also with world == 1.  Every rank then runs the same deterministic assembly and linear solve on the same
      * records, so the result is bit-identical to the unsharded solve.  This is the one exchange step of the path
      * (single-group global relax, src/pipeline/pipeline.cpp:653-655; Ceres itself is single-process). */
     typedef int (*ochip_relax_exchange_fn)(void *user, void *acc_dev, uint64_t acc_bytes_per_rank, void *cost_dev,
                                            uint64_t cost_bytes_per_rank, void *fail_dev, uint64_t fail_bytes_per_rank);
     int ochip_relax_set_shard(ochip_relax_problem *p, uint32_t rank, uint32_t world, ochip_relax_exchange_fn exchange,
                               void *user);
+    /* The native transport for that exchange: RCCL all-gathers, in place, on the context's compute stream (no host
+     * wait: the solver's next kernels are on the same stream).  librccl is resolved at run time; the calls fail with
+     * OCHIP_EHIP where it is absent.  Rank 0 draws the id (ncclGetUniqueId) and hands it to the other ranks by any means;
+     * every rank then creates its communicator on the context its relax problem lives on and passes
+     * ochip_rccl_relax_exchange / the communicator as `exchange` / `user` of ochip_relax_set_shard.
+     * Stands where SURVEY.md section 8b sketches ochip_allreduce_normal_eq over ncclAllReduce: the per-pair records are
+     * 4 MB per evaluation at C3 against 72 MB for the dense normal equations. */
+#define OCHIP_RCCL_ID_BYTES 128
+    typedef struct ochip_rccl_comm ochip_rccl_comm;
+    int ochip_rccl_unique_id(ochip_ctx *ctx, uint8_t *id /* OCHIP_RCCL_ID_BYTES */);
+    int ochip_rccl_comm_create(ochip_ctx *ctx, const uint8_t *id, uint32_t rank, uint32_t world, ochip_rccl_comm **out);
+    void ochip_rccl_comm_destroy(ochip_rccl_comm *comm);
+    int ochip_rccl_comm_stats(const ochip_rccl_comm *comm, uint64_t *exchanges, uint64_t *bytes_gathered);
+    int ochip_rccl_relax_exchange(void *user, void *acc_dev, uint64_t acc_bytes_per_rank, void *cost_dev,
+                                  uint64_t cost_bytes_per_rank, void *fail_dev, uint64_t fail_bytes_per_rank);
     /* cam_q: n_cams x 4; ochip_relax_solve leaves the optimised cameras' quaternions normalised exactly as
      * RelaxProblem::solve does after every Solve (:1410-1413); plane_z: 3 */
     int ochip_relax_get_state(ochip_relax_problem *p, double *cam_q, double *plane_z);

@@ -29,6 +29,8 @@ EXPORTS = [
     "ochip_profile_reset", "ochip_profile_get", "ochip_match_work", "ochip_relax_work",
     "ochip_debug_fp64",
     "ochip_dense_index_create", "ochip_dense_index_destroy", "ochip_dense_match",
+    "ochip_rccl_unique_id", "ochip_rccl_comm_create", "ochip_rccl_comm_destroy", "ochip_rccl_comm_stats",
+    "ochip_rccl_relax_exchange",
 ]
 
 _lib = None
@@ -53,6 +55,11 @@ def load():
         L.ochip_last_error.restype = C.c_char_p
         L.ochip_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(i32), C.POINTER(C.c_size_t)]
         L.ochip_synchronize.argtypes = [vp]
+        L.ochip_rccl_unique_id.argtypes = [vp, vp]
+        L.ochip_rccl_comm_create.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
+        L.ochip_rccl_comm_destroy.argtypes = [vp]
+        L.ochip_rccl_comm_destroy.restype = None
+        L.ochip_rccl_comm_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.ochip_descriptors_reserve.argtypes = [vp, u32, u64]
         L.ochip_upload_descriptors.argtypes = [vp, u32, vp, u32]
         L.ochip_descriptor_count.argtypes = [vp, u32, C.POINTER(u32)]
@@ -73,6 +80,31 @@ def load():
         L.ochip_synth_views_read.argtypes = [vp, vp, u32, i32, i32, vp]
         _lib = L
     return _lib
+
+
+class RcclComm:
+    """ochip_rccl_comm: all-gathers on the owning context's stream (include/ochip.h)."""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self.h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        ctx._check(ctx.L.ochip_rccl_comm_create(ctx.h, buf, self.rank, self.world, C.byref(self.h)), "ochip_rccl_comm_create")
+
+    @property
+    def exchange(self):
+        """(function pointer, user pointer) for ochip_relax_set_shard."""
+        return C.cast(self.ctx.L.ochip_rccl_relax_exchange, C.c_void_p).value, self.h
+
+    def stats(self):
+        n, b = C.c_uint64(), C.c_uint64()
+        self.ctx._check(self.ctx.L.ochip_rccl_comm_stats(self.h, C.byref(n), C.byref(b)), "ochip_rccl_comm_stats")
+        return {"exchanges": n.value, "bytes_gathered": b.value}
+
+    def close(self):
+        if self.h:
+            self.ctx.L.ochip_rccl_comm_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 class Context:
@@ -110,6 +142,16 @@ class Context:
         s.L, s.h, s._owner = self.L, h, self
         s.close = lambda: None          # the owner destroys it
         return s
+
+    def rccl_unique_id(self):
+        """ncclGetUniqueId as bytes (rank 0 draws it and hands it to the other ranks)."""
+        buf = (C.c_uint8 * 128)()
+        self._check(self.L.ochip_rccl_unique_id(self.h, buf), "ochip_rccl_unique_id")
+        return bytes(buf)
+
+    def rccl_comm(self, unique_id, rank, world):
+        """This rank's RCCL communicator on this context (RcclComm): the native transport of the sharded relax."""
+        return RcclComm(self, unique_id, rank, world)
 
     def set_priority(self, high=True):
         self._check(self.L.ochip_ctx_set_priority(self.h, int(high)), "ochip_ctx_set_priority")

@@ -142,7 +142,7 @@ class GroundPlaneProblem
             *error = std::string("ochip_relax_problem_create: ") + ochip_last_error(_ctx);
             return false;
         }
-        if (shard && shard->world > 1 &&
+        if (shard && (shard->world > 1 || shard->exchange) &&
             ochip_relax_set_shard(_dev, shard->rank, shard->world, shard->exchange, shard->user) != OCHIP_OK)
         {
             *error = std::string("ochip_relax_set_shard: ") + ochip_last_error(_ctx);

@@ -983,7 +983,7 @@ int ochip_relax_set_shard(ochip_relax_problem *p, uint32_t rank, uint32_t world,
     p->shard_rank = rank;
     p->shard_world = world;
     p->shard_chunk = chunk;
-    p->exchange = world > 1 ? fn : nullptr;
+    p->exchange = fn;
     p->exchange_user = user;
     return OCHIP_OK;
 }

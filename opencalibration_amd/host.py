@@ -99,7 +99,7 @@ def load():
                                              _u64p, _f64p, _u64p, vp, vp, sz, _u64p, _f64p, _f64p]
         L.och_relax_last_error.restype = C.c_char_p
         L.och_graph_relax_ground_plane.argtypes = [vp, vp, _f64p, _f64p, _f64p]
-        L.och_graph_relax_ground_plane_sharded.argtypes = [vp, vp, _f64p, _f64p, _f64p, u32, u32, RELAX_EXCHANGE_FN, vp]
+        L.och_graph_relax_ground_plane_sharded.argtypes = [vp, vp, _f64p, _f64p, _f64p, u32, u32, vp, vp]
         L.och_surface_create.restype = vp
         L.och_surface_destroy.argtypes = [vp]
         L.och_surface_destroy.restype = None
@@ -671,8 +671,9 @@ class Graph:
     def relax_ground_plane(self, ctx, orientations, shard=None):
         """All nodes as one relax group, every edge whitelisted; updates and returns the orientations.
         shard = (rank, world, exchange): evaluate only this rank's share of the residual blocks; `exchange` is a
-        RELAX_EXCHANGE_FN (parallel.relax_exchange builds one on torch.distributed) and every rank gets the same,
-        bit-identical result."""
+        RELAX_EXCHANGE_FN (parallel.relax_exchange builds one on torch.distributed) or a capi.RcclComm created on `ctx`
+        (the native transport: RCCL all-gathers on the context's stream), and every rank gets the same, bit-identical
+        result."""
         ori = np.ascontiguousarray(orientations, np.float64).copy()
         if ori.shape != (self.num_nodes, 4):
             raise ValueError("orientations must be %d x 4, got %r" % (self.num_nodes, ori.shape))
@@ -681,7 +682,11 @@ class Graph:
             rc = self.L.och_graph_relax_ground_plane(self.h, ctx.h, ori, plane, summary)
         else:
             rank, world, exchange = shard
-            rc = self.L.och_graph_relax_ground_plane_sharded(self.h, ctx.h, ori, plane, summary, rank, world, exchange, None)
+            if isinstance(exchange, capi.RcclComm):
+                fn, user = exchange.exchange
+            else:
+                fn, user = C.cast(exchange, C.c_void_p).value, None
+            rc = self.L.och_graph_relax_ground_plane_sharded(self.h, ctx.h, ori, plane, summary, rank, world, fn, user)
         if rc != 0:
             raise capi.OchipError("relax failed: " + self.L.och_last_error(self.h).decode())
         out = dict(zip(RELAX_SUMMARY_NAMES, summary.tolist()))

@@ -98,6 +98,21 @@ def relax_exchange(group=None):
     return RELAX_EXCHANGE_FN(callback)
 
 
+def relax_exchange_rccl(ctx, group=None):
+    """The native transport of the sharded relax: an RCCL communicator owned by libochip on `ctx` (the context the relax
+    runs on), its all-gathers enqueued on that context's stream by the library itself - no Python in the solve loop, no
+    host wait.  torch.distributed only carries the 128-byte ncclUniqueId from rank 0 to the others (any backend).
+    Returns the capi.RcclComm to pass as Graph.relax_ground_plane(..., shard=(rank, world, comm)); close() it afterwards."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    box = [ctx.rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    return ctx.rccl_comm(box[0], rank, world)
+
+
 def link_sharded(make_graph, ctx, group=None):
     """One survey's link stage over the ranks of `group` on the DEVICE path.  `make_graph()` builds the survey's graph with
     its nodes (all images' features: the descriptor sets are small) and no edges.  Every rank links
