@@ -28,6 +28,16 @@ sys.path.insert(0, ROOT)
 # stream's long kernel in the same queue; 16 queues measured +5-6 % images/s.  Read by the runtime
 # when it initialises, hence set before anything touches HIP.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# A survey's feature lists (1.8 MB per image) are allocated by the host tail and freed with the graph one step later.
+# glibc hands such blocks straight back to the kernel (mmap threshold, heap trimming), so every step would page-fault its
+# 2 GB in again, 4 KB at a time, inside the tail's OpenMP team; a long-running pipeline process keeps them.
+if os.environ.get("OCHIP_BENCH_KEEP_HEAP", "1") != "0":
+    import ctypes as _ctypes
+
+    _libc = _ctypes.CDLL("libc.so.6")
+    _libc.mallopt(-3, 32 << 20)   # M_MMAP_THRESHOLD: its maximum
+    _libc.mallopt(-1, 1 << 30)    # M_TRIM_THRESHOLD
+    _libc.mallopt(-2, 64 << 20)   # M_TOP_PAD
 
 
 def _env_int(name, default):

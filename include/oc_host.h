@@ -82,6 +82,13 @@ extern "C"
      * {x, y, size, angle, response, level} in cv::AKAZE's order -> loc / strength / desc as above; returns the count. */
     size_t och_extract_tail(const float *kp6, const uint64_t *desc, uint32_t n, double scale, double *loc, float *strength,
                             uint64_t *desc_out, uint64_t *num_sparse);
+    /* Cumulative CPU seconds of that tail's phases, recorded while OCHIP_EXTRACT_VERBOSE is set: ordering, NMS, feature
+     * records, total, and the number of images whose responses tied (they take std::sort's route). */
+    void och_extract_tail_profile(double *out5);
+    /* The strength order of that tail alone: the permutation of 0..n-1 that std::sort by descending response produces
+     * (extract_features.cpp:55-56; ties keep whatever order libstdc++'s introsort leaves them in).  use_std != 0 calls
+     * std::sort itself, 0 the library's own implementation of the same sequence of moves (host/sort_like_std.hpp). */
+    void och_sort_by_response(const float *response, uint32_t n, uint32_t *order_out, int use_std);
     /* The load stage's job for a batch of equally sized images (src/pipeline/load_stage.cpp:43-110: extract_features,
      * then one graph node per image): extract on the device in chunks (host tail of chunk k overlapped with the device
      * work of chunk k + 1), then addNode in image order.  positions: n x 3; node_ids_out: n (may be NULL);

@@ -1,4 +1,5 @@
 #include "extract_features.hpp"
+#include "sort_like_std.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -11,6 +12,7 @@
 #include <mutex>
 #include <thread>
 
+#include <emmintrin.h>
 #include <omp.h>
 
 namespace opencalibration_amd
@@ -18,54 +20,111 @@ namespace opencalibration_amd
 
 namespace
 {
-// kept features in a bucket grid (cell = NMS radius in full-resolution pixels): the exact nearest-neighbour
-// squared distance is what enters the decision, as with the reference's KD-tree (extract_features.cpp:66-73)
+// kept features in a bucket grid (cell = NMS radius in full-resolution pixels): the decision of the reference's KD-tree
+// query (extract_features.cpp:66-73) is "nearest kept feature farther than the radius", i.e. NO kept feature within it.
+// Kept features are farther than one cell side from each other, so a cell holds at most four of them (a fifth would
+// have to be within a side of one of the four): a cell is four indices into the coordinate arrays (16 bytes, the 3 x 3
+// neighbourhood is three runs of 48 bytes in a table of half a megabyte), no lists to chase, and since the visiting order
+// is known the lines of the neighbourhoods a few keypoints ahead are requested early (the visits are in strength order,
+// i.e. spatially random: this loop is cache-miss latency, not arithmetic).  The scaled squared distance is monotone in
+// the squared distance, so the test on every candidate separately gives the answer of the test on the minimum.
 struct nn_grid
 {
-    double cell, minx, miny;
-    size_t gw, gh;
-    std::vector<int32_t> head, next;
-    std::vector<std::pair<double, double>> pts;
-    nn_grid(double cell_, double minx_, double miny_, double maxx, double maxy) : cell(cell_), minx(minx_), miny(miny_)
+    static constexpr int CAP = 4;
+    static constexpr uint32_t EMPTY = 0xffffffffu;
+    long gw, gh;
+    uint32_t *cells; // (gh + 2) x (gw + 2) x CAP indices: a border of empty cells saves the clamping
+    const double *px, *py;
+    const uint32_t *home;           // cell of every point (computed once: two divisions per point, not six)
+    std::vector<uint32_t> overflow; // never used by the argument above; kept for safety
+    nn_grid(double cell, double minx, double miny, double maxx, double maxy, const double *px_, const double *py_, uint32_t n)
+        : px(px_), py(py_)
     {
-        gw = (size_t)std::floor((maxx - minx) / cell) + 1;
-        gh = (size_t)std::floor((maxy - miny) / cell) + 1;
-        head.assign(gw * gh, -1);
+        gw = (long)std::floor((maxx - minx) / cell) + 3;
+        gh = (long)std::floor((maxy - miny) / cell) + 3;
+        static thread_local std::vector<uint32_t> buf, homes;
+        if (buf.size() < (size_t)(gw * gh) * CAP)
+            buf.resize((size_t)(gw * gh) * CAP);
+        cells = buf.data();
+        std::memset(cells, 0xff, (size_t)(gw * gh) * CAP * sizeof(uint32_t));
+        homes.resize(n);
+        for (uint32_t i = 0; i < n; i++)
+            homes[i] = (uint32_t)(((long)((py[i] - miny) / cell) + 1) * gw + (long)((px[i] - minx) / cell) + 1);
+        home = homes.data();
     }
-    void add(double x, double y)
+    void prefetch(uint32_t i) const
     {
-        const size_t cx = (size_t)((x - minx) / cell), cy = (size_t)((y - miny) / cell);
-        next.push_back(head[cy * gw + cx]);
-        head[cy * gw + cx] = (int32_t)pts.size();
-        pts.emplace_back(x, y);
+        const uint32_t *c = cells + (size_t)home[i] * CAP;
+        __builtin_prefetch(c - (gw + 1) * CAP);
+        __builtin_prefetch(c - (gw - 1) * CAP + CAP - 1);
+        __builtin_prefetch(c - CAP);
+        __builtin_prefetch(c + 2 * CAP - 1);
+        __builtin_prefetch(c + (gw - 1) * CAP);
+        __builtin_prefetch(c + (gw + 1) * CAP + CAP - 1);
     }
-    double nearest2(double x, double y) const
+    void add(uint32_t i)
     {
-        const long cx = (long)((x - minx) / cell), cy = (long)((y - miny) / cell);
-        double best = std::numeric_limits<double>::infinity();
-        for (long yy = std::max(cy - 1, 0L); yy <= std::min(cy + 1, (long)gh - 1); yy++)
-            for (long xx = std::max(cx - 1, 0L); xx <= std::min(cx + 1, (long)gw - 1); xx++)
-                for (int32_t e = head[(size_t)yy * gw + xx]; e >= 0; e = next[e])
-                {
-                    const double dx = x - pts[e].first, dy = y - pts[e].second;
-                    double d = 0;
-                    d += dx * dx;
-                    d += dy * dy;
-                    best = std::min(best, d);
-                }
-        return best;
+        uint32_t *c = cells + (size_t)home[i] * CAP;
+        for (int e = 0; e < CAP; e++)
+            if (c[e] == EMPTY)
+            {
+                c[e] = i;
+                return;
+            }
+        overflow.push_back(i);
+    }
+    // true if a kept feature lies within the radius of point i: d2 * scale2 <= radius2, d2 accumulated as the KD-tree
+    // does.  Almost all of the 36 slots are empty: the occupied ones of a row are found with three vector compares.
+    bool any_within(uint32_t i, double scale2, double radius2) const
+    {
+        const double x = px[i], y = py[i];
+        auto close = [&](uint32_t k) {
+            const double dx = x - px[k], dy = y - py[k];
+            double d = 0;
+            d += dx * dx;
+            d += dy * dy;
+            return !(d * scale2 > radius2);
+        };
+        const uint32_t *c0 = cells + (size_t)home[i] * CAP;
+        const __m128i empty = _mm_set1_epi32(-1);
+        for (long yy = -1; yy <= 1; yy++)
+        {
+            const uint32_t *row = c0 + (yy * gw - 1) * CAP; // three neighbouring cells = twelve consecutive indices
+            unsigned used = 0;
+            for (int q = 0; q < 3; q++)
+                used |= (unsigned)(0xf ^ _mm_movemask_ps(_mm_castsi128_ps(
+                                             _mm_cmpeq_epi32(_mm_loadu_si128((const __m128i *)(row + 4 * q)), empty))))
+                        << (4 * q);
+            while (used)
+            {
+                const int q = __builtin_ctz(used);
+                used &= used - 1;
+                if (close(row[q]))
+                    return true;
+            }
+        }
+        for (uint32_t k : overflow)
+            if (close(k))
+                return true;
+        return false;
     }
 };
 
 // The host tail of src/extract/extract_features.cpp:38-87 for one image: n device keypoints (k6 = x, y, size,
 // angle, response, level in working-image pixels; AKAZE's detection order) -> [sparse..., dense...] features.
-static double g_tail_prof[5]; // CPU seconds: ordering, NMS, feature records, total (OCHIP_EXTRACT_VERBOSE)
+double g_tail_prof[5]; // CPU seconds: ordering, NMS, feature records, total (OCHIP_EXTRACT_VERBOSE)
 static double thread_cpu_now()
 {
     timespec ts;
     clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+
+struct by_response
+{
+    float response;
+    uint32_t index;
+};
 
 void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale, extracted_features &out)
 {
@@ -74,74 +133,29 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
     double tp1 = 0, tp2 = 0;
     const double nms_pixel_radius = 8;
     // The device hands the keypoints over in AKAZE's detection order (level, row, column of the extremum), which is
-    // what the reference's unstable std::sort by response starts from.  That starting order only matters when two
-    // responses are equal, so the responses are first ordered with a radix sort of their bit patterns (positive floats
-    // order like unsigned integers; three counting passes over 16 k keys); an image in which two keypoints share a
-    // response exactly (most of the rendered benchmark views do) takes the reference's route: std::sort of the
-    // indices 0..n-1, whose compare/move sequence depends only on the comparator's answers and therefore yields the
-    // permutation that sorting the feature structs themselves would.
+    // what the reference's unstable std::sort by response starts from - and that starting order decides the result
+    // wherever two responses are equal, which happens in almost every image (a birthday effect among 20 k floats).  The
+    // order is therefore libstdc++'s introsort's, move for move, computed by sort_like_std (the same algorithm with a
+    // branch-free partition scan) on (response, index) records: the permutation only depends on the comparator's
+    // answers, which are those of sorting the feature structs themselves.
     std::vector<uint32_t> order(n);
-    bool unique_responses = n > 0;
     {
-        static thread_local std::vector<uint64_t> a, c; // ~response bits << 32 | index: ascending = strongest first
-        a.resize(n);
-        c.resize(n);
-        for (uint32_t i = 0; i < n; i++)
-        {
-            uint32_t rb;
-            std::memcpy(&rb, k6 + 6 * (size_t)i + 4, 4);
-            if (rb & 0x80000000u) // a negative (or -0) response does not order like its bits: comparison route
-                unique_responses = false;
-            a[i] = ((uint64_t)(~rb) << 32) | i;
-        }
-        if (unique_responses)
-        {
-            for (int pass = 0; pass < 3; pass++)
-            {
-                const int shift = 32 + 11 * pass;
-                uint32_t count[2048] = {0};
-                for (uint32_t i = 0; i < n; i++)
-                    count[(a[i] >> shift) & 2047]++;
-                uint32_t sum = 0;
-                for (uint32_t d = 0; d < 2048; d++)
-                {
-                    const uint32_t t = count[d];
-                    count[d] = sum;
-                    sum += t;
-                }
-                for (uint32_t i = 0; i < n; i++)
-                    c[count[(a[i] >> shift) & 2047]++] = a[i];
-                a.swap(c);
-            }
-            for (uint32_t i = 0; i < n; i++)
-            {
-                order[i] = (uint32_t)a[i];
-                if (i && (a[i] >> 32) == (a[i - 1] >> 32))
-                    unique_responses = false;
-            }
-        }
-    }
-    if (!unique_responses)
-    {
-        if (prof)
-        {
-#pragma omp atomic
-            g_tail_prof[4] += 1.0;
-        }
-        // the records carry the response next to the index: the comparator then touches one cache line per element
-        // (the permutation only depends on the comparator's answers, which are those of sorting the feature structs)
-        struct by_response
-        {
-            float response;
-            uint32_t index;
-        };
         static thread_local std::vector<by_response> recs;
         recs.resize(n);
         for (uint32_t i = 0; i < n; i++)
             recs[i] = by_response{k6[6 * (size_t)i + 4], i};
-        std::sort(recs.begin(), recs.end(), [](const by_response &a, const by_response &c) -> bool { return a.response > c.response; });
+        sort_like_std(recs.data(), recs.data() + n, [](const by_response &a, const by_response &c) -> bool { return a.response > c.response; });
+        bool tied = false;
         for (uint32_t i = 0; i < n; i++)
+        {
             order[i] = recs[i].index;
+            tied = tied || (i && recs[i].response == recs[i - 1].response);
+        }
+        if (prof && tied)
+        {
+#pragma omp atomic
+            g_tail_prof[4] += 1.0;
+        }
     }
     if (prof)
         tp1 = thread_cpu_now();
@@ -157,8 +171,8 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
     double minx = std::numeric_limits<double>::infinity(), miny = minx, maxx = -minx, maxy = -minx;
     for (uint32_t i = 0; i < n; i++)
     {
-        if (i + 16 < n)
-            __builtin_prefetch(k6 + 6 * (size_t)order[i + 16]);
+        if (i + 32 < n)
+            __builtin_prefetch(k6 + 6 * (size_t)order[i + 32]);
         lx[i] = k6[6 * (size_t)order[i]] / scale;
         ly[i] = k6[6 * (size_t)order[i] + 1] / scale;
         minx = std::min(minx, lx[i]);
@@ -166,18 +180,20 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
         miny = std::min(miny, ly[i]);
         maxy = std::max(maxy, ly[i]);
     }
-    nn_grid grid(nms_pixel_radius / scale, minx, miny, maxx, maxy);
+    nn_grid grid(nms_pixel_radius / scale, minx, miny, maxx, maxy, lx.data(), ly.data(), n);
     std::vector<uint32_t> sparse, dense;
     sparse.reserve(n);
     dense.reserve(n);
-    grid.add(lx[0], ly[0]);
+    grid.add(0);
     sparse.push_back(0);
     for (uint32_t i = 0; i < n; i++)
     {
+        if (i + 12 < n)
+            grid.prefetch(i + 12);
         // nn[0].distance * sqr(scale) > sqr(nms_pixel_radius)
-        if (grid.nearest2(lx[i], ly[i]) * (scale * scale) > nms_pixel_radius * nms_pixel_radius)
+        if (!grid.any_within(i, scale * scale, nms_pixel_radius * nms_pixel_radius))
         {
-            grid.add(lx[i], ly[i]);
+            grid.add(i);
             sparse.push_back(i);
         }
         else
@@ -189,22 +205,23 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
     out.features.reserve(sparse.size() + dense.size());
     auto emit = [&](uint32_t i) { // i = position in strength order
         const uint32_t s = order[i];
-        out.features.emplace_back();
-        feature_2d &p = out.features.back();
+        feature_2d p; // built in registers and written once (emplace_back() + assignment writes the record twice)
         p.location[0] = lx[i]; // keypoints[i].pt.x / scale, extract_features.cpp:44-45
         p.location[1] = ly[i];
         p.strength = k6[6 * (size_t)s + 4];
         std::memcpy(p.descriptor, dd + 8 * (size_t)s, 64);
+        out.features.push_back(p);
     };
     // the records are gathered in strength order, i.e. from random places of the device's arrays: ask for the lines of
     // the entries a few steps ahead while this one is copied
+    static const size_t PREFETCH_AHEAD = std::getenv("OCHIP_TAIL_PREFETCH") ? (size_t)std::atol(std::getenv("OCHIP_TAIL_PREFETCH")) : 24;
     auto emit_all = [&](const std::vector<uint32_t> &list) {
         const size_t m = list.size();
         for (size_t j = 0; j < m; j++)
         {
-            if (j + 8 < m)
+            if (j + PREFETCH_AHEAD < m) // far enough for a DRAM miss (the device's copy does not land in a cache)
             {
-                const uint32_t s = order[list[j + 8]];
+                const uint32_t s = order[list[j + PREFETCH_AHEAD]];
                 __builtin_prefetch(dd + 8 * (size_t)s);
                 __builtin_prefetch(k6 + 6 * (size_t)s + 4);
             }
@@ -339,9 +356,16 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
     std::vector<char> buffer_free(n_bufs, 1);
     uint32_t next_chunk = 0, drivers_done = 0;
 
+    std::vector<double> driver_cpu(n_drivers, 0.0);
     auto driver = [&](uint32_t d) {
         ochip_ctx *dctx = ctxs[d];
         int which = 2 * (int)d;
+        const double cpu0 = thread_cpu_now();
+        struct at_exit
+        {
+            double &out, t0;
+            ~at_exit() { out = thread_cpu_now() - t0; }
+        } record{driver_cpu[d], cpu0};
         for (;;)
         {
             uint32_t c;
@@ -419,6 +443,10 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
     {
         fprintf(stderr, "[extract] %u images: host tail %.3f thread-seconds of wall time (%.2f ms per image)\n", n_images,
                 tail_cpu_seconds, 1e3 * tail_cpu_seconds / n_images);
+        double dc = 0;
+        for (double v : driver_cpu)
+            dc += v;
+        fprintf(stderr, "[extract] CPU seconds of the %u device driver threads (launching and waiting): %.3f\n", n_drivers, dc);
         fprintf(stderr, "[extract] cumulative CPU seconds of the tail: ordering %.3f, NMS %.3f, feature records %.3f, total %.3f; images with tied responses %.0f\n",
                 g_tail_prof[0], g_tail_prof[1], g_tail_prof[2], g_tail_prof[3], g_tail_prof[4]);
     }
@@ -433,6 +461,31 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
 }
 
 } // namespace opencalibration_amd
+
+// cumulative CPU seconds of the tail's phases (ordering, NMS, feature records, total, images with tied responses) when
+// OCHIP_EXTRACT_VERBOSE is set
+extern "C" void och_extract_tail_profile(double *out5)
+{
+    for (int i = 0; i < 5; i++)
+        out5[i] = opencalibration_amd::g_tail_prof[i];
+}
+
+// The strength order alone: order_out = indices 0..n-1 as std::sort by descending response leaves them when it starts
+// from 0..n-1 (use_std != 0: std::sort itself; 0: sort_like_std, which must give the same) - for the tests.
+extern "C" void och_sort_by_response(const float *response, uint32_t n, uint32_t *order_out, int use_std)
+{
+    using opencalibration_amd::by_response;
+    std::vector<by_response> recs(n);
+    for (uint32_t i = 0; i < n; i++)
+        recs[i] = by_response{response[i], i};
+    auto comp = [](const by_response &a, const by_response &c) -> bool { return a.response > c.response; };
+    if (use_std)
+        std::sort(recs.begin(), recs.end(), comp);
+    else
+        opencalibration_amd::sort_like_std(recs.data(), recs.data() + n, comp);
+    for (uint32_t i = 0; i < n; i++)
+        order_out[i] = recs[i].index;
+}
 
 // The host tail alone (no device): what extract_features.cpp:38-87 does with the keypoints cv::AKAZE returned, given
 // as kp6 rows {x, y, size, angle, response, level} in detection order.  For the CPU-side tests.

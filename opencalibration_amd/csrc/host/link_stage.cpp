@@ -1,4 +1,5 @@
 #include "link_stage.hpp"
+#include "sort_like_std.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -373,7 +374,9 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
                 if (best < 0.8 * second)
                     sm.push_back(sorted_match{(uint32_t)a, r[a].best_k, r[a].best_count});
             }
-        std::sort(sm.begin(), sm.end(), [](const sorted_match &f1, const sorted_match &f2) -> bool { return f1.count > f2.count; });
+        // (sort_like_std = libstdc++'s std::sort move for move, host/sort_like_std.hpp: Hamming counts tie all the time)
+        sort_like_std(sm.data(), sm.data() + sm.size(),
+                      [](const sorted_match &f1, const sorted_match &f2) -> bool { return f1.count > f2.count; });
         const size_t M = sm.size();
         matches[p].resize(M);
         rmatches[p].resize(M);
@@ -398,7 +401,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
             std::vector<by_quality> order(M);
             for (size_t i = 0; i < M; i++)
                 order[i] = by_quality{(uint32_t)i, sm[i].count};
-            std::sort(order.begin(), order.end(), [](const by_quality &a, const by_quality &b) { return a.count < b.count; });
+            sort_like_std(order.data(), order.data() + M, [](const by_quality &a, const by_quality &b) { return a.count < b.count; });
             sorted_idx[p].resize(M);
             for (size_t i = 0; i < M; i++)
                 sorted_idx[p][i] = order[i].index;
@@ -475,23 +478,23 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
         std::memcpy(relations.ransac_relation, results[p].H, sizeof relations.ransac_relation);
         relations.relationType = camera_relations::RelationType::HOMOGRAPHY;
 
-        std::vector<bool> coarse_inliers(M);
-        std::vector<double> inlier_rays; // {measurement1, measurement2} of the inliers, in match order
-        inlier_rays.reserve(6 * (size_t)results[p].n_inliers);
-        const auto &ray1 = rays[jobs[p].slot_1], &ray2 = rays[jobs[p].slot_2];
-        size_t num_coarse_inliers = 0;
+        // the cheirality vote reads the inliers' rays where they lie (two gathers per inlier, all solutions in one pass)
+        static thread_local std::vector<uint32_t> inlier_at;
+        inlier_at.clear();
         for (size_t i = 0; i < M; i++)
-        {
-            coarse_inliers[i] = inl[i] != 0;
             if (inl[i])
-            {
-                const double *a = &ray1[3 * rmatches[p][i].k1], *b = &ray2[3 * rmatches[p][i].k2];
-                inlier_rays.insert(inlier_rays.end(), a, a + 3);
-                inlier_rays.insert(inlier_rays.end(), b, b + 3);
-                num_coarse_inliers++;
-            }
-        }
-        const bool can_decompose = h.decompose_inlier_rays(inlier_rays.data(), num_coarse_inliers, relations.relative_poses);
+                inlier_at.push_back((uint32_t)i);
+        const size_t num_coarse_inliers = inlier_at.size();
+        const auto &ray1 = rays[jobs[p].slot_1], &ray2 = rays[jobs[p].slot_2];
+        const ochip_ransac_match *rm = rmatches[p].data();
+        const uint32_t *at = inlier_at.data();
+        const bool can_decompose = h.decompose_with(
+            num_coarse_inliers,
+            [&](size_t j, const double *&m1, const double *&m2) {
+                m1 = &ray1[3 * (size_t)rm[at[j]].k1];
+                m2 = &ray2[3 * (size_t)rm[at[j]].k2];
+            },
+            relations.relative_poses);
         if (keep_debug)
         {
             dbg[p].node_id = jobs[p].node_id;
@@ -507,6 +510,9 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
         if (can_decompose && num_coarse_inliers > h.MINIMUM_POINTS * 1.5)
         {
             relations.matches = std::move(matches[p]);
+            std::vector<bool> coarse_inliers(M);
+            for (size_t i = 0; i < M; i++)
+                coarse_inliers[i] = inl[i] != 0;
             assembleInliers(relations.matches, coarse_inliers, img.features, near_image.features,
                             relations.inlier_matches);
         }

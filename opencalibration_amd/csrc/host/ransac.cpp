@@ -320,30 +320,43 @@ bool homography_model::decompose(const std::vector<correspondence> &corrs, const
 
 bool homography_model::decompose_inlier_rays(const double *m1m2, size_t n_inliers, std::array<decomposed_pose, 4> &poses) const
 {
+    return decompose_with(n_inliers, [m1m2](size_t j, const double *&m1, const double *&m2) {
+        m1 = m1m2 + 6 * j;
+        m2 = m1 + 3;
+    }, poses);
+}
+
+homography_model::vote_plan homography_model::plan_votes() const
+{
+    vote_plan plan;
     motion motions[4];
-    const size_t solutions = decompose_homography(homography, motions);
-    for (size_t i = 0; i < solutions; i++)
+    plan.solutions = decompose_homography(homography, motions);
+    for (size_t i = 0; i < plan.solutions; i++)
     {
         const M3 &R = motions[i].R;
         const double *N = motions[i].n;
-        const double RN[3] = {R.a[0][0] * N[0] + R.a[0][1] * N[1] + R.a[0][2] * N[2],
-                              R.a[1][0] * N[0] + R.a[1][1] * N[1] + R.a[1][2] * N[2],
-                              R.a[2][0] * N[0] + R.a[2][1] * N[1] + R.a[2][2] * N[2]};
-        int score = 0;
-        for (size_t j = 0; j < n_inliers; j++)
-        {
-            const double *m1 = m1m2 + 6 * j, *m2 = m1 + 3;
-            const double dot1 = N[0] * m1[0] + N[1] * m1[1] + N[2] * m1[2];
-            const double dot2 = RN[0] * m2[0] + RN[1] * m2[1] + RN[2] * m2[2];
-            if (dot1 >= 0 && dot2 >= 0)
-                score++;
-        }
-        poses[i].score = score;
-        quaternion_from_rotation(R, poses[i].orientation);
         for (int c = 0; c < 3; c++)
-            poses[i].position[c] = motions[i].t[c];
+        {
+            plan.N[i][c] = N[c];
+            plan.RN[i][c] = R.a[c][0] * N[0] + R.a[c][1] * N[1] + R.a[c][2] * N[2];
+            plan.t[i][c] = motions[i].t[c];
+        }
+        quaternion_from_rotation(R, plan.q[i]);
     }
-    for (size_t i = solutions; i < poses.size(); i++)
+    return plan;
+}
+
+bool homography_model::finish_votes(const vote_plan &plan, const int votes[4], std::array<decomposed_pose, 4> &poses)
+{
+    for (size_t i = 0; i < plan.solutions; i++)
+    {
+        poses[i].score = votes[i];
+        for (int c = 0; c < 4; c++)
+            poses[i].orientation[c] = plan.q[i][c];
+        for (int c = 0; c < 3; c++)
+            poses[i].position[c] = plan.t[i][c];
+    }
+    for (size_t i = plan.solutions; i < poses.size(); i++)
         poses[i].score = -1;
     std::stable_sort(poses.begin(), poses.end(),
                      [](const decomposed_pose &p1, const decomposed_pose &p2) { return p1.score >= p2.score; });

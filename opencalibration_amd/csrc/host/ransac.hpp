@@ -45,6 +45,33 @@ struct homography_model // include/opencalibration/model_inliers/homography_mode
     // the same on the inlier correspondences only, packed as n x {measurement1(3), measurement2(3)}: the vote only
     // ever looks at inliers, so the batch runner does not materialise a correspondence per match
     bool decompose_inlier_rays(const double *m1m2, size_t n_inliers, std::array<decomposed_pose, 4> &poses) const;
+    // the same without packing anything: ray_pair(j, m1, m2) points at the two rays of the j-th inlier.  One pass over
+    // the inliers serves all (up to four) solutions; the votes are integers, so the order of evaluation is free.
+    struct vote_plan
+    {
+        size_t solutions = 0;
+        double N[4][3], RN[4][3];
+        double q[4][4], t[4][3];
+    };
+    vote_plan plan_votes() const;
+    static bool finish_votes(const vote_plan &plan, const int votes[4], std::array<decomposed_pose, 4> &poses);
+    template <class RayPair> bool decompose_with(size_t n_inliers, RayPair ray_pair, std::array<decomposed_pose, 4> &poses) const
+    {
+        const vote_plan plan = plan_votes();
+        int votes[4] = {0, 0, 0, 0};
+        for (size_t j = 0; j < n_inliers; j++)
+        {
+            const double *m1, *m2;
+            ray_pair(j, m1, m2);
+            for (size_t i = 0; i < plan.solutions; i++)
+            {
+                const double dot1 = plan.N[i][0] * m1[0] + plan.N[i][1] * m1[1] + plan.N[i][2] * m1[2];
+                const double dot2 = plan.RN[i][0] * m2[0] + plan.RN[i][1] * m2[1] + plan.RN[i][2] * m2[2];
+                votes[i] += (dot1 >= 0 && dot2 >= 0) ? 1 : 0;
+            }
+        }
+        return finish_votes(plan, votes, poses);
+    }
 };
 
 // ransac.cpp:263-282

@@ -32,3 +32,61 @@ def test_host_tail_matches_restatement(oracle, n, tied, scale):
         assert len(np.unique(est)) < n // 10
     assert gns == ens and len(gst) == len(est) == (n + 1 if n else 0)     # the seeded first keypoint appears twice
     assert np.array_equal(gst, est) and np.array_equal(gloc, eloc) and np.array_equal(gdesc, edesc)
+
+
+def _sort_order(response, use_std):
+    import ctypes as C
+
+    L = host.load()
+    r = np.ascontiguousarray(response, np.float32)
+    out = np.zeros(max(len(r), 1), np.uint32)
+    L.och_sort_by_response.restype = None
+    L.och_sort_by_response.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+    L.och_sort_by_response(r.ctypes.data, len(r), out.ctypes.data, int(use_std))
+    return out[:len(r)]
+
+
+def _median_of_three_killer(n):
+    """Musser's sequence: every median-of-three pivot is the second smallest of its range, so introsort hits its depth
+    limit and falls back to the heap sort."""
+    n -= n % 2
+    k = n // 2
+    a = np.zeros(n, np.float32)
+    for i in range(1, k + 1):
+        if i % 2:
+            a[i - 1] = i
+            a[i] = k + i
+        a[k + i - 1] = 2 * i
+    return -a  # the tail sorts by DEscending response
+
+
+def test_strength_order_is_std_sorts_move_for_move():
+    """The tail's own sort (host/sort_like_std.hpp: libstdc++'s introsort with a block-wise partition scan) must leave
+    equal responses in exactly the order std::sort does - that order reaches the feature list, the NMS and, through the
+    feature indices, every match (extract_features.cpp:55-56)."""
+    rng = np.random.default_rng(12)
+    cases = []
+    for n in [0, 1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 34, 63, 64, 65, 66, 67, 95, 96, 97, 127, 128, 129, 130, 131, 200, 257, 1000, 4099]:
+        cases.append(rng.uniform(0, 1, n))                                   # distinct
+        cases.append(rng.integers(0, 3, n))                                  # almost everything tied
+        cases.append(rng.integers(0, max(n // 4, 1), n))                     # small groups of ties
+        cases.append(np.zeros(n))                                            # all equal
+        cases.append(np.arange(n))                                           # ascending = reversed for this comparator
+        cases.append(np.arange(n)[::-1])                                     # already in order
+        cases.append(np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]))  # organ pipe
+    for n in [20400, 50000]:
+        cases.append(rng.uniform(0, 1, n).astype(np.float32))                # float32 keeps a few natural ties
+        cases.append(rng.integers(0, n // 8, n))
+        cases.append(_median_of_three_killer(n))
+    cases.append(_median_of_three_killer(4096))
+    for seed in range(200):
+        r = np.random.default_rng(seed)
+        n = int(r.integers(0, 700))
+        cases.append(r.integers(0, int(r.integers(1, 50)), n))
+    for c in cases:
+        resp = np.asarray(c, np.float32)
+        want, got = _sort_order(resp, True), _sort_order(resp, False)
+        assert np.array_equal(want, got), (len(resp), np.flatnonzero(want != got)[:5])
+        assert np.all(np.diff(resp[got]) <= 0)
+    tied = np.asarray(cases[1 + 7 * 27], np.float32)                          # the 1 000-element "almost everything tied" case
+    assert not np.array_equal(_sort_order(tied, True), np.argsort(-tied, kind="stable"))  # ...and the order is NOT the stable one
