@@ -304,7 +304,7 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
     // 0.270 s with three, 0.245 s with four, no gain from five or six (each sequence holds a 6 GB arena of level planes).
     uint32_t n_drivers = 4;
     if (const char *e = std::getenv("OCHIP_EXTRACT_STREAMS"))
-        n_drivers = (uint32_t)std::max(1L, std::min(5L, std::atol(e))) // siblings 4.. belong to the link runners (load_link.cpp);
+        n_drivers = (uint32_t)std::max(1L, std::min(5L, std::atol(e))); // siblings 4.. belong to the link runners (load_link.cpp)
     const uint32_t n_chunks = (n_images + chunk - 1) / chunk;
     n_drivers = std::min(n_drivers, n_chunks);
     std::vector<ochip_ctx *> ctxs(n_drivers, ctx);
