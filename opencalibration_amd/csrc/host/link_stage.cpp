@@ -138,8 +138,16 @@ void LinkStage::prepare(const MeasurementGraph &graph)
 
 void LinkStage::run_range(const MeasurementGraph &graph, size_t link_begin, size_t link_end, ochip_ctx *ctx, int omp_threads)
 {
-    if (link_end > link_begin)
-        run_batch(graph, link_begin, link_end, ctx, std::max(1, omp_threads));
+    std::vector<link_pair> pairs;
+    for (size_t i = link_begin; i < link_end; i++)
+        for (size_t match_node_id : _links[i].link_ids)
+            pairs.emplace_back(i, match_node_id);
+    run_batch(graph, pairs, ctx, std::max(1, omp_threads));
+}
+
+void LinkStage::run_pairs(const MeasurementGraph &graph, const std::vector<link_pair> &pairs, ochip_ctx *ctx, int omp_threads)
+{
+    run_batch(graph, pairs, ctx, std::max(1, omp_threads));
 }
 
 std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph &graph)
@@ -176,7 +184,7 @@ std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph
             cuts.push_back(end);
             for (size_t k = 0; k + 1 < cuts.size(); k++)
                 if (cuts[k + 1] > cuts[k])
-                    run_batch(graph, cuts[k], cuts[k + 1], ctx, omp_threads);
+                    run_range(graph, cuts[k], cuts[k + 1], ctx, omp_threads);
         });
     }
     return funcs;
@@ -200,7 +208,7 @@ void link_cpu_report()
             g_link_cpu[0], g_link_cpu[1], g_link_cpu[2], g_link_cpu[3], g_link_cpu[4], g_link_cpu[5]);
 }
 
-void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size_t link_end, ochip_ctx *ctx, int omp_threads)
+void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_pair> &link_pairs, ochip_ctx *ctx, int omp_threads)
 {
     static const bool prof = std::getenv("OCHIP_LINK_VERBOSE") != nullptr;
     LinkTimers lt; // this runner's phases, added to `timers` at the end
@@ -237,13 +245,13 @@ void LinkStage::run_batch(const MeasurementGraph &graph, size_t link_begin, size
         return s;
     };
     std::vector<pair_job> jobs;
-    for (size_t i = link_begin; i < link_end; i++)
-        for (size_t match_node_id : _links[i].link_ids)
-        {
-            if (graph.getNode(match_node_id) == nullptr) // link_stage.cpp:69-73
-                continue;
-            jobs.push_back(pair_job{i, _links[i].node_id, match_node_id, slot_for(_links[i].node_id), slot_for(match_node_id)});
-        }
+    for (const link_pair &lp : link_pairs)
+    {
+        const size_t i = lp.first, match_node_id = lp.second;
+        if (graph.getNode(match_node_id) == nullptr) // link_stage.cpp:69-73
+            continue;
+        jobs.push_back(pair_job{i, _links[i].node_id, match_node_id, slot_for(_links[i].node_id), slot_for(match_node_id)});
+    }
     const size_t n_slots = slot_node.size(), n_pairs = jobs.size();
     if (n_pairs == 0)
         return;

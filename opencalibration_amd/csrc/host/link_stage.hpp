@@ -63,6 +63,11 @@ class LinkStage
     void prepare_index(const MeasurementGraph &graph);
     void prepare_images(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, int threads);
     void run_range(const MeasurementGraph &graph, size_t link_begin, size_t link_end, ochip_ctx *ctx, int omp_threads);
+    // the same for an explicit set of directed pairs {index into links(), id of the image to match against}: which
+    // batch a pair runs in does not show in the graph (finalize() orders the edges), so a caller can put the two
+    // directions of a pair into the same batch, where the device matches both from one pass over their distances
+    typedef std::pair<size_t, size_t> link_pair;
+    void run_pairs(const MeasurementGraph &graph, const std::vector<link_pair> &pairs, ochip_ctx *ctx, int omp_threads);
     const std::vector<NodeLinks> &links() const
     {
         return _links;
@@ -102,7 +107,7 @@ class LinkStage
         camera_relations relations;
     };
     void prepare(const MeasurementGraph &graph); // 40 px subsets + unit rays of every image the links touch
-    void run_batch(const MeasurementGraph &graph, size_t link_begin, size_t link_end, ochip_ctx *ctx, int omp_threads);
+    void run_batch(const MeasurementGraph &graph, const std::vector<link_pair> &pairs, ochip_ctx *ctx, int omp_threads);
 
     ochip_ctx *_ctx;
     int _runners;

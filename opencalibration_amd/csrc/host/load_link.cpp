@@ -80,33 +80,54 @@ extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const ui
         image_of.emplace(ids[b], b);
     const char *env = std::getenv("OCHIP_STREAM_LINK_RANGE");
     const size_t range_len = std::max<size_t>(32, env ? (size_t)std::atol(env) : 125);
+    // A directed pair belongs to the range of its source image - unless its reverse is a pair too: then both go to the
+    // range of the later of the two sources.  Either way a pair can only run once both images are extracted, so nothing
+    // starts later than it could; but the two directions now always sit in the same batch, where the device matches them
+    // from ONE pass over their distance matrix (hamming_2nn_sym_kernel).  With ranges cut by source alone every pair
+    // that straddled a cut (13 % of them on the C3 grid) had its distances computed twice, by the slower one-direction
+    // kernel.  Which batch ran a pair does not show in the graph: finalize() orders the edges.
     struct range
     {
-        size_t begin, end;
+        std::vector<LinkStage::link_pair> pairs;
         uint32_t waiting; // images not ready yet
     };
-    std::vector<range> ranges;
-    std::vector<std::vector<uint32_t>> ranges_of_image(n_images); // image -> ranges that need it
-    for (size_t first = 0; first < links.size(); first += range_len)
+    const size_t n_ranges = (links.size() + range_len - 1) / range_len;
+    std::vector<range> ranges(n_ranges);
     {
-        range r{first, std::min(links.size(), first + range_len), 0};
-        std::vector<uint32_t> need;
-        for (size_t i = r.begin; i < r.end; i++)
-        {
-            need.push_back(image_of.at(links[i].node_id));
+        std::unordered_map<size_t, size_t> link_of; // node id -> index into links
+        for (size_t i = 0; i < links.size(); i++)
+            link_of.emplace(links[i].node_id, i);
+        for (size_t i = 0; i < links.size(); i++)
             for (size_t m : links[i].link_ids)
             {
-                auto it = image_of.find(m);
-                if (it != image_of.end())
-                    need.push_back(it->second);
+                size_t owner = i;
+                auto it = link_of.find(m);
+                if (it != link_of.end() && it->second > i)
+                {
+                    const auto &back = links[it->second].link_ids;
+                    if (std::find(back.begin(), back.end(), links[i].node_id) != back.end())
+                        owner = it->second;
+                }
+                ranges[owner / range_len].pairs.emplace_back(i, m);
             }
+    }
+    std::vector<std::vector<uint32_t>> ranges_of_image(n_images); // image -> ranges that need it
+    for (size_t k = 0; k < n_ranges; k++)
+    {
+        range &r = ranges[k];
+        std::vector<uint32_t> need;
+        for (const auto &lp : r.pairs)
+        {
+            need.push_back(image_of.at(links[lp.first].node_id));
+            auto it = image_of.find(lp.second);
+            if (it != image_of.end())
+                need.push_back(it->second);
         }
         std::sort(need.begin(), need.end());
         need.erase(std::unique(need.begin(), need.end()), need.end());
         r.waiting = (uint32_t)need.size();
         for (uint32_t im : need)
-            ranges_of_image[im].push_back((uint32_t)ranges.size());
-        ranges.push_back(r);
+            ranges_of_image[im].push_back((uint32_t)k);
     }
 
     // ---- link runners: each owns a device context (siblings 4.. of ctx; extraction uses ctx and its first siblings)
@@ -147,7 +168,7 @@ extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const ui
                     k = ready.front();
                     ready.pop_front();
                 }
-                link.run_range(g->graph, ranges[k].begin, ranges[k].end, rctx, runner_threads);
+                link.run_pairs(g->graph, ranges[k].pairs, rctx, runner_threads);
             }
         });
     }
