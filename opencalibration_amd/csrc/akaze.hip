@@ -715,6 +715,7 @@ struct cand_t
 {
     int level, x, y;
     float response;
+    float dx, dy; // sub-pixel offset of the extremum from the quadratic fit of its 3 x 3 determinants (|.| > 1: no keypoint)
 };
 
 // Scale-normalised Hessian determinant of a 64 x 24 tile and its strict 3x3 maxima above the threshold in one
@@ -722,7 +723,7 @@ struct cand_t
 // and the level's sparse maxima map (response at maxima, 0 elsewhere) is written next to the determinant.
 template <int S>
 __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restrict__ Lxy, size_t stride,
-                                                         float *__restrict__ Ldet, float *__restrict__ Rmax, int w, int h,
+                                                         float2 *__restrict__ Fit, float *__restrict__ Rmax, int w, int h,
                                                          float thr, unsigned int *__restrict__ tile_counts, int tile_off,
                                                          int n_tiles, float margin, unsigned long long *__restrict__ mask,
                                                          size_t mask_stride)
@@ -785,15 +786,12 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
             if (idx >= DW * DH)
                 continue;
             const int ly = idx / DW, lx = idx - ly * DW;
-            const int x = x0 - 1 + lx, y = y0 - 1 + ly;
             const int ci = (ly + S) * RW + (lx + S); // (x, y) in the Lx / Ly tiles: their origin is (x0 - S - 1, y0 - S - 1)
             float lxx, lxy, tmp, lyy;
             pattern_lds<S, RW>(&tx[ci], nrm, wn, &lxx, &lxy);
             pattern_lds<S, RW>(&ty[ci], nrm, wn, &tmp, &lyy);
             const float d = (lxx * lyy - lxy * lxy) * s4;
             dreg[it] = d;
-            if (lx >= 1 && lx <= BT_X && ly >= 1 && ly <= DT_Y)
-                Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = d;
         }
     }
     else
@@ -823,8 +821,6 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
         pattern_xy(aty, xm, x, xp, ym, y, yp, nrm, wn, &tmp, &lyy);
         const float d = (lxx * lyy - lxy * lxy) * s4;
         dreg[it] = d;
-        if (lx >= 1 && lx <= BT_X && ly >= 1 && ly <= DT_Y)
-            Ldet[(size_t)blockIdx.z * stride + (size_t)y * w + x] = d;
     }
     __syncthreads(); // every determinant is in a register: the Lx tile's storage becomes the determinant tile
 #pragma unroll
@@ -845,6 +841,7 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
         const int ly = it * 4 + (threadIdx.x >> 6), lx = threadIdx.x & 63;
         const int x = x0 + lx, y = y0 + ly;
         float out = 0.0f;
+        float2 fit = make_float2(0.0f, 0.0f);
         // interior pixel whose descriptor window [round(x - margin) - 1, round(x + margin) + 1] stays inside the level
         // image (AKAZE's Find_Scale_Space_Extrema; margin = 10 sqrt(2) * sigma_size)
         const bool in_bounds = (int)rintf((float)x - margin) - 1 >= 0 && (int)rintf((float)x + margin) + 1 < w &&
@@ -863,12 +860,28 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
                         if ((dx || dy) && !(v > td[ci + dy * DW + dx]))
                             mx = false;
                 if (mx)
+                {
                     out = v;
+                    // the sub-pixel fit of AKAZE's Do_Subpixel_Refinement on the nine determinants around the extremum,
+                    // which are all here: the determinant plane itself is then never written (4 bytes per level pixel
+                    // of HBM traffic that only these few thousand neighbourhoods per image were ever read from)
+                    const float vxp = td[ci + 1], vxm = td[ci - 1], vyp = td[ci + DW], vym = td[ci - DW];
+                    const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
+                    const float Dxx = (vxp + vxm) - 2.0f * v, Dyy = (vyp + vym) - 2.0f * v;
+                    const float Dxy = 0.25f * ((td[ci + DW + 1] + td[ci - DW - 1]) - (td[ci + DW - 1] + td[ci - DW + 1]));
+                    const float det = Dxx * Dyy - Dxy * Dxy;
+                    fit = make_float2(2.0f, 2.0f); // a singular fit is no keypoint
+                    if (det != 0.0f)
+                        fit = make_float2((Dxy * Dy - Dyy * Dx) / det, (Dxy * Dx - Dxx * Dy) / det);
+                }
             }
         }
         const unsigned long long m = __ballot(out != 0.0f);
         if (out != 0.0f)
+        {
             Rmax[(size_t)blockIdx.z * stride + (size_t)y * w + x] = out;
+            Fit[(size_t)blockIdx.z * stride + (size_t)y * w + x] = fit;
+        }
         if (lx == 0 && y < h)
         {
             mask[(size_t)blockIdx.z * mask_stride + (size_t)y * tiles_x + tile_x] = m;
@@ -940,7 +953,8 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(const unsigned int *__r
 
 // One wavefront per tile: lane r holds the mask word of tile row r, a shuffle prefix sum of the popcounts gives each
 // row its slots, and only the responses of set bits are read.  List order inside a tile: row-major.
-__global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restrict__ Rmax, size_t img_stride,
+__global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restrict__ Rmax, const float2 *__restrict__ Fit,
+                                                            size_t img_stride,
                                                             const unsigned long long *__restrict__ mask, size_t mask_stride,
                                                             levels_dev L, const unsigned int *__restrict__ tile_base, int n_tiles,
                                                             cand_t *__restrict__ cands, unsigned int max_cands)
@@ -957,6 +971,7 @@ __global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restr
     const int t = tile - l.tile_off;
     const int ty = t / l.tiles_x, tx = t - ty * l.tiles_x;
     const float *R = Rmax + (size_t)b * img_stride + l.off;
+    const float2 *F = Fit + (size_t)b * img_stride + l.off;
     const int y = ty * DT_Y + lane;
     unsigned long long m = 0;
     if (lane < DT_Y && y < l.h)
@@ -976,7 +991,10 @@ __global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restr
         m &= m - 1;
         const int x = tx * BT_X + bit;
         if (slot < max_cands)
-            cands[(size_t)b * max_cands + slot] = cand_t{level, x, y, R[(size_t)y * l.w + x]};
+        {
+            const float2 f = F[(size_t)y * l.w + x];
+            cands[(size_t)b * max_cands + slot] = cand_t{level, x, y, R[(size_t)y * l.w + x], f.x, f.y};
+        }
         slot++;
     }
 }
@@ -1194,7 +1212,6 @@ template <bool PROFILE>
 __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
                                                       unsigned int max_cands, const unsigned int *__restrict__ live,
                                                       const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
-                                                      const float *__restrict__ Ldet,
                                                       size_t img_stride, levels_dev L, float derivative_factor,
                                                       const float *__restrict__ gw /*13x13*/, const pair_tab *__restrict__ tab,
                                                       float *__restrict__ kp_out /*[b][max][6]*/,
@@ -1213,9 +1230,8 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
     __shared__ float vals_all[4][29][3];
     __shared__ float4 smp_all[4][331]; // 441 x 3 floats, padded to a multiple of 16 bytes
     // wv is the same in all lanes of a wave; saying so lets everything that hangs off it - the list entry, the candidate
-    // record, the level's geometry, the nine determinant values of the sub-pixel fit - travel as scalar loads, a path of
-    // its own beside the vector memory pipeline that the other waves' gathers keep busy (this chain of four dependent
-    // round trips was 47 % of a wave's life when it queued behind them)
+    // record with its sub-pixel fit, the level's geometry - travel as scalar loads, a path of its own beside the vector
+    // memory pipeline that the other waves' gathers keep busy
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float4 *const osmp = smp_all[wv]; // [109]
     float(&vals)[29][3] = vals_all[wv];
@@ -1247,23 +1263,9 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
         tbits[wd] = tab->bits[wd * 64 + lane];
     const level_info l = L.l[c.level];
     const int w = l.w, h = l.h;
-    const float *D = Ldet + (size_t)b * img_stride + l.off;
-    const float v00 = D[(size_t)c.y * w + c.x];
-    const float vxp = D[(size_t)c.y * w + c.x + 1], vxm = D[(size_t)c.y * w + c.x - 1];
-    const float vyp = D[(size_t)(c.y + 1) * w + c.x], vym = D[(size_t)(c.y - 1) * w + c.x];
-    const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
-    const float Dxx = (vxp + vxm) - 2.0f * v00, Dyy = (vyp + vym) - 2.0f * v00;
-    const float Dxy = 0.25f * ((D[(size_t)(c.y + 1) * w + c.x + 1] + D[(size_t)(c.y - 1) * w + c.x - 1]) -
-                               (D[(size_t)(c.y + 1) * w + c.x - 1] + D[(size_t)(c.y - 1) * w + c.x + 1]));
-    const float det = Dxx * Dyy - Dxy * Dxy;
-    bool ok = det != 0.0f;
-    float dx = 0.0f, dy = 0.0f;
-    if (ok)
-    {
-        dx = (Dxy * Dy - Dyy * Dx) / det;
-        dy = (Dxy * Dx - Dxx * Dy) / det;
-        ok = fabsf(dx) <= 1.0f && fabsf(dy) <= 1.0f;
-    }
+    // the sub-pixel fit came with the candidate (det_maxima_kernel had the nine determinants at hand)
+    const float dx = c.dx, dy = c.dy;
+    const bool ok = fabsf(dx) <= 1.0f && fabsf(dy) <= 1.0f;
     if (!ok)
     {
         if (lane == 0)
@@ -1944,7 +1946,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     uint8_t *d_bgr = nullptr, *d_gray = nullptr;
     float *d_img = nullptr, *d_flow = nullptr, *d_ping = nullptr;
     float2 *d_Lxy = nullptr; // (Lx, Ly) interleaved, indexed like the other pyramids
-    float *d_Lt = nullptr, *d_Ldet = nullptr, *d_Rmax = nullptr, *d_kc = nullptr,
+    float2 *d_Fit = nullptr; // (dx, dy) of the sub-pixel fit at the maxima (sparse, like d_Rmax)
+    float *d_Lt = nullptr, *d_Rmax = nullptr, *d_kc = nullptr,
           *d_gw = nullptr, *d_kp = nullptr;
     unsigned int *d_hmax = nullptr, *d_hist = nullptr, *d_ncand = nullptr, *d_pmax = nullptr;
     cand_t *d_cands = nullptr;
@@ -1972,7 +1975,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     AK(up<unsigned int>(ctx, allocs, &d_pmax, nullptr, (size_t)B * n_tiles0));
     AK(up<float>(ctx, allocs, &d_Lt, nullptr, (size_t)B * img_stride));
     AK(up<float2>(ctx, allocs, &d_Lxy, nullptr, (size_t)B * img_stride));
-    AK(up<float>(ctx, allocs, &d_Ldet, nullptr, (size_t)B * img_stride));
+    AK(up<float2>(ctx, allocs, &d_Fit, nullptr, (size_t)B * img_stride));
     AK(up<float>(ctx, allocs, &d_Rmax, nullptr, (size_t)B * img_stride));
     AK(up<float>(ctx, allocs, &d_kc, nullptr, B));
     AK(up<unsigned int>(ctx, allocs, &d_hmax, nullptr, B));
@@ -2267,7 +2270,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         }
         {
             const float2 *lxy = d_Lxy + l.off;
-            float *ld = d_Ldet + l.off, *rm = d_Rmax + l.off;
+            float2 *ld = d_Fit + l.off;
+            float *rm = d_Rmax + l.off;
             const float margin = (10.0f * std::sqrt(2.0f)) * (float)l.sigma_size; // descriptor window half width, M-LDB
             if (l.sigma_size == 2)
                 hipLaunchKernelGGL((det_maxima_kernel<2>), det_tiles(l.w, l.h), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
@@ -2282,7 +2286,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     }
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(B), dim3(256), 0, st, (const unsigned int *)d_tile_counts,
                        (const unsigned int *)d_tile_seq, n_tiles, d_tile_base, d_ncand);
-    hipLaunchKernelGGL(collect_tiles_kernel, dim3((n_tiles + 3) / 4, 1, B), dim3(256), 0, st, (const float *)d_Rmax, img_stride,
+    hipLaunchKernelGGL(collect_tiles_kernel, dim3((n_tiles + 3) / 4, 1, B), dim3(256), 0, st, (const float *)d_Rmax,
+                       (const float2 *)d_Fit, img_stride,
                        (const unsigned long long *)d_mask, mask_stride, LV, (const unsigned int *)d_tile_base, n_tiles, d_cands,
                        max_cands);
     std::vector<unsigned int> ncand(B);
@@ -2321,7 +2326,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
 #define OCHIP_LAUNCH_DESCRIBE(P)                                                                                               \
     hipLaunchKernelGGL(describe_kernel<P>, dim3(512 * (((max_live + 3) / 4 + 511) / 512), 1, B), dim3(256), 0, st,             \
                        (const cand_t *)d_cands, (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live,       \
-                       (const float *)d_Lt, (const float2 *)d_Lxy, (const float *)d_Ldet, img_stride, LV, dfactor,            \
+                       (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, dfactor,                                    \
                        (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap, d_vmask, mask_stride)
         if (max_live == 0)
             ;
