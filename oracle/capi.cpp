@@ -384,3 +384,118 @@ size_t oc_fed_tau(float T, int M, float tau_max, int reordering, float *out, siz
 }
 
 } // extern "C"
+
+// ---- a9: fundamental / essential matrix models (oracle/epipolar.cpp).  model: 0 = fundamental, 1 = essential;
+//      rays6: n x {measurement1, measurement2}; M9 row-major.
+namespace
+{
+std::vector<oracle::correspondence> epipolar_corrs(const double *rays6, const double *quality, size_t n)
+{
+    std::vector<oracle::correspondence> c(n);
+    for (size_t i = 0; i < n; i++)
+    {
+        c[i].measurement1 = {rays6[6 * i], rays6[6 * i + 1], rays6[6 * i + 2]};
+        c[i].measurement2 = {rays6[6 * i + 3], rays6[6 * i + 4], rays6[6 * i + 5]};
+        c[i].quality = quality ? quality[i] : 0.0;
+    }
+    return c;
+}
+void mat_out(const oracle::Mat3 &M, double *M9)
+{
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            M9[3 * r + c] = M(r, c);
+}
+oracle::Mat3 mat_in(const double *M9)
+{
+    oracle::Mat3 M;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            M(r, c) = M9[3 * r + c];
+    return M;
+}
+} // namespace
+
+extern "C" double oc_ransac_epipolar(int model, const double *rays6, const double *quality, size_t n, double threshold, double *M9,
+                                     uint8_t *inliers_out, size_t *iterations)
+{
+    const auto corrs = epipolar_corrs(rays6, quality, n);
+    std::vector<bool> inl;
+    double score;
+    if (model == 0)
+    {
+        oracle::fundamental_matrix_model m;
+        if (threshold > 0)
+            m.inlier_threshold = threshold;
+        score = oracle::ransac(corrs, m, inl, iterations);
+        mat_out(m.fundamental_matrix, M9);
+    }
+    else
+    {
+        oracle::essential_matrix_model m;
+        if (threshold > 0)
+            m.inlier_threshold = threshold;
+        score = oracle::ransac(corrs, m, inl, iterations);
+        mat_out(m.essential_matrix, M9);
+    }
+    for (size_t i = 0; i < inl.size(); i++)
+        inliers_out[i] = inl[i];
+    return score;
+}
+
+extern "C" void oc_epipolar_fit_inliers(int model, const double *rays6, size_t n, const uint8_t *inliers, double *M9)
+{
+    const auto corrs = epipolar_corrs(rays6, nullptr, n);
+    std::vector<bool> inl(inliers, inliers + n);
+    if (model == 0)
+    {
+        oracle::fundamental_matrix_model m;
+        m.fitInliers(corrs, inl);
+        mat_out(m.fundamental_matrix, M9);
+    }
+    else
+    {
+        oracle::essential_matrix_model m;
+        m.fitInliers(corrs, inl);
+        mat_out(m.essential_matrix, M9);
+    }
+}
+
+extern "C" double oc_epipolar_evaluate(const double *M9, const double *rays6, size_t n, double threshold, uint8_t *inliers_out,
+                                       double *errors_out)
+{
+    const auto corrs = epipolar_corrs(rays6, nullptr, n);
+    oracle::fundamental_matrix_model m; // both models share error() and evaluate()
+    m.fundamental_matrix = mat_in(M9);
+    if (threshold > 0)
+        m.inlier_threshold = threshold;
+    std::vector<bool> inl;
+    const double score = m.evaluate(corrs, inl);
+    for (size_t i = 0; i < n; i++)
+    {
+        inliers_out[i] = inl[i];
+        if (errors_out)
+            errors_out[i] = m.error(corrs[i]);
+    }
+    return score;
+}
+
+extern "C" int oc_essential_decompose(const double *E9, double *poses28)
+{
+    oracle::essential_matrix_model m;
+    m.essential_matrix = mat_in(E9);
+    std::array<oracle::decomposed_pose, 4> poses;
+    const bool ok = m.decompose({}, {}, poses);
+    for (int i = 0; i < 4; i++)
+    {
+        const double v[7] = {poses[i].orientation.x, poses[i].orientation.y, poses[i].orientation.z, poses[i].orientation.w,
+                             poses[i].position.x,    poses[i].position.y,    poses[i].position.z};
+        std::copy(v, v + 7, poses28 + 7 * i);
+    }
+    return ok ? 1 : 0;
+}
+
+extern "C" void oc_jacobi_svd(const double *A, int n, double *U, double *S, double *V)
+{
+    oracle::jacobi_svd_square(A, n, U, S, V);
+}

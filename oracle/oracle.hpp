@@ -205,6 +205,39 @@ struct homography_model // homography_model.hpp:16-37, homography_model.cpp
     Mat3 homography, homography_inverse;
 };
 
+// fundamental_matrix_model.hpp:14-31 / essential_matrix_model.hpp:14-33 (oracle/epipolar.cpp): the two RANSAC models the
+// reference's tests exercise and its pipeline never calls
+struct fundamental_matrix_model
+{
+    fundamental_matrix_model();
+    static constexpr size_t MINIMUM_POINTS = 8;
+    void fit(const std::vector<correspondence> &corrs, const std::array<size_t, MINIMUM_POINTS> &initial_indices);
+    void fitInliers(const std::vector<correspondence> &corrs, const std::vector<bool> &inliers);
+    double evaluate(const std::vector<correspondence> &corrs, std::vector<bool> &inliers);
+    double error(const correspondence &cor);
+    void checkDegeneracy(const std::vector<correspondence> &corrs, std::vector<bool> &inliers);
+    double inlier_threshold = 0.01;
+    Mat3 fundamental_matrix;
+};
+struct essential_matrix_model
+{
+    essential_matrix_model();
+    static constexpr size_t MINIMUM_POINTS = 5;
+    void fit(const std::vector<correspondence> &corrs, const std::array<size_t, MINIMUM_POINTS> &initial_indices);
+    void fitInliers(const std::vector<correspondence> &corrs, const std::vector<bool> &inliers);
+    double evaluate(const std::vector<correspondence> &corrs, std::vector<bool> &inliers);
+    double error(const correspondence &cor);
+    bool decompose(const std::vector<correspondence> &corrs, const std::vector<bool> &inliers, std::array<decomposed_pose, 4> &poses);
+    double inlier_threshold = 0.01;
+    Mat3 essential_matrix;
+};
+double ransac(const std::vector<correspondence> &matches, fundamental_matrix_model &model, std::vector<bool> &inliers,
+              size_t *iterations = nullptr); // ransac.cpp:53-257, with checkDegeneracy
+double ransac(const std::vector<correspondence> &matches, essential_matrix_model &model, std::vector<bool> &inliers,
+              size_t *iterations = nullptr);
+// Eigen::JacobiSVD of a square matrix as restated in epipolar.cpp: A = U diag(S) V^T (row-major n x n), S decreasing
+void jacobi_svd_square(const double *A, int n, double *U, double *S, double *V);
+
 struct ransac_trace // optional instrumentation for golden vectors (not in the reference)
 {
     std::vector<std::array<size_t, 4>> samples; // minimal sample of every iteration, in order

@@ -349,6 +349,71 @@ def scene_homography(n_in, n_out, seed):
     return corr, gt, H
 
 
+def scene_fundamental(n_in, n_out, planar_fraction, seed):
+    """SyntheticScene::fundamental of test/test_ransac_benchmark.cpp:60-122."""
+    n = n_in + n_out
+    corr, gt, F = np.zeros((n, 7)), np.zeros(n, np.uint8), np.zeros((3, 3))
+    L = lib()
+    L.oc_scene_fundamental.argtypes = [C.c_size_t, C.c_size_t, C.c_double, C.c_uint, f64p, u8p, f64p]
+    L.oc_scene_fundamental(n_in, n_out, float(planar_fraction), seed, corr, gt, F)
+    return corr, gt, F
+
+
+# ---- a9: fundamental / essential matrix models (oracle/epipolar.cpp); rays: n x 6 {measurement1, measurement2}
+def _epipolar_lib():
+    L = lib()
+    L.oc_ransac_epipolar.restype = C.c_double
+    L.oc_ransac_epipolar.argtypes = [C.c_int, f64p, C.c_void_p, C.c_size_t, C.c_double, f64p, u8p, u64p]
+    L.oc_epipolar_fit_inliers.argtypes = [C.c_int, f64p, C.c_size_t, u8p, f64p]
+    L.oc_epipolar_evaluate.restype = C.c_double
+    L.oc_epipolar_evaluate.argtypes = [f64p, f64p, C.c_size_t, C.c_double, u8p, f64p]
+    L.oc_essential_decompose.restype = C.c_int
+    L.oc_essential_decompose.argtypes = [f64p, f64p]
+    L.oc_jacobi_svd.argtypes = [f64p, C.c_int, f64p, f64p, f64p]
+    return L
+
+
+def ransac_epipolar(model, rays, quality=None, threshold=0.0):
+    """ransac<fundamental_matrix_model> (model 0) / ransac<essential_matrix_model> (model 1), ransac.cpp:53-257.
+    Returns (score, matrix 3x3, inliers, iterations)."""
+    rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+    n = len(rays)
+    M, inl, it = np.zeros((3, 3)), np.zeros(max(n, 1), np.uint8), np.zeros(1, np.uint64)
+    q = None if quality is None else np.ascontiguousarray(quality, np.float64)
+    score = _epipolar_lib().oc_ransac_epipolar(model, rays if n else np.zeros((1, 6)), None if q is None else q.ctypes.data, n,
+                                               float(threshold), M, inl, it)
+    return score, M, inl[:n].astype(bool), int(it[0])
+
+
+def epipolar_fit_inliers(model, rays, inliers):
+    rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+    M = np.zeros((3, 3))
+    _epipolar_lib().oc_epipolar_fit_inliers(model, rays, len(rays), np.ascontiguousarray(inliers, np.uint8), M)
+    return M
+
+
+def epipolar_evaluate(M, rays, threshold=0.0):
+    """(score, inliers, Sampson errors) of fundamental_matrix_model::evaluate / ::error."""
+    rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+    inl, err = np.zeros(len(rays), np.uint8), np.zeros(len(rays))
+    score = _epipolar_lib().oc_epipolar_evaluate(np.ascontiguousarray(M, np.float64), rays, len(rays), float(threshold), inl, err)
+    return score, inl.astype(bool), err
+
+
+def essential_decompose(E):
+    poses = np.zeros((4, 7))
+    ok = _epipolar_lib().oc_essential_decompose(np.ascontiguousarray(E, np.float64), poses)
+    return bool(ok), poses
+
+
+def jacobi_svd(A):
+    A = np.ascontiguousarray(A, np.float64)
+    n = A.shape[0]
+    U, S, V = np.zeros((n, n)), np.zeros(n), np.zeros((n, n))
+    _epipolar_lib().oc_jacobi_svd(A, n, U, S, V)
+    return U, S, V
+
+
 def scene_near_degenerate():
     corr, H = np.zeros((100, 7)), np.zeros((3, 3))
     lib().oc_scene_near_degenerate(corr, H)

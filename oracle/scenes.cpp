@@ -97,4 +97,55 @@ void oc_scene_near_degenerate(double *corr /*100x7*/, double *H_gt)
     }
 }
 
+
+// SyntheticScene::fundamental(n_inliers, n_outliers, planar_fraction, seed), test_ransac_benchmark.cpp:60-122:
+// corr n x 7 {measurement1, measurement2, quality 0}, F_gt = [e2]_x R2 normalised to unit Frobenius norm
+void oc_scene_fundamental(size_t n_inliers, size_t n_outliers, double planar_fraction, unsigned seed, double *corr,
+                          uint8_t *gt_inliers, double *F_gt)
+{
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<double> xy_dist(-1.0, 1.0);
+    std::uniform_real_distribution<double> z_dist(5.0, 15.0);
+    std::uniform_real_distribution<double> outlier_dist(-1.0, 1.0);
+    // R1 = I, t1 = 0; R2 = AngleAxis(0.15, Y); t2 = (0.5, 0, 0)
+    const double c = std::cos(0.15), sn = std::sin(0.15);
+    Mat3 R2;
+    const double r2[3][3] = {{c, 0, sn}, {0, 1, 0}, {-sn, 0, c}};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R2.m[i][j] = r2[i][j];
+    const Vec3 t2{0.5, 0.0, 0.0};
+    const Vec3 e2 = mul(R2, Vec3{0, 0, 0} - t2);
+    Mat3 ex;
+    ex.m[0][0] = 0, ex.m[0][1] = -e2.z, ex.m[0][2] = e2.y;
+    ex.m[1][0] = e2.z, ex.m[1][1] = 0, ex.m[1][2] = -e2.x;
+    ex.m[2][0] = -e2.y, ex.m[2][1] = e2.x, ex.m[2][2] = 0;
+    Mat3 F = mul(ex, R2);
+    const double nf = frobenius(F);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            F_gt[3 * i + j] = F.m[i][j] / nf;
+    const size_t n_planar = static_cast<size_t>(n_inliers * planar_fraction);
+    size_t k = 0;
+    for (size_t i = 0; i < n_inliers; i++, k++)
+    {
+        // (argument evaluation order of the Vector3d constructor is unspecified; the restated tests assert precision /
+        // recall floors that hold either way, as for the homography scene above)
+        const double a = xy_dist(rng), b = xy_dist(rng);
+        const double z = i < n_planar ? 10.0 : z_dist(rng);
+        const Vec3 X{a * 3, b * 3, z};
+        Vec3 x1 = X, x2 = mul(R2, X - t2);
+        x1 = x1 / x1.z;
+        x2 = x2 / x2.z;
+        put(corr, k, x1, x2);
+        gt_inliers[k] = 1;
+    }
+    for (size_t i = 0; i < n_outliers; i++, k++)
+    {
+        const double a = outlier_dist(rng), b = outlier_dist(rng);
+        const double cc = outlier_dist(rng), d = outlier_dist(rng);
+        put(corr, k, Vec3{a, b, 1.0}, Vec3{cc, d, 1.0});
+        gt_inliers[k] = 0;
+    }
+}
 } // extern "C"
