@@ -2360,6 +2360,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     // into the caller's arrays (page-locked ones from ochip_host_alloc make these copies run at link speed)
     OCHIP_HIP(ctx, hipMemcpyAsync(counts, d_counts, B * 4, hipMemcpyDeviceToHost, st));
     OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+    uint32_t most = 0;
     for (uint32_t b = 0; b < B && rc == OCHIP_OK; b++)
     {
         if (counts[b] > max_kp)
@@ -2367,12 +2368,30 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             rc = ochip_fail(ctx, OCHIP_ENOMEM, "image %u has %u keypoints, more than max_kp = %u", b, counts[b], max_kp);
             break;
         }
-        if (counts[b] == 0)
-            continue;
-        OCHIP_HIP(ctx, hipMemcpyAsync(kp6 + (size_t)b * max_kp * 6, d_kpc + (size_t)b * max_kp * 6, (size_t)counts[b] * 24,
-                                      hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(desc + (size_t)b * max_kp * 8, d_descc + (size_t)b * max_kp * 8, (size_t)counts[b] * 64,
-                                      hipMemcpyDeviceToHost, st));
+        most = std::max(most, counts[b]);
+    }
+    if (rc == OCHIP_OK && most > 0)
+    {
+        // one strided copy per array instead of one per image and array (2 x 100 launches per chunk): every image's row is
+        // copied up to the longest list of the chunk - a few per cent more bytes, the counts say where each list ends
+        static const bool per_image = getenv("OCHIP_AKAZE_COPY_PER_IMAGE") != nullptr; // A/B knob
+        if (!per_image)
+        {
+            OCHIP_HIP(ctx, hipMemcpy2DAsync(kp6, (size_t)max_kp * 24, d_kpc, (size_t)max_kp * 24, (size_t)most * 24, B,
+                                            hipMemcpyDeviceToHost, st));
+            OCHIP_HIP(ctx, hipMemcpy2DAsync(desc, (size_t)max_kp * 64, d_descc, (size_t)max_kp * 64, (size_t)most * 64, B,
+                                            hipMemcpyDeviceToHost, st));
+        }
+        else
+            for (uint32_t b = 0; b < B; b++)
+            {
+                if (counts[b] == 0)
+                    continue;
+                OCHIP_HIP(ctx, hipMemcpyAsync(kp6 + (size_t)b * max_kp * 6, d_kpc + (size_t)b * max_kp * 6, (size_t)counts[b] * 24,
+                                              hipMemcpyDeviceToHost, st));
+                OCHIP_HIP(ctx, hipMemcpyAsync(desc + (size_t)b * max_kp * 8, d_descc + (size_t)b * max_kp * 8,
+                                              (size_t)counts[b] * 64, hipMemcpyDeviceToHost, st));
+            }
     }
     if (rc != OCHIP_OK)
         for (uint32_t b = 0; b < B; b++)
