@@ -35,32 +35,32 @@ struct rccl_api
 
 rccl_api *load_rccl()
 {
-    static rccl_api api;
-    static bool tried = false;
-    if (tried)
-        return &api;
-    tried = true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-        if ((api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)))
-            break;
-    if (!api.lib)
-    {
-        api.error = std::string("librccl not found: ") + dlerror();
-        return &api;
-    }
-    auto sym = [&](const char *n) -> void * {
-        void *p = dlsym(api.lib, n);
-        if (!p && api.error.empty())
-            api.error = std::string("librccl lacks ") + n;
-        return p;
-    };
-    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
-    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
-    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
-    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
-    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
-    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
-    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    // initialised once, by whichever thread comes first (a function-local static: the language serialises it)
+    static rccl_api api = [] {
+        rccl_api a;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)))
+                break;
+        if (!a.lib)
+        {
+            a.error = std::string("librccl not found: ") + dlerror();
+            return a;
+        }
+        auto sym = [&](const char *n) -> void * {
+            void *p = dlsym(a.lib, n);
+            if (!p && a.error.empty())
+                a.error = std::string("librccl lacks ") + n;
+            return p;
+        };
+        a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+        a.AllGather = (decltype(a.AllGather))sym("ncclAllGather");
+        a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+        a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+        return a;
+    }();
     return &api;
 }
 } // namespace
@@ -160,14 +160,18 @@ int ochip_rccl_relax_exchange(void *user, void *acc_dev, uint64_t acc_bytes, voi
         uint64_t n;
     } parts[3] = {{acc_dev, acc_bytes}, {cost_dev, cost_bytes}, {fail_dev, fail_bytes}};
     OCHIP_RCCL(ctx, api, api->GroupStart());
+    ncclResult_t first_error = ncclSuccess; // the group is closed whatever happens inside it
     for (const part &q : parts)
-        if (q.p && q.n)
+        if (q.p && q.n && first_error == ncclSuccess)
         {
-            OCHIP_RCCL(ctx, api,
-                       api->AllGather(static_cast<char *>(q.p) + (size_t)c->rank * q.n, q.p, (size_t)q.n, ncclChar, c->comm, ctx->stream));
+            first_error = api->AllGather(static_cast<char *>(q.p) + (size_t)c->rank * q.n, q.p, (size_t)q.n, ncclChar, c->comm,
+                                         ctx->stream);
             c->bytes += q.n * c->world;
         }
-    OCHIP_RCCL(ctx, api, api->GroupEnd());
+    const ncclResult_t end = api->GroupEnd();
+    if (first_error != ncclSuccess || end != ncclSuccess)
+        return ochip_fail(ctx, OCHIP_EHIP, "ncclAllGather of the relax records failed: %s",
+                          api->GetErrorString(first_error != ncclSuccess ? first_error : end));
     c->exchanges++;
     return OCHIP_OK;
 }
