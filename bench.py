@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 # stream's long kernel in the same queue; 16 queues measured +5-6 % images/s.  Read by the runtime
 # when it initialises, hence set before anything touches HIP.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# RCCL across processes needs dmabuf IPC on this driver (already exported on the pool's boxes; kept if it is not)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # A survey's feature lists (1.8 MB per image) are allocated by the host tail and freed with the graph one step later.
 # glibc hands such blocks straight back to the kernel (mmap threshold, heap trimming), so every step would page-fault its
 # 2 GB in again, 4 KB at a time, inside the tail's OpenMP team; a long-running pipeline process keeps them.
