@@ -225,6 +225,24 @@ class Context:
                     "ochip_synth_views_read")
         return out
 
+    def synth_views_read_into(self, ptr, index, width, height, out):
+        """The same into a caller's (height, width, 3) uint8 array (e.g. a slice of host_array())."""
+        self._check(self.L.ochip_synth_views_read(self.h, C.c_void_p(ptr), index, width, height, out.ctypes.data),
+                    "ochip_synth_views_read")
+
+    def host_array(self, shape, dtype=np.uint8):
+        """A numpy array over page-locked host memory (ochip_host_alloc): PCIe copies from it run at link rate.  Returns
+        (array, release); call release() when done (the array must not be used afterwards)."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self.L.ochip_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        self.L.ochip_host_free.argtypes = [C.c_void_p, C.c_void_p]
+        self.L.ochip_host_free.restype = None
+        self._check(self.L.ochip_host_alloc(self.h, nbytes, C.byref(p)), "ochip_host_alloc")
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        return arr, (lambda: self.L.ochip_host_free(self.h, p))
+
     def synth_views_free(self, ptr):
         self.L.ochip_synth_views_free(self.h, C.c_void_p(ptr))
 
