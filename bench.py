@@ -327,9 +327,9 @@ def main():
                 "extract_images_per_s_from_host_memory": round(1.0 / t_host, 1),
                 "extract_images_per_s_from_hbm_same_call": round(1.0 / t_dev, 1),
                 "images_per_s_end_to_end_estimate": round(grid.n_images / (step_s + grid.n_images * max(t_host - t_dev, 0.0)), 1),
-                "note": f"{n_h} views in page-locked host memory (36 MB of BGR each), uploaded chunk by chunk (100 images, "
-                        "synchronous hipMemcpy inside ochip_akaze_batch) by the launch sequences in flight, so one chunk's upload "
-                        "overlaps the others' kernels; the estimate adds the extra seconds per image to the measured step"}
+                "note": f"{n_h} views in page-locked host memory (36 MB of BGR each), uploaded chunk by chunk (100 images, one copy "
+                        "on the chunk's own stream inside ochip_akaze_batch) by the launch sequences in flight, so one chunk's "
+                        "upload overlaps the others' kernels; the estimate adds the extra seconds per image to the measured step"}
             release()
         except Exception as ex:
             extras["pcie_inclusive"] = {"error": str(ex)}

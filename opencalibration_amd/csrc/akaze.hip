@@ -1703,8 +1703,14 @@ int up(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> &allocs, T **dst, 
     if (!d)
         return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation of %zu bytes failed in akaze", n * sizeof(T));
     allocs.emplace_back(d, got);
-    if (src && n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
-        return ochip_fail(ctx, OCHIP_EHIP, "hipMemcpy failed in akaze");
+    // on the context's own stream (not the device's default stream, where the uploads of all contexts would queue up
+    // behind each other); the wait keeps the caller's buffer semantics of a synchronous copy
+    if (src && n)
+    {
+        if (hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            ochip_stream_wait(ctx, ctx->stream) != hipSuccess)
+            return ochip_fail(ctx, OCHIP_EHIP, "hipMemcpy failed in akaze");
+    }
     *dst = (T *)d;
     return OCHIP_OK;
 }
