@@ -603,8 +603,9 @@ template <typename T> int dev_upload(ochip_relax_problem *p, T **dst, const T *s
     if (!d)
         return ochip_fail(p->ctx, OCHIP_ENOMEM, "device allocation of %zu bytes failed in relax problem", n * sizeof(T));
     p->allocs.emplace_back(d, got);
-    if (n && src)
-        if (hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+    if (n && src) // on the context's stream: the device's default stream is a queue shared with every other context
+        if (hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, p->ctx->stream) != hipSuccess ||
+            ochip_stream_wait(p->ctx, p->ctx->stream) != hipSuccess)
             return ochip_fail(p->ctx, OCHIP_EHIP, "hipMemcpy failed in relax problem");
     *dst = (T *)d;
     return OCHIP_OK;
