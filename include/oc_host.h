@@ -109,6 +109,41 @@ extern "C"
                                    const double *positions, const double *orientations, uint64_t *node_ids_out,
                                    double *totals2, double *link_timers8, double *stage_seconds2);
 
+    /* ---- ONE survey's load + link stages over `world` ranks, one process per GPU (opencalibration_amd/csrc/host/shard_link.cpp).
+     *      The reference parallelises one survey over its workers: one load closure per image
+     *      (src/pipeline/load_stage.cpp:36-50), one link closure per directed pair (src/pipeline/link_stage.cpp:75-112),
+     *      run by the worker loop of src/pipeline/pipeline.cpp:42-49.  Rank r extracts a contiguous block of the images and
+     *      links the directed pairs owned by that block; pairs are independent units, no collective runs inside a stage.
+     *      Two exchanges between the calls are the caller's (an all-gather over RCCL, or any transport):
+     *        och_shard_load_link_local  extract the block, link the pairs whose two images are both in it (streamed)
+     *        och_shard_subsets_export   -> all-gather -> och_shard_subsets_import (once per other rank's buffer)
+     *        och_shard_link_remote      the rank's pairs that touch another block
+     *        och_shard_edges_export     -> all-gather -> och_shard_edges_import (once per other rank's buffer)
+     *        och_shard_finalize         LinkStage::finalize: the same edge list, ids included, on every rank
+     *      Buffers handed to the import calls must be 8-byte aligned.  The graph must hold the camera model and no nodes
+     *      of this survey yet; afterwards every rank's graph has all nodes and all edges, and the feature lists of the
+     *      rank's own block. ------------------------------------------------------------------------------------------- */
+    typedef struct och_shard och_shard;
+    void och_shard_block(uint32_t n_images, uint32_t rank, uint32_t world, uint32_t *first, uint32_t *count);
+    och_shard *och_shard_begin(och_graph *g, ochip_ctx *ctx, uint32_t n_images, uint32_t model, const double *positions,
+                               const double *orientations, uint32_t rank, uint32_t world, uint64_t *node_ids_out);
+    void och_shard_destroy(och_shard *s);
+    /* counts4: images of the block, pairs linked inside the block, pairs that touch another block, images of other
+     * blocks those pairs need descriptors of */
+    void och_shard_counts(const och_shard *s, uint64_t *counts4);
+    /* images_bgr: the BLOCK's images (host or device pointer) */
+    int och_shard_load_link_local(och_shard *s, const uint8_t *images_bgr, int width, int height, uint32_t max_keypoints,
+                                  int images_on_device);
+    /* *buf stays valid until the next export on this shard */
+    int och_shard_subsets_export(och_shard *s, const void **buf, uint64_t *bytes);
+    int och_shard_subsets_import(och_shard *s, const void *buf, uint64_t bytes);
+    int och_shard_link_remote(och_shard *s);
+    int och_shard_edges_export(och_shard *s, const void **buf, uint64_t *bytes);
+    int och_shard_edges_import(och_shard *s, const void *buf, uint64_t bytes);
+    /* totals2: {features, sparse features} of the block; link_timers8 as och_link_stage_run; seconds9: extract, block
+     * linked, subsets export, subsets import, remote links, edges export, edges import, finalize, whole stage */
+    int och_shard_finalize(och_shard *s, double *totals2, double *link_timers8, double *seconds9);
+
     /* ---- relax (opencalibration_amd/csrc/host/relax.hpp): relax(graph, nodes, cam_models, edges,
      *      {ORIENTATION, GROUND_PLANE}, {}) of src/relax/relax.cpp:122-134 ------------------------------ */
     /* Stand-alone problem from flat arrays.  graph: n_nodes x {pos3, ori4 xyzw (may be NaN)} + one shared

@@ -323,10 +323,23 @@ extern "C"
         double focal_lo, focal_hi;   /* 100, 20000 */
         uint32_t mono_observations;  /* DistortionMonotonicityCost: weight sqrt(n / 10); 0 = none */
         double mono_r_max;
+        /* sharded evaluation over `shard_world` ranks (0 or 1 = not sharded): every rank creates the same problem and
+         * evaluates its run of the ray blocks; ochip_relaxg_set_exchange names the transport */
+        uint32_t shard_rank, shard_world;
     } ochip_relaxg_desc;
 
     int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *desc, ochip_relaxg_problem **out);
     void ochip_relaxg_problem_destroy(ochip_relaxg_problem *p);
+    /* The exchange step of a problem created with shard_world > 1 (the reference's single global group is
+     * {ORIENTATION, GROUND_MESH}, src/pipeline/pipeline.cpp:645-664): after every evaluation `exchange` all-gathers the
+     * ranks' runs of the record array in place - same contract as ochip_relax_set_shard; ochip_rccl_relax_exchange with a
+     * communicator created on the problem's context is the native transport.  The padded layout keeps every rank's run the
+     * same size; the assembly and the cost sum then run on identical arrays in an order that does not depend on the
+     * sharding, so the solve is bit-identical to the unsharded one on every rank.  A ray block's record is 0.4 - 2.6 KB
+     * (the packed J'J of its 9 - 24 columns), so an evaluation exchanges a few hundred MB at C3 size: the sharding buys
+     * nothing against an evaluation of ~1 ms on one GPU; it exists for memory (a survey whose records do not fit one
+     * device) and for the contract of BASELINE config C4. */
+    int ochip_relaxg_set_exchange(ochip_relaxg_problem *p, ochip_relax_exchange_fn exchange, void *user);
     /* relaxObservedModelOnly (:931-984): 1 = everything but the mesh heights held constant, 0 = undo */
     int ochip_relaxg_set_structure_only(ochip_relaxg_problem *p, int on);
     int ochip_relaxg_solve(ochip_relaxg_problem *p, const ochip_relax_options *opt, ochip_relax_summary *summary);

@@ -255,6 +255,9 @@ int ochip_ctx_sibling(ochip_ctx *ctx, uint32_t index, ochip_ctx **out)
     if (!ctx || !out)
         return OCHIP_EINVAL;
     *out = nullptr;
+    // the list grows under a lock: stage runners on several host threads ask for their contexts at the same time (the
+    // calls ON a context stay the caller's to serialise; handing contexts out is not)
+    std::lock_guard<std::mutex> lock(ctx->siblings_mutex);
     if (index > 64)
         return ochip_fail(ctx, OCHIP_EINVAL, "sibling index %u out of range", index);
     while (ctx->siblings.size() <= index)

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -83,6 +84,7 @@ struct ochip_ctx
     // sibling contexts on the same device (own streams, scratch and pools) handed out by ochip_ctx_sibling so
     // that independent batches can be in flight at once; owned by this context
     std::vector<ochip_ctx *> siblings;
+    std::mutex siblings_mutex; // ochip_ctx_sibling may be called from concurrent runner threads (RelaxStage's group runners)
 };
 
 

@@ -102,6 +102,7 @@ void LinkStage::prepare_index(const MeasurementGraph &graph)
     }
     _subsets.assign(n, {});
     _rays.assign(n, {});
+    _remote.assign(n, {});
 }
 
 void LinkStage::prepare_images(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, int threads)
@@ -265,11 +266,22 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
     auto t0 = clk::now();
     std::vector<const std::vector<size_t> *> subset_p(n_slots);
     std::vector<const std::vector<double> *> rays_p(n_slots);
+    std::vector<const remote_subset *> remote_p(n_slots, nullptr); // images whose features live on another rank
     for (size_t s = 0; s < n_slots; s++)
     {
         const size_t k = _prepared_index.at(slot_node[s]);
         subset_p[s] = &_subsets[k];
         rays_p[s] = &_rays[k];
+        if (!_remote[k].xy.empty())
+        {
+            remote_p[s] = &_remote[k];
+            if (_remote[k].desc.size() != 8 * _subsets[k].size())
+            {
+                std::lock_guard<std::mutex> lock(_measurement_mutex);
+                error = "link stage: an image of this batch has no descriptors on this rank";
+                return;
+            }
+        }
     }
     struct deref_subsets
     {
@@ -311,13 +323,19 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
             const image &img = graph.getNode(slot_node[s])->payload;
             uint64_t *d = dbuf.ptr + slot_off[s] * 8;
             double *xy = xybuf.ptr + slot_off[s] * 2;
-            for (size_t k = 0; k < subset[s].size(); k++)
+            if (remote_p[s])
             {
-                const feature_2d &f = img.features[subset[s][k]];
-                std::memcpy(d + 8 * k, f.descriptor, 64);
-                xy[2 * k] = f.location[0];
-                xy[2 * k + 1] = f.location[1];
+                std::memcpy(d, remote_p[s]->desc.data(), subset[s].size() * 64);
+                std::memcpy(xy, remote_p[s]->xy.data(), subset[s].size() * 16);
             }
+            else
+                for (size_t k = 0; k < subset[s].size(); k++)
+                {
+                    const feature_2d &f = img.features[subset[s][k]];
+                    std::memcpy(d + 8 * k, f.descriptor, 64);
+                    xy[2 * k] = f.location[0];
+                    xy[2 * k + 1] = f.location[1];
+                }
             const CameraModel &m = *img.model;
             const double model8[8] = {m.focal_length_pixels,      m.principle_point[0],      m.principle_point[1],
                                       m.radial_distortion[0],     m.radial_distortion[1],    m.radial_distortion[2],
@@ -518,13 +536,47 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
         if (can_decompose && num_coarse_inliers > h.MINIMUM_POINTS * 1.5)
         {
             relations.matches = std::move(matches[p]);
-            std::vector<bool> coarse_inliers(M);
-            for (size_t i = 0; i < M; i++)
-                coarse_inliers[i] = inl[i] != 0;
-            assembleInliers(relations.matches, coarse_inliers, img.features, near_image.features,
-                            relations.inlier_matches);
+            if (remote_p[jobs[p].slot_1] || remote_p[jobs[p].slot_2])
+            {
+                // assembleInliers (ransac.cpp:263-282) with the pixels read from the subsets: the same numbers, and an
+                // image whose feature list lives on another rank has nothing else
+                auto px_of = [&](uint32_t slot, uint32_t k) -> const double * {
+                    return remote_p[slot] ? &remote_p[slot]->xy[2 * (size_t)k]
+                                          : graph.getNode(slot_node[slot])->payload.features[subset[slot][k]].location;
+                };
+                relations.inlier_matches.reserve(num_coarse_inliers);
+                for (size_t j = 0; j < num_coarse_inliers; j++)
+                {
+                    const size_t i = at[j];
+                    const double *p1 = px_of(jobs[p].slot_1, rm[i].k1), *p2 = px_of(jobs[p].slot_2, rm[i].k2);
+                    feature_match_denormalized fmd;
+                    fmd.pixel_1[0] = p1[0], fmd.pixel_1[1] = p1[1];
+                    fmd.pixel_2[0] = p2[0], fmd.pixel_2[1] = p2[1];
+                    fmd.feature_index_1 = relations.matches[i].feature_index_1;
+                    fmd.feature_index_2 = relations.matches[i].feature_index_2;
+                    fmd.match_index = i;
+                    relations.inlier_matches.push_back(fmd);
+                }
+            }
+            else
+            {
+                std::vector<bool> coarse_inliers(M);
+                for (size_t i = 0; i < M; i++)
+                    coarse_inliers[i] = inl[i] != 0;
+                assembleInliers(relations.matches, coarse_inliers, img.features, near_image.features,
+                                relations.inlier_matches);
+            }
         }
-        payloads[p] = edge_payload{jobs[p].loop_index, jobs[p].node_id, jobs[p].match_node_id, std::move(relations)};
+        payloads[p] = edge_payload{jobs[p].loop_index, jobs[p].node_id, jobs[p].match_node_id, std::move(relations), {}};
+        if (_sharded && !payloads[p].relations.matches.empty())
+        {
+            payloads[p].subset_pos.resize(2 * M);
+            for (size_t i = 0; i < M; i++)
+            {
+                payloads[p].subset_pos[2 * i] = rm[i].k1;
+                payloads[p].subset_pos[2 * i + 1] = rm[i].k2;
+            }
+        }
         if (prof)
         {
             const double tc2 = link_thread_cpu();
@@ -540,6 +592,270 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
             debug.emplace_back(std::move(d));
     }
     lt.decompose_host += since(t0);
+}
+
+// ---- one survey over several ranks -----------------------------------------------------------------------------------
+namespace
+{
+template <typename T> void put(std::vector<uint8_t> &out, const T *v, size_t n)
+{
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(v);
+    out.insert(out.end(), b, b + n * sizeof(T));
+}
+template <typename T> void put1(std::vector<uint8_t> &out, T v)
+{
+    put(out, &v, 1);
+}
+struct reader
+{
+    const uint8_t *p, *end;
+    bool ok = true;
+    template <typename T> const T *take(size_t n) // unaligned reads are done by memcpy from the returned pointer
+    {
+        if (!ok || (size_t)(end - p) < n * sizeof(T))
+        {
+            ok = false;
+            return nullptr;
+        }
+        const T *r = reinterpret_cast<const T *>(p);
+        p += n * sizeof(T);
+        return r;
+    }
+    template <typename T> T one()
+    {
+        T v{};
+        const T *r = take<T>(1);
+        if (r)
+            std::memcpy(&v, r, sizeof(T));
+        return v;
+    }
+};
+struct edge_header // 8-byte aligned: the records of one buffer follow each other padded to 8 bytes
+{
+    uint32_t loop_index, image_1, image_2, n_matches, n_inliers, flags; // flags: bit 0 = HOMOGRAPHY, bit 1 = 32-bit positions
+    double H[9];
+    double poses[4][7];
+    int32_t score[4];
+};
+} // namespace
+
+void LinkStage::set_remote_subset(const MeasurementGraph &graph, size_t node_id, size_t n, const uint32_t *idx, const double *xy,
+                                  const uint64_t *desc)
+{
+    const auto it = _prepared_index.find(node_id);
+    if (it == _prepared_index.end())
+        return; // no link touches the image
+    const size_t s = it->second;
+    _subsets[s].resize(n);
+    for (size_t q = 0; q < n; q++)
+        _subsets[s][q] = idx[q];
+    _remote[s].xy.assign(xy, xy + 2 * n);
+    if (desc)
+    {
+        // the image takes part in this rank's pairs: descriptors for the matcher, unit rays for the decomposition's vote
+        _remote[s].desc.assign(desc, desc + 8 * n);
+        const image &img = graph.getNode(node_id)->payload;
+        _rays[s].resize(3 * n);
+        for (size_t q = 0; q < n; q++)
+            image_to_3d(xy + 2 * q, *img.model, &_rays[s][3 * q]);
+    }
+}
+
+void LinkStage::export_subsets(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, size_t first, size_t count,
+                               std::vector<uint8_t> &out) const
+{
+    for (size_t b = first; b < first + count; b++)
+    {
+        const auto it = _prepared_index.find(node_ids[b]);
+        const std::vector<size_t> empty;
+        const std::vector<size_t> &sub = it == _prepared_index.end() ? empty : _subsets[it->second];
+        const image &img = graph.getNode(node_ids[b])->payload;
+        put1<uint32_t>(out, (uint32_t)b);
+        put1<uint32_t>(out, (uint32_t)sub.size());
+        const size_t at = out.size(), n = sub.size();
+        out.resize(at + n * (4 + 16 + 64) + (n & 1) * 4); // idx | pad to 8 | xy | desc
+        uint8_t *o = out.data() + at;
+        for (size_t q = 0; q < n; q++)
+        {
+            const uint32_t v = (uint32_t)sub[q];
+            std::memcpy(o + 4 * q, &v, 4);
+        }
+        o += 4 * (n + (n & 1));
+        for (size_t q = 0; q < n; q++)
+            std::memcpy(o + 16 * q, img.features[sub[q]].location, 16);
+        o += 16 * n;
+        for (size_t q = 0; q < n; q++)
+            std::memcpy(o + 64 * q, img.features[sub[q]].descriptor, 64);
+    }
+}
+
+void LinkStage::export_edges(const std::unordered_map<size_t, uint32_t> &image_of, std::vector<uint8_t> &out) const
+{
+    for (const edge_payload &pl : _all_inlier_measurements)
+    {
+        const camera_relations &r = pl.relations;
+        const size_t M = r.matches.size(), I = r.inlier_matches.size();
+        bool wide = false;
+        for (uint32_t v : pl.subset_pos)
+            wide = wide || v > 0xFFFFu;
+        edge_header h{};
+        h.loop_index = (uint32_t)pl.loop_index;
+        h.image_1 = image_of.at(pl.node_id);
+        h.image_2 = image_of.at(pl.match_node_id);
+        h.n_matches = (uint32_t)M;
+        h.n_inliers = (uint32_t)I;
+        h.flags = (r.relationType == camera_relations::RelationType::HOMOGRAPHY ? 1u : 0u) | (wide ? 2u : 0u);
+        std::memcpy(h.H, r.ransac_relation, sizeof h.H);
+        for (int i = 0; i < 4; i++)
+        {
+            std::memcpy(h.poses[i], r.relative_poses[i].orientation, 32);
+            std::memcpy(h.poses[i] + 4, r.relative_poses[i].position, 24);
+            h.score[i] = r.relative_poses[i].score;
+        }
+        put1(out, h);
+        // per match: the two subset positions and the Hamming count (distance = count * (1.0 / 486), match_features.cpp:79)
+        for (size_t i = 0; i < M; i++)
+        {
+            const uint16_t count = (uint16_t)std::lround(r.matches[i].distance * feature_2d::DESCRIPTOR_BITS);
+            if (wide)
+                put(out, &pl.subset_pos[2 * i], 2);
+            else
+            {
+                const uint16_t k[2] = {(uint16_t)pl.subset_pos[2 * i], (uint16_t)pl.subset_pos[2 * i + 1]};
+                put(out, k, 2);
+            }
+            put1(out, count);
+        }
+        for (size_t j = 0; j < I; j++)
+            put1<uint32_t>(out, (uint32_t)r.inlier_matches[j].match_index);
+        out.resize((out.size() + 7) & ~(size_t)7);
+    }
+}
+
+bool LinkStage::import_edges(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, const uint8_t *buf, size_t bytes)
+{
+    // first pass: where every record starts (they are variable-sized), then the records are rebuilt in parallel
+    struct rec
+    {
+        const uint8_t *at;
+        edge_header h;
+    };
+    std::vector<rec> recs;
+    reader rd{buf, buf + bytes};
+    while (rd.ok && rd.p < rd.end)
+    {
+        rec r;
+        r.at = rd.p;
+        r.h = rd.one<edge_header>();
+        if (!rd.ok || r.h.image_1 >= node_ids.size() || r.h.image_2 >= node_ids.size() || r.h.n_inliers > r.h.n_matches)
+        {
+            rd.ok = false;
+            break;
+        }
+        const size_t body = (size_t)r.h.n_matches * ((r.h.flags & 2u) ? 10 : 6) + (size_t)r.h.n_inliers * 4;
+        rd.take<uint8_t>((body + 7) & ~(size_t)7);
+        if (rd.ok)
+            recs.push_back(r);
+    }
+    if (!rd.ok)
+    {
+        error = "link stage: malformed edge buffer";
+        return false;
+    }
+    std::vector<edge_payload> payloads(recs.size());
+    bool bad = false;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t e = 0; e < recs.size(); e++)
+    {
+        const edge_header &h = recs[e].h;
+        const size_t id1 = node_ids[h.image_1], id2 = node_ids[h.image_2];
+        edge_payload &pl = payloads[e];
+        pl.loop_index = h.loop_index;
+        pl.node_id = id1;
+        pl.match_node_id = id2;
+        camera_relations &r = pl.relations;
+        r.relationType = (h.flags & 1u) ? camera_relations::RelationType::HOMOGRAPHY : camera_relations::RelationType::UNKNOWN;
+        std::memcpy(r.ransac_relation, h.H, sizeof h.H);
+        for (int i = 0; i < 4; i++)
+        {
+            std::memcpy(r.relative_poses[i].orientation, h.poses[i], 32);
+            std::memcpy(r.relative_poses[i].position, h.poses[i] + 4, 24);
+            r.relative_poses[i].score = h.score[i];
+        }
+        if (h.n_matches == 0)
+            continue;
+        const auto s1 = _prepared_index.find(id1), s2 = _prepared_index.find(id2);
+        if (s1 == _prepared_index.end() || s2 == _prepared_index.end())
+        {
+            bad = true;
+            continue;
+        }
+        const std::vector<size_t> &sub1 = _subsets[s1->second], &sub2 = _subsets[s2->second];
+        auto px_of = [&](size_t id, size_t slot, uint32_t k) -> const double * {
+            return !_remote[slot].xy.empty() ? &_remote[slot].xy[2 * (size_t)k]
+                                             : graph.getNode(id)->payload.features[_subsets[slot][k]].location;
+        };
+        const bool wide = (h.flags & 2u) != 0;
+        const uint8_t *m = recs[e].at + sizeof(edge_header);
+        r.matches.resize(h.n_matches);
+        std::vector<uint32_t> pos(2 * (size_t)h.n_matches);
+        for (size_t i = 0; i < h.n_matches; i++)
+        {
+            uint32_t k1, k2;
+            uint16_t count;
+            if (wide)
+            {
+                std::memcpy(&k1, m + 10 * i, 4);
+                std::memcpy(&k2, m + 10 * i + 4, 4);
+                std::memcpy(&count, m + 10 * i + 8, 2);
+            }
+            else
+            {
+                uint16_t k[3];
+                std::memcpy(k, m + 6 * i, 6);
+                k1 = k[0], k2 = k[1], count = k[2];
+            }
+            if (k1 >= sub1.size() || k2 >= sub2.size())
+            {
+                bad = true;
+                k1 = k2 = 0;
+                if (sub1.empty() || sub2.empty())
+                    break;
+            }
+            pos[2 * i] = k1, pos[2 * i + 1] = k2;
+            r.matches[i] = feature_match{sub1[k1], sub2[k2], (size_t)count * (1.0 / feature_2d::DESCRIPTOR_BITS)};
+        }
+        if (sub1.empty() || sub2.empty())
+            continue;
+        const uint8_t *in = m + (size_t)h.n_matches * (wide ? 10 : 6);
+        r.inlier_matches.resize(h.n_inliers);
+        for (size_t j = 0; j < h.n_inliers; j++)
+        {
+            uint32_t mi;
+            std::memcpy(&mi, in + 4 * j, 4);
+            if (mi >= h.n_matches)
+            {
+                bad = true;
+                mi = 0;
+            }
+            const double *p1 = px_of(id1, s1->second, pos[2 * mi]), *p2 = px_of(id2, s2->second, pos[2 * mi + 1]);
+            feature_match_denormalized &f = r.inlier_matches[j];
+            f.pixel_1[0] = p1[0], f.pixel_1[1] = p1[1];
+            f.pixel_2[0] = p2[0], f.pixel_2[1] = p2[1];
+            f.feature_index_1 = r.matches[mi].feature_index_1;
+            f.feature_index_2 = r.matches[mi].feature_index_2;
+            f.match_index = mi;
+        }
+    }
+    if (bad)
+    {
+        error = "link stage: an imported edge refers to a subset this rank does not hold";
+        return false;
+    }
+    std::lock_guard<std::mutex> lock(_measurement_mutex);
+    for (auto &pl : payloads)
+        _all_inlier_measurements.emplace_back(std::move(pl));
+    return true;
 }
 
 std::vector<size_t> LinkStage::finalize(MeasurementGraph &graph)

@@ -93,6 +93,31 @@ class LinkStage
         }
     }
 
+    // ---- one survey over several ranks (host/shard_link.cpp; SURVEY.md section 8e: directed pairs are independent
+    //      units, so ranks own disjoint sets of pairs and no collective runs inside the stage).  A rank holds the
+    //      features of its own block of images only; of every other image it is given the 40 px subset - feature
+    //      indices, pixel locations and (for the images its own pairs touch) descriptors - which is all a pair needs.
+    //      The payloads a rank produced travel as compact records (subset positions instead of pixels) and are imported
+    //      by every other rank before finalize(), whose sort restores the serial edge order.
+    void enable_sharding()
+    {
+        _sharded = true;
+    }
+    // idx / xy (2 per feature) / desc (8 words per feature, may be NULL: the image is only looked up, never matched)
+    void set_remote_subset(const MeasurementGraph &graph, size_t node_id, size_t n, const uint32_t *idx, const double *xy,
+                           const uint64_t *desc);
+    // {u32 image, u32 n, u32 idx[n], f64 xy[2n], u64 desc[8n]} per image, appended to `out`; image = index into node_ids
+    void export_subsets(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, size_t first, size_t count,
+                        std::vector<uint8_t> &out) const;
+    // payloads this rank produced since the last export, appended to `out` (image numbers index `node_ids`)
+    void export_edges(const std::unordered_map<size_t, uint32_t> &image_of, std::vector<uint8_t> &out) const;
+    // payloads another rank produced; false (and `error`) on a malformed buffer or an image without a subset
+    bool import_edges(const MeasurementGraph &graph, const std::vector<size_t> &node_ids, const uint8_t *buf, size_t bytes);
+    size_t payload_count() const
+    {
+        return _all_inlier_measurements.size();
+    }
+
     bool keep_debug = false;
     std::vector<pair_debug> debug;
     LinkTimers timers; // summed over the concurrent runners (so the phases can add up to more than the wall time)
@@ -105,6 +130,12 @@ class LinkStage
         size_t node_id;
         size_t match_node_id;
         camera_relations relations;
+        std::vector<uint32_t> subset_pos; // sharded runs: per match its two positions in the images' 40 px subsets
+    };
+    struct remote_subset // an image whose features live on another rank
+    {
+        std::vector<double> xy;     // 2 per subset feature
+        std::vector<uint64_t> desc; // 8 per subset feature, or empty
     };
     void prepare(const MeasurementGraph &graph); // 40 px subsets + unit rays of every image the links touch
     void run_batch(const MeasurementGraph &graph, const std::vector<link_pair> &pairs, ochip_ctx *ctx, int omp_threads);
@@ -117,6 +148,8 @@ class LinkStage
     std::unordered_map<size_t, size_t> _prepared_index; // node id -> position in _subsets / _rays
     std::vector<std::vector<size_t>> _subsets;
     std::vector<std::vector<double>> _rays;
+    std::vector<remote_subset> _remote; // parallel to _subsets; xy empty = the image's features are in the graph
+    bool _sharded = false;
     EvalOrderCache _eval_cache;
 };
 

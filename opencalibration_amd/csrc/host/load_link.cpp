@@ -10,6 +10,7 @@
 
 #include "capi_graph.hpp"
 #include "extract_features.hpp"
+#include "load_link.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -23,102 +24,78 @@
 
 using namespace opencalibration_amd;
 
-extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width,
-                                          int height, uint32_t max_keypoints, int images_on_device, uint32_t model,
-                                          const double *positions, const double *orientations, uint64_t *node_ids_out,
-                                          double *totals2, double *link_timers8, double *stage_seconds2)
+namespace opencalibration_amd
+{
+
+std::vector<owned_pair> pair_owners(const std::vector<NodeLinks> &links)
+{
+    // A directed pair belongs to its source image - unless its reverse is a pair too: then both go to the later of the
+    // two sources.  Either way a pair can only run once both images are extracted, so nothing starts later than it
+    // could; but the two directions now always sit in the same batch (and, with one survey over several ranks, on the
+    // same rank), where the device matches them from ONE pass over their distance matrix (hamming_2nn_sym_kernel).
+    // With batches cut by source alone every pair that straddled a cut (13 % of them on the C3 grid) had its distances
+    // computed twice, by the slower one-direction kernel.  Which batch ran a pair does not show in the graph:
+    // finalize() orders the edges.
+    std::vector<owned_pair> out;
+    std::unordered_map<size_t, size_t> link_of; // node id -> index into links
+    for (size_t i = 0; i < links.size(); i++)
+        link_of.emplace(links[i].node_id, i);
+    for (size_t i = 0; i < links.size(); i++)
+        for (size_t m : links[i].link_ids)
+        {
+            size_t owner = i;
+            auto it = link_of.find(m);
+            if (it != link_of.end() && it->second > i)
+            {
+                const auto &back = links[it->second].link_ids;
+                if (std::find(back.begin(), back.end(), links[i].node_id) != back.end())
+                    owner = it->second;
+            }
+            out.push_back(owned_pair{owner, LinkStage::link_pair(i, m)});
+        }
+    return out;
+}
+
+bool load_link_stream(och_graph *g, ochip_ctx *ctx, LinkStage &link, const std::vector<size_t> &ids, uint32_t first,
+                      uint32_t count, const uint8_t *images_bgr, int width, int height, uint32_t max_keypoints,
+                      bool images_on_device, const std::vector<owned_pair> &pairs, double *total_out, double *sparse_out,
+                      double *t_extract_done)
 {
     using clk = std::chrono::steady_clock;
-    auto seconds_since = [](clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); };
-    if (!g || !ctx || (n_images && (!images_bgr || !positions)) || model >= g->models.size())
-    {
-        if (g)
-            g->error = "och_graph_load_link_images: bad argument";
-        return -1;
-    }
     const auto t_begin = clk::now();
-    // ---- nodes first (positions and camera model are known before any pixel is touched): the link stage's kNN only
-    //      needs those, and the node ids come out in image order as with the one-after-the-other path
-    std::vector<size_t> ids(n_images);
-    for (uint32_t b = 0; b < n_images; b++)
-    {
-        image img;
-        img.model = g->models[model];
-        for (int i = 0; i < 3; i++)
-            img.position[i] = positions[3 * (size_t)b + i];
-        if (orientations)
-            for (int i = 0; i < 4; i++)
-                img.orientation[i] = orientations[4 * (size_t)b + i];
-        img.path = "image_" + std::to_string(g->graph.size_nodes());
-        ids[b] = g->graph.addNode(std::move(img));
-        if (node_ids_out)
-            node_ids_out[b] = ids[b];
-    }
-    g->link = std::make_unique<LinkStage>(ctx);
-    LinkStage &link = *g->link;
-    link.init(g->graph, ids);
-    link.prepare_index(g->graph);
     const auto &links = link.links();
-    {
-        // images of earlier calls are link partners of the new ones (the reference links a batch against everything
-        // already in the graph, link_stage.cpp:26-35): their 40 px subsets and rays are prepared here, no range waits
-        // for them
-        std::unordered_map<size_t, char> mine;
-        for (size_t id : ids)
-            mine.emplace(id, 1);
-        std::vector<size_t> earlier;
-        for (const auto &n : g->graph.nodes())
-            if (!mine.count(n.id) && !n.payload.features.empty())
-                earlier.push_back(n.id);
-        if (!earlier.empty())
-            link.prepare_images(g->graph, earlier, omp_get_max_threads());
-    }
-
-    // ---- ranges of links and the images each one waits for
-    std::unordered_map<size_t, uint32_t> image_of; // node id -> image index
-    for (uint32_t b = 0; b < n_images; b++)
-        image_of.emplace(ids[b], b);
+    // ---- ranges of links and the images (of this call's block) each one waits for
+    std::unordered_map<size_t, uint32_t> image_of; // node id -> image index within the block
+    for (uint32_t b = 0; b < count; b++)
+        image_of.emplace(ids[first + b], b);
     const char *env = std::getenv("OCHIP_STREAM_LINK_RANGE");
     const size_t range_len = std::max<size_t>(32, env ? (size_t)std::atol(env) : 125);
-    // A directed pair belongs to the range of its source image - unless its reverse is a pair too: then both go to the
-    // range of the later of the two sources.  Either way a pair can only run once both images are extracted, so nothing
-    // starts later than it could; but the two directions now always sit in the same batch, where the device matches them
-    // from ONE pass over their distance matrix (hamming_2nn_sym_kernel).  With ranges cut by source alone every pair
-    // that straddled a cut (13 % of them on the C3 grid) had its distances computed twice, by the slower one-direction
-    // kernel.  Which batch ran a pair does not show in the graph: finalize() orders the edges.
     struct range
     {
         std::vector<LinkStage::link_pair> pairs;
         uint32_t waiting; // images not ready yet
     };
-    const size_t n_ranges = (links.size() + range_len - 1) / range_len;
-    std::vector<range> ranges(n_ranges);
+    size_t owner_lo = links.size(), owner_hi = 0;
+    for (const owned_pair &op : pairs)
     {
-        std::unordered_map<size_t, size_t> link_of; // node id -> index into links
-        for (size_t i = 0; i < links.size(); i++)
-            link_of.emplace(links[i].node_id, i);
-        for (size_t i = 0; i < links.size(); i++)
-            for (size_t m : links[i].link_ids)
-            {
-                size_t owner = i;
-                auto it = link_of.find(m);
-                if (it != link_of.end() && it->second > i)
-                {
-                    const auto &back = links[it->second].link_ids;
-                    if (std::find(back.begin(), back.end(), links[i].node_id) != back.end())
-                        owner = it->second;
-                }
-                ranges[owner / range_len].pairs.emplace_back(i, m);
-            }
+        owner_lo = std::min(owner_lo, op.owner);
+        owner_hi = std::max(owner_hi, op.owner + 1);
     }
-    std::vector<std::vector<uint32_t>> ranges_of_image(n_images); // image -> ranges that need it
+    const size_t n_ranges = pairs.empty() ? 0 : (owner_hi - owner_lo + range_len - 1) / range_len;
+    std::vector<range> ranges(n_ranges);
+    for (const owned_pair &op : pairs)
+        ranges[(op.owner - owner_lo) / range_len].pairs.push_back(op.pair);
+    std::vector<std::vector<uint32_t>> ranges_of_image(count); // image -> ranges that need it
+    std::vector<uint32_t> ready_at_once;
     for (size_t k = 0; k < n_ranges; k++)
     {
         range &r = ranges[k];
         std::vector<uint32_t> need;
         for (const auto &lp : r.pairs)
         {
-            need.push_back(image_of.at(links[lp.first].node_id));
+            auto a = image_of.find(links[lp.first].node_id);
+            if (a != image_of.end())
+                need.push_back(a->second);
             auto it = image_of.find(lp.second);
             if (it != image_of.end())
                 need.push_back(it->second);
@@ -128,6 +105,8 @@ extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const ui
         r.waiting = (uint32_t)need.size();
         for (uint32_t im : need)
             ranges_of_image[im].push_back((uint32_t)k);
+        if (need.empty() && !r.pairs.empty())
+            ready_at_once.push_back((uint32_t)k);
     }
 
     // ---- link runners: each owns a device context (siblings 4.. of ctx; extraction uses ctx and its first siblings)
@@ -137,9 +116,8 @@ extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const ui
     const int tail_threads = std::max(1, team / 2), runner_threads = std::max(1, team / (2 * n_runners) + 1);
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<uint32_t> ready;
+    std::deque<uint32_t> ready(ready_at_once.begin(), ready_at_once.end());
     bool no_more = false;
-    std::string fail;
     std::vector<std::thread> runners;
     for (int r = 0; r < n_runners; r++)
     {
@@ -150,11 +128,12 @@ extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const ui
             {
                 std::lock_guard<std::mutex> lk(mu);
                 no_more = true;
+                ready.clear();
             }
             cv.notify_all();
             for (auto &t : runners)
                 t.join();
-            return -1;
+            return false;
         }
         runners.emplace_back([&, rctx]() {
             for (;;)
@@ -175,30 +154,31 @@ extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const ui
 
     // ---- extraction; every finished chunk fills its nodes, prepares their 40 px subsets and releases the ranges
     //      that were only waiting for these images
-    double total = 0, sparse = 0, t_extract_done = 0;
+    double total = 0, sparse = 0;
     const bool ok = extract_features_stream(
-        ctx, images_bgr, n_images, width, height, max_keypoints, images_on_device != 0, tail_threads,
-        [&](uint32_t first, uint32_t count, extracted_features *f) {
-            std::vector<size_t> chunk_ids(count);
-            for (uint32_t i = 0; i < count; i++)
+        ctx, images_bgr, count, width, height, max_keypoints, images_on_device, tail_threads,
+        [&](uint32_t chunk_first, uint32_t chunk_count, extracted_features *f) {
+            std::vector<size_t> chunk_ids(chunk_count);
+            for (uint32_t i = 0; i < chunk_count; i++)
             {
-                image &img = g->graph.getNode(ids[first + i])->payload;
+                image &img = g->graph.getNode(ids[first + chunk_first + i])->payload;
                 total += (double)f[i].features.size();
                 sparse += (double)f[i].num_sparse_features;
                 img.features = std::move(f[i].features);
                 img.num_sparse_features = f[i].num_sparse_features;
-                chunk_ids[i] = ids[first + i];
+                chunk_ids[i] = ids[first + chunk_first + i];
             }
             link.prepare_images(g->graph, chunk_ids, tail_threads);
             std::lock_guard<std::mutex> lk(mu);
-            for (uint32_t i = 0; i < count; i++)
-                for (uint32_t k : ranges_of_image[first + i])
+            for (uint32_t i = 0; i < chunk_count; i++)
+                for (uint32_t k : ranges_of_image[chunk_first + i])
                     if (--ranges[k].waiting == 0)
                         ready.push_back(k);
             cv.notify_all();
         },
         &g->error);
-    t_extract_done = seconds_since(t_begin);
+    if (t_extract_done)
+        *t_extract_done = std::chrono::duration<double>(clk::now() - t_begin).count();
     {
         std::lock_guard<std::mutex> lk(mu);
         no_more = true; // runners drain what is queued, then stop
@@ -209,12 +189,81 @@ extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const ui
     for (auto &t : runners)
         t.join();
     if (!ok)
-        return -1;
+        return false;
     if (!link.error.empty())
     {
         g->error = link.error;
+        return false;
+    }
+    if (total_out)
+        *total_out = total;
+    if (sparse_out)
+        *sparse_out = sparse;
+    return true;
+}
+
+std::vector<size_t> add_survey_nodes(och_graph *g, uint32_t n_images, uint32_t model, const double *positions,
+                                     const double *orientations, uint64_t *node_ids_out)
+{
+    // nodes first (positions and camera model are known before any pixel is touched): the link stage's kNN only needs
+    // those, and the node ids come out in image order as with the one-after-the-other path
+    std::vector<size_t> ids(n_images);
+    for (uint32_t b = 0; b < n_images; b++)
+    {
+        image img;
+        img.model = g->models[model];
+        for (int i = 0; i < 3; i++)
+            img.position[i] = positions[3 * (size_t)b + i];
+        if (orientations)
+            for (int i = 0; i < 4; i++)
+                img.orientation[i] = orientations[4 * (size_t)b + i];
+        img.path = "image_" + std::to_string(g->graph.size_nodes());
+        ids[b] = g->graph.addNode(std::move(img));
+        if (node_ids_out)
+            node_ids_out[b] = ids[b];
+    }
+    return ids;
+}
+
+} // namespace opencalibration_amd
+
+extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width,
+                                          int height, uint32_t max_keypoints, int images_on_device, uint32_t model,
+                                          const double *positions, const double *orientations, uint64_t *node_ids_out,
+                                          double *totals2, double *link_timers8, double *stage_seconds2)
+{
+    using clk = std::chrono::steady_clock;
+    auto seconds_since = [](clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); };
+    if (!g || !ctx || (n_images && (!images_bgr || !positions)) || model >= g->models.size())
+    {
+        if (g)
+            g->error = "och_graph_load_link_images: bad argument";
         return -1;
     }
+    const auto t_begin = clk::now();
+    const std::vector<size_t> ids = add_survey_nodes(g, n_images, model, positions, orientations, node_ids_out);
+    g->link = std::make_unique<LinkStage>(ctx);
+    LinkStage &link = *g->link;
+    link.init(g->graph, ids);
+    link.prepare_index(g->graph);
+    {
+        // images of earlier calls are link partners of the new ones (the reference links a batch against everything
+        // already in the graph, link_stage.cpp:26-35): their 40 px subsets and rays are prepared here, no range waits
+        // for them
+        std::unordered_map<size_t, char> mine;
+        for (size_t id : ids)
+            mine.emplace(id, 1);
+        std::vector<size_t> earlier;
+        for (const auto &n : g->graph.nodes())
+            if (!mine.count(n.id) && !n.payload.features.empty())
+                earlier.push_back(n.id);
+        if (!earlier.empty())
+            link.prepare_images(g->graph, earlier, omp_get_max_threads());
+    }
+    double total = 0, sparse = 0, t_extract_done = 0;
+    if (!load_link_stream(g, ctx, link, ids, 0, n_images, images_bgr, width, height, max_keypoints, images_on_device != 0,
+                          pair_owners(link.links()), &total, &sparse, &t_extract_done))
+        return -1;
     link.finalize(g->graph);
     if (totals2)
     {

@@ -843,13 +843,22 @@ std::vector<std::function<void()>> RelaxStage::get_runners(ochip_ctx *ctx, const
     R = std::max<size_t>(1, std::min(R, _groups.size()));
     while (_ctx_mutex.size() < R)
         _ctx_mutex.emplace_back(new std::mutex());
+    // the R contexts are resolved here, on the calling thread, and captured by the runners (creating a sibling touches the
+    // parent context's list and error text)
+    std::vector<ochip_ctx *> contexts(R, ctx);
+    std::string sibling_error;
+    for (size_t r = 1; r < R; r++)
+        if (ochip_ctx_sibling(ctx, (uint32_t)(r - 1), &contexts[r]) != OCHIP_OK)
+        {
+            sibling_error = std::string("ochip_ctx_sibling: ") + ochip_last_error(ctx);
+            contexts[r] = nullptr;
+        }
     std::vector<std::function<void()>> funcs;
     for (size_t i = 0; i < _groups.size(); i++)
-        funcs.push_back([this, i, R, ctx, &graph]() {
-            ochip_ctx *c = ctx;
-            if (i % R > 0 && ochip_ctx_sibling(ctx, (uint32_t)(i % R - 1), &c) != OCHIP_OK)
+        funcs.push_back([this, i, R, c = contexts[i % R], sibling_error, &graph]() {
+            if (!c)
             {
-                _group_errors[i] = std::string("ochip_ctx_sibling: ") + ochip_last_error(ctx);
+                _group_errors[i] = sibling_error;
                 return;
             }
             std::lock_guard<std::mutex> lock(*_ctx_mutex[i % R]);

@@ -1037,7 +1037,10 @@ struct plane_model final : lm_model
             // the ranks' pair records (and failure flags) are all-gathered in place; from here on every rank holds
             // the same arrays and runs the same deterministic assembly.  A failed exchange is a hard error: the ranks
             // would otherwise leave the solve on different schedules and the next collective would hang.
-            OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+            // (the native transport enqueues its all-gathers on this stream: stream order is all it needs; a callback
+            // transport reads the arrays from outside the stream and gets them complete)
+            if (p->exchange != ochip_rccl_relax_exchange)
+                OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
             const int xrc = p->exchange(p->exchange_user, D.pair_acc, with_jac ? (uint64_t)p->shard_chunk * ACC * 8 : 0,
                                         D.pair_cost, (uint64_t)p->shard_chunk * 8, p->fail_ranks, 4);
             if (xrc != 0)

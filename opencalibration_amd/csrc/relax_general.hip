@@ -43,19 +43,24 @@ enum : uint8_t
     T_DIFF = 17,
     T_ANCHOR = 18,
     T_SMOOTH = 19,
-    T_MONO = 20
+    T_MONO = 20,
+    T_NULL = 31 // padding between the ray blocks and the priors of a sharded problem: no unknowns, no data, cost 0
 };
 
 __host__ __device__ inline int rec_dim(int type)
 {
     if (type < T_DOWN)
         return 3 * (type & 7) + 3 + ((type & T_INTR) ? 6 : 0);
+    if (type == T_NULL)
+        return 0;
     return type == T_DOWN ? 3 : type == T_DIFF ? 2 : type == T_ANCHOR ? 1 : type == T_SMOOTH ? 4 : 3;
 }
 __host__ __device__ inline int rec_nvars(int type)
 {
     if (type < T_DOWN)
         return (type & 7) + 3 + ((type & T_INTR) ? 3 : 0);
+    if (type == T_NULL)
+        return 0;
     return type == T_DOWN ? 1 : type == T_DIFF ? 2 : type == T_ANCHOR ? 1 : type == T_SMOOTH ? 4 : 1;
 }
 // local column -> (slot of the record's unknown group, offset inside the group)
@@ -440,14 +445,20 @@ __global__ void prior_kernel(g_dev P, int which, int with_jac)
         atomicOr(P.fail, 1);
 }
 
-// total cost: fixed-order strided sums + tree, one workgroup.  scal[0] = cost
-__global__ __launch_bounds__(1024) void cost_reduce_kernel(const double *rec_cost, uint32_t n, double *scal)
+// total cost: fixed-order strided sums + tree, one workgroup.  scal[0] = cost.  The ray blocks [0, n_ray) and the priors
+// [prior_base, prior_base + n_prior) are walked relative to their own starts, so the order of the additions does not
+// depend on the padding a sharded problem puts between the two (sharded and unsharded solves add the same numbers in the
+// same order)
+__global__ __launch_bounds__(1024) void cost_reduce_kernel(const double *rec_cost, uint32_t n_ray, uint32_t prior_base, uint32_t n_prior,
+                                                           double *scal)
 {
     __shared__ double sh[1024];
     const int t = threadIdx.x;
     double v = 0;
-    for (uint32_t i = t; i < n; i += 1024)
+    for (uint32_t i = t; i < n_ray; i += 1024)
         v += rec_cost[i];
+    for (uint32_t i = t; i < n_prior; i += 1024)
+        v += rec_cost[prior_base + i];
     sh[t] = v;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1)
@@ -813,6 +824,13 @@ struct ochip_relaxg_problem
     uint32_t *var_rec_dev = nullptr, *tail_var_dev = nullptr, *tail_first_dev = nullptr, *tail_count_dev = nullptr;
     double *partials_dev = nullptr;
     uint8_t *cam_optimize_dev = nullptr;
+    // sharded evaluation (ochip_relaxg_desc.shard_world > 1): this rank evaluates the ray blocks [shard_lo, shard_hi); the
+    // record data of rank r lies at r * shard_stride doubles, its costs at r * shard_chunk
+    uint32_t shard_rank = 0, shard_world = 1, shard_chunk = 0, shard_lo = 0, shard_hi = 0;
+    uint64_t shard_stride = 0;
+    int32_t *fail_ranks = nullptr;
+    ochip_relax_exchange_fn exchange = nullptr;
+    void *exchange_user = nullptr;
 };
 
 namespace
@@ -1071,8 +1089,13 @@ struct general_model final : lm_model
         OCHIP_HIP(ctx, hipMemsetAsync(D.fail, 0, 4, st));
         hipEvent_t e0, e1;
         ochip_prof_begin(ctx, OCHIP_K_RELAX_EVAL, &e0, &e1);
-        for (const auto &r : p->ranges)
+        for (const auto &full : p->ranges)
         {
+            // this rank's part of the type's blocks (everything when the problem is not sharded)
+            ochip_relaxg_problem::type_range r = full;
+            const uint32_t a = std::max(full.first, p->shard_lo), b = std::min(full.first + full.count, p->shard_hi);
+            r.first = a;
+            r.count = b > a ? b - a : 0;
             if (r.count == 0)
                 continue;
             const bool intr = (r.type & T_INTR) != 0;
@@ -1096,6 +1119,18 @@ struct general_model final : lm_model
         if (n_prior)
             hipLaunchKernelGGL(prior_kernel, dim3((n_prior + 255) / 256), dim3(256), 0, st, D, which, with_jac ? 1 : 0);
         ochip_prof_end(ctx, OCHIP_K_RELAX_EVAL, e0, e1);
+        if (p->exchange)
+        {
+            // the ranks' records (costs, failure flags) are all-gathered in place; from here on every rank holds the same
+            // arrays and runs the same deterministic assembly.  A failed exchange is a hard error: the ranks would
+            // otherwise leave the solve on different schedules and the next collective would hang.
+            if (p->exchange != ochip_rccl_relax_exchange) // (the native transport is stream-ordered)
+                OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+            const int xrc = p->exchange(p->exchange_user, D.rec_data, with_jac ? p->shard_stride * 8 : 0, D.rec_cost,
+                                        (uint64_t)p->shard_chunk * 8, p->fail_ranks, 4);
+            if (xrc != 0)
+                return ochip_fail(ctx, OCHIP_EHIP, "relax exchange callback failed (%d)", xrc);
+        }
         if (with_jac)
         {
             OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, (size_t)n * n * 8, st));
@@ -1107,14 +1142,17 @@ struct general_model final : lm_model
                 hipLaunchKernelGGL(tail_merge_kernel, dim3(p->n_tail_owners), dim3(256), 0, st, D, p->tail_var_dev, p->tail_first_dev,
                                    p->tail_count_dev, p->partials_dev, p->sys.A, p->sys.g, n, p->tail_begin);
         }
-        hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(1024), 0, st, D.rec_cost, D.n_rec, p->sys.scal);
+        hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(1024), 0, st, D.rec_cost, p->n_blocks, D.prior_base, n_prior, p->sys.scal);
         OCHIP_HIP(ctx, hipGetLastError());
         double h0 = 0;
-        int32_t hfail = 0;
+        std::vector<int32_t> hfails(p->shard_world, 0);
         OCHIP_HIP(ctx, hipMemcpyAsync(&h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(&hfail, D.fail, 4, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(hfails.data(), p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         *cost = h0;
+        int hfail = 0;
+        for (int32_t f : hfails)
+            hfail |= f;
         return hfail ? 1 : 0;
     }
     void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override
@@ -1234,7 +1272,22 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
     ray_px.reserve(2 * (size_t)n_rays);
     const uint32_t n_anchor = d->anchor_weight != 0.0 ? nv : 0;
     const uint32_t n_mono = d->mono_observations > 0 ? 1 : 0;
-    p->n_rec = d->n_blocks + d->n_down + d->n_diff + n_anchor + d->n_smooth + n_mono;
+    // sharded evaluation: the ray blocks (in their type-sorted order) are cut into `world` equal runs of `chunk` records;
+    // the record list is padded to world * chunk entries before the priors, which every rank evaluates itself
+    const uint32_t world = std::max<uint32_t>(1, d->shard_world);
+    if (d->shard_rank >= world)
+    {
+        delete p;
+        return ochip_fail(ctx, OCHIP_EINVAL, "bad shard (rank %u of %u)", d->shard_rank, world);
+    }
+    const uint32_t chunk = std::max<uint32_t>(1, (d->n_blocks + world - 1) / world);
+    const uint32_t n_ray_pad = world > 1 ? world * chunk : d->n_blocks;
+    p->shard_rank = d->shard_rank;
+    p->shard_world = world;
+    p->shard_chunk = chunk;
+    p->shard_lo = world > 1 ? std::min(d->shard_rank * chunk, d->n_blocks) : 0;
+    p->shard_hi = world > 1 ? std::min((d->shard_rank + 1) * chunk, d->n_blocks) : d->n_blocks;
+    p->n_rec = n_ray_pad + d->n_down + d->n_diff + n_anchor + d->n_smooth + n_mono;
     p->rec_type.resize(p->n_rec);
     p->rec_var.assign((size_t)p->n_rec * MAXV, 0);
     std::vector<uint64_t> rec_off(p->n_rec + 1, 0);
@@ -1270,6 +1323,8 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
     }
     {
         uint32_t r = d->n_blocks;
+        for (; r < n_ray_pad; r++)
+            p->rec_type[r] = T_NULL;
         for (uint32_t i = 0; i < d->n_down; i++, r++)
         {
             if (d->down_cam[i] >= nc)
@@ -1317,10 +1372,38 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
             p->rec_var[(size_t)r * MAXV] = vf + 2;
         }
     }
-    for (uint32_t r = 0; r < p->n_rec; r++)
-    {
+    auto rec_size = [&](uint32_t r) {
         const int dd = rec_dim(p->rec_type[r]);
-        rec_off[r + 1] = rec_off[r] + (uint64_t)(dd * (dd + 1) / 2 + dd);
+        return (uint64_t)(dd * (dd + 1) / 2 + dd);
+    };
+    if (world == 1)
+        for (uint32_t r = 0; r < p->n_rec; r++)
+            rec_off[r + 1] = rec_off[r] + rec_size(r);
+    else
+    {
+        // rank k's records start at k * stride (stride = the largest run), so that the exchange is a plain in-place
+        // all-gather of `stride` doubles per rank; the priors' records follow the last run
+        uint64_t stride = 0;
+        for (uint32_t k = 0; k < world; k++)
+        {
+            uint64_t run = 0;
+            for (uint32_t r = k * chunk; r < std::min((k + 1) * chunk, d->n_blocks); r++)
+                run += rec_size(r);
+            stride = std::max(stride, run);
+        }
+        p->shard_stride = stride;
+        for (uint32_t k = 0; k < world; k++)
+        {
+            uint64_t at = (uint64_t)k * stride;
+            for (uint32_t r = k * chunk; r < (k + 1) * chunk; r++)
+            {
+                rec_off[r] = at;
+                at += rec_size(r); // (padding records: size 0)
+            }
+        }
+        rec_off[n_ray_pad] = (uint64_t)world * stride;
+        for (uint32_t r = n_ray_pad; r < p->n_rec; r++)
+            rec_off[r + 1] = rec_off[r] + rec_size(r);
     }
     // CSR unknown group -> records, in record order (the fixed summation order of the assembly)
     p->var_rec_off.assign(p->n_vars + 1, 0);
@@ -1351,7 +1434,7 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
     D.n_anchor = n_anchor;
     D.n_smooth = d->n_smooth;
     D.n_mono = n_mono;
-    D.prior_base = d->n_blocks;
+    D.prior_base = n_ray_pad;
     D.down_w = d->down_weight;
     D.diff_w = d->diff_weight;
     D.anchor_w = d->anchor_weight;
@@ -1388,12 +1471,18 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
     chk(up(p, &D.rec_var, p->rec_var));
     chk(up<double>(p, &D.rec_data, nullptr, (size_t)rec_off[p->n_rec]));
     chk(up<double>(p, &D.rec_cost, nullptr, p->n_rec));
+    chk(up<int32_t>(p, &p->fail_ranks, nullptr, world));
     chk(up(p, &D.down_cam, d->down_cam, d->n_down));
     chk(up(p, &D.diff_v, d->diff_v, (size_t)d->n_diff * 2));
     chk(up(p, &D.smooth_v, d->smooth_v, (size_t)d->n_smooth * 4));
-    chk(up<int32_t>(p, &D.fail, nullptr, 1));
     chk(up(p, &p->var_rec_dev, p->var_rec));
     chk(up(p, &p->cam_optimize_dev, p->cam_optimize));
+    if (rc == OCHIP_OK)
+    {
+        D.fail = p->fail_ranks + p->shard_rank;
+        if (hipMemset(p->fail_ranks, 0, (size_t)world * 4) != hipSuccess || hipMemset(D.rec_cost, 0, (size_t)p->n_rec * 8) != hipSuccess)
+            rc = ochip_fail(ctx, OCHIP_EHIP, "hipMemset failed (relax records)");
+    }
     if (rc == OCHIP_OK)
         rc = assign(p);
     if (rc != OCHIP_OK)
@@ -1402,6 +1491,17 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
         return rc;
     }
     *out = p;
+    return OCHIP_OK;
+}
+
+int ochip_relaxg_set_exchange(ochip_relaxg_problem *p, ochip_relax_exchange_fn fn, void *user)
+{
+    if (!p)
+        return OCHIP_EINVAL;
+    if (p->shard_world > 1 && !fn)
+        return ochip_fail(p->ctx, OCHIP_EINVAL, "a problem sharded over %u ranks needs an exchange function", p->shard_world);
+    p->exchange = fn;
+    p->exchange_user = user;
     return OCHIP_OK;
 }
 

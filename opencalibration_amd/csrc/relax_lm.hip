@@ -272,9 +272,11 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n,
 // blocks K < J whose envelope holds both, accumulated in the matrix cores' registers while the operands arrive; then the
 // diagonal tile is factored (the register kernel of chol_diag_kernel) and an off-diagonal tile is multiplied by the
 // inverse of its column's diagonal block.  Nothing is read-modified-written in HBM.  Workgroups claim tiles from a
-// list in which every tile follows the tiles it needs (rows of the dense tail first - their sums run along the whole
-// factorisation and must start early - then the band, column by column), so a claimed tile only ever waits for tiles that
-// are already running: no co-residency is required.  A tile is handed over as MI355X_MICROARCH.md prescribes
+// list, column by column: in that order every tile follows the tiles it needs, so a claimed tile only ever waits for
+// tiles that are already running and no co-residency is required.  The one exception is made by lm_system_resize when
+// the dense tail is small: its rows - whose sums run along the whole factorisation and should start early - are claimed
+// ahead of the band, which needs free slots for the band's workgroups and is therefore limited to an eighth of the
+// device (see there).  A tile is handed over as MI355X_MICROARCH.md prescribes
 // (per-XCD L2s are not coherent): write-through stores, every storing wave drained, barrier, ONE lane sets the tile's
 // flag with an agent-scope store; the consumer polls that word relaxed, ONE agent-scope acquire, drain, barrier, plain loads.
 struct chol_col
@@ -815,7 +817,12 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
             per_cu = 1;
         const int slots = per_cu * ctx->prop.multiProcessorCount;
         // claim order: the tail's rows first (their sums run along the whole factorisation), then the band, each column
-        // by column; when the tail alone would fill the machine, plain column order
+        // by column.  A tail tile claimed ahead of the band tiles it reads spins until workgroups further down the list
+        // have produced them, i.e. it needs free slots on the device - and factorisations of other contexts run beside
+        // this one (RelaxStage: up to four groups at once, the bench's pipelined relax a fifth), each with its own
+        // spinning tail.  So the tail only goes first while it is a small part of the machine (an eighth of the slots:
+        // five such kernels still leave three eighths to the band tiles); otherwise plain column order, in which a
+        // claimed tile only ever waits for tiles claimed before it - already running - and no co-residency is needed.
         std::vector<unsigned int> order;
         order.reserve((size_t)n_tiles);
         auto rows_of = [&](int J, bool want_tail, bool want_band) {
@@ -833,7 +840,7 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
                 tail_tiles += I >= tb;
             tail_tiles += (size_t)std::max(0, nbr - cols[J].tail_start);
         }
-        if ((long)tail_tiles + 64 <= (long)slots)
+        if ((long)tail_tiles * 8 <= (long)slots)
         {
             for (int J = 0; J < nbc; J++)
                 rows_of(J, true, false);

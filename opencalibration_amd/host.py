@@ -178,6 +178,21 @@ def load():
         L.och_surface_locate.argtypes = [vp, _f64p, sz, _u64p]
         L.och_surface_locate.restype = None
         L.och_mesh_refinement_run.argtypes = [vp, vp, vp, C.c_int, _f64p]
+        L.och_shard_block.argtypes = [u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+        L.och_shard_block.restype = None
+        L.och_shard_begin.restype = vp
+        L.och_shard_begin.argtypes = [vp, vp, u32, u32, _f64p, vp, u32, u32, _u64p]
+        L.och_shard_destroy.argtypes = [vp]
+        L.och_shard_destroy.restype = None
+        L.och_shard_counts.argtypes = [vp, _u64p]
+        L.och_shard_counts.restype = None
+        L.och_shard_load_link_local.argtypes = [vp, vp, C.c_int, C.c_int, u32, C.c_int]
+        for name in ("och_shard_subsets_export", "och_shard_edges_export"):
+            getattr(L, name).argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+        for name in ("och_shard_subsets_import", "och_shard_edges_import"):
+            getattr(L, name).argtypes = [vp, vp, u64]
+        L.och_shard_link_remote.argtypes = [vp]
+        L.och_shard_finalize.argtypes = [vp, _f64p, _f64p, _f64p]
         L.och_hilbert_xy2d.argtypes = [C.c_int, C.c_int, C.c_int]
         L.och_hilbert_xy2d.restype = u32
         _lib = L
@@ -781,6 +796,94 @@ class Graph:
                 continue
             out.append(dict(src=s, dst=d, H=ed["H"], px=ed["px"], match_index=ed["match_index"], dist=ed["dist"]))
         return out
+
+
+SHARD_SECONDS = ["extract", "block_linked", "subsets_export", "subsets_import", "remote_links", "edges_export",
+                 "edges_import", "finalize", "stage"]
+
+
+def shard_block(n_images, rank, world):
+    """(first, count) of the contiguous image block of `rank` (och_shard_block)."""
+    a, b = C.c_uint32(0), C.c_uint32(0)
+    load().och_shard_block(n_images, rank, world, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+class Shard:
+    """One survey's load + link stages on rank `rank` of `world` (include/oc_host.h, och_shard_*): the caller moves the two
+    buffers between the ranks (parallel.survey_sharded does it with torch.distributed)."""
+
+    def __init__(self, graph, ctx, model, positions, orientations, rank, world):
+        self.g, self.L = graph, graph.L
+        pos = np.ascontiguousarray(positions, np.float64).reshape(-1, 3)
+        ori = None if orientations is None else np.ascontiguousarray(orientations, np.float64)
+        ids = np.zeros(max(len(pos), 1), np.uint64)
+        self.h = self.L.och_shard_begin(graph.h, ctx.h, len(pos), model, pos, None if ori is None else ori.ctypes.data, rank, world, ids)
+        if not self.h:
+            raise capi.OchipError("och_shard_begin: " + self.L.och_last_error(graph.h).decode())
+        graph.node_ids += [int(i) for i in ids[:len(pos)]]
+        self.first, self.count = shard_block(len(pos), rank, world)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.och_shard_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise capi.OchipError(what + " failed: " + self.L.och_last_error(self.g.h).decode())
+
+    def counts(self):
+        out = np.zeros(4, np.uint64)
+        self.L.och_shard_counts(self.h, out)
+        return dict(zip(["images", "pairs_in_block", "pairs_across_blocks", "halo_images"], (int(v) for v in out)))
+
+    def load_link_local(self, images_block, width, height, max_keypoints=30000, on_device=True):
+        """images_block: device pointer (on_device) or (count, h, w, 3) uint8 host array of the BLOCK's images."""
+        src = int(images_block) if on_device else np.ascontiguousarray(images_block, np.uint8).ctypes.data
+        self._check(self.L.och_shard_load_link_local(self.h, src, width, height, max_keypoints, int(on_device)), "load + link of the block")
+
+    def _export(self, fn):
+        ptr, n = C.c_void_p(0), C.c_uint64(0)
+        self._check(fn(self.h, C.byref(ptr), C.byref(n)), "export")
+        if n.value == 0:
+            return np.zeros(0, np.uint8)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n.value,))   # a view: copy before the next export
+
+    def subsets_export(self):
+        return self._export(self.L.och_shard_subsets_export)
+
+    def edges_export(self):
+        return self._export(self.L.och_shard_edges_export)
+
+    @staticmethod
+    def _aligned(buf):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        if buf.ctypes.data % 8:
+            tmp = np.zeros(len(buf) + 8, np.uint8)
+            off = (-tmp.ctypes.data) % 8
+            tmp[off:off + len(buf)] = buf
+            buf = tmp[off:off + len(buf)]
+        return buf
+
+    def subsets_import(self, buf):
+        buf = self._aligned(buf)
+        self._check(self.L.och_shard_subsets_import(self.h, buf.ctypes.data, len(buf)), "subset import")
+
+    def edges_import(self, buf):
+        buf = self._aligned(buf)
+        self._check(self.L.och_shard_edges_import(self.h, buf.ctypes.data, len(buf)), "edge import")
+
+    def link_remote(self):
+        self._check(self.L.och_shard_link_remote(self.h), "links across blocks")
+
+    def finalize(self):
+        """Returns (features, sparse features of the block, link timers, stage seconds)."""
+        totals, timers, secs = np.zeros(2), np.zeros(8), np.zeros(9)
+        self._check(self.L.och_shard_finalize(self.h, totals, timers, secs), "finalize")
+        return totals[0], totals[1], dict(zip(LINK_TIMER_NAMES, timers.tolist())), dict(zip(SHARD_SECONDS, secs.tolist()))
 
 
 def extract_tail(kp6, desc, scale):

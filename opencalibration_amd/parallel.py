@@ -141,3 +141,103 @@ def link_sharded(make_graph, ctx, group=None):
             merged.add_edge(e["source"], e["dest"], e["px"], e["f1"], e["f2"], e["match_index"], e["H"], e["dist"], e["poses"],
                             match_idx=e["match_idx"], is_homography=e["is_homography"])
     return merged, len(mine)
+
+
+_pinned = {}
+
+
+def _pinned_bytes(n, tag):
+    """A page-locked host staging tensor of at least n bytes, kept between calls (allocation is the expensive part)."""
+    import torch
+
+    t = _pinned.get(tag)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1) * 5 // 4, dtype=torch.uint8, pin_memory=torch.cuda.is_available())
+        _pinned[tag] = t
+    return t[:n]
+
+
+def all_gather_bytes(buf, group=None, stats=None):
+    """Every rank's byte buffer (numpy uint8, any length) on every rank: a list indexed by rank.  Backend "nccl": an
+    RCCL all-gather of device tensors (xGMI), staged through page-locked host memory on both sides; "gloo": host tensors.
+    The slices start at multiples of 8 bytes.  stats (dict): bytes gathered and exchanges are added to it."""
+    import torch
+    import torch.distributed as dist
+
+    buf = np.ascontiguousarray(buf, np.uint8)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return [buf]
+    on_device = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_device else torch.device("cpu")
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([len(buf)], dtype=torch.int64, device=dev), group=group)
+    sizes = [int(v) for v in sizes.cpu().tolist()]
+    cap = (max(sizes) + 7) // 8 * 8
+    if cap == 0:
+        return [np.zeros(0, np.uint8) for _ in range(world)]
+    if on_device:
+        stage = _pinned_bytes(cap, "send")
+        stage[:len(buf)] = torch.from_numpy(buf)
+        mine = stage.to(dev, non_blocking=True)
+        full = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(full, mine, group=group)
+        back = _pinned_bytes(world * cap, "recv")
+        back.copy_(full, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        host = back.numpy()
+    else:
+        mine = torch.zeros(cap, dtype=torch.uint8)
+        mine[:len(buf)] = torch.from_numpy(buf)
+        full = torch.empty(world * cap, dtype=torch.uint8)
+        dist.all_gather_into_tensor(full, mine, group=group)
+        host = full.numpy()
+    if stats is not None:
+        stats["exchanges"] = stats.get("exchanges", 0) + 1
+        stats["bytes_gathered"] = stats.get("bytes_gathered", 0) + sum(sizes)
+    return [host[r * cap:r * cap + sizes[r]] for r in range(world)]
+
+
+def survey_sharded(ctx, graph, model, positions, orientations, images_block, width, height, group=None, max_keypoints=30000,
+                   on_device=True, edges_to=None):
+    """ONE survey's load + link stages over the ranks of `group` (host.Shard / och_shard_*): this rank extracts its
+    contiguous block of the images (`images_block`: the block's views) and links the directed pairs the block owns; the
+    40 px subsets and then the pairs' results are all-gathered, and every rank finishes with the same graph edges - the
+    ones a single process builds, ids included (LinkStage::finalize's sort, link_stage.cpp:123-127).  `graph` holds the
+    camera model `model` and no nodes.  edges_to = a rank: only that rank imports the other ranks' edges (the one that
+    goes on to relax the survey); the others end with their own edges only.  Returns a dict of the stage's numbers
+    (seconds per phase, gathered bytes)."""
+    import time
+
+    import torch.distributed as dist
+
+    from .host import Shard
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    sh = Shard(graph, ctx, model, positions, orientations, rank, world)
+    stats = {}
+    try:
+        sh.load_link_local(images_block, width, height, max_keypoints, on_device)
+        t_ex = 0.0
+        if world > 1:
+            t0 = time.perf_counter()
+            parts = all_gather_bytes(sh.subsets_export(), group, stats)
+            t_ex += time.perf_counter() - t0
+            for r, part in enumerate(parts):
+                if r != rank:
+                    sh.subsets_import(part)
+            sh.link_remote()
+            t0 = time.perf_counter()
+            parts = all_gather_bytes(sh.edges_export(), group, stats)
+            t_ex += time.perf_counter() - t0
+            for r, part in enumerate(parts):
+                if r != rank and edges_to in (None, rank):
+                    sh.edges_import(part)
+        feats, sparse, link_timers, seconds = sh.finalize()
+        out = dict(features=feats, sparse=sparse, link_timers=link_timers, seconds=seconds, exchange_s=t_ex,
+                   block=(sh.first, sh.count), rank=rank, world=world, **sh.counts())
+        out.update(stats)
+        return out
+    finally:
+        sh.close()

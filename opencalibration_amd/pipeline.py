@@ -13,16 +13,19 @@ import numpy as np
 from . import host, synth
 
 
-def synthetic_views(ctx, grid, seed=7):
-    """Render one 4000x3000-class view per camera of `grid` into HBM.  Returns (device pointer, (n, h, w))."""
+def synthetic_views(ctx, grid, seed=7, block=None):
+    """Render one 4000x3000-class view per camera of `grid` into HBM.  Returns (device pointer, (n, h, w)).
+    block = (first, count): only those cameras' views (one survey over several ranks: a rank holds its block)."""
     w, h = int(grid.model[8]), int(grid.model[9])
     f, pp = float(grid.model[0]), (float(grid.model[1]), float(grid.model[2]))
     # blob lattice: ~21 px apart in the 1600-px working image, i.e. (max(w,h)/1600) * 21 full-resolution pixels
     gsd = (grid.position[0, 2] - (grid.plane[0] * grid.position[0, 0] + grid.plane[1] * grid.position[0, 1])) / f
     spacing = float(os.environ.get("OCHIP_BLOB_SPACING", "21.0")) * (max(w, h) / 1600.0) * gsd
     origin = (float(grid.position[:, 0].min() - 500.0), float(grid.position[:, 1].min() - 500.0))
-    ptr = ctx.synth_views(grid.position, grid.orientation, w, h, f, pp, grid.plane, spacing, origin, seed=seed)
-    return ptr, (grid.n_images, h, w)
+    lo, cnt = (0, grid.n_images) if block is None else block
+    ptr = ctx.synth_views(grid.position[lo:lo + cnt], grid.orientation[lo:lo + cnt], w, h, f, pp, grid.plane, spacing, origin,
+                          seed=seed)
+    return ptr, (cnt, h, w)
 
 
 def relax_step(ctx, g, start_orientation, res, t):

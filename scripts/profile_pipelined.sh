@@ -4,6 +4,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_pipe
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# read by the HIP runtime when rocprofv3's preloaded library initialises it, i.e. before python starts
+export GPU_MAX_HW_QUEUES=16 HSA_ENABLE_IPC_MODE_LEGACY=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench.log 2>&1
 cd $R && python3 - <<'PY'
 import csv, glob, os

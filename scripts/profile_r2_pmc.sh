@@ -6,6 +6,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_r2_pmc
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# read by the HIP runtime when rocprofv3's preloaded library initialises it, i.e. before python starts
+export GPU_MAX_HW_QUEUES=16 HSA_ENABLE_IPC_MODE_LEGACY=0
 rocprofv3 --list-avail > $OUT/list_avail.txt 2>&1
 export OCHIP_PIPELINE_OVERLAP=0 OCHIP_EXTRACT_STREAMS=1 OCHIP_LINK_RUNNERS=1
 i=0

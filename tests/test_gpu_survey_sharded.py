@@ -1,0 +1,47 @@
+"""ONE survey over 2 ranks from pixels (BASELINE config C4): extraction by image block, links by
+owning rank, two all-gathers, sharded relax - everything equal to the single-process run bit for bit; and bench.py's
+launcher + strong mode (`bench.py --gpus 2 --scaling strong`) end to end on the 200-image grid."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_worker(grid, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "sharded_survey_worker.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="8", SHARD_TEST_GRID=grid)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "SHARDED_SURVEY OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_two_ranks_one_survey_from_pixels():
+    _run_worker("4x6", 29551)
+
+
+def test_two_ranks_one_survey_uneven_blocks():
+    _run_worker("3x5", 29553)     # 15 images: blocks of 8 and 7, a block border inside a strip
+
+
+@pytest.mark.parametrize("relax", ["pipelined", "sharded"])
+def test_bench_launches_its_ranks_strong(relax):
+    """`bench.py --gpus 2` with no launcher around it starts two ranks (gloo, sharing the GPU) and prints one line."""
+    env = dict(os.environ, OCHIP_BENCH_BACKEND="gloo", OCHIP_HOST_THREADS="8")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong", "--relax", relax, "--config", "C2",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    ss = line["strong_scaling"]
+    assert len(ss["seconds_per_step_per_rank"]) == 2 and ss["bytes_gathered_per_step"] > 0
+    assert line["relax"]["median_orientation_error_rad_vs_truth"] < 1e-3

@@ -83,3 +83,34 @@ def test_blocks_partition_the_sources():
     parts = [parallel.shard_pairs(pairs, grid.n_images, r, 4) for r in range(4)]
     assert sorted(p for part in parts for p in part) == sorted(pairs)
     assert sum(len(p) for p in parts) == len(pairs)
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    stats = {}
+    mine = (np.arange(1000 * (rank + 1) + 3 * rank) % 251).astype(np.uint8)   # ragged sizes, not multiples of 8
+    parts = parallel.all_gather_bytes(mine, stats=stats)
+    empty = parallel.all_gather_bytes(np.zeros(0, np.uint8))
+    if rank == 1:
+        q.put(([p.tobytes() for p in parts], [len(e) for e in empty], stats, [p.ctypes.data % 8 for p in parts]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_bytes_ragged():
+    """The byte transport of the sharded survey (parallel.all_gather_bytes): ragged buffers, 8-byte aligned slices."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    parts, empty, stats, align = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for r in range(3):
+        assert parts[r] == (np.arange(1000 * (r + 1) + 3 * r) % 251).astype(np.uint8).tobytes()
+    assert empty == [0, 0, 0] and align == [0, 0, 0]
+    assert stats == {"exchanges": 1, "bytes_gathered": sum(1000 * (r + 1) + 3 * r for r in range(3))}
