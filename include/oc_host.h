@@ -202,6 +202,14 @@ extern "C"
     int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
                         const och_surface *previous, och_surface *surface_out, double *summary_out);
 
+    /* The same with the evaluation of the residual blocks sharded over `world` ranks (one process per GPU, each holding the
+     * same graph edges): the single global group of the reference's FINAL_GLOBAL_RELAX ({ORIENTATION, GROUND_MESH},
+     * src/pipeline/pipeline.cpp:645-664) and the plane flavour alike; `exchange` as for
+     * och_graph_relax_ground_plane_sharded.  Bit-identical to the unsharded call on every rank. */
+    int och_graph_relax_sharded(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
+                                const och_surface *previous, och_surface *surface_out, double *summary_out, uint32_t rank,
+                                uint32_t world, ochip_relax_exchange_fn exchange, void *user);
+
     /* RelaxStage (src/pipeline/relax_stage.cpp): init (partition into floor(n / 50) groups - 150 with free intrinsics -
      * by spectral clustering of the link graph, or one group with two rings of context cameras when disable_parallelism),
      * the groups' runners (concurrently, on sibling device contexts), finalize (write-back + merged surface).
@@ -212,6 +220,22 @@ extern "C"
                             int disable_parallelism, uint32_t options, double grid_fraction, size_t max_groups,
                             const och_surface *previous, och_surface *surface_out, int64_t *group_of_node,
                             double *summary_out);
+    /* The same stage in steps, for the groups of one survey over `world` ranks (one process per GPU, the same graph on every
+     * rank): groups are independent during their solves (src/pipeline/relax_stage.cpp:95-111), rank r runs groups
+     * r, r + world, ... of the largest-first list and nothing is exchanged inside a solve.  begin = init (+ trim_groups);
+     * run_groups = this rank's runners; export -> all-gather -> import (once per other rank's buffer) moves the groups'
+     * results (orientations, camera models, surfaces); end = finalize (write-back and mergeSurfaceModels - the
+     * point-count-weighted vertex mean of src/surface/refine_mesh.cpp:931-1010 - over ALL groups in group order, so the
+     * result is the single-process one) and destroys the handle.  och_relax_stage_run is begin + run_groups(0, 1) + end. */
+    typedef struct och_relax_stage och_relax_stage;
+    och_relax_stage *och_relax_stage_begin(och_graph *g, const uint64_t *node_ids, size_t n_ids, int relax_all,
+                                           int disable_parallelism, uint32_t options, double grid_fraction, size_t max_groups,
+                                           const och_surface *previous, int64_t *group_of_node);
+    size_t och_relax_stage_num_groups(const och_relax_stage *st);
+    int och_relax_stage_run_groups(och_relax_stage *st, ochip_ctx *ctx, uint32_t rank, uint32_t world);
+    int och_relax_stage_export(och_relax_stage *st, uint32_t rank, uint32_t world, const void **buf, uint64_t *bytes);
+    int och_relax_stage_import(och_relax_stage *st, const void *buf, uint64_t bytes);
+    int och_relax_stage_end(och_relax_stage *st, och_surface *surface_out, double *summary_out);
     /* the partition alone (no device): group_of_node as above, position_in_group (may be NULL) the node's place in its
      * group's list; returns the number of groups */
     size_t och_relax_partition(const och_graph *g, size_t num_groups, int64_t *group_of_node, int64_t *position_in_group);

@@ -362,8 +362,8 @@ int och_relax(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const doub
     return 0;
 }
 
-int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
-                    const och_surface *previous, och_surface *surface_out, double *summary_out)
+static int graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
+                       const och_surface *previous, och_surface *surface_out, double *summary_out, const RelaxShard *shard)
 {
     auto &nodes = g->graph.nodes();
     std::vector<NodePose> poses(nodes.size());
@@ -392,7 +392,7 @@ int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t op
     RelaxTimers t;
     RelaxMeshStats st;
     surface_model out;
-    if (!relax(ctx, g->graph, poses, cam_models, opt, cfg, prev, &out, &t, &st, &g->error))
+    if (!relax(ctx, g->graph, poses, cam_models, opt, cfg, prev, &out, &t, &st, &g->error, shard))
         return -1;
     for (size_t i = 0; i < nodes.size(); i++)
     {
@@ -405,12 +405,42 @@ int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t op
     return 0;
 }
 
-
-int och_relax_stage_run(och_graph *g, ochip_ctx *ctx, const uint64_t *node_ids, size_t n_ids, int relax_all,
-                        int disable_parallelism, uint32_t options, double grid_fraction, size_t max_groups,
-                        const och_surface *previous, och_surface *surface_out, int64_t *group_of_node, double *summary_out)
+int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
+                    const och_surface *previous, och_surface *surface_out, double *summary_out)
 {
+    return graph_relax(g, ctx, ori_inout, options, grid_fraction, previous, surface_out, summary_out, nullptr);
+}
+
+int och_graph_relax_sharded(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
+                            const och_surface *previous, och_surface *surface_out, double *summary_out, uint32_t rank,
+                            uint32_t world, ochip_relax_exchange_fn exchange, void *user)
+{
+    RelaxShard shard;
+    shard.rank = rank;
+    shard.world = world;
+    shard.exchange = exchange;
+    shard.user = user;
+    return graph_relax(g, ctx, ori_inout, options, grid_fraction, previous, surface_out, summary_out, &shard);
+}
+
+
+struct och_relax_stage
+{
+    och_graph *g = nullptr;
     RelaxStage stage;
+    size_t n_groups = 0;
+    std::vector<uint8_t> buf;
+};
+
+och_relax_stage *och_relax_stage_begin(och_graph *g, const uint64_t *node_ids, size_t n_ids, int relax_all, int disable_parallelism,
+                                       uint32_t options, double grid_fraction, size_t max_groups, const och_surface *previous,
+                                       int64_t *group_of_node)
+{
+    auto *st = new (std::nothrow) och_relax_stage();
+    if (!st)
+        return nullptr;
+    st->g = g;
+    RelaxStage &stage = st->stage;
     RelaxConfig cfg;
     cfg.options = options;
     cfg.ground_mesh_grid_fraction = grid_fraction;
@@ -429,26 +459,79 @@ int och_relax_stage_run(och_graph *g, ochip_ctx *ctx, const uint64_t *node_ids, 
     }
     if (previous)
         stage.setSurfaceModels({previous->s});
-    const size_t n_groups = stage.num_groups();
-    auto runners = stage.get_runners(ctx, g->graph);
+    st->n_groups = stage.num_groups();
+    return st;
+}
+
+size_t och_relax_stage_num_groups(const och_relax_stage *st)
+{
+    return st->n_groups;
+}
+
+int och_relax_stage_run_groups(och_relax_stage *st, ochip_ctx *ctx, uint32_t rank, uint32_t world)
+{
+    auto runners = st->stage.get_runners(ctx, st->g->graph, rank, std::max<uint32_t>(world, 1));
     run_parallel(runners);
+    return 0;
+}
+
+int och_relax_stage_export(och_relax_stage *st, uint32_t rank, uint32_t world, const void **buf, uint64_t *bytes)
+{
+    st->buf.clear();
+    st->stage.export_results(rank, std::max<uint32_t>(world, 1), st->buf);
+    *buf = st->buf.data();
+    *bytes = st->buf.size();
+    return 0;
+}
+
+int och_relax_stage_import(och_relax_stage *st, const void *buf, uint64_t bytes)
+{
+    if (!st->stage.import_results((const uint8_t *)buf, bytes))
+    {
+        st->g->error = st->stage.error();
+        return -1;
+    }
+    return 0;
+}
+
+int och_relax_stage_end(och_relax_stage *st, och_surface *surface_out, double *summary_out)
+{
+    och_graph *g = st->g;
+    RelaxStage &stage = st->stage;
     stage.finalize(g->graph);
+    int rc = 0;
     if (!stage.error().empty())
     {
         g->error = stage.error();
+        rc = -1;
+    }
+    else
+    {
+        if (surface_out)
+        {
+            const auto &s = stage.getSurfaceModels();
+            surface_out->s = s.empty() ? surface_model() : s[0];
+        }
+        if (summary_out)
+        {
+            fill_summary12(stage.timers, stage.stats, summary_out);
+            summary_out[12] = (double)st->n_groups;
+        }
+    }
+    delete st;
+    return rc;
+}
+
+int och_relax_stage_run(och_graph *g, ochip_ctx *ctx, const uint64_t *node_ids, size_t n_ids, int relax_all,
+                        int disable_parallelism, uint32_t options, double grid_fraction, size_t max_groups,
+                        const och_surface *previous, och_surface *surface_out, int64_t *group_of_node, double *summary_out)
+{
+    och_relax_stage *st = och_relax_stage_begin(g, node_ids, n_ids, relax_all, disable_parallelism, options, grid_fraction,
+                                                max_groups, previous, group_of_node);
+    if (!st)
         return -1;
-    }
-    if (surface_out)
-    {
-        const auto &s = stage.getSurfaceModels();
-        surface_out->s = s.empty() ? surface_model() : s[0];
-    }
-    if (summary_out)
-    {
-        fill_summary12(stage.timers, stage.stats, summary_out);
-        summary_out[12] = (double)n_groups;
-    }
-    return 0;
+    och_relax_stage_run_groups(st, ctx, 0, 1);
+    return och_relax_stage_end(st, surface_out, summary_out);
 }
 
 size_t och_relax_partition(const och_graph *g, size_t num_groups, int64_t *group_of_node, int64_t *position_in_group)

@@ -368,7 +368,8 @@ class GroundMeshProblem
     // setupGroundMeshProblem (relax_problem.cpp:83-120)
     bool setup(std::vector<NodePose> &poses, std::vector<std::pair<size_t, CameraModel>> &cam_models,
                const std::vector<size_t> &edges_to_optimize, const RelaxConfig &config,
-               const std::vector<surface_model> &previous, RelaxMeshStats *stats, std::string *error)
+               const std::vector<surface_model> &previous, RelaxMeshStats *stats, std::string *error,
+               const RelaxShard *shard = nullptr)
     {
         const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
         auto tmark = clk::now();
@@ -538,9 +539,20 @@ class GroundMeshProblem
             *error = "relax: the device path optimises one shared lens model per group; this group holds images of several";
             return false;
         }
+        const bool sharded = shard && (shard->world > 1 || shard->exchange);
+        if (sharded)
+        {
+            d.shard_rank = shard->rank;
+            d.shard_world = shard->world;
+        }
         if (ochip_relaxg_problem_create(_ctx, &d, &_dev) != OCHIP_OK)
         {
             *error = std::string("ochip_relaxg_problem_create: ") + ochip_last_error(_ctx);
+            return false;
+        }
+        if (sharded && ochip_relaxg_set_exchange(_dev, shard->exchange, shard->user) != OCHIP_OK)
+        {
+            *error = std::string("ochip_relaxg_set_exchange: ") + ochip_last_error(_ctx);
             return false;
         }
         lap("ochip_relaxg_problem_create");
@@ -1218,13 +1230,13 @@ class GroundMeshProblem
 bool relax(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,
            std::vector<std::pair<size_t, CameraModel>> &cam_models, const std::vector<size_t> &edges_to_optimize,
            const RelaxConfig &config, const std::vector<surface_model> &previous, surface_model *surface, RelaxTimers *timers,
-           RelaxMeshStats *stats, std::string *error)
+           RelaxMeshStats *stats, std::string *error, const RelaxShard *shard)
 {
     if (config.options & OPT_GROUND_MESH) // runGroundMesh (relax.cpp:89-102)
     {
         auto t0 = clk::now();
         GroundMeshProblem rp(ctx, graph);
-        if (!rp.setup(nodes, cam_models, edges_to_optimize, config, previous, stats, error))
+        if (!rp.setup(nodes, cam_models, edges_to_optimize, config, previous, stats, error, shard))
             return false;
         if (timers)
             timers->setup_host += since(t0);
@@ -1246,7 +1258,7 @@ bool relax(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> 
     if (config.options & OPT_GROUND_PLANE) // runGroundPlane (relax.cpp:44-87)
     {
         surface_model_plane plane;
-        if (!relax_ground_plane(ctx, graph, nodes, edges_to_optimize, &plane, timers, error))
+        if (!relax_ground_plane(ctx, graph, nodes, edges_to_optimize, &plane, timers, error, shard))
             return false;
         if (surface)
         {

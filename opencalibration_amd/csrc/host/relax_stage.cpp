@@ -829,6 +829,186 @@ void RelaxStage::trim_groups(size_t max_size)
 
 std::vector<std::function<void()>> RelaxStage::get_runners(ochip_ctx *ctx, const MeasurementGraph &graph)
 {
+    return get_runners(ctx, graph, 0, 1);
+}
+
+// ---- results as bytes ------------------------------------------------------------------------------------------------
+namespace
+{
+template <typename T> void put(std::vector<uint8_t> &out, const T &v)
+{
+    const uint8_t *b = reinterpret_cast<const uint8_t *>(&v);
+    out.insert(out.end(), b, b + sizeof(T));
+}
+template <typename T> bool get(const uint8_t *&p, const uint8_t *end, T *v)
+{
+    if ((size_t)(end - p) < sizeof(T))
+        return false;
+    std::memcpy(v, p, sizeof(T));
+    p += sizeof(T);
+    return true;
+}
+void put_surface(std::vector<uint8_t> &out, const surface_model &s)
+{
+    put<uint64_t>(out, s.mesh.nodes.size());
+    for (const MeshNode &n : s.mesh.nodes)
+        put(out, n);
+    put<uint64_t>(out, s.mesh.edges.size());
+    for (const MeshEdge &e : s.mesh.edges)
+    {
+        const uint64_t v[5] = {e.source, e.dest, e.border ? 1u : 0u, e.triangleOppositeNodes[0], e.triangleOppositeNodes[1]};
+        put(out, v);
+    }
+    for (const auto &list : s.mesh.node_edges) // (the order of a vertex's edges is state of its own, relax_mesh.hpp)
+    {
+        put<uint64_t>(out, list.size());
+        for (size_t e : list)
+            put<uint64_t>(out, e);
+    }
+    put<uint64_t>(out, s.cloud.size());
+    for (const point_cloud &c : s.cloud)
+    {
+        put<uint64_t>(out, c.size());
+        for (const auto &pt : c)
+            put(out, pt);
+    }
+}
+bool get_surface(const uint8_t *&p, const uint8_t *end, surface_model *s)
+{
+    *s = surface_model();
+    uint64_t n = 0;
+    if (!get(p, end, &n) || n > (uint64_t)(end - p))
+        return false;
+    s->mesh.nodes.resize(n);
+    for (MeshNode &nd : s->mesh.nodes)
+        if (!get(p, end, &nd))
+            return false;
+    uint64_t ne = 0;
+    if (!get(p, end, &ne) || ne > (uint64_t)(end - p))
+        return false;
+    s->mesh.edges.resize(ne);
+    for (MeshEdge &e : s->mesh.edges)
+    {
+        uint64_t v[5];
+        if (!get(p, end, &v))
+            return false;
+        e.source = v[0], e.dest = v[1], e.border = v[2] != 0, e.triangleOppositeNodes[0] = v[3], e.triangleOppositeNodes[1] = v[4];
+    }
+    s->mesh.node_edges.resize(n);
+    for (auto &list : s->mesh.node_edges)
+    {
+        uint64_t k = 0;
+        if (!get(p, end, &k) || k > (uint64_t)(end - p))
+            return false;
+        list.resize(k);
+        for (size_t &e : list)
+        {
+            uint64_t v = 0;
+            if (!get(p, end, &v))
+                return false;
+            e = v;
+        }
+    }
+    s->mesh.rebuild_lookup();
+    uint64_t nc = 0;
+    if (!get(p, end, &nc) || nc > (uint64_t)(end - p))
+        return false;
+    s->cloud.resize(nc);
+    for (point_cloud &c : s->cloud)
+    {
+        uint64_t k = 0;
+        if (!get(p, end, &k) || k > (uint64_t)(end - p))
+            return false;
+        c.resize(k);
+        for (auto &pt : c)
+            if (!get(p, end, &pt))
+                return false;
+    }
+    return true;
+}
+} // namespace
+
+void RelaxGroup::export_result(std::vector<uint8_t> &out) const
+{
+    put<uint64_t>(out, _local_poses.size());
+    for (const NodePose &pose : _local_poses)
+    {
+        put<uint64_t>(out, pose.node_id);
+        put(out, pose.orientation);
+    }
+    put<uint64_t>(out, _camera_models.size());
+    for (const auto &m : _camera_models)
+    {
+        put<uint64_t>(out, m.first);
+        const CameraModel &c = m.second;
+        const double v[8] = {c.focal_length_pixels,  c.principle_point[0],   c.principle_point[1],      c.radial_distortion[0],
+                             c.radial_distortion[1], c.radial_distortion[2], c.tangential_distortion[0], c.tangential_distortion[1]};
+        put(out, v);
+    }
+}
+
+bool RelaxGroup::import_result(const uint8_t *&p, const uint8_t *end)
+{
+    uint64_t n = 0;
+    if (!get(p, end, &n) || n != _local_poses.size())
+        return false;
+    for (NodePose &pose : _local_poses)
+    {
+        uint64_t id = 0;
+        if (!get(p, end, &id) || id != pose.node_id || !get(p, end, &pose.orientation))
+            return false;
+    }
+    if (!get(p, end, &n) || n != _camera_models.size())
+        return false;
+    for (auto &m : _camera_models)
+    {
+        uint64_t id = 0;
+        double v[8];
+        if (!get(p, end, &id) || id != m.first || !get(p, end, &v))
+            return false;
+        CameraModel &c = m.second;
+        c.focal_length_pixels = v[0];
+        c.principle_point[0] = v[1], c.principle_point[1] = v[2];
+        c.radial_distortion[0] = v[3], c.radial_distortion[1] = v[4], c.radial_distortion[2] = v[5];
+        c.tangential_distortion[0] = v[6], c.tangential_distortion[1] = v[7];
+    }
+    return true;
+}
+
+void RelaxStage::export_results(size_t rank, size_t world, std::vector<uint8_t> &out) const
+{
+    for (size_t i = rank; i < _groups.size(); i += world)
+    {
+        put<uint64_t>(out, i);
+        _groups[i].export_result(out);
+        put_surface(out, _surface_models[i]);
+        put(out, _group_timers[i]);
+        put(out, _group_stats[i]);
+        put<uint64_t>(out, _group_errors[i].size());
+        out.insert(out.end(), _group_errors[i].begin(), _group_errors[i].end());
+    }
+}
+
+bool RelaxStage::import_results(const uint8_t *p, size_t bytes)
+{
+    const uint8_t *end = p + bytes;
+    while (p < end)
+    {
+        uint64_t i = 0, elen = 0;
+        if (!get(p, end, &i) || i >= _groups.size() || !_groups[i].import_result(p, end) || !get_surface(p, end, &_surface_models[i]) ||
+            !get(p, end, &_group_timers[i]) || !get(p, end, &_group_stats[i]) || !get(p, end, &elen) || elen > (uint64_t)(end - p))
+        {
+            _error = "relax stage: malformed group results";
+            return false;
+        }
+        _group_errors[i].assign(reinterpret_cast<const char *>(p), elen);
+        p += elen;
+    }
+    return true;
+}
+
+std::vector<std::function<void()>> RelaxStage::get_runners(ochip_ctx *ctx, const MeasurementGraph &graph, size_t rank, size_t world)
+{
     std::swap(_surface_models, _previous_surface_models);
     _surface_models.clear();
     _surface_models.resize(_groups.size());
@@ -854,14 +1034,15 @@ std::vector<std::function<void()>> RelaxStage::get_runners(ochip_ctx *ctx, const
             contexts[r] = nullptr;
         }
     std::vector<std::function<void()>> funcs;
-    for (size_t i = 0; i < _groups.size(); i++)
-        funcs.push_back([this, i, R, c = contexts[i % R], sibling_error, &graph]() {
+    world = std::max<size_t>(world, 1);
+    for (size_t i = rank; i < _groups.size(); i += world)
+        funcs.push_back([this, i, R, world, c = contexts[(i / world) % R], sibling_error, &graph]() {
             if (!c)
             {
                 _group_errors[i] = sibling_error;
                 return;
             }
-            std::lock_guard<std::mutex> lock(*_ctx_mutex[i % R]);
+            std::lock_guard<std::mutex> lock(*_ctx_mutex[(i / world) % R]);
             _groups[i].run(c, graph, _previous_surface_models, &_surface_models[i], &_group_timers[i], &_group_stats[i],
                            &_group_errors[i]);
         });

@@ -30,6 +30,9 @@ class RelaxGroup // include/opencalibration/relax/relax_group.hpp
     {
         return _local_poses;
     }
+    // what run() changed - the poses' orientations and the camera models - as bytes, and back (groups over ranks)
+    void export_result(std::vector<uint8_t> &out) const;
+    bool import_result(const uint8_t *&p, const uint8_t *end);
     const std::vector<size_t> &edges_to_optimize() const
     {
         return _edges_to_optimize;
@@ -64,6 +67,17 @@ class RelaxStage // src/pipeline/relax_stage.hpp
     // one runner per group; a runner returns nothing, errors are collected in error()
     std::vector<std::function<void()>> get_runners(ochip_ctx *ctx, const MeasurementGraph &graph);
     std::vector<std::vector<size_t>> finalize(MeasurementGraph &graph);
+    // ---- the groups over `world` ranks (one process per GPU, every rank holding the same graph and having made the same
+    //      init / trim_groups calls): groups are independent during the solve (relax_stage.cpp:95-111), so rank r runs
+    //      groups r, r + world, ... of the largest-first list and no exchange happens inside a
+    //      solve.  get_runners(ctx, graph, rank, world) returns this rank's runners; export_results() packs what they
+    //      produced (orientations, camera models, the group's surface, its counters); every rank imports the other
+    //      ranks' buffers and calls finalize(), which then writes back and merges exactly what a single process would:
+    //      the weighted vertex mean of mergeSurfaceModels (refine_mesh.cpp:931-1010) runs over all groups' surfaces in
+    //      group order on every rank, so the result does not depend on the number of ranks.
+    std::vector<std::function<void()>> get_runners(ochip_ctx *ctx, const MeasurementGraph &graph, size_t rank, size_t world);
+    void export_results(size_t rank, size_t world, std::vector<uint8_t> &out) const;
+    bool import_results(const uint8_t *buf, size_t bytes);
     const std::vector<surface_model> &getSurfaceModels() const
     {
         return _surface_models;

@@ -114,8 +114,17 @@ def load():
         L.och_relax.argtypes = [vp, sz, _f64p, _f64p, _f64p, _u64p, _f64p, sz, _u64p, _f64p, sz, _u64p, _u64p, vp, u8p, _u64p,
                                 _f64p, _u64p, _u64p, vp, vp, sz, _u64p, u32, C.c_double, vp, vp, _f64p, vp]
         L.och_graph_relax.argtypes = [vp, vp, _f64p, u32, C.c_double, vp, vp, _f64p]
+        L.och_graph_relax_sharded.argtypes = [vp, vp, _f64p, u32, C.c_double, vp, vp, _f64p, u32, u32, vp, vp]
         i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
         L.och_relax_stage_run.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, u32, C.c_double, sz, vp, vp, i64p, _f64p]
+        L.och_relax_stage_begin.restype = vp
+        L.och_relax_stage_begin.argtypes = [vp, vp, sz, C.c_int, C.c_int, u32, C.c_double, sz, vp, i64p]
+        L.och_relax_stage_num_groups.argtypes = [vp]
+        L.och_relax_stage_num_groups.restype = sz
+        L.och_relax_stage_run_groups.argtypes = [vp, vp, u32, u32]
+        L.och_relax_stage_export.argtypes = [vp, u32, u32, C.POINTER(vp), C.POINTER(u64)]
+        L.och_relax_stage_import.argtypes = [vp, vp, u64]
+        L.och_relax_stage_end.argtypes = [vp, vp, _f64p]
         L.och_relax_partition.restype = sz
         L.och_relax_partition.argtypes = [vp, sz, i64p, i64p]
         L.och_merge_surfaces.argtypes = [C.POINTER(vp), sz, vp]
@@ -708,13 +717,23 @@ class Graph:
         out.update(orientation=ori, plane=plane.reshape(3, 3))
         return out
 
-    def relax(self, ctx, orientations, options, grid_fraction=0.1, previous=None):
-        """All nodes as one relax group, every edge whitelisted, any flavour (options: relax_options(...))."""
+    def relax(self, ctx, orientations, options, grid_fraction=0.1, previous=None, shard=None):
+        """All nodes as one relax group, every edge whitelisted, any flavour (options: relax_options(...)).
+        shard = (rank, world, exchange) as for relax_ground_plane: the residual blocks' evaluation over the ranks."""
         ori = np.ascontiguousarray(orientations, np.float64).copy()
         summary = np.zeros(12)
         surface = Surface()
-        rc = self.L.och_graph_relax(self.h, ctx.h, ori, options, grid_fraction, previous.h if previous is not None else None,
-                                    surface.h, summary)
+        prev = previous.h if previous is not None else None
+        if shard is None:
+            rc = self.L.och_graph_relax(self.h, ctx.h, ori, options, grid_fraction, prev, surface.h, summary)
+        else:
+            rank, world, exchange = shard
+            if isinstance(exchange, capi.RcclComm):
+                fn, user = exchange.exchange
+            else:
+                fn, user = C.cast(exchange, C.c_void_p).value, None
+            rc = self.L.och_graph_relax_sharded(self.h, ctx.h, ori, options, grid_fraction, prev, surface.h, summary, rank, world,
+                                                fn, user)
         if rc != 0:
             raise capi.OchipError("relax failed: " + self.L.och_last_error(self.h).decode())
         out = dict(zip(RELAX_SUMMARY12, summary.tolist()))
@@ -722,16 +741,37 @@ class Graph:
         return out
 
     def relax_stage(self, ctx, options, grid_fraction=0.1, node_ids=None, disable_parallelism=False, max_groups=0,
-                    previous=None):
+                    previous=None, shard=None):
         """RelaxStage::init + runners + finalize (relax_stage.cpp): node_ids None = relax_all.  Returns the summary, the
-        merged surface, the graph's orientations afterwards and the group of every node (-1: not a primary node)."""
+        merged surface, the graph's orientations afterwards and the group of every node (-1: not a primary node).
+        shard = (rank, world, all_gather): this rank runs groups rank, rank + world, ... and all_gather(bytes) -> list of
+        every rank's bytes (parallel.all_gather_bytes) carries the groups' results; every rank ends with the
+        single-process result."""
         ids = None if node_ids is None else np.ascontiguousarray(node_ids, np.uint64)
         summary = np.zeros(13)
         groups = np.full(max(self.num_nodes, 1), -1, np.int64)
         surface = Surface()
-        rc = self.L.och_relax_stage_run(self.h, ctx.h, None if ids is None else ids.ctypes.data, 0 if ids is None else len(ids),
-                                        int(ids is None), int(disable_parallelism), options, grid_fraction, max_groups,
-                                        previous.h if previous is not None else None, surface.h, groups, summary)
+        if shard is None:
+            rc = self.L.och_relax_stage_run(self.h, ctx.h, None if ids is None else ids.ctypes.data, 0 if ids is None else len(ids),
+                                            int(ids is None), int(disable_parallelism), options, grid_fraction, max_groups,
+                                            previous.h if previous is not None else None, surface.h, groups, summary)
+        else:
+            rank, world, all_gather = shard
+            st = self.L.och_relax_stage_begin(self.h, None if ids is None else ids.ctypes.data, 0 if ids is None else len(ids),
+                                              int(ids is None), int(disable_parallelism), options, grid_fraction, max_groups,
+                                              previous.h if previous is not None else None, groups)
+            if not st:
+                raise MemoryError("och_relax_stage_begin")
+            self.L.och_relax_stage_run_groups(st, ctx.h, rank, world)
+            ptr, n = C.c_void_p(0), C.c_uint64(0)
+            self.L.och_relax_stage_export(st, rank, world, C.byref(ptr), C.byref(n))
+            mine = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n.value,)) if n.value else np.zeros(0, np.uint8)
+            rc = 0
+            for r, part in enumerate(all_gather(mine)):
+                if r != rank and len(part):
+                    part = np.ascontiguousarray(part, np.uint8)
+                    rc = rc or self.L.och_relax_stage_import(st, part.ctypes.data, len(part))
+            rc = self.L.och_relax_stage_end(st, surface.h, summary) or rc
         if rc != 0:
             raise capi.OchipError("relax stage failed: " + self.L.och_last_error(self.h).decode())
         out = dict(zip(RELAX_SUMMARY12 + ["groups"], summary.tolist()))
