@@ -183,6 +183,8 @@ extern "C"
     void och_surface_get(const och_surface *s, double *vertices, uint64_t *edges5, double *cloud);
     void och_surface_set(och_surface *s, size_t n_vertices, const double *vertices, size_t n_edges, const uint64_t *edges5,
                          size_t n_cloud, const double *cloud);
+    /* new heights for the mesh vertices (n_vertices doubles); topology and the order of the mesh's containers stay */
+    void och_surface_set_heights(och_surface *s, const double *z);
     /* rebuildMesh / buildMinimalMesh (src/surface/expand_mesh.cpp) from camera positions and an optional previous surface */
     void och_rebuild_mesh(const double *cam_xyz, size_t n, const och_surface *previous, int minimal, och_surface *out);
     /* Stand-alone problem from flat arrays, as och_relax_ground_plane plus what the mesh flavour reads: per node its

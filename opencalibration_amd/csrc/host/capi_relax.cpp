@@ -244,6 +244,11 @@ void och_surface_set(och_surface *s, size_t n_vertices, const double *vertices, 
         s->s.cloud.push_back(std::move(c));
     }
 }
+void och_surface_set_heights(och_surface *s, const double *z)
+{
+    for (size_t i = 0; i < s->s.mesh.nodes.size(); i++)
+        s->s.mesh.nodes[i].location[2] = z[i];
+}
 void och_rebuild_mesh(const double *cam_xyz, size_t n, const och_surface *previous, int minimal, och_surface *out)
 {
     point_cloud cams(n);

@@ -109,6 +109,8 @@ def load():
         L.och_surface_get.restype = None
         L.och_surface_set.argtypes = [vp, sz, _f64p, sz, _u64p, sz, _f64p]
         L.och_surface_set.restype = None
+        L.och_surface_set_heights.argtypes = [vp, _f64p]
+        L.och_surface_set_heights.restype = None
         L.och_rebuild_mesh.argtypes = [_f64p, sz, vp, C.c_int, vp]
         L.och_rebuild_mesh.restype = None
         L.och_relax.argtypes = [vp, sz, _f64p, _f64p, _f64p, _u64p, _f64p, sz, _u64p, _f64p, sz, _u64p, _u64p, vp, u8p, _u64p,
@@ -304,6 +306,11 @@ class Surface:
                                pad(c, (1, 3), np.float64))
         return self
 
+
+    def set_heights(self, z):
+        """New vertex heights; the mesh's topology and container orders stay (what a relax does to a mesh)."""
+        self.L.och_surface_set_heights(self.h, np.ascontiguousarray(z, np.float64))
+        return self
 
     def clouds(self):
         """The surface's point clouds one by one (arrays() concatenates them)."""

@@ -703,3 +703,67 @@ def kmeans3(xyz, k, iterations, use_ref=False):
     fn.argtypes = [f64p, C.c_size_t, C.c_size_t, C.c_int, u64p, f64p, u64p]
     fn(xyz, len(xyz), k, iterations, a, c, s)
     return a, c, s
+
+
+class RxMesh:
+    """The reference's mesh refinement restated a second time (oracle/refine_mesh.cpp, from src/surface/refine_mesh.cpp): a
+    mesh held in an emulation of the reference's graph container, so that its iteration orders - which the refinement's
+    choices depend on - persist from one refinement to the next.  Vertices are numbered in creation order."""
+
+    NONE = np.iinfo(np.uint64).max
+
+    def __init__(self, vertices, edges5):
+        L = lib()
+        L.ocx_rmesh_create.restype = C.c_void_p
+        L.ocx_rmesh_create.argtypes = [f64p, C.c_size_t, u64p, C.c_size_t]
+        L.ocx_rmesh_destroy.argtypes = [C.c_void_p]
+        L.ocx_rmesh_counts.argtypes = [C.c_void_p, u64p, u64p]
+        L.ocx_rmesh_get.argtypes = [C.c_void_p, f64p, u64p]
+        L.ocx_rmesh_set_heights.argtypes = [C.c_void_p, f64p]
+        L.ocx_rmesh_count_points.restype = C.c_size_t
+        L.ocx_rmesh_count_points.argtypes = [C.c_void_p, C.c_size_t, u64p, f64p, u64p, f64p, C.c_size_t]
+        L.ocx_rmesh_refine_by_point_density.restype = C.c_size_t
+        L.ocx_rmesh_refine_by_point_density.argtypes = [C.c_void_p, C.c_size_t, u64p, f64p, C.c_size_t, C.c_double, C.c_int, C.c_double]
+        L.ocx_rmesh_refine_at_point.restype = C.c_size_t
+        L.ocx_rmesh_refine_at_point.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+        self.L = L
+        v = np.ascontiguousarray(vertices, np.float64).reshape(-1, 3)
+        e = np.ascontiguousarray(edges5, np.uint64).reshape(-1, 5)
+        self.h = L.ocx_rmesh_create(v if len(v) else np.zeros((1, 3)), len(v), e if len(e) else np.zeros((1, 5), np.uint64), len(e))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ocx_rmesh_destroy(self.h)
+            self.h = None
+
+    def arrays(self):
+        nv, ne = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        self.L.ocx_rmesh_counts(self.h, nv, ne)
+        v, e = np.zeros((max(int(nv[0]), 1), 3)), np.zeros((max(int(ne[0]), 1), 5), np.uint64)
+        self.L.ocx_rmesh_get(self.h, v, e)
+        return v[:int(nv[0])], e[:int(ne[0])]
+
+    def set_heights(self, z):
+        self.L.ocx_rmesh_set_heights(self.h, np.ascontiguousarray(z, np.float64))
+
+    @staticmethod
+    def _clouds(clouds):
+        sizes = np.array([len(c) for c in clouds] or [0], np.uint64)
+        xyz = np.ascontiguousarray(np.concatenate([np.asarray(c, np.float64).reshape(-1, 3) for c in clouds])
+                                   if len(clouds) and sizes.sum() else np.zeros((1, 3)))
+        return len(clouds), sizes, xyz
+
+    def count_points_per_triangle(self, clouds):
+        n, sizes, xyz = self._clouds(clouds)
+        cap = 2 * max(len(self.arrays()[1]), 1)
+        tri, st = np.zeros((cap, 3), np.uint64), np.zeros((cap, 2))
+        k = self.L.ocx_rmesh_count_points(self.h, n, sizes, xyz, tri, st, cap)
+        return tri[:k], st[:k, 0].astype(np.int64), st[:k, 1]
+
+    def refine_by_point_density(self, clouds, max_points_per_triangle, min_distance_variance=0.0, max_iterations=10, min_triangle_size=0.0):
+        n, sizes, xyz = self._clouds(clouds)
+        return self.L.ocx_rmesh_refine_by_point_density(self.h, n, sizes, xyz, max_points_per_triangle, min_distance_variance,
+                                                        max_iterations, min_triangle_size)
+
+    def refine_at_point(self, x, y, levels=1):
+        return self.L.ocx_rmesh_refine_at_point(self.h, x, y, levels)

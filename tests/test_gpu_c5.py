@@ -1,0 +1,129 @@
+"""BASELINE config C5 at its size: a 5 000-image survey (50 x 100 grid, ~45 000 directed pairs) through the device link
+stage, the plane relax of all cameras (15 003 unknowns), the clustered ground-mesh stage (floor(n / 50) = 100 groups,
+src/pipeline/relax_stage.cpp:49-57), the CAMERA_PARAMETER_RELAX form - floor(n / 150) = 33 clusters trimmed to the largest,
+focal length + principal point + radial distortion free (src/pipeline/pipeline.cpp:601-634) - and the single global
+ground-mesh group of FINAL_GLOBAL_RELAX's last run (:645-664).  Property checks on everything; oracle parity (poses within
+1e-6 rad, focal length within 1e-6 relative) on three sampled groups re-solved stand-alone: two 50-camera groups of the mesh
+flavour and the 150-camera group with free intrinsics."""
+import time
+
+import numpy as np
+import pytest
+
+from opencalibration_amd import capi, host, pipeline, synth
+from oracle import pyoracle as _po
+from relax_fixtures import qangle
+
+pytestmark = pytest.mark.gpu
+
+O_MESH = ("ORIENTATION", "GROUND_MESH")
+O_INTR = O_MESH + ("FOCAL_LENGTH", "PRINCIPAL_POINT", "LENS_DISTORTIONS_RADIAL", "BROWN246")
+
+
+def _subproblem(grid, g, edges_all, index_of, members, ori):
+    """The cameras `members` (node indices) with every linked edge between two of them, as the flat inputs of the
+    stand-alone relax entry points (host.relax, oracle RxGraph.relax)."""
+    local = {int(m): k for k, m in enumerate(members)}
+    edges = []
+    for ed in edges_all:
+        a, b = index_of[ed["source"]], index_of[ed["dest"]]
+        if a in local and b in local and ed["n_inliers"]:
+            edges.append(dict(src=local[a], dst=local[b], H=ed["H"], px=ed["px"], match_index=ed["match_index"], dist=ed["dist"],
+                              f1=ed["f1"], f2=ed["f2"]))
+    feats = [grid.image(int(m))[0] for m in members]
+    pk = _po.pack_edges(edges)
+    pk["feat"] = np.ascontiguousarray(np.concatenate([np.stack([e["f1"], e["f2"]], 1) for e in edges]), np.uint64)
+    return edges, feats, pk
+
+
+def _both(ctx, oracle, grid, members, edges, feats, pk, start, opts, prev_vertices, prev_edges):
+    n = len(members)
+    pos = grid.position[members]
+    rx = oracle.RxGraph()
+    rx.add_model(grid.model, 42)
+    for k in range(n):
+        rx.add_node(pos[k], start[k], 0, feats[k])
+    for e in edges:
+        rx.add_edge(e["src"], e["dst"], e["px"], e["f1"], e["f2"], e["match_index"], e["H"], e["dist"])
+    oprev = oracle.RxSurface().set(prev_vertices, prev_edges)
+    hprev = host.Surface().set(prev_vertices, prev_edges)
+    t0 = time.time()
+    exp = rx.relax(np.arange(n), start, np.arange(len(edges)), oracle.options(*opts), 0.1, oprev)
+    t_cpu = time.time() - t0
+    cm = np.array(grid.model, float)
+    got = host.relax(ctx, pos, start, grid.model, feats, np.arange(n), start, pk, host.relax_options(*opts), 0.1, previous=hprev,
+                     cam_model=cm)
+    assert got["track_blocks"] == exp["track_blocks"] and got["two_ray_blocks"] == exp["two_ray_blocks"]
+    assert got["residual_blocks"] == exp["residual_blocks"] and got["solves"] == exp["solves"]
+    worst = max(qangle(exp["orientation"][i], got["orientation"][i]) for i in range(n))
+    assert worst < 1e-6, worst
+    assert abs(got["iterations_total"] - exp["iterations_total"]) <= 3
+    if "FOCAL_LENGTH" in opts:
+        em, hm = exp["models"][42], got["cam_model"]
+        assert abs(hm[0] - em[0]) < 1e-6 * em[0], (hm[0], em[0])
+        assert np.allclose(hm[1:3], em[1:3], rtol=0, atol=1e-4) and np.allclose(hm[3:8], em[3:8], rtol=1e-6, atol=1e-7)
+        assert 100.0 <= hm[0] <= 20000.0
+    return got, exp, t_cpu
+
+
+def test_c5_survey_at_size(oracle):
+    ctx = capi.Context(0)
+    grid = synth.make_grid(seed=2025, feats=2048, **{k: v for k, v in synth.CONFIGS["C5"].items() if k != "feats"})
+    n = grid.n_images
+    assert n == 5000
+    g = host.Graph.from_synthetic(grid)
+    start = pipeline.perturbed_orientations(grid, 0.1, 7)
+    g.set_orientations(start)
+    g.link(ctx)
+    assert 8 * n < g.num_edges <= 9 * n
+    index_of = {nid: i for i, nid in enumerate(g.node_ids)}
+    # ---- the plane relax of all cameras as one group: 3 n + 3 unknowns
+    plane = g.relax(ctx, start, host.relax_options("ORIENTATION", "GROUND_PLANE"))
+    assert int(plane["residual_blocks"]) > 1_000_000
+    err = pipeline.orientation_errors(plane["orientation"], grid.orientation)
+    assert np.median(err) < 1e-3 and np.sum(err > 0.02) < n // 100
+    seed = host.rebuild_mesh(grid.position, plane["surface"], minimal=True)
+    sa = seed.arrays()
+    ori0 = plane["orientation"]
+    # ---- clustered ground mesh: 100 groups, every camera in exactly one
+    g.set_orientations(ori0)
+    st = g.relax_stage(ctx, host.relax_options(*O_MESH), 0.1, previous=seed)
+    grp = st["group_of_node"]
+    assert int(st["groups"]) == n // 50 == 100 and grp.min() == 0 and grp.max() == 99
+    sizes = np.bincount(grp)
+    assert sizes.sum() == n and sizes.min() >= 5 and np.all(np.diff(sizes) <= 0)      # largest first
+    ori1 = g.orientations().copy()
+    err1 = pipeline.orientation_errors(ori1, grid.orientation)
+    assert np.median(err1) < 1e-3 and np.all(np.isfinite(ori1))
+    mv = st["surface"].arrays()["vertices"]
+    assert len(mv) == len(sa["vertices"]) and np.all(np.isfinite(mv))
+    ground = grid.plane[0] * mv[:, 0] + grid.plane[1] * mv[:, 1]
+    assert np.max(np.abs(mv[:, 2] - ground)) < 2.0                                     # the merged mesh lies on the ground
+    # ---- CAMERA_PARAMETER_RELAX: 33 clusters, trimmed to the largest; intrinsics free
+    g.set_orientations(ori0)
+    ci = g.relax_stage(ctx, host.relax_options(*O_INTR), 0.1, max_groups=1, previous=seed)
+    gi = ci["group_of_node"]
+    assert int(ci["groups"]) == 1 and 150 <= np.sum(gi == 0) and int(ci["unknowns"]) >= 3 * 150 + 4 + 6
+    model_after = g.models()[0]
+    assert 100.0 <= model_after[0] <= 20000.0 and np.all(np.isfinite(model_after))
+    assert abs(model_after[0] - grid.model[0]) < 0.05 * grid.model[0]
+    g.set_model(0, grid.model)
+    # ---- oracle parity on three sampled groups, re-solved stand-alone from the same start
+    edges_all = g.edges(with_distances=True)
+    report = []
+    for members, opts in ((np.flatnonzero(grp == 0), O_MESH), (np.flatnonzero(grp == 57), O_MESH), (np.flatnonzero(gi == 0), O_INTR)):
+        edges, feats, pk = _subproblem(grid, g, edges_all, index_of, members, ori0)
+        got, exp, t_cpu = _both(ctx, oracle, grid, members, edges, feats, pk, ori0[members], opts, sa["vertices"], sa["edges"])
+        report.append((len(members), len(edges), int(got["residual_blocks"]), int(got["iterations_total"]), round(t_cpu, 1),
+                       round(got["device_s"], 3)))
+    print("C5 sampled groups (cameras, edges, blocks, LM iterations, oracle s, device s):", report)
+    # ---- the single global group of FINAL_GLOBAL_RELAX's last run over all 5 000 cameras
+    g.set_orientations(ori1)
+    fin = g.relax(ctx, ori1, host.relax_options(*O_MESH), 0.1, previous=st["surface"])
+    assert int(fin["unknowns"]) >= 3 * (n - 50) and int(fin["residual_blocks"]) > 500_000
+    errf = pipeline.orientation_errors(fin["orientation"], grid.orientation)
+    assert np.median(errf) < 1e-3 and np.sum(errf > 0.02) < n // 100
+    print("C5 global mesh group: unknowns", int(fin["unknowns"]), "blocks", int(fin["residual_blocks"]), "LM iterations",
+          int(fin["iterations_total"]), "device s", round(fin["device_s"], 2), "median error", float(np.median(errf)))
+    g.close()
+    ctx.close()

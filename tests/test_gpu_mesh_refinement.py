@@ -66,3 +66,87 @@ def test_mesh_refinement_state_runs_to_its_end():
     got = g.orientations()
     assert np.median([qangle(got[i], ori[i]) for i in range(len(ori))]) < 3e-3
     g.close(), ctx.close()
+
+
+def oracle_mesh_refinement(oracle, rx, pos, model, max_steps):
+    """Pipeline::Impl::mesh_refinement (src/pipeline/pipeline.cpp:666-819) written out over the oracle's pieces: the relax
+    stage's single group by the restated RelaxGroup (floor(56 / 50) = 1 cluster), the mesh in the oracle's own restatement of
+    the refinement (oracle/refine_mesh.cpp), whose container orders persist from run to run as the reference's do."""
+    knn = oracle.knn10_bruteforce(pos[:, :2])
+    ordered, depth = oracle.relax_stage_groups(rx, ordered=True)
+    assert len(ordered) == 1
+    O = oracle.options("ORIENTATION", "GROUND_MESH")
+    seed = oracle.rebuild_mesh(pos, minimal=True).arrays()
+    mesh = oracle.RxMesh(seed["vertices"], seed["edges"])
+    level, level_triangles, run, log = 0, 0, 0, []
+    while run < max_steps:
+        gf = 0.1 / 2.0 ** level
+        v, e = mesh.arrays()
+        r = rx.relax_group(ordered[0], knn, depth, O, gf, oracle.RxSurface().set(v, e))
+        out = r["surface"].arrays()
+        assert np.array_equal(out["edges"], e)            # the relax moves heights only
+        mesh.set_heights(out["vertices"][:, 2])
+        clouds = [out["cloud"]]
+        mean_surface_z = float(np.mean(out["vertices"][:, 2]))
+        mean_cam_z, arc, size = float(np.mean(pos[:, 2])), 1.0 / model[0], float(max(model[8], model[9]))
+        gsd = max(0.001, abs(mean_cam_z - mean_surface_z) * arc)
+        reduced = np.sqrt(20 / 8.0) * gf * size * gsd
+        min_var = (2.0 * gsd) ** 2
+        tri, count, var = mesh.count_points_per_triangle(clouds)
+        above = int(np.sum((count > 20) & (var > min_var)))
+        step = dict(level=level, grid_fraction=gf, gsd=gsd, above_threshold=above, max_points=int(count.max()) if len(count) else 0,
+                    created=0, vertices=len(v), repeat=1)
+        converged = above == 0
+        if not converged and run >= 20 - 1:
+            converged = True
+        if not converged:
+            created = mesh.refine_by_point_density(clouds, 20, min_var, 1, reduced)
+            if created == 0:
+                converged = True
+            else:
+                level_triangles += created
+                step.update(created=created, vertices=len(mesh.arrays()[0]))
+                log.append(step)
+                run += 1
+                continue
+        if level_triangles == 0:
+            step["repeat"] = 0
+            log.append(step)
+            break
+        level += 1
+        level_triangles = 0
+        log.append(step)
+        run += 1
+    return mesh, log
+
+
+def test_mesh_refinement_trajectory_equals_the_oracle(oracle):
+    """The whole MESH_REFINEMENT trajectory - triangles above the threshold, triangles created, vertices, grid level of every
+    run - and the final mesh, against the state written out over the oracle (restated RelaxGroup + the second restatement of
+    the refinement): device relax and CPU relax agree to 1e-6, the refinements then make the same choices."""
+    from relax_fixtures import host_paths, rx_graph_from_edges
+
+    ori, pos, edges, ground = rolling_survey(rows=7, cols=8, pts_per_side=40, seed=9)
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(2)
+    start = np.array([qmul(ori[i], axis_angle(rng.normal(size=3), 0.02)) for i in range(len(ori))])
+    g = host_graph_from_edges(host, pos, start, MODEL_600, edges)
+    surface, log = g.mesh_refinement(ctx, max_steps=40)
+    rx, _ = rx_graph_from_edges(oracle, pos, start, MODEL_600, edges, paths=host_paths(len(pos)))
+    omesh, olog = oracle_mesh_refinement(oracle, rx, pos, MODEL_600, 40)
+    # exact: grid level, triangles created, vertices, points in the fullest triangle, whether the state repeats.  The count
+    # of triangles above the variance threshold may differ by one where a triangle's variance sits within the 1e-6 the two
+    # relaxes differ by of the threshold (such a triangle is split either way, as its neighbour's partner)
+    keys = ("level", "max_points", "created", "vertices", "repeat")
+    print([[int(s[k]) for k in keys + ("above_threshold",)] for s in log])
+    print([[int(s[k]) for k in keys + ("above_threshold",)] for s in olog])
+    assert [[int(s[k]) for k in keys] for s in log] == [[int(s[k]) for k in keys] for s in olog]
+    assert all(abs(int(a["above_threshold"]) - int(b["above_threshold"])) <= 1 for a, b in zip(log, olog))
+    assert len(log) >= 3 and sum(s["created"] for s in log) > 20
+    a = surface.arrays()
+    ov, oe = omesh.arrays()
+    assert np.array_equal(a["edges"], oe)
+    assert np.array_equal(a["vertices"][:, :2], ov[:, :2]) and np.allclose(a["vertices"][:, 2], ov[:, 2], rtol=0, atol=1e-5)
+    got, exp = g.orientations(), rx.orientations()
+    assert max(qangle(got[i], exp[i]) for i in range(len(ori))) < 1e-6
+    g.close(), ctx.close()

@@ -300,3 +300,42 @@ def test_checkpoint_failures(tmp_path):
     assert not host.validate_checkpoint(d)
     with pytest.raises(IOError):
         host.load_checkpoint(d)
+
+
+def test_reads_a_graph_typed_from_the_reference_writer():
+    """tests/golden/reference_layout_graph.json was typed from serialize_MeasurementGraph.cpp:210-591 field by field
+    (scripts/make_reference_layout_fixture.py holds the templates; no serializer wrote it): three nodes, two edges, metadata,
+    thumbnails, NaN orientations, an escaped path, exponent-form doubles.  The product's reader must find every value, and
+    its writer must give the text back byte for byte."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_layout_graph.json")
+    text = open(path).read()
+    g = host.Graph().load_json(path)
+    assert g.node_ids == [11, 22, 33] and g.num_edges == 2
+    tab = g.node_table()
+    assert tab["features"].tolist() == [2, 2, 1] and tab["sparse"].tolist() == [1, 2, 1] and tab["model"].tolist() == [0, 0, 0]
+    m = g.models()
+    assert len(m) == 1 and m[0].tolist() == [3000.5, 2000.0, 1500.0, 0.02, -0.07, 0.1, 0.0001, -0.0002, 4000, 3000, 7]
+    n0, n1, n2 = (g.node_payload(i) for i in range(3))
+    assert n0["path"] == "/data/IMG_0001.JPG" and n2["path"] == '/data/IMG "3".JPG'
+    assert n0["position"].tolist() == [10.5, -20.25, 100.0] and n0["orientation"].tolist() == [1.0, 0.0, 0.0, 0.0]
+    assert np.isnan(n1["orientation"]).all() and n2["orientation"].tolist() == [0.0, 0.7071067811865476, 0.0, 0.7071067811865476]
+    assert n0["loc"].tolist() == [[1.5, 2.5], [3999.875, 0.1 + 0.2]] and n0["strength"].tolist() == [0.75, 0.25]
+    assert n1["loc"].tolist() == [[100.0, 200.0], [1e-7, 1.5e-9]]
+    bits = lambda d: [j for j in range(512) if (int(d[j >> 6]) >> (j & 63)) & 1]
+    assert bits(n0["desc"][0]) == [0, 485] and bits(n0["desc"][1]) == [1, 8] and bits(n1["desc"][1]) == [7]
+    e0, e1 = g.edges(with_distances=True)
+    assert (e0["source"], e0["dest"], e0["n_matches"], e0["n_inliers"], e0["is_homography"]) == (11, 22, 2, 1, True)
+    assert e0["match_idx"].tolist() == [[0, 1], [1, 0]] and e0["dist"].tolist() == [20 / 486.0, 0.5]
+    assert e0["px"].tolist() == [[1.5, 2.5, 1e-7, 1.5e-9]] and (e0["f1"][0], e0["f2"][0], e0["match_index"][0]) == (0, 1, 0)
+    assert e0["H"].tolist() == [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.001, -0.002, 1.0]]
+    assert e0["poses"][0].tolist() == [0, 0, 0, 1, 1, 0, 0, 8] and e0["poses"][1].tolist() == [0.1, 0.2, 0.3, 0.9, 0.0, -1.0, 0.5, 3]
+    assert np.isnan(e0["poses"][2, :7]).all() and e0["poses"][2, 7] == 0
+    assert (e1["source"], e1["dest"], e1["n_matches"], e1["n_inliers"], e1["is_homography"]) == (33, 11, 0, 0, False)
+    assert np.isnan(e1["H"]).all()
+    assert g.to_json() == text                                   # member order, indentation, number format, metadata, thumbnail
+    # Python's own JSON reader agrees on the structure (NaN is accepted by it) and the oracle's reader on the values
+    doc = json.loads(text)
+    assert list(doc) == ["version", "nodes", "edges"] and list(doc["nodes"]["11"])[:4] == ["path", "position", "orientation", "thumbnail"]
+    assert doc["nodes"]["22"]["metadata"]["capture_info"]["datum"] == "WGS-84" and doc["nodes"]["33"]["edges"] == ["6"]
+    od = gj.read_graph(text)
+    assert od is not None and gj.write_graph(od) == text

@@ -202,3 +202,58 @@ def test_refine_at_point_levels_and_depth():
     assert c3 >= 6
     validate_mesh(s)
     assert s.refine_at_point(1e6, 1e6, 2) == 0            # outside: nothing to refine
+
+
+# ---- the host refinement against the second restatement (oracle/refine_mesh.cpp, written from the reference's text) ----
+def _oracle_twin(surface):
+    a = surface.arrays()
+    return pyoracle.RxMesh(a["vertices"], a["edges"])
+
+
+def _same_mesh(surface, rx):
+    a = surface.arrays()
+    v, e = rx.arrays()
+    return np.array_equal(a["vertices"], v) and np.array_equal(a["edges"], e)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_refinement_equals_the_oracle_restatement(seed):
+    """countPointsPerTriangle (rows, order, counts, variances) and several rounds of refineByPointDensity with the heights
+    moved between the rounds (as the relax stage moves them): the two restatements keep identical meshes - vertices in
+    creation order, edges in the container's iteration order - and identical counts of created triangles."""
+    rng = np.random.default_rng(seed)
+    cams = np.array([[x, y, 50.0] for x in np.arange(0, 60 + 10 * seed, 20) for y in np.arange(0, 60, 20)], float)
+    cams[:, :2] += rng.uniform(-2, 2, (len(cams), 2))
+    s = host.rebuild_mesh(cams, minimal=(seed % 2 == 0))
+    rx = _oracle_twin(s)
+    assert _same_mesh(s, rx)
+    lo, hi = cams[:, :2].min(0) - 5, cams[:, :2].max(0) + 5
+    total = 0
+    for rnd in range(4):
+        pts = np.concatenate([rng.uniform(lo, hi, (900, 2)), np.zeros((900, 1))], axis=1)
+        pts[:, 2] = 1.5 * np.sin(pts[:, 0] / 7.0 + rnd) * np.cos(pts[:, 1] / 5.0) + rng.normal(0, 0.02, len(pts))
+        clouds = [pts[:400], pts[400:]]
+        s.set_clouds(clouds)
+        ht, hc, hv = s.count_points_per_triangle()
+        ot, oc, ov = rx.count_points_per_triangle(clouds)
+        assert np.array_equal(ht, ot) and np.array_equal(hc, oc) and np.array_equal(hv, ov)
+        created_h = s.refine_by_point_density(20, 0.01, 2, min_triangle_size=1.0)
+        created_o = rx.refine_by_point_density(clouds, 20, 0.01, 2, min_triangle_size=1.0)
+        assert created_h == created_o and _same_mesh(s, rx), (rnd, created_h, created_o)
+        total += created_h
+        # the relax moves the heights and hands the mesh back with its containers untouched
+        a = s.arrays()
+        z = a["vertices"][:, 2] + rng.normal(0, 0.05, len(a["vertices"]))
+        s.set_heights(z)
+        rx.set_heights(z)
+    assert total > 10
+    validate_mesh(s)
+
+
+def test_refine_at_point_equals_the_oracle_restatement():
+    cams = np.array([[x, y, 50.0] for x in range(0, 100, 20) for y in range(0, 80, 20)], float)
+    s = host.rebuild_mesh(cams)
+    rx = _oracle_twin(s)
+    for x, y, lv in [(30, 30, 3), (31, 29, 2), (60, 10, 4), (5, 70, 1), (1e6, 0, 2), (47.3, 33.1, 5)]:
+        assert s.refine_at_point(x, y, lv) == rx.refine_at_point(x, y, lv)
+        assert _same_mesh(s, rx), (x, y)
