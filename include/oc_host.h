@@ -200,6 +200,22 @@ extern "C"
                   const uint64_t *inl_feat, const uint64_t *inl_match_index, const uint64_t *dist_off, const double *dist,
                   size_t n_opt_edges, const uint64_t *opt_edges, uint32_t options, double grid_fraction,
                   const och_surface *previous, och_surface *surface_out, double *summary_out, double *model10_inout);
+    /* och_relax with what the two flavours the reference only reaches from its tests need: edge_poses32 (may be NULL) =
+     * per edge the four homography decompositions 4 x {q xyzw, t xyz, score} of camera_relations::relative_poses - the
+     * relative-orientation flavour (no GROUND_*, no POINTS_3D option: runRelativeOrientation, src/relax/relax.cpp:14-42)
+     * reads them; points_mode >= 0 with POINTS_3D runs TestRelaxProblem (test/test_relax.cpp:470-483) instead of the driver:
+     * setup3dPointProblem, then nothing (0), solve (1) or relaxObservedModelOnly (2); points_before / points_after
+     * (points_cap x 3, may be NULL) receive the tracks' 3-D points after the set-up and at the end, *n_points_out their
+     * number.  points_mode < 0: exactly och_relax (POINTS_3D then runs runPoints, relax.cpp:103-115). */
+    int och_relax_ex(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const double *node_ori, const double *model10,
+                     const uint64_t *feat_off, const double *feat_xy, size_t n_poses, const uint64_t *pose_node,
+                     double *pose_ori, size_t n_edges, const uint64_t *edge_src, const uint64_t *edge_dst, const double *edge_H,
+                     const uint8_t *edge_is_homography, const uint64_t *inl_off, const double *inl_px,
+                     const uint64_t *inl_feat, const uint64_t *inl_match_index, const uint64_t *dist_off, const double *dist,
+                     size_t n_opt_edges, const uint64_t *opt_edges, uint32_t options, double grid_fraction,
+                     const och_surface *previous, och_surface *surface_out, double *summary_out, double *model10_inout,
+                     const double *edge_poses32, int points_mode, double *points_before, double *points_after,
+                     size_t points_cap, size_t *n_points_out);
     /* Every node of a linked graph as one group, every edge whitelisted, any flavour.  ori_inout: n_nodes x 4. */
     int och_graph_relax(och_graph *g, ochip_ctx *ctx, double *ori_inout, uint32_t options, double grid_fraction,
                         const och_surface *previous, och_surface *surface_out, double *summary_out);

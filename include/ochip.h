@@ -326,6 +326,13 @@ extern "C"
         /* sharded evaluation over `shard_world` ranks (0 or 1 = not sharded): every rank creates the same problem and
          * evaluates its run of the ray blocks; ochip_relaxg_set_exchange names the transport */
         uint32_t shard_rank, shard_world;
+        /* relation blocks of setupDecompositionProblem (src/relax/relax_problem.cpp:40-59,311-350):
+         * MultiDecomposedRotationCost (relax_cost_function.hpp:188-307) between cameras rel_cam[2i], rel_cam[2i + 1] over
+         * the four homography decompositions rel_pose[32 i ..] = 4 x {q xyzw, t xyz, score}, HuberLoss(rel_huber_a) */
+        uint32_t n_rel;
+        const uint32_t *rel_cam;
+        const double *rel_pose;
+        double rel_huber_a; /* 10 degrees in radians */
     } ochip_relaxg_desc;
 
     int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *desc, ochip_relaxg_problem **out);
@@ -350,6 +357,45 @@ extern "C"
      * the reduced system in the library's unknown order; order_out (n_cams + n_verts + 3 entries) receives the first
      * unknown of every camera / vertex / f / pp / k or -1. */
     int ochip_relaxg_evaluate(ochip_relaxg_problem *p, double *cost, int *n_out, double *JtJ, double *Jtr, int32_t *order_out);
+
+    /* ---- relax with 3-D points: reprojection bundle adjustment, the points eliminated by a per-point 3 x 3 Schur
+     *      complement (replaces ceres::Solver::Solve with SPARSE_SCHUR on the problem RelaxProblem::setup3dPointProblem
+     *      builds, src/relax/relax_problem.cpp:122-145,986-1187: PixelErrorCost_Orientation[Focal[Radial[Tangential]]],
+     *      relax_cost_function.hpp:309-500, HuberLoss(10 px), focal bounds, SubsetManifold of the radial block,
+     *      DistortionMonotonicityCost :157-185).  Every point is seen by exactly two cameras - the reference makes one
+     *      point per whitelisted inlier of an edge - and the points of one edge form a group: points
+     *      [grp_first[g], grp_first[g + 1]) are seen by cameras grp_cam[2g] (pixels obs_px[2p]) and grp_cam[2g + 1]
+     *      (obs_px[2p + 1]).  Unknowns of the reduced system: 3 per optimised camera (quaternion tangent) and the shared
+     *      lens model's free parameters; the points are back-substituted. ---- */
+    typedef struct ochip_relaxp_problem ochip_relaxp_problem;
+    typedef struct ochip_relaxp_desc
+    {
+        uint32_t n_cams;
+        const double *cam_pos;       /* n_cams x 3 */
+        const double *cam_q;         /* n_cams x 4, x y z w */
+        const uint8_t *cam_optimize; /* n_cams */
+        uint32_t n_points;
+        const double *point_xyz;     /* n_points x 3: the triangulated starting points */
+        uint32_t n_groups;
+        const uint32_t *grp_first;   /* n_groups + 1 */
+        const uint32_t *grp_cam;     /* n_groups x 2 */
+        const double *obs_px;        /* (2 n_points) x 2 pixels */
+        int functor;                 /* 0 Orientation, 1 OrientationFocal, 2 ...Radial, 3 ...RadialTangential */
+        double model[8];             /* f, ppx, ppy, k1, k2, k3, p1, p2 of the shared forward lens model */
+        uint8_t opt_focal, opt_principal, n_radial_free; /* functor >= 1: f / pp variable; functor >= 2: 0..3 leading radial
+                                                            coefficients variable (3 = a free Euclidean block) */
+        double focal_lo, focal_hi;   /* bounds of a variable focal length (100, 20000) */
+        double huber_a;              /* 10 px */
+        uint32_t mono_observations;  /* DistortionMonotonicityCost (functor >= 2): weight sqrt(n / 10); 0 = none */
+        double mono_r_max;
+    } ochip_relaxp_desc;
+    int ochip_relaxp_problem_create(ochip_ctx *ctx, const ochip_relaxp_desc *desc, ochip_relaxp_problem **out);
+    void ochip_relaxp_problem_destroy(ochip_relaxp_problem *p);
+    /* relaxObservedModelOnly (:931-984): 1 = cameras and lens model held constant, only the points move; 0 = undo */
+    int ochip_relaxp_set_structure_only(ochip_relaxp_problem *p, int on);
+    int ochip_relaxp_solve(ochip_relaxp_problem *p, const ochip_relax_options *opt, ochip_relax_summary *summary);
+    /* cam_q: n_cams x 4 (optimised cameras normalised), point_xyz: n_points x 3, model: 8; any may be NULL */
+    int ochip_relaxp_get_state(ochip_relaxp_problem *p, double *cam_q, double *point_xyz, double *model);
 
     /* ---- profiling: HIP-event time of every launch of a kernel since the last reset ------------- */
     int ochip_profile_reset(ochip_ctx *ctx);

@@ -25,7 +25,9 @@ EXPORTS = [
     "ochip_relax_problem_create", "ochip_relax_problem_destroy", "ochip_relax_set_cameras_constant",
     "ochip_relax_solve", "ochip_relax_get_state", "ochip_relax_set_shard",
     "ochip_relaxg_problem_create", "ochip_relaxg_problem_destroy", "ochip_relaxg_set_structure_only", "ochip_relaxg_solve",
-    "ochip_relaxg_get_state", "ochip_relaxg_evaluate",
+    "ochip_relaxg_get_state", "ochip_relaxg_evaluate", "ochip_relaxg_set_exchange",
+    "ochip_relaxp_problem_create", "ochip_relaxp_problem_destroy", "ochip_relaxp_set_structure_only", "ochip_relaxp_solve",
+    "ochip_relaxp_get_state",
     "ochip_profile_reset", "ochip_profile_get", "ochip_match_work", "ochip_relax_work",
     "ochip_debug_fp64",
     "ochip_dense_index_create", "ochip_dense_index_destroy", "ochip_dense_match",

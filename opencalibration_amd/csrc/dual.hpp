@@ -97,6 +97,19 @@ template <int N, typename P> OCHIP_HD Dual<N, P> dacos(const Dual<N, P> &f)
         h.v[i] = (P)d * f.v[i];
     return h;
 }
+template <int N, typename P> OCHIP_HD Dual<N, P> datan2(const Dual<N, P> &y, const Dual<N, P> &x)
+{
+    Dual<N, P> h;
+    h.a = atan2(y.a, x.a);
+    const double d = 1.0 / (x.a * x.a + y.a * y.a);
+    for (int i = 0; i < N; i++)
+        h.v[i] = (P)(d * x.a) * y.v[i] - (P)(d * y.a) * x.v[i];
+    return h;
+}
+OCHIP_HD double datan2(double y, double x)
+{
+    return atan2(y, x);
+}
 OCHIP_HD double dsqrt(double x)
 {
     return sqrt(x);

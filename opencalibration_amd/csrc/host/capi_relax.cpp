@@ -269,6 +269,21 @@ int och_relax(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const doub
               const uint64_t *opt_edges, uint32_t options, double grid_fraction, const och_surface *previous,
               och_surface *surface_out, double *summary_out, double *model10_inout)
 {
+    return och_relax_ex(ctx, n_nodes, node_pos, node_ori, model10, feat_off, feat_xy, n_poses, pose_node, pose_ori, n_edges, edge_src,
+                        edge_dst, edge_H, edge_is_homography, inl_off, inl_px, inl_feat, inl_match_index, dist_off, dist, n_opt_edges,
+                        opt_edges, options, grid_fraction, previous, surface_out, summary_out, model10_inout, nullptr, -1, nullptr,
+                        nullptr, 0, nullptr);
+}
+
+int och_relax_ex(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const double *node_ori, const double *model10,
+                 const uint64_t *feat_off, const double *feat_xy, size_t n_poses, const uint64_t *pose_node, double *pose_ori,
+                 size_t n_edges, const uint64_t *edge_src, const uint64_t *edge_dst, const double *edge_H,
+                 const uint8_t *edge_is_homography, const uint64_t *inl_off, const double *inl_px, const uint64_t *inl_feat,
+                 const uint64_t *inl_match_index, const uint64_t *dist_off, const double *dist, size_t n_opt_edges,
+                 const uint64_t *opt_edges, uint32_t options, double grid_fraction, const och_surface *previous,
+                 och_surface *surface_out, double *summary_out, double *model10_inout, const double *edge_poses32, int points_mode,
+                 double *points_before, double *points_after, size_t points_cap, size_t *n_points_out)
+{
     MeasurementGraph graph;
     auto model = std::make_shared<CameraModel>();
     model->focal_length_pixels = model10[0];
@@ -317,6 +332,13 @@ int och_relax(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const doub
         if (dist_off)
             for (uint64_t k = dist_off[e]; k < dist_off[e + 1]; k++)
                 rel.matches.push_back(feature_match{0, 0, dist[k]});
+        if (edge_poses32)
+            for (int i = 0; i < 4; i++)
+            {
+                std::memcpy(rel.relative_poses[i].orientation, edge_poses32 + 32 * e + 8 * i, 32);
+                std::memcpy(rel.relative_poses[i].position, edge_poses32 + 32 * e + 8 * i + 4, 24);
+                rel.relative_poses[i].score = (int)edge_poses32[32 * e + 8 * i + 7];
+            }
         edge_ids[e] = graph.addEdge(std::move(rel), node_ids[edge_src[e]], node_ids[edge_dst[e]]);
     }
     std::vector<NodePose> poses(n_poses);
@@ -348,7 +370,23 @@ int och_relax(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const doub
     RelaxTimers t;
     RelaxMeshStats st;
     surface_model out;
-    if (!relax(ctx, graph, poses, cam_models, opt, cfg, prev, &out, &t, &st, &g_relax_error))
+    if (points_mode >= 0)
+    {
+        // TestRelaxProblem of test/test_relax.cpp:470-483: the 3-D point problem set up, then solved / structure-only / left
+        std::vector<double> before, after;
+        if (!relax_points(ctx, graph, poses, cam_models, opt, options, &out, &t, &g_relax_error, points_mode, &before, &after))
+            return -1;
+        if (n_points_out)
+            *n_points_out = before.size() / 3;
+        for (size_t i = 0; i < before.size() && i < 3 * points_cap; i++)
+        {
+            if (points_before)
+                points_before[i] = before[i];
+            if (points_after)
+                points_after[i] = i < after.size() ? after[i] : NAN;
+        }
+    }
+    else if (!relax(ctx, graph, poses, cam_models, opt, cfg, prev, &out, &t, &st, &g_relax_error))
         return -1;
     for (size_t i = 0; i < n_poses; i++)
         std::memcpy(pose_ori + 4 * i, poses[i].orientation, 32);

@@ -1255,6 +1255,8 @@ bool relax(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> 
             rp.surface(surface);
         return true;
     }
+    if (config.options & OPT_POINTS_3D) // runPoints (relax.cpp:103-115)
+        return relax_points(ctx, graph, nodes, cam_models, edges_to_optimize, config.options, surface, timers, error);
     if (config.options & OPT_GROUND_PLANE) // runGroundPlane (relax.cpp:44-87)
     {
         surface_model_plane plane;
@@ -1276,8 +1278,10 @@ bool relax(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> 
         }
         return true;
     }
-    *error = "relax: only the GROUND_MESH and GROUND_PLANE flavours run on the device";
-    return false;
+    // runRelativeOrientation (relax.cpp:14-42); its surface model is empty
+    if (surface)
+        *surface = surface_model();
+    return relax_relative_orientation(ctx, graph, nodes, edges_to_optimize, timers, error);
 }
 
 } // namespace opencalibration_amd

@@ -142,4 +142,18 @@ bool relax(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> 
            const RelaxConfig &config, const std::vector<surface_model> &previousSurfaces, surface_model *surface,
            RelaxTimers *timers, RelaxMeshStats *stats, std::string *error, const RelaxShard *shard = nullptr);
 
+// runPoints (src/relax/relax.cpp:103-115) on the device: setup3dPointProblem, relaxObservedModelOnly, solve
+// (host/relax_points.cpp over ochip_relaxp_*).  mode < 0: that driver; 0: set-up only, 1: solve, 2: relaxObservedModelOnly
+// (TestRelaxProblem of test/test_relax.cpp:470-483).  points_before / points_after: the tracks' 3-D points (xyz) after the
+// set-up / at the end.  The surface is the point cloud.
+bool relax_points(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,
+                  std::vector<std::pair<size_t, CameraModel>> &cam_models, const std::vector<size_t> &edges_to_optimize,
+                  uint32_t options, surface_model *surface, RelaxTimers *timers, std::string *error, int mode = -1,
+                  std::vector<double> *points_before = nullptr, std::vector<double> *points_after = nullptr);
+
+// runRelativeOrientation (src/relax/relax.cpp:14-42) on the device: setupDecompositionProblem with the NaN-orientation
+// bootstrap (host/relax_relative.cpp over ochip_relaxg_* relation blocks)
+bool relax_relative_orientation(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,
+                                const std::vector<size_t> &edges_to_optimize, RelaxTimers *timers, std::string *error);
+
 } // namespace opencalibration_amd

@@ -161,6 +161,104 @@ __device__ inline void gdownward_prior(const double *q, double weight, double *r
         jac3[c] = ang.v[c];
 }
 
+// Eigen QuaternionBase::inverse(): conjugate / squared norm (the zero quaternion stays zero)
+template <typename T> __device__ __forceinline__ void gquat_inverse(const T *q, T *out)
+{
+    const T n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (value_of(n2) > 0.0)
+    {
+        out[0] = (T(0.0) - q[0]) / n2;
+        out[1] = (T(0.0) - q[1]) / n2;
+        out[2] = (T(0.0) - q[2]) / n2;
+        out[3] = q[3] / n2;
+    }
+    else
+        out[0] = out[1] = out[2] = out[3] = T(0.0);
+}
+template <typename T> __device__ __forceinline__ void gquat_product(const T *a, const T *b, T *out) // a * b, x y z w
+{
+    out[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    out[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    out[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    out[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+
+// MultiDecomposedRotationCost (:253-307) over DecomposedRotationCost (:188-251): the relative pose of two cameras against
+// up to four homography decompositions {relative rotation q (4), relative translation t (3), score}; of the decompositions
+// scoring more than a quarter of the best, the one with the smallest residual norm is the block's residual.  pos1, pos2:
+// the cameras' positions.  Returns false when no decomposition gives finite residuals (Ceres: evaluation failed).
+template <typename T>
+__device__ bool gmulti_decomposed_rotation(const T *q1, const T *q2, const double *poses32, const double *pos1, const double *pos2, T *res)
+{
+    double max_score = 0;
+    for (int k = 0; k < 4; k++)
+        max_score = fmax(max_score, (double)(int)poses32[8 * k + 7]);
+    const double dvec[3] = {pos2[0] - pos1[0], pos2[1] - pos1[1], pos2[2] - pos1[2]};
+    const double d2 = dvec[0] * dvec[0] + dvec[1] * dvec[1] + dvec[2] * dvec[2];
+    double lowest = 1.7976931348623157e308 * 2; // +inf
+    bool any = false;
+    T inv1[4], inv2[4], r21[4];
+    gquat_inverse(q1, inv1);
+    gquat_inverse(q2, inv2);
+    gquat_product(q1, inv2, r21);
+    for (int k = 0; k < 4; k++)
+    {
+        const double *ps = poses32 + 8 * k;
+        const int score = (int)ps[7];
+        if (!((double)score > 0.25 * max_score))
+            continue;
+        const double t2n = ps[4] * ps[4] + ps[5] * ps[5] + ps[6] * ps[6];
+        const bool has_translation = d2 > 1e-9 && t2n > 1e-9;
+        const double qn = sqrt(ps[0] * ps[0] + ps[1] * ps[1] + ps[2] * ps[2] + ps[3] * ps[3]);
+        const double rel[4] = {ps[0] / qn, ps[1] / qn, ps[2] / qn, ps[3] / qn};
+        // Eigen's normalized(): divide by the norm when it is positive
+        double tdir[3] = {dvec[0], dvec[1], dvec[2]}, rtdir[3] = {ps[4], ps[5], ps[6]};
+        if (d2 > 0)
+            for (int i = 0; i < 3; i++)
+                tdir[i] /= sqrt(d2);
+        if (t2n > 0)
+            for (int i = 0; i < 3; i++)
+                rtdir[i] /= sqrt(t2n);
+        const double weight = sqrt(score / 8.);
+        T r[3];
+        if (has_translation)
+        {
+            const Vec3T<T> t21 = gquat_rotate(inv1, Vec3T<T>{T(tdir[0]), T(tdir[1]), T(tdir[2])});
+            r[0] = gangle_between_unit_vectors<T>(t21, Vec3T<T>{T(rtdir[0]), T(rtdir[1]), T(rtdir[2])});
+            // (relative_rotation * -translation_direction) is a product of doubles, cast afterwards
+            const double relq[4] = {rel[0], rel[1], rel[2], rel[3]};
+            const Vec3T<double> rt = gquat_rotate<double>(relq, Vec3T<double>{-tdir[0], -tdir[1], -tdir[2]});
+            const Vec3T<T> t12 = gquat_rotate(inv2, Vec3T<T>{T(rt.x), T(rt.y), T(rt.z)});
+            r[1] = gangle_between_unit_vectors<T>(t12, Vec3T<T>{T(-rtdir[0]), T(-rtdir[1]), T(-rtdir[2])});
+        }
+        else
+            r[0] = r[1] = T(3.14159265358979323846);
+        const T relT[4] = {T(rel[0]), T(rel[1]), T(rel[2]), T(rel[3])};
+        T prod[4];
+        gquat_product(relT, r21, prod);
+        // Eigen::AngleAxis<T>(q).angle(): 2 atan2(|vec|, |w|), 0 for a zero vector part
+        const T n = dsqrt(prod[0] * prod[0] + prod[1] * prod[1] + prod[2] * prod[2]);
+        r[2] = value_of(n) != 0.0 ? T(2.0) * datan2(n, dabs(prod[3])) : T(0.0);
+        double n2 = 0;
+        bool finite = true;
+        for (int i = 0; i < 3; i++)
+        {
+            r[i] = T(weight) * r[i];
+            const double v = value_of(r[i]);
+            finite = finite && (v - v == 0.0);
+            n2 += v * v;
+        }
+        if (finite && n2 < lowest)
+        {
+            lowest = n2;
+            any = true;
+            for (int i = 0; i < 3; i++)
+                res[i] = r[i];
+        }
+    }
+    return any;
+}
+
 // AdjacentTriangleNormalCost (:119-155): xy = A B C D corners' x,y (8), z = their heights (4)
 template <typename T> __device__ inline T gadjacent_triangle_normal(const double *xy, const T *z, double weight)
 {

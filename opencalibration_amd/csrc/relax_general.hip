@@ -44,6 +44,7 @@ enum : uint8_t
     T_ANCHOR = 18,
     T_SMOOTH = 19,
     T_MONO = 20,
+    T_REL = 21, // MultiDecomposedRotationCost between two cameras (setupDecompositionProblem)
     T_NULL = 31 // padding between the ray blocks and the priors of a sharded problem: no unknowns, no data, cost 0
 };
 
@@ -53,6 +54,8 @@ __host__ __device__ inline int rec_dim(int type)
         return 3 * (type & 7) + 3 + ((type & T_INTR) ? 6 : 0);
     if (type == T_NULL)
         return 0;
+    if (type == T_REL)
+        return 6;
     return type == T_DOWN ? 3 : type == T_DIFF ? 2 : type == T_ANCHOR ? 1 : type == T_SMOOTH ? 4 : 3;
 }
 __host__ __device__ inline int rec_nvars(int type)
@@ -61,6 +64,8 @@ __host__ __device__ inline int rec_nvars(int type)
         return (type & 7) + 3 + ((type & T_INTR) ? 3 : 0);
     if (type == T_NULL)
         return 0;
+    if (type == T_REL)
+        return 2;
     return type == T_DOWN ? 1 : type == T_DIFF ? 2 : type == T_ANCHOR ? 1 : type == T_SMOOTH ? 4 : 1;
 }
 // local column -> (slot of the record's unknown group, offset inside the group)
@@ -102,6 +107,12 @@ __host__ __device__ inline void rec_col(int type, int c, int *slot, int *off)
         *off = c;
         return;
     }
+    if (type == T_REL)
+    {
+        *slot = c / 3;
+        *off = c % 3;
+        return;
+    }
     *slot = c; // DIFF, ANCHOR, SMOOTH: one column per vertex
     *off = 0;
 }
@@ -119,6 +130,8 @@ __host__ __device__ inline int rec_slot_col(int type, int slot)
     }
     if (type == T_DOWN || type == T_MONO)
         return 0;
+    if (type == T_REL)
+        return 3 * slot;
     return slot;
 }
 __host__ __device__ inline int tri_idx(int i, int j, int d) // i <= j, packed upper triangle of a d x d matrix
@@ -144,8 +157,10 @@ struct g_dev
     uint32_t *rec_var; // [n_rec][MAXV]
     double *rec_data, *rec_cost;
     // priors
-    uint32_t n_down, n_diff, n_anchor, n_smooth, n_mono, prior_base; // record ids: prior_base + [down | diff | anchor | smooth | mono]
-    uint32_t *down_cam, *diff_v, *smooth_v;
+    uint32_t n_down, n_diff, n_anchor, n_smooth, n_mono, n_rel, prior_base; // record ids: prior_base + [down | diff | anchor | smooth | mono | rel]
+    uint32_t *down_cam, *diff_v, *smooth_v, *rel_cam;
+    double *rel_pose; // [n_rel][4][8] decompositions: q xyzw, t xyz, score
+    double rel_huber_a;
     double down_w, diff_w, anchor_w, smooth_w, mono_w, mono_rmax, huber_a, f_lo, f_hi;
     uint8_t n_k_free;
     int32_t *fail;
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(W) void ray_record_kernel(g_dev P, uint32_t first, 
 __global__ void prior_kernel(g_dev P, int which, int with_jac)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_all = P.n_down + P.n_diff + P.n_anchor + P.n_smooth + P.n_mono;
+    const uint32_t n_all = P.n_down + P.n_diff + P.n_anchor + P.n_smooth + P.n_mono + P.n_rel;
     if (i >= n_all)
         return;
     const uint32_t rec = P.prior_base + i;
@@ -413,6 +428,58 @@ __global__ void prior_kernel(g_dev P, int which, int with_jac)
             }
         }
         failed |= !(r.a - r.a == 0.0);
+    }
+    else if ((k -= P.n_smooth) >= P.n_mono)
+    {
+        // MultiDecomposedRotationCost (relax_cost_function.hpp:253-307) with HuberLoss(10 degrees): two passes of duals,
+        // one per camera's tangent
+        k -= P.n_mono;
+        const uint32_t c1 = P.rel_cam[2 * k], c2 = P.rel_cam[2 * k + 1];
+        const double *poses = P.rel_pose + 32 * (size_t)k;
+        double r[3], J[3][6];
+        for (int pass = 0; pass < 2; pass++)
+        {
+            Dual<3> q1[4], q2[4], rd[3];
+            if (pass == 0)
+                gseed_quat(Q + 4 * (size_t)c1, q1);
+            else
+                for (int a = 0; a < 4; a++)
+                    q1[a] = Dual<3>(Q[4 * (size_t)c1 + a]);
+            if (pass == 1)
+                gseed_quat(Q + 4 * (size_t)c2, q2);
+            else
+                for (int a = 0; a < 4; a++)
+                    q2[a] = Dual<3>(Q[4 * (size_t)c2 + a]);
+            if (!gmulti_decomposed_rotation<Dual<3>>(q1, q2, poses, P.cam_pos + 3 * (size_t)c1, P.cam_pos + 3 * (size_t)c2, rd))
+            {
+                failed = true;
+                for (int a = 0; a < 3; a++)
+                    rd[a] = Dual<3>(0.0);
+            }
+            for (int a = 0; a < 3; a++)
+            {
+                r[a] = rd[a].a;
+                for (int c = 0; c < 3; c++)
+                {
+                    J[a][3 * pass + c] = rd[a].v[c];
+                    if (!(rd[a].v[c] - rd[a].v[c] == 0.0))
+                        failed = true;
+                }
+            }
+        }
+        const double s = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+        double rho1;
+        huber(s, P.rel_huber_a, true, &rho1, &cost);
+        if (with_jac)
+        {
+            int e = 0;
+            for (int a = 0; a < 6; a++)
+                for (int b = a; b < 6; b++)
+                    o[e++] = rho1 * (J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b]);
+            for (int a = 0; a < 6; a++)
+                o[21 + a] = rho1 * (J[0][a] * r[0] + J[1][a] * r[1] + J[2][a] * r[2]);
+        }
+        failed |= !(s - s == 0.0);
     }
     else
     {
@@ -1115,7 +1182,7 @@ struct general_model final : lm_model
                 break;
             }
         }
-        const uint32_t n_prior = D.n_down + D.n_diff + D.n_anchor + D.n_smooth + D.n_mono;
+        const uint32_t n_prior = D.n_down + D.n_diff + D.n_anchor + D.n_smooth + D.n_mono + D.n_rel;
         if (n_prior)
             hipLaunchKernelGGL(prior_kernel, dim3((n_prior + 255) / 256), dim3(256), 0, st, D, which, with_jac ? 1 : 0);
         ochip_prof_end(ctx, OCHIP_K_RELAX_EVAL, e0, e1);
@@ -1287,7 +1354,7 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
     p->shard_chunk = chunk;
     p->shard_lo = world > 1 ? std::min(d->shard_rank * chunk, d->n_blocks) : 0;
     p->shard_hi = world > 1 ? std::min((d->shard_rank + 1) * chunk, d->n_blocks) : d->n_blocks;
-    p->n_rec = n_ray_pad + d->n_down + d->n_diff + n_anchor + d->n_smooth + n_mono;
+    p->n_rec = n_ray_pad + d->n_down + d->n_diff + n_anchor + d->n_smooth + n_mono + d->n_rel;
     p->rec_type.resize(p->n_rec);
     p->rec_var.assign((size_t)p->n_rec * MAXV, 0);
     std::vector<uint64_t> rec_off(p->n_rec + 1, 0);
@@ -1371,6 +1438,19 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
             p->rec_type[r] = T_MONO;
             p->rec_var[(size_t)r * MAXV] = vf + 2;
         }
+        for (uint32_t i = 0; i < d->n_rel; i++, r++)
+        {
+            p->rec_type[r] = T_REL;
+            for (int k = 0; k < 2; k++)
+            {
+                if (d->rel_cam[2 * i + k] >= nc || d->rel_cam[2 * i] == d->rel_cam[2 * i + 1])
+                {
+                    delete p;
+                    return ochip_fail(ctx, OCHIP_EINVAL, "relation block %u has bad cameras", i);
+                }
+                p->rec_var[(size_t)r * MAXV + k] = d->rel_cam[2 * i + k];
+            }
+        }
     }
     auto rec_size = [&](uint32_t r) {
         const int dd = rec_dim(p->rec_type[r]);
@@ -1434,6 +1514,8 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
     D.n_anchor = n_anchor;
     D.n_smooth = d->n_smooth;
     D.n_mono = n_mono;
+    D.n_rel = d->n_rel;
+    D.rel_huber_a = d->rel_huber_a;
     D.prior_base = n_ray_pad;
     D.down_w = d->down_weight;
     D.diff_w = d->diff_weight;
@@ -1475,6 +1557,8 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
     chk(up(p, &D.down_cam, d->down_cam, d->n_down));
     chk(up(p, &D.diff_v, d->diff_v, (size_t)d->n_diff * 2));
     chk(up(p, &D.smooth_v, d->smooth_v, (size_t)d->n_smooth * 4));
+    chk(up(p, &D.rel_cam, d->rel_cam, (size_t)d->n_rel * 2));
+    chk(up(p, &D.rel_pose, d->rel_pose, (size_t)d->n_rel * 32));
     chk(up(p, &p->var_rec_dev, p->var_rec));
     chk(up(p, &p->cam_optimize_dev, p->cam_optimize));
     if (rc == OCHIP_OK)

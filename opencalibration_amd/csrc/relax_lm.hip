@@ -877,11 +877,21 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
     hipStream_t st = ctx->stream;
     const int n = S.n;
     double h[8];
+    const bool eliminated = M.has_eliminated();
+    M.begin_solve();
     auto grad_and_diag = [&](double *gmax) -> int {
         hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(1024), 0, st, S.A, S.g, S.diag_tmp, n, S.scal);
         OCHIP_HIP(ctx, hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         *gmax = h[4];
+        if (eliminated)
+        {
+            double extra = 0;
+            const int erc = M.gradient_max_extra(&extra);
+            if (erc)
+                return erc;
+            *gmax = std::max(*gmax, extra);
+        }
         return OCHIP_OK;
     };
     auto finish_state = [&]() {
@@ -945,9 +955,12 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         hipEvent_t e0, e1;
         ochip_prof_begin(ctx, OCHIP_K_RELAX_SOLVE, &e0, &e1);
         const size_t nn = (size_t)n * n;
-        hipLaunchKernelGGL(lm_build_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, S.A, S.g, S.scale, S.lm_diag,
-                           S.Wm, S.gs, n);
+        if (n > 0)
+            hipLaunchKernelGGL(lm_build_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, S.A, S.g, S.scale, S.lm_diag,
+                               S.Wm, S.gs, n);
         OCHIP_HIP(ctx, hipMemsetAsync(S.fail_chol, 0, 4, st));
+        if (eliminated)
+            M.launch_schur(radius, S.scale, S.Wm, n, S.fail_chol);
         {
             const size_t need = (size_t)((n + NB - 1) / NB) * NB * NB;
             if (need > S.linv_cap)
@@ -985,7 +998,9 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                     hipLaunchKernelGGL(chol_update_mfma_kernel, dim3(tiles, tiles), dim3(256), 0, st, W, n, rs, k0, nb);
             }
         };
-        if (chain)
+        if (n == 0)
+            ; // (every unknown is eliminated: nothing to factor)
+        else if (chain)
             launch_chain(S.Wm, S.linv, true, true);
         else
         {
@@ -1030,9 +1045,12 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             }
         }
         // row n now holds y = L^-1 gs; back-substitute L' x = y block by block
-        OCHIP_HIP(ctx, hipMemcpyAsync(S.y, S.Wm + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, st, (const double *)S.Wm, n, (const double *)S.linv, S.y,
-                           (const int *)S.first_col_dev, (n + NB - 1) / NB);
+        if (n > 0)
+        {
+            OCHIP_HIP(ctx, hipMemcpyAsync(S.y, S.Wm + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, st, (const double *)S.Wm, n, (const double *)S.linv, S.y,
+                               (const int *)S.first_col_dev, (n + NB - 1) / NB);
+        }
         hipLaunchKernelGGL(lm_model_change_kernel, dim3(1), dim3(1024), 0, st, S.lm_diag, S.gs, S.y, n, S.scal);
         M.launch_candidate(S.y, S.scale, 1.0, S.scal);
         ochip_prof_end(ctx, OCHIP_K_RELAX_SOLVE, e0, e1);
@@ -1082,6 +1100,14 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                 gdd += gh[i] * d;
                 dmax = std::max(dmax, std::abs(d));
             }
+            if (eliminated)
+            {
+                double extra = 0;
+                const int src = M.slope_extra(true, &extra);
+                if (src)
+                    return src;
+                gdd += extra;
+            }
             ls_sample at0, previous, current;
             at0.x = 0, at0.value = x_cost, at0.slope = gdd, at0.valid = true;
             current.x = 1.0, current.value = cand_cost, current.valid = cand_cost < 1e308;
@@ -1105,6 +1131,14 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                     current.slope = 0;
                     for (int i = 0; i < n; i++)
                         current.slope += g1[i] * (-yh[i] * scale[i]);
+                    if (eliminated)
+                    {
+                        double extra = 0;
+                        const int src = M.slope_extra(false, &extra);
+                        if (src)
+                            return src;
+                        current.slope += extra;
+                    }
                     current.valid = erc == 0 && std::isfinite(current.slope);
                 }
                 contracted = true;
@@ -1127,6 +1161,14 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                 current.slope = 0;
                 for (int i = 0; i < n; i++)
                     current.slope += g1[i] * (-yh[i] * scale[i]);
+                if (eliminated)
+                {
+                    double extra = 0;
+                    const int src = M.slope_extra(false, &extra);
+                    if (src)
+                        return src;
+                    current.slope += extra;
+                }
                 current.valid = erc == 0 && std::isfinite(c2) && std::isfinite(current.slope);
             }
             if (contracted)

@@ -73,6 +73,40 @@ struct lm_model
     {
         return false;
     }
+    // ---- parameter blocks eliminated from the system by a Schur complement (relax_points.hip: the 3-D points).  The
+    //      system lm_solve factors then holds the remaining unknowns only (possibly none at all); the model keeps the
+    //      eliminated blocks' part of the normal equations from its last Jacobian evaluation and
+    //        begin_solve            forgets the Jacobi scaling of the eliminated columns (fixed again from the solve's
+    //                               first Jacobian, like the system's own),
+    //        gradient_max_extra     max |g| over the eliminated columns,
+    //        launch_schur           called once the scaled, damped system Wm (n x n and the augmented row n = the scaled
+    //                               gradient) is built: subtracts the eliminated blocks' Schur term from both; the same
+    //                               damping rule (clamp(diag * scale^2, 1e-6, 1e32) / radius) applies to their columns,
+    //        launch_candidate       also back-substitutes the eliminated blocks, adds their share of the model cost
+    //                               change to scal[1], of |step|^2 to scal[2] and of |candidate|^2 to scal[3],
+    //        slope_extra            g . d over the eliminated columns for the projected line search: the gradient of the
+    //                               current point (from_candidate: as launch_candidate left it) or of the Jacobian
+    //                               evaluated last, d = the last full step.
+    virtual void begin_solve()
+    {
+    }
+    virtual bool has_eliminated()
+    {
+        return false;
+    }
+    virtual int gradient_max_extra(double *out)
+    {
+        *out = 0;
+        return OCHIP_OK;
+    }
+    virtual void launch_schur(double radius, const double *scale, double *Wm, int n, int *fail /* set non-zero: invalid step */)
+    {
+    }
+    virtual int slope_extra(bool from_candidate, double *out)
+    {
+        *out = 0;
+        return OCHIP_OK;
+    }
 };
 
 int lm_solve(lm_system &sys, lm_model &model, const ochip_relax_options *opt, ochip_relax_summary *sum);

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(128) void group_u_kernel(p_dev P)
 
 // per LM iteration and point: S V S + D^2 and its inverse.  fix_scale: this is the first Jacobian of the solve - the
 // point's Jacobi scaling 1 / (1 + sqrt(diag)) is taken from it.  D^2 = clamp(diag * scale^2, 1e-6, 1e32) / radius.
-__global__ void point_prepare_kernel(p_dev P, double radius, int fix_scale)
+__global__ void point_prepare_kernel(p_dev P, double radius, int fix_scale, int *fail)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P.n_points)
@@ -306,7 +306,7 @@ __global__ void point_prepare_kernel(p_dev P, double radius, int fix_scale)
     W[4] = i21 * i22;
     W[5] = i22 * i22;
     if (!(W[0] - W[0] == 0.0) || !(W[3] - W[3] == 0.0) || !(W[5] - W[5] == 0.0))
-        atomicOr(P.fail, 2);
+        atomicOr(fail, 1);
 }
 
 // w_i of a point: (scaled) coupling of reduced column i with the point, S_i (J_i' J_p) S_p summed over the observations
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(1024) void p_reduce_kernel(p_dev P, int with_gmax, 
 // back-substitution dp = -Vinv (S g_p - W' y) in scaled unknowns.  One workgroup.  scal[1] += the points' share of the
 // model cost change (alpha = 1), scal[2] = |x - candidate|^2, scal[3] = |candidate|^2, scal[6] = g_p . d_p (slope)
 __global__ __launch_bounds__(1024) void p_candidate_kernel(p_dev P, const double *scale, const double *y, double alpha, double radius,
-                                                           double *scal)
+                                                           int fresh, double *scal)
 {
     __shared__ double sh[1024];
     const int t = threadIdx.x;
@@ -588,7 +588,15 @@ __global__ __launch_bounds__(1024) void p_candidate_kernel(p_dev P, const double
             }
         }
     }
-    for (uint32_t p = t; p < P.n_points; p += 1024)
+    for (uint32_t p = t; p < P.n_points && !fresh; p += 1024)
+        for (int a = 0; a < 3; a++)
+        {
+            const double x0 = P.X[3 * (size_t)p + a], x1 = x0 + alpha * P.pt_d[3 * (size_t)p + a];
+            P.X2[3 * (size_t)p + a] = x1;
+            sn += (x0 - x1) * (x0 - x1);
+            xn += x1 * x1;
+        }
+    for (uint32_t p = t; p < P.n_points && fresh; p += 1024)
     {
         const uint32_t g = P.pt_group[p];
         const double *Sp = P.pt_scale + 3 * (size_t)p, *Vi = P.pt_Vinv + 6 * (size_t)p, *V = P.pt_V + 6 * (size_t)p;
@@ -615,8 +623,7 @@ __global__ __launch_bounds__(1024) void p_candidate_kernel(p_dev P, const double
             const double d2 = fmin(fmax(dg[a] * Sp[a] * Sp[a], 1e-6), 1e32) / radius;
             mc += 0.5 * (d2 * dp[a] * dp[a] - P.pt_g[3 * (size_t)p + a] * Sp[a] * dp[a]);
             const double full = Sp[a] * dp[a], x0 = P.X[3 * (size_t)p + a], x1 = x0 + alpha * full;
-            if (alpha == 1.0)
-                P.pt_d[3 * (size_t)p + a] = full;
+            P.pt_d[3 * (size_t)p + a] = full;
             P.X2[3 * (size_t)p + a] = x1;
             sn += (x0 - x1) * (x0 - x1);
             xn += x1 * x1;
@@ -642,9 +649,11 @@ __global__ __launch_bounds__(1024) void p_candidate_kernel(p_dev P, const double
     {
         scal[2] = out[0];
         scal[3] = out[1];
-        if (alpha == 1.0)
+        if (fresh)
+        {
             scal[1] += out[2];
-        scal[6] = out[3];
+            scal[6] = out[3];
+        }
     }
 }
 
@@ -768,7 +777,7 @@ int assign(ochip_relaxp_problem *p)
 struct points_model final : lm_model
 {
     ochip_relaxp_problem *p;
-    bool scale_fixed = false;
+    bool scale_fixed = false, step_fresh = false;
     double radius_now = 1.0;
     explicit points_model(ochip_relaxp_problem *prob) : p(prob)
     {
@@ -831,13 +840,14 @@ struct points_model final : lm_model
         *out = v;
         return OCHIP_OK;
     }
-    void launch_schur(double radius, const double *scale, double *Wm, int n) override
+    void launch_schur(double radius, const double *scale, double *Wm, int n, int *fail) override
     {
         hipStream_t st = p->ctx->stream;
         p_dev &D = p->dev;
         radius_now = radius;
+        step_fresh = true;
         if (D.n_points)
-            hipLaunchKernelGGL(point_prepare_kernel, dim3((D.n_points + 255) / 256), dim3(256), 0, st, D, radius, scale_fixed ? 0 : 1);
+            hipLaunchKernelGGL(point_prepare_kernel, dim3((D.n_points + 255) / 256), dim3(256), 0, st, D, radius, scale_fixed ? 0 : 1, fail);
         scale_fixed = true;
         if (n > 0 && D.n_groups)
         {
@@ -849,7 +859,11 @@ struct points_model final : lm_model
     }
     void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override
     {
-        hipLaunchKernelGGL(p_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, alpha, radius_now, scal);
+        // the first call after a solve back-substitutes the points (and keeps their full step); the line search's later calls
+        // rescale that step - by then the kept Jacobians may be those of a trial point
+        hipLaunchKernelGGL(p_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, alpha, radius_now,
+                           step_fresh ? 1 : 0, scal);
+        step_fresh = false;
     }
     int slope_extra(bool from_candidate, double *out) override
     {

@@ -115,6 +115,7 @@ def load():
         L.och_rebuild_mesh.restype = None
         L.och_relax.argtypes = [vp, sz, _f64p, _f64p, _f64p, _u64p, _f64p, sz, _u64p, _f64p, sz, _u64p, _u64p, vp, u8p, _u64p,
                                 _f64p, _u64p, _u64p, vp, vp, sz, _u64p, u32, C.c_double, vp, vp, _f64p, vp]
+        L.och_relax_ex.argtypes = L.och_relax.argtypes + [vp, C.c_int, vp, vp, sz, C.POINTER(sz)]
         L.och_graph_relax.argtypes = [vp, vp, _f64p, u32, C.c_double, vp, vp, _f64p]
         L.och_graph_relax_sharded.argtypes = [vp, vp, _f64p, u32, C.c_double, vp, vp, _f64p, u32, u32, vp, vp]
         i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
@@ -407,10 +408,12 @@ def rebuild_mesh(cam_xyz, previous=None, minimal=False):
 
 
 def relax(ctx, node_pos, node_ori, model10, features, pose_node, pose_ori, packed_edges, options, grid_fraction=0.1,
-          opt_edges=None, previous=None, cam_model=None):
+          opt_edges=None, previous=None, cam_model=None, edge_poses=None, points_mode=-1):
     """relax(graph, nodes, cam_models, edges, config, previousSurfaces) on the device, any flavour.  features: per node
     an (k x 2) array of feature locations; packed_edges as for relax_ground_plane plus 'feat' (inliers x 2 feature
-    indices)."""
+    indices).  edge_poses (n_edges x 4 x 8): the edges' homography decompositions (relative-orientation flavour);
+    points_mode 0 / 1 / 2 with POINTS_3D: set up the 3-D point problem and leave it / solve it / run
+    relaxObservedModelOnly, returning the points before and after (test/test_relax.cpp:470-483)."""
     L = load()
     node_pos = np.ascontiguousarray(node_pos, np.float64)
     node_ori = np.ascontiguousarray(node_ori, np.float64)
@@ -425,16 +428,26 @@ def relax(ctx, node_pos, node_ori, model10, features, pose_node, pose_ori, packe
     summary = np.zeros(12)
     out_surface = Surface()
     cm = np.ascontiguousarray(model10 if cam_model is None else cam_model, np.float64).copy()
-    rc = L.och_relax(ctx.h, len(node_pos), node_pos, node_ori, np.ascontiguousarray(model10, np.float64), feat_off, feat_xy,
-                     len(pose_node), pose_node, pose_ori, n_edges, pk["src"], pk["dst"], pk["H"].ctypes.data, pk["is_h"],
-                     pk["inl_off"], pk["px"], np.ascontiguousarray(pk["feat"], np.uint64), pk["match_index"],
-                     pk["dist_off"].ctypes.data, pk["dist"].ctypes.data, len(opt), opt if len(opt) else np.zeros(1, np.uint64),
-                     options, grid_fraction, previous.h if previous is not None else None, out_surface.h, summary,
-                     cm.ctypes.data)
+    ep = None if edge_poses is None else np.ascontiguousarray(edge_poses, np.float64).reshape(-1, 32)
+    cap = 1 << 20
+    before = after = None
+    n_pts = C.c_size_t(0)
+    if points_mode >= 0:
+        before, after = np.zeros((cap, 3)), np.zeros((cap, 3))
+    rc = L.och_relax_ex(ctx.h, len(node_pos), node_pos, node_ori, np.ascontiguousarray(model10, np.float64), feat_off, feat_xy,
+                        len(pose_node), pose_node, pose_ori, n_edges, pk["src"], pk["dst"], pk["H"].ctypes.data, pk["is_h"],
+                        pk["inl_off"], pk["px"], np.ascontiguousarray(pk["feat"], np.uint64), pk["match_index"],
+                        pk["dist_off"].ctypes.data, pk["dist"].ctypes.data, len(opt), opt if len(opt) else np.zeros(1, np.uint64),
+                        options, grid_fraction, previous.h if previous is not None else None, out_surface.h, summary,
+                        cm.ctypes.data, None if ep is None else ep.ctypes.data, points_mode,
+                        None if before is None else before.ctypes.data, None if after is None else after.ctypes.data,
+                        cap if before is not None else 0, C.byref(n_pts))
     if rc != 0:
         raise capi.OchipError("relax failed: " + L.och_relax_last_error().decode())
     out = dict(zip(RELAX_SUMMARY12, summary.tolist()))
     out.update(orientation=pose_ori, surface=out_surface, cam_model=cm)
+    if before is not None:
+        out.update(points_before=before[:n_pts.value].copy(), points_after=after[:n_pts.value].copy())
     for k in ("solves", "iterations_total", "last_iterations", "residual_blocks", "track_blocks", "two_ray_blocks",
               "mesh_vertices", "unknowns"):
         out[k] = int(out[k])
