@@ -78,6 +78,12 @@ extern "C"
      * (n x {measurement1, measurement2}; poses 4 x {q xyzw, t xyz, score}; returns can_decompose) and image_to_3d. */
     int och_homography_decompose(const double *H9, const double *m1m2, size_t n, double *poses);
     void och_image_to_3d(const double *px, size_t n, const double *model10, double *rays);
+    /* ransac<fundamental_matrix_model> (model 0) / ransac<essential_matrix_model> (model 1) on the device
+     * (ochip_ransac_epipolar_batch) for one set of correspondences: rays6 n x {measurement1, measurement2}, quality n or
+     * NULL (PROSAC), threshold = the model's inlier_threshold (0.01).  M9: the matrix (row-major), inliers: n flags,
+     * counts3: {iterations, improvements, inliers}.  Returns ransac()'s score, NAN on a device error. */
+    double och_ransac_epipolar(ochip_ctx *ctx, int model, const double *rays6, const double *quality, size_t n, double threshold,
+                               double *M9, uint8_t *inliers, uint32_t *counts3);
     /* The host tail of extract_features alone (extract_features.cpp:38-87), no device involved: kp6 rows
      * {x, y, size, angle, response, level} in cv::AKAZE's order -> loc / strength / desc as above; returns the count. */
     size_t och_extract_tail(const float *kp6, const uint64_t *desc, uint32_t n, double scale, double *loc, float *strength,

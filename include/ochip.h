@@ -179,6 +179,27 @@ extern "C"
                                       uint64_t total_matches, const uint32_t *eval_order, uint64_t eval_total,
                                       double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers);
 
+    /* ---- the fundamental- and essential-matrix models under the same RANSAC loop (replaces
+     *      ransac<fundamental_matrix_model> / ransac<essential_matrix_model>, src/model_inliers/ransac.cpp:260-261 over
+     *      fundamental_matrix_model.cpp:12-217 (8-point fit, rank-2 constraint, Sampson error, DEGENSAC) and
+     *      essential_matrix_model.cpp:12-123 (5-point linear fit, equal singular values); tests-only in the reference).
+     *      model: 0 = fundamental (threshold 0.01), 1 = essential.  corr6: per correspondence {measurement1,
+     *      measurement2} (any scale: both are divided by their z); sorted_idx / eval_order as for the homography batch
+     *      (sorted_idx is read only by jobs with has_quality != 0).  results[j].H = the matrix, .score = evaluate / n. */
+    typedef struct ochip_epipolar_job
+    {
+        uint32_t n;           /* correspondences */
+        uint32_t rng_state;   /* std::default_random_engine(42) state after std::shuffle(eval_order) */
+        uint32_t has_quality; /* any correspondence.quality != 0: PROSAC sampling over sorted_idx */
+        uint32_t reserved;
+        uint64_t corr_offset; /* into corr6 (x 6), sorted_idx and inliers */
+        uint64_t eval_offset; /* into eval_order */
+    } ochip_epipolar_job;
+    int ochip_ransac_epipolar_batch(ochip_ctx *ctx, int model, const ochip_epipolar_job *jobs, uint32_t n_jobs,
+                                    const double *corr6, const uint32_t *sorted_idx, uint64_t total,
+                                    const uint32_t *eval_order, uint64_t eval_total, double inlier_threshold,
+                                    ochip_ransac_result *results, uint8_t *inliers);
+
     /* ---- re-fit of accepted edges after the camera models changed (replaces the per-edge loop of
      *      RelaxGroup::finalize, src/relax/relax_group.cpp:137-177: distort_keypoints with the current models, then
      *      `rounds` (= 3 there) times fitInliers + evaluate starting from the previous inliers).  jobs / matches as for

@@ -19,7 +19,7 @@ EXPORTS = [
     "ochip_ctx_create", "ochip_ctx_destroy", "ochip_ctx_sibling", "ochip_ctx_set_priority", "ochip_last_error", "ochip_device_info", "ochip_synchronize",
     "ochip_descriptors_reserve", "ochip_upload_descriptors", "ochip_descriptor_count",
     "ochip_match_batch", "ochip_match_launch", "ochip_match_fetch",
-    "ochip_upload_keypoints", "ochip_ransac_homography_batch", "ochip_refit_homography_batch",
+    "ochip_upload_keypoints", "ochip_ransac_homography_batch", "ochip_refit_homography_batch", "ochip_ransac_epipolar_batch",
     "ochip_upload_batch", "ochip_host_alloc", "ochip_host_free", "ochip_akaze_batch", "ochip_akaze_batch_dev",
     "ochip_synth_views_alloc", "ochip_synth_views_free", "ochip_synth_render_views", "ochip_synth_views_read",
     "ochip_relax_problem_create", "ochip_relax_problem_destroy", "ochip_relax_set_cameras_constant",

@@ -393,10 +393,30 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
     }
     __syncthreads();
     // Column pass: a thread takes 4 vertically neighbouring outputs of one column: 4 + 2R reads for 4 outputs
-    constexpr int BHQ = (BH + 3) / 4;
-    for (int idx = threadIdx.x; idx < BW * BHQ; idx += 256)
+    // A wavefront takes the first 64 columns of a group of four rows (lane = column: consecutive banks), the groups dealt
+    // round-robin to the four wavefronts; the 2 M columns beyond 64 of all groups go to the last two wavefronts in one more
+    // pass.  With lanes running across the end of a 64 + 2 M wide row two row groups shared a wavefront, 4 BWP words apart,
+    // and the lanes of the second sat on banks of the first (0.8 conflict cycles per LDS instruction by the counters).
+    constexpr int BHQ = (BH + 3) / 4, XC = BW - BT_X, COL_ITERS = (BHQ + 3) / 4 + (XC > 0 ? 1 : 0);
+    static_assert(BT_X == 64 && XC * BHQ <= 128, "one lane per column; the extra columns fit two wavefronts");
+    for (int pass = 0; pass < COL_ITERS; pass++)
     {
-        const int qy = idx / BW, lx = idx - qy * BW;
+        int qy, lx;
+        if (pass < (BHQ + 3) / 4)
+        {
+            qy = pass * 4 + (int)(threadIdx.x >> 6);
+            lx = (int)(threadIdx.x & 63);
+            if (qy >= BHQ)
+                continue;
+        }
+        else
+        {
+            const int e = (int)threadIdx.x - 128;
+            if (e < 0 || e >= XC * BHQ)
+                continue;
+            qy = e / (XC > 0 ? XC : 1);
+            lx = BT_X + e - qy * (XC > 0 ? XC : 1);
+        }
         const int ly0 = 4 * qy;
         float v[4 + 2 * R];
 #pragma unroll
@@ -739,8 +759,25 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
     const int x0 = tile_x * BT_X, y0 = tile_y * DT_Y;
     const int rx0 = x0 - HW, ry0 = y0 - HW;
     const float2 *XY = Lxy + (size_t)blockIdx.z * stride;
-    constexpr int DITERS = (DW * DH + 255) / 256;
-    float dreg[DITERS]; // this thread's determinants (index threadIdx.x + 256 i); NaN = outside the image, not stored
+    // The determinant tile (DW = 66 columns) is walked a tile row per wavefront - lane = column 0..63, four rows per pass -
+    // and its last two columns in one extra pass: with lanes running across a row wrap (66 is not a multiple of the wave)
+    // two rows share a wavefront and their 72-word pitch puts lanes of the second row on banks of the first (the
+    // counters showed 0.7 conflict cycles per LDS instruction in this kernel).
+    constexpr int ROW_ITERS = (DH + 3) / 4, DITERS = ROW_ITERS + 1;
+    static_assert(BT_X == 64 && 2 * DH <= 256, "one lane per column; the two extra columns fit one pass");
+    float dreg[DITERS]; // this thread's determinants; 0 = outside the image / the tile
+    const int wave_id = threadIdx.x >> 6, lane_id = threadIdx.x & 63;
+    auto cell_of = [&](int it, int *ly, int *lx) -> bool {
+        if (it < ROW_ITERS)
+        {
+            *ly = it * 4 + wave_id;
+            *lx = lane_id;
+            return *ly < DH;
+        }
+        *ly = (int)threadIdx.x >> 1;
+        *lx = 64 + ((int)threadIdx.x & 1);
+        return (int)threadIdx.x < 2 * DH;
+    };
     {
         constexpr int ITERS = (RW * RH + 255) / 256; // all loads in flight before the first LDS store
         float vx[ITERS], vy[ITERS];
@@ -781,11 +818,10 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
 #pragma unroll
         for (int it = 0; it < DITERS; it++)
         {
-            const int idx = threadIdx.x + 256 * it;
+            int ly, lx;
             dreg[it] = 0.0f;
-            if (idx >= DW * DH)
+            if (!cell_of(it, &ly, &lx))
                 continue;
-            const int ly = idx / DW, lx = idx - ly * DW;
             const int ci = (ly + S) * RW + (lx + S); // (x, y) in the Lx / Ly tiles: their origin is (x0 - S - 1, y0 - S - 1)
             float lxx, lxy, tmp, lyy;
             pattern_lds<S, RW>(&tx[ci], nrm, wn, &lxx, &lxy);
@@ -798,11 +834,10 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
 #pragma unroll
     for (int it = 0; it < DITERS; it++)
     {
-        const int idx = threadIdx.x + 256 * it;
+        int ly, lx;
         dreg[it] = 0.0f;
-        if (idx >= DW * DH)
+        if (!cell_of(it, &ly, &lx))
             continue;
-        const int ly = idx / DW, lx = idx - ly * DW;
         const int x = x0 - 1 + lx, y = y0 - 1 + ly;
         if (x < 0 || x >= w || y < 0 || y >= h)
             continue;
@@ -826,9 +861,9 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
 #pragma unroll
     for (int it = 0; it < DITERS; it++)
     {
-        const int idx = threadIdx.x + 256 * it;
-        if (idx < DW * DH)
-            td[idx] = dreg[it];
+        int ly, lx;
+        if (cell_of(it, &ly, &lx))
+            td[ly * DW + lx] = dreg[it];
     }
     __syncthreads();
     // one wavefront per tile row: the row's maxima as one 64-bit word of the level's bit mask, the responses only where a

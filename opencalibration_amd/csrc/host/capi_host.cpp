@@ -4,6 +4,8 @@
 
 #include "match_features.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <thread>
 
@@ -98,6 +100,55 @@ void och_image_to_3d(const double *px, size_t n, const double *m10, double *rays
     m.tangential_distortion[1] = m10[7];
     for (size_t i = 0; i < n; i++)
         image_to_3d(px + 2 * i, m, rays + 3 * i);
+}
+
+// ransac<fundamental_matrix_model> (model 0) / ransac<essential_matrix_model> (model 1) on the device for one set of
+// correspondences (rays6: n x {measurement1, measurement2}; quality: n or NULL).  The PROSAC order (std::sort of the
+// indices by quality, ransac.cpp:83-90) and the shuffled evaluation order (:158) come from libstdc++ here, as for the
+// homography model.  M9: the model, inliers: n flags, counts3: {iterations, improvements, inliers}.  Returns the score
+// (ransac()'s return value), NAN on a device error.
+double och_ransac_epipolar(ochip_ctx *ctx, int model, const double *rays6, const double *quality, size_t n, double threshold,
+                           double *M9, uint8_t *inliers, uint32_t *counts3)
+{
+    static EvalOrderCache cache;
+    bool has_quality = false;
+    for (size_t i = 0; quality && i < n; i++)
+        has_quality = has_quality || quality[i] != 0;
+    std::vector<uint32_t> sorted_idx(std::max<size_t>(n, 1), 0);
+    if (has_quality)
+    {
+        std::vector<size_t> idx(n);
+        for (size_t i = 0; i < n; i++)
+            idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [quality](size_t a, size_t b) { return quality[a] < quality[b]; });
+        for (size_t i = 0; i < n; i++)
+            sorted_idx[i] = (uint32_t)idx[i];
+    }
+    const eval_order_entry &eo = cache.get(n);
+    ochip_epipolar_job job{};
+    job.n = (uint32_t)n;
+    job.rng_state = eo.rng_state;
+    job.has_quality = has_quality ? 1u : 0u;
+    ochip_ransac_result res{};
+    std::vector<uint8_t> inl(std::max<size_t>(n, 1), 0);
+    std::vector<uint32_t> order(eo.order.begin(), eo.order.end());
+    if (order.empty())
+        order.push_back(0);
+    const double none[6] = {0, 0, 1, 0, 0, 1};
+    if (ochip_ransac_epipolar_batch(ctx, model, &job, 1, n ? rays6 : none, sorted_idx.data(), n, order.data(), n, threshold, &res,
+                                    inl.data()) != OCHIP_OK)
+        return NAN;
+    if (M9)
+        std::memcpy(M9, res.H, 72);
+    if (inliers)
+        std::memcpy(inliers, inl.data(), n);
+    if (counts3)
+    {
+        counts3[0] = res.iterations;
+        counts3[1] = res.improvements;
+        counts3[2] = res.n_inliers;
+    }
+    return res.score;
 }
 
 void och_graph_destroy(och_graph *g)

@@ -294,7 +294,14 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
     const int tail_threads = host_threads > 0 ? host_threads : omp_get_max_threads();
     const int max_length_pixels = 1600;
     const double scale = std::min(1.f, float(max_length_pixels) / (float)std::max(width, height));
-    const uint32_t chunk = std::min(extract_chunk_size(), n_images);
+    // Images that start in host memory (the reference's boundary: a cv::Mat per image) are uploaded by the launch sequence
+    // that extracts them, one copy per chunk on the sequence's stream.  With chunks of 100 a sequence's 3.6 GB copy takes
+    // three times as long as its kernels and the four sequences in flight mostly wait for the link together; chunks of 25
+    // keep the PCIe link busy under the other sequences' kernels (OCHIP_EXTRACT_CHUNK_HOST).
+    uint32_t host_chunk = 25;
+    if (const char *e = std::getenv("OCHIP_EXTRACT_CHUNK_HOST"))
+        host_chunk = (uint32_t)std::max(1L, std::min(1024L, std::atol(e)));
+    const uint32_t chunk = std::min(images_on_device ? extract_chunk_size() : host_chunk, n_images);
     const size_t image_bytes = (size_t)width * height * 3;
 
     // Driver threads (one per device context: the caller's and its siblings) keep the device busy - a chunk's

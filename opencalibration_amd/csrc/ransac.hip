@@ -1269,6 +1269,660 @@ __global__ __launch_bounds__(W, 2) void refit_homography_kernel(
         results[job_id] = res;
 }
 
+// ---- a9: the fundamental- and essential-matrix models (src/model_inliers/fundamental_matrix_model.cpp:12-217,
+//      essential_matrix_model.cpp:12-123) under the same ransac<Model> loop (ransac.cpp:53-257).  No pipeline stage calls
+//      them (link_stage.cpp:91-98 instantiates the homography model only); the reference's unit tests and benchmarks do.
+//      One wavefront per job as above: the loop is wave-uniform; the 64 lanes share the scoring walks (Sampson error per
+//      correspondence, MSAC sum in walk order, SPRT exit) and the 81 entries of A'A; the Jacobi SVDs (9 x 9 of A'A for
+//      the null vector, 3 x 3 for the rank / singular-value constraint and DEGENSAC's epipole) are a few hundred
+//      dependent rotations and run on one lane out of LDS.  Eigen::JacobiSVD is restated from its algorithm (two-sided
+//      Jacobi on the scaled matrix, sweeps p > q until every off-diagonal pair is below precision * max |diagonal|,
+//      singular values positive and sorted decreasing); DEGENSAC's homography fits are the kernel's own
+//      (full_piv_lu_solve9, fit_inliers).
+struct emodel_t
+{
+    double F[9]; // row-major
+};
+
+__device__ __forceinline__ double sampson_error(const emodel_t &m, double x1, double y1, double x2, double y2)
+{
+    const double *F = m.F;
+    const double fx = F[0] * x1 + F[1] * y1 + F[2] * 1.0, fy = F[3] * x1 + F[4] * y1 + F[5] * 1.0,
+                 fz = F[6] * x1 + F[7] * y1 + F[8] * 1.0;                                    // F x1
+    const double tx = F[0] * x2 + F[3] * y2 + F[6] * 1.0, ty = F[1] * x2 + F[4] * y2 + F[7] * 1.0; // F' x2 (first two)
+    const double x2tFx1 = x2 * fx + y2 * fy + 1.0 * fz;
+    const double denom = fx * fx + fy * fy + tx * tx + ty * ty;
+    if (denom < 1e-20)
+        return 1.7976931348623157e308;
+    return sqrt((x2tFx1 * x2tFx1) / denom);
+}
+
+// the scoring walk of score_model with the Sampson error (same accumulation: one element at a time in walk order)
+template <bool ORDERED>
+__device__ double score_epipolar(const emodel_t &m, const pair_data &pd, const uint32_t *__restrict__ order, uint8_t *flags, double thr,
+                                 double best_score, bool *rejected, uint32_t *n_inliers)
+{
+    const int lane = threadIdx.x;
+    const uint32_t M = pd.M;
+    const double *X1 = ORDERED ? pd.ex1 : pd.x1, *Y1 = ORDERED ? pd.ey1 : pd.y1, *X2 = ORDERED ? pd.ex2 : pd.x2,
+                 *Y2 = ORDERED ? pd.ey2 : pd.y2;
+    double s = 0;
+    uint32_t count = 0;
+    *rejected = false;
+    for (uint32_t base = 0; base < M; base += W)
+    {
+        const uint32_t pos = base + lane;
+        const bool valid = pos < M;
+        const uint32_t idx = valid ? (ORDERED ? order[pos] : pos) : 0;
+        const double e = valid ? sampson_error(m, X1[pos], Y1[pos], X2[pos], Y2[pos]) : 1.7976931348623157e308;
+        const bool inl = valid && (e < thr);
+        double term = 0;
+        if (inl)
+        {
+            const double ratio = e / thr;
+            term = 1.0 - ratio * ratio;
+        }
+        if (valid)
+            flags[idx] = inl ? 1 : 0;
+        const unsigned long long mask = __ballot(inl);
+        count += __popcll(mask);
+        double pref = s;
+        if (mask)
+        {
+#pragma unroll
+            for (int l = 0; l < W; l++)
+            {
+                s = s + bcast(term, l);
+                if (ORDERED)
+                    pref = lane == l ? s : pref;
+            }
+        }
+        if (ORDERED)
+        {
+            const uint32_t checked = pos + 1;
+            const bool rej = valid && checked > 20 && best_score > 0 && pref < best_score * (double)checked / (double)M * 0.6;
+            if (__ballot(rej))
+            {
+                *rejected = true;
+                return s;
+            }
+        }
+    }
+    *n_inliers = count;
+    return s;
+}
+
+// JacobiRotation::makeJacobi(x, y, z) for the real symmetric 2 x 2 block [x y; y z]
+__device__ __forceinline__ void make_jacobi(double x, double y, double z, double *c, double *sn)
+{
+    const double deno = 2.0 * fabs(y);
+    if (deno < 2.2250738585072014e-308)
+    {
+        *c = 1.0;
+        *sn = 0.0;
+        return;
+    }
+    const double tau = (x - z) / deno;
+    const double w = sqrt(tau * tau + 1.0);
+    const double t = tau > 0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+    const double sign_t = t > 0 ? 1.0 : -1.0;
+    const double n = 1.0 / sqrt(t * t + 1.0);
+    *c = n;
+    *sn = -sign_t * (y / fabs(y)) * fabs(t) * n;
+}
+
+// Eigen::JacobiSVD<Matrix<double, n, n>>(ComputeFullU | ComputeFullV) on row-major n x n arrays in LDS; ONE lane runs it.
+// Wm: the matrix (destroyed), U, V: n x n, S: n.
+__device__ void jacobi_svd_lane(double *Wm, int n, double *U, double *S, double *V)
+{
+    const double precision = 2.0 * 2.220446049250313e-16, consider_as_zero = 2.2250738585072014e-308;
+    double scale = 0;
+    for (int i = 0; i < n * n; i++)
+        scale = fmax(scale, fabs(Wm[i]));
+    if (scale == 0)
+        scale = 1;
+    for (int i = 0; i < n * n; i++)
+    {
+        Wm[i] /= scale;
+        U[i] = V[i] = 0.0;
+    }
+    for (int i = 0; i < n; i++)
+        U[i * n + i] = V[i * n + i] = 1.0;
+    double max_diag = 0;
+    for (int i = 0; i < n; i++)
+        max_diag = fmax(max_diag, fabs(Wm[i * n + i]));
+    bool finished = false;
+    while (!finished)
+    {
+        finished = true;
+        for (int p = 1; p < n; p++)
+            for (int q = 0; q < p; q++)
+            {
+                const double threshold = fmax(consider_as_zero, precision * max_diag);
+                if (fabs(Wm[p * n + q]) > threshold || fabs(Wm[q * n + p]) > threshold)
+                {
+                    finished = false;
+                    // real_2x2_jacobi_svd: a rotation that makes the block symmetric, then makeJacobi
+                    const double m00 = Wm[p * n + p], m01 = Wm[p * n + q], m10 = Wm[q * n + p], m11 = Wm[q * n + q];
+                    const double t = m00 + m11, d = m10 - m01;
+                    double r1c, r1s;
+                    if (fabs(d) < 2.2250738585072014e-308)
+                        r1c = 1.0, r1s = 0.0;
+                    else
+                    {
+                        const double u = t / d, tmp = sqrt(1.0 + u * u);
+                        r1c = u / tmp;
+                        r1s = 1.0 / tmp;
+                    }
+                    const double n00 = r1c * m00 + r1s * m10, n01 = r1c * m01 + r1s * m11, n11 = -r1s * m01 + r1c * m11;
+                    double jrc, jrs;
+                    make_jacobi(n00, n01, n11, &jrc, &jrs);
+                    // j_left = rot1 * j_right.transpose()
+                    const double jtc = jrc, jts = -jrs;
+                    const double jlc = r1c * jtc - r1s * jts, jls = r1c * jts + r1s * jtc;
+                    for (int k = 0; k < n; k++) // Wm.applyOnTheLeft(p, q, j_left)
+                    {
+                        const double x = Wm[p * n + k], y = Wm[q * n + k];
+                        Wm[p * n + k] = jlc * x + jls * y;
+                        Wm[q * n + k] = -jls * x + jlc * y;
+                    }
+                    for (int k = 0; k < n; k++) // U.applyOnTheRight(p, q, j_left.transpose())
+                    {
+                        const double x = U[k * n + p], y = U[k * n + q];
+                        U[k * n + p] = jlc * x - (-jls) * y;
+                        U[k * n + q] = (-jls) * x + jlc * y;
+                    }
+                    for (int k = 0; k < n; k++) // Wm.applyOnTheRight(p, q, j_right)
+                    {
+                        const double x = Wm[k * n + p], y = Wm[k * n + q];
+                        Wm[k * n + p] = jrc * x - jrs * y;
+                        Wm[k * n + q] = jrs * x + jrc * y;
+                    }
+                    for (int k = 0; k < n; k++) // V.applyOnTheRight(p, q, j_right)
+                    {
+                        const double x = V[k * n + p], y = V[k * n + q];
+                        V[k * n + p] = jrc * x - jrs * y;
+                        V[k * n + q] = jrs * x + jrc * y;
+                    }
+                    max_diag = fmax(max_diag, fmax(fabs(Wm[p * n + p]), fabs(Wm[q * n + q])));
+                }
+            }
+    }
+    for (int i = 0; i < n; i++)
+    {
+        const double a = Wm[i * n + i];
+        S[i] = fabs(a);
+        if (a < 0)
+            for (int k = 0; k < n; k++)
+                U[k * n + i] = -U[k * n + i];
+        S[i] *= scale;
+    }
+    for (int i = 0; i < n; i++) // decreasing singular values, the columns of U and V follow
+    {
+        int pos = i;
+        for (int k = i + 1; k < n; k++)
+            if (S[k] > S[pos])
+                pos = k;
+        if (S[pos] == 0)
+            break;
+        if (pos != i)
+        {
+            const double ts = S[i];
+            S[i] = S[pos];
+            S[pos] = ts;
+            for (int k = 0; k < n; k++)
+            {
+                const double tu = U[k * n + i], tv = V[k * n + i];
+                U[k * n + i] = U[k * n + pos];
+                U[k * n + pos] = tu;
+                V[k * n + i] = V[k * n + pos];
+                V[k * n + pos] = tv;
+            }
+        }
+    }
+}
+
+// LDS work area of the SVDs
+struct svd_lds
+{
+    double A[81], U[81], V[81], S[9], B[9], U3[9], V3[9], S3[3], out[9];
+};
+
+// the rank-2 / equal-singular-value constraint (calculateFundamentalMatrix / calculateEssentialMatrix second halves) on the
+// 3 x 3 matrix in L.B -> L.out.  One lane.
+__device__ void enforce_rank2_lane(svd_lds &L, bool equal_singular_values)
+{
+    jacobi_svd_lane(L.B, 3, L.U3, L.S3, L.V3);
+    double sv[3] = {L.S3[0], L.S3[1], 0.0};
+    if (equal_singular_values)
+        sv[0] = sv[1] = (L.S3[0] + L.S3[1]) / 2.0;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+        {
+            double v = 0;
+            for (int k = 0; k < 3; k++)
+                v += L.U3[r * 3 + k] * sv[k] * L.V3[c * 3 + k];
+            L.out[r * 3 + c] = v;
+        }
+}
+
+// entry i of the row  x x', x y', x, y x', y y', y, x', y', 1  of a correspondence
+__device__ __forceinline__ double epi_row(double x, double y, double x_, double y_, int i)
+{
+    switch (i)
+    {
+    case 0:
+        return x * x_;
+    case 1:
+        return x * y_;
+    case 2:
+        return x;
+    case 3:
+        return y * x_;
+    case 4:
+        return y * y_;
+    case 5:
+        return y;
+    case 6:
+        return x_;
+    case 7:
+        return y_;
+    default:
+        return 1.0;
+    }
+}
+
+// model from A'A in L.A (all lanes arrive; lane 0 works): null vector, constraint -> m
+__device__ void epipolar_from_gram(svd_lds &L, bool essential, emodel_t &m)
+{
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        jacobi_svd_lane(L.A, 9, L.U, L.S, L.V);
+        for (int e = 0; e < 9; e++)
+            L.B[e] = L.V[e * 9 + 8];
+        enforce_rank2_lane(L, essential);
+    }
+    __syncthreads();
+    for (int e = 0; e < 9; e++)
+        m.F[e] = L.out[e];
+    __syncthreads();
+}
+
+// fit on a minimal sample (fit(), :41-61 / :39-58): rows in sample order
+template <int K> __device__ void epipolar_fit_sample(const pair_data &pd, const uint32_t *s, svd_lds &L, bool essential, emodel_t &m)
+{
+    __syncthreads();
+    for (int e = threadIdx.x; e < 81; e += W)
+    {
+        const int i = e / 9, j = e % 9;
+        double v = 0;
+        for (int k = 0; k < K; k++)
+        {
+            const double x = pd.x1[s[k]], y = pd.y1[s[k]], x_ = pd.x2[s[k]], y_ = pd.y2[s[k]];
+            v += epi_row(x, y, x_, y_, i) * epi_row(x, y, x_, y_, j);
+        }
+        L.A[e] = v;
+    }
+    epipolar_from_gram(L, essential, m);
+}
+
+// fitInliers (:63-90 / :60-87) on the flags `inl`, of which n_in are set: returns false (model untouched) below K
+template <int K>
+__device__ bool epipolar_fit_inliers(const pair_data &pd, const uint8_t *inl, uint32_t n_in, svd_lds &L, bool essential, emodel_t &m)
+{
+    if (n_in < (uint32_t)K)
+        return false;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 81; e += W)
+    {
+        const int i = e / 9, j = e % 9;
+        double v = 0;
+        for (uint32_t k = 0; k < pd.M; k++)
+            if (inl[k])
+            {
+                const double x = pd.x1[k], y = pd.y1[k], x_ = pd.x2[k], y_ = pd.y2[k];
+                v += epi_row(x, y, x_, y_, i) * epi_row(x, y, x_, y_, j);
+            }
+        L.A[e] = v;
+    }
+    epipolar_from_gram(L, essential, m);
+    return true;
+}
+
+template <int K> __device__ __forceinline__ void draw_distinct_k(uint32_t &rng, uint32_t hi, int first, uint32_t *c)
+{
+    const uniform_range range = make_range(hi);
+    for (int j = first; j < K; j++)
+    {
+        uint32_t cand;
+        bool unique;
+        do
+        {
+            cand = uniform_int(rng, range);
+            unique = true;
+            for (int k = first; k < j; k++)
+                if (c[k] == cand)
+                    unique = false;
+        } while (!unique);
+        c[j] = cand;
+    }
+}
+
+// fundamental_matrix_model::checkDegeneracy (DEGENSAC, :123-215).  inl: the model's inlier flags (rewritten when the
+// candidate wins); f1 / f2 / f3: three more flag arrays of M bytes.  Returns the number of inliers of `inl` afterwards.
+__device__ uint32_t degensac(const pair_data &pd, emodel_t &model, uint8_t *&inl, uint8_t *f1, uint8_t *&f2, uint8_t *f3, uint32_t n_f,
+                             double thr, double *P9, double *T9, svd_lds &L)
+{
+    const int lane = threadIdx.x;
+    const uint32_t M = pd.M;
+    if (n_f < 4)
+        return n_f;
+    // the first four F inliers in index order
+    uint32_t h4[4] = {0, 0, 0, 0};
+    {
+        uint32_t found = 0;
+        for (uint32_t base = 0; base < M && found < 4; base += W)
+        {
+            const uint32_t i = base + lane;
+            const unsigned long long mask = __ballot(i < M && inl[i]);
+            unsigned long long mm = mask;
+            while (mm && found < 4)
+            {
+                h4[found++] = base + (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+            }
+        }
+    }
+    const double thr2 = thr * 2;
+    model_t h;
+    __syncthreads();
+    if (lane < 4)
+        write_dlt_rows(P9, 9, 2 * lane, pd.x1[h4[lane]], pd.y1[h4[lane]], pd.x2[h4[lane]], pd.y2[h4[lane]]);
+    if (lane < 9)
+        P9[lane * 9 + 8] = lane == 8 ? 1.0 : 0.0;
+    double sol[9];
+    full_piv_lu_solve9(P9, 9, sol);
+    model_from_solution(h, sol);
+    // F inliers that are also inliers of that homography
+    uint32_t h_count = 0;
+    for (uint32_t base = 0; base < M; base += W)
+    {
+        const uint32_t i = base + lane;
+        bool f = false;
+        if (i < M)
+        {
+            f = inl[i] && transfer_error(h, pd.x1[i], pd.y1[i], pd.x2[i], pd.y2[i]) < thr2;
+            f1[i] = f ? 1 : 0;
+        }
+        h_count += __popcll(__ballot(f));
+    }
+    const double h_ratio = (double)h_count / (double)n_f;
+    if (h_ratio < 0.7)
+        return n_f;
+    __syncthreads();
+    {
+        pair_data ph = pd;
+        ph.inl = f1;
+        fit_inliers(ph, h_count, T9, h);
+    }
+    __syncthreads();
+    // off-plane F inliers: their Gram matrix of (x2 x H x1)
+    uint32_t non_h = 0;
+    for (uint32_t base = 0; base < M; base += W)
+    {
+        const uint32_t i = base + lane;
+        bool off = false;
+        if (i < M)
+        {
+            off = inl[i] && !(transfer_error(h, pd.x1[i], pd.y1[i], pd.x2[i], pd.y2[i]) < thr2);
+            f3[i] = off ? 1 : 0;
+        }
+        non_h += __popcll(__ballot(off));
+    }
+    if (non_h < 2)
+        return n_f;
+    __syncthreads();
+    if (lane < 9)
+    {
+        const int a = lane / 3, b = lane % 3;
+        double v = 0;
+        for (uint32_t i = 0; i < M; i++)
+            if (f3[i])
+            {
+                const double x1 = pd.x1[i], y1 = pd.y1[i], x2 = pd.x2[i], y2 = pd.y2[i];
+                const double hx = h.H[0] * x1 + h.H[1] * y1 + h.H[2] * 1.0, hy = h.H[3] * x1 + h.H[4] * y1 + h.H[5] * 1.0,
+                             hz = h.H[6] * x1 + h.H[7] * y1 + h.H[8] * 1.0;
+                const double r[3] = {y2 * hz - 1.0 * hy, 1.0 * hx - x2 * hz, x2 * hy - y2 * hx}; // x2 x (H x1)
+                v += r[a] * r[b];
+            }
+        L.B[lane] = v;
+    }
+    __syncthreads();
+    if (lane == 0)
+    {
+        // the epipole: the right singular vector of the smallest singular value (the eigenvector of the Gram matrix's)
+        jacobi_svd_lane(L.B, 3, L.U3, L.S3, L.V3);
+        const double ex = L.V3[0 * 3 + 2], ey = L.V3[1 * 3 + 2], ez = L.V3[2 * 3 + 2];
+        const double ec[9] = {0, -ez, ey, ez, 0, -ex, -ey, ex, 0};
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++)
+            {
+                double v = 0;
+                for (int k = 0; k < 3; k++)
+                    v += ec[r * 3 + k] * h.H[k * 3 + c];
+                L.B[r * 3 + c] = v;
+            }
+        enforce_rank2_lane(L, false);
+    }
+    __syncthreads();
+    emodel_t cand;
+    for (int e = 0; e < 9; e++)
+        cand.F[e] = L.out[e];
+    __syncthreads();
+    // keep the candidate only if it scores better (both evaluated in natural order)
+    bool dummy;
+    uint32_t n_c = 0, n_o = 0;
+    const double candidate_score = score_epipolar<false>(cand, pd, nullptr, f2, thr, 0.0, &dummy, &n_c);
+    __syncthreads();
+    const double original_score = score_epipolar<false>(model, pd, nullptr, inl, thr, 0.0, &dummy, &n_o);
+    __syncthreads();
+    if (candidate_score > original_score)
+    {
+        model = cand;
+        uint8_t *t = inl;
+        inl = f2;
+        f2 = t;
+        return n_c;
+    }
+    return n_o;
+}
+
+struct ochip_epipolar_job_dev
+{
+    uint32_t n, rng_state, has_quality, reserved;
+    uint64_t corr_offset, eval_offset;
+};
+
+template <int K, bool ESSENTIAL>
+__global__ __launch_bounds__(W, 2) void ransac_epipolar_kernel(
+    const ochip_epipolar_job_dev *__restrict__ jobs, const double *__restrict__ corr6, const uint32_t *__restrict__ sorted_idx_all,
+    const uint32_t *__restrict__ eval_order_all, double *__restrict__ coord_scratch /*8 x total*/,
+    uint8_t *__restrict__ flag_scratch /*5 x total*/, double *__restrict__ P_scratch /*9 x (2 total + n_jobs)*/, uint64_t total,
+    double thr, ochip_ransac_result *__restrict__ results, uint8_t *__restrict__ inliers_out)
+{
+    __shared__ double P9[81], T9[81];
+    __shared__ svd_lds L;
+    const int lane = threadIdx.x;
+    const uint32_t job_id = blockIdx.x;
+    const ochip_epipolar_job_dev job = jobs[job_id];
+    const uint32_t M = job.n;
+    const uint64_t mo = job.corr_offset;
+    ochip_ransac_result res;
+    for (int i = 0; i < 9; i++)
+        res.H[i] = __builtin_nan("");
+    res.score = 0;
+    res.iterations = 0;
+    res.n_inliers = 0;
+    res.improvements = 0;
+    res.reserved = 0;
+    if (M < (uint32_t)K) // ransac.cpp:69-72
+    {
+        for (uint32_t i = lane; i < M; i += W)
+            inliers_out[mo + i] = 0;
+        if (lane == 0)
+            results[job_id] = res;
+        return;
+    }
+    const uint32_t *sorted_idx = sorted_idx_all + mo;
+    const uint32_t *eval_order = eval_order_all + job.eval_offset;
+    pair_data pd;
+    double *cx1 = coord_scratch + mo, *cy1 = coord_scratch + total + mo, *cx2 = coord_scratch + 2 * total + mo,
+           *cy2 = coord_scratch + 3 * total + mo;
+    double *ex1 = coord_scratch + 4 * total + mo, *ey1 = coord_scratch + 5 * total + mo, *ex2 = coord_scratch + 6 * total + mo,
+           *ey2 = coord_scratch + 7 * total + mo;
+    for (uint32_t i = lane; i < M; i += W)
+    {
+        const double *c = corr6 + 6 * (mo + i), *ce = corr6 + 6 * (mo + eval_order[i]);
+        cx1[i] = c[0] / c[2];
+        cy1[i] = c[1] / c[2];
+        cx2[i] = c[3] / c[5];
+        cy2[i] = c[4] / c[5];
+        ex1[i] = ce[0] / ce[2];
+        ey1[i] = ce[1] / ce[2];
+        ex2[i] = ce[3] / ce[5];
+        ey2[i] = ce[4] / ce[5];
+    }
+    const bool has_quality = job.has_quality != 0;
+    __syncthreads();
+    pd.x1 = cx1, pd.y1 = cy1, pd.x2 = cx2, pd.y2 = cy2;
+    pd.ex1 = ex1, pd.ey1 = ey1, pd.ex2 = ex2, pd.ey2 = ey2;
+    pd.cand = flag_scratch + mo;
+    pd.inl = flag_scratch + total + mo;
+    uint8_t *f1 = flag_scratch + 2 * total + mo, *f2 = flag_scratch + 3 * total + mo, *f3 = flag_scratch + 4 * total + mo;
+    pd.P = P_scratch + 9 * (2 * mo + job_id);
+    pd.M = M;
+
+    emodel_t model, best_model;
+    for (int e = 0; e < 9; e++)
+        model.F[e] = best_model.F[e] = __builtin_nan("");
+    double best_score = 0;
+    uint32_t rng = job.rng_state;
+    uint32_t prosac_n = has_quality ? (uint32_t)K : M;
+    uint32_t probability_iterations = MAX_ITERATIONS;
+    const double log_1m_p = log(1 - 0.999);
+    uint32_t it = 0;
+    for (; it < probability_iterations; it++)
+    {
+        if (has_quality && prosac_n < M && it > 0 && it % 10 == 0)
+            prosac_n++;
+        uint32_t sk[K], c[K];
+        if (has_quality && prosac_n < M && prosac_n > (uint32_t)K)
+        {
+            c[0] = prosac_n - 1;
+            draw_distinct_k<K>(rng, prosac_n - 2, 1, c);
+            for (int j = 0; j < K; j++)
+                sk[j] = sorted_idx[c[j]];
+        }
+        else
+        {
+            draw_distinct_k<K>(rng, (has_quality ? prosac_n : M) - 1, 0, c);
+            for (int j = 0; j < K; j++)
+                sk[j] = has_quality ? sorted_idx[c[j]] : c[j];
+        }
+        epipolar_fit_sample<K>(pd, sk, L, ESSENTIAL, model);
+        bool rejected;
+        uint32_t n_inl = 0;
+        const double score = score_epipolar<true>(model, pd, eval_order, pd.cand, thr, best_score, &rejected, &n_inl);
+        if (rejected)
+            continue;
+        if (score > best_score)
+        {
+            res.improvements++;
+            best_model = model;
+            best_score = score;
+            __syncthreads();
+            {
+                uint8_t *t = pd.cand; // inliers = candidate flags of this model
+                pd.cand = pd.inl;
+                pd.inl = t;
+            }
+            uint32_t n_in = n_inl;
+            if (!ESSENTIAL)
+            {
+                // checkDegeneracy, then model.evaluate(matches, inliers) (ransac.cpp:213-222)
+                n_in = degensac(pd, model, pd.inl, f1, f2, f3, n_in, thr, P9, T9, L);
+                bool dummy;
+                uint32_t cnt = 0;
+                __syncthreads();
+                const double degen_score = score_epipolar<false>(model, pd, nullptr, pd.inl, thr, 0.0, &dummy, &cnt);
+                __syncthreads();
+                n_in = cnt;
+                if (degen_score > best_score)
+                {
+                    best_model = model;
+                    best_score = degen_score;
+                }
+            }
+            // local optimisation (ransac.cpp:224-245)
+            for (uint32_t j = 0; j < MAX_INNER_ITERATIONS; j++)
+            {
+                epipolar_fit_inliers<K>(pd, pd.inl, n_in, L, ESSENTIAL, model);
+                bool dummy;
+                uint32_t cnt = 0;
+                __syncthreads();
+                const double inlier_score = score_epipolar<false>(model, pd, nullptr, pd.inl, thr, 0.0, &dummy, &cnt);
+                __syncthreads();
+                n_in = cnt;
+                if (inlier_score > best_score)
+                {
+                    best_model = model;
+                    best_score = inlier_score;
+                }
+                else
+                    break;
+            }
+            const double omega = best_score / (double)M;
+            double omega_n;
+            if (K == 8)
+            {
+                double t = omega * omega;
+                t = t * t;
+                omega_n = t * t; // fast_pow<8>
+            }
+            else
+            {
+                const double t = omega * omega;
+                omega_n = t * t * omega; // fast_pow<5>
+            }
+            const double log_1m_omega_n = log(1 - omega_n);
+            const double q = log_1m_p / log_1m_omega_n;
+            uint64_t qi;
+            if (!(q == q))
+                qi = 0x8000000000000000ull;
+            else if (q >= 9223372036854775808.0)
+                qi = (q >= 18446744073709551616.0) ? 0ull : (uint64_t)q;
+            else if (q <= -1.0)
+                qi = (uint64_t)(int64_t)q;
+            else
+                qi = (uint64_t)q;
+            const uint64_t clamped = qi < MAX_ITERATIONS ? qi : MAX_ITERATIONS;
+            probability_iterations = (uint32_t)(clamped > MIN_ITERATIONS ? clamped : MIN_ITERATIONS);
+        }
+    }
+    bool dummy;
+    uint32_t cnt = 0;
+    __syncthreads();
+    const double final_score = score_epipolar<false>(best_model, pd, nullptr, inliers_out + mo, thr, 0.0, &dummy, &cnt);
+    for (int i = 0; i < 9; i++)
+        res.H[i] = best_model.F[i];
+    res.score = final_score / (double)M;
+    res.iterations = it;
+    res.n_inliers = cnt;
+    if (lane == 0)
+        results[job_id] = res;
+}
+
 // pixel -> unit ray, distort_keypoints.cpp:68-103 (csrc/undistort.hpp: lens distortion is inverted per keypoint with
 // the restated TinySolver; one thread per keypoint, the solver's <= 10 iterations are a few hundred flops)
 __global__ void keypoints_to_rays_kernel(const double *__restrict__ xy, const double *__restrict__ models /*[img][8]*/,
@@ -1505,6 +2159,71 @@ int ochip_refit_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, u
     if (total_matches)
         OCHIP_HIP(ctx, hipMemcpyAsync(inliers, inl_dev, (size_t)total_matches, hipMemcpyDeviceToHost, ctx->stream));
     OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
+    return OCHIP_OK;
+}
+
+
+int ochip_ransac_epipolar_batch(ochip_ctx *ctx, int model, const ochip_epipolar_job *jobs, uint32_t n_jobs, const double *corr6,
+                                const uint32_t *sorted_idx, uint64_t total, const uint32_t *eval_order, uint64_t eval_total,
+                                double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers)
+{
+    static_assert(sizeof(ochip_epipolar_job) == sizeof(ochip_epipolar_job_dev), "job layout");
+    if (!ctx)
+        return OCHIP_EINVAL;
+    if (n_jobs == 0)
+        return OCHIP_OK;
+    if (model != 0 && model != 1)
+        return ochip_fail(ctx, OCHIP_EINVAL, "model %d: 0 = fundamental matrix, 1 = essential matrix", model);
+    if (!jobs || !results || (total && (!corr6 || !sorted_idx || !inliers)) || (eval_total && !eval_order))
+        return ochip_fail(ctx, OCHIP_EINVAL, "NULL argument");
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t j = 0; j < n_jobs; j++)
+        if (jobs[j].corr_offset + jobs[j].n > total || jobs[j].eval_offset + jobs[j].n > eval_total)
+            return ochip_fail(ctx, OCHIP_EINVAL, "job %u: offsets exceed the arrays", j);
+    const uint64_t T = total ? total : 1;
+    const size_t sizes[8] = {(size_t)n_jobs * sizeof(ochip_epipolar_job),
+                             (size_t)T * 48,
+                             (size_t)T * 4,
+                             (size_t)(eval_total ? eval_total : 1) * 4,
+                             (size_t)T * 64,
+                             (size_t)T * 5,
+                             (size_t)(2 * T + n_jobs) * 72,
+                             (size_t)n_jobs * sizeof(ochip_ransac_result) + T};
+    for (int i = 0; i < 8; i++)
+    {
+        const int rc = ochip_ensure(ctx, &ctx->scratch_dev[i], &ctx->scratch_cap[i], sizes[i]);
+        if (rc)
+            return rc;
+    }
+    hipStream_t st = ctx->stream;
+    OCHIP_HIP(ctx, hipMemcpyAsync(ctx->scratch_dev[0], jobs, sizes[0], hipMemcpyHostToDevice, st));
+    if (total)
+    {
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->scratch_dev[1], corr6, (size_t)total * 48, hipMemcpyHostToDevice, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->scratch_dev[2], sorted_idx, (size_t)total * 4, hipMemcpyHostToDevice, st));
+    }
+    if (eval_total)
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->scratch_dev[3], eval_order, (size_t)eval_total * 4, hipMemcpyHostToDevice, st));
+    ochip_ransac_result *res_dev = (ochip_ransac_result *)ctx->scratch_dev[7];
+    uint8_t *inl_dev = (uint8_t *)ctx->scratch_dev[7] + (size_t)n_jobs * sizeof(ochip_ransac_result);
+    hipEvent_t e0, e1;
+    ochip_prof_begin(ctx, OCHIP_K_RANSAC, &e0, &e1);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(n_jobs), dim3(W), 0, st, (const ochip_epipolar_job_dev *)ctx->scratch_dev[0],
+                           (const double *)ctx->scratch_dev[1], (const uint32_t *)ctx->scratch_dev[2], (const uint32_t *)ctx->scratch_dev[3],
+                           (double *)ctx->scratch_dev[4], (uint8_t *)ctx->scratch_dev[5], (double *)ctx->scratch_dev[6], (uint64_t)T,
+                           inlier_threshold, res_dev, inl_dev);
+    };
+    if (model == 0)
+        launch(ransac_epipolar_kernel<8, false>);
+    else
+        launch(ransac_epipolar_kernel<5, true>);
+    ochip_prof_end(ctx, OCHIP_K_RANSAC, e0, e1);
+    OCHIP_HIP(ctx, hipGetLastError());
+    OCHIP_HIP(ctx, hipMemcpyAsync(results, res_dev, (size_t)n_jobs * sizeof(ochip_ransac_result), hipMemcpyDeviceToHost, st));
+    if (total)
+        OCHIP_HIP(ctx, hipMemcpyAsync(inliers, inl_dev, (size_t)total, hipMemcpyDeviceToHost, st));
+    OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
     return OCHIP_OK;
 }
 

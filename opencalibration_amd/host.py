@@ -134,6 +134,8 @@ def load():
         L.och_merge_surfaces.restype = None
         L.och_homography_decompose.argtypes = [_f64p, _f64p, sz, _f64p]
         L.och_image_to_3d.argtypes = [_f64p, sz, _f64p, _f64p]
+        L.och_ransac_epipolar.restype = C.c_double
+        L.och_ransac_epipolar.argtypes = [vp, C.c_int, _f64p, vp, sz, C.c_double, _f64p, u8p, np.ctypeslib.ndpointer(np.uint32)]
         L.och_extract_tail.restype = C.c_size_t
         L.och_extract_tail.argtypes = [_f32p, _u64p, u32, C.c_double, _f64p, _f32p, _u64p, _u64p]
         L.och_graph_set_model.argtypes = [vp, u32, _f64p]
@@ -944,6 +946,20 @@ class Shard:
         totals, timers, secs = np.zeros(2), np.zeros(8), np.zeros(9)
         self._check(self.L.och_shard_finalize(self.h, totals, timers, secs), "finalize")
         return totals[0], totals[1], dict(zip(LINK_TIMER_NAMES, timers.tolist())), dict(zip(SHARD_SECONDS, secs.tolist()))
+
+
+def ransac_epipolar(ctx, model, rays, quality=None, threshold=0.01):
+    """ransac<fundamental_matrix_model> (model 0) / ransac<essential_matrix_model> (model 1) on the device.  rays: n x 6
+    {measurement1, measurement2}.  Returns (score, matrix 3 x 3, inliers, iterations, improvements)."""
+    rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+    n = len(rays)
+    M, inl, counts = np.zeros((3, 3)), np.zeros(max(n, 1), np.uint8), np.zeros(3, np.uint32)
+    q = None if quality is None else np.ascontiguousarray(quality, np.float64)
+    score = load().och_ransac_epipolar(ctx.h, model, rays if n else np.zeros((1, 6)), None if q is None else q.ctypes.data, n,
+                                       float(threshold), M.reshape(9), inl, counts)
+    if score != score and n:
+        raise capi.OchipError("epipolar RANSAC failed: " + ctx.last_error() if hasattr(ctx, "last_error") else "epipolar RANSAC failed")
+    return score, M, inl[:n].astype(bool), int(counts[0]), int(counts[1])
 
 
 def extract_tail(kp6, desc, scale):

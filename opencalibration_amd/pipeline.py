@@ -39,10 +39,12 @@ def relax_step(ctx, g, start_orientation, res, t):
     return rel
 
 
-def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000, overlap=True, relax=True):
+def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000, overlap=True, relax=True, host_images=None):
     """load (extract) -> link -> relax.  Returns (graph, result dict, stage seconds).  overlap: the load and link
     stages run overlapped (och_graph_load_link_images) as the reference's pipeline overlaps the stages of consecutive
-    batches; the graph is the same either way.  relax=False: stop after the link stage (relax_step() does the rest)."""
+    batches; the graph is the same either way.  relax=False: stop after the link stage (relax_step() does the rest).
+    host_images: an (n, h, w, 3) uint8 array in host memory to start from instead of the views in HBM (the upload is then
+    part of the load stage)."""
     n, h, w = shape
     t = {}
     g = host.Graph()
@@ -50,7 +52,8 @@ def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000, ov
     if overlap:
         t0, c0 = time.perf_counter(), time.process_time()
         feats_mean, sparse_mean, link_timers, (t_ex, t_all) = g.load_link_images(
-            ctx, images_ptr, mid, grid.position, start_orientation, max_keypoints, device_shape=(n, h, w))
+            ctx, images_ptr if host_images is None else host_images, mid, grid.position, start_orientation, max_keypoints,
+            device_shape=(n, h, w) if host_images is None else None)
         t["extract"], t["link"] = t_ex, time.perf_counter() - t0 - t_ex   # link = what the linking adds after the last features
         t["host_cpu_load_link"] = time.process_time() - c0                 # CPU seconds of all host threads
         if not relax:
