@@ -198,6 +198,13 @@ class Proc:
             self.dist.destroy_process_group()
 
 
+def relax_memory_report(ctx):
+    """The largest reduced system the relaxes of this process held: unknowns, bytes of J'J + factor as stored (tiles of the
+    block envelope) and what the two matrices would take dense."""
+    n, stored, dense = ctx.relax_memory()
+    return {"unknowns": n, "stored_mbytes": round(stored / 1e6, 2), "dense_mbytes": round(dense / 1e6, 2)}
+
+
 def device_rooflines(ctx, capi, steps, images_per_step, t_extract_per_step, shape, overlap, link_work, edges, staged=None):
     """The `roofline` object: the extract launch sequence against HBM, with the match (VALU) and relax (MFMA) entries."""
     def prof(kid):
@@ -255,7 +262,8 @@ def device_rooflines(ctx, capi, steps, images_per_step, t_extract_per_step, shap
                        "note": "latency-bound: one launch per factorisation, a dependency chain of 64 x 64 tiles inside the block "
                                "envelope (critical path = the diagonal tiles); the time base is the whole linear solve (build, "
                                "factorisation, substitutions, step)",
-                       "flops_per_step": round(relax_flops / max(steps, 1)), "solves": n_solve},
+                       "flops_per_step": round(relax_flops / max(steps, 1)), "solves": n_solve,
+                       "system_memory": relax_memory_report(ctx)},
         "other_kernels_avg_ms": {
             "hamming_2nn_kernel": round(ms_match / max(n_match, 1), 3),
             "ransac_homography_kernel": round(ms_ransac / max(n_ransac, 1), 3),

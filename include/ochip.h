@@ -427,6 +427,10 @@ extern "C"
     /* fp64 flops the relax solves issued on the matrix cores (the panel and trailing-update GEMMs of their Cholesky
      * factorisations, inside the block envelope) since the last ochip_profile_reset; their time is OCHIP_K_RELAX_SOLVE's */
     int ochip_relax_work(ochip_ctx *ctx, double *mfma_flops);
+    /* the largest reduced system a relax on this context (or a sibling) has held: its unknowns, the bytes of J'J and its
+     * factor as stored (64 x 64 tiles of the block envelope, lower triangle) and what the same two matrices take dense -
+     * the reference hands this system to ceres::SPARSE_NORMAL_CHOLESKY (src/relax/relax_problem.cpp:30-37) */
+    int ochip_relax_memory(ochip_ctx *ctx, uint64_t *unknowns, uint64_t *stored_bytes, uint64_t *dense_bytes);
 
     /* ---- diagnostics ----------------------------------------------------------------------------- */
     /* out[i] = x[i] op y[i] computed on the device with the hot-path kernels' compile flags:

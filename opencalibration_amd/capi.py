@@ -28,7 +28,7 @@ EXPORTS = [
     "ochip_relaxg_get_state", "ochip_relaxg_evaluate", "ochip_relaxg_set_exchange",
     "ochip_relaxp_problem_create", "ochip_relaxp_problem_destroy", "ochip_relaxp_set_structure_only", "ochip_relaxp_solve",
     "ochip_relaxp_get_state",
-    "ochip_profile_reset", "ochip_profile_get", "ochip_match_work", "ochip_relax_work",
+    "ochip_profile_reset", "ochip_profile_get", "ochip_match_work", "ochip_relax_work", "ochip_relax_memory",
     "ochip_debug_fp64",
     "ochip_dense_index_create", "ochip_dense_index_destroy", "ochip_dense_match",
     "ochip_rccl_unique_id", "ochip_rccl_comm_create", "ochip_rccl_comm_destroy", "ochip_rccl_comm_stats",
@@ -72,6 +72,7 @@ def load():
         L.ochip_profile_get.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(C.c_double)]
         L.ochip_match_work.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
         L.ochip_relax_work.argtypes = [vp, C.POINTER(C.c_double)]
+        L.ochip_relax_memory.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
         L.ochip_debug_fp64.argtypes = [vp, i32, vp, vp, C.c_size_t, vp]
         L.ochip_akaze_batch.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
         L.ochip_akaze_batch_dev.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
@@ -263,6 +264,12 @@ class Context:
         f = C.c_double()
         self._check(self.L.ochip_relax_work(self.h, C.byref(f)), "ochip_relax_work")
         return f.value
+
+    def relax_memory(self):
+        """(unknowns, bytes stored, bytes dense) of the largest reduced system a relax on this context has held."""
+        n, b, d = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.L.ochip_relax_memory(self.h, C.byref(n), C.byref(b), C.byref(d)), "ochip_relax_memory")
+        return n.value, b.value, d.value
 
     def match_work(self):
         """(computed, delivered) descriptor distances of the match launches since the last profile_reset."""

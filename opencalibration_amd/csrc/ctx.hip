@@ -488,6 +488,25 @@ int ochip_relax_work(ochip_ctx *ctx, double *mfma_flops)
     return OCHIP_OK;
 }
 
+int ochip_relax_memory(ochip_ctx *ctx, uint64_t *unknowns, uint64_t *stored_bytes, uint64_t *dense_bytes)
+{
+    if (!ctx || !unknowns || !stored_bytes || !dense_bytes)
+        return OCHIP_EINVAL;
+    *unknowns = *stored_bytes = *dense_bytes = 0;
+    auto take = [&](const ochip_ctx *c) {
+        if (c->relax_system_unknowns > *unknowns)
+        {
+            *unknowns = c->relax_system_unknowns;
+            *stored_bytes = c->relax_system_bytes;
+            *dense_bytes = c->relax_system_dense_bytes;
+        }
+    };
+    take(ctx);
+    for (ochip_ctx *sib : ctx->siblings)
+        take(sib);
+    return OCHIP_OK;
+}
+
 int ochip_match_work(ochip_ctx *ctx, uint64_t *computed, uint64_t *delivered)
 {
     if (!ctx)

@@ -80,6 +80,7 @@ struct ochip_ctx
     // fp64 multiply-adds x 2 the Cholesky factorisations of the relax solves issued on the matrix cores (panel and
     // trailing-update GEMMs over the rows inside the block envelope) since the last profile reset
     double relax_mfma_flops = 0;
+    uint64_t relax_system_bytes = 0, relax_system_dense_bytes = 0, relax_system_unknowns = 0; // largest reduced system held (relax_lm.hip)
 
     // sibling contexts on the same device (own streams, scratch and pools) handed out by ochip_ctx_sibling so
     // that independent batches can be in flight at once; owned by this context

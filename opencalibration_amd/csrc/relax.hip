@@ -328,7 +328,7 @@ __device__ void downward_prior(const double *q, double weight, double *res, doub
 }
 
 // Per-camera gather: diagonal 3x3, camera-plane 3x3, gradient; plus the prior.  One thread per camera.
-__global__ void relax_scatter_cam_kernel(relax_dev P, double *A, double *g, int n, const uint8_t *cam_has_prior)
+__global__ void relax_scatter_cam_kernel(relax_dev P, lm_matrix A, double *g, int n, const uint8_t *cam_has_prior)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= P.n_cams)
@@ -368,8 +368,7 @@ __global__ void relax_scatter_cam_kernel(relax_dev P, double *A, double *g, int 
     for (int i = 0; i < 3; i++)
         for (int j = i; j < 3; j++)
         {
-            A[(size_t)(tc + i) * n + tc + j] = D[k];
-            A[(size_t)(tc + j) * n + tc + i] = D[k];
+            A.tiles[lm_at(A, tc + j, tc + i)] = D[k]; // (lower triangle only: relax_lm.hpp)
             k++;
         }
     for (int i = 0; i < 3; i++)
@@ -380,15 +379,14 @@ __global__ void relax_scatter_cam_kernel(relax_dev P, double *A, double *g, int 
             const int tz = P.z_t[j];
             if (tz >= 0)
             {
-                A[(size_t)(tc + i) * n + tz] = CZ[i * 3 + j];
-                A[(size_t)tz * n + tc + i] = CZ[i * 3 + j];
+                A.tiles[lm_at(A, tz, tc + i)] = CZ[i * 3 + j]; // (the plane unknowns are the tail: tz > tc)
             }
         }
     }
 }
 
 // Per-pair scatter of the off-diagonal camera-camera block.  One thread per pair.
-__global__ void relax_scatter_pair_kernel(relax_dev P, double *A, int n)
+__global__ void relax_scatter_pair_kernel(relax_dev P, lm_matrix A, int n)
 {
     const uint32_t pr = blockIdx.x * blockDim.x + threadIdx.x;
     if (pr >= P.n_pairs)
@@ -401,13 +399,15 @@ __global__ void relax_scatter_pair_kernel(relax_dev P, double *A, int n)
         for (int j = 0; j < 3; j++)
         {
             const double v = a[tri(i, 3 + j)];
-            A[(size_t)(tp + i) * n + tq + j] = v;
-            A[(size_t)(tq + j) * n + tp + i] = v;
+            if (tp > tq)
+                A.tiles[lm_at(A, tp + i, tq + j)] = v;
+            else
+                A.tiles[lm_at(A, tq + j, tp + i)] = v;
         }
 }
 
 // One workgroup: plane-plane block, plane gradient, total cost (pairs + priors).  scal[0] = cost.
-__global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, double *A, double *g, int n,
+__global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm_matrix A, double *g, int n,
                                                                  const uint8_t *cam_has_prior, double *scal,
                                                                  int with_jac, int which_state)
 {
@@ -462,8 +462,7 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, do
                     const int ti = P.z_t[i], tj = P.z_t[j];
                     if (ti >= 0 && tj >= 0)
                     {
-                        A[(size_t)ti * n + tj] = v[k];
-                        A[(size_t)tj * n + ti] = v[k];
+                        A.tiles[lm_at(A, ti > tj ? ti : tj, ti > tj ? tj : ti)] = v[k];
                     }
                     k++;
                 }
@@ -1048,14 +1047,14 @@ struct plane_model final : lm_model
         }
         if (with_jac)
         {
-            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, (size_t)n * n * 8, st));
+            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, p->sys.matrix_bytes(), st));
             OCHIP_HIP(ctx, hipMemsetAsync(p->sys.g, 0, (size_t)n * 8, st));
-            hipLaunchKernelGGL(relax_scatter_cam_kernel, dim3((D.n_cams + 255) / 256), dim3(256), 0, st, D, p->sys.A, p->sys.g,
+            hipLaunchKernelGGL(relax_scatter_cam_kernel, dim3((D.n_cams + 255) / 256), dim3(256), 0, st, D, p->sys.matA(), p->sys.g,
                                n, p->cam_has_prior);
             if (D.n_pairs)
-                hipLaunchKernelGGL(relax_scatter_pair_kernel, dim3((D.n_pairs + 255) / 256), dim3(256), 0, st, D, p->sys.A, n);
+                hipLaunchKernelGGL(relax_scatter_pair_kernel, dim3((D.n_pairs + 255) / 256), dim3(256), 0, st, D, p->sys.matA(), n);
         }
-        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(1), dim3(256), 0, st, D, p->sys.A, p->sys.g, n, p->cam_has_prior,
+        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(1), dim3(256), 0, st, D, p->sys.matA(), p->sys.g, n, p->cam_has_prior,
                            p->sys.scal, with_jac ? 1 : 0, which);
         OCHIP_HIP(ctx, hipGetLastError());
         double h0 = 0;

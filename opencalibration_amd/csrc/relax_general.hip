@@ -549,7 +549,7 @@ struct work_item
 };
 
 // One wavefront per work item.  strip[a][x]: a < rows of the owner, x over [band strip | tail | gradient].
-__global__ __launch_bounds__(W) void gather_kernel(g_dev P, const work_item *items, const uint32_t *var_rec, double *A, double *g,
+__global__ __launch_bounds__(W) void gather_kernel(g_dev P, const work_item *items, const uint32_t *var_rec, lm_matrix A, double *g,
                                                    int n, int tail_begin, double *partials, int strip_cap)
 {
     extern __shared__ double strip[];
@@ -693,17 +693,15 @@ __global__ __launch_bounds__(W) void gather_kernel(g_dev P, const work_item *ite
         }
         return;
     }
+    // (the system keeps its lower triangle only, relax_lm.hpp: of the band part the columns up to the diagonal; the
+    // columns of the tail are the tail rows' band part, mirrored)
     for (int a = 0; a < su; a++)
     {
-        double *row = A + (size_t)(tu + a) * n;
-        for (int x = lane; x < wb; x += W)
-            row[it.col_lo + x] = strip[a * ws + x];
+        const int r = tu + a;
+        for (int x = lane; x < wb && it.col_lo + x <= r; x += W)
+            A.tiles[lm_at(A, r, it.col_lo + x)] = strip[a * ws + x];
         for (int x = lane; x < T; x += W)
-        {
-            const double v = strip[a * ws + wb + x];
-            row[tail_begin + x] = v;
-            A[(size_t)(tail_begin + x) * n + tu + a] = v; // the tail rows' band part is the mirror image
-        }
+            A.tiles[lm_at(A, tail_begin + x, r)] = strip[a * ws + wb + x];
         if (lane == 0)
             g[tu + a] = strip[a * ws + ws - 1];
     }
@@ -711,7 +709,7 @@ __global__ __launch_bounds__(W) void gather_kernel(g_dev P, const work_item *ite
 
 // tail rows: sum of the chunk partials in chunk order.  One workgroup per tail owner.
 __global__ void tail_merge_kernel(g_dev P, const uint32_t *tail_var, const uint32_t *tail_first, const uint32_t *tail_count,
-                                  const double *partials, double *A, double *g, int n, int tail_begin)
+                                  const double *partials, lm_matrix A, double *g, int n, int tail_begin)
 {
     const uint32_t u = tail_var[blockIdx.x];
     const int tu = P.var_t[u], su = P.var_ts[u];
@@ -724,8 +722,8 @@ __global__ void tail_merge_kernel(g_dev P, const uint32_t *tail_var, const uint3
             v += partials[(size_t)(tail_first[blockIdx.x] + c) * 3 * (T + 1) + a * (T + 1) + x];
         if (x == T)
             g[tu + a] = v;
-        else
-            A[(size_t)(tu + a) * n + tail_begin + x] = v;
+        else if (tail_begin + x <= tu + a)
+            A.tiles[lm_at(A, tu + a, tail_begin + x)] = v;
     }
 }
 
@@ -1200,14 +1198,14 @@ struct general_model final : lm_model
         }
         if (with_jac)
         {
-            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, (size_t)n * n * 8, st));
+            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, p->sys.matrix_bytes(), st));
             OCHIP_HIP(ctx, hipMemsetAsync(p->sys.g, 0, (size_t)n * 8, st));
             if (p->n_items)
                 hipLaunchKernelGGL(gather_kernel, dim3(p->n_items), dim3(W), (size_t)p->max_strip * 8, st, D, p->items_dev,
-                                   p->var_rec_dev, p->sys.A, p->sys.g, n, p->tail_begin, p->partials_dev, STRIP_CAP);
+                                   p->var_rec_dev, p->sys.matA(), p->sys.g, n, p->tail_begin, p->partials_dev, STRIP_CAP);
             if (p->n_tail_owners)
                 hipLaunchKernelGGL(tail_merge_kernel, dim3(p->n_tail_owners), dim3(256), 0, st, D, p->tail_var_dev, p->tail_first_dev,
-                                   p->tail_count_dev, p->partials_dev, p->sys.A, p->sys.g, n, p->tail_begin);
+                                   p->tail_count_dev, p->partials_dev, p->sys.matA(), p->sys.g, n, p->tail_begin);
         }
         hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(1024), 0, st, D.rec_cost, p->n_blocks, D.prior_base, n_prior, p->sys.scal);
         OCHIP_HIP(ctx, hipGetLastError());
@@ -1641,7 +1639,11 @@ int ochip_relaxg_evaluate(ochip_relaxg_problem *p, double *cost, int *n_out, dou
     if (rc < 0)
         return rc;
     if (JtJ && n)
-        OCHIP_HIP(ctx, hipMemcpy(JtJ, p->sys.A, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+    {
+        const int drc = lm_download_dense(p->sys, JtJ);
+        if (drc)
+            return drc;
+    }
     if (Jtr && n)
         OCHIP_HIP(ctx, hipMemcpy(Jtr, p->sys.g, (size_t)n * 8, hipMemcpyDeviceToHost));
     return rc;

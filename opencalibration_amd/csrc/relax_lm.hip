@@ -1,8 +1,9 @@
 // libochip.so — the shared part of the relax solve (see relax_lm.hpp): Levenberg-Marquardt trust-region loop with
 // Ceres' semantics and the linear solve of (J'J + D'D) y = J'r on the device.
 //
-// The reduced system is stored dense (row-major) and factored inside its block envelope (relax_lm.hpp: lm_envelope) by
-// ONE launch per factorisation: chol_tiles_kernel, a left-looking tile Cholesky whose workgroups hand 64 x 64 tiles to
+// The reduced system is stored as the 64 x 64 tiles of its block envelope, lower triangle only (relax_lm.hpp: lm_matrix;
+// 6 MB instead of 72 at n = 3003, 50 MB instead of 1.8 GB at the 15 004 unknowns of a 5 000-camera group) and factored in
+// place by ONE launch per factorisation: chol_tiles_kernel, a left-looking tile Cholesky whose workgroups hand 64 x 64 tiles to
 // each other through flags (products on v_mfma_f64_16x16x4f64, the diagonal block and its inverse in registers).  The
 // augmented row carries the forward solve; the backward substitution is one workgroup walking the row envelope.
 // The launch chain it replaced (chol_diag_kernel / chol_panel_kernel / chol_update_mfma_kernel, three dependent launches
@@ -21,23 +22,46 @@ namespace
 constexpr int NB = ochip::LM_NB;
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-// Wm = S A S + diag(D), gs = S g; also column norms^2 of the scaled Jacobian = diag(S A S)
-__global__ void lm_build_kernel(const double *A, const double *g, const double *scale, const double *lm_diag,
-                                double *Wm, double *gs, int n)
+// Wm = S A S + diag(D) tile by tile (one workgroup per stored tile), row n = gs = S g; the part of a diagonal tile above
+// the diagonal and everything beyond the system's last row / column is written as zero
+__global__ __launch_bounds__(256) void lm_build_kernel(lm_matrix A, const unsigned int *__restrict__ tile_ij, const double *g,
+                                                       const double *scale, const double *lm_diag, lm_matrix W, double *gs, int n)
 {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)n * n)
-        return;
-    const int i = (int)(idx / n), j = (int)(idx % n);
-    double v = A[idx] * scale[i] * scale[j];
-    if (i == j)
+    const unsigned int ij = tile_ij[blockIdx.x];
+    const int I = (int)(ij & 0xFFFFu), J = (int)(ij >> 16);
+    const double *a = A.tiles + ((size_t)blockIdx.x << 12);
+    double *w = W.tiles + ((size_t)blockIdx.x << 12);
+    for (int e = threadIdx.x; e < NB * NB; e += 256)
     {
-        v += lm_diag[i];
-        const double gi = g[i] * scale[i];
-        gs[i] = gi;
-        Wm[(size_t)n * n + i] = gi; // augmented row n: the factorisation performs the forward solve L y = gs on it
+        const int i = I * NB + (e >> 6), j = J * NB + (e & 63);
+        double v = 0.0;
+        if (j < n)
+        {
+            if (i < n)
+            {
+                if (j <= i)
+                {
+                    v = a[e] * scale[i] * scale[j];
+                    if (i == j)
+                    {
+                        v += lm_diag[i];
+                        gs[i] = g[i] * scale[i];
+                    }
+                }
+            }
+            else if (i == n)
+                v = g[j] * scale[j]; // augmented row n: the factorisation performs the forward solve L y = gs on it
+        }
+        w[e] = v;
     }
-    Wm[idx] = v;
+}
+
+// the augmented row (after the factorisation: y = L^-1 gs) as a plain vector
+__global__ void lm_aug_row_kernel(lm_matrix W, int n, double *out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n)
+        out[j] = W.tiles[lm_at(W, n, j)];
 }
 
 // Cholesky factor of the 64 x 64 diagonal block and its inverse, one workgroup.  The block lives in registers:
@@ -114,11 +138,12 @@ __device__ __forceinline__ void chol_diag_phase(double (&a)[4][4], double (&x)[4
     }
 }
 
-__global__ __launch_bounds__(256) void chol_diag_kernel(double *A, int n, int k0, int nb, int *fail,
+__global__ __launch_bounds__(256) void chol_diag_kernel(lm_matrix M, int n, int k0, int nb, int *fail,
                                                         double *Linv /*[NB][NB] row-major, zero padded*/)
 {
     __shared__ double colA[2][NB], rowX[2][NB];
     const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    double *A = M.tiles + ((size_t)M.cols[k0 / NB].first_tile << 12); // the diagonal tile
     double a[4][4], x[4][4];
 #pragma unroll
     for (int p = 0; p < 4; p++)
@@ -128,7 +153,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *A, int n, int k0
             const int i = ty + 16 * p, c = tx + 16 * q;
             // only the lower triangle of the input is meaningful; mirror it so that both triangles update alike
             const int lo = i > c ? i : c, hi = i > c ? c : i;
-            a[p][q] = (lo < nb) ? A[(size_t)(k0 + lo) * n + k0 + hi] : (i == c ? 1.0 : 0.0);
+            a[p][q] = (lo < nb) ? A[lo * NB + hi] : (i == c ? 1.0 : 0.0);
             x[p][q] = (i == c) ? 1.0 : 0.0;
         }
     bool bad = false;
@@ -145,7 +170,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(double *A, int n, int k0
         {
             const int i = ty + 16 * p, c = tx + 16 * q;
             if (i < nb && c <= i)
-                A[(size_t)(k0 + i) * n + k0 + c] = a[p][q];
+                A[i * NB + c] = a[p][q];
             Linv[i * NB + c] = (i < nb && c <= i) ? x[p][q] : ((i == c) ? 1.0 : 0.0);
         }
 }
@@ -165,7 +190,7 @@ __device__ __forceinline__ int set_row(const row_set &s, int i)
 
 // rows below the diagonal block: X = A[i, k0:k0+nb] * L_kk^{-T} = A_tile * Linv' as a 64x64x64 GEMM on the
 // matrix cores (same tiling as the trailing update), in place.
-__global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, row_set rs, int k0, int nb, const double *Linv)
+__global__ __launch_bounds__(256) void chol_panel_kernel(lm_matrix M, int n, row_set rs, int k0, int nb, const double *Linv)
 {
     constexpr int KC = 32;
     __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
@@ -183,7 +208,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, row_s
         for (int e = t; e < 64 * KC; e += 256)
         {
             const int r = e / KC, m = e % KC;
-            Pi[r][m] = (r0 + r < rs.total && m0 + m < nb) ? A[(size_t)set_row(rs, r0 + r) * n + k0 + m0 + m] : 0.0;
+            Pi[r][m] = (r0 + r < rs.total && m0 + m < nb) ? M.tiles[lm_at(M, set_row(rs, r0 + r), k0 + m0 + m)] : 0.0;
             Pj[r][m] = Linv[r * NB + m0 + m]; // X[i][c] = sum_m A[i][m] Linv[c][m]
         }
         __syncthreads();
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, row_s
             {
                 const int r = r0 + wr + 16 * i + 4 * e + lk, cc = wc + 16 * j + lr;
                 if (r < rs.total && cc < nb)
-                    A[(size_t)set_row(rs, r) * n + k0 + cc] = acc[i][j][e];
+                    M.tiles[lm_at(M, set_row(rs, r), k0 + cc)] = acc[i][j][e];
             }
 }
 
@@ -213,7 +238,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double *A, int n, row_s
 // Same trailing update on the matrix cores: v_mfma_f64_16x16x4_f64, one 32x32 sub-tile per wave
 // (2x2 accumulators), operands staged through LDS in 32-deep K chunks.  This dense fp64 update of the
 // reduced system is the only MFMA use on the path.
-__global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n, row_set rs, int k0, int nb)
+__global__ __launch_bounds__(256) void chol_update_mfma_kernel(lm_matrix M, int n, row_set rs, int k0, int nb)
 {
     const int ti = blockIdx.y, tj = blockIdx.x;
     if (tj > ti)
@@ -235,8 +260,8 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n,
         for (int e = t; e < 64 * KC; e += 256)
         {
             const int r = e / KC, m = e % KC;
-            Pi[r][m] = (r0 + r < rs.total && m < mc) ? A[(size_t)set_row(rs, r0 + r) * n + k0 + m0 + m] : 0.0;
-            Pj[r][m] = (c0 + r < rs.total && m < mc) ? A[(size_t)set_row(rs, c0 + r) * n + k0 + m0 + m] : 0.0;
+            Pi[r][m] = (r0 + r < rs.total && m < mc) ? M.tiles[lm_at(M, set_row(rs, r0 + r), k0 + m0 + m)] : 0.0;
+            Pj[r][m] = (c0 + r < rs.total && m < mc) ? M.tiles[lm_at(M, set_row(rs, c0 + r), k0 + m0 + m)] : 0.0;
         }
         __syncthreads();
 #pragma unroll
@@ -260,7 +285,7 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n,
                 {
                     const int ar = set_row(rs, r), ac = set_row(rs, cc);
                     if (ac < n)
-                        A[(size_t)ar * n + ac] -= acc[i][j][e];
+                        M.tiles[lm_at(M, ar, ac)] -= acc[i][j][e];
                 }
             }
 }
@@ -279,17 +304,10 @@ __global__ __launch_bounds__(256) void chol_update_mfma_kernel(double *A, int n,
 // device (see there).  A tile is handed over as MI355X_MICROARCH.md prescribes
 // (per-XCD L2s are not coherent): write-through stores, every storing wave drained, barrier, ONE lane sets the tile's
 // flag with an agent-scope store; the consumer polls that word relaxed, ONE agent-scope acquire, drain, barrier, plain loads.
-struct chol_col
-{
-    int first_tile; // index of tile (J, J); the column's tiles follow: rows J + 1 .. bend - 1, then tail_start ..
-    int bend;       // end (exclusive) of the band's row blocks
-    int tail_start; // first tail row block that is not already in the band
-    int pad;
-};
+typedef lm_col chol_col;
 __device__ __forceinline__ int chol_tile_index(const chol_col *cols, int I, int J)
 {
-    const chol_col c = cols[J];
-    return c.first_tile + (I < c.bend ? I - J : (c.bend - J) + (I - c.tail_start));
+    return lm_tile_index(cols, I, J);
 }
 __device__ __forceinline__ void store_through(double *p, double v) // global_store_dwordx2 sc1: write-through, agent scope
 {
@@ -361,15 +379,16 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                 __syncthreads();
                 ready = s_ready; // (rewritten only after every thread has passed the barriers of the loads below)
             }
-            const int kc0 = K * 64;
+            const double *wi = W + ((size_t)chol_tile_index(cols, I, K) << 12);
+            const double *wj = W + ((size_t)chol_tile_index(cols, J, K) << 12);
             for (int m0 = 0; m0 < 64; m0 += KC)
             {
                 __syncthreads();
                 for (int e = t; e < 64 * KC; e += 256)
                 {
                     const int r = e / KC, m = e % KC;
-                    Pi[r][m] = (r0 + r < n_rows) ? W[(size_t)(r0 + r) * n + kc0 + m0 + m] : 0.0;
-                    Pj[r][m] = (c0 + r < n_rows) ? W[(size_t)(c0 + r) * n + kc0 + m0 + m] : 0.0;
+                    Pi[r][m] = wi[r * NB + m0 + m]; // (rows beyond the augmented row are zero in every tile)
+                    Pj[r][m] = wj[r * NB + m0 + m];
                 }
                 __syncthreads();
 #pragma unroll
@@ -385,13 +404,14 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
             }
         }
         // T = A(I, J) - acc (the tile's own entries were written by the launch before this one)
+        double *wt = W + ((size_t)chol_tile_index(cols, I, J) << 12);
         __syncthreads();
         for (int i = 0; i < 2; i++)
             for (int j = 0; j < 2; j++)
                 for (int e = 0; e < 4; e++)
                 {
                     const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
-                    const double a = (r0 + r < n_rows && c < nb) ? W[(size_t)(r0 + r) * n + c0 + c] : 0.0;
+                    const double a = (r0 + r < n_rows && c < nb) ? wt[r * NB + c] : 0.0;
                     T[r][c] = a - acc[i][j][e];
                 }
         __syncthreads();
@@ -430,7 +450,7 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                 {
                     const int i = ty + 16 * p, c = tx + 16 * q;
                     if (i < nb && c <= i)
-                        store_through(&W[(size_t)(c0 + i) * n + c0 + c], a[p][q]);
+                        store_through(&wt[i * NB + c], a[p][q]);
                     store_through(&Li[i * NB + c], (i < nb && c <= i) ? x[p][q] : ((i == c) ? 1.0 : 0.0));
                 }
             if (has_aug)
@@ -450,7 +470,7 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                     double sum = 0;
                     for (int m = 0; m <= t; m++)
                         sum += Pi[m][0] * T[t][m];
-                    store_through(&W[(size_t)n * n + c0 + t], sum);
+                    store_through(&wt[nb * NB + t], sum); // (row n is row nb of this tile)
                 }
             }
         }
@@ -497,7 +517,7 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                     {
                         const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
                         if (r0 + r < n_rows && c < nb)
-                            store_through(&W[(size_t)(r0 + r) * n + c0 + c], acc[i][j][e]);
+                            store_through(&wt[r * NB + c], acc[i][j][e]);
                     }
         }
         // publish: every storing wave drained, barrier, one lane sets the flag
@@ -510,13 +530,16 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
 
 // Backward substitution L' x = y by ONE workgroup, block by block from the bottom: x_k = L_kk^-T y_k out of the stored
 // inverse, then y_i -= sum_m L[k0+m][i] x[k0+m] for the columns i < k0 in which the rows of the block can be non-zero
-// (first_col[k]: the row envelope; everything for the tail rows).  The 94 launches this took per solve cost 1.0 ms, the
+// (first_blk[k]: the first column block whose envelope reaches row block k; everything for the tail rows).  The 94 launches this took per solve cost 1.0 ms, the
 // walk over the envelope takes a tenth of that.
-__global__ __launch_bounds__(1024) void back_solve_kernel(const double *L, int n, const double *Linv, double *x,
-                                                          const int *first_col, int n_blocks)
+__global__ __launch_bounds__(1024) void back_solve_kernel(lm_matrix Lm, int n, const double *Linv, double *x,
+                                                          const int *first_blk, int n_blocks)
 {
     __shared__ double xb[NB];
     const int t = threadIdx.x;
+    const double *L = Lm.tiles;
+    for (int i = t; i < n; i += 1024) // y = L^-1 gs: the augmented row
+        x[i] = L[lm_at(Lm, n, i)];
     for (int k = n_blocks - 1; k >= 0; k--)
     {
         const int k0 = k * NB, nb = min(NB, n - k0);
@@ -548,15 +571,16 @@ __global__ __launch_bounds__(1024) void back_solve_kernel(const double *L, int n
             x[k0 + t] = s;
         }
         __syncthreads();
-        for (int i = first_col[k] + t; i < k0; i += 1024)
+        for (int i = first_blk[k] * NB + t; i < k0; i += 1024)
         {
+            const double *Lc = L + ((size_t)lm_tile_index(Lm.cols, k, i >> 6) << 12) + (i & 63); // column i of tile (k, i / 64)
             double u = 0;
             for (int m0 = 0; m0 < nb; m0 += 16)
             {
                 double v[16];
 #pragma unroll
                 for (int j = 0; j < 16; j++)
-                    v[j] = m0 + j < nb ? L[(size_t)(k0 + m0 + j) * n + i] : 0.0;
+                    v[j] = m0 + j < nb ? Lc[(m0 + j) * NB] : 0.0;
 #pragma unroll
                 for (int j = 0; j < 16; j++)
                     u += v[j] * xb[m0 + j];
@@ -590,7 +614,7 @@ __global__ __launch_bounds__(1024) void lm_model_change_kernel(const double *lm_
 }
 
 // diag(A) and max|g| -> scal[4] = max|g|; diag_out[i] = A_ii
-__global__ __launch_bounds__(1024) void lm_diag_kernel(const double *A, const double *g, double *diag_out, int n,
+__global__ __launch_bounds__(1024) void lm_diag_kernel(lm_matrix A, const double *g, double *diag_out, int n,
                                                        double *scal)
 {
     __shared__ double sh[1024];
@@ -598,7 +622,7 @@ __global__ __launch_bounds__(1024) void lm_diag_kernel(const double *A, const do
     double m = 0;
     for (int i = t; i < n; i += 1024)
     {
-        diag_out[i] = A[(size_t)i * n + i];
+        diag_out[i] = A.tiles[lm_at(A, i, i)];
         m = fmax(m, fabs(g[i]));
     }
     sh[t] = m;
@@ -770,15 +794,13 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
     if (n > s->cap_n)
     {
         // (blocks of a smaller earlier size stay with the owner until it is destroyed)
-        if (lm_dev_upload<double>(ctx, s->allocs, &s->A, nullptr, n * n) != OCHIP_OK ||
-            lm_dev_upload<double>(ctx, s->allocs, &s->Wm, nullptr, (n + 1) * n) != OCHIP_OK ||
-            lm_dev_upload<double>(ctx, s->allocs, &s->g, nullptr, n) != OCHIP_OK ||
+        if (lm_dev_upload<double>(ctx, s->allocs, &s->g, nullptr, n) != OCHIP_OK ||
             lm_dev_upload<double>(ctx, s->allocs, &s->gs, nullptr, n) != OCHIP_OK ||
             lm_dev_upload<double>(ctx, s->allocs, &s->scale, nullptr, n) != OCHIP_OK ||
             lm_dev_upload<double>(ctx, s->allocs, &s->lm_diag, nullptr, n) != OCHIP_OK ||
             lm_dev_upload<double>(ctx, s->allocs, &s->diag_tmp, nullptr, n) != OCHIP_OK ||
             lm_dev_upload<double>(ctx, s->allocs, &s->y, nullptr, n) != OCHIP_OK)
-            return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the %zu x %zu normal matrix failed", n, n);
+            return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the vectors of %zu unknowns failed", n);
         s->cap_n = n;
     }
     if (!s->scal && lm_dev_upload<double>(ctx, s->allocs, &s->scal, nullptr, 8) != OCHIP_OK)
@@ -790,12 +812,13 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
     {
         const int nn = n_in;
         const int nbc = (nn + NB - 1) / NB, nbr = (nn + 1 + NB - 1) / NB, tb = std::min(s->env.tail_begin, nn) / NB;
+        static const bool dense = getenv("OCHIP_CHOL_DENSE") != nullptr; // A/B knob: ignore the envelope (every tile stored)
         std::vector<chol_col> cols((size_t)std::max(nbc, 1));
         std::vector<int> kmin((size_t)std::max(nbr, 1), 0);
         int n_tiles = 0;
         for (int J = 0; J < nbc; J++)
         {
-            int bend = std::max(J + 1, (std::min(s->env.env_end[J], s->env.tail_begin) + NB - 1) / NB);
+            int bend = std::max(J + 1, (std::min(dense ? nn : s->env.env_end[J], s->env.tail_begin) + NB - 1) / NB);
             if (J > 0)
                 bend = std::max(bend, cols[J - 1].bend); // fill stays inside a monotone envelope
             bend = std::min(bend, nbr);
@@ -858,13 +881,71 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
         s->chol_tb = tb;
         s->chol_grid = std::max(1, std::min(n_tiles, slots));
         s->chol_sync_bytes = (((size_t)n_tiles + 4) * 4 + 15) / 16 * 16;
+        // tiles in storage order, and the matrices themselves
+        std::vector<unsigned int> stored((size_t)std::max(n_tiles, 1), 0u);
+        for (int J = 0; J < nbc; J++)
+        {
+            int t = cols[J].first_tile;
+            for (int I = J; I < cols[J].bend; I++)
+                stored[t++] = (unsigned int)I | ((unsigned int)J << 16);
+            for (int I = cols[J].tail_start; I < nbr; I++)
+                stored[t++] = (unsigned int)I | ((unsigned int)J << 16);
+        }
+        if ((size_t)n_tiles > s->cap_tiles)
+        {
+            const size_t doubles = (size_t)std::max(n_tiles, 1) * NB * NB;
+            if (lm_dev_upload<double>(ctx, s->allocs, &s->A, nullptr, doubles) != OCHIP_OK ||
+                lm_dev_upload<double>(ctx, s->allocs, &s->Wm, nullptr, doubles) != OCHIP_OK)
+                return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the reduced system failed (%d tiles of 32 KB, twice)", n_tiles);
+            s->cap_tiles = (size_t)n_tiles;
+        }
+        s->cols_host = cols;
+        if ((uint64_t)nn >= ctx->relax_system_unknowns) // what the bench line reports as the relax's system memory
+        {
+            ctx->relax_system_unknowns = (uint64_t)nn;
+            ctx->relax_system_bytes = 2ull * (uint64_t)n_tiles * NB * NB * 8;            // J'J and the factor
+            ctx->relax_system_dense_bytes = ((uint64_t)nn * nn + (uint64_t)(nn + 1) * nn) * 8; // what rounds 1-2 allocated
+        }
         chol_col *cols_dev = nullptr;
-        if (lm_dev_upload(ctx, s->allocs, &cols_dev, cols.data(), cols.size()) != OCHIP_OK ||
+        if (lm_dev_upload(ctx, s->allocs, &s->tile_ij, stored.data(), stored.size()) != OCHIP_OK ||
+            lm_dev_upload(ctx, s->allocs, &cols_dev, cols.data(), cols.size()) != OCHIP_OK ||
             lm_dev_upload(ctx, s->allocs, &s->chol_kmin, kmin.data(), kmin.size()) != OCHIP_OK ||
             lm_dev_upload(ctx, s->allocs, &s->chol_tiles, order.data(), std::max<size_t>(order.size(), 1)) != OCHIP_OK ||
             lm_dev_upload<unsigned int>(ctx, s->allocs, &s->chol_sync, nullptr, s->chol_sync_bytes / 4) != OCHIP_OK)
             return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (factorisation plan)");
         s->chol_cols = cols_dev;
+    }
+    return OCHIP_OK;
+}
+
+int lm_download_dense(const lm_system &s, double *out)
+{
+    const int n = s.n;
+    if (n <= 0)
+        return OCHIP_OK;
+    std::vector<double> tiles((size_t)s.chol_n_tiles * NB * NB);
+    if (hipMemcpy(tiles.data(), s.A, tiles.size() * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return ochip_fail(s.ctx, OCHIP_EHIP, "hipMemcpy failed (normal matrix)");
+    std::fill(out, out + (size_t)n * n, 0.0);
+    for (int J = 0; J < s.chol_nbc; J++)
+    {
+        const lm_col &c = s.cols_host[(size_t)J];
+        int t = c.first_tile;
+        auto put = [&](int I) {
+            const double *a = tiles.data() + ((size_t)t << 12);
+            for (int r = 0; r < NB; r++)
+                for (int q = 0; q < NB; q++)
+                {
+                    const int i = I * NB + r, j = J * NB + q;
+                    if (i < n && j <= i)
+                        out[(size_t)i * n + j] = out[(size_t)j * n + i] = a[r * NB + q];
+                }
+            t++;
+        };
+        for (int I = J; I < c.bend; I++)
+            put(I);
+        for (int I = c.tail_start; I < s.chol_nbr; I++)
+            put(I);
     }
     return OCHIP_OK;
 }
@@ -880,7 +961,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
     const bool eliminated = M.has_eliminated();
     M.begin_solve();
     auto grad_and_diag = [&](double *gmax) -> int {
-        hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(1024), 0, st, S.A, S.g, S.diag_tmp, n, S.scal);
+        hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(1024), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal);
         OCHIP_HIP(ctx, hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         *gmax = h[4];
@@ -954,13 +1035,12 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         OCHIP_HIP(ctx, hipMemcpyAsync(S.lm_diag, lmd.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
         hipEvent_t e0, e1;
         ochip_prof_begin(ctx, OCHIP_K_RELAX_SOLVE, &e0, &e1);
-        const size_t nn = (size_t)n * n;
         if (n > 0)
-            hipLaunchKernelGGL(lm_build_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, S.A, S.g, S.scale, S.lm_diag,
-                               S.Wm, S.gs, n);
+            hipLaunchKernelGGL(lm_build_kernel, dim3((unsigned)S.chol_n_tiles), dim3(256), 0, st, S.matA(), (const unsigned int *)S.tile_ij,
+                               (const double *)S.g, (const double *)S.scale, (const double *)S.lm_diag, S.matW(), S.gs, n);
         OCHIP_HIP(ctx, hipMemsetAsync(S.fail_chol, 0, 4, st));
         if (eliminated)
-            M.launch_schur(radius, S.scale, S.Wm, n, S.fail_chol);
+            M.launch_schur(radius, S.scale, S.matW(), n, S.fail_chol);
         {
             const size_t need = (size_t)((n + NB - 1) / NB) * NB * NB;
             if (need > S.linv_cap)
@@ -975,18 +1055,20 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         static const bool chain = getenv("OCHIP_CHOL_CHAIN") != nullptr;   // A/B knob: the launch chain per block column
         static const bool verify = getenv("OCHIP_CHOL_VERIFY") != nullptr; // run both on the same system and compare
         // the launch chain on (W, linv); count: add the algorithmic flops of the factorisation to the context's counter
-        auto launch_chain = [&](double *W, double *linv, bool launch, bool count) {
+        auto launch_chain = [&](double *Wt, double *linv, bool launch, bool count) {
+            const lm_matrix W{Wt, S.chol_cols};
             for (int k0 = 0; k0 < n; k0 += NB)
             {
                 const int nb = std::min(NB, n - k0);
                 double *linv_k = linv + (size_t)(k0 / NB) * NB * NB;
                 if (launch)
                     hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, W, n, k0, nb, S.fail_chol, linv_k);
-                // rows below the block that can be non-zero: its envelope, then the tail (dense unknowns + augmented row)
-                static const bool dense = getenv("OCHIP_CHOL_DENSE") != nullptr; // A/B knob: ignore the envelope
+                // rows below the block that can be non-zero: its envelope as the plan stores it (monotone, whole row blocks),
+                // then the tail (dense unknowns + augmented row)
                 const int below = k0 + nb;
-                const int band_end = dense ? n : std::max(below, std::min(S.env.env_end[k0 / NB], S.env.tail_begin));
-                const int tail0 = std::max(dense ? n : S.env.tail_begin, below);
+                const int tail_rows_begin = std::min(S.env.tail_begin, n);
+                const int band_end = std::max(below, std::min(S.cols_host[(size_t)(k0 / NB)].bend * NB, tail_rows_begin));
+                const int tail0 = std::max(tail_rows_begin, below);
                 row_set rs{below, band_end - below, tail0, (band_end - below) + (n + 1 - tail0)};
                 const int tiles = (rs.total + 63) / 64;
                 if (count)
@@ -1008,11 +1090,11 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             size_t got_w = 0, got_l = 0;
             if (verify)
             {
-                Wv = (double *)ochip_pool_get(ctx, ((size_t)n + 1) * n * 8, &got_w);
+                Wv = (double *)ochip_pool_get(ctx, S.matrix_bytes(), &got_w);
                 linv_v = (double *)ochip_pool_get(ctx, (size_t)((n + NB - 1) / NB) * NB * NB * 8, &got_l);
                 if (!Wv || !linv_v)
                     return ochip_fail(ctx, OCHIP_ENOMEM, "OCHIP_CHOL_VERIFY: device allocation failed");
-                OCHIP_HIP(ctx, hipMemcpyAsync(Wv, S.Wm, ((size_t)n + 1) * n * 8, hipMemcpyDeviceToDevice, st));
+                OCHIP_HIP(ctx, hipMemcpyAsync(Wv, S.Wm, S.matrix_bytes(), hipMemcpyDeviceToDevice, st));
             }
             OCHIP_HIP(ctx, hipMemsetAsync(S.chol_sync, 0, S.chol_sync_bytes, st));
             hipLaunchKernelGGL(chol_tiles_kernel, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
@@ -1023,8 +1105,10 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             {
                 launch_chain(Wv, linv_v, true, false);
                 std::vector<double> ya(n), yb(n);
-                OCHIP_HIP(ctx, hipMemcpyAsync(ya.data(), S.Wm + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-                OCHIP_HIP(ctx, hipMemcpyAsync(yb.data(), Wv + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+                hipLaunchKernelGGL(lm_aug_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S.matW(), n, S.y);
+                OCHIP_HIP(ctx, hipMemcpyAsync(ya.data(), S.y, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+                hipLaunchKernelGGL(lm_aug_row_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lm_matrix{Wv, S.chol_cols}, n, S.y);
+                OCHIP_HIP(ctx, hipMemcpyAsync(yb.data(), S.y, (size_t)n * 8, hipMemcpyDeviceToHost, st));
                 OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
                 double worst = 0, scale_y = 0;
                 bool nan = false;
@@ -1047,9 +1131,8 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         // row n now holds y = L^-1 gs; back-substitute L' x = y block by block
         if (n > 0)
         {
-            OCHIP_HIP(ctx, hipMemcpyAsync(S.y, S.Wm + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, st, (const double *)S.Wm, n, (const double *)S.linv, S.y,
-                               (const int *)S.first_col_dev, (n + NB - 1) / NB);
+            hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, st, S.matW(), n, (const double *)S.linv, S.y,
+                               (const int *)S.chol_kmin, (n + NB - 1) / NB);
         }
         hipLaunchKernelGGL(lm_model_change_kernel, dim3(1), dim3(1024), 0, st, S.lm_diag, S.gs, S.y, n, S.scal);
         M.launch_candidate(S.y, S.scale, 1.0, S.scal);

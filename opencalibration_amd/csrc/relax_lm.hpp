@@ -1,7 +1,8 @@
 // libochip.so (internal) — the part of the relax solve every problem flavour shares: Levenberg-Marquardt trust-region
 // loop with Ceres' semantics (ceres::TrustRegionMinimizer + LevenbergMarquardtStrategy, what
 // RelaxProblem::solve -> ceres::Solver::Solve runs, src/relax/relax_problem.cpp:30-37,1404) on a
-// reduced normal-equation system held dense in HBM and factored inside its block envelope (relax_lm.hip).
+// reduced normal-equation system held in HBM as the 64 x 64 tiles of its block envelope (lower triangle only; the
+// reference gives the same system to SPARSE_NORMAL_CHOLESKY, relax_problem.cpp:30-37) and factored in place (relax_lm.hip).
 //
 // A problem flavour (ground plane: relax.hip; mesh / intrinsics: relax_general.hip) implements lm_model: it owns the
 // state, evaluates cost / J'J / J'r into the system's buffers, and applies a step to a candidate state.
@@ -25,15 +26,42 @@ struct lm_envelope
     int tail_begin = 0;
 };
 
+// ---- packed storage of the reduced system: the lower triangle as 64 x 64 tiles (row-major inside a tile) -----------
+// Column block J owns the tiles of the row blocks J .. bend - 1 (the band: fill stays inside the monotone envelope) and
+// tail_start .. (the dense tail and the augmented row n, which carries the right-hand side through the factorisation),
+// stored one after the other from first_tile.  Everything outside these tiles is structurally zero and has no storage.
+struct lm_col
+{
+    int first_tile; // index of tile (J, J); the column's tiles follow: rows J + 1 .. bend - 1, then tail_start ..
+    int bend;       // end (exclusive) of the band's row blocks
+    int tail_start; // first tail row block that is not already in the band
+    int pad;
+};
+struct lm_matrix // device view
+{
+    double *tiles;
+    const lm_col *cols;
+};
+__device__ __forceinline__ int lm_tile_index(const lm_col *cols, int I, int J)
+{
+    const lm_col c = cols[J];
+    return c.first_tile + (I < c.bend ? I - J : (c.bend - J) + (I - c.tail_start));
+}
+// offset of entry (i, j), i >= j, which must lie inside the envelope
+__device__ __forceinline__ size_t lm_at(const lm_matrix &M, int i, int j)
+{
+    return ((size_t)lm_tile_index(M.cols, i >> 6, j >> 6) << 12) + (size_t)(((i & 63) << 6) + (j & 63));
+}
+
 struct lm_system
 {
     ochip_ctx *ctx = nullptr;
     std::vector<std::pair<void *, size_t>> *allocs = nullptr; // device blocks are recorded here (owner returns them to the pool)
     int n = 0;
-    size_t cap_n = 0, linv_cap = 0;
-    double *A = nullptr;       // [n][n] J'J, row-major, both triangles
+    size_t cap_n = 0, linv_cap = 0, cap_tiles = 0;
+    double *A = nullptr;       // J'J: packed lower triangle (lm_matrix), chol_n_tiles tiles; entries (i, j <= i), i < n
     double *g = nullptr;       // [n] J'r
-    double *Wm = nullptr;      // [(n + 1)][n] scaled + damped system, augmented row = scaled gradient
+    double *Wm = nullptr;      // scaled + damped system in the same tiles, row n = scaled gradient; factored in place
     double *gs = nullptr, *scale = nullptr, *lm_diag = nullptr, *diag_tmp = nullptr, *y = nullptr;
     double *scal = nullptr;    // [8] small results: [0] cost [1] model cost change [2] |step|^2 [3] |candidate|^2 [4] max |g|
     int *fail_chol = nullptr;
@@ -41,13 +69,30 @@ struct lm_system
     int *first_col_dev = nullptr;
     lm_envelope env;
     // plan of the one-launch tile factorisation (relax_lm.hip: chol_tiles_kernel), rebuilt with the envelope
-    void *chol_cols = nullptr;       // per column block: first tile, band end, first tail block
+    lm_col *chol_cols = nullptr;     // per column block: first tile, band end, first tail block (device)
+    std::vector<lm_col> cols_host;
+    unsigned int *tile_ij = nullptr; // tiles in storage order: row block | column block << 16
     int *chol_kmin = nullptr;        // per row block: first column block whose envelope reaches it
     unsigned int *chol_tiles = nullptr; // tiles in claim order: row block | column block << 16
     unsigned int *chol_sync = nullptr;  // [0] claim counter, [4 + tile] done flags; zeroed before every factorisation
     int chol_n_tiles = 0, chol_nbc = 0, chol_nbr = 0, chol_tb = 0, chol_grid = 0;
     size_t chol_sync_bytes = 0;
+    lm_matrix matA() const
+    {
+        return lm_matrix{A, chol_cols};
+    }
+    lm_matrix matW() const
+    {
+        return lm_matrix{Wm, chol_cols};
+    }
+    size_t matrix_bytes() const // of A, and of Wm
+    {
+        return (size_t)chol_n_tiles * LM_NB * LM_NB * sizeof(double);
+    }
 };
+
+// J'J as a dense symmetric n x n matrix in host memory (tests, ochip_relaxg_evaluate)
+int lm_download_dense(const lm_system &s, double *out);
 
 // (re)size the buffers for n unknowns and take the envelope; returns OCHIP_OK or a negative code
 int lm_system_resize(lm_system *s, int n, const lm_envelope &env);
@@ -55,8 +100,8 @@ int lm_system_resize(lm_system *s, int n, const lm_envelope &env);
 struct lm_model
 {
     virtual ~lm_model() = default;
-    // Evaluate state `which` (0 = current, 1 = candidate).  with_jac: also fill sys.A (every entry: both triangles, zeros
-    // included) and sys.g.  *cost = total cost.  Returns 0, 1 for a numeric failure (non-finite residual or derivative:
+    // Evaluate state `which` (0 = current, 1 = candidate).  with_jac: also fill sys.A (every entry (i, j <= i) of the
+    // packed lower triangle, zeros included: hipMemsetAsync(sys.A, 0, sys.matrix_bytes()) first) and sys.g.  *cost = total cost.  Returns 0, 1 for a numeric failure (non-finite residual or derivative:
     // Ceres' "evaluation failed"), or a negative OCHIP_E* code for a hard error (HIP call, exchange) which ends the solve.
     virtual int evaluate(bool with_jac, int which, double *cost) = 0;
     // enqueue: candidate = x (+) delta with delta[i] = alpha * (-y[i] * scale[i]); scal[2] = |x - candidate|^2 (ambient),
@@ -79,8 +124,8 @@ struct lm_model
     //        begin_solve            forgets the Jacobi scaling of the eliminated columns (fixed again from the solve's
     //                               first Jacobian, like the system's own),
     //        gradient_max_extra     max |g| over the eliminated columns,
-    //        launch_schur           called once the scaled, damped system Wm (n x n and the augmented row n = the scaled
-    //                               gradient) is built: subtracts the eliminated blocks' Schur term from both; the same
+    //        launch_schur           called once the scaled, damped system Wm (lower triangle and the augmented row n = the
+    //                               scaled gradient) is built: subtracts the eliminated blocks' Schur term from both; the same
     //                               damping rule (clamp(diag * scale^2, 1e-6, 1e32) / radius) applies to their columns,
     //        launch_candidate       also back-substitutes the eliminated blocks, adds their share of the model cost
     //                               change to scal[1], of |step|^2 to scal[2] and of |candidate|^2 to scal[3],
@@ -99,7 +144,7 @@ struct lm_model
         *out = 0;
         return OCHIP_OK;
     }
-    virtual void launch_schur(double radius, const double *scale, double *Wm, int n, int *fail /* set non-zero: invalid step */)
+    virtual void launch_schur(double radius, const double *scale, lm_matrix Wm, int n, int *fail /* set non-zero: invalid step */)
     {
     }
     virtual int slope_extra(bool from_candidate, double *out)

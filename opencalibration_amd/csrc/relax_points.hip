@@ -390,8 +390,16 @@ __global__ __launch_bounds__(128) void group_schur_kernel(p_dev P, const double 
 }
 
 // records -> system: one thread per (camera, row of its block) and one per lens row, each walking its groups in order.
-// sign +1: U into A (n x n) and g; sign -1: the Schur term out of Wm (n x n + the augmented row n).
-__global__ void apply_cam_kernel(p_dev P, const uint32_t *cam_grp_off, const uint32_t *cam_grp, double *A, double *rhs, int n,
+// sign +1: U into A and g; sign -1: the Schur term out of Wm and its augmented row n (rhs == nullptr).  The matrices keep
+// their lower triangle (relax_lm.hpp): a row owner adds the columns up to its diagonal.
+__device__ __forceinline__ void add_rhs(const lm_matrix &A, double *rhs, int n, int row, double v)
+{
+    if (rhs)
+        rhs[row] += v;
+    else
+        A.tiles[lm_at(A, n, row)] += v;
+}
+__global__ void apply_cam_kernel(p_dev P, const uint32_t *cam_grp_off, const uint32_t *cam_grp, lm_matrix A, double *rhs, int n,
                                  double sign)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,13 +418,15 @@ __global__ void apply_cam_kernel(p_dev P, const uint32_t *cam_grp_off, const uin
             const int u = rec_unknown(P, g, j);
             if (u < 0)
                 continue;
+            if (u > row)
+                continue;
             const double v = R[i <= j ? tri_at(i, j) : tri_at(j, i)];
-            A[(size_t)row * n + u] += sign * v;
+            A.tiles[lm_at(A, row, u)] += sign * v;
         }
-        rhs[row] += sign * R[RTRI + i];
+        add_rhs(A, rhs, n, row, sign * R[RTRI + i]);
     }
 }
-__global__ void apply_lens_kernel(p_dev P, double *A, double *rhs, int n, double sign)
+__global__ void apply_lens_kernel(p_dev P, lm_matrix A, double *rhs, int n, double sign)
 {
     const int k = threadIdx.x; // lens column
     if (k >= KI || P.lens_t[k] < 0)
@@ -430,9 +440,11 @@ __global__ void apply_lens_kernel(p_dev P, double *A, double *rhs, int n, double
             const int u = rec_unknown(P, g, j);
             if (u < 0)
                 continue;
-            A[(size_t)row * n + u] += sign * R[i <= j ? tri_at(i, j) : tri_at(j, i)];
+            if (u > row)
+                continue;
+            A.tiles[lm_at(A, row, u)] += sign * R[i <= j ? tri_at(i, j) : tri_at(j, i)];
         }
-        rhs[row] += sign * R[RTRI + i];
+        add_rhs(A, rhs, n, row, sign * R[RTRI + i]);
     }
 }
 
@@ -463,7 +475,7 @@ __global__ void mono_kernel(p_dev P, int which)
     for (int e = 0; e < 9; e++)
         P.mono[1 + e] = acc[e];
 }
-__global__ void mono_apply_kernel(p_dev P, double *A, double *g, int n)
+__global__ void mono_apply_kernel(p_dev P, lm_matrix A, double *g, int n)
 {
     const int at[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
     for (int a = 0; a < 3; a++)
@@ -472,8 +484,8 @@ __global__ void mono_apply_kernel(p_dev P, double *A, double *g, int n)
         if (ua < 0)
             continue;
         for (int b = 0; b < 3; b++)
-            if (P.lens_t[3 + b] >= 0)
-                A[(size_t)ua * n + P.lens_t[3 + b]] += P.mono[1 + at[a][b]];
+            if (P.lens_t[3 + b] >= 0 && P.lens_t[3 + b] <= ua)
+                A.tiles[lm_at(A, ua, P.lens_t[3 + b])] += P.mono[1 + at[a][b]];
         g[ua] += P.mono[7 + a];
     }
 }
@@ -809,17 +821,17 @@ struct points_model final : lm_model
                 hipLaunchKernelGGL(point_kernel, dim3((D.n_points + 255) / 256), dim3(256), 0, st, D);
             if (n > 0)
             {
-                OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, (size_t)n * n * 8, st));
+                OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, p->sys.matrix_bytes(), st));
                 OCHIP_HIP(ctx, hipMemsetAsync(p->sys.g, 0, (size_t)n * 8, st));
                 if (D.n_groups)
                 {
                     hipLaunchKernelGGL(group_u_kernel, dim3(D.n_groups), dim3(128), 0, st, D);
                     hipLaunchKernelGGL(apply_cam_kernel, dim3((3 * D.n_cams + 255) / 256), dim3(256), 0, st, D, p->cam_grp_off, p->cam_grp,
-                                       p->sys.A, p->sys.g, n, 1.0);
-                    hipLaunchKernelGGL(apply_lens_kernel, dim3(1), dim3(KI), 0, st, D, p->sys.A, p->sys.g, n, 1.0);
+                                       p->sys.matA(), p->sys.g, n, 1.0);
+                    hipLaunchKernelGGL(apply_lens_kernel, dim3(1), dim3(KI), 0, st, D, p->sys.matA(), p->sys.g, n, 1.0);
                 }
                 if (D.mono_w > 0)
-                    hipLaunchKernelGGL(mono_apply_kernel, dim3(1), dim3(1), 0, st, D, p->sys.A, p->sys.g, n);
+                    hipLaunchKernelGGL(mono_apply_kernel, dim3(1), dim3(1), 0, st, D, p->sys.matA(), p->sys.g, n);
             }
         }
         ochip_prof_end(ctx, OCHIP_K_RELAX_EVAL, e0, e1);
@@ -840,7 +852,7 @@ struct points_model final : lm_model
         *out = v;
         return OCHIP_OK;
     }
-    void launch_schur(double radius, const double *scale, double *Wm, int n, int *fail) override
+    void launch_schur(double radius, const double *scale, lm_matrix Wm, int n, int *fail) override
     {
         hipStream_t st = p->ctx->stream;
         p_dev &D = p->dev;
@@ -853,8 +865,8 @@ struct points_model final : lm_model
         {
             hipLaunchKernelGGL(group_schur_kernel, dim3(D.n_groups), dim3(128), 0, st, D, scale);
             hipLaunchKernelGGL(apply_cam_kernel, dim3((3 * D.n_cams + 255) / 256), dim3(256), 0, st, D, p->cam_grp_off, p->cam_grp, Wm,
-                               Wm + (size_t)n * n, n, -1.0);
-            hipLaunchKernelGGL(apply_lens_kernel, dim3(1), dim3(KI), 0, st, D, Wm, Wm + (size_t)n * n, n, -1.0);
+                               (double *)nullptr, n, -1.0);
+            hipLaunchKernelGGL(apply_lens_kernel, dim3(1), dim3(KI), 0, st, D, Wm, (double *)nullptr, n, -1.0);
         }
     }
     void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override

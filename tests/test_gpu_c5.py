@@ -85,6 +85,11 @@ def test_c5_survey_at_size(oracle):
     # the cameras of a wide survey's top corners look past it and stay unconstrained in this flavour; the mesh flavours
     # below reach them)
     assert np.median(err) < 1e-3 and np.sum(err > 0.02) < n // 10
+    # storage of the reduced system: the tiles of its block envelope, not n^2 (dense: J'J and the factor of 15 003 unknowns
+    # are 3.6 GB; the reference gives the system to SPARSE_NORMAL_CHOLESKY, relax_problem.cpp:30-37)
+    unknowns, stored, dense = ctx.relax_memory()
+    assert 3 * (n - 500) <= unknowns <= 3 * n + 3 and dense > 3.0e9 and stored < dense / 10
+    print("C5 plane group: unknowns", unknowns, "system stored MB", round(stored / 1e6, 1), "dense MB", round(dense / 1e6, 1))
     seed = host.rebuild_mesh(grid.position, plane["surface"], minimal=True)
     sa = seed.arrays()
     ori0 = plane["orientation"]
@@ -127,6 +132,9 @@ def test_c5_survey_at_size(oracle):
     assert int(fin["unknowns"]) >= 3 * (n - 50) and int(fin["residual_blocks"]) > 500_000
     errf = pipeline.orientation_errors(fin["orientation"], grid.orientation)
     assert np.median(errf) < 1e-3 and np.sum(errf > 0.02) < n // 50
+    unknowns, stored, dense = ctx.relax_memory()
+    assert unknowns >= 3 * (n - 500) and stored < dense / 10
+    print("C5 global mesh group: system stored MB", round(stored / 1e6, 1), "dense MB", round(dense / 1e6, 1))
     print("C5 global mesh group: unknowns", int(fin["unknowns"]), "blocks", int(fin["residual_blocks"]), "LM iterations",
           int(fin["iterations_total"]), "device s", round(fin["device_s"], 2), "median error", float(np.median(errf)))
     g.close()
