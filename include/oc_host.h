@@ -88,6 +88,12 @@ extern "C"
      * {x, y, size, angle, response, level} in cv::AKAZE's order -> loc / strength / desc as above; returns the count. */
     size_t och_extract_tail(const float *kp6, const uint64_t *desc, uint32_t n, double scale, double *loc, float *strength,
                             uint64_t *desc_out, uint64_t *num_sparse);
+    /* The same tail for ONE image on the lists the device prepared (ochip_akaze_features / ochip_feature_lists_from_keypoints,
+     * include/ochip.h: records, response, slot, num_sparse of that image): the host's part is the std::sort order, the copy
+     * and the re-seating inside groups of equal responses; conflict != 0 runs the suppression here as well. */
+    size_t och_extract_tail_prepared(const uint8_t *records, const float *response, const uint32_t *slot, uint32_t num_sparse_in,
+                                     int conflict, uint32_t n, double scale, double *loc, float *strength, uint64_t *desc_out,
+                                     uint64_t *num_sparse);
     /* Cumulative CPU seconds of that tail's phases, recorded while OCHIP_EXTRACT_VERBOSE is set: ordering, NMS, feature
      * records, total, and the number of images whose responses tied (they take std::sort's route). */
     void och_extract_tail_profile(double *out5);

@@ -114,6 +114,44 @@ extern "C"
     int ochip_akaze_batch_dev(ochip_ctx *ctx, const uint8_t *images_bgr_dev, uint32_t n_images, int width, int height,
                               uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh);
 
+    /* ---- the data-parallel part of extract_features' tail (src/extract/extract_features.cpp:38-87) on the device ---- */
+    /* The reference rescales the keypoints, std::sorts them by response (unstable: libstdc++'s order among equal
+     * responses), runs a greedy 8 px suppression in that order and emits [sparse..., dense...].  The sort stays on the host
+     * (it needs `response` in detection order and nothing else); the device prepares everything around it on its own
+     * stable order (descending response, detection index ascending among equals), which differs from the host's only
+     * inside groups of equal responses.  All arrays are the caller's (host; page-locked ones copy at link speed):
+     *   records    [n][max_kp + 1][88]  the image's output list [sparse..., dense...] as feature_2d records (location =
+     *                                   pt / scale as doubles, strength, 4 bytes padding, 8 descriptor words) under the
+     *                                   device's order: counts[i] + 1 records (the strongest feature heads both lists: the
+     *                                   reference visits its seed again, :60-66)
+     *   response   [n][max_kp]          responses in detection order
+     *   slot       [n][max_kp]          slot[s] = where the keypoint of detection index s lies in `records` (the seed:
+     *                                   its sparse slot, 0)
+     *   num_sparse [n]                  length of the sparse list
+     *   conflict   [n]                  non-zero: two equal responses lie within the radius of each other, or the
+     *                                   strongest response is tied - the suppression's outcome then depends on the host's
+     *                                   order, the host runs it itself for this image and only uses the records
+     * Where the host's order differs inside a group of equal responses (and conflict is 0) the group's sparse members keep
+     * the group's sparse slots and its dense members its dense slots, re-seated in the host's order. */
+    typedef struct ochip_feature_lists
+    {
+        uint8_t *records;
+        float *response;
+        uint32_t *slot;
+        uint32_t *num_sparse;
+        uint8_t *conflict;
+    } ochip_feature_lists;
+    /* ochip_akaze_batch / _dev with the tail prepared: counts as there, `lists` instead of kp6 / desc.
+     * scale = working / original size (the reference's `scale`, :26), nms_radius in working pixels (8, :58). */
+    int ochip_akaze_features(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height, uint32_t max_kp,
+                             double nms_radius, uint32_t *counts, const ochip_feature_lists *lists, int *work_wh);
+    int ochip_akaze_features_dev(ochip_ctx *ctx, const uint8_t *images_bgr_dev, uint32_t n_images, int width, int height,
+                                 uint32_t max_kp, double nms_radius, uint32_t *counts, const ochip_feature_lists *lists, int *work_wh);
+    /* the same preparation for keypoints the caller already has (kp6 / desc / counts as ochip_akaze_batch returns them) */
+    int ochip_feature_lists_from_keypoints(ochip_ctx *ctx, const float *kp6, const uint64_t *desc, const uint32_t *counts, uint32_t n_images,
+                            uint32_t max_kp, int work_w, int work_h, double scale, double nms_radius,
+                            const ochip_feature_lists *out);
+
     /* ---- synthetic views: benchmark / test DATA generated directly in HBM (no algorithm of the path) ---- */
     /* A jittered ground lattice of Gaussian blobs on the plane z = a x + b y rendered through pinhole cameras;
      * all views of one seed show the same ground.  cams: n x {pos3, quat4 (x y z w)}; model3 = {f, ppx, ppy};

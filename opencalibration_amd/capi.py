@@ -20,7 +20,7 @@ EXPORTS = [
     "ochip_descriptors_reserve", "ochip_upload_descriptors", "ochip_descriptor_count",
     "ochip_match_batch", "ochip_match_launch", "ochip_match_fetch",
     "ochip_upload_keypoints", "ochip_ransac_homography_batch", "ochip_refit_homography_batch", "ochip_ransac_epipolar_batch",
-    "ochip_upload_batch", "ochip_host_alloc", "ochip_host_free", "ochip_akaze_batch", "ochip_akaze_batch_dev",
+    "ochip_upload_batch", "ochip_host_alloc", "ochip_host_free", "ochip_akaze_batch", "ochip_akaze_batch_dev", "ochip_akaze_features", "ochip_akaze_features_dev", "ochip_feature_lists_from_keypoints",
     "ochip_synth_views_alloc", "ochip_synth_views_free", "ochip_synth_render_views", "ochip_synth_views_read",
     "ochip_relax_problem_create", "ochip_relax_problem_destroy", "ochip_relax_set_cameras_constant",
     "ochip_relax_solve", "ochip_relax_get_state", "ochip_relax_set_shard",
@@ -75,6 +75,7 @@ def load():
         L.ochip_relax_memory.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
         L.ochip_debug_fp64.argtypes = [vp, i32, vp, vp, C.c_size_t, vp]
         L.ochip_akaze_batch.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
+        L.ochip_feature_lists_from_keypoints.argtypes = [vp, vp, vp, vp, u32, u32, i32, i32, C.c_double, C.c_double, vp]
         L.ochip_akaze_batch_dev.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
         L.ochip_synth_views_alloc.argtypes = [vp, u32, i32, i32, C.POINTER(vp)]
         L.ochip_synth_views_free.argtypes = [vp, vp]
@@ -204,6 +205,29 @@ class Context:
         self._check(self.L.ochip_akaze_batch(self.h, imgs.ctypes.data, n, w, h, max_kp, kp.ctypes.data, desc.ctypes.data,
                                              counts.ctypes.data, wh.ctypes.data), "ochip_akaze_batch")
         return [(kp[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(n)], (int(wh[0]), int(wh[1]))
+
+    def feature_lists(self, kp6, desc, work_wh, scale, nms_radius=8.0):
+        """ochip_feature_lists_from_keypoints for ONE image's keypoints (detection order): dict of records ((n + 1) x 88
+        bytes: the output list under the device's order), response, slot (n each), num_sparse and conflict."""
+        kp6 = np.ascontiguousarray(kp6, np.float32).reshape(-1, 6)
+        desc = np.ascontiguousarray(desc, np.uint64).reshape(-1, 8)
+        n = len(kp6)
+        m = max(n, 1)
+        rec, resp = np.zeros((m + 1, 88), np.uint8), np.zeros(m, np.float32)
+        slot, ns, conflict = np.zeros(m, np.uint32), np.zeros(4, np.uint32), np.zeros(16, np.uint8)
+        counts = np.array([n], np.uint32)
+
+        class Lists(C.Structure):
+            _fields_ = [("records", C.c_void_p), ("response", C.c_void_p), ("slot", C.c_void_p), ("num_sparse", C.c_void_p),
+                        ("conflict", C.c_void_p)]
+
+        lists = Lists(rec.ctypes.data, resp.ctypes.data, slot.ctypes.data, ns.ctypes.data, conflict.ctypes.data)
+        kin = kp6 if n else np.zeros((1, 6), np.float32)
+        din = desc if n else np.zeros((1, 8), np.uint64)
+        self._check(self.L.ochip_feature_lists_from_keypoints(self.h, kin.ctypes.data, din.ctypes.data, counts.ctypes.data, 1, m,
+                                                              int(work_wh[0]), int(work_wh[1]), float(scale), float(nms_radius),
+                                                              C.byref(lists)), "ochip_feature_lists_from_keypoints")
+        return dict(records=rec[:n + 1 if n else 0], response=resp[:n], slot=slot[:n], num_sparse=int(ns[0]), conflict=bool(conflict[0]))
 
     def synth_views(self, position, orientation, width, height, f, pp, plane, spacing, origin, seed=7, chunk=64):
         """Render one synthetic view per camera directly into HBM (benchmark / test data).  Returns an opaque

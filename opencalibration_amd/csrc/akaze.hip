@@ -1811,7 +1811,8 @@ __global__ void render_views_kernel(uint8_t *__restrict__ out, int w, int h, con
 }
 
 int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_t n_images, int width, int height,
-              uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh);
+              uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh,
+              const ochip_feature_lists *lists = nullptr, double nms_radius = 8.0);
 
 } // namespace
 
@@ -1828,6 +1829,22 @@ int ochip_akaze_batch_dev(ochip_ctx *ctx, const uint8_t *images_bgr_dev, uint32_
                           uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh)
 {
     return akaze_run(ctx, images_bgr_dev, true, n_images, width, height, max_kp, kp6, desc, counts, work_wh);
+}
+
+int ochip_akaze_features(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height, uint32_t max_kp,
+                         double nms_radius, uint32_t *counts, const ochip_feature_lists *lists, int *work_wh)
+{
+    if (!lists || !lists->records || !lists->response || !lists->slot || !lists->num_sparse || !lists->conflict)
+        return OCHIP_EINVAL;
+    return akaze_run(ctx, images_bgr, false, n_images, width, height, max_kp, nullptr, nullptr, counts, work_wh, lists, nms_radius);
+}
+
+int ochip_akaze_features_dev(ochip_ctx *ctx, const uint8_t *images_bgr_dev, uint32_t n_images, int width, int height, uint32_t max_kp,
+                             double nms_radius, uint32_t *counts, const ochip_feature_lists *lists, int *work_wh)
+{
+    if (!lists || !lists->records || !lists->response || !lists->slot || !lists->num_sparse || !lists->conflict)
+        return OCHIP_EINVAL;
+    return akaze_run(ctx, images_bgr_dev, true, n_images, width, height, max_kp, nullptr, nullptr, counts, work_wh, lists, nms_radius);
 }
 
 int ochip_synth_views_alloc(ochip_ctx *ctx, uint32_t n_images, int width, int height, uint8_t **images_dev)
@@ -1909,9 +1926,10 @@ namespace
 // in unspecified order: kp6 = {x, y, size, angle(rad), response, level} in working-image pixels, desc = 8 x u64,
 // counts[i] = number written for image i (<= max_kp).  work_wh receives the working width/height.
 int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_t n_images, int width, int height,
-              uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh)
+              uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh, const ochip_feature_lists *lists,
+              double nms_radius)
 {
-    if (!ctx || !counts || (n_images && (!images_bgr || !kp6 || !desc)))
+    if (!ctx || !counts || (n_images && (!images_bgr || (!lists && (!kp6 || !desc)))))
         return OCHIP_EINVAL;
     if (width <= 0 || height <= 0)
         return ochip_fail(ctx, OCHIP_EINVAL, "bad image size %d x %d", width, height);
@@ -2411,7 +2429,11 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         }
         most = std::max(most, counts[b]);
     }
-    if (rc == OCHIP_OK && most > 0)
+    if (rc == OCHIP_OK && lists)
+        // the tail of extract_features prepared on the device (features.hip): records, suppression flags, what the
+        // host's sort needs - instead of the raw keypoint arrays
+        rc = ochip::feature_lists_enqueue(ctx, &allocs, B, max_kp, d_kpc, d_descc, d_counts, most, W, H, scale, nms_radius, lists);
+    else if (rc == OCHIP_OK && most > 0)
     {
         // one strided copy per array instead of one per image and array (2 x 100 launches per chunk): every image's row is
         // copied up to the longest list of the chunk - a few per cent more bytes, the counts say where each list ends

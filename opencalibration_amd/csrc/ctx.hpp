@@ -123,3 +123,12 @@ void ochip_prof_end(ochip_ctx *ctx, int kid, hipEvent_t start, hipEvent_t stop);
             return ochip_fail((ctx), OCHIP_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,    \
                               __LINE__);                                                                               \
     } while (0)
+
+namespace ochip
+{
+// features.hip: the tail of extract_features prepared on the device for B images whose compacted keypoints lie in HBM
+// (enqueued on the context's stream, results copied into `out`; the caller waits and returns `allocs` to the pool)
+int feature_lists_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> *allocs, uint32_t B, uint32_t max_kp,
+                          const float *d_kp6, const unsigned long long *d_desc, const unsigned int *d_counts, uint32_t most,
+                          int work_w, int work_h, double scale, double nms_radius, const ochip_feature_lists *out);
+} // namespace ochip

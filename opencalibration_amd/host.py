@@ -136,6 +136,8 @@ def load():
         L.och_image_to_3d.argtypes = [_f64p, sz, _f64p, _f64p]
         L.och_ransac_epipolar.restype = C.c_double
         L.och_ransac_epipolar.argtypes = [vp, C.c_int, _f64p, vp, sz, C.c_double, _f64p, u8p, np.ctypeslib.ndpointer(np.uint32)]
+        L.och_extract_tail_prepared.restype = C.c_size_t
+        L.och_extract_tail_prepared.argtypes = [C.c_void_p, _f32p, C.c_void_p, u32, C.c_int, u32, C.c_double, _f64p, _f32p, _u64p, _u64p]
         L.och_extract_tail.restype = C.c_size_t
         L.och_extract_tail.argtypes = [_f32p, _u64p, u32, C.c_double, _f64p, _f32p, _u64p, _u64p]
         L.och_graph_set_model.argtypes = [vp, u32, _f64p]
@@ -970,6 +972,19 @@ def extract_tail(kp6, desc, scale):
     n = len(kp6)
     loc, st, d, ns = np.zeros((n + 1, 2)), np.zeros(n + 1, np.float32), np.zeros((n + 1, 8), np.uint64), np.zeros(1, np.uint64)  # the seed keypoint appears twice
     m = L.och_extract_tail(kp6 if n else np.zeros((1, 6), np.float32), desc if n else np.zeros((1, 8), np.uint64), n, float(scale), loc, st, d, ns)
+    return loc[:m].copy(), st[:m].copy(), d[:m].copy(), int(ns[0])
+
+
+def extract_tail_prepared(lists, scale, force_host_nms=False):
+    """The host tail on lists the device prepared (capi.Context.feature_lists): (loc, strength, desc, num_sparse)."""
+    L = load()
+    n = len(lists["response"])
+    loc, st, d, ns = np.zeros((n + 1, 2)), np.zeros(n + 1, np.float32), np.zeros((n + 1, 8), np.uint64), np.zeros(1, np.uint64)
+    rec = np.ascontiguousarray(lists["records"], np.uint8) if n else np.zeros((1, 88), np.uint8)
+    resp = np.ascontiguousarray(lists["response"], np.float32) if n else np.zeros(1, np.float32)
+    slot = np.ascontiguousarray(lists["slot"], np.uint32) if n else np.zeros(1, np.uint32)
+    m = L.och_extract_tail_prepared(rec.ctypes.data, resp, slot.ctypes.data, int(lists["num_sparse"]),
+                                    int(bool(lists["conflict"]) or force_host_nms), n, float(scale), loc, st, d, ns)
     return loc[:m].copy(), st[:m].copy(), d[:m].copy(), int(ns[0])
 
 
