@@ -114,25 +114,23 @@ extern "C"
     int ochip_akaze_batch_dev(ochip_ctx *ctx, const uint8_t *images_bgr_dev, uint32_t n_images, int width, int height,
                               uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh);
 
-    /* ---- the data-parallel part of extract_features' tail (src/extract/extract_features.cpp:38-87) on the device ---- */
+    /* ---- extract_features' tail (src/extract/extract_features.cpp:38-87) on the device ---- */
     /* The reference rescales the keypoints, std::sorts them by response (unstable: libstdc++'s order among equal
-     * responses), runs a greedy 8 px suppression in that order and emits [sparse..., dense...].  The sort stays on the host
-     * (it needs `response` in detection order and nothing else); the device prepares everything around it on its own
-     * stable order (descending response, detection index ascending among equals), which differs from the host's only
-     * inside groups of equal responses.  All arrays are the caller's (host; page-locked ones copy at link speed):
+     * responses, restated move for move on the device, csrc/std_sort.hip), runs a greedy 8 px suppression in that order
+     * and emits [sparse..., dense...].  All arrays are the caller's (host; page-locked ones copy at link speed):
      *   records    [n][max_kp + 1][88]  the image's output list [sparse..., dense...] as feature_2d records (location =
-     *                                   pt / scale as doubles, strength, 4 bytes padding, 8 descriptor words) under the
-     *                                   device's order: counts[i] + 1 records (the strongest feature heads both lists: the
-     *                                   reference visits its seed again, :60-66)
+     *                                   pt / scale as doubles, strength, 4 bytes padding, 8 descriptor words):
+     *                                   counts[i] + 1 records (the strongest feature heads both lists: the reference
+     *                                   visits its seed again, :60-66)
      *   response   [n][max_kp]          responses in detection order
      *   slot       [n][max_kp]          slot[s] = where the keypoint of detection index s lies in `records` (the seed:
      *                                   its sparse slot, 0)
      *   num_sparse [n]                  length of the sparse list
-     *   conflict   [n]                  non-zero: two equal responses lie within the radius of each other, or the
-     *                                   strongest response is tied - the suppression's outcome then depends on the host's
-     *                                   order, the host runs it itself for this image and only uses the records
-     * Where the host's order differs inside a group of equal responses (and conflict is 0) the group's sparse members keep
-     * the group's sparse slots and its dense members its dense slots, re-seated in the host's order. */
+     *   conflict   [n]                  non-zero: this image's responses drive introsort to its depth limit, where
+     *                                   libstdc++ switches to a heap sort the device does not restate; `records` then
+     *                                   holds the features in no particular order and the host orders and suppresses
+     *                                   them itself (host/extract_features.cpp: extract_tail_prepared), using `response`
+     *                                   and `slot`.  Never seen on detector output; organ-pipe responses do it. */
     typedef struct ochip_feature_lists
     {
         uint8_t *records;
@@ -471,6 +469,12 @@ extern "C"
     int ochip_relax_memory(ochip_ctx *ctx, uint64_t *unknowns, uint64_t *stored_bytes, uint64_t *dense_bytes);
 
     /* ---- diagnostics ----------------------------------------------------------------------------- */
+    /* libstdc++'s std::sort on the device (csrc/std_sort.hip), for the tests: segment s = [offsets[s], offsets[s + 1]) of
+     * (keys, payload), sorted as std::sort with comp(a, b) = key(a) > key(b) leaves them - the permutation among equal keys
+     * included.  fallback_out[s] != 0: the segment hit introsort's depth limit (libstdc++ heap-sorts there) and is NOT
+     * sorted; callers sort such a segment on the host. */
+    int ochip_debug_std_sort(ochip_ctx *ctx, const uint32_t *keys, const uint32_t *payload, const uint32_t *offsets, uint32_t n_segs,
+                             uint32_t *keys_out, uint32_t *payload_out, uint8_t *fallback_out);
     /* out[i] = x[i] op y[i] computed on the device with the hot-path kernels' compile flags:
      * op 0: x/y, 1: sqrt(x), 2: log(x), 3: x*y+x (unfused), 4: x+y.  Host pointers. */
     int ochip_debug_fp64(ochip_ctx *ctx, int op, const double *x, const double *y, size_t n, double *out);

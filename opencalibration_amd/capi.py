@@ -29,7 +29,7 @@ EXPORTS = [
     "ochip_relaxp_problem_create", "ochip_relaxp_problem_destroy", "ochip_relaxp_set_structure_only", "ochip_relaxp_solve",
     "ochip_relaxp_get_state",
     "ochip_profile_reset", "ochip_profile_get", "ochip_match_work", "ochip_relax_work", "ochip_relax_memory",
-    "ochip_debug_fp64",
+    "ochip_debug_fp64", "ochip_debug_std_sort",
     "ochip_dense_index_create", "ochip_dense_index_destroy", "ochip_dense_match",
     "ochip_rccl_unique_id", "ochip_rccl_comm_create", "ochip_rccl_comm_destroy", "ochip_rccl_comm_stats",
     "ochip_rccl_relax_exchange",
@@ -74,6 +74,7 @@ def load():
         L.ochip_relax_work.argtypes = [vp, C.POINTER(C.c_double)]
         L.ochip_relax_memory.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
         L.ochip_debug_fp64.argtypes = [vp, i32, vp, vp, C.c_size_t, vp]
+        L.ochip_debug_std_sort.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]
         L.ochip_akaze_batch.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
         L.ochip_feature_lists_from_keypoints.argtypes = [vp, vp, vp, vp, u32, u32, i32, i32, C.c_double, C.c_double, vp]
         L.ochip_akaze_batch_dev.argtypes = [vp, vp, u32, i32, i32, u32, vp, vp, vp, vp]
@@ -205,6 +206,21 @@ class Context:
         self._check(self.L.ochip_akaze_batch(self.h, imgs.ctypes.data, n, w, h, max_kp, kp.ctypes.data, desc.ctypes.data,
                                              counts.ctypes.data, wh.ctypes.data), "ochip_akaze_batch")
         return [(kp[i, :counts[i]].copy(), desc[i, :counts[i]].copy()) for i in range(n)], (int(wh[0]), int(wh[1]))
+
+    def std_sort(self, keys, payload, offsets):
+        """ochip_debug_std_sort: (keys, payload, fallback flags) with every segment [offsets[s], offsets[s + 1]) ordered as
+        std::sort by descending key leaves it."""
+        keys = np.ascontiguousarray(keys, np.uint32)
+        payload = np.ascontiguousarray(payload, np.uint32)
+        offsets = np.ascontiguousarray(offsets, np.uint32)
+        n_segs = len(offsets) - 1
+        ko, po = np.zeros(max(len(keys), 1), np.uint32), np.zeros(max(len(keys), 1), np.uint32)
+        fb = np.zeros(max(n_segs, 1), np.uint8)
+        kin = keys if len(keys) else np.zeros(1, np.uint32)
+        pin = payload if len(keys) else np.zeros(1, np.uint32)
+        self._check(self.L.ochip_debug_std_sort(self.h, kin.ctypes.data, pin.ctypes.data, offsets.ctypes.data, n_segs, ko.ctypes.data,
+                                                po.ctypes.data, fb.ctypes.data), "ochip_debug_std_sort")
+        return ko[:len(keys)], po[:len(keys)], fb[:n_segs].astype(bool)
 
     def feature_lists(self, kp6, desc, work_wh, scale, nms_radius=8.0):
         """ochip_feature_lists_from_keypoints for ONE image's keypoints (detection order): dict of records ((n + 1) x 88

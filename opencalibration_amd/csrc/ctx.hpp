@@ -132,3 +132,11 @@ int feature_lists_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>>
                           const float *d_kp6, const unsigned long long *d_desc, const unsigned int *d_counts, uint32_t most,
                           int work_w, int work_h, double scale, double nms_radius, const ochip_feature_lists *out);
 } // namespace ochip
+
+namespace ochip
+{
+// std_sort.hip: libstdc++'s std::sort (comp(a, b) = high half of a > high half of b) on segments of 64-bit records in HBM
+int std_sort_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> *allocs, unsigned long long *recs, size_t total_len,
+                     const unsigned int *seg_begin, const unsigned int *seg_end, uint32_t n_segs, uint32_t max_len,
+                     unsigned char *fallback);
+} // namespace ochip

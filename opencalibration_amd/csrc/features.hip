@@ -1,30 +1,25 @@
-// libochip.so — the data-parallel part of extract_features' host tail on the device (gfx950).
+// libochip.so — extract_features' tail on the device (gfx950).
 //
 // src/extract/extract_features.cpp:38-87 turns the keypoints cv::AKAZE returned into the image's feature list: rescale to
 // original-image pixels, std::sort by descending response, a greedy 8 px non-maximum suppression in that order through a
-// KD-tree, output [sparse..., dense...].  The ORDER is libstdc++'s unstable std::sort's and stays with the host
-// (host/extract_features.cpp: sort_like_std on the responses in detection order - it decides the result wherever two
-// responses are equal, which happens in almost every image).  Everything else is done here on the device's own stable
-// ordering (descending response, detection index ascending among equals), which differs from the host's only inside
-// groups of equal responses:
+// KD-tree, output [sparse..., dense...].  All of it runs here, per chunk of images:
+//   * the ORDER is libstdc++'s unstable std::sort's, reproduced move for move by std_sort.hip on (response, detection
+//     index) records - it decides the result wherever two responses are equal, which happens in almost every image;
 //   * the greedy suppression, as a fixed point: a feature is sparse when every stronger feature within the radius is dense
 //     and dense as soon as one of them is sparse (the greedy pass's answer, reached in as many rounds as the longest chain
 //     of undecided neighbours) - same fp64 distance test as the reference's KD-tree query
 //     (nn[0].distance * scale^2 > radius^2, extract_features.cpp:72);
 //   * the image's whole output list [sparse..., dense...] as 88-byte feature_2d records (location = pt / scale in fp64,
-//     strength, 486-bit descriptor): the host copies it in one piece and re-seats the few members of equal-response
-//     groups where its order differs (slot[s]: where detection index s went);
-//   * a per-image flag when the two orders can disagree about the OUTCOME of the suppression: two features of equal
-//     response within the radius of each other, or a tie for the strongest feature (which the reference seeds the sparse
-//     list with and then visits again, extract_features.cpp:60-66).  The host then runs the suppression itself.
+//     strength, 486-bit descriptor): the host copies it in one piece.
+// The one thing not restated on the device is the heap sort libstdc++ falls back to at introsort's depth limit: an image
+// whose responses drive it there (none has) is flagged, and the host then sorts and suppresses that image itself from the
+// records (slot[s]: where detection index s went), as it did for every image before round 3.
 #include "ctx.hpp"
 
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 using namespace ochip;
 
@@ -46,8 +41,8 @@ struct feat_dev
     const float *kp6;                 // [B][max_kp][6], detection order
     const unsigned long long *desc;   // [B][max_kp][8]
     const unsigned int *counts;       // [B]
-    unsigned long long *keys, *keys2; // [B][S] image << 32 | ~response bits (ascending = image, then descending response)
-    unsigned int *vals, *det;         // [B][S] detection index; det = sorted
+    unsigned long long *recs;         // [B][S] response key << 32 | detection index; sorted in place (std_sort.hip)
+    unsigned int *seg_begin, *seg_end; // [B] the images' segments of recs
     float *resp;                      // [B][S] responses in detection order
     double2 *loc;                     // [B][S] pt / scale of the r-th strongest
     unsigned int *cell;               // [B][S] its grid cell
@@ -79,23 +74,22 @@ __device__ __forceinline__ bool feat_within(const feat_dev &F, const double2 &a,
 __global__ void feat_keys_kernel(feat_dev F)
 {
     const unsigned int b = blockIdx.z, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= F.S)
+    const unsigned int n = feat_count(F, b);
+    if (i == 0)
+    {
+        F.seg_begin[b] = b * F.S;
+        F.seg_end[b] = b * F.S + n;
+    }
+    if (i >= n)
         return;
     const size_t o = (size_t)b * F.S + i;
-    unsigned int inv = 0xFFFFFFFFu; // padding sorts behind the image's keypoints
-    if (i < feat_count(F, b))
-    {
-        const float r = F.kp6[((size_t)b * F.max_kp + i) * 6 + 4];
-        // responses are positive floats (determinants above the detector threshold): they order like their bit patterns;
-        // anything else (never produced by the detector) still gets a total order
-        const unsigned int u = __float_as_uint(r);
-        inv = ~((u & 0x80000000u) ? ~u : (u | 0x80000000u));
-        if (inv == 0xFFFFFFFFu)
-            inv = 0xFFFFFFFEu;
-        F.resp[o] = r;
-    }
-    F.keys[o] = ((unsigned long long)b << 32) | inv;
-    F.vals[o] = i;
+    const float r = F.kp6[((size_t)b * F.max_kp + i) * 6 + 4];
+    // responses are positive floats (determinants above the detector threshold): they order like their bit patterns;
+    // anything else (never produced by the detector) still gets a total order
+    const unsigned int u = __float_as_uint(r);
+    const unsigned int key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    F.resp[o] = r;
+    F.recs[o] = ((unsigned long long)key << 32) | i;
 }
 
 // per feature in strength order: location, grid cell, the cell's population
@@ -105,7 +99,7 @@ __global__ void feat_cells_kernel(feat_dev F)
     if (r >= feat_count(F, b))
         return;
     const size_t o = (size_t)b * F.S + r;
-    const size_t src = (size_t)b * F.max_kp + F.det[o];
+    const size_t src = (size_t)b * F.max_kp + (unsigned int)F.recs[o];
     const float x = F.kp6[src * 6], y = F.kp6[src * 6 + 1];
     F.loc[o] = make_double2((double)x / F.scale, (double)y / F.scale); // keypoints[i].pt / scale, extract_features.cpp:44-45
     const int cx = min(max((int)(x / CELL), 0), F.gw - 1), cy = min(max((int)(y / CELL), 0), F.gh - 1);
@@ -115,20 +109,22 @@ __global__ void feat_cells_kernel(feat_dev F)
 }
 
 // exclusive scan of an image's cell populations; the fill cursors are zeroed for the next kernel.  One workgroup per image.
-__global__ __launch_bounds__(1024) void feat_scan_kernel(feat_dev F)
+constexpr int SCAN_THREADS = 256; // (a 1 024-thread workgroup waits for sixteen free wave slots on one CU: under the other
+                                  // launch sequences' kernels that took up to 12 ms)
+__global__ __launch_bounds__(SCAN_THREADS) void feat_scan_kernel(feat_dev F)
 {
-    __shared__ unsigned int s_scan[1024];
+    __shared__ unsigned int s_scan[SCAN_THREADS];
     const unsigned int b = blockIdx.x, t = threadIdx.x;
     const int n_cells = F.gw * F.gh;
     unsigned int *start = F.cell_start + (size_t)b * (n_cells + 1), *fill = F.cell_fill + (size_t)b * n_cells;
-    const int per = (n_cells + 1023) / 1024;
+    const int per = (n_cells + SCAN_THREADS - 1) / SCAN_THREADS;
     const int c0 = min((int)t * per, n_cells), c1 = min(c0 + per, n_cells);
     unsigned int sum = 0;
     for (int c = c0; c < c1; c++)
         sum += fill[c];
     s_scan[t] = sum;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1)
+    for (int off = 1; off < SCAN_THREADS; off <<= 1)
     {
         const unsigned int v = t >= (unsigned int)off ? s_scan[t - off] : 0u;
         __syncthreads();
@@ -143,8 +139,8 @@ __global__ __launch_bounds__(1024) void feat_scan_kernel(feat_dev F)
         fill[c] = 0;
         run += k;
     }
-    if (t == 1023)
-        start[n_cells] = s_scan[1023];
+    if (t == SCAN_THREADS - 1)
+        start[n_cells] = s_scan[SCAN_THREADS - 1];
 }
 
 __global__ void feat_fill_kernel(feat_dev F)
@@ -209,20 +205,17 @@ __global__ void feat_round_kernel(feat_dev F)
 }
 
 // One workgroup per image: the rounds that are left (in LDS), the order-dependence check, the output slots.
-constexpr int FIN_THREADS = 1024;
+constexpr int FIN_THREADS = 256;
 __global__ __launch_bounds__(FIN_THREADS) void feat_finish_kernel(feat_dev F)
 {
     extern __shared__ unsigned char state[]; // [S]
     __shared__ unsigned int s_scan[FIN_THREADS];
-    __shared__ int s_again, s_conflict;
+    __shared__ int s_again;
     const unsigned int b = blockIdx.x, t = threadIdx.x;
     const unsigned int n = feat_count(F, b);
     const size_t base = (size_t)b * F.S;
     if (t == 0)
-    {
-        s_conflict = 0;
         s_again = 0;
-    }
     for (unsigned int r = t; r < n; r += FIN_THREADS)
         state[r] = F.state[base + r];
     __syncthreads();
@@ -249,21 +242,6 @@ __global__ __launch_bounds__(FIN_THREADS) void feat_finish_kernel(feat_dev F)
         if (!again)
             break;
         __syncthreads();
-    }
-    // ---- can the host's order (libstdc++'s std::sort: any permutation inside a group of equal responses) change the
-    //      outcome?  Only through two members of such a group within the radius of each other, or a tie at the top.
-    const unsigned long long *K = F.keys2 + base;
-    for (unsigned int r = t; r + 1 < n; r += FIN_THREADS)
-    {
-        const unsigned long long k = K[r];
-        if (K[r + 1] != k)
-            continue;
-        if (r == 0)
-            s_conflict = 1;
-        const double2 me = F.loc[base + r];
-        for (unsigned int q = r + 1; q < n && K[q] == k; q++)
-            if (feat_within(F, me, F.loc[base + q]))
-                s_conflict = 1;
     }
     // ---- output slots: sparse features in strength order, then the dense ones, headed by the seed (visited again by the
     //      reference's loop, extract_features.cpp:64-66).  Exclusive scan of the sparse flags, a contiguous run per thread.
@@ -292,10 +270,7 @@ __global__ __launch_bounds__(FIN_THREADS) void feat_finish_kernel(feat_dev F)
     }
     __syncthreads();
     if (t == 0)
-    {
         F.n_sparse[b] = n ? total_sparse : 0u;
-        F.conflict[b] = (unsigned char)s_conflict;
-    }
 }
 
 // the records at their slots (the seed twice: slot 0 and slot n_sparse), slot[s] for the host's re-seating
@@ -305,7 +280,7 @@ __global__ void feat_records_kernel(feat_dev F)
     if (r >= feat_count(F, b))
         return;
     const size_t o = (size_t)b * F.S + r;
-    const unsigned int s = F.det[o];
+    const unsigned int s = (unsigned int)F.recs[o];
     const size_t src = (size_t)b * F.max_kp + s;
     unsigned long long rec[11];
     const double2 l = F.loc[o];
@@ -374,10 +349,9 @@ int feature_lists_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>>
             allocs->emplace_back(p, got);
         return p;
     };
-    F.keys = (unsigned long long *)dev(N * 8);
-    F.keys2 = (unsigned long long *)dev(N * 8);
-    F.vals = (unsigned int *)dev(N * 4);
-    F.det = (unsigned int *)dev(N * 4);
+    F.recs = (unsigned long long *)dev(N * 8);
+    F.seg_begin = (unsigned int *)dev((size_t)B * 4);
+    F.seg_end = (unsigned int *)dev((size_t)B * 4);
     F.resp = (float *)dev(N * 4);
     F.loc = (double2 *)dev(N * 16);
     F.cell = (unsigned int *)dev(N * 4);
@@ -390,26 +364,21 @@ int feature_lists_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>>
     F.n_sparse = (unsigned int *)dev((size_t)B * 4);
     F.conflict = (unsigned char *)dev(B);
     F.records = (unsigned char *)dev((size_t)B * (F.S + 1) * 88);
-    if (!F.keys || !F.keys2 || !F.vals || !F.det || !F.resp || !F.loc || !F.cell || !F.cell_start || !F.cell_fill || !F.items || !F.state ||
+    if (!F.recs || !F.seg_begin || !F.seg_end || !F.resp || !F.loc || !F.cell || !F.cell_start || !F.cell_fill || !F.items || !F.state ||
         !F.slot_of_rank || !F.slot || !F.n_sparse || !F.conflict || !F.records)
         return ochip_fail(ctx, OCHIP_ENOMEM, "feature lists: device allocation failed");
     const dim3 wide((F.S + 255) / 256, 1, B);
     hipLaunchKernelGGL(feat_keys_kernel, wide, dim3(256), 0, st, F);
-    // ONE stable radix sort for the whole chunk: image number above the (inverted) response bits
-    unsigned int image_bits = 1;
-    while ((1u << image_bits) < B)
-        image_bits++;
-    size_t temp_bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, temp_bytes, F.keys, F.keys2, F.vals, F.det, N, 0, 32 + image_bits, st) != hipSuccess)
-        return ochip_fail(ctx, OCHIP_EHIP, "feature lists: sort set-up failed");
-    void *temp = dev(temp_bytes);
-    if (!temp)
-        return ochip_fail(ctx, OCHIP_ENOMEM, "feature lists: device allocation failed (sort, %zu bytes)", temp_bytes);
-    if (rocprim::radix_sort_pairs(temp, temp_bytes, F.keys, F.keys2, F.vals, F.det, N, 0, 32 + image_bits, st) != hipSuccess)
-        return ochip_fail(ctx, OCHIP_EHIP, "feature lists: sort failed");
+    // the strength order: std::sort by descending response from detection order, as the reference's (std_sort.hip);
+    // conflict[b] = that image ran into introsort's depth limit and is the host's
+    {
+        const int src = std_sort_enqueue(ctx, allocs, F.recs, N, F.seg_begin, F.seg_end, B, most, F.conflict);
+        if (src != OCHIP_OK)
+            return src;
+    }
     OCHIP_HIP(ctx, hipMemsetAsync(F.cell_fill, 0, (size_t)B * n_cells * 4, st));
     hipLaunchKernelGGL(feat_cells_kernel, wide, dim3(256), 0, st, F);
-    hipLaunchKernelGGL(feat_scan_kernel, dim3(B), dim3(1024), 0, st, F);
+    hipLaunchKernelGGL(feat_scan_kernel, dim3(B), dim3(SCAN_THREADS), 0, st, F);
     hipLaunchKernelGGL(feat_fill_kernel, wide, dim3(256), 0, st, F);
     static const int rounds = getenv("OCHIP_FEATURE_ROUNDS") ? std::max(0, atoi(getenv("OCHIP_FEATURE_ROUNDS"))) : 6;
     for (int k = 0; k < rounds; k++)

@@ -250,33 +250,32 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
     }
 }
 
-// The same tail when the device has prepared it (csrc/features.hip, ochip_akaze_features): `records` is the image's whole
-// output list [sparse..., dense...] under the device's stable strength order, slot[s] the place of detection index s in it.
-// What is left for the host is the order itself - libstdc++'s std::sort of the responses from detection order - one copy
-// of the list, and, where the two orders differ inside a group of equal responses, re-seating that group's members (its
-// sparse members keep the group's sparse slots, its dense members its dense slots).  conflict: the suppression's outcome
-// depends on the order inside such a group; it is then run here, from the records.
+// The same tail when the device has run it (csrc/features.hip, ochip_akaze_features): `records` is the image's whole output
+// list [sparse..., dense...] - the strength order included, libstdc++'s std::sort restated on the device
+// (csrc/std_sort.hip) - and the host copies it.  conflict: the image's responses drove introsort to its depth limit, where
+// libstdc++ heap-sorts and the device does not follow: the order and the suppression are then computed here, from the
+// records (slot[s]: the record of detection index s) and the responses in detection order.
 void extract_tail_prepared(const uint8_t *records, const float *response, const uint32_t *slot, uint32_t num_sparse, bool conflict,
                            uint32_t n, double scale, extracted_features &out)
 {
     static const bool prof = std::getenv("OCHIP_EXTRACT_VERBOSE") != nullptr;
     const double tp0 = prof ? thread_cpu_now() : 0;
-    double tp1 = 0, tp2 = 0;
+    double tp1 = tp0, tp2 = tp0;
     const double nms_pixel_radius = 8;
     out.features.clear();
     out.num_sparse_features = 0;
     if (n == 0)
         return;
-    static thread_local std::vector<by_response> recs;
-    recs.resize(n);
-    for (uint32_t i = 0; i < n; i++)
-        recs[i] = by_response{response[i], i};
-    sort_like_std(recs.data(), recs.data() + n, [](const by_response &a, const by_response &c) -> bool { return a.response > c.response; });
-    if (prof)
-        tp1 = thread_cpu_now();
     const feature_2d *R = reinterpret_cast<const feature_2d *>(records);
     if (conflict)
     {
+        static thread_local std::vector<by_response> recs;
+        recs.resize(n);
+        for (uint32_t i = 0; i < n; i++)
+            recs[i] = by_response{response[i], i};
+        sort_like_std(recs.data(), recs.data() + n, [](const by_response &a, const by_response &c) -> bool { return a.response > c.response; });
+        if (prof)
+            tp1 = thread_cpu_now();
         static thread_local std::vector<double> lx, ly;
         lx.resize(n);
         ly.resize(n);
@@ -309,40 +308,8 @@ void extract_tail_prepared(const uint8_t *records, const float *response, const 
     }
     else
     {
-        if (prof)
-            tp2 = tp1;
         out.features.assign(R, R + (size_t)n + 1);
         out.num_sparse_features = num_sparse;
-        // groups of equal responses: the device listed a group's members by ascending detection index, std::sort left them
-        // in the order recs holds
-        for (uint32_t i0 = 0; i0 + 1 < n;)
-        {
-            uint32_t i1 = i0 + 1;
-            while (i1 < n && recs[i1].response == recs[i0].response)
-                i1++;
-            if (i1 - i0 > 1)
-            {
-                bool same = true;
-                for (uint32_t i = i0 + 1; i < i1; i++)
-                    same = same && recs[i - 1].index < recs[i].index;
-                if (!same)
-                {
-                    std::vector<uint32_t> sparse_slots, dense_slots;
-                    for (uint32_t i = i0; i < i1; i++)
-                        (slot[recs[i].index] < num_sparse ? sparse_slots : dense_slots).push_back(slot[recs[i].index]);
-                    std::sort(sparse_slots.begin(), sparse_slots.end());
-                    std::sort(dense_slots.begin(), dense_slots.end());
-                    size_t ks = 0, kd = 0;
-                    for (uint32_t i = i0; i < i1; i++)
-                    {
-                        const uint32_t from = slot[recs[i].index];
-                        const uint32_t to = from < num_sparse ? sparse_slots[ks++] : dense_slots[kd++];
-                        out.features[to] = R[from];
-                    }
-                }
-            }
-            i0 = i1;
-        }
     }
     if (prof)
     {

@@ -1,0 +1,584 @@
+// libochip.so (internal) — libstdc++'s std::sort on the device, permutation for permutation (gfx950).
+//
+// Two places of the path order things with an UNSTABLE std::sort whose outcome among equal keys is part of the result:
+// the keypoints by response (src/extract/extract_features.cpp:55-56) and the matches by descriptor distance, then the
+// PROSAC order by quality (src/match/match_features.cpp:100-101, src/model_inliers/ransac.cpp:83-90).  Equal keys are the
+// rule there (a few equal floats among 20 k responses in almost every image; Hamming counts tie all the time), so matching
+// the reference means reproducing what GCC's introsort does to the order it is given: bits/stl_algo.h - __introsort_loop
+// with the median of three moved to the front, __unguarded_partition, depth limit 2 lg n, threshold 16,
+// __final_insertion_sort.  That algorithm is a tree of partitions over disjoint ranges; its moves only depend on the
+// comparator's answers, and a partition's moves can be stated from the range's content BEFORE it:
+//   * the left scan stops at the elements with !comp(x, pivot), the right scan at those with !comp(pivot, x); the k-th
+//     stop from the left is swapped with the k-th stop from the right for as long as the former lies left of the latter
+//     (a swapped element is never looked at again by the scan that passed it), say K times;
+//   * the cut is the (K + 1)-th left stop or the K-th right stop's position, whichever comes first (a scan that runs
+//     into the other side's swapped elements stops at the first of them), or the first left stop when K = 0;
+// so a partition is two prefix counts, a count of the pairs in order, K independent swaps.  The recursion's two ranges are
+// independent: the long ranges of one depth are partitioned by one launch (a workgroup or a wavefront per range), level
+// after level, until a range has at most 1 024 elements; such a range is finished by ONE wavefront in LDS (the same
+// partition, the rest of its recursion from a small stack - no more launches, no more HBM round trips).  Ranges of at most
+// 16 elements go to the final insertion sort, which never moves an element out of its range (everything left of a range
+// is not after it in the order) - one lane per range.  The heap sort
+// libstdc++ falls back to at the depth limit is NOT restated: a segment that gets there is flagged and its caller
+// sorts it on the host (organ pipes and median-of-three killers do; responses and Hamming counts do not).
+// scripts/check_parallel_std_sort.py holds the formulation against std::sort on the CPU, tests/test_gpu_std_sort.py the
+// kernels.
+//
+// Records are 64-bit: key in the high half, payload in the low half; comp(a, b) = key(a) > key(b) (descending; an
+// ascending sort complements its keys).
+#include "ctx.hpp"
+
+#include <algorithm>
+#include <vector>
+
+using namespace ochip;
+
+namespace
+{
+
+typedef unsigned long long u64;
+constexpr unsigned int THRESHOLD = 16;  // _S_threshold
+constexpr unsigned int LOCAL = 1024;    // ranges up to this length are finished by one wavefront in LDS
+constexpr unsigned int BIG = 2048;      // ranges longer than this take a whole workgroup, (LOCAL, BIG] a wavefront, per level
+constexpr int GROUP = 256;              // threads of the workgroup that partitions a long range
+
+struct range_t
+{
+    unsigned int first, last, depth, seg;
+};
+
+struct sort_dev
+{
+    u64 *A;
+    unsigned int *listL, *listR; // scratch: stop positions of the range [lo, hi) at [lo, ...)
+    range_t *queue[3];           // ranges of the current / next level (rotating: the third one's counter is being reset)
+    range_t *big[3];             // same, for the ranges a whole workgroup takes
+    range_t *final_ranges;       // ranges of 2..16 elements
+    range_t *local;              // ranges of 17..LOCAL elements
+    unsigned int *counts;        // [0..2] queue sizes, [3..5] big sizes, [6] final, [7] local, [8] error
+    unsigned int cap_queue, cap_final, cap_level; // of local, final_ranges, the level queues
+    unsigned char *fallback;     // [n_segs]
+    unsigned int *error;         // a queue overflowed (cannot happen with the capacities below; checked anyway)
+};
+
+__device__ __forceinline__ bool comp(u64 a, u64 b)
+{
+    return (unsigned int)(a >> 32) > (unsigned int)(b >> 32);
+}
+
+__device__ __forceinline__ void push_range(const sort_dev &S, int next, unsigned int first, unsigned int last, unsigned int depth,
+                                           unsigned int seg, bool big_allowed)
+{
+    const unsigned int len = last - first;
+    if (len < 2)
+        return;
+    if (len <= THRESHOLD)
+    {
+        const unsigned int at = atomicAdd(&S.counts[6], 1u);
+        if (at < S.cap_final)
+            S.final_ranges[at] = range_t{first, last, depth, seg};
+        else
+            *S.error = 1;
+        return;
+    }
+    if (len <= LOCAL)
+    {
+        const unsigned int at = atomicAdd(&S.counts[7], 1u);
+        if (at < S.cap_queue)
+            S.local[at] = range_t{first, last, depth, seg};
+        else
+            *S.error = 1;
+        return;
+    }
+    const bool to_big = big_allowed && len > BIG;
+    const unsigned int at = atomicAdd(&S.counts[(to_big ? 3 : 0) + next], 1u);
+    if (at < S.cap_level)
+        (to_big ? S.big[next] : S.queue[next])[at] = range_t{first, last, depth, seg};
+    else
+        *S.error = 1;
+}
+
+__global__ void sort_init_kernel(sort_dev S, const unsigned int *__restrict__ seg_begin, const unsigned int *__restrict__ seg_end,
+                                 unsigned int n_segs)
+{
+    const unsigned int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs)
+        return;
+    S.fallback[s] = 0;
+    const unsigned int first = seg_begin[s], last = seg_end[s];
+    if (last <= first)
+        return;
+    unsigned int lg = 0;
+    for (unsigned int n = last - first; n > 1; n >>= 1)
+        lg++;
+    push_range(S, 0, first, last, 2 * lg, s, true);
+}
+
+// ---- group primitives: G threads that partition one range together (a wavefront or a workgroup)
+template <int G> struct group;
+template <> struct group<64>
+{
+    static __device__ __forceinline__ int tid()
+    {
+        return threadIdx.x & 63;
+    }
+    static __device__ __forceinline__ void sync()
+    {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // exclusive prefix of v over the group's threads, *total = the sum
+    static __device__ __forceinline__ unsigned int scan(unsigned int v, unsigned int *total, unsigned int *)
+    {
+        const int lane = tid();
+        unsigned int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const unsigned int o = (unsigned int)__shfl_up((int)incl, off);
+            if (lane >= off)
+                incl += o;
+        }
+        *total = (unsigned int)__shfl((int)incl, 63);
+        return incl - v;
+    }
+};
+template <> struct group<GROUP>
+{
+    static __device__ __forceinline__ int tid()
+    {
+        return threadIdx.x;
+    }
+    static __device__ __forceinline__ void sync()
+    {
+        __syncthreads();
+    }
+    static __device__ __forceinline__ unsigned int scan(unsigned int v, unsigned int *total, unsigned int *lds /*[GROUP]*/)
+    {
+        const int t = threadIdx.x;
+        __syncthreads();
+        lds[t] = v;
+        __syncthreads();
+        for (int off = 1; off < GROUP; off <<= 1)
+        {
+            const unsigned int o = t >= off ? lds[t - off] : 0u;
+            __syncthreads();
+            lds[t] += o;
+            __syncthreads();
+        }
+        *total = lds[GROUP - 1];
+        return lds[t] - v;
+    }
+};
+
+// one step of __introsort_loop on range r: median of three to the front, __unguarded_partition, the two ranges it leaves
+template <int G> __device__ void partition_range(const sort_dev &S, const range_t r, int next, bool big_allowed, unsigned int *lds)
+{
+    u64 *A = S.A;
+    const unsigned int t = (unsigned int)group<G>::tid();
+    const unsigned int first = r.first, last = r.last;
+    if (r.depth == 0)
+    {
+        if (t == 0)
+            S.fallback[r.seg] = 1; // libstdc++ heap-sorts this range; the caller sorts the segment on the host
+        return;
+    }
+    if (t == 0)
+    {
+        // __move_median_to_first(first, first + 1, mid, last - 1)
+        const unsigned int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+        const u64 va = A[a], vb = A[b], vc = A[c];
+        unsigned int pick;
+        if (comp(va, vb))
+            pick = comp(vb, vc) ? b : (comp(va, vc) ? c : a);
+        else
+            pick = comp(va, vc) ? a : (comp(vb, vc) ? c : b);
+        const u64 vf = A[first], vp = A[pick];
+        A[first] = vp;
+        A[pick] = vf;
+    }
+    group<G>::sync();
+    const u64 pivot = A[first];
+    const unsigned int lo = first + 1, hi = last, m = hi - lo;
+    const unsigned int per = (m + G - 1) / G;
+    const unsigned int i0 = lo + min(t * per, m), i1 = min(i0 + per, hi);
+    unsigned int cl = 0, cr = 0;
+    for (unsigned int i = i0; i < i1; i++)
+    {
+        const u64 v = A[i];
+        cl += comp(v, pivot) ? 0u : 1u; // where "while (comp(*first, pivot)) ++first" stops
+        cr += comp(pivot, v) ? 0u : 1u; // where "while (comp(pivot, *last)) --last" stops
+    }
+    unsigned int nL, nR;
+    unsigned int ol = group<G>::scan(cl, &nL, lds);
+    unsigned int orr = group<G>::scan(cr, &nR, lds);
+    unsigned int *LL = S.listL + lo, *LR = S.listR + lo;
+    for (unsigned int i = i0; i < i1; i++)
+    {
+        const u64 v = A[i];
+        if (!comp(v, pivot))
+            LL[ol++] = i;
+        if (!comp(pivot, v))
+            LR[orr++] = i;
+    }
+    group<G>::sync();
+    // the k-th left stop is swapped with the k-th right stop (from the right) while it lies left of it
+    const unsigned int kmax = min(nL, nR);
+    unsigned int mine = 0;
+    for (unsigned int k = t; k < kmax; k += G)
+        mine += LL[k] < LR[nR - 1 - k] ? 1u : 0u;
+    unsigned int K;
+    (void)group<G>::scan(mine, &K, lds);
+    for (unsigned int k = t; k < K; k += G)
+    {
+        const unsigned int i = LL[k], j = LR[nR - 1 - k];
+        const u64 vi = A[i], vj = A[j];
+        A[i] = vj;
+        A[j] = vi;
+    }
+    if (t == 0)
+    {
+        unsigned int cut;
+        if (K == 0)
+            cut = LL[0];
+        else
+        {
+            cut = LR[nR - K];
+            if (K < nL)
+                cut = min(cut, LL[K]);
+        }
+        // __introsort_loop(cut, last, depth_limit) and the loop's next round on [first, cut), both with the decremented limit
+        push_range(S, next, cut, last, r.depth - 1, r.seg, big_allowed);
+        push_range(S, next, first, cut, r.depth - 1, r.seg, big_allowed);
+    }
+}
+
+// one level: the long ranges by the whole workgroup, one after the other, then the others a wavefront each.  The counter
+// of the queues consumed by the level before (refilled by the level after) is reset on the way.
+__global__ __launch_bounds__(GROUP) void sort_level_kernel(sort_dev S, int cur, int next, int stale)
+{
+    __shared__ unsigned int lds[GROUP];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        S.counts[stale] = 0;
+        S.counts[3 + stale] = 0;
+    }
+    const unsigned int nb = min(S.counts[3 + cur], S.cap_level);
+    for (unsigned int idx = blockIdx.x; idx < nb; idx += gridDim.x)
+        partition_range<GROUP>(S, S.big[cur][idx], next, true, lds);
+    const unsigned int n = min(S.counts[cur], S.cap_level);
+    for (unsigned int idx = blockIdx.x * (GROUP / 64) + (threadIdx.x >> 6); idx < n; idx += gridDim.x * (GROUP / 64))
+        partition_range<64>(S, S.queue[cur][idx], next, true, nullptr);
+}
+
+// ranges still waiting in the level queues after the last level launched: the host's
+__global__ void sort_flag_left_kernel(sort_dev S, int cur)
+{
+    const unsigned int nq = min(S.counts[cur], S.cap_level), nb = min(S.counts[3 + cur], S.cap_level);
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq + nb; i += gridDim.x * blockDim.x)
+        S.fallback[(i < nq ? S.queue[cur][i] : S.big[cur][i - nq]).seg] = 1;
+}
+
+// A range of at most LOCAL elements, finished by one wavefront in LDS: the rest of its __introsort_loop recursion from a
+// stack (the order in which ranges are taken does not matter, they are disjoint), then the final insertion sort of its
+// ranges of at most 16, a lane per range.
+__global__ __launch_bounds__(256) void sort_local_kernel(sort_dev S)
+{
+    __shared__ u64 data_all[4][LOCAL];
+    __shared__ unsigned short LL_all[4][LOCAL], LR_all[4][LOCAL];
+    __shared__ unsigned int stack_all[4][64][2], fin_all[4][LOCAL / 2];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u64 *D = data_all[wv];
+    unsigned short *LL = LL_all[wv], *LR = LR_all[wv];
+    unsigned int(*stack)[2] = stack_all[wv];
+    unsigned int *fin = fin_all[wv];
+    const unsigned int n_ranges = min(S.counts[7], S.cap_queue);
+    for (unsigned int idx = blockIdx.x * 4 + wv; idx < n_ranges; idx += gridDim.x * 4)
+    {
+        const range_t r = S.local[idx];
+        const unsigned int len = r.last - r.first;
+        for (unsigned int i = lane; i < len; i += 64)
+            D[i] = S.A[r.first + i];
+        if (lane == 0)
+        {
+            stack[0][0] = len << 16; // first | last << 16
+            stack[0][1] = r.depth;
+        }
+        group<64>::sync();
+        int sp = 1;           // (uniform)
+        unsigned int n_fin = 0;
+        bool failed = false;
+        while (sp > 0)
+        {
+            sp--;
+            const unsigned int fl = stack[sp][0], depth = stack[sp][1];
+            const unsigned int first = fl & 0xFFFFu, last = fl >> 16;
+            group<64>::sync(); // (the entry has been read by every lane before lane 0 reuses its slot)
+            if (last - first <= THRESHOLD)
+            {
+                if (last - first >= 2)
+                {
+                    if (lane == 0)
+                        fin[n_fin] = fl;
+                    n_fin++;
+                }
+                continue;
+            }
+            if (depth == 0)
+            {
+                failed = true; // libstdc++ heap-sorts this range
+                continue;
+            }
+            if (lane == 0)
+            {
+                const unsigned int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+                const u64 va = D[a], vb = D[b], vc = D[c];
+                unsigned int pick;
+                if (comp(va, vb))
+                    pick = comp(vb, vc) ? b : (comp(va, vc) ? c : a);
+                else
+                    pick = comp(va, vc) ? a : (comp(vb, vc) ? c : b);
+                const u64 vf = D[first], vp = D[pick];
+                D[first] = vp;
+                D[pick] = vf;
+            }
+            group<64>::sync();
+            const u64 pivot = D[first];
+            const unsigned int lo = first + 1, hi = last, m = hi - lo;
+            const unsigned int per = (m + 63) / 64;
+            const unsigned int i0 = lo + min((unsigned int)lane * per, m), i1 = min(i0 + per, hi);
+            unsigned int cl = 0, cr = 0;
+            for (unsigned int i = i0; i < i1; i++)
+            {
+                const u64 v = D[i];
+                cl += comp(v, pivot) ? 0u : 1u;
+                cr += comp(pivot, v) ? 0u : 1u;
+            }
+            unsigned int nL, nR;
+            unsigned int ol = group<64>::scan(cl, &nL, nullptr);
+            unsigned int orr = group<64>::scan(cr, &nR, nullptr);
+            for (unsigned int i = i0; i < i1; i++)
+            {
+                const u64 v = D[i];
+                if (!comp(v, pivot))
+                    LL[ol++] = (unsigned short)i;
+                if (!comp(pivot, v))
+                    LR[orr++] = (unsigned short)i;
+            }
+            group<64>::sync();
+            const unsigned int kmax = min(nL, nR);
+            unsigned int mine = 0;
+            for (unsigned int k = lane; k < kmax; k += 64)
+                mine += LL[k] < LR[nR - 1 - k] ? 1u : 0u;
+            unsigned int K;
+            (void)group<64>::scan(mine, &K, nullptr);
+            for (unsigned int k = lane; k < K; k += 64)
+            {
+                const unsigned int i = LL[k], j = LR[nR - 1 - k];
+                const u64 vi = D[i], vj = D[j];
+                D[i] = vj;
+                D[j] = vi;
+            }
+            unsigned int cut;
+            if (K == 0)
+                cut = LL[0];
+            else
+            {
+                cut = LR[nR - K];
+                if (K < nL)
+                    cut = min(cut, (unsigned int)LL[K]);
+            }
+            if (lane == 0)
+            {
+                stack[sp][0] = cut | (last << 16);
+                stack[sp][1] = depth - 1;
+                stack[sp + 1][0] = first | (cut << 16);
+                stack[sp + 1][1] = depth - 1;
+            }
+            sp += 2;
+            group<64>::sync();
+        }
+        group<64>::sync();
+        // __final_insertion_sort, range by range
+        for (unsigned int e = lane; e < n_fin; e += 64)
+        {
+            const unsigned int first = fin[e] & 0xFFFFu, last = fin[e] >> 16;
+            for (unsigned int i = first + 1; i < last; i++)
+            {
+                const u64 v = D[i];
+                unsigned int j = i;
+                while (j > first && comp(v, D[j - 1]))
+                {
+                    D[j] = D[j - 1];
+                    j--;
+                }
+                D[j] = v;
+            }
+        }
+        group<64>::sync();
+        for (unsigned int i = lane; i < len; i += 64)
+            S.A[r.first + i] = D[i];
+        if (failed && lane == 0)
+            S.fallback[r.seg] = 1;
+        group<64>::sync();
+    }
+}
+
+// __final_insertion_sort restricted to a range of at most 16 elements: every element moves left past the elements it is
+// strictly before
+__global__ void sort_final_kernel(sort_dev S)
+{
+    const unsigned int n = min(S.counts[6], S.cap_final);
+    const unsigned int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n)
+        return;
+    const range_t r = S.final_ranges[idx];
+    u64 *A = S.A;
+    for (unsigned int i = r.first + 1; i < r.last; i++)
+    {
+        const u64 v = A[i];
+        unsigned int j = i;
+        while (j > r.first && comp(v, A[j - 1]))
+        {
+            A[j] = A[j - 1];
+            j--;
+        }
+        A[j] = v;
+    }
+}
+
+} // namespace
+
+namespace ochip
+{
+
+// Sorts the segments [seg_begin[s], seg_end[s]) of recs (device arrays) in place as std::sort with comp(a, b) =
+// key(a) > key(b) would; fallback[s] != 0: the segment needs libstdc++'s heap sort and was left partly sorted (its records
+// are a permutation of the input).  Enqueued on the context's stream.
+int std_sort_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> *allocs, unsigned long long *recs, size_t total_len,
+                     const unsigned int *seg_begin, const unsigned int *seg_end, uint32_t n_segs, uint32_t max_len,
+                     unsigned char *fallback)
+{
+    hipStream_t st = ctx->stream;
+    if (n_segs == 0 || total_len == 0)
+        return OCHIP_OK;
+    auto dev = [&](size_t bytes) -> void * {
+        size_t got = 0;
+        void *p = ochip_pool_get(ctx, std::max<size_t>(bytes, 16), &got);
+        if (p)
+            allocs->emplace_back(p, got);
+        return p;
+    };
+    sort_dev S{};
+    S.A = recs;
+    S.cap_queue = (unsigned int)(total_len / (THRESHOLD + 1) + n_segs + 1);
+    S.cap_final = (unsigned int)(total_len / 2 + n_segs + 1);
+    S.listL = (unsigned int *)dev(total_len * 4);
+    S.listR = (unsigned int *)dev(total_len * 4);
+    // (queues of the levels in HBM only hold ranges longer than LOCAL)
+    const size_t cap_level = total_len / LOCAL + n_segs + 1;
+    S.cap_level = (unsigned int)cap_level;
+    for (int i = 0; i < 3; i++)
+    {
+        S.queue[i] = (range_t *)dev(cap_level * sizeof(range_t));
+        S.big[i] = (range_t *)dev(cap_level * sizeof(range_t));
+    }
+    S.final_ranges = (range_t *)dev((size_t)S.cap_final * sizeof(range_t));
+    S.local = (range_t *)dev((size_t)S.cap_queue * sizeof(range_t));
+    S.counts = (unsigned int *)dev(16 * 4);
+    S.fallback = fallback;
+    if (!S.listL || !S.listR || !S.queue[0] || !S.queue[1] || !S.queue[2] || !S.big[0] || !S.big[1] || !S.big[2] || !S.final_ranges || !S.local || !S.counts)
+        return ochip_fail(ctx, OCHIP_ENOMEM, "std_sort: device allocation failed");
+    S.error = S.counts + 8;
+    OCHIP_HIP(ctx, hipMemsetAsync(S.counts, 0, 16 * 4, st));
+    hipLaunchKernelGGL(sort_init_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, S, seg_begin, seg_end, n_segs);
+    // levels in HBM: while a range can still be longer than LOCAL - up to the depth limit (a range that reaches it is
+    // flagged by the level that takes it; the deeper levels of well-split segments find their queues empty)
+    int levels = 0;
+    if (max_len > LOCAL)
+    {
+        unsigned int lg = 0;
+        for (uint32_t n = max_len; n > 1; n >>= 1)
+            lg++;
+        levels = 2 * (int)lg + 1;
+    }
+    for (int level = 0; level < levels; level++)
+    {
+        const double by_depth = (double)n_segs * (double)(1u << std::min(level, 24));
+        const unsigned int most = (unsigned int)std::min<double>((double)cap_level, by_depth);
+        hipLaunchKernelGGL(sort_level_kernel, dim3(std::min(std::max(most, 1u), 2048u)), dim3(GROUP), 0, st, S, level % 3, (level + 1) % 3,
+                           (level + 2) % 3);
+    }
+    if (levels)
+        hipLaunchKernelGGL(sort_flag_left_kernel, dim3(64), dim3(256), 0, st, S, levels % 3);
+    {
+        const unsigned int most_local = (unsigned int)(total_len / (THRESHOLD + 1) + n_segs);
+        hipLaunchKernelGGL(sort_local_kernel, dim3(std::min((most_local + 3) / 4, 2048u)), dim3(256), 0, st, S);
+    }
+    hipLaunchKernelGGL(sort_final_kernel, dim3((S.cap_final + 255) / 256), dim3(256), 0, st, S);
+    OCHIP_HIP(ctx, hipGetLastError());
+    return OCHIP_OK;
+}
+
+} // namespace ochip
+
+// keys / payloads of n_segs segments (host arrays; segment s = [offsets[s], offsets[s + 1])) sorted as
+// std::sort(comp = key(a) > key(b)) leaves them: for the tests.  fallback_out[s] != 0: not sorted (depth limit).
+extern "C" int ochip_debug_std_sort(ochip_ctx *ctx, const uint32_t *keys, const uint32_t *payload, const uint32_t *offsets, uint32_t n_segs,
+                                    uint32_t *keys_out, uint32_t *payload_out, uint8_t *fallback_out)
+{
+    if (!ctx || !offsets || !keys_out || !payload_out || !fallback_out)
+        return OCHIP_EINVAL;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t total = offsets[n_segs];
+    std::vector<unsigned long long> recs(std::max<size_t>(total, 1));
+    for (size_t i = 0; i < total; i++)
+        recs[i] = ((unsigned long long)keys[i] << 32) | payload[i];
+    std::vector<unsigned int> sb(n_segs), se(n_segs);
+    uint32_t max_len = 0;
+    for (uint32_t s = 0; s < n_segs; s++)
+    {
+        sb[s] = offsets[s];
+        se[s] = offsets[s + 1];
+        max_len = std::max(max_len, se[s] - sb[s]);
+    }
+    std::vector<std::pair<void *, size_t>> allocs;
+    auto cleanup = [&]() {
+        (void)ochip_stream_wait(ctx, st);
+        for (auto &a : allocs)
+            ochip_pool_put(ctx, a.first, a.second);
+    };
+    auto dev = [&](size_t bytes) -> void * {
+        size_t got = 0;
+        void *p = ochip_pool_get(ctx, std::max<size_t>(bytes, 16), &got);
+        if (p)
+            allocs.emplace_back(p, got);
+        return p;
+    };
+    unsigned long long *d_recs = (unsigned long long *)dev(recs.size() * 8);
+    unsigned int *d_sb = (unsigned int *)dev((size_t)n_segs * 4), *d_se = (unsigned int *)dev((size_t)n_segs * 4);
+    unsigned char *d_fb = (unsigned char *)dev(std::max<uint32_t>(n_segs, 1));
+    int rc = OCHIP_OK;
+    if (!d_recs || !d_sb || !d_se || !d_fb)
+        rc = ochip_fail(ctx, OCHIP_ENOMEM, "std_sort: device allocation failed");
+    if (rc == OCHIP_OK && n_segs &&
+        (hipMemcpyAsync(d_recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+         hipMemcpyAsync(d_sb, sb.data(), (size_t)n_segs * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+         hipMemcpyAsync(d_se, se.data(), (size_t)n_segs * 4, hipMemcpyHostToDevice, st) != hipSuccess))
+        rc = ochip_fail(ctx, OCHIP_EHIP, "std_sort: upload failed");
+    if (rc == OCHIP_OK)
+        rc = std_sort_enqueue(ctx, &allocs, d_recs, total, d_sb, d_se, n_segs, max_len, d_fb);
+    if (rc == OCHIP_OK && n_segs &&
+        (hipMemcpyAsync(recs.data(), d_recs, recs.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+         hipMemcpyAsync(fallback_out, d_fb, n_segs, hipMemcpyDeviceToHost, st) != hipSuccess))
+        rc = ochip_fail(ctx, OCHIP_EHIP, "std_sort: download failed");
+    cleanup();
+    if (rc == OCHIP_OK)
+        for (size_t i = 0; i < total; i++)
+        {
+            keys_out[i] = (uint32_t)(recs[i] >> 32);
+            payload_out[i] = (uint32_t)recs[i];
+        }
+    return rc;
+}

@@ -1,9 +1,9 @@
-"""The data-parallel part of extract_features' tail on the device (csrc/features.hip) against the all-host tail
+"""extract_features' tail on the device (csrc/features.hip + csrc/std_sort.hip) against the all-host tail
 (host/extract_features.cpp: extract_tail, itself checked against the oracle's restatement of
 src/extract/extract_features.cpp:38-87 in tests/test_host_extract_tail.py): identical feature lists, bit for bit, on
-keypoint sets with clusters (long chains of the suppression's fixed point), equal responses far apart (the orders differ,
-the outcome does not), equal responses within the radius (the flag must come up and the host resolve it), a tie at the top,
-and the empty / single-keypoint cases."""
+keypoint sets with clusters (long chains of the suppression's fixed point), equal responses far apart and within the radius
+of each other, a tie for the strongest feature (all of which depend on std::sort's order among equals), responses that
+drive introsort to its depth limit (flagged, resolved by the host), and the empty / single-keypoint cases."""
 import numpy as np
 import pytest
 
@@ -79,7 +79,7 @@ def test_random_and_clustered_keypoints(ctx, seed):
     assert len(np.unique(lists["slot"])) == len(kp6) and lists["slot"].max() == len(kp6)
 
 
-def test_equal_responses_far_apart_need_no_host_pass(ctx):
+def test_equal_responses_far_apart(ctx):
     rng = np.random.default_rng(11)
     w, h, scale = 1600, 1200, 0.4
     kp6, desc = keypoints(rng, 20000, w, h, clusters=10, ties=300)
@@ -94,17 +94,26 @@ def test_equal_responses_far_apart_need_no_host_pass(ctx):
     assert len(same) > 100 and not lists["conflict"]
 
 
-def test_equal_responses_within_the_radius_raise_the_flag(ctx):
+def test_equal_responses_within_the_radius(ctx):
     rng = np.random.default_rng(12)
     w, h, scale = 1600, 1200, 0.4
     kp6, desc = keypoints(rng, 15000, w, h, clusters=10, ties=50, close_ties=40)
     lists, exp = both(ctx, kp6, desc, w, h, scale)
-    assert lists["conflict"]
+    assert not lists["conflict"]
 
 
-def test_tie_for_the_strongest_raises_the_flag(ctx):
+def test_tie_for_the_strongest(ctx):
     rng = np.random.default_rng(13)
     kp6, desc = keypoints(rng, 5000, 1600, 1200, top_tie=True)
+    lists, exp = both(ctx, kp6, desc, 1600, 1200, 0.4)
+    assert not lists["conflict"]
+
+
+def test_depth_limit_goes_to_the_host(ctx):
+    rng = np.random.default_rng(15)
+    n = 20000
+    kp6, desc = keypoints(rng, n, 1600, 1200, clusters=10)
+    kp6[:, 4] = (np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]) + 1.0) * 1e-4      # organ pipe
     lists, exp = both(ctx, kp6, desc, 1600, 1200, 0.4)
     assert lists["conflict"]
 
