@@ -92,6 +92,14 @@ extern "C"
      * host so libstdc++'s tie order is preserved. */
     int ochip_match_batch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs, const uint64_t *out_offset,
                           ochip_match *out);
+    /* The tail of match_features_subset (match_features.cpp:94-101) on the device, on the records ochip_match_launch left
+     * in HBM (same pairs, offsets and total): Lowe's ratio test (best < 0.8 * second on count / 486 as doubles) and the
+     * std::sort by descending distance - libstdc++'s permutation among equal distances, csrc/std_sort.hip.  The sorted
+     * matches stay in HBM for ochip_ransac_homography_batch_sorted; counts_out[p] = matches of pair p; fallback_out[p] != 0:
+     * the pair's sort needs libstdc++'s heap sort (not restated on the device) - the caller then takes the host route
+     * (ochip_match_fetch, host ratio test and sort, ochip_ransac_homography_batch) for the batch. */
+    int ochip_match_sort(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs, const uint64_t *out_offset, uint64_t out_total,
+                         uint32_t *counts_out, uint8_t *fallback_out);
     /* Asynchronous flavour: results stay in HBM until ochip_match_fetch (lets the caller overlap). */
     int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs, const uint64_t *out_offset,
                            uint64_t out_total);
@@ -242,6 +250,14 @@ extern "C"
      *      ochip_ransac_homography_batch (rng_state and eval_offset unused); the keypoints and the CURRENT models must
      *      have been uploaded (ochip_upload_keypoints / ochip_upload_batch).  inliers: in = the previous inlier flags,
      *      out = the flags of the last evaluate; results[j].H = the last fit, .n_inliers, .score = evaluate / n. */
+    /* The same on the matches ochip_match_sort left in HBM: jobs[j] is pair j of that call with n = counts_out[j]; the
+     * correspondences (their order is the sort's), the PROSAC order (ransac.cpp:83-90, the same device std::sort) are built
+     * on the device.  matches_out[match_offset + i] = correspondence i of the job (for the host's feature_match list);
+     * fallback_out[j] != 0: the PROSAC order of job j needs the host (then nothing of this call is to be used). */
+    int ochip_ransac_homography_batch_sorted(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, uint64_t total_matches,
+                                             const uint32_t *eval_order, uint64_t eval_total, double inlier_threshold,
+                                             ochip_ransac_result *results, uint8_t *inliers, ochip_ransac_match *matches_out,
+                                             uint8_t *fallback_out);
     int ochip_refit_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs,
                                      const ochip_ransac_match *matches, uint64_t total_matches, uint32_t rounds,
                                      double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers);

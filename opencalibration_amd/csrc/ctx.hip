@@ -207,7 +207,8 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
         }
     }
     void *bufs[] = {ctx->desc_dev,      ctx->img_off_dev,   ctx->img_n_dev, ctx->pairs_dev,    ctx->out_off_dev,
-                    ctx->match_out_dev, ctx->kp_xy_dev,     ctx->rays_dev,  ctx->kp_image_dev, ctx->models_dev};
+                    ctx->match_out_dev, ctx->kp_xy_dev,     ctx->rays_dev,  ctx->kp_image_dev, ctx->models_dev,
+                    ctx->ms_recs_dev,   ctx->ms_seg_dev,    ctx->ms_flag_dev};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);

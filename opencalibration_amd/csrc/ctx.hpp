@@ -61,6 +61,11 @@ struct ochip_ctx
     ochip_match *match_out_dev = nullptr;
     size_t match_out_cap = 0;
     uint64_t match_out_total = 0;
+    // ochip_match_sort (match_sort.hip): per pair the matches that pass the ratio test as (count << 32 | query) records at the
+    // pair's offset, in match_features_subset's output order; the pairs' offsets and match counts
+    void *ms_recs_dev = nullptr, *ms_seg_dev = nullptr, *ms_flag_dev = nullptr;
+    size_t ms_recs_cap = 0, ms_seg_cap = 0, ms_flag_cap = 0;
+    uint32_t ms_pairs = 0;
     void *sym_jobs_dev = nullptr, *sym_part_dev = nullptr; // symmetric pairs of a match launch: job table, column partials
     size_t sym_jobs_cap = 0, sym_part_cap = 0;
 

@@ -209,6 +209,8 @@ void link_cpu_report()
             g_link_cpu[0], g_link_cpu[1], g_link_cpu[2], g_link_cpu[3], g_link_cpu[4], g_link_cpu[5]);
 }
 
+static thread_local bool force_host_sort = false; // (run_batch's second attempt after a device sort flagged a pair)
+
 void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_pair> &link_pairs, ochip_ctx *ctx, int omp_threads)
 {
     static const bool prof = std::getenv("OCHIP_LINK_VERBOSE") != nullptr;
@@ -360,12 +362,29 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
         out_off[p] = out_total;
         out_total += subset[jobs[p].slot_1].size();
     }
-    pinned<ochip_match> raw(ctx, out_total ? out_total : 1);
-    if (!raw.ptr)
-        return fail("ochip_host_alloc");
     if (ochip_match_launch(ctx, pairs.data(), (uint32_t)n_pairs, out_off.data(), out_total) != OCHIP_OK)
         return fail("ochip_match_launch");
-    if (ochip_match_fetch(ctx, raw.ptr, out_total) != OCHIP_OK)
+    // The tail of match_features_subset (ratio test, std::sort by distance) and the PROSAC order stay on the device
+    // (csrc/match_sort.hip, csrc/std_sort.hip: libstdc++'s permutation among the equal Hamming counts): the host learns
+    // the pairs' match counts here and receives the sorted correspondences with the RANSAC results.  A pair whose sort
+    // would need libstdc++'s heap sort (flagged; not seen on descriptor distances) sends the batch down the host route
+    // below, which is also what OCHIP_LINK_HOST_SORT=1 selects.
+    static const bool host_sort_env = std::getenv("OCHIP_LINK_HOST_SORT") != nullptr;
+    bool device_sorted = !host_sort_env && !force_host_sort;
+    std::vector<uint32_t> match_counts(n_pairs, 0);
+    std::vector<uint8_t> sort_flags(n_pairs ? n_pairs : 1, 0);
+    if (device_sorted)
+    {
+        if (ochip_match_sort(ctx, pairs.data(), (uint32_t)n_pairs, out_off.data(), out_total, match_counts.data(), sort_flags.data()) !=
+            OCHIP_OK)
+            return fail("ochip_match_sort");
+        for (size_t p = 0; p < n_pairs; p++)
+            device_sorted = device_sorted && !sort_flags[p];
+    }
+    pinned<ochip_match> raw(ctx, !device_sorted && out_total ? out_total : 1);
+    if (!raw.ptr)
+        return fail("ochip_host_alloc");
+    if (!device_sorted && ochip_match_fetch(ctx, raw.ptr, out_total) != OCHIP_OK)
         return fail("ochip_match_fetch");
     lt.match_device += since(t0);
 
@@ -380,7 +399,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
     std::vector<std::vector<ochip_ransac_match>> rmatches(n_pairs);
     std::vector<std::vector<uint32_t>> sorted_idx(n_pairs);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(omp_threads)
-    for (size_t p = 0; p < n_pairs; p++)
+    for (size_t p = 0; p < (device_sorted ? 0 : n_pairs); p++)
     {
         const double tc0 = prof ? link_thread_cpu() : 0;
         const auto &idx1 = subset[jobs[p].slot_1], &idx2 = subset[jobs[p].slot_2];
@@ -445,7 +464,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
     std::vector<uint32_t> eval_table;
     for (size_t p = 0; p < n_pairs; p++)
     {
-        const size_t M = matches[p].size();
+        const size_t M = device_sorted ? match_counts[p] : matches[p].size();
         auto it = eval_off_of.find(M);
         uint32_t rng_state = 42;
         if (it == eval_off_of.end())
@@ -466,7 +485,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
     if (!rm_flat.ptr || !si_flat.ptr || !inl_flat.ptr)
         return fail("ochip_host_alloc");
 #pragma omp parallel for schedule(dynamic, 8) num_threads(omp_threads)
-    for (size_t p = 0; p < n_pairs; p++)
+    for (size_t p = 0; p < (device_sorted ? 0 : n_pairs); p++)
     {
         std::copy(rmatches[p].begin(), rmatches[p].end(), rm_flat.ptr + rjobs[p].match_offset);
         if (!sorted_idx[p].empty())
@@ -480,9 +499,26 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
     t0 = clk::now();
     std::vector<ochip_ransac_result> results(n_pairs);
     const homography_model model_defaults;
-    if (ochip_ransac_homography_batch(ctx, rjobs.data(), (uint32_t)n_pairs, rm_flat.ptr, si_flat.ptr, total_matches,
-                                      eval_table.data(), eval_table.size(), model_defaults.inlier_threshold,
-                                      results.data(), inl_flat.ptr) != OCHIP_OK)
+    if (device_sorted)
+    {
+        // (the correspondences come back in rm_flat; the PROSAC order is built and used on the device)
+        if (ochip_ransac_homography_batch_sorted(ctx, rjobs.data(), (uint32_t)n_pairs, total_matches, eval_table.data(), eval_table.size(),
+                                                 model_defaults.inlier_threshold, results.data(), inl_flat.ptr, rm_flat.ptr,
+                                                 sort_flags.data()) != OCHIP_OK)
+            return fail("ochip_ransac_homography_batch_sorted");
+        for (size_t p = 0; p < n_pairs; p++)
+            if (sort_flags[p])
+            {
+                // the PROSAC order of a pair needs libstdc++'s heap sort: the whole batch again, sorted on the host
+                force_host_sort = true;
+                run_batch(graph, link_pairs, ctx, omp_threads);
+                force_host_sort = false;
+                return;
+            }
+    }
+    else if (ochip_ransac_homography_batch(ctx, rjobs.data(), (uint32_t)n_pairs, rm_flat.ptr, si_flat.ptr, total_matches,
+                                           eval_table.data(), eval_table.size(), model_defaults.inlier_threshold,
+                                           results.data(), inl_flat.ptr) != OCHIP_OK)
         return fail("ochip_ransac_homography_batch");
     lt.ransac_device += since(t0);
 
@@ -496,8 +532,17 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
         const double tc0 = prof ? link_thread_cpu() : 0;
         const image &img = graph.getNode(jobs[p].node_id)->payload;
         const image &near_image = graph.getNode(jobs[p].match_node_id)->payload;
-        const size_t M = matches[p].size();
+        const size_t M = rjobs[p].n;
         const uint8_t *inl = inl_flat.ptr + rjobs[p].match_offset;
+        const ochip_ransac_match *rm = rm_flat.ptr + rjobs[p].match_offset;
+        if (device_sorted)
+        {
+            // match_features_subset's output (match_features.cpp:86-101) from the device's sorted correspondences
+            const auto &idx1 = subset[jobs[p].slot_1], &idx2 = subset[jobs[p].slot_2];
+            matches[p].resize(M);
+            for (size_t i = 0; i < M; i++)
+                matches[p][i] = feature_match{idx1[rm[i].k1], idx2[rm[i].k2], (size_t)rm[i].count * (1.0 / feature_2d::DESCRIPTOR_BITS)};
+        }
         camera_relations relations;
         homography_model h;
         std::memcpy(h.homography, results[p].H, sizeof h.homography);
@@ -512,7 +557,6 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
                 inlier_at.push_back((uint32_t)i);
         const size_t num_coarse_inliers = inlier_at.size();
         const auto &ray1 = rays[jobs[p].slot_1], &ray2 = rays[jobs[p].slot_2];
-        const ochip_ransac_match *rm = rmatches[p].data();
         const uint32_t *at = inlier_at.data();
         const bool can_decompose = h.decompose_with(
             num_coarse_inliers,

@@ -1981,16 +1981,91 @@ int ochip_upload_keypoints(ochip_ctx *ctx, uint32_t image_id, const double *xy, 
     return OCHIP_OK;
 }
 
+} // extern "C"
+
+namespace
+{
+// matches of job j out of ochip_match_sort's records: correspondence i = the i-th sorted record of the pair; and the keys
+// of the PROSAC order (ransac.cpp:83-90: iota sorted by quality ASCENDING with std::sort - complemented counts)
+__global__ void sorted_matches_kernel(const ochip_ransac_job *__restrict__ jobs, const unsigned int *__restrict__ seg_begin,
+                                      const unsigned long long *__restrict__ recs, const ochip_match *__restrict__ raw,
+                                      ochip_ransac_match *__restrict__ matches, unsigned long long *__restrict__ prosac,
+                                      unsigned int *__restrict__ seg2)
+{
+    const unsigned int j = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const ochip_ransac_job jb = jobs[j];
+    if (i == 0)
+    {
+        seg2[j] = (unsigned int)jb.match_offset;
+        seg2[gridDim.y + j] = (unsigned int)jb.match_offset + jb.n;
+    }
+    if (i >= jb.n)
+        return;
+    const unsigned int off = seg_begin[j];
+    const unsigned long long r = recs[off + i];
+    const unsigned int a = (unsigned int)r, count = (unsigned int)(r >> 32);
+    ochip_ransac_match m;
+    m.k1 = a;
+    m.k2 = raw[off + a].best_k;
+    m.count = (uint16_t)count;
+    m.reserved = 0;
+    matches[jb.match_offset + i] = m;
+    prosac[jb.match_offset + i] = ((unsigned long long)(0xFFFFFFFFu - count) << 32) | i;
+}
+__global__ void prosac_order_kernel(const unsigned long long *__restrict__ prosac, uint32_t *__restrict__ sorted_idx, uint64_t total)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total)
+        sorted_idx[i] = (uint32_t)prosac[i];
+}
+
+int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, const ochip_ransac_match *matches,
+                           const uint32_t *sorted_idx, uint64_t total_matches, const uint32_t *eval_order, uint64_t eval_total,
+                           double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers, bool sorted_on_device,
+                           ochip_ransac_match *matches_out, uint8_t *fallback_out);
+} // namespace
+
+extern "C"
+{
+
 int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs,
                                   const ochip_ransac_match *matches, const uint32_t *sorted_idx, uint64_t total_matches,
                                   const uint32_t *eval_order, uint64_t eval_total, double inlier_threshold,
                                   ochip_ransac_result *results, uint8_t *inliers)
 {
+    return ransac_homography_impl(ctx, jobs, n_jobs, matches, sorted_idx, total_matches, eval_order, eval_total, inlier_threshold,
+                                  results, inliers, false, nullptr, nullptr);
+}
+
+int ochip_ransac_homography_batch_sorted(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, uint64_t total_matches,
+                                         const uint32_t *eval_order, uint64_t eval_total, double inlier_threshold,
+                                         ochip_ransac_result *results, uint8_t *inliers, ochip_ransac_match *matches_out,
+                                         uint8_t *fallback_out)
+{
+    if (!ctx)
+        return OCHIP_EINVAL;
+    if (n_jobs && (!matches_out || !fallback_out))
+        return ochip_fail(ctx, OCHIP_EINVAL, "NULL argument");
+    if (n_jobs != ctx->ms_pairs)
+        return ochip_fail(ctx, OCHIP_ESTATE, "ochip_ransac_homography_batch_sorted must follow ochip_match_sort of the same %u pairs", n_jobs);
+    return ransac_homography_impl(ctx, jobs, n_jobs, nullptr, nullptr, total_matches, eval_order, eval_total, inlier_threshold, results,
+                                  inliers, true, matches_out, fallback_out);
+}
+
+} // extern "C"
+
+namespace
+{
+int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, const ochip_ransac_match *matches,
+                           const uint32_t *sorted_idx, uint64_t total_matches, const uint32_t *eval_order, uint64_t eval_total,
+                           double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers, bool sorted_on_device,
+                           ochip_ransac_match *matches_out, uint8_t *fallback_out)
+{
     if (!ctx)
         return OCHIP_EINVAL;
     if (n_jobs == 0)
         return OCHIP_OK;
-    if (!jobs || !results || (total_matches && (!matches || !sorted_idx || !inliers)) || (eval_total && !eval_order))
+    if (!jobs || !results || (total_matches && ((!sorted_on_device && (!matches || !sorted_idx)) || !inliers)) || (eval_total && !eval_order))
         return ochip_fail(ctx, OCHIP_EINVAL, "NULL argument");
     if (!ctx->kp_store_ready)
         return ochip_fail(ctx, OCHIP_ESTATE, "ochip_upload_keypoints has not been called");
@@ -2048,13 +2123,60 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
             return rc;
     }
     OCHIP_HIP(ctx, hipMemcpyAsync(ctx->scratch_dev[S_JOBS], jobs, sizes[S_JOBS], hipMemcpyHostToDevice, ctx->stream));
-    if (total_matches)
+    std::vector<std::pair<void *, size_t>> allocs; // (std_sort's work space, returned to the pool after the wait below)
+    struct put_back
+    {
+        ochip_ctx *ctx;
+        std::vector<std::pair<void *, size_t>> *allocs;
+        ~put_back()
+        {
+            for (auto &a : *allocs)
+                ochip_pool_put(ctx, a.first, a.second);
+        }
+    } put_back_guard{ctx, &allocs};
+    if (total_matches && !sorted_on_device)
     {
         OCHIP_HIP(ctx, hipMemcpyAsync(ctx->scratch_dev[S_MATCH], matches, (size_t)total_matches * sizeof(ochip_ransac_match),
                                       hipMemcpyHostToDevice, ctx->stream));
         OCHIP_HIP(ctx, hipMemcpyAsync(ctx->scratch_dev[S_SORTED], sorted_idx, (size_t)total_matches * 4,
                                       hipMemcpyHostToDevice, ctx->stream));
     }
+    else if (total_matches)
+    {
+        // the correspondences out of ochip_match_sort's records, and their PROSAC order by the same device std::sort
+        if (total_matches >= 0xFFFFFFFFull)
+            return ochip_fail(ctx, OCHIP_EINVAL, "more than 2^32 matches in one batch");
+        uint32_t max_n = 0;
+        for (uint32_t j = 0; j < n_jobs; j++)
+            max_n = std::max(max_n, jobs[j].n);
+        size_t g0 = 0, g1 = 0, g2 = 0;
+        unsigned long long *prosac = (unsigned long long *)ochip_pool_get(ctx, (size_t)total_matches * 8, &g0);
+        unsigned int *seg2 = (unsigned int *)ochip_pool_get(ctx, (size_t)n_jobs * 8, &g1);
+        unsigned char *fb2 = (unsigned char *)ochip_pool_get(ctx, std::max<size_t>(n_jobs, 16), &g2);
+        if (prosac)
+            allocs.emplace_back(prosac, g0);
+        if (seg2)
+            allocs.emplace_back(seg2, g1);
+        if (fb2)
+            allocs.emplace_back(fb2, g2);
+        if (!prosac || !seg2 || !fb2)
+            return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (PROSAC order)");
+        hipLaunchKernelGGL(sorted_matches_kernel, dim3((max_n + 255) / 256, n_jobs), dim3(256), 0, ctx->stream,
+                           (const ochip_ransac_job *)ctx->scratch_dev[S_JOBS], (const unsigned int *)ctx->ms_seg_dev,
+                           (const unsigned long long *)ctx->ms_recs_dev, (const ochip_match *)ctx->match_out_dev,
+                           (ochip_ransac_match *)ctx->scratch_dev[S_MATCH], prosac, seg2);
+        const int src = ochip::std_sort_enqueue(ctx, &allocs, prosac, total_matches, seg2, seg2 + n_jobs, n_jobs, max_n, fb2);
+        if (src != OCHIP_OK)
+            return src;
+        hipLaunchKernelGGL(prosac_order_kernel, dim3((unsigned)((total_matches + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const unsigned long long *)prosac, (uint32_t *)ctx->scratch_dev[S_SORTED], total_matches);
+        OCHIP_HIP(ctx, hipMemcpyAsync(matches_out, ctx->scratch_dev[S_MATCH], (size_t)total_matches * sizeof(ochip_ransac_match),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+        OCHIP_HIP(ctx, hipMemcpyAsync(fallback_out, fb2, n_jobs, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    else if (sorted_on_device)
+        for (uint32_t j = 0; j < n_jobs; j++)
+            fallback_out[j] = 0;
     if (eval_total)
         OCHIP_HIP(ctx, hipMemcpyAsync(ctx->scratch_dev[S_EVAL], eval_order, (size_t)eval_total * 4, hipMemcpyHostToDevice,
                                       ctx->stream));
@@ -2091,6 +2213,10 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
     OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
     return OCHIP_OK;
 }
+} // namespace
+
+extern "C"
+{
 
 int ochip_refit_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, const ochip_ransac_match *matches,
                                  uint64_t total_matches, uint32_t rounds, double inlier_threshold, ochip_ransac_result *results,
