@@ -312,9 +312,11 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
         slot_off[s + 1] = slot_off[s] + counts[s];
     }
     const uint64_t total_desc = slot_off[n_slots];
+    // (the subsets' pixel locations stay at hand for assembleInliers below: 16 bytes per subset feature, one after the other,
+    // instead of a walk through the images' 88-byte feature records)
+    pinned<double> xybuf(ctx, total_desc * 2);
     {
         pinned<uint64_t> dbuf(ctx, total_desc * 8);
-        pinned<double> xybuf(ctx, total_desc * 2);
         std::vector<double> models((size_t)n_slots * 8);
         if (!dbuf.ptr || !xybuf.ptr)
             return fail("ochip_host_alloc");
@@ -530,8 +532,6 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
     for (size_t p = 0; p < n_pairs; p++)
     {
         const double tc0 = prof ? link_thread_cpu() : 0;
-        const image &img = graph.getNode(jobs[p].node_id)->payload;
-        const image &near_image = graph.getNode(jobs[p].match_node_id)->payload;
         const size_t M = rjobs[p].n;
         const uint8_t *inl = inl_flat.ptr + rjobs[p].match_offset;
         const ochip_ransac_match *rm = rm_flat.ptr + rjobs[p].match_offset;
@@ -580,14 +580,10 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
         if (can_decompose && num_coarse_inliers > h.MINIMUM_POINTS * 1.5)
         {
             relations.matches = std::move(matches[p]);
-            if (remote_p[jobs[p].slot_1] || remote_p[jobs[p].slot_2])
             {
-                // assembleInliers (ransac.cpp:263-282) with the pixels read from the subsets: the same numbers, and an
-                // image whose feature list lives on another rank has nothing else
-                auto px_of = [&](uint32_t slot, uint32_t k) -> const double * {
-                    return remote_p[slot] ? &remote_p[slot]->xy[2 * (size_t)k]
-                                          : graph.getNode(slot_node[slot])->payload.features[subset[slot][k]].location;
-                };
+                // assembleInliers (ransac.cpp:263-282) with the pixels read from the subsets' packed copy: the same numbers
+                // (and an image whose feature list lives on another rank has nothing else)
+                auto px_of = [&](uint32_t slot, uint32_t k) -> const double * { return xybuf.ptr + 2 * (slot_off[slot] + k); };
                 relations.inlier_matches.reserve(num_coarse_inliers);
                 for (size_t j = 0; j < num_coarse_inliers; j++)
                 {
@@ -601,14 +597,6 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
                     fmd.match_index = i;
                     relations.inlier_matches.push_back(fmd);
                 }
-            }
-            else
-            {
-                std::vector<bool> coarse_inliers(M);
-                for (size_t i = 0; i < M; i++)
-                    coarse_inliers[i] = inl[i] != 0;
-                assembleInliers(relations.matches, coarse_inliers, img.features, near_image.features,
-                                relations.inlier_matches);
             }
         }
         payloads[p] = edge_payload{jobs[p].loop_index, jobs[p].node_id, jobs[p].match_node_id, std::move(relations), {}};
