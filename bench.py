@@ -350,7 +350,8 @@ def beside_the_headline(ctx, grid, images, shape, start_ori, step_s, rctx=None):
     try:
         # (a) images that start in HOST memory, as the reference's boundary hands them over (cv::Mat): views copied back
         # from HBM into page-locked memory, then a whole step (load + link overlapped, relax) run from there
-        n_h = min(grid.n_images, 400)
+        # (the whole survey when its views fit 48 GB of page-locked memory - C3: 36 GB -, else its first cameras)
+        n_h = min(grid.n_images, max(100, int(48e9 // (h * w * 3))))
         hostviews, release = ctx.host_array((n_h, h, w, 3))
         for i in range(n_h):
             ctx.synth_views_read_into(images, i, w, h, hostviews[i])
@@ -364,6 +365,7 @@ def beside_the_headline(ctx, grid, images, shape, start_ori, step_s, rctx=None):
             gl.close()
             return dt / n_h
 
+        load_seconds(hostviews, None)          # (warm-up: the chunk-of-25 result buffers are allocated on first use)
         t_host = load_seconds(hostviews, None)
         t_dev = load_seconds(images, (n_h, h, w))
         # a whole step from host memory, measured: the first n_h cameras of the survey as a survey of their own (load with
@@ -372,7 +374,7 @@ def beside_the_headline(ctx, grid, images, shape, start_ori, step_s, rctx=None):
         sub_ori = start_ori[:n_h]
         pipeline.run(ctx, sub, None, (n_h, h, w), sub_ori, host_images=hostviews)[0].close()       # warm-up
         # (the relax of survey k under the load + link of survey k + 1 on the relax context, exactly as the timed steps)
-        pending, ts, n_e2e = None, {}, 4
+        pending, ts, n_e2e = None, {}, 5
 
         def relax_of(g, res, t):
             pipeline.relax_step(rctx, g, sub_ori, res, t)
@@ -397,10 +399,10 @@ def beside_the_headline(ctx, grid, images, shape, start_ori, step_s, rctx=None):
             "images_per_s_end_to_end": round(e2e, 1),
             "end_to_end_step_seconds": {k: round(float(v), 4) for k, v in ts.items()},
             "pcie_gbytes_per_s_of_pixels": round(e2e * h * w * 3 / 1e9, 1),
-            "note": f"{n_h} views in page-locked host memory (36 MB of BGR each), uploaded in chunks of 25 images by the launch "
+            "note": f"{n_h} views in page-locked host memory ({h * w * 3 / 1e6:.0f} MB of BGR each), uploaded in chunks of 25 images by the launch "
                     "sequence that extracts them, so one sequence's upload runs under the others' kernels; images_per_s_end_to_end "
                     f"is MEASURED: {n_e2e} steps (load with the uploads, link, relax; the relax of a step under the next step's load as in "
-                    f"the timed region, the last one waited for) over the survey's first {n_h} cameras"}
+                    f"the timed region, the last one waited for) over {n_h} cameras of the survey"}
         release()
     except Exception as ex:
         extras["pcie_inclusive"] = {"error": str(ex)}

@@ -135,3 +135,32 @@ def test_second_batch_links_against_the_first(monkeypatch):
     a.close(), b.close()
     ctx.synth_views_free(images)
     ctx.close()
+
+
+def test_device_tails_equal_the_host_tails(monkeypatch):
+    """Round 3 moved the tail of extract_features (std::sort by response, suppression, records) and the tail of
+    match_features_subset (ratio test, std::sort by distance) with PROSAC's order to the device.  The round-2 host routes are
+    still there (OCHIP_EXTRACT_TAIL=host, OCHIP_LINK_HOST_SORT=1): from the same pixels both must give the same feature lists
+    and the same graph."""
+    from opencalibration_amd import pipeline
+
+    grid = synth.make_grid(seed=5, rows=2, cols=3, feats=64)
+    ctx = capi.Context(0)
+    images, shape = pipeline.synthetic_views(ctx, grid, seed=13)
+    n, h, w = shape
+    start = pipeline.perturbed_orientations(grid, 0.1, 4)
+    feats, sigs = {}, {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("OCHIP_EXTRACT_TAIL", "host")
+            monkeypatch.setenv("OCHIP_LINK_HOST_SORT", "1")
+        feats[mode] = host.extract_features_batch(ctx, images, 30000, device_shape=(n, h, w))
+        g, _, _ = pipeline.run(ctx, grid, images, shape, start, relax=False)
+        sigs[mode] = _edge_signature(g)
+        g.close()
+    for a, b in zip(feats["device"], feats["host"]):
+        assert a[3] == b[3] and len(a[1]) > 5000
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert sigs["device"] == sigs["host"] and len(sigs["device"]) >= 2 * (n - 1)
+    ctx.synth_views_free(images)
+    ctx.close()
