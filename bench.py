@@ -798,11 +798,12 @@ def weak_main(args, proc, cfg):
                                                 "load / link / relax runners of consecutive batches together (pipeline.cpp:543-560); "
                                                 "every relax completes inside the timed region" if relax_overlap else ""))
                                             if overlap else "none (OCHIP_PIPELINE_OVERLAP=0)",
-                       "stages_timed": ["extract: grey + INTER_AREA + AKAZE (device) + strength sort / NMS (host)",
-                                        "link: kNN, 40px subsample (host), upload, Hamming 2-NN (device), ratio+std::sort "
-                                        "(host), homography RANSAC (device), decompose (host)",
-                                        "relax: ground-plane assembly (host) + LM with dense Cholesky, all cameras in one "
-                                        "group (device)"],
+                       "stages_timed": ["extract: grey + INTER_AREA + AKAZE + std::sort by response / 8 px NMS / feature records "
+                                        "(device), one block copy per image (host)",
+                                        "link: kNN, 40px subsample (host), upload, Hamming 2-NN, ratio test + std::sort, PROSAC "
+                                        "order, homography RANSAC (device), decompose + inlier lists (host)",
+                                        "relax: ground-plane assembly (host) + LM with block-envelope Cholesky, all cameras in "
+                                        "one group (device)"],
                        "host_threads_per_rank": int(os.environ["OMP_NUM_THREADS"]), "usable_host_cpus": proc.cores,
                        "per_rank": "one grid of this shape per GPU, no data-path collective"},
             "stage_seconds_per_step": {k: round(v / args.steps, 5) for k, v in acc.items()},
@@ -813,44 +814,44 @@ def weak_main(args, proc, cfg):
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if isinstance(strong, dict) and strong.get("timed_out"):
-        os._exit(0)     # a thread of this rank is still inside a collective that will not complete: leave without teardown
     proc.finish()
 
 
 def run_strong_beside(args, proc, cfg):
-    """A short strong-scaling run after the weak timed region (all ranks).  Returns the report on rank 0 (None elsewhere, or
-    a dict with "error").  If it does not finish within OCHIP_BENCH_STRONG_TIMEOUT seconds every rank gives up on it: the
-    exchanges of this mode have only ever run between ranks sharing one GPU before the scaling run."""
-    import copy
+    """A short strong-scaling run after the weak timed region: every rank starts `bench.py --scaling strong` as a CHILD process
+    (same RANK / WORLD_SIZE, its own rendezvous port) and waits for it.  The exchanges of that mode have only ever run between
+    ranks sharing one GPU before the scaling run; in a child, nothing it does - a hang (bounded by
+    OCHIP_BENCH_STRONG_TIMEOUT), an abort inside a collective - can take the weak headline with it.  Returns rank 0's report
+    (None on the other ranks) or {"error": ...}."""
+    import subprocess
 
-    sargs = copy.copy(args)
-    sargs.steps = max(2, min(args.steps, _env_int("OCHIP_BENCH_STRONG_STEPS", 5)))
-    sargs.warmup = 1
-    result = {}
-    done = threading.Event()
-
-    def body():
-        try:
-            runner = StrongRunner(proc, sargs, cfg)
-            runner.run(sargs.warmup, None)
-            proc.barrier()
-            acc = {}
-            t0 = time.perf_counter()
-            runner.run(sargs.steps, acc)
-            proc.barrier()
-            hot = proc.max_over_ranks(time.perf_counter() - t0)
-            result["report"] = strong_report(runner, proc, sargs, cfg, hot, acc)
-            runner.close()
-        except Exception as ex:   # the weak headline stands on its own
-            result["report"] = {"error": repr(ex)}
-        done.set()
-
-    th = threading.Thread(target=body, daemon=True)
-    th.start()
-    if not done.wait(float(os.environ.get("OCHIP_BENCH_STRONG_TIMEOUT", "240"))):
-        return {"error": "the strong-scaling run did not finish in time", "timed_out": True}
-    return result.get("report") if proc.rank == 0 else None
+    steps = max(2, min(args.steps, _env_int("OCHIP_BENCH_STRONG_STEPS", 5)))
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 17            # (the same on every rank)
+    env = dict(os.environ, MASTER_PORT=str(port), OCHIP_BENCH_STRONG_BESIDE="0")
+    env.pop("OCHIP_BENCH_CPUS", None)                                   # (already pinned: inherited)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(proc.world), "--scaling", "strong", "--relax", args.relax,
+           "--steps", str(steps), "--warmup", "1", "--config", args.config, "--no-cpu-baseline"]
+    try:
+        done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=float(os.environ.get("OCHIP_BENCH_STRONG_TIMEOUT", "300")))
+    except subprocess.TimeoutExpired:
+        return {"error": "the strong-scaling run did not finish in time"}
+    except OSError as ex:
+        return {"error": repr(ex)}
+    if proc.rank != 0:
+        return None
+    if done.returncode != 0:
+        return {"error": f"the strong-scaling run exited with code {done.returncode}"}
+    for line in reversed(done.stdout.decode(errors="replace").splitlines()):
+        if line.startswith("{"):
+            try:
+                child = json.loads(line)
+            except ValueError:
+                break
+            report = child.get("strong_scaling") or {}
+            report.update(images_per_s=child.get("value"), ms_per_step=child.get("ms_per_step"), steps=child.get("steps"),
+                          how="a child process per rank after the weak timed region: bench.py --scaling strong")
+            return report
+    return {"error": "the strong-scaling run printed no line"}
 
 
 def main():

@@ -45,3 +45,20 @@ def test_bench_launches_its_ranks_strong(relax):
     ss = line["strong_scaling"]
     assert len(ss["seconds_per_step_per_rank"]) == 2 and ss["bytes_gathered_per_step"] > 0
     assert line["relax"]["median_orientation_error_rad_vs_truth"] < 1e-3
+
+
+def test_bench_weak_line_carries_the_strong_section():
+    """`bench.py --gpus 2` (the scaling run's command): one weak line, and beside it the strong mode run by a child process per
+    rank (so that nothing it does can take the headline with it)."""
+    env = dict(os.environ, OCHIP_BENCH_BACKEND="gloo", OCHIP_HOST_THREADS="8", OCHIP_BENCH_STRONG_STEPS="2")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C2", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-3000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    ss = line["strong_scaling"]
+    assert "error" not in ss, ss
+    assert ss["images_per_s"] > 0 and len(ss["seconds_per_step_per_rank"]) == 2
