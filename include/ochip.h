@@ -139,6 +139,15 @@ extern "C"
      *                                   holds the features in no particular order and the host orders and suppresses
      *                                   them itself (host/extract_features.cpp: extract_tail_prepared), using `response`
      *                                   and `slot`.  Never seen on detector output; organ-pipe responses do it. */
+    /* Optionally also spatially_subsample_feature_indices(features, subset_spacing, num_sparse)
+     * (src/match/match_features.cpp:8-52: the sparse features' indices std::sorted by strength, then accepted greedily when
+     * no accepted feature lies within the spacing) - what LinkStage computes per image before matching (link_stage.cpp:63-65
+     * with 40 px):
+     *   subset          [n][OCHIP_SUBSET_CAP]  accepted indices into the feature list, in the function's output order
+     *   num_subset      [n]                    their number (> OCHIP_SUBSET_CAP: row truncated, the host computes it)
+     *   subset_conflict [n]                    non-zero: this sort hit the depth limit, the host computes the subset
+     * Leave subset NULL (or subset_spacing 0) to skip it. */
+#define OCHIP_SUBSET_CAP 16384
     typedef struct ochip_feature_lists
     {
         uint8_t *records;
@@ -146,6 +155,10 @@ extern "C"
         uint32_t *slot;
         uint32_t *num_sparse;
         uint8_t *conflict;
+        uint32_t *subset;
+        uint32_t *num_subset;
+        uint8_t *subset_conflict;
+        double subset_spacing;
     } ochip_feature_lists;
     /* ochip_akaze_batch / _dev with the tail prepared: counts as there, `lists` instead of kp6 / desc.
      * scale = working / original size (the reference's `scale`, :26), nms_radius in working pixels (8, :58). */

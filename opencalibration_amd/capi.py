@@ -222,28 +222,35 @@ class Context:
                                                 po.ctypes.data, fb.ctypes.data), "ochip_debug_std_sort")
         return ko[:len(keys)], po[:len(keys)], fb[:n_segs].astype(bool)
 
-    def feature_lists(self, kp6, desc, work_wh, scale, nms_radius=8.0):
+    def feature_lists(self, kp6, desc, work_wh, scale, nms_radius=8.0, subset_spacing=0.0):
         """ochip_feature_lists_from_keypoints for ONE image's keypoints (detection order): dict of records ((n + 1) x 88
-        bytes: the output list under the device's order), response, slot (n each), num_sparse and conflict."""
+        bytes: the output list), response, slot (n each), num_sparse, conflict; with subset_spacing > 0 also subset (indices
+        into the feature list) and subset_conflict."""
         kp6 = np.ascontiguousarray(kp6, np.float32).reshape(-1, 6)
         desc = np.ascontiguousarray(desc, np.uint64).reshape(-1, 8)
         n = len(kp6)
         m = max(n, 1)
         rec, resp = np.zeros((m + 1, 88), np.uint8), np.zeros(m, np.float32)
         slot, ns, conflict = np.zeros(m, np.uint32), np.zeros(4, np.uint32), np.zeros(16, np.uint8)
+        subset, nsub, sconf = np.zeros(16384, np.uint32), np.zeros(4, np.uint32), np.zeros(16, np.uint8)
         counts = np.array([n], np.uint32)
 
         class Lists(C.Structure):
             _fields_ = [("records", C.c_void_p), ("response", C.c_void_p), ("slot", C.c_void_p), ("num_sparse", C.c_void_p),
-                        ("conflict", C.c_void_p)]
+                        ("conflict", C.c_void_p), ("subset", C.c_void_p), ("num_subset", C.c_void_p), ("subset_conflict", C.c_void_p),
+                        ("subset_spacing", C.c_double)]
 
-        lists = Lists(rec.ctypes.data, resp.ctypes.data, slot.ctypes.data, ns.ctypes.data, conflict.ctypes.data)
+        lists = Lists(rec.ctypes.data, resp.ctypes.data, slot.ctypes.data, ns.ctypes.data, conflict.ctypes.data, subset.ctypes.data,
+                      nsub.ctypes.data, sconf.ctypes.data, float(subset_spacing))
         kin = kp6 if n else np.zeros((1, 6), np.float32)
         din = desc if n else np.zeros((1, 8), np.uint64)
         self._check(self.L.ochip_feature_lists_from_keypoints(self.h, kin.ctypes.data, din.ctypes.data, counts.ctypes.data, 1, m,
                                                               int(work_wh[0]), int(work_wh[1]), float(scale), float(nms_radius),
                                                               C.byref(lists)), "ochip_feature_lists_from_keypoints")
-        return dict(records=rec[:n + 1 if n else 0], response=resp[:n], slot=slot[:n], num_sparse=int(ns[0]), conflict=bool(conflict[0]))
+        out = dict(records=rec[:n + 1 if n else 0], response=resp[:n], slot=slot[:n], num_sparse=int(ns[0]), conflict=bool(conflict[0]))
+        if subset_spacing > 0:
+            out.update(subset=subset[:int(nsub[0])].copy(), subset_conflict=bool(sconf[0]))
+        return out
 
     def synth_views(self, position, orientation, width, height, f, pp, plane, spacing, origin, seed=7, chunk=64):
         """Render one synthetic view per camera directly into HBM (benchmark / test data).  Returns an opaque

@@ -72,6 +72,8 @@ int och_graph_load_images(och_graph *g, ochip_ctx *ctx, const uint8_t *images_bg
         sparse += (double)ex[b].num_sparse_features;
         img.features = std::move(ex[b].features);
         img.num_sparse_features = ex[b].num_sparse_features;
+        img.coarse_subset = std::move(ex[b].coarse_subset);
+        img.coarse_spacing = ex[b].coarse_spacing;
         img.model = g->models[model];
         for (int i = 0; i < 3; i++)
             img.position[i] = positions[3 * (size_t)b + i];

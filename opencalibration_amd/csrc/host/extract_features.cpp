@@ -440,7 +440,9 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
         {
             const size_t rows = (size_t)chunk * max_keypoints;
             const size_t o_resp = (rows + chunk) * 88, o_slot = o_resp + rows * 4, o_ns = o_slot + rows * 4, o_conf = o_ns + (size_t)chunk * 4;
-            if (ochip_host_alloc(buf_ctx[i], o_conf + ((size_t)chunk + 15) / 16 * 16, &p) != OCHIP_OK)
+            const size_t pad = ((size_t)chunk + 15) / 16 * 16;
+            const size_t o_sub = o_conf + pad, o_nsub = o_sub + (size_t)chunk * OCHIP_SUBSET_CAP * 4, o_sconf = o_nsub + (size_t)chunk * 4;
+            if (ochip_host_alloc(buf_ctx[i], o_sconf + pad, &p) != OCHIP_OK)
             {
                 release();
                 if (error)
@@ -453,6 +455,11 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
             b.lists.slot = (uint32_t *)(b.prepared + o_slot);
             b.lists.num_sparse = (uint32_t *)(b.prepared + o_ns);
             b.lists.conflict = b.prepared + o_conf;
+            // the 40 px subset LinkStage wants of every image (link_stage.cpp:63-65) comes with the list
+            b.lists.subset = (uint32_t *)(b.prepared + o_sub);
+            b.lists.num_subset = (uint32_t *)(b.prepared + o_nsub);
+            b.lists.subset_conflict = b.prepared + o_sconf;
+            b.lists.subset_spacing = 40.0;
             b.counts.resize(chunk);
             continue;
         }
@@ -553,9 +560,18 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
         {
             const double t0 = omp_get_wtime();
             if (device_tail)
+            {
+                const bool conflict = b.lists.conflict[i] != 0 || force_host_nms;
                 extract_tail_prepared(b.lists.records + (size_t)i * ((size_t)max_keypoints + 1) * 88,
                                       b.lists.response + (size_t)i * max_keypoints, b.lists.slot + (size_t)i * max_keypoints,
-                                      b.lists.num_sparse[i], b.lists.conflict[i] != 0 || force_host_nms, b.counts[i], scale, done[i]);
+                                      b.lists.num_sparse[i], conflict, b.counts[i], scale, done[i]);
+                if (!conflict && !b.lists.subset_conflict[i] && b.lists.num_subset[i] <= OCHIP_SUBSET_CAP)
+                {
+                    const uint32_t *sub = b.lists.subset + (size_t)i * OCHIP_SUBSET_CAP;
+                    done[i].coarse_subset.assign(sub, sub + b.lists.num_subset[i]);
+                    done[i].coarse_spacing = b.lists.subset_spacing;
+                }
+            }
             else
                 extract_tail(b.kp + (size_t)i * max_keypoints * 6, b.desc + (size_t)i * max_keypoints * 8, b.counts[i], scale,
                              done[i]);

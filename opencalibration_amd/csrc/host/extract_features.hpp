@@ -15,6 +15,10 @@ struct extracted_features // extract_features.hpp:10-15
 {
     std::vector<feature_2d> features;
     size_t num_sparse_features = 0;
+    // spatially_subsample_feature_indices(features, coarse_spacing, num_sparse_features) when the device computed it with the
+    // list (csrc/features.hip); coarse_spacing == 0: not computed
+    std::vector<uint32_t> coarse_subset;
+    double coarse_spacing = 0;
 };
 
 // extract_features(const cv::Mat&) for a batch of equally sized BGR images (n x height x width x 3 bytes):

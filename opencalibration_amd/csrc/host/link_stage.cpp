@@ -109,6 +109,7 @@ void LinkStage::prepare_images(const MeasurementGraph &graph, const std::vector<
 {
     const auto t0 = clk::now();
     const double coarse_spacing_pixels = 40.0;
+    static const bool use_host_subset = std::getenv("OCHIP_LINK_HOST_SUBSET") != nullptr; // (A/B and tests)
     const int nt = threads > 0 ? threads : omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
     for (size_t k = 0; k < node_ids.size(); k++)
@@ -118,7 +119,10 @@ void LinkStage::prepare_images(const MeasurementGraph &graph, const std::vector<
             continue;
         const size_t s = it->second;
         const image &img = graph.getNode(node_ids[k])->payload;
-        _subsets[s] = spatially_subsample_feature_indices(img.features, coarse_spacing_pixels, img.num_sparse_features);
+        if (img.coarse_spacing == coarse_spacing_pixels && !use_host_subset) // computed on the device with the feature list
+            _subsets[s].assign(img.coarse_subset.begin(), img.coarse_subset.end());
+        else
+            _subsets[s] = spatially_subsample_feature_indices(img.features, coarse_spacing_pixels, img.num_sparse_features);
         _rays[s].resize(_subsets[s].size() * 3);
         for (size_t q = 0; q < _subsets[s].size(); q++)
             image_to_3d(img.features[_subsets[s][q]].location, *img.model, &_rays[s][3 * q]);

@@ -166,6 +166,8 @@ bool load_link_stream(och_graph *g, ochip_ctx *ctx, LinkStage &link, const std::
                 sparse += (double)f[i].num_sparse_features;
                 img.features = std::move(f[i].features);
                 img.num_sparse_features = f[i].num_sparse_features;
+                img.coarse_subset = std::move(f[i].coarse_subset);
+                img.coarse_spacing = f[i].coarse_spacing;
                 chunk_ids[i] = ids[first + chunk_first + i];
             }
             link.prepare_images(g->graph, chunk_ids, tail_threads);

@@ -85,6 +85,11 @@ struct image // types/image.hpp:17-33 (fields the hot path touches)
     std::string path;
     std::vector<feature_2d> features;
     size_t num_sparse_features = 0;
+    // cache (not a field of the reference's type): spatially_subsample_feature_indices(features, coarse_spacing,
+    // num_sparse_features) as the device computed it with the feature list; coarse_spacing == 0: none.  Anything that
+    // changes `features` must reset it.
+    std::vector<uint32_t> coarse_subset;
+    double coarse_spacing = 0;
     std::shared_ptr<CameraModel> model;
     double position[3] = {NAN, NAN, NAN};
     double orientation[4] = {NAN, NAN, NAN, NAN};

@@ -54,9 +54,13 @@ def keypoints(rng, n, w, h, clusters=0, ties=0, close_ties=0, top_tie=False):
 
 
 def both(ctx, kp6, desc, w, h, scale):
-    lists = ctx.feature_lists(kp6, desc, (w, h), scale)
+    lists = ctx.feature_lists(kp6, desc, (w, h), scale, subset_spacing=40.0)
     got = host.extract_tail_prepared(lists, scale)
     exp = host.extract_tail(kp6, desc, scale)
+    if not lists["conflict"] and not lists["subset_conflict"]:
+        # spatially_subsample_feature_indices(features, 40, num_sparse) (match_features.cpp:8-52) came with the list
+        want = host.subsample(exp[0], exp[1], 40.0, exp[3])
+        assert np.array_equal(lists["subset"], want), (len(lists["subset"]), len(want))
     assert got[3] == exp[3] and len(got[0]) == len(exp[0])
     assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2])
     forced = host.extract_tail_prepared(lists, scale, force_host_nms=True)     # the conflict path on the same lists
