@@ -263,14 +263,23 @@ extern "C"
      *      ochip_ransac_homography_batch (rng_state and eval_offset unused); the keypoints and the CURRENT models must
      *      have been uploaded (ochip_upload_keypoints / ochip_upload_batch).  inliers: in = the previous inlier flags,
      *      out = the flags of the last evaluate; results[j].H = the last fit, .n_inliers, .score = evaluate / n. */
-    /* The same on the matches ochip_match_sort left in HBM: jobs[j] is pair j of that call with n = counts_out[j]; the
+    /* homography_model::decompose (homography_model.cpp:138-185) of a job's result: the four poses of
+     * cv::decomposeHomographyMat(H, I) as {orientation x y z w, position x y z, score = cheirality votes of the inliers} in
+     * std::stable_sort's order (absent solutions: NaN, score -1), can_decompose = decompose()'s return value, n_inliers =
+     * number of inlier flags set. */
+    typedef struct ochip_decomposition
+    {
+        double pose[4][8];
+        uint32_t can_decompose, n_inliers;
+    } ochip_decomposition;
+    /* The same on the matches ochip_match_sort left in HBM (decomp_out: NULL or one ochip_decomposition per job): jobs[j] is pair j of that call with n = counts_out[j]; the
      * correspondences (their order is the sort's), the PROSAC order (ransac.cpp:83-90, the same device std::sort) are built
      * on the device.  matches_out[match_offset + i] = correspondence i of the job (for the host's feature_match list);
      * fallback_out[j] != 0: the PROSAC order of job j needs the host (then nothing of this call is to be used). */
     int ochip_ransac_homography_batch_sorted(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, uint64_t total_matches,
                                              const uint32_t *eval_order, uint64_t eval_total, double inlier_threshold,
                                              ochip_ransac_result *results, uint8_t *inliers, ochip_ransac_match *matches_out,
-                                             uint8_t *fallback_out);
+                                             uint8_t *fallback_out, ochip_decomposition *decomp_out);
     int ochip_refit_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs,
                                      const ochip_ransac_match *matches, uint64_t total_matches, uint32_t rounds,
                                      double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers);

@@ -505,12 +505,14 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
     t0 = clk::now();
     std::vector<ochip_ransac_result> results(n_pairs);
     const homography_model model_defaults;
+    std::vector<ochip_decomposition> decomps(device_sorted ? n_pairs : 0);
     if (device_sorted)
     {
-        // (the correspondences come back in rm_flat; the PROSAC order is built and used on the device)
+        // (the correspondences come back in rm_flat; the PROSAC order is built and used on the device, and
+        // homography_model::decompose with its cheirality vote runs there too: csrc/decompose.hpp is the host's code)
         if (ochip_ransac_homography_batch_sorted(ctx, rjobs.data(), (uint32_t)n_pairs, total_matches, eval_table.data(), eval_table.size(),
                                                  model_defaults.inlier_threshold, results.data(), inl_flat.ptr, rm_flat.ptr,
-                                                 sort_flags.data()) != OCHIP_OK)
+                                                 sort_flags.data(), decomps.data()) != OCHIP_OK)
             return fail("ochip_ransac_homography_batch_sorted");
         for (size_t p = 0; p < n_pairs; p++)
             if (sort_flags[p])
@@ -562,13 +564,26 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
         const size_t num_coarse_inliers = inlier_at.size();
         const auto &ray1 = rays[jobs[p].slot_1], &ray2 = rays[jobs[p].slot_2];
         const uint32_t *at = inlier_at.data();
-        const bool can_decompose = h.decompose_with(
-            num_coarse_inliers,
-            [&](size_t j, const double *&m1, const double *&m2) {
-                m1 = &ray1[3 * (size_t)rm[at[j]].k1];
-                m2 = &ray2[3 * (size_t)rm[at[j]].k2];
-            },
-            relations.relative_poses);
+        bool can_decompose;
+        if (device_sorted)
+        {
+            const ochip_decomposition &d = decomps[p];
+            for (int k = 0; k < 4; k++)
+            {
+                std::memcpy(relations.relative_poses[k].orientation, &d.pose[k][0], 4 * sizeof(double));
+                std::memcpy(relations.relative_poses[k].position, &d.pose[k][4], 3 * sizeof(double));
+                relations.relative_poses[k].score = (int)d.pose[k][7];
+            }
+            can_decompose = d.can_decompose != 0;
+        }
+        else
+            can_decompose = h.decompose_with(
+                num_coarse_inliers,
+                [&](size_t j, const double *&m1, const double *&m2) {
+                    m1 = &ray1[3 * (size_t)rm[at[j]].k1];
+                    m2 = &ray2[3 * (size_t)rm[at[j]].k2];
+                },
+                relations.relative_poses);
         if (keep_debug)
         {
             dbg[p].node_id = jobs[p].node_id;

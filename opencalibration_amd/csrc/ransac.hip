@@ -24,6 +24,7 @@
 // (evaluation order) are executed on the host with the real libstdc++ and handed in.
 #include "ctx.hpp"
 #include "undistort.hpp"
+#include "decompose.hpp"
 
 #include <cmath>
 
@@ -2012,6 +2013,76 @@ __global__ void sorted_matches_kernel(const ochip_ransac_job *__restrict__ jobs,
     matches[jb.match_offset + i] = m;
     prosac[jb.match_offset + i] = ((unsigned long long)(0xFFFFFFFFu - count) << 32) | i;
 }
+// homography_model::decompose (homography_model.cpp:138-185) for every job: cv::decomposeHomographyMat by one lane
+// (csrc/decompose.hpp, the host's code), the cheirality vote over the inliers' rays by the wavefront (integers: the order is
+// free), the poses in std::stable_sort's order.  One wavefront per job.
+__global__ __launch_bounds__(256) void decompose_vote_kernel(const ochip_ransac_job *__restrict__ jobs, unsigned int n_jobs,
+                                                             const ochip_ransac_match *__restrict__ matches,
+                                                             const ochip_ransac_result *__restrict__ results,
+                                                             const uint8_t *__restrict__ inliers, rays_view rv,
+                                                             ochip_decomposition *__restrict__ out)
+{
+    __shared__ ochip_dc::vote_plan plans[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned int j = blockIdx.x * 4 + wv;
+    if (j >= n_jobs)
+        return;
+    const ochip_ransac_job jb = jobs[j];
+    ochip_dc::vote_plan &plan = plans[wv];
+    if (lane == 0)
+        ochip_dc::plan_votes(results[j].H, &plan);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int solutions = plan.solutions;
+    const double *r1 = rv.rays + rv.img_off[jb.image_1] * 3, *r2 = rv.rays + rv.img_off[jb.image_2] * 3;
+    const ochip_ransac_match *mm = matches + jb.match_offset;
+    const uint8_t *inl = inliers + jb.match_offset;
+    int votes[4] = {0, 0, 0, 0};
+    unsigned int n_inl = 0;
+    for (unsigned int i0 = 0; i0 < jb.n; i0 += 64)
+    {
+        const unsigned int i = i0 + lane;
+        const bool on = i < jb.n && inl[i] != 0;
+        bool ok[4] = {false, false, false, false};
+        if (on)
+        {
+            const double *m1 = r1 + 3 * (size_t)mm[i].k1, *m2 = r2 + 3 * (size_t)mm[i].k2;
+            const double a0 = m1[0], a1 = m1[1], a2 = m1[2], b0 = m2[0], b1 = m2[1], b2 = m2[2];
+            for (int s = 0; s < 4; s++)
+                if (s < solutions)
+                {
+                    const double dot1 = plan.N[s][0] * a0 + plan.N[s][1] * a1 + plan.N[s][2] * a2;
+                    const double dot2 = plan.RN[s][0] * b0 + plan.RN[s][1] * b1 + plan.RN[s][2] * b2;
+                    ok[s] = dot1 >= 0 && dot2 >= 0;
+                }
+        }
+        n_inl += (unsigned int)__popcll(__ballot(on));
+        for (int s = 0; s < 4; s++)
+            votes[s] += (int)__popcll(__ballot(ok[s]));
+    }
+    if (lane == 0)
+    {
+        int score[4], order[4];
+        for (int s = 0; s < 4; s++)
+            score[s] = s < solutions ? votes[s] : -1;
+        ochip_dc::order_by_votes(score, order);
+        ochip_decomposition d;
+        const double nan = __longlong_as_double(0x7FF8000000000000ll);
+        for (int k = 0; k < 4; k++)
+        {
+            const int s = order[k];
+            for (int c = 0; c < 4; c++)
+                d.pose[k][c] = s < solutions ? plan.q[s][c] : nan;
+            for (int c = 0; c < 3; c++)
+                d.pose[k][4 + c] = s < solutions ? plan.t[s][c] : nan;
+            d.pose[k][7] = (double)score[s];
+        }
+        d.can_decompose = score[order[0]] > 0 ? 1u : 0u;
+        d.n_inliers = n_inl;
+        out[j] = d;
+    }
+}
+
 __global__ void prosac_order_kernel(const unsigned long long *__restrict__ prosac, uint32_t *__restrict__ sorted_idx, uint64_t total)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2022,7 +2093,7 @@ __global__ void prosac_order_kernel(const unsigned long long *__restrict__ prosa
 int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, const ochip_ransac_match *matches,
                            const uint32_t *sorted_idx, uint64_t total_matches, const uint32_t *eval_order, uint64_t eval_total,
                            double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers, bool sorted_on_device,
-                           ochip_ransac_match *matches_out, uint8_t *fallback_out);
+                           ochip_ransac_match *matches_out, uint8_t *fallback_out, ochip_decomposition *decomp_out);
 } // namespace
 
 extern "C"
@@ -2034,13 +2105,13 @@ int ochip_ransac_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, 
                                   ochip_ransac_result *results, uint8_t *inliers)
 {
     return ransac_homography_impl(ctx, jobs, n_jobs, matches, sorted_idx, total_matches, eval_order, eval_total, inlier_threshold,
-                                  results, inliers, false, nullptr, nullptr);
+                                  results, inliers, false, nullptr, nullptr, nullptr);
 }
 
 int ochip_ransac_homography_batch_sorted(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, uint64_t total_matches,
                                          const uint32_t *eval_order, uint64_t eval_total, double inlier_threshold,
                                          ochip_ransac_result *results, uint8_t *inliers, ochip_ransac_match *matches_out,
-                                         uint8_t *fallback_out)
+                                         uint8_t *fallback_out, ochip_decomposition *decomp_out)
 {
     if (!ctx)
         return OCHIP_EINVAL;
@@ -2049,7 +2120,7 @@ int ochip_ransac_homography_batch_sorted(ochip_ctx *ctx, const ochip_ransac_job 
     if (n_jobs != ctx->ms_pairs)
         return ochip_fail(ctx, OCHIP_ESTATE, "ochip_ransac_homography_batch_sorted must follow ochip_match_sort of the same %u pairs", n_jobs);
     return ransac_homography_impl(ctx, jobs, n_jobs, nullptr, nullptr, total_matches, eval_order, eval_total, inlier_threshold, results,
-                                  inliers, true, matches_out, fallback_out);
+                                  inliers, true, matches_out, fallback_out, decomp_out);
 }
 
 } // extern "C"
@@ -2059,7 +2130,7 @@ namespace
 int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, const ochip_ransac_match *matches,
                            const uint32_t *sorted_idx, uint64_t total_matches, const uint32_t *eval_order, uint64_t eval_total,
                            double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers, bool sorted_on_device,
-                           ochip_ransac_match *matches_out, uint8_t *fallback_out)
+                           ochip_ransac_match *matches_out, uint8_t *fallback_out, ochip_decomposition *decomp_out)
 {
     if (!ctx)
         return OCHIP_EINVAL;
@@ -2206,6 +2277,19 @@ int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_
         launch(ransac_homography_kernel<2>);
     ochip_prof_end(ctx, OCHIP_K_RANSAC, e0, e1);
     OCHIP_HIP(ctx, hipGetLastError());
+    if (decomp_out)
+    {
+        size_t gd = 0;
+        ochip_decomposition *dec_dev = (ochip_decomposition *)ochip_pool_get(ctx, (size_t)n_jobs * sizeof(ochip_decomposition), &gd);
+        if (!dec_dev)
+            return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (decompositions)");
+        allocs.emplace_back(dec_dev, gd);
+        hipLaunchKernelGGL(decompose_vote_kernel, dim3((n_jobs + 3) / 4), dim3(256), 0, ctx->stream,
+                           (const ochip_ransac_job *)ctx->scratch_dev[S_JOBS], n_jobs, (const ochip_ransac_match *)ctx->scratch_dev[S_MATCH],
+                           (const ochip_ransac_result *)res_dev, (const uint8_t *)inl_dev, rv, dec_dev);
+        OCHIP_HIP(ctx, hipMemcpyAsync(decomp_out, dec_dev, (size_t)n_jobs * sizeof(ochip_decomposition), hipMemcpyDeviceToHost,
+                                      ctx->stream));
+    }
     OCHIP_HIP(ctx, hipMemcpyAsync(results, res_dev, (size_t)n_jobs * sizeof(ochip_ransac_result), hipMemcpyDeviceToHost,
                                   ctx->stream));
     if (total_matches)
