@@ -200,26 +200,81 @@ template <int G> __device__ void partition_range(const sort_dev &S, const range_
     group<G>::sync();
     const u64 pivot = A[first];
     const unsigned int lo = first + 1, hi = last, m = hi - lo;
-    const unsigned int per = (m + G - 1) / G;
-    const unsigned int i0 = lo + min(t * per, m), i1 = min(i0 + per, hi);
-    unsigned int cl = 0, cr = 0;
-    for (unsigned int i = i0; i < i1; i++)
+    // the stops of the two scans, in position order: every wavefront of the group takes a contiguous part of the range in
+    // steps of 64 consecutive elements (coalesced), ballots give the order inside a step
+    constexpr unsigned int W = G / 64;
+    const unsigned int wave = t >> 6, lane = t & 63;
+    const unsigned int part = ((m + W - 1) / W + 63) / 64 * 64;
+    const unsigned int p0 = lo + min(wave * part, m), p1 = min(p0 + part, hi);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned int cl = 0, cr = 0; // (wave-uniform)
+    constexpr int UN = 4; // steps whose loads are in flight together (the passes are bound by their round trips)
+    for (unsigned int base = p0; base < p1; base += 64 * UN)
     {
-        const u64 v = A[i];
-        cl += comp(v, pivot) ? 0u : 1u; // where "while (comp(*first, pivot)) ++first" stops
-        cr += comp(pivot, v) ? 0u : 1u; // where "while (comp(pivot, *last)) --last" stops
+        u64 v[UN];
+        bool valid[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+        {
+            const unsigned int i = base + 64 * u + lane;
+            valid[u] = i < p1;
+            v[u] = valid[u] ? A[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+        {
+            cl += (unsigned int)__popcll(__ballot(valid[u] && !comp(v[u], pivot))); // where "while (comp(*first, pivot)) ++first" stops
+            cr += (unsigned int)__popcll(__ballot(valid[u] && !comp(pivot, v[u]))); // where "while (comp(pivot, *last)) --last" stops
+        }
     }
-    unsigned int nL, nR;
-    unsigned int ol = group<G>::scan(cl, &nL, lds);
-    unsigned int orr = group<G>::scan(cr, &nR, lds);
-    unsigned int *LL = S.listL + lo, *LR = S.listR + lo;
-    for (unsigned int i = i0; i < i1; i++)
+    unsigned int nL = cl, nR = cr, ol = 0, orr = 0;
+    if (W > 1)
     {
-        const u64 v = A[i];
-        if (!comp(v, pivot))
-            LL[ol++] = i;
-        if (!comp(pivot, v))
-            LR[orr++] = i;
+        __syncthreads();
+        if (lane == 0)
+        {
+            lds[wave] = cl;
+            lds[W + wave] = cr;
+        }
+        __syncthreads();
+        nL = nR = 0;
+        for (unsigned int w = 0; w < W; w++)
+        {
+            if (w < wave)
+            {
+                ol += lds[w];
+                orr += lds[W + w];
+            }
+            nL += lds[w];
+            nR += lds[W + w];
+        }
+        __syncthreads();
+    }
+    unsigned int *LL = S.listL + lo, *LR = S.listR + lo;
+    for (unsigned int base = p0; base < p1; base += 64 * UN)
+    {
+        u64 v[UN];
+        bool valid[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+        {
+            const unsigned int i = base + 64 * u + lane;
+            valid[u] = i < p1;
+            v[u] = valid[u] ? A[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+        {
+            const unsigned int i = base + 64 * u + lane;
+            const bool sl = valid[u] && !comp(v[u], pivot), sr = valid[u] && !comp(pivot, v[u]);
+            const unsigned long long ml = __ballot(sl), mr = __ballot(sr);
+            if (sl)
+                LL[ol + (unsigned int)__popcll(ml & below)] = i;
+            if (sr)
+                LR[orr + (unsigned int)__popcll(mr & below)] = i;
+            ol += (unsigned int)__popcll(ml);
+            orr += (unsigned int)__popcll(mr);
+        }
     }
     group<G>::sync();
     // the k-th left stop is swapped with the k-th right stop (from the right) while it lies left of it
@@ -344,26 +399,23 @@ __global__ __launch_bounds__(256) void sort_local_kernel(sort_dev S)
             }
             group<64>::sync();
             const u64 pivot = D[first];
-            const unsigned int lo = first + 1, hi = last, m = hi - lo;
-            const unsigned int per = (m + 63) / 64;
-            const unsigned int i0 = lo + min((unsigned int)lane * per, m), i1 = min(i0 + per, hi);
-            unsigned int cl = 0, cr = 0;
-            for (unsigned int i = i0; i < i1; i++)
+            const unsigned int lo = first + 1, hi = last;
+            // the stops of the two scans in position order: 64 consecutive elements per step, ballots for the order
+            const unsigned long long below = (1ull << lane) - 1ull;
+            unsigned int nL = 0, nR = 0;
+            for (unsigned int base = lo; base < hi; base += 64)
             {
-                const u64 v = D[i];
-                cl += comp(v, pivot) ? 0u : 1u;
-                cr += comp(pivot, v) ? 0u : 1u;
-            }
-            unsigned int nL, nR;
-            unsigned int ol = group<64>::scan(cl, &nL, nullptr);
-            unsigned int orr = group<64>::scan(cr, &nR, nullptr);
-            for (unsigned int i = i0; i < i1; i++)
-            {
-                const u64 v = D[i];
-                if (!comp(v, pivot))
-                    LL[ol++] = (unsigned short)i;
-                if (!comp(pivot, v))
-                    LR[orr++] = (unsigned short)i;
+                const unsigned int i = base + lane;
+                const bool valid = i < hi;
+                const u64 v = valid ? D[i] : 0ull;
+                const bool sl = valid && !comp(v, pivot), sr = valid && !comp(pivot, v);
+                const unsigned long long ml = __ballot(sl), mr = __ballot(sr);
+                if (sl)
+                    LL[nL + (unsigned int)__popcll(ml & below)] = (unsigned short)i;
+                if (sr)
+                    LR[nR + (unsigned int)__popcll(mr & below)] = (unsigned short)i;
+                nL += (unsigned int)__popcll(ml);
+                nR += (unsigned int)__popcll(mr);
             }
             group<64>::sync();
             const unsigned int kmax = min(nL, nR);
