@@ -280,6 +280,17 @@ extern "C"
                                              const uint32_t *eval_order, uint64_t eval_total, double inlier_threshold,
                                              ochip_ransac_result *results, uint8_t *inliers, ochip_ransac_match *matches_out,
                                              uint8_t *fallback_out, ochip_decomposition *decomp_out);
+    /* The two lists an accepted edge keeps (camera_relations.matches / .inlier_matches, link_stage.cpp:99-107), gathered on
+     * the device right after ochip_ransac_homography_batch_sorted (same context, same batch):
+     *   feature_match_out  [total_matches] x {u64 feature_index_1, u64 feature_index_2, f64 distance}  (types/feature_match.hpp:
+     *                      feature_match, 24 bytes), job j's matches at its match_offset, in the sort's order
+     *   inlier_match_out   [total_inliers] x {f64 pixel_1[2], pixel_2[2], u64 feature_index_1, feature_index_2, match_index}
+     *                      (feature_match_denormalized, 56 bytes): job j's inliers in match order at inlier_offset[j] (the
+     *                      caller sums ochip_decomposition.n_inliers)
+     * feature_index[k]: index in its image's feature list of the k-th keypoint of the upload (ochip_upload_batch order) -
+     * the 40 px subset's indices. */
+    int ochip_edge_lists(ochip_ctx *ctx, uint32_t n_jobs, uint64_t total_matches, const uint32_t *feature_index, uint64_t n_keypoints,
+                         const uint64_t *inlier_offset, uint64_t total_inliers, void *feature_match_out, void *inlier_match_out);
     int ochip_refit_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs,
                                      const ochip_ransac_match *matches, uint64_t total_matches, uint32_t rounds,
                                      double inlier_threshold, ochip_ransac_result *results, uint8_t *inliers);

@@ -319,6 +319,9 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
     // (the subsets' pixel locations stay at hand for assembleInliers below: 16 bytes per subset feature, one after the other,
     // instead of a walk through the images' 88-byte feature records)
     pinned<double> xybuf(ctx, total_desc * 2);
+    pinned<uint32_t> idxbuf(ctx, total_desc ? total_desc : 1); // the subset features' indices in their images' feature lists
+    if (!idxbuf.ptr)
+        return fail("ochip_host_alloc");
     {
         pinned<uint64_t> dbuf(ctx, total_desc * 8);
         std::vector<double> models((size_t)n_slots * 8);
@@ -331,6 +334,8 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
             const image &img = graph.getNode(slot_node[s])->payload;
             uint64_t *d = dbuf.ptr + slot_off[s] * 8;
             double *xy = xybuf.ptr + slot_off[s] * 2;
+            for (size_t k = 0; k < subset[s].size(); k++)
+                idxbuf.ptr[slot_off[s] + k] = (uint32_t)subset[s][k];
             if (remote_p[s])
             {
                 std::memcpy(d, remote_p[s]->desc.data(), subset[s].size() * 64);
@@ -524,6 +529,22 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
                 return;
             }
     }
+    // the edges' lists (matches, inlier matches) are gathers of data the device holds: written there, copied here
+    std::vector<uint64_t> inlier_off(device_sorted ? n_pairs + 1 : 1, 0);
+    if (device_sorted)
+        for (size_t p = 0; p < n_pairs; p++)
+            inlier_off[p + 1] = inlier_off[p] + decomps[p].n_inliers;
+    const uint64_t total_inliers = inlier_off.back();
+    pinned<feature_match> fm_flat(ctx, device_sorted && total_matches ? total_matches : 1);
+    pinned<feature_match_denormalized> fmd_flat(ctx, device_sorted && total_inliers ? total_inliers : 1);
+    if (!fm_flat.ptr || !fmd_flat.ptr)
+        return fail("ochip_host_alloc");
+    if (device_sorted)
+    {
+        if (ochip_edge_lists(ctx, (uint32_t)n_pairs, total_matches, idxbuf.ptr, total_desc, inlier_off.data(), total_inliers, fm_flat.ptr,
+                             fmd_flat.ptr) != OCHIP_OK)
+            return fail("ochip_edge_lists");
+    }
     else if (ochip_ransac_homography_batch(ctx, rjobs.data(), (uint32_t)n_pairs, rm_flat.ptr, si_flat.ptr, total_matches,
                                            eval_table.data(), eval_table.size(), model_defaults.inlier_threshold,
                                            results.data(), inl_flat.ptr) != OCHIP_OK)
@@ -541,14 +562,8 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
         const size_t M = rjobs[p].n;
         const uint8_t *inl = inl_flat.ptr + rjobs[p].match_offset;
         const ochip_ransac_match *rm = rm_flat.ptr + rjobs[p].match_offset;
-        if (device_sorted)
-        {
-            // match_features_subset's output (match_features.cpp:86-101) from the device's sorted correspondences
-            const auto &idx1 = subset[jobs[p].slot_1], &idx2 = subset[jobs[p].slot_2];
-            matches[p].resize(M);
-            for (size_t i = 0; i < M; i++)
-                matches[p][i] = feature_match{idx1[rm[i].k1], idx2[rm[i].k2], (size_t)rm[i].count * (1.0 / feature_2d::DESCRIPTOR_BITS)};
-        }
+        if (device_sorted) // match_features_subset's output (match_features.cpp:86-101), as the device listed it
+            matches[p].assign(fm_flat.ptr + rjobs[p].match_offset, fm_flat.ptr + rjobs[p].match_offset + M);
         camera_relations relations;
         homography_model h;
         std::memcpy(h.homography, results[p].H, sizeof h.homography);
@@ -558,10 +573,11 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
         // the cheirality vote reads the inliers' rays where they lie (two gathers per inlier, all solutions in one pass)
         static thread_local std::vector<uint32_t> inlier_at;
         inlier_at.clear();
-        for (size_t i = 0; i < M; i++)
-            if (inl[i])
-                inlier_at.push_back((uint32_t)i);
-        const size_t num_coarse_inliers = inlier_at.size();
+        if (!device_sorted)
+            for (size_t i = 0; i < M; i++)
+                if (inl[i])
+                    inlier_at.push_back((uint32_t)i);
+        const size_t num_coarse_inliers = device_sorted ? decomps[p].n_inliers : inlier_at.size();
         const auto &ray1 = rays[jobs[p].slot_1], &ray2 = rays[jobs[p].slot_2];
         const uint32_t *at = inlier_at.data();
         bool can_decompose;
@@ -599,6 +615,9 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
         if (can_decompose && num_coarse_inliers > h.MINIMUM_POINTS * 1.5)
         {
             relations.matches = std::move(matches[p]);
+            if (device_sorted) // assembleInliers (ransac.cpp:263-282), as the device listed it
+                relations.inlier_matches.assign(fmd_flat.ptr + inlier_off[p], fmd_flat.ptr + inlier_off[p + 1]);
+            else
             {
                 // assembleInliers (ransac.cpp:263-282) with the pixels read from the subsets' packed copy: the same numbers
                 // (and an image whose feature list lives on another rank has nothing else)

@@ -2083,6 +2083,69 @@ __global__ __launch_bounds__(256) void decompose_vote_kernel(const ochip_ransac_
     }
 }
 
+// The two lists an accepted edge keeps (camera_relations.matches and .inlier_matches, link_stage.cpp:99-107): pure gathers
+// of what the device holds - the sorted correspondences, the inlier flags, the subsets' pixel locations and the
+// keypoints' indices in their images' feature lists.  One wavefront per job; inliers in match order (ballot prefix).
+struct edge_feature_match // types/feature_match.hpp:11-23
+{
+    uint64_t feature_index_1, feature_index_2;
+    double distance;
+};
+struct edge_inlier_match // types/feature_match.hpp:26-39 (feature_match_denormalized)
+{
+    double pixel_1[2], pixel_2[2];
+    uint64_t feature_index_1, feature_index_2, match_index;
+};
+__global__ __launch_bounds__(256) void edge_lists_kernel(const ochip_ransac_job *__restrict__ jobs, unsigned int n_jobs,
+                                                         const ochip_ransac_match *__restrict__ matches,
+                                                         const uint8_t *__restrict__ inliers, const uint64_t *__restrict__ img_off,
+                                                         const double *__restrict__ kp_xy, const uint32_t *__restrict__ feature_index,
+                                                         const uint64_t *__restrict__ inlier_offset, edge_feature_match *__restrict__ fm,
+                                                         edge_inlier_match *__restrict__ fmd)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n_jobs)
+        return;
+    const ochip_ransac_job jb = jobs[j];
+    const uint64_t o1 = img_off[jb.image_1], o2 = img_off[jb.image_2];
+    const ochip_ransac_match *mm = matches + jb.match_offset;
+    const uint8_t *inl = inliers + jb.match_offset;
+    uint64_t at = inlier_offset[j];
+    for (unsigned int i0 = 0; i0 < jb.n; i0 += 64)
+    {
+        const unsigned int i = i0 + lane;
+        bool on = false;
+        ochip_ransac_match m{};
+        uint64_t f1 = 0, f2 = 0;
+        if (i < jb.n)
+        {
+            m = mm[i];
+            f1 = feature_index[o1 + m.k1];
+            f2 = feature_index[o2 + m.k2];
+            edge_feature_match r;
+            r.feature_index_1 = f1;
+            r.feature_index_2 = f2;
+            r.distance = (double)m.count * (1.0 / 486); // count * (1.0 / feature_2d::DESCRIPTOR_BITS), match_features.cpp:90
+            fm[jb.match_offset + i] = r;
+            on = inl[i] != 0;
+        }
+        const unsigned long long mask = __ballot(on);
+        if (on)
+        {
+            edge_inlier_match r;
+            const double *p1 = kp_xy + 2 * (o1 + m.k1), *p2 = kp_xy + 2 * (o2 + m.k2);
+            r.pixel_1[0] = p1[0], r.pixel_1[1] = p1[1];
+            r.pixel_2[0] = p2[0], r.pixel_2[1] = p2[1];
+            r.feature_index_1 = f1;
+            r.feature_index_2 = f2;
+            r.match_index = i;
+            fmd[at + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
+        }
+        at += (uint64_t)__popcll(mask);
+    }
+}
+
 __global__ void prosac_order_kernel(const unsigned long long *__restrict__ prosac, uint32_t *__restrict__ sorted_idx, uint64_t total)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2301,6 +2364,59 @@ int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_
 
 extern "C"
 {
+
+int ochip_edge_lists(ochip_ctx *ctx, uint32_t n_jobs, uint64_t total_matches, const uint32_t *feature_index, uint64_t n_keypoints,
+                     const uint64_t *inlier_offset, uint64_t total_inliers, void *feature_match_out, void *inlier_match_out)
+{
+    if (!ctx)
+        return OCHIP_EINVAL;
+    if (n_jobs == 0)
+        return OCHIP_OK;
+    if (!feature_index || !inlier_offset || (total_matches && !feature_match_out) || (total_inliers && !inlier_match_out))
+        return ochip_fail(ctx, OCHIP_EINVAL, "NULL argument");
+    if (n_jobs != ctx->ms_pairs || n_keypoints != ctx->desc_used)
+        return ochip_fail(ctx, OCHIP_ESTATE, "ochip_edge_lists must follow ochip_ransac_homography_batch_sorted of the same batch");
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<std::pair<void *, size_t>> allocs;
+    auto dev = [&](size_t bytes) -> void * {
+        size_t got = 0;
+        void *p = ochip_pool_get(ctx, std::max<size_t>(bytes, 16), &got);
+        if (p)
+            allocs.emplace_back(p, got);
+        return p;
+    };
+    uint32_t *idx_dev = (uint32_t *)dev((size_t)n_keypoints * 4);
+    uint64_t *off_dev = (uint64_t *)dev((size_t)n_jobs * 8);
+    edge_feature_match *fm_dev = (edge_feature_match *)dev((size_t)total_matches * sizeof(edge_feature_match));
+    edge_inlier_match *fmd_dev = (edge_inlier_match *)dev((size_t)total_inliers * sizeof(edge_inlier_match));
+    int rc = OCHIP_OK;
+    if (!idx_dev || !off_dev || !fm_dev || !fmd_dev)
+        rc = ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (edge lists)");
+    if (rc == OCHIP_OK && (hipMemcpyAsync(idx_dev, feature_index, (size_t)n_keypoints * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+                           hipMemcpyAsync(off_dev, inlier_offset, (size_t)n_jobs * 8, hipMemcpyHostToDevice, st) != hipSuccess))
+        rc = ochip_fail(ctx, OCHIP_EHIP, "upload failed (edge lists)");
+    if (rc == OCHIP_OK)
+    {
+        // scratch slots as ochip_ransac_homography_batch left them: 0 jobs, 1 matches, 7 results + inlier flags
+        const uint8_t *inl_dev = (const uint8_t *)ctx->scratch_dev[7] + (size_t)n_jobs * sizeof(ochip_ransac_result);
+        hipLaunchKernelGGL(edge_lists_kernel, dim3((n_jobs + 3) / 4), dim3(256), 0, st, (const ochip_ransac_job *)ctx->scratch_dev[0], n_jobs,
+                           (const ochip_ransac_match *)ctx->scratch_dev[1], inl_dev, (const uint64_t *)ctx->img_off_dev,
+                           (const double *)ctx->kp_xy_dev, (const uint32_t *)idx_dev, (const uint64_t *)off_dev, fm_dev, fmd_dev);
+        if (hipGetLastError() != hipSuccess ||
+            (total_matches && hipMemcpyAsync(feature_match_out, fm_dev, (size_t)total_matches * sizeof(edge_feature_match),
+                                             hipMemcpyDeviceToHost, st) != hipSuccess) ||
+            (total_inliers && hipMemcpyAsync(inlier_match_out, fmd_dev, (size_t)total_inliers * sizeof(edge_inlier_match),
+                                             hipMemcpyDeviceToHost, st) != hipSuccess))
+            rc = ochip_fail(ctx, OCHIP_EHIP, "edge lists: launch or download failed");
+    }
+    const hipError_t werr = ochip_stream_wait(ctx, st);
+    for (auto &a : allocs)
+        ochip_pool_put(ctx, a.first, a.second);
+    if (rc == OCHIP_OK && werr != hipSuccess)
+        rc = ochip_fail(ctx, OCHIP_EHIP, "edge lists: %s", hipGetErrorString(werr));
+    return rc;
+}
 
 int ochip_refit_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_t n_jobs, const ochip_ransac_match *matches,
                                  uint64_t total_matches, uint32_t rounds, double inlier_threshold, ochip_ransac_result *results,
