@@ -77,71 +77,130 @@ template <int JB>
 __device__ __forceinline__ void chol_diag_phase(double (&a)[4][4], double (&x)[4][4], double (*colA)[NB], double (*rowX)[NB],
                                                 int ty, int tx, int nb, bool &bad)
 {
+    // TWO pivots per barrier: the owners publish columns j and j + 1 (and rows j, j + 1 of the inverse accumulator) as they
+    // are before pivot j; every thread then derives pivot j + 1's column itself (col_{j+1} - l_j l_{j+1,j}: the update step j
+    // would have applied to it) and applies both rank-1 updates, in the order and with the expressions of the
+    // one-pivot-per-barrier loop, so the factor is the same to the bit with half the barriers on the critical path.
 #pragma unroll 1
-    for (int jt = 0; jt < 16; jt++)
+    for (int jt = 0; jt < 16; jt += 2)
     {
-        const int j = JB * 16 + jt, buf = jt & 1;
+        const int j = JB * 16 + jt, buf = (jt >> 1) & 1;
+        double(*c0) = colA[2 * buf], (*c1) = colA[2 * buf + 1], (*r0) = rowX[2 * buf], (*r1) = rowX[2 * buf + 1];
         if (tx == jt) // owners of column j: rows of band JB and below
 #pragma unroll
             for (int p = JB; p < 4; p++)
-                colA[buf][ty + 16 * p] = a[p][JB];
-        if (ty == jt) // owners of row j of the inverse accumulator: columns up to band JB
+                c0[ty + 16 * p] = a[p][JB];
+        if (tx == jt + 1) // owners of column j + 1
+#pragma unroll
+            for (int p = JB; p < 4; p++)
+                c1[ty + 16 * p] = a[p][JB];
+        if (ty == jt) // owners of rows j / j + 1 of the inverse accumulator: columns up to band JB
 #pragma unroll
             for (int q = 0; q <= JB; q++)
-                rowX[buf][tx + 16 * q] = x[JB][q];
+                r0[tx + 16 * q] = x[JB][q];
+        if (ty == jt + 1)
+#pragma unroll
+            for (int q = 0; q <= JB; q++)
+                r1[tx + 16 * q] = x[JB][q];
         __syncthreads();
-        const double piv = colA[buf][j];
-        if (j < nb && !(piv > 0.0))
+        // ---- pivot j
+        const double piv0 = c0[j];
+        if (j < nb && !(piv0 > 0.0))
             bad = true;
         // 1 / sqrt(pivot): hardware estimate + two Newton steps (the factor is not on a bit-parity path)
-        double rs = __builtin_amdgcn_rsq(piv);
-        rs = rs * (1.5 - 0.5 * piv * rs * rs);
-        rs = rs * (1.5 - 0.5 * piv * rs * rs);
-        double li[4], lc[4], xr[4];
+        double rs0 = __builtin_amdgcn_rsq(piv0);
+        rs0 = rs0 * (1.5 - 0.5 * piv0 * rs0 * rs0);
+        rs0 = rs0 * (1.5 - 0.5 * piv0 * rs0 * rs0);
+        double li0[4], lc0[4], xr0[4], li1[4], lc1[4], xr1[4];
 #pragma unroll
         for (int p = JB; p < 4; p++)
         {
-            const double v = colA[buf][ty + 16 * p] * rs;
-            li[p] = (p > JB || ty > jt) ? v : 0.0;
+            const double v = c0[ty + 16 * p] * rs0;
+            li0[p] = (p > JB || ty > jt) ? v : 0.0;
         }
 #pragma unroll
         for (int q = JB; q < 4; q++)
         {
-            const double v = colA[buf][tx + 16 * q] * rs;
-            lc[q] = (q > JB || tx > jt) ? v : 0.0;
+            const double v = c0[tx + 16 * q] * rs0;
+            lc0[q] = (q > JB || tx > jt) ? v : 0.0;
         }
 #pragma unroll
         for (int q = 0; q <= JB; q++)
-            xr[q] = rowX[buf][tx + 16 * q] * rs;
+            xr0[q] = r0[tx + 16 * q] * rs0;
+        // ---- pivot j + 1: its column and its row of the inverse accumulator after pivot j's update
+        const double cross = c0[j + 1] * rs0; // l_{j+1,j}
+        const double piv1 = c1[j + 1] - cross * cross;
+        if (j + 1 < nb && !(piv1 > 0.0))
+            bad = true;
+        double rs1 = __builtin_amdgcn_rsq(piv1);
+        rs1 = rs1 * (1.5 - 0.5 * piv1 * rs1 * rs1);
+        rs1 = rs1 * (1.5 - 0.5 * piv1 * rs1 * rs1);
+        double col1_own[4]; // updated column j + 1 at this thread's rows (for its owners' final values)
+#pragma unroll
+        for (int p = JB; p < 4; p++)
+        {
+            const int r = ty + 16 * p;
+            const double l0r = (p > JB || ty > jt) ? c0[r] * rs0 : 0.0;
+            const double u = c1[r] - l0r * cross;
+            col1_own[p] = u;
+            const double v = u * rs1;
+            li1[p] = (p > JB || ty > jt + 1) ? v : 0.0;
+        }
+#pragma unroll
+        for (int q = JB; q < 4; q++)
+        {
+            const int c = tx + 16 * q;
+            const double l0c = (q > JB || tx > jt) ? c0[c] * rs0 : 0.0;
+            const double v = (c1[c] - l0c * cross) * rs1;
+            lc1[q] = (q > JB || tx > jt + 1) ? v : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q <= JB; q++)
+            xr1[q] = (r1[tx + 16 * q] - cross * xr0[q]) * rs1;
+        // ---- both rank-1 updates, pivot j first
 #pragma unroll
         for (int p = JB; p < 4; p++)
         {
 #pragma unroll
             for (int q = JB; q < 4; q++)
-                a[p][q] -= li[p] * lc[q];
+            {
+                a[p][q] -= li0[p] * lc0[q];
+                a[p][q] -= li1[p] * lc1[q];
+            }
 #pragma unroll
             for (int q = 0; q <= JB; q++)
-                x[p][q] -= li[p] * xr[q];
+            {
+                x[p][q] -= li0[p] * xr0[q];
+                x[p][q] -= li1[p] * xr1[q];
+            }
         }
-        // column j becomes final (l_ij below the diagonal, sqrt(pivot) = pivot * rs on it, 0 above); row j of X too
+        // columns j, j + 1 become final (l below the diagonal, sqrt(pivot) = pivot * rs on it, 0 above); rows j, j + 1 of X too
         if (tx == jt)
 #pragma unroll
             for (int p = JB; p < 4; p++)
             {
-                const double v = colA[buf][ty + 16 * p] * rs;
+                const double v = c0[ty + 16 * p] * rs0;
                 a[p][JB] = (p > JB || ty >= jt) ? v : 0.0;
             }
+        if (tx == jt + 1)
+#pragma unroll
+            for (int p = JB; p < 4; p++)
+                a[p][JB] = (p > JB || ty >= jt + 1) ? col1_own[p] * rs1 : 0.0;
         if (ty == jt)
 #pragma unroll
             for (int q = 0; q <= JB; q++)
-                x[JB][q] = xr[q];
+                x[JB][q] = xr0[q];
+        if (ty == jt + 1)
+#pragma unroll
+            for (int q = 0; q <= JB; q++)
+                x[JB][q] = xr1[q];
     }
 }
 
 __global__ __launch_bounds__(256) void chol_diag_kernel(lm_matrix M, int n, int k0, int nb, int *fail,
                                                         double *Linv /*[NB][NB] row-major, zero padded*/)
 {
-    __shared__ double colA[2][NB], rowX[2][NB];
+    __shared__ double colA[4][NB], rowX[4][NB]; // two pivots per step, double-buffered
     const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
     double *A = M.tiles + ((size_t)M.cols[k0 / NB].first_tile << 12); // the diagonal tile
     double a[4][4], x[4][4];
@@ -321,7 +380,7 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
     constexpr int KC = 32;
     __shared__ double T[64][65];
     __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
-    __shared__ double colA[2][NB], rowX[2][NB];
+    __shared__ double colA[4][NB], rowX[4][NB]; // two pivots per step, double-buffered
     __shared__ int s_claim, s_ready;
     unsigned int *flags = sync + 4;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
