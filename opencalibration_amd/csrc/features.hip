@@ -47,6 +47,7 @@ struct nms_dev
     unsigned int *cell_id;               // [B][S]
     unsigned int *cell_start, *cell_fill; // [B][gw * gh + 1], [B][gw * gh]
     unsigned int *items;                 // [B][S] points by cell
+    double2 *item_loc;                   // [B][S] their locations, in the same order (a cell row's candidates are one run)
     unsigned char *state;                // [B][S]
 };
 
@@ -176,6 +177,7 @@ __global__ void nms_fill_kernel(nms_dev N)
     const unsigned int c = N.cell_id[o];
     const unsigned int at = N.cell_start[(size_t)b * (n_cells + 1) + c] + atomicAdd(&N.cell_fill[(size_t)b * n_cells + c], 1u);
     N.items[(size_t)b * N.S + at] = r;
+    N.item_loc[(size_t)b * N.S + at] = N.loc[o];
     N.state[o] = UNDECIDED;
 }
 
@@ -189,6 +191,7 @@ __device__ __forceinline__ unsigned char nms_decide(const nms_dev &N, unsigned i
     const int n_cells = N.gw * N.gh;
     const unsigned int *start = N.cell_start + (size_t)b * (n_cells + 1);
     const unsigned int *items = N.items + base;
+    const double2 *item_loc = N.item_loc + base;
     const double2 me = N.loc[base + r];
     const int c = (int)N.cell_id[base + r], cx = c % N.gw, cy = c / N.gw;
     bool open_near = false;
@@ -198,17 +201,17 @@ __device__ __forceinline__ unsigned char nms_decide(const nms_dev &N, unsigned i
         const unsigned int i0 = start[yy * N.gw + max(cx - 1, 0)], i1 = start[yy * N.gw + min(cx + 1, N.gw - 1) + 1];
         for (unsigned int i = i0; i < i1; i++)
         {
+            // (rank and location stream in with the run; the state - a dependent load - only for a stronger point in reach)
             const unsigned int q = items[i];
             if (q >= r)
                 continue;
+            if (!nms_within(N, me, item_loc[i]))
+                continue;
             const unsigned char sq = state_of(q);
-            if (sq == DENSE)
-                continue;
-            if (!nms_within(N, me, N.loc[base + q]))
-                continue;
             if (sq == SPARSE)
                 return DENSE;
-            open_near = true;
+            if (sq == UNDECIDED)
+                open_near = true;
         }
     }
     return open_near ? UNDECIDED : SPARSE;
@@ -425,8 +428,9 @@ int feature_lists_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>>
         M.cell_start = (unsigned int *)dev((size_t)B * (n_cells + 1) * 4);
         M.cell_fill = (unsigned int *)dev((size_t)B * n_cells * 4);
         M.items = (unsigned int *)dev(N * 4);
+        M.item_loc = (double2 *)dev(N * 16);
         M.state = (unsigned char *)dev(N);
-        alloc_ok = alloc_ok && M.cell_id && M.cell_start && M.cell_fill && M.items && M.state;
+        alloc_ok = alloc_ok && M.cell_id && M.cell_start && M.cell_fill && M.items && M.item_loc && M.state;
         return M;
     };
     F.n = (unsigned int *)dev((size_t)B * 4);
