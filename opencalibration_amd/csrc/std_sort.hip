@@ -476,6 +476,15 @@ __global__ __launch_bounds__(256) void sort_local_kernel(sort_dev S)
     }
 }
 
+// a queue overflowed (the capacities rule it out): nothing of this call is to be trusted, every segment goes to the host
+__global__ void sort_error_kernel(sort_dev S, unsigned int n_segs)
+{
+    if (*S.error == 0)
+        return;
+    for (unsigned int s = blockIdx.x * blockDim.x + threadIdx.x; s < n_segs; s += gridDim.x * blockDim.x)
+        S.fallback[s] = 1;
+}
+
 // __final_insertion_sort restricted to a range of at most 16 elements: every element moves left past the elements it is
 // strictly before
 __global__ void sort_final_kernel(sort_dev S)
@@ -568,6 +577,7 @@ int std_sort_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> *all
         hipLaunchKernelGGL(sort_local_kernel, dim3(std::min((most_local + 3) / 4, 2048u)), dim3(256), 0, st, S);
     }
     hipLaunchKernelGGL(sort_final_kernel, dim3((S.cap_final + 255) / 256), dim3(256), 0, st, S);
+    hipLaunchKernelGGL(sort_error_kernel, dim3(16), dim3(256), 0, st, S, n_segs);
     OCHIP_HIP(ctx, hipGetLastError());
     return OCHIP_OK;
 }
