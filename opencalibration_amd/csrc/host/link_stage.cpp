@@ -2,6 +2,7 @@
 #include "sort_like_std.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -207,8 +208,11 @@ static void link_cpu_add(int i, double v)
 #pragma omp atomic
     g_link_cpu[i] += v;
 }
+static std::atomic<long> g_link_batches{0}, g_link_batches_flagged{0}; // batches run, batches a device sort sent to the host route
 void link_cpu_report()
 {
+    fprintf(stderr, "[link] batches %ld, of which a device sort flagged (depth limit) and the host sorted: %ld\n", g_link_batches.load(),
+            g_link_batches_flagged.load());
     fprintf(stderr, "[link] CPU seconds: pack %.3f, ratio+sort %.3f, prosac order %.3f, pack jobs %.3f, decompose %.3f, assemble %.3f\n",
             g_link_cpu[0], g_link_cpu[1], g_link_cpu[2], g_link_cpu[3], g_link_cpu[4], g_link_cpu[5]);
 }
@@ -391,6 +395,9 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
             return fail("ochip_match_sort");
         for (size_t p = 0; p < n_pairs; p++)
             device_sorted = device_sorted && !sort_flags[p];
+        g_link_batches++;
+        if (!device_sorted)
+            g_link_batches_flagged++;
     }
     pinned<ochip_match> raw(ctx, !device_sorted && out_total ? out_total : 1);
     if (!raw.ptr)
@@ -523,6 +530,7 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
             if (sort_flags[p])
             {
                 // the PROSAC order of a pair needs libstdc++'s heap sort: the whole batch again, sorted on the host
+                g_link_batches_flagged++;
                 force_host_sort = true;
                 run_batch(graph, link_pairs, ctx, omp_threads);
                 force_host_sort = false;
