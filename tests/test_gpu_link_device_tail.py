@@ -1,0 +1,66 @@
+"""The link stage's device tail (ratio test, std::sort of the matches, PROSAC order, decompose, the edges' lists:
+csrc/match_sort.hip, std_sort.hip, ransac.hip) against the round-2 host route (OCHIP_LINK_HOST_SORT=1) on the inputs the
+synthetic surveys never produce: images with no, one, two features, identical descriptors (every Hamming count 0: no
+quality for PROSAC), a single candidate in the other image (no second neighbour), pairs with no match at all - and a
+regular scene beside them.  Both routes must build the same graph, byte for byte."""
+import numpy as np
+import pytest
+
+from opencalibration_amd import capi, host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _edge_signature(g):
+    return [(e["source"], e["dest"], e["n_matches"], e["n_inliers"], e["H"].tobytes(), e["f1"].tobytes(), e["f2"].tobytes(),
+             e["poses"].tobytes()) for e in g.edges()]
+
+
+def _graph(grid, mutate):
+    """The synthetic survey's images with some of them replaced by degenerate ones."""
+    g = host.Graph()
+    mid = g.add_model(grid.model)
+    rng = np.random.default_rng(5)
+    for i in range(grid.n_images):
+        loc, strength, desc, _ = grid.image(i)
+        loc, strength, desc = mutate(i, np.array(loc), np.array(strength), np.array(desc), rng)
+        g.add_image(loc, strength, desc, len(strength), mid, grid.position[i])
+    g.set_orientations(grid.orientation)
+    return g
+
+
+def _mutate(i, loc, strength, desc, rng):
+    if i == 0:
+        return loc[:0], strength[:0], desc[:0]                         # no features
+    if i == 1:
+        return loc[:1], strength[:1], desc[:1]                         # one feature: every query has no second neighbour
+    if i == 2:
+        return loc[:2], strength[:2], desc[:2]
+    if i == 3:
+        d = desc.copy()
+        d[:] = d[0]                                                    # identical descriptors: all distances equal
+        return loc, strength, d
+    if i == 4:
+        s = strength.copy()
+        s[:] = s[0]                                                    # identical strengths: the 40 px subset's sort is all ties
+        return loc, s, desc
+    if i == 5:
+        d = rng.integers(0, 2 ** 63, desc.shape, dtype=np.uint64)      # unrelated descriptors: (almost) nothing passes the ratio test
+        return loc, strength, d
+    return loc, strength, desc
+
+
+def test_degenerate_images_both_routes(monkeypatch):
+    grid = synth.make_grid(seed=21, rows=3, cols=4, feats=700)
+    ctx = capi.Context(0)
+    sigs = {}
+    for route in ("device", "host"):
+        if route == "host":
+            monkeypatch.setenv("OCHIP_LINK_HOST_SORT", "1")
+        g = _graph(grid, _mutate)
+        g.link(ctx)
+        sigs[route] = _edge_signature(g)
+        g.close()
+    assert sigs["device"] == sigs["host"]
+    assert len(sigs["device"]) >= 8            # the regular images still link
+    ctx.close()
