@@ -122,6 +122,7 @@ class Context:
         if rc != 0:
             raise OchipError(f"ochip_ctx_create({device}) = {rc}: {self.L.ochip_last_error(None).decode()}")
         self.h = h
+        self.device = device
 
     def close(self):
         if getattr(self, "h", None):
