@@ -328,9 +328,9 @@ __device__ void downward_prior(const double *q, double weight, double *res, doub
 }
 
 // Per-camera gather: diagonal 3x3, camera-plane 3x3, gradient; plus the prior.  One thread per camera.
-__global__ void relax_scatter_cam_kernel(relax_dev P, lm_matrix A, double *g, int n, const uint8_t *cam_has_prior)
+__device__ __forceinline__ void scatter_cam(const relax_dev &P, const lm_matrix &A, double *g, int n, const uint8_t *cam_has_prior,
+                                            uint32_t c)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= P.n_cams)
         return;
     const int tc = P.cam_t[c];
@@ -386,9 +386,8 @@ __global__ void relax_scatter_cam_kernel(relax_dev P, lm_matrix A, double *g, in
 }
 
 // Per-pair scatter of the off-diagonal camera-camera block.  One thread per pair.
-__global__ void relax_scatter_pair_kernel(relax_dev P, lm_matrix A, int n)
+__device__ __forceinline__ void scatter_pair(const relax_dev &P, const lm_matrix &A, int n, uint32_t pr)
 {
-    const uint32_t pr = blockIdx.x * blockDim.x + threadIdx.x;
     if (pr >= P.n_pairs)
         return;
     const int tp = P.cam_t[P.pair_p[pr]], tq = P.cam_t[P.pair_q[pr]];
@@ -404,6 +403,15 @@ __global__ void relax_scatter_pair_kernel(relax_dev P, lm_matrix A, int n)
             else
                 A.tiles[lm_at(A, tq + j, tp + i)] = v;
         }
+}
+
+// both in one launch: the first cam_blocks workgroups take the cameras, the others the pairs (they write disjoint entries)
+__global__ void relax_scatter_kernel(relax_dev P, lm_matrix A, double *g, int n, const uint8_t *cam_has_prior, uint32_t cam_blocks)
+{
+    if (blockIdx.x < cam_blocks)
+        scatter_cam(P, A, g, n, cam_has_prior, blockIdx.x * blockDim.x + threadIdx.x);
+    else
+        scatter_pair(P, A, n, (blockIdx.x - cam_blocks) * blockDim.x + threadIdx.x);
 }
 
 // One workgroup: plane-plane block, plane gradient, total cost (pairs + priors).  scal[0] = cost.
@@ -1048,11 +1056,10 @@ struct plane_model final : lm_model
         if (with_jac)
         {
             OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, p->sys.matrix_bytes(), st));
-            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.g, 0, (size_t)n * 8, st));
-            hipLaunchKernelGGL(relax_scatter_cam_kernel, dim3((D.n_cams + 255) / 256), dim3(256), 0, st, D, p->sys.matA(), p->sys.g,
-                               n, p->cam_has_prior);
-            if (D.n_pairs)
-                hipLaunchKernelGGL(relax_scatter_pair_kernel, dim3((D.n_pairs + 255) / 256), dim3(256), 0, st, D, p->sys.matA(), n);
+            // (J'r needs no clearing: every unknown belongs to an active camera or a free plane height, whose owners write it)
+            const uint32_t cam_blocks = (D.n_cams + 255) / 256, pair_blocks = (D.n_pairs + 255) / 256;
+            hipLaunchKernelGGL(relax_scatter_kernel, dim3(cam_blocks + pair_blocks), dim3(256), 0, st, D, p->sys.matA(), p->sys.g, n,
+                               p->cam_has_prior, cam_blocks);
         }
         hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(1), dim3(256), 0, st, D, p->sys.matA(), p->sys.g, n, p->cam_has_prior,
                            p->sys.scal, with_jac ? 1 : 0, which);

@@ -25,8 +25,20 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // Wm = S A S + diag(D) tile by tile (one workgroup per stored tile), row n = gs = S g; the part of a diagonal tile above
 // the diagonal and everything beyond the system's last row / column is written as zero
 __global__ __launch_bounds__(256) void lm_build_kernel(lm_matrix A, const unsigned int *__restrict__ tile_ij, const double *g,
-                                                       const double *scale, const double *lm_diag, lm_matrix W, double *gs, int n)
+                                                       const double *scale, const double *lm_diag, lm_matrix W, double *gs, int n,
+                                                       unsigned int *chol_sync, int *fail_chol)
 {
+    // (the factorisation's claim counter, its per-tile flags and the failure flag start at zero: cleared here, one launch
+    // instead of three in front of every factorisation)
+    if (threadIdx.x == 0)
+    {
+        chol_sync[4 + blockIdx.x] = 0u;
+        if (blockIdx.x == 0)
+        {
+            chol_sync[0] = chol_sync[1] = chol_sync[2] = chol_sync[3] = 0u;
+            *fail_chol = 0;
+        }
+    }
     const unsigned int ij = tile_ij[blockIdx.x];
     const int I = (int)(ij & 0xFFFFu), J = (int)(ij >> 16);
     const double *a = A.tiles + ((size_t)blockIdx.x << 12);
@@ -592,9 +604,11 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
 // (first_blk[k]: the first column block whose envelope reaches row block k; everything for the tail rows).  The 94 launches this took per solve cost 1.0 ms, the
 // walk over the envelope takes a tenth of that.
 __global__ __launch_bounds__(1024) void back_solve_kernel(lm_matrix Lm, int n, const double *Linv, double *x,
-                                                          const int *first_blk, int n_blocks)
+                                                          const int *first_blk, int n_blocks, const double *lm_diag,
+                                                          const double *gs, double *scal)
 {
     __shared__ double xb[NB];
+    __shared__ double sh[1024];
     const int t = threadIdx.x;
     const double *L = Lm.tiles;
     for (int i = t; i < n; i += 1024) // y = L^-1 gs: the augmented row
@@ -647,6 +661,21 @@ __global__ __launch_bounds__(1024) void back_solve_kernel(lm_matrix Lm, int n, c
             x[i] -= u;
         }
     }
+    // model_cost_change (lm_model_change_kernel's sum, same order) on the way out: one launch less per iteration
+    __syncthreads();
+    double part = 0;
+    for (int i = t; i < n; i += 1024)
+        part += x[i] * gs[i] + lm_diag[i] * x[i] * x[i];
+    sh[t] = part;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1)
+    {
+        if (t < s)
+            sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    if (t == 0)
+        scal[1] = 0.5 * sh[0];
 }
 
 
@@ -1096,8 +1125,10 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         ochip_prof_begin(ctx, OCHIP_K_RELAX_SOLVE, &e0, &e1);
         if (n > 0)
             hipLaunchKernelGGL(lm_build_kernel, dim3((unsigned)S.chol_n_tiles), dim3(256), 0, st, S.matA(), (const unsigned int *)S.tile_ij,
-                               (const double *)S.g, (const double *)S.scale, (const double *)S.lm_diag, S.matW(), S.gs, n);
-        OCHIP_HIP(ctx, hipMemsetAsync(S.fail_chol, 0, 4, st));
+                               (const double *)S.g, (const double *)S.scale, (const double *)S.lm_diag, S.matW(), S.gs, n, S.chol_sync,
+                               S.fail_chol);
+        else
+            OCHIP_HIP(ctx, hipMemsetAsync(S.fail_chol, 0, 4, st));
         if (eliminated)
             M.launch_schur(radius, S.scale, S.matW(), n, S.fail_chol);
         {
@@ -1155,7 +1186,6 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                     return ochip_fail(ctx, OCHIP_ENOMEM, "OCHIP_CHOL_VERIFY: device allocation failed");
                 OCHIP_HIP(ctx, hipMemcpyAsync(Wv, S.Wm, S.matrix_bytes(), hipMemcpyDeviceToDevice, st));
             }
-            OCHIP_HIP(ctx, hipMemsetAsync(S.chol_sync, 0, S.chol_sync_bytes, st));
             hipLaunchKernelGGL(chol_tiles_kernel, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
                                (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_tiles, S.chol_tb, S.chol_sync, S.linv,
                                S.fail_chol);
@@ -1191,9 +1221,10 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         if (n > 0)
         {
             hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, st, S.matW(), n, (const double *)S.linv, S.y,
-                               (const int *)S.chol_kmin, (n + NB - 1) / NB);
+                               (const int *)S.chol_kmin, (n + NB - 1) / NB, (const double *)S.lm_diag, (const double *)S.gs, S.scal);
         }
-        hipLaunchKernelGGL(lm_model_change_kernel, dim3(1), dim3(1024), 0, st, S.lm_diag, S.gs, S.y, n, S.scal);
+        else
+            hipLaunchKernelGGL(lm_model_change_kernel, dim3(1), dim3(1024), 0, st, S.lm_diag, S.gs, S.y, n, S.scal);
         M.launch_candidate(S.y, S.scale, 1.0, S.scal);
         ochip_prof_end(ctx, OCHIP_K_RELAX_SOLVE, e0, e1);
         OCHIP_HIP(ctx, hipGetLastError());
