@@ -1068,6 +1068,8 @@ struct plane_model final : lm_model
         OCHIP_HIP(ctx, hipMemcpyAsync(&h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
         std::vector<int32_t> hfails(p->shard_world, 0);
         OCHIP_HIP(ctx, hipMemcpyAsync(hfails.data(), p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
+        if (before_wait)
+            before_wait();
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         *cost = h0;
         int hfail = 0;

@@ -1213,6 +1213,8 @@ struct general_model final : lm_model
         std::vector<int32_t> hfails(p->shard_world, 0);
         OCHIP_HIP(ctx, hipMemcpyAsync(&h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, hipMemcpyAsync(hfails.data(), p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
+        if (before_wait)
+            before_wait();
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         *cost = h0;
         int hfail = 0;

@@ -1228,10 +1228,32 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         M.launch_candidate(S.y, S.scale, 1.0, S.scal);
         ochip_prof_end(ctx, OCHIP_K_RELAX_SOLVE, e0, e1);
         OCHIP_HIP(ctx, hipGetLastError());
+        // The candidate is evaluated right away (cost only): the step's own results - model cost change, step norms, the
+        // factorisation's failure flag - come back with that evaluation's wait instead of a host round trip of their own.
+        // An invalid step (rare) has then cost one evaluation whose result is ignored.
+        static const bool separate_waits = getenv("OCHIP_LM_SEPARATE_WAITS") != nullptr; // A/B knob: a wait per read-back
         int cfail = 0;
-        OCHIP_HIP(ctx, hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(&cfail, S.fail_chol, 4, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+        double cand_eval = 0;
+        auto read_step = [&]() {
+            (void)hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st);
+            (void)hipMemcpyAsync(&cfail, S.fail_chol, 4, hipMemcpyDeviceToHost, st);
+        };
+        if (separate_waits)
+        {
+            read_step();
+            OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+            erc = 1;
+            if (!cfail && std::isfinite(h[1]) && h[1] > 0.0)
+                erc = M.evaluate(false, 1, &cand_eval);
+        }
+        else
+        {
+            M.before_wait = read_step;
+            erc = M.evaluate(false, 1, &cand_eval);
+            M.before_wait = nullptr;
+        }
+        if (erc < 0)
+            return erc;
         reuse_diagonal = true;
         const double model_cost_change = h[1];
         const bool valid = !cfail && std::isfinite(model_cost_change) && model_cost_change > 0.0;
@@ -1247,15 +1269,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             continue;
         }
         invalid = 0;
-        double cand_cost = 1.7976931348623157e308;
-        {
-            double c;
-            erc = M.evaluate(false, 1, &c);
-            if (erc < 0)
-                return erc;
-            if (erc == 0)
-                cand_cost = c;
-        }
+        double cand_cost = erc == 0 ? cand_eval : 1.7976931348623157e308;
         double step_norm = std::sqrt(h[2]), cand_norm = std::sqrt(h[3]);
         if (M.is_constrained())
         {
@@ -1374,15 +1388,35 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         {
             M.launch_accept();
             x_norm = cand_norm;
+            // (the gradient norm and the diagonal of the new J'J ride on the evaluation's wait)
+            auto read_gradient = [&]() {
+                hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(1024), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal);
+                (void)hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st);
+                if (n > 0)
+                    (void)hipMemcpyAsync(diag.data(), S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost, st);
+            };
+            if (!separate_waits)
+                M.before_wait = read_gradient;
             erc = M.evaluate(true, 0, &x_cost);
+            M.before_wait = nullptr;
             if (erc < 0)
                 return erc;
             if (erc != 0)
                 return finish(OCHIP_RELAX_FAILURE);
-            rc = grad_and_diag(&gmax);
-            if (rc)
-                return rc;
-            OCHIP_HIP(ctx, hipMemcpy(diag.data(), S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost));
+            if (separate_waits)
+            {
+                read_gradient();
+                OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+            }
+            gmax = h[4];
+            if (eliminated)
+            {
+                double extra = 0;
+                const int xrc = M.gradient_max_extra(&extra);
+                if (xrc)
+                    return xrc;
+                gmax = std::max(gmax, extra);
+            }
             const double t = 2.0 * rho - 1.0;
             radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
             radius = std::min(1e16, radius);

@@ -10,6 +10,7 @@
 
 #include "ctx.hpp"
 
+#include <functional>
 #include <vector>
 
 namespace ochip
@@ -104,6 +105,10 @@ struct lm_model
     // packed lower triangle, zeros included: hipMemsetAsync(sys.A, 0, sys.matrix_bytes()) first) and sys.g.  *cost = total cost.  Returns 0, 1 for a numeric failure (non-finite residual or derivative:
     // Ceres' "evaluation failed"), or a negative OCHIP_E* code for a hard error (HIP call, exchange) which ends the solve.
     virtual int evaluate(bool with_jac, int which, double *cost) = 0;
+    // set by the solver around an evaluate() call: called by evaluate once everything of the evaluation is enqueued, right
+    // before it waits for the stream - the solver's own reads (step quality, gradient norm, diagonal) then share that wait
+    // instead of adding host round trips of their own to every iteration
+    std::function<void()> before_wait;
     // enqueue: candidate = x (+) delta with delta[i] = alpha * (-y[i] * scale[i]); scal[2] = |x - candidate|^2 (ambient),
     // scal[3] = |candidate|^2 over the variable parameter blocks.  alpha = 1 except inside the projected line search of a
     // bounds-constrained problem.

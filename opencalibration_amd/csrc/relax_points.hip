@@ -841,6 +841,8 @@ struct points_model final : lm_model
         int32_t hfail = 0;
         OCHIP_HIP(ctx, hipMemcpyAsync(&h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, hipMemcpyAsync(&hfail, D.fail, 4, hipMemcpyDeviceToHost, st));
+        if (before_wait)
+            before_wait();
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         *cost = h0;
         return hfail ? 1 : 0;
