@@ -483,13 +483,13 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
 
 // step = -y with (As + D) y = gs; delta = S step; candidate state = x (+) delta; step_norm^2 in ambient space.
 // One workgroup.  scal: [2] step_norm^2, [3] x_norm^2 (candidate)
-__global__ __launch_bounds__(1024) void plane_candidate_kernel(relax_dev P, const double *scale, const double *y, double alpha, double *scal)
+__global__ __launch_bounds__(LM_TG) void plane_candidate_kernel(relax_dev P, const double *scale, const double *y, double alpha, double *scal)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
     // candidate state
     double sn = 0, xn = 0;
-    for (uint32_t c = t; c < P.n_cams; c += 1024)
+    for (uint32_t c = t; c < P.n_cams; c += LM_TG)
     {
         const int tc = P.cam_t[c];
         const double *q = P.cam_q + (size_t)c * 4;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(1024) void plane_candidate_kernel(relax_dev P, cons
     {
         sh[t] = q == 0 ? sn : xn;
         __syncthreads();
-        for (int s = 512; s > 0; s >>= 1)
+        for (int s = LM_TG / 2; s > 0; s >>= 1)
         {
             if (t < s)
                 sh[t] += sh[t + s];
@@ -1079,7 +1079,7 @@ struct plane_model final : lm_model
     }
     void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override
     {
-        hipLaunchKernelGGL(plane_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, alpha, scal);
+        hipLaunchKernelGGL(plane_candidate_kernel, dim3(1), dim3(LM_TG), 0, p->ctx->stream, p->dev, scale, y, alpha, scal);
     }
     void launch_accept() override
     {

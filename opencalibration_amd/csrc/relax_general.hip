@@ -516,19 +516,19 @@ __global__ void prior_kernel(g_dev P, int which, int with_jac)
 // [prior_base, prior_base + n_prior) are walked relative to their own starts, so the order of the additions does not
 // depend on the padding a sharded problem puts between the two (sharded and unsharded solves add the same numbers in the
 // same order)
-__global__ __launch_bounds__(1024) void cost_reduce_kernel(const double *rec_cost, uint32_t n_ray, uint32_t prior_base, uint32_t n_prior,
+__global__ __launch_bounds__(LM_TG) void cost_reduce_kernel(const double *rec_cost, uint32_t n_ray, uint32_t prior_base, uint32_t n_prior,
                                                            double *scal)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
     double v = 0;
-    for (uint32_t i = t; i < n_ray; i += 1024)
+    for (uint32_t i = t; i < n_ray; i += LM_TG)
         v += rec_cost[i];
-    for (uint32_t i = t; i < n_prior; i += 1024)
+    for (uint32_t i = t; i < n_prior; i += LM_TG)
         v += rec_cost[prior_base + i];
     sh[t] = v;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1)
+    for (int s = LM_TG / 2; s > 0; s >>= 1)
     {
         if (t < s)
             sh[t] += sh[t + s];
@@ -729,12 +729,12 @@ __global__ void tail_merge_kernel(g_dev P, const uint32_t *tail_var, const uint3
 
 // ---- state -------------------------------------------------------------------------------------------------------
 // candidate = x (+) delta, delta = -y .* scale.  One workgroup.  scal[2] = |x - candidate|^2, scal[3] = |candidate|^2
-__global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const double *scale, const double *y, double alpha, double *scal)
+__global__ __launch_bounds__(LM_TG) void general_candidate_kernel(g_dev P, const double *scale, const double *y, double alpha, double *scal)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
     double sn = 0, xn = 0;
-    for (uint32_t c = t; c < P.n_cams; c += 1024)
+    for (uint32_t c = t; c < P.n_cams; c += LM_TG)
     {
         const int tc = P.var_t[c];
         const double *q = P.cam_q + (size_t)c * 4;
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const 
             xn += o[k] * o[k];
         }
     }
-    for (uint32_t v = t; v < P.n_verts; v += 1024)
+    for (uint32_t v = t; v < P.n_verts; v += LM_TG)
     {
         const int tz = P.var_t[P.n_cams + v];
         const double z0 = P.vert_z[v];
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(1024) void general_candidate_kernel(g_dev P, const 
     {
         sh[t] = q == 0 ? sn : xn;
         __syncthreads();
-        for (int s = 512; s > 0; s >>= 1)
+        for (int s = LM_TG / 2; s > 0; s >>= 1)
         {
             if (t < s)
                 sh[t] += sh[t + s];
@@ -1207,7 +1207,7 @@ struct general_model final : lm_model
                 hipLaunchKernelGGL(tail_merge_kernel, dim3(p->n_tail_owners), dim3(256), 0, st, D, p->tail_var_dev, p->tail_first_dev,
                                    p->tail_count_dev, p->partials_dev, p->sys.matA(), p->sys.g, n, p->tail_begin);
         }
-        hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(1024), 0, st, D.rec_cost, p->n_blocks, D.prior_base, n_prior, p->sys.scal);
+        hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(LM_TG), 0, st, D.rec_cost, p->n_blocks, D.prior_base, n_prior, p->sys.scal);
         OCHIP_HIP(ctx, hipGetLastError());
         double h0 = 0;
         std::vector<int32_t> hfails(p->shard_world, 0);
@@ -1224,7 +1224,7 @@ struct general_model final : lm_model
     }
     void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override
     {
-        hipLaunchKernelGGL(general_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, alpha, scal);
+        hipLaunchKernelGGL(general_candidate_kernel, dim3(1), dim3(LM_TG), 0, p->ctx->stream, p->dev, scale, y, alpha, scal);
     }
     void launch_accept() override
     {

@@ -603,15 +603,15 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
 // inverse, then y_i -= sum_m L[k0+m][i] x[k0+m] for the columns i < k0 in which the rows of the block can be non-zero
 // (first_blk[k]: the first column block whose envelope reaches row block k; everything for the tail rows).  The 94 launches this took per solve cost 1.0 ms, the
 // walk over the envelope takes a tenth of that.
-__global__ __launch_bounds__(1024) void back_solve_kernel(lm_matrix Lm, int n, const double *Linv, double *x,
+__global__ __launch_bounds__(LM_TG) void back_solve_kernel(lm_matrix Lm, int n, const double *Linv, double *x,
                                                           const int *first_blk, int n_blocks, const double *lm_diag,
                                                           const double *gs, double *scal)
 {
     __shared__ double xb[NB];
-    __shared__ double sh[1024];
+    __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
     const double *L = Lm.tiles;
-    for (int i = t; i < n; i += 1024) // y = L^-1 gs: the augmented row
+    for (int i = t; i < n; i += LM_TG) // y = L^-1 gs: the augmented row
         x[i] = L[lm_at(Lm, n, i)];
     for (int k = n_blocks - 1; k >= 0; k--)
     {
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(1024) void back_solve_kernel(lm_matrix Lm, int n, c
             x[k0 + t] = s;
         }
         __syncthreads();
-        for (int i = first_blk[k] * NB + t; i < k0; i += 1024)
+        for (int i = first_blk[k] * NB + t; i < k0; i += LM_TG)
         {
             const double *Lc = L + ((size_t)lm_tile_index(Lm.cols, k, i >> 6) << 12) + (i & 63); // column i of tile (k, i / 64)
             double u = 0;
@@ -664,11 +664,11 @@ __global__ __launch_bounds__(1024) void back_solve_kernel(lm_matrix Lm, int n, c
     // model_cost_change (lm_model_change_kernel's sum, same order) on the way out: one launch less per iteration
     __syncthreads();
     double part = 0;
-    for (int i = t; i < n; i += 1024)
+    for (int i = t; i < n; i += LM_TG)
         part += x[i] * gs[i] + lm_diag[i] * x[i] * x[i];
     sh[t] = part;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1)
+    for (int s = LM_TG / 2; s > 0; s >>= 1)
     {
         if (t < s)
             sh[t] += sh[t + s];
@@ -681,17 +681,17 @@ __global__ __launch_bounds__(1024) void back_solve_kernel(lm_matrix Lm, int n, c
 
 // model_cost_change = -(step.gs + step' As step / 2) with step = -y, (As + D) y = gs
 //                   = y.gs - (y.gs - y'D y) / 2 = (y.gs + sum D_i y_i^2) / 2 by the normal equations (no n^2 product).
-__global__ __launch_bounds__(1024) void lm_model_change_kernel(const double *lm_diag, const double *gs, const double *y, int n,
+__global__ __launch_bounds__(LM_TG) void lm_model_change_kernel(const double *lm_diag, const double *gs, const double *y, int n,
                                                                 double *scal)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
     double part = 0;
-    for (int i = t; i < n; i += 1024)
+    for (int i = t; i < n; i += LM_TG)
         part += y[i] * gs[i] + lm_diag[i] * y[i] * y[i];
     sh[t] = part;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1)
+    for (int s = LM_TG / 2; s > 0; s >>= 1)
     {
         if (t < s)
             sh[t] += sh[t + s];
@@ -702,20 +702,20 @@ __global__ __launch_bounds__(1024) void lm_model_change_kernel(const double *lm_
 }
 
 // diag(A) and max|g| -> scal[4] = max|g|; diag_out[i] = A_ii
-__global__ __launch_bounds__(1024) void lm_diag_kernel(lm_matrix A, const double *g, double *diag_out, int n,
+__global__ __launch_bounds__(LM_TG) void lm_diag_kernel(lm_matrix A, const double *g, double *diag_out, int n,
                                                        double *scal)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
     double m = 0;
-    for (int i = t; i < n; i += 1024)
+    for (int i = t; i < n; i += LM_TG)
     {
         diag_out[i] = A.tiles[lm_at(A, i, i)];
         m = fmax(m, fabs(g[i]));
     }
     sh[t] = m;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1)
+    for (int s = LM_TG / 2; s > 0; s >>= 1)
     {
         if (t < s)
             sh[t] = fmax(sh[t], sh[t + s]);
@@ -1049,7 +1049,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
     const bool eliminated = M.has_eliminated();
     M.begin_solve();
     auto grad_and_diag = [&](double *gmax) -> int {
-        hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(1024), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal);
+        hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(LM_TG), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal);
         OCHIP_HIP(ctx, hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         *gmax = h[4];
@@ -1220,11 +1220,11 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         // row n now holds y = L^-1 gs; back-substitute L' x = y block by block
         if (n > 0)
         {
-            hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(1024), 0, st, S.matW(), n, (const double *)S.linv, S.y,
+            hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(LM_TG), 0, st, S.matW(), n, (const double *)S.linv, S.y,
                                (const int *)S.chol_kmin, (n + NB - 1) / NB, (const double *)S.lm_diag, (const double *)S.gs, S.scal);
         }
         else
-            hipLaunchKernelGGL(lm_model_change_kernel, dim3(1), dim3(1024), 0, st, S.lm_diag, S.gs, S.y, n, S.scal);
+            hipLaunchKernelGGL(lm_model_change_kernel, dim3(1), dim3(LM_TG), 0, st, S.lm_diag, S.gs, S.y, n, S.scal);
         M.launch_candidate(S.y, S.scale, 1.0, S.scal);
         ochip_prof_end(ctx, OCHIP_K_RELAX_SOLVE, e0, e1);
         OCHIP_HIP(ctx, hipGetLastError());
@@ -1390,7 +1390,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             x_norm = cand_norm;
             // (the gradient norm and the diagonal of the new J'J ride on the evaluation's wait)
             auto read_gradient = [&]() {
-                hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(1024), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal);
+                hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(LM_TG), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal);
                 (void)hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st);
                 if (n > 0)
                     (void)hipMemcpyAsync(diag.data(), S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost, st);

@@ -17,6 +17,10 @@ namespace ochip
 {
 
 constexpr int LM_NB = 64; // block size of the Cholesky factorisation (a 64 x 64 diagonal block per workgroup)
+// threads of the single-workgroup kernels of a solve (reductions, the back substitution, the candidate step).  They were
+// 1 024 until round 3: such a workgroup needs sixteen free wave slots on ONE compute unit, and beside the extraction's
+// kernels it waited up to 17 ms for them (rocprofv3: back_solve_kernel 0.57 ms on average in the pipeline, 0.17 alone)
+constexpr int LM_TG = 256;
 
 // Block envelope of the reduced system (unknowns numbered so that coupled unknowns are close): per 64-column block the
 // end of the rows that can be non-zero below it, the first row of the dense tail (unknowns coupled to everything: plane

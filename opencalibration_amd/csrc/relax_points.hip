@@ -491,19 +491,19 @@ __global__ void mono_apply_kernel(p_dev P, lm_matrix A, double *g, int n)
 }
 
 // total cost (fixed order), and the largest |g| over the point columns -> scal[0], scal[5]
-__global__ __launch_bounds__(1024) void p_reduce_kernel(p_dev P, int with_gmax, double *scal)
+__global__ __launch_bounds__(LM_TG) void p_reduce_kernel(p_dev P, int with_gmax, double *scal)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
     double v = 0, m = 0;
-    for (uint32_t i = t; i < P.n_obs; i += 1024)
+    for (uint32_t i = t; i < P.n_obs; i += LM_TG)
         v += P.obs_cost[i];
     if (with_gmax)
-        for (uint32_t i = t; i < 3 * P.n_points; i += 1024)
+        for (uint32_t i = t; i < 3 * P.n_points; i += LM_TG)
             m = fmax(m, fabs(P.pt_g[i]));
     sh[t] = v;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1)
+    for (int s = LM_TG / 2; s > 0; s >>= 1)
     {
         if (t < s)
             sh[t] += sh[t + s];
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(1024) void p_reduce_kernel(p_dev P, int with_gmax, 
     __syncthreads();
     sh[t] = m;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1)
+    for (int s = LM_TG / 2; s > 0; s >>= 1)
     {
         if (t < s)
             sh[t] = fmax(sh[t], sh[t + s]);
@@ -530,13 +530,13 @@ __global__ __launch_bounds__(1024) void p_reduce_kernel(p_dev P, int with_gmax, 
 // candidate = x (+) alpha * delta: cameras and lens model from the reduced solution (delta = -y .* scale), the points by
 // back-substitution dp = -Vinv (S g_p - W' y) in scaled unknowns.  One workgroup.  scal[1] += the points' share of the
 // model cost change (alpha = 1), scal[2] = |x - candidate|^2, scal[3] = |candidate|^2, scal[6] = g_p . d_p (slope)
-__global__ __launch_bounds__(1024) void p_candidate_kernel(p_dev P, const double *scale, const double *y, double alpha, double radius,
+__global__ __launch_bounds__(LM_TG) void p_candidate_kernel(p_dev P, const double *scale, const double *y, double alpha, double radius,
                                                            int fresh, double *scal)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
     double sn = 0, xn = 0, mc = 0, slope = 0;
-    for (uint32_t c = t; c < P.n_cams; c += 1024)
+    for (uint32_t c = t; c < P.n_cams; c += LM_TG)
     {
         const int tc = P.cam_t[c];
         const double *q = P.cam_q + (size_t)c * 4;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(1024) void p_candidate_kernel(p_dev P, const double
             }
         }
     }
-    for (uint32_t p = t; p < P.n_points && !fresh; p += 1024)
+    for (uint32_t p = t; p < P.n_points && !fresh; p += LM_TG)
         for (int a = 0; a < 3; a++)
         {
             const double x0 = P.X[3 * (size_t)p + a], x1 = x0 + alpha * P.pt_d[3 * (size_t)p + a];
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(1024) void p_candidate_kernel(p_dev P, const double
             sn += (x0 - x1) * (x0 - x1);
             xn += x1 * x1;
         }
-    for (uint32_t p = t; p < P.n_points && fresh; p += 1024)
+    for (uint32_t p = t; p < P.n_points && fresh; p += LM_TG)
     {
         const uint32_t g = P.pt_group[p];
         const double *Sp = P.pt_scale + 3 * (size_t)p, *Vi = P.pt_Vinv + 6 * (size_t)p, *V = P.pt_V + 6 * (size_t)p;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(1024) void p_candidate_kernel(p_dev P, const double
     {
         sh[t] = part[q];
         __syncthreads();
-        for (int s = 512; s > 0; s >>= 1)
+        for (int s = LM_TG / 2; s > 0; s >>= 1)
         {
             if (t < s)
                 sh[t] += sh[t + s];
@@ -670,16 +670,16 @@ __global__ __launch_bounds__(1024) void p_candidate_kernel(p_dev P, const double
 }
 
 // g_p . d_p with the gradient of the last evaluated Jacobian and the stored full step (line search slopes)
-__global__ __launch_bounds__(1024) void p_slope_kernel(p_dev P, double *scal)
+__global__ __launch_bounds__(LM_TG) void p_slope_kernel(p_dev P, double *scal)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
     double v = 0;
-    for (uint32_t i = t; i < 3 * P.n_points; i += 1024)
+    for (uint32_t i = t; i < 3 * P.n_points; i += LM_TG)
         v += P.pt_g[i] * P.pt_d[i];
     sh[t] = v;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1)
+    for (int s = LM_TG / 2; s > 0; s >>= 1)
     {
         if (t < s)
             sh[t] += sh[t + s];
@@ -835,7 +835,7 @@ struct points_model final : lm_model
             }
         }
         ochip_prof_end(ctx, OCHIP_K_RELAX_EVAL, e0, e1);
-        hipLaunchKernelGGL(p_reduce_kernel, dim3(1), dim3(1024), 0, st, D, with_jac ? 1 : 0, p->sys.scal);
+        hipLaunchKernelGGL(p_reduce_kernel, dim3(1), dim3(LM_TG), 0, st, D, with_jac ? 1 : 0, p->sys.scal);
         OCHIP_HIP(ctx, hipGetLastError());
         double h0 = 0;
         int32_t hfail = 0;
@@ -875,7 +875,7 @@ struct points_model final : lm_model
     {
         // the first call after a solve back-substitutes the points (and keeps their full step); the line search's later calls
         // rescale that step - by then the kept Jacobians may be those of a trial point
-        hipLaunchKernelGGL(p_candidate_kernel, dim3(1), dim3(1024), 0, p->ctx->stream, p->dev, scale, y, alpha, radius_now,
+        hipLaunchKernelGGL(p_candidate_kernel, dim3(1), dim3(LM_TG), 0, p->ctx->stream, p->dev, scale, y, alpha, radius_now,
                            step_fresh ? 1 : 0, scal);
         step_fresh = false;
     }
@@ -885,7 +885,7 @@ struct points_model final : lm_model
         // gradient of the Jacobian evaluated last
         ochip_ctx *ctx = p->ctx;
         if (!from_candidate)
-            hipLaunchKernelGGL(p_slope_kernel, dim3(1), dim3(1024), 0, ctx->stream, p->dev, p->sys.scal);
+            hipLaunchKernelGGL(p_slope_kernel, dim3(1), dim3(LM_TG), 0, ctx->stream, p->dev, p->sys.scal);
         double v = 0;
         OCHIP_HIP(ctx, hipMemcpyAsync(&v, p->sys.scal + 6, 8, hipMemcpyDeviceToHost, ctx->stream));
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
