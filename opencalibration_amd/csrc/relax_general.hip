@@ -512,18 +512,40 @@ __global__ void prior_kernel(g_dev P, int which, int with_jac)
         atomicOr(P.fail, 1);
 }
 
-// total cost: fixed-order strided sums + tree, one workgroup.  scal[0] = cost.  The ray blocks [0, n_ray) and the priors
+// total cost in two levels, both in a fixed order: a workgroup per slice of COST_SLICE ray-block costs (strided sums + tree),
+// then one workgroup over the slices' sums and the priors.  scal[0] = cost.  The ray blocks [0, n_ray) and the priors
 // [prior_base, prior_base + n_prior) are walked relative to their own starts, so the order of the additions does not
 // depend on the padding a sharded problem puts between the two (sharded and unsharded solves add the same numbers in the
-// same order)
-__global__ __launch_bounds__(LM_TG) void cost_reduce_kernel(const double *rec_cost, uint32_t n_ray, uint32_t prior_base, uint32_t n_prior,
-                                                           double *scal)
+// same order).  (One workgroup over 650 k costs took 0.2 ms with 1 024 threads and 0.75 ms with 256: the largest kernel
+// of a mesh relax's iteration.)
+constexpr uint32_t COST_SLICE = 4096;
+__global__ __launch_bounds__(LM_TG) void cost_slices_kernel(const double *rec_cost, uint32_t n_ray, double *slice_sum)
+{
+    __shared__ double sh[LM_TG];
+    const int t = threadIdx.x;
+    const uint32_t lo = blockIdx.x * COST_SLICE, hi = min(lo + COST_SLICE, n_ray);
+    double v = 0;
+    for (uint32_t i = lo + t; i < hi; i += LM_TG)
+        v += rec_cost[i];
+    sh[t] = v;
+    __syncthreads();
+    for (int s = LM_TG / 2; s > 0; s >>= 1)
+    {
+        if (t < s)
+            sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    if (t == 0)
+        slice_sum[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(LM_TG) void cost_reduce_kernel(const double *rec_cost, const double *slice_sum, uint32_t n_slices,
+                                                           uint32_t prior_base, uint32_t n_prior, double *scal)
 {
     __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
     double v = 0;
-    for (uint32_t i = t; i < n_ray; i += LM_TG)
-        v += rec_cost[i];
+    for (uint32_t i = t; i < n_slices; i += LM_TG)
+        v += slice_sum[i];
     for (uint32_t i = t; i < n_prior; i += LM_TG)
         v += rec_cost[prior_base + i];
     sh[t] = v;
@@ -546,11 +568,12 @@ struct work_item
     int32_t col_lo;    // band strip = columns [col_lo, col_hi)  (tail owners: empty)
     int32_t col_hi;
     int32_t partial;   // >= 0: store the strip as partial #partial of a tail owner (tail columns only)
+    int64_t band_off;  // >= 0: a chunk of a band owner with many records: the whole strip goes to band_partials + band_off
 };
 
 // One wavefront per work item.  strip[a][x]: a < rows of the owner, x over [band strip | tail | gradient].
 __global__ __launch_bounds__(W) void gather_kernel(g_dev P, const work_item *items, const uint32_t *var_rec, lm_matrix A, double *g,
-                                                   int n, int tail_begin, double *partials, int strip_cap)
+                                                   int n, int tail_begin, double *partials, int strip_cap, double *band_partials)
 {
     extern __shared__ double strip[];
     __shared__ int16_t colmap[W][24];
@@ -682,6 +705,14 @@ __global__ __launch_bounds__(W) void gather_kernel(g_dev P, const work_item *ite
         }
         __syncthreads();
     }
+    if (it.band_off >= 0)
+    {
+        // a chunk of a band owner: the strip as it is, merged with the owner's other chunks by band_merge_kernel
+        double *o = band_partials + it.band_off;
+        for (int i = lane; i < su * ws; i += W)
+            o[i] = strip[i];
+        return;
+    }
     if (it.partial >= 0)
     {
         // tail owner: its tail columns and gradient go to the partial buffer [partial][su][T + 1]
@@ -724,6 +755,38 @@ __global__ void tail_merge_kernel(g_dev P, const uint32_t *tail_var, const uint3
             g[tu + a] = v;
         else if (tail_begin + x <= tu + a)
             A.tiles[lm_at(A, tu + a, tail_begin + x)] = v;
+    }
+}
+
+// band owners with many records (cameras of a large group, well-observed vertices) are cut into chunks like the tail
+// owners - a wavefront per chunk instead of one wavefront walking thousands of records - and their strips are added here
+// in chunk order (fixed, so the sums stay reproducible).  One workgroup per such owner.
+struct band_owner
+{
+    uint32_t var;
+    int32_t col_lo, col_hi;
+    uint32_t chunks;
+    int64_t first_off; // of its first chunk's strip in band_partials; the chunks follow each other
+};
+__global__ void band_merge_kernel(g_dev P, const band_owner *owners, const double *band_partials, lm_matrix A, double *g, int n,
+                                  int tail_begin)
+{
+    const band_owner bo = owners[blockIdx.x];
+    const int tu = P.var_t[bo.var], su = P.var_ts[bo.var];
+    const int T = n - tail_begin, wb = bo.col_hi - bo.col_lo, ws = wb + T + 1;
+    const size_t stride = (size_t)su * ws;
+    for (int i = threadIdx.x; i < su * ws; i += blockDim.x)
+    {
+        const int a = i / ws, x = i % ws, r = tu + a;
+        double v = 0;
+        for (uint32_t c = 0; c < bo.chunks; c++)
+            v += band_partials[bo.first_off + (int64_t)(c * stride) + i];
+        if (x == ws - 1)
+            g[r] = v;
+        else if (x >= wb)
+            A.tiles[lm_at(A, tail_begin + (x - wb), r)] = v; // the tail rows' band part, mirrored
+        else if (bo.col_lo + x <= r)
+            A.tiles[lm_at(A, r, bo.col_lo + x)] = v;
     }
 }
 
@@ -883,7 +946,9 @@ struct ochip_relaxg_problem
     };
     std::vector<type_range> ranges;
     // assembly plan (rebuilt by assign)
-    uint32_t n_items = 0, n_tail_owners = 0, n_partials = 0;
+    uint32_t n_items = 0, n_tail_owners = 0, n_partials = 0, n_band_owners = 0;
+    band_owner *band_owners_dev = nullptr;
+    double *band_partials_dev = nullptr, *cost_slices_dev = nullptr;
     int max_strip = 0;
     work_item *items_dev = nullptr;
     uint32_t *var_rec_dev = nullptr, *tail_var_dev = nullptr, *tail_first_dev = nullptr, *tail_count_dev = nullptr;
@@ -903,6 +968,7 @@ namespace
 
 constexpr int STRIP_CAP = 2300;       // band + tail columns one owner's LDS strip may span (3 rows x 2301 doubles = 55 KB)
 constexpr uint32_t TAIL_CHUNK = 1024; // records per chunk of a tail owner (a chunk is one wavefront walking its records in order)
+constexpr uint32_t BAND_CHUNK = 512;  // a band owner with more than twice this many records is cut into chunks of this size
 constexpr uint32_t DENSE_VERTS = 8;   // a mesh of at most this many vertices is dense (plane, minimal mesh): tail
 
 template <typename T> int up(ochip_relaxg_problem *p, T **dst, const T *src, size_t n)
@@ -1076,11 +1142,27 @@ int assign(ochip_relaxg_problem *p)
     std::vector<work_item> items;
     std::vector<uint32_t> tail_var, tail_first, tail_count;
     int max_strip = 1;
+    std::vector<band_owner> band_owners;
+    int64_t band_doubles = 0;
+    static const bool no_band_chunks = getenv("OCHIP_RELAX_NO_BAND_CHUNKS") != nullptr; // A/B knob
     for (uint32_t u : band)
     {
-        work_item it{u, p->var_rec_off[u], p->var_rec_off[u + 1], lo[u], hi[u], -1};
-        items.push_back(it);
-        max_strip = std::max(max_strip, (int)p->var_ts[u] * (hi[u] - lo[u] + T + 1));
+        const uint32_t r0 = p->var_rec_off[u], r1 = p->var_rec_off[u + 1];
+        const int64_t strip = (int64_t)p->var_ts[u] * (hi[u] - lo[u] + T + 1);
+        max_strip = std::max(max_strip, (int)strip);
+        if (no_band_chunks || r1 - r0 <= 2 * BAND_CHUNK)
+        {
+            items.push_back(work_item{u, r0, r1, lo[u], hi[u], -1, -1});
+            continue;
+        }
+        band_owner bo{u, lo[u], hi[u], 0, band_doubles};
+        for (uint32_t e = r0; e < r1; e += BAND_CHUNK)
+        {
+            items.push_back(work_item{u, e, std::min(e + BAND_CHUNK, r1), lo[u], hi[u], -1, band_doubles});
+            band_doubles += strip;
+            bo.chunks++;
+        }
+        band_owners.push_back(bo);
     }
     uint32_t n_partials = 0;
     for (uint32_t u : tail)
@@ -1090,7 +1172,7 @@ int assign(ochip_relaxg_problem *p)
         uint32_t cnt = 0;
         for (uint32_t e = p->var_rec_off[u]; e < p->var_rec_off[u + 1] || cnt == 0; e += TAIL_CHUNK)
         {
-            work_item it{u, e, std::min(e + TAIL_CHUNK, p->var_rec_off[u + 1]), 0, 0, (int32_t)n_partials};
+            work_item it{u, e, std::min(e + TAIL_CHUNK, p->var_rec_off[u + 1]), 0, 0, (int32_t)n_partials, -1};
             items.push_back(it);
             n_partials++;
             cnt++;
@@ -1113,6 +1195,10 @@ int assign(ochip_relaxg_problem *p)
     chk(up(p, &p->tail_first_dev, tail_first));
     chk(up(p, &p->tail_count_dev, tail_count));
     chk(up<double>(p, &p->partials_dev, nullptr, (size_t)std::max<uint32_t>(n_partials, 1) * 3 * (T + 1)));
+    p->n_band_owners = (uint32_t)band_owners.size();
+    chk(up(p, &p->band_owners_dev, band_owners));
+    chk(up<double>(p, &p->band_partials_dev, nullptr, (size_t)std::max<int64_t>(band_doubles, 1)));
+    chk(up<double>(p, &p->cost_slices_dev, nullptr, (size_t)p->n_blocks / COST_SLICE + 2));
     if (rc != OCHIP_OK)
         return rc;
     if (hipMemcpy(p->dev.var_t, p->var_t.data(), p->n_vars * 4, hipMemcpyHostToDevice) != hipSuccess ||
@@ -1202,12 +1288,21 @@ struct general_model final : lm_model
             OCHIP_HIP(ctx, hipMemsetAsync(p->sys.g, 0, (size_t)n * 8, st));
             if (p->n_items)
                 hipLaunchKernelGGL(gather_kernel, dim3(p->n_items), dim3(W), (size_t)p->max_strip * 8, st, D, p->items_dev,
-                                   p->var_rec_dev, p->sys.matA(), p->sys.g, n, p->tail_begin, p->partials_dev, STRIP_CAP);
+                                   p->var_rec_dev, p->sys.matA(), p->sys.g, n, p->tail_begin, p->partials_dev, STRIP_CAP,
+                                   p->band_partials_dev);
+            if (p->n_band_owners)
+                hipLaunchKernelGGL(band_merge_kernel, dim3(p->n_band_owners), dim3(256), 0, st, D, (const band_owner *)p->band_owners_dev,
+                                   (const double *)p->band_partials_dev, p->sys.matA(), p->sys.g, n, p->tail_begin);
             if (p->n_tail_owners)
                 hipLaunchKernelGGL(tail_merge_kernel, dim3(p->n_tail_owners), dim3(256), 0, st, D, p->tail_var_dev, p->tail_first_dev,
                                    p->tail_count_dev, p->partials_dev, p->sys.matA(), p->sys.g, n, p->tail_begin);
         }
-        hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(LM_TG), 0, st, D.rec_cost, p->n_blocks, D.prior_base, n_prior, p->sys.scal);
+        const uint32_t n_slices = (p->n_blocks + COST_SLICE - 1) / COST_SLICE;
+        if (n_slices)
+            hipLaunchKernelGGL(cost_slices_kernel, dim3(n_slices), dim3(LM_TG), 0, st, (const double *)D.rec_cost, p->n_blocks,
+                               p->cost_slices_dev);
+        hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(LM_TG), 0, st, (const double *)D.rec_cost, (const double *)p->cost_slices_dev,
+                           n_slices, D.prior_base, n_prior, p->sys.scal);
         OCHIP_HIP(ctx, hipGetLastError());
         double h0 = 0;
         std::vector<int32_t> hfails(p->shard_world, 0);
