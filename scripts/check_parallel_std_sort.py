@@ -102,17 +102,6 @@ def check(keys, name):
     return ok
 
 
-rng = np.random.default_rng(1)
-ok = True
-for n in (0, 1, 2, 15, 16, 17, 18, 33, 100, 1000, 5000, 20477):
-    ok &= check(rng.uniform(0, 1, n), "uniform")
-    ok &= check(rng.integers(0, 8, n), "heavy ties")
-    ok &= check(rng.integers(0, max(n // 4, 1), n), "some ties")
-    ok &= check(np.arange(n), "ascending")
-    ok &= check(np.arange(n)[::-1], "descending")
-    ok &= check(np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]), "organ pipe")
-    ok &= check(np.zeros(n), "all equal")
-# median-of-three killer
 def killer(n):
     k = n // 2
     a = np.zeros(n)
@@ -122,7 +111,34 @@ def killer(n):
             a[i] = k + i
         a[k + i - 1] = 2 * i
     return a
-for n in (200, 2000, 20000):
-    ok &= check(killer(n), "killer")
-    ok &= check(-killer(n), "killer reversed")
-print("ALL OK" if ok else "FAILURES")
+
+
+def main():
+    rng = np.random.default_rng(1)
+    ok = True
+    for n in (0, 1, 2, 15, 16, 17, 18, 33, 100, 1000, 5000, 20477):
+        ok &= check(rng.uniform(0, 1, n), "uniform")
+        ok &= check(rng.integers(0, 8, n), "heavy ties")
+        ok &= check(rng.integers(0, max(n // 4, 1), n), "some ties")
+        ok &= check(np.arange(n), "ascending")
+        ok &= check(np.arange(n)[::-1], "descending")
+        ok &= check(np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]), "organ pipe")
+        ok &= check(np.zeros(n), "all equal")
+    # median-of-three killer
+    def killer(n):
+        k = n // 2
+        a = np.zeros(n)
+        for i in range(1, k + 1):
+            if i % 2 == 1:
+                a[i - 1] = i
+                a[i] = k + i
+            a[k + i - 1] = 2 * i
+        return a
+    for n in (200, 2000, 20000):
+        ok &= check(killer(n), "killer")
+        ok &= check(-killer(n), "killer reversed")
+    print("ALL OK" if ok else "FAILURES")
+
+
+if __name__ == "__main__":
+    main()
