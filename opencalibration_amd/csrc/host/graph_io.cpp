@@ -745,7 +745,16 @@ bool parse_id(const std::string &s, size_t &id) // std::strtoull(name, &end, 10)
 // ---- MeasurementGraph ------------------------------------------------------------------------------------------------
 bool serialize(const MeasurementGraph &graph, std::ostream &out)
 {
+    // the writer only ever appends, so the text goes to the stream a megabyte at a time: a 1 000-image graph.json is
+    // ~2 GB of features and matches and must not be held as one string beside the graph
     std::string text;
+    const auto drain = [&](size_t keep) {
+        if (text.size() > keep)
+        {
+            out.write(text.data(), (std::streamsize)text.size());
+            text.clear();
+        }
+    };
     PrettyWriter w(text);
     w.StartObject();
     w.Key("version");
@@ -762,6 +771,7 @@ bool serialize(const MeasurementGraph &graph, std::ostream &out)
     {
         const MeasurementGraph::Node &node = graph.nodes()[ni];
         const image &img = node.payload;
+        drain(1 << 20);
         w.Key(std::to_string(node.id));
         w.StartObject();
         w.Key("path");
@@ -871,6 +881,7 @@ bool serialize(const MeasurementGraph &graph, std::ostream &out)
     {
         const MeasurementGraph::Edge &edge = graph.edges()[ei];
         const camera_relations &r = edge.payload;
+        drain(1 << 20);
         w.Key(std::to_string(edge.id));
         w.StartObject();
         w.Key("source");
@@ -949,7 +960,7 @@ bool serialize(const MeasurementGraph &graph, std::ostream &out)
     }
     w.EndObject();
     w.EndObject();
-    out.write(text.data(), (std::streamsize)text.size());
+    drain(0);
     out.flush();
     return (bool)out;
 }

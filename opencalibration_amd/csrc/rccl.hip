@@ -12,11 +12,29 @@
 
 #include <cstring>
 
-#include <rccl/rccl.h>
-
 #include "ctx.hpp"
 
+// The library is bound at run time (dlopen below), so the header is only needed for its types; a ROCm install without
+// the RCCL development files still builds libochip.so from the few declarations of the public NCCL ABI used here.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
 static_assert(OCHIP_RCCL_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ochip.h mirrors ncclUniqueId");
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef struct
+{
+    char internal[OCHIP_RCCL_ID_BYTES];
+} ncclUniqueId;
+typedef enum
+{
+    ncclSuccess = 0
+} ncclResult_t;
+typedef enum
+{
+    ncclInt8 = 0,
+    ncclChar = 0
+} ncclDataType_t;
+#endif
 
 namespace
 {
