@@ -623,6 +623,8 @@ int assign_tangent(ochip_relax_problem *p)
     int t = 0;
     p->cam_t.assign(p->n_cams, -1);
     std::vector<uint32_t> active; // cameras that get unknowns, in the order of their unknowns
+    int n_separators = 0;         // the last cameras of `active` when the camera graph was dissected (below)
+    std::vector<int> region_first_block;
     for (uint32_t c = 0; c < p->n_cams; c++)
         if (p->cam_optimize[c] && !p->cams_frozen && p->cam_pair_count[c] + p->cam_has_prior_host[c] > 0)
             active.push_back(c);
@@ -687,6 +689,88 @@ int assign_tangent(ochip_relax_problem *p)
             bfs(start, order, seen);
         }
         std::reverse(order.begin(), order.end());
+        // Dissection (round 3): with the cameras in one band, the factorisation is one chain of diagonal tiles - 47 at
+        // n = 3003, ~22 us each, the whole device waiting on one workgroup.  Cut the order into regions of g cameras
+        // (g a multiple of 64, so that a region starts on a tile boundary: 3 g unknowns = 3 g / 64 tiles): the next g
+        // cameras of the order form a region, every camera further down that is linked to one of them becomes a
+        // separator, and so on; the separators go to the end of the order, in front of the plane unknowns, and are the
+        // tail of the envelope (dense rows).  Regions are then linked to separators only, their chains of tiles are
+        // independent (lm_envelope::region_begin), and the critical path is the longest region plus the tail.  g is
+        // chosen to make that shortest; no dissection when it does not shorten the path to 0.7 of the single chain.
+        static const bool use_dissect = !(getenv("OCHIP_RELAX_DISSECT") && getenv("OCHIP_RELAX_DISSECT")[0] == '0');
+        if (use_dissect && order.size() >= 4 * (size_t)NB)
+        {
+            const int N = (int)order.size();
+            auto cut = [&](int g, std::vector<int> *state_out, int *n_regions) -> int { // -> path length in cameras (or -1)
+                std::vector<int> state((size_t)N, -1);                                  // by slot: region, or -2 = separator
+                int left = N, regions = 0, longest = 0, seps = 0;
+                size_t pos = 0;
+                while (left > 0)
+                {
+                    const bool last = left <= g + g / 2;
+                    const int want = last ? left : g;
+                    int got = 0;
+                    std::vector<uint32_t> mine;
+                    for (; pos < order.size() && got < want; pos++)
+                        if (state[order[pos]] == -1)
+                        {
+                            state[order[pos]] = regions;
+                            mine.push_back(order[pos]);
+                            got++;
+                        }
+                    left -= got;
+                    longest = std::max(longest, got);
+                    regions++;
+                    if (last)
+                        break;
+                    for (uint32_t v : mine)
+                        for (uint32_t u : adj[v])
+                            if (state[u] == -1)
+                            {
+                                state[u] = -2;
+                                seps++;
+                                left--;
+                            }
+                }
+                if (regions < 2)
+                    return -1;
+                if (state_out)
+                    state_out->swap(state);
+                *n_regions = regions;
+                return longest + seps;
+            };
+            int best_g = 0, best_path = N, regions = 0;
+            for (int g = NB; g <= N / 2; g += NB)
+            {
+                int r = 0;
+                const int path = cut(g, nullptr, &r);
+                if (path >= 0 && path < best_path)
+                    best_path = path, best_g = g;
+            }
+            if (best_g > 0 && 10 * best_path <= 7 * N)
+            {
+                std::vector<int> state;
+                cut(best_g, &state, &regions);
+                std::vector<uint32_t> cut_order;
+                cut_order.reserve(order.size());
+                for (uint32_t v : order) // regions were handed out in the order's direction: region numbers ascend
+                    if (state[v] >= 0)
+                        cut_order.push_back(v);
+                n_separators = 0;
+                for (uint32_t v : order)
+                    if (state[v] == -2)
+                    {
+                        cut_order.push_back(v);
+                        n_separators++;
+                    }
+                // (a stable partition by region: a region's cameras may be interleaved with separators of earlier cuts)
+                std::stable_sort(cut_order.begin(), cut_order.end() - n_separators,
+                                 [&](uint32_t a, uint32_t b) { return state[a] < state[b]; });
+                order.swap(cut_order);
+                for (int r = 0; r < regions; r++)
+                    region_first_block.push_back(r * (3 * best_g / NB));
+            }
+        }
         std::vector<uint32_t> reordered(active.size());
         for (size_t i = 0; i < order.size(); i++)
             reordered[i] = active[order[i]];
@@ -709,20 +793,23 @@ int assign_tangent(ochip_relax_problem *p)
         // block envelope of the reduced system J'J: camera unknowns in camera order, then the plane unknowns (coupled to
         // every camera: the tail).  A pair (p, q) puts a 3 x 3 block at rows t_q.., columns t_p..; Cholesky fill stays
         // inside the column envelope once that is made monotone.
-        const int cam_end = 3 * (int)active.size();
+        // (dissected graph: the separator cameras belong to the tail as well, and a link into the tail leaves the band's
+        // envelope alone - the tail's rows are dense under every column)
+        const int cam_end = 3 * ((int)active.size() - n_separators);
         const int n_all = std::max(t, 1), nblk = (n_all + NB - 1) / NB;
         env.tail_begin = cam_end;
+        env.region_begin = region_first_block;
         env.env_end.assign(nblk, 0);
         for (int k = 0; k < nblk; k++)
             env.env_end[k] = std::min((k + 1) * NB, cam_end);
         for (uint32_t c = 0; c < p->n_cams; c++) // a camera's own 3 x 3 block may straddle two column blocks
-            if (p->cam_t[c] >= 0)
+            if (p->cam_t[c] >= 0 && p->cam_t[c] < cam_end)
                 for (int k = p->cam_t[c] / NB; k <= (p->cam_t[c] + 2) / NB; k++)
                     env.env_end[k] = std::max(env.env_end[k], p->cam_t[c] + 3);
         for (size_t i = 0; i < p->pair_p_h.size(); i++)
         {
             const int ta = p->cam_t[p->pair_p_h[i]], tb = p->cam_t[p->pair_q_h[i]];
-            if (ta < 0 || tb < 0)
+            if (ta < 0 || tb < 0 || std::max(ta, tb) >= cam_end)
                 continue;
             const int lo = std::min(ta, tb), hi = std::max(ta, tb) + 3;
             for (int k = lo / NB; k <= (lo + 2) / NB; k++)

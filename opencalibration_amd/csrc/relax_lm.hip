@@ -678,6 +678,125 @@ __global__ __launch_bounds__(LM_TG) void back_solve_kernel(lm_matrix Lm, int n, 
         scal[1] = 0.5 * sh[0];
 }
 
+// The same substitution when the band falls into regions that are coupled through the tail only (lm_envelope::
+// region_begin): one workgroup per region.  Each solves the tail's blocks for itself (the same arithmetic in every
+// workgroup, on a private copy - nothing is exchanged), takes the tail's contribution out of its own region's columns
+// on the way, and then walks its region from the bottom; what were 47 sequential blocks at n = 3003 are 9 + 9.  The
+// workgroup that finishes last adds up the regions' parts of model_cost_change.
+__global__ __launch_bounds__(LM_TG) void back_solve_regions_kernel(lm_matrix Lm, int n, const double *Linv, double *x, double *work,
+                                                                  const int *first_blk, int n_blocks, const int *region, int tb,
+                                                                  const double *lm_diag, const double *gs, double *scal,
+                                                                  unsigned int *arrived)
+{
+    __shared__ double xb[NB];
+    __shared__ double sh[LM_TG];
+    __shared__ int s_last;
+    const int t = threadIdx.x, r = blockIdx.x, m = gridDim.x;
+    const double *L = Lm.tiles;
+    double *xw = work + (size_t)r * n;
+    double *parts = work + (size_t)m * n;
+    const int rb = region[r], re = region[r + 1];          // own column blocks [rb, re)
+    const int c_lo = rb * NB, c_hi = min(re * NB, n);      // own columns
+    const int t_lo = min(tb * NB, n);                      // columns of the tail's blocks
+    for (int i = c_lo + t; i < c_hi; i += LM_TG) // y = L^-1 gs: the augmented row
+        xw[i] = L[lm_at(Lm, n, i)];
+    for (int i = t_lo + t; i < n; i += LM_TG)
+        xw[i] = L[lm_at(Lm, n, i)];
+    auto block_step = [&](int k, int lo0, int hi0, int lo1, int hi1) {
+        const int k0 = k * NB, nb = min(NB, n - k0);
+        const double *Li = Linv + (size_t)k * NB * NB;
+        __syncthreads(); // the updates of the previous block have landed
+        if (t < NB)
+            xb[t] = t < nb ? xw[k0 + t] : 0.0;
+        __syncthreads();
+        double s = 0;
+        if (t < nb)
+        {
+#pragma unroll
+            for (int m0 = 0; m0 < NB; m0 += 16)
+            {
+                double v[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    v[j] = Li[(m0 + j) * NB + t];
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (m0 + j >= t && m0 + j < nb)
+                        s += v[j] * xb[m0 + j];
+            }
+        }
+        __syncthreads();
+        if (t < nb)
+        {
+            xb[t] = s;
+            xw[k0 + t] = s;
+        }
+        __syncthreads();
+        for (int pass = 0; pass < 2; pass++)
+        {
+            const int lo = pass ? lo1 : lo0, hi = pass ? hi1 : hi0;
+            for (int i = lo + t; i < hi; i += LM_TG)
+            {
+                const double *Lc = L + ((size_t)lm_tile_index(Lm.cols, k, i >> 6) << 12) + (i & 63);
+                double u = 0;
+                for (int m0 = 0; m0 < nb; m0 += 16)
+                {
+                    double v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        v[j] = m0 + j < nb ? Lc[(m0 + j) * NB] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
+                        u += v[j] * xb[m0 + j];
+                }
+                xw[i] -= u;
+            }
+        }
+    };
+    for (int k = n_blocks - 1; k >= tb; k--) // the tail's blocks: the tail's own columns below the block, and this region's
+        block_step(k, t_lo, k * NB, c_lo, c_hi);
+    for (int k = min(re, n_blocks) - 1; k >= rb; k--)
+        block_step(k, max(first_blk[k] * NB, c_lo), k * NB, 0, 0);
+    __syncthreads();
+    // results and this region's part of model_cost_change (workgroup 0: the tail's as well)
+    double part = 0;
+    for (int i = c_lo + t; i < c_hi; i += LM_TG)
+    {
+        const double v = xw[i];
+        x[i] = v;
+        part += v * gs[i] + lm_diag[i] * v * v;
+    }
+    if (r == 0)
+        for (int i = t_lo + t; i < n; i += LM_TG)
+        {
+            const double v = xw[i];
+            x[i] = v;
+            part += v * gs[i] + lm_diag[i] * v * v;
+        }
+    sh[t] = part;
+    __syncthreads();
+    for (int s = LM_TG / 2; s > 0; s >>= 1)
+    {
+        if (t < s)
+            sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    if (t == 0)
+    {
+        __hip_atomic_store(&parts[r], sh[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(m - 1);
+        if (s_last)
+        {
+            double sum = 0;
+            for (int q = 0; q < m; q++)
+                sum += __hip_atomic_load(&parts[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            scal[1] = 0.5 * sum;
+            __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 
 // model_cost_change = -(step.gs + step' As step / 2) with step = -y, (As + D) y = gs
 //                   = y.gs - (y.gs - y'D y) / 2 = (y.gs + sum D_i y_i^2) / 2 by the normal equations (no n^2 product).
@@ -951,7 +1070,43 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
                 tail_tiles += I >= tb;
             tail_tiles += (size_t)std::max(0, nbr - cols[J].tail_start);
         }
-        if ((long)tail_tiles * 8 <= (long)slots)
+        // regions of the band (a dissected camera graph): region r's columns only read columns of region r, so the chains
+        // of the regions' diagonal tiles run side by side - provided their workgroups are resident together.  Claim order:
+        // the band's tiles first (the critical path: every region's first column, then every region's second, ...), then
+        // the tail rows' tiles in the same interleaved column order, then the tail's own columns.  Still every tile follows
+        // the tiles it needs.
+        std::vector<int> region_bounds; // [n_regions + 1], block indices; valid regions only
+        {
+            const std::vector<int> &rb = s->env.region_begin;
+            const int limit = std::min(tb, nbc); // (a last region that lies inside the tail's first block is part of the tail)
+            if (!dense && rb.size() > 1 && rb[0] == 0)
+            {
+                for (size_t r = 0; r < rb.size() && rb[r] < limit && (r == 0 || rb[r] > rb[r - 1]); r++)
+                    region_bounds.push_back(rb[r]);
+                region_bounds.push_back(limit);
+                if (region_bounds.size() < 3)
+                    region_bounds.clear();
+            }
+        }
+        s->n_regions = region_bounds.empty() ? 1 : (int)region_bounds.size() - 1;
+        if (s->n_regions > 1)
+        {
+            std::vector<int> band_cols;
+            int longest = 0;
+            for (int r = 0; r < s->n_regions; r++)
+                longest = std::max(longest, region_bounds[r + 1] - region_bounds[r]);
+            for (int d = 0; d < longest; d++)
+                for (int r = 0; r < s->n_regions; r++)
+                    if (region_bounds[r] + d < region_bounds[r + 1])
+                        band_cols.push_back(region_bounds[r] + d);
+            for (int J : band_cols)
+                rows_of(J, false, true);
+            for (int J : band_cols)
+                rows_of(J, true, false);
+            for (int J = region_bounds.back(); J < nbc; J++)
+                rows_of(J, true, true);
+        }
+        else if ((long)tail_tiles * 8 <= (long)slots)
         {
             for (int J = 0; J < nbc; J++)
                 rows_of(J, true, false);
@@ -1002,6 +1157,18 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
             lm_dev_upload<unsigned int>(ctx, s->allocs, &s->chol_sync, nullptr, s->chol_sync_bytes / 4) != OCHIP_OK)
             return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (factorisation plan)");
         s->chol_cols = cols_dev;
+        if (s->n_regions > 1)
+        {
+            const size_t need = (size_t)s->n_regions * ((size_t)std::max(nn, 1) + 1);
+            if (lm_dev_upload(ctx, s->allocs, &s->region_dev, region_bounds.data(), region_bounds.size()) != OCHIP_OK)
+                return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (regions of the factorisation)");
+            if (need > s->back_work_cap)
+            {
+                if (lm_dev_upload<double>(ctx, s->allocs, &s->back_work, nullptr, need) != OCHIP_OK)
+                    return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (backward substitution, %d regions)", s->n_regions);
+                s->back_work_cap = need;
+            }
+        }
     }
     return OCHIP_OK;
 }
@@ -1220,8 +1387,14 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         // row n now holds y = L^-1 gs; back-substitute L' x = y block by block
         if (n > 0)
         {
-            hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(LM_TG), 0, st, S.matW(), n, (const double *)S.linv, S.y,
-                               (const int *)S.chol_kmin, (n + NB - 1) / NB, (const double *)S.lm_diag, (const double *)S.gs, S.scal);
+            if (S.n_regions > 1)
+                hipLaunchKernelGGL(back_solve_regions_kernel, dim3((unsigned)S.n_regions), dim3(LM_TG), 0, st, S.matW(), n,
+                                   (const double *)S.linv, S.y, S.back_work, (const int *)S.chol_kmin, (n + NB - 1) / NB,
+                                   (const int *)S.region_dev, S.chol_tb, (const double *)S.lm_diag, (const double *)S.gs, S.scal,
+                                   S.chol_sync + 1);
+            else
+                hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(LM_TG), 0, st, S.matW(), n, (const double *)S.linv, S.y,
+                                   (const int *)S.chol_kmin, (n + NB - 1) / NB, (const double *)S.lm_diag, (const double *)S.gs, S.scal);
         }
         else
             hipLaunchKernelGGL(lm_model_change_kernel, dim3(1), dim3(LM_TG), 0, st, S.lm_diag, S.gs, S.y, n, S.scal);

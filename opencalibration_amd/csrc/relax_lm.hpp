@@ -25,9 +25,13 @@ constexpr int LM_TG = 256;
 // Block envelope of the reduced system (unknowns numbered so that coupled unknowns are close): per 64-column block the
 // end of the rows that can be non-zero below it, the first row of the dense tail (unknowns coupled to everything: plane
 // heights, shared intrinsics), and per block row the first column that can be non-zero (for the backward solve).
+// region_begin (optional): the band's column blocks fall into regions that are not coupled to each other, only to the
+// tail (a dissection of the camera graph: relax.hip, assign_tangent) - the first column block of each, ascending, [0] = 0;
+// every region boundary is a multiple of 64 unknowns.  The factorisation then walks the regions' columns side by side
+// and the backward substitution runs one workgroup per region.
 struct lm_envelope
 {
-    std::vector<int> env_end, first_col;
+    std::vector<int> env_end, first_col, region_begin;
     int tail_begin = 0;
 };
 
@@ -82,6 +86,12 @@ struct lm_system
     unsigned int *chol_sync = nullptr;  // [0] claim counter, [4 + tile] done flags; zeroed before every factorisation
     int chol_n_tiles = 0, chol_nbc = 0, chol_nbr = 0, chol_tb = 0, chol_grid = 0;
     size_t chol_sync_bytes = 0;
+    // regions of the band (lm_envelope::region_begin): block bounds [n_regions + 1] (the last one = chol_tb), and the
+    // backward substitution's private work vectors, [n_regions][n] + [n_regions] partial sums
+    int n_regions = 1;
+    int *region_dev = nullptr;
+    double *back_work = nullptr;
+    size_t back_work_cap = 0;
     lm_matrix matA() const
     {
         return lm_matrix{A, chol_cols};
