@@ -697,7 +697,7 @@ int assign_tangent(ochip_relax_problem *p)
         // tail of the envelope (dense rows).  Regions are then linked to separators only, their chains of tiles are
         // independent (lm_envelope::region_begin), and the critical path is the longest region plus the tail.  g is
         // chosen to make that shortest; no dissection when it does not shorten the path to 0.7 of the single chain.
-        static const bool use_dissect = !(getenv("OCHIP_RELAX_DISSECT") && getenv("OCHIP_RELAX_DISSECT")[0] == '0');
+        const bool use_dissect = !(getenv("OCHIP_RELAX_DISSECT") && getenv("OCHIP_RELAX_DISSECT")[0] == '0');
         if (use_dissect && order.size() >= 4 * (size_t)NB)
         {
             const int N = (int)order.size();
@@ -740,7 +740,8 @@ int assign_tangent(ochip_relax_problem *p)
                 return longest + seps;
             };
             int best_g = 0, best_path = N, regions = 0;
-            for (int g = NB; g <= N / 2; g += NB)
+            const int forced_g = getenv("OCHIP_RELAX_DISSECT_G") ? atoi(getenv("OCHIP_RELAX_DISSECT_G")) / NB * NB : 0; // A/B knob
+            for (int g = forced_g > 0 ? forced_g : NB; g <= (forced_g > 0 ? forced_g : N / 2); g += NB)
             {
                 int r = 0;
                 const int path = cut(g, nullptr, &r);
@@ -839,8 +840,8 @@ int assign_tangent(ochip_relax_problem *p)
             long band = 0;
             for (int k = 0; k < nblk; k++)
                 band += std::max(0, env.env_end[k] - (k + 1) * NB);
-            fprintf(stderr, "[ochip relax] n=%d blocks=%d tail_begin=%d mean envelope rows below a block %.1f (dense: %.1f)\n", n_all, nblk,
-                    cam_end, (double)band / nblk, (double)n_all / 2);
+            fprintf(stderr, "[ochip relax] n=%d blocks=%d tail_begin=%d mean envelope rows below a block %.1f (dense: %.1f); %zu regions, %d separator cameras\n", n_all, nblk,
+                    cam_end, (double)band / nblk, (double)n_all / 2, std::max<size_t>(region_first_block.size(), 1), n_separators);
         }
     }
     if (hipMemcpy(p->dev.cam_t, p->cam_t.data(), p->n_cams * 4, hipMemcpyHostToDevice) != hipSuccess ||

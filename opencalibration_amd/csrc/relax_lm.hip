@@ -209,6 +209,166 @@ __device__ __forceinline__ void chol_diag_phase(double (&a)[4][4], double (&x)[4
     }
 }
 
+// The blocked form of the same factorisation, used by chol_tiles_kernel (round 3).  The timeline of a factorisation
+// (OCHIP_CHOL_TIMELINE) showed the diagonal tile at 25 us of a column's 39: 32 two-pivot steps of ~200 instructions with
+// one wavefront per SIMD - instruction issue, not the barriers.  Most of those instructions were the rank-1 updates of the
+// trailing matrix and of the inverse accumulator below the pivot's band.  Here a step only touches the pivot's own block
+// of 16 columns (and the band's 16 rows of the inverse); after the 16 pivots of a block the rest follows as ONE rank-16
+// update on the matrix cores: the panel L(rows below, 16) and the finished rows of X go through LDS, the products
+// L L' (trailing blocks) and L X (rows of the inverse below the band) are formed with v_mfma_f64_16x16x4f64 and
+// subtracted from the register tiles.  (Sums in a different order than the one-pivot loop: the factor is not on a
+// bit-parity path; OCHIP_CHOL_VERIFY compares it with the launch chain, which keeps the unblocked phases.)
+template <int JB>
+__device__ __forceinline__ void chol_diag_panel_phase(double (&a)[4][4], double (&x)[4][4], double (*colA)[NB], double (*rowX)[NB],
+                                                      int ty, int tx, int nb, bool &bad)
+{
+#pragma unroll 1
+    for (int jt = 0; jt < 16; jt += 2)
+    {
+        const int j = JB * 16 + jt, buf = (jt >> 1) & 1;
+        double(*c0) = colA[2 * buf], (*c1) = colA[2 * buf + 1], (*r0) = rowX[2 * buf], (*r1) = rowX[2 * buf + 1];
+        if (tx == jt)
+#pragma unroll
+            for (int p = JB; p < 4; p++)
+                c0[ty + 16 * p] = a[p][JB];
+        if (tx == jt + 1)
+#pragma unroll
+            for (int p = JB; p < 4; p++)
+                c1[ty + 16 * p] = a[p][JB];
+        if (ty == jt)
+#pragma unroll
+            for (int q = 0; q <= JB; q++)
+                r0[tx + 16 * q] = x[JB][q];
+        if (ty == jt + 1)
+#pragma unroll
+            for (int q = 0; q <= JB; q++)
+                r1[tx + 16 * q] = x[JB][q];
+        __syncthreads();
+        // What a step costs is latency, not instructions (56 000 cycles per tile for 32 steps whether a step has 90 or 200
+        // instructions: OCHIP_CHOL_TIMELINE).  As first compiled, a step was a string of LDS round trips - every
+        // `condition ? lds[..] * rs : 0` had become a branch around a read with its own wait, issued behind the Newton
+        // chain of the pivot.  So: every LDS operand of the step is requested here, together and unconditionally, nothing
+        // below touches LDS or branches (selects only), and the chains of dependent fp64 operations are short - Newton
+        // steps as two fused operations each (e = 1 - p y y, y += y e / 2), the second pivot's 1 / sqrt from
+        // d = c11 p0 - c10^2 (= p1 p0), which needs nothing of the first pivot's chain: rs1 = rsq(d) sqrt(p0).
+        const double piv0 = c0[j], c10 = c0[j + 1], c11 = c1[j + 1];
+        const double cc0 = c0[tx + 16 * JB], cc1 = c1[tx + 16 * JB]; // columns j, j + 1 at this thread's column of the block
+        double cr0[4], cr1[4], xq0[4], xq1[4];
+#pragma unroll
+        for (int p = JB; p < 4; p++)
+        {
+            cr0[p] = c0[ty + 16 * p];
+            cr1[p] = c1[ty + 16 * p];
+        }
+#pragma unroll
+        for (int q = 0; q <= JB; q++)
+        {
+            xq0[q] = r0[tx + 16 * q];
+            xq1[q] = r1[tx + 16 * q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double d1 = __builtin_fma(c11, piv0, -(c10 * c10));
+        bad = bad || (j < nb && !(piv0 > 0.0)) || (j + 1 < nb && !(d1 > 0.0));
+        double rs0 = __builtin_amdgcn_rsq(piv0), rd1 = __builtin_amdgcn_rsq(d1);
+#pragma unroll
+        for (int it = 0; it < 2; it++)
+        {
+            const double e0 = __builtin_fma(-(piv0 * rs0), rs0, 1.0), e1 = __builtin_fma(-(d1 * rd1), rd1, 1.0);
+            rs0 = __builtin_fma(0.5 * rs0, e0, rs0);
+            rd1 = __builtin_fma(0.5 * rd1, e1, rd1);
+        }
+        const double cross = c10 * rs0;        // l_{j+1,j}
+        const double rs1 = rd1 * (piv0 * rs0); // 1 / sqrt(p1) = sqrt(p0) / sqrt(p1 p0)
+        double li0[4], xr0[4], li1[4], xr1[4], l0full[4], col1_own[4];
+#pragma unroll
+        for (int p = JB; p < 4; p++)
+        {
+            l0full[p] = cr0[p] * rs0;
+            li0[p] = (p > JB || ty > jt) ? l0full[p] : 0.0;
+            col1_own[p] = cr1[p] - li0[p] * cross; // column j + 1 after pivot j's update
+            li1[p] = (p > JB || ty > jt + 1) ? col1_own[p] * rs1 : 0.0;
+        }
+        const double l0c = (tx > jt) ? cc0 * rs0 : 0.0;
+        const double l1c = (tx > jt + 1) ? (cc1 - l0c * cross) * rs1 : 0.0;
+#pragma unroll
+        for (int q = 0; q <= JB; q++)
+        {
+            xr0[q] = xq0[q] * rs0;
+            xr1[q] = (xq1[q] - cross * xr0[q]) * rs1;
+        }
+        // the two rank-1 updates, inside the block's columns and the band's rows of X only; then columns j, j + 1 become
+        // final (l below the diagonal, sqrt(pivot) = pivot * rs on it, 0 above) and rows j, j + 1 of X too
+        const bool own0 = tx == jt, own1 = tx == jt + 1, row0 = ty == jt, row1 = ty == jt + 1;
+#pragma unroll
+        for (int p = JB; p < 4; p++)
+        {
+            double v = a[p][JB];
+            v -= li0[p] * l0c;
+            v -= li1[p] * l1c;
+            const double f0 = (p > JB || ty >= jt) ? l0full[p] : 0.0;
+            const double f1 = (p > JB || ty >= jt + 1) ? col1_own[p] * rs1 : 0.0;
+            a[p][JB] = own0 ? f0 : (own1 ? f1 : v);
+        }
+#pragma unroll
+        for (int q = 0; q <= JB; q++)
+        {
+            double v = x[JB][q];
+            v -= li0[JB] * xr0[q];
+            v -= li1[JB] * xr1[q];
+            x[JB][q] = row0 ? xr0[q] : (row1 ? xr1[q] : v);
+        }
+    }
+}
+
+// after the 16 pivots of block JB: rows below the band, A(p, q) -= L(p, JB) L(q, JB)' for JB < q <= p and
+// X(p, q) -= L(p, JB) X(JB, q) for q <= JB, as 16 x 16 x 16 products on the matrix cores (P: [64][>= 17] staging arrays)
+template <int JB, int PITCH>
+__device__ __forceinline__ void chol_diag_block_update(double (&a)[4][4], double (&x)[4][4], double (*T)[65], double (*Lp)[PITCH],
+                                                       double (*XbT)[PITCH], int ty, int tx, int t)
+{
+    if (JB >= 3)
+        return;
+#pragma unroll
+    for (int p = JB + 1; p < 4; p++)
+        Lp[ty + 16 * p][tx] = a[p][JB]; // L(row, 16 JB + tx)
+#pragma unroll
+    for (int q = 0; q <= JB; q++)
+        XbT[tx + 16 * q][ty] = x[JB][q]; // X(16 JB + ty, column) transposed: [column][row of the band]
+    __syncthreads();
+    const int w = t >> 6, lane = t & 63, lr = lane & 15, lk = lane >> 4;
+    int b = 0;
+#pragma unroll
+    for (int p = JB + 1; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q <= p; q++, b++)
+            if ((b & 3) == w)
+            {
+                v4f64 acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < 16; kk += 4)
+                {
+                    const double av = Lp[16 * p + lr][kk + lk];
+                    const double bv = q <= JB ? XbT[16 * q + lr][kk + lk] : Lp[16 * q + lr][kk + lk];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    T[16 * p + 4 * e + lk][16 * q + lr] = acc[e];
+            }
+    __syncthreads();
+#pragma unroll
+    for (int p = JB + 1; p < 4; p++)
+#pragma unroll
+        for (int q = 0; q <= p; q++)
+        {
+            const double v = T[ty + 16 * p][tx + 16 * q];
+            if (q <= JB)
+                x[p][q] -= v;
+            else
+                a[p][q] -= v;
+        }
+}
+
 __global__ __launch_bounds__(256) void chol_diag_kernel(lm_matrix M, int n, int k0, int nb, int *fail,
                                                         double *Linv /*[NB][NB] row-major, zero padded*/)
 {
@@ -387,9 +547,12 @@ __device__ __forceinline__ void store_through(double *p, double v) // global_sto
 
 __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const chol_col *__restrict__ cols,
                                                          const int *__restrict__ kmin, const unsigned int *__restrict__ tiles,
-                                                         int n_tiles, int tb, unsigned int *sync, double *linv, int *fail)
+                                                         int n_tiles, int tb, unsigned int *sync, double *linv, int *fail,
+                                                         unsigned long long *timeline, const int *__restrict__ korder, int blocked_diag)
 {
-    constexpr int KC = 32;
+    // (KC was 32 until the timeline showed what a column costs beside its diagonal tile: memory round trips.  One
+    // workgroup per compute unit is resident anyway, so the whole 64 x 64 operands go through LDS at once: 104 KB.)
+    constexpr int KC = 64;
     __shared__ double T[64][65];
     __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
     __shared__ double colA[4][NB], rowX[4][NB]; // two pivots per step, double-buffered
@@ -410,6 +573,8 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
             return;
         const unsigned int ij = tiles[claim];
         const int I = (int)(ij & 0xFFFFu), J = (int)(ij >> 16);
+        if (timeline && t == 0) // OCHIP_CHOL_TIMELINE: claimed / operands summed / factored or multiplied / published
+            timeline[6 * claim] = wall_clock64();
         const int r0 = I * 64, c0 = J * 64;
         const int nb = min(64, n - c0); // columns of this block column
         const int k_begin = I < tb ? kmin[I] : (J >= tb ? 0 : kmin[J]);
@@ -417,28 +582,49 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
         for (int i = 0; i < 2; i++)
             for (int j = 0; j < 2; j++)
                 acc[i][j] = v4f64{0, 0, 0, 0};
+        // A tile of the tail's own columns sums over every column of the band.  When the band falls into regions (korder
+        // given), it takes them in the order the regions' chains produce them - the regions' first columns, their second
+        // columns, ... - instead of waiting for the whole first region before it touches the second: its steps then run
+        // under the regions' chains and not after them (208 us of 843 at n = 3003).  A fixed order, whoever arrives when.
+        // the tile's own entries (written by the launch before this one) do not depend on anything: requested now, they
+        // arrive under the waits and sums below instead of costing a memory round trip after them
+        double *wt = W + ((size_t)chol_tile_index(cols, I, J) << 12);
+        double own[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                {
+                    const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
+                    own[i][j][e] = (r0 + r < n_rows && c < nb) ? wt[r * NB + c] : 0.0;
+                }
+        const bool mapped = korder != nullptr && J >= tb;
         int ready = k_begin; // steps whose operands are known to be complete (the same value in every thread)
-        for (int K = k_begin; K < J; K++)
+        for (int step = k_begin; step < J; step++)
         {
-            if (K >= ready)
+            const int K = mapped ? korder[step] : step;
+            if (step >= ready)
             {
                 if (t == 0)
                 {
-                    // wait for the operands of step K, take along the following steps that are complete already,
+                    // wait for the operands of this step, take along the following steps that are complete already,
                     // ONE acquire for all of them
-                    int upto = K;
+                    int upto = step;
                     for (;;)
                     {
-                        const unsigned int *fa = flags + chol_tile_index(cols, I, upto);
-                        const unsigned int *fb = flags + chol_tile_index(cols, J, upto);
+                        const int Ku = mapped ? korder[upto] : upto;
+                        const unsigned int *fa = flags + chol_tile_index(cols, I, Ku);
+                        const unsigned int *fb = flags + chol_tile_index(cols, J, Ku);
                         const bool have = __hip_atomic_load(fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
                                           __hip_atomic_load(fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
                         if (have)
                         {
-                            if (++upto >= J || upto - K >= 16)
+                            if (++upto >= J || upto - step >= 16)
                                 break;
                         }
-                        else if (upto > K)
+                        else if (upto > step)
                             break;
                         else
                             __builtin_amdgcn_s_sleep(2);
@@ -474,16 +660,22 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                 }
             }
         }
+        if (timeline && t == 0)
+        {
+            timeline[6 * claim + 1] = wall_clock64();
+            timeline[6 * claim + 4] = clock64(); // shader clock: cycles the factor / product took
+        }
         // T = A(I, J) - acc (the tile's own entries were written by the launch before this one)
-        double *wt = W + ((size_t)chol_tile_index(cols, I, J) << 12);
         __syncthreads();
+#pragma unroll
         for (int i = 0; i < 2; i++)
+#pragma unroll
             for (int j = 0; j < 2; j++)
+#pragma unroll
                 for (int e = 0; e < 4; e++)
                 {
                     const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
-                    const double a = (r0 + r < n_rows && c < nb) ? wt[r * NB + c] : 0.0;
-                    T[r][c] = a - acc[i][j][e];
+                    T[r][c] = own[i][j][e] - acc[i][j][e];
                 }
         __syncthreads();
         if (I == J)
@@ -505,12 +697,25 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
             // row, kept aside and multiplied by the inverse below
             const bool has_aug = (r0 + nb == n) && nb < 64;
             if (has_aug && t < 64)
-                Pi[t][0] = t < nb ? T[nb][t] : 0.0;
+                Pi[t][KC] = t < nb ? T[nb][t] : 0.0; // (column KC: the block updates stage their panels in columns 0 .. 15)
             bool bad = false;
-            chol_diag_phase<0>(a, x, colA, rowX, ty, tx, nb, bad);
-            chol_diag_phase<1>(a, x, colA, rowX, ty, tx, nb, bad);
-            chol_diag_phase<2>(a, x, colA, rowX, ty, tx, nb, bad);
-            chol_diag_phase<3>(a, x, colA, rowX, ty, tx, nb, bad);
+            if (blocked_diag)
+            {
+                chol_diag_panel_phase<0>(a, x, colA, rowX, ty, tx, nb, bad);
+                chol_diag_block_update<0>(a, x, T, Pi, Pj, ty, tx, t);
+                chol_diag_panel_phase<1>(a, x, colA, rowX, ty, tx, nb, bad);
+                chol_diag_block_update<1>(a, x, T, Pi, Pj, ty, tx, t);
+                chol_diag_panel_phase<2>(a, x, colA, rowX, ty, tx, nb, bad);
+                chol_diag_block_update<2>(a, x, T, Pi, Pj, ty, tx, t);
+                chol_diag_panel_phase<3>(a, x, colA, rowX, ty, tx, nb, bad);
+            }
+            else
+            {
+                chol_diag_phase<0>(a, x, colA, rowX, ty, tx, nb, bad);
+                chol_diag_phase<1>(a, x, colA, rowX, ty, tx, nb, bad);
+                chol_diag_phase<2>(a, x, colA, rowX, ty, tx, nb, bad);
+                chol_diag_phase<3>(a, x, colA, rowX, ty, tx, nb, bad);
+            }
             if (bad)
                 *fail = 1;
             double *Li = linv + (size_t)J * NB * NB;
@@ -540,7 +745,7 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                 {
                     double sum = 0;
                     for (int m = 0; m <= t; m++)
-                        sum += Pi[m][0] * T[t][m];
+                        sum += Pi[m][KC] * T[t][m];
                     store_through(&wt[nb * NB + t], sum); // (row n is row nb of this tile)
                 }
             }
@@ -592,10 +797,17 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                     }
         }
         // publish: every storing wave drained, barrier, one lane sets the flag
+        if (timeline && t == 0)
+        {
+            timeline[6 * claim + 2] = wall_clock64();
+            timeline[6 * claim + 5] = clock64();
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t == 0)
             __hip_atomic_store(flags + chol_tile_index(cols, I, J), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (timeline && t == 0)
+            timeline[6 * claim + 3] = wall_clock64();
     }
 }
 
@@ -710,17 +922,17 @@ __global__ __launch_bounds__(LM_TG) void back_solve_regions_kernel(lm_matrix Lm,
             xb[t] = t < nb ? xw[k0 + t] : 0.0;
         __syncthreads();
         double s = 0;
-        if (t < nb)
+        if (t < nb) // (32 loads in flight: this kernel is a chain of memory round trips)
         {
-#pragma unroll
-            for (int m0 = 0; m0 < NB; m0 += 16)
+#pragma unroll 1
+            for (int m0 = 0; m0 < NB; m0 += 32)
             {
-                double v[16];
+                double v[32];
 #pragma unroll
-                for (int j = 0; j < 16; j++)
+                for (int j = 0; j < 32; j++)
                     v[j] = Li[(m0 + j) * NB + t];
 #pragma unroll
-                for (int j = 0; j < 16; j++)
+                for (int j = 0; j < 32; j++)
                     if (m0 + j >= t && m0 + j < nb)
                         s += v[j] * xb[m0 + j];
             }
@@ -732,24 +944,40 @@ __global__ __launch_bounds__(LM_TG) void back_solve_regions_kernel(lm_matrix Lm,
             xw[k0 + t] = s;
         }
         __syncthreads();
+        // the columns in reach of the block, four neighbouring ones per thread (every range starts and ends on a tile
+        // boundary, a tile's row is contiguous): 32-byte loads, 16 rows in flight - this kernel is a chain of memory round
+        // trips, so what counts is the bytes each one brings.  Per column the sum runs over the rows in order, as before.
         for (int pass = 0; pass < 2; pass++)
         {
             const int lo = pass ? lo1 : lo0, hi = pass ? hi1 : hi0;
-            for (int i = lo + t; i < hi; i += LM_TG)
+            for (int i = lo + 4 * t; i < hi; i += 4 * LM_TG)
             {
                 const double *Lc = L + ((size_t)lm_tile_index(Lm.cols, k, i >> 6) << 12) + (i & 63);
-                double u = 0;
-                for (int m0 = 0; m0 < nb; m0 += 16)
+                double u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+#pragma unroll 1
+                for (int m0 = 0; m0 < NB; m0 += 16)
                 {
-                    double v[16];
+                    v4f64 v[16];
 #pragma unroll
                     for (int j = 0; j < 16; j++)
-                        v[j] = m0 + j < nb ? Lc[(m0 + j) * NB] : 0.0;
+                        v[j] = m0 + j < nb ? *reinterpret_cast<const v4f64 *>(Lc + (m0 + j) * NB) : v4f64{0, 0, 0, 0};
 #pragma unroll
-                    for (int j = 0; j < 16; j++)
-                        u += v[j] * xb[m0 + j];
+                    for (int j = 0; j < 16; j++) // (the augmented row shares the last block's tile: rows >= nb are skipped)
+                    {
+                        const double xm = xb[m0 + j];
+                        u0 += v[j][0] * xm;
+                        u1 += v[j][1] * xm;
+                        u2 += v[j][2] * xm;
+                        u3 += v[j][3] * xm;
+                    }
                 }
-                xw[i] -= u;
+                xw[i] -= u0;
+                if (i + 1 < n)
+                    xw[i + 1] -= u1;
+                if (i + 2 < n)
+                    xw[i + 2] -= u2;
+                if (i + 3 < n)
+                    xw[i + 3] -= u3;
             }
         }
     };
@@ -1076,6 +1304,7 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
         // the tail rows' tiles in the same interleaved column order, then the tail's own columns.  Still every tile follows
         // the tiles it needs.
         std::vector<int> region_bounds; // [n_regions + 1], block indices; valid regions only
+        std::vector<int> korder;
         {
             const std::vector<int> &rb = s->env.region_begin;
             const int limit = std::min(tb, nbc); // (a last region that lies inside the tail's first block is part of the tail)
@@ -1105,6 +1334,9 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
                 rows_of(J, true, false);
             for (int J = region_bounds.back(); J < nbc; J++)
                 rows_of(J, true, true);
+            korder = band_cols; // the order in which the tail's own tiles sum over the band's columns (chol_tiles_kernel)
+            for (int J = region_bounds.back(); J < nbc; J++)
+                korder.push_back(J);
         }
         else if ((long)tail_tiles * 8 <= (long)slots)
         {
@@ -1157,8 +1389,12 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
             lm_dev_upload<unsigned int>(ctx, s->allocs, &s->chol_sync, nullptr, s->chol_sync_bytes / 4) != OCHIP_OK)
             return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (factorisation plan)");
         s->chol_cols = cols_dev;
+        s->chol_korder = nullptr;
         if (s->n_regions > 1)
         {
+            static const bool plain_order = getenv("OCHIP_CHOL_PLAIN_KORDER") != nullptr; // A/B knob
+            if (!plain_order && lm_dev_upload(ctx, s->allocs, &s->chol_korder, korder.data(), korder.size()) != OCHIP_OK)
+                return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (factorisation plan)");
             const size_t need = (size_t)s->n_regions * ((size_t)std::max(nn, 1) + 1);
             if (lm_dev_upload(ctx, s->allocs, &s->region_dev, region_bounds.data(), region_bounds.size()) != OCHIP_OK)
                 return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (regions of the factorisation)");
@@ -1353,9 +1589,45 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                     return ochip_fail(ctx, OCHIP_ENOMEM, "OCHIP_CHOL_VERIFY: device allocation failed");
                 OCHIP_HIP(ctx, hipMemcpyAsync(Wv, S.Wm, S.matrix_bytes(), hipMemcpyDeviceToDevice, st));
             }
+            // OCHIP_CHOL_TIMELINE=<file>: when each tile of the first large factorisation was claimed, had its operands summed,
+            // was factored / multiplied and was published (100 MHz ticks), one line per tile in claim order
+            static const bool unblocked_diag = getenv("OCHIP_CHOL_UNBLOCKED_DIAG") != nullptr; // A/B knob: rank-1 updates all the way
+            static const char *timeline_path = getenv("OCHIP_CHOL_TIMELINE");
+            static bool timeline_done = false;
+            unsigned long long *tl_dev = nullptr;
+            size_t tl_got = 0;
+            if (timeline_path && !timeline_done && n >= 1000)
+            {
+                tl_dev = (unsigned long long *)ochip_pool_get(ctx, (size_t)S.chol_n_tiles * 48, &tl_got);
+                if (tl_dev)
+                    OCHIP_HIP(ctx, hipMemsetAsync(tl_dev, 0, (size_t)S.chol_n_tiles * 48, st));
+            }
             hipLaunchKernelGGL(chol_tiles_kernel, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
                                (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_tiles, S.chol_tb, S.chol_sync, S.linv,
-                               S.fail_chol);
+                               S.fail_chol, tl_dev, (const int *)S.chol_korder, unblocked_diag ? 0 : 1);
+            if (tl_dev)
+            {
+                timeline_done = true;
+                std::vector<unsigned long long> tl((size_t)S.chol_n_tiles * 6);
+                std::vector<unsigned int> order((size_t)S.chol_n_tiles);
+                OCHIP_HIP(ctx, hipMemcpyAsync(tl.data(), tl_dev, tl.size() * 8, hipMemcpyDeviceToHost, st));
+                OCHIP_HIP(ctx, hipMemcpyAsync(order.data(), S.chol_tiles, order.size() * 4, hipMemcpyDeviceToHost, st));
+                OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+                ochip_pool_put(ctx, tl_dev, tl_got);
+                unsigned long long t0 = ~0ull;
+                for (size_t i = 0; i < tl.size(); i += 6)
+                    t0 = std::min(t0, tl[i]);
+                if (FILE *f = fopen(timeline_path, "w"))
+                {
+                    fprintf(f, "# n=%d tiles=%d tb=%d grid=%d regions=%d; us since the first claim: claim I J claimed summed computed published, shader cycles summed -> computed\n", n,
+                            S.chol_n_tiles, S.chol_tb, S.chol_grid, S.n_regions);
+                    for (size_t i = 0; i < order.size(); i++)
+                        fprintf(f, "%zu %u %u %.2f %.2f %.2f %.2f %llu\n", i, order[i] & 0xFFFFu, order[i] >> 16, (tl[6 * i] - t0) * 0.01,
+                                (tl[6 * i + 1] - t0) * 0.01, (tl[6 * i + 2] - t0) * 0.01, (tl[6 * i + 3] - t0) * 0.01,
+                                tl[6 * i + 5] - tl[6 * i + 4]);
+                    fclose(f);
+                }
+            }
             launch_chain(S.Wm, S.linv, false, true);
             if (verify)
             {

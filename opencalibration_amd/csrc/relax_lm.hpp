@@ -82,6 +82,7 @@ struct lm_system
     std::vector<lm_col> cols_host;
     unsigned int *tile_ij = nullptr; // tiles in storage order: row block | column block << 16
     int *chol_kmin = nullptr;        // per row block: first column block whose envelope reaches it
+    int *chol_korder = nullptr;      // regions only: the order in which a tile of the tail's columns takes the band's columns
     unsigned int *chol_tiles = nullptr; // tiles in claim order: row block | column block << 16
     unsigned int *chol_sync = nullptr;  // [0] claim counter, [4 + tile] done flags; zeroed before every factorisation
     int chol_n_tiles = 0, chol_nbc = 0, chol_nbr = 0, chol_tb = 0, chol_grid = 0;
