@@ -414,15 +414,20 @@ __global__ void relax_scatter_kernel(relax_dev P, lm_matrix A, double *g, int n,
         scatter_pair(P, A, n, (blockIdx.x - cam_blocks) * blockDim.x + threadIdx.x);
 }
 
-// One workgroup: plane-plane block, plane gradient, total cost (pairs + priors).  scal[0] = cost.
+// Plane-plane block, plane gradient, total cost (pairs + priors); scal[0] = cost.  REDUCE_GROUPS workgroups each sum a
+// fixed share of the pairs and cameras (one workgroup took 33 us of an iteration: 35 dependent trips to memory per thread),
+// the one that finishes last adds the groups' sums in group order - the same result whoever that is.
+constexpr int REDUCE_GROUPS = 32;
 __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm_matrix A, double *g, int n,
                                                                  const uint8_t *cam_has_prior, double *scal,
-                                                                 int with_jac, int which_state)
+                                                                 int with_jac, int which_state, double *partials /*[groups][10]*/,
+                                                                 unsigned int *arrived)
 {
     __shared__ double sh[256];
-    const int t = threadIdx.x;
+    __shared__ int s_last;
+    const int t = threadIdx.x, b = blockIdx.x, groups = gridDim.x;
     double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // zz (6), gz (3), cost
-    for (uint32_t pr = t; pr < P.n_pairs; pr += 256)
+    for (uint32_t pr = b * 256 + t; pr < P.n_pairs; pr += 256 * groups)
     {
         if (with_jac)
         {
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
         v[9] += P.pair_cost[pr];
     }
     const double *Q = which_state ? P.cam_q2 : P.cam_q;
-    for (uint32_t c = t; c < P.n_cams; c += 256)
+    for (uint32_t c = b * 256 + t; c < P.n_cams; c += 256 * groups)
         if (cam_has_prior[c] && P.cam_t[c] >= 0) // priors of constant cameras are fixed cost (not in the reduced program)
         {
             double r, j3[3];
@@ -446,6 +451,8 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
         }
     for (int q = 0; q < 10; q++)
     {
+        if (!with_jac && q < 9)
+            continue;
         sh[t] = v[q];
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1)
@@ -460,23 +467,38 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
     }
     if (t == 0)
     {
-        scal[0] = v[9];
-        if (with_jac)
+        for (int q = 0; q < 10; q++)
+            __hip_atomic_store(&partials[b * 10 + q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(groups - 1);
+        if (s_last)
         {
-            int k = 0;
-            for (int i = 0; i < 3; i++)
-                for (int j = i; j < 3; j++)
-                {
-                    const int ti = P.z_t[i], tj = P.z_t[j];
-                    if (ti >= 0 && tj >= 0)
+            for (int q = 0; q < 10; q++)
+            {
+                double sum = 0;
+                for (int w = 0; w < groups; w++)
+                    sum += __hip_atomic_load(&partials[w * 10 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[q] = sum;
+            }
+            __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            scal[0] = v[9];
+            if (with_jac)
+            {
+                int k = 0;
+                for (int i = 0; i < 3; i++)
+                    for (int j = i; j < 3; j++)
                     {
-                        A.tiles[lm_at(A, ti > tj ? ti : tj, ti > tj ? tj : ti)] = v[k];
+                        const int ti = P.z_t[i], tj = P.z_t[j];
+                        if (ti >= 0 && tj >= 0)
+                        {
+                            A.tiles[lm_at(A, ti > tj ? ti : tj, ti > tj ? tj : ti)] = v[k];
+                        }
+                        k++;
                     }
-                    k++;
-                }
-            for (int i = 0; i < 3; i++)
-                if (P.z_t[i] >= 0)
-                    g[P.z_t[i]] = v[6 + i];
+                for (int i = 0; i < 3; i++)
+                    if (P.z_t[i] >= 0)
+                        g[P.z_t[i]] = v[6 + i];
+            }
         }
     }
 }
@@ -590,6 +612,8 @@ struct ochip_relax_problem
     uint8_t z_optimize[3] = {1, 1, 1};
     bool cams_frozen = false;
     uint8_t *cam_has_prior = nullptr, *cam_optimize_dev = nullptr;
+    double *reduce_partials = nullptr; // relax_reduce_plane_kernel: the groups' sums, then its arrival counter
+    unsigned int *reduce_arrived = nullptr;
     lm_system sys; // the reduced normal equations and their block envelope (assign_tangent), relax_lm.hpp
     std::vector<uint32_t> pair_p_h, pair_q_h; // host copies of the camera pairs
     uint32_t n_cams = 0;
@@ -696,7 +720,8 @@ int assign_tangent(ochip_relax_problem *p)
         // separator, and so on; the separators go to the end of the order, in front of the plane unknowns, and are the
         // tail of the envelope (dense rows).  Regions are then linked to separators only, their chains of tiles are
         // independent (lm_envelope::region_begin), and the critical path is the longest region plus the tail.  g is
-        // chosen to make that shortest; no dissection when it does not shorten the path to 0.7 of the single chain.
+        // chosen to make that shortest (a separator camera counted 1.5 times); no dissection when it does not shorten the
+        // path to 0.8 of the single chain.
         const bool use_dissect = !(getenv("OCHIP_RELAX_DISSECT") && getenv("OCHIP_RELAX_DISSECT")[0] == '0');
         if (use_dissect && order.size() >= 4 * (size_t)NB)
         {
@@ -737,7 +762,9 @@ int assign_tangent(ochip_relax_problem *p)
                 if (state_out)
                     state_out->swap(state);
                 *n_regions = regions;
-                return longest + seps;
+                // (a column of the tail costs more than a column of a region: its tiles first sum over the whole band.
+                // Measured at n = 3003: g = 128 / 192 / 256 / 320 / 448 cameras -> 684 / 605 / 598 / 592 / 764 us.)
+                return longest + seps + seps / 2;
             };
             int best_g = 0, best_path = N, regions = 0;
             const int forced_g = getenv("OCHIP_RELAX_DISSECT_G") ? atoi(getenv("OCHIP_RELAX_DISSECT_G")) / NB * NB : 0; // A/B knob
@@ -748,7 +775,7 @@ int assign_tangent(ochip_relax_problem *p)
                 if (path >= 0 && path < best_path)
                     best_path = path, best_g = g;
             }
-            if (best_g > 0 && 10 * best_path <= 7 * N)
+            if (best_g > 0 && 10 * best_path <= 8 * N)
             {
                 std::vector<int> state;
                 cut(best_g, &state, &regions);
@@ -1149,20 +1176,35 @@ struct plane_model final : lm_model
             hipLaunchKernelGGL(relax_scatter_kernel, dim3(cam_blocks + pair_blocks), dim3(256), 0, st, D, p->sys.matA(), p->sys.g, n,
                                p->cam_has_prior, cam_blocks);
         }
-        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(1), dim3(256), 0, st, D, p->sys.matA(), p->sys.g, n, p->cam_has_prior,
-                           p->sys.scal, with_jac ? 1 : 0, which);
+        if (!p->reduce_partials)
+        {
+            const int arc = dev_upload<double>(p, &p->reduce_partials, nullptr, (size_t)REDUCE_GROUPS * 10 + 2);
+            if (arc != OCHIP_OK)
+                return arc;
+            p->reduce_arrived = reinterpret_cast<unsigned int *>(p->reduce_partials + (size_t)REDUCE_GROUPS * 10);
+            OCHIP_HIP(ctx, hipMemsetAsync(p->reduce_arrived, 0, 8, st));
+        }
+        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(REDUCE_GROUPS), dim3(256), 0, st, D, p->sys.matA(), p->sys.g, n,
+                           p->cam_has_prior, p->sys.scal, with_jac ? 1 : 0, which, p->reduce_partials, p->reduce_arrived);
         OCHIP_HIP(ctx, hipGetLastError());
-        double h0 = 0;
-        OCHIP_HIP(ctx, hipMemcpyAsync(&h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
-        std::vector<int32_t> hfails(p->shard_world, 0);
-        OCHIP_HIP(ctx, hipMemcpyAsync(hfails.data(), p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
+        // (read-backs into the system's page-locked block: a copy to pageable memory would make the host wait for it)
+        std::vector<int32_t> hfails_pageable;
+        double *const h0 = p->sys.box + lm_system::BOX_COST;
+        int32_t *hfails = reinterpret_cast<int32_t *>(p->sys.box + lm_system::BOX_FAILS);
+        if (p->shard_world > 2 * (lm_system::BOX_VECTORS - lm_system::BOX_FAILS))
+        {
+            hfails_pageable.assign(p->shard_world, 0);
+            hfails = hfails_pageable.data();
+        }
+        OCHIP_HIP(ctx, hipMemcpyAsync(h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(hfails, p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
         if (before_wait)
             before_wait();
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
-        *cost = h0;
+        *cost = *h0;
         int hfail = 0;
-        for (int32_t f : hfails)
-            hfail |= f;
+        for (int r = 0; r < (int)p->shard_world; r++)
+            hfail |= hfails[r];
         return hfail ? 1 : 0;
     }
     void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override

@@ -1304,17 +1304,24 @@ struct general_model final : lm_model
         hipLaunchKernelGGL(cost_reduce_kernel, dim3(1), dim3(LM_TG), 0, st, (const double *)D.rec_cost, (const double *)p->cost_slices_dev,
                            n_slices, D.prior_base, n_prior, p->sys.scal);
         OCHIP_HIP(ctx, hipGetLastError());
-        double h0 = 0;
-        std::vector<int32_t> hfails(p->shard_world, 0);
-        OCHIP_HIP(ctx, hipMemcpyAsync(&h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(hfails.data(), p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
+        // (read-backs into the system's page-locked block: a copy to pageable memory would make the host wait for it)
+        std::vector<int32_t> hfails_pageable;
+        double *const h0 = p->sys.box + lm_system::BOX_COST;
+        int32_t *hfails = reinterpret_cast<int32_t *>(p->sys.box + lm_system::BOX_FAILS);
+        if (p->shard_world > 2 * (lm_system::BOX_VECTORS - lm_system::BOX_FAILS))
+        {
+            hfails_pageable.assign(p->shard_world, 0);
+            hfails = hfails_pageable.data();
+        }
+        OCHIP_HIP(ctx, hipMemcpyAsync(h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(hfails, p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
         if (before_wait)
             before_wait();
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
-        *cost = h0;
+        *cost = *h0;
         int hfail = 0;
-        for (int32_t f : hfails)
-            hfail |= f;
+        for (int r = 0; r < (int)p->shard_world; r++)
+            hfail |= hfails[r];
         return hfail ? 1 : 0;
     }
     void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override

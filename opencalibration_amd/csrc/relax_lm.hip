@@ -572,16 +572,25 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
         if (claim >= n_tiles)
             return;
         const unsigned int ij = tiles[claim];
-        const int I = (int)(ij & 0xFFFFu), J = (int)(ij >> 16);
+        const int I = (int)(ij & 0xFFFFu);
+        int J = (int)((ij >> 16) & 0x7FFFu);
+        // bit 31: tile (J + 1, J) with the diagonal tile (J + 1, J + 1) behind it.  The timeline showed two hand-overs on a
+        // column's critical path - diagonal tile -> the tile below it -> the next diagonal tile, 8 - 9 us each (flag,
+        // acquire, operands back from memory) beside 19 us of factorisation.  The workgroup that owns the tile below the
+        // diagonal therefore goes on to the next diagonal tile itself: it has summed that tile's earlier steps along with
+        // its own (they read the same row of tiles), keeps its product in LDS for the last step, and starts to factor
+        // without waiting for anybody.
+        const bool fuse = (ij >> 31) != 0u;
         if (timeline && t == 0) // OCHIP_CHOL_TIMELINE: claimed / operands summed / factored or multiplied / published
             timeline[6 * claim] = wall_clock64();
-        const int r0 = I * 64, c0 = J * 64;
-        const int nb = min(64, n - c0); // columns of this block column
+        const int r0 = I * 64;
+        int c0 = J * 64;
+        int nb = min(64, n - c0); // columns of this block column
         const int k_begin = I < tb ? kmin[I] : (J >= tb ? 0 : kmin[J]);
-        v4f64 acc[2][2];
+        v4f64 acc[2][2], accd[2][2];
         for (int i = 0; i < 2; i++)
             for (int j = 0; j < 2; j++)
-                acc[i][j] = v4f64{0, 0, 0, 0};
+                acc[i][j] = accd[i][j] = v4f64{0, 0, 0, 0};
         // A tile of the tail's own columns sums over every column of the band.  When the band falls into regions (korder
         // given), it takes them in the order the regions' chains produce them - the regions' first columns, their second
         // columns, ... - instead of waiting for the whole first region before it touches the second: its steps then run
@@ -600,6 +609,22 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                     const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
                     own[i][j][e] = (r0 + r < n_rows && c < nb) ? wt[r * NB + c] : 0.0;
                 }
+        double *wt_d = fuse ? W + ((size_t)chol_tile_index(cols, I, I) << 12) : wt;
+        const int nb_d = min(64, n - r0);
+        double own_d[2][2][4];
+        if (fuse)
+        {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                    {
+                        const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
+                        own_d[i][j][e] = (r0 + r < n_rows && c < nb_d) ? wt_d[r * NB + c] : 0.0;
+                    }
+        }
         const bool mapped = korder != nullptr && J >= tb;
         int ready = k_begin; // steps whose operands are known to be complete (the same value in every thread)
         for (int step = k_begin; step < J; step++)
@@ -657,6 +682,14 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                     acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
                     acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
                     acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+                    if (fuse) // the same step of the diagonal tile (I, I): L(I, K) L(I, K)'
+                    {
+                        const double d0 = Pi[wc + lr][kk + lk], d1 = Pi[wc + 16 + lr][kk + lk];
+                        accd[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, d0, accd[0][0], 0, 0, 0);
+                        accd[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, d1, accd[0][1], 0, 0, 0);
+                        accd[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, d0, accd[1][0], 0, 0, 0);
+                        accd[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, d1, accd[1][1], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -665,6 +698,8 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
             timeline[6 * claim + 1] = wall_clock64();
             timeline[6 * claim + 4] = clock64(); // shader clock: cycles the factor / product took
         }
+        bool second = false; // fused: the diagonal tile (I, I) after the tile (I, J) below the previous diagonal tile
+      finish_tile:
         // T = A(I, J) - acc (the tile's own entries were written by the launch before this one)
         __syncthreads();
 #pragma unroll
@@ -675,7 +710,7 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                 for (int e = 0; e < 4; e++)
                 {
                     const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
-                    T[r][c] = own[i][j][e] - acc[i][j][e];
+                    T[r][c] = second ? own_d[i][j][e] - accd[i][j][e] : own[i][j][e] - acc[i][j][e];
                 }
         __syncthreads();
         if (I == J)
@@ -795,9 +830,32 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                         if (r0 + r < n_rows && c < nb)
                             store_through(&wt[r * NB + c], acc[i][j][e]);
                     }
+            if (fuse)
+            {
+                // the last step of the diagonal tile out of LDS: X X' with X = L(I, J) as just computed
+                __syncthreads();
+                for (int i = 0; i < 2; i++)
+                    for (int j = 0; j < 2; j++)
+                        for (int e = 0; e < 4; e++)
+                        {
+                            const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
+                            Pi[r][c] = (r0 + r < n_rows && c < nb) ? acc[i][j][e] : 0.0;
+                        }
+                __syncthreads();
+#pragma unroll
+                for (int kk = 0; kk < KC; kk += 4)
+                {
+                    const double a0 = Pi[wr + lr][kk + lk], a1 = Pi[wr + 16 + lr][kk + lk];
+                    const double d0 = Pi[wc + lr][kk + lk], d1 = Pi[wc + 16 + lr][kk + lk];
+                    accd[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, d0, accd[0][0], 0, 0, 0);
+                    accd[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, d1, accd[0][1], 0, 0, 0);
+                    accd[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, d0, accd[1][0], 0, 0, 0);
+                    accd[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, d1, accd[1][1], 0, 0, 0);
+                }
+            }
         }
         // publish: every storing wave drained, barrier, one lane sets the flag
-        if (timeline && t == 0)
+        if (timeline && t == 0 && !second)
         {
             timeline[6 * claim + 2] = wall_clock64();
             timeline[6 * claim + 5] = clock64();
@@ -807,7 +865,16 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
         if (t == 0)
             __hip_atomic_store(flags + chol_tile_index(cols, I, J), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (timeline && t == 0)
-            timeline[6 * claim + 3] = wall_clock64();
+            timeline[6 * claim + 3] = wall_clock64(); // (fused: when the diagonal tile was published)
+        if (fuse && !second)
+        {
+            second = true;
+            J = I;
+            c0 = J * 64;
+            nb = nb_d;
+            wt = wt_d;
+            goto finish_tile;
+        }
     }
 }
 
@@ -1218,11 +1285,34 @@ double interpolated_step(const ls_sample &at0, const ls_sample &previous, const 
 namespace ochip
 {
 
+lm_system::~lm_system()
+{
+    if (box && ctx)
+        ochip_host_free(ctx, box);
+}
+
 int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
 {
     ochip_ctx *ctx = s->ctx;
     s->env = env;
     s->n = n_in;
+    {
+        const size_t need = (size_t)lm_system::BOX_VECTORS + 2 * (size_t)std::max(n_in, 1);
+        if (need > s->box_cap)
+        {
+            if (s->box)
+                ochip_host_free(ctx, s->box);
+            s->box = nullptr;
+            s->box_cap = 0;
+            void *b = nullptr;
+            if (ochip_host_alloc(ctx, need * sizeof(double), &b) != OCHIP_OK || !b)
+                return ochip_fail(ctx, OCHIP_ENOMEM, "page-locked host allocation for the solve's read-backs failed (%zu doubles)", need);
+            s->box = static_cast<double *>(b);
+            s->box_cap = need;
+            for (size_t i = 0; i < need; i++)
+                s->box[i] = 0.0;
+        }
+    }
     if (lm_dev_upload(ctx, s->allocs, &s->first_col_dev, s->env.first_col.data(), s->env.first_col.size()) != OCHIP_OK)
         return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (envelope)");
     const size_t n = (size_t)std::max(n_in, 1);
@@ -1283,13 +1373,33 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
         // claimed tile only ever waits for tiles claimed before it - already running - and no co-residency is needed.
         std::vector<unsigned int> order;
         order.reserve((size_t)n_tiles);
+        // Fused pairs (chol_tiles_kernel): the tile (J + 1, J) is followed, in the same workgroup, by the diagonal tile
+        // (J + 1, J + 1), which then has no entry of its own - where both sum over the same range of columns: inside the
+        // band, and among the tail's own columns (the first tail block's diagonal tile sums over the whole band, the tile
+        // beside it does not).  Bit 31 marks the pair.
+        static const bool no_fuse = getenv("OCHIP_CHOL_NO_FUSE") != nullptr; // A/B knob
+        std::vector<char> fused_diag((size_t)std::max(nbc, 1) + 1, 0);
+        if (!no_fuse)
+            for (int J = 0; J + 1 < nbc; J++)
+            {
+                const int I = J + 1;
+                const bool stored = I < cols[J].bend || I >= cols[J].tail_start;
+                if (stored && (I < tb || J >= tb))
+                    fused_diag[(size_t)I] = 1;
+            }
+        auto push_tile = [&](int I, int J) {
+            if (I == J && fused_diag[(size_t)I])
+                return;
+            const unsigned int pair = (I == J + 1 && fused_diag[(size_t)I]) ? 0x80000000u : 0u;
+            order.push_back((unsigned int)I | ((unsigned int)J << 16) | pair);
+        };
         auto rows_of = [&](int J, bool want_tail, bool want_band) {
             for (int I = J; I < cols[J].bend; I++)
                 if ((I >= tb) ? want_tail : want_band)
-                    order.push_back((unsigned int)I | ((unsigned int)J << 16));
+                    push_tile(I, J);
             for (int I = cols[J].tail_start; I < nbr; I++)
                 if (want_tail)
-                    order.push_back((unsigned int)I | ((unsigned int)J << 16));
+                    push_tile(I, J);
         };
         size_t tail_tiles = 0;
         for (int J = 0; J < nbc; J++)
@@ -1348,13 +1458,18 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
         else
             for (int J = 0; J < nbc; J++)
                 rows_of(J, true, true);
-        if (nbr >= 65536 || (int)order.size() != n_tiles)
-            return ochip_fail(ctx, OCHIP_EINVAL, "relax: factorisation plan is inconsistent (%d tiles, %zu listed)", n_tiles, order.size());
+        int n_fused = 0;
+        for (int I = 0; I < nbc; I++)
+            n_fused += fused_diag[(size_t)I];
+        if (nbr >= 32768 || (int)order.size() + n_fused != n_tiles)
+            return ochip_fail(ctx, OCHIP_EINVAL, "relax: factorisation plan is inconsistent (%d tiles, %zu listed, %d fused)", n_tiles,
+                              order.size(), n_fused);
         s->chol_n_tiles = n_tiles;
+        s->chol_n_claims = (int)order.size();
         s->chol_nbc = nbc;
         s->chol_nbr = nbr;
         s->chol_tb = tb;
-        s->chol_grid = std::max(1, std::min(n_tiles, slots));
+        s->chol_grid = std::max(1, std::min((int)order.size(), slots));
         s->chol_sync_bytes = (((size_t)n_tiles + 4) * 4 + 15) / 16 * 16;
         // tiles in storage order, and the matrices themselves
         std::vector<unsigned int> stored((size_t)std::max(n_tiles, 1), 0u);
@@ -1448,7 +1563,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
     ochip_ctx *ctx = S.ctx;
     hipStream_t st = ctx->stream;
     const int n = S.n;
-    double h[8];
+    double *const h = S.box + lm_system::BOX_SCAL; // (page-locked: relax_lm.hpp, lm_system::box)
     const bool eliminated = M.has_eliminated();
     M.begin_solve();
     auto grad_and_diag = [&](double *gmax) -> int {
@@ -1471,7 +1586,8 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         return ochip_stream_wait(ctx, st);
     };
 
-    std::vector<double> diag(n), scale(n, 1.0), lmd(n), diagonal(n, 0.0);
+    std::vector<double> scale(n, 1.0), diagonal(n, 0.0);
+    double *const diag = S.box + lm_system::BOX_VECTORS, *const lmd = diag + std::max(n, 1);
     double x_cost = 0, gmax = 0;
     int erc = M.evaluate(true, 0, &x_cost);
     if (erc < 0)
@@ -1485,7 +1601,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
     int rc = grad_and_diag(&gmax);
     if (rc)
         return rc;
-    OCHIP_HIP(ctx, hipMemcpy(diag.data(), S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost));
+    OCHIP_HIP(ctx, hipMemcpy(diag, S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++)
         scale[i] = 1.0 / (1.0 + std::sqrt(diag[i])); // jacobi scaling, fixed from the first Jacobian
     OCHIP_HIP(ctx, hipMemcpy(S.scale, scale.data(), (size_t)n * 8, hipMemcpyHostToDevice));
@@ -1523,7 +1639,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             const double dd = std::sqrt(diagonal[i] / radius);
             lmd[i] = dd * dd;
         }
-        OCHIP_HIP(ctx, hipMemcpyAsync(S.lm_diag, lmd.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(S.lm_diag, lmd, (size_t)n * 8, hipMemcpyHostToDevice, st));
         hipEvent_t e0, e1;
         ochip_prof_begin(ctx, OCHIP_K_RELAX_SOLVE, &e0, &e1);
         if (n > 0)
@@ -1603,26 +1719,26 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                     OCHIP_HIP(ctx, hipMemsetAsync(tl_dev, 0, (size_t)S.chol_n_tiles * 48, st));
             }
             hipLaunchKernelGGL(chol_tiles_kernel, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
-                               (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_tiles, S.chol_tb, S.chol_sync, S.linv,
+                               (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_claims, S.chol_tb, S.chol_sync, S.linv,
                                S.fail_chol, tl_dev, (const int *)S.chol_korder, unblocked_diag ? 0 : 1);
             if (tl_dev)
             {
                 timeline_done = true;
                 std::vector<unsigned long long> tl((size_t)S.chol_n_tiles * 6);
-                std::vector<unsigned int> order((size_t)S.chol_n_tiles);
+                std::vector<unsigned int> order((size_t)S.chol_n_claims);
                 OCHIP_HIP(ctx, hipMemcpyAsync(tl.data(), tl_dev, tl.size() * 8, hipMemcpyDeviceToHost, st));
                 OCHIP_HIP(ctx, hipMemcpyAsync(order.data(), S.chol_tiles, order.size() * 4, hipMemcpyDeviceToHost, st));
                 OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
                 ochip_pool_put(ctx, tl_dev, tl_got);
                 unsigned long long t0 = ~0ull;
-                for (size_t i = 0; i < tl.size(); i += 6)
-                    t0 = std::min(t0, tl[i]);
+                for (size_t i = 0; i < order.size(); i++)
+                    t0 = std::min(t0, tl[6 * i]);
                 if (FILE *f = fopen(timeline_path, "w"))
                 {
                     fprintf(f, "# n=%d tiles=%d tb=%d grid=%d regions=%d; us since the first claim: claim I J claimed summed computed published, shader cycles summed -> computed\n", n,
                             S.chol_n_tiles, S.chol_tb, S.chol_grid, S.n_regions);
                     for (size_t i = 0; i < order.size(); i++)
-                        fprintf(f, "%zu %u %u %.2f %.2f %.2f %.2f %llu\n", i, order[i] & 0xFFFFu, order[i] >> 16, (tl[6 * i] - t0) * 0.01,
+                        fprintf(f, "%zu %u %u%s %.2f %.2f %.2f %.2f %llu\n", i, order[i] & 0xFFFFu, (order[i] >> 16) & 0x7FFFu, (order[i] >> 31) ? "+" : "", (tl[6 * i] - t0) * 0.01,
                                 (tl[6 * i + 1] - t0) * 0.01, (tl[6 * i + 2] - t0) * 0.01, (tl[6 * i + 3] - t0) * 0.01,
                                 tl[6 * i + 5] - tl[6 * i + 4]);
                     fclose(f);
@@ -1677,11 +1793,12 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         // factorisation's failure flag - come back with that evaluation's wait instead of a host round trip of their own.
         // An invalid step (rare) has then cost one evaluation whose result is ignored.
         static const bool separate_waits = getenv("OCHIP_LM_SEPARATE_WAITS") != nullptr; // A/B knob: a wait per read-back
-        int cfail = 0;
+        volatile int &cfail = *reinterpret_cast<volatile int *>(S.box + lm_system::BOX_CFAIL);
+        cfail = 0;
         double cand_eval = 0;
         auto read_step = [&]() {
             (void)hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st);
-            (void)hipMemcpyAsync(&cfail, S.fail_chol, 4, hipMemcpyDeviceToHost, st);
+            (void)hipMemcpyAsync(S.box + lm_system::BOX_CFAIL, S.fail_chol, 4, hipMemcpyDeviceToHost, st);
         };
         if (separate_waits)
         {
@@ -1838,7 +1955,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                 hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(LM_TG), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal);
                 (void)hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st);
                 if (n > 0)
-                    (void)hipMemcpyAsync(diag.data(), S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost, st);
+                    (void)hipMemcpyAsync(diag, S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost, st);
             };
             if (!separate_waits)
                 M.before_wait = read_gradient;

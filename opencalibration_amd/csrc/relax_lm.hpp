@@ -86,6 +86,7 @@ struct lm_system
     unsigned int *chol_tiles = nullptr; // tiles in claim order: row block | column block << 16
     unsigned int *chol_sync = nullptr;  // [0] claim counter, [4 + tile] done flags; zeroed before every factorisation
     int chol_n_tiles = 0, chol_nbc = 0, chol_nbr = 0, chol_tb = 0, chol_grid = 0;
+    int chol_n_claims = 0; // entries of chol_tiles (a fused pair of tiles is one entry)
     size_t chol_sync_bytes = 0;
     // regions of the band (lm_envelope::region_begin): block bounds [n_regions + 1] (the last one = chol_tb), and the
     // backward substitution's private work vectors, [n_regions][n] + [n_regions] partial sums
@@ -93,6 +94,16 @@ struct lm_system
     int *region_dev = nullptr;
     double *back_work = nullptr;
     size_t back_work_cap = 0;
+    // Page-locked host block the solve's read-backs and uploads go through: a hipMemcpyAsync to or from pageable memory is
+    // staged and makes the host wait for the copy itself - the solver's and the engines' small read-backs (cost, flags,
+    // step norms, diagonal) were eight such round trips per LM iteration beside the two waits it needs.
+    // Layout (doubles): [0, 8) the solver's copy of scal, [8] the engine's cost, [9] the factorisation's failure flag (int),
+    // [16, 32) the engines' failure flags (int32 per rank, at most 32 ranks), [32, 32 + n) diagonal of J'J,
+    // [32 + n, 32 + 2 n) LM diagonal on its way up.
+    double *box = nullptr;
+    size_t box_cap = 0;
+    static constexpr int BOX_SCAL = 0, BOX_COST = 8, BOX_CFAIL = 9, BOX_FAILS = 16, BOX_VECTORS = 32, BOX_MAX_RANKS = 32;
+    ~lm_system();
     lm_matrix matA() const
     {
         return lm_matrix{A, chol_cols};

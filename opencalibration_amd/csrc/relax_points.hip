@@ -837,15 +837,16 @@ struct points_model final : lm_model
         ochip_prof_end(ctx, OCHIP_K_RELAX_EVAL, e0, e1);
         hipLaunchKernelGGL(p_reduce_kernel, dim3(1), dim3(LM_TG), 0, st, D, with_jac ? 1 : 0, p->sys.scal);
         OCHIP_HIP(ctx, hipGetLastError());
-        double h0 = 0;
-        int32_t hfail = 0;
-        OCHIP_HIP(ctx, hipMemcpyAsync(&h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(&hfail, D.fail, 4, hipMemcpyDeviceToHost, st));
+        // (read-backs into the system's page-locked block: a copy to pageable memory would make the host wait for it)
+        double *const h0 = p->sys.box + lm_system::BOX_COST;
+        int32_t *const hfail = reinterpret_cast<int32_t *>(p->sys.box + lm_system::BOX_FAILS);
+        OCHIP_HIP(ctx, hipMemcpyAsync(h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpyAsync(hfail, D.fail, 4, hipMemcpyDeviceToHost, st));
         if (before_wait)
             before_wait();
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
-        *cost = h0;
-        return hfail ? 1 : 0;
+        *cost = *h0;
+        return *hfail ? 1 : 0;
     }
     int gradient_max_extra(double *out) override
     {

@@ -86,9 +86,10 @@ def test_c5_survey_at_size(oracle):
     # below reach them)
     assert np.median(err) < 1e-3 and np.sum(err > 0.02) < n // 10
     # storage of the reduced system: the tiles of its block envelope, not n^2 (dense: J'J and the factor of 15 003 unknowns
-    # are 3.6 GB; the reference gives the system to SPARSE_NORMAL_CHOLESKY, relax_problem.cpp:30-37)
+    # are 3.6 GB; the reference gives the system to SPARSE_NORMAL_CHOLESKY, relax_problem.cpp:30-37).  101 MB as one band;
+    # the dissected camera graph (regions factored side by side) keeps its separators' rows dense under every column: 0.4 GB
     unknowns, stored, dense = ctx.relax_memory()
-    assert 3 * (n - 500) <= unknowns <= 3 * n + 3 and dense > 3.0e9 and stored < dense / 10
+    assert 3 * (n - 500) <= unknowns <= 3 * n + 3 and dense > 3.0e9 and stored < dense / 6
     print("C5 plane group: unknowns", unknowns, "system stored MB", round(stored / 1e6, 1), "dense MB", round(dense / 1e6, 1))
     seed = host.rebuild_mesh(grid.position, plane["surface"], minimal=True)
     sa = seed.arrays()
