@@ -545,14 +545,13 @@ __device__ __forceinline__ void store_through(double *p, double v) // global_sto
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <int KC>
 __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const chol_col *__restrict__ cols,
                                                          const int *__restrict__ kmin, const unsigned int *__restrict__ tiles,
                                                          int n_tiles, int tb, unsigned int *sync, double *linv, int *fail,
                                                          unsigned long long *timeline, const int *__restrict__ korder, int blocked_diag)
 {
-    // (KC was 32 until the timeline showed what a column costs beside its diagonal tile: memory round trips.  One
-    // workgroup per compute unit is resident anyway, so the whole 64 x 64 operands go through LDS at once: 104 KB.)
-    constexpr int KC = 64;
+    // KC = 32: a step's operands go through LDS in two halves (71 KB per workgroup); KC = 64: whole (104 KB) - see the launch.
     __shared__ double T[64][65];
     __shared__ double Pi[64][KC + 1], Pj[64][KC + 1];
     __shared__ double colA[4][NB], rowX[4][NB]; // two pivots per step, double-buffered
@@ -839,14 +838,14 @@ __global__ __launch_bounds__(256) void chol_tiles_kernel(double *W, int n, const
                         for (int e = 0; e < 4; e++)
                         {
                             const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
-                            Pi[r][c] = (r0 + r < n_rows && c < nb) ? acc[i][j][e] : 0.0;
+                            T[r][c] = (r0 + r < n_rows && c < nb) ? acc[i][j][e] : 0.0; // (T's own content went into the product)
                         }
                 __syncthreads();
 #pragma unroll
-                for (int kk = 0; kk < KC; kk += 4)
+                for (int kk = 0; kk < 64; kk += 4)
                 {
-                    const double a0 = Pi[wr + lr][kk + lk], a1 = Pi[wr + 16 + lr][kk + lk];
-                    const double d0 = Pi[wc + lr][kk + lk], d1 = Pi[wc + 16 + lr][kk + lk];
+                    const double a0 = T[wr + lr][kk + lk], a1 = T[wr + 16 + lr][kk + lk];
+                    const double d0 = T[wc + lr][kk + lk], d1 = T[wc + 16 + lr][kk + lk];
                     accd[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, d0, accd[0][0], 0, 0, 0);
                     accd[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, d1, accd[0][1], 0, 0, 0);
                     accd[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, d0, accd[1][0], 0, 0, 0);
@@ -1361,7 +1360,7 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
             kmin[b] = std::min(K, b);
         }
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_tiles_kernel, 256, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_tiles_kernel<32>, 256, 0) != hipSuccess || per_cu < 1)
             per_cu = 1;
         const int slots = per_cu * ctx->prop.multiProcessorCount;
         // claim order: the tail's rows first (their sums run along the whole factorisation), then the band, each column
@@ -1718,9 +1717,18 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                 if (tl_dev)
                     OCHIP_HIP(ctx, hipMemsetAsync(tl_dev, 0, (size_t)S.chol_n_tiles * 48, st));
             }
-            hipLaunchKernelGGL(chol_tiles_kernel, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
-                               (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_claims, S.chol_tb, S.chol_sync, S.linv,
-                               S.fail_chol, tl_dev, (const int *)S.chol_korder, unblocked_diag ? 0 : 1);
+            // operands through LDS in halves (71 KB per workgroup) unless OCHIP_CHOL_KC=64 (whole, 104 KB): measured equal
+            // alone (1 026 against 1 009 LM iterations/s at n = 3003) and better beside the extraction's kernels, whose
+            // workgroups leave 71 KB free on a compute unit sooner than 104 (208 against 193 in the pipeline)
+            static const bool kc32 = !(getenv("OCHIP_CHOL_KC") && atoi(getenv("OCHIP_CHOL_KC")) == 64); // A/B knob
+            if (kc32)
+                hipLaunchKernelGGL(chol_tiles_kernel<32>, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
+                                   (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_claims, S.chol_tb, S.chol_sync,
+                                   S.linv, S.fail_chol, tl_dev, (const int *)S.chol_korder, unblocked_diag ? 0 : 1);
+            else
+                hipLaunchKernelGGL(chol_tiles_kernel<64>, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
+                                   (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_claims, S.chol_tb, S.chol_sync,
+                                   S.linv, S.fail_chol, tl_dev, (const int *)S.chol_korder, unblocked_diag ? 0 : 1);
             if (tl_dev)
             {
                 timeline_done = true;
