@@ -423,7 +423,6 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
                                                                  int with_jac, int which_state, double *partials /*[groups][10]*/,
                                                                  unsigned int *arrived)
 {
-    __shared__ double sh[256];
     __shared__ int s_last;
     const int t = threadIdx.x, b = blockIdx.x, groups = gridDim.x;
     double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // zz (6), gz (3), cost
@@ -449,56 +448,64 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
             downward_prior(Q + (size_t)c * 4, P.prior_weight, &r, j3);
             v[9] += 0.5 * r * r;
         }
-    for (int q = 0; q < 10; q++)
+    // within the workgroup: a fixed shuffle tree per wavefront, then the four wavefronts' sums in order
+    __shared__ double wsum[4][10];
+    for (int q = with_jac ? 0 : 9; q < 10; q++)
     {
-        if (!with_jac && q < 9)
-            continue;
-        sh[t] = v[q];
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1)
-        {
-            if (t < s)
-                sh[t] += sh[t + s];
-            __syncthreads();
-        }
-        if (t == 0)
-            v[q] = sh[0];
-        __syncthreads();
+        double x = v[q];
+        for (int off = 32; off >= 1; off >>= 1)
+            x += __shfl_xor(x, off);
+        if ((t & 63) == 0)
+            wsum[t >> 6][q] = x;
+    }
+    __syncthreads();
+    if (t < 10)
+    {
+        const double sum = (with_jac || t == 9) ? ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t] : 0.0;
+        __hip_atomic_store(&partials[b * 10 + t], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (t == 0)
     {
-        for (int q = 0; q < 10; q++)
-            __hip_atomic_store(&partials[b * 10 + q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // (lanes 0 .. 9 of this wavefront stored the sums)
         s_last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(groups - 1);
-        if (s_last)
+    }
+    __syncthreads();
+    if (!s_last)
+        return;
+    // the last workgroup: every group's sums in one trip to memory, then ten lanes add them in group order
+    __shared__ double part[REDUCE_GROUPS * 10];
+    __shared__ double total[10];
+    for (int i = t; i < groups * 10; i += 256)
+        part[i] = __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (t < 10)
+    {
+        double sum = 0;
+        for (int w = 0; w < groups; w++)
+            sum += part[w * 10 + t];
+        total[t] = sum;
+    }
+    __syncthreads();
+    if (t == 0)
+    {
+        __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scal[0] = total[9];
+        if (with_jac)
         {
-            for (int q = 0; q < 10; q++)
-            {
-                double sum = 0;
-                for (int w = 0; w < groups; w++)
-                    sum += __hip_atomic_load(&partials[w * 10 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[q] = sum;
-            }
-            __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            scal[0] = v[9];
-            if (with_jac)
-            {
-                int k = 0;
-                for (int i = 0; i < 3; i++)
-                    for (int j = i; j < 3; j++)
+            int k = 0;
+            for (int i = 0; i < 3; i++)
+                for (int j = i; j < 3; j++)
+                {
+                    const int ti = P.z_t[i], tj = P.z_t[j];
+                    if (ti >= 0 && tj >= 0)
                     {
-                        const int ti = P.z_t[i], tj = P.z_t[j];
-                        if (ti >= 0 && tj >= 0)
-                        {
-                            A.tiles[lm_at(A, ti > tj ? ti : tj, ti > tj ? tj : ti)] = v[k];
-                        }
-                        k++;
+                        A.tiles[lm_at(A, ti > tj ? ti : tj, ti > tj ? tj : ti)] = total[k];
                     }
-                for (int i = 0; i < 3; i++)
-                    if (P.z_t[i] >= 0)
-                        g[P.z_t[i]] = v[6 + i];
-            }
+                    k++;
+                }
+            for (int i = 0; i < 3; i++)
+                if (P.z_t[i] >= 0)
+                    g[P.z_t[i]] = total[6 + i];
         }
     }
 }
