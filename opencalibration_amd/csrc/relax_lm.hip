@@ -966,84 +966,94 @@ __global__ __launch_bounds__(LM_TG) void back_solve_regions_kernel(lm_matrix Lm,
                                                                   const double *lm_diag, const double *gs, double *scal,
                                                                   unsigned int *arrived)
 {
+    // The kernel is a string of dependent trips to memory (rocprofv3: 0.21 ms for 19 blocks, ~11 us each, as four trips
+    // per update of 16 rows, two for the inverse, one for x).  So: the workgroup's part of x - its region and the tail -
+    // lives in LDS when it fits; a block's rows are split over the four wavefronts (16 rows each, all loads of a step in
+    // flight at once), whose partial sums meet in LDS and are added in wavefront order.
+    constexpr int XCAP = 3072;
+    __shared__ double xl[XCAP];
     __shared__ double xb[NB];
+    __shared__ double part[4][LM_TG];
     __shared__ double sh[LM_TG];
     __shared__ int s_last;
     const int t = threadIdx.x, r = blockIdx.x, m = gridDim.x;
+    const int cq = t & 63, rq = t >> 6;
     const double *L = Lm.tiles;
-    double *xw = work + (size_t)r * n;
     double *parts = work + (size_t)m * n;
-    const int rb = region[r], re = region[r + 1];          // own column blocks [rb, re)
-    const int c_lo = rb * NB, c_hi = min(re * NB, n);      // own columns
-    const int t_lo = min(tb * NB, n);                      // columns of the tail's blocks
+    const int rb = region[r], re = region[r + 1];     // own column blocks [rb, re)
+    const int c_lo = rb * NB, c_hi = min(re * NB, n); // own columns
+    const int t_lo = min(tb * NB, n);                 // columns of the tail's blocks
+    const int n_own = c_hi - c_lo, n_tail = n - t_lo;
+    const bool in_lds = n_own + n_tail <= XCAP;
+    double *const x_own = in_lds ? xl : work + (size_t)r * n + c_lo;
+    double *const x_tail = in_lds ? xl + n_own : work + (size_t)r * n + t_lo;
+    auto X = [&](int i) -> double & { return i < t_lo ? x_own[i - c_lo] : x_tail[i - t_lo]; };
     for (int i = c_lo + t; i < c_hi; i += LM_TG) // y = L^-1 gs: the augmented row
-        xw[i] = L[lm_at(Lm, n, i)];
+        X(i) = L[lm_at(Lm, n, i)];
     for (int i = t_lo + t; i < n; i += LM_TG)
-        xw[i] = L[lm_at(Lm, n, i)];
+        X(i) = L[lm_at(Lm, n, i)];
     auto block_step = [&](int k, int lo0, int hi0, int lo1, int hi1) {
         const int k0 = k * NB, nb = min(NB, n - k0);
         const double *Li = Linv + (size_t)k * NB * NB;
         __syncthreads(); // the updates of the previous block have landed
         if (t < NB)
-            xb[t] = t < nb ? xw[k0 + t] : 0.0;
+            xb[t] = t < nb ? X(k0 + t) : 0.0;
         __syncthreads();
-        double s = 0;
-        if (t < nb) // (32 loads in flight: this kernel is a chain of memory round trips)
         {
-#pragma unroll 1
-            for (int m0 = 0; m0 < NB; m0 += 32)
-            {
-                double v[32];
+            // (L^-T y)[c] = sum_{m >= c} Linv[m][c] y[m] (rows beyond the block are rows of the identity, y is 0 there)
+            double v[16], s = 0;
 #pragma unroll
-                for (int j = 0; j < 32; j++)
-                    v[j] = Li[(m0 + j) * NB + t];
+            for (int j = 0; j < 16; j++)
+                v[j] = Li[(16 * rq + j) * NB + cq];
 #pragma unroll
-                for (int j = 0; j < 32; j++)
-                    if (m0 + j >= t && m0 + j < nb)
-                        s += v[j] * xb[m0 + j];
-            }
+            for (int j = 0; j < 16; j++)
+                if (16 * rq + j >= cq)
+                    s += v[j] * xb[16 * rq + j];
+            part[rq][cq] = s;
         }
         __syncthreads();
-        if (t < nb)
+        if (t < NB)
         {
-            xb[t] = s;
-            xw[k0 + t] = s;
+            const double s = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+            xb[t] = t < nb ? s : 0.0;
+            if (t < nb)
+                X(k0 + t) = s;
         }
         __syncthreads();
-        // the columns in reach of the block, four neighbouring ones per thread (every range starts and ends on a tile
-        // boundary, a tile's row is contiguous): 32-byte loads, 16 rows in flight - this kernel is a chain of memory round
-        // trips, so what counts is the bytes each one brings.  Per column the sum runs over the rows in order, as before.
+        // the columns in reach of the block, 256 at a time: four neighbouring columns per lane (a tile's row is contiguous,
+        // every range starts and ends on a tile boundary: 32-byte loads), 16 rows per wavefront
         for (int pass = 0; pass < 2; pass++)
         {
             const int lo = pass ? lo1 : lo0, hi = pass ? hi1 : hi0;
-            for (int i = lo + 4 * t; i < hi; i += 4 * LM_TG)
+            for (int base = lo; base < hi; base += LM_TG)
             {
-                const double *Lc = L + ((size_t)lm_tile_index(Lm.cols, k, i >> 6) << 12) + (i & 63);
+                const int i = base + 4 * cq;
                 double u0 = 0, u1 = 0, u2 = 0, u3 = 0;
-#pragma unroll 1
-                for (int m0 = 0; m0 < NB; m0 += 16)
+                if (i < hi)
                 {
+                    const double *Lc = L + ((size_t)lm_tile_index(Lm.cols, k, i >> 6) << 12) + (i & 63);
                     v4f64 v[16];
 #pragma unroll
-                    for (int j = 0; j < 16; j++)
-                        v[j] = m0 + j < nb ? *reinterpret_cast<const v4f64 *>(Lc + (m0 + j) * NB) : v4f64{0, 0, 0, 0};
-#pragma unroll
                     for (int j = 0; j < 16; j++) // (the augmented row shares the last block's tile: rows >= nb are skipped)
+                        v[j] = 16 * rq + j < nb ? *reinterpret_cast<const v4f64 *>(Lc + (16 * rq + j) * NB) : v4f64{0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < 16; j++)
                     {
-                        const double xm = xb[m0 + j];
+                        const double xm = xb[16 * rq + j];
                         u0 += v[j][0] * xm;
                         u1 += v[j][1] * xm;
                         u2 += v[j][2] * xm;
                         u3 += v[j][3] * xm;
                     }
                 }
-                xw[i] -= u0;
-                if (i + 1 < n)
-                    xw[i + 1] -= u1;
-                if (i + 2 < n)
-                    xw[i + 2] -= u2;
-                if (i + 3 < n)
-                    xw[i + 3] -= u3;
+                part[rq][4 * cq] = u0;
+                part[rq][4 * cq + 1] = u1;
+                part[rq][4 * cq + 2] = u2;
+                part[rq][4 * cq + 3] = u3;
+                __syncthreads();
+                if (base + t < hi)
+                    X(base + t) -= ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+                __syncthreads();
             }
         }
     };
@@ -1053,21 +1063,21 @@ __global__ __launch_bounds__(LM_TG) void back_solve_regions_kernel(lm_matrix Lm,
         block_step(k, max(first_blk[k] * NB, c_lo), k * NB, 0, 0);
     __syncthreads();
     // results and this region's part of model_cost_change (workgroup 0: the tail's as well)
-    double part = 0;
+    double part_sum = 0;
     for (int i = c_lo + t; i < c_hi; i += LM_TG)
     {
-        const double v = xw[i];
+        const double v = X(i);
         x[i] = v;
-        part += v * gs[i] + lm_diag[i] * v * v;
+        part_sum += v * gs[i] + lm_diag[i] * v * v;
     }
     if (r == 0)
         for (int i = t_lo + t; i < n; i += LM_TG)
         {
-            const double v = xw[i];
+            const double v = X(i);
             x[i] = v;
-            part += v * gs[i] + lm_diag[i] * v * v;
+            part_sum += v * gs[i] + lm_diag[i] * v * v;
         }
-    sh[t] = part;
+    sh[t] = part_sum;
     __syncthreads();
     for (int s = LM_TG / 2; s > 0; s >>= 1)
     {
