@@ -160,6 +160,189 @@ __device__ bool plane_intersection_residuals(const functor_io<T> &in, const doub
     return all_valid;
 }
 
+// ---- the same functor with mixed argument types (round 3).  A Jacobian pass seeds ONE of the three parameter blocks
+// (camera a's tangent, camera b's, the plane heights); run on Dual<3> throughout, the other two blocks and everything
+// that only depends on them - a whole ray with its rotation, or the plane's normal - carried three zero partials through
+// every operation: a third of the kernel's arithmetic (it is bound by fp64 issue: 9 000 wavefronts of ~18 000
+// instructions).  Here the unseeded blocks are plain doubles and an expression becomes a Dual where a seeded value first
+// enters it.  Same operations in the same order on the values; a partial that used to be computed as 0 * x + y is now y.
+typedef Dual<3> D3;
+OCHIP_HD D3 operator+(const D3 &f, double g)
+{
+    D3 h = f;
+    h.a = f.a + g;
+    return h;
+}
+OCHIP_HD D3 operator+(double f, const D3 &g)
+{
+    D3 h = g;
+    h.a = f + g.a;
+    return h;
+}
+OCHIP_HD D3 operator-(const D3 &f, double g)
+{
+    D3 h = f;
+    h.a = f.a - g;
+    return h;
+}
+OCHIP_HD D3 operator-(double f, const D3 &g)
+{
+    D3 h;
+    h.a = f - g.a;
+    for (int i = 0; i < 3; i++)
+        h.v[i] = -g.v[i];
+    return h;
+}
+OCHIP_HD D3 operator*(const D3 &f, double g)
+{
+    D3 h;
+    h.a = f.a * g;
+    for (int i = 0; i < 3; i++)
+        h.v[i] = f.v[i] * g;
+    return h;
+}
+OCHIP_HD D3 operator*(double f, const D3 &g)
+{
+    D3 h;
+    h.a = f * g.a;
+    for (int i = 0; i < 3; i++)
+        h.v[i] = f * g.v[i];
+    return h;
+}
+OCHIP_HD D3 operator/(const D3 &f, double g)
+{
+    D3 h;
+    const double ginv = 1.0 / g;
+    h.a = f.a * ginv;
+    for (int i = 0; i < 3; i++)
+        h.v[i] = f.v[i] * ginv;
+    return h;
+}
+OCHIP_HD D3 operator/(double f, const D3 &g)
+{
+    D3 h;
+    const double ginv = 1.0 / g.a;
+    const double fg = f * ginv;
+    h.a = fg;
+    for (int i = 0; i < 3; i++)
+        h.v[i] = (-(fg * g.v[i])) * ginv;
+    return h;
+}
+template <typename A, typename B> OCHIP_HD auto vadd(const Vec3T<A> &a, const Vec3T<B> &b)
+{
+    using R = decltype(a.x + b.x);
+    return Vec3T<R>{a.x + b.x, a.y + b.y, a.z + b.z};
+}
+template <typename A, typename B> OCHIP_HD auto vsub(const Vec3T<A> &a, const Vec3T<B> &b)
+{
+    using R = decltype(a.x - b.x);
+    return Vec3T<R>{a.x - b.x, a.y - b.y, a.z - b.z};
+}
+template <typename A, typename B> OCHIP_HD auto vscale(const Vec3T<A> &a, const B &s)
+{
+    using R = decltype(a.x * s);
+    return Vec3T<R>{a.x * s, a.y * s, a.z * s};
+}
+template <typename A, typename B> OCHIP_HD auto vdivide(const Vec3T<A> &a, const B &s)
+{
+    using R = decltype(a.x / s);
+    return Vec3T<R>{a.x / s, a.y / s, a.z / s};
+}
+template <typename A, typename B> OCHIP_HD auto vdot(const Vec3T<A> &a, const Vec3T<B> &b)
+{
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+template <typename A, typename B> OCHIP_HD auto vcross(const Vec3T<A> &a, const Vec3T<B> &b)
+{
+    using R = decltype(a.y * b.z - a.z * b.y);
+    return Vec3T<R>{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename A> OCHIP_HD A vnorm(const Vec3T<A> &a)
+{
+    return dsqrt(vdot(a, a));
+}
+template <typename TQ> OCHIP_HD Vec3T<TQ> quat_rotate_mixed(const TQ *q, const Vec3T<double> &v)
+{
+    const Vec3T<TQ> qv{q[0], q[1], q[2]};
+    Vec3T<TQ> uv = vcross(qv, v);
+    uv = vadd(uv, uv);
+    return vadd(vadd(v, vscale(uv, q[3])), vcross(qv, uv));
+}
+
+// TA, TB, TZ: double or Dual<3> (at most one of them a Dual); the residuals come out in the widest of them
+template <typename TA, typename TB, typename TZ, typename R>
+__device__ bool plane_intersection_residuals_mixed(const TA *qa, const TB *qb, const TZ *z, const double *loc_a, const double *loc_b,
+                                                   const double *rays, const double *plane_xy, R *res)
+{
+    // cornerPlane2normOffsetPlane: corners (x, y) are constants, the heights z are the parameters
+    const Vec3T<TZ> e1{TZ(plane_xy[0] - plane_xy[2]), TZ(plane_xy[1] - plane_xy[3]), z[0] - z[1]};
+    const Vec3T<TZ> e2{TZ(plane_xy[0] - plane_xy[4]), TZ(plane_xy[1] - plane_xy[5]), z[0] - z[2]};
+    Vec3T<TZ> nrm = vcross(e1, e2);
+    {
+        const TZ zz = vdot(nrm, nrm);
+        if (value_of(zz) > 0.0)
+            nrm = vdivide(nrm, dsqrt(zz));
+    }
+    const Vec3T<TZ> offset{TZ(plane_xy[0]), TZ(plane_xy[1]), z[0]};
+    const TZ plane_d = vdot(nrm, offset);
+    bool all_valid = true;
+    const Vec3T<double> off_a{loc_a[0], loc_a[1], loc_a[2]}, off_b{loc_b[0], loc_b[1], loc_b[2]};
+    const Vec3T<TA> dir_a = quat_rotate_mixed(qa, Vec3T<double>{rays[0], rays[1], rays[2]});
+    const Vec3T<TB> dir_b = quat_rotate_mixed(qb, Vec3T<double>{rays[3], rays[4], rays[5]});
+    using RA = decltype(vdot(nrm, dir_a));
+    using RB = decltype(vdot(nrm, dir_b));
+    Vec3T<RA> isect_a;
+    Vec3T<RB> isect_b;
+    {
+        const RA denom = vdot(nrm, dir_a);
+        if (fabs(value_of(denom)) < 1e-9)
+        {
+            all_valid = false;
+            isect_a = {RA(NAN), RA(NAN), RA(NAN)};
+        }
+        else
+        {
+            const RA t = (plane_d - vdot(off_a, nrm)) / denom;
+            isect_a = vadd(off_a, vscale(dir_a, t));
+        }
+    }
+    {
+        const RB denom = vdot(nrm, dir_b);
+        if (fabs(value_of(denom)) < 1e-9)
+        {
+            all_valid = false;
+            isect_b = {RB(NAN), RB(NAN), RB(NAN)};
+        }
+        else
+        {
+            const RB t = (plane_d - vdot(off_b, nrm)) / denom;
+            isect_b = vadd(off_b, vscale(dir_b, t));
+        }
+    }
+    R avg_dist = (vnorm(vsub(isect_a, off_a)) + vnorm(vsub(isect_b, off_b))) / 2.0;
+    const R huber_threshold = avg_dist * 0.01;
+    // robustCentroid (relax_cost_function.hpp:73-117), n = 2
+    Vec3T<R> centroid = vdivide(vadd(isect_a, isect_b), 2.0);
+    for (int stage = 0; stage < 3; stage++)
+    {
+        const R err_a = vnorm(vsub(isect_a, centroid)), err_b = vnorm(vsub(isect_b, centroid));
+        R wa = 1.0 / (err_a + 1e-8), wb = 1.0 / (err_b + 1e-8);
+        if (value_of(err_a) > value_of(huber_threshold))
+            wa = wa * (huber_threshold / err_a);
+        if (value_of(err_b) > value_of(huber_threshold))
+            wb = wb * (huber_threshold / err_b);
+        const R total_w = wa + wb;
+        const double min_w = fmin(value_of(wa), value_of(wb)), max_w = fmax(value_of(wa), value_of(wb));
+        centroid = vdivide(vadd(vscale(isect_a, wa), vscale(isect_b, wb)), total_w);
+        if (min_w > max_w * 0.5)
+            break;
+    }
+    const Vec3T<R> ra = vdivide(vsub(isect_a, centroid), avg_dist), rb = vdivide(vsub(isect_b, centroid), avg_dist);
+    res[0] = ra.x, res[1] = ra.y, res[2] = ra.z;
+    res[3] = rb.x, res[4] = rb.y, res[5] = rb.z;
+    return all_valid;
+}
+
 // tangent seed of the EigenQuaternionManifold at q: d(q_delta * q)/d delta (ceres manifold.cc, Order XYZW)
 __device__ __forceinline__ void seed_quat(const double *q, Dual<3> *out)
 {
@@ -229,36 +412,34 @@ __global__ __launch_bounds__(W) void relax_pair_eval_kernel(relax_dev P, int whi
         cost += c;
         if (WITH_JAC)
         {
-#pragma unroll 1
-            for (int pass = 0; pass < 3; pass++)
+            // one pass per parameter block, the other two as plain doubles (plane_intersection_residuals_mixed)
             {
-                functor_io<Dual<3>> in;
-                if (pass == 0)
-                    seed_quat(qa, in.qa);
-                else
-                    for (int k = 0; k < 4; k++)
-                        in.qa[k] = Dual<3>(qa[k]);
-                if (pass == 1)
-                    seed_quat(qb, in.qb);
-                else
-                    for (int k = 0; k < 4; k++)
-                        in.qb[k] = Dual<3>(qb[k]);
+                D3 rd[6], seeded[4];
+                auto take = [&](int pass) {
+                    for (int k = 0; k < 6; k++)
+                        for (int cidx = 0; cidx < 3; cidx++)
+                        {
+                            const double v = rd[k].v[cidx] * sqrt_rho1;
+                            J[k][pass * 3 + cidx] = v;
+                            if (!(v - v == 0.0))
+                                failed = true;
+                        }
+                };
+                static_assert(sizeof(D3) == 4 * sizeof(double), "Dual<3> is a value and three partials");
+                seed_quat(qa, seeded);
+                plane_intersection_residuals_mixed(seeded, qb, Z, la, lb, rays, P.plane, rd);
+                take(0);
+                seed_quat(qb, seeded);
+                plane_intersection_residuals_mixed(qa, seeded, Z, la, lb, rays, P.plane, rd);
+                take(1);
+                D3 zs[3];
                 for (int k = 0; k < 3; k++)
                 {
-                    in.z[k] = Dual<3>(Z[k]);
-                    if (pass == 2)
-                        in.z[k].v[k] = 1.0;
+                    zs[k] = D3(Z[k]);
+                    zs[k].v[k] = 1.0;
                 }
-                Dual<3> rd[6];
-                plane_intersection_residuals<Dual<3>>(in, la, lb, rays, P.plane, rd);
-                for (int k = 0; k < 6; k++)
-                    for (int cidx = 0; cidx < 3; cidx++)
-                    {
-                        const double v = rd[k].v[cidx] * sqrt_rho1;
-                        J[k][pass * 3 + cidx] = v;
-                        if (!(v - v == 0.0))
-                            failed = true;
-                    }
+                plane_intersection_residuals_mixed(qa, qb, zs, la, lb, rays, P.plane, rd);
+                take(2);
             }
             for (int k = 0; k < 6; k++)
                 r[k] *= sqrt_rho1;
