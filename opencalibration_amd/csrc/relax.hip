@@ -359,6 +359,13 @@ __device__ __forceinline__ void seed_quat(const double *q, Dual<3> *out)
 template <bool WITH_JAC>
 __global__ __launch_bounds__(W) void relax_pair_eval_kernel(relax_dev P, int which_state)
 {
+    // One wavefront per camera pair, one lane per residual block (a pair has ~50).  With the Jacobian, a lane used to keep
+    // its block's 6 x 9 Jacobian AND 54 running sums of J'J / J'r in registers (218 VGPRs before the functor's own
+    // temporaries: 896 bytes of scratch per lane, one wavefront per SIMD), followed by a 54-value shuffle tree.  Now a
+    // lane leaves its scaled Jacobian and residuals in LDS (role-normalised columns [p | q | z]) and 54 lanes each form
+    // ONE entry of J'J or J'r, adding the blocks in order; the entries go out as one coalesced store.
+    constexpr int JP = 61; // doubles per lane in LDS: 54 of J, 6 of r, 1 of padding (bank spread)
+    __shared__ double Jl[WITH_JAC ? W : 1][JP];
     const int lane = threadIdx.x;
     const uint32_t pair = P.pair_lo + blockIdx.x;
     const uint32_t b0 = P.pair_off[pair], b1 = P.pair_off[pair + 1];
@@ -367,71 +374,89 @@ __global__ __launch_bounds__(W) void relax_pair_eval_kernel(relax_dev P, int whi
     const double *Z = P.plane + (which_state ? 9 : 6);
     const double a2 = P.huber_a * P.huber_a;
 
-    double acc[WITH_JAC ? ACC : 1];
-    for (int i = 0; i < (WITH_JAC ? ACC : 1); i++)
-        acc[i] = 0;
+    // this lane's entry of the pair's 9 x 9 block (upper triangle, tri(i, j)) or of its gradient (45 + i)
+    int ei = 0, ej = 0;
+    if (WITH_JAC)
+    {
+        if (lane < 45)
+        {
+            int rem = lane;
+            while (rem >= 9 - ei)
+            {
+                rem -= 9 - ei;
+                ei++;
+            }
+            ej = ei + rem;
+        }
+        else
+            ei = lane - 45;
+    }
+    double entry = 0;
     double cost = 0;
     bool failed = false;
 
-    for (uint32_t blk = b0 + lane; blk < b1; blk += W)
+    for (uint32_t first = b0; first < b1; first += W)
     {
-        const uint32_t ca = P.blk_a[blk], cb = P.blk_b[blk];
-        const double *rays = P.blk_rays + (size_t)blk * 6;
-        const double *la = P.cam_pos + (size_t)ca * 3, *lb = P.cam_pos + (size_t)cb * 3;
-        const double *qa = Q + (size_t)ca * 4, *qb = Q + (size_t)cb * 4;
-        double r[6];
-        double J[6][9]; // columns: a-tangent | b-tangent | z
+        const uint32_t blk = first + lane;
+        if (blk < b1)
         {
-            functor_io<double> in;
-            for (int k = 0; k < 4; k++)
+            const uint32_t ca = P.blk_a[blk], cb = P.blk_b[blk];
+            const double *rays = P.blk_rays + (size_t)blk * 6;
+            const double *la = P.cam_pos + (size_t)ca * 3, *lb = P.cam_pos + (size_t)cb * 3;
+            const double *qa = Q + (size_t)ca * 4, *qb = Q + (size_t)cb * 4;
+            double r[6];
             {
-                in.qa[k] = qa[k];
-                in.qb[k] = qb[k];
+                functor_io<double> in;
+                for (int k = 0; k < 4; k++)
+                {
+                    in.qa[k] = qa[k];
+                    in.qb[k] = qb[k];
+                }
+                for (int k = 0; k < 3; k++)
+                    in.z[k] = Z[k];
+                if (!plane_intersection_residuals<double>(in, la, lb, rays, P.plane, r))
+                    failed = true;
             }
-            for (int k = 0; k < 3; k++)
-                in.z[k] = Z[k];
-            if (!plane_intersection_residuals<double>(in, la, lb, rays, P.plane, r))
-                failed = true;
-        }
-        double s = 0;
-        for (int k = 0; k < 6; k++)
-        {
-            s += r[k] * r[k];
-            if (!(r[k] - r[k] == 0.0))
-                failed = true;
-        }
-        // Huber + Triggs corrector (rho'' <= 0 for Huber: plain sqrt(rho') scaling)
-        double sqrt_rho1 = 1.0, c = 0.5 * s;
-        if (s > a2)
-        {
-            const double rn = sqrt(s);
-            const double rho1 = fmax(2.2250738585072014e-308, P.huber_a / rn);
-            sqrt_rho1 = sqrt(rho1);
-            c = 0.5 * (2.0 * P.huber_a * rn - a2);
-        }
-        cost += c;
-        if (WITH_JAC)
-        {
-            // one pass per parameter block, the other two as plain doubles (plane_intersection_residuals_mixed)
+            double s = 0;
+            for (int k = 0; k < 6; k++)
             {
+                s += r[k] * r[k];
+                if (!(r[k] - r[k] == 0.0))
+                    failed = true;
+            }
+            // Huber + Triggs corrector (rho'' <= 0 for Huber: plain sqrt(rho') scaling)
+            double sqrt_rho1 = 1.0, c = 0.5 * s;
+            if (s > a2)
+            {
+                const double rn = sqrt(s);
+                const double rho1 = fmax(2.2250738585072014e-308, P.huber_a / rn);
+                sqrt_rho1 = sqrt(rho1);
+                c = 0.5 * (2.0 * P.huber_a * rn - a2);
+            }
+            cost += c;
+            if (WITH_JAC)
+            {
+                // one pass per parameter block, the other two as plain doubles (plane_intersection_residuals_mixed);
+                // role normalisation: the pair's columns are [p | q | z], this block's cameras may be (q, p)
+                const int first_col = ca != p ? 3 : 0, second_col = ca != p ? 0 : 3;
+                double *mine = Jl[lane];
                 D3 rd[6], seeded[4];
-                auto take = [&](int pass) {
+                auto take = [&](int col0) {
                     for (int k = 0; k < 6; k++)
                         for (int cidx = 0; cidx < 3; cidx++)
                         {
                             const double v = rd[k].v[cidx] * sqrt_rho1;
-                            J[k][pass * 3 + cidx] = v;
+                            mine[k * 9 + col0 + cidx] = v;
                             if (!(v - v == 0.0))
                                 failed = true;
                         }
                 };
-                static_assert(sizeof(D3) == 4 * sizeof(double), "Dual<3> is a value and three partials");
                 seed_quat(qa, seeded);
                 plane_intersection_residuals_mixed(seeded, qb, Z, la, lb, rays, P.plane, rd);
-                take(0);
+                take(first_col);
                 seed_quat(qb, seeded);
                 plane_intersection_residuals_mixed(qa, seeded, Z, la, lb, rays, P.plane, rd);
-                take(1);
+                take(second_col);
                 D3 zs[3];
                 for (int k = 0; k < 3; k++)
                 {
@@ -439,52 +464,44 @@ __global__ __launch_bounds__(W) void relax_pair_eval_kernel(relax_dev P, int whi
                     zs[k].v[k] = 1.0;
                 }
                 plane_intersection_residuals_mixed(qa, qb, zs, la, lb, rays, P.plane, rd);
-                take(2);
-            }
-            for (int k = 0; k < 6; k++)
-                r[k] *= sqrt_rho1;
-            // role normalisation: pair columns are [p | q | z]
-            const bool flip = ca != p;
-            int col[9];
-            for (int k = 0; k < 9; k++)
-                col[k] = k < 6 ? (flip ? (k + 3) % 6 : k) : k;
-            for (int i = 0; i < 9; i++)
-            {
-                double g = 0;
+                take(6);
                 for (int k = 0; k < 6; k++)
-                    g += J[k][i] * r[k];
-                acc[45 + col[i]] += g;
-                for (int j = i; j < 9; j++)
+                    mine[54 + k] = r[k] * sqrt_rho1;
+            }
+        }
+        if (WITH_JAC)
+        {
+            __syncthreads();
+            const int blocks = (int)min((uint32_t)W, b1 - first);
+            if (lane < 54)
+            {
+                const int cb2 = lane < 45 ? ej : 54; // second factor: column ej of J, or the residual
+                for (int b = 0; b < blocks; b++)
                 {
+                    const double *jb = Jl[b];
                     double m = 0;
                     for (int k = 0; k < 6; k++)
-                        m += J[k][i] * J[k][j];
-                    const int ci = col[i], cj = col[j];
-                    acc[ci <= cj ? tri(ci, cj) : tri(cj, ci)] += m;
+                        m += jb[k * 9 + ei] * (lane < 45 ? jb[k * 9 + cb2] : jb[54 + k]);
+                    entry += m;
                 }
             }
+            __syncthreads();
         }
     }
     // fixed shuffle tree: bitwise reproducible
     for (int off = 32; off >= 1; off >>= 1)
-    {
         cost += __shfl_xor(cost, off);
-        if (WITH_JAC)
-            for (int i = 0; i < 54; i++)
-                acc[i] += __shfl_xor(acc[i], off);
-    }
     if (__ballot(failed) && lane == 0)
         atomicOr(P.fail, 1);
     if (lane == 0)
-    {
         P.pair_cost[pair] = cost;
-        if (WITH_JAC)
-        {
-            double *o = P.pair_acc + (size_t)pair * ACC;
-            for (int i = 0; i < 54; i++)
-                o[i] = acc[i];
+    if (WITH_JAC)
+    {
+        double *o = P.pair_acc + (size_t)pair * ACC;
+        if (lane < 54)
+            o[lane] = entry;
+        if (lane == 0)
             o[54] = cost;
-        }
     }
 }
 
