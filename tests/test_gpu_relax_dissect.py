@@ -42,13 +42,22 @@ def test_dissected_relax_equals_the_single_band(monkeypatch):
     assert err < 5e-3, err
 
 
-def test_tile_factorisation_equals_the_chain_under_the_dissection():
+@pytest.mark.parametrize("knobs", [{}, {"OCHIP_CHOL_NO_FUSE": "1"}, {"OCHIP_CHOL_KC": "64"}, {"OCHIP_CHOL_UNBLOCKED_DIAG": "1"},
+                                   {"OCHIP_CHOL_PLAIN_KORDER": "1"}, {"OCHIP_RELAX_DISSECT_G": "64"}, {"OCHIP_RELAX_DISSECT": "0"}],
+                         ids=lambda k: "+".join("%s=%s" % kv for kv in k.items()) or "default")
+def test_tile_factorisation_equals_the_chain_under_the_dissection(knobs):
     """OCHIP_CHOL_VERIFY=1 factors every system of the solve both ways (one launch of tiles / the launch chain) and fails
-    the relax when the forward solves differ by more than 1e-9 relative; the knob is read once per process."""
-    env = dict(os.environ, OCHIP_CHOL_VERIFY="1", OCHIP_RELAX_VERBOSE="1")
+    the relax when the forward solves differ by more than 1e-9 relative; the knobs are read once per process, so every
+    variant of the tile kernel (fused pairs or not, operands in halves or whole, blocked or rank-1 diagonal tile, the
+    tail's summation order, region size, one band) runs in a process of its own."""
+    env = dict(os.environ, OCHIP_CHOL_VERIFY="1", OCHIP_RELAX_VERBOSE="1", **knobs)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probe_relax_dissect.py"), "16x20x512", "1"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "factorisation check" in r.stderr and "LM it/s" in r.stdout
     regions = [l for l in r.stderr.splitlines() if "regions" in l and "n=963" in l]
-    assert regions and " 1 regions" not in regions[0], regions
+    assert regions
+    if knobs.get("OCHIP_RELAX_DISSECT") == "0":
+        assert " 1 regions" in regions[0], regions
+    else:
+        assert " 1 regions" not in regions[0], regions
