@@ -1145,20 +1145,21 @@ int assign(ochip_relaxg_problem *p)
     std::vector<band_owner> band_owners;
     int64_t band_doubles = 0;
     static const bool no_band_chunks = getenv("OCHIP_RELAX_NO_BAND_CHUNKS") != nullptr; // A/B knob
+    static const uint32_t band_chunk = getenv("OCHIP_RELAX_BAND_CHUNK") ? std::max(64, atoi(getenv("OCHIP_RELAX_BAND_CHUNK"))) : BAND_CHUNK;
     for (uint32_t u : band)
     {
         const uint32_t r0 = p->var_rec_off[u], r1 = p->var_rec_off[u + 1];
         const int64_t strip = (int64_t)p->var_ts[u] * (hi[u] - lo[u] + T + 1);
         max_strip = std::max(max_strip, (int)strip);
-        if (no_band_chunks || r1 - r0 <= 2 * BAND_CHUNK)
+        if (no_band_chunks || r1 - r0 <= 2 * band_chunk)
         {
             items.push_back(work_item{u, r0, r1, lo[u], hi[u], -1, -1});
             continue;
         }
         band_owner bo{u, lo[u], hi[u], 0, band_doubles};
-        for (uint32_t e = r0; e < r1; e += BAND_CHUNK)
+        for (uint32_t e = r0; e < r1; e += band_chunk)
         {
-            items.push_back(work_item{u, e, std::min(e + BAND_CHUNK, r1), lo[u], hi[u], -1, band_doubles});
+            items.push_back(work_item{u, e, std::min(e + band_chunk, r1), lo[u], hi[u], -1, band_doubles});
             band_doubles += strip;
             bo.chunks++;
         }

@@ -964,7 +964,7 @@ __global__ __launch_bounds__(LM_TG) void back_solve_kernel(lm_matrix Lm, int n, 
 __global__ __launch_bounds__(LM_TG) void back_solve_regions_kernel(lm_matrix Lm, int n, const double *Linv, double *x, double *work,
                                                                   const int *first_blk, int n_blocks, const int *region, int tb,
                                                                   const double *lm_diag, const double *gs, double *scal,
-                                                                  unsigned int *arrived)
+                                                                  unsigned int *arrived, int x_in_lds)
 {
     // The kernel is a string of dependent trips to memory (rocprofv3: 0.21 ms for 19 blocks, ~11 us each, as four trips
     // per update of 16 rows, two for the inverse, one for x).  So: the workgroup's part of x - its region and the tail -
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(LM_TG) void back_solve_regions_kernel(lm_matrix Lm,
     const int c_lo = rb * NB, c_hi = min(re * NB, n); // own columns
     const int t_lo = min(tb * NB, n);                 // columns of the tail's blocks
     const int n_own = c_hi - c_lo, n_tail = n - t_lo;
-    const bool in_lds = n_own + n_tail <= XCAP;
+    const bool in_lds = x_in_lds && n_own + n_tail <= XCAP; // (otherwise: this workgroup's vector in `work`)
     double *const x_own = in_lds ? xl : work + (size_t)r * n + c_lo;
     double *const x_tail = in_lds ? xl + n_own : work + (size_t)r * n + t_lo;
     auto X = [&](int i) -> double & { return i < t_lo ? x_own[i - c_lo] : x_tail[i - t_lo]; };
@@ -1519,6 +1519,10 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
             static const bool plain_order = getenv("OCHIP_CHOL_PLAIN_KORDER") != nullptr; // A/B knob
             if (!plain_order && lm_dev_upload(ctx, s->allocs, &s->chol_korder, korder.data(), korder.size()) != OCHIP_OK)
                 return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (factorisation plan)");
+        }
+        else
+            region_bounds = {0, std::min(tb, nbc)}; // one band: the backward substitution's one "region"
+        {
             const size_t need = (size_t)s->n_regions * ((size_t)std::max(nn, 1) + 1);
             if (lm_dev_upload(ctx, s->allocs, &s->region_dev, region_bounds.data(), region_bounds.size()) != OCHIP_OK)
                 return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (regions of the factorisation)");
@@ -1793,11 +1797,15 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         // row n now holds y = L^-1 gs; back-substitute L' x = y block by block
         if (n > 0)
         {
-            if (S.n_regions > 1)
+            // (the per-region kernel also serves the single band, as one region: it is the faster walk - rows of a block
+            // split over the wavefronts, x in LDS; OCHIP_BACK_SOLVE_SINGLE=1: the round-2 kernel)
+            static const bool single = getenv("OCHIP_BACK_SOLVE_SINGLE") != nullptr;
+            static const bool x_global = getenv("OCHIP_BACK_SOLVE_X_GLOBAL") != nullptr; // test knob: x in HBM even when it fits LDS
+            if (S.n_regions > 1 || (!single && S.region_dev))
                 hipLaunchKernelGGL(back_solve_regions_kernel, dim3((unsigned)S.n_regions), dim3(LM_TG), 0, st, S.matW(), n,
                                    (const double *)S.linv, S.y, S.back_work, (const int *)S.chol_kmin, (n + NB - 1) / NB,
                                    (const int *)S.region_dev, S.chol_tb, (const double *)S.lm_diag, (const double *)S.gs, S.scal,
-                                   S.chol_sync + 1);
+                                   S.chol_sync + 1, x_global ? 0 : 1);
             else
                 hipLaunchKernelGGL(back_solve_kernel, dim3(1), dim3(LM_TG), 0, st, S.matW(), n, (const double *)S.linv, S.y,
                                    (const int *)S.chol_kmin, (n + NB - 1) / NB, (const double *)S.lm_diag, (const double *)S.gs, S.scal);

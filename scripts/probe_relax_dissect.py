@@ -28,5 +28,6 @@ for r in range(repeats):
     rates.append(it / dev)
     mem = ctx.relax_memory()
 print("%s: %d iterations, device %.4f s, LM it/s %s, system %s" % (config, it, dev, ["%.0f" % x for x in rates], mem), flush=True)
+print("final_cost %.17g orientation_checksum %.17g" % (float(res["final_cost"]), float(np.abs(res["orientation"]).sum())), flush=True)
 g.close()
 ctx.close()

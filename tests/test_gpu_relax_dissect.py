@@ -61,3 +61,26 @@ def test_tile_factorisation_equals_the_chain_under_the_dissection(knobs):
         assert " 1 regions" in regions[0], regions
     else:
         assert " 1 regions" not in regions[0], regions
+
+
+def _probe(knobs):
+    env = dict(os.environ, **knobs)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probe_relax_dissect.py"), "16x20x512", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("final_cost")][0].split()
+    iterations = int([l for l in r.stdout.splitlines() if "iterations" in l][0].split(":")[1].split()[0])
+    return iterations, float(line[1]), float(line[3])
+
+
+def test_back_substitution_variants_agree():
+    """The backward substitution with its part of x in LDS or in HBM (the fallback for systems that do not fit), and the
+    round-2 single-workgroup kernel beside the split-wavefront one on a single band: same LM trajectory."""
+    base = _probe({})
+    hbm = _probe({"OCHIP_BACK_SOLVE_X_GLOBAL": "1"})
+    assert hbm[0] == base[0] and hbm[1] == base[1] and hbm[2] == base[2]        # same arithmetic: same bits
+    band = _probe({"OCHIP_RELAX_DISSECT": "0"})
+    old = _probe({"OCHIP_RELAX_DISSECT": "0", "OCHIP_BACK_SOLVE_SINGLE": "1"})
+    assert band[0] == old[0] == base[0]
+    for other in (band, old):
+        assert abs(other[1] - base[1]) <= 1e-9 * abs(base[1]) and abs(other[2] - base[2]) <= 1e-9 * abs(base[2])
