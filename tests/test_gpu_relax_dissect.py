@@ -47,7 +47,7 @@ def test_dissected_relax_equals_the_single_band(monkeypatch):
                          ids=lambda k: "+".join("%s=%s" % kv for kv in k.items()) or "default")
 def test_tile_factorisation_equals_the_chain_under_the_dissection(knobs):
     """OCHIP_CHOL_VERIFY=1 factors every system of the solve both ways (one launch of tiles / the launch chain) and fails
-    the relax when the forward solves differ by more than 1e-9 relative; the knobs are read once per process, so every
+    the relax when the forward solves differ by more than 1e-7 relative; the knobs are read once per process, so every
     variant of the tile kernel (fused pairs or not, operands in halves or whole, blocked or rank-1 diagonal tile, the
     tail's summation order, region size, one band) runs in a process of its own."""
     env = dict(os.environ, OCHIP_CHOL_VERIFY="1", OCHIP_RELAX_VERBOSE="1", **knobs)
