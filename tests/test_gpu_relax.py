@@ -120,7 +120,7 @@ def test_graph_without_edges(ctx, oracle):
 def test_tile_factorisation_equals_the_launch_chain():
     """OCHIP_CHOL_VERIFY=1 factors every reduced system twice - the one-launch tile Cholesky (workgroups handing tiles to
     each other) and the chain of dependent launches - and fails the solve when the forward solves differ by more than
-    1e-9 relative.  Run in a child process (the switch is read once) over a plane problem with the augmented row inside
+    1e-7 relative (1e-9 until the diagonal tile was blocked: nearly singular 12-unknown systems differ by 2e-9).  Run in a child process (the switch is read once) over a plane problem with the augmented row inside
     the last diagonal tile (n % 64 != 0), one with n % 64 == 0, and a mesh problem with a dense tail."""
     import os
     import subprocess
