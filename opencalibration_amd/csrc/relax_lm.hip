@@ -1479,6 +1479,8 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
         s->chol_nbr = nbr;
         s->chol_tb = tb;
         s->chol_grid = std::max(1, std::min((int)order.size(), slots));
+        if (const char *e = getenv("OCHIP_CHOL_GRID")) // A/B knob: fewer workgroups walking the claim list
+            s->chol_grid = std::max(1, std::min(s->chol_grid, atoi(e)));
         s->chol_sync_bytes = (((size_t)n_tiles + 4) * 4 + 15) / 16 * 16;
         // tiles in storage order, and the matrices themselves
         std::vector<unsigned int> stored((size_t)std::max(n_tiles, 1), 0u);
