@@ -348,6 +348,8 @@ extern "C"
         double initial_cost, final_cost;
     } ochip_relax_summary;
 
+    /* A problem (this one and the ochip_relaxg_ / ochip_relaxp_ ones below) holds device blocks and a page-locked host
+       block of its context: destroy it before the context. */
     int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *desc, ochip_relax_problem **out);
     void ochip_relax_problem_destroy(ochip_relax_problem *p);
     /* relaxObservedModelOnly (:931-984): freeze every camera, leave the plane heights variable (or undo) */
