@@ -970,7 +970,7 @@ __global__ __launch_bounds__(LM_TG) void back_solve_regions_kernel(lm_matrix Lm,
     // per update of 16 rows, two for the inverse, one for x).  So: the workgroup's part of x - its region and the tail -
     // lives in LDS when it fits; a block's rows are split over the four wavefronts (16 rows each, all loads of a step in
     // flight at once), whose partial sums meet in LDS and are added in wavefront order.
-    constexpr int XCAP = 3072;
+    constexpr int XCAP = 4608; // (36 KB: a 5 000-camera survey's region of 36 blocks and its 1 428 tail unknowns fit)
     __shared__ double xl[XCAP];
     __shared__ double xb[NB];
     __shared__ double part[4][LM_TG];
