@@ -16,7 +16,9 @@
 // candidate does suppression and description.  DESIGN.md section 4.4 has the per-kernel numbers.
 #include "ctx.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstring>
 #include <vector>
 
@@ -1228,6 +1230,7 @@ struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cell
     unsigned int ori_q[128]; // orientation samples: position (i + 6) * 13 + (j + 6) of the n-th member of the radius-6 disc
     float ori_g[128];        // and its Gaussian weight
     float win_ang1[64];      // start angles of the 42 orientation windows: for (a = 0; a < 2 pi; a += 0.15f)
+    unsigned int chain[64];  // describe2_kernel: what lane i sums (see there); 3 << 11 = idle
 };
 
 // One 64-thread workgroup per surviving candidate: sub-pixel fit, dominant orientation, 486-bit M-LDB.
@@ -1539,6 +1542,522 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
                  1ull << (c.x & 63));
     }
     DESC_T(5)
+}
+
+// ---- round 4: the descriptor as three launches.  What bounded describe_kernel above was the CU's LDS pipe
+// and vector issue, both spent on two sequential summations that keep few lanes busy: a window's 109 orientation samples
+// (42 lanes, one 16-byte LDS broadcast and four vector instructions per sample) and a grid cell's up to 100 lattice
+// samples (29 lanes, a 12-byte LDS read and two adds per step).  The order of both sums is the restatement's and stays.
+//  * orient_samples_kernel: one THREAD per orientation sample (gather, Gaussian weight, angle) and, new, the set of
+//    windows the sample's angle lies in as a 42-bit mask, written as a 16-byte record.
+//  * orient_angle_kernel: one wavefront per keypoint, lane = window.  The records arrive by SCALAR loads, so a sample is
+//    `s_mov exec, mask; v_pk_add_f32 sum, sum, s[x:y]`: one vector instruction per sample instead of four, no LDS at
+//    all, the adds in sample order in every window.
+//  * describe2_kernel: the lattice and the cells.  Every (cell, channel) sum is a chain of its own on its own lane
+//    (4-byte LDS reads at immediate offsets, one add per step): 13 lanes' worth of cells x 3 channels = 39 lanes, the
+//    3 x 3 grid's cells chained in pairs and the 4 x 4 grid's in fours so that every lane walks ~100 samples.
+struct osample
+{
+    float x, y;            // Gaussian-weighted (Lx, Ly) of the sample
+    unsigned int mlo, mhi; // orientation windows (bit = window index) whose open interval contains the sample's angle
+};
+constexpr int OS_STRIDE = 112; // records per keypoint: 109 samples padded to 28 x 64 bytes (the scalar loads take 128 at a time)
+
+struct orient_tab // angle -> windows, exactly as the restatement's predicate decides (built and self-checked on the host)
+{
+    float4 bucket[104];  // per 1/16 rad: {number of window edges below the bucket (int bits), the up to three edges inside (inf = none)}
+    ulonglong2 mask[88]; // i = number of edges below the angle: .x the windows containing the open interval (E[i-1], E[i]), .y those containing E[i] itself
+};
+
+__device__ __forceinline__ unsigned long long orient_window_mask(float a, const orient_tab *__restrict__ T)
+{
+    const float TWO_PI = 6.28318530717958647692f;
+    if (!(a > 0.0f && a < TWO_PI))
+        return 0ull; // an angle of exactly 0 or 2 pi lies in no window
+    const int k = (int)(a * 16.0f);
+    const float4 bk = T->bucket[k];
+    const int i = __float_as_int(bk.x) + (bk.y < a ? 1 : 0) + (bk.z < a ? 1 : 0) + (bk.w < a ? 1 : 0);
+    const bool on_edge = bk.y == a || bk.z == a || bk.w == a;
+    const ulonglong2 m = T->mask[i];
+    return on_edge ? m.y : m.x;
+}
+
+// geometry of a keypoint in its level image, shared by the three kernels (same expressions, same roundings)
+struct kp_geom
+{
+    float kx, ky, size, xf, yf;
+    int s;
+};
+__device__ __forceinline__ kp_geom keypoint_geometry(const cand_t &c, const level_info &l, float derivative_factor)
+{
+    kp_geom g;
+    // ratio is a power of two: x / ratio == x * (1 / ratio) bit for bit (no result here comes near the denormals),
+    // and 1 / ratio is an exponent field - three IEEE division sequences less per keypoint and kernel
+    const float ratio = (float)(1 << l.octave), inv_ratio = __uint_as_float((unsigned int)(127 - l.octave) << 23);
+    g.kx = ((float)c.x + c.dx) * ratio + 0.5f * (ratio - 1.0f);
+    g.ky = ((float)c.y + c.dy) * ratio + 0.5f * (ratio - 1.0f);
+    g.size = 2.0f * (l.esigma * derivative_factor);
+    g.xf = g.kx * inv_ratio;
+    g.yf = g.ky * inv_ratio;
+    g.s = (int)rintf(0.5f * g.size * inv_ratio);
+    return g;
+}
+
+// Two wavefronts per keypoint (128 slots for 109 samples), four consecutive survivors per workgroup.
+__global__ __launch_bounds__(512) void orient_samples_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
+                                                             unsigned int max_cands, const unsigned int *__restrict__ live,
+                                                             const float2 *__restrict__ Lxy, size_t img_stride, levels_dev L,
+                                                             float derivative_factor, const pair_tab *__restrict__ tab,
+                                                             const orient_tab *__restrict__ otab, osample *__restrict__ out,
+                                                             unsigned int cap, int remap)
+{
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned int b = blockIdx.z, n = n_live[b];
+    unsigned int kb;
+    if (!xcd_contiguous(blockIdx.x, (n + 3) / 4, &kb, remap))
+        return;
+    const unsigned int kl = kb * 4 + (wv >> 1);
+    if (kl >= n)
+        return;
+    const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
+    const cand_t c = cands[slot];
+    const int q = (wv & 1) * 64 + lane;
+    const unsigned int oq = tab->ori_q[q];
+    const float og = tab->ori_g[q];
+    if (!(fabsf(c.dx) <= 1.0f && fabsf(c.dy) <= 1.0f))
+        return; // no keypoint: nobody reads its records
+    if (q >= OS_STRIDE)
+        return;
+    const level_info l = L.l[c.level];
+    const kp_geom g = keypoint_geometry(c, l, derivative_factor);
+    osample r = {0.0f, 0.0f, 0u, 0u};
+    if (q < 109)
+    {
+        // index order i (outer), j (inner) over the radius-6 disc
+        const int i = (int)oq / 13 - 6, j = (int)oq % 13 - 6;
+        const int iy = clampi((int)rintf(g.yf + (float)(j * g.s)), 0, l.h - 1), ix = clampi((int)rintf(g.xf + (float)(i * g.s)), 0, l.w - 1);
+        const float2 gr = (Lxy + (size_t)b * img_stride + l.off)[(size_t)iy * l.w + ix];
+        const float rx = og * gr.x, ry = og * gr.y;
+        const unsigned long long m = orient_window_mask(fast_atan2(ry, rx), otab);
+        // a sample in no window is never added: its values need not be kept
+        r = osample{rx, ry, (unsigned int)m, (unsigned int)(m >> 32)};
+    }
+    reinterpret_cast<float4 *>(out)[((size_t)b * cap + kl) * OS_STRIDE + q] =
+        make_float4(r.x, r.y, __uint_as_float(r.mlo), __uint_as_float(r.mhi));
+}
+
+// s[36:67] and s[68:99]: two buffers of eight records; s[34:35] keeps EXEC
+#define OCHIP_OS_SAMPLE(x0, x1, m0, m1) "s_mov_b64 exec, s[" #m0 ":" #m1 "]\n\tv_pk_add_f32 %0, %0, s[" #x0 ":" #x1 "]\n\t"
+#define OCHIP_OS_PROC_A                                                                                                      \
+    OCHIP_OS_SAMPLE(36, 37, 38, 39) OCHIP_OS_SAMPLE(40, 41, 42, 43) OCHIP_OS_SAMPLE(44, 45, 46, 47) OCHIP_OS_SAMPLE(48, 49, 50, 51)  \
+    OCHIP_OS_SAMPLE(52, 53, 54, 55) OCHIP_OS_SAMPLE(56, 57, 58, 59) OCHIP_OS_SAMPLE(60, 61, 62, 63) OCHIP_OS_SAMPLE(64, 65, 66, 67)
+#define OCHIP_OS_PROC_B                                                                                                      \
+    OCHIP_OS_SAMPLE(68, 69, 70, 71) OCHIP_OS_SAMPLE(72, 73, 74, 75) OCHIP_OS_SAMPLE(76, 77, 78, 79) OCHIP_OS_SAMPLE(80, 81, 82, 83)  \
+    OCHIP_OS_SAMPLE(84, 85, 86, 87) OCHIP_OS_SAMPLE(88, 89, 90, 91) OCHIP_OS_SAMPLE(92, 93, 94, 95) OCHIP_OS_SAMPLE(96, 97, 98, 99)
+#define OCHIP_OS_LOAD_A(o0, o1) "s_load_dwordx16 s[36:51], %1, " #o0 "\n\ts_load_dwordx16 s[52:67], %1, " #o1 "\n\t"
+#define OCHIP_OS_LOAD_B(o0, o1) "s_load_dwordx16 s[68:83], %1, " #o0 "\n\ts_load_dwordx16 s[84:99], %1, " #o1 "\n\t"
+#define OCHIP_OS_WAIT "s_waitcnt lgkmcnt(0)\n\t"
+#define OCHIP_OS_CLOBBERS                                                                                                    \
+    "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", \
+        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68",   \
+        "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",   \
+        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+
+// One wavefront per keypoint, lane = window.  The 112 records (14 groups of eight) come through the scalar cache into
+// two alternating sets of 32 SGPRs; a sample is one s_mov to EXEC and one packed add with SGPR operands, so a window
+// that does not contain the sample does nothing and the others add it - in sample order, as the restatement's loop.
+__global__ __launch_bounds__(256) void orient_angle_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
+                                                           unsigned int max_cands, const unsigned int *__restrict__ live,
+                                                           const osample *__restrict__ recs, unsigned int cap,
+                                                           float *__restrict__ angles, int remap)
+{
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned int b = blockIdx.z, n = n_live[b];
+    unsigned int kb;
+    if (!xcd_contiguous(blockIdx.x, (n + 3) / 4, &kb, remap))
+        return;
+    const unsigned int kl = kb * 4 + wv;
+    if (kl >= n)
+        return;
+    const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
+    const float cdx = cands[slot].dx, cdy = cands[slot].dy;
+    if (!(fabsf(cdx) <= 1.0f && fabsf(cdy) <= 1.0f))
+        return;
+    const osample *r = recs + ((size_t)b * cap + kl) * OS_STRIDE;
+    pkf2 sum = {0.0f, 0.0f}; // (sumX, sumY)
+    asm volatile("s_mov_b64 s[34:35], exec\n\t"                                         //
+                 OCHIP_OS_LOAD_A(0x0, 0x40) OCHIP_OS_WAIT                                //
+                 OCHIP_OS_LOAD_B(0x80, 0xc0) OCHIP_OS_PROC_A OCHIP_OS_WAIT               //
+                 OCHIP_OS_LOAD_A(0x100, 0x140) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x180, 0x1c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_A(0x200, 0x240) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x280, 0x2c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_A(0x300, 0x340) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x380, 0x3c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_A(0x400, 0x440) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x480, 0x4c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_A(0x500, 0x540) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x580, 0x5c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_A(0x600, 0x640) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x680, 0x6c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_PROC_B                                                         //
+                 "s_mov_b64 exec, s[34:35]"
+                 : "+v"(sum)
+                 : "s"(r)
+                 : OCHIP_OS_CLOBBERS, "memory");
+    float wmag = -1.0f, wangle = 0.0f;
+    if (lane < 42)
+    {
+        wmag = sum.x * sum.x + sum.y * sum.y;
+        wangle = fast_atan2(sum.y, sum.x);
+    }
+    // first strict maximum in window order (the sequential loop's choice): largest magnitude, lowest window on ties
+    int widx = lane;
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        const float om = __shfl_xor(wmag, off), oa = __shfl_xor(wangle, off);
+        const int oi = __shfl_xor(widx, off);
+        if (om > wmag || (om == wmag && oi < widx))
+        {
+            wmag = om;
+            wangle = oa;
+            widx = oi;
+        }
+    }
+    if (lane == 0)
+        angles[(size_t)b * cap + kl] = wmag > 0.0f ? wangle : 0.0f;
+}
+
+// orient_samples_kernel + orient_angle_kernel in one launch, one wavefront per keypoint: the wave writes its 112 records
+// (two rounds of 64 samples), waits for its stores to reach the L2 and reads them back through the scalar cache, which
+// hangs off the same L2.  A keypoint's records have an address of their own that nothing reads before they are written,
+// so the scalar cache cannot hold an older copy; the loads hit the L2 instead of the HBM the two-launch form sent them
+// to (14 dependent round trips per wave either way: 1.1 ms per 100 images there).
+__global__ __launch_bounds__(256) void orient_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
+                                                     unsigned int max_cands, const unsigned int *__restrict__ live,
+                                                     const float2 *__restrict__ Lxy, size_t img_stride, levels_dev L,
+                                                     float derivative_factor, const pair_tab *__restrict__ tab,
+                                                     const orient_tab *__restrict__ otab, osample *__restrict__ recs,
+                                                     unsigned int cap, float *__restrict__ angles, int remap)
+{
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned int b = blockIdx.z, n = n_live[b];
+    unsigned int kb;
+    if (!xcd_contiguous(blockIdx.x, (n + 3) / 4, &kb, remap))
+        return;
+    const unsigned int kl = kb * 4 + wv;
+    if (kl >= n)
+        return;
+    const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
+    const cand_t c = cands[slot];
+    const unsigned int oq0 = tab->ori_q[lane], oq1 = tab->ori_q[lane + 64];
+    const float og0 = tab->ori_g[lane], og1 = tab->ori_g[lane + 64];
+    if (!(fabsf(c.dx) <= 1.0f && fabsf(c.dy) <= 1.0f))
+        return;
+    const level_info l = L.l[c.level];
+    const kp_geom g = keypoint_geometry(c, l, derivative_factor);
+    osample *r = recs + ((size_t)b * cap + kl) * OS_STRIDE;
+    {
+        const float2 *pLxy = Lxy + (size_t)b * img_stride + l.off;
+        // index order i (outer), j (inner) over the radius-6 disc; lane handles samples lane and lane + 64, both loads issued together
+        const int i0 = (int)oq0 / 13 - 6, j0 = (int)oq0 % 13 - 6, i1 = (int)oq1 / 13 - 6, j1 = (int)oq1 % 13 - 6;
+        const bool second = lane + 64 < 109;
+        const int iy0 = clampi((int)rintf(g.yf + (float)(j0 * g.s)), 0, l.h - 1), ix0 = clampi((int)rintf(g.xf + (float)(i0 * g.s)), 0, l.w - 1);
+        const int iy1 = clampi((int)rintf(g.yf + (float)(j1 * g.s)), 0, l.h - 1), ix1 = clampi((int)rintf(g.xf + (float)(i1 * g.s)), 0, l.w - 1);
+        const float2 g0 = pLxy[(unsigned int)(iy0 * l.w + ix0)];
+        const float2 g1 = second ? pLxy[(unsigned int)(iy1 * l.w + ix1)] : make_float2(0.0f, 0.0f);
+        const float rx0 = og0 * g0.x, ry0 = og0 * g0.y, rx1 = og1 * g1.x, ry1 = og1 * g1.y;
+        const unsigned long long m0 = orient_window_mask(fast_atan2(ry0, rx0), otab);
+        const unsigned long long m1 = second ? orient_window_mask(fast_atan2(ry1, rx1), otab) : 0ull;
+        float4 *out = reinterpret_cast<float4 *>(r);
+        out[lane] = make_float4(rx0, ry0, __uint_as_float((unsigned int)m0), __uint_as_float((unsigned int)(m0 >> 32)));
+        if (lane + 64 < OS_STRIDE)
+            out[lane + 64] = make_float4(rx1, ry1, __uint_as_float((unsigned int)m1), __uint_as_float((unsigned int)(m1 >> 32)));
+    }
+    pkf2 sum = {0.0f, 0.0f}; // (sumX, sumY)
+    asm volatile("s_waitcnt vmcnt(0)\n\t" // the records are in the L2
+                 "s_mov_b64 s[34:35], exec\n\t"                                        //
+                 OCHIP_OS_LOAD_A(0x0, 0x40) OCHIP_OS_WAIT                                //
+                 OCHIP_OS_LOAD_B(0x80, 0xc0) OCHIP_OS_PROC_A OCHIP_OS_WAIT               //
+                 OCHIP_OS_LOAD_A(0x100, 0x140) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x180, 0x1c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_A(0x200, 0x240) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x280, 0x2c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_A(0x300, 0x340) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x380, 0x3c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_A(0x400, 0x440) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x480, 0x4c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_A(0x500, 0x540) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x580, 0x5c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_A(0x600, 0x640) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
+                 OCHIP_OS_LOAD_B(0x680, 0x6c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
+                 OCHIP_OS_PROC_B                                                         //
+                 "s_mov_b64 exec, s[34:35]"
+                 : "+v"(sum)
+                 : "s"(r)
+                 : OCHIP_OS_CLOBBERS, "memory");
+    float wmag = -1.0f, wangle = 0.0f;
+    if (lane < 42)
+    {
+        wmag = sum.x * sum.x + sum.y * sum.y;
+        wangle = fast_atan2(sum.y, sum.x);
+    }
+    // first strict maximum in window order (the sequential loop's choice): largest magnitude, lowest window on ties
+    int widx = lane;
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        const float om = __shfl_xor(wmag, off), oa = __shfl_xor(wangle, off);
+        const int oi = __shfl_xor(widx, off);
+        if (om > wmag || (om == wmag && oi < widx))
+        {
+            wmag = om;
+            wangle = oa;
+            widx = oi;
+        }
+    }
+    if (lane == 0)
+        angles[(size_t)b * cap + kl] = wmag > 0.0f ? wangle : 0.0f;
+}
+
+// What describe2_kernel needs of a keypoint besides its pixels, computed by one THREAD per keypoint: the same few dozen
+// instructions (position, sine and cosine of the orientation) cost a whole wavefront's issue slots each when the
+// keypoint's wavefront computes them for itself.
+struct kp_frame
+{
+    float xf, yf, fs; // position in the level image, sample spacing
+    float si, co;     // rotation of the lattice
+    float kx, ky, size; // the keypoint as it is reported
+};
+__global__ __launch_bounds__(256) void kp_frame_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
+                                                       unsigned int max_cands, const unsigned int *__restrict__ live,
+                                                       const float *__restrict__ angles, unsigned int cap,
+                                                       const levels_dev *__restrict__ L, float derivative_factor,
+                                                       kp_frame *__restrict__ frames)
+{
+    const unsigned int b = blockIdx.z, kl = blockIdx.x * 256 + threadIdx.x;
+    if (kl >= n_live[b])
+        return;
+    const cand_t c = cands[(size_t)b * max_cands + live[(size_t)b * max_cands + kl]];
+    if (!(fabsf(c.dx) <= 1.0f && fabsf(c.dy) <= 1.0f))
+        return;
+    const kp_geom g = keypoint_geometry(c, L->l[c.level], derivative_factor);
+    kp_frame f;
+    f.xf = g.xf, f.yf = g.yf, f.fs = (float)g.s;
+    sincos_poly(angles[(size_t)b * cap + kl], &f.si, &f.co);
+    f.kx = g.kx, f.ky = g.ky, f.size = g.size;
+    float4 *o = reinterpret_cast<float4 *>(frames + (size_t)b * cap + kl);
+    o[0] = make_float4(f.xf, f.yf, f.fs, f.si);
+    o[1] = make_float4(f.co, f.kx, f.ky, f.size);
+}
+
+// Lattice gather, cell sums, descriptor bits of one surviving candidate per wavefront (four consecutive ones per
+// workgroup, wave-level barriers only); the orientation comes from orient_angle_kernel.
+__global__ __launch_bounds__(256) void describe2_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
+                                                       unsigned int max_cands, const unsigned int *__restrict__ live,
+                                                       const float *__restrict__ angles, const kp_frame *__restrict__ frames,
+                                                       unsigned int cap, const float *__restrict__ Lt,
+                                                       const float2 *__restrict__ Lxy, size_t img_stride, levels_dev L,
+                                                       const pair_tab *__restrict__ tab, float *__restrict__ kp_out /*[b][max][6]*/,
+                                                       unsigned long long *__restrict__ desc_out /*[b][max][8]*/,
+                                                       unsigned char *__restrict__ valid_out, int remap,
+                                                       unsigned long long *__restrict__ vmask, size_t mask_stride)
+{
+    __shared__ float vals_all[4][30][3]; // cell sums, then cell means; row 29 takes the store of a chain that has no cell left
+    __shared__ float smp_all[4][441 * 3 + 1];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float(&vals)[30][3] = vals_all[wv];
+    float *const smp = smp_all[wv];
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // LDS writes of the wave before LDS reads after
+        __builtin_amdgcn_wave_barrier();
+    };
+    const unsigned int b = blockIdx.z;
+    const unsigned int n = n_live[b];
+    unsigned int kb;
+    if (!xcd_contiguous(blockIdx.x, (n + 3) / 4, &kb, remap))
+        return;
+    const unsigned int kl = kb * 4 + wv;
+    if (kl >= n)
+        return;
+    const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
+    // everything whose address is known up front is requested here, together
+    const cand_t c = cands[slot];
+    const float angle = angles[(size_t)b * cap + kl];
+    const kp_frame fr = frames[(size_t)b * cap + kl];
+    const unsigned int chain = tab->chain[lane];
+    unsigned int tbits[8];
+#pragma unroll
+    for (int wd = 0; wd < 8; wd++)
+        tbits[wd] = tab->bits[wd * 64 + lane];
+    const level_info l = L.l[c.level];
+    const int w = l.w, h = l.h;
+    if (!(fabsf(c.dx) <= 1.0f && fabsf(c.dy) <= 1.0f))
+    {
+        if (lane == 0)
+            valid_out[slot] = 0;
+        return;
+    }
+    const float xf = fr.xf, yf = fr.yf, si = fr.si, co = fr.co, fs = fr.fs;
+    const float *pLt = Lt + (size_t)b * img_stride + l.off;
+    const float2 *pLxy = Lxy + (size_t)b * img_stride + l.off;
+    bool all_inside = true;
+    // every grid (2x2, 3x3, 4x4) samples the same rotated 21 x 21 lattice: gather it once with all lanes (7 rounds of
+    // 64 points: first every address, then every load - 14 in flight per lane -, then the rotations and the LDS stores)
+    {
+        float ri[7], rx[7], ry[7];
+        bool inside[7];
+        const float a0 = (float)(lane / 21 - 10), b0 = (float)(lane % 21 - 10);
+#pragma unroll
+        for (int t = 0; t < 7; t++)
+        {
+            const int p = lane + 64 * t;
+            // (a, bb) = (p / 21 - 10, p % 21 - 10) without the divisions: 64 = 3 * 21 + 1, so a round moves a point three
+            // rows down and one column on, and at most once over the seven rounds past the end of its row
+            const bool wrapped = b0 + (float)t > 10.0f;
+            const float fa = a0 + (float)(3 * t) + (wrapped ? 1.0f : 0.0f), fb = b0 + (float)t - (wrapped ? 21.0f : 0.0f);
+            const float sy = yf + (fb * co * fs + fa * si * fs);
+            const float sx = xf + (-fb * si * fs + fa * co * fs);
+            const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
+            inside[t] = p < 441 && !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
+            // 32-bit byte offsets from a wave-uniform base (a level plane is far below 2^29 pixels): the loads take the
+            // base from SGPRs and the offset from one VGPR, no 64-bit address arithmetic per lane
+            const unsigned int o = inside[t] ? (unsigned int)(y1 * w + x1) : 0u;
+            ri[t] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pLt) + o * 4u);
+            const float2 gr = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(pLxy) + o * 8u);
+            rx[t] = gr.x;
+            ry[t] = gr.y;
+        }
+#pragma unroll
+        for (int t = 0; t < 7; t++)
+        {
+            const int p = lane + 64 * t;
+            if (p < 441)
+            {
+                const float rry = rx[t] * co + ry[t] * si, rrx = -rx[t] * si + ry[t] * co;
+                // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
+                // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch in the sums
+                smp[3 * p] = inside[t] ? ri[t] : 0.0f;
+                smp[3 * p + 1] = inside[t] ? rrx : 0.0f;
+                smp[3 * p + 2] = inside[t] ? rry : 0.0f;
+                all_inside = all_inside && inside[t];
+            }
+        }
+    }
+    all_inside = __all(all_inside) != 0;
+    wave_sync();
+    // ---- cell sums.  chain word (host table): lattice point of the first sample | channel << 9 | class << 11 | first cell <<
+    // 13 | "the pair's second cell follows the first in memory" << 18.  Classes: 0 = a 10 x 10 cell of the 2 x 2 grid,
+    // 1 = two 7 x 7 cells of the 3 x 3 grid one after the other (the ninth alone), 2 = four 5 x 5 cells of the 4 x 4 grid,
+    // 3 = idle lane.  All lanes execute the same 100 reads at immediate offsets 12 t from their own pointer; where a
+    // lane's walk does not continue 12 bytes on (its cell's row ends, its next cell begins) the pointer takes the
+    // difference: one add of a per-lane constant at the steps where some class turns, 32 in all.
+    {
+        const int cls = (int)((chain >> 11) & 3u), ch = (int)((chain >> 9) & 3u);
+        if (cls != 3)
+        {
+            const char *pb = reinterpret_cast<const char *>(smp + 3 * (chain & 511u) + ch);
+            float *sp = &vals[(chain >> 13) & 31u][ch];
+            const bool big = cls == 0, med = cls == 1, sml = cls == 2;
+            const int r5row = sml ? 192 : 0, r5cell = sml ? -1008 : 0;
+            const int r10row = sml ? 192 : (big ? 132 : 0), r10cell = sml ? -1008 : (big ? 132 : 0);
+            const int r7row = med ? 168 : 0, r7cell = (med && !((chain >> 18) & 1u)) ? -1512 : 0;
+            // a chain whose cells are used up stores into the spare row
+            const int sp_step = (med && ((chain >> 13) & 31u) == 12u) ? (29 - 12) * 3 : 3;
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 100; t++)
+            {
+                acc = acc + *reinterpret_cast<const float *>(pb + 12 * t);
+                const bool end5 = t % 25 == 24, end7 = t == 48 || t == 97, end10 = t == 99;
+                if (end5 || end10)
+                {
+                    if (sml || (end10 && big))
+                    {
+                        *sp = acc;
+                        sp += sp_step;
+                        acc = 0.0f;
+                    }
+                }
+                if (end7)
+                {
+                    if (med)
+                    {
+                        *sp = acc;
+                        sp += sp_step;
+                        acc = 0.0f;
+                    }
+                }
+                if (t % 5 == 4 && t != 99)
+                    pb += (t % 10 == 4) ? ((t == 24 || t == 74) ? r5cell : r5row) : (t == 49 ? r10cell : r10row);
+                if (t == 48)
+                    pb += r7cell;
+                else if (t < 97 && (t % 49) % 7 == 6)
+                    pb += r7row;
+            }
+        }
+    }
+    wave_sync();
+    if (lane < 29)
+    {
+        int lvl, cell;
+        if (lane < 4)
+            lvl = 0, cell = lane;
+        else if (lane < 13)
+            lvl = 1, cell = lane - 4;
+        else
+            lvl = 2, cell = lane - 13;
+        const int gsz = lvl + 2;
+        const int step = (lvl == 0) ? 10 : (lvl == 1 ? 7 : 5); // ceil(20 / g)
+        // number of samples of the cell inside the image: all of them, except for a keypoint near a border, whose lanes
+        // repeat the lattice arithmetic of the gather above (same expressions, same roundings, same answers)
+        int count = step * step;
+        if (!all_inside)
+        {
+            const int i0 = -10 + (cell / gsz) * step, j0 = -10 + (cell % gsz) * step;
+            count = 0;
+            for (int a = i0; a < i0 + step; a++)
+                for (int bb = j0; bb < j0 + step; bb++)
+                {
+                    const float sy = yf + ((float)bb * co * fs + (float)a * si * fs);
+                    const float sx = xf + (-(float)bb * si * fs + (float)a * co * fs);
+                    const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
+                    count += !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h) ? 1 : 0;
+                }
+        }
+        const float inv = fmaxf((float)count, 1.0f);
+        const float di = vals[lane][0], ddx = vals[lane][1], ddy = vals[lane][2];
+        vals[lane][0] = di / inv;
+        vals[lane][1] = ddx / inv;
+        vals[lane][2] = ddy / inv;
+    }
+    wave_sync();
+    for (int wd = 0; wd < 8; wd++)
+    {
+        const int bit = wd * 64 + lane;
+        bool on = false;
+        if (bit < 486)
+        {
+            const unsigned int e = tbits[wd], ch = e >> 16;
+            on = vals[e & 255u][ch] > vals[(e >> 8) & 255u][ch];
+        }
+        const unsigned long long word = __ballot(on);
+        if (lane == 0)
+            desc_out[slot * 8 + wd] = word;
+    }
+    if (lane == 0)
+    {
+        float *o = kp_out + slot * 6;
+        o[0] = fr.kx;
+        o[1] = fr.ky;
+        o[2] = fr.size;
+        o[3] = angle;
+        o[4] = c.response;
+        o[5] = (float)c.level;
+        valid_out[slot] = 1;
+        // the keypoint's bit in the image's (level, y, x)-ordered mask: its rank there is its place in the output
+        atomicOr(&vmask[(size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6)],
+                 1ull << (c.x & 63));
+    }
 }
 
 // The keypoints leave the device in AKAZE's detection order (level, then row, then column of the extremum - the order
@@ -1921,6 +2440,119 @@ int ochip_synth_render_views(ochip_ctx *ctx, uint8_t *images_dev, uint32_t first
 namespace
 {
 
+// orient_tab from the 42 float-accumulated window starts: every window is an open interval (ang1, ang2) of (0, 2 pi),
+// or - wrapped - the union (0, ang2) + (ang1, 2 pi) (the predicate of the CPU restatement, its akaze.cpp:606-614).  The 84
+// interval ends cut (0, 2 pi) into pieces on which the set of windows containing an angle is constant; an angle ON an
+// end lies in the windows common to the two pieces it separates.  The table is checked against the predicate itself at
+// every end, at its float neighbours and over a sweep of angles before it is used (once per process).
+struct orient_windows
+{
+    float a1[42], a2[42];
+    orient_tab T;
+    bool ok = false;
+
+    unsigned long long direct(float a) const // the predicate of the restatement's window loop
+    {
+        const float TWO_PI_F = 6.28318530717958647692f;
+        unsigned long long m = 0;
+        for (int w = 0; w < 42; w++)
+            if ((a1[w] < a2[w] && a1[w] < a && a < a2[w]) || (a2[w] < a1[w] && ((a > 0.0f && a < a2[w]) || (a > a1[w] && a < TWO_PI_F))))
+                m |= 1ull << w;
+        return m;
+    }
+    unsigned long long lookup(float a) const // orient_window_mask on the host
+    {
+        const float TWO_PI_F = 6.28318530717958647692f;
+        if (!(a > 0.0f && a < TWO_PI_F))
+            return 0ull;
+        const float4 bk = T.bucket[(int)(a * 16.0f)];
+        int base;
+        std::memcpy(&base, &bk.x, 4);
+        const int i = base + (bk.y < a ? 1 : 0) + (bk.z < a ? 1 : 0) + (bk.w < a ? 1 : 0);
+        const bool on_edge = bk.y == a || bk.z == a || bk.w == a;
+        return on_edge ? T.mask[i].y : T.mask[i].x;
+    }
+    orient_windows()
+    {
+        const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
+        int nw = 0;
+        for (float a = 0.0f; a < TWO_PI_F && nw < 42; a += 0.15f) // for (ang1 = 0; ang1 < 2 pi; ang1 += 0.15f)
+            a1[nw++] = a;
+        if (nw != 42 || !(a1[41] + 0.15f >= TWO_PI_F))
+            return;
+        for (int w = 0; w < 42; w++)
+            a2[w] = (a1[w] + PI_F / 3.0f > TWO_PI_F) ? a1[w] - 5.0f * PI_F / 3.0f : a1[w] + PI_F / 3.0f;
+        std::vector<float> E(a1, a1 + 42);
+        E.insert(E.end(), a2, a2 + 42);
+        std::sort(E.begin(), E.end());
+        E.erase(std::unique(E.begin(), E.end()), E.end());
+        const int n = (int)E.size();
+        if (n + 1 > 88 || E.front() < 0.0f || !(E.back() < TWO_PI_F))
+            return;
+        std::vector<unsigned long long> M(n + 2, 0ull);
+        for (int i = 0; i <= n; i++)
+        {
+            const float lo = i == 0 ? 0.0f : E[i - 1], hi = i == n ? TWO_PI_F : E[i]; // the piece (lo, hi)
+            for (int w = 0; w < 42; w++)
+            {
+                const bool in = a1[w] < a2[w] ? (a1[w] <= lo && hi <= a2[w]) : (a2[w] < a1[w] && (hi <= a2[w] || a1[w] <= lo));
+                if (in)
+                    M[i] |= 1ull << w;
+            }
+        }
+        M[n + 1] = M[n];
+        for (int i = 0; i < 88; i++)
+        {
+            const int k = std::min(i, n);
+            T.mask[i] = make_ulonglong2(M[k], M[k] & M[k + 1]);
+        }
+        const float INF = std::numeric_limits<float>::infinity();
+        if ((int)(TWO_PI_F * 16.0f) + 1 > 104)
+            return;
+        for (int k = 0; k < 104; k++)
+        {
+            int base = 0, n_in = 0;
+            float in[3] = {INF, INF, INF};
+            for (float e : E)
+            {
+                const int ke = (int)(e * 16.0f);
+                if (ke < k)
+                    base++;
+                else if (ke == k)
+                {
+                    if (n_in == 3)
+                        return;
+                    in[n_in++] = e;
+                }
+            }
+            float fbase;
+            std::memcpy(&fbase, &base, 4);
+            T.bucket[k] = make_float4(fbase, in[0], in[1], in[2]);
+        }
+        for (float e : E)
+        {
+            float a = e;
+            for (int k = 0; k < 3; k++)
+                a = std::nextafter(a, -INF);
+            for (int k = 0; k < 7; k++, a = std::nextafter(a, INF))
+                if (lookup(a) != direct(a))
+                    return;
+        }
+        for (int k = 0; k <= 100000; k++)
+        {
+            const float a = (float)k * (TWO_PI_F / 100000.0f);
+            if (lookup(a) != direct(a))
+                return;
+        }
+        ok = true;
+    }
+};
+const orient_windows &host_orient_windows()
+{
+    static const orient_windows W;
+    return W;
+}
+
 // images: n_images x h x w x 3 BGR bytes (host, or device when on_device).  Working size: the INTER_AREA
 // downscale to max side 1600 of extract_features.cpp:26-27.  Outputs (host): per image up to max_kp keypoints,
 // in unspecified order: kp6 = {x, y, size, angle(rad), response, level} in working-image pixels, desc = 8 x u64,
@@ -2017,6 +2649,11 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned long long *d_mask = nullptr, *d_vmask = nullptr;
     unsigned int *d_wbase = nullptr, *d_live = nullptr, *d_nlive = nullptr;
     pair_tab *d_tab = nullptr;
+    orient_tab *d_otab = nullptr;
+    osample *d_osamp = nullptr;
+    float *d_angles = nullptr;
+    kp_frame *d_frames = nullptr;
+    levels_dev *d_levels = nullptr;
     const size_t src_px = (size_t)width * height;
     // 1-D tile grids padded to a multiple of 8 workgroups (xcd_tile)
     auto tiles = [&](int w, int h) { return dim3(8 * ((((w + BT_X - 1) / BT_X) * ((h + BT_Y - 1) / BT_Y) + 7) / 8), 1, B); };
@@ -2125,7 +2762,39 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 nq++;
             }
         }
+        // describe2_kernel's chains: lane 3 c + channel sums channel `channel` of chain c - the four 10 x 10 cells, the
+        // 7 x 7 cells in pairs (the ninth alone), the 5 x 5 cells in fours; cells numbered 0..3 | 4..12 | 13..28
+        {
+            for (int i = 0; i < 64; i++)
+                tab.chain[i] = 3u << 11;
+            struct ch_t
+            {
+                int cls, first_cell, i, j, follows;
+            };
+            std::vector<ch_t> chains;
+            for (int k = 0; k < 4; k++)
+                chains.push_back({0, k, -10 + (k / 2) * 10, -10 + (k % 2) * 10, 0});
+            for (int k = 0; k < 9; k += 2) // cell 2 ends at lattice point 146 and cell 3 begins at 147
+                chains.push_back({1, 4 + k, -10 + (k / 3) * 7, -10 + (k % 3) * 7, k == 2 ? 1 : 0});
+            for (int k = 0; k < 16; k += 4)
+                chains.push_back({2, 13 + k, -10 + (k / 4) * 5, -10, 0});
+            for (size_t cidx = 0; cidx < chains.size(); cidx++)
+                for (int ch = 0; ch < 3; ch++)
+                {
+                    const ch_t &cc = chains[cidx];
+                    const unsigned int p0 = (unsigned int)((cc.i + 10) * 21 + (cc.j + 10));
+                    tab.chain[3 * cidx + ch] = p0 | ((unsigned int)ch << 9) | ((unsigned int)cc.cls << 11) |
+                                               ((unsigned int)cc.first_cell << 13) | ((unsigned int)cc.follows << 18);
+                }
+        }
         AK(up(ctx, allocs, &d_tab, &tab, 1));
+        const orient_windows &ow = host_orient_windows();
+        if (!ow.ok || std::memcmp(ow.a1, tab.win_ang1, sizeof ow.a1) != 0)
+        {
+            cleanup();
+            return ochip_fail(ctx, OCHIP_EINVAL, "akaze: the orientation-window table disagrees with the window predicate");
+        }
+        AK(up(ctx, allocs, &d_otab, &ow.T, 1));
     }
     if (rc != OCHIP_OK)
     {
@@ -2387,8 +3056,45 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                        (const cand_t *)d_cands, (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live,       \
                        (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, dfactor,                                    \
                        (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap, d_vmask, mask_stride)
+        static const bool describe_v1 = getenv("OCHIP_DESCRIBE_V1") != nullptr; // A/B: the one-launch descriptor of rounds 1-3
         if (max_live == 0)
             ;
+        else if (!describe_v1)
+        {
+            // orientation samples -> orientation -> lattice + cells + bits, over the survivors
+            AK(up<osample>(ctx, allocs, &d_osamp, nullptr, (size_t)B * max_live * OS_STRIDE));
+            AK(up<float>(ctx, allocs, &d_angles, nullptr, (size_t)B * max_live));
+            AK(up<kp_frame>(ctx, allocs, &d_frames, nullptr, (size_t)B * max_live));
+            AK(up(ctx, allocs, &d_levels, &LV, 1));
+            if (rc != OCHIP_OK)
+            {
+                cleanup();
+                return rc;
+            }
+            const dim3 dgrid(512 * (((max_live + 3) / 4 + 511) / 512), 1, B);
+            static const bool orient_two = getenv("OCHIP_ORIENT_TWO_LAUNCHES") != nullptr; // A/B
+            if (orient_two)
+            {
+                hipLaunchKernelGGL(orient_samples_kernel, dgrid, dim3(512), 0, st, (const cand_t *)d_cands,
+                                   (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live, (const float2 *)d_Lxy,
+                                   img_stride, LV, dfactor, (const pair_tab *)d_tab, (const orient_tab *)d_otab, d_osamp, max_live,
+                                   xcd_remap);
+                hipLaunchKernelGGL(orient_angle_kernel, dgrid, dim3(256), 0, st, (const cand_t *)d_cands,
+                                   (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live, (const osample *)d_osamp,
+                                   max_live, d_angles, xcd_remap);
+            }
+            else
+                hipLaunchKernelGGL(orient_kernel, dgrid, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_nlive,
+                                   max_cands, (const unsigned int *)d_live, (const float2 *)d_Lxy, img_stride, LV, dfactor,
+                                   (const pair_tab *)d_tab, (const orient_tab *)d_otab, d_osamp, max_live, d_angles, xcd_remap);
+            hipLaunchKernelGGL(kp_frame_kernel, dim3((max_live + 255) / 256, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
+                               (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live, (const float *)d_angles,
+                               max_live, (const levels_dev *)d_levels, dfactor, d_frames);
+            hipLaunchKernelGGL(describe2_kernel, dgrid, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_nlive,
+                               max_cands, (const unsigned int *)d_live, (const float *)d_angles, (const kp_frame *)d_frames,
+                               max_live, (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, (const pair_tab *)d_tab,
+                               d_kp, d_desc, d_valid, xcd_remap, d_vmask, mask_stride);
+        }
         else if (!profile_describe)
             OCHIP_LAUNCH_DESCRIBE(false);
         else
@@ -2465,3 +3171,18 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
 }
 
 } // namespace
+
+extern "C" int ochip_debug_orientation_windows(const float *angles, uint32_t n, uint64_t *by_table, uint64_t *by_predicate)
+{
+    if ((n && !angles) || !by_table || !by_predicate)
+        return OCHIP_EINVAL;
+    const orient_windows &ow = host_orient_windows();
+    if (!ow.ok)
+        return OCHIP_EINVAL;
+    for (uint32_t i = 0; i < n; i++)
+    {
+        by_table[i] = ow.lookup(angles[i]);
+        by_predicate[i] = ow.direct(angles[i]);
+    }
+    return OCHIP_OK;
+}

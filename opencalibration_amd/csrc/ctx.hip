@@ -219,6 +219,9 @@ void ochip_ctx_destroy(ochip_ctx *ctx)
         (void)hipFree(ctx->sym_jobs_dev);
     if (ctx->sym_part_dev)
         (void)hipFree(ctx->sym_part_dev);
+    for (void *b : {ctx->desc_fp4_dev, ctx->desc_negpop_dev, ctx->desc_pop_dev})
+        if (b)
+            (void)hipFree(b);
     for (auto &b : ctx->dev_pool)
         (void)hipFree(b.first);
     for (auto &b : ctx->pinned_pool)
@@ -311,6 +314,7 @@ int ochip_descriptors_reserve(ochip_ctx *ctx, uint32_t n_images, uint64_t total_
     ctx->rays_dirty = false;
     ctx->kp_store_ready = false;
     ctx->desc_capacity = ctx->desc_used = 0;
+    ctx->fp4_valid = 0;
     ctx->n_images = n_images;
     ctx->img_off.assign(n_images, 0);
     ctx->img_n.assign(n_images, 0);

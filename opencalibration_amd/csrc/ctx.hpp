@@ -68,6 +68,12 @@ struct ochip_ctx
     uint32_t ms_pairs = 0;
     void *sym_jobs_dev = nullptr, *sym_part_dev = nullptr; // symmetric pairs of a match launch: job table, column partials
     size_t sym_jobs_cap = 0, sym_part_cap = 0;
+    // operands of the matrix-core matcher (match.hip, hamming_2nn_mfma_kernel), same indexing as the descriptor arena: the
+    // descriptor's 512 bits as FP4 values 0 / 1 (256 bytes), (512 - popcount) * 8192 as a float, the popcount; features
+    // [0, fp4_valid) are expanded, the rest is done by the next match launch
+    void *desc_fp4_dev = nullptr, *desc_negpop_dev = nullptr, *desc_pop_dev = nullptr;
+    size_t desc_fp4_cap = 0, desc_negpop_cap = 0, desc_pop_cap = 0;
+    uint64_t fp4_valid = 0;
 
     // generic scratch for the RANSAC / relax kernels (grown on demand)
     void *scratch_dev[8] = {nullptr};

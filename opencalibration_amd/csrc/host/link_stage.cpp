@@ -842,7 +842,7 @@ bool LinkStage::import_edges(const MeasurementGraph &graph, const std::vector<si
     }
     std::vector<edge_payload> payloads(recs.size());
     bool bad = false;
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 16) reduction(|| : bad)
     for (size_t e = 0; e < recs.size(); e++)
     {
         const edge_header &h = recs[e].h;

@@ -67,6 +67,14 @@ och_shard *och_shard_begin(och_graph *g, ochip_ctx *ctx, uint32_t n_images, uint
             g->error = "och_shard_begin: bad argument";
         return nullptr;
     }
+    if (g->graph.size_nodes() != 0)
+    {
+        // the link stage's k-NN runs over every node of the graph: a pair whose partner is an image of an earlier survey
+        // has no owner among this survey's blocks and would be dropped without a word, so the sharded edge set would
+        // differ from the single-process one
+        g->error = "och_shard_begin: the graph already holds nodes; a sharded survey starts from an empty graph";
+        return nullptr;
+    }
     auto *s = new och_shard();
     s->g = g;
     s->ctx = ctx;
@@ -94,7 +102,11 @@ och_shard *och_shard_begin(och_graph *g, ochip_ctx *ctx, uint32_t n_images, uint
         const uint32_t a = (uint32_t)op.pair.first; // links are in image order
         const auto it = s->image_of.find(op.pair.second);
         if (it == s->image_of.end())
-            continue; // (an image of an earlier survey: not supported here, the graph is this survey's)
+        {
+            g->error = "och_shard_begin: a link's partner is not an image of this survey";
+            delete s;
+            return nullptr;
+        }
         const uint32_t b = it->second;
         const bool a_in = a >= s->lo && a < s->hi, b_in = b >= s->lo && b < s->hi;
         if (a_in && b_in)

@@ -304,6 +304,191 @@ __global__ __launch_bounds__(BLOCK) void sym_merge_kernel(const sym_job *__restr
     out[jb.off_ba + r] = m;
 }
 
+// ---- the same 2-NN on the matrix cores ---------------------------------------------------------------------------
+// popcount(a ^ b) = |a| + |b| - 2 a.b, and a.b of two 486-bit vectors is a small integer: an MFMA over the bits taken as
+// numbers computes 1 024 of them per instruction where the vector pipe needs 32 instructions per 64.  The descriptors are
+// expanded once to FP4 (E2M1) values 0 / 1 - 256 bytes each - and v_mfma_scale_f32_32x32x64_f8f6f4 (eight per 32 x 32
+// tile of distances) accumulates, in fp32 and exactly (every term is an integer below 2^24):
+//     key(query, reference k) = (512 - |ref|) * 8192 + (8191 - k) + 16384 * (query . ref)
+// - the first two terms enter as the accumulator's initial value, 16 384 is the block scale of the reference operand.
+// key / 8192 = 512 - |ref| + 2 q.r = 512 + |q| - distance, so the LARGEST key of a query is its nearest reference, the
+// lowest k among equals, and the second largest key carries the second smallest distance - the reference's scan with its
+// strict '<' (match_features.cpp:80-92) again; the vector pipe is left with two instructions per distance-lane-register
+// (v_med3_f32, v_max_f32), 64 per 2 048 distances, and the result tile never leaves the registers: an MFMA tile has its
+// column on the lane, so with the queries as columns every lane folds its own query's 16 references.
+// A wavefront keeps 64 queries as B operands in registers (two tiles); the four waves of a workgroup share the reference
+// tiles (32 references, 8 KB) through LDS, double-buffered, XOR-swizzled so that the 16-byte operand reads are conflict
+// free.  References beyond n2 start from -1e9 and never win.  Needs n2 <= 8 192 (k in 13 bits); larger images take the
+// popcount kernels above.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+constexpr uint32_t MFMA_MAX_REFS = 8192;
+constexpr int MFMA_QUERIES = 256; // per workgroup: 4 waves x 64
+
+// bits -> FP4: one thread per byte of a descriptor (8 bits -> 8 nibbles of value 0b0010 = 1.0 or 0), a wave per feature
+__global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restrict__ desc, uint64_t first, uint64_t n,
+                                                         uint32_t *__restrict__ fp4, float *__restrict__ negpop,
+                                                         uint32_t *__restrict__ pop)
+{
+    const uint64_t f = first + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= first + n)
+        return;
+    const int j = threadIdx.x & 63;
+    const uint32_t x = (desc[f * 16 + (j >> 2)] >> (8 * (j & 3))) & 0xFFu;
+    uint32_t t = (x | (x << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    fp4[f * 64 + j] = t << 1;
+    uint32_t c = (uint32_t)__popc(x);
+    for (int off = 32; off >= 1; off >>= 1)
+        c += (uint32_t)__shfl_xor((int)c, off);
+    if (j == 0)
+    {
+        pop[f] = c;
+        negpop[f] = (float)((512 - (int)c) * 8192);
+    }
+}
+
+__device__ __forceinline__ float med3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max_f32(float a, float b) // fmaxf without the canonicalising v_max x, x in front (no NaN here)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__restrict__ fp4, const float *__restrict__ negpop,
+                                                               const uint32_t *__restrict__ pop,
+                                                               const uint64_t *__restrict__ img_off,
+                                                               const uint32_t *__restrict__ img_n,
+                                                               const ochip_pair *__restrict__ pairs,
+                                                               const uint64_t *__restrict__ out_off,
+                                                               ochip_match *__restrict__ out, uint32_t chunks_per_pair)
+{
+    __shared__ uint4 tileA[2][32 * 16]; // reference rows of a tile: [row][16 x 16 bytes], slot j of row r at j ^ (r & 15)
+    __shared__ float tileC[2][32];      // the rows' accumulator start: (512 - |ref|) * 8192 + (8191 - k)
+    const uint32_t pair = blockIdx.x / chunks_per_pair;
+    const uint32_t chunk = blockIdx.x - pair * chunks_per_pair;
+    const ochip_pair pr = pairs[pair];
+    const uint32_t n1 = img_n[pr.image_1], n2 = img_n[pr.image_2];
+    const uint32_t q0 = chunk * MFMA_QUERIES;
+    if (q0 >= n1 || n2 == 0) // uniform for the workgroup (n2 == 0: the caller fills "no match")
+        return;
+    const uint64_t off1 = img_off[pr.image_1], off2 = img_off[pr.image_2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+    // queries of this wave: columns r of its two tiles; lane (r, h) holds the k range [64 s + 32 h, + 32) of step s
+    v8i Bq[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+    {
+        uint32_t qi = q0 + wv * 64 + t * 32 + r;
+        qi = qi < n1 ? qi : n1 - 1;
+        const uint4 *src = fp4 + (off1 + qi) * 16;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; sidx++)
+        {
+            const uint4 v = src[2 * sidx + h];
+            Bq[t][sidx] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+        }
+    }
+    float best[2] = {-1.0f, -1.0f}, second[2] = {-1.0f, -1.0f};
+    const uint32_t n_tiles = (n2 + 31) / 32;
+    // staging: thread tid moves 16-byte pieces tid and tid + 256 of the tile's 512 (rows are consecutive features: one
+    // contiguous 8 KB read); rows beyond n2 re-read the last feature and are disabled through tileC
+    auto tile_piece = [&](uint32_t jt, int piece) -> uint4 {
+        const uint32_t row = (uint32_t)piece >> 4;
+        uint32_t k = jt * 32 + row;
+        k = k < n2 ? k : n2 - 1;
+        return fp4[(off2 + k) * 16 + (piece & 15)];
+    };
+    auto tile_c = [&](uint32_t jt) -> float {
+        const uint32_t k = jt * 32 + (uint32_t)tid;
+        return (tid < 32 && k < n2) ? negpop[off2 + k] + (float)(8191 - (int)k) : -1e9f;
+    };
+    auto put_tile = [&](int buf, uint4 p0, uint4 p1, float c) {
+        const int r0 = tid >> 4, j0 = tid & 15, r1 = (tid + 256) >> 4;
+        tileA[buf][r0 * 16 + (j0 ^ (r0 & 15))] = p0;
+        tileA[buf][r1 * 16 + (j0 ^ (r1 & 15))] = p1;
+        if (tid < 32)
+            tileC[buf][tid] = c;
+    };
+    {
+        const uint4 p0 = tile_piece(0, tid), p1 = tile_piece(0, tid + 256);
+        put_tile(0, p0, p1, tile_c(0));
+    }
+    __syncthreads();
+    for (uint32_t jt = 0; jt < n_tiles; jt++)
+    {
+        const int cur = (int)(jt & 1);
+        const bool more = jt + 1 < n_tiles;
+        uint4 n0 = make_uint4(0, 0, 0, 0), n1v = n0;
+        float nc = 0.0f;
+        if (more) // the next tile's loads fly under this tile's MFMAs
+        {
+            n0 = tile_piece(jt + 1, tid);
+            n1v = tile_piece(jt + 1, tid + 256);
+            nc = tile_c(jt + 1);
+        }
+        // accumulator start: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h
+        v16f c0;
+#pragma unroll
+        for (int gidx = 0; gidx < 4; gidx++)
+        {
+            const float4 c4 = *reinterpret_cast<const float4 *>(&tileC[cur][8 * gidx + 4 * h]);
+            c0[4 * gidx + 0] = c4.x;
+            c0[4 * gidx + 1] = c4.y;
+            c0[4 * gidx + 2] = c4.z;
+            c0[4 * gidx + 3] = c4.w;
+        }
+        v16f acc0 = c0, acc1 = c0;
+#pragma unroll
+        for (int sidx = 0; sidx < 8; sidx++)
+        {
+            const uint4 a = tileA[cur][r * 16 + ((2 * sidx + h) ^ (r & 15))];
+            const v8i A = v8i{(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
+            // FP4 both sides (cbsz = blgp = 4); block scales: 2^14 on the references (E8M0 141), 1 on the queries (127)
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[0][sidx], acc0, 4, 4, 0, 141, 0, 127);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[1][sidx], acc1, 4, 4, 0, 141, 0, 127);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            second[0] = med3_f32(best[0], second[0], acc0[i]);
+            best[0] = max_f32(best[0], acc0[i]);
+            second[1] = med3_f32(best[1], second[1], acc1[i]);
+            best[1] = max_f32(best[1], acc1[i]);
+        }
+        if (more)
+            put_tile(cur ^ 1, n0, n1v, nc);
+        __syncthreads();
+    }
+    // the two half-waves hold the same queries' other 16 rows per tile
+    ochip_match *__restrict__ o = out + out_off[pair];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+    {
+        const float ob = __shfl_xor(best[t], 32), os = __shfl_xor(second[t], 32);
+        const float hi = fmaxf(best[t], ob), lo = fminf(best[t], ob), ms = fmaxf(second[t], os);
+        const float b2 = fmaxf(lo, ms);
+        const uint32_t qi = q0 + wv * 64 + t * 32 + r;
+        if (h == 0 && qi < n1)
+        {
+            const uint32_t pq = pop[off1 + qi];
+            const int kb = (int)hi; // exact: an integer below 2^24
+            ochip_match m;
+            m.best_k = 8191u - ((uint32_t)kb & 8191u);
+            m.best_count = (uint16_t)(pq + 512u - ((uint32_t)kb >> 13));
+            m.second_count = b2 < 0.0f ? (uint16_t)OCHIP_NO_SECOND : (uint16_t)(pq + 512u - ((uint32_t)(int)b2 >> 13));
+            o[qi] = m;
+        }
+    }
+}
+
 } // namespace
 
 extern "C"
@@ -338,7 +523,27 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
         max_n1 = ctx->img_n[pr.image_1] > max_n1 ? ctx->img_n[pr.image_1] : max_n1;
     }
 
-    // ---- pairs whose reverse is in the batch too are matched in both directions from one pass over their distances
+    // ---- pairs whose reference image fits the matrix-core kernel's 13-bit index go there, each direction on its own
+    static const bool use_mfma = !(getenv("OCHIP_MATCH_MFMA") && getenv("OCHIP_MATCH_MFMA")[0] == '0'); // A/B knob
+    std::vector<ochip_pair> mfma_pairs;
+    std::vector<uint64_t> mfma_off;
+    uint32_t mfma_max_n1 = 0;
+    std::vector<char> claimed(n_pairs, 0);
+    if (use_mfma)
+        for (uint32_t p = 0; p < n_pairs; p++)
+        {
+            const uint32_t na = ctx->img_n[pairs[p].image_1], nb = ctx->img_n[pairs[p].image_2];
+            if (na == 0 || nb == 0 || nb > MFMA_MAX_REFS)
+                continue;
+            claimed[p] = 1;
+            mfma_pairs.push_back(pairs[p]);
+            mfma_off.push_back(out_offset[p]);
+            mfma_max_n1 = std::max(mfma_max_n1, na);
+            ctx->match_computed += (uint64_t)na * nb;
+            ctx->match_delivered += (uint64_t)na * nb;
+        }
+    const uint32_t n_mfma = (uint32_t)mfma_pairs.size();
+    // ---- of the others, pairs whose reverse is in the batch too are matched in both directions from one pass over their distances
     static const bool use_sym = !(getenv("OCHIP_MATCH_SYM") && getenv("OCHIP_MATCH_SYM")[0] == '0'); // A/B knob
     std::vector<sym_job> sym;
     std::vector<ochip_pair> single_pairs;
@@ -350,8 +555,8 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
         std::unordered_map<uint64_t, uint32_t> first; // (image_1, image_2) -> first pair with these images
         if (use_sym)
             for (uint32_t p = 0; p < n_pairs; p++)
-                first.emplace(((uint64_t)pairs[p].image_1 << 32) | pairs[p].image_2, p);
-        std::vector<char> claimed(n_pairs, 0);
+                if (!claimed[p])
+                    first.emplace(((uint64_t)pairs[p].image_1 << 32) | pairs[p].image_2, p);
         for (uint32_t p = 0; p < n_pairs; p++)
         {
             if (claimed[p])
@@ -404,7 +609,7 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
                                       hipMemcpyHostToDevice, ctx->stream));
         ctx->img_tables_dirty = false;
     }
-    if (n_single > ctx->pairs_cap)
+    if (n_single + n_mfma > ctx->pairs_cap)
     {
         if (ctx->pairs_dev)
             OCHIP_HIP(ctx, hipFree(ctx->pairs_dev));
@@ -413,10 +618,33 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
         ctx->pairs_dev = nullptr;
         ctx->out_off_dev = nullptr;
         ctx->pairs_cap = 0;
-        if (hipMalloc((void **)&ctx->pairs_dev, (size_t)n_single * sizeof(ochip_pair)) != hipSuccess ||
-            hipMalloc((void **)&ctx->out_off_dev, (size_t)n_single * 8) != hipSuccess)
+        if (hipMalloc((void **)&ctx->pairs_dev, (size_t)(n_single + n_mfma) * sizeof(ochip_pair)) != hipSuccess ||
+            hipMalloc((void **)&ctx->out_off_dev, (size_t)(n_single + n_mfma) * 8) != hipSuccess)
             return ochip_fail(ctx, OCHIP_ENOMEM, "hipMalloc for the pair table failed");
-        ctx->pairs_cap = n_single;
+        ctx->pairs_cap = n_single + n_mfma;
+    }
+    if (n_mfma)
+    {
+        // operands of the matrix-core kernel for the features uploaded since the last launch
+        int rc = ochip_ensure(ctx, &ctx->desc_fp4_dev, &ctx->desc_fp4_cap, (size_t)ctx->desc_capacity * 256);
+        if (rc == OCHIP_OK)
+            rc = ochip_ensure(ctx, &ctx->desc_negpop_dev, &ctx->desc_negpop_cap, (size_t)ctx->desc_capacity * 4);
+        if (rc == OCHIP_OK)
+            rc = ochip_ensure(ctx, &ctx->desc_pop_dev, &ctx->desc_pop_cap, (size_t)ctx->desc_capacity * 4);
+        if (rc)
+            return rc;
+        if (ctx->fp4_valid < ctx->desc_used)
+        {
+            const uint64_t n_new = ctx->desc_used - ctx->fp4_valid;
+            hipLaunchKernelGGL(expand_fp4_kernel, dim3((uint32_t)((n_new + 3) / 4)), dim3(256), 0, ctx->stream, ctx->desc_dev,
+                               ctx->fp4_valid, n_new, (uint32_t *)ctx->desc_fp4_dev, (float *)ctx->desc_negpop_dev,
+                               (uint32_t *)ctx->desc_pop_dev);
+            ctx->fp4_valid = ctx->desc_used;
+        }
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->pairs_dev + n_single, mfma_pairs.data(), (size_t)n_mfma * sizeof(ochip_pair),
+                                      hipMemcpyHostToDevice, ctx->stream));
+        OCHIP_HIP(ctx, hipMemcpyAsync(ctx->out_off_dev + n_single, mfma_off.data(), (size_t)n_mfma * 8, hipMemcpyHostToDevice,
+                                      ctx->stream));
     }
     {
         void *p = ctx->match_out_dev;
@@ -457,10 +685,17 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
     const uint64_t blocks = (uint64_t)chunks * n_single;
     const uint32_t sym_chunks = (sym_max_na + BLOCK - 1) / BLOCK;
     const uint64_t sym_blocks = (uint64_t)sym_chunks * n_sym;
-    if (blocks > 0x7FFFFFFFull || sym_blocks > 0x7FFFFFFFull)
-        return ochip_fail(ctx, OCHIP_EINVAL, "batch too large: %llu workgroups", (unsigned long long)(blocks + sym_blocks));
+    const uint32_t mfma_chunks = (mfma_max_n1 + MFMA_QUERIES - 1) / MFMA_QUERIES;
+    const uint64_t mfma_blocks = (uint64_t)mfma_chunks * n_mfma;
+    if (blocks > 0x7FFFFFFFull || sym_blocks > 0x7FFFFFFFull || mfma_blocks > 0x7FFFFFFFull)
+        return ochip_fail(ctx, OCHIP_EINVAL, "batch too large: %llu workgroups", (unsigned long long)(blocks + sym_blocks + mfma_blocks));
     hipEvent_t e0, e1;
     ochip_prof_begin(ctx, OCHIP_K_MATCH, &e0, &e1);
+    if (mfma_blocks)
+        hipLaunchKernelGGL(hamming_2nn_mfma_kernel, dim3((uint32_t)mfma_blocks), dim3(256), 0, ctx->stream,
+                           (const uint4 *)ctx->desc_fp4_dev, (const float *)ctx->desc_negpop_dev,
+                           (const uint32_t *)ctx->desc_pop_dev, ctx->img_off_dev, ctx->img_n_dev, ctx->pairs_dev + n_single,
+                           ctx->out_off_dev + n_single, ctx->match_out_dev, mfma_chunks);
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(BLOCK), 0, ctx->stream, ctx->desc_dev,
                            ctx->img_off_dev, ctx->img_n_dev, ctx->pairs_dev, ctx->out_off_dev, ctx->match_out_dev,

@@ -2264,6 +2264,10 @@ int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_
         std::vector<std::pair<void *, size_t>> *allocs;
         ~put_back()
         {
+            // an early error return can leave kernels in flight that still touch these blocks: the pool must not hand
+            // them to the next caller before the stream has drained (on the normal path it already has)
+            if (!allocs->empty())
+                (void)ochip_stream_wait(ctx, ctx->stream);
             for (auto &a : *allocs)
                 ochip_pool_put(ctx, a.first, a.second);
         }

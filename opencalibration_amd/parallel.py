@@ -195,7 +195,8 @@ def all_gather_bytes(buf, group=None, stats=None):
     if stats is not None:
         stats["exchanges"] = stats.get("exchanges", 0) + 1
         stats["bytes_gathered"] = stats.get("bytes_gathered", 0) + sum(sizes)
-    return [host[r * cap:r * cap + sizes[r]] for r in range(world)]
+    # copies: on the RCCL path `host` views a page-locked staging buffer that the next call overwrites
+    return [host[r * cap:r * cap + sizes[r]].copy() for r in range(world)]
 
 
 def survey_sharded(ctx, graph, model, positions, orientations, images_block, width, height, group=None, max_keypoints=30000,

@@ -150,7 +150,37 @@ def test_parity_holds_when_the_partials_do_not_fit():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OCHIP_MATCH_SYM_CAP_MB="1")
+    env = dict(os.environ, OCHIP_MATCH_SYM_CAP_MB="1", OCHIP_MATCH_MFMA="0")   # (the popcount kernels: see the last test)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_match.py"), os.path.join(root, "tests", "test_gpu_link.py"),
-                        "-x", "-q", "-m", "gpu", "-k", "not partials_do_not_fit"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+                        "-x", "-q", "-m", "gpu", "-k", "not partials_do_not_fit and not popcount_kernels"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n1,n2", [(100, 8192), (70, 8193)])
+def test_reference_sets_at_the_matrix_core_kernels_limit(ctx, n1, n2):
+    """The matrix-core kernel carries the reference index in 13 bits of an fp32 key: 8 192 references are its largest
+    set, one more goes to the popcount kernels.  Both sides of the limit must give the brute-force answer."""
+    rng = np.random.default_rng(n2)
+    d2 = synth.descriptors_for_ids(np.arange(n2) + 50_000)
+    d1 = d2[rng.permutation(n2)[:n1]].copy()
+    bits = rng.integers(0, 486, (n1, 12))
+    for j in range(12):
+        d1[np.arange(n1), bits[:, j] >> 6] ^= np.uint64(1) << (bits[:, j] & 63).astype(np.uint64)
+    d2[n2 - 1] = d2[n2 - 2]     # a tie between the last two references
+    _upload(ctx, [d1, d2])
+    out = ctx.match_batch(np.array([(0, 1)], capi.PAIR_DTYPE), np.array([0], np.uint64), n1)
+    bk, bc, sc = _expect(d1, d2)
+    assert np.array_equal(out["best_k"], bk) and np.array_equal(out["best_count"], bc) and np.array_equal(out["second_count"], sc)
+
+
+def test_popcount_kernels_still_agree():
+    """OCHIP_MATCH_MFMA=0 sends every pair to the popcount kernels (the path of images with more than 8 192 features in
+    the matcher).  The switch is read once per process: this file's parity tests are re-run in a child with it set."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, OCHIP_MATCH_MFMA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
+                        "raw_top2 or mixed_batch or full_size or subset_parity"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
