@@ -54,7 +54,7 @@ if os.environ.get("OCHIP_BENCH_KEEP_HEAP", "1") != "0":
     _libc.mallopt(-2, 64 << 20)   # M_TOP_PAD
 
 METRIC = "images/sec end-to-end (extract+match+relax) on synthetic aerial grid; LM iters/sec"
-DTYPE = "f32 (extract) + u32 popcount (match) + f64 (RANSAC, relax)"
+DTYPE = "f32 (extract) + fp4 0/1 bits, f32 accumulate, exact (match) + f64 (RANSAC, relax)"
 
 
 def _env_int(name, default):
@@ -161,6 +161,7 @@ class Proc:
         import torch.distributed as dist
 
         self.torch, self.dist = torch, dist
+        self.preflight_s = None
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback)")
         # one rank per GPU over RCCL ("nccl").  OCHIP_BENCH_BACKEND=gloo is a test hook: it lets the N > 1 code path
@@ -174,6 +175,42 @@ class Proc:
             else:
                 dist.init_process_group(self.backend)
             self.world = dist.get_world_size()       # the ranks that really joined the communicator
+            self.preflight_s = self._preflight()
+
+    def _preflight(self):
+        """The first collective of a scaling run is also the first time these ranks talk: a 4 MB all-gather (the
+        size of the relax exchange) checked against what every rank must hold afterwards, under a watchdog, so
+        that a transport that cannot work ends the job with one line and a non-zero code instead of hanging in the first
+        exchange of the timed region."""
+        torch, dist = self.torch, self.dist
+        limit = float(os.environ.get("OCHIP_BENCH_PREFLIGHT_TIMEOUT", "60"))
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(limit):
+                sys.stderr.write(f"bench.py: rank {self.rank}: the {self.backend} pre-flight all-gather did not finish in "
+                                 f"{limit:.0f} s (communicator of {self.world} ranks); giving up\n")
+                sys.stderr.flush()
+                os._exit(3)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        t0 = time.perf_counter()
+        n = (4 << 20) // 8 // self.world
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        full = torch.zeros(self.world * n, dtype=torch.float64, device=dev)
+        mine = torch.arange(n, dtype=torch.float64, device=dev) + float(self.rank) * 1e6
+        dist.all_gather_into_tensor(full, mine)
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        expect = (torch.arange(n, dtype=torch.float64).repeat(self.world)
+                  + torch.arange(self.world, dtype=torch.float64).repeat_interleave(n) * 1e6)
+        ok = bool(torch.equal(full.cpu(), expect))
+        done.set()
+        if not ok:
+            sys.stderr.write(f"bench.py: rank {self.rank}: the {self.backend} pre-flight all-gather returned wrong data\n")
+            sys.stderr.flush()
+            os._exit(4)
+        return round(time.perf_counter() - t0, 3)
 
     def barrier(self):
         if self.world > 1:
@@ -218,6 +255,7 @@ def device_rooflines(ctx, capi, steps, images_per_step, t_extract_per_step, shap
     n_akaze, ms_akaze = prof(capi.K_AKAZE)
     match_computed, match_delivered = ctx.match_work()
     relax_flops = ctx.relax_work()
+    work = ctx.work_counters()
     _, h, w = shape
     alg_bytes_img = extract_algorithmic_bytes(w, h)
     imgs_per_launch = images_per_step * steps / max(n_akaze, 1)
@@ -240,18 +278,39 @@ def device_rooflines(ctx, capi, steps, images_per_step, t_extract_per_step, shap
         "algorithmic_bytes_per_launch": round(alg_bytes_img * imgs_per_launch),
         "algorithmic_bytes_per_image": round(alg_bytes_img),
         "staged": staged,
-        # match: integer-VALU bound (16 v_xor + 16 accumulating v_bcnt per 512-bit distance per lane; the bound is the
-        # measured issue rate of exactly that instruction mix, scripts/ubench_valu.hip: 1.3e12 distances/s on 256 CUs).
-        # HBM traffic of the kernels is negligible (descriptors are read once per tile from L2, 64 B per feature).
-        "match": {"kernel": "hamming_2nn_sym_kernel + hamming_2nn_kernel + sym_merge_kernel", "bound": "valu",
-                  "achieved": round(match_computed / max(ms_match, 1e-9) * 1e3 / 1e12, 4), "peak": 1.3,
-                  "unit": "1e12 descriptor distances/s computed",
-                  "frac": round(match_computed / max(ms_match, 1e-9) * 1e3 / 1.3e12, 4),
-                  "delivered_1e12_per_s": round(match_delivered / max(ms_match, 1e-9) * 1e3 / 1e12, 4),
+        # match: the 2-NN runs on the matrix cores (hamming_2nn_mfma_kernel: popcount(a ^ b) = |a| + |b| - 2 a.b with the bits
+        # as FP4 0 / 1, v_mfma_scale_f32_32x32x64_f8f6f4, 8 instructions per 32 x 32 tile of distances): 2 x 512 flop per
+        # distance against the dense FP4 peak of 10 PFLOP/s = 9.8e12 distances/s.  Every direction of a pair is a job of
+        # its own (the vector-pipe kernels of rounds 1-3 took both directions from one pass; they remain for images with
+        # more than 8 192 features in the matcher).  HBM traffic is negligible (256 B per feature and tile pass, from L2).
+        "match": {"kernel": "hamming_2nn_mfma_kernel (+ expand_fp4_kernel)", "bound": "mfma",
+                  "achieved": round(match_computed / max(ms_match, 1e-9) * 1e3 / 1e12, 4), "peak": 9.8,
+                  "unit": "1e12 descriptor distances/s (FP4 MFMA: 1 024 flop each, dense peak 10 PFLOP/s)",
+                  "frac": round(match_computed / max(ms_match, 1e-9) * 1e3 / 9.8e12, 4),
+                  "tflops": round(match_computed * 1024 / max(ms_match, 1e-9) * 1e3 / 1e12, 1),
                   "distances_per_step": round(match_computed / max(steps, 1)),
                   "features_entering_matcher_per_image": None if not link_work else round(link_work["subset_features"] / max(link_work.get("images", 1), 1), 1),
                   "directed_pairs": int(edges), "launches": n_match,
                   "device_ms_per_step": round(ms_match / max(steps, 1), 3)},
+        # RANSAC scoring: fp64 on the vector pipe.  Per (hypothesis, correspondence): two 3 x 3 matrix-vector products, two
+        # perspective divisions, the symmetric transfer error with its square root and the MSAC term, ~50 flops
+        # (homography_model.cpp:89-118).  The count is loop trips x correspondences, an upper bound (SPRT leaves early).
+        "ransac": {"kernel": "ransac_homography_kernel", "bound": "fp64 valu",
+                   "achieved": round(work["ransac_hyp_corr"] * 50 / max(ms_ransac, 1e-9) * 1e3 / 1e12, 4), "peak": 78.6, "unit": "TFLOP/s",
+                   "frac": round(work["ransac_hyp_corr"] * 50 / max(ms_ransac, 1e-9) * 1e3 / 78.6e12, 5),
+                   "hypothesis_correspondence_pairs_per_step": round(work["ransac_hyp_corr"] / max(steps, 1)),
+                   "note": "latency-bound by design: one wavefront per image pair walks the reference's sequential loop (sample, "
+                           "9 x 9 LU, score with early exit, local optimisation); the scoring is a fraction of its instructions",
+                   "device_ms_per_step": round(ms_ransac / max(steps, 1), 3)},
+        # relax evaluation (ground-plane engine): per 2-ray residual block 56 B in (two rays, two camera indices) and its
+        # share of the pair's packed J'J record out; ~4 kflop with 11-wide duals, ~0.4 kflop for the cost alone
+        "relax_eval": {"kernel": "relax_pair_eval_kernel<true|false>", "bound": "neither (register-limited occupancy)",
+                       "blocks_with_jacobian": work["relax_blocks_jac"], "blocks_cost_only": work["relax_blocks_cost"],
+                       "achieved_tflops": round((work["relax_blocks_jac"] * 4000 + work["relax_blocks_cost"] * 400) / max(ms_eval, 1e-9) * 1e3 / 1e12, 3),
+                       "frac_of_fp64_vector_peak": round((work["relax_blocks_jac"] * 4000 + work["relax_blocks_cost"] * 400) / max(ms_eval, 1e-9) * 1e3 / 78.6e12, 4),
+                       "achieved_gbs": round((work["relax_blocks_jac"] + work["relax_blocks_cost"]) * 56 / max(ms_eval, 1e-9) * 1e3 / 1e9, 1),
+                       "frac_of_hbm_peak": round((work["relax_blocks_jac"] + work["relax_blocks_cost"]) * 56 / max(ms_eval, 1e-9) * 1e3 / 8e12, 5),
+                       "device_ms_per_step": round(ms_eval / max(steps, 1), 3)},
         # relax linear solve: the only MFMA use on the path (v_mfma_f64_16x16x4f64 in the tile products of the block-envelope
         # Cholesky, one launch per factorisation).  The factorisation is a dependency chain of 64 x 64 tiles and is bound by
         # the diagonal tiles' latency, not by the matrix cores; the dense figure is the peak the guide's FP64-matrix rate
@@ -265,7 +324,7 @@ def device_rooflines(ctx, capi, steps, images_per_step, t_extract_per_step, shap
                        "flops_per_step": round(relax_flops / max(steps, 1)), "solves": n_solve,
                        "system_memory": relax_memory_report(ctx)},
         "other_kernels_avg_ms": {
-            "hamming_2nn_kernel": round(ms_match / max(n_match, 1), 3),
+            "match launch (all pairs of a link range)": round(ms_match / max(n_match, 1), 3),
             "ransac_homography_kernel": round(ms_ransac / max(n_ransac, 1), 3),
             "relax_pair_eval_kernel": round(ms_eval / max(n_eval, 1), 4),
             "relax_linear_solve (build + tile Cholesky + substitutions + step)": round(ms_solve / max(n_solve, 1), 3)},
@@ -626,7 +685,9 @@ def strong_report(runner, proc, args, cfg, hot_max, acc):
         "ranks": proc.world, "steps": steps,
         "relax": ("pipelined over surveys: rank k mod N relaxes survey k alone, in the shadow of the following surveys' load + link; "
                   "every relax completes inside the timed region") if runner.pipelined else
-                 "sharded inside the step: residual blocks over all ranks, one all-gather of the per-pair records per evaluation",
+                 "sharded inside the step: residual blocks over all ranks, one all-gather of the per-pair records per evaluation; "
+                 "the Cholesky factorisation of the reduced system (0.6 of an iteration's ~1.3 ms at 3 003 unknowns) is "
+                 "replicated on every rank, which bounds the sharded solve's speed-up at ~1.4 x by design",
         "lm_iters_per_s_in_pipeline": round(lm_iters / max(relax_dev, 1e-9), 2),
         "block_images_rank0": runner.cnt, "pairs_in_block_rank0": st.get("pairs_in_block"),
         "pairs_across_blocks_rank0": st.get("pairs_across_blocks"), "halo_images_rank0": st.get("halo_images"),
@@ -670,6 +731,8 @@ def strong_main(args, proc, cfg):
             "metric": METRIC, "value": report["images_per_s"], "unit": "images/s", "n_gpus": proc.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": report["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "images_per_s_strong_one_survey_over_all_gpus": report["images_per_s"],
+            "rccl_ranks": proc.world if proc.backend == "nccl" else 0, "collective_preflight_s": proc.preflight_s,
             "config": {"workload": f"{args.config} as ONE survey over {proc.world} rank(s) (BASELINE config C4): {grid.n_images}-image "
                                    f"synthetic aerial grid {cfg['rows']}x{cfg['cols']}, {w}x{h} rendered views resident in HBM "
                                    f"(each rank holds its block), {st['features'] / max(runner.cnt, 1):.0f} AKAZE features/image, "
@@ -764,10 +827,15 @@ def weak_main(args, proc, cfg):
     ctx.profile_reset()
     proc.barrier()
     acc = {}
+    cpu_begin = time.process_time()
     t_begin = time.perf_counter()
     run_steps(args.steps, acc)
     proc.barrier()
     hot_max = proc.max_over_ranks(time.perf_counter() - t_begin)
+    # CPU seconds of this process (all its threads) over the whole timed region: the per-stage figures of
+    # stage_seconds_per_step are process-wide deltas over intervals that overlap each other in the pipelined step (relax of
+    # survey k under load + link of survey k + 1) and so count each other's threads; this one counts everything once
+    host_cpu_total = (time.process_time() - cpu_begin) / args.steps
     value = grid.n_images * world * args.steps / hot_max
 
     res = last["res"]
@@ -831,6 +899,19 @@ def weak_main(args, proc, cfg):
             "ms_per_step": round(hot_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE,
             "data": "synthetic",
+            # both curves by name: `value` is the weak one (a survey per GPU, the unit the reference parallelises over:
+            # pipeline.cpp:42-49, 543-560); the strong one is BASELINE config C4 (ONE 1 000-image survey over the N GPUs)
+            # the boundary of the reference hands over host images (cv::Mat, load_stage.cpp:35-50): the same step measured
+            # from page-locked host memory, PCIe inclusive (best of one / two surveys in flight); never `value`
+            "images_per_s_from_host_memory": (lambda p: None if not isinstance(p, dict) or "error" in p else
+                                              max(p.get("images_per_s_end_to_end") or 0.0,
+                                                  p.get("images_per_s_end_to_end_two_surveys_in_flight") or 0.0))(
+                                                      (extras or {}).get("pcie_inclusive")),
+            "value_assumes": "views resident in HBM when the timed region starts (bench contract); PCIe-inclusive rate beside it",
+            "images_per_s_weak_one_survey_per_gpu": round(value, 3),
+            "images_per_s_strong_one_survey_over_all_gpus": (round(value, 3) if world == 1 else
+                                                             (strong or {}).get("images_per_s")),
+            "rccl_ranks": world if proc.backend == "nccl" else 0, "collective_preflight_s": proc.preflight_s,
             "config": {"workload": f"{args.config}: {grid.n_images}-image synthetic aerial grid {cfg['rows']}x{cfg['cols']}, "
                                    f"{w}x{h} rendered views resident in HBM, {res['features_per_image']:.0f} AKAZE "
                                    f"features/image ({res['sparse_per_image']:.0f} after the 8 px NMS), {res['edges']} edges",
@@ -847,6 +928,7 @@ def weak_main(args, proc, cfg):
                                         "one group (device)"],
                        "host_threads_per_rank": int(os.environ["OMP_NUM_THREADS"]), "usable_host_cpus": proc.cores,
                        "per_rank": "one grid of this shape per GPU, no data-path collective"},
+            "host_cpu_s_per_step_total": round(host_cpu_total, 4),
             "stage_seconds_per_step": {k: round(v / args.steps, 5) for k, v in acc.items()},
             "relax": relax_info,
             "beside_the_headline": extras,

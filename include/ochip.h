@@ -520,6 +520,11 @@ extern "C"
     /* fp64 flops the relax solves issued on the matrix cores (the panel and trailing-update GEMMs of their Cholesky
      * factorisations, inside the block envelope) since the last ochip_profile_reset; their time is OCHIP_K_RELAX_SOLVE's */
     int ochip_relax_work(ochip_ctx *ctx, double *mfma_flops);
+    /* roofline bookkeeping since the last ochip_profile_reset (siblings included): counters3[0] = sum over the homography
+     * RANSAC jobs of loop trips x correspondences (an upper bound of the (hypothesis, correspondence) errors evaluated -
+     * the SPRT exit of src/model_inliers/ransac.cpp:197-200 leaves a hypothesis early; time: OCHIP_K_RANSAC),
+     * [1] / [2] = 2-ray residual blocks the ground-plane engine evaluated with / without Jacobians (OCHIP_K_RELAX_EVAL) */
+    int ochip_work_counters(ochip_ctx *ctx, uint64_t *counters3);
     /* the largest reduced system a relax on this context (or a sibling) has held: its unknowns, the bytes of J'J and its
      * factor as stored (64 x 64 tiles of the block envelope, lower triangle) and what the same two matrices take dense -
      * the reference hands this system to ceres::SPARSE_NORMAL_CHOLESKY (src/relax/relax_problem.cpp:30-37) */

@@ -28,7 +28,7 @@ EXPORTS = [
     "ochip_relaxg_get_state", "ochip_relaxg_evaluate", "ochip_relaxg_set_exchange",
     "ochip_relaxp_problem_create", "ochip_relaxp_problem_destroy", "ochip_relaxp_set_structure_only", "ochip_relaxp_solve",
     "ochip_relaxp_get_state",
-    "ochip_profile_reset", "ochip_profile_get", "ochip_match_work", "ochip_relax_work", "ochip_relax_memory",
+    "ochip_profile_reset", "ochip_profile_get", "ochip_match_work", "ochip_relax_work", "ochip_relax_memory", "ochip_work_counters",
     "ochip_debug_fp64", "ochip_debug_std_sort", "ochip_debug_orientation_windows", "ochip_match_sort", "ochip_ransac_homography_batch_sorted", "ochip_edge_lists",
     "ochip_dense_index_create", "ochip_dense_index_destroy", "ochip_dense_match",
     "ochip_rccl_unique_id", "ochip_rccl_comm_create", "ochip_rccl_comm_destroy", "ochip_rccl_comm_stats",
@@ -312,6 +312,13 @@ class Context:
         f = C.c_double()
         self._check(self.L.ochip_relax_work(self.h, C.byref(f)), "ochip_relax_work")
         return f.value
+
+    def work_counters(self):
+        """{ransac loop trips x correspondences, relax residual blocks with / without Jacobians} since the last profile reset."""
+        out = (C.c_uint64 * 3)()
+        self.L.ochip_work_counters.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self.L.ochip_work_counters(self.h, out), "ochip_work_counters")
+        return {"ransac_hyp_corr": int(out[0]), "relax_blocks_jac": int(out[1]), "relax_blocks_cost": int(out[2])}
 
     def relax_memory(self):
         """(unknowns, bytes stored, bytes dense) of the largest reduced system a relax on this context has held."""

@@ -1544,25 +1544,23 @@ __global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict_
     DESC_T(5)
 }
 
-// ---- round 4: the descriptor as three launches.  What bounded describe_kernel above was the CU's LDS pipe
-// and vector issue, both spent on two sequential summations that keep few lanes busy: a window's 109 orientation samples
-// (42 lanes, one 16-byte LDS broadcast and four vector instructions per sample) and a grid cell's up to 100 lattice
-// samples (29 lanes, a 12-byte LDS read and two adds per step).  The order of both sums is the restatement's and stays.
-//  * orient_samples_kernel: one THREAD per orientation sample (gather, Gaussian weight, angle) and, new, the set of
-//    windows the sample's angle lies in as a 42-bit mask, written as a 16-byte record.
-//  * orient_angle_kernel: one wavefront per keypoint, lane = window.  The records arrive by SCALAR loads, so a sample is
-//    `s_mov exec, mask; v_pk_add_f32 sum, sum, s[x:y]`: one vector instruction per sample instead of four, no LDS at
-//    all, the adds in sample order in every window.
-//  * describe2_kernel: the lattice and the cells.  Every (cell, channel) sum is a chain of its own on its own lane
-//    (4-byte LDS reads at immediate offsets, one add per step): 13 lanes' worth of cells x 3 channels = 39 lanes, the
-//    3 x 3 grid's cells chained in pairs and the 4 x 4 grid's in fours so that every lane walks ~100 samples.
-struct osample
-{
-    float x, y;            // Gaussian-weighted (Lx, Ly) of the sample
-    unsigned int mlo, mhi; // orientation windows (bit = window index) whose open interval contains the sample's angle
-};
-constexpr int OS_STRIDE = 112; // records per keypoint: 109 samples padded to 28 x 64 bytes (the scalar loads take 128 at a time)
-
+// ---- round 4: the descriptor kernel again.  The counters of round 3 had the CU's LDS pipe as busy as
+// its vector issue; with both relieved (below) what bounds the kernel is the rate at which a CU's L1 looks up the cache
+// lines of the gathers: ~800 line accesses per keypoint, about one per cycle.  Three changes, every sum still in the
+// restatement's sequential order:
+//  * orientation windows by EXEC mask.  A sample lies in a cyclic run of the 42 windows; which ones is read off a table of
+//    the 84 window ends (orient_tab, checked against the restatement's comparison chain on the host).  The window loop
+//    sets EXEC to the sample's mask (two v_readlane from the lane that owns the sample) and adds: 3 vector instructions
+//    and an 8-byte LDS broadcast per sample instead of 4 and 16 bytes.  (Tried and dropped: the masks and samples through
+//    the scalar cache - one vector instruction per sample, but 14 dependent scalar-memory round trips per wave, 1.7 ms per
+//    100 images against the 0.6 ms the whole orientation took before.)
+//  * cell sums: every (cell, channel) sum is a chain of its own on its own lane (4-byte LDS reads at immediate offsets,
+//    one add per step): 13 lanes' worth of cells x 3 channels = 39 lanes, the 3 x 3 grid's cells chained in pairs and the
+//    4 x 4 grid's in fours so that every lane walks ~100 samples - half the adds, a quarter of the LDS cycles.
+//  * gathers in image order.  Which lane fetches which lattice point is free (the LDS image is indexed by the point): the
+//    points are dealt to the lanes sorted by image row, then column, for the keypoint's orientation (32 classes, host
+//    table), so a gather instruction covers a band of a few image rows whose neighbouring lanes share cache lines; the
+//    orientation samples likewise go row by row.
 struct orient_tab // angle -> windows, exactly as the restatement's predicate decides (built and self-checked on the host)
 {
     float4 bucket[104];  // per 1/16 rad: {number of window edges below the bucket (int bits), the up to three edges inside (inf = none)}
@@ -1603,261 +1601,24 @@ __device__ __forceinline__ kp_geom keypoint_geometry(const cand_t &c, const leve
     return g;
 }
 
-// Two wavefronts per keypoint (128 slots for 109 samples), four consecutive survivors per workgroup.
-__global__ __launch_bounds__(512) void orient_samples_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
-                                                             unsigned int max_cands, const unsigned int *__restrict__ live,
-                                                             const float2 *__restrict__ Lxy, size_t img_stride, levels_dev L,
-                                                             float derivative_factor, const pair_tab *__restrict__ tab,
-                                                             const orient_tab *__restrict__ otab, osample *__restrict__ out,
-                                                             unsigned int cap, int remap)
+struct gather_tab
 {
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned int b = blockIdx.z, n = n_live[b];
-    unsigned int kb;
-    if (!xcd_contiguous(blockIdx.x, (n + 3) / 4, &kb, remap))
-        return;
-    const unsigned int kl = kb * 4 + (wv >> 1);
-    if (kl >= n)
-        return;
-    const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
-    const cand_t c = cands[slot];
-    const int q = (wv & 1) * 64 + lane;
-    const unsigned int oq = tab->ori_q[q];
-    const float og = tab->ori_g[q];
-    if (!(fabsf(c.dx) <= 1.0f && fabsf(c.dy) <= 1.0f))
-        return; // no keypoint: nobody reads its records
-    if (q >= OS_STRIDE)
-        return;
-    const level_info l = L.l[c.level];
-    const kp_geom g = keypoint_geometry(c, l, derivative_factor);
-    osample r = {0.0f, 0.0f, 0u, 0u};
-    if (q < 109)
-    {
-        // index order i (outer), j (inner) over the radius-6 disc
-        const int i = (int)oq / 13 - 6, j = (int)oq % 13 - 6;
-        const int iy = clampi((int)rintf(g.yf + (float)(j * g.s)), 0, l.h - 1), ix = clampi((int)rintf(g.xf + (float)(i * g.s)), 0, l.w - 1);
-        const float2 gr = (Lxy + (size_t)b * img_stride + l.off)[(size_t)iy * l.w + ix];
-        const float rx = og * gr.x, ry = og * gr.y;
-        const unsigned long long m = orient_window_mask(fast_atan2(ry, rx), otab);
-        // a sample in no window is never added: its values need not be kept
-        r = osample{rx, ry, (unsigned int)m, (unsigned int)(m >> 32)};
-    }
-    reinterpret_cast<float4 *>(out)[((size_t)b * cap + kl) * OS_STRIDE + q] =
-        make_float4(r.x, r.y, __uint_as_float(r.mlo), __uint_as_float(r.mhi));
-}
-
-// s[36:67] and s[68:99]: two buffers of eight records; s[34:35] keeps EXEC
-#define OCHIP_OS_SAMPLE(x0, x1, m0, m1) "s_mov_b64 exec, s[" #m0 ":" #m1 "]\n\tv_pk_add_f32 %0, %0, s[" #x0 ":" #x1 "]\n\t"
-#define OCHIP_OS_PROC_A                                                                                                      \
-    OCHIP_OS_SAMPLE(36, 37, 38, 39) OCHIP_OS_SAMPLE(40, 41, 42, 43) OCHIP_OS_SAMPLE(44, 45, 46, 47) OCHIP_OS_SAMPLE(48, 49, 50, 51)  \
-    OCHIP_OS_SAMPLE(52, 53, 54, 55) OCHIP_OS_SAMPLE(56, 57, 58, 59) OCHIP_OS_SAMPLE(60, 61, 62, 63) OCHIP_OS_SAMPLE(64, 65, 66, 67)
-#define OCHIP_OS_PROC_B                                                                                                      \
-    OCHIP_OS_SAMPLE(68, 69, 70, 71) OCHIP_OS_SAMPLE(72, 73, 74, 75) OCHIP_OS_SAMPLE(76, 77, 78, 79) OCHIP_OS_SAMPLE(80, 81, 82, 83)  \
-    OCHIP_OS_SAMPLE(84, 85, 86, 87) OCHIP_OS_SAMPLE(88, 89, 90, 91) OCHIP_OS_SAMPLE(92, 93, 94, 95) OCHIP_OS_SAMPLE(96, 97, 98, 99)
-#define OCHIP_OS_LOAD_A(o0, o1) "s_load_dwordx16 s[36:51], %1, " #o0 "\n\ts_load_dwordx16 s[52:67], %1, " #o1 "\n\t"
-#define OCHIP_OS_LOAD_B(o0, o1) "s_load_dwordx16 s[68:83], %1, " #o0 "\n\ts_load_dwordx16 s[84:99], %1, " #o1 "\n\t"
-#define OCHIP_OS_WAIT "s_waitcnt lgkmcnt(0)\n\t"
-#define OCHIP_OS_CLOBBERS                                                                                                    \
-    "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", \
-        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68",   \
-        "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",   \
-        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
-
-// One wavefront per keypoint, lane = window.  The 112 records (14 groups of eight) come through the scalar cache into
-// two alternating sets of 32 SGPRs; a sample is one s_mov to EXEC and one packed add with SGPR operands, so a window
-// that does not contain the sample does nothing and the others add it - in sample order, as the restatement's loop.
-__global__ __launch_bounds__(256) void orient_angle_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
-                                                           unsigned int max_cands, const unsigned int *__restrict__ live,
-                                                           const osample *__restrict__ recs, unsigned int cap,
-                                                           float *__restrict__ angles, int remap)
-{
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned int b = blockIdx.z, n = n_live[b];
-    unsigned int kb;
-    if (!xcd_contiguous(blockIdx.x, (n + 3) / 4, &kb, remap))
-        return;
-    const unsigned int kl = kb * 4 + wv;
-    if (kl >= n)
-        return;
-    const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
-    const float cdx = cands[slot].dx, cdy = cands[slot].dy;
-    if (!(fabsf(cdx) <= 1.0f && fabsf(cdy) <= 1.0f))
-        return;
-    const osample *r = recs + ((size_t)b * cap + kl) * OS_STRIDE;
-    pkf2 sum = {0.0f, 0.0f}; // (sumX, sumY)
-    asm volatile("s_mov_b64 s[34:35], exec\n\t"                                         //
-                 OCHIP_OS_LOAD_A(0x0, 0x40) OCHIP_OS_WAIT                                //
-                 OCHIP_OS_LOAD_B(0x80, 0xc0) OCHIP_OS_PROC_A OCHIP_OS_WAIT               //
-                 OCHIP_OS_LOAD_A(0x100, 0x140) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x180, 0x1c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_A(0x200, 0x240) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x280, 0x2c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_A(0x300, 0x340) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x380, 0x3c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_A(0x400, 0x440) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x480, 0x4c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_A(0x500, 0x540) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x580, 0x5c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_A(0x600, 0x640) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x680, 0x6c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_PROC_B                                                         //
-                 "s_mov_b64 exec, s[34:35]"
-                 : "+v"(sum)
-                 : "s"(r)
-                 : OCHIP_OS_CLOBBERS, "memory");
-    float wmag = -1.0f, wangle = 0.0f;
-    if (lane < 42)
-    {
-        wmag = sum.x * sum.x + sum.y * sum.y;
-        wangle = fast_atan2(sum.y, sum.x);
-    }
-    // first strict maximum in window order (the sequential loop's choice): largest magnitude, lowest window on ties
-    int widx = lane;
-    for (int off = 32; off >= 1; off >>= 1)
-    {
-        const float om = __shfl_xor(wmag, off), oa = __shfl_xor(wangle, off);
-        const int oi = __shfl_xor(widx, off);
-        if (om > wmag || (om == wmag && oi < widx))
-        {
-            wmag = om;
-            wangle = oa;
-            widx = oi;
-        }
-    }
-    if (lane == 0)
-        angles[(size_t)b * cap + kl] = wmag > 0.0f ? wangle : 0.0f;
-}
-
-// orient_samples_kernel + orient_angle_kernel in one launch, one wavefront per keypoint: the wave writes its 112 records
-// (two rounds of 64 samples), waits for its stores to reach the L2 and reads them back through the scalar cache, which
-// hangs off the same L2.  A keypoint's records have an address of their own that nothing reads before they are written,
-// so the scalar cache cannot hold an older copy; the loads hit the L2 instead of the HBM the two-launch form sent them
-// to (14 dependent round trips per wave either way: 1.1 ms per 100 images there).
-__global__ __launch_bounds__(256) void orient_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
-                                                     unsigned int max_cands, const unsigned int *__restrict__ live,
-                                                     const float2 *__restrict__ Lxy, size_t img_stride, levels_dev L,
-                                                     float derivative_factor, const pair_tab *__restrict__ tab,
-                                                     const orient_tab *__restrict__ otab, osample *__restrict__ recs,
-                                                     unsigned int cap, float *__restrict__ angles, int remap)
-{
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned int b = blockIdx.z, n = n_live[b];
-    unsigned int kb;
-    if (!xcd_contiguous(blockIdx.x, (n + 3) / 4, &kb, remap))
-        return;
-    const unsigned int kl = kb * 4 + wv;
-    if (kl >= n)
-        return;
-    const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
-    const cand_t c = cands[slot];
-    const unsigned int oq0 = tab->ori_q[lane], oq1 = tab->ori_q[lane + 64];
-    const float og0 = tab->ori_g[lane], og1 = tab->ori_g[lane + 64];
-    if (!(fabsf(c.dx) <= 1.0f && fabsf(c.dy) <= 1.0f))
-        return;
-    const level_info l = L.l[c.level];
-    const kp_geom g = keypoint_geometry(c, l, derivative_factor);
-    osample *r = recs + ((size_t)b * cap + kl) * OS_STRIDE;
-    {
-        const float2 *pLxy = Lxy + (size_t)b * img_stride + l.off;
-        // index order i (outer), j (inner) over the radius-6 disc; lane handles samples lane and lane + 64, both loads issued together
-        const int i0 = (int)oq0 / 13 - 6, j0 = (int)oq0 % 13 - 6, i1 = (int)oq1 / 13 - 6, j1 = (int)oq1 % 13 - 6;
-        const bool second = lane + 64 < 109;
-        const int iy0 = clampi((int)rintf(g.yf + (float)(j0 * g.s)), 0, l.h - 1), ix0 = clampi((int)rintf(g.xf + (float)(i0 * g.s)), 0, l.w - 1);
-        const int iy1 = clampi((int)rintf(g.yf + (float)(j1 * g.s)), 0, l.h - 1), ix1 = clampi((int)rintf(g.xf + (float)(i1 * g.s)), 0, l.w - 1);
-        const float2 g0 = pLxy[(unsigned int)(iy0 * l.w + ix0)];
-        const float2 g1 = second ? pLxy[(unsigned int)(iy1 * l.w + ix1)] : make_float2(0.0f, 0.0f);
-        const float rx0 = og0 * g0.x, ry0 = og0 * g0.y, rx1 = og1 * g1.x, ry1 = og1 * g1.y;
-        const unsigned long long m0 = orient_window_mask(fast_atan2(ry0, rx0), otab);
-        const unsigned long long m1 = second ? orient_window_mask(fast_atan2(ry1, rx1), otab) : 0ull;
-        float4 *out = reinterpret_cast<float4 *>(r);
-        out[lane] = make_float4(rx0, ry0, __uint_as_float((unsigned int)m0), __uint_as_float((unsigned int)(m0 >> 32)));
-        if (lane + 64 < OS_STRIDE)
-            out[lane + 64] = make_float4(rx1, ry1, __uint_as_float((unsigned int)m1), __uint_as_float((unsigned int)(m1 >> 32)));
-    }
-    pkf2 sum = {0.0f, 0.0f}; // (sumX, sumY)
-    asm volatile("s_waitcnt vmcnt(0)\n\t" // the records are in the L2
-                 "s_mov_b64 s[34:35], exec\n\t"                                        //
-                 OCHIP_OS_LOAD_A(0x0, 0x40) OCHIP_OS_WAIT                                //
-                 OCHIP_OS_LOAD_B(0x80, 0xc0) OCHIP_OS_PROC_A OCHIP_OS_WAIT               //
-                 OCHIP_OS_LOAD_A(0x100, 0x140) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x180, 0x1c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_A(0x200, 0x240) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x280, 0x2c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_A(0x300, 0x340) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x380, 0x3c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_A(0x400, 0x440) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x480, 0x4c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_A(0x500, 0x540) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x580, 0x5c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_A(0x600, 0x640) OCHIP_OS_PROC_B OCHIP_OS_WAIT             //
-                 OCHIP_OS_LOAD_B(0x680, 0x6c0) OCHIP_OS_PROC_A OCHIP_OS_WAIT             //
-                 OCHIP_OS_PROC_B                                                         //
-                 "s_mov_b64 exec, s[34:35]"
-                 : "+v"(sum)
-                 : "s"(r)
-                 : OCHIP_OS_CLOBBERS, "memory");
-    float wmag = -1.0f, wangle = 0.0f;
-    if (lane < 42)
-    {
-        wmag = sum.x * sum.x + sum.y * sum.y;
-        wangle = fast_atan2(sum.y, sum.x);
-    }
-    // first strict maximum in window order (the sequential loop's choice): largest magnitude, lowest window on ties
-    int widx = lane;
-    for (int off = 32; off >= 1; off >>= 1)
-    {
-        const float om = __shfl_xor(wmag, off), oa = __shfl_xor(wangle, off);
-        const int oi = __shfl_xor(widx, off);
-        if (om > wmag || (om == wmag && oi < widx))
-        {
-            wmag = om;
-            wangle = oa;
-            widx = oi;
-        }
-    }
-    if (lane == 0)
-        angles[(size_t)b * cap + kl] = wmag > 0.0f ? wangle : 0.0f;
-}
-
-// What describe2_kernel needs of a keypoint besides its pixels, computed by one THREAD per keypoint: the same few dozen
-// instructions (position, sine and cosine of the orientation) cost a whole wavefront's issue slots each when the
-// keypoint's wavefront computes them for itself.
-struct kp_frame
-{
-    float xf, yf, fs; // position in the level image, sample spacing
-    float si, co;     // rotation of the lattice
-    float kx, ky, size; // the keypoint as it is reported
+    // orientation samples in image order: entry L = q | (i + 6) << 8 | (j + 6) << 16 of the L-th sample sorted by row j, then
+    // column i (q = its place in the restatement's i-outer, j-inner order); 0xFFFFFFFF beyond the 109 samples
+    unsigned int ori[128];
+    float ori_g[128]; // its Gaussian weight
+    // lattice points in image order for 32 orientation classes: (a + 10) | (bb + 10) << 8; 0xFFFF = no point
+    unsigned short lat[32][448];
 };
-__global__ __launch_bounds__(256) void kp_frame_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
-                                                       unsigned int max_cands, const unsigned int *__restrict__ live,
-                                                       const float *__restrict__ angles, unsigned int cap,
-                                                       const levels_dev *__restrict__ L, float derivative_factor,
-                                                       kp_frame *__restrict__ frames)
-{
-    const unsigned int b = blockIdx.z, kl = blockIdx.x * 256 + threadIdx.x;
-    if (kl >= n_live[b])
-        return;
-    const cand_t c = cands[(size_t)b * max_cands + live[(size_t)b * max_cands + kl]];
-    if (!(fabsf(c.dx) <= 1.0f && fabsf(c.dy) <= 1.0f))
-        return;
-    const kp_geom g = keypoint_geometry(c, L->l[c.level], derivative_factor);
-    kp_frame f;
-    f.xf = g.xf, f.yf = g.yf, f.fs = (float)g.s;
-    sincos_poly(angles[(size_t)b * cap + kl], &f.si, &f.co);
-    f.kx = g.kx, f.ky = g.ky, f.size = g.size;
-    float4 *o = reinterpret_cast<float4 *>(frames + (size_t)b * cap + kl);
-    o[0] = make_float4(f.xf, f.yf, f.fs, f.si);
-    o[1] = make_float4(f.co, f.kx, f.ky, f.size);
-}
 
-// Lattice gather, cell sums, descriptor bits of one surviving candidate per wavefront (four consecutive ones per
-// workgroup, wave-level barriers only); the orientation comes from orient_angle_kernel.
-__global__ __launch_bounds__(256) void describe2_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
+// One 64-thread wavefront per surviving candidate (four consecutive ones per workgroup, wave-level barriers only):
+// sub-pixel position, dominant orientation, 486-bit M-LDB.
+__global__ __launch_bounds__(256) void describe3_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
                                                        unsigned int max_cands, const unsigned int *__restrict__ live,
-                                                       const float *__restrict__ angles, const kp_frame *__restrict__ frames,
-                                                       unsigned int cap, const float *__restrict__ Lt,
-                                                       const float2 *__restrict__ Lxy, size_t img_stride, levels_dev L,
-                                                       const pair_tab *__restrict__ tab, float *__restrict__ kp_out /*[b][max][6]*/,
+                                                       const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
+                                                       size_t img_stride, levels_dev L, float derivative_factor,
+                                                       const pair_tab *__restrict__ tab, const gather_tab *__restrict__ gtab,
+                                                       const orient_tab *__restrict__ otab, float *__restrict__ kp_out /*[b][max][6]*/,
                                                        unsigned long long *__restrict__ desc_out /*[b][max][8]*/,
                                                        unsigned char *__restrict__ valid_out, int remap,
                                                        unsigned long long *__restrict__ vmask, size_t mask_stride)
@@ -1867,6 +1628,9 @@ __global__ __launch_bounds__(256) void describe2_kernel(const cand_t *__restrict
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float(&vals)[30][3] = vals_all[wv];
     float *const smp = smp_all[wv];
+    // the orientation's data are dead before the lattice is stored and share its LDS
+    float2 *const osmp = reinterpret_cast<float2 *>(smp);                              // [109] weighted (Lx, Ly) by sample
+    unsigned long long *const omask = reinterpret_cast<unsigned long long *>(smp) + 112; // [128] window masks by sample
     auto wave_sync = []() {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // LDS writes of the wave before LDS reads after
         __builtin_amdgcn_wave_barrier();
@@ -1882,8 +1646,8 @@ __global__ __launch_bounds__(256) void describe2_kernel(const cand_t *__restrict
     const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
     // everything whose address is known up front is requested here, together
     const cand_t c = cands[slot];
-    const float angle = angles[(size_t)b * cap + kl];
-    const kp_frame fr = frames[(size_t)b * cap + kl];
+    const unsigned int oe0 = gtab->ori[lane], oe1 = gtab->ori[lane + 64];
+    const float og0 = gtab->ori_g[lane], og1 = gtab->ori_g[lane + 64];
     const unsigned int chain = tab->chain[lane];
     unsigned int tbits[8];
 #pragma unroll
@@ -1897,28 +1661,112 @@ __global__ __launch_bounds__(256) void describe2_kernel(const cand_t *__restrict
             valid_out[slot] = 0;
         return;
     }
-    const float xf = fr.xf, yf = fr.yf, si = fr.si, co = fr.co, fs = fr.fs;
+    const kp_geom g = keypoint_geometry(c, l, derivative_factor);
+    const float xf = g.xf, yf = g.yf;
     const float *pLt = Lt + (size_t)b * img_stride + l.off;
     const float2 *pLxy = Lxy + (size_t)b * img_stride + l.off;
-    bool all_inside = true;
-    // every grid (2x2, 3x3, 4x4) samples the same rotated 21 x 21 lattice: gather it once with all lanes (7 rounds of
-    // 64 points: first every address, then every load - 14 in flight per lane -, then the rotations and the LDS stores)
+
+    // ---- dominant orientation: 109 samples of the radius-6 disc, two per lane, in image order
     {
+        const bool second = oe1 != 0xFFFFFFFFu; // (lanes 0..44)
+        const int q0 = (int)(oe0 & 255u), i0 = (int)((oe0 >> 8) & 255u) - 6, j0 = (int)((oe0 >> 16) & 255u) - 6;
+        const int q1 = (int)(oe1 & 255u), i1 = (int)((oe1 >> 8) & 255u) - 6, j1 = (int)((oe1 >> 16) & 255u) - 6;
+        const int iy0 = clampi((int)rintf(yf + (float)(j0 * g.s)), 0, h - 1), ix0 = clampi((int)rintf(xf + (float)(i0 * g.s)), 0, w - 1);
+        const int iy1 = clampi((int)rintf(yf + (float)(j1 * g.s)), 0, h - 1), ix1 = clampi((int)rintf(xf + (float)(i1 * g.s)), 0, w - 1);
+        const float2 g0 = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(pLxy) + (unsigned int)(iy0 * w + ix0) * 8u);
+        const float2 g1 = second ? *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(pLxy) + (unsigned int)(iy1 * w + ix1) * 8u)
+                                 : make_float2(0.0f, 0.0f);
+        const float rx0 = og0 * g0.x, ry0 = og0 * g0.y, rx1 = og1 * g1.x, ry1 = og1 * g1.y;
+        const unsigned long long m0 = orient_window_mask(fast_atan2(ry0, rx0), otab);
+        osmp[q0] = make_float2(rx0, ry0);
+        omask[q0] = m0;
+        if (second)
+        {
+            osmp[q1] = make_float2(rx1, ry1);
+            omask[q1] = orient_window_mask(fast_atan2(ry1, rx1), otab);
+        }
+    }
+    wave_sync();
+    float angle;
+    {
+        // lane q keeps the masks of samples q and q + 64; the window loop reads them with v_readlane (the lane number is
+        // a constant of the unrolled loop), so a sample is: mask -> EXEC, one packed add of its LDS-broadcast (x, y)
+        const unsigned long long mq0 = omask[lane], mq1 = lane + 64 < 109 ? omask[lane + 64] : 0ull;
+        const unsigned int mq0lo = (unsigned int)mq0, mq0hi = (unsigned int)(mq0 >> 32), mq1lo = (unsigned int)mq1, mq1hi = (unsigned int)(mq1 >> 32);
+        pkf2 sum = {0.0f, 0.0f}; // (sumX, sumY) of the lane's window
+        // (the add is written out: as an `if` the compiler branches around every add and reads the sample inside the
+        // branch, one exposed LDS latency per sample; the samples are read 16 at a time ahead of their adds.  All 64 lanes
+        // are active here - every exit above is taken by whole waves.)
+#pragma unroll
+        for (int q0 = 0; q0 < 109; q0 += 16)
+        {
+            pkf2 xy[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (q0 + k < 109)
+                {
+                    const float2 sm = osmp[q0 + k];
+                    xy[k] = pkf2{sm.x, sm.y};
+                }
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (q0 + k < 109)
+                {
+                    const int q = q0 + k;
+                    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(q < 64 ? mq0lo : mq1lo), q & 63);
+                    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(q < 64 ? mq0hi : mq1hi), q & 63);
+                    const unsigned long long in_window = ((unsigned long long)hi << 32) | lo;
+                    asm volatile("s_mov_b64 exec, %2\n\tv_pk_add_f32 %0, %0, %1\n\ts_mov_b64 exec, -1"
+                                 : "+v"(sum)
+                                 : "v"(xy[k]), "s"(in_window));
+                }
+        }
+        float wmag = -1.0f, wangle = 0.0f;
+        if (lane < 42)
+        {
+            wmag = sum.x * sum.x + sum.y * sum.y;
+            wangle = fast_atan2(sum.y, sum.x);
+        }
+        // first strict maximum in window order (the sequential loop's choice): largest magnitude, lowest window on ties
+        int widx = lane;
+        for (int off = 32; off >= 1; off >>= 1)
+        {
+            const float om = __shfl_xor(wmag, off), oa = __shfl_xor(wangle, off);
+            const int oi = __shfl_xor(widx, off);
+            if (om > wmag || (om == wmag && oi < widx))
+            {
+                wmag = om;
+                wangle = oa;
+                widx = oi;
+            }
+        }
+        angle = wmag > 0.0f ? wangle : 0.0f;
+    }
+    float si, co;
+    sincos_poly(angle, &si, &co);
+    const float fs = (float)g.s;
+    bool all_inside = true;
+    // ---- every grid (2x2, 3x3, 4x4) samples the same rotated 21 x 21 lattice: gather it once with all lanes (7 rounds of
+    // 64 points in the image order of the keypoint's orientation class: first every address, then every load - 14 in
+    // flight per lane -, then the rotations and the LDS stores at the points' own places)
+    {
+        const int cls = __builtin_amdgcn_readfirstlane(min(31, (int)(angle * 5.0929581789406507f))); // 32 / (2 pi)
+        const unsigned short *order = gtab->lat[cls];
+        unsigned int pe[7];
+#pragma unroll
+        for (int t = 0; t < 7; t++)
+            pe[t] = order[lane + 64 * t];
+        wave_sync(); // the orientation's LDS has been read by every lane
         float ri[7], rx[7], ry[7];
         bool inside[7];
-        const float a0 = (float)(lane / 21 - 10), b0 = (float)(lane % 21 - 10);
 #pragma unroll
         for (int t = 0; t < 7; t++)
         {
-            const int p = lane + 64 * t;
-            // (a, bb) = (p / 21 - 10, p % 21 - 10) without the divisions: 64 = 3 * 21 + 1, so a round moves a point three
-            // rows down and one column on, and at most once over the seven rounds past the end of its row
-            const bool wrapped = b0 + (float)t > 10.0f;
-            const float fa = a0 + (float)(3 * t) + (wrapped ? 1.0f : 0.0f), fb = b0 + (float)t - (wrapped ? 21.0f : 0.0f);
+            const float fa = (float)((int)(pe[t] & 255u) - 10), fb = (float)((int)(pe[t] >> 8) - 10);
             const float sy = yf + (fb * co * fs + fa * si * fs);
             const float sx = xf + (-fb * si * fs + fa * co * fs);
             const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
-            inside[t] = p < 441 && !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
+            inside[t] = pe[t] != 0xFFFFu && !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
             // 32-bit byte offsets from a wave-uniform base (a level plane is far below 2^29 pixels): the loads take the
             // base from SGPRs and the offset from one VGPR, no 64-bit address arithmetic per lane
             const unsigned int o = inside[t] ? (unsigned int)(y1 * w + x1) : 0u;
@@ -1930,9 +1778,9 @@ __global__ __launch_bounds__(256) void describe2_kernel(const cand_t *__restrict
 #pragma unroll
         for (int t = 0; t < 7; t++)
         {
-            const int p = lane + 64 * t;
-            if (p < 441)
+            if (pe[t] != 0xFFFFu)
             {
+                const int p = (int)(pe[t] & 255u) * 21 + (int)(pe[t] >> 8);
                 const float rry = rx[t] * co + ry[t] * si, rrx = -rx[t] * si + ry[t] * co;
                 // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
                 // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch in the sums
@@ -2047,9 +1895,9 @@ __global__ __launch_bounds__(256) void describe2_kernel(const cand_t *__restrict
     if (lane == 0)
     {
         float *o = kp_out + slot * 6;
-        o[0] = fr.kx;
-        o[1] = fr.ky;
-        o[2] = fr.size;
+        o[0] = g.kx;
+        o[1] = g.ky;
+        o[2] = g.size;
         o[3] = angle;
         o[4] = c.response;
         o[5] = (float)c.level;
@@ -2553,6 +2401,58 @@ const orient_windows &host_orient_windows()
     return W;
 }
 
+// gather_tab: which lane fetches which sample (any assignment is correct - the LDS images are indexed by the sample; this
+// one makes the lanes of a gather instruction neighbours in the image, so that they share cache lines).
+const gather_tab &host_gather_tab(const std::vector<float> &gw /*13 x 13 orientation weights*/)
+{
+    static const gather_tab G = [&]() {
+        gather_tab T{};
+        // orientation samples: the restatement walks i (x) outer, j (y) inner; image order is j outer, i inner
+        struct os
+        {
+            int q, i, j;
+        };
+        std::vector<os> S;
+        int q = 0;
+        for (int i = -6; i <= 6; i++)
+            for (int j = -6; j <= 6; j++)
+                if (i * i + j * j < 36)
+                    S.push_back({q++, i, j});
+        std::sort(S.begin(), S.end(), [](const os &a, const os &b) { return a.j != b.j ? a.j < b.j : a.i < b.i; });
+        for (int L = 0; L < 128; L++)
+        {
+            T.ori[L] = 0xFFFFFFFFu;
+            T.ori_g[L] = 0.0f;
+            if (L < (int)S.size())
+            {
+                T.ori[L] = (unsigned int)S[L].q | ((unsigned int)(S[L].i + 6) << 8) | ((unsigned int)(S[L].j + 6) << 16);
+                T.ori_g[L] = gw[(size_t)(S[L].i + 6) * 13 + (S[L].j + 6)];
+            }
+        }
+        // lattice points (a, bb) land at (x, y) = xf + s (-bb sin + a cos), yf + s (bb cos + a sin): sorted by image row
+        // (rounded for a typical spacing of 3 pixels), then by column, for the middle of each of 32 orientation classes
+        for (int c = 0; c < 32; c++)
+        {
+            const double th = (c + 0.5) * (2.0 * M_PI / 32.0), si = std::sin(th), co = std::cos(th);
+            struct lp
+            {
+                long row;
+                double x;
+                int a, bb;
+            };
+            std::vector<lp> P;
+            for (int a = -10; a <= 10; a++)
+                for (int bb = -10; bb <= 10; bb++)
+                    P.push_back({std::lround(3.0 * (bb * co + a * si)), -bb * si + a * co, a, bb});
+            std::sort(P.begin(), P.end(), [](const lp &u, const lp &v) { return u.row != v.row ? u.row < v.row : u.x < v.x; });
+            for (int k = 0; k < 448; k++)
+                T.lat[c][k] = k < (int)P.size() ? (unsigned short)((P[k].a + 10) | ((P[k].bb + 10) << 8)) : (unsigned short)0xFFFF;
+        }
+        return T;
+    }();
+    return G;
+}
+
 // images: n_images x h x w x 3 BGR bytes (host, or device when on_device).  Working size: the INTER_AREA
 // downscale to max side 1600 of extract_features.cpp:26-27.  Outputs (host): per image up to max_kp keypoints,
 // in unspecified order: kp6 = {x, y, size, angle(rad), response, level} in working-image pixels, desc = 8 x u64,
@@ -2650,10 +2550,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned int *d_wbase = nullptr, *d_live = nullptr, *d_nlive = nullptr;
     pair_tab *d_tab = nullptr;
     orient_tab *d_otab = nullptr;
-    osample *d_osamp = nullptr;
-    float *d_angles = nullptr;
-    kp_frame *d_frames = nullptr;
-    levels_dev *d_levels = nullptr;
+    gather_tab *d_gtab = nullptr;
     const size_t src_px = (size_t)width * height;
     // 1-D tile grids padded to a multiple of 8 workgroups (xcd_tile)
     auto tiles = [&](int w, int h) { return dim3(8 * ((((w + BT_X - 1) / BT_X) * ((h + BT_Y - 1) / BT_Y) + 7) / 8), 1, B); };
@@ -2795,6 +2692,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             return ochip_fail(ctx, OCHIP_EINVAL, "akaze: the orientation-window table disagrees with the window predicate");
         }
         AK(up(ctx, allocs, &d_otab, &ow.T, 1));
+        AK(up(ctx, allocs, &d_gtab, &host_gather_tab(gw), 1));
     }
     if (rc != OCHIP_OK)
     {
@@ -3060,41 +2958,11 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         if (max_live == 0)
             ;
         else if (!describe_v1)
-        {
-            // orientation samples -> orientation -> lattice + cells + bits, over the survivors
-            AK(up<osample>(ctx, allocs, &d_osamp, nullptr, (size_t)B * max_live * OS_STRIDE));
-            AK(up<float>(ctx, allocs, &d_angles, nullptr, (size_t)B * max_live));
-            AK(up<kp_frame>(ctx, allocs, &d_frames, nullptr, (size_t)B * max_live));
-            AK(up(ctx, allocs, &d_levels, &LV, 1));
-            if (rc != OCHIP_OK)
-            {
-                cleanup();
-                return rc;
-            }
-            const dim3 dgrid(512 * (((max_live + 3) / 4 + 511) / 512), 1, B);
-            static const bool orient_two = getenv("OCHIP_ORIENT_TWO_LAUNCHES") != nullptr; // A/B
-            if (orient_two)
-            {
-                hipLaunchKernelGGL(orient_samples_kernel, dgrid, dim3(512), 0, st, (const cand_t *)d_cands,
-                                   (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live, (const float2 *)d_Lxy,
-                                   img_stride, LV, dfactor, (const pair_tab *)d_tab, (const orient_tab *)d_otab, d_osamp, max_live,
-                                   xcd_remap);
-                hipLaunchKernelGGL(orient_angle_kernel, dgrid, dim3(256), 0, st, (const cand_t *)d_cands,
-                                   (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live, (const osample *)d_osamp,
-                                   max_live, d_angles, xcd_remap);
-            }
-            else
-                hipLaunchKernelGGL(orient_kernel, dgrid, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_nlive,
-                                   max_cands, (const unsigned int *)d_live, (const float2 *)d_Lxy, img_stride, LV, dfactor,
-                                   (const pair_tab *)d_tab, (const orient_tab *)d_otab, d_osamp, max_live, d_angles, xcd_remap);
-            hipLaunchKernelGGL(kp_frame_kernel, dim3((max_live + 255) / 256, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
-                               (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live, (const float *)d_angles,
-                               max_live, (const levels_dev *)d_levels, dfactor, d_frames);
-            hipLaunchKernelGGL(describe2_kernel, dgrid, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_nlive,
-                               max_cands, (const unsigned int *)d_live, (const float *)d_angles, (const kp_frame *)d_frames,
-                               max_live, (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, (const pair_tab *)d_tab,
-                               d_kp, d_desc, d_valid, xcd_remap, d_vmask, mask_stride);
-        }
+            hipLaunchKernelGGL(describe3_kernel, dim3(512 * (((max_live + 3) / 4 + 511) / 512), 1, B), dim3(256), 0, st,
+                               (const cand_t *)d_cands, (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live,
+                               (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, dfactor, (const pair_tab *)d_tab,
+                               (const gather_tab *)d_gtab, (const orient_tab *)d_otab, d_kp, d_desc, d_valid, xcd_remap, d_vmask,
+                               mask_stride);
         else if (!profile_describe)
             OCHIP_LAUNCH_DESCRIBE(false);
         else

@@ -474,6 +474,7 @@ int ochip_profile_reset(ochip_ctx *ctx)
     }
     ctx->match_computed = ctx->match_delivered = 0;
     ctx->relax_mfma_flops = 0;
+    ctx->ransac_hyp_corr = ctx->relax_blocks_jac = ctx->relax_blocks_cost = 0;
     for (ochip_ctx *sib : ctx->siblings)
     {
         const int rc = ochip_profile_reset(sib);
@@ -490,6 +491,22 @@ int ochip_relax_work(ochip_ctx *ctx, double *mfma_flops)
     *mfma_flops = ctx->relax_mfma_flops;
     for (ochip_ctx *sib : ctx->siblings)
         *mfma_flops += sib->relax_mfma_flops;
+    return OCHIP_OK;
+}
+
+int ochip_work_counters(ochip_ctx *ctx, uint64_t *counters3)
+{
+    if (!ctx || !counters3)
+        return OCHIP_EINVAL;
+    counters3[0] = ctx->ransac_hyp_corr;
+    counters3[1] = ctx->relax_blocks_jac;
+    counters3[2] = ctx->relax_blocks_cost;
+    for (ochip_ctx *sib : ctx->siblings)
+    {
+        counters3[0] += sib->ransac_hyp_corr;
+        counters3[1] += sib->relax_blocks_jac;
+        counters3[2] += sib->relax_blocks_cost;
+    }
     return OCHIP_OK;
 }
 

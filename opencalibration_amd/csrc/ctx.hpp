@@ -91,6 +91,10 @@ struct ochip_ctx
     // fp64 multiply-adds x 2 the Cholesky factorisations of the relax solves issued on the matrix cores (panel and
     // trailing-update GEMMs over the rows inside the block envelope) since the last profile reset
     double relax_mfma_flops = 0;
+    // roofline bookkeeping since the last profile reset: RANSAC loop trips x correspondences of their job (an upper bound of the
+    // (hypothesis, correspondence) errors evaluated: the SPRT exit of ransac.cpp:197-200 leaves a hypothesis early), residual
+    // blocks the relax evaluation kernels processed with / without Jacobians
+    uint64_t ransac_hyp_corr = 0, relax_blocks_jac = 0, relax_blocks_cost = 0;
     uint64_t relax_system_bytes = 0, relax_system_dense_bytes = 0, relax_system_unknowns = 0; // largest reduced system held (relax_lm.hip)
 
     // sibling contexts on the same device (own streams, scratch and pools) handed out by ochip_ctx_sibling so

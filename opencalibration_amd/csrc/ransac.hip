@@ -2362,6 +2362,8 @@ int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_
     if (total_matches)
         OCHIP_HIP(ctx, hipMemcpyAsync(inliers, inl_dev, (size_t)total_matches, hipMemcpyDeviceToHost, ctx->stream));
     OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
+    for (uint32_t j = 0; j < n_jobs; j++)
+        ctx->ransac_hyp_corr += (uint64_t)results[j].iterations * jobs[j].n;
     return OCHIP_OK;
 }
 } // namespace

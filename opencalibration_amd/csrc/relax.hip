@@ -1369,6 +1369,7 @@ struct plane_model final : lm_model
                 hipLaunchKernelGGL(relax_pair_eval_kernel<false>, dim3(my_pairs), dim3(W), 0, st, D, which);
         }
         ochip_prof_end(ctx, OCHIP_K_RELAX_EVAL, e0, e1);
+        (with_jac ? ctx->relax_blocks_jac : ctx->relax_blocks_cost) += my_pairs;
         if (p->exchange)
         {
             // the ranks' pair records (and failure flags) are all-gathered in place; from here on every rank holds

@@ -62,3 +62,24 @@ def test_bench_weak_line_carries_the_strong_section():
     ss = line["strong_scaling"]
     assert "error" not in ss, ss
     assert ss["images_per_s"] > 0 and len(ss["seconds_per_step_per_rank"]) == 2
+    # both curves by name at the top level, and the collective pre-flight ran
+    assert line["images_per_s_weak_one_survey_per_gpu"] == line["value"]
+    assert line["images_per_s_strong_one_survey_over_all_gpus"] == ss["images_per_s"]
+    assert line["collective_preflight_s"] is not None and line["rccl_ranks"] == 0     # (gloo here)
+
+
+def test_one_rank_strong_equals_the_default_line():
+    """At N = 1 "one survey over all GPUs" and "a survey per GPU" are the same job: the strong mode's rate must agree with
+    the default line's within run-to-run noise (both modes run the C2 grid here, relax pipelined over surveys)."""
+    env = dict(os.environ, OCHIP_HOST_THREADS="8")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
+    rates = {}
+    for mode in ("weak", "strong"):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scaling", mode, "--config", "C2", "--steps", "6", "--warmup", "2",
+               "--no-cpu-baseline"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 1 and line["scaling"] == mode
+        rates[mode] = line["value"]
+    assert abs(rates["strong"] / rates["weak"] - 1.0) < 0.15, rates
