@@ -609,18 +609,22 @@ class StrongRunner:
             acc["relax_lm_iterations"] = acc.get("relax_lm_iterations", 0.0) + res["relax"]["iterations_total"]
             acc["relaxes"] = acc.get("relaxes", 0) + 1
 
-    def step(self, acc):
-        proc, host = self.proc, self.host
+    def _survey(self, owner):
+        """load + link of one survey over the ranks: (graph, report, seconds, CPU seconds)"""
         _, h, w = self.shape
-        owner = self.k % proc.world if self.pipelined else None
-        self.k += 1
         c0 = time.process_time()
         t0 = time.perf_counter()
-        g = host.Graph()
+        g = self.host.Graph()
         mid = g.add_model(self.grid.model)
         st = self.parallel.survey_sharded(self.ctx, g, mid, self.grid.position, self.start_ori, self.images, w, h,
                                           edges_to=owner)
-        t_link = time.perf_counter() - t0
+        return g, st, time.perf_counter() - t0, time.process_time() - c0
+
+    def step(self, acc, survey=None):
+        proc = self.proc
+        owner = self.k % proc.world if self.pipelined else None
+        self.k += 1
+        g, st, t_link, cpu_link = survey.result() if survey is not None else self._survey(owner)
         res = dict(edges=g.num_edges, survey=st)
         t = {}
         if self.pipelined:
@@ -654,7 +658,7 @@ class StrongRunner:
             for k, v in (("load_link", t_link), ("extract", sec["extract"]), ("block_linked", sec["block_linked"]),
                          ("exchange", st["exchange_s"]), ("subsets_import", sec["subsets_import"]),
                          ("remote_links", sec["remote_links"]), ("edges_import", sec["edges_import"]),
-                         ("finalize", sec["finalize"]), ("host_cpu_load_link", time.process_time() - c0),
+                         ("finalize", sec["finalize"]), ("host_cpu_load_link", cpu_link),
                          ("bytes_gathered", st.get("bytes_gathered", 0)), ("exchanges", st.get("exchanges", 0))):
                 acc[k] = acc.get(k, 0.0) + v
             acc["steps"] = acc.get("steps", 0) + 1
@@ -662,8 +666,23 @@ class StrongRunner:
         self.last["edges"] = max(self.last.get("edges", 0), res["edges"])
 
     def run(self, n_steps, acc):
-        for _ in range(n_steps):
-            self.step(acc)
+        # One rank: two surveys in flight as in the weak mode (the next survey extracts beside this one's link tail).  With
+        # several ranks the surveys stay one after the other: two surveys' collectives issued from two threads would have
+        # to reach the communicator in the same order on every rank.
+        if self.proc.world == 1 and self.pipelined and os.environ.get("OCHIP_PIPELINE_SURVEYS", "2") != "1":
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(2) as pool:
+                futures = [pool.submit(self._survey, 0) for _ in range(min(2, n_steps))]
+                for step in range(n_steps):
+                    f = futures.pop(0)
+                    f.result()
+                    if step + 2 < n_steps:
+                        futures.append(pool.submit(self._survey, 0))
+                    self.step(acc, survey=f)
+        else:
+            for _ in range(n_steps):
+                self.step(acc)
         self._collect(acc)
 
     def close(self):
@@ -773,6 +792,7 @@ def weak_main(args, proc, cfg):
     # and relax runners of consecutive batches together (pipeline.cpp:543-560); here successive steps are successive surveys.
     # Every relax finishes inside the timed region (the last one is joined before the closing barrier).
     relax_overlap = overlap and os.environ.get("OCHIP_PIPELINE_RELAX_OVERLAP", "1") != "0"
+    surveys_in_flight = os.environ.get("OCHIP_PIPELINE_SURVEYS", "2") != "1"
     rctx = ctx.sibling(12) if relax_overlap else ctx      # (created here, before any runner thread asks for a sibling)
     if relax_overlap and os.environ.get("OCHIP_RELAX_PRIORITY", "1") != "0":
         rctx.set_priority(True)                            # the latency-bound solve goes ahead of the throughput kernels
@@ -795,9 +815,21 @@ def weak_main(args, proc, cfg):
                     acc[k] = acc.get(k, 0.0) + v
 
         verbose = os.environ.get("OCHIP_BENCH_VERBOSE") is not None
-        for _ in range(n_steps):
+        # load + link of survey k + 1 beside the link tail of survey k (two host threads; the native side lets one survey
+        # extract at a time and gives alternating surveys their own link contexts, csrc/host/load_link.cpp): the
+        # reference runs the load runners of a batch beside the link runners of the batch before it (pipeline.cpp:543-560)
+        from concurrent.futures import ThreadPoolExecutor
+
+        in_flight = 2 if (overlap and relax_overlap and surveys_in_flight) else 1
+        pool = ThreadPoolExecutor(in_flight)
+        futures = [pool.submit(pipeline.run, ctx, grid, images, shape, start_ori, overlap=overlap, relax=not relax_overlap)
+                   for _ in range(min(in_flight, n_steps))]
+        for step in range(n_steps):
             ta = time.perf_counter()
-            g, res, t = pipeline.run(ctx, grid, images, shape, start_ori, overlap=overlap, relax=not relax_overlap)
+            g, res, t = futures.pop(0).result()
+            if step + in_flight < n_steps:
+                futures.append(pool.submit(pipeline.run, ctx, grid, images, shape, start_ori, overlap=overlap,
+                                           relax=not relax_overlap))
             tb = time.perf_counter()
             last["link_work"] = dict(g.match_work(), images=grid.n_images)
             if relax_overlap:
@@ -822,6 +854,7 @@ def weak_main(args, proc, cfg):
                 collect((th, g, res, t))
         while pending:
             collect(pending.pop())
+        pool.shutdown()
 
     run_steps(args.warmup, None)
     ctx.profile_reset()
@@ -918,7 +951,11 @@ def weak_main(args, proc, cfg):
                        "stages_overlapped": ("load and link (ranges of links start as soon as their images are extracted)"
                                              + ("; relax of survey k with load + link of survey k + 1, as the reference runs the "
                                                 "load / link / relax runners of consecutive batches together (pipeline.cpp:543-560); "
-                                                "every relax completes inside the timed region" if relax_overlap else ""))
+                                                "every relax completes inside the timed region" if relax_overlap else "")
+                                             + ("; the extraction of survey k + 1 starts when survey k's last image is extracted, "
+                                                "beside survey k's remaining link ranges (two surveys in flight, one extracting at a "
+                                                "time; every survey is linked and relaxed inside the timed region)"
+                                                if relax_overlap and surveys_in_flight else ""))
                                             if overlap else "none (OCHIP_PIPELINE_OVERLAP=0)",
                        "stages_timed": ["extract: grey + INTER_AREA + AKAZE + std::sort by response / 8 px NMS / feature records "
                                         "(device), one block copy per image (host)",

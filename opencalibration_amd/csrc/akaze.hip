@@ -1224,325 +1224,6 @@ __global__ __launch_bounds__(256) void live_list_kernel(const unsigned char *__r
 
 typedef float pkf2 __attribute__((ext_vector_type(2))); // two fp32 lanes of one packed VALU instruction
 
-struct pair_tab // M-LDB comparison list: bit -> (cell a, cell b, channel); cells numbered 0..3 | 4..12 | 13..28
-{
-    unsigned int bits[512];  // bit -> a | b << 8 | channel << 16 (one dword per comparison; entries >= 486 unused)
-    unsigned int ori_q[128]; // orientation samples: position (i + 6) * 13 + (j + 6) of the n-th member of the radius-6 disc
-    float ori_g[128];        // and its Gaussian weight
-    float win_ang1[64];      // start angles of the 42 orientation windows: for (a = 0; a < 2 pi; a += 0.15f)
-    unsigned int chain[64];  // describe2_kernel: what lane i sums (see there); 3 << 11 = idle
-};
-
-// One 64-thread workgroup per surviving candidate: sub-pixel fit, dominant orientation, 486-bit M-LDB.
-// Sums run in the restatement's sequential order (one lane per window / per grid cell) so bits agree.
-// OCHIP_DESCRIBE_PROFILE=1: wave-resident cycles per phase of describe_kernel, summed over all waves (lane 0 of a wave
-// adds the time since the previous mark), printed after every launch - where a keypoint's life goes
-__device__ unsigned long long g_desc_prof[8];
-#define DESC_T(i)                                                                                                            \
-    if (PROFILE)                                                                                                             \
-    {                                                                                                                        \
-        const unsigned long long tn = __builtin_readcyclecounter();                                                          \
-        if (lane == 0)                                                                                                       \
-            atomicAdd(&g_desc_prof[i], tn - tprev);                                                                          \
-        tprev = tn;                                                                                                          \
-    }
-template <bool PROFILE>
-__global__ __launch_bounds__(256) void describe_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
-                                                      unsigned int max_cands, const unsigned int *__restrict__ live,
-                                                      const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
-                                                      size_t img_stride, levels_dev L, float derivative_factor,
-                                                      const float *__restrict__ gw /*13x13*/, const pair_tab *__restrict__ tab,
-                                                      float *__restrict__ kp_out /*[b][max][6]*/,
-                                                      unsigned long long *__restrict__ desc_out /*[b][max][8]*/,
-                                                      unsigned char *__restrict__ valid_out, int remap,
-                                                      unsigned long long *__restrict__ vmask, size_t mask_stride)
-{
-    // four wavefronts = four CONSECUTIVE candidates per workgroup: list neighbours are spatial neighbours, their patches
-    // overlap, and a workgroup's waves share the CU's L1 - the descriptor is bound by the 128-byte lines its gathers pull
-    // from the L2.  The waves do not talk to each other: every wave has its own LDS arrays and only wave-level barriers.
-    // LDS is what limits the waves a CU holds here (59 VGPRs would allow 8 per SIMD), and the kernel spends its time
-    // waiting for gathers: the lattice is kept as 12-byte records (intensity, rotated dx, rotated dy - whether a sample
-    // lies inside the image is recomputed for the few keypoints near a border instead of stored), and the orientation
-    // samples (weighted dx, dy, their angle: one 16-byte LDS read each), dead before the lattice is gathered, share its
-    // space: 22.6 KB per workgroup, 7 waves per SIMD instead of 4.
-    __shared__ float vals_all[4][29][3];
-    __shared__ float4 smp_all[4][331]; // 441 x 3 floats, padded to a multiple of 16 bytes
-    // wv is the same in all lanes of a wave; saying so lets everything that hangs off it - the list entry, the candidate
-    // record with its sub-pixel fit, the level's geometry - travel as scalar loads, a path of its own beside the vector
-    // memory pipeline that the other waves' gathers keep busy
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float4 *const osmp = smp_all[wv]; // [109]
-    float(&vals)[29][3] = vals_all[wv];
-    float *const smp = reinterpret_cast<float *>(smp_all[wv]);
-    auto wave_sync = []() {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // LDS writes of the wave before LDS reads after
-        __builtin_amdgcn_wave_barrier();
-    };
-    const unsigned int b = blockIdx.z;
-    const unsigned int n = n_live[b];
-    unsigned int kb;
-    if (!xcd_contiguous(blockIdx.x, (n + 3) / 4, &kb, remap))
-        return;
-    const unsigned int kl = kb * 4 + wv;
-    if (kl >= n)
-        return;
-    const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
-    // A keypoint is a chain of dependent phases; what bounds this kernel is the number of memory round trips on
-    // that chain times the waves a CU can hold.  Everything whose address is known up front is therefore requested
-    // here, together: the candidate record, the per-lane table entries of the orientation samples and of the
-    // descriptor bits (the compiler keeps them in flight across the early exits).
-    unsigned long long tprev = PROFILE ? __builtin_readcyclecounter() : 0;
-    const cand_t c = cands[slot];
-    const unsigned int oq0 = tab->ori_q[lane], oq1 = tab->ori_q[lane + 64];
-    const float og0 = tab->ori_g[lane], og1 = tab->ori_g[lane + 64];
-    unsigned int tbits[8];
-#pragma unroll
-    for (int wd = 0; wd < 8; wd++)
-        tbits[wd] = tab->bits[wd * 64 + lane];
-    const level_info l = L.l[c.level];
-    const int w = l.w, h = l.h;
-    // the sub-pixel fit came with the candidate (det_maxima_kernel had the nine determinants at hand)
-    const float dx = c.dx, dy = c.dy;
-    const bool ok = fabsf(dx) <= 1.0f && fabsf(dy) <= 1.0f;
-    if (!ok)
-    {
-        if (lane == 0)
-            valid_out[slot] = 0;
-        return;
-    }
-    DESC_T(0)
-    const float ratio = (float)(1 << l.octave);
-    const float kx = ((float)c.x + dx) * ratio + 0.5f * (ratio - 1.0f);
-    const float ky = ((float)c.y + dy) * ratio + 0.5f * (ratio - 1.0f);
-    const float size = 2.0f * (l.esigma * derivative_factor);
-    const float xf = kx / ratio, yf = ky / ratio;
-    const int s = (int)rintf(0.5f * size / ratio);
-    const float *pLt = Lt + (size_t)b * img_stride + l.off;
-    const float2 *pLxy = Lxy + (size_t)b * img_stride + l.off;
-
-    // orientation samples: index order i (outer), j (inner) over the radius-6 disc; lane handles samples lane and
-    // lane + 64, the four loads issued together
-    {
-        const int i0 = (int)oq0 / 13 - 6, j0 = (int)oq0 % 13 - 6, i1 = (int)oq1 / 13 - 6, j1 = (int)oq1 % 13 - 6;
-        const bool second = lane + 64 < 109;
-        const int iy0 = clampi((int)rintf(yf + (float)(j0 * s)), 0, h - 1), ix0 = clampi((int)rintf(xf + (float)(i0 * s)), 0, w - 1);
-        const int iy1 = clampi((int)rintf(yf + (float)(j1 * s)), 0, h - 1), ix1 = clampi((int)rintf(xf + (float)(i1 * s)), 0, w - 1);
-        const float2 g0 = pLxy[(size_t)iy0 * w + ix0];
-        const float2 g1 = second ? pLxy[(size_t)iy1 * w + ix1] : make_float2(0.0f, 0.0f);
-        const float lx0 = g0.x, ly0 = g0.y, lx1 = g1.x, ly1 = g1.y;
-        // an angle of exactly 0 or 2 pi lies in no window (they are open intervals inside (0, 2 pi)): such a sample is
-        // stored as (+0, +0), which leaves every sum unchanged whether a window test lets it in or not - so the test
-        // itself never has to exclude it
-        const float TWO_PI = 6.28318530717958647692f;
-        const float rx0 = og0 * lx0, ry0 = og0 * ly0;
-        const float a0 = fast_atan2(ry0, rx0);
-        osmp[lane] = (a0 > 0.0f && a0 < TWO_PI) ? make_float4(rx0, ry0, a0, 0.0f) : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-        if (second)
-        {
-            const float rx1 = og1 * lx1, ry1 = og1 * ly1;
-            const float a1 = fast_atan2(ry1, rx1);
-            osmp[lane + 64] =
-                (a1 > 0.0f && a1 < TWO_PI) ? make_float4(rx1, ry1, a1, 0.0f) : make_float4(0.0f, 0.0f, 1.0f, 0.0f);
-        }
-    }
-    wave_sync();
-    DESC_T(1)
-    const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
-    // 42 sliding windows of pi/3, one per lane; the sums run over the samples in their order.  A sample outside the
-    // window adds +0, which leaves a sum that starts at +0 unchanged bit for bit.
-    float wmag = -1.0f, wangle = 0.0f;
-    if (lane < 42)
-    {
-        const float ang1 = tab->win_ang1[lane]; // float-accumulated window starts (host table, as the restatement's loop)
-        const float ang2 = (ang1 + PI_F / 3.0f > TWO_PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
-        // the window is the open interval (ang1, ang2), or - wrapped - (0, ang2) and (ang1, 2 pi).  All these angles
-        // are positive floats, which order like their bit patterns, so "inside (ang1, ang2)" is ONE unsigned range
-        // test, (a - (ang1 + 1 ulp)) <= (ang2 - ang1 - 2 ulp) in wrapping integer arithmetic, and a wrapped window is
-        // the complement of the closed range [ang2, ang1]: the lane's constants (range start, length, and which of 1.0
-        // and 0.0 the test's two answers stand for) carry the case, the loop is four VALU instructions per sample
-        // without branches.  The selected sample enters as x * 1 + sum (one rounding, that of the add) or x * 0 + sum
-        // (the sum, unchanged).
-        const bool wrapped = ang2 < ang1;
-        const unsigned int u1 = __float_as_uint(ang1), u2 = __float_as_uint(ang2);
-        const unsigned int range_start = wrapped ? u2 : u1 + 1u, range_len = wrapped ? u1 - u2 : u2 - u1 - 2u;
-        const float in_range = wrapped ? 0.0f : 1.0f, out_of_range = wrapped ? 1.0f : 0.0f;
-        pkf2 sum = {0.0f, 0.0f}; // (sumX, sumY): one packed fp32 FMA per sample (v_pk_fma_f32), IEEE per component
-#pragma unroll 8
-        for (int q = 0; q < 109; q++)
-        {
-            const float4 sm = osmp[q];
-            const float in = (__float_as_uint(sm.z) - range_start <= range_len) ? in_range : out_of_range;
-            sum = __builtin_elementwise_fma(pkf2{sm.x, sm.y}, pkf2{in, in}, sum);
-        }
-        const float sumX = sum.x, sumY = sum.y;
-        wmag = sumX * sumX + sumY * sumY;
-        wangle = fast_atan2(sumY, sumX);
-    }
-    // first strict maximum in window order (the sequential loop's choice): largest magnitude, lowest window on ties
-    int widx = lane;
-    for (int off = 32; off >= 1; off >>= 1)
-    {
-        const float om = __shfl_xor(wmag, off), oa = __shfl_xor(wangle, off);
-        const int oi = __shfl_xor(widx, off);
-        if (om > wmag || (om == wmag && oi < widx))
-        {
-            wmag = om;
-            wangle = oa;
-            widx = oi;
-        }
-    }
-    const float angle = wmag > 0.0f ? wangle : 0.0f;
-    DESC_T(2)
-    float si, co;
-    sincos_poly(angle, &si, &co);
-    const float fs = (float)s;
-    bool all_inside = true;
-    // every grid (2x2, 3x3, 4x4) samples the same rotated 21 x 21 lattice: gather it once with all lanes,
-    // then run the per-cell sums in their sequential order out of LDS
-    {
-        // 7 rounds of 64 lattice points: first every address, then every load (21 in flight per lane), then the
-        // rotations and the LDS stores
-        float ri[7], rx[7], ry[7];
-        bool inside[7];
-#pragma unroll
-        for (int t = 0; t < 7; t++)
-        {
-            const int p = lane + 64 * t;
-            const int a = p / 21 - 10, bb = p % 21 - 10;
-            const float sy = yf + ((float)bb * co * fs + (float)a * si * fs);
-            const float sx = xf + (-(float)bb * si * fs + (float)a * co * fs);
-            const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
-            inside[t] = p < 441 && !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
-            const size_t o = inside[t] ? (size_t)y1 * w + x1 : 0;
-            ri[t] = pLt[o];
-            const float2 g = pLxy[o];
-            rx[t] = g.x;
-            ry[t] = g.y;
-        }
-        wave_sync(); // the orientation samples (same LDS) have been read by every window
-#pragma unroll
-        for (int t = 0; t < 7; t++)
-        {
-            const int p = lane + 64 * t;
-            if (p < 441)
-            {
-                const float rry = rx[t] * co + ry[t] * si, rrx = -rx[t] * si + ry[t] * co;
-                smp[3 * p] = inside[t] ? ri[t] : 0.0f;
-                smp[3 * p + 1] = inside[t] ? rrx : 0.0f;
-                smp[3 * p + 2] = inside[t] ? rry : 0.0f;
-                all_inside = all_inside && inside[t];
-            }
-        }
-    }
-    all_inside = __all(all_inside) != 0;
-    wave_sync();
-    DESC_T(3)
-    if (lane < 29)
-    {
-        int lvl, cell;
-        if (lane < 4)
-            lvl = 0, cell = lane;
-        else if (lane < 13)
-            lvl = 1, cell = lane - 4;
-        else
-            lvl = 2, cell = lane - 13;
-        const int g = lvl + 2;
-        const int step = (lvl == 0) ? 10 : (lvl == 1 ? 7 : 5); // ceil(20 / g)
-        const int i0 = -10 + (cell / g) * step, j0 = -10 + (cell % g) * step;
-        pkf2 acc01 = {0.0f, 0.0f}; // (di, ddx): packed fp32 adds, IEEE per component
-        float acc2 = 0.0f;         // ddy
-        // every cell walks its step x step samples row by row; the walk is written once over the largest cell (10 x 10,
-        // fully unrolled, LDS offsets immediate) and a lane takes part in a step while it is inside its own cell:
-        // the 4 x 4 grid's lanes (13..28, step 5) in the first 5 x 5, the 3 x 3 grid's (4..12, step 7) in the first
-        // 7 x 7, the 2 x 2 grid's (0..3) everywhere - each lane still adds its samples in its own row-major order
-        const float *pb = &smp[3 * ((i0 + 10) * 21 + (j0 + 10))];
-        // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
-        // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch here
-        auto run = [&](int a, int b0, int b1) { // columns b0..b1-1 of row a (compile-time after unrolling)
-#pragma unroll
-            for (int bb = b0; bb < b1; bb++)
-            {
-                const float *v = pb + 3 * (a * 21 + bb);
-                acc01 = acc01 + pkf2{v[0], v[1]};
-                acc2 = acc2 + v[2];
-            }
-        };
-        // the set of lanes only changes where a row leaves a smaller cell: 22 predicated regions, not 100
-#pragma unroll
-        for (int a = 0; a < 5; a++)
-        {
-            run(a, 0, 5); // every lane (29)
-            if (lane < 13)
-                run(a, 5, 7);
-            if (lane < 4)
-                run(a, 7, 10);
-        }
-#pragma unroll
-        for (int a = 5; a < 7; a++)
-        {
-            if (lane < 13)
-                run(a, 0, 7);
-            if (lane < 4)
-                run(a, 7, 10);
-        }
-        if (lane < 4)
-        {
-#pragma unroll
-            for (int a = 7; a < 10; a++)
-                run(a, 0, 10);
-        }
-        // number of samples of the cell inside the image: all of them, except for a keypoint near a border, whose lanes
-        // repeat the lattice arithmetic of the gather above (same expressions, same roundings, same answers)
-        int count = step * step;
-        if (!all_inside)
-        {
-            count = 0;
-            for (int a = i0; a < i0 + step; a++)
-                for (int bb = j0; bb < j0 + step; bb++)
-                {
-                    const float sy = yf + ((float)bb * co * fs + (float)a * si * fs);
-                    const float sx = xf + (-(float)bb * si * fs + (float)a * co * fs);
-                    const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
-                    count += !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h) ? 1 : 0;
-                }
-        }
-        const float di = acc01.x, ddx = acc01.y, ddy = acc2, ns = (float)count;
-        const float inv = fmaxf(ns, 1.0f);
-        vals[lane][0] = di / inv;
-        vals[lane][1] = ddx / inv;
-        vals[lane][2] = ddy / inv;
-    }
-    wave_sync();
-    DESC_T(4)
-    for (int wd = 0; wd < 8; wd++)
-    {
-        const int bit = wd * 64 + lane;
-        bool on = false;
-        if (bit < 486)
-        {
-            const unsigned int e = tbits[wd], ch = e >> 16;
-            on = vals[e & 255u][ch] > vals[(e >> 8) & 255u][ch];
-        }
-        const unsigned long long word = __ballot(on);
-        if (lane == 0)
-            desc_out[slot * 8 + wd] = word;
-    }
-    if (lane == 0)
-    {
-        float *o = kp_out + slot * 6;
-        o[0] = kx;
-        o[1] = ky;
-        o[2] = size;
-        o[3] = angle;
-        o[4] = c.response;
-        o[5] = (float)c.level;
-        valid_out[slot] = 1;
-        // the keypoint's bit in the image's (level, y, x)-ordered mask: its rank there is its place in the output
-        atomicOr(&vmask[(size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6)],
-                 1ull << (c.x & 63));
-    }
-    DESC_T(5)
-}
 
 // ---- round 4: the descriptor kernel again.  The counters of round 3 had the CU's LDS pipe as busy as
 // its vector issue; with both relieved (below) what bounds the kernel is the rate at which a CU's L1 looks up the cache
@@ -1607,8 +1288,14 @@ struct gather_tab
     // column i (q = its place in the restatement's i-outer, j-inner order); 0xFFFFFFFF beyond the 109 samples
     unsigned int ori[128];
     float ori_g[128]; // its Gaussian weight
-    // lattice points in image order for 32 orientation classes: (a + 10) | (bb + 10) << 8; 0xFFFF = no point
-    unsigned short lat[32][448];
+    // lattice points in image order for 32 orientation classes: (a + 10) | (bb + 10) << 8 | byte offset of the point's
+    // record in the LDS image << 16; 0xFFFFFFFF = no point
+    unsigned int lat[32][448];
+    // M-LDB comparison list: bit -> byte offsets of its two cell means in the LDS array of means, a | b << 16 (entries
+    // beyond 485: 0, a value against itself)
+    unsigned int bit_ofs[512];
+    // what lane i sums in the cell phase (describe3_kernel, "cell sums"); 3 << 11 = idle
+    unsigned int chain[64];
 };
 
 // One 64-thread wavefront per surviving candidate (four consecutive ones per workgroup, wave-level barriers only):
@@ -1617,7 +1304,7 @@ __global__ __launch_bounds__(256) void describe3_kernel(const cand_t *__restrict
                                                        unsigned int max_cands, const unsigned int *__restrict__ live,
                                                        const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
                                                        size_t img_stride, levels_dev L, float derivative_factor,
-                                                       const pair_tab *__restrict__ tab, const gather_tab *__restrict__ gtab,
+                                                       const gather_tab *__restrict__ gtab,
                                                        const orient_tab *__restrict__ otab, float *__restrict__ kp_out /*[b][max][6]*/,
                                                        unsigned long long *__restrict__ desc_out /*[b][max][8]*/,
                                                        unsigned char *__restrict__ valid_out, int remap,
@@ -1648,11 +1335,11 @@ __global__ __launch_bounds__(256) void describe3_kernel(const cand_t *__restrict
     const cand_t c = cands[slot];
     const unsigned int oe0 = gtab->ori[lane], oe1 = gtab->ori[lane + 64];
     const float og0 = gtab->ori_g[lane], og1 = gtab->ori_g[lane + 64];
-    const unsigned int chain = tab->chain[lane];
+    const unsigned int chain = gtab->chain[lane];
     unsigned int tbits[8];
 #pragma unroll
     for (int wd = 0; wd < 8; wd++)
-        tbits[wd] = tab->bits[wd * 64 + lane];
+        tbits[wd] = gtab->bit_ofs[wd * 64 + lane];
     const level_info l = L.l[c.level];
     const int w = l.w, h = l.h;
     if (!(fabsf(c.dx) <= 1.0f && fabsf(c.dy) <= 1.0f))
@@ -1727,20 +1414,18 @@ __global__ __launch_bounds__(256) void describe3_kernel(const cand_t *__restrict
             wmag = sum.x * sum.x + sum.y * sum.y;
             wangle = fast_atan2(sum.y, sum.x);
         }
-        // first strict maximum in window order (the sequential loop's choice): largest magnitude, lowest window on ties
-        int widx = lane;
+        // first strict maximum in window order (the sequential loop's choice): the largest magnitude, and of the windows
+        // that have it the lowest - a butterfly maximum, a ballot of the lanes that hold it, the first of them
+        float mx = wmag;
+#pragma unroll
         for (int off = 32; off >= 1; off >>= 1)
         {
-            const float om = __shfl_xor(wmag, off), oa = __shfl_xor(wangle, off);
-            const int oi = __shfl_xor(widx, off);
-            if (om > wmag || (om == wmag && oi < widx))
-            {
-                wmag = om;
-                wangle = oa;
-                widx = oi;
-            }
+            const float o = __shfl_xor(mx, off);
+            asm("v_max_f32 %0, %0, %1" : "+v"(mx) : "v"(o)); // (no NaN here: fmaxf would canonicalise both operands first)
         }
-        angle = wmag > 0.0f ? wangle : 0.0f;
+        const int widx = __builtin_ctzll(__ballot(wmag == mx));
+        const float best_angle = __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(wangle), widx));
+        angle = mx > 0.0f ? best_angle : 0.0f;
     }
     float si, co;
     sincos_poly(angle, &si, &co);
@@ -1748,47 +1433,81 @@ __global__ __launch_bounds__(256) void describe3_kernel(const cand_t *__restrict
     bool all_inside = true;
     // ---- every grid (2x2, 3x3, 4x4) samples the same rotated 21 x 21 lattice: gather it once with all lanes (7 rounds of
     // 64 points in the image order of the keypoint's orientation class: first every address, then every load - 14 in
-    // flight per lane -, then the rotations and the LDS stores at the points' own places)
+    // flight per lane -, then the rotations and the LDS stores at the points' own places).  A lattice point lies within
+    // 10 s (|cos| + |sin|) < 14.2 s pixels of (xf, yf) in x and in y; the detector only keeps extrema whose window is
+    // inside the level image (Find_Scale_Space_Extrema's margin), so the whole-patch test below holds for every keypoint
+    // and the per-point tests of the restatement are only compiled for the case that it does not.
     {
         const int cls = __builtin_amdgcn_readfirstlane(min(31, (int)(angle * 5.0929581789406507f))); // 32 / (2 pi)
-        const unsigned short *order = gtab->lat[cls];
+        const unsigned int *order = gtab->lat[cls];
         unsigned int pe[7];
 #pragma unroll
         for (int t = 0; t < 7; t++)
             pe[t] = order[lane + 64 * t];
         wave_sync(); // the orientation's LDS has been read by every lane
+        const float reach = 14.2f * fs + 2.0f;
+        const bool patch_inside = xf - reach >= 0.0f && yf - reach >= 0.0f && xf + reach <= (float)(w - 1) && yf + reach <= (float)(h - 1);
         float ri[7], rx[7], ry[7];
-        bool inside[7];
-#pragma unroll
-        for (int t = 0; t < 7; t++)
+        char *const smp_b = reinterpret_cast<char *>(smp);
+        if (patch_inside) // (wave-uniform)
         {
-            const float fa = (float)((int)(pe[t] & 255u) - 10), fb = (float)((int)(pe[t] >> 8) - 10);
-            const float sy = yf + (fb * co * fs + fa * si * fs);
-            const float sx = xf + (-fb * si * fs + fa * co * fs);
-            const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
-            inside[t] = pe[t] != 0xFFFFu && !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
-            // 32-bit byte offsets from a wave-uniform base (a level plane is far below 2^29 pixels): the loads take the
-            // base from SGPRs and the offset from one VGPR, no 64-bit address arithmetic per lane
-            const unsigned int o = inside[t] ? (unsigned int)(y1 * w + x1) : 0u;
-            ri[t] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pLt) + o * 4u);
-            const float2 gr = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(pLxy) + o * 8u);
-            rx[t] = gr.x;
-            ry[t] = gr.y;
-        }
 #pragma unroll
-        for (int t = 0; t < 7; t++)
-        {
-            if (pe[t] != 0xFFFFu)
+            for (int t = 0; t < 7; t++)
             {
-                const int p = (int)(pe[t] & 255u) * 21 + (int)(pe[t] >> 8);
-                const float rry = rx[t] * co + ry[t] * si, rrx = -rx[t] * si + ry[t] * co;
-                // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
-                // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch in the sums
-                smp[3 * p] = inside[t] ? ri[t] : 0.0f;
-                smp[3 * p + 1] = inside[t] ? rrx : 0.0f;
-                smp[3 * p + 2] = inside[t] ? rry : 0.0f;
-                all_inside = all_inside && inside[t];
+                const float fa = (float)(pe[t] & 255u) - 10.0f, fb = (float)((pe[t] >> 8) & 255u) - 10.0f;
+                const float sy = yf + (fb * co * fs + fa * si * fs);
+                const float sx = xf + (-fb * si * fs + fa * co * fs);
+                const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
+                // 32-bit byte offsets from a wave-uniform base (a level plane is far below 2^29 pixels): the loads take
+                // the base from SGPRs and the offset from one VGPR, no 64-bit address arithmetic per lane
+                const unsigned int o = pe[t] != 0xFFFFFFFFu ? (unsigned int)(y1 * w + x1) : 0u;
+                // (loads that bypass the L1 - nt / sc1 - were measured: 94 us per image against 63; the kernel sits at the rate the
+                // L2 delivers lines to the L1s, ~17 TB/s chip-wide, and what hits in the L1 is what keeps it there)
+                ri[t] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pLt) + o * 4u);
+                const float2 gr = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(pLxy) + o * 8u);
+                rx[t] = gr.x;
+                ry[t] = gr.y;
             }
+#pragma unroll
+            for (int t = 0; t < 7; t++)
+                if (pe[t] != 0xFFFFFFFFu)
+                {
+                    float *rec = reinterpret_cast<float *>(smp_b + (pe[t] >> 16));
+                    rec[0] = ri[t];
+                    rec[1] = -rx[t] * si + ry[t] * co;
+                    rec[2] = rx[t] * co + ry[t] * si;
+                }
+        }
+        else
+        {
+            bool inside[7];
+#pragma unroll
+            for (int t = 0; t < 7; t++)
+            {
+                const float fa = (float)(pe[t] & 255u) - 10.0f, fb = (float)((pe[t] >> 8) & 255u) - 10.0f;
+                const float sy = yf + (fb * co * fs + fa * si * fs);
+                const float sx = xf + (-fb * si * fs + fa * co * fs);
+                const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
+                inside[t] = pe[t] != 0xFFFFFFFFu && !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
+                const unsigned int o = inside[t] ? (unsigned int)(y1 * w + x1) : 0u;
+                ri[t] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(pLt) + o * 4u);
+                const float2 gr = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(pLxy) + o * 8u);
+                rx[t] = gr.x;
+                ry[t] = gr.y;
+            }
+#pragma unroll
+            for (int t = 0; t < 7; t++)
+                if (pe[t] != 0xFFFFFFFFu)
+                {
+                    const float rry = rx[t] * co + ry[t] * si, rrx = -rx[t] * si + ry[t] * co;
+                    // samples outside the image are stored as +0: x + 0 == x (only a -0 sum would turn +0, which no
+                    // `>` comparison of the descriptor can see), so the skip of the restatement needs no branch in the sums
+                    float *rec = reinterpret_cast<float *>(smp_b + (pe[t] >> 16));
+                    rec[0] = inside[t] ? ri[t] : 0.0f;
+                    rec[1] = inside[t] ? rrx : 0.0f;
+                    rec[2] = inside[t] ? rry : 0.0f;
+                    all_inside = all_inside && inside[t];
+                }
         }
     }
     all_inside = __all(all_inside) != 0;
@@ -1881,13 +1600,10 @@ __global__ __launch_bounds__(256) void describe3_kernel(const cand_t *__restrict
     wave_sync();
     for (int wd = 0; wd < 8; wd++)
     {
-        const int bit = wd * 64 + lane;
-        bool on = false;
-        if (bit < 486)
-        {
-            const unsigned int e = tbits[wd], ch = e >> 16;
-            on = vals[e & 255u][ch] > vals[(e >> 8) & 255u][ch];
-        }
+        // (entries beyond bit 485 compare a value with itself)
+        const unsigned int e = tbits[wd];
+        const char *vb = reinterpret_cast<const char *>(&vals[0][0]);
+        const bool on = *reinterpret_cast<const float *>(vb + (e & 0xFFFFu)) > *reinterpret_cast<const float *>(vb + (e >> 16));
         const unsigned long long word = __ballot(on);
         if (lane == 0)
             desc_out[slot * 8 + wd] = word;
@@ -2403,10 +2119,15 @@ const orient_windows &host_orient_windows()
 
 // gather_tab: which lane fetches which sample (any assignment is correct - the LDS images are indexed by the sample; this
 // one makes the lanes of a gather instruction neighbours in the image, so that they share cache lines).
-const gather_tab &host_gather_tab(const std::vector<float> &gw /*13 x 13 orientation weights*/)
+const gather_tab &host_gather_tab()
 {
-    static const gather_tab G = [&]() {
+    static const gather_tab G = []() {
         gather_tab T{};
+        std::vector<float> gw(169); // 13 x 13 Gaussian weights of the orientation samples (sigma 2.5), computed in double
+        for (int i = -6; i <= 6; i++)
+            for (int j = -6; j <= 6; j++)
+                gw[(i + 6) * 13 + (j + 6)] =
+                    (float)(std::exp(-(double)(i * i + j * j) / (2.0 * 2.5 * 2.5)) / (2.0 * M_PI * 2.5 * 2.5));
         // orientation samples: the restatement walks i (x) outer, j (y) inner; image order is j outer, i inner
         struct os
         {
@@ -2446,8 +2167,46 @@ const gather_tab &host_gather_tab(const std::vector<float> &gw /*13 x 13 orienta
                     P.push_back({std::lround(3.0 * (bb * co + a * si)), -bb * si + a * co, a, bb});
             std::sort(P.begin(), P.end(), [](const lp &u, const lp &v) { return u.row != v.row ? u.row < v.row : u.x < v.x; });
             for (int k = 0; k < 448; k++)
-                T.lat[c][k] = k < (int)P.size() ? (unsigned short)((P[k].a + 10) | ((P[k].bb + 10) << 8)) : (unsigned short)0xFFFF;
+                T.lat[c][k] = k < (int)P.size() ? (unsigned int)(P[k].a + 10) | ((unsigned int)(P[k].bb + 10) << 8) |
+                                                      ((unsigned int)(((P[k].a + 10) * 21 + (P[k].bb + 10)) * 12) << 16)
+                                                : 0xFFFFFFFFu;
         }
+        // the comparison list in the order the descriptor's bits are written: per grid, per channel, cell pairs a < b;
+        // cells numbered 0..3 | 4..12 | 13..28, a mean at vals[cell][channel]
+        int dpos = 0;
+        const int base[3] = {0, 4, 13};
+        for (int lvl = 0; lvl < 3; lvl++)
+        {
+            const int nval = (lvl + 2) * (lvl + 2);
+            for (int ch = 0; ch < 3; ch++)
+                for (int a = 0; a < nval; a++)
+                    for (int bb = a + 1; bb < nval; bb++)
+                        T.bit_ofs[dpos++] = (unsigned int)(((base[lvl] + a) * 3 + ch) * 4) | ((unsigned int)(((base[lvl] + bb) * 3 + ch) * 4) << 16);
+        }
+        // the cell chains: lane 3 c + channel sums channel `channel` of chain c - the four 10 x 10 cells, the 7 x 7 cells in
+        // pairs (the ninth alone), the 5 x 5 cells in fours.  Word: lattice point of the first sample | channel << 9 |
+        // class << 11 | first cell << 13 | "the pair's second cell follows the first in memory" << 18
+        for (int i = 0; i < 64; i++)
+            T.chain[i] = 3u << 11;
+        struct ch_t
+        {
+            int cls, first_cell, i, j, follows;
+        };
+        std::vector<ch_t> chains;
+        for (int k = 0; k < 4; k++)
+            chains.push_back({0, k, -10 + (k / 2) * 10, -10 + (k % 2) * 10, 0});
+        for (int k = 0; k < 9; k += 2) // cell 2 ends at lattice point 146 and cell 3 begins at 147
+            chains.push_back({1, 4 + k, -10 + (k / 3) * 7, -10 + (k % 3) * 7, k == 2 ? 1 : 0});
+        for (int k = 0; k < 16; k += 4)
+            chains.push_back({2, 13 + k, -10 + (k / 4) * 5, -10, 0});
+        for (size_t cidx = 0; cidx < chains.size(); cidx++)
+            for (int ch = 0; ch < 3; ch++)
+            {
+                const ch_t &cc = chains[cidx];
+                const unsigned int p0 = (unsigned int)((cc.i + 10) * 21 + (cc.j + 10));
+                T.chain[3 * cidx + ch] = p0 | ((unsigned int)ch << 9) | ((unsigned int)cc.cls << 11) |
+                                         ((unsigned int)cc.first_cell << 13) | ((unsigned int)cc.follows << 18);
+            }
         return T;
     }();
     return G;
@@ -2539,7 +2298,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     float2 *d_Lxy = nullptr; // (Lx, Ly) interleaved, indexed like the other pyramids
     float2 *d_Fit = nullptr; // (dx, dy) of the sub-pixel fit at the maxima (sparse, like d_Rmax)
     float *d_Lt = nullptr, *d_Rmax = nullptr, *d_kc = nullptr,
-          *d_gw = nullptr, *d_kp = nullptr;
+          *d_kp = nullptr;
     unsigned int *d_hmax = nullptr, *d_hist = nullptr, *d_ncand = nullptr, *d_pmax = nullptr;
     cand_t *d_cands = nullptr;
     unsigned char *d_dead = nullptr, *d_valid = nullptr;
@@ -2548,7 +2307,6 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned int *d_counts = nullptr, *d_tile_counts = nullptr, *d_tile_base = nullptr, *d_tile_seq = nullptr;
     unsigned long long *d_mask = nullptr, *d_vmask = nullptr;
     unsigned int *d_wbase = nullptr, *d_live = nullptr, *d_nlive = nullptr;
-    pair_tab *d_tab = nullptr;
     orient_tab *d_otab = nullptr;
     gather_tab *d_gtab = nullptr;
     const size_t src_px = (size_t)width * height;
@@ -2618,81 +2376,15 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         AK(up(ctx, allocs, &d_tile_seq, seq.data(), seq.size()));
     }
     {
-        std::vector<float> gw(169);
-        for (int i = -6; i <= 6; i++)
-            for (int j = -6; j <= 6; j++)
-                gw[(i + 6) * 13 + (j + 6)] =
-                    (float)(std::exp(-(double)(i * i + j * j) / (2.0 * 2.5 * 2.5)) / (2.0 * M_PI * 2.5 * 2.5));
-        AK(up(ctx, allocs, &d_gw, gw.data(), gw.size()));
-        pair_tab tab{};
-        int dpos = 0;
-        const int base[3] = {0, 4, 13};
-        for (int lvl = 0; lvl < 3; lvl++)
-        {
-            const int nval = (lvl + 2) * (lvl + 2);
-            for (int ch = 0; ch < 3; ch++)
-                for (int a = 0; a < nval; a++)
-                    for (int bb = a + 1; bb < nval; bb++)
-                    {
-                        tab.bits[dpos] = (unsigned int)(base[lvl] + a) | ((unsigned int)(base[lvl] + bb) << 8) | ((unsigned int)ch << 16);
-                        dpos++;
-                    }
-        }
-        {
-            int nw = 0;
-            for (float a1 = 0.0f; a1 < 6.28318530717958647692f && nw < 64; a1 += 0.15f)
-                tab.win_ang1[nw++] = a1;
-            if (nw != 42)
-            {
-                cleanup();
-                return ochip_fail(ctx, OCHIP_EINVAL, "akaze: %d orientation windows instead of 42", nw);
-            }
-        }
-        int nq = 0;
-        for (int q = 0; q < 169; q++)
-        {
-            const int i = q / 13 - 6, j = q % 13 - 6;
-            if (i * i + j * j < 36)
-            {
-                tab.ori_q[nq] = (unsigned int)q;
-                tab.ori_g[nq] = gw[q];
-                nq++;
-            }
-        }
-        // describe2_kernel's chains: lane 3 c + channel sums channel `channel` of chain c - the four 10 x 10 cells, the
-        // 7 x 7 cells in pairs (the ninth alone), the 5 x 5 cells in fours; cells numbered 0..3 | 4..12 | 13..28
-        {
-            for (int i = 0; i < 64; i++)
-                tab.chain[i] = 3u << 11;
-            struct ch_t
-            {
-                int cls, first_cell, i, j, follows;
-            };
-            std::vector<ch_t> chains;
-            for (int k = 0; k < 4; k++)
-                chains.push_back({0, k, -10 + (k / 2) * 10, -10 + (k % 2) * 10, 0});
-            for (int k = 0; k < 9; k += 2) // cell 2 ends at lattice point 146 and cell 3 begins at 147
-                chains.push_back({1, 4 + k, -10 + (k / 3) * 7, -10 + (k % 3) * 7, k == 2 ? 1 : 0});
-            for (int k = 0; k < 16; k += 4)
-                chains.push_back({2, 13 + k, -10 + (k / 4) * 5, -10, 0});
-            for (size_t cidx = 0; cidx < chains.size(); cidx++)
-                for (int ch = 0; ch < 3; ch++)
-                {
-                    const ch_t &cc = chains[cidx];
-                    const unsigned int p0 = (unsigned int)((cc.i + 10) * 21 + (cc.j + 10));
-                    tab.chain[3 * cidx + ch] = p0 | ((unsigned int)ch << 9) | ((unsigned int)cc.cls << 11) |
-                                               ((unsigned int)cc.first_cell << 13) | ((unsigned int)cc.follows << 18);
-                }
-        }
-        AK(up(ctx, allocs, &d_tab, &tab, 1));
+        // the descriptor kernel's tables (built once per process): orientation windows, gather orders, cell chains, bit list
         const orient_windows &ow = host_orient_windows();
-        if (!ow.ok || std::memcmp(ow.a1, tab.win_ang1, sizeof ow.a1) != 0)
+        if (!ow.ok)
         {
             cleanup();
             return ochip_fail(ctx, OCHIP_EINVAL, "akaze: the orientation-window table disagrees with the window predicate");
         }
         AK(up(ctx, allocs, &d_otab, &ow.T, 1));
-        AK(up(ctx, allocs, &d_gtab, &host_gather_tab(gw), 1));
+        AK(up(ctx, allocs, &d_gtab, &host_gather_tab(), 1));
     }
     if (rc != OCHIP_OK)
     {
@@ -2948,33 +2640,12 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         OCHIP_HIP(ctx, hipMemcpyAsync(nlive.data(), d_nlive, B * 4, hipMemcpyDeviceToHost, st));
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         const unsigned int max_live = *std::max_element(nlive.begin(), nlive.end());
-        static const bool profile_describe = getenv("OCHIP_DESCRIBE_PROFILE") != nullptr;
-#define OCHIP_LAUNCH_DESCRIBE(P)                                                                                               \
-    hipLaunchKernelGGL(describe_kernel<P>, dim3(512 * (((max_live + 3) / 4 + 511) / 512), 1, B), dim3(256), 0, st,             \
-                       (const cand_t *)d_cands, (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live,       \
-                       (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, dfactor,                                    \
-                       (const float *)d_gw, (const pair_tab *)d_tab, d_kp, d_desc, d_valid, xcd_remap, d_vmask, mask_stride)
-        static const bool describe_v1 = getenv("OCHIP_DESCRIBE_V1") != nullptr; // A/B: the one-launch descriptor of rounds 1-3
-        if (max_live == 0)
-            ;
-        else if (!describe_v1)
+        if (max_live > 0)
             hipLaunchKernelGGL(describe3_kernel, dim3(512 * (((max_live + 3) / 4 + 511) / 512), 1, B), dim3(256), 0, st,
                                (const cand_t *)d_cands, (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live,
-                               (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, dfactor, (const pair_tab *)d_tab,
+                               (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, dfactor,
                                (const gather_tab *)d_gtab, (const orient_tab *)d_otab, d_kp, d_desc, d_valid, xcd_remap, d_vmask,
                                mask_stride);
-        else if (!profile_describe)
-            OCHIP_LAUNCH_DESCRIBE(false);
-        else
-        {
-            OCHIP_LAUNCH_DESCRIBE(true);
-            unsigned long long hp[8];
-            OCHIP_HIP(ctx, hipStreamSynchronize(st));
-            OCHIP_HIP(ctx, hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_desc_prof), sizeof(hp)));
-            fprintf(stderr, "[describe] cumulative wave cycles: fit %llu, orientation gather %llu, windows %llu, lattice gather %llu, cells %llu, bits %llu\n",
-                    hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]);
-        }
-#undef OCHIP_LAUNCH_DESCRIBE
     }
     if (max_n > 0)
     {

@@ -13,6 +13,7 @@
 #include "load_link.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -56,13 +57,58 @@ std::vector<owned_pair> pair_owners(const std::vector<NodeLinks> &links)
     return out;
 }
 
+// Surveys in flight.  Two calls may overlap (two host threads, a graph each, the same device context): the second one's
+// extraction starts when the first one's has finished, and runs beside the first one's remaining link ranges - the tail of
+// a survey's link stage (its last ranges can only start once its last images are extracted, and RANSAC is a chain of
+// dependent steps per pair that leaves most of the device idle) then no longer stands alone on the device.  This is the
+// reference's own schedule: its pipeline runs the load runners of one batch beside the link runners of the batch before
+// (Pipeline::Impl::initial_processing, src/pipeline/pipeline.cpp:543-560).  The extraction contexts (ctx and its first
+// siblings) are used by one survey at a time - the gate below -, the link runners of alternating calls use two different
+// sets of sibling contexts.
+namespace
+{
+std::mutex g_extract_gate_mu;
+std::condition_variable g_extract_gate_cv;
+bool g_extract_gate_busy = false;
+std::atomic<unsigned> g_survey_counter{0};
+thread_local double g_last_gate_wait = 0; // seconds the calling thread's last load_link_stream waited at the gate
+struct extract_gate
+{
+    bool held = false;
+    void acquire()
+    {
+        std::unique_lock<std::mutex> lk(g_extract_gate_mu);
+        g_extract_gate_cv.wait(lk, [] { return !g_extract_gate_busy; });
+        g_extract_gate_busy = true;
+        held = true;
+    }
+    void release()
+    {
+        if (!held)
+            return;
+        {
+            std::lock_guard<std::mutex> lk(g_extract_gate_mu);
+            g_extract_gate_busy = false;
+        }
+        g_extract_gate_cv.notify_all();
+        held = false;
+    }
+    ~extract_gate() { release(); }
+};
+} // namespace
+
 bool load_link_stream(och_graph *g, ochip_ctx *ctx, LinkStage &link, const std::vector<size_t> &ids, uint32_t first,
                       uint32_t count, const uint8_t *images_bgr, int width, int height, uint32_t max_keypoints,
                       bool images_on_device, const std::vector<owned_pair> &pairs, double *total_out, double *sparse_out,
                       double *t_extract_done)
 {
     using clk = std::chrono::steady_clock;
+    const unsigned lane = g_survey_counter.fetch_add(1) & 1u;
+    extract_gate gate;
+    const auto t_gate = clk::now();
+    gate.acquire(); // (released when this survey's last chunk is extracted; on every return path by the destructor)
     const auto t_begin = clk::now();
+    g_last_gate_wait = std::chrono::duration<double>(t_begin - t_gate).count();
     const auto &links = link.links();
     // ---- ranges of links and the images (of this call's block) each one waits for
     std::unordered_map<size_t, uint32_t> image_of; // node id -> image index within the block
@@ -122,7 +168,7 @@ bool load_link_stream(och_graph *g, ochip_ctx *ctx, LinkStage &link, const std::
     for (int r = 0; r < n_runners; r++)
     {
         ochip_ctx *rctx = nullptr;
-        if (ochip_ctx_sibling(ctx, (uint32_t)(4 + r), &rctx) != OCHIP_OK)
+        if (ochip_ctx_sibling(ctx, (uint32_t)((lane ? 13 : 4) + r), &rctx) != OCHIP_OK) // (sibling 12: the bench's relax context)
         {
             g->error = std::string("ochip_ctx_sibling: ") + ochip_last_error(ctx);
             {
@@ -179,6 +225,7 @@ bool load_link_stream(och_graph *g, ochip_ctx *ctx, LinkStage &link, const std::
             cv.notify_all();
         },
         &g->error);
+    gate.release(); // the next survey may extract while this one's remaining ranges are linked
     if (t_extract_done)
         *t_extract_done = std::chrono::duration<double>(clk::now() - t_begin).count();
     {
@@ -266,6 +313,7 @@ extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const ui
     if (!load_link_stream(g, ctx, link, ids, 0, n_images, images_bgr, width, height, max_keypoints, images_on_device != 0,
                           pair_owners(link.links()), &total, &sparse, &t_extract_done))
         return -1;
+    const double gate_wait = g_last_gate_wait;
     link.finalize(g->graph);
     if (totals2)
     {
@@ -283,7 +331,7 @@ extern "C" int och_graph_load_link_images(och_graph *g, ochip_ctx *ctx, const ui
     if (stage_seconds2)
     {
         stage_seconds2[0] = t_extract_done;            // until the last chunk's features were final
-        stage_seconds2[1] = seconds_since(t_begin);     // until the graph was linked
+        stage_seconds2[1] = seconds_since(t_begin) - gate_wait; // until the graph was linked (not counting the wait for the survey before to finish extracting)
     }
     return 0;
 }

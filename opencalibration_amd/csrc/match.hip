@@ -446,11 +446,22 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
             c0[4 * gidx + 3] = c4.w;
         }
         v16f acc0 = c0, acc1 = c0;
+        // the tile's eight reference operands are requested together, ahead of the sixteen MFMAs (read one step at a time
+        // the matrix pipe waited out an LDS round trip between every two instructions)
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        v4i a[8];
 #pragma unroll
         for (int sidx = 0; sidx < 8; sidx++)
         {
-            const uint4 a = tileA[cur][r * 16 + ((2 * sidx + h) ^ (r & 15))];
-            const v8i A = v8i{(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
+            const uint4 t = tileA[cur][r * 16 + ((2 * sidx + h) ^ (r & 15))];
+            a[sidx] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+        }
+        // (an empty statement that needs all eight in registers at once: left alone the compiler sinks every read to its use)
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+#pragma unroll
+        for (int sidx = 0; sidx < 8; sidx++)
+        {
+            const v8i A = v8i{a[sidx].x, a[sidx].y, a[sidx].z, a[sidx].w, 0, 0, 0, 0};
             // FP4 both sides (cbsz = blgp = 4); block scales: 2^14 on the references (E8M0 141), 1 on the queries (127)
             acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[0][sidx], acc0, 4, 4, 0, 141, 0, 127);
             acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[1][sidx], acc1, 4, 4, 0, 141, 0, 127);

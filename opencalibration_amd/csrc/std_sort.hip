@@ -40,7 +40,8 @@ typedef unsigned long long u64;
 constexpr unsigned int THRESHOLD = 16;  // _S_threshold
 constexpr unsigned int LOCAL = 1024;    // ranges up to this length are finished by one wavefront in LDS
 constexpr unsigned int BIG = 2048;      // ranges longer than this take a whole workgroup, (LOCAL, BIG] a wavefront, per level
-constexpr int GROUP = 256;              // threads of the workgroup that partitions a long range
+constexpr int GROUP = 1024;             // threads of the workgroup that partitions a long range (256 until round 4: the first levels of a
+                                        // chunk are one range per image, a pass over 20 k records is a chain of memory round trips per thread)
 
 struct range_t
 {

@@ -54,7 +54,8 @@ def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000, ov
         feats_mean, sparse_mean, link_timers, (t_ex, t_all) = g.load_link_images(
             ctx, images_ptr if host_images is None else host_images, mid, grid.position, start_orientation, max_keypoints,
             device_shape=(n, h, w) if host_images is None else None)
-        t["extract"], t["link"] = t_ex, time.perf_counter() - t0 - t_ex   # link = what the linking adds after the last features
+        t["extract"], t["link"] = t_ex, t_all - t_ex   # link = what the linking adds after the last features (native clocks:
+        #                                                  the wait for the previous survey's extraction is in neither)
         t["host_cpu_load_link"] = time.process_time() - c0                 # CPU seconds of all host threads
         if not relax:
             return g, dict(features_per_image=feats_mean, sparse_per_image=sparse_mean, link_timers=link_timers, edges=g.num_edges), t
