@@ -16,6 +16,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
              "-Wno-unused-result"]
+# match.hip: the matrix-core matcher folds its accumulators with vector instructions right after the MFMAs; with the
+# accumulators in VGPRs (instead of the AGPR half of the file) that needs no v_accvgpr_read per register and tile
+HIP_FLAGS_PER_FILE = {"match.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off", "-Wall", "-Wextra",
               "-Wno-unused-parameter"]
 
@@ -40,7 +43,7 @@ def build_ochip(force=False, verbose=False):
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC, *HIP_FLAGS, "-c", "-o", o, s]
+            cmd = [HIPCC, *HIP_FLAGS, *HIP_FLAGS_PER_FILE.get(os.path.basename(s), []), "-c", "-o", o, s]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((cmd, subprocess.Popen(cmd)))

@@ -2622,7 +2622,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         }
         max_n = std::max(max_n, ncand[b]);
     }
-    static const int xcd_remap = getenv("OCHIP_XCD_REMAP") ? atoi(getenv("OCHIP_XCD_REMAP")) : 2; // tuning knob, see xcd_contiguous
+    const int xcd_remap = 2; // groups of 64 list neighbours per XCD (see xcd_contiguous; 0, 1 and 3 measured slower)
     if (max_n > 0)
     {
         OCHIP_HIP(ctx, hipMemsetAsync(d_vmask, 0, (size_t)B * mask_stride * 8, st));
@@ -2682,24 +2682,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     {
         // one strided copy per array instead of one per image and array (2 x 100 launches per chunk): every image's row is
         // copied up to the longest list of the chunk - a few per cent more bytes, the counts say where each list ends
-        static const bool per_image = getenv("OCHIP_AKAZE_COPY_PER_IMAGE") != nullptr; // A/B knob
-        if (!per_image)
-        {
-            OCHIP_HIP(ctx, hipMemcpy2DAsync(kp6, (size_t)max_kp * 24, d_kpc, (size_t)max_kp * 24, (size_t)most * 24, B,
-                                            hipMemcpyDeviceToHost, st));
-            OCHIP_HIP(ctx, hipMemcpy2DAsync(desc, (size_t)max_kp * 64, d_descc, (size_t)max_kp * 64, (size_t)most * 64, B,
-                                            hipMemcpyDeviceToHost, st));
-        }
-        else
-            for (uint32_t b = 0; b < B; b++)
-            {
-                if (counts[b] == 0)
-                    continue;
-                OCHIP_HIP(ctx, hipMemcpyAsync(kp6 + (size_t)b * max_kp * 6, d_kpc + (size_t)b * max_kp * 6, (size_t)counts[b] * 24,
-                                              hipMemcpyDeviceToHost, st));
-                OCHIP_HIP(ctx, hipMemcpyAsync(desc + (size_t)b * max_kp * 8, d_descc + (size_t)b * max_kp * 8,
-                                              (size_t)counts[b] * 64, hipMemcpyDeviceToHost, st));
-            }
+        OCHIP_HIP(ctx, hipMemcpy2DAsync(kp6, (size_t)max_kp * 24, d_kpc, (size_t)max_kp * 24, (size_t)most * 24, B, hipMemcpyDeviceToHost, st));
+        OCHIP_HIP(ctx, hipMemcpy2DAsync(desc, (size_t)max_kp * 64, d_descc, (size_t)max_kp * 64, (size_t)most * 64, B, hipMemcpyDeviceToHost, st));
     }
     if (rc != OCHIP_OK)
         for (uint32_t b = 0; b < B; b++)

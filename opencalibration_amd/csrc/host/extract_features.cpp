@@ -222,7 +222,7 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
     };
     // the records are gathered in strength order, i.e. from random places of the device's arrays: ask for the lines of
     // the entries a few steps ahead while this one is copied
-    static const size_t PREFETCH_AHEAD = std::getenv("OCHIP_TAIL_PREFETCH") ? (size_t)std::atol(std::getenv("OCHIP_TAIL_PREFETCH")) : 24;
+    constexpr size_t PREFETCH_AHEAD = 24;
     auto emit_all = [&](const std::vector<uint32_t> &list) {
         const size_t m = list.size();
         for (size_t j = 0; j < m; j++)

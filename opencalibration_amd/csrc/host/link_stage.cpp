@@ -161,15 +161,11 @@ std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph
     std::vector<std::function<void()>> funcs;
     prepare(graph);
     // a runner needs enough pairs to fill the device; the debug record is kept in runner order, so one runner then.
-    // A runner may walk its range in sub-batches (OCHIP_LINK_SUBBATCHES) so that the runners drift out of phase;
-    // measured on C3 it does not pay (smaller launches, more uploads), so the default is one batch per runner.
+    // One batch per runner (walking a range in sub-batches so that the runners drift out of phase did not pay on C3:
+    // smaller launches, more uploads), the OpenMP team divided among the runners.
     size_t n = keep_debug ? 1 : std::min<size_t>((size_t)_runners, std::max<size_t>(1, _links.size() / 64));
-    static const size_t sub_env = std::getenv("OCHIP_LINK_SUBBATCHES") ? (size_t)std::atoi(std::getenv("OCHIP_LINK_SUBBATCHES")) : 1;
-    const size_t sub = keep_debug ? 1 : std::max<size_t>(1, std::min<size_t>(sub_env, _links.size() / (n * 64)));
-    // share of the OpenMP team per runner: OCHIP_LINK_TEAM_SHARE = 1 gives every runner the whole team (their host
-    // phases rarely coincide), the default divides it
-    static const bool whole_team = std::getenv("OCHIP_LINK_TEAM_SHARE") && std::atoi(std::getenv("OCHIP_LINK_TEAM_SHARE")) == 1;
-    const int omp_threads = whole_team ? omp_get_max_threads() : std::max(1, omp_get_max_threads() / (int)n);
+    const size_t sub = 1;
+    const int omp_threads = std::max(1, omp_get_max_threads() / (int)n);
     for (size_t r = 0; r < n; r++)
     {
         const size_t begin = _links.size() * r / n, end = _links.size() * (r + 1) / n;

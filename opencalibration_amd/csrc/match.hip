@@ -317,7 +317,7 @@ __global__ __launch_bounds__(BLOCK) void sym_merge_kernel(const sym_job *__restr
 // (v_med3_f32, v_max_f32), 64 per 2 048 distances, and the result tile never leaves the registers: an MFMA tile has its
 // column on the lane, so with the queries as columns every lane folds its own query's 16 references.
 // A wavefront keeps 64 queries as B operands in registers (two tiles); the four waves of a workgroup share the reference
-// tiles (32 references, 8 KB) through LDS, double-buffered, XOR-swizzled so that the 16-byte operand reads are conflict
+// tiles (64 references, 16 KB) through LDS, double-buffered, rows padded so that the 16-byte operand reads are conflict
 // free.  References beyond n2 start from -1e9 and never win.  Needs n2 <= 8 192 (k in 13 bits); larger images take the
 // popcount kernels above.
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -349,17 +349,19 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restr
     }
 }
 
+// top-2 bookkeeping on keys: second' = median(best, second, key), best' = max(best, key).  As compiler builtins (v_med3_f32,
+// v_max_i32) - NOT as inline asm: the
+// accumulators are VGPRs written by the MFMAs just before, and the wait states between a matrix instruction and a vector
+// instruction that reads its result are the compiler's to insert, which it cannot do inside an asm statement.
 __device__ __forceinline__ float med3_f32(float a, float b, float c)
 {
-    float r;
-    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    return __builtin_amdgcn_fmed3f(a, b, c);
 }
-__device__ __forceinline__ float max_f32(float a, float b) // fmaxf without the canonicalising v_max x, x in front (no NaN here)
+__device__ __forceinline__ float max_f32(float a, float b)
 {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    // as integers: the keys that matter are positive floats, which order like their bit patterns, and every negative value
+    // ("no reference here") stays below them - one v_max_i32, where fmaxf is three instructions with its canonicalising
+    return __int_as_float(max(__float_as_int(a), __float_as_int(b)));
 }
 
 __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__restrict__ fp4, const float *__restrict__ negpop,
@@ -370,8 +372,12 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
                                                                const uint64_t *__restrict__ out_off,
                                                                ochip_match *__restrict__ out, uint32_t chunks_per_pair)
 {
-    __shared__ uint4 tileA[2][32 * 16]; // reference rows of a tile: [row][16 x 16 bytes], slot j of row r at j ^ (r & 15)
-    __shared__ float tileC[2][32];      // the rows' accumulator start: (512 - |ref|) * 8192 + (8191 - k)
+    // reference rows of a tile: [row][16 x 16 bytes], rows 272 bytes apart: the 16 lanes of a ds_read_b128 group then sit 4
+    // banks apart (conflict free) and a lane reads its eight operands at immediate offsets from one address.  A tile is 64
+    // references, two MFMA row blocks: one workgroup barrier and one round of staging loads per 32 matrix instructions.
+    constexpr int TR = 64;
+    __shared__ uint4 tileA[2][TR * 17];
+    __shared__ float tileC[2][TR]; // the rows' accumulator start: (512 - |ref|) * 8192 + (8191 - k)
     const uint32_t pair = blockIdx.x / chunks_per_pair;
     const uint32_t chunk = blockIdx.x - pair * chunks_per_pair;
     const ochip_pair pr = pairs[pair];
@@ -397,85 +403,116 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
         }
     }
     float best[2] = {-1.0f, -1.0f}, second[2] = {-1.0f, -1.0f};
-    const uint32_t n_tiles = (n2 + 31) / 32;
-    // staging: thread tid moves 16-byte pieces tid and tid + 256 of the tile's 512 (rows are consecutive features: one
-    // contiguous 8 KB read); rows beyond n2 re-read the last feature and are disabled through tileC
-    auto tile_piece = [&](uint32_t jt, int piece) -> uint4 {
-        const uint32_t row = (uint32_t)piece >> 4;
-        uint32_t k = jt * 32 + row;
-        k = k < n2 ? k : n2 - 1;
-        return fp4[(off2 + k) * 16 + (piece & 15)];
+    const uint32_t n_tiles = (n2 + TR - 1) / TR;
+    // staging: a tile's rows are consecutive features, 16 KB in one piece; thread tid moves its 16-byte pieces tid + 256 i.
+    // Only the last tile can have rows beyond n2: they re-read the last feature and are disabled through tileC.
+    const uint4 *gsrc = fp4 + off2 * 16 + tid;
+    const float *gneg = negpop + off2 + (tid & 63);
+    const int st0 = (tid >> 4) * 17 + (tid & 15); // LDS slot of the first piece; the others lie 16 rows further each
+    auto load_tile = [&](uint32_t jt, uint4 (&p)[4], float &c) {
+        if ((jt + 1) * TR <= n2) // (uniform)
+        {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                p[i] = gsrc[(size_t)jt * (TR * 16) + 256 * i];
+            c = gneg[jt * TR] + (float)(8191 - (int)(jt * TR + (uint32_t)(tid & 63)));
+        }
+        else
+        {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const uint32_t k = jt * TR + ((uint32_t)tid >> 4) + 16 * i;
+                p[i] = fp4[(off2 + (k < n2 ? k : n2 - 1)) * 16 + (tid & 15)];
+            }
+            const uint32_t kc = jt * TR + (uint32_t)(tid & 63);
+            c = kc < n2 ? negpop[off2 + kc] + (float)(8191 - (int)kc) : -1e9f;
+        }
     };
-    auto tile_c = [&](uint32_t jt) -> float {
-        const uint32_t k = jt * 32 + (uint32_t)tid;
-        return (tid < 32 && k < n2) ? negpop[off2 + k] + (float)(8191 - (int)k) : -1e9f;
-    };
-    auto put_tile = [&](int buf, uint4 p0, uint4 p1, float c) {
-        const int r0 = tid >> 4, j0 = tid & 15, r1 = (tid + 256) >> 4;
-        tileA[buf][r0 * 16 + (j0 ^ (r0 & 15))] = p0;
-        tileA[buf][r1 * 16 + (j0 ^ (r1 & 15))] = p1;
-        if (tid < 32)
+    auto put_tile = [&](int buf, const uint4 (&p)[4], float c) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            tileA[buf][st0 + 16 * 17 * i] = p[i];
+        if (tid < TR)
             tileC[buf][tid] = c;
     };
     {
-        const uint4 p0 = tile_piece(0, tid), p1 = tile_piece(0, tid + 256);
-        put_tile(0, p0, p1, tile_c(0));
+        uint4 p[4];
+        float c;
+        load_tile(0, p, c);
+        put_tile(0, p, c);
     }
     __syncthreads();
     for (uint32_t jt = 0; jt < n_tiles; jt++)
     {
         const int cur = (int)(jt & 1);
         const bool more = jt + 1 < n_tiles;
-        uint4 n0 = make_uint4(0, 0, 0, 0), n1v = n0;
+        uint4 nx[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
         float nc = 0.0f;
         if (more) // the next tile's loads fly under this tile's MFMAs
-        {
-            n0 = tile_piece(jt + 1, tid);
-            n1v = tile_piece(jt + 1, tid + 256);
-            nc = tile_c(jt + 1);
-        }
-        // accumulator start: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h
-        v16f c0;
+            load_tile(jt + 1, nx, nc);
+        // Four accumulator tiles at once - the tile's two row blocks x the wave's two query blocks -, so that a matrix
+        // instruction's successor on the same accumulator comes three instructions later: with two chains the matrix pipe
+        // ran at half its rate (a dependent v_mfma_scale waits for its predecessor's result, ~2 issue slots).
+        v16f acc[2][2];
 #pragma unroll
-        for (int gidx = 0; gidx < 4; gidx++)
+        for (int sub = 0; sub < 2; sub++)
         {
-            const float4 c4 = *reinterpret_cast<const float4 *>(&tileC[cur][8 * gidx + 4 * h]);
-            c0[4 * gidx + 0] = c4.x;
-            c0[4 * gidx + 1] = c4.y;
-            c0[4 * gidx + 2] = c4.z;
-            c0[4 * gidx + 3] = c4.w;
+            // accumulator start: register i of lane (r, h) is row (i & 3) + 8 (i >> 2) + 4 h of the row block
+#pragma unroll
+            for (int gidx = 0; gidx < 4; gidx++)
+            {
+                const float4 c4 = *reinterpret_cast<const float4 *>(&tileC[cur][32 * sub + 8 * gidx + 4 * h]);
+                acc[sub][0][4 * gidx + 0] = c4.x;
+                acc[sub][0][4 * gidx + 1] = c4.y;
+                acc[sub][0][4 * gidx + 2] = c4.z;
+                acc[sub][0][4 * gidx + 3] = c4.w;
+            }
+            acc[sub][1] = acc[sub][0];
         }
-        v16f acc0 = c0, acc1 = c0;
-        // the tile's eight reference operands are requested together, ahead of the sixteen MFMAs (read one step at a time
-        // the matrix pipe waited out an LDS round trip between every two instructions)
         typedef int v4i __attribute__((ext_vector_type(4)));
-        v4i a[8];
 #pragma unroll
-        for (int sidx = 0; sidx < 8; sidx++)
+        for (int half = 0; half < 2; half++)
         {
-            const uint4 t = tileA[cur][r * 16 + ((2 * sidx + h) ^ (r & 15))];
-            a[sidx] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
-        }
-        // (an empty statement that needs all eight in registers at once: left alone the compiler sinks every read to its use)
-        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+            // the operands of four k-steps of both row blocks are requested together, ahead of their sixteen MFMAs (read
+            // one step at a time the matrix pipe waited out an LDS round trip between instructions)
+            v4i a[2][4];
 #pragma unroll
-        for (int sidx = 0; sidx < 8; sidx++)
-        {
-            const v8i A = v8i{a[sidx].x, a[sidx].y, a[sidx].z, a[sidx].w, 0, 0, 0, 0};
-            // FP4 both sides (cbsz = blgp = 4); block scales: 2^14 on the references (E8M0 141), 1 on the queries (127)
-            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[0][sidx], acc0, 4, 4, 0, 141, 0, 127);
-            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[1][sidx], acc1, 4, 4, 0, 141, 0, 127);
+            for (int sub = 0; sub < 2; sub++)
+            {
+                const uint4 *arow = &tileA[cur][(32 * sub + r) * 17 + h + 8 * half];
+#pragma unroll
+                for (int sidx = 0; sidx < 4; sidx++)
+                {
+                    const uint4 t = arow[2 * sidx];
+                    a[sub][sidx] = v4i{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+                }
+            }
+            // (an empty statement that needs all eight in registers at once: left alone the compiler sinks every read to its use)
+            asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]));
+#pragma unroll
+            for (int sidx = 0; sidx < 4; sidx++)
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++)
+                {
+                    const v8i A = v8i{a[sub][sidx].x, a[sub][sidx].y, a[sub][sidx].z, a[sub][sidx].w, 0, 0, 0, 0};
+                    // FP4 both sides (cbsz = blgp = 4); block scales: 2^14 on the references (E8M0 141), 1 on the queries (127)
+                    acc[sub][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[0][4 * half + sidx], acc[sub][0], 4, 4, 0, 141, 0, 127);
+                    acc[sub][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[1][4 * half + sidx], acc[sub][1], 4, 4, 0, 141, 0, 127);
+                }
         }
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-        {
-            second[0] = med3_f32(best[0], second[0], acc0[i]);
-            best[0] = max_f32(best[0], acc0[i]);
-            second[1] = med3_f32(best[1], second[1], acc1[i]);
-            best[1] = max_f32(best[1], acc1[i]);
-        }
+        for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+            {
+                second[0] = med3_f32(best[0], second[0], acc[sub][0][i]);
+                best[0] = max_f32(best[0], acc[sub][0][i]);
+                second[1] = med3_f32(best[1], second[1], acc[sub][1][i]);
+                best[1] = max_f32(best[1], acc[sub][1][i]);
+            }
         if (more)
-            put_tile(cur ^ 1, n0, n1v, nc);
+            put_tile(cur ^ 1, nx, nc);
         __syncthreads();
     }
     // the two half-waves hold the same queries' other 16 rows per tile
@@ -555,7 +592,7 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
         }
     const uint32_t n_mfma = (uint32_t)mfma_pairs.size();
     // ---- of the others, pairs whose reverse is in the batch too are matched in both directions from one pass over their distances
-    static const bool use_sym = !(getenv("OCHIP_MATCH_SYM") && getenv("OCHIP_MATCH_SYM")[0] == '0'); // A/B knob
+    constexpr bool use_sym = true;
     std::vector<sym_job> sym;
     std::vector<ochip_pair> single_pairs;
     std::vector<uint64_t> single_off;
@@ -687,11 +724,7 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
     if (max_n1 == 0)
         return OCHIP_OK;
 
-    static const int qpt = []() {
-        const char *e = getenv("OCHIP_MATCH_QPT"); // tuning knob; default chosen from measurements
-        const int v = e ? atoi(e) : 1;
-        return (v == 1 || v == 2 || v == 4) ? v : 1;
-    }();
+    constexpr int qpt = 1; // queries per lane of the popcount kernel (2 and 4 measured slower: register pressure)
     const uint32_t chunks = (max_n1_single + BLOCK * qpt - 1) / (BLOCK * qpt);
     const uint64_t blocks = (uint64_t)chunks * n_single;
     const uint32_t sym_chunks = (sym_max_na + BLOCK - 1) / BLOCK;
@@ -713,14 +746,7 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
                            chunks);
     };
     if (blocks)
-    {
-        if (qpt == 1)
-            launch(hamming_2nn_kernel<1>);
-        else if (qpt == 4)
-            launch(hamming_2nn_kernel<4>);
-        else
-            launch(hamming_2nn_kernel<2>);
-    }
+        launch(hamming_2nn_kernel<1>);
     sym_groups.push_back(n_sym);
     for (size_t gi = 0; gi + 1 < sym_groups.size(); gi++)
     {

@@ -867,8 +867,7 @@ int assign_tangent(ochip_relax_problem *p)
     for (uint32_t c = 0; c < p->n_cams; c++)
         if (p->cam_optimize[c] && !p->cams_frozen && p->cam_pair_count[c] + p->cam_has_prior_host[c] > 0)
             active.push_back(c);
-    static const bool use_rcm = !(getenv("OCHIP_RELAX_RCM") && getenv("OCHIP_RELAX_RCM")[0] == '0');
-    if (use_rcm && active.size() > 2 * (size_t)NB / 3)
+    if (active.size() > 2 * (size_t)NB / 3)
     {
         // Reverse Cuthill-McKee over the camera graph (a link = a pair with residual blocks): the block envelope the
         // factorisation works in then does not depend on the order the images happen to arrive in.  Per connected

@@ -1346,7 +1346,7 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
     {
         const int nn = n_in;
         const int nbc = (nn + NB - 1) / NB, nbr = (nn + 1 + NB - 1) / NB, tb = std::min(s->env.tail_begin, nn) / NB;
-        static const bool dense = getenv("OCHIP_CHOL_DENSE") != nullptr; // A/B knob: ignore the envelope (every tile stored)
+        constexpr bool dense = false; // (true: ignore the envelope, every tile stored - the round-2 storage)
         std::vector<chol_col> cols((size_t)std::max(nbc, 1));
         std::vector<int> kmin((size_t)std::max(nbr, 1), 0);
         int n_tiles = 0;
@@ -1386,16 +1386,14 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
         // (J + 1, J + 1), which then has no entry of its own - where both sum over the same range of columns: inside the
         // band, and among the tail's own columns (the first tail block's diagonal tile sums over the whole band, the tile
         // beside it does not).  Bit 31 marks the pair.
-        static const bool no_fuse = getenv("OCHIP_CHOL_NO_FUSE") != nullptr; // A/B knob
         std::vector<char> fused_diag((size_t)std::max(nbc, 1) + 1, 0);
-        if (!no_fuse)
-            for (int J = 0; J + 1 < nbc; J++)
-            {
-                const int I = J + 1;
-                const bool stored = I < cols[J].bend || I >= cols[J].tail_start;
-                if (stored && (I < tb || J >= tb))
-                    fused_diag[(size_t)I] = 1;
-            }
+        for (int J = 0; J + 1 < nbc; J++)
+        {
+            const int I = J + 1;
+            const bool stored = I < cols[J].bend || I >= cols[J].tail_start;
+            if (stored && (I < tb || J >= tb))
+                fused_diag[(size_t)I] = 1;
+        }
         auto push_tile = [&](int I, int J) {
             if (I == J && fused_diag[(size_t)I])
                 return;
@@ -1479,8 +1477,6 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
         s->chol_nbr = nbr;
         s->chol_tb = tb;
         s->chol_grid = std::max(1, std::min((int)order.size(), slots));
-        if (const char *e = getenv("OCHIP_CHOL_GRID")) // A/B knob: fewer workgroups walking the claim list
-            s->chol_grid = std::max(1, std::min(s->chol_grid, atoi(e)));
         s->chol_sync_bytes = (((size_t)n_tiles + 4) * 4 + 15) / 16 * 16;
         // tiles in storage order, and the matrices themselves
         std::vector<unsigned int> stored((size_t)std::max(n_tiles, 1), 0u);
@@ -1518,8 +1514,7 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
         s->chol_korder = nullptr;
         if (s->n_regions > 1)
         {
-            static const bool plain_order = getenv("OCHIP_CHOL_PLAIN_KORDER") != nullptr; // A/B knob
-            if (!plain_order && lm_dev_upload(ctx, s->allocs, &s->chol_korder, korder.data(), korder.size()) != OCHIP_OK)
+            if (lm_dev_upload(ctx, s->allocs, &s->chol_korder, korder.data(), korder.size()) != OCHIP_OK)
                 return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (factorisation plan)");
         }
         else
@@ -1720,54 +1715,11 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                     return ochip_fail(ctx, OCHIP_ENOMEM, "OCHIP_CHOL_VERIFY: device allocation failed");
                 OCHIP_HIP(ctx, hipMemcpyAsync(Wv, S.Wm, S.matrix_bytes(), hipMemcpyDeviceToDevice, st));
             }
-            // OCHIP_CHOL_TIMELINE=<file>: when each tile of the first large factorisation was claimed, had its operands summed,
-            // was factored / multiplied and was published (100 MHz ticks), one line per tile in claim order
-            static const bool unblocked_diag = getenv("OCHIP_CHOL_UNBLOCKED_DIAG") != nullptr; // A/B knob: rank-1 updates all the way
-            static const char *timeline_path = getenv("OCHIP_CHOL_TIMELINE");
-            static bool timeline_done = false;
-            unsigned long long *tl_dev = nullptr;
-            size_t tl_got = 0;
-            if (timeline_path && !timeline_done && n >= 1000)
-            {
-                tl_dev = (unsigned long long *)ochip_pool_get(ctx, (size_t)S.chol_n_tiles * 48, &tl_got);
-                if (tl_dev)
-                    OCHIP_HIP(ctx, hipMemsetAsync(tl_dev, 0, (size_t)S.chol_n_tiles * 48, st));
-            }
-            // operands through LDS in halves (71 KB per workgroup) unless OCHIP_CHOL_KC=64 (whole, 104 KB): measured equal
-            // alone (1 026 against 1 009 LM iterations/s at n = 3003) and better beside the extraction's kernels, whose
-            // workgroups leave 71 KB free on a compute unit sooner than 104 (208 against 193 in the pipeline)
-            static const bool kc32 = !(getenv("OCHIP_CHOL_KC") && atoi(getenv("OCHIP_CHOL_KC")) == 64); // A/B knob
-            if (kc32)
-                hipLaunchKernelGGL(chol_tiles_kernel<32>, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
-                                   (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_claims, S.chol_tb, S.chol_sync,
-                                   S.linv, S.fail_chol, tl_dev, (const int *)S.chol_korder, unblocked_diag ? 0 : 1);
-            else
-                hipLaunchKernelGGL(chol_tiles_kernel<64>, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
-                                   (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_claims, S.chol_tb, S.chol_sync,
-                                   S.linv, S.fail_chol, tl_dev, (const int *)S.chol_korder, unblocked_diag ? 0 : 1);
-            if (tl_dev)
-            {
-                timeline_done = true;
-                std::vector<unsigned long long> tl((size_t)S.chol_n_tiles * 6);
-                std::vector<unsigned int> order((size_t)S.chol_n_claims);
-                OCHIP_HIP(ctx, hipMemcpyAsync(tl.data(), tl_dev, tl.size() * 8, hipMemcpyDeviceToHost, st));
-                OCHIP_HIP(ctx, hipMemcpyAsync(order.data(), S.chol_tiles, order.size() * 4, hipMemcpyDeviceToHost, st));
-                OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
-                ochip_pool_put(ctx, tl_dev, tl_got);
-                unsigned long long t0 = ~0ull;
-                for (size_t i = 0; i < order.size(); i++)
-                    t0 = std::min(t0, tl[6 * i]);
-                if (FILE *f = fopen(timeline_path, "w"))
-                {
-                    fprintf(f, "# n=%d tiles=%d tb=%d grid=%d regions=%d; us since the first claim: claim I J claimed summed computed published, shader cycles summed -> computed\n", n,
-                            S.chol_n_tiles, S.chol_tb, S.chol_grid, S.n_regions);
-                    for (size_t i = 0; i < order.size(); i++)
-                        fprintf(f, "%zu %u %u%s %.2f %.2f %.2f %.2f %llu\n", i, order[i] & 0xFFFFu, (order[i] >> 16) & 0x7FFFu, (order[i] >> 31) ? "+" : "", (tl[6 * i] - t0) * 0.01,
-                                (tl[6 * i + 1] - t0) * 0.01, (tl[6 * i + 2] - t0) * 0.01, (tl[6 * i + 3] - t0) * 0.01,
-                                tl[6 * i + 5] - tl[6 * i + 4]);
-                    fclose(f);
-                }
-            }
+            // operands through LDS in halves (71 KB per workgroup; whole, 104 KB, measured equal alone and slower beside the
+            // extraction's kernels, whose workgroups leave 71 KB free on a compute unit sooner); blocked diagonal tiles
+            hipLaunchKernelGGL(chol_tiles_kernel<32>, dim3((unsigned)S.chol_grid), dim3(256), 0, st, S.Wm, n, (const chol_col *)S.chol_cols,
+                               (const int *)S.chol_kmin, (const unsigned int *)S.chol_tiles, S.chol_n_claims, S.chol_tb, S.chol_sync,
+                               S.linv, S.fail_chol, (unsigned long long *)nullptr, (const int *)S.chol_korder, 1);
             launch_chain(S.Wm, S.linv, false, true);
             if (verify)
             {
@@ -1804,7 +1756,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         {
             // (the per-region kernel also serves the single band, as one region: it is the faster walk - rows of a block
             // split over the wavefronts, x in LDS; OCHIP_BACK_SOLVE_SINGLE=1: the round-2 kernel)
-            static const bool single = getenv("OCHIP_BACK_SOLVE_SINGLE") != nullptr;
+            constexpr bool single = false; // (true: the round-2 single-workgroup kernel on a single band)
             static const bool x_global = getenv("OCHIP_BACK_SOLVE_X_GLOBAL") != nullptr; // test knob: x in HBM even when it fits LDS
             if (S.n_regions > 1 || (!single && S.region_dev))
                 hipLaunchKernelGGL(back_solve_regions_kernel, dim3((unsigned)S.n_regions), dim3(LM_TG), 0, st, S.matW(), n,
@@ -1823,7 +1775,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         // The candidate is evaluated right away (cost only): the step's own results - model cost change, step norms, the
         // factorisation's failure flag - come back with that evaluation's wait instead of a host round trip of their own.
         // An invalid step (rare) has then cost one evaluation whose result is ignored.
-        static const bool separate_waits = getenv("OCHIP_LM_SEPARATE_WAITS") != nullptr; // A/B knob: a wait per read-back
+        constexpr bool separate_waits = false; // (true: a wait per read-back, the round-2 schedule)
         volatile int &cfail = *reinterpret_cast<volatile int *>(S.box + lm_system::BOX_CFAIL);
         cfail = 0;
         double cand_eval = 0;

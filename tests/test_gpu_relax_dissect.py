@@ -42,14 +42,13 @@ def test_dissected_relax_equals_the_single_band(monkeypatch):
     assert err < 5e-3, err
 
 
-@pytest.mark.parametrize("knobs", [{}, {"OCHIP_CHOL_NO_FUSE": "1"}, {"OCHIP_CHOL_KC": "64"}, {"OCHIP_CHOL_UNBLOCKED_DIAG": "1"},
-                                   {"OCHIP_CHOL_PLAIN_KORDER": "1"}, {"OCHIP_RELAX_DISSECT_G": "64"}, {"OCHIP_RELAX_DISSECT": "0"}],
+@pytest.mark.parametrize("knobs", [{}, {"OCHIP_RELAX_DISSECT_G": "64"}, {"OCHIP_RELAX_DISSECT": "0"}],
                          ids=lambda k: "+".join("%s=%s" % kv for kv in k.items()) or "default")
 def test_tile_factorisation_equals_the_chain_under_the_dissection(knobs):
     """OCHIP_CHOL_VERIFY=1 factors every system of the solve both ways (one launch of tiles / the launch chain) and fails
     the relax when the forward solves differ by more than 1e-7 relative; the knobs are read once per process, so every
-    variant of the tile kernel (fused pairs or not, operands in halves or whole, blocked or rank-1 diagonal tile, the
-    tail's summation order, region size, one band) runs in a process of its own."""
+    ordering (default regions, small regions, one band) runs in a process of its own.  (The kernel's round-3 A/B variants -
+    unfused pairs, whole-tile operands, rank-1 diagonal tiles, plain summation order - lost and are gone.)"""
     env = dict(os.environ, OCHIP_CHOL_VERIFY="1", OCHIP_RELAX_VERBOSE="1", **knobs)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probe_relax_dissect.py"), "16x20x512", "1"], env=env,
                        capture_output=True, text=True, timeout=600)
@@ -74,13 +73,11 @@ def _probe(knobs):
 
 
 def test_back_substitution_variants_agree():
-    """The backward substitution with its part of x in LDS or in HBM (the fallback for systems that do not fit), and the
-    round-2 single-workgroup kernel beside the split-wavefront one on a single band: same LM trajectory."""
+    """The backward substitution with its part of x in LDS or in HBM (the fallback for systems that do not fit), dissected
+    and as one band: same LM trajectory."""
     base = _probe({})
     hbm = _probe({"OCHIP_BACK_SOLVE_X_GLOBAL": "1"})
     assert hbm[0] == base[0] and hbm[1] == base[1] and hbm[2] == base[2]        # same arithmetic: same bits
     band = _probe({"OCHIP_RELAX_DISSECT": "0"})
-    old = _probe({"OCHIP_RELAX_DISSECT": "0", "OCHIP_BACK_SOLVE_SINGLE": "1"})
-    assert band[0] == old[0] == base[0]
-    for other in (band, old):
-        assert abs(other[1] - base[1]) <= 1e-9 * abs(base[1]) and abs(other[2] - base[2]) <= 1e-9 * abs(base[2])
+    assert band[0] == base[0]
+    assert abs(band[1] - base[1]) <= 1e-9 * abs(base[1]) and abs(band[2] - base[2]) <= 1e-9 * abs(base[2])
