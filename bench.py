@@ -91,7 +91,7 @@ def committed_traffic_per_image():
     """HBM bytes per image of the extract sequence from the committed PMC pass (FETCH_SIZE x 2 + WRITE_SIZE per the guide's
     gfx950 correction, scripts/summarise_profile.py): (bytes, file) or (None, None).  The counters cannot be read from
     inside this process; the figure is a constant of the code version the file was taken with."""
-    for name in ("r03_e2e_pmc_hbm.json", "r02_e2e_pmc_hbm.json"):
+    for name in ("r04_e2e_pmc_hbm.json", "r03_e2e_pmc_hbm.json", "r02_e2e_pmc_hbm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return float(json.load(fh)["extract_hbm_bytes_per_image"]), "profiles/" + name
@@ -669,7 +669,7 @@ class StrongRunner:
         # One rank: two surveys in flight as in the weak mode (the next survey extracts beside this one's link tail).  With
         # several ranks the surveys stay one after the other: two surveys' collectives issued from two threads would have
         # to reach the communicator in the same order on every rank.
-        if self.proc.world == 1 and self.pipelined and os.environ.get("OCHIP_PIPELINE_SURVEYS", "2") != "1":
+        if self.proc.world == 1 and self.pipelined and os.environ.get("OCHIP_PIPELINE_SURVEYS", "2" if self.proc.cores >= 4 else "1") != "1":
             from concurrent.futures import ThreadPoolExecutor
 
             with ThreadPoolExecutor(2) as pool:
@@ -792,7 +792,9 @@ def weak_main(args, proc, cfg):
     # and relax runners of consecutive batches together (pipeline.cpp:543-560); here successive steps are successive surveys.
     # Every relax finishes inside the timed region (the last one is joined before the closing barrier).
     relax_overlap = overlap and os.environ.get("OCHIP_PIPELINE_RELAX_OVERLAP", "1") != "0"
-    surveys_in_flight = os.environ.get("OCHIP_PIPELINE_SURVEYS", "2") != "1"
+    # two surveys in flight need host threads for two surveys' host phases at once: with 2 CPUs per rank one in flight is
+    # faster (1 746 against 1 660 images/s), from 4 CPUs on two are (OCHIP_PIPELINE_SURVEYS overrides)
+    surveys_in_flight = os.environ.get("OCHIP_PIPELINE_SURVEYS", "2" if proc.cores // max(world, 1) >= 4 else "1") != "1"
     rctx = ctx.sibling(12) if relax_overlap else ctx      # (created here, before any runner thread asks for a sibling)
     if relax_overlap and os.environ.get("OCHIP_RELAX_PRIORITY", "1") != "0":
         rctx.set_priority(True)                            # the latency-bound solve goes ahead of the throughput kernels

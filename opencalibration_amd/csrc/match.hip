@@ -323,7 +323,8 @@ __global__ __launch_bounds__(BLOCK) void sym_merge_kernel(const sym_job *__restr
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr uint32_t MFMA_MAX_REFS = 8192;
-constexpr int MFMA_QUERIES = 256; // per workgroup: 4 waves x 64
+constexpr int MFMA_QT = 2;      // blocks of 32 queries per wavefront (2: 212 VGPRs, two waves per SIMD, 4.4e12 distances/s; 1: 167 VGPRs, three waves, 4.0e12)
+constexpr int MFMA_QUERIES = 4 * 32 * MFMA_QT; // per workgroup of four waves
 
 // bits -> FP4: one thread per byte of a descriptor (8 bits -> 8 nibbles of value 0b0010 = 1.0 or 0), a wave per feature
 __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint32_t *__restrict__ desc, uint64_t first, uint64_t n,
@@ -388,11 +389,12 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
     const uint64_t off1 = img_off[pr.image_1], off2 = img_off[pr.image_2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
     // queries of this wave: columns r of its two tiles; lane (r, h) holds the k range [64 s + 32 h, + 32) of step s
-    v8i Bq[2][8];
+    constexpr int QT = MFMA_QT;
+    v8i Bq[QT][8];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < QT; t++)
     {
-        uint32_t qi = q0 + wv * 64 + t * 32 + r;
+        uint32_t qi = q0 + wv * (32 * QT) + t * 32 + r;
         qi = qi < n1 ? qi : n1 - 1;
         const uint4 *src = fp4 + (off1 + qi) * 16;
 #pragma unroll
@@ -402,7 +404,10 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
             Bq[t][sidx] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
         }
     }
-    float best[2] = {-1.0f, -1.0f}, second[2] = {-1.0f, -1.0f};
+    float best[QT], second[QT];
+#pragma unroll
+    for (int t = 0; t < QT; t++)
+        best[t] = second[t] = -1.0f;
     const uint32_t n_tiles = (n2 + TR - 1) / TR;
     // staging: a tile's rows are consecutive features, 16 KB in one piece; thread tid moves its 16-byte pieces tid + 256 i.
     // Only the last tile can have rows beyond n2: they re-read the last feature and are disabled through tileC.
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
         // Four accumulator tiles at once - the tile's two row blocks x the wave's two query blocks -, so that a matrix
         // instruction's successor on the same accumulator comes three instructions later: with two chains the matrix pipe
         // ran at half its rate (a dependent v_mfma_scale waits for its predecessor's result, ~2 issue slots).
-        v16f acc[2][2];
+        v16f acc[2][QT];
 #pragma unroll
         for (int sub = 0; sub < 2; sub++)
         {
@@ -468,7 +473,9 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
                 acc[sub][0][4 * gidx + 2] = c4.z;
                 acc[sub][0][4 * gidx + 3] = c4.w;
             }
-            acc[sub][1] = acc[sub][0];
+#pragma unroll
+            for (int t = 1; t < QT; t++)
+                acc[sub][t] = acc[sub][0];
         }
         typedef int v4i __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -497,8 +504,9 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
                 {
                     const v8i A = v8i{a[sub][sidx].x, a[sub][sidx].y, a[sub][sidx].z, a[sub][sidx].w, 0, 0, 0, 0};
                     // FP4 both sides (cbsz = blgp = 4); block scales: 2^14 on the references (E8M0 141), 1 on the queries (127)
-                    acc[sub][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[0][4 * half + sidx], acc[sub][0], 4, 4, 0, 141, 0, 127);
-                    acc[sub][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[1][4 * half + sidx], acc[sub][1], 4, 4, 0, 141, 0, 127);
+#pragma unroll
+                    for (int t = 0; t < QT; t++)
+                        acc[sub][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, Bq[t][4 * half + sidx], acc[sub][t], 4, 4, 0, 141, 0, 127);
                 }
         }
 #pragma unroll
@@ -506,10 +514,12 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
 #pragma unroll
             for (int i = 0; i < 16; i++)
             {
-                second[0] = med3_f32(best[0], second[0], acc[sub][0][i]);
-                best[0] = max_f32(best[0], acc[sub][0][i]);
-                second[1] = med3_f32(best[1], second[1], acc[sub][1][i]);
-                best[1] = max_f32(best[1], acc[sub][1][i]);
+#pragma unroll
+                for (int t = 0; t < QT; t++)
+                {
+                    second[t] = med3_f32(best[t], second[t], acc[sub][t][i]);
+                    best[t] = max_f32(best[t], acc[sub][t][i]);
+                }
             }
         if (more)
             put_tile(cur ^ 1, nx, nc);
@@ -518,12 +528,12 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
     // the two half-waves hold the same queries' other 16 rows per tile
     ochip_match *__restrict__ o = out + out_off[pair];
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+    for (int t = 0; t < QT; t++)
     {
         const float ob = __shfl_xor(best[t], 32), os = __shfl_xor(second[t], 32);
         const float hi = fmaxf(best[t], ob), lo = fminf(best[t], ob), ms = fmaxf(second[t], os);
         const float b2 = fmaxf(lo, ms);
-        const uint32_t qi = q0 + wv * 64 + t * 32 + r;
+        const uint32_t qi = q0 + wv * (32 * QT) + t * 32 + r;
         if (h == 0 && qi < n1)
         {
             const uint32_t pq = pop[off1 + qi];
