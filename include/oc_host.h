@@ -172,6 +172,11 @@ extern "C"
                                const double *dist, size_t n_opt_edges, const uint64_t *opt_edges, double *plane_out,
                                double *summary_out);
     const char *och_relax_last_error(void);
+    /* Test hook.  on = 1: every ground-plane relax set-up from now on repeats gridFilterMatchesPerImage and the block
+     * assembly (relax_problem.cpp:234-309, :388-560) with the host code and fails unless the blocks the device built
+     * (ochip_plane_setup_*, include/ochip.h) equal them bit for bit; 0: off (default); < 0: unchanged.  Returns the
+     * number of set-ups compared so far. */
+    int och_debug_relax_setup_check(int on);
     /* Every node of a linked graph as one group, every edge whitelisted (the single-group global relax,
      * src/pipeline/pipeline.cpp:653-655).  ori_inout: n_nodes x 4 in node order. */
     int och_graph_relax_ground_plane(och_graph *g, ochip_ctx *ctx, double *ori_inout, double *plane_out,

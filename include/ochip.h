@@ -354,6 +354,45 @@ extern "C"
         double initial_cost, final_cost;
     } ochip_relax_summary;
 
+    /* ---- set-up of the ground-plane relax: gridFilterMatchesPerImage + the residual-block list -------------------
+     * Replaces, for the edges of one RelaxProblem::setupGroundPlaneProblem, src/relax/relax_problem.cpp:234-309 (score every
+     * inlier match, keep the best one per cell of each image's grid: GridFilter::addMeasurement,
+     * include/opencalibration/relax/grid_filter.hpp:33-51) and :388-560 with fixed intrinsics (a kept match whose rays'
+     * closest approach lies over the plane's border triangle becomes a residual block), one wavefront per edge. */
+    typedef struct ochip_plane_edge
+    {
+        uint32_t cam_a, cam_b;     /* rows of cam_pos / cam_q: the source and the destination image's pose */
+        uint32_t model_a, model_b; /* rows of models10 */
+        uint32_t n_inliers;
+        uint32_t flags;            /* bit 0: relationType == HOMOGRAPHY (H scores the match, :279-287) */
+        uint64_t inlier_offset;    /* first record of the edge in `inliers` */
+        double H[9];               /* camera_relations::ransac_relation, row-major */
+    } ochip_plane_edge;
+    typedef struct ochip_plane_inlier
+    {
+        double px1[2], px2[2];   /* feature_match_denormalized::pixel_1 / pixel_2 */
+        double descriptor_score; /* 1 - matches[match_index].distance (1 if the index is out of range), :273-275 */
+    } ochip_plane_inlier;
+    typedef struct ochip_plane_setup ochip_plane_setup;
+    /* Scores and filters.  cam_pos [n_cams][3], cam_q [n_cams][4] (x, y, z, w); models10 [n_models][10] = f, ppx, ppy,
+     * k1, k2, k3, p1, p2, pixels_cols, pixels_rows; triangle_xy6 = the border triangle's corners in the searcher's order
+     * (after its orientation fix-up, src/surface/intersect.cpp:56-163); grid_fraction = 0.15 (:66).
+     * keep_out[i] (n_inliers bytes): bit 0 = match i is on the source image's whitelist, bit 1 = on the destination's.
+     * inexact_out[e] != 0 (n_edges bytes): two matches of edge e share the best score of a cell (the reference's unstable
+     * std::sort decides, grid_filter.hpp:33-51) or a match lies outside the cell table - the caller computes that edge's
+     * flags itself and passes them to ochip_plane_setup_override.  The handle holds device blocks of `ctx`. */
+    int ochip_plane_setup_create(ochip_ctx *ctx, const ochip_plane_edge *edges, uint32_t n_edges, const ochip_plane_inlier *inliers,
+                                 uint64_t n_inliers, const double *cam_pos, const double *cam_q, uint32_t n_cams,
+                                 const double *models10, uint32_t n_models, const double *triangle_xy6, double grid_fraction,
+                                 uint8_t *keep_out, uint8_t *inexact_out, ochip_plane_setup **out);
+    int ochip_plane_setup_override(ochip_plane_setup *s, uint64_t first_inlier, uint64_t n, const uint8_t *keep);
+    /* The residual blocks in edge order, matches in index order: cameras (rows of cam_pos) and the two camera-frame unit
+     * rays (6 doubles) of each - the arrays ochip_relax_desc takes.  All three arrays NULL: only *n_blocks is returned; it
+     * is set even when capacity is too small (OCHIP_ENOMEM). */
+    int ochip_plane_setup_blocks(ochip_plane_setup *s, uint32_t *blk_cam_a, uint32_t *blk_cam_b, double *blk_rays, uint64_t capacity,
+                                 uint64_t *n_blocks);
+    void ochip_plane_setup_destroy(ochip_plane_setup *s);
+
     /* A problem (this one and the ochip_relaxg_ / ochip_relaxp_ ones below) holds device blocks and a page-locked host
        block of its context: destroy it before the context. */
     int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *desc, ochip_relax_problem **out);

@@ -38,6 +38,11 @@ const char *och_relax_last_error(void)
     return g_relax_error.c_str();
 }
 
+int och_debug_relax_setup_check(int on)
+{
+    return opencalibration_amd::relax_setup_check(on);
+}
+
 int och_relax_ground_plane(ochip_ctx *ctx, size_t n_nodes, const double *node_pos, const double *node_ori,
                            const double *model10, size_t n_poses, const uint64_t *pose_node, double *pose_ori,
                            size_t n_edges, const uint64_t *edge_src, const uint64_t *edge_dst, const double *edge_H,

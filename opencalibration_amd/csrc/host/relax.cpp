@@ -6,7 +6,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
+#include <memory>
 #include <unordered_map>
 
 namespace opencalibration_amd
@@ -15,6 +17,8 @@ namespace opencalibration_amd
 namespace
 {
 using namespace relax_detail;
+
+std::atomic<int> g_setup_check{0}, g_setup_checked{0};
 
 // One ground-plane problem: host assembly + device solve.
 class GroundPlaneProblem
@@ -69,47 +73,133 @@ class GroundPlaneProblem
                 n_filter = k;
         }
         lap("pose lookup");
-        std::vector<std::vector<uint8_t>> keep(edges_to_optimize.size());
-#pragma omp parallel for schedule(dynamic, 1)
+        // gridFilterMatchesPerImage (:234-309) and addRayTriangleMeasurementCost (:388-560, fixed intrinsics) on the
+        // device: ochip_plane_setup_* (csrc/relax_setup.hip).  The searcher's orientation fix-up of the single triangle
+        // happens on its first use and is the same for every edge.  Edges past the first one without poses get no
+        // filter pass, hence no whitelist and no blocks.
+        fix_triangle_orientation();
+        std::vector<ochip_plane_edge> pe;
+        std::vector<const MeasurementGraph::Edge *> pe_edge;
+        std::vector<pose_ref> pe_src, pe_dst;
+        std::unordered_map<const CameraModel *, uint32_t> model_index;
+        std::vector<double> models10;
+        auto model_of = [&](const CameraModel *m) {
+            auto it = model_index.find(m);
+            if (it != model_index.end())
+                return it->second;
+            const double row[10] = {m->focal_length_pixels,   m->principle_point[0],   m->principle_point[1],      m->radial_distortion[0],
+                                    m->radial_distortion[1],  m->radial_distortion[2], m->tangential_distortion[0], m->tangential_distortion[1],
+                                    (double)m->pixels_cols,   (double)m->pixels_rows};
+            models10.insert(models10.end(), row, row + 10);
+            return model_index.emplace(m, (uint32_t)model_index.size()).first->second;
+        };
+        uint64_t n_inliers = 0;
         for (size_t k = 0; k < n_filter; k++)
         {
             const MeasurementGraph::Edge *e = _graph.getEdge(edges_to_optimize[k]);
-            if (e != nullptr)
-                keep[k] = grid_filter(_graph, *e, src[k], dst[k], 0.15);
-        }
-
-        // addRayTriangleMeasurementCost (:388-560), fixed intrinsics.  The searcher's orientation fix-up of
-        // the single triangle happens on its first use and is the same for every edge, so do it once and
-        // build the per-edge block lists in parallel; they are concatenated in edge order.
-        lap("grid filter");
-        fix_triangle_orientation();
-        std::vector<edge_blocks> per_edge(edges_to_optimize.size());
-#pragma omp parallel for schedule(dynamic, 8)
-        for (size_t k = 0; k < edges_to_optimize.size(); k++)
-        {
-            const MeasurementGraph::Edge *e = _graph.getEdge(edges_to_optimize[k]);
-            if (e == nullptr || src[k].loc == nullptr || dst[k].loc == nullptr)
+            if (e == nullptr)
                 continue;
-            add_edge_blocks(*e, src[k], dst[k], keep[k], per_edge[k]);
+            const camera_relations &rel = e->payload;
+            ochip_plane_edge r{};
+            r.cam_a = src[k].cam;
+            r.cam_b = dst[k].cam;
+            r.model_a = model_of(_graph.getNode(e->source)->payload.model.get());
+            r.model_b = model_of(_graph.getNode(e->dest)->payload.model.get());
+            r.n_inliers = (uint32_t)rel.inlier_matches.size();
+            r.flags = rel.relationType == camera_relations::RelationType::HOMOGRAPHY ? 1u : 0u;
+            r.inlier_offset = n_inliers;
+            std::memcpy(r.H, rel.ransac_relation, sizeof r.H);
+            n_inliers += r.n_inliers;
+            pe.push_back(r);
+            pe_edge.push_back(e);
+            pe_src.push_back(src[k]);
+            pe_dst.push_back(dst[k]);
         }
-        lap("edge blocks");
-        size_t total_blocks = 0;
-        for (const auto &pe : per_edge)
-            total_blocks += pe.a.size();
-        // concatenated in edge order (offsets first, then a parallel copy)
-        std::vector<size_t> first_block(per_edge.size() + 1, 0);
-        for (size_t k = 0; k < per_edge.size(); k++)
-            first_block[k + 1] = first_block[k] + per_edge[k].a.size();
+        // page-locked staging from the context's pool: no first-touch faults on ~40 bytes x every inlier of the survey,
+        // and the upload runs at the link rate
+        struct staging
+        {
+            ochip_ctx *ctx;
+            void *p = nullptr;
+            ~staging()
+            {
+                if (p)
+                    ochip_host_free(ctx, p);
+            }
+            ochip_plane_inlier *get() const
+            {
+                return static_cast<ochip_plane_inlier *>(p);
+            }
+        } inl{_ctx};
+        if (ochip_host_alloc(_ctx, (n_inliers ? n_inliers : 1) * sizeof(ochip_plane_inlier), &inl.p) != OCHIP_OK)
+            return fail(error, "ochip_host_alloc");
+#pragma omp parallel for schedule(dynamic, 16)
+        for (size_t j = 0; j < pe.size(); j++)
+        {
+            const camera_relations &rel = pe_edge[j]->payload;
+            ochip_plane_inlier *o = inl.get() + pe[j].inlier_offset;
+            for (size_t idx = 0; idx < rel.inlier_matches.size(); idx++)
+            {
+                const feature_match_denormalized &m = rel.inlier_matches[idx];
+                o[idx].px1[0] = m.pixel_1[0], o[idx].px1[1] = m.pixel_1[1];
+                o[idx].px2[0] = m.pixel_2[0], o[idx].px2[1] = m.pixel_2[1];
+                o[idx].descriptor_score = m.match_index < rel.matches.size() ? 1.0 - rel.matches[m.match_index].distance : 1.0;
+            }
+        }
+        lap("gather inliers");
+        double tri[6];
+        for (int i = 0; i < 3; i++)
+        {
+            tri[2 * i] = _xy[_tri[i]][0];
+            tri[2 * i + 1] = _xy[_tri[i]][1];
+        }
+        std::vector<uint8_t> keep(n_inliers), inexact(pe.size());
+        ochip_plane_setup *ps = nullptr;
+        if (ochip_plane_setup_create(_ctx, pe.data(), (uint32_t)pe.size(), inl.get(), n_inliers, _cam_pos.data(), _cam_q.data(),
+                                     (uint32_t)_cam_opt.size(), models10.data(), (uint32_t)model_index.size(), tri, 0.15, keep.data(),
+                                     inexact.data(), &ps) != OCHIP_OK)
+            return fail(error, "ochip_plane_setup_create");
+        struct drop
+        {
+            ochip_plane_setup *p;
+            ~drop()
+            {
+                ochip_plane_setup_destroy(p);
+            }
+        } drop_ps{ps};
+        lap("grid filter (device)");
+        // edges whose filter depends on the order std::sort leaves equal scores in: the host walk decides
+        for (size_t j = 0; j < pe.size(); j++)
+            if (inexact[j])
+            {
+                const std::vector<uint8_t> k8 = grid_filter(_graph, *pe_edge[j], pe_src[j], pe_dst[j], 0.15);
+                std::copy(k8.begin(), k8.end(), keep.begin() + pe[j].inlier_offset);
+                if (ochip_plane_setup_override(ps, pe[j].inlier_offset, k8.size(), k8.data()) != OCHIP_OK)
+                    return fail(error, "ochip_plane_setup_override");
+            }
+        uint64_t total_blocks = 0;
+        if (ochip_plane_setup_blocks(ps, nullptr, nullptr, nullptr, 0, &total_blocks) != OCHIP_OK)
+            return fail(error, "ochip_plane_setup_blocks");
         _blk_a.resize(total_blocks);
         _blk_b.resize(total_blocks);
         _blk_rays.resize(total_blocks * 6);
-#pragma omp parallel for schedule(static)
-        for (size_t k = 0; k < per_edge.size(); k++)
+        if (ochip_plane_setup_blocks(ps, _blk_a.data(), _blk_b.data(), _blk_rays.data(), total_blocks, &total_blocks) != OCHIP_OK)
+            return fail(error, "ochip_plane_setup_blocks");
+        lap("edge blocks (device)");
+        if (g_setup_check.load())
         {
-            const auto &pe = per_edge[k];
-            std::copy(pe.a.begin(), pe.a.end(), _blk_a.begin() + first_block[k]);
-            std::copy(pe.b.begin(), pe.b.end(), _blk_b.begin() + first_block[k]);
-            std::copy(pe.rays.begin(), pe.rays.end(), _blk_rays.begin() + 6 * first_block[k]);
+            // the same two passes with the host code (relax_util.hpp), compared bit for bit
+            edge_blocks all;
+            for (size_t j = 0; j < pe.size(); j++)
+                add_edge_blocks(*pe_edge[j], pe_src[j], pe_dst[j], grid_filter(_graph, *pe_edge[j], pe_src[j], pe_dst[j], 0.15), all);
+            if (all.a != _blk_a || all.b != _blk_b || all.rays.size() != _blk_rays.size() ||
+                std::memcmp(all.rays.data(), _blk_rays.data(), all.rays.size() * sizeof(double)) != 0)
+            {
+                *error = "relax set-up: the device's residual blocks differ from the host's (" + std::to_string(_blk_a.size()) + " vs " +
+                         std::to_string(all.a.size()) + ")";
+                return false;
+            }
+            g_setup_checked.fetch_add(1);
         }
         // addDownwardsPrior (:1290-1301)
         for (size_t i = 0; i < poses.size(); i++)
@@ -350,6 +440,13 @@ class GroundPlaneProblem
 };
 
 } // namespace
+
+int relax_setup_check(int on)
+{
+    if (on >= 0)
+        g_setup_check.store(on);
+    return g_setup_checked.load();
+}
 
 bool relax_ground_plane(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,
                         const std::vector<size_t> &edges_to_optimize, surface_model_plane *surface,

@@ -49,4 +49,9 @@ bool relax_ground_plane(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
                         const std::vector<size_t> &edges_to_optimize, surface_model_plane *surface,
                         RelaxTimers *timers, std::string *error, const RelaxShard *shard = nullptr);
 
+// Test hook: on = 1 makes every ground-plane set-up repeat the grid filter and the block assembly with the host code
+// (relax_util.hpp) and fail unless the device's blocks equal them bit for bit; on < 0 leaves the switch alone.  Returns
+// the number of set-ups compared so far.
+int relax_setup_check(int on);
+
 } // namespace opencalibration_amd

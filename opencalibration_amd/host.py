@@ -98,6 +98,7 @@ def load():
         L.och_relax_ground_plane.argtypes = [vp, sz, _f64p, _f64p, _f64p, sz, _u64p, _f64p, sz, _u64p, _u64p, _f64p, u8p,
                                              _u64p, _f64p, _u64p, vp, vp, sz, _u64p, _f64p, _f64p]
         L.och_relax_last_error.restype = C.c_char_p
+        L.och_debug_relax_setup_check.argtypes = [C.c_int]
         L.och_graph_relax_ground_plane.argtypes = [vp, vp, _f64p, _f64p, _f64p]
         L.och_graph_relax_ground_plane_sharded.argtypes = [vp, vp, _f64p, _f64p, _f64p, u32, u32, vp, vp]
         L.och_surface_create.restype = vp
@@ -456,6 +457,12 @@ def relax(ctx, node_pos, node_ori, model10, features, pose_node, pose_ori, packe
               "mesh_vertices", "unknowns"):
         out[k] = int(out[k])
     return out
+
+
+def relax_setup_check(on=-1):
+    """Test hook (och_debug_relax_setup_check): on=1 makes every ground-plane relax set-up also run the host's grid filter
+    and block assembly and fail unless the device's blocks equal them bit for bit.  Returns the set-ups compared so far."""
+    return int(load().och_debug_relax_setup_check(int(on)))
 
 
 def relax_ground_plane(ctx, node_pos, node_ori, model10, pose_node, pose_ori, packed_edges, opt_edges=None):
