@@ -51,7 +51,8 @@ struct relax_dev
     int32_t *cam_t;   // tangent offset or -1
     double z[2][3];   // unused on device (kept on host)
     // plane
-    double *plane;    // [0..5] xy of 3 corners, [6..8] z current, [9..11] z candidate
+    double *plane;    // [0..5] xy of 3 corners, [6..8] and [9..11]: the heights of the current and the candidate state
+    int zcur;         // where the current state's heights start (6 or 9); the candidate's start at 15 - zcur
     int32_t *z_t;     // [3]
     // blocks sorted by pair
     uint32_t n_blocks, n_pairs, n_prior;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(W) void relax_pair_eval_kernel(relax_dev P, int whi
     const uint32_t b0 = P.pair_off[pair], b1 = P.pair_off[pair + 1];
     const uint32_t p = P.pair_p[pair];
     const double *Q = which_state ? P.cam_q2 : P.cam_q;
-    const double *Z = P.plane + (which_state ? 9 : 6);
+    const double *Z = P.plane + (which_state ? 15 - P.zcur : P.zcur);
     const double a2 = P.huber_a * P.huber_a;
 
     // this lane's entry of the pair's 9 x 9 block (upper triangle, tri(i, j)) or of its gradient (45 + i)
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(W) void relax_pair_eval_kernel(relax_dev P, int whi
     }
     double entry = 0;
     double cost = 0;
-    bool failed = false;
+    bool failed = false, failed_jac = false; // a residual / a derivative that is not finite
 
     for (uint32_t first = b0; first < b1; first += W)
     {
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(W) void relax_pair_eval_kernel(relax_dev P, int whi
                             const double v = rd[k].v[cidx] * sqrt_rho1;
                             mine[k * 9 + col0 + cidx] = v;
                             if (!(v - v == 0.0))
-                                failed = true;
+                                failed_jac = true;
                         }
                 };
                 seed_quat(qa, seeded);
@@ -491,8 +492,9 @@ __global__ __launch_bounds__(W) void relax_pair_eval_kernel(relax_dev P, int whi
     // fixed shuffle tree: bitwise reproducible
     for (int off = 32; off >= 1; off >>= 1)
         cost += __shfl_xor(cost, off);
-    if (__ballot(failed) && lane == 0)
-        atomicOr(P.fail, 1);
+    const int fail_bits = (__ballot(failed) ? 1 : 0) | (__ballot(failed_jac) ? 2 : 0);
+    if (fail_bits && lane == 0)
+        atomicOr(P.fail, fail_bits);
     if (lane == 0)
         P.pair_cost[pair] = cost;
     if (WITH_JAC)
@@ -629,7 +631,8 @@ constexpr int REDUCE_GROUPS = 32;
 __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm_matrix A, double *g, int n,
                                                                  const uint8_t *cam_has_prior, double *scal,
                                                                  int with_jac, int which_state, double *partials /*[groups][10]*/,
-                                                                 unsigned int *arrived)
+                                                                 unsigned int *arrived, lm_mail mail, const double *diag_scale,
+                                                                 double *diagonal)
 {
     __shared__ int s_last;
     const int t = threadIdx.x, b = blockIdx.x, groups = gridDim.x;
@@ -716,6 +719,23 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
                     g[P.z_t[i]] = total[6 + i];
         }
     }
+    if (diag_scale) // (uniform) what lm_diag_kernel would do behind this kernel: max |g| and the damping's clamped diagonal
+    {
+        __shared__ double shd[256];
+        __threadfence(); // thread 0's entries of A and g, for the other wavefronts of this workgroup
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const double gmax = lm_diag_pass<256>(A, g, nullptr, n, diag_scale, diagonal, shd);
+        if (t == 0)
+            scal[4] = gmax;
+    }
+    if (t == 0)
+    {
+        // the evaluation's results go to the host block from here (no copies behind this kernel), and this rank's
+        // failure flag is clear again for the next evaluation (no memset in front of it)
+        lm_mail_post(mail);
+        *P.fail = 0;
+    }
 }
 
 // step = -y with (As + D) y = gs; delta = S step; candidate state = x (+) delta; step_norm^2 in ambient space.
@@ -765,9 +785,9 @@ __global__ __launch_bounds__(LM_TG) void plane_candidate_kernel(relax_dev P, con
     if (t < 3)
     {
         const int tz = P.z_t[t];
-        const double z0 = P.plane[6 + t];
+        const double z0 = P.plane[P.zcur + t];
         const double z1 = tz >= 0 ? z0 + alpha * (-y[tz] * scale[tz]) : z0;
-        P.plane[9 + t] = z1;
+        P.plane[15 - P.zcur + t] = z1;
         if (tz >= 0)
         {
             sn += (z0 - z1) * (z0 - z1);
@@ -797,7 +817,7 @@ __global__ void lm_accept_kernel(relax_dev P)
     if (i < P.n_cams * 4)
         P.cam_q[i] = P.cam_q2[i];
     if (i < 3)
-        P.plane[6 + i] = P.plane[9 + i];
+        P.plane[P.zcur + i] = P.plane[15 - P.zcur + i];
 }
 
 // p.second->orientation.normalize() for every node of _nodes_to_optimize (relax_problem.cpp:1410-1413)
@@ -1090,6 +1110,7 @@ int assign_tangent(ochip_relax_problem *p)
         return ochip_fail(p->ctx, OCHIP_EHIP, "hipMemcpy failed (tangent map)");
     p->sys.ctx = p->ctx;
     p->sys.allocs = &p->allocs;
+    p->sys.speculative = true; // (the candidate is evaluated with its Jacobian: plane_model::evaluate_candidate_jac)
     const int rrc = lm_system_resize(&p->sys, t, env);
     if (rrc != OCHIP_OK)
         return rrc;
@@ -1238,6 +1259,7 @@ int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *d, ochip_
     chk(dev_upload(p, &D.cam_q2, d->cam_q, (size_t)d->n_cams * 4));
     chk(dev_upload<int32_t>(p, &D.cam_t, nullptr, d->n_cams));
     chk(dev_upload(p, &D.plane, plane, 12));
+    D.zcur = 6;
     chk(dev_upload<int32_t>(p, &D.z_t, nullptr, 3));
     chk(dev_upload(p, &D.blk_a, blk_a.data(), blk_a.size()));
     chk(dev_upload(p, &D.blk_b, blk_b.data(), blk_b.size()));
@@ -1253,6 +1275,8 @@ int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *d, ochip_
     chk(dev_upload<double>(p, &D.pair_acc, nullptr, (size_t)n_pairs * ACC));
     chk(dev_upload<double>(p, &D.pair_cost, nullptr, n_pairs));
     chk(dev_upload<int32_t>(p, &p->fail_ranks, nullptr, 1));
+    if (rc == OCHIP_OK && hipMemsetAsync(p->fail_ranks, 0, 4, ctx->stream) != hipSuccess) // (evaluations expect it clear and leave it clear)
+        rc = ochip_fail(ctx, OCHIP_EHIP, "hipMemsetAsync failed in relax problem");
     D.fail = p->fail_ranks;
     D.pair_lo = 0;
     p->pair_hi = n_pairs;
@@ -1334,7 +1358,7 @@ int ochip_relax_get_state(ochip_relax_problem *p, double *cam_q, double *plane_z
     if (cam_q)
         OCHIP_HIP(ctx, hipMemcpy(cam_q, p->dev.cam_q, (size_t)p->n_cams * 32, hipMemcpyDeviceToHost));
     if (plane_z)
-        OCHIP_HIP(ctx, hipMemcpy(plane_z, p->dev.plane + 6, 24, hipMemcpyDeviceToHost));
+        OCHIP_HIP(ctx, hipMemcpy(plane_z, p->dev.plane + p->dev.zcur, 24, hipMemcpyDeviceToHost));
     return OCHIP_OK;
 }
 
@@ -1352,11 +1376,42 @@ struct plane_model final : lm_model
     }
     int evaluate(bool with_jac, int which, double *cost) override
     {
+        int mask = 0;
+        const int rc = run(p->dev, with_jac, which, false, nullptr, cost, &mask);
+        return rc < 0 ? rc : (mask ? 1 : 0);
+    }
+    // The candidate as the current state of a view of the problem (state buffers exchanged), evaluated with its Jacobian
+    // into the system's second set; accept_swap() makes the view the problem.
+    relax_dev candidate_view() const
+    {
+        relax_dev V = p->dev;
+        std::swap(V.cam_q, V.cam_q2);
+        V.zcur = 15 - V.zcur;
+        return V;
+    }
+    bool speculates() override
+    {
+        return mails_results() && p->sys.A2 != nullptr;
+    }
+    int evaluate_candidate_jac(const double *scale, double *cost, int *fail_mask) override
+    {
+        return run(candidate_view(), true, 0, true, scale, cost, fail_mask);
+    }
+    void accept_swap() override
+    {
+        p->dev = candidate_view();
+    }
+    // one evaluation of state `which` of D: pair records (sharded + exchanged when ochip_relax_set_shard is in effect),
+    // deterministic assembly into the system's first or second set, results mailed to the host block
+    int run(const relax_dev &D, bool with_jac, int which, bool second_set, const double *diag_scale, double *cost, int *fail_mask)
+    {
         ochip_ctx *ctx = p->ctx;
         hipStream_t st = ctx->stream;
-        relax_dev &D = p->dev;
         const int n = p->n_tangent;
-        OCHIP_HIP(ctx, hipMemsetAsync(D.fail, 0, 4, st));
+        const lm_matrix Am = second_set ? p->sys.matA2() : p->sys.matA();
+        double *const gv = second_set ? p->sys.g2 : p->sys.g;
+        bool &clean = second_set ? p->sys.A2_clean : p->sys.A_clean;
+        // (D.fail is zero here: cleared at creation and by the reduction that ended the evaluation before this one)
         hipEvent_t e0, e1;
         ochip_prof_begin(ctx, OCHIP_K_RELAX_EVAL, &e0, &e1);
         const uint32_t my_pairs = p->pair_hi > D.pair_lo ? p->pair_hi - D.pair_lo : 0;
@@ -1368,7 +1423,7 @@ struct plane_model final : lm_model
                 hipLaunchKernelGGL(relax_pair_eval_kernel<false>, dim3(my_pairs), dim3(W), 0, st, D, which);
         }
         ochip_prof_end(ctx, OCHIP_K_RELAX_EVAL, e0, e1);
-        (with_jac ? ctx->relax_blocks_jac : ctx->relax_blocks_cost) += my_pairs;
+        (with_jac ? ctx->relax_blocks_jac : ctx->relax_blocks_cost) += D.n_blocks ? (uint64_t)D.n_blocks * my_pairs / std::max(D.n_pairs, 1u) : 0;
         if (p->exchange)
         {
             // the ranks' pair records (and failure flags) are all-gathered in place; from here on every rank holds
@@ -1385,11 +1440,17 @@ struct plane_model final : lm_model
         }
         if (with_jac)
         {
-            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, p->sys.matrix_bytes(), st));
+            // the entries of A that the scatter and the reduction write are the same from one evaluation to the next (fixed
+            // by the layout), and nothing else writes A: the rest is cleared once per layout, not once per Jacobian (23 MB)
+            if (!clean)
+            {
+                OCHIP_HIP(ctx, hipMemsetAsync(Am.tiles, 0, p->sys.matrix_bytes(), st));
+                clean = true;
+            }
             // (J'r needs no clearing: every unknown belongs to an active camera or a free plane height, whose owners write it)
             const uint32_t cam_blocks = (D.n_cams + 3) / 4, pair_blocks = (D.n_pairs + 255) / 256;
-            hipLaunchKernelGGL(relax_scatter_kernel, dim3(cam_blocks + pair_blocks), dim3(256), 0, st, D, p->sys.matA(), p->sys.g, n,
-                               p->cam_has_prior, cam_blocks);
+            hipLaunchKernelGGL(relax_scatter_kernel, dim3(cam_blocks + pair_blocks), dim3(256), 0, st, D, Am, gv, n, p->cam_has_prior,
+                               cam_blocks);
         }
         if (!p->reduce_partials)
         {
@@ -1399,8 +1460,13 @@ struct plane_model final : lm_model
             p->reduce_arrived = reinterpret_cast<unsigned int *>(p->reduce_partials + (size_t)REDUCE_GROUPS * 10);
             OCHIP_HIP(ctx, hipMemsetAsync(p->reduce_arrived, 0, 8, st));
         }
-        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(REDUCE_GROUPS), dim3(256), 0, st, D, p->sys.matA(), p->sys.g, n,
-                           p->cam_has_prior, p->sys.scal, with_jac ? 1 : 0, which, p->reduce_partials, p->reduce_arrived);
+        const bool mailed = mails_results();
+        lm_mail mail{};
+        if (mailed)
+            mail = lm_mail{p->sys.box, p->sys.scal, p->sys.fail_chol, p->fail_ranks, (int)p->shard_world, 1};
+        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(REDUCE_GROUPS), dim3(256), 0, st, D, Am, gv, n, p->cam_has_prior, p->sys.scal,
+                           with_jac ? 1 : 0, which, p->reduce_partials, p->reduce_arrived, mail, diag_scale,
+                           second_set ? p->sys.diagonal2 : p->sys.diagonal);
         OCHIP_HIP(ctx, hipGetLastError());
         // (read-backs into the system's page-locked block: a copy to pageable memory would make the host wait for it)
         std::vector<int32_t> hfails_pageable;
@@ -1411,8 +1477,11 @@ struct plane_model final : lm_model
             hfails_pageable.assign(p->shard_world, 0);
             hfails = hfails_pageable.data();
         }
-        OCHIP_HIP(ctx, hipMemcpyAsync(h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(hfails, p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
+        if (!mailed)
+        {
+            OCHIP_HIP(ctx, hipMemcpyAsync(h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
+            OCHIP_HIP(ctx, hipMemcpyAsync(hfails, p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
+        }
         if (before_wait)
             before_wait();
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
@@ -1420,7 +1489,12 @@ struct plane_model final : lm_model
         int hfail = 0;
         for (int r = 0; r < (int)p->shard_world; r++)
             hfail |= hfails[r];
-        return hfail ? 1 : 0;
+        *fail_mask = hfail;
+        return OCHIP_OK;
+    }
+    bool mails_results() override
+    {
+        return p->shard_world <= (uint32_t)(2 * (lm_system::BOX_VECTORS - lm_system::BOX_FAILS)) && p->sys.box != nullptr;
     }
     void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override
     {
@@ -1442,7 +1516,7 @@ struct plane_model final : lm_model
         std::vector<double> q((size_t)p->n_cams * 4);
         double z[3], x_norm = 0;
         OCHIP_HIP(ctx, hipMemcpy(q.data(), p->dev.cam_q, q.size() * 8, hipMemcpyDeviceToHost));
-        OCHIP_HIP(ctx, hipMemcpy(z, p->dev.plane + 6, 24, hipMemcpyDeviceToHost));
+        OCHIP_HIP(ctx, hipMemcpy(z, p->dev.plane + p->dev.zcur, 24, hipMemcpyDeviceToHost));
         for (uint32_t c = 0; c < p->n_cams; c++)
             if (p->cam_t[c] >= 0)
                 for (int k = 0; k < 4; k++)

@@ -24,9 +24,11 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // Wm = S A S + diag(D) tile by tile (one workgroup per stored tile), row n = gs = S g; the part of a diagonal tile above
 // the diagonal and everything beyond the system's last row / column is written as zero
+// The damping: D_ii^2 = diagonal[i] / radius as LevenbergMarquardtStrategy forms it (sqrt, then squared by the solver),
+// computed here from the device's copy of the clamped diagonal and kept in lm_diag for the model cost change.
 __global__ __launch_bounds__(256) void lm_build_kernel(lm_matrix A, const unsigned int *__restrict__ tile_ij, const double *g,
-                                                       const double *scale, const double *lm_diag, lm_matrix W, double *gs, int n,
-                                                       unsigned int *chol_sync, int *fail_chol)
+                                                       const double *scale, const double *diagonal, double radius, double *lm_diag,
+                                                       lm_matrix W, double *gs, int n, unsigned int *chol_sync, int *fail_chol)
 {
     // (the factorisation's claim counter, its per-tile flags and the failure flag start at zero: cleared here, one launch
     // instead of three in front of every factorisation)
@@ -56,7 +58,9 @@ __global__ __launch_bounds__(256) void lm_build_kernel(lm_matrix A, const unsign
                     v = a[e] * scale[i] * scale[j];
                     if (i == j)
                     {
-                        v += lm_diag[i];
+                        const double dd = sqrt(diagonal[i] / radius), lm = dd * dd;
+                        lm_diag[i] = lm;
+                        v += lm;
                         gs[i] = g[i] * scale[i];
                     }
                 }
@@ -1124,28 +1128,19 @@ __global__ __launch_bounds__(LM_TG) void lm_model_change_kernel(const double *lm
         scal[1] = 0.5 * sh[0];
 }
 
-// diag(A) and max|g| -> scal[4] = max|g|; diag_out[i] = A_ii
-__global__ __launch_bounds__(LM_TG) void lm_diag_kernel(lm_matrix A, const double *g, double *diag_out, int n,
-                                                       double *scal)
+// diag(A) and max|g| -> scal[4] = max|g|; diag_out[i] = A_ii; scale != nullptr: diagonal[i] = clamp(A_ii scale_i^2, 1e-6, 1e32),
+// what the iterations after an accepted step damp with (std::min / std::max's comparisons, NaN passes through); the
+// results then go to the host block (mail.box != nullptr)
+__global__ __launch_bounds__(LM_TG) void lm_diag_kernel(lm_matrix A, const double *g, double *diag_out, int n, double *scal,
+                                                       const double *scale, double *diagonal, lm_mail mail)
 {
     __shared__ double sh[LM_TG];
-    const int t = threadIdx.x;
-    double m = 0;
-    for (int i = t; i < n; i += LM_TG)
+    const double gmax = lm_diag_pass<LM_TG>(A, g, diag_out, n, scale, diagonal, sh);
+    if (threadIdx.x == 0)
     {
-        diag_out[i] = A.tiles[lm_at(A, i, i)];
-        m = fmax(m, fabs(g[i]));
+        scal[4] = gmax;
+        lm_mail_post(mail);
     }
-    sh[t] = m;
-    __syncthreads();
-    for (int s = LM_TG / 2; s > 0; s >>= 1)
-    {
-        if (t < s)
-            sh[t] = fmax(sh[t], sh[t + s]);
-        __syncthreads();
-    }
-    if (t == 0)
-        scal[4] = sh[0];
 }
 
 
@@ -1305,6 +1300,7 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
     ochip_ctx *ctx = s->ctx;
     s->env = env;
     s->n = n_in;
+    s->A_clean = false; // (new layout, possibly new blocks)
     {
         const size_t need = (size_t)lm_system::BOX_VECTORS + 2 * (size_t)std::max(n_in, 1);
         if (need > s->box_cap)
@@ -1333,10 +1329,19 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
             lm_dev_upload<double>(ctx, s->allocs, &s->scale, nullptr, n) != OCHIP_OK ||
             lm_dev_upload<double>(ctx, s->allocs, &s->lm_diag, nullptr, n) != OCHIP_OK ||
             lm_dev_upload<double>(ctx, s->allocs, &s->diag_tmp, nullptr, n) != OCHIP_OK ||
+            lm_dev_upload<double>(ctx, s->allocs, &s->diagonal, nullptr, n) != OCHIP_OK ||
             lm_dev_upload<double>(ctx, s->allocs, &s->y, nullptr, n) != OCHIP_OK)
             return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the vectors of %zu unknowns failed", n);
         s->cap_n = n;
     }
+    if (s->speculative && n > s->cap_n2)
+    {
+        if (lm_dev_upload<double>(ctx, s->allocs, &s->g2, nullptr, n) != OCHIP_OK ||
+            lm_dev_upload<double>(ctx, s->allocs, &s->diagonal2, nullptr, n) != OCHIP_OK)
+            return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the second set of vectors of %zu unknowns failed", n);
+        s->cap_n2 = n;
+    }
+    s->A2_clean = false;
     if (!s->scal && lm_dev_upload<double>(ctx, s->allocs, &s->scal, nullptr, 8) != OCHIP_OK)
         return OCHIP_ENOMEM;
     if (!s->fail_chol && lm_dev_upload<int>(ctx, s->allocs, &s->fail_chol, nullptr, 1) != OCHIP_OK)
@@ -1496,6 +1501,12 @@ int lm_system_resize(lm_system *s, int n_in, const lm_envelope &env)
                 return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the reduced system failed (%d tiles of 32 KB, twice)", n_tiles);
             s->cap_tiles = (size_t)n_tiles;
         }
+        if (s->speculative && (size_t)n_tiles > s->cap_tiles2)
+        {
+            if (lm_dev_upload<double>(ctx, s->allocs, &s->A2, nullptr, (size_t)std::max(n_tiles, 1) * NB * NB) != OCHIP_OK)
+                return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation for the candidate's reduced system failed (%d tiles of 32 KB)", n_tiles);
+            s->cap_tiles2 = (size_t)n_tiles;
+        }
         s->cols_host = cols;
         if ((uint64_t)nn >= ctx->relax_system_unknowns) // what the bench line reports as the relax's system memory
         {
@@ -1576,9 +1587,12 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
     double *const h = S.box + lm_system::BOX_SCAL; // (page-locked: relax_lm.hpp, lm_system::box)
     const bool eliminated = M.has_eliminated();
     M.begin_solve();
-    auto grad_and_diag = [&](double *gmax) -> int {
-        hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(LM_TG), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal);
-        OCHIP_HIP(ctx, hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st));
+    // the solver's own mail: scal[0, 8) (and the factorisation's flag) into the host block by the kernel that ends a phase
+    const lm_mail mail{S.box, S.scal, S.fail_chol, nullptr, 0, 0};
+    auto grad_and_diag = [&](double *gmax, bool refresh) -> int {
+        hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(LM_TG), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal,
+                           refresh ? (const double *)S.scale : (const double *)nullptr, S.diagonal, mail);
+        OCHIP_HIP(ctx, hipGetLastError());
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
         *gmax = h[4];
         if (eliminated)
@@ -1596,8 +1610,8 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         return ochip_stream_wait(ctx, st);
     };
 
-    std::vector<double> scale(n, 1.0), diagonal(n, 0.0);
-    double *const diag = S.box + lm_system::BOX_VECTORS, *const lmd = diag + std::max(n, 1);
+    std::vector<double> scale(n, 1.0);
+    double *const diag = S.box + lm_system::BOX_VECTORS;
     double x_cost = 0, gmax = 0;
     int erc = M.evaluate(true, 0, &x_cost);
     if (erc < 0)
@@ -1608,13 +1622,16 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         OCHIP_HIP(ctx, finish_state());
         return OCHIP_OK;
     }
-    int rc = grad_and_diag(&gmax);
+    int rc = grad_and_diag(&gmax, false);
     if (rc)
         return rc;
     OCHIP_HIP(ctx, hipMemcpy(diag, S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++)
         scale[i] = 1.0 / (1.0 + std::sqrt(diag[i])); // jacobi scaling, fixed from the first Jacobian
     OCHIP_HIP(ctx, hipMemcpy(S.scale, scale.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    rc = grad_and_diag(&gmax, true); // (the damping diagonal of the first iterations, now that the scaling exists)
+    if (rc)
+        return rc;
     double x_norm = 0;
     rc = M.x_norm(&x_norm);
     if (rc)
@@ -1622,7 +1639,6 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
     sum->initial_cost = x_cost;
     sum->iterations = 1; // iteration 0
     double radius = opt->initial_trust_region_radius, decrease_factor = 2.0;
-    bool reuse_diagonal = false;
     int invalid = 0, iter = 0;
     auto finish = [&](int term) -> int {
         sum->termination = term;
@@ -1641,21 +1657,14 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             return finish(OCHIP_RELAX_CONVERGENCE_RADIUS);
         iter++;
         sum->iterations++;
-        if (!reuse_diagonal)
-            for (int i = 0; i < n; i++)
-                diagonal[i] = std::min(std::max(diag[i] * scale[i] * scale[i], 1e-6), 1e32);
-        for (int i = 0; i < n; i++)
-        {
-            const double dd = std::sqrt(diagonal[i] / radius);
-            lmd[i] = dd * dd;
-        }
-        OCHIP_HIP(ctx, hipMemcpyAsync(S.lm_diag, lmd, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        // (the damping D^2 = clamp(diag(J'J) scale^2) / radius: the clamped diagonal is refreshed on the device with every
+        // accepted point's Jacobian - lm_diag_kernel - and divided by this iteration's radius inside lm_build_kernel)
         hipEvent_t e0, e1;
         ochip_prof_begin(ctx, OCHIP_K_RELAX_SOLVE, &e0, &e1);
         if (n > 0)
             hipLaunchKernelGGL(lm_build_kernel, dim3((unsigned)S.chol_n_tiles), dim3(256), 0, st, S.matA(), (const unsigned int *)S.tile_ij,
-                               (const double *)S.g, (const double *)S.scale, (const double *)S.lm_diag, S.matW(), S.gs, n, S.chol_sync,
-                               S.fail_chol);
+                               (const double *)S.g, (const double *)S.scale, (const double *)S.diagonal, radius, S.lm_diag, S.matW(), S.gs,
+                               n, S.chol_sync, S.fail_chol);
         else
             OCHIP_HIP(ctx, hipMemsetAsync(S.fail_chol, 0, 4, st));
         if (eliminated)
@@ -1779,7 +1788,12 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         volatile int &cfail = *reinterpret_cast<volatile int *>(S.box + lm_system::BOX_CFAIL);
         cfail = 0;
         double cand_eval = 0;
+        const bool mailed = M.mails_results();
+        const bool spec = M.speculates() && !M.is_constrained() && !eliminated && S.A2 != nullptr;
+        int fail_mask = 0;
         auto read_step = [&]() {
+            if (mailed)
+                return; // (the evaluation's last kernel posts them)
             (void)hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st);
             (void)hipMemcpyAsync(S.box + lm_system::BOX_CFAIL, S.fail_chol, 4, hipMemcpyDeviceToHost, st);
         };
@@ -1791,6 +1805,14 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             if (!cfail && std::isfinite(h[1]) && h[1] > 0.0)
                 erc = M.evaluate(false, 1, &cand_eval);
         }
+        else if (spec)
+        {
+            // the candidate with its Jacobian, into the second set: if the step is accepted (nearly always) everything the
+            // next iteration needs is there already
+            erc = M.evaluate_candidate_jac(S.scale, &cand_eval, &fail_mask);
+            if (erc == 0 && (fail_mask & 1))
+                erc = 1;
+        }
         else
         {
             M.before_wait = read_step;
@@ -1799,7 +1821,6 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         }
         if (erc < 0)
             return erc;
-        reuse_diagonal = true;
         const double model_cost_change = h[1];
         const bool valid = !cfail && std::isfinite(model_cost_change) && model_cost_change > 0.0;
         static const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
@@ -1929,16 +1950,31 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
         if (std::abs(cost_change) <= opt->function_tolerance * x_cost)
             return finish(OCHIP_RELAX_CONVERGENCE_FUNCTION);
         const double rho = cost_change / model_cost_change;
-        if (rho > 1e-3)
+        if (rho > 1e-3 && spec)
+        {
+            M.accept_swap();
+            S.swap_sets();
+            x_norm = cand_norm;
+            x_cost = cand_eval;
+            if (fail_mask & 2) // (a derivative at the accepted point is not finite: Ceres' "evaluation failed")
+                return finish(OCHIP_RELAX_FAILURE);
+            gmax = h[4];
+            const double t = 2.0 * rho - 1.0;
+            radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+            radius = std::min(1e16, radius);
+            decrease_factor = 2.0;
+            sum->successful_steps++;
+            if (gmax <= opt->gradient_tolerance)
+                return finish(OCHIP_RELAX_CONVERGENCE_GRADIENT);
+        }
+        else if (rho > 1e-3)
         {
             M.launch_accept();
             x_norm = cand_norm;
             // (the gradient norm and the diagonal of the new J'J ride on the evaluation's wait)
             auto read_gradient = [&]() {
-                hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(LM_TG), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal);
-                (void)hipMemcpyAsync(h, S.scal, 64, hipMemcpyDeviceToHost, st);
-                if (n > 0)
-                    (void)hipMemcpyAsync(diag, S.diag_tmp, (size_t)n * 8, hipMemcpyDeviceToHost, st);
+                hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(LM_TG), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal,
+                                   (const double *)S.scale, S.diagonal, mail);
             };
             if (!separate_waits)
                 M.before_wait = read_gradient;
@@ -1966,7 +2002,6 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
             radius = std::min(1e16, radius);
             decrease_factor = 2.0;
-            reuse_diagonal = false;
             sum->successful_steps++;
             if (gmax <= opt->gradient_tolerance)
                 return finish(OCHIP_RELAX_CONVERGENCE_GRADIENT);

@@ -11,6 +11,7 @@
 #include "ctx.hpp"
 
 #include <functional>
+#include <utility>
 #include <vector>
 
 namespace ochip
@@ -72,6 +73,26 @@ struct lm_system
     double *g = nullptr;       // [n] J'r
     double *Wm = nullptr;      // scaled + damped system in the same tiles, row n = scaled gradient; factored in place
     double *gs = nullptr, *scale = nullptr, *lm_diag = nullptr, *diag_tmp = nullptr, *y = nullptr;
+    double *diagonal = nullptr; // [n] clamp(diag(J'J) scale^2, 1e-6, 1e32) of the Jacobian of the last accepted point (lm_diag_kernel);
+                                // the damping of an iteration, diagonal / radius, is formed where it is added (lm_build_kernel)
+    bool A_clean = false;       // every entry of A that no engine kernel writes is zero (the layout has not changed since it was cleared)
+    // Second set of everything a Jacobian evaluation produces (engines that evaluate the candidate WITH its Jacobian,
+    // lm_model::speculates): the candidate's J'J, J'r and clamped diagonal land here and an accepted step swaps the sets
+    bool speculative = false;   // set by the owner before lm_system_resize: allocate the second set
+    double *A2 = nullptr, *g2 = nullptr, *diagonal2 = nullptr;
+    bool A2_clean = false;
+    size_t cap_tiles2 = 0, cap_n2 = 0;
+    void swap_sets()
+    {
+        std::swap(A, A2);
+        std::swap(g, g2);
+        std::swap(diagonal, diagonal2);
+        std::swap(A_clean, A2_clean);
+    }
+    lm_matrix matA2() const
+    {
+        return lm_matrix{A2, chol_cols};
+    }
     double *scal = nullptr;    // [8] small results: [0] cost [1] model cost change [2] |step|^2 [3] |candidate|^2 [4] max |g|
     int *fail_chol = nullptr;
     double *linv = nullptr;    // inverses of the diagonal blocks
@@ -94,12 +115,14 @@ struct lm_system
     int *region_dev = nullptr;
     double *back_work = nullptr;
     size_t back_work_cap = 0;
-    // Page-locked host block the solve's read-backs and uploads go through: a hipMemcpyAsync to or from pageable memory is
-    // staged and makes the host wait for the copy itself - the solver's and the engines' small read-backs (cost, flags,
-    // step norms, diagonal) were eight such round trips per LM iteration beside the two waits it needs.
+    // Page-locked host block the solve's read-backs go through.  Round 2: a hipMemcpyAsync to or from pageable memory is
+    // staged and makes the host wait for the copy itself - eight such round trips per LM iteration.  Round 4: the kernel that
+    // ends an evaluation writes the small results (cost, flags, step norms, gradient norm) into this block itself
+    // (lm_mail) - a device-to-host copy is a blit kernel that queues for a compute unit like any other, ~70 us each beside
+    // the extraction's kernels; an iteration had nine of them.
     // Layout (doubles): [0, 8) the solver's copy of scal, [8] the engine's cost, [9] the factorisation's failure flag (int),
-    // [16, 32) the engines' failure flags (int32 per rank, at most 32 ranks), [32, 32 + n) diagonal of J'J,
-    // [32 + n, 32 + 2 n) LM diagonal on its way up.
+    // [16, 32) the engines' failure flags (int32 per rank, at most 32 ranks), [32, 32 + n) diagonal of J'J (the solve's
+    // first Jacobian only: the Jacobi scaling is computed on the host).
     double *box = nullptr;
     size_t box_cap = 0;
     static constexpr int BOX_SCAL = 0, BOX_COST = 8, BOX_CFAIL = 9, BOX_FAILS = 16, BOX_VECTORS = 32, BOX_MAX_RANKS = 32;
@@ -124,9 +147,90 @@ int lm_download_dense(const lm_system &s, double *out);
 // (re)size the buffers for n unknowns and take the envelope; returns OCHIP_OK or a negative code
 int lm_system_resize(lm_system *s, int n, const lm_envelope &env);
 
+// What the kernel that ends an evaluation writes to the host block (lm_system::box) when the engine mails its results:
+// box[0, 8) = scal[0, 8), box[8] = scal[0] (the cost), the factorisation's failure flag, the ranks' evaluation flags.
+struct lm_mail
+{
+    double *box = nullptr; // nullptr: nothing is mailed (the caller copies)
+    const double *scal = nullptr;
+    const int *fail_chol = nullptr;
+    const int32_t *fail_ranks = nullptr;
+    int world = 0;
+    int with_cost = 0; // scal[0] is the evaluation's cost: box[8] takes it as well
+};
+#if defined(__HIPCC__)
+// diag(A), max |g| and the clamped diagonal of the damping, by the TG threads of one workgroup (what lm_diag_kernel does;
+// also the tail of an engine's last evaluation kernel).  Returns max |g| to thread 0.  sh: TG doubles of LDS.
+template <int TG>
+__device__ __forceinline__ double lm_diag_pass(const lm_matrix &A, const double *g, double *diag_out, int n, const double *scale,
+                                               double *diagonal, double *sh)
+{
+    const int t = threadIdx.x;
+    double m = 0;
+    for (int i = t; i < n; i += TG)
+    {
+        const double d = A.tiles[lm_at(A, i, i)];
+        if (diag_out)
+            diag_out[i] = d;
+        if (scale)
+        {
+            const double v = d * scale[i] * scale[i];
+            const double lo = v < 1e-6 ? 1e-6 : v; // std::max(v, 1e-6), then std::min(.., 1e32): NaN passes through
+            diagonal[i] = 1e32 < lo ? 1e32 : lo;
+        }
+        m = fmax(m, fabs(g[i]));
+    }
+    sh[t] = m;
+    __syncthreads();
+    for (int s = TG / 2; s > 0; s >>= 1)
+    {
+        if (t < s)
+            sh[t] = fmax(sh[t], sh[t + s]);
+        __syncthreads();
+    }
+    return sh[0];
+}
+__device__ __forceinline__ void lm_mail_post(const lm_mail &m) // one thread, after everything it mails is written
+{
+    if (!m.box)
+        return;
+    for (int i = 0; i < 8; i++)
+        m.box[lm_system::BOX_SCAL + i] = m.scal[i];
+    if (m.with_cost)
+        m.box[lm_system::BOX_COST] = m.scal[0];
+    if (m.fail_chol)
+        *reinterpret_cast<int *>(m.box + lm_system::BOX_CFAIL) = *m.fail_chol;
+    int32_t *f = reinterpret_cast<int32_t *>(m.box + lm_system::BOX_FAILS);
+    for (int r = 0; r < m.world; r++)
+        f[r] = m.fail_ranks[r];
+}
+#endif
+
 struct lm_model
 {
     virtual ~lm_model() = default;
+    // true: evaluate() delivers scal[0, 8), the cost and both kinds of failure flags into sys.box by itself (lm_mail_post in
+    // its last kernel); the solver then enqueues no copies of its own for them
+    virtual bool mails_results()
+    {
+        return false;
+    }
+    // Speculative engines: the candidate is evaluated WITH its Jacobian, into the system's second set (sys.A2, g2,
+    // diagonal2 = the clamped diagonal for `scale`; scal[4] = max |g2|), everything mailed: one evaluation and one wait
+    // per iteration instead of two of each - nearly every step of these solves is accepted.  *fail_mask: bit 0 = a
+    // residual was not finite (the candidate's cost is unusable), bit 1 = a derivative was not.  accept_swap(): the
+    // candidate becomes the current state (the engine swaps its state buffers; the solver swaps the system's sets).
+    virtual bool speculates()
+    {
+        return false;
+    }
+    virtual int evaluate_candidate_jac(const double *scale, double *cost, int *fail_mask)
+    {
+        return OCHIP_EINVAL;
+    }
+    virtual void accept_swap()
+    {
+    }
     // Evaluate state `which` (0 = current, 1 = candidate).  with_jac: also fill sys.A (every entry (i, j <= i) of the
     // packed lower triangle, zeros included: hipMemsetAsync(sys.A, 0, sys.matrix_bytes()) first) and sys.g.  *cost = total cost.  Returns 0, 1 for a numeric failure (non-finite residual or derivative:
     // Ceres' "evaluation failed"), or a negative OCHIP_E* code for a hard error (HIP call, exchange) which ends the solve.

@@ -357,8 +357,8 @@ int ochip_plane_setup_create(ochip_ctx *ctx, const ochip_plane_edge *edges, uint
     if (!ctx || !out)
         return OCHIP_EINVAL;
     *out = nullptr;
-    if ((n_edges && (!edges || !inexact_out)) || (n_inliers && (!inliers || !keep_out)) || !cam_pos || !cam_q || !models10 ||
-        !triangle_xy6 || !(grid_fraction > 0))
+    if ((n_edges && (!edges || !inexact_out)) || (n_inliers && (!inliers || !keep_out)) || (n_cams && (!cam_pos || !cam_q)) ||
+        (n_models && !models10) || !triangle_xy6 || !(grid_fraction > 0))
         return ochip_fail(ctx, OCHIP_EINVAL, "ochip_plane_setup_create: bad argument");
     for (uint32_t e = 0; e < n_edges; e++)
         if (edges[e].cam_a >= n_cams || edges[e].cam_b >= n_cams || edges[e].model_a >= n_models || edges[e].model_b >= n_models ||
