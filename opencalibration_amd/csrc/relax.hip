@@ -20,6 +20,7 @@
 #include "ctx.hpp"
 #include "dual.hpp"
 #include "relax_lm.hpp"
+#include "relax_lm_back.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -615,15 +616,6 @@ __device__ __forceinline__ void scatter_pair(const relax_dev &P, const lm_matrix
         }
 }
 
-// both in one launch: the first cam_blocks workgroups take the cameras, the others the pairs (they write disjoint entries)
-__global__ void relax_scatter_kernel(relax_dev P, lm_matrix A, double *g, int n, const uint8_t *cam_has_prior, uint32_t cam_blocks)
-{
-    if (blockIdx.x < cam_blocks) // (four cameras per workgroup, one per wavefront)
-        scatter_cam(P, A, g, n, cam_has_prior, blockIdx.x * (blockDim.x / W) + threadIdx.x / W, threadIdx.x % W);
-    else
-        scatter_pair(P, A, n, (blockIdx.x - cam_blocks) * blockDim.x + threadIdx.x);
-}
-
 // Plane-plane block, plane gradient, total cost (pairs + priors); scal[0] = cost.  REDUCE_GROUPS workgroups each sum a
 // fixed share of the pairs and cameras (one workgroup took 33 us of an iteration: 35 dependent trips to memory per thread),
 // the one that finishes last adds the groups' sums in group order - the same result whoever that is.
@@ -632,57 +624,80 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
                                                                  const uint8_t *cam_has_prior, double *scal,
                                                                  int with_jac, int which_state, double *partials /*[groups][10]*/,
                                                                  unsigned int *arrived, lm_mail mail, const double *diag_scale,
-                                                                 double *diagonal)
+                                                                 double *diagonal, uint32_t cam_blocks, uint32_t scatter_blocks)
 {
+    // The last `scatter_blocks` workgroups of the launch do what relax_scatter_kernel does (cameras, then pairs): one launch
+    // per Jacobian evaluation less.  Whichever workgroup of the whole launch arrives last finishes the evaluation.
     __shared__ int s_last;
-    const int t = threadIdx.x, b = blockIdx.x, groups = gridDim.x;
-    double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // zz (6), gz (3), cost
-    for (uint32_t pr = b * 256 + t; pr < P.n_pairs; pr += 256 * groups)
-    {
-        if (with_jac)
-        {
-            const double *a = P.pair_acc + (size_t)pr * ACC;
-            int k = 0;
-            for (int i = 0; i < 3; i++)
-                for (int j = i; j < 3; j++)
-                    v[k++] += a[tri(6 + i, 6 + j)];
-            for (int i = 0; i < 3; i++)
-                v[6 + i] += a[45 + 6 + i];
-        }
-        v[9] += P.pair_cost[pr];
-    }
-    const double *Q = which_state ? P.cam_q2 : P.cam_q;
-    for (uint32_t c = b * 256 + t; c < P.n_cams; c += 256 * groups)
-        if (cam_has_prior[c] && P.cam_t[c] >= 0) // priors of constant cameras are fixed cost (not in the reduced program)
-        {
-            double r, j3[3];
-            downward_prior(Q + (size_t)c * 4, P.prior_weight, &r, j3);
-            v[9] += 0.5 * r * r;
-        }
-    // within the workgroup: a fixed shuffle tree per wavefront, then the four wavefronts' sums in order
     __shared__ double wsum[4][10];
-    for (int q = with_jac ? 0 : 9; q < 10; q++)
+    const int t = threadIdx.x, groups = (int)(gridDim.x - scatter_blocks), b = blockIdx.x;
+    if (b >= groups)
     {
-        double x = v[q];
-        for (int off = 32; off >= 1; off >>= 1)
-            x += __shfl_xor(x, off);
-        if ((t & 63) == 0)
-            wsum[t >> 6][q] = x;
+        const uint32_t sb = (uint32_t)(b - groups);
+        if (sb < cam_blocks)
+            scatter_cam(P, A, g, n, cam_has_prior, sb * (256 / W) + t / W, t % W);
+        else
+            scatter_pair(P, A, n, (sb - cam_blocks) * 256 + t);
+        __syncthreads(); // (every wavefront's stores are out: __syncthreads waits for them)
+        if (t == 0)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            s_last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (!s_last)
+            return;
     }
-    __syncthreads();
-    if (t < 10)
+    else
     {
-        const double sum = (with_jac || t == 9) ? ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t] : 0.0;
-        __hip_atomic_store(&partials[b * 10 + t], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // zz (6), gz (3), cost
+        for (uint32_t pr = b * 256 + t; pr < P.n_pairs; pr += 256 * groups)
+        {
+            if (with_jac)
+            {
+                const double *a = P.pair_acc + (size_t)pr * ACC;
+                int k = 0;
+                for (int i = 0; i < 3; i++)
+                    for (int j = i; j < 3; j++)
+                        v[k++] += a[tri(6 + i, 6 + j)];
+                for (int i = 0; i < 3; i++)
+                    v[6 + i] += a[45 + 6 + i];
+            }
+            v[9] += P.pair_cost[pr];
+        }
+        const double *Q = which_state ? P.cam_q2 : P.cam_q;
+        for (uint32_t c = b * 256 + t; c < P.n_cams; c += 256 * groups)
+            if (cam_has_prior[c] && P.cam_t[c] >= 0) // priors of constant cameras are fixed cost (not in the reduced program)
+            {
+                double r, j3[3];
+                downward_prior(Q + (size_t)c * 4, P.prior_weight, &r, j3);
+                v[9] += 0.5 * r * r;
+            }
+        // within the workgroup: a fixed shuffle tree per wavefront, then the four wavefronts' sums in order
+        for (int q = with_jac ? 0 : 9; q < 10; q++)
+        {
+            double x = v[q];
+            for (int off = 32; off >= 1; off >>= 1)
+                x += __shfl_xor(x, off);
+            if ((t & 63) == 0)
+                wsum[t >> 6][q] = x;
+        }
+        __syncthreads();
+        if (t < 10)
+        {
+            const double sum = (with_jac || t == 9) ? ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t] : 0.0;
+            __hip_atomic_store(&partials[b * 10 + t], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (t == 0)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // (lanes 0 .. 9 of this wavefront stored the sums)
+            s_last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        }
+        __syncthreads();
+        if (!s_last)
+            return;
     }
-    if (t == 0)
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // (lanes 0 .. 9 of this wavefront stored the sums)
-        s_last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(groups - 1);
-    }
-    __syncthreads();
-    if (!s_last)
-        return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (the other workgroups' entries of A and g, their partial sums)
     // the last workgroup: every group's sums in one trip to memory, then ten lanes add them in group order
     __shared__ double part[REDUCE_GROUPS * 10];
     __shared__ double total[10];
@@ -740,7 +755,7 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
 
 // step = -y with (As + D) y = gs; delta = S step; candidate state = x (+) delta; step_norm^2 in ambient space.
 // One workgroup.  scal: [2] step_norm^2, [3] x_norm^2 (candidate)
-__global__ __launch_bounds__(LM_TG) void plane_candidate_kernel(relax_dev P, const double *scale, const double *y, double alpha, double *scal)
+__device__ __forceinline__ void plane_candidate_body(const relax_dev &P, const double *scale, const double *y, double alpha, double *scal)
 {
     __shared__ double sh[LM_TG];
     const int t = threadIdx.x;
@@ -809,6 +824,22 @@ __global__ __launch_bounds__(LM_TG) void plane_candidate_kernel(relax_dev P, con
             scal[2 + q] = sh[0];
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(LM_TG) void plane_candidate_kernel(relax_dev P, const double *scale, const double *y, double alpha, double *scal)
+{
+    plane_candidate_body(P, scale, y, alpha, scal);
+}
+
+// the backward substitution (relax_lm_back.hpp) with the candidate state as its tail: the workgroup that finishes last has
+// the whole step and computes the candidate (alpha = 1) - one launch instead of two
+__global__ __launch_bounds__(LM_TG) void plane_back_solve_candidate_kernel(lm_matrix Lm, int n, const double *Linv, double *x, double *work,
+                                                                          const int *first_blk, int n_blocks, const int *region, int tb,
+                                                                          const double *lm_diag, const double *gs, double *scal,
+                                                                          unsigned int *arrived, int x_in_lds, relax_dev P, const double *scale)
+{
+    back_solve_regions_body(Lm, n, Linv, x, work, first_blk, n_blocks, region, tb, lm_diag, gs, scal, arrived, x_in_lds,
+                            [&]() { plane_candidate_body(P, scale, x, 1.0, scal); });
 }
 
 __global__ void lm_accept_kernel(relax_dev P)
@@ -1401,6 +1432,13 @@ struct plane_model final : lm_model
     {
         p->dev = candidate_view();
     }
+    bool launch_back_solve_candidate(const back_args &a, const double *scale) override
+    {
+        hipLaunchKernelGGL(plane_back_solve_candidate_kernel, dim3((unsigned)a.n_regions), dim3(LM_TG), 0, p->ctx->stream, a.W, a.n, a.linv,
+                           a.y, a.work, a.first_blk, a.n_blocks, a.region, a.tb, a.lm_diag, a.gs, a.scal, a.arrived, a.x_in_lds, p->dev,
+                           scale);
+        return true;
+    }
     // one evaluation of state `which` of D: pair records (sharded + exchanged when ochip_relax_set_shard is in effect),
     // deterministic assembly into the system's first or second set, results mailed to the host block
     int run(const relax_dev &D, bool with_jac, int which, bool second_set, const double *diag_scale, double *cost, int *fail_mask)
@@ -1448,9 +1486,6 @@ struct plane_model final : lm_model
                 clean = true;
             }
             // (J'r needs no clearing: every unknown belongs to an active camera or a free plane height, whose owners write it)
-            const uint32_t cam_blocks = (D.n_cams + 3) / 4, pair_blocks = (D.n_pairs + 255) / 256;
-            hipLaunchKernelGGL(relax_scatter_kernel, dim3(cam_blocks + pair_blocks), dim3(256), 0, st, D, Am, gv, n, p->cam_has_prior,
-                               cam_blocks);
         }
         if (!p->reduce_partials)
         {
@@ -1464,9 +1499,11 @@ struct plane_model final : lm_model
         lm_mail mail{};
         if (mailed)
             mail = lm_mail{p->sys.box, p->sys.scal, p->sys.fail_chol, p->fail_ranks, (int)p->shard_world, 1};
-        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(REDUCE_GROUPS), dim3(256), 0, st, D, Am, gv, n, p->cam_has_prior, p->sys.scal,
-                           with_jac ? 1 : 0, which, p->reduce_partials, p->reduce_arrived, mail, diag_scale,
-                           second_set ? p->sys.diagonal2 : p->sys.diagonal);
+        // (with the Jacobian: the scatter of the pair records into A and g rides in the same launch)
+        const uint32_t cam_blocks = with_jac ? (D.n_cams + 3) / 4 : 0, pair_blocks = with_jac ? (D.n_pairs + 255) / 256 : 0;
+        hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(REDUCE_GROUPS + cam_blocks + pair_blocks), dim3(256), 0, st, D, Am, gv, n,
+                           p->cam_has_prior, p->sys.scal, with_jac ? 1 : 0, which, p->reduce_partials, p->reduce_arrived, mail, diag_scale,
+                           second_set ? p->sys.diagonal2 : p->sys.diagonal, cam_blocks, cam_blocks + pair_blocks);
         OCHIP_HIP(ctx, hipGetLastError());
         // (read-backs into the system's page-locked block: a copy to pageable memory would make the host wait for it)
         std::vector<int32_t> hfails_pageable;

@@ -224,6 +224,28 @@ struct lm_model
     {
         return false;
     }
+    // The backward substitution over the band's regions with the engine's candidate step as its tail (relax_lm_back.hpp:
+    // the workgroup that finishes last computes the candidate state, alpha = 1): one launch less per iteration.  false:
+    // not offered - the solver launches back_solve_regions_kernel and launch_candidate.
+    struct back_args
+    {
+        lm_matrix W;
+        int n;
+        const double *linv;
+        double *y, *work;
+        const int *first_blk;
+        int n_blocks;
+        const int *region;
+        int tb;
+        const double *lm_diag, *gs;
+        double *scal;
+        unsigned int *arrived;
+        int x_in_lds, n_regions;
+    };
+    virtual bool launch_back_solve_candidate(const back_args &a, const double *scale)
+    {
+        return false;
+    }
     virtual int evaluate_candidate_jac(const double *scale, double *cost, int *fail_mask)
     {
         return OCHIP_EINVAL;
