@@ -45,13 +45,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # A survey's feature lists (1.8 MB per image) are allocated by the host tail and freed with the graph one step later.
 # glibc hands such blocks straight back to the kernel (mmap threshold, heap trimming), so every step would page-fault its
 # 2 GB in again, 4 KB at a time, inside the tail's OpenMP team; a long-running pipeline process keeps them.
-if os.environ.get("OCHIP_BENCH_KEEP_HEAP", "1") != "0":
-    import ctypes as _ctypes
+import ctypes as _ctypes
 
-    _libc = _ctypes.CDLL("libc.so.6")
-    _libc.mallopt(-3, 32 << 20)   # M_MMAP_THRESHOLD: its maximum
-    _libc.mallopt(-1, 1 << 30)    # M_TRIM_THRESHOLD
-    _libc.mallopt(-2, 64 << 20)   # M_TOP_PAD
+_libc = _ctypes.CDLL("libc.so.6")
+_libc.mallopt(-3, 32 << 20)   # M_MMAP_THRESHOLD: its maximum
+_libc.mallopt(-1, 1 << 30)    # M_TRIM_THRESHOLD
+_libc.mallopt(-2, 64 << 20)   # M_TOP_PAD
 
 METRIC = "images/sec end-to-end (extract+match+relax) on synthetic aerial grid; LM iters/sec"
 DTYPE = "f32 (extract) + fp4 0/1 bits, f32 accumulate, exact (match) + f64 (RANSAC, relax)"
@@ -183,7 +182,7 @@ class Proc:
         that a transport that cannot work ends the job with one line and a non-zero code instead of hanging in the first
         exchange of the timed region."""
         torch, dist = self.torch, self.dist
-        limit = float(os.environ.get("OCHIP_BENCH_PREFLIGHT_TIMEOUT", "60"))
+        limit = 60.0
         done = threading.Event()
 
         def watchdog():
@@ -457,7 +456,7 @@ def beside_the_headline(ctx, grid, images, shape, start_ori, step_s, rctx=None):
         # uploads of the next - the reference's pipeline keeps consecutive batches in flight the same way
         # (pipeline.cpp:543-560).  Relaxes one at a time on the relax context.
         e2e_two = None
-        if rctx is not None and os.environ.get("OCHIP_BENCH_PCIE_TWO", "1") != "0":
+        if rctx is not None:
             from opencalibration_amd import capi as _capi
 
             ctx_b = _capi.Context(getattr(ctx, "device", 0))
@@ -578,8 +577,7 @@ class StrongRunner:
         self.images, self.shape = pipeline.synthetic_views(self.ctx, self.grid, seed=7, block=(self.lo, self.cnt))
         self.start_ori = pipeline.perturbed_orientations(self.grid, 0.1, 99)
         self.rctx = self.ctx.sibling(12)              # (created here, before any runner thread asks for a sibling)
-        if os.environ.get("OCHIP_RELAX_PRIORITY", "1") != "0":
-            self.rctx.set_priority(True)              # the latency-bound solve goes ahead of the throughput kernels
+        self.rctx.set_priority(True)                  # the latency-bound solve goes ahead of the throughput kernels
         self.pipelined = args.relax == "pipelined"
         self.k = 0                                    # surveys started (the same count on every rank)
         self.pending = None                           # this rank's relax in flight
@@ -791,12 +789,12 @@ def weak_main(args, proc, cfg):
     # relax of survey k overlapped with load + link of survey k + 1: Pipeline::Impl::initial_processing runs the load, link
     # and relax runners of consecutive batches together (pipeline.cpp:543-560); here successive steps are successive surveys.
     # Every relax finishes inside the timed region (the last one is joined before the closing barrier).
-    relax_overlap = overlap and os.environ.get("OCHIP_PIPELINE_RELAX_OVERLAP", "1") != "0"
+    relax_overlap = overlap
     # two surveys in flight need host threads for two surveys' host phases at once: with 2 CPUs per rank one in flight is
     # faster (1 746 against 1 660 images/s), from 4 CPUs on two are (OCHIP_PIPELINE_SURVEYS overrides)
     surveys_in_flight = os.environ.get("OCHIP_PIPELINE_SURVEYS", "2" if proc.cores // max(world, 1) >= 4 else "1") != "1"
     rctx = ctx.sibling(12) if relax_overlap else ctx      # (created here, before any runner thread asks for a sibling)
-    if relax_overlap and os.environ.get("OCHIP_RELAX_PRIORITY", "1") != "0":
+    if relax_overlap:
         rctx.set_priority(True)                            # the latency-bound solve goes ahead of the throughput kernels
 
     def run_steps(n_steps, acc):
@@ -816,7 +814,7 @@ def weak_main(args, proc, cfg):
                          ("relax_lm_iterations", res["relax"]["iterations_total"])]:
                     acc[k] = acc.get(k, 0.0) + v
 
-        verbose = os.environ.get("OCHIP_BENCH_VERBOSE") is not None
+        verbose = "bench" in os.environ.get("OCHIP_VERBOSE", "").split(",")
         # load + link of survey k + 1 beside the link tail of survey k (two host threads; the native side lets one survey
         # extract at a time and gives alternating surveys their own link contexts, csrc/host/load_link.cpp): the
         # reference runs the load runners of a batch beside the link runners of the batch before it (pipeline.cpp:543-560)
@@ -983,18 +981,18 @@ def run_strong_beside(args, proc, cfg):
     """A short strong-scaling run after the weak timed region: every rank starts `bench.py --scaling strong` as a CHILD process
     (same RANK / WORLD_SIZE, its own rendezvous port) and waits for it.  The exchanges of that mode have only ever run between
     ranks sharing one GPU before the scaling run; in a child, nothing it does - a hang (bounded by
-    OCHIP_BENCH_STRONG_TIMEOUT), an abort inside a collective - can take the weak headline with it.  Returns rank 0's report
+    300 s), an abort inside a collective - can take the weak headline with it.  Returns rank 0's report
     (None on the other ranks) or {"error": ...}."""
     import subprocess
 
-    steps = max(2, min(args.steps, _env_int("OCHIP_BENCH_STRONG_STEPS", 5)))
+    steps = max(2, min(args.steps, 5))
     port = int(os.environ.get("MASTER_PORT", "29500")) + 17            # (the same on every rank)
     env = dict(os.environ, MASTER_PORT=str(port), OCHIP_BENCH_STRONG_BESIDE="0")
     env.pop("OCHIP_BENCH_CPUS", None)                                   # (already pinned: inherited)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(proc.world), "--scaling", "strong", "--relax", args.relax,
            "--steps", str(steps), "--warmup", "1", "--config", args.config, "--no-cpu-baseline"]
     try:
-        done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=float(os.environ.get("OCHIP_BENCH_STRONG_TIMEOUT", "300")))
+        done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=300.0)
     except subprocess.TimeoutExpired:
         return {"error": "the strong-scaling run did not finish in time"}
     except OSError as ex:

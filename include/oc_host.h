@@ -94,7 +94,7 @@ extern "C"
     size_t och_extract_tail_prepared(const uint8_t *records, const float *response, const uint32_t *slot, uint32_t num_sparse_in,
                                      int conflict, uint32_t n, double scale, double *loc, float *strength, uint64_t *desc_out,
                                      uint64_t *num_sparse);
-    /* Cumulative CPU seconds of that tail's phases, recorded while OCHIP_EXTRACT_VERBOSE is set: ordering, NMS, feature
+    /* Cumulative CPU seconds of that tail's phases, recorded while OCHIP_VERBOSE=extract is set: ordering, NMS, feature
      * records, total, and the number of images whose responses tied (they take std::sort's route). */
     void och_extract_tail_profile(double *out5);
     /* The strength order of that tail alone: the permutation of 0..n-1 that std::sort by descending response produces

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/ochip.h"
+#include "env.hpp"
 
 struct ochip_profile_slot
 {

@@ -9,7 +9,7 @@ namespace ochip
 {
 
 // P: the type the partials are kept and propagated in.  double everywhere on the path; float only for the C5 sweep of
-// Jacobian precision (OCHIP_RELAX_JACOBIAN_FP32, relax_general.hip) - values stay fp64 either way.
+// Jacobian precision (OCHIP_TEST_HOOKS=jacobian_fp32, relax_general.hip) - values stay fp64 either way.
 template <int N, typename P = double> struct Dual
 {
     double a;

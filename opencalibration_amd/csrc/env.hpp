@@ -1,0 +1,38 @@
+// The two environment switches every part of the library shares (README.md, "Knobs"); plain C++, read on every call.
+//   OCHIP_VERBOSE    = 1 | all | comma list of relax, link, extract      progress lines on stderr
+//   OCHIP_TEST_HOOKS = comma list of the alternative routes the tests compare the default ones with:
+//                      host_sort, host_subset, host_tail, host_nms (the round-2 host code of the link / extract tails),
+//                      popcount_match (no matrix-core matcher), chol_verify (factor every system both ways and compare),
+//                      back_solve_x_global (step vector in HBM even when it fits LDS), no_dissect (one band, no regions),
+//                      jacobian_fp32 (profiles/r04_jacobian_precision_sweep_c5.json)
+#pragma once
+
+#include <cstdlib>
+#include <cstring>
+
+inline bool ochip_env_list_has(const char *var, const char *name, bool one_means_all)
+{
+    const char *e = std::getenv(var);
+    if (!e || !*e)
+        return false;
+    if (one_means_all && (std::strcmp(e, "1") == 0 || std::strcmp(e, "all") == 0))
+        return true;
+    const size_t len = std::strlen(name);
+    for (const char *p = e; *p;)
+    {
+        const char *q = std::strchr(p, ',');
+        const size_t n = q ? (size_t)(q - p) : std::strlen(p);
+        if (n == len && std::strncmp(p, name, len) == 0)
+            return true;
+        p += n + (q ? 1 : 0);
+    }
+    return false;
+}
+inline bool ochip_verbose(const char *what)
+{
+    return ochip_env_list_has("OCHIP_VERBOSE", what, true);
+}
+inline bool ochip_test_hook(const char *name)
+{
+    return ochip_env_list_has("OCHIP_TEST_HOOKS", name, false);
+}

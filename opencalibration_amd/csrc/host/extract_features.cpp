@@ -1,3 +1,4 @@
+#include "../env.hpp"
 #include "extract_features.hpp"
 #include "sort_like_std.hpp"
 
@@ -112,7 +113,7 @@ struct nn_grid
 
 // The host tail of src/extract/extract_features.cpp:38-87 for one image: n device keypoints (k6 = x, y, size,
 // angle, response, level in working-image pixels; AKAZE's detection order) -> [sparse..., dense...] features.
-double g_tail_prof[5]; // CPU seconds: ordering, NMS, feature records, total (OCHIP_EXTRACT_VERBOSE)
+double g_tail_prof[5]; // CPU seconds: ordering, NMS, feature records, total (OCHIP_VERBOSE=extract)
 static double thread_cpu_now()
 {
     timespec ts;
@@ -153,7 +154,7 @@ void suppress_in_order(const double *lx, const double *ly, uint32_t n, double mi
 
 void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale, extracted_features &out)
 {
-    static const bool prof = std::getenv("OCHIP_EXTRACT_VERBOSE") != nullptr;
+    static const bool prof = ochip_verbose("extract");
     const double tp0 = prof ? thread_cpu_now() : 0;
     double tp1 = 0, tp2 = 0;
     const double nms_pixel_radius = 8;
@@ -258,7 +259,7 @@ void extract_tail(const float *k6, const uint64_t *dd, uint32_t n, double scale,
 void extract_tail_prepared(const uint8_t *records, const float *response, const uint32_t *slot, uint32_t num_sparse, bool conflict,
                            uint32_t n, double scale, extracted_features &out)
 {
-    static const bool prof = std::getenv("OCHIP_EXTRACT_VERBOSE") != nullptr;
+    static const bool prof = ochip_verbose("extract");
     const double tp0 = prof ? thread_cpu_now() : 0;
     double tp1 = tp0, tp2 = tp0;
     const double nms_pixel_radius = 8;
@@ -381,10 +382,8 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
     // Images that start in host memory (the reference's boundary: a cv::Mat per image) are uploaded by the launch sequence
     // that extracts them, one copy per chunk on the sequence's stream.  With chunks of 100 a sequence's 3.6 GB copy takes
     // three times as long as its kernels and the four sequences in flight mostly wait for the link together; chunks of 25
-    // keep the PCIe link busy under the other sequences' kernels (OCHIP_EXTRACT_CHUNK_HOST).
-    uint32_t host_chunk = 25;
-    if (const char *e = std::getenv("OCHIP_EXTRACT_CHUNK_HOST"))
-        host_chunk = (uint32_t)std::max(1L, std::min(1024L, std::atol(e)));
+    // keep the PCIe link busy under the other sequences' kernels.
+    const uint32_t host_chunk = 25;
     const uint32_t chunk = std::min(images_on_device ? extract_chunk_size() : host_chunk, n_images);
     const size_t image_bytes = (size_t)width * height * 3;
 
@@ -406,12 +405,11 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
                 *error = std::string("ochip_ctx_sibling: ") + ochip_last_error(ctx);
             return false;
         }
-    // the tail's data-parallel part on the device (csrc/features.hip); OCHIP_EXTRACT_TAIL=host: all of it here, from the raw
+    // the tail's data-parallel part on the device (csrc/features.hip); OCHIP_TEST_HOOKS=host_tail: all of it here, from the raw
     // keypoint arrays (the two must give the same lists: tests/test_gpu_extract.py)
-    const char *tail_env = std::getenv("OCHIP_EXTRACT_TAIL");
-    const bool device_tail = !(tail_env && std::string(tail_env) == "host");
+    const bool device_tail = !ochip_test_hook("host_tail");
     const double nms_pixel_radius = 8;
-    const bool force_host_nms = std::getenv("OCHIP_EXTRACT_HOST_NMS") != nullptr; // (test knob: the conflict path for every image)
+    const bool force_host_nms = ochip_test_hook("host_nms"); // (test knob: the conflict path for every image)
     const uint32_t n_bufs = 2 * n_drivers;
     std::vector<chunk_buffers> bufs(n_bufs);
     std::vector<ochip_ctx *> buf_ctx(n_bufs);
@@ -588,7 +586,7 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
     }
     for (auto &t : drivers)
         t.join();
-    if (std::getenv("OCHIP_EXTRACT_VERBOSE"))
+    if (ochip_verbose("extract"))
     {
         fprintf(stderr, "[extract] %u images: host tail %.3f thread-seconds of wall time (%.2f ms per image)\n", n_images,
                 tail_cpu_seconds, 1e3 * tail_cpu_seconds / n_images);
@@ -612,7 +610,7 @@ bool extract_features_stream(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t
 } // namespace opencalibration_amd
 
 // cumulative CPU seconds of the tail's phases (ordering, NMS, feature records, total, images with tied responses) when
-// OCHIP_EXTRACT_VERBOSE is set
+// OCHIP_VERBOSE=extract is set
 extern "C" void och_extract_tail_profile(double *out5)
 {
     for (int i = 0; i < 5; i++)

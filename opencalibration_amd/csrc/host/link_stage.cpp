@@ -1,3 +1,4 @@
+#include "../env.hpp"
 #include "link_stage.hpp"
 #include "sort_like_std.hpp"
 
@@ -110,7 +111,7 @@ void LinkStage::prepare_images(const MeasurementGraph &graph, const std::vector<
 {
     const auto t0 = clk::now();
     const double coarse_spacing_pixels = 40.0;
-    static const bool use_host_subset = std::getenv("OCHIP_LINK_HOST_SUBSET") != nullptr; // (A/B and tests)
+    const bool use_host_subset = ochip_test_hook("host_subset"); // (tests)
     const int nt = threads > 0 ? threads : omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nt)
     for (size_t k = 0; k < node_ids.size(); k++)
@@ -192,7 +193,7 @@ std::vector<std::function<void()>> LinkStage::get_runners(const MeasurementGraph
     return funcs;
 }
 
-static double g_link_cpu[6]; // CPU seconds (OCHIP_LINK_VERBOSE): pack+upload, ratio+sort, prosac, pack jobs, decompose, assemble
+static double g_link_cpu[6]; // CPU seconds (OCHIP_VERBOSE=link): pack+upload, ratio+sort, prosac, pack jobs, decompose, assemble
 static double link_thread_cpu()
 {
     timespec ts;
@@ -217,7 +218,7 @@ static thread_local bool force_host_sort = false; // (run_batch's second attempt
 
 void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_pair> &link_pairs, ochip_ctx *ctx, int omp_threads)
 {
-    static const bool prof = std::getenv("OCHIP_LINK_VERBOSE") != nullptr;
+    static const bool prof = ochip_verbose("link");
     LinkTimers lt; // this runner's phases, added to `timers` at the end
     struct timers_guard
     {
@@ -379,8 +380,8 @@ void LinkStage::run_batch(const MeasurementGraph &graph, const std::vector<link_
     // (csrc/match_sort.hip, csrc/std_sort.hip: libstdc++'s permutation among the equal Hamming counts): the host learns
     // the pairs' match counts here and receives the sorted correspondences with the RANSAC results.  A pair whose sort
     // would need libstdc++'s heap sort (flagged; not seen on descriptor distances) sends the batch down the host route
-    // below, which is also what OCHIP_LINK_HOST_SORT=1 selects.
-    static const bool host_sort_env = std::getenv("OCHIP_LINK_HOST_SORT") != nullptr;
+    // below, which is also what OCHIP_TEST_HOOKS=host_sort selects.
+    const bool host_sort_env = ochip_test_hook("host_sort");
     bool device_sorted = !host_sort_env && !force_host_sort;
     std::vector<uint32_t> match_counts(n_pairs, 0);
     std::vector<uint8_t> sort_flags(n_pairs ? n_pairs : 1, 0);
@@ -949,7 +950,7 @@ std::vector<size_t> LinkStage::finalize(MeasurementGraph &graph)
         node_ids.push_back(link.node_id);
     _links.clear();
     timers.link_finalize += since(t0);
-    if (std::getenv("OCHIP_LINK_VERBOSE"))
+    if (ochip_verbose("link"))
         link_cpu_report();
     return node_ids;
 }

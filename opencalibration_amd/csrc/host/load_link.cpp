@@ -114,8 +114,7 @@ bool load_link_stream(och_graph *g, ochip_ctx *ctx, LinkStage &link, const std::
     std::unordered_map<size_t, uint32_t> image_of; // node id -> image index within the block
     for (uint32_t b = 0; b < count; b++)
         image_of.emplace(ids[first + b], b);
-    const char *env = std::getenv("OCHIP_STREAM_LINK_RANGE");
-    const size_t range_len = std::max<size_t>(32, env ? (size_t)std::atol(env) : 125);
+    constexpr size_t range_len = 125;
     struct range
     {
         std::vector<LinkStage::link_pair> pairs;

@@ -1,3 +1,4 @@
+#include "../env.hpp"
 #include "relax.hpp"
 
 #include "relax_util.hpp"
@@ -37,7 +38,7 @@ class GroundPlaneProblem
     bool setup(std::vector<NodePose> &poses, const std::vector<size_t> &edges_to_optimize, std::string *error,
                const RelaxShard *shard = nullptr)
     {
-        const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+        const bool verbose = ochip_verbose("relax");
         auto tmark = clk::now();
         auto lap = [&](const char *what) {
             if (verbose)

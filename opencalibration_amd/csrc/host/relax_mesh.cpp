@@ -1,3 +1,4 @@
+#include "../env.hpp"
 #include "relax_mesh.hpp"
 #include "triangle_walker.hpp"
 
@@ -371,7 +372,7 @@ class GroundMeshProblem
                const std::vector<surface_model> &previous, RelaxMeshStats *stats, std::string *error,
                const RelaxShard *shard = nullptr)
     {
-        const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+        const bool verbose = ochip_verbose("relax");
         auto tmark = clk::now();
         auto lap = [&](const char *what) {
             if (verbose)
@@ -775,7 +776,7 @@ class GroundMeshProblem
                       const std::vector<pose_ref> &dst, double frac)
     {
         const size_t n_nodes = _graph.size_nodes();
-        const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+        const bool verbose = ochip_verbose("relax");
         auto tmark = clk::now();
         auto lap = [&](const char *what) {
             if (verbose)

@@ -582,7 +582,7 @@ int ochip_match_launch(ochip_ctx *ctx, const ochip_pair *pairs, uint32_t n_pairs
     }
 
     // ---- pairs whose reference image fits the matrix-core kernel's 13-bit index go there, each direction on its own
-    static const bool use_mfma = !(getenv("OCHIP_MATCH_MFMA") && getenv("OCHIP_MATCH_MFMA")[0] == '0'); // A/B knob
+    static const bool use_mfma = !ochip_test_hook("popcount_match");
     std::vector<ochip_pair> mfma_pairs;
     std::vector<uint64_t> mfma_off;
     uint32_t mfma_max_n1 = 0;

@@ -2323,13 +2323,9 @@ int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_
     uint8_t *inl_dev = (uint8_t *)ctx->scratch_dev[S_OUT] + (size_t)n_jobs * sizeof(ochip_ransac_result);
     hipEvent_t e0, e1;
     ochip_prof_begin(ctx, OCHIP_K_RANSAC, &e0, &e1);
-    static const int occ = []() {
-        const char *e = getenv("OCHIP_RANSAC_OCC"); // waves per SIMD the register allocator targets (tuning knob)
-        // the wave keeps two models, a sample and the LU rows of a round in VGPRs (uniform fp64 values have no scalar
-        // home on gfx950): 2 waves per SIMD leaves it 256 registers, 1 leaves it 512
-        const int v = e ? atoi(e) : 2;
-        return (v == 1 || v == 2) ? v : 2;
-    }();
+    // the wave keeps two models, a sample and the LU rows of a round in VGPRs (uniform fp64 values have no scalar
+    // home on gfx950): 2 waves per SIMD leaves it 256 registers, 1 leaves it 512 (measured slower)
+    constexpr int occ = 2;
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(n_jobs), dim3(W), 0, ctx->stream,
                            (const ochip_ransac_job *)ctx->scratch_dev[S_JOBS],

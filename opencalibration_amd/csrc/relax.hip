@@ -987,7 +987,7 @@ int assign_tangent(ochip_relax_problem *p)
         // independent (lm_envelope::region_begin), and the critical path is the longest region plus the tail.  g is
         // chosen to make that shortest (a separator camera counted 1.5 times); no dissection when it does not shorten the
         // path to 0.8 of the single chain.
-        const bool use_dissect = !(getenv("OCHIP_RELAX_DISSECT") && getenv("OCHIP_RELAX_DISSECT")[0] == '0');
+        const bool use_dissect = !ochip_test_hook("no_dissect");
         if (use_dissect && order.size() >= 4 * (size_t)NB)
         {
             const int N = (int)order.size();
@@ -1127,7 +1127,7 @@ int assign_tangent(ochip_relax_problem *p)
                     }
             env.first_col[k] = first;
         }
-        if (getenv("OCHIP_RELAX_VERBOSE"))
+        if (ochip_verbose("relax"))
         {
             long band = 0;
             for (int k = 0; k < nblk; k++)

@@ -1123,7 +1123,7 @@ int assign(ochip_relaxg_problem *p)
                     }
             env.first_col[k] = first;
         }
-        if (getenv("OCHIP_RELAX_VERBOSE"))
+        if (ochip_verbose("relax"))
         {
             long bandsum = 0;
             for (int k = 0; k < nblk; k++)
@@ -1144,8 +1144,8 @@ int assign(ochip_relaxg_problem *p)
     int max_strip = 1;
     std::vector<band_owner> band_owners;
     int64_t band_doubles = 0;
-    static const bool no_band_chunks = getenv("OCHIP_RELAX_NO_BAND_CHUNKS") != nullptr; // A/B knob
-    static const uint32_t band_chunk = getenv("OCHIP_RELAX_BAND_CHUNK") ? std::max(64, atoi(getenv("OCHIP_RELAX_BAND_CHUNK"))) : BAND_CHUNK;
+    constexpr bool no_band_chunks = false; // (true: whole bands, the round-3 A/B)
+    constexpr uint32_t band_chunk = BAND_CHUNK;
     for (uint32_t u : band)
     {
         const uint32_t r0 = p->var_rec_off[u], r1 = p->var_rec_off[u + 1];
@@ -1216,7 +1216,7 @@ template <int N, bool INTR> void launch_ray(const g_dev &D, hipStream_t st, uint
         // SURVEY §8 / BASELINE C5: "fp32-vs-fp64 Jacobian sweep".  The path computes Jacobians in fp64 as Ceres does; this
         // switch (read once) propagates the dual parts of the ray blocks in fp32 instead - residual values, J'J accumulation
         // and the solve stay fp64 - so that scripts/sweep_jacobian_precision.py can measure what fp32 derivatives would cost
-        static const bool jac32 = getenv("OCHIP_RELAX_JACOBIAN_FP32") != nullptr;
+        static const bool jac32 = ochip_test_hook("jacobian_fp32");
         if (jac32)
             hipLaunchKernelGGL((ray_record_kernel<N, INTR, Dual<3, float>>), dim3((count + G - 1) / G), dim3(W), 0, st, D, first, count, which);
         else

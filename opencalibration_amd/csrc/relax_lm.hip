@@ -7,7 +7,7 @@
 // each other through flags (products on v_mfma_f64_16x16x4f64, the diagonal block and its inverse in registers).  The
 // augmented row carries the forward solve; the backward substitution is one workgroup walking the row envelope.
 // The launch chain it replaced (chol_diag_kernel / chol_panel_kernel / chol_update_mfma_kernel, three dependent launches
-// per block column) stays behind OCHIP_CHOL_CHAIN=1 for A/B runs.
+// per block column) stays as the second opinion of OCHIP_TEST_HOOKS=chol_verify.
 #include "relax_lm.hpp"
 #include "relax_lm_back.hpp"
 
@@ -222,7 +222,7 @@ __device__ __forceinline__ void chol_diag_phase(double (&a)[4][4], double (&x)[4
 // update on the matrix cores: the panel L(rows below, 16) and the finished rows of X go through LDS, the products
 // L L' (trailing blocks) and L X (rows of the inverse below the band) are formed with v_mfma_f64_16x16x4f64 and
 // subtracted from the register tiles.  (Sums in a different order than the one-pivot loop: the factor is not on a
-// bit-parity path; OCHIP_CHOL_VERIFY compares it with the launch chain, which keeps the unblocked phases.)
+// bit-parity path; the chol_verify hook compares it with the launch chain, which keeps the unblocked phases.)
 template <int JB>
 __device__ __forceinline__ void chol_diag_panel_phase(double (&a)[4][4], double (&x)[4][4], double (*colA)[NB], double (*rowX)[NB],
                                                       int ty, int tx, int nb, bool &bad)
@@ -1549,8 +1549,8 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                 S.linv_cap = need;
             }
         }
-        static const bool chain = getenv("OCHIP_CHOL_CHAIN") != nullptr;   // A/B knob: the launch chain per block column
-        static const bool verify = getenv("OCHIP_CHOL_VERIFY") != nullptr; // run both on the same system and compare
+        constexpr bool chain = false; // (true: the launch chain per block column, the round-2 schedule; chol_verify runs it beside the tiles)
+        static const bool verify = ochip_test_hook("chol_verify"); // run both on the same system and compare
         // the launch chain on (W, linv); count: add the algorithmic flops of the factorisation to the context's counter
         auto launch_chain = [&](double *Wt, double *linv, bool launch, bool count) {
             const lm_matrix W{Wt, S.chol_cols};
@@ -1590,7 +1590,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                 Wv = (double *)ochip_pool_get(ctx, S.matrix_bytes(), &got_w);
                 linv_v = (double *)ochip_pool_get(ctx, (size_t)((n + NB - 1) / NB) * NB * NB * 8, &got_l);
                 if (!Wv || !linv_v)
-                    return ochip_fail(ctx, OCHIP_ENOMEM, "OCHIP_CHOL_VERIFY: device allocation failed");
+                    return ochip_fail(ctx, OCHIP_ENOMEM, "chol_verify: device allocation failed");
                 OCHIP_HIP(ctx, hipMemcpyAsync(Wv, S.Wm, S.matrix_bytes(), hipMemcpyDeviceToDevice, st));
             }
             // operands through LDS in halves (71 KB per workgroup; whole, 104 KB, measured equal alone and slower beside the
@@ -1618,14 +1618,14 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
                 }
                 ochip_pool_put(ctx, Wv, got_w);
                 ochip_pool_put(ctx, linv_v, got_l);
-                static const bool loud = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+                const bool loud = ochip_verbose("relax");
                 if (loud)
                     fprintf(stderr, "[ochip relax] factorisation check: n=%d forward solve differs by %.3g (scale %.3g)\n", n, worst, scale_y);
                 // (1e-7: the two factorisations round differently - blocked against rank-1 updates, the second pivot of a step
                 // from p1 p0 - and a nearly singular system amplifies that: 1.7e-9 on the 12 unknowns of a point triangulation
                 // with a trust region of 1e16; a misplaced tile shows up as O(1))
                 if (nan || worst > 1e-7 * std::max(scale_y, 1e-300))
-                    return ochip_fail(ctx, OCHIP_EINVAL, "OCHIP_CHOL_VERIFY: the tile factorisation and the launch chain disagree (n = %d, "
+                    return ochip_fail(ctx, OCHIP_EINVAL, "chol_verify: the tile factorisation and the launch chain disagree (n = %d, "
                                       "forward solve differs by %g at scale %g)", n, worst, scale_y);
             }
         }
@@ -1636,7 +1636,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             // (the per-region kernel also serves the single band, as one region: it is the faster walk - rows of a block
             // split over the wavefronts, x in LDS; OCHIP_BACK_SOLVE_SINGLE=1: the round-2 kernel)
             constexpr bool single = false; // (true: the round-2 single-workgroup kernel on a single band)
-            static const bool x_global = getenv("OCHIP_BACK_SOLVE_X_GLOBAL") != nullptr; // test knob: x in HBM even when it fits LDS
+            static const bool x_global = ochip_test_hook("back_solve_x_global"); // test knob: x in HBM even when it fits LDS
             if (S.n_regions > 1 || (!single && S.region_dev))
             {
                 const lm_model::back_args ba{S.matW(), n, S.linv, S.y, S.back_work, S.chol_kmin, (n + NB - 1) / NB, S.region_dev, S.chol_tb,
@@ -1701,7 +1701,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
             return erc;
         const double model_cost_change = h[1];
         const bool valid = !cfail && std::isfinite(model_cost_change) && model_cost_change > 0.0;
-        static const bool verbose = getenv("OCHIP_RELAX_VERBOSE") != nullptr;
+        static const bool verbose = ochip_verbose("relax");
         if (verbose)
             fprintf(stderr, "[ochip relax] n=%d iter=%d cost=%.17g radius=%.6g model=%.17g step_norm=%.6g cfail=%d gmax=%.6g\n",
                     n, iter, x_cost, radius, model_cost_change, std::sqrt(h[2]), cfail, gmax);

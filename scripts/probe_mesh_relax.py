@@ -1,5 +1,5 @@
 """The single-group GROUND_MESH relax of a C3-sized survey (1 000 cameras, ~650 k residual blocks): device seconds per LM
-iteration.  A/B: OCHIP_RELAX_NO_BAND_CHUNKS=1 (one wavefront per band owner in the assembly)."""
+iteration."""
 import os
 import sys
 import time

@@ -33,9 +33,8 @@ def run():
 
 run()
 for streams in (4, 5, 3):
-    for chunk in (25, 12, 50):
+    for chunk in (25,):  # (images per upload: fixed at 25 since round 4, extract_features.cpp)
         os.environ["OCHIP_EXTRACT_STREAMS"] = str(streams)
-        os.environ["OCHIP_EXTRACT_CHUNK_HOST"] = str(chunk)
         best = min(run() for _ in range(2))
         print(f"streams {streams} chunk {chunk:3d}: {n / best:7.1f} images/s  {n * h * w * 3 / best / 1e9:5.1f} GB/s", flush=True)
 release()

@@ -1,5 +1,5 @@
 """LM iterations per second of the C3 ground-plane relax (3 003 unknowns) alone on the device, from synthetic features
-(no extraction): A/B of the camera-graph dissection (OCHIP_RELAX_DISSECT, OCHIP_RELAX_DISSECT_G) - one process per
+(no extraction): A/B of the camera-graph dissection (OCHIP_TEST_HOOKS=no_dissect, OCHIP_RELAX_DISSECT_G) - one process per
 setting, the knobs are read once.  usage: python scripts/probe_relax_dissect.py [C3 | ROWSxCOLS[xFEATURES]] [repeats]"""
 import os, sys
 import numpy as np

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Where the host part of the ground-plane relax goes: one C3 survey (load + link + relax) with OCHIP_RELAX_VERBOSE=1
+"""Where the host part of the ground-plane relax goes: one C3 survey (load + link + relax) with OCHIP_VERBOSE=relax
 (lap times of RelaxProblem::setup on stderr).  usage: [taskset -c 0,1] probe_relax_setup.py [C2|C3]"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("OCHIP_BLOB_SPACING", "16")
-os.environ["OCHIP_RELAX_VERBOSE"] = "1"
+os.environ["OCHIP_VERBOSE"] = "relax"
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 from opencalibration_amd import capi, pipeline, synth
 

@@ -1,7 +1,7 @@
 """BASELINE config C5's "fp32-vs-fp64 Jacobian sweep": the pipeline's CAMERA_PARAMETER_RELAX schedule (pipeline.cpp:601-631:
 focal length; + radial BROWN2; + BROWN24; + principal point and BROWN246) on a camera grid with tracks whose group starts with
 a 3 % wrong focal length and no distortion knowledge, once with the ray blocks' Jacobians propagated in fp64 (the path) and
-once in fp32 (OCHIP_RELAX_JACOBIAN_FP32=1; values, J'J accumulation and solve stay fp64).  Prints one JSON object per
+once in fp32 (OCHIP_TEST_HOOKS=jacobian_fp32; values, J'J accumulation and solve stay fp64).  Prints one JSON object per
 precision: LM iterations, final cost, the intrinsics reached, pose error against the truth.  Run on the GPU box."""
 import json
 import os
@@ -81,9 +81,9 @@ print(json.dumps(dict(cameras=n, residual_blocks=int(out["residual_blocks"]), un
 
 def run(fp32, rows, cols, pts):
     env = dict(os.environ)
-    env.pop("OCHIP_RELAX_JACOBIAN_FP32", None)
+    env.pop("OCHIP_TEST_HOOKS", None)
     if fp32:
-        env["OCHIP_RELAX_JACOBIAN_FP32"] = "1"
+        env["OCHIP_TEST_HOOKS"] = "jacobian_fp32"
     r = subprocess.run([sys.executable, "-c", CHILD, str(rows), str(cols), str(pts)], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=1500)
     if r.returncode != 0:

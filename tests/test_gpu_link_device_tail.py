@@ -1,5 +1,5 @@
 """The link stage's device tail (ratio test, std::sort of the matches, PROSAC order, decompose, the edges' lists:
-csrc/match_sort.hip, std_sort.hip, ransac.hip) against the round-2 host route (OCHIP_LINK_HOST_SORT=1) on the inputs the
+csrc/match_sort.hip, std_sort.hip, ransac.hip) against the round-2 host route (OCHIP_TEST_HOOKS=host_sort) on the inputs the
 synthetic surveys never produce: images with no, one, two features, identical descriptors (every Hamming count 0: no
 quality for PROSAC), a single candidate in the other image (no second neighbour), pairs with no match at all - and a
 regular scene beside them.  Both routes must build the same graph, byte for byte."""
@@ -56,7 +56,7 @@ def test_degenerate_images_both_routes(monkeypatch):
     sigs = {}
     for route in ("device", "host"):
         if route == "host":
-            monkeypatch.setenv("OCHIP_LINK_HOST_SORT", "1")
+            monkeypatch.setenv("OCHIP_TEST_HOOKS", "host_sort")
         g = _graph(grid, _mutate)
         g.link(ctx)
         sigs[route] = _edge_signature(g)

@@ -150,7 +150,7 @@ def test_parity_holds_when_the_partials_do_not_fit():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, OCHIP_MATCH_SYM_CAP_MB="1", OCHIP_MATCH_MFMA="0")   # (the popcount kernels: see the last test)
+    env = dict(os.environ, OCHIP_MATCH_SYM_CAP_MB="1", OCHIP_TEST_HOOKS="popcount_match")   # (the popcount kernels: see the last test)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_match.py"), os.path.join(root, "tests", "test_gpu_link.py"),
                         "-x", "-q", "-m", "gpu", "-k", "not partials_do_not_fit and not popcount_kernels"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -174,13 +174,13 @@ def test_reference_sets_at_the_matrix_core_kernels_limit(ctx, n1, n2):
 
 
 def test_popcount_kernels_still_agree():
-    """OCHIP_MATCH_MFMA=0 sends every pair to the popcount kernels (the path of images with more than 8 192 features in
+    """OCHIP_TEST_HOOKS=popcount_match sends every pair to the popcount kernels (the path of images with more than 8 192 features in
     the matcher).  The switch is read once per process: this file's parity tests are re-run in a child with it set."""
     import os
     import subprocess
     import sys
 
-    env = dict(os.environ, OCHIP_MATCH_MFMA="0")
+    env = dict(os.environ, OCHIP_TEST_HOOKS="popcount_match")
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
                         "raw_top2 or mixed_batch or full_size or subset_parity"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

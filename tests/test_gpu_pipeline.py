@@ -140,7 +140,7 @@ def test_second_batch_links_against_the_first(monkeypatch):
 def test_device_tails_equal_the_host_tails(monkeypatch):
     """Round 3 moved the tail of extract_features (std::sort by response, suppression, records) and the tail of
     match_features_subset (ratio test, std::sort by distance) with PROSAC's order and the 40 px subsets to the device.  The round-2
-    host routes are still there (OCHIP_EXTRACT_TAIL=host, OCHIP_LINK_HOST_SORT=1, OCHIP_LINK_HOST_SUBSET=1): from the same pixels both must give the same feature lists
+    host routes are still there (OCHIP_TEST_HOOKS=host_tail,host_sort,host_subset): from the same pixels both must give the same feature lists
     and the same graph."""
     from opencalibration_amd import pipeline
 
@@ -152,9 +152,7 @@ def test_device_tails_equal_the_host_tails(monkeypatch):
     feats, sigs = {}, {}
     for mode in ("device", "host"):
         if mode == "host":
-            monkeypatch.setenv("OCHIP_EXTRACT_TAIL", "host")
-            monkeypatch.setenv("OCHIP_LINK_HOST_SORT", "1")
-            monkeypatch.setenv("OCHIP_LINK_HOST_SUBSET", "1")
+            monkeypatch.setenv("OCHIP_TEST_HOOKS", "host_tail,host_sort,host_subset")
         feats[mode] = host.extract_features_batch(ctx, images, 30000, device_shape=(n, h, w))
         g, _, _ = pipeline.run(ctx, grid, images, shape, start, relax=False)
         sigs[mode] = _edge_signature(g)

@@ -118,7 +118,7 @@ def test_graph_without_edges(ctx, oracle):
 
 
 def test_tile_factorisation_equals_the_launch_chain():
-    """OCHIP_CHOL_VERIFY=1 factors every reduced system twice - the one-launch tile Cholesky (workgroups handing tiles to
+    """OCHIP_TEST_HOOKS=chol_verify factors every reduced system twice - the one-launch tile Cholesky (workgroups handing tiles to
     each other) and the chain of dependent launches - and fails the solve when the forward solves differ by more than
     1e-7 relative (1e-9 until the diagonal tile was blocked: nearly singular 12-unknown systems differ by 2e-9).  Run in a child process (the switch is read once) over a plane problem with the augmented row inside
     the last diagonal tile (n % 64 != 0), one with n % 64 == 0, and a mesh problem with a dense tail."""
@@ -149,7 +149,7 @@ out = host.relax(ctx, pos, ori, model, feats, np.arange(len(pos)), ori, pk, host
 assert out["unknowns"] > 500 and out["iterations_total"] > 1, out
 print("verified", out["unknowns"])
 '''
-    env = dict(os.environ, OCHIP_CHOL_VERIFY="1")
+    env = dict(os.environ, OCHIP_TEST_HOOKS="chol_verify")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "verified" in r.stdout, r.stdout + r.stderr

@@ -21,7 +21,7 @@ def test_dissected_relax_equals_the_single_band(monkeypatch):
     out, mem = {}, {}
     for mode in ("dissected", "band"):
         if mode == "band":
-            monkeypatch.setenv("OCHIP_RELAX_DISSECT", "0")
+            monkeypatch.setenv("OCHIP_TEST_HOOKS", "no_dissect")
         ctx = capi.Context(0)
         g = host.Graph.from_synthetic(grid)
         g.link(ctx)
@@ -42,21 +42,22 @@ def test_dissected_relax_equals_the_single_band(monkeypatch):
     assert err < 5e-3, err
 
 
-@pytest.mark.parametrize("knobs", [{}, {"OCHIP_RELAX_DISSECT_G": "64"}, {"OCHIP_RELAX_DISSECT": "0"}],
+@pytest.mark.parametrize("knobs", [{}, {"OCHIP_RELAX_DISSECT_G": "64"}, {"OCHIP_TEST_HOOKS": "no_dissect"}],
                          ids=lambda k: "+".join("%s=%s" % kv for kv in k.items()) or "default")
 def test_tile_factorisation_equals_the_chain_under_the_dissection(knobs):
-    """OCHIP_CHOL_VERIFY=1 factors every system of the solve both ways (one launch of tiles / the launch chain) and fails
+    """OCHIP_TEST_HOOKS=chol_verify factors every system of the solve both ways (one launch of tiles / the launch chain) and fails
     the relax when the forward solves differ by more than 1e-7 relative; the knobs are read once per process, so every
     ordering (default regions, small regions, one band) runs in a process of its own.  (The kernel's round-3 A/B variants -
     unfused pairs, whole-tile operands, rank-1 diagonal tiles, plain summation order - lost and are gone.)"""
-    env = dict(os.environ, OCHIP_CHOL_VERIFY="1", OCHIP_RELAX_VERBOSE="1", **knobs)
+    env = dict(os.environ, OCHIP_VERBOSE="relax", **knobs)
+    env["OCHIP_TEST_HOOKS"] = ",".join(["chol_verify"] + ([knobs["OCHIP_TEST_HOOKS"]] if "OCHIP_TEST_HOOKS" in knobs else []))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probe_relax_dissect.py"), "16x20x512", "1"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "factorisation check" in r.stderr and "LM it/s" in r.stdout
     regions = [l for l in r.stderr.splitlines() if "regions" in l and "n=963" in l]
     assert regions
-    if knobs.get("OCHIP_RELAX_DISSECT") == "0":
+    if knobs.get("OCHIP_TEST_HOOKS") == "no_dissect":
         assert " 1 regions" in regions[0], regions
     else:
         assert " 1 regions" not in regions[0], regions
@@ -76,8 +77,8 @@ def test_back_substitution_variants_agree():
     """The backward substitution with its part of x in LDS or in HBM (the fallback for systems that do not fit), dissected
     and as one band: same LM trajectory."""
     base = _probe({})
-    hbm = _probe({"OCHIP_BACK_SOLVE_X_GLOBAL": "1"})
+    hbm = _probe({"OCHIP_TEST_HOOKS": "back_solve_x_global"})
     assert hbm[0] == base[0] and hbm[1] == base[1] and hbm[2] == base[2]        # same arithmetic: same bits
-    band = _probe({"OCHIP_RELAX_DISSECT": "0"})
+    band = _probe({"OCHIP_TEST_HOOKS": "no_dissect"})
     assert band[0] == base[0]
     assert abs(band[1] - base[1]) <= 1e-9 * abs(base[1]) and abs(band[2] - base[2]) <= 1e-9 * abs(base[2])
