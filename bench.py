@@ -607,6 +607,43 @@ class StrongRunner:
             acc["relax_lm_iterations"] = acc.get("relax_lm_iterations", 0.0) + res["relax"]["iterations_total"]
             acc["relaxes"] = acc.get("relaxes", 0) + 1
 
+    def _general_engine_sharded(self):
+        """(untimed, once, in a warm-up step) The flavour the reference's later pipeline states run - {ORIENTATION, GROUND_MESH},
+        pipeline.cpp:582-704 - as ONE group with its residual blocks over the ranks: the general engine (relax_general.hip)
+        behind the same exchange as the plane engine's.  The sharded survey leaves remote images with their 40 px subsets
+        only, so the mesh flavour (which reads the feature lists) runs on a small graph every rank builds identically from
+        synthetic features, and must reproduce the unsharded solve to the bit."""
+        proc = self.proc
+        try:
+            from opencalibration_amd import synth
+
+            grid = synth.make_grid(3, 5, feats=512, seed=17)
+            g = self.host.Graph.from_synthetic(grid)
+            g.link(self.ctx)
+            start = self.pipeline.perturbed_orientations(grid, 0.05, 3)
+            g.set_orientations(start)
+            plane = g.relax(self.rctx, start, self.host.relax_options("ORIENTATION", "GROUND_PLANE"))
+            seed = self.host.rebuild_mesh(grid.position, plane["surface"], minimal=True)
+            opts = self.host.relax_options("ORIENTATION", "GROUND_MESH")
+            g.set_orientations(plane["orientation"])
+            ref = g.relax(self.rctx, plane["orientation"], opts, 0.1, previous=seed)
+            g.set_orientations(plane["orientation"])
+            t2 = time.perf_counter()
+            got = g.relax(self.rctx, plane["orientation"], opts, 0.1, previous=seed, shard=(proc.rank, proc.world, self.exchange))
+            self.rctx.synchronize()
+            dt = time.perf_counter() - t2
+            g.close()
+            same = bool(np.array_equal(ref["orientation"], got["orientation"]) and ref["final_cost"] == got["final_cost"] and
+                        ref["iterations_total"] == got["iterations_total"])
+            errm = self.pipeline.orientation_errors(got["orientation"], grid.orientation)
+            return {"flavour": "ORIENTATION + GROUND_MESH, one group of 15 cameras built identically on every rank, residual blocks "
+                               "over the ranks", "ranks": proc.world, "seconds": round(dt, 4),
+                    "lm_iterations": int(got["iterations_total"]), "residual_blocks": int(got["residual_blocks"]),
+                    "equals_the_unsharded_solve_bit_for_bit": same,
+                    "median_orientation_error_rad_vs_truth": float(np.median(errm))}
+        except Exception as ex:
+            return {"error": repr(ex)}
+
     def _survey(self, owner):
         """load + link of one survey over the ranks: (graph, report, seconds, CPU seconds)"""
         _, h, w = self.shape
@@ -647,6 +684,8 @@ class StrongRunner:
             self.rctx.synchronize()
             t["relax"] = time.perf_counter() - t1
             res["relax"] = rel
+            if acc is None and "general_engine_sharded" not in self.last:
+                self.last["general_engine_sharded"] = self._general_engine_sharded()
             g.close()
             self.pending = (threading.Thread(target=lambda: None), res, t)
             self.pending[0].start()
@@ -711,6 +750,7 @@ def strong_report(runner, proc, args, cfg, hot_max, acc):
         "seconds_per_step_per_rank": per_rank,
         "exchanges_per_step": 0 if proc.world == 1 else 2,
         "bytes_gathered_per_step": per_rank[0].get("bytes_gathered", 0),
+        **({"general_engine_sharded": runner.last["general_engine_sharded"]} if "general_engine_sharded" in runner.last else {}),
     }
 
 

@@ -45,12 +45,16 @@ def test_bench_launches_its_ranks_strong(relax):
     ss = line["strong_scaling"]
     assert len(ss["seconds_per_step_per_rank"]) == 2 and ss["bytes_gathered_per_step"] > 0
     assert line["relax"]["median_orientation_error_rad_vs_truth"] < 1e-3
+    if relax == "sharded":  # the general engine (mesh flavour) ran behind the same exchange, once, in the warm-up step
+        ge = ss["general_engine_sharded"]
+        assert "error" not in ge, ge
+        assert ge["ranks"] == 2 and ge["lm_iterations"] > 0 and ge["equals_the_unsharded_solve_bit_for_bit"]
 
 
 def test_bench_weak_line_carries_the_strong_section():
     """`bench.py --gpus 2` (the scaling run's command): one weak line, and beside it the strong mode run by a child process per
     rank (so that nothing it does can take the headline with it)."""
-    env = dict(os.environ, OCHIP_BENCH_BACKEND="gloo", OCHIP_HOST_THREADS="8", OCHIP_BENCH_STRONG_STEPS="2")
+    env = dict(os.environ, OCHIP_BENCH_BACKEND="gloo", OCHIP_HOST_THREADS="8")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C2", "--steps", "2", "--warmup", "1"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
