@@ -608,6 +608,20 @@ extern "C"
     void ochip_dense_index_destroy(ochip_dense_index *ix);
     int ochip_dense_match(ochip_dense_index *ix, const ochip_dense_query *queries, uint64_t n_queries, double radius,
                           ochip_dense_result *out);
+    /* densifyMesh after the mesh intersections, whole survey, on the device (replaces the rest of the per-feature loop of
+     * src/dense/dense_stereo.cpp:174-297 - the k nearest cameras of the hit point, its projection into each, the disc
+     * search, the accept rule - and the union of the matched measurements; ochip_dense_match stays for callers that
+     * build their queries themselves).
+     * cams17 [n_images][17]: position (3), orientation.inverse() (4, xyzw), model10 (f ppx ppy k1 k2 k3 p1 p2 cols rows);
+     * id_of_pos [total]: the reference's measurement id (image offset + dense feature number) of every index position;
+     * hits3 [total][3] by index position: where the feature's ray meets the mesh, x = NaN: nowhere (:196-207).
+     * max_candidates = MAX_CANDIDATE_IMAGES (10), descriptor_bits = 486, ratio = 0.85, max_abs = 0.35 (:51-56).
+     * root_out [total] by measurement id: the smallest member of the measurement's track, 0xFFFFFFFF = unmatched;
+     * counts2: queries issued, matches accepted; slot_dst_out (may be NULL) [total][11]: per feature and candidate in
+     * nearest-camera order the accepted match's measurement id or 0xFFFFFFFF (tests: the reference's match order). */
+    int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t *id_of_pos, const double *hits3, double radius,
+                         uint32_t max_candidates, uint32_t descriptor_bits, double ratio, double max_abs, uint32_t *root_out,
+                         uint64_t *counts2, uint32_t *slot_dst_out);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,9 @@
 // follow each other hit the same cells (the host emits them along the source image's Hilbert walk).
 #include "ctx.hpp"
 
+#include <algorithm>
 #include <new>
+#include <vector>
 
 namespace
 {
@@ -58,25 +60,19 @@ __device__ __forceinline__ lane_state merge(const lane_state &a, const lane_stat
     return r;
 }
 
-__global__ __launch_bounds__(256) void dense_match_kernel(const dense_image_meta *__restrict__ meta, const uint64_t *__restrict__ desc,
-                                                          const double2 *__restrict__ loc, const uint32_t *__restrict__ cell_start,
-                                                          const ochip_dense_query *__restrict__ queries, uint64_t n_queries,
-                                                          double radius_sq, double cell_size, ochip_dense_result *__restrict__ out)
+// the search of one query by one wavefront: every lane ends with the merged (best, second, index, count)
+__device__ __forceinline__ lane_state dense_search(const dense_image_meta &m, const uint64_t *__restrict__ desc, const double2 *__restrict__ loc,
+                                                   const uint32_t *__restrict__ cell_start, uint32_t src_feature, double qx, double qy,
+                                                   double radius_sq, double cell_size, int lane)
 {
-    const uint64_t qi = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= n_queries)
-        return;
-    const int lane = threadIdx.x & 63;
-    const ochip_dense_query q = queries[qi];
-    const dense_image_meta m = meta[q.cand_image];
     uint64_t qd[8];
     {
-        const uint64_t *p = desc + 8 * (size_t)q.src_feature;
+        const uint64_t *p = desc + 8 * (size_t)src_feature;
 #pragma unroll
         for (int w = 0; w < 8; w++)
             qd[w] = p[w];
     }
-    const int cx = (int)floor((q.px - m.ox) / cell_size), cy = (int)floor((q.py - m.oy) / cell_size);
+    const int cx = (int)floor((qx - m.ox) / cell_size), cy = (int)floor((qy - m.oy) / cell_size);
     lane_state s{NONE_COUNT, NONE_COUNT, 0xFFFFFFFFu, 0u};
     const int c0 = max(cx - 1, 0), c1 = min(cx + 1, m.ncx - 1);
     if (c0 <= c1)
@@ -87,7 +83,7 @@ __global__ __launch_bounds__(256) void dense_match_kernel(const dense_image_meta
             for (uint32_t k = begin + lane; k < end; k += 64)
             {
                 const double2 p = loc[m.feat_base + k];
-                const double dx = p.x - q.px, dy = p.y - q.py;
+                const double dx = p.x - qx, dy = p.y - qy;
                 if (!(dx * dx + dy * dy < radius_sq))
                     continue;
                 const uint64_t *cd = desc + 8 * (m.feat_base + k);
@@ -118,6 +114,20 @@ __global__ __launch_bounds__(256) void dense_match_kernel(const dense_image_meta
         o.count = __shfl_xor(s.count, off);
         s = merge(s, o);
     }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void dense_match_kernel(const dense_image_meta *__restrict__ meta, const uint64_t *__restrict__ desc,
+                                                          const double2 *__restrict__ loc, const uint32_t *__restrict__ cell_start,
+                                                          const ochip_dense_query *__restrict__ queries, uint64_t n_queries,
+                                                          double radius_sq, double cell_size, ochip_dense_result *__restrict__ out)
+{
+    const uint64_t qi = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= n_queries)
+        return;
+    const int lane = threadIdx.x & 63;
+    const ochip_dense_query q = queries[qi];
+    const lane_state s = dense_search(meta[q.cand_image], desc, loc, cell_start, q.src_feature, q.px, q.py, radius_sq, cell_size, lane);
     if (lane == 0)
     {
         ochip_dense_result r;
@@ -127,6 +137,228 @@ __global__ __launch_bounds__(256) void dense_match_kernel(const dense_image_meta
         r.nearby = s.count;
         out[qi] = r;
     }
+}
+
+// ---- densifyMesh after the mesh intersections, on the device (ochip_dense_link) ------------------------------------
+// Per dense feature with a hit point: the 11 nearest cameras (camera_tree.search(point, max, k + 1), dense_stereo.cpp:
+// 212-216: squared distance, then index), the point projected into each but the source image (image_from_3d, :225-236),
+// one query slot per candidate inside its image; per slot: the disc search above, the accept rule of :278-283 in fp64 as
+// the reference writes it, and the union of the two measurements (:285-297) in a lock-free union-find whose partition does
+// not depend on the order of the unions (the larger root goes under the smaller).
+constexpr int DENSE_K = 11; // MAX_CANDIDATE_IMAGES + 1 (:53, :213)
+struct dense_cam
+{
+    double pos[3], q_inv[4], model[10]; // f ppx ppy k1 k2 k3 p1 p2 cols rows
+};
+
+struct dv3
+{
+    double x, y, z;
+};
+__device__ __forceinline__ dv3 dcross(const dv3 &a, const dv3 &b)
+{
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// Eigen QuaternionBase::_transformVector (host: relax_util.hpp rotate)
+__device__ __forceinline__ dv3 drotate(const double *q, const dv3 &v)
+{
+    const dv3 qv{q[0], q[1], q[2]};
+    dv3 uv = dcross(qv, v);
+    uv = dv3{uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+    const dv3 c = dcross(qv, uv);
+    return {(v.x + uv.x * q[3]) + c.x, (v.y + uv.y * q[3]) + c.y, (v.z + uv.z * q[3]) + c.z};
+}
+// image_from_3d(point, model, position, orientation): host dense_stereo.cpp project() + invert_distortion.cpp image_from_3d
+__device__ __forceinline__ void dense_project(const dv3 &point, const dense_cam &c, double px[2])
+{
+    const dv3 rel{point.x - c.pos[0], point.y - c.pos[1], point.z - c.pos[2]};
+    const dv3 r = drotate(c.q_inv, rel);
+    const double z = r.z < 1e-3 ? 1e-3 : r.z;
+    const double p[2] = {r.x / z, r.y / z};
+    double r2[3];
+    r2[0] = p[0] * p[0] + p[1] * p[1];
+    r2[1] = r2[0] * r2[0];
+    r2[2] = r2[1] * r2[0];
+    const double *k = c.model + 3, *t = c.model + 6;
+    const double radial = k[0] * r2[0] + k[1] * r2[1] + k[2] * r2[2];
+    const double prod = p[0] * p[1];
+    for (int i = 0; i < 2; i++)
+    {
+        const double d = (1.0 + radial) * p[i] + 2.0 * prod * t[i] + t[1 - i] * (r2[0] + 2.0 * p[i] * p[i]);
+        px[i] = d * c.model[0] + c.model[1 + i];
+    }
+}
+
+// one thread per dense feature of the batch's images (blockIdx.y = image of the batch)
+__global__ __launch_bounds__(256) void dense_predict_kernel(const dense_image_meta *__restrict__ meta, const dense_cam *__restrict__ cams,
+                                                            uint32_t n_images, uint32_t first_image, const double *__restrict__ hits,
+                                                            uint64_t batch_feat_base, uint32_t *__restrict__ cand_img,
+                                                            double2 *__restrict__ cand_px, unsigned long long *__restrict__ n_queries)
+{
+    const uint32_t src = first_image + blockIdx.y;
+    const uint64_t f0 = meta[src].feat_base, n = meta[src + 1].feat_base - f0; // (meta has n_images + 1 entries)
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned int emitted = 0;
+    if (k < n)
+    {
+        const uint64_t f = f0 + k, slot0 = (f - batch_feat_base) * DENSE_K;
+        const dv3 hit{hits[3 * f], hits[3 * f + 1], hits[3 * f + 2]};
+        int used = 0;
+        if (!isnan(hit.x))
+        {
+            double bd[DENSE_K];
+            uint32_t bc[DENSE_K];
+#pragma unroll
+            for (int s = 0; s < DENSE_K; s++)
+            {
+                bd[s] = INFINITY;
+                bc[s] = 0xFFFFFFFFu;
+            }
+            for (uint32_t c = 0; c < n_images; c++)
+            {
+                const double dx = cams[c].pos[0] - hit.x, dy = cams[c].pos[1] - hit.y, dz = cams[c].pos[2] - hit.z;
+                double d = dx * dx + dy * dy + dz * dz;
+                uint32_t id = c;
+                if (!(d < bd[DENSE_K - 1] || (d == bd[DENSE_K - 1] && id < bc[DENSE_K - 1])))
+                    continue;
+#pragma unroll
+                for (int s = 0; s < DENSE_K; s++) // sorted insertion: the displaced entries move up, the last one falls off
+                {
+                    const bool lt = d < bd[s] || (d == bd[s] && id < bc[s]);
+                    const double td = lt ? bd[s] : d;
+                    const uint32_t tc = lt ? bc[s] : id;
+                    bd[s] = lt ? d : bd[s];
+                    bc[s] = lt ? id : bc[s];
+                    d = td;
+                    id = tc;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < DENSE_K; s++)
+            {
+                const uint32_t c = bc[s];
+                if (c == 0xFFFFFFFFu || c == src)
+                    continue;
+                double px[2];
+                const dense_cam cam = cams[c];
+                dense_project(hit, cam, px);
+                if (px[0] < 0 || px[0] >= cam.model[8] || px[1] < 0 || px[1] >= cam.model[9])
+                    continue;
+                cand_img[slot0 + used] = c;
+                cand_px[slot0 + used] = make_double2(px[0], px[1]);
+                used++;
+            }
+        }
+        emitted = (unsigned int)used;
+        for (int s = used; s < DENSE_K; s++)
+            cand_img[slot0 + s] = 0xFFFFFFFFu;
+    }
+    // the batch's number of queries: one atomic per workgroup
+    __shared__ unsigned int wsum[4];
+    for (int off = 32; off >= 1; off >>= 1)
+        emitted += (unsigned int)__shfl_xor((int)emitted, off);
+    if ((threadIdx.x & 63) == 0)
+        wsum[threadIdx.x >> 6] = emitted;
+    __syncthreads();
+    if (threadIdx.x == 0 && wsum[0] + wsum[1] + wsum[2] + wsum[3])
+        atomicAdd(n_queries, (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
+}
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
+{
+    while (true)
+    {
+        uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x)
+            return x;
+        const uint32_t gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp != p)
+            atomicCAS(&parent[x], p, gp); // path halving; losing the race is harmless
+        x = p;
+    }
+}
+__device__ __forceinline__ void uf_unite(uint32_t *parent, uint32_t a, uint32_t b)
+{
+    while (true)
+    {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b)
+            return;
+        if (a < b)
+        {
+            const uint32_t t = a;
+            a = b;
+            b = t;
+        }
+        if (atomicCAS(&parent[a], a, b) == a) // the larger root goes under the smaller: a component's root is its smallest member
+            return;
+    }
+}
+
+// one wavefront per SLOTS_PER_WAVE query slots: search, accept, unite
+constexpr int SLOTS_PER_WAVE = 8;
+__global__ __launch_bounds__(256) void dense_link_kernel(const dense_image_meta *__restrict__ meta, const uint64_t *__restrict__ desc,
+                                                         const double2 *__restrict__ loc, const uint32_t *__restrict__ cell_start,
+                                                         const uint32_t *__restrict__ cand_img, const double2 *__restrict__ cand_px,
+                                                         uint64_t n_slots, uint64_t batch_feat_base, const uint32_t *__restrict__ id_of_pos,
+                                                         double radius_sq, double cell_size, double inv_bits, double ratio, double max_abs,
+                                                         uint32_t *__restrict__ parent, uint8_t *__restrict__ matched,
+                                                         uint32_t *__restrict__ slot_dst, unsigned long long *__restrict__ n_matches)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    unsigned int accepted = 0;
+    for (int j = 0; j < SLOTS_PER_WAVE; j++)
+    {
+        const uint64_t slot = w * SLOTS_PER_WAVE + j;
+        if (slot >= n_slots)
+            break;
+        const uint32_t cand = cand_img[slot]; // (wave-uniform)
+        uint32_t dst = 0xFFFFFFFFu;
+        if (cand != 0xFFFFFFFFu)
+        {
+            const uint32_t src_feature = (uint32_t)(batch_feat_base + slot / DENSE_K);
+            const double2 q = cand_px[slot];
+            const dense_image_meta m = meta[cand];
+            const lane_state s = dense_search(m, desc, loc, cell_start, src_feature, q.x, q.y, radius_sq, cell_size, lane);
+            if (lane == 0 && s.count != 0)
+            {
+                const double best_dist = s.best * inv_bits;
+                const double second_best_dist = s.second == NONE_COUNT ? INFINITY : s.second * inv_bits;
+                const bool good = s.count >= 2 ? best_dist < ratio * second_best_dist : best_dist < max_abs;
+                if (good)
+                {
+                    const uint32_t src_id = id_of_pos[src_feature];
+                    dst = id_of_pos[m.feat_base + s.idx];
+                    matched[src_id] = 1;
+                    matched[dst] = 1;
+                    uf_unite(parent, src_id, dst);
+                    accepted++;
+                }
+            }
+        }
+        if (slot_dst && lane == 0)
+            slot_dst[slot] = dst;
+    }
+    if (lane == 0 && accepted)
+        atomicAdd(n_matches, (unsigned long long)accepted);
+}
+
+__global__ void dense_uf_init_kernel(uint32_t *parent, uint8_t *matched, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+        parent[i] = (uint32_t)i;
+        matched[i] = 0;
+    }
+}
+__global__ void dense_uf_roots_kernel(uint32_t *parent, const uint8_t *matched, uint64_t n, uint32_t *root)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        root[i] = matched[i] ? uf_find(parent, (uint32_t)i) : 0xFFFFFFFFu;
 }
 
 } // namespace
@@ -161,7 +393,8 @@ int ochip_dense_index_create(ochip_ctx *ctx, uint32_t n_images, const uint64_t *
     ix->n_images = n_images;
     ix->total_features = feat_off[n_images];
     ix->cell_size = cell_size;
-    std::vector<dense_image_meta> meta(n_images ? n_images : 1);
+    std::vector<dense_image_meta> meta((size_t)n_images + 1); // (one more: where the last image's features end)
+    meta[n_images] = dense_image_meta{feat_off[n_images], cell_off[n_images], 0, 0, 0.0, 0.0};
     for (uint32_t i = 0; i < n_images; i++)
     {
         meta[i].feat_base = feat_off[i];
@@ -263,6 +496,114 @@ int ochip_dense_match(ochip_dense_index *ix, const ochip_dense_query *queries, u
     if (dr)
         ochip_pool_put(ctx, dr, got_r);
     return rc;
+}
+
+int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t *id_of_pos, const double *hits3, double radius,
+                     uint32_t max_candidates, uint32_t descriptor_bits, double ratio, double max_abs, uint32_t *root_out,
+                     uint64_t *counts2, uint32_t *slot_dst_out)
+{
+    if (!ix || !cams17 || !id_of_pos || !hits3 || !root_out || !counts2)
+        return OCHIP_EINVAL;
+    ochip_ctx *ctx = ix->ctx;
+    counts2[0] = counts2[1] = 0;
+    if (!(radius > 0) || !(radius < ix->cell_size))
+        return ochip_fail(ctx, OCHIP_EINVAL, "ochip_dense_link: the search radius %g must be below the index's cell size %g", radius,
+                          ix->cell_size);
+    if (max_candidates + 1 != (uint32_t)DENSE_K || descriptor_bits == 0)
+        return ochip_fail(ctx, OCHIP_EINVAL, "ochip_dense_link: built for %d candidate images per feature", DENSE_K - 1);
+    const uint64_t total = ix->total_features;
+    const uint32_t n_images = ix->n_images;
+    if (total == 0 || n_images == 0)
+        return OCHIP_OK;
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<std::pair<void *, size_t>> blocks;
+    int rc = OCHIP_OK;
+    auto get = [&](size_t bytes) -> void * {
+        size_t got = 0;
+        void *d = ochip_pool_get(ctx, bytes ? bytes : 16, &got);
+        if (!d)
+            rc = ochip_fail(ctx, OCHIP_ENOMEM, "ochip_dense_link: device allocation of %zu bytes failed", bytes);
+        else
+            blocks.emplace_back(d, got);
+        return d;
+    };
+    auto done = [&](int code) {
+        (void)ochip_stream_wait(ctx, st);
+        for (auto &b : blocks)
+            ochip_pool_put(ctx, b.first, b.second);
+        return code;
+    };
+    // batches of source images: bounded slot arrays (the reference walks its images in batches of OpenMP tasks too)
+    std::vector<uint64_t> feat_base(n_images + 1);
+    {
+        std::vector<dense_image_meta> meta((size_t)n_images + 1);
+        if (hipMemcpyAsync(meta.data(), ix->meta, meta.size() * sizeof(dense_image_meta), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            ochip_stream_wait(ctx, st) != hipSuccess)
+            return ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_link: reading the index failed");
+        for (uint32_t i = 0; i <= n_images; i++)
+            feat_base[i] = meta[i].feat_base;
+    }
+    const uint32_t BATCH = 64;
+    uint64_t max_batch_feats = 0, max_image_feats = 0;
+    for (uint32_t b0 = 0; b0 < n_images; b0 += BATCH)
+        max_batch_feats = std::max(max_batch_feats, feat_base[std::min(n_images, b0 + BATCH)] - feat_base[b0]);
+    for (uint32_t i = 0; i < n_images; i++)
+        max_image_feats = std::max(max_image_feats, feat_base[i + 1] - feat_base[i]);
+    dense_cam *cams = (dense_cam *)get((size_t)n_images * sizeof(dense_cam));
+    uint32_t *ids = (uint32_t *)get(total * 4);
+    double *hits = (double *)get(total * 24);
+    uint32_t *parent = (uint32_t *)get(total * 4), *root = (uint32_t *)get(total * 4);
+    uint8_t *matched = (uint8_t *)get(total);
+    uint32_t *cand_img = (uint32_t *)get(max_batch_feats * DENSE_K * 4);
+    double2 *cand_px = (double2 *)get(max_batch_feats * DENSE_K * 16);
+    uint32_t *slot_dst = slot_dst_out ? (uint32_t *)get(max_batch_feats * DENSE_K * 4) : nullptr;
+    unsigned long long *counters = (unsigned long long *)get(16);
+    if (rc != OCHIP_OK)
+        return done(rc);
+    static_assert(sizeof(dense_cam) == 17 * sizeof(double), "cams17 is the kernel's camera record");
+    if (hipMemcpyAsync(cams, cams17, (size_t)n_images * sizeof(dense_cam), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(ids, id_of_pos, total * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(hits, hits3, total * 24, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(counters, 0, 16, st) != hipSuccess)
+        return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_link: upload failed"));
+    hipLaunchKernelGGL(dense_uf_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, parent, matched, total);
+    const double inv_bits = 1.0 / (double)descriptor_bits;
+    for (uint32_t b0 = 0; b0 < n_images; b0 += BATCH)
+    {
+        const uint32_t b1 = std::min(n_images, b0 + BATCH);
+        const uint64_t base = feat_base[b0], feats = feat_base[b1] - base, slots = feats * DENSE_K;
+        if (feats == 0)
+            continue;
+        uint64_t widest = 0;
+        for (uint32_t i = b0; i < b1; i++)
+            widest = std::max(widest, feat_base[i + 1] - feat_base[i]);
+        hipLaunchKernelGGL(dense_predict_kernel, dim3((unsigned)((widest + 255) / 256), b1 - b0), dim3(256), 0, st, ix->meta, cams, n_images,
+                           b0, hits, base, cand_img, cand_px, counters);
+        hipEvent_t e0, e1;
+        ochip_prof_begin(ctx, OCHIP_K_DENSE, &e0, &e1);
+        const uint64_t waves = (slots + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE;
+        hipLaunchKernelGGL(dense_link_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ix->meta, ix->desc, ix->loc, ix->cell_start,
+                           cand_img, cand_px, slots, base, ids, radius * radius, ix->cell_size, inv_bits, ratio, max_abs, parent, matched,
+                           slot_dst, counters + 1);
+        ochip_prof_end(ctx, OCHIP_K_DENSE, e0, e1);
+        if (hipGetLastError() != hipSuccess)
+            return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_link: launch failed"));
+        if (slot_dst_out)
+        {
+            if (hipMemcpyAsync(slot_dst_out + base * DENSE_K, slot_dst, slots * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                ochip_stream_wait(ctx, st) != hipSuccess)
+                return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_link: reading the slots failed"));
+        }
+    }
+    hipLaunchKernelGGL(dense_uf_roots_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, parent, matched, total, root);
+    unsigned long long host_counts[2] = {0, 0};
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(root_out, root, total * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(host_counts, counters, 16, hipMemcpyDeviceToHost, st) != hipSuccess || ochip_stream_wait(ctx, st) != hipSuccess)
+        return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_link: %s", hipGetErrorString(hipGetLastError())));
+    counts2[0] = host_counts[0];
+    counts2[1] = host_counts[1];
+    return done(OCHIP_OK);
 }
 
 } // extern "C"

@@ -5,7 +5,6 @@
 #include "triangle_walker.hpp"
 
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -25,101 +24,13 @@ constexpr int MAX_CANDIDATE_IMAGES = 10;
 constexpr double MAX_ABSOLUTE_DESCRIPTOR_DISTANCE = 0.35;
 constexpr double MAX_REPROJECTION_ERROR_PIXELS = 8.0;
 constexpr double CELL_SIZE = SEARCH_RADIUS_PIXELS + 1.0; // grid of the device index: a disc touches at most 3 x 3 cells
+// (camera_tree.searcher().search(point, max, k), jk::KDTree 3-D - the k cameras nearest to a hit point, nearest first, ties
+// to the lower index - is a scan over the cameras inside dense_predict_kernel, csrc/dense.hip)
 
 double seconds_since(const std::chrono::steady_clock::time_point &t0)
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
-
-// camera_tree.searcher().search(point, max, k) (jk::KDTree, 3-D): the k cameras nearest to a point, nearest first.
-// Exact: cameras binned on an x-y grid, rings of cells around the query until the k-th best squared distance is below
-// the squared x-y distance every camera of an unvisited ring must have.  Ties (measure zero) go to the camera added first.
-class CameraGrid
-{
-  public:
-    void build(const std::vector<std::array<double, 3>> &positions)
-    {
-        _pos = &positions;
-        const size_t n = positions.size();
-        _x0 = _y0 = INFINITY;
-        double x1 = -INFINITY, y1 = -INFINITY;
-        for (const auto &p : positions)
-        {
-            _x0 = std::min(_x0, p[0]), _y0 = std::min(_y0, p[1]);
-            x1 = std::max(x1, p[0]), y1 = std::max(y1, p[1]);
-        }
-        const double area = std::max((x1 - _x0) * (y1 - _y0), 1e-12);
-        _cell = std::max(std::max(std::sqrt(area / std::max<size_t>(n, 1)), std::max(x1 - _x0, y1 - _y0) / 4000.0), 1e-6);
-        _nx = (long)((x1 - _x0) / _cell) + 1;
-        _ny = (long)((y1 - _y0) / _cell) + 1;
-        _start.assign((size_t)_nx * _ny + 1, 0);
-        std::vector<uint32_t> cell_of(n);
-        for (size_t i = 0; i < n; i++)
-        {
-            const long cx = std::min(_nx - 1, (long)((positions[i][0] - _x0) / _cell)), cy = std::min(_ny - 1, (long)((positions[i][1] - _y0) / _cell));
-            cell_of[i] = (uint32_t)(cy * _nx + cx);
-            _start[cell_of[i] + 1]++;
-        }
-        for (size_t c = 0; c < (size_t)_nx * _ny; c++)
-            _start[c + 1] += _start[c];
-        _items.resize(n);
-        std::vector<uint32_t> fill(_start.begin(), _start.end() - 1);
-        for (size_t i = 0; i < n; i++)
-            _items[fill[cell_of[i]]++] = (uint32_t)i;
-    }
-    // out: up to k (squared distance, camera) pairs, ascending
-    void nearest(const v3 &p, size_t k, std::vector<std::pair<double, uint32_t>> &out) const
-    {
-        out.clear();
-        const long cx = (long)std::floor((p.x - _x0) / _cell), cy = (long)std::floor((p.y - _y0) / _cell);
-        const long far = std::max(std::max(std::labs(cx), std::labs(cx - (_nx - 1))), std::max(std::labs(cy), std::labs(cy - (_ny - 1))));
-        for (long r = 0; r <= far; r++)
-        {
-            auto visit = [&](long x, long y) {
-                if (x < 0 || y < 0 || x >= _nx || y >= _ny)
-                    return;
-                const size_t c = (size_t)(y * _nx + x);
-                for (uint32_t it = _start[c]; it < _start[c + 1]; it++)
-                {
-                    const uint32_t cam = _items[it];
-                    const auto &q = (*_pos)[cam];
-                    const double dx = q[0] - p.x, dy = q[1] - p.y, dz = q[2] - p.z;
-                    const std::pair<double, uint32_t> e{dx * dx + dy * dy + dz * dz, cam};
-                    if (out.size() < k)
-                        out.insert(std::upper_bound(out.begin(), out.end(), e), e);
-                    else if (e < out.back())
-                    {
-                        out.pop_back();
-                        out.insert(std::upper_bound(out.begin(), out.end(), e), e);
-                    }
-                }
-            };
-            if (r == 0)
-                visit(cx, cy);
-            else
-            {
-                for (long x = std::max(0L, cx - r); x <= std::min(_nx - 1, cx + r); x++) // the ring's two rows
-                {
-                    visit(x, cy - r);
-                    visit(x, cy + r);
-                }
-                for (long y = std::max(0L, cy - r + 1); y <= std::min(_ny - 1, cy + r - 1); y++) // and two columns
-                {
-                    visit(cx - r, y);
-                    visit(cx + r, y);
-                }
-            }
-            if (out.size() >= k && out.back().first < (double)r * _cell * (double)r * _cell)
-                break;
-        }
-    }
-
-  private:
-    const std::vector<std::array<double, 3>> *_pos = nullptr;
-    double _x0 = 0, _y0 = 0, _cell = 1;
-    long _nx = 1, _ny = 1;
-    std::vector<uint32_t> _start, _items;
-};
 
 struct DenseImage
 {
@@ -289,187 +200,109 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     std::vector<double>().swap(loc2);
     st.index_seconds = seconds_since(t0);
 
-    std::vector<std::array<double, 3>> cam_pos(n_img);
-    for (size_t i = 0; i < n_img; i++)
-        cam_pos[i] = {images[i].img->position[0], images[i].img->position[1], images[i].img->position[2]};
-    CameraGrid camera_grid;
-    camera_grid.build(cam_pos);
-
     const MeshGraph &mesh = surfaces[0].mesh;
-    // union-find over the measurements, lock-free: the larger root goes under the smaller one, so a component's root is its
-    // smallest member and the partition does not depend on the order of the unions (the reference unites under a mutex
-    // in whatever order its OpenMP threads finish; only the partition reaches the result)
-    std::unique_ptr<std::atomic<uint32_t>[]> parent(new std::atomic<uint32_t>[std::max<size_t>(total, 1)]);
-    std::unique_ptr<std::atomic<uint8_t>[]> matched(new std::atomic<uint8_t>[std::max<size_t>(total, 1)]);
-#pragma omp parallel for schedule(static)
-    for (size_t i = 0; i < total; i++)
-    {
-        parent[i].store((uint32_t)i, std::memory_order_relaxed);
-        matched[i].store(0, std::memory_order_relaxed);
-    }
-    auto find = [&](uint32_t x) {
-        while (true)
-        {
-            uint32_t p = parent[x].load(std::memory_order_relaxed);
-            if (p == x)
-                return x;
-            const uint32_t gp = parent[p].load(std::memory_order_relaxed);
-            if (gp != p)
-                parent[x].compare_exchange_weak(p, gp, std::memory_order_relaxed);
-            x = p;
-        }
-    };
-    auto unite = [&](uint32_t a, uint32_t b) {
-        matched[a].store(1, std::memory_order_relaxed);
-        matched[b].store(1, std::memory_order_relaxed);
-        while (true)
-        {
-            a = find(a);
-            b = find(b);
-            if (a == b)
-                return;
-            if (a < b)
-                std::swap(a, b);
-            uint32_t expected = a;
-            if (parent[a].compare_exchange_strong(expected, b, std::memory_order_relaxed))
-                return;
-        }
-    };
-    bool device_failed = false;
-    // batches of source images: rays, mesh intersections and predictions on the host threads, the descriptor search of
-    // the whole batch in one device call, the accept decisions and the union-find on the host
-    const size_t BATCH = 64;
-    for (size_t b0 = 0; b0 < n_img && !device_failed; b0 += BATCH)
-    {
-        const size_t b1 = std::min(n_img, b0 + BATCH);
-        auto t1 = std::chrono::steady_clock::now();
-        std::vector<std::vector<ochip_dense_query>> per_image(b1 - b0);
+    // ---- where every dense feature's ray meets the mesh (:174-207): the walker starts from the triangle of the previous
+    //      feature of the image's Hilbert walk (hilbertFeatureOrder, :24-49), so an image is one sequential task
+    auto t1 = std::chrono::steady_clock::now();
+    std::unique_ptr<double[]> hits(new double[3 * std::max<size_t>(total, 1)]);
+    std::vector<uint32_t> id_of_pos(total);
+    std::vector<std::vector<uint32_t>> walk_order(matches_out ? n_img : 0); // dense feature numbers in Hilbert order (tests only)
 #pragma omp parallel for schedule(dynamic, 1)
-        for (size_t si = b0; si < b1; si++)
+    for (size_t si = 0; si < n_img; si++)
+    {
+        const DenseImage &src = images[si];
+        const image &img = *src.img;
+        for (size_t k = 0; k < src.n_dense; k++)
+        {
+            id_of_pos[src.feat_base + src.dense_to_sorted[k]] = (uint32_t)(src.offset + k);
+            hits[3 * (src.feat_base + k)] = NAN;
+        }
+        TriangleWalker walker;
+        if (!walker.init(mesh))
+            continue;
+        const int w = (int)img.model->pixels_cols, h = (int)img.model->pixels_rows;
+        int order = 1;
+        while (order < std::max(w, h))
+            order *= 2;
+        std::vector<std::pair<uint32_t, size_t>> indexed(src.n_dense);
+        for (size_t k = 0; k < src.n_dense; k++)
+        {
+            const double *l = img.features[img.num_sparse_features + k].location;
+            indexed[k] = {hilbert_xy2d(order, std::clamp((int)l[0], 0, w - 1), std::clamp((int)l[1], 0, h - 1)), k};
+        }
+        std::sort(indexed.begin(), indexed.end());
+        if (matches_out)
+        {
+            walk_order[si].resize(src.n_dense);
+            for (size_t i = 0; i < src.n_dense; i++)
+                walk_order[si][i] = (uint32_t)indexed[i].second;
+        }
+        const v3 origin{img.position[0], img.position[1], img.position[2]};
+        for (const auto &entry : indexed)
+        {
+            const size_t k = entry.second;
+            double ray[3];
+            image_to_3d(img.features[img.num_sparse_features + k].location, *img.model, ray);
+            const v3 dir = rotate(img.orientation, v3{ray[0], ray[1], ray[2]});
+            if (walker.find(dir, origin) != TriangleWalker::INTERSECTION)
+                continue;
+            double *o = &hits[3 * (src.feat_base + src.dense_to_sorted[k])];
+            o[0] = walker.hit.x, o[1] = walker.hit.y, o[2] = walker.hit.z;
+            if (std::isnan(o[0])) // (cannot happen after INTERSECTION; NaN in x is the device's "no hit")
+                o[0] = NAN;
+        }
+    }
+    st.rays_seconds = seconds_since(t1);
+
+    // ---- nearest cameras, predictions, descriptor search, accept rule and the unions: the device (ochip_dense_link)
+    t1 = std::chrono::steady_clock::now();
+    std::vector<double> cams17(17 * n_img);
+    for (size_t i = 0; i < n_img; i++)
+    {
+        const DenseImage &d = images[i];
+        const CameraModel &m = *d.img->model;
+        double *c = &cams17[17 * i];
+        std::memcpy(c, d.img->position, 24);
+        std::memcpy(c + 3, d.q_inv, 32);
+        const double model10[10] = {m.focal_length_pixels,   m.principle_point[0],   m.principle_point[1],      m.radial_distortion[0],
+                                    m.radial_distortion[1],  m.radial_distortion[2], m.tangential_distortion[0], m.tangential_distortion[1],
+                                    (double)m.pixels_cols,   (double)m.pixels_rows};
+        std::memcpy(c + 7, model10, 80);
+    }
+    std::vector<uint32_t> root(total);
+    std::vector<uint32_t> slot_dst(matches_out ? total * (MAX_CANDIDATE_IMAGES + 1) : 0);
+    uint64_t counts[2] = {0, 0};
+    const int lrc = ochip_dense_link(index, cams17.data(), id_of_pos.data(), hits.get(), SEARCH_RADIUS_PIXELS, MAX_CANDIDATE_IMAGES,
+                                     feature_2d::DESCRIPTOR_BITS, RATIO_THRESHOLD, MAX_ABSOLUTE_DESCRIPTOR_DISTANCE, root.data(), counts,
+                                     matches_out ? slot_dst.data() : nullptr);
+    ochip_dense_index_destroy(index);
+    if (lrc != OCHIP_OK)
+    {
+        if (error)
+            *error = std::string("ochip_dense_link: ") + ochip_last_error(ctx);
+        return finish(false);
+    }
+    st.queries = counts[0];
+    st.matches = counts[1];
+    st.device_seconds = seconds_since(t1);
+    if (matches_out) // the reference's order: source images in graph order, features along the Hilbert walk, candidates nearest first
+        for (size_t si = 0; si < n_img; si++)
         {
             const DenseImage &src = images[si];
-            const image &img = *src.img;
-            TriangleWalker walker;
-            if (!walker.init(mesh))
-                continue;
-            // hilbertFeatureOrder (:24-49)
-            const int w = (int)img.model->pixels_cols, h = (int)img.model->pixels_rows;
-            int order = 1;
-            while (order < std::max(w, h))
-                order *= 2;
-            std::vector<std::pair<uint32_t, size_t>> indexed(src.n_dense);
-            for (size_t k = 0; k < src.n_dense; k++)
+            for (uint32_t k : walk_order[si])
             {
-                const double *l = img.features[img.num_sparse_features + k].location;
-                indexed[k] = {hilbert_xy2d(order, std::clamp((int)l[0], 0, w - 1), std::clamp((int)l[1], 0, h - 1)), k};
-            }
-            std::sort(indexed.begin(), indexed.end());
-            std::vector<ochip_dense_query> &queries = per_image[si - b0];
-            queries.reserve(src.n_dense * MAX_CANDIDATE_IMAGES);
-            std::vector<std::pair<double, uint32_t>> cams;
-            const v3 origin{img.position[0], img.position[1], img.position[2]};
-            for (const auto &entry : indexed)
-            {
-                const size_t k = entry.second;
-                double ray[3];
-                image_to_3d(img.features[img.num_sparse_features + k].location, *img.model, ray);
-                const v3 dir = rotate(img.orientation, v3{ray[0], ray[1], ray[2]});
-                if (walker.find(dir, origin) != TriangleWalker::INTERSECTION)
-                    continue;
-                const v3 pt3d = walker.hit;
-                camera_grid.nearest(pt3d, MAX_CANDIDATE_IMAGES + 1, cams);
-                for (const auto &cand : cams)
-                {
-                    if (cand.second == si)
-                        continue;
-                    const DenseImage &ci = images[cand.second];
-                    double px[2];
-                    project(pt3d, ci, px);
-                    if (px[0] < 0 || px[0] >= (double)ci.img->model->pixels_cols || px[1] < 0 || px[1] >= (double)ci.img->model->pixels_rows)
-                        continue;
-                    ochip_dense_query q;
-                    q.src_feature = (uint32_t)(src.feat_base + src.dense_to_sorted[k]);
-                    q.cand_image = cand.second;
-                    q.px = px[0];
-                    q.py = px[1];
-                    queries.push_back(q);
-                }
+                const uint32_t *sd = &slot_dst[(src.feat_base + src.dense_to_sorted[k]) * (MAX_CANDIDATE_IMAGES + 1)];
+                for (int j = 0; j <= MAX_CANDIDATE_IMAGES; j++)
+                    if (sd[j] != UINT32_MAX)
+                        matches_out->emplace_back(src.offset + k, (size_t)sd[j]);
             }
         }
-        std::vector<ochip_dense_query> queries;
-        {
-            size_t n = 0;
-            for (const auto &v : per_image)
-                n += v.size();
-            queries.reserve(n);
-            for (const auto &v : per_image)
-                queries.insert(queries.end(), v.begin(), v.end());
-        }
-        st.rays_seconds += seconds_since(t1);
-        st.queries += queries.size();
-        t1 = std::chrono::steady_clock::now();
-        std::vector<ochip_dense_result> results(queries.size());
-        if (ochip_dense_match(index, queries.data(), queries.size(), SEARCH_RADIUS_PIXELS, results.data()) != OCHIP_OK)
-        {
-            if (error)
-                *error = std::string("ochip_dense_match: ") + ochip_last_error(ctx);
-            device_failed = true;
-            break;
-        }
-        st.device_seconds += seconds_since(t1);
-        t1 = std::chrono::steady_clock::now();
-        // the accept decisions (dense_stereo.cpp:278-283) and the unions, one source image per task
-        std::vector<size_t> q_off(per_image.size() + 1, 0);
-        for (size_t i = 0; i < per_image.size(); i++)
-            q_off[i + 1] = q_off[i] + per_image[i].size();
-        std::vector<size_t> accepted(per_image.size(), 0);
-        std::vector<std::vector<std::pair<size_t, size_t>>> kept(matches_out ? per_image.size() : 0);
-#pragma omp parallel for schedule(dynamic, 1)
-        for (size_t k = 0; k < per_image.size(); k++)
-        {
-            const DenseImage &src = images[b0 + k];
-            for (size_t qi = q_off[k]; qi < q_off[k + 1]; qi++)
-            {
-                const ochip_dense_result &r = results[qi];
-                if (r.nearby == 0)
-                    continue;
-                const double best_dist = r.best_count * (1.0 / feature_2d::DESCRIPTOR_BITS);
-                const double second_best_dist =
-                    r.second_count == 0xFFFF ? INFINITY : r.second_count * (1.0 / feature_2d::DESCRIPTOR_BITS);
-                const bool good_match =
-                    r.nearby >= 2 ? best_dist < RATIO_THRESHOLD * second_best_dist : best_dist < MAX_ABSOLUTE_DESCRIPTOR_DISTANCE;
-                if (!good_match)
-                    continue;
-                const DenseImage &dst = images[queries[qi].cand_image];
-                const size_t src_id = src.offset + src.sorted_to_dense[queries[qi].src_feature - src.feat_base];
-                const size_t dst_id = dst.offset + dst.sorted_to_dense[r.best_feature];
-                if (matches_out)
-                    kept[k].emplace_back(src_id, dst_id);
-                accepted[k]++;
-                unite((uint32_t)src_id, (uint32_t)dst_id);
-            }
-        }
-        for (size_t k = 0; k < per_image.size(); k++)
-        {
-            st.matches += accepted[k];
-            if (matches_out)
-                matches_out->insert(matches_out->end(), kept[k].begin(), kept[k].end());
-        }
-        st.tracks_seconds += seconds_since(t1);
-    }
-    ochip_dense_index_destroy(index);
-    if (device_failed)
-        return finish(false);
 
     // ---- tracks, in the order of their smallest member (:299-340), triangulated from their first two rays
     auto t2 = std::chrono::steady_clock::now();
     std::vector<std::vector<size_t>> multi_tracks;
     {
         // a matched measurement's component: tracks in the order of their smallest member (= their root), members ascending
-        std::vector<uint32_t> root(total);
-#pragma omp parallel for schedule(static)
-        for (size_t i = 0; i < total; i++)
-            root[i] = matched[i].load(std::memory_order_relaxed) ? find((uint32_t)i) : UINT32_MAX;
         std::vector<size_t> track_of_root(total, (size_t)-1);
         for (size_t i = 0; i < total; i++)
         {
