@@ -43,6 +43,17 @@ struct DenseImage
     double q_inv[4];         // orientation.inverse()
 };
 
+struct pinned_block // page-locked host memory from the context's pool
+{
+    ochip_ctx *ctx;
+    void *p = nullptr;
+    ~pinned_block()
+    {
+        if (p)
+            ochip_host_free(ctx, p);
+    }
+};
+
 inline void project(const v3 &point, const DenseImage &im, double pixel[2]) // image_from_3d(point, model, position, orientation)
 {
     const v3 rel{point.x - im.img->position[0], point.y - im.img->position[1], point.z - im.img->position[2]};
@@ -133,8 +144,19 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     std::vector<uint64_t> feat_off(n_img + 1), cell_off(n_img + 1);
     std::vector<int32_t> grid2(2 * n_img);
     std::vector<double> origin2(2 * n_img);
-    std::vector<uint64_t> desc8(8 * total);
-    std::vector<double> loc2(2 * total);
+    // (descriptors and locations in cell order: 80 bytes per dense feature, written once and uploaded - page-locked staging
+    // from the context's pool, no zero fill and no first-touch faults)
+    pinned_block desc_stage{ctx}, loc_stage{ctx}, hits_stage{ctx};
+    if (ochip_host_alloc(ctx, std::max<size_t>(total, 1) * 64, &desc_stage.p) != OCHIP_OK ||
+        ochip_host_alloc(ctx, std::max<size_t>(total, 1) * 16, &loc_stage.p) != OCHIP_OK ||
+        ochip_host_alloc(ctx, std::max<size_t>(total, 1) * 24, &hits_stage.p) != OCHIP_OK)
+    {
+        if (error)
+            *error = std::string("ochip_host_alloc: ") + ochip_last_error(ctx);
+        return finish(false);
+    }
+    uint64_t *const desc8 = static_cast<uint64_t *>(desc_stage.p);
+    double *const loc2 = static_cast<double *>(loc_stage.p);
     for (size_t i = 0; i < n_img; i++)
     {
         const DenseImage &d = images[i];
@@ -189,22 +211,20 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
         }
     }
     ochip_dense_index *index = nullptr;
-    if (ochip_dense_index_create(ctx, (uint32_t)n_img, feat_off.data(), desc8.data(), loc2.data(), cell_off.data(), cell_start.data(),
+    if (ochip_dense_index_create(ctx, (uint32_t)n_img, feat_off.data(), desc8, loc2, cell_off.data(), cell_start.data(),
                                  grid2.data(), origin2.data(), CELL_SIZE, &index) != OCHIP_OK)
     {
         if (error)
             *error = std::string("ochip_dense_index_create: ") + ochip_last_error(ctx);
         return finish(false);
     }
-    std::vector<uint64_t>().swap(desc8);
-    std::vector<double>().swap(loc2);
     st.index_seconds = seconds_since(t0);
 
     const MeshGraph &mesh = surfaces[0].mesh;
     // ---- where every dense feature's ray meets the mesh (:174-207): the walker starts from the triangle of the previous
     //      feature of the image's Hilbert walk (hilbertFeatureOrder, :24-49), so an image is one sequential task
     auto t1 = std::chrono::steady_clock::now();
-    std::unique_ptr<double[]> hits(new double[3 * std::max<size_t>(total, 1)]);
+    double *const hits = static_cast<double *>(hits_stage.p);
     std::vector<uint32_t> id_of_pos(total);
     std::vector<std::vector<uint32_t>> walk_order(matches_out ? n_img : 0); // dense feature numbers in Hilbert order (tests only)
 #pragma omp parallel for schedule(dynamic, 1)
@@ -272,7 +292,7 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     std::vector<uint32_t> root(total);
     std::vector<uint32_t> slot_dst(matches_out ? total * (MAX_CANDIDATE_IMAGES + 1) : 0);
     uint64_t counts[2] = {0, 0};
-    const int lrc = ochip_dense_link(index, cams17.data(), id_of_pos.data(), hits.get(), SEARCH_RADIUS_PIXELS, MAX_CANDIDATE_IMAGES,
+    const int lrc = ochip_dense_link(index, cams17.data(), id_of_pos.data(), hits, SEARCH_RADIUS_PIXELS, MAX_CANDIDATE_IMAGES,
                                      feature_2d::DESCRIPTOR_BITS, RATIO_THRESHOLD, MAX_ABSOLUTE_DESCRIPTOR_DISTANCE, root.data(), counts,
                                      matches_out ? slot_dst.data() : nullptr);
     ochip_dense_index_destroy(index);
@@ -300,24 +320,29 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
 
     // ---- tracks, in the order of their smallest member (:299-340), triangulated from their first two rays
     auto t2 = std::chrono::steady_clock::now();
-    std::vector<std::vector<size_t>> multi_tracks;
+    // a matched measurement's component = a track; tracks in the order of their smallest member (= their root), members
+    // ascending: two counting passes into one flat array (800 k small vectors were a third of this phase)
+    std::vector<uint32_t> track_start, track_member;
     {
-        // a matched measurement's component: tracks in the order of their smallest member (= their root), members ascending
-        std::vector<size_t> track_of_root(total, (size_t)-1);
+        std::vector<uint32_t> rank_of_root(total, UINT32_MAX);
+        uint32_t n_tracks = 0;
         for (size_t i = 0; i < total; i++)
-        {
-            if (root[i] == UINT32_MAX) // is_singleton
-                continue;
-            size_t &t = track_of_root[root[i]];
-            if (t == (size_t)-1)
-            {
-                t = multi_tracks.size();
-                multi_tracks.emplace_back();
-            }
-            multi_tracks[t].push_back(i);
-        }
+            if (root[i] == (uint32_t)i) // a root is the smallest member of its track: it comes first
+                rank_of_root[i] = n_tracks++;
+        track_start.assign((size_t)n_tracks + 1, 0);
+        for (size_t i = 0; i < total; i++)
+            if (root[i] != UINT32_MAX) // (UINT32_MAX: is_singleton)
+                track_start[rank_of_root[root[i]] + 1]++;
+        for (size_t t = 0; t < n_tracks; t++)
+            track_start[t + 1] += track_start[t];
+        track_member.resize(track_start[n_tracks]);
+        std::vector<uint32_t> fill(track_start.begin(), track_start.end() - 1);
+        for (size_t i = 0; i < total; i++)
+            if (root[i] != UINT32_MAX)
+                track_member[fill[rank_of_root[root[i]]]++] = (uint32_t)i;
     }
-    st.tracks = multi_tracks.size();
+    const size_t n_tracks = track_start.size() - 1;
+    st.tracks = n_tracks;
     auto image_of // measurement id -> image: offsets ascend
          = [&](size_t id) {
         size_t lo = 0, hi = n_img - 1;
@@ -332,13 +357,13 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
         return lo;
     };
     const double max_err_sq = MAX_REPROJECTION_ERROR_PIXELS * MAX_REPROJECTION_ERROR_PIXELS;
-    std::vector<std::array<double, 3>> track_results(multi_tracks.size());
-    std::vector<char> track_valid(multi_tracks.size(), 0);
+    std::vector<std::array<double, 3>> track_results(n_tracks);
+    std::vector<char> track_valid(n_tracks, 0);
 #pragma omp parallel for schedule(dynamic, 64)
-    for (size_t ti = 0; ti < multi_tracks.size(); ti++)
+    for (size_t ti = 0; ti < n_tracks; ti++)
     {
-        const auto &ids = multi_tracks[ti];
-        if (ids.size() < 2)
+        const uint32_t *ids_begin = track_member.data() + track_start[ti], *ids_end = track_member.data() + track_start[ti + 1];
+        if (ids_end - ids_begin < 2)
             continue;
         struct RayMeasurement
         {
@@ -347,9 +372,10 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
             const DenseImage *im;
         };
         std::vector<RayMeasurement> ms;
-        ms.reserve(ids.size());
-        for (size_t id : ids)
+        ms.reserve((size_t)(ids_end - ids_begin));
+        for (const uint32_t *ip = ids_begin; ip != ids_end; ip++)
         {
+            const size_t id = *ip;
             const DenseImage &im = images[image_of(id)];
             const image &img = *im.img;
             const double *px = img.features[img.num_sparse_features + (id - im.offset)].location;
@@ -384,7 +410,7 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
         track_valid[ti] = 1;
     }
     point_cloud merged;
-    for (size_t ti = 0; ti < multi_tracks.size(); ti++)
+    for (size_t ti = 0; ti < n_tracks; ti++)
         if (track_valid[ti])
             merged.push_back(track_results[ti]);
     st.points = merged.size();

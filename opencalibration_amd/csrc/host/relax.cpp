@@ -79,105 +79,23 @@ class GroundPlaneProblem
         // happens on its first use and is the same for every edge.  Edges past the first one without poses get no
         // filter pass, hence no whitelist and no blocks.
         fix_triangle_orientation();
-        std::vector<ochip_plane_edge> pe;
-        std::vector<const MeasurementGraph::Edge *> pe_edge;
-        std::vector<pose_ref> pe_src, pe_dst;
-        std::unordered_map<const CameraModel *, uint32_t> model_index;
-        std::vector<double> models10;
-        auto model_of = [&](const CameraModel *m) {
-            auto it = model_index.find(m);
-            if (it != model_index.end())
-                return it->second;
-            const double row[10] = {m->focal_length_pixels,   m->principle_point[0],   m->principle_point[1],      m->radial_distortion[0],
-                                    m->radial_distortion[1],  m->radial_distortion[2], m->tangential_distortion[0], m->tangential_distortion[1],
-                                    (double)m->pixels_cols,   (double)m->pixels_rows};
-            models10.insert(models10.end(), row, row + 10);
-            return model_index.emplace(m, (uint32_t)model_index.size()).first->second;
-        };
-        uint64_t n_inliers = 0;
-        for (size_t k = 0; k < n_filter; k++)
-        {
-            const MeasurementGraph::Edge *e = _graph.getEdge(edges_to_optimize[k]);
-            if (e == nullptr)
-                continue;
-            const camera_relations &rel = e->payload;
-            ochip_plane_edge r{};
-            r.cam_a = src[k].cam;
-            r.cam_b = dst[k].cam;
-            r.model_a = model_of(_graph.getNode(e->source)->payload.model.get());
-            r.model_b = model_of(_graph.getNode(e->dest)->payload.model.get());
-            r.n_inliers = (uint32_t)rel.inlier_matches.size();
-            r.flags = rel.relationType == camera_relations::RelationType::HOMOGRAPHY ? 1u : 0u;
-            r.inlier_offset = n_inliers;
-            std::memcpy(r.H, rel.ransac_relation, sizeof r.H);
-            n_inliers += r.n_inliers;
-            pe.push_back(r);
-            pe_edge.push_back(e);
-            pe_src.push_back(src[k]);
-            pe_dst.push_back(dst[k]);
-        }
-        // page-locked staging from the context's pool: no first-touch faults on ~40 bytes x every inlier of the survey,
-        // and the upload runs at the link rate
-        struct staging
-        {
-            ochip_ctx *ctx;
-            void *p = nullptr;
-            ~staging()
-            {
-                if (p)
-                    ochip_host_free(ctx, p);
-            }
-            ochip_plane_inlier *get() const
-            {
-                return static_cast<ochip_plane_inlier *>(p);
-            }
-        } inl{_ctx};
-        if (ochip_host_alloc(_ctx, (n_inliers ? n_inliers : 1) * sizeof(ochip_plane_inlier), &inl.p) != OCHIP_OK)
-            return fail(error, "ochip_host_alloc");
-#pragma omp parallel for schedule(dynamic, 16)
-        for (size_t j = 0; j < pe.size(); j++)
-        {
-            const camera_relations &rel = pe_edge[j]->payload;
-            ochip_plane_inlier *o = inl.get() + pe[j].inlier_offset;
-            for (size_t idx = 0; idx < rel.inlier_matches.size(); idx++)
-            {
-                const feature_match_denormalized &m = rel.inlier_matches[idx];
-                o[idx].px1[0] = m.pixel_1[0], o[idx].px1[1] = m.pixel_1[1];
-                o[idx].px2[0] = m.pixel_2[0], o[idx].px2[1] = m.pixel_2[1];
-                o[idx].descriptor_score = m.match_index < rel.matches.size() ? 1.0 - rel.matches[m.match_index].distance : 1.0;
-            }
-        }
-        lap("gather inliers");
         double tri[6];
         for (int i = 0; i < 3; i++)
         {
             tri[2 * i] = _xy[_tri[i]][0];
             tri[2 * i + 1] = _xy[_tri[i]][1];
         }
-        std::vector<uint8_t> keep(n_inliers), inexact(pe.size());
-        ochip_plane_setup *ps = nullptr;
-        if (ochip_plane_setup_create(_ctx, pe.data(), (uint32_t)pe.size(), inl.get(), n_inliers, _cam_pos.data(), _cam_q.data(),
-                                     (uint32_t)_cam_opt.size(), models10.data(), (uint32_t)model_index.size(), tri, 0.15, keep.data(),
-                                     inexact.data(), &ps) != OCHIP_OK)
-            return fail(error, "ochip_plane_setup_create");
-        struct drop
-        {
-            ochip_plane_setup *p;
-            ~drop()
-            {
-                ochip_plane_setup_destroy(p);
-            }
-        } drop_ps{ps};
+        std::vector<const MeasurementGraph::Edge *> edges(n_filter, nullptr);
+        for (size_t k = 0; k < n_filter; k++)
+            edges[k] = _graph.getEdge(edges_to_optimize[k]);
+        device_filter df;
+        if (!df.run(_ctx, _graph, edges, src, dst, n_filter, _cam_pos, _cam_q, tri, 0.15, error))
+            return false;
+        ochip_plane_setup *const ps = df.handle;
+        const std::vector<ochip_plane_edge> &pe = df.pe;
+        const std::vector<const MeasurementGraph::Edge *> &pe_edge = df.edge;
+        const std::vector<pose_ref> &pe_src = df.src, &pe_dst = df.dst;
         lap("grid filter (device)");
-        // edges whose filter depends on the order std::sort leaves equal scores in: the host walk decides
-        for (size_t j = 0; j < pe.size(); j++)
-            if (inexact[j])
-            {
-                const std::vector<uint8_t> k8 = grid_filter(_graph, *pe_edge[j], pe_src[j], pe_dst[j], 0.15);
-                std::copy(k8.begin(), k8.end(), keep.begin() + pe[j].inlier_offset);
-                if (ochip_plane_setup_override(ps, pe[j].inlier_offset, k8.size(), k8.data()) != OCHIP_OK)
-                    return fail(error, "ochip_plane_setup_override");
-            }
         uint64_t total_blocks = 0;
         if (ochip_plane_setup_blocks(ps, nullptr, nullptr, nullptr, 0, &total_blocks) != OCHIP_OK)
             return fail(error, "ochip_plane_setup_blocks");
@@ -447,6 +365,15 @@ int relax_setup_check(int on)
     if (on >= 0)
         g_setup_check.store(on);
     return g_setup_checked.load();
+}
+
+bool relax_setup_check_on()
+{
+    return g_setup_check.load() != 0;
+}
+void relax_setup_check_passed()
+{
+    g_setup_checked.fetch_add(1);
 }
 
 bool relax_ground_plane(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,

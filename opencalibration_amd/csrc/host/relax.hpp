@@ -53,5 +53,7 @@ bool relax_ground_plane(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
 // (relax_util.hpp) and fail unless the device's blocks equal them bit for bit; on < 0 leaves the switch alone.  Returns
 // the number of set-ups compared so far.
 int relax_setup_check(int on);
+bool relax_setup_check_on();   // (for the other flavours' set-ups)
+void relax_setup_check_passed();
 
 } // namespace opencalibration_amd

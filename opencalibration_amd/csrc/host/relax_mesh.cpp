@@ -422,11 +422,32 @@ class GroundMeshProblem
                 n_filter = k;
                 break;
             }
+        // on the device (ochip_plane_setup_create through relax_util.hpp's device_filter: the scores and the per-cell
+        // selection; edges it only flags are decided by the host's grid_filter)
         std::vector<std::vector<uint8_t>> keep(edges.size());
-#pragma omp parallel for schedule(dynamic, 1)
-        for (size_t k = 0; k < n_filter; k++)
-            keep[k] = grid_filter(_graph, *edges[k], src[k], dst[k], frac);
-        lap("grid filter");
+        {
+            const double no_triangle[6] = {0, 0, 1, 0, 0, 1}; // (only the plane flavour's block list uses it)
+            device_filter df;
+            if (!df.run(_ctx, _graph, edges, src, dst, n_filter, _cam_pos, _cam_q, no_triangle, frac, error))
+                return false;
+            for (size_t j = 0, k = 0; j < df.pe.size(); j++, k++)
+            {
+                while (edges[k] != df.edge[j]) // (run skips nothing here: every entry of `edges` is an edge)
+                    k++;
+                keep[k].assign(df.keep.begin() + df.pe[j].inlier_offset, df.keep.begin() + df.pe[j].inlier_offset + df.pe[j].n_inliers);
+            }
+            if (relax_setup_check_on())
+            {
+                for (size_t k = 0; k < n_filter; k++)
+                    if (keep[k] != grid_filter(_graph, *edges[k], src[k], dst[k], frac))
+                    {
+                        *error = "relax mesh set-up: the device's grid filter differs from the host's on edge " + std::to_string(k);
+                        return false;
+                    }
+                relax_setup_check_passed();
+            }
+        }
+        lap("grid filter (device)");
         // addRayTriangleMeasurementCost (:388-560) per edge, every edge with a mesh walker of its own
         std::vector<edge_blocks> per_edge(edges.size());
         const bool mesh_ok = _mesh.size_nodes() > 0 && _mesh.size_edges() > 0;

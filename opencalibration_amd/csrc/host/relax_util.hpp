@@ -9,7 +9,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <string>
 #include <unordered_map>
+#include <vector>
 
 namespace opencalibration_amd
 {
@@ -223,6 +225,123 @@ inline std::vector<uint8_t> grid_filter(const MeasurementGraph &_graph, const Me
     }
     return keep;
 }
+
+
+// gridFilterMatchesPerImage (relax_problem.cpp:234-309) of a list of edges on the device (ochip_plane_setup_create,
+// csrc/relax_setup.hip): the edges' inlier matches are packed into page-locked staging (40 bytes each), one wavefront per
+// edge scores and filters them, and the edges the device only flags - two matches sharing a cell's best score, which the
+// reference's unstable std::sort decides, or a match outside the cell table - are decided by grid_filter above.
+// keep: the edges' flags back to back (edge j's start at pe[j].inlier_offset).  The handle stays open for the caller
+// (the ground-plane set-up goes on to ochip_plane_setup_blocks); destroy it with ochip_plane_setup_destroy.
+struct device_filter
+{
+    std::vector<ochip_plane_edge> pe;
+    std::vector<const MeasurementGraph::Edge *> edge;
+    std::vector<pose_ref> src, dst;
+    std::vector<uint8_t> keep;
+    ochip_plane_setup *handle = nullptr;
+    double seconds_pack = 0;
+    ~device_filter()
+    {
+        if (handle)
+            ochip_plane_setup_destroy(handle);
+    }
+    // edges[k] with poses src[k] / dst[k]; nullptr entries are skipped.  triangle: the plane's border triangle (only the
+    // block list uses it).  Returns false with *error set when a device call fails.
+    bool run(ochip_ctx *ctx, const MeasurementGraph &graph, const std::vector<const MeasurementGraph::Edge *> &edges,
+             const std::vector<pose_ref> &srcs, const std::vector<pose_ref> &dsts, size_t n_edges, const std::vector<double> &cam_pos,
+             const std::vector<double> &cam_q, const double triangle_xy6[6], double fraction, std::string *error)
+    {
+        const auto t0 = clk::now();
+        std::unordered_map<const CameraModel *, uint32_t> model_index;
+        std::vector<double> models10;
+        auto model_of = [&](const CameraModel *m) {
+            auto it = model_index.find(m);
+            if (it != model_index.end())
+                return it->second;
+            const double row[10] = {m->focal_length_pixels,   m->principle_point[0],   m->principle_point[1],      m->radial_distortion[0],
+                                    m->radial_distortion[1],  m->radial_distortion[2], m->tangential_distortion[0], m->tangential_distortion[1],
+                                    (double)m->pixels_cols,   (double)m->pixels_rows};
+            models10.insert(models10.end(), row, row + 10);
+            return model_index.emplace(m, (uint32_t)model_index.size()).first->second;
+        };
+        uint64_t n_inliers = 0;
+        for (size_t k = 0; k < n_edges; k++)
+        {
+            const MeasurementGraph::Edge *e = edges[k];
+            if (e == nullptr)
+                continue;
+            const camera_relations &rel = e->payload;
+            ochip_plane_edge r{};
+            r.cam_a = srcs[k].cam;
+            r.cam_b = dsts[k].cam;
+            r.model_a = model_of(graph.getNode(e->source)->payload.model.get());
+            r.model_b = model_of(graph.getNode(e->dest)->payload.model.get());
+            r.n_inliers = (uint32_t)rel.inlier_matches.size();
+            r.flags = rel.relationType == camera_relations::RelationType::HOMOGRAPHY ? 1u : 0u;
+            r.inlier_offset = n_inliers;
+            std::memcpy(r.H, rel.ransac_relation, sizeof r.H);
+            n_inliers += r.n_inliers;
+            pe.push_back(r);
+            edge.push_back(e);
+            src.push_back(srcs[k]);
+            dst.push_back(dsts[k]);
+        }
+        // page-locked staging from the context's pool: no first-touch faults on ~40 bytes x every inlier of the survey,
+        // and the upload runs at the link rate
+        struct staging
+        {
+            ochip_ctx *ctx;
+            void *p = nullptr;
+            ~staging()
+            {
+                if (p)
+                    ochip_host_free(ctx, p);
+            }
+        } inl{ctx};
+        if (ochip_host_alloc(ctx, (n_inliers ? n_inliers : 1) * sizeof(ochip_plane_inlier), &inl.p) != OCHIP_OK)
+        {
+            *error = std::string("ochip_host_alloc: ") + ochip_last_error(ctx);
+            return false;
+        }
+        ochip_plane_inlier *const rec = static_cast<ochip_plane_inlier *>(inl.p);
+#pragma omp parallel for schedule(dynamic, 16)
+        for (size_t j = 0; j < pe.size(); j++)
+        {
+            const camera_relations &rel = edge[j]->payload;
+            ochip_plane_inlier *o = rec + pe[j].inlier_offset;
+            for (size_t idx = 0; idx < rel.inlier_matches.size(); idx++)
+            {
+                const feature_match_denormalized &m = rel.inlier_matches[idx];
+                o[idx].px1[0] = m.pixel_1[0], o[idx].px1[1] = m.pixel_1[1];
+                o[idx].px2[0] = m.pixel_2[0], o[idx].px2[1] = m.pixel_2[1];
+                o[idx].descriptor_score = m.match_index < rel.matches.size() ? 1.0 - rel.matches[m.match_index].distance : 1.0;
+            }
+        }
+        seconds_pack = since(t0);
+        keep.assign(n_inliers, 0);
+        std::vector<uint8_t> inexact(pe.size());
+        if (ochip_plane_setup_create(ctx, pe.data(), (uint32_t)pe.size(), rec, n_inliers, cam_pos.data(), cam_q.data(),
+                                     (uint32_t)(cam_q.size() / 4), models10.data(), (uint32_t)model_index.size(), triangle_xy6, fraction,
+                                     keep.data(), inexact.data(), &handle) != OCHIP_OK)
+        {
+            *error = std::string("ochip_plane_setup_create: ") + ochip_last_error(ctx);
+            return false;
+        }
+        for (size_t j = 0; j < pe.size(); j++)
+            if (inexact[j])
+            {
+                const std::vector<uint8_t> k8 = grid_filter(graph, *edge[j], src[j], dst[j], fraction);
+                std::copy(k8.begin(), k8.end(), keep.begin() + pe[j].inlier_offset);
+                if (ochip_plane_setup_override(handle, pe[j].inlier_offset, k8.size(), k8.data()) != OCHIP_OK)
+                {
+                    *error = std::string("ochip_plane_setup_override: ") + ochip_last_error(ctx);
+                    return false;
+                }
+            }
+        return true;
+    }
+};
 
 
 } // namespace relax_detail

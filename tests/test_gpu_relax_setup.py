@@ -53,6 +53,24 @@ def test_distorted_cameras_too(checked):
     ctx.close()
 
 
+def test_mesh_flavour_filters_on_the_device_too(checked):
+    """setupGroundMeshProblem's gridFilterMatchesPerImage (grid fraction 0.1) through the same kernel: whitelists equal
+    to the host's on every edge, then the usual mesh relax."""
+    grid = synth.make_grid(seed=5, rows=4, cols=6, feats=1024)
+    ctx = capi.Context(0)
+    g = host.Graph.from_synthetic(grid)
+    g.link(ctx)
+    start = perturbed(grid.orientation, 0.05, 2)
+    g.set_orientations(start)
+    plane = g.relax(ctx, start, host.relax_options("ORIENTATION", "GROUND_PLANE"))
+    seed = host.rebuild_mesh(grid.position, plane["surface"], minimal=True)
+    n0 = checked()
+    mesh = g.relax(ctx, plane["orientation"], host.relax_options("ORIENTATION", "GROUND_MESH"), 0.1, previous=seed)
+    assert checked() > n0 and int(mesh["residual_blocks"]) > 0
+    g.close()
+    ctx.close()
+
+
 def _setup(ctx, edges, inliers, cam_pos, cam_q, models, tri, frac=0.15):
     L = ctx.L
     vp = C.c_void_p
