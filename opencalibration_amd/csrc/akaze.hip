@@ -1300,7 +1300,8 @@ struct gather_tab
 
 // One 64-thread wavefront per surviving candidate (four consecutive ones per workgroup, wave-level barriers only):
 // sub-pixel position, dominant orientation, 486-bit M-LDB.
-__global__ __launch_bounds__(256) void describe3_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
+constexpr int DESC_WPB = 4; // keypoints (wavefronts) per workgroup (8: 66.6 us per image against 63.3 - sharing a CU among more list neighbours does not raise the L1 hit rate)
+__global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_live,
                                                        unsigned int max_cands, const unsigned int *__restrict__ live,
                                                        const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
                                                        size_t img_stride, levels_dev L, float derivative_factor,
@@ -1310,8 +1311,8 @@ __global__ __launch_bounds__(256) void describe3_kernel(const cand_t *__restrict
                                                        unsigned char *__restrict__ valid_out, int remap,
                                                        unsigned long long *__restrict__ vmask, size_t mask_stride)
 {
-    __shared__ float vals_all[4][30][3]; // cell sums, then cell means; row 29 takes the store of a chain that has no cell left
-    __shared__ float smp_all[4][441 * 3 + 1];
+    __shared__ float vals_all[DESC_WPB][30][3]; // cell sums, then cell means; row 29 takes the store of a chain that has no cell left
+    __shared__ float smp_all[DESC_WPB][441 * 3 + 1];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float(&vals)[30][3] = vals_all[wv];
     float *const smp = smp_all[wv];
@@ -1325,9 +1326,9 @@ __global__ __launch_bounds__(256) void describe3_kernel(const cand_t *__restrict
     const unsigned int b = blockIdx.z;
     const unsigned int n = n_live[b];
     unsigned int kb;
-    if (!xcd_contiguous(blockIdx.x, (n + 3) / 4, &kb, remap))
+    if (!xcd_contiguous(blockIdx.x, (n + DESC_WPB - 1) / DESC_WPB, &kb, remap))
         return;
-    const unsigned int kl = kb * 4 + wv;
+    const unsigned int kl = kb * DESC_WPB + wv;
     if (kl >= n)
         return;
     const size_t slot = (size_t)b * max_cands + live[(size_t)b * max_cands + kl];
@@ -2643,7 +2644,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         // (capping the workgroups a CU holds with unused dynamic LDS, to leave wave slots to the other sequences' HBM-bound
         // kernels beside this L2-bound one, was measured: 3 120 images/s with none, 3 100 / 2 940 / 2 830 at 4 / 3 / 2 per CU)
         if (max_live > 0)
-            hipLaunchKernelGGL(describe3_kernel, dim3(512 * (((max_live + 3) / 4 + 511) / 512), 1, B), dim3(256), 0, st,
+            hipLaunchKernelGGL(describe3_kernel, dim3(512 * (((max_live + DESC_WPB - 1) / DESC_WPB + 511) / 512), 1, B), dim3(64 * DESC_WPB), 0, st,
                                (const cand_t *)d_cands, (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live,
                                (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, dfactor,
                                (const gather_tab *)d_gtab, (const orient_tab *)d_otab, d_kp, d_desc, d_valid, xcd_remap, d_vmask,
