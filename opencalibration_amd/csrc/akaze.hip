@@ -780,6 +780,39 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
         *lx = 64 + ((int)threadIdx.x & 1);
         return (int)threadIdx.x < 2 * DH;
     };
+    // uniform per workgroup: tile + halo inside the image -> no reflection, every pixel exists, fixed LDS offsets
+    const bool inner_tile = rx0 >= 0 && ry0 >= 0 && x0 + BT_X + HW <= w && y0 + DT_Y + HW <= h;
+    if (inner_tile)
+    {
+        // a tile row per wavefront and pass: lane = column (the row's first 64 pixels are one 512-byte run), the RW - 64
+        // columns beyond ride on the first lanes; no index arithmetic per element, no bounds to test (the flattened walk
+        // below spent ~15 vector instructions per element on idx / RW and the four comparisons)
+        constexpr int RITERS = (RH + 3) / 4;
+        static_assert(RW > 64 && RW - 64 <= 64, "a row is 64 columns and a remainder of at most 64");
+        float2 va[RITERS], vb[RITERS];
+        const float2 *row0 = XY + (size_t)(ry0 + wave_id) * w + rx0 + lane_id;
+#pragma unroll
+        for (int it = 0; it < RITERS; it++) // all loads in flight before the first LDS store
+        {
+            const bool row = it * 4 + wave_id < RH;
+            va[it] = row ? row0[(size_t)(4 * it) * w] : make_float2(0.0f, 0.0f);
+            vb[it] = row && lane_id < RW - 64 ? row0[(size_t)(4 * it) * w + 64] : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int it = 0; it < RITERS; it++)
+            if (it * 4 + wave_id < RH)
+            {
+                const int o = (it * 4 + wave_id) * RW + lane_id;
+                tx[o] = va[it].x;
+                ty[o] = va[it].y;
+                if (lane_id < RW - 64)
+                {
+                    tx[o + 64] = vb[it].x;
+                    ty[o + 64] = vb[it].y;
+                }
+            }
+    }
+    else
     {
         constexpr int ITERS = (RW * RH + 255) / 256; // all loads in flight before the first LDS store
         float vx[ITERS], vy[ITERS];
@@ -813,8 +846,6 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
     auto atx = [&](int xx, int yy) { return tx[(yy - ry0) * RW + (xx - rx0)]; };
     auto aty = [&](int xx, int yy) { return ty[(yy - ry0) * RW + (xx - rx0)]; };
     const bool tiny = w <= 2 * S + 2 || h <= 2 * S + 2; // uniform: only then can an index need more than one reflection
-    // uniform per workgroup: tile + halo inside the image -> no reflection, every pixel exists, fixed LDS offsets
-    const bool inner_tile = rx0 >= 0 && ry0 >= 0 && x0 + BT_X + HW <= w && y0 + DT_Y + HW <= h;
     if (inner_tile)
     {
 #pragma unroll
@@ -872,18 +903,20 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
     // bit is set (the rest of Rmax is never read: the list builder and the suppression walk the mask)
     unsigned int found = 0;
     static_assert(BT_X == 64 && DT_Y % 4 == 0, "a wavefront per tile row, four rows per pass");
+    // interior pixel whose descriptor window [round(x - margin) - 1, round(x + margin) + 1] stays inside the level
+    // image (AKAZE's Find_Scale_Space_Extrema; margin = 10 sqrt(2) * sigma_size): the column's half of the test once per
+    // lane (a lane keeps its column through the passes), the row's half once per pass
+    const int mx = x0 + (int)(threadIdx.x & 63);
+    const bool x_ok = mx >= 1 && mx < w - 1 && (int)rintf((float)mx - margin) - 1 >= 0 && (int)rintf((float)mx + margin) + 1 < w;
 #pragma unroll
     for (int it = 0; it < DT_Y / 4; it++)
     {
-        const int ly = it * 4 + (threadIdx.x >> 6), lx = threadIdx.x & 63;
-        const int x = x0 + lx, y = y0 + ly;
+        const int ly = it * 4 + wave_id, lx = threadIdx.x & 63;
+        const int x = mx, y = y0 + ly;
         float out = 0.0f;
         float2 fit = make_float2(0.0f, 0.0f);
-        // interior pixel whose descriptor window [round(x - margin) - 1, round(x + margin) + 1] stays inside the level
-        // image (AKAZE's Find_Scale_Space_Extrema; margin = 10 sqrt(2) * sigma_size)
-        const bool in_bounds = (int)rintf((float)x - margin) - 1 >= 0 && (int)rintf((float)x + margin) + 1 < w &&
-                               (int)rintf((float)y - margin) - 1 >= 0 && (int)rintf((float)y + margin) + 1 < h;
-        if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1 && in_bounds)
+        const bool y_ok = y >= 1 && y < h - 1 && (int)rintf((float)y - margin) - 1 >= 0 && (int)rintf((float)y + margin) + 1 < h;
+        if (x_ok && y_ok)
         {
             const int ci = (ly + 1) * DW + (lx + 1);
             const float v = td[ci];
