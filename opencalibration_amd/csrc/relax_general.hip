@@ -1134,6 +1134,7 @@ int assign(ochip_relaxg_problem *p)
     }
     p->sys.ctx = p->ctx;
     p->sys.allocs = &p->allocs;
+    p->sys.speculative = true; // (the candidate is evaluated with its Jacobian into the second set: general_model::evaluate_candidate_jac)
     int rc = lm_system_resize(&p->sys, n, env);
     if (rc != OCHIP_OK)
         return rc;
@@ -1328,6 +1329,30 @@ struct general_model final : lm_model
     void launch_candidate(const double *y, const double *scale, double alpha, double *scal) override
     {
         hipLaunchKernelGGL(general_candidate_kernel, dim3(1), dim3(LM_TG), 0, p->ctx->stream, p->dev, scale, y, alpha, scal);
+    }
+    // The candidate with its Jacobian, through the generic route: the system's sets are exchanged around a plain
+    // evaluate(true, 1), so J'J, J'r and - by lm_launch_diag riding on the evaluation's wait - the clamped diagonal and
+    // max |g| of the candidate land in the second set; an accepted step copies the state (launch_accept) and the solver
+    // swaps the sets.  One evaluation and one wait per iteration instead of two of each.  (Any non-finite value counts
+    // as a failed cost: the step is rejected.)
+    bool speculates() override
+    {
+        return p->sys.A2 != nullptr;
+    }
+    int evaluate_candidate_jac(const double *scale, double *cost, int *fail_mask) override
+    {
+        lm_system &S = p->sys;
+        S.swap_sets();
+        before_wait = [&S, scale]() { lm_launch_diag(S, scale); };
+        const int rc = evaluate(true, 1, cost);
+        before_wait = nullptr;
+        S.swap_sets();
+        *fail_mask = rc > 0 ? 1 : 0;
+        return rc < 0 ? rc : OCHIP_OK;
+    }
+    void accept_swap() override
+    {
+        launch_accept();
     }
     void launch_accept() override
     {

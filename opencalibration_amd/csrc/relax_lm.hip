@@ -1446,6 +1446,13 @@ int lm_download_dense(const lm_system &s, double *out)
     return OCHIP_OK;
 }
 
+void lm_launch_diag(lm_system &S, const double *scale)
+{
+    const lm_mail mail{S.box, S.scal, S.fail_chol, nullptr, 0, 0};
+    hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(LM_TG), 0, S.ctx->stream, S.matA(), (const double *)S.g, S.diag_tmp, S.n, S.scal, scale,
+                       S.diagonal, mail);
+}
+
 // Trust-region Levenberg-Marquardt, monotonic steps (Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy semantics,
 // SURVEY.md Appendix B).  The control flow runs on the host side of the library; every O(problem) operation is a kernel.
 int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_relax_summary *sum)

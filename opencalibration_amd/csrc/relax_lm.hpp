@@ -313,6 +313,11 @@ struct lm_model
 
 int lm_solve(lm_system &sys, lm_model &model, const ochip_relax_options *opt, ochip_relax_summary *sum);
 
+// enqueue lm_diag_kernel on the system's CURRENT set: scal[4] = max |g|, diagonal = clamp(diag(A) scale^2) when scale is not
+// nullptr, scal[0, 8) and the factorisation's flag mailed to the host block (engines that evaluate a candidate with its
+// Jacobian through the generic route: swap_sets, evaluate(true, 1) with this as before_wait, swap_sets)
+void lm_launch_diag(lm_system &sys, const double *scale);
+
 // shared by the flavours' problem_create: a device block from the context's pool, recorded in `allocs`
 template <typename T>
 inline int lm_dev_upload(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> *allocs, T **dst, const T *src, size_t n)
