@@ -937,7 +937,7 @@ struct ochip_relaxg_problem
     std::vector<uint32_t> var_rec_off, var_rec; // CSR unknown group -> (record << 4 | slot)
     std::vector<int32_t> var_t;
     std::vector<uint8_t> var_ts;
-    int n_tangent = 0, tail_begin = 0;
+    int n_tangent = 0, tail_begin = 0, n_padding = 0; // (n_padding: unowned unknowns that align the band's regions to tiles)
     // per block type: first record and count
     struct type_range
     {
@@ -1005,90 +1005,191 @@ int assign(ochip_relaxg_problem *p)
     auto size_of = [&](uint32_t u) -> int { return u < nc ? 3 : u < vf ? 1 : u == vf ? 1 : u == vf + 1 ? 2 : (int)p->n_k_free; };
 
     // band order: along the long axis of the bounding box of the band unknowns (cameras and vertices live in the same
-    // ground coordinates; an unknown is coupled to what lies within a camera footprint of it)
+    // ground coordinates; an unknown is coupled to what lies within a camera footprint of it).  Regions (round 4): the band
+    // cut into stretches of the sweep that are coupled through the tail only (below); a region starts on a tile boundary,
+    // the gap in front of it is padding - unknowns nobody owns: zero rows of J'J that the damping makes positive, zero step.
     std::vector<uint32_t> band, tail;
-    std::vector<int> lo, hi;
-    for (int round = 0; round < 4; round++)
+    std::vector<int> lo, hi, region_of(p->n_vars, 0), region_first_block;
+    int n_regions = 1, n_padding = 0;
+    // one layout: order, tangent offsets, coupling ranges; unknowns whose strip would not fit join the tail and it repeats
+    auto layout = [&]() -> int {
+        for (int round = 0;; round++)
+        {
+            band.clear();
+            tail.clear();
+            for (uint32_t u = 0; u < p->n_vars; u++)
+                if (variable[u])
+                    (is_tail[u] ? tail : band).push_back(u);
+            auto xy = [&](uint32_t u, int a) { return u < nc ? p->cam_xy[2 * u + a] : p->vert_xy[2 * (u - nc) + a]; };
+            double mn[2] = {1e300, 1e300}, mx[2] = {-1e300, -1e300};
+            for (uint32_t u : band)
+                for (int a = 0; a < 2; a++)
+                {
+                    mn[a] = std::min(mn[a], xy(u, a));
+                    mx[a] = std::max(mx[a], xy(u, a));
+                }
+            const int ax = (mx[0] - mn[0]) >= (mx[1] - mn[1]) ? 0 : 1;
+            std::stable_sort(band.begin(), band.end(), [&](uint32_t a, uint32_t b) {
+                if (region_of[a] != region_of[b])
+                    return region_of[a] < region_of[b];
+                const double ka = xy(a, ax), kb = xy(b, ax);
+                if (ka != kb)
+                    return ka < kb;
+                return xy(a, 1 - ax) < xy(b, 1 - ax);
+            });
+            p->var_t.assign(p->n_vars, -1);
+            p->var_ts.assign(p->n_vars, 0);
+            region_first_block.clear();
+            n_padding = 0;
+            int t = 0, current = -1;
+            for (uint32_t u : band)
+            {
+                if (n_regions > 1 && region_of[u] != current)
+                {
+                    const int aligned = (t + NB - 1) / NB * NB;
+                    n_padding += aligned - t;
+                    t = aligned;
+                    region_first_block.push_back(t / NB);
+                    current = region_of[u];
+                }
+                p->var_t[u] = t;
+                p->var_ts[u] = (uint8_t)size_of(u);
+                t += size_of(u);
+            }
+            p->tail_begin = t;
+            for (uint32_t u : tail)
+            {
+                p->var_t[u] = t;
+                p->var_ts[u] = (uint8_t)size_of(u);
+                t += size_of(u);
+            }
+            p->n_tangent = t;
+            // coupling ranges of the band unknowns: over every record, the span of its band unknowns
+            lo.assign(p->n_vars, INT32_MAX);
+            hi.assign(p->n_vars, -1);
+            for (uint32_t r = 0; r < p->n_rec; r++)
+            {
+                const int nvr = rec_nvars(p->rec_type[r]);
+                int rlo = INT32_MAX, rhi = -1;
+                for (int s = 0; s < nvr; s++)
+                {
+                    const uint32_t u = p->rec_var[(size_t)r * MAXV + s];
+                    if (p->var_t[u] >= 0 && !is_tail[u])
+                    {
+                        rlo = std::min(rlo, p->var_t[u]);
+                        rhi = std::max(rhi, p->var_t[u] + p->var_ts[u]);
+                    }
+                }
+                if (rhi < 0)
+                    continue;
+                for (int s = 0; s < nvr; s++)
+                {
+                    const uint32_t u = p->rec_var[(size_t)r * MAXV + s];
+                    if (p->var_t[u] >= 0 && !is_tail[u])
+                    {
+                        lo[u] = std::min(lo[u], rlo);
+                        hi[u] = std::max(hi[u], rhi);
+                    }
+                }
+            }
+            // an unknown coupled to more columns than an LDS strip holds joins the tail; then order again
+            const int T = p->n_tangent - p->tail_begin;
+            bool moved = false;
+            for (uint32_t u : band)
+                if (hi[u] - lo[u] + T > STRIP_CAP)
+                {
+                    is_tail[u] = 1;
+                    moved = true;
+                }
+            if (!moved)
+                return OCHIP_OK;
+            if (round == 3)
+                return OCHIP_EINVAL;
+        }
+    };
+    if (layout() != OCHIP_OK)
+        return ochip_fail(p->ctx, OCHIP_EINVAL, "relax: the coupling structure does not fit the assembly strips");
+    // Dissection of the band (as the plane engine's camera graph, relax.hip): cut the sweep at R - 1 places; what lies
+    // behind a cut and is coupled to something in front of it becomes a separator - tail, dense rows -, and the stretches
+    // between are regions whose chains of diagonal tiles factor side by side.  R minimises the longest region plus 1.5 x
+    // the tail; no dissection unless that is below 0.8 of the single chain and the tail stays within its 1 024 unknowns.
+    if (!ochip_test_hook("no_dissect") && p->tail_begin >= 8 * NB)
     {
-        band.clear();
-        tail.clear();
-        for (uint32_t u = 0; u < p->n_vars; u++)
-            if (variable[u])
-                (is_tail[u] ? tail : band).push_back(u);
-        auto xy = [&](uint32_t u, int a) { return u < nc ? p->cam_xy[2 * u + a] : p->vert_xy[2 * (u - nc) + a]; };
-        double mn[2] = {1e300, 1e300}, mx[2] = {-1e300, -1e300};
-        for (uint32_t u : band)
-            for (int a = 0; a < 2; a++)
-            {
-                mn[a] = std::min(mn[a], xy(u, a));
-                mx[a] = std::max(mx[a], xy(u, a));
-            }
-        const int ax = (mx[0] - mn[0]) >= (mx[1] - mn[1]) ? 0 : 1;
-        std::stable_sort(band.begin(), band.end(), [&](uint32_t a, uint32_t b) {
-            const double ka = xy(a, ax), kb = xy(b, ax);
-            if (ka != kb)
-                return ka < kb;
-            return xy(a, 1 - ax) < xy(b, 1 - ax);
-        });
-        p->var_t.assign(p->n_vars, -1);
-        p->var_ts.assign(p->n_vars, 0);
-        int t = 0;
-        for (uint32_t u : band)
+        const int B = p->tail_begin, T0 = p->n_tangent - p->tail_begin;
+        int best_r = 0, best_path = B + T0 + T0 / 2;
+        std::vector<char> best_sep;
+        for (int R = 2; R <= 16; R++)
         {
-            p->var_t[u] = t;
-            p->var_ts[u] = (uint8_t)size_of(u);
-            t += size_of(u);
-        }
-        p->tail_begin = t;
-        for (uint32_t u : tail)
-        {
-            p->var_t[u] = t;
-            p->var_ts[u] = (uint8_t)size_of(u);
-            t += size_of(u);
-        }
-        p->n_tangent = t;
-        // coupling ranges of the band unknowns: over every record, the span of its band unknowns
-        lo.assign(p->n_vars, INT32_MAX);
-        hi.assign(p->n_vars, -1);
-        for (uint32_t r = 0; r < p->n_rec; r++)
-        {
-            const int nvr = rec_nvars(p->rec_type[r]);
-            int rlo = INT32_MAX, rhi = -1;
-            for (int s = 0; s < nvr; s++)
-            {
-                const uint32_t u = p->rec_var[(size_t)r * MAXV + s];
-                if (p->var_t[u] >= 0 && !is_tail[u])
-                {
-                    rlo = std::min(rlo, p->var_t[u]);
-                    rhi = std::max(rhi, p->var_t[u] + p->var_ts[u]);
-                }
-            }
-            if (rhi < 0)
+            std::vector<int> cuts;
+            for (int i = 1; i < R; i++)
+                cuts.push_back((int)((long)B * i / R));
+            std::vector<char> sep(p->n_vars, 0);
+            int seps = 0;
+            for (uint32_t u : band)
+                for (int c : cuts)
+                    if (p->var_t[u] >= c && lo[u] < c)
+                    {
+                        sep[u] = 1;
+                        seps += p->var_ts[u];
+                        break;
+                    }
+            if (T0 + seps > 1024)
                 continue;
-            for (int s = 0; s < nvr; s++)
+            int longest = 0, prev = 0;
+            for (size_t i = 0; i <= cuts.size(); i++)
             {
-                const uint32_t u = p->rec_var[(size_t)r * MAXV + s];
-                if (p->var_t[u] >= 0 && !is_tail[u])
-                {
-                    lo[u] = std::min(lo[u], rlo);
-                    hi[u] = std::max(hi[u], rhi);
-                }
+                const int end = i < cuts.size() ? cuts[i] : B;
+                int size = 0;
+                for (uint32_t u : band)
+                    if (!sep[u] && p->var_t[u] >= prev && p->var_t[u] < end)
+                        size += p->var_ts[u];
+                longest = std::max(longest, size);
+                prev = end;
+            }
+            const int path = longest + (T0 + seps) + (T0 + seps) / 2;
+            if (path < best_path)
+            {
+                best_path = path;
+                best_r = R;
+                best_sep.swap(sep);
             }
         }
-        // an unknown coupled to more columns than an LDS strip holds joins the tail; then order again
-        const int T = p->n_tangent - p->tail_begin;
-        bool moved = false;
-        for (uint32_t u : band)
-            if (hi[u] - lo[u] + T > STRIP_CAP)
+        if (best_r >= 2 && 10 * best_path <= 8 * (B + T0 + T0 / 2))
+        {
+            const std::vector<char> tail_before = is_tail;
+            for (uint32_t u : band)
             {
-                is_tail[u] = 1;
-                moved = true;
+                region_of[u] = std::min(best_r - 1, (int)((long)p->var_t[u] * best_r / B));
+                // (the cut places are B i / R: the region of tangent offset t is the number of cuts at or below it)
+                int r = 0;
+                for (int i = 1; i < best_r; i++)
+                    if (p->var_t[u] >= (int)((long)B * i / best_r))
+                        r = i;
+                region_of[u] = r;
+                if (best_sep[u])
+                    is_tail[u] = 1;
             }
-        if (!moved)
-            break;
-        if (round == 3)
-            return ochip_fail(p->ctx, OCHIP_EINVAL, "relax: the coupling structure does not fit the assembly strips");
+            n_regions = best_r;
+            bool ok = layout() == OCHIP_OK && p->n_tangent - p->tail_begin <= 1024 && (int)region_first_block.size() == n_regions;
+            if (ok) // every band unknown is coupled inside its own region only
+                for (uint32_t u : band)
+                {
+                    const int r = region_of[u];
+                    const int r_lo = region_first_block[r] * NB, r_hi = r + 1 < n_regions ? region_first_block[r + 1] * NB : p->tail_begin;
+                    if (hi[u] >= 0 && (lo[u] < r_lo || hi[u] > r_hi))
+                        ok = false;
+                }
+            if (!ok)
+            {
+                is_tail = tail_before;
+                std::fill(region_of.begin(), region_of.end(), 0);
+                n_regions = 1;
+                if (layout() != OCHIP_OK)
+                    return ochip_fail(p->ctx, OCHIP_EINVAL, "relax: the coupling structure does not fit the assembly strips");
+            }
+        }
     }
+    p->n_padding = n_padding;
     const int n = p->n_tangent, T = n - p->tail_begin;
     if (T > 1024)
         return ochip_fail(p->ctx, OCHIP_EINVAL, "relax: %d dense unknowns (limit 1024)", T);
@@ -1099,6 +1200,8 @@ int assign(ochip_relaxg_problem *p)
         const int band_end = p->tail_begin;
         const int n_all = std::max(n, 1), nblk = (n_all + NB - 1) / NB;
         env.tail_begin = band_end;
+        if (n_regions > 1)
+            env.region_begin = region_first_block;
         env.env_end.assign(nblk, 0);
         for (int k = 0; k < nblk; k++)
             env.env_end[k] = std::min((k + 1) * NB, band_end);
@@ -1128,8 +1231,8 @@ int assign(ochip_relaxg_problem *p)
             long bandsum = 0;
             for (int k = 0; k < nblk; k++)
                 bandsum += std::max(0, env.env_end[k] - (k + 1) * NB);
-            fprintf(stderr, "[ochip relaxg] n=%d band=%d tail=%d blocks=%d mean envelope rows below a block %.1f\n", n, band_end, T,
-                    nblk, (double)bandsum / nblk);
+            fprintf(stderr, "[ochip relaxg] n=%d band=%d tail=%d blocks=%d mean envelope rows below a block %.1f; %d regions, %d padding\n",
+                    n, band_end, T, nblk, (double)bandsum / nblk, n_regions, n_padding);
         }
     }
     p->sys.ctx = p->ctx;
@@ -1787,7 +1890,7 @@ int ochip_relaxg_solve(ochip_relaxg_problem *p, const ochip_relax_options *opt, 
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
     *sum = ochip_relax_summary{};
     general_model model(p);
-    sum->num_parameters = p->n_tangent;
+    sum->num_parameters = p->n_tangent - p->n_padding;
     sum->num_residual_blocks = model.num_residual_blocks();
     if (p->n_rec == 0)
     {
