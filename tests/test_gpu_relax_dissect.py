@@ -82,3 +82,31 @@ def test_back_substitution_variants_agree():
     band = _probe({"OCHIP_TEST_HOOKS": "no_dissect"})
     assert band[0] == base[0]
     assert abs(band[1] - base[1]) <= 1e-9 * abs(base[1]) and abs(band[2] - base[2]) <= 1e-9 * abs(base[2])
+
+
+def _mesh_probe(extra):
+    env = dict(os.environ, OCHIP_VERBOSE="relax", **extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probe_relax_mesh.py"), "C3", "256"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = {}
+    for line in r.stdout.splitlines():
+        for name in ("mesh, 4 vertices", "mesh, grid"):
+            if line.startswith(name):
+                d = eval(line[line.index("{"):line.index("}") + 1])
+                rows[name] = (int(d["iterations_total"]), float(d["final_cost"]))
+    regions = [int(l.split(";")[1].split()[0]) for l in r.stderr.splitlines() if "[ochip relaxg]" in l and "regions" in l]
+    return rows, max(regions) if regions else 0
+
+
+def test_general_engine_regions_equal_the_single_band():
+    """The mesh flavours' band dissected into regions (relax_general.hip, assign): the same LM trajectory as the single band
+    (same iterations; costs equal to rounding of the different elimination order), and the dissection does trigger at 1 000
+    cameras."""
+    cut, r_cut = _mesh_probe({})
+    band, r_band = _mesh_probe({"OCHIP_TEST_HOOKS": "no_dissect"})
+    assert r_cut >= 2 and r_band == 1
+    assert set(cut) == {"mesh, 4 vertices", "mesh, grid"}
+    for name in cut:
+        assert cut[name][0] == band[name][0], (name, cut[name], band[name])
+        assert abs(cut[name][1] - band[name][1]) <= 1e-9 * abs(band[name][1]), (name, cut[name], band[name])
