@@ -552,7 +552,7 @@ def beside_the_headline(ctx, grid, images, shape, start_ori, step_s, rctx=None):
             "seconds_by_phase": {"index": round(ds["index_s"], 4), "rays_and_mesh_walk_host": round(ds["rays_s"], 4),
                                  "nearest_cameras_predictions_search_unions_device_incl_pcie": round(ds["device_s"], 4),
                                  "tracks_host": round(ds["tracks_s"], 4)},
-            "search_kernel_ms": round(kd_ms, 3),
+            "search_accept_union_kernel_ms": round(kd_ms, 3),
             "queries_per_s_kernel": round(ds["queries"] / max(kd_ms * 1e-3, 1e-9), 1),
             "median_abs_height_error_m": float(np.median(np.abs(dz))) if len(dz) else None}
         gg.close()
