@@ -707,7 +707,7 @@ class StrongRunner:
         # One rank: two surveys in flight as in the weak mode (the next survey extracts beside this one's link tail).  With
         # several ranks the surveys stay one after the other: two surveys' collectives issued from two threads would have
         # to reach the communicator in the same order on every rank.
-        if self.proc.world == 1 and self.pipelined and os.environ.get("OCHIP_PIPELINE_SURVEYS", "2" if self.proc.cores >= 4 else "1") != "1":
+        if self.proc.world == 1 and self.pipelined and os.environ.get("OCHIP_PIPELINE_SURVEYS", "2" if self.proc.cores >= 2 else "1") != "1":
             from concurrent.futures import ThreadPoolExecutor
 
             with ThreadPoolExecutor(2) as pool:
@@ -831,9 +831,10 @@ def weak_main(args, proc, cfg):
     # and relax runners of consecutive batches together (pipeline.cpp:543-560); here successive steps are successive surveys.
     # Every relax finishes inside the timed region (the last one is joined before the closing barrier).
     relax_overlap = overlap
-    # two surveys in flight need host threads for two surveys' host phases at once: with 2 CPUs per rank one in flight is
-    # faster (1 746 against 1 660 images/s), from 4 CPUs on two are (OCHIP_PIPELINE_SURVEYS overrides)
-    surveys_in_flight = os.environ.get("OCHIP_PIPELINE_SURVEYS", "2" if proc.cores // max(world, 1) >= 4 else "1") != "1"
+    # two surveys in flight need host threads for two surveys' host phases at once: worth it from 2 CPUs per rank on since
+    # the relax set-up moved to the device (2 CPUs: 2 580 against 2 450 images/s; 3 CPUs: 2 920 against 2 590; before that
+    # move one in flight was faster at 2 CPUs, 1 746 against 1 660).  OCHIP_PIPELINE_SURVEYS overrides.
+    surveys_in_flight = os.environ.get("OCHIP_PIPELINE_SURVEYS", "2" if proc.cores // max(world, 1) >= 2 else "1") != "1"
     rctx = ctx.sibling(12) if relax_overlap else ctx      # (created here, before any runner thread asks for a sibling)
     if relax_overlap:
         rctx.set_priority(True)                            # the latency-bound solve goes ahead of the throughput kernels
