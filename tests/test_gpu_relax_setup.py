@@ -53,6 +53,28 @@ def test_distorted_cameras_too(checked):
     ctx.close()
 
 
+def test_tied_scores_go_to_the_hosts_sort(checked):
+    """Every inlier match twice: every cell's best score is shared by two matches, the device flags every edge and the
+    host's walk over its std::sort decides which of the two stays; the blocks must still equal the host's own."""
+    grid = synth.make_grid(seed=11, rows=3, cols=4, feats=512)
+    ctx = capi.Context(0)
+    g = host.Graph.from_synthetic(grid)
+    g.link(ctx)
+    g2 = host.Graph.from_synthetic(grid)
+    for e in g.edges(with_distances=True):
+        twice = lambda a: np.concatenate([a, a])
+        g2.add_edge(e["source"], e["dest"], twice(e["px"]), twice(e["f1"]), twice(e["f2"]), twice(e["match_index"]), e["H"], e["dist"],
+                    e["poses"], match_idx=e["match_idx"], is_homography=e["is_homography"])
+    assert g2.num_edges == g.num_edges > 0
+    start = perturbed(grid.orientation, 0.05, 5)
+    g2.set_orientations(start)
+    got = g2.relax_ground_plane(ctx, start)
+    assert checked() >= 1 and int(got["residual_blocks"]) > 0
+    g.close()
+    g2.close()
+    ctx.close()
+
+
 def test_mesh_flavour_filters_on_the_device_too(checked):
     """setupGroundMeshProblem's gridFilterMatchesPerImage (grid fraction 0.1) through the same kernel: whitelists equal
     to the host's on every edge, then the usual mesh relax."""
