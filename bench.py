@@ -270,6 +270,9 @@ def device_rooflines(ctx, capi, steps, images_per_step, t_extract_per_step, shap
                   "%s" % (round(imgs_per_launch), "; in the timed steps it shares the device with the link kernels" if overlap else ""),
         "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+        "peak_note": "8 TB/s is the part's HBM peak (MI355X_MICROARCH.md); pure streaming kernels measured on this part "
+                     "(scripts/ubench_hbm.hip, profiles/r04_hbm_stream_ubench.txt) reach 6.2-6.4 TB/s read-only and 4.9-5.5 TB/s "
+                     "at the read : write mixes of this sequence's passes",
         "traffic_source": None if traffic is None else f"rocprofv3 --pmc pass committed as {traffic_file} (FETCH_SIZE x 2 + "
                                                           "WRITE_SIZE per image x images per launch); not re-measured in this run",
         "avg_launch_ms": round(launch_ms, 3), "launches": n_akaze,
