@@ -519,7 +519,7 @@ size_t och_relax_stage_num_groups(const och_relax_stage *st)
 int och_relax_stage_run_groups(och_relax_stage *st, ochip_ctx *ctx, uint32_t rank, uint32_t world)
 {
     auto runners = st->stage.get_runners(ctx, st->g->graph, rank, std::max<uint32_t>(world, 1));
-    run_parallel(runners);
+    run_parallel(runners, st->stage.runner_contexts()); // (a thread per device context: OCHIP_RELAX_RUNNERS)
     return 0;
 }
 

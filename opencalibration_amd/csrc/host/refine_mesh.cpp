@@ -648,7 +648,7 @@ bool mesh_refinement_step(ochip_ctx *ctx, MeasurementGraph &graph, std::vector<s
     config.ground_mesh_grid_fraction = gridFraction;
     stage.init(graph, {}, true, false, config);
     auto runners = stage.get_runners(ctx, graph);
-    run_parallel(runners);
+    run_parallel(runners, stage.runner_contexts());
     stage.finalize(graph);
     if (!stage.error().empty())
     {

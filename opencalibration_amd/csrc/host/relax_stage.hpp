@@ -114,6 +114,15 @@ class RelaxStage // src/pipeline/relax_stage.hpp
     std::vector<std::string> _group_errors;
     std::string _error;
     std::vector<std::unique_ptr<std::mutex>> _ctx_mutex; // runners that share a device context take turns
+
+  public:
+    // device contexts the runners of the last get_runners call were dealt to: as many threads can run them side by side
+    size_t runner_contexts() const
+    {
+        return std::max<size_t>(1, _ctx_mutex.size());
+    }
+
+  private:
 };
 
 } // namespace opencalibration_amd
