@@ -1498,7 +1498,7 @@ struct plane_model final : lm_model
         const bool mailed = mails_results();
         lm_mail mail{};
         if (mailed)
-            mail = lm_mail{p->sys.box, p->sys.scal, p->sys.fail_chol, p->fail_ranks, (int)p->shard_world, 1};
+            mail = lm_mail{p->sys.box, p->sys.scal, p->sys.fail_chol, p->fail_ranks, (int)p->shard_world, 1, nullptr};
         // (with the Jacobian: the scatter of the pair records into A and g rides in the same launch)
         const uint32_t cam_blocks = with_jac ? (D.n_cams + 3) / 4 : 0, pair_blocks = with_jac ? (D.n_pairs + 255) / 256 : 0;
         hipLaunchKernelGGL(relax_reduce_plane_kernel, dim3(REDUCE_GROUPS + cam_blocks + pair_blocks), dim3(256), 0, st, D, Am, gv, n,

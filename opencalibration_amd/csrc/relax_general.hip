@@ -967,7 +967,8 @@ namespace
 {
 
 constexpr int STRIP_CAP = 2300;       // band + tail columns one owner's LDS strip may span (3 rows x 2301 doubles = 55 KB)
-constexpr uint32_t TAIL_CHUNK = 1024; // records per chunk of a tail owner (a chunk is one wavefront walking its records in order)
+constexpr uint32_t TAIL_CHUNK = 1024;  // most records per chunk of a tail owner (a chunk is one wavefront walking its records in order; the length is chosen
+                                      // per owner, assign())
 constexpr uint32_t BAND_CHUNK = 512;  // a band owner with more than twice this many records is cut into chunks of this size
 constexpr uint32_t DENSE_VERTS = 8;   // a mesh of at most this many vertices is dense (plane, minimal mesh): tail
 
@@ -1275,9 +1276,14 @@ int assign(ochip_relaxg_problem *p)
         tail_var.push_back(u);
         tail_first.push_back(n_partials);
         uint32_t cnt = 0;
-        for (uint32_t e = p->var_rec_off[u]; e < p->var_rec_off[u + 1] || cnt == 0; e += TAIL_CHUNK)
+        // chunk length: a chunk is walked record by record by one wavefront (~0.5 us each) and the owner's chunks are summed
+        // one after the other (~0.3 us each): both chains are shortest near sqrt(0.6 records) - 96 for the 16 k records of a
+        // 50-camera group (whose evaluation was one 540 us walk with chunks of 1 024), 530 for the 480 k of a whole survey
+        const uint32_t n_rec_u = p->var_rec_off[u + 1] - p->var_rec_off[u];
+        const uint32_t chunk = std::min(TAIL_CHUNK, std::max(64u, ((uint32_t)std::sqrt(0.6 * (double)n_rec_u) + 31u) / 32u * 32u));
+        for (uint32_t e = p->var_rec_off[u]; e < p->var_rec_off[u + 1] || cnt == 0; e += chunk)
         {
-            work_item it{u, e, std::min(e + TAIL_CHUNK, p->var_rec_off[u + 1]), 0, 0, (int32_t)n_partials, -1};
+            work_item it{u, e, std::min(e + chunk, p->var_rec_off[u + 1]), 0, 0, (int32_t)n_partials, -1};
             items.push_back(it);
             n_partials++;
             cnt++;
@@ -1333,6 +1339,7 @@ template <int N, bool INTR> void launch_ray(const g_dev &D, hipStream_t st, uint
 struct general_model final : lm_model
 {
     ochip_relaxg_problem *p;
+    bool mail_by_diag = false, fail_is_clear = false;
     explicit general_model(ochip_relaxg_problem *prob) : p(prob)
     {
     }
@@ -1342,7 +1349,12 @@ struct general_model final : lm_model
         hipStream_t st = ctx->stream;
         g_dev &D = p->dev;
         const int n = p->n_tangent;
-        OCHIP_HIP(ctx, hipMemsetAsync(D.fail, 0, 4, st));
+        // (this rank's failure flag: the kernel that mails an evaluation's results clears it again - evaluate_candidate_jac -,
+        // any other evaluation leaves it to this memset)
+        if (!fail_is_clear)
+            OCHIP_HIP(ctx, hipMemsetAsync(D.fail, 0, 4, st));
+        const bool mailed = mail_by_diag && p->shard_world <= (uint32_t)(2 * (lm_system::BOX_VECTORS - lm_system::BOX_FAILS));
+        fail_is_clear = mailed;
         hipEvent_t e0, e1;
         ochip_prof_begin(ctx, OCHIP_K_RELAX_EVAL, &e0, &e1);
         for (const auto &full : p->ranges)
@@ -1389,8 +1401,14 @@ struct general_model final : lm_model
         }
         if (with_jac)
         {
-            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, p->sys.matrix_bytes(), st));
-            OCHIP_HIP(ctx, hipMemsetAsync(p->sys.g, 0, (size_t)n * 8, st));
+            // the assembly ASSIGNS the same entries of A and g at every evaluation (fixed by the layout) and nothing else
+            // writes them: what it leaves alone - fill-in positions, padding unknowns - is cleared once per layout and set
+            if (!p->sys.A_clean)
+            {
+                OCHIP_HIP(ctx, hipMemsetAsync(p->sys.A, 0, p->sys.matrix_bytes(), st));
+                OCHIP_HIP(ctx, hipMemsetAsync(p->sys.g, 0, (size_t)n * 8, st));
+                p->sys.A_clean = true;
+            }
             if (p->n_items)
                 hipLaunchKernelGGL(gather_kernel, dim3(p->n_items), dim3(W), (size_t)p->max_strip * 8, st, D, p->items_dev,
                                    p->var_rec_dev, p->sys.matA(), p->sys.g, n, p->tail_begin, p->partials_dev, STRIP_CAP,
@@ -1418,8 +1436,11 @@ struct general_model final : lm_model
             hfails_pageable.assign(p->shard_world, 0);
             hfails = hfails_pageable.data();
         }
-        OCHIP_HIP(ctx, hipMemcpyAsync(h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
-        OCHIP_HIP(ctx, hipMemcpyAsync(hfails, p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
+        if (!mailed) // (mailed: the solver's diagonal kernel, enqueued by before_wait, posts the cost and the flags too)
+        {
+            OCHIP_HIP(ctx, hipMemcpyAsync(h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
+            OCHIP_HIP(ctx, hipMemcpyAsync(hfails, p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
+        }
         if (before_wait)
             before_wait();
         OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
@@ -1446,8 +1467,11 @@ struct general_model final : lm_model
     {
         lm_system &S = p->sys;
         S.swap_sets();
-        before_wait = [&S, scale]() { lm_launch_diag(S, scale); };
+        ochip_relaxg_problem *const prob = p;
+        before_wait = [&S, scale, prob]() { lm_launch_diag(S, scale, prob->fail_ranks, (int)prob->shard_world, 1, prob->dev.fail); };
+        mail_by_diag = true;
         const int rc = evaluate(true, 1, cost);
+        mail_by_diag = false;
         before_wait = nullptr;
         S.swap_sets();
         *fail_mask = rc > 0 ? 1 : 0;

@@ -1446,9 +1446,9 @@ int lm_download_dense(const lm_system &s, double *out)
     return OCHIP_OK;
 }
 
-void lm_launch_diag(lm_system &S, const double *scale)
+void lm_launch_diag(lm_system &S, const double *scale, const int32_t *fail_ranks, int world, int with_cost, int32_t *clear_after)
 {
-    const lm_mail mail{S.box, S.scal, S.fail_chol, nullptr, 0, 0};
+    const lm_mail mail{S.box, S.scal, S.fail_chol, fail_ranks, world, with_cost, clear_after};
     hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(LM_TG), 0, S.ctx->stream, S.matA(), (const double *)S.g, S.diag_tmp, S.n, S.scal, scale,
                        S.diagonal, mail);
 }
@@ -1464,7 +1464,7 @@ int lm_solve(lm_system &S, lm_model &M, const ochip_relax_options *opt, ochip_re
     const bool eliminated = M.has_eliminated();
     M.begin_solve();
     // the solver's own mail: scal[0, 8) (and the factorisation's flag) into the host block by the kernel that ends a phase
-    const lm_mail mail{S.box, S.scal, S.fail_chol, nullptr, 0, 0};
+    const lm_mail mail{S.box, S.scal, S.fail_chol, nullptr, 0, 0, nullptr};
     auto grad_and_diag = [&](double *gmax, bool refresh) -> int {
         hipLaunchKernelGGL(lm_diag_kernel, dim3(1), dim3(LM_TG), 0, st, S.matA(), (const double *)S.g, S.diag_tmp, n, S.scal,
                            refresh ? (const double *)S.scale : (const double *)nullptr, S.diagonal, mail);

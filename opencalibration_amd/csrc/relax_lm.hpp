@@ -157,6 +157,7 @@ struct lm_mail
     const int32_t *fail_ranks = nullptr;
     int world = 0;
     int with_cost = 0; // scal[0] is the evaluation's cost: box[8] takes it as well
+    int32_t *clear_after = nullptr; // this rank's evaluation flag: zero again once it is posted (no memset in front of the next one)
 };
 #if defined(__HIPCC__)
 // diag(A), max |g| and the clamped diagonal of the damping, by the TG threads of one workgroup (what lm_diag_kernel does;
@@ -203,6 +204,8 @@ __device__ __forceinline__ void lm_mail_post(const lm_mail &m) // one thread, af
     int32_t *f = reinterpret_cast<int32_t *>(m.box + lm_system::BOX_FAILS);
     for (int r = 0; r < m.world; r++)
         f[r] = m.fail_ranks[r];
+    if (m.clear_after)
+        *m.clear_after = 0;
 }
 #endif
 
@@ -316,7 +319,8 @@ int lm_solve(lm_system &sys, lm_model &model, const ochip_relax_options *opt, oc
 // enqueue lm_diag_kernel on the system's CURRENT set: scal[4] = max |g|, diagonal = clamp(diag(A) scale^2) when scale is not
 // nullptr, scal[0, 8) and the factorisation's flag mailed to the host block (engines that evaluate a candidate with its
 // Jacobian through the generic route: swap_sets, evaluate(true, 1) with this as before_wait, swap_sets)
-void lm_launch_diag(lm_system &sys, const double *scale);
+void lm_launch_diag(lm_system &sys, const double *scale, const int32_t *fail_ranks = nullptr, int world = 0, int with_cost = 0,
+                    int32_t *clear_after = nullptr);
 
 // shared by the flavours' problem_create: a device block from the context's pool, recorded in `allocs`
 template <typename T>

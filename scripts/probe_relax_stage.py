@@ -35,3 +35,6 @@ for rep in range(3):
     t3 = time.perf_counter()
     print("rep %d: begin (partition) %.3f s, run groups %.3f s, end (merge) %.3f s; rc %d, groups %d, host set-up summed %.3f, device summed %.3f"
           % (rep, t1 - t0, t2 - t1, t3 - t2, rc, int(summary[12]), summary[6] if len(summary) > 6 else -1, summary[7] if len(summary) > 7 else -1), flush=True)
+for kid, name in ((capi.K_RELAX_EVAL, "eval"), (capi.K_RELAX_SOLVE, "solve")):
+    n, ms = ctx.profile_get(kid)
+    print(name, n, "profiled intervals", round(ms, 2), "ms total", round(ms / max(n, 1), 4), "ms avg")
