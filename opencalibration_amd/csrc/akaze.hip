@@ -636,7 +636,7 @@ __global__ void kcontrast_kernel(const unsigned int *__restrict__ hist, const un
 // ---- diffusion (the PM-G2 conductivity is BLUR_FLOW above)
 // Up to FED_FUSE explicit diffusion steps per launch, in registers.  A wavefront owns a 64-column x (NLD_TY + 2K)-row
 // strip: each lane keeps its column of L and of the two conductivity sums (c[i] + c[i+1], c[i] + c[i+w]) in
-// VGPRs, the horizontal neighbours arrive by lane shuffles, and the strip is swept top to bottom once per step,
+// VGPRs, the horizontal neighbours arrive by DPP wavefront shifts, and the strip is swept top to bottom once per step,
 // in place (a row needs the old row below and the already computed flux from the row above).  The valid region
 // shrinks by one pixel per step, so 64 - 2K columns x NLD_TY rows are written: 12 B/pixel of HBM traffic per launch
 // instead of per step, at ~14 VALU instructions per pixel-step (the LDS-tiled form of this loop was VALU-bound).
@@ -648,6 +648,21 @@ struct fed_tau_group
 {
     float tau[FED_FUSE];
 };
+// the neighbouring lane's value by a DPP wavefront shift (one vector move; __shfl_down / __shfl_up by one went through the LDS
+// crossbar: two ds_bpermute and their waits per pixel-step): lane i takes lane i + 1 (i - 1); the last (first) lane keeps its
+// own value, as the shuffles did.  (39.5 -> 37 us per image.  Tried on top and dropped: a second instantiation without
+// the border selects for strips inside the image - 18.6 + 18.6 against 17.6 + 18.1 us.)
+__device__ __forceinline__ float lane_right(float x)
+{
+    const int xi = __float_as_int(x);
+    return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_left(float x)
+{
+    const int xi = __float_as_int(x);
+    return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void nld_fused_kernel(const float *__restrict__ Lin, const float *__restrict__ cflow,
                                                         float *__restrict__ Lout, int w, int h, size_t l_stride,
@@ -674,7 +689,7 @@ __global__ __launch_bounds__(256) void nld_fused_kernel(const float *__restrict_
     }
 #pragma unroll
     for (int r = 0; r < RH; r++)
-        cx[r] = cy[r] + __shfl_down(cy[r], 1);
+        cx[r] = cy[r] + lane_right(cy[r]);
 #pragma unroll
     for (int r = 0; r + 1 < RH; r++)
         cy[r] = cy[r] + cy[r + 1];
@@ -688,9 +703,9 @@ __global__ __launch_bounds__(256) void nld_fused_kernel(const float *__restrict_
         {
             const int gy = Y0 - K + r;
             const float Lc = Lr[r];
-            const float d = __shfl_down(Lc, 1) - Lc;
+            const float d = lane_right(Lc) - Lc;
             const float xpos = has_right ? cx[r] * d : 0.0f;
-            const float xleft = __shfl_up(xpos, 1);
+            const float xleft = lane_left(xpos);
             const float xneg = has_left ? xleft : 0.0f;
             float ypos = 0.0f;
             if (r + 1 < RH)
