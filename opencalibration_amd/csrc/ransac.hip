@@ -31,6 +31,46 @@
 namespace
 {
 
+// The pivot search's reduction over the wavefront: the largest value, ties to the smaller (column, row) - the first maximum
+// of the column-by-column scan, whatever order the candidates meet in.  Every lane ends with the result.  The six
+// butterfly stages used to be four LDS-crossbar shuffles each (__shfl_xor of a double and two indices: 24 dependent
+// ds_bpermute per pivot, 9 pivots per hypothesis - the critical path of a kernel that is one wavefront per image pair);
+// now the indices travel as one word and the four stages inside a row of 16 lanes are DPP moves (quad permutes, then
+// rotations by 4 and 8: any pairing that ends with every lane having met every other serves a commutative, associative
+// choice), two stages across the rows remain shuffles.
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_word(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ void first_maximum_take(double &bv, uint32_t &key, double ov, uint32_t ok)
+{
+    if (ov > bv || (ov == bv && ok < key))
+    {
+        bv = ov;
+        key = ok;
+    }
+}
+template <int CTRL> __device__ __forceinline__ void first_maximum_stage(double &bv, uint32_t &key)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(bv);
+    const uint32_t lo = dpp_word<CTRL>((uint32_t)bits), hi = dpp_word<CTRL>((uint32_t)(bits >> 32));
+    const uint32_t ok = dpp_word<CTRL>(key);
+    first_maximum_take(bv, key, __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)), ok);
+}
+__device__ __forceinline__ void wave_first_maximum(double &bv, uint32_t &bi, uint32_t &bj)
+{
+    uint32_t key = (bj << 16) | bi; // (column, row): both below 65 536
+    first_maximum_stage<0xB1>(bv, key);  // quad_perm [1, 0, 3, 2]
+    first_maximum_stage<0x4E>(bv, key);  // quad_perm [2, 3, 0, 1]
+    first_maximum_stage<0x124>(bv, key); // row_ror:4
+    first_maximum_stage<0x128>(bv, key); // row_ror:8
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1)
+        first_maximum_take(bv, key, __shfl_xor(bv, off), __shfl_xor(key, off));
+    bi = key & 0xFFFFu;
+    bj = key >> 16;
+}
+
 constexpr int W = 64;
 constexpr uint32_t MIN_ITERATIONS = 20, MAX_ITERATIONS = 10000, MAX_INNER_ITERATIONS = 5;
 
@@ -298,18 +338,7 @@ __device__ void full_piv_lu_solve9(double *A, uint32_t rows, double *sol /*[9], 
                     bj = j;
                 }
             }
-        for (int off = 32; off >= 1; off >>= 1)
-        {
-            const double ov = __shfl_xor(bv, off);
-            const uint32_t oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
-            const bool better = ov > bv || (ov == bv && (oj < bj || (oj == bj && oi < bi)));
-            if (better)
-            {
-                bv = ov;
-                bi = oi;
-                bj = oj;
-            }
-        }
+        wave_first_maximum(bv, bi, bj);
         const double akk = A[(size_t)k * ld + k];
         if (akk != akk) // a NaN in the first scanned cell sticks (nothing compares greater than NaN)
         {
@@ -396,12 +425,7 @@ __device__ __forceinline__ void piv_take(piv_t &b, double v, uint32_t i, uint32_
 }
 __device__ __forceinline__ void piv_reduce(piv_t &b)
 {
-    for (int off = 32; off >= 1; off >>= 1)
-    {
-        const double ov = __shfl_xor(b.v, off);
-        const uint32_t oi = __shfl_xor(b.i, off), oj = __shfl_xor(b.j, off);
-        piv_take(b, ov, oi, oj);
-    }
+    wave_first_maximum(b.v, b.i, b.j);
 }
 
 constexpr int RB = 4; // rows per lane and round
