@@ -352,6 +352,29 @@ __global__ void feat_records_kernel(feat_dev F)
         F.sub_recs[(size_t)b * F.S + at] = (sorted & 0xFFFFFFFF00000000ull) | at;
 }
 
+// The sparse list is in strength order already (it is the strength-sorted list minus the suppressed features), so the
+// subset's std::sort can only change it where two neighbours have EQUAL strength (what an unstable sort does to equal keys
+// is the one thing that depends on the order it is given).  An image without such a pair has its segment emptied here:
+// the sort then leaves its records alone, which is their sorted order - the only one distinct keys have.
+__global__ __launch_bounds__(256) void feat_subset_ties_kernel(feat_dev F)
+{
+    const unsigned int b = blockIdx.x;
+    const unsigned int n = F.n[b] ? F.n_sparse[b] : 0u;
+    __shared__ int tied;
+    if (threadIdx.x == 0)
+        tied = 0;
+    __syncthreads();
+    const unsigned long long *r = F.sub_recs + (size_t)b * F.S;
+    int mine = 0;
+    for (unsigned int i = threadIdx.x; i + 1 < n; i += 256)
+        mine |= (r[i] >> 32) == (r[i + 1] >> 32);
+    if (mine)
+        tied = 1; // (benign race: every writer stores 1)
+    __syncthreads();
+    if (threadIdx.x == 0 && !tied)
+        F.sub_end[b] = F.sub_begin[b];
+}
+
 // location of the r-th strongest sparse feature (after the subset's sort)
 __global__ void feat_subset_loc_kernel(feat_dev F)
 {
@@ -495,6 +518,7 @@ int feature_lists_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>>
     {
         // spatially_subsample_feature_indices over the sparse list: indices std::sorted by strength from list order, then
         // the greedy 40 px pass in that order
+        hipLaunchKernelGGL(feat_subset_ties_kernel, dim3(B), dim3(256), 0, st, F);
         const int src = std_sort_enqueue(ctx, allocs, F.sub_recs, N, F.sub_begin, F.sub_end, B, most, conflict2);
         if (src != OCHIP_OK)
             return src;
