@@ -115,6 +115,24 @@ __global__ void sort_init_kernel(sort_dev S, const unsigned int *__restrict__ se
     push_range(S, 0, first, last, 2 * lg, s, true);
 }
 
+// inclusive prefix sum over the 64 lanes with DPP moves (row shifts inside the rows of 16, then the broadcasts of lanes 15
+// and 31): six vector instructions where six __shfl_up went through the LDS crossbar one after the other
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ unsigned int dpp_add_from(unsigned int x)
+{
+    // lanes outside ROW_MASK, and lanes whose source lies outside their row, take 0
+    return x + (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ unsigned int wave_inclusive_scan(unsigned int v)
+{
+    v = dpp_add_from<0x111, 0xf>(v); // row_shr:1
+    v = dpp_add_from<0x112, 0xf>(v); // row_shr:2
+    v = dpp_add_from<0x114, 0xf>(v); // row_shr:4
+    v = dpp_add_from<0x118, 0xf>(v); // row_shr:8
+    v = dpp_add_from<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v = dpp_add_from<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // ---- group primitives: G threads that partition one range together (a wavefront or a workgroup)
 template <int G> struct group;
 template <> struct group<64>
@@ -131,16 +149,8 @@ template <> struct group<64>
     // exclusive prefix of v over the group's threads, *total = the sum
     static __device__ __forceinline__ unsigned int scan(unsigned int v, unsigned int *total, unsigned int *)
     {
-        const int lane = tid();
-        unsigned int incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1)
-        {
-            const unsigned int o = (unsigned int)__shfl_up((int)incl, off);
-            if (lane >= off)
-                incl += o;
-        }
-        *total = (unsigned int)__shfl((int)incl, 63);
+        const unsigned int incl = wave_inclusive_scan(v);
+        *total = (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
         return incl - v;
     }
 };
@@ -154,21 +164,29 @@ template <> struct group<GROUP>
     {
         __syncthreads();
     }
+    // a wavefront scan per wavefront, the wavefronts' totals scanned by the first one: two barriers (a Hillis-Steele scan
+    // over the workgroup in LDS took twenty)
     static __device__ __forceinline__ unsigned int scan(unsigned int v, unsigned int *total, unsigned int *lds /*[GROUP]*/)
     {
-        const int t = threadIdx.x;
+        static_assert(GROUP / 64 <= 16, "the wavefronts' totals fit one row of a wavefront scan");
+        const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+        const unsigned int incl = wave_inclusive_scan(v);
+        __syncthreads(); // (lds may still be read as the previous scan's result)
+        if (lane == 63)
+            lds[wv] = incl;
         __syncthreads();
-        lds[t] = v;
-        __syncthreads();
-        for (int off = 1; off < GROUP; off <<= 1)
+        if (wv == 0)
         {
-            const unsigned int o = t >= off ? lds[t - off] : 0u;
-            __syncthreads();
-            lds[t] += o;
-            __syncthreads();
+            const unsigned int w = lane < GROUP / 64 ? lds[lane] : 0u;
+            const unsigned int wi = wave_inclusive_scan(w);
+            if (lane < GROUP / 64)
+                lds[32 + lane] = wi - w; // exclusive prefix of the wavefronts' totals
+            if (lane == GROUP / 64 - 1)
+                lds[64] = wi;
         }
-        *total = lds[GROUP - 1];
-        return lds[t] - v;
+        __syncthreads();
+        *total = lds[64];
+        return lds[32 + wv] + incl - v;
     }
 };
 
