@@ -60,6 +60,12 @@ __device__ __forceinline__ lane_state merge(const lane_state &a, const lane_stat
     return r;
 }
 
+template <int CTRL> __device__ __forceinline__ lane_state dpp_state(const lane_state &s)
+{
+    auto mv = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xf, 0xf, false); };
+    return lane_state{mv(s.best), mv(s.second), mv(s.idx), mv(s.count)};
+}
+
 // the search of one query by one wavefront: every lane ends with the merged (best, second, index, count)
 __device__ __forceinline__ lane_state dense_search(const dense_image_meta &m, const uint64_t *__restrict__ desc, const double2 *__restrict__ loc,
                                                    const uint32_t *__restrict__ cell_start, uint32_t src_feature, double qx, double qy,
@@ -105,7 +111,15 @@ __device__ __forceinline__ lane_state dense_search(const dense_image_meta &m, co
                 }
             }
         }
-    for (int off = 32; off >= 1; off >>= 1)
+    // all-lanes merge: inside the rows of 16 lanes by DPP moves (quad permutes, then rotations by 4 and 8 - merge is
+    // commutative and associative and every lane's state enters once), across the rows by two shuffle stages; six stages of
+    // four LDS-crossbar shuffles each were as long as the search of a sparsely populated disc
+    s = merge(s, dpp_state<0xB1>(s));  // quad_perm [1, 0, 3, 2]
+    s = merge(s, dpp_state<0x4E>(s));  // quad_perm [2, 3, 0, 1]
+    s = merge(s, dpp_state<0x124>(s)); // row_ror:4
+    s = merge(s, dpp_state<0x128>(s)); // row_ror:8
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1)
     {
         lane_state o;
         o.best = __shfl_xor(s.best, off);
