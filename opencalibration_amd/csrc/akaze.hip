@@ -985,6 +985,184 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
             wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// ---- round 5: the same determinant + maxima pass as a register strip.  The counters had det_maxima_kernel issue-bound
+// (145 vector instructions per pixel: sixteen LDS taps, their address arithmetic and the products of every pixel's own
+// copy of the Scharr pattern).  The pattern's terms are shared between pixels: with hd(x, y) = f(x + S, y) - f(x - S, y)
+// and vd(x, y) = f(x, y + S) - f(x, y - S),
+//     d/dx f = (wa hd(x, y - S) + wb hd(x, y)) + wa hd(x, y + S),     d/dy f = (wa vd(x - S, y) + wb vd(x, y)) + wa vd(x + S, y)
+// - the same float expressions pattern_lds evaluates, every difference and every product formed once per pixel instead of
+// three times.  A wavefront owns a strip of 128 columns (a PAIR per lane: every operation is a packed fp32 instruction)
+// and walks it top to bottom with the rows it still needs in registers; what comes from the lanes S columns away goes
+// through a row buffer in LDS that belongs to the wavefront (no workgroup barrier anywhere).  ~20 vector instructions
+// per pixel.  Nothing reflects: a maximum needs its descriptor window inside the image (margin >= 28 pixels), so no
+// determinant within the stencil's reach of the border is ever looked at; loads outside the image are clamped into it.
+// The maxima leave as bits of the level's mask words by atomicOr and as per-tile counts by atomicAdd (both zeroed by
+// the host; integers, so the order is free): a strip is 116 / 120 columns wide, not a multiple of the 64-pixel words.
+constexpr int DS_PAD = 8;  // columns of padding on either side of a wavefront's row buffers (>= S)
+constexpr int DS_RING = 1; // the ring of requested rows is DS_RING (2 S + 1) long (2: 10 - 16 rows in flight per lane at 2 - 3
+                           // wavefronts per SIMD instead of 4 at 4: 31.1 us per image against 28.5)
+template <int S> struct det_strip_geom
+{
+    static constexpr int HALO = (S + 2) & ~1;   // columns of stencil margin on either side, even: 16-byte aligned pair loads
+    static constexpr int OW = 128 - 2 * HALO;   // output columns per strip
+    // the rows a strip still needs live in rings of U = 2 S + 1 registers; the row loop is unrolled U times (ring slots
+    // are then compile-time constants) and rolled over NB blocks: NB U input rows give NB U - 2 S - 2 rows of maxima
+    // (the loop body is RB = 2 U rows, which lets the ring of requested rows be RB long: RB - 2 row loads in flight per lane)
+    static constexpr int U = 2 * S + 1, RB = DS_RING * U, NB = (32 + 2 * S + 2 + RB - 1) / RB, NR = NB * RB;
+    static constexpr int H = NR - 2 * S - 2;    // output rows per strip (34, 34, 35)
+};
+
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); // (no NaN among determinants of finite pixels)
+    return r;
+}
+__device__ __forceinline__ float max2f(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); // (fmaxf would canonicalise both operands first)
+    return r;
+}
+__device__ __forceinline__ float2 subpixel_fit(float v, float vxm, float vxp, float vym, float vyp, float vmm, float vpm, float vmp, float vpp)
+{
+    // AKAZE's Do_Subpixel_Refinement on the nine determinants around an extremum (vpm = (x + 1, y - 1), ...)
+    const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
+    const float Dxx = (vxp + vxm) - 2.0f * v, Dyy = (vyp + vym) - 2.0f * v;
+    const float Dxy = 0.25f * ((vpp + vmm) - (vmp + vpm));
+    const float det = Dxx * Dyy - Dxy * Dxy;
+    if (det == 0.0f)
+        return make_float2(2.0f, 2.0f); // a singular fit is no keypoint
+    return make_float2((Dxy * Dy - Dyy * Dx) / det, (Dxy * Dx - Dxx * Dy) / det);
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void det_strip_kernel(const float2 *__restrict__ Lxy, size_t stride, float2 *__restrict__ Fit,
+                                                        float *__restrict__ Rmax, int w, int h, float thr,
+                                                        unsigned int *__restrict__ tile_counts, int tile_off, int n_tiles,
+                                                        int4 win /*columns .x .. .y and rows .z .. .w may hold a maximum*/,
+                                                        unsigned long long *__restrict__ mask, size_t mask_stride)
+{
+    typedef float pk2 __attribute__((ext_vector_type(2)));
+    typedef det_strip_geom<S> G;
+    constexpr int HALO = G::HALO, OW = G::OW, U = G::U, RB = G::RB, NB = G::NB, SH = G::H;
+    constexpr int LROW = 128 + 2 * DS_PAD;
+    __shared__ __attribute__((aligned(16))) float ex[4][3][LROW];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strips_x = (w + OW - 1) / OW, strips_y = (h + SH - 1) / SH;
+    const int groups = (strips_x * strips_y + 3) / 4, chunk = (groups + 7) / 8;
+    // workgroups go to the XCDs round-robin: every XCD takes a contiguous eighth of the strips (neighbours share halos in its L2)
+    const int g = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || g >= groups)
+        return;
+    const int sid = g * 4 + wv;
+    if (sid >= strips_x * strips_y)
+        return;
+    const int sy = sid / strips_x, sx = sid - sy * strips_x;
+    const int X0 = sx * OW, Y0 = sy * SH;
+    const int cx = X0 - HALO + 2 * lane;                // this lane's two columns: cx, cx + 1
+    const int cxc = min(max(cx, 0), max(w - 2, 0));     // clamped into the image (such columns are never maxima)
+    const float2 *XY = Lxy + (size_t)blockIdx.z * stride;
+    float *const eX = &ex[wv][0][DS_PAD + 2 * lane], *const eA = &ex[wv][1][DS_PAD + 2 * lane], *const eB = &ex[wv][2][DS_PAD + 2 * lane];
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // LDS writes of the wave before LDS reads after
+        __builtin_amdgcn_wave_barrier();
+    };
+    const float wgt = 10.0f / 3.0f;
+    const float nrm = 1.0f / (2.0f * (float)S * (wgt + 2.0f));
+    const float wn = wgt * nrm;
+    const float s4 = (float)(S * S * S * S);
+    const pk2 wa = {nrm, nrm}, wb = {wn, wn}, s44 = {s4, s4};
+    // a column this strip owns, inside the window of interior pixels whose descriptor patch stays inside the level image
+    // (Find_Scale_Space_Extrema's margin test is monotone in x and in y: the host evaluates it once per level, det_window)
+    auto col_ok = [&](int x) { return x >= X0 && x < X0 + OW && x >= win.x && x <= win.y; };
+    const bool xok0 = col_ok(cx), xok1 = col_ok(cx + 1);
+    const int tiles_x = (w + BT_X - 1) / BT_X;
+
+    constexpr int PF = RB - 2 < 4 ? RB - 2 : (DS_RING == 1 ? 4 : RB - 2); // rows requested ahead
+    float4 ld[RB];
+    auto request = [&](int r, int slot) {
+        const int gy = min(max(Y0 - (S + 1) + r, 0), h - 1);
+        ld[slot] = *reinterpret_cast<const float4 *>(XY + (size_t)gy * w + cxc);
+    };
+#pragma unroll
+    for (int r = 0; r < PF; r++)
+        request(r, r);
+    // rings indexed by (input row) mod U; what a slot holds before its first row arrives is never looked at by a row
+    // whose maxima count (the warm-up rows fall outside [Y0, Y0 + SH))
+    pk2 X[U], Y[U], pa_hd[U], pb_hd[U], D[U], T[U], Sd[U];
+    float DL[U], DR[U];
+#pragma unroll
+    for (int j = 0; j < U; j++)
+    {
+        X[j] = Y[j] = pa_hd[j] = pb_hd[j] = D[j] = T[j] = Sd[j] = pk2{0.0f, 0.0f};
+        DL[j] = DR[j] = 0.0f;
+    }
+    for (int k = 0; k < NB; k++)
+    {
+#pragma unroll
+        for (int jj = 0; jj < RB; jj++)
+        {
+            const int r = k * RB + jj;              // input row of the strip; image row Y0 - (S + 1) + r
+            constexpr int UU = U;                   // (ring slots: r - 2 S -> j + 1, c = r - S -> j + S + 1, m = c - 1 -> j + S, m - 1 -> j + S - 1)
+            const int j = jj % UU;
+            const int s_top = (j + 1) % UU, s_c = (j + S + 1) % UU, s_m = (j + S) % UU, s_mm = (j + S - 1) % UU;
+            request(r + PF, (jj + PF) % RB);
+            X[j] = pk2{ld[jj].x, ld[jj].z};
+            Y[j] = pk2{ld[jj].y, ld[jj].w};
+            const pk2 vdx = X[j] - X[s_top], vdy = Y[j] - Y[s_top];
+            const pk2 pbx = wb * vdx, pby = wb * vdy;
+            *reinterpret_cast<pk2 *>(eX) = X[j];
+            *reinterpret_cast<pk2 *>(eA) = wa * vdx;
+            *reinterpret_cast<pk2 *>(eB) = wa * vdy;
+            wave_sync();
+            const pk2 XL = {eX[-S], eX[-S + 1]}, XR = {eX[S], eX[S + 1]};
+            const pk2 paxL = {eA[-S], eA[-S + 1]}, paxR = {eA[S], eA[S + 1]};
+            const pk2 payL = {eB[-S], eB[-S + 1]}, payR = {eB[S], eB[S + 1]};
+            const pk2 hd = XR - XL;
+            pa_hd[j] = wa * hd;
+            pb_hd[j] = wb * hd;
+            // row c = r - S: its determinants are complete now
+            const pk2 lxx = (pa_hd[s_top] + pb_hd[s_c]) + pa_hd[j];
+            const pk2 lxy = (paxL + pbx) + paxR;
+            const pk2 lyy = (payL + pby) + payR;
+            const pk2 d = (lxx * lyy - lxy * lxy) * s44;
+            D[s_c] = d;
+            DL[s_c] = lane_left(d.y);  // determinant at column cx - 1
+            DR[s_c] = lane_right(d.x); // at column cx + 2
+            T[s_c] = pk2{max3f(DL[s_c], d.x, d.y), max3f(d.x, d.y, DR[s_c])};
+            Sd[s_c] = pk2{max2f(DL[s_c], d.y), max2f(d.x, DR[s_c])};
+            // row m = c - 1: rows m - 1, m, m + 1 are there once r >= 2 S + 2.  A strict maximum of its 3 x 3 neighbourhood
+            // is greater than the largest of the eight (straight-line code: the tests are cheaper than branches around them)
+            const int y = Y0 - (S + 1) + r - S - 1;
+            const bool y_ok = (r >= 2 * S + 2) & (y >= win.z) & (y <= win.w);
+            const float v0 = D[s_m].x, v1 = D[s_m].y;
+            const bool is0 = y_ok & xok0 & (v0 > thr) & (v0 > max3f(T[s_mm].x, T[s_c].x, Sd[s_m].x));
+            const bool is1 = y_ok & xok1 & (v1 > thr) & (v1 > max3f(T[s_mm].y, T[s_c].y, Sd[s_m].y));
+            if (__ballot(is0 | is1)) // (a few per cent of the rows of a strip hold a maximum)
+            {
+                const size_t row = (size_t)blockIdx.z * stride + (size_t)y * w;
+                if (is0)
+                {
+                    Rmax[row + cx] = v0;
+                    Fit[row + cx] = subpixel_fit(v0, DL[s_m], v1, D[s_mm].x, D[s_c].x, DL[s_mm], D[s_mm].y, DL[s_c], D[s_c].y);
+                    atomicOr(&mask[(size_t)blockIdx.z * mask_stride + (size_t)y * tiles_x + (cx >> 6)], 1ull << (cx & 63));
+                    atomicAdd(&tile_counts[(size_t)blockIdx.z * n_tiles + tile_off + (y / DT_Y) * tiles_x + (cx >> 6)], 1u);
+                }
+                if (is1)
+                {
+                    const int x = cx + 1;
+                    Rmax[row + x] = v1;
+                    Fit[row + x] = subpixel_fit(v1, v0, DR[s_m], D[s_mm].y, D[s_c].y, D[s_mm].x, DR[s_mm], D[s_c].x, DR[s_c]);
+                    atomicOr(&mask[(size_t)blockIdx.z * mask_stride + (size_t)y * tiles_x + (x >> 6)], 1ull << (x & 63));
+                    atomicAdd(&tile_counts[(size_t)blockIdx.z * n_tiles + tile_off + (y / DT_Y) * tiles_x + (x >> 6)], 1u);
+                }
+            }
+            wave_sync(); // the row buffers have been read by every lane before the next row's stores
+        }
+    }
+}
+
 struct levels_dev
 {
     int n;
@@ -2612,6 +2790,18 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     }
     // ---- derivatives, determinant, maxima
     OCHIP_HIP(ctx, hipMemsetAsync(d_ncand, 0, B * 4, st));
+    // the register-strip form loads pairs of float2 with 16-byte loads: even widths and plane offsets (every level of an
+    // image whose working width is a multiple of 8; the tile form takes the rest, and OCHIP_TEST_HOOKS=tile_det all)
+    static const bool strip_hook = !ochip_test_hook("tile_det");
+    bool det_strips = strip_hook && (img_stride & 1) == 0 && ((uintptr_t)d_Lxy & 15) == 0;
+    for (int i = 0; i < LV.n; i++)
+        det_strips = det_strips && (LV.l[i].w & 1) == 0 && (LV.l[i].off & 1) == 0 && LV.l[i].w >= 2;
+    if (det_strips)
+    {
+        // the strips add their maxima to zeroed masks and tile counts (the tile form writes every word itself)
+        OCHIP_HIP(ctx, hipMemsetAsync(d_mask, 0, (size_t)B * mask_stride * 8, st));
+        OCHIP_HIP(ctx, hipMemsetAsync(d_tile_counts, 0, (size_t)B * n_tiles * 4, st));
+    }
     for (int i = 0; i < LV.n; i++)
     {
         const level_info &l = LV.l[i];
@@ -2640,7 +2830,38 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             float2 *ld = d_Fit + l.off;
             float *rm = d_Rmax + l.off;
             const float margin = (10.0f * std::sqrt(2.0f)) * (float)l.sigma_size; // descriptor window half width, M-LDB
-            if (l.sigma_size == 2)
+            // the columns / rows whose descriptor window [round(x - margin) - 1, round(x + margin) + 1] stays inside the level
+            // (the predicate det_maxima_kernel evaluates per pixel: an interval in x and in y)
+            int4 win = make_int4(1, 0, 1, 0);
+            {
+                auto span = [&](int n, int *lo, int *hi) {
+                    bool any = false;
+                    for (int v = 1; v < n - 1; v++)
+                        if ((int)std::rint((float)v - margin) - 1 >= 0 && (int)std::rint((float)v + margin) + 1 < n)
+                        {
+                            if (!any)
+                                *lo = v;
+                            *hi = v;
+                            any = true;
+                        }
+                };
+                span(l.w, &win.x, &win.y);
+                span(l.h, &win.z, &win.w);
+            }
+            auto strip_grid = [&](int ow, int sh) {
+                const int strips = ((l.w + ow - 1) / ow) * ((l.h + sh - 1) / sh);
+                return dim3(8 * (((strips + 3) / 4 + 7) / 8), 1, B);
+            };
+            if (det_strips && l.sigma_size == 2)
+                hipLaunchKernelGGL((det_strip_kernel<2>), strip_grid(det_strip_geom<2>::OW, det_strip_geom<2>::H), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, win, d_mask + l.mask_off, mask_stride);
+            else if (det_strips && l.sigma_size == 3)
+                hipLaunchKernelGGL((det_strip_kernel<3>), strip_grid(det_strip_geom<3>::OW, det_strip_geom<3>::H), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, win, d_mask + l.mask_off, mask_stride);
+            else if (det_strips)
+                hipLaunchKernelGGL((det_strip_kernel<4>), strip_grid(det_strip_geom<4>::OW, det_strip_geom<4>::H), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
+                                   l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, win, d_mask + l.mask_off, mask_stride);
+            else if (l.sigma_size == 2)
                 hipLaunchKernelGGL((det_maxima_kernel<2>), det_tiles(l.w, l.h), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin, d_mask + l.mask_off, mask_stride);
             else if (l.sigma_size == 3)

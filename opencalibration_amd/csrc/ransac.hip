@@ -59,7 +59,7 @@ template <int CTRL> __device__ __forceinline__ void first_maximum_stage(double &
 }
 __device__ __forceinline__ void wave_first_maximum(double &bv, uint32_t &bi, uint32_t &bj)
 {
-    uint32_t key = (bj << 16) | bi; // (column, row): both below 65 536
+    uint32_t key = (bj << 28) | bi; // (column, row): a column is below 9 (4 bits), which leaves 28 bits to the row
     first_maximum_stage<0xB1>(bv, key);  // quad_perm [1, 0, 3, 2]
     first_maximum_stage<0x4E>(bv, key);  // quad_perm [2, 3, 0, 1]
     first_maximum_stage<0x124>(bv, key); // row_ror:4
@@ -67,8 +67,8 @@ __device__ __forceinline__ void wave_first_maximum(double &bv, uint32_t &bi, uin
 #pragma unroll
     for (int off = 16; off <= 32; off <<= 1)
         first_maximum_take(bv, key, __shfl_xor(bv, off), __shfl_xor(key, off));
-    bi = key & 0xFFFFu;
-    bj = key >> 16;
+    bi = key & 0x0FFFFFFFu;
+    bj = key >> 28;
 }
 
 constexpr int W = 64;
