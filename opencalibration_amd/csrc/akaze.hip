@@ -20,6 +20,7 @@
 #include <cmath>
 #include <limits>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace
@@ -286,7 +287,48 @@ struct blur_args
     float *out2;               // unused.  DERIV: out0 = the interleaved (Lx, Ly) float2 plane, out_stride in float2;
                                // FLOW_DERIV: out1 = that plane with out2_stride (float2), out0 = conductivity with out_stride
     size_t out2_stride;
+    int frame;                 // > 0: only the tiles within `frame` pixels of the image border (the strip kernel has done the rest; frame_tile)
 };
+
+// the tiles that hold a pixel within `reach` pixels of the image border, one per workgroup: tile row 0 and the last nb tile
+// rows in full, of the rows between them tile column 0 and the last nr tile columns (nb, nr: 1, or 2 when the last tile
+// row / column is thinner than the reach)
+struct frame_dims
+{
+    int nb, nr, count;
+};
+__host__ __device__ inline frame_dims frame_tiles(int w, int h, int reach)
+{
+    const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
+    frame_dims f;
+    const int yb = (h - reach > 0 ? h - reach : 0) / BT_Y, xb = (w - reach > 0 ? w - reach : 0) / BT_X;
+    f.nb = tiles_y - yb < tiles_y - 1 ? tiles_y - yb : tiles_y - 1; // tile rows from the one holding row h - reach down
+    f.nr = tiles_x - xb < tiles_x - 1 ? tiles_x - xb : tiles_x - 1;
+    const int mid = tiles_y - 1 - f.nb > 0 ? tiles_y - 1 - f.nb : 0;
+    f.count = tiles_x * (1 + f.nb) + mid * (1 + f.nr < tiles_x ? 1 + f.nr : tiles_x);
+    return f;
+}
+__device__ __forceinline__ bool frame_tile(int w, int h, int reach, int *tx, int *ty)
+{
+    const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
+    const frame_dims f = frame_tiles(w, h, reach);
+    int t = (int)blockIdx.x;
+    if (t >= f.count)
+        return false;
+    if (t < tiles_x * (1 + f.nb))
+    {
+        const int row = t / tiles_x;
+        *tx = t - row * tiles_x;
+        *ty = row == 0 ? 0 : tiles_y - f.nb + (row - 1);
+        return true;
+    }
+    t -= tiles_x * (1 + f.nb);
+    const int per = 1 + f.nr < tiles_x ? 1 + f.nr : tiles_x;
+    const int row = t / per, c = t - row * per;
+    *ty = 1 + row;
+    *tx = c == 0 ? 0 : tiles_x - f.nr + (c - 1);
+    return true;
+}
 
 template <int MODE, int M /*margin of the blurred tile*/, int R /*tap radius*/>
 __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
@@ -301,7 +343,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
     const int w = A.w, h = A.h;
     const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
     int tile_x, tile_y;
-    if (!xcd_tile(tiles_x, tiles_y, &tile_x, &tile_y))
+    if (!(A.frame ? frame_tile(w, h, A.frame, &tile_x, &tile_y) : xcd_tile(tiles_x, tiles_y, &tile_x, &tile_y)))
         return;
     const int x0 = tile_x * BT_X, y0 = tile_y * BT_Y;
     const int bx0 = x0 - M, by0 = y0 - M;
@@ -1159,6 +1201,304 @@ __global__ __launch_bounds__(256) void det_strip_kernel(const float2 *__restrict
                 }
             }
             wave_sync(); // the row buffers have been read by every lane before the next row's stores
+        }
+    }
+}
+
+// ---- round 5: a level's passes in ONE launch, in the same register-strip form: Lsmooth (Gaussian(1) of the image the
+// level starts from) -> conductivity and scale-s derivatives (blur_fused_kernel<FLOW_DERIV>), and behind them the level's
+// first K <= 4 explicit diffusion steps (nld_fused_kernel<K>) - for the levels of the first octave all of them, so that the
+// conductivity plane is neither written nor read and the image is read once: 16 bytes per pixel and level instead of 28.
+// A wavefront owns 128 columns (a pair per lane) and streams its rows top to bottom; every stage keeps the few rows
+// it still needs in registers and runs a fixed number of rows behind the loads:
+//     input row r -> row pass (neighbour pairs by DPP wavefront shifts) -> column pass: Lsmooth row c = r - 2
+//     -> conductivity of row f = r - 3 (Scharr pattern at distance 1: neighbours by DPP; reflected taps along the image
+//        border are selects, so the plane is exact everywhere - the diffusion spreads it)
+//     -> (Lx, Ly) of row r - 2 - S (pattern at distance S: the lanes S columns away through the wavefront's own LDS rows,
+//        one wavefront-level synchronisation per row, two alternating sets of rows)
+//     -> diffusion step q = 1..K on row f - q: each step lags the one before by a row and keeps one row of its input and
+//        the flux through its upper edge (the in-place sweep of nld_fused_kernel, turned into a pipeline)
+// Every value is the float expression of the tile / sweep kernels (ascending taps from 0; the pattern's (wa a + wb b) + wa c
+// with every difference and product formed once; the flux (c_a + c_b)(L_b - L_a) used with both signs, 0 across the
+// border).  Replicated borders of the Gaussian: clamped loads.  The reflected taps of the scale-s pattern within S pixels of
+// the border: other ring slots for the rows (wave-uniform selects), per-lane LDS offsets for the columns of a border strip.
+// Measured and dropped: the determinant + maxima stage of det_strip_kernel behind the derivatives in this launch (156 - 208
+// registers, two wavefronts per SIMD: 70 us per image for the fused launch against 63 for the two).
+template <int S, int K> struct level_strip_geom
+{
+    static constexpr int U = 2 * S + 1;
+    static constexpr int RD = S + 2, RN = K > 0 ? K + 3 : 3;
+    static constexpr int REACH = RD > RN ? RD : RN; // input rows / columns beyond an output, and rows an output lags its last input
+    static constexpr int HALO = (REACH + 1) & ~1;
+    static constexpr int OW = 128 - 2 * HALO;
+    static constexpr int NB = (64 + 2 * REACH + U - 1) / U, NR = NB * U, H = NR - 2 * REACH;
+};
+struct level_strip_args
+{
+    const float *in;
+    size_t in_stride;
+    float *flow;
+    size_t flow_stride;
+    float2 *Lxy;
+    size_t lxy_stride;
+    float *Lout; // the image after the K steps
+    size_t lout_stride;
+    int w, h;
+    const float *kcontrast;
+    int n_octave_steps;
+    float k[5]; // Gaussian(1) taps
+    fed_tau_group T;
+};
+
+// 1 / d for 1 <= d < 2^96, correctly rounded: the compiler's own division sequence (v_rcp_f32, Newton step, quotient,
+// two residual corrections) without the scaling and fix-up instructions that only act outside that range
+__device__ __forceinline__ float recip_ge1(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = r; // 1.0f * r
+    const float e2 = __builtin_fmaf(-d, q, 1.0f);
+    q = __builtin_fmaf(e2, r, q);
+    const float e3 = __builtin_fmaf(-d, q, 1.0f);
+    return __builtin_fmaf(e3, r, q);
+}
+
+template <int S, int K, bool SF /*the conductivity plane is stored: later launches of the level need it*/>
+__global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
+{
+    typedef float pk2 __attribute__((ext_vector_type(2)));
+    typedef level_strip_geom<S, K> G;
+    constexpr int HALO = G::HALO, OW = G::OW, U = G::U, NB = G::NB, SH = G::H, REACH = G::REACH;
+    constexpr int LROW = 128 + 2 * DS_PAD, SET = 2 * LROW;
+    __shared__ __attribute__((aligned(16))) float ex[4][2][SET];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = A.w, h = A.h;
+    const int strips_x = (w + OW - 1) / OW, strips_y = (h + SH - 1) / SH;
+    const int groups = (strips_x * strips_y + 3) / 4, chunk = (groups + 7) / 8;
+    const int g = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || g >= groups)
+        return;
+    const int sid = g * 4 + wv;
+    if (sid >= strips_x * strips_y)
+        return;
+    const int sy = sid / strips_x, sx = sid - sy * strips_x;
+    const int X0 = sx * OW, Y0 = sy * SH;
+    const int cx = X0 - HALO + 2 * lane;            // this lane's two columns: cx, cx + 1 (cx and w are even)
+    const int cxc = min(max(cx, 0), w - 2);
+    const bool own_cols = cx >= X0 && cx < X0 + OW && cx < w;
+    const float *I = A.in + (size_t)blockIdx.z * A.in_stride;
+    float *const e0 = &ex[wv][0][DS_PAD + 2 * lane];
+    float kc = A.kcontrast[blockIdx.z];
+    for (int i = 0; i < A.n_octave_steps; i++) // kcontrast *= 0.75 at every new octave, one rounding per step
+        kc = kc * 0.75f;
+    const float inv1 = 1.0f / (kc * kc);
+    const float wgt = 10.0f / 3.0f;
+    const float nrm1 = 1.0f / (2.0f * (float)S * (wgt + 2.0f));
+    const float wn1 = wgt * nrm1;
+    const pk2 wa = {nrm1, nrm1}, wb = {wn1, wn1}, inv = {inv1, inv1};
+    const pk2 k0 = {A.k[0], A.k[0]}, k1 = {A.k[1], A.k[1]}, k2 = {A.k[2], A.k[2]}, k3 = {A.k[3], A.k[3]}, k4 = {A.k[4], A.k[4]};
+    const pk2 c3 = {3.0f, 3.0f}, c10 = {10.0f, 10.0f}, zero = {0.0f, 0.0f}, one = {1.0f, 1.0f};
+    // rows of the planes this strip writes: a wave-uniform base plus this lane's byte offset
+    char *const flow_b = reinterpret_cast<char *>(A.flow + (size_t)blockIdx.z * A.flow_stride);
+    char *const lxy_b = reinterpret_cast<char *>(A.Lxy + (size_t)blockIdx.z * A.lxy_stride);
+    char *const lout_b = reinterpret_cast<char *>(A.Lout + (size_t)blockIdx.z * A.lout_stride);
+    const unsigned int col4 = (unsigned int)cxc * 4u, col8 = (unsigned int)cxc * 8u;
+    const int row_end = min(Y0 + SH, h); // rows [Y0, row_end) are this strip's
+
+    constexpr int PF = U - 1 < 6 ? U - 1 : 6; // rows requested ahead
+    // rings indexed by (row) mod U
+    float2 ld[U];
+    pk2 gr[U], Ls[U], p3[U], p10[U], paS[U], pbS[U], Lraw[U], C[U], CX[U], CY[U];
+    pk2 Lsave[K + 1], Fsave[K + 1];
+    auto request = [&](int r, int slot) {
+        const int gy = min(max(Y0 - REACH + r, 0), h - 1);
+        ld[slot] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(I + (size_t)gy * w) + col4);
+    };
+#pragma unroll
+    for (int r = 0; r < PF; r++)
+        request(r, r);
+#pragma unroll
+    for (int j = 0; j < U; j++)
+        gr[j] = Ls[j] = p3[j] = p10[j] = paS[j] = pbS[j] = Lraw[j] = C[j] = CX[j] = CY[j] = zero;
+#pragma unroll
+    for (int q = 0; q <= K; q++)
+        Lsave[q] = Fsave[q] = zero;
+
+    // One input row.  EDGE: the strip comes within reach of the image border - replicated columns for the Gaussian,
+    // reflected taps for the two patterns, no flux across the border; the strips inside the image (three quarters of a
+    // 1600 x 1200 level) run the same rows without any of those selects.
+    auto row = [&](auto edge_tag, const int r, const int j) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        constexpr auto sl = [](int x) constexpr { return ((x % (2 * S + 1)) + (2 * S + 1)) % (2 * S + 1); };
+        auto wave_sync = []() {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+        const int gy = Y0 - REACH + r; // image row of this input row
+        float *const eb = e0 + (r & 1) * SET;
+        float *const eL = eb, *const eV = eb + LROW;
+        request(r + PF, sl(j + PF));
+        // ---- row pass
+        pk2 own = {ld[j].x, ld[j].y};
+        if (EDGE) // replicate border: both columns of a lane outside the image take the border pixel
+            own = cx < 0 ? pk2{own.x, own.x} : (cx >= w ? pk2{own.y, own.y} : own);
+        Lraw[j] = own;
+        const pk2 Lm = {lane_left(own.x), lane_left(own.y)}, Lp = {lane_right(own.x), lane_right(own.y)};
+        pk2 t = zero + k0 * Lm;
+        t = t + k1 * pk2{Lm.y, own.x};
+        t = t + k2 * own;
+        t = t + k3 * pk2{own.y, Lp.x};
+        t = t + k4 * Lp;
+        gr[j] = t;
+        // ---- column pass: Lsmooth of row c = r - 2
+        pk2 a = zero + k0 * gr[sl(j - 4)];
+        a = a + k1 * gr[sl(j - 3)];
+        a = a + k2 * gr[sl(j - 2)];
+        a = a + k3 * gr[sl(j - 1)];
+        a = a + k4 * gr[j];
+        const int s_c = sl(j - 2);
+        // ---- conductivity of row f = c - 1 (image row yf); reflected taps: row / column -1 is 1, h is h - 2
+        const int yf = gy - 3, s_f = sl(j - 3);
+        const bool first_col = EDGE && cx == 0, last_col = EDGE && cx == w - 2;
+        const bool f_top = EDGE && yf == 0, f_bot = EDGE && yf == h - 1;
+        pk2 cf;
+        {
+            // (the wavefront shifts run with every lane active - a lane masked off would hand its neighbour nothing -
+            // and the border lanes choose afterwards)
+            const float lft_n = lane_left(a.y), rgt_n = lane_right(a.x);
+            const float lft = first_col ? a.y : lft_n, rgt = last_col ? a.x : rgt_n;
+            const pk2 hd1 = pk2{a.y, rgt} - pk2{lft, a.x};
+            p3[s_c] = c3 * hd1;
+            p10[s_c] = c10 * hd1;
+            const pk2 vd1 = (f_top || f_bot) ? zero : a - Ls[sl(s_c - 2)];
+            const pk2 q3 = c3 * vd1, q10 = c10 * vd1;
+            const float q3l_n = lane_left(q3.y), q3r_n = lane_right(q3.x);
+            const float q3l = first_col ? q3.y : q3l_n, q3r = last_col ? q3.x : q3r_n;
+            const pk2 ptop = f_top ? p3[s_c] : p3[sl(s_c - 2)], pbot = f_bot ? p3[sl(s_c - 2)] : p3[s_c];
+            const pk2 lx = (ptop + p10[sl(s_c - 1)]) + pbot;
+            const pk2 ly = (pk2{q3l, q3.x} + q10) + pk2{q3.y, q3r};
+            const pk2 den = one + inv * (lx * lx + ly * ly);
+            cf = pk2{recip_ge1(den.x), recip_ge1(den.y)};
+            if (SF && own_cols && yf >= Y0 && yf < row_end)
+                *reinterpret_cast<float2 *>(flow_b + (size_t)yf * w * 4 + col4) = make_float2(cf.x, cf.y);
+        }
+        // ---- what the lanes S columns away need of this row: Lsmooth (row c) and wa vd (row d = c - S).  The pattern's
+        // rows d - S and d + S reflect at the image border (BORDER_REFLECT_101): row -t is row t, i.e. the ring slot 2 t
+        // rows back when d = t < S; row h - 1 + e is row h - 1 - e, the slot 2 e rows back.
+        const int yd = gy - 2 - S;           // image row of d
+        const int e_bot = gy - 2 - (h - 1);  // > 0: row c lies e_bot rows below the image
+        pk2 LsT = Ls[sl(s_c + 1)], LsB = a;  // rows c - 2 S and c
+        if (EDGE && yd < S)
+        {
+#pragma unroll
+            for (int tt = 0; tt < S; tt++)
+                if (yd == tt)
+                    LsT = tt == 0 ? a : Ls[sl(s_c - 2 * tt)];
+        }
+        if (EDGE && e_bot > 0)
+        {
+#pragma unroll
+            for (int ee = 1; ee <= S; ee++)
+                if (e_bot == ee)
+                    LsB = Ls[sl(s_c - 2 * ee)];
+        }
+        const pk2 vdS = LsB - LsT;
+        Ls[s_c] = a;
+        const pk2 pbv = wb * vdS;
+        *reinterpret_cast<pk2 *>(eL) = a;
+        *reinterpret_cast<pk2 *>(eV) = wa * vdS;
+        wave_sync();
+        pk2 aL, aR, vL, vR;
+        if (!EDGE)
+        {
+            aL = pk2{eL[-S], eL[-S + 1]}, aR = pk2{eL[S], eL[S + 1]};
+            vL = pk2{eV[-S], eV[-S + 1]}, vR = pk2{eV[S], eV[S + 1]};
+        }
+        else
+        {
+            // columns reflect too: every lane reads where its own taps land (relative to column cx)
+            const int cxi = min(max(cx, 0), w - 2);
+            const int oLx = reflect101_once(cxi - S, w) - cx, oLy = reflect101_once(cxi + 1 - S, w) - cx;
+            const int oRx = reflect101_once(cxi + S, w) - cx, oRy = reflect101_once(cxi + 1 + S, w) - cx;
+            aL = pk2{eL[oLx], eL[oLy]}, aR = pk2{eL[oRx], eL[oRy]};
+            vL = pk2{eV[oLx], eV[oLy]}, vR = pk2{eV[oRx], eV[oRy]};
+        }
+        // ---- diffusion steps (independent of the exchange: they fill its latency)
+        if (K > 0)
+        {
+            C[s_f] = cf;
+            const float crx = lane_right(cf.x);
+            CX[s_f] = cf + pk2{cf.y, crx};         // c(x) + c(x + 1)
+            CY[sl(s_f - 1)] = C[sl(s_f - 1)] + cf; // c(y) + c(y + 1) of row f - 1
+            pk2 Ln = Lraw[s_f];                    // the previous step's row below the one a step works on
+            // a right neighbour of column cx + 1 / a left neighbour of column cx exists
+            const bool hr1 = !EDGE || cx + 2 < w, hl0 = !EDGE || cx > 0;
+#pragma unroll
+            for (int q = 1; q <= K; q++)
+            {
+                const int s_y = sl(s_f - q), yq = yf - q; // step q works on image row yq
+                const pk2 Lc = q == 1 ? Lraw[s_y] : Lsave[q - 1];
+                const float right = lane_right(Lc.x);
+                const pk2 d = pk2{Lc.y, right} - Lc;
+                pk2 xpos = CX[s_y] * d;
+                xpos.y = hr1 ? xpos.y : 0.0f;
+                const float xl = lane_left(xpos.y);
+                const pk2 xneg = {hl0 ? xl : 0.0f, xpos.x};
+                const pk2 ypos = (!EDGE || yq + 1 < h) ? CY[s_y] * (Ln - Lc) : zero;
+                const pk2 yneg = (!EDGE || yq > 0) ? Fsave[q] : zero;
+                const float half = 0.5f * A.T.tau[q - 1];
+                const pk2 Lq = Lc + pk2{half, half} * ((xpos - xneg) + (ypos - yneg));
+                Fsave[q] = ypos;
+                if (q > 1)
+                    Lsave[q - 1] = Ln;
+                Ln = Lq;
+                if (q == K && own_cols && yq >= Y0 && yq < row_end)
+                    *reinterpret_cast<float2 *>(lout_b + (size_t)yq * w * 4 + col4) = make_float2(Lq.x, Lq.y);
+            }
+        }
+        // ---- (Lx, Ly) of row d = c - S
+        const pk2 hdS = aR - aL;
+        paS[s_c] = wa * hdS;
+        pbS[s_c] = wb * hdS;
+        pk2 paT = paS[sl(s_c + 1)], paB = paS[s_c];
+        if (EDGE && yd < S)
+        {
+#pragma unroll
+            for (int tt = 0; tt < S; tt++)
+                if (yd == tt)
+                    paT = paS[sl(s_c - 2 * tt)];
+        }
+        if (EDGE && e_bot > 0)
+        {
+#pragma unroll
+            for (int ee = 1; ee <= S; ee++)
+                if (e_bot == ee)
+                    paB = paS[sl(s_c - 2 * ee)];
+        }
+        const pk2 Lx = (paT + pbS[sl(s_c - S)]) + paB;
+        const pk2 Ly = (vL + pbv) + vR;
+        if (own_cols && yd >= Y0 && yd < row_end)
+            *reinterpret_cast<float4 *>(lxy_b + (size_t)yd * w * 8 + col8) = make_float4(Lx.x, Ly.x, Lx.y, Ly.y);
+    };
+    // does any row or column this strip touches come within reach of the border?  (wave-uniform)
+    const bool edge = Y0 - REACH - 4 < S || Y0 + SH + REACH + 4 > h - 1 - S || X0 - HALO - 2 < S || X0 - HALO + 130 > w - 1 - S;
+    if (edge)
+    {
+        for (int k = 0; k < NB; k++)
+        {
+#pragma unroll
+            for (int j = 0; j < U; j++)
+                row(std::true_type{}, k * U + j, j);
+        }
+    }
+    else
+    {
+        for (int k = 0; k < NB; k++)
+        {
+#pragma unroll
+            for (int j = 0; j < U; j++)
+                row(std::false_type{}, k * U + j, j);
         }
     }
 }
@@ -2719,6 +3059,42 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         blur_args a{d_img, plane0, d_Lt + LV.l[0].off, nullptr, img_stride, W, H, nullptr, 0, nullptr, nullptr, 0};
         hipLaunchKernelGGL((blur_fused_kernel<BLUR_PLAIN, 0, 4>), tiles0, dim3(256), 0, st, a, g0);
     }
+    // the register-strip kernels load pairs of pixels with 8 / 16-byte loads: even widths and plane offsets (every level
+    // of an image whose working width is a multiple of 8; the tile kernels take the rest, and OCHIP_TEST_HOOKS=tile_det
+    // / tile_levels all of it)
+    static const bool strip_hook = !ochip_test_hook("tile_det"), level_hook = !ochip_test_hook("tile_levels");
+    bool det_strips = strip_hook && (img_stride & 1) == 0 && (plane0 & 1) == 0 && ((uintptr_t)d_Lxy & 15) == 0 && ((uintptr_t)d_Lt & 15) == 0 &&
+                      ((uintptr_t)d_flow & 15) == 0 && ((uintptr_t)d_ping & 15) == 0;
+    for (int i = 0; i < LV.n; i++)
+        det_strips = det_strips && (LV.l[i].w & 1) == 0 && (LV.l[i].off & 1) == 0 && LV.l[i].w >= 8 && LV.l[i].h >= 8;
+    const bool level_strips = det_strips && level_hook;
+    OCHIP_HIP(ctx, hipMemsetAsync(d_ncand, 0, B * 4, st));
+    if (det_strips)
+    {
+        // the strips add their maxima to zeroed masks and tile counts (the tile form writes every word itself)
+        OCHIP_HIP(ctx, hipMemsetAsync(d_mask, 0, (size_t)B * mask_stride * 8, st));
+        OCHIP_HIP(ctx, hipMemsetAsync(d_tile_counts, 0, (size_t)B * n_tiles * 4, st));
+    }
+    // the columns / rows whose descriptor window [round(x - margin) - 1, round(x + margin) + 1] stays inside the level
+    // (the predicate det_maxima_kernel evaluates per pixel: an interval in x and in y)
+    auto det_window = [&](const level_info &l) {
+        const float margin = (10.0f * std::sqrt(2.0f)) * (float)l.sigma_size; // descriptor window half width, M-LDB
+        int4 win = make_int4(1, 0, 1, 0);
+        auto span = [&](int n, int *lo, int *hi) {
+            bool any = false;
+            for (int v = 1; v < n - 1; v++)
+                if ((int)std::rint((float)v - margin) - 1 >= 0 && (int)std::rint((float)v + margin) + 1 < n)
+                {
+                    if (!any)
+                        *lo = v;
+                    *hi = v;
+                    any = true;
+                }
+        };
+        span(l.w, &win.x, &win.y);
+        span(l.h, &win.z, &win.w);
+        return win;
+    };
     int octave_steps = 0;
     for (int i = 1; i < LV.n; i++)
     {
@@ -2741,6 +3117,71 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             src_stride = dst_stride;
             octave_steps++;
         }
+        // balanced groups of <= FED_FUSE steps
+        auto group_size = [&](size_t g) { return n_steps / n_groups + (g < n_steps % n_groups ? 1 : 0); };
+        size_t first_group = 0; // launches of nld_fused_kernel start at this group
+        const bool strip_level = level_strips && l.sigma_size >= 2 && l.sigma_size <= 4 && l.w >= 64 && l.h >= 64 &&
+                                 (n_groups == 0 || (group_size(0) >= 2 && group_size(0) <= 4));
+        if (strip_level)
+        {
+            // ONE launch: Lsmooth -> conductivity + (Lx, Ly), and the level's first group of diffusion steps behind them (the
+            // whole cycle for the levels of the first octave: then the conductivity plane is not even stored)
+            const int K = n_groups ? (int)group_size(0) : 0;
+            const bool to_cur = n_groups == 0 || ((n_groups - 1) % 2) == 0;
+            float *dst = to_cur ? cur : d_ping;
+            const size_t dst_stride = to_cur ? img_stride : plane0;
+            level_strip_args sa{};
+            sa.in = src, sa.in_stride = src_stride;
+            sa.flow = d_flow, sa.flow_stride = plane0;
+            sa.Lxy = d_Lxy + l.off, sa.lxy_stride = img_stride;
+            sa.Lout = dst, sa.lout_stride = dst_stride;
+            sa.w = l.w, sa.h = l.h;
+            sa.kcontrast = d_kc, sa.n_octave_steps = octave_steps;
+            for (int q = 0; q < 5; q++)
+                sa.k[q] = g1.k[q];
+            for (int q = 0; q < K; q++)
+                sa.T.tau[q] = tsteps[i][q];
+            const bool store_flow = n_groups > 1 || std::getenv("OCHIP_DUMP_PLANES") != nullptr;
+            auto sgrid = [&](int ow, int sh) {
+                const int strips = ((l.w + ow - 1) / ow) * ((l.h + sh - 1) / sh);
+                return dim3(8 * (((strips + 3) / 4 + 7) / 8), 1, B);
+            };
+#define OCHIP_LEVEL_STRIP(SS, KK, FF)                                                                                                     \
+    hipLaunchKernelGGL((level_strip_kernel<SS, KK, FF>), sgrid(level_strip_geom<SS, KK>::OW, level_strip_geom<SS, KK>::H), dim3(256), 0, st, sa)
+#define OCHIP_LEVEL_STRIP_K(SS)                                                                                                           \
+    do                                                                                                                                    \
+    {                                                                                                                                     \
+        if (K == 0)                                                                                                                       \
+            OCHIP_LEVEL_STRIP(SS, 0, true);                                                                                               \
+        else if (K == 2 && store_flow)                                                                                                    \
+            OCHIP_LEVEL_STRIP(SS, 2, true);                                                                                               \
+        else if (K == 2)                                                                                                                  \
+            OCHIP_LEVEL_STRIP(SS, 2, false);                                                                                              \
+        else if (K == 3 && store_flow)                                                                                                    \
+            OCHIP_LEVEL_STRIP(SS, 3, true);                                                                                               \
+        else if (K == 3)                                                                                                                  \
+            OCHIP_LEVEL_STRIP(SS, 3, false);                                                                                              \
+        else if (store_flow)                                                                                                              \
+            OCHIP_LEVEL_STRIP(SS, 4, true);                                                                                               \
+        else                                                                                                                              \
+            OCHIP_LEVEL_STRIP(SS, 4, false);                                                                                              \
+    } while (0)
+            if (l.sigma_size == 2)
+                OCHIP_LEVEL_STRIP_K(2);
+            else if (l.sigma_size == 3)
+                OCHIP_LEVEL_STRIP_K(3);
+            else
+                OCHIP_LEVEL_STRIP_K(4);
+#undef OCHIP_LEVEL_STRIP_K
+#undef OCHIP_LEVEL_STRIP
+            if (n_groups)
+            {
+                src = dst;
+                src_stride = dst_stride;
+                first_group = 1;
+            }
+        }
+        else
         {
             // Lsmooth of the level (Gaussian(1) of the image it starts from) -> conductivity AND the detector's
             // scale-s derivatives Lx, Ly (AKAZE computes both on evolution[i].Lsmooth), one pass
@@ -2757,16 +3198,31 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 return ochip_fail(ctx, OCHIP_EINVAL, "akaze: derivative scale %d outside 2..4", l.sigma_size);
             }
         }
+        if (const char *dump = std::getenv("OCHIP_DUMP_PLANES"))
+            if (i == 1)
+            {
+                // debugging aid: level 1's conductivity plane of the first image
+                std::vector<float> hf(np);
+                OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+                OCHIP_HIP(ctx, hipMemcpy(hf.data(), d_flow, np * 4, hipMemcpyDeviceToHost));
+                if (FILE *f = std::fopen((std::string(dump) + "_flow1.f32").c_str(), "wb"))
+                {
+                    std::fwrite(hf.data(), 4, hf.size(), f);
+                    std::fclose(f);
+                }
+            }
         if (n_steps == 0)
             hipLaunchKernelGGL(copy_plane_kernel, dim3((unsigned)((np + 255) / 256), 1, B), dim3(256), 0, st, src, src_stride,
                                cur, img_stride, np);
         for (size_t g = 0, k = 0; g < n_groups; g++)
         {
-            const size_t gsz = n_steps / n_groups + (g < n_steps % n_groups ? 1 : 0); // balanced groups of <= FED_FUSE steps
+            const size_t gsz = group_size(g);
             fed_tau_group T{};
             for (size_t q = 0; q < gsz; q++)
                 T.tau[q] = tsteps[i][k + q];
             k += gsz;
+            if (g < first_group)
+                continue;
             const bool to_cur = ((n_groups - 1 - g) % 2) == 0;
             float *dst = to_cur ? cur : d_ping;
             const size_t dst_stride = to_cur ? img_stride : plane0;
@@ -2788,20 +3244,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             src_stride = dst_stride;
         }
     }
-    // ---- derivatives, determinant, maxima
-    OCHIP_HIP(ctx, hipMemsetAsync(d_ncand, 0, B * 4, st));
-    // the register-strip form loads pairs of float2 with 16-byte loads: even widths and plane offsets (every level of an
-    // image whose working width is a multiple of 8; the tile form takes the rest, and OCHIP_TEST_HOOKS=tile_det all)
-    static const bool strip_hook = !ochip_test_hook("tile_det");
-    bool det_strips = strip_hook && (img_stride & 1) == 0 && ((uintptr_t)d_Lxy & 15) == 0;
-    for (int i = 0; i < LV.n; i++)
-        det_strips = det_strips && (LV.l[i].w & 1) == 0 && (LV.l[i].off & 1) == 0 && LV.l[i].w >= 2;
-    if (det_strips)
-    {
-        // the strips add their maxima to zeroed masks and tile counts (the tile form writes every word itself)
-        OCHIP_HIP(ctx, hipMemsetAsync(d_mask, 0, (size_t)B * mask_stride * 8, st));
-        OCHIP_HIP(ctx, hipMemsetAsync(d_tile_counts, 0, (size_t)B * n_tiles * 4, st));
-    }
+    // ---- derivatives of level 0, determinant, maxima
     for (int i = 0; i < LV.n; i++)
     {
         const level_info &l = LV.l[i];
@@ -2830,24 +3273,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             float2 *ld = d_Fit + l.off;
             float *rm = d_Rmax + l.off;
             const float margin = (10.0f * std::sqrt(2.0f)) * (float)l.sigma_size; // descriptor window half width, M-LDB
-            // the columns / rows whose descriptor window [round(x - margin) - 1, round(x + margin) + 1] stays inside the level
-            // (the predicate det_maxima_kernel evaluates per pixel: an interval in x and in y)
-            int4 win = make_int4(1, 0, 1, 0);
-            {
-                auto span = [&](int n, int *lo, int *hi) {
-                    bool any = false;
-                    for (int v = 1; v < n - 1; v++)
-                        if ((int)std::rint((float)v - margin) - 1 >= 0 && (int)std::rint((float)v + margin) + 1 < n)
-                        {
-                            if (!any)
-                                *lo = v;
-                            *hi = v;
-                            any = true;
-                        }
-                };
-                span(l.w, &win.x, &win.y);
-                span(l.h, &win.z, &win.w);
-            }
+            const int4 win = det_window(l);
             auto strip_grid = [&](int ow, int sh) {
                 const int strips = ((l.w + ow - 1) / ow) * ((l.h + sh - 1) / sh);
                 return dim3(8 * (((strips + 3) / 4 + 7) / 8), 1, B);
@@ -2871,6 +3297,20 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 hipLaunchKernelGGL((det_maxima_kernel<4>), det_tiles(l.w, l.h), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, margin, d_mask + l.mask_off, mask_stride);
         }
+    }
+    if (const char *dump = std::getenv("OCHIP_DUMP_PLANES"))
+    {
+        // debugging aid: the first image's Lt and (Lx, Ly) pyramids as raw float files <prefix>_lt.f32 / _lxy.f32
+        std::vector<float> hl(img_stride), hx(2 * img_stride);
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+        OCHIP_HIP(ctx, hipMemcpy(hl.data(), d_Lt, img_stride * 4, hipMemcpyDeviceToHost));
+        OCHIP_HIP(ctx, hipMemcpy(hx.data(), d_Lxy, img_stride * 8, hipMemcpyDeviceToHost));
+        for (int which = 0; which < 2; which++)
+            if (FILE *f = std::fopen((std::string(dump) + (which ? "_lxy.f32" : "_lt.f32")).c_str(), "wb"))
+            {
+                std::fwrite(which ? hx.data() : hl.data(), 4, which ? hx.size() : hl.size(), f);
+                std::fclose(f);
+            }
     }
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(B), dim3(256), 0, st, (const unsigned int *)d_tile_counts,
                        (const unsigned int *)d_tile_seq, n_tiles, d_tile_base, d_ncand);
