@@ -1041,6 +1041,10 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
 // The maxima leave as bits of the level's mask words by atomicOr and as per-tile counts by atomicAdd (both zeroed by
 // the host; integers, so the order is free): a strip is 116 / 120 columns wide, not a multiple of the 64-pixel words.
 constexpr int DS_PAD = 8;  // columns of padding on either side of a wavefront's row buffers (>= S)
+// output rows of a strip, rounded up to whole ring turns.  The taller, the smaller the share of the rows above and below that
+// only feed the stencils - and the fewer, longer wavefronts a launch has: 120 rows for both kernels measured 257 us per image
+// against 239 with these (the last round of a launch runs half empty, the small levels have too few strips)
+constexpr int DET_STRIP_ROWS = 32, LEVEL_STRIP_ROWS = 64;
 constexpr int DS_RING = 1; // the ring of requested rows is DS_RING (2 S + 1) long (2: 10 - 16 rows in flight per lane at 2 - 3
                            // wavefronts per SIMD instead of 4 at 4: 31.1 us per image against 28.5)
 template <int S> struct det_strip_geom
@@ -1050,8 +1054,8 @@ template <int S> struct det_strip_geom
     // the rows a strip still needs live in rings of U = 2 S + 1 registers; the row loop is unrolled U times (ring slots
     // are then compile-time constants) and rolled over NB blocks: NB U input rows give NB U - 2 S - 2 rows of maxima
     // (the loop body is RB = 2 U rows, which lets the ring of requested rows be RB long: RB - 2 row loads in flight per lane)
-    static constexpr int U = 2 * S + 1, RB = DS_RING * U, NB = (32 + 2 * S + 2 + RB - 1) / RB, NR = NB * RB;
-    static constexpr int H = NR - 2 * S - 2;    // output rows per strip (34, 34, 35)
+    static constexpr int U = 2 * S + 1, RB = DS_RING * U, NB = (DET_STRIP_ROWS + 2 * S + 2 + RB - 1) / RB, NR = NB * RB;
+    static constexpr int H = NR - 2 * S - 2;    // output rows per strip
 };
 
 __device__ __forceinline__ float max3f(float a, float b, float c)
@@ -1231,7 +1235,7 @@ template <int S, int K> struct level_strip_geom
     static constexpr int REACH = RD > RN ? RD : RN; // input rows / columns beyond an output, and rows an output lags its last input
     static constexpr int HALO = (REACH + 1) & ~1;
     static constexpr int OW = 128 - 2 * HALO;
-    static constexpr int NB = (64 + 2 * REACH + U - 1) / U, NR = NB * U, H = NR - 2 * REACH;
+    static constexpr int NB = (LEVEL_STRIP_ROWS + 2 * REACH + U - 1) / U, NR = NB * U, H = NR - 2 * REACH;
 };
 struct level_strip_args
 {
@@ -1306,7 +1310,11 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
     const unsigned int col4 = (unsigned int)cxc * 4u, col8 = (unsigned int)cxc * 8u;
     const int row_end = min(Y0 + SH, h); // rows [Y0, row_end) are this strip's
 
-    constexpr int PF = U - 1 < 6 ? U - 1 : 6; // rows requested ahead
+    // rows requested ahead.  The diffusion needs the raw rows r - 3 and r - 4 again: where the ring is long enough for both
+    // (S = 4: 4 rows ahead + 5 behind = 9 slots) they simply stay in the ring of loaded rows (10 registers less: 3 wavefronts
+    // per SIMD instead of 2 for S = 4, K = 4)
+    constexpr bool RAW_IN_LD = K > 0 && 4 + 5 <= U;
+    constexpr int PF = RAW_IN_LD ? 4 : (U - 1 < 6 ? U - 1 : 6);
     // rings indexed by (row) mod U
     float2 ld[U];
     pk2 gr[U], Ls[U], p3[U], p10[U], paS[U], pbS[U], Lraw[U], C[U], CX[U], CY[U];
@@ -1343,7 +1351,11 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
         pk2 own = {ld[j].x, ld[j].y};
         if (EDGE) // replicate border: both columns of a lane outside the image take the border pixel
             own = cx < 0 ? pk2{own.x, own.x} : (cx >= w ? pk2{own.y, own.y} : own);
-        Lraw[j] = own;
+        if (RAW_IN_LD)
+            ld[j] = make_float2(own.x, own.y);
+        else
+            Lraw[j] = own;
+        auto raw_row = [&](int slot) { return RAW_IN_LD ? pk2{ld[slot].x, ld[slot].y} : Lraw[slot]; };
         const pk2 Lm = {lane_left(own.x), lane_left(own.y)}, Lp = {lane_right(own.x), lane_right(own.y)};
         pk2 t = zero + k0 * Lm;
         t = t + k1 * pk2{Lm.y, own.x};
@@ -1431,14 +1443,14 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
             const float crx = lane_right(cf.x);
             CX[s_f] = cf + pk2{cf.y, crx};         // c(x) + c(x + 1)
             CY[sl(s_f - 1)] = C[sl(s_f - 1)] + cf; // c(y) + c(y + 1) of row f - 1
-            pk2 Ln = Lraw[s_f];                    // the previous step's row below the one a step works on
+            pk2 Ln = raw_row(s_f);                 // the previous step's row below the one a step works on
             // a right neighbour of column cx + 1 / a left neighbour of column cx exists
             const bool hr1 = !EDGE || cx + 2 < w, hl0 = !EDGE || cx > 0;
 #pragma unroll
             for (int q = 1; q <= K; q++)
             {
                 const int s_y = sl(s_f - q), yq = yf - q; // step q works on image row yq
-                const pk2 Lc = q == 1 ? Lraw[s_y] : Lsave[q - 1];
+                const pk2 Lc = q == 1 ? raw_row(s_y) : Lsave[q - 1];
                 const float right = lane_right(Lc.x);
                 const pk2 d = pk2{Lc.y, right} - Lc;
                 pk2 xpos = CX[s_y] * d;

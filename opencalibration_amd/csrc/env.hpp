@@ -4,7 +4,9 @@
 //                      host_sort, host_subset, host_tail, host_nms (the round-2 host code of the link / extract tails),
 //                      popcount_match (no matrix-core matcher), chol_verify (factor every system both ways and compare),
 //                      back_solve_x_global (step vector in HBM even when it fits LDS), no_dissect (one band, no regions),
-//                      jacobian_fp32 (profiles/r04_jacobian_precision_sweep_c5.json)
+//                      jacobian_fp32 (profiles/r04_jacobian_precision_sweep_c5.json),
+//                      tile_levels, tile_det (the LDS-tile kernels of the scale space / the determinant instead of round 5's register
+//                      strips)
 #pragma once
 
 #include <cstdlib>

@@ -70,8 +70,34 @@ namespace
 std::mutex g_extract_gate_mu;
 std::condition_variable g_extract_gate_cv;
 bool g_extract_gate_busy = false;
-std::atomic<unsigned> g_survey_counter{0};
 thread_local double g_last_gate_wait = 0; // seconds the calling thread's last load_link_stream waited at the gate
+// The two sets of link-runner contexts (siblings 4.. and 13.. of ctx): a call OWNS one from its first runner to its last
+// (a free-list, not the parity of a call counter: calls need not finish in the order they started, and a third overlapping
+// call waits here instead of driving a context set that is still in use).
+std::mutex g_lane_mu;
+std::condition_variable g_lane_cv;
+bool g_lane_busy[2] = {false, false};
+struct runner_lane
+{
+    int lane = -1;
+    void acquire()
+    {
+        std::unique_lock<std::mutex> lk(g_lane_mu);
+        g_lane_cv.wait(lk, [] { return !g_lane_busy[0] || !g_lane_busy[1]; });
+        lane = g_lane_busy[0] ? 1 : 0;
+        g_lane_busy[lane] = true;
+    }
+    ~runner_lane()
+    {
+        if (lane < 0)
+            return;
+        {
+            std::lock_guard<std::mutex> lk(g_lane_mu);
+            g_lane_busy[lane] = false;
+        }
+        g_lane_cv.notify_all();
+    }
+};
 struct extract_gate
 {
     bool held = false;
@@ -103,7 +129,10 @@ bool load_link_stream(och_graph *g, ochip_ctx *ctx, LinkStage &link, const std::
                       double *t_extract_done)
 {
     using clk = std::chrono::steady_clock;
-    const unsigned lane = g_survey_counter.fetch_add(1) & 1u;
+    // (declared before the gate: destroyed after it - and after every runner thread below has been joined)
+    runner_lane lane_guard;
+    lane_guard.acquire();
+    const int lane = lane_guard.lane;
     extract_gate gate;
     const auto t_gate = clk::now();
     gate.acquire(); // (released when this survey's last chunk is extracted; on every return path by the destructor)

@@ -114,7 +114,8 @@ class GroundPlaneProblem
             if (all.a != _blk_a || all.b != _blk_b || all.rays.size() != _blk_rays.size() ||
                 std::memcmp(all.rays.data(), _blk_rays.data(), all.rays.size() * sizeof(double)) != 0)
             {
-                *error = "relax set-up: the device's residual blocks differ from the host's (" + std::to_string(_blk_a.size()) + " vs " +
+                if (error)
+                    *error = "relax set-up: the device's residual blocks differ from the host's (" + std::to_string(_blk_a.size()) + " vs " +
                          std::to_string(all.a.size()) + ")";
                 return false;
             }
@@ -148,13 +149,15 @@ class GroundPlaneProblem
         d.prior_weight = 1e-3;
         if (ochip_relax_problem_create(_ctx, &d, &_dev) != OCHIP_OK)
         {
-            *error = std::string("ochip_relax_problem_create: ") + ochip_last_error(_ctx);
+            if (error)
+                *error = std::string("ochip_relax_problem_create: ") + ochip_last_error(_ctx);
             return false;
         }
         if (shard && (shard->world > 1 || shard->exchange) &&
             ochip_relax_set_shard(_dev, shard->rank, shard->world, shard->exchange, shard->user) != OCHIP_OK)
         {
-            *error = std::string("ochip_relax_set_shard: ") + ochip_last_error(_ctx);
+            if (error)
+                *error = std::string("ochip_relax_set_shard: ") + ochip_last_error(_ctx);
             return false;
         }
         lap("ochip_relax_problem_create");
@@ -221,7 +224,8 @@ class GroundPlaneProblem
   private:
     bool fail(std::string *error, const char *what)
     {
-        *error = std::string(what) + ": " + ochip_last_error(_ctx);
+        if (error)
+            *error = std::string(what) + ": " + ochip_last_error(_ctx);
         return false;
     }
     void push_camera(const double *pos, const double *q, bool optimize)

@@ -441,7 +441,8 @@ class GroundMeshProblem
                 for (size_t k = 0; k < n_filter; k++)
                     if (keep[k] != grid_filter(_graph, *edges[k], src[k], dst[k], frac))
                     {
-                        *error = "relax mesh set-up: the device's grid filter differs from the host's on edge " + std::to_string(k);
+                        if (error)
+                            *error = "relax mesh set-up: the device's grid filter differs from the host's on edge " + std::to_string(k);
                         return false;
                     }
                 relax_setup_check_passed();
@@ -558,7 +559,8 @@ class GroundMeshProblem
         d.focal_hi = 20000.0;
         if (_several_models)
         {
-            *error = "relax: the device path optimises one shared lens model per group; this group holds images of several";
+            if (error)
+                *error = "relax: the device path optimises one shared lens model per group; this group holds images of several";
             return false;
         }
         const bool sharded = shard && (shard->world > 1 || shard->exchange);
@@ -569,12 +571,14 @@ class GroundMeshProblem
         }
         if (ochip_relaxg_problem_create(_ctx, &d, &_dev) != OCHIP_OK)
         {
-            *error = std::string("ochip_relaxg_problem_create: ") + ochip_last_error(_ctx);
+            if (error)
+                *error = std::string("ochip_relaxg_problem_create: ") + ochip_last_error(_ctx);
             return false;
         }
         if (sharded && ochip_relaxg_set_exchange(_dev, shard->exchange, shard->user) != OCHIP_OK)
         {
-            *error = std::string("ochip_relaxg_set_exchange: ") + ochip_last_error(_ctx);
+            if (error)
+                *error = std::string("ochip_relaxg_set_exchange: ") + ochip_last_error(_ctx);
             return false;
         }
         lap("ochip_relaxg_problem_create");
@@ -720,7 +724,8 @@ class GroundMeshProblem
 
     bool fail(std::string *error, const char *what)
     {
-        *error = std::string(what) + ": " + ochip_last_error(_ctx);
+        if (error)
+            *error = std::string(what) + ": " + ochip_last_error(_ctx);
         return false;
     }
     void push_camera(const double *pos, const double *q, bool optimize)

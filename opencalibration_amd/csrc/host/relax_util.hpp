@@ -301,7 +301,8 @@ struct device_filter
         } inl{ctx};
         if (ochip_host_alloc(ctx, (n_inliers ? n_inliers : 1) * sizeof(ochip_plane_inlier), &inl.p) != OCHIP_OK)
         {
-            *error = std::string("ochip_host_alloc: ") + ochip_last_error(ctx);
+            if (error)
+                *error = std::string("ochip_host_alloc: ") + ochip_last_error(ctx);
             return false;
         }
         ochip_plane_inlier *const rec = static_cast<ochip_plane_inlier *>(inl.p);
@@ -325,7 +326,8 @@ struct device_filter
                                      (uint32_t)(cam_q.size() / 4), models10.data(), (uint32_t)model_index.size(), triangle_xy6, fraction,
                                      keep.data(), inexact.data(), &handle) != OCHIP_OK)
         {
-            *error = std::string("ochip_plane_setup_create: ") + ochip_last_error(ctx);
+            if (error)
+                *error = std::string("ochip_plane_setup_create: ") + ochip_last_error(ctx);
             return false;
         }
         for (size_t j = 0; j < pe.size(); j++)
@@ -335,7 +337,8 @@ struct device_filter
                 std::copy(k8.begin(), k8.end(), keep.begin() + pe[j].inlier_offset);
                 if (ochip_plane_setup_override(handle, pe[j].inlier_offset, k8.size(), k8.data()) != OCHIP_OK)
                 {
-                    *error = std::string("ochip_plane_setup_override: ") + ochip_last_error(ctx);
+                    if (error)
+                        *error = std::string("ochip_plane_setup_override: ") + ochip_last_error(ctx);
                     return false;
                 }
             }

@@ -638,10 +638,14 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
             scatter_cam(P, A, g, n, cam_has_prior, sb * (256 / W) + t / W, t % W);
         else
             scatter_pair(P, A, n, (sb - cam_blocks) * 256 + t);
-        __syncthreads(); // (every wavefront's stores are out: __syncthreads waits for them)
+        // every wavefront's stores have left it before the barrier in front of the arrival (a workgroup barrier alone does not
+        // wait for the other wavefronts' vmcnt: MI355X_MICROARCH.md, producer side of a cross-CU hand-off)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (t == 0)
         {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the compiler may drop the fence's own wait: MI355X_MICROARCH.md, compiler hazard)
             s_last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
         }
         __syncthreads();
@@ -691,6 +695,7 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
         if (t == 0)
         {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // (lanes 0 .. 9 of this wavefront stored the sums)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             s_last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
         }
         __syncthreads();
@@ -749,7 +754,8 @@ __global__ __launch_bounds__(256) void relax_reduce_plane_kernel(relax_dev P, lm
         // the evaluation's results go to the host block from here (no copies behind this kernel), and this rank's
         // failure flag is clear again for the next evaluation (no memset in front of it)
         lm_mail_post(mail);
-        *P.fail = 0;
+        if (mail.box) // (not mailed - no page-locked block -: the host copies the flags behind this kernel and clears them itself)
+            *P.fail = 0;
     }
 }
 
@@ -1349,8 +1355,9 @@ int ochip_relax_set_shard(ochip_relax_problem *p, uint32_t rank, uint32_t world,
     if (!p)
         return OCHIP_EINVAL;
     ochip_ctx *ctx = p->ctx;
-    if (world == 0 || rank >= world || (world > 1 && !fn))
-        return ochip_fail(ctx, OCHIP_EINVAL, "bad shard (rank %u of %u%s)", rank, world, fn ? "" : ", no exchange function");
+    if (world == 0 || rank >= world || (world > 1 && !fn) || world > (uint32_t)lm_system::BOX_MAX_RANKS)
+        return ochip_fail(ctx, OCHIP_EINVAL, "bad shard (rank %u of %u%s; at most %d ranks: their failure flags travel in the solver's page-locked block)",
+                          rank, world, fn ? "" : ", no exchange function", lm_system::BOX_MAX_RANKS);
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
     relax_dev &D = p->dev;
     const uint32_t n_pairs = D.n_pairs;
@@ -1518,6 +1525,7 @@ struct plane_model final : lm_model
         {
             OCHIP_HIP(ctx, hipMemcpyAsync(h0, p->sys.scal, 8, hipMemcpyDeviceToHost, st));
             OCHIP_HIP(ctx, hipMemcpyAsync(hfails, p->fail_ranks, (size_t)p->shard_world * 4, hipMemcpyDeviceToHost, st));
+            OCHIP_HIP(ctx, hipMemsetAsync(D.fail, 0, 4, st)); // this rank's flag, clear for the next evaluation
         }
         if (before_wait)
             before_wait();

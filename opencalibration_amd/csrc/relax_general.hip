@@ -1597,10 +1597,11 @@ int ochip_relaxg_problem_create(ochip_ctx *ctx, const ochip_relaxg_desc *d, ochi
     // sharded evaluation: the ray blocks (in their type-sorted order) are cut into `world` equal runs of `chunk` records;
     // the record list is padded to world * chunk entries before the priors, which every rank evaluates itself
     const uint32_t world = std::max<uint32_t>(1, d->shard_world);
-    if (d->shard_rank >= world)
+    if (d->shard_rank >= world || world > (uint32_t)lm_system::BOX_MAX_RANKS)
     {
+        // (the ranks' failure flags travel in the solver's page-locked block: BOX_MAX_RANKS of them - four 8-GPU nodes)
         delete p;
-        return ochip_fail(ctx, OCHIP_EINVAL, "bad shard (rank %u of %u)", d->shard_rank, world);
+        return ochip_fail(ctx, OCHIP_EINVAL, "bad shard (rank %u of %u; at most %d ranks)", d->shard_rank, world, lm_system::BOX_MAX_RANKS);
     }
     const uint32_t chunk = std::max<uint32_t>(1, (d->n_blocks + world - 1) / world);
     const uint32_t n_ray_pad = world > 1 ? world * chunk : d->n_blocks;

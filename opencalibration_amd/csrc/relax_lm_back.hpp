@@ -140,6 +140,8 @@ __device__ __forceinline__ void back_solve_regions_body(lm_matrix Lm, int n, con
             part_sum += v * gs[i] + lm_diag[i] * v * v;
         }
     sh[t] = part_sum;
+    // (x[] / X's stores of every wavefront have left it before the barriers in front of thread 0's release and arrival)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int s = LM_TG / 2; s > 0; s >>= 1)
     {
@@ -151,6 +153,7 @@ __device__ __forceinline__ void back_solve_regions_body(lm_matrix Lm, int n, con
     {
         __hip_atomic_store(&parts[r], sh[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         s_last = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(m - 1);
         if (s_last)
         {

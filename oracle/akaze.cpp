@@ -1,4 +1,36 @@
 // ORACLE — test infrastructure only.  See akaze.hpp: restated AKAZE + extract_features, PARITY UNPINNED.
+//
+// KNOWN DEPARTURES FROM OpenCV's AKAZE (features2d/src/kaze/AKAZEFeatures.cpp, nldiffusion_functions.cpp [3P: not under
+// /root/reference, absent from this image - what OpenCV does is quoted from its published source, not checked here]).
+// Each is a place where this file is deliberately NOT a transcription; scripts/akaze_pin.py --compare attributes what it
+// finds to them (classes `suppression`, `angle`, `descriptor`).
+//
+//  D1  cross-level suppression            this file: detect_and_describe, step 2 ("scale-space suppression", the `dead` loop)
+//      here:   symmetric and order-free - a candidate dies if ANY stronger maximum (ties: lower (level, y, x)) of its own
+//              or an adjacent level lies within its own size esigma * derivative_factor.
+//      OpenCV: AKAZEFeatures::Find_Scale_Space_Extrema walks the levels in order and keeps a running list: a new point is
+//              compared with the points ALREADY in the list of its own and the previous level (the first one within its
+//              size: the new point replaces it when stronger, is dropped otherwise), and a second pass removes points that
+//              have a stronger point of the NEXT level within their size.  The outcome depends on the insertion order and
+//              differs from the rule above where three or more maxima chain (A near B near C, A not near C).
+//      why:    the sequential list cannot be evaluated in parallel without reproducing its order; which of two valid
+//              definitions of "the same blob at neighbouring scales" is used moves a few keypoints per thousand.
+//  D2  atan2 / sin / cos                  this file: fast_atan2, sincos_poly; used in detect_and_describe, step 3
+//      here:   one polynomial in RADIANS built from + - * / only (bit-identical on CPU and device), Taylor sin / cos.
+//      OpenCV: Compute_Main_Orientation uses cv::fastAtan2 (the same odd polynomial with its coefficients scaled to
+//              DEGREES, 0.3 degree accuracy) times pi / 180; the descriptor uses cos(angle), sin(angle) of libm.  Angles
+//              agree to the polynomial's accuracy, not to the bit; a sample that sits on a rounding boundary of
+//              cvRound(x + ...) can move by one pixel, a window sum on an edge of its 60 degree sector can flip.
+//  D3  sub-pixel refinement               this file: the 2 x 2 solve by Cramer's rule (det_maxima / subpixel fit)
+//      OpenCV: cv::solve(A, b, dst, DECOMP_LU) on the same 2 x 2 system - same solution up to rounding.
+//  D4  order of float sums                this file: every sum in one fixed, written order (no FMA)
+//      OpenCV: its loops are vectorised (universal intrinsics) where the build allows; sums of the Gaussian taps, the
+//              diffusion step's four fluxes and the descriptor's cell means may associate differently.  Not a semantic
+//              departure, but a reason why bit-identity with a given OpenCV build cannot be expected even without D1 - D3.
+// Everything else (level table, FED step sizes and their reordering, k-contrast percentile, Scharr kernels and their
+// normalisation, determinant scaling, the extremum test and its border margin, M-LDB grid and bit order) follows OpenCV's
+// structure as recalled; the property tests (tests/test_oracle_akaze_properties.py) hold the restatement to what the
+// algorithm must satisfy, nothing holds it to OpenCV's bits.
 #include "akaze.hpp"
 
 #include <algorithm>

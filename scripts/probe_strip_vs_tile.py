@@ -13,6 +13,10 @@ def run(tag):
     from opencalibration_amd import capi, synth
     w, h = int(sys.argv[2]), int(sys.argv[3])
     img = synth.render_blobs(w, h, 9)
+    if os.environ.get("PROBE_NOISE"):
+        rng = np.random.default_rng(w)
+        base = synth.render_blobs(w, h, 31)
+        img = np.clip(base.astype(np.int32) + rng.integers(0, 40, (h, w, 1)) - 20, 0, 255).astype(np.uint8)
     if os.environ.get("PROBE_TINT"):
         rng = np.random.default_rng(5)
         tint = rng.integers(0, 40, (h, w, 3), dtype=np.uint8)

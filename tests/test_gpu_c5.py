@@ -1,5 +1,6 @@
 """BASELINE config C5 at its size: a 5 000-image survey (50 x 100 grid, ~45 000 directed pairs) through the device link
-stage, the plane relax of all cameras (15 003 unknowns), the clustered ground-mesh stage (floor(n / 50) = 100 groups,
+stage (130 sampled directed pairs against the oracle: match lists, homographies, inlier sets bit for bit), the plane relax of
+all cameras (15 003 unknowns), the clustered ground-mesh stage (floor(n / 50) = 100 groups,
 src/pipeline/relax_stage.cpp:49-57), the CAMERA_PARAMETER_RELAX form - floor(n / 150) = 33 clusters trimmed to the largest,
 focal length + principal point + radial distortion free (src/pipeline/pipeline.cpp:601-634) - and the single global
 ground-mesh group of FINAL_GLOBAL_RELAX's last run (:645-664).  Property checks on everything; oracle parity (poses within
@@ -66,9 +67,38 @@ def _both(ctx, oracle, grid, members, edges, feats, pk, start, opts, prev_vertic
     return got, exp, t_cpu
 
 
+def _check_sampled_edges(oracle, grid, edges_all, index_of, n_sample):
+    """The link stage's result for evenly sampled directed pairs against the oracle's link_pair: the match list (feature
+    indices and distances in the sort's order), the homography and the inlier set, bit for bit."""
+    pick = np.unique(np.linspace(0, len(edges_all) - 1, n_sample).astype(int))
+    subset_cache = {}
+
+    def subset(i):
+        if i not in subset_cache:
+            loc, st = grid.image(i)[:2]
+            subset_cache[i] = oracle.subsample(loc, st, 40.0, int(grid.num_sparse[i]))
+        return subset_cache[i]
+
+    accepted = 0
+    for p in pick:
+        ed = edges_all[p]
+        a, b = index_of[ed["source"]], index_of[ed["dest"]]
+        la, _, da, _ = grid.image(a)
+        lb, _, db, _ = grid.image(b)
+        e = oracle.link_pair(la, da, subset(a), lb, db, subset(b), grid.model, grid.model)
+        assert np.array_equal(ed["H"], e["H"], equal_nan=True), (a, b)
+        if e["accepted"]:
+            accepted += 1
+            assert np.array_equal(ed["match_idx"][:, 0], e["i1"]) and np.array_equal(ed["match_idx"][:, 1], e["i2"]), (a, b)
+            assert np.array_equal(ed["dist"], e["dist"]) and np.array_equal(ed["match_index"], np.flatnonzero(e["inliers"])), (a, b)
+        else:
+            assert ed["n_inliers"] == 0, (a, b)   # an edge that was not accepted carries no matches (link_stage.cpp:104-110)
+    return len(pick), accepted
+
+
 def test_c5_survey_at_size(oracle):
     ctx = capi.Context(0)
-    grid = synth.make_grid(seed=2025, feats=2048, **{k: v for k, v in synth.CONFIGS["C5"].items() if k != "feats"})
+    grid = synth.make_grid(seed=2025, **synth.CONFIGS["C5"])      # BASELINE's C5: 50 x 100 cameras, 4 096 features each
     n = grid.n_images
     assert n == 5000
     g = host.Graph.from_synthetic(grid)
@@ -77,6 +107,10 @@ def test_c5_survey_at_size(oracle):
     g.link(ctx)
     assert 8 * n < g.num_edges <= 9 * n
     index_of = {nid: i for i, nid in enumerate(g.node_ids)}
+    edges_all = g.edges(with_distances=True)
+    checked, accepted = _check_sampled_edges(oracle, grid, edges_all, index_of, 130)
+    assert checked >= 120 and accepted >= 100
+    print("C5 link stage: %d of %d directed pairs against the oracle (%d accepted edges)" % (checked, len(edges_all), accepted))
     # ---- the plane relax of all cameras as one group: 3 n + 3 unknowns
     plane = g.relax(ctx, start, host.relax_options("ORIENTATION", "GROUND_PLANE"))
     assert int(plane["residual_blocks"]) > 1_000_000
@@ -119,7 +153,6 @@ def test_c5_survey_at_size(oracle):
     assert 100.0 <= model_after[0] <= 20000.0 and np.all(np.isfinite(model_after))
     g.set_model(0, grid.model)
     # ---- oracle parity on three sampled groups, re-solved stand-alone from the same start
-    edges_all = g.edges(with_distances=True)
     report = []
     for members, opts in ((np.flatnonzero(grp == 0), O_MESH), (np.flatnonzero(grp == 57), O_MESH), (np.flatnonzero(gi == 0), O_INTR)):
         edges, feats, pk = _subproblem(grid, g, edges_all, index_of, members, ori0)

@@ -30,7 +30,8 @@ def test_densify_matches_the_restatement(kw):
     exp, got, surface, exp_surface, g = _both(scene, ctx)
     assert got["matches"] == exp["matches"] > 300
     assert np.array_equal(got["match_pairs"], exp["match_pairs"])               # same matches, same order
-    assert got["tracks"] >= exp["tracks"] and got["points"] == len(exp["points"])
+    # a track = a component of the matches' union-find with at least two measurements, on both sides
+    assert got["tracks"] == exp["tracks"] and got["points"] == len(exp["points"])
     cloud = surface.clouds()[-1]
     assert np.allclose(cloud, exp["points"], rtol=0, atol=1e-9)
     dz = cloud[:, 2] - scene["ground"](cloud[:, 0], cloud[:, 1])

@@ -134,3 +134,35 @@ def test_featureless_tiny_and_overflowing_inputs(ctx, oracle):
     # the context is still usable afterwards
     got, _ = ctx.akaze_batch(busy[None], max_kp=20000)
     assert len(got[0][0]) > 500
+
+
+@pytest.mark.parametrize("w,h", [(1600, 1200), (776, 584), (808, 610)])
+def test_strip_kernels_on_noisy_views_up_to_the_border(ctx, oracle, w, h):
+    """Round 5's register-strip kernels (level_strip_kernel, det_strip_kernel) on views with pixel noise: the diffusion spreads
+    whatever the conductivity's reflected taps and the Gaussian's replicated border produce along the image border a few
+    pixels further at every level, and descriptors of keypoints near the border sample it.  Widths that are not a multiple
+    of the strips' 104 - 120 columns, heights that are not a multiple of their rows; 1600 x 1200 is the working size of
+    the bench's 4000 x 3000 views."""
+    rng = np.random.default_rng(w)
+    base = synth.render_blobs(w, h, 31)
+    img = np.clip(base.astype(np.int32) + rng.integers(0, 40, (h, w, 1)) - 20, 0, 255).astype(np.uint8)
+    got, (ww, wh) = ctx.akaze_batch(img[None], max_kp=40000)
+    assert (ww, wh) == (w, h)
+    ekp, edesc = oracle.akaze(img[:, :, 0])
+    gkp, gdesc = got[0]
+    assert len(gkp) == len(ekp) > 500
+    assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32)) and np.array_equal(gdesc, edesc)
+
+
+def test_tile_kernels_still_agree():
+    """OCHIP_TEST_HOOKS=tile_levels,tile_det sends the extraction through the tile kernels of rounds 2 - 4 (blur_fused / nld_fused /
+    det_maxima: the route of images whose level widths are odd).  The switches are read once per process: this file's parity
+    tests run again in a child."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, OCHIP_TEST_HOOKS="tile_levels,tile_det")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
+                        "restatement_bitwise or grey_and_area or host_tail or tied_responses or noisy_views"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

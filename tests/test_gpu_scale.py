@@ -1,6 +1,7 @@
 """Parity at the sizes of BASELINE.json's configs C2 (200 images x 4k features) and C3 (1 000 images x 4k features, the
 configuration the headline metric is quoted on): the device link stage against the oracle on sampled directed pairs
-(match lists, inlier sets, RANSAC scores and homographies bit for bit), then the relax of the WHOLE linked graph against
+(match lists, inlier sets, RANSAC scores and homographies bit for bit) and, at C3, on ALL 9 000 pairs (match and inlier
+counts, homographies), then the relax of the WHOLE linked graph against
 the oracle's solve (3 003 unknowns at C3: the envelope / reordered Cholesky path of the device against the oracle's plain
 factorisation), poses within 1e-6 rad.  C2 also runs the {ORIENTATION, GROUND_MESH} flavour on the linked graph (tracks
 formed by real matches) against the oracle."""
@@ -104,10 +105,39 @@ def test_c2_link_relax_and_mesh(ctx, oracle):
     g.close()
 
 
+def _check_all_pairs(oracle, grid, g):
+    """EVERY directed pair of the survey against the oracle's link stage run over all of them (oc_link_batch_cpu: one closure
+    per pair under OpenMP, the reference's own scheduling): number of matches, number of inliers and the homography of
+    every pair, bit for bit."""
+    import os
+
+    index_of = {nid: i for i, nid in enumerate(g.node_ids)}
+    dbg = g.link_debug()
+    pairs = np.ascontiguousarray(np.array([(index_of[d["node"]], index_of[d["match_node"]]) for d in dbg], np.uint32))
+    feats = [grid.image(i) for i in range(grid.n_images)]
+    off = np.concatenate([[0], np.cumsum([len(f[1]) for f in feats])]).astype(np.uint64)
+    loc = np.ascontiguousarray(np.concatenate([f[0] for f in feats]), np.float64)
+    st = np.ascontiguousarray(np.concatenate([f[1] for f in feats]), np.float32)
+    de = np.ascontiguousarray(np.concatenate([f[2] for f in feats]), np.uint64)
+    ns = np.array([int(grid.num_sparse[i]) for i in range(grid.n_images)], np.uint64)
+    counts, Hs, secs = np.zeros((len(pairs), 2), np.uint64), np.zeros((len(pairs), 9)), np.zeros(4)
+    threads = len(os.sched_getaffinity(0))
+    oracle.lib().oc_link_batch_cpu(loc, st, de, off, len(feats), ns, np.ascontiguousarray(grid.model, np.float64), pairs, len(pairs), 0,
+                                   threads, counts, Hs, secs)
+    edges = {(e["source"], e["dest"]): e for e in g.edges()}
+    for p, d in enumerate(dbg):
+        assert len(d["i1"]) == counts[p, 0] and int(np.sum(d["inliers"])) == counts[p, 1], (p, pairs[p])
+        assert np.array_equal(edges[(d["node"], d["match_node"])]["H"].ravel(), Hs[p], equal_nan=True), (p, pairs[p])
+    return len(pairs), secs[0], threads
+
+
 def test_c3_link_and_relax(ctx, oracle):
     grid, g, start = _linked(ctx, "C3")
     checked, total = _check_sampled_pairs(oracle, grid, g, 120)
     assert checked >= 100 and total == 9000
+    n_all, cpu_s, threads = _check_all_pairs(oracle, grid, g)
+    assert n_all == 9000
+    print("C3: all %d directed pairs equal to the oracle's link stage (%.1f s on %d threads)" % (n_all, cpu_s, threads))
     got, exp = _relax_plane_both(ctx, oracle, grid, g, start)
     assert int(got["residual_blocks"]) > 300000
     err = pipeline.orientation_errors(got["orientation"], grid.orientation)
