@@ -119,7 +119,11 @@ __global__ __launch_bounds__(256) void resize_area_kernel(const uint8_t *__restr
 // FROM_BGR: the staging converts the BGR source to grey on the way in (cvtColor's fixed-point weights, four pixels from
 // three dwords as in gray4_kernel), so the full-resolution grey image is neither written nor read.
 constexpr int RS_PITCH = 704, RS_ROWS = 32; // bytes per staged row, staged rows (2.5 : 1 needs 648 x 21)
-template <bool FROM_BGR>
+// (round 5: the kernel was issue-bound.  MAXT: the host knows the longest run of horizontal taps - 4 at the 2.5 : 1 of a
+// 4000-pixel view - and the tap loop is unrolled to it instead of to 8 predicated trips; the grey conversion takes a pixel's
+// three bytes as one dword - the fourth byte meets a zero weight - through two v_dot4_u32_u8 with the 14-bit weights split
+// into bytes: 1868 = 7 * 256 + 76, 9617 = 37 * 256 + 145, 4899 = 19 * 256 + 35; integers, the same value.)
+template <bool FROM_BGR, int MAXT>
 __global__ __launch_bounds__(256) void resize_area_lds_kernel(const uint8_t *__restrict__ src, int sw, int sh, float *__restrict__ dst,
                                                               int dw, int dh, const int *__restrict__ xoff,
                                                               const int *__restrict__ xsi, const float *__restrict__ xal,
@@ -133,22 +137,49 @@ __global__ __launch_bounds__(256) void resize_area_lds_kernel(const uint8_t *__r
     const int ry0 = ysi[yoff[y0]], ry1 = ysi[yoff[y1] - 1];      // source rows ry0..ry1
     const int nd = (cx1 - cx0) / 4 + 1, nr = ry1 - ry0 + 1;
     const uint8_t *s = src + (size_t)blockIdx.z * sw * sh * (FROM_BGR ? 3 : 1);
-    for (int idx = threadIdx.x; idx < nd * nr; idx += 256)
+    // the window's loads go out eight trips at a time before the first of them is converted (one trip per loop turn waited
+    // out a memory round trip each: fourteen in a row per thread at 2.5 : 1, which is what bounded this kernel)
+    constexpr int STAGE = 8;
+    for (int base = threadIdx.x; base < nd * nr; base += 256 * STAGE)
     {
-        const int row = idx / nd, d = idx - row * nd;
-        if (FROM_BGR)
+        uint32_t w0[STAGE], w1[STAGE], w2[STAGE];
+#pragma unroll
+        for (int u = 0; u < STAGE; u++)
         {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(s + 3 * ((size_t)(ry0 + row) * sw + cx0 + 4 * d));
-            const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
-            auto g = [](uint32_t b, uint32_t gg, uint32_t r) { return (b * 1868u + gg * 9617u + r * 4899u + (1u << 13)) >> 14; };
-            const uint32_t p0 = g(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
-            const uint32_t p1 = g(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
-            const uint32_t p2 = g((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
-            const uint32_t p3 = g((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
-            tile[row * (RS_PITCH / 4) + d] = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+            const int idx = base + 256 * u;
+            const int row = idx / nd, d = idx - row * nd;
+            w0[u] = w1[u] = w2[u] = 0;
+            if (idx < nd * nr)
+            {
+                if (FROM_BGR)
+                {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(s + 3 * ((size_t)(ry0 + row) * sw + cx0 + 4 * d));
+                    w0[u] = q[0], w1[u] = q[1], w2[u] = q[2];
+                }
+                else
+                    w0[u] = *reinterpret_cast<const unsigned int *>(s + (size_t)(ry0 + row) * sw + cx0 + 4 * d);
+            }
         }
-        else
-            tile[row * (RS_PITCH / 4) + d] = *reinterpret_cast<const unsigned int *>(s + (size_t)(ry0 + row) * sw + cx0 + 4 * d);
+#pragma unroll
+        for (int u = 0; u < STAGE; u++)
+        {
+            const int idx = base + 256 * u;
+            const int row = idx / nd, d = idx - row * nd;
+            if (idx >= nd * nr)
+                continue;
+            if (FROM_BGR)
+            {
+                auto g = [](uint32_t bgrx) { // b 1868 + g 9617 + r 4899 + 2^13 >> 14 of the low three bytes
+                    const uint32_t hi = __builtin_amdgcn_udot4(bgrx, 0x00132507u, 0u, false);
+                    return __builtin_amdgcn_udot4(bgrx, 0x0023914Cu, (hi << 8) + (1u << 13), false) >> 14;
+                };
+                const uint32_t p0 = g(w0[u]), p1 = g(__builtin_amdgcn_alignbit(w1[u], w0[u], 24)),
+                               p2 = g(__builtin_amdgcn_alignbit(w2[u], w1[u], 16)), p3 = g(w2[u] >> 8);
+                tile[row * (RS_PITCH / 4) + d] = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+            }
+            else
+                tile[row * (RS_PITCH / 4) + d] = w0[u];
+        }
     }
     __syncthreads();
     const int x = x0 + threadIdx.x;
@@ -156,10 +187,10 @@ __global__ __launch_bounds__(256) void resize_area_lds_kernel(const uint8_t *__r
         return;
     const uint8_t *t8 = reinterpret_cast<const uint8_t *>(tile);
     const int k0 = xoff[x], nk = xoff[x + 1] - k0;
-    int si[RESIZE_MAX_TAPS];
-    float al[RESIZE_MAX_TAPS];
+    int si[MAXT];
+    float al[MAXT];
 #pragma unroll
-    for (int k = 0; k < RESIZE_MAX_TAPS; k++)
+    for (int k = 0; k < MAXT; k++)
     {
         si[k] = k < nk ? xsi[k0 + k] - cx0 : 0;
         al[k] = k < nk ? xal[k0 + k] : 0.0f;
@@ -172,7 +203,7 @@ __global__ __launch_bounds__(256) void resize_area_lds_kernel(const uint8_t *__r
             const uint8_t *row = t8 + (ysi[e] - ry0) * RS_PITCH;
             float rr = 0.0f;
 #pragma unroll
-            for (int k = 0; k < RESIZE_MAX_TAPS; k++)
+            for (int k = 0; k < MAXT; k++)
                 if (k < nk)
                     rr += (float)row[si[k]] * al[k];
             acc += rr * yal[e];
@@ -705,6 +736,17 @@ __device__ __forceinline__ float lane_left(float x)
     return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
 }
 
+// the same shifts for the strip kernels, whose first and last lane hold stencil margin only: what those lanes receive does
+// not matter, so the move needs no copy of the old value in front of it (bound_ctrl: lanes without a source take 0)
+__device__ __forceinline__ float strip_right(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float strip_left(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void nld_fused_kernel(const float *__restrict__ Lin, const float *__restrict__ cflow,
                                                         float *__restrict__ Lout, int w, int h, size_t l_stride,
@@ -1045,6 +1087,7 @@ constexpr int DS_PAD = 8;  // columns of padding on either side of a wavefront's
 // only feed the stencils - and the fewer, longer wavefronts a launch has: 120 rows for both kernels measured 257 us per image
 // against 239 with these (the last round of a launch runs half empty, the small levels have too few strips)
 constexpr int DET_STRIP_ROWS = 32, LEVEL_STRIP_ROWS = 64;
+constexpr int DS_NOTES = 64; // noted maxima a wavefront works off together (det_strip_kernel)
 constexpr int DS_RING = 1; // the ring of requested rows is DS_RING (2 S + 1) long (2: 10 - 16 rows in flight per lane at 2 - 3
                            // wavefronts per SIMD instead of 4 at 4: 31.1 us per image against 28.5)
 template <int S> struct det_strip_geom
@@ -1125,7 +1168,7 @@ __global__ __launch_bounds__(256) void det_strip_kernel(const float2 *__restrict
     const bool xok0 = col_ok(cx), xok1 = col_ok(cx + 1);
     const int tiles_x = (w + BT_X - 1) / BT_X;
 
-    constexpr int PF = RB - 2 < 4 ? RB - 2 : (DS_RING == 1 ? 4 : RB - 2); // rows requested ahead
+    constexpr int PF = RB - 2 < 4 ? RB - 2 : (DS_RING == 1 ? (S == 3 ? 3 : 4) : RB - 2); // rows requested ahead (S = 3: one less keeps it at 128 registers)
     float4 ld[RB];
     auto request = [&](int r, int slot) {
         const int gy = min(max(Y0 - (S + 1) + r, 0), h - 1);
@@ -1144,6 +1187,23 @@ __global__ __launch_bounds__(256) void det_strip_kernel(const float2 *__restrict
         X[j] = Y[j] = pa_hd[j] = pb_hd[j] = D[j] = T[j] = Sd[j] = pk2{0.0f, 0.0f};
         DL[j] = DR[j] = 0.0f;
     }
+    // noted maxima: {x, y, v, v(x - 1)}, {v(x + 1), v(y - 1), v(y + 1), v(x - 1, y - 1)}, {v(x + 1, y - 1), v(x - 1, y + 1), v(x + 1, y + 1), -}
+    __shared__ float4 notes[4][DS_NOTES][3];
+    unsigned int n_noted = 0; // (wave-uniform)
+    auto flush_notes = [&](unsigned int n) {
+        wave_sync();
+        if ((unsigned int)lane < n)
+        {
+            const float4 r0 = notes[wv][lane][0], r1 = notes[wv][lane][1], r2 = notes[wv][lane][2];
+            const int x = __float_as_int(r0.x), y = __float_as_int(r0.y);
+            const size_t at = (size_t)blockIdx.z * stride + (size_t)y * w + x;
+            Rmax[at] = r0.z;
+            Fit[at] = subpixel_fit(r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z);
+            atomicOr(&mask[(size_t)blockIdx.z * mask_stride + (size_t)y * tiles_x + (x >> 6)], 1ull << (x & 63));
+            atomicAdd(&tile_counts[(size_t)blockIdx.z * n_tiles + tile_off + (y / DT_Y) * tiles_x + (x >> 6)], 1u);
+        }
+        wave_sync();
+    };
     for (int k = 0; k < NB; k++)
     {
 #pragma unroll
@@ -1174,8 +1234,8 @@ __global__ __launch_bounds__(256) void det_strip_kernel(const float2 *__restrict
             const pk2 lyy = (payL + pby) + payR;
             const pk2 d = (lxx * lyy - lxy * lxy) * s44;
             D[s_c] = d;
-            DL[s_c] = lane_left(d.y);  // determinant at column cx - 1
-            DR[s_c] = lane_right(d.x); // at column cx + 2
+            DL[s_c] = strip_left(d.y);  // determinant at column cx - 1
+            DR[s_c] = strip_right(d.x); // at column cx + 2
             T[s_c] = pk2{max3f(DL[s_c], d.x, d.y), max3f(d.x, d.y, DR[s_c])};
             Sd[s_c] = pk2{max2f(DL[s_c], d.y), max2f(d.x, DR[s_c])};
             // row m = c - 1: rows m - 1, m, m + 1 are there once r >= 2 S + 2.  A strict maximum of its 3 x 3 neighbourhood
@@ -1185,28 +1245,41 @@ __global__ __launch_bounds__(256) void det_strip_kernel(const float2 *__restrict
             const float v0 = D[s_m].x, v1 = D[s_m].y;
             const bool is0 = y_ok & xok0 & (v0 > thr) & (v0 > max3f(T[s_mm].x, T[s_c].x, Sd[s_m].x));
             const bool is1 = y_ok & xok1 & (v1 > thr) & (v1 > max3f(T[s_mm].y, T[s_c].y, Sd[s_m].y));
-            if (__ballot(is0 | is1)) // (a few per cent of the rows of a strip hold a maximum)
+            // a maximum is only NOTED here - position, value, the eight determinants around it, into the wavefront's list in LDS -
+            // and worked off (sub-pixel fit, two divisions; the response, the mask bit and the tile count in HBM) by all lanes
+            // together when the list is full or the strip done: in the row loop it cost every row with a maximum (one in
+            // five) some 130 instructions for one or two active lanes
+            const unsigned long long m0 = __ballot(is0), m1 = __ballot(is1);
+            if (m0 | m1)
             {
-                const size_t row = (size_t)blockIdx.z * stride + (size_t)y * w;
+                const unsigned int n0 = (unsigned int)__popcll(m0), n1 = (unsigned int)__popcll(m1);
+                if (n_noted + n0 + n1 > DS_NOTES)
+                {
+                    flush_notes(n_noted);
+                    n_noted = 0;
+                }
+                const unsigned long long below = (1ull << lane) - 1ull;
                 if (is0)
                 {
-                    Rmax[row + cx] = v0;
-                    Fit[row + cx] = subpixel_fit(v0, DL[s_m], v1, D[s_mm].x, D[s_c].x, DL[s_mm], D[s_mm].y, DL[s_c], D[s_c].y);
-                    atomicOr(&mask[(size_t)blockIdx.z * mask_stride + (size_t)y * tiles_x + (cx >> 6)], 1ull << (cx & 63));
-                    atomicAdd(&tile_counts[(size_t)blockIdx.z * n_tiles + tile_off + (y / DT_Y) * tiles_x + (cx >> 6)], 1u);
+                    float4 *rec = &notes[wv][n_noted + (unsigned int)__popcll(m0 & below)][0];
+                    rec[0] = make_float4(__int_as_float(cx), __int_as_float(y), v0, DL[s_m]);
+                    rec[1] = make_float4(v1, D[s_mm].x, D[s_c].x, DL[s_mm]);
+                    rec[2] = make_float4(D[s_mm].y, DL[s_c], D[s_c].y, 0.0f);
                 }
                 if (is1)
                 {
-                    const int x = cx + 1;
-                    Rmax[row + x] = v1;
-                    Fit[row + x] = subpixel_fit(v1, v0, DR[s_m], D[s_mm].y, D[s_c].y, D[s_mm].x, DR[s_mm], D[s_c].x, DR[s_c]);
-                    atomicOr(&mask[(size_t)blockIdx.z * mask_stride + (size_t)y * tiles_x + (x >> 6)], 1ull << (x & 63));
-                    atomicAdd(&tile_counts[(size_t)blockIdx.z * n_tiles + tile_off + (y / DT_Y) * tiles_x + (x >> 6)], 1u);
+                    float4 *rec = &notes[wv][n_noted + n0 + (unsigned int)__popcll(m1 & below)][0];
+                    rec[0] = make_float4(__int_as_float(cx + 1), __int_as_float(y), v1, v0);
+                    rec[1] = make_float4(DR[s_m], D[s_mm].y, D[s_c].y, D[s_mm].x);
+                    rec[2] = make_float4(DR[s_mm], D[s_c].x, DR[s_c], 0.0f);
                 }
+                n_noted += n0 + n1;
             }
             wave_sync(); // the row buffers have been read by every lane before the next row's stores
         }
     }
+    if (n_noted)
+        flush_notes(n_noted);
 }
 
 // ---- round 5: a level's passes in ONE launch, in the same register-strip form: Lsmooth (Gaussian(1) of the image the
@@ -1356,7 +1429,7 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
         else
             Lraw[j] = own;
         auto raw_row = [&](int slot) { return RAW_IN_LD ? pk2{ld[slot].x, ld[slot].y} : Lraw[slot]; };
-        const pk2 Lm = {lane_left(own.x), lane_left(own.y)}, Lp = {lane_right(own.x), lane_right(own.y)};
+        const pk2 Lm = {strip_left(own.x), strip_left(own.y)}, Lp = {strip_right(own.x), strip_right(own.y)};
         pk2 t = zero + k0 * Lm;
         t = t + k1 * pk2{Lm.y, own.x};
         t = t + k2 * own;
@@ -1378,14 +1451,14 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
         {
             // (the wavefront shifts run with every lane active - a lane masked off would hand its neighbour nothing -
             // and the border lanes choose afterwards)
-            const float lft_n = lane_left(a.y), rgt_n = lane_right(a.x);
+            const float lft_n = strip_left(a.y), rgt_n = strip_right(a.x);
             const float lft = first_col ? a.y : lft_n, rgt = last_col ? a.x : rgt_n;
             const pk2 hd1 = pk2{a.y, rgt} - pk2{lft, a.x};
             p3[s_c] = c3 * hd1;
             p10[s_c] = c10 * hd1;
             const pk2 vd1 = (f_top || f_bot) ? zero : a - Ls[sl(s_c - 2)];
             const pk2 q3 = c3 * vd1, q10 = c10 * vd1;
-            const float q3l_n = lane_left(q3.y), q3r_n = lane_right(q3.x);
+            const float q3l_n = strip_left(q3.y), q3r_n = strip_right(q3.x);
             const float q3l = first_col ? q3.y : q3l_n, q3r = last_col ? q3.x : q3r_n;
             const pk2 ptop = f_top ? p3[s_c] : p3[sl(s_c - 2)], pbot = f_bot ? p3[sl(s_c - 2)] : p3[s_c];
             const pk2 lx = (ptop + p10[sl(s_c - 1)]) + pbot;
@@ -1440,7 +1513,7 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
         if (K > 0)
         {
             C[s_f] = cf;
-            const float crx = lane_right(cf.x);
+            const float crx = strip_right(cf.x);
             CX[s_f] = cf + pk2{cf.y, crx};         // c(x) + c(x + 1)
             CY[sl(s_f - 1)] = C[sl(s_f - 1)] + cf; // c(y) + c(y + 1) of row f - 1
             pk2 Ln = raw_row(s_f);                 // the previous step's row below the one a step works on
@@ -1451,11 +1524,11 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
             {
                 const int s_y = sl(s_f - q), yq = yf - q; // step q works on image row yq
                 const pk2 Lc = q == 1 ? raw_row(s_y) : Lsave[q - 1];
-                const float right = lane_right(Lc.x);
+                const float right = strip_right(Lc.x);
                 const pk2 d = pk2{Lc.y, right} - Lc;
                 pk2 xpos = CX[s_y] * d;
                 xpos.y = hr1 ? xpos.y : 0.0f;
-                const float xl = lane_left(xpos.y);
+                const float xl = strip_left(xpos.y);
                 const pk2 xneg = {hl0 ? xl : 0.0f, xpos.x};
                 const pk2 ypos = (!EDGE || yq + 1 < h) ? CY[s_y] * (Ln - Lc) : zero;
                 const pk2 yneg = (!EDGE || yq > 0) ? Fsave[q] : zero;
@@ -3044,11 +3117,17 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             return rc;
         }
         const dim3 rgrid((W + 255) / 256, (H + RESIZE_ROWS - 1) / RESIZE_ROWS, B);
-        if (fused_grey)
-            hipLaunchKernelGGL((resize_area_lds_kernel<true>), rgrid, dim3(256), 0, st, (const uint8_t *)d_bgr, width, height, d_img,
+        int most_taps = 0;
+        for (int x = 0; x < W; x++)
+            most_taps = std::max(most_taps, tx.off[x + 1] - tx.off[x]);
+        if (fused_grey && most_taps <= 4)
+            hipLaunchKernelGGL((resize_area_lds_kernel<true, 4>), rgrid, dim3(256), 0, st, (const uint8_t *)d_bgr, width, height, d_img,
+                               W, H, xo, xs, xa, yo, ys, ya);
+        else if (fused_grey)
+            hipLaunchKernelGGL((resize_area_lds_kernel<true, RESIZE_MAX_TAPS>), rgrid, dim3(256), 0, st, (const uint8_t *)d_bgr, width, height, d_img,
                                W, H, xo, xs, xa, yo, ys, ya);
         else if (staged)
-            hipLaunchKernelGGL((resize_area_lds_kernel<false>), rgrid, dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs,
+            hipLaunchKernelGGL((resize_area_lds_kernel<false, RESIZE_MAX_TAPS>), rgrid, dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs,
                                xa, yo, ys, ya);
         else
             hipLaunchKernelGGL(resize_area_kernel, rgrid, dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs, xa, yo, ys,
