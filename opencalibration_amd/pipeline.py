@@ -86,6 +86,38 @@ def run(ctx, grid, images_ptr, shape, start_orientation, max_keypoints=30000, ov
     return g, res, t
 
 
+def run_incremental(ctx, grid, images_ptr, shape, batch=100, max_keypoints=30000):
+    """The reference's own schedule of INITIAL_PROCESSING (Pipeline::Impl::initial_processing, src/pipeline/pipeline.cpp:522-570):
+    the survey arrives in batches; every batch is loaded (extract) and linked against everything loaded so far, and its
+    cameras - which start WITHOUT an orientation (NaN) - are relaxed as one group {ORIENTATION, GROUND_PLANE} together with two
+    rings of already oriented context cameras held fixed (RelaxStage::init with the batch's ids, relax_group.cpp:40-66);
+    relax() initialises the NaN cameras one at a time, a solve each, before the group's solve (src/relax/relax.cpp:52-80).
+    Returns (graph, dict of counts and seconds)."""
+    n, h, w = shape
+    g = host.Graph()
+    mid = g.add_model(grid.model)
+    opts = host.relax_options("ORIENTATION", "GROUND_PLANE")
+    out = dict(batches=0, solves=0, lm_iterations=0, residual_blocks=0, load_link_s=0.0, relax_s=0.0)
+    t_all = time.perf_counter()
+    for lo in range(0, n, batch):
+        cnt = min(batch, n - lo)
+        t0 = time.perf_counter()
+        nan = np.full((cnt, 4), np.nan)
+        g.load_link_images(ctx, images_ptr + lo * h * w * 3, mid, grid.position[lo:lo + cnt], nan, max_keypoints, device_shape=(cnt, h, w))
+        out["load_link_s"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        st = g.relax_stage(ctx, opts, node_ids=g.node_ids[lo:lo + cnt])
+        ctx.synchronize()
+        out["relax_s"] += time.perf_counter() - t0
+        out["batches"] += 1
+        out["solves"] += int(st["solves"])
+        out["lm_iterations"] += int(st["iterations_total"])
+        out["residual_blocks"] += int(st["residual_blocks"])
+    out["seconds"] = time.perf_counter() - t_all
+    out["edges"] = g.num_edges
+    return g, out
+
+
 def perturbed_orientations(grid, sigma=0.1, seed=99):
     """True orientation with a `sigma` rad error about a random axis (test/test_relax.cpp:421)."""
     rng = np.random.default_rng(seed)
