@@ -953,30 +953,46 @@ __device__ uint32_t fast_forward(const pair_data &pd, const uint32_t *__restrict
     }
     double s = 0;
     bool rej = false;
-    for (uint32_t pos0 = 0; pos0 < M; pos0 += 2)
+    // (round 5: the walk took its four coordinates of every position straight from memory - the same address in all
+    // lanes, one L2 round trip per two positions with the exit test between them, 14 k loads per pair and two thirds of the
+    // kernel's cycles in s_waitcnt.  Now a chunk of 64 positions is loaded once, a position per lane, and the walk takes a
+    // position's coordinates from the lane that holds it: one round trip per 64 positions, and most walks end inside the
+    // first chunk.)
+    for (uint32_t base = 0; base < M; base += W)
     {
         if (__ballot(lane < 32 && live && !rej) == 0)
             break;
-        const uint32_t pos = pos0 + (uint32_t)half;
-        double term = 0;
-        if (pos < M)
+        const uint32_t mine = base + (uint32_t)lane;
+        const double c_x1 = mine < M ? pd.ex1[mine] : 0.0, c_y1 = mine < M ? pd.ey1[mine] : 0.0;
+        const double c_x2 = mine < M ? pd.ex2[mine] : 0.0, c_y2 = mine < M ? pd.ey2[mine] : 0.0;
+        const uint32_t chunk_end = min(base + (uint32_t)W, M);
+        for (uint32_t pos0 = base; pos0 < chunk_end; pos0 += 2)
         {
-            const double e = transfer_error(mm, pd.ex1[pos], pd.ey1[pos], pd.ex2[pos], pd.ey2[pos]);
-            if (e < thr)
+            if (__ballot(lane < 32 && live && !rej) == 0)
+                break;
+            const uint32_t pos = pos0 + (uint32_t)half;
+            const int holder = (int)(pos - base) & (W - 1); // (pos == chunk_end: the upper half-wave's unused odd position)
+            const double px1 = __shfl(c_x1, holder), py1 = __shfl(c_y1, holder), px2 = __shfl(c_x2, holder), py2 = __shfl(c_y2, holder);
+            double term = 0;
+            if (pos < M)
             {
-                const double ratio = e / thr;
-                term = 1.0 - ratio * ratio;
+                const double e = transfer_error(mm, px1, py1, px2, py2);
+                if (e < thr)
+                {
+                    const double ratio = e / thr;
+                    term = 1.0 - ratio * ratio;
+                }
             }
-        }
-        const double term_odd = __shfl(term, src + 32);
-        s = s + term; // position pos0 (lower half-wave; the upper half's sums are not used)
-        if (pos0 + 1 > 20 && best_score > 0 && s < best_score * (double)(pos0 + 1) / (double)M * 0.6)
-            rej = true;
-        if (pos0 + 1 < M)
-        {
-            s = s + term_odd; // position pos0 + 1
-            if (pos0 + 2 > 20 && best_score > 0 && s < best_score * (double)(pos0 + 2) / (double)M * 0.6)
+            const double term_odd = __shfl(term, src + 32);
+            s = s + term; // position pos0 (lower half-wave; the upper half's sums are not used)
+            if (pos0 + 1 > 20 && best_score > 0 && s < best_score * (double)(pos0 + 1) / (double)M * 0.6)
                 rej = true;
+            if (pos0 + 1 < M)
+            {
+                s = s + term_odd; // position pos0 + 1
+                if (pos0 + 2 > 20 && best_score > 0 && s < best_score * (double)(pos0 + 2) / (double)M * 0.6)
+                    rej = true;
+            }
         }
     }
     const unsigned long long improving = __ballot(lane < 32 && live && !rej && s > best_score);
