@@ -6,7 +6,7 @@
 //                      back_solve_x_global (step vector in HBM even when it fits LDS), no_dissect (one band, no regions),
 //                      jacobian_fp32 (profiles/r04_jacobian_precision_sweep_c5.json),
 //                      tile_levels, tile_det (the LDS-tile kernels of the scale space / the determinant instead of round 5's register
-//                      strips)
+//                      strips), sort_per_level (a launch per introsort level instead of a workgroup per segment)
 #pragma once
 
 #include <cstdlib>

@@ -485,7 +485,7 @@ int feature_lists_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>>
     if (!alloc_ok)
         return ochip_fail(ctx, OCHIP_ENOMEM, "feature lists: device allocation failed");
     const dim3 wide((F.S + 255) / 256, 1, B);
-    constexpr int rounds = 4; // (6 until round 5: the fifth and sixth round found a handful of points for a launch over all of them; the per-image finish takes those)
+    constexpr int rounds = 6; // (4 measured in round 5: the two launches saved cost the per-image finish more than they took)
     auto suppress = [&](const nms_dev &M, bool subset) -> int {
         OCHIP_HIP(ctx, hipMemsetAsync(M.cell_fill, 0, (size_t)B * M.gw * M.gh * 4, st));
         hipLaunchKernelGGL(nms_cells_kernel, wide, dim3(256), 0, st, M);

@@ -18,9 +18,10 @@
 // after level, until a range has at most 1 024 elements; such a range is finished by ONE wavefront in LDS (the same
 // partition, the rest of its recursion from a small stack - no more launches, no more HBM round trips).  Ranges of at most
 // 16 elements go to the final insertion sort, which never moves an element out of its range (everything left of a range
-// is not after it in the order) - one lane per range.  The heap sort
-// libstdc++ falls back to at the depth limit is NOT restated: a segment that gets there is flagged and its caller
-// sorts it on the host (organ pipes and median-of-three killers do; responses and Hamming counts do not).
+// is not after it in the order) - one lane per range.  The heap sort libstdc++ falls back to at the depth limit
+// (std::__partial_sort: organ pipes and median-of-three killers get there; responses and Hamming counts do not) is restated
+// too, move for move, and runs sequentially on one lane (round 5; until then such a segment was flagged for the host).
+// fallback[] is now only set when a queue overflows.
 // scripts/check_parallel_std_sort.py holds the formulation against std::sort on the CPU, tests/test_gpu_std_sort.py the
 // kernels.
 //
@@ -56,7 +57,8 @@ struct sort_dev
     range_t *big[3];             // same, for the ranges a whole workgroup takes
     range_t *final_ranges;       // ranges of 2..16 elements
     range_t *local;              // ranges of 17..LOCAL elements
-    unsigned int *counts;        // [0..2] queue sizes, [3..5] big sizes, [6] final, [7] local, [8] error
+    range_t *heap;               // ranges longer than LOCAL that reached the depth limit (counts[10])
+    unsigned int *counts;        // [0..2] queue sizes, [3..5] big sizes, [6] final, [7] local, [8] error, [10] heap
     unsigned int cap_queue, cap_final, cap_level; // of local, final_ranges, the level queues
     unsigned char *fallback;     // [n_segs]
     unsigned int *error;         // a queue overflowed (cannot happen with the capacities below; checked anyway)
@@ -133,6 +135,58 @@ __device__ __forceinline__ unsigned int wave_inclusive_scan(unsigned int v)
     return v;
 }
 
+// ---- the depth limit: std::__partial_sort(first, last, last) = __make_heap + __sort_heap of libstdc++'s bits/stl_heap.h
+// (__adjust_heap, __push_heap, __pop_heap restated move for move; comp as above).  Sequential, one lane: a range gets here
+// on adversarial inputs only (organ pipes, median-of-three killers), never on responses or Hamming counts; what matters is
+// that such a segment comes out as std::sort leaves it without leaving the device.  A: the range's first element
+// (LDS or HBM).
+template <typename Ptr> __device__ void heap_adjust(Ptr A, unsigned int hole, unsigned int len, u64 value)
+{
+    const unsigned int top = hole;
+    unsigned int child = hole;
+    while (child < (len - 1) / 2)
+    {
+        child = 2 * (child + 1);
+        if (comp(A[child], A[child - 1]))
+            child--;
+        A[hole] = A[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2)
+    {
+        child = 2 * (child + 1);
+        A[hole] = A[child - 1];
+        hole = child - 1;
+    }
+    // __push_heap(first, hole, top, value)
+    unsigned int parent = (hole - 1) / 2;
+    while (hole > top && comp(A[parent], value))
+    {
+        A[hole] = A[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    A[hole] = value;
+}
+template <typename Ptr> __device__ void heap_sort(Ptr A, unsigned int len)
+{
+    if (len < 2)
+        return;
+    for (unsigned int parent = (len - 2) / 2;; parent--) // __make_heap
+    {
+        heap_adjust(A, parent, len, A[parent]);
+        if (parent == 0)
+            break;
+    }
+    for (unsigned int last = len; last > 1;) // __sort_heap: __pop_heap(first, last - 1, last - 1)
+    {
+        --last;
+        const u64 value = A[last];
+        A[last] = A[0];
+        heap_adjust(A, 0u, last, value);
+    }
+}
+
 // ---- group primitives: G threads that partition one range together (a wavefront or a workgroup)
 template <int G> struct group;
 template <> struct group<64>
@@ -191,15 +245,32 @@ template <> struct group<GROUP>
 };
 
 // one step of __introsort_loop on range r: median of three to the front, __unguarded_partition, the two ranges it leaves
-template <int G> __device__ void partition_range(const sort_dev &S, const range_t r, int next, bool big_allowed, unsigned int *lds)
+// (Sink: where the two ranges a partition leaves go - the level queues in HBM, or a workgroup's own queues in LDS)
+struct level_sink
+{
+    const sort_dev &S;
+    int next;
+    bool big_allowed;
+    __device__ __forceinline__ void operator()(unsigned int first, unsigned int last, unsigned int depth, unsigned int seg) const
+    {
+        push_range(S, next, first, last, depth, seg, big_allowed);
+    }
+};
+template <int G, typename Sink> __device__ void partition_range(const sort_dev &S, const range_t r, const Sink &sink, unsigned int *lds)
 {
     u64 *A = S.A;
     const unsigned int t = (unsigned int)group<G>::tid();
     const unsigned int first = r.first, last = r.last;
     if (r.depth == 0)
     {
-        if (t == 0)
-            S.fallback[r.seg] = 1; // libstdc++ heap-sorts this range; the caller sorts the segment on the host
+        if (t == 0) // libstdc++ heap-sorts this range: sort_heap_kernel does, behind the levels
+        {
+            const unsigned int at = atomicAdd(&S.counts[10], 1u);
+            if (at < S.cap_level)
+                S.heap[at] = r;
+            else
+                *S.error = 1;
+        }
         return;
     }
     if (t == 0)
@@ -322,8 +393,8 @@ template <int G> __device__ void partition_range(const sort_dev &S, const range_
                 cut = min(cut, LL[K]);
         }
         // __introsort_loop(cut, last, depth_limit) and the loop's next round on [first, cut), both with the decremented limit
-        push_range(S, next, cut, last, r.depth - 1, r.seg, big_allowed);
-        push_range(S, next, first, cut, r.depth - 1, r.seg, big_allowed);
+        sink(cut, last, r.depth - 1, r.seg);
+        sink(first, cut, r.depth - 1, r.seg);
     }
 }
 
@@ -338,11 +409,95 @@ __global__ __launch_bounds__(GROUP) void sort_level_kernel(sort_dev S, int cur, 
         S.counts[3 + stale] = 0;
     }
     const unsigned int nb = min(S.counts[3 + cur], S.cap_level);
+    const level_sink sink{S, next, true};
     for (unsigned int idx = blockIdx.x; idx < nb; idx += gridDim.x)
-        partition_range<GROUP>(S, S.big[cur][idx], next, true, lds);
+        partition_range<GROUP>(S, S.big[cur][idx], sink, lds);
     const unsigned int n = min(S.counts[cur], S.cap_level);
     for (unsigned int idx = blockIdx.x * (GROUP / 64) + (threadIdx.x >> 6); idx < n; idx += gridDim.x * (GROUP / 64))
-        partition_range<64>(S, S.queue[cur][idx], next, true, nullptr);
+        partition_range<64>(S, S.queue[cur][idx], sink, nullptr);
+}
+
+// ---- round 5: ONE launch for all levels above LOCAL, a workgroup per SEGMENT.  The ranges of one segment never meet those
+// of another, so a workgroup can walk its own segment's partition tree with workgroup barriers only: the long ranges
+// (> BIG) one after the other with all 16 wavefronts, the ranges in (LOCAL, BIG] a wavefront each, round after round,
+// from two small queues in LDS; what falls to LOCAL or below goes to the same queues in HBM as before (sort_local_kernel,
+// sort_final_kernel).  The launch-per-level form walked 2 lg n + 1 = 29 levels for every call - most of them empty - and
+// the 100 segments of a chunk are only busy for the first eight: 58 launches per chunk for the two sorts of
+// extract_features, now 2.  Segments longer than SEG_MAX (queues sized for it) and calls with few long segments keep
+// the level launches.
+constexpr unsigned int SEG_MAX = 1u << 17, SEG_BIGQ = 64, SEG_MIDQ = 192;
+struct segment_queues
+{
+    range_t big[2][SEG_BIGQ], mid[2][SEG_MIDQ];
+    unsigned int n_big[2], n_mid[2];
+    unsigned int overflow;
+};
+struct segment_sink
+{
+    const sort_dev &S;
+    segment_queues *Q;
+    int next;
+    __device__ __forceinline__ void operator()(unsigned int first, unsigned int last, unsigned int depth, unsigned int seg) const
+    {
+        const unsigned int len = last - first;
+        if (len <= LOCAL)
+        {
+            push_range(S, 0, first, last, depth, seg, true); // (<= LOCAL: the final / local queues in HBM)
+            return;
+        }
+        const bool to_big = len > BIG;
+        const unsigned int at = atomicAdd(to_big ? &Q->n_big[next] : &Q->n_mid[next], 1u);
+        if (at < (to_big ? SEG_BIGQ : SEG_MIDQ))
+            (to_big ? Q->big[next] : Q->mid[next])[at] = range_t{first, last, depth, seg};
+        else
+            Q->overflow = 1;
+    }
+};
+__global__ __launch_bounds__(GROUP) void sort_segments_kernel(sort_dev S, const unsigned int *__restrict__ seg_begin,
+                                                             const unsigned int *__restrict__ seg_end)
+{
+    __shared__ unsigned int lds[GROUP];
+    __shared__ segment_queues Q;
+    const unsigned int seg = blockIdx.x;
+    const unsigned int first = seg_begin[seg], last = seg_end[seg];
+    if (threadIdx.x == 0)
+    {
+        S.fallback[seg] = 0;
+        Q.n_big[0] = Q.n_big[1] = Q.n_mid[0] = Q.n_mid[1] = 0;
+        Q.overflow = 0;
+    }
+    __syncthreads();
+    if (last <= first)
+        return;
+    if (threadIdx.x == 0)
+    {
+        unsigned int lg = 0;
+        for (unsigned int n = last - first; n > 1; n >>= 1)
+            lg++;
+        segment_sink{S, &Q, 0}(first, last, 2 * lg, seg);
+    }
+    __syncthreads();
+    for (int cur = 0;; cur ^= 1)
+    {
+        const int next = cur ^ 1;
+        const unsigned int nb = min(Q.n_big[cur], SEG_BIGQ), nm = min(Q.n_mid[cur], SEG_MIDQ);
+        if (nb == 0 && nm == 0)
+            break;
+        const segment_sink sink{S, &Q, next};
+        for (unsigned int idx = 0; idx < nb; idx++)
+        {
+            partition_range<GROUP>(S, Q.big[cur][idx], sink, lds);
+            __syncthreads();
+        }
+        for (unsigned int idx = threadIdx.x >> 6; idx < nm; idx += GROUP / 64)
+            partition_range<64>(S, Q.mid[cur][idx], sink, nullptr);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            Q.n_big[cur] = Q.n_mid[cur] = 0;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && Q.overflow)
+        S.fallback[seg] = 1; // (a queue of this workgroup overflowed: the caller sorts the segment on the host)
 }
 
 // ranges still waiting in the level queues after the last level launched: the host's
@@ -381,7 +536,6 @@ __global__ __launch_bounds__(256) void sort_local_kernel(sort_dev S)
         group<64>::sync();
         int sp = 1;           // (uniform)
         unsigned int n_fin = 0;
-        bool failed = false;
         while (sp > 0)
         {
             sp--;
@@ -400,7 +554,9 @@ __global__ __launch_bounds__(256) void sort_local_kernel(sort_dev S)
             }
             if (depth == 0)
             {
-                failed = true; // libstdc++ heap-sorts this range
+                if (lane == 0) // libstdc++ heap-sorts this range (the depth limit: adversarial inputs)
+                    heap_sort(D + first, last - first);
+                group<64>::sync();
                 continue;
             }
             if (lane == 0)
@@ -489,9 +645,36 @@ __global__ __launch_bounds__(256) void sort_local_kernel(sort_dev S)
         group<64>::sync();
         for (unsigned int i = lane; i < len; i += 64)
             S.A[r.first + i] = D[i];
-        if (failed && lane == 0)
-            S.fallback[r.seg] = 1;
         group<64>::sync();
+    }
+}
+
+// the ranges longer than LOCAL that reached the depth limit, a wavefront each: through LDS when they fit (HEAP_LDS records),
+// in place otherwise
+constexpr unsigned int HEAP_LDS = 8192;
+__global__ __launch_bounds__(64) void sort_heap_kernel(sort_dev S)
+{
+    __shared__ u64 D[HEAP_LDS];
+    const unsigned int n = min(S.counts[10], S.cap_level);
+    const int lane = threadIdx.x;
+    for (unsigned int idx = blockIdx.x; idx < n; idx += gridDim.x)
+    {
+        const range_t r = S.heap[idx];
+        const unsigned int len = r.last - r.first;
+        if (len <= HEAP_LDS)
+        {
+            for (unsigned int i = lane; i < len; i += 64)
+                D[i] = S.A[r.first + i];
+            group<64>::sync();
+            if (lane == 0)
+                heap_sort(D, len);
+            group<64>::sync();
+            for (unsigned int i = lane; i < len; i += 64)
+                S.A[r.first + i] = D[i];
+            group<64>::sync();
+        }
+        else if (lane == 0)
+            heap_sort(S.A + r.first, len);
     }
 }
 
@@ -563,19 +746,33 @@ int std_sort_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> *all
         S.queue[i] = (range_t *)dev(cap_level * sizeof(range_t));
         S.big[i] = (range_t *)dev(cap_level * sizeof(range_t));
     }
+    S.heap = (range_t *)dev(cap_level * sizeof(range_t));
     S.final_ranges = (range_t *)dev((size_t)S.cap_final * sizeof(range_t));
     S.local = (range_t *)dev((size_t)S.cap_queue * sizeof(range_t));
     S.counts = (unsigned int *)dev(16 * 4);
     S.fallback = fallback;
-    if (!S.listL || !S.listR || !S.queue[0] || !S.queue[1] || !S.queue[2] || !S.big[0] || !S.big[1] || !S.big[2] || !S.final_ranges || !S.local || !S.counts)
+    if (!S.heap || !S.listL || !S.listR || !S.queue[0] || !S.queue[1] || !S.queue[2] || !S.big[0] || !S.big[1] || !S.big[2] || !S.final_ranges || !S.local || !S.counts)
         return ochip_fail(ctx, OCHIP_ENOMEM, "std_sort: device allocation failed");
     S.error = S.counts + 8;
     OCHIP_HIP(ctx, hipMemsetAsync(S.counts, 0, 16 * 4, st));
-    hipLaunchKernelGGL(sort_init_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, S, seg_begin, seg_end, n_segs);
+    // a workgroup per segment walks the levels above LOCAL by itself when there are enough segments to fill the device that
+    // way (the chunks of extract_features: 100 segments of ~20 k records); few long segments keep a launch per level, which
+    // spreads one level's ranges over all workgroups
+    static const bool per_level_hook = ochip_test_hook("sort_per_level");
+    const bool by_segment = !per_level_hook && n_segs >= 32 && max_len <= SEG_MAX;
+    if (by_segment)
+    {
+        if (max_len > LOCAL)
+            hipLaunchKernelGGL(sort_segments_kernel, dim3(n_segs), dim3(GROUP), 0, st, S, seg_begin, seg_end);
+        else
+            hipLaunchKernelGGL(sort_init_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, S, seg_begin, seg_end, n_segs);
+    }
+    else
+        hipLaunchKernelGGL(sort_init_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, S, seg_begin, seg_end, n_segs);
     // levels in HBM: while a range can still be longer than LOCAL - up to the depth limit (a range that reaches it is
     // flagged by the level that takes it; the deeper levels of well-split segments find their queues empty)
     int levels = 0;
-    if (max_len > LOCAL)
+    if (max_len > LOCAL && !by_segment)
     {
         unsigned int lg = 0;
         for (uint32_t n = max_len; n > 1; n >>= 1)
@@ -595,6 +792,8 @@ int std_sort_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> *all
     }
     if (levels)
         hipLaunchKernelGGL(sort_flag_left_kernel, dim3(64), dim3(256), 0, st, S, levels % 3);
+    if (max_len > LOCAL)
+        hipLaunchKernelGGL(sort_heap_kernel, dim3(64), dim3(64), 0, st, S);
     {
         const unsigned int most_local = (unsigned int)(total_len / (THRESHOLD + 1) + n_segs);
         hipLaunchKernelGGL(sort_local_kernel, dim3(std::min((most_local + 3) / 4, 2048u)), dim3(256), 0, st, S);

@@ -113,13 +113,15 @@ def test_tie_for_the_strongest(ctx):
     assert not lists["conflict"]
 
 
-def test_depth_limit_goes_to_the_host(ctx):
+def test_depth_limit_stays_on_the_device(ctx):
+    """An organ pipe of responses runs std::sort into its heap-sort fallback: restated on the device since round 5, so the
+    lists come back complete and equal to the host's (until then the image was flagged and its tail redone on the host)."""
     rng = np.random.default_rng(15)
     n = 20000
     kp6, desc = keypoints(rng, n, 1600, 1200, clusters=10)
     kp6[:, 4] = (np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]) + 1.0) * 1e-4      # organ pipe
     lists, exp = both(ctx, kp6, desc, 1600, 1200, 0.4)
-    assert lists["conflict"]
+    assert not lists["conflict"] and not lists["subset_conflict"]
 
 
 def test_small_cases(ctx):

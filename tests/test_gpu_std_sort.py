@@ -1,6 +1,6 @@
 """libstdc++'s std::sort on the device (csrc/std_sort.hip) against std::sort itself (och_sort_by_response(use_std=1) calls
-it on (response, index) records with comp = response greater): the permutation must be identical, also among equal keys;
-segments that hit introsort's depth limit must be flagged instead."""
+it on (response, index) records with comp = response greater): the permutation must be identical, also among equal keys and
+for segments that hit introsort's depth limit (heap sort)."""
 import ctypes as C
 
 import numpy as np
@@ -95,8 +95,22 @@ def test_match_sized_segments_with_heavy_ties(ctx):
     assert run(ctx, segs) == 0
 
 
-def test_depth_limit_is_flagged_not_missorted(ctx):
-    segs = [killer(200), -killer(200) + 1000, killer(20000), np.concatenate([np.arange(10000), np.arange(10477)[::-1]]),
-            np.random.default_rng(4).uniform(0, 1, 5000)]
-    flagged = run(ctx, segs)
-    assert 1 <= flagged <= 4
+def test_depth_limit_heap_sort_on_the_device(ctx):
+    """Median-of-three killers and organ pipes run introsort into its depth limit, where libstdc++ heap-sorts the range
+    (std::__partial_sort): restated on the device since round 5 (one lane, sequential) - nothing is flagged for the host any
+    more and the permutation is std::sort's, for ranges that end in LDS (killer(200), killer(3000)), for long ones
+    (killer(20000): heap-sorted through LDS; killer(40000): in place) and with ties."""
+    rng = np.random.default_rng(4)
+    tied = np.floor(killer(6000) / 3)
+    segs = [killer(200), -killer(200) + 1000, killer(3000), killer(20000), killer(40000), tied,
+            np.concatenate([np.arange(10000), np.arange(10477)[::-1]]), rng.uniform(0, 1, 5000)]
+    assert run(ctx, segs) == 0
+
+
+def test_many_segments_take_the_workgroup_per_segment_route(ctx):
+    """32 or more segments: one workgroup per segment walks the levels above 1 024 records by itself (sort_segments_kernel);
+    fewer take a launch per level - both against std::sort, killers among them."""
+    rng = np.random.default_rng(6)
+    segs = [rng.uniform(0, 1, int(rng.integers(900, 26000))) for _ in range(40)] + [killer(20000), rng.integers(0, 50, 30000)]
+    assert run(ctx, segs) == 0
+    assert run(ctx, segs[:5] + [killer(20000)]) == 0
