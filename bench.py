@@ -63,34 +63,63 @@ def _env_int(name, default):
         return default
 
 
-def extract_algorithmic_bytes(w, h):
-    """Algorithmic HBM bytes of the extract (AKAZE) launch sequence per image, counting every data-dependent pass as one
-    read of its inputs and one write of its outputs:
-      source: BGR read (3 B/px) + grey write/read (2 B/px) at full resolution, working image write (4 B/px)
-      k-contrast: image read, gradient magnitude write + read                            3 floats / working px
-      level 0: Gaussian(1.6) read + write                                               2
-      per evolution level: Lsmooth pass (read L; write conductivity, Lx, Ly) 4; FED steps: 3 (read L, c; write L) per
-        group of <= 4 steps (steps fused in registers are not charged: the figure is what the pass structure must move)
-      level 0: derivatives (read L, write Lx, Ly) 3
-      per level detection: determinant (read Lx, Ly, write) 3, maxima (r, w) 2
-      per level description: maxima map read once (list + suppression) 1, L / Lx / Ly read once by the sampler 3"""
+def fed_steps_per_level():
+    """FED steps of the 16 levels (4 octaves x 4 sublevels, sigma0 1.6, tau_max 0.25): AKAZE's fed_tau_by_process_time."""
+    sig = [1.6 * 2.0 ** (j / 4.0 + o) for o in range(4) for j in range(4)]
+    return [0] + [int(np.ceil(np.sqrt(3.0 * (0.5 * (sig[i] ** 2 - sig[i - 1] ** 2)) / 0.25 + 0.25) - 0.5 - 1e-8))
+                  for i in range(1, 16)]
+
+
+def extract_algorithmic_bytes(w, h, reference_passes=False):
+    """Algorithmic HBM bytes of the extract (AKAZE) launch sequence per image: every data-dependent pass of the CURRENT pass
+    structure reads its inputs and writes its outputs once; what a launch keeps in registers is not
+    charged.  Round 5 (level_strip_kernel: Lsmooth, conductivity, (Lx, Ly) and the first group of <= 4 FED steps in one
+    launch; grey conversion inside the resize):
+      source: BGR read 3 B / full-resolution px; working image write 1 float / working px
+      k-contrast: image read 1, gradient magnitude write 1 + read 1
+      level 0: Gaussian(1.6) read 1 + write 1; derivatives read 1 + write 2 (Lx, Ly); determinant read 2
+      level i >= 1: level launch read L 1, write (Lx, Ly) 2, write L 1 (+ conductivity write 1 when FED groups follow);
+        every further group of <= 4 FED steps read L 1 + conductivity 1, write L 1; determinant read 2
+      description: L, Lx, Ly read once by the sampler 3 per level (the maxima maps are sparse: not charged)
+    reference_passes=True: the pass structure of rounds 2 - 4 (Lsmooth pass, every FED group and the determinant as launches
+    of their own, grey written and read): 0.756 GB per 4000 x 3000 image, kept for the comparison across rounds."""
     sc = min(1.0, 1600.0 / max(w, h))
     W, H = int(round(w * sc)), int(round(h * sc))
-    sig = [1.6 * 2.0 ** (j / 4.0 + o) for o in range(4) for j in range(4)]
-    fed = [0] + [int(np.ceil(np.sqrt(3.0 * (0.5 * (sig[i] ** 2 - sig[i - 1] ** 2)) / 0.25 + 0.25) - 0.5 - 1e-8))
-                 for i in range(1, 16)]
-    px_floats = 5.0 * W * H
+    fed = fed_steps_per_level()
+    if reference_passes:
+        px_floats = 5.0 * W * H
+        for lvl in range(16):
+            px = (W >> (lvl // 4)) * (H >> (lvl // 4))
+            px_floats += px * (9 + (4 + 3 * ((fed[lvl] + 3) // 4) if lvl else 3))
+        return 4.0 * px_floats + w * h * 5.0
+    px_floats = 1.0 * W * H + 3.0 * W * H      # working image; k-contrast
     for lvl in range(16):
         px = (W >> (lvl // 4)) * (H >> (lvl // 4))
-        px_floats += px * (9 + (4 + 3 * ((fed[lvl] + 3) // 4) if lvl else 3))
-    return 4.0 * px_floats + w * h * 5.0
+        if lvl == 0:
+            per = 2 + 3 + 2 + 3
+        else:
+            groups = (fed[lvl] + 3) // 4
+            per = 4 + (1 if groups > 1 else 0) + 3 * max(groups - 1, 0) + 2 + 3
+        px_floats += px * per
+    return 4.0 * px_floats + w * h * 3.0
+
+
+def committed_valu_per_image():
+    """Vector (VALU) wavefront instructions per image of the extract sequence from the committed counter pass
+    (profiles/r05_extract_valu.json): (instructions, peak per second, file) or (None, None, None)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_extract_valu.json")) as fh:
+            d = json.load(fh)
+        return float(d["extract_valu_wave_instructions_per_image"]), float(d["issue_peak_wave_instructions_per_s"]), "profiles/r05_extract_valu.json"
+    except (OSError, KeyError, ValueError):
+        return None, None, None
 
 
 def committed_traffic_per_image():
     """HBM bytes per image of the extract sequence from the committed PMC pass (FETCH_SIZE x 2 + WRITE_SIZE per the guide's
     gfx950 correction, scripts/summarise_profile.py): (bytes, file) or (None, None).  The counters cannot be read from
     inside this process; the figure is a constant of the code version the file was taken with."""
-    for name in ("r04_e2e_pmc_hbm.json", "r03_e2e_pmc_hbm.json", "r02_e2e_pmc_hbm.json"):
+    for name in ("r05_e2e_pmc_hbm.json", "r04_e2e_pmc_hbm.json", "r03_e2e_pmc_hbm.json", "r02_e2e_pmc_hbm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return float(json.load(fh)["extract_hbm_bytes_per_image"]), "profiles/" + name
@@ -241,6 +270,21 @@ def relax_memory_report(ctx):
     return {"unknowns": n, "stored_mbytes": round(stored / 1e6, 2), "dense_mbytes": round(dense / 1e6, 2)}
 
 
+def valu_issue(images, seconds):
+    """What bounds the extract kernels since round 5 is the rate at which a CU issues vector instructions (the counters have
+    every large kernel of the sequence issue-bound: DESIGN.md section 4.1), so the sequence is also priced against that:
+    wavefront instructions per image from the committed counter pass x images / seconds, against 256 CUs x 4 SIMDs x
+    2.4 GHz / 4 cycles per wavefront instruction."""
+    n, peak, src = committed_valu_per_image()
+    if n is None:
+        return None
+    ach = n * images / seconds
+    return {"bound": "vector issue", "achieved": round(ach / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "1e9 wavefront instructions/s",
+            "frac": round(ach / peak, 4), "wave_instructions_per_image": round(n),
+            "source": f"{src} (rocprofv3 --pmc SQ_INSTS_VALU over the extract stage alone; not re-measured in this run); the peak is at "
+                      "the 2.4 GHz top clock - under these kernels the part runs nearer 1.7 - 2.0 GHz (SQ_BUSY_CYCLES in the same file)"}
+
+
 def device_rooflines(ctx, capi, steps, images_per_step, t_extract_per_step, shape, overlap, link_work, edges, staged=None):
     """The `roofline` object: the extract launch sequence against HBM, with the match (VALU) and relax (MFMA) entries."""
     def prof(kid):
@@ -279,6 +323,12 @@ def device_rooflines(ctx, capi, steps, images_per_step, t_extract_per_step, shap
         "hip_event_ms_per_sequence_overlapped": round(avg_ms_akaze, 3),
         "algorithmic_bytes_per_launch": round(alg_bytes_img * imgs_per_launch),
         "algorithmic_bytes_per_image": round(alg_bytes_img),
+        "algorithmic_bytes_note": "the CURRENT pass structure (round 5: a level's Lsmooth, conductivity, derivatives and first FED "
+                                  "group are one launch, the grey image is never written); with the pass structure of rounds 2 - 4 "
+                                  "the same launch sequence would be charged %.3f GB per image and `frac` would read %.3f"
+                                  % (extract_algorithmic_bytes(w, h, True) / 1e9,
+                                     extract_algorithmic_bytes(w, h, True) * images_per_step / t_extract_per_step / 8e12),
+        "valu_issue": valu_issue(images_per_step, t_extract_per_step),
         "staged": staged,
         # match: the 2-NN runs on the matrix cores (hamming_2nn_mfma_kernel: popcount(a ^ b) = |a| + |b| - 2 a.b with the bits
         # as FP4 0 / 1, v_mfma_scale_f32_32x32x64_f8f6f4, 8 instructions per 32 x 32 tile of distances): 2 x 512 flop per
@@ -953,6 +1003,8 @@ def weak_main(args, proc, cfg):
         ach2 = extract_algorithmic_bytes(w, h) * grid.n_images / t2["extract"] / 1e9
         roofline["staged"] = {"what": "one untimed step with the stages one after the other (extraction alone on the device)",
                               "achieved": round(ach2, 1), "frac": round(ach2 / 8000.0, 4),
+                              "frac_with_the_pass_structure_of_rounds_2_to_4": round(extract_algorithmic_bytes(w, h, True) * grid.n_images / t2["extract"] / 8e12, 4),
+                              "valu_issue": valu_issue(grid.n_images, t2["extract"]),
                               "avg_launch_ms": round(t2["extract"] * 1e3 / max(n2, 1), 3),
                               "hip_event_ms_per_sequence_overlapped": round(ms2 / max(n2, 1), 3),
                               "stage_seconds": {k: round(float(v), 4) for k, v in t2.items()}}
