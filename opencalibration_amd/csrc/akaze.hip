@@ -1588,6 +1588,10 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
     }
 }
 
+// Measured and dropped: the diffusion pipeline of level_strip_kernel on its own for the FED groups a level kernel leaves (K <= 8
+// steps per launch instead of nld_fused_kernel's 4: 31 -> 19 launches per chunk).  Those groups belong to the upper octaves,
+// whose launches have too few strips to fill the SIMDs: 19.1 us per image against the tile kernel's 11.0.
+
 struct levels_dev
 {
     int n;
@@ -3153,7 +3157,14 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     // the register-strip kernels load pairs of pixels with 8 / 16-byte loads: even widths and plane offsets (every level
     // of an image whose working width is a multiple of 8; the tile kernels take the rest, and OCHIP_TEST_HOOKS=tile_det
     // / tile_levels all of it)
+    // Which form pays depends on how many strips a launch has: a strip is one wavefront walking 40 - 90 rows, and a level of
+    // 400 x 300 pixels x 100 images is 2 400 of them on 1 024 SIMDs (level kernel: 150 us per launch against the tile kernels'
+    // 75; 200 x 150: 150 against 30) - the strips take the levels of >= STRIP_MIN_PIXELS pixels per launch (the first two
+    // octaves of a chunk of the bench), the tiles the rest; OCHIP_TEST_HOOKS=strip_levels / strip_det: strips wherever they can
     static const bool strip_hook = !ochip_test_hook("tile_det"), level_hook = !ochip_test_hook("tile_levels");
+    static const bool force_level_strips = ochip_test_hook("strip_levels"), force_det_strips = ochip_test_hook("strip_det");
+    constexpr size_t STRIP_MIN_PIXELS = (size_t)32 << 20;
+    auto strips_pay = [&](const level_info &l, bool forced) { return forced || (size_t)l.w * l.h * B >= STRIP_MIN_PIXELS; };
     bool det_strips = strip_hook && (img_stride & 1) == 0 && (plane0 & 1) == 0 && ((uintptr_t)d_Lxy & 15) == 0 && ((uintptr_t)d_Lt & 15) == 0 &&
                       ((uintptr_t)d_flow & 15) == 0 && ((uintptr_t)d_ping & 15) == 0;
     for (int i = 0; i < LV.n; i++)
@@ -3193,7 +3204,16 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         float *cur = d_Lt + l.off;
         const size_t np = (size_t)l.w * l.h;
         const size_t n_steps = tsteps[i].size();
-        const size_t n_groups = (n_steps + FED_FUSE - 1) / FED_FUSE; // launches: up to FED_FUSE steps fused in each
+        // the level's FED steps in balanced groups of <= FED_FUSE, a launch each; the first group of a strip level (2 .. 4 steps)
+        // rides in the level's launch
+        const size_t tile_groups = (n_steps + FED_FUSE - 1) / FED_FUSE;
+        const size_t first_size = tile_groups ? n_steps / tile_groups + (n_steps % tile_groups ? 1 : 0) : 0;
+        const bool strip_level = level_strips && strips_pay(l, force_level_strips) && l.sigma_size >= 2 && l.sigma_size <= 4 && l.w >= 64 &&
+                                 l.h >= 64 && (tile_groups == 0 || (first_size >= 2 && first_size <= 4));
+        std::vector<size_t> group_sizes;
+        for (size_t g = 0; g < tile_groups; g++)
+            group_sizes.push_back(n_steps / tile_groups + (g < n_steps % tile_groups ? 1 : 0));
+        const size_t n_groups = group_sizes.size();
         // the level starts from the previous level's image (half-sampled at a new octave); the FED steps ping-pong
         // between the level plane and a scratch plane, arranged so that the last step lands in the level plane
         const float *src = d_Lt + p.off;
@@ -3208,11 +3228,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             src_stride = dst_stride;
             octave_steps++;
         }
-        // balanced groups of <= FED_FUSE steps
-        auto group_size = [&](size_t g) { return n_steps / n_groups + (g < n_steps % n_groups ? 1 : 0); };
-        size_t first_group = 0; // launches of nld_fused_kernel start at this group
-        const bool strip_level = level_strips && l.sigma_size >= 2 && l.sigma_size <= 4 && l.w >= 64 && l.h >= 64 &&
-                                 (n_groups == 0 || (group_size(0) >= 2 && group_size(0) <= 4));
+        auto group_size = [&](size_t g) { return group_sizes[g]; };
+        size_t first_group = 0; // launches of the diffusion kernels start at this group
         if (strip_level)
         {
             // ONE launch: Lsmooth -> conductivity + (Lx, Ly), and the level's first group of diffusion steps behind them (the
@@ -3369,13 +3386,14 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 const int strips = ((l.w + ow - 1) / ow) * ((l.h + sh - 1) / sh);
                 return dim3(8 * (((strips + 3) / 4 + 7) / 8), 1, B);
             };
-            if (det_strips && l.sigma_size == 2)
+            const bool det_strip = det_strips && strips_pay(l, force_det_strips);
+            if (det_strip && l.sigma_size == 2)
                 hipLaunchKernelGGL((det_strip_kernel<2>), strip_grid(det_strip_geom<2>::OW, det_strip_geom<2>::H), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, win, d_mask + l.mask_off, mask_stride);
-            else if (det_strips && l.sigma_size == 3)
+            else if (det_strip && l.sigma_size == 3)
                 hipLaunchKernelGGL((det_strip_kernel<3>), strip_grid(det_strip_geom<3>::OW, det_strip_geom<3>::H), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, win, d_mask + l.mask_off, mask_stride);
-            else if (det_strips)
+            else if (det_strip)
                 hipLaunchKernelGGL((det_strip_kernel<4>), strip_grid(det_strip_geom<4>::OW, det_strip_geom<4>::H), dim3(256), 0, st, lxy, img_stride, ld, rm, l.w,
                                    l.h, dthreshold, d_tile_counts, l.tile_off, n_tiles, win, d_mask + l.mask_off, mask_stride);
             else if (l.sigma_size == 2)

@@ -5,8 +5,9 @@
 //                      popcount_match (no matrix-core matcher), chol_verify (factor every system both ways and compare),
 //                      back_solve_x_global (step vector in HBM even when it fits LDS), no_dissect (one band, no regions),
 //                      jacobian_fp32 (profiles/r04_jacobian_precision_sweep_c5.json),
-//                      tile_levels, tile_det (the LDS-tile kernels of the scale space / the determinant instead of round 5's register
-//                      strips), sort_per_level (a launch per introsort level instead of a workgroup per segment)
+//                      tile_levels, tile_det / strip_levels, strip_det (the LDS-tile kernels of the scale space / the determinant
+//                      for every level / round 5's register strips for every level they can take, instead of the choice by
+//                      level size), sort_per_level (a launch per introsort level instead of a workgroup per segment)
 #pragma once
 
 #include <cstdlib>

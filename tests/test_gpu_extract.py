@@ -154,15 +154,19 @@ def test_strip_kernels_on_noisy_views_up_to_the_border(ctx, oracle, w, h):
     assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32)) and np.array_equal(gdesc, edesc)
 
 
-def test_tile_kernels_still_agree():
-    """OCHIP_TEST_HOOKS=tile_levels,tile_det sends the extraction through the tile kernels of rounds 2 - 4 (blur_fused / nld_fused /
-    det_maxima: the route of images whose level widths are odd).  The switches are read once per process: this file's parity
-    tests run again in a child."""
+@pytest.mark.parametrize("hooks", ["tile_levels,tile_det", "strip_levels,strip_det"])
+def test_tile_and_strip_kernels_agree(hooks):
+    """The scale space and the detector have two forms: the register-strip kernels of round 5 (level_strip_kernel,
+    det_strip_kernel) for launches with enough strips to fill the device (>= 32 Mpixel per level and launch: the first two
+    octaves of a 100-image chunk), and the tile kernels of rounds 2 - 4 (blur_fused / nld_fused / det_maxima) for the rest
+    and for levels of odd width.  A single test image takes the tiles everywhere; OCHIP_TEST_HOOKS=strip_levels,strip_det
+    sends every level the strips can take through them, tile_levels,tile_det every level through the tiles.  The switches
+    are read once per process: this file's parity tests run again in a child per route."""
     import os
     import subprocess
     import sys
 
-    env = dict(os.environ, OCHIP_TEST_HOOKS="tile_levels,tile_det")
+    env = dict(os.environ, OCHIP_TEST_HOOKS=hooks)
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
                         "restatement_bitwise or grey_and_area or host_tail or tied_responses or noisy_views"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
