@@ -1943,7 +1943,7 @@ struct gather_tab
     // column i (q = its place in the restatement's i-outer, j-inner order); 0xFFFFFFFF beyond the 109 samples
     unsigned int ori[128];
     float ori_g[128]; // its Gaussian weight
-    // lattice points in image order for 32 orientation classes: (a + 10) | (bb + 10) << 8 | byte offset of the point's
+    // lattice points in image order for 32 orientation classes: 4 (a + 10) | 4 (bb + 10) << 8 | byte offset of the point's
     // record in the LDS image << 16; 0xFFFFFFFF = no point
     unsigned int lat[32][448];
     // M-LDB comparison list: bit -> byte offsets of its two cell means in the LDS array of means, a | b << 16 (entries
@@ -1953,6 +1953,13 @@ struct gather_tab
     unsigned int chain[64];
 };
 
+// Round 5: a seventh of the vector instructions went (the lattice's coordinates from a 2 x 21-entry table in LDS instead of
+// sixteen instructions per point; the upper ten window bits of three samples per v_readlane) and the kernel's time did not
+// move (63.9 -> 64.3 us per image): with every lane of a gather its own cache-line lookup - 441 x 2 + 109 per keypoint, one
+// per cycle and CU - the L1's tag pipe is what the kernel waits for, 40 us per image of lookups at the measured clock before
+// any miss.  One lookup per point would need (Lx, Ly, Lt) interleaved in one plane: +8 .. 16 bytes per pixel for the
+// HBM-bound level and determinant kernels, which costs what it saves.  The leaner issue stays (it leaves slots to the
+// other launch sequences' kernels).
 // One 64-thread wavefront per surviving candidate (four consecutive ones per workgroup, wave-level barriers only):
 // sub-pixel position, dominant orientation, 486-bit M-LDB.
 constexpr int DESC_WPB = 4; // keypoints (wavefronts) per workgroup (8: 66.6 us per image against 63.3 - sharing a CU among more list neighbours does not raise the L1 hit rate)
@@ -1968,6 +1975,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
 {
     __shared__ float vals_all[DESC_WPB][30][3]; // cell sums, then cell means; row 29 takes the store of a chain that has no cell left
     __shared__ float smp_all[DESC_WPB][441 * 3 + 1];
+    __shared__ float lat_all[DESC_WPB][2][32]; // ((k - 10) cos) s and ((k - 10) sin) s, k = 0 .. 20: the lattice's coordinates
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float(&vals)[30][3] = vals_all[wv];
     float *const smp = smp_all[wv];
@@ -2034,8 +2042,14 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
     {
         // lane q keeps the masks of samples q and q + 64; the window loop reads them with v_readlane (the lane number is
         // a constant of the unrolled loop), so a sample is: mask -> EXEC, one packed add of its LDS-broadcast (x, y)
+        // (the windows are lanes 0 .. 41: the upper words hold ten bits - three samples' worth go into one register, and a
+        // v_readlane fetches them for three samples; the fields come apart on the scalar unit)
         const unsigned long long mq0 = omask[lane], mq1 = lane + 64 < 109 ? omask[lane + 64] : 0ull;
-        const unsigned int mq0lo = (unsigned int)mq0, mq0hi = (unsigned int)(mq0 >> 32), mq1lo = (unsigned int)mq1, mq1hi = (unsigned int)(mq1 >> 32);
+        const unsigned int mq0lo = (unsigned int)mq0, mq1lo = (unsigned int)mq1;
+        const unsigned int *const omask_hi = reinterpret_cast<const unsigned int *>(omask) + 1;
+        unsigned int hi3 = 0;
+        if (lane < 37)
+            hi3 = omask_hi[6 * lane] | (omask_hi[6 * lane + 2] << 10) | ((3 * lane + 2 < 109 ? omask_hi[6 * lane + 4] : 0u) << 20);
         pkf2 sum = {0.0f, 0.0f}; // (sumX, sumY) of the lane's window
         // (the add is written out: as an `if` the compiler branches around every add and reads the sample inside the
         // branch, one exposed LDS latency per sample; the samples are read 16 at a time ahead of their adds.  All 64 lanes
@@ -2057,7 +2071,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
                 {
                     const int q = q0 + k;
                     const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(q < 64 ? mq0lo : mq1lo), q & 63);
-                    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(q < 64 ? mq0hi : mq1hi), q & 63);
+                    const unsigned int hi = ((unsigned int)__builtin_amdgcn_readlane((int)hi3, q / 3) >> (10 * (q % 3))) & 0x3FFu;
                     const unsigned long long in_window = ((unsigned long long)hi << 32) | lo;
                     asm volatile("s_mov_b64 exec, %2\n\tv_pk_add_f32 %0, %0, %1\n\ts_mov_b64 exec, -1"
                                  : "+v"(sum)
@@ -2100,7 +2114,24 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
 #pragma unroll
         for (int t = 0; t < 7; t++)
             pe[t] = order[lane + 64 * t];
+        // a lattice point (a, bb) sits at yf + (bb cos s + a sin s), xf + (-bb sin s + a cos s), products left to right: the four
+        // products take 21 values each per keypoint ((-bb sin) s = -((bb sin) s)) - formed once here by 21 lanes, read by
+        // every point from LDS at the byte offsets the table carries, instead of 16 vector instructions per point
+        if (lane < 21)
+        {
+            const float fk = (float)(lane - 10);
+            lat_all[wv][0][lane] = fk * co * fs;
+            lat_all[wv][1][lane] = fk * si * fs;
+        }
         wave_sync(); // the orientation's LDS has been read by every lane
+        const char *const lat_b = reinterpret_cast<const char *>(&lat_all[wv][0][0]);
+        auto lattice_at = [&](unsigned int e, float *sy, float *sx) {
+            const unsigned int oa = e & 0x7Cu, ob = (e >> 8) & 0x7Cu; // 4 (a + 10), 4 (bb + 10)
+            const float ca = *reinterpret_cast<const float *>(lat_b + oa), sa = *reinterpret_cast<const float *>(lat_b + 128 + oa);
+            const float cb = *reinterpret_cast<const float *>(lat_b + ob), sb = *reinterpret_cast<const float *>(lat_b + 128 + ob);
+            *sy = yf + (cb + sa);
+            *sx = xf + (-sb + ca);
+        };
         const float reach = 14.2f * fs + 2.0f;
         const bool patch_inside = xf - reach >= 0.0f && yf - reach >= 0.0f && xf + reach <= (float)(w - 1) && yf + reach <= (float)(h - 1);
         float ri[7], rx[7], ry[7];
@@ -2110,9 +2141,8 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
 #pragma unroll
             for (int t = 0; t < 7; t++)
             {
-                const float fa = (float)(pe[t] & 255u) - 10.0f, fb = (float)((pe[t] >> 8) & 255u) - 10.0f;
-                const float sy = yf + (fb * co * fs + fa * si * fs);
-                const float sx = xf + (-fb * si * fs + fa * co * fs);
+                float sy, sx;
+                lattice_at(pe[t], &sy, &sx);
                 const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
                 // 32-bit byte offsets from a wave-uniform base (a level plane is far below 2^29 pixels): the loads take
                 // the base from SGPRs and the offset from one VGPR, no 64-bit address arithmetic per lane
@@ -2140,9 +2170,8 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
 #pragma unroll
             for (int t = 0; t < 7; t++)
             {
-                const float fa = (float)(pe[t] & 255u) - 10.0f, fb = (float)((pe[t] >> 8) & 255u) - 10.0f;
-                const float sy = yf + (fb * co * fs + fa * si * fs);
-                const float sx = xf + (-fb * si * fs + fa * co * fs);
+                float sy, sx;
+                lattice_at(pe[t], &sy, &sx);
                 const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
                 inside[t] = pe[t] != 0xFFFFFFFFu && !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h);
                 const unsigned int o = inside[t] ? (unsigned int)(y1 * w + x1) : 0u;
@@ -2823,7 +2852,7 @@ const gather_tab &host_gather_tab()
                     P.push_back({std::lround(3.0 * (bb * co + a * si)), -bb * si + a * co, a, bb});
             std::sort(P.begin(), P.end(), [](const lp &u, const lp &v) { return u.row != v.row ? u.row < v.row : u.x < v.x; });
             for (int k = 0; k < 448; k++)
-                T.lat[c][k] = k < (int)P.size() ? (unsigned int)(P[k].a + 10) | ((unsigned int)(P[k].bb + 10) << 8) |
+                T.lat[c][k] = k < (int)P.size() ? (unsigned int)(4 * (P[k].a + 10)) | ((unsigned int)(4 * (P[k].bb + 10)) << 8) |
                                                       ((unsigned int)(((P[k].a + 10) * 21 + (P[k].bb + 10)) * 12) << 16)
                                                 : 0xFFFFFFFFu;
         }
@@ -3462,11 +3491,13 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         // (capping the workgroups a CU holds with unused dynamic LDS, to leave wave slots to the other sequences' HBM-bound
         // kernels beside this L2-bound one, was measured: 3 120 images/s with none, 3 100 / 2 940 / 2 830 at 4 / 3 / 2 per CU)
         if (max_live > 0)
+        {
             hipLaunchKernelGGL(describe3_kernel, dim3(512 * (((max_live + DESC_WPB - 1) / DESC_WPB + 511) / 512), 1, B), dim3(64 * DESC_WPB), 0, st,
                                (const cand_t *)d_cands, (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live,
                                (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, dfactor,
                                (const gather_tab *)d_gtab, (const orient_tab *)d_otab, d_kp, d_desc, d_valid, xcd_remap, d_vmask,
                                mask_stride);
+        }
     }
     if (max_n > 0)
     {

@@ -72,6 +72,28 @@ __device__ __forceinline__ void wave_first_maximum(double &bv, uint32_t &bi, uin
 }
 
 constexpr int W = 64;
+// -DOCHIP_RANSAC_PHASES: shader-clock cycles per phase of ransac_homography_kernel, summed over the wavefronts of a launch and
+// printed by the host after it (how the kernel's time divides; not part of the product build)
+#ifdef OCHIP_RANSAC_PHASES
+__device__ unsigned long long g_phase[16];
+#define OCHIP_PHASE_T0(t) const unsigned long long t = clock64()
+#define OCHIP_PHASE_ADD(t, slot)                                                                                       \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (threadIdx.x == 0)                                                                                          \
+            atomicAdd(&g_phase[slot], clock64() - t);                                                                  \
+    } while (0)
+#define OCHIP_PHASE_COUNT(slot, n)                                                                                     \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (threadIdx.x == 0)                                                                                          \
+            atomicAdd(&g_phase[slot], (unsigned long long)(n));                                                        \
+    } while (0)
+#else
+#define OCHIP_PHASE_T0(t)
+#define OCHIP_PHASE_ADD(t, slot)
+#define OCHIP_PHASE_COUNT(slot, n)
+#endif
 constexpr uint32_t MIN_ITERATIONS = 20, MAX_ITERATIONS = 10000, MAX_INNER_ITERATIONS = 5;
 
 struct rays_view
@@ -402,12 +424,7 @@ __device__ void full_piv_lu_solve9(double *A, uint32_t rows, double *sol /*[9], 
     lu_finish(A, rows, size, st, sol);
 }
 
-// ---- the tall (2n+1) x 9 system of fitInliers, column-major in HBM / L2, rows > 9.
-//      The same factorisation, arranged so that the wave goes over the tall matrix ONCE per elimination step and never
-//      waits for one load at a time: a lane takes RB of its rows per round and requests all their remaining columns
-//      together ((9 - k) * RB loads in flight), applies the column transposition of the step in registers, eliminates,
-//      stores, and looks for the next pivot among the values it just produced.  (Walking the columns with one load per
-//      loop trip, as the 9 x 9 version does, spent ~1 ms per factorisation waiting on memory latency.)
+// ---- the tall (2n+1) x 9 system of fitInliers (rows > 9): the same factorisation
 struct piv_t
 {
     double v;
@@ -428,27 +445,346 @@ __device__ __forceinline__ void piv_reduce(piv_t &b)
     wave_first_maximum(b.v, b.i, b.j);
 }
 
-constexpr int RB = 4; // rows per lane and round
+// ---- Round 5: the factorisation of the tall system WITHOUT the system.  Rounds 2 - 4 kept it column-major in HBM and went
+//      over it once per elimination step: the (2 n + 1) x 9 matrix of a pair (170 KB at 1 180 matches) read and written
+//      once per elimination step, 2.4 factorisations per pair, 2 048 pairs resident - 40 GB per 9 000-pair launch, 59 % of
+//      the kernel's cycles.  A row of the system is a function of its correspondence's four coordinates, and what the
+//      eliminations do to a row depends on nothing but the row and the pivot rows so far (which ARE the U part of the
+//      factored leading block, 81 doubles in LDS).  So step k regenerates every row from its coordinates, applies the k
+//      eliminations so far - the float operations of the stored form in its order, column for column - and looks for the
+//      next pivot among the results; nothing is written.  36 eliminations per row instead of 9, 33 bytes read per
+//      correspondence and step instead of ~1 600 per factorisation step.
+//      Bookkeeping.  Positions: a row that never took part in a row transposition stands where it started (2 rank + a/b);
+//      the rows that did - the nine that start in the leading block, every pivot row, the last row (0 .. 0 1), and the sibling
+//      of a pivot row - live in a table of at most 29 entries in LDS with their position, and the sweep over the
+//      correspondences skips them (rank < 5, or one of the <= 9 correspondences a pivot came from).  Columns: sigma maps
+//      position -> original column (a nibble each); the U rows in LDS are kept in the current arrangement, so a regenerated
+//      row is permuted once and every elimination is the stored form's.
+__device__ __forceinline__ uint32_t nib_get(uint64_t p, uint32_t k)
+{
+    return (uint32_t)(p >> (4 * k)) & 15u;
+}
+__device__ __forceinline__ uint64_t nib_set(uint64_t p, uint32_t k, uint32_t v)
+{
+    return (p & ~(15ull << (4 * k))) | ((uint64_t)v << (4 * k));
+}
+typedef double dvec16 __attribute__((ext_vector_type(16))); // (indexed by a wave-uniform value: s_set_gpr_idx, no select chain)
+
+struct tall_tab
+{
+    double xy[32][4];      // x, y, x', y' of the entry's correspondence
+    uint32_t pos[32];      // where the row stands now
+    uint32_t kind[32];     // 0 / 1: first / second row of its correspondence, 2: the last row; | 4: a pivot row (done)
+    uint32_t top[9];       // entry at position 0 .. 8
+    uint32_t piv_match[9]; // correspondence whose two rows entered the table at step t (~0u: none did)
+    uint32_t n;
+};
+typedef __attribute__((address_space(3))) tall_tab lds_tab;
+typedef __attribute__((address_space(3))) double lds_double;
+typedef const __attribute__((address_space(3))) double lds_cdouble;
+typedef const __attribute__((address_space(1))) double glb_cdouble;
+typedef const __attribute__((address_space(1))) uint8_t glb_cbyte;
+struct regen_in // what the factorisation reads of a pair, in global memory
+{
+    glb_cdouble *x1, *y1, *x2, *y2;
+    glb_cbyte *inl;
+    uint32_t M;
+};
+
+// A row of the system has eight values to draw from - write_dlt_rows' {-x, -y, -1, 0, x x', y x', x'} (second row: y' for x') and
+// the last row's 1 - and a map from column to value: 0x654333210 / 0x654210333 / 0x733333333, a nibble per column.
+typedef double dvec8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ dvec8 dlt_values(double x, double y, double xp)
+{
+    dvec8 o;
+    o[0] = -x, o[1] = -y, o[2] = -1.0, o[3] = 0.0, o[4] = x * xp, o[5] = y * xp, o[6] = xp, o[7] = 1.0;
+    return o;
+}
+__device__ __forceinline__ unsigned long long dlt_map(uint32_t kind)
+{
+    return kind == 0 ? 0x654333210ull : (kind == 1 ? 0x654210333ull : 0x733333333ull);
+}
+
+// a row in position order from its values.  `pick` = the value index of every position, a nibble each (wave-uniform: sigma
+// through the row kind's map)
+__device__ __forceinline__ void row_pick(const dvec8 &o, uint32_t pick_lo, uint32_t pick_hi, double (&v)[9])
+{
+#pragma unroll
+    for (int pos = 0; pos < 9; pos++)
+        v[pos] = o[pos < 8 ? (pick_lo >> (4 * pos)) & 7u : pick_hi & 7u];
+}
+// NR rows after K eliminations: v[t] for t < K becomes the row's multiplier of step t (what the stored form leaves in
+// column t), v[K ..] the values the search for pivot K looks at.  The U row of the next step is requested while this
+// step's arithmetic runs and no further ahead (left to itself the compiler asks for all 44 entries first: 88 registers)
+// The multiplier v / p is a true division: what the compiler emits for one is v_div_scale x 2, v_rcp, four fma on the
+// reciprocal, a product, a residual, v_div_fmas, v_div_fixup.  The reciprocal chain depends on p alone - wave-uniform here, one
+// chain per step and trip instead of one per row - and when neither operand is near the ends of the exponent range
+// v_div_scale passes both through, v_div_fmas is an fma and v_div_fixup sets the sign of the operands on the magnitude
+// (also for a zero numerator): the FAST form below.  |v| <= |p| (full pivoting), so "near the ends" is: p outside
+// [2^-100, 2^100] or not finite, or 0 < |v| < 2^-900; any lane that sees one reports it and the trip's rows are done
+// again with the plain division.
+__device__ __forceinline__ double refined_reciprocal(double p)
+{
+    const double r0 = __builtin_amdgcn_rcp(p);
+    const double e0 = __builtin_fma(-p, r0, 1.0);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-p, r1, 1.0);
+    return __builtin_fma(r1, e1, r1);
+}
+__device__ __forceinline__ double divide_in_range(double v, double p, double r2)
+{
+    const double q0 = v * r2;
+    const double e2 = __builtin_fma(-p, q0, v);
+    const double q1 = __builtin_fma(e2, r2, q0);
+    const unsigned long long qb = (unsigned long long)__double_as_longlong(q1);
+    const uint32_t sign = ((uint32_t)((unsigned long long)__double_as_longlong(v) >> 32) ^ (uint32_t)((unsigned long long)__double_as_longlong(p) >> 32)) & 0x80000000u;
+    const uint32_t hi = ((uint32_t)(qb >> 32) & 0x7FFFFFFFu) | sign;
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (qb & 0xFFFFFFFFull)));
+}
+template <int K, int NR, bool FAST>
+__device__ __forceinline__ bool rows_eliminate(lds_cdouble *T9, double (&v)[NR][9])
+{
+    bool out_of_range = false;
+    if (K == 0)
+        return out_of_range;
+    double u[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++)
+        u[j] = T9[j * 9];
+#pragma unroll
+    for (int t = 0; t < K; t++)
+    {
+        double nu[9];
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            nu[j] = (t + 1 < K && j > t) ? T9[j * 9 + t + 1] : 0.0;
+        asm volatile("" ::: "memory");
+        const double p = u[t];
+        double r2 = 0.0;
+        if (FAST)
+        {
+            r2 = refined_reciprocal(p);
+            out_of_range |= !((fabs(p) >= 0x1p-100) & (fabs(p) <= 0x1p100));
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+        {
+            if (FAST)
+                out_of_range |= (fabs(v[r][t]) < 0x1p-900) & (v[r][t] != 0.0);
+            const double l = FAST ? divide_in_range(v[r][t], p, r2) : v[r][t] / p;
+            v[r][t] = l;
+#pragma unroll
+            for (int j = t + 1; j < 9; j++)
+                v[r][j] = v[r][j] - l * u[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            u[j] = nu[j];
+    }
+    return out_of_range;
+}
+// sigma (position -> column) through a kind's map (column -> value): position -> value
+__device__ __forceinline__ void compose_pick(uint32_t kind, uint32_t sig_lo, uint32_t sig_hi, uint32_t *pick_lo, uint32_t *pick_hi)
+{
+    const unsigned long long m = dlt_map(kind);
+    uint32_t lo = 0;
+#pragma unroll
+    for (int pos = 0; pos < 8; pos++)
+        lo |= (uint32_t)((m >> (4 * ((sig_lo >> (4 * pos)) & 15u))) & 15ull) << (4 * pos);
+    *pick_lo = lo;
+    *pick_hi = (uint32_t)((m >> (4 * (sig_hi & 15u))) & 15ull);
+}
+
+// the row's first maximum among positions K .. 8 (columns ascend, strict '>': the earliest column of the largest value;
+// NaN never wins), offered to the lane's running first maximum
+template <int K>
+__device__ __forceinline__ bool row_offer(const double (&v)[9], uint32_t pos, piv_t &pv)
+{
+    double bv = -1.0;
+    uint32_t bj = K;
+#pragma unroll
+    for (int j = K; j < 9; j++)
+    {
+        const double a = fabs(v[j]);
+        if (a > bv)
+        {
+            bv = a;
+            bj = j;
+        }
+    }
+    const bool better = bv >= 0 && (bv > pv.v || (bv == pv.v && (bj < pv.j || (bj == pv.j && pos < pv.i))));
+    if (better)
+    {
+        pv.v = bv;
+        pv.i = pos;
+        pv.j = bj;
+    }
+    return better;
+}
+
+// writes row `q` of the factored leading block: multipliers and remaining values of the table entry / correspondence row
+template <int K>
+__device__ __forceinline__ void leading_row(lds_double *T9, int q, uint32_t kind, double x, double y, double x_, double y_, uint32_t sig_lo,
+                                            uint32_t sig_hi)
+{
+    double v[1][9];
+    uint32_t pick_lo, pick_hi; // (kind and sigma are wave-uniform here)
+    compose_pick((uint32_t)__builtin_amdgcn_readfirstlane((int)kind), sig_lo, sig_hi, &pick_lo, &pick_hi);
+    row_pick(dlt_values(x, y, kind == 0 ? x_ : y_), pick_lo, pick_hi, v[0]);
+    asm volatile("" ::: "memory");
+    rows_eliminate<K, 1, false>(T9, v);
+    if (threadIdx.x == 0)
+    {
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            T9[j * 9 + q] = v[0][j];
+    }
+}
 
 template <int K>
-__device__ __forceinline__ bool tall_lu_step(double *__restrict__ A, uint32_t rows, uint32_t ld, piv_t &pv, lu_state &st)
+__device__ __forceinline__ bool regen_lu_step(const regen_in &pd, uint32_t rows, lds_double *T9, lds_tab &tab, lu_state &st, uint32_t &sig_lo,
+                                              uint32_t &sig_hi)
 {
     const int lane = threadIdx.x;
-    __syncthreads(); // the stores of the previous step have landed
+    const uint32_t M = pd.M;
+    __syncthreads(); // the table and the leading block of the previous step have landed
+    sig_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)sig_lo); // (wave-uniform by construction; the register indices want it in SGPRs)
+    sig_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)sig_hi);
+    piv_t pv{-1.0, (uint32_t)K, (uint32_t)K};
+    uint32_t cand = 0; // where the lane's best row came from: correspondence slot << 1 | a/b, or 0x80000000 | table entry
+    uint32_t touched[K > 0 ? K : 1];
+#pragma unroll
+    for (int t = 0; t < K; t++)
+        touched[t] = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab.piv_match[t]);
+    uint32_t pick_lo[3], pick_hi[3]; // position -> value index, per kind of row
+#pragma unroll
+    for (uint32_t kind = 0; kind < 3; kind++)
+        compose_pick(kind, sig_lo, sig_hi, &pick_lo[kind], &pick_hi[kind]);
+    // ---- the rows that never moved: a sweep over the correspondences, both rows of an inlier
+    {
+        // Two correspondences per lane and trip: four rows whose eliminations the scheduler interleaves (a row's steps are one
+        // dependent chain of fp64 operations, and with two wavefronts on a SIMD there is little else to issue meanwhile).
+        // The next trip's flags stay raw bytes until that trip (turned into predicates here they are waited for here, a
+        // memory round trip per trip), and the loads take a clamped index instead of a branch around them (after a join
+        // the compiler waits for every load).
+        constexpr int SL = 2;
+        uint32_t before = 0;
+        uint32_t nflag[SL];
+        double nx1[SL], ny1[SL], nx2[SL], ny2[SL];
+#pragma unroll
+        for (int q = 0; q < SL; q++)
+        {
+            const uint32_t c = min((uint32_t)(q * W + lane), M - 1);
+            nflag[q] = pd.inl[c];
+            nx1[q] = pd.x1[c], ny1[q] = pd.y1[c], nx2[q] = pd.x2[c], ny2[q] = pd.y2[c];
+        }
+        for (uint32_t base = 0; base < M; base += SL * W)
+        {
+            // (the U rows come from LDS in every trip: kept in registers across the loop they are up to 88 of them)
+            asm volatile("" ::: "memory");
+            bool take[SL];
+            uint32_t rank[SL];
+            double x1[SL], y1[SL], x2[SL], y2[SL];
+#pragma unroll
+            for (int q = 0; q < SL; q++)
+            {
+                const uint32_t i = base + q * W + lane;
+                const bool f = i < M && nflag[q] != 0;
+                x1[q] = nx1[q], y1[q] = ny1[q], x2[q] = nx2[q], y2[q] = ny2[q];
+                const uint32_t nc = min(i + SL * W, M - 1);
+                nflag[q] = pd.inl[nc];
+                nx1[q] = pd.x1[nc], ny1[q] = pd.y1[nc], nx2[q] = pd.x2[nc], ny2[q] = pd.y2[nc];
+                const unsigned long long mask = __ballot(f);
+                rank[q] = before + __popcll(mask & ((1ull << lane) - 1ull));
+                before += __popcll(mask);
+                take[q] = f && rank[q] >= 5;
+#pragma unroll
+                for (int t = 0; t < K; t++)
+                    take[q] = take[q] && i != touched[t];
+            }
+            if (take[0] || take[1])
+            {
+                double v[2 * SL][9];
+                auto rows = [&]() {
+#pragma unroll
+                    for (int q = 0; q < SL; q++)
+                    {
+                        row_pick(dlt_values(x1[q], y1[q], x2[q]), pick_lo[0], pick_hi[0], v[2 * q]);
+                        row_pick(dlt_values(x1[q], y1[q], y2[q]), pick_lo[1], pick_hi[1], v[2 * q + 1]);
+                    }
+                };
+                rows();
+                if (__ballot(rows_eliminate<K, 2 * SL, true>(T9, v)) != 0)
+                {
+#ifdef OCHIP_RANSAC_PHASES
+                    if ((int)threadIdx.x == __builtin_ctzll(__ballot(true)))
+                        atomicAdd(&g_phase[12], 1ull);
+#endif
+                    rows();
+                    rows_eliminate<K, 2 * SL, false>(T9, v);
+                }
+#pragma unroll
+                for (int q = 0; q < SL; q++)
+                    if (take[q])
+                    {
+                        if (row_offer<K>(v[2 * q], 2 * rank[q], pv))
+                            cand = (base / W + q) << 1;
+                        if (row_offer<K>(v[2 * q + 1], 2 * rank[q] + 1, pv))
+                            cand = (base / W + q) << 1 | 1u;
+                    }
+            }
+        }
+    }
+    // ---- the rows of the table that are not pivots yet, one per lane
+    double v_kk = 0.0; // (of the lane whose entry stands at position K: the value at (K, K))
+    {
+        // (the kind differs from lane to lane and the value picks are wave-uniform: a turn per kind, its lanes only)
+        const bool mine = (uint32_t)lane < tab.n && !(tab.kind[lane] & 4u);
+        const uint32_t kind = mine ? tab.kind[lane] : 3u;
+        const double ex = mine ? tab.xy[lane][0] : 0.0, ey = mine ? tab.xy[lane][1] : 0.0;
+        const double exp_ = mine ? (kind == 0 ? tab.xy[lane][2] : tab.xy[lane][3]) : 0.0;
+        const uint32_t epos = mine ? tab.pos[lane] : 0u;
+#pragma unroll
+        for (uint32_t kd = 0; kd < 3; kd++)
+            if (kind == kd)
+            {
+                double v[1][9];
+                row_pick(dlt_values(ex, ey, exp_), pick_lo[kd], pick_hi[kd], v[0]);
+                asm volatile("" ::: "memory");
+                rows_eliminate<K, 1, false>(T9, v);
+                v_kk = v[0][K];
+                if (row_offer<K>(v[0], epos, pv))
+                    cand = 0x80000000u | (uint32_t)lane;
+            }
+    }
+    const double lv = pv.v;
+    const uint32_t li = pv.i, lj = pv.j;
+    piv_reduce(pv);
     double bv = pv.v;
-    uint32_t bi = pv.i, bj = pv.j;
-    const double akk = A[(size_t)K * ld + K];
+    uint32_t bi = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.i), bj = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.j);
+    const uint32_t at_k = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab.top[K]);
+    const double akk = bcast(v_kk, (int)at_k);
+    uint32_t who; // the pivot row: cand of the lane that found it, or the entry at position K
     if (akk != akk) // a NaN in the first scanned cell sticks (nothing compares greater than NaN)
     {
         bv = akk;
         bi = K;
         bj = K;
+        who = 0x80000000u | at_k;
     }
     else if (bv < 0) // every candidate was NaN: keep (k,k)
     {
         bv = fabs(akk);
         bi = K;
         bj = K;
+        who = 0x80000000u | at_k;
+    }
+    else
+    {
+        const unsigned long long won = __ballot(lv == bv && li == bi && lj == bj);
+        who = (uint32_t)__builtin_amdgcn_readlane((int)cand, __builtin_ctzll(won));
+        if (!(who & 0x80000000u))
+            who |= (uint32_t)__builtin_ctzll(won) << 24; // (a correspondence row: slot < 2^22, its lane beside it)
     }
     if (bv == 0.0)
         return false;
@@ -456,114 +792,119 @@ __device__ __forceinline__ bool tall_lu_step(double *__restrict__ A, uint32_t ro
         st.maxpivot = bv;
     st.rowT[K] = bi;
     st.colT[K] = bj;
-    // row swap k <-> bi over all nine columns
-    if (K != bi && lane < 9)
+    // ---- the pivot row: identity, then its multipliers and values into row K of the leading block (after the column
+    //      transposition K <-> bj, which the rows above take too)
+    uint32_t kind, entry = ~0u, match = ~0u;
+    double x, y, x_, y_;
+    if (who & 0x80000000u)
     {
-        const double t = A[(size_t)lane * ld + K];
-        A[(size_t)lane * ld + K] = A[(size_t)lane * ld + bi];
-        A[(size_t)lane * ld + bi] = t;
+        entry = who & 31u;
+        kind = tab.kind[entry] & 3u;
+        x = tab.xy[entry][0], y = tab.xy[entry][1], x_ = tab.xy[entry][2], y_ = tab.xy[entry][3];
+    }
+    else
+    {
+        match = ((who & 0x00FFFFFFu) >> 1) * W + (who >> 24);
+        kind = who & 1u;
+        x = pd.x1[match], y = pd.y1[match], x_ = pd.x2[match], y_ = pd.y2[match];
+    }
+    __syncthreads(); // every lane has read the U rows in the old arrangement
+    if (bj != (uint32_t)K && lane < K)
+    {
+        const double t = T9[K * 9 + lane];
+        T9[K * 9 + lane] = T9[bj * 9 + lane];
+        T9[bj * 9 + lane] = t;
     }
     __syncthreads();
-    // column swap k <-> bj: rows 0..k here, the rows below inside the elimination pass
-    if (K != bj && lane <= K)
+    if (bj != (uint32_t)K) // sigma: positions K and bj trade columns
     {
-        const double t = A[(size_t)K * ld + lane];
-        A[(size_t)K * ld + lane] = A[(size_t)bj * ld + lane];
-        A[(size_t)bj * ld + lane] = t;
+        unsigned long long sg = ((unsigned long long)sig_hi << 32) | sig_lo;
+        const uint32_t a = nib_get(sg, K), b = nib_get(sg, bj);
+        sg = nib_set(nib_set(sg, K, b), bj, a);
+        sig_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sg);
+        sig_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sg >> 32));
     }
-    __syncthreads();
-    const double p = A[(size_t)K * ld + K];
-    double rowk[9];
-#pragma unroll
-    for (int j = K + 1; j < 9; j++)
-        rowk[j] = A[(size_t)j * ld + K];
-    piv_t nb{-1.0, (uint32_t)K + 1, (uint32_t)K + 1};
-    for (uint32_t base = K + 1; base < rows; base += W * RB)
+    leading_row<K>(T9, K, kind, x, y, x_, y_, sig_lo, sig_hi); // (regenerated in the new arrangement: its value at position K is the pivot)
+    // ---- the table: the pivot row goes to position K, the row that stood there to where the pivot row came from
+    if (lane == 0)
     {
-        double v[RB][9];
-#pragma unroll
-        for (int u = 0; u < RB; u++)
+        uint32_t e = entry;
+        if (e == ~0u)
         {
-            const uint32_t i = base + lane + W * u;
-#pragma unroll
-            for (int j = K; j < 9; j++)
-                v[u][j] = i < rows ? A[(size_t)j * ld + i] : 0.0;
+            e = tab.n;
+            tab.xy[e][0] = x, tab.xy[e][1] = y, tab.xy[e][2] = x_, tab.xy[e][3] = y_;
+            tab.xy[e + 1][0] = x, tab.xy[e + 1][1] = y, tab.xy[e + 1][2] = x_, tab.xy[e + 1][3] = y_;
+            tab.kind[e + 1] = kind ^ 1u; // the sibling row stays where it is, but the sweep now skips its correspondence
+            tab.pos[e + 1] = bi ^ 1u;
+            tab.n = e + 2;
         }
-#pragma unroll
-        for (int u = 0; u < RB; u++)
+        tab.piv_match[K] = match;
+        tab.kind[e] = kind | 4u;
+        tab.pos[e] = K;
+        if (at_k != e)
         {
-            const uint32_t i = base + lane + W * u;
-#pragma unroll
-            for (int j = K + 1; j < 9; j++)
-                if ((uint32_t)j == bj)
-                {
-                    const double t = v[u][K];
-                    v[u][K] = v[u][j];
-                    v[u][j] = t;
-                }
-            // col(k).tail /= pivot; block(k+1,k+1) -= col(k).tail * row(k).tail
-            const double l = v[u][K] / p;
-            v[u][K] = l;
-#pragma unroll
-            for (int j = K + 1; j < 9; j++)
-                v[u][j] = v[u][j] - l * rowk[j];
-            if (i < rows)
-            {
-#pragma unroll
-                for (int j = K; j < 9; j++)
-                    A[(size_t)j * ld + i] = v[u][j];
-#pragma unroll
-                for (int j = K + 1; j < 9; j++)
-                    piv_take(nb, fabs(v[u][j]), i, (uint32_t)j);
-            }
+            tab.pos[at_k] = bi;
+            if (bi < 9)
+                tab.top[bi] = at_k;
         }
-    }
-    if (K < 8)
-    {
-        piv_reduce(nb);
-        pv = nb;
+        tab.top[K] = e;
     }
     return true;
 }
 
-__device__ void tall_lu_solve9(double *__restrict__ A, uint32_t rows, double *T9 /*LDS 81*/, double *sol /*[9], uniform*/)
+// (not inlined: the RANSAC kernels hold two models and a sample stream in registers around it, and with nine unrolled steps
+// inside them the allocator gave up on two wavefronts per SIMD.  The pointers carry their address spaces across the call -
+// generic ones would make every LDS access a flat one.)
+__device__ __attribute__((noinline)) void regen_lu_solve9(regen_in pd, uint32_t n_in, lds_double *T9 /*LDS 81*/, lds_tab *tab_p, double *sol /*[9], uniform*/)
 {
+    lds_tab &tab = *tab_p;
     const int lane = threadIdx.x;
-    const uint32_t ld = rows;
+    const uint32_t M = pd.M, rows = 2 * n_in + 1;
     lu_state st;
     st.nonzero_pivots = 9;
     st.maxpivot = 0;
-    __syncthreads(); // the system's stores have landed
-    piv_t pv{-1.0, 0, 0};
-    for (uint32_t base = 0; base < rows; base += W * RB)
+    __syncthreads();
+    // the table starts with the rows of the first five inliers (rows 0 .. 9: the leading block and the row below it) and the last row
     {
-        double v[RB][9];
-#pragma unroll
-        for (int u = 0; u < RB; u++)
+        uint32_t before = 0;
+        for (uint32_t base = 0; base < M && before < 5; base += W)
         {
-            const uint32_t i = base + lane + W * u;
-#pragma unroll
-            for (int j = 0; j < 9; j++)
-                v[u][j] = i < rows ? A[(size_t)j * ld + i] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < RB; u++)
-        {
-            const uint32_t i = base + lane + W * u;
-            if (i < rows)
+            const uint32_t i = base + lane;
+            const bool f = i < M && pd.inl[i];
+            const unsigned long long mask = __ballot(f);
+            const uint32_t rank = before + __popcll(mask & ((1ull << lane) - 1ull));
+            before += __popcll(mask);
+            if (f && rank < 5)
             {
-#pragma unroll
-                for (int j = 0; j < 9; j++)
-                    piv_take(pv, fabs(v[u][j]), i, (uint32_t)j);
+                const double x = pd.x1[i], y = pd.y1[i], x_ = pd.x2[i], y_ = pd.y2[i];
+                for (uint32_t ab = 0; ab < 2; ab++)
+                {
+                    const uint32_t e = 2 * rank + ab;
+                    tab.xy[e][0] = x, tab.xy[e][1] = y, tab.xy[e][2] = x_, tab.xy[e][3] = y_;
+                    tab.kind[e] = ab;
+                    tab.pos[e] = e;
+                }
             }
         }
+        if (lane < 9)
+        {
+            tab.top[lane] = lane;
+            tab.piv_match[lane] = ~0u;
+        }
+        if (lane == 0)
+        {
+            tab.xy[10][0] = tab.xy[10][1] = tab.xy[10][2] = tab.xy[10][3] = 0.0;
+            tab.kind[10] = 2;
+            tab.pos[10] = rows - 1;
+            tab.n = 11;
+        }
     }
-    piv_reduce(pv);
-    int stop = 9; // the step at which the remaining block was all zero
+    uint32_t sig_lo = 0x76543210u, sig_hi = 8u;
+    int stop = 9;
     do
     {
 #define OCHIP_LU_STEP(K)                                                                                               \
-    if (!tall_lu_step<K>(A, rows, ld, pv, st))                                                                         \
+    if (!regen_lu_step<K>(pd, rows, T9, tab, st, sig_lo, sig_hi))                                                      \
     {                                                                                                                  \
         stop = K;                                                                                                      \
         break;                                                                                                         \
@@ -581,19 +922,38 @@ __device__ void tall_lu_solve9(double *__restrict__ A, uint32_t rows, double *T9
     } while (false);
     if (stop < 9)
     {
+        // the remaining block is all zero: the rows standing at positions stop .. 8 close the leading block as they are
         st.nonzero_pivots = (uint32_t)stop;
         for (int i = stop; i < 9; i++)
         {
             st.rowT[i] = (uint32_t)i;
             st.colT[i] = (uint32_t)i;
         }
+        __syncthreads();
+        for (int q = stop; q < 9; q++)
+        {
+            const uint32_t e = tab.top[q];
+            const uint32_t kind = tab.kind[e] & 3u;
+            const double x = tab.xy[e][0], y = tab.xy[e][1], x_ = tab.xy[e][2], y_ = tab.xy[e][3];
+            switch (stop)
+            {
+#define OCHIP_LEAD(K)                                                                                                  \
+    case K: leading_row<K>(T9, q, kind, x, y, x_, y_, sig_lo, sig_hi); break;
+                OCHIP_LEAD(0)
+                OCHIP_LEAD(1)
+                OCHIP_LEAD(2)
+                OCHIP_LEAD(3)
+                OCHIP_LEAD(4)
+                OCHIP_LEAD(5)
+                OCHIP_LEAD(6)
+                OCHIP_LEAD(7)
+                OCHIP_LEAD(8)
+#undef OCHIP_LEAD
+            }
+        }
     }
     __syncthreads();
-    // the factored leading 9 x 9 block, once, into LDS for the (uniform, latency-bound) substitution
-    for (int t = lane; t < 81; t += W)
-        T9[t] = A[(size_t)(t / 9) * ld + (t % 9)];
-    __syncthreads();
-    lu_finish(T9, rows, 9, st, sol);
+    lu_finish((const double *)T9, rows, 9, st, sol);
 }
 
 // the two DLT rows of one correspondence (homography_model.cpp:26-35), written column-major
@@ -611,13 +971,24 @@ __device__ __forceinline__ void write_dlt_rows(double *A, uint32_t ld, uint32_t 
 
 // homography_model::fitInliers (homography_model.cpp:52-87) on the flags pd.inl, of which n_in are set: the
 // (2 n_in + 1) x 9 system in index order, its full-pivot LU, H from the solution.
-__device__ __forceinline__ void fit_inliers(const pair_data &pd, uint32_t n_in, double *T9 /*LDS 81*/, model_t &model)
+__device__ __forceinline__ void fit_inliers(const pair_data &pd, uint32_t n_in, double *T9 /*LDS 81*/, tall_tab *tab /*LDS*/, model_t &model)
 {
     const int lane = threadIdx.x;
     const uint32_t M = pd.M;
     double sol[9];
-    // build the (2 n_in + 1) x 9 system in index order (homography_model.cpp:52-79)
     const uint32_t rows = 2 * n_in + 1, ld = rows;
+    if (rows > 9)
+    {
+        regen_in in;
+        in.x1 = (glb_cdouble *)pd.x1, in.y1 = (glb_cdouble *)pd.y1, in.x2 = (glb_cdouble *)pd.x2, in.y2 = (glb_cdouble *)pd.y2;
+        in.inl = (glb_cbyte *)pd.inl;
+        in.M = pd.M;
+        regen_lu_solve9(in, n_in, (lds_double *)T9, (lds_tab *)tab, sol);
+        model_from_solution(model, sol);
+        return;
+    }
+    // fewer than five inliers: the (2 n_in + 1) x 9 system in index order (homography_model.cpp:52-79), at most 9 x 9; the
+    // small factorisation runs it from LDS
     uint32_t before = 0;
     bool nf = (uint32_t)lane < M && pd.inl[lane];
     double nx1 = nf ? pd.x1[lane] : 0.0, ny1 = nf ? pd.y1[lane] : 0.0, nx2 = nf ? pd.x2[lane] : 0.0,
@@ -642,16 +1013,10 @@ __device__ __forceinline__ void fit_inliers(const pair_data &pd, uint32_t n_in, 
     }
     if (lane < 9)
         pd.P[(size_t)lane * ld + rows - 1] = lane == 8 ? 1.0 : 0.0;
-    if (rows > 9)
-        tall_lu_solve9(pd.P, rows, T9, sol);
-    else
-    {
-        // fewer than five inliers: the system is at most 9 x 9; the small factorisation runs it from LDS
-        __syncthreads();
-        for (uint32_t t = lane; t < rows * 9; t += W)
-            T9[(t / rows) * 9 + (t % rows)] = pd.P[t];
-        full_piv_lu_solve9(T9, rows, sol);
-    }
+    __syncthreads();
+    for (uint32_t t = lane; t < rows * 9; t += W)
+        T9[(t / rows) * 9 + (t % rows)] = pd.P[t];
+    full_piv_lu_solve9(T9, rows, sol);
     model_from_solution(model, sol);
 }
 
@@ -688,14 +1053,6 @@ __device__ __forceinline__ void draw_distinct(uint32_t &rng, uint32_t hi, int fi
 // improve are skipped (rng and PROSAC state advanced past them); that iteration itself then runs on the normal path.
 constexpr int FB = 32;
 
-__device__ __forceinline__ uint32_t nib_get(uint64_t p, uint32_t k)
-{
-    return (uint32_t)(p >> (4 * k)) & 15u;
-}
-__device__ __forceinline__ uint64_t nib_set(uint64_t p, uint32_t k, uint32_t v)
-{
-    return (p & ~(15ull << (4 * k))) | ((uint64_t)v << (4 * k));
-}
 
 // homography_model::fit of one lane's sample; element (i, j) of the lane's 9 x 9 system lives at Aq[(j * 9 + i) * FB]
 __device__ void lane_fit(double *Aq /*already offset by the lane*/, const double *px, const double *py, const double *qx,
@@ -886,6 +1243,8 @@ __device__ uint32_t fast_forward(const pair_data &pd, const uint32_t *__restrict
 {
     const int lane = threadIdx.x;
     const uint32_t M = pd.M;
+    OCHIP_PHASE_COUNT(8, 1);
+    OCHIP_PHASE_T0(t_fit);
     // ---- replay the sample stream of the next n iterations (ransac.cpp:100-154); lane L keeps iteration it + L
     uint32_t rng_s = rng, prosac_s = prosac_n;
     uint32_t my_rng = 0, my_prosac = 0, my_c[4] = {0, 0, 0, 0};
@@ -940,6 +1299,8 @@ __device__ uint32_t fast_forward(const pair_data &pd, const uint32_t *__restrict
         if (live)
             lane_fit(AQs + lane, px, py, qx, qy, m);
     }
+    OCHIP_PHASE_ADD(t_fit, 1);
+    OCHIP_PHASE_T0(t_walk);
     // ---- SPRT-pruned MSAC walk in evaluation order, one model per lane of the lower half-wave; the upper half-wave
     //      evaluates the odd positions for the same 32 models (the error is the expensive part, the running sum takes
     //      the two terms in order)
@@ -995,6 +1356,7 @@ __device__ uint32_t fast_forward(const pair_data &pd, const uint32_t *__restrict
             }
         }
     }
+    OCHIP_PHASE_ADD(t_walk, 2);
     const unsigned long long improving = __ballot(lane < 32 && live && !rej && s > best_score);
     if (improving == 0)
     {
@@ -1010,16 +1372,17 @@ __device__ uint32_t fast_forward(const pair_data &pd, const uint32_t *__restrict
     return (uint32_t)first;
 }
 
-template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_kernel(
+template <int OCC> __global__ __launch_bounds__(W, OCC) __attribute__((amdgpu_num_vgpr(248))) void ransac_homography_kernel(
     const ochip_ransac_job *__restrict__ jobs, const ochip_ransac_match *__restrict__ matches,
     const uint32_t *__restrict__ sorted_idx_all, const uint32_t *__restrict__ eval_order_all, rays_view rv,
     double *__restrict__ coord_scratch /*8 x total*/, uint8_t *__restrict__ flag_scratch /*2 x total*/,
-    double *__restrict__ P_scratch /*9 x (2 total + n_jobs)*/, uint64_t total, double thr,
-    ochip_ransac_result *__restrict__ results, uint8_t *__restrict__ inliers_out)
+    double *__restrict__ P_scratch /*81 x n_jobs*/, uint64_t total, double thr,
+    ochip_ransac_result *__restrict__ results, uint8_t *__restrict__ inliers_out, const uint32_t *__restrict__ launch_order)
 {
     __shared__ double P9[81], T9[81], AQs[81 * FB];
+    static_assert(sizeof(tall_tab) <= sizeof(double) * 81 * FB, "the factorisation's table borrows the lane fits' LDS");
     const int lane = threadIdx.x;
-    const uint32_t job_id = blockIdx.x;
+    const uint32_t job_id = launch_order[blockIdx.x]; // (the pairs with the most matches first: see the launch)
     const ochip_ransac_job job = jobs[job_id];
     const uint32_t M = job.n;
     const uint64_t mo = job.match_offset;
@@ -1045,6 +1408,7 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
     // ---- prologue: gather the unit rays of the matched keypoints, divide by z once (error() and fit()
     //      both start from measurement / measurement.z), detect has_quality (ransac.cpp:74-82); the same
     //      coordinates once more in evaluation order for the SPRT walks
+    OCHIP_PHASE_T0(t_total);
     const uint32_t *sorted_idx = sorted_idx_all + mo;
     const uint32_t *eval_order = eval_order_all + job.eval_offset;
     pair_data pd;
@@ -1074,6 +1438,7 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
     }
     const bool has_quality = __ballot(hq_lane) != 0;
     __syncthreads();
+    OCHIP_PHASE_ADD(t_total, 0);
     pd.x1 = cx1;
     pd.y1 = cy1;
     pd.x2 = cx2;
@@ -1086,12 +1451,23 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
     // inliers); the final evaluation writes the caller's array
     pd.cand = flag_scratch + mo;
     pd.inl = flag_scratch + total + mo;
-    pd.P = P_scratch + 9 * (2 * mo + job_id);
+    pd.P = P_scratch + 81 * (size_t)job_id;
     pd.M = M;
 
-    model_t model, best_model;
+    // (the best model lives in LDS: it is written on an improvement and read once at the end, and 36 registers held across
+    // the factorisations of the local optimisation were the difference between two wavefronts per SIMD and one)
+    __shared__ double best_model_lds[18];
+    auto keep_best = [&](const model_t &m) {
+        __syncthreads();
+        if (lane < 9)
+        {
+            best_model_lds[lane] = m.H[lane];
+            best_model_lds[9 + lane] = m.Hi[lane];
+        }
+    };
+    model_t model;
     set_nan(model);
-    set_nan(best_model);
+    keep_best(model);
     double best_score = 0;
     uint32_t rng = job.rng_state;
     uint32_t prosac_n = has_quality ? 4u : M;
@@ -1116,6 +1492,7 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
         if (has_quality && prosac_n < M && it > 0 && it % 10 == 0)
             prosac_n++;
 
+        OCHIP_PHASE_T0(t_sample);
         // ---- minimal sample (ransac.cpp:104-154)
         uint32_t s4[4];
         if (has_quality && prosac_n < M && prosac_n > 4)
@@ -1165,18 +1542,22 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
         double sol[9];
         full_piv_lu_solve9(P9, 9, sol);
         model_from_solution(model, sol);
+        OCHIP_PHASE_ADD(t_sample, 3);
 
         // ---- SPRT-pruned MSAC scoring in shuffled order (ransac.cpp:177-205)
         bool rejected;
         uint32_t n_inl = 0;
+        OCHIP_PHASE_T0(t_score);
         const double score = score_model<true>(model, pd, eval_order, pd.cand, thr, best_score, &rejected, &n_inl);
+        OCHIP_PHASE_ADD(t_score, 4);
+        OCHIP_PHASE_COUNT(9, 1);
         if (rejected)
             continue;
 
         if (score > best_score)
         {
             res.improvements++;
-            best_model = model;
+            keep_best(model);
             best_score = score;
             __syncthreads();
             {
@@ -1189,16 +1570,21 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
             // local optimisation: fitInliers + evaluate, up to MAX_INNER_ITERATIONS (ransac.cpp:224-245)
             for (uint32_t j = 0; j < MAX_INNER_ITERATIONS; j++)
             {
-                fit_inliers(pd, n_in, T9, model);
+                OCHIP_PHASE_T0(t_fi);
+                fit_inliers(pd, n_in, T9, reinterpret_cast<tall_tab *>(AQs), model); // (the lane fits' LDS is idle here)
+                OCHIP_PHASE_ADD(t_fi, 5);
+                OCHIP_PHASE_COUNT(10, 1);
                 bool dummy;
                 uint32_t cnt = 0;
                 __syncthreads();
+                OCHIP_PHASE_T0(t_sf);
                 const double inlier_score = score_model<false>(model, pd, nullptr, pd.inl, thr, 0.0, &dummy, &cnt);
                 __syncthreads();
+                OCHIP_PHASE_ADD(t_sf, 6);
                 n_in = cnt;
                 if (inlier_score > best_score)
                 {
-                    best_model = model;
+                    keep_best(model);
                     best_score = inlier_score;
                 }
                 else
@@ -1229,26 +1615,45 @@ template <int OCC> __global__ __launch_bounds__(W, OCC) void ransac_homography_k
     bool dummy;
     uint32_t cnt = 0;
     __syncthreads();
-    const double final_score = score_model<false>(best_model, pd, nullptr, inliers_out + mo, thr, 0.0, &dummy, &cnt);
     for (int i = 0; i < 9; i++)
-        res.H[i] = best_model.H[i];
+    {
+        model.H[i] = best_model_lds[i];
+        model.Hi[i] = best_model_lds[9 + i];
+    }
+    const double final_score = score_model<false>(model, pd, nullptr, inliers_out + mo, thr, 0.0, &dummy, &cnt);
+    for (int i = 0; i < 9; i++)
+        res.H[i] = model.H[i];
     res.score = final_score / (double)M;
     res.iterations = it;
     res.n_inliers = cnt;
     if (lane == 0)
         results[job_id] = res;
+    OCHIP_PHASE_ADD(t_total, 7);
+    OCHIP_PHASE_COUNT(11, res.improvements);
+#ifdef OCHIP_RANSAC_PHASES
+    if (threadIdx.x == 0)
+    {
+        const unsigned long long mine = clock64() - t_total;
+        atomicMax(&g_phase[13], mine);
+        if (mine > 20000000ull)
+            atomicAdd(&g_phase[14], 1ull);
+        if (mine > 10000000ull)
+            atomicAdd(&g_phase[15], 1ull);
+    }
+#endif
 }
 
 // ---- re-fit of an edge's homography on its previous inliers after the camera models changed
 //      (RelaxGroup::finalize, src/relax/relax_group.cpp:137-177): rays from the current models, then `rounds` times
 //      fitInliers + evaluate starting from the previous inlier set.  One wavefront per edge, the RANSAC kernel's
 //      device functions.
-__global__ __launch_bounds__(W, 2) void refit_homography_kernel(
+__global__ __launch_bounds__(W, 2) __attribute__((amdgpu_num_vgpr(248))) void refit_homography_kernel(
     const ochip_ransac_job *__restrict__ jobs, const ochip_ransac_match *__restrict__ matches, rays_view rv,
-    double *__restrict__ coord_scratch /*4 x total*/, double *__restrict__ P_scratch /*9 x (2 total + n_jobs)*/, uint64_t total,
+    double *__restrict__ coord_scratch /*4 x total*/, double *__restrict__ P_scratch /*81 x n_jobs*/, uint64_t total,
     double thr, uint32_t rounds, ochip_ransac_result *__restrict__ results, uint8_t *__restrict__ inliers /*in: previous, out: new*/)
 {
     __shared__ double T9[81];
+    __shared__ tall_tab tall;
     const int lane = threadIdx.x;
     const uint32_t job_id = blockIdx.x;
     const ochip_ransac_job job = jobs[job_id];
@@ -1284,7 +1689,7 @@ __global__ __launch_bounds__(W, 2) void refit_homography_kernel(
     pd.ex1 = pd.ey1 = pd.ex2 = pd.ey2 = nullptr;
     pd.cand = nullptr;
     pd.inl = inliers + mo;
-    pd.P = P_scratch + 9 * (2 * mo + job_id);
+    pd.P = P_scratch + 81 * (size_t)job_id;
     pd.M = M;
     model_t model;
     set_nan(model);
@@ -1292,7 +1697,7 @@ __global__ __launch_bounds__(W, 2) void refit_homography_kernel(
     uint32_t cnt = n_in;
     for (uint32_t r = 0; r < rounds; r++)
     {
-        fit_inliers(pd, cnt, T9, model);
+        fit_inliers(pd, cnt, T9, &tall, model);
         bool dummy;
         __syncthreads();
         score = score_model<false>(model, pd, nullptr, pd.inl, thr, 0.0, &dummy, &cnt);
@@ -1703,9 +2108,10 @@ __device__ uint32_t degensac(const pair_data &pd, emodel_t &model, uint8_t *&inl
         return n_f;
     __syncthreads();
     {
+        __shared__ tall_tab tab;
         pair_data ph = pd;
         ph.inl = f1;
-        fit_inliers(ph, h_count, T9, h);
+        fit_inliers(ph, h_count, T9, &tab, h);
     }
     __syncthreads();
     // off-plane F inliers: their Gram matrix of (x2 x H x1)
@@ -1786,10 +2192,10 @@ struct ochip_epipolar_job_dev
 };
 
 template <int K, bool ESSENTIAL>
-__global__ __launch_bounds__(W, 2) void ransac_epipolar_kernel(
+__global__ __launch_bounds__(W, 2) __attribute__((amdgpu_num_vgpr(248))) void ransac_epipolar_kernel(
     const ochip_epipolar_job_dev *__restrict__ jobs, const double *__restrict__ corr6, const uint32_t *__restrict__ sorted_idx_all,
     const uint32_t *__restrict__ eval_order_all, double *__restrict__ coord_scratch /*8 x total*/,
-    uint8_t *__restrict__ flag_scratch /*5 x total*/, double *__restrict__ P_scratch /*9 x (2 total + n_jobs)*/, uint64_t total,
+    uint8_t *__restrict__ flag_scratch /*5 x total*/, double *__restrict__ P_scratch /*81 x n_jobs*/, uint64_t total,
     double thr, ochip_ransac_result *__restrict__ results, uint8_t *__restrict__ inliers_out)
 {
     __shared__ double P9[81], T9[81];
@@ -1841,7 +2247,7 @@ __global__ __launch_bounds__(W, 2) void ransac_epipolar_kernel(
     pd.cand = flag_scratch + mo;
     pd.inl = flag_scratch + total + mo;
     uint8_t *f1 = flag_scratch + 2 * total + mo, *f2 = flag_scratch + 3 * total + mo, *f3 = flag_scratch + 4 * total + mo;
-    pd.P = P_scratch + 9 * (2 * mo + job_id);
+    pd.P = P_scratch + 81 * (size_t)job_id;
     pd.M = M;
 
     emodel_t model, best_model;
@@ -2288,7 +2694,7 @@ int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_
                              (size_t)(eval_total ? eval_total : 1) * 4,
                              (size_t)T * 64,
                              (size_t)T * 2,
-                             (size_t)(2 * T + n_jobs) * 72,
+                             (size_t)n_jobs * 81 * 8,
                              (size_t)n_jobs * sizeof(ochip_ransac_result) + T};
     for (int i = 0; i < 8; i++)
     {
@@ -2361,6 +2767,23 @@ int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_
     rays_view rv{ctx->rays_dev, ctx->img_off_dev};
     ochip_ransac_result *res_dev = (ochip_ransac_result *)ctx->scratch_dev[S_OUT];
     uint8_t *inl_dev = (uint8_t *)ctx->scratch_dev[S_OUT] + (size_t)n_jobs * sizeof(ochip_ransac_result);
+    // A pair is one wavefront from its first sample to its last evaluation, 2 048 of them at a time, and what a pair costs
+    // goes with its matches (every scoring, walk and factorisation is a sweep over them): taken in the caller's order the
+    // launch ended with a few long pairs that had started late - 17.3 ms for 9 000 pairs whose work fills the device for
+    // 9.8.  Longest first.
+    uint32_t *order_dev = nullptr;
+    std::vector<uint32_t> order(n_jobs); // (read by the copy below until the stream wait at the end)
+    {
+        for (uint32_t j = 0; j < n_jobs; j++)
+            order[j] = j;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return jobs[a].n > jobs[b].n; });
+        size_t go = 0;
+        order_dev = (uint32_t *)ochip_pool_get(ctx, (size_t)n_jobs * 4, &go);
+        if (!order_dev)
+            return ochip_fail(ctx, OCHIP_ENOMEM, "device allocation failed (launch order)");
+        allocs.emplace_back(order_dev, go);
+        OCHIP_HIP(ctx, hipMemcpyAsync(order_dev, order.data(), (size_t)n_jobs * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     hipEvent_t e0, e1;
     ochip_prof_begin(ctx, OCHIP_K_RANSAC, &e0, &e1);
     // the wave keeps two models, a sample and the LU rows of a round in VGPRs (uniform fp64 values have no scalar
@@ -2372,14 +2795,26 @@ int ransac_homography_impl(ochip_ctx *ctx, const ochip_ransac_job *jobs, uint32_
                            (const ochip_ransac_match *)ctx->scratch_dev[S_MATCH],
                            (const uint32_t *)ctx->scratch_dev[S_SORTED], (const uint32_t *)ctx->scratch_dev[S_EVAL], rv,
                            (double *)ctx->scratch_dev[S_COORD], (uint8_t *)ctx->scratch_dev[S_FLAGS],
-                           (double *)ctx->scratch_dev[S_P], (uint64_t)T, inlier_threshold, res_dev, inl_dev);
+                           (double *)ctx->scratch_dev[S_P], (uint64_t)T, inlier_threshold, res_dev, inl_dev, (const uint32_t *)order_dev);
     };
-    if (occ == 1)
-        launch(ransac_homography_kernel<1>);
-    else
-        launch(ransac_homography_kernel<2>);
+    static_assert(occ == 2, "the kernel's register cap is written for two wavefronts per SIMD");
+    launch(ransac_homography_kernel<2>);
     ochip_prof_end(ctx, OCHIP_K_RANSAC, e0, e1);
     OCHIP_HIP(ctx, hipGetLastError());
+#ifdef OCHIP_RANSAC_PHASES
+    {
+        unsigned long long ph[16], zero[16] = {};
+        OCHIP_HIP(ctx, ochip_stream_wait(ctx, ctx->stream));
+        OCHIP_HIP(ctx, hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof ph));
+        OCHIP_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof zero));
+        static const char *names[13] = {"prologue", "ff replay + fits", "ff walk", "sample + fit", "score (SPRT)", "fit_inliers", "score (inliers)", "total",
+                                        "ff calls", "scored iterations", "inner iterations", "improvements", "plain-division trips"};
+        std::fprintf(stderr, "ransac phases, %u pairs:", n_jobs);
+        for (int i = 0; i < 13; i++)
+            std::fprintf(stderr, " %s %.3g%s", names[i], i < 8 ? (double)ph[i] / (double)ph[7] : (double)ph[i] / n_jobs, i < 8 ? "" : "/pair");
+        std::fprintf(stderr, "; total %.0f clocks per pair, slowest pair %.0f, pairs over 20 M clocks %llu, over 10 M %llu\n", (double)ph[7] / n_jobs, (double)ph[13], ph[14], ph[15]);
+    }
+#endif
     if (decomp_out)
     {
         size_t gd = 0;
@@ -2502,7 +2937,7 @@ int ochip_refit_homography_batch(ochip_ctx *ctx, const ochip_ransac_job *jobs, u
     // scratch slots as in ochip_ransac_homography_batch: 0 jobs, 1 matches, 4 coordinates, 6 LU workspaces, 7 results + flags
     const int slot[5] = {0, 1, 4, 6, 7};
     const size_t sizes[5] = {(size_t)n_jobs * sizeof(ochip_ransac_job), (size_t)T * sizeof(ochip_ransac_match), (size_t)T * 64,
-                             (size_t)(2 * T + n_jobs) * 72, (size_t)n_jobs * sizeof(ochip_ransac_result) + T};
+                             (size_t)n_jobs * 81 * 8, (size_t)n_jobs * sizeof(ochip_ransac_result) + T};
     for (int i = 0; i < 5; i++)
     {
         int rc = ochip_ensure(ctx, &ctx->scratch_dev[slot[i]], &ctx->scratch_cap[slot[i]], sizes[i]);
@@ -2555,7 +2990,7 @@ int ochip_ransac_epipolar_batch(ochip_ctx *ctx, int model, const ochip_epipolar_
                              (size_t)(eval_total ? eval_total : 1) * 4,
                              (size_t)T * 64,
                              (size_t)T * 5,
-                             (size_t)(2 * T + n_jobs) * 72,
+                             (size_t)n_jobs * 81 * 8,
                              (size_t)n_jobs * sizeof(ochip_ransac_result) + T};
     for (int i = 0; i < 8; i++)
     {
