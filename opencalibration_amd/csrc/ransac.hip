@@ -1301,11 +1301,18 @@ __device__ uint32_t fast_forward(const pair_data &pd, const uint32_t *__restrict
     }
     OCHIP_PHASE_ADD(t_fit, 1);
     OCHIP_PHASE_T0(t_walk);
-    // ---- SPRT-pruned MSAC walk in evaluation order, one model per lane of the lower half-wave; the upper half-wave
-    //      evaluates the odd positions for the same 32 models (the error is the expensive part, the running sum takes
-    //      the two terms in order)
-    static_assert(FB == 32, "the two half-waves share the FB models");
-    const int half = lane >> 5, src = lane & 31;
+    // ---- SPRT-pruned MSAC walk in evaluation order.  The error of a (model, position) is the expensive part (four divisions
+    //      and a square root in fp64), the running sum of a model takes its terms one position after the other.  The n <= 32
+    //      models sit in lanes 0 .. n - 1; the wave's other lanes evaluate the same models at the following positions - P =
+    //      2 .. 4 positions per trip, as many as 64 lanes hold groups of n (19 models, the usual number behind the 20-iteration
+    //      floor: 3 positions, 57 lanes busy; rounds 3 - 4 used two half-waves whatever n was) - and hand term and SPRT
+    //      limit of their position to the model's lane, which adds and tests them in order.
+    static_assert(FB == 32, "two groups of FB models fill the wave");
+    const uint32_t P = n > 21 ? 2u : (n > 16 ? 3u : 4u);
+    const uint32_t CH = ((uint32_t)W / P) * P; // positions per chunk: whole trips
+    const uint32_t slot = ((uint32_t)lane >= n ? 1u : 0u) + ((uint32_t)lane >= 2 * n ? 1u : 0u) + ((uint32_t)lane >= 3 * n ? 1u : 0u);
+    const bool evaluates = (uint32_t)lane < P * n;
+    const int src = evaluates ? lane - (int)(slot * n) : 0;
     model_t mm;
     for (int i = 0; i < 9; i++)
     {
@@ -1317,25 +1324,25 @@ __device__ uint32_t fast_forward(const pair_data &pd, const uint32_t *__restrict
     // (round 5: the walk took its four coordinates of every position straight from memory - the same address in all
     // lanes, one L2 round trip per two positions with the exit test between them, 14 k loads per pair and two thirds of the
     // kernel's cycles in s_waitcnt.  Now a chunk of 64 positions is loaded once, a position per lane, and the walk takes a
-    // position's coordinates from the lane that holds it: one round trip per 64 positions, and most walks end inside the
-    // first chunk.)
-    for (uint32_t base = 0; base < M; base += W)
+    // position's coordinates from the lane that holds it: one round trip per chunk, and most walks of a pair with few
+    // inliers end inside the first.)
+    for (uint32_t base = 0; base < M; base += CH)
     {
         if (__ballot(lane < 32 && live && !rej) == 0)
             break;
         const uint32_t mine = base + (uint32_t)lane;
         const double c_x1 = mine < M ? pd.ex1[mine] : 0.0, c_y1 = mine < M ? pd.ey1[mine] : 0.0;
         const double c_x2 = mine < M ? pd.ex2[mine] : 0.0, c_y2 = mine < M ? pd.ey2[mine] : 0.0;
-        const uint32_t chunk_end = min(base + (uint32_t)W, M);
-        for (uint32_t pos0 = base; pos0 < chunk_end; pos0 += 2)
+        const uint32_t chunk_end = min(base + CH, M);
+        for (uint32_t pos0 = base; pos0 < chunk_end; pos0 += P)
         {
             if (__ballot(lane < 32 && live && !rej) == 0)
                 break;
-            const uint32_t pos = pos0 + (uint32_t)half;
-            const int holder = (int)(pos - base) & (W - 1); // (pos == chunk_end: the upper half-wave's unused odd position)
+            const uint32_t pos = pos0 + (evaluates ? slot : 0u);
+            const int holder = (int)(pos - base); // (< CH + P - 1 <= 64; a position past the chunk's last is past M or unused)
             const double px1 = __shfl(c_x1, holder), py1 = __shfl(c_y1, holder), px2 = __shfl(c_x2, holder), py2 = __shfl(c_y2, holder);
-            double term = 0;
-            if (pos < M)
+            double term = 0, limit = 0;
+            if (evaluates && pos < chunk_end)
             {
                 const double e = transfer_error(mm, px1, py1, px2, py2);
                 if (e < thr)
@@ -1343,17 +1350,21 @@ __device__ uint32_t fast_forward(const pair_data &pd, const uint32_t *__restrict
                     const double ratio = e / thr;
                     term = 1.0 - ratio * ratio;
                 }
+                limit = best_score * (double)(pos + 1) / (double)M * 0.6;
             }
-            const double term_odd = __shfl(term, src + 32);
-            s = s + term; // position pos0 (lower half-wave; the upper half's sums are not used)
-            if (pos0 + 1 > 20 && best_score > 0 && s < best_score * (double)(pos0 + 1) / (double)M * 0.6)
-                rej = true;
-            if (pos0 + 1 < M)
-            {
-                s = s + term_odd; // position pos0 + 1
-                if (pos0 + 2 > 20 && best_score > 0 && s < best_score * (double)(pos0 + 2) / (double)M * 0.6)
-                    rej = true;
-            }
+#pragma unroll
+            for (uint32_t sl = 0; sl < 4; sl++)
+                if (sl < P) // (wave-uniform)
+                {
+                    const int from = (lane + (int)(sl * n)) & (W - 1);
+                    const double t = sl == 0 ? term : __shfl(term, from), lim = sl == 0 ? limit : __shfl(limit, from);
+                    if (pos0 + sl < chunk_end)
+                    {
+                        s = s + t; // position pos0 + sl (lanes 0 .. n - 1; the other lanes' sums are not used)
+                        if (pos0 + sl + 1 > 20 && best_score > 0 && s < lim)
+                            rej = true;
+                    }
+                }
         }
     }
     OCHIP_PHASE_ADD(t_walk, 2);
