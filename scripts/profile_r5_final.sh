@@ -27,7 +27,21 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ovl -- python3 $R/b
 cp $(ls -t $OUT/ovl/*/*_kernel_stats.csv | head -1) $OUT/r05_e2e_kernel_stats.csv; rm -rf $OUT/ovl
 OCHIP_PIPELINE_OVERLAP=0 OCHIP_EXTRACT_STREAMS=1 OCHIP_LINK_RUNNERS=1 OCHIP_BENCH_EXTRAS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/single -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/single.json 2> $OUT/single.err
 cp $(ls -t $OUT/single/*/*_kernel_stats.csv | head -1) $OUT/r05_e2e_single_stream_kernel_stats.csv; rm -rf $OUT/single
+# 5. the RANSAC kernel's counters (one C2 step of the bench, one link runner, no overlap)
+i=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  OCHIP_PIPELINE_OVERLAP=0 OCHIP_EXTRACT_STREAMS=1 OCHIP_LINK_RUNNERS=1 OCHIP_BENCH_EXTRAS=0 timeout 600 rocprofv3 --pmc $grp --kernel-include-regex "ransac_homography" --output-format csv -d $OUT/rpmc/g$i -- python3 $R/bench.py --config C2 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/rpmc_g$i.log 2>&1
+done
+python3 $R/scripts/summarise_pmc.py $OUT/rpmc $OUT/r05_ransac_pmc.json > /dev/null 2>&1
+rm -rf $OUT/rpmc
 tail -30 $OUT/extract_only_trace.txt
+python3 - $OUT/r05_ransac_pmc.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))["kernels"]
+for k, v in d.items():
+    print("==", k[:60], "SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (v.get("SQ_WAIT_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 1), 1)), "HBM read+write bytes", v.get("FETCH_SIZE"), v.get("WRITE_SIZE"))
+PY
 python3 -c "
 import json; d=json.load(open('$OUT/r05_e2e_pmc_hbm.json')); print('HBM bytes per image', d['extract_hbm_bytes_per_image'], d['calibration'])
 d=json.load(open('$OUT/r05_extract_valu.json')); print('VALU wave-instructions per image', d['extract_valu_wave_instructions_per_image'], 'issue us', d['extract_issue_us_per_image_at_2.4GHz'])"
