@@ -77,13 +77,21 @@ def test_one_rank_strong_equals_the_default_line():
     the default line's within run-to-run noise (both modes run the C2 grid here, relax pipelined over surveys)."""
     env = dict(os.environ, OCHIP_HOST_THREADS="8")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None)
-    rates = {}
-    for mode in ("weak", "strong"):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scaling", mode, "--config", "C2", "--steps", "6", "--warmup", "2",
-               "--no-cpu-baseline"]
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-        assert line["n_gpus"] == 1 and line["scaling"] == mode
-        rates[mode] = line["value"]
+    def measure():
+        rates = {}
+        for mode in ("weak", "strong"):
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scaling", mode, "--config", "C2", "--steps", "6", "--warmup", "2",
+                   "--no-cpu-baseline"]
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+            assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+            line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+            assert line["n_gpus"] == 1 and line["scaling"] == mode
+            rates[mode] = line["value"]
+        return rates
+
+    # (six 50 ms steps of a 200-image grid: a busy box moves one of the two runs by more than the tolerance now and then -
+    # the pair is measured once more before the test fails)
+    rates = measure()
+    if abs(rates["strong"] / rates["weak"] - 1.0) >= 0.15:
+        rates = measure()
     assert abs(rates["strong"] / rates["weak"] - 1.0) < 0.15, rates
