@@ -448,14 +448,24 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
         put_tile(0, p, c);
     }
     __syncthreads();
-    for (uint32_t jt = 0; jt < n_tiles; jt++)
-    {
+    // Two tiles in flight in registers: the loads of tile j + 2 are issued at the start of tile j and stored to LDS at the
+    // end of tile j + 1 - two tile times (~4 000 cycles) for a round trip that takes about one of them when every CU asks at
+    // once; with one tile ahead the store at the end of a tile waited for loads issued at its beginning.
+    uint4 nx[2][4];
+    float nc[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            nx[q][i] = make_uint4(0, 0, 0, 0);
+    if (n_tiles > 1)
+        load_tile(1, nx[1], nc[1]);
+    auto tile = [&](uint32_t jt, uint4 (&mine)[4], float &mine_c, uint4 (&ahead)[4], float &ahead_c) {
+        // `mine`: tile jt + 1, requested one tile ago; `ahead`: the registers tile jt's own data came through, free again
         const int cur = (int)(jt & 1);
         const bool more = jt + 1 < n_tiles;
-        uint4 nx[4] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-        float nc = 0.0f;
-        if (more) // the next tile's loads fly under this tile's MFMAs
-            load_tile(jt + 1, nx, nc);
+        if (jt + 2 < n_tiles)
+            load_tile(jt + 2, ahead, ahead_c);
         // Four accumulator tiles at once - the tile's two row blocks x the wave's two query blocks -, so that a matrix
         // instruction's successor on the same accumulator comes three instructions later: with two chains the matrix pipe
         // ran at half its rate (a dependent v_mfma_scale waits for its predecessor's result, ~2 issue slots).
@@ -522,8 +532,14 @@ __global__ __launch_bounds__(256) void hamming_2nn_mfma_kernel(const uint4 *__re
                 }
             }
         if (more)
-            put_tile(cur ^ 1, nx, nc);
+            put_tile(cur ^ 1, mine, mine_c);
         __syncthreads();
+    };
+    for (uint32_t jt = 0; jt < n_tiles; jt += 2)
+    {
+        tile(jt, nx[1], nc[1], nx[0], nc[0]);
+        if (jt + 1 < n_tiles)
+            tile(jt + 1, nx[0], nc[0], nx[1], nc[1]);
     }
     // the two half-waves hold the same queries' other 16 rows per tile
     ochip_match *__restrict__ o = out + out_off[pair];
