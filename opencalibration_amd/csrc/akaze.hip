@@ -1648,49 +1648,65 @@ __global__ __launch_bounds__(256) void scan_tiles_kernel(const unsigned int *__r
 
 // One wavefront per tile: lane r holds the mask word of tile row r, a shuffle prefix sum of the popcounts gives each
 // row its slots, and only the responses of set bits are read.  List order inside a tile: row-major.
+constexpr int COLLECT_TPW = 4; // tiles per wavefront of collect_tiles_kernel
 __global__ __launch_bounds__(256) void collect_tiles_kernel(const float *__restrict__ Rmax, const float2 *__restrict__ Fit,
                                                             size_t img_stride,
                                                             const unsigned long long *__restrict__ mask, size_t mask_stride,
                                                             levels_dev L, const unsigned int *__restrict__ tile_base, int n_tiles,
-                                                            cand_t *__restrict__ cands, unsigned int max_cands)
+                                                            cand_t *__restrict__ cands, unsigned int max_cands,
+                                                            const unsigned int *__restrict__ tile_counts)
 {
-    static_assert(DT_Y <= 64, "one lane per tile row");
+    // (a wavefront takes COLLECT_TPW tiles, two at a time - lanes 0 .. 23 and 24 .. 47 hold the rows of one tile each -: with a
+    // wavefront per tile the launch was 680 k wavefronts of a few instructions per chunk, 4.9 us per image of dispatching)
+    static_assert(2 * DT_Y <= 64, "two tiles' rows per wavefront");
     const unsigned int b = blockIdx.z;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (tile >= n_tiles)
-        return;
-    int level = 0;
-    while (level + 1 < L.n && tile >= L.l[level + 1].tile_off)
-        level++;
-    const level_info l = L.l[level];
-    const int t = tile - l.tile_off;
-    const int ty = t / l.tiles_x, tx = t - ty * l.tiles_x;
-    const float *R = Rmax + (size_t)b * img_stride + l.off;
-    const float2 *F = Fit + (size_t)b * img_stride + l.off;
-    const int y = ty * DT_Y + lane;
-    unsigned long long m = 0;
-    if (lane < DT_Y && y < l.h)
-        m = mask[(size_t)b * mask_stride + (size_t)l.mask_off + (size_t)y * l.tiles_x + tx];
-    const unsigned int cnt = (unsigned int)__popcll(m);
-    unsigned int incl = cnt;
-    for (int off = 1; off < 64; off <<= 1)
+    const int lane = threadIdx.x & 63, half = lane >= DT_Y ? 1 : 0, row = lane - half * DT_Y;
+    const int first = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * COLLECT_TPW;
+    for (int pair = 0; pair < COLLECT_TPW; pair += 2)
     {
-        const unsigned int v = (unsigned int)__shfl_up((int)incl, off);
-        if (lane >= off)
-            incl += v;
-    }
-    unsigned int slot = tile_base[(size_t)b * n_tiles + tile] + incl - cnt;
-    while (m)
-    {
-        const int bit = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int x = tx * BT_X + bit;
-        if (slot < max_cands)
+        if (first + pair >= n_tiles) // (wave-uniform)
+            break;
+        const int tile = first + pair + half;
+        bool live = lane < 2 * DT_Y && tile < n_tiles;
+        // (a tile without maxima - half of them on the coarse levels - is done before its mask rows are asked for)
+        live = live && tile_counts[(size_t)b * n_tiles + tile] != 0;
+        if (__ballot(live) == 0)
+            continue;
+        int level = 0;
+        while (level + 1 < L.n && tile >= L.l[level + 1].tile_off)
+            level++;
+        const level_info l = L.l[level];
+        const int t = tile - l.tile_off;
+        const int ty = t / l.tiles_x, tx = t - ty * l.tiles_x;
+        const float *R = Rmax + (size_t)b * img_stride + l.off;
+        const float2 *F = Fit + (size_t)b * img_stride + l.off;
+        const int y = ty * DT_Y + row;
+        unsigned long long m = 0;
+        if (live && y < l.h)
+            m = mask[(size_t)b * mask_stride + (size_t)l.mask_off + (size_t)y * l.tiles_x + tx];
+        const unsigned int cnt = (unsigned int)__popcll(m);
+        unsigned int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1)
         {
-            const float2 f = F[(size_t)y * l.w + x];
-            cands[(size_t)b * max_cands + slot] = cand_t{level, x, y, R[(size_t)y * l.w + x], f.x, f.y};
+            const unsigned int v = (unsigned int)__shfl_up((int)incl, off);
+            if (lane >= off)
+                incl += v;
         }
-        slot++;
+        // (the second tile's rows start counting after the first tile's last row)
+        const unsigned int first_total = (unsigned int)__builtin_amdgcn_readlane((int)incl, DT_Y - 1);
+        unsigned int slot = (live ? tile_base[(size_t)b * n_tiles + tile] : 0u) + incl - cnt - (half ? first_total : 0u);
+        while (m)
+        {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int x = tx * BT_X + bit;
+            if (slot < max_cands)
+            {
+                const float2 f = F[(size_t)y * l.w + x];
+                cands[(size_t)b * max_cands + slot] = cand_t{level, x, y, R[(size_t)y * l.w + x], f.x, f.y};
+            }
+            slot++;
+        }
     }
 }
 
@@ -3455,10 +3471,10 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     }
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(B), dim3(256), 0, st, (const unsigned int *)d_tile_counts,
                        (const unsigned int *)d_tile_seq, n_tiles, d_tile_base, d_ncand);
-    hipLaunchKernelGGL(collect_tiles_kernel, dim3((n_tiles + 3) / 4, 1, B), dim3(256), 0, st, (const float *)d_Rmax,
+    hipLaunchKernelGGL(collect_tiles_kernel, dim3((n_tiles + 4 * COLLECT_TPW - 1) / (4 * COLLECT_TPW), 1, B), dim3(256), 0, st, (const float *)d_Rmax,
                        (const float2 *)d_Fit, img_stride,
                        (const unsigned long long *)d_mask, mask_stride, LV, (const unsigned int *)d_tile_base, n_tiles, d_cands,
-                       max_cands);
+                       max_cands, (const unsigned int *)d_tile_counts);
     std::vector<unsigned int> ncand(B);
     OCHIP_HIP(ctx, hipMemcpyAsync(ncand.data(), d_ncand, B * 4, hipMemcpyDeviceToHost, st));
     OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
