@@ -430,16 +430,6 @@ struct piv_t
     double v;
     uint32_t i, j;
 };
-__device__ __forceinline__ void piv_take(piv_t &b, double v, uint32_t i, uint32_t j)
-{
-    // the first maximum in column-by-column scan order, whatever order the candidates arrive in
-    if (v > b.v || (v == b.v && (j < b.j || (j == b.j && i < b.i))))
-    {
-        b.v = v;
-        b.i = i;
-        b.j = j;
-    }
-}
 __device__ __forceinline__ void piv_reduce(piv_t &b)
 {
     wave_first_maximum(b.v, b.i, b.j);
@@ -564,13 +554,13 @@ __device__ __forceinline__ bool rows_eliminate(lds_cdouble *T9, double (&v)[NR][
         if (FAST)
         {
             r2 = refined_reciprocal(p);
-            out_of_range |= !((fabs(p) >= 0x1p-100) & (fabs(p) <= 0x1p100));
+            out_of_range |= !((int)(fabs(p) >= 0x1p-100) & (int)(fabs(p) <= 0x1p100)); // (no short circuit: straight-line code)
         }
 #pragma unroll
         for (int r = 0; r < NR; r++)
         {
             if (FAST)
-                out_of_range |= (fabs(v[r][t]) < 0x1p-900) & (v[r][t] != 0.0);
+                out_of_range |= (bool)((int)(fabs(v[r][t]) < 0x1p-900) & (int)(v[r][t] != 0.0));
             const double l = FAST ? divide_in_range(v[r][t], p, r2) : v[r][t] / p;
             v[r][t] = l;
 #pragma unroll
