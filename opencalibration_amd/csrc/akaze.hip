@@ -318,48 +318,7 @@ struct blur_args
     float *out2;               // unused.  DERIV: out0 = the interleaved (Lx, Ly) float2 plane, out_stride in float2;
                                // FLOW_DERIV: out1 = that plane with out2_stride (float2), out0 = conductivity with out_stride
     size_t out2_stride;
-    int frame;                 // > 0: only the tiles within `frame` pixels of the image border (the strip kernel has done the rest; frame_tile)
 };
-
-// the tiles that hold a pixel within `reach` pixels of the image border, one per workgroup: tile row 0 and the last nb tile
-// rows in full, of the rows between them tile column 0 and the last nr tile columns (nb, nr: 1, or 2 when the last tile
-// row / column is thinner than the reach)
-struct frame_dims
-{
-    int nb, nr, count;
-};
-__host__ __device__ inline frame_dims frame_tiles(int w, int h, int reach)
-{
-    const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
-    frame_dims f;
-    const int yb = (h - reach > 0 ? h - reach : 0) / BT_Y, xb = (w - reach > 0 ? w - reach : 0) / BT_X;
-    f.nb = tiles_y - yb < tiles_y - 1 ? tiles_y - yb : tiles_y - 1; // tile rows from the one holding row h - reach down
-    f.nr = tiles_x - xb < tiles_x - 1 ? tiles_x - xb : tiles_x - 1;
-    const int mid = tiles_y - 1 - f.nb > 0 ? tiles_y - 1 - f.nb : 0;
-    f.count = tiles_x * (1 + f.nb) + mid * (1 + f.nr < tiles_x ? 1 + f.nr : tiles_x);
-    return f;
-}
-__device__ __forceinline__ bool frame_tile(int w, int h, int reach, int *tx, int *ty)
-{
-    const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
-    const frame_dims f = frame_tiles(w, h, reach);
-    int t = (int)blockIdx.x;
-    if (t >= f.count)
-        return false;
-    if (t < tiles_x * (1 + f.nb))
-    {
-        const int row = t / tiles_x;
-        *tx = t - row * tiles_x;
-        *ty = row == 0 ? 0 : tiles_y - f.nb + (row - 1);
-        return true;
-    }
-    t -= tiles_x * (1 + f.nb);
-    const int per = 1 + f.nr < tiles_x ? 1 + f.nr : tiles_x;
-    const int row = t / per, c = t - row * per;
-    *ty = 1 + row;
-    *tx = c == 0 ? 0 : tiles_x - f.nr + (c - 1);
-    return true;
-}
 
 template <int MODE, int M /*margin of the blurred tile*/, int R /*tap radius*/>
 __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
@@ -374,7 +333,7 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
     const int w = A.w, h = A.h;
     const int tiles_x = (w + BT_X - 1) / BT_X, tiles_y = (h + BT_Y - 1) / BT_Y;
     int tile_x, tile_y;
-    if (!(A.frame ? frame_tile(w, h, A.frame, &tile_x, &tile_y) : xcd_tile(tiles_x, tiles_y, &tile_x, &tile_y)))
+    if (!xcd_tile(tiles_x, tiles_y, &tile_x, &tile_y))
         return;
     const int x0 = tile_x * BT_X, y0 = tile_y * BT_Y;
     const int bx0 = x0 - M, by0 = y0 - M;
@@ -1088,7 +1047,8 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
 constexpr int DS_PAD = 8;  // columns of padding on either side of a wavefront's row buffers (>= S)
 // output rows of a strip, rounded up to whole ring turns.  The taller, the smaller the share of the rows above and below that
 // only feed the stencils - and the fewer, longer wavefronts a launch has: 120 rows for both kernels measured 257 us per image
-// against 239 with these (the last round of a launch runs half empty, the small levels have too few strips)
+// against 239 with these (the last round of a launch runs half empty, the small levels have too few strips); 48 rows for the
+// determinant alone 22.8 against 22.1
 constexpr int DET_STRIP_ROWS = 32, LEVEL_STRIP_ROWS = 64;
 constexpr int DS_NOTES = 64; // noted maxima a wavefront works off together (det_strip_kernel)
 constexpr int DS_RING = 1; // the ring of requested rows is DS_RING (2 S + 1) long (2: 10 - 16 rows in flight per lane at 2 - 3
