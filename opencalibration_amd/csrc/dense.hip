@@ -35,41 +35,67 @@ struct lane_state
     uint32_t best, second, idx, count;
 };
 
-__device__ __forceinline__ lane_state merge(const lane_state &a, const lane_state &b)
+// The search of one query by one wavefront: every lane ends with the same (best, second, index, count).
+// Round 5.  The counters had a query at 7 us of which 73 % waiting for memory (SQ_WAIT_ANY / SQ_WAVE_CYCLES): a chain of
+// dependent round trips - the query's slot record, its image's record, per cell row the two run bounds, then the row's
+// locations, then the descriptors of the candidates inside the disc.  Now
+//  * a query is PLANNED by one lane - image record, cell, the (up to three) runs' bounds: dense_plan - so that the eight
+//    queries of a wavefront are planned side by side by eight lanes (dense_link_kernel): three round trips per wavefront
+//    instead of per query;
+//  * the runs are walked as one index space with the locations of DS_ROUNDS x 64 candidates in flight;
+//  * the candidates inside the disc - a handful of the ~160 scanned - are handed a lane each through a wavefront-private LDS
+//    list, their distances come back through a second list, and every lane walks the (distance, index) pairs in list order:
+//    ascending index, the reference's sequential rule (:262-276) as it stands, instead of a per-lane state and a six-stage
+//    tie-aware butterfly.
+constexpr int DS_ROUNDS = 4; // rounds of 64 candidates whose locations are requested together
+__device__ __forceinline__ double bcast64(double v, int src)
 {
-    lane_state r;
-    r.count = a.count + b.count;
-    if (a.best < b.best)
-    {
-        r.best = a.best;
-        r.idx = a.idx;
-        r.second = min(a.second, b.best);
-    }
-    else if (b.best < a.best)
-    {
-        r.best = b.best;
-        r.idx = b.idx;
-        r.second = min(b.second, a.best);
-    }
-    else // two candidates tie for the best distance: second best == best, the ratio test fails on the host
-    {
-        r.best = a.best;
-        r.idx = min(a.idx, b.idx);
-        r.second = a.best;
-    }
-    return r;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-
-template <int CTRL> __device__ __forceinline__ lane_state dpp_state(const lane_state &s)
+struct dense_plan_t
 {
-    auto mv = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xf, 0xf, false); };
-    return lane_state{mv(s.best), mv(s.second), mv(s.idx), mv(s.count)};
+    uint64_t feat_base;
+    uint32_t rb[3], rn[3]; // the runs of cell rows cy - 1 .. cy + 1: first candidate, length (a row outside the grid: empty)
+};
+__device__ __forceinline__ dense_plan_t dense_plan(const dense_image_meta &m, const uint32_t *__restrict__ cell_start, double qx, double qy,
+                                                   double cell_size)
+{
+    dense_plan_t P;
+    P.feat_base = m.feat_base;
+    const int cx = (int)floor((qx - m.ox) / cell_size), cy = (int)floor((qy - m.oy) / cell_size);
+    const int c0 = max(cx - 1, 0), c1 = min(cx + 1, m.ncx - 1);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+    {
+        const int ry = cy - 1 + r;
+        const bool row_ok = c0 <= c1 && ry >= 0 && ry < m.ncy;
+        const uint32_t *cs = cell_start + m.cell_base + (size_t)(row_ok ? ry : 0) * m.ncx;
+        const uint32_t begin = row_ok ? cs[c0] : 0u, end = row_ok ? cs[c1 + 1] : 0u;
+        P.rb[r] = begin;
+        P.rn[r] = end - begin;
+    }
+    return P;
 }
-
-// the search of one query by one wavefront: every lane ends with the merged (best, second, index, count)
-__device__ __forceinline__ lane_state dense_search(const dense_image_meta &m, const uint64_t *__restrict__ desc, const double2 *__restrict__ loc,
-                                                   const uint32_t *__restrict__ cell_start, uint32_t src_feature, double qx, double qy,
-                                                   double radius_sq, double cell_size, int lane)
+// the plan of the lane `src`, in every lane
+__device__ __forceinline__ dense_plan_t dense_plan_from(const dense_plan_t &P, int src)
+{
+    auto get = [&](uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); };
+    dense_plan_t Q;
+    Q.feat_base = ((uint64_t)get((uint32_t)(P.feat_base >> 32)) << 32) | get((uint32_t)P.feat_base);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+    {
+        Q.rb[r] = get(P.rb[r]);
+        Q.rn[r] = get(P.rn[r]);
+    }
+    return Q;
+}
+// P, qx, qy, src_feature: wave-uniform
+__device__ __forceinline__ lane_state dense_scan(const dense_plan_t &P, const uint64_t *__restrict__ desc, const double2 *__restrict__ loc,
+                                                 uint32_t src_feature, double qx, double qy, double radius_sq, int lane,
+                                                 uint32_t *inside_list /*LDS, 64 + 128 words per wavefront*/)
 {
     uint64_t qd[8];
     {
@@ -78,57 +104,87 @@ __device__ __forceinline__ lane_state dense_search(const dense_image_meta &m, co
         for (int w = 0; w < 8; w++)
             qd[w] = p[w];
     }
-    const int cx = (int)floor((qx - m.ox) / cell_size), cy = (int)floor((qy - m.oy) / cell_size);
     lane_state s{NONE_COUNT, NONE_COUNT, 0xFFFFFFFFu, 0u};
-    const int c0 = max(cx - 1, 0), c1 = min(cx + 1, m.ncx - 1);
-    if (c0 <= c1)
-        for (int ry = max(cy - 1, 0); ry <= min(cy + 1, m.ncy - 1); ry++)
+    const uint32_t n0 = P.rn[0], n01 = n0 + P.rn[1], total = n01 + P.rn[2];
+    auto candidate = [&](uint32_t f) { return f < n0 ? P.rb[0] + f : (f < n01 ? P.rb[1] + (f - n0) : P.rb[2] + (f - n01)); };
+    auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    unsigned long long *const pairs = reinterpret_cast<unsigned long long *>(inside_list + 64);
+    auto work_off = [&](uint32_t n) {
+        wave_sync();
+        if ((uint32_t)lane < n)
         {
-            const uint32_t *cs = cell_start + m.cell_base + (size_t)ry * m.ncx;
-            const uint32_t begin = cs[c0], end = cs[c1 + 1];
-            for (uint32_t k = begin + lane; k < end; k += 64)
-            {
-                const double2 p = loc[m.feat_base + k];
-                const double dx = p.x - qx, dy = p.y - qy;
-                if (!(dx * dx + dy * dy < radius_sq))
-                    continue;
-                const uint64_t *cd = desc + 8 * (m.feat_base + k);
-                uint32_t d = 0;
+            const uint32_t k = inside_list[lane];
+            const uint64_t *cd = desc + 8 * (P.feat_base + k);
+            uint32_t d = 0;
 #pragma unroll
-                for (int w = 0; w < 8; w++)
-                    d += (uint32_t)__popcll(cd[w] ^ qd[w]);
-                s.count++;
-                if (d < s.second) // the reference's sequential rule (:262-276)
+            for (int w = 0; w < 8; w++)
+                d += (uint32_t)__popcll(cd[w] ^ qd[w]);
+            pairs[lane] = ((unsigned long long)d << 32) | k;
+        }
+        wave_sync();
+        for (uint32_t j = 0; j < n; j++)
+        {
+            const unsigned long long e = pairs[j];
+            const uint32_t d = (uint32_t)(e >> 32), k = (uint32_t)e;
+            if (d < s.second)
+            {
+                if (d < s.best)
                 {
-                    if (d < s.best)
-                    {
-                        s.second = s.best;
-                        s.best = d;
-                        s.idx = k;
-                    }
-                    else
-                        s.second = d;
+                    s.second = s.best;
+                    s.best = d;
+                    s.idx = k;
                 }
+                else
+                    s.second = d;
             }
         }
-    // all-lanes merge: inside the rows of 16 lanes by DPP moves (quad permutes, then rotations by 4 and 8 - merge is
-    // commutative and associative and every lane's state enters once), across the rows by two shuffle stages; six stages of
-    // four LDS-crossbar shuffles each were as long as the search of a sparsely populated disc
-    s = merge(s, dpp_state<0xB1>(s));  // quad_perm [1, 0, 3, 2]
-    s = merge(s, dpp_state<0x4E>(s));  // quad_perm [2, 3, 0, 1]
-    s = merge(s, dpp_state<0x124>(s)); // row_ror:4
-    s = merge(s, dpp_state<0x128>(s)); // row_ror:8
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1)
+        s.count += n;
+        wave_sync(); // (the lists are rewritten by the next candidates)
+    };
+    uint32_t listed = 0; // candidates inside the disc waiting in the list (wave-uniform)
+    for (uint32_t f0 = 0; f0 < total; f0 += 64 * DS_ROUNDS)
     {
-        lane_state o;
-        o.best = __shfl_xor(s.best, off);
-        o.second = __shfl_xor(s.second, off);
-        o.idx = __shfl_xor(s.idx, off);
-        o.count = __shfl_xor(s.count, off);
-        s = merge(s, o);
+        double2 p[DS_ROUNDS];
+        uint32_t k[DS_ROUNDS];
+#pragma unroll
+        for (int u = 0; u < DS_ROUNDS; u++)
+        {
+            const uint32_t f = f0 + 64 * u + lane;
+            k[u] = candidate(f < total ? f : total - 1);
+            p[u] = loc[P.feat_base + k[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < DS_ROUNDS; u++)
+        {
+            const uint32_t f = f0 + 64 * u + lane;
+            const double dx = p[u].x - qx, dy = p[u].y - qy;
+            const bool in = f < total && dx * dx + dy * dy < radius_sq;
+            const unsigned long long mask = __ballot(in);
+            if (mask == 0)
+                continue;
+            const uint32_t n_in = (uint32_t)__popcll(mask);
+            if (listed + n_in > 64) // the list is full: its candidates take their lanes now
+            {
+                work_off(listed);
+                listed = 0;
+            }
+            if (in)
+                inside_list[listed + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = k[u];
+            listed += n_in;
+        }
     }
+    if (listed)
+        work_off(listed);
     return s;
+}
+__device__ __forceinline__ lane_state dense_search(const dense_image_meta &m, const uint64_t *__restrict__ desc, const double2 *__restrict__ loc,
+                                                   const uint32_t *__restrict__ cell_start, uint32_t src_feature, double qx, double qy,
+                                                   double radius_sq, double cell_size, int lane, uint32_t *inside_list)
+{
+    return dense_scan(dense_plan(m, cell_start, qx, qy, cell_size), desc, loc, src_feature, qx, qy, radius_sq, lane, inside_list);
 }
 
 __global__ __launch_bounds__(256) void dense_match_kernel(const dense_image_meta *__restrict__ meta, const uint64_t *__restrict__ desc,
@@ -141,7 +197,9 @@ __global__ __launch_bounds__(256) void dense_match_kernel(const dense_image_meta
         return;
     const int lane = threadIdx.x & 63;
     const ochip_dense_query q = queries[qi];
-    const lane_state s = dense_search(meta[q.cand_image], desc, loc, cell_start, q.src_feature, q.px, q.py, radius_sq, cell_size, lane);
+    __shared__ __attribute__((aligned(8))) uint32_t inside_lists[4][192];
+    const lane_state s = dense_search(meta[q.cand_image], desc, loc, cell_start, q.src_feature, q.px, q.py, radius_sq, cell_size, lane,
+                                      inside_lists[threadIdx.x >> 6]);
     if (lane == 0)
     {
         ochip_dense_result r;
@@ -160,6 +218,7 @@ __global__ __launch_bounds__(256) void dense_match_kernel(const dense_image_meta
 // the reference writes it, and the union of the two measurements (:285-297) in a lock-free union-find whose partition does
 // not depend on the order of the unions (the larger root goes under the smaller).
 constexpr int DENSE_K = 11; // MAX_CANDIDATE_IMAGES + 1 (:53, :213)
+constexpr int DENSE_COUNTERS = 1024; // words per statistics counter (queries, matches): summed by the host
 struct dense_cam
 {
     double pos[3], q_inv[4], model[10]; // f ppx ppy k1 k2 k3 p1 p2 cols rows
@@ -275,19 +334,29 @@ __global__ __launch_bounds__(256) void dense_predict_kernel(const dense_image_me
         wsum[threadIdx.x >> 6] = emitted;
     __syncthreads();
     if (threadIdx.x == 0 && wsum[0] + wsum[1] + wsum[2] + wsum[3])
-        atomicAdd(n_queries, (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
+        atomicAdd(n_queries + ((blockIdx.x + 31 * blockIdx.y) & (DENSE_COUNTERS - 1)), (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
 }
 
+// Lock-free union-find over all measurements of the survey.  Invariant: parent[x] <= x, and a parent pointer only ever moves to
+// a smaller member of the same component - so ANY value parent[x] ever held is an ancestor of x.  The walk towards the root
+// can therefore read through the caches (an XCD's L2 is not coherent with the others': a stale parent is an ancestor, the walk
+// is at worst longer); only the link - root under a smaller node - is a device-scope compare-and-swap, and when it fails it
+// says where the node points now.  Round 5: with every step of the walk a device-scope atomic load and every halving a
+// device-scope CAS, the kernel ran at the rate the memory side executes those (~0.5 G per 130 ms), whatever the search cost.
+__device__ __forceinline__ uint32_t uf_cached_parent(const uint32_t *parent, uint32_t x)
+{
+    return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); // (a plain load the compiler may not hoist)
+}
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x)
 {
     while (true)
     {
-        uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t p = uf_cached_parent(parent, x);
         if (p == x)
             return x;
-        const uint32_t gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t gp = uf_cached_parent(parent, p);
         if (gp != p)
-            atomicCAS(&parent[x], p, gp); // path halving; losing the race is harmless
+            __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); // path halving: an ancestor, whoever wins
         x = p;
     }
 }
@@ -305,8 +374,11 @@ __device__ __forceinline__ void uf_unite(uint32_t *parent, uint32_t a, uint32_t 
             a = b;
             b = t;
         }
-        if (atomicCAS(&parent[a], a, b) == a) // the larger root goes under the smaller: a component's root is its smallest member
+        // the larger (apparent) root goes under the smaller node: a component's root is its smallest member
+        const uint32_t was = atomicCAS(&parent[a], a, b);
+        if (was == a)
             return;
+        a = was; // not a root any more (this XCD's copy was stale): go on from where it points now
     }
 }
 
@@ -320,43 +392,74 @@ __global__ __launch_bounds__(256) void dense_link_kernel(const dense_image_meta 
                                                          uint32_t *__restrict__ parent, uint8_t *__restrict__ matched,
                                                          uint32_t *__restrict__ slot_dst, unsigned long long *__restrict__ n_matches)
 {
+    __shared__ __attribute__((aligned(8))) uint32_t inside_lists[4][192];
     const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    unsigned int accepted = 0;
+    // an accepted match is a union of two measurements: a chain of dependent loads along the parents of both (and a CAS).  Done
+    // by lane 0 slot after slot it was most of the kernel's time; the wave's SLOTS_PER_WAVE matches are kept, one per lane, and
+    // united side by side after the searches (the partition does not depend on the order of the unions)
+    uint32_t my_src_pos = 0xFFFFFFFFu, my_dst_pos = 0xFFFFFFFFu;
+    // lane j plans slot j: candidate image, its record, the predicted pixel's cell, the runs' bounds
+    const uint64_t plan_slot = w * SLOTS_PER_WAVE + (uint64_t)lane;
+    const bool planner = lane < SLOTS_PER_WAVE && plan_slot < n_slots;
+    const uint32_t plan_cand = planner ? cand_img[plan_slot] : 0xFFFFFFFFu;
+    double2 plan_q = make_double2(0.0, 0.0);
+    dense_plan_t plan{};
+    if (plan_cand != 0xFFFFFFFFu)
+    {
+        plan_q = cand_px[plan_slot];
+        plan = dense_plan(meta[plan_cand], cell_start, plan_q.x, plan_q.y, cell_size);
+    }
     for (int j = 0; j < SLOTS_PER_WAVE; j++)
     {
         const uint64_t slot = w * SLOTS_PER_WAVE + j;
         if (slot >= n_slots)
             break;
-        const uint32_t cand = cand_img[slot]; // (wave-uniform)
-        uint32_t dst = 0xFFFFFFFFu;
+        const uint32_t cand = (uint32_t)__builtin_amdgcn_readlane((int)plan_cand, j);
+        uint32_t src_pos = 0xFFFFFFFFu, dst_pos = 0xFFFFFFFFu;
         if (cand != 0xFFFFFFFFu)
         {
             const uint32_t src_feature = (uint32_t)(batch_feat_base + slot / DENSE_K);
-            const double2 q = cand_px[slot];
-            const dense_image_meta m = meta[cand];
-            const lane_state s = dense_search(m, desc, loc, cell_start, src_feature, q.x, q.y, radius_sq, cell_size, lane);
-            if (lane == 0 && s.count != 0)
+            const dense_plan_t P = dense_plan_from(plan, j);
+            const double qx = bcast64(plan_q.x, j), qy = bcast64(plan_q.y, j);
+            const lane_state s = dense_scan(P, desc, loc, src_feature, qx, qy, radius_sq, lane, inside_lists[threadIdx.x >> 6]);
+            // (every lane holds the same state: the decision is wave-uniform)
+            if (s.count != 0)
             {
                 const double best_dist = s.best * inv_bits;
                 const double second_best_dist = s.second == NONE_COUNT ? INFINITY : s.second * inv_bits;
                 const bool good = s.count >= 2 ? best_dist < ratio * second_best_dist : best_dist < max_abs;
                 if (good)
                 {
-                    const uint32_t src_id = id_of_pos[src_feature];
-                    dst = id_of_pos[m.feat_base + s.idx];
-                    matched[src_id] = 1;
-                    matched[dst] = 1;
-                    uf_unite(parent, src_id, dst);
-                    accepted++;
+                    src_pos = src_feature;
+                    dst_pos = (uint32_t)(P.feat_base + s.idx);
                 }
             }
         }
-        if (slot_dst && lane == 0)
-            slot_dst[slot] = dst;
+        if (lane == j)
+        {
+            my_src_pos = src_pos;
+            my_dst_pos = dst_pos;
+        }
     }
+    uint32_t dst = 0xFFFFFFFFu;
+    if (my_dst_pos != 0xFFFFFFFFu)
+    {
+        const uint32_t src_id = id_of_pos[my_src_pos];
+        dst = id_of_pos[my_dst_pos];
+        matched[src_id] = 1;
+        matched[dst] = 1;
+        uf_unite(parent, src_id, dst);
+    }
+    const uint64_t my_slot = w * SLOTS_PER_WAVE + (uint64_t)lane;
+    if (slot_dst && lane < SLOTS_PER_WAVE && my_slot < n_slots)
+        slot_dst[my_slot] = dst;
+    const unsigned int accepted = (unsigned int)__popcll(__ballot(dst != 0xFFFFFFFFu));
+    // (one counter for every wavefront of the launch was 700 k atomic adds to ONE address per launch, which the memory side
+    // takes one after the other: 8.6 ms per launch whatever the searches cost - round 5's counters found the wait, five
+    // rewrites of the search did not move it.  DENSE_COUNTERS words, a workgroup adds to its own.)
     if (lane == 0 && accepted)
-        atomicAdd(n_matches, (unsigned long long)accepted);
+        atomicAdd(n_matches + (blockIdx.x & (DENSE_COUNTERS - 1)), (unsigned long long)accepted);
 }
 
 __global__ void dense_uf_init_kernel(uint32_t *parent, uint8_t *matched, uint64_t n)
@@ -572,14 +675,14 @@ int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t
     uint32_t *cand_img = (uint32_t *)get(max_batch_feats * DENSE_K * 4);
     double2 *cand_px = (double2 *)get(max_batch_feats * DENSE_K * 16);
     uint32_t *slot_dst = slot_dst_out ? (uint32_t *)get(max_batch_feats * DENSE_K * 4) : nullptr;
-    unsigned long long *counters = (unsigned long long *)get(16);
+    unsigned long long *counters = (unsigned long long *)get(2 * DENSE_COUNTERS * 8);
     if (rc != OCHIP_OK)
         return done(rc);
     static_assert(sizeof(dense_cam) == 17 * sizeof(double), "cams17 is the kernel's camera record");
     if (hipMemcpyAsync(cams, cams17, (size_t)n_images * sizeof(dense_cam), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(ids, id_of_pos, total * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(hits, hits3, total * 24, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemsetAsync(counters, 0, 16, st) != hipSuccess)
+        hipMemsetAsync(counters, 0, 2 * DENSE_COUNTERS * 8, st) != hipSuccess)
         return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_link: upload failed"));
     hipLaunchKernelGGL(dense_uf_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, parent, matched, total);
     const double inv_bits = 1.0 / (double)descriptor_bits;
@@ -599,7 +702,7 @@ int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t
         const uint64_t waves = (slots + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE;
         hipLaunchKernelGGL(dense_link_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ix->meta, ix->desc, ix->loc, ix->cell_start,
                            cand_img, cand_px, slots, base, ids, radius * radius, ix->cell_size, inv_bits, ratio, max_abs, parent, matched,
-                           slot_dst, counters + 1);
+                           slot_dst, counters + DENSE_COUNTERS);
         ochip_prof_end(ctx, OCHIP_K_DENSE, e0, e1);
         if (hipGetLastError() != hipSuccess)
             return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_link: launch failed"));
@@ -611,12 +714,17 @@ int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t
         }
     }
     hipLaunchKernelGGL(dense_uf_roots_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, parent, matched, total, root);
-    unsigned long long host_counts[2] = {0, 0};
+    std::vector<unsigned long long> host_counts(2 * DENSE_COUNTERS, 0);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(root_out, root, total * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(host_counts, counters, 16, hipMemcpyDeviceToHost, st) != hipSuccess || ochip_stream_wait(ctx, st) != hipSuccess)
+        hipMemcpyAsync(host_counts.data(), counters, 2 * DENSE_COUNTERS * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        ochip_stream_wait(ctx, st) != hipSuccess)
         return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_link: %s", hipGetErrorString(hipGetLastError())));
-    counts2[0] = host_counts[0];
-    counts2[1] = host_counts[1];
+    counts2[0] = counts2[1] = 0;
+    for (int i = 0; i < DENSE_COUNTERS; i++)
+    {
+        counts2[0] += host_counts[i];
+        counts2[1] += host_counts[DENSE_COUNTERS + i];
+    }
     return done(OCHIP_OK);
 }
 

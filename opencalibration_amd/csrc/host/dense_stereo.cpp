@@ -157,6 +157,9 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     }
     uint64_t *const desc8 = static_cast<uint64_t *>(desc_stage.p);
     double *const loc2 = static_cast<double *>(loc_stage.p);
+    // (every image's bounding box: a pass over the 88-byte records of all dense features - 0.8 GB for a 1 000-image survey -,
+    // one image per task like the sort below)
+#pragma omp parallel for schedule(dynamic, 4)
     for (size_t i = 0; i < n_img; i++)
     {
         const DenseImage &d = images[i];
@@ -371,8 +374,24 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
             const double *pixel;
             const DenseImage *im;
         };
-        std::vector<RayMeasurement> ms;
-        ms.reserve((size_t)(ids_end - ids_begin));
+        // (a track has a handful of members - at most one per candidate image -: no heap allocation for the usual ones;
+        // 650 k tracks made 1.3 M of them)
+        const size_t n_ms = (size_t)(ids_end - ids_begin);
+        RayMeasurement ms_small[16];
+        std::vector<RayMeasurement> ms_large;
+        RayMeasurement *ms_data = ms_small;
+        if (n_ms > 16)
+        {
+            ms_large.resize(n_ms);
+            ms_data = ms_large.data();
+        }
+        struct
+        {
+            RayMeasurement *p;
+            size_t n;
+            size_t size() const { return n; }
+            RayMeasurement &operator[](size_t i) const { return p[i]; }
+        } ms{ms_data, 0};
         for (const uint32_t *ip = ids_begin; ip != ids_end; ip++)
         {
             const size_t id = *ip;
@@ -381,7 +400,7 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
             const double *px = img.features[img.num_sparse_features + (id - im.offset)].location;
             double ray[3];
             image_to_3d(px, *img.model, ray);
-            ms.push_back({rotate(img.orientation, v3{ray[0], ray[1], ray[2]}), v3{img.position[0], img.position[1], img.position[2]}, px, &im});
+            ms.p[ms.n++] = RayMeasurement{rotate(img.orientation, v3{ray[0], ray[1], ray[2]}), v3{img.position[0], img.position[1], img.position[2]}, px, &im};
         }
         v3 point;
         double err;
@@ -389,20 +408,25 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
         auto finite = [](const v3 &p) { return std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z); };
         if (!finite(point) || err < 0)
             continue;
-        std::vector<size_t> inliers;
+        // (only the number of inliers and the first two of them matter)
+        size_t n_inliers = 0, first_two[2] = {0, 0};
         for (size_t i = 0; i < ms.size(); i++)
         {
             double reproj[2];
             project(point, *ms[i].im, reproj);
             const double ex = reproj[0] - ms[i].pixel[0], ey = reproj[1] - ms[i].pixel[1];
             if (ex * ex + ey * ey <= max_err_sq)
-                inliers.push_back(i);
+            {
+                if (n_inliers < 2)
+                    first_two[n_inliers] = i;
+                n_inliers++;
+            }
         }
-        if (inliers.size() < 2)
+        if (n_inliers < 2)
             continue;
-        if (inliers.size() < ms.size())
+        if (n_inliers < ms.size())
         {
-            ray_intersection(ms[inliers[0]].dir, ms[inliers[0]].origin, ms[inliers[1]].dir, ms[inliers[1]].origin, &point, &err);
+            ray_intersection(ms[first_two[0]].dir, ms[first_two[0]].origin, ms[first_two[1]].dir, ms[first_two[1]].origin, &point, &err);
             if (!finite(point) || err < 0)
                 continue;
         }
