@@ -592,6 +592,12 @@ def beside_the_headline(ctx, grid, images, shape, start_ori, step_s, rctx=None):
         gv = ga["vertices"].copy()
         gv[:, 2] = grid.plane[0] * gv[:, 0] + grid.plane[1] * gv[:, 1]
         ground.set(gv, ga["edges"])
+        # (a first call fills the context's page-locked staging pool - 0.9 GB for this survey's index -, like the warm-up steps of
+        # the timed region; the second is the one reported, `first_call_seconds` beside it)
+        warm = host.Surface().set(gv, ga["edges"])
+        t0 = time.perf_counter()
+        gg.densify_mesh(ctx, warm)
+        tds_first = time.perf_counter() - t0
         ctx.profile_reset()
         t0 = time.perf_counter()
         ds = gg.densify_mesh(ctx, ground)
@@ -601,7 +607,7 @@ def beside_the_headline(ctx, grid, images, shape, start_ori, step_s, rctx=None):
         dz = cloud[:, 2] - (grid.plane[0] * cloud[:, 0] + grid.plane[1] * cloud[:, 1])
         extras["dense_guided_matching"] = {
             "images": ds["images"], "dense_features": ds["dense_features"], "queries": ds["queries"], "matches": ds["matches"],
-            "tracks": ds["tracks"], "points": ds["points"], "seconds": round(tds, 4),
+            "tracks": ds["tracks"], "points": ds["points"], "seconds": round(tds, 4), "first_call_seconds": round(tds_first, 4),
             "seconds_by_phase": {"index": round(ds["index_s"], 4), "rays_and_mesh_walk_host": round(ds["rays_s"], 4),
                                  "nearest_cameras_predictions_search_unions_device_incl_pcie": round(ds["device_s"], 4),
                                  "tracks_host": round(ds["tracks_s"], 4)},

@@ -5,6 +5,7 @@
 #include "triangle_walker.hpp"
 
 #include <algorithm>
+#include <omp.h>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -327,22 +328,55 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     // ascending: two counting passes into one flat array (800 k small vectors were a third of this phase)
     std::vector<uint32_t> track_start, track_member;
     {
+        // (four passes over all measurements with scattered accesses: in parallel - the roots' ranks by per-thread counts, the
+        // tracks' sizes and the members' places by atomic increments; a track's members are put in ascending order by the
+        // task that triangulates it)
         std::vector<uint32_t> rank_of_root(total, UINT32_MAX);
-        uint32_t n_tracks = 0;
-        for (size_t i = 0; i < total; i++)
-            if (root[i] == (uint32_t)i) // a root is the smallest member of its track: it comes first
-                rank_of_root[i] = n_tracks++;
+        const int nt = std::max(1, omp_get_max_threads());
+        std::vector<size_t> chunk_roots((size_t)nt + 1, 0);
+        const size_t per = (total + (size_t)nt - 1) / (size_t)nt;
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int t = 0; t < nt; t++)
+        {
+            size_t c = 0;
+            for (size_t i = (size_t)t * per; i < std::min(total, (size_t)(t + 1) * per); i++)
+                c += root[i] == (uint32_t)i;
+            chunk_roots[(size_t)t + 1] = c;
+        }
+        for (int t = 0; t < nt; t++)
+            chunk_roots[(size_t)t + 1] += chunk_roots[(size_t)t];
+        const uint32_t n_tracks = (uint32_t)chunk_roots[(size_t)nt];
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int t = 0; t < nt; t++)
+        {
+            uint32_t r = (uint32_t)chunk_roots[(size_t)t];
+            for (size_t i = (size_t)t * per; i < std::min(total, (size_t)(t + 1) * per); i++)
+                if (root[i] == (uint32_t)i) // a root is the smallest member of its track: it comes first
+                    rank_of_root[i] = r++;
+        }
         track_start.assign((size_t)n_tracks + 1, 0);
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < total; i++)
             if (root[i] != UINT32_MAX) // (UINT32_MAX: is_singleton)
-                track_start[rank_of_root[root[i]] + 1]++;
+            {
+                uint32_t &slot = track_start[rank_of_root[root[i]] + 1];
+#pragma omp atomic
+                slot++;
+            }
         for (size_t t = 0; t < n_tracks; t++)
             track_start[t + 1] += track_start[t];
         track_member.resize(track_start[n_tracks]);
         std::vector<uint32_t> fill(track_start.begin(), track_start.end() - 1);
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < total; i++)
             if (root[i] != UINT32_MAX)
-                track_member[fill[rank_of_root[root[i]]]++] = (uint32_t)i;
+            {
+                uint32_t at;
+                uint32_t &slot = fill[rank_of_root[root[i]]];
+#pragma omp atomic capture
+                at = slot++;
+                track_member[at] = (uint32_t)i;
+            }
     }
     const size_t n_tracks = track_start.size() - 1;
     st.tracks = n_tracks;
@@ -365,9 +399,10 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
 #pragma omp parallel for schedule(dynamic, 64)
     for (size_t ti = 0; ti < n_tracks; ti++)
     {
-        const uint32_t *ids_begin = track_member.data() + track_start[ti], *ids_end = track_member.data() + track_start[ti + 1];
+        uint32_t *ids_begin = track_member.data() + track_start[ti], *ids_end = track_member.data() + track_start[ti + 1];
         if (ids_end - ids_begin < 2)
             continue;
+        std::sort(ids_begin, ids_end); // (members ascending: the parallel grouping left them in arrival order)
         struct RayMeasurement
         {
             v3 dir, origin;
