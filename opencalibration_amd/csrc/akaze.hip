@@ -1824,36 +1824,64 @@ __device__ __forceinline__ void sincos_poly(float a, float *s, float *c)
 
 // The candidates that survived the suppression, in list (tile) order: the descriptor kernel runs over these only, so that
 // the four wavefronts of one of its workgroups are four live spatial neighbours.  One workgroup per image, ballot prefix.
-__global__ __launch_bounds__(256) void live_list_kernel(const unsigned char *__restrict__ dead, const unsigned int *__restrict__ n_cands,
-                                                        unsigned int max_cands, unsigned int *__restrict__ live,
-                                                        unsigned int *__restrict__ n_live)
+// (these one-workgroup-per-image scans: 1 024 threads, eight items per thread and trip, one barrier per trip - the wavefronts'
+// sums alternate between two LDS rows and every thread keeps the running total itself.  With 256 threads, one item per
+// thread and three barriers per trip live_list_kernel took 105 trips for an image's 27 k candidates: 2.0 us per image)
+constexpr int SCAN_THREADS = 1024, SCAN_WAVES = SCAN_THREADS / 64, SCAN_PER = 8;
+// exclusive prefix of `total` over the workgroup's threads (+ what `carry` holds), `carry` advanced by the workgroup's sum
+__device__ __forceinline__ unsigned int scan_workgroup(unsigned int total, unsigned int (&wsum)[2][SCAN_WAVES], int trip, unsigned int &carry)
 {
-    __shared__ unsigned int wsum[4], base;
-    const unsigned int b = blockIdx.x, n = min(n_cands[b], max_cands);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0)
-        base = 0;
-    __syncthreads();
-    for (unsigned int start = 0; start < n; start += 256)
+    unsigned int incl = total; // inclusive scan of the threads' totals inside the wavefront
+    for (int off = 1; off < 64; off <<= 1)
     {
-        const unsigned int k = start + threadIdx.x;
-        const bool v = k < n && dead[(size_t)b * max_cands + k] == 0;
-        const unsigned long long mask = __ballot(v);
-        if (lane == 0)
-            wsum[wv] = (unsigned int)__popcll(mask);
-        __syncthreads();
-        unsigned int pos = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
-        for (int j = 0; j < wv; j++)
-            pos += wsum[j];
-        if (v)
-            live[(size_t)b * max_cands + pos] = k;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
+        const unsigned int t = (unsigned int)__shfl_up((int)incl, off);
+        if (lane >= off)
+            incl += t;
+    }
+    if (lane == 63)
+        wsum[trip & 1][wv] = incl;
+    __syncthreads();
+    unsigned int before = 0, all = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_WAVES; j++)
+    {
+        const unsigned int v = wsum[trip & 1][j];
+        before += j < wv ? v : 0u;
+        all += v;
+    }
+    const unsigned int excl = carry + before + incl - total;
+    carry += all;
+    return excl;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void live_list_kernel(const unsigned char *__restrict__ dead, const unsigned int *__restrict__ n_cands,
+                                                                 unsigned int max_cands, unsigned int *__restrict__ live,
+                                                                 unsigned int *__restrict__ n_live)
+{
+    __shared__ unsigned int wsum[2][SCAN_WAVES];
+    const unsigned int b = blockIdx.x, n = min(n_cands[b], max_cands);
+    unsigned int carry = 0;
+    int trip = 0;
+    for (unsigned int start = 0; start < n; start += SCAN_THREADS * SCAN_PER, trip++)
+    {
+        const unsigned int first = start + threadIdx.x * SCAN_PER;
+        unsigned int alive = 0, total = 0; // bit i: candidate first + i survives
+#pragma unroll
+        for (int i = 0; i < SCAN_PER; i++)
+        {
+            const bool v = first + i < n && dead[(size_t)b * max_cands + first + i] == 0;
+            alive |= v ? 1u << i : 0u;
+            total += v ? 1u : 0u;
+        }
+        unsigned int pos = scan_workgroup(total, wsum, trip, carry);
+#pragma unroll
+        for (int i = 0; i < SCAN_PER; i++)
+            if (alive & (1u << i))
+                live[(size_t)b * max_cands + pos++] = first + i;
     }
     if (threadIdx.x == 0)
-        n_live[b] = base;
+        n_live[b] = carry;
 }
 
 typedef float pkf2 __attribute__((ext_vector_type(2))); // two fp32 lanes of one packed VALU instruction
@@ -2296,19 +2324,17 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
 // valid mask into per-word exclusive counts (one workgroup per image, 8 words per thread and pass), and
 // compact_ordered_kernel places every valid slot.  Entries beyond max_kp are dropped; counts[b] is the number found
 // and the host reports the overflow.
-__global__ __launch_bounds__(256) void rank_scan_kernel(const unsigned long long *__restrict__ vmask, size_t mask_stride,
-                                                        unsigned int *__restrict__ wbase, unsigned int *__restrict__ counts)
+__global__ __launch_bounds__(SCAN_THREADS) void rank_scan_kernel(const unsigned long long *__restrict__ vmask, size_t mask_stride,
+                                                                 unsigned int *__restrict__ wbase, unsigned int *__restrict__ counts)
 {
-    constexpr int PER = 8;
-    __shared__ unsigned int wsum[4], carry;
+    constexpr int PER = SCAN_PER;
+    __shared__ unsigned int wsum[2][SCAN_WAVES];
     const unsigned int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long *M = vmask + (size_t)b * mask_stride;
     unsigned int *Wb = wbase + (size_t)b * mask_stride;
-    if (threadIdx.x == 0)
-        carry = 0;
-    __syncthreads();
-    for (size_t start = 0; start < mask_stride; start += 256 * PER)
+    unsigned int carry = 0;
+    int trip = 0;
+    for (size_t start = 0; start < mask_stride; start += (size_t)SCAN_THREADS * PER, trip++)
     {
         const size_t first = start + (size_t)threadIdx.x * PER;
         unsigned int pc[PER], total = 0;
@@ -2318,19 +2344,7 @@ __global__ __launch_bounds__(256) void rank_scan_kernel(const unsigned long long
             pc[i] = first + i < mask_stride ? (unsigned int)__popcll(M[first + i]) : 0u;
             total += pc[i];
         }
-        unsigned int incl = total; // inclusive scan of the threads' totals inside the wavefront
-        for (int off = 1; off < 64; off <<= 1)
-        {
-            const unsigned int t = (unsigned int)__shfl_up((int)incl, off);
-            if (lane >= off)
-                incl += t;
-        }
-        if (lane == 63)
-            wsum[wv] = incl;
-        __syncthreads();
-        unsigned int base = carry + incl - total;
-        for (int j = 0; j < wv; j++)
-            base += wsum[j];
+        unsigned int base = scan_workgroup(total, wsum, trip, carry);
 #pragma unroll
         for (int i = 0; i < PER; i++)
         {
@@ -2338,10 +2352,6 @@ __global__ __launch_bounds__(256) void rank_scan_kernel(const unsigned long long
                 Wb[first + i] = base;
             base += pc[i];
         }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
     }
     if (threadIdx.x == 0)
         counts[b] = carry;
@@ -3457,7 +3467,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                            (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride,
                            (const unsigned long long *)d_mask, mask_stride, LV, dfactor, d_dead);
         // the survivors in list order, then the descriptor over those only (slots it never visits stay invalid)
-        hipLaunchKernelGGL(live_list_kernel, dim3(B), dim3(256), 0, st, (const unsigned char *)d_dead, (const unsigned int *)d_ncand,
+        hipLaunchKernelGGL(live_list_kernel, dim3(B), dim3(SCAN_THREADS), 0, st, (const unsigned char *)d_dead, (const unsigned int *)d_ncand,
                            max_cands, d_live, d_nlive);
         OCHIP_HIP(ctx, hipMemsetAsync(d_valid, 0, (size_t)B * max_cands, st));
         // the grid covers the longest list of survivors, not of candidates (a third to a half of the workgroups would
@@ -3480,7 +3490,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     }
     if (max_n > 0)
     {
-        hipLaunchKernelGGL(rank_scan_kernel, dim3(B), dim3(256), 0, st, (const unsigned long long *)d_vmask, mask_stride, d_wbase,
+        hipLaunchKernelGGL(rank_scan_kernel, dim3(B), dim3(SCAN_THREADS), 0, st, (const unsigned long long *)d_vmask, mask_stride, d_wbase,
                            d_counts);
         hipLaunchKernelGGL(compact_ordered_kernel, dim3((max_n + 255) / 256, 1, B), dim3(256), 0, st,
                            (const unsigned char *)d_valid, (const cand_t *)d_cands, (const unsigned int *)d_ncand, max_cands,
