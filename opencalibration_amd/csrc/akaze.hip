@@ -1271,7 +1271,10 @@ template <int S, int K> struct level_strip_geom
     static constexpr int REACH = RD > RN ? RD : RN; // input rows / columns beyond an output, and rows an output lags its last input
     static constexpr int HALO = (REACH + 1) & ~1;
     static constexpr int OW = 128 - 2 * HALO;
-    static constexpr int NB = (LEVEL_STRIP_ROWS + 2 * REACH + U - 1) / U, NR = NB * U, H = NR - 2 * REACH;
+    // (an even number of ring turns: U is odd, so the strip's H = NB U - 2 REACH output rows are even then and the half-sampled
+    // rows of the epilogue - pairs of output rows - never straddle two strips)
+    static constexpr int NB0 = (LEVEL_STRIP_ROWS + 2 * REACH + U - 1) / U, NB = NB0 + (NB0 & 1), NR = NB * U, H = NR - 2 * REACH;
+    static_assert((H & 1) == 0, "a strip owns whole pairs of rows");
 };
 struct level_strip_args
 {
@@ -1283,6 +1286,8 @@ struct level_strip_args
     size_t lxy_stride;
     float *Lout; // the image after the K steps
     size_t lout_stride;
+    float *half_out; // not null: the next octave's first image too - halfsample_kernel's 2 x 2 means of Lout - (w / 2) x (h / 2), w and h even
+    size_t half_stride;
     int w, h;
     const float *kcontrast;
     int n_octave_steps;
@@ -1355,6 +1360,7 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
     float2 ld[U];
     pk2 gr[U], Ls[U], p3[U], p10[U], paS[U], pbS[U], Lraw[U], C[U], CX[U], CY[U];
     pk2 Lsave[K + 1], Fsave[K + 1];
+    float half_even = 0.0f; // (half-sampling epilogue: the even row's pair sum)
     auto request = [&](int r, int slot) {
         const int gy = min(max(Y0 - REACH + r, 0), h - 1);
         ld[slot] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(I + (size_t)gy * w) + col4);
@@ -1502,7 +1508,17 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
                     Lsave[q - 1] = Ln;
                 Ln = Lq;
                 if (q == K && own_cols && yq >= Y0 && yq < row_end)
+                {
                     *reinterpret_cast<float2 *>(lout_b + (size_t)yq * w * 4 + col4) = make_float2(Lq.x, Lq.y);
+                    if (A.half_out) // (wave-uniform) the lane's pair of columns and this pair of rows are one half-sampled pixel
+                    {
+                        const float pair_sum = Lq.x + Lq.y;
+                        if (yq & 1)
+                            A.half_out[(size_t)blockIdx.z * A.half_stride + (size_t)(yq >> 1) * (w >> 1) + (cx >> 1)] = (half_even + pair_sum) * 0.25f;
+                        else
+                            half_even = pair_sum;
+                    }
+                }
             }
         }
         // ---- (Lx, Ly) of row d = c - S
@@ -3216,6 +3232,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         return win;
     };
     int octave_steps = 0;
+    int half_sampled_level = -1; // the level whose first image a level kernel has already written (half-sampling epilogue)
     for (int i = 1; i < LV.n; i++)
     {
         const level_info &l = LV.l[i], &p = LV.l[i - 1];
@@ -3240,8 +3257,9 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         {
             float *dst = (n_groups % 2 == 0) ? cur : d_ping;
             const size_t dst_stride = (n_groups % 2 == 0) ? img_stride : plane0;
-            hipLaunchKernelGGL(halfsample_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Lt + p.off), p.w, p.h,
-                               img_stride, dst, l.w, l.h, dst_stride);
+            if (half_sampled_level != i) // (else: the last level kernel of the octave before wrote it with its own rows)
+                hipLaunchKernelGGL(halfsample_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Lt + p.off), p.w, p.h,
+                                   img_stride, dst, l.w, l.h, dst_stride);
             src = dst;
             src_stride = dst_stride;
             octave_steps++;
@@ -3267,6 +3285,19 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 sa.k[q] = g1.k[q];
             for (int q = 0; q < K; q++)
                 sa.T.tau[q] = tsteps[i][q];
+            // the octave's last level with its whole FED cycle in this launch: the next octave's first image - 2 x 2 means of this
+            // level's final rows, a lane's pair of columns x a pair of rows - leaves with them (halfsample_kernel read the
+            // level again: 2.5 us per image at the first octave boundary)
+            sa.half_out = nullptr;
+            sa.half_stride = 0;
+            if (i + 1 < LV.n && LV.l[i + 1].octave > l.octave && n_groups == 1 && K > 0 && l.w == 2 * LV.l[i + 1].w && l.h == 2 * LV.l[i + 1].h)
+            {
+                const size_t next_groups = (tsteps[i + 1].size() + FED_FUSE - 1) / FED_FUSE;
+                const bool next_to_cur = next_groups % 2 == 0;
+                sa.half_out = next_to_cur ? d_Lt + LV.l[i + 1].off : d_ping;
+                sa.half_stride = next_to_cur ? img_stride : plane0;
+                half_sampled_level = i + 1;
+            }
             const bool store_flow = n_groups > 1 || std::getenv("OCHIP_DUMP_PLANES") != nullptr;
             auto sgrid = [&](int ow, int sh) {
                 const int strips = ((l.w + ow - 1) / ow) * ((l.h + sh - 1) / sh);
