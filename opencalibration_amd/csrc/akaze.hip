@@ -315,7 +315,7 @@ struct blur_args
     const float *kcontrast; // FLOW
     int n_octave_steps;     // FLOW
     unsigned int *partial_max; // MODG: [image][workgroup] bit patterns of the tile maxima
-    float *out2;               // unused.  DERIV: out0 = the interleaved (Lx, Ly) float2 plane, out_stride in float2;
+    float *out2;               // DERIV: not null = the blurred image too (stride out2_stride).  DERIV: out0 = the interleaved (Lx, Ly) float2 plane, out_stride in float2;
                                // FLOW_DERIV: out1 = that plane with out2_stride (float2), out0 = conductivity with out_stride
     size_t out2_stride;
 };
@@ -516,7 +516,11 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
                 // Lx and Ly leave as one interleaved float2 plane: their consumers (determinant, orientation, descriptor)
                 // always want both at the same pixel, and the descriptor's gathers are what bounds it
                 if (MODE == BLUR_DERIV)
+                {
                     reinterpret_cast<float2 *>(A.out0)[o] = make_float2(dx, dy);
+                    if (A.out2) // (wave-uniform) the blurred image itself: level 0's base image and its derivatives in one launch
+                        A.out2[(size_t)blockIdx.z * A.out2_stride + (size_t)y * w + x] = c[0];
+                }
                 else
                     reinterpret_cast<float2 *>(A.out1)[(size_t)blockIdx.z * A.out2_stride + (size_t)y * w + x] = make_float2(dx, dy);
             }
@@ -559,7 +563,11 @@ __global__ __launch_bounds__(256) void blur_fused_kernel(blur_args A, taps_t t)
                            reflect101_once(y + M, h), nrm, wn, &dx, &dy);
 
             if (MODE == BLUR_DERIV)
+            {
                 reinterpret_cast<float2 *>(A.out0)[o] = make_float2(dx, dy);
+                if (A.out2)
+                    A.out2[(size_t)blockIdx.z * A.out2_stride + (size_t)y * w + x] = at(x, y);
+            }
             else
                 reinterpret_cast<float2 *>(A.out1)[(size_t)blockIdx.z * A.out2_stride + (size_t)y * w + x] = make_float2(dx, dy);
         }
@@ -3184,9 +3192,25 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     hipLaunchKernelGGL(kcontrast_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_hist, d_hmax, 300, 0.7f, d_kc, (int)B);
 
     // ---- nonlinear scale space
+    // level 0: the base image (Gaussian(soffset) of the resized view) and - its Lsmooth being its Lt - the detector's scale-s
+    // derivatives of it, one launch (two before: the derivative pass read the base image again)
+    bool level0_derivatives_done = false;
     {
-        blur_args a{d_img, plane0, d_Lt + LV.l[0].off, nullptr, img_stride, W, H, nullptr, 0, nullptr, nullptr, 0};
-        hipLaunchKernelGGL((blur_fused_kernel<BLUR_PLAIN, 0, 4>), tiles0, dim3(256), 0, st, a, g0);
+        const level_info &l0 = LV.l[0];
+        blur_args a{d_img, plane0, (float *)(d_Lxy + l0.off), nullptr, img_stride, W, H, nullptr, 0, nullptr, d_Lt + l0.off, img_stride};
+        level0_derivatives_done = true;
+        if (l0.sigma_size == 2)
+            hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 2, 4>), tiles0, dim3(256), 0, st, a, g0);
+        else if (l0.sigma_size == 3)
+            hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 3, 4>), tiles0, dim3(256), 0, st, a, g0);
+        else if (l0.sigma_size == 4)
+            hipLaunchKernelGGL((blur_fused_kernel<BLUR_DERIV, 4, 4>), tiles0, dim3(256), 0, st, a, g0);
+        else
+        {
+            level0_derivatives_done = false;
+            blur_args p{d_img, plane0, d_Lt + l0.off, nullptr, img_stride, W, H, nullptr, 0, nullptr, nullptr, 0};
+            hipLaunchKernelGGL((blur_fused_kernel<BLUR_PLAIN, 0, 4>), tiles0, dim3(256), 0, st, p, g0);
+        }
     }
     // the register-strip kernels load pairs of pixels with 8 / 16-byte loads: even widths and plane offsets (every level
     // of an image whose working width is a multiple of 8; the tile kernels take the rest, and OCHIP_TEST_HOOKS=tile_det
@@ -3405,7 +3429,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     for (int i = 0; i < LV.n; i++)
     {
         const level_info &l = LV.l[i];
-        if (i == 0)
+        if (i == 0 && !level0_derivatives_done)
         {
             // level 0's Lsmooth is its Lt: derivatives without a further blur (a one-tap identity kernel keeps the
             // same code path; 0 + 1 * x is exact)
