@@ -77,7 +77,7 @@ def extract_algorithmic_bytes(w, h, reference_passes=False):
     launch; grey conversion inside the resize):
       source: BGR read 3 B / full-resolution px; working image write 1 float / working px
       k-contrast: image read 1, gradient magnitude write 1 + read 1
-      level 0: Gaussian(1.6) read 1 + write 1; derivatives read 1 + write 2 (Lx, Ly); determinant read 2
+      level 0: Gaussian(1.6) read 1 + write 1 and, in the same launch, its derivatives write 2 (Lx, Ly); determinant read 2
       level i >= 1: level launch read L 1, write (Lx, Ly) 2, write L 1 (+ conductivity write 1 when FED groups follow);
         every further group of <= 4 FED steps read L 1 + conductivity 1, write L 1; determinant read 2
       description: L, Lx, Ly read once by the sampler 3 per level (the maxima maps are sparse: not charged)
@@ -96,7 +96,7 @@ def extract_algorithmic_bytes(w, h, reference_passes=False):
     for lvl in range(16):
         px = (W >> (lvl // 4)) * (H >> (lvl // 4))
         if lvl == 0:
-            per = 2 + 3 + 2 + 3
+            per = 4 + 2 + 3
         else:
             groups = (fed[lvl] + 3) // 4
             per = 4 + (1 if groups > 1 else 0) + 3 * max(groups - 1, 0) + 2 + 3
