@@ -1294,6 +1294,7 @@ struct level_strip_args
     size_t lxy_stride;
     float *Lout; // the image after the K steps
     size_t lout_stride;
+    unsigned int *hmax_bits; // MODG: per image, the bit pattern of the largest gradient magnitude (zeroed by the host)
     float *half_out; // not null: the next octave's first image too - halfsample_kernel's 2 x 2 means of Lout - (w / 2) x (h / 2), w and h even
     size_t half_stride;
     int w, h;
@@ -1317,7 +1318,9 @@ __device__ __forceinline__ float recip_ge1(float d)
     return __builtin_fmaf(e3, r, q);
 }
 
-template <int S, int K, bool SF /*the conductivity plane is stored: later launches of the level need it*/>
+template <int S, int K, bool SF /*the conductivity plane is stored: later launches of the level need it*/,
+          bool MODG = false /*the contrast factor's pass instead: |gradient| of the Gaussian(1) image (0 along the border) into the
+                              flow plane and its maximum per image; nothing else*/>
 __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
 {
     typedef float pk2 __attribute__((ext_vector_type(2)));
@@ -1342,7 +1345,8 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
     const bool own_cols = cx >= X0 && cx < X0 + OW && cx < w;
     const float *I = A.in + (size_t)blockIdx.z * A.in_stride;
     float *const e0 = &ex[wv][0][DS_PAD + 2 * lane];
-    float kc = A.kcontrast[blockIdx.z];
+    float kc = MODG ? 1.0f : A.kcontrast[blockIdx.z];
+    float grad_max = 0.0f; // (MODG: over the pixels this lane owns)
     for (int i = 0; i < A.n_octave_steps; i++) // kcontrast *= 0.75 at every new octave, one rounding per step
         kc = kc * 0.75f;
     const float inv1 = 1.0f / (kc * kc);
@@ -1440,10 +1444,27 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
             const pk2 ptop = f_top ? p3[s_c] : p3[sl(s_c - 2)], pbot = f_bot ? p3[sl(s_c - 2)] : p3[s_c];
             const pk2 lx = (ptop + p10[sl(s_c - 1)]) + pbot;
             const pk2 ly = (pk2{q3l, q3.x} + q10) + pk2{q3.y, q3r};
-            const pk2 den = one + inv * (lx * lx + ly * ly);
-            cf = pk2{recip_ge1(den.x), recip_ge1(den.y)};
+            if (MODG)
+            {
+                // blur_fused_kernel<BLUR_MODG>'s value: sqrtf(lx^2 + ly^2), 0 on the image's outermost pixels
+                const pk2 sum = lx * lx + ly * ly;
+                const bool row_in = yf >= 1 && yf < h - 1;
+                cf = pk2{(row_in && cx >= 1) ? sqrtf(sum.x) : 0.0f, (row_in && cx + 1 < w - 1) ? sqrtf(sum.y) : 0.0f};
+                if (own_cols && yf >= Y0 && yf < row_end)
+                    grad_max = fmaxf(grad_max, fmaxf(cf.x, cf.y));
+            }
+            else
+            {
+                const pk2 den = one + inv * (lx * lx + ly * ly);
+                cf = pk2{recip_ge1(den.x), recip_ge1(den.y)};
+            }
             if (SF && own_cols && yf >= Y0 && yf < row_end)
                 *reinterpret_cast<float2 *>(flow_b + (size_t)yf * w * 4 + col4) = make_float2(cf.x, cf.y);
+        }
+        if (MODG)
+        {
+            Ls[s_c] = a; // (the next rows' vertical differences; the stages below are not part of this pass)
+            return;
         }
         // ---- what the lanes S columns away need of this row: Lsmooth (row c) and wa vd (row d = c - S).  The pattern's
         // rows d - S and d + S reflect at the image border (BORDER_REFLECT_101): row -t is row t, i.e. the ring slot 2 t
@@ -1572,6 +1593,15 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
             for (int j = 0; j < U; j++)
                 row(std::false_type{}, k * U + j, j);
         }
+    }
+    if (MODG)
+    {
+        // the image's maximum: non-negative floats order like their bit patterns; a wavefront's maximum, then one atomic per strip
+        unsigned int bits = __float_as_uint(grad_max);
+        for (int off = 32; off >= 1; off >>= 1)
+            bits = max(bits, (unsigned int)__shfl_xor((int)bits, off));
+        if (lane == 0 && bits)
+            atomicMax(&A.hmax_bits[blockIdx.z], bits);
     }
 }
 
@@ -3182,6 +3212,26 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
 
     // ---- contrast factor: Gaussian(1) + gradient magnitude + per-tile maxima in one pass, then the histogram
     OCHIP_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)B * 301 * 4, st));
+    // (as a register strip - the level kernel's Gaussian and distance-1 pattern with the magnitude where the conductivity is - when
+    // the launch has the strips to fill the device, like the levels below; else the tile kernel and the reduction of its tile maxima)
+    static const bool modg_tiles = ochip_test_hook("tile_levels"), modg_force = ochip_test_hook("strip_levels");
+    const bool modg_strip = !modg_tiles && (W & 1) == 0 && (plane0 & 1) == 0 && W >= 64 && H >= 64 && ((uintptr_t)d_img & 15) == 0 &&
+                            ((uintptr_t)d_flow & 15) == 0 && (modg_force || (size_t)W * H * B >= ((size_t)32 << 20));
+    if (modg_strip)
+    {
+        OCHIP_HIP(ctx, hipMemsetAsync(d_hmax, 0, (size_t)B * 4, st));
+        level_strip_args sa{};
+        sa.in = d_img, sa.in_stride = plane0;
+        sa.flow = d_flow, sa.flow_stride = plane0;
+        sa.w = W, sa.h = H;
+        sa.hmax_bits = d_hmax;
+        for (int q = 0; q < 5; q++)
+            sa.k[q] = g1.k[q];
+        typedef level_strip_geom<2, 0> MG;
+        const int strips = ((W + MG::OW - 1) / MG::OW) * ((H + MG::H - 1) / MG::H);
+        hipLaunchKernelGGL((level_strip_kernel<2, 0, true, true>), dim3(8 * (((strips + 3) / 4 + 7) / 8), 1, B), dim3(256), 0, st, sa);
+    }
+    else
     {
         blur_args a{d_img, plane0, d_flow, nullptr, plane0, W, H, nullptr, 0, d_pmax, nullptr, 0};
         hipLaunchKernelGGL((blur_fused_kernel<BLUR_MODG, 1, 2>), tiles0, dim3(256), 0, st, a, g1);
