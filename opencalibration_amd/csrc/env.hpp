@@ -1,5 +1,5 @@
 // The two environment switches every part of the library shares (README.md, "Knobs"); plain C++, read on every call.
-//   OCHIP_VERBOSE    = 1 | all | comma list of relax, link, extract      progress lines on stderr
+//   OCHIP_VERBOSE    = 1 | all | comma list of relax, link, extract, dense      progress lines on stderr
 //   OCHIP_TEST_HOOKS = comma list of the alternative routes the tests compare the default ones with:
 //                      host_sort, host_subset, host_tail, host_nms (the round-2 host code of the link / extract tails),
 //                      popcount_match (no matrix-core matcher), chol_verify (factor every system both ways and compare),

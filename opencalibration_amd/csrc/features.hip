@@ -11,9 +11,10 @@
 //     (nn[0].distance * scale^2 > radius^2, extract_features.cpp:72);
 //   * the image's whole output list [sparse..., dense...] as 88-byte feature_2d records (location = pt / scale in fp64,
 //     strength, 486-bit descriptor): the host copies it in one piece.
-// The one thing not restated on the device is the heap sort libstdc++ falls back to at introsort's depth limit: an image
-// whose responses drive it there (none has) is flagged, and the host then sorts and suppresses that image itself from the
-// records (slot[s]: where detection index s went), as it did for every image before round 3.
+// The heap sort libstdc++ falls back to at introsort's depth limit is restated on the device as well (std_sort.hip, round 5):
+// conflict[b] is only set when one of the sort's work queues overflows (their capacities rule it out), and the host then
+// sorts and suppresses that image itself from the records (slot[s]: where detection index s went), as it did for every
+// image before round 3.
 #include "ctx.hpp"
 
 #include <algorithm>

@@ -1,5 +1,6 @@
 #include "dense_stereo.hpp"
 
+#include "../env.hpp"
 #include "invert_distortion.hpp"
 #include "relax_util.hpp"
 #include "triangle_walker.hpp"
@@ -65,7 +66,11 @@ inline void project(const v3 &point, const DenseImage &im, double pixel[2]) // i
 
 } // namespace
 
-uint32_t hilbert_xy2d(int order, int x, int y)
+namespace
+{
+
+// types/hilbert.hpp:9-28 as written: one level per trip, the quadrant's reflection and transposition applied to (x, y)
+uint32_t hilbert_by_levels(int order, int x, int y)
 {
     uint32_t d = 0;
     for (int s = order / 2; s > 0; s /= 2)
@@ -83,6 +88,101 @@ uint32_t hilbert_xy2d(int order, int x, int y)
         }
     }
     return d;
+}
+
+// The same index four levels per table look-up.  What a level does to the bits below it is a transposition and / or a
+// complement of both coordinates (s - 1 - x is ~x in the bits below s; the two commute), so the walk is a four-state machine
+// over the ORIGINAL bits: state = transposed | complemented << 1, a level's digit (3 rx) ^ ry from the state's view of its
+// two bits.  A level above the order sees two zero bits: digit 0 and one transposition - starting `extra` levels early
+// needs the start state transposed when `extra` is odd.  (A survey's 9.2 M dense features took 94 ns each by levels.)
+struct hilbert_table
+{
+    uint16_t step[4][256]; // [state][x nibble << 4 | y nibble] -> four digits | next state << 8
+    hilbert_table()
+    {
+        for (int state = 0; state < 4; state++)
+            for (int xy = 0; xy < 256; xy++)
+            {
+                int transposed = state & 1, complemented = state >> 1;
+                unsigned digits = 0;
+                for (int bit = 3; bit >= 0; bit--)
+                {
+                    const int a = (xy >> (4 + bit)) & 1, b = (xy >> bit) & 1;
+                    const int rx = (transposed ? b : a) ^ complemented, ry = (transposed ? a : b) ^ complemented;
+                    digits = digits << 2 | (unsigned)((3 * rx) ^ ry);
+                    if (ry == 0)
+                    {
+                        complemented ^= rx;
+                        transposed ^= 1;
+                    }
+                }
+                step[state][xy] = (uint16_t)(digits | (unsigned)(transposed | complemented << 1) << 8);
+            }
+    }
+};
+const hilbert_table HILBERT;
+
+inline uint32_t hilbert_by_table(int levels, uint32_t x, uint32_t y) // order = 1 << levels <= 65 536, x and y below it
+{
+    const int groups = (levels + 3) / 4;
+    unsigned state = (unsigned)(4 * groups - levels) & 1u;
+    uint32_t d = 0;
+    for (int g = groups - 1; g >= 0; g--)
+    {
+        const unsigned e = HILBERT.step[state][((x >> (4 * g)) & 15u) << 4 | ((y >> (4 * g)) & 15u)];
+        d = d << 8 | (e & 255u);
+        state = e >> 8;
+    }
+    return d;
+}
+
+// (key, feature number) records in the order std::sort puts the reference's (index, feature number) pairs: the numbers
+// are distinct and ascend in the input, so a stable sort by key is that order - three counting passes
+struct hilbert_rec
+{
+    uint32_t key, k;
+};
+void sort_by_key(std::vector<hilbert_rec> &recs, std::vector<hilbert_rec> &other, int key_bits)
+{
+    const int bits = std::max(1, (key_bits + 2) / 3);
+    const uint32_t mask = (1u << bits) - 1;
+    const size_t n = recs.size();
+    std::vector<uint32_t> hist((size_t)3 << bits, 0u);
+    uint32_t *h0 = hist.data(), *h1 = h0 + ((size_t)1 << bits), *h2 = h1 + ((size_t)1 << bits);
+    for (size_t i = 0; i < n; i++)
+    {
+        const uint32_t key = recs[i].key;
+        h0[key & mask]++, h1[(key >> bits) & mask]++, h2[(key >> (2 * bits)) & mask]++;
+    }
+    for (uint32_t *h : {h0, h1, h2})
+    {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b <= mask; b++)
+        {
+            const uint32_t c = h[b];
+            h[b] = run;
+            run += c;
+        }
+    }
+    hilbert_rec *src = recs.data(), *dst = other.data();
+    int pass = 0;
+    for (uint32_t *h : {h0, h1, h2})
+    {
+        for (size_t i = 0; i < n; i++)
+            dst[h[(src[i].key >> (pass * bits)) & mask]++] = src[i];
+        std::swap(src, dst);
+        pass++;
+    }
+    recs.swap(other); // three passes: the result is in `other`'s storage
+}
+
+} // namespace
+
+uint32_t hilbert_xy2d(int order, int x, int y)
+{
+    if (order >= 2 && order <= 65536 && (order & (order - 1)) == 0 && x >= 0 && y >= 0 && x < order && y < order)
+        return hilbert_by_table(__builtin_ctz((unsigned)order), (uint32_t)x, (uint32_t)y);
+    return hilbert_by_levels(order, x, y);
 }
 
 bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surface_model> &surfaces, DenseStats *stats, std::string *error,
@@ -248,23 +348,27 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
         int order = 1;
         while (order < std::max(w, h))
             order *= 2;
-        std::vector<std::pair<uint32_t, size_t>> indexed(src.n_dense);
+        std::vector<hilbert_rec> indexed(src.n_dense), other(src.n_dense);
         for (size_t k = 0; k < src.n_dense; k++)
         {
             const double *l = img.features[img.num_sparse_features + k].location;
-            indexed[k] = {hilbert_xy2d(order, std::clamp((int)l[0], 0, w - 1), std::clamp((int)l[1], 0, h - 1)), k};
+            indexed[k] = {hilbert_xy2d(order, std::clamp((int)l[0], 0, w - 1), std::clamp((int)l[1], 0, h - 1)), (uint32_t)k};
         }
-        std::sort(indexed.begin(), indexed.end());
+        if (order <= 65536)
+            sort_by_key(indexed, other, 2 * __builtin_ctz((unsigned)order));
+        else
+            std::sort(indexed.begin(), indexed.end(),
+                      [](const hilbert_rec &a, const hilbert_rec &b) { return a.key != b.key ? a.key < b.key : a.k < b.k; });
         if (matches_out)
         {
             walk_order[si].resize(src.n_dense);
             for (size_t i = 0; i < src.n_dense; i++)
-                walk_order[si][i] = (uint32_t)indexed[i].second;
+                walk_order[si][i] = indexed[i].k;
         }
         const v3 origin{img.position[0], img.position[1], img.position[2]};
-        for (const auto &entry : indexed)
+        for (const hilbert_rec &entry : indexed)
         {
-            const size_t k = entry.second;
+            const size_t k = entry.k;
             double ray[3];
             image_to_3d(img.features[img.num_sparse_features + k].location, *img.model, ray);
             const v3 dir = rotate(img.orientation, v3{ray[0], ray[1], ray[2]});
@@ -328,10 +432,8 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     // ascending: two counting passes into one flat array (800 k small vectors were a third of this phase)
     std::vector<uint32_t> track_start, track_member;
     {
-        // (four passes over all measurements with scattered accesses: in parallel - the roots' ranks by per-thread counts, the
-        // tracks' sizes and the members' places by atomic increments; a track's members are put in ascending order by the
-        // task that triangulates it)
-        std::vector<uint32_t> rank_of_root(total, UINT32_MAX);
+        // (the roots' ranks by per-thread counts)
+        const std::unique_ptr<uint32_t[]> rank_of_root(new uint32_t[total]); // (only the roots' entries are written and read)
         const int nt = std::max(1, omp_get_max_threads());
         std::vector<size_t> chunk_roots((size_t)nt + 1, 0);
         const size_t per = (total + (size_t)nt - 1) / (size_t)nt;
@@ -354,32 +456,45 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
                 if (root[i] == (uint32_t)i) // a root is the smallest member of its track: it comes first
                     rank_of_root[i] = r++;
         }
+        // members to tracks without atomics: the measurements' (rank, id) records are dealt into buckets by the part of
+        // the root range their track's root lies in (ranks ascend with the roots, so a bucket column owns a contiguous run
+        // of tracks), one row of buckets per source thread; a column's task then counts and places its records row after
+        // row - ids ascend inside a row and from row to row, so every track's members arrive in ascending order
+        int shift = 0;
+        while (((total - 1) >> shift) >= 128)
+            shift++;
+        const size_t n_owner = ((total - 1) >> shift) + 1;
+        std::vector<std::vector<uint64_t>> bucket((size_t)nt * n_owner);
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+        for (int t = 0; t < nt; t++)
+        {
+            std::vector<uint64_t> *row = bucket.data() + (size_t)t * n_owner;
+            const size_t i0 = (size_t)t * per, i1 = std::min(total, (size_t)(t + 1) * per);
+            for (size_t o = 0; o < n_owner; o++)
+                row[o].reserve((i1 > i0 ? i1 - i0 : 0) / n_owner + 64);
+            for (size_t i = i0; i < i1; i++)
+                if (root[i] != UINT32_MAX) // (UINT32_MAX: is_singleton)
+                    row[root[i] >> shift].push_back((uint64_t)rank_of_root[root[i]] << 32 | (uint64_t)i);
+        }
         track_start.assign((size_t)n_tracks + 1, 0);
-#pragma omp parallel for schedule(static)
-        for (size_t i = 0; i < total; i++)
-            if (root[i] != UINT32_MAX) // (UINT32_MAX: is_singleton)
-            {
-                uint32_t &slot = track_start[rank_of_root[root[i]] + 1];
-#pragma omp atomic
-                slot++;
-            }
+#pragma omp parallel for schedule(dynamic, 1)
+        for (size_t o = 0; o < n_owner; o++)
+            for (int t = 0; t < nt; t++)
+                for (const uint64_t e : bucket[(size_t)t * n_owner + o])
+                    track_start[(size_t)(e >> 32) + 1]++; // (slot rank + 1 belongs to the track of that rank: this column's)
         for (size_t t = 0; t < n_tracks; t++)
             track_start[t + 1] += track_start[t];
         track_member.resize(track_start[n_tracks]);
         std::vector<uint32_t> fill(track_start.begin(), track_start.end() - 1);
-#pragma omp parallel for schedule(static)
-        for (size_t i = 0; i < total; i++)
-            if (root[i] != UINT32_MAX)
-            {
-                uint32_t at;
-                uint32_t &slot = fill[rank_of_root[root[i]]];
-#pragma omp atomic capture
-                at = slot++;
-                track_member[at] = (uint32_t)i;
-            }
+#pragma omp parallel for schedule(dynamic, 1)
+        for (size_t o = 0; o < n_owner; o++)
+            for (int t = 0; t < nt; t++)
+                for (const uint64_t e : bucket[(size_t)t * n_owner + o])
+                    track_member[fill[(size_t)(e >> 32)]++] = (uint32_t)e;
     }
     const size_t n_tracks = track_start.size() - 1;
     st.tracks = n_tracks;
+    const double grouping_seconds = seconds_since(t2);
     // measurement id -> image (offsets ascend): a table, filled image by image (a binary search per track member was 4 M searches)
     std::vector<uint32_t> image_of_id(total);
 #pragma omp parallel for schedule(dynamic, 4)
@@ -392,10 +507,9 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
 #pragma omp parallel for schedule(dynamic, 64)
     for (size_t ti = 0; ti < n_tracks; ti++)
     {
-        uint32_t *ids_begin = track_member.data() + track_start[ti], *ids_end = track_member.data() + track_start[ti + 1];
+        const uint32_t *ids_begin = track_member.data() + track_start[ti], *ids_end = track_member.data() + track_start[ti + 1];
         if (ids_end - ids_begin < 2)
             continue;
-        std::sort(ids_begin, ids_end); // (members ascending: the parallel grouping left them in arrival order)
         struct RayMeasurement
         {
             v3 dir, origin;
@@ -461,6 +575,7 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
         track_results[ti] = {point.x, point.y, point.z};
         track_valid[ti] = 1;
     }
+    const double triangulated_seconds = seconds_since(t2);
     point_cloud merged;
     for (size_t ti = 0; ti < n_tracks; ti++)
         if (track_valid[ti])
@@ -469,6 +584,10 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     if (!merged.empty())
         surfaces[0].cloud.push_back(std::move(merged));
     st.tracks_seconds += seconds_since(t2);
+    if (ochip_verbose("dense"))
+        fprintf(stderr, "[dense] index %.4f s, rays %.4f, device %.4f, tracks %.4f (grouping %.4f, triangulation %.4f, cloud %.4f)\n", st.index_seconds,
+                st.rays_seconds, st.device_seconds, st.tracks_seconds, grouping_seconds, triangulated_seconds - grouping_seconds,
+                st.tracks_seconds - triangulated_seconds);
     return finish(true);
 }
 

@@ -75,3 +75,23 @@ def test_restated_densify_recovers_the_ground():
     dz = out["points"][:, 2] - scene["ground"](out["points"][:, 0], out["points"][:, 1])
     assert np.median(np.abs(dz)) < 0.15 and np.mean(np.abs(dz) < 1.0) > 0.97
     assert len(surface.arrays()["cloud"]) == len(out["points"])
+
+
+def test_host_hilbert_index_by_table_is_the_restatement():
+    """liboc_host's index takes four levels per table look-up (a four-state machine over the original bits); the
+    restatement walks level by level like types/hilbert.hpp.  Exhaustive on the small squares, sampled on the large ones,
+    and the arguments the table does not take (order not a power of two, points outside the square) go level by level."""
+    from opencalibration_amd import host
+    L = host.load()
+    for levels in range(1, 7):
+        order = 1 << levels
+        for x in range(order):
+            for y in range(order):
+                assert L.och_hilbert_xy2d(order, x, y) == pyoracle.hilbert_xy2d(order, x, y), (order, x, y)
+    rng = np.random.default_rng(5)
+    for levels in range(7, 17):
+        order = 1 << levels
+        for x, y in rng.integers(0, order, (300, 2)):
+            assert L.och_hilbert_xy2d(order, int(x), int(y)) == pyoracle.hilbert_xy2d(order, int(x), int(y)), (order, x, y)
+    for order, x, y in ((8192, 5471, 3647), (8192, 0, 0), (8192, 8191, 8191), (6, 3, 5), (1000, 999, 17), (16, 20, 3), (16, -1, 2), (1, 0, 0)):
+        assert L.och_hilbert_xy2d(order, x, y) == pyoracle.hilbert_xy2d(order, x, y), (order, x, y)
