@@ -44,9 +44,8 @@ struct lane_state
 //    instead of per query;
 //  * the runs are walked as one index space with the locations of DS_ROUNDS x 64 candidates in flight;
 //  * the candidates inside the disc - a handful of the ~160 scanned - are handed a lane each through a wavefront-private LDS
-//    list, their distances come back through a second list, and every lane walks the (distance, index) pairs in list order:
-//    ascending index, the reference's sequential rule (:262-276) as it stands, instead of a per-lane state and a six-stage
-//    tie-aware butterfly.
+//    list in ascending index, the order of the reference's sequential rule (:262-276); what that rule leaves (the smallest
+//    distance at its first candidate, the smallest of the others) is two wavefront minima (work_off).
 constexpr int DS_ROUNDS = 4; // rounds of 64 candidates whose locations are requested together
 __device__ __forceinline__ double bcast64(double v, int src)
 {
@@ -92,10 +91,25 @@ __device__ __forceinline__ dense_plan_t dense_plan_from(const dense_plan_t &P, i
     }
     return Q;
 }
+// the smallest value of a wavefront, in every lane (as a scalar): four DPP stages inside the rows of 16 lanes, the rows' results read out
+template <int CTRL> __device__ __forceinline__ uint32_t dense_dpp(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, dense_dpp<0xB1>(v));  // quad_perm [1, 0, 3, 2]
+    v = min(v, dense_dpp<0x4E>(v));  // quad_perm [2, 3, 0, 1]
+    v = min(v, dense_dpp<0x124>(v)); // row_ror:4
+    v = min(v, dense_dpp<0x128>(v)); // row_ror:8
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                   r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
 // P, qx, qy, src_feature: wave-uniform
 __device__ __forceinline__ lane_state dense_scan(const dense_plan_t &P, const uint64_t *__restrict__ desc, const double2 *__restrict__ loc,
                                                  uint32_t src_feature, double qx, double qy, double radius_sq, int lane,
-                                                 uint32_t *inside_list /*LDS, 64 + 128 words per wavefront*/)
+                                                 uint32_t *inside_list /*LDS, 64 words per wavefront*/)
 {
     uint64_t qd[8];
     {
@@ -111,38 +125,40 @@ __device__ __forceinline__ lane_state dense_scan(const dense_plan_t &P, const ui
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    unsigned long long *const pairs = reinterpret_cast<unsigned long long *>(inside_list + 64);
     auto work_off = [&](uint32_t n) {
         wave_sync();
+        // lane j takes the j-th listed candidate (ascending index: the order the reference meets them in, :262-276).  Its rule
+        // - a distance below the second best replaces it, one below the best moves the best down - leaves: best = the smallest
+        // distance, at its FIRST candidate; second = the smallest among all the others.  Two wavefront minima over
+        // (distance << 6 | list position) instead of a walk through the list (a dependent LDS read per candidate:
+        // 1.3 us of a 5 us search at ~32 candidates)
+        uint32_t key = 0xFFFFFFFFu, k = 0;
         if ((uint32_t)lane < n)
         {
-            const uint32_t k = inside_list[lane];
+            k = inside_list[lane];
             const uint64_t *cd = desc + 8 * (P.feat_base + k);
             uint32_t d = 0;
 #pragma unroll
             for (int w = 0; w < 8; w++)
                 d += (uint32_t)__popcll(cd[w] ^ qd[w]);
-            pairs[lane] = ((unsigned long long)d << 32) | k;
+            key = d << 6 | (uint32_t)lane;
         }
-        wave_sync();
-        for (uint32_t j = 0; j < n; j++)
+        const uint32_t first = wave_min_u32(key);
+        const int at = (int)(first & 63u);
+        const uint32_t b2 = first >> 6, k2 = (uint32_t)__builtin_amdgcn_readlane((int)k, at);
+        const uint32_t others = wave_min_u32(lane == at ? 0xFFFFFFFFu : key);
+        const uint32_t s2 = n >= 2 ? others >> 6 : NONE_COUNT;
+        // behind the candidates worked off before (ties stay with the earlier ones)
+        if (b2 < s.best)
         {
-            const unsigned long long e = pairs[j];
-            const uint32_t d = (uint32_t)(e >> 32), k = (uint32_t)e;
-            if (d < s.second)
-            {
-                if (d < s.best)
-                {
-                    s.second = s.best;
-                    s.best = d;
-                    s.idx = k;
-                }
-                else
-                    s.second = d;
-            }
+            s.second = min(s.best, s2);
+            s.best = b2;
+            s.idx = k2;
         }
+        else
+            s.second = min(s.second, b2);
         s.count += n;
-        wave_sync(); // (the lists are rewritten by the next candidates)
+        wave_sync(); // (the list is rewritten by the next candidates)
     };
     uint32_t listed = 0; // candidates inside the disc waiting in the list (wave-uniform)
     for (uint32_t f0 = 0; f0 < total; f0 += 64 * DS_ROUNDS)
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(256) void dense_match_kernel(const dense_image_meta
         return;
     const int lane = threadIdx.x & 63;
     const ochip_dense_query q = queries[qi];
-    __shared__ __attribute__((aligned(8))) uint32_t inside_lists[4][192];
+    __shared__ __attribute__((aligned(8))) uint32_t inside_lists[4][64];
     const lane_state s = dense_search(meta[q.cand_image], desc, loc, cell_start, q.src_feature, q.px, q.py, radius_sq, cell_size, lane,
                                       inside_lists[threadIdx.x >> 6]);
     if (lane == 0)
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(256) void dense_link_kernel(const dense_image_meta 
                                                          uint32_t *__restrict__ parent, uint8_t *__restrict__ matched,
                                                          uint32_t *__restrict__ slot_dst, unsigned long long *__restrict__ n_matches)
 {
-    __shared__ __attribute__((aligned(8))) uint32_t inside_lists[4][192];
+    __shared__ __attribute__((aligned(8))) uint32_t inside_lists[4][64];
     const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     // an accepted match is a union of two measurements: a chain of dependent loads along the parents of both (and a CAS).  Done
