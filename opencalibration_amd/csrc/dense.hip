@@ -399,6 +399,9 @@ __device__ __forceinline__ void uf_unite(uint32_t *parent, uint32_t a, uint32_t 
 }
 
 // one wavefront per SLOTS_PER_WAVE query slots: search, accept, unite
+// (measured and dropped, round 5: a slot's first trip of locations requested while the slot before it is searched - one of a
+// search's two dependent round trips off its critical path, but 132 registers with four rounds in flight (three waves per SIMD):
+// 4.25 ms per launch, 3.58 with two rounds (108 registers), against 2.81 for this form at 88)
 constexpr int SLOTS_PER_WAVE = 8;
 __global__ __launch_bounds__(256) void dense_link_kernel(const dense_image_meta *__restrict__ meta, const uint64_t *__restrict__ desc,
                                                          const double2 *__restrict__ loc, const uint32_t *__restrict__ cell_start,
