@@ -13,6 +13,7 @@
 // the candidates' descriptors (64 B per candidate in the disc, 16 B per candidate in the 3 x 3 cells); queries that
 // follow each other hit the same cells (the host emits them along the source image's Hilbert walk).
 #include "ctx.hpp"
+#include "env.hpp"
 
 #include <algorithm>
 #include <new>
@@ -278,12 +279,33 @@ __device__ __forceinline__ void dense_project(const dv3 &point, const dense_cam 
     }
 }
 
-// one thread per dense feature of the batch's images (blockIdx.y = image of the batch)
+// one thread per dense feature of the batch's images (blockIdx.y = image of the batch).
+// The 11 nearest cameras are the 11 smallest (distance, index) pairs whatever order the cameras are met in, and the order
+// decides the cost: a camera that does not beat the lane's 11th pair costs a subtraction, three products and a comparison, one
+// that does is an 11-stage insertion - which a wavefront pays as soon as one of its 64 lanes inserts.  Met in index order the
+// lanes of a wavefront kept inserting all along the list (~50 each at different places: nearly every trip); the cameras are
+// met outwards from the source image's own index instead (src, src + 1, src - 1, ...: a flight's neighbours in time are mostly
+// its neighbours in space, and nothing depends on it when they are not), so the 11th pair is tight after the first few dozen.
+// The positions come from LDS (all of them, staged once per workgroup; PRED_LDS_CAMS at most - larger surveys read the
+// camera records through the scalar cache in the same order), four per trip so that their reads are in flight together.
+constexpr uint32_t PRED_LDS_CAMS = 2048;
+template <bool STAGED>
 __global__ __launch_bounds__(256) void dense_predict_kernel(const dense_image_meta *__restrict__ meta, const dense_cam *__restrict__ cams,
                                                             uint32_t n_images, uint32_t first_image, const double *__restrict__ hits,
                                                             uint64_t batch_feat_base, uint32_t *__restrict__ cand_img,
                                                             double2 *__restrict__ cand_px, unsigned long long *__restrict__ n_queries)
 {
+    extern __shared__ double cam_pos_lds[]; // [n_images][3] when STAGED
+    if (STAGED)
+    {
+        for (uint32_t i = threadIdx.x; i < n_images; i += 256)
+        {
+            cam_pos_lds[3 * i] = cams[i].pos[0];
+            cam_pos_lds[3 * i + 1] = cams[i].pos[1];
+            cam_pos_lds[3 * i + 2] = cams[i].pos[2];
+        }
+        __syncthreads();
+    }
     const uint32_t src = first_image + blockIdx.y;
     const uint64_t f0 = meta[src].feat_base, n = meta[src + 1].feat_base - f0; // (meta has n_images + 1 entries)
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -303,23 +325,44 @@ __global__ __launch_bounds__(256) void dense_predict_kernel(const dense_image_me
                 bd[s] = INFINITY;
                 bc[s] = 0xFFFFFFFFu;
             }
-            for (uint32_t c = 0; c < n_images; c++)
+            // the t-th camera outwards from src (wave-uniform): src, src + 1, src - 1, ... while both sides last, then the rest
+            const uint32_t below = src, above = n_images - 1 - src, both = 2 * min(below, above);
+            auto camera_at = [&](uint32_t t) { return t <= both ? ((t & 1u) ? src + (t + 1) / 2 : src - t / 2) : (below > above ? n_images - 1 - t : t); };
+            constexpr int PER_TRIP = 4;
+            for (uint32_t t0 = 0; t0 < n_images; t0 += PER_TRIP)
             {
-                const double dx = cams[c].pos[0] - hit.x, dy = cams[c].pos[1] - hit.y, dz = cams[c].pos[2] - hit.z;
-                double d = dx * dx + dy * dy + dz * dz;
-                uint32_t id = c;
-                if (!(d < bd[DENSE_K - 1] || (d == bd[DENSE_K - 1] && id < bc[DENSE_K - 1])))
-                    continue;
+                uint32_t cs[PER_TRIP];
+                double px[PER_TRIP], py[PER_TRIP], pz[PER_TRIP];
 #pragma unroll
-                for (int s = 0; s < DENSE_K; s++) // sorted insertion: the displaced entries move up, the last one falls off
+                for (int u = 0; u < PER_TRIP; u++)
                 {
-                    const bool lt = d < bd[s] || (d == bd[s] && id < bc[s]);
-                    const double td = lt ? bd[s] : d;
-                    const uint32_t tc = lt ? bc[s] : id;
-                    bd[s] = lt ? d : bd[s];
-                    bc[s] = lt ? id : bc[s];
-                    d = td;
-                    id = tc;
+                    cs[u] = camera_at(min(t0 + u, n_images - 1)); // (the last trip's spare places: read, not used)
+                    if (STAGED)
+                        px[u] = cam_pos_lds[3 * cs[u]], py[u] = cam_pos_lds[3 * cs[u] + 1], pz[u] = cam_pos_lds[3 * cs[u] + 2];
+                    else
+                        px[u] = cams[cs[u]].pos[0], py[u] = cams[cs[u]].pos[1], pz[u] = cams[cs[u]].pos[2];
+                }
+#pragma unroll
+                for (int u = 0; u < PER_TRIP; u++)
+                {
+                    if (t0 + u >= n_images) // (wave-uniform)
+                        break;
+                    const double dx = px[u] - hit.x, dy = py[u] - hit.y, dz = pz[u] - hit.z;
+                    double d = dx * dx + dy * dy + dz * dz;
+                    uint32_t id = cs[u];
+                    if (!(d < bd[DENSE_K - 1] || (d == bd[DENSE_K - 1] && id < bc[DENSE_K - 1])))
+                        continue;
+#pragma unroll
+                    for (int s = 0; s < DENSE_K; s++) // sorted insertion: the displaced entries move up, the last one falls off
+                    {
+                        const bool lt = d < bd[s] || (d == bd[s] && id < bc[s]);
+                        const double td = lt ? bd[s] : d;
+                        const uint32_t tc = lt ? bc[s] : id;
+                        bd[s] = lt ? d : bd[s];
+                        bc[s] = lt ? id : bc[s];
+                        d = td;
+                        id = tc;
+                    }
                 }
             }
 #pragma unroll
@@ -705,6 +748,7 @@ int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t
         return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_link: upload failed"));
     hipLaunchKernelGGL(dense_uf_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, parent, matched, total);
     const double inv_bits = 1.0 / (double)descriptor_bits;
+    const bool unstaged_hook = ochip_test_hook("dense_predict_unstaged"); // (tests: the route of surveys above PRED_LDS_CAMS cameras)
     for (uint32_t b0 = 0; b0 < n_images; b0 += BATCH)
     {
         const uint32_t b1 = std::min(n_images, b0 + BATCH);
@@ -714,8 +758,12 @@ int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t
         uint64_t widest = 0;
         for (uint32_t i = b0; i < b1; i++)
             widest = std::max(widest, feat_base[i + 1] - feat_base[i]);
-        hipLaunchKernelGGL(dense_predict_kernel, dim3((unsigned)((widest + 255) / 256), b1 - b0), dim3(256), 0, st, ix->meta, cams, n_images,
-                           b0, hits, base, cand_img, cand_px, counters);
+        if (n_images <= PRED_LDS_CAMS && !unstaged_hook)
+            hipLaunchKernelGGL(dense_predict_kernel<true>, dim3((unsigned)((widest + 255) / 256), b1 - b0), dim3(256), (size_t)n_images * 24, st,
+                               ix->meta, cams, n_images, b0, hits, base, cand_img, cand_px, counters);
+        else
+            hipLaunchKernelGGL(dense_predict_kernel<false>, dim3((unsigned)((widest + 255) / 256), b1 - b0), dim3(256), 0, st, ix->meta, cams,
+                               n_images, b0, hits, base, cand_img, cand_px, counters);
         hipEvent_t e0, e1;
         ochip_prof_begin(ctx, OCHIP_K_DENSE, &e0, &e1);
         const uint64_t waves = (slots + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE;

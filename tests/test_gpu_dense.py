@@ -23,8 +23,14 @@ def _both(scene, ctx):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(seed=5, distortion=(0.02, -0.07, 0.1, 1e-4, -2e-4)),
-                                dict(seed=8, n_points=700, distractors=5, rows=2, cols=3)])
-def test_densify_matches_the_restatement(kw):
+                                dict(seed=8, n_points=700, distractors=5, rows=2, cols=3),
+                                dict(seed=3, rows=5, cols=6, n_points=3000),                 # 30 cameras: the 11 nearest are a choice
+                                dict(seed=3, rows=5, cols=6, n_points=3000, hook="dense_predict_unstaged")])
+def test_densify_matches_the_restatement(kw, monkeypatch):
+    kw = dict(kw)
+    hook = kw.pop("hook", None)
+    if hook:
+        monkeypatch.setenv("OCHIP_TEST_HOOKS", hook)
     scene = dense_scene(**kw)
     ctx = capi.Context(0)
     exp, got, surface, exp_surface, g = _both(scene, ctx)
