@@ -243,6 +243,8 @@ int ochip_ctx_set_priority(ochip_ctx *ctx, int high)
 {
     if (!ctx)
         return OCHIP_EINVAL;
+    if (ctx->stream_priority == (high ? 1 : 0))
+        return OCHIP_OK; // (asked again by the next survey's runner: the stream stays)
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
     int least = 0, greatest = 0;
     OCHIP_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -251,6 +253,7 @@ int ochip_ctx_set_priority(ochip_ctx *ctx, int high)
     OCHIP_HIP(ctx, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least));
     ctx->retired_streams.push_back(ctx->stream); // destroyed with the context, not here: tools that trace the process
     ctx->stream = s;                             // (rocprofv3) keep per-stream state that other threads may still touch
+    ctx->stream_priority = high ? 1 : 0;
     return OCHIP_OK;
 }
 

@@ -26,6 +26,7 @@ struct ochip_ctx
     hipStream_t stream = nullptr;     // compute stream: every kernel of the hot path is launched here
     hipStream_t copy_stream = nullptr;
     std::vector<hipStream_t> retired_streams; // replaced by ochip_ctx_set_priority
+    int stream_priority = -1; // what ochip_ctx_set_priority last set (-1: the default stream)
     hipEvent_t sync_event = nullptr;  // ochip_stream_wait: a blocking-sync event (created on first use)
     bool blocking_wait = true;        // OCHIP_BLOCKING_SYNC=0: let the runtime poll instead
     std::string error;
