@@ -623,6 +623,14 @@ extern "C"
                          uint32_t max_candidates, uint32_t descriptor_bits, double ratio, double max_abs, uint32_t *root_out,
                          uint64_t *counts2, uint32_t *slot_dst_out);
 
+    /* The tracks' 3-D points (dense_stereo.cpp:299-340 with triangulateTrack, :112-172) after ochip_dense_link on the same
+     * index: track t = the measurement ids track_member[track_start[t] .. track_start[t + 1]) in ascending order; its first two
+     * rays meet in a point, members reprojecting within max_reprojection_error px are inliers, fewer than two give no point,
+     * fewer than all give the point of the first two inliers.  cam_q4 [n_images][4]: the images' orientations (x y z w).
+     * points3_out [n_tracks][3], valid_out [n_tracks] (0: the track has no point). */
+    int ochip_dense_triangulate(ochip_dense_index *ix, const double *cam_q4, uint32_t n_tracks, const uint32_t *track_start,
+                                const uint32_t *track_member, double max_reprojection_error, double *points3_out, uint8_t *valid_out);
+
 #ifdef __cplusplus
 }
 #endif

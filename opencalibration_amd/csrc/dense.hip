@@ -14,6 +14,7 @@
 // follow each other hit the same cells (the host emits them along the source image's Hilbert walk).
 #include "ctx.hpp"
 #include "env.hpp"
+#include "undistort.hpp"
 
 #include <algorithm>
 #include <new>
@@ -540,6 +541,196 @@ __global__ void dense_uf_roots_kernel(uint32_t *parent, const uint8_t *matched, 
         root[i] = matched[i] ? uf_find(parent, (uint32_t)i) : 0xFFFFFFFFu;
 }
 
+// ---- the tracks' points (dense_stereo.cpp:299-340): one thread per track ---------------------------------------------
+// triangulateTrack (:112-172) as the host wrote it (host/dense_stereo.cpp): the first two members' rays meet in a point;
+// members whose reprojection is within 8 px are inliers; fewer than two: no point; fewer than all: the point again from the
+// first two inliers.  Same operations in the same order as the host's (undistort.hpp is shared, the rotation, the intersection
+// and the projection are the ones the link uses), -ffp-contract=off on both sides.
+__global__ void dense_pos_of_id_kernel(const uint32_t *__restrict__ id_of_pos, uint32_t *__restrict__ pos_of_id, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        pos_of_id[id_of_pos[i]] = (uint32_t)i;
+}
+__device__ __forceinline__ void dense_ray_intersection(const dv3 &d1, const dv3 &o1, const dv3 &d2, const dv3 &o2, dv3 *mid, double *err)
+{
+    auto dot = [](const dv3 &a, const dv3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    *mid = {nan, nan, nan};
+    *err = nan;
+    const double n11 = dot(d1, d1), n12 = dot(d1, d2), n22 = dot(d2, d2);
+    const double denom = n11 * n22 - n12 * n12;
+    if (fabs(denom) > 1e-9)
+    {
+        const dv3 off{o1.x - o2.x, o1.y - o2.y, o1.z - o2.z};
+        const double od1 = dot(off, d1), od2 = dot(off, d2);
+        const double t = (n12 * od2 - n22 * od1) / denom;
+        const double s = (n11 * od2 - n12 * od1) / denom;
+        const dv3 p1{o1.x + d1.x * t, o1.y + d1.y * t, o1.z + d1.z * t}, p2{o2.x + d2.x * s, o2.y + d2.y * s, o2.z + d2.z * s};
+        *mid = {(p1.x + p2.x) * 0.5, (p1.y + p2.y) * 0.5, (p1.z + p2.z) * 0.5};
+        const dv3 g{p1.x - p2.x, p1.y - p2.y, p1.z - p2.z};
+        *err = dot(g, g) * (t >= 0 && s >= 0 ? 1 : -1);
+    }
+}
+struct dense_tri_args
+{
+    const dense_image_meta *meta;
+    uint32_t n_images, n_tracks;
+    const dense_cam *cams;
+    const double *cam_q; // [n_images][4] orientation (the records hold its inverse)
+    const double2 *loc;
+    const uint32_t *pos_of_id, *track_start, *track_member;
+    double max_err_sq;
+    double *points;  // [n_tracks][3]
+    uint8_t *valid;  // [n_tracks]
+    uint32_t *large, *n_large; // tracks of more than TRI_LARGE members: a wavefront each, behind the one-thread-per-track pass
+};
+constexpr uint32_t TRI_LARGE = 32, TRI_LDS_IMAGES = 2048;
+// the images' first positions in LDS (a member's image is a binary search over them: ten dependent reads per member)
+struct dense_tri_images
+{
+    const dense_image_meta *meta;
+    const uint32_t *first; // LDS copy, or nullptr above TRI_LDS_IMAGES images
+    uint32_t n_images;
+    __device__ uint32_t of(uint32_t pos) const // the image whose positions hold pos (every image of the index has features)
+    {
+        uint32_t lo = 0, hi = n_images;
+        while (hi - lo > 1)
+        {
+            const uint32_t mid = (lo + hi) / 2;
+            const bool below = first ? first[mid] <= pos : meta[mid].feat_base <= pos;
+            lo = below ? mid : lo;
+            hi = below ? hi : mid;
+        }
+        return lo;
+    }
+};
+__device__ __forceinline__ dense_tri_images dense_tri_stage(const dense_tri_args &A, uint32_t *lds)
+{
+    const bool staged = A.n_images <= TRI_LDS_IMAGES;
+    if (staged)
+    {
+        for (uint32_t i = threadIdx.x; i < A.n_images; i += blockDim.x)
+            lds[i] = (uint32_t)A.meta[i].feat_base;
+        __syncthreads();
+    }
+    return dense_tri_images{A.meta, staged ? lds : nullptr, A.n_images};
+}
+struct dense_tri_member
+{
+    uint32_t image;
+    double2 px;
+};
+__device__ __forceinline__ dense_tri_member dense_tri_member_at(const dense_tri_args &A, const dense_tri_images &I, uint32_t m)
+{
+    const uint32_t pos = A.pos_of_id[A.track_member[m]];
+    return dense_tri_member{I.of(pos), A.loc[pos]};
+}
+__device__ __forceinline__ void dense_tri_ray(const dense_tri_args &A, const dense_tri_member &M, dv3 *dir, dv3 *origin)
+{
+    const dense_cam &c = A.cams[M.image];
+    const double key[2] = {M.px.x, M.px.y};
+    double ray[3];
+    ochip_ud::image_to_3d(key, c.model, ray);
+    *dir = drotate(A.cam_q + 4 * (size_t)M.image, dv3{ray[0], ray[1], ray[2]});
+    *origin = dv3{c.pos[0], c.pos[1], c.pos[2]};
+}
+__device__ __forceinline__ bool dense_tri_point(const dense_tri_args &A, const dense_tri_images &I, uint32_t ma, uint32_t mb, dv3 *point)
+{
+    dv3 d1, o1, d2, o2;
+    double err;
+    dense_tri_ray(A, dense_tri_member_at(A, I, ma), &d1, &o1);
+    dense_tri_ray(A, dense_tri_member_at(A, I, mb), &d2, &o2);
+    dense_ray_intersection(d1, o1, d2, o2, point, &err);
+    return isfinite(point->x) && isfinite(point->y) && isfinite(point->z) && !(err < 0);
+}
+__device__ __forceinline__ bool dense_tri_inlier(const dense_tri_args &A, const dense_tri_images &I, const dv3 &point, uint32_t m)
+{
+    const dense_tri_member M = dense_tri_member_at(A, I, m);
+    double reproj[2];
+    dense_project(point, A.cams[M.image], reproj);
+    const double ex = reproj[0] - M.px.x, ey = reproj[1] - M.px.y;
+    return ex * ex + ey * ey <= A.max_err_sq;
+}
+__global__ __launch_bounds__(128) void dense_triangulate_kernel(dense_tri_args A)
+{
+    __shared__ uint32_t first_pos[TRI_LDS_IMAGES];
+    const dense_tri_images I = dense_tri_stage(A, first_pos);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= A.n_tracks)
+        return;
+    A.valid[t] = 0;
+    const uint32_t m0 = A.track_start[t], n = A.track_start[t + 1] - m0;
+    if (n < 2)
+        return;
+    if (n > TRI_LARGE) // (a merged track of thousands of members would keep this thread for the whole launch)
+    {
+        A.large[atomicAdd(A.n_large, 1u)] = t;
+        return;
+    }
+    dv3 point;
+    if (!dense_tri_point(A, I, m0, m0 + 1, &point)) // only the first two rays (:145-161)
+        return;
+    uint32_t n_inliers = 0, f0 = 0, f1 = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (dense_tri_inlier(A, I, point, m0 + i))
+        {
+            f0 = n_inliers == 0 ? i : f0;
+            f1 = n_inliers == 1 ? i : f1;
+            n_inliers++;
+        }
+    if (n_inliers < 2)
+        return;
+    if (n_inliers < n && !dense_tri_point(A, I, m0 + f0, m0 + f1, &point))
+        return;
+    A.points[3 * (size_t)t] = point.x;
+    A.points[3 * (size_t)t + 1] = point.y;
+    A.points[3 * (size_t)t + 2] = point.z;
+    A.valid[t] = 1;
+}
+// the same for a track of many members, by a wavefront: the members' reprojections lane by lane, the number of inliers and the
+// two smallest inlier indices by wavefront reductions
+__global__ __launch_bounds__(256) void dense_triangulate_large_kernel(dense_tri_args A)
+{
+    __shared__ uint32_t first_pos[TRI_LDS_IMAGES];
+    const dense_tri_images I = dense_tri_stage(A, first_pos);
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= *A.n_large)
+        return;
+    const uint32_t t = A.large[w];
+    const uint32_t m0 = A.track_start[t], n = A.track_start[t + 1] - m0;
+    dv3 point;
+    if (!dense_tri_point(A, I, m0, m0 + 1, &point)) // (every lane: the same point)
+        return;
+    uint32_t mine = 0, first = 0xFFFFFFFFu, second = 0xFFFFFFFFu; // this lane's inliers: how many, the two smallest indices
+    for (uint32_t i = lane; i < n; i += 64)
+        if (dense_tri_inlier(A, I, point, m0 + i))
+        {
+            second = mine == 1 ? i : second;
+            first = mine == 0 ? i : first;
+            mine++;
+        }
+    uint32_t n_inliers = mine;
+    for (int off = 32; off >= 1; off >>= 1)
+        n_inliers += (uint32_t)__shfl_xor((int)n_inliers, off);
+    if (n_inliers < 2)
+        return;
+    if (n_inliers < n)
+    {
+        const uint32_t f0 = wave_min_u32(first);
+        const uint32_t f1 = wave_min_u32(first == f0 ? second : first);
+        if (!dense_tri_point(A, I, m0 + f0, m0 + f1, &point))
+            return;
+    }
+    if (lane == 0)
+    {
+        A.points[3 * (size_t)t] = point.x;
+        A.points[3 * (size_t)t + 1] = point.y;
+        A.points[3 * (size_t)t + 2] = point.z;
+        A.valid[t] = 1;
+    }
+}
+
 } // namespace
 
 struct ochip_dense_index
@@ -553,6 +744,8 @@ struct ochip_dense_index
     uint64_t *desc = nullptr;
     double2 *loc = nullptr;
     uint32_t *cell_start = nullptr;
+    void *cams = nullptr;    // ochip_dense_link's camera records and measurement ids (by position), kept for
+    uint32_t *ids = nullptr; // ochip_dense_triangulate
 };
 
 extern "C"
@@ -729,8 +922,22 @@ int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t
         max_batch_feats = std::max(max_batch_feats, feat_base[std::min(n_images, b0 + BATCH)] - feat_base[b0]);
     for (uint32_t i = 0; i < n_images; i++)
         max_image_feats = std::max(max_image_feats, feat_base[i + 1] - feat_base[i]);
-    dense_cam *cams = (dense_cam *)get((size_t)n_images * sizeof(dense_cam));
-    uint32_t *ids = (uint32_t *)get(total * 4);
+    // (the camera records and the ids stay with the index: ochip_dense_triangulate reads them)
+    auto keep = [&](size_t bytes) -> void * {
+        size_t got = 0;
+        void *d = ochip_pool_get(ctx, bytes ? bytes : 16, &got);
+        if (!d)
+            rc = ochip_fail(ctx, OCHIP_ENOMEM, "ochip_dense_link: device allocation of %zu bytes failed", bytes);
+        else
+            ix->blocks.emplace_back(d, got);
+        return d;
+    };
+    if (!ix->cams)
+        ix->cams = keep((size_t)n_images * sizeof(dense_cam));
+    if (!ix->ids)
+        ix->ids = (uint32_t *)keep(total * 4);
+    dense_cam *cams = (dense_cam *)ix->cams;
+    uint32_t *ids = ix->ids;
     double *hits = (double *)get(total * 24);
     uint32_t *parent = (uint32_t *)get(total * 4), *root = (uint32_t *)get(total * 4);
     uint8_t *matched = (uint8_t *)get(total);
@@ -792,6 +999,79 @@ int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t
         counts2[0] += host_counts[i];
         counts2[1] += host_counts[DENSE_COUNTERS + i];
     }
+    return done(OCHIP_OK);
+}
+
+int ochip_dense_triangulate(ochip_dense_index *ix, const double *cam_q4, uint32_t n_tracks, const uint32_t *track_start,
+                            const uint32_t *track_member, double max_reprojection_error, double *points3_out, uint8_t *valid_out)
+{
+    if (!ix || !cam_q4 || (n_tracks && (!track_start || !track_member || !points3_out || !valid_out)))
+        return OCHIP_EINVAL;
+    ochip_ctx *ctx = ix->ctx;
+    if (n_tracks == 0)
+        return OCHIP_OK;
+    if (!ix->cams || !ix->ids)
+        return ochip_fail(ctx, OCHIP_ESTATE, "ochip_dense_triangulate: ochip_dense_link has not run on this index");
+    OCHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t total = ix->total_features;
+    const uint64_t n_members = track_start[n_tracks];
+    for (uint32_t t = 0; t < n_tracks; t++)
+        if (track_start[t] > track_start[t + 1])
+            return ochip_fail(ctx, OCHIP_EINVAL, "ochip_dense_triangulate: track_start does not ascend at track %u", t);
+    std::vector<std::pair<void *, size_t>> blocks;
+    int rc = OCHIP_OK;
+    auto get = [&](size_t bytes) -> void * {
+        size_t got = 0;
+        void *d = ochip_pool_get(ctx, bytes ? bytes : 16, &got);
+        if (!d)
+            rc = ochip_fail(ctx, OCHIP_ENOMEM, "ochip_dense_triangulate: device allocation of %zu bytes failed", bytes);
+        else
+            blocks.emplace_back(d, got);
+        return d;
+    };
+    auto done = [&](int code) {
+        (void)ochip_stream_wait(ctx, st);
+        for (auto &b : blocks)
+            ochip_pool_put(ctx, b.first, b.second);
+        return code;
+    };
+    double *q = (double *)get((size_t)ix->n_images * 32);
+    uint32_t *pos_of_id = (uint32_t *)get(total * 4);
+    uint32_t *start = (uint32_t *)get(((size_t)n_tracks + 1) * 4), *members = (uint32_t *)get(n_members * 4);
+    double *points = (double *)get((size_t)n_tracks * 24);
+    uint8_t *valid = (uint8_t *)get(n_tracks);
+    const uint32_t max_large = (uint32_t)(n_members / (TRI_LARGE + 1)) + 1;
+    uint32_t *large = (uint32_t *)get(((size_t)max_large + 1) * 4);
+    if (rc != OCHIP_OK)
+        return done(rc);
+    if (hipMemsetAsync(large + max_large, 0, 4, st) != hipSuccess)
+        return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_triangulate: memset failed"));
+    if (hipMemcpyAsync(q, cam_q4, (size_t)ix->n_images * 32, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(start, track_start, ((size_t)n_tracks + 1) * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        (n_members && hipMemcpyAsync(members, track_member, n_members * 4, hipMemcpyHostToDevice, st) != hipSuccess))
+        return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_triangulate: upload failed"));
+    hipLaunchKernelGGL(dense_pos_of_id_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ix->ids, pos_of_id, total);
+    dense_tri_args A{};
+    A.meta = ix->meta;
+    A.n_images = ix->n_images;
+    A.n_tracks = n_tracks;
+    A.cams = (const dense_cam *)ix->cams;
+    A.cam_q = q;
+    A.loc = ix->loc;
+    A.pos_of_id = pos_of_id;
+    A.track_start = start;
+    A.track_member = members;
+    A.max_err_sq = max_reprojection_error * max_reprojection_error;
+    A.points = points;
+    A.valid = valid;
+    A.large = large;
+    A.n_large = large + max_large;
+    hipLaunchKernelGGL(dense_triangulate_kernel, dim3((n_tracks + 127) / 128), dim3(128), 0, st, A);
+    hipLaunchKernelGGL(dense_triangulate_large_kernel, dim3((max_large + 3) / 4), dim3(256), 0, st, A);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(points3_out, points, (size_t)n_tracks * 24, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(valid_out, valid, n_tracks, hipMemcpyDeviceToHost, st) != hipSuccess || ochip_stream_wait(ctx, st) != hipSuccess)
+        return done(ochip_fail(ctx, OCHIP_EHIP, "ochip_dense_triangulate: %s", hipGetErrorString(hipGetLastError())));
     return done(OCHIP_OK);
 }
 

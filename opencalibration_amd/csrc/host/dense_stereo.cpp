@@ -403,7 +403,11 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     const int lrc = ochip_dense_link(index, cams17.data(), id_of_pos.data(), hits, SEARCH_RADIUS_PIXELS, MAX_CANDIDATE_IMAGES,
                                      feature_2d::DESCRIPTOR_BITS, RATIO_THRESHOLD, MAX_ABSOLUTE_DESCRIPTOR_DISTANCE, root.data(), counts,
                                      matches_out ? slot_dst.data() : nullptr);
-    ochip_dense_index_destroy(index);
+    struct index_guard // (the index outlives the link: ochip_dense_triangulate reads its locations, cameras and ids)
+    {
+        ochip_dense_index *ix;
+        ~index_guard() { ochip_dense_index_destroy(ix); }
+    } index_owner{index};
     if (lrc != OCHIP_OK)
     {
         if (error)
@@ -430,7 +434,10 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     auto t2 = std::chrono::steady_clock::now();
     // a matched measurement's component = a track; tracks in the order of their smallest member (= their root), members
     // ascending: two counting passes into one flat array (800 k small vectors were a third of this phase)
-    std::vector<uint32_t> track_start, track_member;
+    // (the members and the points cross the PCIe link for ochip_dense_triangulate: page-locked blocks of the context's pool)
+    std::vector<uint32_t> track_start;
+    pinned_block member_stage{ctx}, result_stage{ctx};
+    uint32_t *track_member = nullptr;
     {
         // (the roots' ranks by per-thread counts)
         const std::unique_ptr<uint32_t[]> rank_of_root(new uint32_t[total]); // (only the roots' entries are written and read)
@@ -484,7 +491,13 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
                     track_start[(size_t)(e >> 32) + 1]++; // (slot rank + 1 belongs to the track of that rank: this column's)
         for (size_t t = 0; t < n_tracks; t++)
             track_start[t + 1] += track_start[t];
-        track_member.resize(track_start[n_tracks]);
+        if (ochip_host_alloc(ctx, std::max<size_t>(track_start[n_tracks], 1) * 4, &member_stage.p) != OCHIP_OK)
+        {
+            if (error)
+                *error = std::string("ochip_host_alloc: ") + ochip_last_error(ctx);
+            return finish(false);
+        }
+        track_member = static_cast<uint32_t *>(member_stage.p);
         std::vector<uint32_t> fill(track_start.begin(), track_start.end() - 1);
 #pragma omp parallel for schedule(dynamic, 1)
         for (size_t o = 0; o < n_owner; o++)
@@ -502,12 +515,36 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
         std::fill(image_of_id.begin() + (ptrdiff_t)images[i].offset, image_of_id.begin() + (ptrdiff_t)(images[i].offset + images[i].n_dense), (uint32_t)i);
     auto image_of = [&](size_t id) { return (size_t)image_of_id[id]; };
     const double max_err_sq = MAX_REPROJECTION_ERROR_PIXELS * MAX_REPROJECTION_ERROR_PIXELS;
-    std::vector<std::array<double, 3>> track_results(n_tracks);
-    std::vector<char> track_valid(n_tracks, 0);
-#pragma omp parallel for schedule(dynamic, 64)
-    for (size_t ti = 0; ti < n_tracks; ti++)
+    static_assert(sizeof(std::array<double, 3>) == 24, "points are three doubles");
+    if (ochip_host_alloc(ctx, std::max<size_t>(n_tracks, 1) * 25, &result_stage.p) != OCHIP_OK) // points, then a flag per track
     {
-        const uint32_t *ids_begin = track_member.data() + track_start[ti], *ids_end = track_member.data() + track_start[ti + 1];
+        if (error)
+            *error = std::string("ochip_host_alloc: ") + ochip_last_error(ctx);
+        return finish(false);
+    }
+    std::array<double, 3> *const track_results = static_cast<std::array<double, 3> *>(result_stage.p);
+    uint8_t *const track_valid = static_cast<uint8_t *>(result_stage.p) + n_tracks * 24;
+    std::memset(track_valid, 0, n_tracks);
+    // the tracks' points on the device (ochip_dense_triangulate: a thread per track, the operations of the loop below in its
+    // order); OCHIP_TEST_HOOKS=host_triangulation keeps the loop - the tests hold the two to each other bit for bit
+    const bool on_device = !ochip_test_hook("host_triangulation") && n_tracks > 0;
+    if (on_device)
+    {
+        std::vector<double> cam_q(4 * n_img);
+        for (size_t i = 0; i < n_img; i++)
+            std::memcpy(&cam_q[4 * i], images[i].img->orientation, 32);
+        if (ochip_dense_triangulate(index, cam_q.data(), (uint32_t)n_tracks, track_start.data(), track_member, MAX_REPROJECTION_ERROR_PIXELS,
+                                    track_results[0].data(), track_valid) != OCHIP_OK)
+        {
+            if (error)
+                *error = std::string("ochip_dense_triangulate: ") + ochip_last_error(ctx);
+            return finish(false);
+        }
+    }
+#pragma omp parallel for schedule(dynamic, 64)
+    for (size_t ti = 0; ti < (on_device ? 0 : n_tracks); ti++)
+    {
+        const uint32_t *ids_begin = track_member + track_start[ti], *ids_end = track_member + track_start[ti + 1];
         if (ids_end - ids_begin < 2)
             continue;
         struct RayMeasurement

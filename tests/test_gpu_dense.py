@@ -45,6 +45,25 @@ def test_densify_matches_the_restatement(kw, monkeypatch):
     g.close(), ctx.close()
 
 
+@pytest.mark.parametrize("kw", [dict(seed=5, distortion=(0.02, -0.07, 0.1, 1e-4, -2e-4)), dict(seed=3, rows=5, cols=6, n_points=3000)])
+def test_track_points_on_the_device_are_the_host_loops(kw, monkeypatch):
+    """ochip_dense_triangulate (a thread per track) against the host loop it replaces (OCHIP_TEST_HOOKS=host_triangulation):
+    the same tracks get a point and the points are the same doubles - with lens distortion (the iterative inverse) and with
+    tracks whose outliers send them to the second intersection."""
+    scene = dense_scene(**kw)
+    ctx = capi.Context(0)
+    v, e = ground_mesh_arrays(pyoracle.rebuild_mesh, scene)
+    g = host_graph(host, scene)
+    on_device, by_host = host.Surface().set(v, e), host.Surface().set(v, e)
+    got_d = g.densify_mesh(ctx, on_device)
+    monkeypatch.setenv("OCHIP_TEST_HOOKS", "host_triangulation")
+    got_h = g.densify_mesh(ctx, by_host)
+    assert got_d["tracks"] == got_h["tracks"] and got_d["points"] == got_h["points"] > 100
+    assert got_d["points"] <= got_d["tracks"]
+    assert np.array_equal(on_device.clouds()[-1], by_host.clouds()[-1])
+    g.close(), ctx.close()
+
+
 def test_raw_search_against_brute_force():
     """ochip_dense_match alone, through the C ABI: nearest / second nearest Hamming distance and the disc population for
     random queries, against numpy - including empty discs, single-candidate discs, exact ties and the open disc edge."""
