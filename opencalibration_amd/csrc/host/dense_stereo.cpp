@@ -322,6 +322,11 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
             *error = std::string("ochip_dense_index_create: ") + ochip_last_error(ctx);
         return finish(false);
     }
+    struct index_guard // (the index outlives the link: ochip_dense_triangulate reads its locations, cameras and ids)
+    {
+        ochip_dense_index *ix;
+        ~index_guard() { ochip_dense_index_destroy(ix); }
+    } index_owner{index};
     st.index_seconds = seconds_since(t0);
 
     const MeshGraph &mesh = surfaces[0].mesh;
@@ -329,7 +334,15 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     //      feature of the image's Hilbert walk (hilbertFeatureOrder, :24-49), so an image is one sequential task
     auto t1 = std::chrono::steady_clock::now();
     double *const hits = static_cast<double *>(hits_stage.p);
-    std::vector<uint32_t> id_of_pos(total);
+    // (the ids go up and the roots come back over PCIe: page-locked like the hits - 33 MB each for a 1 000-image survey)
+    pinned_block ids_stage{ctx}, root_stage{ctx};
+    if (ochip_host_alloc(ctx, total * 4, &ids_stage.p) != OCHIP_OK || ochip_host_alloc(ctx, total * 4, &root_stage.p) != OCHIP_OK)
+    {
+        if (error)
+            *error = std::string("ochip_host_alloc: ") + ochip_last_error(ctx);
+        return finish(false);
+    }
+    uint32_t *const id_of_pos = static_cast<uint32_t *>(ids_stage.p);
     std::vector<std::vector<uint32_t>> walk_order(matches_out ? n_img : 0); // dense feature numbers in Hilbert order (tests only)
 #pragma omp parallel for schedule(dynamic, 1)
     for (size_t si = 0; si < n_img; si++)
@@ -397,17 +410,12 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
                                     (double)m.pixels_cols,   (double)m.pixels_rows};
         std::memcpy(c + 7, model10, 80);
     }
-    std::vector<uint32_t> root(total);
+    uint32_t *const root = static_cast<uint32_t *>(root_stage.p);
     std::vector<uint32_t> slot_dst(matches_out ? total * (MAX_CANDIDATE_IMAGES + 1) : 0);
     uint64_t counts[2] = {0, 0};
-    const int lrc = ochip_dense_link(index, cams17.data(), id_of_pos.data(), hits, SEARCH_RADIUS_PIXELS, MAX_CANDIDATE_IMAGES,
-                                     feature_2d::DESCRIPTOR_BITS, RATIO_THRESHOLD, MAX_ABSOLUTE_DESCRIPTOR_DISTANCE, root.data(), counts,
+    const int lrc = ochip_dense_link(index, cams17.data(), id_of_pos, hits, SEARCH_RADIUS_PIXELS, MAX_CANDIDATE_IMAGES,
+                                     feature_2d::DESCRIPTOR_BITS, RATIO_THRESHOLD, MAX_ABSOLUTE_DESCRIPTOR_DISTANCE, root, counts,
                                      matches_out ? slot_dst.data() : nullptr);
-    struct index_guard // (the index outlives the link: ochip_dense_triangulate reads its locations, cameras and ids)
-    {
-        ochip_dense_index *ix;
-        ~index_guard() { ochip_dense_index_destroy(ix); }
-    } index_owner{index};
     if (lrc != OCHIP_OK)
     {
         if (error)

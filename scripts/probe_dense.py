@@ -16,7 +16,7 @@ a = s.arrays()
 v = a["vertices"].copy()
 v[:, 2] = grid.plane[0] * v[:, 0] + grid.plane[1] * v[:, 1]
 s.set(v, a["edges"])
-for rep in range(2):
+for rep in range(int(os.environ.get("OCHIP_PROBE_REPS", "2"))):
     s2 = host.Surface().set(v, a["edges"])
     t0 = time.perf_counter()
     st = g.densify_mesh(ctx, s2)
