@@ -584,6 +584,7 @@ struct dense_tri_args
     double *points;  // [n_tracks][3]
     uint8_t *valid;  // [n_tracks]
     uint32_t *large, *n_large; // tracks of more than TRI_LARGE members: a wavefront each, behind the one-thread-per-track pass
+    uint32_t lds_images;       // the images' first positions go to LDS up to this many images (TRI_LDS_IMAGES; 0: the test hook)
 };
 constexpr uint32_t TRI_LARGE = 32, TRI_LDS_IMAGES = 2048;
 // the images' first positions in LDS (a member's image is a binary search over them: ten dependent reads per member)
@@ -607,7 +608,7 @@ struct dense_tri_images
 };
 __device__ __forceinline__ dense_tri_images dense_tri_stage(const dense_tri_args &A, uint32_t *lds)
 {
-    const bool staged = A.n_images <= TRI_LDS_IMAGES;
+    const bool staged = A.n_images <= A.lds_images;
     if (staged)
     {
         for (uint32_t i = threadIdx.x; i < A.n_images; i += blockDim.x)
@@ -1066,6 +1067,7 @@ int ochip_dense_triangulate(ochip_dense_index *ix, const double *cam_q4, uint32_
     A.points = points;
     A.valid = valid;
     A.large = large;
+    A.lds_images = ochip_test_hook("dense_predict_unstaged") ? 0u : TRI_LDS_IMAGES; // (tests: the route of surveys above 2 048 images)
     A.n_large = large + max_large;
     hipLaunchKernelGGL(dense_triangulate_kernel, dim3((n_tracks + 127) / 128), dim3(128), 0, st, A);
     hipLaunchKernelGGL(dense_triangulate_large_kernel, dim3((max_large + 3) / 4), dim3(256), 0, st, A);

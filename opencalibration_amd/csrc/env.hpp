@@ -9,7 +9,8 @@
 //                      for every level / round 5's register strips for every level they can take, instead of the choice by
 //                      level size), sort_per_level (a launch per introsort level instead of a workgroup per segment),
 //                      host_triangulation (densifyMesh's track points by the host loop instead of ochip_dense_triangulate),
-//                      dense_predict_unstaged (the nearest-camera scan reads the camera records instead of LDS, as it does above 2 048 cameras)
+//                      dense_predict_unstaged (the nearest-camera scan and the tracks' member -> image search read the device's records instead of
+//                      their LDS copies, as they do above 2 048 cameras)
 #pragma once
 
 #include <cstdlib>
