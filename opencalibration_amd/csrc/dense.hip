@@ -907,7 +907,9 @@ int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t
             ochip_pool_put(ctx, b.first, b.second);
         return code;
     };
-    // batches of source images: bounded slot arrays (the reference walks its images in batches of OpenMP tasks too)
+    // batches of source images: bounded slot arrays (the reference walks its images in batches of OpenMP tasks too).
+    // (measured and dropped, round 5: a batch's nearest-camera pass on the context's second stream under the search of the batch
+    // before it, two sets of candidate arrays - the device phase stayed at 56.5 ms: the search fills the device by itself)
     std::vector<uint64_t> feat_base(n_images + 1);
     {
         std::vector<dense_image_meta> meta((size_t)n_images + 1);
