@@ -89,9 +89,16 @@ def test_one_rank_strong_equals_the_default_line():
             rates[mode] = line["value"]
         return rates
 
-    # (six 50 ms steps of a 200-image grid: a busy box moves one of the two runs by more than the tolerance now and then -
-    # the pair is measured once more before the test fails)
-    rates = measure()
-    if abs(rates["strong"] / rates["weak"] - 1.0) >= 0.15:
+    # (six 50 ms steps of a 200-image grid under the box's CPU quota: one of the two runs is moved by more than the tolerance
+    # now and then, in either direction.  What must hold is that neither mode is systematically slower: the best rate of
+    # each mode over up to four measurements of the pair, which a slow run cannot lower)
+    best = {"weak": 0.0, "strong": 0.0}
+    seen = []
+    for _ in range(4):
         rates = measure()
-    assert abs(rates["strong"] / rates["weak"] - 1.0) < 0.15, rates
+        seen.append(rates)
+        for mode in best:
+            best[mode] = max(best[mode], rates[mode])
+        if abs(best["strong"] / best["weak"] - 1.0) < 0.15:
+            break
+    assert abs(best["strong"] / best["weak"] - 1.0) < 0.15, seen
