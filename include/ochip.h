@@ -393,6 +393,47 @@ extern "C"
                                  uint64_t *n_blocks);
     void ochip_plane_setup_destroy(ochip_plane_setup *s);
 
+    /* ---- the NaN bootstrap of runGroundPlane as one resident launch (csrc/relax_chain.hip) -------------------------
+     * Replaces the loop of src/relax/relax.cpp:52-80: every camera of a batch that arrives without an orientation takes
+     * the orientation of the pose in front of it and is relaxed - setupGroundPlaneProblem, relaxObservedModelOnly, solve -
+     * before the next one.  The group's cameras, edges (in edges_to_optimize's order) and inlier matches are uploaded
+     * once; ochip_plane_chain_run walks the steps on the device without a host round trip in between.
+     * A step: `cam` takes the current orientation of `prev_cam` (prev_cam < 0: prev_q), the plane is the triangle tri_xy
+     * (corners in the mesh searcher's order, initializeGroundPlane :1189-1242) at height z0, the edges [0, n_filter) take
+     * part (gridFilterMatchesPerImage stops at the first edge without usable poses, :251-252).  mode 0: `cam` alone is
+     * optimised, every other camera is constant (relax.cpp:61-68: the caller puts the first edge that touches a camera
+     * without an orientation in the graph at n_filter); mode 1: every camera with cam_optimize set (relax.cpp:70-75). */
+    typedef struct ochip_plane_chain_step
+    {
+        uint32_t cam, mode, n_filter;
+        int32_t prev_cam;
+        double prev_q[4];
+        double tri_xy[6];
+        double z0;
+    } ochip_plane_chain_step;
+    typedef struct ochip_plane_chain_result
+    {
+        uint32_t steps_done; /* the steps before this one are finished and in cam_q_out */
+        int32_t status;      /* 0: every step done; 1: step `steps_done` needs the host's grid filter (a tie for a cell's best
+                                score, a match outside the cell table); 2: given up (a wait on the device ran into its limit).
+                                The caller continues from that step with its own loop. */
+        int32_t solves, iterations_total, last_iterations, last_residual_blocks; /* as ochip_relax_summary counts them */
+        double last_initial_cost, last_final_cost;
+        int32_t grid_syncs, workgroups;
+    } ochip_plane_chain_result;
+    typedef struct ochip_plane_chain ochip_plane_chain;
+    /* cam_pos [n_cams][3], cam_q [n_cams][4] (NaN: not oriented yet), cam_optimize [n_cams] (mode 1), models10 as for
+     * ochip_plane_setup_create; huber_a, prior_weight as in ochip_relax_desc.  Fails with OCHIP_EINVAL for what the chain
+     * does not take (more than 340 optimised cameras, a grid finer than 1 / 15, an edge from a camera to itself). */
+    int ochip_plane_chain_create(ochip_ctx *ctx, const ochip_plane_edge *edges, uint32_t n_edges, const ochip_plane_inlier *inliers,
+                                 uint64_t n_inliers, const double *cam_pos, const double *cam_q, const uint8_t *cam_optimize,
+                                 uint32_t n_cams, const double *models10, uint32_t n_models, double grid_fraction, double huber_a,
+                                 double prior_weight, const ochip_plane_chain_step *steps, uint32_t n_steps, ochip_plane_chain **out);
+    /* stepped != 0: one phase per launch (the test route; same code, same numbers).  cam_q_out [n_cams][4]: the state after
+     * the last finished step, normalised as RelaxProblem::solve leaves it (:1410-1413). */
+    int ochip_plane_chain_run(ochip_plane_chain *chain, int stepped, double *cam_q_out, ochip_plane_chain_result *result);
+    void ochip_plane_chain_destroy(ochip_plane_chain *chain);
+
     /* A problem (this one and the ochip_relaxg_ / ochip_relaxp_ ones below) holds device blocks and a page-locked host
        block of its context: destroy it before the context. */
     int ochip_relax_problem_create(ochip_ctx *ctx, const ochip_relax_desc *desc, ochip_relax_problem **out);

@@ -25,6 +25,7 @@ EXPORTS = [
     "ochip_relax_problem_create", "ochip_relax_problem_destroy", "ochip_relax_set_cameras_constant",
     "ochip_relax_solve", "ochip_relax_get_state", "ochip_relax_set_shard",
     "ochip_plane_setup_create", "ochip_plane_setup_override", "ochip_plane_setup_blocks", "ochip_plane_setup_destroy",
+    "ochip_plane_chain_create", "ochip_plane_chain_run", "ochip_plane_chain_destroy",
     "ochip_relaxg_problem_create", "ochip_relaxg_problem_destroy", "ochip_relaxg_set_structure_only", "ochip_relaxg_solve",
     "ochip_relaxg_get_state", "ochip_relaxg_evaluate", "ochip_relaxg_set_exchange",
     "ochip_relaxp_problem_create", "ochip_relaxp_problem_destroy", "ochip_relaxp_set_structure_only", "ochip_relaxp_solve",

@@ -380,6 +380,293 @@ void relax_setup_check_passed()
     g_setup_checked.fetch_add(1);
 }
 
+namespace
+{
+
+// initializeGroundPlane (:1189-1242) + the searcher's orientation fix-up of the single triangle, for a list of camera positions:
+// the corners in the searcher's order and the start height
+void bootstrap_plane(const std::vector<const double *> &positions, double tri_xy[6], double *z0)
+{
+    double lo[2] = {1e12, 1e12}, hi[2] = {-1e12, -1e12}, height = 0;
+    for (const double *p : positions)
+    {
+        for (int a = 0; a < 2; a++)
+        {
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+        height += p[2];
+    }
+    height /= (double)positions.size();
+    const double margin = 50;
+    height -= margin;
+    const double cx = (lo[0] + hi[0]) / 2, cy = (lo[1] + hi[1]) / 2;
+    const double spacing = std::max(hi[0] - lo[0], hi[1] - lo[1]) + margin;
+    const double c[3][2] = {{-spacing + cx, -spacing + cy}, {spacing + cx, -spacing + cy}, {0 + cx, spacing + cy}};
+    int tri[3] = {0, 1, 2};
+    if ((c[1][0] - c[0][0]) * (c[2][1] - c[0][1]) - (c[1][1] - c[0][1]) * (c[2][0] - c[0][0]) < 0) // anticlockwise(a, b, c)
+        std::swap(tri[0], tri[1]);
+    for (int i = 0; i < 3; i++)
+    {
+        tri_xy[2 * i] = c[tri[i]][0];
+        tri_xy[2 * i + 1] = c[tri[i]][1];
+    }
+    *z0 = height;
+}
+
+// The loop of runGroundPlane over the poses without an orientation (src/relax/relax.cpp:52-80) as one resident launch on the
+// device (ochip_plane_chain_*, csrc/relax_chain.hip).  Returns 1: the poses up to *resume_pose are done (== nodes.size():
+// all of them), 0: not taken (something the chain does not do: the caller's loop runs from the first pose), -1: error.
+int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,
+                        const std::vector<size_t> &edges_to_optimize, RelaxTimers *timers, std::string *error, size_t *resume_pose)
+{
+    const auto t_begin = clk::now();
+    const bool just_this = graph.size_nodes() > 2 * nodes.size(); // relax.cpp:61
+    // poses: the first pose of a node is the one that is optimised (relax_problem.cpp:150-154)
+    std::unordered_map<size_t, size_t> first_pose;
+    std::vector<size_t> stepped;
+    for (size_t i = 0; i < nodes.size(); i++)
+    {
+        const bool first = first_pose.emplace(nodes[i].node_id, i).second;
+        if (hasnan4(nodes[i].orientation))
+        {
+            if (!first)
+                return 0; // a second pose of a node without an orientation: the host loop knows what that means
+            stepped.push_back(i);
+        }
+    }
+    if (stepped.empty())
+        return 0;
+    auto graph_finite = [&](size_t node_id) -> const MeasurementGraph::Node * {
+        const MeasurementGraph::Node *n = graph.getNode(node_id);
+        return n != nullptr && finite4(n->payload.orientation) && finite3(n->payload.position) ? n : nullptr;
+    };
+    std::vector<double> cam_pos, cam_q;
+    std::vector<uint8_t> cam_opt;
+    std::unordered_map<size_t, uint32_t> cam_of_node;
+    std::vector<uint32_t> pose_cam(nodes.size(), UINT32_MAX);
+    auto push_cam = [&](size_t node_id, const double *pos, const double *q, bool optimise) {
+        const uint32_t c = (uint32_t)cam_opt.size();
+        cam_pos.insert(cam_pos.end(), pos, pos + 3);
+        cam_q.insert(cam_q.end(), q, q + 4);
+        cam_opt.push_back(optimise ? 1 : 0);
+        cam_of_node.emplace(node_id, c);
+        return c;
+    };
+    if (just_this)
+    {
+        for (size_t i : stepped)
+        {
+            if (graph_finite(nodes[i].node_id))
+                return 0; // (a pose without an orientation whose graph node has one: two cameras for one node)
+            pose_cam[i] = push_cam(nodes[i].node_id, nodes[i].position, nodes[i].orientation, false);
+        }
+    }
+    else
+        for (size_t i = 0; i < nodes.size(); i++)
+            if (first_pose.at(nodes[i].node_id) == i)
+                pose_cam[i] = push_cam(nodes[i].node_id, nodes[i].position, nodes[i].orientation, true);
+    const uint32_t n_pose_cams = (uint32_t)cam_opt.size();
+    if (!just_this && n_pose_cams > 330)
+        return 0; // (the chain's dense system ends at 1 023 unknowns)
+    auto cam_of = [&](size_t node_id) -> uint32_t {
+        auto it = cam_of_node.find(node_id);
+        if (it != cam_of_node.end())
+            return it->second;
+        const MeasurementGraph::Node *n = graph_finite(node_id);
+        return n ? push_cam(node_id, n->payload.position, n->payload.orientation, false) : UINT32_MAX;
+    };
+    // the edges in the whitelist's order; gridFilterMatchesPerImage stops at the first one without usable poses
+    std::unordered_map<const CameraModel *, uint32_t> model_index;
+    std::vector<double> models10;
+    auto model_of = [&](const CameraModel *m) {
+        auto it = model_index.find(m);
+        if (it != model_index.end())
+            return it->second;
+        const double row[10] = {m->focal_length_pixels,  m->principle_point[0],   m->principle_point[1],       m->radial_distortion[0],
+                                m->radial_distortion[1], m->radial_distortion[2], m->tangential_distortion[0], m->tangential_distortion[1],
+                                (double)m->pixels_cols,  (double)m->pixels_rows};
+        models10.insert(models10.end(), row, row + 10);
+        return model_index.emplace(m, (uint32_t)model_index.size()).first->second;
+    };
+    std::vector<ochip_plane_edge> pe;
+    std::vector<const MeasurementGraph::Edge *> pe_edge;
+    uint64_t n_inliers = 0;
+    // mode 0: the first edge that is usable for one stepped camera only (idx1, that camera u1), the first one for another (idx2)
+    size_t idx1 = SIZE_MAX, idx2 = SIZE_MAX, u1 = 0;
+    for (size_t k = 0; k < edges_to_optimize.size(); k++)
+    {
+        const MeasurementGraph::Edge *e = graph.getEdge(edges_to_optimize[k]);
+        if (e == nullptr)
+            continue;
+        if (e->source == e->dest)
+            return 0;
+        const uint32_t ca = cam_of(e->source), cb = cam_of(e->dest);
+        if (ca == UINT32_MAX || cb == UINT32_MAX)
+            break; // never usable: no step gets past it
+        if (just_this)
+        {
+            const bool sa = ca < n_pose_cams, sb = cb < n_pose_cams; // a stepped camera: usable only while it is the step's own
+            if (sa && sb)
+                break;
+            if (sa || sb)
+            {
+                const size_t u = sa ? e->source : e->dest;
+                if (idx1 == SIZE_MAX)
+                    idx1 = pe.size(), u1 = u;
+                else if (u != u1)
+                {
+                    idx2 = pe.size();
+                    break;
+                }
+            }
+        }
+        const camera_relations &rel = e->payload;
+        ochip_plane_edge r{};
+        r.cam_a = ca;
+        r.cam_b = cb;
+        r.model_a = model_of(graph.getNode(e->source)->payload.model.get());
+        r.model_b = model_of(graph.getNode(e->dest)->payload.model.get());
+        r.n_inliers = (uint32_t)rel.inlier_matches.size();
+        r.flags = rel.relationType == camera_relations::RelationType::HOMOGRAPHY ? 1u : 0u;
+        r.inlier_offset = n_inliers;
+        std::memcpy(r.H, rel.ransac_relation, sizeof r.H);
+        n_inliers += r.n_inliers;
+        pe.push_back(r);
+        pe_edge.push_back(e);
+    }
+    struct staging
+    {
+        ochip_ctx *ctx;
+        void *p = nullptr;
+        ~staging()
+        {
+            if (p)
+                ochip_host_free(ctx, p);
+        }
+    } inl{ctx};
+    if (ochip_host_alloc(ctx, (n_inliers ? n_inliers : 1) * sizeof(ochip_plane_inlier), &inl.p) != OCHIP_OK)
+    {
+        if (error)
+            *error = std::string("ochip_host_alloc: ") + ochip_last_error(ctx);
+        return -1;
+    }
+    ochip_plane_inlier *const rec = static_cast<ochip_plane_inlier *>(inl.p);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (size_t j = 0; j < pe.size(); j++)
+    {
+        const camera_relations &rel = pe_edge[j]->payload;
+        ochip_plane_inlier *o = rec + pe[j].inlier_offset;
+        for (size_t idx = 0; idx < rel.inlier_matches.size(); idx++)
+        {
+            const feature_match_denormalized &m = rel.inlier_matches[idx];
+            o[idx].px1[0] = m.pixel_1[0], o[idx].px1[1] = m.pixel_1[1];
+            o[idx].px2[0] = m.pixel_2[0], o[idx].px2[1] = m.pixel_2[1];
+            o[idx].descriptor_score = m.match_index < rel.matches.size() ? 1.0 - rel.matches[m.match_index].distance : 1.0;
+        }
+    }
+    // the steps
+    std::vector<ochip_plane_chain_step> steps(stepped.size());
+    double tri_all[6], z_all = 0;
+    if (!just_this)
+    {
+        std::vector<const double *> positions;
+        for (size_t i = 0; i < nodes.size(); i++)
+            if (pose_cam[i] != UINT32_MAX)
+                positions.push_back(nodes[i].position);
+        bootstrap_plane(positions, tri_all, &z_all);
+    }
+    const double down[4] = {std::sin(M_PI / 2), 0.0, 0.0, std::cos(M_PI / 2)}; // DOWN_ORIENTED_NORTH, relax.cpp:12
+    std::vector<char> is_stepped(nodes.size(), 0);
+    for (size_t i : stepped)
+        is_stepped[i] = 1;
+    for (size_t k = 0; k < stepped.size(); k++)
+    {
+        const size_t i = stepped[k];
+        ochip_plane_chain_step &st = steps[k];
+        st.cam = pose_cam[i];
+        st.mode = just_this ? 0u : 1u;
+        st.prev_cam = -1;
+        if (i == 0)
+            std::memcpy(st.prev_q, down, sizeof down);
+        else
+        {
+            // previous = the pose in front, as it is when this step starts: a camera of the chain's state where the chain moves
+            // it (a stepped camera; in mode 1 every first pose), else what the pose list holds
+            const bool moving = pose_cam[i - 1] != UINT32_MAX && (just_this ? is_stepped[i - 1] != 0 : true);
+            if (moving)
+                st.prev_cam = (int32_t)pose_cam[i - 1];
+            std::memcpy(st.prev_q, nodes[i - 1].orientation, sizeof st.prev_q);
+        }
+        if (just_this)
+        {
+            bootstrap_plane({nodes[i].position}, st.tri_xy, &st.z0);
+            const size_t own = nodes[i].node_id == u1 && idx1 != SIZE_MAX ? idx2 : idx1;
+            st.n_filter = (uint32_t)std::min(pe.size(), own);
+        }
+        else
+        {
+            std::memcpy(st.tri_xy, tri_all, sizeof tri_all);
+            st.z0 = z_all;
+            st.n_filter = (uint32_t)pe.size();
+        }
+    }
+    ochip_plane_chain *chain = nullptr;
+    const int crc = ochip_plane_chain_create(ctx, pe.data(), (uint32_t)pe.size(), rec, n_inliers, cam_pos.data(), cam_q.data(), cam_opt.data(),
+                                             (uint32_t)cam_opt.size(), models10.data(), (uint32_t)model_index.size(), 0.15, 1 * M_PI / 180, 1e-3,
+                                             steps.data(), (uint32_t)steps.size(), &chain);
+    if (crc == OCHIP_EINVAL)
+        return 0; // (not for the chain: the host loop)
+    if (crc != OCHIP_OK)
+    {
+        if (error)
+            *error = std::string("ochip_plane_chain_create: ") + ochip_last_error(ctx);
+        return -1;
+    }
+    if (timers)
+        timers->setup_host += since(t_begin);
+    const auto t_run = clk::now();
+    std::vector<double> q_out(cam_q.size());
+    ochip_plane_chain_result res{};
+    const int rrc = ochip_plane_chain_run(chain, ochip_test_hook("chain_stepped") ? 1 : 0, q_out.data(), &res);
+    ochip_plane_chain_destroy(chain);
+    if (rrc != OCHIP_OK)
+    {
+        if (error)
+            *error = std::string("ochip_plane_chain_run: ") + ochip_last_error(ctx);
+        return -1;
+    }
+    if (ochip_verbose("relax"))
+        fprintf(stderr, "[relax chain] %zu poses without an orientation (%s), %zu edges, %llu inlier matches: %u steps done (status %d), %d solves, "
+                        "%d iterations, %d grid syncs on %d workgroups, %.3f ms\n",
+                stepped.size(), just_this ? "one at a time" : "with the group", pe.size(), (unsigned long long)n_inliers, res.steps_done, res.status,
+                res.solves, res.iterations_total, res.grid_syncs, res.workgroups, since(t_run) * 1e3);
+    if (timers)
+    {
+        timers->device += since(t_run);
+        timers->solves += res.solves;
+        timers->iterations_total += res.iterations_total;
+        timers->last_iterations = res.last_iterations;
+        timers->last_initial_cost = res.last_initial_cost;
+        timers->last_final_cost = res.last_final_cost;
+        timers->last_residual_blocks = res.last_residual_blocks;
+    }
+    // what relax() wrote back after every finished step
+    if (just_this)
+    {
+        for (size_t k = 0; k < res.steps_done && k < stepped.size(); k++)
+            std::memcpy(nodes[stepped[k]].orientation, &q_out[4 * (size_t)pose_cam[stepped[k]]], 4 * sizeof(double));
+    }
+    else if (res.steps_done > 0)
+        for (size_t i = 0; i < nodes.size(); i++)
+            if (pose_cam[i] != UINT32_MAX)
+                std::memcpy(nodes[i].orientation, &q_out[4 * (size_t)pose_cam[i]], 4 * sizeof(double));
+    *resume_pose = res.steps_done >= stepped.size() ? nodes.size() : stepped[res.steps_done];
+    return 1;
+}
+
+} // namespace
+
 bool relax_ground_plane(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,
                         const std::vector<size_t> &edges_to_optimize, surface_model_plane *surface,
                         RelaxTimers *timers, std::string *error, const RelaxShard *shard)
@@ -402,8 +689,26 @@ bool relax_ground_plane(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
     };
     // DOWN_ORIENTED_NORTH = Quaterniond(AngleAxisd(M_PI, UnitX)), relax.cpp:12
     double previous[4] = {std::sin(M_PI / 2), 0.0, 0.0, std::cos(M_PI / 2)};
-    for (auto &node : nodes)
+    // the poses without an orientation: one resident launch walks them on the device (csrc/relax_chain.hip); what it does not
+    // take - and OCHIP_TEST_HOOKS=host_bootstrap - goes through the loop below, a problem and two solves per camera
+    size_t first = 0;
+    const bool sharded = shard && (shard->world > 1 || shard->exchange);
+    if (!sharded && !ochip_test_hook("host_bootstrap"))
     {
+        size_t resume = 0;
+        const int brc = bootstrap_on_device(ctx, graph, nodes, edges_to_optimize, timers, error, &resume);
+        if (brc < 0)
+            return false;
+        if (brc > 0)
+        {
+            first = resume;
+            if (first > 0 && first <= nodes.size())
+                std::memcpy(previous, nodes[first - 1].orientation, sizeof previous);
+        }
+    }
+    for (size_t i = first; i < nodes.size(); i++)
+    {
+        NodePose &node = nodes[i];
         if (hasnan4(node.orientation))
         {
             std::memcpy(node.orientation, previous, sizeof previous);
