@@ -121,6 +121,25 @@ extern "C"
                                    const double *positions, const double *orientations, uint64_t *node_ids_out,
                                    double *totals2, double *link_timers8, double *stage_seconds2);
 
+    /* ---- INITIAL_PROCESSING with the reference's software pipelining (Pipeline::Impl::initial_processing,
+     *      src/pipeline/pipeline.cpp:522-570; opencalibration_amd/csrc/host/initial_processing.cpp): one step loads (extracts)
+     *      the batch it is given, links the batch of the step before against everything loaded before it, and relaxes the
+     *      batch of two steps before as ONE group with two rings of context cameras ({ORIENTATION, GROUND_PLANE},
+     *      disable_parallelism, :545-546) - the three stages' runners side by side (:548-556), finalized in the reference's
+     *      order (:558-560).  Images arrive WITHOUT orientations (types/image.hpp:31); the relax stage initialises them
+     *      (src/relax/relax.cpp:44-87).  n_images == 0 drains the pipeline: call until och_initial_processing_pending() is 0.
+     *      sequential != 0: the three stages one after the other on the calling thread (the test route: the same graph).
+     *      stats16 (may be NULL): seconds of the step, its init, its runners, its finalize; seconds of the load, link and
+     *      relax runners; features and sparse features extracted; images linked and relaxed in this step; the relax
+     *      stage's solves, LM iterations, host set-up seconds, device seconds; images handed to the next step's relax. */
+    typedef struct och_initial_processing och_initial_processing;
+    och_initial_processing *och_initial_processing_create(och_graph *g, ochip_ctx *ctx);
+    void och_initial_processing_destroy(och_initial_processing *ip);
+    int och_initial_processing_pending(const och_initial_processing *ip);
+    int och_initial_processing_step(och_initial_processing *ip, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
+                                    uint32_t max_keypoints, int images_on_device, uint32_t model, const double *positions,
+                                    int sequential, uint64_t *node_ids_out, double *stats16);
+
     /* ---- ONE survey's load + link stages over `world` ranks, one process per GPU (opencalibration_amd/csrc/host/shard_link.cpp).
      *      The reference parallelises one survey over its workers: one load closure per image
      *      (src/pipeline/load_stage.cpp:36-50), one link closure per directed pair (src/pipeline/link_stage.cpp:75-112),

@@ -402,7 +402,9 @@ extern "C"
      * (corners in the mesh searcher's order, initializeGroundPlane :1189-1242) at height z0, the edges [0, n_filter) take
      * part (gridFilterMatchesPerImage stops at the first edge without usable poses, :251-252).  mode 0: `cam` alone is
      * optimised, every other camera is constant (relax.cpp:61-68: the caller puts the first edge that touches a camera
-     * without an orientation in the graph at n_filter); mode 1: every camera with cam_optimize set (relax.cpp:70-75). */
+     * without an orientation in the graph at n_filter); mode 1: every camera with cam_optimize set (relax.cpp:70-75);
+     * mode 2: the group's own solve behind the loop (relax.cpp:81-84): as mode 1, but nobody takes an orientation (cam, prev_*
+     * unused). */
     typedef struct ochip_plane_chain_step
     {
         uint32_t cam, mode, n_filter;
@@ -420,6 +422,7 @@ extern "C"
         int32_t solves, iterations_total, last_iterations, last_residual_blocks; /* as ochip_relax_summary counts them */
         double last_initial_cost, last_final_cost;
         int32_t grid_syncs, workgroups;
+        double plane_z[3];   /* the last step's corner heights, in tri_xy's order */
     } ochip_plane_chain_result;
     typedef struct ochip_plane_chain ochip_plane_chain;
     /* cam_pos [n_cams][3], cam_q [n_cams][4] (NaN: not oriented yet), cam_optimize [n_cams] (mode 1), models10 as for

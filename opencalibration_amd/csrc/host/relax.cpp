@@ -384,8 +384,8 @@ namespace
 {
 
 // initializeGroundPlane (:1189-1242) + the searcher's orientation fix-up of the single triangle, for a list of camera positions:
-// the corners in the searcher's order and the start height
-void bootstrap_plane(const std::vector<const double *> &positions, double tri_xy[6], double *z0)
+// the corners in the searcher's order (corner_of[i]: which corner of the surface model stands at place i) and the start height
+void bootstrap_plane(const std::vector<const double *> &positions, double tri_xy[6], double *z0, int corner_of[3] = nullptr)
 {
     double lo[2] = {1e12, 1e12}, hi[2] = {-1e12, -1e12}, height = 0;
     for (const double *p : positions)
@@ -410,17 +410,23 @@ void bootstrap_plane(const std::vector<const double *> &positions, double tri_xy
     {
         tri_xy[2 * i] = c[tri[i]][0];
         tri_xy[2 * i + 1] = c[tri[i]][1];
+        if (corner_of)
+            corner_of[i] = tri[i];
     }
     *z0 = height;
 }
 
-// The loop of runGroundPlane over the poses without an orientation (src/relax/relax.cpp:52-80) as one resident launch on the
-// device (ochip_plane_chain_*, csrc/relax_chain.hip).  Returns 1: the poses up to *resume_pose are done (== nodes.size():
-// all of them), 0: not taken (something the chain does not do: the caller's loop runs from the first pose), -1: error.
+// runGroundPlane (src/relax/relax.cpp:44-87) as one resident launch on the device (ochip_plane_chain_*, csrc/relax_chain.hip):
+// the loop over the poses without an orientation - each takes the orientation of the pose in front of it and is relaxed,
+// on its own against the oriented cameras of the graph or together with the group - and the group's own solve behind it.
+// Returns 1: the poses up to *resume_pose are done (== nodes.size(): all of them; *all_done: the group's solve too, `surface`
+// is written), 0: not taken (something the chain does not do: the caller's loop runs from the first pose), -1: error.
 int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<NodePose> &nodes,
-                        const std::vector<size_t> &edges_to_optimize, RelaxTimers *timers, std::string *error, size_t *resume_pose)
+                        const std::vector<size_t> &edges_to_optimize, surface_model_plane *surface, RelaxTimers *timers,
+                        std::string *error, size_t *resume_pose, bool *all_done)
 {
     const auto t_begin = clk::now();
+    *all_done = false;
     const bool just_this = graph.size_nodes() > 2 * nodes.size(); // relax.cpp:61
     // poses: the first pose of a node is the one that is optimised (relax_problem.cpp:150-154)
     std::unordered_map<size_t, size_t> first_pose;
@@ -441,40 +447,49 @@ int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
         const MeasurementGraph::Node *n = graph.getNode(node_id);
         return n != nullptr && finite4(n->payload.orientation) && finite3(n->payload.position) ? n : nullptr;
     };
+    // cameras: the first pose of every node (the group's solve optimises them all), then the graph's oriented cameras the
+    // edges reach.  While one camera is relaxed on its own the others stand as the GRAPH has them (nodeid2poseopt, :182-232):
+    // that is what the pose list holds too - RelaxGroup::init copies it - and where it is not, the host loop runs
     std::vector<double> cam_pos, cam_q;
-    std::vector<uint8_t> cam_opt;
+    std::vector<uint8_t> cam_opt, cam_stepped;
     std::unordered_map<size_t, uint32_t> cam_of_node;
     std::vector<uint32_t> pose_cam(nodes.size(), UINT32_MAX);
-    auto push_cam = [&](size_t node_id, const double *pos, const double *q, bool optimise) {
+    auto push_cam = [&](size_t node_id, const double *pos, const double *q, bool optimise, bool is_stepped) {
         const uint32_t c = (uint32_t)cam_opt.size();
         cam_pos.insert(cam_pos.end(), pos, pos + 3);
         cam_q.insert(cam_q.end(), q, q + 4);
         cam_opt.push_back(optimise ? 1 : 0);
+        cam_stepped.push_back(is_stepped ? 1 : 0);
         cam_of_node.emplace(node_id, c);
         return c;
     };
-    if (just_this)
+    std::vector<char> is_stepped(nodes.size(), 0);
+    for (size_t i : stepped)
+        is_stepped[i] = 1;
+    for (size_t i = 0; i < nodes.size(); i++)
     {
-        for (size_t i : stepped)
+        if (first_pose.at(nodes[i].node_id) != i)
+            continue;
+        if (just_this)
         {
-            if (graph_finite(nodes[i].node_id))
-                return 0; // (a pose without an orientation whose graph node has one: two cameras for one node)
-            pose_cam[i] = push_cam(nodes[i].node_id, nodes[i].position, nodes[i].orientation, false);
+            const MeasurementGraph::Node *n = graph.getNode(nodes[i].node_id);
+            if (n == nullptr)
+                return 0;
+            if (is_stepped[i] ? graph_finite(nodes[i].node_id) != nullptr
+                              : (std::memcmp(n->payload.orientation, nodes[i].orientation, sizeof nodes[i].orientation) != 0 ||
+                                 std::memcmp(n->payload.position, nodes[i].position, sizeof nodes[i].position) != 0))
+                return 0;
         }
+        pose_cam[i] = push_cam(nodes[i].node_id, nodes[i].position, nodes[i].orientation, true, is_stepped[i] != 0);
     }
-    else
-        for (size_t i = 0; i < nodes.size(); i++)
-            if (first_pose.at(nodes[i].node_id) == i)
-                pose_cam[i] = push_cam(nodes[i].node_id, nodes[i].position, nodes[i].orientation, true);
-    const uint32_t n_pose_cams = (uint32_t)cam_opt.size();
-    if (!just_this && n_pose_cams > 330)
+    if (cam_opt.size() > 330)
         return 0; // (the chain's dense system ends at 1 023 unknowns)
     auto cam_of = [&](size_t node_id) -> uint32_t {
         auto it = cam_of_node.find(node_id);
         if (it != cam_of_node.end())
             return it->second;
         const MeasurementGraph::Node *n = graph_finite(node_id);
-        return n ? push_cam(node_id, n->payload.position, n->payload.orientation, false) : UINT32_MAX;
+        return n ? push_cam(node_id, n->payload.position, n->payload.orientation, false, false) : UINT32_MAX;
     };
     // the edges in the whitelist's order; gridFilterMatchesPerImage stops at the first one without usable poses
     std::unordered_map<const CameraModel *, uint32_t> model_index;
@@ -492,8 +507,10 @@ int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
     std::vector<ochip_plane_edge> pe;
     std::vector<const MeasurementGraph::Edge *> pe_edge;
     uint64_t n_inliers = 0;
-    // mode 0: the first edge that is usable for one stepped camera only (idx1, that camera u1), the first one for another (idx2)
-    size_t idx1 = SIZE_MAX, idx2 = SIZE_MAX, u1 = 0;
+    // one camera at a time: a camera without an orientation in the graph is usable only as the step's own camera.  idx1: the
+    // first edge with such a camera (u1), idx2: the first edge with another one - or with two of them
+    size_t idx1 = SIZE_MAX, idx2 = SIZE_MAX;
+    uint32_t u1 = UINT32_MAX;
     for (size_t k = 0; k < edges_to_optimize.size(); k++)
     {
         const MeasurementGraph::Edge *e = graph.getEdge(edges_to_optimize[k]);
@@ -503,22 +520,19 @@ int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
             return 0;
         const uint32_t ca = cam_of(e->source), cb = cam_of(e->dest);
         if (ca == UINT32_MAX || cb == UINT32_MAX)
-            break; // never usable: no step gets past it
-        if (just_this)
+            break; // never usable: nothing gets past it
+        if (idx2 == SIZE_MAX)
         {
-            const bool sa = ca < n_pose_cams, sb = cb < n_pose_cams; // a stepped camera: usable only while it is the step's own
+            const bool sa = cam_stepped[ca] != 0, sb = cam_stepped[cb] != 0;
             if (sa && sb)
-                break;
-            if (sa || sb)
+                idx2 = pe.size(), idx1 = std::min(idx1, idx2);
+            else if (sa || sb)
             {
-                const size_t u = sa ? e->source : e->dest;
+                const uint32_t u = sa ? ca : cb;
                 if (idx1 == SIZE_MAX)
                     idx1 = pe.size(), u1 = u;
                 else if (u != u1)
-                {
                     idx2 = pe.size();
-                    break;
-                }
             }
         }
         const camera_relations &rel = e->payload;
@@ -565,21 +579,20 @@ int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
             o[idx].descriptor_score = m.match_index < rel.matches.size() ? 1.0 - rel.matches[m.match_index].distance : 1.0;
         }
     }
-    // the steps
-    std::vector<ochip_plane_chain_step> steps(stepped.size());
+    // the steps: the poses without an orientation in the list's order, then the group's own solve
+    std::vector<ochip_plane_chain_step> steps;
+    steps.reserve(stepped.size() + 1);
+    steps.resize(stepped.size());
     double tri_all[6], z_all = 0;
-    if (!just_this)
+    int corner_of[3] = {0, 1, 2};
     {
         std::vector<const double *> positions;
         for (size_t i = 0; i < nodes.size(); i++)
             if (pose_cam[i] != UINT32_MAX)
                 positions.push_back(nodes[i].position);
-        bootstrap_plane(positions, tri_all, &z_all);
+        bootstrap_plane(positions, tri_all, &z_all, corner_of);
     }
     const double down[4] = {std::sin(M_PI / 2), 0.0, 0.0, std::cos(M_PI / 2)}; // DOWN_ORIENTED_NORTH, relax.cpp:12
-    std::vector<char> is_stepped(nodes.size(), 0);
-    for (size_t i : stepped)
-        is_stepped[i] = 1;
     for (size_t k = 0; k < stepped.size(); k++)
     {
         const size_t i = stepped[k];
@@ -592,7 +605,7 @@ int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
         else
         {
             // previous = the pose in front, as it is when this step starts: a camera of the chain's state where the chain moves
-            // it (a stepped camera; in mode 1 every first pose), else what the pose list holds
+            // it (a stepped camera; with the group every first pose), else what the pose list holds
             const bool moving = pose_cam[i - 1] != UINT32_MAX && (just_this ? is_stepped[i - 1] != 0 : true);
             if (moving)
                 st.prev_cam = (int32_t)pose_cam[i - 1];
@@ -601,7 +614,7 @@ int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
         if (just_this)
         {
             bootstrap_plane({nodes[i].position}, st.tri_xy, &st.z0);
-            const size_t own = nodes[i].node_id == u1 && idx1 != SIZE_MAX ? idx2 : idx1;
+            const size_t own = pose_cam[i] == u1 ? idx2 : idx1;
             st.n_filter = (uint32_t)std::min(pe.size(), own);
         }
         else
@@ -610,6 +623,17 @@ int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
             st.z0 = z_all;
             st.n_filter = (uint32_t)pe.size();
         }
+    }
+    {
+        ochip_plane_chain_step st{}; // runGroundPlane's last problem (relax.cpp:81-84)
+        st.cam = 0;
+        st.mode = 2u;
+        st.prev_cam = -1;
+        std::memcpy(st.prev_q, down, sizeof down);
+        std::memcpy(st.tri_xy, tri_all, sizeof tri_all);
+        st.z0 = z_all;
+        st.n_filter = (uint32_t)pe.size();
+        steps.push_back(st);
     }
     ochip_plane_chain *chain = nullptr;
     const int crc = ochip_plane_chain_create(ctx, pe.data(), (uint32_t)pe.size(), rec, n_inliers, cam_pos.data(), cam_q.data(), cam_opt.data(),
@@ -637,8 +661,8 @@ int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
         return -1;
     }
     if (ochip_verbose("relax"))
-        fprintf(stderr, "[relax chain] %zu poses without an orientation (%s), %zu edges, %llu inlier matches: %u steps done (status %d), %d solves, "
-                        "%d iterations, %d grid syncs on %d workgroups, %.3f ms\n",
+        fprintf(stderr, "[relax chain] %zu poses without an orientation (%s) + the group, %zu edges, %llu inlier matches: %u steps done (status %d), "
+                        "%d solves, %d iterations, %d grid syncs on %d workgroups, %.3f ms\n",
                 stepped.size(), just_this ? "one at a time" : "with the group", pe.size(), (unsigned long long)n_inliers, res.steps_done, res.status,
                 res.solves, res.iterations_total, res.grid_syncs, res.workgroups, since(t_run) * 1e3);
     if (timers)
@@ -652,7 +676,8 @@ int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
         timers->last_residual_blocks = res.last_residual_blocks;
     }
     // what relax() wrote back after every finished step
-    if (just_this)
+    const bool everything = res.steps_done >= steps.size();
+    if (just_this && !everything)
     {
         for (size_t k = 0; k < res.steps_done && k < stepped.size(); k++)
             std::memcpy(nodes[stepped[k]].orientation, &q_out[4 * (size_t)pose_cam[stepped[k]]], 4 * sizeof(double));
@@ -662,6 +687,17 @@ int bootstrap_on_device(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
             if (pose_cam[i] != UINT32_MAX)
                 std::memcpy(nodes[i].orientation, &q_out[4 * (size_t)pose_cam[i]], 4 * sizeof(double));
     *resume_pose = res.steps_done >= stepped.size() ? nodes.size() : stepped[res.steps_done];
+    if (everything)
+    {
+        *all_done = true;
+        if (surface)
+            for (int i = 0; i < 3; i++)
+            {
+                surface->corner[corner_of[i]][0] = tri_all[2 * i];
+                surface->corner[corner_of[i]][1] = tri_all[2 * i + 1];
+                surface->corner[corner_of[i]][2] = res.plane_z[i];
+            }
+    }
     return 1;
 }
 
@@ -696,9 +732,12 @@ bool relax_ground_plane(ochip_ctx *ctx, const MeasurementGraph &graph, std::vect
     if (!sharded && !ochip_test_hook("host_bootstrap"))
     {
         size_t resume = 0;
-        const int brc = bootstrap_on_device(ctx, graph, nodes, edges_to_optimize, timers, error, &resume);
+        bool all_done = false;
+        const int brc = bootstrap_on_device(ctx, graph, nodes, edges_to_optimize, surface, timers, error, &resume, &all_done);
         if (brc < 0)
             return false;
+        if (all_done)
+            return true;
         if (brc > 0)
         {
             first = resume;

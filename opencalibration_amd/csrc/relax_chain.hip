@@ -50,6 +50,7 @@ constexpr int N_SMALL = 12;  // systems up to this size are factored by one thre
 constexpr int N_LIMIT = 1023;
 constexpr int KC = 32;       // the tile factorisation stages its operands through LDS in halves
 constexpr size_t LDS_EVAL = (size_t)4 * WV * JP * sizeof(double); // 124 928 bytes: the evaluation's share, and the most any phase needs
+constexpr int V_WAVES = 1024; // the plane block / cost are summed per virtual wavefront (chunks i, i + 1024, ...), whatever the grid is
 constexpr unsigned long long SPIN_LIMIT_TICKS = 300000000ull;    // 3 s of the 100 MHz wall clock
 
 enum
@@ -58,8 +59,7 @@ enum
     PH_SETUP,    // grid filter + residual-block list of the step's edges
     PH_EVAL,     // the residual blocks of one state: records per (edge, 64 blocks)
     PH_ASM,      // records -> J'J, J'r, cost
-    PH_BUILD,    // scaled + damped system, augmented row
-    PH_CHOL,     // tile Cholesky
+    PH_CHOL,     // tile Cholesky of the scaled + damped system (formed on the way in)
     PH_DONE
 };
 
@@ -77,17 +77,18 @@ struct chain_ctl
     int cur;                // the current state buffer and system set
     int mode, n_filter, cam;
     int n, n_active, nz, nbc, nbr, n_claims;
-    int n_blocks, n_prior;
+    int n_blocks, n_prior, n_live;
     int lm_first;
     int iter, invalid, iterations, successful, unsuccessful;
     int eval_state, eval_set, eval_cams;
     int fail_bits, chol_fail;
     int steps_done, solves, iterations_total, last_iterations, last_blocks, last_termination;
-    int syncs, pad0;
+    int syncs;
     double radius, decrease, x_cost, x_norm, gmax, mcc, step_norm2, cand_norm2;
     double initial_cost, last_initial_cost, last_final_cost;
     double plane_xy[6];
     double z[2][3];
+    double tot[10]; // the evaluation under way: the plane's block (6), its gradient (3), the cost
     // where the launch's time goes, in ticks of the 100 MHz wall clock: per phase the time from the previous sync's release
     // to the last arrival (the parallel part and the sync itself), the epilogue behind it, and how often it ran
     unsigned long long t_last, t_phase[8], t_epilogue[8], n_phase[8];
@@ -128,7 +129,8 @@ struct chain_dev
     double *scale, *gs, *lm_diag, *y;
     unsigned int *chol_sync;     // [0] claim counter, [4 + tile] flags
     unsigned int *chol_claims;   // tiles in claim order
-    double *partials;            // [workgroups][10]
+    uint32_t *live;              // [n_chunks] the chunks that hold blocks in this step, ascending
+    double *partials;            // [V_WAVES][10]
     chain_ctl *ctl;
     chain_bar *bar;
     const ochip_plane_chain_step *steps;
@@ -384,9 +386,12 @@ __device__ void phase_setup(const chain_dev &D, unsigned char *lds)
 
 // the residual blocks of one (edge, 64 blocks) chunk: relax.hip's relax_pair_eval_kernel for one trip of a wavefront
 template <bool CAMS> __device__ void eval_chunk(const chain_dev &D, const double *Q, const double *Z, const double *plane_xy, double *rec,
-                                                uint32_t chunk, double (*Jl)[JP], int lane, bool &failed, bool &failed_jac)
+                                                uint32_t chunk, double (*Jl)[JP], int lane, bool &failed, bool &failed_jac, double &entry_out,
+                                                double &cost_out)
 {
     const uint32_t e = D.chunk_edge[chunk], first = D.chunk_first[chunk], cnt = D.blk_cnt[e];
+    entry_out = 0;
+    cost_out = 0;
     if (first >= cnt)
         return;
     const ochip_plane_edge &ed = D.edges[e];
@@ -491,11 +496,13 @@ template <bool CAMS> __device__ void eval_chunk(const chain_dev &D, const double
             entry += m;
         }
         rec[lane] = entry;
+        entry_out = entry;
     }
     for (int off = 32; off >= 1; off >>= 1)
         cost += __shfl_xor(cost, off);
     if (lane == 0)
         rec[54] = cost;
+    cost_out = cost;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
@@ -521,13 +528,31 @@ __device__ void phase_eval(const chain_dev &D, unsigned char *lds)
     for (int k = 0; k < 6; k++)
         xy[k] = D.ctl->plane_xy[k];
     bool failed = false, failed_jac = false;
-    for (uint32_t c = gw; c < D.n_chunks; c += waves)
+    const uint32_t n_live = (uint32_t)ld_ctl(&D.ctl->n_live);
+    // a virtual wavefront takes the live chunks vw, vw + V_WAVES, ... and leaves the sums of their plane entries, plane
+    // gradient and cost: the serial part adds the V_WAVES sums in a fixed tree, the result does not depend on the grid
+    for (uint32_t vw = gw; vw < min((uint32_t)V_WAVES, n_live); vw += waves)
     {
-        double *rec = D.rec[set] + (size_t)c * REC;
-        if (cams)
-            eval_chunk<true>(D, Q, Z, xy, rec, c, Jl, lane, failed, failed_jac);
-        else
-            eval_chunk<false>(D, Q, Z, xy, rec, c, Jl, lane, failed, failed_jac);
+        double acc = 0, cost_acc = 0;
+        for (uint32_t i = vw; i < n_live; i += V_WAVES)
+        {
+            const uint32_t c = D.live[i];
+            double *rec = D.rec[set] + (size_t)c * REC;
+            double entry, cost;
+            if (cams)
+                eval_chunk<true>(D, Q, Z, xy, rec, c, Jl, lane, failed, failed_jac, entry, cost);
+            else
+                eval_chunk<false>(D, Q, Z, xy, rec, c, Jl, lane, failed, failed_jac, entry, cost);
+            acc += entry;
+            cost_acc += cost;
+        }
+        double *o = D.partials + (size_t)vw * 10;
+        if (lane >= 39 && lane < 45) // plane_tri(6 + i, 6 + j): entries 39 .. 44
+            o[lane - 39] = acc;
+        if (lane >= 51 && lane < 54) // the plane's gradient: entries 45 + 6 ..
+            o[6 + lane - 51] = acc;
+        if (lane == 0)
+            o[9] = cost_acc;
     }
     const int fail_bits = (__ballot(failed) ? 1 : 0) | (__ballot(failed_jac) ? 2 : 0);
     if (fail_bits && lane == 0)
@@ -637,95 +662,6 @@ __device__ void phase_asm(const chain_dev &D, unsigned char *lds)
                 }
         }
     }
-    // the plane's block (6), its gradient (3), the cost: this workgroup's chunks and cameras, a fixed tree
-    double(*wsum)[10] = reinterpret_cast<double(*)[10]>(lds);
-    double v[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t c = blockIdx.x * TG + t; c < D.n_chunks; c += gridDim.x * TG)
-    {
-        if (!chunk_live(D, c))
-            continue;
-        const double *a = R + (size_t)c * REC;
-        int k = 0;
-        for (int i = 0; i < 3; i++)
-            for (int j = i; j < 3; j++)
-                v[k++] += a[plane_tri(6 + i, 6 + j)];
-        for (int i = 0; i < 3; i++)
-            v[6 + i] += a[45 + 6 + i];
-        v[9] += a[54];
-    }
-    for (uint32_t c = blockIdx.x * TG + t; c < D.n_cams; c += gridDim.x * TG)
-        if (D.cam_prior[c] && D.cam_t[c] >= 0) // priors of constant cameras are fixed cost (not in the reduced program)
-        {
-            double r, j3[3];
-            downward_prior(Q + (size_t)c * 4, D.prior_weight, &r, j3);
-            v[9] += 0.5 * r * r;
-        }
-    __syncthreads();
-    for (int q = 0; q < 10; q++)
-    {
-        double x = v[q];
-        for (int off = 32; off >= 1; off >>= 1)
-            x += __shfl_xor(x, off);
-        if (lane == 0)
-            wsum[wv][q] = x;
-    }
-    __syncthreads();
-    if (t < 10)
-        D.partials[blockIdx.x * 10 + t] = ((wsum[0][t] + wsum[1][t]) + wsum[2][t]) + wsum[3][t];
-    __syncthreads();
-}
-
-// W = S A S + diag(damping) tile by tile, row n = S g; the factorisation's claim counter and flags cleared
-__device__ void phase_build(const chain_dev &D)
-{
-    const int t = threadIdx.x;
-    const int n = ld_ctl(&D.ctl->n), nbc = ld_ctl(&D.ctl->nbc), nbr = ld_ctl(&D.ctl->nbr), cur = ld_ctl(&D.ctl->cur);
-    const double radius = D.ctl->radius;
-    const double *A = D.A[cur], *g = D.g[cur], *diagonal = D.diagonal[cur];
-    int item = 0;
-    for (int J = 0; J < nbc; J++)
-        for (int I = J; I < nbr; I++, item++)
-        {
-            if (item % (int)gridDim.x != (int)blockIdx.x)
-                continue;
-            const int tl = tile_of(I, J);
-            if (t == 0)
-            {
-                D.chol_sync[4 + tl] = 0u;
-                if (item == 0)
-                {
-                    D.chol_sync[0] = D.chol_sync[1] = D.chol_sync[2] = D.chol_sync[3] = 0u;
-                    D.ctl->chol_fail = 0;
-                }
-            }
-            const double *a = A + ((size_t)tl << 12);
-            double *w = D.W + ((size_t)tl << 12);
-            for (int e = t; e < NB * NB; e += TG)
-            {
-                const int i = I * NB + (e >> 6), j = J * NB + (e & 63);
-                double v = 0.0;
-                if (j < n)
-                {
-                    if (i < n)
-                    {
-                        if (j <= i)
-                        {
-                            v = a[e] * D.scale[i] * D.scale[j];
-                            if (i == j)
-                            {
-                                const double dd = sqrt(diagonal[i] / radius), lm = dd * dd;
-                                D.lm_diag[i] = lm;
-                                v += lm;
-                                D.gs[i] = g[i] * D.scale[i];
-                            }
-                        }
-                    }
-                    else if (i == n)
-                        v = g[j] * D.scale[j];
-                }
-                w[e] = v;
-            }
-        }
 }
 
 // relax_lm.hip's chol_tiles_kernel on the dense lower triangle: every tile computed once (left-looking), tiles claimed in
@@ -739,8 +675,26 @@ __device__ void phase_chol(const chain_dev &D, unsigned char *lds)
     double(*colA)[NB] = reinterpret_cast<double(*)[NB]>(reinterpret_cast<unsigned char *>(Pj + 64));
     double(*rowX)[NB] = colA + 4;
     int *s_claim = reinterpret_cast<int *>(rowX + 4), *s_ready = s_claim + 1;
-    const int n = ld_ctl(&D.ctl->n), n_claims = ld_ctl(&D.ctl->n_claims);
+    const int n = ld_ctl(&D.ctl->n), n_claims = ld_ctl(&D.ctl->n_claims), cur = ld_ctl(&D.ctl->cur);
     double *W = D.W;
+    const double *A = D.A[cur];
+    // entry (r, c) of tile (I, J) of the system the factorisation starts from: S A S + the damping on the diagonal, row n =
+    // S g, zero elsewhere (what a build pass wrote into W before round 6's fold: the same expressions)
+    auto start_value = [&](int I, int J, int r, int c) -> double {
+        const int i = I * NB + r, j = J * NB + c;
+        if (j >= n)
+            return 0.0;
+        if (i < n)
+        {
+            if (j > i)
+                return 0.0;
+            double v = A[((size_t)tile_of(I, J) << 12) + (size_t)(r * NB + c)] * D.scale[i] * D.scale[j];
+            if (i == j)
+                v += D.lm_diag[i];
+            return v;
+        }
+        return i == n ? D.gs[j] : 0.0;
+    };
     unsigned int *sync = D.chol_sync, *flags = sync + 4;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = (w >> 1) * 32, wc = (w & 1) * 32;
@@ -776,7 +730,7 @@ __device__ void phase_chol(const chain_dev &D, unsigned char *lds)
                 for (int e = 0; e < 4; e++)
                 {
                     const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
-                    own[i][j][e] = (r0 + r < n_rows && c < nb) ? wt[r * NB + c] : 0.0;
+                    own[i][j][e] = (r0 + r < n_rows && c < nb) ? start_value(I, J, r, c) : 0.0;
                 }
         double *wt_d = fuse ? W + ((size_t)tile_of(I, I) << 12) : wt;
         const int nb_d = min(64, n - r0);
@@ -791,7 +745,7 @@ __device__ void phase_chol(const chain_dev &D, unsigned char *lds)
                     for (int e = 0; e < 4; e++)
                     {
                         const int r = wr + 16 * i + 4 * e + lk, c = wc + 16 * j + lr;
-                        own_d[i][j][e] = (r0 + r < n_rows && c < nb_d) ? wt_d[r * NB + c] : 0.0;
+                        own_d[i][j][e] = (r0 + r < n_rows && c < nb_d) ? start_value(I, I, r, c) : 0.0;
                     }
         }
         int ready = 0;
@@ -1057,6 +1011,7 @@ enum
     ACT_BEGIN_SOLVE,
     ACT_FINISH,
     ACT_AFTER_SOLVE,
+    ACT_AFTER_EVAL,
     ACT_AFTER_ASM,
     ACT_START_ITERATION,
     ACT_AFTER_CHOL,
@@ -1137,9 +1092,12 @@ struct epi
             C.cam = (int)st.cam;
             C.mode = (int)st.mode;
             C.n_filter = (int)st.n_filter;
-            double *q = D.q[C.cur] + 4 * (size_t)st.cam;
-            for (int k = 0; k < 4; k++)
-                q[k] = st.prev_cam >= 0 ? D.q[C.cur][4 * (size_t)st.prev_cam + k] : st.prev_q[k];
+            if (st.mode != 2u) // (mode 2: the group's own solve behind the bootstrap, relax.cpp:81-84 - nobody takes an orientation)
+            {
+                double *q = D.q[C.cur] + 4 * (size_t)st.cam;
+                for (int k = 0; k < 4; k++)
+                    q[k] = st.prev_cam >= 0 ? D.q[C.cur][4 * (size_t)st.prev_cam + k] : st.prev_q[k];
+            }
             for (int k = 0; k < 6; k++)
                 C.plane_xy[k] = st.tri_xy[k];
             for (int k = 0; k < 3; k++)
@@ -1169,6 +1127,32 @@ struct epi
             }
             __syncthreads();
             return ACT_NONE;
+        }
+        // the chunks that hold blocks, ascending: every thread takes a run of chunks, counts, an exclusive scan places them
+        {
+            const uint32_t per = (D.n_chunks + TG - 1) / TG, lo = min(D.n_chunks, t * per), hi = min(D.n_chunks, lo + per);
+            uint32_t mine = 0;
+            for (uint32_t c = lo; c < hi; c++)
+                mine += chunk_live(D, c) ? 1u : 0u;
+            uint32_t *cnt = reinterpret_cast<uint32_t *>(xs);
+            __syncthreads();
+            cnt[t] = mine;
+            __syncthreads();
+            for (int off = 1; off < TG; off <<= 1)
+            {
+                const uint32_t o = t >= off ? cnt[t - off] : 0u;
+                __syncthreads();
+                cnt[t] += o;
+                __syncthreads();
+            }
+            uint32_t at_ = cnt[t] - mine;
+            const uint32_t total = cnt[TG - 1];
+            for (uint32_t c = lo; c < hi; c++)
+                if (chunk_live(D, c))
+                    D.live[at_++] = c;
+            __syncthreads();
+            if (t == 0)
+                C.n_live = (int)total;
         }
         double priors = 0;
         const double *Q = D.q[C.cur];
@@ -1202,19 +1186,41 @@ struct epi
         __syncthreads();
         if (C.n_blocks == 0 && C.n_prior == 0)
             return ACT_AFTER_SOLVE; // RelaxProblem::solve returns before Solve (:1398-1402)
+        // tangent offsets of the active cameras, in camera order: a run of cameras per thread, an exclusive scan
+        {
+            const uint32_t per = (D.n_cams + TG - 1) / TG, lo = min(D.n_cams, t * per), hi = min(D.n_cams, lo + per);
+            uint32_t mine = 0;
+            for (uint32_t c = lo; c < hi; c++)
+                mine += (which == 1 && optimised(c) && (D.cam_blocks[c] || D.cam_prior[c])) ? 1u : 0u;
+            uint32_t *cnt = reinterpret_cast<uint32_t *>(xs);
+            __syncthreads();
+            cnt[t] = mine;
+            __syncthreads();
+            for (int off = 1; off < TG; off <<= 1)
+            {
+                const uint32_t o = t >= off ? cnt[t - off] : 0u;
+                __syncthreads();
+                cnt[t] += o;
+                __syncthreads();
+            }
+            uint32_t k = cnt[t] - mine;
+            const uint32_t total = cnt[TG - 1];
+            for (uint32_t c = lo; c < hi; c++)
+            {
+                const bool active = which == 1 && optimised(c) && (D.cam_blocks[c] || D.cam_prior[c]);
+                D.cam_t[c] = active ? (int32_t)(3 * k++) : -1;
+            }
+            __syncthreads();
+            if (t == 0)
+                C.n_active = (int)total;
+        }
+        __syncthreads();
         if (t == 0)
         {
             C.solves++;
             C.last_blocks = C.n_blocks + C.n_prior;
-            int k = 0;
-            for (uint32_t c = 0; c < D.n_cams; c++)
-            {
-                const bool active = which == 1 && optimised(c) && (D.cam_blocks[c] || D.cam_prior[c]);
-                D.cam_t[c] = active ? 3 * k++ : -1;
-            }
-            C.n_active = k;
             C.nz = C.n_blocks > 0 ? 3 : 0;
-            C.n = 3 * k + C.nz;
+            C.n = 3 * C.n_active + C.nz;
             C.nbc = (C.n + NB - 1) / NB;
             C.nbr = (C.n + 1 + NB - 1) / NB;
             C.iterations = 0;
@@ -1301,6 +1307,72 @@ struct epi
         return ACT_BEGIN_STEP;
     }
 
+    // after PH_EVAL: the virtual wavefronts' sums in a fixed tree (4 per thread, 16 threads' sums, 16 of those), the priors'
+    // cost; without camera derivatives (the plane's heights alone) nothing is left to assemble
+    __device__ int after_eval()
+    {
+        double *s1 = xs, *s2 = xs + TG * 10; // [TG][10], [10][16]
+        {
+            double v[10];
+            for (int q = 0; q < 10; q++)
+                v[q] = 0;
+            for (int r = 0; r < V_WAVES / TG; r++)
+                if (t + r * TG < C.n_live) // (a virtual wavefront without chunks leaves nothing)
+                {
+                    const double *p = D.partials + (size_t)(t + r * TG) * 10;
+                    for (int q = 0; q < 10; q++)
+                        v[q] += p[q];
+                }
+            for (int q = 0; q < 10; q++)
+                s1[t * 10 + q] = v[q];
+        }
+        __syncthreads();
+        if (t < 160)
+        {
+            const int q = t >> 4, part = t & 15;
+            double sum = 0;
+            for (int k = 0; k < 16; k++)
+                sum += s1[(part * 16 + k) * 10 + q];
+            s2[q * 16 + part] = sum;
+        }
+        __syncthreads();
+        if (t < 10)
+        {
+            double sum = 0;
+            for (int k = 0; k < 16; k++)
+                sum += s2[t * 16 + k];
+            sh[t] = sum;
+        }
+        __syncthreads();
+        const double blocks_total[10] = {sh[0], sh[1], sh[2], sh[3], sh[4], sh[5], sh[6], sh[7], sh[8], sh[9]};
+        // priors of constant cameras are fixed cost (not in the reduced program)
+        double pc = 0;
+        const double *Q = D.q[C.eval_state];
+        for (uint32_t c = t; c < D.n_cams; c += TG)
+            if (D.cam_prior[c] && D.cam_t[c] >= 0)
+            {
+                double r, j3[3];
+                downward_prior(Q + (size_t)c * 4, D.prior_weight, &r, j3);
+                pc += 0.5 * r * r;
+            }
+        const double prior_cost = reduce_sum(pc);
+        if (t == 0)
+        {
+            for (int q = 0; q < 9; q++)
+                C.tot[q] = blocks_total[q];
+            C.tot[9] = blocks_total[9] + prior_cost;
+        }
+        __syncthreads();
+        if (C.eval_cams)
+        {
+            if (t == 0)
+                C.phase = PH_ASM;
+            __syncthreads();
+            return ACT_NONE;
+        }
+        return ACT_AFTER_ASM;
+    }
+
     // after PH_ASM: the groups' partial sums in group order, then the trust-region logic
     __device__ int after_asm()
     {
@@ -1308,12 +1380,7 @@ struct epi
         double *A = D.A[set], *g = D.g[set];
         __syncthreads();
         if (t < 10)
-        {
-            double sum = 0;
-            for (unsigned int w = 0; w < gridDim.x; w++)
-                sum += D.partials[w * 10 + t];
-            sh[t] = sum;
-        }
+            sh[t] = C.tot[t];
         __syncthreads();
         const double cost = sh[9];
         if (t == 0 && C.nz)
@@ -1347,17 +1414,19 @@ struct epi
                 m = fmax(m, fabs(g[i]));
             }
             const double gmax = reduce_max(m);
-            if (t == 0)
+            double xn_part = 0;
             {
-                double xn = 0;
                 const double *Q = D.q[C.cur];
-                for (uint32_t c = 0; c < D.n_cams; c++)
+                for (uint32_t c = t; c < D.n_cams; c += TG)
                     if (D.cam_t[c] >= 0)
                         for (int k = 0; k < 4; k++)
-                            xn += Q[c * 4 + k] * Q[c * 4 + k];
-                if (C.nz)
-                    for (int i = 0; i < 3; i++)
-                        xn += C.z[C.cur][i] * C.z[C.cur][i];
+                            xn_part += Q[c * 4 + k] * Q[c * 4 + k];
+                if (t < 3 && C.nz)
+                    xn_part += C.z[C.cur][t] * C.z[C.cur][t];
+            }
+            const double xn = reduce_sum(xn_part);
+            if (t == 0)
+            {
                 C.x_norm = sqrt(xn);
                 C.x_cost = cost;
                 C.initial_cost = cost;
@@ -1453,25 +1522,57 @@ struct epi
             C.iter = iter + 1;
             C.iterations++;
             if (n > N_SMALL)
-                C.phase = PH_BUILD;
+            {
+                C.phase = PH_CHOL;
+                C.chol_fail = 0;
+            }
         }
-        __syncthreads();
         if (n > N_SMALL)
+        {
+            // what the factorisation starts from is formed tile by tile on its way in (phase_chol: start_value); here the
+            // damping D_ii^2 = diagonal_i / radius as LevenbergMarquardtStrategy forms it (sqrt, then squared), the scaled
+            // gradient, and the claim counter and tile flags back to zero
+            const double *g = D.g[cur], *diagonal = D.diagonal[cur];
+            for (int i = t; i < n; i += TG)
+            {
+                const double dd = sqrt(diagonal[i] / radius);
+                D.lm_diag[i] = dd * dd;
+                D.gs[i] = g[i] * D.scale[i];
+            }
+            const int tiles = tile_of(C.nbr, 0) + 4;
+            for (int i = t; i < tiles; i += TG)
+                D.chol_sync[i] = 0u;
+            __syncthreads();
             return ACT_NONE;
-        // a small system: scaled, damped, factored and solved by one thread
-        if (t == 0)
+        }
+        // a small system: scaled, damped, factored and solved by one thread (its entries come in one trip to memory)
+        double *sm = xs + N_LIMIT + 1; // [n][n] of A, then g, diagonal, scale
         {
             const double *A = D.A[cur], *g = D.g[cur], *diagonal = D.diagonal[cur];
+            for (int e = t; e < n * n; e += TG)
+                if (e % n <= e / n)
+                    sm[e] = A[at(e / n, e % n)];
+            for (int i = t; i < n; i += TG)
+            {
+                sm[n * n + i] = g[i];
+                sm[n * n + n + i] = diagonal[i];
+                sm[n * n + 2 * n + i] = D.scale[i];
+            }
+        }
+        __syncthreads();
+        if (t == 0)
+        {
+            const double *g = sm + n * n, *diagonal = g + n, *scale = diagonal + n;
             double Wm[N_SMALL][N_SMALL], gs[N_SMALL], lm[N_SMALL], y[N_SMALL];
             bool bad = false;
             for (int i = 0; i < n; i++)
             {
                 for (int j = 0; j <= i; j++)
-                    Wm[i][j] = A[at(i, j)] * D.scale[i] * D.scale[j];
+                    Wm[i][j] = sm[i * n + j] * scale[i] * scale[j];
                 const double dd = sqrt(diagonal[i] / radius);
                 lm[i] = dd * dd;
                 Wm[i][i] += lm[i];
-                gs[i] = g[i] * D.scale[i];
+                gs[i] = g[i] * scale[i];
             }
             for (int j = 0; j < n; j++)
             {
@@ -1671,15 +1772,10 @@ struct epi
             act = ACT_AFTER_SETUP;
             break;
         case PH_EVAL:
-            if (t == 0)
-                C.phase = PH_ASM;
+            act = ACT_AFTER_EVAL;
             break;
         case PH_ASM:
             act = ACT_AFTER_ASM;
-            break;
-        case PH_BUILD:
-            if (t == 0)
-                C.phase = PH_CHOL;
             break;
         case PH_CHOL:
             act = ACT_AFTER_CHOL;
@@ -1705,6 +1801,9 @@ struct epi
                 break;
             case ACT_AFTER_SOLVE:
                 act = after_solve();
+                break;
+            case ACT_AFTER_EVAL:
+                act = after_eval();
                 break;
             case ACT_AFTER_ASM:
                 act = after_asm();
@@ -1752,9 +1851,6 @@ __global__ __launch_bounds__(TG) void plane_chain_kernel(chain_dev D, int steppe
             break;
         case PH_ASM:
             phase_asm(D, lds);
-            break;
-        case PH_BUILD:
-            phase_build(D);
             break;
         case PH_CHOL:
             phase_chol(D, lds);
@@ -1868,7 +1964,7 @@ int ochip_plane_chain_create(ochip_ctx *ctx, const ochip_plane_edge *edges, uint
             edges[e].model_b >= n_models || edges[e].inlier_offset + edges[e].n_inliers > n_inliers)
             return ochip_fail(ctx, OCHIP_EINVAL, "ochip_plane_chain_create: edge %u is out of range (or links a camera to itself)", e);
     for (uint32_t s = 0; s < n_steps; s++)
-        if (steps[s].cam >= n_cams || steps[s].mode > 1u || steps[s].n_filter > n_edges || steps[s].prev_cam >= (int32_t)n_cams)
+        if (steps[s].cam >= n_cams || steps[s].mode > 2u || steps[s].n_filter > n_edges || steps[s].prev_cam >= (int32_t)n_cams)
             return ochip_fail(ctx, OCHIP_EINVAL, "ochip_plane_chain_create: step %u is out of range", s);
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -2037,9 +2133,19 @@ int ochip_plane_chain_create(ochip_ctx *ctx, const ochip_plane_edge *edges, uint
     unsigned int grid = (unsigned int)std::max(1, ctx->prop.multiProcessorCount / 2);
     if (const char *env = std::getenv("OCHIP_CHAIN_WORKGROUPS"))
         grid = (unsigned int)std::max(1, std::min(std::atoi(env), ctx->prop.multiProcessorCount * per_cu));
-    grid = std::min(grid, std::max(1u, (n_chunks + 3) / 4));
+    {
+        // a wavefront per chunk of the edges that ever take part: a batch whose cameras only have their priors (the usual
+        // case once the graph is more than twice the group, relax.cpp:61-68) runs on ONE workgroup
+        uint32_t most_edges = 0, used_chunks = 0;
+        for (uint32_t s = 0; s < n_steps; s++)
+            most_edges = std::max(most_edges, steps[s].n_filter);
+        for (uint32_t c = 0; c < n_chunks; c++)
+            used_chunks += chunk_edge[c] < most_edges ? 1u : 0u;
+        grid = std::min(grid, std::max(1u, (used_chunks + 3) / 4));
+    }
     c->grid = grid;
-    D.partials = (double *)dev((size_t)grid * 10 * 8);
+    D.partials = (double *)dev((size_t)V_WAVES * 10 * 8);
+    D.live = (uint32_t *)dev((size_t)n_chunks * 4);
     D.ctl = (chain_ctl *)dev(sizeof(chain_ctl));
     D.bar = (chain_bar *)dev(sizeof(chain_bar));
     if (rc == OCHIP_OK && ochip_host_alloc(ctx, sizeof(chain_ctl) + 16 + (size_t)n_cams * 32, (void **)&c->ctl_host) != OCHIP_OK)
@@ -2053,6 +2159,8 @@ int ochip_plane_chain_create(ochip_ctx *ctx, const ochip_plane_edge *edges, uint
         hipError_t e = hipMemcpyAsync(D.ctl, c->ctl_host, sizeof(chain_ctl), hipMemcpyHostToDevice, st);
         if (e == hipSuccess)
             e = hipMemsetAsync(D.bar, 0, sizeof(chain_bar), st);
+        if (e == hipSuccess) // (rows of a last, partial row block that no factorisation writes are read as operands: finite, once)
+            e = hipMemsetAsync(D.W, 0, tile_doubles * 8, st);
         if (e == hipSuccess)
             e = hipMemcpyAsync(D.q[1], D.q[0], (size_t)n_cams * 32, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess)
@@ -2124,9 +2232,11 @@ int ochip_plane_chain_run(ochip_plane_chain *c, int stepped, double *cam_q_out, 
     result->last_final_cost = C.last_final_cost;
     result->grid_syncs = C.syncs;
     result->workgroups = c->grid;
+    for (int i = 0; i < 3; i++)
+        result->plane_z[i] = C.z[C.cur][i];
     if (ochip_verbose("relax"))
     {
-        static const char *names[7] = {"rays", "set-up", "evaluate", "assemble", "build", "factor", "-"};
+        static const char *names[7] = {"rays", "set-up", "evaluate", "assemble", "factor", "-", "-"};
         for (int p = 0; p < PH_DONE; p++)
             if (C.n_phase[p])
                 fprintf(stderr, "[relax chain]   %-9s %7llu times, parallel part + sync %9.3f ms (%6.1f us each), serial part behind it %9.3f ms (%6.1f us each)\n",

@@ -148,6 +148,12 @@ def load():
         L.och_graph_load_images.argtypes = [vp, vp, vp, u32, C.c_int, C.c_int, u32, C.c_int, u32, _f64p, _u64p, _f64p]
         L.och_graph_load_link_images.argtypes = [vp, vp, vp, u32, C.c_int, C.c_int, u32, C.c_int, u32, _f64p, vp, _u64p,
                                                  _f64p, _f64p, _f64p]
+        L.och_initial_processing_create.restype = vp
+        L.och_initial_processing_create.argtypes = [vp, vp]
+        L.och_initial_processing_destroy.restype = None
+        L.och_initial_processing_destroy.argtypes = [vp]
+        L.och_initial_processing_pending.argtypes = [vp]
+        L.och_initial_processing_step.argtypes = [vp, vp, u32, C.c_int, C.c_int, u32, C.c_int, u32, vp, C.c_int, vp, _f64p]
         L.och_graph_to_json.argtypes = [vp, C.POINTER(sz)]
         L.och_graph_to_json.restype = vp
         L.och_free.argtypes = [vp]
@@ -664,6 +670,10 @@ class Graph:
         self.node_ids += [int(i) for i in ids[:n]]
         return totals[0] / max(n, 1), totals[1] / max(n, 1), dict(zip(LINK_TIMER_NAMES, timers.tolist())), (stage[0], stage[1])
 
+    def initial_processing(self, ctx):
+        """Pipeline::Impl::initial_processing's stepper (och_initial_processing_*): see InitialProcessing."""
+        return InitialProcessing(self, ctx)
+
     @classmethod
     def from_synthetic(cls, grid):
         g = cls()
@@ -1030,3 +1040,53 @@ def matches_from_device(raw, idx1, idx2):
         raise ValueError("raw shorter than idx1")
     m = load().och_matches_from_device(raw.ctypes.data, idx1, len(idx1), idx2, len(idx2), i1, i2, d)
     return i1[:m].copy(), i2[:m].copy(), d[:m].copy()
+
+
+IP_STATS16 = ["step_s", "init_s", "runners_s", "finalize_s", "load_runner_s", "link_runner_s", "relax_runner_s", "features", "sparse_features",
+              "images_linked", "images_relaxed", "relax_solves", "relax_iterations", "relax_setup_host_s", "relax_device_s", "images_to_relax_next"]
+
+
+class InitialProcessing:
+    """INITIAL_PROCESSING as the reference pipelines it (src/pipeline/pipeline.cpp:522-570): step(batch) loads the batch, links
+    the batch before and relaxes the batch before that, side by side; step() without images drains."""
+
+    def __init__(self, graph, ctx):
+        self.g, self.ctx = graph, ctx
+        self.h = graph.L.och_initial_processing_create(graph.h, ctx.h)
+        if not self.h:
+            raise MemoryError("och_initial_processing_create")
+
+    def close(self):
+        if self.h:
+            self.g.L.och_initial_processing_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def pending(self):
+        return bool(self.g.L.och_initial_processing_pending(self.h))
+
+    def step(self, images_bgr=None, model=0, positions=None, max_keypoints=30000, device_shape=None, sequential=False):
+        if images_bgr is None:
+            n, h, w, src, on_dev, pos, ids = 0, 0, 0, None, 0, None, None
+        else:
+            if device_shape is None:
+                imgs = np.ascontiguousarray(images_bgr, np.uint8)
+                n, h, w, _ = imgs.shape
+                src, on_dev = imgs.ctypes.data, 0
+            else:
+                n, h, w = device_shape
+                src, on_dev = int(images_bgr), 1
+            pos = np.ascontiguousarray(positions, np.float64).reshape(-1, 3)
+            ids = np.zeros(max(n, 1), np.uint64)
+        stats = np.zeros(16)
+        rc = self.g.L.och_initial_processing_step(self.h, src, n, w, h, max_keypoints, on_dev, model,
+                                                  None if pos is None else pos.ctypes.data, int(sequential),
+                                                  None if ids is None else ids.ctypes.data, stats)
+        if rc != 0:
+            raise capi.OchipError("initial processing step failed: " + self.g.L.och_last_error(self.g.h).decode())
+        if n:
+            self.g.node_ids += [int(i) for i in ids[:n]]
+        return dict(zip(IP_STATS16, stats.tolist()))

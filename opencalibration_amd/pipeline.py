@@ -106,7 +106,7 @@ def run_incremental(ctx, grid, images_ptr, shape, batch=100, max_keypoints=30000
         g.load_link_images(ctx, images_ptr + lo * h * w * 3, mid, grid.position[lo:lo + cnt], nan, max_keypoints, device_shape=(cnt, h, w))
         out["load_link_s"] += time.perf_counter() - t0
         t0 = time.perf_counter()
-        st = g.relax_stage(ctx, opts, node_ids=g.node_ids[lo:lo + cnt])
+        st = g.relax_stage(ctx, opts, node_ids=g.node_ids[lo:lo + cnt], disable_parallelism=True)   # (pipeline.cpp:545-546)
         ctx.synchronize()
         out["relax_s"] += time.perf_counter() - t0
         out["batches"] += 1
@@ -115,6 +115,41 @@ def run_incremental(ctx, grid, images_ptr, shape, batch=100, max_keypoints=30000
         out["residual_blocks"] += int(st["residual_blocks"])
     out["seconds"] = time.perf_counter() - t_all
     out["edges"] = g.num_edges
+    return g, out
+
+
+def run_initial_processing(ctx, grid, images_ptr, shape, batch=100, max_keypoints=30000, sequential=False):
+    """INITIAL_PROCESSING exactly as the reference schedules it (Pipeline::Impl::initial_processing, src/pipeline/pipeline.cpp:522-570;
+    host.InitialProcessing): the survey arrives in batches WITHOUT orientations; step k extracts batch k, links batch k - 1
+    against everything loaded before it and relaxes batch k - 2 as one group {ORIENTATION, GROUND_PLANE} with two rings of
+    context cameras - the three side by side - until the pipeline is drained.  Returns (graph, dict of counts and seconds)."""
+    n, h, w = shape
+    g = host.Graph()
+    mid = g.add_model(grid.model)
+    ip = g.initial_processing(ctx)
+    out = dict(batches=0, steps=0, solves=0, lm_iterations=0, load_runner_s=0.0, link_runner_s=0.0, relax_runner_s=0.0,
+               relax_device_s=0.0, relax_setup_host_s=0.0, step_seconds=[])
+    t_all = time.perf_counter()
+    lo = 0
+    while lo < n or ip.pending:
+        if lo < n:
+            cnt = min(batch, n - lo)
+            st = ip.step(images_ptr + lo * h * w * 3, mid, grid.position[lo:lo + cnt], max_keypoints, device_shape=(cnt, h, w),
+                         sequential=sequential)
+            lo += cnt
+            out["batches"] += 1
+        else:
+            st = ip.step(sequential=sequential)
+        out["steps"] += 1
+        out["solves"] += int(st["relax_solves"])
+        out["lm_iterations"] += int(st["relax_iterations"])
+        for k in ("load_runner_s", "link_runner_s", "relax_runner_s", "relax_device_s", "relax_setup_host_s"):
+            out[k] += st[k]
+        out["step_seconds"].append(round(st["step_s"], 4))
+    ctx.synchronize()
+    out["seconds"] = time.perf_counter() - t_all
+    out["edges"] = g.num_edges
+    ip.close()
     return g, out
 
 
