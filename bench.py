@@ -619,21 +619,33 @@ def beside_the_headline(ctx, grid, images, shape, start_ori, step_s, rctx=None):
         extras["relax_extras_error"] = str(ex)
     try:
         # (e) the reference's real schedule of INITIAL_PROCESSING beside the headline's one batch: the survey in batches of 100
-        # that start without orientations, each loaded + linked against everything before it and relaxed as one group with
-        # two rings of fixed context cameras, the new cameras bootstrapped one solve each (pipeline.cpp:522-570,
-        # relax.cpp:52-80, relax_group.cpp:40-66)
-        gi, inc = pipeline.run_incremental(ctx, grid, images, shape, batch=100)
-        erri = pipeline.orientation_errors(gi.orientations(), grid.orientation)
+        # that start without orientations; step k extracts batch k, links batch k - 1 against everything loaded before it and
+        # relaxes batch k - 2 as ONE group with two rings of context cameras, the three stages' runners side by side
+        # (pipeline.cpp:522-570; host.InitialProcessing); the new cameras are bootstrapped one solve each (relax.cpp:52-80) by
+        # one resident launch on the device (csrc/relax_chain.hip).  Best of two runs (the first one warms the pools).
+        best = None
+        for _ in range(2):
+            gi, inc = pipeline.run_initial_processing(ctx, grid, images, shape, batch=100)
+            erri = pipeline.orientation_errors(gi.orientations(), grid.orientation)
+            gi.close()
+            if best is None or inc["seconds"] < best[0]["seconds"]:
+                best = (inc, erri)
+        inc, erri = best
         extras["incremental_batches"] = {
-            "batches": inc["batches"], "images": int(n), "seconds": round(inc["seconds"], 4),
-            "images_per_s": round(n / inc["seconds"], 1), "load_link_seconds": round(inc["load_link_s"], 4),
-            "relax_seconds": round(inc["relax_s"], 4), "lm_solves": inc["solves"], "lm_iterations": inc["lm_iterations"],
-            "lm_iters_per_s": round(inc["lm_iterations"] / max(inc["relax_s"], 1e-9), 1), "edges": int(inc["edges"]),
+            "batches": inc["batches"], "steps": inc["steps"], "images": int(n), "seconds": round(inc["seconds"], 4),
+            "images_per_s": round(n / inc["seconds"], 1), "step_seconds": inc["step_seconds"],
+            "load_runner_seconds": round(inc["load_runner_s"], 4), "link_runner_seconds": round(inc["link_runner_s"], 4),
+            "relax_runner_seconds": round(inc["relax_runner_s"], 4), "relax_device_seconds": round(inc["relax_device_s"], 4),
+            "relax_host_setup_seconds": round(inc["relax_setup_host_s"], 4),
+            "lm_solves": inc["solves"], "lm_iterations": inc["lm_iterations"],
+            "lm_iters_per_s": round(inc["lm_iterations"] / max(inc["relax_runner_s"], 1e-9), 1), "edges": int(inc["edges"]),
             "median_orientation_error_rad_vs_truth": float(np.median(erri)),
             "cameras_left_unoriented": int(np.sum(~np.isfinite(erri))),
-            "note": "every camera starts with a NaN orientation; one batch at a time, nothing overlapped: the latency of the "
-                    "reference's schedule, not a throughput figure"}
-        gi.close()
+            "note": "every camera starts with a NaN orientation; ONE relax group per batch (RelaxStage::init with "
+                    "disable_parallelism, pipeline.cpp:545-546: round 5's figure split a batch into two groups of 50, which the "
+                    "reference does not) whose cameras are bootstrapped together with the group while the graph is smaller than "
+                    "twice the group (the first batches: ~2 500 LM iterations on up to 450 unknowns per batch) and one at a time "
+                    "after that (relax.cpp:61-75); the three stages of consecutive batches run side by side as in the reference"}
     except Exception as ex:
         extras["incremental_batches"] = {"error": str(ex)}
     return extras
@@ -1062,6 +1074,10 @@ def weak_main(args, proc, cfg):
                                               max(p.get("images_per_s_end_to_end") or 0.0,
                                                   p.get("images_per_s_end_to_end_two_surveys_in_flight") or 0.0))(
                                                       (extras or {}).get("pcie_inclusive")),
+            # the same survey through the reference's own schedule of INITIAL_PROCESSING (batches of 100 without orientations,
+            # extract k | link k - 1 | relax k - 2 side by side, every new camera bootstrapped by a solve of its own): never `value`
+            "images_per_s_reference_schedule": (lambda p: None if not isinstance(p, dict) or "error" in p else p.get("images_per_s"))(
+                (extras or {}).get("incremental_batches")),
             "value_assumes": "views resident in HBM when the timed region starts (bench contract); PCIe-inclusive rate beside it",
             "images_per_s_weak_one_survey_per_gpu": round(value, 3),
             "images_per_s_strong_one_survey_over_all_gpus": (round(value, 3) if world == 1 else
