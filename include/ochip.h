@@ -657,7 +657,8 @@ extern "C"
      * search, the accept rule - and the union of the matched measurements; ochip_dense_match stays for callers that
      * build their queries themselves).
      * cams17 [n_images][17]: position (3), orientation.inverse() (4, xyzw), model10 (f ppx ppy k1 k2 k3 p1 p2 cols rows);
-     * id_of_pos [total]: the reference's measurement id (image offset + dense feature number) of every index position;
+     * id_of_pos [total]: the reference's measurement id (image offset + dense feature number) of every index position - a
+     * permutation of [0, total), anything else is OCHIP_EINVAL;
      * hits3 [total][3] by index position: where the feature's ray meets the mesh, x = NaN: nowhere (:196-207).
      * max_candidates = MAX_CANDIDATE_IMAGES (10), descriptor_bits = 486, ratio = 0.85, max_abs = 0.35 (:51-56).
      * root_out [total] by measurement id: the smallest member of the measurement's track, 0xFFFFFFFF = unmatched;
@@ -670,7 +671,8 @@ extern "C"
     /* The tracks' 3-D points (dense_stereo.cpp:299-340 with triangulateTrack, :112-172) after ochip_dense_link on the same
      * index: track t = the measurement ids track_member[track_start[t] .. track_start[t + 1]) in ascending order; its first two
      * rays meet in a point, members reprojecting within max_reprojection_error px are inliers, fewer than two give no point,
-     * fewer than all give the point of the first two inliers.  cam_q4 [n_images][4]: the images' orientations (x y z w).
+     * fewer than all give the point of the first two inliers (a member >= the index's measurement count: OCHIP_EINVAL).
+     * cam_q4 [n_images][4]: the images' orientations (x y z w).
      * points3_out [n_tracks][3], valid_out [n_tracks] (0: the track has no point). */
     int ochip_dense_triangulate(ochip_dense_index *ix, const double *cam_q4, uint32_t n_tracks, const uint32_t *track_start,
                                 const uint32_t *track_member, double max_reprojection_error, double *points3_out, uint8_t *valid_out);

@@ -255,6 +255,22 @@ struct taps_t
 // Every value is the same float expression as the separate passes (ascending tap order, clamped source
 // coordinates for the blur, reflected coordinates for the stencil), so the fusion does not change a bit.
 constexpr int BT_X = 64, BT_Y = 32; // blur tiles
+// cv::solve(A, b, dst, DECOMP_LU) for AKAZE's 2 x 2 system [Dxx Dxy; Dxy Dyy] d = -[Dx Dy] (core/src/lapack.cpp, the 2 x 2 fast
+// path for CV_32FC1): Cramer's rule in double; a singular system leaves the offset at (0, 0) - the restatement's subpixel_solve
+__device__ __forceinline__ float2 subpixel_solve(float Dxx, float Dxy, float Dyy, float Dx, float Dy)
+{
+    const float b0 = -Dx, b1 = -Dy;
+    double d = (double)Dxx * Dyy - (double)Dxy * Dxy;
+    float2 r = make_float2(0.0f, 0.0f);
+    if (d != 0.)
+    {
+        d = 1. / d;
+        r.x = (float)(((double)b0 * Dyy - (double)b1 * Dxy) * d);
+        r.y = (float)(((double)b1 * Dxx - (double)b0 * Dxy) * d);
+    }
+    return r;
+}
+
 constexpr int DT_Y = 24;             // detection tiles are 64 x 24 (16, 24, 32 rows measured: 43, 39, 40 us per image for the determinant kernels)
 enum
 {
@@ -1013,10 +1029,7 @@ __global__ __launch_bounds__(256) void det_maxima_kernel(const float2 *__restric
                     const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
                     const float Dxx = (vxp + vxm) - 2.0f * v, Dyy = (vyp + vym) - 2.0f * v;
                     const float Dxy = 0.25f * ((td[ci + DW + 1] + td[ci - DW - 1]) - (td[ci + DW - 1] + td[ci - DW + 1]));
-                    const float det = Dxx * Dyy - Dxy * Dxy;
-                    fit = make_float2(2.0f, 2.0f); // a singular fit is no keypoint
-                    if (det != 0.0f)
-                        fit = make_float2((Dxy * Dy - Dyy * Dx) / det, (Dxy * Dx - Dxx * Dy) / det);
+                    fit = subpixel_solve(Dxx, Dxy, Dyy, Dx, Dy);
                 }
             }
         }
@@ -1095,10 +1108,7 @@ __device__ __forceinline__ float2 subpixel_fit(float v, float vxm, float vxp, fl
     const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
     const float Dxx = (vxp + vxm) - 2.0f * v, Dyy = (vyp + vym) - 2.0f * v;
     const float Dxy = 0.25f * ((vpp + vmm) - (vmp + vpm));
-    const float det = Dxx * Dyy - Dxy * Dxy;
-    if (det == 0.0f)
-        return make_float2(2.0f, 2.0f); // a singular fit is no keypoint
-    return make_float2((Dxy * Dy - Dyy * Dx) / det, (Dxy * Dx - Dxx * Dy) / det);
+    return subpixel_solve(Dxx, Dxy, Dyy, Dx, Dy);
 }
 
 template <int S>
@@ -1823,11 +1833,13 @@ __global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict_
     dead[(size_t)b * max_cands + k] = is_dead ? 1 : 0;
 }
 
-// ---- float-only math shared with the CPU restatement (deterministic: + - * / and compares only)
-__device__ __forceinline__ float fast_atan2(float y, float x)
+// ---- the float functions of the orientation and the descriptor, as the CPU restatement has them (oracle D2): cv::fastAtan2 in
+// degrees, hal::fastAtan32f's radians = degrees * (float)(CV_PI / 180), glibc's sinf / cosf (double kernels, reduction by pi / 2)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
-    const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f, HALF_PI_F = 1.57079632679489661923f;
-    const float p1 = 0.9997878412794807f, p3 = -0.3258083974640975f, p5 = 0.1555786518463281f, p7 = -0.04432655554792128f;
+    const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale,
+                p7 = -0.04432655554792128f * scale;
     const float ax = fabsf(x), ay = fabsf(y);
     float a, c, c2;
     if (ax >= ay)
@@ -1840,45 +1852,65 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
     {
         c = ax / (ay + 2.220446e-16f);
         c2 = c * c;
-        a = HALF_PI_F - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     }
     if (x < 0)
-        a = PI_F - a;
+        a = 180.f - a;
     if (y < 0)
-        a = TWO_PI_F - a;
+        a = 360.f - a;
     return a;
 }
-
-__device__ __forceinline__ void sincos_poly(float a, float *s, float *c)
+#define OCHIP_DEG2RAD_F ((float)(3.1415926535897932384626433832795 / 180.0))
+__device__ __forceinline__ float fast_atan2(float y, float x)
 {
-    const float HALF_PI_F = 1.57079632679489661923f;
-    int q = (int)(a / HALF_PI_F);
-    if (q > 3)
-        q = 3;
-    float r = a - (float)q * HALF_PI_F;
-    bool swp = false;
-    if (r > 0.78539816339744830962f)
+    return fast_atan2_deg(y, x) * OCHIP_DEG2RAD_F;
+}
+
+// glibc's sinf / cosf for |a| < 120 (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h; the restatement's libm_sinf /
+// libm_cosf, which tests/test_oracle_akaze_properties.py pins to libm over every float of [0, 6.3])
+__device__ __forceinline__ float libm_sinf_poly(double x, double x2, bool negated, int n)
+{
+    const double sgn = negated ? -1.0 : 1.0;
+    if ((n & 1) == 0)
     {
-        r = HALF_PI_F - r;
-        swp = true;
+        const double x3 = x * x2;
+        const double s1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13;
+        const double x7 = x3 * x2;
+        const double s = x + x3 * -0x1.555545995a603p-3;
+        return (float)(s + x7 * s1);
     }
-    const float r2 = r * r;
-    float sn = r * (1.0f + r2 * (-1.0f / 6.0f + r2 * (1.0f / 120.0f + r2 * (-1.0f / 5040.0f + r2 * (1.0f / 362880.0f)))));
-    float cs = 1.0f + r2 * (-0.5f + r2 * (1.0f / 24.0f + r2 * (-1.0f / 720.0f + r2 * (1.0f / 40320.0f))));
-    if (swp)
+    const double x4 = x2 * x2;
+    const double c2 = sgn * -0x1.6c087e89a359dp-10 + x2 * (sgn * 0x1.99343027bf8c3p-16);
+    const double c1 = sgn * -0x1.ffffffd0c621cp-2 + x2 * (sgn * 0x1.55553e1068f19p-5);
+    const double x6 = x4 * x2;
+    const double c = sgn * 0x1p0 + x2 * c1;
+    return (float)(c + x6 * c2);
+}
+__device__ __forceinline__ void libm_sincosf(float a, float *s, float *c)
+{
+    const unsigned int top = (__float_as_uint(a) >> 20) & 0x7ffu;
+    double x = a;
+    if (top < ((0x3f490fdbu >> 20) & 0x7ffu)) // |a| < pi / 4 (abstop12 of 0x1.921FB6p-1f)
     {
-        const float t = sn;
-        sn = cs;
-        cs = t;
+        const double x2 = x * x;
+        if (top < ((0x39800000u >> 20) & 0x7ffu)) // |a| < 2^-12
+        {
+            *s = a;
+            *c = 1.0f;
+            return;
+        }
+        *s = libm_sinf_poly(x, x2, false, 0);
+        *c = libm_sinf_poly(x, x2, false, 1);
+        return;
     }
-    if (q == 0)
-        *s = sn, *c = cs;
-    else if (q == 1)
-        *s = cs, *c = -sn;
-    else if (q == 2)
-        *s = -sn, *c = -cs;
-    else
-        *s = -cs, *c = sn;
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int)r + 0x800000) >> 24;
+    x = x - n * 0x1.921FB54442D18p0;
+    const double sign[4] = {1.0, -1.0, -1.0, 1.0};
+    const double sg = sign[n & 3];
+    const bool negated = (n & 2) != 0;
+    *s = libm_sinf_poly(x * sg, x * x, negated, n);
+    *c = libm_sinf_poly(x * sg, x * x, negated, n ^ 1);
 }
 
 // The candidates that survived the suppression, in list (tile) order: the descriptor kernel runs over these only, so that
@@ -2148,7 +2180,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
         if (lane < 42)
         {
             wmag = sum.x * sum.x + sum.y * sum.y;
-            wangle = fast_atan2(sum.y, sum.x);
+            wangle = fast_atan2_deg(sum.y, sum.x); // (KeyPoint::angle: degrees)
         }
         // first strict maximum in window order (the sequential loop's choice): the largest magnitude, and of the windows
         // that have it the lowest - a butterfly maximum, a ballot of the lanes that hold it, the first of them
@@ -2161,10 +2193,10 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
         }
         const int widx = __builtin_ctzll(__ballot(wmag == mx));
         const float best_angle = __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(wangle), widx));
-        angle = mx > 0.0f ? best_angle : 0.0f;
+        angle = (mx > 0.0f ? best_angle : 0.0f) * OCHIP_DEG2RAD_F; // what the descriptor rotates by (and the interface reports)
     }
     float si, co;
-    sincos_poly(angle, &si, &co);
+    libm_sincosf(angle, &si, &co);
     const float fs = (float)g.s;
     bool all_inside = true;
     // ---- every grid (2x2, 3x3, 4x4) samples the same rotated 21 x 21 lattice: gather it once with all lanes (7 rounds of
@@ -3219,7 +3251,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     OCHIP_HIP(ctx, hipMemsetAsync(d_hist, 0, (size_t)B * 301 * 4, st));
     // (as a register strip - the level kernel's Gaussian and distance-1 pattern with the magnitude where the conductivity is - when
     // the launch has the strips to fill the device, like the levels below; else the tile kernel and the reduction of its tile maxima)
-    static const bool modg_tiles = ochip_test_hook("tile_levels"), modg_force = ochip_test_hook("strip_levels");
+    const bool modg_tiles = ochip_test_hook("tile_levels"), modg_force = ochip_test_hook("strip_levels");
     const bool modg_strip = !modg_tiles && (W & 1) == 0 && (plane0 & 1) == 0 && W >= 64 && H >= 64 && ((uintptr_t)d_img & 15) == 0 &&
                             ((uintptr_t)d_flow & 15) == 0 && (modg_force || (size_t)W * H * B >= ((size_t)32 << 20));
     if (modg_strip)
@@ -3274,9 +3306,12 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     // 400 x 300 pixels x 100 images is 2 400 of them on 1 024 SIMDs (level kernel: 150 us per launch against the tile kernels'
     // 75; 200 x 150: 150 against 30) - the strips take the levels of >= STRIP_MIN_PIXELS pixels per launch (the first two
     // octaves of a chunk of the bench), the tiles the rest; OCHIP_TEST_HOOKS=strip_levels / strip_det: strips wherever they can
-    static const bool strip_hook = !ochip_test_hook("tile_det"), level_hook = !ochip_test_hook("tile_levels");
-    static const bool force_level_strips = ochip_test_hook("strip_levels"), force_det_strips = ochip_test_hook("strip_det");
-    constexpr size_t STRIP_MIN_PIXELS = (size_t)32 << 20;
+    const bool strip_hook = !ochip_test_hook("tile_det"), level_hook = !ochip_test_hook("tile_levels");
+    const bool force_level_strips = ochip_test_hook("strip_levels"), force_det_strips = ochip_test_hook("strip_det");
+    // (OCHIP_STRIP_MIN_PIXELS: the tests lower the threshold so that a small batch takes the mixed route of a bench chunk -
+    // strips on its large levels, tiles on the small ones - and is compared with the restatement)
+    const char *strip_env = std::getenv("OCHIP_STRIP_MIN_PIXELS");
+    const size_t STRIP_MIN_PIXELS = strip_env && *strip_env ? (size_t)std::strtoull(strip_env, nullptr, 10) : (size_t)32 << 20;
     auto strips_pay = [&](const level_info &l, bool forced) { return forced || (size_t)l.w * l.h * B >= STRIP_MIN_PIXELS; };
     bool det_strips = strip_hook && (img_stride & 1) == 0 && (plane0 & 1) == 0 && ((uintptr_t)d_Lxy & 15) == 0 && ((uintptr_t)d_Lt & 15) == 0 &&
                       ((uintptr_t)d_flow & 15) == 0 && ((uintptr_t)d_ping & 15) == 0;

@@ -549,7 +549,7 @@ __global__ void dense_uf_roots_kernel(uint32_t *parent, const uint8_t *matched, 
 __global__ void dense_pos_of_id_kernel(const uint32_t *__restrict__ id_of_pos, uint32_t *__restrict__ pos_of_id, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
+    if (i < n && id_of_pos[i] < n) // (id_of_pos is a permutation of [0, n): ochip_dense_link rejects anything else)
         pos_of_id[id_of_pos[i]] = (uint32_t)i;
 }
 __device__ __forceinline__ void dense_ray_intersection(const dv3 &d1, const dv3 &o1, const dv3 &d2, const dv3 &o2, dv3 *mid, double *err)
@@ -888,6 +888,17 @@ int ochip_dense_link(ochip_dense_index *ix, const double *cams17, const uint32_t
     const uint32_t n_images = ix->n_images;
     if (total == 0 || n_images == 0)
         return OCHIP_OK;
+    {
+        // id_of_pos is a permutation of [0, total): the kernels scatter and gather through it and through its inverse
+        std::vector<uint8_t> seen((size_t)total, 0);
+        for (uint64_t i = 0; i < total; i++)
+        {
+            if (id_of_pos[i] >= total || seen[id_of_pos[i]])
+                return ochip_fail(ctx, OCHIP_EINVAL, "ochip_dense_link: id_of_pos is not a permutation of the %llu measurements (position %llu)",
+                                  (unsigned long long)total, (unsigned long long)i);
+            seen[id_of_pos[i]] = 1;
+        }
+    }
     OCHIP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     std::vector<std::pair<void *, size_t>> blocks;
@@ -1022,6 +1033,10 @@ int ochip_dense_triangulate(ochip_dense_index *ix, const double *cam_q4, uint32_
     for (uint32_t t = 0; t < n_tracks; t++)
         if (track_start[t] > track_start[t + 1])
             return ochip_fail(ctx, OCHIP_EINVAL, "ochip_dense_triangulate: track_start does not ascend at track %u", t);
+    for (uint64_t m = 0; m < n_members; m++) // (a member is a measurement id of the index: the kernels gather pos_of_id[member])
+        if (track_member[m] >= total)
+            return ochip_fail(ctx, OCHIP_EINVAL, "ochip_dense_triangulate: track member %llu is measurement %u of %llu", (unsigned long long)m,
+                              track_member[m], (unsigned long long)total);
     std::vector<std::pair<void *, size_t>> blocks;
     int rc = OCHIP_OK;
     auto get = [&](size_t bytes) -> void * {

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <memory>
 #include <numeric>
+#include <future>
 #include <thread>
 
 namespace opencalibration_amd
@@ -327,10 +328,21 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     // upload is a thread of its own that is the only one to use the context until it is joined
     ochip_dense_index *index = nullptr;
     int create_rc = OCHIP_OK;
-    std::thread uploader([&]() {
+    // (a future from std::async joins in its destructor: nothing that throws between here and the wait below can leave a
+    // joinable thread behind; where no thread can be started the index is created right here)
+    auto create_index = [&]() {
         create_rc = ochip_dense_index_create(ctx, (uint32_t)n_img, feat_off.data(), desc8, loc2, cell_off.data(), cell_start.data(),
                                              grid2.data(), origin2.data(), CELL_SIZE, &index);
-    });
+    };
+    std::future<void> uploader;
+    try
+    {
+        uploader = std::async(std::launch::async, create_index);
+    }
+    catch (const std::system_error &)
+    {
+        create_index();
+    }
     st.index_seconds = seconds_since(t0);
 
     const MeshGraph &mesh = surfaces[0].mesh;
@@ -391,7 +403,8 @@ bool densifyMesh(ochip_ctx *ctx, const MeasurementGraph &graph, std::vector<surf
     }
     st.rays_seconds = seconds_since(t1);
     t1 = std::chrono::steady_clock::now();
-    uploader.join();
+    if (uploader.valid())
+        uploader.get();
     st.index_seconds += seconds_since(t1); // (what is left of the upload)
     if (create_rc != OCHIP_OK)
     {

@@ -564,7 +564,7 @@ class GroundMeshProblem
             return false;
         }
         const bool sharded = shard && (shard->world > 1 || shard->exchange);
-        if (sharded && _views_without_features)
+        if (sharded && _views_without_features.load())
         {
             // a view whose node carries no feature list is skipped (the reference's bounds check), so a rank that holds only
             // its own block's features (och_shard_*: the sharded survey) would build other blocks than its peers and the
@@ -980,8 +980,8 @@ class GroundMeshProblem
                         present = tr[k].node == v.node;
                     if (!present && pose_of_node[v.node] >= 0 && v.feature < gnodes[v.node].payload.features.size())
                         tr[nr++] = v;
-                    else if (!present && pose_of_node[v.node] >= 0)
-                        _views_without_features = true; // (every thread that sees one writes the same value)
+                    else if (!present && pose_of_node[v.node] >= 0 && gnodes[v.node].payload.features.empty())
+                        _views_without_features.store(true, std::memory_order_relaxed); // (the node's feature list is not on this rank: a graph from survey_sharded; a single index out of range is skipped on every rank alike, as the reference's bounds check does)
                     if (finite_point)
                     {
                         bool seen = false;
@@ -1252,7 +1252,8 @@ class GroundMeshProblem
     std::vector<uint8_t> _blk_intr;
     std::vector<twin> _twins;
     uint32_t _options = 0;
-    bool _intrinsics = false, _several_models = false, _views_without_features = false;
+    bool _intrinsics = false, _several_models = false;
+    std::atomic<bool> _views_without_features{false};
     size_t _shared_model = (size_t)-1, _mono_count = 0;
     double _mono_focal = 1;
     std::vector<uint8_t> _cam_opt, _blk_n;

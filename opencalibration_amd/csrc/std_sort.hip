@@ -758,8 +758,10 @@ int std_sort_enqueue(ochip_ctx *ctx, std::vector<std::pair<void *, size_t>> *all
     // a workgroup per segment walks the levels above LOCAL by itself when there are enough segments to fill the device that
     // way (the chunks of extract_features: 100 segments of ~20 k records); few long segments keep a launch per level, which
     // spreads one level's ranges over all workgroups
-    static const bool per_level_hook = ochip_test_hook("sort_per_level");
-    const bool by_segment = !per_level_hook && n_segs >= 32 && max_len <= SEG_MAX;
+    // (from 8 segments on: a chunk of 25 images uploaded from host memory sorted with a launch per level - 29 levels, 2.1 ms -
+    // where its 25 workgroups walk their trees in 0.4 ms, round 5's threshold of 32 kept the from-host path on the slow route)
+    const bool per_level_hook = ochip_test_hook("sort_per_level");
+    const bool by_segment = !per_level_hook && n_segs >= 8 && max_len <= SEG_MAX;
     if (by_segment)
     {
         if (max_len > LOCAL)

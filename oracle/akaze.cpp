@@ -3,7 +3,14 @@
 // KNOWN DEPARTURES FROM OpenCV's AKAZE (features2d/src/kaze/AKAZEFeatures.cpp, nldiffusion_functions.cpp [3P: not under
 // /root/reference, absent from this image - what OpenCV does is quoted from its published source, not checked here]).
 // Each is a place where this file is deliberately NOT a transcription; scripts/akaze_pin.py --compare attributes what it
-// finds to them (classes `suppression`, `angle`, `descriptor`).
+// finds to them (classes `suppression`, `angle`, `descriptor`).  STRUCTURE: this restatement follows the original A-KAZE /
+// OpenCV 3.x code path (per-sample rounding of the orientation samples, 42 windows stepped by 0.15 rad, out-of-image descriptor
+// samples skipped).  OpenCV 4.x rewrote three places (as recalled, unverified): Find_Scale_Space_Extrema became three mask
+// passes (per level in raster order - the first keypoint already set within sigma_size is cleared when the new one is stronger,
+// else the new one is dropped - then against the level below, then against the level above), Compute_Main_Orientation samples
+// around cvRound(pt / ratio) and slides a 7-slice window over a counting sort of the angles into 42 slices, and the M-LDB
+// sampler clamps coordinates into the image.  A reference built against 4.x differs from this file in those places whatever
+// D1 - D4 say; none of it can be pinned in this image.
 //
 //  D1  cross-level suppression            this file: detect_and_describe, step 2 ("scale-space suppression", the `dead` loop)
 //      here:   symmetric and order-free - a candidate dies if ANY stronger maximum (ties: lower (level, y, x)) of its own
@@ -15,14 +22,20 @@
 //              differs from the rule above where three or more maxima chain (A near B near C, A not near C).
 //      why:    the sequential list cannot be evaluated in parallel without reproducing its order; which of two valid
 //              definitions of "the same blob at neighbouring scales" is used moves a few keypoints per thousand.
-//  D2  atan2 / sin / cos                  this file: fast_atan2, sincos_poly; used in detect_and_describe, step 3
-//      here:   one polynomial in RADIANS built from + - * / only (bit-identical on CPU and device), Taylor sin / cos.
-//      OpenCV: Compute_Main_Orientation uses cv::fastAtan2 (the same odd polynomial with its coefficients scaled to
-//              DEGREES, 0.3 degree accuracy) times pi / 180; the descriptor uses cos(angle), sin(angle) of libm.  Angles
-//              agree to the polynomial's accuracy, not to the bit; a sample that sits on a rounding boundary of
-//              cvRound(x + ...) can move by one pixel, a window sum on an edge of its 60 degree sector can flip.
-//  D3  sub-pixel refinement               this file: the 2 x 2 solve by Cramer's rule (det_maxima / subpixel fit)
-//      OpenCV: cv::solve(A, b, dst, DECOMP_LU) on the same 2 x 2 system - same solution up to rounding.
+//  D2  atan2 / sin / cos                  (removed in round 6) this file: cv_fast_atan2_deg, libm_sincosf; used in detect_and_describe, step 3
+//      now:    the sample angles are cv::fastAtan2 (core/src/mathfuncs_core.simd.hpp, atan_f32: the odd polynomial with its
+//              coefficients scaled to DEGREES, 90 / 180 / 360 folds) times (float)(CV_PI / 180) as hal::fastAtan32f(.., false)
+//              returns them; the keypoint's angle is fastAtan2 of the best window's sums in degrees; the descriptor rotates by
+//              cosf / sinf of angle * (float)(CV_PI / 180) - glibc's sinf / cosf (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c,
+//              sincosf.h: double-precision kernels, reduction by pi / 2) restated and PINNED: tests/test_oracle_akaze_properties.py
+//              compares libm_sincosf with this image's libm over every float in [0, 6.3] and a sweep beyond.
+//      before: one polynomial in radians and Taylor sin / cos (rounds 2 - 5): angles differed from OpenCV's by the
+//              polynomials' accuracy, a sample on a rounding boundary could move by a pixel.
+//  D3  sub-pixel refinement               (removed in round 6) this file: subpixel_solve
+//      now:    cv::solve(Matx22f, Vec2f, DECOMP_LU) takes lapack.cpp's 2 x 2 fast path: Cramer's rule in DOUBLE - det2 =
+//              (double)a00 * a11 - (double)a01 * a10, d = 1. / det2, x0 = (float)(((double)b0 * a11 - (double)b1 * a01) * d), x1
+//              likewise - and a singular system leaves the offset at (0, 0) (AKAZE does not look at solve's result).
+//      before: the same rule in float, a singular system dropped the keypoint.
 //  D4  order of float sums                this file: every sum in one fixed, written order (no FMA)
 //      OpenCV: its loops are vectorised (universal intrinsics) where the build allows; sums of the Gaussian taps, the
 //              diffusion step's four fluxes and the descriptor's cell means may associate differently.  Not a semantic
@@ -437,16 +450,19 @@ ScaleSpace build_scale_space(const std::vector<float> &img, int w, int h, const 
 
 // ------------------------------------------------------------------------ float-only math helpers
 // (deterministic across CPU and GPU: only + - * / and comparisons)
-static const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f, HALF_PI_F = 1.57079632679489661923f;
+static const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
 
-float fast_atan2(float y, float x) // cv::fastAtan2's polynomial, radians in [0, 2 pi)
+// cv::fastAtan2 (modules/core/src/mathfuncs_core.simd.hpp, atan_f32): degrees in [0, 360]
+float cv_fast_atan2_deg(float y, float x)
 {
-    const float p1 = 0.9997878412794807f, p3 = -0.3258083974640975f, p5 = 0.1555786518463281f, p7 = -0.04432655554792128f;
+    const float scale = (float)(180.0 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale, p5 = 0.1555786518463281f * scale,
+                p7 = -0.04432655554792128f * scale;
     const float ax = std::fabs(x), ay = std::fabs(y);
     float a, c, c2;
     if (ax >= ay)
     {
-        c = ay / (ax + 2.220446e-16f);
+        c = ay / (ax + 2.220446e-16f); // (float)DBL_EPSILON
         c2 = c * c;
         a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     }
@@ -454,46 +470,120 @@ float fast_atan2(float y, float x) // cv::fastAtan2's polynomial, radians in [0,
     {
         c = ax / (ay + 2.220446e-16f);
         c2 = c * c;
-        a = HALF_PI_F - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     }
     if (x < 0)
-        a = PI_F - a;
+        a = 180.f - a;
     if (y < 0)
-        a = TWO_PI_F - a;
+        a = 360.f - a;
     return a;
 }
-
-void sincos_poly(float a, float *s, float *c) // a in [0, 2 pi): quadrant reduction + Taylor polynomials
+static const float DEG2RAD_F = (float)(3.1415926535897932384626433832795 / 180.0);
+float fast_atan2(float y, float x) // hal::fastAtan32f(y, x, angle, n, false): the degrees above times (float)(CV_PI / 180)
 {
-    int q = (int)(a / HALF_PI_F);
-    if (q > 3)
-        q = 3;
-    float r = a - (float)q * HALF_PI_F; // [0, pi/2)
-    bool swap = false;
-    if (r > 0.78539816339744830962f)
+    return cv_fast_atan2_deg(y, x) * DEG2RAD_F;
+}
+
+// glibc's sinf and cosf (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c with sincosf.h, the non-FMA C code): for |x| < 120 the
+// argument goes to double, is reduced by multiples of pi / 2 (reduce_fast) and one of two double polynomials gives the value.
+// Arguments of 120 and more (and NaN / inf) do not occur here: an angle is within [0, 2 pi].
+namespace
+{
+struct sincos_tab
+{
+    double sign[4], hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3;
+};
+const sincos_tab SINCOSF_TABLE[2] = {
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5,
+     -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13},
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5,
+     0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13}};
+inline float sinf_poly(double x, double x2, const sincos_tab *p, int n)
+{
+    if ((n & 1) == 0)
     {
-        r = HALF_PI_F - r;
-        swap = true;
+        const double x3 = x * x2;
+        const double s1 = p->s2 + x2 * p->s3;
+        const double x7 = x3 * x2;
+        const double s = x + x3 * p->s1;
+        return (float)(s + x7 * s1);
     }
-    const float r2 = r * r;
-    float sn = r * (1.0f + r2 * (-1.0f / 6.0f + r2 * (1.0f / 120.0f + r2 * (-1.0f / 5040.0f + r2 * (1.0f / 362880.0f)))));
-    float cs = 1.0f + r2 * (-0.5f + r2 * (1.0f / 24.0f + r2 * (-1.0f / 720.0f + r2 * (1.0f / 40320.0f))));
-    if (swap)
-        std::swap(sn, cs);
-    switch (q)
+    const double x4 = x2 * x2;
+    const double c2 = p->c3 + x2 * p->c4;
+    const double c1 = p->c1 + x2 * p->c2;
+    const double x6 = x4 * x2;
+    const double c = p->c0 + x2 * c1;
+    return (float)(c + x6 * c2);
+}
+inline uint32_t abstop12(float x)
+{
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    return (u >> 20) & 0x7ff;
+}
+inline double reduce_fast(double x, const sincos_tab *p, int *np)
+{
+    const double r = x * p->hpi_inv;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return x - n * p->hpi;
+}
+} // namespace
+float libm_sinf(float y)
+{
+    double x = y;
+    const sincos_tab *p = &SINCOSF_TABLE[0];
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) // |y| < pi / 4
     {
-    case 0:
-        *s = sn, *c = cs;
-        break;
-    case 1:
-        *s = cs, *c = -sn;
-        break;
-    case 2:
-        *s = -sn, *c = -cs;
-        break;
-    default:
-        *s = -cs, *c = sn;
-        break;
+        const double s = x * x;
+        if (abstop12(y) < abstop12(0x1p-12f))
+            return y;
+        return sinf_poly(x, s, p, 0);
+    }
+    int n;
+    x = reduce_fast(x, p, &n);
+    const double s = p->sign[n & 3];
+    if (n & 2)
+        p = &SINCOSF_TABLE[1];
+    return sinf_poly(x * s, x * x, p, n);
+}
+float libm_cosf(float y)
+{
+    double x = y;
+    const sincos_tab *p = &SINCOSF_TABLE[0];
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f))
+    {
+        const double x2 = x * x;
+        if (abstop12(y) < abstop12(0x1p-12f))
+            return 1.0f;
+        return sinf_poly(x, x2, p, 1);
+    }
+    int n;
+    x = reduce_fast(x, p, &n);
+    const double s = p->sign[n & 3];
+    if (n & 2)
+        p = &SINCOSF_TABLE[1];
+    return sinf_poly(x * s, x * x, p, n ^ 1);
+}
+void libm_sincosf(float a, float *s, float *c)
+{
+    *s = libm_sinf(a);
+    *c = libm_cosf(a);
+}
+
+// cv::solve(A, b, dst, DECOMP_LU) for AKAZE's 2 x 2 system [Dxx Dxy; Dxy Dyy] d = -[Dx Dy] (core/src/lapack.cpp, the 2 x 2
+// fast path for CV_32FC1): Cramer's rule in double; a singular system leaves dst = (0, 0)
+void subpixel_solve(float Dxx, float Dxy, float Dyy, float Dx, float Dy, float *dx, float *dy)
+{
+    const float b0 = -Dx, b1 = -Dy;
+    double d = (double)Dxx * Dyy - (double)Dxy * Dxy;
+    *dx = 0.0f;
+    *dy = 0.0f;
+    if (d != 0.)
+    {
+        d = 1. / d;
+        *dx = (float)(((double)b0 * Dyy - (double)b1 * Dxy) * d);
+        *dy = (float)(((double)b1 * Dxx - (double)b0 * Dxy) * d);
     }
 }
 
@@ -599,11 +689,8 @@ std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o
         const float Dxx = (at(c.x + 1, c.y) + at(c.x - 1, c.y)) - 2.0f * at(c.x, c.y);
         const float Dyy = (at(c.x, c.y + 1) + at(c.x, c.y - 1)) - 2.0f * at(c.x, c.y);
         const float Dxy = 0.25f * ((at(c.x + 1, c.y + 1) + at(c.x - 1, c.y - 1)) - (at(c.x - 1, c.y + 1) + at(c.x + 1, c.y - 1)));
-        const float det = Dxx * Dyy - Dxy * Dxy;
-        if (det == 0.0f)
-            continue;
-        const float dx = (Dxy * Dy - Dyy * Dx) / det; // solves [Dxx Dxy; Dxy Dyy] d = -[Dx Dy]
-        const float dy = (Dxy * Dx - Dxx * Dy) / det;
+        float dx, dy;
+        subpixel_solve(Dxx, Dxy, Dyy, Dx, Dy, &dx, &dy);
         if (!(std::fabs(dx) <= 1.0f && std::fabs(dy) <= 1.0f))
             continue;
         const float ratio = (float)(1 << l.octave);
@@ -653,13 +740,14 @@ std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o
             if (m > best)
             {
                 best = m;
-                angle = fast_atan2(sumY, sumX);
+                angle = cv_fast_atan2_deg(sumY, sumX); // KeyPoint::angle is in degrees
             }
         }
+        angle = angle * DEG2RAD_F; // what the descriptor rotates by (and what this interface reports: radians)
         kp.angle = angle;
         // M-LDB, 3 channels, grids 2x2 / 3x3 / 4x4 over [-10, 10) * scale, rotated by the orientation
         float si, co;
-        sincos_poly(angle, &si, &co);
+        libm_sincosf(angle, &si, &co);
         std::memset(kp.desc, 0, sizeof kp.desc);
         int dpos = 0;
         const int P = o.descriptor_pattern_size;

@@ -58,6 +58,12 @@ struct Keypoint
 std::vector<float> gaussian_kernel(float sigma);                 // odd length, normalised, cv::GaussianBlur sizing
 std::vector<Level> make_levels(int width, int height, const Options &o);
 void fed_tau_by_process_time(float T, int M, float tau_max, bool reordering, std::vector<float> &tau);
+// the float functions of the orientation and the descriptor (akaze.cpp: D2, D3): cv::fastAtan2 in degrees, glibc's sinf / cosf
+// restated, cv::solve's 2 x 2 fast path
+float cv_fast_atan2_deg(float y, float x);
+float libm_sinf(float x);
+float libm_cosf(float x);
+void subpixel_solve(float Dxx, float Dxy, float Dyy, float Dx, float Dy, float *dx, float *dy);
 std::vector<float> orientation_weights();                        // 13 x 13 Gaussian (sigma 2.5), SURF's gauss25
 
 // building blocks (float images, row-major)

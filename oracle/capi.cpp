@@ -373,6 +373,39 @@ int oc_num_threads()
 #endif
 }
 
+// the restated sinf / cosf against THIS process's libm over every float of [lo_bits, hi_bits] (bit patterns): the number of
+// arguments where either differs, the first such argument in *first_bad
+uint64_t oc_libm_sincosf_mismatches(uint32_t lo_bits, uint32_t hi_bits, uint32_t *first_bad)
+{
+    uint64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (int64_t b = (int64_t)lo_bits; b <= (int64_t)hi_bits; b++)
+    {
+        const uint32_t u = (uint32_t)b;
+        float x;
+        std::memcpy(&x, &u, 4);
+        const float s0 = sinf(x), c0 = cosf(x), s1 = oracle::akaze::libm_sinf(x), c1 = oracle::akaze::libm_cosf(x);
+        if (std::memcmp(&s0, &s1, 4) != 0 || std::memcmp(&c0, &c1, 4) != 0)
+        {
+            bad++;
+#pragma omp critical
+            if (first_bad && (*first_bad == 0 || u < *first_bad))
+                *first_bad = u;
+        }
+    }
+    return bad;
+}
+void oc_akaze_float_functions(float y, float x, float *atan2_deg, float *sin_x, float *cos_x)
+{
+    *atan2_deg = oracle::akaze::cv_fast_atan2_deg(y, x);
+    *sin_x = oracle::akaze::libm_sinf(x);
+    *cos_x = oracle::akaze::libm_cosf(x);
+}
+void oc_akaze_subpixel_solve(float Dxx, float Dxy, float Dyy, float Dx, float Dy, float *dxy2)
+{
+    oracle::akaze::subpixel_solve(Dxx, Dxy, Dyy, Dx, Dy, dxy2, dxy2 + 1);
+}
+
 // FED step sizes of one diffusion cycle (fed_tau_by_process_time, fed.cpp of AKAZE [3P]); returns their number
 size_t oc_fed_tau(float T, int M, float tau_max, int reordering, float *out, size_t cap)
 {

@@ -8,10 +8,9 @@ from dense_fixtures import dense_scene, ground_mesh_arrays
 
 
 def _ref():
-    r = pyoracle.ref()
-    if r is None or not hasattr(r, "ref_hilbert_xy2d"):
-        pytest.skip("oracle/_ref was built without the dense pins")
-    return r
+    from conftest import require_ref
+
+    return require_ref(pyoracle, "ref_hilbert_xy2d")
 
 
 def test_hilbert_index_is_the_reference_header():

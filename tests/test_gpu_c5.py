@@ -96,6 +96,37 @@ def _check_sampled_edges(oracle, grid, edges_all, index_of, n_sample):
     return len(pick), accepted
 
 
+def _check_many_edges(oracle, grid, edges_all, index_of, n_sample):
+    """Evenly sampled directed pairs of the survey through the oracle's whole link stage (oc_link_batch_cpu: a closure per pair
+    under OpenMP, as tests/test_gpu_scale.py does for every pair of C3): the number of matches and of inliers and the
+    homography of every sampled pair, bit for bit."""
+    import os
+
+    pick = np.unique(np.linspace(0, len(edges_all) - 1, n_sample).astype(int))
+    pairs = np.ascontiguousarray(np.array([(index_of[edges_all[p]["source"]], index_of[edges_all[p]["dest"]]) for p in pick], np.uint32))
+    used = np.unique(pairs)
+    remap = {int(i): k for k, i in enumerate(used)}
+    feats = [grid.image(int(i)) for i in used]                          # (only the images the sample touches)
+    off = np.concatenate([[0], np.cumsum([len(f[1]) for f in feats])]).astype(np.uint64)
+    loc = np.ascontiguousarray(np.concatenate([f[0] for f in feats]), np.float64)
+    st = np.ascontiguousarray(np.concatenate([f[1] for f in feats]), np.float32)
+    de = np.ascontiguousarray(np.concatenate([f[2] for f in feats]), np.uint64)
+    ns = np.array([int(grid.num_sparse[int(i)]) for i in used], np.uint64)
+    local = np.ascontiguousarray(np.array([(remap[int(a)], remap[int(b)]) for a, b in pairs], np.uint32))
+    counts, Hs, secs = np.zeros((len(local), 2), np.uint64), np.zeros((len(local), 9)), np.zeros(4)
+    threads = len(os.sched_getaffinity(0))
+    oracle.lib().oc_link_batch_cpu(loc, st, de, off, len(feats), ns, np.ascontiguousarray(grid.model, np.float64), local, len(local), 0,
+                                   threads, counts, Hs, secs)
+    accepted = 0
+    for k, p in enumerate(pick):
+        ed = edges_all[p]
+        assert np.array_equal(ed["H"].ravel(), Hs[k], equal_nan=True), (p, pairs[k])
+        if ed["n_inliers"] > 0:                      # (an edge that was not accepted carries no matches, link_stage.cpp:104-110)
+            accepted += 1
+            assert ed["n_matches"] == counts[k, 0] and ed["n_inliers"] == counts[k, 1], (p, pairs[k])
+    return len(pick), accepted, secs[0], threads
+
+
 def test_c5_survey_at_size(oracle):
     ctx = capi.Context(0)
     grid = synth.make_grid(seed=2025, **synth.CONFIGS["C5"])      # BASELINE's C5: 50 x 100 cameras, 4 096 features each
@@ -110,7 +141,11 @@ def test_c5_survey_at_size(oracle):
     edges_all = g.edges(with_distances=True)
     checked, accepted = _check_sampled_edges(oracle, grid, edges_all, index_of, 130)
     assert checked >= 120 and accepted >= 100
-    print("C5 link stage: %d of %d directed pairs against the oracle (%d accepted edges)" % (checked, len(edges_all), accepted))
+    print("C5 link stage: %d of %d directed pairs against the oracle's link_pair (%d accepted edges)" % (checked, len(edges_all), accepted))
+    many, many_accepted, cpu_s, threads = _check_many_edges(oracle, grid, edges_all, index_of, 2400)
+    assert many >= 2300 and many_accepted >= 2000
+    print("C5 link stage: %d more evenly sampled pairs equal to the oracle's link stage (matches, inliers, homography; %.1f s on %d threads)"
+          % (many, cpu_s, threads))
     # ---- the plane relax of all cameras as one group: 3 n + 3 unknowns
     plane = g.relax(ctx, start, host.relax_options("ORIENTATION", "GROUND_PLANE"))
     assert int(plane["residual_blocks"]) > 1_000_000
@@ -152,13 +187,16 @@ def test_c5_survey_at_size(oracle):
     # the value itself wanders, inside its bounds; the oracle parity below is the check that it wanders correctly)
     assert 100.0 <= model_after[0] <= 20000.0 and np.all(np.isfinite(model_after))
     g.set_model(0, grid.model)
-    # ---- oracle parity on three sampled groups, re-solved stand-alone from the same start
+    # ---- oracle parity on ten of the hundred mesh groups (every tenth, largest to smallest) and the intrinsics group, re-solved
+    #      stand-alone from the same start
     report = []
-    for members, opts in ((np.flatnonzero(grp == 0), O_MESH), (np.flatnonzero(grp == 57), O_MESH), (np.flatnonzero(gi == 0), O_INTR)):
+    sampled = [(np.flatnonzero(grp == k), O_MESH) for k in (0, 11, 22, 33, 44, 57, 66, 77, 88, 99)] + [(np.flatnonzero(gi == 0), O_INTR)]
+    for members, opts in sampled:
         edges, feats, pk = _subproblem(grid, g, edges_all, index_of, members, ori0)
         got, exp, t_cpu = _both(ctx, oracle, grid, members, edges, feats, pk, ori0[members], opts, sa["vertices"], sa["edges"])
         report.append((len(members), len(edges), int(got["residual_blocks"]), int(got["iterations_total"]), round(t_cpu, 1),
                        round(got["device_s"], 3)))
+    assert len(report) == 11
     print("C5 sampled groups (cameras, edges, blocks, LM iterations, oracle s, device s):", report)
     # ---- the single global group of FINAL_GLOBAL_RELAX's last run over all 5 000 cameras
     g.set_orientations(ori1)

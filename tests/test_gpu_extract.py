@@ -136,13 +136,14 @@ def test_featureless_tiny_and_overflowing_inputs(ctx, oracle):
     assert len(got[0][0]) > 500
 
 
-@pytest.mark.parametrize("w,h", [(1600, 1200), (776, 584), (808, 610)])
+@pytest.mark.parametrize("w,h", [(1600, 1200), (784, 600), (1584, 1192), (776, 584)])
 def test_strip_kernels_on_noisy_views_up_to_the_border(ctx, oracle, w, h):
     """Round 5's register-strip kernels (level_strip_kernel, det_strip_kernel) on views with pixel noise: the diffusion spreads
     whatever the conductivity's reflected taps and the Gaussian's replicated border produce along the image border a few
-    pixels further at every level, and descriptors of keypoints near the border sample it.  Widths that are not a multiple
-    of the strips' 104 - 120 columns, heights that are not a multiple of their rows; 1600 x 1200 is the working size of
-    the bench's 4000 x 3000 views."""
+    pixels further at every level, and descriptors of keypoints near the border sample it.  Widths that are a multiple of 16
+    (every level of every octave has an even width: the strips can take them all) but not of the strips' 104 - 120 columns,
+    heights that are not a multiple of their rows; 1600 x 1200 is the working size of the bench's 4000 x 3000 views;
+    776 x 584 reaches an odd width in the last octave: the tile kernels everywhere, whatever the route."""
     rng = np.random.default_rng(w)
     base = synth.render_blobs(w, h, 31)
     img = np.clip(base.astype(np.int32) + rng.integers(0, 40, (h, w, 1)) - 20, 0, 255).astype(np.uint8)
@@ -154,14 +155,35 @@ def test_strip_kernels_on_noisy_views_up_to_the_border(ctx, oracle, w, h):
     assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32)) and np.array_equal(gdesc, edesc)
 
 
+def test_the_mixed_route_of_a_bench_chunk(oracle, monkeypatch):
+    """The default routing of a bench chunk - strips on the levels of >= 32 Mpixel per launch (octaves 0 - 1 of 100 views), tiles
+    and the tile form of the contrast pass on the rest - on a batch small enough for the restatement: OCHIP_STRIP_MIN_PIXELS
+    puts the threshold between the second and the third octave of three 784 x 600 views."""
+    monkeypatch.setenv("OCHIP_STRIP_MIN_PIXELS", str(3 * 392 * 300))      # octave 1 and up are strips, octaves 2 - 3 tiles
+    c = capi.Context(0)
+    rng = np.random.default_rng(5)
+    imgs = []
+    for k in range(3):
+        base = synth.render_blobs(784, 600, 40 + k)
+        imgs.append(np.clip(base.astype(np.int32) + rng.integers(0, 30, (600, 784, 1)) - 15, 0, 255).astype(np.uint8))
+    got, (ww, wh) = c.akaze_batch(np.stack(imgs), max_kp=40000)
+    assert (ww, wh) == (784, 600)
+    for k in range(3):
+        ekp, edesc = oracle.akaze(imgs[k][:, :, 0])
+        gkp, gdesc = got[k]
+        assert len(gkp) == len(ekp) > 300
+        assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32)) and np.array_equal(gdesc, edesc)
+    c.close()
+
+
 @pytest.mark.parametrize("hooks", ["tile_levels,tile_det", "strip_levels,strip_det"])
 def test_tile_and_strip_kernels_agree(hooks):
     """The scale space and the detector have two forms: the register-strip kernels of round 5 (level_strip_kernel,
     det_strip_kernel) for launches with enough strips to fill the device (>= 32 Mpixel per level and launch: the first two
     octaves of a 100-image chunk), and the tile kernels of rounds 2 - 4 (blur_fused / nld_fused / det_maxima) for the rest
     and for levels of odd width.  A single test image takes the tiles everywhere; OCHIP_TEST_HOOKS=strip_levels,strip_det
-    sends every level the strips can take through them, tile_levels,tile_det every level through the tiles.  The switches
-    are read once per process: this file's parity tests run again in a child per route."""
+    sends every level the strips can take through them, tile_levels,tile_det every level through the tiles.  This file's
+    parity tests run again in a child per route."""
     import os
     import subprocess
     import sys

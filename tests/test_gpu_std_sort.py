@@ -114,3 +114,14 @@ def test_many_segments_take_the_workgroup_per_segment_route(ctx):
     segs = [rng.uniform(0, 1, int(rng.integers(900, 26000))) for _ in range(40)] + [killer(20000), rng.integers(0, 50, 30000)]
     assert run(ctx, segs) == 0
     assert run(ctx, segs[:5] + [killer(20000)]) == 0
+
+
+def test_both_routes_on_the_same_segments(ctx, monkeypatch):
+    """The workgroup-per-segment route (from 8 segments on: a from-host chunk of 25 images takes it too) and the launch-per-level
+    route (OCHIP_TEST_HOOKS=sort_per_level, read per call) on the same segments: both are libstdc++'s permutation."""
+    rng = np.random.default_rng(23)
+    segs = [rng.integers(0, 4000, int(rng.integers(15000, 26000))) for _ in range(25)]       # 25 images' keypoints, tied responses
+    assert run(ctx, segs) == 0
+    assert run(ctx, segs[:8]) == 0 and run(ctx, segs[:7]) == 0                                 # either side of the threshold
+    monkeypatch.setenv("OCHIP_TEST_HOOKS", "sort_per_level")
+    assert run(ctx, segs) == 0

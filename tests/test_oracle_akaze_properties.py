@@ -164,3 +164,46 @@ def test_descriptor_has_486_bits(scene):
     assert ((d[:, 7] >> np.uint64(486 - 7 * 64)) == 0).all()          # nothing beyond bit 485
     bits = np.unpackbits(d.view(np.uint8), axis=1, bitorder="little")[:, :486]
     assert 0.2 < bits.mean() < 0.8 and bits.any(axis=0).mean() > 0.95   # every comparison fires somewhere
+
+
+def test_restated_sinf_cosf_are_this_images_libm():
+    """D2: the descriptor rotates by cosf / sinf of the keypoint's angle (libm).  The restatement of glibc's sinf / cosf
+    (oracle/akaze.cpp: libm_sinf, libm_cosf) against THIS image's libm for every float an angle can be - [0, 2 pi] and some - :
+    a pin in the brief's sense (a known-answer check against the third-party code itself, 1.09e9 arguments each)."""
+    import ctypes as C
+    import struct
+
+    L = pyoracle.lib()
+    L.oc_libm_sincosf_mismatches.restype = C.c_uint64
+    L.oc_libm_sincosf_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    hi = struct.unpack("<I", struct.pack("<f", 6.3))[0]
+    first = C.c_uint32(0)
+    assert L.oc_libm_sincosf_mismatches(0, hi, C.byref(first)) == 0, hex(first.value)
+
+
+def test_fast_atan2_and_the_two_by_two_solve():
+    """D2: cv::fastAtan2's polynomial in degrees (0.3 degrees of the true angle, the folds at 90 / 180 / 360); D3: cv::solve's
+    2 x 2 fast path (Cramer's rule in double, a singular system leaves (0, 0))."""
+    import ctypes as C
+
+    L = pyoracle.lib()
+    L.oc_akaze_float_functions.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.oc_akaze_subpixel_solve.argtypes = [C.c_float] * 5 + [C.POINTER(C.c_float)]
+    rng = np.random.default_rng(3)
+    a, s, c = C.c_float(), C.c_float(), C.c_float()
+    for y, x in [(0.0, 1.0), (1.0, 0.0), (0.0, -1.0), (-1.0, 0.0), (1.0, 1.0)] + rng.normal(size=(2000, 2)).tolist():
+        L.oc_akaze_float_functions(y, x, C.byref(a), C.byref(s), C.byref(c))
+        true = np.degrees(np.arctan2(y, x)) % 360.0
+        d = abs(a.value - true)
+        assert min(d, 360.0 - d) < 0.3 and 0.0 <= a.value <= 360.0, (y, x, a.value, true)
+    L.oc_akaze_float_functions(1.0, 1.0, C.byref(a), C.byref(s), C.byref(c))
+    assert abs(a.value - 45.0) < 0.01
+    out = (C.c_float * 2)()
+    for _ in range(500):
+        Dxx, Dxy, Dyy, Dx, Dy = (rng.normal(size=5) * [4, 1, 4, 1, 1]).astype(np.float32)
+        L.oc_akaze_subpixel_solve(Dxx, Dxy, Dyy, Dx, Dy, out)
+        A = np.array([[Dxx, Dxy], [Dxy, Dyy]], np.float64)
+        exp = np.linalg.solve(A, -np.array([Dx, Dy], np.float64))
+        assert np.allclose([out[0], out[1]], exp, rtol=2e-6, atol=1e-6)
+    L.oc_akaze_subpixel_solve(1.0, 2.0, 4.0, 0.3, 0.2, out)        # singular: the offset stays at the pixel
+    assert out[0] == 0.0 and out[1] == 0.0

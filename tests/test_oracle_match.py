@@ -40,8 +40,9 @@ def test_spatial_subsample_properties(oracle):  # test_match.cpp:44-88 (monotone
 
 def test_subsample_matches_reference_kdtree(oracle):
     """The hash-grid restatement must agree with the reference's jk::tree::KDTree driver loop."""
-    if oracle.ref() is None:
-        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    from conftest import require_ref
+
+    require_ref(oracle)
     rng = np.random.default_rng(11)
     for n, spacing in ((1, 40.0), (50, 40.0), (4000, 40.0), (4000, 8.0), (2000, 123.5)):
         loc = rng.uniform(0, 4000, (n, 2))
@@ -113,8 +114,9 @@ def test_distort_radial_tangential(oracle):  # test_distort.cpp:57-68
 
 def test_knn_reference_has_no_ties_on_synthetic_grid(oracle):
     """positions are jittered so the kNN(10) pair set is tree-independent."""
-    if oracle.ref() is None:
-        pytest.skip("oracle/_ref not built")
+    from conftest import require_ref
+
+    require_ref(oracle)
     g = synth.make_grid(4, 6, feats=64, seed=1)
     knn = oracle.ref_knn(g.position[:, :2], 10)
     xy = g.position[:, :2]

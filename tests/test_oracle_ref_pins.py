@@ -10,9 +10,9 @@ import pytest
 
 @pytest.fixture(scope="module")
 def ref(oracle):
-    r = oracle.ref()
-    if r is None or not hasattr(r, "ref_grid_filter_values"):
-        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    from conftest import require_ref
+
+    r = require_ref(oracle, "ref_grid_filter_values")
     u64p, f64p = oracle.u64p, oracle.f64p
     for lib in (r, oracle.lib()):
         pre = "ref" if lib is r else "ocx"

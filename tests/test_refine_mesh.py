@@ -64,9 +64,9 @@ def _grid_cloud(lo, hi, step, zf):
 def test_unordered_dense_erase_moves_the_last_element():
     """The restated containers (vectors with swap-and-pop) are the real header's behaviour."""
     import ctypes as C
-    r = pyoracle.ref()
-    if r is None or not hasattr(r, "ref_dense_set_order"):
-        pytest.skip("oracle/_ref was built without the container pin")
+    from conftest import require_ref
+
+    r = require_ref(pyoracle, "ref_dense_set_order")
     r.ref_dense_set_order.restype = C.c_size_t
     r.ref_dense_set_order.argtypes = [np.ctypeslib.ndpointer(np.int64), C.c_size_t, np.ctypeslib.ndpointer(np.uint64)]
     rng = np.random.default_rng(1)
