@@ -46,6 +46,12 @@ double since(clk::time_point t0)
     return std::chrono::duration<double>(clk::now() - t0).count();
 }
 
+bool stage_priority()
+{
+    const char *e = std::getenv("OCHIP_IP_PRIORITY");
+    return !(e && e[0] == '0');
+}
+
 // the link stage's runners over `link`'s pairs: ranges of 125 links, each on a runner thread with its own device context
 bool run_link_runners(och_graph *g, ochip_ctx *ctx, LinkStage &link)
 {
@@ -78,6 +84,10 @@ bool run_link_runners(och_graph *g, ochip_ctx *ctx, LinkStage &link)
             sibling_error = std::string("ochip_ctx_sibling: ") + ochip_last_error(ctx);
             break;
         }
+        // a batch's link stage is a chain of short launches (900 pairs do not fill the device; RANSAC is as long as its
+        // slowest pair) beside the extraction's launches that do: its streams go ahead of them (OCHIP_IP_PRIORITY=0: not)
+        if (stage_priority())
+            (void)ochip_ctx_set_priority(rctx, 1);
         runners.emplace_back([&, rctx]() {
             for (;;)
             {
@@ -217,6 +227,8 @@ int och_initial_processing_step(och_initial_processing *ip, const uint8_t *image
         ochip_ctx *rctx = nullptr;
         if (ochip_ctx_sibling(ctx, 12, &rctx) != OCHIP_OK)
             rctx = ctx;
+        else if (stage_priority())
+            (void)ochip_ctx_set_priority(rctx, 1);
         auto runners = relax.get_runners(rctx, g->graph);
         run_parallel(runners, relax.runner_contexts());
         t_relax = since(t0);

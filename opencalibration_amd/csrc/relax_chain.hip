@@ -1012,6 +1012,7 @@ enum
     ACT_FINISH,
     ACT_AFTER_SOLVE,
     ACT_AFTER_EVAL,
+    ACT_EVAL_SERIAL,
     ACT_AFTER_ASM,
     ACT_START_ITERATION,
     ACT_AFTER_CHOL,
@@ -1105,7 +1106,81 @@ struct epi
             C.phase = PH_SETUP;
         }
         __syncthreads();
-        return ACT_NONE;
+        if (C.n_filter > 0)
+            return ACT_NONE;
+        // no edge takes part (the usual step once the graph is more than twice the group: the first edge of the whitelist
+        // already touches a camera without an orientation, relax_problem.cpp:251-252): nothing to filter, no blocks - the
+        // camera's prior is all there is, and the whole step runs right here, without a phase and without a sync
+        const double *Q = D.q[C.cur];
+        double priors = 0;
+        for (uint32_t c = t; c < D.n_cams; c += TG)
+        {
+            const bool pr = optimised(c) && !nan4(Q + 4 * (size_t)c);
+            D.cam_prior[c] = pr ? 1 : 0;
+            D.cam_blocks[c] = 0;
+            priors += pr ? 1.0 : 0.0;
+        }
+        for (uint32_t e = t; e < D.n_edges; e += TG)
+            D.blk_cnt[e] = 0;
+        const double n_prior = reduce_sum(priors);
+        if (t == 0)
+        {
+            C.n_blocks = 0;
+            C.n_live = 0;
+            C.n_prior = (int)n_prior;
+        }
+        __syncthreads();
+        arg_which = 0;
+        return ACT_BEGIN_SOLVE;
+    }
+
+    // an evaluation without residual blocks (the priors alone) of a small system: what PH_EVAL and PH_ASM would leave - the
+    // priors' 3 x 3 blocks, gradients and cost, zeros elsewhere - written by this workgroup
+    __device__ int eval_serial()
+    {
+        __syncthreads();
+        const int set = C.eval_set, n = C.n;
+        double *A = D.A[set], *g = D.g[set];
+        const double *Q = D.q[C.eval_state];
+        for (int e = t; e < n * n; e += TG)
+            if (e % n <= e / n)
+                A[at(e / n, e % n)] = 0.0;
+        for (int i = t; i < n; i += TG)
+            g[i] = 0.0;
+        __syncthreads();
+        double pc = 0;
+        for (uint32_t c = t; c < D.n_cams; c += TG)
+        {
+            const int tc = D.cam_t[c];
+            if (tc < 0 || !D.cam_prior[c])
+                continue;
+            double r, j3[3];
+            downward_prior(Q + (size_t)c * 4, D.prior_weight, &r, j3);
+            double Dd[6] = {0, 0, 0, 0, 0, 0}, G[3] = {0, 0, 0}; // (the sums the camera's gather starts from)
+            int k = 0;
+            for (int i = 0; i < 3; i++)
+            {
+                for (int j = i; j < 3; j++)
+                    Dd[k++] += j3[i] * j3[j];
+                G[i] += j3[i] * r;
+            }
+            k = 0;
+            for (int i = 0; i < 3; i++)
+                for (int j = i; j < 3; j++)
+                    A[at(tc + j, tc + i)] = Dd[k++];
+            for (int i = 0; i < 3; i++)
+                g[tc + i] = G[i];
+            pc += 0.5 * r * r;
+        }
+        const double prior_cost = reduce_sum(pc);
+        if (t == 0)
+        {
+            for (int q = 0; q < 9; q++)
+                C.tot[q] = 0.0;
+            C.tot[9] = 0.0 + prior_cost;
+        }
+        __syncthreads();
+        return ACT_AFTER_ASM;
     }
 
     // after PH_SETUP: block count, priors, which cameras have blocks
@@ -1258,7 +1333,7 @@ struct epi
             C.phase = PH_EVAL;
         }
         __syncthreads();
-        return ACT_NONE;
+        return (C.n_live == 0 && C.n <= N_SMALL) ? ACT_EVAL_SERIAL : ACT_NONE;
     }
 
     // p.second->orientation.normalize() (:1410-1413), the solve's figures, on to the next solve or step
@@ -1756,7 +1831,7 @@ struct epi
             C.phase = PH_EVAL;
         }
         __syncthreads();
-        return ACT_NONE;
+        return (C.n_live == 0 && C.n <= N_SMALL) ? ACT_EVAL_SERIAL : ACT_NONE;
     }
 
     __device__ void advance(int phase)
@@ -1804,6 +1879,9 @@ struct epi
                 break;
             case ACT_AFTER_EVAL:
                 act = after_eval();
+                break;
+            case ACT_EVAL_SERIAL:
+                act = eval_serial();
                 break;
             case ACT_AFTER_ASM:
                 act = after_asm();

@@ -146,6 +146,8 @@ def run_initial_processing(ctx, grid, images_ptr, shape, batch=100, max_keypoint
         for k in ("load_runner_s", "link_runner_s", "relax_runner_s", "relax_device_s", "relax_setup_host_s"):
             out[k] += st[k]
         out["step_seconds"].append(round(st["step_s"], 4))
+        out.setdefault("step_stage_seconds", []).append([round(st[k], 4) for k in ("init_s", "load_runner_s", "link_runner_s", "relax_runner_s",
+                                                                                   "finalize_s")])
     ctx.synchronize()
     out["seconds"] = time.perf_counter() - t_all
     out["edges"] = g.num_edges

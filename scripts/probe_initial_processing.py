@@ -21,4 +21,6 @@ for rep in range(3):
           "median error %.2e, unoriented %d" % (rep, inc["seconds"], grid.n_images / inc["seconds"], inc["step_seconds"], inc["load_runner_s"],
                                                  inc["link_runner_s"], inc["relax_runner_s"], inc["relax_device_s"], inc["relax_setup_host_s"],
                                                  inc["solves"], inc["lm_iterations"], float(np.median(err)), int(np.sum(~np.isfinite(err)))), flush=True)
+    if rep == 2:
+        print("per step [init, load runner, link runner, relax runner, finalize]:", inc["step_stage_seconds"], flush=True)
     g.close()
