@@ -10,7 +10,15 @@
 //                      level size), sort_per_level (a launch per introsort level instead of a workgroup per segment),
 //                      host_triangulation (densifyMesh's track points by the host loop instead of ochip_dense_triangulate),
 //                      dense_predict_unstaged (the nearest-camera scan and the tracks' member -> image search read the device's records instead of
-//                      their LDS copies, as they do above 2 048 cameras)
+//                      their LDS copies, as they do above 2 048 cameras),
+//                      host_bootstrap (runGroundPlane's cameras without an orientation by round 5's host loop - a problem and two
+//                      solves each - instead of the resident launch of csrc/relax_chain.hip), chain_stepped (that launch one phase
+//                      at a time: the same code, a launch per phase), chain_partial (it takes the first half of the cameras and
+//                      hands the rest to the host loop, as it does when it gives up)
+// Other switches (read where they apply): OCHIP_CHAIN_WORKGROUPS (grid of the resident launch; default half the compute units),
+// OCHIP_IP_PRIORITY=0 (och_initial_processing_step: link and relax streams at the default priority), OCHIP_STRIP_MIN_PIXELS
+// (pixels per launch from which a level takes the register-strip kernels), OCHIP_EXTRACT_GATE=0 (two surveys may extract at once),
+// OCHIP_REQUIRE_REF=1 (tests: the pins against the reference's own headers must run)
 #pragma once
 
 #include <cstdlib>

@@ -66,3 +66,21 @@ def test_resident_launch_equals_its_stepped_form_and_the_host_loop(rows, cols, b
     err = np.array([qangle(resident[-1][i], grid.orientation[i]) for i in range(grid.n_images)])
     assert np.median(err) < 2e-3
     ctx.close()
+
+
+def test_a_chain_that_stops_half_way_hands_over_to_the_host_loop(monkeypatch):
+    """The chain gives up when a step needs the host's grid filter (a tie for a cell's best score) or a wait on the device runs
+    into its limit: the poses it finished are written back and the host loop continues from the next one.
+    OCHIP_TEST_HOOKS=chain_partial makes it stop after half of every group's cameras: the same solves, iterations and (to
+    rounding) orientations as the chain alone and the host loop alone."""
+    ctx = capi.Context(0)
+    grid = synth.make_grid(4, 10, feats=512, seed=4)
+    whole, s_whole = _schedule(ctx, grid, 10, None, monkeypatch)
+    half, s_half = _schedule(ctx, grid, 10, "chain_partial", monkeypatch)
+    loop, s_loop = _schedule(ctx, grid, 10, "host_bootstrap", monkeypatch)
+    for b in range(len(whole)):
+        upto = min((b + 1) * 10, grid.n_images)
+        assert s_half[b] == s_whole[b] == s_loop[b], (b, s_half[b], s_whole[b], s_loop[b])
+        assert max(qangle(half[b][i], whole[b][i]) for i in range(upto)) < 1e-7
+        assert max(qangle(half[b][i], loop[b][i]) for i in range(upto)) < 1e-7
+    ctx.close()
