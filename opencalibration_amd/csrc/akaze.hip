@@ -1766,71 +1766,309 @@ __device__ __forceinline__ bool xcd_contiguous(unsigned int block, unsigned int 
     return *item < n_items;
 }
 
-// A candidate dies if a stronger maximum (ties: lower (level, y, x) wins) of an adjacent level lies within
-// its own size esigma * derivative_factor (base-image pixels).  One THREAD per candidate, walking the maxima bit
-// masks of up to three levels: a window is at most ~17 pixels wide, i.e. one or two 64-bit words per row, and almost
-// every word is zero, so a candidate costs ~100 word loads and a handful of response reads.  (A wavefront per candidate
-// - first over the float maps, then over the masks - spent ~300 wave instructions per candidate however little its
-// lanes had to do: 30 us per image, VALU-issue bound.)  List neighbours are spatial neighbours (tile order), so the
-// lanes of a wave read the same few mask lines.
-__global__ __launch_bounds__(256) void suppress_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
-                                                       unsigned int max_cands, const float *__restrict__ Rmax, size_t img_stride,
-                                                       const unsigned long long *__restrict__ mask, size_t mask_stride,
-                                                       levels_dev L, float derivative_factor, unsigned char *__restrict__ dead)
+// ---- AKAZEFeatures::Find_Scale_Space_Extrema's suppression (OpenCV 4.x: three passes over per-level keypoint masks; the CPU
+// restatement's suppress_masks_4x quotes the rule).  Pass 1, inside a level in raster order:
+// a maximum looks for the FIRST keypoint already set within sigma_size (window [y - r, y + r) x [x - r, x + r) in raster order,
+// Euclidean test) - none: it is set; it is stronger: that one is cleared and it is set; otherwise it is dropped.  Pass 2, levels
+// upwards: a set keypoint clears the first set keypoint of the level BELOW within sigma_size * octave step of its projection
+// if it is stronger.  Pass 3, levels downwards: the same against the level ABOVE (radius: that level's sigma_size).  The
+// outcome depends on the order of the turns, so the order is reproduced - in rounds instead of in sequence (DESIGN.md section
+// 4.1 has the argument; the CPU restatement's suppress_masks_4x_in_rounds is this kernel's schedule and agrees with
+// the sequential form on every candidate of the census images):
+//   * pass 1: a maximum takes its turn once every maximum in front of it in raster order within 2 sigma_size - 1 (Chebyshev)
+//     has had its own: two maxima further apart read and write disjoint windows;
+//   * passes 2 and 3 clear keypoints of the OTHER level only and read their own level as the previous pass left it, so the
+//     levels of a pass do not depend on each other, and inside a level a keypoint waits for the keypoints in front of it whose
+//     windows in the other level can overlap its own (2 sigma_size - 1 / 2 sigma_size' * octave step - 1).
+// A launch per pass, a workgroup per (level, image) - the candidate list is level by level (tile_seq), so a level's candidates
+// are one range of it.  A round = every point still waiting tests the `pending` mask of its box, a barrier, the ready ones take
+// their turns (atomics on the mask words), a barrier.  Nothing a workgroup reads is written by another one during a launch (pass 1
+// stays inside the level; in passes 2 and 3 a level's workgroup reads its own copy of the level's bits and is the only one to
+// clear bits of the level below / above), so workgroup-scope ordering - the barriers - is all it takes: an agent-scope fence per
+// round (L2 write-back + invalidate on this part) made the three launches 9 ms per 100 images.  Rounds are latency-bound, ~10 -
+// 15 per level in passes 1 and 2 and ~25 in pass 3 on a 1600 x 1200 image.
+constexpr int SUP_THREADS = 256;
+constexpr int SUP_LDS = 2048; // list entries a workgroup keeps in LDS (two lists); a longer list continues in HBM
+constexpr unsigned int SUP_READY = 0x80000000u; // list entry: x | y << 16 | this flag
+
+__device__ __forceinline__ unsigned long long sup_window(int lo, int hi) // bits lo .. hi of a word, 0 <= lo <= hi <= 63
 {
-    const unsigned int b = blockIdx.z;
-    const unsigned int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= min(n_cands[b], max_cands))
-        return;
-    const cand_t c = cands[(size_t)b * max_cands + k];
-    const level_info lc = L.l[c.level];
-    const float ratio_c = (float)(1 << lc.octave);
-    const float rad = lc.esigma * derivative_factor, r2 = rad * rad;
-    const float cx = (float)c.x * ratio_c, cy = (float)c.y * ratio_c;
-    bool is_dead = false;
-    for (int j = max(c.level - 1, 0); j <= min(c.level + 1, L.n - 1) && !is_dead; j++)
+    return (~0ull << lo) & (~0ull >> (63 - hi));
+}
+// a point of this pass in front of (x, y) in raster order inside the box of half-width r that has not had its turn.  r <= 7
+// (every level of the default scale space: sigma_size is 2, 3 or 4): seven rows above and the row itself, two words each,
+// requested without a branch - a row outside the box or the image reads row 0 and is masked out
+__device__ __forceinline__ bool sup_pending(const unsigned long long *Pm, const level_info &l, int x, int y, int r)
+{
+    const int x0 = max(x - r, 0), x1 = min(x + r, l.w - 1);
+    const int w0 = x0 >> 6, w1 = x1 >> 6;
+    const unsigned long long win0 = sup_window(x0 - w0 * 64, min(x1 - w0 * 64, 63)), win1 = w1 > w0 ? sup_window(0, x1 - w1 * 64) : 0ull;
+    unsigned long long any = 0;
+    if (r <= 7)
     {
-        const level_info lj = L.l[j];
-        const float ratio = (float)(1 << lj.octave), inv = 1.0f / ratio; // power of two: * inv == / ratio, bit for bit
-        const int x0 = max((int)floorf((cx - rad) * inv), 0), x1 = min((int)ceilf((cx + rad) * inv), lj.w - 1);
-        const int y0 = max((int)floorf((cy - rad) * inv), 0), y1 = min((int)ceilf((cy + rad) * inv), lj.h - 1);
-        const float *R = Rmax + (size_t)b * img_stride + lj.off;
-        const unsigned long long *M = mask + (size_t)b * mask_stride + (size_t)lj.mask_off;
-        for (int wx = x0 >> 6; wx <= (x1 >> 6) && !is_dead; wx++)
+#pragma unroll
+        for (int q = 1; q <= 7; q++)
         {
-            // bits of this word column inside [x0, x1]
-            const int lo = max(x0 - wx * 64, 0), hi = min(x1 - wx * 64, 63);
-            const unsigned long long window = (~0ull << lo) & (~0ull >> (63 - hi));
-            for (int yb = y0; yb <= y1 && !is_dead; yb += 4)
+            const bool inside = q <= r && y - q >= 0;
+            const size_t row = (size_t)(inside ? y - q : 0) * l.tiles_x;
+            const unsigned long long a = Pm[row + w0] & win0, c = Pm[row + w1] & win1;
+            any |= inside ? (a | c) : 0ull;
+        }
+    }
+    else
+        for (int i = max(y - r, 0); i < y; i++)
+            any |= (Pm[(size_t)i * l.tiles_x + w0] & win0) | (Pm[(size_t)i * l.tiles_x + w1] & win1);
+    // row y: the columns in front of x
+    if (x - 1 >= x0)
+    {
+        const int h0 = min(x - 1 - w0 * 64, 63);
+        any |= Pm[(size_t)y * l.tiles_x + w0] & sup_window(x0 - w0 * 64, h0);
+        if (w1 > w0 && x - 1 >= w1 * 64)
+            any |= Pm[(size_t)y * l.tiles_x + w1] & sup_window(0, x - 1 - w1 * 64);
+    }
+    return any != 0;
+}
+// find_neighbor_point: the first set bit, in raster order, of [y - r, y + r) x [x - r, x + r) within r (Euclidean) of (x, y)
+__device__ __forceinline__ bool sup_first_set(const unsigned long long *W, const level_info &l, int x, int y, int r, int *fx, int *fy)
+{
+    const int x0 = max(x - r, 0), x1 = min(x + r, l.w) - 1, y0 = max(y - r, 0), y1 = min(y + r, l.h) - 1;
+    if (x1 < x0)
+        return false;
+    const int w0 = x0 >> 6, w1 = x1 >> 6; // (a window is at most 16 wide: one word or two)
+    const unsigned long long win0 = sup_window(x0 - w0 * 64, min(x1 - w0 * 64, 63)), win1 = w1 > w0 ? sup_window(0, x1 - w1 * 64) : 0ull;
+    for (int yb = y0; yb <= y1; yb += 4)
+    {
+        unsigned long long m0[4], m1[4]; // four rows requested together
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            m0[q] = yb + q <= y1 ? W[(size_t)(yb + q) * l.tiles_x + w0] & win0 : 0ull;
+            m1[q] = yb + q <= y1 && w1 > w0 ? W[(size_t)(yb + q) * l.tiles_x + w1] & win1 : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            for (int half = 0; half < 2; half++)
             {
-                unsigned long long m[4]; // four rows' words requested together
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    m[r] = yb + r <= y1 ? M[(size_t)(yb + r) * lj.tiles_x + wx] & window : 0ull;
-#pragma unroll
-                for (int r = 0; r < 4; r++)
+                unsigned long long bits = half ? m1[q] : m0[q];
+                while (bits)
                 {
-                    unsigned long long bits = m[r];
-                    const int yy = yb + r;
-                    while (bits)
+                    const int j = (half ? w1 : w0) * 64 + __ffsll((long long)bits) - 1, i = yb + q;
+                    bits &= bits - 1;
+                    if ((j - x) * (j - x) + (i - y) * (i - y) <= r * r)
                     {
-                        const int xx = wx * 64 + __ffsll((long long)bits) - 1;
-                        bits &= bits - 1;
-                        if (j == c.level && xx == c.x && yy == c.y)
-                            continue;
-                        const float ex = (float)xx * ratio - cx, ey = (float)yy * ratio - cy;
-                        if (ex * ex + ey * ey <= r2)
-                        {
-                            const float rr = R[(size_t)yy * lj.w + xx];
-                            const bool lower_key = j < c.level || (j == c.level && (yy < c.y || (yy == c.y && xx < c.x)));
-                            is_dead = is_dead || rr > c.response || (rr == c.response && lower_key);
-                        }
+                        *fx = j;
+                        *fy = i;
+                        return true;
                     }
                 }
             }
+    }
+    return false;
+}
+// first list entry of a level (the list is complete: n <= max_cands was checked)
+__device__ __forceinline__ unsigned int sup_level_begin(const levels_dev &L, int level, unsigned int n, const unsigned int *tile_base,
+                                                        const unsigned int *tile_seq)
+{
+    return level >= L.n ? n : tile_base[tile_seq[L.l[level].tile_off]];
+}
+
+// Round 0 of a pass, one THREAD per candidate over the whole chunk: whether a point can take its turn at once depends on the
+// static masks only (pass 1: the maxima, passes 2 / 3: `own`, a copy of the keypoints the previous pass left - the pass clears
+// keypoints of the levels next to the one whose turns it takes, so who HAS a turn is read from the copy).  Two thirds to nine
+// tenths of the points can, and since which ones is known without looking at anything the launch writes, test and turn are
+// one step here (no barrier): a ready point's window holds nothing another ready point writes.  In pass 1 such a turn is
+// "set the bit" (a keypoint already set inside its window would be a point in front of it that has not had its turn).  The
+// others are marked in `pend` for the rounds kernel.
+template <int PASS>
+__global__ __launch_bounds__(256) void suppress_round0_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
+                                                              unsigned int max_cands, const float *__restrict__ Rmax, size_t img_stride,
+                                                              const unsigned long long *__restrict__ own, unsigned long long *pend,
+                                                              unsigned long long *kmask, size_t mask_stride, levels_dev L,
+                                                              const unsigned int *__restrict__ tile_base,
+                                                              const unsigned int *__restrict__ tile_seq, int n_tiles,
+                                                              unsigned int *__restrict__ turns, unsigned int *__restrict__ waiting)
+{
+    const unsigned int b = blockIdx.z, k = blockIdx.x * 256 + threadIdx.x, n = min(n_cands[b], max_cands);
+    cand_t c = cand_t{0, 0, 0, 0.f, 0.f, 0.f};
+    bool has_turn = k < n;
+    if (has_turn)
+    {
+        c = cands[(size_t)b * max_cands + k];
+        has_turn = !((PASS == 2 && c.level == 0) || (PASS == 3 && c.level == L.n - 1)); // (no level below / above: no turns)
+    }
+    // (list neighbours are of one level except where two levels' ranges meet: the level's constants by scalar loads when the
+    // wavefront agrees on the level, per lane - a dozen vector loads each - otherwise)
+    const int lv0 = __builtin_amdgcn_readfirstlane(c.level);
+    const bool one_level = __all(k >= n || c.level == lv0);
+    const level_info l = one_level ? L.l[lv0] : L.l[c.level];
+    const size_t word = (size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6);
+    const unsigned long long bit = 1ull << (c.x & 63);
+    if (PASS != 1 && has_turn)
+        has_turn = (own[word] & bit) != 0;
+    bool waits = false;
+    if (has_turn)
+    {
+        const int other = PASS == 1 ? 0 : (PASS == 2 ? -1 : 1);
+        const level_info lo = one_level ? L.l[lv0 + other] : L.l[c.level + other];
+        const int diff = PASS == 2 ? 1 << (l.octave - lo.octave) : 1, shift = PASS == 3 ? lo.octave - l.octave : 0;
+        const int box = PASS == 3 ? 2 * lo.sigma_size * (1 << shift) - 1 : 2 * l.sigma_size - 1;
+        waits = sup_pending(own + (size_t)b * mask_stride + l.mask_off, l, c.x, c.y, box);
+        if (waits)
+            atomicOr(&pend[word], bit);
+        else if (PASS == 1)
+            atomicOr(&kmask[word], bit);
+        else
+        {
+            unsigned long long *Wo = kmask + (size_t)b * mask_stride + lo.mask_off;
+            const int r = PASS == 2 ? l.sigma_size * diff : lo.sigma_size;
+            const int px = PASS == 2 ? c.x * diff : c.x >> shift, py = PASS == 2 ? c.y * diff : c.y >> shift;
+            int fx = 0, fy = 0;
+            if (sup_first_set(Wo, lo, px, py, r, &fx, &fy) && c.response > Rmax[(size_t)b * img_stride + lo.off + (size_t)fy * lo.w + fx])
+                atomicAnd(&Wo[(size_t)fy * lo.tiles_x + (fx >> 6)], ~(1ull << (fx & 63)));
         }
     }
-    dead[(size_t)b * max_cands + k] = is_dead ? 1 : 0;
+    // the waiting points go to their level's list (its range of `turns`: a level's candidates are one range of the candidate
+    // list), one counter update per wavefront and level - the lanes of a wavefront are list neighbours, of one level or two
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(waits);
+    while (todo)
+    {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lv = __builtin_amdgcn_readlane(c.level, leader);
+        const unsigned long long same = __ballot(waits && c.level == lv);
+        unsigned int base = 0;
+        if (lane == leader)
+            base = atomicAdd(&waiting[(size_t)b * L.n + lv], (unsigned int)__popcll(same));
+        base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+        if (waits && c.level == lv)
+            turns[(size_t)b * 2 * max_cands + sup_level_begin(L, lv, n, tile_base + (size_t)b * n_tiles, tile_seq) + base +
+                  (unsigned int)__popcll(same & ((1ull << lane) - 1ull))] = (unsigned int)c.x | ((unsigned int)c.y << 16);
+        todo &= ~same;
+    }
+}
+
+// The rounds after round 0: a workgroup per (image, level) on the list round 0 left - short (a tenth to a third of the level's
+// points, shrinking fast), so small workgroups: with 1 024 threads each the launch held every wave slot of the device through its
+// barriers and the other launch sequences' bandwidth-bound kernels beside it lost a seventh of their rate.
+template <int PASS>
+__global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsigned int *__restrict__ n_cands, unsigned int max_cands,
+                                                                      const float *__restrict__ Rmax, size_t img_stride,
+                                                                      unsigned long long *pend, unsigned long long *kmask, size_t mask_stride,
+                                                                      levels_dev L, const unsigned int *__restrict__ tile_base,
+                                                                      const unsigned int *__restrict__ tile_seq, int n_tiles,
+                                                                      unsigned int *turns, unsigned int *waiting, unsigned int *__restrict__ stats)
+{
+    // pend: the points round 0 left waiting (all zero again when the launch ends); kmask: the keypoints
+    // (image fastest: workgroups go to the 8 XCDs round-robin, and with the level fastest the four levels of the first octave -
+    // 2/3 of all points - met on four XCDs)
+    const unsigned int b = blockIdx.x, tid = threadIdx.x;
+    const int level = (int)blockIdx.y + (PASS == 2 ? 1 : 0); // (pass 2: no level below level 0; pass 3: none above the last)
+    const unsigned int m0 = waiting[(size_t)b * L.n + level];
+    if (m0 == 0)
+        return;
+    const long long t_begin = stats ? (long long)wall_clock64() : 0;
+    const unsigned int n = min(n_cands[b], max_cands);
+    const unsigned int first = sup_level_begin(L, level, n, tile_base + (size_t)b * n_tiles, tile_seq);
+    const level_info l = L.l[level], lo = L.l[PASS == 1 ? level : (PASS == 2 ? level - 1 : level + 1)];
+    unsigned long long *Pm = pend + (size_t)b * mask_stride + l.mask_off, *W = kmask + (size_t)b * mask_stride + l.mask_off,
+                       *Wo = kmask + (size_t)b * mask_stride + lo.mask_off;
+    const float *R = Rmax + (size_t)b * img_stride + l.off, *Ro = Rmax + (size_t)b * img_stride + lo.off;
+    // the windows of two points can overlap when the points are at most `box` apart; the window in the other level
+    const int diff = PASS == 2 ? 1 << (l.octave - lo.octave) : 1, shift = PASS == 3 ? lo.octave - l.octave : 0;
+    const int box = PASS == 3 ? 2 * lo.sigma_size * (1 << shift) - 1 : 2 * l.sigma_size - 1;
+    const int r = PASS == 1 ? l.sigma_size : (PASS == 2 ? l.sigma_size * diff : lo.sigma_size);
+    // the two lists of points waiting for their turn: the first SUP_LDS entries in LDS, the rest in the level's range of `turns`
+    __shared__ unsigned int s_list[2][SUP_LDS];
+    __shared__ unsigned int s_n[2];
+    unsigned int *spill0 = turns + (size_t)b * 2 * max_cands + first, *spill1 = spill0 + max_cands;
+    auto get = [&](int which, unsigned int idx) { return idx < SUP_LDS ? s_list[which][idx] : (which ? spill1 : spill0)[idx]; };
+    auto put = [&](int which, unsigned int idx, unsigned int v) {
+        if (idx < SUP_LDS)
+            s_list[which][idx] = v;
+        else
+            (which ? spill1 : spill0)[idx] = v;
+    };
+    for (unsigned int idx = tid; idx < min(m0, (unsigned int)SUP_LDS); idx += SUP_THREADS)
+        s_list[0][idx] = spill0[idx];
+    if (tid == 0)
+        s_n[0] = m0;
+    __syncthreads();
+    int cur = 0;
+    unsigned int rounds = 0;
+    for (;; rounds++)
+    {
+        const unsigned int m = s_n[cur];
+        if (m == 0)
+            break;
+        if (tid == 0)
+            s_n[cur ^ 1] = 0;
+        for (unsigned int idx = tid; idx < m; idx += SUP_THREADS) // who is ready
+        {
+            const unsigned int e = get(cur, idx);
+            if (!sup_pending(Pm, l, (int)(e & 0xffffu), (int)(e >> 16), box))
+                put(cur, idx, e | SUP_READY);
+        }
+        __syncthreads();
+        for (unsigned int idx = tid; idx < m; idx += SUP_THREADS) // the turns
+        {
+            const unsigned int e = get(cur, idx);
+            if (!(e & SUP_READY))
+            {
+                put(cur ^ 1, atomicAdd(&s_n[cur ^ 1], 1u), e);
+                continue;
+            }
+            const int x = (int)(e & 0xffffu), y = (int)((e & ~SUP_READY) >> 16);
+            const size_t word = (size_t)y * l.tiles_x + (x >> 6);
+            const unsigned long long bit = 1ull << (x & 63);
+            const float response = R[(size_t)y * l.w + x];
+            int fx = 0, fy = 0;
+            if (PASS == 1)
+            {
+                bool keep = true;
+                if (sup_first_set(W, l, x, y, r, &fx, &fy))
+                {
+                    if (response > R[(size_t)fy * l.w + fx])
+                        atomicAnd(&W[(size_t)fy * l.tiles_x + (fx >> 6)], ~(1ull << (fx & 63)));
+                    else
+                        keep = false;
+                }
+                if (keep)
+                    atomicOr(&W[word], bit);
+            }
+            else
+            {
+                const int px = PASS == 2 ? x * diff : x >> shift, py = PASS == 2 ? y * diff : y >> shift;
+                if (sup_first_set(Wo, lo, px, py, r, &fx, &fy) && response > Ro[(size_t)fy * lo.w + fx])
+                    atomicAnd(&Wo[(size_t)fy * lo.tiles_x + (fx >> 6)], ~(1ull << (fx & 63)));
+            }
+            atomicAnd(&Pm[word], ~bit);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (tid == 0)
+    {
+        waiting[(size_t)b * L.n + level] = 0; // (for the next pass)
+        if (stats) // (OCHIP_VERBOSE=extract) rounds, 100 MHz ticks and points of this (pass, image, level)
+        {
+            unsigned int *o = stats + (((size_t)(PASS - 1) * gridDim.x + b) * L.n + level) * 3;
+            o[0] = rounds, o[1] = (unsigned int)((long long)wall_clock64() - t_begin), o[2] = m0;
+        }
+    }
+}
+
+// the list's flags once the three passes are through
+__global__ __launch_bounds__(256) void suppress_dead_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
+                                                            unsigned int max_cands, const unsigned long long *__restrict__ kmask,
+                                                            size_t mask_stride, levels_dev L, unsigned char *__restrict__ dead)
+{
+    const unsigned int b = blockIdx.z, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= min(n_cands[b], max_cands))
+        return;
+    const cand_t c = cands[(size_t)b * max_cands + k];
+    const level_info l = L.l[c.level];
+    const unsigned long long w = kmask[(size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6)];
+    dead[(size_t)b * max_cands + k] = (w >> (c.x & 63)) & 1ull ? 0 : 1;
 }
 
 // ---- the float functions of the orientation and the descriptor, as the CPU restatement has them (oracle D2): cv::fastAtan2 in
@@ -3070,7 +3308,9 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned long long *d_desc = nullptr, *d_descc = nullptr;
     float *d_kpc = nullptr;
     unsigned int *d_counts = nullptr, *d_tile_counts = nullptr, *d_tile_base = nullptr, *d_tile_seq = nullptr;
-    unsigned long long *d_mask = nullptr, *d_vmask = nullptr;
+    // maxima / valid keypoints / the suppression's keypoints, its copy of them between passes, its points waiting for a turn
+    unsigned long long *d_mask = nullptr, *d_vmask = nullptr, *d_kmask = nullptr, *d_smask = nullptr, *d_pmask = nullptr;
+    unsigned int *d_turns = nullptr, *d_waiting = nullptr; // its two lists of points waiting for their turn, their lengths per (image, level)
     unsigned int *d_wbase = nullptr, *d_live = nullptr, *d_nlive = nullptr;
     orient_tab *d_otab = nullptr;
     gather_tab *d_gtab = nullptr;
@@ -3109,6 +3349,11 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     AK(up<unsigned int>(ctx, allocs, &d_tile_base, nullptr, (size_t)B * n_tiles));
     AK(up<unsigned long long>(ctx, allocs, &d_mask, nullptr, (size_t)B * mask_stride));
     AK(up<unsigned long long>(ctx, allocs, &d_vmask, nullptr, (size_t)B * mask_stride));
+    AK(up<unsigned long long>(ctx, allocs, &d_kmask, nullptr, (size_t)B * mask_stride));
+    AK(up<unsigned long long>(ctx, allocs, &d_smask, nullptr, (size_t)B * mask_stride));
+    AK(up<unsigned long long>(ctx, allocs, &d_pmask, nullptr, (size_t)B * mask_stride));
+    AK(up<unsigned int>(ctx, allocs, &d_turns, nullptr, (size_t)B * 2 * max_cands));
+    AK(up<unsigned int>(ctx, allocs, &d_waiting, nullptr, (size_t)B * LV.n));
     AK(up<unsigned int>(ctx, allocs, &d_wbase, nullptr, (size_t)B * mask_stride));
     AK(up<unsigned int>(ctx, allocs, &d_live, nullptr, (size_t)B * max_cands));
     AK(up<unsigned int>(ctx, allocs, &d_nlive, nullptr, B));
@@ -3608,9 +3853,58 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     if (max_n > 0)
     {
         OCHIP_HIP(ctx, hipMemsetAsync(d_vmask, 0, (size_t)B * mask_stride * 8, st));
-        hipLaunchKernelGGL(suppress_kernel, dim3((max_n + 255) / 256, 1, B), dim3(256), 0, st, (const cand_t *)d_cands,
-                           (const unsigned int *)d_ncand, max_cands, (const float *)d_Rmax, img_stride,
-                           (const unsigned long long *)d_mask, mask_stride, LV, dfactor, d_dead);
+        OCHIP_HIP(ctx, hipMemsetAsync(d_kmask, 0, (size_t)B * mask_stride * 8, st));
+        const dim3 per_cand((max_n + 255) / 256, 1, B);
+        unsigned int *d_sup_stats = nullptr;
+        if (ochip_verbose("extract"))
+        {
+            AK(up<unsigned int>(ctx, allocs, &d_sup_stats, nullptr, (size_t)3 * B * LV.n * 3));
+            OCHIP_HIP(ctx, hipMemsetAsync(d_sup_stats, 0, (size_t)3 * B * LV.n * 3 * 4, st));
+        }
+        OCHIP_HIP(ctx, hipMemsetAsync(d_pmask, 0, (size_t)B * mask_stride * 8, st));
+        OCHIP_HIP(ctx, hipMemsetAsync(d_waiting, 0, (size_t)B * LV.n * 4, st));
+#define SUP_PASS(PASS, OWN, LEVELS)                                                                                                            \
+    hipLaunchKernelGGL(suppress_round0_kernel<PASS>, per_cand, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_ncand,       \
+                       max_cands, (const float *)d_Rmax, img_stride, (const unsigned long long *)(OWN), d_pmask, d_kmask, mask_stride, LV,     \
+                       (const unsigned int *)d_tile_base, (const unsigned int *)d_tile_seq, n_tiles, d_turns, d_waiting);                      \
+    hipLaunchKernelGGL(suppress_rounds_kernel<PASS>, dim3(B, (LEVELS)), dim3(SUP_THREADS), 0, st, (const unsigned int *)d_ncand, max_cands,    \
+                       (const float *)d_Rmax, img_stride, d_pmask, d_kmask, mask_stride, LV, (const unsigned int *)d_tile_base,                \
+                       (const unsigned int *)d_tile_seq, n_tiles, d_turns, d_waiting, d_sup_stats)
+        SUP_PASS(1, d_mask, LV.n);
+        if (LV.n > 1)
+        {
+            OCHIP_HIP(ctx, hipMemcpyAsync(d_smask, d_kmask, (size_t)B * mask_stride * 8, hipMemcpyDeviceToDevice, st));
+            SUP_PASS(2, d_smask, LV.n - 1);
+            OCHIP_HIP(ctx, hipMemcpyAsync(d_smask, d_kmask, (size_t)B * mask_stride * 8, hipMemcpyDeviceToDevice, st));
+            SUP_PASS(3, d_smask, LV.n - 1);
+        }
+#undef SUP_PASS
+        hipLaunchKernelGGL(suppress_dead_kernel, per_cand, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_ncand,
+                           max_cands, (const unsigned long long *)d_kmask, mask_stride, LV, d_dead);
+        if (d_sup_stats)
+        {
+            std::vector<unsigned int> hs((size_t)3 * B * LV.n * 3);
+            OCHIP_HIP(ctx, hipMemcpyAsync(hs.data(), d_sup_stats, hs.size() * 4, hipMemcpyDeviceToHost, st));
+            OCHIP_HIP(ctx, ochip_stream_wait(ctx, st));
+            for (int pass = 0; pass < 3; pass++)
+            {
+                std::string line;
+                for (int i = 0; i < LV.n; i++)
+                {
+                    unsigned int rounds = 0, ticks = 0, pts = 0;
+                    for (uint32_t b = 0; b < B; b++)
+                    {
+                        const unsigned int *o = &hs[(((size_t)pass * B + b) * LV.n + i) * 3];
+                        rounds = std::max(rounds, o[0]), ticks = std::max(ticks, o[1]), pts = std::max(pts, o[2]);
+                    }
+                    char buf[64];
+                    std::snprintf(buf, sizeof buf, " %u/%.0fus/%u", rounds, ticks * 0.01, pts);
+                    line += buf;
+                }
+                std::fprintf(stderr, "[ochip extract] suppression pass %d, per level max over %u images of rounds/time/points:%s\n", pass + 1, B,
+                             line.c_str());
+            }
+        }
         // the survivors in list order, then the descriptor over those only (slots it never visits stay invalid)
         hipLaunchKernelGGL(live_list_kernel, dim3(B), dim3(SCAN_THREADS), 0, st, (const unsigned char *)d_dead, (const unsigned int *)d_ncand,
                            max_cands, d_live, d_nlive);

@@ -3,25 +3,29 @@
 // KNOWN DEPARTURES FROM OpenCV's AKAZE (features2d/src/kaze/AKAZEFeatures.cpp, nldiffusion_functions.cpp [3P: not under
 // /root/reference, absent from this image - what OpenCV does is quoted from its published source, not checked here]).
 // Each is a place where this file is deliberately NOT a transcription; scripts/akaze_pin.py --compare attributes what it
-// finds to them (classes `suppression`, `angle`, `descriptor`).  STRUCTURE: this restatement follows the original A-KAZE /
-// OpenCV 3.x code path (per-sample rounding of the orientation samples, 42 windows stepped by 0.15 rad, out-of-image descriptor
-// samples skipped).  OpenCV 4.x rewrote three places (as recalled, unverified): Find_Scale_Space_Extrema became three mask
-// passes (per level in raster order - the first keypoint already set within sigma_size is cleared when the new one is stronger,
-// else the new one is dropped - then against the level below, then against the level above), Compute_Main_Orientation samples
-// around cvRound(pt / ratio) and slides a 7-slice window over a counting sort of the angles into 42 slices, and the M-LDB
-// sampler clamps coordinates into the image.  A reference built against 4.x differs from this file in those places whatever
-// D1 - D4 say; none of it can be pinned in this image.
+// finds to them (classes `suppression`, `angle`, `descriptor`).  STRUCTURE: OpenCV 4.x rewrote three places of the
+// original A-KAZE / OpenCV 3.x code (as recalled, unverified): Find_Scale_Space_Extrema became three passes over per-level
+// keypoint masks, Compute_Main_Orientation samples around cvRound(pt / ratio) and slides a 7-slice window over a counting
+// sort of the angles into 42 slices, and the M-LDB sampler clamps coordinates into the image.  This restatement follows 4.x
+// in the first (since round 6, see D1) and the 3.x path in the other two (per-sample rounding of the orientation samples, 42
+// windows stepped by 0.15 rad, out-of-image descriptor samples skipped): a reference built against either version differs
+// from this file in the places where it follows the other, whatever D1 - D4 say; none of it can be pinned in this image.
 //
-//  D1  cross-level suppression            this file: detect_and_describe, step 2 ("scale-space suppression", the `dead` loop)
-//      here:   symmetric and order-free - a candidate dies if ANY stronger maximum (ties: lower (level, y, x)) of its own
-//              or an adjacent level lies within its own size esigma * derivative_factor.
-//      OpenCV: AKAZEFeatures::Find_Scale_Space_Extrema walks the levels in order and keeps a running list: a new point is
-//              compared with the points ALREADY in the list of its own and the previous level (the first one within its
-//              size: the new point replaces it when stronger, is dropped otherwise), and a second pass removes points that
-//              have a stronger point of the NEXT level within their size.  The outcome depends on the insertion order and
-//              differs from the rule above where three or more maxima chain (A near B near C, A not near C).
-//      why:    the sequential list cannot be evaluated in parallel without reproducing its order; which of two valid
-//              definitions of "the same blob at neighbouring scales" is used moves a few keypoints per thousand.
+//  D1  scale-space suppression            (removed in round 6) this file: suppress_masks_4x, called by detect_and_describe, step 2
+//      now:    OpenCV 4.x's three passes, in their order.  (1) Per level in raster order, a 3 x 3 maximum looks for the FIRST
+//              keypoint already set in [y - r, y + r) x [x - r, x + r) within r = sigma_size (Euclidean; find_neighbor_point's
+//              raster scan): none - it is set; it is stronger - that one is cleared and it is set; otherwise it is dropped.
+//              (2) Levels upwards, a set keypoint projects into the level below (x, y times the octave step) and clears the
+//              first set keypoint there within sigma_size * octave step if it is stronger ("else this pt may be pruned by the
+//              upper scale").  (3) Levels downwards, the same against the level above (x, y divided by the octave step, radius
+//              that level's sigma_size).  The device evaluates the same passes in dependency rounds instead of in sequence
+//              (suppress_masks_4x_in_rounds is its schedule, restated here so that the CPU suite proves the two forms equal).
+//      before: a symmetric, order-free rule (rounds 2 - 5; kept as suppress_order_free for the census): a candidate died if ANY
+//              stronger maximum of its own or an adjacent level lay within its own size.  scripts/akaze_d1_census.py counts, on
+//              rendered 1600 x 1200 views, 2.1 % of its survivors decided differently from the 4.x passes (25 768 against 25 908
+//              survivors of 76 034 candidates) - and 43 % differently from the 3.x running list as recalled (suppress_list_3x:
+//              36 408 survivors; a new point is compared with the first list entry of its own or the previous level within its
+//              size only), so the two OpenCV generations differ from each other far more than the old rule did from 4.x.
 //  D2  atan2 / sin / cos                  (removed in round 6) this file: cv_fast_atan2_deg, libm_sincosf; used in detect_and_describe, step 3
 //      now:    the sample angles are cv::fastAtan2 (core/src/mathfuncs_core.simd.hpp, atan_f32: the odd polynomial with its
 //              coefficients scaled to DEGREES, 90 / 180 / 360 folds) times (float)(CV_PI / 180) as hal::fastAtan32f(.., false)
@@ -594,10 +598,13 @@ struct cand
     float response;
 };
 
-std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o)
+// step 1 of detect_and_describe: the strict 3 x 3 maxima of every level above the threshold whose descriptor window stays inside
+// the level, in detection order (level, row, column)
+static std::vector<cand> find_candidates(const ScaleSpace &ss, const Options &o)
 {
     const size_t N = ss.levels.size();
-    // 1. per-level 3x3 maxima above the threshold
+    (void)N;
+    // per-level 3x3 maxima above the threshold
     std::vector<cand> cands;
     for (size_t i = 0; i < N; i++)
     {
@@ -628,7 +635,13 @@ std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o
                     cands.push_back(cand{(int)i, x, y, v});
             }
     }
-    // 2. scale-space suppression: a candidate dies if a stronger one (ties: lower (level,y,x) wins) of
+    return cands;
+}
+
+// the rule of rounds 2 - 5 (header, D1 'before'): symmetric and order-free.  Census only.
+static std::vector<char> suppress_order_free(const ScaleSpace &ss, const Options &o, const std::vector<cand> &cands)
+{
+    // scale-space suppression: a candidate dies if a stronger one (ties: lower (level,y,x) wins) of
     //    an adjacent level lies within its own size (esigma * derivative_factor, base-image pixels)
     std::vector<char> dead(cands.size(), 0);
     {
@@ -672,6 +685,309 @@ std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o
                 }
         }
     }
+    return dead;
+}
+
+// ---- OpenCV's two sequential rules on the same candidates, as recalled (header of this file).  detect_and_describe runs the
+// 4.x one; the 3.x one is here so that the difference between the generations can be COUNTED (scripts/akaze_d1_census.py).
+// OpenCV 3.x (the original A-KAZE loop): a running list in detection order; a new point is compared with the FIRST list entry of
+// its own or the previous level within its size - it takes that entry's place when stronger, is dropped otherwise -, then
+// every list entry is dropped that has a stronger entry of the next level behind it in the list within its size.
+static std::vector<char> suppress_list_3x(const ScaleSpace &ss, const Options &o, const std::vector<cand> &cands)
+{
+    struct entry
+    {
+        int cand, class_id;
+        float x, y, size, response;
+    };
+    std::vector<entry> list;
+    for (size_t k = 0; k < cands.size(); k++)
+    {
+        const cand &c = cands[k];
+        const Level &l = ss.levels[c.level];
+        const float ratio = (float)(1 << l.octave), size = l.esigma * o.derivative_factor;
+        bool is_extremum = true, repeated = false;
+        size_t id_repeated = 0;
+        for (size_t ik = 0; ik < list.size(); ik++)
+            if (list[ik].class_id == c.level - 1 || list[ik].class_id == c.level)
+            {
+                const float dx = (float)c.x * ratio - list[ik].x, dy = (float)c.y * ratio - list[ik].y;
+                if (dx * dx + dy * dy <= size * size)
+                {
+                    if (c.response > list[ik].response)
+                        id_repeated = ik, repeated = true;
+                    else
+                        is_extremum = false;
+                    break;
+                }
+            }
+        if (!is_extremum)
+            continue;
+        const entry e{(int)k, c.level, (float)((float)c.x * ratio + .5 * (ratio - 1.0)), (float)((float)c.y * ratio + .5 * (ratio - 1.0)), size,
+                      c.response};
+        if (repeated)
+            list[id_repeated] = e;
+        else
+            list.push_back(e);
+    }
+    std::vector<char> dead(cands.size(), 1);
+    for (size_t i = 0; i < list.size(); i++)
+    {
+        bool repeated = false;
+        for (size_t j = i + 1; j < list.size() && !repeated; j++)
+            if (list[i].class_id + 1 == list[j].class_id)
+            {
+                const float dx = list[i].x - list[j].x, dy = list[i].y - list[j].y;
+                repeated = dx * dx + dy * dy <= list[i].size * list[i].size && list[i].response < list[j].response;
+            }
+        if (!repeated)
+            dead[(size_t)list[i].cand] = 0;
+    }
+    return dead;
+}
+// OpenCV 4.x: per-level masks (header, D1 'now').  Same level (raster order): the first keypoint already set within sigma_size of
+// the new one is cleared when the new one is stronger, else the new one is dropped.  Then every level against the level below (in
+// raster order, the first set keypoint of the lower level within sigma_size * octave step of the projected position is cleared
+// when the upper one is stronger - the upper one stays either way), then every level against the level above, from the top down.
+static std::vector<char> suppress_masks_4x(const ScaleSpace &ss, const Options &o, const std::vector<cand> &cands)
+{
+    const size_t N = ss.levels.size();
+    std::vector<std::vector<int>> mask(N); // candidate index + 1 at its pixel, 0 elsewhere
+    for (size_t i = 0; i < N; i++)
+        mask[i].assign((size_t)ss.levels[i].width * ss.levels[i].height, 0);
+    auto find_neighbor = [&](size_t lvl, int x, int y, int r, int *idx) {
+        const int w = ss.levels[lvl].width, h = ss.levels[lvl].height;
+        for (int i = std::max(y - r, 0); i < std::min(y + r, h); i++)
+            for (int j = std::max(x - r, 0); j < std::min(x + r, w); j++)
+                if (mask[lvl][(size_t)i * w + j] != 0 && (j - x) * (j - x) + (i - y) * (i - y) <= r * r)
+                {
+                    *idx = i * w + j;
+                    return true;
+                }
+        return false;
+    };
+    for (size_t k = 0; k < cands.size(); k++) // (detection order = level by level, raster inside a level)
+    {
+        const cand &c = cands[k];
+        const int w = ss.levels[c.level].width;
+        int idx = 0;
+        if (find_neighbor((size_t)c.level, c.x, c.y, ss.levels[c.level].sigma_size, &idx))
+        {
+            if (c.response > cands[(size_t)mask[c.level][idx] - 1].response)
+                mask[c.level][idx] = 0;
+            else
+                continue;
+        }
+        mask[c.level][(size_t)c.y * w + c.x] = (int)k + 1;
+    }
+    for (size_t i = 1; i < N; i++) // against the level below
+    {
+        const int w = ss.levels[i].width, h = ss.levels[i].height;
+        const int diff = (1 << ss.levels[i].octave) / (1 << ss.levels[i - 1].octave), r = ss.levels[i].sigma_size * diff;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+            {
+                const int me = mask[i][(size_t)y * w + x];
+                int idx = 0;
+                if (me != 0 && find_neighbor(i - 1, x * diff, y * diff, r, &idx))
+                {
+                    if (cands[(size_t)me - 1].response > cands[(size_t)mask[i - 1][idx] - 1].response)
+                        mask[i - 1][idx] = 0; // (else: the pass from the top down may prune this point)
+                }
+            }
+    }
+    for (int i = (int)N - 2; i >= 0; i--) // against the level above
+    {
+        const int w = ss.levels[i].width, h = ss.levels[i].height;
+        const int diff = (1 << ss.levels[i + 1].octave) / (1 << ss.levels[i].octave), r = ss.levels[i + 1].sigma_size;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+            {
+                const int me = mask[i][(size_t)y * w + x];
+                int idx = 0;
+                if (me != 0 && find_neighbor((size_t)i + 1, x / diff, y / diff, r, &idx))
+                {
+                    if (cands[(size_t)me - 1].response > cands[(size_t)mask[i + 1][idx] - 1].response)
+                        mask[i + 1][idx] = 0;
+                }
+            }
+    }
+    std::vector<char> dead(cands.size(), 1);
+    for (size_t i = 0; i < N; i++)
+        for (int v : mask[i])
+            if (v != 0)
+                dead[(size_t)v - 1] = 0;
+    return dead;
+}
+// The 4.x rule as the DEVICE evaluates it (csrc/akaze.hip, suppress_rounds_kernel): not in sequence but in rounds.  Pass 1
+// (inside a level): a maximum takes its turn once every maximum in front of it in raster order within 2 sigma_size (Chebyshev)
+// has had its own - two maxima further apart read and write disjoint neighbourhoods.  Passes 2 and 3 only ever clear keypoints
+// of the OTHER level and read their own level as the previous pass left it, so the levels of a pass are independent given that
+// snapshot, and inside a level a keypoint waits for the keypoints in front of it whose search windows can overlap its own.
+// Must give suppress_masks_4x's masks exactly; rounds[p] = rounds pass p needed.
+static std::vector<char> suppress_masks_4x_in_rounds(const ScaleSpace &ss, const Options &o, const std::vector<cand> &cands, int rounds[3])
+{
+    (void)o;
+    const size_t N = ss.levels.size();
+    std::vector<std::vector<int>> own(N), W(N); // candidate index + 1 at its pixel: who takes turns in this pass / the masks searched and cleared
+    std::vector<std::vector<char>> D(N);        // per pixel: the candidate there has had its turn in the current pass
+    for (size_t i = 0; i < N; i++)
+    {
+        own[i].assign((size_t)ss.levels[i].width * ss.levels[i].height, 0);
+        W[i] = own[i];
+        D[i].assign(own[i].size(), 0);
+    }
+    for (size_t k = 0; k < cands.size(); k++)
+        own[cands[k].level][(size_t)cands[k].y * ss.levels[cands[k].level].width + cands[k].x] = (int)k + 1;
+    auto first_set = [&](size_t lvl, int x, int y, int r, int *idx) {
+        const int w = ss.levels[lvl].width, h = ss.levels[lvl].height;
+        for (int i = std::max(y - r, 0); i < std::min(y + r, h); i++)
+            for (int j = std::max(x - r, 0); j < std::min(x + r, w); j++)
+                if (W[lvl][(size_t)i * w + j] != 0 && (j - x) * (j - x) + (i - y) * (i - y) <= r * r)
+                {
+                    *idx = i * w + j;
+                    return true;
+                }
+        return false;
+    };
+    // a point of this pass in front of (x, y) in raster order, inside the box of half-width r, that has not had its turn
+    auto pending = [&](size_t lvl, int x, int y, int r) {
+        const int w = ss.levels[lvl].width;
+        for (int i = std::max(y - r, 0); i <= y; i++)
+            for (int j = std::max(x - r, 0); j <= std::min(x + r, w - 1); j++)
+            {
+                if (i == y && j >= x)
+                    break;
+                if (own[lvl][(size_t)i * w + j] != 0 && !D[lvl][(size_t)i * w + j])
+                    return true;
+            }
+        return false;
+    };
+    auto run_pass = [&](int pass) {
+        for (size_t i = 0; i < N; i++)
+            std::fill(D[i].begin(), D[i].end(), 0);
+        std::vector<size_t> todo;
+        for (size_t k = 0; k < cands.size(); k++)
+        {
+            const size_t i = (size_t)cands[k].level;
+            const bool has_turn = own[i][(size_t)cands[k].y * ss.levels[i].width + cands[k].x] == (int)k + 1 &&
+                                  !(pass == 2 && i == 0) && !(pass == 3 && i == N - 1);
+            if (has_turn)
+                todo.push_back(k);
+        }
+        int n_rounds = 0;
+        while (!todo.empty())
+        {
+            std::vector<size_t> ready, later;
+            for (size_t k : todo)
+            {
+                const cand &c = cands[k];
+                const size_t i = (size_t)c.level;
+                int box; // (two windows [p - r, p + r) overlap iff the centres are at most 2 r - 1 apart)
+                if (pass == 1 || pass == 2)
+                    box = 2 * ss.levels[i].sigma_size - 1;
+                else
+                    box = 2 * ss.levels[i + 1].sigma_size * ((1 << ss.levels[i + 1].octave) / (1 << ss.levels[i].octave)) - 1;
+                (pending(i, c.x, c.y, box) ? later : ready).push_back(k);
+            }
+            n_rounds++;
+            // the round's turns: every ready point reads the masks as the round found them (ready points do not influence each other)
+            struct change
+            {
+                size_t lvl;
+                int idx, value;
+            };
+            std::vector<change> changes;
+            for (size_t k : ready)
+            {
+                const cand &c = cands[k];
+                const size_t i = (size_t)c.level;
+                int idx = 0;
+                if (pass == 1)
+                {
+                    bool keep = true;
+                    if (first_set(i, c.x, c.y, ss.levels[i].sigma_size, &idx))
+                    {
+                        if (c.response > cands[(size_t)W[i][idx] - 1].response)
+                            changes.push_back({i, idx, 0});
+                        else
+                            keep = false;
+                    }
+                    if (keep)
+                        changes.push_back({i, c.y * ss.levels[i].width + c.x, (int)k + 1});
+                }
+                else
+                {
+                    const size_t j = pass == 2 ? i - 1 : i + 1;
+                    int px, py, r;
+                    if (pass == 2)
+                    {
+                        const int diff = (1 << ss.levels[i].octave) / (1 << ss.levels[i - 1].octave);
+                        px = c.x * diff, py = c.y * diff, r = ss.levels[i].sigma_size * diff;
+                    }
+                    else
+                    {
+                        const int diff = (1 << ss.levels[i + 1].octave) / (1 << ss.levels[i].octave);
+                        px = c.x / diff, py = c.y / diff, r = ss.levels[i + 1].sigma_size;
+                    }
+                    if (first_set(j, px, py, r, &idx) && c.response > cands[(size_t)W[j][idx] - 1].response)
+                        changes.push_back({j, idx, 0});
+                }
+            }
+            for (const change &ch : changes)
+                W[ch.lvl][(size_t)ch.idx] = ch.value;
+            for (size_t k : ready)
+                D[cands[k].level][(size_t)cands[k].y * ss.levels[cands[k].level].width + cands[k].x] = 1;
+            todo.swap(later);
+        }
+        return n_rounds;
+    };
+    rounds[0] = run_pass(1); // (own = every maximum, W starts empty)
+    own = W;
+    rounds[1] = run_pass(2);
+    own = W;
+    rounds[2] = run_pass(3);
+    std::vector<char> dead(cands.size(), 1);
+    for (size_t i = 0; i < N; i++)
+        for (int v : W[i])
+            if (v != 0)
+                dead[(size_t)v - 1] = 0;
+    return dead;
+}
+// counts[0] = candidates, [1..3] = survivors of the order-free rule / the 3.x list / the 4.x masks, [4] = candidates on which
+// the order-free rule and the 3.x list disagree, [5] = ... and the 4.x masks, [6] = the 3.x list and the 4.x masks, [7] = the 4.x
+// masks evaluated in rounds against the sequential evaluation (0), [8..10] = rounds the three passes needed
+void suppression_census(const ScaleSpace &ss, const Options &o, uint64_t counts[11])
+{
+    const std::vector<cand> cands = find_candidates(ss, o);
+    const std::vector<char> a = suppress_order_free(ss, o, cands), b = suppress_list_3x(ss, o, cands), c = suppress_masks_4x(ss, o, cands);
+    int rounds[3];
+    const std::vector<char> d = suppress_masks_4x_in_rounds(ss, o, cands, rounds);
+    for (int i = 0; i < 11; i++)
+        counts[i] = 0;
+    for (size_t k = 0; k < cands.size(); k++)
+        counts[7] += c[k] != d[k]; // (the rounds form against the sequential one: must be 0)
+    for (int p = 0; p < 3; p++)
+        counts[8 + p] = (uint64_t)rounds[p];
+    counts[0] = cands.size();
+    for (size_t k = 0; k < cands.size(); k++)
+    {
+        counts[1] += !a[k];
+        counts[2] += !b[k];
+        counts[3] += !c[k];
+        counts[4] += a[k] != b[k];
+        counts[5] += a[k] != c[k];
+        counts[6] += b[k] != c[k];
+    }
+}
+
+std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o)
+{
+    // 1. per-level 3x3 maxima above the threshold
+    const std::vector<cand> cands = find_candidates(ss, o);
+    // 2. scale-space suppression: a candidate dies if a stronger one (ties: lower (level,y,x) wins) of
+    //    an adjacent level lies within its own size (esigma * derivative_factor, base-image pixels)
+    const std::vector<char> dead = suppress_masks_4x(ss, o, cands);
     // 3. sub-pixel fit, orientation, descriptor
     const std::vector<float> gw = orientation_weights();
     std::vector<Keypoint> out;
@@ -934,6 +1250,17 @@ size_t oc_akaze(const uint8_t *gray, int w, int h, size_t max_kp, float *kp6, ui
         std::memcpy(desc + 8 * i, kps[i].desc, 64);
     }
     return kps.size();
+}
+
+// census of the suppression rules on one grey image (suppression_census): counts11 as documented there
+void oc_akaze_suppression_census(const uint8_t *gray, int w, int h, uint64_t *counts11)
+{
+    std::vector<float> img((size_t)w * h);
+    for (size_t i = 0; i < img.size(); i++)
+        img[i] = (float)gray[i] * (1.0f / 255.0f);
+    Options o;
+    const ScaleSpace ss = build_scale_space(img, w, h, o);
+    suppression_census(ss, o, counts11);
 }
 
 // level images for stage-by-stage parity: which = 0 Lt, 1 Lx, 2 Ly, 3 Ldet; returns w*h of the level

@@ -207,3 +207,24 @@ def test_fast_atan2_and_the_two_by_two_solve():
         assert np.allclose([out[0], out[1]], exp, rtol=2e-6, atol=1e-6)
     L.oc_akaze_subpixel_solve(1.0, 2.0, 4.0, 0.3, 0.2, out)        # singular: the offset stays at the pixel
     assert out[0] == 0.0 and out[1] == 0.0
+
+
+def test_suppression_in_rounds_is_the_sequential_suppression():
+    """Find_Scale_Space_Extrema's three passes (OpenCV 4.x, oracle/akaze.cpp header D1) depend on the order of the turns; the
+    device takes the turns in dependency rounds (csrc/akaze.hip, suppress_round0_kernel / suppress_rounds_kernel).  The CPU
+    restatement of that schedule must decide every candidate as the sequential passes do - on scenes dense enough for
+    chains of dependent maxima - and the census must show the rule doing something (not every maximum survives)."""
+    import ctypes as C
+    L = pyoracle.lib()
+    L.oc_akaze_suppression_census.argtypes = [np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.c_int, C.c_int,
+                                              np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
+    for seed, (w, h) in ((3, (640, 480)), (4, (800, 600)), (5, (333, 517)), (6, (1200, 900))):
+        img = synth.render_blobs(w, h, seed=seed, channels=1)
+        rng = np.random.default_rng(seed)
+        gray = np.clip(img.astype(np.int32) + rng.integers(0, 20, img.shape) - 10, 0, 255).astype(np.uint8)
+        c = np.zeros(11, np.uint64)
+        L.oc_akaze_suppression_census(np.ascontiguousarray(gray), w, h, c)
+        candidates, survivors_4x = int(c[0]), int(c[3])
+        assert candidates > 500 and 0 < survivors_4x < candidates
+        assert int(c[7]) == 0, f"{int(c[7])} candidates decided differently in rounds ({w} x {h})"
+        assert all(int(r) >= 3 for r in c[8:11])  # (chains of dependent maxima: the rounds are exercised)
