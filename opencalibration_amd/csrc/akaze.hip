@@ -1872,13 +1872,54 @@ __device__ __forceinline__ unsigned int sup_level_begin(const levels_dev &L, int
     return level >= L.n ? n : tile_base[tile_seq[L.l[level].tile_off]];
 }
 
+// Passes 2 and 3, before round 0: which keypoints have anything to do.  A keypoint whose window in the other level holds no
+// keypoint when the pass starts never finds one (the pass only clears) and clears nothing: it takes no turn and nobody waits
+// for it.  That is five of six keypoints - and what keeps the dependence graph of the second octave (a maximum per 55 pixels,
+// boxes of 11 x 6) under its percolation threshold: 7 - 9 rounds instead of 29 - 35.  `own` is the copy of the keypoints the
+// previous pass left (the pass clears keypoints of the levels next to the one whose turns it takes, so who has a turn is read
+// from the copy); found[k] = x | y << 16 | SUP_READY of the first keypoint in the window, 0 without one; `has` gets the bits of
+// the keypoints that found one.
+constexpr unsigned int SUP_FOUND = 0x80000000u;
+template <int PASS>
+__global__ __launch_bounds__(256) void suppress_window_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
+                                                              unsigned int max_cands, const unsigned long long *__restrict__ own,
+                                                              unsigned long long *__restrict__ has, size_t mask_stride, levels_dev L,
+                                                              unsigned int *__restrict__ found)
+{
+    const unsigned int b = blockIdx.z, k = blockIdx.x * 256 + threadIdx.x, n = min(n_cands[b], max_cands);
+    if (k >= n)
+        return;
+    const cand_t c = cands[(size_t)b * max_cands + k];
+    unsigned int f = 0;
+    if (!((PASS == 2 && c.level == 0) || (PASS == 3 && c.level == L.n - 1))) // (no level below / above: no turns)
+    {
+        const level_info l = L.l[c.level];
+        const size_t word = (size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6);
+        const unsigned long long bit = 1ull << (c.x & 63);
+        if (own[word] & bit)
+        {
+            const level_info lo = L.l[PASS == 2 ? c.level - 1 : c.level + 1];
+            const int diff = PASS == 2 ? 1 << (l.octave - lo.octave) : 1, shift = PASS == 3 ? lo.octave - l.octave : 0;
+            const int r = PASS == 2 ? l.sigma_size * diff : lo.sigma_size;
+            const int px = PASS == 2 ? c.x * diff : c.x >> shift, py = PASS == 2 ? c.y * diff : c.y >> shift;
+            int fx = 0, fy = 0;
+            if (sup_first_set(own + (size_t)b * mask_stride + lo.mask_off, lo, px, py, r, &fx, &fy))
+            {
+                f = (unsigned int)fx | ((unsigned int)fy << 16) | SUP_FOUND;
+                atomicOr(&has[word], bit);
+            }
+        }
+    }
+    found[(size_t)b * max_cands + k] = f;
+}
+
 // Round 0 of a pass, one THREAD per candidate over the whole chunk: whether a point can take its turn at once depends on the
-// static masks only (pass 1: the maxima, passes 2 / 3: `own`, a copy of the keypoints the previous pass left - the pass clears
-// keypoints of the levels next to the one whose turns it takes, so who HAS a turn is read from the copy).  Two thirds to nine
-// tenths of the points can, and since which ones is known without looking at anything the launch writes, test and turn are
+// static masks only (`own`: pass 1 - the maxima, passes 2 / 3 - the keypoints suppress_window_kernel found something for).  85 -
+// 99 % of the points can, and since which ones is known without looking at anything the launch writes, test and turn are
 // one step here (no barrier): a ready point's window holds nothing another ready point writes.  In pass 1 such a turn is
-// "set the bit" (a keypoint already set inside its window would be a point in front of it that has not had its turn).  The
-// others are marked in `pend` for the rounds kernel.
+// "set the bit" (a keypoint already set inside its window would be a point in front of it that has not had its turn); in
+// passes 2 and 3 the first keypoint in the window is still the one suppress_window_kernel found.  The others are marked in
+// `pend` and appended to their level's list for the rounds kernel.
 template <int PASS>
 __global__ __launch_bounds__(256) void suppress_round0_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
                                                               unsigned int max_cands, const float *__restrict__ Rmax, size_t img_stride,
@@ -1886,31 +1927,36 @@ __global__ __launch_bounds__(256) void suppress_round0_kernel(const cand_t *__re
                                                               unsigned long long *kmask, size_t mask_stride, levels_dev L,
                                                               const unsigned int *__restrict__ tile_base,
                                                               const unsigned int *__restrict__ tile_seq, int n_tiles,
-                                                              unsigned int *__restrict__ turns, unsigned int *__restrict__ waiting)
+                                                              unsigned int *__restrict__ turns, unsigned int *__restrict__ waiting,
+                                                              const unsigned int *__restrict__ found)
 {
     const unsigned int b = blockIdx.z, k = blockIdx.x * 256 + threadIdx.x, n = min(n_cands[b], max_cands);
     cand_t c = cand_t{0, 0, 0, 0.f, 0.f, 0.f};
     bool has_turn = k < n;
+    unsigned int f = 0;
     if (has_turn)
     {
-        c = cands[(size_t)b * max_cands + k];
-        has_turn = !((PASS == 2 && c.level == 0) || (PASS == 3 && c.level == L.n - 1)); // (no level below / above: no turns)
+        if (PASS != 1)
+        {
+            f = found[(size_t)b * max_cands + k];
+            has_turn = f != 0;
+        }
+        if (has_turn)
+            c = cands[(size_t)b * max_cands + k];
     }
     // (list neighbours are of one level except where two levels' ranges meet: the level's constants by scalar loads when the
     // wavefront agrees on the level, per lane - a dozen vector loads each - otherwise)
     const int lv0 = __builtin_amdgcn_readfirstlane(c.level);
-    const bool one_level = __all(k >= n || c.level == lv0);
-    const level_info l = one_level ? L.l[lv0] : L.l[c.level];
-    const size_t word = (size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6);
-    const unsigned long long bit = 1ull << (c.x & 63);
-    if (PASS != 1 && has_turn)
-        has_turn = (own[word] & bit) != 0;
+    const bool one_level = __all(!has_turn || c.level == lv0);
     bool waits = false;
     if (has_turn)
     {
+        const level_info l = one_level ? L.l[lv0] : L.l[c.level];
+        const size_t word = (size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6);
+        const unsigned long long bit = 1ull << (c.x & 63);
         const int other = PASS == 1 ? 0 : (PASS == 2 ? -1 : 1);
         const level_info lo = one_level ? L.l[lv0 + other] : L.l[c.level + other];
-        const int diff = PASS == 2 ? 1 << (l.octave - lo.octave) : 1, shift = PASS == 3 ? lo.octave - l.octave : 0;
+        const int shift = PASS == 3 ? lo.octave - l.octave : 0;
         const int box = PASS == 3 ? 2 * lo.sigma_size * (1 << shift) - 1 : 2 * l.sigma_size - 1;
         waits = sup_pending(own + (size_t)b * mask_stride + l.mask_off, l, c.x, c.y, box);
         if (waits)
@@ -1919,12 +1965,9 @@ __global__ __launch_bounds__(256) void suppress_round0_kernel(const cand_t *__re
             atomicOr(&kmask[word], bit);
         else
         {
-            unsigned long long *Wo = kmask + (size_t)b * mask_stride + lo.mask_off;
-            const int r = PASS == 2 ? l.sigma_size * diff : lo.sigma_size;
-            const int px = PASS == 2 ? c.x * diff : c.x >> shift, py = PASS == 2 ? c.y * diff : c.y >> shift;
-            int fx = 0, fy = 0;
-            if (sup_first_set(Wo, lo, px, py, r, &fx, &fy) && c.response > Rmax[(size_t)b * img_stride + lo.off + (size_t)fy * lo.w + fx])
-                atomicAnd(&Wo[(size_t)fy * lo.tiles_x + (fx >> 6)], ~(1ull << (fx & 63)));
+            const int fx = (int)(f & 0xffffu), fy = (int)((f & ~SUP_FOUND) >> 16);
+            if (c.response > Rmax[(size_t)b * img_stride + lo.off + (size_t)fy * lo.w + fx])
+                atomicAnd(&kmask[(size_t)b * mask_stride + lo.mask_off + (size_t)fy * lo.tiles_x + (fx >> 6)], ~(1ull << (fx & 63)));
         }
     }
     // the waiting points go to their level's list (its range of `turns`: a level's candidates are one range of the candidate
@@ -3310,6 +3353,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned int *d_counts = nullptr, *d_tile_counts = nullptr, *d_tile_base = nullptr, *d_tile_seq = nullptr;
     // maxima / valid keypoints / the suppression's keypoints, its copy of them between passes, its points waiting for a turn
     unsigned long long *d_mask = nullptr, *d_vmask = nullptr, *d_kmask = nullptr, *d_smask = nullptr, *d_pmask = nullptr;
+    unsigned int *d_found = nullptr;                       // the suppression's passes 2 / 3: a keypoint's first keypoint of the other level
     unsigned int *d_turns = nullptr, *d_waiting = nullptr; // its two lists of points waiting for their turn, their lengths per (image, level)
     unsigned int *d_wbase = nullptr, *d_live = nullptr, *d_nlive = nullptr;
     orient_tab *d_otab = nullptr;
@@ -3354,6 +3398,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     AK(up<unsigned long long>(ctx, allocs, &d_pmask, nullptr, (size_t)B * mask_stride));
     AK(up<unsigned int>(ctx, allocs, &d_turns, nullptr, (size_t)B * 2 * max_cands));
     AK(up<unsigned int>(ctx, allocs, &d_waiting, nullptr, (size_t)B * LV.n));
+    AK(up<unsigned int>(ctx, allocs, &d_found, nullptr, (size_t)B * max_cands));
     AK(up<unsigned int>(ctx, allocs, &d_wbase, nullptr, (size_t)B * mask_stride));
     AK(up<unsigned int>(ctx, allocs, &d_live, nullptr, (size_t)B * max_cands));
     AK(up<unsigned int>(ctx, allocs, &d_nlive, nullptr, B));
@@ -3866,18 +3911,26 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
 #define SUP_PASS(PASS, OWN, LEVELS)                                                                                                            \
     hipLaunchKernelGGL(suppress_round0_kernel<PASS>, per_cand, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_ncand,       \
                        max_cands, (const float *)d_Rmax, img_stride, (const unsigned long long *)(OWN), d_pmask, d_kmask, mask_stride, LV,     \
-                       (const unsigned int *)d_tile_base, (const unsigned int *)d_tile_seq, n_tiles, d_turns, d_waiting);                      \
+                       (const unsigned int *)d_tile_base, (const unsigned int *)d_tile_seq, n_tiles, d_turns, d_waiting,                       \
+                       (const unsigned int *)d_found);                                                                                         \
     hipLaunchKernelGGL(suppress_rounds_kernel<PASS>, dim3(B, (LEVELS)), dim3(SUP_THREADS), 0, st, (const unsigned int *)d_ncand, max_cands,    \
                        (const float *)d_Rmax, img_stride, d_pmask, d_kmask, mask_stride, LV, (const unsigned int *)d_tile_base,                \
                        (const unsigned int *)d_tile_seq, n_tiles, d_turns, d_waiting, d_sup_stats)
+#define SUP_WINDOWS(PASS)                                                                                                                      \
+    OCHIP_HIP(ctx, hipMemcpyAsync(d_smask, d_kmask, (size_t)B * mask_stride * 8, hipMemcpyDeviceToDevice, st));                                \
+    OCHIP_HIP(ctx, hipMemsetAsync(d_mask, 0, (size_t)B * mask_stride * 8, st));                                                                \
+    hipLaunchKernelGGL(suppress_window_kernel<PASS>, per_cand, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_ncand,       \
+                       max_cands, (const unsigned long long *)d_smask, d_mask, mask_stride, LV, d_found)
         SUP_PASS(1, d_mask, LV.n);
         if (LV.n > 1)
         {
-            OCHIP_HIP(ctx, hipMemcpyAsync(d_smask, d_kmask, (size_t)B * mask_stride * 8, hipMemcpyDeviceToDevice, st));
-            SUP_PASS(2, d_smask, LV.n - 1);
-            OCHIP_HIP(ctx, hipMemcpyAsync(d_smask, d_kmask, (size_t)B * mask_stride * 8, hipMemcpyDeviceToDevice, st));
-            SUP_PASS(3, d_smask, LV.n - 1);
+            // (the maxima masks are through: d_mask takes the bits of the keypoints with something in their window)
+            SUP_WINDOWS(2);
+            SUP_PASS(2, d_mask, LV.n - 1);
+            SUP_WINDOWS(3);
+            SUP_PASS(3, d_mask, LV.n - 1);
         }
+#undef SUP_WINDOWS
 #undef SUP_PASS
         hipLaunchKernelGGL(suppress_dead_kernel, per_cand, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_ncand,
                            max_cands, (const unsigned long long *)d_kmask, mask_stride, LV, d_dead);

@@ -869,12 +869,33 @@ static std::vector<char> suppress_masks_4x_in_rounds(const ScaleSpace &ss, const
         std::vector<size_t> todo;
         for (size_t k = 0; k < cands.size(); k++)
         {
-            const size_t i = (size_t)cands[k].level;
-            const bool has_turn = own[i][(size_t)cands[k].y * ss.levels[i].width + cands[k].x] == (int)k + 1 &&
-                                  !(pass == 2 && i == 0) && !(pass == 3 && i == N - 1);
+            const cand &c = cands[k];
+            const size_t i = (size_t)c.level;
+            bool has_turn = own[i][(size_t)c.y * ss.levels[i].width + c.x] == (int)k + 1 && !(pass == 2 && i == 0) && !(pass == 3 && i == N - 1);
+            if (has_turn && pass != 1)
+            {
+                // a keypoint whose window holds no keypoint of the other level when the pass starts never finds one (the pass
+                // only clears) and clears nothing: it has no turn to take and nobody waits for it
+                int idx = 0;
+                if (pass == 2)
+                {
+                    const int diff = (1 << ss.levels[i].octave) / (1 << ss.levels[i - 1].octave);
+                    has_turn = first_set(i - 1, c.x * diff, c.y * diff, ss.levels[i].sigma_size * diff, &idx);
+                }
+                else
+                {
+                    const int diff = (1 << ss.levels[i + 1].octave) / (1 << ss.levels[i].octave);
+                    has_turn = first_set(i + 1, c.x / diff, c.y / diff, ss.levels[i + 1].sigma_size, &idx);
+                }
+            }
             if (has_turn)
                 todo.push_back(k);
         }
+        // (who waits for whom is asked of the points WITH a turn only)
+        for (size_t i = 0; i < N; i++)
+            std::fill(own[i].begin(), own[i].end(), 0);
+        for (size_t k : todo)
+            own[cands[k].level][(size_t)cands[k].y * ss.levels[cands[k].level].width + cands[k].x] = (int)k + 1;
         int n_rounds = 0;
         while (!todo.empty())
         {
