@@ -33,6 +33,7 @@ struct level_info
     size_t off; // plane offset (floats) inside one image's pyramid
     int tile_off, tiles_x; // first id and row length of the level's 64 x 24 detection tiles
     int mask_off;          // first word of the level's maxima bit mask (one 64-bit word per row of a tile column)
+    int sup_off, sup_tx;   // the suppression's masks: first word and words per row of the level's 8 x 8-pixel mask words
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi)
@@ -1795,89 +1796,171 @@ __device__ __forceinline__ unsigned long long sup_window(int lo, int hi) // bits
 {
     return (~0ull << lo) & (~0ull >> (63 - hi));
 }
+// The suppression's masks hold 8 x 8 pixels per 64-bit word - bit (y & 7) * 8 + (x & 7) of word (y >> 3) * sup_tx + (x >> 3) -: a
+// box of 15 x 8 pixels is 3 x 2 words and a window of 16 x 16 at most 3 x 3, where the maxima masks' layout (64 x 1 pixels
+// per word) takes a word or two per ROW, 16 - 32 loads per point, each lane of a wavefront in a cache line of its own.
+__device__ __forceinline__ size_t sup_word(const level_info &l, int x, int y)
+{
+    return (size_t)(y >> 3) * l.sup_tx + (x >> 3);
+}
+__device__ __forceinline__ unsigned long long sup_bit(int x, int y)
+{
+    return 1ull << (((y & 7) << 3) | (x & 7));
+}
+// columns lo .. hi of every row of a word / rows lo .. hi of a word (0 .. 7; nothing when hi < lo)
+__device__ __forceinline__ unsigned long long sup_cols(int lo, int hi)
+{
+    return hi < lo ? 0ull : (unsigned long long)(((2u << hi) - 1u) & ~((1u << lo) - 1u)) * 0x0101010101010101ull;
+}
+__device__ __forceinline__ unsigned long long sup_rows(int lo, int hi)
+{
+    return hi < lo ? 0ull : sup_window(8 * lo, 8 * hi + 7);
+}
 // a point of this pass in front of (x, y) in raster order inside the box of half-width r that has not had its turn.  r <= 7
-// (every level of the default scale space: sigma_size is 2, 3 or 4): seven rows above and the row itself, two words each,
-// requested without a branch - a row outside the box or the image reads row 0 and is masked out
+// (every level of the default scale space: sigma_size is 2, 3 or 4): 3 x 2 words requested without a branch - a word
+// outside the box is read again and masked out
 __device__ __forceinline__ bool sup_pending(const unsigned long long *Pm, const level_info &l, int x, int y, int r)
 {
-    const int x0 = max(x - r, 0), x1 = min(x + r, l.w - 1);
-    const int w0 = x0 >> 6, w1 = x1 >> 6;
-    const unsigned long long win0 = sup_window(x0 - w0 * 64, min(x1 - w0 * 64, 63)), win1 = w1 > w0 ? sup_window(0, x1 - w1 * 64) : 0ull;
+    const int x0 = max(x - r, 0), x1 = min(x + r, l.w - 1), y0 = max(y - r, 0);
+    const int txa = x0 >> 3, txb = x1 >> 3, tya = y0 >> 3, tyb = y >> 3;
     unsigned long long any = 0;
     if (r <= 7)
     {
+        // rows y0 .. y - 1 of the upper word row, rows 0 .. y - 1 of the lower one when there are two, and in the word row
+        // of y the columns in front of x
+        const unsigned long long rows_a = sup_rows(y0 - 8 * tya, min(y - 1 - 8 * tya, 7)),
+                                 rows_b = tyb != tya ? sup_rows(0, y - 1 - 8 * tyb) : 0ull, row_y = sup_rows(y & 7, y & 7);
 #pragma unroll
-        for (int q = 1; q <= 7; q++)
+        for (int j = 0; j < 3; j++)
         {
-            const bool inside = q <= r && y - q >= 0;
-            const size_t row = (size_t)(inside ? y - q : 0) * l.tiles_x;
-            const unsigned long long a = Pm[row + w0] & win0, c = Pm[row + w1] & win1;
-            any |= inside ? (a | c) : 0ull;
+            const int tx = min(txa + j, txb);
+            const bool inside = txa + j <= txb;
+            const unsigned long long wa = Pm[(size_t)tya * l.sup_tx + tx], wb = Pm[(size_t)tyb * l.sup_tx + tx];
+            const unsigned long long cols = sup_cols(max(x0 - 8 * tx, 0), min(x1 - 8 * tx, 7)),
+                                     front = sup_cols(max(x0 - 8 * tx, 0), min(x - 1 - 8 * tx, 7));
+            any |= inside ? (wa & cols & rows_a) | (wb & ((cols & rows_b) | (front & row_y))) : 0ull;
         }
     }
     else
-        for (int i = max(y - r, 0); i < y; i++)
-            any |= (Pm[(size_t)i * l.tiles_x + w0] & win0) | (Pm[(size_t)i * l.tiles_x + w1] & win1);
-    // row y: the columns in front of x
-    if (x - 1 >= x0)
-    {
-        const int h0 = min(x - 1 - w0 * 64, 63);
-        any |= Pm[(size_t)y * l.tiles_x + w0] & sup_window(x0 - w0 * 64, h0);
-        if (w1 > w0 && x - 1 >= w1 * 64)
-            any |= Pm[(size_t)y * l.tiles_x + w1] & sup_window(0, x - 1 - w1 * 64);
-    }
+        for (int ty = tya; ty <= tyb; ty++)
+            for (int tx = txa; tx <= txb; tx++)
+            {
+                const unsigned long long cols = sup_cols(max(x0 - 8 * tx, 0), min(x1 - 8 * tx, 7)),
+                                         front = sup_cols(max(x0 - 8 * tx, 0), min(x - 1 - 8 * tx, 7));
+                any |= Pm[(size_t)ty * l.sup_tx + tx] & ((cols & sup_rows(max(y0 - 8 * ty, 0), min(y - 1 - 8 * ty, 7))) |
+                                                         (ty == tyb ? front & sup_rows(y & 7, y & 7) : 0ull));
+            }
     return any != 0;
 }
-// find_neighbor_point: the first set bit, in raster order, of [y - r, y + r) x [x - r, x + r) within r (Euclidean) of (x, y)
+// find_neighbor_point: the first set bit, in raster order, of [y - r, y + r) x [x - r, x + r) within r (Euclidean) of (x, y).
+// r <= 8 (sigma_size times an octave step of at most 2): at most 3 x 3 words, requested together
 __device__ __forceinline__ bool sup_first_set(const unsigned long long *W, const level_info &l, int x, int y, int r, int *fx, int *fy)
 {
     const int x0 = max(x - r, 0), x1 = min(x + r, l.w) - 1, y0 = max(y - r, 0), y1 = min(y + r, l.h) - 1;
-    if (x1 < x0)
+    if (x1 < x0 || y1 < y0)
         return false;
-    const int w0 = x0 >> 6, w1 = x1 >> 6; // (a window is at most 16 wide: one word or two)
-    const unsigned long long win0 = sup_window(x0 - w0 * 64, min(x1 - w0 * 64, 63)), win1 = w1 > w0 ? sup_window(0, x1 - w1 * 64) : 0ull;
-    for (int yb = y0; yb <= y1; yb += 4)
+    const int txa = x0 >> 3, txb = x1 >> 3, tya = y0 >> 3, tyb = y1 >> 3;
+    if (r <= 8)
     {
-        unsigned long long m0[4], m1[4]; // four rows requested together
+        unsigned long long m[3][3], any = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-        {
-            m0[q] = yb + q <= y1 ? W[(size_t)(yb + q) * l.tiles_x + w0] & win0 : 0ull;
-            m1[q] = yb + q <= y1 && w1 > w0 ? W[(size_t)(yb + q) * l.tiles_x + w1] & win1 : 0ull;
-        }
+        for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            for (int half = 0; half < 2; half++)
+            for (int j = 0; j < 3; j++)
             {
-                unsigned long long bits = half ? m1[q] : m0[q];
-                while (bits)
+                const int ty = min(tya + i, tyb), tx = min(txa + j, txb);
+                const unsigned long long v = W[(size_t)ty * l.sup_tx + tx];
+                m[i][j] = tya + i <= tyb && txa + j <= txb
+                              ? v & sup_cols(max(x0 - 8 * tx, 0), min(x1 - 8 * tx, 7)) & sup_rows(max(y0 - 8 * ty, 0), min(y1 - 8 * ty, 7))
+                              : 0ull;
+                any |= m[i][j];
+            }
+        if (any == 0)
+            return false;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+        {
+            if ((m[i][0] | m[i][1] | m[i][2]) == 0)
+                continue;
+            for (int q = 0; q < 8; q++) // the word row's pixel rows top down, 24 columns each
+            {
+                unsigned int row = (unsigned int)((m[i][0] >> (8 * q)) & 0xffull) | ((unsigned int)((m[i][1] >> (8 * q)) & 0xffull) << 8) |
+                                   ((unsigned int)((m[i][2] >> (8 * q)) & 0xffull) << 16);
+                const int yy = 8 * (tya + i) + q;
+                while (row)
                 {
-                    const int j = (half ? w1 : w0) * 64 + __ffsll((long long)bits) - 1, i = yb + q;
-                    bits &= bits - 1;
-                    if ((j - x) * (j - x) + (i - y) * (i - y) <= r * r)
+                    const int xx = 8 * txa + __ffs((int)row) - 1;
+                    row &= row - 1;
+                    if ((xx - x) * (xx - x) + (yy - y) * (yy - y) <= r * r)
                     {
-                        *fx = j;
-                        *fy = i;
+                        *fx = xx;
+                        *fy = yy;
                         return true;
                     }
                 }
             }
+        }
+        return false;
     }
+    for (int yy = y0; yy <= y1; yy++)
+        for (int xx = x0; xx <= x1; xx++)
+            if ((W[sup_word(l, xx, yy)] & sup_bit(xx, yy)) && (xx - x) * (xx - x) + (yy - y) * (yy - y) <= r * r)
+            {
+                *fx = xx;
+                *fy = yy;
+                return true;
+            }
     return false;
 }
-// first list entry of a level (the list is complete: n <= max_cands was checked)
-__device__ __forceinline__ unsigned int sup_level_begin(const levels_dev &L, int level, unsigned int n, const unsigned int *tile_base,
-                                                        const unsigned int *tile_seq)
+// the maxima masks (64 x 1 pixels per word) in the suppression's layout: one thread per 64 x 8 pixels - eight row words in, a
+// byte transpose, up to eight 8 x 8 words out (a thread per 8 x 8 word asked for every row word eight times: 0.19 ms per 100 images)
+__global__ __launch_bounds__(256) void suppress_tiles_kernel(const unsigned long long *__restrict__ mask, size_t mask_stride,
+                                                             unsigned long long *__restrict__ out, size_t sup_stride, levels_dev L)
 {
-    return level >= L.n ? n : tile_base[tile_seq[L.l[level].tile_off]];
+    const int rel = blockIdx.x * 256 + threadIdx.x;
+    const unsigned int b = blockIdx.z;
+    const level_info l = L.l[blockIdx.y];
+    if (rel >= l.tiles_x * ((l.h + 7) / 8))
+        return;
+    const int ty = rel / l.tiles_x, wx = rel - ty * l.tiles_x;
+    unsigned long long in[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+        in[q] = 8 * ty + q < l.h ? mask[(size_t)b * mask_stride + (size_t)l.mask_off + (size_t)(8 * ty + q) * l.tiles_x + wx] : 0ull;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+    {
+        if (8 * wx + j >= l.sup_tx)
+            break;
+        unsigned long long o = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            o |= ((in[q] >> (8 * j)) & 0xffull) << (8 * q);
+        out[(size_t)b * sup_stride + (size_t)l.sup_off + (size_t)ty * l.sup_tx + 8 * wx + j] = o;
+    }
+}
+// first list entry of every level of every image (the candidate list is level by level, tile_seq; it is complete: n <= max_cands
+// was checked) - looked up once per chunk: as two dependent loads in front of every wavefront's list append it was the
+// longest chain of the round-0 launches
+__global__ __launch_bounds__(64) void suppress_level_first_kernel(const unsigned int *__restrict__ n_cands, unsigned int max_cands, levels_dev L,
+                                                                  const unsigned int *__restrict__ tile_base,
+                                                                  const unsigned int *__restrict__ tile_seq, int n_tiles,
+                                                                  unsigned int *__restrict__ level_first)
+{
+    const unsigned int b = blockIdx.x;
+    const int level = threadIdx.x;
+    if (level > L.n)
+        return;
+    level_first[(size_t)b * (L.n + 1) + level] =
+        level == L.n ? min(n_cands[b], max_cands) : tile_base[(size_t)b * n_tiles + tile_seq[L.l[level].tile_off]];
 }
 
 // Passes 2 and 3, before round 0: which keypoints have anything to do.  A keypoint whose window in the other level holds no
 // keypoint when the pass starts never finds one (the pass only clears) and clears nothing: it takes no turn and nobody waits
 // for it.  That is five of six keypoints - and what keeps the dependence graph of the second octave (a maximum per 55 pixels,
-// boxes of 11 x 6) under its percolation threshold: 7 - 9 rounds instead of 29 - 35.  `own` is the copy of the keypoints the
-// previous pass left (the pass clears keypoints of the levels next to the one whose turns it takes, so who has a turn is read
-// from the copy); found[k] = x | y << 16 | SUP_READY of the first keypoint in the window, 0 without one; `has` gets the bits of
+// boxes of 11 x 6) under its percolation threshold: 7 - 9 rounds instead of 29 - 35.  `own` are the keypoints the previous
+// pass left: nothing writes them during this launch, and the launches after it ask `found` and `has`, not the masks, who has
+// a turn (the pass clears keypoints of the levels next to the one whose turns it takes); found[k] = x | y << 16 | SUP_READY of the first keypoint in the window, 0 without one; `has` gets the bits of
 // the keypoints that found one.
 constexpr unsigned int SUP_FOUND = 0x80000000u;
 template <int PASS>
@@ -1894,8 +1977,8 @@ __global__ __launch_bounds__(256) void suppress_window_kernel(const cand_t *__re
     if (!((PASS == 2 && c.level == 0) || (PASS == 3 && c.level == L.n - 1))) // (no level below / above: no turns)
     {
         const level_info l = L.l[c.level];
-        const size_t word = (size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6);
-        const unsigned long long bit = 1ull << (c.x & 63);
+        const size_t word = (size_t)b * mask_stride + (size_t)l.sup_off + sup_word(l, c.x, c.y);
+        const unsigned long long bit = sup_bit(c.x, c.y);
         if (own[word] & bit)
         {
             const level_info lo = L.l[PASS == 2 ? c.level - 1 : c.level + 1];
@@ -1903,7 +1986,7 @@ __global__ __launch_bounds__(256) void suppress_window_kernel(const cand_t *__re
             const int r = PASS == 2 ? l.sigma_size * diff : lo.sigma_size;
             const int px = PASS == 2 ? c.x * diff : c.x >> shift, py = PASS == 2 ? c.y * diff : c.y >> shift;
             int fx = 0, fy = 0;
-            if (sup_first_set(own + (size_t)b * mask_stride + lo.mask_off, lo, px, py, r, &fx, &fy))
+            if (sup_first_set(own + (size_t)b * mask_stride + lo.sup_off, lo, px, py, r, &fx, &fy))
             {
                 f = (unsigned int)fx | ((unsigned int)fy << 16) | SUP_FOUND;
                 atomicOr(&has[word], bit);
@@ -1925,8 +2008,7 @@ __global__ __launch_bounds__(256) void suppress_round0_kernel(const cand_t *__re
                                                               unsigned int max_cands, const float *__restrict__ Rmax, size_t img_stride,
                                                               const unsigned long long *__restrict__ own, unsigned long long *pend,
                                                               unsigned long long *kmask, size_t mask_stride, levels_dev L,
-                                                              const unsigned int *__restrict__ tile_base,
-                                                              const unsigned int *__restrict__ tile_seq, int n_tiles,
+                                                              const unsigned int *__restrict__ level_first,
                                                               unsigned int *__restrict__ turns, unsigned int *__restrict__ waiting,
                                                               const unsigned int *__restrict__ found)
 {
@@ -1952,13 +2034,13 @@ __global__ __launch_bounds__(256) void suppress_round0_kernel(const cand_t *__re
     if (has_turn)
     {
         const level_info l = one_level ? L.l[lv0] : L.l[c.level];
-        const size_t word = (size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6);
-        const unsigned long long bit = 1ull << (c.x & 63);
+        const size_t word = (size_t)b * mask_stride + (size_t)l.sup_off + sup_word(l, c.x, c.y);
+        const unsigned long long bit = sup_bit(c.x, c.y);
         const int other = PASS == 1 ? 0 : (PASS == 2 ? -1 : 1);
         const level_info lo = one_level ? L.l[lv0 + other] : L.l[c.level + other];
         const int shift = PASS == 3 ? lo.octave - l.octave : 0;
         const int box = PASS == 3 ? 2 * lo.sigma_size * (1 << shift) - 1 : 2 * l.sigma_size - 1;
-        waits = sup_pending(own + (size_t)b * mask_stride + l.mask_off, l, c.x, c.y, box);
+        waits = sup_pending(own + (size_t)b * mask_stride + l.sup_off, l, c.x, c.y, box);
         if (waits)
             atomicOr(&pend[word], bit);
         else if (PASS == 1)
@@ -1967,7 +2049,7 @@ __global__ __launch_bounds__(256) void suppress_round0_kernel(const cand_t *__re
         {
             const int fx = (int)(f & 0xffffu), fy = (int)((f & ~SUP_FOUND) >> 16);
             if (c.response > Rmax[(size_t)b * img_stride + lo.off + (size_t)fy * lo.w + fx])
-                atomicAnd(&kmask[(size_t)b * mask_stride + lo.mask_off + (size_t)fy * lo.tiles_x + (fx >> 6)], ~(1ull << (fx & 63)));
+                atomicAnd(&kmask[(size_t)b * mask_stride + lo.sup_off + sup_word(lo, fx, fy)], ~sup_bit(fx, fy));
         }
     }
     // the waiting points go to their level's list (its range of `turns`: a level's candidates are one range of the candidate
@@ -1984,7 +2066,7 @@ __global__ __launch_bounds__(256) void suppress_round0_kernel(const cand_t *__re
             base = atomicAdd(&waiting[(size_t)b * L.n + lv], (unsigned int)__popcll(same));
         base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
         if (waits && c.level == lv)
-            turns[(size_t)b * 2 * max_cands + sup_level_begin(L, lv, n, tile_base + (size_t)b * n_tiles, tile_seq) + base +
+            turns[(size_t)b * 2 * max_cands + level_first[(size_t)b * (L.n + 1) + lv] + base +
                   (unsigned int)__popcll(same & ((1ull << lane) - 1ull))] = (unsigned int)c.x | ((unsigned int)c.y << 16);
         todo &= ~same;
     }
@@ -1997,8 +2079,7 @@ template <int PASS>
 __global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsigned int *__restrict__ n_cands, unsigned int max_cands,
                                                                       const float *__restrict__ Rmax, size_t img_stride,
                                                                       unsigned long long *pend, unsigned long long *kmask, size_t mask_stride,
-                                                                      levels_dev L, const unsigned int *__restrict__ tile_base,
-                                                                      const unsigned int *__restrict__ tile_seq, int n_tiles,
+                                                                      levels_dev L, const unsigned int *__restrict__ level_first,
                                                                       unsigned int *turns, unsigned int *waiting, unsigned int *__restrict__ stats)
 {
     // pend: the points round 0 left waiting (all zero again when the launch ends); kmask: the keypoints
@@ -2010,11 +2091,10 @@ __global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsi
     if (m0 == 0)
         return;
     const long long t_begin = stats ? (long long)wall_clock64() : 0;
-    const unsigned int n = min(n_cands[b], max_cands);
-    const unsigned int first = sup_level_begin(L, level, n, tile_base + (size_t)b * n_tiles, tile_seq);
+    const unsigned int first = level_first[(size_t)b * (L.n + 1) + level];
     const level_info l = L.l[level], lo = L.l[PASS == 1 ? level : (PASS == 2 ? level - 1 : level + 1)];
-    unsigned long long *Pm = pend + (size_t)b * mask_stride + l.mask_off, *W = kmask + (size_t)b * mask_stride + l.mask_off,
-                       *Wo = kmask + (size_t)b * mask_stride + lo.mask_off;
+    unsigned long long *Pm = pend + (size_t)b * mask_stride + l.sup_off, *W = kmask + (size_t)b * mask_stride + l.sup_off,
+                       *Wo = kmask + (size_t)b * mask_stride + lo.sup_off;
     const float *R = Rmax + (size_t)b * img_stride + l.off, *Ro = Rmax + (size_t)b * img_stride + lo.off;
     // the windows of two points can overlap when the points are at most `box` apart; the window in the other level
     const int diff = PASS == 2 ? 1 << (l.octave - lo.octave) : 1, shift = PASS == 3 ? lo.octave - l.octave : 0;
@@ -2061,8 +2141,8 @@ __global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsi
                 continue;
             }
             const int x = (int)(e & 0xffffu), y = (int)((e & ~SUP_READY) >> 16);
-            const size_t word = (size_t)y * l.tiles_x + (x >> 6);
-            const unsigned long long bit = 1ull << (x & 63);
+            const size_t word = sup_word(l, x, y);
+            const unsigned long long bit = sup_bit(x, y);
             const float response = R[(size_t)y * l.w + x];
             int fx = 0, fy = 0;
             if (PASS == 1)
@@ -2071,7 +2151,7 @@ __global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsi
                 if (sup_first_set(W, l, x, y, r, &fx, &fy))
                 {
                     if (response > R[(size_t)fy * l.w + fx])
-                        atomicAnd(&W[(size_t)fy * l.tiles_x + (fx >> 6)], ~(1ull << (fx & 63)));
+                        atomicAnd(&W[sup_word(l, fx, fy)], ~sup_bit(fx, fy));
                     else
                         keep = false;
                 }
@@ -2082,7 +2162,7 @@ __global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsi
             {
                 const int px = PASS == 2 ? x * diff : x >> shift, py = PASS == 2 ? y * diff : y >> shift;
                 if (sup_first_set(Wo, lo, px, py, r, &fx, &fy) && response > Ro[(size_t)fy * lo.w + fx])
-                    atomicAnd(&Wo[(size_t)fy * lo.tiles_x + (fx >> 6)], ~(1ull << (fx & 63)));
+                    atomicAnd(&Wo[sup_word(lo, fx, fy)], ~sup_bit(fx, fy));
             }
             atomicAnd(&Pm[word], ~bit);
         }
@@ -2110,8 +2190,7 @@ __global__ __launch_bounds__(256) void suppress_dead_kernel(const cand_t *__rest
         return;
     const cand_t c = cands[(size_t)b * max_cands + k];
     const level_info l = L.l[c.level];
-    const unsigned long long w = kmask[(size_t)b * mask_stride + (size_t)l.mask_off + (size_t)c.y * l.tiles_x + (c.x >> 6)];
-    dead[(size_t)b * max_cands + k] = (w >> (c.x & 63)) & 1ull ? 0 : 1;
+    dead[(size_t)b * max_cands + k] = kmask[(size_t)b * mask_stride + (size_t)l.sup_off + sup_word(l, c.x, c.y)] & sup_bit(c.x, c.y) ? 0 : 1;
 }
 
 // ---- the float functions of the orientation and the descriptor, as the CPU restatement has them (oracle D2): cv::fastAtan2 in
@@ -3292,6 +3371,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     size_t img_stride = 0;
     int n_tiles = 0;
     size_t mask_stride = 0; // words of one image's maxima bit masks
+    size_t sup_stride = 0;  // words of one image's masks of the suppression (8 x 8 pixels per word)
     {
         std::vector<float> etime;
         for (int i = 0; i < omax; i++)
@@ -3315,6 +3395,9 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
                 n_tiles += l.tiles_x * ((lh + DT_Y - 1) / DT_Y);
                 l.mask_off = (int)mask_stride;
                 mask_stride += (size_t)l.tiles_x * lh;
+                l.sup_off = (int)sup_stride;
+                l.sup_tx = (lw + 7) / 8;
+                sup_stride += (size_t)l.sup_tx * ((lh + 7) / 8);
                 etime.push_back(0.5f * (l.esigma * l.esigma));
             }
         }
@@ -3351,9 +3434,11 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned long long *d_desc = nullptr, *d_descc = nullptr;
     float *d_kpc = nullptr;
     unsigned int *d_counts = nullptr, *d_tile_counts = nullptr, *d_tile_base = nullptr, *d_tile_seq = nullptr;
-    // maxima / valid keypoints / the suppression's keypoints, its copy of them between passes, its points waiting for a turn
-    unsigned long long *d_mask = nullptr, *d_vmask = nullptr, *d_kmask = nullptr, *d_smask = nullptr, *d_pmask = nullptr;
+    // maxima / valid keypoints; the suppression's masks (8 x 8 pixels per word): keypoints, points waiting for a turn, points
+    // with a turn (pass 1: the maxima in this layout)
+    unsigned long long *d_mask = nullptr, *d_vmask = nullptr, *d_kmask = nullptr, *d_pmask = nullptr, *d_rmask = nullptr;
     unsigned int *d_found = nullptr;                       // the suppression's passes 2 / 3: a keypoint's first keypoint of the other level
+    unsigned int *d_level_first = nullptr;                 // first candidate of every level of every image (+ the list's length)
     unsigned int *d_turns = nullptr, *d_waiting = nullptr; // its two lists of points waiting for their turn, their lengths per (image, level)
     unsigned int *d_wbase = nullptr, *d_live = nullptr, *d_nlive = nullptr;
     orient_tab *d_otab = nullptr;
@@ -3393,11 +3478,12 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     AK(up<unsigned int>(ctx, allocs, &d_tile_base, nullptr, (size_t)B * n_tiles));
     AK(up<unsigned long long>(ctx, allocs, &d_mask, nullptr, (size_t)B * mask_stride));
     AK(up<unsigned long long>(ctx, allocs, &d_vmask, nullptr, (size_t)B * mask_stride));
-    AK(up<unsigned long long>(ctx, allocs, &d_kmask, nullptr, (size_t)B * mask_stride));
-    AK(up<unsigned long long>(ctx, allocs, &d_smask, nullptr, (size_t)B * mask_stride));
-    AK(up<unsigned long long>(ctx, allocs, &d_pmask, nullptr, (size_t)B * mask_stride));
+    AK(up<unsigned long long>(ctx, allocs, &d_kmask, nullptr, (size_t)B * sup_stride));
+    AK(up<unsigned long long>(ctx, allocs, &d_pmask, nullptr, (size_t)B * sup_stride));
+    AK(up<unsigned long long>(ctx, allocs, &d_rmask, nullptr, (size_t)B * sup_stride));
     AK(up<unsigned int>(ctx, allocs, &d_turns, nullptr, (size_t)B * 2 * max_cands));
     AK(up<unsigned int>(ctx, allocs, &d_waiting, nullptr, (size_t)B * LV.n));
+    AK(up<unsigned int>(ctx, allocs, &d_level_first, nullptr, (size_t)B * (LV.n + 1)));
     AK(up<unsigned int>(ctx, allocs, &d_found, nullptr, (size_t)B * max_cands));
     AK(up<unsigned int>(ctx, allocs, &d_wbase, nullptr, (size_t)B * mask_stride));
     AK(up<unsigned int>(ctx, allocs, &d_live, nullptr, (size_t)B * max_cands));
@@ -3898,7 +3984,6 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     if (max_n > 0)
     {
         OCHIP_HIP(ctx, hipMemsetAsync(d_vmask, 0, (size_t)B * mask_stride * 8, st));
-        OCHIP_HIP(ctx, hipMemsetAsync(d_kmask, 0, (size_t)B * mask_stride * 8, st));
         const dim3 per_cand((max_n + 255) / 256, 1, B);
         unsigned int *d_sup_stats = nullptr;
         if (ochip_verbose("extract"))
@@ -3906,34 +3991,36 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             AK(up<unsigned int>(ctx, allocs, &d_sup_stats, nullptr, (size_t)3 * B * LV.n * 3));
             OCHIP_HIP(ctx, hipMemsetAsync(d_sup_stats, 0, (size_t)3 * B * LV.n * 3 * 4, st));
         }
-        OCHIP_HIP(ctx, hipMemsetAsync(d_pmask, 0, (size_t)B * mask_stride * 8, st));
+        OCHIP_HIP(ctx, hipMemsetAsync(d_kmask, 0, (size_t)B * sup_stride * 8, st));
+        OCHIP_HIP(ctx, hipMemsetAsync(d_pmask, 0, (size_t)B * sup_stride * 8, st));
         OCHIP_HIP(ctx, hipMemsetAsync(d_waiting, 0, (size_t)B * LV.n * 4, st));
-#define SUP_PASS(PASS, OWN, LEVELS)                                                                                                            \
+        hipLaunchKernelGGL(suppress_level_first_kernel, dim3(B), dim3(64), 0, st, (const unsigned int *)d_ncand, max_cands, LV,
+                           (const unsigned int *)d_tile_base, (const unsigned int *)d_tile_seq, n_tiles, d_level_first);
+        // (64 x 8-pixel groups: the grid covers the largest level, a level per blockIdx.y)
+        hipLaunchKernelGGL(suppress_tiles_kernel, dim3((unsigned int)((LV.l[0].tiles_x * ((LV.l[0].h + 7) / 8) + 255) / 256), LV.n, B),
+                           dim3(256), 0, st, (const unsigned long long *)d_mask, mask_stride, d_rmask, sup_stride, LV);
+#define SUP_PASS(PASS, LEVELS)                                                                                                                 \
     hipLaunchKernelGGL(suppress_round0_kernel<PASS>, per_cand, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_ncand,       \
-                       max_cands, (const float *)d_Rmax, img_stride, (const unsigned long long *)(OWN), d_pmask, d_kmask, mask_stride, LV,     \
-                       (const unsigned int *)d_tile_base, (const unsigned int *)d_tile_seq, n_tiles, d_turns, d_waiting,                       \
-                       (const unsigned int *)d_found);                                                                                         \
+                       max_cands, (const float *)d_Rmax, img_stride, (const unsigned long long *)d_rmask, d_pmask, d_kmask, sup_stride, LV,    \
+                       (const unsigned int *)d_level_first, d_turns, d_waiting, (const unsigned int *)d_found);                                \
     hipLaunchKernelGGL(suppress_rounds_kernel<PASS>, dim3(B, (LEVELS)), dim3(SUP_THREADS), 0, st, (const unsigned int *)d_ncand, max_cands,    \
-                       (const float *)d_Rmax, img_stride, d_pmask, d_kmask, mask_stride, LV, (const unsigned int *)d_tile_base,                \
-                       (const unsigned int *)d_tile_seq, n_tiles, d_turns, d_waiting, d_sup_stats)
+                       (const float *)d_Rmax, img_stride, d_pmask, d_kmask, sup_stride, LV, (const unsigned int *)d_level_first, d_turns,      \
+                       d_waiting, d_sup_stats)
 #define SUP_WINDOWS(PASS)                                                                                                                      \
-    OCHIP_HIP(ctx, hipMemcpyAsync(d_smask, d_kmask, (size_t)B * mask_stride * 8, hipMemcpyDeviceToDevice, st));                                \
-    OCHIP_HIP(ctx, hipMemsetAsync(d_mask, 0, (size_t)B * mask_stride * 8, st));                                                                \
+    OCHIP_HIP(ctx, hipMemsetAsync(d_rmask, 0, (size_t)B * sup_stride * 8, st));                                                                \
     hipLaunchKernelGGL(suppress_window_kernel<PASS>, per_cand, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_ncand,       \
-                       max_cands, (const unsigned long long *)d_smask, d_mask, mask_stride, LV, d_found)
-        SUP_PASS(1, d_mask, LV.n);
+                       max_cands, (const unsigned long long *)d_kmask, d_rmask, sup_stride, LV, d_found)
+        SUP_PASS(1, LV.n);
         if (LV.n > 1)
         {
-            // (the maxima masks are through: d_mask takes the bits of the keypoints with something in their window)
             SUP_WINDOWS(2);
-            SUP_PASS(2, d_mask, LV.n - 1);
+            SUP_PASS(2, LV.n - 1);
             SUP_WINDOWS(3);
-            SUP_PASS(3, d_mask, LV.n - 1);
+            SUP_PASS(3, LV.n - 1);
         }
 #undef SUP_WINDOWS
-#undef SUP_PASS
         hipLaunchKernelGGL(suppress_dead_kernel, per_cand, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_ncand,
-                           max_cands, (const unsigned long long *)d_kmask, mask_stride, LV, d_dead);
+                           max_cands, (const unsigned long long *)d_kmask, sup_stride, LV, d_dead);
         if (d_sup_stats)
         {
             std::vector<unsigned int> hs((size_t)3 * B * LV.n * 3);
