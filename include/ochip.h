@@ -118,12 +118,6 @@ extern "C"
     int ochip_akaze_batch(ochip_ctx *ctx, const uint8_t *images_bgr, uint32_t n_images, int width, int height,
                           uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh);
 
-    /* Test hook, host only (no device needed): the windows of AKAZE's dominant-orientation search - 42 sliding windows of
-     * pi / 3, one every 0.15 rad - that contain each angle, bit = window index.  by_table: as the orientation kernels
-     * decide it (a table of the 84 window ends, csrc/akaze.hip orient_window_mask); by_predicate: the restatement's
-     * comparison chain evaluated window by window (oracle/akaze.cpp:606-614).  The two must agree for every float. */
-    int ochip_debug_orientation_windows(const float *angles, uint32_t n, uint64_t *by_table, uint64_t *by_predicate);
-
     /* Same with the images already resident in HBM (device pointer): the PCIe upload is outside the call. */
     int ochip_akaze_batch_dev(ochip_ctx *ctx, const uint8_t *images_bgr_dev, uint32_t n_images, int width, int height,
                               uint32_t max_kp, float *kp6, uint64_t *desc, uint32_t *counts, int *work_wh);

@@ -31,7 +31,7 @@ EXPORTS = [
     "ochip_relaxp_problem_create", "ochip_relaxp_problem_destroy", "ochip_relaxp_set_structure_only", "ochip_relaxp_solve",
     "ochip_relaxp_get_state",
     "ochip_profile_reset", "ochip_profile_get", "ochip_match_work", "ochip_relax_work", "ochip_relax_memory", "ochip_work_counters",
-    "ochip_debug_fp64", "ochip_debug_std_sort", "ochip_debug_orientation_windows", "ochip_match_sort", "ochip_ransac_homography_batch_sorted", "ochip_edge_lists",
+    "ochip_debug_fp64", "ochip_debug_std_sort", "ochip_match_sort", "ochip_ransac_homography_batch_sorted", "ochip_edge_lists",
     "ochip_dense_index_create", "ochip_dense_index_destroy", "ochip_dense_match", "ochip_dense_link", "ochip_dense_triangulate",
     "ochip_rccl_unique_id", "ochip_rccl_comm_create", "ochip_rccl_comm_destroy", "ochip_rccl_comm_stats",
     "ochip_rccl_relax_exchange",

@@ -2342,12 +2342,11 @@ typedef float pkf2 __attribute__((ext_vector_type(2))); // two fp32 lanes of one
 // its vector issue; with both relieved (below) what bounds the kernel is the rate at which a CU's L1 looks up the cache
 // lines of the gathers: ~800 line accesses per keypoint, about one per cycle.  Three changes, every sum still in the
 // restatement's sequential order:
-//  * orientation windows by EXEC mask.  A sample lies in a cyclic run of the 42 windows; which ones is read off a table of
-//    the 84 window ends (orient_tab, checked against the restatement's comparison chain on the host).  The window loop
-//    sets EXEC to the sample's mask (two v_readlane from the lane that owns the sample) and adds: 3 vector instructions
-//    and an 8-byte LDS broadcast per sample instead of 4 and 16 bytes.  (Tried and dropped: the masks and samples through
-//    the scalar cache - one vector instruction per sample, but 14 dependent scalar-memory round trips per wave, 1.7 ms per
-//    100 images against the 0.6 ms the whole orientation took before.)
+//  * orientation windows (round 6: OpenCV 4.x's form).  The 109 samples are sorted into 42 angle slices - a
+//    slice's members as a 128-bit set in LDS (atomic OR), its start by a lane scan of the sets' sizes, a sample's place from
+//    the members with a higher number -, and lane w sums window w: one run of the sorted, cyclic list, eight LDS reads ahead of
+//    their adds.  (Rounds 4 - 5 had the 3.x form: a table of the 84 window ends gave every sample a 42-bit membership mask and
+//    the window loop set EXEC to it, 109 masked adds per keypoint.)
 //  * cell sums: every (cell, channel) sum is a chain of its own on its own lane (4-byte LDS reads at immediate offsets,
 //    one add per step): 13 lanes' worth of cells x 3 channels = 39 lanes, the 3 x 3 grid's cells chained in pairs and the
 //    4 x 4 grid's in fours so that every lane walks ~100 samples - half the adds, a quarter of the LDS cycles.
@@ -2355,25 +2354,6 @@ typedef float pkf2 __attribute__((ext_vector_type(2))); // two fp32 lanes of one
 //    points are dealt to the lanes sorted by image row, then column, for the keypoint's orientation (32 classes, host
 //    table), so a gather instruction covers a band of a few image rows whose neighbouring lanes share cache lines; the
 //    orientation samples likewise go row by row.
-struct orient_tab // angle -> windows, exactly as the restatement's predicate decides (built and self-checked on the host)
-{
-    float4 bucket[104];  // per 1/16 rad: {number of window edges below the bucket (int bits), the up to three edges inside (inf = none)}
-    ulonglong2 mask[88]; // i = number of edges below the angle: .x the windows containing the open interval (E[i-1], E[i]), .y those containing E[i] itself
-};
-
-__device__ __forceinline__ unsigned long long orient_window_mask(float a, const orient_tab *__restrict__ T)
-{
-    const float TWO_PI = 6.28318530717958647692f;
-    if (!(a > 0.0f && a < TWO_PI))
-        return 0ull; // an angle of exactly 0 or 2 pi lies in no window
-    const int k = (int)(a * 16.0f);
-    const float4 bk = T->bucket[k];
-    const int i = __float_as_int(bk.x) + (bk.y < a ? 1 : 0) + (bk.z < a ? 1 : 0) + (bk.w < a ? 1 : 0);
-    const bool on_edge = bk.y == a || bk.z == a || bk.w == a;
-    const ulonglong2 m = T->mask[i];
-    return on_edge ? m.y : m.x;
-}
-
 // geometry of a keypoint in its level image, shared by the three kernels (same expressions, same roundings)
 struct kp_geom
 {
@@ -2426,7 +2406,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
                                                        const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
                                                        size_t img_stride, levels_dev L, float derivative_factor,
                                                        const gather_tab *__restrict__ gtab,
-                                                       const orient_tab *__restrict__ otab, float *__restrict__ kp_out /*[b][max][6]*/,
+                                                       float *__restrict__ kp_out /*[b][max][6]*/,
                                                        unsigned long long *__restrict__ desc_out /*[b][max][8]*/,
                                                        unsigned char *__restrict__ valid_out, int remap,
                                                        unsigned long long *__restrict__ vmask, size_t mask_stride)
@@ -2438,8 +2418,9 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
     float(&vals)[30][3] = vals_all[wv];
     float *const smp = smp_all[wv];
     // the orientation's data are dead before the lattice is stored and share its LDS
-    float2 *const osmp = reinterpret_cast<float2 *>(smp);                              // [109] weighted (Lx, Ly) by sample
-    unsigned long long *const omask = reinterpret_cast<unsigned long long *>(smp) + 112; // [128] window masks by sample
+    float2 *const osmp = reinterpret_cast<float2 *>(smp);                          // [109] weighted (Lx, Ly), sorted by angle slice
+    unsigned long long *const oset = reinterpret_cast<unsigned long long *>(smp) + 112; // [42][2] a slice's samples as a set of their numbers
+    int *const oslice = reinterpret_cast<int *>(smp) + 2 * 112 + 4 * 42;                // [43] samples in the slices below
     auto wave_sync = []() {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // LDS writes of the wave before LDS reads after
         __builtin_amdgcn_wave_barrier();
@@ -2475,66 +2456,86 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
     const float *pLt = Lt + (size_t)b * img_stride + l.off;
     const float2 *pLxy = Lxy + (size_t)b * img_stride + l.off;
 
-    // ---- dominant orientation: 109 samples of the radius-6 disc, two per lane, in image order
+    // ---- dominant orientation (OpenCV 4.x's Compute_Main_Orientation): 109 samples of the radius-6 disc around the ROUNDED
+    // position, two per lane, fetched in image order; a counting sort of their angles into 42 slices - inside a slice the LATER
+    // sample first (quantized_counting_sort fills each slice from its end) -; 42 windows of 7 slices, each summed in sorted order
     {
         const bool second = oe1 != 0xFFFFFFFFu; // (lanes 0..44)
         const int q0 = (int)(oe0 & 255u), i0 = (int)((oe0 >> 8) & 255u) - 6, j0 = (int)((oe0 >> 16) & 255u) - 6;
         const int q1 = (int)(oe1 & 255u), i1 = (int)((oe1 >> 8) & 255u) - 6, j1 = (int)((oe1 >> 16) & 255u) - 6;
-        const int iy0 = clampi((int)rintf(yf + (float)(j0 * g.s)), 0, h - 1), ix0 = clampi((int)rintf(xf + (float)(i0 * g.s)), 0, w - 1);
-        const int iy1 = clampi((int)rintf(yf + (float)(j1 * g.s)), 0, h - 1), ix1 = clampi((int)rintf(xf + (float)(i1 * g.s)), 0, w - 1);
+        const int x0 = (int)rintf(xf), y0 = (int)rintf(yf);
+        const int iy0 = clampi(y0 + j0 * g.s, 0, h - 1), ix0 = clampi(x0 + i0 * g.s, 0, w - 1);
+        const int iy1 = clampi(y0 + j1 * g.s, 0, h - 1), ix1 = clampi(x0 + i1 * g.s, 0, w - 1);
         const float2 g0 = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(pLxy) + (unsigned int)(iy0 * w + ix0) * 8u);
         const float2 g1 = second ? *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(pLxy) + (unsigned int)(iy1 * w + ix1) * 8u)
                                  : make_float2(0.0f, 0.0f);
+        // (the slices' member sets are cleared while the loads are in flight)
+        if (lane < 42)
+            oset[2 * lane] = 0ull, oset[2 * lane + 1] = 0ull;
+        wave_sync();
         const float rx0 = og0 * g0.x, ry0 = og0 * g0.y, rx1 = og1 * g1.x, ry1 = og1 * g1.y;
-        const unsigned long long m0 = orient_window_mask(fast_atan2(ry0, rx0), otab);
-        osmp[q0] = make_float2(rx0, ry0);
-        omask[q0] = m0;
+        const float ang_step = (float)(2.0 * 3.14159265358979323846 / 42);
+        int k0 = (int)(fast_atan2(ry0, rx0) / ang_step), k1 = (int)(fast_atan2(ry1, rx1) / ang_step);
+        k0 = (k0 < 0 || k0 >= 42) ? 0 : k0;
+        k1 = (k1 < 0 || k1 >= 42) ? 0 : k1;
+        // a slice's members as a 128-bit set of sample numbers (LDS atomics: whatever order they arrive in, the set is the same)
+        atomicOr(&oset[2 * k0 + (q0 >> 6)], 1ull << (q0 & 63));
         if (second)
+            atomicOr(&oset[2 * k1 + (q1 >> 6)], 1ull << (q1 & 63));
+        wave_sync();
+        // slice[k] = samples in the slices below k (lanes 0 .. 42: an exclusive scan of the sets' sizes)
+        const int cnt = lane < 42 ? __popcll(oset[2 * lane]) + __popcll(oset[2 * lane + 1]) : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
         {
-            osmp[q1] = make_float2(rx1, ry1);
-            omask[q1] = orient_window_mask(fast_atan2(ry1, rx1), otab);
+            const int t = __shfl_up(incl, off);
+            if (lane >= off)
+                incl += t;
         }
+        if (lane < 43)
+            oslice[lane] = incl - cnt;
+        wave_sync();
+        // a sample's place: its slice's start + the members of the slice with a HIGHER number
+        auto place = [&](int k, int q) {
+            const unsigned long long mx = oset[2 * k], my = oset[2 * k + 1];
+            const unsigned long long above = q < 64 ? (q == 63 ? 0ull : mx >> (q + 1)) : 0ull;
+            const unsigned long long above_hi = q < 64 ? my : (q == 127 ? 0ull : my >> (q - 63));
+            return oslice[k] + __popcll(above) + __popcll(above_hi);
+        };
+        osmp[place(k0, q0)] = make_float2(rx0, ry0);
+        if (second)
+            osmp[place(k1, q1)] = make_float2(rx1, ry1);
     }
     wave_sync();
     float angle;
     {
-        // lane q keeps the masks of samples q and q + 64; the window loop reads them with v_readlane (the lane number is
-        // a constant of the unrolled loop), so a sample is: mask -> EXEC, one packed add of its LDS-broadcast (x, y)
-        // (the windows are lanes 0 .. 41: the upper words hold ten bits - three samples' worth go into one register, and a
-        // v_readlane fetches them for three samples; the fields come apart on the scalar unit)
-        const unsigned long long mq0 = omask[lane], mq1 = lane + 64 < 109 ? omask[lane + 64] : 0ull;
-        const unsigned int mq0lo = (unsigned int)mq0, mq1lo = (unsigned int)mq1;
-        const unsigned int *const omask_hi = reinterpret_cast<const unsigned int *>(omask) + 1;
-        unsigned int hi3 = 0;
-        if (lane < 37)
-            hi3 = omask_hi[6 * lane] | (omask_hi[6 * lane + 2] << 10) | ((3 * lane + 2 < 109 ? omask_hi[6 * lane + 4] : 0u) << 20);
+        // lane sn < 42 sums window sn: the sorted samples from slice[sn] on, slice[min(sn + 7, 42)] - slice[sn] of them and,
+        // for the last six windows, slice[sn + 7 - 42] more from the start of the list - one run of the cyclic list
+        const int sn = min(lane, 41), last = min(sn + 7, 42), remain = sn + 7 - 42;
+        const int start = oslice[sn];
+        const int len = lane < 42 ? oslice[last] - start + (remain > 0 ? oslice[remain] : 0) : 0;
+        int longest = len;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            longest = max(longest, __shfl_xor(longest, off));
+        longest = __builtin_amdgcn_readfirstlane(longest);
         pkf2 sum = {0.0f, 0.0f}; // (sumX, sumY) of the lane's window
-        // (the add is written out: as an `if` the compiler branches around every add and reads the sample inside the
-        // branch, one exposed LDS latency per sample; the samples are read 16 at a time ahead of their adds.  All 64 lanes
-        // are active here - every exit above is taken by whole waves.)
-#pragma unroll
-        for (int q0 = 0; q0 < 109; q0 += 16)
+        for (int t0 = 0; t0 < longest; t0 += 8)
         {
-            pkf2 xy[16];
+            pkf2 xy[8]; // (read eight ahead of their adds)
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (q0 + k < 109)
-                {
-                    const float2 sm = osmp[q0 + k];
-                    xy[k] = pkf2{sm.x, sm.y};
-                }
+            for (int u = 0; u < 8; u++)
+            {
+                int i = start + t0 + u;
+                i = i >= 109 ? i - 109 : i;
+                const float2 sm = osmp[min(i, 108)];
+                xy[u] = pkf2{sm.x, sm.y};
+            }
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (q0 + k < 109)
-                {
-                    const int q = q0 + k;
-                    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(q < 64 ? mq0lo : mq1lo), q & 63);
-                    const unsigned int hi = ((unsigned int)__builtin_amdgcn_readlane((int)hi3, q / 3) >> (10 * (q % 3))) & 0x3FFu;
-                    const unsigned long long in_window = ((unsigned long long)hi << 32) | lo;
-                    asm volatile("s_mov_b64 exec, %2\n\tv_pk_add_f32 %0, %0, %1\n\ts_mov_b64 exec, -1"
-                                 : "+v"(sum)
-                                 : "v"(xy[k]), "s"(in_window));
-                }
+            for (int u = 0; u < 8; u++)
+                if (t0 + u < len)
+                    sum += xy[u];
         }
         float wmag = -1.0f, wangle = 0.0f;
         if (lane < 42)
@@ -2542,8 +2543,8 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
             wmag = sum.x * sum.x + sum.y * sum.y;
             wangle = fast_atan2_deg(sum.y, sum.x); // (KeyPoint::angle: degrees)
         }
-        // first strict maximum in window order (the sequential loop's choice): the largest magnitude, and of the windows
-        // that have it the lowest - a butterfly maximum, a ballot of the lanes that hold it, the first of them
+        // the first window with the largest norm (the loop's strict `norm > maxNorm` from window 0 on): a butterfly maximum, a
+        // ballot of the lanes that hold it, the first of them
         float mx = wmag;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1)
@@ -2553,7 +2554,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
         }
         const int widx = __builtin_ctzll(__ballot(wmag == mx));
         const float best_angle = __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)__float_as_uint(wangle), widx));
-        angle = (mx > 0.0f ? best_angle : 0.0f) * OCHIP_DEG2RAD_F; // what the descriptor rotates by (and the interface reports)
+        angle = best_angle * OCHIP_DEG2RAD_F; // what the descriptor rotates by (and the interface reports)
     }
     float si, co;
     libm_sincosf(angle, &si, &co);
@@ -2734,11 +2735,15 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
                     count += !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h) ? 1 : 0;
                 }
         }
-        const float inv = fmaxf((float)count, 1.0f);
-        const float di = vals[lane][0], ddx = vals[lane][1], ddy = vals[lane][2];
-        vals[lane][0] = di / inv;
-        vals[lane][1] = ddx / inv;
-        vals[lane][2] = ddy / inv;
+        // (MLDB_Fill_Values, OpenCV 4.x: the sums times nsamples_inv = 1.0f / nsamples; a cell without a sample keeps its zeros)
+        if (count > 0)
+        {
+            const float ninv = 1.0f / (float)count;
+            const float di = vals[lane][0], ddx = vals[lane][1], ddy = vals[lane][2];
+            vals[lane][0] = di * ninv;
+            vals[lane][1] = ddx * ninv;
+            vals[lane][2] = ddy * ninv;
+        }
     }
     wave_sync();
     for (int wd = 0; wd < 8; wd++)
@@ -3129,119 +3134,6 @@ int ochip_synth_render_views(ochip_ctx *ctx, uint8_t *images_dev, uint32_t first
 namespace
 {
 
-// orient_tab from the 42 float-accumulated window starts: every window is an open interval (ang1, ang2) of (0, 2 pi),
-// or - wrapped - the union (0, ang2) + (ang1, 2 pi) (the predicate of the CPU restatement, its akaze.cpp:606-614).  The 84
-// interval ends cut (0, 2 pi) into pieces on which the set of windows containing an angle is constant; an angle ON an
-// end lies in the windows common to the two pieces it separates.  The table is checked against the predicate itself at
-// every end, at its float neighbours and over a sweep of angles before it is used (once per process).
-struct orient_windows
-{
-    float a1[42], a2[42];
-    orient_tab T;
-    bool ok = false;
-
-    unsigned long long direct(float a) const // the predicate of the restatement's window loop
-    {
-        const float TWO_PI_F = 6.28318530717958647692f;
-        unsigned long long m = 0;
-        for (int w = 0; w < 42; w++)
-            if ((a1[w] < a2[w] && a1[w] < a && a < a2[w]) || (a2[w] < a1[w] && ((a > 0.0f && a < a2[w]) || (a > a1[w] && a < TWO_PI_F))))
-                m |= 1ull << w;
-        return m;
-    }
-    unsigned long long lookup(float a) const // orient_window_mask on the host
-    {
-        const float TWO_PI_F = 6.28318530717958647692f;
-        if (!(a > 0.0f && a < TWO_PI_F))
-            return 0ull;
-        const float4 bk = T.bucket[(int)(a * 16.0f)];
-        int base;
-        std::memcpy(&base, &bk.x, 4);
-        const int i = base + (bk.y < a ? 1 : 0) + (bk.z < a ? 1 : 0) + (bk.w < a ? 1 : 0);
-        const bool on_edge = bk.y == a || bk.z == a || bk.w == a;
-        return on_edge ? T.mask[i].y : T.mask[i].x;
-    }
-    orient_windows()
-    {
-        const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
-        int nw = 0;
-        for (float a = 0.0f; a < TWO_PI_F && nw < 42; a += 0.15f) // for (ang1 = 0; ang1 < 2 pi; ang1 += 0.15f)
-            a1[nw++] = a;
-        if (nw != 42 || !(a1[41] + 0.15f >= TWO_PI_F))
-            return;
-        for (int w = 0; w < 42; w++)
-            a2[w] = (a1[w] + PI_F / 3.0f > TWO_PI_F) ? a1[w] - 5.0f * PI_F / 3.0f : a1[w] + PI_F / 3.0f;
-        std::vector<float> E(a1, a1 + 42);
-        E.insert(E.end(), a2, a2 + 42);
-        std::sort(E.begin(), E.end());
-        E.erase(std::unique(E.begin(), E.end()), E.end());
-        const int n = (int)E.size();
-        if (n + 1 > 88 || E.front() < 0.0f || !(E.back() < TWO_PI_F))
-            return;
-        std::vector<unsigned long long> M(n + 2, 0ull);
-        for (int i = 0; i <= n; i++)
-        {
-            const float lo = i == 0 ? 0.0f : E[i - 1], hi = i == n ? TWO_PI_F : E[i]; // the piece (lo, hi)
-            for (int w = 0; w < 42; w++)
-            {
-                const bool in = a1[w] < a2[w] ? (a1[w] <= lo && hi <= a2[w]) : (a2[w] < a1[w] && (hi <= a2[w] || a1[w] <= lo));
-                if (in)
-                    M[i] |= 1ull << w;
-            }
-        }
-        M[n + 1] = M[n];
-        for (int i = 0; i < 88; i++)
-        {
-            const int k = std::min(i, n);
-            T.mask[i] = make_ulonglong2(M[k], M[k] & M[k + 1]);
-        }
-        const float INF = std::numeric_limits<float>::infinity();
-        if ((int)(TWO_PI_F * 16.0f) + 1 > 104)
-            return;
-        for (int k = 0; k < 104; k++)
-        {
-            int base = 0, n_in = 0;
-            float in[3] = {INF, INF, INF};
-            for (float e : E)
-            {
-                const int ke = (int)(e * 16.0f);
-                if (ke < k)
-                    base++;
-                else if (ke == k)
-                {
-                    if (n_in == 3)
-                        return;
-                    in[n_in++] = e;
-                }
-            }
-            float fbase;
-            std::memcpy(&fbase, &base, 4);
-            T.bucket[k] = make_float4(fbase, in[0], in[1], in[2]);
-        }
-        for (float e : E)
-        {
-            float a = e;
-            for (int k = 0; k < 3; k++)
-                a = std::nextafter(a, -INF);
-            for (int k = 0; k < 7; k++, a = std::nextafter(a, INF))
-                if (lookup(a) != direct(a))
-                    return;
-        }
-        for (int k = 0; k <= 100000; k++)
-        {
-            const float a = (float)k * (TWO_PI_F / 100000.0f);
-            if (lookup(a) != direct(a))
-                return;
-        }
-        ok = true;
-    }
-};
-const orient_windows &host_orient_windows()
-{
-    static const orient_windows W;
-    return W;
-}
-
 // gather_tab: which lane fetches which sample (any assignment is correct - the LDS images are indexed by the sample; this
 // one makes the lanes of a gather instruction neighbours in the image, so that they share cache lines).
 const gather_tab &host_gather_tab()
@@ -3441,7 +3333,6 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     unsigned int *d_level_first = nullptr;                 // first candidate of every level of every image (+ the list's length)
     unsigned int *d_turns = nullptr, *d_waiting = nullptr; // its two lists of points waiting for their turn, their lengths per (image, level)
     unsigned int *d_wbase = nullptr, *d_live = nullptr, *d_nlive = nullptr;
-    orient_tab *d_otab = nullptr;
     gather_tab *d_gtab = nullptr;
     const size_t src_px = (size_t)width * height;
     // 1-D tile grids padded to a multiple of 8 workgroups (xcd_tile)
@@ -3517,14 +3408,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         AK(up(ctx, allocs, &d_tile_seq, seq.data(), seq.size()));
     }
     {
-        // the descriptor kernel's tables (built once per process): orientation windows, gather orders, cell chains, bit list
-        const orient_windows &ow = host_orient_windows();
-        if (!ow.ok)
-        {
-            cleanup();
-            return ochip_fail(ctx, OCHIP_EINVAL, "akaze: the orientation-window table disagrees with the window predicate");
-        }
-        AK(up(ctx, allocs, &d_otab, &ow.T, 1));
+        // the descriptor kernel's tables (built once per process): gather orders, cell chains, bit list
         AK(up(ctx, allocs, &d_gtab, &host_gather_tab(), 1));
     }
     if (rc != OCHIP_OK)
@@ -4063,7 +3947,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
             hipLaunchKernelGGL(describe3_kernel, dim3(512 * (((max_live + DESC_WPB - 1) / DESC_WPB + 511) / 512), 1, B), dim3(64 * DESC_WPB), 0, st,
                                (const cand_t *)d_cands, (const unsigned int *)d_nlive, max_cands, (const unsigned int *)d_live,
                                (const float *)d_Lt, (const float2 *)d_Lxy, img_stride, LV, dfactor,
-                               (const gather_tab *)d_gtab, (const orient_tab *)d_otab, d_kp, d_desc, d_valid, xcd_remap, d_vmask,
+                               (const gather_tab *)d_gtab, d_kp, d_desc, d_valid, xcd_remap, d_vmask,
                                mask_stride);
         }
     }
@@ -4115,17 +3999,3 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
 
 } // namespace
 
-extern "C" int ochip_debug_orientation_windows(const float *angles, uint32_t n, uint64_t *by_table, uint64_t *by_predicate)
-{
-    if ((n && !angles) || !by_table || !by_predicate)
-        return OCHIP_EINVAL;
-    const orient_windows &ow = host_orient_windows();
-    if (!ow.ok)
-        return OCHIP_EINVAL;
-    for (uint32_t i = 0; i < n; i++)
-    {
-        by_table[i] = ow.lookup(angles[i]);
-        by_predicate[i] = ow.direct(angles[i]);
-    }
-    return OCHIP_OK;
-}

@@ -3,13 +3,20 @@
 // KNOWN DEPARTURES FROM OpenCV's AKAZE (features2d/src/kaze/AKAZEFeatures.cpp, nldiffusion_functions.cpp [3P: not under
 // /root/reference, absent from this image - what OpenCV does is quoted from its published source, not checked here]).
 // Each is a place where this file is deliberately NOT a transcription; scripts/akaze_pin.py --compare attributes what it
-// finds to them (classes `suppression`, `angle`, `descriptor`).  STRUCTURE: OpenCV 4.x rewrote three places of the
-// original A-KAZE / OpenCV 3.x code (as recalled, unverified): Find_Scale_Space_Extrema became three passes over per-level
-// keypoint masks, Compute_Main_Orientation samples around cvRound(pt / ratio) and slides a 7-slice window over a counting
-// sort of the angles into 42 slices, and the M-LDB sampler clamps coordinates into the image.  This restatement follows 4.x
-// in the first (since round 6, see D1) and the 3.x path in the other two (per-sample rounding of the orientation samples, 42
-// windows stepped by 0.15 rad, out-of-image descriptor samples skipped): a reference built against either version differs
-// from this file in the places where it follows the other, whatever D1 - D4 say; none of it can be pinned in this image.
+// finds to them (classes `suppression`, `angle`, `descriptor`).  STRUCTURE: OpenCV 4.x rewrote parts of the original A-KAZE
+// / OpenCV 3.x code, and 4.x is what the reference is built and tested against: its CI runs on ubuntu-24.04 with the
+// distribution's libopencv-dev, OpenCV 4.6 (/root/reference/.github/workflows/ci.yml:11, tools/install_dependencies.sh:5).
+// Since round 6 this restatement follows the 4.x forms, as recalled (unverifiable in this image):
+//   * Find_Scale_Space_Extrema: three passes over per-level keypoint masks (D1 below);
+//   * Compute_Main_Orientation: the 109 samples of the radius-6 disc around the ROUNDED position (Sample_Derivative_Response_
+//     Radius6: x0 = cvRound(pt.x / ratio), x = x0 + i * scale), their angles sorted into 42 slices of 2 pi / 42 by
+//     quantized_counting_sort (slice = (int)(angle / step), out of range -> 0; it fills each slice from its end, so inside a
+//     slice the later sample comes first), a window of 7 slices slid over the 42 starts, the last six wrapping; every window
+//     summed in sorted order from zero, the first window with the largest norm wins.  (3.x, rounds 2 - 5: per-sample rounding
+//     cvRound(xf + i * s), 42 windows stepped by 0.15f rad with strict comparisons, sums in sample order.)
+//   * MLDB_Fill_Values: a cell's sums are multiplied by nsamples_inv = 1.0f / nsamples (3.x divided by the count); samples
+//     outside the image are skipped and a cell without a sample keeps its zeros.
+// A reference built against 3.x would differ in exactly these places.
 //
 //  D1  scale-space suppression            (removed in round 6) this file: suppress_masks_4x, called by detect_and_describe, step 2
 //      now:    OpenCV 4.x's three passes, in their order.  (1) Per level in raster order, a 3 x 3 maximum looks for the FIRST
@@ -1041,45 +1048,71 @@ std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o
         const float *Lt = ss.Lt[c.level].data(), *Lx = ss.Lx[c.level].data(), *Ly = ss.Ly[c.level].data();
         const float xf = kp.x / ratio, yf = kp.y / ratio;
         const int s = (int)std::lrintf(0.5f * kp.size / ratio);
-        // dominant orientation: 109 samples in a radius-6 disc, pi/3 sliding window
+        // dominant orientation (OpenCV 4.x's Compute_Main_Orientation, header "STRUCTURE"): 109 samples of a radius-6 disc around the
+        // ROUNDED position (Sample_Derivative_Response_Radius6: x0 = cvRound(pt.x / ratio), offsets i * scale), their angles sorted
+        // into 42 slices of 2 pi / 42 (quantized_counting_sort: slice (int)(angle / step), out of range -> 0; inside a slice the
+        // LATER sample first), and a window of 7 slices (pi / 3) slid over the slices - sums in sorted order, the last six windows
+        // wrapping from the last slice to the first
         float resX[109], resY[109], Ang[109];
-        int idx = 0;
-        for (int i = -6; i <= 6; i++)
-            for (int j = -6; j <= 6; j++)
-                if (i * i + j * j < 36)
-                {
-                    const int iy = clampi((int)std::lrintf(yf + (float)(j * s)), 0, h - 1);
-                    const int ix = clampi((int)std::lrintf(xf + (float)(i * s)), 0, w - 1);
-                    const float g = gw[(i + 6) * 13 + (j + 6)];
-                    resX[idx] = g * Lx[(size_t)iy * w + ix];
-                    resY[idx] = g * Ly[(size_t)iy * w + ix];
-                    Ang[idx] = fast_atan2(resY[idx], resX[idx]);
-                    idx++;
-                }
-        float best = 0.0f, angle = 0.0f;
-        // for (ang1 = 0; ang1 < 2 pi; ang1 += 0.15f), as AKAZE's Compute_Main_Orientation steps its window: the start
-        // angles are the float-accumulated sums (42 of them), not multiples of 0.15
-        for (float ang1 = 0.0f; ang1 < TWO_PI_F; ang1 += 0.15f)
         {
-            const float ang2 = (ang1 + PI_F / 3.0f > TWO_PI_F) ? ang1 - 5.0f * PI_F / 3.0f : ang1 + PI_F / 3.0f;
-            float sumX = 0.0f, sumY = 0.0f;
+            const int x0 = (int)std::lrintf(xf), y0 = (int)std::lrintf(yf);
+            int idx = 0;
+            for (int i = -6; i <= 6; i++)
+                for (int j = -6; j <= 6; j++)
+                    if (i * i + j * j < 36)
+                    {
+                        const int iy = clampi(y0 + j * s, 0, h - 1), ix = clampi(x0 + i * s, 0, w - 1);
+                        const float g = gw[(i + 6) * 13 + (j + 6)];
+                        resX[idx] = g * Lx[(size_t)iy * w + ix];
+                        resY[idx] = g * Ly[(size_t)iy * w + ix];
+                        Ang[idx] = fast_atan2(resY[idx], resX[idx]);
+                        idx++;
+                    }
+        }
+        constexpr int slices = 42, win = 7;
+        const float ang_step = (float)(2.0 * 3.14159265358979323846 / slices);
+        int slice[slices + 1], sorted_idx[109];
+        {
+            for (int i = 0; i <= slices; i++)
+                slice[i] = 0;
+            auto key = [&](int q) {
+                const int k = (int)(Ang[q] / ang_step);
+                return (k < 0 || k >= slices) ? 0 : k;
+            };
             for (int q = 0; q < 109; q++)
+                slice[key(q)]++;
+            for (int i = 1; i <= slices; i++) // inclusive prefix sums: the slices' ends
+                slice[i] += slice[i - 1];
+            for (int q = 0; q < 109; q++) // filled from each slice's end downwards; slice[] becomes the slices' starts
+                sorted_idx[--slice[key(q)]] = q;
+        }
+        float maxX = 0.0f, maxY = 0.0f;
+        for (int i = slice[0]; i < slice[win]; i++)
+        {
+            maxX = maxX + resX[sorted_idx[i]];
+            maxY = maxY + resY[sorted_idx[i]];
+        }
+        float best = maxX * maxX + maxY * maxY;
+        for (int sn = 1; sn < slices; sn++)
+        {
+            // (OpenCV skips a window whose contents did not change; it would not be strictly larger than itself either)
+            float sumX = 0.0f, sumY = 0.0f;
+            const int last = std::min(sn + win, slices), remain = sn + win - slices;
+            for (int i = slice[sn]; i < slice[last]; i++)
             {
-                const float a = Ang[q];
-                if ((ang1 < ang2 && ang1 < a && a < ang2) ||
-                    (ang2 < ang1 && ((a > 0.0f && a < ang2) || (a > ang1 && a < TWO_PI_F))))
-                {
-                    sumX = sumX + resX[q];
-                    sumY = sumY + resY[q];
-                }
+                sumX = sumX + resX[sorted_idx[i]];
+                sumY = sumY + resY[sorted_idx[i]];
+            }
+            for (int i = slice[0]; remain > 0 && i < slice[remain]; i++)
+            {
+                sumX = sumX + resX[sorted_idx[i]];
+                sumY = sumY + resY[sorted_idx[i]];
             }
             const float m = sumX * sumX + sumY * sumY;
             if (m > best)
-            {
-                best = m;
-                angle = cv_fast_atan2_deg(sumY, sumX); // KeyPoint::angle is in degrees
-            }
+                best = m, maxX = sumX, maxY = sumY;
         }
+        float angle = cv_fast_atan2_deg(maxY, maxX); // KeyPoint::angle is in degrees
         angle = angle * DEG2RAD_F; // what the descriptor rotates by (and what this interface reports: radians)
         kp.angle = angle;
         // M-LDB, 3 channels, grids 2x2 / 3x3 / 4x4 over [-10, 10) * scale, rotated by the orientation
@@ -1115,10 +1148,16 @@ std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o
                             ddy = ddy + rry;
                             ns++;
                         }
-                    const float inv = (float)std::max(ns, 1);
-                    vals[cell][0] = di / inv;
-                    vals[cell][1] = ddx / inv;
-                    vals[cell][2] = ddy / inv;
+                    if (ns > 0) // (MLDB_Fill_Values, OpenCV 4.x: the sums times nsamples_inv, not divided by the count)
+                    {
+                        const float ninv = 1.0f / (float)ns;
+                        di = di * ninv;
+                        ddx = ddx * ninv;
+                        ddy = ddy * ninv;
+                    }
+                    vals[cell][0] = di;
+                    vals[cell][1] = ddx;
+                    vals[cell][2] = ddy;
                     cell++;
                 }
             for (int ch = 0; ch < 3; ch++)
