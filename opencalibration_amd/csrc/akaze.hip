@@ -1819,12 +1819,12 @@ __device__ __forceinline__ unsigned long long sup_rows(int lo, int hi)
 // a point of this pass in front of (x, y) in raster order inside the box of half-width r that has not had its turn.  r <= 7
 // (every level of the default scale space: sigma_size is 2, 3 or 4): 3 x 2 words requested without a branch - a word
 // outside the box is read again and masked out
-__device__ __forceinline__ bool sup_pending(const unsigned long long *Pm, const level_info &l, int x, int y, int r)
+__device__ __forceinline__ bool sup_pending(const unsigned long long *Pm, const level_info &l, int x, int y, int r, bool generic)
 {
     const int x0 = max(x - r, 0), x1 = min(x + r, l.w - 1), y0 = max(y - r, 0);
     const int txa = x0 >> 3, txb = x1 >> 3, tya = y0 >> 3, tyb = y >> 3;
     unsigned long long any = 0;
-    if (r <= 7)
+    if (r <= 7 && !generic)
     {
         // rows y0 .. y - 1 of the upper word row, rows 0 .. y - 1 of the lower one when there are two, and in the word row
         // of y the columns in front of x
@@ -1854,13 +1854,14 @@ __device__ __forceinline__ bool sup_pending(const unsigned long long *Pm, const 
 }
 // find_neighbor_point: the first set bit, in raster order, of [y - r, y + r) x [x - r, x + r) within r (Euclidean) of (x, y).
 // r <= 8 (sigma_size times an octave step of at most 2): at most 3 x 3 words, requested together
-__device__ __forceinline__ bool sup_first_set(const unsigned long long *W, const level_info &l, int x, int y, int r, int *fx, int *fy)
+__device__ __forceinline__ bool sup_first_set(const unsigned long long *W, const level_info &l, int x, int y, int r, int *fx, int *fy,
+                                              bool generic)
 {
     const int x0 = max(x - r, 0), x1 = min(x + r, l.w) - 1, y0 = max(y - r, 0), y1 = min(y + r, l.h) - 1;
     if (x1 < x0 || y1 < y0)
         return false;
     const int txa = x0 >> 3, txb = x1 >> 3, tya = y0 >> 3, tyb = y1 >> 3;
-    if (r <= 8)
+    if (r <= 8 && !generic)
     {
         unsigned long long m[3][3], any = 0;
 #pragma unroll
@@ -1967,7 +1968,7 @@ template <int PASS>
 __global__ __launch_bounds__(256) void suppress_window_kernel(const cand_t *__restrict__ cands, const unsigned int *__restrict__ n_cands,
                                                               unsigned int max_cands, const unsigned long long *__restrict__ own,
                                                               unsigned long long *__restrict__ has, size_t mask_stride, levels_dev L,
-                                                              unsigned int *__restrict__ found)
+                                                              unsigned int *__restrict__ found, int hooks)
 {
     const unsigned int b = blockIdx.z, k = blockIdx.x * 256 + threadIdx.x, n = min(n_cands[b], max_cands);
     if (k >= n)
@@ -1986,7 +1987,7 @@ __global__ __launch_bounds__(256) void suppress_window_kernel(const cand_t *__re
             const int r = PASS == 2 ? l.sigma_size * diff : lo.sigma_size;
             const int px = PASS == 2 ? c.x * diff : c.x >> shift, py = PASS == 2 ? c.y * diff : c.y >> shift;
             int fx = 0, fy = 0;
-            if (sup_first_set(own + (size_t)b * mask_stride + lo.sup_off, lo, px, py, r, &fx, &fy))
+            if (sup_first_set(own + (size_t)b * mask_stride + lo.sup_off, lo, px, py, r, &fx, &fy, (hooks & 1) != 0))
             {
                 f = (unsigned int)fx | ((unsigned int)fy << 16) | SUP_FOUND;
                 atomicOr(&has[word], bit);
@@ -2010,8 +2011,10 @@ __global__ __launch_bounds__(256) void suppress_round0_kernel(const cand_t *__re
                                                               unsigned long long *kmask, size_t mask_stride, levels_dev L,
                                                               const unsigned int *__restrict__ level_first,
                                                               unsigned int *__restrict__ turns, unsigned int *__restrict__ waiting,
-                                                              const unsigned int *__restrict__ found)
+                                                              const unsigned int *__restrict__ found, int hooks)
 {
+    // (a list of the keypoints pass 1 left instead of a thread per candidate in passes 2 / 3 - a third of the wavefronts - was
+    // measured: the list's one counter per image cost 0.97 ms per 100 images, and the launches on the list were no faster)
     const unsigned int b = blockIdx.z, k = blockIdx.x * 256 + threadIdx.x, n = min(n_cands[b], max_cands);
     cand_t c = cand_t{0, 0, 0, 0.f, 0.f, 0.f};
     bool has_turn = k < n;
@@ -2040,7 +2043,7 @@ __global__ __launch_bounds__(256) void suppress_round0_kernel(const cand_t *__re
         const level_info lo = one_level ? L.l[lv0 + other] : L.l[c.level + other];
         const int shift = PASS == 3 ? lo.octave - l.octave : 0;
         const int box = PASS == 3 ? 2 * lo.sigma_size * (1 << shift) - 1 : 2 * l.sigma_size - 1;
-        waits = sup_pending(own + (size_t)b * mask_stride + l.sup_off, l, c.x, c.y, box);
+        waits = sup_pending(own + (size_t)b * mask_stride + l.sup_off, l, c.x, c.y, box, (hooks & 1) != 0);
         if (waits)
             atomicOr(&pend[word], bit);
         else if (PASS == 1)
@@ -2080,7 +2083,8 @@ __global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsi
                                                                       const float *__restrict__ Rmax, size_t img_stride,
                                                                       unsigned long long *pend, unsigned long long *kmask, size_t mask_stride,
                                                                       levels_dev L, const unsigned int *__restrict__ level_first,
-                                                                      unsigned int *turns, unsigned int *waiting, unsigned int *__restrict__ stats)
+                                                                      unsigned int *turns, unsigned int *waiting, unsigned int *__restrict__ stats,
+                                                                      int hooks)
 {
     // pend: the points round 0 left waiting (all zero again when the launch ends); kmask: the keypoints
     // (image fastest: workgroups go to the 8 XCDs round-robin, and with the level fastest the four levels of the first octave -
@@ -2104,14 +2108,15 @@ __global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsi
     __shared__ unsigned int s_list[2][SUP_LDS];
     __shared__ unsigned int s_n[2];
     unsigned int *spill0 = turns + (size_t)b * 2 * max_cands + first, *spill1 = spill0 + max_cands;
-    auto get = [&](int which, unsigned int idx) { return idx < SUP_LDS ? s_list[which][idx] : (which ? spill1 : spill0)[idx]; };
+    const unsigned int in_lds = (hooks & 2) ? 64u : (unsigned int)SUP_LDS; // (test hook sup_small_lists: the HBM part of the lists)
+    auto get = [&](int which, unsigned int idx) { return idx < in_lds ? s_list[which][idx] : (which ? spill1 : spill0)[idx]; };
     auto put = [&](int which, unsigned int idx, unsigned int v) {
-        if (idx < SUP_LDS)
+        if (idx < in_lds)
             s_list[which][idx] = v;
         else
             (which ? spill1 : spill0)[idx] = v;
     };
-    for (unsigned int idx = tid; idx < min(m0, (unsigned int)SUP_LDS); idx += SUP_THREADS)
+    for (unsigned int idx = tid; idx < min(m0, in_lds); idx += SUP_THREADS)
         s_list[0][idx] = spill0[idx];
     if (tid == 0)
         s_n[0] = m0;
@@ -2128,7 +2133,7 @@ __global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsi
         for (unsigned int idx = tid; idx < m; idx += SUP_THREADS) // who is ready
         {
             const unsigned int e = get(cur, idx);
-            if (!sup_pending(Pm, l, (int)(e & 0xffffu), (int)(e >> 16), box))
+            if (!sup_pending(Pm, l, (int)(e & 0xffffu), (int)(e >> 16), box, (hooks & 1) != 0))
                 put(cur, idx, e | SUP_READY);
         }
         __syncthreads();
@@ -2148,7 +2153,7 @@ __global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsi
             if (PASS == 1)
             {
                 bool keep = true;
-                if (sup_first_set(W, l, x, y, r, &fx, &fy))
+                if (sup_first_set(W, l, x, y, r, &fx, &fy, (hooks & 1) != 0))
                 {
                     if (response > R[(size_t)fy * l.w + fx])
                         atomicAnd(&W[sup_word(l, fx, fy)], ~sup_bit(fx, fy));
@@ -2161,7 +2166,7 @@ __global__ __launch_bounds__(SUP_THREADS) void suppress_rounds_kernel(const unsi
             else
             {
                 const int px = PASS == 2 ? x * diff : x >> shift, py = PASS == 2 ? y * diff : y >> shift;
-                if (sup_first_set(Wo, lo, px, py, r, &fx, &fy) && response > Ro[(size_t)fy * lo.w + fx])
+                if (sup_first_set(Wo, lo, px, py, r, &fx, &fy, (hooks & 1) != 0) && response > Ro[(size_t)fy * lo.w + fx])
                     atomicAnd(&Wo[sup_word(lo, fx, fy)], ~sup_bit(fx, fy));
             }
             atomicAnd(&Pm[word], ~bit);
@@ -3869,6 +3874,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     {
         OCHIP_HIP(ctx, hipMemsetAsync(d_vmask, 0, (size_t)B * mask_stride * 8, st));
         const dim3 per_cand((max_n + 255) / 256, 1, B);
+        // test hooks: the suppression's code for radii beyond the default scale space's / its lists beyond their LDS part
+        const int sup_hooks = (ochip_test_hook("sup_generic") ? 1 : 0) | (ochip_test_hook("sup_small_lists") ? 2 : 0);
         unsigned int *d_sup_stats = nullptr;
         if (ochip_verbose("extract"))
         {
@@ -3886,14 +3893,14 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
 #define SUP_PASS(PASS, LEVELS)                                                                                                                 \
     hipLaunchKernelGGL(suppress_round0_kernel<PASS>, per_cand, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_ncand,       \
                        max_cands, (const float *)d_Rmax, img_stride, (const unsigned long long *)d_rmask, d_pmask, d_kmask, sup_stride, LV,    \
-                       (const unsigned int *)d_level_first, d_turns, d_waiting, (const unsigned int *)d_found);                                \
+                       (const unsigned int *)d_level_first, d_turns, d_waiting, (const unsigned int *)d_found, sup_hooks);                     \
     hipLaunchKernelGGL(suppress_rounds_kernel<PASS>, dim3(B, (LEVELS)), dim3(SUP_THREADS), 0, st, (const unsigned int *)d_ncand, max_cands,    \
                        (const float *)d_Rmax, img_stride, d_pmask, d_kmask, sup_stride, LV, (const unsigned int *)d_level_first, d_turns,      \
-                       d_waiting, d_sup_stats)
+                       d_waiting, d_sup_stats, sup_hooks)
 #define SUP_WINDOWS(PASS)                                                                                                                      \
     OCHIP_HIP(ctx, hipMemsetAsync(d_rmask, 0, (size_t)B * sup_stride * 8, st));                                                                \
     hipLaunchKernelGGL(suppress_window_kernel<PASS>, per_cand, dim3(256), 0, st, (const cand_t *)d_cands, (const unsigned int *)d_ncand,       \
-                       max_cands, (const unsigned long long *)d_kmask, d_rmask, sup_stride, LV, d_found)
+                       max_cands, (const unsigned long long *)d_kmask, d_rmask, sup_stride, LV, d_found, sup_hooks)
         SUP_PASS(1, LV.n);
         if (LV.n > 1)
         {

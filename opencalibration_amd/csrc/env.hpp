@@ -14,7 +14,9 @@
 //                      host_bootstrap (runGroundPlane's cameras without an orientation by round 5's host loop - a problem and two
 //                      solves each - instead of the resident launch of csrc/relax_chain.hip), chain_stepped (that launch one phase
 //                      at a time: the same code, a launch per phase), chain_partial (it takes the first half of the cameras and
-//                      hands the rest to the host loop, as it does when it gives up)
+//                      hands the rest to the host loop, as it does when it gives up),
+//                      sup_generic, sup_small_lists (AKAZE's suppression: the mask probes written for any radius instead of the
+//                      branch-free ones for the default scale space's radii; 64 instead of 2 048 list entries in LDS)
 // Other switches (read where they apply): OCHIP_CHAIN_WORKGROUPS (grid of the resident launch; default half the compute units),
 // OCHIP_IP_PRIORITY=0 (och_initial_processing_step: link and relax streams at the default priority), OCHIP_STRIP_MIN_PIXELS
 // (pixels per launch from which a level takes the register-strip kernels), OCHIP_EXTRACT_GATE=0 (two surveys may extract at once),

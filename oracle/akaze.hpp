@@ -79,7 +79,8 @@ struct ScaleSpace
 };
 ScaleSpace build_scale_space(const std::vector<float> &img, int w, int h, const Options &o);
 std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o);
-// D1 census (akaze.cpp): the order-free suppression rule this project runs against OpenCV's two sequential rules as recalled
+// census of the suppression rules (akaze.cpp): OpenCV 4.x's passes (what detect_and_describe runs), their evaluation in rounds,
+// the order-free rule of rounds 2 - 5 and the 3.x running list as recalled
 void suppression_census(const ScaleSpace &ss, const Options &o, uint64_t counts[11]);
 
 // extract_features(cv::Mat) restated: gray, INTER_AREA downscale to max side 1600, AKAZE, strength sort,

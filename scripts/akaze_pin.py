@@ -21,8 +21,9 @@ CPU restatement.  This script closes that gap the day an OpenCV build is at hand
 
 The comparison reports, per view: keypoint counts, how many OpenCV keypoints have a device keypoint at the same evolution
 level within 0.01 px (and the worst position / size / angle / response difference among those), and the Hamming distance
-of the paired descriptors (0 = bit-identical), and attributes what differs to the known departures D1 - D4 listed at the
-top of oracle/akaze.cpp (cross-level suppression rule, polynomial atan2 / sin / cos, 2 x 2 solve, summation order).
+of the paired descriptors (0 = bit-identical), and attributes what differs to the classes listed at the top of
+oracle/akaze.cpp: `suppression` (a different member of one blob kept - since round 6 the restatement runs OpenCV 4.x's passes,
+so this class points at a 3.x build or at a mis-recalled detail), `angle`, `descriptor` (summation order, D4).
 Exit code 0 only when every view is identical (positions bit-equal, descriptors equal)."""
 import argparse
 import os
@@ -80,8 +81,9 @@ def compare(path):
             hams.append(int(np.unpackbits(gbytes[j] ^ rdesc[k]).sum()))
         hams = np.array(hams if hams else [0])
         # ---- attribution to the known departures listed at the top of oracle/akaze.cpp
-        #  suppression (D1): a keypoint of one side without a partner that has a keypoint of the OTHER side at its own or an
-        #                    adjacent level within its size - the two suppression rules kept different members of one blob
+        #  suppression:      a keypoint of one side without a partner that has a keypoint of the OTHER side at its own or an
+        #                    adjacent level within its size - the two sides kept different members of one blob (D1 is removed:
+        #                    expected 0 against an OpenCV 4.x build)
         #  angle (D2):       paired, same position, orientation differs by less than the polynomial's 0.3 degrees
         #  descriptor (D2/D4): paired, same position and angle class, descriptor bits differ
         def near_other(kp_a, level_a, kp_b, level_b):
@@ -94,9 +96,9 @@ def compare(path):
         r_un = np.array([k for k in range(len(rkp)) if not np.any((gkp[:, 5] == rkp[k, 6]) & (np.hypot(gkp[:, 0] - rkp[k, 0], gkp[:, 1] - rkp[k, 1]) <= 0.01))], int)
         g_un = np.array([k for k in range(len(gkp)) if not np.any((rkp[:, 6] == gkp[k, 5]) & (np.hypot(rkp[:, 0] - gkp[k, 0], rkp[:, 1] - gkp[k, 1]) <= 0.01))], int)
         d1 = near_other(rkp[r_un][:, :3], rkp[r_un][:, 6], gkp[:, :3], gkp[:, 5]) + near_other(gkp[g_un][:, :3], gkp[g_un][:, 5], rkp[:, :3], rkp[:, 6])
-        print(f"   unpaired: OpenCV {len(r_un)}, device {len(g_un)}; {d1} of them explained by D1 (a keypoint of the other side at an "
+        print(f"   unpaired: OpenCV {len(r_un)}, device {len(g_un)}; {d1} of them are another member of a blob the other side kept (class `suppression`: a keypoint of the other side at an "
               f"adjacent level within their size); angle differences up to {np.rad2deg(worst[2]):.3f} degrees "
-              f"({'within' if np.rad2deg(worst[2]) <= 0.3 else 'BEYOND'} D2's 0.3); {int((hams > 0).sum())} paired descriptors differ (D2 / D4)")
+              f"({'within' if np.rad2deg(worst[2]) <= 0.3 else 'BEYOND'} the polynomial's 0.3); {int((hams > 0).sum())} paired descriptors differ (D2 / D4)")
         same = paired == len(rkp) == len(gkp) and worst.max() == 0 and hams.max() == 0
         identical &= same
         print(f"view {s}: OpenCV {len(rkp)} keypoints, device {len(gkp)}, paired {paired}; worst |dx| {worst[0]:.3g} px, "

@@ -192,3 +192,20 @@ def test_tile_and_strip_kernels_agree(hooks):
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
                         "restatement_bitwise or grey_and_area or host_tail or tied_responses or noisy_views"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("hooks", ["sup_generic", "sup_small_lists", "sup_generic,sup_small_lists"])
+def test_suppression_routes_agree(hooks):
+    """Find_Scale_Space_Extrema's suppression (csrc/akaze.hip, suppress_*_kernel) has code the default scale space never
+    reaches on the test images: mask probes written for any radius (the branch-free ones cover the radii of sigma_size 2 - 4)
+    and the part of a level's waiting list that does not fit its 2 048 LDS entries.  OCHIP_TEST_HOOKS=sup_generic sends every
+    probe through the former, sup_small_lists keeps 64 entries in LDS; this file's parity tests run again in a child per
+    route."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, OCHIP_TEST_HOOKS=hooks)
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
+                        "restatement_bitwise or noisy_views or mixed_route"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
