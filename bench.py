@@ -106,20 +106,22 @@ def extract_algorithmic_bytes(w, h, reference_passes=False):
 
 def committed_valu_per_image():
     """Vector (VALU) wavefront instructions per image of the extract sequence from the committed counter pass
-    (profiles/r05_extract_valu.json): (instructions, peak per second, file) or (None, None, None)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r05_extract_valu.json")) as fh:
-            d = json.load(fh)
-        return float(d["extract_valu_wave_instructions_per_image"]), float(d["issue_peak_wave_instructions_per_s"]), "profiles/r05_extract_valu.json"
-    except (OSError, KeyError, ValueError):
-        return None, None, None
+    (profiles/r06_extract_valu.json, else round 5's): (instructions, peak per second, file) or (None, None, None)."""
+    for name in ("r06_extract_valu.json", "r05_extract_valu.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                d = json.load(fh)
+            return float(d["extract_valu_wave_instructions_per_image"]), float(d["issue_peak_wave_instructions_per_s"]), "profiles/" + name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None, None
 
 
 def committed_traffic_per_image():
     """HBM bytes per image of the extract sequence from the committed PMC pass (FETCH_SIZE x 2 + WRITE_SIZE per the guide's
     gfx950 correction, scripts/summarise_profile.py): (bytes, file) or (None, None).  The counters cannot be read from
     inside this process; the figure is a constant of the code version the file was taken with."""
-    for name in ("r05_e2e_pmc_hbm.json", "r04_e2e_pmc_hbm.json", "r03_e2e_pmc_hbm.json", "r02_e2e_pmc_hbm.json"):
+    for name in ("r06_e2e_pmc_hbm.json", "r05_e2e_pmc_hbm.json", "r04_e2e_pmc_hbm.json", "r03_e2e_pmc_hbm.json", "r02_e2e_pmc_hbm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 return float(json.load(fh)["extract_hbm_bytes_per_image"]), "profiles/" + name

@@ -43,3 +43,6 @@ cat $OUT/r06_chain_phase_clock.txt
 grep -i "plane_chain" $OUT/r06_initial_processing_kernel_stats.csv | head -3
 python3 -c "
 import json; d=json.load(open('$OUT/r06_e2e_pmc_hbm.json')); print('HBM bytes per image', d['extract_hbm_bytes_per_image'], d['calibration'])"
+# 7. the suppression's rounds, workgroup times and waiting points per (pass, level) (profiles/r06_suppression_rounds.txt quotes them)
+OCHIP_EXTRACT_STREAMS=1 OCHIP_VERBOSE=extract python3 $R/scripts/extract_only.py 100 1 2>&1 | grep -i "suppression\|repeat" > $OUT/r06_suppression_levels.txt
+grep -i "suppress" $OUT/r06_extract_only_kernel_stats.csv | cut -c1-200 >> $OUT/r06_suppression_levels.txt
