@@ -209,3 +209,29 @@ def test_suppression_routes_agree(hooks):
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
                         "restatement_bitwise or noisy_views or mixed_route"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("kind", ["periodic", "noise", "lattice"])
+def test_order_dependent_suppression_on_hard_images(ctx, oracle, kind):
+    """Find_Scale_Space_Extrema's passes (OpenCV 4.x) decide by the ORDER of the turns and by strict comparisons of responses;
+    the device takes the turns in dependency rounds.  Images that stress exactly that: a periodic texture (many maxima with
+    EQUAL responses next to each other - the earlier one stays), pure noise (maxima at the highest density the 3 x 3 test allows:
+    the longest chains of dependent turns, waiting lists beyond their LDS part) and a sine lattice (maxima lined up along rows, the
+    raster order's worst case).  Bit-identical keypoints and descriptors, as everywhere."""
+    w, h = 640, 480
+    rng = np.random.default_rng(7)
+    if kind == "periodic":
+        cell = synth.render_blobs(64, 48, 3)[:, :, 0]
+        img = np.tile(cell, (h // 48, w // 64))
+    elif kind == "noise":
+        img = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    else:
+        x = np.arange(w)[None, :]
+        y = np.arange(h)[:, None]
+        img = (127 + 100 * np.sin(x * 0.5) * np.sin(y * 0.37)).astype(np.uint8)
+    bgr = np.ascontiguousarray(np.repeat(img[:, :, None], 3, axis=2))
+    got, _ = ctx.akaze_batch(bgr[None], max_kp=60000)
+    ekp, edesc = oracle.akaze(img)
+    gkp, gdesc = got[0]
+    assert len(gkp) == len(ekp) > 100, (len(gkp), len(ekp))
+    assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32)) and np.array_equal(gdesc, edesc)
