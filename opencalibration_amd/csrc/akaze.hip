@@ -2578,14 +2578,15 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
 #pragma unroll
         for (int t = 0; t < 7; t++)
             pe[t] = order[lane + 64 * t];
-        // a lattice point (a, bb) sits at yf + (bb cos s + a sin s), xf + (-bb sin s + a cos s), products left to right: the four
-        // products take 21 values each per keypoint ((-bb sin) s = -((bb sin) s)) - formed once here by 21 lanes, read by
-        // every point from LDS at the byte offsets the table carries, instead of 16 vector instructions per point
+        // a lattice point (a, bb) sits at yf + ((bb s) cos + (a s) sin), xf + ((-bb s) sin + (a s) cos) - the subset sampler's
+        // expression (MLDB_Descriptor_Subset_Invoker: l * scale * co with an integer scale): the four products take 21 values each
+        // per keypoint ((-bb s) sin = -((bb s) sin)) - formed once here by 21 lanes, read by every point from LDS at the byte
+        // offsets the table carries, instead of 16 vector instructions per point
         if (lane < 21)
         {
-            const float fk = (float)(lane - 10);
-            lat_all[wv][0][lane] = fk * co * fs;
-            lat_all[wv][1][lane] = fk * si * fs;
+            const float fk = (float)((lane - 10) * g.s);
+            lat_all[wv][0][lane] = fk * co;
+            lat_all[wv][1][lane] = fk * si;
         }
         wave_sync(); // the orientation's LDS has been read by every lane
         const char *const lat_b = reinterpret_cast<const char *>(&lat_all[wv][0][0]);
@@ -2713,44 +2714,7 @@ __global__ __launch_bounds__(64 * DESC_WPB) void describe3_kernel(const cand_t *
         }
     }
     wave_sync();
-    if (lane < 29)
-    {
-        int lvl, cell;
-        if (lane < 4)
-            lvl = 0, cell = lane;
-        else if (lane < 13)
-            lvl = 1, cell = lane - 4;
-        else
-            lvl = 2, cell = lane - 13;
-        const int gsz = lvl + 2;
-        const int step = (lvl == 0) ? 10 : (lvl == 1 ? 7 : 5); // ceil(20 / g)
-        // number of samples of the cell inside the image: all of them, except for a keypoint near a border, whose lanes
-        // repeat the lattice arithmetic of the gather above (same expressions, same roundings, same answers)
-        int count = step * step;
-        if (!all_inside)
-        {
-            const int i0 = -10 + (cell / gsz) * step, j0 = -10 + (cell % gsz) * step;
-            count = 0;
-            for (int a = i0; a < i0 + step; a++)
-                for (int bb = j0; bb < j0 + step; bb++)
-                {
-                    const float sy = yf + ((float)bb * co * fs + (float)a * si * fs);
-                    const float sx = xf + (-(float)bb * si * fs + (float)a * co * fs);
-                    const int y1 = (int)rintf(sy), x1 = (int)rintf(sx);
-                    count += !(x1 < 0 || y1 < 0 || x1 >= w || y1 >= h) ? 1 : 0;
-                }
-        }
-        // (MLDB_Fill_Values, OpenCV 4.x: the sums times nsamples_inv = 1.0f / nsamples; a cell without a sample keeps its zeros)
-        if (count > 0)
-        {
-            const float ninv = 1.0f / (float)count;
-            const float di = vals[lane][0], ddx = vals[lane][1], ddy = vals[lane][2];
-            vals[lane][0] = di * ninv;
-            vals[lane][1] = ddx * ninv;
-            vals[lane][2] = ddy * ninv;
-        }
-    }
-    wave_sync();
+    // (the subset path compares the cells' SUMS: no means)
     for (int wd = 0; wd < 8; wd++)
     {
         // (entries beyond bit 485 compare a value with itself)
@@ -3193,17 +3157,34 @@ const gather_tab &host_gather_tab()
                                                       ((unsigned int)(((P[k].a + 10) * 21 + (P[k].bb + 10)) * 12) << 16)
                                                 : 0xFFFFFFFFu;
         }
-        // the comparison list in the order the descriptor's bits are written: per grid, per channel, cell pairs a < b;
-        // cells numbered 0..3 | 4..12 | 13..28, a mean at vals[cell][channel]
-        int dpos = 0;
-        const int base[3] = {0, 4, 13};
-        for (int lvl = 0; lvl < 3; lvl++)
+        // the comparison list in the order the descriptor's bits are written.  The reference asks for descriptor_size = 486, and
+        // any size other than 0 takes OpenCV's subset path: generateDescriptorSubsample (AKAZEFeatures.cpp) draws the 162 cell
+        // pairs in the order of cv::RNG(1024) (state = (uint64)(unsigned)state * 4164903690U + (unsigned)(state >> 32); rng(N) =
+        // next() % N; the first six picks forced to rows 0 .. 5 after the draw; the row picked is overwritten by the last live
+        // one), bit 3 i + c = pick i in channel c of (Lt, rx co + ry si, -rx si + ry co).  Here the cells are numbered 0..3 |
+        // 4..12 | 13..28 with the a (= k) range as the slow index, a sum at vals[cell][channel], channels (Lt, -rx si + ry co,
+        // rx co + ry si): OpenCV's cell j of grid g is (a range j % g, bb range j / g), its channels 1 and 2 are ours 2 and 1.
         {
-            const int nval = (lvl + 2) * (lvl + 2);
-            for (int ch = 0; ch < 3; ch++)
-                for (int a = 0; a < nval; a++)
-                    for (int bb = a + 1; bb < nval; bb++)
-                        T.bit_ofs[dpos++] = (unsigned int)(((base[lvl] + a) * 3 + ch) * 4) | ((unsigned int)(((base[lvl] + bb) * 3 + ch) * 4) << 16);
+            int full[162][3], c = 0; // grid, first cell, second cell (OpenCV's numbering)
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < (i + 2) * (i + 2); j++)
+                    for (int k = j + 1; k < (i + 2) * (i + 2); k++, c++)
+                        full[c][0] = i, full[c][1] = j, full[c][2] = k;
+            const int base[3] = {0, 4, 13}, channel_of[3] = {0, 2, 1};
+            auto cell_of = [&](int grid, int j) { return base[grid] + (j % (grid + 2)) * (grid + 2) + j / (grid + 2); };
+            uint64_t state = 1024;
+            for (int i = 0; i < 162; i++)
+            {
+                state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32);
+                int k = (int)((uint32_t)state % (uint32_t)(162 - i));
+                if (i < 6)
+                    k = i;
+                for (int ch = 0; ch < 3; ch++)
+                    T.bit_ofs[3 * i + ch] = (unsigned int)((cell_of(full[k][0], full[k][1]) * 3 + channel_of[ch]) * 4) |
+                                            ((unsigned int)((cell_of(full[k][0], full[k][2]) * 3 + channel_of[ch]) * 4) << 16);
+                for (int q = 0; q < 3; q++)
+                    full[k][q] = full[162 - i - 1][q];
+            }
         }
         // the cell chains: lane 3 c + channel sums channel `channel` of chain c - the four 10 x 10 cells, the 7 x 7 cells in
         // pairs (the ninth alone), the 5 x 5 cells in fours.  Word: lattice point of the first sample | channel << 9 |

@@ -14,9 +14,15 @@
 //     slice the later sample comes first), a window of 7 slices slid over the 42 starts, the last six wrapping; every window
 //     summed in sorted order from zero, the first window with the largest norm wins.  (3.x, rounds 2 - 5: per-sample rounding
 //     cvRound(xf + i * s), 42 windows stepped by 0.15f rad with strict comparisons, sums in sample order.)
-//   * MLDB_Fill_Values: a cell's sums are multiplied by nsamples_inv = 1.0f / nsamples (3.x divided by the count); samples
-//     outside the image are skipped and a cell without a sample keeps its zeros.
-// A reference built against 3.x would differ in exactly these places.
+//   * the descriptor: the reference passes descriptor_size = 486 (extract_features.cpp:35), and AKAZEFeatures takes the FULL
+//     path (MLDB_Full_Descriptor_Invoker: cell means, bits per grid, channel and cell pair) only for descriptor_size == 0; any
+//     other size - the full length included - goes through MLDB_Descriptor_Subset_Invoker with the tables of
+//     generateDescriptorSubsample: the 162 cell pairs in the order cv::RNG(1024) draws them (mldb_subset_tables), three
+//     channel bits per pair, cell SUMS compared (no means), channels (Lt, rx co + ry si, -rx si + ry co), samples at
+//     yf + ((l scale) co + (k scale) si).  Rounds 2 - 5 and the first half of round 6 restated the full path: the same 486
+//     comparisons in another bit order (Hamming distances between two descriptors of one extractor do not see the order; a
+//     descriptor stored by the reference and one from here would).
+// A reference built against 3.x would differ in the first two places and in the orientation's details.
 //
 //  D1  scale-space suppression            (removed in round 6) this file: suppress_masks_4x, called by detect_and_describe, step 2
 //      now:    OpenCV 4.x's three passes, in their order.  (1) Per level in raster order, a 3 x 3 maximum looks for the FIRST
@@ -1009,6 +1015,77 @@ void suppression_census(const ScaleSpace &ss, const Options &o, uint64_t counts[
     }
 }
 
+// generateDescriptorSubsample (AKAZEFeatures.cpp) for nbits = 486, pattern_size = 10, 3 channels, with cv::RNG(1024) restated
+// (core/operations.hpp: state = (uint64)(unsigned)state * 4164903690U + (unsigned)(state >> 32), the draw is the low word; rng(N) =
+// next() % N).  fullM lists the 162 cell pairs (grid i, cell j < cell k; cell j covers [psz (j % g) - 10, +psz) in k and
+// [psz (j / g) - 10, +psz) in l); every pick takes one of the rows not yet taken (the first six picks are forced to rows 0 .. 5,
+// after the draw), enters its two cells in the sample list if they are new, and the row picked is overwritten by the last live
+// one.  comps[3 i + c] = {3 first + c, 3 second + c}: indices into the values, three channels per cell.
+struct mldb_subset
+{
+    int n_samples = 0;
+    int samples[29][3];
+    int comps[486][2];
+};
+static const mldb_subset &mldb_subset_tables()
+{
+    static const mldb_subset T = []() {
+        mldb_subset t;
+        const int P = 10, nch = 3, nbits = 486;
+        int full[162][5], c = 0;
+        for (int i = 0; i < 3; i++)
+        {
+            const int g = i + 2, gsz = g * g, psz = (2 * P + g - 1) / g;
+            for (int j = 0; j < gsz; j++)
+                for (int k = j + 1; k < gsz; k++, c++)
+                {
+                    full[c][0] = i;
+                    full[c][1] = psz * (j % g) - P;
+                    full[c][2] = psz * (j / g) - P;
+                    full[c][3] = psz * (k % g) - P;
+                    full[c][4] = psz * (k / g) - P;
+                }
+        }
+        uint64_t state = 1024;
+        auto next = [&]() {
+            state = (uint64_t)(uint32_t)state * 4164903690u + (uint32_t)(state >> 32);
+            return (uint32_t)state;
+        };
+        const int npicks = (nbits + nch - 1) / nch;
+        int count = 0;
+        for (int i = 0; i < npicks; i++)
+        {
+            int k = (int)(next() % (uint32_t)(162 - i));
+            if (i < 6)
+                k = i; // "Force use of the coarser grid values and comparisons"
+            for (int side = 0; side < 2; side++)
+            {
+                const int c0 = full[k][0], c1 = full[k][side ? 3 : 1], c2 = full[k][side ? 4 : 2];
+                int at = -1;
+                for (int j = 0; j < count && at < 0; j++)
+                    if (t.samples[j][0] == c0 && t.samples[j][1] == c1 && t.samples[j][2] == c2)
+                        at = j;
+                if (at < 0)
+                {
+                    if (count >= 29)
+                        std::abort(); // (4 + 9 + 16 cells: cannot happen)
+                    at = count++;
+                    t.samples[at][0] = c0;
+                    t.samples[at][1] = c1;
+                    t.samples[at][2] = c2;
+                }
+                for (int ch = 0; ch < nch; ch++)
+                    t.comps[i * nch + ch][side] = nch * at + ch;
+            }
+            for (int q = 0; q < 5; q++)
+                full[k][q] = full[162 - i - 1][q];
+        }
+        t.n_samples = count;
+        return t;
+    }();
+    return T;
+}
+
 std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o)
 {
     // 1. per-level 3x3 maxima above the threshold
@@ -1115,60 +1192,41 @@ std::vector<Keypoint> detect_and_describe(const ScaleSpace &ss, const Options &o
         float angle = cv_fast_atan2_deg(maxY, maxX); // KeyPoint::angle is in degrees
         angle = angle * DEG2RAD_F; // what the descriptor rotates by (and what this interface reports: radians)
         kp.angle = angle;
-        // M-LDB, 3 channels, grids 2x2 / 3x3 / 4x4 over [-10, 10) * scale, rotated by the orientation
+        // M-LDB, 3 channels, grids 2x2 / 3x3 / 4x4 over [-10, 10) * scale, rotated by the orientation.  The reference asks for
+        // descriptor_size = 486 (extract_features.cpp:35), and any descriptor_size other than 0 takes OpenCV's SUBSET path
+        // (AKAZEFeatures.cpp: MLDB_Descriptor_Subset_Invoker with generateDescriptorSubsample's tables - header "STRUCTURE"):
+        // a cell's value is the SUM over its samples (no mean), the channels are Lt, rx co + ry si, -rx si + ry co, a sample sits
+        // at yf + ((l scale) co + (k scale) si), xf + ((-l scale) si + (k scale) co), and bit 3 i + c is comparison picks[i] in
+        // channel c - all 162 comparisons, in the order cv::RNG(1024) draws them
         float si, co;
         libm_sincosf(angle, &si, &co);
         std::memset(kp.desc, 0, sizeof kp.desc);
-        int dpos = 0;
-        const int P = o.descriptor_pattern_size;
-        const float fs = (float)s;
-        for (int lvl = 0; lvl < 3; lvl++)
+        const mldb_subset &T = mldb_subset_tables();
+        float values[29 * 3];
+        for (int i = 0; i < T.n_samples; i++)
         {
-            const int g = lvl + 2, nval = g * g;
-            const int step = (int)std::ceil((float)(P * 2) / (float)g);
-            float vals[16][3];
-            int cell = 0;
-            for (int i = -P; i < P; i += step)
-                for (int j = -P; j < P; j += step)
+            const int step = T.samples[i][0] == 0 ? 10 : (T.samples[i][0] == 1 ? 7 : 5);
+            float di = 0.0f, dx = 0.0f, dy = 0.0f;
+            for (int k = T.samples[i][1]; k < T.samples[i][1] + step; k++)
+                for (int l = T.samples[i][2]; l < T.samples[i][2] + step; l++)
                 {
-                    float di = 0.0f, ddx = 0.0f, ddy = 0.0f;
-                    int ns = 0;
-                    for (int a = i; a < i + step; a++)
-                        for (int b = j; b < j + step; b++)
-                        {
-                            const float sy = yf + ((float)b * co * fs + (float)a * si * fs);
-                            const float sx = xf + (-(float)b * si * fs + (float)a * co * fs);
-                            const int y1 = (int)std::lrintf(sy), x1 = (int)std::lrintf(sx);
-                            if (x1 < 0 || y1 < 0 || x1 >= w || y1 >= h)
-                                continue;
-                            const float ri = Lt[(size_t)y1 * w + x1], rx = Lx[(size_t)y1 * w + x1], ry = Ly[(size_t)y1 * w + x1];
-                            di = di + ri;
-                            const float rry = rx * co + ry * si, rrx = -rx * si + ry * co;
-                            ddx = ddx + rrx;
-                            ddy = ddy + rry;
-                            ns++;
-                        }
-                    if (ns > 0) // (MLDB_Fill_Values, OpenCV 4.x: the sums times nsamples_inv, not divided by the count)
-                    {
-                        const float ninv = 1.0f / (float)ns;
-                        di = di * ninv;
-                        ddx = ddx * ninv;
-                        ddy = ddy * ninv;
-                    }
-                    vals[cell][0] = di;
-                    vals[cell][1] = ddx;
-                    vals[cell][2] = ddy;
-                    cell++;
+                    const float sy = yf + ((float)(l * s) * co + (float)(k * s) * si);
+                    const float sx = xf + ((float)(-l * s) * si + (float)(k * s) * co);
+                    const int y1 = (int)std::lrintf(sy), x1 = (int)std::lrintf(sx);
+                    if (x1 < 0 || y1 < 0 || x1 >= w || y1 >= h)
+                        continue;
+                    const float rx = Lx[(size_t)y1 * w + x1], ry = Ly[(size_t)y1 * w + x1];
+                    di = di + Lt[(size_t)y1 * w + x1];
+                    dx = dx + (rx * co + ry * si);
+                    dy = dy + (-rx * si + ry * co);
                 }
-            for (int ch = 0; ch < 3; ch++)
-                for (int a = 0; a < nval; a++)
-                    for (int b = a + 1; b < nval; b++)
-                    {
-                        if (vals[a][ch] > vals[b][ch])
-                            kp.desc[dpos >> 6] |= (uint64_t)1 << (dpos & 63);
-                        dpos++;
-                    }
+            values[3 * i] = di;
+            values[3 * i + 1] = dx;
+            values[3 * i + 2] = dy;
         }
+        for (int i = 0; i < 486; i++)
+            if (values[T.comps[i][0]] > values[T.comps[i][1]])
+                kp.desc[i >> 6] |= (uint64_t)1 << (i & 63);
         out.push_back(kp);
     }
     return out;
