@@ -3256,7 +3256,7 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         {
             const float rfactor = 1.0f / (float)(1 << i);
             const int lw = (int)(W * rfactor), lh = (int)(H * rfactor);
-            if ((lw < 80 || lh < 80) && i != 0)
+            if ((lw < 80 || lh < 40) && i != 0) // (Allocate_Memory_Evolution: "smallest possible octave" - 80 wide, 40 high)
                 break;
             for (int j = 0; j < nsub; j++)
             {

@@ -22,6 +22,8 @@
 //     yf + ((l scale) co + (k scale) si).  Rounds 2 - 5 and the first half of round 6 restated the full path: the same 486
 //     comparisons in another bit order (Hamming distances between two descriptors of one extractor do not see the order; a
 //     descriptor stored by the reference and one from here would).
+//   * the level table ends with the first octave below 80 pixels wide or 40 HIGH (Allocate_Memory_Evolution; rounds 2 - 5 had 80
+//     for both, one octave less for images of 160 - 319 rows after the resize to 1600).
 // A reference built against 3.x would differ in the first two places and in the orientation's details.
 //
 //  D1  scale-space suppression            (removed in round 6) this file: suppress_masks_4x, called by detect_and_describe, step 2
@@ -151,7 +153,7 @@ std::vector<Level> make_levels(int width, int height, const Options &o)
     {
         const float rfactor = 1.0f / (float)(1 << i);
         const int lw = (int)(width * rfactor), lh = (int)(height * rfactor);
-        if ((lw < 80 || lh < 80) && i != 0)
+        if ((lw < 80 || lh < 40) && i != 0) // (Allocate_Memory_Evolution: "smallest possible octave" - 80 wide, 40 high)
             break;
         for (int j = 0; j < o.nsublevels; j++)
         {

@@ -35,7 +35,7 @@ print("oracle keypoints", n, "kcontrast", kc[0], "device keypoints", len(got[0][
 off = 0
 for lvl in range(16):
     lw, lh = w >> (lvl // 4), h >> (lvl // 4)
-    if lvl // 4 and (lw < 80 or lh < 80):
+    if lvl // 4 and (lw < 80 or lh < 40):
         break
     out = np.zeros(lw * lh, np.float32)
     a, b = C.c_int(0), C.c_int(0)
