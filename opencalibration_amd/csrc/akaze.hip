@@ -660,22 +660,14 @@ __global__ void hist_kernel(const float *__restrict__ modg, int w, int h, size_t
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const float hmax = __uint_as_float(hmax_bits[blockIdx.z]);
     const int rows_per_block = HIST_ROWS;
+    // compute_kcontrast (OpenCV 4.x): every interior pixel, zeros included, goes to bin (int)(m * ((nbins - 1) / hmax))
+    const float to_bin = (float)(nbins - 1) / hmax;
     for (int r = 0; r < rows_per_block; r++)
     {
         const int y = blockIdx.y * rows_per_block + r;
-        const bool inside = !(x < 1 || x >= w - 1 || y < 1 || y >= h - 1);
-        const float m = inside ? modg[(size_t)blockIdx.z * stride + (size_t)y * w + x] : 0.0f;
-        const bool counted = m != 0.0f;
-        if (counted)
-        {
-            int nbin = (int)floorf((float)nbins * (m / hmax));
-            if (nbin == nbins)
-                nbin--;
-            atomicAdd(&lh[nbin], 1u);
-        }
-        const unsigned long long mask = __ballot(counted);
-        if ((threadIdx.x & 63) == 0 && mask)
-            atomicAdd(&lh[nbins], (unsigned int)__popcll(mask)); // npoints
+        const bool inside = !(x < 1 || x >= w - 1 || y < 1 || y >= h - 1) && hmax != 0.0f;
+        if (inside)
+            atomicAdd(&lh[(int)(modg[(size_t)blockIdx.z * stride + (size_t)y * w + x] * to_bin)], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= nbins; i += blockDim.x)
@@ -684,18 +676,30 @@ __global__ void hist_kernel(const float *__restrict__ modg, int w, int h, size_t
 }
 
 __global__ void kcontrast_kernel(const unsigned int *__restrict__ hist, const unsigned int *__restrict__ hmax_bits,
-                                 int nbins, float perc, float *__restrict__ kcontrast, int n_images)
+                                 int nbins, float perc, float *__restrict__ kcontrast, int n_images, int total)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_images)
         return;
+    // bin 0 is the background; the contrast is hmax * k / nbins at the first k >= 1 whose lower bins 1 .. k - 1 hold the percentile
     const unsigned int *hh = hist + (size_t)b * (nbins + 1);
-    const int npoints = (int)hh[nbins];
-    const int nthreshold = (int)((float)npoints * perc);
-    int nelements = 0, k = 0;
-    for (k = 0; nelements < nthreshold && k < nbins; k++)
-        nelements += (int)hh[k];
-    kcontrast[b] = nelements < nthreshold ? 0.03f : __uint_as_float(hmax_bits[b]) * ((float)k / (float)nbins);
+    const float hmax = __uint_as_float(hmax_bits[b]);
+    float kc = 0.03f;
+    if (hmax != 0.0f)
+    {
+        const int nthreshold = (int)((float)(total - (int)hh[0]) * perc);
+        int nelements = 0;
+        for (int k = 1; k < nbins; k++)
+        {
+            if (nelements >= nthreshold)
+            {
+                kc = hmax * (float)k / (float)nbins;
+                break;
+            }
+            nelements += (int)hh[k];
+        }
+    }
+    kcontrast[b] = kc;
 }
 
 // ---- diffusion (the PM-G2 conductivity is BLUR_FLOW above)
@@ -3522,7 +3526,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     }
     hipLaunchKernelGGL(hist_kernel, dim3((W + 255) / 256, (H + HIST_ROWS - 1) / HIST_ROWS, B), dim3(256), 0, st, (const float *)d_flow, W, H,
                        plane0, d_hmax, 300, d_hist);
-    hipLaunchKernelGGL(kcontrast_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_hist, d_hmax, 300, 0.7f, d_kc, (int)B);
+    hipLaunchKernelGGL(kcontrast_kernel, dim3((B + 63) / 64), dim3(64), 0, st, d_hist, d_hmax, 300, 0.7f, d_kc, (int)B,
+                       (int)((W - 2) * (H - 2))); // (the interior pixels)
 
     // ---- nonlinear scale space
     // level 0: the base image (Gaussian(soffset) of the resized view) and - its Lsmooth being its Lt - the detector's scale-s

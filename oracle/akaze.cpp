@@ -320,29 +320,27 @@ float compute_k_percentile(const std::vector<float> &img, int w, int h, const Op
             if (m > hmax)
                 hmax = m;
         }
+    // OpenCV 4.x's compute_kcontrast (rounds 2 - 5 had 3.x's compute_k_percentile: nbins * (m / hmax) floored, zeros left out,
+    // bins counted from 0, hmax * (k / nbins)): every interior pixel goes to bin (int)(m * ((nbins - 1) / hmax)), bin 0 is the
+    // background, and the contrast is hmax * k / nbins at the first k >= 1 whose lower bins 1 .. k - 1 hold the percentile
+    if (hmax == 0.0f)
+        return 0.03f; // (a blank image)
     const int nbins = o.kcontrast_nbins;
     std::vector<int> hist(nbins, 0);
-    int npoints = 0;
+    const float to_bin = (float)(nbins - 1) / hmax;
     for (int y = 1; y < h - 1; y++)
         for (int x = 1; x < w - 1; x++)
-        {
-            const float m = modg[(size_t)y * w + x];
-            if (m != 0.0f)
-            {
-                int nbin = (int)std::floor((float)nbins * (m / hmax));
-                if (nbin == nbins)
-                    nbin--;
-                hist[nbin]++;
-                npoints++;
-            }
-        }
-    const int nthreshold = (int)((float)npoints * o.kcontrast_percentile);
-    int nelements = 0, k = 0;
-    for (k = 0; nelements < nthreshold && k < nbins; k++)
-        nelements += hist[k];
-    if (nelements < nthreshold)
-        return 0.03f;
-    return hmax * ((float)k / (float)nbins);
+            hist[(int)(modg[(size_t)y * w + x] * to_bin)]++;
+    const int total = (w - 2) * (h - 2);
+    const int nthreshold = (int)((float)(total - hist[0]) * o.kcontrast_percentile);
+    int nelements = 0;
+    for (int k = 1; k < nbins; k++)
+    {
+        if (nelements >= nthreshold)
+            return hmax * (float)k / (float)nbins;
+        nelements = nelements + hist[k];
+    }
+    return 0.03f;
 }
 
 static void pm_g2_flow(const std::vector<float> &sm, std::vector<float> &flow, int w, int h, float k)
