@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void nld_fused_kernel(const float *__restrict_
             if (r + 1 < RH)
                 ypos = (gy + 1 < h) ? cy[r] * (Lr[r + 1] - Lc) : 0.0f;
             const float yneg = gy > 0 ? flux_above : 0.0f;
-            Lr[r] = Lc + half * ((xpos - xneg) + (ypos - yneg));
+            Lr[r] = Lc + half * (((xpos - xneg) + ypos) - yneg); // (xpos - xneg + ypos - yneg, as the C expression associates)
             flux_above = ypos;
         }
     }
@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(256) void level_strip_kernel(level_strip_args A)
                 const pk2 ypos = (!EDGE || yq + 1 < h) ? CY[s_y] * (Ln - Lc) : zero;
                 const pk2 yneg = (!EDGE || yq > 0) ? Fsave[q] : zero;
                 const float half = 0.5f * A.T.tau[q - 1];
-                const pk2 Lq = Lc + pk2{half, half} * ((xpos - xneg) + (ypos - yneg));
+                const pk2 Lq = Lc + pk2{half, half} * (((xpos - xneg) + ypos) - yneg); // (xpos - xneg + ypos - yneg, left to right)
                 Fsave[q] = ypos;
                 if (q > 1)
                     Lsave[q - 1] = Ln;

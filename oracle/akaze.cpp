@@ -368,7 +368,7 @@ static void nld_step(const std::vector<float> &L, const std::vector<float> &c, s
             const float xneg = x > 0 ? (c[i - 1] + c[i]) * (L[i] - L[i - 1]) : 0.0f;
             const float ypos = y + 1 < h ? (c[i] + c[i + w]) * (L[i + w] - L[i]) : 0.0f;
             const float yneg = y > 0 ? (c[i - w] + c[i]) * (L[i] - L[i - w]) : 0.0f;
-            out[i] = L[i] + half * ((xpos - xneg) + (ypos - yneg));
+            out[i] = L[i] + half * (((xpos - xneg) + ypos) - yneg); // (NonLinearScalarDiffusionStep writes xpos - xneg + ypos - yneg)
         }
 }
 
