@@ -819,6 +819,57 @@ __global__ void halfsample_kernel(const float *__restrict__ in, int w, int h, si
         ((I[(size_t)y0 * w + x0] + I[(size_t)y0 * w + x1]) + (I[(size_t)y1 * w + x0] + I[(size_t)y1 * w + x1])) * 0.25f;
 }
 
+// The next octave's first image when a dimension of the octave before is odd (1067 -> 533 rows of a 3:2 image): cv::resize
+// INTER_AREA no longer sees an integer scale and runs its general area path on BOTH axes - computeResizeAreaTab's overlap weights
+// (the ones resize_area_kernel uses for the 8-bit image), per source row buf += S * alpha in table order, then sum = beta * buf
+// for the first source row of a destination row and sum += beta * buf for the others.  One thread per destination pixel; the
+// table entries of its column and row (at most four each at a scale of two) are recomputed in double as the table builder does.
+struct area_taps
+{
+    int first, n; // source indices first .. first + n - 1
+    float a[4];
+};
+__device__ __forceinline__ area_taps area_taps_of(int d, int ssize, int dsize)
+{
+    const double scale = (double)ssize / dsize;
+    const double f1 = d * scale, f2 = f1 + scale, cell = fmin(scale, ssize - f1);
+    int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+    s2 = min(s2, ssize - 1);
+    s1 = min(s1, s2);
+    area_taps t;
+    t.n = 0;
+    t.first = s1;
+    if (s1 - f1 > 1e-3)
+    {
+        t.first = s1 - 1;
+        t.a[t.n++] = (float)((s1 - f1) / cell);
+    }
+    for (int sx = s1; sx < s2 && t.n < 4; sx++)
+        t.a[t.n++] = (float)(1.0 / cell);
+    if (f2 - s2 > 1e-3 && t.n < 4)
+        t.a[t.n++] = (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell);
+    return t;
+}
+__global__ void halfsample_area_kernel(const float *__restrict__ in, int w, int h, size_t in_stride, float *__restrict__ out,
+                                       int ow, int oh, size_t out_stride)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow)
+        return;
+    const float *I = in + (size_t)blockIdx.z * in_stride;
+    const area_taps tx = area_taps_of(x, w, ow), ty = area_taps_of(y, h, oh);
+    float sum = 0.0f;
+    for (int e = 0; e < ty.n; e++)
+    {
+        const float *S = I + (size_t)(ty.first + e) * w + tx.first;
+        float buf = 0.0f;
+        for (int k = 0; k < tx.n; k++)
+            buf = buf + S[k] * tx.a[k];
+        sum = e == 0 ? ty.a[e] * buf : sum + ty.a[e] * buf;
+    }
+    out[(size_t)blockIdx.z * out_stride + (size_t)y * ow + x] = sum;
+}
+
 __global__ void copy_plane_kernel(const float *__restrict__ in, size_t in_stride, float *__restrict__ out,
                                   size_t out_stride, size_t n)
 {
@@ -3622,7 +3673,10 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         {
             float *dst = (n_groups % 2 == 0) ? cur : d_ping;
             const size_t dst_stride = (n_groups % 2 == 0) ? img_stride : plane0;
-            if (half_sampled_level != i) // (else: the last level kernel of the octave before wrote it with its own rows)
+            if (p.w != 2 * l.w || p.h != 2 * l.h) // (an odd dimension: OpenCV's general area path, see halfsample_area_kernel)
+                hipLaunchKernelGGL(halfsample_area_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Lt + p.off), p.w, p.h,
+                                   img_stride, dst, l.w, l.h, dst_stride);
+            else if (half_sampled_level != i) // (else: the last level kernel of the octave before wrote it with its own rows)
                 hipLaunchKernelGGL(halfsample_kernel, grid2(l.w, l.h), dim3(256), 0, st, (const float *)(d_Lt + p.off), p.w, p.h,
                                    img_stride, dst, l.w, l.h, dst_stride);
             src = dst;

@@ -22,6 +22,12 @@
 //     yf + ((l scale) co + (k scale) si).  Rounds 2 - 5 and the first half of round 6 restated the full path: the same 486
 //     comparisons in another bit order (Hamming distances between two descriptors of one extractor do not see the order; a
 //     descriptor stored by the reference and one from here would).
+//   * the contrast factor: compute_kcontrast - every interior pixel's gradient magnitude goes to bin (int)(m * ((nbins - 1) /
+//     hmax)), bin 0 is the background, k = hmax * bin / nbins at the first bin >= 1 whose lower bins hold the percentile (3.x's
+//     compute_k_percentile: floor(nbins * (m / hmax)), zeros left out, counted from bin 0);
+//   * the diffusion step sums its fluxes as the C expression xpos - xneg + ypos - yneg associates (left to right);
+//   * a new octave's first image is cv::resize(.., INTER_AREA): the 2 x 2 mean only when BOTH dimensions halve exactly, the general
+//     area path (overlap weights on both axes) as soon as one is odd - 1067 -> 533 rows of a 3:2 image (halfsample);
 //   * the level table ends with the first octave below 80 pixels wide or 40 HIGH (Allocate_Memory_Evolution; rounds 2 - 5 had 80
 //     for both, one octave less for images of 160 - 319 rows after the resize to 1600).
 // A reference built against 3.x would differ in the first two places and in the orientation's details.
@@ -59,6 +65,10 @@
 //      OpenCV: its loops are vectorised (universal intrinsics) where the build allows; sums of the Gaussian taps, the
 //              diffusion step's four fluxes and the descriptor's cell means may associate differently.  Not a semantic
 //              departure, but a reason why bit-identity with a given OpenCV build cannot be expected even without D1 - D3.
+//  D5  integer down-scaling of the 8-bit image   this file: resize_area (the general area path only)
+//      OpenCV: cv::resize(INTER_AREA) with an exactly integer scale (a 3200- or 6400-pixel side -> 1600) takes ResizeAreaFast,
+//              whose vector body rounds (sum + 2) >> 2 and whose scalar tail rounds sum * 0.25f to even - the split between the
+//              two depends on the build's vector width.  Not restated; every other source size goes the general path as here.
 // Everything else (level table, FED step sizes and their reordering, k-contrast percentile, Scharr kernels and their
 // normalisation, determinant scaling, the extremum test and its border margin, M-LDB grid and bit order) follows OpenCV's
 // structure as recalled; the property tests (tests/test_oracle_akaze_properties.py) hold the restatement to what the
@@ -372,18 +382,43 @@ static void nld_step(const std::vector<float> &L, const std::vector<float> &c, s
         }
 }
 
+// The next octave's first image: cv::resize(Lt, size / 2, INTER_AREA) on a float plane.  With both dimensions exactly halved
+// OpenCV takes its integer-scale path (ResizeAreaFast: the 2 x 2 mean, ((a + b) + (c + d)) * 0.25f in its vector body); as soon as
+// one dimension is odd - 1067 -> 533 rows of a 3:2 image, 333 -> 166 - neither scale is an integer to it and the GENERAL
+// area path runs on both axes: computeResizeAreaTab's overlap weights (area_table above, the same as for the 8-bit resize), per
+// source row buf[dx] += S[sx] * alpha in table order, then sum = beta * buf for a destination row's first source row and
+// sum += beta * buf for the others.  (Rounds 2 - 5 clamped the 2 x 2 mean at the odd edge instead.)
 static void halfsample(const std::vector<float> &in, int w, int h, std::vector<float> &out, int ow, int oh)
 {
     out.resize((size_t)ow * oh);
-    for (int y = 0; y < oh; y++)
-        for (int x = 0; x < ow; x++)
-        {
-            const int x0 = std::min(2 * x, w - 1), x1 = std::min(2 * x + 1, w - 1);
-            const int y0 = std::min(2 * y, h - 1), y1 = std::min(2 * y + 1, h - 1);
-            out[(size_t)y * ow + x] = ((in[(size_t)y0 * w + x0] + in[(size_t)y0 * w + x1]) +
-                                       (in[(size_t)y1 * w + x0] + in[(size_t)y1 * w + x1])) *
-                                      0.25f;
-        }
+    if (w == 2 * ow && h == 2 * oh)
+    {
+        for (int y = 0; y < oh; y++)
+            for (int x = 0; x < ow; x++)
+                out[(size_t)y * ow + x] = ((in[(size_t)(2 * y) * w + 2 * x] + in[(size_t)(2 * y) * w + 2 * x + 1]) +
+                                           (in[(size_t)(2 * y + 1) * w + 2 * x] + in[(size_t)(2 * y + 1) * w + 2 * x + 1])) *
+                                          0.25f;
+        return;
+    }
+    const area_tab tx = area_table(w, ow), ty = area_table(h, oh);
+    std::vector<float> buf(ow);
+    int prev_dy = -1;
+    for (size_t e = 0; e < ty.si.size(); e++)
+    {
+        std::fill(buf.begin(), buf.end(), 0.0f);
+        const float *S = in.data() + (size_t)ty.si[e] * w;
+        for (size_t k = 0; k < tx.si.size(); k++)
+            buf[tx.di[k]] = buf[tx.di[k]] + S[tx.si[k]] * tx.alpha[k];
+        float *sum = out.data() + (size_t)ty.di[e] * ow;
+        const float beta = ty.alpha[e];
+        if (ty.di[e] != prev_dy)
+            for (int x = 0; x < ow; x++)
+                sum[x] = beta * buf[x];
+        else
+            for (int x = 0; x < ow; x++)
+                sum[x] = sum[x] + beta * buf[x];
+        prev_dy = ty.di[e];
+    }
 }
 
 // first derivatives at integer scale s: Scharr-like 3-tap kernels spread to distance s, reflect101

@@ -22,7 +22,7 @@ def _sorted(kp, desc):
     return kp[order], desc[order]
 
 
-@pytest.mark.parametrize("w,h", [(320, 240), (640, 480), (500, 333), (502, 331), (640, 200)])   # 502: rows not 16-byte aligned; 640 x 200: an octave of 160 x 50 (octaves end below 80 wide or 40 high)
+@pytest.mark.parametrize("w,h", [(320, 240), (640, 480), (500, 333), (502, 331), (640, 200), (501, 334)])   # 502: rows not 16-byte aligned; 640 x 200: an octave of 160 x 50 (octaves end below 80 wide or 40 high); odd widths / heights: the general INTER_AREA path between octaves
 def test_akaze_matches_restatement_bitwise(ctx, oracle, w, h):
     imgs = np.stack([synth.render_blobs(w, h, seed) for seed in (1, 2, 3)])
     got, (ww, wh) = ctx.akaze_batch(imgs, max_kp=20000)

@@ -219,6 +219,7 @@ def test_suppression_in_rounds_is_the_sequential_suppression():
     L = pyoracle.lib()
     L.oc_akaze_suppression_census.argtypes = [np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS"), C.c_int, C.c_int,
                                               np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
+    deepest = 0
     for seed, (w, h) in ((3, (640, 480)), (4, (800, 600)), (5, (333, 517)), (6, (1200, 900))):
         img = synth.render_blobs(w, h, seed=seed, channels=1)
         rng = np.random.default_rng(seed)
@@ -228,4 +229,5 @@ def test_suppression_in_rounds_is_the_sequential_suppression():
         candidates, survivors_4x = int(c[0]), int(c[3])
         assert candidates > 500 and 0 < survivors_4x < candidates
         assert int(c[7]) == 0, f"{int(c[7])} candidates decided differently in rounds ({w} x {h})"
-        assert all(int(r) >= 3 for r in c[8:11])  # (chains of dependent maxima: the rounds are exercised)
+        deepest = max(deepest, *(int(r) for r in c[8:11]))
+    assert deepest >= 5  # (chains of dependent maxima: the rounds are exercised)
