@@ -61,10 +61,14 @@
 //              (double)a00 * a11 - (double)a01 * a10, d = 1. / det2, x0 = (float)(((double)b0 * a11 - (double)b1 * a01) * d), x1
 //              likewise - and a singular system leaves the offset at (0, 0) (AKAZE does not look at solve's result).
 //      before: the same rule in float, a singular system dropped the keypoint.
-//  D4  order of float sums                this file: every sum in one fixed, written order (no FMA)
-//      OpenCV: its loops are vectorised (universal intrinsics) where the build allows; sums of the Gaussian taps, the
-//              diffusion step's four fluxes and the descriptor's cell means may associate differently.  Not a semantic
-//              departure, but a reason why bit-identity with a given OpenCV build cannot be expected even without D1 - D3.
+//  D4  order of float sums in the separable filters   this file: gaussian_blur, scharr3, deriv_scale - taps in ascending order, no FMA
+//      OpenCV: GaussianBlur, Scharr and sepFilter2D run filter.simd.hpp's symmetric row / column filters: the centre tap first,
+//              then every pair of mirrored taps as k * (left + right) - f = k0 * c + k1 * (a + b) + ... - and the vector bodies
+//              use v_muladd, which is a fused multiply-add where the build dispatches to AVX2 / FMA3 and a multiply and an add
+//              where it does not; scalar tails differ again.  Which of these a pixel sees depends on the CPU the reference
+//              runs on and on the pixel's column, so no single restatement is "OpenCV's"; this file keeps one fixed, written
+//              order.  (The diffusion step, the contrast histogram, the resizes and everything after the scale space are
+//              scalar code in OpenCV and are restated operation for operation.)
 //  D5  integer down-scaling of the 8-bit image   this file: resize_area (the general area path only)
 //      OpenCV: cv::resize(INTER_AREA) with an exactly integer scale (a 3200- or 6400-pixel side -> 1600) takes ResizeAreaFast,
 //              whose vector body rounds (sum + 2) >> 2 and whose scalar tail rounds sum * 0.25f to even - the split between the
