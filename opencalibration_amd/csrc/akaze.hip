@@ -1829,20 +1829,23 @@ __device__ __forceinline__ bool xcd_contiguous(unsigned int block, unsigned int 
 // upwards: a set keypoint clears the first set keypoint of the level BELOW within sigma_size * octave step of its projection
 // if it is stronger.  Pass 3, levels downwards: the same against the level ABOVE (radius: that level's sigma_size).  The
 // outcome depends on the order of the turns, so the order is reproduced - in rounds instead of in sequence (DESIGN.md section
-// 4.1 has the argument; the CPU restatement's suppress_masks_4x_in_rounds is this kernel's schedule and agrees with
+// 4.1 has the argument; the CPU restatement's suppress_masks_4x_in_rounds is this schedule and agrees with
 // the sequential form on every candidate of the census images):
 //   * pass 1: a maximum takes its turn once every maximum in front of it in raster order within 2 sigma_size - 1 (Chebyshev)
 //     has had its own: two maxima further apart read and write disjoint windows;
-//   * passes 2 and 3 clear keypoints of the OTHER level only and read their own level as the previous pass left it, so the
-//     levels of a pass do not depend on each other, and inside a level a keypoint waits for the keypoints in front of it whose
-//     windows in the other level can overlap its own (2 sigma_size - 1 / 2 sigma_size' * octave step - 1).
-// A launch per pass, a workgroup per (level, image) - the candidate list is level by level (tile_seq), so a level's candidates
-// are one range of it.  A round = every point still waiting tests the `pending` mask of its box, a barrier, the ready ones take
-// their turns (atomics on the mask words), a barrier.  Nothing a workgroup reads is written by another one during a launch (pass 1
-// stays inside the level; in passes 2 and 3 a level's workgroup reads its own copy of the level's bits and is the only one to
-// clear bits of the level below / above), so workgroup-scope ordering - the barriers - is all it takes: an agent-scope fence per
-// round (L2 write-back + invalidate on this part) made the three launches 9 ms per 100 images.  Rounds are latency-bound, ~10 -
-// 15 per level in passes 1 and 2 and ~25 in pass 3 on a 1600 x 1200 image.
+//   * passes 2 and 3 clear keypoints of the OTHER level only, so the levels of a pass do not depend on each other; a keypoint
+//     whose window in the other level is empty when the pass starts has no turn at all (suppress_window_kernel), and inside a
+//     level a keypoint waits for the keypoints with a turn in front of it whose windows in the other level can overlap its own
+//     (2 sigma_size - 1 / 2 sigma_size' * octave step - 1).
+// Per pass: round 0 as one launch over all candidates (suppress_round0_kernel: whether a point can go at once is a question to
+// masks the launch does not write, so test and turn are one step), then a workgroup per (image, level) on the list round 0
+// left (suppress_rounds_kernel) - the candidate list is level by level (tile_seq), so a level's candidates are one range of it.
+// A round there = every point still waiting tests the `pending` mask of its box, a barrier, the ready ones take their turns
+// (atomics on the mask words), a barrier.  Nothing a workgroup reads is written by another one during a launch (pass 1 stays
+// inside the level; in passes 2 and 3 a level's workgroup is the only one to clear bits of the level below / above, and who
+// has a turn comes from `found`, not from the masks), so workgroup-scope ordering - the barriers - is all it takes: an
+// agent-scope fence per round (L2 write-back + invalidate on this part) made the three launches 9 ms per 100 images.  Rounds
+// are latency-bound (~8 us each): 2 - 14 per level on a 1600 x 1200 image.
 constexpr int SUP_THREADS = 256;
 constexpr int SUP_LDS = 2048; // list entries a workgroup keeps in LDS (two lists); a longer list continues in HBM
 constexpr unsigned int SUP_READY = 0x80000000u; // list entry: x | y << 16 | this flag
