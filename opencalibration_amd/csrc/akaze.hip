@@ -831,7 +831,7 @@ struct area_taps
 };
 __device__ __forceinline__ area_taps area_taps_of(int d, int ssize, int dsize)
 {
-    const double scale = (double)ssize / dsize;
+    const double scale = 1.0 / ((double)dsize / ssize); // (cv::resize given a size: scale_x = 1. / inv_scale_x, inv_scale_x = dsize / ssize)
     const double f1 = d * scale, f2 = f1 + scale, cell = fmin(scale, ssize - f1);
     int s1 = (int)ceil(f1), s2 = (int)floor(f2);
     s2 = min(s2, ssize - 1);
@@ -2938,10 +2938,12 @@ struct area_tab
     std::vector<int> off, si;
     std::vector<float> alpha;
 };
-area_tab area_table(int ssize, int dsize) // cv::resize INTER_AREA decimation table
+// cv::resize INTER_AREA decimation table (computeResizeAreaTab).  `scale` is cv::resize's own scale_x = 1. / inv_scale_x - with
+// inv_scale_x the fx it was called with (extract_features passes the FLOAT 1600 / max side as a double: 1 / 0.4000000059604645 is
+// not 2.5, and the taps' weights differ in their last bits) or dsize / ssize when it was given a size
+area_tab area_table(int ssize, int dsize, double scale)
 {
     area_tab t;
-    const double scale = (double)ssize / dsize;
     for (int dx = 0; dx < dsize; dx++)
     {
         t.off.push_back((int)t.si.size());
@@ -3484,8 +3486,8 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
     bool staged = false; // can every resize workgroup stage its source window in LDS? (taps per column, window size)
     if (resized)
     {
-        tx = area_table(width, W);
-        ty = area_table(height, H);
+        tx = area_table(width, W, 1.0 / scale);
+        ty = area_table(height, H, 1.0 / scale);
         staged = width % 4 == 0;
         for (int x0 = 0; x0 < W && staged; x0 += 256)
         {

@@ -28,6 +28,9 @@
 //   * the diffusion step sums its fluxes as the C expression xpos - xneg + ypos - yneg associates (left to right);
 //   * a new octave's first image is cv::resize(.., INTER_AREA): the 2 x 2 mean only when BOTH dimensions halve exactly, the general
 //     area path (overlap weights on both axes) as soon as one is odd - 1067 -> 533 rows of a 3:2 image (halfsample);
+//   * both resizes' overlap tables are built from cv::resize's own scale_x = 1. / inv_scale_x: for the 8-bit working image
+//     inv_scale_x is the fx extract_features passes - the FLOAT 1600 / max side as a double, 0.4000000059604645 for a 4000-pixel
+//     side, whose reciprocal is not 2.5: the same taps with weights that differ in their last bits;
 //   * the level table ends with the first octave below 80 pixels wide or 40 HIGH (Allocate_Memory_Evolution; rounds 2 - 5 had 80
 //     for both, one octave less for images of 160 - 319 rows after the resize to 1600).
 // A reference built against 3.x would differ in the first two places and in the orientation's details.
@@ -209,10 +212,12 @@ struct area_tab
     std::vector<int> si, di;
     std::vector<float> alpha;
 };
-static area_tab area_table(int ssize, int dsize)
+// computeResizeAreaTab.  `scale` is cv::resize's scale_x = 1. / inv_scale_x: inv_scale_x is the fx it was called with
+// (extract_features.cpp:26-27 passes the FLOAT 1600 / max side as a double - 1 / 0.4000000059604645 is not 2.5) or dsize / ssize
+// when it was given a size (the octaves' half-sampling).
+static area_tab area_table(int ssize, int dsize, double scale)
 {
     area_tab t;
-    const double scale = (double)ssize / dsize;
     for (int dx = 0; dx < dsize; dx++)
     {
         const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
@@ -241,14 +246,14 @@ static area_tab area_table(int ssize, int dsize)
     }
     return t;
 }
-void resize_area(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
+void resize_area(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, double inv_scale)
 {
     if (sw == dw && sh == dh)
     {
         std::memcpy(dst, src, (size_t)sw * sh);
         return;
     }
-    const area_tab tx = area_table(sw, dw), ty = area_table(sh, dh);
+    const area_tab tx = area_table(sw, dw, 1.0 / inv_scale), ty = area_table(sh, dh, 1.0 / inv_scale);
     std::vector<float> acc((size_t)dw * dh, 0.0f), row(dw);
     for (size_t e = 0; e < ty.si.size(); e++)
     {
@@ -404,7 +409,7 @@ static void halfsample(const std::vector<float> &in, int w, int h, std::vector<f
                                           0.25f;
         return;
     }
-    const area_tab tx = area_table(w, ow), ty = area_table(h, oh);
+    const area_tab tx = area_table(w, ow, 1.0 / ((double)ow / w)), ty = area_table(h, oh, 1.0 / ((double)oh / h));
     std::vector<float> buf(ow);
     int prev_dy = -1;
     for (size_t e = 0; e < ty.si.size(); e++)
@@ -1342,7 +1347,7 @@ Extracted extract_features(const uint8_t *bgr, int w, int h) // src/extract/extr
     const double scale = std::min(1.f, float(1600) / (float)std::max(w, h));
     const int sw = (int)std::lrint(w * scale), sh = (int)std::lrint(h * scale);
     std::vector<uint8_t> small((size_t)sw * sh);
-    resize_area(gray.data(), w, h, small.data(), sw, sh);
+    resize_area(gray.data(), w, h, small.data(), sw, sh, scale);
     std::vector<float> img((size_t)sw * sh);
     for (size_t i = 0; i < img.size(); i++)
         img[i] = (float)small[i] * (1.0f / 255.0f);
@@ -1453,7 +1458,9 @@ void oc_gray_resize(const uint8_t *bgr, int w, int h, uint8_t *out, int ow, int 
 {
     std::vector<uint8_t> gray((size_t)w * h);
     bgr_to_gray(bgr, w, h, gray.data());
-    resize_area(gray.data(), w, h, out, ow, oh);
+    // (the working image of extract_features: cv::resize is called with fx = fy = the float scale, ow x oh is what it derives)
+    const double scale = std::min(1.f, float(1600) / (float)std::max(w, h));
+    resize_area(gray.data(), w, h, out, ow, oh, scale);
 }
 
 } // extern "C"

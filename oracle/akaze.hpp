@@ -68,7 +68,7 @@ std::vector<float> orientation_weights();                        // 13 x 13 Gaus
 
 // building blocks (float images, row-major)
 void bgr_to_gray(const uint8_t *bgr, int w, int h, uint8_t *gray);
-void resize_area(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh);
+void resize_area(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, double inv_scale); // inv_scale: cv::resize's fx = fy
 float compute_k_percentile(const std::vector<float> &img, int w, int h, const Options &o);
 
 struct ScaleSpace
