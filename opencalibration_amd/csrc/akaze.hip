@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void resize_area_kernel(const uint8_t *__restr
                                                           int dw, int dh, const int *__restrict__ xoff,
                                                           const int *__restrict__ xsi, const float *__restrict__ xal,
                                                           const int *__restrict__ yoff, const int *__restrict__ ysi,
-                                                          const float *__restrict__ yal)
+                                                          const float *__restrict__ yal, int half_up_cols)
 {
     // a thread keeps the horizontal taps of its destination column in registers and walks RESIZE_ROWS rows; the
     // vertical taps are uniform per row.  Sums run in table order exactly like the per-pixel form.
@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void resize_area_kernel(const uint8_t *__restr
                     rr += (float)row[xsi[k]] * xal[k];
             acc += rr * yal[e];
         }
-        const float v = rintf(acc);
+        // (half_up_cols: a scale of exactly 2 is cv::resize's integer path, whose vector body rounds (a + b + c + d + 2) >> 2 - acc
+        // is exact there - and whose scalar tail, the last dw % 16 columns at most, rounds to even like the general path)
+        const float v = x < half_up_cols ? floorf(acc + 0.5f) : rintf(acc);
         // saturate to the 8-bit working image, then the 1/255 float conversion in front of AKAZE
         dst[(size_t)blockIdx.z * dw * dh + (size_t)y * dw + x] = (float)(uint8_t)fminf(255.0f, fmaxf(0.0f, v)) * (1.0f / 255.0f);
     }
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void resize_area_lds_kernel(const uint8_t *__r
                                                               int dw, int dh, const int *__restrict__ xoff,
                                                               const int *__restrict__ xsi, const float *__restrict__ xal,
                                                               const int *__restrict__ yoff, const int *__restrict__ ysi,
-                                                              const float *__restrict__ yal)
+                                                              const float *__restrict__ yal, int half_up_cols)
 {
     __shared__ unsigned int tile[RS_ROWS * RS_PITCH / 4];
     const int x0 = blockIdx.x * 256, y0 = blockIdx.y * RESIZE_ROWS;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void resize_area_lds_kernel(const uint8_t *__r
                     rr += (float)row[si[k]] * al[k];
             acc += rr * yal[e];
         }
-        const float v = rintf(acc);
+        const float v = x < half_up_cols ? floorf(acc + 0.5f) : rintf(acc); // (see resize_area_kernel)
         dst[(size_t)blockIdx.z * dw * dh + (size_t)y * dw + x] = (float)(uint8_t)fminf(255.0f, fmaxf(0.0f, v)) * (1.0f / 255.0f);
     }
 }
@@ -3539,18 +3541,22 @@ int akaze_run(ochip_ctx *ctx, const uint8_t *images_bgr, bool on_device, uint32_
         int most_taps = 0;
         for (int x = 0; x < W; x++)
             most_taps = std::max(most_taps, tx.off[x + 1] - tx.off[x]);
+        // a scale of exactly 2 (a 3200-pixel side): cv::resize's integer path - the vector body of ResizeAreaFast rounds
+        // (sum + 2) >> 2, sixteen columns at a time (the 16-bit lanes of an AVX2 build; the scalar tail rounds to even like
+        // the general path).  Scales of 4 and 8 give the same bytes either way (every operation is exact).
+        const int half_up_cols = scale == 0.5 ? W - W % 16 : 0;
         if (fused_grey && most_taps <= 4)
             hipLaunchKernelGGL((resize_area_lds_kernel<true, 4>), rgrid, dim3(256), 0, st, (const uint8_t *)d_bgr, width, height, d_img,
-                               W, H, xo, xs, xa, yo, ys, ya);
+                               W, H, xo, xs, xa, yo, ys, ya, half_up_cols);
         else if (fused_grey)
             hipLaunchKernelGGL((resize_area_lds_kernel<true, RESIZE_MAX_TAPS>), rgrid, dim3(256), 0, st, (const uint8_t *)d_bgr, width, height, d_img,
-                               W, H, xo, xs, xa, yo, ys, ya);
+                               W, H, xo, xs, xa, yo, ys, ya, half_up_cols);
         else if (staged)
             hipLaunchKernelGGL((resize_area_lds_kernel<false, RESIZE_MAX_TAPS>), rgrid, dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs,
-                               xa, yo, ys, ya);
+                               xa, yo, ys, ya, half_up_cols);
         else
             hipLaunchKernelGGL(resize_area_kernel, rgrid, dim3(256), 0, st, d_gray, width, height, d_img, W, H, xo, xs, xa, yo, ys,
-                               ya);
+                               ya, half_up_cols);
     }
 
     // ---- contrast factor: Gaussian(1) + gradient magnitude + per-tile maxima in one pass, then the histogram

@@ -72,10 +72,11 @@
 //              runs on and on the pixel's column, so no single restatement is "OpenCV's"; this file keeps one fixed, written
 //              order.  (The diffusion step, the contrast histogram, the resizes and everything after the scale space are
 //              scalar code in OpenCV and are restated operation for operation.)
-//  D5  integer down-scaling of the 8-bit image   this file: resize_area (the general area path only)
-//      OpenCV: cv::resize(INTER_AREA) with an exactly integer scale (a 3200- or 6400-pixel side -> 1600) takes ResizeAreaFast,
-//              whose vector body rounds (sum + 2) >> 2 and whose scalar tail rounds sum * 0.25f to even - the split between the
-//              two depends on the build's vector width.  Not restated; every other source size goes the general path as here.
+//  D5  down-scaling the 8-bit image by exactly 2   this file: resize_area (half_up_cols)
+//      OpenCV: cv::resize(INTER_AREA) with an exactly integer scale takes ResizeAreaFast.  For 4 and 8 its result equals the
+//              general path's (every operation exact); for 2 (a 3200-pixel side) its vector body rounds (sum + 2) >> 2 and its
+//              scalar tail rounds to even.  Restated for the AVX2 build's split - sixteen columns per vector step, the tail the
+//              last dw % 16 columns -; a build with 8-lane vectors would round up to eight more columns upwards.
 // Everything else (level table, FED step sizes and their reordering, k-contrast percentile, Scharr kernels and their
 // normalisation, determinant scaling, the extremum test and its border margin, M-LDB grid and bit order) follows OpenCV's
 // structure as recalled; the property tests (tests/test_oracle_akaze_properties.py) hold the restatement to what the
@@ -265,9 +266,12 @@ void resize_area(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int d
         for (int x = 0; x < dw; x++)
             a[x] += row[x] * ty.alpha[e];
     }
+    // a scale of exactly 2 is cv::resize's integer path (ResizeAreaFast): its vector body rounds (a + b + c + d + 2) >> 2 - acc is
+    // exact there -, sixteen columns at a time on an AVX2 build, and its scalar tail rounds to even like the general path (D5)
+    const int half_up_cols = inv_scale == 0.5 ? dw - dw % 16 : 0;
     for (size_t i = 0; i < acc.size(); i++)
     {
-        const long v = std::lrintf(acc[i]);
+        const long v = (int)(i % (size_t)dw) < half_up_cols ? (long)std::floor(acc[i] + 0.5f) : std::lrintf(acc[i]);
         dst[i] = (uint8_t)std::min(255L, std::max(0L, v));
     }
 }

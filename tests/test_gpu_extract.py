@@ -53,6 +53,28 @@ def test_grey_and_area_resize(ctx, oracle):
     assert np.array_equal(gdesc, edesc)
 
 
+@pytest.mark.parametrize("w,h", [(3200, 2400), (2392, 3200)])
+def test_a_scale_of_exactly_two(ctx, oracle, w, h):
+    """A 3200-pixel side makes the float scale exactly 0.5, and cv::resize(INTER_AREA) takes its integer path: the vector body
+    rounds (a + b + c + d + 2) >> 2 where the general path rounds to even (oracle/akaze.cpp, D5).  Noise makes sums of
+    4 n + 2 as common as any; 2392 x 3200 -> 1196 columns: the last 1196 % 16 = 12 are the scalar tail."""
+    rng = np.random.default_rng(w)
+    base = synth.render_blobs(w, h, 17)[:, :, :1].astype(np.int32)
+    img = np.clip(base + rng.integers(0, 4, (h, w, 1)), 0, 255).astype(np.uint8).repeat(3, axis=2)    # (every residue of the sums)
+    got, (ww, wh) = ctx.akaze_batch(img[None], max_kp=60000)
+    assert (ww, wh) == (w // 2, h // 2)
+    small = oracle.gray_resize(img, ww, wh)
+    g = img[:, :, 0].astype(np.int32)
+    quad = g[0::2, 0::2] + g[0::2, 1::2] + g[1::2, 0::2] + g[1::2, 1::2]
+    cols = ww - ww % 16
+    assert np.array_equal(small[:, :cols], ((quad + 2) >> 2)[:, :cols].astype(np.uint8))     # the oracle does what it says
+    assert np.count_nonzero(quad[:, :cols] % 4 == 2) > 1000                                   # ... where it matters
+    ekp, edesc = _sorted(*oracle.akaze(small))
+    gkp, gdesc = _sorted(*got[0])
+    assert len(gkp) == len(ekp)
+    assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32)) and np.array_equal(gdesc, edesc)
+
+
 def test_resize_fallback_for_unaligned_width(ctx, oracle):
     """A source width that is not a multiple of 4 cannot be staged by dword loads: the separate grey and per-tap resize
     kernels run instead and must give the same working image."""
