@@ -3173,11 +3173,19 @@ const gather_tab &host_gather_tab()
 {
     static const gather_tab G = []() {
         gather_tab T{};
-        std::vector<float> gw(169); // 13 x 13 Gaussian weights of the orientation samples (sigma 2.5), computed in double
+        // the orientation samples' weights: OpenCV's literal table gauss25 (Sample_Derivative_Response_Radius6; the Gaussian of
+        // sigma 2.5 printed to eight decimals with pi = 3.14159), weight = gauss25[|i|][|j|]
+        static const float gauss25[7][7] = {{0.02546481f, 0.02350698f, 0.01849125f, 0.01239505f, 0.00708017f, 0.00344629f, 0.00142946f},
+                                            {0.02350698f, 0.02169968f, 0.01706957f, 0.01144208f, 0.00653582f, 0.00318132f, 0.00131956f},
+                                            {0.01849125f, 0.01706957f, 0.01342740f, 0.00900066f, 0.00514126f, 0.00250252f, 0.00103800f},
+                                            {0.01239505f, 0.01144208f, 0.00900066f, 0.00603332f, 0.00344629f, 0.00167749f, 0.00069579f},
+                                            {0.00708017f, 0.00653582f, 0.00514126f, 0.00344629f, 0.00196855f, 0.00095820f, 0.00039744f},
+                                            {0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f},
+                                            {0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f}};
+        std::vector<float> gw(169);
         for (int i = -6; i <= 6; i++)
             for (int j = -6; j <= 6; j++)
-                gw[(i + 6) * 13 + (j + 6)] =
-                    (float)(std::exp(-(double)(i * i + j * j) / (2.0 * 2.5 * 2.5)) / (2.0 * M_PI * 2.5 * 2.5));
+                gw[(i + 6) * 13 + (j + 6)] = gauss25[std::abs(i)][std::abs(j)];
         // orientation samples: the restatement walks i (x) outer, j (y) inner; image order is j outer, i inner
         struct os
         {

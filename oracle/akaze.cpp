@@ -14,6 +14,8 @@
 //     slice the later sample comes first), a window of 7 slices slid over the 42 starts, the last six wrapping; every window
 //     summed in sorted order from zero, the first window with the largest norm wins.  (3.x, rounds 2 - 5: per-sample rounding
 //     cvRound(xf + i * s), 42 windows stepped by 0.15f rad with strict comparisons, sums in sample order.)
+//     The samples' weights are OpenCV's literal table gauss25 (orientation_weights: checkable - it is the Gaussian with pi =
+//     3.14159 printed to eight decimals - and 10 float steps away from the exact Gaussian rounds 2 - 5 computed);
 //   * the descriptor: the reference passes descriptor_size = 486 (extract_features.cpp:35), and AKAZEFeatures takes the FULL
 //     path (MLDB_Full_Descriptor_Invoker: cell means, bits per grid, channel and cell pair) only for descriptor_size == 0; any
 //     other size - the full length included - goes through MLDB_Descriptor_Subset_Invoker with the tables of
@@ -191,12 +193,22 @@ std::vector<Level> make_levels(int width, int height, const Options &o)
     return levels;
 }
 
+// Sample_Derivative_Response_Radius6's weights: OpenCV's literal table gauss25 (SURF's: the Gaussian of sigma 2.5 printed to eight
+// decimals with pi = 3.14159 - every entry 7.5e-7 above the exact value, which is how the recalled table can be checked: it
+// equals round(exp(-(i^2 + j^2) / 12.5) / (2 * 3.14159 * 6.25), 8) in all 49 places; scripts/check_gauss25.py), weight = [|i|][|j|]
 std::vector<float> orientation_weights()
 {
+    static const float gauss25[7][7] = {{0.02546481f, 0.02350698f, 0.01849125f, 0.01239505f, 0.00708017f, 0.00344629f, 0.00142946f},
+                                        {0.02350698f, 0.02169968f, 0.01706957f, 0.01144208f, 0.00653582f, 0.00318132f, 0.00131956f},
+                                        {0.01849125f, 0.01706957f, 0.01342740f, 0.00900066f, 0.00514126f, 0.00250252f, 0.00103800f},
+                                        {0.01239505f, 0.01144208f, 0.00900066f, 0.00603332f, 0.00344629f, 0.00167749f, 0.00069579f},
+                                        {0.00708017f, 0.00653582f, 0.00514126f, 0.00344629f, 0.00196855f, 0.00095820f, 0.00039744f},
+                                        {0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f},
+                                        {0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f}};
     std::vector<float> w(13 * 13);
     for (int i = -6; i <= 6; i++)
         for (int j = -6; j <= 6; j++)
-            w[(i + 6) * 13 + (j + 6)] = (float)(std::exp(-(double)(i * i + j * j) / (2.0 * 2.5 * 2.5)) / (2.0 * M_PI * 2.5 * 2.5));
+            w[(i + 6) * 13 + (j + 6)] = gauss25[std::abs(i)][std::abs(j)];
     return w;
 }
 

@@ -231,3 +231,12 @@ def test_suppression_in_rounds_is_the_sequential_suppression():
         assert int(c[7]) == 0, f"{int(c[7])} candidates decided differently in rounds ({w} x {h})"
         deepest = max(deepest, *(int(r) for r in c[8:11]))
     assert deepest >= 5  # (chains of dependent maxima: the rounds are exercised)
+
+
+def test_orientation_weights_are_opencvs_literal_table():
+    """Sample_Derivative_Response_Radius6 weighs its samples with a literal table (gauss25).  The recalled table can be checked
+    against its origin: the Gaussian of sigma 2.5 with pi = 3.14159 printed to eight decimals reproduces all 49 entries, in the
+    restatement and in the device code's host table alike (scripts/check_gauss25.py)."""
+    import os
+    import runpy
+    runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "check_gauss25.py"))
