@@ -72,8 +72,9 @@
 //              use v_muladd, which is a fused multiply-add where the build dispatches to AVX2 / FMA3 and a multiply and an add
 //              where it does not; scalar tails differ again.  Which of these a pixel sees depends on the CPU the reference
 //              runs on and on the pixel's column, so no single restatement is "OpenCV's"; this file keeps one fixed, written
-//              order.  (The diffusion step, the contrast histogram, the resizes and everything after the scale space are
-//              scalar code in OpenCV and are restated operation for operation.)
+//              order.  The same holds for hal::fastAtan32f's polynomial (v_fma in its vector body; restated without fusing, D2).
+//              (The diffusion step, the contrast histogram, the resizes and the rest of detection and description are scalar
+//              code in OpenCV and are restated operation for operation.)
 //  D5  down-scaling the 8-bit image by exactly 2   this file: resize_area (half_up_cols)
 //      OpenCV: cv::resize(INTER_AREA) with an exactly integer scale takes ResizeAreaFast.  For 4 and 8 its result equals the
 //              general path's (every operation exact); for 2 (a 3200-pixel side) its vector body rounds (sum + 2) >> 2 and its
