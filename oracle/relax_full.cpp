@@ -2482,3 +2482,63 @@ void ocx_union_find(size_t n, const uint64_t *pairs, size_t n_pairs, uint64_t *r
         roots[i] = uf.find(i);
 }
 }
+
+// ---- test exports: the geometry primitives and the plain cost functors, for the reference's own unit tests restated in
+// tests/test_reference_unit_tests.py (test/test_geometry.cpp, test_cost_functions.cpp, test_meshgraph.cpp)
+extern "C"
+{
+// rayIntersection (intersection.cpp:116-143): out4 = point (3), signed squared distance
+void ocx_ray_intersection(const double *d1, const double *o1, const double *d2, const double *o2, double *out4)
+{
+    const auto r = oracle::rx::rayIntersection(oracle::Vec3{d1[0], d1[1], d1[2]}, oracle::Vec3{o1[0], o1[1], o1[2]},
+                                               oracle::Vec3{d2[0], d2[1], d2[2]}, oracle::Vec3{o2[0], o2[1], o2[2]});
+    out4[0] = r.first.x, out4[1] = r.first.y, out4[2] = r.first.z, out4[3] = r.second;
+}
+// cornerPlane2normOffsetPlane (intersection.hpp:26-34)
+void ocx_corner_plane(const double *c9, double *norm3, double *off3)
+{
+    const oracle::Vec3 c[3] = {{c9[0], c9[1], c9[2]}, {c9[3], c9[4], c9[5]}, {c9[6], c9[7], c9[8]}};
+    const auto p = oracle::rx::cornerPlane2normOffsetPlane_d(c);
+    norm3[0] = p.norm.x, norm3[1] = p.norm.y, norm3[2] = p.norm.z;
+    off3[0] = p.offset.x, off3[1] = p.offset.y, off3[2] = p.offset.z;
+}
+// rayPlaneIntersection (intersection.hpp:36-47)
+int ocx_ray_plane(const double *dir3, const double *off3, const double *norm3, const double *poff3, double *out3)
+{
+    oracle::rx::plane_no p;
+    p.norm = oracle::Vec3{norm3[0], norm3[1], norm3[2]};
+    p.offset = oracle::Vec3{poff3[0], poff3[1], poff3[2]};
+    oracle::Vec3 out{NAN, NAN, NAN};
+    const bool ok = oracle::rx::rayPlaneIntersection_d(oracle::Vec3{dir3[0], dir3[1], dir3[2]}, oracle::Vec3{off3[0], off3[1], off3[2]}, p, out);
+    out3[0] = out.x, out3[1] = out.y, out3[2] = out.z;
+    return ok ? 1 : 0;
+}
+// the cost functors on doubles (relax_cost_function.hpp:16-19, :51-69, :119-155, :157-185)
+double ocx_angle_between_unit_vectors(const double *a3, const double *b3)
+{
+    return oracle::angleBetweenUnitVectors<double>(oracle::V3<double>{a3[0], a3[1], a3[2]}, oracle::V3<double>{b3[0], b3[1], b3[2]});
+}
+double ocx_difference_cost(double weight, double v1, double v2)
+{
+    double r = NAN;
+    oracle::DifferenceCost f(weight);
+    f(&v1, &v2, &r);
+    return r;
+}
+void ocx_distortion_monotonicity(double r_max, double weight, const double *radial3, double *residuals10)
+{
+    oracle::DistortionMonotonicityCost f;
+    f.r_max = r_max, f.weight = weight;
+    f(radial3, residuals10);
+}
+double ocx_adjacent_triangle_normal(const double *xy8, const double *z4, double weight)
+{
+    oracle::AdjacentTriangleNormalCost f;
+    for (int i = 0; i < 2; i++)
+        f.xyA[i] = xy8[i], f.xyB[i] = xy8[2 + i], f.xyC[i] = xy8[4 + i], f.xyD[i] = xy8[6 + i];
+    f.weight = weight;
+    double r = NAN;
+    f(&z4[0], &z4[1], &z4[2], &z4[3], &r);
+    return r;
+}
+}

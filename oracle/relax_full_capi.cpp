@@ -456,3 +456,17 @@ void ocx_image_to_3d_inverse(const double *px, size_t n, const double *inverse_m
 }
 
 } // extern "C"
+
+// a ray against a surface's mesh (MeshIntersectionSearcher::triangleIntersect, intersect.cpp:39-163): the IntersectionInfo type,
+// the intersection point and the triangle's node indexes - for test/test_meshgraph.cpp restated
+extern "C" int ocx_surface_intersect(void *s, const double *dir3, const double *off3, double *loc3, uint64_t *tri3)
+{
+    MeshIntersectionSearcher searcher;
+    if (!searcher.init(((surface_model *)s)->mesh))
+        return -1;
+    const auto &info = searcher.triangleIntersect(Vec3{dir3[0], dir3[1], dir3[2]}, Vec3{off3[0], off3[1], off3[2]});
+    loc3[0] = info.intersectionLocation.x, loc3[1] = info.intersectionLocation.y, loc3[2] = info.intersectionLocation.z;
+    for (int i = 0; i < 3; i++)
+        tri3[i] = info.nodeIndexes[i];
+    return (int)info.type;
+}
