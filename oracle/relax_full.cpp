@@ -2542,3 +2542,14 @@ double ocx_adjacent_triangle_normal(const double *xy8, const double *z4, double 
     return r;
 }
 }
+
+// DecomposedRotationCost (relax_cost_function.hpp:187-251) on doubles: quaternions x y z w, for test/test_relax.cpp:250-296 restated
+extern "C" void ocx_decomposed_rotation_cost(const double *rel_rot4, const double *rel_pos3, const double *pos1, const double *pos2,
+                                             int score, const double *q1, const double *q2, double *residuals3)
+{
+    oracle::Quat r;
+    r.x = rel_rot4[0], r.y = rel_rot4[1], r.z = rel_rot4[2], r.w = rel_rot4[3];
+    const oracle::DecomposedRotationCost f(r, oracle::Vec3{rel_pos3[0], rel_pos3[1], rel_pos3[2]}, oracle::Vec3{pos1[0], pos1[1], pos1[2]},
+                                           oracle::Vec3{pos2[0], pos2[1], pos2[2]}, score);
+    f(q1, q2, residuals3);
+}

@@ -202,3 +202,44 @@ def test_interleave_and_kdtree_known_answers(oracle):
     knn = np.zeros((4, 3), np.uint64)
     r.ref_knn(np.ascontiguousarray(pts), 4, 3, knn)
     assert knn[3].tolist() == [3, 2, 1]                           # itself, Melvin (7, 7), Harold (1, 3)
+
+
+# ---- test_relax.cpp:250-296: DecomposedRotationCost's residuals at the truth and at fixed offsets (fixture :30-37)
+def _q(axis, angle):                                              # Eigen::AngleAxisd as a quaternion, x y z w
+    a = np.asarray(axis, np.float64)
+    return np.concatenate([np.sin(angle / 2) * a / np.linalg.norm(a), [np.cos(angle / 2)]])
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return v(aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw,
+             aw * bw - ax * bx - ay * by - az * bz)
+
+
+def _qrot(q, x):
+    qv = q[:3]
+    uv = 2 * np.cross(qv, x)
+    return x + q[3] * uv + np.cross(qv, uv)
+
+
+def test_rel_rot_cost_function(oracle):
+    L = oracle._rx()
+    L.ocx_decomposed_rotation_cost.argtypes = [D3, D3, D3, D3, C.c_int, D3, D3, D3]
+    down = _q((1, 0, 0), np.pi)
+    ori = [_qmul(_q((0, 0, 1), 0.2), down), _qmul(_q((0, 1, 0), -0.3), down)]
+    pos = [v(9, 9, 9), v(11, 9, 9)]
+    inv0 = ori[0] * v(-1, -1, -1, 1)
+    rel_rot, rel_pos = _qmul(ori[1], inv0), _qrot(inv0, pos[1] - pos[0])
+
+    def cost(q0, q1):
+        r = np.full(3, np.nan)
+        L.ocx_decomposed_rotation_cost(rel_rot, rel_pos, pos[0], pos[1], 8, np.ascontiguousarray(q0), np.ascontiguousarray(q1), r)
+        return r
+
+    r = cost(ori[0], ori[1])                                       # a perfect guess
+    assert abs(r[0]) < 1e-5 and abs(r[1]) < 1e-5 and abs(r[2]) < 1e-12
+    r = cost(_qmul(ori[0], _q((0, 0, 1), 0.3)), ori[1])            # camera 0 turned by 0.3 about its axis
+    assert abs(r[0] - 0.3) < 1e-12 and abs(r[1]) < 1e-5 and abs(r[2] - 0.3) < 1e-12
+    r = cost(ori[0], _qmul(ori[1], _q((0, 0, 1), -0.3)))           # camera 1 turned by -0.3
+    assert abs(r[0]) < 1e-5 and abs(r[1] - 0.3) < 1e-12 and abs(r[2] - 0.3) < 1e-12
