@@ -257,3 +257,17 @@ def test_order_dependent_suppression_on_hard_images(ctx, oracle, kind):
     gkp, gdesc = got[0]
     assert len(gkp) == len(ekp) > 100, (len(gkp), len(ekp))
     assert np.array_equal(gkp.view(np.uint32), ekp.view(np.uint32)) and np.array_equal(gdesc, edesc)
+
+
+def test_verbose_extraction_reports_the_suppression_rounds(capfd, monkeypatch, oracle):
+    """OCHIP_VERBOSE=extract makes the suppression keep rounds / time / waiting points per (pass, image, level) and print their
+    maxima (profiles/r06_suppression_levels.txt comes from it): the diagnostic path must not change the result."""
+    monkeypatch.setenv("OCHIP_VERBOSE", "extract")
+    img = synth.render_blobs(640, 480, 11)
+    c = capi.Context(0)
+    got, _ = c.akaze_batch(img[None], max_kp=20000)
+    c.close()
+    err = capfd.readouterr().err
+    assert err.count("suppression pass") == 3 and "rounds/time/points" in err
+    ekp, edesc = oracle.akaze(img[:, :, 0])
+    assert np.array_equal(got[0][0].view(np.uint32), ekp.view(np.uint32)) and np.array_equal(got[0][1], edesc)
